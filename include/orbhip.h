@@ -1,0 +1,147 @@
+/* orbhip.h — C ABI of the MI355X-native ORB front-end (liborbhip.so, gfx950 only).
+ *
+ * This is the drop-in boundary for the ONE hot path of raulmur/ORB_SLAM2 that this repository replaces:
+ * src/ORBextractor.cc + the Hamming / Frame-to-Frame part of src/ORBmatcher.cc.  The reference has no FFI
+ * layer (it is a single C++ library); the C++ classes ORB_SLAM2::ORBextractor / ORB_SLAM2::ORBmatcher in
+ * include/ORBextractor.h / include/ORBmatcher.h keep the reference's signatures and forward to the entry
+ * points below (see INTEGRATION.md for the binding a maintainer adds).  Plain C types only: pointers and
+ * sizes, int status returns, caller-allocated outputs, one opaque context per extractor instance.
+ *
+ * Threading: one context is used by one thread at a time (like one ORBextractor instance,
+ * Frame.cc:78-81 runs the left and right instances on two threads -> use two contexts); the stateless
+ * entry points (orbhip_descriptor_distance, orbhip_hamming_nn, orbhip_search_for_initialization) are
+ * re-entrant (Tracking / LocalMapping / LoopClosing threads all call the matcher).
+ *
+ * Error behaviour: the reference's operator() returns void and silently returns on an empty image
+ * (ORBextractor.cc:1046-1047).  Here every call returns an orbhip_status; an empty image yields ORBHIP_OK
+ * with *n_out = 0.  There is NO CPU fallback: without a usable HIP device orbhip_create fails with
+ * ORBHIP_ERR_HIP and orbhip_last_error() says why.
+ */
+#ifndef ORBHIP_H
+#define ORBHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orbhip_ctx orbhip_ctx;
+
+typedef enum {
+    ORBHIP_OK = 0,
+    ORBHIP_ERR_INVALID = 1,     /* bad argument */
+    ORBHIP_ERR_HIP = 2,         /* HIP runtime error (no device, launch failure, ...) */
+    ORBHIP_ERR_CAPACITY = 3,    /* caller buffer too small; *n_out still reports the needed size */
+    ORBHIP_ERR_UNSUPPORTED = 4  /* configuration outside the supported envelope */
+} orbhip_status;
+
+/* == cv::KeyPoint memory layout (pt.x, pt.y, size, angle, response, octave, class_id), 28 bytes */
+typedef struct {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} orbhip_keypoint;
+
+typedef struct {
+    /* ORBextractor constructor arguments, ORBextractor.h:52-53 / ORBextractor.cc:410-413 */
+    int32_t nfeatures;
+    float scale_factor;
+    int32_t nlevels;
+    int32_t ini_th_fast;
+    int32_t min_th_fast;
+    /* geometry of the frames this context processes (the reference re-allocates per call; here the pyramid,
+       candidate and keypoint buffers are laid out once in HBM for a fixed size) */
+    int32_t width, height;
+    int32_t max_batch;        /* frames (independent cameras) processed per batched call, >= 1 */
+    int32_t device;           /* HIP device ordinal */
+    void* stream;             /* hipStream_t to run on; NULL = the context creates its own stream */
+    int32_t blur_round_mode;  /* 0 = OpenCV generic C++ rounding (default), 1 = x86 SSE2 build rounding; DESIGN.md */
+} orbhip_config;
+
+const char* orbhip_version(void);
+/* last error message of the calling thread ("" if none) */
+const char* orbhip_last_error(void);
+
+/* -------- ORBextractor (ORBextractor.h:45-111) ------------------------------------------------------- */
+orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cfg);            /* ORBextractor::ORBextractor */
+void orbhip_destroy(orbhip_ctx* ctx);                                               /* ~ORBextractor */
+int orbhip_keypoint_capacity(const orbhip_ctx* ctx);  /* upper bound of keypoints per frame: sum_l max(N_l+3, 4*nIni_l) */
+/* GetLevels / GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares / GetInverseScaleSigmaSquares
+   (ORBextractor.h:63-84) and mnFeaturesPerLevel; each output may be NULL, each holds nlevels entries */
+orbhip_status orbhip_get_scale_tables(const orbhip_ctx* ctx, float* scale_factors, float* inv_scale_factors,
+                                      float* level_sigma2, float* inv_level_sigma2, int32_t* features_per_level);
+orbhip_status orbhip_level_size(const orbhip_ctx* ctx, int level, int* w, int* h);
+
+/* ORBextractor::operator() (ORBextractor.h:59-61, ORBextractor.cc:1043-1105): host image in, host keypoints +
+   descriptors out, synchronous.  Keypoints are level-major, quadtree-list order within a level; descriptor
+   row i belongs to keypoint i.  img == NULL or an empty image -> *n_out = 0 (silent return of the reference). */
+orbhip_status orbhip_extract(orbhip_ctx* ctx, const uint8_t* img, int stride_bytes,
+                             orbhip_keypoint* kps, uint8_t* desc /* cap x 32 */, int cap, int* n_out);
+/* the same for nimg <= max_batch frames in one pass; outputs are [nimg][cap] */
+orbhip_status orbhip_extract_batch(orbhip_ctx* ctx, int nimg, const uint8_t* const* imgs, int stride_bytes,
+                                   orbhip_keypoint* kps, uint8_t* desc, int cap, int* n_out /* nimg */);
+/* mvImagePyramid[level] of frame `frame` of the last call (ORBextractor.h:85; read by Frame.cc:473,563-580) */
+orbhip_status orbhip_pyramid_level(orbhip_ctx* ctx, int frame, int level, uint8_t* dst, int dst_stride);
+
+/* -------- device-resident pipeline (inputs already in HBM, results stay in HBM) ----------------------- */
+/* d_imgs: device pointer to nimg frames, frame f at d_imgs + f*frame_stride, rows row_stride bytes apart.
+   Asynchronous on the context's stream.  If match_prev != 0 each frame (camera slot) f is additionally
+   matched against the frame the same slot processed in the previous call with
+   ORBmatcher(nnratio, check_ori).SearchForInitialization(F_prev, F_cur, prev = F_prev keypoints, window)
+   (ORBmatcher.cc:405-520; the unit of work of BASELINE.json's metric). */
+orbhip_status orbhip_extract_device(orbhip_ctx* ctx, int nimg, const uint8_t* d_imgs, size_t frame_stride,
+                                    int row_stride, int match_prev, int window, float nnratio, int check_ori);
+orbhip_status orbhip_sync(orbhip_ctx* ctx);
+/* copy results of the last orbhip_extract_device call to the host (synchronises) */
+orbhip_status orbhip_fetch(orbhip_ctx* ctx, int nimg, orbhip_keypoint* kps, uint8_t* desc, int cap, int* n_out);
+/* matches of the last call with match_prev != 0: matches12 is [nimg][cap1] (index into the current frame's
+   keypoints per previous-frame keypoint, -1 = none), nmatches[nimg]; n1_out[nimg] = previous-frame keypoint count */
+orbhip_status orbhip_fetch_matches(orbhip_ctx* ctx, int nimg, int32_t* matches12, int cap1, int32_t* n1_out,
+                                   int32_t* nmatches);
+
+/* -------- ORBmatcher (ORBmatcher.h:37-102) ------------------------------------------------------------ */
+/* ORBmatcher::DescriptorDistance (ORBmatcher.cc:1647-1663): 256-bit Hamming distance of two 32-byte descriptors.
+   Scalar host helper (one pair is not GPU work); the batched forms below are the HIP path. */
+int orbhip_descriptor_distance(const uint8_t* a, const uint8_t* b);
+
+/* Brute-force nearest neighbour (BASELINE.json config 5; matcher idiom ORBmatcher.cc:102-114,447-456):
+   for every query descriptor the best (strict '<', lowest index wins ties) and second-best distance over db.
+   Host buffers, synchronous.  db_index_base is added to reported indices (shards of one DB across GPUs). */
+orbhip_status orbhip_hamming_nn(int device, const uint8_t* q, int nq, const uint8_t* db, int64_t ndb,
+                                int64_t db_index_base, int64_t* best_idx, int32_t* best_dist, int32_t* second_dist);
+/* same with device-resident buffers on a given stream (NULL = default stream); asynchronous */
+orbhip_status orbhip_hamming_nn_device(void* stream, const uint8_t* d_q, int nq, const uint8_t* d_db, int64_t ndb,
+                                       int64_t db_index_base, int64_t* d_best_idx, int32_t* d_best_dist,
+                                       int32_t* d_second_dist);
+
+/* ORBmatcher(nnratio, check_ori).SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, window)
+   (ORBmatcher.h:69, ORBmatcher.cc:405-520) on host buffers.  The Frame members it reads are passed flat:
+   mvKeysUn / mDescriptors of both frames and the image bounds (mnMinX = mnMinY = 0, mnMaxX = im_w,
+   mnMaxY = im_h: undistorted input, Frame.cc:455-463).  prev_matched (n1 x 2 floats, x then y) is updated in
+   place exactly like vbPrevMatched; matches12 has n1 entries.  Returns the match count in *nmatches. */
+orbhip_status orbhip_search_for_initialization(int device,
+                                               const orbhip_keypoint* kps1, const uint8_t* desc1, int n1,
+                                               const orbhip_keypoint* kps2, const uint8_t* desc2, int n2,
+                                               int im_w, int im_h, float* prev_matched, int32_t* matches12,
+                                               int window, float nnratio, int check_ori, int* nmatches);
+
+/* -------- measurement + stage dumps (parity tests) ----------------------------------------------------- */
+/* per-kernel HIP-event timing on the context's stream: enable, run, then read accumulated stats */
+orbhip_status orbhip_profile_enable(orbhip_ctx* ctx, int on);
+int orbhip_profile_num_kernels(const orbhip_ctx* ctx);
+orbhip_status orbhip_profile_get(orbhip_ctx* ctx, int k, const char** name, double* total_ms, int64_t* launches);
+orbhip_status orbhip_profile_reset(orbhip_ctx* ctx);
+/* algorithmic bytes one frame moves (BASELINE.md §3 formula B(W,H,N)) */
+int64_t orbhip_algorithmic_bytes_per_frame(const orbhip_ctx* ctx);
+/* the terms of that formula moved by profiled kernel k (0 for kernels outside the formula) */
+int64_t orbhip_algorithmic_bytes_per_frame_kernel(const orbhip_ctx* ctx, int k);
+
+orbhip_status orbhip_debug_blurred_level(orbhip_ctx* ctx, int frame, int level, uint8_t* dst, int dst_stride);
+/* (x, y, score) int32 triples in vToDistributeKeys order (cell-space coordinates, ORBextractor.cc:820-825) */
+orbhip_status orbhip_debug_candidates(orbhip_ctx* ctx, int frame, int level, int32_t* xys, int cap, int* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBHIP_H */

@@ -1,0 +1,827 @@
+// orb_oracle.cpp — CPU ORACLE for the ORB front-end hot path.  TEST INFRASTRUCTURE ONLY.
+//
+// This file is the checker, never the product: only tests/, __graft_entry__.smoke()
+// and bench.py's cpu_baseline leg may load it.  The shipped path (liborbhip.so) never
+// links, loads or calls anything in here.
+//
+// What it is: a line-by-line CPU restatement of the reference algorithm
+//   raulmur/ORB_SLAM2  src/ORBextractor.cc:72-147,410-853,1034-1132
+//                      src/ORBmatcher.cc:37-39,405-520,1601-1663
+//                      src/Frame.cc:230-245,327-392  (64x48 feature grid)
+// with the OpenCV primitives the reference calls (cv::resize INTER_LINEAR 8U,
+// cv::FAST 9/16 + NMS, cv::GaussianBlur 7x7 s=2 8U, cv::fastAtan2, cvRound) and the
+// libm call (sincosf) restated from their published algorithms, because OpenCV is a
+// third-party dependency that is NOT vendored in /root/reference (CMakeLists.txt:31-37
+// "find_package(OpenCV 3.0) else 2.4.3", README.md:68 "tested with 2.4.11 and 3.2").
+//
+// PARITY UNPINNED at the OpenCV boundary: the reference ships no tests / golden
+// vectors for this path and neither OpenCV nor the reference can be
+// built in this container, so the restated primitives (target: OpenCV 3.2 generic
+// C++ code paths) are pinned only by hand-derivable known-answer tests
+// (tests/test_oracle_kat.py).  The one piece that IS pinned against a real binary is
+// sincosf: glibc_sincosf() below is checked bit-for-bit against this box's libm.
+//
+// Declared canonicalisations:
+//   H1  quadtree tie-break: the reference sorts pair<int,ExtractorNode*> (ORBextractor.cc:684),
+//       i.e. ties in node size are broken by heap address.  Here: ties -> later-created
+//       node first (what a monotonic bump allocator gives).
+//   H2  OpenCV 3.2 generic C++ paths (no IPP / OpenCL).  GaussianBlur's final rounding
+//       has two documented modes, see gaussian_blur_7x7().
+//   H3  built with -ffp-contract=off (two roundings for x*b + y*a).
+//   H4  sincosf = glibc 2.35 algorithm restated (double polynomial), no FMA.
+//
+// Build: see oracle/Makefile (g++ -O2 -ffp-contract=off -fno-fast-math).
+#include <cstdint>
+#include <cstring>
+#include <cmath>
+#include <climits>
+#include <cassert>
+#include <vector>
+#include <list>
+#include <algorithm>
+#include <utility>
+
+namespace {
+
+// ---------------------------------------------------------------- basic helpers
+// cvRound: round-half-to-even (OpenCV uses cvtsd2si / lrint).  SURVEY App. D.
+inline int cvRoundD(double v) { return (int)lrint(v); }
+inline int cvRoundF(float v) { return (int)lrintf(v); }
+inline int cvFloorF(float v) { int i = (int)v; return i - (i > v); }
+inline int cvCeilF(float v) { int i = (int)v; return i + (i < v); }
+inline short sat_short(int v) { return (short)(v < -32768 ? -32768 : v > 32767 ? 32767 : v); }
+inline uint8_t sat_u8(int v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
+
+struct View {          // non-owning 8-bit single channel image view (cv::Mat ROI analogue)
+    const uint8_t* p; int w, h, stride;
+    const uint8_t* row(int y) const { return p + (size_t)y * stride; }
+    View roi(int x0, int y0, int x1, int y1) const { return View{p + (size_t)y0 * stride + x0, x1 - x0, y1 - y0, stride}; }
+};
+struct Image {         // owning, contiguous
+    int w = 0, h = 0; std::vector<uint8_t> d;
+    void create(int W, int H) { w = W; h = H; d.assign((size_t)W * H, 0); }
+    View view() const { return View{d.data(), w, h, w}; }
+    uint8_t* row(int y) { return d.data() + (size_t)y * w; }
+};
+
+struct KeyPoint {      // == cv::KeyPoint memory layout, 28 bytes
+    float x, y, size, angle, response; int octave, class_id;
+};
+
+// ---------------------------------------------------------------- cv::resize, INTER_LINEAR, CV_8UC1
+// Restated from OpenCV 3.2 imgproc/imgwarp.cpp: resize() coefficient tables, HResizeLinear<uchar,int,short,2048>,
+// VResizeLinear<uchar,int,short,FixedPtCast<int,uchar,22>>.  Called at ORBextractor.cc:1120.
+void resize_linear_8u(const View& src, Image& dst, int dw, int dh)
+{
+    const int sw = src.w, sh = src.h;
+    dst.create(dw, dh);
+    const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+    const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+    std::vector<int> xofs(dw), yofs(dh);
+    std::vector<short> ialpha(2 * dw), ibeta(2 * dh);
+    int xmax = dw;
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = cvFloorF(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx + 1 >= sw) { xmax = std::min(xmax, dx); if (sx >= sw - 1) { fx = 0; sx = sw - 1; } }
+        xofs[dx] = sx;
+        float c0 = 1.f - fx, c1 = fx;
+        ialpha[2 * dx] = sat_short(cvRoundF(c0 * 2048.f));
+        ialpha[2 * dx + 1] = sat_short(cvRoundF(c1 * 2048.f));
+    }
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = cvFloorF(fy);
+        fy -= sy;
+        yofs[dy] = sy;
+        float c0 = 1.f - fy, c1 = fy;
+        ibeta[2 * dy] = sat_short(cvRoundF(c0 * 2048.f));
+        ibeta[2 * dy + 1] = sat_short(cvRoundF(c1 * 2048.f));
+    }
+    std::vector<int> r0(dw), r1(dw);
+    auto hresize = [&](int sy, std::vector<int>& D) {
+        const uint8_t* S = src.row(sy);
+        int dx = 0;
+        for (; dx < xmax; dx++) { int sx = xofs[dx]; D[dx] = S[sx] * ialpha[2 * dx] + S[sx + 1] * ialpha[2 * dx + 1]; }
+        for (; dx < dw; dx++) D[dx] = S[xofs[dx]] * 2048;
+    };
+    for (int dy = 0; dy < dh; dy++) {
+        int sy0 = yofs[dy];
+        int ya = std::min(std::max(sy0, 0), sh - 1), yb = std::min(std::max(sy0 + 1, 0), sh - 1);  // clip(), weights not reset
+        hresize(ya, r0); hresize(yb, r1);
+        int b0 = ibeta[2 * dy], b1 = ibeta[2 * dy + 1];
+        uint8_t* D = dst.row(dy);
+        for (int x = 0; x < dw; x++)
+            D[x] = (uint8_t)((((b0 * (r0[x] >> 4)) >> 16) + ((b1 * (r1[x] >> 4)) >> 16) + 2) >> 2);
+    }
+}
+
+// ---------------------------------------------------------------- cv::GaussianBlur 7x7, sigma 2, CV_8U, BORDER_REFLECT_101
+// Restated from OpenCV 3.2 imgproc/smooth.cpp getGaussianKernel() + filter.cpp createSeparableLinearFilter():
+// float kernel -> 8-bit fixed point ints (cvRound(k*256)), int32 row pass, column pass rounded back with 16 bits.
+// Called at ORBextractor.cc:1086 on a clone of the level interior (border synthesised from the interior).
+// round_mode 0: generic C++ FixedPtCastEx  -> (sum + 32768) >> 16                     (default)
+// round_mode 1: x86 SSE2 build behaviour   -> columns x < (w & ~3) use round-half-EVEN of sum/65536
+//               (SymmColumnVec_32s8u goes through float + cvtps2dq), the <4-wide tail uses mode 0.
+void gaussian_kernel_7_sigma2_fixed(int k[7])
+{
+    const int n = 7; const double sigma = 2.0;
+    float cf[7]; double sum = 0;
+    double scale2X = -0.5 / (sigma * sigma);
+    for (int i = 0; i < n; i++) { double x = i - (n - 1) * 0.5; double t = std::exp(scale2X * x * x); cf[i] = (float)t; sum += cf[i]; }
+    sum = 1. / sum;
+    for (int i = 0; i < n; i++) { cf[i] = (float)(cf[i] * sum); k[i] = cvRoundF(cf[i] * 256.f); }
+}
+inline int reflect101(int p, int len) {        // cv::borderInterpolate, BORDER_REFLECT_101
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) { if (p < 0) p = -p; else p = 2 * (len - 1) - p; }
+    return p;
+}
+void gaussian_blur_7x7(const View& src, Image& dst, int round_mode)
+{
+    int k[7]; gaussian_kernel_7_sigma2_fixed(k);
+    const int w = src.w, h = src.h;
+    dst.create(w, h);
+    std::vector<int> rows((size_t)w * h);
+    for (int y = 0; y < h; y++) {
+        const uint8_t* S = src.row(y); int* R = &rows[(size_t)y * w];
+        for (int x = 0; x < w; x++) {
+            int s = 0;
+            for (int i = 0; i < 7; i++) s += k[i] * S[reflect101(x + i - 3, w)];
+            R[x] = s;
+        }
+    }
+    const int wv = w & ~3;
+    for (int y = 0; y < h; y++) {
+        uint8_t* D = dst.row(y);
+        const int* R[7];
+        for (int i = 0; i < 7; i++) R[i] = &rows[(size_t)reflect101(y + i - 3, h) * w];
+        for (int x = 0; x < w; x++) {
+            int s = 0;
+            for (int i = 0; i < 7; i++) s += k[i] * R[i][x];
+            int v;
+            if (round_mode == 1 && x < wv) { v = s >> 16; int rem = s & 0xFFFF; if (rem > 0x8000 || (rem == 0x8000 && (v & 1))) v++; }
+            else v = (s + (1 << 15)) >> 16;
+            D[x] = sat_u8(v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- cv::FAST (TYPE_9_16) with non-max suppression
+// Restated from OpenCV 3.2 features2d/fast.cpp FAST_t<16>() + fast_score.cpp cornerScore<16>().
+// Called per 30-px cell at ORBextractor.cc:809-815.  Output in row-major scan order; kp=(x,y,7,-1,score).
+const int kCircle[16][2] = {{0,3},{1,3},{2,2},{3,1},{3,0},{3,-1},{2,-2},{1,-3},{0,-3},{-1,-3},{-2,-2},{-3,-1},{-3,0},{-3,1},{-2,2},{-1,3}};
+
+int corner_score16(const uint8_t* ptr, const int pixel[25], int threshold)
+{
+    const int K = 8, N = K * 3 + 1;
+    int k, v = ptr[0]; short d[N];
+    for (k = 0; k < N; k++) d[k] = (short)(v - ptr[pixel[k]]);
+    int a0 = threshold;
+    for (k = 0; k < 16; k += 2) {
+        int a = std::min((int)d[k + 1], (int)d[k + 2]);
+        a = std::min(a, (int)d[k + 3]);
+        if (a <= a0) continue;
+        a = std::min(a, (int)d[k + 4]); a = std::min(a, (int)d[k + 5]); a = std::min(a, (int)d[k + 6]);
+        a = std::min(a, (int)d[k + 7]); a = std::min(a, (int)d[k + 8]);
+        a0 = std::max(a0, std::min(a, (int)d[k]));
+        a0 = std::max(a0, std::min(a, (int)d[k + 9]));
+    }
+    int b0 = -a0;
+    for (k = 0; k < 16; k += 2) {
+        int b = std::max((int)d[k + 1], (int)d[k + 2]);
+        b = std::max(b, (int)d[k + 3]); b = std::max(b, (int)d[k + 4]); b = std::max(b, (int)d[k + 5]);
+        if (b >= b0) continue;
+        b = std::max(b, (int)d[k + 6]); b = std::max(b, (int)d[k + 7]); b = std::max(b, (int)d[k + 8]);
+        b0 = std::min(b0, std::max(b, (int)d[k]));
+        b0 = std::min(b0, std::max(b, (int)d[k + 9]));
+    }
+    return -b0 - 1;
+}
+
+void fast9_16(const View& img, std::vector<KeyPoint>& keypoints, int threshold, bool nms)
+{
+    keypoints.clear();
+    const int K = 8, N = 16 + K + 1;
+    int pixel[25];
+    for (int k = 0; k < 16; k++) pixel[k] = kCircle[k][0] + kCircle[k][1] * img.stride;
+    for (int k = 16; k < 25; k++) pixel[k] = pixel[k - 16];
+    threshold = std::min(std::max(threshold, 0), 255);
+    const int cols = img.w, rows = img.h;
+    if (cols < 7 || rows < 7) return;
+    std::vector<uint8_t> bufv((size_t)cols * 3, 0);
+    std::vector<int> cpv((size_t)(cols + 1) * 3, 0);
+    uint8_t* buf[3] = {bufv.data(), bufv.data() + cols, bufv.data() + 2 * cols};
+    int* cpbuf[3] = {cpv.data() + 1, cpv.data() + 1 + (cols + 1), cpv.data() + 1 + 2 * (cols + 1)};
+    for (int i = 3; i < rows - 2; i++) {
+        const uint8_t* ptr = img.row(i) + 3;
+        uint8_t* curr = buf[(i - 3) % 3];
+        int* cornerpos = cpbuf[(i - 3) % 3];
+        memset(curr, 0, cols);
+        int ncorners = 0;
+        if (i < rows - 3) {
+            for (int j = 3; j < cols - 3; j++, ptr++) {
+                int v = ptr[0];
+                bool found = false;
+                {   // darker arc: x < v - t
+                    int vt = v - threshold, count = 0;
+                    for (int k = 0; k < N; k++) { int x = ptr[pixel[k]]; if (x < vt) { if (++count > K) { found = true; break; } } else count = 0; }
+                }
+                if (!found) {   // brighter arc: x > v + t
+                    int vt = v + threshold, count = 0;
+                    for (int k = 0; k < N; k++) { int x = ptr[pixel[k]]; if (x > vt) { if (++count > K) { found = true; break; } } else count = 0; }
+                }
+                if (found) {
+                    cornerpos[ncorners++] = j;
+                    if (nms) curr[j] = (uint8_t)corner_score16(ptr, pixel, threshold);
+                }
+            }
+        }
+        cornerpos[-1] = ncorners;
+        if (i == 3) continue;
+        const uint8_t* prev = buf[(i - 4 + 3) % 3];
+        const uint8_t* pprev = buf[(i - 5 + 3) % 3];
+        cornerpos = cpbuf[(i - 4 + 3) % 3];
+        ncorners = cornerpos[-1];
+        for (int k = 0; k < ncorners; k++) {
+            int j = cornerpos[k];
+            int score = prev[j];
+            if (!nms || (score > prev[j + 1] && score > prev[j - 1] &&
+                         score > pprev[j - 1] && score > pprev[j] && score > pprev[j + 1] &&
+                         score > curr[j - 1] && score > curr[j] && score > curr[j + 1]))
+                keypoints.push_back(KeyPoint{(float)j, (float)(i - 1), 7.f, -1.f, (float)score, 0, -1});
+        }
+    }
+}
+
+// ---------------------------------------------------------------- cv::fastAtan2 (degrees), OpenCV 3.2 core/mathfuncs_core.cpp
+float fast_atan2_deg(float y, float x)
+{
+    const float s = (float)(180 / 3.14159265358979323846);
+    const float p1 = 0.9997878412794807f * s, p3 = -0.3258083974640975f * s, p5 = 0.1555786518463281f * s, p7 = -0.04432655554792128f * s;
+    float ax = std::fabs(x), ay = std::fabs(y), a, c, c2;
+    if (ax >= ay) { c = ay / (ax + (float)2.2204460492503131e-16); c2 = c * c; a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+    else          { c = ax / (ay + (float)2.2204460492503131e-16); c2 = c * c; a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+// ---------------------------------------------------------------- sincosf, glibc 2.35 sysdeps/ieee754/flt-32/s_sincosf.c (H4)
+// (float)cos/(float)sin at ORBextractor.cc:113 resolve to libm sincosf.  Double-precision polynomial, |y| < 120 only.
+struct SinCosTab { double sign[4], hpi_inv, hpi, c0, c1, c2, c3, c4, s1, s2, s3; };
+const SinCosTab kSC[2] = {
+    {{1.0, -1.0, -1.0, 1.0}, 0x1.45F306DC9C883p+23, 0x1.921FB54442D18p0, 0x1p0, -0x1.ffffffd0c621cp-2, 0x1.55553e1068f19p-5,
+     -0x1.6c087e89a359dp-10, 0x1.99343027bf8c3p-16, -0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13},
+    {{1.0, -1.0, -1.0, 1.0}, 0x1.45F306DC9C883p+23, 0x1.921FB54442D18p0, -0x1p0, 0x1.ffffffd0c621cp-2, -0x1.55553e1068f19p-5,
+     0x1.6c087e89a359dp-10, -0x1.99343027bf8c3p-16, -0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13}};
+inline uint32_t abstop12(float x) { uint32_t u; memcpy(&u, &x, 4); return (u >> 20) & 0x7ff; }
+inline void sincosf_poly(double x, double x2, const SinCosTab* p, int n, float* sinp, float* cosp)
+{
+    double x3, x4, x5, x6, s, c, c1, c2, s1;
+    x4 = x2 * x2; x3 = x2 * x;
+    c2 = p->c3 + x2 * p->c4; s1 = p->s2 + x2 * p->s3;
+    float* tmp = (n & 1 ? cosp : sinp); cosp = (n & 1 ? sinp : cosp); sinp = tmp;
+    c1 = p->c0 + x2 * p->c1; x5 = x3 * x2; x6 = x4 * x2;
+    s = x + x3 * p->s1; c = c1 + x4 * p->c2;
+    *sinp = (float)(s + x5 * s1); *cosp = (float)(c + x6 * c2);
+}
+void glibc_sincosf(float y, float* sinp, float* cosp)
+{
+    double x = y; const SinCosTab* p = &kSC[0];
+    if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {
+        double x2 = x * x;
+        if (abstop12(y) < abstop12(0x1p-12f)) { *sinp = y; *cosp = 1.0f; return; }
+        sincosf_poly(x, x2, p, 0, sinp, cosp);
+    } else {   // abstop12(y) < abstop12(120.0f) for every angle in [0, 2*pi]
+        double r = x * p->hpi_inv;
+        int n = ((int32_t)r + 0x800000) >> 24;
+        x = x - n * p->hpi;
+        double s = p->sign[n & 3];
+        if (n & 2) p = &kSC[1];
+        sincosf_poly(x * s, x * x, p, n, sinp, cosp);
+    }
+}
+
+// ---------------------------------------------------------------- rBRIEF pattern (ORBextractor.cc:150-408)
+const int kPattern[256 * 4] = {
+#include "../orb_slam2_amd/csrc/brief_pattern_31.inc"
+};
+
+const int PATCH_SIZE = 31, HALF_PATCH_SIZE = 15, EDGE_THRESHOLD = 19;   // ORBextractor.cc:72-74
+
+// ORBextractor.cc:77-104
+float IC_Angle(const View& image, float ptx, float pty, const std::vector<int>& u_max)
+{
+    int m_01 = 0, m_10 = 0;
+    const uint8_t* center = image.row(cvRoundF(pty)) + cvRoundF(ptx);
+    for (int u = -HALF_PATCH_SIZE; u <= HALF_PATCH_SIZE; ++u) m_10 += u * center[u];
+    int step = image.stride;
+    for (int v = 1; v <= HALF_PATCH_SIZE; ++v) {
+        int v_sum = 0, d = u_max[v];
+        for (int u = -d; u <= d; ++u) {
+            int val_plus = center[u + v * step], val_minus = center[u - v * step];
+            v_sum += (val_plus - val_minus);
+            m_10 += u * (val_plus + val_minus);
+        }
+        m_01 += v * v_sum;
+    }
+    return fast_atan2_deg((float)m_01, (float)m_10);
+}
+
+// ORBextractor.cc:107-147
+const float factorPI = (float)(3.14159265358979323846 / 180.f);
+void computeOrbDescriptor(const KeyPoint& kpt, const View& img, uint8_t* desc)
+{
+    float angle = (float)kpt.angle * factorPI;
+    float a, b; glibc_sincosf(angle, &b, &a);      // a = cos, b = sin
+    const uint8_t* center = img.row(cvRoundF(kpt.y)) + cvRoundF(kpt.x);
+    const int step = img.stride;
+    const int* pat = kPattern;
+    for (int i = 0; i < 32; ++i, pat += 32) {
+        int val = 0;
+        for (int k = 0; k < 8; k++) {
+            int x0 = pat[4 * k], y0 = pat[4 * k + 1], x1 = pat[4 * k + 2], y1 = pat[4 * k + 3];
+            int t0 = center[cvRoundF(x0 * b + y0 * a) * step + cvRoundF(x0 * a - y0 * b)];
+            int t1 = center[cvRoundF(x1 * b + y1 * a) * step + cvRoundF(x1 * a - y1 * b)];
+            val |= (t0 < t1) << k;
+        }
+        desc[i] = (uint8_t)val;
+    }
+}
+
+// ---------------------------------------------------------------- quadtree (ORBextractor.cc:481-763)
+struct Pt { int x, y; };
+struct Node {
+    std::vector<KeyPoint> vKeys; Pt UL, UR, BL, BR; std::list<Node>::iterator lit; bool bNoMore = false;
+    long seq = 0;   // creation order, canonical replacement for the heap address (H1)
+    void Divide(Node& n1, Node& n2, Node& n3, Node& n4) const
+    {
+        const int halfX = (int)ceilf((float)(UR.x - UL.x) / 2);
+        const int halfY = (int)ceilf((float)(BR.y - UL.y) / 2);
+        n1.UL = UL; n1.UR = Pt{UL.x + halfX, UL.y}; n1.BL = Pt{UL.x, UL.y + halfY}; n1.BR = Pt{UL.x + halfX, UL.y + halfY};
+        n2.UL = n1.UR; n2.UR = UR; n2.BL = n1.BR; n2.BR = Pt{UR.x, UL.y + halfY};
+        n3.UL = n1.BL; n3.UR = n1.BR; n3.BL = BL; n3.BR = Pt{n1.BR.x, BL.y};
+        n4.UL = n3.UR; n4.UR = n2.BR; n4.BL = n3.BR; n4.BR = BR;
+        for (size_t i = 0; i < vKeys.size(); i++) {
+            const KeyPoint& kp = vKeys[i];
+            if (kp.x < n1.UR.x) { if (kp.y < n1.BR.y) n1.vKeys.push_back(kp); else n3.vKeys.push_back(kp); }
+            else if (kp.y < n1.BR.y) n2.vKeys.push_back(kp);
+            else n4.vKeys.push_back(kp);
+        }
+        if (n1.vKeys.size() == 1) n1.bNoMore = true;
+        if (n2.vKeys.size() == 1) n2.bNoMore = true;
+        if (n3.vKeys.size() == 1) n3.bNoMore = true;
+        if (n4.vKeys.size() == 1) n4.bNoMore = true;
+    }
+};
+struct SizeSeqNode { int size; long seq; Node* node; bool operator<(const SizeSeqNode& o) const { return size != o.size ? size < o.size : seq < o.seq; } };
+
+std::vector<KeyPoint> DistributeOctTree(const std::vector<KeyPoint>& vToDistributeKeys, int minX, int maxX, int minY, int maxY, int N)
+{
+    std::vector<KeyPoint> vResultKeys;
+    const int nIni = (int)roundf((float)(maxX - minX) / (maxY - minY));
+    if (nIni <= 0) return vResultKeys;          // reference divides by zero here (portrait images) — documented UB, not exercised
+    const float hX = (float)(maxX - minX) / nIni;
+    std::list<Node> lNodes; std::vector<Node*> vpIniNodes(nIni);
+    long seq = 0;
+    for (int i = 0; i < nIni; i++) {
+        Node ni;
+        ni.UL = Pt{(int)(hX * (float)i), 0}; ni.UR = Pt{(int)(hX * (float)(i + 1)), 0};
+        ni.BL = Pt{ni.UL.x, maxY - minY}; ni.BR = Pt{ni.UR.x, maxY - minY};
+        ni.seq = seq++;
+        lNodes.push_back(ni); vpIniNodes[i] = &lNodes.back();
+    }
+    for (size_t i = 0; i < vToDistributeKeys.size(); i++) {
+        const KeyPoint& kp = vToDistributeKeys[i];
+        vpIniNodes[(int)(kp.x / hX)]->vKeys.push_back(kp);
+    }
+    auto lit = lNodes.begin();
+    while (lit != lNodes.end()) {
+        if (lit->vKeys.size() == 1) { lit->bNoMore = true; lit++; }
+        else if (lit->vKeys.empty()) lit = lNodes.erase(lit);
+        else lit++;
+    }
+    bool bFinish = false;
+    std::vector<SizeSeqNode> vSizeAndPointerToNode;
+    auto add_children = [&](Node* ch[4], int* nToExpand) {
+        for (int c = 0; c < 4; c++) {
+            if (ch[c]->vKeys.size() > 0) {
+                ch[c]->seq = seq++;
+                lNodes.push_front(*ch[c]);
+                if (ch[c]->vKeys.size() > 1) {
+                    if (nToExpand) (*nToExpand)++;
+                    vSizeAndPointerToNode.push_back(SizeSeqNode{(int)ch[c]->vKeys.size(), lNodes.front().seq, &lNodes.front()});
+                    lNodes.front().lit = lNodes.begin();
+                }
+            }
+        }
+    };
+    while (!bFinish) {
+        int prevSize = (int)lNodes.size();
+        lit = lNodes.begin();
+        int nToExpand = 0;
+        vSizeAndPointerToNode.clear();
+        while (lit != lNodes.end()) {
+            if (lit->bNoMore) { lit++; continue; }
+            Node n1, n2, n3, n4; lit->Divide(n1, n2, n3, n4);
+            Node* ch[4] = {&n1, &n2, &n3, &n4};
+            add_children(ch, &nToExpand);
+            lit = lNodes.erase(lit);
+        }
+        if ((int)lNodes.size() >= N || (int)lNodes.size() == prevSize) bFinish = true;
+        else if (((int)lNodes.size() + nToExpand * 3) > N) {
+            while (!bFinish) {
+                prevSize = (int)lNodes.size();
+                std::vector<SizeSeqNode> vPrev = vSizeAndPointerToNode;
+                vSizeAndPointerToNode.clear();
+                std::sort(vPrev.begin(), vPrev.end());
+                for (int j = (int)vPrev.size() - 1; j >= 0; j--) {
+                    Node n1, n2, n3, n4; vPrev[j].node->Divide(n1, n2, n3, n4);
+                    Node* ch[4] = {&n1, &n2, &n3, &n4};
+                    add_children(ch, nullptr);
+                    lNodes.erase(vPrev[j].node->lit);
+                    if ((int)lNodes.size() >= N) break;
+                }
+                if ((int)lNodes.size() >= N || (int)lNodes.size() == prevSize) bFinish = true;
+            }
+        }
+    }
+    vResultKeys.reserve(lNodes.size());
+    for (auto it = lNodes.begin(); it != lNodes.end(); it++) {
+        std::vector<KeyPoint>& vNodeKeys = it->vKeys;
+        KeyPoint* pKP = &vNodeKeys[0]; float maxResponse = pKP->response;
+        for (size_t k = 1; k < vNodeKeys.size(); k++)
+            if (vNodeKeys[k].response > maxResponse) { pKP = &vNodeKeys[k]; maxResponse = vNodeKeys[k].response; }
+        vResultKeys.push_back(*pKP);
+    }
+    return vResultKeys;
+}
+
+// ---------------------------------------------------------------- the extractor (ORBextractor.cc:410-470, 765-853, 1043-1132)
+struct Extractor {
+    int nfeatures; double scaleFactor; int nlevels, iniThFAST, minThFAST; int blur_round_mode = 0;
+    std::vector<int> mnFeaturesPerLevel, umax;
+    std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+    std::vector<Image> pyr, blurred;                       // level interiors (apron never read)
+    std::vector<std::vector<KeyPoint>> candidates;         // per level, pre-quadtree (cell coords, relative to (16,16))
+    std::vector<std::vector<KeyPoint>> levelKeys;          // per level, post-quadtree+orientation, level coords
+    std::vector<KeyPoint> keys; std::vector<uint8_t> desc; // final outputs
+
+    Extractor(int nf, float sf, int nl, int ini, int mn) : nfeatures(nf), scaleFactor(sf), nlevels(nl), iniThFAST(ini), minThFAST(mn)
+    {
+        mvScaleFactor.resize(nlevels); mvLevelSigma2.resize(nlevels);
+        mvScaleFactor[0] = 1.0f; mvLevelSigma2[0] = 1.0f;
+        for (int i = 1; i < nlevels; i++) { mvScaleFactor[i] = mvScaleFactor[i - 1] * scaleFactor; mvLevelSigma2[i] = mvScaleFactor[i] * mvScaleFactor[i]; }
+        mvInvScaleFactor.resize(nlevels); mvInvLevelSigma2.resize(nlevels);
+        for (int i = 0; i < nlevels; i++) { mvInvScaleFactor[i] = 1.0f / mvScaleFactor[i]; mvInvLevelSigma2[i] = 1.0f / mvLevelSigma2[i]; }
+        mnFeaturesPerLevel.resize(nlevels);
+        float factor = 1.0f / scaleFactor;
+        float nDesiredFeaturesPerScale = nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nlevels));
+        int sumFeatures = 0;
+        for (int level = 0; level < nlevels - 1; level++) {
+            mnFeaturesPerLevel[level] = cvRoundF(nDesiredFeaturesPerScale);
+            sumFeatures += mnFeaturesPerLevel[level];
+            nDesiredFeaturesPerScale *= factor;
+        }
+        mnFeaturesPerLevel[nlevels - 1] = std::max(nfeatures - sumFeatures, 0);
+        umax.resize(HALF_PATCH_SIZE + 1);
+        int v, v0, vmax = cvFloorF(HALF_PATCH_SIZE * sqrtf(2.f) / 2 + 1);
+        int vmin = cvCeilF(HALF_PATCH_SIZE * sqrtf(2.f) / 2);
+        const double hp2 = HALF_PATCH_SIZE * HALF_PATCH_SIZE;
+        for (v = 0; v <= vmax; ++v) umax[v] = cvRoundD(sqrt(hp2 - v * v));
+        for (v = HALF_PATCH_SIZE, v0 = 0; v >= vmin; --v) { while (umax[v0] == umax[v0 + 1]) ++v0; umax[v] = v0; ++v0; }
+    }
+
+    void ComputePyramid(const View& image)
+    {
+        pyr.resize(nlevels);
+        for (int level = 0; level < nlevels; ++level) {
+            float scale = mvInvScaleFactor[level];
+            int sw = cvRoundF((float)image.w * scale), sh = cvRoundF((float)image.h * scale);
+            if (level != 0) resize_linear_8u(pyr[level - 1].view(), pyr[level], sw, sh);
+            else { pyr[0].create(image.w, image.h); for (int y = 0; y < image.h; y++) memcpy(pyr[0].row(y), image.row(y), image.w); }
+        }
+    }
+
+    void ComputeKeyPointsOctTree(std::vector<std::vector<KeyPoint>>& allKeypoints)
+    {
+        allKeypoints.resize(nlevels); candidates.assign(nlevels, {});
+        const float W = 30;
+        for (int level = 0; level < nlevels; ++level) {
+            const View lv = pyr[level].view();
+            const int minBorderX = EDGE_THRESHOLD - 3, minBorderY = minBorderX;
+            const int maxBorderX = lv.w - EDGE_THRESHOLD + 3, maxBorderY = lv.h - EDGE_THRESHOLD + 3;
+            std::vector<KeyPoint> vToDistributeKeys; vToDistributeKeys.reserve(nfeatures * 10);
+            const float width = (maxBorderX - minBorderX), height = (maxBorderY - minBorderY);
+            const int nCols = width / W, nRows = height / W;
+            const int wCell = ceil(width / nCols), hCell = ceil(height / nRows);
+            for (int i = 0; i < nRows; i++) {
+                const float iniY = minBorderY + i * hCell; float maxY = iniY + hCell + 6;
+                if (iniY >= maxBorderY - 3) continue;
+                if (maxY > maxBorderY) maxY = maxBorderY;
+                for (int j = 0; j < nCols; j++) {
+                    const float iniX = minBorderX + j * wCell; float maxX = iniX + wCell + 6;
+                    if (iniX >= maxBorderX - 6) continue;
+                    if (maxX > maxBorderX) maxX = maxBorderX;
+                    std::vector<KeyPoint> vKeysCell;
+                    View cell = lv.roi((int)iniX, (int)iniY, (int)maxX, (int)maxY);
+                    fast9_16(cell, vKeysCell, iniThFAST, true);
+                    if (vKeysCell.empty()) fast9_16(cell, vKeysCell, minThFAST, true);
+                    for (auto& k : vKeysCell) { k.x += j * wCell; k.y += i * hCell; vToDistributeKeys.push_back(k); }
+                }
+            }
+            candidates[level] = vToDistributeKeys;
+            std::vector<KeyPoint>& keypoints = allKeypoints[level];
+            keypoints = DistributeOctTree(vToDistributeKeys, minBorderX, maxBorderX, minBorderY, maxBorderY, mnFeaturesPerLevel[level]);
+            const int scaledPatchSize = PATCH_SIZE * mvScaleFactor[level];
+            for (auto& k : keypoints) { k.x += minBorderX; k.y += minBorderY; k.octave = level; k.size = scaledPatchSize; }
+        }
+        for (int level = 0; level < nlevels; ++level)
+            for (auto& k : allKeypoints[level]) k.angle = IC_Angle(pyr[level].view(), k.x, k.y, umax);
+    }
+
+    // ORBextractor::operator()  (ORBextractor.cc:1043-1105); returns number of keypoints
+    int run(const View& image)
+    {
+        keys.clear(); desc.clear();
+        if (image.w == 0 || image.h == 0) return 0;
+        ComputePyramid(image);
+        std::vector<std::vector<KeyPoint>> allKeypoints;
+        ComputeKeyPointsOctTree(allKeypoints);
+        int nkeypoints = 0;
+        for (int level = 0; level < nlevels; ++level) nkeypoints += (int)allKeypoints[level].size();
+        desc.assign((size_t)nkeypoints * 32, 0);
+        keys.reserve(nkeypoints);
+        blurred.assign(nlevels, Image());
+        levelKeys = allKeypoints;
+        int offset = 0;
+        for (int level = 0; level < nlevels; ++level) {
+            std::vector<KeyPoint>& keypoints = allKeypoints[level];
+            int n = (int)keypoints.size();
+            if (n == 0) continue;
+            gaussian_blur_7x7(pyr[level].view(), blurred[level], blur_round_mode);
+            View wm = blurred[level].view();
+            for (int i = 0; i < n; i++) computeOrbDescriptor(keypoints[i], wm, &desc[(size_t)(offset + i) * 32]);
+            offset += n;
+            if (level != 0) { float scale = mvScaleFactor[level]; for (auto& k : keypoints) { k.x *= scale; k.y *= scale; } }
+            keys.insert(keys.end(), keypoints.begin(), keypoints.end());
+        }
+        return nkeypoints;
+    }
+};
+
+// ---------------------------------------------------------------- matcher side
+// ORBmatcher::DescriptorDistance, ORBmatcher.cc:1647-1663 (SWAR popcount over 8 int32 words)
+int DescriptorDistance(const uint8_t* a, const uint8_t* b)
+{
+    int32_t pa[8], pb[8]; memcpy(pa, a, 32); memcpy(pb, b, 32);
+    int dist = 0;
+    for (int i = 0; i < 8; i++) {
+        unsigned int v = pa[i] ^ pb[i];
+        v = v - ((v >> 1) & 0x55555555);
+        v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+        dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+    }
+    return dist;
+}
+
+const int FRAME_GRID_ROWS = 48, FRAME_GRID_COLS = 64;   // Frame.h:37-38
+const int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30; // ORBmatcher.cc:37-39
+
+// The slice of ORB_SLAM2::Frame the matcher reads: undistorted keys (== keys when k1==0, Frame.cc:406-410),
+// descriptors, image bounds (Frame.cc:455-463) and the 64x48 grid (Frame.cc:230-245, 382-392).
+struct FrameLite {
+    int N = 0; std::vector<KeyPoint> keys; std::vector<uint8_t> desc;
+    float mnMinX, mnMaxX, mnMinY, mnMaxY, gwInv, ghInv;
+    std::vector<size_t> grid[FRAME_GRID_COLS][FRAME_GRID_ROWS];
+    void build(const KeyPoint* k, const uint8_t* d, int n, int imw, int imh)
+    {
+        N = n; keys.assign(k, k + n); desc.assign(d, d + (size_t)n * 32);
+        mnMinX = 0.0f; mnMaxX = imw; mnMinY = 0.0f; mnMaxY = imh;
+        gwInv = (float)FRAME_GRID_COLS / (float)(mnMaxX - mnMinX);
+        ghInv = (float)FRAME_GRID_ROWS / (float)(mnMaxY - mnMinY);
+        for (auto& col : grid) for (auto& c : col) c.clear();
+        for (int i = 0; i < N; i++) {
+            int px = (int)roundf((keys[i].x - mnMinX) * gwInv), py = (int)roundf((keys[i].y - mnMinY) * ghInv);
+            if (px < 0 || px >= FRAME_GRID_COLS || py < 0 || py >= FRAME_GRID_ROWS) continue;
+            grid[px][py].push_back(i);
+        }
+    }
+    // Frame::GetFeaturesInArea, Frame.cc:327-380
+    std::vector<size_t> GetFeaturesInArea(float x, float y, float r, int minLevel, int maxLevel) const
+    {
+        std::vector<size_t> vIndices;
+        const int nMinCellX = std::max(0, (int)floorf((x - mnMinX - r) * gwInv));
+        if (nMinCellX >= FRAME_GRID_COLS) return vIndices;
+        const int nMaxCellX = std::min((int)FRAME_GRID_COLS - 1, (int)ceilf((x - mnMinX + r) * gwInv));
+        if (nMaxCellX < 0) return vIndices;
+        const int nMinCellY = std::max(0, (int)floorf((y - mnMinY - r) * ghInv));
+        if (nMinCellY >= FRAME_GRID_ROWS) return vIndices;
+        const int nMaxCellY = std::min((int)FRAME_GRID_ROWS - 1, (int)ceilf((y - mnMinY + r) * ghInv));
+        if (nMaxCellY < 0) return vIndices;
+        const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+        for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+            for (int iy = nMinCellY; iy <= nMaxCellY; iy++)
+                for (size_t idx : grid[ix][iy]) {
+                    const KeyPoint& kp = keys[idx];
+                    if (bCheckLevels) { if (kp.octave < minLevel) continue; if (maxLevel >= 0 && kp.octave > maxLevel) continue; }
+                    const float distx = kp.x - x, disty = kp.y - y;
+                    if (fabsf(distx) < r && fabsf(disty) < r) vIndices.push_back(idx);
+                }
+        return vIndices;
+    }
+};
+
+// ORBmatcher::ComputeThreeMaxima, ORBmatcher.cc:1601-1642
+void ComputeThreeMaxima(std::vector<int>* histo, int L, int& ind1, int& ind2, int& ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = (int)histo[i].size();
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+// ORBmatcher::SearchForInitialization, ORBmatcher.cc:405-520
+int SearchForInitialization(const FrameLite& F1, const FrameLite& F2, float* vbPrevMatched /*N1 x 2*/, int* vnMatches12,
+                            int windowSize, float mfNNratio, bool mbCheckOrientation)
+{
+    int nmatches = 0;
+    for (int i = 0; i < F1.N; i++) vnMatches12[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    std::vector<int> vMatchedDistance(F2.N, INT_MAX), vnMatches21(F2.N, -1);
+    for (int i1 = 0; i1 < F1.N; i1++) {
+        const KeyPoint& kp1 = F1.keys[i1];
+        int level1 = kp1.octave;
+        if (level1 > 0) continue;
+        std::vector<size_t> vIndices2 = F2.GetFeaturesInArea(vbPrevMatched[2 * i1], vbPrevMatched[2 * i1 + 1], windowSize, level1, level1);
+        if (vIndices2.empty()) continue;
+        const uint8_t* d1 = &F1.desc[(size_t)i1 * 32];
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (size_t i2 : vIndices2) {
+            int dist = DescriptorDistance(d1, &F2.desc[i2 * 32]);
+            if (vMatchedDistance[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = (int)i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= TH_LOW) {
+            if (bestDist < (float)bestDist2 * mfNNratio) {
+                if (vnMatches21[bestIdx2] >= 0) { vnMatches12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+                vnMatches12[i1] = bestIdx2; vnMatches21[bestIdx2] = i1; vMatchedDistance[bestIdx2] = bestDist; nmatches++;
+                if (mbCheckOrientation) {
+                    float rot = F1.keys[i1].angle - F2.keys[bestIdx2].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)roundf(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin].push_back(i1);
+                }
+            }
+        }
+    }
+    if (mbCheckOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx1 : rotHist[i]) if (vnMatches12[idx1] >= 0) { vnMatches12[idx1] = -1; nmatches--; }
+        }
+    }
+    for (int i1 = 0; i1 < F1.N; i1++)
+        if (vnMatches12[i1] >= 0) { vbPrevMatched[2 * i1] = F2.keys[vnMatches12[i1]].x; vbPrevMatched[2 * i1 + 1] = F2.keys[vnMatches12[i1]].y; }
+    return nmatches;
+}
+
+}  // namespace
+
+// ================================================================ C API (ctypes)
+extern "C" {
+
+void* orb_oracle_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST)
+{ return new Extractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST); }
+void orb_oracle_destroy(void* h) { delete (Extractor*)h; }
+void orb_oracle_set_blur_round_mode(void* h, int mode) { ((Extractor*)h)->blur_round_mode = mode; }
+
+// runs ORBextractor::operator(); returns N; copies up to cap keypoints (28 B each) and descriptors (32 B each)
+int orb_oracle_extract(void* h, const uint8_t* img, int w, int ht, int stride, void* kps, uint8_t* desc, int cap)
+{
+    Extractor* e = (Extractor*)h;
+    int n = e->run(View{img, w, ht, stride});
+    int m = std::min(n, cap);
+    if (kps && m > 0) memcpy(kps, e->keys.data(), (size_t)m * sizeof(KeyPoint));
+    if (desc && m > 0) memcpy(desc, e->desc.data(), (size_t)m * 32);
+    return n;
+}
+void orb_oracle_get_params(void* h, int* featuresPerLevel, float* scaleFactors, float* invScaleFactors, float* sigma2, float* invSigma2, int* umax16)
+{
+    Extractor* e = (Extractor*)h;
+    for (int i = 0; i < e->nlevels; i++) {
+        if (featuresPerLevel) featuresPerLevel[i] = e->mnFeaturesPerLevel[i];
+        if (scaleFactors) scaleFactors[i] = e->mvScaleFactor[i];
+        if (invScaleFactors) invScaleFactors[i] = e->mvInvScaleFactor[i];
+        if (sigma2) sigma2[i] = e->mvLevelSigma2[i];
+        if (invSigma2) invSigma2[i] = e->mvInvLevelSigma2[i];
+    }
+    if (umax16) for (int i = 0; i < 16; i++) umax16[i] = e->umax[i];
+}
+// stage dumps of the last orb_oracle_extract call
+int orb_oracle_level_size(void* h, int level, int* w, int* ht)
+{ Extractor* e = (Extractor*)h; if (level < 0 || level >= (int)e->pyr.size()) return -1; *w = e->pyr[level].w; *ht = e->pyr[level].h; return 0; }
+int orb_oracle_get_level(void* h, int level, uint8_t* dst)
+{ Extractor* e = (Extractor*)h; if (level < 0 || level >= (int)e->pyr.size()) return -1; memcpy(dst, e->pyr[level].d.data(), e->pyr[level].d.size()); return 0; }
+int orb_oracle_get_blurred(void* h, int level, uint8_t* dst)   // returns 0 if the level had no keypoints (never blurred by the reference)
+{ Extractor* e = (Extractor*)h; if (level < 0 || level >= (int)e->blurred.size() || e->blurred[level].d.empty()) return 0; memcpy(dst, e->blurred[level].d.data(), e->blurred[level].d.size()); return 1; }
+int orb_oracle_get_candidates(void* h, int level, int* xys, int cap)   // (x,y,score) triples in vToDistributeKeys order, cell-space coords
+{
+    Extractor* e = (Extractor*)h; const auto& c = e->candidates[level];
+    int m = std::min((int)c.size(), cap);
+    for (int i = 0; i < m; i++) { xys[3 * i] = (int)c[i].x; xys[3 * i + 1] = (int)c[i].y; xys[3 * i + 2] = (int)c[i].response; }
+    return (int)c.size();
+}
+int orb_oracle_get_level_keypoints(void* h, int level, void* kps, int cap)   // post-quadtree + orientation, level coords
+{
+    Extractor* e = (Extractor*)h; const auto& c = e->levelKeys[level];
+    int m = std::min((int)c.size(), cap);
+    if (m > 0) memcpy(kps, c.data(), (size_t)m * sizeof(KeyPoint));
+    return (int)c.size();
+}
+
+// primitives (known-answer tests)
+void orb_oracle_resize(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh)
+{ Image o; resize_linear_8u(View{src, sw, sh, sstride}, o, dw, dh); memcpy(dst, o.d.data(), o.d.size()); }
+void orb_oracle_blur(const uint8_t* src, int w, int ht, int stride, uint8_t* dst, int round_mode)
+{ Image o; gaussian_blur_7x7(View{src, w, ht, stride}, o, round_mode); memcpy(dst, o.d.data(), o.d.size()); }
+void orb_oracle_gauss_kernel(int* k7) { gaussian_kernel_7_sigma2_fixed(k7); }
+int orb_oracle_fast(const uint8_t* img, int w, int ht, int stride, int threshold, int nms, int* xys, int cap)
+{
+    std::vector<KeyPoint> k; fast9_16(View{img, w, ht, stride}, k, threshold, nms != 0);
+    int m = std::min((int)k.size(), cap);
+    for (int i = 0; i < m; i++) { xys[3 * i] = (int)k[i].x; xys[3 * i + 1] = (int)k[i].y; xys[3 * i + 2] = (int)k[i].response; }
+    return (int)k.size();
+}
+float orb_oracle_fastatan2(float y, float x) { return fast_atan2_deg(y, x); }
+void orb_oracle_sincosf(float a, float* s, float* c) { glibc_sincosf(a, s, c); }
+// sweep: compares glibc_sincosf against THIS box's libm sincosf for every float bit pattern in [lo_bits, hi_bits]; returns mismatch count
+long orb_oracle_sincosf_vs_libm(uint32_t lo_bits, uint32_t hi_bits, uint32_t step)
+{
+    long bad = 0;
+    for (uint64_t u = lo_bits; u <= hi_bits; u += step) {
+        uint32_t b = (uint32_t)u; float a; memcpy(&a, &b, 4);
+        float s0, c0, s1, c1; glibc_sincosf(a, &s0, &c0); sincosf(a, &s1, &c1);
+        if (memcmp(&s0, &s1, 4) || memcmp(&c0, &c1, 4)) bad++;
+    }
+    return bad;
+}
+int orb_oracle_distribute(const int* xys, int n, int minX, int maxX, int minY, int maxY, int N, int* out_xys, int cap)
+{
+    std::vector<KeyPoint> in(n);
+    for (int i = 0; i < n; i++) in[i] = KeyPoint{(float)xys[3 * i], (float)xys[3 * i + 1], 7.f, -1.f, (float)xys[3 * i + 2], 0, -1};
+    std::vector<KeyPoint> out = DistributeOctTree(in, minX, maxX, minY, maxY, N);
+    int m = std::min((int)out.size(), cap);
+    for (int i = 0; i < m; i++) { out_xys[3 * i] = (int)out[i].x; out_xys[3 * i + 1] = (int)out[i].y; out_xys[3 * i + 2] = (int)out[i].response; }
+    return (int)out.size();
+}
+int orb_oracle_hamming(const uint8_t* a, const uint8_t* b) { return DescriptorDistance(a, b); }
+
+// brute-force NN, SURVEY App. B.4 (matcher idiom ORBmatcher.cc:102-114,447-456): strict '<', first index wins
+void orb_oracle_bf_nn(const uint8_t* q, int nq, const uint8_t* db, int ndb, int* best_idx, int* best_dist, int* second_dist)
+{
+    for (int i = 0; i < nq; i++) {
+        int best = INT_MAX, second = INT_MAX, idx = -1;
+        for (int j = 0; j < ndb; j++) {
+            int d = DescriptorDistance(q + (size_t)i * 32, db + (size_t)j * 32);
+            if (d < best) { second = best; best = d; idx = j; } else if (d < second) second = d;
+        }
+        best_idx[i] = idx; best_dist[i] = best; second_dist[i] = second;
+    }
+}
+
+// SearchForInitialization on two key/descriptor sets.  prev (N1 x 2 floats) is updated in place like vbPrevMatched.
+int orb_oracle_search_for_initialization(const void* kps1, const uint8_t* desc1, int n1, const void* kps2, const uint8_t* desc2, int n2,
+                                         int imw, int imh, float* prev, int* matches12, int windowSize, float nnratio, int checkOri)
+{
+    FrameLite* F1 = new FrameLite; FrameLite* F2 = new FrameLite;
+    F1->build((const KeyPoint*)kps1, desc1, n1, imw, imh); F2->build((const KeyPoint*)kps2, desc2, n2, imw, imh);
+    int r = SearchForInitialization(*F1, *F2, prev, matches12, windowSize, nnratio, checkOri != 0);
+    delete F1; delete F2;
+    return r;
+}
+int orb_oracle_features_in_area(const void* kps, int n, int imw, int imh, float x, float y, float r, int minLevel, int maxLevel, int* out, int cap)
+{
+    FrameLite* F = new FrameLite; std::vector<uint8_t> d((size_t)n * 32, 0);
+    F->build((const KeyPoint*)kps, d.data(), n, imw, imh);
+    std::vector<size_t> v = F->GetFeaturesInArea(x, y, r, minLevel, maxLevel);
+    int m = std::min((int)v.size(), cap);
+    for (int i = 0; i < m; i++) out[i] = (int)v[i];
+    delete F;
+    return (int)v.size();
+}
+
+}  // extern "C"

@@ -1,0 +1,230 @@
+"""ctypes binding of the CPU oracle (oracle/orb_oracle.cpp).  TEST INFRASTRUCTURE ONLY.
+
+Importable only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg — never from the
+orb_slam2_amd package (the product path fails loudly without its HIP library instead of falling back).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+# == cv::KeyPoint memory layout (28 B), see include/orbhip.h orbhip_keypoint
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                           ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+
+
+def build(force=False):
+    """Compile the oracle with its Makefile (g++ only; no reference sources, no OpenCV)."""
+    so = os.path.join(_HERE, "liborb_oracle.so")
+    if force or not os.path.exists(so) or not os.path.exists(os.path.join(_HERE, "liborb_oracle_fast.so")) \
+            or os.path.getmtime(so) < os.path.getmtime(os.path.join(_HERE, "orb_oracle.cpp")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return so
+
+
+_libs = {}
+
+
+def lib(fast=False):
+    name = "liborb_oracle_fast.so" if fast else "liborb_oracle.so"
+    if name in _libs:
+        return _libs[name]
+    path = os.path.join(_HERE, name)
+    if not os.path.exists(path):
+        build()
+    L = C.CDLL(path)
+    u8p, i32p, f32p, vp = C.POINTER(C.c_uint8), C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_void_p
+    L.orb_oracle_create.restype = vp
+    L.orb_oracle_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+    L.orb_oracle_destroy.argtypes = [vp]
+    L.orb_oracle_set_blur_round_mode.argtypes = [vp, C.c_int]
+    L.orb_oracle_extract.restype = C.c_int
+    L.orb_oracle_extract.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int]
+    L.orb_oracle_get_params.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.orb_oracle_level_size.argtypes = [vp, C.c_int, i32p, i32p]
+    L.orb_oracle_get_level.argtypes = [vp, C.c_int, vp]
+    L.orb_oracle_get_blurred.argtypes = [vp, C.c_int, vp]
+    L.orb_oracle_get_candidates.argtypes = [vp, C.c_int, vp, C.c_int]
+    L.orb_oracle_get_level_keypoints.argtypes = [vp, C.c_int, vp, C.c_int]
+    L.orb_oracle_resize.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int]
+    L.orb_oracle_blur.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+    L.orb_oracle_gauss_kernel.argtypes = [vp]
+    L.orb_oracle_fast.restype = C.c_int
+    L.orb_oracle_fast.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+    L.orb_oracle_fastatan2.restype = C.c_float
+    L.orb_oracle_fastatan2.argtypes = [C.c_float, C.c_float]
+    L.orb_oracle_sincosf.argtypes = [C.c_float, f32p, f32p]
+    L.orb_oracle_sincosf_vs_libm.restype = C.c_long
+    L.orb_oracle_sincosf_vs_libm.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+    L.orb_oracle_distribute.restype = C.c_int
+    L.orb_oracle_distribute.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+    L.orb_oracle_hamming.restype = C.c_int
+    L.orb_oracle_hamming.argtypes = [vp, vp]
+    L.orb_oracle_bf_nn.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp]
+    L.orb_oracle_search_for_initialization.restype = C.c_int
+    L.orb_oracle_search_for_initialization.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp,
+                                                       C.c_int, C.c_float, C.c_int]
+    L.orb_oracle_features_in_area.restype = C.c_int
+    L.orb_oracle_features_in_area.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                                              C.c_int, C.c_int, vp, C.c_int]
+    _libs[name] = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OracleExtractor:
+    """CPU restatement of ORB_SLAM2::ORBextractor (ORBextractor.h:45-111)."""
+
+    def __init__(self, nfeatures=2000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7, fast=False,
+                 blur_round_mode=0):
+        self.L = lib(fast)
+        self.nlevels = nlevels
+        self.nfeatures = nfeatures
+        self.h = self.L.orb_oracle_create(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)
+        self.L.orb_oracle_set_blur_round_mode(self.h, blur_round_mode)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orb_oracle_destroy(self.h)
+            self.h = None
+
+    def extract(self, img):
+        """img: HxW uint8 (any row stride).  Returns (keypoints[KEYPOINT_DTYPE], descriptors[N,32] uint8)."""
+        assert img.dtype == np.uint8 and img.ndim == 2 and img.strides[1] == 1
+        cap = self.nfeatures + 3 * self.nlevels + 64
+        while True:
+            kps = np.zeros(cap, KEYPOINT_DTYPE)
+            desc = np.zeros((cap, 32), np.uint8)
+            n = self.L.orb_oracle_extract(self.h, _p(img), img.shape[1], img.shape[0], img.strides[0], _p(kps), _p(desc), cap)
+            if n <= cap:
+                return kps[:n].copy(), desc[:n].copy()
+            cap = n
+
+    def params(self):
+        n = self.nlevels
+        fpl = np.zeros(n, np.int32)
+        sf, isf, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        umax = np.zeros(16, np.int32)
+        self.L.orb_oracle_get_params(self.h, _p(fpl), _p(sf), _p(isf), _p(s2), _p(is2), _p(umax))
+        return dict(features_per_level=fpl, scale_factors=sf, inv_scale_factors=isf, sigma2=s2, inv_sigma2=is2, umax=umax)
+
+    def level_size(self, level):
+        w, h = C.c_int(), C.c_int()
+        assert self.L.orb_oracle_level_size(self.h, level, C.byref(w), C.byref(h)) == 0
+        return w.value, h.value
+
+    def level(self, level):
+        w, h = self.level_size(level)
+        out = np.zeros((h, w), np.uint8)
+        self.L.orb_oracle_get_level(self.h, level, _p(out))
+        return out
+
+    def blurred(self, level):
+        w, h = self.level_size(level)
+        out = np.zeros((h, w), np.uint8)
+        ok = self.L.orb_oracle_get_blurred(self.h, level, _p(out))
+        return out if ok else None
+
+    def candidates(self, level):
+        cap = 1 << 16
+        while True:
+            out = np.zeros((cap, 3), np.int32)
+            n = self.L.orb_oracle_get_candidates(self.h, level, _p(out), cap)
+            if n <= cap:
+                return out[:n].copy()
+            cap = n
+
+    def level_keypoints(self, level):
+        cap = self.nfeatures + 64
+        out = np.zeros(cap, KEYPOINT_DTYPE)
+        n = self.L.orb_oracle_get_level_keypoints(self.h, level, _p(out), cap)
+        assert n <= cap
+        return out[:n].copy()
+
+
+def resize(src, dw, dh):
+    out = np.zeros((dh, dw), np.uint8)
+    lib().orb_oracle_resize(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(out), dw, dh)
+    return out
+
+
+def blur(src, round_mode=0):
+    out = np.zeros(src.shape, np.uint8)
+    lib().orb_oracle_blur(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(out), round_mode)
+    return out
+
+
+def gauss_kernel():
+    k = np.zeros(7, np.int32)
+    lib().orb_oracle_gauss_kernel(_p(k))
+    return k
+
+
+def fast(img, threshold, nms=True):
+    cap = img.size
+    out = np.zeros((cap, 3), np.int32)
+    n = lib().orb_oracle_fast(_p(img), img.shape[1], img.shape[0], img.strides[0], threshold, int(nms), _p(out), cap)
+    return out[:n].copy()
+
+
+def fastatan2(y, x):
+    return lib().orb_oracle_fastatan2(y, x)
+
+
+def sincosf(a):
+    s, c = C.c_float(), C.c_float()
+    lib().orb_oracle_sincosf(a, C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def distribute(xys, minX, maxX, minY, maxY, N):
+    xys = np.ascontiguousarray(xys, np.int32)
+    cap = max(N + 64, 4 * 64)
+    out = np.zeros((cap, 3), np.int32)
+    n = lib().orb_oracle_distribute(_p(xys), len(xys), minX, maxX, minY, maxY, N, _p(out), cap)
+    assert n <= cap
+    return out[:n].copy()
+
+
+def hamming(a, b):
+    return lib().orb_oracle_hamming(_p(np.ascontiguousarray(a)), _p(np.ascontiguousarray(b)))
+
+
+def bf_nn(q, db, fast=False):
+    q = np.ascontiguousarray(q, np.uint8)
+    db = np.ascontiguousarray(db, np.uint8)
+    bi = np.zeros(len(q), np.int32)
+    bd = np.zeros(len(q), np.int32)
+    sd = np.zeros(len(q), np.int32)
+    lib(fast).orb_oracle_bf_nn(_p(q), len(q), _p(db), len(db), _p(bi), _p(bd), _p(sd))
+    return bi, bd, sd
+
+
+def search_for_initialization(kps1, desc1, kps2, desc2, imw, imh, prev=None, window=100, nnratio=0.9, check_ori=True,
+                              fast=False):
+    """ORBmatcher(nnratio, check_ori).SearchForInitialization(F1, F2, prev, matches12, window).
+    Returns (nmatches, matches12[int32 N1], prev_updated[N1,2] float32)."""
+    kps1 = np.ascontiguousarray(kps1)
+    kps2 = np.ascontiguousarray(kps2)
+    desc1 = np.ascontiguousarray(desc1)
+    desc2 = np.ascontiguousarray(desc2)
+    if prev is None:
+        prev = np.stack([kps1["x"], kps1["y"]], axis=1)
+    prev = np.ascontiguousarray(prev, np.float32).copy()
+    m12 = np.full(len(kps1), -1, np.int32)
+    n = lib(fast).orb_oracle_search_for_initialization(_p(kps1), _p(desc1), len(kps1), _p(kps2), _p(desc2), len(kps2),
+                                                       imw, imh, _p(prev), _p(m12), window, nnratio, int(check_ori))
+    return n, m12, prev
+
+
+def features_in_area(kps, imw, imh, x, y, r, min_level, max_level):
+    kps = np.ascontiguousarray(kps)
+    out = np.zeros(len(kps) + 1, np.int32)
+    n = lib().orb_oracle_features_in_area(_p(kps), len(kps), imw, imh, x, y, r, min_level, max_level, _p(out), len(out))
+    return out[:n].copy()

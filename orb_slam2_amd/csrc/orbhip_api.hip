@@ -1,0 +1,572 @@
+// orbhip_api.hip — host orchestration and the C ABI of liborbhip.so (include/orbhip.h).
+//
+// Host side of the drop-in: what ORBextractor::ORBextractor computes once (scale tables, features per level,
+// ORBextractor.cc:410-470) plus everything the reference recomputes per frame although it only depends on the image
+// size (level sizes :1111-1112, FAST cell grid :773-806, cv::resize coefficient tables, Gaussian kernel) is computed
+// here at context creation and uploaded; per call the host only enqueues kernels on the context's HIP stream.
+// Float expressions mirror the reference's types step by step (file built with -ffp-contract=off).
+#include "orbhip_internal.h"
+#include <cmath>
+#include <cstdio>
+#include <cstdarg>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <algorithm>
+#include <mutex>
+
+static thread_local std::string g_err;
+static orbhip_status fail(orbhip_status st, const char* fmt, ...)
+{
+    char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf; return st;
+}
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(ORBHIP_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+static inline int cvRoundF(float v) { return (int)lrintf(v); }         // round-half-even, like cvRound
+static inline int cvRoundD(double v) { return (int)lrint(v); }
+static inline int cvFloorF(float v) { int i = (int)v; return i - (i > v); }
+static inline short satShort(int v) { return (short)(v < -32768 ? -32768 : v > 32767 ? 32767 : v); }
+
+enum { K_PYRAMID = 0, K_FAST, K_BLUR, K_QUADTREE, K_DESCRIBE, K_MGRID, K_MCAND, K_MSELECT, K_COUNT };
+static const char* kKernelNames[K_COUNT] = {"k_pyramid_level", "k_fast_cells", "k_blur", "k_quadtree", "k_describe",
+                                            "k_match_grid", "k_match_candidates", "k_match_select"};
+
+struct ProfSpan { int k; hipEvent_t a, b; };
+
+struct orbhip_ctx {
+    orbhip_config cfg; int L = 0, B = 0;
+    std::vector<LevelGeom> geom; std::vector<float> sf, isf, s2, is2; std::vector<int> nfeat;
+    std::vector<CellDesc> cells; std::vector<TileDesc> blur_tiles; std::vector<int2> xtab, ytab;
+    int gk[4] = {0, 0, 0, 0};
+    hipStream_t stream = nullptr; bool own_stream = false;
+    long long plane_frame_bytes = 0, cand_slots_per_frame = 0, qt_per_frame = 0; int lvl_kp_per_frame = 0, out_cap = 0, qt_maxn = 0, qt_maxcells = 0, lvl0_cap = 0;
+    // device
+    LevelGeom* d_geom = nullptr; CellDesc* d_cells = nullptr; TileDesc* d_tiles = nullptr; int2* d_xtab = nullptr; int2* d_ytab = nullptr; signed char* d_pattern = nullptr;
+    uint8_t* d_pyr = nullptr; uint8_t* d_blur = nullptr; int* d_cell_count = nullptr; unsigned* d_cell_cand = nullptr;
+    unsigned* d_qt_val = nullptr; unsigned* d_qt_code = nullptr; int* d_qt_node = nullptr; unsigned* d_lvl_kp = nullptr;
+    int* d_lvl_n[2] = {nullptr, nullptr}; orbhip_keypoint* d_out_kp[2] = {nullptr, nullptr}; uint8_t* d_out_desc[2] = {nullptr, nullptr}; int* d_out_n[2] = {nullptr, nullptr};
+    int cur = 0; int last_nimg = 0; bool last_matched = false; bool last_from_host = false;
+    // matcher workspace
+    int* d_grid_start = nullptr; int* d_grid_items = nullptr; unsigned* d_cand = nullptr; int* d_ncand = nullptr; float* d_prev = nullptr; int* d_m12 = nullptr; int* d_nm = nullptr;
+    // profiling
+    bool prof = false; std::vector<ProfSpan> pending; std::vector<hipEvent_t> pool; double tot_ms[K_COUNT] = {0}; long long launches[K_COUNT] = {0};
+};
+
+static const signed char kPatternHost[256 * 4] = {
+#include "brief_pattern_31.inc"
+};
+
+// ---------------------------------------------------------------------------------------------- profiling helpers
+static hipEvent_t prof_event(orbhip_ctx* c)
+{
+    if (!c->pool.empty()) { hipEvent_t e = c->pool.back(); c->pool.pop_back(); return e; }
+    hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
+}
+struct ProfScope {
+    orbhip_ctx* c; int k; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(orbhip_ctx* c_, int k_) : c(c_), k(k_) { if (c->prof) { a = prof_event(c); b = prof_event(c); (void)hipEventRecord(a, c->stream); } }
+    ~ProfScope() { if (c->prof) { (void)hipEventRecord(b, c->stream); c->pending.push_back(ProfSpan{k, a, b}); } }
+};
+static void prof_collect(orbhip_ctx* c)
+{
+    for (auto& s : c->pending) {
+        (void)hipEventSynchronize(s.b);
+        float ms = 0; (void)hipEventElapsedTime(&ms, s.a, s.b);
+        c->tot_ms[s.k] += ms; c->launches[s.k]++;
+        c->pool.push_back(s.a); c->pool.push_back(s.b);
+    }
+    c->pending.clear();
+}
+
+// ---------------------------------------------------------------------------------------------- creation
+template <typename T> static hipError_t dalloc(T** p, size_t count) { return hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T)); }
+template <typename T> static hipError_t upload(T** p, const std::vector<T>& v)
+{
+    hipError_t e = dalloc(p, v.size()); if (e != hipSuccess) return e;
+    return v.empty() ? hipSuccess : hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+}
+
+static void build_resize_table(int sw, int dw, std::vector<int2>& tab)   // cv::resize coefficient tables (OpenCV 3.2 imgwarp.cpp)
+{
+    const double inv_scale = (double)dw / sw, scale = 1. / inv_scale;
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale - 0.5);
+        int sx = cvFloorF(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        const int a0 = satShort(cvRoundF((1.f - fx) * 2048.f)), a1 = satShort(cvRoundF(fx * 2048.f));
+        int2 e; e.x = sx; e.y = (a0 & 0xffff) | (a1 << 16);
+        tab.push_back(e);
+    }
+}
+static void build_yresize_table(int sh, int dh, std::vector<int2>& tab)  // rows are clipped in the kernel, weights are not reset
+{
+    const double inv_scale = (double)dh / sh, scale = 1. / inv_scale;
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale - 0.5);
+        int sy = cvFloorF(fy);
+        fy -= sy;
+        const int b0 = satShort(cvRoundF((1.f - fy) * 2048.f)), b1 = satShort(cvRoundF(fy * 2048.f));
+        int2 e; e.x = sy; e.y = (b0 & 0xffff) | (b1 << 16);
+        tab.push_back(e);
+    }
+}
+
+extern "C" const char* orbhip_version(void) { return "orbhip 0.1 (gfx950)"; }
+extern "C" const char* orbhip_last_error(void) { return g_err.c_str(); }
+
+extern "C" void orbhip_destroy(orbhip_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    for (auto e : c->pool) (void)hipEventDestroy(e);
+    void* ptrs[] = {c->d_geom, c->d_cells, c->d_tiles, c->d_xtab, c->d_ytab, c->d_pattern, c->d_pyr, c->d_blur, c->d_cell_count, c->d_cell_cand,
+                    c->d_qt_val, c->d_qt_code, c->d_qt_node, c->d_lvl_kp, c->d_lvl_n[0], c->d_lvl_n[1], c->d_out_kp[0], c->d_out_kp[1],
+                    c->d_out_desc[0], c->d_out_desc[1], c->d_out_n[0], c->d_out_n[1], c->d_grid_start, c->d_grid_items, c->d_cand, c->d_ncand,
+                    c->d_prev, c->d_m12, c->d_nm};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cfg)
+{
+    if (!out || !cfg) return fail(ORBHIP_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->nfeatures < 0 || cfg->nlevels < 1 || cfg->nlevels > ORBHIP_MAX_LEVELS || cfg->scale_factor <= 1.0f || cfg->max_batch < 1 ||
+        cfg->width < 1 || cfg->height < 1)
+        return fail(ORBHIP_ERR_INVALID, "bad configuration (nfeatures %d, nlevels %d, scale %f, %dx%d, batch %d)", cfg->nfeatures, cfg->nlevels,
+                    cfg->scale_factor, cfg->width, cfg->height, cfg->max_batch);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(ORBHIP_ERR_HIP, "no HIP device available: the ORB front-end has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(ORBHIP_ERR_INVALID, "device %d out of range (%d devices)", cfg->device, ndev);
+    HIPCHK(hipSetDevice(cfg->device));
+
+    orbhip_ctx* c = new orbhip_ctx; c->cfg = *cfg; c->L = cfg->nlevels; c->B = cfg->max_batch;
+    const int L = c->L;
+    // ---- ORBextractor::ORBextractor (ORBextractor.cc:410-446): double scaleFactor member initialised from the float argument
+    const double scaleFactor = (double)cfg->scale_factor;
+    c->sf.assign(L, 1.0f); c->s2.assign(L, 1.0f); c->isf.assign(L, 1.0f); c->is2.assign(L, 1.0f); c->nfeat.assign(L, 0);
+    for (int i = 1; i < L; i++) { c->sf[i] = (float)(c->sf[i - 1] * scaleFactor); c->s2[i] = c->sf[i] * c->sf[i]; }
+    for (int i = 0; i < L; i++) { c->isf[i] = 1.0f / c->sf[i]; c->is2[i] = 1.0f / c->s2[i]; }
+    {
+        float factor = (float)(1.0f / scaleFactor);
+        float nDesired = cfg->nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)L));
+        int sum = 0;
+        for (int l = 0; l < L - 1; l++) { c->nfeat[l] = cvRoundF(nDesired); sum += c->nfeat[l]; nDesired *= factor; }
+        c->nfeat[L - 1] = std::max(cfg->nfeatures - sum, 0);
+    }
+    // ---- Gaussian kernel of cv::GaussianBlur(7x7, sigma 2) in 8-bit fixed point (getGaussianKernel + convertTo(CV_32S, 256))
+    {
+        float cf[7]; double sum = 0; const double scale2X = -0.5 / (2.0 * 2.0);
+        for (int i = 0; i < 7; i++) { double x = i - 3.0; cf[i] = (float)std::exp(scale2X * x * x); sum += cf[i]; }
+        sum = 1. / sum;
+        for (int i = 0; i < 4; i++) c->gk[i] = cvRoundF((float)(cf[3 + i] * sum) * 256.f);      // centre, +-1, +-2, +-3
+    }
+    // ---- per level geometry (ORBextractor.cc:1111-1112, 773-806, 543-545)
+    c->geom.resize(L);
+    long long plane_off = 0, cand_off = 0; int kp_off = 0;
+    for (int l = 0; l < L; l++) {
+        LevelGeom& g = c->geom[l]; memset(&g, 0, sizeof g);
+        g.w = cvRoundF((float)cfg->width * c->isf[l]); g.h = cvRoundF((float)cfg->height * c->isf[l]);
+        if (g.w < 32 + 30 || g.h < 32 + 30 || g.w > 4095 || g.h > 4095) { delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "level %d is %dx%d: supported level sizes are 62..4095 px per side (the reference divides by zero below 30 px of interior)", l, g.w, g.h); }
+        g.pitch = (g.w + 63) & ~63; g.plane_off = (int)plane_off; plane_off += (long long)g.pitch * g.h;
+        g.maxBorderX = g.w - ORBHIP_EDGE; g.maxBorderY = g.h - ORBHIP_EDGE;
+        const float width = (float)(g.maxBorderX - ORBHIP_EDGE), height = (float)(g.maxBorderY - ORBHIP_EDGE), W = 30;
+        g.nCols = (int)(width / W); g.nRows = (int)(height / W);
+        g.wCell = (int)ceil(width / g.nCols); g.hCell = (int)ceil(height / g.nRows);
+        if (g.wCell > 59 || g.hCell > 59) { delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "cell %dx%d too large", g.wCell, g.hCell); }
+        g.cell_first = (int)c->cells.size(); g.ncells = g.nCols * g.nRows;
+        g.cand_total_off = (int)cand_off;
+        for (int i = 0; i < g.nRows; i++) {
+            const float iniY = ORBHIP_EDGE + i * g.hCell; float maxY = iniY + g.hCell + 6;
+            const bool skipY = iniY >= g.maxBorderY - 3;
+            if (maxY > g.maxBorderY) maxY = (float)g.maxBorderY;
+            for (int j = 0; j < g.nCols; j++) {
+                const float iniX = ORBHIP_EDGE + j * g.wCell; float maxX = iniX + g.wCell + 6;
+                const bool skipX = iniX >= g.maxBorderX - 6;
+                if (maxX > g.maxBorderX) maxX = (float)g.maxBorderX;
+                CellDesc cd; memset(&cd, 0, sizeof cd);
+                cd.level = (short)l; cd.skipped = (skipX || skipY) ? 1 : 0;
+                cd.iniX = (short)iniX; cd.iniY = (short)iniY; cd.maxX = (short)maxX; cd.maxY = (short)maxY;
+                cd.shiftX = (short)(j * g.wCell); cd.shiftY = (short)(i * g.hCell);
+                const int cw = std::max((int)maxX - (int)iniX - 6, 0), ch = std::max((int)maxY - (int)iniY - 6, 0);
+                cd.cand_cap = cd.skipped ? 0 : ((cw + 1) / 2) * ((ch + 1) / 2);       // strict 3x3 maxima are never 8-adjacent
+                cd.cand_idx = (int)cand_off; cand_off += cd.cand_cap;
+                c->cells.push_back(cd);
+            }
+        }
+        g.cand_total_cap = (int)(cand_off - g.cand_total_off);
+        g.nfeat = c->nfeat[l];
+        g.nIni = (int)roundf((float)(g.maxBorderX - ORBHIP_EDGE) / (g.maxBorderY - ORBHIP_EDGE));
+        if (g.nIni < 1) { delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "portrait image: the reference quadtree has zero root nodes (ORBextractor.cc:543-545 divides by zero)"); }
+        g.hX = (float)(g.maxBorderX - ORBHIP_EDGE) / g.nIni;
+        g.kp_cap = std::max(g.nfeat + 3, 4 * g.nIni); g.kp_off = kp_off; kp_off += g.kp_cap;
+        g.scale = c->sf[l]; g.kp_size = (float)(int)(31 * c->sf[l]);                 // scaledPatchSize (:837)
+        c->qt_maxn = std::max(c->qt_maxn, g.kp_cap); c->qt_maxcells = std::max(c->qt_maxcells, g.ncells);
+        if (l > 0) {
+            g.src_w = c->geom[l - 1].w; g.src_h = c->geom[l - 1].h;
+            g.xtab_off = (int)c->xtab.size(); build_resize_table(g.src_w, g.w, c->xtab);
+            g.ytab_off = (int)c->ytab.size(); build_yresize_table(g.src_h, g.h, c->ytab);
+        }
+        for (int y0 = 0; y0 < g.h; y0 += 16) for (int x0 = 0; x0 < g.w; x0 += 64) { TileDesc t; t.level = (short)l; t.x0 = (short)x0; t.y0 = (short)y0; t.pad = 0; c->blur_tiles.push_back(t); }
+    }
+    c->plane_frame_bytes = (plane_off + 255) & ~255LL; c->cand_slots_per_frame = cand_off; c->qt_per_frame = cand_off;
+    c->lvl_kp_per_frame = kp_off; c->out_cap = kp_off; c->lvl0_cap = c->geom[0].kp_cap;
+    if (cand_off >= (1 << 24)) { delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "too many candidate slots"); }
+    if (orbhip_quadtree_lds_bytes(c->qt_maxn, c->qt_maxcells) > 150 * 1024) { delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "nfeatures too large for the LDS quadtree (%d nodes)", c->qt_maxn); }
+    if ((size_t)(2 * c->out_cap + 2 * c->lvl0_cap + 64) * sizeof(int) > 150 * 1024) { delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "nfeatures too large for the LDS matcher"); }
+
+    // ---- device
+    if (cfg->stream) c->stream = (hipStream_t)cfg->stream;
+    else { hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); if (e != hipSuccess) { delete c; return fail(ORBHIP_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); } c->own_stream = true; }
+    const size_t B = (size_t)c->B;
+    std::vector<signed char> pat(kPatternHost, kPatternHost + 1024);
+    hipError_t e = hipSuccess;
+#define TRY(x) do { if (e == hipSuccess) e = (x); } while (0)
+    TRY(upload(&c->d_geom, c->geom)); TRY(upload(&c->d_cells, c->cells)); TRY(upload(&c->d_tiles, c->blur_tiles));
+    TRY(upload(&c->d_xtab, c->xtab)); TRY(upload(&c->d_ytab, c->ytab)); TRY(upload(&c->d_pattern, pat));
+    TRY(dalloc(&c->d_pyr, B * c->plane_frame_bytes + 256)); TRY(dalloc(&c->d_blur, B * c->plane_frame_bytes + 256));
+    TRY(dalloc(&c->d_cell_count, B * c->cells.size())); TRY(dalloc(&c->d_cell_cand, B * c->cand_slots_per_frame));
+    TRY(dalloc(&c->d_qt_val, B * c->qt_per_frame)); TRY(dalloc(&c->d_qt_code, B * c->qt_per_frame)); TRY(dalloc(&c->d_qt_node, B * c->qt_per_frame));
+    TRY(dalloc(&c->d_lvl_kp, B * c->lvl_kp_per_frame));
+    for (int k = 0; k < 2; k++) {
+        TRY(dalloc(&c->d_lvl_n[k], B * L)); TRY(dalloc(&c->d_out_kp[k], B * c->out_cap)); TRY(dalloc(&c->d_out_desc[k], B * c->out_cap * 32)); TRY(dalloc(&c->d_out_n[k], B));
+        if (e == hipSuccess) e = hipMemset(c->d_lvl_n[k], 0, B * L * sizeof(int));
+        if (e == hipSuccess) e = hipMemset(c->d_out_n[k], 0, B * sizeof(int));
+    }
+    TRY(dalloc(&c->d_grid_start, B * (ORBHIP_GRID_CELLS + 1))); TRY(dalloc(&c->d_grid_items, B * c->out_cap));
+    TRY(dalloc(&c->d_cand, B * c->lvl0_cap * (size_t)c->lvl0_cap)); TRY(dalloc(&c->d_ncand, B * c->lvl0_cap));
+    TRY(dalloc(&c->d_prev, B * c->out_cap * 2)); TRY(dalloc(&c->d_m12, B * c->out_cap)); TRY(dalloc(&c->d_nm, B));
+#undef TRY
+    if (e != hipSuccess) { fail(ORBHIP_ERR_HIP, "device allocation failed: %s", hipGetErrorString(e)); orbhip_destroy(c); return ORBHIP_ERR_HIP; }
+    *out = c;
+    return ORBHIP_OK;
+}
+
+extern "C" int orbhip_keypoint_capacity(const orbhip_ctx* c) { return c ? c->out_cap : 0; }
+
+extern "C" orbhip_status orbhip_get_scale_tables(const orbhip_ctx* c, float* sf, float* isf, float* s2, float* is2, int32_t* fpl)
+{
+    if (!c) return fail(ORBHIP_ERR_INVALID, "null context");
+    for (int i = 0; i < c->L; i++) { if (sf) sf[i] = c->sf[i]; if (isf) isf[i] = c->isf[i]; if (s2) s2[i] = c->s2[i]; if (is2) is2[i] = c->is2[i]; if (fpl) fpl[i] = c->nfeat[i]; }
+    return ORBHIP_OK;
+}
+extern "C" orbhip_status orbhip_level_size(const orbhip_ctx* c, int level, int* w, int* h)
+{
+    if (!c || level < 0 || level >= c->L) return fail(ORBHIP_ERR_INVALID, "bad level");
+    if (w) *w = c->geom[level].w; if (h) *h = c->geom[level].h;
+    return ORBHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- pipeline
+static ExtractParams make_params(orbhip_ctx* c, const uint8_t* d_img0, long long frame_stride, int row_stride)
+{
+    ExtractParams P; memset(&P, 0, sizeof P);
+    P.geom = c->d_geom; P.nlevels = c->L;
+    P.img0 = d_img0; P.img0_frame_stride = frame_stride; P.img0_pitch = row_stride;
+    P.pyr = c->d_pyr; P.blur = c->d_blur; P.plane_frame_bytes = c->plane_frame_bytes;
+    P.cells = c->d_cells; P.ncells_total = (int)c->cells.size();
+    P.cell_count = c->d_cell_count; P.cell_cand = c->d_cell_cand; P.cand_slots_per_frame = c->cand_slots_per_frame;
+    P.qt_val = c->d_qt_val; P.qt_code = c->d_qt_code; P.qt_node = c->d_qt_node; P.qt_per_frame = c->qt_per_frame;
+    P.lvl_kp = c->d_lvl_kp; P.lvl_kp_per_frame = c->lvl_kp_per_frame; P.lvl_n = c->d_lvl_n[c->cur];
+    P.out_kp = c->d_out_kp[c->cur]; P.out_desc = c->d_out_desc[c->cur]; P.out_n = c->d_out_n[c->cur]; P.out_cap = c->out_cap;
+    P.blur_tiles = c->d_tiles; P.nblur_tiles = (int)c->blur_tiles.size();
+    P.xtab = c->d_xtab; P.ytab = c->d_ytab; P.pattern = c->d_pattern;
+    P.iniTh = c->cfg.ini_th_fast; P.minTh = c->cfg.min_th_fast; P.blur_round_mode = c->cfg.blur_round_mode;
+    P.qt_maxn = c->qt_maxn; P.qt_maxcells = c->qt_maxcells;
+    return P;
+}
+
+static orbhip_status run_pipeline(orbhip_ctx* c, int nimg, const uint8_t* d_img0, long long frame_stride, int row_stride,
+                                  int match_prev, int window, float nnratio, int check_ori)
+{
+    HIPCHK(hipSetDevice(c->cfg.device));
+    c->cur ^= 1;
+    const ExtractParams P = make_params(c, d_img0, frame_stride, row_stride);
+    { ProfScope ps(c, K_PYRAMID); for (int l = 1; l < c->L; l++) orbhip_launch_pyramid_level(P, l, c->geom[l].w, c->geom[l].h, nimg, c->stream); }
+    { ProfScope ps(c, K_FAST); orbhip_launch_fast_cells(P, nimg, c->stream); }
+    { ProfScope ps(c, K_BLUR); orbhip_launch_blur(P, c->gk, nimg, c->stream); }
+    { ProfScope ps(c, K_QUADTREE); orbhip_launch_quadtree(P, nimg, c->stream); }
+    { ProfScope ps(c, K_DESCRIBE); orbhip_launch_describe(P, nimg, c->stream); }
+    c->last_matched = false;
+    if (match_prev) {
+        const int prev = c->cur ^ 1;
+        MatchParams M; memset(&M, 0, sizeof M);
+        M.kp1 = c->d_out_kp[prev]; M.desc1 = c->d_out_desc[prev]; M.n1 = c->d_out_n[prev]; M.n1_lvl0 = c->d_lvl_n[prev];
+        M.kp2 = c->d_out_kp[c->cur]; M.desc2 = c->d_out_desc[c->cur]; M.n2 = c->d_out_n[c->cur];
+        M.lvl_stride = c->L; M.list1 = nullptr; M.prev_from_kp1 = 1;
+        M.cap = c->out_cap; M.im_w = c->cfg.width; M.im_h = c->cfg.height;
+        M.grid_start = c->d_grid_start; M.grid_items = c->d_grid_items; M.cand = c->d_cand; M.ncand = c->d_ncand; M.cand_stride = c->lvl0_cap; M.lvl0_cap = c->lvl0_cap;
+        M.prev = c->d_prev; M.matches12 = c->d_m12; M.nmatches = c->d_nm; M.window = window; M.nnratio = nnratio; M.check_ori = check_ori;
+        { ProfScope ps(c, K_MGRID); orbhip_launch_match_grid(M, nimg, c->stream); }
+        { ProfScope ps(c, K_MCAND); orbhip_launch_match_candidates(M, nimg, c->stream); }
+        { ProfScope ps(c, K_MSELECT); orbhip_launch_match_select(M, nimg, c->stream); }
+        c->last_matched = true;
+    }
+    c->last_nimg = nimg;
+    HIPCHK(hipGetLastError());
+    return ORBHIP_OK;
+}
+
+extern "C" orbhip_status orbhip_extract_device(orbhip_ctx* c, int nimg, const uint8_t* d_imgs, size_t frame_stride, int row_stride,
+                                               int match_prev, int window, float nnratio, int check_ori)
+{
+    if (!c || !d_imgs) return fail(ORBHIP_ERR_INVALID, "null argument");
+    if (nimg < 1 || nimg > c->B) return fail(ORBHIP_ERR_INVALID, "nimg %d outside 1..%d", nimg, c->B);
+    if (row_stride < c->cfg.width) return fail(ORBHIP_ERR_INVALID, "row stride %d < width %d", row_stride, c->cfg.width);
+    c->last_from_host = false;
+    return run_pipeline(c, nimg, d_imgs, (long long)frame_stride, row_stride, match_prev, window, nnratio, check_ori);
+}
+
+extern "C" orbhip_status orbhip_sync(orbhip_ctx* c)
+{
+    if (!c) return fail(ORBHIP_ERR_INVALID, "null context");
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    return ORBHIP_OK;
+}
+
+extern "C" orbhip_status orbhip_fetch(orbhip_ctx* c, int nimg, orbhip_keypoint* kps, uint8_t* desc, int cap, int* n_out)
+{
+    if (!c || !n_out) return fail(ORBHIP_ERR_INVALID, "null argument");
+    if (nimg < 1 || nimg > c->last_nimg) return fail(ORBHIP_ERR_INVALID, "nimg %d but the last call processed %d frames", nimg, c->last_nimg);
+    orbhip_status st = orbhip_sync(c); if (st != ORBHIP_OK) return st;
+    std::vector<int> n(nimg);
+    HIPCHK(hipMemcpy(n.data(), c->d_out_n[c->cur], nimg * sizeof(int), hipMemcpyDeviceToHost));
+    bool overflow = false;
+    for (int f = 0; f < nimg; f++) {
+        n_out[f] = n[f];
+        const int m = std::min(n[f], cap);
+        if (n[f] > cap) overflow = true;
+        if (m > 0 && kps) HIPCHK(hipMemcpy(kps + (size_t)f * cap, c->d_out_kp[c->cur] + (size_t)f * c->out_cap, (size_t)m * sizeof(orbhip_keypoint), hipMemcpyDeviceToHost));
+        if (m > 0 && desc) HIPCHK(hipMemcpy(desc + (size_t)f * cap * 32, c->d_out_desc[c->cur] + (size_t)f * c->out_cap * 32, (size_t)m * 32, hipMemcpyDeviceToHost));
+    }
+    return overflow ? fail(ORBHIP_ERR_CAPACITY, "keypoint buffer too small") : ORBHIP_OK;
+}
+
+extern "C" orbhip_status orbhip_fetch_matches(orbhip_ctx* c, int nimg, int32_t* matches12, int cap1, int32_t* n1_out, int32_t* nmatches)
+{
+    if (!c) return fail(ORBHIP_ERR_INVALID, "null context");
+    if (!c->last_matched) return fail(ORBHIP_ERR_INVALID, "the last call did not run the matcher");
+    if (nimg < 1 || nimg > c->last_nimg) return fail(ORBHIP_ERR_INVALID, "bad nimg");
+    orbhip_status st = orbhip_sync(c); if (st != ORBHIP_OK) return st;
+    std::vector<int> n1(nimg);
+    HIPCHK(hipMemcpy(n1.data(), c->d_out_n[c->cur ^ 1], nimg * sizeof(int), hipMemcpyDeviceToHost));
+    if (nmatches) HIPCHK(hipMemcpy(nmatches, c->d_nm, nimg * sizeof(int), hipMemcpyDeviceToHost));
+    for (int f = 0; f < nimg; f++) {
+        if (n1_out) n1_out[f] = n1[f];
+        const int m = std::min(n1[f], cap1);
+        if (m > 0 && matches12) HIPCHK(hipMemcpy(matches12 + (size_t)f * cap1, c->d_m12 + (size_t)f * c->out_cap, (size_t)m * sizeof(int), hipMemcpyDeviceToHost));
+    }
+    return ORBHIP_OK;
+}
+
+extern "C" orbhip_status orbhip_extract_batch(orbhip_ctx* c, int nimg, const uint8_t* const* imgs, int stride, orbhip_keypoint* kps, uint8_t* desc, int cap, int* n_out)
+{
+    if (!c || !imgs || !n_out) return fail(ORBHIP_ERR_INVALID, "null argument");
+    if (nimg < 1 || nimg > c->B) return fail(ORBHIP_ERR_INVALID, "nimg %d outside 1..%d", nimg, c->B);
+    if (stride < c->cfg.width) return fail(ORBHIP_ERR_INVALID, "stride %d < width %d", stride, c->cfg.width);
+    HIPCHK(hipSetDevice(c->cfg.device));
+    const LevelGeom& g0 = c->geom[0];
+    for (int f = 0; f < nimg; f++) {
+        if (!imgs[f]) return fail(ORBHIP_ERR_INVALID, "image %d is null", f);
+        HIPCHK(hipMemcpy2DAsync(c->d_pyr + (size_t)f * c->plane_frame_bytes + g0.plane_off, g0.pitch, imgs[f], stride, c->cfg.width, c->cfg.height, hipMemcpyHostToDevice, c->stream));
+    }
+    c->last_from_host = true;
+    orbhip_status st = run_pipeline(c, nimg, c->d_pyr + g0.plane_off, c->plane_frame_bytes, g0.pitch, 0, 0, 0.f, 0);
+    if (st != ORBHIP_OK) return st;
+    return orbhip_fetch(c, nimg, kps, desc, cap, n_out);
+}
+
+extern "C" orbhip_status orbhip_extract(orbhip_ctx* c, const uint8_t* img, int stride, orbhip_keypoint* kps, uint8_t* desc, int cap, int* n_out)
+{
+    if (!c || !n_out) return fail(ORBHIP_ERR_INVALID, "null argument");
+    if (!img) { *n_out = 0; return ORBHIP_OK; }                       // if(_image.empty()) return;  (ORBextractor.cc:1046-1047)
+    const uint8_t* imgs[1] = {img};
+    return orbhip_extract_batch(c, 1, imgs, stride, kps, desc, cap, n_out);
+}
+
+static orbhip_status copy_plane(orbhip_ctx* c, const uint8_t* d_base, int pitch, int w, int h, uint8_t* dst, int dst_stride)
+{
+    orbhip_status st = orbhip_sync(c); if (st != ORBHIP_OK) return st;
+    HIPCHK(hipMemcpy2DAsync(dst, dst_stride, d_base, pitch, w, h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return ORBHIP_OK;
+}
+extern "C" orbhip_status orbhip_pyramid_level(orbhip_ctx* c, int frame, int level, uint8_t* dst, int dst_stride)
+{
+    if (!c || !dst || level < 0 || level >= c->L || frame < 0 || frame >= c->last_nimg) return fail(ORBHIP_ERR_INVALID, "bad argument");
+    const LevelGeom& g = c->geom[level];
+    if (level == 0 && !c->last_from_host) return fail(ORBHIP_ERR_INVALID, "level 0 of a device-resident call is the caller's own buffer");
+    return copy_plane(c, c->d_pyr + (size_t)frame * c->plane_frame_bytes + g.plane_off, g.pitch, g.w, g.h, dst, dst_stride);
+}
+extern "C" orbhip_status orbhip_debug_blurred_level(orbhip_ctx* c, int frame, int level, uint8_t* dst, int dst_stride)
+{
+    if (!c || !dst || level < 0 || level >= c->L || frame < 0 || frame >= c->last_nimg) return fail(ORBHIP_ERR_INVALID, "bad argument");
+    const LevelGeom& g = c->geom[level];
+    return copy_plane(c, c->d_blur + (size_t)frame * c->plane_frame_bytes + g.plane_off, g.pitch, g.w, g.h, dst, dst_stride);
+}
+extern "C" orbhip_status orbhip_debug_candidates(orbhip_ctx* c, int frame, int level, int32_t* xys, int cap, int* n_out)
+{
+    if (!c || !n_out || level < 0 || level >= c->L || frame < 0 || frame >= c->last_nimg) return fail(ORBHIP_ERR_INVALID, "bad argument");
+    orbhip_status st = orbhip_sync(c); if (st != ORBHIP_OK) return st;
+    const LevelGeom& g = c->geom[level];
+    std::vector<int> counts(g.ncells);
+    HIPCHK(hipMemcpy(counts.data(), c->d_cell_count + (size_t)frame * c->cells.size() + g.cell_first, g.ncells * sizeof(int), hipMemcpyDeviceToHost));
+    long long n = 0; for (int v : counts) n += v;
+    *n_out = (int)n;
+    const int m = (int)std::min<long long>(n, cap);
+    if (m > 0 && xys) {
+        std::vector<unsigned> v(m);
+        HIPCHK(hipMemcpy(v.data(), c->d_qt_val + (size_t)frame * c->qt_per_frame + g.cand_total_off, (size_t)m * sizeof(unsigned), hipMemcpyDeviceToHost));
+        for (int i = 0; i < m; i++) { xys[3 * i] = v[i] & 0xfff; xys[3 * i + 1] = (v[i] >> 12) & 0xfff; xys[3 * i + 2] = v[i] >> 24; }
+    }
+    return ORBHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- measurement
+extern "C" orbhip_status orbhip_profile_enable(orbhip_ctx* c, int on) { if (!c) return fail(ORBHIP_ERR_INVALID, "null context"); c->prof = on != 0; return ORBHIP_OK; }
+extern "C" int orbhip_profile_num_kernels(const orbhip_ctx*) { return K_COUNT; }
+extern "C" orbhip_status orbhip_profile_get(orbhip_ctx* c, int k, const char** name, double* total_ms, int64_t* launches)
+{
+    if (!c || k < 0 || k >= K_COUNT) return fail(ORBHIP_ERR_INVALID, "bad kernel index");
+    prof_collect(c);
+    if (name) *name = kKernelNames[k]; if (total_ms) *total_ms = c->tot_ms[k]; if (launches) *launches = c->launches[k];
+    return ORBHIP_OK;
+}
+extern "C" orbhip_status orbhip_profile_reset(orbhip_ctx* c)
+{
+    if (!c) return fail(ORBHIP_ERR_INVALID, "null context");
+    prof_collect(c);
+    for (int k = 0; k < K_COUNT; k++) { c->tot_ms[k] = 0; c->launches[k] = 0; }
+    return ORBHIP_OK;
+}
+extern "C" int64_t orbhip_algorithmic_bytes_per_frame(const orbhip_ctx* c)
+{   // B(W,H,N) = P0 + (SP-P0) + (SP-P7) + SP + 2*SP + N*(749+512) + N*(28+32)      
+    if (!c) return 0;
+    long long SP = 0; for (auto& g : c->geom) SP += (long long)g.w * g.h;
+    const long long P0 = (long long)c->geom[0].w * c->geom[0].h, PL = (long long)c->geom[c->L - 1].w * c->geom[c->L - 1].h, N = c->cfg.nfeatures;
+    return P0 + (SP - P0) + (SP - PL) + SP + 2 * SP + N * (749 + 512) + N * (28 + 32);
+}
+extern "C" int64_t orbhip_algorithmic_bytes_per_frame_kernel(const orbhip_ctx* c, int k)
+{   // the terms of B(W,H,N) attributed to the kernel that moves them
+    if (!c) return 0;
+    long long SP = 0; for (auto& g : c->geom) SP += (long long)g.w * g.h;
+    const long long P0 = (long long)c->geom[0].w * c->geom[0].h, PL = (long long)c->geom[c->L - 1].w * c->geom[c->L - 1].h, N = c->cfg.nfeatures;
+    switch (k) {
+        case K_PYRAMID: return (SP - PL) + (SP - P0);
+        case K_FAST: return SP;
+        case K_BLUR: return 2 * SP;
+        case K_DESCRIBE: return N * (749 + 512) + N * (28 + 32);
+        default: return 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- stateless matcher entry points
+extern "C" int orbhip_descriptor_distance(const uint8_t* a, const uint8_t* b)
+{
+    unsigned long long x[4], y[4]; memcpy(x, a, 32); memcpy(y, b, 32);
+    return __builtin_popcountll(x[0] ^ y[0]) + __builtin_popcountll(x[1] ^ y[1]) + __builtin_popcountll(x[2] ^ y[2]) + __builtin_popcountll(x[3] ^ y[3]);
+}
+
+static thread_local void* g_nn_ws = nullptr; static thread_local size_t g_nn_ws_bytes = 0;
+void* orbhip_nn_workspace(size_t bytes, hipStream_t s)
+{
+    if (bytes > g_nn_ws_bytes) {
+        if (g_nn_ws) { (void)hipStreamSynchronize(s); (void)hipFree(g_nn_ws); g_nn_ws = nullptr; g_nn_ws_bytes = 0; }
+        if (hipMalloc(&g_nn_ws, bytes) != hipSuccess) { g_nn_ws = nullptr; return nullptr; }
+        g_nn_ws_bytes = bytes;
+    }
+    return g_nn_ws;
+}
+
+extern "C" orbhip_status orbhip_hamming_nn_device(void* stream, const uint8_t* d_q, int nq, const uint8_t* d_db, int64_t ndb, int64_t base,
+                                                  int64_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second)
+{
+    if (nq < 0 || ndb < 0 || (nq > 0 && (!d_q || !d_best_idx || !d_best_dist || !d_second)) || (ndb > 0 && !d_db)) return fail(ORBHIP_ERR_INVALID, "bad argument");
+    orbhip_launch_hamming_nn(d_q, nq, d_db, ndb, base, (long long*)d_best_idx, d_best_dist, d_second, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return ORBHIP_OK;
+}
+
+extern "C" orbhip_status orbhip_hamming_nn(int device, const uint8_t* q, int nq, const uint8_t* db, int64_t ndb, int64_t base,
+                                           int64_t* best_idx, int32_t* best_dist, int32_t* second_dist)
+{
+    if (nq < 0 || ndb < 0 || (nq > 0 && (!q || !best_idx || !best_dist || !second_dist)) || (ndb > 0 && !db)) return fail(ORBHIP_ERR_INVALID, "bad argument");
+    if (nq == 0) return ORBHIP_OK;
+    int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(ORBHIP_ERR_HIP, "no HIP device available: no CPU fallback");
+    HIPCHK(hipSetDevice(device));
+    uint8_t *dq = nullptr, *ddb = nullptr; long long* dbi = nullptr; int *dbd = nullptr, *dsd = nullptr;
+    orbhip_status st = ORBHIP_OK;
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = hipMalloc((void**)&dq, (size_t)nq * 32);
+    if (e == hipSuccess) e = hipMalloc((void**)&ddb, std::max<size_t>((size_t)ndb * 32, 32));
+    if (e == hipSuccess) e = hipMalloc((void**)&dbi, (size_t)nq * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&dbd, (size_t)nq * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&dsd, (size_t)nq * 4);
+    if (e == hipSuccess) e = hipMemcpy(dq, q, (size_t)nq * 32, hipMemcpyHostToDevice);
+    if (e == hipSuccess && ndb > 0) e = hipMemcpy(ddb, db, (size_t)ndb * 32, hipMemcpyHostToDevice);
+    if (e == hipSuccess) { orbhip_launch_hamming_nn(dq, nq, ddb, ndb, base, dbi, dbd, dsd, nullptr); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(best_idx, dbi, (size_t)nq * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(best_dist, dbd, (size_t)nq * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(second_dist, dsd, (size_t)nq * 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) st = fail(ORBHIP_ERR_HIP, "hamming_nn: %s", hipGetErrorString(e));
+    (void)hipFree(dq); (void)hipFree(ddb); (void)hipFree(dbi); (void)hipFree(dbd); (void)hipFree(dsd);
+    return st;
+}
+
+extern "C" orbhip_status orbhip_search_for_initialization(int device, const orbhip_keypoint* kps1, const uint8_t* desc1, int n1,
+                                                          const orbhip_keypoint* kps2, const uint8_t* desc2, int n2, int im_w, int im_h,
+                                                          float* prev_matched, int32_t* matches12, int window, float nnratio, int check_ori, int* nmatches)
+{
+    if (n1 < 0 || n2 < 0 || !nmatches || (n1 > 0 && (!kps1 || !desc1 || !prev_matched || !matches12)) || (n2 > 0 && (!kps2 || !desc2)) || im_w < 1 || im_h < 1)
+        return fail(ORBHIP_ERR_INVALID, "bad argument");
+    *nmatches = 0;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    if (n1 == 0) return ORBHIP_OK;
+    int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(ORBHIP_ERR_HIP, "no HIP device available: no CPU fallback");
+    HIPCHK(hipSetDevice(device));
+    // Frame members flattened: level-0 keypoints of F1 in index order (the loop at ORBmatcher.cc:418-423 skips the rest)
+    std::vector<int> list1; for (int i = 0; i < n1; i++) if (kps1[i].octave <= 0) list1.push_back(i);
+    int n2l0 = 0; for (int i = 0; i < n2; i++) n2l0 += kps2[i].octave == 0;
+    const int cap = std::max(std::max(n1, n2), 1), l0cap = std::max((int)list1.size(), 1), cstride = std::max(n2l0, 1);
+    if ((size_t)(2 * cap + 2 * l0cap + 64) * sizeof(int) > 150 * 1024) return fail(ORBHIP_ERR_UNSUPPORTED, "too many keypoints for the LDS matcher");
+    orbhip_keypoint *dk1 = nullptr, *dk2 = nullptr; uint8_t *dd1 = nullptr, *dd2 = nullptr; int *dn = nullptr, *dlist = nullptr, *dgs = nullptr, *dgi = nullptr, *dnc = nullptr, *dm12 = nullptr;
+    unsigned* dcand = nullptr; float* dprev = nullptr;
+    hipError_t e = hipSuccess;
+#define TRY(x) do { if (e == hipSuccess) e = (x); } while (0)
+    TRY(dalloc(&dk1, cap)); TRY(dalloc(&dk2, cap)); TRY(dalloc(&dd1, (size_t)cap * 32)); TRY(dalloc(&dd2, (size_t)cap * 32)); TRY(dalloc(&dn, 8));
+    TRY(dalloc(&dlist, l0cap)); TRY(dalloc(&dgs, ORBHIP_GRID_CELLS + 1)); TRY(dalloc(&dgi, cap)); TRY(dalloc(&dnc, l0cap)); TRY(dalloc(&dm12, cap));
+    TRY(dalloc(&dcand, (size_t)l0cap * cstride)); TRY(dalloc(&dprev, (size_t)cap * 2));
+    const int hn[4] = {n1, n2, (int)list1.size(), 0};
+    TRY(hipMemcpy(dk1, kps1, (size_t)n1 * sizeof(orbhip_keypoint), hipMemcpyHostToDevice)); TRY(hipMemcpy(dd1, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice));
+    if (n2 > 0) { TRY(hipMemcpy(dk2, kps2, (size_t)n2 * sizeof(orbhip_keypoint), hipMemcpyHostToDevice)); TRY(hipMemcpy(dd2, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice)); }
+    TRY(hipMemcpy(dn, hn, sizeof hn, hipMemcpyHostToDevice));
+    if (!list1.empty()) TRY(hipMemcpy(dlist, list1.data(), list1.size() * sizeof(int), hipMemcpyHostToDevice));
+    TRY(hipMemcpy(dprev, prev_matched, (size_t)n1 * 2 * sizeof(float), hipMemcpyHostToDevice));
+    if (e == hipSuccess) {
+        MatchParams M; memset(&M, 0, sizeof M);
+        M.kp1 = dk1; M.desc1 = dd1; M.n1 = dn; M.n1_lvl0 = dn + 2; M.kp2 = dk2; M.desc2 = dd2; M.n2 = dn + 1; M.lvl_stride = 0; M.list1 = dlist; M.prev_from_kp1 = 0;
+        M.cap = cap; M.im_w = im_w; M.im_h = im_h; M.grid_start = dgs; M.grid_items = dgi; M.cand = dcand; M.ncand = dnc; M.cand_stride = cstride; M.lvl0_cap = l0cap;
+        M.prev = dprev; M.matches12 = dm12; M.nmatches = dn + 3; M.window = window; M.nnratio = nnratio; M.check_ori = check_ori;
+        orbhip_launch_match_grid(M, 1, nullptr); orbhip_launch_match_candidates(M, 1, nullptr); orbhip_launch_match_select(M, 1, nullptr);
+        e = hipGetLastError();
+    }
+    TRY(hipDeviceSynchronize());
+    TRY(hipMemcpy(matches12, dm12, (size_t)n1 * sizeof(int), hipMemcpyDeviceToHost));
+    TRY(hipMemcpy(prev_matched, dprev, (size_t)n1 * 2 * sizeof(float), hipMemcpyDeviceToHost));
+    TRY(hipMemcpy(nmatches, dn + 3, sizeof(int), hipMemcpyDeviceToHost));
+#undef TRY
+    orbhip_status st = ORBHIP_OK;
+    if (e != hipSuccess) st = fail(ORBHIP_ERR_HIP, "search_for_initialization: %s", hipGetErrorString(e));
+    void* ptrs[] = {dk1, dk2, dd1, dd2, dn, dlist, dgs, dgi, dnc, dm12, dcand, dprev};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    return st;
+}

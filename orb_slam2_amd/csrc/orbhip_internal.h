@@ -1,0 +1,99 @@
+// orbhip_internal.h — layouts shared by the host orchestration (orbhip_api.cpp) and the gfx950 kernels.
+//
+// HBM layout of one context (fixed W x H, B = max_batch camera slots); all arrays are [frame][...]:
+//   planes      u8   per frame: levels 0..L-1, level l at plane_off[l], row pitch[l] (multiple of 64 B).
+//               Two plane sets: pyramid (its level-0 slot is only used by the host-image API; the device API
+//               reads level 0 straight from the caller's buffer) and blurred.  FAST scores never reach HBM:
+//               one wavefront per grid cell computes, suppresses and emits them from LDS.
+//   cell_count  i32  per frame: one counter per FAST grid cell of every level
+//   cell_cand   u32  per frame: per-cell candidate slots (cand_idx + rank), packed x | y<<12 | score<<24 in
+//                    cell-space coordinates (ORBextractor.cc:820-825), row-major inside the cell
+//   qt_val/qt_code/qt_node  per frame, per level dense candidate arrays in canonical vToDistributeKeys order
+//   lvl_kp      u32  per frame: post-quadtree keypoints per level in list order (kp_off[l] + pos), packed like
+//                    cell_cand but in level coordinates; lvl_n i32[L] counts
+//   out_kp / out_desc / out_n: final level-major output (ORBextractor.cc:1075-1104), double-buffered per call
+//                    parity so the previous frame of every camera slot stays resident for the matcher.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "../../include/orbhip.h"
+
+#define ORBHIP_MAX_LEVELS 16
+#define ORBHIP_QT_DEPTH 13          // quadtree path digits kept per candidate (2 bits each)
+#define ORBHIP_GRID_COLS 64         // Frame.h:37-38
+#define ORBHIP_GRID_ROWS 48
+#define ORBHIP_GRID_CELLS (ORBHIP_GRID_COLS * ORBHIP_GRID_ROWS)
+#define ORBHIP_HISTO_LENGTH 30      // ORBmatcher.cc:39
+#define ORBHIP_TH_LOW 50            // ORBmatcher.cc:38
+#define ORBHIP_EDGE 16              // minBorder = EDGE_THRESHOLD-3 (ORBextractor.cc:773)
+
+struct LevelGeom {
+    int w, h, pitch, plane_off;                 // level image
+    int nCols, nRows, wCell, hCell;             // FAST grid (ORBextractor.cc:781-787)
+    int maxBorderX, maxBorderY;                 // cols-16, rows-16 (ORBextractor.cc:775-776)
+    int cell_first, ncells;                     // index range in the CellDesc table
+    int cand_total_off, cand_total_cap;         // dense per-level candidate arrays (quadtree workspace)
+    int nfeat, kp_cap, kp_off;                  // mnFeaturesPerLevel, capacity max(nfeat+3, 4*nIni), offset
+    int nIni; float hX;                         // quadtree roots (ORBextractor.cc:543-545)
+    float scale, kp_size;                       // mvScaleFactor[l], (float)(int)(31*scale)
+    int xtab_off, ytab_off;                     // resize coefficient tables (levels >= 1): {src index, a0 | a1<<16}
+    int src_w, src_h;                           // size of level l-1
+};
+
+struct CellDesc {           // one FAST cell (ORBextractor.cc:789-816)
+    short level, skipped;
+    short iniX, iniY, maxX, maxY;   // sub-image [iniY,maxY) x [iniX,maxX) in level coordinates
+    short shiftX, shiftY;           // j*wCell, i*hCell (added to cell-local coordinates, :822-823)
+    int cand_idx;                   // first slot of this cell in cell_cand (per frame)
+    int cand_cap;
+};
+
+struct TileDesc { short level, x0, y0, pad; };
+
+struct ExtractParams {
+    const LevelGeom* geom; int nlevels;
+    const uint8_t* img0; long long img0_frame_stride; int img0_pitch;      // level-0 source
+    uint8_t* pyr; uint8_t* blur; long long plane_frame_bytes;
+    const CellDesc* cells; int ncells_total;
+    int* cell_count; unsigned* cell_cand; long long cand_slots_per_frame;
+    unsigned* qt_val; unsigned* qt_code; int* qt_node; long long qt_per_frame;
+    unsigned* lvl_kp; int lvl_kp_per_frame; int* lvl_n;
+    orbhip_keypoint* out_kp; uint8_t* out_desc; int* out_n; int out_cap;
+    const TileDesc* blur_tiles; int nblur_tiles;
+    const int2* xtab; const int2* ytab;
+    const signed char* pattern;                                            // 256 x (x0,y0,x1,y1)
+    int iniTh, minTh, blur_round_mode;
+    int qt_maxn;                                                           // LDS node capacity of the quadtree kernel
+    int qt_maxcells;                                                       // max cells of one level
+};
+
+struct MatchParams {        // SearchForInitialization over camera slots (ORBmatcher.cc:405-520)
+    const orbhip_keypoint* kp1; const uint8_t* desc1; const int* n1;    // previous frames [slot][cap], counts [slot]
+    const int* n1_lvl0; int lvl_stride;                                 // number of level-0 keypoints of F1: n1_lvl0[slot*lvl_stride]
+    const int* list1;                                                   // indices of F1's level-0 keypoints [slot][lvl0_cap]; NULL = identity
+    int prev_from_kp1;                                                  // 1: vbPrevMatched starts as F1's keypoint positions (Tracking.cc:590-592)
+    const orbhip_keypoint* kp2; const uint8_t* desc2; const int* n2;    // current frames
+    int cap;                                      // keypoint capacity per frame (stride of the arrays above)
+    int im_w, im_h;
+    int* grid_start; int* grid_items;             // [slot][GRID_CELLS+1], [slot][cap]  (Frame.cc:230-245 on F2)
+    unsigned* cand; int* ncand; int cand_stride;  // [slot][n1_lvl0_cap][cand_stride]: i2 | dist<<16, canonical order
+    int lvl0_cap;
+    float* prev;                                  // [slot][cap][2] vbPrevMatched (in/out)
+    int* matches12; int* nmatches;                // [slot][cap], [slot]
+    int window; float nnratio; int check_ori;
+};
+
+// kernel launchers (orbhip_kernels_extract.hip / orbhip_kernels_match.hip)
+void orbhip_launch_pyramid_level(const ExtractParams& P, int level, int w, int h, int nframes, hipStream_t s);
+void orbhip_launch_blur(const ExtractParams& P, const int gk[4], int nframes, hipStream_t s);
+void orbhip_launch_fast_cells(const ExtractParams& P, int nframes, hipStream_t s);
+void orbhip_launch_quadtree(const ExtractParams& P, int nframes, hipStream_t s);
+void orbhip_launch_describe(const ExtractParams& P, int nframes, hipStream_t s);
+size_t orbhip_quadtree_lds_bytes(int maxn, int maxcells);
+void* orbhip_nn_workspace(size_t bytes, hipStream_t s);
+
+void orbhip_launch_hamming_nn(const uint8_t* d_q, int nq, const uint8_t* d_db, long long ndb, long long base,
+                              long long* d_best_idx, int* d_best_dist, int* d_second, hipStream_t s);
+void orbhip_launch_match_grid(const MatchParams& M, int nslots, hipStream_t s);
+void orbhip_launch_match_candidates(const MatchParams& M, int nslots, hipStream_t s);
+void orbhip_launch_match_select(const MatchParams& M, int nslots, hipStream_t s);

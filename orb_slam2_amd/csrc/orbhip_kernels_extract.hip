@@ -1,0 +1,582 @@
+// orbhip_kernels_extract.hip — gfx950 kernels of the ORB extractor (replaces src/ORBextractor.cc of the reference).
+//
+// Kernels (one launch each covers every camera slot of the batch; grid.y / grid.z = frame):
+//   k_pyramid_level  level l from level l-1, fixed-point bilinear        (ORBextractor.cc:1107-1132, cv::resize)
+//   k_blur           7x7 sigma-2 fixed-point Gaussian, LDS tiled          (ORBextractor.cc:1085-1086, cv::GaussianBlur)
+//   k_fast_cells     ONE WAVEFRONT PER GRID CELL: FAST-9/16 scores in LDS, iniTh/minTh fallback, 3x3 NMS inside
+//                    the cell, row-major emission                          (ORBextractor.cc:789-829, cv::FAST)
+//   k_quadtree       one workgroup per (frame, level): DistributeOctTree replayed with exact list order
+//                    (ORBextractor.cc:539-763) on per-candidate quad-path codes instead of std::list nodes
+//   k_describe       one wavefront per keypoint: IC_Angle, fastAtan2, steered BRIEF via 4 ballots
+//                    (ORBextractor.cc:77-147, 1034-1104)
+// Everything is integer / bitwise except the orientation and the pattern rotation, which use explicitly
+// rounded IEEE ops (__fmul_rn ...; file built with -ffp-contract=off) so results are bit-identical to the CPU
+// oracle's two-rounding form.  No MFMA: nothing here is GEMM-shaped.
+#include "orbhip_internal.h"
+
+#define WAVE 64
+
+__device__ __forceinline__ const uint8_t* level_src(const ExtractParams& P, int frame, int level, int& pitch)
+{
+    if (level == 0) { pitch = P.img0_pitch; return P.img0 + (long long)frame * P.img0_frame_stride; }
+    pitch = P.geom[level].pitch;
+    return P.pyr + (long long)frame * P.plane_frame_bytes + P.geom[level].plane_off;
+}
+
+// ------------------------------------------------------------------------------------------------ pyramid
+// cv::resize INTER_LINEAR CV_8U (OpenCV 3.2 HResizeLinear / VResizeLinear fixed point, 11-bit coefficients).
+// Coefficient tables are built on the host exactly as OpenCV builds them; the kernel is pure integer.
+// 4 output pixels per thread, one 32-bit store.
+__global__ __launch_bounds__(256) void k_pyramid_level(ExtractParams P, int level)
+{
+    const LevelGeom g = P.geom[level];
+    const int frame = blockIdx.z;
+    const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (y >= g.h || x4 >= g.w) return;
+    int spitch; const uint8_t* src = level_src(P, frame, level - 1, spitch);
+    uint8_t* dst = P.pyr + (long long)frame * P.plane_frame_bytes + g.plane_off + (long long)y * g.pitch;
+    const int2 yt = P.ytab[g.ytab_off + y];
+    const int b0 = yt.y & 0xffff, b1 = (yt.y >> 16) & 0xffff;
+    const int ya = min(max(yt.x, 0), g.src_h - 1), yb = min(max(yt.x + 1, 0), g.src_h - 1);
+    const uint8_t* r0 = src + (long long)ya * spitch;
+    const uint8_t* r1 = src + (long long)yb * spitch;
+    unsigned out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int x = x4 + k;
+        if (x < g.w) {
+            const int2 xt = P.xtab[g.xtab_off + x];
+            const int a0 = xt.y & 0xffff, a1 = (xt.y >> 16) & 0xffff;
+            const int sx = xt.x, sx1 = min(sx + 1, g.src_w - 1);
+            const int h0 = r0[sx] * a0 + r0[sx1] * a1;
+            const int h1 = r1[sx] * a0 + r1[sx1] * a1;
+            const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            out |= (unsigned)(v & 0xff) << (8 * k);
+        }
+    }
+    *reinterpret_cast<unsigned*>(dst + x4) = out;
+}
+
+void orbhip_launch_pyramid_level(const ExtractParams& P, int level, int w, int h, int nframes, hipStream_t s)
+{
+    dim3 grid((w + 255) / 256, (h + 3) / 4, nframes), block(64, 4, 1);
+    hipLaunchKernelGGL(k_pyramid_level, grid, block, 0, s, P, level);
+}
+
+// ------------------------------------------------------------------------------------------------ blur
+// cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) on 8U: int kernel {k3,k2,k1,k0,k1,k2,k3} = {18,34,49,55,49,34,18}
+// (computed on the host from getGaussianKernel + cvRound(k*256)), int32 row pass, column pass rounded with 16 bits.
+#define BLUR_TW 64
+#define BLUR_TH 16
+__device__ __forceinline__ int reflect101_clamped(int p, int len)
+{
+    if (p < 0) p = -p; else if (p >= len) p = 2 * (len - 1) - p;
+    return min(max(p, 0), len - 1);      // second clamp only touches halo positions no output reads
+}
+struct BlurK { int k0, k1, k2, k3; };
+__global__ __launch_bounds__(256) void k_blur(ExtractParams P, BlurK K)
+{
+    const TileDesc t = P.blur_tiles[blockIdx.x];
+    const int frame = blockIdx.y, tid = threadIdx.x;
+    const LevelGeom g = P.geom[t.level];
+    int spitch; const uint8_t* src = level_src(P, frame, t.level, spitch);
+    __shared__ uint8_t s_src[BLUR_TH + 6][BLUR_TW + 8];
+    __shared__ unsigned short s_h[BLUR_TH + 6][BLUR_TW];
+    for (int i = tid; i < (BLUR_TH + 6) * (BLUR_TW + 6); i += 256) {
+        const int r = i / (BLUR_TW + 6), c = i - r * (BLUR_TW + 6);
+        const int sy = reflect101_clamped(t.y0 - 3 + r, g.h), sx = reflect101_clamped(t.x0 - 3 + c, g.w);
+        s_src[r][c] = src[(long long)sy * spitch + sx];
+    }
+    __syncthreads();
+    for (int i = tid; i < (BLUR_TH + 6) * BLUR_TW; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        const uint8_t* p = &s_src[r][c];
+        const int sum = K.k3 * (p[0] + p[6]) + K.k2 * (p[1] + p[5]) + K.k1 * (p[2] + p[4]) + K.k0 * p[3];
+        s_h[r][c] = (unsigned short)sum;            // <= 255 * 257 = 65535
+    }
+    __syncthreads();
+    const int x = (tid & 15) * 4, y = tid >> 4;
+    const int gx = t.x0 + x, gy = t.y0 + y;
+    if (gy >= g.h || gx >= g.w) return;
+    const int wv = g.w & ~3;
+    unsigned out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int c = x + k;
+        const int sum = K.k3 * ((int)s_h[y][c] + s_h[y + 6][c]) + K.k2 * ((int)s_h[y + 1][c] + s_h[y + 5][c]) +
+                        K.k1 * ((int)s_h[y + 2][c] + s_h[y + 4][c]) + K.k0 * (int)s_h[y + 3][c];
+        int v;
+        if (P.blur_round_mode == 1 && (gx + k) < wv) {   // x86 SSE2 build of OpenCV: round-half-even via cvtps2dq
+            v = sum >> 16; const int rem = sum & 0xFFFF;
+            if (rem > 0x8000 || (rem == 0x8000 && (v & 1))) v++;
+        } else v = (sum + (1 << 15)) >> 16;              // generic FixedPtCastEx
+        v = min(v, 255);
+        out |= (unsigned)v << (8 * k);
+    }
+    uint8_t* dst = P.blur + (long long)frame * P.plane_frame_bytes + g.plane_off + (long long)gy * g.pitch + gx;
+    *reinterpret_cast<unsigned*>(dst) = out;             // pitch is a multiple of 64, gx of 4: pad bytes absorb the tail
+}
+
+void orbhip_launch_blur(const ExtractParams& P, const int gk[4], int nframes, hipStream_t s)
+{
+    BlurK K; K.k0 = gk[0]; K.k1 = gk[1]; K.k2 = gk[2]; K.k3 = gk[3];
+    hipLaunchKernelGGL(k_blur, dim3(P.nblur_tiles, nframes, 1), dim3(256, 1, 1), 0, s, P, K);
+}
+
+// ------------------------------------------------------------------------------------------------ FAST per cell
+// One wavefront per 30-px grid cell (4 cells per workgroup).  The cell's sub-image (<= 65x65) is staged in LDS,
+// every examined pixel gets its intrinsic FAST-9/16 score
+//     S = max over the 16 nine-pixel arcs of min |centre - ring| margin (dark or bright)  - 1      (cornerScore<16>)
+// which satisfies "corner at threshold t  <=>  S >= t", so ONE score pass serves both cv::FAST calls of the
+// reference (iniThFAST, then minThFAST if the first returned nothing).  3x3 non-max suppression sees only scores of
+// the same cell (neighbours outside the examined interior count as 0, exactly like FAST on the cell sub-image);
+// survivors are emitted in row-major order with ballot/popcount ranks.
+#define FC_WAVES 4
+#define FC_PSTRIDE 68      // LDS patch row stride (bytes), sub-image width <= 65
+#define FC_PROWS 66
+#define FC_SSTRIDE 64      // score row stride: interior width <= 59, +2 ring
+#define FC_SROWS 62
+
+__device__ __forceinline__ int fast_score16(const uint8_t* c, int ps)
+{
+    const int v = c[0];
+    int d[16];
+    d[0] = v - c[3 * ps];          d[1] = v - c[3 * ps + 1];    d[2] = v - c[2 * ps + 2];    d[3] = v - c[ps + 3];
+    d[4] = v - c[3];               d[5] = v - c[-ps + 3];       d[6] = v - c[-2 * ps + 2];   d[7] = v - c[-3 * ps + 1];
+    d[8] = v - c[-3 * ps];         d[9] = v - c[-3 * ps - 1];   d[10] = v - c[-2 * ps - 2];  d[11] = v - c[-ps - 3];
+    d[12] = v - c[-3];             d[13] = v - c[ps - 3];       d[14] = v - c[2 * ps - 2];   d[15] = v - c[3 * ps - 1];
+    int lo2[16], hi2[16], lo4[16], hi4[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) { lo2[i] = min(d[i], d[(i + 1) & 15]); hi2[i] = max(d[i], d[(i + 1) & 15]); }
+#pragma unroll
+    for (int i = 0; i < 16; i++) { lo4[i] = min(lo2[i], lo2[(i + 2) & 15]); hi4[i] = max(hi2[i], hi2[(i + 2) & 15]); }
+    int best_dark = -256, best_bright = 256;       // max_s min_arc d   and   min_s max_arc d
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int lo9 = min(min(lo4[i], lo4[(i + 4) & 15]), d[(i + 8) & 15]);
+        const int hi9 = max(max(hi4[i], hi4[(i + 4) & 15]), d[(i + 8) & 15]);
+        best_dark = max(best_dark, lo9); best_bright = min(best_bright, hi9);
+    }
+    return max(best_dark, -best_bright) - 1;
+}
+
+__global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
+{
+    __shared__ uint8_t s_patch[FC_WAVES][FC_PROWS * FC_PSTRIDE];
+    __shared__ uint8_t s_score[FC_WAVES][FC_SROWS * FC_SSTRIDE];
+    __shared__ unsigned long long s_mini[FC_WAVES][64], s_mmin[FC_WAVES][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, frame = blockIdx.y;
+    const int cell_id = blockIdx.x * FC_WAVES + wave;
+    const bool active = cell_id < P.ncells_total;
+    CellDesc cd; cd.skipped = 1; cd.level = 0; cd.iniX = cd.iniY = cd.maxX = cd.maxY = 0; cd.shiftX = cd.shiftY = 0; cd.cand_idx = 0; cd.cand_cap = 0;
+    if (active) cd = P.cells[cell_id];
+    const int pw = cd.maxX - cd.iniX, ph = cd.maxY - cd.iniY;       // sub-image
+    const int cw = pw - 6, ch = ph - 6;                              // examined interior (rows/cols 3 .. n-4)
+    const bool work = active && !cd.skipped && cw > 0 && ch > 0;
+    uint8_t* patch = s_patch[wave]; uint8_t* score = s_score[wave];
+    if (work) {
+        int spitch; const uint8_t* src = level_src(P, frame, cd.level, spitch);
+        src += (long long)cd.iniY * spitch + cd.iniX;
+        int r = 0, c = lane;
+        while (c >= pw) { c -= pw; r++; }
+        while (r < ph) {
+            patch[r * FC_PSTRIDE + c] = src[(long long)r * spitch + c];
+            c += 64; while (c >= pw) { c -= pw; r++; }
+        }
+        for (int i = lane; i < (ch + 2) * FC_SSTRIDE; i += 64) score[i] = 0;
+    }
+    __syncthreads();
+    const int rp = work ? 64 / cw : 1;                                // interior rows handled per wave iteration
+    const int sr = work ? lane / cw : 0, sx = work ? lane - sr * cw : 0;
+    const int iters = work ? (ch + rp - 1) / rp : 0;
+    const bool lane_ok = work && sr < rp;
+    for (int it = 0; it < iters; it++) {
+        const int y = it * rp + sr;
+        if (lane_ok && y < ch) {
+            int sc = fast_score16(&patch[(y + 3) * FC_PSTRIDE + sx + 3], FC_PSTRIDE);
+            if (sc < P.minTh) sc = 0;
+            score[(y + 1) * FC_SSTRIDE + sx + 1] = (uint8_t)sc;     // sc <= 254
+        }
+    }
+    __syncthreads();
+    int count_ini = 0, count_min = 0;
+    for (int it = 0; it < iters; it++) {
+        const int y = it * rp + sr;
+        bool keep = false; int sc = 0;
+        if (lane_ok && y < ch) {
+            const uint8_t* q = &score[(y + 1) * FC_SSTRIDE + sx + 1];
+            sc = q[0];
+            keep = sc > 0 && sc > q[-1] && sc > q[1] && sc > q[-FC_SSTRIDE - 1] && sc > q[-FC_SSTRIDE] && sc > q[-FC_SSTRIDE + 1] &&
+                   sc > q[FC_SSTRIDE - 1] && sc > q[FC_SSTRIDE] && sc > q[FC_SSTRIDE + 1];
+        }
+        const unsigned long long mmin = __ballot(keep), mini = __ballot(keep && sc >= P.iniTh);
+        if (lane == 0) { s_mmin[wave][it] = mmin; s_mini[wave][it] = mini; }
+        count_min += __popcll(mmin); count_ini += __popcll(mini);
+    }
+    __syncthreads();
+    if (!active) return;
+    const bool use_ini = count_ini > 0;                               // vKeysCell.empty() after the iniThFAST call?
+    const int total = use_ini ? count_ini : count_min;
+    int base = 0;
+    unsigned* out = P.cell_cand + (long long)frame * P.cand_slots_per_frame + cd.cand_idx;
+    for (int it = 0; it < iters; it++) {
+        const unsigned long long m = use_ini ? s_mini[wave][it] : s_mmin[wave][it];
+        if ((m >> lane) & 1ull) {
+            const int y = it * rp + sr;
+            const int rank = base + __popcll(m & ((1ull << lane) - 1ull));
+            const int sc = score[(y + 1) * FC_SSTRIDE + sx + 1];
+            // FAST reports cell-local (x, y); the reference adds (j*wCell, i*hCell)  (ORBextractor.cc:822-823)
+            const unsigned px = (unsigned)(sx + 3 + cd.shiftX), py = (unsigned)(y + 3 + cd.shiftY);
+            if (rank < cd.cand_cap) out[rank] = px | (py << 12) | ((unsigned)sc << 24);
+        }
+        base += __popcll(m);
+    }
+    if (lane == 0) P.cell_count[(long long)frame * P.ncells_total + cell_id] = min(total, cd.cand_cap);
+}
+
+void orbhip_launch_fast_cells(const ExtractParams& P, int nframes, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_fast_cells, dim3((P.ncells_total + FC_WAVES - 1) / FC_WAVES, nframes, 1), dim3(256, 1, 1), 0, s, P);
+}
+
+// ------------------------------------------------------------------------------------------------ quadtree
+// DistributeOctTree (ORBextractor.cc:539-763) without pointers.  Observations that make it data-parallel:
+//  * a key's path through the quadtree depends only on its own coordinates (children halve the parent rectangle
+//    with ceil, DivideNode :483-490), so every candidate gets a 2-bit-per-depth path code once;
+//  * children are always push_front'ed and parents erased, so the std::list is at any time sorted by DESCENDING
+//    creation order -> a node is identified by its position in that order; one pass = one compaction;
+//  * the final phase (:673-738) splits nodes largest-first until the list reaches N: sort keys, a prefix sum of
+//    (children-1) over that order and the first position where the running size reaches N reproduce the `break`.
+// Canonical tie-break H1: equal sizes -> later-created node first == smaller list position first.
+// One workgroup per (frame, level); node tables in LDS, per-candidate arrays in an L2-resident HBM workspace.
+#define QT_T 256
+
+__device__ __forceinline__ int qt_digit(unsigned code, int depth)
+{   // child index of a key at a node of the given depth; beyond the stored depth every key goes to n1 (unsupported sizes only)
+    return depth < ORBHIP_QT_DEPTH ? (int)((code >> (2 * (ORBHIP_QT_DEPTH - 1 - depth))) & 3u) : 0;
+}
+
+__device__ __forceinline__ int qt_block_exscan(int* a, int n, int* scratch, int tid)
+{   // in-place exclusive scan of a[0..n), returns the total; all QT_T threads must call
+    const int c = (n + QT_T - 1) / QT_T, lo = min(tid * c, n), hi = min(lo + c, n);
+    int sum = 0;
+    for (int i = lo; i < hi; i++) sum += a[i];
+    scratch[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < QT_T; off <<= 1) {
+        const int v = (tid >= off) ? scratch[tid - off] : 0;
+        __syncthreads();
+        scratch[tid] += v;
+        __syncthreads();
+    }
+    const int total = scratch[QT_T - 1];
+    int run = scratch[tid] - sum;
+    for (int i = lo; i < hi; i++) { const int v = a[i]; a[i] = run; run += v; }
+    __syncthreads();
+    return total;
+}
+
+size_t orbhip_quadtree_lds_bytes(int maxn, int maxcells)
+{
+    // s_pref[maxcells+1] | cnt[2][maxn] | depth[2][maxn] | cc[4*maxn] | map[4*maxn] | a[maxn] | b[maxn] | sidx[maxn] | split[maxn] | best[maxn] | scratch[QT_T] | misc[16]
+    return sizeof(int) * ((size_t)(maxcells + 1) + (size_t)maxn * (2 + 2 + 4 + 4 + 5) + QT_T + 16);
+}
+
+__global__ __launch_bounds__(QT_T) void k_quadtree(ExtractParams P)
+{
+    const int level = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x;
+    const LevelGeom g = P.geom[level];
+    const int maxn = P.qt_maxn, N = g.nfeat;
+    HIP_DYNAMIC_SHARED(int, lds)
+    int* s_pref = lds;
+    int* s_cntA = s_pref + (P.qt_maxcells + 1);
+    int* s_cntB = s_cntA + maxn;
+    int* s_depA = s_cntB + maxn;
+    int* s_depB = s_depA + maxn;
+    int* s_cc = s_depB + maxn;
+    int* s_map = s_cc + 4 * maxn;
+    int* s_a = s_map + 4 * maxn;
+    int* s_b = s_a + maxn;
+    int* s_sidx = s_b + maxn;
+    int* s_split = s_sidx + maxn;
+    int* s_best = s_split + maxn;
+    int* s_scratch = s_best + maxn;
+    int* s_misc = s_scratch + QT_T;
+
+    unsigned* qval = P.qt_val + (long long)frame * P.qt_per_frame + g.cand_total_off;
+    unsigned* qcode = P.qt_code + (long long)frame * P.qt_per_frame + g.cand_total_off;
+    int* qnode = P.qt_node + (long long)frame * P.qt_per_frame + g.cand_total_off;
+
+    // ---- A. dense canonical candidate order: cells row-major, row-major inside a cell (ORBextractor.cc:789-829)
+    const int* ccount = P.cell_count + (long long)frame * P.ncells_total + g.cell_first;
+    for (int c = tid; c < g.ncells; c += QT_T) s_pref[c] = ccount[c];
+    for (int r = tid; r < maxn; r += QT_T) s_cntA[r] = 0;
+    __syncthreads();
+    int n = qt_block_exscan(s_pref, g.ncells, s_scratch, tid);
+    n = min(n, g.cand_total_cap);
+    const unsigned* cand = P.cell_cand + (long long)frame * P.cand_slots_per_frame;
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int c = wave; c < g.ncells; c += QT_T / 64) {
+        const int start = s_pref[c];
+        const int cnt = ((c + 1 < g.ncells) ? s_pref[c + 1] : n) - start;
+        const int slot = P.cells[g.cell_first + c].cand_idx;
+        for (int r = lane; r < cnt; r += 64) {
+            const unsigned v = cand[slot + r];
+            const int x = v & 0xfff, y = (v >> 12) & 0xfff;
+            int root = __float2int_rz(__fdiv_rn((float)x, g.hX));                    // vpIniNodes[kp.pt.x/hX]  (:569)
+            root = min(max(root, 0), g.nIni - 1);
+            int ULx = __float2int_rz(__fmul_rn(g.hX, (float)root)), URx = __float2int_rz(__fmul_rn(g.hX, (float)(root + 1)));   // :555-556
+            int ULy = 0, BRy = g.maxBorderY - ORBHIP_EDGE;
+            unsigned code = 0;
+#pragma unroll
+            for (int d = 0; d < ORBHIP_QT_DEPTH; d++) {                               // DivideNode :483-526
+                const int mx = ULx + ((URx - ULx + 1) >> 1), my = ULy + ((BRy - ULy + 1) >> 1);
+                const int right = !(x < mx), bottom = !(y < my);
+                code = (code << 2) | (unsigned)(right + 2 * bottom);                  // n1=0 n2=1 n3=2 n4=3
+                if (right) ULx = mx; else URx = mx;
+                if (bottom) ULy = my; else BRy = my;
+            }
+            const int idx = start + r;
+            if (idx < n) { qval[idx] = v; qcode[idx] = code; qnode[idx] = root; atomicAdd(&s_cntA[root], 1); }
+        }
+    }
+    __syncthreads();
+    // ---- B. initial list: non-empty roots in order (:552-585)
+    if (tid == 0) {
+        int m0 = 0;
+        for (int r = 0; r < g.nIni; r++) { const int c = s_cntA[r]; if (c > 0) { s_map[r] = m0; s_cntB[m0] = c; s_depB[m0] = 0; m0++; } else s_map[r] = 0; }
+        s_misc[0] = m0;
+    }
+    __syncthreads();
+    int m = s_misc[0];
+    for (int k = tid; k < n; k += QT_T) qnode[k] = s_map[qnode[k]];
+    int* cnt = s_cntB; int* dep = s_depB; int* cnt2 = s_cntA; int* dep2 = s_depA;
+    __syncthreads();
+
+    // ---- C. passes
+    bool modeB = false;
+    for (int guard = 0; guard < 4096; guard++) {
+        for (int i = tid; i < 4 * m; i += QT_T) s_cc[i] = 0;
+        if (tid == 0) { s_misc[1] = 0; s_misc[2] = 0x7fffffff; s_misc[3] = 0; }
+        __syncthreads();
+        for (int k = tid; k < n; k += QT_T) {
+            const int p = qnode[k];
+            if (cnt[p] > 1) atomicAdd(&s_cc[4 * p + qt_digit(qcode[k], dep[p])], 1);
+        }
+        __syncthreads();
+        int Ctot, nsplit;
+        if (!modeB) {
+            // every node with more than one key is divided, walking the list front to back (:606-665)
+            for (int p = tid; p < m; p += QT_T) {
+                const bool e = cnt[p] > 1;
+                s_a[p] = e ? ((s_cc[4 * p] > 0) + (s_cc[4 * p + 1] > 0) + (s_cc[4 * p + 2] > 0) + (s_cc[4 * p + 3] > 0)) : 0;
+                s_b[p] = e ? 0 : 1; s_split[p] = e ? 1 : 0;
+            }
+            __syncthreads();
+            Ctot = qt_block_exscan(s_a, m, s_scratch, tid);
+            const int Stot = qt_block_exscan(s_b, m, s_scratch, tid);
+            nsplit = m - Stot;
+            for (int p = tid; p < m; p += QT_T) {
+                if (s_split[p]) {
+                    int q = s_a[p];
+                    for (int d = 0; d < 4; d++) { const int c = s_cc[4 * p + d]; if (c > 0) { const int pos = Ctot - 1 - q; q++; cnt2[pos] = c; dep2[pos] = dep[p] + 1; s_map[4 * p + d] = pos; } }
+                } else { const int pos = Ctot + s_b[p]; cnt2[pos] = cnt[p]; dep2[pos] = dep[p]; s_map[4 * p] = pos; }
+            }
+        } else {
+            // final phase: expandable nodes sorted by (size, creation) ascending, processed from the back (:684-732)
+            for (int p = tid; p < m; p += QT_T) {
+                s_split[p] = 0;
+                const int c = cnt[p];
+                if (c > 1) {
+                    int rank = 0;
+                    for (int o = 0; o < m; o++) { const int co = cnt[o]; rank += (co > 1) && (co > c || (co == c && o < p)); }
+                    s_sidx[rank] = p; atomicAdd(&s_misc[1], 1);
+                }
+            }
+            __syncthreads();
+            const int E = s_misc[1];
+            for (int j = tid; j < E; j += QT_T) {
+                const int p = s_sidx[j];
+                s_a[j] = (s_cc[4 * p] > 0) + (s_cc[4 * p + 1] > 0) + (s_cc[4 * p + 2] > 0) + (s_cc[4 * p + 3] > 0);
+                s_b[j] = s_a[j];
+            }
+            __syncthreads();
+            const int Call = qt_block_exscan(s_a, E, s_scratch, tid);     // s_a[j] = children created before sorted node j
+            for (int j = tid; j < E; j += QT_T) {                          // list size after processing sorted node j
+                const int size_after = m + s_a[j] + s_b[j] - (j + 1);
+                if (size_after >= N) atomicMin(&s_misc[2], j);            // first position where `break` fires (:730-731)
+            }
+            __syncthreads();
+            const int jstar = s_misc[2];
+            nsplit = (jstar == 0x7fffffff) ? E : jstar + 1;
+            Ctot = (nsplit == E) ? Call : s_a[nsplit];
+            __syncthreads();
+            for (int j = tid; j < nsplit; j += QT_T) s_split[s_sidx[j]] = 1 + j;
+            __syncthreads();
+            for (int p = tid; p < m; p += QT_T) s_best[p] = s_split[p] ? 0 : 1;
+            __syncthreads();
+            qt_block_exscan(s_best, m, s_scratch, tid);
+            for (int p = tid; p < m; p += QT_T) {
+                if (s_split[p]) {
+                    int q = s_a[s_split[p] - 1];
+                    for (int d = 0; d < 4; d++) { const int c = s_cc[4 * p + d]; if (c > 0) { const int pos = Ctot - 1 - q; q++; cnt2[pos] = c; dep2[pos] = dep[p] + 1; s_map[4 * p + d] = pos; } }
+                } else { const int pos = Ctot + s_best[p]; cnt2[pos] = cnt[p]; dep2[pos] = dep[p]; s_map[4 * p] = pos; }
+            }
+        }
+        __syncthreads();
+        const int m2 = Ctot + (m - nsplit);
+        for (int k = tid; k < n; k += QT_T) {
+            const int p = qnode[k];
+            qnode[k] = s_split[p] ? s_map[4 * p + qt_digit(qcode[k], dep[p])] : s_map[4 * p];
+        }
+        int nexp = 0;
+        for (int p = tid; p < m2; p += QT_T) nexp += cnt2[p] > 1;
+        if (nexp) atomicAdd(&s_misc[3], nexp);
+        __syncthreads();
+        const int nToExpand = s_misc[3];
+        int* t = cnt; cnt = cnt2; cnt2 = t; t = dep; dep = dep2; dep2 = t;
+        const int prev = m; m = m2;
+        __syncthreads();
+        if (m >= N || m == prev) break;                                    // :669-672 / :734-735
+        if (!modeB && (m + 3 * nToExpand) > N) modeB = true;               // :673
+    }
+
+    // ---- D. best response per leaf, first wins (:744-760); list order = output order
+    for (int p = tid; p < m; p += QT_T) s_best[p] = 0;
+    __syncthreads();
+    for (int k = tid; k < n; k += QT_T)
+        atomicMax((unsigned*)&s_best[qnode[k]], (unsigned)((qval[k] >> 24) << 24) | (0xFFFFFFu - (unsigned)k));
+    __syncthreads();
+    unsigned* outk = P.lvl_kp + (long long)frame * P.lvl_kp_per_frame + g.kp_off;
+    const int mout = min(m, g.kp_cap);
+    for (int p = tid; p < mout; p += QT_T) {
+        const unsigned k = 0xFFFFFFu - ((unsigned)s_best[p] & 0xFFFFFFu);
+        const unsigned v = qval[k];
+        const unsigned x = (v & 0xfff) + ORBHIP_EDGE, y = ((v >> 12) & 0xfff) + ORBHIP_EDGE;   // :843-844
+        outk[p] = x | (y << 12) | (v & 0xff000000u);
+    }
+    if (tid == 0) P.lvl_n[frame * P.nlevels + level] = mout;
+}
+
+void orbhip_launch_quadtree(const ExtractParams& P, int nframes, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_quadtree, dim3(P.nlevels, nframes, 1), dim3(QT_T, 1, 1), orbhip_quadtree_lds_bytes(P.qt_maxn, P.qt_maxcells), s, P);
+}
+
+// ------------------------------------------------------------------------------------------------ describe
+// One wavefront per keypoint slot.  IC_Angle over the 749-pixel circular patch (two lanes per row), cv::fastAtan2,
+// glibc-style sincosf in double, then 4 rounds of 64 rotated BRIEF tests whose ballots ARE the descriptor words.
+__device__ __forceinline__ float dev_fast_atan2(float y, float x)       // OpenCV 3.2 mathfuncs_core.cpp, degrees
+{
+    const float sc = (float)(180 / 3.14159265358979323846);
+    const float p1 = 0.9997878412794807f * sc, p3 = -0.3258083974640975f * sc, p5 = 0.1555786518463281f * sc, p7 = -0.04432655554792128f * sc;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, __fadd_rn(ax, (float)2.2204460492503131e-16)); c2 = __fmul_rn(c, c);
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    } else {
+        c = __fdiv_rn(ax, __fadd_rn(ay, (float)2.2204460492503131e-16)); c2 = __fmul_rn(c, c);
+        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+    }
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+
+// sincosf, glibc 2.35 sysdeps/ieee754/flt-32/s_sincosf.c restated (|y| < 120): every double op individually rounded.
+__device__ __forceinline__ void dev_sincosf(float y, float* sinp, float* cosp)
+{
+    const double hpi_inv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
+    const double C0 = 0x1p0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5, C3 = -0x1.6c087e89a359dp-10, C4 = 0x1.99343027bf8c3p-16;
+    const double S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7, S3 = -0x1.994eb3774cf24p-13;
+    const unsigned top = (__float_as_uint(y) >> 20) & 0x7ff;
+    double x = (double)y; int n = 0; double sgn = 1.0; bool neg = false;
+    if (top < ((0x3f490fdbu >> 20) & 0x7ff)) {                  // abstop12(y) < abstop12(pi/4)
+        if (top < ((0x39800000u >> 20) & 0x7ff)) { *sinp = y; *cosp = 1.0f; return; }   // |y| < 2^-12
+    } else {
+        const double r = __dmul_rn(x, hpi_inv);
+        n = (__double2int_rz(r) + 0x800000) >> 24;
+        x = __dsub_rn(x, __dmul_rn((double)n, hpi));
+        sgn = (n & 1) ? -1.0 : 1.0;  if (n & 2) sgn = -sgn;     // sign[n&3] = {1,-1,-1,1}
+        neg = (n & 2) != 0;                                       // second table: cosine coefficients negated
+    }
+    const double x2 = __dmul_rn(x, x);
+    const double xs = __dmul_rn(x, sgn);
+    const double c0 = neg ? -C0 : C0, c1k = neg ? -C1 : C1, c2k = neg ? -C2 : C2, c3k = neg ? -C3 : C3, c4k = neg ? -C4 : C4;
+    const double x4 = __dmul_rn(x2, x2), x3 = __dmul_rn(x2, xs);
+    const double c2 = __dadd_rn(c3k, __dmul_rn(x2, c4k)), s1 = __dadd_rn(S2, __dmul_rn(x2, S3));
+    const double c1 = __dadd_rn(c0, __dmul_rn(x2, c1k));
+    const double x5 = __dmul_rn(x3, x2), x6 = __dmul_rn(x4, x2);
+    const double s = __dadd_rn(xs, __dmul_rn(x3, S1)), c = __dadd_rn(c1, __dmul_rn(x4, c2k));
+    const float sv = __double2float_rn(__dadd_rn(s, __dmul_rn(x5, s1)));
+    const float cv = __double2float_rn(__dadd_rn(c, __dmul_rn(x6, c2)));
+    if (n & 1) { *cosp = sv; *sinp = cv; } else { *sinp = sv; *cosp = cv; }
+}
+
+#define DS_WAVES 4
+__global__ __launch_bounds__(256) void k_describe(ExtractParams P)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, frame = blockIdx.y;
+    const int slot = blockIdx.x * DS_WAVES + wave;
+    if (slot >= P.lvl_kp_per_frame) return;
+    int level = 0;
+    for (int l = 1; l < P.nlevels; l++) if (slot >= P.geom[l].kp_off) level = l;
+    const LevelGeom g = P.geom[level];
+    const int i = slot - g.kp_off;
+    const int* ln = P.lvl_n + frame * P.nlevels;
+    if (slot == 0 && lane == 0) { int tot = 0; for (int l = 0; l < P.nlevels; l++) tot += ln[l]; P.out_n[frame] = min(tot, P.out_cap); }
+    if (i >= ln[level]) return;
+    int obase = 0;
+    for (int l = 0; l < level; l++) obase += ln[l];
+    const int oi = obase + i;
+    if (oi >= P.out_cap) return;
+    const unsigned v = P.lvl_kp[(long long)frame * P.lvl_kp_per_frame + slot];
+    const int cx = v & 0xfff, cy = (v >> 12) & 0xfff, sc = v >> 24;
+
+    // ---- IC_Angle (ORBextractor.cc:77-104): lanes 0..61 -> row v = lane/2 - 15, left/right half
+    int spitch; const uint8_t* img = level_src(P, frame, level, spitch);
+    int m10 = 0, m01 = 0;
+    if (lane < 62) {
+        const int vr = (lane >> 1) - 15, av = vr < 0 ? -vr : vr;
+        // umax (ORBextractor.cc:452-469) for HALF_PATCH_SIZE 15
+        const int um = (av <= 3) ? 15 : (av <= 6) ? 14 : (av <= 8) ? 13 : (av == 9) ? 12 : (av == 10) ? 11 : (av == 11) ? 10 : (av == 12) ? 9 : (av == 13) ? 8 : (av == 14) ? 6 : 3;
+        const uint8_t* row = img + (long long)(cy + vr) * spitch + cx;
+        int u0, u1;
+        if (lane & 1) { u0 = 1; u1 = um; } else { u0 = -um; u1 = 0; }
+        int su = 0, s = 0;
+        for (int u = u0; u <= u1; u++) { const int px = row[u]; su += u * px; s += px; }
+        m10 = su; m01 = vr * s;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { m10 += __shfl_xor(m10, off); m01 += __shfl_xor(m01, off); }
+    const float angle = dev_fast_atan2((float)m01, (float)m10);
+
+    // ---- steered BRIEF (ORBextractor.cc:107-147) on the blurred level
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    float a, b; dev_sincosf(__fmul_rn(angle, factorPI), &b, &a);
+    const uint8_t* bl = P.blur + (long long)frame * P.plane_frame_bytes + g.plane_off + (long long)cy * g.pitch + cx;
+    unsigned long long* dout = reinterpret_cast<unsigned long long*>(P.out_desc + ((long long)frame * P.out_cap + oi) * 32);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const signed char* pt = P.pattern + (r * 64 + lane) * 4;
+        const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
+        const int iy0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a))), ix0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+        const int iy1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a))), ix1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+        const int t0 = bl[(long long)iy0 * g.pitch + ix0], t1 = bl[(long long)iy1 * g.pitch + ix1];
+        const unsigned long long bits = __ballot(t0 < t1);       // test 64r+lane -> byte (64r+lane)/8, bit lane%8
+        if (lane == 0) dout[r] = bits;
+    }
+    if (lane == 0) {
+        orbhip_keypoint kp;
+        kp.x = __fmul_rn((float)cx, g.scale); kp.y = __fmul_rn((float)cy, g.scale);     // pt *= scale (:1095-1101); scale[0] == 1
+        kp.size = g.kp_size; kp.angle = angle; kp.response = (float)sc; kp.octave = level; kp.class_id = -1;
+        P.out_kp[(long long)frame * P.out_cap + oi] = kp;
+    }
+}
+
+void orbhip_launch_describe(const ExtractParams& P, int nframes, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_describe, dim3((P.lvl_kp_per_frame + DS_WAVES - 1) / DS_WAVES, nframes, 1), dim3(256, 1, 1), 0, s, P);
+}

@@ -1,0 +1,317 @@
+// orbhip_kernels_match.hip — gfx950 kernels of the matcher side (replaces the Hamming / Frame-to-Frame part of
+// src/ORBmatcher.cc and the Frame feature grid it reads).
+//
+//   k_hamming_nn / k_hamming_merge   brute-force 256-bit Hamming NN, queries in registers, DB rows broadcast from LDS,
+//                                    __popcll on 4 x u64 per pair (ORBmatcher::DescriptorDistance, ORBmatcher.cc:1647-1663;
+//                                    best/second idiom :102-114, :447-456).  Integer-VALU bound (v_xor + v_bcnt), no MFMA.
+//   k_match_grid                     Frame::AssignFeaturesToGrid (Frame.cc:230-245, 382-392): 64x48 buckets, keypoint order
+//   k_match_candidates               Frame::GetFeaturesInArea (Frame.cc:327-380) in canonical order + all Hamming distances,
+//                                    one wavefront per previous-frame keypoint
+//   k_match_select                   the order-dependent part of SearchForInitialization (ORBmatcher.cc:418-517): one
+//                                    wavefront per camera slot replays the i1 loop with wave reductions, rotation histogram,
+//                                    ComputeThreeMaxima (:1601-1642) and the vbPrevMatched update.
+#include "orbhip_internal.h"
+
+#define WAVE 64
+#define IMAX 0x7fffffff
+
+__device__ __forceinline__ int hamming256(const unsigned long long* a, const unsigned long long* b)
+{
+    return __popcll(a[0] ^ b[0]) + __popcll(a[1] ^ b[1]) + __popcll(a[2] ^ b[2]) + __popcll(a[3] ^ b[3]);
+}
+
+// ------------------------------------------------------------------------------------------------ brute-force NN
+#define NN_T 256
+#define NN_QPT 4                       // queries held in registers per thread
+#define NN_ROWS 256                    // DB rows staged in LDS per step (8 KB)
+#define NN_CHUNK 8192                  // DB rows per workgroup
+
+struct NNPart { int best, second; long long idx; };
+
+__global__ __launch_bounds__(NN_T) void k_hamming_nn(const unsigned long long* q, int nq, const unsigned long long* db, long long ndb,
+                                                     long long base, NNPart* parts, int nchunks)
+{
+    __shared__ unsigned long long s_db[NN_ROWS * 4];
+    const int tid = threadIdx.x, chunk = blockIdx.y;
+    const int q0 = (blockIdx.x * NN_T + tid) * NN_QPT;
+    unsigned long long qa[NN_QPT][4];
+    int best[NN_QPT], second[NN_QPT]; long long bidx[NN_QPT];
+#pragma unroll
+    for (int k = 0; k < NN_QPT; k++) {
+        const int qi = min(q0 + k, nq - 1);
+#pragma unroll
+        for (int w = 0; w < 4; w++) qa[k][w] = q[(long long)qi * 4 + w];
+        best[k] = IMAX; second[k] = IMAX; bidx[k] = -1;
+    }
+    const long long row0 = (long long)chunk * NN_CHUNK;
+    const long long row1 = min(row0 + (long long)NN_CHUNK, ndb);
+    for (long long r = row0; r < row1; r += NN_ROWS) {
+        const int nr = (int)min((long long)NN_ROWS, row1 - r);
+        __syncthreads();
+        for (int i = tid; i < nr * 4; i += NN_T) s_db[i] = db[r * 4 + i];
+        __syncthreads();
+        for (int j = 0; j < nr; j++) {
+            const unsigned long long d0 = s_db[4 * j], d1 = s_db[4 * j + 1], d2 = s_db[4 * j + 2], d3 = s_db[4 * j + 3];   // LDS broadcast
+#pragma unroll
+            for (int k = 0; k < NN_QPT; k++) {
+                const int d = __popcll(qa[k][0] ^ d0) + __popcll(qa[k][1] ^ d1) + __popcll(qa[k][2] ^ d2) + __popcll(qa[k][3] ^ d3);
+                if (d < best[k]) { second[k] = best[k]; best[k] = d; bidx[k] = r + j; }
+                else if (d < second[k]) second[k] = d;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NN_QPT; k++)
+        if (q0 + k < nq) { NNPart p; p.best = best[k]; p.second = second[k]; p.idx = bidx[k] < 0 ? -1 : bidx[k] + base; parts[(long long)(q0 + k) * nchunks + chunk] = p; }
+}
+
+// fold the per-chunk partials of one query in ascending DB order: stable arg-min + second smallest of the multiset
+__device__ __forceinline__ void nn_combine(int& b, long long& i, int& s, int rb, long long ri, int rs)
+{
+    if (rb < b) { s = min(b, rs); b = rb; i = ri; } else { s = min(s, rb); }
+}
+__global__ __launch_bounds__(256) void k_hamming_merge(const NNPart* parts, int nq, int nchunks, long long* best_idx, int* best_dist, int* second_dist)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * 4 + wave;
+    if (qi >= nq) return;
+    int b = IMAX, s = IMAX; long long i = -1;
+    const int per = (nchunks + 63) / 64;                     // contiguous runs per lane keep the index order
+    for (int c = lane * per; c < min((lane + 1) * per, nchunks); c++) { const NNPart p = parts[(long long)qi * nchunks + c]; nn_combine(b, i, s, p.best, p.idx, p.second); }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {                 // lanes hold ascending index ranges; combine neighbours left-to-right
+        const int rb = __shfl_down(b, off), rs = __shfl_down(s, off); const long long ri = __shfl_down(i, off);
+        if (((lane & (2 * off - 1)) == 0) && lane + off < 64) nn_combine(b, i, s, rb, ri, rs);
+    }
+    if (lane == 0) { best_idx[qi] = i; best_dist[qi] = b; second_dist[qi] = s; }
+}
+
+// workspace for the partials lives in a small per-thread cache owned by the API layer
+
+void orbhip_launch_hamming_nn(const uint8_t* d_q, int nq, const uint8_t* d_db, long long ndb, long long base,
+                              long long* d_best_idx, int* d_best_dist, int* d_second, hipStream_t s)
+{
+    if (nq <= 0) return;
+    const int nchunks = (int)max(1LL, (ndb + NN_CHUNK - 1) / NN_CHUNK);
+    NNPart* parts = (NNPart*)orbhip_nn_workspace(sizeof(NNPart) * (size_t)nq * nchunks, s);
+    if (!parts) return;
+    const int qblocks = (nq + NN_T * NN_QPT - 1) / (NN_T * NN_QPT);
+    hipLaunchKernelGGL(k_hamming_nn, dim3(qblocks, nchunks, 1), dim3(NN_T, 1, 1), 0, s, (const unsigned long long*)d_q, nq,
+                       (const unsigned long long*)d_db, ndb, base, parts, nchunks);
+    hipLaunchKernelGGL(k_hamming_merge, dim3((nq + 3) / 4, 1, 1), dim3(256, 1, 1), 0, s, (const NNPart*)parts, nq, nchunks, d_best_idx, d_best_dist, d_second);
+}
+
+// ------------------------------------------------------------------------------------------------ frame grid
+// Frame::AssignFeaturesToGrid on the current frame F2.  posX = round((x-mnMinX)*inv) — `round`, not floor (Frame.cc:384-385).
+__global__ __launch_bounds__(256) void k_match_grid(MatchParams M, float gwInv, float ghInv)
+{
+    __shared__ int s_cnt[ORBHIP_GRID_CELLS + 1];
+    __shared__ int s_scan[256];
+    const int slot = blockIdx.x, tid = threadIdx.x;
+    const int n2 = M.n2[slot];
+    const orbhip_keypoint* kp = M.kp2 + (long long)slot * M.cap;
+    int* gstart = M.grid_start + (long long)slot * (ORBHIP_GRID_CELLS + 1);
+    int* gitems = M.grid_items + (long long)slot * M.cap;
+    for (int c = tid; c <= ORBHIP_GRID_CELLS; c += 256) s_cnt[c] = 0;
+    __syncthreads();
+    for (int i = tid; i < n2; i += 256) {
+        const int px = (int)roundf(__fmul_rn(__fsub_rn(kp[i].x, 0.0f), gwInv)), py = (int)roundf(__fmul_rn(__fsub_rn(kp[i].y, 0.0f), ghInv));
+        if (px < 0 || px >= ORBHIP_GRID_COLS || py < 0 || py >= ORBHIP_GRID_ROWS) continue;
+        atomicAdd(&s_cnt[px * ORBHIP_GRID_ROWS + py], 1);
+    }
+    __syncthreads();
+    // exclusive scan of 3072 counters: 12 per thread
+    const int per = ORBHIP_GRID_CELLS / 256;
+    int sum = 0;
+    for (int k = 0; k < per; k++) sum += s_cnt[tid * per + k];
+    s_scan[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) { const int v = tid >= off ? s_scan[tid - off] : 0; __syncthreads(); s_scan[tid] += v; __syncthreads(); }
+    int run = s_scan[tid] - sum;
+    for (int k = 0; k < per; k++) { const int v = s_cnt[tid * per + k]; s_cnt[tid * per + k] = run; gstart[tid * per + k] = run; run += v; }
+    if (tid == 255) gstart[ORBHIP_GRID_CELLS] = run;
+    __syncthreads();
+    for (int i = tid; i < n2; i += 256) {
+        const int px = (int)roundf(__fmul_rn(__fsub_rn(kp[i].x, 0.0f), gwInv)), py = (int)roundf(__fmul_rn(__fsub_rn(kp[i].y, 0.0f), ghInv));
+        if (px < 0 || px >= ORBHIP_GRID_COLS || py < 0 || py >= ORBHIP_GRID_ROWS) continue;
+        gitems[atomicAdd(&s_cnt[px * ORBHIP_GRID_ROWS + py], 1)] = i;
+    }
+    __syncthreads();
+    // cells are tiny: restore keypoint order inside each cell (mGrid[x][y].push_back(i) for ascending i)
+    for (int c = tid; c < ORBHIP_GRID_CELLS; c += 256) {
+        const int a = gstart[c], b = s_cnt[c];          // after the scatter s_cnt[c] == end of cell c
+        for (int i = a + 1; i < b; i++) { const int v = gitems[i]; int j = i - 1; while (j >= a && gitems[j] > v) { gitems[j + 1] = gitems[j]; j--; } gitems[j + 1] = v; }
+    }
+}
+
+void orbhip_launch_match_grid(const MatchParams& M, int nslots, hipStream_t s)
+{
+    const float gwInv = (float)ORBHIP_GRID_COLS / (float)((float)M.im_w - 0.0f), ghInv = (float)ORBHIP_GRID_ROWS / (float)((float)M.im_h - 0.0f);   // Frame.cc:101-102
+    hipLaunchKernelGGL(k_match_grid, dim3(nslots, 1, 1), dim3(256, 1, 1), 0, s, M, gwInv, ghInv);
+}
+
+// ------------------------------------------------------------------------------------------------ candidates
+// For the j-th level-0 keypoint of the previous frame: F2.GetFeaturesInArea(prev.x, prev.y, window, 0, 0) in the
+// reference's order (ix outer, iy inner, keypoint order inside a cell) + DescriptorDistance to each candidate.
+__global__ __launch_bounds__(256) void k_match_candidates(MatchParams M, float gwInv, float ghInv)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, slot = blockIdx.y;
+    const int j1 = blockIdx.x * 4 + wave;
+    const int n1l = M.n1_lvl0[slot * M.lvl_stride];
+    if (j1 >= n1l || j1 >= M.lvl0_cap) return;
+    const int i1 = M.list1 ? M.list1[(long long)slot * M.lvl0_cap + j1] : j1;   // level-major extractor output: level 0 = indices [0, n_lvl0)
+    const orbhip_keypoint* kp2 = M.kp2 + (long long)slot * M.cap;
+    const int* gstart = M.grid_start + (long long)slot * (ORBHIP_GRID_CELLS + 1);
+    const int* gitems = M.grid_items + (long long)slot * M.cap;
+    unsigned* cand = M.cand + ((long long)slot * M.lvl0_cap + j1) * M.cand_stride;
+    const orbhip_keypoint* kp1 = M.kp1 + (long long)slot * M.cap;
+    const float x = M.prev_from_kp1 ? kp1[i1].x : M.prev[((long long)slot * M.cap + i1) * 2];
+    const float y = M.prev_from_kp1 ? kp1[i1].y : M.prev[((long long)slot * M.cap + i1) * 2 + 1];
+    const float r = (float)M.window;
+    const unsigned long long* d1 = (const unsigned long long*)(M.desc1 + ((long long)slot * M.cap + i1) * 32);
+    const unsigned long long q0 = d1[0], q1 = d1[1], q2 = d1[2], q3 = d1[3];
+    int nc = 0;
+    const int minCX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, 0.0f), r), gwInv)));
+    const int maxCX = min(ORBHIP_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, 0.0f), r), gwInv)));
+    const int minCY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, 0.0f), r), ghInv)));
+    const int maxCY = min(ORBHIP_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, 0.0f), r), ghInv)));
+    if (minCX < ORBHIP_GRID_COLS && maxCX >= 0 && minCY < ORBHIP_GRID_ROWS && maxCY >= 0 && maxCX >= minCX && maxCY >= minCY) {
+        const int ny = maxCY - minCY + 1, ncell = (maxCX - minCX + 1) * ny;
+        for (int cb = 0; cb < ncell; cb += 64) {
+            const int c = cb + lane;
+            int a = 0, b = 0;
+            if (c < ncell) { const int ix = minCX + c / ny, iy = minCY + c % ny; const int cell = ix * ORBHIP_GRID_ROWS + iy; a = gstart[cell]; b = gstart[cell + 1]; }
+            int cnt = 0;
+            for (int t = a; t < b; t++) {
+                const orbhip_keypoint k = kp2[gitems[t]];
+                if (k.octave != 0) continue;                     // minLevel = maxLevel = 0 (ORBmatcher.cc:425)
+                cnt += (fabsf(__fsub_rn(k.x, x)) < r && fabsf(__fsub_rn(k.y, y)) < r);
+            }
+            int incl = cnt;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+            int pos = nc + incl - cnt;
+            for (int t = a; t < b; t++) {
+                const int i2 = gitems[t]; const orbhip_keypoint k = kp2[i2];
+                if (k.octave != 0) continue;
+                if (fabsf(__fsub_rn(k.x, x)) < r && fabsf(__fsub_rn(k.y, y)) < r) {
+                    if (pos < M.cand_stride) {
+                        const unsigned long long* d2 = (const unsigned long long*)(M.desc2 + ((long long)slot * M.cap + i2) * 32);
+                        const int dist = __popcll(q0 ^ d2[0]) + __popcll(q1 ^ d2[1]) + __popcll(q2 ^ d2[2]) + __popcll(q3 ^ d2[3]);
+                        cand[pos] = (unsigned)i2 | ((unsigned)dist << 20);      // DescriptorDistance (ORBmatcher.cc:442)
+                    }
+                    pos++;
+                }
+            }
+            nc += __shfl(incl, 63);
+        }
+    }
+    nc = min(nc, M.cand_stride);
+    if (lane == 0) M.ncand[(long long)slot * M.lvl0_cap + j1] = nc;
+}
+
+void orbhip_launch_match_candidates(const MatchParams& M, int nslots, hipStream_t s)
+{
+    const float gwInv = (float)ORBHIP_GRID_COLS / (float)((float)M.im_w - 0.0f), ghInv = (float)ORBHIP_GRID_ROWS / (float)((float)M.im_h - 0.0f);
+    hipLaunchKernelGGL(k_match_candidates, dim3((M.lvl0_cap + 3) / 4, nslots, 1), dim3(256, 1, 1), 0, s, M, gwInv, ghInv);
+}
+
+// ------------------------------------------------------------------------------------------------ select
+__device__ __forceinline__ int wave_min_i(int v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = min(v, __shfl_xor(v, off));
+    return v;
+}
+
+__global__ __launch_bounds__(64) void k_match_select(MatchParams M)
+{
+    const int slot = blockIdx.x, lane = threadIdx.x;
+    const int n1 = M.n1[slot], n2 = M.n2[slot];
+    const int n1l = min(M.n1_lvl0[slot * M.lvl_stride], M.lvl0_cap);
+    const int* list1 = M.list1 ? M.list1 + (long long)slot * M.lvl0_cap : nullptr;
+    HIP_DYNAMIC_SHARED(int, lds)
+    int* s_md = lds;                        // vMatchedDistance[i2]
+    int* s_m21 = s_md + M.cap;              // vnMatches21[i2]
+    int* s_m12 = s_m21 + M.cap;             // vnMatches12[i1] for level-0 i1
+    int* s_bin = s_m12 + M.lvl0_cap;        // rotation bin of the accepted match of i1, -1 = none
+    int* s_hist = s_bin + M.lvl0_cap;       // [HISTO_LENGTH] + misc
+    const orbhip_keypoint* kp1 = M.kp1 + (long long)slot * M.cap;
+    const orbhip_keypoint* kp2 = M.kp2 + (long long)slot * M.cap;
+    int* m12 = M.matches12 + (long long)slot * M.cap;
+    float* prev = M.prev + (long long)slot * M.cap * 2;
+    for (int i = lane; i < n2; i += 64) { s_md[i] = IMAX; s_m21[i] = -1; }
+    for (int i = lane; i < n1l; i += 64) { s_m12[i] = -1; s_bin[i] = -1; }
+    for (int i = lane; i < ORBHIP_HISTO_LENGTH + 8; i += 64) s_hist[i] = 0;
+    for (int i = lane; i < n1; i += 64) { m12[i] = -1; if (M.prev_from_kp1) { prev[2 * i] = kp1[i].x; prev[2 * i + 1] = kp1[i].y; } }
+    __syncthreads();
+    const float factor = 1.0f / ORBHIP_HISTO_LENGTH;
+    for (int j1 = 0; j1 < n1l; j1++) {
+        const int nc = M.ncand[(long long)slot * M.lvl0_cap + j1];
+        if (nc == 0) continue;
+        const unsigned* cand = M.cand + ((long long)slot * M.lvl0_cap + j1) * M.cand_stride;
+        int best = IMAX, second = IMAX, bidx = -1;
+        for (int cb = 0; cb < nc; cb += 64) {
+            const int t = cb + lane;
+            int d = IMAX, i2 = 0;
+            if (t < nc) { const unsigned e = cand[t]; i2 = (int)(e & 0xFFFFFu); const int dist = (int)(e >> 20); if (!(s_md[i2] <= dist)) d = dist; }   // :444-445
+            const int wmin = wave_min_i(d);
+            if (wmin == IMAX) continue;
+            const unsigned long long mk = __ballot(d == wmin);
+            const int first = __ffsll((long long)mk) - 1;        // strict '<': the first candidate with the minimum wins (:447-452)
+            const int ci = __shfl(i2, first);
+            const int wsec = wave_min_i(lane == first ? IMAX : d);
+            if (wmin < best) { second = min(best, wsec); best = wmin; bidx = ci; } else second = min(second, wmin);
+        }
+        if (best <= ORBHIP_TH_LOW && (float)best < __fmul_rn((float)second, M.nnratio)) {      // :459-461
+            if (lane == 0) {
+                const int old = s_m21[bidx];
+                if (old >= 0) s_m12[old] = -1;
+                s_m12[j1] = bidx; s_m21[bidx] = j1; s_md[bidx] = best;
+                if (M.check_ori) {
+                    float rot = __fsub_rn(kp1[list1 ? list1[j1] : j1].angle, kp2[bidx].angle);
+                    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                    int bin = (int)roundf(__fmul_rn(rot, factor));
+                    if (bin == ORBHIP_HISTO_LENGTH) bin = 0;
+                    bin = min(max(bin, 0), ORBHIP_HISTO_LENGTH - 1);
+                    s_bin[j1] = bin; s_hist[bin]++;               // rotHist[bin].push_back(i1): never removed when stolen
+                }
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    // nmatches of the reference (++ on accept, -- on steal :463-467 and on rotation reject :504-508) == final count of set entries
+    if (M.check_ori) {
+        if (lane == 0) {                                          // ComputeThreeMaxima (:1601-1642)
+            int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+            for (int i = 0; i < ORBHIP_HISTO_LENGTH; i++) {
+                const int s = s_hist[i];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+                else if (s > max3) { max3 = s; ind3 = i; }
+            }
+            if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+            else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
+            s_hist[ORBHIP_HISTO_LENGTH] = ind1; s_hist[ORBHIP_HISTO_LENGTH + 1] = ind2; s_hist[ORBHIP_HISTO_LENGTH + 2] = ind3;
+        }
+        __syncthreads();
+        const int ind1 = s_hist[ORBHIP_HISTO_LENGTH], ind2 = s_hist[ORBHIP_HISTO_LENGTH + 1], ind3 = s_hist[ORBHIP_HISTO_LENGTH + 2];
+        for (int j = lane; j < n1l; j += 64) { const int b = s_bin[j]; if (b >= 0 && b != ind1 && b != ind2 && b != ind3) s_m12[j] = -1; }
+        __syncthreads();
+    }
+    int cnt = 0;
+    for (int j = lane; j < n1l; j += 64) {
+        const int m = s_m12[j];
+        if (m >= 0) { const int i1 = list1 ? list1[j] : j; cnt++; m12[i1] = m; prev[2 * i1] = kp2[m].x; prev[2 * i1 + 1] = kp2[m].y; }      // :515-517
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if (lane == 0) M.nmatches[slot] = cnt;
+}
+
+void orbhip_launch_match_select(const MatchParams& M, int nslots, hipStream_t s)
+{
+    const size_t lds = sizeof(int) * ((size_t)2 * M.cap + (size_t)2 * M.lvl0_cap + ORBHIP_HISTO_LENGTH + 8);
+    hipLaunchKernelGGL(k_match_select, dim3(nslots, 1, 1), dim3(64, 1, 1), lds, s, M);
+}

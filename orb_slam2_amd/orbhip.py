@@ -1,0 +1,296 @@
+"""ctypes binding of liborbhip.so (include/orbhip.h) — the host-side mirror of the reference's two classes.
+
+`ORBextractor` and `ORBmatcher` below keep the names, argument meaning and outputs of ORB_SLAM2::ORBextractor
+(ORBextractor.h:45-111) and ORB_SLAM2::ORBmatcher (ORBmatcher.h:37-102) for the hot path this repository
+replaces; they call the C ABI only.  There is no CPU fallback: if the HIP library is missing or no GPU is usable
+the constructors raise `OrbHipError`.
+
+ORBHIP_LIBRARY=<path> overrides the shared object (the CPU test-suite points it at the fiber-emulation build of
+the same sources, tests/emu/liborbhip_emu.so, to check kernel logic where no GPU exists).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                           ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+
+# every symbol include/orbhip.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "orbhip_version", "orbhip_last_error", "orbhip_create", "orbhip_destroy", "orbhip_keypoint_capacity",
+    "orbhip_get_scale_tables", "orbhip_level_size", "orbhip_extract", "orbhip_extract_batch", "orbhip_pyramid_level",
+    "orbhip_extract_device", "orbhip_sync", "orbhip_fetch", "orbhip_fetch_matches", "orbhip_descriptor_distance",
+    "orbhip_hamming_nn", "orbhip_hamming_nn_device", "orbhip_search_for_initialization", "orbhip_profile_enable",
+    "orbhip_profile_num_kernels", "orbhip_profile_get", "orbhip_profile_reset", "orbhip_algorithmic_bytes_per_frame",
+    "orbhip_algorithmic_bytes_per_frame_kernel", "orbhip_debug_blurred_level", "orbhip_debug_candidates",
+]
+
+
+class OrbHipError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32), ("ini_th_fast", C.c_int32),
+                ("min_th_fast", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("max_batch", C.c_int32),
+                ("device", C.c_int32), ("stream", C.c_void_p), ("blur_round_mode", C.c_int32)]
+
+
+def library_path():
+    return os.environ.get("ORBHIP_LIBRARY") or os.path.join(_HERE, "liborbhip.so")
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise OrbHipError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    L = C.CDLL(path)
+    vp, i32p, ip = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int)
+    L.orbhip_version.restype = C.c_char_p
+    L.orbhip_last_error.restype = C.c_char_p
+    L.orbhip_create.argtypes = [C.POINTER(vp), C.POINTER(Config)]
+    L.orbhip_destroy.argtypes = [vp]
+    L.orbhip_destroy.restype = None
+    L.orbhip_keypoint_capacity.argtypes = [vp]
+    L.orbhip_get_scale_tables.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.orbhip_level_size.argtypes = [vp, C.c_int, ip, ip]
+    L.orbhip_extract.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, ip]
+    L.orbhip_extract_batch.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp]
+    L.orbhip_pyramid_level.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
+    L.orbhip_extract_device.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]
+    L.orbhip_sync.argtypes = [vp]
+    L.orbhip_fetch.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp]
+    L.orbhip_fetch_matches.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
+    L.orbhip_descriptor_distance.argtypes = [vp, vp]
+    L.orbhip_hamming_nn.argtypes = [C.c_int, vp, C.c_int, vp, C.c_int64, C.c_int64, vp, vp, vp]
+    L.orbhip_hamming_nn_device.argtypes = [vp, vp, C.c_int, vp, C.c_int64, C.c_int64, vp, vp, vp]
+    L.orbhip_search_for_initialization.argtypes = [C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp,
+                                                   C.c_int, C.c_float, C.c_int, ip]
+    L.orbhip_profile_enable.argtypes = [vp, C.c_int]
+    L.orbhip_profile_num_kernels.argtypes = [vp]
+    L.orbhip_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.orbhip_profile_reset.argtypes = [vp]
+    L.orbhip_algorithmic_bytes_per_frame.argtypes = [vp]
+    L.orbhip_algorithmic_bytes_per_frame.restype = C.c_int64
+    L.orbhip_algorithmic_bytes_per_frame_kernel.argtypes = [vp, C.c_int]
+    L.orbhip_algorithmic_bytes_per_frame_kernel.restype = C.c_int64
+    L.orbhip_debug_blurred_level.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
+    L.orbhip_debug_candidates.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, ip]
+    _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _check(st, what):
+    if st != 0:
+        raise OrbHipError(f"{what} failed (status {st}): {lib().orbhip_last_error().decode()}")
+
+
+class ORBextractor:
+    """ORB_SLAM2::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST) on one MI355X.
+
+    The reference extractor accepts any image size per call; here the HBM layout is fixed at construction
+    (width, height, max_batch) — construct one per camera geometry.  `__call__(image)` is operator().
+    """
+    HARRIS_SCORE, FAST_SCORE = 0, 1
+
+    def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, width, height, max_batch=1, device=0,
+                 stream=None, blur_round_mode=0):
+        self.L = lib()
+        self.cfg = Config(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, width, height, max_batch, device,
+                          C.c_void_p(stream) if stream else None, blur_round_mode)
+        self.h = C.c_void_p()
+        _check(self.L.orbhip_create(C.byref(self.h), C.byref(self.cfg)), "orbhip_create")
+        self.width, self.height, self.nlevels, self.max_batch = width, height, nlevels, max_batch
+        self.capacity = self.L.orbhip_keypoint_capacity(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.orbhip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- accessors (ORBextractor.h:63-84)
+    def GetLevels(self):
+        return self.nlevels
+
+    def GetScaleFactor(self):
+        return float(np.float32(self.cfg.scale_factor))
+
+    def _tables(self):
+        n = self.nlevels
+        sf, isf, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        fpl = np.zeros(n, np.int32)
+        _check(self.L.orbhip_get_scale_tables(self.h, _p(sf), _p(isf), _p(s2), _p(is2), _p(fpl)), "orbhip_get_scale_tables")
+        return sf, isf, s2, is2, fpl
+
+    def GetScaleFactors(self):
+        return self._tables()[0]
+
+    def GetInverseScaleFactors(self):
+        return self._tables()[1]
+
+    def GetScaleSigmaSquares(self):
+        return self._tables()[2]
+
+    def GetInverseScaleSigmaSquares(self):
+        return self._tables()[3]
+
+    def features_per_level(self):
+        return self._tables()[4]
+
+    def level_size(self, level):
+        w, h = C.c_int(), C.c_int()
+        _check(self.L.orbhip_level_size(self.h, level, C.byref(w), C.byref(h)), "orbhip_level_size")
+        return w.value, h.value
+
+    # ---- operator()
+    def __call__(self, image, mask=None):
+        """Returns (keypoints[KEYPOINT_DTYPE], descriptors[N,32] uint8).  `mask` is ignored like in the reference."""
+        if image is None or image.size == 0:
+            return np.zeros(0, KEYPOINT_DTYPE), np.zeros((0, 32), np.uint8)
+        k, d = self.extract_batch([image])
+        return k[0], d[0]
+
+    def extract_batch(self, images):
+        n = len(images)
+        assert 1 <= n <= self.max_batch
+        imgs = [np.ascontiguousarray(im, np.uint8) for im in images]
+        for im in imgs:
+            assert im.shape == (self.height, self.width), (im.shape, (self.height, self.width))
+        ptrs = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
+        cap = self.capacity
+        kps = np.zeros((n, cap), KEYPOINT_DTYPE)
+        desc = np.zeros((n, cap, 32), np.uint8)
+        nout = np.zeros(n, np.int32)
+        _check(self.L.orbhip_extract_batch(self.h, n, ptrs, self.width, _p(kps), _p(desc), cap, _p(nout)), "orbhip_extract_batch")
+        return [kps[f, :nout[f]].copy() for f in range(n)], [desc[f, :nout[f]].copy() for f in range(n)]
+
+    def mvImagePyramid(self, level, frame=0):
+        w, h = self.level_size(level)
+        out = np.zeros((h, w), np.uint8)
+        _check(self.L.orbhip_pyramid_level(self.h, frame, level, _p(out), w), "orbhip_pyramid_level")
+        return out
+
+    # ---- device-resident pipeline
+    def extract_device(self, dptr, nimg, frame_stride, row_stride, match_prev=False, window=100, nnratio=0.9, check_ori=True):
+        _check(self.L.orbhip_extract_device(self.h, nimg, C.c_void_p(dptr), frame_stride, row_stride, int(match_prev), window,
+                                            nnratio, int(check_ori)), "orbhip_extract_device")
+
+    def sync(self):
+        _check(self.L.orbhip_sync(self.h), "orbhip_sync")
+
+    def fetch(self, nimg):
+        cap = self.capacity
+        kps = np.zeros((nimg, cap), KEYPOINT_DTYPE)
+        desc = np.zeros((nimg, cap, 32), np.uint8)
+        nout = np.zeros(nimg, np.int32)
+        _check(self.L.orbhip_fetch(self.h, nimg, _p(kps), _p(desc), cap, _p(nout)), "orbhip_fetch")
+        return [kps[f, :nout[f]].copy() for f in range(nimg)], [desc[f, :nout[f]].copy() for f in range(nimg)]
+
+    def fetch_matches(self, nimg):
+        cap = self.capacity
+        m12 = np.full((nimg, cap), -1, np.int32)
+        n1 = np.zeros(nimg, np.int32)
+        nm = np.zeros(nimg, np.int32)
+        _check(self.L.orbhip_fetch_matches(self.h, nimg, _p(m12), cap, _p(n1), _p(nm)), "orbhip_fetch_matches")
+        return [m12[f, :n1[f]].copy() for f in range(nimg)], nm
+
+    # ---- measurement / stage dumps
+    def profile_enable(self, on=True):
+        _check(self.L.orbhip_profile_enable(self.h, int(on)), "orbhip_profile_enable")
+
+    def profile_reset(self):
+        _check(self.L.orbhip_profile_reset(self.h), "orbhip_profile_reset")
+
+    def profile(self):
+        out = {}
+        for k in range(self.L.orbhip_profile_num_kernels(self.h)):
+            name, ms, n = C.c_char_p(), C.c_double(), C.c_int64()
+            _check(self.L.orbhip_profile_get(self.h, k, C.byref(name), C.byref(ms), C.byref(n)), "orbhip_profile_get")
+            out[name.value.decode()] = dict(index=k, total_ms=ms.value, launches=n.value,
+                                            alg_bytes_per_frame=self.L.orbhip_algorithmic_bytes_per_frame_kernel(self.h, k))
+        return out
+
+    def algorithmic_bytes_per_frame(self):
+        return self.L.orbhip_algorithmic_bytes_per_frame(self.h)
+
+    def blurred_level(self, level, frame=0):
+        w, h = self.level_size(level)
+        out = np.zeros((h, w), np.uint8)
+        _check(self.L.orbhip_debug_blurred_level(self.h, frame, level, _p(out), w), "orbhip_debug_blurred_level")
+        return out
+
+    def candidates(self, level, frame=0):
+        n = C.c_int()
+        _check(self.L.orbhip_debug_candidates(self.h, frame, level, None, 0, C.byref(n)), "orbhip_debug_candidates")
+        out = np.zeros((max(n.value, 1), 3), np.int32)
+        _check(self.L.orbhip_debug_candidates(self.h, frame, level, _p(out), n.value, C.byref(n)), "orbhip_debug_candidates")
+        return out[:n.value].copy()
+
+
+class ORBmatcher:
+    """The Frame-to-Frame / Hamming part of ORB_SLAM2::ORBmatcher(nnratio=0.6, checkOri=true) on one MI355X."""
+    TH_LOW, TH_HIGH, HISTO_LENGTH = 50, 100, 30
+
+    def __init__(self, nnratio=0.6, checkOri=True, device=0):
+        self.L = lib()
+        self.nnratio, self.checkOri, self.device = float(nnratio), bool(checkOri), device
+
+    @staticmethod
+    def DescriptorDistance(a, b):
+        a = np.ascontiguousarray(a, np.uint8)
+        b = np.ascontiguousarray(b, np.uint8)
+        assert a.size == 32 and b.size == 32
+        return lib().orbhip_descriptor_distance(_p(a), _p(b))
+
+    def SearchForInitialization(self, kps1, desc1, kps2, desc2, im_w, im_h, vbPrevMatched=None, windowSize=10):
+        """F1/F2 are passed as (mvKeysUn, mDescriptors) + the image bounds.  Returns (nmatches, vnMatches12, vbPrevMatched)."""
+        kps1 = np.ascontiguousarray(kps1)
+        kps2 = np.ascontiguousarray(kps2)
+        desc1 = np.ascontiguousarray(desc1, np.uint8)
+        desc2 = np.ascontiguousarray(desc2, np.uint8)
+        if vbPrevMatched is None:
+            vbPrevMatched = np.stack([kps1["x"], kps1["y"]], axis=1)
+        prev = np.ascontiguousarray(vbPrevMatched, np.float32).copy()
+        m12 = np.full(max(len(kps1), 1), -1, np.int32)
+        nm = C.c_int()
+        _check(self.L.orbhip_search_for_initialization(self.device, _p(kps1), _p(desc1), len(kps1), _p(kps2), _p(desc2), len(kps2),
+                                                       im_w, im_h, _p(prev), _p(m12), windowSize, self.nnratio, int(self.checkOri),
+                                                       C.byref(nm)), "orbhip_search_for_initialization")
+        return nm.value, m12[:len(kps1)], prev
+
+
+def hamming_nn(q, db, device=0, index_base=0):
+    """Brute-force NN of every query descriptor over db: (best_idx int64, best_dist, second_dist)."""
+    q = np.ascontiguousarray(q, np.uint8)
+    db = np.ascontiguousarray(db, np.uint8)
+    bi = np.zeros(len(q), np.int64)
+    bd = np.zeros(len(q), np.int32)
+    sd = np.zeros(len(q), np.int32)
+    _check(lib().orbhip_hamming_nn(device, _p(q), len(q), _p(db), len(db), index_base, _p(bi), _p(bd), _p(sd)), "orbhip_hamming_nn")
+    return bi, bd, sd
+
+
+def hamming_nn_device(stream, d_q, nq, d_db, ndb, d_best_idx, d_best_dist, d_second, index_base=0):
+    _check(lib().orbhip_hamming_nn_device(C.c_void_p(stream) if stream else None, C.c_void_p(d_q), nq, C.c_void_p(d_db), ndb,
+                                          index_base, C.c_void_p(d_best_idx), C.c_void_p(d_best_dist), C.c_void_p(d_second)),
+           "orbhip_hamming_nn_device")

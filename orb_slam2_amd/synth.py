@@ -1,0 +1,126 @@
+"""Seeded synthetic grayscale frames for tests and bench (datasets are not available).
+
+image i = 3-octave value noise (uniform u8 grids at 1/8, 1/16, 1/32 resolution, bilinearly upsampled, weights
+0.5/0.3/0.2), over-painted by 400 random shapes (axis-aligned rectangles, ellipses, rotated rectangles; side
+6..60 px; uniform grey), plus uniform integer noise in [-6, 6], clipped to u8.  Consecutive frames of a
+sequence are the same scene translated by (3, 1) px with fresh noise, so the frame-to-frame matcher finds matches.
+"""
+import numpy as np
+
+BASE_SEED = 20260921
+
+
+def _upsample(grid, h, w):
+    gh, gw = grid.shape
+    ys = (np.arange(h) + 0.5) * gh / h - 0.5
+    xs = (np.arange(w) + 0.5) * gw / w - 0.5
+    y0 = np.clip(np.floor(ys).astype(int), 0, gh - 1)
+    x0 = np.clip(np.floor(xs).astype(int), 0, gw - 1)
+    y1 = np.clip(y0 + 1, 0, gh - 1)
+    x1 = np.clip(x0 + 1, 0, gw - 1)
+    fy = np.clip(ys - np.floor(ys), 0, 1)[:, None]
+    fx = np.clip(xs - np.floor(xs), 0, 1)[None, :]
+    g = grid.astype(np.float64)
+    top = g[y0][:, x0] * (1 - fx) + g[y0][:, x1] * fx
+    bot = g[y1][:, x0] * (1 - fx) + g[y1][:, x1] * fx
+    return top * (1 - fy) + bot * fy
+
+
+def scene(width, height, seed=0, margin=64, nshapes=400):
+    """Noise-free scene, (height+2*margin) x (width+2*margin) float64, so translated crops stay in-bounds."""
+    rng = np.random.default_rng(BASE_SEED + seed)
+    H, W = height + 2 * margin, width + 2 * margin
+    img = np.zeros((H, W))
+    for div, wgt in ((8, 0.5), (16, 0.3), (32, 0.2)):
+        grid = rng.integers(0, 256, size=(max(H // div, 2), max(W // div, 2)))
+        img += wgt * _upsample(grid, H, W)
+    n = int(nshapes * (H * W) / (1241.0 * 376.0 + 1e-9) * 0.75) if (width, height) != (1241, 376) else nshapes
+    n = max(n, 40)
+    for _ in range(n):
+        kind = rng.integers(0, 3)
+        cx, cy = rng.integers(0, W), rng.integers(0, H)
+        a, b = rng.integers(6, 61) / 2.0, rng.integers(6, 61) / 2.0
+        grey = float(rng.integers(0, 256))
+        r = int(np.ceil(np.hypot(a, b))) + 1
+        x0, x1 = max(cx - r, 0), min(cx + r + 1, W)
+        y0, y1 = max(cy - r, 0), min(cy + r + 1, H)
+        if x0 >= x1 or y0 >= y1:
+            continue
+        yy, xx = np.mgrid[y0:y1, x0:x1]
+        dx, dy = xx - cx, yy - cy
+        if kind == 0:
+            m = (np.abs(dx) <= a) & (np.abs(dy) <= b)
+        elif kind == 1:
+            m = (dx / a) ** 2 + (dy / b) ** 2 <= 1.0
+        else:
+            th = rng.uniform(0, np.pi)
+            c, s = np.cos(th), np.sin(th)
+            u, v = dx * c + dy * s, -dx * s + dy * c
+            m = (np.abs(u) <= a) & (np.abs(v) <= b)
+        img[y0:y1, x0:x1][m] = grey
+    return img
+
+
+def frame_from_scene(sc, width, height, t=0, seed=0, margin=64, shift=(3, 1)):
+    """Frame t of the sequence: crop translated by t*shift, plus fresh uniform noise in [-6, 6]."""
+    rng = np.random.default_rng((BASE_SEED + seed) * 1000003 + 7919 * t + 1)
+    ox = margin + (t * shift[0]) % (2 * margin - 1) - margin // 2
+    oy = margin + (t * shift[1]) % (2 * margin - 1) - margin // 2
+    crop = sc[oy:oy + height, ox:ox + width]
+    noise = rng.integers(-6, 7, size=(height, width))
+    return np.clip(np.rint(crop) + noise, 0, 255).astype(np.uint8)
+
+
+def frame(width, height, seed=0, t=0):
+    return frame_from_scene(scene(width, height, seed), width, height, t=t, seed=seed)
+
+
+def sequence(width, height, nframes, seed=0):
+    sc = scene(width, height, seed)
+    return [frame_from_scene(sc, width, height, t=t, seed=seed) for t in range(nframes)]
+
+
+# degenerate cases the parity tests cover
+def zeros(width, height):
+    return np.zeros((height, width), np.uint8)
+
+
+def checkerboard(width, height, cell=8, lo=40, hi=210):
+    yy, xx = np.mgrid[0:height, 0:width]
+    return np.where(((yy // cell) + (xx // cell)) % 2 == 0, lo, hi).astype(np.uint8)
+
+
+def ramp(width, height):
+    xx = np.arange(width)[None, :] * 255.0 / max(width - 1, 1)
+    yy = np.arange(height)[:, None] * 64.0 / max(height - 1, 1)
+    return np.clip(xx * 0.75 + yy, 0, 255).astype(np.uint8)
+
+
+def low_texture(width, height, seed=3):
+    """Smooth image with a few weak blobs: exercises the minThFAST fallback and < nfeatures outputs."""
+    rng = np.random.default_rng(BASE_SEED + 77 + seed)
+    img = np.full((height, width), 120.0)
+    for _ in range(12):
+        cx, cy = rng.integers(30, width - 30), rng.integers(30, height - 30)
+        s = rng.integers(3, 9)
+        img[cy - s:cy + s, cx - s:cx + s] += rng.integers(9, 30)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def descriptor_db(n_keyframes, per_kf, seed=7):
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, 256, size=(n_keyframes * per_kf, 32), dtype=np.uint8)
+
+
+def descriptor_query(db, nq, seed=7, planted_frac=0.5, max_flips=20):
+    """Query set with a fraction of planted near-duplicates of DB rows (<= max_flips bit flips)."""
+    rng = np.random.default_rng(seed + 1)
+    q = rng.integers(0, 256, size=(nq, 32), dtype=np.uint8)
+    planted = rng.random(nq) < planted_frac
+    src = rng.integers(0, len(db), size=nq)
+    for i in np.nonzero(planted)[0]:
+        d = db[src[i]].copy()
+        for bit in rng.integers(0, 256, size=rng.integers(0, max_flips + 1)):
+            d[bit >> 3] ^= np.uint8(1 << (bit & 7))
+        q[i] = d
+    return q

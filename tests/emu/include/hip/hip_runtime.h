@@ -1,0 +1,207 @@
+// hip_runtime.h — TEST-ONLY functional emulation of the subset of HIP that orb_slam2_amd/csrc uses.
+//
+// Purpose: this container has no GPU.  To debug kernel LOGIC (index math, barriers, wave collectives,
+// list-order semantics) before spending scarce GPU minutes, tests/emu builds the unmodified product sources
+// (orb_slam2_amd/csrc/*.hip, *.cpp) with g++ against this header and runs every workgroup as a set of
+// cooperatively scheduled fibers (ucontext).  __syncthreads and the wave64 collectives (__ballot, __shfl*,
+// __any/__all) are rendezvous points.  It is NOT a product path, NOT a CPU fallback and is never shipped or
+// benchmarked: liborbhip.so is built by hipcc for gfx950 only and fails loudly without a GPU.
+// Semantics emulated: wave = 64 consecutive threads of a block; collectives are assumed to be called
+// convergently by all live lanes of a wave (as on hardware, anything else is a kernel bug).
+#pragma once
+#include <ucontext.h>
+#include <time.h>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <cstdio>
+#include <cmath>
+#include <vector>
+#include <algorithm>
+#include <functional>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __constant__ static const
+#define __launch_bounds__(...)
+#define __restrict__ __restrict
+#define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(hipemu::g.dyn_shared);
+
+struct dim3 { unsigned x, y, z; constexpr dim3(unsigned X = 1, unsigned Y = 1, unsigned Z = 1) : x(X), y(Y), z(Z) {} };
+struct uint3 { unsigned x, y, z; };
+struct int2 { int x, y; };
+struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+struct uchar4 { unsigned char x, y, z, w; };
+
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
+typedef struct hipemuStream* hipStream_t;
+typedef struct hipemuEvent { double t; }* hipEvent_t;
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+enum { hipHostMallocDefault = 0, hipStreamNonBlocking = 1, hipEventDefault = 0 };
+struct hipDeviceProp_t { char name[256]; int multiProcessorCount; size_t totalGlobalMem; char gcnArchName[256]; };
+
+namespace hipemu {
+
+struct Fiber {
+    ucontext_t ctx; char* stack = nullptr; bool done = false; uint3 tid; int lane, wave;
+};
+struct Wave {
+    int live = 0, arrived = 0; unsigned gen = 0;
+    uint64_t in[64]; int src[64]; uint64_t out[64]; bool present[64];
+};
+struct Globals {
+    ucontext_t sched; Fiber* cur = nullptr; std::vector<Fiber> fibers; std::vector<Wave> waves;
+    uint3 bid; dim3 bdim, gdim; int live = 0, bar_count = 0; unsigned bar_gen = 0;
+    char* dyn_shared = nullptr; std::function<void()> body; size_t stack_size = 128 * 1024;
+};
+inline Globals g;
+
+inline void yield() { swapcontext(&g.cur->ctx, &g.sched); }
+inline void fiber_main() {
+    g.body();
+    Fiber* f = g.cur; f->done = true; g.live--; g.waves[f->wave].live--;
+    swapcontext(&f->ctx, &g.sched);
+}
+inline void syncthreads() {
+    unsigned gen = g.bar_gen; g.bar_count++;
+    while (g.bar_gen == gen) { if (g.bar_count >= g.live) { g.bar_count = 0; g.bar_gen++; break; } yield(); }
+}
+enum Op { OP_BALLOT, OP_SHFL };
+// rendezvous of all live lanes of the calling wave; the last arriver computes every lane's result
+inline uint64_t wave_collective(Op op, uint64_t val, int srclane) {
+    Fiber* f = g.cur; Wave& w = g.waves[f->wave];
+    unsigned gen = w.gen; w.in[f->lane] = val; w.src[f->lane] = srclane; w.present[f->lane] = true; w.arrived++;
+    while (w.gen == gen) {
+        if (w.arrived >= w.live) {
+            if (op == OP_BALLOT) { uint64_t m = 0; for (int l = 0; l < 64; l++) if (w.present[l] && w.in[l]) m |= 1ull << l; for (int l = 0; l < 64; l++) w.out[l] = m; }
+            else for (int l = 0; l < 64; l++) { int s = w.src[l]; w.out[l] = (w.present[l] && s >= 0 && s < 64 && w.present[s]) ? w.in[s] : w.in[l]; }
+            for (int l = 0; l < 64; l++) w.present[l] = false;
+            w.arrived = 0; w.gen++; break;
+        }
+        yield();
+    }
+    return w.out[f->lane];
+}
+
+template <typename K, typename... A>
+void launch(K kernel, dim3 grid, dim3 block, size_t shmem, A... args) {
+    const int T = (int)(block.x * block.y * block.z);
+    std::vector<char> dyn(shmem + 64);
+    g.dyn_shared = dyn.data(); g.bdim = block; g.gdim = grid;
+    if ((int)g.fibers.size() < T) { size_t old = g.fibers.size(); g.fibers.resize(T); for (size_t i = old; i < (size_t)T; i++) g.fibers[i].stack = (char*)malloc(g.stack_size); }
+    g.body = [&]() { kernel(args...); };
+    for (unsigned bz = 0; bz < grid.z; bz++) for (unsigned by = 0; by < grid.y; by++) for (unsigned bx = 0; bx < grid.x; bx++) {
+        g.bid = uint3{bx, by, bz}; g.live = T; g.bar_count = 0; g.bar_gen = 0;
+        g.waves.assign((T + 63) / 64, Wave());
+        for (auto& w : g.waves) for (int l = 0; l < 64; l++) w.present[l] = false;
+        for (int t = 0; t < T; t++) {
+            Fiber& f = g.fibers[t]; f.done = false;
+            f.tid = uint3{(unsigned)(t % block.x), (unsigned)((t / block.x) % block.y), (unsigned)(t / (block.x * block.y))};
+            f.lane = t & 63; f.wave = t >> 6; g.waves[f.wave].live++;
+            getcontext(&f.ctx); f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = g.stack_size; f.ctx.uc_link = nullptr;
+            makecontext(&f.ctx, (void (*)())fiber_main, 0);
+        }
+        while (g.live > 0)
+            for (int t = 0; t < T; t++) { Fiber& f = g.fibers[t]; if (f.done) continue; g.cur = &f; swapcontext(&g.sched, &f.ctx); }
+    }
+    g.cur = nullptr;
+}
+}  // namespace hipemu
+
+#define threadIdx (hipemu::g.cur->tid)
+#define blockIdx (hipemu::g.bid)
+#define blockDim (hipemu::g.bdim)
+#define gridDim (hipemu::g.gdim)
+#define warpSize 64
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) hipemu::launch(kernel, dim3(grid), dim3(block), (size_t)(shmem), ##__VA_ARGS__)
+
+inline void __syncthreads() { hipemu::syncthreads(); }
+inline unsigned long long __ballot(int pred) { return hipemu::wave_collective(hipemu::OP_BALLOT, pred != 0, 0); }
+inline int __any(int pred) { return __ballot(pred) != 0; }
+inline int __all(int pred) { return hipemu::wave_collective(hipemu::OP_BALLOT, pred == 0, 0) == 0; }
+inline int __lane_id() { return hipemu::g.cur->lane; }
+template <typename T> inline T hipemu_shfl(T v, int src) {
+    static_assert(sizeof(T) <= 8, "shfl size"); uint64_t raw = 0; memcpy(&raw, &v, sizeof(T));
+    raw = hipemu::wave_collective(hipemu::OP_SHFL, raw, src); T r; memcpy(&r, &raw, sizeof(T)); return r;
+}
+template <typename T> inline T __shfl(T v, int srcLane, int width = 64) { int l = __lane_id(); return hipemu_shfl(v, (l & ~(width - 1)) + (srcLane & (width - 1))); }
+template <typename T> inline T __shfl_down(T v, unsigned d, int width = 64) { int l = __lane_id(); int s = l + (int)d; if ((s & ~(width - 1)) != (l & ~(width - 1))) s = l; return hipemu_shfl(v, s); }
+template <typename T> inline T __shfl_up(T v, unsigned d, int width = 64) { int l = __lane_id(); int s = l - (int)d; if (s < 0 || (s & ~(width - 1)) != (l & ~(width - 1))) s = l; return hipemu_shfl(v, s); }
+template <typename T> inline T __shfl_xor(T v, int m, int width = 64) { int l = __lane_id(); int s = l ^ m; if ((s & ~(width - 1)) != (l & ~(width - 1))) s = l; return hipemu_shfl(v, s); }
+
+inline int __popc(unsigned v) { return __builtin_popcount(v); }
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __ffs(int v) { return __builtin_ffs(v); }
+inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
+inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
+
+// atomics (single OS thread: plain read-modify-write is atomic w.r.t. fibers)
+template <typename T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+template <typename T> inline T atomicSub(T* p, T v) { T o = *p; *p = o - v; return o; }
+template <typename T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <typename T> inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
+template <typename T> inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
+template <typename T> inline T atomicAnd(T* p, T v) { T o = *p; *p = o & v; return o; }
+template <typename T> inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
+template <typename T> inline T atomicCAS(T* p, T c, T v) { T o = *p; if (o == c) *p = v; return o; }
+inline void __threadfence() {}
+inline void __threadfence_block() {}
+
+// IEEE round-to-nearest arithmetic intrinsics (the emu build uses -ffp-contract=off, so plain ops are exact)
+inline float __fmul_rn(float a, float b) { return a * b; }
+inline float __fadd_rn(float a, float b) { return a + b; }
+inline float __fsub_rn(float a, float b) { return a - b; }
+inline float __fdiv_rn(float a, float b) { return a / b; }
+inline double __dmul_rn(double a, double b) { return a * b; }
+inline double __dadd_rn(double a, double b) { return a + b; }
+inline double __dsub_rn(double a, double b) { return a - b; }
+inline int __float2int_rn(float v) { return (int)lrintf(v); }
+inline int __float2int_rz(float v) { return (int)v; }
+inline int __double2int_rz(double v) { return (int)v; }
+inline float __double2float_rn(double v) { return (float)v; }
+inline float __int2float_rn(int v) { return (float)v; }
+inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
+inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
+using std::min; using std::max;
+inline int min(int a, unsigned b) { return a < (int)b ? a : (int)b; }
+
+// ---- host API
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { memset(p, 0, sizeof(*p)); strcpy(p->name, "hipemu (CPU fibers, test only)"); strcpy(p->gcnArchName, "emu"); p->multiProcessorCount = 1; return hipSuccess; }
+inline hipError_t hipMalloc(void** p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+template <typename T> inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
+inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
+template <typename T> inline hipError_t hipHostMalloc(T** p, size_t n, unsigned f = 0) { return hipMalloc((void**)p, n); }
+inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t = nullptr) {
+    for (size_t y = 0; y < h; y++) memcpy((char*)d + y * dp, (const char*)s + y * sp, w); return hipSuccess; }
+inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { memset(d, v, n); return hipSuccess; }
+inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipemu error"; }
+inline double hipemu_now_ms() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipemuEvent{0}; return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = hipemu_now_ms(); return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return hipSuccess; }
