@@ -1,0 +1,11 @@
+"""orb_slam2_amd — MI355X-native ORB front-end (extract + match) behind the ORB_SLAM2 class signatures.
+
+Only what the hot path needs: csrc/ (hand-written HIP kernels for gfx950 + the C ABI of include/orbhip.h),
+orbhip.py (ctypes mirror of ORB_SLAM2::ORBextractor / ORBmatcher), sharding.py (frames / DB shards across the GPUs
+of a node, no collective) and synth.py (seeded synthetic frames).  No CPU fallback lives in this package.
+"""
+from .orbhip import (KEYPOINT_DTYPE, ORBextractor, ORBmatcher, OrbHipError, hamming_nn, hamming_nn_device, lib,
+                     library_path)
+
+__all__ = ["KEYPOINT_DTYPE", "ORBextractor", "ORBmatcher", "OrbHipError", "hamming_nn", "hamming_nn_device", "lib",
+           "library_path"]

@@ -43,14 +43,14 @@ def library_path():
     return os.environ.get("ORBHIP_LIBRARY") or os.path.join(_HERE, "liborbhip.so")
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is not None:
-        return _lib
-    path = library_path()
+def lib(path=None):
+    """Load (once per path) and return the ctypes handle; path=None -> ORBHIP_LIBRARY or the in-tree liborbhip.so."""
+    path = os.path.abspath(path or library_path())
+    if path in _libs:
+        return _libs[path]
     if not os.path.exists(path):
         raise OrbHipError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
@@ -86,7 +86,7 @@ def lib():
     L.orbhip_algorithmic_bytes_per_frame_kernel.restype = C.c_int64
     L.orbhip_debug_blurred_level.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
     L.orbhip_debug_candidates.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, ip]
-    _lib = L
+    _libs[path] = L
     return L
 
 
@@ -94,9 +94,9 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def _check(st, what):
+def _check(st, what, L=None):
     if st != 0:
-        raise OrbHipError(f"{what} failed (status {st}): {lib().orbhip_last_error().decode()}")
+        raise OrbHipError(f"{what} failed (status {st}): {(L or lib()).orbhip_last_error().decode()}")
 
 
 class ORBextractor:
@@ -108,12 +108,12 @@ class ORBextractor:
     HARRIS_SCORE, FAST_SCORE = 0, 1
 
     def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, width, height, max_batch=1, device=0,
-                 stream=None, blur_round_mode=0):
-        self.L = lib()
+                 stream=None, blur_round_mode=0, library=None):
+        self.L = lib(library)
         self.cfg = Config(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, width, height, max_batch, device,
                           C.c_void_p(stream) if stream else None, blur_round_mode)
         self.h = C.c_void_p()
-        _check(self.L.orbhip_create(C.byref(self.h), C.byref(self.cfg)), "orbhip_create")
+        _check(self.L.orbhip_create(C.byref(self.h), C.byref(self.cfg)), "orbhip_create", self.L)
         self.width, self.height, self.nlevels, self.max_batch = width, height, nlevels, max_batch
         self.capacity = self.L.orbhip_keypoint_capacity(self.h)
 
@@ -251,16 +251,16 @@ class ORBmatcher:
     """The Frame-to-Frame / Hamming part of ORB_SLAM2::ORBmatcher(nnratio=0.6, checkOri=true) on one MI355X."""
     TH_LOW, TH_HIGH, HISTO_LENGTH = 50, 100, 30
 
-    def __init__(self, nnratio=0.6, checkOri=True, device=0):
-        self.L = lib()
+    def __init__(self, nnratio=0.6, checkOri=True, device=0, library=None):
+        self.L = lib(library)
         self.nnratio, self.checkOri, self.device = float(nnratio), bool(checkOri), device
 
     @staticmethod
-    def DescriptorDistance(a, b):
+    def DescriptorDistance(a, b, library=None):
         a = np.ascontiguousarray(a, np.uint8)
         b = np.ascontiguousarray(b, np.uint8)
         assert a.size == 32 and b.size == 32
-        return lib().orbhip_descriptor_distance(_p(a), _p(b))
+        return lib(library).orbhip_descriptor_distance(_p(a), _p(b))
 
     def SearchForInitialization(self, kps1, desc1, kps2, desc2, im_w, im_h, vbPrevMatched=None, windowSize=10):
         """F1/F2 are passed as (mvKeysUn, mDescriptors) + the image bounds.  Returns (nmatches, vnMatches12, vbPrevMatched)."""
@@ -279,18 +279,19 @@ class ORBmatcher:
         return nm.value, m12[:len(kps1)], prev
 
 
-def hamming_nn(q, db, device=0, index_base=0):
+def hamming_nn(q, db, device=0, index_base=0, library=None):
     """Brute-force NN of every query descriptor over db: (best_idx int64, best_dist, second_dist)."""
     q = np.ascontiguousarray(q, np.uint8)
     db = np.ascontiguousarray(db, np.uint8)
     bi = np.zeros(len(q), np.int64)
     bd = np.zeros(len(q), np.int32)
     sd = np.zeros(len(q), np.int32)
-    _check(lib().orbhip_hamming_nn(device, _p(q), len(q), _p(db), len(db), index_base, _p(bi), _p(bd), _p(sd)), "orbhip_hamming_nn")
+    L = lib(library)
+    _check(L.orbhip_hamming_nn(device, _p(q), len(q), _p(db), len(db), index_base, _p(bi), _p(bd), _p(sd)), "orbhip_hamming_nn", L)
     return bi, bd, sd
 
 
-def hamming_nn_device(stream, d_q, nq, d_db, ndb, d_best_idx, d_best_dist, d_second, index_base=0):
-    _check(lib().orbhip_hamming_nn_device(C.c_void_p(stream) if stream else None, C.c_void_p(d_q), nq, C.c_void_p(d_db), ndb,
+def hamming_nn_device(stream, d_q, nq, d_db, ndb, d_best_idx, d_best_dist, d_second, index_base=0, library=None):
+    _check(lib(library).orbhip_hamming_nn_device(C.c_void_p(stream) if stream else None, C.c_void_p(d_q), nq, C.c_void_p(d_db), ndb,
                                           index_base, C.c_void_p(d_best_idx), C.c_void_p(d_best_dist), C.c_void_p(d_second)),
            "orbhip_hamming_nn_device")

@@ -1,0 +1,64 @@
+"""Test configuration.
+
+Markers:   gpu  — needs a real MI355X (run by the driver with `-m gpu`; everything else runs on CPU).
+Backends:  the parity tests are written once and parametrised over
+           "emu" — the product kernel sources compiled against the TEST-ONLY fiber emulation of HIP
+                   (tests/emu/, CPU; checks kernel logic where no GPU exists; never shipped / benchmarked), and
+           "gpu" — the real liborbhip.so (hipcc, gfx950) through the C ABI; marked gpu.
+The oracle (oracle/) is only ever the checker.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+EMU_LIB = os.path.join(ROOT, "tests", "emu", "liborbhip_emu.so")
+GPU_LIB = os.path.join(ROOT, "orb_slam2_amd", "liborbhip.so")
+CSRC = os.path.join(ROOT, "orb_slam2_amd", "csrc")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X GPU (liborbhip.so built for gfx950)")
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(s) <= t for s in sources if os.path.exists(s))
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import orb_oracle as O
+    O.build()
+    return O
+
+
+@pytest.fixture(scope="session")
+def emu_lib():
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc"))]
+    srcs += [os.path.join(ROOT, "include", "orbhip.h"), os.path.join(ROOT, "tests", "emu", "include", "hip", "hip_runtime.h")]
+    if not _newer(EMU_LIB, srcs):
+        subprocess.check_call(["make", "-C", CSRC, "-s", "emu"])
+    return EMU_LIB
+
+
+@pytest.fixture(scope="session")
+def gpu_lib():
+    if not os.path.exists(GPU_LIB):
+        pytest.fail(f"{GPU_LIB} missing: run `python -c 'import __graft_entry__ as g; g.build()'` — no CPU fallback exists")
+    return GPU_LIB
+
+
+@pytest.fixture(params=["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
+def backend(request):
+    """Path of the library the parity test drives through the C ABI."""
+    if request.param == "emu":
+        return request.getfixturevalue("emu_lib")
+    return request.getfixturevalue("gpu_lib")

@@ -1,0 +1,104 @@
+"""Parity of the HIP extractor (through the C ABI) with the CPU oracle: bit-exact keypoints, angles, descriptors and
+every intermediate stage, on seeded synthetic frames and the degenerate inputs of SURVEY.md §8d.
+
+backend = "emu" (kernel sources under the test-only fiber emulation, CPU) or "gpu" (real liborbhip.so, marked gpu).
+"""
+import numpy as np
+import pytest
+
+import orb_slam2_amd
+from orb_slam2_amd import synth
+
+
+def _same(kg, dg, ko, do):
+    assert len(kg) == len(ko), (len(kg), len(ko))
+    for f in ko.dtype.names:           # raw IEEE-754 bits of pt.x pt.y size angle response, ints octave class_id
+        assert np.array_equal(kg[f].view(np.int32), ko[f].view(np.int32)), f
+    assert np.array_equal(dg, do)
+
+
+@pytest.mark.parametrize("w,h,n,seed", [(320, 240, 500, 1), (400, 250, 300, 2), (640, 480, 1000, 3)])
+def test_extract_bit_exact_with_stages(backend, oracle, w, h, n, seed):
+    img = synth.frame(w, h, seed=seed)
+    ora = oracle.OracleExtractor(n, 1.2, 8, 20, 7)
+    ko, do = ora.extract(img)
+    ex = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, library=backend)
+    kg, dg = ex(img)
+    p = ora.params()
+    assert np.array_equal(ex.GetScaleFactors(), p["scale_factors"]) and np.array_equal(ex.GetInverseScaleFactors(), p["inv_scale_factors"])
+    assert np.array_equal(ex.GetScaleSigmaSquares(), p["sigma2"]) and np.array_equal(ex.GetInverseScaleSigmaSquares(), p["inv_sigma2"])
+    assert np.array_equal(ex.features_per_level(), p["features_per_level"]) and ex.GetLevels() == 8
+    for l in range(8):
+        assert ex.level_size(l) == ora.level_size(l)
+        assert np.array_equal(ex.mvImagePyramid(l), ora.level(l)), f"pyramid level {l}"
+        assert np.array_equal(ex.candidates(l), ora.candidates(l)), f"FAST candidates level {l}"
+        b = ora.blurred(l)
+        if b is not None:
+            assert np.array_equal(ex.blurred_level(l), b), f"blurred level {l}"
+    _same(kg, dg, ko, do)
+    ex.close()
+
+
+@pytest.mark.parametrize("name", ["zeros", "checkerboard", "ramp", "low_texture", "saturated"])
+def test_degenerate_inputs(backend, oracle, name):
+    w, h, n = 320, 240, 400
+    img = {"zeros": synth.zeros(w, h), "checkerboard": synth.checkerboard(w, h, cell=8), "ramp": synth.ramp(w, h),
+           "low_texture": synth.low_texture(w, h), "saturated": np.full((h, w), 255, np.uint8)}[name]
+    ko, do = oracle.OracleExtractor(n, 1.2, 8, 20, 7).extract(img)
+    ex = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, library=backend)
+    kg, dg = ex(img)
+    _same(kg, dg, ko, do)
+    if name in ("zeros", "saturated"):
+        assert len(kg) == 0 and dg.shape == (0, 32)          # descriptors released, keypoints cleared
+    k0, d0 = ex(None)                                         # empty image: silent return (ORBextractor.cc:1046-1047)
+    assert len(k0) == 0
+    ex.close()
+
+
+def test_batch_strides_thresholds_and_round_mode(backend, oracle):
+    w, h, n = 352, 288, 350
+    seq = synth.sequence(w, h, 3, seed=7)
+    # non-default thresholds / levels / scale factor, SSE2 rounding mode of the blur
+    ora = oracle.OracleExtractor(n, 1.25, 6, 12, 5, blur_round_mode=1)
+    ex = orb_slam2_amd.ORBextractor(n, 1.25, 6, 12, 5, w, h, max_batch=3, blur_round_mode=1, library=backend)
+    ks, ds = ex.extract_batch(seq)
+    for f in range(3):
+        ko, do = ora.extract(seq[f])
+        _same(ks[f], ds[f], ko, do)
+    # a frame alone == the same frame inside a batch (slots are independent)
+    k1, d1 = ex(seq[1])
+    _same(k1, d1, ks[1], ds[1])
+    # padded row stride through the raw C ABI
+    import ctypes as C
+    padded = np.zeros((h, w + 37), np.uint8)
+    padded[:, :w] = seq[2]
+    cap = ex.capacity
+    kps = np.zeros(cap, orb_slam2_amd.KEYPOINT_DTYPE)
+    desc = np.zeros((cap, 32), np.uint8)
+    nout = C.c_int()
+    st = ex.L.orbhip_extract(ex.h, padded.ctypes.data_as(C.c_void_p), w + 37, kps.ctypes.data_as(C.c_void_p), desc.ctypes.data_as(C.c_void_p), cap, C.byref(nout))
+    assert st == 0
+    _same(kps[:nout.value], desc[:nout.value], ks[2], ds[2])
+    # too-small caller buffer: ORBHIP_ERR_CAPACITY, n_out still reports the true count
+    st = ex.L.orbhip_extract(ex.h, padded.ctypes.data_as(C.c_void_p), w + 37, kps.ctypes.data_as(C.c_void_p), desc.ctypes.data_as(C.c_void_p), 10, C.byref(nout))
+    assert st == 3 and nout.value == len(ks[2])
+    ex.close()
+
+
+def test_unsupported_and_invalid_configs(backend):
+    with pytest.raises(orb_slam2_amd.OrbHipError):
+        orb_slam2_amd.ORBextractor(500, 1.2, 8, 20, 7, 200, 120, library=backend)     # top level < 62 px: the reference itself divides by zero
+    with pytest.raises(orb_slam2_amd.OrbHipError):
+        orb_slam2_amd.ORBextractor(500, 1.2, 4, 20, 7, 240, 640, library=backend)     # portrait: zero quadtree roots (ORBextractor.cc:543)
+    with pytest.raises(orb_slam2_amd.OrbHipError):
+        orb_slam2_amd.ORBextractor(500, 1.0, 8, 20, 7, 640, 480, library=backend)     # scale factor must exceed 1
+
+
+def test_golden_fixture(backend):
+    """Committed golden vectors (tests/golden/): the HIP path reproduces them without the oracle library present."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "extract_320x240_n300_seed21.npz"))
+    ex = orb_slam2_amd.ORBextractor(300, 1.2, 8, 20, 7, 320, 240, library=backend)
+    k, d = ex(g["image"])
+    assert k.tobytes() == g["keypoints"].tobytes() and np.array_equal(d, g["descriptors"])
+    ex.close()
