@@ -40,6 +40,7 @@ struct orbhip_ctx {
     std::vector<CellDesc> cells; std::vector<TileDesc> blur_tiles; std::vector<int2> xtab, ytab;
     int gk[4] = {0, 0, 0, 0};
     hipStream_t stream = nullptr; bool own_stream = false;
+    int fc_maxpw = 0, fc_maxph = 0;
     long long plane_frame_bytes = 0, cand_slots_per_frame = 0, qt_per_frame = 0; int lvl_kp_per_frame = 0, out_cap = 0, qt_maxn = 0, qt_maxcells = 0, lvl0_cap = 0;
     // device
     LevelGeom* d_geom = nullptr; CellDesc* d_cells = nullptr; TileDesc* d_tiles = nullptr; int2* d_xtab = nullptr; int2* d_ytab = nullptr; signed char* d_pattern = nullptr;
@@ -196,6 +197,7 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
                 cd.shiftX = (short)(j * g.wCell); cd.shiftY = (short)(i * g.hCell);
                 const int cw = std::max((int)maxX - (int)iniX - 6, 0), ch = std::max((int)maxY - (int)iniY - 6, 0);
                 cd.cand_cap = cd.skipped ? 0 : ((cw + 1) / 2) * ((ch + 1) / 2);       // strict 3x3 maxima are never 8-adjacent
+                if (!cd.skipped) { c->fc_maxpw = std::max(c->fc_maxpw, (int)maxX - (int)iniX); c->fc_maxph = std::max(c->fc_maxph, (int)maxY - (int)iniY); }
                 cd.cand_idx = (int)cand_off; cand_off += cd.cand_cap;
                 c->cells.push_back(cd);
             }
@@ -213,13 +215,13 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
             g.xtab_off = (int)c->xtab.size(); build_resize_table(g.src_w, g.w, c->xtab);
             g.ytab_off = (int)c->ytab.size(); build_yresize_table(g.src_h, g.h, c->ytab);
         }
-        for (int y0 = 0; y0 < g.h; y0 += 16) for (int x0 = 0; x0 < g.w; x0 += 64) { TileDesc t; t.level = (short)l; t.x0 = (short)x0; t.y0 = (short)y0; t.pad = 0; c->blur_tiles.push_back(t); }
+        for (int y0 = 0; y0 < g.h; y0 += 32) for (int x0 = 0; x0 < g.w; x0 += 128) { TileDesc t; t.level = (short)l; t.x0 = (short)x0; t.y0 = (short)y0; t.pad = 0; c->blur_tiles.push_back(t); }
     }
     c->plane_frame_bytes = (plane_off + 255) & ~255LL; c->cand_slots_per_frame = cand_off; c->qt_per_frame = cand_off;
     c->lvl_kp_per_frame = kp_off; c->out_cap = kp_off; c->lvl0_cap = c->geom[0].kp_cap;
     if (cand_off >= (1 << 24)) { delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "too many candidate slots"); }
     if (orbhip_quadtree_lds_bytes(c->qt_maxn, c->qt_maxcells) > 150 * 1024) { delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "nfeatures too large for the LDS quadtree (%d nodes)", c->qt_maxn); }
-    if ((size_t)(2 * c->out_cap + 2 * c->lvl0_cap + 64) * sizeof(int) > 150 * 1024) { delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "nfeatures too large for the LDS matcher"); }
+    if ((size_t)(2 * c->out_cap + 3 * c->lvl0_cap + 64) * sizeof(int) > 150 * 1024) { delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "nfeatures too large for the LDS matcher"); }
 
     // ---- device
     if (cfg->stream) c->stream = (hipStream_t)cfg->stream;
@@ -279,6 +281,8 @@ static ExtractParams make_params(orbhip_ctx* c, const uint8_t* d_img0, long long
     P.xtab = c->d_xtab; P.ytab = c->d_ytab; P.pattern = c->d_pattern;
     P.iniTh = c->cfg.ini_th_fast; P.minTh = c->cfg.min_th_fast; P.blur_round_mode = c->cfg.blur_round_mode;
     P.qt_maxn = c->qt_maxn; P.qt_maxcells = c->qt_maxcells;
+    P.fc_pstride = (c->fc_maxpw + 4 + 3) & ~3; P.fc_prows = c->fc_maxph; P.fc_sstride = std::max(c->fc_maxpw - 6, 0) + 2; P.fc_srows = std::max(c->fc_maxph - 6, 0) + 2;
+    P.fc_listcap = std::max(c->fc_maxpw - 6, 0) * std::max(c->fc_maxph - 6, 0);
     return P;
 }
 
@@ -537,7 +541,7 @@ extern "C" orbhip_status orbhip_search_for_initialization(int device, const orbh
     std::vector<int> list1; for (int i = 0; i < n1; i++) if (kps1[i].octave <= 0) list1.push_back(i);
     int n2l0 = 0; for (int i = 0; i < n2; i++) n2l0 += kps2[i].octave == 0;
     const int cap = std::max(std::max(n1, n2), 1), l0cap = std::max((int)list1.size(), 1), cstride = std::max(n2l0, 1);
-    if ((size_t)(2 * cap + 2 * l0cap + 64) * sizeof(int) > 150 * 1024) return fail(ORBHIP_ERR_UNSUPPORTED, "too many keypoints for the LDS matcher");
+    if ((size_t)(2 * cap + 3 * l0cap + 64) * sizeof(int) > 150 * 1024) return fail(ORBHIP_ERR_UNSUPPORTED, "too many keypoints for the LDS matcher");
     orbhip_keypoint *dk1 = nullptr, *dk2 = nullptr; uint8_t *dd1 = nullptr, *dd2 = nullptr; int *dn = nullptr, *dlist = nullptr, *dgs = nullptr, *dgi = nullptr, *dnc = nullptr, *dm12 = nullptr;
     unsigned* dcand = nullptr; float* dprev = nullptr;
     hipError_t e = hipSuccess;

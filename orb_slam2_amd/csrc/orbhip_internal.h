@@ -65,6 +65,7 @@ struct ExtractParams {
     int iniTh, minTh, blur_round_mode;
     int qt_maxn;                                                           // LDS node capacity of the quadtree kernel
     int qt_maxcells;                                                       // max cells of one level
+    int fc_pstride, fc_prows, fc_sstride, fc_srows, fc_listcap;            // per-wave LDS layout of k_fast_cells (largest cell of the context)
 };
 
 struct MatchParams {        // SearchForInitialization over camera slots (ORBmatcher.cc:405-520)

@@ -67,55 +67,78 @@ void orbhip_launch_pyramid_level(const ExtractParams& P, int level, int w, int h
 // ------------------------------------------------------------------------------------------------ blur
 // cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) on 8U: int kernel {k3,k2,k1,k0,k1,k2,k3} = {18,34,49,55,49,34,18}
 // (computed on the host from getGaussianKernel + cvRound(k*256)), int32 row pass, column pass rounded with 16 bits.
-#define BLUR_TW 64
-#define BLUR_TH 16
+#define BLUR_TW 128
+#define BLUR_TH 32
+#define BLUR_SROW 144                  // LDS source row stride in bytes (136 used: x0-4 .. x0+131)
 __device__ __forceinline__ int reflect101_clamped(int p, int len)
 {
     if (p < 0) p = -p; else if (p >= len) p = 2 * (len - 1) - p;
     return min(max(p, 0), len - 1);      // second clamp only touches halo positions no output reads
 }
 struct BlurK { int k0, k1, k2, k3; };
+// 128x32 outputs per workgroup.  Stage (32+6) x (128+8) source bytes with 32-bit loads (byte-wise reflect only at the
+// image border), horizontal pass -> packed u16 sums in LDS, vertical pass: one 4-pixel x 4-row strip per thread,
+// 4 coalesced 32-bit stores.
 __global__ __launch_bounds__(256) void k_blur(ExtractParams P, BlurK K)
 {
     const TileDesc t = P.blur_tiles[blockIdx.x];
     const int frame = blockIdx.y, tid = threadIdx.x;
     const LevelGeom g = P.geom[t.level];
     int spitch; const uint8_t* src = level_src(P, frame, t.level, spitch);
-    __shared__ uint8_t s_src[BLUR_TH + 6][BLUR_TW + 8];
-    __shared__ unsigned short s_h[BLUR_TH + 6][BLUR_TW];
-    for (int i = tid; i < (BLUR_TH + 6) * (BLUR_TW + 6); i += 256) {
-        const int r = i / (BLUR_TW + 6), c = i - r * (BLUR_TW + 6);
-        const int sy = reflect101_clamped(t.y0 - 3 + r, g.h), sx = reflect101_clamped(t.x0 - 3 + c, g.w);
-        s_src[r][c] = src[(long long)sy * spitch + sx];
+    __shared__ unsigned s_src[(BLUR_TH + 6) * (BLUR_SROW / 4)];
+    __shared__ uint2 s_h[(BLUR_TH + 6) * (BLUR_TW / 4)];
+    const bool aligned = ((((unsigned long long)src) | (unsigned long long)spitch) & 3ull) == 0;
+    for (int i = tid; i < (BLUR_TH + 6) * 34; i += 256) {
+        const int r = i / 34, d = i - r * 34;
+        const int gy = reflect101_clamped(t.y0 - 3 + r, g.h), gx = t.x0 - 4 + 4 * d;
+        const uint8_t* row = src + (long long)gy * spitch;
+        unsigned v;
+        if (aligned && gx >= 0 && gx + 3 < g.w) v = *reinterpret_cast<const unsigned*>(row + gx);
+        else v = (unsigned)row[reflect101_clamped(gx, g.w)] | ((unsigned)row[reflect101_clamped(gx + 1, g.w)] << 8) |
+                 ((unsigned)row[reflect101_clamped(gx + 2, g.w)] << 16) | ((unsigned)row[reflect101_clamped(gx + 3, g.w)] << 24);
+        s_src[r * (BLUR_SROW / 4) + d] = v;
     }
     __syncthreads();
-    for (int i = tid; i < (BLUR_TH + 6) * BLUR_TW; i += 256) {
-        const int r = i >> 6, c = i & 63;
-        const uint8_t* p = &s_src[r][c];
-        const int sum = K.k3 * (p[0] + p[6]) + K.k2 * (p[1] + p[5]) + K.k1 * (p[2] + p[4]) + K.k0 * p[3];
-        s_h[r][c] = (unsigned short)sum;            // <= 255 * 257 = 65535
-    }
-    __syncthreads();
-    const int x = (tid & 15) * 4, y = tid >> 4;
-    const int gx = t.x0 + x, gy = t.y0 + y;
-    if (gy >= g.h || gx >= g.w) return;
-    const int wv = g.w & ~3;
-    unsigned out = 0;
+    for (int i = tid; i < (BLUR_TH + 6) * 32; i += 256) {
+        const int r = i >> 5, q = i & 31;
+        const unsigned* p = &s_src[r * (BLUR_SROW / 4) + q];
+        const unsigned w0 = p[0], w1 = p[1], w2 = p[2];
+        int b[12];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int c = x + k;
-        const int sum = K.k3 * ((int)s_h[y][c] + s_h[y + 6][c]) + K.k2 * ((int)s_h[y + 1][c] + s_h[y + 5][c]) +
-                        K.k1 * ((int)s_h[y + 2][c] + s_h[y + 4][c]) + K.k0 * (int)s_h[y + 3][c];
-        int v;
-        if (P.blur_round_mode == 1 && (gx + k) < wv) {   // x86 SSE2 build of OpenCV: round-half-even via cvtps2dq
-            v = sum >> 16; const int rem = sum & 0xFFFF;
-            if (rem > 0x8000 || (rem == 0x8000 && (v & 1))) v++;
-        } else v = (sum + (1 << 15)) >> 16;              // generic FixedPtCastEx
-        v = min(v, 255);
-        out |= (unsigned)v << (8 * k);
+        for (int k = 0; k < 4; k++) { b[k] = (w0 >> (8 * k)) & 0xff; b[4 + k] = (w1 >> (8 * k)) & 0xff; b[8 + k] = (w2 >> (8 * k)) & 0xff; }
+        unsigned hs[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)      // output pixel x0+4q+k reads tile bytes 4q+k+1 .. 4q+k+7; sum <= 255*257 = 65535
+            hs[k] = K.k3 * (b[k + 1] + b[k + 7]) + K.k2 * (b[k + 2] + b[k + 6]) + K.k1 * (b[k + 3] + b[k + 5]) + K.k0 * b[k + 4];
+        uint2 o; o.x = hs[0] | (hs[1] << 16); o.y = hs[2] | (hs[3] << 16);
+        s_h[r * (BLUR_TW / 4) + q] = o;
     }
-    uint8_t* dst = P.blur + (long long)frame * P.plane_frame_bytes + g.plane_off + (long long)gy * g.pitch + gx;
-    *reinterpret_cast<unsigned*>(dst) = out;             // pitch is a multiple of 64, gx of 4: pad bytes absorb the tail
+    __syncthreads();
+    const int q = tid & 31, rg = tid >> 5;
+    const int gx = t.x0 + 4 * q;
+    if (gx >= g.w) return;
+    int h[10][4];
+#pragma unroll
+    for (int r = 0; r < 10; r++) { const uint2 v = s_h[(4 * rg + r) * (BLUR_TW / 4) + q]; h[r][0] = v.x & 0xffff; h[r][1] = v.x >> 16; h[r][2] = v.y & 0xffff; h[r][3] = v.y >> 16; }
+    const int wv = g.w & ~3;
+    uint8_t* dstbase = P.blur + (long long)frame * P.plane_frame_bytes + g.plane_off + gx;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int gy = t.y0 + 4 * rg + r;
+        if (gy >= g.h) break;
+        unsigned out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int sum = K.k3 * (h[r][k] + h[r + 6][k]) + K.k2 * (h[r + 1][k] + h[r + 5][k]) + K.k1 * (h[r + 2][k] + h[r + 4][k]) + K.k0 * h[r + 3][k];
+            int v;
+            if (P.blur_round_mode == 1 && (gx + k) < wv) {   // x86 SSE2 build of OpenCV: round-half-even via cvtps2dq
+                v = sum >> 16; const int rem = sum & 0xFFFF;
+                if (rem > 0x8000 || (rem == 0x8000 && (v & 1))) v++;
+            } else v = (sum + (1 << 15)) >> 16;              // generic FixedPtCastEx
+            out |= (unsigned)min(v, 255) << (8 * k);
+        }
+        *reinterpret_cast<unsigned*>(dstbase + (long long)gy * g.pitch) = out;   // pitch multiple of 64, gx of 4: pad bytes absorb the tail
+    }
 }
 
 void orbhip_launch_blur(const ExtractParams& P, const int gk[4], int nframes, hipStream_t s)
@@ -125,27 +148,47 @@ void orbhip_launch_blur(const ExtractParams& P, const int gk[4], int nframes, hi
 }
 
 // ------------------------------------------------------------------------------------------------ FAST per cell
-// One wavefront per 30-px grid cell (4 cells per workgroup).  The cell's sub-image (<= 65x65) is staged in LDS,
-// every examined pixel gets its intrinsic FAST-9/16 score
-//     S = max over the 16 nine-pixel arcs of min |centre - ring| margin (dark or bright)  - 1      (cornerScore<16>)
-// which satisfies "corner at threshold t  <=>  S >= t", so ONE score pass serves both cv::FAST calls of the
-// reference (iniThFAST, then minThFAST if the first returned nothing).  3x3 non-max suppression sees only scores of
-// the same cell (neighbours outside the examined interior count as 0, exactly like FAST on the cell sub-image);
-// survivors are emitted in row-major order with ballot/popcount ranks.
+// One wavefront per 30-px grid cell (4 cells per workgroup).  The cell's sub-image is staged in LDS, then
+//   A. every examined pixel gets the exact FAST-9/16 segment test at minThFAST as two 16-bit ring masks
+//      (darker / brighter) and a "9 consecutive bits" check; corners are compacted into an LDS list with
+//      ballot/popcount ranks, in row-major order;
+//   B. only the listed corners get the intrinsic score
+//        S = max over the 16 nine-pixel arcs of min |centre - ring| margin (dark or bright) - 1     (cornerScore<16>)
+//      which satisfies "corner at threshold t  <=>  S >= t", so ONE pass serves both cv::FAST calls of the
+//      reference (iniThFAST, then minThFAST if the first returned nothing);
+//   C. 3x3 non-max suppression over the list; it sees only scores of the same cell (neighbours outside the examined
+//      interior count as 0, exactly like FAST on the cell sub-image);
+//   D. survivors are emitted in row-major order.
 #define FC_WAVES 4
-#define FC_PSTRIDE 68      // LDS patch row stride (bytes), sub-image width <= 65
-#define FC_PROWS 66
-#define FC_SSTRIDE 64      // score row stride: interior width <= 59, +2 ring
-#define FC_SROWS 62
 
+__device__ __forceinline__ void fast_ring(const uint8_t* c, int ps, int r[16])
+{
+    r[0] = c[3 * ps];       r[1] = c[3 * ps + 1];   r[2] = c[2 * ps + 2];   r[3] = c[ps + 3];
+    r[4] = c[3];            r[5] = c[-ps + 3];      r[6] = c[-2 * ps + 2];  r[7] = c[-3 * ps + 1];
+    r[8] = c[-3 * ps];      r[9] = c[-3 * ps - 1];  r[10] = c[-2 * ps - 2]; r[11] = c[-ps - 3];
+    r[12] = c[-3];          r[13] = c[ps - 3];      r[14] = c[2 * ps - 2];  r[15] = c[3 * ps - 1];
+}
+__device__ __forceinline__ bool has9(unsigned m)        // 16-bit circular mask contains 9 consecutive ones
+{
+    m |= m << 16;
+    unsigned a = m & (m >> 1); a &= a >> 2; a &= a >> 4; a &= m >> 8;
+    return (a & 0xffffu) != 0;
+}
+__device__ __forceinline__ bool fast_is_corner(const uint8_t* c, int ps, int t)
+{
+    int r[16]; fast_ring(c, ps, r);
+    const int lo = (int)c[0] - t, hi = (int)c[0] + t;
+    unsigned dm = 0, bm = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { dm |= (unsigned)(r[k] < lo) << k; bm |= (unsigned)(r[k] > hi) << k; }
+    return has9(dm) || has9(bm);
+}
 __device__ __forceinline__ int fast_score16(const uint8_t* c, int ps)
 {
+    int d[16]; fast_ring(c, ps, d);
     const int v = c[0];
-    int d[16];
-    d[0] = v - c[3 * ps];          d[1] = v - c[3 * ps + 1];    d[2] = v - c[2 * ps + 2];    d[3] = v - c[ps + 3];
-    d[4] = v - c[3];               d[5] = v - c[-ps + 3];       d[6] = v - c[-2 * ps + 2];   d[7] = v - c[-3 * ps + 1];
-    d[8] = v - c[-3 * ps];         d[9] = v - c[-3 * ps - 1];   d[10] = v - c[-2 * ps - 2];  d[11] = v - c[-ps - 3];
-    d[12] = v - c[-3];             d[13] = v - c[ps - 3];       d[14] = v - c[2 * ps - 2];   d[15] = v - c[3 * ps - 1];
+#pragma unroll
+    for (int i = 0; i < 16; i++) d[i] = v - d[i];
     int lo2[16], hi2[16], lo4[16], hi4[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) { lo2[i] = min(d[i], d[(i + 1) & 15]); hi2[i] = max(d[i], d[(i + 1) & 15]); }
@@ -161,10 +204,14 @@ __device__ __forceinline__ int fast_score16(const uint8_t* c, int ps)
     return max(best_dark, -best_bright) - 1;
 }
 
+__host__ __device__ __forceinline__ int fc_wave_bytes(int pstride, int prows, int sstride, int srows, int listcap)
+{
+    return ((pstride * prows + 15) & ~15) + ((sstride * srows + 15) & ~15) + ((2 * listcap + 15) & ~15);
+}
+
 __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
 {
-    __shared__ uint8_t s_patch[FC_WAVES][FC_PROWS * FC_PSTRIDE];
-    __shared__ uint8_t s_score[FC_WAVES][FC_SROWS * FC_SSTRIDE];
+    HIP_DYNAMIC_SHARED(uint8_t, fc_lds)
     __shared__ unsigned long long s_mini[FC_WAVES][64], s_mmin[FC_WAVES][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, frame = blockIdx.y;
     const int cell_id = blockIdx.x * FC_WAVES + wave;
@@ -174,60 +221,87 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
     const int pw = cd.maxX - cd.iniX, ph = cd.maxY - cd.iniY;       // sub-image
     const int cw = pw - 6, ch = ph - 6;                              // examined interior (rows/cols 3 .. n-4)
     const bool work = active && !cd.skipped && cw > 0 && ch > 0;
-    uint8_t* patch = s_patch[wave]; uint8_t* score = s_score[wave];
+    const int PS = P.fc_pstride, SS = P.fc_sstride;
+    uint8_t* wbase = fc_lds + wave * fc_wave_bytes(PS, P.fc_prows, SS, P.fc_srows, P.fc_listcap);
+    uint8_t* patch = wbase;
+    uint8_t* score = wbase + ((PS * P.fc_prows + 15) & ~15);
+    unsigned short* list = reinterpret_cast<unsigned short*>(score + ((SS * P.fc_srows + 15) & ~15));
     if (work) {
         int spitch; const uint8_t* src = level_src(P, frame, cd.level, spitch);
         src += (long long)cd.iniY * spitch + cd.iniX;
-        int r = 0, c = lane;
-        while (c >= pw) { c -= pw; r++; }
-        while (r < ph) {
-            patch[r * FC_PSTRIDE + c] = src[(long long)r * spitch + c];
-            c += 64; while (c >= pw) { c -= pw; r++; }
+        if (((((unsigned long long)src - cd.iniX) | (unsigned long long)spitch) & 3ull) == 0) {
+            const int shift = cd.iniX & 3, nd = (shift + pw + 3) >> 2;      // aligned 32-bit loads, uniform byte shift per row
+            int r = 0, d = lane;
+            while (d >= nd) { d -= nd; r++; }
+            while (r < ph) {
+                *reinterpret_cast<unsigned*>(patch + r * PS + 4 * d) = *reinterpret_cast<const unsigned*>(src - shift + (long long)r * spitch + 4 * d);
+                d += 64; while (d >= nd) { d -= nd; r++; }
+            }
+            patch += shift;
+        } else {
+            int r = 0, c = lane;
+            while (c >= pw) { c -= pw; r++; }
+            while (r < ph) {
+                patch[r * PS + c] = src[(long long)r * spitch + c];
+                c += 64; while (c >= pw) { c -= pw; r++; }
+            }
         }
-        for (int i = lane; i < (ch + 2) * FC_SSTRIDE; i += 64) score[i] = 0;
+        for (int i = lane; i < (((ch + 2) * SS + 3) >> 2); i += 64) reinterpret_cast<unsigned*>(score)[i] = 0;
     }
     __syncthreads();
+    // ---- A. segment test + compaction
     const int rp = work ? 64 / cw : 1;                                // interior rows handled per wave iteration
     const int sr = work ? lane / cw : 0, sx = work ? lane - sr * cw : 0;
     const int iters = work ? (ch + rp - 1) / rp : 0;
     const bool lane_ok = work && sr < rp;
+    int ncorn = 0;
     for (int it = 0; it < iters; it++) {
         const int y = it * rp + sr;
-        if (lane_ok && y < ch) {
-            int sc = fast_score16(&patch[(y + 3) * FC_PSTRIDE + sx + 3], FC_PSTRIDE);
-            if (sc < P.minTh) sc = 0;
-            score[(y + 1) * FC_SSTRIDE + sx + 1] = (uint8_t)sc;     // sc <= 254
-        }
+        const bool corner = lane_ok && y < ch && fast_is_corner(&patch[(y + 3) * PS + sx + 3], PS, P.minTh);
+        const unsigned long long m = __ballot(corner);
+        if (corner) list[ncorn + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)((y << 8) | sx);
+        ncorn += __popcll(m);
     }
     __syncthreads();
+    // ---- B. scores of the corners
+    for (int i = lane; i < ncorn; i += 64) {
+        const int id = list[i], y = id >> 8, x = id & 0xff;
+        const int sc = fast_score16(&patch[(y + 3) * PS + x + 3], PS);
+        score[(y + 1) * SS + x + 1] = (uint8_t)min(max(sc, 0), 255);      // corner at minTh => minTh <= sc <= 254
+    }
+    __syncthreads();
+    // ---- C. non-max suppression inside the cell
     int count_ini = 0, count_min = 0;
-    for (int it = 0; it < iters; it++) {
-        const int y = it * rp + sr;
+    const int nchunks = (ncorn + 63) >> 6;
+    for (int cb = 0; cb < nchunks; cb++) {
+        const int i = cb * 64 + lane;
         bool keep = false; int sc = 0;
-        if (lane_ok && y < ch) {
-            const uint8_t* q = &score[(y + 1) * FC_SSTRIDE + sx + 1];
+        if (i < ncorn) {
+            const int id = list[i];
+            const uint8_t* q = &score[((id >> 8) + 1) * SS + (id & 0xff) + 1];
             sc = q[0];
-            keep = sc > 0 && sc > q[-1] && sc > q[1] && sc > q[-FC_SSTRIDE - 1] && sc > q[-FC_SSTRIDE] && sc > q[-FC_SSTRIDE + 1] &&
-                   sc > q[FC_SSTRIDE - 1] && sc > q[FC_SSTRIDE] && sc > q[FC_SSTRIDE + 1];
+            keep = sc > 0 && sc > q[-1] && sc > q[1] && sc > q[-SS - 1] && sc > q[-SS] && sc > q[-SS + 1] &&
+                   sc > q[SS - 1] && sc > q[SS] && sc > q[SS + 1];
         }
         const unsigned long long mmin = __ballot(keep), mini = __ballot(keep && sc >= P.iniTh);
-        if (lane == 0) { s_mmin[wave][it] = mmin; s_mini[wave][it] = mini; }
+        if (lane == 0) { s_mmin[wave][cb] = mmin; s_mini[wave][cb] = mini; }
         count_min += __popcll(mmin); count_ini += __popcll(mini);
     }
     __syncthreads();
     if (!active) return;
+    // ---- D. emission
     const bool use_ini = count_ini > 0;                               // vKeysCell.empty() after the iniThFAST call?
     const int total = use_ini ? count_ini : count_min;
     int base = 0;
     unsigned* out = P.cell_cand + (long long)frame * P.cand_slots_per_frame + cd.cand_idx;
-    for (int it = 0; it < iters; it++) {
-        const unsigned long long m = use_ini ? s_mini[wave][it] : s_mmin[wave][it];
+    for (int cb = 0; cb < nchunks; cb++) {
+        const unsigned long long m = use_ini ? s_mini[wave][cb] : s_mmin[wave][cb];
         if ((m >> lane) & 1ull) {
-            const int y = it * rp + sr;
+            const int id = list[cb * 64 + lane], y = id >> 8, x = id & 0xff;
             const int rank = base + __popcll(m & ((1ull << lane) - 1ull));
-            const int sc = score[(y + 1) * FC_SSTRIDE + sx + 1];
+            const int sc = score[(y + 1) * SS + x + 1];
             // FAST reports cell-local (x, y); the reference adds (j*wCell, i*hCell)  (ORBextractor.cc:822-823)
-            const unsigned px = (unsigned)(sx + 3 + cd.shiftX), py = (unsigned)(y + 3 + cd.shiftY);
+            const unsigned px = (unsigned)(x + 3 + cd.shiftX), py = (unsigned)(y + 3 + cd.shiftY);
             if (rank < cd.cand_cap) out[rank] = px | (py << 12) | ((unsigned)sc << 24);
         }
         base += __popcll(m);
@@ -237,7 +311,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
 
 void orbhip_launch_fast_cells(const ExtractParams& P, int nframes, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_fast_cells, dim3((P.ncells_total + FC_WAVES - 1) / FC_WAVES, nframes, 1), dim3(256, 1, 1), 0, s, P);
+    const size_t lds = (size_t)FC_WAVES * fc_wave_bytes(P.fc_pstride, P.fc_prows, P.fc_sstride, P.fc_srows, P.fc_listcap);
+    hipLaunchKernelGGL(k_fast_cells, dim3((P.ncells_total + FC_WAVES - 1) / FC_WAVES, nframes, 1), dim3(256, 1, 1), lds, s, P);
 }
 
 // ------------------------------------------------------------------------------------------------ quadtree

@@ -217,11 +217,13 @@ void orbhip_launch_match_candidates(const MatchParams& M, int nslots, hipStream_
 }
 
 // ------------------------------------------------------------------------------------------------ select
-__device__ __forceinline__ int wave_min_i(int v)
+// Lanes holding the minimum of a 9-bit key (0..256) among the lanes of `M`: MSB-first elimination with ballots
+// (v_cmp + scalar mask ops, no cross-lane data movement).
+__device__ __forceinline__ unsigned long long wave_argmin_mask(int d, unsigned long long M)
 {
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = min(v, __shfl_xor(v, off));
-    return v;
+    for (int b = 8; b >= 0; b--) { const unsigned long long z = __ballot(((d >> b) & 1) == 0) & M; if (z) M = z; }
+    return M;
 }
 
 __global__ __launch_bounds__(64) void k_match_select(MatchParams M)
@@ -235,32 +237,40 @@ __global__ __launch_bounds__(64) void k_match_select(MatchParams M)
     int* s_m21 = s_md + M.cap;              // vnMatches21[i2]
     int* s_m12 = s_m21 + M.cap;             // vnMatches12[i1] for level-0 i1
     int* s_bin = s_m12 + M.lvl0_cap;        // rotation bin of the accepted match of i1, -1 = none
-    int* s_hist = s_bin + M.lvl0_cap;       // [HISTO_LENGTH] + misc
+    int* s_nc = s_bin + M.lvl0_cap;         // candidate count per level-0 i1
+    int* s_hist = s_nc + M.lvl0_cap;        // [HISTO_LENGTH] + misc
     const orbhip_keypoint* kp1 = M.kp1 + (long long)slot * M.cap;
     const orbhip_keypoint* kp2 = M.kp2 + (long long)slot * M.cap;
     int* m12 = M.matches12 + (long long)slot * M.cap;
     float* prev = M.prev + (long long)slot * M.cap * 2;
     for (int i = lane; i < n2; i += 64) { s_md[i] = IMAX; s_m21[i] = -1; }
-    for (int i = lane; i < n1l; i += 64) { s_m12[i] = -1; s_bin[i] = -1; }
+    for (int i = lane; i < n1l; i += 64) { s_m12[i] = -1; s_bin[i] = -1; s_nc[i] = M.ncand[(long long)slot * M.lvl0_cap + i]; }
     for (int i = lane; i < ORBHIP_HISTO_LENGTH + 8; i += 64) s_hist[i] = 0;
     for (int i = lane; i < n1; i += 64) { m12[i] = -1; if (M.prev_from_kp1) { prev[2 * i] = kp1[i].x; prev[2 * i + 1] = kp1[i].y; } }
     __syncthreads();
     const float factor = 1.0f / ORBHIP_HISTO_LENGTH;
+    const unsigned* cand0 = M.cand + (long long)slot * M.lvl0_cap * M.cand_stride;
+    unsigned e_next = (n1l > 0 && lane < s_nc[0]) ? cand0[lane] : 0u;          // software prefetch of the next keypoint's first chunk
     for (int j1 = 0; j1 < n1l; j1++) {
-        const int nc = M.ncand[(long long)slot * M.lvl0_cap + j1];
+        const int nc = s_nc[j1];
+        const unsigned* cand = cand0 + (long long)j1 * M.cand_stride;
+        unsigned e = e_next;
+        if (j1 + 1 < n1l) e_next = (lane < s_nc[j1 + 1]) ? cand[M.cand_stride + lane] : 0u;
         if (nc == 0) continue;
-        const unsigned* cand = M.cand + ((long long)slot * M.lvl0_cap + j1) * M.cand_stride;
         int best = IMAX, second = IMAX, bidx = -1;
         for (int cb = 0; cb < nc; cb += 64) {
             const int t = cb + lane;
-            int d = IMAX, i2 = 0;
-            if (t < nc) { const unsigned e = cand[t]; i2 = (int)(e & 0xFFFFFu); const int dist = (int)(e >> 20); if (!(s_md[i2] <= dist)) d = dist; }   // :444-445
-            const int wmin = wave_min_i(d);
-            if (wmin == IMAX) continue;
-            const unsigned long long mk = __ballot(d == wmin);
+            if (cb > 0) e = (t < nc) ? cand[t] : 0u;
+            const int i2 = (int)(e & 0xFFFFFu), dist = (int)(e >> 20);
+            const bool valid = t < nc && !(s_md[i2] <= dist);                    // :444-445
+            const unsigned long long V = __ballot(valid);
+            if (V == 0) continue;
+            const unsigned long long mk = wave_argmin_mask(dist, V);
             const int first = __ffsll((long long)mk) - 1;        // strict '<': the first candidate with the minimum wins (:447-452)
-            const int ci = __shfl(i2, first);
-            const int wsec = wave_min_i(lane == first ? IMAX : d);
+            const int wmin = __shfl(dist, first), ci = __shfl(i2, first);
+            const unsigned long long V2 = V & ~(1ull << first);
+            int wsec = IMAX;
+            if (V2) { const unsigned long long mk2 = wave_argmin_mask(dist, V2); wsec = __shfl(dist, __ffsll((long long)mk2) - 1); }
             if (wmin < best) { second = min(best, wsec); best = wmin; bidx = ci; } else second = min(second, wmin);
         }
         if (best <= ORBHIP_TH_LOW && (float)best < __fmul_rn((float)second, M.nnratio)) {      // :459-461
@@ -312,6 +322,6 @@ __global__ __launch_bounds__(64) void k_match_select(MatchParams M)
 
 void orbhip_launch_match_select(const MatchParams& M, int nslots, hipStream_t s)
 {
-    const size_t lds = sizeof(int) * ((size_t)2 * M.cap + (size_t)2 * M.lvl0_cap + ORBHIP_HISTO_LENGTH + 8);
+    const size_t lds = sizeof(int) * ((size_t)2 * M.cap + (size_t)3 * M.lvl0_cap + ORBHIP_HISTO_LENGTH + 8);
     hipLaunchKernelGGL(k_match_select, dim3(nslots, 1, 1), dim3(64, 1, 1), lds, s, M);
 }
