@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="camera slots (frames) per step per GPU")
     ap.add_argument("--tsteps", type=int, default=4, help="distinct resident time steps cycled through")
+    ap.add_argument("--streams", type=int, default=4, help="HIP streams the library splits each batch over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -112,7 +113,7 @@ def main():
     host_frames = make_frames(B, T, pitch, rank)
     d_frames = torch.from_numpy(host_frames).to(f"cuda:{local_rank}")          # inputs resident in HBM before timing
     torch.cuda.synchronize()
-    ex = orb_slam2_amd.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, W, H, max_batch=B, device=local_rank)
+    ex = orb_slam2_amd.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, W, H, max_batch=B, device=local_rank, num_streams=args.streams)
     frame_stride, step_stride = H * pitch, B * H * pitch
     base = d_frames.data_ptr()
 
@@ -170,7 +171,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "KITTI-shaped 1241x376 u8, 2000 features, 8 levels, scale 1.2, FAST 20/7, extract + SearchForInitialization(win 100, nnratio 0.9)",
-                       "frames_per_step_per_gpu": B, "resident_time_steps": T, "row_pitch": pitch, "parallelism": f"frames sharded over {world} GPU(s), no collective"},
+                       "frames_per_step_per_gpu": B, "resident_time_steps": T, "row_pitch": pitch, "streams_per_gpu": args.streams, "parallelism": f"frames sharded over {world} GPU(s), no collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "alg_bytes_per_launch": alg * B, "launch_ms": round(kern[dom]["ms_per_launch"], 4), "note": note},

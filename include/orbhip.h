@@ -57,6 +57,8 @@ typedef struct {
     int32_t device;           /* HIP device ordinal */
     void* stream;             /* hipStream_t to run on; NULL = the context creates its own stream */
     int32_t blur_round_mode;  /* 0 = OpenCV generic C++ rounding (default), 1 = x86 SSE2 build rounding; DESIGN.md */
+    int32_t num_streams;      /* >1: a batched call is split into this many groups of camera slots, each enqueued on its own HIP
+                                 stream so latency-bound kernels of one group overlap throughput kernels of another; 0/1 = one stream */
 } orbhip_config;
 
 const char* orbhip_version(void);

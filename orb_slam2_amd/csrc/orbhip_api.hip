@@ -40,6 +40,7 @@ struct orbhip_ctx {
     std::vector<CellDesc> cells; std::vector<TileDesc> blur_tiles; std::vector<int2> xtab, ytab;
     int gk[4] = {0, 0, 0, 0};
     hipStream_t stream = nullptr; bool own_stream = false;
+    std::vector<hipStream_t> xstreams; std::vector<hipEvent_t> xevents; hipEvent_t ev_fork = nullptr;     // extra streams of a multi-stream context
     int fc_maxpw = 0, fc_maxph = 0;
     long long plane_frame_bytes = 0, cand_slots_per_frame = 0, qt_per_frame = 0; int lvl_kp_per_frame = 0, out_cap = 0, qt_maxn = 0, qt_maxcells = 0, lvl0_cap = 0;
     // device
@@ -49,7 +50,7 @@ struct orbhip_ctx {
     int* d_lvl_n[2] = {nullptr, nullptr}; orbhip_keypoint* d_out_kp[2] = {nullptr, nullptr}; uint8_t* d_out_desc[2] = {nullptr, nullptr}; int* d_out_n[2] = {nullptr, nullptr};
     int cur = 0; int last_nimg = 0; bool last_matched = false; bool last_from_host = false;
     // matcher workspace
-    int* d_grid_start = nullptr; int* d_grid_items = nullptr; unsigned* d_cand = nullptr; int* d_ncand = nullptr; float* d_prev = nullptr; int* d_m12 = nullptr; int* d_nm = nullptr;
+    int* d_grid_start = nullptr; int* d_grid_items = nullptr; float2* d_grid_xy = nullptr; unsigned* d_cand = nullptr; int* d_ncand = nullptr; float* d_prev = nullptr; int* d_m12 = nullptr; int* d_nm = nullptr;
     // profiling
     bool prof = false; std::vector<ProfSpan> pending; std::vector<hipEvent_t> pool; double tot_ms[K_COUNT] = {0}; long long launches[K_COUNT] = {0};
 };
@@ -65,9 +66,9 @@ static hipEvent_t prof_event(orbhip_ctx* c)
     hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
 }
 struct ProfScope {
-    orbhip_ctx* c; int k; hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(orbhip_ctx* c_, int k_) : c(c_), k(k_) { if (c->prof) { a = prof_event(c); b = prof_event(c); (void)hipEventRecord(a, c->stream); } }
-    ~ProfScope() { if (c->prof) { (void)hipEventRecord(b, c->stream); c->pending.push_back(ProfSpan{k, a, b}); } }
+    orbhip_ctx* c; int k; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(orbhip_ctx* c_, int k_, hipStream_t s_) : c(c_), k(k_), s(s_) { if (c->prof) { a = prof_event(c); b = prof_event(c); (void)hipEventRecord(a, s); } }
+    ~ProfScope() { if (c->prof) { (void)hipEventRecord(b, s); c->pending.push_back(ProfSpan{k, a, b}); } }
 };
 static void prof_collect(orbhip_ctx* c)
 {
@@ -123,11 +124,14 @@ extern "C" void orbhip_destroy(orbhip_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto xs : c->xstreams) { (void)hipStreamSynchronize(xs); (void)hipStreamDestroy(xs); }
+    for (auto e : c->xevents) (void)hipEventDestroy(e);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     prof_collect(c);
     for (auto e : c->pool) (void)hipEventDestroy(e);
     void* ptrs[] = {c->d_geom, c->d_cells, c->d_tiles, c->d_xtab, c->d_ytab, c->d_pattern, c->d_pyr, c->d_blur, c->d_cell_count, c->d_cell_cand,
                     c->d_qt_val, c->d_qt_code, c->d_qt_node, c->d_lvl_kp, c->d_lvl_n[0], c->d_lvl_n[1], c->d_out_kp[0], c->d_out_kp[1],
-                    c->d_out_desc[0], c->d_out_desc[1], c->d_out_n[0], c->d_out_n[1], c->d_grid_start, c->d_grid_items, c->d_cand, c->d_ncand,
+                    c->d_out_desc[0], c->d_out_desc[1], c->d_out_n[0], c->d_out_n[1], c->d_grid_start, c->d_grid_items, c->d_grid_xy, c->d_cand, c->d_ncand,
                     c->d_prev, c->d_m12, c->d_nm};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -226,6 +230,12 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
     // ---- device
     if (cfg->stream) c->stream = (hipStream_t)cfg->stream;
     else { hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); if (e != hipSuccess) { delete c; return fail(ORBHIP_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); } c->own_stream = true; }
+    for (int i = 1; i < std::min(cfg->num_streams, cfg->max_batch); i++) {
+        hipStream_t xs = nullptr; hipEvent_t xe = nullptr;
+        if (hipStreamCreateWithFlags(&xs, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&xe, hipEventDisableTiming) != hipSuccess) { orbhip_destroy(c); return fail(ORBHIP_ERR_HIP, "extra stream creation failed"); }
+        c->xstreams.push_back(xs); c->xevents.push_back(xe);
+    }
+    if (!c->xstreams.empty() && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { orbhip_destroy(c); return fail(ORBHIP_ERR_HIP, "event creation failed"); }
     const size_t B = (size_t)c->B;
     std::vector<signed char> pat(kPatternHost, kPatternHost + 1024);
     hipError_t e = hipSuccess;
@@ -241,7 +251,7 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
         if (e == hipSuccess) e = hipMemset(c->d_lvl_n[k], 0, B * L * sizeof(int));
         if (e == hipSuccess) e = hipMemset(c->d_out_n[k], 0, B * sizeof(int));
     }
-    TRY(dalloc(&c->d_grid_start, B * (ORBHIP_GRID_CELLS + 1))); TRY(dalloc(&c->d_grid_items, B * c->out_cap));
+    TRY(dalloc(&c->d_grid_start, B * (ORBHIP_GRID_CELLS + 1))); TRY(dalloc(&c->d_grid_items, B * c->out_cap)); TRY(dalloc(&c->d_grid_xy, B * c->out_cap));
     TRY(dalloc(&c->d_cand, B * c->lvl0_cap * (size_t)c->lvl0_cap)); TRY(dalloc(&c->d_ncand, B * c->lvl0_cap));
     TRY(dalloc(&c->d_prev, B * c->out_cap * 2)); TRY(dalloc(&c->d_m12, B * c->out_cap)); TRY(dalloc(&c->d_nm, B));
 #undef TRY
@@ -291,27 +301,40 @@ static orbhip_status run_pipeline(orbhip_ctx* c, int nimg, const uint8_t* d_img0
 {
     HIPCHK(hipSetDevice(c->cfg.device));
     c->cur ^= 1;
-    const ExtractParams P = make_params(c, d_img0, frame_stride, row_stride);
-    { ProfScope ps(c, K_PYRAMID); for (int l = 1; l < c->L; l++) orbhip_launch_pyramid_level(P, l, c->geom[l].w, c->geom[l].h, nimg, c->stream); }
-    { ProfScope ps(c, K_FAST); orbhip_launch_fast_cells(P, nimg, c->stream); }
-    { ProfScope ps(c, K_BLUR); orbhip_launch_blur(P, c->gk, nimg, c->stream); }
-    { ProfScope ps(c, K_QUADTREE); orbhip_launch_quadtree(P, nimg, c->stream); }
-    { ProfScope ps(c, K_DESCRIBE); orbhip_launch_describe(P, nimg, c->stream); }
-    c->last_matched = false;
+    ExtractParams P = make_params(c, d_img0, frame_stride, row_stride);
+    MatchParams M; memset(&M, 0, sizeof M);
     if (match_prev) {
         const int prev = c->cur ^ 1;
-        MatchParams M; memset(&M, 0, sizeof M);
         M.kp1 = c->d_out_kp[prev]; M.desc1 = c->d_out_desc[prev]; M.n1 = c->d_out_n[prev]; M.n1_lvl0 = c->d_lvl_n[prev];
         M.kp2 = c->d_out_kp[c->cur]; M.desc2 = c->d_out_desc[c->cur]; M.n2 = c->d_out_n[c->cur];
         M.lvl_stride = c->L; M.list1 = nullptr; M.prev_from_kp1 = 1;
         M.cap = c->out_cap; M.im_w = c->cfg.width; M.im_h = c->cfg.height;
-        M.grid_start = c->d_grid_start; M.grid_items = c->d_grid_items; M.cand = c->d_cand; M.ncand = c->d_ncand; M.cand_stride = c->lvl0_cap; M.lvl0_cap = c->lvl0_cap;
+        M.grid_start = c->d_grid_start; M.grid_items = c->d_grid_items; M.grid_xy = c->d_grid_xy; M.cand = c->d_cand; M.ncand = c->d_ncand; M.cand_stride = c->lvl0_cap; M.lvl0_cap = c->lvl0_cap;
         M.prev = c->d_prev; M.matches12 = c->d_m12; M.nmatches = c->d_nm; M.window = window; M.nnratio = nnratio; M.check_ori = check_ori;
-        { ProfScope ps(c, K_MGRID); orbhip_launch_match_grid(M, nimg, c->stream); }
-        { ProfScope ps(c, K_MCAND); orbhip_launch_match_candidates(M, nimg, c->stream); }
-        { ProfScope ps(c, K_MSELECT); orbhip_launch_match_select(M, nimg, c->stream); }
-        c->last_matched = true;
     }
+    // camera slots are independent: split the batch into groups, one HIP stream each, so the latency-bound kernels of one
+    // group (quadtree, match select) overlap the throughput kernels of another (FAST, blur, pyramid)
+    const int ngroups = std::min((int)c->xstreams.size() + 1, nimg);
+    if (ngroups > 1) { HIPCHK(hipEventRecord(c->ev_fork, c->stream)); }
+    for (int gi = 0; gi < ngroups; gi++) {
+        const int f0 = (int)((long long)nimg * gi / ngroups), f1 = (int)((long long)nimg * (gi + 1) / ngroups), nf = f1 - f0;
+        hipStream_t s = gi == 0 ? c->stream : c->xstreams[gi - 1];
+        if (gi > 0) HIPCHK(hipStreamWaitEvent(s, c->ev_fork, 0));
+        if (nf <= 0) continue;
+        P.frame0 = f0; M.slot0 = f0;
+        { ProfScope ps(c, K_PYRAMID, s); for (int l = 1; l < c->L; l++) orbhip_launch_pyramid_level(P, l, c->geom[l].w, c->geom[l].h, nf, s); }
+        { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nf, s); }
+        { ProfScope ps(c, K_BLUR, s); orbhip_launch_blur(P, c->gk, nf, s); }
+        { ProfScope ps(c, K_QUADTREE, s); orbhip_launch_quadtree(P, nf, s); }
+        { ProfScope ps(c, K_DESCRIBE, s); orbhip_launch_describe(P, nf, s); }
+        if (match_prev) {
+            { ProfScope ps(c, K_MGRID, s); orbhip_launch_match_grid(M, nf, s); }
+            { ProfScope ps(c, K_MCAND, s); orbhip_launch_match_candidates(M, nf, s); }
+            { ProfScope ps(c, K_MSELECT, s); orbhip_launch_match_select(M, nf, s); }
+        }
+        if (gi > 0) { HIPCHK(hipEventRecord(c->xevents[gi - 1], s)); HIPCHK(hipStreamWaitEvent(c->stream, c->xevents[gi - 1], 0)); }
+    }
+    c->last_matched = match_prev != 0;
     c->last_nimg = nimg;
     HIPCHK(hipGetLastError());
     return ORBHIP_OK;
@@ -542,12 +565,12 @@ extern "C" orbhip_status orbhip_search_for_initialization(int device, const orbh
     int n2l0 = 0; for (int i = 0; i < n2; i++) n2l0 += kps2[i].octave == 0;
     const int cap = std::max(std::max(n1, n2), 1), l0cap = std::max((int)list1.size(), 1), cstride = std::max(n2l0, 1);
     if ((size_t)(2 * cap + 3 * l0cap + 64) * sizeof(int) > 150 * 1024) return fail(ORBHIP_ERR_UNSUPPORTED, "too many keypoints for the LDS matcher");
-    orbhip_keypoint *dk1 = nullptr, *dk2 = nullptr; uint8_t *dd1 = nullptr, *dd2 = nullptr; int *dn = nullptr, *dlist = nullptr, *dgs = nullptr, *dgi = nullptr, *dnc = nullptr, *dm12 = nullptr;
+    orbhip_keypoint *dk1 = nullptr, *dk2 = nullptr; uint8_t *dd1 = nullptr, *dd2 = nullptr; int *dn = nullptr, *dlist = nullptr, *dgs = nullptr, *dgi = nullptr, *dnc = nullptr, *dm12 = nullptr; float2* dgxy = nullptr;
     unsigned* dcand = nullptr; float* dprev = nullptr;
     hipError_t e = hipSuccess;
 #define TRY(x) do { if (e == hipSuccess) e = (x); } while (0)
     TRY(dalloc(&dk1, cap)); TRY(dalloc(&dk2, cap)); TRY(dalloc(&dd1, (size_t)cap * 32)); TRY(dalloc(&dd2, (size_t)cap * 32)); TRY(dalloc(&dn, 8));
-    TRY(dalloc(&dlist, l0cap)); TRY(dalloc(&dgs, ORBHIP_GRID_CELLS + 1)); TRY(dalloc(&dgi, cap)); TRY(dalloc(&dnc, l0cap)); TRY(dalloc(&dm12, cap));
+    TRY(dalloc(&dlist, l0cap)); TRY(dalloc(&dgs, ORBHIP_GRID_CELLS + 1)); TRY(dalloc(&dgi, cap)); TRY(dalloc(&dgxy, cap)); TRY(dalloc(&dnc, l0cap)); TRY(dalloc(&dm12, cap));
     TRY(dalloc(&dcand, (size_t)l0cap * cstride)); TRY(dalloc(&dprev, (size_t)cap * 2));
     const int hn[4] = {n1, n2, (int)list1.size(), 0};
     TRY(hipMemcpy(dk1, kps1, (size_t)n1 * sizeof(orbhip_keypoint), hipMemcpyHostToDevice)); TRY(hipMemcpy(dd1, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice));
@@ -558,7 +581,7 @@ extern "C" orbhip_status orbhip_search_for_initialization(int device, const orbh
     if (e == hipSuccess) {
         MatchParams M; memset(&M, 0, sizeof M);
         M.kp1 = dk1; M.desc1 = dd1; M.n1 = dn; M.n1_lvl0 = dn + 2; M.kp2 = dk2; M.desc2 = dd2; M.n2 = dn + 1; M.lvl_stride = 0; M.list1 = dlist; M.prev_from_kp1 = 0;
-        M.cap = cap; M.im_w = im_w; M.im_h = im_h; M.grid_start = dgs; M.grid_items = dgi; M.cand = dcand; M.ncand = dnc; M.cand_stride = cstride; M.lvl0_cap = l0cap;
+        M.cap = cap; M.im_w = im_w; M.im_h = im_h; M.grid_start = dgs; M.grid_items = dgi; M.grid_xy = dgxy; M.cand = dcand; M.ncand = dnc; M.cand_stride = cstride; M.lvl0_cap = l0cap;
         M.prev = dprev; M.matches12 = dm12; M.nmatches = dn + 3; M.window = window; M.nnratio = nnratio; M.check_ori = check_ori;
         orbhip_launch_match_grid(M, 1, nullptr); orbhip_launch_match_candidates(M, 1, nullptr); orbhip_launch_match_select(M, 1, nullptr);
         e = hipGetLastError();
@@ -570,7 +593,7 @@ extern "C" orbhip_status orbhip_search_for_initialization(int device, const orbh
 #undef TRY
     orbhip_status st = ORBHIP_OK;
     if (e != hipSuccess) st = fail(ORBHIP_ERR_HIP, "search_for_initialization: %s", hipGetErrorString(e));
-    void* ptrs[] = {dk1, dk2, dd1, dd2, dn, dlist, dgs, dgi, dnc, dm12, dcand, dprev};
+    void* ptrs[] = {dk1, dk2, dd1, dd2, dn, dlist, dgs, dgi, dgxy, dnc, dm12, dcand, dprev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     return st;
 }

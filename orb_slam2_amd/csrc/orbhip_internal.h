@@ -52,6 +52,7 @@ struct TileDesc { short level, x0, y0, pad; };
 
 struct ExtractParams {
     const LevelGeom* geom; int nlevels;
+    int frame0;                                                            // first frame (camera slot) of this launch group
     const uint8_t* img0; long long img0_frame_stride; int img0_pitch;      // level-0 source
     uint8_t* pyr; uint8_t* blur; long long plane_frame_bytes;
     const CellDesc* cells; int ncells_total;
@@ -76,12 +77,13 @@ struct MatchParams {        // SearchForInitialization over camera slots (ORBmat
     const orbhip_keypoint* kp2; const uint8_t* desc2; const int* n2;    // current frames
     int cap;                                      // keypoint capacity per frame (stride of the arrays above)
     int im_w, im_h;
-    int* grid_start; int* grid_items;             // [slot][GRID_CELLS+1], [slot][cap]  (Frame.cc:230-245 on F2)
+    int* grid_start; int* grid_items; float2* grid_xy;   // [slot][GRID_CELLS+1], [slot][cap], [slot][cap]  (Frame.cc:230-245 on F2, level 0 only)
     unsigned* cand; int* ncand; int cand_stride;  // [slot][n1_lvl0_cap][cand_stride]: i2 | dist<<16, canonical order
     int lvl0_cap;
     float* prev;                                  // [slot][cap][2] vbPrevMatched (in/out)
     int* matches12; int* nmatches;                // [slot][cap], [slot]
     int window; float nnratio; int check_ori;
+    int slot0;                                    // first camera slot of this launch group
 };
 
 // kernel launchers (orbhip_kernels_extract.hip / orbhip_kernels_match.hip)

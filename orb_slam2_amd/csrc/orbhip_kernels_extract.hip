@@ -30,7 +30,7 @@ __device__ __forceinline__ const uint8_t* level_src(const ExtractParams& P, int 
 __global__ __launch_bounds__(256) void k_pyramid_level(ExtractParams P, int level)
 {
     const LevelGeom g = P.geom[level];
-    const int frame = blockIdx.z;
+    const int frame = blockIdx.z + P.frame0;
     const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int y = blockIdx.y * 4 + threadIdx.y;
     if (y >= g.h || x4 >= g.w) return;
@@ -82,7 +82,7 @@ struct BlurK { int k0, k1, k2, k3; };
 __global__ __launch_bounds__(256) void k_blur(ExtractParams P, BlurK K)
 {
     const TileDesc t = P.blur_tiles[blockIdx.x];
-    const int frame = blockIdx.y, tid = threadIdx.x;
+    const int frame = blockIdx.y + P.frame0, tid = threadIdx.x;
     const LevelGeom g = P.geom[t.level];
     int spitch; const uint8_t* src = level_src(P, frame, t.level, spitch);
     __shared__ unsigned s_src[(BLUR_TH + 6) * (BLUR_SROW / 4)];
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
 {
     HIP_DYNAMIC_SHARED(uint8_t, fc_lds)
     __shared__ unsigned long long s_mini[FC_WAVES][64], s_mmin[FC_WAVES][64];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, frame = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, frame = blockIdx.y + P.frame0;
     const int cell_id = blockIdx.x * FC_WAVES + wave;
     const bool active = cell_id < P.ncells_total;
     CellDesc cd; cd.skipped = 1; cd.level = 0; cd.iniX = cd.iniY = cd.maxX = cd.maxY = 0; cd.shiftX = cd.shiftY = 0; cd.cand_idx = 0; cd.cand_cap = 0;
@@ -360,7 +360,7 @@ size_t orbhip_quadtree_lds_bytes(int maxn, int maxcells)
 
 __global__ __launch_bounds__(QT_T) void k_quadtree(ExtractParams P)
 {
-    const int level = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x;
+    const int level = blockIdx.x, frame = blockIdx.y + P.frame0, tid = threadIdx.x;
     const LevelGeom g = P.geom[level];
     const int maxn = P.qt_maxn, N = g.nfeat;
     HIP_DYNAMIC_SHARED(int, lds)
@@ -593,7 +593,7 @@ __device__ __forceinline__ void dev_sincosf(float y, float* sinp, float* cosp)
 #define DS_WAVES 4
 __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
 {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, frame = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, frame = blockIdx.y + P.frame0;
     const int slot = blockIdx.x * DS_WAVES + wave;
     if (slot >= P.lvl_kp_per_frame) return;
     int level = 0;
@@ -617,11 +617,14 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
         const int vr = (lane >> 1) - 15, av = vr < 0 ? -vr : vr;
         // umax (ORBextractor.cc:452-469) for HALF_PATCH_SIZE 15
         const int um = (av <= 3) ? 15 : (av <= 6) ? 14 : (av <= 8) ? 13 : (av == 9) ? 12 : (av == 10) ? 11 : (av == 11) ? 10 : (av == 12) ? 9 : (av == 13) ? 8 : (av == 14) ? 6 : 3;
-        const uint8_t* row = img + (long long)(cy + vr) * spitch + cx;
-        int u0, u1;
-        if (lane & 1) { u0 = 1; u1 = um; } else { u0 = -um; u1 = 0; }
+        const int ub = (lane & 1) ? 1 : -15;                      // even lane: u = -15..0, odd lane: u = 1..16 (u = 16 masked; still inside the image)
+        const uint8_t* row = img + (long long)(cy + vr) * spitch + cx + ub;
+        int px[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) px[k] = row[k];              // 16 independent loads in flight, one latency
         int su = 0, s = 0;
-        for (int u = u0; u <= u1; u++) { const int px = row[u]; su += u * px; s += px; }
+#pragma unroll
+        for (int k = 0; k < 16; k++) { const int u = ub + k; const int p = (u >= -um && u <= um) ? px[k] : 0; su += u * p; s += p; }
         m10 = su; m01 = vr * s;
     }
 #pragma unroll
@@ -633,14 +636,18 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
     float a, b; dev_sincosf(__fmul_rn(angle, factorPI), &b, &a);
     const uint8_t* bl = P.blur + (long long)frame * P.plane_frame_bytes + g.plane_off + (long long)cy * g.pitch + cx;
     unsigned long long* dout = reinterpret_cast<unsigned long long*>(P.out_desc + ((long long)frame * P.out_cap + oi) * 32);
+    int t0[4], t1[4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
+    for (int r = 0; r < 4; r++) {                                  // all 8 gathers issued before the first ballot
         const signed char* pt = P.pattern + (r * 64 + lane) * 4;
         const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
         const int iy0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a))), ix0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
         const int iy1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a))), ix1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        const int t0 = bl[(long long)iy0 * g.pitch + ix0], t1 = bl[(long long)iy1 * g.pitch + ix1];
-        const unsigned long long bits = __ballot(t0 < t1);       // test 64r+lane -> byte (64r+lane)/8, bit lane%8
+        t0[r] = bl[(long long)iy0 * g.pitch + ix0]; t1[r] = bl[(long long)iy1 * g.pitch + ix1];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const unsigned long long bits = __ballot(t0[r] < t1[r]);   // test 64r+lane -> byte (64r+lane)/8, bit lane%8
         if (lane == 0) dout[r] = bits;
     }
     if (lane == 0) {

@@ -107,14 +107,18 @@ __global__ __launch_bounds__(256) void k_match_grid(MatchParams M, float gwInv, 
 {
     __shared__ int s_cnt[ORBHIP_GRID_CELLS + 1];
     __shared__ int s_scan[256];
-    const int slot = blockIdx.x, tid = threadIdx.x;
+    const int slot = blockIdx.x + M.slot0, tid = threadIdx.x;
     const int n2 = M.n2[slot];
     const orbhip_keypoint* kp = M.kp2 + (long long)slot * M.cap;
     int* gstart = M.grid_start + (long long)slot * (ORBHIP_GRID_CELLS + 1);
     int* gitems = M.grid_items + (long long)slot * M.cap;
+    float2* gxy = M.grid_xy + (long long)slot * M.cap;
     for (int c = tid; c <= ORBHIP_GRID_CELLS; c += 256) s_cnt[c] = 0;
     __syncthreads();
+    // Only level-0 keypoints can ever be returned by GetFeaturesInArea(.., minLevel 0, maxLevel 0) (Frame.cc:362-370), and
+    // filtering a cell keeps the relative order of its entries, so the buckets are built from level-0 keypoints only.
     for (int i = tid; i < n2; i += 256) {
+        if (kp[i].octave != 0) continue;
         const int px = (int)roundf(__fmul_rn(__fsub_rn(kp[i].x, 0.0f), gwInv)), py = (int)roundf(__fmul_rn(__fsub_rn(kp[i].y, 0.0f), ghInv));
         if (px < 0 || px >= ORBHIP_GRID_COLS || py < 0 || py >= ORBHIP_GRID_ROWS) continue;
         atomicAdd(&s_cnt[px * ORBHIP_GRID_ROWS + py], 1);
@@ -132,6 +136,7 @@ __global__ __launch_bounds__(256) void k_match_grid(MatchParams M, float gwInv, 
     if (tid == 255) gstart[ORBHIP_GRID_CELLS] = run;
     __syncthreads();
     for (int i = tid; i < n2; i += 256) {
+        if (kp[i].octave != 0) continue;
         const int px = (int)roundf(__fmul_rn(__fsub_rn(kp[i].x, 0.0f), gwInv)), py = (int)roundf(__fmul_rn(__fsub_rn(kp[i].y, 0.0f), ghInv));
         if (px < 0 || px >= ORBHIP_GRID_COLS || py < 0 || py >= ORBHIP_GRID_ROWS) continue;
         gitems[atomicAdd(&s_cnt[px * ORBHIP_GRID_ROWS + py], 1)] = i;
@@ -141,6 +146,7 @@ __global__ __launch_bounds__(256) void k_match_grid(MatchParams M, float gwInv, 
     for (int c = tid; c < ORBHIP_GRID_CELLS; c += 256) {
         const int a = gstart[c], b = s_cnt[c];          // after the scatter s_cnt[c] == end of cell c
         for (int i = a + 1; i < b; i++) { const int v = gitems[i]; int j = i - 1; while (j >= a && gitems[j] > v) { gitems[j + 1] = gitems[j]; j--; } gitems[j + 1] = v; }
+        for (int i = a; i < b; i++) { const orbhip_keypoint k = kp[gitems[i]]; float2 xy; xy.x = k.x; xy.y = k.y; gxy[i] = xy; }
     }
 }
 
@@ -155,14 +161,14 @@ void orbhip_launch_match_grid(const MatchParams& M, int nslots, hipStream_t s)
 // reference's order (ix outer, iy inner, keypoint order inside a cell) + DescriptorDistance to each candidate.
 __global__ __launch_bounds__(256) void k_match_candidates(MatchParams M, float gwInv, float ghInv)
 {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, slot = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, slot = blockIdx.y + M.slot0;
     const int j1 = blockIdx.x * 4 + wave;
     const int n1l = M.n1_lvl0[slot * M.lvl_stride];
     if (j1 >= n1l || j1 >= M.lvl0_cap) return;
     const int i1 = M.list1 ? M.list1[(long long)slot * M.lvl0_cap + j1] : j1;   // level-major extractor output: level 0 = indices [0, n_lvl0)
-    const orbhip_keypoint* kp2 = M.kp2 + (long long)slot * M.cap;
     const int* gstart = M.grid_start + (long long)slot * (ORBHIP_GRID_CELLS + 1);
     const int* gitems = M.grid_items + (long long)slot * M.cap;
+    const float2* gxy = M.grid_xy + (long long)slot * M.cap;
     unsigned* cand = M.cand + ((long long)slot * M.lvl0_cap + j1) * M.cand_stride;
     const orbhip_keypoint* kp1 = M.kp1 + (long long)slot * M.cap;
     const float x = M.prev_from_kp1 ? kp1[i1].x : M.prev[((long long)slot * M.cap + i1) * 2];
@@ -182,9 +188,8 @@ __global__ __launch_bounds__(256) void k_match_candidates(MatchParams M, float g
             int a = 0, b = 0;
             if (c < ncell) { const int ix = minCX + c / ny, iy = minCY + c % ny; const int cell = ix * ORBHIP_GRID_ROWS + iy; a = gstart[cell]; b = gstart[cell + 1]; }
             int cnt = 0;
-            for (int t = a; t < b; t++) {
-                const orbhip_keypoint k = kp2[gitems[t]];
-                if (k.octave != 0) continue;                     // minLevel = maxLevel = 0 (ORBmatcher.cc:425)
+            for (int t = a; t < b; t++) {                        // buckets hold level-0 keypoints only (minLevel = maxLevel = 0, ORBmatcher.cc:425)
+                const float2 k = gxy[t];
                 cnt += (fabsf(__fsub_rn(k.x, x)) < r && fabsf(__fsub_rn(k.y, y)) < r);
             }
             int incl = cnt;
@@ -192,9 +197,9 @@ __global__ __launch_bounds__(256) void k_match_candidates(MatchParams M, float g
             for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
             int pos = nc + incl - cnt;
             for (int t = a; t < b; t++) {
-                const int i2 = gitems[t]; const orbhip_keypoint k = kp2[i2];
-                if (k.octave != 0) continue;
+                const float2 k = gxy[t];
                 if (fabsf(__fsub_rn(k.x, x)) < r && fabsf(__fsub_rn(k.y, y)) < r) {
+                    const int i2 = gitems[t];
                     if (pos < M.cand_stride) {
                         const unsigned long long* d2 = (const unsigned long long*)(M.desc2 + ((long long)slot * M.cap + i2) * 32);
                         const int dist = __popcll(q0 ^ d2[0]) + __popcll(q1 ^ d2[1]) + __popcll(q2 ^ d2[2]) + __popcll(q3 ^ d2[3]);
@@ -228,7 +233,7 @@ __device__ __forceinline__ unsigned long long wave_argmin_mask(int d, unsigned l
 
 __global__ __launch_bounds__(64) void k_match_select(MatchParams M)
 {
-    const int slot = blockIdx.x, lane = threadIdx.x;
+    const int slot = blockIdx.x + M.slot0, lane = threadIdx.x;
     const int n1 = M.n1[slot], n2 = M.n2[slot];
     const int n1l = min(M.n1_lvl0[slot * M.lvl_stride], M.lvl0_cap);
     const int* list1 = M.list1 ? M.list1 + (long long)slot * M.lvl0_cap : nullptr;

@@ -36,7 +36,7 @@ class OrbHipError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32), ("ini_th_fast", C.c_int32),
                 ("min_th_fast", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("max_batch", C.c_int32),
-                ("device", C.c_int32), ("stream", C.c_void_p), ("blur_round_mode", C.c_int32)]
+                ("device", C.c_int32), ("stream", C.c_void_p), ("blur_round_mode", C.c_int32), ("num_streams", C.c_int32)]
 
 
 def library_path():
@@ -108,10 +108,10 @@ class ORBextractor:
     HARRIS_SCORE, FAST_SCORE = 0, 1
 
     def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, width, height, max_batch=1, device=0,
-                 stream=None, blur_round_mode=0, library=None):
+                 stream=None, blur_round_mode=0, library=None, num_streams=1):
         self.L = lib(library)
         self.cfg = Config(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, width, height, max_batch, device,
-                          C.c_void_p(stream) if stream else None, blur_round_mode)
+                          C.c_void_p(stream) if stream else None, blur_round_mode, num_streams)
         self.h = C.c_void_p()
         _check(self.L.orbhip_create(C.byref(self.h), C.byref(self.cfg)), "orbhip_create", self.L)
         self.width, self.height, self.nlevels, self.max_batch = width, height, nlevels, max_batch

@@ -105,13 +105,15 @@ def test_brute_force_nn(backend, oracle):
     assert all(np.array_equal(a, b) for a, b in zip(merged, want))
 
 
-def test_device_pipeline_extract_and_match(backend, oracle):
-    """orbhip_extract_device on two camera slots over three time steps, matched against each slot's previous frame."""
+@pytest.mark.parametrize("num_streams", [1, 2])
+def test_device_pipeline_extract_and_match(backend, oracle, num_streams):
+    """orbhip_extract_device on two camera slots over three time steps, matched against each slot's previous frame
+    (num_streams = 2: the two slots run concurrently on two HIP streams)."""
     w, h, n = 400, 300, 500
     seqs = [synth.sequence(w, h, 3, seed=s) for s in (12, 15)]
     ora = oracle.OracleExtractor(n, 1.2, 8, 20, 7)
     K = [[ora.extract(im) for im in s] for s in seqs]
-    ex = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, max_batch=2, library=backend)
+    ex = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, max_batch=2, library=backend, num_streams=num_streams)
     pitch = 448
     is_gpu = not backend.endswith("_emu.so")
     if is_gpu:                                           # plain HIP runtime through ctypes: device memory is plumbing, not product

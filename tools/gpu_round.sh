@@ -10,9 +10,14 @@ export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.log
 timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke exit $?" >> $OUT/smoke.log
 timeout 600 python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?" >> $OUT/bench.err
-timeout 300 python bench.py --steps 20 --warmup 3 --batch 64 --no-cpu-baseline > $OUT/bench_b64.json 2>> $OUT/bench.err
+for cfg in "64 1" "64 4" "256 1" "256 2" "256 8" "512 4" "512 8"; do set -- $cfg; timeout 200 python bench.py --steps 20 --warmup 3 --batch $1 --streams $2 --no-cpu-baseline >> $OUT/bench_sweep.jsonl 2>> $OUT/bench.err; done
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o orb -- python $OLDPWD/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OLDPWD/$OUT/rocprof_bench.json 2> $OLDPWD/$OUT/rocprof.err )
 find /tmp/prof_$TAG -name "*stats*" -o -name "*kernel_trace*" | head -20 > $OUT/prof_files.txt
 for f in $(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -2); do cp $f $OUT/; done
 for f in $(find /tmp/prof_$TAG -name "*kernel_trace.csv" | head -1); do head -400 $f > $OUT/kernel_trace_head.csv; done
-tail -5 $OUT/pytest_gpu.log; tail -3 $OUT/smoke.log; cat $OUT/bench.json; cat $OUT/bench_b64.json; cat $OUT/*kernel_stats.csv | head -30; tail -3 $OUT/bench.err; ls $OUT
+tail -5 $OUT/pytest_gpu.log; tail -3 $OUT/smoke.log; cat $OUT/bench.json; python - <<PY
+import json
+for l in open('$OUT/bench_sweep.jsonl'):
+    d=json.loads(l); print(d['config']['frames_per_step_per_gpu'], d['config']['streams_per_gpu'], d['value'], d['kernels_ms_per_launch'])
+PY
+ cat $OUT/*kernel_stats.csv | head -30; tail -3 $OUT/bench.err; ls $OUT
