@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="camera slots (frames) per step per GPU")
     ap.add_argument("--tsteps", type=int, default=4, help="distinct resident time steps cycled through")
-    ap.add_argument("--streams", type=int, default=4, help="HIP streams the library splits each batch over")
+    ap.add_argument("--streams", type=int, default=1, help="HIP streams the library splits each batch over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

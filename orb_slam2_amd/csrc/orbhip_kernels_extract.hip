@@ -27,40 +27,76 @@ __device__ __forceinline__ const uint8_t* level_src(const ExtractParams& P, int 
 // cv::resize INTER_LINEAR CV_8U (OpenCV 3.2 HResizeLinear / VResizeLinear fixed point, 11-bit coefficients).
 // Coefficient tables are built on the host exactly as OpenCV builds them; the kernel is pure integer.
 // 4 output pixels per thread, one 32-bit store.
+// Workgroup = 256 x 8 output pixels: the source footprint (<= 12 rows x ~312 bytes) is staged in LDS with 32-bit loads,
+// each thread then produces 4 pixels of 2 rows (one 32-bit store per row).
+#define PYR_TW 256
+#define PYR_TH 8
+#define PYR_SROWS 12
+#define PYR_SDW 84                      // dwords per staged source row (>= (256*1.25+2+3)/4)
 __global__ __launch_bounds__(256) void k_pyramid_level(ExtractParams P, int level)
 {
     const LevelGeom g = P.geom[level];
     const int frame = blockIdx.z + P.frame0;
-    const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    const int y = blockIdx.y * 4 + threadIdx.y;
-    if (y >= g.h || x4 >= g.w) return;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const int x0 = blockIdx.x * PYR_TW, y0 = blockIdx.y * PYR_TH;
     int spitch; const uint8_t* src = level_src(P, frame, level - 1, spitch);
-    uint8_t* dst = P.pyr + (long long)frame * P.plane_frame_bytes + g.plane_off + (long long)y * g.pitch;
-    const int2 yt = P.ytab[g.ytab_off + y];
-    const int b0 = yt.y & 0xffff, b1 = (yt.y >> 16) & 0xffff;
-    const int ya = min(max(yt.x, 0), g.src_h - 1), yb = min(max(yt.x + 1, 0), g.src_h - 1);
-    const uint8_t* r0 = src + (long long)ya * spitch;
-    const uint8_t* r1 = src + (long long)yb * spitch;
-    unsigned out = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int x = x4 + k;
-        if (x < g.w) {
-            const int2 xt = P.xtab[g.xtab_off + x];
-            const int a0 = xt.y & 0xffff, a1 = (xt.y >> 16) & 0xffff;
-            const int sx = xt.x, sx1 = min(sx + 1, g.src_w - 1);
-            const int h0 = r0[sx] * a0 + r0[sx1] * a1;
-            const int h1 = r1[sx] * a0 + r1[sx1] * a1;
-            const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-            out |= (unsigned)(v & 0xff) << (8 * k);
+    __shared__ unsigned s_t[PYR_SROWS * PYR_SDW];
+    const int2* xt = P.xtab + g.xtab_off; const int2* yt = P.ytab + g.ytab_off;
+    const int xl = min(x0 + PYR_TW - 1, g.w - 1), yl = min(y0 + PYR_TH - 1, g.h - 1);
+    const int sxa = xt[x0].x & ~3, sxb = min(xt[xl].x + 1, g.src_w - 1);                    // staged source columns [sxa, sxb]
+    const int sya = min(max(yt[y0].x, 0), g.src_h - 1), syb = min(max(yt[yl].x + 1, 0), g.src_h - 1);
+    const int ndw = ((sxb - sxa) >> 2) + 1, nrows = syb - sya + 1;
+    const bool fits = ndw <= PYR_SDW && nrows <= PYR_SROWS;                                  // always true for scale factors >= ~1.05
+    const bool aligned = ((((unsigned long long)src) | (unsigned long long)spitch) & 3ull) == 0;
+    if (fits) {
+        for (int i = tid; i < nrows * ndw; i += 256) {
+            const int r = i / ndw, d = i - r * ndw;
+            const uint8_t* row = src + (long long)(sya + r) * spitch + sxa + 4 * d;
+            unsigned v;
+            if (aligned && sxa + 4 * d + 3 < g.src_w) v = *reinterpret_cast<const unsigned*>(row);
+            else { v = 0; for (int k = 0; k < 4; k++) if (sxa + 4 * d + k < g.src_w) v |= (unsigned)row[k] << (8 * k); }
+            s_t[r * PYR_SDW + d] = v;
         }
     }
-    *reinterpret_cast<unsigned*>(dst + x4) = out;
+    __syncthreads();
+    const int x4 = x0 + threadIdx.x * 4;
+    if (x4 >= g.w) return;
+    const uint8_t* t8 = reinterpret_cast<const uint8_t*>(s_t);
+    int sx[4], sx1[4], a0[4], a1[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int2 e = xt[min(x4 + k, g.w - 1)];
+        sx[k] = e.x; sx1[k] = min(e.x + 1, g.src_w - 1); a0[k] = e.y & 0xffff; a1[k] = (e.y >> 16) & 0xffff;
+    }
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+        const int y = y0 + threadIdx.y * 2 + rr;
+        if (y >= g.h) break;
+        const int2 ye = yt[y];
+        const int b0 = ye.y & 0xffff, b1 = (ye.y >> 16) & 0xffff;
+        const int ya = min(max(ye.x, 0), g.src_h - 1), yb = min(max(ye.x + 1, 0), g.src_h - 1);
+        unsigned out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int p00, p01, p10, p11;
+            if (fits) {
+                const uint8_t* r0 = t8 + (ya - sya) * (PYR_SDW * 4) - sxa, *r1 = t8 + (yb - sya) * (PYR_SDW * 4) - sxa;
+                p00 = r0[sx[k]]; p01 = r0[sx1[k]]; p10 = r1[sx[k]]; p11 = r1[sx1[k]];
+            } else {
+                const uint8_t* r0 = src + (long long)ya * spitch, *r1 = src + (long long)yb * spitch;
+                p00 = r0[sx[k]]; p01 = r0[sx1[k]]; p10 = r1[sx[k]]; p11 = r1[sx1[k]];
+            }
+            const int h0 = p00 * a0[k] + p01 * a1[k], h1 = p10 * a0[k] + p11 * a1[k];
+            const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            if (x4 + k < g.w) out |= (unsigned)(v & 0xff) << (8 * k);
+        }
+        *reinterpret_cast<unsigned*>(P.pyr + (long long)frame * P.plane_frame_bytes + g.plane_off + (long long)y * g.pitch + x4) = out;
+    }
 }
 
 void orbhip_launch_pyramid_level(const ExtractParams& P, int level, int w, int h, int nframes, hipStream_t s)
 {
-    dim3 grid((w + 255) / 256, (h + 3) / 4, nframes), block(64, 4, 1);
+    dim3 grid((w + PYR_TW - 1) / PYR_TW, (h + PYR_TH - 1) / PYR_TH, nframes), block(64, 4, 1);
     hipLaunchKernelGGL(k_pyramid_level, grid, block, 0, s, P, level);
 }
 
@@ -332,30 +368,45 @@ __device__ __forceinline__ int qt_digit(unsigned code, int depth)
     return depth < ORBHIP_QT_DEPTH ? (int)((code >> (2 * (ORBHIP_QT_DEPTH - 1 - depth))) & 3u) : 0;
 }
 
+#define QT_SCR 512
+__device__ __forceinline__ int qt_wave_incl_scan(int v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(v, off); if (lane >= off) v += u; }
+    return v;
+}
 __device__ __forceinline__ int qt_block_exscan(int* a, int n, int* scratch, int tid)
-{   // in-place exclusive scan of a[0..n), returns the total; all QT_T threads must call
-    const int c = (n + QT_T - 1) / QT_T, lo = min(tid * c, n), hi = min(lo + c, n);
-    int sum = 0;
-    for (int i = lo; i < hi; i++) sum += a[i];
-    scratch[tid] = sum;
-    __syncthreads();
-    for (int off = 1; off < QT_T; off <<= 1) {
-        const int v = (tid >= off) ? scratch[tid - off] : 0;
-        __syncthreads();
-        scratch[tid] += v;
-        __syncthreads();
+{   // in-place exclusive scan of a[0..n), n <= 64*(QT_SCR-1); returns the total; all QT_T threads must call.
+    // 64-element chunks are scanned with wave shuffles, chunk totals by wave 0: three barriers in all.
+    const int lane = tid & 63, wave = tid >> 6, nch = (n + 63) >> 6;
+    for (int c = wave; c < nch; c += QT_T / 64) {
+        const int i = c * 64 + lane, v = i < n ? a[i] : 0;
+        const int incl = qt_wave_incl_scan(v, lane);
+        if (i < n) a[i] = incl - v;
+        if (lane == 63) scratch[c] = incl;
     }
-    const int total = scratch[QT_T - 1];
-    int run = scratch[tid] - sum;
-    for (int i = lo; i < hi; i++) { const int v = a[i]; a[i] = run; run += v; }
+    __syncthreads();
+    if (wave == 0) {
+        int run = 0;
+        for (int cb = 0; cb < nch; cb += 64) {
+            const int v = (cb + lane < nch) ? scratch[cb + lane] : 0;
+            const int incl = qt_wave_incl_scan(v, lane);
+            if (cb + lane < nch) scratch[cb + lane] = run + incl - v;
+            run += __shfl(incl, 63);
+        }
+        if (lane == 0) scratch[QT_SCR - 1] = run;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += QT_T) a[i] += scratch[i >> 6];
+    const int total = scratch[QT_SCR - 1];
     __syncthreads();
     return total;
 }
 
 size_t orbhip_quadtree_lds_bytes(int maxn, int maxcells)
 {
-    // s_pref[maxcells+1] | cnt[2][maxn] | depth[2][maxn] | cc[4*maxn] | map[4*maxn] | a[maxn] | b[maxn] | sidx[maxn] | split[maxn] | best[maxn] | scratch[QT_T] | misc[16]
-    return sizeof(int) * ((size_t)(maxcells + 1) + (size_t)maxn * (2 + 2 + 4 + 4 + 5) + QT_T + 16);
+    // s_pref[maxcells+1] | cnt[2][maxn] | depth[2][maxn] | cc[4*maxn] | map[4*maxn] | a[maxn] | b[maxn] | sidx[maxn] | split[maxn] | best[maxn] | scratch[QT_SCR] | misc[16]
+    return sizeof(int) * ((size_t)(maxcells + 1) + (size_t)maxn * (2 + 2 + 4 + 4 + 5) + QT_SCR + 16);
 }
 
 __global__ __launch_bounds__(QT_T) void k_quadtree(ExtractParams P)
@@ -377,7 +428,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(ExtractParams P)
     int* s_split = s_sidx + maxn;
     int* s_best = s_split + maxn;
     int* s_scratch = s_best + maxn;
-    int* s_misc = s_scratch + QT_T;
+    int* s_misc = s_scratch + QT_SCR;
 
     unsigned* qval = P.qt_val + (long long)frame * P.qt_per_frame + g.cand_total_off;
     unsigned* qcode = P.qt_code + (long long)frame * P.qt_per_frame + g.cand_total_off;

@@ -231,9 +231,14 @@ __device__ __forceinline__ unsigned long long wave_argmin_mask(int d, unsigned l
     return M;
 }
 
-__global__ __launch_bounds__(64) void k_match_select(MatchParams M)
+#define MS_T 256
+#define MS_CANDCAP 20480               // candidate records staged in LDS (80 KB); longer lists are read from HBM
+
+// Workgroup of 4 waves per camera slot: all waves stage the slot's candidate lists (i2 | dist<<20, canonical order) in LDS,
+// then wave 0 alone replays the order-dependent loop over F1's level-0 keypoints.
+__global__ __launch_bounds__(MS_T) void k_match_select(MatchParams M)
 {
-    const int slot = blockIdx.x + M.slot0, lane = threadIdx.x;
+    const int slot = blockIdx.x + M.slot0, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n1 = M.n1[slot], n2 = M.n2[slot];
     const int n1l = min(M.n1_lvl0[slot * M.lvl_stride], M.lvl0_cap);
     const int* list1 = M.list1 ? M.list1 + (long long)slot * M.lvl0_cap : nullptr;
@@ -243,29 +248,51 @@ __global__ __launch_bounds__(64) void k_match_select(MatchParams M)
     int* s_m12 = s_m21 + M.cap;             // vnMatches12[i1] for level-0 i1
     int* s_bin = s_m12 + M.lvl0_cap;        // rotation bin of the accepted match of i1, -1 = none
     int* s_nc = s_bin + M.lvl0_cap;         // candidate count per level-0 i1
-    int* s_hist = s_nc + M.lvl0_cap;        // [HISTO_LENGTH] + misc
+    int* s_off = s_nc + M.lvl0_cap;         // start of its list in s_cand
+    int* s_hist = s_off + M.lvl0_cap + 1;   // [HISTO_LENGTH] + misc
+    unsigned* s_cand = reinterpret_cast<unsigned*>(s_hist + ORBHIP_HISTO_LENGTH + 8);
     const orbhip_keypoint* kp1 = M.kp1 + (long long)slot * M.cap;
     const orbhip_keypoint* kp2 = M.kp2 + (long long)slot * M.cap;
     int* m12 = M.matches12 + (long long)slot * M.cap;
     float* prev = M.prev + (long long)slot * M.cap * 2;
-    for (int i = lane; i < n2; i += 64) { s_md[i] = IMAX; s_m21[i] = -1; }
-    for (int i = lane; i < n1l; i += 64) { s_m12[i] = -1; s_bin[i] = -1; s_nc[i] = M.ncand[(long long)slot * M.lvl0_cap + i]; }
-    for (int i = lane; i < ORBHIP_HISTO_LENGTH + 8; i += 64) s_hist[i] = 0;
-    for (int i = lane; i < n1; i += 64) { m12[i] = -1; if (M.prev_from_kp1) { prev[2 * i] = kp1[i].x; prev[2 * i + 1] = kp1[i].y; } }
-    __syncthreads();
-    const float factor = 1.0f / ORBHIP_HISTO_LENGTH;
     const unsigned* cand0 = M.cand + (long long)slot * M.lvl0_cap * M.cand_stride;
-    unsigned e_next = (n1l > 0 && lane < s_nc[0]) ? cand0[lane] : 0u;          // software prefetch of the next keypoint's first chunk
+    for (int i = tid; i < n2; i += MS_T) { s_md[i] = IMAX; s_m21[i] = -1; }
+    for (int i = tid; i < n1l; i += MS_T) { s_m12[i] = -1; s_bin[i] = -1; s_nc[i] = M.ncand[(long long)slot * M.lvl0_cap + i]; }
+    for (int i = tid; i < ORBHIP_HISTO_LENGTH + 8; i += MS_T) s_hist[i] = 0;
+    for (int i = tid; i < n1; i += MS_T) { m12[i] = -1; if (M.prev_from_kp1) { prev[2 * i] = kp1[i].x; prev[2 * i + 1] = kp1[i].y; } }
+    __syncthreads();
+    if (wave == 0) {                        // exclusive scan of the list lengths
+        int run = 0;
+        for (int cb = 0; cb < n1l; cb += 64) {
+            const int v = (cb + lane < n1l) ? s_nc[cb + lane] : 0;
+            int incl = v;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(incl, off); if (lane >= off) incl += u; }
+            if (cb + lane < n1l) s_off[cb + lane] = run + incl - v;
+            run += __shfl(incl, 63);
+        }
+        if (lane == 0) s_off[n1l] = run;
+    }
+    __syncthreads();
+    for (int j1 = wave; j1 < n1l; j1 += MS_T / 64) {
+        const int nc = s_nc[j1], o = s_off[j1];
+        if (o + nc > MS_CANDCAP) continue;
+        for (int t = lane; t < nc; t += 64) s_cand[o + t] = cand0[(long long)j1 * M.cand_stride + t];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    const float factor = 1.0f / ORBHIP_HISTO_LENGTH;
     for (int j1 = 0; j1 < n1l; j1++) {
         const int nc = s_nc[j1];
-        const unsigned* cand = cand0 + (long long)j1 * M.cand_stride;
-        unsigned e = e_next;
-        if (j1 + 1 < n1l) e_next = (lane < s_nc[j1 + 1]) ? cand[M.cand_stride + lane] : 0u;
         if (nc == 0) continue;
+        const int o = s_off[j1];
+        const bool staged = o + nc <= MS_CANDCAP;
+        const unsigned* cand = cand0 + (long long)j1 * M.cand_stride;
         int best = IMAX, second = IMAX, bidx = -1;
         for (int cb = 0; cb < nc; cb += 64) {
             const int t = cb + lane;
-            if (cb > 0) e = (t < nc) ? cand[t] : 0u;
+            unsigned e = 0;
+            if (t < nc) e = staged ? s_cand[o + t] : cand[t];
             const int i2 = (int)(e & 0xFFFFFu), dist = (int)(e >> 20);
             const bool valid = t < nc && !(s_md[i2] <= dist);                    // :444-445
             const unsigned long long V = __ballot(valid);
@@ -327,6 +354,6 @@ __global__ __launch_bounds__(64) void k_match_select(MatchParams M)
 
 void orbhip_launch_match_select(const MatchParams& M, int nslots, hipStream_t s)
 {
-    const size_t lds = sizeof(int) * ((size_t)2 * M.cap + (size_t)3 * M.lvl0_cap + ORBHIP_HISTO_LENGTH + 8);
-    hipLaunchKernelGGL(k_match_select, dim3(nslots, 1, 1), dim3(64, 1, 1), lds, s, M);
+    const size_t lds = sizeof(int) * ((size_t)2 * M.cap + (size_t)4 * M.lvl0_cap + 1 + ORBHIP_HISTO_LENGTH + 8 + MS_CANDCAP);
+    hipLaunchKernelGGL(k_match_select, dim3(nslots, 1, 1), dim3(MS_T, 1, 1), lds, s, M);
 }
