@@ -226,7 +226,7 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
     c->lvl_kp_per_frame = kp_off; c->out_cap = kp_off; c->lvl0_cap = c->geom[0].kp_cap;
     if (cand_off >= (1 << 24)) { delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "too many candidate slots"); }
     if (orbhip_quadtree_lds_bytes(c->qt_maxn, c->qt_maxcells) > 150 * 1024) { delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "nfeatures too large for the LDS quadtree (%d nodes)", c->qt_maxn); }
-    if ((size_t)(2 * c->out_cap + 4 * c->lvl0_cap + 64 + 20480) * sizeof(int) > 158 * 1024) { delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "nfeatures too large for the LDS matcher"); }
+    if ((size_t)(3 * c->out_cap + 5 * c->lvl0_cap + 64 + 20480) * sizeof(int) > 158 * 1024) { delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "nfeatures too large for the LDS matcher"); }
 
     // ---- device
     if (cfg->stream) c->stream = (hipStream_t)cfg->stream;
@@ -565,7 +565,7 @@ extern "C" orbhip_status orbhip_search_for_initialization(int device, const orbh
     std::vector<int> list1; for (int i = 0; i < n1; i++) if (kps1[i].octave <= 0) list1.push_back(i);
     int n2l0 = 0; for (int i = 0; i < n2; i++) n2l0 += kps2[i].octave == 0;
     const int cap = std::max(std::max(n1, n2), 1), l0cap = std::max((int)list1.size(), 1), cstride = std::max(n2l0, 1);
-    if ((size_t)(2 * cap + 4 * l0cap + 64 + 20480) * sizeof(int) > 158 * 1024) return fail(ORBHIP_ERR_UNSUPPORTED, "too many keypoints for the LDS matcher");
+    if ((size_t)(3 * cap + 5 * l0cap + 64 + 20480) * sizeof(int) > 158 * 1024) return fail(ORBHIP_ERR_UNSUPPORTED, "too many keypoints for the LDS matcher");
     orbhip_keypoint *dk1 = nullptr, *dk2 = nullptr; uint8_t *dd1 = nullptr, *dd2 = nullptr; int *dn = nullptr, *dlist = nullptr, *dgs = nullptr, *dgi = nullptr, *dnc = nullptr, *dm12 = nullptr; float2* dgxy = nullptr;
     unsigned* dcand = nullptr; float* dprev = nullptr;
     hipError_t e = hipSuccess;

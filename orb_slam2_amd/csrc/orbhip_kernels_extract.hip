@@ -403,81 +403,78 @@ __device__ __forceinline__ int qt_block_exscan(int* a, int n, int* scratch, int 
     return total;
 }
 
+#define QT_LDSKEYS 4096                 // candidates per (frame, level) whose keys stay in LDS (7 B each); more -> HBM workspace
+
 size_t orbhip_quadtree_lds_bytes(int maxn, int maxcells)
 {
-    // s_pref[maxcells+1] | cnt[2][maxn] | depth[2][maxn] | cc[4*maxn] | map[4*maxn] | a[maxn] | b[maxn] | sidx[maxn] | split[maxn] | best[maxn] | scratch[QT_SCR] | misc[16]
-    return sizeof(int) * ((size_t)(maxcells + 1) + (size_t)maxn * (2 + 2 + 4 + 4 + 5) + QT_SCR + 16);
+    // s_pref[maxcells+1] | s_slot[maxcells] | cnt[2][maxn] | depth[2][maxn] | cc[4*maxn] | map[4*maxn] | a | b | sidx | split | best [maxn each]
+    // | scratch[QT_SCR] | misc[16] | key code u32 / node u16 / score u8 [QT_LDSKEYS]
+    return sizeof(int) * ((size_t)(2 * maxcells + 1) + (size_t)maxn * (2 + 2 + 4 + 4 + 5) + QT_SCR + 16) + (size_t)QT_LDSKEYS * 7 + 16;
 }
 
-__global__ __launch_bounds__(QT_T) void k_quadtree(ExtractParams P)
+// per-candidate state of the quadtree replay: path code, current node (list position), FAST score
+struct QtKeysLds {
+    unsigned* code; unsigned short* node; uint8_t* score;
+    __device__ __forceinline__ unsigned getCode(int k) const { return code[k]; }
+    __device__ __forceinline__ int getNode(int k) const { return node[k]; }
+    __device__ __forceinline__ int getScore(int k) const { return score[k]; }
+    __device__ __forceinline__ void setNode(int k, int v) const { node[k] = (unsigned short)v; }
+    __device__ __forceinline__ void init(int k, unsigned c, int nd, int sc) const { code[k] = c; node[k] = (unsigned short)nd; score[k] = (uint8_t)sc; }
+};
+struct QtKeysHbm {
+    unsigned* code; int* node; const unsigned* val;
+    __device__ __forceinline__ unsigned getCode(int k) const { return code[k]; }
+    __device__ __forceinline__ int getNode(int k) const { return node[k]; }
+    __device__ __forceinline__ int getScore(int k) const { return (int)(val[k] >> 24); }
+    __device__ __forceinline__ void setNode(int k, int v) const { node[k] = v; }
+    __device__ __forceinline__ void init(int k, unsigned c, int nd, int) const { code[k] = c; node[k] = nd; }
+};
+
+struct QtLds {
+    int *pref, *slot, *cntA, *cntB, *depA, *depB, *cc, *map, *a, *b, *sidx, *split, *best, *scratch, *misc;
+};
+
+template <class Keys>
+__device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeom& g, const QtLds& L, const Keys keys, unsigned* qval, int n,
+                                          int frame, int level, int tid)
 {
-    const int level = blockIdx.x, frame = blockIdx.y + P.frame0, tid = threadIdx.x;
-    const LevelGeom g = P.geom[level];
-    const int maxn = P.qt_maxn, N = g.nfeat;
-    HIP_DYNAMIC_SHARED(int, lds)
-    int* s_pref = lds;
-    int* s_cntA = s_pref + (P.qt_maxcells + 1);
-    int* s_cntB = s_cntA + maxn;
-    int* s_depA = s_cntB + maxn;
-    int* s_depB = s_depA + maxn;
-    int* s_cc = s_depB + maxn;
-    int* s_map = s_cc + 4 * maxn;
-    int* s_a = s_map + 4 * maxn;
-    int* s_b = s_a + maxn;
-    int* s_sidx = s_b + maxn;
-    int* s_split = s_sidx + maxn;
-    int* s_best = s_split + maxn;
-    int* s_scratch = s_best + maxn;
-    int* s_misc = s_scratch + QT_SCR;
-
-    unsigned* qval = P.qt_val + (long long)frame * P.qt_per_frame + g.cand_total_off;
-    unsigned* qcode = P.qt_code + (long long)frame * P.qt_per_frame + g.cand_total_off;
-    int* qnode = P.qt_node + (long long)frame * P.qt_per_frame + g.cand_total_off;
-
-    // ---- A. dense canonical candidate order: cells row-major, row-major inside a cell (ORBextractor.cc:789-829)
-    const int* ccount = P.cell_count + (long long)frame * P.ncells_total + g.cell_first;
-    for (int c = tid; c < g.ncells; c += QT_T) s_pref[c] = ccount[c];
-    for (int r = tid; r < maxn; r += QT_T) s_cntA[r] = 0;
-    __syncthreads();
-    int n = qt_block_exscan(s_pref, g.ncells, s_scratch, tid);
-    n = min(n, g.cand_total_cap);
-    const unsigned* cand = P.cell_cand + (long long)frame * P.cand_slots_per_frame;
+    const int N = g.nfeat;
     const int wave = tid >> 6, lane = tid & 63;
-    for (int c = wave; c < g.ncells; c += QT_T / 64) {
-        const int start = s_pref[c];
-        const int cnt = ((c + 1 < g.ncells) ? s_pref[c + 1] : n) - start;
-        const int slot = P.cells[g.cell_first + c].cand_idx;
-        for (int r = lane; r < cnt; r += 64) {
-            const unsigned v = cand[slot + r];
-            const int x = v & 0xfff, y = (v >> 12) & 0xfff;
-            int root = __float2int_rz(__fdiv_rn((float)x, g.hX));                    // vpIniNodes[kp.pt.x/hX]  (:569)
-            root = min(max(root, 0), g.nIni - 1);
-            int ULx = __float2int_rz(__fmul_rn(g.hX, (float)root)), URx = __float2int_rz(__fmul_rn(g.hX, (float)(root + 1)));   // :555-556
-            int ULy = 0, BRy = g.maxBorderY - ORBHIP_EDGE;
-            unsigned code = 0;
+    // ---- A. dense canonical candidate order: cells row-major, row-major inside a cell (ORBextractor.cc:789-829).
+    //      One thread per candidate: its cell is found by bisection on the per-cell prefix sums.
+    const unsigned* cand = P.cell_cand + (long long)frame * P.cand_slots_per_frame;
+    for (int idx = tid; idx < n; idx += QT_T) {
+        int lo = 0, hi = g.ncells - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (L.pref[mid] <= idx) lo = mid; else hi = mid - 1; }
+        const unsigned v = cand[L.slot[lo] + (idx - L.pref[lo])];
+        const int x = v & 0xfff, y = (v >> 12) & 0xfff;
+        int root = __float2int_rz(__fdiv_rn((float)x, g.hX));                    // vpIniNodes[kp.pt.x/hX]  (:569)
+        root = min(max(root, 0), g.nIni - 1);
+        int ULx = __float2int_rz(__fmul_rn(g.hX, (float)root)), URx = __float2int_rz(__fmul_rn(g.hX, (float)(root + 1)));   // :555-556
+        int ULy = 0, BRy = g.maxBorderY - ORBHIP_EDGE;
+        unsigned code = 0;
 #pragma unroll
-            for (int d = 0; d < ORBHIP_QT_DEPTH; d++) {                               // DivideNode :483-526
-                const int mx = ULx + ((URx - ULx + 1) >> 1), my = ULy + ((BRy - ULy + 1) >> 1);
-                const int right = !(x < mx), bottom = !(y < my);
-                code = (code << 2) | (unsigned)(right + 2 * bottom);                  // n1=0 n2=1 n3=2 n4=3
-                if (right) ULx = mx; else URx = mx;
-                if (bottom) ULy = my; else BRy = my;
-            }
-            const int idx = start + r;
-            if (idx < n) { qval[idx] = v; qcode[idx] = code; qnode[idx] = root; atomicAdd(&s_cntA[root], 1); }
+        for (int d = 0; d < ORBHIP_QT_DEPTH; d++) {                               // DivideNode :483-526
+            const int mx = ULx + ((URx - ULx + 1) >> 1), my = ULy + ((BRy - ULy + 1) >> 1);
+            const int right = !(x < mx), bottom = !(y < my);
+            code = (code << 2) | (unsigned)(right + 2 * bottom);                  // n1=0 n2=1 n3=2 n4=3
+            if (right) ULx = mx; else URx = mx;
+            if (bottom) ULy = my; else BRy = my;
         }
+        qval[idx] = v; keys.init(idx, code, root, (int)(v >> 24)); atomicAdd(&L.cntA[root], 1);
     }
     __syncthreads();
     // ---- B. initial list: non-empty roots in order (:552-585)
     if (tid == 0) {
         int m0 = 0;
-        for (int r = 0; r < g.nIni; r++) { const int c = s_cntA[r]; if (c > 0) { s_map[r] = m0; s_cntB[m0] = c; s_depB[m0] = 0; m0++; } else s_map[r] = 0; }
-        s_misc[0] = m0;
+        for (int r = 0; r < g.nIni; r++) { const int c = L.cntA[r]; if (c > 0) { L.map[r] = m0; L.cntB[m0] = c; L.depB[m0] = 0; m0++; } else L.map[r] = 0; }
+        L.misc[0] = m0;
     }
     __syncthreads();
-    int m = s_misc[0];
-    for (int k = tid; k < n; k += QT_T) qnode[k] = s_map[qnode[k]];
-    int* cnt = s_cntB; int* dep = s_depB; int* cnt2 = s_cntA; int* dep2 = s_depA;
+    int m = L.misc[0];
+    for (int k = tid; k < n; k += QT_T) keys.setNode(k, L.map[keys.getNode(k)]);
+    int* cnt = L.cntB; int* dep = L.depB; int* cnt2 = L.cntA; int* dep2 = L.depA;
+    int *s_cc = L.cc, *s_map = L.map, *s_a = L.a, *s_b = L.b, *s_sidx = L.sidx, *s_split = L.split, *s_best = L.best, *s_scratch = L.scratch, *s_misc = L.misc;
     __syncthreads();
 
     // ---- C. passes
@@ -487,8 +484,8 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(ExtractParams P)
         if (tid == 0) { s_misc[1] = 0; s_misc[2] = 0x7fffffff; s_misc[3] = 0; }
         __syncthreads();
         for (int k = tid; k < n; k += QT_T) {
-            const int p = qnode[k];
-            if (cnt[p] > 1) atomicAdd(&s_cc[4 * p + qt_digit(qcode[k], dep[p])], 1);
+            const int p = keys.getNode(k);
+            if (cnt[p] > 1) atomicAdd(&s_cc[4 * p + qt_digit(keys.getCode(k), dep[p])], 1);
         }
         __syncthreads();
         int Ctot, nsplit;
@@ -553,8 +550,8 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(ExtractParams P)
         __syncthreads();
         const int m2 = Ctot + (m - nsplit);
         for (int k = tid; k < n; k += QT_T) {
-            const int p = qnode[k];
-            qnode[k] = s_split[p] ? s_map[4 * p + qt_digit(qcode[k], dep[p])] : s_map[4 * p];
+            const int p = keys.getNode(k);
+            keys.setNode(k, s_split[p] ? s_map[4 * p + qt_digit(keys.getCode(k), dep[p])] : s_map[4 * p]);
         }
         int nexp = 0;
         for (int p = tid; p < m2; p += QT_T) nexp += cnt2[p] > 1;
@@ -572,7 +569,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(ExtractParams P)
     for (int p = tid; p < m; p += QT_T) s_best[p] = 0;
     __syncthreads();
     for (int k = tid; k < n; k += QT_T)
-        atomicMax((unsigned*)&s_best[qnode[k]], (unsigned)((qval[k] >> 24) << 24) | (0xFFFFFFu - (unsigned)k));
+        atomicMax((unsigned*)&s_best[keys.getNode(k)], ((unsigned)keys.getScore(k) << 24) | (0xFFFFFFu - (unsigned)k));
     __syncthreads();
     unsigned* outk = P.lvl_kp + (long long)frame * P.lvl_kp_per_frame + g.kp_off;
     const int mout = min(m, g.kp_cap);
@@ -583,6 +580,39 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(ExtractParams P)
         outk[p] = x | (y << 12) | (v & 0xff000000u);
     }
     if (tid == 0) P.lvl_n[frame * P.nlevels + level] = mout;
+    (void)wave; (void)lane;
+}
+
+__global__ __launch_bounds__(QT_T) void k_quadtree(ExtractParams P)
+{
+    const int level = blockIdx.x, frame = blockIdx.y + P.frame0, tid = threadIdx.x;
+    const LevelGeom g = P.geom[level];
+    const int maxn = P.qt_maxn;
+    HIP_DYNAMIC_SHARED(int, lds)
+    QtLds L;
+    L.pref = lds; L.slot = L.pref + (P.qt_maxcells + 1);
+    L.cntA = L.slot + P.qt_maxcells; L.cntB = L.cntA + maxn; L.depA = L.cntB + maxn; L.depB = L.depA + maxn;
+    L.cc = L.depB + maxn; L.map = L.cc + 4 * maxn; L.a = L.map + 4 * maxn; L.b = L.a + maxn; L.sidx = L.b + maxn; L.split = L.sidx + maxn;
+    L.best = L.split + maxn; L.scratch = L.best + maxn; L.misc = L.scratch + QT_SCR;
+    unsigned* kcode = reinterpret_cast<unsigned*>(L.misc + 16);
+    unsigned short* knode = reinterpret_cast<unsigned short*>(kcode + QT_LDSKEYS);
+    uint8_t* kscore = reinterpret_cast<uint8_t*>(knode + QT_LDSKEYS);
+
+    const int* ccount = P.cell_count + (long long)frame * P.ncells_total + g.cell_first;
+    for (int c = tid; c < g.ncells; c += QT_T) { L.pref[c] = ccount[c]; L.slot[c] = P.cells[g.cell_first + c].cand_idx; }
+    for (int r = tid; r < maxn; r += QT_T) L.cntA[r] = 0;
+    __syncthreads();
+    int n = qt_block_exscan(L.pref, g.ncells, L.scratch, tid);
+    n = min(n, g.cand_total_cap);
+    unsigned* qval = P.qt_val + (long long)frame * P.qt_per_frame + g.cand_total_off;
+    if (n <= QT_LDSKEYS) {
+        QtKeysLds keys; keys.code = kcode; keys.node = knode; keys.score = kscore;
+        qt_replay(P, g, L, keys, qval, n, frame, level, tid);
+    } else {
+        QtKeysHbm keys; keys.code = P.qt_code + (long long)frame * P.qt_per_frame + g.cand_total_off;
+        keys.node = P.qt_node + (long long)frame * P.qt_per_frame + g.cand_total_off; keys.val = qval;
+        qt_replay(P, g, L, keys, qval, n, frame, level, tid);
+    }
 }
 
 void orbhip_launch_quadtree(const ExtractParams& P, int nframes, hipStream_t s)

@@ -250,14 +250,16 @@ __global__ __launch_bounds__(MS_T) void k_match_select(MatchParams M)
     int* s_nc = s_bin + M.lvl0_cap;         // candidate count per level-0 i1
     int* s_off = s_nc + M.lvl0_cap;         // start of its list in s_cand
     int* s_hist = s_off + M.lvl0_cap + 1;   // [HISTO_LENGTH] + misc
-    unsigned* s_cand = reinterpret_cast<unsigned*>(s_hist + ORBHIP_HISTO_LENGTH + 8);
+    float* s_ang1 = reinterpret_cast<float*>(s_hist + ORBHIP_HISTO_LENGTH + 8);   // angle of F1's level-0 keypoint j1
+    float* s_ang2 = s_ang1 + M.lvl0_cap;                                           // angle of F2's keypoint i2
+    unsigned* s_cand = reinterpret_cast<unsigned*>(s_ang2 + M.cap);
     const orbhip_keypoint* kp1 = M.kp1 + (long long)slot * M.cap;
     const orbhip_keypoint* kp2 = M.kp2 + (long long)slot * M.cap;
     int* m12 = M.matches12 + (long long)slot * M.cap;
     float* prev = M.prev + (long long)slot * M.cap * 2;
     const unsigned* cand0 = M.cand + (long long)slot * M.lvl0_cap * M.cand_stride;
-    for (int i = tid; i < n2; i += MS_T) { s_md[i] = IMAX; s_m21[i] = -1; }
-    for (int i = tid; i < n1l; i += MS_T) { s_m12[i] = -1; s_bin[i] = -1; s_nc[i] = M.ncand[(long long)slot * M.lvl0_cap + i]; }
+    for (int i = tid; i < n2; i += MS_T) { s_md[i] = IMAX; s_m21[i] = -1; s_ang2[i] = kp2[i].angle; }
+    for (int i = tid; i < n1l; i += MS_T) { s_m12[i] = -1; s_bin[i] = -1; s_nc[i] = M.ncand[(long long)slot * M.lvl0_cap + i]; s_ang1[i] = kp1[list1 ? list1[i] : i].angle; }
     for (int i = tid; i < ORBHIP_HISTO_LENGTH + 8; i += MS_T) s_hist[i] = 0;
     for (int i = tid; i < n1; i += MS_T) { m12[i] = -1; if (M.prev_from_kp1) { prev[2 * i] = kp1[i].x; prev[2 * i + 1] = kp1[i].y; } }
     __syncthreads();
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(MS_T) void k_match_select(MatchParams M)
                 if (old >= 0) s_m12[old] = -1;
                 s_m12[j1] = bidx; s_m21[bidx] = j1; s_md[bidx] = best;
                 if (M.check_ori) {
-                    float rot = __fsub_rn(kp1[list1 ? list1[j1] : j1].angle, kp2[bidx].angle);
+                    float rot = __fsub_rn(s_ang1[j1], s_ang2[bidx]);
                     if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
                     int bin = (int)roundf(__fmul_rn(rot, factor));
                     if (bin == ORBHIP_HISTO_LENGTH) bin = 0;
@@ -354,6 +356,6 @@ __global__ __launch_bounds__(MS_T) void k_match_select(MatchParams M)
 
 void orbhip_launch_match_select(const MatchParams& M, int nslots, hipStream_t s)
 {
-    const size_t lds = sizeof(int) * ((size_t)2 * M.cap + (size_t)4 * M.lvl0_cap + 1 + ORBHIP_HISTO_LENGTH + 8 + MS_CANDCAP);
+    const size_t lds = sizeof(int) * ((size_t)3 * M.cap + (size_t)5 * M.lvl0_cap + 1 + ORBHIP_HISTO_LENGTH + 8 + MS_CANDCAP);
     hipLaunchKernelGGL(k_match_select, dim3(nslots, 1, 1), dim3(MS_T, 1, 1), lds, s, M);
 }

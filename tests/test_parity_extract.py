@@ -39,6 +39,22 @@ def test_extract_bit_exact_with_stages(backend, oracle, w, h, n, seed):
     ex.close()
 
 
+def test_dense_candidates_overflow_lds_keys(backend, oracle):
+    """White noise: > 4096 FAST candidates on level 0, so the quadtree keeps its per-candidate keys in the HBM workspace
+    instead of LDS, and the quadtree is ~40x over-subscribed."""
+    w, h, n = 352, 288, 600
+    img = np.random.default_rng(17).integers(0, 256, (h, w), dtype=np.uint8)
+    ora = oracle.OracleExtractor(n, 1.2, 8, 20, 7)
+    ko, do = ora.extract(img)
+    assert len(ora.candidates(0)) > 4096
+    ex = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, library=backend)
+    kg, dg = ex(img)
+    for l in range(8):
+        assert np.array_equal(ex.candidates(l), ora.candidates(l))
+    _same(kg, dg, ko, do)
+    ex.close()
+
+
 @pytest.mark.parametrize("name", ["zeros", "checkerboard", "ramp", "low_texture", "saturated"])
 def test_degenerate_inputs(backend, oracle, name):
     w, h, n = 320, 240, 400
