@@ -292,7 +292,7 @@ static ExtractParams make_params(orbhip_ctx* c, const uint8_t* d_img0, long long
     P.xtab = c->d_xtab; P.ytab = c->d_ytab; P.pattern = c->d_pattern;
     P.iniTh = c->cfg.ini_th_fast; P.minTh = c->cfg.min_th_fast; P.blur_round_mode = c->cfg.blur_round_mode;
     P.qt_maxn = c->qt_maxn; P.qt_maxcells = c->qt_maxcells;
-    P.fc_pstride = (c->fc_maxpw + 4 + 3) & ~3; P.fc_prows = c->fc_maxph; P.fc_sstride = std::max(c->fc_maxpw - 6, 0) + 2; P.fc_srows = std::max(c->fc_maxph - 6, 0) + 2;
+    P.fc_pstride = (c->fc_maxpw + 8 + 3) & ~3; P.fc_prows = c->fc_maxph; P.fc_sstride = 8 + 4 * ((std::max(c->fc_maxpw - 6, 0) + 3) / 4); P.fc_srows = std::max(c->fc_maxph - 6, 0) + 2;
     P.fc_listcap = std::max(c->fc_maxpw - 6, 0) * std::max(c->fc_maxph - 6, 0);
     return P;
 }

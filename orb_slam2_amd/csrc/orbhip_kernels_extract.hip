@@ -197,47 +197,43 @@ void orbhip_launch_blur(const ExtractParams& P, const int gk[4], int nframes, hi
 //   D. survivors are emitted in row-major order.
 #define FC_WAVES 4
 
-__device__ __forceinline__ void fast_ring(const uint8_t* c, int ps, int r[16])
+typedef unsigned short pku16 __attribute__((vector_size(4)));      // two u16 lanes in one VGPR -> v_pk_min_u16 / v_pk_max_u16
+typedef short pki16 __attribute__((vector_size(4)));
+__device__ __forceinline__ pku16 pmin(pku16 a, pku16 b) { return a < b ? a : b; }
+__device__ __forceinline__ pku16 pmax(pku16 a, pku16 b) { return a > b ? a : b; }
+
+// bytes (I, I+1) of the 12-byte row {w0,w1,w2} as two zero-extended u16 lanes (one v_perm_b32)
+template <int I> __device__ __forceinline__ pku16 row_pair(unsigned w0, unsigned w1, unsigned w2)
 {
-    r[0] = c[3 * ps];       r[1] = c[3 * ps + 1];   r[2] = c[2 * ps + 2];   r[3] = c[ps + 3];
-    r[4] = c[3];            r[5] = c[-ps + 3];      r[6] = c[-2 * ps + 2];  r[7] = c[-3 * ps + 1];
-    r[8] = c[-3 * ps];      r[9] = c[-3 * ps - 1];  r[10] = c[-2 * ps - 2]; r[11] = c[-ps - 3];
-    r[12] = c[-3];          r[13] = c[ps - 3];      r[14] = c[2 * ps - 2];  r[15] = c[3 * ps - 1];
+    unsigned r;
+    if (I <= 6) r = __builtin_amdgcn_perm(w1, w0, 0x0c000c00u | (unsigned)I | ((unsigned)(I + 1) << 16));
+    else r = __builtin_amdgcn_perm(w2, w1, 0x0c000c00u | (unsigned)(I - 4) | ((unsigned)(I - 3) << 16));
+    return (pku16)r;
 }
-__device__ __forceinline__ bool has9(unsigned m)        // 16-bit circular mask contains 9 consecutive ones
+
+// Intrinsic FAST score of two horizontally adjacent pixels.  With ring values R_k and centre C:
+//   best dark margin   = max_arcs min_k (C - R_k) = C - min_arcs max_k R_k
+//   best bright margin = max_arcs min_k (R_k - C) = max_arcs min_k R_k - C
+// so only u8 min / max of ring values are needed (no per-element subtraction).  The 16 nine-element circular windows
+// come from prefix / suffix minima of the two 8-element blocks: win[i] = op(suffix[i], prefix[(i+8)&15]).
+__device__ __forceinline__ pki16 fast_score_pair(const pku16 r[16], pku16 c)
 {
-    m |= m << 16;
-    unsigned a = m & (m >> 1); a &= a >> 2; a &= a >> 4; a &= m >> 8;
-    return (a & 0xffffu) != 0;
-}
-__device__ __forceinline__ bool fast_is_corner(const uint8_t* c, int ps, int t)
-{
-    int r[16]; fast_ring(c, ps, r);
-    const int lo = (int)c[0] - t, hi = (int)c[0] + t;
-    unsigned dm = 0, bm = 0;
+    pku16 pn[16], sn[16], px[16], sx[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) { dm |= (unsigned)(r[k] < lo) << k; bm |= (unsigned)(r[k] > hi) << k; }
-    return has9(dm) || has9(bm);
-}
-__device__ __forceinline__ int fast_score16(const uint8_t* c, int ps)
-{
-    int d[16]; fast_ring(c, ps, d);
-    const int v = c[0];
+    for (int b = 0; b < 16; b += 8) {
+        pn[b] = r[b]; px[b] = r[b]; sn[b + 7] = r[b + 7]; sx[b + 7] = r[b + 7];
 #pragma unroll
-    for (int i = 0; i < 16; i++) d[i] = v - d[i];
-    int lo2[16], hi2[16], lo4[16], hi4[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) { lo2[i] = min(d[i], d[(i + 1) & 15]); hi2[i] = max(d[i], d[(i + 1) & 15]); }
-#pragma unroll
-    for (int i = 0; i < 16; i++) { lo4[i] = min(lo2[i], lo2[(i + 2) & 15]); hi4[i] = max(hi2[i], hi2[(i + 2) & 15]); }
-    int best_dark = -256, best_bright = 256;       // max_s min_arc d   and   min_s max_arc d
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const int lo9 = min(min(lo4[i], lo4[(i + 4) & 15]), d[(i + 8) & 15]);
-        const int hi9 = max(max(hi4[i], hi4[(i + 4) & 15]), d[(i + 8) & 15]);
-        best_dark = max(best_dark, lo9); best_bright = min(best_bright, hi9);
+        for (int i = 1; i < 8; i++) {
+            pn[b + i] = pmin(pn[b + i - 1], r[b + i]); px[b + i] = pmax(px[b + i - 1], r[b + i]);
+            sn[b + 7 - i] = pmin(sn[b + 8 - i], r[b + 7 - i]); sx[b + 7 - i] = pmax(sx[b + 8 - i], r[b + 7 - i]);
+        }
     }
-    return max(best_dark, -best_bright) - 1;
+    pku16 lo = pmax(sx[0], px[8]), hi = pmin(sn[0], pn[8]);         // min over arcs of the arc maximum / max over arcs of the arc minimum
+#pragma unroll
+    for (int i = 1; i < 16; i++) { lo = pmin(lo, pmax(sx[i], px[(i + 8) & 15])); hi = pmax(hi, pmin(sn[i], pn[(i + 8) & 15])); }
+    const pki16 dark = (pki16)c - (pki16)lo, bright = (pki16)hi - (pki16)c;
+    const pki16 one = {1, 1};
+    return (dark > bright ? dark : bright) - one;
 }
 
 __host__ __device__ __forceinline__ int fc_wave_bytes(int pstride, int prows, int sstride, int srows, int listcap)
@@ -247,7 +243,7 @@ __host__ __device__ __forceinline__ int fc_wave_bytes(int pstride, int prows, in
 
 __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
 {
-    HIP_DYNAMIC_SHARED(uint8_t, fc_lds)
+    HIP_DYNAMIC_SHARED(unsigned, fc_lds)
     __shared__ unsigned long long s_mini[FC_WAVES][64], s_mmin[FC_WAVES][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, frame = blockIdx.y + P.frame0;
     const int cell_id = blockIdx.x * FC_WAVES + wave;
@@ -257,23 +253,27 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
     const int pw = cd.maxX - cd.iniX, ph = cd.maxY - cd.iniY;       // sub-image
     const int cw = pw - 6, ch = ph - 6;                              // examined interior (rows/cols 3 .. n-4)
     const bool work = active && !cd.skipped && cw > 0 && ch > 0;
-    const int PS = P.fc_pstride, SS = P.fc_sstride;
-    uint8_t* wbase = fc_lds + wave * fc_wave_bytes(PS, P.fc_prows, SS, P.fc_srows, P.fc_listcap);
-    uint8_t* patch = wbase;
-    uint8_t* score = wbase + ((PS * P.fc_prows + 15) & ~15);
+    const int PS = P.fc_pstride, SS = P.fc_sstride;                  // byte strides, multiples of 4
+    uint8_t* wbase = reinterpret_cast<uint8_t*>(fc_lds) + wave * fc_wave_bytes(PS, P.fc_prows, SS, P.fc_srows, P.fc_listcap);
+    uint8_t* patch = wbase;                                          // patch column 0 is 4-byte aligned
+    uint8_t* score = wbase + ((PS * P.fc_prows + 15) & ~15);         // interior (x, y) at score[(y+1)*SS + 4 + x]; zero ring around it
     unsigned short* list = reinterpret_cast<unsigned short*>(score + ((SS * P.fc_srows + 15) & ~15));
+    const int ng = (cw + 3) >> 2;                                    // 4-pixel groups per interior row
     if (work) {
         int spitch; const uint8_t* src = level_src(P, frame, cd.level, spitch);
         src += (long long)cd.iniY * spitch + cd.iniX;
+        const int nd = (pw + 3) >> 2;
         if (((((unsigned long long)src - cd.iniX) | (unsigned long long)spitch) & 3ull) == 0) {
-            const int shift = cd.iniX & 3, nd = (shift + pw + 3) >> 2;      // aligned 32-bit loads, uniform byte shift per row
+            // aligned 32-bit loads, funnel-shifted so that patch column 0 lands on an LDS dword boundary
+            const int sh = 8 * (cd.iniX & 3);
             int r = 0, d = lane;
             while (d >= nd) { d -= nd; r++; }
             while (r < ph) {
-                *reinterpret_cast<unsigned*>(patch + r * PS + 4 * d) = *reinterpret_cast<const unsigned*>(src - shift + (long long)r * spitch + 4 * d);
+                const unsigned* gp = reinterpret_cast<const unsigned*>(src - (cd.iniX & 3) + (long long)r * spitch) + d;
+                const unsigned long long two = (unsigned long long)gp[0] | ((unsigned long long)(sh ? gp[1] : 0u) << 32);
+                reinterpret_cast<unsigned*>(patch + r * PS)[d] = (unsigned)(two >> sh);
                 d += 64; while (d >= nd) { d -= nd; r++; }
             }
-            patch += shift;
         } else {
             int r = 0, c = lane;
             while (c >= pw) { c -= pw; r++; }
@@ -282,28 +282,49 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
                 c += 64; while (c >= pw) { c -= pw; r++; }
             }
         }
-        for (int i = lane; i < (((ch + 2) * SS + 3) >> 2); i += 64) reinterpret_cast<unsigned*>(score)[i] = 0;
+        // zero ring of the score map: first / last row, and the left pad dword + right pad dword of every row
+        const int sdw = SS >> 2;
+        for (int i = lane; i < sdw; i += 64) { reinterpret_cast<unsigned*>(score)[i] = 0; reinterpret_cast<unsigned*>(score + (ch + 1) * SS)[i] = 0; }
+        for (int r = lane; r < ch; r += 64) { unsigned* row = reinterpret_cast<unsigned*>(score + (r + 1) * SS); row[0] = 0; row[1 + ng] = 0; }
     }
     __syncthreads();
-    // ---- A. segment test + compaction
-    const int rp = work ? 64 / cw : 1;                                // interior rows handled per wave iteration
-    const int sr = work ? lane / cw : 0, sx = work ? lane - sr * cw : 0;
+    // ---- A. scores of all examined pixels, 4 pixels (two packed pairs) per lane; corners compacted in row-major order
+    const int rp = work ? 64 / ng : 1;                                // interior rows handled per wave iteration
+    const int sr = work ? lane / ng : 0, grp = work ? lane - sr * ng : 0;
     const int iters = work ? (ch + rp - 1) / rp : 0;
     const bool lane_ok = work && sr < rp;
     int ncorn = 0;
     for (int it = 0; it < iters; it++) {
         const int y = it * rp + sr;
-        const bool corner = lane_ok && y < ch && fast_is_corner(&patch[(y + 3) * PS + sx + 3], PS, P.minTh);
-        const unsigned long long m = __ballot(corner);
-        if (corner) list[ncorn + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)((y << 8) | sx);
-        ncorn += __popcll(m);
-    }
-    __syncthreads();
-    // ---- B. scores of the corners
-    for (int i = lane; i < ncorn; i += 64) {
-        const int id = list[i], y = id >> 8, x = id & 0xff;
-        const int sc = fast_score16(&patch[(y + 3) * PS + x + 3], PS);
-        score[(y + 1) * SS + x + 1] = (uint8_t)min(max(sc, 0), 255);      // corner at minTh => minTh <= sc <= 254
+        int sc[4] = {0, 0, 0, 0};
+        if (lane_ok && y < ch) {
+            const unsigned* prow = reinterpret_cast<const unsigned*>(patch + y * PS) + grp;
+            unsigned w[7][3];
+#pragma unroll
+            for (int r = 0; r < 7; r++) { w[r][0] = prow[r * (PS >> 2)]; w[r][1] = prow[r * (PS >> 2) + 1]; w[r][2] = prow[r * (PS >> 2) + 2]; }
+            // ring element k of pixel q sits at row 3+dy_k, byte 3+q+dx_k of the 12-byte row window (circle: ORB/FAST 16-point Bresenham)
+#define FC_RING(Q) { \
+            row_pair<3 + Q + 0>(w[6][0], w[6][1], w[6][2]), row_pair<3 + Q + 1>(w[6][0], w[6][1], w[6][2]), row_pair<3 + Q + 2>(w[5][0], w[5][1], w[5][2]), row_pair<3 + Q + 3>(w[4][0], w[4][1], w[4][2]), \
+            row_pair<3 + Q + 3>(w[3][0], w[3][1], w[3][2]), row_pair<3 + Q + 3>(w[2][0], w[2][1], w[2][2]), row_pair<3 + Q + 2>(w[1][0], w[1][1], w[1][2]), row_pair<3 + Q + 1>(w[0][0], w[0][1], w[0][2]), \
+            row_pair<3 + Q + 0>(w[0][0], w[0][1], w[0][2]), row_pair<3 + Q - 1>(w[0][0], w[0][1], w[0][2]), row_pair<3 + Q - 2>(w[1][0], w[1][1], w[1][2]), row_pair<3 + Q - 3>(w[2][0], w[2][1], w[2][2]), \
+            row_pair<3 + Q - 3>(w[3][0], w[3][1], w[3][2]), row_pair<3 + Q - 3>(w[4][0], w[4][1], w[4][2]), row_pair<3 + Q - 2>(w[5][0], w[5][1], w[5][2]), row_pair<3 + Q - 1>(w[6][0], w[6][1], w[6][2]) }
+            const pku16 ra[16] = FC_RING(0);
+            const pku16 rb[16] = FC_RING(2);
+#undef FC_RING
+            const pki16 sa = fast_score_pair(ra, row_pair<3>(w[3][0], w[3][1], w[3][2]));
+            const pki16 sb = fast_score_pair(rb, row_pair<5>(w[3][0], w[3][1], w[3][2]));
+            const int x0 = 4 * grp;
+            sc[0] = sa[0]; sc[1] = sa[1]; sc[2] = sb[0]; sc[3] = sb[1];
+#pragma unroll
+            for (int q = 0; q < 4; q++) if (sc[q] < P.minTh || x0 + q >= cw) sc[q] = 0;          // corner at minThFAST  <=>  score >= minThFAST
+            *reinterpret_cast<unsigned*>(score + (y + 1) * SS + 4 + x0) = (unsigned)sc[0] | ((unsigned)sc[1] << 8) | ((unsigned)sc[2] << 16) | ((unsigned)sc[3] << 24);
+        }
+        const unsigned long long m0 = __ballot(sc[0] > 0), m1 = __ballot(sc[1] > 0), m2 = __ballot(sc[2] > 0), m3 = __ballot(sc[3] > 0);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        int pos = ncorn + __popcll(m0 & below) + __popcll(m1 & below) + __popcll(m2 & below) + __popcll(m3 & below);
+#pragma unroll
+        for (int q = 0; q < 4; q++) if (sc[q] > 0) list[pos++] = (unsigned short)((y << 8) | (4 * grp + q));
+        ncorn += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
     }
     __syncthreads();
     // ---- C. non-max suppression inside the cell
@@ -314,9 +335,9 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
         bool keep = false; int sc = 0;
         if (i < ncorn) {
             const int id = list[i];
-            const uint8_t* q = &score[((id >> 8) + 1) * SS + (id & 0xff) + 1];
+            const uint8_t* q = &score[((id >> 8) + 1) * SS + (id & 0xff) + 4];
             sc = q[0];
-            keep = sc > 0 && sc > q[-1] && sc > q[1] && sc > q[-SS - 1] && sc > q[-SS] && sc > q[-SS + 1] &&
+            keep = sc > q[-1] && sc > q[1] && sc > q[-SS - 1] && sc > q[-SS] && sc > q[-SS + 1] &&
                    sc > q[SS - 1] && sc > q[SS] && sc > q[SS + 1];
         }
         const unsigned long long mmin = __ballot(keep), mini = __ballot(keep && sc >= P.iniTh);
@@ -335,7 +356,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
         if ((m >> lane) & 1ull) {
             const int id = list[cb * 64 + lane], y = id >> 8, x = id & 0xff;
             const int rank = base + __popcll(m & ((1ull << lane) - 1ull));
-            const int sc = score[(y + 1) * SS + x + 1];
+            const int sc = score[(y + 1) * SS + x + 4];
             // FAST reports cell-local (x, y); the reference adds (j*wCell, i*hCell)  (ORBextractor.cc:822-823)
             const unsigned px = (unsigned)(x + 3 + cd.shiftX), py = (unsigned)(y + 3 + cd.shiftY);
             if (rank < cd.cand_cap) out[rank] = px | (py << 12) | ((unsigned)sc << 24);

@@ -142,6 +142,13 @@ inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
 
+// v_perm_b32: selector bytes 0-3 pick bytes of s1, 4-7 bytes of s0, 0x0c -> 0x00, >= 0x0d -> 0xff
+inline unsigned __builtin_amdgcn_perm(unsigned s0, unsigned s1, unsigned sel) {
+    const unsigned long long src = ((unsigned long long)s0 << 32) | s1; unsigned r = 0;
+    for (int i = 0; i < 4; i++) { const unsigned c = (sel >> (8 * i)) & 0xff; unsigned b;
+        if (c <= 7) b = (unsigned)(src >> (8 * c)) & 0xff; else if (c == 0x0c) b = 0; else b = 0xff; r |= b << (8 * i); }
+    return r;
+}
 // atomics (single OS thread: plain read-modify-write is atomic w.r.t. fibers)
 template <typename T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <typename T> inline T atomicSub(T* p, T v) { T o = *p; *p = o - v; return o; }
