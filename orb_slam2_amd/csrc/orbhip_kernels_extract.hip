@@ -196,6 +196,7 @@ void orbhip_launch_blur(const ExtractParams& P, const int gk[4], int nframes, hi
 //      interior count as 0, exactly like FAST on the cell sub-image);
 //   D. survivors are emitted in row-major order.
 #define FC_WAVES 4
+#define FC_LD 8                        // patch dwords a lane keeps in flight
 
 typedef unsigned short pku16 __attribute__((vector_size(4)));      // two u16 lanes in one VGPR -> v_pk_min_u16 / v_pk_max_u16
 typedef short pki16 __attribute__((vector_size(4)));
@@ -264,15 +265,24 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
         src += (long long)cd.iniY * spitch + cd.iniX;
         const int nd = (pw + 3) >> 2;
         if (((((unsigned long long)src - cd.iniX) | (unsigned long long)spitch) & 3ull) == 0) {
-            // aligned 32-bit loads, funnel-shifted so that patch column 0 lands on an LDS dword boundary
-            const int sh = 8 * (cd.iniX & 3);
+            // aligned 32-bit loads, funnel-shifted so that patch column 0 lands on an LDS dword boundary; FC_LD loads are
+            // put in flight before the first LDS write (one memory latency per batch instead of one per dword)
+            const int sa = cd.iniX & 3, sh = 8 * sa;
+            const uint8_t* gbase = src - sa;
             int r = 0, d = lane;
             while (d >= nd) { d -= nd; r++; }
             while (r < ph) {
-                const unsigned* gp = reinterpret_cast<const unsigned*>(src - (cd.iniX & 3) + (long long)r * spitch) + d;
-                const unsigned long long two = (unsigned long long)gp[0] | ((unsigned long long)(sh ? gp[1] : 0u) << 32);
-                reinterpret_cast<unsigned*>(patch + r * PS)[d] = (unsigned)(two >> sh);
-                d += 64; while (d >= nd) { d -= nd; r++; }
+                int rr[FC_LD], dd[FC_LD]; unsigned lo[FC_LD], hi[FC_LD];
+#pragma unroll
+                for (int k = 0; k < FC_LD; k++) { rr[k] = r; dd[k] = d; d += 64; while (d >= nd) { d -= nd; r++; } }
+#pragma unroll
+                for (int k = 0; k < FC_LD; k++) {
+                    lo[k] = 0; hi[k] = 0;
+                    if (rr[k] < ph) { const unsigned* gp = reinterpret_cast<const unsigned*>(gbase + (long long)rr[k] * spitch) + dd[k]; lo[k] = gp[0]; if (sa) hi[k] = gp[1]; }
+                }
+#pragma unroll
+                for (int k = 0; k < FC_LD; k++)
+                    if (rr[k] < ph) reinterpret_cast<unsigned*>(patch + rr[k] * PS)[dd[k]] = (unsigned)((((unsigned long long)hi[k] << 32) | lo[k]) >> sh);
             }
         } else {
             int r = 0, c = lane;
@@ -693,8 +703,11 @@ __device__ __forceinline__ void dev_sincosf(float y, float* sinp, float* cosp)
 }
 
 #define DS_WAVES 4
+#define DS_WROWS 37                    // blurred window rows: pattern reach is +-18 after rotation
+#define DS_WDW 11                      // dwords per staged window row (37 bytes + up to 3 bytes of alignment slack)
 __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
 {
+    __shared__ unsigned s_win[DS_WAVES][DS_WROWS * DS_WDW];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, frame = blockIdx.y + P.frame0;
     const int slot = blockIdx.x * DS_WAVES + wave;
     if (slot >= P.lvl_kp_per_frame) return;
@@ -712,44 +725,65 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
     const unsigned v = P.lvl_kp[(long long)frame * P.lvl_kp_per_frame + slot];
     const int cx = v & 0xfff, cy = (v >> 12) & 0xfff, sc = v >> 24;
 
-    // ---- IC_Angle (ORBextractor.cc:77-104): lanes 0..61 -> row v = lane/2 - 15, left/right half
+    // ---- all global loads of this keypoint are issued up-front
+    // (a) rBRIEF pattern of this lane's 4 tests
+    const unsigned* pat = reinterpret_cast<const unsigned*>(P.pattern);
+    unsigned pt[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) pt[r] = pat[r * 64 + lane];
+    // (b) 31x31 orientation patch of the un-blurred level: lane = column u (coalesced rows), two rows per load
     int spitch; const uint8_t* img = level_src(P, frame, level, spitch);
+    const int half = lane >> 5, u = (lane & 31) - 15;              // lanes 0..30 and 32..62 carry columns -15..15
+    const bool col_ok = (lane & 31) < 31;
+    int pxv[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int vr = 2 * k + half - 15;                           // rows -15..16; row 16 (k = 15, half = 1) is unused
+        pxv[k] = (col_ok && vr <= 15) ? img[(long long)(cy + vr) * spitch + cx + u] : 0;
+    }
+    // (c) 37-row window of the blurred level -> LDS with aligned 32-bit loads (keypoints keep >= 19 px from every border)
+    const uint8_t* blv = P.blur + (long long)frame * P.plane_frame_bytes + g.plane_off;
+    const int wx0 = (cx - 18) & ~3;                                 // window byte x of LDS column 0 (level pitch and plane offsets are multiples of 4)
+    unsigned* win = s_win[wave];
+    unsigned wv[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        const int idx = lane + 64 * k, r = idx / DS_WDW, d = idx - r * DS_WDW;
+        wv[k] = (idx < DS_WROWS * DS_WDW) ? *reinterpret_cast<const unsigned*>(blv + (long long)(cy - 18 + r) * g.pitch + wx0 + 4 * d) : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 7; k++) { const int idx = lane + 64 * k; if (idx < DS_WROWS * DS_WDW) win[idx] = wv[k]; }
+
+    // ---- IC_Angle (ORBextractor.cc:77-104): m10 = sum u*I, m01 = sum v*I over the circular patch
     int m10 = 0, m01 = 0;
-    if (lane < 62) {
-        const int vr = (lane >> 1) - 15, av = vr < 0 ? -vr : vr;
-        // umax (ORBextractor.cc:452-469) for HALF_PATCH_SIZE 15
-        const int um = (av <= 3) ? 15 : (av <= 6) ? 14 : (av <= 8) ? 13 : (av == 9) ? 12 : (av == 10) ? 11 : (av == 11) ? 10 : (av == 12) ? 9 : (av == 13) ? 8 : (av == 14) ? 6 : 3;
-        const int ub = (lane & 1) ? 1 : -15;                      // even lane: u = -15..0, odd lane: u = 1..16 (u = 16 masked; still inside the image)
-        const uint8_t* row = img + (long long)(cy + vr) * spitch + cx + ub;
-        int px[16];
+    {
+        const int au = u < 0 ? -u : u;
+        // vmax(|u|): by symmetry of the circle the row limit for column u equals umax[|u|] (ORBextractor.cc:452-469)
+        const int vm = (au <= 3) ? 15 : (au <= 6) ? 14 : (au <= 8) ? 13 : (au == 9) ? 12 : (au == 10) ? 11 : (au == 11) ? 10 : (au == 12) ? 9 : (au == 13) ? 8 : (au == 14) ? 6 : 3;
+        int s = 0, sv = 0;
 #pragma unroll
-        for (int k = 0; k < 16; k++) px[k] = row[k];              // 16 independent loads in flight, one latency
-        int su = 0, s = 0;
-#pragma unroll
-        for (int k = 0; k < 16; k++) { const int u = ub + k; const int p = (u >= -um && u <= um) ? px[k] : 0; su += u * p; s += p; }
-        m10 = su; m01 = vr * s;
+        for (int k = 0; k < 16; k++) { const int vr = 2 * k + half - 15; const int p = (vr >= -vm && vr <= vm) ? pxv[k] : 0; s += p; sv += vr * p; }
+        m10 = u * s; m01 = sv;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) { m10 += __shfl_xor(m10, off); m01 += __shfl_xor(m01, off); }
     const float angle = dev_fast_atan2((float)m01, (float)m10);
 
-    // ---- steered BRIEF (ORBextractor.cc:107-147) on the blurred level
+    // ---- steered BRIEF (ORBextractor.cc:107-147) on the blurred window in LDS
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     float a, b; dev_sincosf(__fmul_rn(angle, factorPI), &b, &a);
-    const uint8_t* bl = P.blur + (long long)frame * P.plane_frame_bytes + g.plane_off + (long long)cy * g.pitch + cx;
+    __syncthreads();                                               // window visible to all lanes of the wave (exited waves do not participate)
+    const uint8_t* w8 = reinterpret_cast<const uint8_t*>(win);
+    const int ox = cx - wx0, oy = 18;                               // keypoint position inside the window
     unsigned long long* dout = reinterpret_cast<unsigned long long*>(P.out_desc + ((long long)frame * P.out_cap + oi) * 32);
-    int t0[4], t1[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {                                  // all 8 gathers issued before the first ballot
-        const signed char* pt = P.pattern + (r * 64 + lane) * 4;
-        const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
-        const int iy0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a))), ix0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-        const int iy1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a))), ix1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        t0[r] = bl[(long long)iy0 * g.pitch + ix0]; t1[r] = bl[(long long)iy1 * g.pitch + ix1];
-    }
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        const unsigned long long bits = __ballot(t0[r] < t1[r]);   // test 64r+lane -> byte (64r+lane)/8, bit lane%8
+        const float x0 = (float)(signed char)(pt[r] & 0xff), y0 = (float)(signed char)((pt[r] >> 8) & 0xff);
+        const float x1 = (float)(signed char)((pt[r] >> 16) & 0xff), y1 = (float)(signed char)(pt[r] >> 24);
+        const int iy0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a))), ix0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+        const int iy1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a))), ix1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+        const int t0 = w8[(oy + iy0) * (DS_WDW * 4) + ox + ix0], t1 = w8[(oy + iy1) * (DS_WDW * 4) + ox + ix1];
+        const unsigned long long bits = __ballot(t0 < t1);       // test 64r+lane -> byte (64r+lane)/8, bit lane%8
         if (lane == 0) dout[r] = bits;
     }
     if (lane == 0) {

@@ -284,27 +284,37 @@ __global__ __launch_bounds__(MS_T) void k_match_select(MatchParams M)
     __syncthreads();
     if (wave != 0) return;
     const float factor = 1.0f / ORBHIP_HISTO_LENGTH;
+    // software pipeline: the list head of keypoint j1+1 (length, offset, first 64 records) is fetched while j1 is processed,
+    // so the only LDS round trip left on the critical path is vMatchedDistance[i2]
+    int nc_n = n1l > 0 ? s_nc[0] : 0, o_n = n1l > 0 ? s_off[0] : 0;
+    unsigned e_n = 0;
+    if (lane < nc_n) e_n = (o_n + nc_n <= MS_CANDCAP) ? s_cand[o_n + lane] : cand0[lane];
     for (int j1 = 0; j1 < n1l; j1++) {
-        const int nc = s_nc[j1];
+        const int nc = nc_n, o = o_n;
+        const unsigned e0 = e_n;
+        if (j1 + 1 < n1l) {
+            nc_n = s_nc[j1 + 1]; o_n = s_off[j1 + 1];
+            e_n = 0;
+            if (lane < nc_n) e_n = (o_n + nc_n <= MS_CANDCAP) ? s_cand[o_n + lane] : cand0[(long long)(j1 + 1) * M.cand_stride + lane];
+        }
         if (nc == 0) continue;
-        const int o = s_off[j1];
         const bool staged = o + nc <= MS_CANDCAP;
         const unsigned* cand = cand0 + (long long)j1 * M.cand_stride;
         int best = IMAX, second = IMAX, bidx = -1;
         for (int cb = 0; cb < nc; cb += 64) {
             const int t = cb + lane;
-            unsigned e = 0;
-            if (t < nc) e = staged ? s_cand[o + t] : cand[t];
+            unsigned e = e0;
+            if (cb > 0) { e = 0; if (t < nc) e = staged ? s_cand[o + t] : cand[t]; }
             const int i2 = (int)(e & 0xFFFFFu), dist = (int)(e >> 20);
             const bool valid = t < nc && !(s_md[i2] <= dist);                    // :444-445
             const unsigned long long V = __ballot(valid);
             if (V == 0) continue;
             const unsigned long long mk = wave_argmin_mask(dist, V);
             const int first = __ffsll((long long)mk) - 1;        // strict '<': the first candidate with the minimum wins (:447-452)
-            const int wmin = __shfl(dist, first), ci = __shfl(i2, first);
+            const int wmin = __builtin_amdgcn_readlane(dist, first), ci = __builtin_amdgcn_readlane(i2, first);
             const unsigned long long V2 = V & ~(1ull << first);
             int wsec = IMAX;
-            if (V2) { const unsigned long long mk2 = wave_argmin_mask(dist, V2); wsec = __shfl(dist, __ffsll((long long)mk2) - 1); }
+            if (V2) { const unsigned long long mk2 = wave_argmin_mask(dist, V2); wsec = __builtin_amdgcn_readlane(dist, __ffsll((long long)mk2) - 1); }
             if (wmin < best) { second = min(best, wsec); best = wmin; bidx = ci; } else second = min(second, wmin);
         }
         if (best <= ORBHIP_TH_LOW && (float)best < __fmul_rn((float)second, M.nnratio)) {      // :459-461

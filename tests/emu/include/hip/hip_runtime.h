@@ -135,6 +135,7 @@ template <typename T> inline T __shfl_down(T v, unsigned d, int width = 64) { in
 template <typename T> inline T __shfl_up(T v, unsigned d, int width = 64) { int l = __lane_id(); int s = l - (int)d; if (s < 0 || (s & ~(width - 1)) != (l & ~(width - 1))) s = l; return hipemu_shfl(v, s); }
 template <typename T> inline T __shfl_xor(T v, int m, int width = 64) { int l = __lane_id(); int s = l ^ m; if ((s & ~(width - 1)) != (l & ~(width - 1))) s = l; return hipemu_shfl(v, s); }
 
+inline int __builtin_amdgcn_readlane(int v, int srcLane) { return hipemu_shfl(v, srcLane); }     // v_readlane_b32: uniform source lane
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffs(int v) { return __builtin_ffs(v); }
