@@ -52,7 +52,7 @@ struct TileDesc { short level, x0, y0, pad; };
 
 struct ExtractParams {
     const LevelGeom* geom; int nlevels;
-    int frame0;                                                            // first frame (camera slot) of this launch group
+    int frame0, nframes;                                                   // first frame (camera slot) and frame count of this launch group
     const uint8_t* img0; long long img0_frame_stride; int img0_pitch;      // level-0 source
     uint8_t* pyr; uint8_t* blur; long long plane_frame_bytes;
     const CellDesc* cells; int ncells_total;

@@ -16,6 +16,17 @@
 
 #define WAVE 64
 
+// XCD-aware block -> (tile, frame) map.  The dispatcher places consecutive workgroup ids round-robin over the 8 XCDs
+// (observed, used for speed only): giving all workgroups of frame f ids congruent to f mod 8 keeps that frame's planes
+// (~3 MB) in ONE XCD's 4 MiB L2 instead of being re-fetched from HBM by all eight.
+__device__ __forceinline__ bool xcd_frame_map(int nb, int nframes, int& tile, int& frame)
+{
+    const int id = blockIdx.x, j = id >> 3, fg = j / nb;
+    tile = j - fg * nb; frame = fg * 8 + (id & 7);
+    return frame < nframes;
+}
+static inline unsigned xcd_grid(int nb, int nframes) { return (unsigned)nb * 8u * (unsigned)((nframes + 7) / 8); }
+
 __device__ __forceinline__ const uint8_t* level_src(const ExtractParams& P, int frame, int level, int& pitch)
 {
     if (level == 0) { pitch = P.img0_pitch; return P.img0 + (long long)frame * P.img0_frame_stride; }
@@ -36,9 +47,12 @@ __device__ __forceinline__ const uint8_t* level_src(const ExtractParams& P, int 
 __global__ __launch_bounds__(256) void k_pyramid_level(ExtractParams P, int level)
 {
     const LevelGeom g = P.geom[level];
-    const int frame = blockIdx.z + P.frame0;
+    const int gx = (g.w + PYR_TW - 1) / PYR_TW, gy = (g.h + PYR_TH - 1) / PYR_TH;
+    int tile, frame;
+    if (!xcd_frame_map(gx * gy, P.nframes, tile, frame)) return;
+    frame += P.frame0;
     const int tid = threadIdx.y * 64 + threadIdx.x;
-    const int x0 = blockIdx.x * PYR_TW, y0 = blockIdx.y * PYR_TH;
+    const int x0 = (tile % gx) * PYR_TW, y0 = (tile / gx) * PYR_TH;
     int spitch; const uint8_t* src = level_src(P, frame, level - 1, spitch);
     __shared__ unsigned s_t[PYR_SROWS * PYR_SDW];
     const int2* xt = P.xtab + g.xtab_off; const int2* yt = P.ytab + g.ytab_off;
@@ -49,13 +63,19 @@ __global__ __launch_bounds__(256) void k_pyramid_level(ExtractParams P, int leve
     const bool fits = ndw <= PYR_SDW && nrows <= PYR_SROWS;                                  // always true for scale factors >= ~1.05
     const bool aligned = ((((unsigned long long)src) | (unsigned long long)spitch) & 3ull) == 0;
     if (fits) {
-        for (int i = tid; i < nrows * ndw; i += 256) {
-            const int r = i / ndw, d = i - r * ndw;
-            const uint8_t* row = src + (long long)(sya + r) * spitch + sxa + 4 * d;
-            unsigned v;
-            if (aligned && sxa + 4 * d + 3 < g.src_w) v = *reinterpret_cast<const unsigned*>(row);
-            else { v = 0; for (int k = 0; k < 4; k++) if (sxa + 4 * d + k < g.src_w) v |= (unsigned)row[k] << (8 * k); }
-            s_t[r * PYR_SDW + d] = v;
+        unsigned v[4]; bool edge[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = tid + 256 * k, r = i / ndw, d = i - r * ndw;
+            const bool in = i < nrows * ndw;
+            edge[k] = in && !(aligned && sxa + 4 * d + 3 < g.src_w);
+            v[k] = (in && !edge[k]) ? *reinterpret_cast<const unsigned*>(src + (long long)(sya + r) * spitch + sxa + 4 * d) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = tid + 256 * k, r = i / ndw, d = i - r * ndw;
+            if (edge[k]) { const uint8_t* row = src + (long long)(sya + r) * spitch + sxa + 4 * d; for (int q = 0; q < 4; q++) if (sxa + 4 * d + q < g.src_w) v[k] |= (unsigned)row[q] << (8 * q); }
+            if (i < nrows * ndw) s_t[r * PYR_SDW + d] = v[k];
         }
     }
     __syncthreads();
@@ -96,8 +116,9 @@ __global__ __launch_bounds__(256) void k_pyramid_level(ExtractParams P, int leve
 
 void orbhip_launch_pyramid_level(const ExtractParams& P, int level, int w, int h, int nframes, hipStream_t s)
 {
-    dim3 grid((w + PYR_TW - 1) / PYR_TW, (h + PYR_TH - 1) / PYR_TH, nframes), block(64, 4, 1);
-    hipLaunchKernelGGL(k_pyramid_level, grid, block, 0, s, P, level);
+    ExtractParams Q = P; Q.nframes = nframes;
+    dim3 grid(xcd_grid(((w + PYR_TW - 1) / PYR_TW) * ((h + PYR_TH - 1) / PYR_TH), nframes), 1, 1), block(64, 4, 1);
+    hipLaunchKernelGGL(k_pyramid_level, grid, block, 0, s, Q, level);
 }
 
 // ------------------------------------------------------------------------------------------------ blur
@@ -117,22 +138,37 @@ struct BlurK { int k0, k1, k2, k3; };
 // 4 coalesced 32-bit stores.
 __global__ __launch_bounds__(256) void k_blur(ExtractParams P, BlurK K)
 {
-    const TileDesc t = P.blur_tiles[blockIdx.x];
-    const int frame = blockIdx.y + P.frame0, tid = threadIdx.x;
+    int tile, frame;
+    if (!xcd_frame_map(P.nblur_tiles, P.nframes, tile, frame)) return;
+    frame += P.frame0;
+    const TileDesc t = P.blur_tiles[tile];
+    const int tid = threadIdx.x;
     const LevelGeom g = P.geom[t.level];
     int spitch; const uint8_t* src = level_src(P, frame, t.level, spitch);
     __shared__ unsigned s_src[(BLUR_TH + 6) * (BLUR_SROW / 4)];
     __shared__ uint2 s_h[(BLUR_TH + 6) * (BLUR_TW / 4)];
     const bool aligned = ((((unsigned long long)src) | (unsigned long long)spitch) & 3ull) == 0;
-    for (int i = tid; i < (BLUR_TH + 6) * 34; i += 256) {
-        const int r = i / 34, d = i - r * 34;
-        const int gy = reflect101_clamped(t.y0 - 3 + r, g.h), gx = t.x0 - 4 + 4 * d;
-        const uint8_t* row = src + (long long)gy * spitch;
-        unsigned v;
-        if (aligned && gx >= 0 && gx + 3 < g.w) v = *reinterpret_cast<const unsigned*>(row + gx);
-        else v = (unsigned)row[reflect101_clamped(gx, g.w)] | ((unsigned)row[reflect101_clamped(gx + 1, g.w)] << 8) |
-                 ((unsigned)row[reflect101_clamped(gx + 2, g.w)] << 16) | ((unsigned)row[reflect101_clamped(gx + 3, g.w)] << 24);
-        s_src[r * (BLUR_SROW / 4) + d] = v;
+    {   // (38 x 34) dwords, 6 per thread, all loads in flight before the first LDS write; border dwords are patched afterwards
+        unsigned v[6]; bool edge[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int i = tid + 256 * k, r = i / 34, d = i - r * 34;
+            const int gy = reflect101_clamped(t.y0 - 3 + r, g.h), gx = t.x0 - 4 + 4 * d;
+            const bool in = i < (BLUR_TH + 6) * 34;
+            edge[k] = in && !(aligned && gx >= 0 && gx + 3 < g.w);
+            v[k] = (in && !edge[k]) ? *reinterpret_cast<const unsigned*>(src + (long long)gy * spitch + gx) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int i = tid + 256 * k, r = i / 34, d = i - r * 34;
+            if (edge[k]) {
+                const int gy = reflect101_clamped(t.y0 - 3 + r, g.h), gx = t.x0 - 4 + 4 * d;
+                const uint8_t* row = src + (long long)gy * spitch;
+                v[k] = (unsigned)row[reflect101_clamped(gx, g.w)] | ((unsigned)row[reflect101_clamped(gx + 1, g.w)] << 8) |
+                       ((unsigned)row[reflect101_clamped(gx + 2, g.w)] << 16) | ((unsigned)row[reflect101_clamped(gx + 3, g.w)] << 24);
+            }
+            if (i < (BLUR_TH + 6) * 34) s_src[r * (BLUR_SROW / 4) + d] = v[k];
+        }
     }
     __syncthreads();
     for (int i = tid; i < (BLUR_TH + 6) * 32; i += 256) {
@@ -180,7 +216,8 @@ __global__ __launch_bounds__(256) void k_blur(ExtractParams P, BlurK K)
 void orbhip_launch_blur(const ExtractParams& P, const int gk[4], int nframes, hipStream_t s)
 {
     BlurK K; K.k0 = gk[0]; K.k1 = gk[1]; K.k2 = gk[2]; K.k3 = gk[3];
-    hipLaunchKernelGGL(k_blur, dim3(P.nblur_tiles, nframes, 1), dim3(256, 1, 1), 0, s, P, K);
+    ExtractParams Q = P; Q.nframes = nframes;
+    hipLaunchKernelGGL(k_blur, dim3(xcd_grid(P.nblur_tiles, nframes), 1, 1), dim3(256, 1, 1), 0, s, Q, K);
 }
 
 // ------------------------------------------------------------------------------------------------ FAST per cell
@@ -246,8 +283,11 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
 {
     HIP_DYNAMIC_SHARED(unsigned, fc_lds)
     __shared__ unsigned long long s_mini[FC_WAVES][64], s_mmin[FC_WAVES][64];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, frame = blockIdx.y + P.frame0;
-    const int cell_id = blockIdx.x * FC_WAVES + wave;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int tile, frame;
+    if (!xcd_frame_map((P.ncells_total + FC_WAVES - 1) / FC_WAVES, P.nframes, tile, frame)) return;
+    frame += P.frame0;
+    const int cell_id = tile * FC_WAVES + wave;
     const bool active = cell_id < P.ncells_total;
     CellDesc cd; cd.skipped = 1; cd.level = 0; cd.iniX = cd.iniY = cd.maxX = cd.maxY = 0; cd.shiftX = cd.shiftY = 0; cd.cand_idx = 0; cd.cand_cap = 0;
     if (active) cd = P.cells[cell_id];
@@ -379,7 +419,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
 void orbhip_launch_fast_cells(const ExtractParams& P, int nframes, hipStream_t s)
 {
     const size_t lds = (size_t)FC_WAVES * fc_wave_bytes(P.fc_pstride, P.fc_prows, P.fc_sstride, P.fc_srows, P.fc_listcap);
-    hipLaunchKernelGGL(k_fast_cells, dim3((P.ncells_total + FC_WAVES - 1) / FC_WAVES, nframes, 1), dim3(256, 1, 1), lds, s, P);
+    ExtractParams Q = P; Q.nframes = nframes;
+    hipLaunchKernelGGL(k_fast_cells, dim3(xcd_grid((P.ncells_total + FC_WAVES - 1) / FC_WAVES, nframes), 1, 1), dim3(256, 1, 1), lds, s, Q);
 }
 
 // ------------------------------------------------------------------------------------------------ quadtree
@@ -616,7 +657,10 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
 
 __global__ __launch_bounds__(QT_T) void k_quadtree(ExtractParams P)
 {
-    const int level = blockIdx.x, frame = blockIdx.y + P.frame0, tid = threadIdx.x;
+    int level, frame;
+    if (!xcd_frame_map(P.nlevels, P.nframes, level, frame)) return;
+    frame += P.frame0;
+    const int tid = threadIdx.x;
     const LevelGeom g = P.geom[level];
     const int maxn = P.qt_maxn;
     HIP_DYNAMIC_SHARED(int, lds)
@@ -648,7 +692,8 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(ExtractParams P)
 
 void orbhip_launch_quadtree(const ExtractParams& P, int nframes, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_quadtree, dim3(P.nlevels, nframes, 1), dim3(QT_T, 1, 1), orbhip_quadtree_lds_bytes(P.qt_maxn, P.qt_maxcells), s, P);
+    ExtractParams Q = P; Q.nframes = nframes;
+    hipLaunchKernelGGL(k_quadtree, dim3(xcd_grid(P.nlevels, nframes), 1, 1), dim3(QT_T, 1, 1), orbhip_quadtree_lds_bytes(P.qt_maxn, P.qt_maxcells), s, Q);
 }
 
 // ------------------------------------------------------------------------------------------------ describe
@@ -708,8 +753,11 @@ __device__ __forceinline__ void dev_sincosf(float y, float* sinp, float* cosp)
 __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
 {
     __shared__ unsigned s_win[DS_WAVES][DS_WROWS * DS_WDW];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, frame = blockIdx.y + P.frame0;
-    const int slot = blockIdx.x * DS_WAVES + wave;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int tile, frame;
+    if (!xcd_frame_map((P.lvl_kp_per_frame + DS_WAVES - 1) / DS_WAVES, P.nframes, tile, frame)) return;
+    frame += P.frame0;
+    const int slot = tile * DS_WAVES + wave;
     if (slot >= P.lvl_kp_per_frame) return;
     int level = 0;
     for (int l = 1; l < P.nlevels; l++) if (slot >= P.geom[l].kp_off) level = l;
@@ -796,5 +844,6 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
 
 void orbhip_launch_describe(const ExtractParams& P, int nframes, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_describe, dim3((P.lvl_kp_per_frame + DS_WAVES - 1) / DS_WAVES, nframes, 1), dim3(256, 1, 1), 0, s, P);
+    ExtractParams Q = P; Q.nframes = nframes;
+    hipLaunchKernelGGL(k_describe, dim3(xcd_grid((P.lvl_kp_per_frame + DS_WAVES - 1) / DS_WAVES, nframes), 1, 1), dim3(256, 1, 1), 0, s, Q);
 }
