@@ -47,7 +47,9 @@ struct orbhip_ctx {
     LevelGeom* d_geom = nullptr; CellDesc* d_cells = nullptr; TileDesc* d_tiles = nullptr; int2* d_xtab = nullptr; int2* d_ytab = nullptr; signed char* d_pattern = nullptr;
     uint8_t* d_pyr = nullptr; uint8_t* d_blur = nullptr; int* d_cell_count = nullptr; unsigned* d_cell_cand = nullptr;
     unsigned* d_qt_val = nullptr; unsigned* d_qt_code = nullptr; int* d_qt_node = nullptr; unsigned* d_lvl_kp = nullptr;
-    int* d_lvl_n[2] = {nullptr, nullptr}; orbhip_keypoint* d_out_kp[2] = {nullptr, nullptr}; uint8_t* d_out_desc[2] = {nullptr, nullptr}; int* d_out_n[2] = {nullptr, nullptr};
+    // outputs are triple-buffered: batch t writes buffer t%3 while the matcher of batch t-1 (own stream) still reads buffers (t-1)%3 and (t-2)%3
+    int* d_lvl_n[3] = {nullptr, nullptr, nullptr}; orbhip_keypoint* d_out_kp[3] = {nullptr, nullptr, nullptr}; uint8_t* d_out_desc[3] = {nullptr, nullptr, nullptr}; int* d_out_n[3] = {nullptr, nullptr, nullptr};
+    hipStream_t mstream = nullptr; hipEvent_t ev_extract = nullptr; hipEvent_t ev_match[3] = {nullptr, nullptr, nullptr}; bool match_pending[3] = {false, false, false};
     int cur = 0; int last_nimg = 0; bool last_matched = false; bool last_from_host = false;
     // matcher workspace
     int* d_grid_start = nullptr; int* d_grid_items = nullptr; float2* d_grid_xy = nullptr; unsigned* d_cand = nullptr; int* d_ncand = nullptr; float* d_prev = nullptr; int* d_m12 = nullptr; int* d_nm = nullptr;
@@ -124,14 +126,17 @@ extern "C" void orbhip_destroy(orbhip_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->mstream) { (void)hipStreamSynchronize(c->mstream); (void)hipStreamDestroy(c->mstream); }
+    if (c->ev_extract) (void)hipEventDestroy(c->ev_extract);
+    for (auto e : c->ev_match) if (e) (void)hipEventDestroy(e);
     for (auto xs : c->xstreams) { (void)hipStreamSynchronize(xs); (void)hipStreamDestroy(xs); }
     for (auto e : c->xevents) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     prof_collect(c);
     for (auto e : c->pool) (void)hipEventDestroy(e);
     void* ptrs[] = {c->d_geom, c->d_cells, c->d_tiles, c->d_xtab, c->d_ytab, c->d_pattern, c->d_pyr, c->d_blur, c->d_cell_count, c->d_cell_cand,
-                    c->d_qt_val, c->d_qt_code, c->d_qt_node, c->d_lvl_kp, c->d_lvl_n[0], c->d_lvl_n[1], c->d_out_kp[0], c->d_out_kp[1],
-                    c->d_out_desc[0], c->d_out_desc[1], c->d_out_n[0], c->d_out_n[1], c->d_grid_start, c->d_grid_items, c->d_grid_xy, c->d_cand, c->d_ncand,
+                    c->d_qt_val, c->d_qt_code, c->d_qt_node, c->d_lvl_kp, c->d_lvl_n[0], c->d_lvl_n[1], c->d_lvl_n[2], c->d_out_kp[0], c->d_out_kp[1], c->d_out_kp[2],
+                    c->d_out_desc[0], c->d_out_desc[1], c->d_out_desc[2], c->d_out_n[0], c->d_out_n[1], c->d_out_n[2], c->d_grid_start, c->d_grid_items, c->d_grid_xy, c->d_cand, c->d_ncand,
                     c->d_prev, c->d_m12, c->d_nm};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -237,6 +242,11 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
         c->xstreams.push_back(xs); c->xevents.push_back(xe);
     }
     if (!c->xstreams.empty() && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { orbhip_destroy(c); return fail(ORBHIP_ERR_HIP, "event creation failed"); }
+    {   // the matcher runs on its own stream so that it overlaps the next batch's extraction
+        bool ok = hipStreamCreateWithFlags(&c->mstream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&c->ev_extract, hipEventDisableTiming) == hipSuccess;
+        for (int k = 0; k < 3 && ok; k++) ok = hipEventCreateWithFlags(&c->ev_match[k], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { orbhip_destroy(c); return fail(ORBHIP_ERR_HIP, "match stream creation failed"); }
+    }
     const size_t B = (size_t)c->B;
     std::vector<signed char> pat(kPatternHost, kPatternHost + 1024);
     hipError_t e = hipSuccess;
@@ -247,7 +257,7 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
     TRY(dalloc(&c->d_cell_count, B * c->cells.size())); TRY(dalloc(&c->d_cell_cand, B * c->cand_slots_per_frame));
     TRY(dalloc(&c->d_qt_val, B * c->qt_per_frame)); TRY(dalloc(&c->d_qt_code, B * c->qt_per_frame)); TRY(dalloc(&c->d_qt_node, B * c->qt_per_frame));
     TRY(dalloc(&c->d_lvl_kp, B * c->lvl_kp_per_frame));
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < 3; k++) {
         TRY(dalloc(&c->d_lvl_n[k], B * L)); TRY(dalloc(&c->d_out_kp[k], B * c->out_cap)); TRY(dalloc(&c->d_out_desc[k], B * c->out_cap * 32)); TRY(dalloc(&c->d_out_n[k], B));
         if (e == hipSuccess) e = hipMemset(c->d_lvl_n[k], 0, B * L * sizeof(int));
         if (e == hipSuccess) e = hipMemset(c->d_out_n[k], 0, B * sizeof(int));
@@ -301,20 +311,12 @@ static orbhip_status run_pipeline(orbhip_ctx* c, int nimg, const uint8_t* d_img0
                                   int match_prev, int window, float nnratio, int check_ori)
 {
     HIPCHK(hipSetDevice(c->cfg.device));
-    c->cur ^= 1;
+    c->cur = (c->cur + 1) % 3;
+    const int cur = c->cur, prev = (cur + 2) % 3;
+    // the buffer about to be overwritten was the "previous frame" of the matcher launched two calls ago
+    for (int k = 0; k < 3; k++) if (c->match_pending[k] && (k == (cur + 1) % 3)) { HIPCHK(hipStreamWaitEvent(c->stream, c->ev_match[k], 0)); c->match_pending[k] = false; }
     ExtractParams P = make_params(c, d_img0, frame_stride, row_stride);
-    MatchParams M; memset(&M, 0, sizeof M);
-    if (match_prev) {
-        const int prev = c->cur ^ 1;
-        M.kp1 = c->d_out_kp[prev]; M.desc1 = c->d_out_desc[prev]; M.n1 = c->d_out_n[prev]; M.n1_lvl0 = c->d_lvl_n[prev];
-        M.kp2 = c->d_out_kp[c->cur]; M.desc2 = c->d_out_desc[c->cur]; M.n2 = c->d_out_n[c->cur];
-        M.lvl_stride = c->L; M.list1 = nullptr; M.prev_from_kp1 = 1;
-        M.cap = c->out_cap; M.im_w = c->cfg.width; M.im_h = c->cfg.height;
-        M.grid_start = c->d_grid_start; M.grid_items = c->d_grid_items; M.grid_xy = c->d_grid_xy; M.cand = c->d_cand; M.ncand = c->d_ncand; M.cand_stride = c->lvl0_cap; M.lvl0_cap = c->lvl0_cap;
-        M.prev = c->d_prev; M.matches12 = c->d_m12; M.nmatches = c->d_nm; M.window = window; M.nnratio = nnratio; M.check_ori = check_ori;
-    }
-    // camera slots are independent: split the batch into groups, one HIP stream each, so the latency-bound kernels of one
-    // group (quadtree, match select) overlap the throughput kernels of another (FAST, blur, pyramid)
+    // camera slots are independent: optionally split the batch into groups, one HIP stream each
     const int ngroups = std::min((int)c->xstreams.size() + 1, nimg);
     if (ngroups > 1) { HIPCHK(hipEventRecord(c->ev_fork, c->stream)); }
     for (int gi = 0; gi < ngroups; gi++) {
@@ -322,18 +324,30 @@ static orbhip_status run_pipeline(orbhip_ctx* c, int nimg, const uint8_t* d_img0
         hipStream_t s = gi == 0 ? c->stream : c->xstreams[gi - 1];
         if (gi > 0) HIPCHK(hipStreamWaitEvent(s, c->ev_fork, 0));
         if (nf <= 0) continue;
-        P.frame0 = f0; M.slot0 = f0;
+        P.frame0 = f0;
         { ProfScope ps(c, K_PYRAMID, s); for (int l = 1; l < c->L; l++) orbhip_launch_pyramid_level(P, l, c->geom[l].w, c->geom[l].h, nf, s); }
         { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nf, s); }
         { ProfScope ps(c, K_BLUR, s); orbhip_launch_blur(P, c->gk, nf, s); }
         { ProfScope ps(c, K_QUADTREE, s); orbhip_launch_quadtree(P, nf, s); }
         { ProfScope ps(c, K_DESCRIBE, s); orbhip_launch_describe(P, nf, s); }
-        if (match_prev) {
-            { ProfScope ps(c, K_MGRID, s); orbhip_launch_match_grid(M, nf, s); }
-            { ProfScope ps(c, K_MCAND, s); orbhip_launch_match_candidates(M, nf, s); }
-            { ProfScope ps(c, K_MSELECT, s); orbhip_launch_match_select(M, nf, s); }
-        }
         if (gi > 0) { HIPCHK(hipEventRecord(c->xevents[gi - 1], s)); HIPCHK(hipStreamWaitEvent(c->stream, c->xevents[gi - 1], 0)); }
+    }
+    if (match_prev) {
+        MatchParams M; memset(&M, 0, sizeof M);
+        M.kp1 = c->d_out_kp[prev]; M.desc1 = c->d_out_desc[prev]; M.n1 = c->d_out_n[prev]; M.n1_lvl0 = c->d_lvl_n[prev];
+        M.kp2 = c->d_out_kp[cur]; M.desc2 = c->d_out_desc[cur]; M.n2 = c->d_out_n[cur];
+        M.lvl_stride = c->L; M.list1 = nullptr; M.prev_from_kp1 = 1;
+        M.cap = c->out_cap; M.im_w = c->cfg.width; M.im_h = c->cfg.height;
+        M.grid_start = c->d_grid_start; M.grid_items = c->d_grid_items; M.grid_xy = c->d_grid_xy; M.cand = c->d_cand; M.ncand = c->d_ncand; M.cand_stride = c->lvl0_cap; M.lvl0_cap = c->lvl0_cap;
+        M.prev = c->d_prev; M.matches12 = c->d_m12; M.nmatches = c->d_nm; M.window = window; M.nnratio = nnratio; M.check_ori = check_ori; M.slot0 = 0;
+        // matcher of this batch on its own stream: latency-bound (one wave per slot), overlaps the next call's extraction
+        HIPCHK(hipEventRecord(c->ev_extract, c->stream));
+        HIPCHK(hipStreamWaitEvent(c->mstream, c->ev_extract, 0));
+        { ProfScope ps(c, K_MGRID, c->mstream); orbhip_launch_match_grid(M, nimg, c->mstream); }
+        { ProfScope ps(c, K_MCAND, c->mstream); orbhip_launch_match_candidates(M, nimg, c->mstream); }
+        { ProfScope ps(c, K_MSELECT, c->mstream); orbhip_launch_match_select(M, nimg, c->mstream); }
+        HIPCHK(hipEventRecord(c->ev_match[cur], c->mstream));
+        c->match_pending[cur] = true;
     }
     c->last_matched = match_prev != 0;
     c->last_nimg = nimg;
@@ -356,6 +370,8 @@ extern "C" orbhip_status orbhip_sync(orbhip_ctx* c)
     if (!c) return fail(ORBHIP_ERR_INVALID, "null context");
     HIPCHK(hipSetDevice(c->cfg.device));
     HIPCHK(hipStreamSynchronize(c->stream));
+    for (auto xs : c->xstreams) HIPCHK(hipStreamSynchronize(xs));
+    if (c->mstream) HIPCHK(hipStreamSynchronize(c->mstream));
     prof_collect(c);
     return ORBHIP_OK;
 }
@@ -385,7 +401,7 @@ extern "C" orbhip_status orbhip_fetch_matches(orbhip_ctx* c, int nimg, int32_t* 
     if (nimg < 1 || nimg > c->last_nimg) return fail(ORBHIP_ERR_INVALID, "bad nimg");
     orbhip_status st = orbhip_sync(c); if (st != ORBHIP_OK) return st;
     std::vector<int> n1(nimg);
-    HIPCHK(hipMemcpy(n1.data(), c->d_out_n[c->cur ^ 1], nimg * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(n1.data(), c->d_out_n[(c->cur + 2) % 3], nimg * sizeof(int), hipMemcpyDeviceToHost));
     if (nmatches) HIPCHK(hipMemcpy(nmatches, c->d_nm, nimg * sizeof(int), hipMemcpyDeviceToHost));
     for (int f = 0; f < nimg; f++) {
         if (n1_out) n1_out[f] = n1[f];

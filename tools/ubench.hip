@@ -1,41 +1,65 @@
-// Instruction-rate micro-benchmark (gfx950): dependent-free chains of one op type per kernel, 256 CUs x 8 waves/SIMD.
+// Instruction-rate micro-benchmark (gfx950): 8 independent chains per lane of one instruction (inline asm), 8 waves/SIMD.
 #include <hip/hip_runtime.h>
 #include <cstdio>
-typedef unsigned short pku16 __attribute__((vector_size(4)));
-#define N_IT 4096
-template <int OP> __global__ __launch_bounds__(256) void k(unsigned* out, unsigned seed)
+#define N_IT 2048
+#define DEFK(NAME, ASM) \
+__global__ __launch_bounds__(256) void NAME(unsigned* out, unsigned seed) { \
+    unsigned a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
+    unsigned b = seed ^ 0x3c003c00u, c = seed | 0x11u; \
+    for (int it = 0; it < N_IT; it++) { \
+        asm volatile(ASM(0) ASM(1) ASM(2) ASM(3) ASM(4) ASM(5) ASM(6) ASM(7) \
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c)); } \
+    out[blockIdx.x * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7; }
+#define A_ADD(i)      "v_add_u32 %" #i ", %" #i ", %8\n"
+#define A_MINU(i)     "v_min_u32 %" #i ", %" #i ", %8\n"
+#define A_PKMINU16(i) "v_pk_min_u16 %" #i ", %" #i ", %8\n"
+#define A_PKMINF16(i) "v_pk_min_f16 %" #i ", %" #i ", %8\n"
+#define A_PKMAXI16(i) "v_pk_max_i16 %" #i ", %" #i ", %8\n"
+#define A_MINF32(i)   "v_min_f32 %" #i ", %" #i ", %8\n"
+#define A_FMAF32(i)   "v_fma_f32 %" #i ", %" #i ", %8, %9\n"
+#define A_MULF32(i)   "v_mul_f32 %" #i ", %" #i ", %8\n"
+#define A_MIN3U(i)    "v_min3_u32 %" #i ", %" #i ", %8, %9\n"
+#define A_MAX3F(i)    "v_max3_f32 %" #i ", %" #i ", %8, %9\n"
+#define A_PERM(i)     "v_perm_b32 %" #i ", %" #i ", %8, %9\n"
+#define A_MAD24(i)    "v_mad_u32_u24 %" #i ", %" #i ", %8, %9\n"
+#define A_LSHLADD(i)  "v_lshl_add_u32 %" #i ", %" #i ", 2, %8\n"
+#define A_ANDOR(i)    "v_and_or_b32 %" #i ", %" #i ", %8, %9\n"
+#define A_CVTF(i)     "v_cvt_f32_i32 %" #i ", %" #i "\n"
+#define A_RNDNE(i)    "v_rndne_f32 %" #i ", %" #i "\n"
+#define A_CVTI(i)     "v_cvt_i32_f32 %" #i ", %" #i "\n"
+#define A_MULLO(i)    "v_mul_lo_u32 %" #i ", %" #i ", %8\n"
+#define A_BFE(i)      "v_bfe_u32 %" #i ", %" #i ", 3, 8\n"
+#define A_ALIGNBIT(i) "v_alignbit_b32 %" #i ", %" #i ", %8, 8\n"
+#define A_PKADDF16(i) "v_pk_add_f16 %" #i ", %" #i ", %8\n"
+#define A_PKMULF16(i) "v_pk_mul_f16 %" #i ", %" #i ", %8\n"
+#define A_BCNT(i)     "v_bcnt_u32_b32 %" #i ", %" #i ", %8\n"
+#define A_XOR(i)      "v_xor_b32 %" #i ", %" #i ", %8\n"
+#define A_SADU8(i)    "v_sad_u8 %" #i ", %" #i ", %8, %9\n"
+#define A_CMPSEL(i)   "v_cmp_lt_u32 vcc, %" #i ", %8\n v_cndmask_b32 %" #i ", %" #i ", %9, vcc\n"
+#define A_DPP(i)      "v_mov_b32_dpp %" #i ", %" #i " row_shr:1 row_mask:0xf bank_mask:0xf\n"
+#define A_BPERM(i)    "ds_bpermute_b32 %" #i ", %8, %" #i "\n s_waitcnt lgkmcnt(0)\n"
+DEFK(k_add, A_ADD) DEFK(k_minu, A_MINU) DEFK(k_pkminu16, A_PKMINU16) DEFK(k_pkminf16, A_PKMINF16) DEFK(k_pkmaxi16, A_PKMAXI16)
+DEFK(k_minf32, A_MINF32) DEFK(k_fmaf32, A_FMAF32) DEFK(k_mulf32, A_MULF32) DEFK(k_min3u, A_MIN3U) DEFK(k_max3f, A_MAX3F)
+DEFK(k_perm, A_PERM) DEFK(k_mad24, A_MAD24) DEFK(k_lshladd, A_LSHLADD) DEFK(k_andor, A_ANDOR) DEFK(k_cvtf, A_CVTF) DEFK(k_rndne, A_RNDNE)
+DEFK(k_cvti, A_CVTI) DEFK(k_mullo, A_MULLO) DEFK(k_bfe, A_BFE) DEFK(k_alignbit, A_ALIGNBIT) DEFK(k_pkaddf16, A_PKADDF16) DEFK(k_pkmulf16, A_PKMULF16)
+DEFK(k_bcnt, A_BCNT) DEFK(k_xor, A_XOR) DEFK(k_sadu8, A_SADU8) DEFK(k_cmpsel, A_CMPSEL) DEFK(k_dpp, A_DPP) DEFK(k_bperm, A_BPERM)
+typedef void (*kfn)(unsigned*, unsigned);
+static void run(const char* name, kfn f, int inst_per_slot)
 {
-    unsigned a[8];
-    for (int i = 0; i < 8; i++) a[i] = seed + threadIdx.x * 7 + i;
-    unsigned b = seed ^ 0x9e3779b9u;
-    for (int it = 0; it < N_IT; it++) {
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            if (OP == 0) { pku16 x = (pku16)a[i], y = (pku16)b; a[i] = (unsigned)(x < y ? x : y) + 1; }                     // v_pk_min_u16 (+ add to defeat idempotence)
-            if (OP == 1) a[i] = min(a[i], b) + 1;                                                                              // v_min_u32 + v_add
-            if (OP == 2) a[i] = __builtin_amdgcn_perm(a[i], b, 0x0c010c00u) + 1;                                               // v_perm_b32 + add
-            if (OP == 3) a[i] = a[i] * 3 + b;                                                                                  // v_mad_u32_u24-ish / mul+add
-            if (OP == 4) a[i] = a[i] + b;                                                                                      // v_add_u32
-            if (OP == 5) { pku16 x = (pku16)a[i], y = (pku16)b; a[i] = (unsigned)(x + y); }                                   // v_pk_add_u16
-        }
-    }
-    unsigned s = 0; for (int i = 0; i < 8; i++) s ^= a[i];
-    out[blockIdx.x * 256 + threadIdx.x] = s;
-}
-template <int OP> void run(const char* name, int ops_per_inner)
-{
-    unsigned* d; hipMalloc(&d, 8192 * 256 * 4);
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(k<OP>, dim3(8192), dim3(256), 0, 0, d, 1u);
-    hipEventRecord(e0); hipLaunchKernelGGL(k<OP>, dim3(8192), dim3(256), 0, 0, d, 2u); hipEventRecord(e1); hipEventSynchronize(e1);
-    float ms; hipEventElapsedTime(&ms, e0, e1);
-    double winst = 8192.0 * 4 * N_IT * 8 * ops_per_inner;          // wave-instructions
-    printf("%-28s %8.3f ms  %.2f G wave-inst/s  -> %.2f cycles/inst/SIMD @2.4GHz (1024 SIMDs)\n", name, ms, winst / ms / 1e6, 1024 * 2.4e9 / (winst / (ms * 1e-3)));
-    hipFree(d);
+    unsigned* d; (void)hipMalloc(&d, 8192 * 256 * 4);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(f, dim3(8192), dim3(256), 0, 0, d, 1u);
+    (void)hipEventRecord(e0); hipLaunchKernelGGL(f, dim3(8192), dim3(256), 0, 0, d, 2u); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    double winst = 8192.0 * 4 * N_IT * 8 * inst_per_slot;
+    printf("%-16s %8.3f ms  %6.2f cycles/inst/SIMD @2.4GHz\n", name, ms, 1024 * 2.4e9 / (winst / (ms * 1e-3)));
+    (void)hipFree(d);
 }
 int main()
 {
-    run<4>("v_add_u32", 1); run<1>("v_min_u32 + v_add", 2); run<0>("v_pk_min_u16 + v_add", 2); run<5>("v_pk_add_u16", 1);
-    run<2>("v_perm_b32 + v_add", 2); run<3>("mul + add", 2);
+#define R(n, c) run(#n, n, c)
+    R(k_add, 1); R(k_xor, 1); R(k_minu, 1); R(k_min3u, 1); R(k_pkminu16, 1); R(k_pkmaxi16, 1); R(k_pkminf16, 1); R(k_pkaddf16, 1); R(k_pkmulf16, 1);
+    R(k_minf32, 1); R(k_max3f, 1); R(k_mulf32, 1); R(k_fmaf32, 1); R(k_perm, 1); R(k_mad24, 1); R(k_lshladd, 1); R(k_andor, 1); R(k_bfe, 1);
+    R(k_alignbit, 1); R(k_cvtf, 1); R(k_rndne, 1); R(k_cvti, 1); R(k_mullo, 1); R(k_bcnt, 1); R(k_sadu8, 1); R(k_cmpsel, 2); R(k_dpp, 1); R(k_bperm, 1);
     return 0;
 }
