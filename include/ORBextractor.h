@@ -1,0 +1,69 @@
+// ORBextractor.h — drop-in replacement for raulmur/ORB_SLAM2 include/ORBextractor.h (ORBextractor.h:45-111 there):
+// same namespace, class name, enum, constructor, operator() and accessors, same public mvImagePyramid member, so
+// Frame.cc / Tracking.cc compile and call it unchanged (Frame::ExtractORB, Frame.cc:247-253; Tracking.cc:119-125).
+// The work happens on an MI355X through the C ABI of include/orbhip.h; there is no CPU path behind this class.
+#ifndef ORBEXTRACTOR_H
+#define ORBEXTRACTOR_H
+
+#include <list>
+#include <vector>
+#ifdef ORBHIP_USE_OPENCV
+#include <opencv/cv.h>
+#else
+#include "cvlite/cvlite.h"
+#endif
+
+struct orbhip_ctx;
+
+namespace ORB_SLAM2
+{
+
+class ORBextractor
+{
+public:
+    enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
+
+    ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST);
+    ~ORBextractor();
+
+    // Compute the ORB features and descriptors on an image (mask is ignored, as in the reference).
+    void operator()(cv::InputArray image, cv::InputArray mask, std::vector<cv::KeyPoint>& keypoints, cv::OutputArray descriptors);
+
+    int inline GetLevels() { return nlevels; }
+    float inline GetScaleFactor() { return scaleFactor; }
+    std::vector<float> inline GetScaleFactors() { return mvScaleFactor; }
+    std::vector<float> inline GetInverseScaleFactors() { return mvInvScaleFactor; }
+    std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
+    std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
+
+    // mvImagePyramid[l] is filled after every call (read by Frame::ComputeStereoMatches, Frame.cc:473,563-580).
+    // Monocular / RGB-D pipelines never read it: SetPyramidDownload(false) skips the 8 device-to-host copies.
+    std::vector<cv::Mat> mvImagePyramid;
+    void SetPyramidDownload(bool on) { mbDownloadPyramid = on; }
+    // HIP device this extractor runs on (default 0); takes effect at the next (re)creation of the device context.
+    void SetDevice(int device) { mnDevice = device; }
+
+protected:
+    void EnsureContext(int width, int height);
+
+    int nfeatures;
+    double scaleFactor;
+    int nlevels;
+    int iniThFAST;
+    int minThFAST;
+
+    std::vector<int> mnFeaturesPerLevel;
+    std::vector<float> mvScaleFactor;
+    std::vector<float> mvInvScaleFactor;
+    std::vector<float> mvLevelSigma2;
+    std::vector<float> mvInvLevelSigma2;
+
+    orbhip_ctx* mpCtx;          // device context for the current image size (created lazily, re-created on a size change)
+    int mnCtxW, mnCtxH, mnDevice;
+    bool mbDownloadPyramid;
+    float mfScaleFactorArg;
+};
+
+} // namespace ORB_SLAM2
+
+#endif

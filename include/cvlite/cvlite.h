@@ -1,0 +1,86 @@
+// cvlite.h — the handful of OpenCV types the ORB front-end's class signatures mention, for containers WITHOUT OpenCV
+// (this build container has none).  Same spelling as OpenCV 2.4/3.x so include/ORBextractor.h and include/ORBmatcher.h
+// compile unchanged against either; define ORBHIP_USE_OPENCV to use the real headers instead.  Types only — no image
+// processing lives here (that is all in liborbhip.so).
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#define CV_8U 0
+#define CV_8UC1 0
+#define CV_32F 5
+
+namespace cv {
+
+typedef unsigned char uchar;
+
+template <typename T> struct Point_ {
+    T x, y;
+    Point_() : x(0), y(0) {}
+    Point_(T x_, T y_) : x(x_), y(y_) {}
+    Point_& operator*=(float s) { x = (T)(x * s); y = (T)(y * s); return *this; }
+};
+typedef Point_<int> Point2i;
+typedef Point_<int> Point;
+typedef Point_<float> Point2f;
+struct Size { int width, height; Size() : width(0), height(0) {} Size(int w, int h) : width(w), height(h) {} };
+struct Rect { int x, y, width, height; Rect() : x(0), y(0), width(0), height(0) {} Rect(int x_, int y_, int w, int h) : x(x_), y(y_), width(w), height(h) {} };
+
+class KeyPoint {            // same field order and size (28 B) as cv::KeyPoint == orbhip_keypoint
+public:
+    Point2f pt; float size, angle, response; int octave, class_id;
+    KeyPoint() : pt(0, 0), size(0), angle(-1), response(0), octave(0), class_id(-1) {}
+    KeyPoint(float x, float y, float s, float a = -1, float r = 0, int o = 0, int c = -1) : pt(x, y), size(s), angle(a), response(r), octave(o), class_id(c) {}
+};
+
+class Mat {                 // 8-bit / 32-bit single-channel, ref-counted or borrowed storage
+public:
+    int rows, cols, flags_type; size_t step; uchar* data;
+    Mat() : rows(0), cols(0), flags_type(CV_8U), step(0), data(nullptr) {}
+    Mat(int r, int c, int type) : Mat() { create(r, c, type); }
+    Mat(int r, int c, int type, void* ext, size_t step_ = 0) : rows(r), cols(c), flags_type(type), step(step_ ? step_ : (size_t)c * elemSize1(type)), data((uchar*)ext) {}
+    static size_t elemSize1(int type) { return type == CV_32F ? 4 : 1; }
+    void create(int r, int c, int type)
+    {
+        if (r == rows && c == cols && type == flags_type && data && owner_) return;
+        rows = r; cols = c; flags_type = type; step = (size_t)c * elemSize1(type);
+        owner_ = std::shared_ptr<uchar>(new uchar[(size_t)r * step + 64], std::default_delete<uchar[]>()); data = owner_.get();
+    }
+    void release() { owner_.reset(); data = nullptr; rows = cols = 0; step = 0; }
+    bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
+    int type() const { return flags_type; }
+    bool isContinuous() const { return step == (size_t)cols * elemSize1(flags_type); }
+    Mat clone() const { Mat m(rows, cols, flags_type); for (int y = 0; y < rows; y++) memcpy(m.data + y * m.step, data + y * step, cols * elemSize1(flags_type)); return m; }
+    Mat row(int y) const { Mat m; m.rows = 1; m.cols = cols; m.flags_type = flags_type; m.step = step; m.data = data + (size_t)y * step; m.owner_ = owner_; return m; }
+    template <typename T> T* ptr(int y = 0) { return (T*)(data + (size_t)y * step); }
+    template <typename T> const T* ptr(int y = 0) const { return (const T*)(data + (size_t)y * step); }
+    uchar* ptr(int y = 0) { return data + (size_t)y * step; }
+    const uchar* ptr(int y = 0) const { return data + (size_t)y * step; }
+    template <typename T> T& at(int y, int x) { return ((T*)(data + (size_t)y * step))[x]; }
+    template <typename T> const T& at(int y, int x) const { return ((const T*)(data + (size_t)y * step))[x]; }
+private:
+    std::shared_ptr<uchar> owner_;
+};
+
+class _InputArray {
+public:
+    _InputArray() : m_(nullptr) {}
+    _InputArray(const Mat& m) : m_(const_cast<Mat*>(&m)) {}
+    Mat getMat() const { return m_ ? *m_ : Mat(); }
+    bool empty() const { return !m_ || m_->empty(); }
+protected:
+    Mat* m_;
+};
+class _OutputArray : public _InputArray {
+public:
+    _OutputArray() {}
+    _OutputArray(Mat& m) : _InputArray(m) {}
+    void create(int rows, int cols, int type) const { if (m_) m_->create(rows, cols, type); }
+    void release() const { if (m_) m_->release(); }
+};
+typedef const _InputArray& InputArray;
+typedef const _OutputArray& OutputArray;
+
+}  // namespace cv

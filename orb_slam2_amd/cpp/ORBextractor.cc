@@ -1,0 +1,81 @@
+// ORBextractor.cc — host side of the drop-in ORB_SLAM2::ORBextractor: forwards to the C ABI (include/orbhip.h).
+// Replaces src/ORBextractor.cc of the reference; constructor bookkeeping follows ORBextractor.cc:410-446 so the accessors
+// return the same tables even before the first image has been seen.
+#include "ORBextractor.h"
+#include "orbhip.h"
+
+#include <cassert>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace ORB_SLAM2
+{
+
+static_assert(sizeof(cv::KeyPoint) == sizeof(orbhip_keypoint), "cv::KeyPoint and orbhip_keypoint must share one 28-byte layout");
+
+ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST)
+    : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST),
+      mpCtx(NULL), mnCtxW(0), mnCtxH(0), mnDevice(0), mbDownloadPyramid(true), mfScaleFactorArg(_scaleFactor)
+{
+    mvScaleFactor.resize(nlevels); mvLevelSigma2.resize(nlevels);
+    mvScaleFactor[0] = 1.0f; mvLevelSigma2[0] = 1.0f;
+    for (int i = 1; i < nlevels; i++) { mvScaleFactor[i] = (float)(mvScaleFactor[i - 1] * scaleFactor); mvLevelSigma2[i] = mvScaleFactor[i] * mvScaleFactor[i]; }
+    mvInvScaleFactor.resize(nlevels); mvInvLevelSigma2.resize(nlevels);
+    for (int i = 0; i < nlevels; i++) { mvInvScaleFactor[i] = 1.0f / mvScaleFactor[i]; mvInvLevelSigma2[i] = 1.0f / mvLevelSigma2[i]; }
+    mvImagePyramid.resize(nlevels);
+    mnFeaturesPerLevel.resize(nlevels);
+    if (const char* dev = getenv("ORBHIP_DEVICE")) mnDevice = atoi(dev);
+}
+
+ORBextractor::~ORBextractor() { if (mpCtx) orbhip_destroy(mpCtx); }
+
+void ORBextractor::EnsureContext(int width, int height)
+{
+    if (mpCtx && width == mnCtxW && height == mnCtxH) return;
+    if (mpCtx) { orbhip_destroy(mpCtx); mpCtx = NULL; }
+    orbhip_config cfg; memset(&cfg, 0, sizeof cfg);
+    cfg.nfeatures = nfeatures; cfg.scale_factor = mfScaleFactorArg; cfg.nlevels = nlevels; cfg.ini_th_fast = iniThFAST; cfg.min_th_fast = minThFAST;
+    cfg.width = width; cfg.height = height; cfg.max_batch = 1; cfg.device = mnDevice; cfg.stream = NULL; cfg.blur_round_mode = 0; cfg.num_streams = 1;
+    if (orbhip_create(&mpCtx, &cfg) != ORBHIP_OK) {
+        // the reference cannot fail here; a missing GPU must not silently produce empty frames
+        fprintf(stderr, "ORBextractor: %s\n", orbhip_last_error());
+        abort();
+    }
+    mnCtxW = width; mnCtxH = height;
+    // the device tables are the authority (bit-identical to the constructor's by construction; checked in tests)
+    orbhip_get_scale_tables(mpCtx, &mvScaleFactor[0], &mvInvScaleFactor[0], &mvLevelSigma2[0], &mvInvLevelSigma2[0], &mnFeaturesPerLevel[0]);
+}
+
+void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, std::vector<cv::KeyPoint>& _keypoints, cv::OutputArray _descriptors)
+{
+    if (_image.empty()) return;                                  // ORBextractor.cc:1046-1047
+    cv::Mat image = _image.getMat();
+    assert(image.type() == CV_8UC1);
+    EnsureContext(image.cols, image.rows);
+
+    const int cap = orbhip_keypoint_capacity(mpCtx);
+    _keypoints.resize(cap);
+    std::vector<unsigned char> desc((size_t)cap * 32);
+    int n = 0;
+    if (orbhip_extract(mpCtx, image.data, (int)image.step, reinterpret_cast<orbhip_keypoint*>(&_keypoints[0]), &desc[0], cap, &n) != ORBHIP_OK) {
+        fprintf(stderr, "ORBextractor: %s\n", orbhip_last_error());
+        abort();
+    }
+    _keypoints.resize(n);
+    if (n == 0) _descriptors.release();                          // ORBextractor.cc:1064-1065
+    else {
+        _descriptors.create(n, 32, CV_8U);                       // :1068
+        cv::Mat d = _descriptors.getMat();
+        for (int i = 0; i < n; i++) memcpy(d.ptr(i), &desc[(size_t)i * 32], 32);
+    }
+    if (mbDownloadPyramid)
+        for (int l = 0; l < nlevels; l++) {
+            int w = 0, h = 0; orbhip_level_size(mpCtx, l, &w, &h);
+            mvImagePyramid[l].create(h, w, CV_8UC1);
+            orbhip_pyramid_level(mpCtx, 0, l, mvImagePyramid[l].data, (int)mvImagePyramid[l].step);
+        }
+}
+
+} // namespace ORB_SLAM2

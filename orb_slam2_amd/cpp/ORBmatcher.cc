@@ -1,0 +1,45 @@
+// ORBmatcher.cc — host side of the drop-in ORB_SLAM2::ORBmatcher for the map-free part of the hot path:
+// constructor, constants, DescriptorDistance (ORBmatcher.cc:1647-1663 of the reference) and SearchForInitialization
+// (ORBmatcher.cc:405-520), forwarded to the C ABI (include/orbhip.h).  The Frame members it reads are exactly the ones the
+// reference reads: mvKeysUn, mDescriptors, mnMinX/mnMaxX/mnMinY/mnMaxY (Frame.h:120-190).
+#include "ORBmatcher.h"
+#include "orbhip.h"
+#ifndef ORBHIP_USE_OPENCV
+#include "Frame.h"          // the caller's Frame (tests/cpp/Frame.h stands in for the reference's include/Frame.h here)
+#endif
+
+#include <cstdio>
+#include <cstdlib>
+
+namespace ORB_SLAM2
+{
+
+const int ORBmatcher::TH_HIGH = 100;
+const int ORBmatcher::TH_LOW = 50;
+const int ORBmatcher::HISTO_LENGTH = 30;
+
+ORBmatcher::ORBmatcher(float nnratio, bool checkOri) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+
+int ORBmatcher::DescriptorDistance(const cv::Mat& a, const cv::Mat& b)
+{
+    return orbhip_descriptor_distance(a.ptr<unsigned char>(), b.ptr<unsigned char>());
+}
+
+int ORBmatcher::SearchForInitialization(Frame& F1, Frame& F2, std::vector<cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12, int windowSize)
+{
+    const int n1 = (int)F1.mvKeysUn.size(), n2 = (int)F2.mvKeysUn.size();
+    vnMatches12 = std::vector<int>(n1, -1);
+    if (n1 == 0) return 0;
+    // undistorted input: mnMinX = mnMinY = 0 and mnMax = image size (Frame.cc:455-463); a distorted camera needs the bounds too
+    const int im_w = (int)(Frame::mnMaxX - Frame::mnMinX), im_h = (int)(Frame::mnMaxY - Frame::mnMinY);
+    int nmatches = 0;
+    const int device = getenv("ORBHIP_DEVICE") ? atoi(getenv("ORBHIP_DEVICE")) : 0;
+    const orbhip_status st = orbhip_search_for_initialization(
+        device, reinterpret_cast<const orbhip_keypoint*>(&F1.mvKeysUn[0]), F1.mDescriptors.ptr<unsigned char>(), n1,
+        n2 ? reinterpret_cast<const orbhip_keypoint*>(&F2.mvKeysUn[0]) : NULL, n2 ? F2.mDescriptors.ptr<unsigned char>() : NULL, n2,
+        im_w, im_h, reinterpret_cast<float*>(&vbPrevMatched[0]), &vnMatches12[0], windowSize, mfNNratio, mbCheckOrientation ? 1 : 0, &nmatches);
+    if (st != ORBHIP_OK) { fprintf(stderr, "ORBmatcher: %s\n", orbhip_last_error()); abort(); }
+    return nmatches;
+}
+
+} // namespace ORB_SLAM2

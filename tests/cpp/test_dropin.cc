@@ -1,0 +1,43 @@
+// Drives the drop-in classes exactly like the reference's callers do (Tracking.cc:119-125 constructs the extractor,
+// Frame::Frame calls ExtractORB, Tracking.cc:599-600 calls SearchForInitialization) and dumps the results for pytest.
+// usage: test_dropin W H nfeatures in0.raw in1.raw out.bin
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "ORBextractor.h"
+#include "ORBmatcher.h"
+#include "Frame.h"
+
+float ORB_SLAM2::Frame::mnMinX, ORB_SLAM2::Frame::mnMaxX, ORB_SLAM2::Frame::mnMinY, ORB_SLAM2::Frame::mnMaxY;
+
+static void dump(FILE* f, const ORB_SLAM2::Frame& F)
+{
+    int n = F.N; fwrite(&n, 4, 1, f);
+    if (n) { fwrite(&F.mvKeys[0], sizeof(cv::KeyPoint), n, f); for (int i = 0; i < n; i++) fwrite(F.mDescriptors.ptr(i), 1, 32, f); }
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 7) return 2;
+    const int W = atoi(argv[1]), H = atoi(argv[2]), N = atoi(argv[3]);
+    cv::Mat im[2];
+    for (int k = 0; k < 2; k++) { im[k].create(H, W, CV_8UC1); FILE* f = fopen(argv[4 + k], "rb"); if (!f || fread(im[k].data, 1, (size_t)W * H, f) != (size_t)W * H) return 3; fclose(f); }
+    ORB_SLAM2::ORBextractor* ex = new ORB_SLAM2::ORBextractor(N, 1.2f, 8, 20, 7);
+    ORB_SLAM2::Frame F1(im[0], ex), F2(im[1], ex);
+    std::vector<cv::Point2f> prev(F1.mvKeysUn.size());
+    for (size_t i = 0; i < prev.size(); i++) prev[i] = F1.mvKeysUn[i].pt;          // Tracking.cc:590-592
+    std::vector<int> matches;
+    ORB_SLAM2::ORBmatcher matcher(0.9, true);
+    const int nm = matcher.SearchForInitialization(F1, F2, prev, matches, 100);     // Tracking.cc:599-600
+    FILE* f = fopen(argv[6], "wb");
+    dump(f, F1); dump(f, F2);
+    fwrite(&nm, 4, 1, f);
+    if (!matches.empty()) fwrite(&matches[0], 4, matches.size(), f);
+    if (!prev.empty()) fwrite(&prev[0], 8, prev.size(), f);
+    int lv = ex->GetLevels(); fwrite(&lv, 4, 1, f);
+    for (int l = 0; l < lv; l++) { int wh[2] = {ex->mvImagePyramid[l].cols, ex->mvImagePyramid[l].rows}; fwrite(wh, 4, 2, f); fwrite(ex->mvImagePyramid[l].data, 1, (size_t)wh[0] * wh[1], f); }
+    const int d = ORB_SLAM2::ORBmatcher::DescriptorDistance(F1.mDescriptors.row(0), F2.mDescriptors.row(0)); fwrite(&d, 4, 1, f);
+    fclose(f);
+    delete ex;
+    return 0;
+}

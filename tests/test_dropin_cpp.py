@@ -1,0 +1,69 @@
+"""The drop-in C++ classes (include/ORBextractor.h, include/ORBmatcher.h + orb_slam2_amd/cpp/*.cc) used exactly like the
+reference's callers use them — Tracking constructs the extractor, Frame::Frame calls ExtractORB, Tracking calls
+SearchForInitialization — compiled against the in-repo `cv` type shim (OpenCV is absent here) and checked against the oracle."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import orb_slam2_amd
+from orb_slam2_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CPP = os.path.join(ROOT, "tests", "cpp")
+
+
+def _run(exe, tmp_path, oracle):
+    w, h, n = 400, 300, 500
+    seq = synth.sequence(w, h, 2, seed=31)
+    for k in range(2):
+        seq[k].tofile(str(tmp_path / f"in{k}.raw"))
+    out = tmp_path / "out.bin"
+    subprocess.check_call([exe, str(w), str(h), str(n), str(tmp_path / "in0.raw"), str(tmp_path / "in1.raw"), str(out)])
+    buf = out.read_bytes()
+    off = 0
+    frames = []
+    for _ in range(2):
+        (nk,) = struct.unpack_from("<i", buf, off); off += 4
+        k = np.frombuffer(buf, orb_slam2_amd.KEYPOINT_DTYPE, nk, off); off += 28 * nk
+        d = np.frombuffer(buf, np.uint8, 32 * nk, off).reshape(nk, 32); off += 32 * nk
+        frames.append((k, d))
+    (nm,) = struct.unpack_from("<i", buf, off); off += 4
+    n1 = len(frames[0][0])
+    m12 = np.frombuffer(buf, np.int32, n1, off); off += 4 * n1
+    prev = np.frombuffer(buf, np.float32, 2 * n1, off).reshape(n1, 2); off += 8 * n1
+    (lv,) = struct.unpack_from("<i", buf, off); off += 4
+    pyr = []
+    for _ in range(lv):
+        pw, ph = struct.unpack_from("<ii", buf, off); off += 8
+        pyr.append(np.frombuffer(buf, np.uint8, pw * ph, off).reshape(ph, pw)); off += pw * ph
+    (dd,) = struct.unpack_from("<i", buf, off)
+
+    ora = oracle.OracleExtractor(n, 1.2, 8, 20, 7)
+    ref = [ora.extract(im) for im in seq]
+    for f in range(2):
+        assert frames[f][0].tobytes() == ref[f][0].tobytes() and np.array_equal(frames[f][1], ref[f][1])
+    for l in range(8):                                    # mvImagePyramid of the LAST call (second frame)
+        assert np.array_equal(pyr[l], ora.level(l))
+    n_o, m_o, p_o = oracle.search_for_initialization(ref[0][0], ref[0][1], ref[1][0], ref[1][1], w, h, window=100, nnratio=0.9)
+    assert nm == n_o and np.array_equal(m12, m_o) and prev.tobytes() == p_o.tobytes()
+    assert dd == oracle.hamming(ref[0][1][0], ref[1][1][0])
+
+
+def _build(target):
+    subprocess.check_call(["make", "-C", CPP, "-s", target])
+    return os.path.join(CPP, target)
+
+
+def test_dropin_classes_emulation(tmp_path, oracle, emu_lib):
+    _run(_build("test_dropin_emu"), tmp_path, oracle)
+
+
+@pytest.mark.gpu
+def test_dropin_classes_gpu(tmp_path, oracle, gpu_lib):
+    exe = os.path.join(CPP, "test_dropin_gpu")
+    if not os.path.exists(exe):
+        exe = _build("test_dropin_gpu")
+    _run(exe, tmp_path, oracle)

@@ -15,6 +15,7 @@ for cfg in "64 1" "128 1" "256 1" "512 1" "256 2"; do set -- $cfg; timeout 200 p
 find /tmp/prof_$TAG -name "*stats*" -o -name "*kernel_trace*" | head -20 > $OUT/prof_files.txt
 for f in $(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -2); do cp $f $OUT/; done
 for f in $(find /tmp/prof_$TAG -name "*kernel_trace.csv" | head -1); do head -400 $f > $OUT/kernel_trace_head.csv; done
+timeout 120 python tools/host_io_rate.py > $OUT/host_io.json 2>> $OUT/bench.err; cat $OUT/host_io.json
 timeout 120 tools/ubench > $OUT/ubench.txt 2>&1; cat $OUT/ubench.txt
 tail -5 $OUT/pytest_gpu.log; tail -3 $OUT/smoke.log; cat $OUT/bench.json; python - <<PY
 import json
