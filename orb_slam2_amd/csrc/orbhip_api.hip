@@ -51,6 +51,8 @@ struct orbhip_ctx {
     int* d_lvl_n[3] = {nullptr, nullptr, nullptr}; orbhip_keypoint* d_out_kp[3] = {nullptr, nullptr, nullptr}; uint8_t* d_out_desc[3] = {nullptr, nullptr, nullptr}; int* d_out_n[3] = {nullptr, nullptr, nullptr};
     hipStream_t mstream = nullptr; hipEvent_t ev_extract = nullptr; hipEvent_t ev_match[3] = {nullptr, nullptr, nullptr}; bool match_pending[3] = {false, false, false};
     int cur = 0; int last_nimg = 0; bool last_matched = false; bool last_from_host = false;
+    // host-buffer API staging: one contiguous device input buffer + pinned host mirrors (single bulk copies instead of per-frame pageable copies)
+    uint8_t* d_in = nullptr; uint8_t* h_in = nullptr; orbhip_keypoint* h_kp = nullptr; uint8_t* h_desc = nullptr; int* h_n = nullptr; int in_pitch = 0;
     // matcher workspace
     int* d_grid_start = nullptr; int* d_grid_items = nullptr; float2* d_grid_xy = nullptr; unsigned* d_cand = nullptr; int* d_ncand = nullptr; float* d_prev = nullptr; int* d_m12 = nullptr; int* d_nm = nullptr;
     // profiling
@@ -139,6 +141,11 @@ extern "C" void orbhip_destroy(orbhip_ctx* c)
                     c->d_out_desc[0], c->d_out_desc[1], c->d_out_desc[2], c->d_out_n[0], c->d_out_n[1], c->d_out_n[2], c->d_grid_start, c->d_grid_items, c->d_grid_xy, c->d_cand, c->d_ncand,
                     c->d_prev, c->d_m12, c->d_nm};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (c->d_in) (void)hipFree(c->d_in);
+    if (c->h_in) (void)hipHostFree(c->h_in);
+    if (c->h_kp) (void)hipHostFree(c->h_kp);
+    if (c->h_desc) (void)hipHostFree(c->h_desc);
+    if (c->h_n) (void)hipHostFree(c->h_n);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -376,20 +383,42 @@ extern "C" orbhip_status orbhip_sync(orbhip_ctx* c)
     return ORBHIP_OK;
 }
 
+static orbhip_status ensure_host_staging(orbhip_ctx* c, bool input)
+{
+    const size_t B = (size_t)c->B;
+    if (!c->h_n) {
+        HIPCHK(hipHostMalloc((void**)&c->h_n, B * sizeof(int), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void**)&c->h_kp, B * c->out_cap * sizeof(orbhip_keypoint), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void**)&c->h_desc, B * c->out_cap * 32, hipHostMallocDefault));
+    }
+    if (input && !c->d_in) {
+        c->in_pitch = c->geom[0].pitch;
+        const size_t bytes = B * (size_t)c->in_pitch * c->cfg.height + 256;
+        HIPCHK(hipMalloc((void**)&c->d_in, bytes));
+        HIPCHK(hipHostMalloc((void**)&c->h_in, bytes, hipHostMallocDefault));
+    }
+    return ORBHIP_OK;
+}
+
 extern "C" orbhip_status orbhip_fetch(orbhip_ctx* c, int nimg, orbhip_keypoint* kps, uint8_t* desc, int cap, int* n_out)
 {
     if (!c || !n_out) return fail(ORBHIP_ERR_INVALID, "null argument");
     if (nimg < 1 || nimg > c->last_nimg) return fail(ORBHIP_ERR_INVALID, "nimg %d but the last call processed %d frames", nimg, c->last_nimg);
-    orbhip_status st = orbhip_sync(c); if (st != ORBHIP_OK) return st;
-    std::vector<int> n(nimg);
-    HIPCHK(hipMemcpy(n.data(), c->d_out_n[c->cur], nimg * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipSetDevice(c->cfg.device));
+    orbhip_status st = ensure_host_staging(c, false); if (st != ORBHIP_OK) return st;
+    // bulk device-to-host copies into pinned mirrors, ordered after the extraction on the context's stream
+    HIPCHK(hipMemcpyAsync(c->h_n, c->d_out_n[c->cur], nimg * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (kps) HIPCHK(hipMemcpyAsync(c->h_kp, c->d_out_kp[c->cur], (size_t)nimg * c->out_cap * sizeof(orbhip_keypoint), hipMemcpyDeviceToHost, c->stream));
+    if (desc) HIPCHK(hipMemcpyAsync(c->h_desc, c->d_out_desc[c->cur], (size_t)nimg * c->out_cap * 32, hipMemcpyDeviceToHost, c->stream));
+    st = orbhip_sync(c); if (st != ORBHIP_OK) return st;
     bool overflow = false;
     for (int f = 0; f < nimg; f++) {
-        n_out[f] = n[f];
-        const int m = std::min(n[f], cap);
-        if (n[f] > cap) overflow = true;
-        if (m > 0 && kps) HIPCHK(hipMemcpy(kps + (size_t)f * cap, c->d_out_kp[c->cur] + (size_t)f * c->out_cap, (size_t)m * sizeof(orbhip_keypoint), hipMemcpyDeviceToHost));
-        if (m > 0 && desc) HIPCHK(hipMemcpy(desc + (size_t)f * cap * 32, c->d_out_desc[c->cur] + (size_t)f * c->out_cap * 32, (size_t)m * 32, hipMemcpyDeviceToHost));
+        const int n = c->h_n[f];
+        n_out[f] = n;
+        const int m = std::min(n, cap);
+        if (n > cap) overflow = true;
+        if (m > 0 && kps) memcpy(kps + (size_t)f * cap, c->h_kp + (size_t)f * c->out_cap, (size_t)m * sizeof(orbhip_keypoint));
+        if (m > 0 && desc) memcpy(desc + (size_t)f * cap * 32, c->h_desc + (size_t)f * c->out_cap * 32, (size_t)m * 32);
     }
     return overflow ? fail(ORBHIP_ERR_CAPACITY, "keypoint buffer too small") : ORBHIP_OK;
 }
@@ -417,13 +446,18 @@ extern "C" orbhip_status orbhip_extract_batch(orbhip_ctx* c, int nimg, const uin
     if (nimg < 1 || nimg > c->B) return fail(ORBHIP_ERR_INVALID, "nimg %d outside 1..%d", nimg, c->B);
     if (stride < c->cfg.width) return fail(ORBHIP_ERR_INVALID, "stride %d < width %d", stride, c->cfg.width);
     HIPCHK(hipSetDevice(c->cfg.device));
-    const LevelGeom& g0 = c->geom[0];
+    orbhip_status st = ensure_host_staging(c, true); if (st != ORBHIP_OK) return st;
+    HIPCHK(hipStreamSynchronize(c->stream));                          // the pinned input mirror may still feed the previous call
+    const size_t fbytes = (size_t)c->in_pitch * c->cfg.height;
     for (int f = 0; f < nimg; f++) {
         if (!imgs[f]) return fail(ORBHIP_ERR_INVALID, "image %d is null", f);
-        HIPCHK(hipMemcpy2DAsync(c->d_pyr + (size_t)f * c->plane_frame_bytes + g0.plane_off, g0.pitch, imgs[f], stride, c->cfg.width, c->cfg.height, hipMemcpyHostToDevice, c->stream));
+        uint8_t* dst = c->h_in + f * fbytes;
+        if (stride == c->in_pitch) memcpy(dst, imgs[f], fbytes);
+        else for (int y = 0; y < c->cfg.height; y++) memcpy(dst + (size_t)y * c->in_pitch, imgs[f] + (size_t)y * stride, c->cfg.width);
     }
+    HIPCHK(hipMemcpyAsync(c->d_in, c->h_in, nimg * fbytes, hipMemcpyHostToDevice, c->stream));
     c->last_from_host = true;
-    orbhip_status st = run_pipeline(c, nimg, c->d_pyr + g0.plane_off, c->plane_frame_bytes, g0.pitch, 0, 0, 0.f, 0);
+    st = run_pipeline(c, nimg, c->d_in, (long long)fbytes, c->in_pitch, 0, 0, 0.f, 0);
     if (st != ORBHIP_OK) return st;
     return orbhip_fetch(c, nimg, kps, desc, cap, n_out);
 }
@@ -448,6 +482,7 @@ extern "C" orbhip_status orbhip_pyramid_level(orbhip_ctx* c, int frame, int leve
     if (!c || !dst || level < 0 || level >= c->L || frame < 0 || frame >= c->last_nimg) return fail(ORBHIP_ERR_INVALID, "bad argument");
     const LevelGeom& g = c->geom[level];
     if (level == 0 && !c->last_from_host) return fail(ORBHIP_ERR_INVALID, "level 0 of a device-resident call is the caller's own buffer");
+    if (level == 0) return copy_plane(c, c->d_in + (size_t)frame * c->in_pitch * c->cfg.height, c->in_pitch, g.w, g.h, dst, dst_stride);
     return copy_plane(c, c->d_pyr + (size_t)frame * c->plane_frame_bytes + g.plane_off, g.pitch, g.w, g.h, dst, dst_stride);
 }
 extern "C" orbhip_status orbhip_debug_blurred_level(orbhip_ctx* c, int frame, int level, uint8_t* dst, int dst_stride)
