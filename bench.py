@@ -163,6 +163,16 @@ def main():
         if alg == 0:
             alg = {"k_quadtree": 16 * 12 * 1024, "k_match_grid": NFEAT * 32, "k_match_candidates": 434 * 40 * 36, "k_match_select": 434 * 40 * 4}.get(dom, 0)
             note = "dominant kernel is latency-bound list/control work outside B(W,H,N); bytes = records it streams (DESIGN.md §4)"
+        # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs,
+        # B = 256 frames per launch): FETCH_SIZE counts half of a wide coalesced read on gfx950 (MI355X_MICROARCH.md §HBM) -> x2.
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
+                for row in json.load(f):
+                    if row["kernel"] == dom:
+                        traffic = int((2 * row["fetch_MB_per_dispatch_raw"] + row["write_MB_per_dispatch_raw"]) * 1024 * 1024 * B / 256)
+        except Exception:
+            traffic = None
         dur_s = kern[dom]["ms_per_launch"] * 1e-3
         achieved = (alg * B / dur_s) / 1e9 if dur_s > 0 else 0.0
         out = {
@@ -173,7 +183,7 @@ def main():
             "config": {"workload": "KITTI-shaped 1241x376 u8, 2000 features, 8 levels, scale 1.2, FAST 20/7, extract + SearchForInitialization(win 100, nnratio 0.9)",
                        "frames_per_step_per_gpu": B, "resident_time_steps": T, "row_pitch": pitch, "streams_per_gpu": args.streams, "parallelism": f"frames sharded over {world} GPU(s), no collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "alg_bytes_per_launch": alg * B, "launch_ms": round(kern[dom]["ms_per_launch"], 4), "note": note},
             "pipeline_roofline": {"alg_bytes_per_frame": ex.algorithmic_bytes_per_frame(),
                                   "achieved_GBps": round(ex.algorithmic_bytes_per_frame() * value / world / 1e9, 2),
