@@ -44,7 +44,7 @@ struct orbhip_ctx {
     int fc_maxpw = 0, fc_maxph = 0;
     long long plane_frame_bytes = 0, cand_slots_per_frame = 0, qt_per_frame = 0; int lvl_kp_per_frame = 0, out_cap = 0, qt_maxn = 0, qt_maxcells = 0, lvl0_cap = 0;
     // device
-    LevelGeom* d_geom = nullptr; CellDesc* d_cells = nullptr; TileDesc* d_tiles = nullptr; int2* d_xtab = nullptr; int2* d_ytab = nullptr; signed char* d_pattern = nullptr;
+    LevelGeom* d_geom = nullptr; CellDesc* d_cells = nullptr; TileDesc* d_tiles = nullptr; int2* d_xtab = nullptr; int2* d_ytab = nullptr; float* d_pattern = nullptr;
     uint8_t* d_pyr = nullptr; uint8_t* d_blur = nullptr; int* d_cell_count = nullptr; unsigned* d_cell_cand = nullptr;
     unsigned* d_qt_val = nullptr; unsigned* d_qt_code = nullptr; int* d_qt_node = nullptr; unsigned* d_lvl_kp = nullptr;
     // outputs are triple-buffered: batch t writes buffer t%3 while the matcher of batch t-1 (own stream) still reads buffers (t-1)%3 and (t-2)%3
@@ -255,7 +255,7 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
         if (!ok) { orbhip_destroy(c); return fail(ORBHIP_ERR_HIP, "match stream creation failed"); }
     }
     const size_t B = (size_t)c->B;
-    std::vector<signed char> pat(kPatternHost, kPatternHost + 1024);
+    std::vector<float> pat(kPatternHost, kPatternHost + 1024);
     hipError_t e = hipSuccess;
 #define TRY(x) do { if (e == hipSuccess) e = (x); } while (0)
     TRY(upload(&c->d_geom, c->geom)); TRY(upload(&c->d_cells, c->cells)); TRY(upload(&c->d_tiles, c->blur_tiles));
@@ -306,7 +306,7 @@ static ExtractParams make_params(orbhip_ctx* c, const uint8_t* d_img0, long long
     P.lvl_kp = c->d_lvl_kp; P.lvl_kp_per_frame = c->lvl_kp_per_frame; P.lvl_n = c->d_lvl_n[c->cur];
     P.out_kp = c->d_out_kp[c->cur]; P.out_desc = c->d_out_desc[c->cur]; P.out_n = c->d_out_n[c->cur]; P.out_cap = c->out_cap;
     P.blur_tiles = c->d_tiles; P.nblur_tiles = (int)c->blur_tiles.size();
-    P.xtab = c->d_xtab; P.ytab = c->d_ytab; P.pattern = c->d_pattern;
+    P.xtab = c->d_xtab; P.ytab = c->d_ytab; P.patternf = c->d_pattern;
     P.iniTh = c->cfg.ini_th_fast; P.minTh = c->cfg.min_th_fast; P.blur_round_mode = c->cfg.blur_round_mode;
     P.qt_maxn = c->qt_maxn; P.qt_maxcells = c->qt_maxcells;
     P.fc_pstride = (c->fc_maxpw + 8 + 3) & ~3; P.fc_prows = c->fc_maxph; P.fc_sstride = 8 + 4 * ((std::max(c->fc_maxpw - 6, 0) + 3) / 4); P.fc_srows = std::max(c->fc_maxph - 6, 0) + 2;

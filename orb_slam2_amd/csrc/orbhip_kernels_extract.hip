@@ -233,7 +233,7 @@ void orbhip_launch_blur(const ExtractParams& P, const int gk[4], int nframes, hi
 //      interior count as 0, exactly like FAST on the cell sub-image);
 //   D. survivors are emitted in row-major order.
 #define FC_WAVES 4
-#define FC_LD 8                        // patch dwords a lane keeps in flight
+#define FC_LD 6                        // patch-load passes a lane keeps in flight
 
 typedef unsigned short pku16 __attribute__((vector_size(4)));      // two u16 lanes in one VGPR -> v_pk_min_u16 / v_pk_max_u16
 typedef short pki16 __attribute__((vector_size(4)));
@@ -282,7 +282,7 @@ __host__ __device__ __forceinline__ int fc_wave_bytes(int pstride, int prows, in
 __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
 {
     HIP_DYNAMIC_SHARED(unsigned, fc_lds)
-    __shared__ unsigned long long s_mini[FC_WAVES][64], s_mmin[FC_WAVES][64];
+    __shared__ unsigned long long s_mmin[FC_WAVES][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int tile, frame;
     if (!xcd_frame_map((P.ncells_total + FC_WAVES - 1) / FC_WAVES, P.nframes, tile, frame)) return;
@@ -305,24 +305,27 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
         src += (long long)cd.iniY * spitch + cd.iniX;
         const int nd = (pw + 3) >> 2;
         if (((((unsigned long long)src - cd.iniX) | (unsigned long long)spitch) & 3ull) == 0) {
-            // aligned 32-bit loads, funnel-shifted so that patch column 0 lands on an LDS dword boundary; FC_LD loads are
-            // put in flight before the first LDS write (one memory latency per batch instead of one per dword)
+            // aligned 32-bit loads, funnel-shifted so that patch column 0 lands on an LDS dword boundary.  Lane = (row, dword
+            // column) with 16 (or 32) lanes per row; FC_LD passes are put in flight before the first LDS write.
             const int sa = cd.iniX & 3, sh = 8 * sa;
-            const uint8_t* gbase = src - sa;
-            int r = 0, d = lane;
-            while (d >= nd) { d -= nd; r++; }
-            while (r < ph) {
-                int rr[FC_LD], dd[FC_LD]; unsigned lo[FC_LD], hi[FC_LD];
-#pragma unroll
-                for (int k = 0; k < FC_LD; k++) { rr[k] = r; dd[k] = d; d += 64; while (d >= nd) { d -= nd; r++; } }
+            const int lw = nd <= 16 ? 4 : 5, rpp = 64 >> lw;             // log2 lanes per row, rows per pass
+            const int d = lane & ((1 << lw) - 1), r0 = lane >> lw;
+            const unsigned* gp = reinterpret_cast<const unsigned*>(src - sa) + d;
+            unsigned* lp = reinterpret_cast<unsigned*>(patch) + d;
+            const int gstep = spitch >> 2, lstep = PS >> 2;
+            for (int rb = 0; rb < ph; rb += FC_LD * rpp) {
+                unsigned lo[FC_LD], hi[FC_LD];
 #pragma unroll
                 for (int k = 0; k < FC_LD; k++) {
+                    const int r = rb + k * rpp + r0;
                     lo[k] = 0; hi[k] = 0;
-                    if (rr[k] < ph) { const unsigned* gp = reinterpret_cast<const unsigned*>(gbase + (long long)rr[k] * spitch) + dd[k]; lo[k] = gp[0]; if (sa) hi[k] = gp[1]; }
+                    if (d < nd && r < ph) { lo[k] = gp[(long long)r * gstep]; if (sa) hi[k] = gp[(long long)r * gstep + 1]; }
                 }
 #pragma unroll
-                for (int k = 0; k < FC_LD; k++)
-                    if (rr[k] < ph) reinterpret_cast<unsigned*>(patch + rr[k] * PS)[dd[k]] = (unsigned)((((unsigned long long)hi[k] << 32) | lo[k]) >> sh);
+                for (int k = 0; k < FC_LD; k++) {
+                    const int r = rb + k * rpp + r0;
+                    if (d < nd && r < ph) lp[r * lstep] = (unsigned)((((unsigned long long)hi[k] << 32) | lo[k]) >> sh);
+                }
             }
         } else {
             int r = 0, c = lane;
@@ -377,41 +380,51 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
         ncorn += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
     }
     __syncthreads();
-    // ---- C. non-max suppression inside the cell
+    // ---- C. non-max suppression inside the cell.  Survivors with score >= iniThFAST are emitted on the fly (the common
+    //      case: the first cv::FAST call of the reference returned something); the minThFAST set is only kept as masks.
     int count_ini = 0, count_min = 0;
     const int nchunks = (ncorn + 63) >> 6;
+    unsigned* out = P.cell_cand + (long long)frame * P.cand_slots_per_frame + cd.cand_idx;
+    const unsigned long long below = (1ull << lane) - 1ull;
     for (int cb = 0; cb < nchunks; cb++) {
         const int i = cb * 64 + lane;
-        bool keep = false; int sc = 0;
+        bool keep = false; int sc = 0, id = 0;
         if (i < ncorn) {
-            const int id = list[i];
+            id = list[i];
             const uint8_t* q = &score[((id >> 8) + 1) * SS + (id & 0xff) + 4];
             sc = q[0];
             keep = sc > q[-1] && sc > q[1] && sc > q[-SS - 1] && sc > q[-SS] && sc > q[-SS + 1] &&
                    sc > q[SS - 1] && sc > q[SS] && sc > q[SS + 1];
         }
-        const unsigned long long mmin = __ballot(keep), mini = __ballot(keep && sc >= P.iniTh);
-        if (lane == 0) { s_mmin[wave][cb] = mmin; s_mini[wave][cb] = mini; }
+        const bool kini = keep && sc >= P.iniTh;
+        const unsigned long long mmin = __ballot(keep), mini = __ballot(kini);
+        if (kini) {
+            const int rank = count_ini + __popcll(mini & below);
+            // FAST reports cell-local (x, y); the reference adds (j*wCell, i*hCell)  (ORBextractor.cc:822-823)
+            const unsigned px = (unsigned)((id & 0xff) + 3 + cd.shiftX), py = (unsigned)((id >> 8) + 3 + cd.shiftY);
+            if (rank < cd.cand_cap) out[rank] = px | (py << 12) | ((unsigned)sc << 24);
+        }
+        if (lane == 0) s_mmin[wave][cb] = mmin;
         count_min += __popcll(mmin); count_ini += __popcll(mini);
     }
     __syncthreads();
     if (!active) return;
-    // ---- D. emission
-    const bool use_ini = count_ini > 0;                               // vKeysCell.empty() after the iniThFAST call?
+    // ---- D. vKeysCell.empty() after the iniThFAST call -> the minThFAST set is emitted instead (ORBextractor.cc:812-816)
+    const bool use_ini = count_ini > 0;
     const int total = use_ini ? count_ini : count_min;
-    int base = 0;
-    unsigned* out = P.cell_cand + (long long)frame * P.cand_slots_per_frame + cd.cand_idx;
-    for (int cb = 0; cb < nchunks; cb++) {
-        const unsigned long long m = use_ini ? s_mini[wave][cb] : s_mmin[wave][cb];
-        if ((m >> lane) & 1ull) {
-            const int id = list[cb * 64 + lane], y = id >> 8, x = id & 0xff;
-            const int rank = base + __popcll(m & ((1ull << lane) - 1ull));
-            const int sc = score[(y + 1) * SS + x + 4];
-            // FAST reports cell-local (x, y); the reference adds (j*wCell, i*hCell)  (ORBextractor.cc:822-823)
-            const unsigned px = (unsigned)(x + 3 + cd.shiftX), py = (unsigned)(y + 3 + cd.shiftY);
-            if (rank < cd.cand_cap) out[rank] = px | (py << 12) | ((unsigned)sc << 24);
+    if (!use_ini) {
+        int base = 0;
+        for (int cb = 0; cb < nchunks; cb++) {
+            const unsigned long long m = s_mmin[wave][cb];
+            if ((m >> lane) & 1ull) {
+                const int id = list[cb * 64 + lane], y = id >> 8, x = id & 0xff;
+                const int rank = base + __popcll(m & below);
+                const int sc = score[(y + 1) * SS + x + 4];
+                const unsigned px = (unsigned)(x + 3 + cd.shiftX), py = (unsigned)(y + 3 + cd.shiftY);
+                if (rank < cd.cand_cap) out[rank] = px | (py << 12) | ((unsigned)sc << 24);
+            }
+            base += __popcll(m);
         }
-        base += __popcll(m);
     }
     if (lane == 0) P.cell_count[(long long)frame * P.ncells_total + cell_id] = min(total, cd.cand_cap);
 }
@@ -747,6 +760,20 @@ __device__ __forceinline__ void dev_sincosf(float y, float* sinp, float* cosp)
     if (n & 1) { *cosp = sv; *sinp = cv; } else { *sinp = sv; *cosp = cv; }
 }
 
+// wave64 sum with DPP row shifts / broadcasts (4-cycle VALU ops) instead of 24-cycle ds_bpermute shuffles; total in lane 63
+__device__ __forceinline__ int wave_sum_dpp(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);      // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);      // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xe, true);      // row_shr:4, banks 1-3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xc, true);      // row_shr:8, banks 2-3  -> lane 15 of each row = row total
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);      // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);      // row_bcast:31 into rows 2 and 3 -> lane 63 = wave total
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// cvRound for |x| < 2^22: adding 1.5*2^23 rounds to the nearest integer, ties to even, exactly like cvRound / rint
+__device__ __forceinline__ int round_half_even_small(float x) { return __float_as_int(__fadd_rn(x, 12582912.0f)) - 0x4B400000; }
+
 #define DS_WAVES 4
 #define DS_WROWS 37                    // blurred window rows: pattern reach is +-18 after rotation
 #define DS_WDW 11                      // dwords per staged window row (37 bytes + up to 3 bytes of alignment slack)
@@ -773,22 +800,21 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
     const unsigned v = P.lvl_kp[(long long)frame * P.lvl_kp_per_frame + slot];
     const int cx = v & 0xfff, cy = (v >> 12) & 0xfff, sc = v >> 24;
 
-    // ---- all global loads of this keypoint are issued up-front
-    // (a) rBRIEF pattern of this lane's 4 tests
-    const unsigned* pat = reinterpret_cast<const unsigned*>(P.pattern);
-    unsigned pt[4];
+    // ---- all global loads of this keypoint are issued up-front (wave-uniform base + 32-bit lane offsets)
+    // (a) rBRIEF pattern of this lane's 4 tests, stored as floats (x0, y0, x1, y1)
+    const float4* pat = reinterpret_cast<const float4*>(P.patternf);
+    float4 pt[4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) pt[r] = pat[r * 64 + lane];
+    for (int r = 0; r < 4; r++) pt[r] = pat[(unsigned)(r * 64 + lane)];
     // (b) 31x31 orientation patch of the un-blurred level: lane = column u (coalesced rows), two rows per load
     int spitch; const uint8_t* img = level_src(P, frame, level, spitch);
     const int half = lane >> 5, u = (lane & 31) - 15;              // lanes 0..30 and 32..62 carry columns -15..15
     const bool col_ok = (lane & 31) < 31;
+    const unsigned ioff = (unsigned)((cy + half - 15) * spitch + cx + u);
     int pxv[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int vr = 2 * k + half - 15;                           // rows -15..16; row 16 (k = 15, half = 1) is unused
-        pxv[k] = (col_ok && vr <= 15) ? img[(long long)(cy + vr) * spitch + cx + u] : 0;
-    }
+    for (int k = 0; k < 16; k++)                                    // rows 2k + half - 15 = -15..16; row 16 (k = 15, half = 1) is unused
+        pxv[k] = (col_ok && 2 * k + half <= 30) ? img[ioff + (unsigned)(2 * k * spitch)] : 0;
     // (c) 37-row window of the blurred level -> LDS with aligned 32-bit loads (keypoints keep >= 19 px from every border)
     const uint8_t* blv = P.blur + (long long)frame * P.plane_frame_bytes + g.plane_off;
     const int wx0 = (cx - 18) & ~3;                                 // window byte x of LDS column 0 (level pitch and plane offsets are multiples of 4)
@@ -797,7 +823,7 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
 #pragma unroll
     for (int k = 0; k < 7; k++) {
         const int idx = lane + 64 * k, r = idx / DS_WDW, d = idx - r * DS_WDW;
-        wv[k] = (idx < DS_WROWS * DS_WDW) ? *reinterpret_cast<const unsigned*>(blv + (long long)(cy - 18 + r) * g.pitch + wx0 + 4 * d) : 0u;
+        wv[k] = (idx < DS_WROWS * DS_WDW) ? *reinterpret_cast<const unsigned*>(blv + (unsigned)((cy - 18 + r) * g.pitch + wx0 + 4 * d)) : 0u;
     }
 #pragma unroll
     for (int k = 0; k < 7; k++) { const int idx = lane + 64 * k; if (idx < DS_WROWS * DS_WDW) win[idx] = wv[k]; }
@@ -813,24 +839,21 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
         for (int k = 0; k < 16; k++) { const int vr = 2 * k + half - 15; const int p = (vr >= -vm && vr <= vm) ? pxv[k] : 0; s += p; sv += vr * p; }
         m10 = u * s; m01 = sv;
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { m10 += __shfl_xor(m10, off); m01 += __shfl_xor(m01, off); }
+    m10 = wave_sum_dpp(m10); m01 = wave_sum_dpp(m01);
     const float angle = dev_fast_atan2((float)m01, (float)m10);
 
     // ---- steered BRIEF (ORBextractor.cc:107-147) on the blurred window in LDS
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     float a, b; dev_sincosf(__fmul_rn(angle, factorPI), &b, &a);
     __syncthreads();                                               // window visible to all lanes of the wave (exited waves do not participate)
-    const uint8_t* w8 = reinterpret_cast<const uint8_t*>(win);
-    const int ox = cx - wx0, oy = 18;                               // keypoint position inside the window
+    const uint8_t* w8 = reinterpret_cast<const uint8_t*>(win) + 18 * (DS_WDW * 4) + (cx - wx0);   // keypoint position inside the window
     unsigned long long* dout = reinterpret_cast<unsigned long long*>(P.out_desc + ((long long)frame * P.out_cap + oi) * 32);
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        const float x0 = (float)(signed char)(pt[r] & 0xff), y0 = (float)(signed char)((pt[r] >> 8) & 0xff);
-        const float x1 = (float)(signed char)((pt[r] >> 16) & 0xff), y1 = (float)(signed char)(pt[r] >> 24);
-        const int iy0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a))), ix0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-        const int iy1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a))), ix1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        const int t0 = w8[(oy + iy0) * (DS_WDW * 4) + ox + ix0], t1 = w8[(oy + iy1) * (DS_WDW * 4) + ox + ix1];
+        const float x0 = pt[r].x, y0 = pt[r].y, x1 = pt[r].z, y1 = pt[r].w;
+        const int iy0 = round_half_even_small(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a))), ix0 = round_half_even_small(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+        const int iy1 = round_half_even_small(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a))), ix1 = round_half_even_small(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+        const int t0 = w8[iy0 * (DS_WDW * 4) + ix0], t1 = w8[iy1 * (DS_WDW * 4) + ix1];
         const unsigned long long bits = __ballot(t0 < t1);       // test 64r+lane -> byte (64r+lane)/8, bit lane%8
         if (lane == 0) dout[r] = bits;
     }
