@@ -37,7 +37,7 @@ struct ProfSpan { int k; hipEvent_t a, b; };
 struct orbhip_ctx {
     orbhip_config cfg; int L = 0, B = 0;
     std::vector<LevelGeom> geom; std::vector<float> sf, isf, s2, is2; std::vector<int> nfeat;
-    std::vector<CellDesc> cells; std::vector<TileDesc> blur_tiles; std::vector<int2> xtab, ytab;
+    std::vector<CellDesc> cells; std::vector<TileDesc> blur_tiles; std::vector<int2> xtab, ytab; std::vector<char> pyr_staged;
     int gk[4] = {0, 0, 0, 0};
     hipStream_t stream = nullptr; bool own_stream = false;
     std::vector<hipStream_t> xstreams; std::vector<hipEvent_t> xevents; hipEvent_t ev_fork = nullptr;     // extra streams of a multi-stream context
@@ -231,6 +231,11 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
             g.src_w = c->geom[l - 1].w; g.src_h = c->geom[l - 1].h;
             g.xtab_off = (int)c->xtab.size(); build_resize_table(g.src_w, g.w, c->xtab);
             g.ytab_off = (int)c->ytab.size(); build_yresize_table(g.src_h, g.h, c->ytab);
+            // does every output tile's source footprint fit the LDS stage of k_pyramid_level?
+            const int tw = orbhip_pyramid_tile_w(), th = orbhip_pyramid_tile_h(); bool fits = true;
+            for (int x0 = 0; x0 < g.w; x0 += tw) { const int xl = std::min(x0 + tw - 1, g.w - 1); const int a = c->xtab[g.xtab_off + x0].x & ~3, b = std::min(c->xtab[g.xtab_off + xl].x + 1, g.src_w - 1); fits = fits && orbhip_pyramid_tile_fits(b - a + 1, 1); }
+            for (int y0 = 0; y0 < g.h; y0 += th) { const int yl = std::min(y0 + th - 1, g.h - 1); const int a = std::min(std::max(c->ytab[g.ytab_off + y0].x, 0), g.src_h - 1), b = std::min(std::max(c->ytab[g.ytab_off + yl].x + 1, 0), g.src_h - 1); fits = fits && orbhip_pyramid_tile_fits(1, b - a + 1); }
+            c->pyr_staged.resize(L, 0); c->pyr_staged[l] = fits ? 1 : 0;
         }
         for (int y0 = 0; y0 < g.h; y0 += 32) for (int x0 = 0; x0 < g.w; x0 += 128) { TileDesc t; t.level = (short)l; t.x0 = (short)x0; t.y0 = (short)y0; t.pad = 0; c->blur_tiles.push_back(t); }
     }
@@ -332,7 +337,7 @@ static orbhip_status run_pipeline(orbhip_ctx* c, int nimg, const uint8_t* d_img0
         if (gi > 0) HIPCHK(hipStreamWaitEvent(s, c->ev_fork, 0));
         if (nf <= 0) continue;
         P.frame0 = f0;
-        { ProfScope ps(c, K_PYRAMID, s); for (int l = 1; l < c->L; l++) orbhip_launch_pyramid_level(P, l, c->geom[l].w, c->geom[l].h, nf, s); }
+        { ProfScope ps(c, K_PYRAMID, s); for (int l = 1; l < c->L; l++) orbhip_launch_pyramid_level(P, l, c->geom[l].w, c->geom[l].h, c->pyr_staged[l] != 0, nf, s); }
         { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nf, s); }
         { ProfScope ps(c, K_BLUR, s); orbhip_launch_blur(P, c->gk, nf, s); }
         { ProfScope ps(c, K_QUADTREE, s); orbhip_launch_quadtree(P, nf, s); }

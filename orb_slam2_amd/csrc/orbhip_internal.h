@@ -87,7 +87,10 @@ struct MatchParams {        // SearchForInitialization over camera slots (ORBmat
 };
 
 // kernel launchers (orbhip_kernels_extract.hip / orbhip_kernels_match.hip)
-void orbhip_launch_pyramid_level(const ExtractParams& P, int level, int w, int h, int nframes, hipStream_t s);
+void orbhip_launch_pyramid_level(const ExtractParams& P, int level, int w, int h, bool staged, int nframes, hipStream_t s);
+bool orbhip_pyramid_tile_fits(int src_cols_per_tile, int src_rows_per_tile);
+int orbhip_pyramid_tile_w();
+int orbhip_pyramid_tile_h();
 void orbhip_launch_blur(const ExtractParams& P, const int gk[4], int nframes, hipStream_t s);
 void orbhip_launch_fast_cells(const ExtractParams& P, int nframes, hipStream_t s);
 void orbhip_launch_quadtree(const ExtractParams& P, int nframes, hipStream_t s);

@@ -38,6 +38,35 @@ __device__ __forceinline__ const uint8_t* level_src(const ExtractParams& P, int 
 // cv::resize INTER_LINEAR CV_8U (OpenCV 3.2 HResizeLinear / VResizeLinear fixed point, 11-bit coefficients).
 // Coefficient tables are built on the host exactly as OpenCV builds them; the kernel is pure integer.
 // 4 output pixels per thread, one 32-bit store.
+// 4 output pixels of 2 consecutive rows from source rows addressed as rows[(y - row0) * rpitch + x]
+__device__ __forceinline__ void pyr_rows(const LevelGeom& g, const int2* xt, const int2* yt, const uint8_t* rows, int rpitch, int row0, int x4, int ytop, uint8_t* dstp)
+{
+    int sx[4], sx1[4], a0[4], a1[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int2 e = xt[min(x4 + k, g.w - 1)];
+        sx[k] = e.x; sx1[k] = min(e.x + 1, g.src_w - 1); a0[k] = e.y & 0xffff; a1[k] = (e.y >> 16) & 0xffff;
+    }
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+        const int y = ytop + rr;
+        if (y >= g.h) break;
+        const int2 ye = yt[y];
+        const int b0 = ye.y & 0xffff, b1 = (ye.y >> 16) & 0xffff;
+        const int ya = min(max(ye.x, 0), g.src_h - 1), yb = min(max(ye.x + 1, 0), g.src_h - 1);
+        const uint8_t* r0 = rows + (long long)(ya - row0) * rpitch;
+        const uint8_t* r1 = rows + (long long)(yb - row0) * rpitch;
+        unsigned out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int h0 = r0[sx[k]] * a0[k] + r0[sx1[k]] * a1[k], h1 = r1[sx[k]] * a0[k] + r1[sx1[k]] * a1[k];
+            const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            if (x4 + k < g.w) out |= (unsigned)(v & 0xff) << (8 * k);
+        }
+        *reinterpret_cast<unsigned*>(dstp + (long long)y * g.pitch) = out;
+    }
+}
+
 // Workgroup = 256 x 8 output pixels: the source footprint (<= 12 rows x ~312 bytes) is staged in LDS with 32-bit loads,
 // each thread then produces 4 pixels of 2 rows (one 32-bit store per row).
 #define PYR_TW 256
@@ -60,9 +89,8 @@ __global__ __launch_bounds__(256) void k_pyramid_level(ExtractParams P, int leve
     const int sxa = xt[x0].x & ~3, sxb = min(xt[xl].x + 1, g.src_w - 1);                    // staged source columns [sxa, sxb]
     const int sya = min(max(yt[y0].x, 0), g.src_h - 1), syb = min(max(yt[yl].x + 1, 0), g.src_h - 1);
     const int ndw = ((sxb - sxa) >> 2) + 1, nrows = syb - sya + 1;
-    const bool fits = ndw <= PYR_SDW && nrows <= PYR_SROWS;                                  // always true for scale factors >= ~1.05
     const bool aligned = ((((unsigned long long)src) | (unsigned long long)spitch) & 3ull) == 0;
-    if (fits) {
+    {
         unsigned v[4]; bool edge[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -81,44 +109,35 @@ __global__ __launch_bounds__(256) void k_pyramid_level(ExtractParams P, int leve
     __syncthreads();
     const int x4 = x0 + threadIdx.x * 4;
     if (x4 >= g.w) return;
-    const uint8_t* t8 = reinterpret_cast<const uint8_t*>(s_t);
-    int sx[4], sx1[4], a0[4], a1[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int2 e = xt[min(x4 + k, g.w - 1)];
-        sx[k] = e.x; sx1[k] = min(e.x + 1, g.src_w - 1); a0[k] = e.y & 0xffff; a1[k] = (e.y >> 16) & 0xffff;
-    }
-#pragma unroll
-    for (int rr = 0; rr < 2; rr++) {
-        const int y = y0 + threadIdx.y * 2 + rr;
-        if (y >= g.h) break;
-        const int2 ye = yt[y];
-        const int b0 = ye.y & 0xffff, b1 = (ye.y >> 16) & 0xffff;
-        const int ya = min(max(ye.x, 0), g.src_h - 1), yb = min(max(ye.x + 1, 0), g.src_h - 1);
-        unsigned out = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            int p00, p01, p10, p11;
-            if (fits) {
-                const uint8_t* r0 = t8 + (ya - sya) * (PYR_SDW * 4) - sxa, *r1 = t8 + (yb - sya) * (PYR_SDW * 4) - sxa;
-                p00 = r0[sx[k]]; p01 = r0[sx1[k]]; p10 = r1[sx[k]]; p11 = r1[sx1[k]];
-            } else {
-                const uint8_t* r0 = src + (long long)ya * spitch, *r1 = src + (long long)yb * spitch;
-                p00 = r0[sx[k]]; p01 = r0[sx1[k]]; p10 = r1[sx[k]]; p11 = r1[sx1[k]];
-            }
-            const int h0 = p00 * a0[k] + p01 * a1[k], h1 = p10 * a0[k] + p11 * a1[k];
-            const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-            if (x4 + k < g.w) out |= (unsigned)(v & 0xff) << (8 * k);
-        }
-        *reinterpret_cast<unsigned*>(P.pyr + (long long)frame * P.plane_frame_bytes + g.plane_off + (long long)y * g.pitch + x4) = out;
-    }
+    uint8_t* dstp = P.pyr + (long long)frame * P.plane_frame_bytes + g.plane_off + x4;
+    pyr_rows(g, xt, yt, reinterpret_cast<const uint8_t*>(s_t) - sxa, PYR_SDW * 4, sya, x4, y0 + threadIdx.y * 2, dstp);
 }
 
-void orbhip_launch_pyramid_level(const ExtractParams& P, int level, int w, int h, int nframes, hipStream_t s)
+// Same arithmetic straight from global memory: used for scale factors whose source footprint does not fit the LDS tile
+// (the host decides per level from the coefficient tables).
+__global__ __launch_bounds__(256) void k_pyramid_level_direct(ExtractParams P, int level)
+{
+    const LevelGeom g = P.geom[level];
+    const int gx = (g.w + PYR_TW - 1) / PYR_TW, gy = (g.h + PYR_TH - 1) / PYR_TH;
+    int tile, frame;
+    if (!xcd_frame_map(gx * gy, P.nframes, tile, frame)) return;
+    frame += P.frame0;
+    const int x4 = (tile % gx) * PYR_TW + threadIdx.x * 4, ytop = (tile / gx) * PYR_TH + threadIdx.y * 2;
+    if (x4 >= g.w) return;
+    int spitch; const uint8_t* src = level_src(P, frame, level - 1, spitch);
+    pyr_rows(g, P.xtab + g.xtab_off, P.ytab + g.ytab_off, src, spitch, 0, x4, ytop, P.pyr + (long long)frame * P.plane_frame_bytes + g.plane_off + x4);
+}
+
+bool orbhip_pyramid_tile_fits(int src_cols_per_tile, int src_rows_per_tile) { return ((src_cols_per_tile + 3) >> 2) + 1 <= PYR_SDW && src_rows_per_tile <= PYR_SROWS; }
+int orbhip_pyramid_tile_w() { return PYR_TW; }
+int orbhip_pyramid_tile_h() { return PYR_TH; }
+
+void orbhip_launch_pyramid_level(const ExtractParams& P, int level, int w, int h, bool staged, int nframes, hipStream_t s)
 {
     ExtractParams Q = P; Q.nframes = nframes;
     dim3 grid(xcd_grid(((w + PYR_TW - 1) / PYR_TW) * ((h + PYR_TH - 1) / PYR_TH), nframes), 1, 1), block(64, 4, 1);
-    hipLaunchKernelGGL(k_pyramid_level, grid, block, 0, s, Q, level);
+    if (staged) hipLaunchKernelGGL(k_pyramid_level, grid, block, 0, s, Q, level);
+    else hipLaunchKernelGGL(k_pyramid_level_direct, grid, block, 0, s, Q, level);
 }
 
 // ------------------------------------------------------------------------------------------------ blur

@@ -26,9 +26,13 @@ def test_library_is_built_for_gfx950_and_exports_every_declared_symbol():
     from orb_slam2_amd import orbhip
     assert sorted(orbhip.SYMBOLS) == names, "orbhip.py binding list out of sync with the header"
     # the code object inside is gfx950 (no other offload target is ever built)
-    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", LIB], capture_output=True, text=True).stdout
+    import shutil
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:                      # llvm-objdump --offloading drops the extracted code object next to its input
+        tmp = shutil.copy(LIB, td)
+        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", tmp], capture_output=True, text=True, cwd=td).stdout
     if out.strip():
-        assert "gfx950" in out and "gfx9" in out
+        assert "gfx950" in out
 
 
 def test_no_cpu_fallback_without_gpu():

@@ -101,6 +101,20 @@ def test_batch_strides_thresholds_and_round_mode(backend, oracle):
     ex.close()
 
 
+def test_large_scale_factor_uses_direct_pyramid(backend, oracle):
+    """scaleFactor 1.6: the 256-px output tile's source footprint exceeds the LDS stage -> direct-from-global pyramid kernel."""
+    w, h, n = 640, 480, 300
+    img = synth.frame(w, h, seed=5)
+    ora = oracle.OracleExtractor(n, 1.6, 4, 20, 7)
+    ko, do = ora.extract(img)
+    ex = orb_slam2_amd.ORBextractor(n, 1.6, 4, 20, 7, w, h, library=backend)
+    kg, dg = ex(img)
+    for l in range(4):
+        assert np.array_equal(ex.mvImagePyramid(l), ora.level(l))
+    _same(kg, dg, ko, do)
+    ex.close()
+
+
 def test_unsupported_and_invalid_configs(backend):
     with pytest.raises(orb_slam2_amd.OrbHipError):
         orb_slam2_amd.ORBextractor(500, 1.2, 8, 20, 7, 200, 120, library=backend)     # top level < 62 px: the reference itself divides by zero
