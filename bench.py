@@ -102,10 +102,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the ORB front-end has no CPU fallback")
+    # ORB_BENCH_SHARE_GPU=1 (test aid): all ranks use GPU 0 and rendezvous over gloo, to exercise the N>1 code path on a 1-GPU box
+    share = os.environ.get("ORB_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     import orb_slam2_amd
 
     B, T = args.batch, max(args.tsteps, 2)
@@ -140,7 +147,7 @@ def main():
     prof = ex.profile()
     ex.profile_enable(False)
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else f"cuda:{local_rank}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

@@ -15,6 +15,7 @@ for cfg in "64 1" "128 1" "256 1" "512 1" "256 2"; do set -- $cfg; timeout 200 p
 find /tmp/prof_$TAG -name "*stats*" -o -name "*kernel_trace*" | head -20 > $OUT/prof_files.txt
 for f in $(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -2); do cp $f $OUT/; done
 for f in $(find /tmp/prof_$TAG -name "*kernel_trace.csv" | head -1); do head -400 $f > $OUT/kernel_trace_head.csv; done
+ORB_BENCH_SHARE_GPU=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 --batch 32 > $OUT/bench_2rank_shared.json 2>> $OUT/bench.err; cat $OUT/bench_2rank_shared.json | cut -c1-300
 timeout 120 python tools/host_io_rate.py > $OUT/host_io.json 2>> $OUT/bench.err; cat $OUT/host_io.json
 timeout 120 tools/ubench > $OUT/ubench.txt 2>&1; cat $OUT/ubench.txt
 tail -5 $OUT/pytest_gpu.log; tail -3 $OUT/smoke.log; cat $OUT/bench.json; python - <<PY
