@@ -49,6 +49,7 @@ struct orbhip_ctx {
     unsigned* d_qt_val = nullptr; unsigned* d_qt_code = nullptr; int* d_qt_node = nullptr; unsigned* d_lvl_kp = nullptr;
     // outputs are triple-buffered: batch t writes buffer t%3 while the matcher of batch t-1 (own stream) still reads buffers (t-1)%3 and (t-2)%3
     int* d_lvl_n[3] = {nullptr, nullptr, nullptr}; orbhip_keypoint* d_out_kp[3] = {nullptr, nullptr, nullptr}; uint8_t* d_out_desc[3] = {nullptr, nullptr, nullptr}; int* d_out_n[3] = {nullptr, nullptr, nullptr};
+    hipStream_t bstream = nullptr; hipEvent_t ev_pyr = nullptr, ev_blur = nullptr;      // blur runs beside FAST + quadtree (independent until describe)
     hipStream_t mstream = nullptr; hipEvent_t ev_extract = nullptr; hipEvent_t ev_match[3] = {nullptr, nullptr, nullptr}; bool match_pending[3] = {false, false, false};
     int cur = 0; int last_nimg = 0; bool last_matched = false; bool last_from_host = false;
     // host-buffer API staging: one contiguous device input buffer + pinned host mirrors (single bulk copies instead of per-frame pageable copies)
@@ -129,6 +130,9 @@ extern "C" void orbhip_destroy(orbhip_ctx* c)
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->mstream) { (void)hipStreamSynchronize(c->mstream); (void)hipStreamDestroy(c->mstream); }
+    if (c->bstream) { (void)hipStreamSynchronize(c->bstream); (void)hipStreamDestroy(c->bstream); }
+    if (c->ev_pyr) (void)hipEventDestroy(c->ev_pyr);
+    if (c->ev_blur) (void)hipEventDestroy(c->ev_blur);
     if (c->ev_extract) (void)hipEventDestroy(c->ev_extract);
     for (auto e : c->ev_match) if (e) (void)hipEventDestroy(e);
     for (auto xs : c->xstreams) { (void)hipStreamSynchronize(xs); (void)hipStreamDestroy(xs); }
@@ -255,7 +259,9 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
     }
     if (!c->xstreams.empty() && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { orbhip_destroy(c); return fail(ORBHIP_ERR_HIP, "event creation failed"); }
     {   // the matcher runs on its own stream so that it overlaps the next batch's extraction
-        bool ok = hipStreamCreateWithFlags(&c->mstream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&c->ev_extract, hipEventDisableTiming) == hipSuccess;
+        bool ok = hipStreamCreateWithFlags(&c->mstream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&c->ev_extract, hipEventDisableTiming) == hipSuccess &&
+                  hipStreamCreateWithFlags(&c->bstream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&c->ev_pyr, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&c->ev_blur, hipEventDisableTiming) == hipSuccess;
         for (int k = 0; k < 3 && ok; k++) ok = hipEventCreateWithFlags(&c->ev_match[k], hipEventDisableTiming) == hipSuccess;
         if (!ok) { orbhip_destroy(c); return fail(ORBHIP_ERR_HIP, "match stream creation failed"); }
     }
@@ -338,9 +344,19 @@ static orbhip_status run_pipeline(orbhip_ctx* c, int nimg, const uint8_t* d_img0
         if (nf <= 0) continue;
         P.frame0 = f0;
         { ProfScope ps(c, K_PYRAMID, s); for (int l = 1; l < c->L; l++) orbhip_launch_pyramid_level(P, l, c->geom[l].w, c->geom[l].h, c->pyr_staged[l] != 0, nf, s); }
-        { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nf, s); }
-        { ProfScope ps(c, K_BLUR, s); orbhip_launch_blur(P, c->gk, nf, s); }
-        { ProfScope ps(c, K_QUADTREE, s); orbhip_launch_quadtree(P, nf, s); }
+        if (ngroups == 1) {
+            // the blur only meets the detector again in k_describe: run it on its own stream beside FAST + quadtree
+            HIPCHK(hipEventRecord(c->ev_pyr, s)); HIPCHK(hipStreamWaitEvent(c->bstream, c->ev_pyr, 0));
+            { ProfScope ps(c, K_BLUR, c->bstream); orbhip_launch_blur(P, c->gk, nf, c->bstream); }
+            HIPCHK(hipEventRecord(c->ev_blur, c->bstream));
+            { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nf, s); }
+            { ProfScope ps(c, K_QUADTREE, s); orbhip_launch_quadtree(P, nf, s); }
+            HIPCHK(hipStreamWaitEvent(s, c->ev_blur, 0));
+        } else {
+            { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nf, s); }
+            { ProfScope ps(c, K_BLUR, s); orbhip_launch_blur(P, c->gk, nf, s); }
+            { ProfScope ps(c, K_QUADTREE, s); orbhip_launch_quadtree(P, nf, s); }
+        }
         { ProfScope ps(c, K_DESCRIBE, s); orbhip_launch_describe(P, nf, s); }
         if (gi > 0) { HIPCHK(hipEventRecord(c->xevents[gi - 1], s)); HIPCHK(hipStreamWaitEvent(c->stream, c->xevents[gi - 1], 0)); }
     }
@@ -384,6 +400,7 @@ extern "C" orbhip_status orbhip_sync(orbhip_ctx* c)
     HIPCHK(hipStreamSynchronize(c->stream));
     for (auto xs : c->xstreams) HIPCHK(hipStreamSynchronize(xs));
     if (c->mstream) HIPCHK(hipStreamSynchronize(c->mstream));
+    if (c->bstream) HIPCHK(hipStreamSynchronize(c->bstream));
     prof_collect(c);
     return ORBHIP_OK;
 }
