@@ -345,11 +345,12 @@ static orbhip_status run_pipeline(orbhip_ctx* c, int nimg, const uint8_t* d_img0
         P.frame0 = f0;
         { ProfScope ps(c, K_PYRAMID, s); for (int l = 1; l < c->L; l++) orbhip_launch_pyramid_level(P, l, c->geom[l].w, c->geom[l].h, c->pyr_staged[l] != 0, nf, s); }
         if (ngroups == 1) {
-            // the blur only meets the detector again in k_describe: run it on its own stream beside FAST + quadtree
+            // the blur only meets the detector again in k_describe: it runs on its own stream beside the quadtree, whose
+            // workgroups are latency-bound (barriers, one per (frame, level)) and leave the VALUs idle
+            { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nf, s); }
             HIPCHK(hipEventRecord(c->ev_pyr, s)); HIPCHK(hipStreamWaitEvent(c->bstream, c->ev_pyr, 0));
             { ProfScope ps(c, K_BLUR, c->bstream); orbhip_launch_blur(P, c->gk, nf, c->bstream); }
             HIPCHK(hipEventRecord(c->ev_blur, c->bstream));
-            { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nf, s); }
             { ProfScope ps(c, K_QUADTREE, s); orbhip_launch_quadtree(P, nf, s); }
             HIPCHK(hipStreamWaitEvent(s, c->ev_blur, 0));
         } else {
