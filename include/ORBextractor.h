@@ -40,6 +40,10 @@ public:
     // Monocular / RGB-D pipelines never read it: SetPyramidDownload(false) skips the 8 device-to-host copies.
     std::vector<cv::Mat> mvImagePyramid;
     void SetPyramidDownload(bool on) { mbDownloadPyramid = on; }
+    // Frame::ComputeStereoMatches (Frame.cc:466-640) on the GPU.  `this` is the left extractor, `right` the right one; both
+    // must have processed their image of the current frame (Frame.cc:78-81).  N = number of left keypoints (Frame::N).
+    // Fills mvuRight / mvDepth exactly like the reference; reads keypoints, descriptors and pyramids that are still in HBM.
+    void ComputeStereoMatches(ORBextractor& right, float mbf, float mb, int N, std::vector<float>& mvuRight, std::vector<float>& mvDepth);
     // HIP device this extractor runs on (default 0); takes effect at the next (re)creation of the device context.
     void SetDevice(int device) { mnDevice = device; }
 

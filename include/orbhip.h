@@ -128,6 +128,15 @@ orbhip_status orbhip_search_for_initialization(int device,
                                                int im_w, int im_h, float* prev_matched, int32_t* matches12,
                                                int window, float nnratio, int check_ori, int* nmatches);
 
+/* -------- Frame::ComputeStereoMatches (Frame.h:94-95, Frame.cc:466-640) ------------------------------- */
+/* For nimg stereo pairs: slot f of `left` against slot f of `right`, using the keypoints, descriptors and image
+   pyramids both contexts still hold in HBM from their LAST extract call (the reference reads mvKeys/mvKeysRight,
+   mDescriptors/mDescriptorsRight and both extractors' mvImagePyramid).  mbf / mb as in Frame.h:104-107.
+   u_right / depth are [nimg][cap] (mvuRight / mvDepth, -1 = no match).  Synchronous.  The contexts must share device,
+   image size, level count and scale factor. */
+orbhip_status orbhip_compute_stereo_matches(orbhip_ctx* left, orbhip_ctx* right, int nimg, float mbf, float mb,
+                                            float* u_right, float* depth, int cap);
+
 /* -------- measurement + stage dumps (parity tests) ----------------------------------------------------- */
 /* per-kernel HIP-event timing on the context's stream: enable, run, then read accumulated stats */
 orbhip_status orbhip_profile_enable(orbhip_ctx* ctx, int on);

@@ -699,6 +699,95 @@ int SearchForInitialization(const FrameLite& F1, const FrameLite& F2, float* vbP
     return nmatches;
 }
 
+
+// ---------------------------------------------------------------- Frame::ComputeStereoMatches, Frame.cc:466-640
+// Inputs are the members the reference reads: mvKeys / mDescriptors of the left frame, mvKeysRight / mDescriptorsRight,
+// both extractors' mvImagePyramid, mvScaleFactors / mvInvScaleFactors, mbf, mb.  Outputs mvuRight, mvDepth (N entries).
+// The one undefined spot of the reference (vDistIdx[size/2] on an empty vector, :626-627) is defined as "nothing to prune".
+void ComputeStereoMatches(const Extractor& EL, const Extractor& ER, float mbf, float mb, std::vector<float>& mvuRight, std::vector<float>& mvDepth)
+{
+    const std::vector<KeyPoint>& mvKeys = EL.keys; const std::vector<KeyPoint>& mvKeysRight = ER.keys;
+    const int N = (int)mvKeys.size();
+    mvuRight.assign(N, -1.0f); mvDepth.assign(N, -1.0f);
+    if (N == 0) return;
+    const int thOrbDist = (TH_HIGH + TH_LOW) / 2;
+    const int nRows = EL.pyr[0].h;
+    std::vector<std::vector<size_t>> vRowIndices(nRows);
+    const int Nr = (int)mvKeysRight.size();
+    for (int iR = 0; iR < Nr; iR++) {
+        const KeyPoint& kp = mvKeysRight[iR];
+        const float kpY = kp.y;
+        const float r = 2.0f * EL.mvScaleFactor[kp.octave];
+        const int maxr = (int)ceilf(kpY + r), minr = (int)floorf(kpY - r);
+        for (int yi = minr; yi <= maxr; yi++) if (yi >= 0 && yi < nRows) vRowIndices[yi].push_back(iR);
+    }
+    const float minZ = mb, minD = 0, maxD = mbf / minZ;
+    std::vector<std::pair<int, int>> vDistIdx;
+    for (int iL = 0; iL < N; iL++) {
+        const KeyPoint& kpL = mvKeys[iL];
+        const int levelL = kpL.octave; const float vL = kpL.y, uL = kpL.x;
+        const std::vector<size_t>& vCandidates = vRowIndices[(size_t)vL];
+        if (vCandidates.empty()) continue;
+        const float minU = uL - maxD, maxU = uL - minD;
+        if (maxU < 0) continue;
+        int bestDist = TH_HIGH; size_t bestIdxR = 0;
+        const uint8_t* dL = &EL.desc[(size_t)iL * 32];
+        for (size_t iC = 0; iC < vCandidates.size(); iC++) {
+            const size_t iR = vCandidates[iC];
+            const KeyPoint& kpR = mvKeysRight[iR];
+            if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
+            const float uR = kpR.x;
+            if (uR >= minU && uR <= maxU) {
+                const int dist = DescriptorDistance(dL, &ER.desc[iR * 32]);
+                if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
+            }
+        }
+        if (bestDist < thOrbDist) {
+            const float uR0 = mvKeysRight[bestIdxR].x;
+            const float scaleFactor = EL.mvInvScaleFactor[kpL.octave];
+            const float scaleduL = roundf(kpL.x * scaleFactor), scaledvL = roundf(kpL.y * scaleFactor), scaleduR0 = roundf(uR0 * scaleFactor);
+            const int w = 5, L = 5;
+            const Image& PL = EL.pyr[kpL.octave]; const Image& PR = ER.pyr[kpL.octave];
+            float IL[11][11];
+            for (int y = 0; y < 11; y++) for (int x = 0; x < 11; x++) IL[y][x] = (float)PL.d[(size_t)((int)scaledvL - w + y) * PL.w + ((int)scaleduL - w + x)];
+            { const float c = IL[w][w]; for (int y = 0; y < 11; y++) for (int x = 0; x < 11; x++) IL[y][x] = IL[y][x] - c; }
+            int bestDistS = INT_MAX, bestincR = 0;
+            float vDists[2 * 5 + 1];
+            const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
+            if (iniu < 0 || endu >= PR.w) continue;
+            for (int incR = -L; incR <= +L; incR++) {
+                float IR[11][11];
+                for (int y = 0; y < 11; y++) for (int x = 0; x < 11; x++) IR[y][x] = (float)PR.d[(size_t)((int)scaledvL - w + y) * PR.w + ((int)scaleduR0 + incR - w + x)];
+                const float c = IR[w][w];
+                double acc = 0;
+                for (int y = 0; y < 11; y++) for (int x = 0; x < 11; x++) acc += fabs((double)(IL[y][x] - (IR[y][x] - c)));      // cv::norm(IL, IR, NORM_L1)
+                const float dist = (float)acc;
+                if (dist < bestDistS) { bestDistS = dist; bestincR = incR; }
+                vDists[L + incR] = dist;
+            }
+            if (bestincR == -L || bestincR == L) continue;
+            const float dist1 = vDists[L + bestincR - 1], dist2 = vDists[L + bestincR], dist3 = vDists[L + bestincR + 1];
+            const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+            if (deltaR < -1 || deltaR > 1) continue;
+            float bestuR = EL.mvScaleFactor[kpL.octave] * ((float)scaleduR0 + (float)bestincR + deltaR);
+            float disparity = (uL - bestuR);
+            if (disparity >= minD && disparity < maxD) {
+                if (disparity <= 0) { disparity = 0.01; bestuR = uL - 0.01; }
+                mvDepth[iL] = mbf / disparity; mvuRight[iL] = bestuR;
+                vDistIdx.push_back(std::pair<int, int>(bestDistS, iL));
+            }
+        }
+    }
+    if (vDistIdx.empty()) return;
+    std::sort(vDistIdx.begin(), vDistIdx.end());
+    const float median = vDistIdx[vDistIdx.size() / 2].first;
+    const float thDist = 1.5f * 1.4f * median;
+    for (int i = (int)vDistIdx.size() - 1; i >= 0; i--) {
+        if (vDistIdx[i].first < thDist) break;
+        mvuRight[vDistIdx[i].second] = -1; mvDepth[vDistIdx[i].second] = -1;
+    }
+}
+
 }  // namespace
 
 // ================================================================ C API (ctypes)
@@ -789,6 +878,14 @@ int orb_oracle_distribute(const int* xys, int n, int minX, int maxX, int minY, i
     return (int)out.size();
 }
 int orb_oracle_hamming(const uint8_t* a, const uint8_t* b) { return DescriptorDistance(a, b); }
+// Frame::ComputeStereoMatches on the results of the last orb_oracle_extract calls of a left and a right extractor; returns N
+int orb_oracle_stereo_matches(void* hl, void* hr, float mbf, float mb, float* uRight, float* depth, int cap)
+{
+    std::vector<float> u, d; ComputeStereoMatches(*(Extractor*)hl, *(Extractor*)hr, mbf, mb, u, d);
+    const int m = std::min((int)u.size(), cap);
+    for (int i = 0; i < m; i++) { uRight[i] = u[i]; depth[i] = d[i]; }
+    return (int)u.size();
+}
 
 // brute-force NN, SURVEY App. B.4 (matcher idiom ORBmatcher.cc:102-114,447-456): strict '<', first index wins
 void orb_oracle_bf_nn(const uint8_t* q, int nq, const uint8_t* db, int ndb, int* best_idx, int* best_dist, int* second_dist)

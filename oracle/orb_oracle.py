@@ -64,6 +64,8 @@ def lib(fast=False):
     L.orb_oracle_hamming.restype = C.c_int
     L.orb_oracle_hamming.argtypes = [vp, vp]
     L.orb_oracle_bf_nn.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp]
+    L.orb_oracle_stereo_matches.restype = C.c_int
+    L.orb_oracle_stereo_matches.argtypes = [vp, vp, C.c_float, C.c_float, vp, vp, C.c_int]
     L.orb_oracle_search_for_initialization.restype = C.c_int
     L.orb_oracle_search_for_initialization.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp,
                                                        C.c_int, C.c_float, C.c_int]
@@ -146,6 +148,16 @@ class OracleExtractor:
         n = self.L.orb_oracle_get_level_keypoints(self.h, level, _p(out), cap)
         assert n <= cap
         return out[:n].copy()
+
+
+def stereo_matches(left, right, mbf, mb):
+    """Frame::ComputeStereoMatches on the last extract() of two OracleExtractor instances: (mvuRight, mvDepth) float32[N]."""
+    cap = left.nfeatures + 3 * left.nlevels + 64
+    u = np.zeros(cap, np.float32)
+    d = np.zeros(cap, np.float32)
+    n = left.L.orb_oracle_stereo_matches(left.h, right.h, mbf, mb, _p(u), _p(d), cap)
+    assert n <= cap
+    return u[:n].copy(), d[:n].copy()
 
 
 def resize(src, dw, dh):

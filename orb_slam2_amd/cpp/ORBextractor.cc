@@ -78,4 +78,15 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
         }
 }
 
+void ORBextractor::ComputeStereoMatches(ORBextractor& right, float mbf, float mb, int N, std::vector<float>& mvuRight, std::vector<float>& mvDepth)
+{
+    mvuRight = std::vector<float>(N, -1.0f);                     // Frame.cc:468-469
+    mvDepth = std::vector<float>(N, -1.0f);
+    if (N == 0 || !mpCtx || !right.mpCtx) return;
+    if (orbhip_compute_stereo_matches(mpCtx, right.mpCtx, 1, mbf, mb, &mvuRight[0], &mvDepth[0], N) != ORBHIP_OK) {
+        fprintf(stderr, "ORBextractor::ComputeStereoMatches: %s\n", orbhip_last_error());
+        abort();
+    }
+}
+
 } // namespace ORB_SLAM2

@@ -54,6 +54,9 @@ struct orbhip_ctx {
     int cur = 0; int last_nimg = 0; bool last_matched = false; bool last_from_host = false;
     // host-buffer API staging: one contiguous device input buffer + pinned host mirrors (single bulk copies instead of per-frame pageable copies)
     uint8_t* d_in = nullptr; uint8_t* h_in = nullptr; orbhip_keypoint* h_kp = nullptr; uint8_t* h_desc = nullptr; int* h_n = nullptr; int in_pitch = 0;
+    // stereo (Frame::ComputeStereoMatches): level-0 source of the last call + lazily allocated workspace on the LEFT context
+    const uint8_t* last_img0 = nullptr; long long last_img0_fstride = 0; int last_img0_pitch = 0;
+    int* d_st_rowstart = nullptr; int* d_st_rowitems = nullptr; int st_rowcap = 0; float* d_st_u = nullptr; float* d_st_depth = nullptr; int* d_st_sad = nullptr;
     // matcher workspace
     int* d_grid_start = nullptr; int* d_grid_items = nullptr; float2* d_grid_xy = nullptr; unsigned* d_cand = nullptr; int* d_ncand = nullptr; float* d_prev = nullptr; int* d_m12 = nullptr; int* d_nm = nullptr;
     // profiling
@@ -145,6 +148,7 @@ extern "C" void orbhip_destroy(orbhip_ctx* c)
                     c->d_out_desc[0], c->d_out_desc[1], c->d_out_desc[2], c->d_out_n[0], c->d_out_n[1], c->d_out_n[2], c->d_grid_start, c->d_grid_items, c->d_grid_xy, c->d_cand, c->d_ncand,
                     c->d_prev, c->d_m12, c->d_nm};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    { void* st[] = {c->d_st_rowstart, c->d_st_rowitems, c->d_st_u, c->d_st_depth, c->d_st_sad}; for (void* q : st) if (q) (void)hipFree(q); }
     if (c->d_in) (void)hipFree(c->d_in);
     if (c->h_in) (void)hipHostFree(c->h_in);
     if (c->h_kp) (void)hipHostFree(c->h_kp);
@@ -228,7 +232,7 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
         if (g.nIni < 1) { delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "portrait image: the reference quadtree has zero root nodes (ORBextractor.cc:543-545 divides by zero)"); }
         g.hX = (float)(g.maxBorderX - ORBHIP_EDGE) / g.nIni;
         g.kp_cap = std::max(g.nfeat + 3, 4 * g.nIni); g.kp_off = kp_off; kp_off += g.kp_cap;
-        g.scale = c->sf[l]; g.kp_size = (float)(int)(31 * c->sf[l]);                 // scaledPatchSize (:837)
+        g.scale = c->sf[l]; g.kp_size = (float)(int)(31 * c->sf[l]); g.inv_scale = c->isf[l];   // scaledPatchSize (:837)
         c->qt_maxn = std::max(c->qt_maxn, g.kp_cap); c->qt_maxcells = std::max(c->qt_maxcells, g.ncells);
         if (g.ncells > 64 * 511 || g.kp_cap > 64 * 511) { delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "level %d: too many cells / features for the quadtree scan", l); }
         if (l > 0) {
@@ -331,6 +335,7 @@ static orbhip_status run_pipeline(orbhip_ctx* c, int nimg, const uint8_t* d_img0
     HIPCHK(hipSetDevice(c->cfg.device));
     c->cur = (c->cur + 1) % 3;
     const int cur = c->cur, prev = (cur + 2) % 3;
+    c->last_img0 = d_img0; c->last_img0_fstride = frame_stride; c->last_img0_pitch = row_stride;
     // the buffer about to be overwritten was the "previous frame" of the matcher launched two calls ago
     for (int k = 0; k < 3; k++) if (c->match_pending[k] && (k == (cur + 1) % 3)) { HIPCHK(hipStreamWaitEvent(c->stream, c->ev_match[k], 0)); c->match_pending[k] = false; }
     ExtractParams P = make_params(c, d_img0, frame_stride, row_stride);
@@ -528,6 +533,61 @@ extern "C" orbhip_status orbhip_debug_candidates(orbhip_ctx* c, int frame, int l
         std::vector<unsigned> v(m);
         HIPCHK(hipMemcpy(v.data(), c->d_qt_val + (size_t)frame * c->qt_per_frame + g.cand_total_off, (size_t)m * sizeof(unsigned), hipMemcpyDeviceToHost));
         for (int i = 0; i < m; i++) { xys[3 * i] = v[i] & 0xfff; xys[3 * i + 1] = (v[i] >> 12) & 0xfff; xys[3 * i + 2] = v[i] >> 24; }
+    }
+    return ORBHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- stereo
+static StereoSide stereo_side(orbhip_ctx* c)
+{
+    StereoSide S; memset(&S, 0, sizeof S);
+    S.kp = c->d_out_kp[c->cur]; S.desc = c->d_out_desc[c->cur]; S.n = c->d_out_n[c->cur];
+    S.img0 = c->last_img0; S.img0_frame_stride = c->last_img0_fstride; S.img0_pitch = c->last_img0_pitch;
+    S.pyr = c->d_pyr; S.plane_frame_bytes = c->plane_frame_bytes;
+    return S;
+}
+
+extern "C" orbhip_status orbhip_compute_stereo_matches(orbhip_ctx* l, orbhip_ctx* r, int nimg, float mbf, float mb, float* u_right, float* depth, int cap)
+{
+    if (!l || !r || !u_right || !depth) return fail(ORBHIP_ERR_INVALID, "null argument");
+    if (l->cfg.device != r->cfg.device || l->cfg.width != r->cfg.width || l->cfg.height != r->cfg.height || l->L != r->L ||
+        l->cfg.scale_factor != r->cfg.scale_factor || l->out_cap != r->out_cap)
+        return fail(ORBHIP_ERR_INVALID, "left and right contexts must share device, image size, levels and scale factor");
+    if (nimg < 1 || nimg > l->last_nimg || nimg > r->last_nimg) return fail(ORBHIP_ERR_INVALID, "nimg %d but the last calls processed %d / %d frames", nimg, l->last_nimg, r->last_nimg);
+    if (!(mb > 0) || !(mbf > 0)) return fail(ORBHIP_ERR_INVALID, "mbf and mb must be positive");
+    if (l->out_cap >= 65536) return fail(ORBHIP_ERR_UNSUPPORTED, "too many keypoints per frame for the stereo matcher");
+    HIPCHK(hipSetDevice(l->cfg.device));
+    orbhip_status st = orbhip_sync(r); if (st != ORBHIP_OK) return st;           // the right frame's results must be complete; left work is stream-ordered
+    const size_t B = (size_t)l->B;
+    if (!l->d_st_rowstart) {
+        l->st_rowcap = l->out_cap * ((int)ceilf(4.0f * l->sf[l->L - 1]) + 3);      // rows [floor(y-r), ceil(y+r)], r = 2*scale
+        hipError_t e = hipSuccess;
+        if (e == hipSuccess) e = dalloc(&l->d_st_rowstart, B * (l->cfg.height + 1));
+        if (e == hipSuccess) e = dalloc(&l->d_st_rowitems, B * (size_t)l->st_rowcap);
+        if (e == hipSuccess) e = dalloc(&l->d_st_u, B * l->out_cap);
+        if (e == hipSuccess) e = dalloc(&l->d_st_depth, B * l->out_cap);
+        if (e == hipSuccess) e = dalloc(&l->d_st_sad, B * l->out_cap);
+        if (e != hipSuccess) return fail(ORBHIP_ERR_HIP, "stereo workspace allocation failed: %s", hipGetErrorString(e));
+    }
+    StereoParams T; memset(&T, 0, sizeof T);
+    T.geom = l->d_geom; T.L = stereo_side(l); T.R = stereo_side(r);
+    T.cap = l->out_cap; T.im_h = l->cfg.height;
+    T.row_start = l->d_st_rowstart; T.row_items = l->d_st_rowitems; T.row_cap = l->st_rowcap;
+    T.u_right = l->d_st_u; T.depth = l->d_st_depth; T.sad = l->d_st_sad;
+    T.mbf = mbf; T.maxD = mbf / mb;                                                 // minZ = mb, maxD = mbf/minZ (Frame.cc:496-498)
+    orbhip_launch_stereo(T, nimg, l->out_cap, l->stream);
+    HIPCHK(hipGetLastError());
+    st = ensure_host_staging(l, false); if (st != ORBHIP_OK) return st;
+    std::vector<int> n(nimg);
+    HIPCHK(hipMemcpyAsync(l->h_n, l->d_out_n[l->cur], nimg * sizeof(int), hipMemcpyDeviceToHost, l->stream));
+    float* hu = reinterpret_cast<float*>(l->h_kp); float* hd = hu + (size_t)nimg * l->out_cap;       // pinned mirror reused (28 B/keypoint >= 8 B)
+    HIPCHK(hipMemcpyAsync(hu, l->d_st_u, (size_t)nimg * l->out_cap * sizeof(float), hipMemcpyDeviceToHost, l->stream));
+    HIPCHK(hipMemcpyAsync(hd, l->d_st_depth, (size_t)nimg * l->out_cap * sizeof(float), hipMemcpyDeviceToHost, l->stream));
+    st = orbhip_sync(l); if (st != ORBHIP_OK) return st;
+    for (int f = 0; f < nimg; f++) {
+        const int m = std::min(l->h_n[f], cap);
+        for (int i = 0; i < cap; i++) { u_right[(size_t)f * cap + i] = -1.0f; depth[(size_t)f * cap + i] = -1.0f; }
+        if (m > 0) { memcpy(u_right + (size_t)f * cap, hu + (size_t)f * l->out_cap, m * sizeof(float)); memcpy(depth + (size_t)f * cap, hd + (size_t)f * l->out_cap, m * sizeof(float)); }
     }
     return ORBHIP_OK;
 }

@@ -35,7 +35,7 @@ struct LevelGeom {
     int cand_total_off, cand_total_cap;         // dense per-level candidate arrays (quadtree workspace)
     int nfeat, kp_cap, kp_off;                  // mnFeaturesPerLevel, capacity max(nfeat+3, 4*nIni), offset
     int nIni; float hX;                         // quadtree roots (ORBextractor.cc:543-545)
-    float scale, kp_size;                       // mvScaleFactor[l], (float)(int)(31*scale)
+    float scale, kp_size, inv_scale;            // mvScaleFactor[l], (float)(int)(31*scale), mvInvScaleFactor[l]
     int xtab_off, ytab_off;                     // resize coefficient tables (levels >= 1): {src index, a0 | a1<<16}
     int src_w, src_h;                           // size of level l-1
 };
@@ -85,6 +85,20 @@ struct MatchParams {        // SearchForInitialization over camera slots (ORBmat
     int window; float nnratio; int check_ori;
     int slot0;                                    // first camera slot of this launch group
 };
+
+struct StereoSide {         // device-resident results + pyramid of one extractor context (its last call)
+    const orbhip_keypoint* kp; const uint8_t* desc; const int* n;
+    const uint8_t* img0; long long img0_frame_stride; int img0_pitch;      // level 0
+    const uint8_t* pyr; long long plane_frame_bytes;                       // levels >= 1
+};
+struct StereoParams {       // Frame::ComputeStereoMatches (Frame.cc:466-640)
+    const LevelGeom* geom; StereoSide L, R;
+    int cap, im_h;
+    int* row_start; int* row_items; int row_cap;                           // [slot][im_h+1], [slot][row_cap]
+    float* u_right; float* depth; int* sad;                                // [slot][cap]
+    float mbf, maxD;                                                       // maxD = mbf / mb
+};
+void orbhip_launch_stereo(const StereoParams& T, int nslots, int max_left, hipStream_t s);
 
 // kernel launchers (orbhip_kernels_extract.hip / orbhip_kernels_match.hip)
 void orbhip_launch_pyramid_level(const ExtractParams& P, int level, int w, int h, bool staged, int nframes, hipStream_t s);

@@ -26,6 +26,7 @@ SYMBOLS = [
     "orbhip_hamming_nn", "orbhip_hamming_nn_device", "orbhip_search_for_initialization", "orbhip_profile_enable",
     "orbhip_profile_num_kernels", "orbhip_profile_get", "orbhip_profile_reset", "orbhip_algorithmic_bytes_per_frame",
     "orbhip_algorithmic_bytes_per_frame_kernel", "orbhip_debug_blurred_level", "orbhip_debug_candidates",
+    "orbhip_compute_stereo_matches",
 ]
 
 
@@ -76,6 +77,7 @@ def lib(path=None):
     L.orbhip_hamming_nn_device.argtypes = [vp, vp, C.c_int, vp, C.c_int64, C.c_int64, vp, vp, vp]
     L.orbhip_search_for_initialization.argtypes = [C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp,
                                                    C.c_int, C.c_float, C.c_int, ip]
+    L.orbhip_compute_stereo_matches.argtypes = [vp, vp, C.c_int, C.c_float, C.c_float, vp, vp, C.c_int]
     L.orbhip_profile_enable.argtypes = [vp, C.c_int]
     L.orbhip_profile_num_kernels.argtypes = [vp]
     L.orbhip_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
@@ -213,6 +215,15 @@ class ORBextractor:
         nm = np.zeros(nimg, np.int32)
         _check(self.L.orbhip_fetch_matches(self.h, nimg, _p(m12), cap, _p(n1), _p(nm)), "orbhip_fetch_matches")
         return [m12[f, :n1[f]].copy() for f in range(nimg)], nm
+
+    # ---- Frame::ComputeStereoMatches (this extractor = left camera)
+    def ComputeStereoMatches(self, right, mbf, mb, nimg=1):
+        """mvuRight, mvDepth (float32 [N] per frame) for the frames both extractors processed in their last call."""
+        cap = self.capacity
+        u = np.zeros((nimg, cap), np.float32)
+        d = np.zeros((nimg, cap), np.float32)
+        _check(self.L.orbhip_compute_stereo_matches(self.h, right.h, nimg, mbf, mb, _p(u), _p(d), cap), "orbhip_compute_stereo_matches", self.L)
+        return u, d
 
     # ---- measurement / stage dumps
     def profile_enable(self, on=True):

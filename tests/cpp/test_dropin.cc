@@ -37,7 +37,15 @@ int main(int argc, char** argv)
     int lv = ex->GetLevels(); fwrite(&lv, 4, 1, f);
     for (int l = 0; l < lv; l++) { int wh[2] = {ex->mvImagePyramid[l].cols, ex->mvImagePyramid[l].rows}; fwrite(wh, 4, 2, f); fwrite(ex->mvImagePyramid[l].data, 1, (size_t)wh[0] * wh[1], f); }
     const int d = ORB_SLAM2::ORBmatcher::DescriptorDistance(F1.mDescriptors.row(0), F2.mDescriptors.row(0)); fwrite(&d, 4, 1, f);
+    // stereo: two extractor instances like Tracking.cc:119-122, Frame::ComputeStereoMatches replaced by the GPU entry point
+    ORB_SLAM2::ORBextractor* exL = new ORB_SLAM2::ORBextractor(N, 1.2f, 8, 20, 7);
+    ORB_SLAM2::ORBextractor* exR = new ORB_SLAM2::ORBextractor(N, 1.2f, 8, 20, 7);
+    ORB_SLAM2::Frame FL(im[0], exL), FR(im[1], exR);
+    std::vector<float> uRight, depth;
+    exL->ComputeStereoMatches(*exR, 386.1448f, 386.1448f / 718.856f, FL.N, uRight, depth);
+    int ns = (int)uRight.size(); fwrite(&ns, 4, 1, f);
+    if (ns) { fwrite(&uRight[0], 4, ns, f); fwrite(&depth[0], 4, ns, f); }
     fclose(f);
-    delete ex;
+    delete ex; delete exL; delete exR;
     return 0;
 }

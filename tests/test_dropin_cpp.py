@@ -39,7 +39,10 @@ def _run(exe, tmp_path, oracle):
     for _ in range(lv):
         pw, ph = struct.unpack_from("<ii", buf, off); off += 8
         pyr.append(np.frombuffer(buf, np.uint8, pw * ph, off).reshape(ph, pw)); off += pw * ph
-    (dd,) = struct.unpack_from("<i", buf, off)
+    (dd,) = struct.unpack_from("<i", buf, off); off += 4
+    (ns,) = struct.unpack_from("<i", buf, off); off += 4
+    u_right = np.frombuffer(buf, np.float32, ns, off); off += 4 * ns
+    depth = np.frombuffer(buf, np.float32, ns, off)
 
     ora = oracle.OracleExtractor(n, 1.2, 8, 20, 7)
     ref = [ora.extract(im) for im in seq]
@@ -50,6 +53,11 @@ def _run(exe, tmp_path, oracle):
     n_o, m_o, p_o = oracle.search_for_initialization(ref[0][0], ref[0][1], ref[1][0], ref[1][1], w, h, window=100, nnratio=0.9)
     assert nm == n_o and np.array_equal(m12, m_o) and prev.tobytes() == p_o.tobytes()
     assert dd == oracle.hamming(ref[0][1][0], ref[1][1][0])
+    eL, eR = oracle.OracleExtractor(n, 1.2, 8, 20, 7), oracle.OracleExtractor(n, 1.2, 8, 20, 7)
+    eL.extract(seq[0])
+    eR.extract(seq[1])
+    uo, do = oracle.stereo_matches(eL, eR, np.float32(386.1448), np.float32(386.1448) / np.float32(718.856))
+    assert ns == len(uo) and u_right.tobytes() == uo.tobytes() and depth.tobytes() == do.tobytes()
 
 
 def _build(target):

@@ -1,0 +1,65 @@
+"""Frame::ComputeStereoMatches (Frame.cc:466-640) on the device-resident results of a left and a right
+extractor: mvuRight / mvDepth bit-identical to the oracle's restatement."""
+import numpy as np
+import pytest
+
+import orb_slam2_amd
+from orb_slam2_amd import synth
+
+MBF, MB = 386.1448, 386.1448 / 718.856           # KITTI00-02.yaml: Camera.bf, bf / fx
+
+
+def stereo_pair(w, h, seed, disp):
+    """Left frame + the same scene seen `disp` px further left (uniform disparity) with independent sensor noise."""
+    m = 64
+    sc = synth.scene(w, h, seed=seed)
+    left = synth.frame_from_scene(sc, w, h, t=0, seed=seed)
+    rng = np.random.default_rng(1000 + seed)
+    right = np.clip(np.rint(sc[m // 2:m // 2 + h, m // 2 + disp:m // 2 + disp + w]) + rng.integers(-6, 7, size=(h, w)), 0, 255).astype(np.uint8)
+    return left, right
+
+
+def _check(backend, oracle, w, h, n, pairs):
+    eL, eR = oracle.OracleExtractor(n, 1.2, 8, 20, 7), oracle.OracleExtractor(n, 1.2, 8, 20, 7)
+    xl = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, max_batch=len(pairs), library=backend)
+    xr = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, max_batch=len(pairs), library=backend)
+    xl.extract_batch([p[0] for p in pairs])
+    xr.extract_batch([p[1] for p in pairs])
+    u, d = xl.ComputeStereoMatches(xr, MBF, MB, nimg=len(pairs))
+    matched = []
+    for f, (left, right) in enumerate(pairs):
+        kl, _ = eL.extract(left)
+        eR.extract(right)
+        uo, do = oracle.stereo_matches(eL, eR, MBF, MB)
+        nk = len(uo)
+        assert u[f, :nk].tobytes() == uo.tobytes() and d[f, :nk].tobytes() == do.tobytes()
+        assert np.all(u[f, nk:] == -1) and np.all(d[f, nk:] == -1)
+        matched.append((kl, uo))
+    xl.close()
+    xr.close()
+    return matched
+
+
+def test_stereo_matches_bit_exact(backend, oracle):
+    w, h, n = 480, 360, 600
+    res = _check(backend, oracle, w, h, n, [stereo_pair(w, h, 4, 9), stereo_pair(w, h, 5, 21)])
+    for (kl, uo), disp in zip(res, (9, 21)):
+        ok = uo >= 0
+        assert ok.sum() > 100
+        assert abs(np.median(kl["x"][ok] - uo[ok]) - disp) < 0.5          # the synthetic rig's disparity is recovered
+
+
+def test_stereo_edge_cases(backend, oracle):
+    w, h, n = 400, 300, 400
+    left, right = stereo_pair(w, h, 6, 0)
+    # zero disparity (identical scenes): the `disparity <= 0 -> 0.01` branch (Frame.cc:611-615); no right keypoints at all;
+    # no left keypoints at all
+    _check(backend, oracle, w, h, n, [(left, right), (left, synth.zeros(w, h)), (synth.zeros(w, h), right), (left, left)])
+
+
+@pytest.mark.gpu
+def test_stereo_kitti_config(gpu_lib, oracle):
+    """configs[1]: KITTI stereo 1241x376, 2000 features per image."""
+    w, h, n = 1241, 376, 2000
+    res = _check(gpu_lib, oracle, w, h, n, [stereo_pair(w, h, 7, 14), stereo_pair(w, h, 8, 40)])
+    assert all((uo >= 0).sum() > 500 for _, uo in res)
