@@ -211,6 +211,8 @@ void fast9_16(const View& img, std::vector<KeyPoint>& keypoints, int threshold, 
     threshold = std::min(std::max(threshold, 0), 255);
     const int cols = img.w, rows = img.h;
     if (cols < 7 || rows < 7) return;
+    uint8_t threshold_tab[512];
+    for (int i = -255; i <= 255; i++) threshold_tab[i + 255] = (uint8_t)(i < -threshold ? 1 : i > threshold ? 2 : 0);
     std::vector<uint8_t> bufv((size_t)cols * 3, 0);
     std::vector<int> cpv((size_t)(cols + 1) * 3, 0);
     uint8_t* buf[3] = {bufv.data(), bufv.data() + cols, bufv.data() + 2 * cols};
@@ -225,11 +227,24 @@ void fast9_16(const View& img, std::vector<KeyPoint>& keypoints, int threshold, 
             for (int j = 3; j < cols - 3; j++, ptr++) {
                 int v = ptr[0];
                 bool found = false;
-                {   // darker arc: x < v - t
+                // OpenCV's scalar path: threshold_tab lookups on opposite ring pairs reject most pixels early
+                // (bit 1 = darker than v - t, bit 2 = brighter than v + t); a 9-arc needs one of every opposite pair.
+                const uint8_t* tab = &threshold_tab[0] - v + 255;
+                int d = tab[ptr[pixel[0]]] | tab[ptr[pixel[8]]];
+                if (d == 0) continue;
+                d &= tab[ptr[pixel[2]]] | tab[ptr[pixel[10]]];
+                d &= tab[ptr[pixel[4]]] | tab[ptr[pixel[12]]];
+                d &= tab[ptr[pixel[6]]] | tab[ptr[pixel[14]]];
+                if (d == 0) continue;
+                d &= tab[ptr[pixel[1]]] | tab[ptr[pixel[9]]];
+                d &= tab[ptr[pixel[3]]] | tab[ptr[pixel[11]]];
+                d &= tab[ptr[pixel[5]]] | tab[ptr[pixel[13]]];
+                d &= tab[ptr[pixel[7]]] | tab[ptr[pixel[15]]];
+                if (d & 1) {   // darker arc: x < v - t
                     int vt = v - threshold, count = 0;
                     for (int k = 0; k < N; k++) { int x = ptr[pixel[k]]; if (x < vt) { if (++count > K) { found = true; break; } } else count = 0; }
                 }
-                if (!found) {   // brighter arc: x > v + t
+                if (!found && (d & 2)) {   // brighter arc: x > v + t
                     int vt = v + threshold, count = 0;
                     for (int k = 0; k < N; k++) { int x = ptr[pixel[k]]; if (x > vt) { if (++count > K) { found = true; break; } } else count = 0; }
                 }
