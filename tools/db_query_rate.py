@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""BASELINE.json config 5: brute-force 256-bit Hamming of a 2000-descriptor query frame against a keyframe descriptor DB
+resident in HBM (10 000 keyframes x 2000 descriptors = 640 MB).  Reports pair distances/s against the integer-VALU issue
+peak (8 v_xor_b32 @2 cycles + 8 v_bcnt_u32_b32 @4 cycles per 64 pairs and SIMD) and the DB streaming rate against HBM."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import orb_slam2_amd  # noqa: E402
+
+NKF = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+NQ, PER = 2000, 2000
+g = torch.Generator(device="cuda").manual_seed(7)
+db = torch.randint(0, 256, (NKF * PER, 32), dtype=torch.uint8, device="cuda", generator=g)
+q = db[torch.randint(0, NKF * PER, (NQ,), device="cuda", generator=g)].clone()
+q[::2, 0] ^= 0x5A                                            # half the queries are near-duplicates, half exact
+bi = torch.zeros(NQ, dtype=torch.int64, device="cuda")
+bd = torch.zeros(NQ, dtype=torch.int32, device="cuda")
+sd = torch.zeros(NQ, dtype=torch.int32, device="cuda")
+torch.cuda.synchronize()
+
+
+def run():
+    orb_slam2_amd.hamming_nn_device(None, q.data_ptr(), NQ, db.data_ptr(), NKF * PER, bi.data_ptr(), bd.data_ptr(), sd.data_ptr())
+    torch.cuda.synchronize()
+
+
+run()
+t0 = time.perf_counter()
+reps = 3
+for _ in range(reps):
+    run()
+dt = (time.perf_counter() - t0) / reps
+pairs = NQ * NKF * PER
+peak_pairs = 1024 * 64 / (8 * 2 + 8 * 4) * 2.4e9
+assert int((bd <= 4).sum()) == NQ
+print(json.dumps({"db_keyframes": NKF, "db_bytes": NKF * PER * 32, "query_ms": round(dt * 1e3, 2), "pair_distances_per_s": float(f"{pairs / dt:.4g}"),
+                  "frac_of_int_valu_issue_peak": round(pairs / dt / peak_pairs, 3), "db_stream_GBps": round(NKF * PER * 32 / dt / 1e9, 1),
+                  "queries_per_s_vs_full_db": round(NQ / dt, 1)}))

@@ -18,6 +18,7 @@ for f in $(find /tmp/prof_$TAG -name "*kernel_trace.csv" | head -1); do head -40
 ORB_BENCH_SHARE_GPU=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 --batch 32 > $OUT/bench_2rank_shared.json 2>> $OUT/bench.err; cat $OUT/bench_2rank_shared.json | cut -c1-300
 timeout 120 python tools/host_io_rate.py > $OUT/host_io.json 2>> $OUT/bench.err; cat $OUT/host_io.json
 timeout 200 python tools/stereo_rate.py > $OUT/stereo_rate.json 2>> $OUT/bench.err; cat $OUT/stereo_rate.json
+timeout 200 python tools/db_query_rate.py > $OUT/db_query.json 2>> $OUT/bench.err; cat $OUT/db_query.json
 timeout 120 tools/ubench > $OUT/ubench.txt 2>&1; cat $OUT/ubench.txt
 tail -5 $OUT/pytest_gpu.log; tail -3 $OUT/smoke.log; cat $OUT/bench.json; python - <<PY
 import json
