@@ -35,13 +35,16 @@ __global__ __launch_bounds__(NN_T) void k_hamming_nn(const unsigned long long* q
     const int tid = threadIdx.x, chunk = blockIdx.y;
     const int q0 = (blockIdx.x * NN_T + tid) * NN_QPT;
     unsigned long long qa[NN_QPT][4];
-    int best[NN_QPT], second[NN_QPT]; long long bidx[NN_QPT];
+    // per query: the two smallest keys (distance << 13 | row-in-chunk).  Keys are unique and ordered like (distance, index), so
+    //   best' = min(best, x);  second' = min(second, max(best, x))
+    // is exactly the matcher's `if (d < best) {second = best; best = d;} else if (d < second) second = d` with lowest-index ties.
+    unsigned kb[NN_QPT], ks[NN_QPT];
 #pragma unroll
     for (int k = 0; k < NN_QPT; k++) {
         const int qi = min(q0 + k, nq - 1);
 #pragma unroll
         for (int w = 0; w < 4; w++) qa[k][w] = q[(long long)qi * 4 + w];
-        best[k] = IMAX; second[k] = IMAX; bidx[k] = -1;
+        kb[k] = 0xffffffffu; ks[k] = 0xffffffffu;
     }
     const long long row0 = (long long)chunk * NN_CHUNK;
     const long long row1 = min(row0 + (long long)NN_CHUNK, ndb);
@@ -50,19 +53,27 @@ __global__ __launch_bounds__(NN_T) void k_hamming_nn(const unsigned long long* q
         __syncthreads();
         for (int i = tid; i < nr * 4; i += NN_T) s_db[i] = db[r * 4 + i];
         __syncthreads();
+        const unsigned jbase = (unsigned)(r - row0);
         for (int j = 0; j < nr; j++) {
             const unsigned long long d0 = s_db[4 * j], d1 = s_db[4 * j + 1], d2 = s_db[4 * j + 2], d3 = s_db[4 * j + 3];   // LDS broadcast
 #pragma unroll
             for (int k = 0; k < NN_QPT; k++) {
-                const int d = __popcll(qa[k][0] ^ d0) + __popcll(qa[k][1] ^ d1) + __popcll(qa[k][2] ^ d2) + __popcll(qa[k][3] ^ d3);
-                if (d < best[k]) { second[k] = best[k]; best[k] = d; bidx[k] = r + j; }
-                else if (d < second[k]) second[k] = d;
+                const unsigned d = (unsigned)(__popcll(qa[k][0] ^ d0) + __popcll(qa[k][1] ^ d1) + __popcll(qa[k][2] ^ d2) + __popcll(qa[k][3] ^ d3));
+                const unsigned x = (d << 13) | (jbase + j);
+                ks[k] = min(ks[k], max(kb[k], x));
+                kb[k] = min(kb[k], x);
             }
         }
     }
 #pragma unroll
     for (int k = 0; k < NN_QPT; k++)
-        if (q0 + k < nq) { NNPart p; p.best = best[k]; p.second = second[k]; p.idx = bidx[k] < 0 ? -1 : bidx[k] + base; parts[(long long)(q0 + k) * nchunks + chunk] = p; }
+        if (q0 + k < nq) {
+            NNPart p;
+            p.best = kb[k] == 0xffffffffu ? IMAX : (int)(kb[k] >> 13);
+            p.second = ks[k] == 0xffffffffu ? IMAX : (int)(ks[k] >> 13);
+            p.idx = kb[k] == 0xffffffffu ? -1 : row0 + (long long)(kb[k] & 0x1fffu) + base;
+            parts[(long long)(q0 + k) * nchunks + chunk] = p;
+        }
 }
 
 // fold the per-chunk partials of one query in ascending DB order: stable arg-min + second smallest of the multiset
