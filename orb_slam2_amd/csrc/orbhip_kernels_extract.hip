@@ -38,7 +38,8 @@ __device__ __forceinline__ const uint8_t* level_src(const ExtractParams& P, int 
 // cv::resize INTER_LINEAR CV_8U (OpenCV 3.2 HResizeLinear / VResizeLinear fixed point, 11-bit coefficients).
 // Coefficient tables are built on the host exactly as OpenCV builds them; the kernel is pure integer.
 // 4 output pixels per thread, one 32-bit store.
-// 4 output pixels of 2 consecutive rows from source rows addressed as rows[(y - row0) * rpitch + x]
+#define PYR_RPT 4                       // output rows per thread (4 pixels each): coefficient unpacking is amortised over them
+// 4 output pixels of PYR_RPT consecutive rows from source rows addressed as rows[(y - row0) * rpitch + x]
 __device__ __forceinline__ void pyr_rows(const LevelGeom& g, const int2* xt, const int2* yt, const uint8_t* rows, int rpitch, int row0, int x4, int ytop, uint8_t* dstp)
 {
     int sx[4], sx1[4], a0[4], a1[4];
@@ -48,7 +49,7 @@ __device__ __forceinline__ void pyr_rows(const LevelGeom& g, const int2* xt, con
         sx[k] = e.x; sx1[k] = min(e.x + 1, g.src_w - 1); a0[k] = e.y & 0xffff; a1[k] = (e.y >> 16) & 0xffff;
     }
 #pragma unroll
-    for (int rr = 0; rr < 2; rr++) {
+    for (int rr = 0; rr < PYR_RPT; rr++) {
         const int y = ytop + rr;
         if (y >= g.h) break;
         const int2 ye = yt[y];
@@ -67,12 +68,13 @@ __device__ __forceinline__ void pyr_rows(const LevelGeom& g, const int2* xt, con
     }
 }
 
-// Workgroup = 256 x 8 output pixels: the source footprint (<= 12 rows x ~312 bytes) is staged in LDS with 32-bit loads,
-// each thread then produces 4 pixels of 2 rows (one 32-bit store per row).
+// Workgroup = 256 x 16 output pixels: the source footprint (<= 24 rows x ~312 bytes) is staged in LDS with 32-bit loads,
+// each thread then produces 4 pixels of 4 rows (one 32-bit store per row).
 #define PYR_TW 256
-#define PYR_TH 8
-#define PYR_SROWS 12
+#define PYR_TH (4 * PYR_RPT)
+#define PYR_SROWS 24
 #define PYR_SDW 84                      // dwords per staged source row (>= (256*1.25+2+3)/4)
+#define PYR_LD ((PYR_SROWS * PYR_SDW + 255) / 256)   // staging dwords per thread
 __global__ __launch_bounds__(256) void k_pyramid_level(ExtractParams P, int level)
 {
     const LevelGeom g = P.geom[level];
@@ -91,16 +93,16 @@ __global__ __launch_bounds__(256) void k_pyramid_level(ExtractParams P, int leve
     const int ndw = ((sxb - sxa) >> 2) + 1, nrows = syb - sya + 1;
     const bool aligned = ((((unsigned long long)src) | (unsigned long long)spitch) & 3ull) == 0;
     {
-        unsigned v[4]; bool edge[4];
+        unsigned v[PYR_LD]; bool edge[PYR_LD];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < PYR_LD; k++) {
             const int i = tid + 256 * k, r = i / ndw, d = i - r * ndw;
             const bool in = i < nrows * ndw;
             edge[k] = in && !(aligned && sxa + 4 * d + 3 < g.src_w);
             v[k] = (in && !edge[k]) ? *reinterpret_cast<const unsigned*>(src + (long long)(sya + r) * spitch + sxa + 4 * d) : 0u;
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < PYR_LD; k++) {
             const int i = tid + 256 * k, r = i / ndw, d = i - r * ndw;
             if (edge[k]) { const uint8_t* row = src + (long long)(sya + r) * spitch + sxa + 4 * d; for (int q = 0; q < 4; q++) if (sxa + 4 * d + q < g.src_w) v[k] |= (unsigned)row[q] << (8 * q); }
             if (i < nrows * ndw) s_t[r * PYR_SDW + d] = v[k];
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(256) void k_pyramid_level(ExtractParams P, int leve
     const int x4 = x0 + threadIdx.x * 4;
     if (x4 >= g.w) return;
     uint8_t* dstp = P.pyr + (long long)frame * P.plane_frame_bytes + g.plane_off + x4;
-    pyr_rows(g, xt, yt, reinterpret_cast<const uint8_t*>(s_t) - sxa, PYR_SDW * 4, sya, x4, y0 + threadIdx.y * 2, dstp);
+    pyr_rows(g, xt, yt, reinterpret_cast<const uint8_t*>(s_t) - sxa, PYR_SDW * 4, sya, x4, y0 + threadIdx.y * PYR_RPT, dstp);
 }
 
 // Same arithmetic straight from global memory: used for scale factors whose source footprint does not fit the LDS tile
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256) void k_pyramid_level_direct(ExtractParams P, i
     int tile, frame;
     if (!xcd_frame_map(gx * gy, P.nframes, tile, frame)) return;
     frame += P.frame0;
-    const int x4 = (tile % gx) * PYR_TW + threadIdx.x * 4, ytop = (tile / gx) * PYR_TH + threadIdx.y * 2;
+    const int x4 = (tile % gx) * PYR_TW + threadIdx.x * 4, ytop = (tile / gx) * PYR_TH + threadIdx.y * PYR_RPT;
     if (x4 >= g.w) return;
     int spitch; const uint8_t* src = level_src(P, frame, level - 1, spitch);
     pyr_rows(g, P.xtab + g.xtab_off, P.ytab + g.ytab_off, src, spitch, 0, x4, ytop, P.pyr + (long long)frame * P.plane_frame_bytes + g.plane_off + x4);

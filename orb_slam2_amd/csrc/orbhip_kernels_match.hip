@@ -15,11 +15,6 @@
 #define WAVE 64
 #define IMAX 0x7fffffff
 
-__device__ __forceinline__ int hamming256(const unsigned long long* a, const unsigned long long* b)
-{
-    return __popcll(a[0] ^ b[0]) + __popcll(a[1] ^ b[1]) + __popcll(a[2] ^ b[2]) + __popcll(a[3] ^ b[3]);
-}
-
 // ------------------------------------------------------------------------------------------------ brute-force NN
 #define NN_T 256
 #define NN_QPT 4                       // queries held in registers per thread

@@ -5,8 +5,8 @@
 replaces; they call the C ABI only.  There is no CPU fallback: if the HIP library is missing or no GPU is usable
 the constructors raise `OrbHipError`.
 
-ORBHIP_LIBRARY=<path> overrides the shared object (the CPU test-suite points it at the fiber-emulation build of
-the same sources, tests/emu/liborbhip_emu.so, to check kernel logic where no GPU exists).
+The optional `library=` constructor argument names another build of the same C ABI; only the CPU test-suite uses it
+(the fiber-emulation build of the same kernel sources, tests/emu/liborbhip_emu.so, where no GPU exists).
 """
 import ctypes as C
 import os
@@ -41,14 +41,14 @@ class Config(C.Structure):
 
 
 def library_path():
-    return os.environ.get("ORBHIP_LIBRARY") or os.path.join(_HERE, "liborbhip.so")
+    return os.path.join(_HERE, "liborbhip.so")
 
 
 _libs = {}
 
 
 def lib(path=None):
-    """Load (once per path) and return the ctypes handle; path=None -> ORBHIP_LIBRARY or the in-tree liborbhip.so."""
+    """Load (once per path) and return the ctypes handle; path=None -> the in-tree liborbhip.so (hipcc, gfx950)."""
     path = os.path.abspath(path or library_path())
     if path in _libs:
         return _libs[path]
