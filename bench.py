@@ -89,7 +89,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="camera slots (frames) per step per GPU")
+    ap.add_argument("--batch", type=int, default=512, help="camera slots (frames) per step per GPU")
     ap.add_argument("--tsteps", type=int, default=4, help="distinct resident time steps cycled through")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the library splits each batch over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -177,7 +177,7 @@ def main():
             with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
                 for row in json.load(f):
                     if row["kernel"] == dom:
-                        traffic = int((2 * row["fetch_MB_per_dispatch_raw"] + row["write_MB_per_dispatch_raw"]) * 1024 * 1024 * B / 256)
+                        traffic = int((2 * row["fetch_MB_per_dispatch_raw"] + row["write_MB_per_dispatch_raw"]) * 1024 * 1024 * B / 256)   # PMC passes ran at B = 256
         except Exception:
             traffic = None
         dur_s = kern[dom]["ms_per_launch"] * 1e-3

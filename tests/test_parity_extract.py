@@ -115,6 +115,26 @@ def test_large_scale_factor_uses_direct_pyramid(backend, oracle):
     ex.close()
 
 
+@pytest.mark.parametrize("w,h,levels", [(91, 75, 2), (124, 62, 1), (150, 97, 3)])
+def test_tiny_images_single_cell_levels(backend, oracle, w, h, levels):
+    """Smallest supported shapes: one FAST cell per level up to 59 px wide (65-px sub-image, 17 dwords per patch row),
+    levels narrower than one blur / pyramid tile, more quadtree roots than features."""
+    rng = np.random.default_rng(w * 1000 + h)
+    img = np.clip(synth.frame(max(w, 320), max(h, 240), seed=13)[:h, :w].astype(int) + rng.integers(-20, 21, (h, w)), 0, 255).astype(np.uint8)
+    for n in (5, 60):
+        ora = oracle.OracleExtractor(n, 1.2, levels, 20, 7)
+        ko, do = ora.extract(img)
+        ex = orb_slam2_amd.ORBextractor(n, 1.2, levels, 20, 7, w, h, library=backend)
+        kg, dg = ex(img)
+        for l in range(levels):
+            assert np.array_equal(ex.mvImagePyramid(l), ora.level(l)) and np.array_equal(ex.candidates(l), ora.candidates(l))
+            b = ora.blurred(l)
+            if b is not None:
+                assert np.array_equal(ex.blurred_level(l), b)
+        _same(kg, dg, ko, do)
+        ex.close()
+
+
 def test_unsupported_and_invalid_configs(backend):
     with pytest.raises(orb_slam2_amd.OrbHipError):
         orb_slam2_amd.ORBextractor(500, 1.2, 8, 20, 7, 200, 120, library=backend)     # top level < 62 px: the reference itself divides by zero

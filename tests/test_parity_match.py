@@ -76,6 +76,20 @@ def test_search_for_initialization_edge_cases(backend, oracle, frames):
     assert n_g == n_o and np.array_equal(m_g, m_o) and p_g.tobytes() == p_o.tobytes()
 
 
+def test_search_for_initialization_long_candidate_lists(backend, oracle):
+    """Window larger than the image: every level-0 keypoint of F2 is a candidate of every level-0 keypoint of F1, more
+    candidate records than the matcher stages in LDS (the lists are then read from HBM)."""
+    w, h, n = 640, 480, 1000
+    seq = synth.sequence(w, h, 2, seed=14)
+    ora = oracle.OracleExtractor(n, 1.2, 8, 20, 7)
+    (k1, d1), (k2, d2) = ora.extract(seq[0]), ora.extract(seq[1])
+    assert int((k1["octave"] == 0).sum()) * int((k2["octave"] == 0).sum()) > 20480
+    m = orb_slam2_amd.ORBmatcher(0.9, True, library=backend)
+    n_o, m_o, p_o = oracle.search_for_initialization(k1, d1, k2, d2, w, h, window=700, nnratio=0.9, check_ori=True)
+    n_g, m_g, p_g = m.SearchForInitialization(k1, d1, k2, d2, w, h, windowSize=700)
+    assert n_g == n_o and np.array_equal(m_g, m_o) and p_g.tobytes() == p_o.tobytes()
+
+
 def test_brute_force_nn(backend, oracle):
     db = synth.descriptor_db(3, 600, seed=7)
     q = synth.descriptor_query(db, 257, seed=7)
