@@ -128,6 +128,32 @@ orbhip_status orbhip_search_for_initialization(int device,
                                                int im_w, int im_h, float* prev_matched, int32_t* matches12,
                                                int window, float nnratio, int check_ori, int* nmatches);
 
+/* -------- projection-guided matchers --------------------------------------------------- */
+/* One query per map point that passed the caller's own filters (frustum / isBad / projection inside the image):
+   the caller keeps Map, MapPoint and pose types and flattens what the search loop reads. */
+typedef struct {
+    float x, y;          /* projected position: pMP->mTrackProjX/Y (ORBmatcher.cc:69) or u, v (ORBmatcher.cc:1369-1370) */
+    float radius;        /* window radius already multiplied by the scale factor: r*F.mvScaleFactors[level] / th*mvScaleFactors[octave] */
+    float ur;            /* projected right coordinate: mTrackProjXR / u - mbf*invzc; gated against mvuRight of stereo features */
+    int32_t min_level;   /* level arguments of Frame::GetFeaturesInArea (Frame.cc:327) */
+    int32_t max_level;
+    int32_t blocks;      /* pMP->Observations() > 0: once assigned to a feature, later queries skip that feature */
+    float angle;         /* mode 1 only: LastFrame.mvKeysUn[i].angle */
+} orbhip_proj_query;
+
+/* Search loop of
+     mode 0: ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*>&, th)            ORBmatcher.h:50, ORBmatcher.cc:45-129
+     mode 1: ORBmatcher::SearchByProjection(Frame &Current, const Frame &Last, th, bMono)      ORBmatcher.h:54, ORBmatcher.cc:1328-1470
+   on one frame given flat: kps / desc = F.mvKeysUn / F.mDescriptors (n), u_right = F.mvuRight or NULL, blocked[i] =
+   (F.mvpMapPoints[i] && F.mvpMapPoints[i]->Observations() > 0) or NULL, image bounds as for SearchForInitialization.
+   feature_query[i] receives the index of the query whose map point the reference would leave in F.mvpMapPoints[i]
+   (-1 = untouched); *nmatches is the function's return value.  th_high = TH_HIGH (100).  Host buffers, synchronous. */
+orbhip_status orbhip_search_by_projection(int device, const orbhip_keypoint* kps, const uint8_t* desc, const float* u_right,
+                                          const uint8_t* blocked, int n, int im_w, int im_h,
+                                          const orbhip_proj_query* queries, const uint8_t* query_desc, int nq,
+                                          int mode, float nnratio, int th_high, int check_ori,
+                                          int32_t* feature_query, int* nmatches);
+
 /* -------- Frame::ComputeStereoMatches (Frame.h:94-95, Frame.cc:466-640) ------------------------------- */
 /* For nimg stereo pairs: slot f of `left` against slot f of `right`, using the keypoints, descriptors and image
    pyramids both contexts still hold in HBM from their LAST extract call (the reference reads mvKeys/mvKeysRight,

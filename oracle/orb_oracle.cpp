@@ -715,6 +715,65 @@ int SearchForInitialization(const FrameLite& F1, const FrameLite& F2, float* vbP
 }
 
 
+// ---------------------------------------------------------------- projection-guided matchers on flat data
+// The search core shared by ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th)  (ORBmatcher.cc:45-129, mode 0)
+// and ORBmatcher::SearchByProjection(Frame& Current, const Frame& Last, th, bMono)               (ORBmatcher.cc:1328-1470, mode 1).
+// Everything that needs Map / MapPoint / pose types stays with the caller and arrives flattened, one query per map point
+// that passed the caller's own filters (mbTrackInView / isBad / projection inside the image):
+//   x, y       projected position (pMP->mTrackProjX/Y, or u, v)
+//   radius     search radius already multiplied by the scale factor (r*F.mvScaleFactors[level], th*mvScaleFactors[octave])
+//   ur         projected right coordinate (mTrackProjXR, u - mbf*invzc); compared with mvuRight of stereo features
+//   min/max    level arguments of F.GetFeaturesInArea
+//   blocks     pMP->Observations() > 0: once assigned, the feature is skipped by later queries
+//   angle      LastFrame.mvKeysUn[i].angle (mode 1 only)
+// blocked[i] on entry = F.mvpMapPoints[i] && F.mvpMapPoints[i]->Observations() > 0.  feature_query[i] = index of the query
+// whose map point ends up in F.mvpMapPoints[i] (-1: untouched).  Returns nmatches with the reference's counting.
+struct ProjQuery { float x, y, radius, ur; int min_level, max_level, blocks; float angle; };
+int SearchByProjectionFlat(const FrameLite& F, const float* mvuRight, std::vector<uint8_t> blocked, const ProjQuery* Q, const uint8_t* qdesc, int nq,
+                           int mode, float mfNNratio, int th_high, bool mbCheckOrientation, int* feature_query)
+{
+    int nmatches = 0;
+    for (int i = 0; i < F.N; i++) feature_query[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int iq = 0; iq < nq; iq++) {
+        const ProjQuery& q = Q[iq];
+        const std::vector<size_t> vIndices = F.GetFeaturesInArea(q.x, q.y, q.radius, q.min_level, q.max_level);
+        if (vIndices.empty()) continue;
+        const uint8_t* MPdescriptor = qdesc + (size_t)iq * 32;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (size_t idx : vIndices) {
+            if (blocked[idx]) continue;                                                   // mvpMapPoints[idx] && Observations()>0
+            if (mvuRight && mvuRight[idx] > 0) { const float er = fabsf(q.ur - mvuRight[idx]); if (er > q.radius) continue; }
+            const int dist = DescriptorDistance(MPdescriptor, &F.desc[idx * 32]);
+            if (mode == 0) {
+                if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = F.keys[idx].octave; bestIdx = (int)idx; }
+                else if (dist < bestDist2) { bestLevel2 = F.keys[idx].octave; bestDist2 = dist; }
+            } else if (dist < bestDist) { bestDist = dist; bestIdx = (int)idx; }
+        }
+        if (bestDist <= th_high) {
+            if (mode == 0 && bestLevel == bestLevel2 && bestDist > mfNNratio * bestDist2) continue;
+            feature_query[bestIdx] = iq; blocked[bestIdx] = q.blocks ? 1 : 0;
+            nmatches++;
+            if (mode == 1 && mbCheckOrientation) {
+                float rot = q.angle - F.keys[bestIdx].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdx);
+            }
+        }
+    }
+    if (mode == 1 && mbCheckOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int idx : rotHist[i]) { feature_query[idx] = -1; nmatches--; }
+    }
+    return nmatches;
+}
+
 // ---------------------------------------------------------------- Frame::ComputeStereoMatches, Frame.cc:466-640
 // Inputs are the members the reference reads: mvKeys / mDescriptors of the left frame, mvKeysRight / mDescriptorsRight,
 // both extractors' mvImagePyramid, mvScaleFactors / mvInvScaleFactors, mbf, mb.  Outputs mvuRight, mvDepth (N entries).
@@ -893,6 +952,16 @@ int orb_oracle_distribute(const int* xys, int n, int minX, int maxX, int minY, i
     return (int)out.size();
 }
 int orb_oracle_hamming(const uint8_t* a, const uint8_t* b) { return DescriptorDistance(a, b); }
+// q: nq x {x, y, radius, ur, (int)min_level, (int)max_level, (int)blocks, angle} as 8 x 4-byte words each
+int orb_oracle_search_by_projection(const void* kps, const uint8_t* desc, const float* u_right, const uint8_t* blocked, int n, int imw, int imh,
+                                    const void* q, const uint8_t* qdesc, int nq, int mode, float nnratio, int th_high, int check_ori, int* feature_query)
+{
+    FrameLite* F = new FrameLite; F->build((const KeyPoint*)kps, desc, n, imw, imh);
+    std::vector<uint8_t> b(n, 0); if (blocked) b.assign(blocked, blocked + n);
+    const int r = SearchByProjectionFlat(*F, u_right, b, (const ProjQuery*)q, qdesc, nq, mode, nnratio, th_high, check_ori != 0, feature_query);
+    delete F;
+    return r;
+}
 // Frame::ComputeStereoMatches on the results of the last orb_oracle_extract calls of a left and a right extractor; returns N
 int orb_oracle_stereo_matches(void* hl, void* hr, float mbf, float mb, float* uRight, float* depth, int cap)
 {

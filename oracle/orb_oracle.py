@@ -64,6 +64,8 @@ def lib(fast=False):
     L.orb_oracle_hamming.restype = C.c_int
     L.orb_oracle_hamming.argtypes = [vp, vp]
     L.orb_oracle_bf_nn.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp]
+    L.orb_oracle_search_by_projection.restype = C.c_int
+    L.orb_oracle_search_by_projection.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, vp]
     L.orb_oracle_stereo_matches.restype = C.c_int
     L.orb_oracle_stereo_matches.argtypes = [vp, vp, C.c_float, C.c_float, vp, vp, C.c_int]
     L.orb_oracle_search_for_initialization.restype = C.c_int
@@ -148,6 +150,25 @@ class OracleExtractor:
         n = self.L.orb_oracle_get_level_keypoints(self.h, level, _p(out), cap)
         assert n <= cap
         return out[:n].copy()
+
+
+PROJ_QUERY_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("radius", "<f4"), ("ur", "<f4"), ("min_level", "<i4"), ("max_level", "<i4"),
+                             ("blocks", "<i4"), ("angle", "<f4")])
+
+
+def search_by_projection(kps, desc, imw, imh, queries, qdesc, mode, nnratio=0.8, th_high=100, check_ori=True, u_right=None, blocked=None):
+    """Search core of SearchByProjection(Frame, MapPoints) (mode 0) / SearchByProjection(Current, Last) (mode 1) on flat data.
+    Returns (nmatches, feature_query int32[n])."""
+    kps = np.ascontiguousarray(kps)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    queries = np.ascontiguousarray(queries, PROJ_QUERY_DTYPE)
+    qdesc = np.ascontiguousarray(qdesc, np.uint8)
+    ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    bl = None if blocked is None else np.ascontiguousarray(blocked, np.uint8)
+    fq = np.full(max(len(kps), 1), -1, np.int32)
+    n = lib().orb_oracle_search_by_projection(_p(kps), _p(desc), None if ur is None else _p(ur), None if bl is None else _p(bl), len(kps), imw, imh,
+                                              _p(queries), _p(qdesc), len(queries), mode, nnratio, th_high, int(check_ori), _p(fq))
+    return n, fq[:len(kps)]
 
 
 def stereo_matches(left, right, mbf, mb):

@@ -537,6 +537,57 @@ extern "C" orbhip_status orbhip_debug_candidates(orbhip_ctx* c, int frame, int l
     return ORBHIP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- projection-guided search
+extern "C" orbhip_status orbhip_search_by_projection(int device, const orbhip_keypoint* kps, const uint8_t* desc, const float* u_right,
+                                                     const uint8_t* blocked, int n, int im_w, int im_h,
+                                                     const orbhip_proj_query* queries, const uint8_t* query_desc, int nq,
+                                                     int mode, float nnratio, int th_high, int check_ori, int32_t* feature_query, int* nmatches)
+{
+    if (n < 0 || nq < 0 || !nmatches || (n > 0 && (!kps || !desc || !feature_query)) || (nq > 0 && (!queries || !query_desc)) || im_w < 1 || im_h < 1 || (mode != 0 && mode != 1))
+        return fail(ORBHIP_ERR_INVALID, "bad argument");
+    *nmatches = 0;
+    for (int i = 0; i < n; i++) feature_query[i] = -1;
+    if (n == 0 || nq == 0) return ORBHIP_OK;
+    if (n >= (1 << 19)) return fail(ORBHIP_ERR_UNSUPPORTED, "too many features");
+    if (orbhip_proj_select_lds(n) > 150 * 1024) return fail(ORBHIP_ERR_UNSUPPORTED, "too many features for the LDS matcher (%d)", n);
+    int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(ORBHIP_ERR_HIP, "no HIP device available: no CPU fallback");
+    HIPCHK(hipSetDevice(device));
+    orbhip_keypoint* dk = nullptr; uint8_t *dd = nullptr, *dqd = nullptr; unsigned char *dbl_in = nullptr; float* dur = nullptr; int *dn = nullptr, *dgs = nullptr, *dgi = nullptr, *dnc = nullptr, *dfq = nullptr, *dev = nullptr;
+    float2* dgxy = nullptr; orbhip_proj_query* dq = nullptr; unsigned* dcand = nullptr;
+    hipError_t e = hipSuccess;
+#define TRY(x) do { if (e == hipSuccess) e = (x); } while (0)
+    TRY(dalloc(&dk, n)); TRY(dalloc(&dd, (size_t)n * 32)); TRY(dalloc(&dqd, (size_t)nq * 32)); TRY(dalloc(&dq, nq)); TRY(dalloc(&dn, 8));
+    TRY(dalloc(&dgs, ORBHIP_GRID_CELLS + 1)); TRY(dalloc(&dgi, n)); TRY(dalloc(&dgxy, n)); TRY(dalloc(&dnc, nq)); TRY(dalloc(&dfq, n)); TRY(dalloc(&dev, nq));
+    TRY(dalloc(&dcand, (size_t)nq * n));
+    if (u_right) { TRY(dalloc(&dur, n)); TRY(hipMemcpy(dur, u_right, (size_t)n * sizeof(float), hipMemcpyHostToDevice)); }
+    if (blocked) { TRY(dalloc(&dbl_in, n)); TRY(hipMemcpy(dbl_in, blocked, (size_t)n, hipMemcpyHostToDevice)); }
+    const int hn[2] = {n, 0};
+    TRY(hipMemcpy(dk, kps, (size_t)n * sizeof(orbhip_keypoint), hipMemcpyHostToDevice)); TRY(hipMemcpy(dd, desc, (size_t)n * 32, hipMemcpyHostToDevice));
+    TRY(hipMemcpy(dq, queries, (size_t)nq * sizeof(orbhip_proj_query), hipMemcpyHostToDevice)); TRY(hipMemcpy(dqd, query_desc, (size_t)nq * 32, hipMemcpyHostToDevice));
+    TRY(hipMemcpy(dn, hn, sizeof hn, hipMemcpyHostToDevice));
+    if (e == hipSuccess) {
+        MatchParams M; memset(&M, 0, sizeof M);
+        M.kp2 = dk; M.n2 = dn; M.cap = n; M.im_w = im_w; M.im_h = im_h; M.grid_start = dgs; M.grid_items = dgi; M.grid_xy = dgxy; M.grid_all_levels = 1;
+        orbhip_launch_match_grid(M, 1, nullptr);
+        ProjParams J; memset(&J, 0, sizeof J);
+        J.kp = dk; J.desc = dd; J.u_right = dur; J.n = n; J.im_w = im_w; J.im_h = im_h; J.grid_start = dgs; J.grid_items = dgi; J.grid_xy = dgxy;
+        J.q = dq; J.qdesc = dqd; J.nq = nq; J.cand = dcand; J.ncand = dnc; J.cand_stride = n;
+        J.blocked_in = dbl_in; J.blocked_out = nullptr; J.feature_query = dfq; J.nmatches = dn + 1; J.events = dev;
+        J.mode = mode; J.nnratio = nnratio; J.th_high = th_high; J.check_ori = check_ori;
+        orbhip_launch_proj(J, nullptr);
+        e = hipGetLastError();
+    }
+    TRY(hipDeviceSynchronize());
+    TRY(hipMemcpy(feature_query, dfq, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    TRY(hipMemcpy(nmatches, dn + 1, sizeof(int), hipMemcpyDeviceToHost));
+#undef TRY
+    orbhip_status st = ORBHIP_OK;
+    if (e != hipSuccess) st = fail(ORBHIP_ERR_HIP, "search_by_projection: %s", hipGetErrorString(e));
+    void* ptrs[] = {dk, dd, dqd, dq, dn, dgs, dgi, dgxy, dnc, dfq, dev, dcand, dur, dbl_in};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    return st;
+}
+
 // ---------------------------------------------------------------------------------------------- stereo
 static StereoSide stereo_side(orbhip_ctx* c)
 {

@@ -84,6 +84,7 @@ struct MatchParams {        // SearchForInitialization over camera slots (ORBmat
     int* matches12; int* nmatches;                // [slot][cap], [slot]
     int window; float nnratio; int check_ori;
     int slot0;                                    // first camera slot of this launch group
+    int grid_all_levels;                          // 0: buckets hold level-0 keypoints only (SearchForInitialization); 1: all keypoints
 };
 
 struct StereoSide {         // device-resident results + pyramid of one extractor context (its last call)
@@ -99,6 +100,18 @@ struct StereoParams {       // Frame::ComputeStereoMatches (Frame.cc:466-640)
     float mbf, maxD;                                                       // maxD = mbf / mb
 };
 void orbhip_launch_stereo(const StereoParams& T, int nslots, int max_left, hipStream_t s);
+
+struct ProjParams {         // projection-guided search core (ORBmatcher.cc:45-129 and :1328-1470), one frame
+    const orbhip_keypoint* kp; const uint8_t* desc; const float* u_right; int n;           // the Frame being searched
+    int im_w, im_h;
+    const int* grid_start; const int* grid_items; const float2* grid_xy;                   // 64x48 grid over ALL keypoints
+    const orbhip_proj_query* q; const uint8_t* qdesc; int nq;
+    unsigned* cand; int* ncand; int cand_stride;                                            // per query: i2 | dist<<19 | level<<28, reference order
+    const unsigned char* blocked_in; unsigned char* blocked_out; int* feature_query; int* nmatches; int* events;
+    int mode; float nnratio; int th_high, check_ori;
+};
+void orbhip_launch_proj(const ProjParams& J, hipStream_t s);
+size_t orbhip_proj_select_lds(int n);
 
 // kernel launchers (orbhip_kernels_extract.hip / orbhip_kernels_match.hip)
 void orbhip_launch_pyramid_level(const ExtractParams& P, int level, int w, int h, bool staged, int nframes, hipStream_t s);

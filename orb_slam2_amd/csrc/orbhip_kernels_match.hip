@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void k_match_grid(MatchParams M, float gwInv, 
     // Only level-0 keypoints can ever be returned by GetFeaturesInArea(.., minLevel 0, maxLevel 0) (Frame.cc:362-370), and
     // filtering a cell keeps the relative order of its entries, so the buckets are built from level-0 keypoints only.
     for (int i = tid; i < n2; i += 256) {
-        if (kp[i].octave != 0) continue;
+        if (!M.grid_all_levels && kp[i].octave != 0) continue;
         const int px = (int)roundf(__fmul_rn(__fsub_rn(kp[i].x, 0.0f), gwInv)), py = (int)roundf(__fmul_rn(__fsub_rn(kp[i].y, 0.0f), ghInv));
         if (px < 0 || px >= ORBHIP_GRID_COLS || py < 0 || py >= ORBHIP_GRID_ROWS) continue;
         atomicAdd(&s_cnt[px * ORBHIP_GRID_ROWS + py], 1);
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void k_match_grid(MatchParams M, float gwInv, 
     if (tid == 255) gstart[ORBHIP_GRID_CELLS] = run;
     __syncthreads();
     for (int i = tid; i < n2; i += 256) {
-        if (kp[i].octave != 0) continue;
+        if (!M.grid_all_levels && kp[i].octave != 0) continue;
         const int px = (int)roundf(__fmul_rn(__fsub_rn(kp[i].x, 0.0f), gwInv)), py = (int)roundf(__fmul_rn(__fsub_rn(kp[i].y, 0.0f), ghInv));
         if (px < 0 || px >= ORBHIP_GRID_COLS || py < 0 || py >= ORBHIP_GRID_ROWS) continue;
         gitems[atomicAdd(&s_cnt[px * ORBHIP_GRID_ROWS + py], 1)] = i;

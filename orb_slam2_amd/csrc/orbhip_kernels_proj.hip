@@ -1,0 +1,200 @@
+// orbhip_kernels_proj.hip — search core of the projection-guided matchers:
+//   mode 0  ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th)          ORBmatcher.cc:45-129   (TrackLocalMap)
+//   mode 1  ORBmatcher::SearchByProjection(Frame& Current, const Frame& Last, th, bMono)  ORBmatcher.cc:1328-1470 (TrackWithMotionModel)
+// The caller keeps everything that needs Map / MapPoint / pose types (frustum test, projection, radius, Observations()) and
+// passes one flat query per map point (orbhip_proj_query, include/orbhip.h).  On the GPU:
+//   k_match_grid (all levels)  Frame::AssignFeaturesToGrid                                  Frame.cc:230-245
+//   k_proj_candidates          one wavefront per query: Frame::GetFeaturesInArea in reference order with the level
+//                              arguments of the call, the stereo right-coordinate gate and DescriptorDistance
+//   k_proj_select              one wave replays the order-dependent loop: features claimed by a map point with observations are
+//                              skipped by later queries; best / second-best with the same-level ratio rule (mode 0) or best only +
+//                              rotation histogram (mode 1); ComputeThreeMaxima                ORBmatcher.cc:1601-1642
+#include "orbhip_internal.h"
+
+#define IMAX 0x7fffffff
+#define PJ_T 256
+#define PJ_BLK 1024                    // queries staged per round
+#define PJ_CANDCAP 12288               // candidate records staged in LDS per round (48 KB)
+
+__global__ __launch_bounds__(256) void k_proj_candidates(ProjParams J, float gwInv, float ghInv)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int iq = blockIdx.x * 4 + wave;
+    if (iq >= J.nq) return;
+    const orbhip_proj_query q = J.q[iq];
+    unsigned* cand = J.cand + (long long)iq * J.cand_stride;
+    const unsigned long long* d1 = (const unsigned long long*)(J.qdesc + (long long)iq * 32);
+    const unsigned long long q0 = d1[0], q1 = d1[1], q2 = d1[2], q3 = d1[3];
+    const float x = q.x, y = q.y, r = q.radius;
+    const bool check_levels = (q.min_level > 0) || (q.max_level >= 0);                   // Frame.cc:350
+    int nc = 0;
+    const int minCX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, 0.0f), r), gwInv)));
+    const int maxCX = min(ORBHIP_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, 0.0f), r), gwInv)));
+    const int minCY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, 0.0f), r), ghInv)));
+    const int maxCY = min(ORBHIP_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, 0.0f), r), ghInv)));
+    if (minCX < ORBHIP_GRID_COLS && maxCX >= 0 && minCY < ORBHIP_GRID_ROWS && maxCY >= 0 && maxCX >= minCX && maxCY >= minCY) {
+        const int ny = maxCY - minCY + 1, ncell = (maxCX - minCX + 1) * ny;
+        for (int cb = 0; cb < ncell; cb += 64) {
+            const int c = cb + lane;
+            int a = 0, b = 0;
+            if (c < ncell) { const int ix = minCX + c / ny, iy = minCY + c % ny; const int cell = ix * ORBHIP_GRID_ROWS + iy; a = J.grid_start[cell]; b = J.grid_start[cell + 1]; }
+            auto passes = [&](int t) -> bool {                                            // the filters of GetFeaturesInArea + the stereo gate
+                const float2 k = J.grid_xy[t];
+                if (!(fabsf(__fsub_rn(k.x, x)) < r && fabsf(__fsub_rn(k.y, y)) < r)) return false;
+                const int i2 = J.grid_items[t];
+                if (check_levels) { const int oct = J.kp[i2].octave; if (oct < q.min_level) return false; if (q.max_level >= 0 && oct > q.max_level) return false; }
+                if (J.u_right) { const float ur = J.u_right[i2]; if (ur > 0 && fabsf(__fsub_rn(q.ur, ur)) > r) return false; }   // ORBmatcher.cc:91-96, 1408-1414
+                return true;
+            };
+            int cnt = 0;
+            for (int t = a; t < b; t++) cnt += passes(t) ? 1 : 0;
+            int incl = cnt;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+            int pos = nc + incl - cnt;
+            for (int t = a; t < b; t++) {
+                if (!passes(t)) continue;
+                const int i2 = J.grid_items[t];
+                if (pos < J.cand_stride) {
+                    const unsigned long long* d2 = (const unsigned long long*)(J.desc + (long long)i2 * 32);
+                    const unsigned dist = (unsigned)(__popcll(q0 ^ d2[0]) + __popcll(q1 ^ d2[1]) + __popcll(q2 ^ d2[2]) + __popcll(q3 ^ d2[3]));
+                    cand[pos] = (unsigned)i2 | (dist << 19) | ((unsigned)(J.kp[i2].octave & 15) << 28);
+                }
+                pos++;
+            }
+            nc += __shfl(incl, 63);
+        }
+    }
+    if (lane == 0) J.ncand[iq] = min(nc, J.cand_stride);
+}
+
+__device__ __forceinline__ unsigned long long pj_argmin_mask(int d, unsigned long long M)
+{
+#pragma unroll
+    for (int b = 8; b >= 0; b--) { const unsigned long long z = __ballot(((d >> b) & 1) == 0) & M; if (z) M = z; }
+    return M;
+}
+
+__global__ __launch_bounds__(PJ_T) void k_proj_select(ProjParams J)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = J.n;
+    HIP_DYNAMIC_SHARED(int, lds)
+    int* s_blocked = lds;                                   // F.mvpMapPoints[i] && Observations() > 0
+    int* s_fq = s_blocked + n;                              // query whose map point sits in F.mvpMapPoints[i]
+    float* s_fang = reinterpret_cast<float*>(s_fq + n);     // mvKeysUn[i].angle
+    int* s_nc = reinterpret_cast<int*>(s_fang + n);         // per staged query: list length, start, blocks flag, angle
+    int* s_off = s_nc + PJ_BLK;
+    int* s_qblocks = s_off + PJ_BLK + 1;
+    float* s_qang = reinterpret_cast<float*>(s_qblocks + PJ_BLK);
+    int* s_hist = reinterpret_cast<int*>(s_qang + PJ_BLK);  // [HISTO_LENGTH] + 8 misc
+    unsigned* s_cand = reinterpret_cast<unsigned*>(s_hist + ORBHIP_HISTO_LENGTH + 8);
+    for (int i = tid; i < n; i += PJ_T) { s_blocked[i] = J.blocked_in ? (int)J.blocked_in[i] : 0; s_fq[i] = -1; s_fang[i] = J.kp[i].angle; }
+    for (int i = tid; i < ORBHIP_HISTO_LENGTH + 8; i += PJ_T) s_hist[i] = 0;
+    __syncthreads();
+    const float factor = 1.0f / ORBHIP_HISTO_LENGTH;
+    int nmatches = 0, nev = 0;                               // meaningful in wave 0 only
+    for (int qb = 0; qb < J.nq; qb += PJ_BLK) {
+        const int nb = min(PJ_BLK, J.nq - qb);
+        for (int i = tid; i < nb; i += PJ_T) { s_nc[i] = J.ncand[qb + i]; s_qblocks[i] = J.q[qb + i].blocks; s_qang[i] = J.q[qb + i].angle; }
+        __syncthreads();
+        if (wave == 0) {
+            int run = 0;
+            for (int cb = 0; cb < nb; cb += 64) {
+                const int v = (cb + lane < nb) ? s_nc[cb + lane] : 0;
+                int incl = v;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(incl, off); if (lane >= off) incl += u; }
+                if (cb + lane < nb) s_off[cb + lane] = run + incl - v;
+                run += __shfl(incl, 63);
+            }
+        }
+        __syncthreads();
+        for (int j = wave; j < nb; j += PJ_T / 64) {
+            const int nc = s_nc[j], o = s_off[j];
+            if (o + nc > PJ_CANDCAP) continue;
+            for (int t = lane; t < nc; t += 64) s_cand[o + t] = J.cand[(long long)(qb + j) * J.cand_stride + t];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            for (int j = 0; j < nb; j++) {
+                const int nc = s_nc[j];
+                if (nc == 0) continue;                                                      // vIndices.empty()
+                const int o = s_off[j];
+                const bool staged = o + nc <= PJ_CANDCAP;
+                const unsigned* cand = J.cand + (long long)(qb + j) * J.cand_stride;
+                int best = 256, blevel = -1, second = 256, slevel = -1, bidx = -1;
+                for (int cb = 0; cb < nc; cb += 64) {
+                    const int t = cb + lane;
+                    unsigned e = 0;
+                    if (t < nc) e = staged ? s_cand[o + t] : cand[t];
+                    const int i2 = (int)(e & 0x7FFFFu), dist = (int)((e >> 19) & 0x1FFu), lvl = (int)(e >> 28);
+                    const bool valid = t < nc && dist < 256 && !s_blocked[i2];
+                    const unsigned long long V = __ballot(valid);
+                    if (V == 0) continue;
+                    const int f1 = __ffsll((long long)pj_argmin_mask(dist, V)) - 1;       // first candidate with the minimum
+                    const int wmin = __builtin_amdgcn_readlane(dist, f1), ci = __builtin_amdgcn_readlane(i2, f1), cl = __builtin_amdgcn_readlane(lvl, f1);
+                    const unsigned long long V2 = V & ~(1ull << f1);
+                    int wsec = 256, l2 = -1;
+                    if (V2) { const int f2 = __ffsll((long long)pj_argmin_mask(dist, V2)) - 1; wsec = __builtin_amdgcn_readlane(dist, f2); l2 = __builtin_amdgcn_readlane(lvl, f2); }
+                    // the two smallest (distance, list position) keys == the reference's sequential best / second-best update
+                    if (wmin < best) {
+                        if (best <= wsec) { second = best; slevel = blevel; } else { second = wsec; slevel = l2; }
+                        best = wmin; bidx = ci; blevel = cl;
+                    } else if (wmin < second) { second = wmin; slevel = cl; }
+                }
+                if (best <= J.th_high) {
+                    if (J.mode == 0 && blevel == slevel && (float)best > __fmul_rn(J.nnratio, (float)second)) continue;   // ORBmatcher.cc:118-121
+                    if (lane == 0) {
+                        s_fq[bidx] = qb + j; s_blocked[bidx] = s_qblocks[j] ? 1 : 0;
+                        if (J.mode == 1 && J.check_ori) {
+                            float rot = __fsub_rn(s_qang[j], s_fang[bidx]);
+                            if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                            int bin = (int)roundf(__fmul_rn(rot, factor));
+                            if (bin == ORBHIP_HISTO_LENGTH) bin = 0;
+                            bin = min(max(bin, 0), ORBHIP_HISTO_LENGTH - 1);
+                            s_hist[bin]++; J.events[nev] = (bin << 20) | bidx;              // rotHist[bin].push_back(bestIdx2)
+                        }
+                    }
+                    nmatches++; nev++;
+                    __builtin_amdgcn_wave_barrier();              // lane 0's claim precedes the next query's reads (same wave: LDS ops stay in order)
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        if (J.mode == 1 && J.check_ori) {
+            if (lane == 0) {
+                int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+                for (int i = 0; i < ORBHIP_HISTO_LENGTH; i++) {
+                    const int s = s_hist[i];
+                    if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                    else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+                    else if (s > max3) { max3 = s; ind3 = i; }
+                }
+                if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+                else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
+                int removed = 0;
+                for (int k = 0; k < nev; k++) {                                            // ORBmatcher.cc:1452-1466: one decrement per histogram entry
+                    const int ev = J.events[k], bin = ev >> 20, idx = ev & 0xFFFFF;
+                    if (bin != ind1 && bin != ind2 && bin != ind3) { s_fq[idx] = -1; removed++; }
+                }
+                s_hist[ORBHIP_HISTO_LENGTH] = removed;
+            }
+            __builtin_amdgcn_wave_barrier();
+            nmatches -= s_hist[ORBHIP_HISTO_LENGTH];
+        }
+        if (lane == 0) *J.nmatches = nmatches;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += PJ_T) { J.feature_query[i] = s_fq[i]; if (J.blocked_out) J.blocked_out[i] = (unsigned char)s_blocked[i]; }
+}
+
+size_t orbhip_proj_select_lds(int n) { return sizeof(int) * ((size_t)3 * n + 4 * PJ_BLK + 1 + ORBHIP_HISTO_LENGTH + 8 + PJ_CANDCAP); }
+
+void orbhip_launch_proj(const ProjParams& J, hipStream_t s)
+{
+    const float gwInv = (float)ORBHIP_GRID_COLS / (float)((float)J.im_w - 0.0f), ghInv = (float)ORBHIP_GRID_ROWS / (float)((float)J.im_h - 0.0f);
+    if (J.nq > 0) hipLaunchKernelGGL(k_proj_candidates, dim3((J.nq + 3) / 4, 1, 1), dim3(256, 1, 1), 0, s, J, gwInv, ghInv);
+    hipLaunchKernelGGL(k_proj_select, dim3(1, 1, 1), dim3(PJ_T, 1, 1), orbhip_proj_select_lds(J.n), s, J);
+}

@@ -26,7 +26,7 @@ SYMBOLS = [
     "orbhip_hamming_nn", "orbhip_hamming_nn_device", "orbhip_search_for_initialization", "orbhip_profile_enable",
     "orbhip_profile_num_kernels", "orbhip_profile_get", "orbhip_profile_reset", "orbhip_algorithmic_bytes_per_frame",
     "orbhip_algorithmic_bytes_per_frame_kernel", "orbhip_debug_blurred_level", "orbhip_debug_candidates",
-    "orbhip_compute_stereo_matches",
+    "orbhip_compute_stereo_matches", "orbhip_search_by_projection",
 ]
 
 
@@ -77,6 +77,7 @@ def lib(path=None):
     L.orbhip_hamming_nn_device.argtypes = [vp, vp, C.c_int, vp, C.c_int64, C.c_int64, vp, vp, vp]
     L.orbhip_search_for_initialization.argtypes = [C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp,
                                                    C.c_int, C.c_float, C.c_int, ip]
+    L.orbhip_search_by_projection.argtypes = [C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, vp, ip]
     L.orbhip_compute_stereo_matches.argtypes = [vp, vp, C.c_int, C.c_float, C.c_float, vp, vp, C.c_int]
     L.orbhip_profile_enable.argtypes = [vp, C.c_int]
     L.orbhip_profile_num_kernels.argtypes = [vp]
@@ -288,6 +289,29 @@ class ORBmatcher:
                                                        im_w, im_h, _p(prev), _p(m12), windowSize, self.nnratio, int(self.checkOri),
                                                        C.byref(nm)), "orbhip_search_for_initialization")
         return nm.value, m12[:len(kps1)], prev
+
+
+PROJ_QUERY_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("radius", "<f4"), ("ur", "<f4"), ("min_level", "<i4"), ("max_level", "<i4"),
+                             ("blocks", "<i4"), ("angle", "<f4")])          # orbhip_proj_query
+
+
+def search_by_projection(kps, desc, im_w, im_h, queries, query_desc, mode, nnratio=0.8, th_high=100, check_ori=True, u_right=None,
+                         blocked=None, device=0, library=None):
+    """Search loop of ORBmatcher::SearchByProjection(Frame, MapPoints) (mode 0) / (Current, Last) (mode 1) on flat data.
+    Returns (nmatches, feature_query int32[n])."""
+    L = lib(library)
+    kps = np.ascontiguousarray(kps)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    queries = np.ascontiguousarray(queries, PROJ_QUERY_DTYPE)
+    query_desc = np.ascontiguousarray(query_desc, np.uint8)
+    ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    bl = None if blocked is None else np.ascontiguousarray(blocked, np.uint8)
+    fq = np.full(max(len(kps), 1), -1, np.int32)
+    nm = C.c_int()
+    _check(L.orbhip_search_by_projection(device, _p(kps), _p(desc), None if ur is None else _p(ur), None if bl is None else _p(bl), len(kps), im_w, im_h,
+                                         _p(queries), _p(query_desc), len(queries), mode, nnratio, th_high, int(check_ori), _p(fq), C.byref(nm)),
+           "orbhip_search_by_projection", L)
+    return nm.value, fq[:len(kps)]
 
 
 def hamming_nn(q, db, device=0, index_base=0, library=None):

@@ -1,0 +1,86 @@
+"""Search loops of the projection-guided matchers on flat data: ORBmatcher::SearchByProjection(Frame&,
+vector<MapPoint*>&, th) (ORBmatcher.cc:45-129, mode 0) and SearchByProjection(Current, Last, th, bMono) (:1328-1470, mode 1).
+The queries play the map points the caller would have projected; assignments must equal the oracle's restatement."""
+import numpy as np
+import pytest
+
+import orb_slam2_amd
+from orb_slam2_amd import synth
+
+
+@pytest.fixture(scope="module")
+def scene(oracle):
+    w, h, n = 480, 360, 700
+    seq = synth.sequence(w, h, 2, seed=41)
+    ora = oracle.OracleExtractor(n, 1.2, 8, 20, 7)
+    last, cur = ora.extract(seq[0]), ora.extract(seq[1])
+    return w, h, ora.params()["scale_factors"], last, cur
+
+
+def _queries(oracle, scene, mode, th, rng, level_rule):
+    w, h, sf, (kl, dl), (kc, dc) = scene
+    q = np.zeros(len(kl), oracle.PROJ_QUERY_DTYPE)
+    # last-frame keypoints "projected" with the true image motion (3, 1) px plus a little pose error
+    q["x"] = kl["x"] - 3.0 + rng.normal(0, 1.0, len(kl)).astype(np.float32)
+    q["y"] = kl["y"] - 1.0 + rng.normal(0, 1.0, len(kl)).astype(np.float32)
+    oct_ = kl["octave"]
+    q["radius"] = (np.float32(th) * sf[oct_]).astype(np.float32)
+    q["ur"] = q["x"] - rng.uniform(2, 40, len(kl)).astype(np.float32)
+    if level_rule == "local_map":                       # GetFeaturesInArea(x, y, r, level-1, level)      ORBmatcher.cc:69
+        q["min_level"], q["max_level"] = oct_ - 1, oct_
+    elif level_rule == "forward":                       # GetFeaturesInArea(u, v, radius, octave)          ORBmatcher.cc:1384
+        q["min_level"], q["max_level"] = oct_, -1
+    elif level_rule == "backward":                      # GetFeaturesInArea(u, v, radius, 0, octave)       ORBmatcher.cc:1386
+        q["min_level"], q["max_level"] = 0, oct_
+    else:                                               # GetFeaturesInArea(u, v, radius, octave-1, octave+1)
+        q["min_level"], q["max_level"] = oct_ - 1, oct_ + 1
+    q["blocks"] = rng.random(len(kl)) < 0.9            # most map points have observations
+    q["angle"] = kl["angle"]
+    keep = rng.random(len(kl)) < 0.85                  # some map points failed the caller's frustum test
+    return q[keep], dl[keep]
+
+
+@pytest.mark.parametrize("mode,rule,th,ratio,stereo", [(0, "local_map", 3.0, 0.8, False), (0, "local_map", 5.0, 0.8, True),
+                                                     (1, "window", 7.0, 0.9, False), (1, "forward", 15.0, 0.9, True),
+                                                     (1, "backward", 15.0, 0.9, False)])
+def test_search_by_projection(backend, oracle, scene, mode, rule, th, ratio, stereo):
+    w, h, sf, (kl, dl), (kc, dc) = scene
+    rng = np.random.default_rng(mode * 100 + int(th))
+    q, qd = _queries(oracle, scene, mode, th, rng, rule)
+    u_right = None
+    if stereo:
+        u_right = np.where(rng.random(len(kc)) < 0.6, kc["x"] - rng.uniform(1, 45, len(kc)), -1).astype(np.float32)
+    blocked = (rng.random(len(kc)) < 0.15).astype(np.uint8)
+    for check_ori in (True, False):
+        n_o, f_o = oracle.search_by_projection(kc, dc, w, h, q, qd, mode, nnratio=ratio, th_high=100, check_ori=check_ori, u_right=u_right, blocked=blocked)
+        n_g, f_g = orb_slam2_amd.search_by_projection(kc, dc, w, h, q, qd, mode, nnratio=ratio, th_high=100, check_ori=check_ori, u_right=u_right,
+                                                      blocked=blocked, library=backend)
+        assert n_g == n_o and np.array_equal(f_g, f_o)
+        assert n_o > 50
+
+
+def test_search_by_projection_edge_cases(backend, oracle, scene):
+    w, h, sf, (kl, dl), (kc, dc) = scene
+    rng = np.random.default_rng(3)
+    q, qd = _queries(oracle, scene, 0, 4.0, rng, "local_map")
+    # no queries / no features
+    n_g, f_g = orb_slam2_amd.search_by_projection(kc, dc, w, h, q[:0], qd[:0], 0, library=backend)
+    assert n_g == 0 and np.all(f_g == -1)
+    n_g, f_g = orb_slam2_amd.search_by_projection(kc[:0], dc[:0], w, h, q, qd, 0, library=backend)
+    assert n_g == 0 and len(f_g) == 0
+    # every map point projects onto the same spot with non-blocking map points: the last query wins each overwritten feature,
+    # and the reference still counts every assignment
+    q2 = q[:60].copy()
+    q2["x"], q2["y"], q2["radius"], q2["min_level"], q2["max_level"], q2["blocks"] = kc["x"][5], kc["y"][5], 40.0, 0, -1, 0
+    for mode in (0, 1):
+        n_o, f_o = oracle.search_by_projection(kc, dc, w, h, q2, qd[:60], mode, nnratio=0.8, check_ori=True)
+        n_g, f_g = orb_slam2_amd.search_by_projection(kc, dc, w, h, q2, qd[:60], mode, nnratio=0.8, check_ori=True, library=backend)
+        assert n_g == n_o and np.array_equal(f_g, f_o)
+    # more than one staging round of queries (> 1024) and windows covering the whole image (lists beyond the LDS stage)
+    big = np.concatenate([q] * 3)[:1500].copy()
+    big["radius"] = 600.0
+    big["min_level"], big["max_level"] = 0, -1
+    bigd = np.concatenate([qd] * 3)[:1500]
+    n_o, f_o = oracle.search_by_projection(kc, dc, w, h, big, bigd, 0, nnratio=0.8)
+    n_g, f_g = orb_slam2_amd.search_by_projection(kc, dc, w, h, big, bigd, 0, nnratio=0.8, library=backend)
+    assert n_g == n_o and np.array_equal(f_g, f_o)
