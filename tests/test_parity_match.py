@@ -161,6 +161,33 @@ def test_device_pipeline_extract_and_match(backend, oracle, num_streams):
     ex.close()
 
 
+def test_device_pipeline_unaligned_input(backend, oracle):
+    """Caller buffer with an odd base address and an odd row pitch: every kernel that prefers aligned 32-bit loads on level 0
+    (FAST patch staging, blur, pyramid level 1) must take its byte path and still be bit-exact."""
+    w, h, n = 333, 250, 300
+    img = synth.frame(w, h, seed=19)
+    ko, do = oracle.OracleExtractor(n, 1.2, 6, 20, 7).extract(img)
+    ex = orb_slam2_amd.ORBextractor(n, 1.2, 6, 20, 7, w, h, max_batch=1, library=backend)
+    pitch = w + 6                                            # 339: not a multiple of 4
+    host = np.zeros(1 + h * pitch + 64, np.uint8)
+    host[1:1 + h * pitch].reshape(h, pitch)[:, :w] = img   # frame starts at byte offset 1
+    if backend.endswith("_emu.so"):
+        ptr = host.ctypes.data + 1
+    else:
+        import ctypes as C
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        dptr = C.c_void_p()
+        assert hip.hipMalloc(C.byref(dptr), host.nbytes) == 0
+        assert hip.hipMemcpy(dptr, host.ctypes.data_as(C.c_void_p), host.nbytes, 1) == 0
+        ptr = dptr.value + 1
+    ex.extract_device(ptr, 1, h * pitch, pitch)
+    ks, ds = ex.fetch(1)
+    assert ks[0].tobytes() == ko.tobytes() and np.array_equal(ds[0], do)
+    ex.close()
+
+
 def test_golden_match_fixture(backend):
     g = np.load(os.path.join(GOLDEN, "match_320x240_n300_seed21.npz"))
     m = orb_slam2_amd.ORBmatcher(0.9, True, library=backend)
