@@ -52,8 +52,6 @@ struct orbhip_ctx {
     hipStream_t bstream = nullptr; hipEvent_t ev_pyr = nullptr, ev_blur = nullptr;      // blur runs beside FAST + quadtree (independent until describe)
     hipStream_t mstream = nullptr; hipEvent_t ev_extract = nullptr; hipEvent_t ev_match[3] = {nullptr, nullptr, nullptr}; bool match_pending[3] = {false, false, false};
     int cur = 0; int last_nimg = 0; bool last_matched = false; bool last_from_host = false;
-    // host-buffer API: the whole call (H2D, 7+4 kernels on two streams, 3 D2H copies) is replayed from a hipGraph, one per output buffer
-    struct GraphRec { hipGraphExec_t exec = nullptr; int nimg = 0; } graphs[3]; bool use_graph = true;
     // host-buffer API staging: one contiguous device input buffer + pinned host mirrors (single bulk copies instead of per-frame pageable copies)
     uint8_t* d_in = nullptr; uint8_t* h_in = nullptr; orbhip_keypoint* h_kp = nullptr; uint8_t* h_desc = nullptr; int* h_n = nullptr; int in_pitch = 0;
     // stereo (Frame::ComputeStereoMatches): level-0 source of the last call + lazily allocated workspace on the LEFT context
@@ -151,7 +149,6 @@ extern "C" void orbhip_destroy(orbhip_ctx* c)
                     c->d_prev, c->d_m12, c->d_nm};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     { void* st[] = {c->d_st_rowstart, c->d_st_rowitems, c->d_st_u, c->d_st_depth, c->d_st_sad}; for (void* q : st) if (q) (void)hipFree(q); }
-    for (auto& gr : c->graphs) if (gr.exec) (void)hipGraphExecDestroy(gr.exec);
     if (c->d_in) (void)hipFree(c->d_in);
     if (c->h_in) (void)hipHostFree(c->h_in);
     if (c->h_kp) (void)hipHostFree(c->h_kp);
@@ -496,35 +493,8 @@ extern "C" orbhip_status orbhip_extract_batch(orbhip_ctx* c, int nimg, const uin
         else for (int y = 0; y < c->cfg.height; y++) memcpy(dst + (size_t)y * c->in_pitch, imgs[f] + (size_t)y * stride, c->cfg.width);
     }
     c->last_from_host = true;
-    // Launch-bound regime (one or two frames per call, the SLAM drop-in case): replay the whole call from a hipGraph.
-    bool pending = false; for (bool p : c->match_pending) pending = pending || p;
-    if (c->use_graph && !c->prof && c->xstreams.empty() && !pending) {
-        const int ncur = (c->cur + 1) % 3;
-        orbhip_ctx::GraphRec& G = c->graphs[ncur];
-        if (!G.exec || G.nimg != nimg) {
-            if (G.exec) { (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; }
-            const int saved_cur = c->cur;
-            if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                bool ok = hipMemcpyAsync(c->d_in, c->h_in, nimg * fbytes, hipMemcpyHostToDevice, c->stream) == hipSuccess;
-                ok = ok && run_pipeline(c, nimg, c->d_in, (long long)fbytes, c->in_pitch, 0, 0, 0.f, 0) == ORBHIP_OK;
-                ok = ok && enqueue_fetch(c, nimg, true, true) == ORBHIP_OK;
-                hipGraph_t graph = nullptr;
-                const hipError_t ee = hipStreamEndCapture(c->stream, &graph);
-                if (ok && ee == hipSuccess && graph && hipGraphInstantiate(&G.exec, graph, nullptr, nullptr, 0) == hipSuccess) G.nimg = nimg; else G.exec = nullptr;
-                if (graph) (void)hipGraphDestroy(graph);
-            }
-            c->cur = saved_cur;                                       // capturing enqueues nothing
-            (void)hipGetLastError();
-            if (!G.exec) c->use_graph = false;                        // capture unsupported here: plain launches from now on
-        }
-        if (G.exec) {
-            c->cur = ncur; c->last_img0 = c->d_in; c->last_img0_fstride = (long long)fbytes; c->last_img0_pitch = c->in_pitch;
-            c->last_matched = false; c->last_nimg = nimg;
-            HIPCHK(hipGraphLaunch(G.exec, c->stream));
-            st = orbhip_sync(c); if (st != ORBHIP_OK) return st;
-            return finish_fetch(c, nimg, kps, desc, cap, n_out);
-        }
-    }
+    // (a hipGraph replay of this whole call was measured and is NOT used: 0.52 ms vs 0.31 ms per single-frame call with plain
+    //  launches on ROCm 7.2 — see DESIGN.md §5)
     HIPCHK(hipMemcpyAsync(c->d_in, c->h_in, nimg * fbytes, hipMemcpyHostToDevice, c->stream));
     st = run_pipeline(c, nimg, c->d_in, (long long)fbytes, c->in_pitch, 0, 0, 0.f, 0);
     if (st != ORBHIP_OK) return st;

@@ -227,14 +227,5 @@ inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipE
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = hipemu_now_ms(); return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
-// stream capture / graphs are not emulated: BeginCapture fails and the library falls back to plain launches
-typedef struct hipemuGraph* hipGraph_t; typedef struct hipemuGraphExec* hipGraphExec_t;
-enum hipStreamCaptureMode { hipStreamCaptureModeGlobal = 0, hipStreamCaptureModeThreadLocal = 1, hipStreamCaptureModeRelaxed = 2 };
-inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return hipErrorInvalidValue; }
-inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = nullptr; return hipErrorInvalidValue; }
-inline hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, void*, void*, size_t) { return hipErrorInvalidValue; }
-inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorInvalidValue; }
-inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
-inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned = 0) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return hipSuccess; }
