@@ -691,6 +691,7 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
 
 __global__ __launch_bounds__(QT_T) void k_quadtree(ExtractParams P)
 {
+    __builtin_amdgcn_s_setprio(3);          // latency-bound: win issue arbitration against the VALU-bound blur running beside it
     int level, frame;
     if (!xcd_frame_map(P.nlevels, P.nframes, level, frame)) return;
     frame += P.frame0;

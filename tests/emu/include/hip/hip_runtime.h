@@ -149,6 +149,7 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask,
     if (s < 0) return bound_ctrl ? 0 : old;
     return got;
 }
+inline void __builtin_amdgcn_s_setprio(int) {}
 inline void __builtin_amdgcn_wave_barrier() { hipemu::wave_collective(hipemu::OP_BALLOT, 0, 0); }   // rendezvous of the wave's lanes
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
