@@ -354,9 +354,9 @@ static orbhip_status run_pipeline(orbhip_ctx* c, int nimg, const uint8_t* d_img0
             // workgroups are latency-bound (barriers, one per (frame, level)) and leave the VALUs idle
             { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nf, s); }
             HIPCHK(hipEventRecord(c->ev_pyr, s)); HIPCHK(hipStreamWaitEvent(c->bstream, c->ev_pyr, 0));
+            { ProfScope ps(c, K_QUADTREE, s); orbhip_launch_quadtree(P, nf, s); }       // enqueued first: its few, long workgroups get CUs before the blur floods them
             { ProfScope ps(c, K_BLUR, c->bstream); orbhip_launch_blur(P, c->gk, nf, c->bstream); }
             HIPCHK(hipEventRecord(c->ev_blur, c->bstream));
-            { ProfScope ps(c, K_QUADTREE, s); orbhip_launch_quadtree(P, nf, s); }
             HIPCHK(hipStreamWaitEvent(s, c->ev_blur, 0));
         } else {
             { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nf, s); }
