@@ -509,23 +509,23 @@ __device__ __forceinline__ int qt_block_exscan(int* a, int n, int* scratch, int 
     return total;
 }
 
-#define QT_LDSKEYS 4096                 // candidates per (frame, level) whose keys stay in LDS (7 B each); more -> HBM workspace
+#define QT_LDSKEYS 4096                 // candidates per (frame, level) whose keys stay in LDS (6 B each); more -> HBM workspace
 
 size_t orbhip_quadtree_lds_bytes(int maxn, int maxcells)
 {
     // s_pref[maxcells+1] | s_slot[maxcells] | cnt[2][maxn] | depth[2][maxn] | cc[4*maxn] | map[4*maxn] | a | b | sidx | split | best [maxn each]
-    // | scratch[QT_SCR] | misc[16] | key code u32 / node u16 / score u8 [QT_LDSKEYS]
-    return sizeof(int) * ((size_t)(2 * maxcells + 1) + (size_t)maxn * (2 + 2 + 4 + 4 + 5) + QT_SCR + 16) + (size_t)QT_LDSKEYS * 7 + 16;
+    // | scratch[QT_SCR] | misc[16] | key code u32 / node u16 [QT_LDSKEYS]      (KITTI shape: 52.9 KB -> three workgroups per CU)
+    return sizeof(int) * ((size_t)(2 * maxcells + 1) + (size_t)maxn * (2 + 2 + 4 + 4 + 5) + QT_SCR + 16) + (size_t)QT_LDSKEYS * 6;
 }
 
 // per-candidate state of the quadtree replay: path code, current node (list position), FAST score
 struct QtKeysLds {
-    unsigned* code; unsigned short* node; uint8_t* score;
+    unsigned* code; unsigned short* node; const unsigned* val;
     __device__ __forceinline__ unsigned getCode(int k) const { return code[k]; }
     __device__ __forceinline__ int getNode(int k) const { return node[k]; }
-    __device__ __forceinline__ int getScore(int k) const { return score[k]; }
+    __device__ __forceinline__ int getScore(int k) const { return (int)(val[k] >> 24); }      // read once, at the very end
     __device__ __forceinline__ void setNode(int k, int v) const { node[k] = (unsigned short)v; }
-    __device__ __forceinline__ void init(int k, unsigned c, int nd, int sc) const { code[k] = c; node[k] = (unsigned short)nd; score[k] = (uint8_t)sc; }
+    __device__ __forceinline__ void init(int k, unsigned c, int nd, int) const { code[k] = c; node[k] = (unsigned short)nd; }
 };
 struct QtKeysHbm {
     unsigned* code; int* node; const unsigned* val;
@@ -706,7 +706,6 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(ExtractParams P)
     L.best = L.split + maxn; L.scratch = L.best + maxn; L.misc = L.scratch + QT_SCR;
     unsigned* kcode = reinterpret_cast<unsigned*>(L.misc + 16);
     unsigned short* knode = reinterpret_cast<unsigned short*>(kcode + QT_LDSKEYS);
-    uint8_t* kscore = reinterpret_cast<uint8_t*>(knode + QT_LDSKEYS);
 
     const int* ccount = P.cell_count + (long long)frame * P.ncells_total + g.cell_first;
     for (int c = tid; c < g.ncells; c += QT_T) { L.pref[c] = ccount[c]; L.slot[c] = P.cells[g.cell_first + c].cand_idx; }
@@ -716,7 +715,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(ExtractParams P)
     n = min(n, g.cand_total_cap);
     unsigned* qval = P.qt_val + (long long)frame * P.qt_per_frame + g.cand_total_off;
     if (n <= QT_LDSKEYS) {
-        QtKeysLds keys; keys.code = kcode; keys.node = knode; keys.score = kscore;
+        QtKeysLds keys; keys.code = kcode; keys.node = knode; keys.val = qval;
         qt_replay(P, g, L, keys, qval, n, frame, level, tid);
     } else {
         QtKeysHbm keys; keys.code = P.qt_code + (long long)frame * P.qt_per_frame + g.cand_total_off;
