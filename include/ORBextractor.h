@@ -29,6 +29,12 @@ public:
     // Compute the ORB features and descriptors on an image (mask is ignored, as in the reference).
     void operator()(cv::InputArray image, cv::InputArray mask, std::vector<cv::KeyPoint>& keypoints, cv::OutputArray descriptors);
 
+    // The same for an interleaved 8-bit colour frame (3 or 4 channels): Tracking::GrabImage* (Tracking.cc:172-198, 217-229,
+    // 248-260) converts with cv::cvtColor on the CPU before building the Frame; here the conversion runs on the GPU and
+    // mvImagePyramid[0] is the gray frame.  bRGB is Tracking::mbRGB (Camera.RGB, Tracking.cc:82): true = R first.
+    void ExtractColor(const unsigned char* data, int step, int cols, int rows, int channels, bool bRGB,
+                      std::vector<cv::KeyPoint>& keypoints, cv::OutputArray descriptors);
+
     int inline GetLevels() { return nlevels; }
     float inline GetScaleFactor() { return scaleFactor; }
     std::vector<float> inline GetScaleFactors() { return mvScaleFactor; }
@@ -49,6 +55,7 @@ public:
 
 protected:
     void EnsureContext(int width, int height);
+    void Deliver(int n, const std::vector<unsigned char>& desc, std::vector<cv::KeyPoint>& keypoints, cv::OutputArray descriptors);
 
     int nfeatures;
     double scaleFactor;

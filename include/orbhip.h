@@ -83,6 +83,14 @@ orbhip_status orbhip_extract(orbhip_ctx* ctx, const uint8_t* img, int stride_byt
 /* the same for nimg <= max_batch frames in one pass; outputs are [nimg][cap] */
 orbhip_status orbhip_extract_batch(orbhip_ctx* ctx, int nimg, const uint8_t* const* imgs, int stride_bytes,
                                    orbhip_keypoint* kps, uint8_t* desc, int cap, int* n_out /* nimg */);
+/* Colour frames: Tracking::GrabImageStereo/RGBD/Monocular (Tracking.cc:172-198, 217-229, 248-260) run
+   cv::cvtColor(RGB2GRAY | BGR2GRAY | RGBA2GRAY | BGRA2GRAY) on the CPU before the extractor is called; these entry
+   points take the interleaved 8-bit colour frame instead and convert on the device (OpenCV 3.2 fixed point:
+   gray = (4899 R + 9617 G + 1868 B + 8192) >> 14, alpha ignored) into the context's level-0 plane.
+   channels = 3 or 4; rgb_order != 0 means R is the first channel (mbRGB, Tracking.cc:82), 0 means B first. */
+orbhip_status orbhip_extract_batch_color(orbhip_ctx* ctx, int nimg, const uint8_t* const* imgs, int stride_bytes,
+                                         int channels, int rgb_order,
+                                         orbhip_keypoint* kps, uint8_t* desc, int cap, int* n_out /* nimg */);
 /* mvImagePyramid[level] of frame `frame` of the last call (ORBextractor.h:85; read by Frame.cc:473,563-580) */
 orbhip_status orbhip_pyramid_level(orbhip_ctx* ctx, int frame, int level, uint8_t* dst, int dst_stride);
 
@@ -94,6 +102,10 @@ orbhip_status orbhip_pyramid_level(orbhip_ctx* ctx, int frame, int level, uint8_
    (ORBmatcher.cc:405-520; the unit of work of BASELINE.json's metric). */
 orbhip_status orbhip_extract_device(orbhip_ctx* ctx, int nimg, const uint8_t* d_imgs, size_t frame_stride,
                                     int row_stride, int match_prev, int window, float nnratio, int check_ori);
+/* the same for interleaved colour frames resident in HBM (see orbhip_extract_batch_color) */
+orbhip_status orbhip_extract_device_color(orbhip_ctx* ctx, int nimg, const uint8_t* d_imgs, size_t frame_stride,
+                                          int row_stride, int channels, int rgb_order,
+                                          int match_prev, int window, float nnratio, int check_ori);
 orbhip_status orbhip_sync(orbhip_ctx* ctx);
 /* copy results of the last orbhip_extract_device call to the host (synchronises) */
 orbhip_status orbhip_fetch(orbhip_ctx* ctx, int nimg, orbhip_keypoint* kps, uint8_t* desc, int cap, int* n_out);

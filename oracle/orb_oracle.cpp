@@ -921,6 +921,24 @@ void orb_oracle_resize(const uint8_t* src, int sw, int sh, int sstride, uint8_t*
 { Image o; resize_linear_8u(View{src, sw, sh, sstride}, o, dw, dh); memcpy(dst, o.d.data(), o.d.size()); }
 void orb_oracle_blur(const uint8_t* src, int w, int ht, int stride, uint8_t* dst, int round_mode)
 { Image o; gaussian_blur_7x7(View{src, w, ht, stride}, o, round_mode); memcpy(dst, o.d.data(), o.d.size()); }
+// cv::cvtColor(src, dst, CV_RGB2GRAY | CV_BGR2GRAY | CV_RGBA2GRAY | CV_BGRA2GRAY) on 8U as Tracking.cc:172-198,
+// 217-229, 248-260 call it: OpenCV 3.2 imgproc/src/color.cpp RGB2Gray<uchar> — three 256-entry tables built by
+// repeated addition from b = 0, g = 0, r = 1 << (yuv_shift-1) with R2Y = 4899, G2Y = 9617, B2Y = 1868, yuv_shift = 14,
+// summed and shifted; alpha is skipped.  (PARITY UNPINNED at the OpenCV boundary like the other primitives.)
+void orb_oracle_cvt_gray(const uint8_t* src, int w, int ht, int sstride, int channels, int rgb_order, uint8_t* dst, int dstride)
+{
+    int tab[768];
+    const int cr = 4899, cg = 9617, cb = 1868, shift = 14;
+    const int c0 = rgb_order ? cr : cb, c2 = rgb_order ? cb : cr;      // weight of channel 0 / channel 2
+    int a0 = 0, a1 = 0, a2 = 0;
+    int* half_into = rgb_order ? &a0 : &a2;                             // the rounding half rides on the R table
+    *half_into = 1 << (shift - 1);
+    for (int i = 0; i < 256; i++, a0 += c0, a1 += cg, a2 += c2) { tab[i] = a0; tab[256 + i] = a1; tab[512 + i] = a2; }
+    for (int y = 0; y < ht; y++) {
+        const uint8_t* s = src + (size_t)y * sstride; uint8_t* d = dst + (size_t)y * dstride;
+        for (int x = 0; x < w; x++, s += channels) d[x] = (uint8_t)((tab[s[0]] + tab[256 + s[1]] + tab[512 + s[2]]) >> shift);
+    }
+}
 void orb_oracle_gauss_kernel(int* k7) { gaussian_kernel_7_sigma2_fixed(k7); }
 int orb_oracle_fast(const uint8_t* img, int w, int ht, int stride, int threshold, int nms, int* xys, int cap)
 {

@@ -51,6 +51,7 @@ def lib(fast=False):
     L.orb_oracle_get_level_keypoints.argtypes = [vp, C.c_int, vp, C.c_int]
     L.orb_oracle_resize.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int]
     L.orb_oracle_blur.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+    L.orb_oracle_cvt_gray.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
     L.orb_oracle_gauss_kernel.argtypes = [vp]
     L.orb_oracle_fast.restype = C.c_int
     L.orb_oracle_fast.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
@@ -190,6 +191,15 @@ def resize(src, dw, dh):
 def blur(src, round_mode=0):
     out = np.zeros(src.shape, np.uint8)
     lib().orb_oracle_blur(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(out), round_mode)
+    return out
+
+
+def cvt_gray(src, rgb=True):
+    """cv::cvtColor(src, RGB2GRAY/BGR2GRAY/RGBA2GRAY/BGRA2GRAY) for [H,W,3|4] uint8 (Tracking.cc:172-198)."""
+    src = np.ascontiguousarray(src, np.uint8)
+    h, w, ch = src.shape
+    out = np.zeros((h, w), np.uint8)
+    lib().orb_oracle_cvt_gray(_p(src), w, h, src.strides[0], ch, int(rgb), _p(out), w)
     return out
 
 

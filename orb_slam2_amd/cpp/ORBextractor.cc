@@ -63,6 +63,28 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
         fprintf(stderr, "ORBextractor: %s\n", orbhip_last_error());
         abort();
     }
+    Deliver(n, desc, _keypoints, _descriptors);
+}
+
+void ORBextractor::ExtractColor(const unsigned char* data, int step, int cols, int rows, int channels, bool bRGB,
+                                std::vector<cv::KeyPoint>& _keypoints, cv::OutputArray _descriptors)
+{
+    if (!data || cols <= 0 || rows <= 0) return;
+    EnsureContext(cols, rows);
+    const int cap = orbhip_keypoint_capacity(mpCtx);
+    _keypoints.resize(cap);
+    std::vector<unsigned char> desc((size_t)cap * 32);
+    int n = 0;
+    const uint8_t* imgs[1] = {data};
+    if (orbhip_extract_batch_color(mpCtx, 1, imgs, step, channels, bRGB ? 1 : 0, reinterpret_cast<orbhip_keypoint*>(&_keypoints[0]), &desc[0], cap, &n) != ORBHIP_OK) {
+        fprintf(stderr, "ORBextractor: %s\n", orbhip_last_error());
+        abort();
+    }
+    Deliver(n, desc, _keypoints, _descriptors);
+}
+
+void ORBextractor::Deliver(int n, const std::vector<unsigned char>& desc, std::vector<cv::KeyPoint>& _keypoints, cv::OutputArray _descriptors)
+{
     _keypoints.resize(n);
     if (n == 0) _descriptors.release();                          // ORBextractor.cc:1064-1065
     else {

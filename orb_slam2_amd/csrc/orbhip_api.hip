@@ -53,7 +53,7 @@ struct orbhip_ctx {
     hipStream_t mstream = nullptr; hipEvent_t ev_extract = nullptr; hipEvent_t ev_match[3] = {nullptr, nullptr, nullptr}; bool match_pending[3] = {false, false, false};
     int cur = 0; int last_nimg = 0; bool last_matched = false; bool last_from_host = false;
     // host-buffer API staging: one contiguous device input buffer + pinned host mirrors (single bulk copies instead of per-frame pageable copies)
-    uint8_t* d_in = nullptr; uint8_t* h_in = nullptr; orbhip_keypoint* h_kp = nullptr; uint8_t* h_desc = nullptr; int* h_n = nullptr; int in_pitch = 0;
+    uint8_t* d_in = nullptr; uint8_t* h_in = nullptr; uint8_t* d_col = nullptr; uint8_t* h_col = nullptr; size_t col_bytes = 0; orbhip_keypoint* h_kp = nullptr; uint8_t* h_desc = nullptr; int* h_n = nullptr; int in_pitch = 0;
     // stereo (Frame::ComputeStereoMatches): level-0 source of the last call + lazily allocated workspace on the LEFT context
     const uint8_t* last_img0 = nullptr; long long last_img0_fstride = 0; int last_img0_pitch = 0;
     int* d_st_rowstart = nullptr; int* d_st_rowitems = nullptr; int st_rowcap = 0; float* d_st_u = nullptr; float* d_st_depth = nullptr; int* d_st_sad = nullptr;
@@ -151,6 +151,8 @@ extern "C" void orbhip_destroy(orbhip_ctx* c)
     { void* st[] = {c->d_st_rowstart, c->d_st_rowitems, c->d_st_u, c->d_st_depth, c->d_st_sad}; for (void* q : st) if (q) (void)hipFree(q); }
     if (c->d_in) (void)hipFree(c->d_in);
     if (c->h_in) (void)hipHostFree(c->h_in);
+    if (c->d_col) (void)hipFree(c->d_col);
+    if (c->h_col) (void)hipHostFree(c->h_col);
     if (c->h_kp) (void)hipHostFree(c->h_kp);
     if (c->h_desc) (void)hipHostFree(c->h_desc);
     if (c->h_n) (void)hipHostFree(c->h_n);
@@ -497,6 +499,55 @@ extern "C" orbhip_status orbhip_extract_batch(orbhip_ctx* c, int nimg, const uin
     //  launches on ROCm 7.2 — see DESIGN.md §5)
     HIPCHK(hipMemcpyAsync(c->d_in, c->h_in, nimg * fbytes, hipMemcpyHostToDevice, c->stream));
     st = run_pipeline(c, nimg, c->d_in, (long long)fbytes, c->in_pitch, 0, 0, 0.f, 0);
+    if (st != ORBHIP_OK) return st;
+    return orbhip_fetch(c, nimg, kps, desc, cap, n_out);
+}
+
+// Colour input (Tracking.cc:172-198, 217-229, 248-260 convert with cv::cvtColor before building the Frame): the
+// conversion runs on the device into the context's level-0 plane, so the gray image never exists on the host.
+static orbhip_status check_color_args(orbhip_ctx* c, int nimg, int row_stride, int channels)
+{
+    if (nimg < 1 || nimg > c->B) return fail(ORBHIP_ERR_INVALID, "nimg %d outside 1..%d", nimg, c->B);
+    if (channels != 3 && channels != 4) return fail(ORBHIP_ERR_INVALID, "channels %d (3 or 4 expected; 1-channel frames go through orbhip_extract*)", channels);
+    if (row_stride < c->cfg.width * channels) return fail(ORBHIP_ERR_INVALID, "row stride %d < width*channels %d", row_stride, c->cfg.width * channels);
+    return ORBHIP_OK;
+}
+extern "C" orbhip_status orbhip_extract_device_color(orbhip_ctx* c, int nimg, const uint8_t* d_imgs, size_t frame_stride, int row_stride,
+                                                     int channels, int rgb_order, int match_prev, int window, float nnratio, int check_ori)
+{
+    if (!c || !d_imgs) return fail(ORBHIP_ERR_INVALID, "null argument");
+    orbhip_status st = check_color_args(c, nimg, row_stride, channels); if (st != ORBHIP_OK) return st;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    st = ensure_host_staging(c, true); if (st != ORBHIP_OK) return st;
+    const size_t fbytes = (size_t)c->in_pitch * c->cfg.height;
+    orbhip_launch_to_gray(d_imgs, (long long)frame_stride, row_stride, c->d_in, (long long)fbytes, c->in_pitch, c->cfg.width, c->cfg.height,
+                          channels, rgb_order != 0, nimg, c->stream);
+    HIPCHK(hipGetLastError());
+    c->last_from_host = true;                                          // level 0 lives in the context's own plane
+    return run_pipeline(c, nimg, c->d_in, (long long)fbytes, c->in_pitch, match_prev, window, nnratio, check_ori);
+}
+extern "C" orbhip_status orbhip_extract_batch_color(orbhip_ctx* c, int nimg, const uint8_t* const* imgs, int stride, int channels, int rgb_order,
+                                                    orbhip_keypoint* kps, uint8_t* desc, int cap, int* n_out)
+{
+    if (!c || !imgs || !n_out) return fail(ORBHIP_ERR_INVALID, "null argument");
+    orbhip_status st = check_color_args(c, nimg, stride, channels); if (st != ORBHIP_OK) return st;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    st = ensure_host_staging(c, true); if (st != ORBHIP_OK) return st;
+    const size_t cpitch = ((size_t)c->cfg.width * 4 + 63) & ~(size_t)63, cfbytes = cpitch * c->cfg.height;   // room for 4 channels
+    if (!c->d_col) {
+        c->col_bytes = (size_t)c->B * cfbytes + 256;
+        HIPCHK(hipMalloc((void**)&c->d_col, c->col_bytes));
+        HIPCHK(hipHostMalloc((void**)&c->h_col, c->col_bytes, hipHostMallocDefault));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const size_t rowbytes = (size_t)c->cfg.width * channels;
+    for (int f = 0; f < nimg; f++) {
+        if (!imgs[f]) return fail(ORBHIP_ERR_INVALID, "image %d is null", f);
+        uint8_t* dst = c->h_col + f * cfbytes;
+        for (int y = 0; y < c->cfg.height; y++) memcpy(dst + (size_t)y * cpitch, imgs[f] + (size_t)y * stride, rowbytes);
+    }
+    HIPCHK(hipMemcpyAsync(c->d_col, c->h_col, nimg * cfbytes, hipMemcpyHostToDevice, c->stream));
+    st = orbhip_extract_device_color(c, nimg, c->d_col, cfbytes, (int)cpitch, channels, rgb_order, 0, 0, 0.f, 0);
     if (st != ORBHIP_OK) return st;
     return orbhip_fetch(c, nimg, kps, desc, cap, n_out);
 }

@@ -116,6 +116,8 @@ size_t orbhip_proj_select_lds(int n);
 // kernel launchers (orbhip_kernels_extract.hip / orbhip_kernels_match.hip)
 void orbhip_launch_pyramid_level(const ExtractParams& P, int level, int w, int h, bool staged, int nframes, hipStream_t s);
 bool orbhip_pyramid_tile_fits(int src_cols_per_tile, int src_rows_per_tile);
+void orbhip_launch_to_gray(const uint8_t* src, long long src_frame_stride, int src_row_stride, uint8_t* dst, long long dst_frame_stride,
+                           int dst_pitch, int w, int h, int channels, bool rgb_order, int nframes, hipStream_t s);
 int orbhip_pyramid_tile_w();
 int orbhip_pyramid_tile_h();
 void orbhip_launch_blur(const ExtractParams& P, const int gk[4], int nframes, hipStream_t s);

@@ -142,6 +142,61 @@ void orbhip_launch_pyramid_level(const ExtractParams& P, int level, int w, int h
     else hipLaunchKernelGGL(k_pyramid_level_direct, grid, block, 0, s, Q, level);
 }
 
+// ------------------------------------------------------------------------------------------------ colour -> gray
+// cv::cvtColor(RGB2GRAY / BGR2GRAY / RGBA2GRAY / BGRA2GRAY) on 8U as Tracking::GrabImage* applies it before the
+// extractor sees the frame (Tracking.cc:172-198, 217-229, 248-260): gray = (R*4899 + G*9617 + B*1868 + 8192) >> 14
+// (OpenCV 3.2 RGB2Gray<uchar>, 14-bit fixed point; alpha ignored).  One thread converts 4 pixels: 3 or 4 aligned
+// 32-bit loads, one 32-bit store; the byte path serves unaligned sources and the ragged end of a row.
+struct GrayParams {
+    const uint8_t* src; long long src_frame_stride; int src_row_stride;
+    uint8_t* dst; long long dst_frame_stride; int dst_pitch;
+    int w, h, channels, k0, k2;         // k0 weighs channel 0, k2 channel 2 (4899/1868 for RGB order, swapped for BGR)
+};
+__device__ __forceinline__ uint32_t gray14(uint32_t c0, uint32_t c1, uint32_t c2, int k0, int k2)
+{
+    return (c0 * (uint32_t)k0 + c1 * 9617u + c2 * (uint32_t)k2 + 8192u) >> 14;
+}
+__global__ __launch_bounds__(256) void k_to_gray(GrayParams G)
+{
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y, f = blockIdx.z;
+    if (x >= G.w) return;
+    const uint8_t* srow = G.src + (long long)f * G.src_frame_stride + (long long)y * G.src_row_stride + (long long)x * G.channels;
+    uint8_t* drow = G.dst + (long long)f * G.dst_frame_stride + (long long)y * G.dst_pitch + x;
+    const bool whole = x + 4 <= G.w, aligned = (((uintptr_t)srow) & 3) == 0;
+    if (whole && aligned) {
+        const uint32_t* s4 = (const uint32_t*)srow;
+        uint32_t g0, g1, g2, g3;
+        if (G.channels == 3) {
+            const uint32_t a = s4[0], b = s4[1], c = s4[2];          // bytes 0..11 = p0.c0 p0.c1 p0.c2 p1.c0 ...
+            g0 = gray14(a & 255, (a >> 8) & 255, (a >> 16) & 255, G.k0, G.k2);
+            g1 = gray14(a >> 24, b & 255, (b >> 8) & 255, G.k0, G.k2);
+            g2 = gray14((b >> 16) & 255, b >> 24, c & 255, G.k0, G.k2);
+            g3 = gray14((c >> 8) & 255, (c >> 16) & 255, c >> 24, G.k0, G.k2);
+        } else {
+            const uint32_t a = s4[0], b = s4[1], c = s4[2], d = s4[3];
+            g0 = gray14(a & 255, (a >> 8) & 255, (a >> 16) & 255, G.k0, G.k2);
+            g1 = gray14(b & 255, (b >> 8) & 255, (b >> 16) & 255, G.k0, G.k2);
+            g2 = gray14(c & 255, (c >> 8) & 255, (c >> 16) & 255, G.k0, G.k2);
+            g3 = gray14(d & 255, (d >> 8) & 255, (d >> 16) & 255, G.k0, G.k2);
+        }
+        *(uint32_t*)drow = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+    } else {
+        const int n = min(4, G.w - x);
+        for (int i = 0; i < n; i++) {
+            const uint8_t* p = srow + i * G.channels;
+            drow[i] = (uint8_t)gray14(p[0], p[1], p[2], G.k0, G.k2);
+        }
+    }
+}
+void orbhip_launch_to_gray(const uint8_t* src, long long src_frame_stride, int src_row_stride, uint8_t* dst, long long dst_frame_stride,
+                           int dst_pitch, int w, int h, int channels, bool rgb_order, int nframes, hipStream_t s)
+{
+    GrayParams G{src, src_frame_stride, src_row_stride, dst, dst_frame_stride, dst_pitch, w, h, channels,
+                 rgb_order ? 4899 : 1868, rgb_order ? 1868 : 4899};
+    dim3 grid((w + 1023) / 1024, h, nframes), block(256, 1, 1);
+    hipLaunchKernelGGL(k_to_gray, grid, block, 0, s, G);
+}
+
 // ------------------------------------------------------------------------------------------------ blur
 // cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) on 8U: int kernel {k3,k2,k1,k0,k1,k2,k3} = {18,34,49,55,49,34,18}
 // (computed on the host from getGaussianKernel + cvRound(k*256)), int32 row pass, column pass rounded with 16 bits.

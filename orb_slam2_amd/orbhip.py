@@ -26,7 +26,8 @@ SYMBOLS = [
     "orbhip_hamming_nn", "orbhip_hamming_nn_device", "orbhip_search_for_initialization", "orbhip_profile_enable",
     "orbhip_profile_num_kernels", "orbhip_profile_get", "orbhip_profile_reset", "orbhip_algorithmic_bytes_per_frame",
     "orbhip_algorithmic_bytes_per_frame_kernel", "orbhip_debug_blurred_level", "orbhip_debug_candidates",
-    "orbhip_compute_stereo_matches", "orbhip_search_by_projection",
+    "orbhip_compute_stereo_matches", "orbhip_search_by_projection", "orbhip_extract_batch_color",
+    "orbhip_extract_device_color",
 ]
 
 
@@ -69,6 +70,8 @@ def lib(path=None):
     L.orbhip_extract_batch.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp]
     L.orbhip_pyramid_level.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
     L.orbhip_extract_device.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]
+    L.orbhip_extract_batch_color.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp]
+    L.orbhip_extract_device_color.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]
     L.orbhip_sync.argtypes = [vp]
     L.orbhip_fetch.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp]
     L.orbhip_fetch_matches.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
@@ -187,6 +190,24 @@ class ORBextractor:
         _check(self.L.orbhip_extract_batch(self.h, n, ptrs, self.width, _p(kps), _p(desc), cap, _p(nout)), "orbhip_extract_batch")
         return [kps[f, :nout[f]].copy() for f in range(n)], [desc[f, :nout[f]].copy() for f in range(n)]
 
+    def extract_batch_color(self, images, rgb=True):
+        """Interleaved 8-bit colour frames [H,W,3|4]; `rgb` is the reference's mbRGB (Tracking.cc:82): True = R first,
+        False = B first.  The cvtColor of Tracking::GrabImage* (Tracking.cc:172-198) runs on the device."""
+        n = len(images)
+        assert 1 <= n <= self.max_batch
+        imgs = [np.ascontiguousarray(im, np.uint8) for im in images]
+        ch = imgs[0].shape[2]
+        for im in imgs:
+            assert im.shape == (self.height, self.width, ch), (im.shape, (self.height, self.width, ch))
+        ptrs = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
+        cap = self.capacity
+        kps = np.zeros((n, cap), KEYPOINT_DTYPE)
+        desc = np.zeros((n, cap, 32), np.uint8)
+        nout = np.zeros(n, np.int32)
+        _check(self.L.orbhip_extract_batch_color(self.h, n, ptrs, self.width * ch, ch, int(rgb), _p(kps), _p(desc), cap, _p(nout)),
+               "orbhip_extract_batch_color")
+        return [kps[f, :nout[f]].copy() for f in range(n)], [desc[f, :nout[f]].copy() for f in range(n)]
+
     def mvImagePyramid(self, level, frame=0):
         w, h = self.level_size(level)
         out = np.zeros((h, w), np.uint8)
@@ -197,6 +218,11 @@ class ORBextractor:
     def extract_device(self, dptr, nimg, frame_stride, row_stride, match_prev=False, window=100, nnratio=0.9, check_ori=True):
         _check(self.L.orbhip_extract_device(self.h, nimg, C.c_void_p(dptr), frame_stride, row_stride, int(match_prev), window,
                                             nnratio, int(check_ori)), "orbhip_extract_device")
+
+    def extract_device_color(self, dptr, nimg, frame_stride, row_stride, channels, rgb=True, match_prev=False, window=100,
+                             nnratio=0.9, check_ori=True):
+        _check(self.L.orbhip_extract_device_color(self.h, nimg, C.c_void_p(dptr), frame_stride, row_stride, channels, int(rgb),
+                                                  int(match_prev), window, nnratio, int(check_ori)), "orbhip_extract_device_color")
 
     def sync(self):
         _check(self.L.orbhip_sync(self.h), "orbhip_sync")

@@ -45,6 +45,14 @@ int main(int argc, char** argv)
     exL->ComputeStereoMatches(*exR, 386.1448f, 386.1448f / 718.856f, FL.N, uRight, depth);
     int ns = (int)uRight.size(); fwrite(&ns, 4, 1, f);
     if (ns) { fwrite(&uRight[0], 4, ns, f); fwrite(&depth[0], 4, ns, f); }
+    // colour: BGR frame with channels (im[0], im[1], im[0]) like a Camera.RGB: 0 sequence entering Tracking::GrabImageMonocular
+    std::vector<unsigned char> bgr((size_t)W * H * 3);
+    for (size_t i = 0; i < (size_t)W * H; i++) { bgr[3 * i] = im[0].data[i]; bgr[3 * i + 1] = im[1].data[i]; bgr[3 * i + 2] = im[0].data[i]; }
+    std::vector<cv::KeyPoint> kc; cv::Mat dc;
+    ex->ExtractColor(&bgr[0], 3 * W, W, H, 3, false, kc, dc);
+    int nc = (int)kc.size(); fwrite(&nc, 4, 1, f);
+    if (nc) { fwrite(&kc[0], sizeof(cv::KeyPoint), nc, f); for (int i = 0; i < nc; i++) fwrite(dc.ptr(i), 1, 32, f); }
+    fwrite(ex->mvImagePyramid[0].data, 1, (size_t)W * H, f);
     fclose(f);
     delete ex; delete exL; delete exR;
     return 0;

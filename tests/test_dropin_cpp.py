@@ -42,7 +42,11 @@ def _run(exe, tmp_path, oracle):
     (dd,) = struct.unpack_from("<i", buf, off); off += 4
     (ns,) = struct.unpack_from("<i", buf, off); off += 4
     u_right = np.frombuffer(buf, np.float32, ns, off); off += 4 * ns
-    depth = np.frombuffer(buf, np.float32, ns, off)
+    depth = np.frombuffer(buf, np.float32, ns, off); off += 4 * ns
+    (nc,) = struct.unpack_from("<i", buf, off); off += 4
+    kc = np.frombuffer(buf, orb_slam2_amd.KEYPOINT_DTYPE, nc, off); off += 28 * nc
+    dc = np.frombuffer(buf, np.uint8, 32 * nc, off).reshape(nc, 32); off += 32 * nc
+    gray0 = np.frombuffer(buf, np.uint8, w * h, off).reshape(h, w)
 
     ora = oracle.OracleExtractor(n, 1.2, 8, 20, 7)
     ref = [ora.extract(im) for im in seq]
@@ -58,6 +62,9 @@ def _run(exe, tmp_path, oracle):
     eR.extract(seq[1])
     uo, do = oracle.stereo_matches(eL, eR, np.float32(386.1448), np.float32(386.1448) / np.float32(718.856))
     assert ns == len(uo) and u_right.tobytes() == uo.tobytes() and depth.tobytes() == do.tobytes()
+    gray = oracle.cvt_gray(np.stack([seq[0], seq[1], seq[0]], axis=-1), rgb=False)
+    kco, dco = oracle.OracleExtractor(n, 1.2, 8, 20, 7).extract(gray)
+    assert np.array_equal(gray0, gray) and kc.tobytes() == kco.tobytes() and np.array_equal(dc, dco)
 
 
 def _build(target):

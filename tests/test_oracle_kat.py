@@ -89,6 +89,21 @@ def test_resize_fixed_point(oracle):
     assert out.shape == (10, 50)
 
 
+def test_cvt_gray_fixed_point(oracle):
+    """cvtColor(*2GRAY) of Tracking.cc:172-198: 14-bit fixed point, coefficients 4899/9617/1868, alpha skipped."""
+    rng = np.random.default_rng(5)
+    for ch in (3, 4):
+        src = rng.integers(0, 256, (37, 53, ch), dtype=np.uint8)
+        s = src.astype(np.int64)
+        for rgb in (True, False):
+            r, b = (s[..., 0], s[..., 2]) if rgb else (s[..., 2], s[..., 0])
+            want = ((r * 4899 + s[..., 1] * 9617 + b * 1868 + 8192) >> 14).astype(np.uint8)
+            assert np.array_equal(oracle.cvt_gray(src, rgb=rgb), want)
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [0, 0, 0], [128, 128, 128]]], np.uint8)
+    assert oracle.cvt_gray(px, rgb=True).tolist() == [[76, 150, 29, 255, 0, 128]]
+    assert oracle.cvt_gray(px, rgb=False).tolist() == [[29, 150, 76, 255, 0, 128]]
+
+
 def test_fast_known_corner(oracle):
     # isolated bright pixel: all 16 ring pixels are darker by exactly 100 -> corner with score 100 - 1, no other corner
     img = np.full((21, 23), 100, np.uint8)

@@ -135,6 +135,28 @@ def test_tiny_images_single_cell_levels(backend, oracle, w, h, levels):
         ex.close()
 
 
+@pytest.mark.parametrize("channels,rgb,w,h", [(3, True, 321, 243), (3, False, 320, 240), (4, True, 402, 250), (4, False, 319, 241)])
+def test_colour_input_converted_on_device(backend, oracle, channels, rgb, w, h):
+    """Tracking::GrabImage* (Tracking.cc:172-198) converts colour frames with cvtColor before the extractor; the colour entry
+    points do that on the device.  Widths not divisible by 4 exercise the ragged row end, 3-channel odd widths the unaligned rows."""
+    n = 400
+    planes = [synth.frame(w, h, seed=40 + c) for c in range(channels)]
+    col = np.stack(planes, axis=-1)
+    gray = oracle.cvt_gray(col, rgb=rgb)
+    ora = oracle.OracleExtractor(n, 1.2, 8, 20, 7)
+    ex = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, max_batch=2, library=backend)
+    ks, ds = ex.extract_batch_color([col, col[::-1].copy()], rgb=rgb)
+    assert np.array_equal(ex.mvImagePyramid(0, frame=0), gray)
+    assert np.array_equal(ex.mvImagePyramid(0, frame=1), gray[::-1])
+    ko, do = ora.extract(gray)
+    _same(ks[0], ds[0], ko, do)
+    ko, do = ora.extract(np.ascontiguousarray(gray[::-1]))
+    _same(ks[1], ds[1], ko, do)
+    with pytest.raises(orb_slam2_amd.OrbHipError):
+        ex.extract_batch_color([col[..., :2].copy()], rgb=rgb)
+    ex.close()
+
+
 def test_unsupported_and_invalid_configs(backend):
     with pytest.raises(orb_slam2_amd.OrbHipError):
         orb_slam2_amd.ORBextractor(500, 1.2, 8, 20, 7, 200, 120, library=backend)     # top level < 62 px: the reference itself divides by zero

@@ -188,6 +188,41 @@ def test_device_pipeline_unaligned_input(backend, oracle):
     ex.close()
 
 
+def test_device_pipeline_colour_unaligned_with_matching(backend, oracle):
+    """orbhip_extract_device_color on BGR frames resident in device memory at an odd base address and odd row pitch (byte path of
+    the conversion), two time steps with frame-to-frame matching: equals cvtColor + extract + SearchForInitialization."""
+    w, h, n = 322, 246, 300
+    seq = [np.stack([synth.sequence(w, h, 2, seed=31 + c)[t] for c in range(3)], axis=-1) for t in range(2)]
+    ora = oracle.OracleExtractor(n, 1.2, 8, 20, 7)
+    K = [ora.extract(oracle.cvt_gray(col, rgb=False)) for col in seq]
+    ex = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, max_batch=1, library=backend)
+    pitch = 3 * w + 5
+    is_gpu = not backend.endswith("_emu.so")
+    if is_gpu:
+        import ctypes as C
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        dptr = C.c_void_p()
+        assert hip.hipMalloc(C.byref(dptr), 1 + h * pitch + 64) == 0
+    for t in range(2):
+        host = np.zeros(1 + h * pitch + 64, np.uint8)
+        host[1:1 + h * pitch].reshape(h, pitch)[:, :3 * w] = seq[t].reshape(h, 3 * w)
+        if is_gpu:
+            ex.sync()
+            assert hip.hipMemcpy(dptr, host.ctypes.data_as(C.c_void_p), host.nbytes, 1) == 0
+            ptr = dptr.value + 1
+        else:
+            ptr = host.ctypes.data + 1
+        ex.extract_device_color(ptr, 1, h * pitch, pitch, 3, rgb=False, match_prev=(t > 0), window=100, nnratio=0.9, check_ori=True)
+        ks, ds = ex.fetch(1)
+        assert ks[0].tobytes() == K[t][0].tobytes() and np.array_equal(ds[0], K[t][1])
+    m12, nm = ex.fetch_matches(1)
+    n_o, m_o, _ = oracle.search_for_initialization(K[0][0], K[0][1], K[1][0], K[1][1], w, h, window=100, nnratio=0.9)
+    assert nm[0] == n_o and np.array_equal(m12[0], m_o)
+    ex.close()
+
+
 def test_golden_match_fixture(backend):
     g = np.load(os.path.join(GOLDEN, "match_320x240_n300_seed21.npz"))
     m = orb_slam2_amd.ORBmatcher(0.9, True, library=backend)
