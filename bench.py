@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--tsteps", type=int, default=4, help="distinct resident time steps cycled through")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the library splits each batch over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extract-only", action="store_true", help="diagnostic: skip the matcher (NOT the metric's workload; the JSON line says so)")
     args = ap.parse_args()
 
     import torch
@@ -125,7 +126,7 @@ def main():
     base = d_frames.data_ptr()
 
     def step(i):
-        ex.extract_device(base + (i % T) * step_stride, B, frame_stride, pitch, match_prev=True, window=WINDOW, nnratio=NNRATIO, check_ori=True)
+        ex.extract_device(base + (i % T) * step_stride, B, frame_stride, pitch, match_prev=not args.extract_only, window=WINDOW, nnratio=NNRATIO, check_ori=True)
 
     def barrier():
         torch.cuda.synchronize()
@@ -153,7 +154,7 @@ def main():
 
     # sanity of the timed work (not timed): every slot produced keypoints and matches
     kps, _ = ex.fetch(B)
-    _, nm = ex.fetch_matches(B)
+    nm = np.zeros(B, np.int32) if args.extract_only else ex.fetch_matches(B)[1]
     nkp = [len(k) for k in kps]
 
     if rank == 0:
@@ -183,7 +184,7 @@ def main():
         dur_s = kern[dom]["ms_per_launch"] * 1e-3
         achieved = (alg * B / dur_s) / 1e9 if dur_s > 0 else 0.0
         out = {
-            "metric": "frames/s ORB extract+match, 1241x376 gray, 2000 kpts, 8 lvls",
+            "metric": "frames/s ORB extract+match, 1241x376 gray, 2000 kpts, 8 lvls" if not args.extract_only else "DIAGNOSTIC extract only (not the metric)",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",

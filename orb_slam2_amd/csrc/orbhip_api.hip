@@ -53,6 +53,7 @@ struct orbhip_ctx {
     hipStream_t mstream = nullptr; hipEvent_t ev_extract = nullptr; hipEvent_t ev_match[3] = {nullptr, nullptr, nullptr}; bool match_pending[3] = {false, false, false};
     int cur = 0; int last_nimg = 0; bool last_matched = false; bool last_from_host = false;
     // host-buffer API staging: one contiguous device input buffer + pinned host mirrors (single bulk copies instead of per-frame pageable copies)
+    bool serial = false;      // ORBHIP_SERIAL=1 (measurement only): every kernel on the main stream, no overlap
     uint8_t* d_in = nullptr; uint8_t* h_in = nullptr; uint8_t* d_col = nullptr; uint8_t* h_col = nullptr; size_t col_bytes = 0; orbhip_keypoint* h_kp = nullptr; uint8_t* h_desc = nullptr; int* h_n = nullptr; int in_pitch = 0;
     // stereo (Frame::ComputeStereoMatches): level-0 source of the last call + lazily allocated workspace on the LEFT context
     const uint8_t* last_img0 = nullptr; long long last_img0_fstride = 0; int last_img0_pitch = 0;
@@ -253,7 +254,7 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
     c->lvl_kp_per_frame = kp_off; c->out_cap = kp_off; c->lvl0_cap = c->geom[0].kp_cap;
     if (cand_off >= (1 << 24)) { delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "too many candidate slots"); }
     if (orbhip_quadtree_lds_bytes(c->qt_maxn, c->qt_maxcells) > 150 * 1024) { delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "nfeatures too large for the LDS quadtree (%d nodes)", c->qt_maxn); }
-    if ((size_t)(3 * c->out_cap + 5 * c->lvl0_cap + 64 + 20480) * sizeof(int) > 158 * 1024) { delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "nfeatures too large for the LDS matcher"); }
+    if ((size_t)(3 * c->out_cap + 4 * c->lvl0_cap + 64) * sizeof(int) > 158 * 1024) { delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "nfeatures too large for the LDS matcher"); }
 
     // ---- device
     if (cfg->stream) c->stream = (hipStream_t)cfg->stream;
@@ -264,6 +265,7 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
         c->xstreams.push_back(xs); c->xevents.push_back(xe);
     }
     if (!c->xstreams.empty() && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { orbhip_destroy(c); return fail(ORBHIP_ERR_HIP, "event creation failed"); }
+    { const char* e = getenv("ORBHIP_SERIAL"); c->serial = e && e[0] == '1'; }
     {   // the matcher runs on its own stream so that it overlaps the next batch's extraction
         bool ok = hipStreamCreateWithFlags(&c->mstream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&c->ev_extract, hipEventDisableTiming) == hipSuccess &&
                   hipStreamCreateWithFlags(&c->bstream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&c->ev_pyr, hipEventDisableTiming) == hipSuccess &&
@@ -355,10 +357,11 @@ static orbhip_status run_pipeline(orbhip_ctx* c, int nimg, const uint8_t* d_img0
             // the blur only meets the detector again in k_describe: it runs on its own stream beside the quadtree, whose
             // workgroups are latency-bound (barriers, one per (frame, level)) and leave the VALUs idle
             { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nf, s); }
-            HIPCHK(hipEventRecord(c->ev_pyr, s)); HIPCHK(hipStreamWaitEvent(c->bstream, c->ev_pyr, 0));
+            hipStream_t bs = c->serial ? s : c->bstream;
+            HIPCHK(hipEventRecord(c->ev_pyr, s)); HIPCHK(hipStreamWaitEvent(bs, c->ev_pyr, 0));
             { ProfScope ps(c, K_QUADTREE, s); orbhip_launch_quadtree(P, nf, s); }       // enqueued first: its few, long workgroups get CUs before the blur floods them
-            { ProfScope ps(c, K_BLUR, c->bstream); orbhip_launch_blur(P, c->gk, nf, c->bstream); }
-            HIPCHK(hipEventRecord(c->ev_blur, c->bstream));
+            { ProfScope ps(c, K_BLUR, bs); orbhip_launch_blur(P, c->gk, nf, bs); }
+            HIPCHK(hipEventRecord(c->ev_blur, bs));
             HIPCHK(hipStreamWaitEvent(s, c->ev_blur, 0));
         } else {
             { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nf, s); }
@@ -377,12 +380,13 @@ static orbhip_status run_pipeline(orbhip_ctx* c, int nimg, const uint8_t* d_img0
         M.grid_start = c->d_grid_start; M.grid_items = c->d_grid_items; M.grid_xy = c->d_grid_xy; M.cand = c->d_cand; M.ncand = c->d_ncand; M.cand_stride = c->lvl0_cap; M.lvl0_cap = c->lvl0_cap;
         M.prev = c->d_prev; M.matches12 = c->d_m12; M.nmatches = c->d_nm; M.window = window; M.nnratio = nnratio; M.check_ori = check_ori; M.slot0 = 0;
         // matcher of this batch on its own stream: latency-bound (one wave per slot), overlaps the next call's extraction
+        hipStream_t ms = c->serial ? c->stream : c->mstream;
         HIPCHK(hipEventRecord(c->ev_extract, c->stream));
-        HIPCHK(hipStreamWaitEvent(c->mstream, c->ev_extract, 0));
-        { ProfScope ps(c, K_MGRID, c->mstream); orbhip_launch_match_grid(M, nimg, c->mstream); }
-        { ProfScope ps(c, K_MCAND, c->mstream); orbhip_launch_match_candidates(M, nimg, c->mstream); }
-        { ProfScope ps(c, K_MSELECT, c->mstream); orbhip_launch_match_select(M, nimg, c->mstream); }
-        HIPCHK(hipEventRecord(c->ev_match[cur], c->mstream));
+        HIPCHK(hipStreamWaitEvent(ms, c->ev_extract, 0));
+        { ProfScope ps(c, K_MGRID, ms); orbhip_launch_match_grid(M, nimg, ms); }
+        { ProfScope ps(c, K_MCAND, ms); orbhip_launch_match_candidates(M, nimg, ms); }
+        { ProfScope ps(c, K_MSELECT, ms); orbhip_launch_match_select(M, nimg, ms); }
+        HIPCHK(hipEventRecord(c->ev_match[cur], ms));
         c->match_pending[cur] = true;
     }
     c->last_matched = match_prev != 0;

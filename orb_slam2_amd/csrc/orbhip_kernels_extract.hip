@@ -13,6 +13,7 @@
 // rounded IEEE ops (__fmul_rn ...; file built with -ffp-contract=off) so results are bit-identical to the CPU
 // oracle's two-rounding form.  No MFMA: nothing here is GEMM-shaped.
 #include "orbhip_internal.h"
+#include <type_traits>
 
 #define WAVE 64
 
@@ -53,7 +54,7 @@ __device__ __forceinline__ void pyr_rows(const LevelGeom& g, const int2* xt, con
         const int y = ytop + rr;
         if (y >= g.h) break;
         const int2 ye = yt[y];
-        const int b0 = ye.y & 0xffff, b1 = (ye.y >> 16) & 0xffff;
+        const unsigned b0s = (unsigned)ye.y << 16, b1s = (unsigned)ye.y & 0xffff0000u;    // coefficients << 16: (b * t) >> 16 == mul_hi(b << 16, t)
         const int ya = min(max(ye.x, 0), g.src_h - 1), yb = min(max(ye.x + 1, 0), g.src_h - 1);
         const uint8_t* r0 = rows + (long long)(ya - row0) * rpitch;
         const uint8_t* r1 = rows + (long long)(yb - row0) * rpitch;
@@ -61,7 +62,7 @@ __device__ __forceinline__ void pyr_rows(const LevelGeom& g, const int2* xt, con
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int h0 = r0[sx[k]] * a0[k] + r0[sx1[k]] * a1[k], h1 = r1[sx[k]] * a0[k] + r1[sx1[k]] * a1[k];
-            const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            const int v = (int)(__umulhi(b0s, (unsigned)h0 >> 4) + __umulhi(b1s, (unsigned)h1 >> 4) + 2u) >> 2;
             if (x4 + k < g.w) out |= (unsigned)(v & 0xff) << (8 * k);
         }
         *reinterpret_cast<unsigned*>(dstp + (long long)y * g.pitch) = out;
@@ -74,7 +75,6 @@ __device__ __forceinline__ void pyr_rows(const LevelGeom& g, const int2* xt, con
 #define PYR_TH (4 * PYR_RPT)
 #define PYR_SROWS 24
 #define PYR_SDW 84                      // dwords per staged source row (>= (256*1.25+2+3)/4)
-#define PYR_LD ((PYR_SROWS * PYR_SDW + 255) / 256)   // staging dwords per thread
 __global__ __launch_bounds__(256) void k_pyramid_level(ExtractParams P, int level)
 {
     const LevelGeom g = P.geom[level];
@@ -92,20 +92,39 @@ __global__ __launch_bounds__(256) void k_pyramid_level(ExtractParams P, int leve
     const int sya = min(max(yt[y0].x, 0), g.src_h - 1), syb = min(max(yt[yl].x + 1, 0), g.src_h - 1);
     const int ndw = ((sxb - sxa) >> 2) + 1, nrows = syb - sya + 1;
     const bool aligned = ((((unsigned long long)src) | (unsigned long long)spitch) & 3ull) == 0;
-    {
-        unsigned v[PYR_LD]; bool edge[PYR_LD];
+    {   // wave w stages source rows w, w+4, ...: row address on the scalar unit, lane = dword (two chunks of 64), all loads
+        // in flight before the first LDS write; byte path only for the ragged row end / unaligned sources
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+        unsigned v[PYR_SROWS / 4][2];
+        bool edge[2];
 #pragma unroll
-        for (int k = 0; k < PYR_LD; k++) {
-            const int i = tid + 256 * k, r = i / ndw, d = i - r * ndw;
-            const bool in = i < nrows * ndw;
-            edge[k] = in && !(aligned && sxa + 4 * d + 3 < g.src_w);
-            v[k] = (in && !edge[k]) ? *reinterpret_cast<const unsigned*>(src + (long long)(sya + r) * spitch + sxa + 4 * d) : 0u;
+        for (int c = 0; c < 2; c++) { const int d = lane + 64 * c; edge[c] = d < ndw && !(aligned && sxa + 4 * d + 3 < g.src_w); }
+#pragma unroll
+        for (int j = 0; j < PYR_SROWS / 4; j++) {
+            const uint8_t* row = src + (long long)(sya + min(wave + 4 * j, nrows - 1)) * spitch + sxa;     // wave-uniform -> SGPR base
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const int d = lane + 64 * c;
+                v[j][c] = (d < ndw && !edge[c]) ? *reinterpret_cast<const unsigned*>(row + (unsigned)(4 * d)) : 0u;
+            }
         }
 #pragma unroll
-        for (int k = 0; k < PYR_LD; k++) {
-            const int i = tid + 256 * k, r = i / ndw, d = i - r * ndw;
-            if (edge[k]) { const uint8_t* row = src + (long long)(sya + r) * spitch + sxa + 4 * d; for (int q = 0; q < 4; q++) if (sxa + 4 * d + q < g.src_w) v[k] |= (unsigned)row[q] << (8 * q); }
-            if (i < nrows * ndw) s_t[r * PYR_SDW + d] = v[k];
+        for (int c = 0; c < 2; c++)
+            if (edge[c]) {
+                const int d = lane + 64 * c;
+#pragma unroll
+                for (int j = 0; j < PYR_SROWS / 4; j++) {
+                    const uint8_t* row = src + (long long)(sya + min(wave + 4 * j, nrows - 1)) * spitch + sxa + 4 * d;
+                    unsigned w = 0;
+                    for (int q = 0; q < 4; q++) if (sxa + 4 * d + q < g.src_w) w |= (unsigned)row[q] << (8 * q);
+                    v[j][c] = w;
+                }
+            }
+#pragma unroll
+        for (int j = 0; j < PYR_SROWS / 4; j++) {
+            const int r = wave + 4 * j;
+#pragma unroll
+            for (int c = 0; c < 2; c++) { const int d = lane + 64 * c; if (r < nrows && d < ndw) s_t[r * PYR_SDW + d] = v[j][c]; }
         }
     }
     __syncthreads();
@@ -208,10 +227,18 @@ __device__ __forceinline__ int reflect101_clamped(int p, int len)
     if (p < 0) p = -p; else if (p >= len) p = 2 * (len - 1) - p;
     return min(max(p, 0), len - 1);      // second clamp only touches halo positions no output reads
 }
-struct BlurK { int k0, k1, k2, k3; };
-// 128x32 outputs per workgroup.  Stage (32+6) x (128+8) source bytes with 32-bit loads (byte-wise reflect only at the
-// image border), horizontal pass -> packed u16 sums in LDS, vertical pass: one 4-pixel x 4-row strip per thread,
-// 4 coalesced 32-bit stores.
+struct BlurK { float k0, k1, k2, k3; unsigned dot_lo, dot_hi; };
+#define BLUR_SDW (BLUR_SROW / 4)       // 36 dwords per staged source row, 34 used
+#define BLUR_SROWS (BLUR_TH + 6)
+// 128x32 outputs per workgroup, 3 phases:
+//  1. stage (32+6) x (128+8) source bytes: wave w owns rows w, w+4, ... (row address on the scalar unit, lane = dword),
+//     ten 32-bit loads in flight per lane; byte-wise reflect only for lanes on the image border / unaligned sources;
+//  2. horizontal pass, 4 pixels per thread-iteration: two v_dot4_u32_u8 per pixel on byte-aligned windows, result
+//     (<= 255*257) converted to fp32 and kept in LDS as float4;
+//  3. vertical pass, a 4-pixel x 4-row strip per thread in fp32 (add/mul/fma issue at twice the integer rate on this
+//     part and every partial sum below 2^24 is exact; a final sum >= 2^24 means >= 256 and saturates either way),
+//     rounding = floor(s/65536 + 0.5) (generic OpenCV) or round-half-even (x86 SSE2 build) folded into the
+//     saturating round-to-nearest-even of v_cvt_pk_u8_f32; four coalesced 32-bit stores.
 __global__ __launch_bounds__(256) void k_blur(ExtractParams P, BlurK K)
 {
     int tile, frame;
@@ -221,77 +248,82 @@ __global__ __launch_bounds__(256) void k_blur(ExtractParams P, BlurK K)
     const int tid = threadIdx.x;
     const LevelGeom g = P.geom[t.level];
     int spitch; const uint8_t* src = level_src(P, frame, t.level, spitch);
-    __shared__ unsigned s_src[(BLUR_TH + 6) * (BLUR_SROW / 4)];
-    __shared__ uint2 s_h[(BLUR_TH + 6) * (BLUR_TW / 4)];
+    __shared__ unsigned s_src[BLUR_SROWS * BLUR_SDW];
+    __shared__ float4 s_h[BLUR_SROWS * (BLUR_TW / 4)];
     const bool aligned = ((((unsigned long long)src) | (unsigned long long)spitch) & 3ull) == 0;
-    {   // (38 x 34) dwords, 6 per thread, all loads in flight before the first LDS write; border dwords are patched afterwards
-        unsigned v[6]; bool edge[6];
+    {
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+        const int gx = t.x0 - 4 + 4 * lane;
+        const bool act = lane < 34, edge = act && !(aligned && gx >= 0 && gx + 3 < g.w);
+        unsigned v[10];
 #pragma unroll
-        for (int k = 0; k < 6; k++) {
-            const int i = tid + 256 * k, r = i / 34, d = i - r * 34;
-            const int gy = reflect101_clamped(t.y0 - 3 + r, g.h), gx = t.x0 - 4 + 4 * d;
-            const bool in = i < (BLUR_TH + 6) * 34;
-            edge[k] = in && !(aligned && gx >= 0 && gx + 3 < g.w);
-            v[k] = (in && !edge[k]) ? *reinterpret_cast<const unsigned*>(src + (long long)gy * spitch + gx) : 0u;
+        for (int j = 0; j < 10; j++) {
+            const uint8_t* row = src + (long long)reflect101_clamped(t.y0 - 3 + wave + 4 * j, g.h) * spitch + (t.x0 - 4);   // wave-uniform -> SGPR base
+            v[j] = (act && !edge) ? *reinterpret_cast<const unsigned*>(row + (unsigned)(4 * lane)) : 0u;
+        }
+        if (edge) {
+            const int x0r = reflect101_clamped(gx, g.w), x1r = reflect101_clamped(gx + 1, g.w), x2r = reflect101_clamped(gx + 2, g.w), x3r = reflect101_clamped(gx + 3, g.w);
+#pragma unroll
+            for (int j = 0; j < 10; j++) {
+                const uint8_t* row = src + (long long)reflect101_clamped(t.y0 - 3 + wave + 4 * j, g.h) * spitch;
+                v[j] = (unsigned)row[x0r] | ((unsigned)row[x1r] << 8) | ((unsigned)row[x2r] << 16) | ((unsigned)row[x3r] << 24);
+            }
         }
 #pragma unroll
-        for (int k = 0; k < 6; k++) {
-            const int i = tid + 256 * k, r = i / 34, d = i - r * 34;
-            if (edge[k]) {
-                const int gy = reflect101_clamped(t.y0 - 3 + r, g.h), gx = t.x0 - 4 + 4 * d;
-                const uint8_t* row = src + (long long)gy * spitch;
-                v[k] = (unsigned)row[reflect101_clamped(gx, g.w)] | ((unsigned)row[reflect101_clamped(gx + 1, g.w)] << 8) |
-                       ((unsigned)row[reflect101_clamped(gx + 2, g.w)] << 16) | ((unsigned)row[reflect101_clamped(gx + 3, g.w)] << 24);
-            }
-            if (i < (BLUR_TH + 6) * 34) s_src[r * (BLUR_SROW / 4) + d] = v[k];
+        for (int j = 0; j < 10; j++) {
+            const int r = wave + 4 * j;
+            if (act && r < BLUR_SROWS) s_src[r * BLUR_SDW + lane] = v[j];
         }
     }
     __syncthreads();
-    for (int i = tid; i < (BLUR_TH + 6) * 32; i += 256) {
+    for (int i = tid; i < BLUR_SROWS * 32; i += 256) {
         const int r = i >> 5, q = i & 31;
-        const unsigned* p = &s_src[r * (BLUR_SROW / 4) + q];
-        const unsigned w0 = p[0], w1 = p[1], w2 = p[2];
-        int b[12];
-#pragma unroll
-        for (int k = 0; k < 4; k++) { b[k] = (w0 >> (8 * k)) & 0xff; b[4 + k] = (w1 >> (8 * k)) & 0xff; b[8 + k] = (w2 >> (8 * k)) & 0xff; }
-        unsigned hs[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++)      // output pixel x0+4q+k reads tile bytes 4q+k+1 .. 4q+k+7; sum <= 255*257 = 65535
-            hs[k] = K.k3 * (b[k + 1] + b[k + 7]) + K.k2 * (b[k + 2] + b[k + 6]) + K.k1 * (b[k + 3] + b[k + 5]) + K.k0 * b[k + 4];
-        uint2 o; o.x = hs[0] | (hs[1] << 16); o.y = hs[2] | (hs[3] << 16);
+        const unsigned* p = &s_src[r * BLUR_SDW + q];
+        const unsigned w0 = p[0], w1 = p[1], w2 = p[2];           // tile bytes 4q .. 4q+11; output pixel 4q+k reads bytes 4q+k+1 .. 4q+k+7
+        float4 o;
+        o.x = (float)__builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), K.dot_lo, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), K.dot_hi, 0u, false), false);
+        o.y = (float)__builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), K.dot_lo, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), K.dot_hi, 0u, false), false);
+        o.z = (float)__builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), K.dot_lo, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), K.dot_hi, 0u, false), false);
+        o.w = (float)__builtin_amdgcn_udot4(w1, K.dot_lo, __builtin_amdgcn_udot4(w2, K.dot_hi, 0u, false), false);
         s_h[r * (BLUR_TW / 4) + q] = o;
     }
     __syncthreads();
     const int q = tid & 31, rg = tid >> 5;
     const int gx = t.x0 + 4 * q;
     if (gx >= g.w) return;
-    int h[10][4];
+    float h[10][4];
 #pragma unroll
-    for (int r = 0; r < 10; r++) { const uint2 v = s_h[(4 * rg + r) * (BLUR_TW / 4) + q]; h[r][0] = v.x & 0xffff; h[r][1] = v.x >> 16; h[r][2] = v.y & 0xffff; h[r][3] = v.y >> 16; }
-    const int wv = g.w & ~3;
+    for (int r = 0; r < 10; r++) { const float4 v = s_h[(4 * rg + r) * (BLUR_TW / 4) + q]; h[r][0] = v.x; h[r][1] = v.y; h[r][2] = v.z; h[r][3] = v.w; }
+    const bool half_even = P.blur_round_mode == 1 && gx < (g.w & ~3);      // x86 SSE2 build of OpenCV: cvtps2dq on whole 4-column groups
     uint8_t* dstbase = P.blur + (long long)frame * P.plane_frame_bytes + g.plane_off + gx;
+    auto strip = [&](auto he) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int gy = t.y0 + 4 * rg + r;
-        if (gy >= g.h) break;
-        unsigned out = 0;
+        for (int r = 0; r < 4; r++) {
+            const int gy = t.y0 + 4 * rg + r;
+            if (gy >= g.h) break;
+            unsigned out = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int sum = K.k3 * (h[r][k] + h[r + 6][k]) + K.k2 * (h[r + 1][k] + h[r + 5][k]) + K.k1 * (h[r + 2][k] + h[r + 4][k]) + K.k0 * h[r + 3][k];
-            int v;
-            if (P.blur_round_mode == 1 && (gx + k) < wv) {   // x86 SSE2 build of OpenCV: round-half-even via cvtps2dq
-                v = sum >> 16; const int rem = sum & 0xFFFF;
-                if (rem > 0x8000 || (rem == 0x8000 && (v & 1))) v++;
-            } else v = (sum + (1 << 15)) >> 16;              // generic FixedPtCastEx
-            out |= (unsigned)min(v, 255) << (8 * k);
+            for (int k = 0; k < 4; k++) {
+                float sum = K.k0 * h[r + 3][k];
+                sum = __builtin_fmaf(K.k1, h[r + 2][k] + h[r + 4][k], sum);
+                sum = __builtin_fmaf(K.k2, h[r + 1][k] + h[r + 5][k], sum);
+                sum = __builtin_fmaf(K.k3, h[r][k] + h[r + 6][k], sum);
+                // generic FixedPtCastEx: (sum + 2^15) >> 16, the saturating RNE conversion then sees an integer;
+                // SSE2 build: the conversion's own round-half-even is the cvtps2dq
+                const float v = decltype(he)::value ? sum * (1.0f / 65536.0f) : __builtin_floorf(__builtin_fmaf(sum, 1.0f / 65536.0f, 0.5f));
+                out = __builtin_amdgcn_cvt_pk_u8_f32(v, (unsigned)k, out);
+            }
+            *reinterpret_cast<unsigned*>(dstbase + (long long)gy * g.pitch) = out;   // pitch multiple of 64, gx of 4: pad bytes absorb the tail
         }
-        *reinterpret_cast<unsigned*>(dstbase + (long long)gy * g.pitch) = out;   // pitch multiple of 64, gx of 4: pad bytes absorb the tail
-    }
+    };
+    if (half_even) strip(std::true_type{}); else strip(std::false_type{});
 }
 
 void orbhip_launch_blur(const ExtractParams& P, const int gk[4], int nframes, hipStream_t s)
 {
-    BlurK K; K.k0 = gk[0]; K.k1 = gk[1]; K.k2 = gk[2]; K.k3 = gk[3];
+    BlurK K; K.k0 = (float)gk[0]; K.k1 = (float)gk[1]; K.k2 = (float)gk[2]; K.k3 = (float)gk[3];
+    K.dot_lo = (unsigned)gk[3] | ((unsigned)gk[2] << 8) | ((unsigned)gk[1] << 16) | ((unsigned)gk[0] << 24);    // bytes x-3 .. x
+    K.dot_hi = (unsigned)gk[1] | ((unsigned)gk[2] << 8) | ((unsigned)gk[3] << 16);                              // bytes x+1 .. x+3
     ExtractParams Q = P; Q.nframes = nframes;
     hipLaunchKernelGGL(k_blur, dim3(xcd_grid(P.nblur_tiles, nframes), 1, 1), dim3(256, 1, 1), 0, s, Q, K);
 }
@@ -747,8 +779,12 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
 __global__ __launch_bounds__(QT_T) void k_quadtree(ExtractParams P)
 {
     __builtin_amdgcn_s_setprio(3);          // latency-bound: win issue arbitration against the VALU-bound blur running beside it
-    int level, frame;
-    if (!xcd_frame_map(P.nlevels, P.nframes, level, frame)) return;
+    // level-major ids (still frame == id mod 8 for the XCD affinity): workgroups are dispatched in id order and a level-0
+    // workgroup runs ~4x longer than a level-7 one, so the long ones start first and the short ones fill the tail
+    const int nfg = (P.nframes + 7) >> 3, jj = (int)blockIdx.x >> 3;
+    const int level = jj / nfg;
+    int frame = (jj - level * nfg) * 8 + ((int)blockIdx.x & 7);
+    if (frame >= P.nframes) return;
     frame += P.frame0;
     const int tid = threadIdx.x;
     const LevelGeom g = P.geom[level];

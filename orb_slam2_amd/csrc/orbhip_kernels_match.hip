@@ -238,10 +238,13 @@ __device__ __forceinline__ unsigned long long wave_argmin_mask(int d, unsigned l
 }
 
 #define MS_T 256
-#define MS_CANDCAP 20480               // candidate records staged in LDS (80 KB); longer lists are read from HBM
+#define MS_DEPTH 4                      // candidate lists are fetched this many keypoints ahead of the replay
 
-// Workgroup of 4 waves per camera slot: all waves stage the slot's candidate lists (i2 | dist<<20, canonical order) in LDS,
-// then wave 0 alone replays the order-dependent loop over F1's level-0 keypoints.
+// One workgroup per camera slot.  All 4 waves initialise the per-slot tables in LDS, then wave 0 alone replays the
+// order-dependent loop over F1's level-0 keypoints.  The candidate lists (i2 | dist<<20, canonical order) stay in HBM/L2:
+// the first 128 records of the list of keypoint j1+MS_DEPTH are loaded while j1 is processed (a register ring), so the memory
+// latency is off the critical path and the kernel's LDS footprint stays small enough not to displace the workgroups of the
+// extraction kernels it runs beside (an 80 KB staged copy of the lists used to halve k_fast_cells' occupancy on every CU).
 __global__ __launch_bounds__(MS_T) void k_match_select(MatchParams M)
 {
     const int slot = blockIdx.x + M.slot0, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -254,11 +257,9 @@ __global__ __launch_bounds__(MS_T) void k_match_select(MatchParams M)
     int* s_m12 = s_m21 + M.cap;             // vnMatches12[i1] for level-0 i1
     int* s_bin = s_m12 + M.lvl0_cap;        // rotation bin of the accepted match of i1, -1 = none
     int* s_nc = s_bin + M.lvl0_cap;         // candidate count per level-0 i1
-    int* s_off = s_nc + M.lvl0_cap;         // start of its list in s_cand
-    int* s_hist = s_off + M.lvl0_cap + 1;   // [HISTO_LENGTH] + misc
+    int* s_hist = s_nc + M.lvl0_cap;        // [HISTO_LENGTH] + misc
     float* s_ang1 = reinterpret_cast<float*>(s_hist + ORBHIP_HISTO_LENGTH + 8);   // angle of F1's level-0 keypoint j1
     float* s_ang2 = s_ang1 + M.lvl0_cap;                                           // angle of F2's keypoint i2
-    unsigned* s_cand = reinterpret_cast<unsigned*>(s_ang2 + M.cap);
     const orbhip_keypoint* kp1 = M.kp1 + (long long)slot * M.cap;
     const orbhip_keypoint* kp2 = M.kp2 + (long long)slot * M.cap;
     int* m12 = M.matches12 + (long long)slot * M.cap;
@@ -269,78 +270,68 @@ __global__ __launch_bounds__(MS_T) void k_match_select(MatchParams M)
     for (int i = tid; i < ORBHIP_HISTO_LENGTH + 8; i += MS_T) s_hist[i] = 0;
     for (int i = tid; i < n1; i += MS_T) { m12[i] = -1; if (M.prev_from_kp1) { prev[2 * i] = kp1[i].x; prev[2 * i + 1] = kp1[i].y; } }
     __syncthreads();
-    if (wave == 0) {                        // exclusive scan of the list lengths
-        int run = 0;
-        for (int cb = 0; cb < n1l; cb += 64) {
-            const int v = (cb + lane < n1l) ? s_nc[cb + lane] : 0;
-            int incl = v;
+    if (wave == 0) {
+        const float factor = 1.0f / ORBHIP_HISTO_LENGTH;
+        unsigned ring[MS_DEPTH][2];          // records [lane] and [64 + lane] of the lists of keypoints j1 .. j1+MS_DEPTH-1
+        auto fetch = [&](int j, unsigned (&r)[2]) {
+            r[0] = 0; r[1] = 0;
+            if (j < n1l) {
+                const int ncj = s_nc[j];
+                const unsigned* c = cand0 + (long long)j * M.cand_stride;
+                if (lane < ncj) r[0] = c[lane];
+                if (64 + lane < ncj) r[1] = c[64 + lane];
+            }
+        };
 #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(incl, off); if (lane >= off) incl += u; }
-            if (cb + lane < n1l) s_off[cb + lane] = run + incl - v;
-            run += __shfl(incl, 63);
-        }
-        if (lane == 0) s_off[n1l] = run;
-    }
-    __syncthreads();
-    for (int j1 = wave; j1 < n1l; j1 += MS_T / 64) {
-        const int nc = s_nc[j1], o = s_off[j1];
-        if (o + nc > MS_CANDCAP) continue;
-        for (int t = lane; t < nc; t += 64) s_cand[o + t] = cand0[(long long)j1 * M.cand_stride + t];
-    }
-    __syncthreads();
-    if (wave != 0) return;
-    const float factor = 1.0f / ORBHIP_HISTO_LENGTH;
-    // software pipeline: the list head of keypoint j1+1 (length, offset, first 64 records) is fetched while j1 is processed,
-    // so the only LDS round trip left on the critical path is vMatchedDistance[i2]
-    int nc_n = n1l > 0 ? s_nc[0] : 0, o_n = n1l > 0 ? s_off[0] : 0;
-    unsigned e_n = 0;
-    if (lane < nc_n) e_n = (o_n + nc_n <= MS_CANDCAP) ? s_cand[o_n + lane] : cand0[lane];
-    for (int j1 = 0; j1 < n1l; j1++) {
-        const int nc = nc_n, o = o_n;
-        const unsigned e0 = e_n;
-        if (j1 + 1 < n1l) {
-            nc_n = s_nc[j1 + 1]; o_n = s_off[j1 + 1];
-            e_n = 0;
-            if (lane < nc_n) e_n = (o_n + nc_n <= MS_CANDCAP) ? s_cand[o_n + lane] : cand0[(long long)(j1 + 1) * M.cand_stride + lane];
-        }
-        if (nc == 0) continue;
-        const bool staged = o + nc <= MS_CANDCAP;
-        const unsigned* cand = cand0 + (long long)j1 * M.cand_stride;
-        int best = IMAX, second = IMAX, bidx = -1;
-        for (int cb = 0; cb < nc; cb += 64) {
-            const int t = cb + lane;
-            unsigned e = e0;
-            if (cb > 0) { e = 0; if (t < nc) e = staged ? s_cand[o + t] : cand[t]; }
-            const int i2 = (int)(e & 0xFFFFFu), dist = (int)(e >> 20);
-            const bool valid = t < nc && !(s_md[i2] <= dist);                    // :444-445
-            const unsigned long long V = __ballot(valid);
-            if (V == 0) continue;
-            const unsigned long long mk = wave_argmin_mask(dist, V);
-            const int first = __ffsll((long long)mk) - 1;        // strict '<': the first candidate with the minimum wins (:447-452)
-            const int wmin = __builtin_amdgcn_readlane(dist, first), ci = __builtin_amdgcn_readlane(i2, first);
-            const unsigned long long V2 = V & ~(1ull << first);
-            int wsec = IMAX;
-            if (V2) { const unsigned long long mk2 = wave_argmin_mask(dist, V2); wsec = __builtin_amdgcn_readlane(dist, __ffsll((long long)mk2) - 1); }
-            if (wmin < best) { second = min(best, wsec); best = wmin; bidx = ci; } else second = min(second, wmin);
-        }
-        if (best <= ORBHIP_TH_LOW && (float)best < __fmul_rn((float)second, M.nnratio)) {      // :459-461
-            if (lane == 0) {
-                const int old = s_m21[bidx];
-                if (old >= 0) s_m12[old] = -1;
-                s_m12[j1] = bidx; s_m21[bidx] = j1; s_md[bidx] = best;
-                if (M.check_ori) {
-                    float rot = __fsub_rn(s_ang1[j1], s_ang2[bidx]);
-                    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
-                    int bin = (int)roundf(__fmul_rn(rot, factor));
-                    if (bin == ORBHIP_HISTO_LENGTH) bin = 0;
-                    bin = min(max(bin, 0), ORBHIP_HISTO_LENGTH - 1);
-                    s_bin[j1] = bin; s_hist[bin]++;               // rotHist[bin].push_back(i1): never removed when stolen
+        for (int u = 0; u < MS_DEPTH; u++) fetch(u, ring[u]);
+        for (int jb = 0; jb < n1l; jb += MS_DEPTH) {
+#pragma unroll
+            for (int u = 0; u < MS_DEPTH; u++) {
+                const int j1 = jb + u;
+                const unsigned e0 = ring[u][0], e1 = ring[u][1];
+                fetch(j1 + MS_DEPTH, ring[u]);
+                const int nc = j1 < n1l ? s_nc[j1] : 0;
+                if (nc != 0) {
+                    const unsigned* cand = cand0 + (long long)j1 * M.cand_stride;
+                    int best = IMAX, second = IMAX, bidx = -1;
+                    for (int cb = 0; cb < nc; cb += 64) {
+                        const int t = cb + lane;
+                        unsigned e = cb == 0 ? e0 : e1;
+                        if (cb >= 128) { e = 0; if (t < nc) e = cand[t]; }              // lists longer than the prefetched 128 records
+                        const int i2 = (int)(e & 0xFFFFFu), dist = (int)(e >> 20);
+                        const bool valid = t < nc && !(s_md[i2] <= dist);                    // :444-445
+                        const unsigned long long V = __ballot(valid);
+                        if (V == 0) continue;
+                        const unsigned long long mk = wave_argmin_mask(dist, V);
+                        const int first = __ffsll((long long)mk) - 1;        // strict '<': the first candidate with the minimum wins (:447-452)
+                        const int wmin = __builtin_amdgcn_readlane(dist, first), ci = __builtin_amdgcn_readlane(i2, first);
+                        const unsigned long long V2 = V & ~(1ull << first);
+                        int wsec = IMAX;
+                        if (V2) { const unsigned long long mk2 = wave_argmin_mask(dist, V2); wsec = __builtin_amdgcn_readlane(dist, __ffsll((long long)mk2) - 1); }
+                        if (wmin < best) { second = min(best, wsec); best = wmin; bidx = ci; } else second = min(second, wmin);
+                    }
+                    if (best <= ORBHIP_TH_LOW && (float)best < __fmul_rn((float)second, M.nnratio)) {      // :459-461
+                        if (lane == 0) {
+                            const int old = s_m21[bidx];
+                            if (old >= 0) s_m12[old] = -1;
+                            s_m12[j1] = bidx; s_m21[bidx] = j1; s_md[bidx] = best;
+                            if (M.check_ori) {
+                                float rot = __fsub_rn(s_ang1[j1], s_ang2[bidx]);
+                                if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                                int bin = (int)roundf(__fmul_rn(rot, factor));
+                                if (bin == ORBHIP_HISTO_LENGTH) bin = 0;
+                                bin = min(max(bin, 0), ORBHIP_HISTO_LENGTH - 1);
+                                s_bin[j1] = bin; s_hist[bin]++;               // rotHist[bin].push_back(i1): never removed when stolen
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();                     // lane 0's LDS updates are read by the whole wave next
+                    }
                 }
             }
-            __syncthreads();
         }
     }
-    __syncthreads();
+    if (wave != 0) return;
+    __builtin_amdgcn_wave_barrier();
     // nmatches of the reference (++ on accept, -- on steal :463-467 and on rotation reject :504-508) == final count of set entries
     if (M.check_ori) {
         if (lane == 0) {                                          // ComputeThreeMaxima (:1601-1642)
@@ -355,10 +346,10 @@ __global__ __launch_bounds__(MS_T) void k_match_select(MatchParams M)
             else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
             s_hist[ORBHIP_HISTO_LENGTH] = ind1; s_hist[ORBHIP_HISTO_LENGTH + 1] = ind2; s_hist[ORBHIP_HISTO_LENGTH + 2] = ind3;
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
         const int ind1 = s_hist[ORBHIP_HISTO_LENGTH], ind2 = s_hist[ORBHIP_HISTO_LENGTH + 1], ind3 = s_hist[ORBHIP_HISTO_LENGTH + 2];
         for (int j = lane; j < n1l; j += 64) { const int b = s_bin[j]; if (b >= 0 && b != ind1 && b != ind2 && b != ind3) s_m12[j] = -1; }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
     }
     int cnt = 0;
     for (int j = lane; j < n1l; j += 64) {
@@ -372,6 +363,6 @@ __global__ __launch_bounds__(MS_T) void k_match_select(MatchParams M)
 
 void orbhip_launch_match_select(const MatchParams& M, int nslots, hipStream_t s)
 {
-    const size_t lds = sizeof(int) * ((size_t)3 * M.cap + (size_t)5 * M.lvl0_cap + 1 + ORBHIP_HISTO_LENGTH + 8 + MS_CANDCAP);
+    const size_t lds = sizeof(int) * ((size_t)3 * M.cap + (size_t)4 * M.lvl0_cap + ORBHIP_HISTO_LENGTH + 8);
     hipLaunchKernelGGL(k_match_select, dim3(nslots, 1, 1), dim3(MS_T, 1, 1), lds, s, M);
 }

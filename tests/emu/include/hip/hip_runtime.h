@@ -151,6 +151,7 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask,
 }
 inline void __builtin_amdgcn_s_setprio(int) {}
 inline void __builtin_amdgcn_wave_barrier() { hipemu::wave_collective(hipemu::OP_BALLOT, 0, 0); }   // rendezvous of the wave's lanes
+inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffs(int v) { return __builtin_ffs(v); }
@@ -165,6 +166,24 @@ inline unsigned __builtin_amdgcn_perm(unsigned s0, unsigned s1, unsigned sel) {
         if (c <= 7) b = (unsigned)(src >> (8 * c)) & 0xff; else if (c == 0x0c) b = 0; else b = 0xff; r |= b << (8 * i); }
     return r;
 }
+// v_alignbyte_b32: ({hi,lo} >> 8*shift)[31:0]
+inline unsigned __builtin_amdgcn_alignbyte(unsigned hi, unsigned lo, unsigned shift) {
+    return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (8 * (shift & 3)));
+}
+// v_dot4_u32_u8: sum of the four byte products + c
+inline unsigned __builtin_amdgcn_udot4(unsigned a, unsigned b, unsigned c, bool /*clamp*/) {
+    for (int i = 0; i < 4; i++) c += ((a >> (8 * i)) & 0xff) * ((b >> (8 * i)) & 0xff);
+    return c;
+}
+// v_cvt_pk_u8_f32: round to nearest even, saturate to [0, 255], insert into byte `pos` of `old` (measured on MI355X:
+// 0.5 -> 0, 1.5 -> 2, 2.5 -> 2, 255.7 -> 255, 300 -> 255, -1 -> 0; tools/ubench.hip probe)
+inline unsigned __builtin_amdgcn_cvt_pk_u8_f32(float v, unsigned pos, unsigned old) {
+    float r = __builtin_nearbyintf(v); if (!(r > 0.0f)) r = 0.0f; if (r > 255.0f) r = 255.0f;
+    const unsigned sh = 8 * (pos & 3);
+    return (old & ~(0xffu << sh)) | ((unsigned)r << sh);
+}
+// v_readfirstlane_b32: the kernels only apply it to wave-uniform values (to move them to the scalar unit)
+inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 // atomics (single OS thread: plain read-modify-write is atomic w.r.t. fibers)
 template <typename T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <typename T> inline T atomicSub(T* p, T v) { T o = *p; *p = o - v; return o; }
@@ -216,6 +235,8 @@ inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return 
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { memset(d, v, n); return hipSuccess; }
 inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return hipSuccess; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = 0; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }

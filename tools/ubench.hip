@@ -37,12 +37,29 @@ __global__ __launch_bounds__(256) void NAME(unsigned* out, unsigned seed) { \
 #define A_SADU8(i)    "v_sad_u8 %" #i ", %" #i ", %8, %9\n"
 #define A_CMPSEL(i)   "v_cmp_lt_u32 vcc, %" #i ", %8\n v_cndmask_b32 %" #i ", %" #i ", %9, vcc\n"
 #define A_DPP(i)      "v_mov_b32_dpp %" #i ", %" #i " row_shr:1 row_mask:0xf bank_mask:0xf\n"
+#define A_PKMADU16(i) "v_pk_mad_u16 %" #i ", %" #i ", %8, %9\n"
+#define A_PKMULU16(i) "v_pk_mul_lo_u16 %" #i ", %" #i ", %8\n"
+#define A_PKADDU16(i) "v_pk_add_u16 %" #i ", %" #i ", %8\n"
+#define A_DOT4U8(i)   "v_dot4_u32_u8 %" #i ", %" #i ", %8, %9\n"
+#define A_ADDF32(i)   "v_add_f32 %" #i ", %" #i ", %8\n"
+#define A_CVTUB1(i)   "v_cvt_f32_ubyte1 %" #i ", %" #i "\n"
+#define A_FLOOR(i)    "v_floor_f32 %" #i ", %" #i "\n"
+#define A_CVTPKU8(i)  "v_cvt_pk_u8_f32 %" #i ", %" #i ", 1, %8\n"
+#define A_ALIGNBYTE(i) "v_alignbyte_b32 %" #i ", %" #i ", %8, 1\n"
+#define A_ADDSDWA(i)  "v_add_u32_sdwa %" #i ", %" #i ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_2\n"
+#define A_CVTU32F(i)  "v_cvt_u32_f32 %" #i ", %" #i "\n"
 #define A_BPERM(i)    "ds_bpermute_b32 %" #i ", %8, %" #i "\n s_waitcnt lgkmcnt(0)\n"
 DEFK(k_add, A_ADD) DEFK(k_minu, A_MINU) DEFK(k_pkminu16, A_PKMINU16) DEFK(k_pkminf16, A_PKMINF16) DEFK(k_pkmaxi16, A_PKMAXI16)
 DEFK(k_minf32, A_MINF32) DEFK(k_fmaf32, A_FMAF32) DEFK(k_mulf32, A_MULF32) DEFK(k_min3u, A_MIN3U) DEFK(k_max3f, A_MAX3F)
 DEFK(k_perm, A_PERM) DEFK(k_mad24, A_MAD24) DEFK(k_lshladd, A_LSHLADD) DEFK(k_andor, A_ANDOR) DEFK(k_cvtf, A_CVTF) DEFK(k_rndne, A_RNDNE)
 DEFK(k_cvti, A_CVTI) DEFK(k_mullo, A_MULLO) DEFK(k_bfe, A_BFE) DEFK(k_alignbit, A_ALIGNBIT) DEFK(k_pkaddf16, A_PKADDF16) DEFK(k_pkmulf16, A_PKMULF16)
+DEFK(k_pkmadu16, A_PKMADU16) DEFK(k_pkmulu16, A_PKMULU16) DEFK(k_pkaddu16, A_PKADDU16) DEFK(k_dot4u8, A_DOT4U8) DEFK(k_addf32, A_ADDF32)
+DEFK(k_cvtub1, A_CVTUB1) DEFK(k_floor, A_FLOOR) DEFK(k_cvtpku8, A_CVTPKU8) DEFK(k_alignbyte, A_ALIGNBYTE) DEFK(k_addsdwa, A_ADDSDWA) DEFK(k_cvtu32f, A_CVTU32F)
 DEFK(k_bcnt, A_BCNT) DEFK(k_xor, A_XOR) DEFK(k_sadu8, A_SADU8) DEFK(k_cmpsel, A_CMPSEL) DEFK(k_dpp, A_DPP) DEFK(k_bperm, A_BPERM)
+__global__ void k_probe_cvtpk(const float* in, unsigned* out)
+{
+    if (threadIdx.x < 12) out[threadIdx.x] = __builtin_amdgcn_cvt_pk_u8_f32(in[threadIdx.x], 1u, 0xAA0000BBu);
+}
 typedef void (*kfn)(unsigned*, unsigned);
 static void run(const char* name, kfn f, int inst_per_slot)
 {
@@ -61,5 +78,16 @@ int main()
     R(k_add, 1); R(k_xor, 1); R(k_minu, 1); R(k_min3u, 1); R(k_pkminu16, 1); R(k_pkmaxi16, 1); R(k_pkminf16, 1); R(k_pkaddf16, 1); R(k_pkmulf16, 1);
     R(k_minf32, 1); R(k_max3f, 1); R(k_mulf32, 1); R(k_fmaf32, 1); R(k_perm, 1); R(k_mad24, 1); R(k_lshladd, 1); R(k_andor, 1); R(k_bfe, 1);
     R(k_alignbit, 1); R(k_cvtf, 1); R(k_rndne, 1); R(k_cvti, 1); R(k_mullo, 1); R(k_bcnt, 1); R(k_sadu8, 1); R(k_cmpsel, 2); R(k_dpp, 1); R(k_bperm, 1);
+    R(k_pkmadu16, 1); R(k_pkmulu16, 1); R(k_pkaddu16, 1); R(k_dot4u8, 1); R(k_addf32, 1); R(k_cvtub1, 1); R(k_floor, 1); R(k_cvtpku8, 1);
+    R(k_alignbyte, 1); R(k_addsdwa, 1); R(k_cvtu32f, 1);
+    // semantics probe: v_cvt_pk_u8_f32 rounding / saturation
+    {
+        const float in[12] = {0.0f, 0.49f, 0.5f, 0.99f, 1.5f, 2.5f, 254.99f, 255.0f, 255.7f, 256.0f, 300.0f, -1.0f};
+        float* di; unsigned* dout; (void)hipMalloc(&di, sizeof(in)); (void)hipMalloc(&dout, 12 * 4);
+        (void)hipMemcpy(di, in, sizeof(in), hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(k_probe_cvtpk, dim3(1), dim3(64), 0, 0, di, dout);
+        unsigned out[12]; (void)hipMemcpy(out, dout, sizeof(out), hipMemcpyDeviceToHost);
+        for (int i = 0; i < 12; i++) printf("cvt_pk_u8_f32(%g) -> 0x%08x\n", in[i], out[i]);
+    }
     return 0;
 }
