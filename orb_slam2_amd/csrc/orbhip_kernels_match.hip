@@ -165,6 +165,15 @@ void orbhip_launch_match_grid(const MatchParams& M, int nslots, hipStream_t s)
 // ------------------------------------------------------------------------------------------------ candidates
 // For the j-th level-0 keypoint of the previous frame: F2.GetFeaturesInArea(prev.x, prev.y, window, 0, 0) in the
 // reference's order (ix outer, iy inner, keypoint order inside a cell) + DescriptorDistance to each candidate.
+//
+// The bucket table written by k_match_grid lists F2's (level-0) keypoints in exactly that order: by cell ix*ROWS+iy, then by
+// index.  GetFeaturesInArea visits the cells [floor((x-r)/w) .. ceil((x+r)/w)] x [..] and keeps keypoints with |dx| < r and
+// |dy| < r (Frame.cc:327-380); a keypoint that passes the distance test always lies in a visited cell (its cell is
+// round(kx/w), and floor(a) <= round(v) <= ceil(b) for a < v < b; the sub-ulp slack of the float subtraction is far below
+// the 0.5 of the rounding), so the result is the sub-sequence of the whole table that passes the distance test.  One
+// wavefront scans the table (a few hundred entries: coalesced, all loads in flight at once) instead of walking ~300
+// mostly empty cells with dependent loads; ballot ranks keep the order.
+#define MC_CHUNKS 8
 __global__ __launch_bounds__(256) void k_match_candidates(MatchParams M, float gwInv, float ghInv)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, slot = blockIdx.y + M.slot0;
@@ -172,7 +181,7 @@ __global__ __launch_bounds__(256) void k_match_candidates(MatchParams M, float g
     const int n1l = M.n1_lvl0[slot * M.lvl_stride];
     if (j1 >= n1l || j1 >= M.lvl0_cap) return;
     const int i1 = M.list1 ? M.list1[(long long)slot * M.lvl0_cap + j1] : j1;   // level-major extractor output: level 0 = indices [0, n_lvl0)
-    const int* gstart = M.grid_start + (long long)slot * (ORBHIP_GRID_CELLS + 1);
+    const int nitems = M.grid_start[(long long)slot * (ORBHIP_GRID_CELLS + 1) + ORBHIP_GRID_CELLS];
     const int* gitems = M.grid_items + (long long)slot * M.cap;
     const float2* gxy = M.grid_xy + (long long)slot * M.cap;
     unsigned* cand = M.cand + ((long long)slot * M.lvl0_cap + j1) * M.cand_stride;
@@ -182,39 +191,29 @@ __global__ __launch_bounds__(256) void k_match_candidates(MatchParams M, float g
     const float r = (float)M.window;
     const unsigned long long* d1 = (const unsigned long long*)(M.desc1 + ((long long)slot * M.cap + i1) * 32);
     const unsigned long long q0 = d1[0], q1 = d1[1], q2 = d1[2], q3 = d1[3];
+    const unsigned long long below = (1ull << lane) - 1ull;
     int nc = 0;
-    const int minCX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, 0.0f), r), gwInv)));
-    const int maxCX = min(ORBHIP_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, 0.0f), r), gwInv)));
-    const int minCY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, 0.0f), r), ghInv)));
-    const int maxCY = min(ORBHIP_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, 0.0f), r), ghInv)));
-    if (minCX < ORBHIP_GRID_COLS && maxCX >= 0 && minCY < ORBHIP_GRID_ROWS && maxCY >= 0 && maxCX >= minCX && maxCY >= minCY) {
-        const int ny = maxCY - minCY + 1, ncell = (maxCX - minCX + 1) * ny;
-        for (int cb = 0; cb < ncell; cb += 64) {
-            const int c = cb + lane;
-            int a = 0, b = 0;
-            if (c < ncell) { const int ix = minCX + c / ny, iy = minCY + c % ny; const int cell = ix * ORBHIP_GRID_ROWS + iy; a = gstart[cell]; b = gstart[cell + 1]; }
-            int cnt = 0;
-            for (int t = a; t < b; t++) {                        // buckets hold level-0 keypoints only (minLevel = maxLevel = 0, ORBmatcher.cc:425)
-                const float2 k = gxy[t];
-                cnt += (fabsf(__fsub_rn(k.x, x)) < r && fabsf(__fsub_rn(k.y, y)) < r);
-            }
-            int incl = cnt;
+    for (int tb = 0; tb < nitems; tb += 64 * MC_CHUNKS) {
+        float2 k[MC_CHUNKS]; int it[MC_CHUNKS];
 #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
-            int pos = nc + incl - cnt;
-            for (int t = a; t < b; t++) {
-                const float2 k = gxy[t];
-                if (fabsf(__fsub_rn(k.x, x)) < r && fabsf(__fsub_rn(k.y, y)) < r) {
-                    const int i2 = gitems[t];
-                    if (pos < M.cand_stride) {
-                        const unsigned long long* d2 = (const unsigned long long*)(M.desc2 + ((long long)slot * M.cap + i2) * 32);
-                        const int dist = __popcll(q0 ^ d2[0]) + __popcll(q1 ^ d2[1]) + __popcll(q2 ^ d2[2]) + __popcll(q3 ^ d2[3]);
-                        cand[pos] = (unsigned)i2 | ((unsigned)dist << 20);      // DescriptorDistance (ORBmatcher.cc:442)
-                    }
-                    pos++;
-                }
+        for (int c = 0; c < MC_CHUNKS; c++) {
+            const int t = tb + 64 * c + lane;
+            k[c].x = 0.0f; k[c].y = 0.0f; it[c] = 0;
+            if (t < nitems) { k[c] = gxy[t]; it[c] = gitems[t]; }
+        }
+#pragma unroll
+        for (int c = 0; c < MC_CHUNKS; c++) {
+            if (tb + 64 * c >= nitems) break;
+            const bool ok = tb + 64 * c + lane < nitems && fabsf(__fsub_rn(k[c].x, x)) < r && fabsf(__fsub_rn(k[c].y, y)) < r;    // Frame.cc:367-371
+            const unsigned long long m = __ballot(ok);
+            if (m == 0) continue;
+            const int pos = nc + __popcll(m & below);
+            if (ok && pos < M.cand_stride) {
+                const unsigned long long* d2 = (const unsigned long long*)(M.desc2 + ((long long)slot * M.cap + it[c]) * 32);
+                const int dist = __popcll(q0 ^ d2[0]) + __popcll(q1 ^ d2[1]) + __popcll(q2 ^ d2[2]) + __popcll(q3 ^ d2[3]);
+                cand[pos] = (unsigned)it[c] | ((unsigned)dist << 20);          // DescriptorDistance (ORBmatcher.cc:442)
             }
-            nc += __shfl(incl, 63);
+            nc += __popcll(m);
         }
     }
     nc = min(nc, M.cand_stride);
