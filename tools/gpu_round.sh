@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.log
 timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke exit $?" >> $OUT/smoke.log
 timeout 600 python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?" >> $OUT/bench.err
-for cfg in "64 1" "128 1" "256 1" "512 1" "256 2"; do set -- $cfg; timeout 200 python bench.py --steps 20 --warmup 3 --batch $1 --streams $2 --no-cpu-baseline >> $OUT/bench_sweep.jsonl 2>> $OUT/bench.err; done
+for cfg in "64 1" "128 1" "256 1" "512 1" "1024 1" "256 2"; do set -- $cfg; timeout 200 python bench.py --steps 20 --warmup 3 --batch $1 --streams $2 --no-cpu-baseline >> $OUT/bench_sweep.jsonl 2>> $OUT/bench.err; done
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o orb -- python $OLDPWD/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OLDPWD/$OUT/rocprof_bench.json 2> $OLDPWD/$OUT/rocprof.err )
 find /tmp/prof_$TAG -name "*stats*" -o -name "*kernel_trace*" | head -20 > $OUT/prof_files.txt
 for f in $(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -2); do cp $f $OUT/; done
@@ -19,6 +19,7 @@ ORB_BENCH_SHARE_GPU=1 timeout 300 python -m torch.distributed.run --nnodes=1 --n
 timeout 120 python tools/host_io_rate.py > $OUT/host_io.json 2>> $OUT/bench.err; cat $OUT/host_io.json
 timeout 200 python tools/stereo_rate.py > $OUT/stereo_rate.json 2>> $OUT/bench.err; cat $OUT/stereo_rate.json
 timeout 200 python tools/db_query_rate.py > $OUT/db_query.json 2>> $OUT/bench.err; cat $OUT/db_query.json
+ORBHIP_SERIAL=1 timeout 200 python bench.py --steps 20 --warmup 3 --batch 256 --no-cpu-baseline > $OUT/bench_serial_b256.json 2>> $OUT/bench.err
 timeout 120 tools/ubench > $OUT/ubench.txt 2>&1; cat $OUT/ubench.txt
 tail -5 $OUT/pytest_gpu.log; tail -3 $OUT/smoke.log; cat $OUT/bench.json; python - <<PY
 import json
