@@ -52,6 +52,7 @@ public:
     bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
     int type() const { return flags_type; }
     bool isContinuous() const { return step == (size_t)cols * elemSize1(flags_type); }
+    static Mat zeros(int r, int c, int type) { Mat m(r, c, type); memset(m.data, 0, (size_t)r * m.step); return m; }
     Mat clone() const { Mat m(rows, cols, flags_type); for (int y = 0; y < rows; y++) memcpy(m.data + y * m.step, data + y * step, cols * elemSize1(flags_type)); return m; }
     Mat row(int y) const { Mat m; m.rows = 1; m.cols = cols; m.flags_type = flags_type; m.step = step; m.data = data + (size_t)y * step; m.owner_ = owner_; return m; }
     template <typename T> T* ptr(int y = 0) { return (T*)(data + (size_t)y * step); }

@@ -175,6 +175,36 @@ orbhip_status orbhip_search_by_projection(int device, const orbhip_keypoint* kps
 orbhip_status orbhip_compute_stereo_matches(orbhip_ctx* left, orbhip_ctx* right, int nimg, float mbf, float mb,
                                             float* u_right, float* depth, int cap);
 
+/* -------- DBoW2 vocabulary ----------------------------------------------------------
+   ORBVocabulary = DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> (include/ORBVocabulary.h:31-32).  BowVector and
+   FeatureVector (std::map in the reference) are returned flattened in map (ascending key) order:
+     bow_id[i], bow_val[i]                      i < nbow           BowVector: word id -> weight (double)
+     fv_node[j], fv_feat[fv_off[j] .. fv_off[j+1])  j < nfv        FeatureVector: node id -> feature indices, ascending
+   Caller buffers hold n entries (fv_off: n + 1).  At most 7168 features per frame. */
+typedef struct orbhip_voc orbhip_voc;
+/* TemplatedVocabulary::loadFromTextFile (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1425; System.cc:68).  Blank lines
+   are ignored (the reference reads uninitialised variables on the empty last line of a newline-terminated file). */
+orbhip_status orbhip_voc_load_text(orbhip_voc** out, const char* path, int device);
+void orbhip_voc_destroy(orbhip_voc* voc);
+/* m_k, m_L, m_scoring, m_weighting, m_nodes.size(), size() */
+orbhip_status orbhip_voc_info(const orbhip_voc* voc, int* k, int* L, int* scoring, int* weighting, int* nnodes, int* nwords);
+/* transform(feature, word_id, weight, nid, levelsup) for n features (TemplatedVocabulary.h:1218-1262); outputs may be NULL */
+orbhip_status orbhip_voc_transform_features(orbhip_voc* voc, const uint8_t* desc /* n x 32 */, int n, int levelsup,
+                                            uint32_t* word, double* weight, uint32_t* node);
+/* transform(features, BowVector&, FeatureVector&, levelsup) (TemplatedVocabulary.h:1127-1194), host descriptors in, synchronous */
+orbhip_status orbhip_voc_transform(orbhip_voc* voc, const uint8_t* desc /* n x 32 */, int n, int levelsup,
+                                   uint32_t* bow_id, double* bow_val, int* nbow,
+                                   uint32_t* fv_node, int32_t* fv_off, uint32_t* fv_feat, int* nfv);
+/* Frame::ComputeBoW (Frame.cc:395-402) for the first nimg frames of the extractor's last call: reads the descriptors where
+   the extraction left them in HBM, asynchronous on the extractor's stream; orbhip_fetch_bow copies one frame's result out. */
+orbhip_status orbhip_compute_bow(orbhip_ctx* ctx, orbhip_voc* voc, int nimg, int levelsup);
+orbhip_status orbhip_fetch_bow(orbhip_ctx* ctx, orbhip_voc* voc, int frame, uint32_t* bow_id, double* bow_val, int* nbow,
+                               uint32_t* fv_node, int32_t* fv_off, uint32_t* fv_feat, int* nfv);
+/* TemplatedVocabulary::score(v1, v2) with the scoring object named by the file header (ScoringObject.cpp:24-313;
+   KeyFrameDatabase.cc:133,249, LoopClosing.cc:134); host arithmetic */
+double orbhip_voc_score(const orbhip_voc* voc, const uint32_t* id1, const double* val1, int n1,
+                        const uint32_t* id2, const double* val2, int n2);
+
 /* -------- measurement + stage dumps (parity tests) ----------------------------------------------------- */
 /* per-kernel HIP-event timing on the context's stream: enable, run, then read accumulated stats */
 orbhip_status orbhip_profile_enable(orbhip_ctx* ctx, int on);

@@ -20,7 +20,7 @@ def build(force=False):
     """Compile the oracle with its Makefile (g++ only; no reference sources, no OpenCV)."""
     so = os.path.join(_HERE, "liborb_oracle.so")
     if force or not os.path.exists(so) or not os.path.exists(os.path.join(_HERE, "liborb_oracle_fast.so")) \
-            or os.path.getmtime(so) < os.path.getmtime(os.path.join(_HERE, "orb_oracle.cpp")):
+            or os.path.getmtime(so) < max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("orb_oracle.cpp", "bow_oracle.cpp")):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return so
 
@@ -51,6 +51,15 @@ def lib(fast=False):
     L.orb_oracle_get_level_keypoints.argtypes = [vp, C.c_int, vp, C.c_int]
     L.orb_oracle_resize.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int]
     L.orb_oracle_blur.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+    L.orb_oracle_voc_load.argtypes = [C.c_char_p]; L.orb_oracle_voc_load.restype = vp
+    L.orb_oracle_voc_free.argtypes = [vp]
+    L.orb_oracle_voc_info.argtypes = [vp, vp]
+    L.orb_oracle_voc_transform_features.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp]
+    L.orb_oracle_voc_transform.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
+    L.orb_oracle_voc_transform.restype = C.c_int
+    L.orb_oracle_voc_score.argtypes = [C.c_int, vp, vp, C.c_int, vp, vp, C.c_int]
+    L.orb_oracle_voc_score.restype = C.c_double
+    L.orb_oracle_forb_distance.argtypes = [vp, vp]
     L.orb_oracle_cvt_gray.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
     L.orb_oracle_gauss_kernel.argtypes = [vp]
     L.orb_oracle_fast.restype = C.c_int
@@ -271,3 +280,52 @@ def features_in_area(kps, imw, imh, x, y, r, min_level, max_level):
     out = np.zeros(len(kps) + 1, np.int32)
     n = lib().orb_oracle_features_in_area(_p(kps), len(kps), imw, imh, x, y, r, min_level, max_level, _p(out), len(out))
     return out[:n].copy()
+
+
+class OracleVocabulary:
+    """DBoW2 vocabulary (TemplatedVocabulary<FORB>) restated: text loader, transform, scoring (oracle/bow_oracle.cpp)."""
+
+    def __init__(self, path):
+        self.h = lib().orb_oracle_voc_load(str(path).encode())
+        if not self.h:
+            raise ValueError(f"not a vocabulary text file: {path}")
+        info = np.zeros(6, np.int32)
+        lib().orb_oracle_voc_info(self.h, _p(info))
+        self.k, self.L, self.scoring, self.weighting, self.nnodes, self.nwords = [int(v) for v in info]
+
+    def close(self):
+        if self.h:
+            lib().orb_oracle_voc_free(self.h)
+            self.h = None
+
+    def transform_features(self, desc, levelsup):
+        desc = np.ascontiguousarray(desc, np.uint8)
+        n = len(desc)
+        w = np.zeros(n, np.uint32); v = np.zeros(n, np.float64); nd = np.zeros(n, np.uint32)
+        lib().orb_oracle_voc_transform_features(self.h, _p(desc), n, levelsup, _p(w), _p(v), _p(nd))
+        return w, v, nd
+
+    def transform(self, desc, levelsup):
+        """-> (bow ids, bow values, featvec node ids, featvec offsets [len+1], featvec feature indices), all in std::map order"""
+        desc = np.ascontiguousarray(desc, np.uint8)
+        n = len(desc)
+        bid = np.zeros(max(n, 1), np.uint32); bval = np.zeros(max(n, 1), np.float64)
+        fnode = np.zeros(max(n, 1), np.uint32); foff = np.zeros(n + 2, np.int32); ffeat = np.zeros(max(n, 1), np.uint32)
+        nfv = C.c_int(0)
+        m = lib().orb_oracle_voc_transform(self.h, _p(desc), n, levelsup, _p(bid), _p(bval), C.byref(nfv), _p(fnode), _p(foff), _p(ffeat))
+        q = nfv.value
+        return bid[:m].copy(), bval[:m].copy(), fnode[:q].copy(), foff[:q + 1].copy(), ffeat[:foff[q]].copy()
+
+    def score(self, id1, val1, id2, val2, scoring=None):
+        return voc_score(self.scoring if scoring is None else scoring, id1, val1, id2, val2)
+
+
+def voc_score(scoring, id1, val1, id2, val2):
+    id1 = np.ascontiguousarray(id1, np.uint32); id2 = np.ascontiguousarray(id2, np.uint32)
+    val1 = np.ascontiguousarray(val1, np.float64); val2 = np.ascontiguousarray(val2, np.float64)
+    return lib().orb_oracle_voc_score(int(scoring), _p(id1), _p(val1), len(id1), _p(id2), _p(val2), len(id2))
+
+
+def forb_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    return lib().orb_oracle_forb_distance(_p(a), _p(b))

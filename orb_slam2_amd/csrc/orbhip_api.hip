@@ -21,6 +21,11 @@ static orbhip_status fail(orbhip_status st, const char* fmt, ...)
     char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
     g_err = buf; return st;
 }
+orbhip_status orbhip_set_error(orbhip_status st, const char* fmt, ...)      // for the other translation units (orbhip_bow.hip)
+{
+    char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf; return st;
+}
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(ORBHIP_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 
 static inline int cvRoundF(float v) { return (int)lrintf(v); }         // round-half-even, like cvRound
@@ -403,6 +408,11 @@ extern "C" orbhip_status orbhip_extract_device(orbhip_ctx* c, int nimg, const ui
     if (row_stride < c->cfg.width) return fail(ORBHIP_ERR_INVALID, "row stride %d < width %d", row_stride, c->cfg.width);
     c->last_from_host = false;
     return run_pipeline(c, nimg, d_imgs, (long long)frame_stride, row_stride, match_prev, window, nnratio, check_ori);
+}
+
+void orbhip_internal_outputs(orbhip_ctx* c, const uint8_t** d_desc, const int** d_n, int* cap, int* last_nimg, int* device, hipStream_t* s)
+{   // where the last extraction left its descriptors (orbhip_bow.hip reads them in place)
+    *d_desc = c->d_out_desc[c->cur]; *d_n = c->d_out_n[c->cur]; *cap = c->out_cap; *last_nimg = c->last_nimg; *device = c->cfg.device; *s = c->stream;
 }
 
 extern "C" orbhip_status orbhip_sync(orbhip_ctx* c)

@@ -1,0 +1,417 @@
+// orbhip_bow.hip — DBoW2 vocabulary path of ORB_SLAM2 on gfx950:
+//   TemplatedVocabulary::loadFromTextFile      Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1425   (host, once)
+//   TemplatedVocabulary::transform             :1127-1194, :1218-1262 (tree descent with FORB::distance, FORB.cpp:81-101)
+//   BowVector::addWeight / normalize            BowVector.cpp:34-94;  FeatureVector::addFeature  FeatureVector.cpp:29-43
+//   scoring objects                             ScoringObject.cpp:24-313                                   (host, tiny)
+// as called by Frame::ComputeBoW (Frame.cc:395-402: transform(vCurrentDesc, mBowVec, mFeatVec, 4)).
+//
+// Device layout: the k-ary tree as CSR (child_start[nnodes+1], child_ids[]), 32-byte node descriptors, f64 weights, word ids.
+// ORBvoc.txt (k = 10, L = 6) is 1.1 M nodes = 35 MB of descriptors: resident in HBM, hot upper levels in L2.
+//  k_bow_descend   one thread per feature walks the tree (<= L dependent steps, k Hamming distances each, strict '<' so the
+//                  first minimum wins) -> word id, weight, node id `levelsup` levels above the leaf.
+//  k_bow_assemble  one workgroup per frame turns the per-feature triples into the two std::map's of the reference, flattened
+//                  in key order: keys (word << 32 | feature index) are rank-sorted in LDS, run heads become entries, weights of a
+//                  word are added in feature order and the L1 norm is summed in word order by ONE lane (f64 addition order is
+//                  part of the result), then every value is divided by it.  Same for (node << 32 | index) -> FeatureVector.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+#include <algorithm>
+#include "../../include/orbhip.h"
+#include "orbhip_internal.h"
+
+#define BOWCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return orbhip_set_error(ORBHIP_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+struct BowParams {
+    const uint8_t* desc; long long desc_frame_stride;        // features of frame f at desc + f*stride, 32 B each
+    const int* nfeat; int nfeat_fixed; int cap;                // per-frame count (device) or one fixed count; output stride
+    const int* child_start; const int* child_ids; const uint8_t* node_desc; const double* node_weight; const int* node_word;
+    int L, levelsup, accumulate, must_normalize, l2;
+    uint32_t* word; double* weight; uint32_t* node;            // [frame][cap]
+    uint32_t* bow_id; double* bow_val; int* nbow;              // [frame][cap], [frame]
+    uint32_t* fv_node; int* fv_off; uint32_t* fv_feat; int* nfv;   // [frame][cap], [frame][cap+1], [frame][cap], [frame]
+};
+
+__device__ __forceinline__ int bow_count(const BowParams& P, int frame) { return min(P.nfeat ? P.nfeat[frame] : P.nfeat_fixed, P.cap); }
+
+// transform(feature, word_id, weight, nid, levelsup)  (TemplatedVocabulary.h:1218-1262)
+__global__ __launch_bounds__(256) void k_bow_descend(BowParams P)
+{
+    const int frame = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= bow_count(P, frame)) return;
+    const uint4* f4 = reinterpret_cast<const uint4*>(P.desc + (long long)frame * P.desc_frame_stride + (long long)i * 32);
+    const uint4 fa = f4[0], fb = f4[1];
+    const int nid_level = P.L - P.levelsup;
+    int final_id = 0, level = 0, nid = 0;
+    int a = P.child_start[0], b = P.child_start[1];
+    do {
+        ++level;
+        int best = 0x7fffffff, best_id = 0;
+        for (int c = a; c < b; c++) {
+            const int id = P.child_ids[c];
+            const uint4* d4 = reinterpret_cast<const uint4*>(P.node_desc + (long long)id * 32);
+            const uint4 da = d4[0], db = d4[1];
+            const int d = __popc(fa.x ^ da.x) + __popc(fa.y ^ da.y) + __popc(fa.z ^ da.z) + __popc(fa.w ^ da.w) +
+                          __popc(fb.x ^ db.x) + __popc(fb.y ^ db.y) + __popc(fb.z ^ db.z) + __popc(fb.w ^ db.w);    // FORB::distance
+            if (d < best) { best = d; best_id = id; }                                   // strict: first minimum wins (:1243-1247)
+        }
+        final_id = best_id;
+        if (level == nid_level) nid = final_id;
+        a = P.child_start[final_id]; b = P.child_start[final_id + 1];
+    } while (b > a);                                                                     // !isLeaf()
+    const long long o = (long long)frame * P.cap + i;
+    P.word[o] = (uint32_t)P.node_word[final_id]; P.weight[o] = P.node_weight[final_id]; P.node[o] = (uint32_t)nid;
+}
+
+#define BA_T 256
+// in-place exclusive scan of a[0..n) by the whole workgroup, returns the total (scratch: BA_T/64 + 1 ints)
+__device__ __forceinline__ int ba_exscan(int* a, int n, int* scratch, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    const int per = (n + BA_T - 1) / BA_T, lo = min(tid * per, n), hi = min(lo + per, n);
+    int sum = 0;
+    for (int i = lo; i < hi; i++) sum += a[i];
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(incl, off); if (lane >= off) incl += u; }
+    if (lane == 63) scratch[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; w++) base += scratch[w];
+    int total = 0;
+    for (int w = 0; w < BA_T / 64; w++) total += scratch[w];
+    int run = base + incl - sum;
+    for (int i = lo; i < hi; i++) { const int v = a[i]; a[i] = run; run += v; }
+    __syncthreads();
+    return total;
+}
+
+// rank sort of n unique 64-bit keys (invalid = ~0 sorts last): out[rank] = key
+__device__ __forceinline__ void ba_rank_sort(const unsigned long long* key, unsigned long long* out, int n, int tid)
+{
+    for (int i = tid; i < n; i += BA_T) {
+        const unsigned long long k = key[i];
+        if (k == ~0ull) continue;
+        int r = 0;
+        for (int j = 0; j < n; j++) r += key[j] < k;
+        out[r] = k;
+    }
+}
+
+__global__ __launch_bounds__(BA_T) void k_bow_assemble(BowParams P)
+{
+    HIP_DYNAMIC_SHARED(unsigned long long, lds64)
+    const int frame = blockIdx.x, tid = threadIdx.x, n = bow_count(P, frame), cap = P.cap;
+    unsigned long long* key = lds64;                       // [cap]  (reused as f64 values after the sort)
+    unsigned long long* sorted = lds64 + cap;              // [cap]
+    int* flag = reinterpret_cast<int*>(lds64 + 2 * cap);   // [cap]
+    int* scratch = flag + cap;                             // [8]
+    double* vals = reinterpret_cast<double*>(key);
+    const uint32_t* word = P.word + (long long)frame * cap; const double* wt = P.weight + (long long)frame * cap; const uint32_t* node = P.node + (long long)frame * cap;
+    uint32_t* bow_id = P.bow_id + (long long)frame * cap; double* bow_val = P.bow_val + (long long)frame * cap;
+    uint32_t* fv_node = P.fv_node + (long long)frame * cap; int* fv_off = P.fv_off + (long long)frame * (cap + 1); uint32_t* fv_feat = P.fv_feat + (long long)frame * cap;
+
+    // ---- BowVector: v.addWeight(id, w) for every feature with w > 0, in feature order (:1157-1161)
+    for (int i = tid; i < n; i += BA_T) { key[i] = wt[i] > 0 ? (((unsigned long long)word[i] << 32) | (unsigned)i) : ~0ull; flag[i] = wt[i] > 0; }
+    __syncthreads();
+    const int m = ba_exscan(flag, n, scratch, tid);        // features that are "not stopped"
+    ba_rank_sort(key, sorted, n, tid);
+    __syncthreads();
+    for (int i = tid; i < m; i += BA_T) flag[i] = (i == 0) || ((sorted[i] >> 32) != (sorted[i - 1] >> 32));
+    __syncthreads();
+    for (int i = tid; i < m; i += BA_T) key[i] = (unsigned long long)flag[i];      // keep the head marks: the scan overwrites flag
+    __syncthreads();
+    const int nb = ba_exscan(flag, m, scratch, tid);
+    for (int i = tid; i < m; i += BA_T) {
+        if (!key[i]) continue;
+        const uint32_t w = (uint32_t)(sorted[i] >> 32);
+        double v = wt[(uint32_t)sorted[i]];
+        if (P.accumulate) for (int j = i + 1; j < m && (uint32_t)(sorted[j] >> 32) == w; j++) v += wt[(uint32_t)sorted[j]];   // `vit->second += v`
+        bow_id[flag[i]] = w; bow_val[flag[i]] = v;                                         // addIfNotExist keeps the first
+    }
+    __syncthreads();
+    for (int i = tid; i < nb; i += BA_T) vals[i] = bow_val[i];
+    __syncthreads();
+    if (P.accumulate && nb > 0 && !P.must_normalize) {                                      // :1164-1170
+        const double nd = (double)nb;
+        for (int i = tid; i < nb; i += BA_T) { vals[i] = vals[i] / nd; bow_val[i] = vals[i]; }
+    }
+    if (P.must_normalize) {                                                                 // BowVector::normalize
+        if (tid == 0) {
+            double norm = 0.0;
+            if (!P.l2) for (int i = 0; i < nb; i++) norm += fabs(vals[i]);
+            else { for (int i = 0; i < nb; i++) norm += vals[i] * vals[i]; norm = sqrt(norm); }
+            reinterpret_cast<double*>(sorted)[0] = norm;
+        }
+        __syncthreads();
+        const double norm = reinterpret_cast<double*>(sorted)[0];
+        if (norm > 0.0) for (int i = tid; i < nb; i += BA_T) bow_val[i] = vals[i] / norm;
+    }
+    if (tid == 0) P.nbow[frame] = nb;
+    __syncthreads();
+
+    // ---- FeatureVector: fv.addFeature(nid, i_feature) for the same features
+    for (int i = tid; i < n; i += BA_T) key[i] = wt[i] > 0 ? (((unsigned long long)node[i] << 32) | (unsigned)i) : ~0ull;
+    __syncthreads();
+    ba_rank_sort(key, sorted, n, tid);
+    __syncthreads();
+    for (int i = tid; i < m; i += BA_T) { flag[i] = (i == 0) || ((sorted[i] >> 32) != (sorted[i - 1] >> 32)); fv_feat[i] = (uint32_t)sorted[i]; }
+    __syncthreads();
+    for (int i = tid; i < m; i += BA_T) key[i] = (unsigned long long)flag[i];
+    __syncthreads();
+    const int nf = ba_exscan(flag, m, scratch, tid);
+    for (int i = tid; i < m; i += BA_T) if (key[i]) { fv_node[flag[i]] = (uint32_t)(sorted[i] >> 32); fv_off[flag[i]] = i; }
+    if (tid == 0) { fv_off[nf] = m; P.nfv[frame] = nf; }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct orbhip_voc {
+    int k = 0, L = 0, scoring = 0, weighting = 0, nnodes = 0, nwords = 0, device = 0;
+    std::vector<int> child_start, child_ids, node_word; std::vector<uint8_t> node_desc; std::vector<double> node_weight;
+    int *d_child_start = nullptr, *d_child_ids = nullptr, *d_node_word = nullptr; uint8_t* d_node_desc = nullptr; double* d_node_weight = nullptr;
+    hipStream_t stream = nullptr;
+    // workspace for nframes x cap features
+    int ws_frames = 0, ws_cap = 0;
+    uint8_t* d_desc = nullptr; uint32_t *d_word = nullptr, *d_node = nullptr, *d_bow_id = nullptr, *d_fv_node = nullptr, *d_fv_feat = nullptr;
+    double *d_weight = nullptr, *d_bow_val = nullptr; int *d_nbow = nullptr, *d_nfv = nullptr, *d_fv_off = nullptr;
+    int last_frames = 0;
+};
+
+static void voc_free_ws(orbhip_voc* v)
+{
+    void* ptrs[] = {v->d_desc, v->d_word, v->d_node, v->d_bow_id, v->d_fv_node, v->d_fv_feat, v->d_weight, v->d_bow_val, v->d_nbow, v->d_nfv, v->d_fv_off};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    v->d_desc = nullptr; v->d_word = v->d_node = v->d_bow_id = v->d_fv_node = v->d_fv_feat = nullptr; v->d_weight = v->d_bow_val = nullptr; v->d_nbow = v->d_nfv = v->d_fv_off = nullptr;
+    v->ws_frames = v->ws_cap = 0;
+}
+
+#define BOW_MAX_FEATURES 7168          // 20 B of LDS per feature in k_bow_assemble
+
+static orbhip_status voc_ensure_ws(orbhip_voc* v, int nframes, int cap, bool with_desc)
+{
+    if (cap > BOW_MAX_FEATURES) return orbhip_set_error(ORBHIP_ERR_UNSUPPORTED, "%d features per frame (at most %d)", cap, BOW_MAX_FEATURES);
+    if (nframes <= v->ws_frames && cap == v->ws_cap && (!with_desc || v->d_desc)) return ORBHIP_OK;
+    BOWCHK(hipStreamSynchronize(v->stream));
+    voc_free_ws(v);
+    const size_t F = (size_t)nframes, C = (size_t)cap;
+    BOWCHK(hipMalloc((void**)&v->d_desc, F * C * 32 + 64));
+    BOWCHK(hipMalloc((void**)&v->d_word, F * C * 4)); BOWCHK(hipMalloc((void**)&v->d_node, F * C * 4)); BOWCHK(hipMalloc((void**)&v->d_weight, F * C * 8));
+    BOWCHK(hipMalloc((void**)&v->d_bow_id, F * C * 4)); BOWCHK(hipMalloc((void**)&v->d_bow_val, F * C * 8));
+    BOWCHK(hipMalloc((void**)&v->d_fv_node, F * C * 4)); BOWCHK(hipMalloc((void**)&v->d_fv_feat, F * C * 4)); BOWCHK(hipMalloc((void**)&v->d_fv_off, F * (C + 1) * 4));
+    BOWCHK(hipMalloc((void**)&v->d_nbow, F * 4)); BOWCHK(hipMalloc((void**)&v->d_nfv, F * 4));
+    v->ws_frames = nframes; v->ws_cap = cap;
+    return ORBHIP_OK;
+}
+
+static orbhip_status voc_run(orbhip_voc* v, const uint8_t* d_desc, long long frame_stride, const int* d_nfeat, int nfeat_fixed, int nframes, int cap,
+                             int levelsup, bool assemble, hipStream_t s)
+{
+    BowParams P; memset(&P, 0, sizeof P);
+    P.desc = d_desc; P.desc_frame_stride = frame_stride; P.nfeat = d_nfeat; P.nfeat_fixed = nfeat_fixed; P.cap = cap;
+    P.child_start = v->d_child_start; P.child_ids = v->d_child_ids; P.node_desc = v->d_node_desc; P.node_weight = v->d_node_weight; P.node_word = v->d_node_word;
+    P.L = v->L; P.levelsup = levelsup;
+    P.accumulate = (v->weighting == 0 || v->weighting == 1);                     // TF_IDF, TF (:1142) vs IDF, BINARY (:1173)
+    P.must_normalize = v->scoring != 5; P.l2 = v->scoring == 1;                    // ScoringObject.h:73-90
+    P.word = v->d_word; P.weight = v->d_weight; P.node = v->d_node;
+    P.bow_id = v->d_bow_id; P.bow_val = v->d_bow_val; P.nbow = v->d_nbow; P.fv_node = v->d_fv_node; P.fv_off = v->d_fv_off; P.fv_feat = v->d_fv_feat; P.nfv = v->d_nfv;
+    if (cap <= 0 || nframes <= 0) return ORBHIP_OK;
+    hipLaunchKernelGGL(k_bow_descend, dim3((cap + 255) / 256, nframes, 1), dim3(256, 1, 1), 0, s, P);
+    if (assemble) hipLaunchKernelGGL(k_bow_assemble, dim3(nframes, 1, 1), dim3(BA_T, 1, 1), (size_t)cap * 20 + 64, s, P);
+    BOWCHK(hipGetLastError());
+    v->last_frames = nframes;
+    return ORBHIP_OK;
+}
+
+extern "C" void orbhip_voc_destroy(orbhip_voc* v)
+{
+    if (!v) return;
+    (void)hipSetDevice(v->device);
+    if (v->stream) (void)hipStreamSynchronize(v->stream);
+    voc_free_ws(v);
+    void* ptrs[] = {v->d_child_start, v->d_child_ids, v->d_node_word, v->d_node_desc, v->d_node_weight};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (v->stream) (void)hipStreamDestroy(v->stream);
+    delete v;
+}
+
+// TemplatedVocabulary::loadFromTextFile (TemplatedVocabulary.h:1338-1425).  Blank lines are ignored (the
+// reference reads uninitialised locals on the empty last line of a file that ends with a newline).
+extern "C" orbhip_status orbhip_voc_load_text(orbhip_voc** out, const char* path, int device)
+{
+    if (!out || !path) return orbhip_set_error(ORBHIP_ERR_INVALID, "null argument");
+    *out = nullptr;
+    std::ifstream f(path);
+    if (!f.is_open()) return orbhip_set_error(ORBHIP_ERR_INVALID, "cannot open vocabulary file %s", path);
+    std::string s;
+    std::getline(f, s);
+    int k = -1, L = -1, n1 = -1, n2 = -1;
+    { std::stringstream ss; ss << s; ss >> k; ss >> L; ss >> n1; ss >> n2; }
+    if (k < 0 || k > 20 || L < 1 || L > 10 || n1 < 0 || n1 > 5 || n2 < 0 || n2 > 3)                 // :1358-1362
+        return orbhip_set_error(ORBHIP_ERR_INVALID, "Vocabulary loading failure: This is not a correct text file!");
+    std::vector<int> parent(1, 0), word(1, -1); std::vector<uint8_t> desc(32, 0); std::vector<double> weight(1, 0.0);
+    std::vector<int> nchild(1, 0);
+    int nwords = 0;
+    while (std::getline(f, s)) {
+        if (s.find_first_not_of(" \t\r\n") == std::string::npos) continue;
+        const char* p = s.c_str(); char* e = nullptr;
+        const int nid = (int)parent.size();
+        const long pid = strtol(p, &e, 10); p = e;
+        if (pid < 0 || pid >= nid) return orbhip_set_error(ORBHIP_ERR_INVALID, "vocabulary node %d names parent %ld", nid, pid);
+        const long leaf = strtol(p, &e, 10); p = e;
+        parent.push_back((int)pid); nchild.push_back(0); nchild[pid]++;
+        desc.resize((size_t)(nid + 1) * 32);
+        for (int i = 0; i < 32; i++) { const long b = strtol(p, &e, 10); p = e; desc[(size_t)nid * 32 + i] = (uint8_t)b; }   // FORB::fromString
+        weight.push_back(strtod(p, &e));
+        word.push_back(leaf > 0 ? nwords++ : -1);
+    }
+    const int nn = (int)parent.size();
+    orbhip_voc* v = new orbhip_voc();
+    v->k = k; v->L = L; v->scoring = n1; v->weighting = n2; v->nnodes = nn; v->nwords = nwords; v->device = device;
+    v->child_start.assign(nn + 1, 0);
+    for (int i = 0; i < nn; i++) v->child_start[i + 1] = v->child_start[i] + nchild[i];
+    v->child_ids.assign(std::max(nn - 1, 1), 0);
+    { std::vector<int> fill(v->child_start.begin(), v->child_start.end() - 1); for (int i = 1; i < nn; i++) v->child_ids[fill[parent[i]]++] = i; }   // children in file order
+    v->node_word = word; v->node_desc = desc; v->node_weight = weight;
+    for (int i = 0; i < nn; i++)                                     // a leaf flag on an inner node / a childless inner node would make the descent undefined
+        if ((word[i] >= 0) != (nchild[i] == 0) && i != 0) { delete v; return orbhip_set_error(ORBHIP_ERR_INVALID, "vocabulary node %d: leaf flag and children disagree", i); }
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void**)&v->d_child_start, (size_t)(nn + 1) * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&v->d_child_ids, v->child_ids.size() * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&v->d_node_word, (size_t)nn * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&v->d_node_desc, (size_t)nn * 32);
+    if (e == hipSuccess) e = hipMalloc((void**)&v->d_node_weight, (size_t)nn * 8);
+    if (e == hipSuccess) e = hipMemcpy(v->d_child_start, v->child_start.data(), (size_t)(nn + 1) * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(v->d_child_ids, v->child_ids.data(), v->child_ids.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(v->d_node_word, v->node_word.data(), (size_t)nn * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(v->d_node_desc, v->node_desc.data(), (size_t)nn * 32, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(v->d_node_weight, v->node_weight.data(), (size_t)nn * 8, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { orbhip_voc_destroy(v); return orbhip_set_error(ORBHIP_ERR_HIP, "vocabulary upload failed: %s", hipGetErrorString(e)); }
+    *out = v;
+    return ORBHIP_OK;
+}
+
+extern "C" orbhip_status orbhip_voc_info(const orbhip_voc* v, int* k, int* L, int* scoring, int* weighting, int* nnodes, int* nwords)
+{
+    if (!v) return orbhip_set_error(ORBHIP_ERR_INVALID, "null vocabulary");
+    if (k) *k = v->k; if (L) *L = v->L; if (scoring) *scoring = v->scoring; if (weighting) *weighting = v->weighting; if (nnodes) *nnodes = v->nnodes; if (nwords) *nwords = v->nwords;
+    return ORBHIP_OK;
+}
+
+static orbhip_status voc_upload(orbhip_voc* v, const uint8_t* desc, int n)
+{
+    BOWCHK(hipSetDevice(v->device));
+    orbhip_status st = voc_ensure_ws(v, 1, std::max(n, 1), true); if (st != ORBHIP_OK) return st;
+    if (n > 0) BOWCHK(hipMemcpyAsync(v->d_desc, desc, (size_t)n * 32, hipMemcpyHostToDevice, v->stream));
+    return ORBHIP_OK;
+}
+
+extern "C" orbhip_status orbhip_voc_transform_features(orbhip_voc* v, const uint8_t* desc, int n, int levelsup, uint32_t* word, double* weight, uint32_t* node)
+{
+    if (!v || (n > 0 && !desc) || n < 0) return orbhip_set_error(ORBHIP_ERR_INVALID, "bad argument");
+    if (v->nwords == 0 || n == 0) return ORBHIP_OK;
+    orbhip_status st = voc_upload(v, desc, n); if (st != ORBHIP_OK) return st;
+    st = voc_run(v, v->d_desc, 0, nullptr, n, 1, v->ws_cap, levelsup, false, v->stream); if (st != ORBHIP_OK) return st;
+    if (word) BOWCHK(hipMemcpyAsync(word, v->d_word, (size_t)n * 4, hipMemcpyDeviceToHost, v->stream));
+    if (weight) BOWCHK(hipMemcpyAsync(weight, v->d_weight, (size_t)n * 8, hipMemcpyDeviceToHost, v->stream));
+    if (node) BOWCHK(hipMemcpyAsync(node, v->d_node, (size_t)n * 4, hipMemcpyDeviceToHost, v->stream));
+    BOWCHK(hipStreamSynchronize(v->stream));
+    return ORBHIP_OK;
+}
+
+static orbhip_status voc_fetch(orbhip_voc* v, int frame, hipStream_t s, uint32_t* bow_id, double* bow_val, int* nbow, uint32_t* fv_node, int32_t* fv_off, uint32_t* fv_feat, int* nfv)
+{
+    const size_t C = (size_t)v->ws_cap;
+    int cnt[2] = {0, 0};
+    BOWCHK(hipMemcpyAsync(&cnt[0], v->d_nbow + frame, 4, hipMemcpyDeviceToHost, s));
+    BOWCHK(hipMemcpyAsync(&cnt[1], v->d_nfv + frame, 4, hipMemcpyDeviceToHost, s));
+    BOWCHK(hipStreamSynchronize(s));
+    const int nb = cnt[0], nf = cnt[1];
+    int m = 0;
+    if (nf > 0 || fv_off) { BOWCHK(hipMemcpyAsync(&m, v->d_fv_off + frame * (C + 1) + nf, 4, hipMemcpyDeviceToHost, s)); BOWCHK(hipStreamSynchronize(s)); }
+    if (nb > 0 && bow_id) BOWCHK(hipMemcpyAsync(bow_id, v->d_bow_id + frame * C, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
+    if (nb > 0 && bow_val) BOWCHK(hipMemcpyAsync(bow_val, v->d_bow_val + frame * C, (size_t)nb * 8, hipMemcpyDeviceToHost, s));
+    if (nf > 0 && fv_node) BOWCHK(hipMemcpyAsync(fv_node, v->d_fv_node + frame * C, (size_t)nf * 4, hipMemcpyDeviceToHost, s));
+    if (fv_off) BOWCHK(hipMemcpyAsync(fv_off, v->d_fv_off + frame * (C + 1), (size_t)(nf + 1) * 4, hipMemcpyDeviceToHost, s));
+    if (m > 0 && fv_feat) BOWCHK(hipMemcpyAsync(fv_feat, v->d_fv_feat + frame * C, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+    BOWCHK(hipStreamSynchronize(s));
+    if (nbow) *nbow = nb; if (nfv) *nfv = nf;
+    return ORBHIP_OK;
+}
+
+extern "C" orbhip_status orbhip_voc_transform(orbhip_voc* v, const uint8_t* desc, int n, int levelsup, uint32_t* bow_id, double* bow_val, int* nbow,
+                                              uint32_t* fv_node, int32_t* fv_off, uint32_t* fv_feat, int* nfv)
+{
+    if (!v || (n > 0 && !desc) || n < 0) return orbhip_set_error(ORBHIP_ERR_INVALID, "bad argument");
+    if (nbow) *nbow = 0; if (nfv) *nfv = 0; if (fv_off) fv_off[0] = 0;
+    if (v->nwords == 0 || n == 0) return ORBHIP_OK;                              // v.clear(); fv.clear(); if(empty()) return;  (:1130-1136)
+    orbhip_status st = voc_upload(v, desc, n); if (st != ORBHIP_OK) return st;
+    st = voc_run(v, v->d_desc, 0, nullptr, n, 1, v->ws_cap, levelsup, true, v->stream); if (st != ORBHIP_OK) return st;
+    return voc_fetch(v, 0, v->stream, bow_id, bow_val, nbow, fv_node, fv_off, fv_feat, nfv);
+}
+
+// Frame::ComputeBoW (Frame.cc:395-402) for the frames of the extractor's last call: descriptors are read where k_describe left them
+extern "C" orbhip_status orbhip_compute_bow(orbhip_ctx* ctx, orbhip_voc* v, int nimg, int levelsup)
+{
+    if (!ctx || !v) return orbhip_set_error(ORBHIP_ERR_INVALID, "null argument");
+    const uint8_t* d_desc = nullptr; const int* d_n = nullptr; int cap = 0, last = 0, device = 0; hipStream_t s = nullptr;
+    orbhip_internal_outputs(ctx, &d_desc, &d_n, &cap, &last, &device, &s);
+    if (nimg < 1 || nimg > last) return orbhip_set_error(ORBHIP_ERR_INVALID, "nimg %d but the last call processed %d frames", nimg, last);
+    if (device != v->device) return orbhip_set_error(ORBHIP_ERR_INVALID, "extractor on device %d, vocabulary on device %d", device, v->device);
+    BOWCHK(hipSetDevice(v->device));
+    orbhip_status st = voc_ensure_ws(v, nimg, cap, false); if (st != ORBHIP_OK) return st;
+    if (v->nwords == 0) { BOWCHK(hipMemsetAsync(v->d_nbow, 0, (size_t)nimg * 4, s)); BOWCHK(hipMemsetAsync(v->d_nfv, 0, (size_t)nimg * 4, s)); BOWCHK(hipMemsetAsync(v->d_fv_off, 0, (size_t)nimg * (cap + 1) * 4, s)); return ORBHIP_OK; }
+    return voc_run(v, d_desc, (long long)cap * 32, d_n, 0, nimg, cap, levelsup, true, s);     // on the extractor's stream: ordered after k_describe
+}
+
+extern "C" orbhip_status orbhip_fetch_bow(orbhip_ctx* ctx, orbhip_voc* v, int frame, uint32_t* bow_id, double* bow_val, int* nbow,
+                                          uint32_t* fv_node, int32_t* fv_off, uint32_t* fv_feat, int* nfv)
+{
+    if (!ctx || !v) return orbhip_set_error(ORBHIP_ERR_INVALID, "null argument");
+    if (frame < 0 || frame >= v->last_frames) return orbhip_set_error(ORBHIP_ERR_INVALID, "frame %d outside the %d frames of the last orbhip_compute_bow", frame, v->last_frames);
+    const uint8_t* d_desc = nullptr; const int* d_n = nullptr; int cap = 0, last = 0, device = 0; hipStream_t s = nullptr;
+    orbhip_internal_outputs(ctx, &d_desc, &d_n, &cap, &last, &device, &s);
+    BOWCHK(hipSetDevice(v->device));
+    return voc_fetch(v, frame, s, bow_id, bow_val, nbow, fv_node, fv_off, fv_feat, nfv);
+}
+
+// TemplatedVocabulary::score -> the scoring object selected by the file header (ScoringObject.cpp:24-313); two ascending
+// (id, value) arrays.  A few thousand flops on the host: not worth a launch.
+extern "C" double orbhip_voc_score(const orbhip_voc* v, const uint32_t* id1, const double* val1, int n1, const uint32_t* id2, const double* val2, int n2)
+{
+    if (!v) return 0.0;
+    const int sc = v->scoring;
+    static const double LOG_EPS = std::log(2.220446049250313e-16);
+    int a = 0, b = 0; double s = 0;
+    while (a < n1 && b < n2) {
+        const double vi = val1[a], wi = val2[b];
+        if (id1[a] == id2[b]) {
+            switch (sc) {
+            case 0: s += std::fabs(vi - wi) - std::fabs(vi) - std::fabs(wi); break;
+            case 1: case 5: s += vi * wi; break;
+            case 2: if (vi + wi != 0.0) s += vi * wi / (vi + wi); break;
+            case 3: if (vi != 0 && wi != 0) s += vi * std::log(vi / wi); break;
+            case 4: s += std::sqrt(vi * wi); break;
+            }
+            a++; b++;
+        } else if (id1[a] < id2[b]) {
+            if (sc == 3) { s += vi * (std::log(vi) - LOG_EPS); a++; }
+            else a = (int)(std::lower_bound(id1 + a, id1 + n1, id2[b]) - id1);
+        } else b = (int)(std::lower_bound(id2 + b, id2 + n2, id1[a]) - id2);
+    }
+    switch (sc) {
+    case 0: return -s / 2.0;
+    case 1: return s >= 1 ? 1.0 : 1.0 - std::sqrt(1.0 - s);
+    case 2: return 2. * s;
+    case 3: for (; a < n1; a++) if (val1[a] != 0) s += val1[a] * (std::log(val1[a]) - LOG_EPS); return s;
+    default: return s;
+    }
+}

@@ -132,3 +132,7 @@ void orbhip_launch_hamming_nn(const uint8_t* d_q, int nq, const uint8_t* d_db, l
 void orbhip_launch_match_grid(const MatchParams& M, int nslots, hipStream_t s);
 void orbhip_launch_match_candidates(const MatchParams& M, int nslots, hipStream_t s);
 void orbhip_launch_match_select(const MatchParams& M, int nslots, hipStream_t s);
+
+// shared with orbhip_bow.hip
+orbhip_status orbhip_set_error(orbhip_status st, const char* fmt, ...);
+void orbhip_internal_outputs(orbhip_ctx* c, const uint8_t** d_desc, const int** d_n, int* cap, int* last_nimg, int* device, hipStream_t* s);

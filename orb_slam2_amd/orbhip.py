@@ -27,7 +27,8 @@ SYMBOLS = [
     "orbhip_profile_num_kernels", "orbhip_profile_get", "orbhip_profile_reset", "orbhip_algorithmic_bytes_per_frame",
     "orbhip_algorithmic_bytes_per_frame_kernel", "orbhip_debug_blurred_level", "orbhip_debug_candidates",
     "orbhip_compute_stereo_matches", "orbhip_search_by_projection", "orbhip_extract_batch_color",
-    "orbhip_extract_device_color",
+    "orbhip_extract_device_color", "orbhip_voc_load_text", "orbhip_voc_destroy", "orbhip_voc_info", "orbhip_voc_transform_features",
+    "orbhip_voc_transform", "orbhip_compute_bow", "orbhip_fetch_bow", "orbhip_voc_score",
 ]
 
 
@@ -72,6 +73,16 @@ def lib(path=None):
     L.orbhip_extract_device.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]
     L.orbhip_extract_batch_color.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp]
     L.orbhip_extract_device_color.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]
+    L.orbhip_voc_load_text.argtypes = [C.POINTER(vp), C.c_char_p, C.c_int]
+    L.orbhip_voc_destroy.argtypes = [vp]
+    L.orbhip_voc_destroy.restype = None
+    L.orbhip_voc_info.argtypes = [vp, ip, ip, ip, ip, ip, ip]
+    L.orbhip_voc_transform_features.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp]
+    L.orbhip_voc_transform.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, ip, vp, vp, vp, ip]
+    L.orbhip_compute_bow.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.orbhip_fetch_bow.argtypes = [vp, vp, C.c_int, vp, vp, ip, vp, vp, vp, ip]
+    L.orbhip_voc_score.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int]
+    L.orbhip_voc_score.restype = C.c_double
     L.orbhip_sync.argtypes = [vp]
     L.orbhip_fetch.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp]
     L.orbhip_fetch_matches.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
@@ -356,3 +367,82 @@ def hamming_nn_device(stream, d_q, nq, d_db, ndb, d_best_idx, d_best_dist, d_sec
     _check(lib(library).orbhip_hamming_nn_device(C.c_void_p(stream) if stream else None, C.c_void_p(d_q), nq, C.c_void_p(d_db), ndb,
                                           index_base, C.c_void_p(d_best_idx), C.c_void_p(d_best_dist), C.c_void_p(d_second)),
            "orbhip_hamming_nn_device")
+
+
+class ORBVocabulary:
+    """Mirror of ORB_SLAM2::ORBVocabulary (include/ORBVocabulary.h:31-32 = DBoW2::TemplatedVocabulary<FORB>): text loader,
+    transform (Frame::ComputeBoW, Frame.cc:395-402) and score on the GPU library.  BowVector / FeatureVector come back as
+    flat arrays in std::map order: (word ids, values) and (node ids, offsets, feature indices)."""
+
+    def __init__(self, path=None, device=0, library=None):
+        self.L_ = lib(library)
+        self.h = C.c_void_p()
+        self.device = device
+        if path is not None and not self.loadFromTextFile(path):
+            raise OrbHipError(self.L_.orbhip_last_error().decode())
+
+    def loadFromTextFile(self, path):
+        self.close()
+        st = self.L_.orbhip_voc_load_text(C.byref(self.h), str(path).encode(), self.device)
+        if st != 0:
+            self.h = C.c_void_p()
+            return False
+        v = [C.c_int() for _ in range(6)]
+        _check(self.L_.orbhip_voc_info(self.h, *[C.byref(x) for x in v]), "orbhip_voc_info", self.L_)
+        self.k, self.L, self.scoring, self.weighting, self.nnodes, self.nwords = [x.value for x in v]
+        return True
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L_.orbhip_voc_destroy(self.h)
+        self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def size(self):
+        return self.nwords
+
+    def transform_features(self, desc, levelsup):
+        desc = np.ascontiguousarray(desc, np.uint8)
+        n = len(desc)
+        w = np.zeros(n, np.uint32); v = np.zeros(n, np.float64); nd = np.zeros(n, np.uint32)
+        _check(self.L_.orbhip_voc_transform_features(self.h, _p(desc), n, levelsup, _p(w), _p(v), _p(nd)), "orbhip_voc_transform_features", self.L_)
+        return w, v, nd
+
+    @staticmethod
+    def _outputs(n):
+        return (np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.float64), np.zeros(max(n, 1), np.uint32),
+                np.zeros(n + 2, np.int32), np.zeros(max(n, 1), np.uint32), C.c_int(0), C.c_int(0))
+
+    @staticmethod
+    def _trim(bid, bval, fnode, foff, ffeat, nb, nf):
+        m, q = nb.value, nf.value
+        return bid[:m].copy(), bval[:m].copy(), fnode[:q].copy(), foff[:q + 1].copy(), ffeat[:foff[q]].copy()
+
+    def transform(self, desc, levelsup=4):
+        desc = np.ascontiguousarray(desc, np.uint8)
+        n = len(desc)
+        bid, bval, fnode, foff, ffeat, nb, nf = self._outputs(n)
+        _check(self.L_.orbhip_voc_transform(self.h, _p(desc), n, levelsup, _p(bid), _p(bval), C.byref(nb), _p(fnode), _p(foff), _p(ffeat), C.byref(nf)),
+               "orbhip_voc_transform", self.L_)
+        return self._trim(bid, bval, fnode, foff, ffeat, nb, nf)
+
+    def compute_bow(self, extractor, nimg, levelsup=4):
+        """Frame::ComputeBoW for the frames of `extractor`'s last call, descriptors read in place on the device."""
+        _check(self.L_.orbhip_compute_bow(extractor.h, self.h, nimg, levelsup), "orbhip_compute_bow", self.L_)
+
+    def fetch_bow(self, extractor, frame):
+        n = extractor.capacity
+        bid, bval, fnode, foff, ffeat, nb, nf = self._outputs(n)
+        _check(self.L_.orbhip_fetch_bow(extractor.h, self.h, frame, _p(bid), _p(bval), C.byref(nb), _p(fnode), _p(foff), _p(ffeat), C.byref(nf)),
+               "orbhip_fetch_bow", self.L_)
+        return self._trim(bid, bval, fnode, foff, ffeat, nb, nf)
+
+    def score(self, id1, val1, id2, val2):
+        id1 = np.ascontiguousarray(id1, np.uint32); id2 = np.ascontiguousarray(id2, np.uint32)
+        val1 = np.ascontiguousarray(val1, np.float64); val2 = np.ascontiguousarray(val2, np.float64)
+        return self.L_.orbhip_voc_score(self.h, _p(id1), _p(val1), len(id1), _p(id2), _p(val2), len(id2))
