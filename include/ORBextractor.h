@@ -50,6 +50,8 @@ public:
     // must have processed their image of the current frame (Frame.cc:78-81).  N = number of left keypoints (Frame::N).
     // Fills mvuRight / mvDepth exactly like the reference; reads keypoints, descriptors and pyramids that are still in HBM.
     void ComputeStereoMatches(ORBextractor& right, float mbf, float mb, int N, std::vector<float>& mvuRight, std::vector<float>& mvDepth);
+    // The device context of the last image (NULL before the first call): ORBVocabulary::ComputeBoW reads the descriptors there.
+    orbhip_ctx* Context() { return mpCtx; }
     // HIP device this extractor runs on (default 0); takes effect at the next (re)creation of the device context.
     void SetDevice(int device) { mnDevice = device; }
 

@@ -1,11 +1,12 @@
 // Drives the drop-in classes exactly like the reference's callers do (Tracking.cc:119-125 constructs the extractor,
 // Frame::Frame calls ExtractORB, Tracking.cc:599-600 calls SearchForInitialization) and dumps the results for pytest.
-// usage: test_dropin W H nfeatures in0.raw in1.raw out.bin
+// usage: test_dropin W H nfeatures in0.raw in1.raw out.bin [vocabulary.txt]
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 #include "ORBextractor.h"
 #include "ORBmatcher.h"
+#include "ORBVocabulary.h"
 #include "Frame.h"
 
 float ORB_SLAM2::Frame::mnMinX, ORB_SLAM2::Frame::mnMaxX, ORB_SLAM2::Frame::mnMinY, ORB_SLAM2::Frame::mnMaxY;
@@ -53,6 +54,30 @@ int main(int argc, char** argv)
     int nc = (int)kc.size(); fwrite(&nc, 4, 1, f);
     if (nc) { fwrite(&kc[0], sizeof(cv::KeyPoint), nc, f); for (int i = 0; i < nc; i++) fwrite(dc.ptr(i), 1, 32, f); }
     fwrite(ex->mvImagePyramid[0].data, 1, (size_t)W * H, f);
+    // bag of words like System.cc:68 + Frame::ComputeBoW (Frame.cc:395-402) + KeyFrameDatabase.cc:133
+    if (argc > 7) {
+        ORB_SLAM2::ORBVocabulary voc;
+        if (!voc.loadFromTextFile(argv[7])) return 4;
+        DBoW2::BowVector b1, b2, b3; DBoW2::FeatureVector f1, f2, f3;
+        std::vector<cv::Mat> rows(F1.mDescriptors.rows);                                   // Converter::toDescriptorVector
+        for (int i = 0; i < F1.mDescriptors.rows; i++) rows[i] = F1.mDescriptors.row(i);
+        voc.transform(rows, b1, f1, 4);
+        voc.transform(F2.mDescriptors, b2, f2, 4);
+        std::vector<cv::KeyPoint> kk; cv::Mat dd;
+        (*ex)(im[1], cv::Mat(), kk, dd);
+        voc.ComputeBoW(*ex, b3, f3, 4);                                                    // descriptors of im[1] still on the device
+        const DBoW2::BowVector* bs[3] = {&b1, &b2, &b3}; const DBoW2::FeatureVector* fs[3] = {&f1, &f2, &f3};
+        for (int q = 0; q < 3; q++) {
+            int nb = (int)bs[q]->size(); fwrite(&nb, 4, 1, f);
+            for (DBoW2::BowVector::const_iterator it = bs[q]->begin(); it != bs[q]->end(); ++it) { fwrite(&it->first, 4, 1, f); fwrite(&it->second, 8, 1, f); }
+            int nf = (int)fs[q]->size(); fwrite(&nf, 4, 1, f);
+            for (DBoW2::FeatureVector::const_iterator it = fs[q]->begin(); it != fs[q]->end(); ++it) {
+                int cnt = (int)it->second.size(); fwrite(&it->first, 4, 1, f); fwrite(&cnt, 4, 1, f); fwrite(&it->second[0], 4, cnt, f);
+            }
+        }
+        const double sc = voc.score(b1, b2); fwrite(&sc, 8, 1, f);
+        const unsigned int nw = voc.size(); fwrite(&nw, 4, 1, f);
+    }
     fclose(f);
     delete ex; delete exL; delete exR;
     return 0;

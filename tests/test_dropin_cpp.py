@@ -21,7 +21,8 @@ def _run(exe, tmp_path, oracle):
     for k in range(2):
         seq[k].tofile(str(tmp_path / f"in{k}.raw"))
     out = tmp_path / "out.bin"
-    subprocess.check_call([exe, str(w), str(h), str(n), str(tmp_path / "in0.raw"), str(tmp_path / "in1.raw"), str(out)])
+    voc_path = os.path.join(ROOT, "tests", "golden", "voc_k6_L3_ref.txt")
+    subprocess.check_call([exe, str(w), str(h), str(n), str(tmp_path / "in0.raw"), str(tmp_path / "in1.raw"), str(out), voc_path])
     buf = out.read_bytes()
     off = 0
     frames = []
@@ -47,6 +48,20 @@ def _run(exe, tmp_path, oracle):
     kc = np.frombuffer(buf, orb_slam2_amd.KEYPOINT_DTYPE, nc, off); off += 28 * nc
     dc = np.frombuffer(buf, np.uint8, 32 * nc, off).reshape(nc, 32); off += 32 * nc
     gray0 = np.frombuffer(buf, np.uint8, w * h, off).reshape(h, w)
+    off += w * h
+    bows = []
+    for _ in range(3):
+        (nb,) = struct.unpack_from("<i", buf, off); off += 4
+        rec = np.frombuffer(buf, np.dtype([("id", "<u4"), ("val", "<f8")]), nb, off); off += 12 * nb
+        (nf,) = struct.unpack_from("<i", buf, off); off += 4
+        fnode, foff, ffeat = [], [0], []
+        for _ in range(nf):
+            nid, cnt = struct.unpack_from("<Ii", buf, off); off += 8
+            ffeat.extend(np.frombuffer(buf, np.uint32, cnt, off).tolist()); off += 4 * cnt
+            fnode.append(nid); foff.append(len(ffeat))
+        bows.append((rec["id"].copy(), rec["val"].copy(), np.array(fnode, np.uint32), np.array(foff, np.int32), np.array(ffeat, np.uint32)))
+    (score12,) = struct.unpack_from("<d", buf, off); off += 8
+    (nwords,) = struct.unpack_from("<I", buf, off); off += 4
 
     ora = oracle.OracleExtractor(n, 1.2, 8, 20, 7)
     ref = [ora.extract(im) for im in seq]
@@ -65,6 +80,11 @@ def _run(exe, tmp_path, oracle):
     gray = oracle.cvt_gray(np.stack([seq[0], seq[1], seq[0]], axis=-1), rgb=False)
     kco, dco = oracle.OracleExtractor(n, 1.2, 8, 20, 7).extract(gray)
     assert np.array_equal(gray0, gray) and kc.tobytes() == kco.tobytes() and np.array_equal(dc, dco)
+    ov = oracle.OracleVocabulary(voc_path)
+    want = [ov.transform(ref[0][1], 4), ov.transform(ref[1][1], 4), ov.transform(ref[1][1], 4)]
+    for got, exp in zip(bows, want):
+        assert all(g.tobytes() == e.astype(g.dtype).tobytes() for g, e in zip(got, exp))
+    assert score12 == ov.score(want[0][0], want[0][1], want[1][0], want[1][1]) and nwords == ov.nwords
 
 
 def _build(target):
