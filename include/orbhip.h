@@ -200,6 +200,19 @@ orbhip_status orbhip_voc_transform(orbhip_voc* voc, const uint8_t* desc /* n x 3
 orbhip_status orbhip_compute_bow(orbhip_ctx* ctx, orbhip_voc* voc, int nimg, int levelsup);
 orbhip_status orbhip_fetch_bow(orbhip_ctx* ctx, orbhip_voc* voc, int frame, uint32_t* bow_id, double* bow_val, int* nbow,
                                uint32_t* fv_node, int32_t* fv_off, uint32_t* fv_feat, int* nfv);
+/* ORBmatcher::SearchByBoW on flat data.  mode 0 = SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (ORBmatcher.h:60,
+   ORBmatcher.cc:159-288), mode 1 = SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12) (ORBmatcher.h:61, ORBmatcher.cc:522-655).
+   Side 1 is the key frame whose map points are handed over: valid1[i] = "vpMapPoints1[i] != NULL && !isBad()", angle1 =
+   mvKeysUn[i].angle; side 2 the frame (mode 0: mvKeys[i].angle, valid2 ignored) or the second key frame (mode 1: valid2
+   likewise).  fvX_* = the FeatureVector flattened as returned by orbhip_voc_transform.  match12[i1] = index on side 2 or -1;
+   the caller writes vpMapPointMatches[match12[i1]] = vpMapPoints1[i1] (mode 0) / vpMatches12[i1] = vpMapPoints2[match12[i1]]
+   (mode 1).  *nmatches = the reference's return value.  Synchronous, host pointers. */
+orbhip_status orbhip_search_by_bow(int device, int mode,
+                                   const uint8_t* desc1, const float* angle1, const uint8_t* valid1, int n1,
+                                   const uint32_t* fv1_node, const int32_t* fv1_off, const uint32_t* fv1_feat, int nfv1,
+                                   const uint8_t* desc2, const float* angle2, const uint8_t* valid2, int n2,
+                                   const uint32_t* fv2_node, const int32_t* fv2_off, const uint32_t* fv2_feat, int nfv2,
+                                   float nnratio, int check_ori, int32_t* match12, int* nmatches);
 /* TemplatedVocabulary::score(v1, v2) with the scoring object named by the file header (ScoringObject.cpp:24-313;
    KeyFrameDatabase.cc:133,249, LoopClosing.cc:134); host arithmetic */
 double orbhip_voc_score(const orbhip_voc* voc, const uint32_t* id1, const double* val1, int n1,

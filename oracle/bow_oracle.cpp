@@ -178,6 +178,78 @@ static double score(int scoring, const uint32_t* i1, const double* v1, int n1, c
     }
 }
 
+// ORBmatcher::ComputeThreeMaxima (ORBmatcher.cc:1601-1642) on bin sizes
+static void three_maxima(const int* size, int L, int& ind1, int& ind2, int& ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0; ind1 = ind2 = ind3 = -1;
+    for (int i = 0; i < L; i++) {
+        const int s = size[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+// ORBmatcher::SearchByBoW on flat data.  mode 0 = (KeyFrame*, Frame&, vpMapPointMatches) ORBmatcher.cc:159-288,
+// mode 1 = (KeyFrame*, KeyFrame*, vpMatches12) :522-655.  Side 1 = the key frame whose map points are handed over
+// (valid1[i] = "vpMapPoints1[i] exists and is not bad"), side 2 = the frame / second key frame (valid2 only in mode 1).
+// match12[i1] = index on side 2 (the caller turns it into vpMapPointMatches[match12[i1]] = vpMapPointsKF[i1] resp.
+// vpMatches12[i1] = vpMapPoints2[match12[i1]]); returns nmatches.
+static int search_by_bow(int mode, const uint8_t* d1, const float* ang1, const uint8_t* valid1, int n1,
+                         const uint32_t* fn1, const int* fo1, const uint32_t* ff1, int nf1,
+                         const uint8_t* d2, const float* ang2, const uint8_t* valid2, int n2,
+                         const uint32_t* fn2, const int* fo2, const uint32_t* ff2, int nf2,
+                         float nnratio, bool check_ori, int* match12)
+{
+    const int TH_LOW = 50, HISTO_LENGTH = 30;
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    std::vector<uint8_t> matched2(n2, 0);
+    std::vector<int> bin_of(n1, -1);
+    int hist[HISTO_LENGTH] = {0};
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nmatches = 0, a = 0, b = 0;
+    while (a < nf1 && b < nf2) {
+        if (fn1[a] == fn2[b]) {
+            for (int i1 = fo1[a]; i1 < fo1[a + 1]; i1++) {
+                const unsigned idx1 = ff1[i1];
+                if (!valid1[idx1]) continue;                                       // !pMP || pMP->isBad()
+                int best1 = 256, bestIdx = -1, best2 = 256;
+                for (int i2 = fo2[b]; i2 < fo2[b + 1]; i2++) {
+                    const unsigned idx2 = ff2[i2];
+                    if (matched2[idx2]) continue;                                  // vpMapPointMatches[realIdxF] / vbMatched2[idx2]
+                    if (mode == 1 && !valid2[idx2]) continue;
+                    const int dist = distance(d1 + (size_t)idx1 * 32, d2 + (size_t)idx2 * 32);
+                    if (dist < best1) { best2 = best1; best1 = dist; bestIdx = (int)idx2; }
+                    else if (dist < best2) best2 = dist;
+                }
+                const bool close = mode == 0 ? best1 <= TH_LOW : best1 < TH_LOW;   // :221 vs :588
+                if (close && (float)best1 < nnratio * (float)best2) {
+                    match12[idx1] = bestIdx; matched2[bestIdx] = 1;
+                    if (check_ori) {
+                        float rot = ang1[idx1] - ang2[bestIdx];
+                        if (rot < 0.0) rot += 360.0f;
+                        int bin = (int)roundf(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        bin_of[idx1] = bin; hist[bin]++;
+                    }
+                    nmatches++;
+                }
+            }
+            a++; b++;
+        } else if (fn1[a] < fn2[b]) a = (int)(std::lower_bound(fn1 + a, fn1 + nf1, fn2[b]) - fn1);
+        else b = (int)(std::lower_bound(fn2 + b, fn2 + nf2, fn1[a]) - fn2);
+    }
+    if (check_ori) {
+        int ind1, ind2, ind3;
+        three_maxima(hist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < n1; i++)
+            if (bin_of[i] >= 0 && bin_of[i] != ind1 && bin_of[i] != ind2 && bin_of[i] != ind3) { match12[i] = -1; nmatches--; }
+    }
+    return nmatches;
+}
+
 }  // namespace bow
 
 extern "C" {
@@ -216,5 +288,13 @@ double orb_oracle_voc_score(int scoring, const uint32_t* i1, const double* v1, i
     return bow::score(scoring, i1, v1, n1, i2, v2, n2);
 }
 int orb_oracle_forb_distance(const uint8_t* a, const uint8_t* b) { return bow::distance(a, b); }
+int orb_oracle_search_by_bow(int mode, const uint8_t* d1, const float* ang1, const uint8_t* valid1, int n1,
+                             const uint32_t* fn1, const int* fo1, const uint32_t* ff1, int nf1,
+                             const uint8_t* d2, const float* ang2, const uint8_t* valid2, int n2,
+                             const uint32_t* fn2, const int* fo2, const uint32_t* ff2, int nf2,
+                             float nnratio, int check_ori, int* match12)
+{
+    return bow::search_by_bow(mode, d1, ang1, valid1, n1, fn1, fo1, ff1, nf1, d2, ang2, valid2, n2, fn2, fo2, ff2, nf2, nnratio, check_ori != 0, match12);
+}
 
 }  // extern "C"

@@ -60,6 +60,8 @@ def lib(fast=False):
     L.orb_oracle_voc_score.argtypes = [C.c_int, vp, vp, C.c_int, vp, vp, C.c_int]
     L.orb_oracle_voc_score.restype = C.c_double
     L.orb_oracle_forb_distance.argtypes = [vp, vp]
+    L.orb_oracle_search_by_bow.argtypes = [C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp]
+    L.orb_oracle_search_by_bow.restype = C.c_int
     L.orb_oracle_cvt_gray.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
     L.orb_oracle_gauss_kernel.argtypes = [vp]
     L.orb_oracle_fast.restype = C.c_int
@@ -329,3 +331,19 @@ def voc_score(scoring, id1, val1, id2, val2):
 def forb_distance(a, b):
     a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
     return lib().orb_oracle_forb_distance(_p(a), _p(b))
+
+
+def search_by_bow(mode, desc1, angle1, valid1, fv1, desc2, angle2, valid2, fv2, nnratio=0.7, check_ori=True):
+    """ORBmatcher::SearchByBoW on flat data (mode 0: KeyFrame vs Frame, ORBmatcher.cc:159-288; mode 1: KeyFrame vs KeyFrame,
+    :522-655).  fv = (node ids, offsets, feature indices) of a FeatureVector.  -> (nmatches, match12[n1])"""
+    desc1 = np.ascontiguousarray(desc1, np.uint8); desc2 = np.ascontiguousarray(desc2, np.uint8)
+    angle1 = np.ascontiguousarray(angle1, np.float32); angle2 = np.ascontiguousarray(angle2, np.float32)
+    valid1 = np.ascontiguousarray(valid1, np.uint8)
+    valid2 = np.ones(len(desc2), np.uint8) if valid2 is None else np.ascontiguousarray(valid2, np.uint8)
+    f1 = [np.ascontiguousarray(fv1[0], np.uint32), np.ascontiguousarray(fv1[1], np.int32), np.ascontiguousarray(fv1[2], np.uint32)]
+    f2 = [np.ascontiguousarray(fv2[0], np.uint32), np.ascontiguousarray(fv2[1], np.int32), np.ascontiguousarray(fv2[2], np.uint32)]
+    m12 = np.full(len(desc1), -1, np.int32)
+    n = lib().orb_oracle_search_by_bow(mode, _p(desc1), _p(angle1), _p(valid1), len(desc1), _p(f1[0]), _p(f1[1]), _p(f1[2]), len(f1[0]),
+                                       _p(desc2), _p(angle2), _p(valid2), len(desc2), _p(f2[0]), _p(f2[1]), _p(f2[2]), len(f2[0]),
+                                       nnratio, int(check_ori), _p(m12))
+    return n, m12

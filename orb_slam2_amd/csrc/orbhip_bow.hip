@@ -172,6 +172,117 @@ __global__ __launch_bounds__(BA_T) void k_bow_assemble(BowParams P)
     if (tid == 0) { fv_off[nf] = m; P.nfv[frame] = nf; }
 }
 
+// ------------------------------------------------------------------------------------------------ SearchByBoW
+// ORBmatcher::SearchByBoW (ORBmatcher.cc:159-288 key frame vs frame, :522-655 key frame vs key frame) on flat data.  The
+// reference merge-joins the two FeatureVectors and, inside a common vocabulary node, walks side 1's features in order;
+// a side-2 feature taken by an earlier one is skipped.  A side-2 feature lives in exactly one node, so nodes are independent:
+// one wavefront per node of side 1 (binary search for the same node on side 2), sequential over its side-1 features, lanes
+// over the side-2 features of the node (chunks of 64, "taken" flags as per-lane bit masks), ballot arg-min for best /
+// second-best exactly like the scan order of the reference (first minimum wins, second = smallest of the rest).
+struct BowMatchParams {
+    int mode; float nnratio; int check_ori;
+    const uint8_t* d1; const float* ang1; const uint8_t* valid1; int n1; const uint32_t* fn1; const int* fo1; const uint32_t* ff1; int nf1;
+    const uint8_t* d2; const float* ang2; const uint8_t* valid2; int n2; const uint32_t* fn2; const int* fo2; const uint32_t* ff2; int nf2;
+    int* match12; int* bin12; int* hist; int* nmatches; int* overflow;
+};
+#define BM_CHUNKS 128                   // side-2 features of one node handled per wave: 64 * BM_CHUNKS
+
+__device__ __forceinline__ unsigned long long bm_argmin_mask(int d, unsigned long long M)
+{   // lanes of M holding the minimum of a 9-bit key: MSB-first elimination with ballots
+#pragma unroll
+    for (int b = 8; b >= 0; b--) { const unsigned long long z = __ballot(((d >> b) & 1) == 0) & M; if (z) M = z; }
+    return M;
+}
+
+__global__ __launch_bounds__(256) void k_bow_match(BowMatchParams P)
+{
+    const int lane = threadIdx.x & 63, a = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (a >= P.nf1) return;
+    const uint32_t node = P.fn1[a];
+    int lo = 0, hi = P.nf2;                                    // lower_bound on side 2's node ids
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (P.fn2[mid] < node) lo = mid + 1; else hi = mid; }
+    if (lo >= P.nf2 || P.fn2[lo] != node) return;
+    const int b1 = P.fo1[a], e1 = P.fo1[a + 1], b2 = P.fo2[lo], len2 = P.fo2[lo + 1] - b2;
+    if (len2 > 64 * BM_CHUNKS) { if (lane == 0) atomicAdd(P.overflow, 1); return; }
+    const int nch = (len2 + 63) >> 6;
+    unsigned long long taken_lo = 0, taken_hi = 0;             // bit c: this lane's entry of chunk c is matched (c < 64 / c >= 64)
+    for (int i1 = b1; i1 < e1; i1++) {
+        const unsigned idx1 = P.ff1[i1];
+        if (!P.valid1[idx1]) continue;                         // !pMP || pMP->isBad()   (:195-199)
+        const uint4* q4 = reinterpret_cast<const uint4*>(P.d1 + (long long)idx1 * 32);
+        const uint4 qa = q4[0], qb = q4[1];
+        int best = 256, second = 256, bidx = -1, bchunk = 0, blane = 0;
+        for (int c = 0; c < nch; c++) {
+            const int t = c * 64 + lane;
+            int idx2 = 0, dist = 256; bool ok = false;
+            if (t < len2) {
+                idx2 = (int)P.ff2[b2 + t];
+                const bool taken = c < 64 ? (taken_lo >> c) & 1ull : (taken_hi >> (c - 64)) & 1ull;
+                ok = !taken && !(P.mode == 1 && !P.valid2[idx2]);           // :207-208 / :574-579
+                if (ok) {
+                    const uint4* d4 = reinterpret_cast<const uint4*>(P.d2 + (long long)idx2 * 32);
+                    const uint4 da = d4[0], db = d4[1];
+                    dist = __popc(qa.x ^ da.x) + __popc(qa.y ^ da.y) + __popc(qa.z ^ da.z) + __popc(qa.w ^ da.w) +
+                           __popc(qb.x ^ db.x) + __popc(qb.y ^ db.y) + __popc(qb.z ^ db.z) + __popc(qb.w ^ db.w);
+                }
+            }
+            const unsigned long long V = __ballot(ok && dist < 256);        // dist == 256 can never pass `dist < bestDist` (init 256)
+            if (V == 0) continue;
+            const unsigned long long mk = bm_argmin_mask(dist, V);
+            const int first = __ffsll((long long)mk) - 1;
+            const int wmin = __builtin_amdgcn_readlane(dist, first), ci = __builtin_amdgcn_readlane(idx2, first);
+            const unsigned long long V2 = V & ~(1ull << first);
+            int wsec = 256;
+            if (V2) { const unsigned long long mk2 = bm_argmin_mask(dist, V2); wsec = __builtin_amdgcn_readlane(dist, __ffsll((long long)mk2) - 1); }
+            if (wmin < best) { second = min(best, wsec); best = wmin; bidx = ci; bchunk = c; blane = first; } else second = min(second, wmin);
+        }
+        const bool close = P.mode == 0 ? best <= ORBHIP_TH_LOW : best < ORBHIP_TH_LOW;                 // :221 / :588
+        if (close && (float)best < __fmul_rn(P.nnratio, (float)second)) {                               // :223 / :590
+            if (lane == blane) { if (bchunk < 64) taken_lo |= 1ull << bchunk; else taken_hi |= 1ull << (bchunk - 64); }
+            if (lane == 0) {
+                P.match12[idx1] = bidx;
+                if (P.check_ori) {
+                    float rot = __fsub_rn(P.ang1[idx1], P.ang2[bidx]);
+                    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                    int bin = (int)roundf(__fmul_rn(rot, 1.0f / ORBHIP_HISTO_LENGTH));
+                    if (bin == ORBHIP_HISTO_LENGTH) bin = 0;
+                    bin = min(max(bin, 0), ORBHIP_HISTO_LENGTH - 1);
+                    P.bin12[idx1] = bin; atomicAdd(&P.hist[bin], 1);
+                }
+            }
+        }
+    }
+}
+
+// ComputeThreeMaxima (ORBmatcher.cc:1601-1642), rejection of the other bins (:262-285 / :629-652), nmatches
+__global__ __launch_bounds__(256) void k_bow_match_finish(BowMatchParams P)
+{
+    __shared__ int s_ind[3]; __shared__ int s_cnt;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < ORBHIP_HISTO_LENGTH; i++) {
+            const int s = P.hist[i];
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
+        s_ind[0] = ind1; s_ind[1] = ind2; s_ind[2] = ind3; s_cnt = 0;
+    }
+    __syncthreads();
+    int cnt = 0;
+    for (int i = tid; i < P.n1; i += 256) {
+        if (P.match12[i] < 0) continue;
+        const int b = P.bin12[i];
+        if (P.check_ori && b != s_ind[0] && b != s_ind[1] && b != s_ind[2]) P.match12[i] = -1; else cnt++;
+    }
+    if (cnt) atomicAdd(&s_cnt, cnt);
+    __syncthreads();
+    if (tid == 0) *P.nmatches = s_cnt;
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 struct orbhip_voc {
     int k = 0, L = 0, scoring = 0, weighting = 0, nnodes = 0, nwords = 0, device = 0;
@@ -414,4 +525,57 @@ extern "C" double orbhip_voc_score(const orbhip_voc* v, const uint32_t* id1, con
     case 3: for (; a < n1; a++) if (val1[a] != 0) s += val1[a] * (std::log(val1[a]) - LOG_EPS); return s;
     default: return s;
     }
+}
+
+static thread_local void* g_bm_ws = nullptr; static thread_local size_t g_bm_ws_bytes = 0; static thread_local int g_bm_dev = -1;
+
+// ORBmatcher::SearchByBoW on flat data; see include/orbhip.h
+extern "C" orbhip_status orbhip_search_by_bow(int device, int mode,
+    const uint8_t* desc1, const float* angle1, const uint8_t* valid1, int n1, const uint32_t* fv1_node, const int32_t* fv1_off, const uint32_t* fv1_feat, int nfv1,
+    const uint8_t* desc2, const float* angle2, const uint8_t* valid2, int n2, const uint32_t* fv2_node, const int32_t* fv2_off, const uint32_t* fv2_feat, int nfv2,
+    float nnratio, int check_ori, int32_t* match12, int* nmatches)
+{
+    if (!match12 || !nmatches || n1 < 0 || n2 < 0 || nfv1 < 0 || nfv2 < 0 || (mode != 0 && mode != 1)) return orbhip_set_error(ORBHIP_ERR_INVALID, "bad argument");
+    *nmatches = 0;
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    if (n1 == 0 || n2 == 0 || nfv1 == 0 || nfv2 == 0) return ORBHIP_OK;
+    if (!desc1 || !desc2 || !angle1 || !angle2 || !valid1 || !fv1_node || !fv1_off || !fv1_feat || !fv2_node || !fv2_off || !fv2_feat || (mode == 1 && !valid2))
+        return orbhip_set_error(ORBHIP_ERR_INVALID, "null argument");
+    BOWCHK(hipSetDevice(device));
+    const int m1 = fv1_off[nfv1], m2 = fv2_off[nfv2];
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t sz[] = {al((size_t)n1 * 32), al((size_t)n1 * 4), al((size_t)n1), al((size_t)nfv1 * 4), al((size_t)(nfv1 + 1) * 4), al((size_t)std::max(m1, 1) * 4),
+                         al((size_t)n2 * 32), al((size_t)n2 * 4), al((size_t)n2), al((size_t)nfv2 * 4), al((size_t)(nfv2 + 1) * 4), al((size_t)std::max(m2, 1) * 4),
+                         al((size_t)n1 * 4), al((size_t)n1 * 4), al((ORBHIP_HISTO_LENGTH + 2) * 4)};
+    size_t total = 0; for (size_t b : sz) total += b;
+    if (g_bm_dev != device || g_bm_ws_bytes < total) {
+        if (g_bm_ws) (void)hipFree(g_bm_ws);
+        g_bm_ws = nullptr; g_bm_ws_bytes = 0;
+        BOWCHK(hipMalloc(&g_bm_ws, total)); g_bm_ws_bytes = total; g_bm_dev = device;
+    }
+    uint8_t* base = (uint8_t*)g_bm_ws; uint8_t* p[15]; { size_t o = 0; for (int i = 0; i < 15; i++) { p[i] = base + o; o += sz[i]; } }
+    std::vector<uint8_t> ones;
+    if (!valid2) { ones.assign(n2, 1); valid2 = ones.data(); }
+    const void* src[12] = {desc1, angle1, valid1, fv1_node, fv1_off, fv1_feat, desc2, angle2, valid2, fv2_node, fv2_off, fv2_feat};
+    const size_t nb[12] = {(size_t)n1 * 32, (size_t)n1 * 4, (size_t)n1, (size_t)nfv1 * 4, (size_t)(nfv1 + 1) * 4, (size_t)m1 * 4,
+                           (size_t)n2 * 32, (size_t)n2 * 4, (size_t)n2, (size_t)nfv2 * 4, (size_t)(nfv2 + 1) * 4, (size_t)m2 * 4};
+    for (int i = 0; i < 12; i++) if (nb[i]) BOWCHK(hipMemcpyAsync(p[i], src[i], nb[i], hipMemcpyHostToDevice, 0));
+    BOWCHK(hipMemsetAsync(p[12], 0xff, (size_t)n1 * 4, 0));                // match12 = -1
+    BOWCHK(hipMemsetAsync(p[13], 0xff, (size_t)n1 * 4, 0));                // bin12 = -1
+    BOWCHK(hipMemsetAsync(p[14], 0, (ORBHIP_HISTO_LENGTH + 2) * 4, 0));    // hist, nmatches, overflow
+    BowMatchParams P; memset(&P, 0, sizeof P);
+    P.mode = mode; P.nnratio = nnratio; P.check_ori = check_ori;
+    P.d1 = p[0]; P.ang1 = (const float*)p[1]; P.valid1 = p[2]; P.n1 = n1; P.fn1 = (const uint32_t*)p[3]; P.fo1 = (const int*)p[4]; P.ff1 = (const uint32_t*)p[5]; P.nf1 = nfv1;
+    P.d2 = p[6]; P.ang2 = (const float*)p[7]; P.valid2 = p[8]; P.n2 = n2; P.fn2 = (const uint32_t*)p[9]; P.fo2 = (const int*)p[10]; P.ff2 = (const uint32_t*)p[11]; P.nf2 = nfv2;
+    P.match12 = (int*)p[12]; P.bin12 = (int*)p[13]; P.hist = (int*)p[14]; P.nmatches = P.hist + ORBHIP_HISTO_LENGTH; P.overflow = P.nmatches + 1;
+    hipLaunchKernelGGL(k_bow_match, dim3((nfv1 + 3) / 4, 1, 1), dim3(256, 1, 1), 0, 0, P);
+    hipLaunchKernelGGL(k_bow_match_finish, dim3(1, 1, 1), dim3(256, 1, 1), 0, 0, P);
+    BOWCHK(hipGetLastError());
+    int tail[2] = {0, 0};
+    BOWCHK(hipMemcpyAsync(match12, p[12], (size_t)n1 * 4, hipMemcpyDeviceToHost, 0));
+    BOWCHK(hipMemcpyAsync(tail, P.nmatches, 8, hipMemcpyDeviceToHost, 0));
+    BOWCHK(hipStreamSynchronize(0));
+    if (tail[1]) return orbhip_set_error(ORBHIP_ERR_UNSUPPORTED, "a vocabulary node holds more than %d features of side 2", 64 * BM_CHUNKS);
+    *nmatches = tail[0];
+    return ORBHIP_OK;
 }

@@ -28,7 +28,7 @@ SYMBOLS = [
     "orbhip_algorithmic_bytes_per_frame_kernel", "orbhip_debug_blurred_level", "orbhip_debug_candidates",
     "orbhip_compute_stereo_matches", "orbhip_search_by_projection", "orbhip_extract_batch_color",
     "orbhip_extract_device_color", "orbhip_voc_load_text", "orbhip_voc_destroy", "orbhip_voc_info", "orbhip_voc_transform_features",
-    "orbhip_voc_transform", "orbhip_compute_bow", "orbhip_fetch_bow", "orbhip_voc_score",
+    "orbhip_voc_transform", "orbhip_compute_bow", "orbhip_fetch_bow", "orbhip_voc_score", "orbhip_search_by_bow",
 ]
 
 
@@ -83,6 +83,7 @@ def lib(path=None):
     L.orbhip_fetch_bow.argtypes = [vp, vp, C.c_int, vp, vp, ip, vp, vp, vp, ip]
     L.orbhip_voc_score.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int]
     L.orbhip_voc_score.restype = C.c_double
+    L.orbhip_search_by_bow.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp, ip]
     L.orbhip_sync.argtypes = [vp]
     L.orbhip_fetch.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp]
     L.orbhip_fetch_matches.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
@@ -446,3 +447,21 @@ class ORBVocabulary:
         id1 = np.ascontiguousarray(id1, np.uint32); id2 = np.ascontiguousarray(id2, np.uint32)
         val1 = np.ascontiguousarray(val1, np.float64); val2 = np.ascontiguousarray(val2, np.float64)
         return self.L_.orbhip_voc_score(self.h, _p(id1), _p(val1), len(id1), _p(id2), _p(val2), len(id2))
+
+
+def search_by_bow(mode, desc1, angle1, valid1, fv1, desc2, angle2, valid2, fv2, nnratio=0.7, check_ori=True, device=0, library=None):
+    """ORBmatcher(nnratio, check_ori).SearchByBoW on flat data: mode 0 = (KeyFrame, Frame) ORBmatcher.cc:159-288, mode 1 =
+    (KeyFrame, KeyFrame) :522-655.  fv = (node ids, offsets, feature indices).  -> (nmatches, match12[n1])"""
+    L = lib(library)
+    desc1 = np.ascontiguousarray(desc1, np.uint8); desc2 = np.ascontiguousarray(desc2, np.uint8)
+    angle1 = np.ascontiguousarray(angle1, np.float32); angle2 = np.ascontiguousarray(angle2, np.float32)
+    valid1 = np.ascontiguousarray(valid1, np.uint8)
+    valid2 = None if valid2 is None else np.ascontiguousarray(valid2, np.uint8)
+    f1 = [np.ascontiguousarray(fv1[0], np.uint32), np.ascontiguousarray(fv1[1], np.int32), np.ascontiguousarray(fv1[2], np.uint32)]
+    f2 = [np.ascontiguousarray(fv2[0], np.uint32), np.ascontiguousarray(fv2[1], np.int32), np.ascontiguousarray(fv2[2], np.uint32)]
+    m12 = np.full(len(desc1), -1, np.int32)
+    nm = C.c_int(0)
+    _check(L.orbhip_search_by_bow(device, mode, _p(desc1), _p(angle1), _p(valid1), len(desc1), _p(f1[0]), _p(f1[1]), _p(f1[2]), len(f1[0]),
+                                  _p(desc2), _p(angle2), None if valid2 is None else _p(valid2), len(desc2), _p(f2[0]), _p(f2[1]), _p(f2[2]), len(f2[0]),
+                                  nnratio, int(check_ori), _p(m12), C.byref(nm)), "orbhip_search_by_bow", L)
+    return nm.value, m12
