@@ -44,16 +44,28 @@ public:
     static size_t elemSize1(int type) { return type == CV_32F ? 4 : 1; }
     void create(int r, int c, int type)
     {
-        if (r == rows && c == cols && type == flags_type && data && owner_) return;
+        if (r == rows && c == cols && type == flags_type && data) return;     // like cv::Mat::create: a fitting buffer (also a view) is kept
         rows = r; cols = c; flags_type = type; step = (size_t)c * elemSize1(type);
         owner_ = std::shared_ptr<uchar>(new uchar[(size_t)r * step + 64], std::default_delete<uchar[]>()); data = owner_.get();
     }
     void release() { owner_.reset(); data = nullptr; rows = cols = 0; step = 0; }
     bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
     int type() const { return flags_type; }
+    size_t step1() const { return step / elemSize1(flags_type); }
     bool isContinuous() const { return step == (size_t)cols * elemSize1(flags_type); }
-    static Mat zeros(int r, int c, int type) { Mat m(r, c, type); memset(m.data, 0, (size_t)r * m.step); return m; }
+    // cv::Mat::zeros returns a MatExpr: assigning it to a Mat that already has the right size and type (e.g. a rowRange view)
+    // fills that buffer IN PLACE — src/ORBextractor.cc:1037 relies on it to write into the caller's descriptor rows
+    struct ZerosExpr { int rows, cols, type; };
+    static ZerosExpr zeros(int r, int c, int type) { ZerosExpr e = {r, c, type}; return e; }
+    Mat(const ZerosExpr& e) : Mat() { *this = e; }
+    Mat& operator=(const ZerosExpr& e) { create(e.rows, e.cols, e.type); for (int y = 0; y < rows; y++) memset(data + (size_t)y * step, 0, (size_t)cols * elemSize1(flags_type)); return *this; }
     Mat clone() const { Mat m(rows, cols, flags_type); for (int y = 0; y < rows; y++) memcpy(m.data + y * m.step, data + y * step, cols * elemSize1(flags_type)); return m; }
+    Mat(Size sz, int type) : Mat() { create(sz.height, sz.width, type); }
+    Size size() const { return Size(cols, rows); }
+    // views sharing the storage (ROI semantics of cv::Mat)
+    Mat rowRange(int a, int b) const { Mat m = *this; m.rows = b - a; m.data = data + (size_t)a * step; return m; }
+    Mat colRange(int a, int b) const { Mat m = *this; m.cols = b - a; m.data = data + (size_t)a * elemSize1(flags_type); return m; }
+    Mat operator()(const Rect& r) const { return rowRange(r.y, r.y + r.height).colRange(r.x, r.x + r.width); }
     Mat row(int y) const { Mat m; m.rows = 1; m.cols = cols; m.flags_type = flags_type; m.step = step; m.data = data + (size_t)y * step; m.owner_ = owner_; return m; }
     template <typename T> T* ptr(int y = 0) { return (T*)(data + (size_t)y * step); }
     template <typename T> const T* ptr(int y = 0) const { return (const T*)(data + (size_t)y * step); }

@@ -14,12 +14,18 @@
 // third-party dependency that is NOT vendored in /root/reference (CMakeLists.txt:31-37
 // "find_package(OpenCV 3.0) else 2.4.3", README.md:68 "tested with 2.4.11 and 3.2").
 //
-// PARITY UNPINNED at the OpenCV boundary: the reference ships no tests / golden
-// vectors for this path and neither OpenCV nor the reference can be
-// built in this container, so the restated primitives (target: OpenCV 3.2 generic
-// C++ code paths) are pinned only by hand-derivable known-answer tests
-// (tests/test_oracle_kat.py).  The one piece that IS pinned against a real binary is
-// sincosf: glibc_sincosf() below is checked bit-for-bit against this box's libm.
+// PARITY: pinned against the reference's own code everywhere except the four OpenCV primitives.
+//   * The reference's src/ORBextractor.cc itself compiles here (oracle/_ref/liborbextractor_ref.so, `make -C oracle ref`)
+//     against a types-only stand-in for the OpenCV headers whose resize / GaussianBlur / FAST / fastAtan2 forward to the
+//     restatements in THIS file; tests/test_reference_extractor.py checks this file's Extractor against it bit for bit
+//     (keypoints, descriptors, pyramids, constructor tables) on every parity configuration.  So the extractor logic —
+//     tables, per-cell loop, threshold fallback, DistributeOctTree on a real std::list, IC_Angle, steered BRIEF, assembly —
+//     is the reference's, verified.
+//   * PARITY UNPINNED at the OpenCV boundary only: cv::resize, cv::GaussianBlur, cv::FAST, cv::fastAtan2 (and cvtColor for
+//     the colour entry points) are restated from their published algorithms (target: OpenCV 3.2 generic C++ paths) because
+//     OpenCV is not vendored and cannot be built here; the reference ships no golden vectors for them, so
+//     they are pinned by hand-derivable known-answer tests only (tests/test_oracle_kat.py).
+//   * sincosf: glibc_sincosf() below is checked bit-for-bit against this box's libm (all 1.09e9 floats in [0, 2pi]).
 //
 // Declared canonicalisations:
 //   H1  quadtree tie-break: the reference sorts pair<int,ExtractorNode*> (ORBextractor.cc:684),
