@@ -4,6 +4,7 @@
 // processing lives here (that is all in liborbhip.so).
 #pragma once
 #include <cstdint>
+#include <cmath>
 #include <cstring>
 #include <memory>
 #include <vector>
@@ -73,9 +74,60 @@ public:
     const uchar* ptr(int y = 0) const { return data + (size_t)y * step; }
     template <typename T> T& at(int y, int x) { return ((T*)(data + (size_t)y * step))[x]; }
     template <typename T> const T& at(int y, int x) const { return ((const T*)(data + (size_t)y * step))[x]; }
+#ifdef CVLITE_ALGEBRA
+    // ---- small CV_32F matrix algebra.  NOT needed by the drop-in classes: it exists so that the reference's own Frame.cc /
+    // ORBmatcher.cc compile for the oracle/_ref builds (pose products, norms, the L1 patch correlation of stereo matching).
+    template <typename T> T& at(int i) { return rows == 1 ? ((T*)data)[i] : *(T*)(data + (size_t)i * step); }
+    template <typename T> const T& at(int i) const { return rows == 1 ? ((const T*)data)[i] : *(const T*)(data + (size_t)i * step); }
+    static Mat ones(int r, int c, int type) { Mat m(r, c, type); for (int y = 0; y < r; y++) for (int x = 0; x < c; x++) { if (type == CV_32F) m.at<float>(y, x) = 1.0f; else m.at<uchar>(y, x) = 1; } return m; }
+    static Mat eye(int r, int c, int type) { Mat m = Mat(zeros(r, c, type)); for (int i = 0; i < r && i < c; i++) { if (type == CV_32F) m.at<float>(i, i) = 1.0f; else m.at<uchar>(i, i) = 1; } return m; }
+    Mat col(int x) const { return colRange(x, x + 1); }
+    Mat t() const { Mat m(cols, rows, flags_type); for (int y = 0; y < rows; y++) for (int x = 0; x < cols; x++) m.at<float>(x, y) = at<float>(y, x); return m; }
+    double dot(const Mat& o) const { double s = 0; for (int y = 0; y < rows; y++) for (int x = 0; x < cols; x++) s += (double)at<float>(y, x) * o.at<float>(y, x); return s; }
+    void copyTo(Mat& m) const { m = clone(); }
+    void convertTo(Mat& m, int rtype) const
+    {
+        Mat o(rows, cols, rtype);
+        for (int y = 0; y < rows; y++) for (int x = 0; x < cols; x++) {
+            const float v = flags_type == CV_32F ? at<float>(y, x) : (float)at<uchar>(y, x);
+            if (rtype == CV_32F) o.at<float>(y, x) = v; else o.at<uchar>(y, x) = (uchar)v;
+        }
+        m = o;
+    }
+    Mat reshape(int, int = 0) const;    // only reached for distorted cameras (cv::undistortPoints): aborts, see ref_shim
+#endif
 private:
     std::shared_ptr<uchar> owner_;
 };
+
+#ifdef CVLITE_ALGEBRA
+enum { NORM_L1 = 2, NORM_L2 = 4 };
+inline Mat operator*(const Mat& a, const Mat& b)
+{
+    Mat m(a.rows, b.cols, CV_32F);
+    for (int y = 0; y < a.rows; y++) for (int x = 0; x < b.cols; x++) { double s = 0; for (int k = 0; k < a.cols; k++) s += (double)a.at<float>(y, k) * b.at<float>(k, x); m.at<float>(y, x) = (float)s; }
+    return m;
+}
+inline Mat operator*(float f, const Mat& a) { Mat m(a.rows, a.cols, CV_32F); for (int y = 0; y < a.rows; y++) for (int x = 0; x < a.cols; x++) m.at<float>(y, x) = f * a.at<float>(y, x); return m; }
+inline Mat operator*(const Mat& a, float f) { return f * a; }
+inline Mat operator/(const Mat& a, float f) { Mat m(a.rows, a.cols, CV_32F); for (int y = 0; y < a.rows; y++) for (int x = 0; x < a.cols; x++) m.at<float>(y, x) = a.at<float>(y, x) / f; return m; }
+inline Mat operator-(const Mat& a, const Mat& b) { Mat m(a.rows, a.cols, CV_32F); for (int y = 0; y < a.rows; y++) for (int x = 0; x < a.cols; x++) m.at<float>(y, x) = a.at<float>(y, x) - b.at<float>(y, x); return m; }
+inline Mat operator+(const Mat& a, const Mat& b) { Mat m(a.rows, a.cols, CV_32F); for (int y = 0; y < a.rows; y++) for (int x = 0; x < a.cols; x++) m.at<float>(y, x) = a.at<float>(y, x) + b.at<float>(y, x); return m; }
+inline Mat operator-(const Mat& a) { return -1.0f * a; }
+inline double norm(const Mat& a) { return std::sqrt(a.dot(a)); }
+inline double norm(const Mat& a, const Mat& b, int type)
+{
+    double s = 0;
+    for (int y = 0; y < a.rows; y++) for (int x = 0; x < a.cols; x++) { const double d = (double)a.at<float>(y, x) - b.at<float>(y, x); s += type == NORM_L1 ? std::fabs(d) : d * d; }
+    return type == NORM_L1 ? s : std::sqrt(s);
+}
+template <typename T> class Mat_ : public Mat {           // (cv::Mat_<float>(3,1) << x, y, z)
+public:
+    Mat_(int r, int c) : Mat(r, c, CV_32F) {}
+    struct Init { Mat m; int i; Init& operator,(T v) { m.at<T>(i / m.cols, i % m.cols) = v; i++; return *this; } operator Mat() const { return m; } };
+    Init operator<<(T v) { Init in = {*this, 0}; in, v; return in; }
+};
+#endif
 
 class _InputArray {
 public:

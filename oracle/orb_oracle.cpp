@@ -21,6 +21,9 @@
 //     (keypoints, descriptors, pyramids, constructor tables) on every parity configuration.  So the extractor logic —
 //     tables, per-cell loop, threshold fallback, DistributeOctTree on a real std::list, IC_Angle, steered BRIEF, assembly —
 //     is the reference's, verified.
+//   * src/Frame.cc and src/ORBmatcher.cc compile the same way (oracle/_ref/liborbslam_ref.so): tests/test_reference_matchers.py
+//     checks SearchForInitialization, the two per-frame SearchByProjection overloads, ComputeStereoMatches and
+//     GetFeaturesInArea of this file against the reference's own Frame / ORBmatcher objects.
 //   * PARITY UNPINNED at the OpenCV boundary only: cv::resize, cv::GaussianBlur, cv::FAST, cv::fastAtan2 (and cvtColor for
 //     the colour entry points) are restated from their published algorithms (target: OpenCV 3.2 generic C++ paths) because
 //     OpenCV is not vendored and cannot be built here; the reference ships no golden vectors for them, so

@@ -1,0 +1,114 @@
+"""ctypes binding of oracle/_ref/liborbslam_ref.so: the REFERENCE's own src/Frame.cc + src/ORBmatcher.cc (+ ORBextractor.cc),
+compiled from /root/reference by `make -C oracle ref` (OpenCV image primitives = the oracle's restatements, MapPoint / KeyFrame
+accessors = getters in the wrapper).  Pins the matcher / stereo / feature-grid restatements of orb_oracle.cpp against the
+reference's real code.  Test infrastructure."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PATH = os.path.join(HERE, "_ref", "liborbslam_ref.so")
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+_lib = None
+
+
+def available():
+    return os.path.exists(PATH)
+
+
+def build():
+    import subprocess
+    if os.path.isdir("/root/reference/src"):
+        subprocess.check_call(["make", "-C", HERE, "-s", "ref"])
+    return available()
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(PATH)
+        vp, i, f = C.c_void_p, C.c_int, C.c_float
+        L.orbslam_ref_frame_mono.restype = vp
+        L.orbslam_ref_frame_mono.argtypes = [vp, i, i, i, i, f, i, i, i, f, f, f, f, f, f, i]
+        L.orbslam_ref_frame_stereo.restype = vp
+        L.orbslam_ref_frame_stereo.argtypes = [vp, vp, i, i, i, i, f, i, i, i, f, f, f, f, f, f, i]
+        L.orbslam_ref_frame_delete.argtypes = [vp]
+        L.orbslam_ref_frame_n.argtypes = [vp]
+        L.orbslam_ref_frame_get.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.orbslam_ref_features_in_area.argtypes = [vp, f, f, f, i, i, vp, i]
+        L.orbslam_ref_search_for_initialization.argtypes = [vp, vp, vp, vp, i, f, i]
+        L.orbslam_ref_descriptor_distance.argtypes = [vp, vp]
+        L.orbslam_ref_search_by_projection_points.argtypes = [vp, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f, f, vp]
+        L.orbslam_ref_search_by_projection_last.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f, i, f, i, vp]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class RefFrame:
+    """ORB_SLAM2::Frame built by the reference's own constructor."""
+    _geometry = None
+
+    def __init__(self, img, right=None, nfeatures=1000, scale=1.2, nlevels=8, ini_th=20, min_th=7, fx=1.0, fy=1.0, cx=0.0, cy=0.0, bf=40.0, th_depth=35.0):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        geom = (w, h, fx, fy, cx, cy)
+        new = RefFrame._geometry != geom
+        RefFrame._geometry = geom
+        if right is None:
+            self.h = lib().orbslam_ref_frame_mono(_p(img), w, h, img.strides[0], nfeatures, scale, nlevels, ini_th, min_th, fx, fy, cx, cy, bf, th_depth, int(new))
+        else:
+            right = np.ascontiguousarray(right, np.uint8)
+            self.h = lib().orbslam_ref_frame_stereo(_p(img), _p(right), w, h, img.strides[0], nfeatures, scale, nlevels, ini_th, min_th, fx, fy, cx, cy, bf, th_depth, int(new))
+        self.N = lib().orbslam_ref_frame_n(self.h)
+        self.keys = np.zeros(self.N, KEYPOINT_DTYPE); self.keys_un = np.zeros(self.N, KEYPOINT_DTYPE)
+        self.desc = np.zeros((self.N, 32), np.uint8); self.u_right = np.zeros(self.N, np.float32); self.depth = np.zeros(self.N, np.float32)
+        lib().orbslam_ref_frame_get(self.h, _p(self.keys), _p(self.keys_un), _p(self.desc), _p(self.u_right), _p(self.depth))
+
+    def close(self):
+        if self.h:
+            lib().orbslam_ref_frame_delete(self.h)
+            self.h = None
+
+    def features_in_area(self, x, y, r, min_level=-1, max_level=-1):
+        out = np.zeros(max(self.N, 1), np.int32)
+        n = lib().orbslam_ref_features_in_area(self.h, x, y, r, min_level, max_level, _p(out), len(out))
+        return out[:n].copy()
+
+
+def search_for_initialization(f1, f2, prev=None, window=100, nnratio=0.9, check_ori=True):
+    prev = np.ascontiguousarray(np.stack([f1.keys_un["x"], f1.keys_un["y"]], axis=1) if prev is None else prev, np.float32).copy()
+    m12 = np.full(f1.N, -1, np.int32)
+    n = lib().orbslam_ref_search_for_initialization(f1.h, f2.h, _p(prev), _p(m12), window, nnratio, int(check_ori))
+    return n, m12, prev
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    return lib().orbslam_ref_descriptor_distance(_p(a), _p(b))
+
+
+def search_by_projection_points(frame, px, py, pxr, level, viewcos, inview, bad, nobs, desc, feature_state=None, th=1.0, nnratio=0.8):
+    a = [np.ascontiguousarray(px, np.float32), np.ascontiguousarray(py, np.float32), np.ascontiguousarray(pxr, np.float32), np.ascontiguousarray(level, np.int32),
+         np.ascontiguousarray(viewcos, np.float32), np.ascontiguousarray(inview, np.uint8), np.ascontiguousarray(bad, np.uint8), np.ascontiguousarray(nobs, np.int32),
+         np.ascontiguousarray(desc, np.uint8)]
+    st = None if feature_state is None else np.ascontiguousarray(feature_state, np.uint8)
+    fq = np.full(frame.N, -1, np.int32)
+    n = lib().orbslam_ref_search_by_projection_points(frame.h, len(a[0]), *[_p(v) for v in a], _p(st), th, nnratio, _p(fq))
+    return n, fq
+
+
+def search_by_projection_last(cur, last, has_point, X, Y, Z, desc, outlier=None, bad=None, cur_state=None, th=7.0, mono=True, nnratio=0.9, check_ori=True):
+    hp = np.ascontiguousarray(has_point, np.uint8)
+    X, Y, Z = [np.ascontiguousarray(v, np.float32) for v in (X, Y, Z)]
+    desc = np.ascontiguousarray(desc, np.uint8)
+    out = None if outlier is None else np.ascontiguousarray(outlier, np.uint8)
+    bd = None if bad is None else np.ascontiguousarray(bad, np.uint8)
+    st = None if cur_state is None else np.ascontiguousarray(cur_state, np.uint8)
+    fq = np.full(cur.N, -1, np.int32)
+    n = lib().orbslam_ref_search_by_projection_last(cur.h, last.h, _p(hp), _p(X), _p(Y), _p(Z), _p(desc), _p(out), _p(bd), _p(st), th, int(mono), nnratio, int(check_ori), _p(fq))
+    return n, fq

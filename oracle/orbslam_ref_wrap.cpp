@@ -1,0 +1,235 @@
+// C API around the REFERENCE's own src/Frame.cc and src/ORBmatcher.cc (plus src/ORBextractor.cc and the vendored DBoW2 map
+// types), compiled where they lie under /root/reference by oracle/Makefile into oracle/_ref/liborbslam_ref.so.
+//
+// What is the reference's code in this build: the Frame constructors (ExtractORB on the extractor, UndistortKeyPoints'
+// zero-distortion path, ComputeImageBounds, AssignFeaturesToGrid, PosInGrid), Frame::GetFeaturesInArea,
+// Frame::ComputeStereoMatches, and every ORBmatcher member — here SearchForInitialization, the two per-frame
+// SearchByProjection overloads, DescriptorDistance and ComputeThreeMaxima are exercised.
+// What is NOT: the OpenCV image primitives (the oracle's restatements, ref_shim/cv_image_shim.h), a few lines of CV_32F
+// matrix algebra (include/cvlite/cvlite.h, CVLITE_ALGEBRA) and the MapPoint / KeyFrame members below — MapPoint.cc and
+// KeyFrame.cc pull in the whole map / optimiser, so the handful of accessors the two files call are defined here as plain
+// getters over the same members.  Test infrastructure only.
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <new>
+#include <vector>
+#include "Frame.h"
+#include "KeyFrame.h"
+#include "MapPoint.h"
+#include "ORBmatcher.h"
+#include "ORBextractor.h"
+
+using namespace ORB_SLAM2;
+
+// ---- bump arena for std::list<ExtractorNode> nodes: (size, pointer) sort of DistributeOctTree == tie-break H1 (see orbextractor_ref_wrap.cpp)
+namespace {
+const size_t kNodeBytes = sizeof(std::_List_node<ORB_SLAM2::ExtractorNode>);
+const size_t kArenaBytes = (size_t)256 << 20;
+char* g_arena = nullptr; size_t g_used = 0;
+inline bool in_arena(void* p) { return g_arena && (char*)p >= g_arena && (char*)p < g_arena + kArenaBytes; }
+}
+void* operator new(size_t n)
+{
+    if (n == kNodeBytes) {
+        if (!g_arena) g_arena = (char*)malloc(kArenaBytes);
+        const size_t a = (n + 15) & ~(size_t)15;
+        const size_t at = __atomic_fetch_add(&g_used, a, __ATOMIC_RELAXED);      // the stereo constructor extracts on two threads
+        if (g_arena && at + a <= kArenaBytes) return g_arena + at;
+    }
+    void* p = malloc(n ? n : 1);
+    if (!p) throw std::bad_alloc();
+    return p;
+}
+void operator delete(void* p) noexcept { if (p && !in_arena(p)) free(p); }
+void operator delete(void* p, size_t) noexcept { if (p && !in_arena(p)) free(p); }
+
+// ---- MapPoint / KeyFrame members referenced by Frame.cc / ORBmatcher.cc (their own .cc files are not part of this build)
+namespace ORB_SLAM2 {
+long unsigned int MapPoint::nNextId = 0;
+std::mutex MapPoint::mGlobalMutex;
+static const uint8_t* g_next_desc = nullptr;          // descriptor handed to the next ComputeDistinctiveDescriptors()
+MapPoint::MapPoint(const cv::Mat& Pos, KeyFrame* pRefKF, Map* pMap)
+    : mnFirstKFid(0), mnFirstFrame(0), nObs(0), mTrackProjX(0), mTrackProjY(0), mTrackProjXR(0), mbTrackInView(false), mnTrackScaleLevel(0),
+      mTrackViewCos(1.0f), mnTrackReferenceForFrame(0), mnLastFrameSeen(0), mnBALocalForKF(0), mnFuseCandidateForKF(0), mnLoopPointForKF(0),
+      mnCorrectedByKF(0), mnCorrectedReference(0), mnBAGlobalForKF(0), mpRefKF(pRefKF), mnVisible(1), mnFound(1), mbBad(false),
+      mpReplaced(static_cast<MapPoint*>(NULL)), mfMinDistance(0), mfMaxDistance(0), mpMap(pMap)
+{
+    Pos.copyTo(mWorldPos);
+    mNormalVector = cv::Mat(cv::Mat::zeros(3, 1, CV_32F));
+    mnId = nNextId++;
+}
+cv::Mat MapPoint::GetWorldPos() { return mWorldPos.clone(); }
+cv::Mat MapPoint::GetNormal() { return mNormalVector.clone(); }
+cv::Mat MapPoint::GetDescriptor() { return mDescriptor.clone(); }
+int MapPoint::Observations() { return nObs; }
+bool MapPoint::isBad() { return mbBad; }
+void MapPoint::SetBadFlag() { mbBad = true; }
+void MapPoint::ComputeDistinctiveDescriptors() { mDescriptor.create(1, 32, CV_8U); memcpy(mDescriptor.data, g_next_desc, 32); }
+float MapPoint::GetMinDistanceInvariance() { return 0.8f * mfMinDistance; }
+float MapPoint::GetMaxDistanceInvariance() { return 1.2f * mfMaxDistance; }
+void MapPoint::AddObservation(KeyFrame*, size_t) { nObs++; }
+int MapPoint::GetIndexInKeyFrame(KeyFrame*) { return -1; }
+bool MapPoint::IsInKeyFrame(KeyFrame*) { return false; }
+void MapPoint::Replace(MapPoint*) {}
+int MapPoint::PredictScale(const float&, KeyFrame*) { return 0; }
+int MapPoint::PredictScale(const float&, Frame*) { return 0; }
+static void not_built(const char* what) { fprintf(stderr, "%s is not part of the oracle build\n", what); abort(); }
+void KeyFrame::AddMapPoint(MapPoint*, const size_t&) { not_built("KeyFrame::AddMapPoint"); }
+cv::Mat KeyFrame::GetCameraCenter() { not_built("KeyFrame::GetCameraCenter"); return cv::Mat(); }
+std::vector<size_t> KeyFrame::GetFeaturesInArea(const float&, const float&, const float&) const { not_built("KeyFrame::GetFeaturesInArea"); return std::vector<size_t>(); }
+MapPoint* KeyFrame::GetMapPoint(const size_t&) { not_built("KeyFrame::GetMapPoint"); return NULL; }
+std::vector<MapPoint*> KeyFrame::GetMapPointMatches() { not_built("KeyFrame::GetMapPointMatches"); return std::vector<MapPoint*>(); }
+std::set<MapPoint*> KeyFrame::GetMapPoints() { not_built("KeyFrame::GetMapPoints"); return std::set<MapPoint*>(); }
+cv::Mat KeyFrame::GetRotation() { not_built("KeyFrame::GetRotation"); return cv::Mat(); }
+cv::Mat KeyFrame::GetTranslation() { not_built("KeyFrame::GetTranslation"); return cv::Mat(); }
+bool KeyFrame::IsInImage(const float&, const float&) const { not_built("KeyFrame::IsInImage"); return false; }
+}  // namespace ORB_SLAM2
+
+namespace {
+struct Rig { ORBextractor* left; ORBextractor* right; };
+std::map<std::vector<int>, Rig> g_rigs;
+Rig& rig(int nfeat, float scale, int nlevels, int ini, int mn)
+{
+    std::vector<int> key = {nfeat, (int)(scale * 100000), nlevels, ini, mn};
+    auto it = g_rigs.find(key);
+    if (it == g_rigs.end()) { Rig r = {new ORBextractor(nfeat, scale, nlevels, ini, mn), new ORBextractor(nfeat, scale, nlevels, ini, mn)}; it = g_rigs.insert(std::make_pair(key, r)).first; }
+    return it->second;
+}
+cv::Mat camera(float fx, float fy, float cx, float cy)
+{
+    cv::Mat K = cv::Mat::eye(3, 3, CV_32F);
+    K.at<float>(0, 0) = fx; K.at<float>(1, 1) = fy; K.at<float>(0, 2) = cx; K.at<float>(1, 2) = cy;
+    return K;
+}
+std::vector<MapPoint*> g_keep;           // map points live as long as the process (the reference never frees them either)
+MapPoint* make_point(float x, float y, float z, const uint8_t* desc, int nobs, bool bad)
+{
+    cv::Mat pos(3, 1, CV_32F); pos.at<float>(0) = x; pos.at<float>(1) = y; pos.at<float>(2) = z;
+    MapPoint* p = new MapPoint(pos, NULL, NULL);
+    if (desc) { ORB_SLAM2::g_next_desc = desc; p->ComputeDistinctiveDescriptors(); }
+    p->nObs = nobs;
+    if (bad) p->SetBadFlag();
+    g_keep.push_back(p);
+    return p;
+}
+}
+
+extern "C" {
+
+// Frame::Frame(imGray, timeStamp, extractor, voc, K, distCoef, bf, thDepth)  (Frame.cc:174-225).  new_geometry != 0 resets the
+// static image bounds / grid cell sizes the first Frame of a run computes (Frame.cc:204-221).
+void* orbslam_ref_frame_mono(const uint8_t* img, int w, int h, int stride, int nfeat, float scale, int nlevels, int ini, int mn,
+                             float fx, float fy, float cx, float cy, float bf, float thDepth, int new_geometry)
+{
+    g_used = 0;
+    if (new_geometry) Frame::mbInitialComputations = true;
+    cv::Mat im(h, w, CV_8UC1, (void*)img, (size_t)stride), K = camera(fx, fy, cx, cy), D = cv::Mat(cv::Mat::zeros(4, 1, CV_32F));
+    return new Frame(im, 0.0, rig(nfeat, scale, nlevels, ini, mn).left, NULL, K, D, bf, thDepth);
+}
+// Frame::Frame(imLeft, imRight, ...)  (Frame.cc:62-115): two extractor threads, ComputeStereoMatches
+void* orbslam_ref_frame_stereo(const uint8_t* imgL, const uint8_t* imgR, int w, int h, int stride, int nfeat, float scale, int nlevels, int ini, int mn,
+                               float fx, float fy, float cx, float cy, float bf, float thDepth, int new_geometry)
+{
+    g_used = 0;
+    if (new_geometry) Frame::mbInitialComputations = true;
+    cv::Mat L(h, w, CV_8UC1, (void*)imgL, (size_t)stride), R(h, w, CV_8UC1, (void*)imgR, (size_t)stride), K = camera(fx, fy, cx, cy), D = cv::Mat(cv::Mat::zeros(4, 1, CV_32F));
+    Rig& r = rig(nfeat, scale, nlevels, ini, mn);
+    // The stereo constructor calls ComputeStereoMatches() (Frame.cc:89) BEFORE it assigns `mb = mbf/fx` (Frame.cc:113), and `mb` is
+    // not in the initialiser list: ComputeStereoMatches reads it uninitialised (Frame.cc:496-498).  In the running system the Frame
+    // is a temporary whose storage still holds the previous frame's value, which is what makes it work from the second frame on.
+    // Here the storage is pre-seeded with that steady-state value.
+    void* mem = ::operator new(sizeof(Frame));
+    memset(mem, 0, sizeof(Frame));
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(mem) + ((char*)&((Frame*)mem)->mb - (char*)mem)) = bf / fx;
+    return new (mem) Frame(L, R, 0.0, r.left, r.right, NULL, K, D, bf, thDepth);
+}
+void orbslam_ref_frame_delete(void* f) { delete (Frame*)f; }
+int orbslam_ref_frame_n(void* f) { return ((Frame*)f)->N; }
+void orbslam_ref_frame_get(void* fp, void* keys, void* keysUn, uint8_t* desc, float* uRight, float* depth)
+{
+    Frame* f = (Frame*)fp;
+    static_assert(sizeof(cv::KeyPoint) == 28, "KeyPoint layout");
+    for (int i = 0; i < f->N; i++) {
+        if (keys) memcpy((char*)keys + (size_t)i * 28, &f->mvKeys[i], 28);
+        if (keysUn) memcpy((char*)keysUn + (size_t)i * 28, &f->mvKeysUn[i], 28);
+        if (desc) memcpy(desc + (size_t)i * 32, f->mDescriptors.ptr(i), 32);
+        if (uRight) uRight[i] = f->mvuRight[i];
+        if (depth) depth[i] = f->mvDepth[i];
+    }
+}
+// Frame::GetFeaturesInArea (Frame.cc:327-380)
+int orbslam_ref_features_in_area(void* fp, float x, float y, float r, int minLevel, int maxLevel, int* out, int cap)
+{
+    std::vector<size_t> v = ((Frame*)fp)->GetFeaturesInArea(x, y, r, minLevel, maxLevel);
+    for (size_t i = 0; i < v.size() && (int)i < cap; i++) out[i] = (int)v[i];
+    return (int)v.size();
+}
+// ORBmatcher(nnratio, checkOri).SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize)  (ORBmatcher.cc:405-520)
+int orbslam_ref_search_for_initialization(void* f1, void* f2, float* prev_xy, int* matches12, int window, float nnratio, int check_ori)
+{
+    Frame &F1 = *(Frame*)f1, &F2 = *(Frame*)f2;
+    std::vector<cv::Point2f> prev(F1.N);
+    for (int i = 0; i < F1.N; i++) prev[i] = cv::Point2f(prev_xy[2 * i], prev_xy[2 * i + 1]);
+    std::vector<int> m12;
+    ORBmatcher matcher(nnratio, check_ori != 0);
+    const int n = matcher.SearchForInitialization(F1, F2, prev, m12, window);
+    for (int i = 0; i < F1.N; i++) { matches12[i] = m12[i]; prev_xy[2 * i] = prev[i].x; prev_xy[2 * i + 1] = prev[i].y; }
+    return n;
+}
+int orbslam_ref_descriptor_distance(const uint8_t* a, const uint8_t* b)
+{
+    cv::Mat ma(1, 32, CV_8U), mb(1, 32, CV_8U); memcpy(ma.data, a, 32); memcpy(mb.data, b, 32);
+    return ORBmatcher::DescriptorDistance(ma, mb);
+}
+// preset F.mvpMapPoints: state[i] = 0 none, 1 a map point without observations, 2 a map point with observations
+static void preset(Frame& F, const uint8_t* state)
+{
+    for (int i = 0; i < F.N; i++) F.mvpMapPoints[i] = (!state || state[i] == 0) ? NULL : make_point(0, 0, 1, NULL, state[i] == 2 ? 1 : 0, false);
+}
+// ORBmatcher(nnratio).SearchByProjection(F, vpMapPoints, th)  (ORBmatcher.cc:45-129).  Query q = a local-map point the caller
+// already projected (Frame::isInFrustum fills mTrackProjX/Y/XR, mnTrackScaleLevel, mTrackViewCos, mbTrackInView).
+int orbslam_ref_search_by_projection_points(void* fp, int nq, const float* px, const float* py, const float* pxr, const int* level, const float* viewcos,
+                                            const uint8_t* inview, const uint8_t* bad, const int* nobs, const uint8_t* desc, const uint8_t* feature_state,
+                                            float th, float nnratio, int* feature_query)
+{
+    Frame& F = *(Frame*)fp;
+    preset(F, feature_state);
+    std::vector<MapPoint*> pts(nq);
+    std::map<MapPoint*, int> index;
+    for (int q = 0; q < nq; q++) {
+        MapPoint* p = make_point(0, 0, 1, desc + (size_t)q * 32, nobs[q], bad[q] != 0);
+        p->mTrackProjX = px[q]; p->mTrackProjY = py[q]; p->mTrackProjXR = pxr[q]; p->mnTrackScaleLevel = level[q]; p->mTrackViewCos = viewcos[q]; p->mbTrackInView = inview[q] != 0;
+        pts[q] = p; index[p] = q;
+    }
+    ORBmatcher matcher(nnratio);
+    const int n = matcher.SearchByProjection(F, pts, th);
+    for (int i = 0; i < F.N; i++) { auto it = index.find(F.mvpMapPoints[i]); feature_query[i] = it == index.end() ? -1 : it->second; }
+    return n;
+}
+// ORBmatcher(nnratio, checkOri).SearchByProjection(CurrentFrame, LastFrame, th, bMono)  (ORBmatcher.cc:1328-1470) with the
+// current pose = identity: a last-frame map point at world (X, Y, Z) projects to (fx X / Z + cx, fy Y / Z + cy).
+int orbslam_ref_search_by_projection_last(void* cur, void* last, const uint8_t* has_point, const float* X, const float* Y, const float* Z, const uint8_t* desc,
+                                          const uint8_t* outlier, const uint8_t* bad, const uint8_t* cur_state, float th, int mono, float nnratio, int check_ori,
+                                          int* feature_query)
+{
+    Frame &C = *(Frame*)cur, &Lf = *(Frame*)last;
+    preset(C, cur_state);
+    cv::Mat T = cv::Mat::eye(4, 4, CV_32F);
+    C.SetPose(T); Lf.SetPose(T);
+    std::map<MapPoint*, int> index;
+    for (int i = 0; i < Lf.N; i++) {
+        Lf.mvpMapPoints[i] = NULL; Lf.mvbOutlier[i] = outlier && outlier[i];
+        if (!has_point[i]) continue;
+        MapPoint* p = make_point(X[i], Y[i], Z[i], desc + (size_t)i * 32, 1, bad && bad[i]);
+        Lf.mvpMapPoints[i] = p; index[p] = i;
+    }
+    ORBmatcher matcher(nnratio, check_ori != 0);
+    const int n = matcher.SearchByProjection(C, Lf, th, mono != 0);
+    for (int i = 0; i < C.N; i++) { auto it = index.find(C.mvpMapPoints[i]); feature_query[i] = it == index.end() ? -1 : it->second; }
+    return n;
+}
+
+}  // extern "C"

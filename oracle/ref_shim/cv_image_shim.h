@@ -8,6 +8,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cassert>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -87,6 +89,16 @@ static inline void copyMakeBorder(InputArray src, OutputArray dst, int top, int 
     Mat d = dst.getMat();
     for (int y = 0; y < tmp.rows; y++) memcpy(d.ptr(y), tmp.ptr(y), tmp.cols);
 }
+
+#ifdef CVLITE_ALGEBRA
+// distorted cameras only (Frame::UndistortKeyPoints / ComputeImageBounds take this branch when mDistCoef[0] != 0): not part of
+// the oracle builds, which use rectified / undistorted synthetic cameras
+static inline void undistortPoints(InputArray, OutputArray, InputArray, InputArray, InputArray, InputArray)
+{
+    fprintf(stderr, "cv::undistortPoints is not part of the oracle build (use zero distortion coefficients)\n"); abort();
+}
+inline Mat Mat::reshape(int, int) const { fprintf(stderr, "cv::Mat::reshape is not part of the oracle build\n"); abort(); }
+#endif
 
 struct KeyPointsFilter {                                         // only used by the dead ComputeKeyPointsOld (ORBextractor.cc:1006,1024)
     static void retainBest(std::vector<KeyPoint>& k, int n)
