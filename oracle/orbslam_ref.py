@@ -41,6 +41,7 @@ def lib():
         L.orbslam_ref_descriptor_distance.argtypes = [vp, vp]
         L.orbslam_ref_search_by_projection_points.argtypes = [vp, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f, f, vp]
         L.orbslam_ref_search_by_projection_last.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f, i, f, i, vp]
+        L.orbslam_ref_search_by_bow.argtypes = [i, vp, vp, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, vp, i, f, i, vp]
         _lib = L
     return _lib
 
@@ -112,3 +113,15 @@ def search_by_projection_last(cur, last, has_point, X, Y, Z, desc, outlier=None,
     fq = np.full(cur.N, -1, np.int32)
     n = lib().orbslam_ref_search_by_projection_last(cur.h, last.h, _p(hp), _p(X), _p(Y), _p(Z), _p(desc), _p(out), _p(bd), _p(st), th, int(mono), nnratio, int(check_ori), _p(fq))
     return n, fq
+
+
+def search_by_bow(mode, f1, has1, bad1, fv1, f2, has2, bad2, fv2, nnratio=0.7, check_ori=True):
+    """ORBmatcher::SearchByBoW through real KeyFrame / Frame objects; fv = (node ids, offsets, feature indices)"""
+    u8 = lambda a, n: np.zeros(n, np.uint8) if a is None else np.ascontiguousarray(a, np.uint8)
+    has1, bad1, has2, bad2 = u8(has1, f1.N), u8(bad1, f1.N), u8(has2, f2.N), u8(bad2, f2.N)
+    a1 = [np.ascontiguousarray(fv1[0], np.uint32), np.ascontiguousarray(fv1[1], np.int32), np.ascontiguousarray(fv1[2], np.uint32)]
+    a2 = [np.ascontiguousarray(fv2[0], np.uint32), np.ascontiguousarray(fv2[1], np.int32), np.ascontiguousarray(fv2[2], np.uint32)]
+    m12 = np.full(f1.N, -1, np.int32)
+    n = lib().orbslam_ref_search_by_bow(mode, f1.h, _p(has1), _p(bad1), _p(a1[0]), _p(a1[1]), _p(a1[2]), len(a1[0]),
+                                        f2.h, _p(has2), _p(bad2), _p(a2[0]), _p(a2[1]), _p(a2[2]), len(a2[0]), nnratio, int(check_ori), _p(m12))
+    return n, m12

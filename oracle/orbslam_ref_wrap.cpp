@@ -81,7 +81,25 @@ void KeyFrame::AddMapPoint(MapPoint*, const size_t&) { not_built("KeyFrame::AddM
 cv::Mat KeyFrame::GetCameraCenter() { not_built("KeyFrame::GetCameraCenter"); return cv::Mat(); }
 std::vector<size_t> KeyFrame::GetFeaturesInArea(const float&, const float&, const float&) const { not_built("KeyFrame::GetFeaturesInArea"); return std::vector<size_t>(); }
 MapPoint* KeyFrame::GetMapPoint(const size_t&) { not_built("KeyFrame::GetMapPoint"); return NULL; }
-std::vector<MapPoint*> KeyFrame::GetMapPointMatches() { not_built("KeyFrame::GetMapPointMatches"); return std::vector<MapPoint*>(); }
+std::vector<MapPoint*> KeyFrame::GetMapPointMatches() { return mvpMapPoints; }
+long unsigned int KeyFrame::nNextId = 0;
+// KeyFrame(Frame&, Map*, KeyFrameDatabase*): a key frame is a frozen copy of the frame's features (the real constructor lives in
+// KeyFrame.cc, which drags the map in); every const member is taken from the frame it is made of
+KeyFrame::KeyFrame(Frame& F, Map* pMap, KeyFrameDatabase* pKFDB)
+    : mnFrameId(F.mnId), mTimeStamp(F.mTimeStamp), mnGridCols(FRAME_GRID_COLS), mnGridRows(FRAME_GRID_ROWS),
+      mfGridElementWidthInv(F.mfGridElementWidthInv), mfGridElementHeightInv(F.mfGridElementHeightInv),
+      mnTrackReferenceForFrame(0), mnFuseTargetForKF(0), mnBALocalForKF(0), mnBAFixedForKF(0), mnLoopQuery(0), mnLoopWords(0), mLoopScore(0),
+      mnRelocQuery(0), mnRelocWords(0), mRelocScore(0), mnBAGlobalForKF(0),
+      fx(F.fx), fy(F.fy), cx(F.cx), cy(F.cy), invfx(F.invfx), invfy(F.invfy), mbf(F.mbf), mb(F.mb), mThDepth(F.mThDepth), N(F.N),
+      mvKeys(F.mvKeys), mvKeysUn(F.mvKeysUn), mvuRight(F.mvuRight), mvDepth(F.mvDepth), mDescriptors(F.mDescriptors.clone()),
+      mBowVec(F.mBowVec), mFeatVec(F.mFeatVec), mnScaleLevels(F.mnScaleLevels), mfScaleFactor(F.mfScaleFactor), mfLogScaleFactor(F.mfLogScaleFactor),
+      mvScaleFactors(F.mvScaleFactors), mvLevelSigma2(F.mvLevelSigma2), mvInvLevelSigma2(F.mvInvLevelSigma2),
+      mnMinX(F.mnMinX), mnMinY(F.mnMinY), mnMaxX(F.mnMaxX), mnMaxY(F.mnMaxY), mK(F.mK),
+      mvpMapPoints(F.mvpMapPoints), mpKeyFrameDB(pKFDB), mpORBvocabulary(F.mpORBvocabulary), mbFirstConnection(true), mpParent(NULL),
+      mbNotErase(false), mbToBeErased(false), mbBad(false), mHalfBaseline(F.mb / 2), mpMap(pMap)
+{
+    mnId = nNextId++;
+}
 std::set<MapPoint*> KeyFrame::GetMapPoints() { not_built("KeyFrame::GetMapPoints"); return std::set<MapPoint*>(); }
 cv::Mat KeyFrame::GetRotation() { not_built("KeyFrame::GetRotation"); return cv::Mat(); }
 cv::Mat KeyFrame::GetTranslation() { not_built("KeyFrame::GetTranslation"); return cv::Mat(); }
@@ -229,6 +247,52 @@ int orbslam_ref_search_by_projection_last(void* cur, void* last, const uint8_t* 
     ORBmatcher matcher(nnratio, check_ori != 0);
     const int n = matcher.SearchByProjection(C, Lf, th, mono != 0);
     for (int i = 0; i < C.N; i++) { auto it = index.find(C.mvpMapPoints[i]); feature_query[i] = it == index.end() ? -1 : it->second; }
+    return n;
+}
+
+static void fill_fv(DBoW2::FeatureVector& fv, const uint32_t* node, const int* off, const uint32_t* feat, int nfv)
+{
+    fv.clear();
+    for (int j = 0; j < nfv; j++) fv.insert(fv.end(), std::make_pair(node[j], std::vector<unsigned int>(feat + off[j], feat + off[j + 1])));
+}
+static void give_points(Frame& F, const uint8_t* valid, const uint8_t* bad, std::map<MapPoint*, int>& index)
+{
+    for (int i = 0; i < F.N; i++) {
+        F.mvpMapPoints[i] = NULL;
+        if (!valid[i]) continue;
+        MapPoint* p = make_point(0, 0, 1, NULL, 1, bad && bad[i]);
+        F.mvpMapPoints[i] = p; index[p] = i;
+    }
+}
+// ORBmatcher(nnratio, checkOri).SearchByBoW.  mode 0: (KeyFrame* made of frame f1, Frame f2, vpMapPointMatches)  ORBmatcher.cc:159-288;
+// mode 1: (KeyFrame* of f1, KeyFrame* of f2, vpMatches12) :522-655.  has1/has2 = the feature carries a map point, bad1/bad2 = that
+// point isBad().  match12[i1] = matched feature of side 2 or -1.
+int orbslam_ref_search_by_bow(int mode, void* f1, const uint8_t* has1, const uint8_t* bad1, const uint32_t* n1, const int* o1, const uint32_t* ft1, int nf1,
+                              void* f2, const uint8_t* has2, const uint8_t* bad2, const uint32_t* n2, const int* o2, const uint32_t* ft2, int nf2,
+                              float nnratio, int check_ori, int* match12)
+{
+    Frame &F1 = *(Frame*)f1, &F2 = *(Frame*)f2;
+    std::map<MapPoint*, int> idx1, idx2;
+    give_points(F1, has1, bad1, idx1);
+    fill_fv(F1.mFeatVec, n1, o1, ft1, nf1);
+    fill_fv(F2.mFeatVec, n2, o2, ft2, nf2);
+    for (int i = 0; i < F1.N; i++) match12[i] = -1;
+    ORBmatcher matcher(nnratio, check_ori != 0);
+    KeyFrame* kf1 = new KeyFrame(F1, NULL, NULL);
+    int n = 0;
+    if (mode == 0) {
+        std::vector<MapPoint*> out;
+        n = matcher.SearchByBoW(kf1, F2, out);
+        for (int i2 = 0; i2 < F2.N; i2++) if (out[i2]) match12[idx1[out[i2]]] = i2;
+    } else {
+        give_points(F2, has2, bad2, idx2);
+        KeyFrame* kf2 = new KeyFrame(F2, NULL, NULL);
+        std::vector<MapPoint*> out;
+        n = matcher.SearchByBoW(kf1, kf2, out);
+        for (int i1 = 0; i1 < F1.N; i1++) if (out[i1]) match12[i1] = idx2[out[i1]];
+        delete kf2;
+    }
+    delete kf1;
     return n;
 }
 

@@ -3,7 +3,8 @@
 oracle/_ref/liborbslam_ref.so = those two files + src/ORBextractor.cc compiled where they lie under /root/reference
 (`make -C oracle ref`): the Frame constructors (mono and stereo, with the reference's two extractor threads),
 AssignFeaturesToGrid / GetFeaturesInArea, ComputeStereoMatches and every ORBmatcher member are the reference's code; the
-OpenCV image primitives are the oracle's restatements, MapPoint / KeyFrame accessors are plain getters in the wrapper
+OpenCV image primitives are the oracle's restatements, MapPoint / KeyFrame accessors (and the KeyFrame-from-Frame constructor)
+are plain member copies in the wrapper
 (oracle/orbslam_ref_wrap.cpp).  Cameras: zero distortion; for the projection searches identity pose and fx = fy = 1,
 cx = cy = 0, so that a map point at (X, Y, 1) projects to (X, Y) exactly and the reference's own projection code feeds its
 search loop with the same numbers the flat queries carry.  Skipped where neither /root/reference nor a prebuilt library exists."""
@@ -157,6 +158,25 @@ def test_search_by_projection_last_frame(ref, oracle, pair, th, ori, stereo):
     assert n_o > 100
     if stereo:
         cur.close()
+
+
+@pytest.mark.parametrize("mode,levelsup,ratio,ori", [(0, 2, 0.7, True), (0, 1, 0.75, False), (1, 2, 0.8, True), (1, 3, 0.9, True), (0, 4, 0.7, True)])
+def test_search_by_bow(ref, oracle, pair, mode, levelsup, ratio, ori):
+    """ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ..) (ORBmatcher.cc:159-288) and (KeyFrame*, KeyFrame*, ..) (:522-655) through real
+    KeyFrame / Frame objects whose mFeatVec comes from the golden vocabulary; some map points missing, some bad."""
+    w, h, n, seq, sf, K, F = pair
+    (k1, d1), (k2, d2) = K
+    ov = oracle.OracleVocabulary(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "voc_k6_L3_ref.txt"))
+    fv1, fv2 = ov.transform(d1, levelsup)[2:], ov.transform(d2, levelsup)[2:]
+    rng = np.random.default_rng(mode * 10 + levelsup)
+    has1 = (rng.random(len(k1)) < 0.75).astype(np.uint8); bad1 = (rng.random(len(k1)) < 0.07).astype(np.uint8)
+    has2 = (rng.random(len(k2)) < 0.85).astype(np.uint8); bad2 = (rng.random(len(k2)) < 0.07).astype(np.uint8)
+    n_r, m_r = ref.search_by_bow(mode, F[0], has1, bad1, fv1, F[1], has2, bad2, fv2, nnratio=ratio, check_ori=ori)
+    v1 = (has1 & (1 - bad1)).astype(np.uint8)
+    v2 = (has2 & (1 - bad2)).astype(np.uint8) if mode == 1 else None
+    n_o, m_o = oracle.search_by_bow(mode, d1, k1["angle"], v1, fv1, d2, k2["angle"], v2, fv2, nnratio=ratio, check_ori=ori)
+    assert n_r == n_o and np.array_equal(m_r, m_o)
+    assert n_o > 30
 
 
 def test_product_equals_reference_matcher_and_stereo(ref, pair, emu_lib):
