@@ -387,28 +387,55 @@ __host__ __device__ __forceinline__ int fc_wave_bytes(int pstride, int prows, in
     return ((pstride * prows + 15) & ~15) + ((sstride * srows + 15) & ~15) + ((2 * listcap + 15) & ~15);
 }
 
+// ring of the pixel pair (Q, Q+1) of a 4-pixel group whose 7 x 12-byte window is w[7][3] (circle: FAST 16-point Bresenham);
+// ring element k of pixel q sits at row 3+dy_k, byte 3+q+dx_k
+#define FC_RING(Q) { \
+    row_pair<3 + Q + 0>(w[6][0], w[6][1], w[6][2]), row_pair<3 + Q + 1>(w[6][0], w[6][1], w[6][2]), row_pair<3 + Q + 2>(w[5][0], w[5][1], w[5][2]), row_pair<3 + Q + 3>(w[4][0], w[4][1], w[4][2]), \
+    row_pair<3 + Q + 3>(w[3][0], w[3][1], w[3][2]), row_pair<3 + Q + 3>(w[2][0], w[2][1], w[2][2]), row_pair<3 + Q + 2>(w[1][0], w[1][1], w[1][2]), row_pair<3 + Q + 1>(w[0][0], w[0][1], w[0][2]), \
+    row_pair<3 + Q + 0>(w[0][0], w[0][1], w[0][2]), row_pair<3 + Q - 1>(w[0][0], w[0][1], w[0][2]), row_pair<3 + Q - 2>(w[1][0], w[1][1], w[1][2]), row_pair<3 + Q - 3>(w[2][0], w[2][1], w[2][2]), \
+    row_pair<3 + Q - 3>(w[3][0], w[3][1], w[3][2]), row_pair<3 + Q - 3>(w[4][0], w[4][1], w[4][2]), row_pair<3 + Q - 2>(w[5][0], w[5][1], w[5][2]), row_pair<3 + Q - 1>(w[6][0], w[6][1], w[6][2]) }
+
+// Necessary condition for "corner at threshold t" of a pixel pair: a 9-arc contains one pixel of every opposite pair (k, k+8),
+// so all eight max(r_k, r_k+8) exceed C + t (bright arc) or all eight min(r_k, r_k+8) are below C - t (dark arc).
+// Returns per 16-bit lane a non-zero value where the test passes.  30 packed min/max instead of 118 for the exact score.
+__device__ __forceinline__ pki16 fast_pretest_pair(const pku16 r[16], pku16 c, int t)
+{
+    pku16 mn = pmax(r[0], r[8]), mx = pmin(r[0], r[8]);
+#pragma unroll
+    for (int k = 1; k < 8; k++) { mn = pmin(mn, pmax(r[k], r[k + 8])); mx = pmax(mx, pmin(r[k], r[k + 8])); }
+    const pki16 tt = {(short)t, (short)t};
+    const pki16 bright = (pki16)mn - (pki16)c, dark = (pki16)c - (pki16)mx;          // margins of the weakest opposite pair
+    return (bright > tt) | (dark > tt);
+}
+
+__device__ __forceinline__ void fc_load_window(const uint8_t* patch, int PS, int y, int grp, unsigned (&w)[7][3])
+{
+    const unsigned* prow = reinterpret_cast<const unsigned*>(patch + y * PS) + grp;
+#pragma unroll
+    for (int r = 0; r < 7; r++) { w[r][0] = prow[r * (PS >> 2)]; w[r][1] = prow[r * (PS >> 2) + 1]; w[r][2] = prow[r * (PS >> 2) + 2]; }
+}
+
 __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
 {
     HIP_DYNAMIC_SHARED(unsigned, fc_lds)
-    __shared__ unsigned long long s_mmin[FC_WAVES][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int tile, frame;
     if (!xcd_frame_map((P.ncells_total + FC_WAVES - 1) / FC_WAVES, P.nframes, tile, frame)) return;
     frame += P.frame0;
     const int cell_id = tile * FC_WAVES + wave;
-    const bool active = cell_id < P.ncells_total;
-    CellDesc cd; cd.skipped = 1; cd.level = 0; cd.iniX = cd.iniY = cd.maxX = cd.maxY = 0; cd.shiftX = cd.shiftY = 0; cd.cand_idx = 0; cd.cand_cap = 0;
-    if (active) cd = P.cells[cell_id];
+    if (cell_id >= P.ncells_total) return;                              // every LDS region below is private to its wave: no workgroup barriers
+    const CellDesc cd = P.cells[cell_id];
     const int pw = cd.maxX - cd.iniX, ph = cd.maxY - cd.iniY;       // sub-image
     const int cw = pw - 6, ch = ph - 6;                              // examined interior (rows/cols 3 .. n-4)
-    const bool work = active && !cd.skipped && cw > 0 && ch > 0;
+    const bool work = !cd.skipped && cw > 0 && ch > 0;
+    if (!work) { if (lane == 0) P.cell_count[(long long)frame * P.ncells_total + cell_id] = 0; return; }
     const int PS = P.fc_pstride, SS = P.fc_sstride;                  // byte strides, multiples of 4
     uint8_t* wbase = reinterpret_cast<uint8_t*>(fc_lds) + wave * fc_wave_bytes(PS, P.fc_prows, SS, P.fc_srows, P.fc_listcap);
     uint8_t* patch = wbase;                                          // patch column 0 is 4-byte aligned
     uint8_t* score = wbase + ((PS * P.fc_prows + 15) & ~15);         // interior (x, y) at score[(y+1)*SS + 4 + x]; zero ring around it
     unsigned short* list = reinterpret_cast<unsigned short*>(score + ((SS * P.fc_srows + 15) & ~15));
     const int ng = (cw + 3) >> 2;                                    // 4-pixel groups per interior row
-    if (work) {
+    {
         int spitch; const uint8_t* src = level_src(P, frame, cd.level, spitch);
         src += (long long)cd.iniY * spitch + cd.iniX;
         const int nd = (pw + 3) >> 2;
@@ -443,35 +470,111 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
                 c += 64; while (c >= pw) { c -= pw; r++; }
             }
         }
-        // zero ring of the score map: first / last row, and the left pad dword + right pad dword of every row
-        const int sdw = SS >> 2;
-        for (int i = lane; i < sdw; i += 64) { reinterpret_cast<unsigned*>(score)[i] = 0; reinterpret_cast<unsigned*>(score + (ch + 1) * SS)[i] = 0; }
-        for (int r = lane; r < ch; r += 64) { unsigned* row = reinterpret_cast<unsigned*>(score + (r + 1) * SS); row[0] = 0; row[1 + ng] = 0; }
+        // the whole score map starts at zero: the first pass below only fills the 4-pixel groups it examines
+        for (int i = lane; i < (SS >> 2) * (ch + 2); i += 64) reinterpret_cast<unsigned*>(score)[i] = 0;
     }
-    __syncthreads();
-    // ---- A. scores of all examined pixels, 4 pixels (two packed pairs) per lane; corners compacted in row-major order
-    const int rp = work ? 64 / ng : 1;                                // interior rows handled per wave iteration
-    const int sr = work ? lane / ng : 0, grp = work ? lane - sr * ng : 0;
-    const int iters = work ? (ch + rp - 1) / rp : 0;
-    const bool lane_ok = work && sr < rp;
+    __builtin_amdgcn_wave_barrier();
+    const int rp = 64 / ng;                                           // interior rows handled per wave iteration
+    const int sr = lane / ng, grp = lane - sr * ng;
+    const int iters = (ch + rp - 1) / rp;
+    const bool lane_ok = sr < rp;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    unsigned* out = P.cell_cand + (long long)frame * P.cand_slots_per_frame + cd.cand_idx;
+
+    // ---- 1. the first cv::FAST call of the reference (iniThFAST, ORBextractor.cc:809-810).  Only pixels with score >= iniThFAST
+    //      matter for it, and NMS at iniThFAST sees every weaker pixel as 0, so:
+    //      a. cheap necessary test at iniThFAST on every 4-pixel group -> ordered list of the groups that may hold such a pixel
+    //      b. exact scores of those groups only (compacted: a lane per listed group)
+    //      c. NMS + row-major emission over the listed groups
+    int nq = 0;
+    for (int it = 0; it < iters; it++) {
+        const int y = it * rp + sr;
+        bool pass = false;
+        if (lane_ok && y < ch) {
+            unsigned w[7][3];
+            fc_load_window(patch, PS, y, grp, w);
+            const pku16 ra[16] = FC_RING(0);
+            const pku16 rb[16] = FC_RING(2);
+            const pki16 pa = fast_pretest_pair(ra, row_pair<3>(w[3][0], w[3][1], w[3][2]), P.iniTh);         // score >= t  <=>  best arc margin > t  =>  every opposite pair's margin > t
+            const pki16 pb = fast_pretest_pair(rb, row_pair<5>(w[3][0], w[3][1], w[3][2]), P.iniTh);
+            pass = (pa[0] | pa[1] | pb[0] | pb[1]) != 0;
+        }
+        const unsigned long long m = __ballot(pass);
+        if (pass) list[nq + __popcll(m & below)] = (unsigned short)((y << 8) | grp);
+        nq += __popcll(m);
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int qb = 0; qb < nq; qb += 64) {
+        if (qb + lane < nq) {
+            const int id = list[qb + lane], y = id >> 8, g = id & 0xff, x0 = 4 * g;
+            unsigned w[7][3];
+            fc_load_window(patch, PS, y, g, w);
+            const pku16 ra[16] = FC_RING(0);
+            const pku16 rb[16] = FC_RING(2);
+            const pki16 sa = fast_score_pair(ra, row_pair<3>(w[3][0], w[3][1], w[3][2]));
+            const pki16 sb = fast_score_pair(rb, row_pair<5>(w[3][0], w[3][1], w[3][2]));
+            int sc[4] = {sa[0], sa[1], sb[0], sb[1]};
+#pragma unroll
+            for (int q = 0; q < 4; q++) if (sc[q] < P.iniTh || x0 + q >= cw) sc[q] = 0;
+            *reinterpret_cast<unsigned*>(score + (y + 1) * SS + 4 + x0) = (unsigned)sc[0] | ((unsigned)sc[1] << 8) | ((unsigned)sc[2] << 16) | ((unsigned)sc[3] << 24);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    int count_ini = 0;
+    for (int qb = 0; qb < nq; qb += 64) {
+        bool keep[4] = {false, false, false, false}; int scv[4] = {0, 0, 0, 0}; int y = 0, x0 = 0;
+        if (qb + lane < nq) {
+            const int id = list[qb + lane];
+            y = id >> 8; x0 = 4 * (id & 0xff);
+            const uint8_t* q0 = &score[(y + 1) * SS + 4 + x0];
+            // rows above / at / below, bytes x0-1 .. x0+4 (the pad dwords left and right of a row are zero)
+            const unsigned a0 = *reinterpret_cast<const unsigned*>(q0 - SS - 4), a1 = *reinterpret_cast<const unsigned*>(q0 - SS), a2 = *reinterpret_cast<const unsigned*>(q0 - SS + 4);
+            const unsigned b0 = *reinterpret_cast<const unsigned*>(q0 - 4), b1 = *reinterpret_cast<const unsigned*>(q0), b2 = *reinterpret_cast<const unsigned*>(q0 + 4);
+            const unsigned c0 = *reinterpret_cast<const unsigned*>(q0 + SS - 4), c1 = *reinterpret_cast<const unsigned*>(q0 + SS), c2 = *reinterpret_cast<const unsigned*>(q0 + SS + 4);
+            const unsigned long long ra6 = ((unsigned long long)(a0 >> 24)) | ((unsigned long long)a1 << 8) | ((unsigned long long)(a2 & 0xff) << 40);
+            const unsigned long long rb6 = ((unsigned long long)(b0 >> 24)) | ((unsigned long long)b1 << 8) | ((unsigned long long)(b2 & 0xff) << 40);
+            const unsigned long long rc6 = ((unsigned long long)(c0 >> 24)) | ((unsigned long long)c1 << 8) | ((unsigned long long)(c2 & 0xff) << 40);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int sc = (int)((rb6 >> (8 * (q + 1))) & 0xff);
+                scv[q] = sc;
+                if (sc > 0) {
+                    const int l = (int)((rb6 >> (8 * q)) & 0xff), r = (int)((rb6 >> (8 * (q + 2))) & 0xff);
+                    const int u0 = (int)((ra6 >> (8 * q)) & 0xff), u1 = (int)((ra6 >> (8 * (q + 1))) & 0xff), u2 = (int)((ra6 >> (8 * (q + 2))) & 0xff);
+                    const int d0 = (int)((rc6 >> (8 * q)) & 0xff), d1 = (int)((rc6 >> (8 * (q + 1))) & 0xff), d2 = (int)((rc6 >> (8 * (q + 2))) & 0xff);
+                    keep[q] = sc > l && sc > r && sc > u0 && sc > u1 && sc > u2 && sc > d0 && sc > d1 && sc > d2;
+                }
+            }
+        }
+        const unsigned long long m0 = __ballot(keep[0]), m1 = __ballot(keep[1]), m2 = __ballot(keep[2]), m3 = __ballot(keep[3]);
+        int rank = count_ini + __popcll(m0 & below) + __popcll(m1 & below) + __popcll(m2 & below) + __popcll(m3 & below);
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (keep[q]) {
+                // FAST reports cell-local (x, y); the reference adds (j*wCell, i*hCell)  (ORBextractor.cc:822-823)
+                const unsigned px = (unsigned)(x0 + q + 3 + cd.shiftX), py = (unsigned)(y + 3 + cd.shiftY);
+                if (rank < cd.cand_cap) out[rank] = px | (py << 12) | ((unsigned)scv[q] << 24);
+                rank++;
+            }
+        count_ini += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+    }
+    if (count_ini > 0) {
+        if (lane == 0) P.cell_count[(long long)frame * P.ncells_total + cell_id] = min(count_ini, cd.cand_cap);
+        return;
+    }
+
+    // ---- 2. vKeysCell.empty() -> cv::FAST again with minThFAST (ORBextractor.cc:812-816): exact scores of every examined pixel,
+    //      corners compacted in row-major order, NMS over that list.  Rare on textured frames.
+    __builtin_amdgcn_wave_barrier();
     int ncorn = 0;
     for (int it = 0; it < iters; it++) {
         const int y = it * rp + sr;
         int sc[4] = {0, 0, 0, 0};
         if (lane_ok && y < ch) {
-            const unsigned* prow = reinterpret_cast<const unsigned*>(patch + y * PS) + grp;
             unsigned w[7][3];
-#pragma unroll
-            for (int r = 0; r < 7; r++) { w[r][0] = prow[r * (PS >> 2)]; w[r][1] = prow[r * (PS >> 2) + 1]; w[r][2] = prow[r * (PS >> 2) + 2]; }
-            // ring element k of pixel q sits at row 3+dy_k, byte 3+q+dx_k of the 12-byte row window (circle: ORB/FAST 16-point Bresenham)
-#define FC_RING(Q) { \
-            row_pair<3 + Q + 0>(w[6][0], w[6][1], w[6][2]), row_pair<3 + Q + 1>(w[6][0], w[6][1], w[6][2]), row_pair<3 + Q + 2>(w[5][0], w[5][1], w[5][2]), row_pair<3 + Q + 3>(w[4][0], w[4][1], w[4][2]), \
-            row_pair<3 + Q + 3>(w[3][0], w[3][1], w[3][2]), row_pair<3 + Q + 3>(w[2][0], w[2][1], w[2][2]), row_pair<3 + Q + 2>(w[1][0], w[1][1], w[1][2]), row_pair<3 + Q + 1>(w[0][0], w[0][1], w[0][2]), \
-            row_pair<3 + Q + 0>(w[0][0], w[0][1], w[0][2]), row_pair<3 + Q - 1>(w[0][0], w[0][1], w[0][2]), row_pair<3 + Q - 2>(w[1][0], w[1][1], w[1][2]), row_pair<3 + Q - 3>(w[2][0], w[2][1], w[2][2]), \
-            row_pair<3 + Q - 3>(w[3][0], w[3][1], w[3][2]), row_pair<3 + Q - 3>(w[4][0], w[4][1], w[4][2]), row_pair<3 + Q - 2>(w[5][0], w[5][1], w[5][2]), row_pair<3 + Q - 1>(w[6][0], w[6][1], w[6][2]) }
+            fc_load_window(patch, PS, y, grp, w);
             const pku16 ra[16] = FC_RING(0);
             const pku16 rb[16] = FC_RING(2);
-#undef FC_RING
             const pki16 sa = fast_score_pair(ra, row_pair<3>(w[3][0], w[3][1], w[3][2]));
             const pki16 sb = fast_score_pair(rb, row_pair<5>(w[3][0], w[3][1], w[3][2]));
             const int x0 = 4 * grp;
@@ -481,19 +584,14 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
             *reinterpret_cast<unsigned*>(score + (y + 1) * SS + 4 + x0) = (unsigned)sc[0] | ((unsigned)sc[1] << 8) | ((unsigned)sc[2] << 16) | ((unsigned)sc[3] << 24);
         }
         const unsigned long long m0 = __ballot(sc[0] > 0), m1 = __ballot(sc[1] > 0), m2 = __ballot(sc[2] > 0), m3 = __ballot(sc[3] > 0);
-        const unsigned long long below = (1ull << lane) - 1ull;
         int pos = ncorn + __popcll(m0 & below) + __popcll(m1 & below) + __popcll(m2 & below) + __popcll(m3 & below);
 #pragma unroll
         for (int q = 0; q < 4; q++) if (sc[q] > 0) list[pos++] = (unsigned short)((y << 8) | (4 * grp + q));
         ncorn += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
     }
-    __syncthreads();
-    // ---- C. non-max suppression inside the cell.  Survivors with score >= iniThFAST are emitted on the fly (the common
-    //      case: the first cv::FAST call of the reference returned something); the minThFAST set is only kept as masks.
-    int count_ini = 0, count_min = 0;
+    __builtin_amdgcn_wave_barrier();
+    int count_min = 0;
     const int nchunks = (ncorn + 63) >> 6;
-    unsigned* out = P.cell_cand + (long long)frame * P.cand_slots_per_frame + cd.cand_idx;
-    const unsigned long long below = (1ull << lane) - 1ull;
     for (int cb = 0; cb < nchunks; cb++) {
         const int i = cb * 64 + lane;
         bool keep = false; int sc = 0, id = 0;
@@ -504,38 +602,17 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
             keep = sc > q[-1] && sc > q[1] && sc > q[-SS - 1] && sc > q[-SS] && sc > q[-SS + 1] &&
                    sc > q[SS - 1] && sc > q[SS] && sc > q[SS + 1];
         }
-        const bool kini = keep && sc >= P.iniTh;
-        const unsigned long long mmin = __ballot(keep), mini = __ballot(kini);
-        if (kini) {
-            const int rank = count_ini + __popcll(mini & below);
-            // FAST reports cell-local (x, y); the reference adds (j*wCell, i*hCell)  (ORBextractor.cc:822-823)
+        const unsigned long long mmin = __ballot(keep);
+        if (keep) {
+            const int rank = count_min + __popcll(mmin & below);
             const unsigned px = (unsigned)((id & 0xff) + 3 + cd.shiftX), py = (unsigned)((id >> 8) + 3 + cd.shiftY);
             if (rank < cd.cand_cap) out[rank] = px | (py << 12) | ((unsigned)sc << 24);
         }
-        if (lane == 0) s_mmin[wave][cb] = mmin;
-        count_min += __popcll(mmin); count_ini += __popcll(mini);
+        count_min += __popcll(mmin);
     }
-    __syncthreads();
-    if (!active) return;
-    // ---- D. vKeysCell.empty() after the iniThFAST call -> the minThFAST set is emitted instead (ORBextractor.cc:812-816)
-    const bool use_ini = count_ini > 0;
-    const int total = use_ini ? count_ini : count_min;
-    if (!use_ini) {
-        int base = 0;
-        for (int cb = 0; cb < nchunks; cb++) {
-            const unsigned long long m = s_mmin[wave][cb];
-            if ((m >> lane) & 1ull) {
-                const int id = list[cb * 64 + lane], y = id >> 8, x = id & 0xff;
-                const int rank = base + __popcll(m & below);
-                const int sc = score[(y + 1) * SS + x + 4];
-                const unsigned px = (unsigned)(x + 3 + cd.shiftX), py = (unsigned)(y + 3 + cd.shiftY);
-                if (rank < cd.cand_cap) out[rank] = px | (py << 12) | ((unsigned)sc << 24);
-            }
-            base += __popcll(m);
-        }
-    }
-    if (lane == 0) P.cell_count[(long long)frame * P.ncells_total + cell_id] = min(total, cd.cand_cap);
+    if (lane == 0) P.cell_count[(long long)frame * P.ncells_total + cell_id] = min(count_min, cd.cand_cap);
 }
+#undef FC_RING
 
 void orbhip_launch_fast_cells(const ExtractParams& P, int nframes, hipStream_t s)
 {
