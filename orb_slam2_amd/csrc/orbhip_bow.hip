@@ -196,7 +196,7 @@ __device__ __forceinline__ unsigned long long bm_argmin_mask(int d, unsigned lon
 
 __global__ __launch_bounds__(256) void k_bow_match(BowMatchParams P)
 {
-    const int lane = threadIdx.x & 63, a = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, a = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (a >= P.nf1) return;
     const uint32_t node = P.fn1[a];
     int lo = 0, hi = P.nf2;                                    // lower_bound on side 2's node ids

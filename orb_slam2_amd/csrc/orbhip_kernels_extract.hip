@@ -418,7 +418,7 @@ __device__ __forceinline__ void fc_load_window(const uint8_t* patch, int PS, int
 __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
 {
     HIP_DYNAMIC_SHARED(unsigned, fc_lds)
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int tile, frame;
     if (!xcd_frame_map((P.ncells_total + FC_WAVES - 1) / FC_WAVES, P.nframes, tile, frame)) return;
     frame += P.frame0;
@@ -969,7 +969,7 @@ __device__ __forceinline__ int round_half_even_small(float x) { return __float_a
 __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
 {
     __shared__ unsigned s_win[DS_WAVES][DS_WROWS * DS_WDW];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int tile, frame;
     if (!xcd_frame_map((P.lvl_kp_per_frame + DS_WAVES - 1) / DS_WAVES, P.nframes, tile, frame)) return;
     frame += P.frame0;

@@ -78,7 +78,7 @@ __device__ __forceinline__ void nn_combine(int& b, long long& i, int& s, int rb,
 }
 __global__ __launch_bounds__(256) void k_hamming_merge(const NNPart* parts, int nq, int nchunks, long long* best_idx, int* best_dist, int* second_dist)
 {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int qi = blockIdx.x * 4 + wave;
     if (qi >= nq) return;
     int b = IMAX, s = IMAX; long long i = -1;
@@ -176,7 +176,7 @@ void orbhip_launch_match_grid(const MatchParams& M, int nslots, hipStream_t s)
 #define MC_CHUNKS 8
 __global__ __launch_bounds__(256) void k_match_candidates(MatchParams M, float gwInv, float ghInv)
 {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, slot = blockIdx.y + M.slot0;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, slot = blockIdx.y + M.slot0;
     const int j1 = blockIdx.x * 4 + wave;
     const int n1l = M.n1_lvl0[slot * M.lvl_stride];
     if (j1 >= n1l || j1 >= M.lvl0_cap) return;

@@ -18,7 +18,7 @@
 
 __global__ __launch_bounds__(256) void k_proj_candidates(ProjParams J, float gwInv, float ghInv)
 {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int iq = blockIdx.x * 4 + wave;
     if (iq >= J.nq) return;
     const orbhip_proj_query q = J.q[iq];

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void k_stereo_rows(StereoParams T)
 // ------------------------------------------------------------------------------------------------ match + sub-pixel
 __global__ __launch_bounds__(256) void k_stereo_match(StereoParams T)
 {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, slot = blockIdx.y;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, slot = blockIdx.y;
     const int iL = blockIdx.x * 4 + wave;
     const int nl = T.L.n[slot];
     if (iL >= nl) return;
