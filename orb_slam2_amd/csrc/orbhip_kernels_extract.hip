@@ -28,6 +28,13 @@ __device__ __forceinline__ bool xcd_frame_map(int nb, int nframes, int& tile, in
 }
 static inline unsigned xcd_grid(int nb, int nframes) { return (unsigned)nb * 8u * (unsigned)((nframes + 7) / 8); }
 
+// a pointer every lane of the wave agrees on, moved to SGPRs so that loads use the scalar-base + 32-bit lane offset form
+template <typename T> __device__ __forceinline__ T* uniform_ptr(T* p)
+{
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    return (T*)(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ const uint8_t* level_src(const ExtractParams& P, int frame, int level, int& pitch)
 {
     if (level == 0) { pitch = P.img0_pitch; return P.img0 + (long long)frame * P.img0_frame_stride; }
@@ -975,47 +982,54 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
     frame += P.frame0;
     const int slot = tile * DS_WAVES + wave;
     if (slot >= P.lvl_kp_per_frame) return;
+    // everything about "which keypoint" is the same for the 64 lanes: kept on the scalar unit (U() = v_readfirstlane)
+#define U(x) __builtin_amdgcn_readfirstlane(x)
     int level = 0;
-    for (int l = 1; l < P.nlevels; l++) if (slot >= P.geom[l].kp_off) level = l;
+    for (int l = 1; l < P.nlevels; l++) if (slot >= U(P.geom[l].kp_off)) level = l;
     const LevelGeom g = P.geom[level];
-    const int i = slot - g.kp_off;
+    const int i = slot - U(g.kp_off);
     const int* ln = P.lvl_n + frame * P.nlevels;
     if (slot == 0 && lane == 0) { int tot = 0; for (int l = 0; l < P.nlevels; l++) tot += ln[l]; P.out_n[frame] = min(tot, P.out_cap); }
-    if (i >= ln[level]) return;
+    if (i >= U(ln[level])) return;
     int obase = 0;
-    for (int l = 0; l < level; l++) obase += ln[l];
+    for (int l = 0; l < level; l++) obase += U(ln[l]);
     const int oi = obase + i;
     if (oi >= P.out_cap) return;
-    const unsigned v = P.lvl_kp[(long long)frame * P.lvl_kp_per_frame + slot];
+    const unsigned v = (unsigned)U((int)P.lvl_kp[(long long)frame * P.lvl_kp_per_frame + slot]);
     const int cx = v & 0xfff, cy = (v >> 12) & 0xfff, sc = v >> 24;
 
-    // ---- all global loads of this keypoint are issued up-front (wave-uniform base + 32-bit lane offsets)
+    // ---- all global loads of this keypoint are issued up-front (wave-uniform base + 32-bit lane offsets, no predication:
+    //      keypoints keep >= 19 px from every border, so every address below is inside the plane)
     // (a) rBRIEF pattern of this lane's 4 tests, stored as floats (x0, y0, x1, y1)
     const float4* pat = reinterpret_cast<const float4*>(P.patternf);
     float4 pt[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) pt[r] = pat[(unsigned)(r * 64 + lane)];
     // (b) 31x31 orientation patch of the un-blurred level: lane = column u (coalesced rows), two rows per load
-    int spitch; const uint8_t* img = level_src(P, frame, level, spitch);
+    int spitch_v; const uint8_t* img_v = level_src(P, frame, level, spitch_v);
+    const int spitch = U(spitch_v);
+    const uint8_t* img = uniform_ptr(img_v);
     const int half = lane >> 5, u = (lane & 31) - 15;              // lanes 0..30 and 32..62 carry columns -15..15
     const bool col_ok = (lane & 31) < 31;
-    const unsigned ioff = (unsigned)((cy + half - 15) * spitch + cx + u);
+    const unsigned ioff = (unsigned)((cy + half - 15) * spitch + cx + min(u, 15));
     int pxv[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++)                                    // rows 2k + half - 15 = -15..16; row 16 (k = 15, half = 1) is unused
-        pxv[k] = (col_ok && 2 * k + half <= 30) ? img[ioff + (unsigned)(2 * k * spitch)] : 0;
-    // (c) 37-row window of the blurred level -> LDS with aligned 32-bit loads (keypoints keep >= 19 px from every border)
-    const uint8_t* blv = P.blur + (long long)frame * P.plane_frame_bytes + g.plane_off;
+    for (int k = 0; k < 16; k++)                                    // rows 2k + half - 15 = -15..16; row 16 (k = 15, half = 1) is loaded but unused
+        pxv[k] = img[ioff + (unsigned)(2 * k * spitch)];
+    // (c) 37-row window of the blurred level -> LDS with aligned 32-bit loads: 16 lanes per row (11 used), 4 rows per pass
+    const uint8_t* blv = uniform_ptr(P.blur + (long long)frame * P.plane_frame_bytes + U(g.plane_off));
+    const int bpitch = U(g.pitch);
     const int wx0 = (cx - 18) & ~3;                                 // window byte x of LDS column 0 (level pitch and plane offsets are multiples of 4)
     unsigned* win = s_win[wave];
-    unsigned wv[7];
+    const int wr = lane >> 4, wd = min(lane & 15, DS_WDW - 1);
+    const unsigned woff = (unsigned)((cy - 18 + wr) * bpitch + wx0 + 4 * wd);
+    unsigned wv[10];
 #pragma unroll
-    for (int k = 0; k < 7; k++) {
-        const int idx = lane + 64 * k, r = idx / DS_WDW, d = idx - r * DS_WDW;
-        wv[k] = (idx < DS_WROWS * DS_WDW) ? *reinterpret_cast<const unsigned*>(blv + (unsigned)((cy - 18 + r) * g.pitch + wx0 + 4 * d)) : 0u;
-    }
+    for (int k = 0; k < 10; k++)                                    // rows wr + 4k = 0..39: rows 37..39 clamp to 36 (in bounds, not stored)
+        wv[k] = *reinterpret_cast<const unsigned*>(blv + woff + (unsigned)(min(4 * k, DS_WROWS - 1 - wr) * bpitch));
 #pragma unroll
-    for (int k = 0; k < 7; k++) { const int idx = lane + 64 * k; if (idx < DS_WROWS * DS_WDW) win[idx] = wv[k]; }
+    for (int k = 0; k < 10; k++) { const int r = wr + 4 * k; if (r < DS_WROWS && (lane & 15) < DS_WDW) win[r * DS_WDW + wd] = wv[k]; }
+#undef U
 
     // ---- IC_Angle (ORBextractor.cc:77-104): m10 = sum u*I, m01 = sum v*I over the circular patch
     int m10 = 0, m01 = 0;
@@ -1025,7 +1039,7 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
         const int vm = (au <= 3) ? 15 : (au <= 6) ? 14 : (au <= 8) ? 13 : (au == 9) ? 12 : (au == 10) ? 11 : (au == 11) ? 10 : (au == 12) ? 9 : (au == 13) ? 8 : (au == 14) ? 6 : 3;
         int s = 0, sv = 0;
 #pragma unroll
-        for (int k = 0; k < 16; k++) { const int vr = 2 * k + half - 15; const int p = (vr >= -vm && vr <= vm) ? pxv[k] : 0; s += p; sv += vr * p; }
+        for (int k = 0; k < 16; k++) { const int vr = 2 * k + half - 15; const int p = (col_ok && vr >= -vm && vr <= vm) ? pxv[k] : 0; s += p; sv += vr * p; }
         m10 = u * s; m01 = sv;
     }
     m10 = wave_sum_dpp(m10); m01 = wave_sum_dpp(m01);
