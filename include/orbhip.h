@@ -213,6 +213,19 @@ orbhip_status orbhip_search_by_bow(int device, int mode,
                                    const uint8_t* desc2, const float* angle2, const uint8_t* valid2, int n2,
                                    const uint32_t* fv2_node, const int32_t* fv2_off, const uint32_t* fv2_feat, int nfv2,
                                    float nnratio, int check_ori, int32_t* match12, int* nmatches);
+/* ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo) (ORBmatcher.h:65-66, ORBmatcher.cc:657-823,
+   CheckDistEpipolarLine :140-157) on flat data.  Per key frame: descriptors, kp = 4 floats per feature (mvKeysUn x, y, angle,
+   octave), has_mp[i] = "GetMapPoint(i) != NULL" (such features are skipped), stereo[i] = "mvuRight[i] >= 0", the FeatureVector.
+   F12 = the 3x3 fundamental matrix, row-major; (ex, ey) = the epipole the caller computes from the poses (:663-669);
+   scale_factors2 / level_sigma2_2 = pKF2->mvScaleFactors / mvLevelSigma2 (nlevels2 entries).  match12[i1] = index in key frame 2
+   or -1 (vMatchedPairs = the pairs (i1, match12[i1]) in ascending i1); *nmatches = the return value.  Synchronous, host pointers. */
+orbhip_status orbhip_search_for_triangulation(int device,
+    const uint8_t* desc1, const float* kp1, const uint8_t* has_mp1, const uint8_t* stereo1, int n1,
+    const uint32_t* fv1_node, const int32_t* fv1_off, const uint32_t* fv1_feat, int nfv1,
+    const uint8_t* desc2, const float* kp2, const uint8_t* has_mp2, const uint8_t* stereo2, int n2,
+    const uint32_t* fv2_node, const int32_t* fv2_off, const uint32_t* fv2_feat, int nfv2,
+    const float* F12, float ex, float ey, const float* scale_factors2, const float* level_sigma2_2, int nlevels2,
+    int only_stereo, int check_ori, int32_t* match12, int* nmatches);
 /* TemplatedVocabulary::score(v1, v2) with the scoring object named by the file header (ScoringObject.cpp:24-313;
    KeyFrameDatabase.cc:133,249, LoopClosing.cc:134); host arithmetic */
 double orbhip_voc_score(const orbhip_voc* voc, const uint32_t* id1, const double* val1, int n1,

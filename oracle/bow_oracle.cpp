@@ -250,6 +250,76 @@ static int search_by_bow(int mode, const uint8_t* d1, const float* ang1, const u
     return nmatches;
 }
 
+// ORBmatcher::SearchForTriangulation (ORBmatcher.cc:657-823) + CheckDistEpipolarLine (:140-157) on flat data.  Side 1 / 2 = the
+// two key frames: has_mp = the feature already has a map point (skipped), stereo = mvuRight >= 0.  kp = (x, y, angle, octave) of
+// mvKeysUn.  (ex, ey) = the epipole the caller computed from the two poses (:663-669), F12 row-major.  Note: the reference never
+// sets vbMatched2 (:729 reads it, nothing writes it), so a feature of side 2 may be handed to several features of side 1.
+static int search_for_triangulation(const uint8_t* d1, const float* kp1 /*n1 x 4*/, const uint8_t* has1, const uint8_t* st1, int n1,
+                                    const uint32_t* fn1, const int* fo1, const uint32_t* ff1, int nf1,
+                                    const uint8_t* d2, const float* kp2 /*n2 x 4*/, const uint8_t* has2, const uint8_t* st2, int n2,
+                                    const uint32_t* fn2, const int* fo2, const uint32_t* ff2, int nf2,
+                                    const float* F12, float ex, float ey, const float* scale2, const float* sigma2_2, bool only_stereo, bool check_ori, int* match12)
+{
+    const int TH_LOW = 50, HISTO_LENGTH = 30;
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    std::vector<int> bin_of(n1, -1);
+    int hist[HISTO_LENGTH] = {0};
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nmatches = 0, a = 0, b = 0;
+    while (a < nf1 && b < nf2) {
+        if (fn1[a] == fn2[b]) {
+            for (int i1 = fo1[a]; i1 < fo1[a + 1]; i1++) {
+                const unsigned idx1 = ff1[i1];
+                if (has1[idx1]) continue;                                          // "If there is already a MapPoint skip"
+                const bool bStereo1 = st1[idx1] != 0;
+                if (only_stereo && !bStereo1) continue;
+                const float x1 = kp1[4 * idx1], y1 = kp1[4 * idx1 + 1];
+                int bestDist = TH_LOW, bestIdx2 = -1;
+                for (int i2 = fo2[b]; i2 < fo2[b + 1]; i2++) {
+                    const unsigned idx2 = ff2[i2];
+                    if (has2[idx2]) continue;                                      // vbMatched2 is never set by the reference
+                    const bool bStereo2 = st2[idx2] != 0;
+                    if (only_stereo && !bStereo2) continue;
+                    const int dist = distance(d1 + (size_t)idx1 * 32, d2 + (size_t)idx2 * 32);
+                    if (dist > TH_LOW || dist > bestDist) continue;
+                    const float x2 = kp2[4 * idx2], y2 = kp2[4 * idx2 + 1]; const int oct2 = (int)kp2[4 * idx2 + 3];
+                    if (!bStereo1 && !bStereo2) {
+                        const float distex = ex - x2, distey = ey - y2;
+                        if (distex * distex + distey * distey < 100 * scale2[oct2]) continue;
+                    }
+                    const float la = x1 * F12[0] + y1 * F12[3] + F12[6];            // l = x1' F12 = [a b c]
+                    const float lb = x1 * F12[1] + y1 * F12[4] + F12[7];
+                    const float lc = x1 * F12[2] + y1 * F12[5] + F12[8];
+                    const float num = la * x2 + lb * y2 + lc;
+                    const float den = la * la + lb * lb;
+                    if (den == 0) continue;
+                    const float dsqr = num * num / den;
+                    if (dsqr < 3.84 * sigma2_2[oct2]) { bestIdx2 = (int)idx2; bestDist = dist; }
+                }
+                if (bestIdx2 >= 0) {
+                    match12[idx1] = bestIdx2; nmatches++;
+                    if (check_ori) {
+                        float rot = kp1[4 * idx1 + 2] - kp2[4 * bestIdx2 + 2];
+                        if (rot < 0.0) rot += 360.0f;
+                        int bin = (int)roundf(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        bin_of[idx1] = bin; hist[bin]++;
+                    }
+                }
+            }
+            a++; b++;
+        } else if (fn1[a] < fn2[b]) a = (int)(std::lower_bound(fn1 + a, fn1 + nf1, fn2[b]) - fn1);
+        else b = (int)(std::lower_bound(fn2 + b, fn2 + nf2, fn1[a]) - fn2);
+    }
+    if (check_ori) {
+        int ind1, ind2, ind3;
+        three_maxima(hist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < n1; i++)
+            if (bin_of[i] >= 0 && bin_of[i] != ind1 && bin_of[i] != ind2 && bin_of[i] != ind3) { match12[i] = -1; nmatches--; }
+    }
+    return nmatches;
+}
+
 }  // namespace bow
 
 extern "C" {
@@ -288,6 +358,15 @@ double orb_oracle_voc_score(int scoring, const uint32_t* i1, const double* v1, i
     return bow::score(scoring, i1, v1, n1, i2, v2, n2);
 }
 int orb_oracle_forb_distance(const uint8_t* a, const uint8_t* b) { return bow::distance(a, b); }
+int orb_oracle_search_for_triangulation(const uint8_t* d1, const float* kp1, const uint8_t* has1, const uint8_t* st1, int n1,
+                                        const uint32_t* fn1, const int* fo1, const uint32_t* ff1, int nf1,
+                                        const uint8_t* d2, const float* kp2, const uint8_t* has2, const uint8_t* st2, int n2,
+                                        const uint32_t* fn2, const int* fo2, const uint32_t* ff2, int nf2,
+                                        const float* F12, float ex, float ey, const float* scale2, const float* sigma2_2, int only_stereo, int check_ori, int* match12)
+{
+    return bow::search_for_triangulation(d1, kp1, has1, st1, n1, fn1, fo1, ff1, nf1, d2, kp2, has2, st2, n2, fn2, fo2, ff2, nf2, F12, ex, ey, scale2, sigma2_2,
+                                         only_stereo != 0, check_ori != 0, match12);
+}
 int orb_oracle_search_by_bow(int mode, const uint8_t* d1, const float* ang1, const uint8_t* valid1, int n1,
                              const uint32_t* fn1, const int* fo1, const uint32_t* ff1, int nf1,
                              const uint8_t* d2, const float* ang2, const uint8_t* valid2, int n2,

@@ -60,6 +60,8 @@ def lib(fast=False):
     L.orb_oracle_voc_score.argtypes = [C.c_int, vp, vp, C.c_int, vp, vp, C.c_int]
     L.orb_oracle_voc_score.restype = C.c_double
     L.orb_oracle_forb_distance.argtypes = [vp, vp]
+    L.orb_oracle_search_for_triangulation.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, C.c_float, C.c_float, vp, vp, C.c_int, C.c_int, vp]
+    L.orb_oracle_search_for_triangulation.restype = C.c_int
     L.orb_oracle_search_by_bow.argtypes = [C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp]
     L.orb_oracle_search_by_bow.restype = C.c_int
     L.orb_oracle_cvt_gray.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
@@ -346,4 +348,25 @@ def search_by_bow(mode, desc1, angle1, valid1, fv1, desc2, angle2, valid2, fv2, 
     n = lib().orb_oracle_search_by_bow(mode, _p(desc1), _p(angle1), _p(valid1), len(desc1), _p(f1[0]), _p(f1[1]), _p(f1[2]), len(f1[0]),
                                        _p(desc2), _p(angle2), _p(valid2), len(desc2), _p(f2[0]), _p(f2[1]), _p(f2[2]), len(f2[0]),
                                        nnratio, int(check_ori), _p(m12))
+    return n, m12
+
+
+def _kp4(k):
+    return np.ascontiguousarray(np.stack([k["x"], k["y"], k["angle"], k["octave"].astype(np.float32)], axis=1), np.float32)
+
+
+def search_for_triangulation(desc1, kps1, has_mp1, stereo1, fv1, desc2, kps2, has_mp2, stereo2, fv2, F12, ex, ey, scale_factors2, level_sigma2_2,
+                             only_stereo=False, check_ori=True):
+    """ORBmatcher::SearchForTriangulation (ORBmatcher.cc:657-823) on flat data.  kps = KEYPOINT arrays (mvKeysUn); -> (nmatches, match12)"""
+    desc1 = np.ascontiguousarray(desc1, np.uint8); desc2 = np.ascontiguousarray(desc2, np.uint8)
+    k1, k2 = _kp4(kps1), _kp4(kps2)
+    a = [np.ascontiguousarray(v, np.uint8) for v in (has_mp1, stereo1, has_mp2, stereo2)]
+    f1 = [np.ascontiguousarray(fv1[0], np.uint32), np.ascontiguousarray(fv1[1], np.int32), np.ascontiguousarray(fv1[2], np.uint32)]
+    f2 = [np.ascontiguousarray(fv2[0], np.uint32), np.ascontiguousarray(fv2[1], np.int32), np.ascontiguousarray(fv2[2], np.uint32)]
+    F = np.ascontiguousarray(F12, np.float32).reshape(9)
+    sc = np.ascontiguousarray(scale_factors2, np.float32); sg = np.ascontiguousarray(level_sigma2_2, np.float32)
+    m12 = np.full(len(desc1), -1, np.int32)
+    n = lib().orb_oracle_search_for_triangulation(_p(desc1), _p(k1), _p(a[0]), _p(a[1]), len(desc1), _p(f1[0]), _p(f1[1]), _p(f1[2]), len(f1[0]),
+                                                  _p(desc2), _p(k2), _p(a[2]), _p(a[3]), len(desc2), _p(f2[0]), _p(f2[1]), _p(f2[2]), len(f2[0]),
+                                                  _p(F), float(ex), float(ey), _p(sc), _p(sg), int(only_stereo), int(check_ori), _p(m12))
     return n, m12

@@ -78,9 +78,16 @@ int MapPoint::PredictScale(const float&, KeyFrame*) { return 0; }
 int MapPoint::PredictScale(const float&, Frame*) { return 0; }
 static void not_built(const char* what) { fprintf(stderr, "%s is not part of the oracle build\n", what); abort(); }
 void KeyFrame::AddMapPoint(MapPoint*, const size_t&) { not_built("KeyFrame::AddMapPoint"); }
-cv::Mat KeyFrame::GetCameraCenter() { not_built("KeyFrame::GetCameraCenter"); return cv::Mat(); }
+cv::Mat KeyFrame::GetCameraCenter() { return Ow.clone(); }
+void KeyFrame::SetPose(const cv::Mat& Tcw_)
+{   // KeyFrame.cc:61-79 without the stereo centre: Tcw, Ow = -Rcw' tcw, Twc
+    Tcw_.copyTo(Tcw);
+    cv::Mat Rcw = Tcw.rowRange(0, 3).colRange(0, 3), tcw = Tcw.rowRange(0, 3).col(3), Rwc = Rcw.t();
+    Ow = -Rwc * tcw;
+    Twc = cv::Mat::eye(4, 4, CV_32F);
+}
 std::vector<size_t> KeyFrame::GetFeaturesInArea(const float&, const float&, const float&) const { not_built("KeyFrame::GetFeaturesInArea"); return std::vector<size_t>(); }
-MapPoint* KeyFrame::GetMapPoint(const size_t&) { not_built("KeyFrame::GetMapPoint"); return NULL; }
+MapPoint* KeyFrame::GetMapPoint(const size_t& idx) { return mvpMapPoints[idx]; }
 std::vector<MapPoint*> KeyFrame::GetMapPointMatches() { return mvpMapPoints; }
 long unsigned int KeyFrame::nNextId = 0;
 // KeyFrame(Frame&, Map*, KeyFrameDatabase*): a key frame is a frozen copy of the frame's features (the real constructor lives in
@@ -101,8 +108,8 @@ KeyFrame::KeyFrame(Frame& F, Map* pMap, KeyFrameDatabase* pKFDB)
     mnId = nNextId++;
 }
 std::set<MapPoint*> KeyFrame::GetMapPoints() { not_built("KeyFrame::GetMapPoints"); return std::set<MapPoint*>(); }
-cv::Mat KeyFrame::GetRotation() { not_built("KeyFrame::GetRotation"); return cv::Mat(); }
-cv::Mat KeyFrame::GetTranslation() { not_built("KeyFrame::GetTranslation"); return cv::Mat(); }
+cv::Mat KeyFrame::GetRotation() { return Tcw.rowRange(0, 3).colRange(0, 3).clone(); }
+cv::Mat KeyFrame::GetTranslation() { return Tcw.rowRange(0, 3).col(3).clone(); }
 bool KeyFrame::IsInImage(const float&, const float&) const { not_built("KeyFrame::IsInImage"); return false; }
 }  // namespace ORB_SLAM2
 
@@ -293,6 +300,34 @@ int orbslam_ref_search_by_bow(int mode, void* f1, const uint8_t* has1, const uin
         delete kf2;
     }
     delete kf1;
+    return n;
+}
+
+// ORBmatcher(nnratio, checkOri).SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo)  (ORBmatcher.cc:657-823).
+// Key frame 1 at the origin, key frame 2 with identity rotation and translation t2w: the epipole the reference computes is
+// (fx t.x / t.z + cx, fy t.y / t.z + cy).
+int orbslam_ref_search_for_triangulation(void* f1, const uint8_t* has1, const uint32_t* n1, const int* o1, const uint32_t* ft1, int nf1,
+                                         void* f2, const uint8_t* has2, const uint32_t* n2, const int* o2, const uint32_t* ft2, int nf2,
+                                         const float* F12, const float* t2w, int only_stereo, int check_ori, int* match12)
+{
+    Frame &F1 = *(Frame*)f1, &F2 = *(Frame*)f2;
+    std::map<MapPoint*, int> idx1, idx2;
+    give_points(F1, has1, NULL, idx1);
+    give_points(F2, has2, NULL, idx2);
+    fill_fv(F1.mFeatVec, n1, o1, ft1, nf1);
+    fill_fv(F2.mFeatVec, n2, o2, ft2, nf2);
+    KeyFrame *kf1 = new KeyFrame(F1, NULL, NULL), *kf2 = new KeyFrame(F2, NULL, NULL);
+    cv::Mat T1 = cv::Mat::eye(4, 4, CV_32F), T2 = cv::Mat::eye(4, 4, CV_32F);
+    for (int i = 0; i < 3; i++) T2.at<float>(i, 3) = t2w[i];
+    kf1->SetPose(T1); kf2->SetPose(T2);
+    cv::Mat F(3, 3, CV_32F);
+    for (int i = 0; i < 9; i++) F.at<float>(i / 3, i % 3) = F12[i];
+    std::vector<std::pair<size_t, size_t> > pairs;
+    ORBmatcher matcher(0.6f, check_ori != 0);
+    const int n = matcher.SearchForTriangulation(kf1, kf2, F, pairs, only_stereo != 0);
+    for (int i = 0; i < F1.N; i++) match12[i] = -1;
+    for (size_t i = 0; i < pairs.size(); i++) match12[pairs[i].first] = (int)pairs[i].second;
+    delete kf1; delete kf2;
     return n;
 }
 

@@ -5,7 +5,7 @@ orbhip.py (ctypes mirror of ORB_SLAM2::ORBextractor / ORBmatcher), sharding.py (
 of a node, no collective) and synth.py (seeded synthetic frames).  No CPU fallback lives in this package.
 """
 from .orbhip import (KEYPOINT_DTYPE, PROJ_QUERY_DTYPE, ORBextractor, ORBmatcher, ORBVocabulary, OrbHipError, hamming_nn, hamming_nn_device, lib,
-                     library_path, search_by_bow, search_by_projection)
+                     library_path, search_by_bow, search_by_projection, search_for_triangulation)
 
-__all__ = ["KEYPOINT_DTYPE", "PROJ_QUERY_DTYPE", "search_by_projection", "search_by_bow", "ORBextractor", "ORBmatcher", "ORBVocabulary", "OrbHipError", "hamming_nn", "hamming_nn_device", "lib",
+__all__ = ["KEYPOINT_DTYPE", "PROJ_QUERY_DTYPE", "search_by_projection", "search_by_bow", "search_for_triangulation", "ORBextractor", "ORBmatcher", "ORBVocabulary", "OrbHipError", "hamming_nn", "hamming_nn_device", "lib",
            "library_path"]

@@ -283,6 +283,90 @@ __global__ __launch_bounds__(256) void k_bow_match_finish(BowMatchParams P)
     if (tid == 0) *P.nmatches = s_cnt;
 }
 
+// ------------------------------------------------------------------------------------------------ SearchForTriangulation
+// ORBmatcher::SearchForTriangulation (ORBmatcher.cc:657-823) + CheckDistEpipolarLine (:140-157) on flat data: features of two
+// key frames that have no map point yet, same vocabulary node, descriptor distance <= TH_LOW, not too close to the epipole
+// (mono-mono pairs), within 3.84 sigma^2 of the epipolar line.  The reference keeps the candidate if `dist <= bestDist`, so among
+// the admissible candidates the LAST one with the smallest distance wins; it never marks side-2 features as taken (vbMatched2
+// is read, never written), so the side-1 features of a node are independent.  Same wave-per-node layout as k_bow_match.
+struct TriParams {
+    BowMatchParams M;                      // descriptors, valid1/valid2 = "already has a map point", FeatureVectors, outputs
+    const float* kp1; const float* kp2;    // (x, y, angle, octave) of mvKeysUn
+    const uint8_t* st1; const uint8_t* st2;    // mvuRight >= 0
+    float F[9]; float ex, ey; const float* scale2; const float* sigma2_2; int only_stereo;
+};
+
+__global__ __launch_bounds__(256) void k_bow_triangulate(TriParams T)
+{
+    const BowMatchParams& P = T.M;
+    const int lane = threadIdx.x & 63, a = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (a >= P.nf1) return;
+    const uint32_t node = P.fn1[a];
+    int lo = 0, hi = P.nf2;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (P.fn2[mid] < node) lo = mid + 1; else hi = mid; }
+    if (lo >= P.nf2 || P.fn2[lo] != node) return;
+    const int b1 = P.fo1[a], e1 = P.fo1[a + 1], b2 = P.fo2[lo], len2 = P.fo2[lo + 1] - b2;
+    const int nch = (len2 + 63) >> 6;
+    for (int i1 = b1; i1 < e1; i1++) {
+        const unsigned idx1 = P.ff1[i1];
+        if (P.valid1[idx1]) continue;                                   // "If there is already a MapPoint skip" (:698-700)
+        const bool stereo1 = T.st1[idx1] != 0;
+        if (T.only_stereo && !stereo1) continue;
+        const float x1 = T.kp1[4 * idx1], y1 = T.kp1[4 * idx1 + 1];
+        // epipolar line of kp1 in image 2: l = x1' F12 = [a b c]  (:143-145), left-to-right sums like the reference's expression
+        const float la = __fadd_rn(__fadd_rn(__fmul_rn(x1, T.F[0]), __fmul_rn(y1, T.F[3])), T.F[6]);
+        const float lb = __fadd_rn(__fadd_rn(__fmul_rn(x1, T.F[1]), __fmul_rn(y1, T.F[4])), T.F[7]);
+        const float lc = __fadd_rn(__fadd_rn(__fmul_rn(x1, T.F[2]), __fmul_rn(y1, T.F[5])), T.F[8]);
+        const float den = __fadd_rn(__fmul_rn(la, la), __fmul_rn(lb, lb));
+        const uint4* q4 = reinterpret_cast<const uint4*>(P.d1 + (long long)idx1 * 32);
+        const uint4 qa = q4[0], qb = q4[1];
+        int best = ORBHIP_TH_LOW, bidx = -1;
+        for (int c = 0; c < nch; c++) {
+            const int t = c * 64 + lane;
+            int idx2 = 0, dist = 256; bool ok = false;
+            if (t < len2) {
+                idx2 = (int)P.ff2[b2 + t];
+                const bool stereo2 = T.st2[idx2] != 0;
+                ok = !P.valid2[idx2] && !(T.only_stereo && !stereo2);   // :727-736
+                if (ok) {
+                    const uint4* d4 = reinterpret_cast<const uint4*>(P.d2 + (long long)idx2 * 32);
+                    const uint4 da = d4[0], db = d4[1];
+                    dist = __popc(qa.x ^ da.x) + __popc(qa.y ^ da.y) + __popc(qa.z ^ da.z) + __popc(qa.w ^ da.w) +
+                           __popc(qb.x ^ db.x) + __popc(qb.y ^ db.y) + __popc(qb.z ^ db.z) + __popc(qb.w ^ db.w);
+                    ok = dist <= ORBHIP_TH_LOW;                        // :742
+                }
+                if (ok) {
+                    const float x2 = T.kp2[4 * idx2], y2 = T.kp2[4 * idx2 + 1]; const int oct2 = (int)T.kp2[4 * idx2 + 3];
+                    if (!stereo1 && !stereo2) {                         // :747-753
+                        const float dx = __fsub_rn(T.ex, x2), dy = __fsub_rn(T.ey, y2);
+                        if (__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)) < __fmul_rn(100.0f, T.scale2[oct2])) ok = false;
+                    }
+                    const float num = __fadd_rn(__fadd_rn(__fmul_rn(la, x2), __fmul_rn(lb, y2)), lc);
+                    const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
+                    if (den == 0.0f || !((double)dsqr < 3.84 * (double)T.sigma2_2[oct2])) ok = false;      // :149-156
+                }
+            }
+            const unsigned long long V = __ballot(ok);
+            if (V == 0) continue;
+            const unsigned long long mk = bm_argmin_mask(dist, V);
+            const int last = 63 - __clzll((long long)mk);              // `dist <= bestDist` keeps the LAST of equal candidates
+            const int wmin = __builtin_amdgcn_readlane(dist, last), ci = __builtin_amdgcn_readlane(idx2, last);
+            if (wmin <= best) { best = wmin; bidx = ci; }
+        }
+        if (bidx >= 0 && lane == 0) {
+            P.match12[idx1] = bidx;
+            if (P.check_ori) {
+                float rot = __fsub_rn(T.kp1[4 * idx1 + 2], T.kp2[4 * bidx + 2]);
+                if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                int bin = (int)roundf(__fmul_rn(rot, 1.0f / ORBHIP_HISTO_LENGTH));
+                if (bin == ORBHIP_HISTO_LENGTH) bin = 0;
+                bin = min(max(bin, 0), ORBHIP_HISTO_LENGTH - 1);
+                P.bin12[idx1] = bin; atomicAdd(&P.hist[bin], 1);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 struct orbhip_voc {
     int k = 0, L = 0, scoring = 0, weighting = 0, nnodes = 0, nwords = 0, device = 0;
@@ -577,5 +661,56 @@ extern "C" orbhip_status orbhip_search_by_bow(int device, int mode,
     BOWCHK(hipStreamSynchronize(0));
     if (tail[1]) return orbhip_set_error(ORBHIP_ERR_UNSUPPORTED, "a vocabulary node holds more than %d features of side 2", 64 * BM_CHUNKS);
     *nmatches = tail[0];
+    return ORBHIP_OK;
+}
+
+// ORBmatcher::SearchForTriangulation on flat data; see include/orbhip.h
+extern "C" orbhip_status orbhip_search_for_triangulation(int device,
+    const uint8_t* desc1, const float* kp1, const uint8_t* has_mp1, const uint8_t* stereo1, int n1, const uint32_t* fv1_node, const int32_t* fv1_off, const uint32_t* fv1_feat, int nfv1,
+    const uint8_t* desc2, const float* kp2, const uint8_t* has_mp2, const uint8_t* stereo2, int n2, const uint32_t* fv2_node, const int32_t* fv2_off, const uint32_t* fv2_feat, int nfv2,
+    const float* F12, float ex, float ey, const float* scale_factors2, const float* level_sigma2_2, int nlevels2, int only_stereo, int check_ori,
+    int32_t* match12, int* nmatches)
+{
+    if (!match12 || !nmatches || n1 < 0 || n2 < 0 || nfv1 < 0 || nfv2 < 0 || nlevels2 < 1) return orbhip_set_error(ORBHIP_ERR_INVALID, "bad argument");
+    *nmatches = 0;
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    if (n1 == 0 || n2 == 0 || nfv1 == 0 || nfv2 == 0) return ORBHIP_OK;
+    if (!desc1 || !desc2 || !kp1 || !kp2 || !has_mp1 || !has_mp2 || !stereo1 || !stereo2 || !fv1_node || !fv1_off || !fv1_feat || !fv2_node || !fv2_off || !fv2_feat ||
+        !F12 || !scale_factors2 || !level_sigma2_2) return orbhip_set_error(ORBHIP_ERR_INVALID, "null argument");
+    BOWCHK(hipSetDevice(device));
+    const int m1 = fv1_off[nfv1], m2 = fv2_off[nfv2];
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const void* src[18] = {desc1, kp1, has_mp1, stereo1, fv1_node, fv1_off, fv1_feat, desc2, kp2, has_mp2, stereo2, fv2_node, fv2_off, fv2_feat, scale_factors2, level_sigma2_2, nullptr, nullptr};
+    const size_t nb[18] = {(size_t)n1 * 32, (size_t)n1 * 16, (size_t)n1, (size_t)n1, (size_t)nfv1 * 4, (size_t)(nfv1 + 1) * 4, (size_t)std::max(m1, 1) * 4,
+                           (size_t)n2 * 32, (size_t)n2 * 16, (size_t)n2, (size_t)n2, (size_t)nfv2 * 4, (size_t)(nfv2 + 1) * 4, (size_t)std::max(m2, 1) * 4,
+                           (size_t)nlevels2 * 4, (size_t)nlevels2 * 4, (size_t)n1 * 4, (size_t)n1 * 4};
+    size_t total = al((ORBHIP_HISTO_LENGTH + 2) * 4); for (size_t b : nb) total += al(b);
+    if (g_bm_dev != device || g_bm_ws_bytes < total) {
+        if (g_bm_ws) (void)hipFree(g_bm_ws);
+        g_bm_ws = nullptr; g_bm_ws_bytes = 0;
+        BOWCHK(hipMalloc(&g_bm_ws, total)); g_bm_ws_bytes = total; g_bm_dev = device;
+    }
+    uint8_t* p[19]; { size_t o = 0; for (int i = 0; i < 18; i++) { p[i] = (uint8_t*)g_bm_ws + o; o += al(nb[i]); } p[18] = (uint8_t*)g_bm_ws + o; }
+    for (int i = 0; i < 16; i++) if (src[i] && nb[i] && !((i == 6 && m1 == 0) || (i == 13 && m2 == 0))) BOWCHK(hipMemcpyAsync(p[i], src[i], i == 6 ? (size_t)m1 * 4 : i == 13 ? (size_t)m2 * 4 : nb[i], hipMemcpyHostToDevice, 0));
+    BOWCHK(hipMemsetAsync(p[16], 0xff, (size_t)n1 * 4, 0));
+    BOWCHK(hipMemsetAsync(p[17], 0xff, (size_t)n1 * 4, 0));
+    BOWCHK(hipMemsetAsync(p[18], 0, (ORBHIP_HISTO_LENGTH + 2) * 4, 0));
+    TriParams T; memset(&T, 0, sizeof T);
+    BowMatchParams& P = T.M;
+    P.mode = 0; P.nnratio = 0.f; P.check_ori = check_ori;
+    P.d1 = p[0]; P.valid1 = p[2]; P.n1 = n1; P.fn1 = (const uint32_t*)p[4]; P.fo1 = (const int*)p[5]; P.ff1 = (const uint32_t*)p[6]; P.nf1 = nfv1;
+    P.d2 = p[7]; P.valid2 = p[9]; P.n2 = n2; P.fn2 = (const uint32_t*)p[11]; P.fo2 = (const int*)p[12]; P.ff2 = (const uint32_t*)p[13]; P.nf2 = nfv2;
+    P.match12 = (int*)p[16]; P.bin12 = (int*)p[17]; P.hist = (int*)p[18]; P.nmatches = P.hist + ORBHIP_HISTO_LENGTH; P.overflow = P.nmatches + 1;
+    T.kp1 = (const float*)p[1]; T.kp2 = (const float*)p[8]; T.st1 = p[3]; T.st2 = p[10];
+    for (int i = 0; i < 9; i++) T.F[i] = F12[i];
+    T.ex = ex; T.ey = ey; T.scale2 = (const float*)p[14]; T.sigma2_2 = (const float*)p[15]; T.only_stereo = only_stereo;
+    hipLaunchKernelGGL(k_bow_triangulate, dim3((nfv1 + 3) / 4, 1, 1), dim3(256, 1, 1), 0, 0, T);
+    hipLaunchKernelGGL(k_bow_match_finish, dim3(1, 1, 1), dim3(256, 1, 1), 0, 0, P);
+    BOWCHK(hipGetLastError());
+    int nm = 0;
+    BOWCHK(hipMemcpyAsync(match12, p[16], (size_t)n1 * 4, hipMemcpyDeviceToHost, 0));
+    BOWCHK(hipMemcpyAsync(&nm, P.nmatches, 4, hipMemcpyDeviceToHost, 0));
+    BOWCHK(hipStreamSynchronize(0));
+    *nmatches = nm;
     return ORBHIP_OK;
 }

@@ -28,7 +28,7 @@ SYMBOLS = [
     "orbhip_algorithmic_bytes_per_frame_kernel", "orbhip_debug_blurred_level", "orbhip_debug_candidates",
     "orbhip_compute_stereo_matches", "orbhip_search_by_projection", "orbhip_extract_batch_color",
     "orbhip_extract_device_color", "orbhip_voc_load_text", "orbhip_voc_destroy", "orbhip_voc_info", "orbhip_voc_transform_features",
-    "orbhip_voc_transform", "orbhip_compute_bow", "orbhip_fetch_bow", "orbhip_voc_score", "orbhip_search_by_bow",
+    "orbhip_voc_transform", "orbhip_compute_bow", "orbhip_fetch_bow", "orbhip_voc_score", "orbhip_search_by_bow", "orbhip_search_for_triangulation",
 ]
 
 
@@ -84,6 +84,8 @@ def lib(path=None):
     L.orbhip_voc_score.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int]
     L.orbhip_voc_score.restype = C.c_double
     L.orbhip_search_by_bow.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp, ip]
+    L.orbhip_search_for_triangulation.argtypes = [C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int,
+                                                  vp, C.c_float, C.c_float, vp, vp, C.c_int, C.c_int, C.c_int, vp, ip]
     L.orbhip_sync.argtypes = [vp]
     L.orbhip_fetch.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp]
     L.orbhip_fetch_matches.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
@@ -464,4 +466,25 @@ def search_by_bow(mode, desc1, angle1, valid1, fv1, desc2, angle2, valid2, fv2, 
     _check(L.orbhip_search_by_bow(device, mode, _p(desc1), _p(angle1), _p(valid1), len(desc1), _p(f1[0]), _p(f1[1]), _p(f1[2]), len(f1[0]),
                                   _p(desc2), _p(angle2), None if valid2 is None else _p(valid2), len(desc2), _p(f2[0]), _p(f2[1]), _p(f2[2]), len(f2[0]),
                                   nnratio, int(check_ori), _p(m12), C.byref(nm)), "orbhip_search_by_bow", L)
+    return nm.value, m12
+
+
+def search_for_triangulation(desc1, kps1, has_mp1, stereo1, fv1, desc2, kps2, has_mp2, stereo2, fv2, F12, ex, ey, scale_factors2, level_sigma2_2,
+                             only_stereo=False, check_ori=True, device=0, library=None):
+    """ORBmatcher::SearchForTriangulation (ORBmatcher.cc:657-823) on flat data; kps = KEYPOINT arrays (mvKeysUn).  -> (nmatches, match12[n1])"""
+    L = lib(library)
+    kp4 = lambda k: np.ascontiguousarray(np.stack([k["x"], k["y"], k["angle"], k["octave"].astype(np.float32)], axis=1), np.float32)
+    desc1 = np.ascontiguousarray(desc1, np.uint8); desc2 = np.ascontiguousarray(desc2, np.uint8)
+    k1, k2 = kp4(kps1), kp4(kps2)
+    a = [np.ascontiguousarray(v, np.uint8) for v in (has_mp1, stereo1, has_mp2, stereo2)]
+    f1 = [np.ascontiguousarray(fv1[0], np.uint32), np.ascontiguousarray(fv1[1], np.int32), np.ascontiguousarray(fv1[2], np.uint32)]
+    f2 = [np.ascontiguousarray(fv2[0], np.uint32), np.ascontiguousarray(fv2[1], np.int32), np.ascontiguousarray(fv2[2], np.uint32)]
+    F = np.ascontiguousarray(F12, np.float32).reshape(9)
+    sc = np.ascontiguousarray(scale_factors2, np.float32); sg = np.ascontiguousarray(level_sigma2_2, np.float32)
+    m12 = np.full(len(desc1), -1, np.int32)
+    nm = C.c_int(0)
+    _check(L.orbhip_search_for_triangulation(device, _p(desc1), _p(k1), _p(a[0]), _p(a[1]), len(desc1), _p(f1[0]), _p(f1[1]), _p(f1[2]), len(f1[0]),
+                                             _p(desc2), _p(k2), _p(a[2]), _p(a[3]), len(desc2), _p(f2[0]), _p(f2[1]), _p(f2[2]), len(f2[0]),
+                                             _p(F), float(ex), float(ey), _p(sc), _p(sg), len(sc), int(only_stereo), int(check_ori), _p(m12), C.byref(nm)),
+           "orbhip_search_for_triangulation", L)
     return nm.value, m12

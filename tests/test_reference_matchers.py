@@ -179,6 +179,36 @@ def test_search_by_bow(ref, oracle, pair, mode, levelsup, ratio, ori):
     assert n_o > 30
 
 
+@pytest.mark.parametrize("fx,cx,cy,stereo,only,ori,levelsup,t2w", [(1.0, 0.0, 0.0, False, False, True, 2, (0.3, 0.1, 1.0)), (64.0, 240.0, 180.0, False, False, True, 1, (2.0, 1.0, 4.0)),
+                                                                    (64.0, 200.0, 150.0, True, False, True, 2, (0.5, 0.2, 1.0)), (64.0, 200.0, 150.0, True, True, False, 3, (0.5, 0.2, 1.0))])
+def test_search_for_triangulation(ref, oracle, pair_oracle, fx, cx, cy, stereo, only, ori, levelsup, t2w):
+    """ORBmatcher::SearchForTriangulation (ORBmatcher.cc:657-823) through real KeyFrame objects: key frame 1 at the origin, key
+    frame 2 = [I | t2w], so the epipole the reference derives is (fx t.x / t.z + cx, fy t.y / t.z + cy)."""
+    w, h, n, seq, sf, K = pair_oracle
+    (k1, d1), (k2, d2) = K
+    ref.RefFrame._geometry = None
+    if stereo:
+        F1 = ref.RefFrame(seq[0], np.roll(seq[0], -9, axis=1), nfeatures=n, fx=fx, fy=fx, cx=cx, cy=cy, bf=40.0)
+        F2 = ref.RefFrame(seq[1], np.roll(seq[1], -7, axis=1), nfeatures=n, fx=fx, fy=fx, cx=cx, cy=cy, bf=40.0)
+    else:
+        F1, F2 = ref.RefFrame(seq[0], nfeatures=n, fx=fx, fy=fx, cx=cx, cy=cy), ref.RefFrame(seq[1], nfeatures=n, fx=fx, fy=fx, cx=cx, cy=cy)
+    par = oracle.OracleExtractor(n, 1.2, 8, 20, 7).params()
+    ov = oracle.OracleVocabulary(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "voc_k6_L3_ref.txt"))
+    fv1, fv2 = ov.transform(d1, levelsup)[2:], ov.transform(d2, levelsup)[2:]
+    rng = np.random.default_rng(int(fx) + levelsup)
+    has1 = (rng.random(len(k1)) < 0.3).astype(np.uint8); has2 = (rng.random(len(k2)) < 0.3).astype(np.uint8)
+    F = np.array([[0, -1e-3, 1.0 / 300], [1e-3, 0, -3.0 / 300], [-1.0 / 300, 3.0 / 300, 0]], np.float32) + rng.normal(0, 1e-5, (3, 3)).astype(np.float32)
+    t = np.array(t2w, np.float32)
+    n_r, m_r = ref.search_for_triangulation(F1, has1, fv1, F2, has2, fv2, F, t, only_stereo=only, check_ori=ori)
+    invz = np.float32(1.0) / t[2]
+    ex, ey = np.float32(fx) * t[0] * invz + np.float32(cx), np.float32(fx) * t[1] * invz + np.float32(cy)      # :667-669
+    n_o, m_o = oracle.search_for_triangulation(d1, k1, has1, F1.u_right >= 0, fv1, d2, k2, has2, F2.u_right >= 0, fv2, F, ex, ey, par["scale_factors"], par["sigma2"],
+                                               only_stereo=only, check_ori=ori)
+    assert n_r == n_o and np.array_equal(m_r, m_o)
+    assert n_o > 30
+    F1.close(); F2.close()
+
+
 def test_product_equals_reference_matcher_and_stereo(ref, pair, emu_lib):
     """HIP kernel sources (emulation build) against the reference's code directly: frame-to-frame matching and stereo matching."""
     w, h, n, seq, sf, K, F = pair
