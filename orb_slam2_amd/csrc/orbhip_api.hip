@@ -242,7 +242,7 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
         g.kp_cap = std::max(g.nfeat + 3, 4 * g.nIni); g.kp_off = kp_off; kp_off += g.kp_cap;
         g.scale = c->sf[l]; g.kp_size = (float)(int)(31 * c->sf[l]); g.inv_scale = c->isf[l];   // scaledPatchSize (:837)
         c->qt_maxn = std::max(c->qt_maxn, g.kp_cap); c->qt_maxcells = std::max(c->qt_maxcells, g.ncells);
-        if (g.ncells > 64 * 511 || g.kp_cap > 64 * 511) { delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "level %d: too many cells / features for the quadtree scan", l); }
+        if (g.ncells > 65535 || g.kp_cap > 16383) { delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "level %d: too many cells / features for the quadtree scan", l); }
         if (l > 0) {
             g.src_w = c->geom[l - 1].w; g.src_h = c->geom[l - 1].h;
             g.xtab_off = (int)c->xtab.size(); build_resize_table(g.src_w, g.w, c->xtab);
@@ -332,7 +332,7 @@ static ExtractParams make_params(orbhip_ctx* c, const uint8_t* d_img0, long long
     P.blur_tiles = c->d_tiles; P.nblur_tiles = (int)c->blur_tiles.size();
     P.xtab = c->d_xtab; P.ytab = c->d_ytab; P.patternf = c->d_pattern;
     P.iniTh = c->cfg.ini_th_fast; P.minTh = c->cfg.min_th_fast; P.blur_round_mode = c->cfg.blur_round_mode;
-    P.qt_maxn = c->qt_maxn; P.qt_maxcells = c->qt_maxcells;
+    P.qt_maxn = c->qt_maxn; P.qt_maxcells = c->qt_maxcells; P.qt_scr = orbhip_quadtree_scr(c->qt_maxn, c->qt_maxcells);
     P.fc_pstride = (c->fc_maxpw + 8 + 3) & ~3; P.fc_prows = c->fc_maxph; P.fc_sstride = 8 + 4 * ((std::max(c->fc_maxpw - 6, 0) + 3) / 4); P.fc_srows = std::max(c->fc_maxph - 6, 0) + 2;
     P.fc_listcap = std::max(c->fc_maxpw - 6, 0) * std::max(c->fc_maxph - 6, 0);
     return P;

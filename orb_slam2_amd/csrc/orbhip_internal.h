@@ -66,6 +66,7 @@ struct ExtractParams {
     int iniTh, minTh, blur_round_mode;
     int qt_maxn;                                                           // LDS node capacity of the quadtree kernel
     int qt_maxcells;                                                       // max cells of one level
+    int qt_scr;                                                            // ints of scan scratch in the quadtree's LDS layout
     int fc_pstride, fc_prows, fc_sstride, fc_srows, fc_listcap;            // per-wave LDS layout of k_fast_cells (largest cell of the context)
 };
 
@@ -125,6 +126,7 @@ void orbhip_launch_fast_cells(const ExtractParams& P, int nframes, hipStream_t s
 void orbhip_launch_quadtree(const ExtractParams& P, int nframes, hipStream_t s);
 void orbhip_launch_describe(const ExtractParams& P, int nframes, hipStream_t s);
 size_t orbhip_quadtree_lds_bytes(int maxn, int maxcells);
+int orbhip_quadtree_scr(int maxn, int maxcells);
 void* orbhip_nn_workspace(size_t bytes, hipStream_t s);
 
 void orbhip_launch_hamming_nn(const uint8_t* d_q, int nq, const uint8_t* d_db, long long ndb, long long base,

@@ -645,7 +645,7 @@ __device__ __forceinline__ int qt_digit(unsigned code, int depth)
     return depth < ORBHIP_QT_DEPTH ? (int)((code >> (2 * (ORBHIP_QT_DEPTH - 1 - depth))) & 3u) : 0;
 }
 
-#define QT_SCR 512
+// scan scratch: one int per 64-element chunk of the longest scanned array + the total (sized on the host, see orbhip_quadtree_scr)
 __device__ __forceinline__ int qt_wave_incl_scan(int v, int lane)
 {
 #pragma unroll
@@ -653,7 +653,7 @@ __device__ __forceinline__ int qt_wave_incl_scan(int v, int lane)
     return v;
 }
 __device__ __forceinline__ int qt_block_exscan(int* a, int n, int* scratch, int tid)
-{   // in-place exclusive scan of a[0..n), n <= 64*(QT_SCR-1); returns the total; all QT_T threads must call.
+{   // in-place exclusive scan of a[0..n), n <= 64*(scr-1); the total lands in scratch[-1] (the slot in front); all QT_T threads must call.
     // 64-element chunks are scanned with wave shuffles, chunk totals by wave 0: three barriers in all.
     const int lane = tid & 63, wave = tid >> 6, nch = (n + 63) >> 6;
     for (int c = wave; c < nch; c += QT_T / 64) {
@@ -671,22 +671,25 @@ __device__ __forceinline__ int qt_block_exscan(int* a, int n, int* scratch, int 
             if (cb + lane < nch) scratch[cb + lane] = run + incl - v;
             run += __shfl(incl, 63);
         }
-        if (lane == 0) scratch[QT_SCR - 1] = run;
+        if (lane == 0) scratch[-1] = run;
     }
     __syncthreads();
     for (int i = tid; i < n; i += QT_T) a[i] += scratch[i >> 6];
-    const int total = scratch[QT_SCR - 1];
+    const int total = scratch[-1];
     __syncthreads();
     return total;
 }
 
 #define QT_LDSKEYS 4096                 // candidates per (frame, level) whose keys stay in LDS (6 B each); more -> HBM workspace
 
+int orbhip_quadtree_scr(int maxn, int maxcells) { return (std::max(maxn, maxcells) + 63) / 64 + 2; }
 size_t orbhip_quadtree_lds_bytes(int maxn, int maxcells)
 {
-    // s_pref[maxcells+1] | s_slot[maxcells] | cnt[2][maxn] | depth[2][maxn] | cc[4*maxn] | map[4*maxn] | a | b | sidx | split | best [maxn each]
-    // | scratch[QT_SCR] | misc[16] | key code u32 / node u16 [QT_LDSKEYS]      (KITTI shape: 52.9 KB -> three workgroups per CU)
-    return sizeof(int) * ((size_t)(2 * maxcells + 1) + (size_t)maxn * (2 + 2 + 4 + 4 + 5) + QT_SCR + 16) + (size_t)QT_LDSKEYS * 6;
+    // ints: s_pref[maxcells+1] | s_slot[maxcells] | cnt[2][maxn] | cc[4*maxn] | a | b | sidx | split | best [maxn each] | scratch[scr] | misc[16]
+    // then key code u32 [QT_LDSKEYS] | map u16 [4*maxn] | key node u16 [QT_LDSKEYS] | depth u8 [2][maxn]
+    // KITTI shape: 51.9 KB -> three workgroups per CU (with 32-bit map / depth tables it was 59.9 KB -> two: 0.23 -> 0.18 ms)
+    const size_t ints = (size_t)(2 * maxcells + 1) + (size_t)maxn * (2 + 4 + 5) + orbhip_quadtree_scr(maxn, maxcells) + 16;
+    return sizeof(int) * ints + (size_t)QT_LDSKEYS * 6 + (size_t)maxn * 4 * 2 + (((size_t)maxn * 2 + 3) & ~(size_t)3);
 }
 
 // per-candidate state of the quadtree replay: path code, current node (list position), FAST score
@@ -708,7 +711,8 @@ struct QtKeysHbm {
 };
 
 struct QtLds {
-    int *pref, *slot, *cntA, *cntB, *depA, *depB, *cc, *map, *a, *b, *sidx, *split, *best, *scratch, *misc;
+    int *pref, *slot, *cntA, *cntB, *cc, *a, *b, *sidx, *split, *best, *scratch, *misc;
+    unsigned short* map; unsigned char *depA, *depB;
 };
 
 template <class Keys>
@@ -750,8 +754,9 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
     __syncthreads();
     int m = L.misc[0];
     for (int k = tid; k < n; k += QT_T) keys.setNode(k, L.map[keys.getNode(k)]);
-    int* cnt = L.cntB; int* dep = L.depB; int* cnt2 = L.cntA; int* dep2 = L.depA;
-    int *s_cc = L.cc, *s_map = L.map, *s_a = L.a, *s_b = L.b, *s_sidx = L.sidx, *s_split = L.split, *s_best = L.best, *s_scratch = L.scratch, *s_misc = L.misc;
+    int* cnt = L.cntB; unsigned char* dep = L.depB; int* cnt2 = L.cntA; unsigned char* dep2 = L.depA;
+    unsigned short* s_map = L.map;
+    int *s_cc = L.cc, *s_a = L.a, *s_b = L.b, *s_sidx = L.sidx, *s_split = L.split, *s_best = L.best, *s_scratch = L.scratch, *s_misc = L.misc;
     __syncthreads();
 
     // ---- C. passes
@@ -780,8 +785,8 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
             for (int p = tid; p < m; p += QT_T) {
                 if (s_split[p]) {
                     int q = s_a[p];
-                    for (int d = 0; d < 4; d++) { const int c = s_cc[4 * p + d]; if (c > 0) { const int pos = Ctot - 1 - q; q++; cnt2[pos] = c; dep2[pos] = dep[p] + 1; s_map[4 * p + d] = pos; } }
-                } else { const int pos = Ctot + s_b[p]; cnt2[pos] = cnt[p]; dep2[pos] = dep[p]; s_map[4 * p] = pos; }
+                    for (int d = 0; d < 4; d++) { const int c = s_cc[4 * p + d]; if (c > 0) { const int pos = Ctot - 1 - q; q++; cnt2[pos] = c; dep2[pos] = (unsigned char)(dep[p] + 1); s_map[4 * p + d] = (unsigned short)pos; } }
+                } else { const int pos = Ctot + s_b[p]; cnt2[pos] = cnt[p]; dep2[pos] = dep[p]; s_map[4 * p] = (unsigned short)pos; }
             }
         } else {
             // final phase: expandable nodes sorted by (size, creation) ascending, processed from the back (:684-732)
@@ -820,8 +825,8 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
             for (int p = tid; p < m; p += QT_T) {
                 if (s_split[p]) {
                     int q = s_a[s_split[p] - 1];
-                    for (int d = 0; d < 4; d++) { const int c = s_cc[4 * p + d]; if (c > 0) { const int pos = Ctot - 1 - q; q++; cnt2[pos] = c; dep2[pos] = dep[p] + 1; s_map[4 * p + d] = pos; } }
-                } else { const int pos = Ctot + s_best[p]; cnt2[pos] = cnt[p]; dep2[pos] = dep[p]; s_map[4 * p] = pos; }
+                    for (int d = 0; d < 4; d++) { const int c = s_cc[4 * p + d]; if (c > 0) { const int pos = Ctot - 1 - q; q++; cnt2[pos] = c; dep2[pos] = (unsigned char)(dep[p] + 1); s_map[4 * p + d] = (unsigned short)pos; } }
+                } else { const int pos = Ctot + s_best[p]; cnt2[pos] = cnt[p]; dep2[pos] = dep[p]; s_map[4 * p] = (unsigned short)pos; }
             }
         }
         __syncthreads();
@@ -835,7 +840,7 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
         if (nexp) atomicAdd(&s_misc[3], nexp);
         __syncthreads();
         const int nToExpand = s_misc[3];
-        int* t = cnt; cnt = cnt2; cnt2 = t; t = dep; dep = dep2; dep2 = t;
+        int* t = cnt; cnt = cnt2; cnt2 = t; unsigned char* td = dep; dep = dep2; dep2 = td;
         const int prev = m; m = m2;
         __syncthreads();
         if (m >= N || m == prev) break;                                    // :669-672 / :734-735
@@ -876,11 +881,13 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(ExtractParams P)
     HIP_DYNAMIC_SHARED(int, lds)
     QtLds L;
     L.pref = lds; L.slot = L.pref + (P.qt_maxcells + 1);
-    L.cntA = L.slot + P.qt_maxcells; L.cntB = L.cntA + maxn; L.depA = L.cntB + maxn; L.depB = L.depA + maxn;
-    L.cc = L.depB + maxn; L.map = L.cc + 4 * maxn; L.a = L.map + 4 * maxn; L.b = L.a + maxn; L.sidx = L.b + maxn; L.split = L.sidx + maxn;
-    L.best = L.split + maxn; L.scratch = L.best + maxn; L.misc = L.scratch + QT_SCR;
+    L.cntA = L.slot + P.qt_maxcells; L.cntB = L.cntA + maxn;
+    L.cc = L.cntB + maxn; L.a = L.cc + 4 * maxn; L.b = L.a + maxn; L.sidx = L.b + maxn; L.split = L.sidx + maxn;
+    L.best = L.split + maxn; L.scratch = L.best + maxn + 1; L.misc = L.scratch - 1 + P.qt_scr;      // scratch[-1] holds the scan total
     unsigned* kcode = reinterpret_cast<unsigned*>(L.misc + 16);
-    unsigned short* knode = reinterpret_cast<unsigned short*>(kcode + QT_LDSKEYS);
+    L.map = reinterpret_cast<unsigned short*>(kcode + QT_LDSKEYS);
+    unsigned short* knode = L.map + 4 * maxn;
+    L.depA = reinterpret_cast<unsigned char*>(knode + QT_LDSKEYS); L.depB = L.depA + maxn;
 
     const int* ccount = P.cell_count + (long long)frame * P.ncells_total + g.cell_first;
     for (int c = tid; c < g.ncells; c += QT_T) { L.pref[c] = ccount[c]; L.slot[c] = P.cells[g.cell_first + c].cand_idx; }
