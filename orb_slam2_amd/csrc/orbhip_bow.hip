@@ -497,7 +497,12 @@ extern "C" orbhip_status orbhip_voc_load_text(orbhip_voc** out, const char* path
 extern "C" orbhip_status orbhip_voc_info(const orbhip_voc* v, int* k, int* L, int* scoring, int* weighting, int* nnodes, int* nwords)
 {
     if (!v) return orbhip_set_error(ORBHIP_ERR_INVALID, "null vocabulary");
-    if (k) *k = v->k; if (L) *L = v->L; if (scoring) *scoring = v->scoring; if (weighting) *weighting = v->weighting; if (nnodes) *nnodes = v->nnodes; if (nwords) *nwords = v->nwords;
+    if (k) *k = v->k;
+    if (L) *L = v->L;
+    if (scoring) *scoring = v->scoring;
+    if (weighting) *weighting = v->weighting;
+    if (nnodes) *nnodes = v->nnodes;
+    if (nwords) *nwords = v->nwords;
     return ORBHIP_OK;
 }
 
@@ -538,7 +543,8 @@ static orbhip_status voc_fetch(orbhip_voc* v, int frame, hipStream_t s, uint32_t
     if (fv_off) BOWCHK(hipMemcpyAsync(fv_off, v->d_fv_off + frame * (C + 1), (size_t)(nf + 1) * 4, hipMemcpyDeviceToHost, s));
     if (m > 0 && fv_feat) BOWCHK(hipMemcpyAsync(fv_feat, v->d_fv_feat + frame * C, (size_t)m * 4, hipMemcpyDeviceToHost, s));
     BOWCHK(hipStreamSynchronize(s));
-    if (nbow) *nbow = nb; if (nfv) *nfv = nf;
+    if (nbow) *nbow = nb;
+    if (nfv) *nfv = nf;
     return ORBHIP_OK;
 }
 
@@ -546,7 +552,9 @@ extern "C" orbhip_status orbhip_voc_transform(orbhip_voc* v, const uint8_t* desc
                                               uint32_t* fv_node, int32_t* fv_off, uint32_t* fv_feat, int* nfv)
 {
     if (!v || (n > 0 && !desc) || n < 0) return orbhip_set_error(ORBHIP_ERR_INVALID, "bad argument");
-    if (nbow) *nbow = 0; if (nfv) *nfv = 0; if (fv_off) fv_off[0] = 0;
+    if (nbow) *nbow = 0;
+    if (nfv) *nfv = 0;
+    if (fv_off) fv_off[0] = 0;
     if (v->nwords == 0 || n == 0) return ORBHIP_OK;                              // v.clear(); fv.clear(); if(empty()) return;  (:1130-1136)
     orbhip_status st = voc_upload(v, desc, n); if (st != ORBHIP_OK) return st;
     st = voc_run(v, v->d_desc, 0, nullptr, n, 1, v->ws_cap, levelsup, true, v->stream); if (st != ORBHIP_OK) return st;
