@@ -9,6 +9,16 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PATH = os.path.join(HERE, "_ref", "liborbslam_ref.so")
+FAST_PATH = os.path.join(HERE, "_ref", "liborbslam_ref_fast.so")      # -O3 timing build of the same sources (bench.py cpu_baseline)
+_use_fast = False
+
+
+def use_fast_build(on=True):
+    """Select the timing build; call before the first frame is made in this process."""
+    global _use_fast, _lib
+    assert _lib is None or _use_fast == on, "library already loaded"
+    _use_fast = on
+
 KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
 _lib = None
 
@@ -27,7 +37,7 @@ def build():
 def lib():
     global _lib
     if _lib is None:
-        L = C.CDLL(PATH)
+        L = C.CDLL(FAST_PATH if _use_fast else PATH)
         vp, i, f = C.c_void_p, C.c_int, C.c_float
         L.orbslam_ref_frame_mono.restype = vp
         L.orbslam_ref_frame_mono.argtypes = [vp, i, i, i, i, f, i, i, i, f, f, f, f, f, f, i]
