@@ -110,6 +110,7 @@ inline Mat operator*(const Mat& a, const Mat& b)
 }
 inline Mat operator*(float f, const Mat& a) { Mat m(a.rows, a.cols, CV_32F); for (int y = 0; y < a.rows; y++) for (int x = 0; x < a.cols; x++) m.at<float>(y, x) = f * a.at<float>(y, x); return m; }
 inline Mat operator*(const Mat& a, float f) { return f * a; }
+inline Mat operator*(double f, const Mat& a) { return (float)f * a; }
 inline Mat operator/(const Mat& a, float f) { Mat m(a.rows, a.cols, CV_32F); for (int y = 0; y < a.rows; y++) for (int x = 0; x < a.cols; x++) m.at<float>(y, x) = a.at<float>(y, x) / f; return m; }
 inline Mat operator-(const Mat& a, const Mat& b) { Mat m(a.rows, a.cols, CV_32F); for (int y = 0; y < a.rows; y++) for (int x = 0; x < a.cols; x++) m.at<float>(y, x) = a.at<float>(y, x) - b.at<float>(y, x); return m; }
 inline Mat operator+(const Mat& a, const Mat& b) { Mat m(a.rows, a.cols, CV_32F); for (int y = 0; y < a.rows; y++) for (int x = 0; x < a.cols; x++) m.at<float>(y, x) = a.at<float>(y, x) + b.at<float>(y, x); return m; }

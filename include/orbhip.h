@@ -175,6 +175,27 @@ orbhip_status orbhip_search_by_projection(int device, const orbhip_keypoint* kps
 orbhip_status orbhip_compute_stereo_matches(orbhip_ctx* left, orbhip_ctx* right, int nimg, float mbf, float mb,
                                             float* u_right, float* depth, int cap);
 
+/* The candidate loop of ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th) (ORBmatcher.h:75, ORBmatcher.cc:825-972), of its
+   Sim3 overload (ORBmatcher.h:78, :974-1100: the same loop without the chi-square gate) and of the two passes of
+   ORBmatcher::SearchBySim3 (ORBmatcher.h:71-72, ORBmatcher.cc:1102-1326) on flat data.  The caller projects its
+   map points (pose / Sim3 algebra, frustum and distance tests, PredictScale) and hands over one query per surviving point:
+   (x, y) = projection, radius = th * mvScaleFactors[level], ur = u - bf/z (only read by the stereo chi-square test), level = the
+   predicted octave.  Per query the key points of KeyFrame::GetFeaturesInArea(x, y, radius) with octave level-1 .. level are
+   compared; with chi2_gate != 0 Fuse's reprojection test (7.8 stereo / 5.99 mono, ORBmatcher.cc:901-926; the Sim3 overload of
+   Fuse and SearchBySim3 use chi2_gate = 0) is applied first.  best_idx[q] = the first key point with the smallest descriptor
+   distance (-1: none; a candidate at distance 256 is never reported — it cannot pass either threshold), best_dist[q] its distance;
+   the caller applies `<= TH_LOW` (Fuse) / `<= TH_HIGH` (SearchBySim3) and does
+   the map surgery / the mutual-consistency check.  Queries do not interact.
+   The other pose-guided matchers are parameterisations of orbhip_search_by_projection mode 1: SearchByProjection(KeyFrame*, Scw,
+   vpPoints, vpMatched, th) (ORBmatcher.cc:290-403) = levels [L-1, L], th_high = TH_LOW, no orientation check, blocked = vpMatched
+   set; SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) (:1472-1599) = levels [L-1, L+1], th_high = ORBdist,
+   blocked = any map point (tests/test_reference_matchers.py runs both against the reference's own code). */
+typedef struct { float x, y, radius, ur; int32_t level; } orbhip_best_query;
+orbhip_status orbhip_search_best_in_window(int device, const orbhip_keypoint* kps, const uint8_t* desc, const float* u_right /* may be NULL */,
+                                           int n, int im_w, int im_h, const float* inv_level_sigma2, int nlevels,
+                                           const orbhip_best_query* queries, const uint8_t* query_desc, int nq, int chi2_gate,
+                                           int32_t* best_idx, int32_t* best_dist);
+
 /* -------- DBoW2 vocabulary ----------------------------------------------------------
    ORBVocabulary = DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> (include/ORBVocabulary.h:31-32).  BowVector and
    FeatureVector (std::map in the reference) are returned flattened in map (ascending key) order:

@@ -871,6 +871,43 @@ void ComputeStereoMatches(const Extractor& EL, const Extractor& ER, float mbf, f
     }
 }
 
+// The candidate loop shared by ORBmatcher::Fuse (both overloads, ORBmatcher.cc:884-948 / 1038-1079) and the two passes of
+// SearchBySim3 (:1188-1224 / 1268-1304) on flat data: a map point projected to (x, y) with predicted level L searches
+// KeyFrame::GetFeaturesInArea(x, y, radius) (KeyFrame.cc:569-608: the frame grid without level filter), keeps key points of level
+// L-1 .. L, optionally gates them with the reprojection chi-square test of Fuse (stereo 7.8 / mono 5.99, :903-929), and takes the
+// FIRST smallest descriptor distance.  Queries do not interact.  best_idx[q] = -1 if no candidate survived; the caller applies
+// `bestDist <= TH_LOW` (Fuse) / `<= TH_HIGH` (SearchBySim3) and does the map surgery / the mutual-consistency check.
+struct BestQuery { float x, y, radius, ur; int level; };
+void SearchBestInWindow(const FrameLite& F, const float* mvuRight, const float* invLevelSigma2, const BestQuery* Q, const uint8_t* qdesc, int nq,
+                        bool chi2_gate, int* best_idx, int* best_dist)
+{
+    for (int iq = 0; iq < nq; iq++) {
+        const BestQuery& q = Q[iq];
+        best_idx[iq] = -1; best_dist[iq] = 256;
+        const std::vector<size_t> vIndices = F.GetFeaturesInArea(q.x, q.y, q.radius, -1, -1);
+        int bestDist = 256, bestIdx = -1;
+        for (size_t idx : vIndices) {
+            const KeyPoint& kp = F.keys[idx];
+            const int kpLevel = kp.octave;
+            if (kpLevel < q.level - 1 || kpLevel > q.level) continue;
+            if (chi2_gate) {
+                if (mvuRight && mvuRight[idx] >= 0) {
+                    const float ex = q.x - kp.x, ey = q.y - kp.y, er = q.ur - mvuRight[idx];
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if (e2 * invLevelSigma2[kpLevel] > 7.8) continue;
+                } else {
+                    const float ex = q.x - kp.x, ey = q.y - kp.y;
+                    const float e2 = ex * ex + ey * ey;
+                    if (e2 * invLevelSigma2[kpLevel] > 5.99) continue;
+                }
+            }
+            const int dist = DescriptorDistance(qdesc + (size_t)iq * 32, &F.desc[idx * 32]);
+            if (dist < bestDist) { bestDist = dist; bestIdx = (int)idx; }
+        }
+        best_idx[iq] = bestIdx; best_dist[iq] = bestDist;
+    }
+}
+
 }  // namespace
 
 // ================================================================ C API (ctypes)
@@ -988,6 +1025,13 @@ int orb_oracle_search_by_projection(const void* kps, const uint8_t* desc, const 
     const int r = SearchByProjectionFlat(*F, u_right, b, (const ProjQuery*)q, qdesc, nq, mode, nnratio, th_high, check_ori != 0, feature_query);
     delete F;
     return r;
+}
+void orb_oracle_search_best_in_window(const void* kps, const uint8_t* desc, const float* u_right, int n, int imw, int imh, const float* inv_level_sigma2,
+                                      const void* q, const uint8_t* qdesc, int nq, int chi2_gate, int* best_idx, int* best_dist)
+{
+    FrameLite* F = new FrameLite; F->build((const KeyPoint*)kps, desc, n, imw, imh);
+    SearchBestInWindow(*F, u_right, inv_level_sigma2, (const BestQuery*)q, qdesc, nq, chi2_gate != 0, best_idx, best_dist);
+    delete F;
 }
 // Frame::ComputeStereoMatches on the results of the last orb_oracle_extract calls of a left and a right extractor; returns N
 int orb_oracle_stereo_matches(void* hl, void* hr, float mbf, float mb, float* uRight, float* depth, int cap)

@@ -62,6 +62,7 @@ def lib(fast=False):
     L.orb_oracle_forb_distance.argtypes = [vp, vp]
     L.orb_oracle_search_for_triangulation.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, C.c_float, C.c_float, vp, vp, C.c_int, C.c_int, vp]
     L.orb_oracle_search_for_triangulation.restype = C.c_int
+    L.orb_oracle_search_best_in_window.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, vp]
     L.orb_oracle_search_by_bow.argtypes = [C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp]
     L.orb_oracle_search_by_bow.restype = C.c_int
     L.orb_oracle_cvt_gray.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
@@ -370,3 +371,18 @@ def search_for_triangulation(desc1, kps1, has_mp1, stereo1, fv1, desc2, kps2, ha
                                                   _p(desc2), _p(k2), _p(a[2]), _p(a[3]), len(desc2), _p(f2[0]), _p(f2[1]), _p(f2[2]), len(f2[0]),
                                                   _p(F), float(ex), float(ey), _p(sc), _p(sg), int(only_stereo), int(check_ori), _p(m12))
     return n, m12
+
+
+BEST_QUERY_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("radius", "<f4"), ("ur", "<f4"), ("level", "<i4")])
+
+
+def search_best_in_window(kps, desc, imw, imh, inv_level_sigma2, queries, qdesc, chi2_gate, u_right=None):
+    """Candidate loop of ORBmatcher::Fuse / SearchBySim3 on flat data -> (best_idx[nq], best_dist[nq])"""
+    kps = np.ascontiguousarray(kps); desc = np.ascontiguousarray(desc, np.uint8)
+    queries = np.ascontiguousarray(queries, BEST_QUERY_DTYPE); qdesc = np.ascontiguousarray(qdesc, np.uint8)
+    inv = np.ascontiguousarray(inv_level_sigma2, np.float32)
+    ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    bi = np.full(len(queries), -1, np.int32); bd = np.full(len(queries), 256, np.int32)
+    lib().orb_oracle_search_best_in_window(_p(kps), _p(desc), None if ur is None else _p(ur), len(kps), imw, imh, _p(inv), _p(queries), _p(qdesc), len(queries),
+                                           int(chi2_gate), _p(bi), _p(bd))
+    return bi, bd

@@ -53,6 +53,10 @@ def lib():
         L.orbslam_ref_search_by_projection_last.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f, i, f, i, vp]
         L.orbslam_ref_search_by_bow.argtypes = [i, vp, vp, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, vp, i, f, i, vp]
         L.orbslam_ref_search_for_triangulation.argtypes = [vp, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, i, vp, vp, i, i, vp]
+        L.orbslam_ref_fuse.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, vp, vp, f, vp]
+        L.orbslam_ref_search_by_projection_kf.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, vp, i, vp]
+        L.orbslam_ref_search_by_projection_reloc.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f, i, f, i, vp]
+        L.orbslam_ref_search_by_sim3.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f, vp]
         _lib = L
     return _lib
 
@@ -147,4 +151,47 @@ def search_for_triangulation(f1, has1, fv1, f2, has2, fv2, F12, t2w, only_stereo
     m12 = np.full(f1.N, -1, np.int32)
     n = lib().orbslam_ref_search_for_triangulation(f1.h, _p(has1), _p(a1[0]), _p(a1[1]), _p(a1[2]), len(a1[0]), f2.h, _p(has2), _p(a2[0]), _p(a2[1]), _p(a2[2]), len(a2[0]),
                                                    _p(F), _p(t), int(only_stereo), int(check_ori), _p(m12))
+    return n, m12
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def _u8(a, n):
+    return np.zeros(n, np.uint8) if a is None else np.ascontiguousarray(a, np.uint8)
+
+
+def fuse(frame, kf_state, X, Y, Z, level, nobs, bad, desc, th=3.0):
+    """ORBmatcher::Fuse(pKF, vpMapPoints, th) with the key frame (made of `frame`) at the origin -> (nFused, best_idx[nq])"""
+    nq = len(X)
+    best = np.full(nq, -1, np.int32)
+    a = [_f32(X), _f32(Y), _f32(Z), np.ascontiguousarray(level, np.int32), np.ascontiguousarray(nobs, np.int32), _u8(bad, nq), np.ascontiguousarray(desc, np.uint8)]
+    st = _u8(kf_state, frame.N)
+    n = lib().orbslam_ref_fuse(frame.h, _p(st), nq, *[_p(v) for v in a], th, _p(best))
+    return n, best
+
+
+def search_by_projection_kf(frame, matched_state, X, Y, Z, level, bad, desc, th=10):
+    nq = len(X)
+    fq = np.full(frame.N, -1, np.int32)
+    a = [_f32(X), _f32(Y), _f32(Z), np.ascontiguousarray(level, np.int32), _u8(bad, nq), np.ascontiguousarray(desc, np.uint8)]
+    n = lib().orbslam_ref_search_by_projection_kf(frame.h, _p(_u8(matched_state, frame.N)), nq, *[_p(v) for v in a], int(th), _p(fq))
+    return n, fq
+
+
+def search_by_projection_reloc(cur, kf_frame, has_point, X, Y, Z, level, bad, found, desc, cur_state, th=10.0, orb_dist=100, nnratio=0.9, check_ori=True):
+    n1 = kf_frame.N
+    fq = np.full(cur.N, -1, np.int32)
+    a = [_u8(has_point, n1), _f32(X), _f32(Y), _f32(Z), np.ascontiguousarray(level, np.int32), _u8(bad, n1), _u8(found, n1), np.ascontiguousarray(desc, np.uint8), _u8(cur_state, cur.N)]
+    n = lib().orbslam_ref_search_by_projection_reloc(cur.h, kf_frame.h, *[_p(v) for v in a], th, int(orb_dist), nnratio, int(check_ori), _p(fq))
+    return n, fq
+
+
+def search_by_sim3(f1, has1, X1, Y1, Z1, level1, desc1, f2, has2, X2, Y2, Z2, level2, desc2, already12=None, th=7.5):
+    m12 = np.full(f1.N, -1, np.int32)
+    al = np.full(f1.N, -1, np.int32) if already12 is None else np.ascontiguousarray(already12, np.int32)
+    a1 = [_u8(has1, f1.N), _f32(X1), _f32(Y1), _f32(Z1), np.ascontiguousarray(level1, np.int32), np.ascontiguousarray(desc1, np.uint8)]
+    a2 = [_u8(has2, f2.N), _f32(X2), _f32(Y2), _f32(Z2), np.ascontiguousarray(level2, np.int32), np.ascontiguousarray(desc2, np.uint8)]
+    n = lib().orbslam_ref_search_by_sim3(f1.h, *[_p(v) for v in a1], f2.h, *[_p(v) for v in a2], _p(al), th, _p(m12))
     return n, m12

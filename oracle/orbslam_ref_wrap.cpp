@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <set>
 #include <new>
 #include <vector>
 #include "Frame.h"
@@ -70,14 +71,21 @@ void MapPoint::SetBadFlag() { mbBad = true; }
 void MapPoint::ComputeDistinctiveDescriptors() { mDescriptor.create(1, 32, CV_8U); memcpy(mDescriptor.data, g_next_desc, 32); }
 float MapPoint::GetMinDistanceInvariance() { return 0.8f * mfMinDistance; }
 float MapPoint::GetMaxDistanceInvariance() { return 1.2f * mfMaxDistance; }
-void MapPoint::AddObservation(KeyFrame*, size_t) { nObs++; }
-int MapPoint::GetIndexInKeyFrame(KeyFrame*) { return -1; }
+void MapPoint::AddObservation(KeyFrame* pKF, size_t idx) { mObservations[pKF] = idx; mnBALocalForKF = idx + 1; }   // also records where Fuse attached the point
+int MapPoint::GetIndexInKeyFrame(KeyFrame* pKF) { std::map<KeyFrame*, size_t>::iterator it = mObservations.find(pKF); return it == mObservations.end() ? -1 : (int)it->second; }
 bool MapPoint::IsInKeyFrame(KeyFrame*) { return false; }
-void MapPoint::Replace(MapPoint*) {}
-int MapPoint::PredictScale(const float&, KeyFrame*) { return 0; }
-int MapPoint::PredictScale(const float&, Frame*) { return 0; }
+std::vector<std::pair<MapPoint*, MapPoint*> > g_replaced;             // (replaced, by): what Fuse decided for features that already had a point
+void MapPoint::Replace(MapPoint* pMP) { g_replaced.push_back(std::make_pair(this, pMP)); }
+// the level is handed in by the test (the real function is a log of the distance ratio, MapPoint.cc:393-421; not on this path)
+int MapPoint::PredictScale(const float&, KeyFrame*) { return mnTrackScaleLevel; }
+int MapPoint::PredictScale(const float&, Frame*) { return mnTrackScaleLevel; }
+void MapPoint::UpdateNormalAndDepth()
+{   // viewing direction = from the origin to the point, scale-invariance range wide open
+    const float n = (float)cv::norm(mWorldPos);
+    mNormalVector = mWorldPos / n; mfMinDistance = 0.0f; mfMaxDistance = 1e30f;
+}
 static void not_built(const char* what) { fprintf(stderr, "%s is not part of the oracle build\n", what); abort(); }
-void KeyFrame::AddMapPoint(MapPoint*, const size_t&) { not_built("KeyFrame::AddMapPoint"); }
+void KeyFrame::AddMapPoint(MapPoint*, const size_t&) {}      // Fuse's bookkeeping; the search result is read from the map point (AddObservation above)
 cv::Mat KeyFrame::GetCameraCenter() { return Ow.clone(); }
 void KeyFrame::SetPose(const cv::Mat& Tcw_)
 {   // KeyFrame.cc:61-79 without the stereo centre: Tcw, Ow = -Rcw' tcw, Twc
@@ -86,7 +94,9 @@ void KeyFrame::SetPose(const cv::Mat& Tcw_)
     Ow = -Rwc * tcw;
     Twc = cv::Mat::eye(4, 4, CV_32F);
 }
-std::vector<size_t> KeyFrame::GetFeaturesInArea(const float&, const float&, const float&) const { not_built("KeyFrame::GetFeaturesInArea"); return std::vector<size_t>(); }
+static std::map<const KeyFrame*, Frame*> g_kf_frame;
+// KeyFrame.cc:569-608 is Frame::GetFeaturesInArea (Frame.cc:327-380) without the level filter on a copy of the same grid
+std::vector<size_t> KeyFrame::GetFeaturesInArea(const float& x, const float& y, const float& r) const { return g_kf_frame[this]->GetFeaturesInArea(x, y, r, -1, -1); }
 MapPoint* KeyFrame::GetMapPoint(const size_t& idx) { return mvpMapPoints[idx]; }
 std::vector<MapPoint*> KeyFrame::GetMapPointMatches() { return mvpMapPoints; }
 long unsigned int KeyFrame::nNextId = 0;
@@ -106,11 +116,12 @@ KeyFrame::KeyFrame(Frame& F, Map* pMap, KeyFrameDatabase* pKFDB)
       mbNotErase(false), mbToBeErased(false), mbBad(false), mHalfBaseline(F.mb / 2), mpMap(pMap)
 {
     mnId = nNextId++;
+    g_kf_frame[this] = &F;
 }
 std::set<MapPoint*> KeyFrame::GetMapPoints() { not_built("KeyFrame::GetMapPoints"); return std::set<MapPoint*>(); }
 cv::Mat KeyFrame::GetRotation() { return Tcw.rowRange(0, 3).colRange(0, 3).clone(); }
 cv::Mat KeyFrame::GetTranslation() { return Tcw.rowRange(0, 3).col(3).clone(); }
-bool KeyFrame::IsInImage(const float&, const float&) const { not_built("KeyFrame::IsInImage"); return false; }
+bool KeyFrame::IsInImage(const float& x, const float& y) const { return (x >= mnMinX && x < mnMaxX && y >= mnMinY && y < mnMaxY); }     // KeyFrame.cc:610-613
 }  // namespace ORB_SLAM2
 
 namespace {
@@ -327,6 +338,118 @@ int orbslam_ref_search_for_triangulation(void* f1, const uint8_t* has1, const ui
     const int n = matcher.SearchForTriangulation(kf1, kf2, F, pairs, only_stereo != 0);
     for (int i = 0; i < F1.N; i++) match12[i] = -1;
     for (size_t i = 0; i < pairs.size(); i++) match12[pairs[i].first] = (int)pairs[i].second;
+    delete kf1; delete kf2;
+    return n;
+}
+
+static MapPoint* make_query_point(float x, float y, float z, const uint8_t* desc, int level, int nobs, bool bad)
+{
+    MapPoint* p = make_point(x, y, z, desc, nobs, bad);
+    p->mnTrackScaleLevel = level;
+    p->UpdateNormalAndDepth();
+    return p;
+}
+static KeyFrame* identity_keyframe(Frame& F)
+{
+    KeyFrame* kf = new KeyFrame(F, NULL, NULL);
+    cv::Mat T = cv::Mat::eye(4, 4, CV_32F);
+    kf->SetPose(T);
+    return kf;
+}
+// ORBmatcher.Fuse(pKF, vpMapPoints, th)  (ORBmatcher.cc:825-972), key frame at the origin.  kf_state[i]: 0 no map point, 1 a good
+// one, 2 a bad one.  best_idx[q] = the key frame feature the reference decided on for map point q (attached, or merged with the
+// point already there), -1 if none.  Returns nFused.
+int orbslam_ref_fuse(void* fp, const uint8_t* kf_state, int nq, const float* X, const float* Y, const float* Z, const int* level, const int* nobs, const uint8_t* bad,
+                     const uint8_t* desc, float th, int* best_idx)
+{
+    Frame& F = *(Frame*)fp;
+    std::map<MapPoint*, int> kfIndex;
+    for (int i = 0; i < F.N; i++) {
+        F.mvpMapPoints[i] = NULL;
+        if (kf_state && kf_state[i]) { MapPoint* p = make_point(0, 0, 1, NULL, 2, kf_state[i] == 2); F.mvpMapPoints[i] = p; kfIndex[p] = i; }
+    }
+    KeyFrame* kf = identity_keyframe(F);
+    std::vector<MapPoint*> pts(nq);
+    for (int q = 0; q < nq; q++) pts[q] = make_query_point(X[q], Y[q], Z[q], desc + (size_t)q * 32, level[q], nobs[q], bad[q] != 0);
+    ORB_SLAM2::g_replaced.clear();
+    ORBmatcher matcher(0.6f, true);
+    const int n = matcher.Fuse(kf, pts, th);
+    std::map<MapPoint*, int> qIndex;
+    for (int q = 0; q < nq; q++) { qIndex[pts[q]] = q; best_idx[q] = pts[q]->mnBALocalForKF ? (int)pts[q]->mnBALocalForKF - 1 : -1; }
+    for (size_t r = 0; r < ORB_SLAM2::g_replaced.size(); r++) {
+        MapPoint *a = ORB_SLAM2::g_replaced[r].first, *b = ORB_SLAM2::g_replaced[r].second;
+        if (qIndex.count(a) && kfIndex.count(b)) best_idx[qIndex[a]] = kfIndex[b];
+        if (qIndex.count(b) && kfIndex.count(a)) best_idx[qIndex[b]] = kfIndex[a];
+    }
+    delete kf;
+    return n;
+}
+// ORBmatcher.SearchByProjection(pKF, Scw = identity, vpPoints, vpMatched, th)  (ORBmatcher.cc:290-403).  matched_state[i] != 0:
+// vpMatched[i] already holds a point.  feature_query[i] = index of the candidate point placed into vpMatched[i].
+int orbslam_ref_search_by_projection_kf(void* fp, const uint8_t* matched_state, int nq, const float* X, const float* Y, const float* Z, const int* level,
+                                        const uint8_t* bad, const uint8_t* desc, int th, int* feature_query)
+{
+    Frame& F = *(Frame*)fp;
+    for (int i = 0; i < F.N; i++) F.mvpMapPoints[i] = NULL;
+    KeyFrame* kf = identity_keyframe(F);
+    std::vector<MapPoint*> matched(F.N, static_cast<MapPoint*>(NULL)), pts(nq);
+    for (int i = 0; i < F.N; i++) if (matched_state && matched_state[i]) matched[i] = make_point(0, 0, 1, NULL, 1, false);
+    std::map<MapPoint*, int> qIndex;
+    for (int q = 0; q < nq; q++) { pts[q] = make_query_point(X[q], Y[q], Z[q], desc + (size_t)q * 32, level[q], 1, bad[q] != 0); qIndex[pts[q]] = q; }
+    ORBmatcher matcher(0.75f, true);
+    cv::Mat S = cv::Mat::eye(4, 4, CV_32F);
+    const int n = matcher.SearchByProjection(kf, S, pts, matched, th);
+    for (int i = 0; i < F.N; i++) { std::map<MapPoint*, int>::iterator it = qIndex.find(matched[i]); feature_query[i] = it == qIndex.end() ? -1 : it->second; }
+    delete kf;
+    return n;
+}
+// ORBmatcher(nnratio, checkOri).SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist)  (ORBmatcher.cc:1472-1599): the
+// relocalisation matcher; current pose = identity.  Key frame feature i carries a point iff has_point[i]; found[i]: it is in sAlreadyFound.
+int orbslam_ref_search_by_projection_reloc(void* cur, void* kfp, const uint8_t* has_point, const float* X, const float* Y, const float* Z, const int* level,
+                                           const uint8_t* bad, const uint8_t* found, const uint8_t* desc, const uint8_t* cur_state, float th, int orb_dist,
+                                           float nnratio, int check_ori, int* feature_query)
+{
+    Frame &C = *(Frame*)cur, &Fk = *(Frame*)kfp;
+    preset(C, cur_state);
+    cv::Mat T = cv::Mat::eye(4, 4, CV_32F);
+    C.SetPose(T);
+    std::map<MapPoint*, int> index;
+    std::set<MapPoint*> already;
+    for (int i = 0; i < Fk.N; i++) {
+        Fk.mvpMapPoints[i] = NULL;
+        if (!has_point[i]) continue;
+        MapPoint* p = make_query_point(X[i], Y[i], Z[i], desc + (size_t)i * 32, level[i], 1, bad && bad[i]);
+        Fk.mvpMapPoints[i] = p; index[p] = i;
+        if (found && found[i]) already.insert(p);
+    }
+    KeyFrame* kf = identity_keyframe(Fk);
+    ORBmatcher matcher(nnratio, check_ori != 0);
+    const int n = matcher.SearchByProjection(C, kf, already, th, orb_dist);
+    for (int i = 0; i < C.N; i++) { std::map<MapPoint*, int>::iterator it = index.find(C.mvpMapPoints[i]); feature_query[i] = it == index.end() ? -1 : it->second; }
+    delete kf;
+    return n;
+}
+// ORBmatcher.SearchBySim3(pKF1, pKF2, vpMatches12, s12 = 1, R12 = I, t12 = 0, th)  (ORBmatcher.cc:1102-1326), both key frames at the
+// origin.  has_point / X,Y,Z / level per feature of each key frame; already12[i1] >= 0: vpMatches12[i1] is preset to the point of
+// feature already12[i1] of key frame 2.  match12[i1] = the feature of key frame 2 whose point ends up in vpMatches12[i1].
+int orbslam_ref_search_by_sim3(void* f1, const uint8_t* has1, const float* X1, const float* Y1, const float* Z1, const int* level1, const uint8_t* desc1,
+                               void* f2, const uint8_t* has2, const float* X2, const float* Y2, const float* Z2, const int* level2, const uint8_t* desc2,
+                               const int* already12, float th, int* match12)
+{
+    Frame &F1 = *(Frame*)f1, &F2 = *(Frame*)f2;
+    std::map<MapPoint*, int> idx2;
+    for (int i = 0; i < F1.N; i++) F1.mvpMapPoints[i] = has1[i] ? make_query_point(X1[i], Y1[i], Z1[i], desc1 + (size_t)i * 32, level1[i], 1, false) : NULL;
+    for (int i = 0; i < F2.N; i++) { F2.mvpMapPoints[i] = has2[i] ? make_query_point(X2[i], Y2[i], Z2[i], desc2 + (size_t)i * 32, level2[i], 1, false) : NULL; if (has2[i]) idx2[F2.mvpMapPoints[i]] = i; }
+    KeyFrame *kf1 = identity_keyframe(F1), *kf2 = identity_keyframe(F2);
+    std::vector<MapPoint*> m12(F1.N, static_cast<MapPoint*>(NULL));
+    for (int i = 0; i < F1.N; i++) if (already12 && already12[i] >= 0 && F2.mvpMapPoints[already12[i]]) {
+        m12[i] = F2.mvpMapPoints[already12[i]];
+        m12[i]->AddObservation(kf2, already12[i]);
+    }
+    ORBmatcher matcher(0.75f, true);
+    cv::Mat R = cv::Mat::eye(3, 3, CV_32F), t = cv::Mat(cv::Mat::zeros(3, 1, CV_32F));
+    const int n = matcher.SearchBySim3(kf1, kf2, m12, 1.0f, R, t, th);
+    for (int i = 0; i < F1.N; i++) { std::map<MapPoint*, int>::iterator it = idx2.find(m12[i]); match12[i] = it == idx2.end() ? -1 : it->second; }
     delete kf1; delete kf2;
     return n;
 }

@@ -664,6 +664,49 @@ extern "C" orbhip_status orbhip_search_by_projection(int device, const orbhip_ke
     return st;
 }
 
+extern "C" orbhip_status orbhip_search_best_in_window(int device, const orbhip_keypoint* kps, const uint8_t* desc, const float* u_right, int n, int im_w, int im_h,
+                                                      const float* inv_level_sigma2, int nlevels, const orbhip_best_query* queries, const uint8_t* query_desc, int nq,
+                                                      int chi2_gate, int32_t* best_idx, int32_t* best_dist)
+{
+    if (n < 0 || nq < 0 || (nq > 0 && (!queries || !query_desc || !best_idx || !best_dist)) || (n > 0 && (!kps || !desc)) || im_w < 1 || im_h < 1 ||
+        (chi2_gate && (!inv_level_sigma2 || nlevels < 1))) return fail(ORBHIP_ERR_INVALID, "bad argument");
+    for (int i = 0; i < nq; i++) { best_idx[i] = -1; best_dist[i] = 256; }
+    if (n == 0 || nq == 0) return ORBHIP_OK;
+    int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(ORBHIP_ERR_HIP, "no HIP device available: no CPU fallback");
+    HIPCHK(hipSetDevice(device));
+    orbhip_keypoint* dk = nullptr; uint8_t *dd = nullptr, *dqd = nullptr; float *dur = nullptr, *dsg = nullptr; int *dn = nullptr, *dgs = nullptr, *dgi = nullptr, *dbi = nullptr, *dbd = nullptr;
+    float2* dgxy = nullptr; orbhip_best_query* dq = nullptr;
+    hipError_t e = hipSuccess;
+#define TRY(x) do { if (e == hipSuccess) e = (x); } while (0)
+    TRY(dalloc(&dk, n)); TRY(dalloc(&dd, (size_t)n * 32)); TRY(dalloc(&dqd, (size_t)nq * 32)); TRY(dalloc(&dq, nq)); TRY(dalloc(&dn, 8));
+    TRY(dalloc(&dgs, ORBHIP_GRID_CELLS + 1)); TRY(dalloc(&dgi, n)); TRY(dalloc(&dgxy, n)); TRY(dalloc(&dbi, nq)); TRY(dalloc(&dbd, nq));
+    if (u_right) { TRY(dalloc(&dur, n)); TRY(hipMemcpy(dur, u_right, (size_t)n * sizeof(float), hipMemcpyHostToDevice)); }
+    if (inv_level_sigma2 && nlevels > 0) { TRY(dalloc(&dsg, nlevels)); TRY(hipMemcpy(dsg, inv_level_sigma2, (size_t)nlevels * sizeof(float), hipMemcpyHostToDevice)); }
+    const int hn[2] = {n, 0};
+    TRY(hipMemcpy(dk, kps, (size_t)n * sizeof(orbhip_keypoint), hipMemcpyHostToDevice)); TRY(hipMemcpy(dd, desc, (size_t)n * 32, hipMemcpyHostToDevice));
+    TRY(hipMemcpy(dq, queries, (size_t)nq * sizeof(orbhip_best_query), hipMemcpyHostToDevice)); TRY(hipMemcpy(dqd, query_desc, (size_t)nq * 32, hipMemcpyHostToDevice));
+    TRY(hipMemcpy(dn, hn, sizeof hn, hipMemcpyHostToDevice));
+    if (e == hipSuccess) {
+        MatchParams M; memset(&M, 0, sizeof M);
+        M.kp2 = dk; M.n2 = dn; M.cap = n; M.im_w = im_w; M.im_h = im_h; M.grid_start = dgs; M.grid_items = dgi; M.grid_xy = dgxy; M.grid_all_levels = 1;
+        orbhip_launch_match_grid(M, 1, nullptr);
+        BestParams B; memset(&B, 0, sizeof B);
+        B.kp = dk; B.desc = dd; B.u_right = dur; B.inv_level_sigma2 = dsg; B.grid_start = dgs; B.grid_items = dgi; B.grid_xy = dgxy;
+        B.q = dq; B.qdesc = dqd; B.nq = nq; B.chi2_gate = chi2_gate; B.best_idx = dbi; B.best_dist = dbd;
+        orbhip_launch_best_in_window(B, nullptr);
+        e = hipGetLastError();
+    }
+    TRY(hipDeviceSynchronize());
+    TRY(hipMemcpy(best_idx, dbi, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost));
+    TRY(hipMemcpy(best_dist, dbd, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost));
+#undef TRY
+    orbhip_status st = ORBHIP_OK;
+    if (e != hipSuccess) st = fail(ORBHIP_ERR_HIP, "search_best_in_window: %s", hipGetErrorString(e));
+    void* ptrs[] = {dk, dd, dqd, dq, dn, dgs, dgi, dgxy, dbi, dbd, dur, dsg};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    return st;
+}
+
 // ---------------------------------------------------------------------------------------------- stereo
 static StereoSide stereo_side(orbhip_ctx* c)
 {

@@ -112,6 +112,13 @@ struct ProjParams {         // projection-guided search core (ORBmatcher.cc:45-1
     int mode; float nnratio; int th_high, check_ori;
 };
 void orbhip_launch_proj(const ProjParams& J, hipStream_t s);
+struct BestParams {
+    const orbhip_keypoint* kp; const uint8_t* desc; const float* u_right; const float* inv_level_sigma2;
+    const int* grid_start; const int* grid_items; const float2* grid_xy;        // ordered bucket table over ALL key points (k_match_grid, grid_all_levels)
+    const orbhip_best_query* q; const uint8_t* qdesc; int nq; int chi2_gate;
+    int* best_idx; int* best_dist;
+};
+void orbhip_launch_best_in_window(const BestParams& B, hipStream_t s);
 size_t orbhip_proj_select_lds(int n);
 
 // kernel launchers (orbhip_kernels_extract.hip / orbhip_kernels_match.hip)

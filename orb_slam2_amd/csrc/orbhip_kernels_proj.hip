@@ -198,3 +198,67 @@ void orbhip_launch_proj(const ProjParams& J, hipStream_t s)
     if (J.nq > 0) hipLaunchKernelGGL(k_proj_candidates, dim3((J.nq + 3) / 4, 1, 1), dim3(256, 1, 1), 0, s, J, gwInv, ghInv);
     hipLaunchKernelGGL(k_proj_select, dim3(1, 1, 1), dim3(PJ_T, 1, 1), orbhip_proj_select_lds(J.n), s, J);
 }
+
+
+// ------------------------------------------------------------------------------------------------ best candidate in a window
+// The candidate loop of ORBmatcher::Fuse (both overloads, ORBmatcher.cc:884-948 / 1038-1079) and of the two passes of
+// ORBmatcher::SearchBySim3 (:1188-1224 / 1268-1304): KeyFrame::GetFeaturesInArea(x, y, radius) (KeyFrame.cc:569-608), key points
+// of level L-1 .. L, Fuse's reprojection chi-square gate (stereo 7.8, mono 5.99; f32 product compared in f64 like the reference's
+// literals), FIRST smallest descriptor distance.  Queries do not interact: one wavefront per query scans the ordered bucket table
+// (cell ix*ROWS+iy, then index == GetFeaturesInArea's order; a key point within the radius always lies in a visited cell, see
+// k_match_candidates), lane-parallel, first-minimum by (distance, table position).
+__global__ __launch_bounds__(256) void k_best_in_window(BestParams B)
+{
+    const int lane = threadIdx.x & 63, iq = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (iq >= B.nq) return;
+    const orbhip_best_query q = B.q[iq];
+    const uint4* q4 = reinterpret_cast<const uint4*>(B.qdesc + (long long)iq * 32);
+    const uint4 qa = q4[0], qb = q4[1];
+    const int nitems = B.grid_start[ORBHIP_GRID_CELLS];
+    int best = 256, bidx = -1;
+    for (int tb = 0; tb < nitems; tb += 64) {
+        const int t = tb + lane;
+        int idx = 0, dist = 256; bool ok = false;
+        if (t < nitems) {
+            const float2 k = B.grid_xy[t];
+            ok = fabsf(__fsub_rn(k.x, q.x)) < q.radius && fabsf(__fsub_rn(k.y, q.y)) < q.radius;      // KeyFrame.cc:598-602
+            if (ok) {
+                idx = B.grid_items[t];
+                const int lvl = B.kp[idx].octave;
+                ok = !(lvl < q.level - 1 || lvl > q.level);                                            // :896-899
+                if (ok && B.chi2_gate) {
+                    const float ex = __fsub_rn(q.x, k.x), ey = __fsub_rn(q.y, k.y);
+                    const float ur = B.u_right ? B.u_right[idx] : -1.0f;
+                    if (ur >= 0) {                                                                       // :901-914
+                        const float er = __fsub_rn(q.ur, ur);
+                        const float e2 = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(er, er));
+                        ok = !((double)__fmul_rn(e2, B.inv_level_sigma2[lvl]) > 7.8);
+                    } else {                                                                             // :915-926
+                        const float e2 = __fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey));
+                        ok = !((double)__fmul_rn(e2, B.inv_level_sigma2[lvl]) > 5.99);
+                    }
+                }
+                if (ok) {
+                    const uint4* d4 = reinterpret_cast<const uint4*>(B.desc + (long long)idx * 32);
+                    const uint4 da = d4[0], db = d4[1];
+                    dist = __popc(qa.x ^ da.x) + __popc(qa.y ^ da.y) + __popc(qa.z ^ da.z) + __popc(qa.w ^ da.w) +
+                           __popc(qb.x ^ db.x) + __popc(qb.y ^ db.y) + __popc(qb.z ^ db.z) + __popc(qb.w ^ db.w);
+                }
+            }
+        }
+        const unsigned long long V = __ballot(ok && dist < 256);
+        if (V == 0) continue;
+        unsigned long long mk = V;
+#pragma unroll
+        for (int b = 8; b >= 0; b--) { const unsigned long long z = __ballot(((dist >> b) & 1) == 0) & mk; if (z) mk = z; }
+        const int first = __ffsll((long long)mk) - 1;
+        const int wmin = __builtin_amdgcn_readlane(dist, first), ci = __builtin_amdgcn_readlane(idx, first);
+        if (wmin < best) { best = wmin; bidx = ci; }                                                    // strict: earlier table position wins ties
+    }
+    if (lane == 0) { B.best_idx[iq] = bidx; B.best_dist[iq] = best; }
+}
+
+void orbhip_launch_best_in_window(const BestParams& B, hipStream_t s)
+{
+    if (B.nq > 0) hipLaunchKernelGGL(k_best_in_window, dim3((B.nq + 3) / 4, 1, 1), dim3(256, 1, 1), 0, s, B);
+}

@@ -28,7 +28,7 @@ SYMBOLS = [
     "orbhip_algorithmic_bytes_per_frame_kernel", "orbhip_debug_blurred_level", "orbhip_debug_candidates",
     "orbhip_compute_stereo_matches", "orbhip_search_by_projection", "orbhip_extract_batch_color",
     "orbhip_extract_device_color", "orbhip_voc_load_text", "orbhip_voc_destroy", "orbhip_voc_info", "orbhip_voc_transform_features",
-    "orbhip_voc_transform", "orbhip_compute_bow", "orbhip_fetch_bow", "orbhip_voc_score", "orbhip_search_by_bow", "orbhip_search_for_triangulation",
+    "orbhip_voc_transform", "orbhip_compute_bow", "orbhip_fetch_bow", "orbhip_voc_score", "orbhip_search_by_bow", "orbhip_search_for_triangulation", "orbhip_search_best_in_window",
 ]
 
 
@@ -86,6 +86,7 @@ def lib(path=None):
     L.orbhip_search_by_bow.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp, ip]
     L.orbhip_search_for_triangulation.argtypes = [C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int,
                                                   vp, C.c_float, C.c_float, vp, vp, C.c_int, C.c_int, C.c_int, vp, ip]
+    L.orbhip_search_best_in_window.argtypes = [C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp]
     L.orbhip_sync.argtypes = [vp]
     L.orbhip_fetch.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp]
     L.orbhip_fetch_matches.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
@@ -488,3 +489,19 @@ def search_for_triangulation(desc1, kps1, has_mp1, stereo1, fv1, desc2, kps2, ha
                                              _p(F), float(ex), float(ey), _p(sc), _p(sg), len(sc), int(only_stereo), int(check_ori), _p(m12), C.byref(nm)),
            "orbhip_search_for_triangulation", L)
     return nm.value, m12
+
+
+BEST_QUERY_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("radius", "<f4"), ("ur", "<f4"), ("level", "<i4")])
+
+
+def search_best_in_window(kps, desc, im_w, im_h, inv_level_sigma2, queries, qdesc, chi2_gate, u_right=None, device=0, library=None):
+    """Candidate loop of ORBmatcher::Fuse / SearchBySim3 on flat data (include/orbhip.h) -> (best_idx[nq], best_dist[nq])"""
+    L = lib(library)
+    kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
+    queries = np.ascontiguousarray(queries, BEST_QUERY_DTYPE); qdesc = np.ascontiguousarray(qdesc, np.uint8)
+    inv = np.ascontiguousarray(inv_level_sigma2, np.float32)
+    ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    bi = np.full(len(queries), -1, np.int32); bd = np.full(len(queries), 256, np.int32)
+    _check(L.orbhip_search_best_in_window(device, _p(kps), _p(desc), None if ur is None else _p(ur), len(kps), im_w, im_h, _p(inv), len(inv),
+                                          _p(queries), _p(qdesc), len(queries), int(chi2_gate), _p(bi), _p(bd)), "orbhip_search_best_in_window", L)
+    return bi, bd

@@ -85,3 +85,26 @@ def test_search_by_projection_edge_cases(backend, oracle, scene):
     n_o, f_o = oracle.search_by_projection(kc, dc, w, h, big, bigd, 0, nnratio=0.8)
     n_g, f_g = orb_slam2_amd.search_by_projection(kc, dc, w, h, big, bigd, 0, nnratio=0.8, library=backend)
     assert n_g == n_o and np.array_equal(f_g, f_o)
+
+
+@pytest.mark.parametrize("chi2,stereo,th", [(True, False, 3.0), (True, True, 3.0), (False, False, 7.5), (False, True, 12.0)])
+def test_search_best_in_window(backend, oracle, scene, chi2, stereo, th):
+    """Candidate loop of ORBmatcher::Fuse (chi-square gate, stereo and mono branches) and of SearchBySim3's passes (no gate)."""
+    w, h, sf, (kl, dl), (kc, dc) = scene
+    inv = (1.0 / (sf * sf)).astype(np.float32)
+    rng = np.random.default_rng(int(th * 10) + chi2)
+    nq = len(kl)
+    q = np.zeros(nq, oracle.BEST_QUERY_DTYPE)
+    q["x"] = kl["x"] - 3.0 + rng.normal(0, 1.2, nq).astype(np.float32)
+    q["y"] = kl["y"] - 1.0 + rng.normal(0, 1.2, nq).astype(np.float32)
+    q["level"] = np.clip(kl["octave"] + rng.integers(0, 2, nq), 0, 7)
+    q["radius"] = (np.float32(th) * sf[q["level"]]).astype(np.float32)
+    q["ur"] = q["x"] - np.float32(9.0)
+    q["x"][:3] = -50.0; q["y"][3:5] = h + 80.0                                   # windows that miss the image: no candidate
+    u_right = np.where(rng.random(len(kc)) < 0.6, kc["x"] - rng.uniform(8, 10, len(kc)), -1).astype(np.float32) if stereo else None
+    bi_o, bd_o = oracle.search_best_in_window(kc, dc, w, h, inv, q, dl, chi2, u_right=u_right)
+    bi_g, bd_g = orb_slam2_amd.search_best_in_window(kc, dc, w, h, inv, q, dl, chi2, u_right=u_right, library=backend)
+    assert np.array_equal(bi_g, bi_o) and np.array_equal(bd_g, bd_o)
+    assert int((bd_o <= 50).sum()) > 100 and np.all(bi_o[:5] == -1)
+    e = orb_slam2_amd.search_best_in_window(kc, dc, w, h, inv, q[:0], dl[:0], chi2, library=backend)
+    assert len(e[0]) == 0

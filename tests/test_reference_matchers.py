@@ -209,6 +209,114 @@ def test_search_for_triangulation(ref, oracle, pair_oracle, fx, cx, cy, stereo, 
     F1.close(); F2.close()
 
 
+def _world(rng, kl, w, h):
+    nq = len(kl)
+    X = (kl["x"] - 3.0 + rng.normal(0, 1.2, nq)).astype(np.float32); Y = (kl["y"] - 1.0 + rng.normal(0, 1.2, nq)).astype(np.float32)
+    X[:4] = -2.0; X[4:7] = w + 1.0; Y[7:9] = h                                   # outside the image: skipped by IsInImage / the bounds test
+    level = np.clip(kl["octave"] + rng.integers(0, 2, nq), 0, 7).astype(np.int32)
+    return X, Y, level
+
+
+@pytest.mark.parametrize("th,stereo", [(3.0, False), (5.0, False), (3.0, True)])
+def test_fuse(ref, oracle, pair, th, stereo):
+    """ORBmatcher::Fuse(pKF, vpMapPoints, th) (ORBmatcher.cc:825-972) through a real KeyFrame at the origin: the feature each map
+    point is attached to / merged at equals the oracle's best-in-window search (chi-square gate, mono and stereo branches)."""
+    w, h, n, seq, sf, K, F = pair
+    (kl, dl), (kc, dc) = K
+    par = oracle.OracleExtractor(n, 1.2, 8, 20, 7).params()
+    rng = np.random.default_rng(int(th) + stereo)
+    X, Y, level = _world(rng, kl, w, h)
+    nq = len(kl)
+    bad = (rng.random(nq) < 0.05).astype(np.uint8); nobs = rng.integers(0, 4, nq).astype(np.int32)
+    kf, fx = F[1], np.float32(1.0)
+    if stereo:
+        fx = np.float32(64.0)
+        kf = ref.RefFrame(seq[1], np.roll(seq[1], -9, axis=1), nfeatures=n, fx=64.0, fy=64.0, cx=0.0, cy=0.0, bf=40.0)
+        assert int((kf.u_right >= 0).sum()) > 100
+    state = rng.choice([0, 0, 1], len(kc)).astype(np.uint8)                       # features that already carry a (good) map point
+    n_r, b_r = ref.fuse(kf, state, X / fx, Y / fx, np.ones(nq, np.float32), level, nobs, bad, dl, th=th)
+    keep = np.nonzero((bad == 0) & (X >= 0) & (X < w) & (Y >= 0) & (Y < h))[0]
+    q = np.zeros(len(keep), oracle.BEST_QUERY_DTYPE)
+    q["x"], q["y"], q["radius"], q["ur"], q["level"] = X[keep], Y[keep], (np.float32(th) * sf[level[keep]]).astype(np.float32), X[keep] - np.float32(40.0), level[keep]
+    bi, bd = oracle.search_best_in_window(kc, dc, w, h, par["inv_sigma2"], q, dl[keep], True, u_right=kf.u_right)
+    b_o = np.full(nq, -1, np.int32)
+    ok = bd <= 50
+    b_o[keep[ok]] = bi[ok]
+    assert n_r == int(ok.sum()) and np.array_equal(b_r, b_o) and n_r > 50
+    if stereo:
+        kf.close()
+
+
+def test_search_by_projection_keyframe_sim3(ref, oracle, pair):
+    """ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (ORBmatcher.cc:290-403, loop closing) = the flat mode-1 search
+    with levels [L-1, L], TH_LOW, no orientation check, vpMatched as the blocked set."""
+    w, h, n, seq, sf, K, F = pair
+    (kl, dl), (kc, dc) = K
+    rng = np.random.default_rng(4)
+    X, Y, level = _world(rng, kl, w, h)
+    nq = len(kl)
+    bad = (rng.random(nq) < 0.05).astype(np.uint8)
+    ms = (rng.random(len(kc)) < 0.2).astype(np.uint8)
+    n_r, fq_r = ref.search_by_projection_kf(F[1], ms, X, Y, np.ones(nq, np.float32), level, bad, dl, th=10)
+    keep = np.nonzero((bad == 0) & (X >= 0) & (X < w) & (Y >= 0) & (Y < h))[0]
+    q = np.zeros(len(keep), oracle.PROJ_QUERY_DTYPE)
+    q["x"], q["y"], q["radius"] = X[keep], Y[keep], (np.float32(10) * sf[level[keep]]).astype(np.float32)
+    q["min_level"], q["max_level"], q["blocks"] = level[keep] - 1, level[keep], 1
+    n_o, fq_o = oracle.search_by_projection(kc, dc, w, h, q, dl[keep], 1, nnratio=0.75, th_high=50, check_ori=False, blocked=ms)
+    assert n_r == n_o and np.array_equal(fq_r, np.where(fq_o >= 0, keep[np.maximum(fq_o, 0)], -1)) and n_o > 100
+
+
+@pytest.mark.parametrize("th,orb_dist,ori", [(10.0, 100, True), (3.0, 64, True), (10.0, 100, False)])
+def test_search_by_projection_relocalisation(ref, oracle, pair, th, orb_dist, ori):
+    """ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1472-1599) = the flat mode-1
+    search with levels [L-1, L+1], th_high = ORBdist, every feature that already has a map point blocked."""
+    w, h, n, seq, sf, K, F = pair
+    (kl, dl), (kc, dc) = K
+    rng = np.random.default_rng(int(th) + orb_dist)
+    X, Y, level = _world(rng, kl, w, h)
+    nq = len(kl)
+    bad = (rng.random(nq) < 0.05).astype(np.uint8)
+    has = (rng.random(nq) < 0.8).astype(np.uint8); found = (rng.random(nq) < 0.1).astype(np.uint8)
+    cs = _cur_state(rng, len(kc))
+    n_r, fq_r = ref.search_by_projection_reloc(F[1], F[0], has, X, Y, np.ones(nq, np.float32), level, bad, found, dl, cs, th=th, orb_dist=orb_dist, nnratio=0.9, check_ori=ori)
+    keep = np.nonzero((has == 1) & (bad == 0) & (found == 0) & ~((X < 0) | (X > w) | (Y < 0) | (Y > h)))[0]
+    q = np.zeros(len(keep), oracle.PROJ_QUERY_DTYPE)
+    q["x"], q["y"], q["radius"] = X[keep], Y[keep], (np.float32(th) * sf[level[keep]]).astype(np.float32)
+    q["min_level"], q["max_level"], q["blocks"], q["angle"] = level[keep] - 1, level[keep] + 1, 1, kl["angle"][keep]
+    n_o, fq_o = oracle.search_by_projection(kc, dc, w, h, q, dl[keep], 1, nnratio=0.9, th_high=orb_dist, check_ori=ori, blocked=(cs != 0).astype(np.uint8))
+    assert n_r == n_o and np.array_equal(fq_r, np.where(fq_o >= 0, keep[np.maximum(fq_o, 0)], -1)) and n_o > 100
+
+
+def test_search_by_sim3(ref, oracle, pair):
+    """ORBmatcher::SearchBySim3 (ORBmatcher.cc:1102-1326) with the identity similarity: two best-in-window passes + the mutual check."""
+    w, h, n, seq, sf, K, F = pair
+    (kl, dl), (kc, dc) = K
+    par = oracle.OracleExtractor(n, 1.2, 8, 20, 7).params()
+    rng = np.random.default_rng(6)
+    X1, Y1, lev1 = _world(rng, kl, w, h)
+    X2 = (kc["x"] + 3.0 + rng.normal(0, 1.2, len(kc))).astype(np.float32); Y2 = (kc["y"] + 1.0 + rng.normal(0, 1.2, len(kc))).astype(np.float32)
+    lev2 = np.clip(kc["octave"] + rng.integers(0, 2, len(kc)), 0, 7).astype(np.int32)
+    has1 = (rng.random(len(kl)) < 0.8).astype(np.uint8); has2 = (rng.random(len(kc)) < 0.8).astype(np.uint8)
+    n_r, m_r = ref.search_by_sim3(F[0], has1, X1, Y1, np.ones(len(kl), np.float32), lev1, dl, F[1], has2, X2, Y2, np.ones(len(kc), np.float32), lev2, dc, th=7.5)
+
+    def one_pass(hasA, XA, YA, levA, dA, kB, dB):
+        keep = np.nonzero((hasA == 1) & (XA >= 0) & (XA < w) & (YA >= 0) & (YA < h))[0]
+        q = np.zeros(len(keep), oracle.BEST_QUERY_DTYPE)
+        q["x"], q["y"], q["radius"], q["level"] = XA[keep], YA[keep], (np.float32(7.5) * sf[levA[keep]]).astype(np.float32), levA[keep]
+        bi, bd = oracle.search_best_in_window(kB, dB, w, h, par["inv_sigma2"], q, dA[keep], False)
+        out = np.full(len(hasA), -1, np.int32)
+        ok = (bd <= 100) & (bi >= 0)
+        out[keep[ok]] = bi[ok]
+        return out
+
+    v1, v2 = one_pass(has1, X1, Y1, lev1, dl, kc, dc), one_pass(has2, X2, Y2, lev2, dc, kl, dl)
+    m_o = np.full(len(kl), -1, np.int32)
+    for i1 in range(len(kl)):
+        if v1[i1] >= 0 and v2[v1[i1]] == i1:
+            m_o[i1] = v1[i1]
+    assert n_r == int((m_o >= 0).sum()) and np.array_equal(m_r, m_o) and n_r > 100
+
+
 def test_product_equals_reference_matcher_and_stereo(ref, pair, emu_lib):
     """HIP kernel sources (emulation build) against the reference's code directly: frame-to-frame matching and stereo matching."""
     w, h, n, seq, sf, K, F = pair
