@@ -28,6 +28,7 @@ __device__ __forceinline__ bool xcd_frame_map(int nb, int nframes, int& tile, in
 }
 static inline unsigned xcd_grid(int nb, int nframes) { return (unsigned)nb * 8u * (unsigned)((nframes + 7) / 8); }
 
+typedef unsigned u32_unaligned __attribute__((aligned(1)));     // a 32-bit global load at any byte address
 // a pointer every lane of the wave agrees on, moved to SGPRs so that loads use the scalar-base + 32-bit lane offset form
 template <typename T> __device__ __forceinline__ T* uniform_ptr(T* p)
 {
@@ -448,35 +449,30 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
         int spitch; const uint8_t* src = level_src(P, frame, cd.level, spitch);
         src += (long long)cd.iniY * spitch + cd.iniX;
         const int nd = (pw + 3) >> 2;
-        if (((((unsigned long long)src - cd.iniX) | (unsigned long long)spitch) & 3ull) == 0) {
-            // aligned 32-bit loads, funnel-shifted so that patch column 0 lands on an LDS dword boundary.  Lane = (row, dword
-            // column) with 16 (or 32) lanes per row; FC_LD passes are put in flight before the first LDS write.
-            const int sa = cd.iniX & 3, sh = 8 * sa;
+        {
+            // 32-bit loads at the patch's own byte alignment (global loads need no alignment on this target), so patch column 0
+            // lands on an LDS dword boundary without any shifting.  Lane = (row, dword column) with 16 (or 32) lanes per row;
+            // FC_LD passes are put in flight before the first LDS write.  The last dword of a row may read up to 3 bytes past
+            // the patch: still inside the image row (cells end >= 16 px before the right border).
             const int lw = nd <= 16 ? 4 : 5, rpp = 64 >> lw;             // log2 lanes per row, rows per pass
             const int d = lane & ((1 << lw) - 1), r0 = lane >> lw;
-            const unsigned* gp = reinterpret_cast<const unsigned*>(src - sa) + d;
+            const uint8_t* gp = uniform_ptr(src);
+            const unsigned off0 = (unsigned)(r0 * spitch + 4 * d);
             unsigned* lp = reinterpret_cast<unsigned*>(patch) + d;
-            const int gstep = spitch >> 2, lstep = PS >> 2;
+            const int lstep = PS >> 2;
             for (int rb = 0; rb < ph; rb += FC_LD * rpp) {
-                unsigned lo[FC_LD], hi[FC_LD];
+                unsigned v[FC_LD];
 #pragma unroll
                 for (int k = 0; k < FC_LD; k++) {
                     const int r = rb + k * rpp + r0;
-                    lo[k] = 0; hi[k] = 0;
-                    if (d < nd && r < ph) { lo[k] = gp[(long long)r * gstep]; if (sa) hi[k] = gp[(long long)r * gstep + 1]; }
+                    v[k] = 0;
+                    if (d < nd && r < ph) v[k] = *reinterpret_cast<const u32_unaligned*>(gp + off0 + (unsigned)((rb + k * rpp) * spitch));
                 }
 #pragma unroll
                 for (int k = 0; k < FC_LD; k++) {
                     const int r = rb + k * rpp + r0;
-                    if (d < nd && r < ph) lp[r * lstep] = (unsigned)((((unsigned long long)hi[k] << 32) | lo[k]) >> sh);
+                    if (d < nd && r < ph) lp[r * lstep] = v[k];
                 }
-            }
-        } else {
-            int r = 0, c = lane;
-            while (c >= pw) { c -= pw; r++; }
-            while (r < ph) {
-                patch[r * PS + c] = src[(long long)r * spitch + c];
-                c += 64; while (c >= pw) { c -= pw; r++; }
             }
         }
         // the whole score map starts at zero: the first pass below only fills the 4-pixel groups it examines
