@@ -97,6 +97,26 @@ static void prof_collect(orbhip_ctx* c)
 
 // ---------------------------------------------------------------------------------------------- creation
 template <typename T> static hipError_t dalloc(T** p, size_t count) { return hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T)); }
+// Per-thread, grow-only device scratch for the host-pointer matcher entry points: one hipMalloc the first time (or when a call
+// needs more), none afterwards — hipMalloc / hipFree cost more than the kernels of a single-frame call.
+static thread_local void* g_scratch = nullptr; static thread_local size_t g_scratch_bytes = 0; static thread_local int g_scratch_dev = -1;
+struct Arena {
+    uint8_t* base = nullptr; size_t off = 0;
+    template <typename T> void take(T** p, size_t count) { *p = reinterpret_cast<T*>(base + off); off += (std::max<size_t>(count, 1) * sizeof(T) + 255) & ~(size_t)255; }
+};
+template <typename Layout> static hipError_t arena_layout(int device, Layout layout)
+{
+    Arena dry; layout(dry);                                   // first pass: sizes only
+    if (g_scratch_dev != device || g_scratch_bytes < dry.off) {
+        if (g_scratch) (void)hipFree(g_scratch);
+        g_scratch = nullptr; g_scratch_bytes = 0;
+        const hipError_t e = hipMalloc(&g_scratch, dry.off + dry.off / 4);
+        if (e != hipSuccess) return e;
+        g_scratch_bytes = dry.off + dry.off / 4; g_scratch_dev = device;
+    }
+    Arena real; real.base = static_cast<uint8_t*>(g_scratch); layout(real);
+    return hipSuccess;
+}
 template <typename T> static hipError_t upload(T** p, const std::vector<T>& v)
 {
     hipError_t e = dalloc(p, v.size()); if (e != hipSuccess) return e;
@@ -632,11 +652,15 @@ extern "C" orbhip_status orbhip_search_by_projection(int device, const orbhip_ke
     float2* dgxy = nullptr; orbhip_proj_query* dq = nullptr; unsigned* dcand = nullptr;
     hipError_t e = hipSuccess;
 #define TRY(x) do { if (e == hipSuccess) e = (x); } while (0)
-    TRY(dalloc(&dk, n)); TRY(dalloc(&dd, (size_t)n * 32)); TRY(dalloc(&dqd, (size_t)nq * 32)); TRY(dalloc(&dq, nq)); TRY(dalloc(&dn, 8));
-    TRY(dalloc(&dgs, ORBHIP_GRID_CELLS + 1)); TRY(dalloc(&dgi, n)); TRY(dalloc(&dgxy, n)); TRY(dalloc(&dnc, nq)); TRY(dalloc(&dfq, n)); TRY(dalloc(&dev, nq));
-    TRY(dalloc(&dcand, (size_t)nq * n));
-    if (u_right) { TRY(dalloc(&dur, n)); TRY(hipMemcpy(dur, u_right, (size_t)n * sizeof(float), hipMemcpyHostToDevice)); }
-    if (blocked) { TRY(dalloc(&dbl_in, n)); TRY(hipMemcpy(dbl_in, blocked, (size_t)n, hipMemcpyHostToDevice)); }
+    TRY(arena_layout(device, [&](Arena& A) {
+        A.take(&dk, n); A.take(&dd, (size_t)n * 32); A.take(&dqd, (size_t)nq * 32); A.take(&dq, nq); A.take(&dn, 8);
+        A.take(&dgs, ORBHIP_GRID_CELLS + 1); A.take(&dgi, n); A.take(&dgxy, n); A.take(&dnc, nq); A.take(&dfq, n); A.take(&dev, nq);
+        A.take(&dcand, (size_t)nq * n);
+        if (u_right) A.take(&dur, n);
+        if (blocked) A.take(&dbl_in, n);
+    }));
+    if (u_right) TRY(hipMemcpy(dur, u_right, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    if (blocked) TRY(hipMemcpy(dbl_in, blocked, (size_t)n, hipMemcpyHostToDevice));
     const int hn[2] = {n, 0};
     TRY(hipMemcpy(dk, kps, (size_t)n * sizeof(orbhip_keypoint), hipMemcpyHostToDevice)); TRY(hipMemcpy(dd, desc, (size_t)n * 32, hipMemcpyHostToDevice));
     TRY(hipMemcpy(dq, queries, (size_t)nq * sizeof(orbhip_proj_query), hipMemcpyHostToDevice)); TRY(hipMemcpy(dqd, query_desc, (size_t)nq * 32, hipMemcpyHostToDevice));
@@ -659,8 +683,6 @@ extern "C" orbhip_status orbhip_search_by_projection(int device, const orbhip_ke
 #undef TRY
     orbhip_status st = ORBHIP_OK;
     if (e != hipSuccess) st = fail(ORBHIP_ERR_HIP, "search_by_projection: %s", hipGetErrorString(e));
-    void* ptrs[] = {dk, dd, dqd, dq, dn, dgs, dgi, dgxy, dnc, dfq, dev, dcand, dur, dbl_in};
-    for (void* p : ptrs) if (p) (void)hipFree(p);
     return st;
 }
 
@@ -678,10 +700,14 @@ extern "C" orbhip_status orbhip_search_best_in_window(int device, const orbhip_k
     float2* dgxy = nullptr; orbhip_best_query* dq = nullptr;
     hipError_t e = hipSuccess;
 #define TRY(x) do { if (e == hipSuccess) e = (x); } while (0)
-    TRY(dalloc(&dk, n)); TRY(dalloc(&dd, (size_t)n * 32)); TRY(dalloc(&dqd, (size_t)nq * 32)); TRY(dalloc(&dq, nq)); TRY(dalloc(&dn, 8));
-    TRY(dalloc(&dgs, ORBHIP_GRID_CELLS + 1)); TRY(dalloc(&dgi, n)); TRY(dalloc(&dgxy, n)); TRY(dalloc(&dbi, nq)); TRY(dalloc(&dbd, nq));
-    if (u_right) { TRY(dalloc(&dur, n)); TRY(hipMemcpy(dur, u_right, (size_t)n * sizeof(float), hipMemcpyHostToDevice)); }
-    if (inv_level_sigma2 && nlevels > 0) { TRY(dalloc(&dsg, nlevels)); TRY(hipMemcpy(dsg, inv_level_sigma2, (size_t)nlevels * sizeof(float), hipMemcpyHostToDevice)); }
+    TRY(arena_layout(device, [&](Arena& A) {
+        A.take(&dk, n); A.take(&dd, (size_t)n * 32); A.take(&dqd, (size_t)nq * 32); A.take(&dq, nq); A.take(&dn, 8);
+        A.take(&dgs, ORBHIP_GRID_CELLS + 1); A.take(&dgi, n); A.take(&dgxy, n); A.take(&dbi, nq); A.take(&dbd, nq);
+        if (u_right) A.take(&dur, n);
+        if (inv_level_sigma2 && nlevels > 0) A.take(&dsg, nlevels);
+    }));
+    if (u_right) TRY(hipMemcpy(dur, u_right, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    if (inv_level_sigma2 && nlevels > 0) TRY(hipMemcpy(dsg, inv_level_sigma2, (size_t)nlevels * sizeof(float), hipMemcpyHostToDevice));
     const int hn[2] = {n, 0};
     TRY(hipMemcpy(dk, kps, (size_t)n * sizeof(orbhip_keypoint), hipMemcpyHostToDevice)); TRY(hipMemcpy(dd, desc, (size_t)n * 32, hipMemcpyHostToDevice));
     TRY(hipMemcpy(dq, queries, (size_t)nq * sizeof(orbhip_best_query), hipMemcpyHostToDevice)); TRY(hipMemcpy(dqd, query_desc, (size_t)nq * 32, hipMemcpyHostToDevice));
@@ -702,8 +728,6 @@ extern "C" orbhip_status orbhip_search_best_in_window(int device, const orbhip_k
 #undef TRY
     orbhip_status st = ORBHIP_OK;
     if (e != hipSuccess) st = fail(ORBHIP_ERR_HIP, "search_best_in_window: %s", hipGetErrorString(e));
-    void* ptrs[] = {dk, dd, dqd, dq, dn, dgs, dgi, dgxy, dbi, dbd, dur, dsg};
-    for (void* p : ptrs) if (p) (void)hipFree(p);
     return st;
 }
 
@@ -869,14 +893,16 @@ extern "C" orbhip_status orbhip_search_for_initialization(int device, const orbh
     std::vector<int> list1; for (int i = 0; i < n1; i++) if (kps1[i].octave <= 0) list1.push_back(i);
     int n2l0 = 0; for (int i = 0; i < n2; i++) n2l0 += kps2[i].octave == 0;
     const int cap = std::max(std::max(n1, n2), 1), l0cap = std::max((int)list1.size(), 1), cstride = std::max(n2l0, 1);
-    if ((size_t)(3 * cap + 5 * l0cap + 64 + 20480) * sizeof(int) > 158 * 1024) return fail(ORBHIP_ERR_UNSUPPORTED, "too many keypoints for the LDS matcher");
+    if ((size_t)(3 * cap + 4 * l0cap + 64) * sizeof(int) > 158 * 1024) return fail(ORBHIP_ERR_UNSUPPORTED, "too many keypoints for the LDS matcher");
     orbhip_keypoint *dk1 = nullptr, *dk2 = nullptr; uint8_t *dd1 = nullptr, *dd2 = nullptr; int *dn = nullptr, *dlist = nullptr, *dgs = nullptr, *dgi = nullptr, *dnc = nullptr, *dm12 = nullptr; float2* dgxy = nullptr;
     unsigned* dcand = nullptr; float* dprev = nullptr;
     hipError_t e = hipSuccess;
 #define TRY(x) do { if (e == hipSuccess) e = (x); } while (0)
-    TRY(dalloc(&dk1, cap)); TRY(dalloc(&dk2, cap)); TRY(dalloc(&dd1, (size_t)cap * 32)); TRY(dalloc(&dd2, (size_t)cap * 32)); TRY(dalloc(&dn, 8));
-    TRY(dalloc(&dlist, l0cap)); TRY(dalloc(&dgs, ORBHIP_GRID_CELLS + 1)); TRY(dalloc(&dgi, cap)); TRY(dalloc(&dgxy, cap)); TRY(dalloc(&dnc, l0cap)); TRY(dalloc(&dm12, cap));
-    TRY(dalloc(&dcand, (size_t)l0cap * cstride)); TRY(dalloc(&dprev, (size_t)cap * 2));
+    TRY(arena_layout(device, [&](Arena& A) {
+        A.take(&dk1, cap); A.take(&dk2, cap); A.take(&dd1, (size_t)cap * 32); A.take(&dd2, (size_t)cap * 32); A.take(&dn, 8);
+        A.take(&dlist, l0cap); A.take(&dgs, ORBHIP_GRID_CELLS + 1); A.take(&dgi, cap); A.take(&dgxy, cap); A.take(&dnc, l0cap); A.take(&dm12, cap);
+        A.take(&dcand, (size_t)l0cap * cstride); A.take(&dprev, (size_t)cap * 2);
+    }));
     const int hn[4] = {n1, n2, (int)list1.size(), 0};
     TRY(hipMemcpy(dk1, kps1, (size_t)n1 * sizeof(orbhip_keypoint), hipMemcpyHostToDevice)); TRY(hipMemcpy(dd1, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice));
     if (n2 > 0) { TRY(hipMemcpy(dk2, kps2, (size_t)n2 * sizeof(orbhip_keypoint), hipMemcpyHostToDevice)); TRY(hipMemcpy(dd2, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice)); }
@@ -898,7 +924,5 @@ extern "C" orbhip_status orbhip_search_for_initialization(int device, const orbh
 #undef TRY
     orbhip_status st = ORBHIP_OK;
     if (e != hipSuccess) st = fail(ORBHIP_ERR_HIP, "search_for_initialization: %s", hipGetErrorString(e));
-    void* ptrs[] = {dk1, dk2, dd1, dd2, dn, dlist, dgs, dgi, dgxy, dnc, dm12, dcand, dprev};
-    for (void* p : ptrs) if (p) (void)hipFree(p);
     return st;
 }

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Secondary measurement: wall-clock latency of the host-pointer matcher entry points (one call = upload, kernels, download) on
+KITTI-sized inputs: 2000 features per frame, ~1500 queries.  Prints one JSON line."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import orb_slam2_amd  # noqa: E402
+from orb_slam2_amd import synth  # noqa: E402
+
+
+def timed(fn, reps=30):
+    fn(); fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    return round((time.perf_counter() - t0) / reps * 1e3, 3)
+
+
+def main():
+    W, H, N = 1241, 376, 2000
+    seq = synth.sequence(W, H, 2, seed=5)
+    ex = orb_slam2_amd.ORBextractor(N, 1.2, 8, 20, 7, W, H, max_batch=2)
+    ks, ds = ex.extract_batch(seq)
+    sf = ex.GetScaleFactors()
+    (k1, d1), (k2, d2) = (ks[0], ds[0]), (ks[1], ds[1])
+    rng = np.random.default_rng(1)
+    keep = rng.random(len(k1)) < 0.75
+    q = np.zeros(int(keep.sum()), orb_slam2_amd.PROJ_QUERY_DTYPE)
+    q["x"], q["y"] = k1["x"][keep] - 3, k1["y"][keep] - 1
+    q["radius"] = (7.0 * sf[k1["octave"][keep]]).astype(np.float32)
+    q["min_level"], q["max_level"], q["blocks"], q["angle"] = k1["octave"][keep] - 1, k1["octave"][keep] + 1, 1, k1["angle"][keep]
+    bq = np.zeros(len(q), orb_slam2_amd.BEST_QUERY_DTYPE)
+    bq["x"], bq["y"], bq["radius"], bq["level"] = q["x"], q["y"], q["radius"], k1["octave"][keep]
+    inv = (1.0 / (sf * sf)).astype(np.float32)
+    m = orb_slam2_amd.ORBmatcher(0.9, True)
+    out = {
+        "features": [len(k1), len(k2)], "queries": len(q),
+        "search_for_initialization_ms": timed(lambda: m.SearchForInitialization(k1, d1, k2, d2, W, H, windowSize=100)),
+        "search_by_projection_last_frame_ms": timed(lambda: orb_slam2_amd.search_by_projection(k2, d2, W, H, q, d1[keep], 1, nnratio=0.9)),
+        "search_by_projection_local_map_ms": timed(lambda: orb_slam2_amd.search_by_projection(k2, d2, W, H, q, d1[keep], 0, nnratio=0.8)),
+        "search_best_in_window_ms": timed(lambda: orb_slam2_amd.search_best_in_window(k2, d2, W, H, inv, bq, d1[keep], True)),
+        "extract_single_frame_ms": timed(lambda: ex(seq[0])),
+    }
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
