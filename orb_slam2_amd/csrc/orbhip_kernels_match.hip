@@ -236,6 +236,18 @@ __device__ __forceinline__ unsigned long long wave_argmin_mask(int d, unsigned l
     return M;
 }
 
+// wave64 minimum with DPP row shifts / broadcasts (6 dependent 4-cycle VALU steps); result broadcast from lane 63
+__device__ __forceinline__ int wave_min_dpp(int v)
+{
+    v = min(v, __builtin_amdgcn_update_dpp(IMAX, v, 0x111, 0xf, 0xf, false));      // row_shr:1
+    v = min(v, __builtin_amdgcn_update_dpp(IMAX, v, 0x112, 0xf, 0xf, false));      // row_shr:2
+    v = min(v, __builtin_amdgcn_update_dpp(IMAX, v, 0x114, 0xf, 0xe, false));      // row_shr:4
+    v = min(v, __builtin_amdgcn_update_dpp(IMAX, v, 0x118, 0xf, 0xc, false));      // row_shr:8 -> lane 15 of each row = row minimum
+    v = min(v, __builtin_amdgcn_update_dpp(IMAX, v, 0x142, 0xa, 0xf, false));      // row_bcast:15 into rows 1 and 3
+    v = min(v, __builtin_amdgcn_update_dpp(IMAX, v, 0x143, 0xc, 0xf, false));      // row_bcast:31 into rows 2 and 3 -> lane 63 = wave minimum
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 #define MS_T 256
 #define MS_DEPTH 4                      // candidate lists are fetched this many keypoints ahead of the replay
 
@@ -299,14 +311,14 @@ __global__ __launch_bounds__(MS_T) void k_match_select(MatchParams M)
                         if (cb >= 128) { e = 0; if (t < nc) e = cand[t]; }              // lists longer than the prefetched 128 records
                         const int i2 = (int)(e & 0xFFFFFu), dist = (int)(e >> 20);
                         const bool valid = t < nc && !(s_md[i2] <= dist);                    // :444-445
-                        const unsigned long long V = __ballot(valid);
-                        if (V == 0) continue;
-                        const unsigned long long mk = wave_argmin_mask(dist, V);
-                        const int first = __ffsll((long long)mk) - 1;        // strict '<': the first candidate with the minimum wins (:447-452)
-                        const int wmin = __builtin_amdgcn_readlane(dist, first), ci = __builtin_amdgcn_readlane(i2, first);
-                        const unsigned long long V2 = V & ~(1ull << first);
-                        int wsec = IMAX;
-                        if (V2) { const unsigned long long mk2 = wave_argmin_mask(dist, V2); wsec = __builtin_amdgcn_readlane(dist, __ffsll((long long)mk2) - 1); }
+                        // smallest (distance, lane) key by a DPP min network: strict '<' means the first candidate with the minimum
+                        // wins (:447-452); the runner-up is the minimum with that lane masked out
+                        const int key = valid ? ((dist << 6) | lane) : IMAX;
+                        const int k1 = wave_min_dpp(key);
+                        if (k1 == IMAX) continue;
+                        const int first = k1 & 63, wmin = k1 >> 6, ci = __builtin_amdgcn_readlane(i2, first);
+                        const int k2 = wave_min_dpp(lane == first ? IMAX : key);
+                        const int wsec = k2 == IMAX ? IMAX : (k2 >> 6);
                         if (wmin < best) { second = min(best, wsec); best = wmin; bidx = ci; } else second = min(second, wmin);
                     }
                     if (best <= ORBHIP_TH_LOW && (float)best < __fmul_rn((float)second, M.nnratio)) {      // :459-461
