@@ -68,6 +68,17 @@ __global__ __launch_bounds__(256) void k_proj_candidates(ProjParams J, float gwI
     if (lane == 0) J.ncand[iq] = min(nc, J.cand_stride);
 }
 
+// wave64 minimum with DPP row shifts / broadcasts (6 dependent VALU steps), broadcast from lane 63
+__device__ __forceinline__ int pj_wave_min(int v)
+{
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x111, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x112, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x114, 0xf, 0xe, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x118, 0xf, 0xc, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x142, 0xa, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x143, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
 __device__ __forceinline__ unsigned long long pj_argmin_mask(int d, unsigned long long M)
 {
 #pragma unroll
@@ -129,13 +140,13 @@ __global__ __launch_bounds__(PJ_T) void k_proj_select(ProjParams J)
                     if (t < nc) e = staged ? s_cand[o + t] : cand[t];
                     const int i2 = (int)(e & 0x7FFFFu), dist = (int)((e >> 19) & 0x1FFu), lvl = (int)(e >> 28);
                     const bool valid = t < nc && dist < 256 && !s_blocked[i2];
-                    const unsigned long long V = __ballot(valid);
-                    if (V == 0) continue;
-                    const int f1 = __ffsll((long long)pj_argmin_mask(dist, V)) - 1;       // first candidate with the minimum
-                    const int wmin = __builtin_amdgcn_readlane(dist, f1), ci = __builtin_amdgcn_readlane(i2, f1), cl = __builtin_amdgcn_readlane(lvl, f1);
-                    const unsigned long long V2 = V & ~(1ull << f1);
-                    int wsec = 256, l2 = -1;
-                    if (V2) { const int f2 = __ffsll((long long)pj_argmin_mask(dist, V2)) - 1; wsec = __builtin_amdgcn_readlane(dist, f2); l2 = __builtin_amdgcn_readlane(lvl, f2); }
+                    // two smallest (distance, lane) keys by DPP min networks; the key carries the level so no extra readlane is needed
+                    const int key = valid ? ((dist << 10) | (lane << 4) | lvl) : 0x7fffffff;
+                    const int k1 = pj_wave_min(key);
+                    if (k1 == 0x7fffffff) continue;
+                    const int f1 = (k1 >> 4) & 63, wmin = k1 >> 10, cl = k1 & 15, ci = __builtin_amdgcn_readlane(i2, f1);      // first candidate with the minimum
+                    const int k2 = pj_wave_min(lane == f1 ? 0x7fffffff : key);
+                    const int wsec = k2 == 0x7fffffff ? 256 : (k2 >> 10), l2 = k2 == 0x7fffffff ? -1 : (k2 & 15);
                     // the two smallest (distance, list position) keys == the reference's sequential best / second-best update
                     if (wmin < best) {
                         if (best <= wsec) { second = best; slevel = blevel; } else { second = wsec; slevel = l2; }
