@@ -1,7 +1,9 @@
 """Generates the committed golden fixtures from the CPU oracle (run from the repo root: python tests/golden/make_golden.py).
 
-The reference itself cannot be run here (needs OpenCV), so these vectors pin the ORACLE against drift and give the
-GPU tests a fixture that does not need the oracle library; they are not outputs of the reference binary.
+The fixtures pin the oracle against drift and give the GPU tests vectors that need neither the oracle nor the reference.
+Where /root/reference is mounted the script also runs the reference's OWN src/ORBextractor.cc, src/Frame.cc and
+src/ORBmatcher.cc (oracle/_ref builds; OpenCV replaced by a type stand-in + the oracle's four image primitives) on the same
+inputs and refuses to write fixtures that differ from them.
 """
 import os
 import sys
@@ -23,4 +25,11 @@ np.savez_compressed(os.path.join(here, "extract_320x240_n300_seed21.npz"), image
 n, m12, prev = O.search_for_initialization(k1, d1, k2, d2, 320, 240, window=100, nnratio=0.9)
 np.savez_compressed(os.path.join(here, "match_320x240_n300_seed21.npz"), image2=seq[1], k1=k1, d1=d1, k2=k2, d2=d2,
                     nmatches=n, matches12=m12, prev=prev)
+from oracle import orbslam_ref as S  # noqa: E402
+if S.build():
+    F1, F2 = S.RefFrame(seq[0], nfeatures=300), S.RefFrame(seq[1], nfeatures=300)
+    assert F1.keys.tobytes() == k1.tobytes() and np.array_equal(F1.desc, d1) and F2.keys.tobytes() == k2.tobytes() and np.array_equal(F2.desc, d2)
+    n_r, m_r, p_r = S.search_for_initialization(F1, F2, window=100, nnratio=0.9)
+    assert n_r == n and np.array_equal(m_r, m12) and p_r.tobytes() == prev.tobytes()
+    print("golden: identical to the reference's own Frame / ORBextractor / ORBmatcher code")
 print("golden:", len(k1), len(k2), "keypoints,", n, "matches")
