@@ -96,6 +96,8 @@ def cpu_baseline(frames, budget_s=8.0):
     with ctx.Pool(1) as pool:                                   # the single-thread rate in a child too: the library choice is per process
         one_done, one_dt = pool.map(_cpu_worker, [(slots[0], min(budget_s, 6.0), kind)])[0]
         port_done, port_dt = pool.map(_cpu_worker, [(slots[0], 3.0, "port")])[0] if kind == "reference" else (one_done, one_dt)
+    with ctx.Pool(2) as pool:                                   # the reference's own stereo concurrency: two extractor threads (Frame.cc:78-81)
+        two = pool.map(_cpu_worker, [(slots[i % len(slots)], 4.0, kind) for i in range(2)])
     t0 = time.perf_counter()
     with ctx.Pool(ncores) as pool:
         res = pool.map(_cpu_worker, [(slots[i % len(slots)], budget_s, kind) for i in range(ncores)])
@@ -106,7 +108,8 @@ def cpu_baseline(frames, budget_s=8.0):
             "primitives are the oracle's restatements)") if kind == "reference" else "oracle -O3 -march=x86-64-v3 build"
     return {"value": round(rate, 1), "unit": "frames/s", "cores": ncores, "kind": kind,
             "sample": f"{total} frames 1241x376 (extract + SearchForInitialization vs previous frame) over {ncores} processes x {budget_s:.0f} s (wall {wall:.1f} s), {what}",
-            "single_thread_value": round(one_done / one_dt, 2), "oracle_port_single_thread_value": round(port_done / port_dt, 2)}
+            "single_thread_value": round(one_done / one_dt, 2), "two_thread_value": round(sum(r[0] / r[1] for r in two), 2),
+            "oracle_port_single_thread_value": round(port_done / port_dt, 2)}
 
 
 def main():
