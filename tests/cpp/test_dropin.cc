@@ -1,8 +1,10 @@
 // Drives the drop-in classes exactly like the reference's callers do (Tracking.cc:119-125 constructs the extractor,
 // Frame::Frame calls ExtractORB, Tracking.cc:599-600 calls SearchForInitialization) and dumps the results for pytest.
-// usage: test_dropin W H nfeatures in0.raw in1.raw out.bin [vocabulary.txt]
+// usage: test_dropin W H nfeatures in0.raw in1.raw out.bin [vocabulary.txt [threads]]
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <thread>
 #include <vector>
 #include "ORBextractor.h"
 #include "ORBmatcher.h"
@@ -77,6 +79,20 @@ int main(int argc, char** argv)
         }
         const double sc = voc.score(b1, b2); fwrite(&sc, 8, 1, f);
         const unsigned int nw = voc.size(); fwrite(&nw, 4, 1, f);
+    }
+    // the reference extracts the left and the right image on two std::threads (Frame.cc:78-81): two extractor objects, two device
+    // contexts, concurrent calls into the library.  (Real library only: the CPU emulation of HIP is single-threaded.)
+    if (argc > 8 && !strcmp(argv[8], "threads")) {
+        int ok = 1;
+        for (int rep = 0; rep < 20 && ok; rep++) {
+            std::vector<cv::KeyPoint> kL, kR; cv::Mat dL, dR;
+            std::thread tl([&]() { (*exL)(im[0], cv::Mat(), kL, dL); }), tr([&]() { (*exR)(im[1], cv::Mat(), kR, dR); });
+            tl.join(); tr.join();
+            ok = (int)kL.size() == F1.N && (int)kR.size() == F2.N && !memcmp(&kL[0], &F1.mvKeys[0], sizeof(cv::KeyPoint) * kL.size()) && !memcmp(&kR[0], &F2.mvKeys[0], sizeof(cv::KeyPoint) * kR.size());
+            for (int i = 0; i < F1.N && ok; i++) ok = !memcmp(dL.ptr(i), F1.mDescriptors.ptr(i), 32);
+            for (int i = 0; i < F2.N && ok; i++) ok = !memcmp(dR.ptr(i), F2.mDescriptors.ptr(i), 32);
+        }
+        fwrite(&ok, 4, 1, f);
     }
     fclose(f);
     delete ex; delete exL; delete exR;

@@ -15,14 +15,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CPP = os.path.join(ROOT, "tests", "cpp")
 
 
-def _run(exe, tmp_path, oracle):
+def _run(exe, tmp_path, oracle, threads=False):
     w, h, n = 400, 300, 500
     seq = synth.sequence(w, h, 2, seed=31)
     for k in range(2):
         seq[k].tofile(str(tmp_path / f"in{k}.raw"))
     out = tmp_path / "out.bin"
     voc_path = os.path.join(ROOT, "tests", "golden", "voc_k6_L3_ref.txt")
-    subprocess.check_call([exe, str(w), str(h), str(n), str(tmp_path / "in0.raw"), str(tmp_path / "in1.raw"), str(out), voc_path])
+    subprocess.check_call([exe, str(w), str(h), str(n), str(tmp_path / "in0.raw"), str(tmp_path / "in1.raw"), str(out), voc_path] + (["threads"] if threads else []))
     buf = out.read_bytes()
     off = 0
     frames = []
@@ -62,6 +62,8 @@ def _run(exe, tmp_path, oracle):
         bows.append((rec["id"].copy(), rec["val"].copy(), np.array(fnode, np.uint32), np.array(foff, np.int32), np.array(ffeat, np.uint32)))
     (score12,) = struct.unpack_from("<d", buf, off); off += 8
     (nwords,) = struct.unpack_from("<I", buf, off); off += 4
+    if threads:                                           # 20 rounds of concurrent left / right extraction reproduced the sequential results
+        assert struct.unpack_from("<i", buf, off)[0] == 1
 
     ora = oracle.OracleExtractor(n, 1.2, 8, 20, 7)
     ref = [ora.extract(im) for im in seq]
@@ -99,4 +101,4 @@ def test_dropin_classes_emulation(tmp_path, oracle, emu_lib):
 @pytest.mark.gpu
 def test_dropin_classes_gpu(tmp_path, oracle, gpu_lib):
     exe = _build("test_dropin_gpu")               # make: a no-op when the binary built by __graft_entry__.build() is current
-    _run(exe, tmp_path, oracle)
+    _run(exe, tmp_path, oracle, threads=True)
