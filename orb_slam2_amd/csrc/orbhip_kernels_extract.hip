@@ -488,13 +488,14 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
 
     // ---- 1. the first cv::FAST call of the reference (iniThFAST, ORBextractor.cc:809-810).  Only pixels with score >= iniThFAST
     //      matter for it, and NMS at iniThFAST sees every weaker pixel as 0, so:
-    //      a. cheap necessary test at iniThFAST on every 4-pixel group -> ordered list of the groups that may hold such a pixel
-    //      b. exact scores of those groups only (compacted: a lane per listed group)
-    //      c. NMS + row-major emission over the listed groups
+    //      a. cheap necessary test at iniThFAST on every pixel pair (a lane tests the two pairs of its 4-pixel group) -> ordered
+    //         list of the pairs that may hold such a pixel
+    //      b. exact scores of those pairs only (compacted: a lane per listed pair)
+    //      c. NMS + row-major emission over the listed pairs
     int nq = 0;
     for (int it = 0; it < iters; it++) {
         const int y = it * rp + sr;
-        bool pass = false;
+        bool pass_a = false, pass_b = false;
         if (lane_ok && y < ch) {
             unsigned w[7][3];
             fc_load_window(patch, PS, y, grp, w);
@@ -502,66 +503,73 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
             const pku16 rb[16] = FC_RING(2);
             const pki16 pa = fast_pretest_pair(ra, row_pair<3>(w[3][0], w[3][1], w[3][2]), P.iniTh);         // score >= t  <=>  best arc margin > t  =>  every opposite pair's margin > t
             const pki16 pb = fast_pretest_pair(rb, row_pair<5>(w[3][0], w[3][1], w[3][2]), P.iniTh);
-            pass = (pa[0] | pa[1] | pb[0] | pb[1]) != 0;
+            pass_a = (pa[0] | pa[1]) != 0; pass_b = (pb[0] | pb[1]) != 0;
         }
-        const unsigned long long m = __ballot(pass);
-        if (pass) list[nq + __popcll(m & below)] = (unsigned short)((y << 8) | grp);
-        nq += __popcll(m);
+        const unsigned long long ma = __ballot(pass_a), mb = __ballot(pass_b);
+        int pos = nq + __popcll(ma & below) + __popcll(mb & below);
+        if (pass_a) list[pos++] = (unsigned short)((y << 8) | (2 * grp));          // id = row << 8 | pair index in the row
+        if (pass_b) list[pos] = (unsigned short)((y << 8) | (2 * grp + 1));
+        nq += __popcll(ma) + __popcll(mb);
     }
     __builtin_amdgcn_wave_barrier();
     for (int qb = 0; qb < nq; qb += 64) {
         if (qb + lane < nq) {
-            const int id = list[qb + lane], y = id >> 8, g = id & 0xff, x0 = 4 * g;
+            const int id = list[qb + lane], y = id >> 8, pr = id & 0xff, x0 = 2 * pr;
+            // the pair's 7 x 8-byte window, shifted so that it starts at byte 0 of the first dword whichever half of the group it is
+            const unsigned* prow = reinterpret_cast<const unsigned*>(patch + y * PS) + (pr >> 1);
+            const unsigned sh = 2u * (unsigned)(pr & 1);
             unsigned w[7][3];
-            fc_load_window(patch, PS, y, g, w);
-            const pku16 ra[16] = FC_RING(0);
-            const pku16 rb[16] = FC_RING(2);
-            const pki16 sa = fast_score_pair(ra, row_pair<3>(w[3][0], w[3][1], w[3][2]));
-            const pki16 sb = fast_score_pair(rb, row_pair<5>(w[3][0], w[3][1], w[3][2]));
-            int sc[4] = {sa[0], sa[1], sb[0], sb[1]};
 #pragma unroll
-            for (int q = 0; q < 4; q++) if (sc[q] < P.iniTh || x0 + q >= cw) sc[q] = 0;
-            *reinterpret_cast<unsigned*>(score + (y + 1) * SS + 4 + x0) = (unsigned)sc[0] | ((unsigned)sc[1] << 8) | ((unsigned)sc[2] << 16) | ((unsigned)sc[3] << 24);
+            for (int r = 0; r < 7; r++) {
+                const unsigned d0 = prow[r * (PS >> 2)], d1 = prow[r * (PS >> 2) + 1], d2 = prow[r * (PS >> 2) + 2];
+                w[r][0] = __builtin_amdgcn_alignbyte(d1, d0, sh); w[r][1] = __builtin_amdgcn_alignbyte(d2, d1, sh); w[r][2] = 0;
+            }
+            const pku16 ra[16] = FC_RING(0);
+            const pki16 sa = fast_score_pair(ra, row_pair<3>(w[3][0], w[3][1], w[3][2]));
+            int s0 = sa[0], s1 = sa[1];
+            if (s0 < P.iniTh || x0 >= cw) s0 = 0;
+            if (s1 < P.iniTh || x0 + 1 >= cw) s1 = 0;
+            *reinterpret_cast<unsigned short*>(score + (y + 1) * SS + 4 + x0) = (unsigned short)(s0 | (s1 << 8));
         }
     }
     __builtin_amdgcn_wave_barrier();
     int count_ini = 0;
     for (int qb = 0; qb < nq; qb += 64) {
-        bool keep[4] = {false, false, false, false}; int scv[4] = {0, 0, 0, 0}; int y = 0, x0 = 0;
+        bool keep[2] = {false, false}; int scv[2] = {0, 0}; int y = 0, x0 = 0;
         if (qb + lane < nq) {
             const int id = list[qb + lane];
-            y = id >> 8; x0 = 4 * (id & 0xff);
-            const uint8_t* q0 = &score[(y + 1) * SS + 4 + x0];
-            // rows above / at / below, bytes x0-1 .. x0+4 (the pad dwords left and right of a row are zero)
-            const unsigned a0 = *reinterpret_cast<const unsigned*>(q0 - SS - 4), a1 = *reinterpret_cast<const unsigned*>(q0 - SS), a2 = *reinterpret_cast<const unsigned*>(q0 - SS + 4);
-            const unsigned b0 = *reinterpret_cast<const unsigned*>(q0 - 4), b1 = *reinterpret_cast<const unsigned*>(q0), b2 = *reinterpret_cast<const unsigned*>(q0 + 4);
-            const unsigned c0 = *reinterpret_cast<const unsigned*>(q0 + SS - 4), c1 = *reinterpret_cast<const unsigned*>(q0 + SS), c2 = *reinterpret_cast<const unsigned*>(q0 + SS + 4);
-            const unsigned long long ra6 = ((unsigned long long)(a0 >> 24)) | ((unsigned long long)a1 << 8) | ((unsigned long long)(a2 & 0xff) << 40);
-            const unsigned long long rb6 = ((unsigned long long)(b0 >> 24)) | ((unsigned long long)b1 << 8) | ((unsigned long long)(b2 & 0xff) << 40);
-            const unsigned long long rc6 = ((unsigned long long)(c0 >> 24)) | ((unsigned long long)c1 << 8) | ((unsigned long long)(c2 & 0xff) << 40);
+            y = id >> 8; x0 = 2 * (id & 0xff);
+            // rows above / at / below, bytes x0-1 .. x0+2 (the pad dwords left and right of a row are zero)
+            const uint8_t* q0 = &score[(y + 1) * SS + 4 + x0 - 1];
+            const unsigned* qa = reinterpret_cast<const unsigned*>(reinterpret_cast<uintptr_t>(q0) & ~(uintptr_t)3);
+            const unsigned shb = (unsigned)(reinterpret_cast<uintptr_t>(q0) & 3);
+            const int sdw = SS >> 2;
+            const unsigned ra4 = __builtin_amdgcn_alignbyte(qa[1 - sdw], qa[-sdw], shb);
+            const unsigned rb4 = __builtin_amdgcn_alignbyte(qa[1], qa[0], shb);
+            const unsigned rc4 = __builtin_amdgcn_alignbyte(qa[1 + sdw], qa[sdw], shb);
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int sc = (int)((rb6 >> (8 * (q + 1))) & 0xff);
+            for (int q = 0; q < 2; q++) {
+                const int sc = (int)((rb4 >> (8 * (q + 1))) & 0xff);
                 scv[q] = sc;
                 if (sc > 0) {
-                    const int l = (int)((rb6 >> (8 * q)) & 0xff), r = (int)((rb6 >> (8 * (q + 2))) & 0xff);
-                    const int u0 = (int)((ra6 >> (8 * q)) & 0xff), u1 = (int)((ra6 >> (8 * (q + 1))) & 0xff), u2 = (int)((ra6 >> (8 * (q + 2))) & 0xff);
-                    const int d0 = (int)((rc6 >> (8 * q)) & 0xff), d1 = (int)((rc6 >> (8 * (q + 1))) & 0xff), d2 = (int)((rc6 >> (8 * (q + 2))) & 0xff);
+                    const int l = (int)((rb4 >> (8 * q)) & 0xff), r = (int)((rb4 >> (8 * (q + 2))) & 0xff);
+                    const int u0 = (int)((ra4 >> (8 * q)) & 0xff), u1 = (int)((ra4 >> (8 * (q + 1))) & 0xff), u2 = (int)((ra4 >> (8 * (q + 2))) & 0xff);
+                    const int d0 = (int)((rc4 >> (8 * q)) & 0xff), d1 = (int)((rc4 >> (8 * (q + 1))) & 0xff), d2 = (int)((rc4 >> (8 * (q + 2))) & 0xff);
                     keep[q] = sc > l && sc > r && sc > u0 && sc > u1 && sc > u2 && sc > d0 && sc > d1 && sc > d2;
                 }
             }
         }
-        const unsigned long long m0 = __ballot(keep[0]), m1 = __ballot(keep[1]), m2 = __ballot(keep[2]), m3 = __ballot(keep[3]);
-        int rank = count_ini + __popcll(m0 & below) + __popcll(m1 & below) + __popcll(m2 & below) + __popcll(m3 & below);
+        const unsigned long long m0 = __ballot(keep[0]), m1 = __ballot(keep[1]);
+        int rank = count_ini + __popcll(m0 & below) + __popcll(m1 & below);
 #pragma unroll
-        for (int q = 0; q < 4; q++)
+        for (int q = 0; q < 2; q++)
             if (keep[q]) {
                 // FAST reports cell-local (x, y); the reference adds (j*wCell, i*hCell)  (ORBextractor.cc:822-823)
                 const unsigned px = (unsigned)(x0 + q + 3 + cd.shiftX), py = (unsigned)(y + 3 + cd.shiftY);
                 if (rank < cd.cand_cap) out[rank] = px | (py << 12) | ((unsigned)scv[q] << 24);
                 rank++;
             }
-        count_ini += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+        count_ini += __popcll(m0) + __popcll(m1);
     }
     if (count_ini > 0) {
         if (lane == 0) P.cell_count[(long long)frame * P.ncells_total + cell_id] = min(count_ini, cd.cand_cap);
