@@ -52,6 +52,18 @@ public:
     void ComputeStereoMatches(ORBextractor& right, float mbf, float mb, int N, std::vector<float>& mvuRight, std::vector<float>& mvDepth);
     // The device context of the last image (NULL before the first call): ORBVocabulary::ComputeBoW reads the descriptors there.
     orbhip_ctx* Context() { return mpCtx; }
+    // Distorted cameras (TUM1-3.yaml).  SetCamera takes Frame's mK / mDistCoef (CV_32F; 4 or 5 coefficients, Tracking.cc:60-82);
+    // UndistortKeyPoints then is the body of Frame::UndistortKeyPoints (Frame.cc:404-434) for the image this extractor processed
+    // last — mvKeysUn was computed on the device behind the descriptors — and ComputeImageBounds the body of
+    // Frame::ComputeImageBounds (Frame.cc:436-464).
+    void SetCamera(const cv::Mat& K, const cv::Mat& distCoef);
+    void UndistortKeyPoints(std::vector<cv::KeyPoint>& mvKeysUn);
+    void ComputeImageBounds(int cols, int rows, float& mnMinX, float& mnMaxX, float& mnMinY, float& mnMaxY);
+    // Raw (unrectified) stereo input: the cv::remap(im, imRect, M1, M2, cv::INTER_LINEAR) the EuRoC example runs before TrackStereo
+    // (Examples/Stereo/stereo_euroc.cc:136-137) moves onto the device.  M1 / M2: the CV_32FC1 maps of initUndistortRectifyMap
+    // (stereo_euroc.cc:97-98).  ExtractRectified(raw, ..) == operator()(remap(raw), ..); mvImagePyramid[0] is the rectified image.
+    void SetRectification(const cv::Mat& M1, const cv::Mat& M2, int rawCols, int rawRows);
+    void ExtractRectified(const cv::Mat& raw, std::vector<cv::KeyPoint>& keypoints, cv::OutputArray descriptors);
     // HIP device this extractor runs on (default 0); takes effect at the next (re)creation of the device context.
     void SetDevice(int device) { mnDevice = device; }
 
@@ -71,6 +83,9 @@ protected:
     std::vector<float> mvLevelSigma2;
     std::vector<float> mvInvLevelSigma2;
 
+    float mCamera[9]; bool mbHasCamera;                         // fx, fy, cx, cy, k1, k2, p1, p2, k3
+    std::vector<float> mvMapX, mvMapY; int mnRawCols, mnRawRows; // rectification maps (applied when the context is (re)created)
+    int mnLastN;                                                 // key points of the last image
     orbhip_ctx* mpCtx;          // device context for the current image size (created lazily, re-created on a size change)
     int mnCtxW, mnCtxH, mnDevice;
     bool mbDownloadPyramid;

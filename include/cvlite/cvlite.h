@@ -94,7 +94,7 @@ public:
         }
         m = o;
     }
-    Mat reshape(int, int = 0) const;    // only reached for distorted cameras (cv::undistortPoints): aborts, see ref_shim
+    Mat reshape(int, int = 0) const;    // only reached for distorted cameras (cv::undistortPoints); defined in oracle/ref_shim
 #endif
 private:
     std::shared_ptr<uchar> owner_;

@@ -252,6 +252,53 @@ orbhip_status orbhip_search_for_triangulation(int device,
 double orbhip_voc_score(const orbhip_voc* voc, const uint32_t* id1, const double* val1, int n1,
                         const uint32_t* id2, const double* val2, int n2);
 
+/* -------- distorted cameras and rectification -------------------------------------------
+   Monocular / RGB-D cameras with lens distortion (TUM1-3.yaml): Frame's constructors call UndistortKeyPoints (Frame.cc:404-434)
+   and, once, ComputeImageBounds (Frame.cc:436-464); the 64x48 grid and every windowed search then work on mvKeysUn inside the
+   undistorted bounds.  Both run cv::undistortPoints(pts, pts, mK, mDistCoef, cv::Mat(), mK): double arithmetic, five fixed-point
+   iterations (OpenCV 3.2 imgproc/undistort.cpp). */
+typedef struct { float fx, fy, cx, cy; float k1, k2, p1, p2, k3; } orbhip_camera;   /* mK (Tracking.cc:60-68), mDistCoef (:70-82; k3 = 0 if absent) */
+typedef struct { float min_x, min_y, max_x, max_y; } orbhip_bounds;                  /* Frame::mnMinX, mnMinY, mnMaxX, mnMaxY (Frame.h:187-190) */
+/* cv::undistortPoints(xy, xy_out, K, D, Mat(), K) for n points (x, y interleaved), host buffers, synchronous */
+orbhip_status orbhip_undistort_points(int device, const orbhip_camera* cam, const float* xy, int n, float* xy_out);
+/* Frame::ComputeImageBounds for an im_w x im_h image (k1 == 0: 0, 0, im_w, im_h without touching the device) */
+orbhip_status orbhip_image_bounds(int device, const orbhip_camera* cam, int im_w, int im_h, orbhip_bounds* out);
+/* Attach the camera to an extractor context (NULL or k1 == 0: undistorted, the default).  With a distorted camera every
+   extraction also leaves mvKeysUn in HBM (Frame::UndistortKeyPoints fused behind the descriptor kernel) and the match_prev
+   matcher of the device-resident pipeline works on mvKeysUn over the undistorted bounds, like SearchForInitialization on
+   distorted TUM frames.  orbhip_fetch_undistorted copies mvKeysUn of the last call ([nimg][cap], same counts as orbhip_fetch;
+   == the key points themselves for an undistorted camera, Frame.cc:406-410). */
+orbhip_status orbhip_set_camera(orbhip_ctx* ctx, const orbhip_camera* cam);
+orbhip_status orbhip_get_bounds(const orbhip_ctx* ctx, orbhip_bounds* out);
+orbhip_status orbhip_fetch_undistorted(orbhip_ctx* ctx, int nimg, orbhip_keypoint* kps_un, int cap);
+/* The windowed searches above with explicit image bounds (their im_w / im_h forms are these with bounds = 0, 0, im_w, im_h) */
+orbhip_status orbhip_search_for_initialization_bounds(int device,
+                                               const orbhip_keypoint* kps1, const uint8_t* desc1, int n1,
+                                               const orbhip_keypoint* kps2, const uint8_t* desc2, int n2,
+                                               const orbhip_bounds* bounds, float* prev_matched, int32_t* matches12,
+                                               int window, float nnratio, int check_ori, int* nmatches);
+orbhip_status orbhip_search_by_projection_bounds(int device, const orbhip_keypoint* kps, const uint8_t* desc, const float* u_right,
+                                          const uint8_t* blocked, int n, const orbhip_bounds* bounds,
+                                          const orbhip_proj_query* queries, const uint8_t* query_desc, int nq,
+                                          int mode, float nnratio, int th_high, int check_ori,
+                                          int32_t* feature_query, int* nmatches);
+orbhip_status orbhip_search_best_in_window_bounds(int device, const orbhip_keypoint* kps, const uint8_t* desc, const float* u_right /* may be NULL */,
+                                           int n, const orbhip_bounds* bounds, const float* inv_level_sigma2, int nlevels,
+                                           const orbhip_best_query* queries, const uint8_t* query_desc, int nq, int chi2_gate,
+                                           int32_t* best_idx, int32_t* best_dist);
+
+/* Stereo rectification on the input side: the EuRoC example runs cv::remap(raw, rect, M1, M2, cv::INTER_LINEAR) on the CPU for both
+   images of every pair before TrackStereo (Examples/Stereo/stereo_euroc.cc:136-137; maps from cv::initUndistortRectifyMap(..,
+   CV_32F, ..) :97-98).  orbhip_set_rectification uploads the two CV_32FC1 maps ([height][width] of the context, contiguous; they
+   address a src_w x src_h raw image) once; the *_rectify entry points then take RAW frames and remap on the device (OpenCV's
+   fixed-point bilinear: 5 fractional bits, constant 0 border) straight into the context's level-0 plane — the rectified image never
+   exists on the host.  map_x == NULL removes the maps. */
+orbhip_status orbhip_set_rectification(orbhip_ctx* ctx, const float* map_x, const float* map_y, int src_w, int src_h);
+orbhip_status orbhip_extract_batch_rectify(orbhip_ctx* ctx, int nimg, const uint8_t* const* raw_imgs, int stride_bytes,
+                                           orbhip_keypoint* kps, uint8_t* desc, int cap, int* n_out /* nimg */);
+orbhip_status orbhip_extract_device_rectify(orbhip_ctx* ctx, int nimg, const uint8_t* d_raw, size_t frame_stride, int row_stride,
+                                            int match_prev, int window, float nnratio, int check_ori);
+
 /* -------- measurement + stage dumps (parity tests) ----------------------------------------------------- */
 /* per-kernel HIP-event timing on the context's stream: enable, run, then read accumulated stats */
 orbhip_status orbhip_profile_enable(orbhip_ctx* ctx, int on);

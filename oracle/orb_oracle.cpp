@@ -25,7 +25,7 @@
 //     checks SearchForInitialization, the two per-frame SearchByProjection overloads, ComputeStereoMatches and
 //     GetFeaturesInArea of this file against the reference's own Frame / ORBmatcher objects.
 //   * PARITY UNPINNED at the OpenCV boundary only: cv::resize, cv::GaussianBlur, cv::FAST, cv::fastAtan2 (and cvtColor for
-//     the colour entry points) are restated from their published algorithms (target: OpenCV 3.2 generic C++ paths) because
+//     the colour entry points, cv::undistortPoints for distorted cameras, cv::remap for the EuRoC rectification) are restated from their published algorithms (target: OpenCV 3.2 generic C++ paths) because
 //     OpenCV is not vendored and cannot be built here; the reference ships no golden vectors for them, so
 //     they are pinned by hand-derivable known-answer tests only (tests/test_oracle_kat.py).
 //   * sincosf: glibc_sincosf() below is checked bit-for-bit against this box's libm (all 1.09e9 floats in [0, 2pi]).
@@ -615,6 +615,65 @@ int DescriptorDistance(const uint8_t* a, const uint8_t* b)
 const int FRAME_GRID_ROWS = 48, FRAME_GRID_COLS = 64;   // Frame.h:37-38
 const int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30; // ORBmatcher.cc:37-39
 
+// Image bounds of a distorted camera (Frame::ComputeImageBounds, Frame.cc:436-464): set by orb_oracle_set_image_bounds for the
+// FrameLite objects built afterwards; unset = the undistorted case (0, 0, cols, rows).
+bool g_bounds_set = false; float g_bounds[4] = {0, 0, 0, 0};
+
+// ---------------------------------------------------------------- cv::undistortPoints(src, dst, K, D, Mat(), K)
+// Called by Frame::UndistortKeyPoints (Frame.cc:404-434) and Frame::ComputeImageBounds (Frame.cc:436-464) when mDistCoef[0] != 0.
+// Restated from OpenCV 3.2 imgproc/undistort.cpp cvUndistortPoints (same arithmetic in 2.4): everything in double; K and D are the
+// CV_32F matrices Tracking builds (Tracking.cc:60-82) converted to double; 5 fixed-point iterations of the inverse distortion;
+// R = identity, P = K.  The terms of the 14-coefficient model that the reference never sets (k4..k6, s1..s4, tilt) are zero and
+// drop out exactly: 1 + ((0*r2 + 0)*r2 + 0)*r2 == 1, x + 0*r2 + 0*r2*r2 == x, the identity tilt matrix and RR[0][1] = 0 products
+// add exact zeros, ww = 1./1.  PARITY UNPINNED (OpenCV is not vendored); known-answer tests in tests/test_oracle_kat.py.
+void undistort_points(const float* K4 /* fx, fy, cx, cy */, const float* D5 /* k1, k2, p1, p2, k3 */, const float* in, int n, float* out)
+{
+    const double fx = K4[0], fy = K4[1], cx = K4[2], cy = K4[3], ifx = 1. / fx, ify = 1. / fy;
+    const double k0 = D5[0], k1 = D5[1], k2 = D5[2], k3 = D5[3], k4 = D5[4];
+    for (int i = 0; i < n; i++) {
+        double x = in[2 * i], y = in[2 * i + 1];
+        x = (x - cx) * ifx; y = (y - cy) * ify;
+        const double x0 = x, y0 = y;
+        for (int j = 0; j < 5; j++) {
+            const double r2 = x * x + y * y;
+            const double icdist = 1 / (1 + ((k4 * r2 + k1) * r2 + k0) * r2);
+            const double deltaX = 2 * k2 * x * y + k3 * (r2 + 2 * x * x);
+            const double deltaY = k2 * (r2 + 2 * y * y) + 2 * k3 * x * y;
+            x = (x0 - deltaX) * icdist;
+            y = (y0 - deltaY) * icdist;
+        }
+        out[2 * i] = (float)(fx * x + cx);
+        out[2 * i + 1] = (float)(fy * y + cy);
+    }
+}
+
+// ---------------------------------------------------------------- cv::remap(src, dst, map1 CV_32FC1, map2 CV_32FC1, INTER_LINEAR)
+// The EuRoC stereo example rectifies both images with it before TrackStereo (Examples/Stereo/stereo_euroc.cc:136-137, maps from
+// initUndistortRectifyMap(.., CV_32F, ..) :97-98); border mode BORDER_CONSTANT, value 0 (the defaults).
+// Restated from OpenCV 3.2 imgproc/imgwarp.cpp (RemapInvoker + remapBilinear<FixedPtCast<int,uchar,15>, .., short>):
+//   sx = cvRound(map1*32), sy = cvRound(map2*32); integer part sx>>5 (saturated to short), 5-bit fractions a = sx&31, b = sy&31;
+//   weights = BilinearTab_i[b*32+a] = shorts of (1-b/32)(1-a/32)*32768 ... — exact integers 32*(32-b)*(32-a) etc.  (The a = b = 0 entry does not fit a
+//   short: 32768 saturates to 32767 and the table's sum correction puts the missing 1 on another tap; for 8-bit taps
+//   (32767 p + q + 16384) >> 15 == p == (32768 p + 16384) >> 15, so the plain weight is used here.)
+//   dst = (sum of 4 taps * weights + 16384) >> 15; taps outside the source read the border value 0, a window entirely outside gives 0.
+// PARITY UNPINNED (OpenCV is not vendored); known-answer tests in tests/test_oracle_kat.py.
+void remap_linear_8u(const View& src, const float* mapx, const float* mapy, int map_stride, uint8_t* dst, int dw, int dh, int dstride)
+{
+    for (int y = 0; y < dh; y++)
+        for (int x = 0; x < dw; x++) {
+            const int sxq = cvRoundF(mapx[(size_t)y * map_stride + x] * 32), syq = cvRoundF(mapy[(size_t)y * map_stride + x] * 32);
+            const int sx = sat_short(sxq >> 5), sy = sat_short(syq >> 5), a = sxq & 31, b = syq & 31;
+            int out = 0;
+            if (!(sx >= src.w || sx + 1 < 0 || sy >= src.h || sy + 1 < 0)) {
+                auto tap = [&](int xx, int yy) -> int { return ((unsigned)xx < (unsigned)src.w && (unsigned)yy < (unsigned)src.h) ? src.row(yy)[xx] : 0; };
+                const int w0 = 32 * (32 - b) * (32 - a), w1 = 32 * (32 - b) * a, w2 = 32 * b * (32 - a), w3 = 32 * b * a;
+                const int acc = tap(sx, sy) * w0 + tap(sx + 1, sy) * w1 + tap(sx, sy + 1) * w2 + tap(sx + 1, sy + 1) * w3;
+                out = sat_u8((acc + (1 << 14)) >> 15);
+            }
+            dst[(size_t)y * dstride + x] = (uint8_t)out;
+        }
+}
+
 // The slice of ORB_SLAM2::Frame the matcher reads: undistorted keys (== keys when k1==0, Frame.cc:406-410),
 // descriptors, image bounds (Frame.cc:455-463) and the 64x48 grid (Frame.cc:230-245, 382-392).
 struct FrameLite {
@@ -625,6 +684,7 @@ struct FrameLite {
     {
         N = n; keys.assign(k, k + n); desc.assign(d, d + (size_t)n * 32);
         mnMinX = 0.0f; mnMaxX = imw; mnMinY = 0.0f; mnMaxY = imh;
+        if (g_bounds_set) { mnMinX = g_bounds[0]; mnMinY = g_bounds[1]; mnMaxX = g_bounds[2]; mnMaxY = g_bounds[3]; }   // distorted camera, Frame.cc:438-454
         gwInv = (float)FRAME_GRID_COLS / (float)(mnMaxX - mnMinX);
         ghInv = (float)FRAME_GRID_ROWS / (float)(mnMaxY - mnMinY);
         for (auto& col : grid) for (auto& c : col) c.clear();
@@ -1016,6 +1076,22 @@ int orb_oracle_distribute(const int* xys, int n, int minX, int maxX, int minY, i
     return (int)out.size();
 }
 int orb_oracle_hamming(const uint8_t* a, const uint8_t* b) { return DescriptorDistance(a, b); }
+// bounds = {mnMinX, mnMinY, mnMaxX, mnMaxY} for every FrameLite built afterwards; NULL = back to (0, 0, cols, rows)
+void orb_oracle_set_image_bounds(const float* bounds) { g_bounds_set = bounds != nullptr; if (bounds) memcpy(g_bounds, bounds, sizeof g_bounds); }
+void orb_oracle_undistort_points(const float* K4, const float* D5, const float* in, int n, float* out) { undistort_points(K4, D5, in, n, out); }
+// Frame::ComputeImageBounds (Frame.cc:436-464): out = {mnMinX, mnMinY, mnMaxX, mnMaxY}
+void orb_oracle_image_bounds(const float* K4, const float* D5, int cols, int rows, float* out)
+{
+    if (D5[0] != 0.0f) {
+        const float corners[8] = {0.0f, 0.0f, (float)cols, 0.0f, 0.0f, (float)rows, (float)cols, (float)rows};
+        float m[8]; undistort_points(K4, D5, corners, 4, m);
+        out[0] = std::min(m[0], m[4]); out[2] = std::max(m[2], m[6]); out[1] = std::min(m[1], m[3]); out[3] = std::max(m[5], m[7]);
+    } else { out[0] = 0.0f; out[2] = (float)cols; out[1] = 0.0f; out[3] = (float)rows; }
+}
+void orb_oracle_remap(const uint8_t* src, int sw, int sh, int sstride, const float* mapx, const float* mapy, int map_stride, uint8_t* dst, int dw, int dh, int dstride)
+{
+    remap_linear_8u(View{src, sw, sh, sstride}, mapx, mapy, map_stride, dst, dw, dh, dstride);
+}
 // q: nq x {x, y, radius, ur, (int)min_level, (int)max_level, (int)blocks, angle} as 8 x 4-byte words each
 int orb_oracle_search_by_projection(const void* kps, const uint8_t* desc, const float* u_right, const uint8_t* blocked, int n, int imw, int imh,
                                     const void* q, const uint8_t* qdesc, int nq, int mode, float nnratio, int th_high, int check_ori, int* feature_query)

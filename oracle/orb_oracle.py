@@ -67,6 +67,10 @@ def lib(fast=False):
     L.orb_oracle_search_by_bow.restype = C.c_int
     L.orb_oracle_cvt_gray.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
     L.orb_oracle_gauss_kernel.argtypes = [vp]
+    L.orb_oracle_set_image_bounds.argtypes = [vp]
+    L.orb_oracle_undistort_points.argtypes = [vp, vp, vp, C.c_int, vp]
+    L.orb_oracle_image_bounds.argtypes = [vp, vp, C.c_int, C.c_int, vp]
+    L.orb_oracle_remap.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]
     L.orb_oracle_fast.restype = C.c_int
     L.orb_oracle_fast.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
     L.orb_oracle_fastatan2.restype = C.c_float
@@ -214,6 +218,63 @@ def cvt_gray(src, rgb=True):
     h, w, ch = src.shape
     out = np.zeros((h, w), np.uint8)
     lib().orb_oracle_cvt_gray(_p(src), w, h, src.strides[0], ch, int(rgb), _p(out), w)
+    return out
+
+
+def _camera(camera):
+    """(fx, fy, cx, cy, k1, k2, p1, p2[, k3]) -> K4, D5 float arrays (mK / mDistCoef, Tracking.cc:60-82)"""
+    c = [float(v) for v in camera]
+    assert len(c) in (8, 9)
+    return np.array(c[:4], np.float32), np.array((c[4:] + [0.0])[:5], np.float32)
+
+
+def undistort_points(camera, xy):
+    """cv::undistortPoints(xy, xy, K, D, Mat(), K) for [n,2] float points (Frame.cc:421)"""
+    K4, D5 = _camera(camera)
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    out = np.zeros_like(xy)
+    lib().orb_oracle_undistort_points(_p(K4), _p(D5), _p(xy), len(xy), _p(out))
+    return out
+
+
+def image_bounds(camera, w, h):
+    """Frame::ComputeImageBounds (Frame.cc:436-464): (mnMinX, mnMinY, mnMaxX, mnMaxY)"""
+    K4, D5 = _camera(camera)
+    out = np.zeros(4, np.float32)
+    lib().orb_oracle_image_bounds(_p(K4), _p(D5), w, h, _p(out))
+    return out
+
+
+def undistort_keypoints(camera, kps):
+    """Frame::UndistortKeyPoints (Frame.cc:404-434): mvKeysUn from mvKeys"""
+    K4, D5 = _camera(camera)
+    un = np.array(kps, copy=True)
+    if D5[0] != 0.0 and len(un):
+        xy = undistort_points(camera, np.stack([kps["x"], kps["y"]], axis=1))
+        un["x"], un["y"] = xy[:, 0], xy[:, 1]
+    return un
+
+
+class image_bounds_set:
+    """with image_bounds_set(b): the frames the matcher entry points build inside use the bounds b of a distorted camera"""
+
+    def __init__(self, bounds):
+        self.b = None if bounds is None else np.ascontiguousarray(bounds, np.float32)
+
+    def __enter__(self):
+        lib().orb_oracle_set_image_bounds(_p(self.b))
+
+    def __exit__(self, *a):
+        lib().orb_oracle_set_image_bounds(None)
+
+
+def remap(src, map_x, map_y):
+    """cv::remap(src, dst, map_x, map_y, INTER_LINEAR) with CV_32FC1 maps, constant 0 border (stereo_euroc.cc:136-137)"""
+    src = np.ascontiguousarray(src, np.uint8)
+    mx = np.ascontiguousarray(map_x, np.float32); my = np.ascontiguousarray(map_y, np.float32)
+    assert mx.shape == my.shape
+    out = np.zeros(mx.shape, np.uint8)
+    lib().orb_oracle_remap(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(mx), _p(my), mx.shape[1], _p(out), mx.shape[1], mx.shape[0], mx.shape[1])
     return out
 
 

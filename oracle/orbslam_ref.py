@@ -41,6 +41,9 @@ def lib():
         vp, i, f = C.c_void_p, C.c_int, C.c_float
         L.orbslam_ref_frame_mono.restype = vp
         L.orbslam_ref_frame_mono.argtypes = [vp, i, i, i, i, f, i, i, i, f, f, f, f, f, f, i]
+        L.orbslam_ref_frame_mono_dist.restype = vp
+        L.orbslam_ref_frame_mono_dist.argtypes = [vp, i, i, i, i, f, i, i, i, f, f, f, f, vp, i, f, f, i]
+        L.orbslam_ref_frame_bounds.argtypes = [vp]
         L.orbslam_ref_frame_stereo.restype = vp
         L.orbslam_ref_frame_stereo.argtypes = [vp, vp, i, i, i, i, f, i, i, i, f, f, f, f, f, f, i]
         L.orbslam_ref_frame_delete.argtypes = [vp]
@@ -69,13 +72,18 @@ class RefFrame:
     """ORB_SLAM2::Frame built by the reference's own constructor."""
     _geometry = None
 
-    def __init__(self, img, right=None, nfeatures=1000, scale=1.2, nlevels=8, ini_th=20, min_th=7, fx=1.0, fy=1.0, cx=0.0, cy=0.0, bf=40.0, th_depth=35.0):
+    def __init__(self, img, right=None, nfeatures=1000, scale=1.2, nlevels=8, ini_th=20, min_th=7, fx=1.0, fy=1.0, cx=0.0, cy=0.0, bf=40.0, th_depth=35.0,
+                 dist=None):
         img = np.ascontiguousarray(img, np.uint8)
         h, w = img.shape
-        geom = (w, h, fx, fy, cx, cy)
+        geom = (w, h, fx, fy, cx, cy, None if dist is None else tuple(float(v) for v in dist))
         new = RefFrame._geometry != geom
         RefFrame._geometry = geom
-        if right is None:
+        if dist is not None:                  # distorted mono / RGB-D camera (mDistCoef, Tracking.cc:70-82)
+            assert right is None
+            d = np.ascontiguousarray(dist, np.float32)
+            self.h = lib().orbslam_ref_frame_mono_dist(_p(img), w, h, img.strides[0], nfeatures, scale, nlevels, ini_th, min_th, fx, fy, cx, cy, _p(d), len(d), bf, th_depth, int(new))
+        elif right is None:
             self.h = lib().orbslam_ref_frame_mono(_p(img), w, h, img.strides[0], nfeatures, scale, nlevels, ini_th, min_th, fx, fy, cx, cy, bf, th_depth, int(new))
         else:
             right = np.ascontiguousarray(right, np.uint8)
@@ -84,6 +92,13 @@ class RefFrame:
         self.keys = np.zeros(self.N, KEYPOINT_DTYPE); self.keys_un = np.zeros(self.N, KEYPOINT_DTYPE)
         self.desc = np.zeros((self.N, 32), np.uint8); self.u_right = np.zeros(self.N, np.float32); self.depth = np.zeros(self.N, np.float32)
         lib().orbslam_ref_frame_get(self.h, _p(self.keys), _p(self.keys_un), _p(self.desc), _p(self.u_right), _p(self.depth))
+
+    @staticmethod
+    def bounds():
+        """(mnMinX, mnMinY, mnMaxX, mnMaxY): the static image bounds the first Frame of the current geometry computed"""
+        out = np.zeros(4, np.float32)
+        lib().orbslam_ref_frame_bounds(_p(out))
+        return out
 
     def close(self):
         if self.h:

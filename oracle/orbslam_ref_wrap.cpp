@@ -165,6 +165,18 @@ void* orbslam_ref_frame_mono(const uint8_t* img, int w, int h, int stride, int n
     cv::Mat im(h, w, CV_8UC1, (void*)img, (size_t)stride), K = camera(fx, fy, cx, cy), D = cv::Mat(cv::Mat::zeros(4, 1, CV_32F));
     return new Frame(im, 0.0, rig(nfeat, scale, nlevels, ini, mn).left, NULL, K, D, bf, thDepth);
 }
+// the same with a distorted camera: mDistCoef = (k1, k2, p1, p2[, k3]) (Tracking.cc:70-82) -> UndistortKeyPoints / ComputeImageBounds
+// take their cv::undistortPoints branches (Frame.cc:404-464) and the grid is laid over the undistorted bounds
+void* orbslam_ref_frame_mono_dist(const uint8_t* img, int w, int h, int stride, int nfeat, float scale, int nlevels, int ini, int mn,
+                                  float fx, float fy, float cx, float cy, const float* dist, int ndist, float bf, float thDepth, int new_geometry)
+{
+    g_used = 0;
+    if (new_geometry) Frame::mbInitialComputations = true;
+    cv::Mat im(h, w, CV_8UC1, (void*)img, (size_t)stride), K = camera(fx, fy, cx, cy), D(ndist, 1, CV_32F);
+    for (int i = 0; i < ndist; i++) D.at<float>(i) = dist[i];
+    return new Frame(im, 0.0, rig(nfeat, scale, nlevels, ini, mn).left, NULL, K, D, bf, thDepth);
+}
+void orbslam_ref_frame_bounds(float* out) { out[0] = Frame::mnMinX; out[1] = Frame::mnMinY; out[2] = Frame::mnMaxX; out[3] = Frame::mnMaxY; }
 // Frame::Frame(imLeft, imRight, ...)  (Frame.cc:62-115): two extractor threads, ComputeStereoMatches
 void* orbslam_ref_frame_stereo(const uint8_t* imgL, const uint8_t* imgR, int w, int h, int stride, int nfeat, float scale, int nlevels, int ini, int mn,
                                float fx, float fy, float cx, float cy, float bf, float thDepth, int new_geometry)

@@ -91,13 +91,26 @@ static inline void copyMakeBorder(InputArray src, OutputArray dst, int top, int 
 }
 
 #ifdef CVLITE_ALGEBRA
-// distorted cameras only (Frame::UndistortKeyPoints / ComputeImageBounds take this branch when mDistCoef[0] != 0): not part of
-// the oracle builds, which use rectified / undistorted synthetic cameras
-static inline void undistortPoints(InputArray, OutputArray, InputArray, InputArray, InputArray, InputArray)
+// Distorted cameras (Frame::UndistortKeyPoints / ComputeImageBounds, Frame.cc:404-464, take this branch when mDistCoef[0] != 0):
+// cv::undistortPoints(mat, mat, mK, mDistCoef, cv::Mat(), mK) forwards to the oracle's restatement.  cvlite has no channels, so
+// reshape(2) / reshape(1) return the same N x 2 float matrix and the points are read as its rows.
+extern "C" void orb_oracle_undistort_points(const float* K4, const float* D5, const float* in, int n, float* out);
+static inline void undistortPoints(InputArray src, OutputArray dst, InputArray cameraMatrix, InputArray distCoeffs, InputArray, InputArray)
 {
-    fprintf(stderr, "cv::undistortPoints is not part of the oracle build (use zero distortion coefficients)\n"); abort();
+    const Mat s = src.getMat(), K = cameraMatrix.getMat(), D = distCoeffs.getMat();
+    if (s.cols != 2 || s.type() != CV_32F || K.type() != CV_32F || D.type() != CV_32F) { fprintf(stderr, "undistortPoints shim: N x 2 CV_32F points, CV_32F K and D expected\n"); abort(); }
+    const float K4[4] = {K.at<float>(0, 0), K.at<float>(1, 1), K.at<float>(0, 2), K.at<float>(1, 2)};
+    float D5[5] = {0, 0, 0, 0, 0};
+    const int nd = D.rows * D.cols;
+    for (int i = 0; i < nd && i < 5; i++) D5[i] = D.rows == 1 ? D.at<float>(0, i) : D.at<float>(i, 0);
+    std::vector<float> in((size_t)s.rows * 2), out((size_t)s.rows * 2);
+    for (int i = 0; i < s.rows; i++) { in[2 * i] = s.at<float>(i, 0); in[2 * i + 1] = s.at<float>(i, 1); }
+    orb_oracle_undistort_points(K4, D5, in.data(), s.rows, out.data());
+    dst.create(s.rows, 2, CV_32F);
+    Mat d = dst.getMat();
+    for (int i = 0; i < s.rows; i++) { d.at<float>(i, 0) = out[2 * i]; d.at<float>(i, 1) = out[2 * i + 1]; }
 }
-inline Mat Mat::reshape(int, int) const { fprintf(stderr, "cv::Mat::reshape is not part of the oracle build\n"); abort(); }
+inline Mat Mat::reshape(int, int) const { return *this; }
 #endif
 
 struct KeyPointsFilter {                                         // only used by the dead ComputeKeyPointsOld (ORBextractor.cc:1006,1024)

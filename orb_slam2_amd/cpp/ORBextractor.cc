@@ -17,8 +17,10 @@ static_assert(sizeof(cv::KeyPoint) == sizeof(orbhip_keypoint), "cv::KeyPoint and
 
 ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST)
     : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST),
+      mbHasCamera(false), mnRawCols(0), mnRawRows(0), mnLastN(0),
       mpCtx(NULL), mnCtxW(0), mnCtxH(0), mnDevice(0), mbDownloadPyramid(true), mfScaleFactorArg(_scaleFactor)
 {
+    memset(mCamera, 0, sizeof mCamera);
     mvScaleFactor.resize(nlevels); mvLevelSigma2.resize(nlevels);
     mvScaleFactor[0] = 1.0f; mvLevelSigma2[0] = 1.0f;
     for (int i = 1; i < nlevels; i++) { mvScaleFactor[i] = (float)(mvScaleFactor[i - 1] * scaleFactor); mvLevelSigma2[i] = mvScaleFactor[i] * mvScaleFactor[i]; }
@@ -44,6 +46,12 @@ void ORBextractor::EnsureContext(int width, int height)
         abort();
     }
     mnCtxW = width; mnCtxH = height;
+    if (mbHasCamera) {
+        orbhip_camera cam; memcpy(&cam, mCamera, sizeof cam);
+        if (orbhip_set_camera(mpCtx, &cam) != ORBHIP_OK) { fprintf(stderr, "ORBextractor: %s\n", orbhip_last_error()); abort(); }
+    }
+    if (!mvMapX.empty() && (size_t)width * height == mvMapX.size() &&
+        orbhip_set_rectification(mpCtx, &mvMapX[0], &mvMapY[0], mnRawCols, mnRawRows) != ORBHIP_OK) { fprintf(stderr, "ORBextractor: %s\n", orbhip_last_error()); abort(); }
     // the device tables are the authority (bit-identical to the constructor's by construction; checked in tests)
     orbhip_get_scale_tables(mpCtx, &mvScaleFactor[0], &mvInvScaleFactor[0], &mvLevelSigma2[0], &mvInvLevelSigma2[0], &mnFeaturesPerLevel[0]);
 }
@@ -83,8 +91,72 @@ void ORBextractor::ExtractColor(const unsigned char* data, int step, int cols, i
     Deliver(n, desc, _keypoints, _descriptors);
 }
 
+static_assert(sizeof(orbhip_camera) == 9 * sizeof(float), "orbhip_camera is nine floats");
+
+void ORBextractor::SetCamera(const cv::Mat& K, const cv::Mat& distCoef)
+{
+    mCamera[0] = K.at<float>(0, 0); mCamera[1] = K.at<float>(1, 1); mCamera[2] = K.at<float>(0, 2); mCamera[3] = K.at<float>(1, 2);
+    const int nd = distCoef.rows * distCoef.cols;                 // 4x1, or 5x1 when Camera.k3 != 0 (Tracking.cc:70-82)
+    for (int i = 0; i < 5; i++) mCamera[4 + i] = i < nd ? (distCoef.rows == 1 ? distCoef.at<float>(0, i) : distCoef.at<float>(i, 0)) : 0.0f;
+    mbHasCamera = true;
+    if (mpCtx) {
+        orbhip_camera cam; memcpy(&cam, mCamera, sizeof cam);
+        if (orbhip_set_camera(mpCtx, &cam) != ORBHIP_OK) { fprintf(stderr, "ORBextractor: %s\n", orbhip_last_error()); abort(); }
+    }
+}
+
+void ORBextractor::UndistortKeyPoints(std::vector<cv::KeyPoint>& mvKeysUn)
+{
+    mvKeysUn.resize(mnLastN);
+    if (mnLastN == 0 || !mpCtx) return;
+    if (orbhip_fetch_undistorted(mpCtx, 1, reinterpret_cast<orbhip_keypoint*>(&mvKeysUn[0]), mnLastN) != ORBHIP_OK) {
+        fprintf(stderr, "ORBextractor::UndistortKeyPoints: %s\n", orbhip_last_error());
+        abort();
+    }
+}
+
+void ORBextractor::ComputeImageBounds(int cols, int rows, float& mnMinX, float& mnMaxX, float& mnMinY, float& mnMaxY)
+{
+    orbhip_bounds b = {0.0f, 0.0f, (float)cols, (float)rows};     // Frame.cc:455-463
+    if (mbHasCamera) {
+        orbhip_camera cam; memcpy(&cam, mCamera, sizeof cam);
+        if (orbhip_image_bounds(mnDevice, &cam, cols, rows, &b) != ORBHIP_OK) { fprintf(stderr, "ORBextractor::ComputeImageBounds: %s\n", orbhip_last_error()); abort(); }
+    }
+    mnMinX = b.min_x; mnMaxX = b.max_x; mnMinY = b.min_y; mnMaxY = b.max_y;
+}
+
+void ORBextractor::SetRectification(const cv::Mat& M1, const cv::Mat& M2, int rawCols, int rawRows)
+{
+    assert(M1.type() == CV_32F && M2.type() == CV_32F && M1.rows == M2.rows && M1.cols == M2.cols);
+    mvMapX.resize((size_t)M1.rows * M1.cols); mvMapY.resize(mvMapX.size());
+    for (int y = 0; y < M1.rows; y++) {
+        memcpy(&mvMapX[(size_t)y * M1.cols], M1.ptr<float>(y), sizeof(float) * M1.cols);
+        memcpy(&mvMapY[(size_t)y * M1.cols], M2.ptr<float>(y), sizeof(float) * M1.cols);
+    }
+    mnRawCols = rawCols; mnRawRows = rawRows;
+    if (mpCtx) { orbhip_destroy(mpCtx); mpCtx = NULL; }            // the context of the rectified size is re-created with the maps
+    EnsureContext(M1.cols, M1.rows);
+}
+
+void ORBextractor::ExtractRectified(const cv::Mat& raw, std::vector<cv::KeyPoint>& _keypoints, cv::OutputArray _descriptors)
+{
+    if (raw.empty() || !mpCtx || mvMapX.empty()) return;
+    assert(raw.type() == CV_8UC1 && raw.cols == mnRawCols && raw.rows == mnRawRows);
+    const int cap = orbhip_keypoint_capacity(mpCtx);
+    _keypoints.resize(cap);
+    std::vector<unsigned char> desc((size_t)cap * 32);
+    int n = 0;
+    const uint8_t* imgs[1] = {raw.data};
+    if (orbhip_extract_batch_rectify(mpCtx, 1, imgs, (int)raw.step, reinterpret_cast<orbhip_keypoint*>(&_keypoints[0]), &desc[0], cap, &n) != ORBHIP_OK) {
+        fprintf(stderr, "ORBextractor: %s\n", orbhip_last_error());
+        abort();
+    }
+    Deliver(n, desc, _keypoints, _descriptors);
+}
+
 void ORBextractor::Deliver(int n, const std::vector<unsigned char>& desc, std::vector<cv::KeyPoint>& _keypoints, cv::OutputArray _descriptors)
 {
+    mnLastN = n;
     _keypoints.resize(n);
     if (n == 0) _descriptors.release();                          // ORBextractor.cc:1064-1065
     else {

@@ -30,14 +30,14 @@ int ORBmatcher::SearchForInitialization(Frame& F1, Frame& F2, std::vector<cv::Po
     const int n1 = (int)F1.mvKeysUn.size(), n2 = (int)F2.mvKeysUn.size();
     vnMatches12 = std::vector<int>(n1, -1);
     if (n1 == 0) return 0;
-    // undistorted input: mnMinX = mnMinY = 0 and mnMax = image size (Frame.cc:455-463); a distorted camera needs the bounds too
-    const int im_w = (int)(Frame::mnMaxX - Frame::mnMinX), im_h = (int)(Frame::mnMaxY - Frame::mnMinY);
+    // the grid of GetFeaturesInArea spans the (undistorted) image bounds (Frame.cc:101-102, 327-346, 436-464)
+    const orbhip_bounds bounds = {Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY};
     int nmatches = 0;
     const int device = getenv("ORBHIP_DEVICE") ? atoi(getenv("ORBHIP_DEVICE")) : 0;
-    const orbhip_status st = orbhip_search_for_initialization(
+    const orbhip_status st = orbhip_search_for_initialization_bounds(
         device, reinterpret_cast<const orbhip_keypoint*>(&F1.mvKeysUn[0]), F1.mDescriptors.ptr<unsigned char>(), n1,
         n2 ? reinterpret_cast<const orbhip_keypoint*>(&F2.mvKeysUn[0]) : NULL, n2 ? F2.mDescriptors.ptr<unsigned char>() : NULL, n2,
-        im_w, im_h, reinterpret_cast<float*>(&vbPrevMatched[0]), &vnMatches12[0], windowSize, mfNNratio, mbCheckOrientation ? 1 : 0, &nmatches);
+        &bounds, reinterpret_cast<float*>(&vbPrevMatched[0]), &vnMatches12[0], windowSize, mfNNratio, mbCheckOrientation ? 1 : 0, &nmatches);
     if (st != ORBHIP_OK) { fprintf(stderr, "ORBmatcher: %s\n", orbhip_last_error()); abort(); }
     return nmatches;
 }

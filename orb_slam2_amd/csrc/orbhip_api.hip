@@ -33,9 +33,9 @@ static inline int cvRoundD(double v) { return (int)lrint(v); }
 static inline int cvFloorF(float v) { int i = (int)v; return i - (i > v); }
 static inline short satShort(int v) { return (short)(v < -32768 ? -32768 : v > 32767 ? 32767 : v); }
 
-enum { K_PYRAMID = 0, K_FAST, K_BLUR, K_QUADTREE, K_DESCRIBE, K_MGRID, K_MCAND, K_MSELECT, K_COUNT };
+enum { K_PYRAMID = 0, K_FAST, K_BLUR, K_QUADTREE, K_DESCRIBE, K_MGRID, K_MCAND, K_MSELECT, K_UNDISTORT, K_REMAP, K_COUNT };
 static const char* kKernelNames[K_COUNT] = {"k_pyramid_level", "k_fast_cells", "k_blur", "k_quadtree", "k_describe",
-                                            "k_match_grid", "k_match_candidates", "k_match_select"};
+                                            "k_match_grid", "k_match_candidates", "k_match_select", "k_undistort_keys", "k_remap"};
 
 struct ProfSpan { int k; hipEvent_t a, b; };
 
@@ -65,6 +65,9 @@ struct orbhip_ctx {
     int* d_st_rowstart = nullptr; int* d_st_rowitems = nullptr; int st_rowcap = 0; float* d_st_u = nullptr; float* d_st_depth = nullptr; int* d_st_sad = nullptr;
     // matcher workspace
     int* d_grid_start = nullptr; int* d_grid_items = nullptr; float2* d_grid_xy = nullptr; unsigned* d_cand = nullptr; int* d_ncand = nullptr; float* d_prev = nullptr; int* d_m12 = nullptr; int* d_nm = nullptr;
+    // camera geometry: undistorted key points of a distorted camera, rectification maps of a raw stereo camera
+    orbhip_bounds bounds = {0, 0, 0, 0}; bool distorted = false; CameraD cam = {}; orbhip_keypoint* d_out_kpun[3] = {nullptr, nullptr, nullptr}; orbhip_keypoint* h_kpun = nullptr;
+    float* d_map_x = nullptr; float* d_map_y = nullptr; int src_w = 0, src_h = 0, raw_pitch = 0; uint8_t* d_raw = nullptr; uint8_t* h_raw = nullptr;
     // profiling
     bool prof = false; std::vector<ProfSpan> pending; std::vector<hipEvent_t> pool; double tot_ms[K_COUNT] = {0}; long long launches[K_COUNT] = {0};
 };
@@ -179,6 +182,9 @@ extern "C" void orbhip_destroy(orbhip_ctx* c)
     if (c->h_in) (void)hipHostFree(c->h_in);
     if (c->d_col) (void)hipFree(c->d_col);
     if (c->h_col) (void)hipHostFree(c->h_col);
+    { void* g[] = {c->d_out_kpun[0], c->d_out_kpun[1], c->d_out_kpun[2], c->d_map_x, c->d_map_y, c->d_raw}; for (void* q : g) if (q) (void)hipFree(q); }
+    if (c->h_kpun) (void)hipHostFree(c->h_kpun);
+    if (c->h_raw) (void)hipHostFree(c->h_raw);
     if (c->h_kp) (void)hipHostFree(c->h_kp);
     if (c->h_desc) (void)hipHostFree(c->h_desc);
     if (c->h_n) (void)hipHostFree(c->h_n);
@@ -200,6 +206,7 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
     HIPCHK(hipSetDevice(cfg->device));
 
     orbhip_ctx* c = new orbhip_ctx; c->cfg = *cfg; c->L = cfg->nlevels; c->B = cfg->max_batch;
+    c->bounds.max_x = (float)cfg->width; c->bounds.max_y = (float)cfg->height;       // undistorted camera until orbhip_set_camera says otherwise
     const int L = c->L;
     // ---- ORBextractor::ORBextractor (ORBextractor.cc:410-446): double scaleFactor member initialised from the float argument
     const double scaleFactor = (double)cfg->scale_factor;
@@ -396,12 +403,17 @@ static orbhip_status run_pipeline(orbhip_ctx* c, int nimg, const uint8_t* d_img0
         { ProfScope ps(c, K_DESCRIBE, s); orbhip_launch_describe(P, nf, s); }
         if (gi > 0) { HIPCHK(hipEventRecord(c->xevents[gi - 1], s)); HIPCHK(hipStreamWaitEvent(c->stream, c->xevents[gi - 1], 0)); }
     }
+    if (c->distorted) {   // Frame::UndistortKeyPoints (Frame.cc:404-434) behind the descriptor kernel: mvKeysUn stays in HBM beside mvKeys
+        ProfScope ps(c, K_UNDISTORT, c->stream);
+        orbhip_launch_undistort_keys(c->cam, c->d_out_kp[cur], c->d_out_n[cur], c->d_out_kpun[cur], c->out_cap, nimg, c->stream);
+    }
     if (match_prev) {
         MatchParams M; memset(&M, 0, sizeof M);
-        M.kp1 = c->d_out_kp[prev]; M.desc1 = c->d_out_desc[prev]; M.n1 = c->d_out_n[prev]; M.n1_lvl0 = c->d_lvl_n[prev];
-        M.kp2 = c->d_out_kp[cur]; M.desc2 = c->d_out_desc[cur]; M.n2 = c->d_out_n[cur];
+        // the matcher reads mvKeysUn of both frames (ORBmatcher.cc:418, 443 via GetFeaturesInArea)
+        M.kp1 = c->distorted ? c->d_out_kpun[prev] : c->d_out_kp[prev]; M.desc1 = c->d_out_desc[prev]; M.n1 = c->d_out_n[prev]; M.n1_lvl0 = c->d_lvl_n[prev];
+        M.kp2 = c->distorted ? c->d_out_kpun[cur] : c->d_out_kp[cur]; M.desc2 = c->d_out_desc[cur]; M.n2 = c->d_out_n[cur];
         M.lvl_stride = c->L; M.list1 = nullptr; M.prev_from_kp1 = 1;
-        M.cap = c->out_cap; M.im_w = c->cfg.width; M.im_h = c->cfg.height;
+        M.cap = c->out_cap; M.min_x = c->bounds.min_x; M.min_y = c->bounds.min_y; M.max_x = c->bounds.max_x; M.max_y = c->bounds.max_y;
         M.grid_start = c->d_grid_start; M.grid_items = c->d_grid_items; M.grid_xy = c->d_grid_xy; M.cand = c->d_cand; M.ncand = c->d_ncand; M.cand_stride = c->lvl0_cap; M.lvl0_cap = c->lvl0_cap;
         M.prev = c->d_prev; M.matches12 = c->d_m12; M.nmatches = c->d_nm; M.window = window; M.nnratio = nnratio; M.check_ori = check_ori; M.slot0 = 0;
         // matcher of this batch on its own stream: latency-bound (one wave per slot), overlaps the next call's extraction
@@ -634,12 +646,12 @@ extern "C" orbhip_status orbhip_debug_candidates(orbhip_ctx* c, int frame, int l
 }
 
 // ---------------------------------------------------------------------------------------------- projection-guided search
-extern "C" orbhip_status orbhip_search_by_projection(int device, const orbhip_keypoint* kps, const uint8_t* desc, const float* u_right,
-                                                     const uint8_t* blocked, int n, int im_w, int im_h,
+extern "C" orbhip_status orbhip_search_by_projection_bounds(int device, const orbhip_keypoint* kps, const uint8_t* desc, const float* u_right,
+                                                     const uint8_t* blocked, int n, const orbhip_bounds* bounds,
                                                      const orbhip_proj_query* queries, const uint8_t* query_desc, int nq,
                                                      int mode, float nnratio, int th_high, int check_ori, int32_t* feature_query, int* nmatches)
 {
-    if (n < 0 || nq < 0 || !nmatches || (n > 0 && (!kps || !desc || !feature_query)) || (nq > 0 && (!queries || !query_desc)) || im_w < 1 || im_h < 1 || (mode != 0 && mode != 1))
+    if (n < 0 || nq < 0 || !nmatches || (n > 0 && (!kps || !desc || !feature_query)) || (nq > 0 && (!queries || !query_desc)) || !bounds || !(bounds->max_x > bounds->min_x) || !(bounds->max_y > bounds->min_y) || (mode != 0 && mode != 1))
         return fail(ORBHIP_ERR_INVALID, "bad argument");
     *nmatches = 0;
     for (int i = 0; i < n; i++) feature_query[i] = -1;
@@ -667,10 +679,10 @@ extern "C" orbhip_status orbhip_search_by_projection(int device, const orbhip_ke
     TRY(hipMemcpy(dn, hn, sizeof hn, hipMemcpyHostToDevice));
     if (e == hipSuccess) {
         MatchParams M; memset(&M, 0, sizeof M);
-        M.kp2 = dk; M.n2 = dn; M.cap = n; M.im_w = im_w; M.im_h = im_h; M.grid_start = dgs; M.grid_items = dgi; M.grid_xy = dgxy; M.grid_all_levels = 1;
+        M.kp2 = dk; M.n2 = dn; M.cap = n; M.min_x = bounds->min_x; M.min_y = bounds->min_y; M.max_x = bounds->max_x; M.max_y = bounds->max_y; M.grid_start = dgs; M.grid_items = dgi; M.grid_xy = dgxy; M.grid_all_levels = 1;
         orbhip_launch_match_grid(M, 1, nullptr);
         ProjParams J; memset(&J, 0, sizeof J);
-        J.kp = dk; J.desc = dd; J.u_right = dur; J.n = n; J.im_w = im_w; J.im_h = im_h; J.grid_start = dgs; J.grid_items = dgi; J.grid_xy = dgxy;
+        J.kp = dk; J.desc = dd; J.u_right = dur; J.n = n; J.min_x = bounds->min_x; J.min_y = bounds->min_y; J.max_x = bounds->max_x; J.max_y = bounds->max_y; J.grid_start = dgs; J.grid_items = dgi; J.grid_xy = dgxy;
         J.q = dq; J.qdesc = dqd; J.nq = nq; J.cand = dcand; J.ncand = dnc; J.cand_stride = n;
         J.blocked_in = dbl_in; J.blocked_out = nullptr; J.feature_query = dfq; J.nmatches = dn + 1; J.events = dev;
         J.mode = mode; J.nnratio = nnratio; J.th_high = th_high; J.check_ori = check_ori;
@@ -686,11 +698,11 @@ extern "C" orbhip_status orbhip_search_by_projection(int device, const orbhip_ke
     return st;
 }
 
-extern "C" orbhip_status orbhip_search_best_in_window(int device, const orbhip_keypoint* kps, const uint8_t* desc, const float* u_right, int n, int im_w, int im_h,
+extern "C" orbhip_status orbhip_search_best_in_window_bounds(int device, const orbhip_keypoint* kps, const uint8_t* desc, const float* u_right, int n, const orbhip_bounds* bounds,
                                                       const float* inv_level_sigma2, int nlevels, const orbhip_best_query* queries, const uint8_t* query_desc, int nq,
                                                       int chi2_gate, int32_t* best_idx, int32_t* best_dist)
 {
-    if (n < 0 || nq < 0 || (nq > 0 && (!queries || !query_desc || !best_idx || !best_dist)) || (n > 0 && (!kps || !desc)) || im_w < 1 || im_h < 1 ||
+    if (n < 0 || nq < 0 || (nq > 0 && (!queries || !query_desc || !best_idx || !best_dist)) || (n > 0 && (!kps || !desc)) || !bounds || !(bounds->max_x > bounds->min_x) || !(bounds->max_y > bounds->min_y) ||
         (chi2_gate && (!inv_level_sigma2 || nlevels < 1))) return fail(ORBHIP_ERR_INVALID, "bad argument");
     for (int i = 0; i < nq; i++) { best_idx[i] = -1; best_dist[i] = 256; }
     if (n == 0 || nq == 0) return ORBHIP_OK;
@@ -714,7 +726,7 @@ extern "C" orbhip_status orbhip_search_best_in_window(int device, const orbhip_k
     TRY(hipMemcpy(dn, hn, sizeof hn, hipMemcpyHostToDevice));
     if (e == hipSuccess) {
         MatchParams M; memset(&M, 0, sizeof M);
-        M.kp2 = dk; M.n2 = dn; M.cap = n; M.im_w = im_w; M.im_h = im_h; M.grid_start = dgs; M.grid_items = dgi; M.grid_xy = dgxy; M.grid_all_levels = 1;
+        M.kp2 = dk; M.n2 = dn; M.cap = n; M.min_x = bounds->min_x; M.min_y = bounds->min_y; M.max_x = bounds->max_x; M.max_y = bounds->max_y; M.grid_start = dgs; M.grid_items = dgi; M.grid_xy = dgxy; M.grid_all_levels = 1;
         orbhip_launch_match_grid(M, 1, nullptr);
         BestParams B; memset(&B, 0, sizeof B);
         B.kp = dk; B.desc = dd; B.u_right = dur; B.inv_level_sigma2 = dsg; B.grid_start = dgs; B.grid_items = dgi; B.grid_xy = dgxy;
@@ -824,6 +836,139 @@ extern "C" int64_t orbhip_algorithmic_bytes_per_frame_kernel(const orbhip_ctx* c
     }
 }
 
+// ---------------------------------------------------------------------------------------------- camera geometry
+static bool camera_ok(const orbhip_camera* cam) { return cam && cam->fx != 0.0f && cam->fy != 0.0f; }
+static CameraD widen(const orbhip_camera& k)
+{   // cvUndistortPoints converts the CV_32F mK / mDistCoef to double and forms ifx = 1./fx on the host
+    CameraD C; C.fx = k.fx; C.fy = k.fy; C.cx = k.cx; C.cy = k.cy; C.ifx = 1. / C.fx; C.ify = 1. / C.fy; C.k1 = k.k1; C.k2 = k.k2; C.p1 = k.p1; C.p2 = k.p2; C.k3 = k.k3;
+    return C;
+}
+extern "C" orbhip_status orbhip_undistort_points(int device, const orbhip_camera* cam, const float* xy, int n, float* xy_out)
+{
+    if (!camera_ok(cam) || n < 0 || (n > 0 && (!xy || !xy_out))) return fail(ORBHIP_ERR_INVALID, "bad argument");
+    if (n == 0) return ORBHIP_OK;
+    int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(ORBHIP_ERR_HIP, "no HIP device available: no CPU fallback");
+    HIPCHK(hipSetDevice(device));
+    float *din = nullptr, *dout = nullptr;
+    HIPCHK(arena_layout(device, [&](Arena& A) { A.take(&din, (size_t)n * 2); A.take(&dout, (size_t)n * 2); }));
+    HIPCHK(hipMemcpyAsync(din, xy, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, nullptr));
+    orbhip_launch_undistort_points(widen(*cam), din, n, dout, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(xy_out, dout, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost, nullptr));
+    HIPCHK(hipStreamSynchronize(nullptr));
+    return ORBHIP_OK;
+}
+extern "C" orbhip_status orbhip_image_bounds(int device, const orbhip_camera* cam, int im_w, int im_h, orbhip_bounds* out)
+{
+    if (!camera_ok(cam) || !out || im_w < 1 || im_h < 1) return fail(ORBHIP_ERR_INVALID, "bad argument");
+    if (cam->k1 == 0.0f) { out->min_x = 0.0f; out->max_x = (float)im_w; out->min_y = 0.0f; out->max_y = (float)im_h; return ORBHIP_OK; }     // Frame.cc:455-463
+    const float corners[8] = {0.0f, 0.0f, (float)im_w, 0.0f, 0.0f, (float)im_h, (float)im_w, (float)im_h};                                 // Frame.cc:440-444
+    float m[8];
+    const orbhip_status st = orbhip_undistort_points(device, cam, corners, 4, m); if (st != ORBHIP_OK) return st;
+    out->min_x = std::min(m[0], m[4]); out->max_x = std::max(m[2], m[6]); out->min_y = std::min(m[1], m[3]); out->max_y = std::max(m[5], m[7]);   // Frame.cc:451-454
+    return ORBHIP_OK;
+}
+extern "C" orbhip_status orbhip_set_camera(orbhip_ctx* c, const orbhip_camera* cam)
+{
+    if (!c || (cam && !camera_ok(cam))) return fail(ORBHIP_ERR_INVALID, "bad argument");
+    orbhip_status st = orbhip_sync(c); if (st != ORBHIP_OK) return st;
+    const bool distorted = cam && cam->k1 != 0.0f;                        // if(mDistCoef.at<float>(0)==0.0) mvKeysUn = mvKeys  (Frame.cc:406-410)
+    orbhip_bounds b = {0.0f, 0.0f, (float)c->cfg.width, (float)c->cfg.height};
+    if (distorted) {
+        st = orbhip_image_bounds(c->cfg.device, cam, c->cfg.width, c->cfg.height, &b); if (st != ORBHIP_OK) return st;
+        if (!(b.max_x > b.min_x) || !(b.max_y > b.min_y)) return fail(ORBHIP_ERR_INVALID, "the distortion model folds the image corners (bounds %g..%g x %g..%g)", b.min_x, b.max_x, b.min_y, b.max_y);
+        for (int k = 0; k < 3; k++) if (!c->d_out_kpun[k]) HIPCHK(dalloc(&c->d_out_kpun[k], (size_t)c->B * c->out_cap));
+        c->cam = widen(*cam);
+    }
+    c->distorted = distorted; c->bounds = b;
+    // frames extracted under the previous camera are no "previous frame" for the matcher any more
+    for (int k = 0; k < 3; k++) { HIPCHK(hipMemsetAsync(c->d_out_n[k], 0, (size_t)c->B * sizeof(int), c->stream)); HIPCHK(hipMemsetAsync(c->d_lvl_n[k], 0, (size_t)c->B * c->L * sizeof(int), c->stream)); }
+    c->last_nimg = 0; c->last_matched = false;
+    return orbhip_sync(c);
+}
+extern "C" orbhip_status orbhip_get_bounds(const orbhip_ctx* c, orbhip_bounds* out)
+{
+    if (!c || !out) return fail(ORBHIP_ERR_INVALID, "null argument");
+    *out = c->bounds; return ORBHIP_OK;
+}
+extern "C" orbhip_status orbhip_fetch_undistorted(orbhip_ctx* c, int nimg, orbhip_keypoint* kps_un, int cap)
+{
+    if (!c || !kps_un || cap < 0) return fail(ORBHIP_ERR_INVALID, "bad argument");
+    if (nimg < 1 || nimg > c->last_nimg) return fail(ORBHIP_ERR_INVALID, "nimg %d but the last call processed %d frames", nimg, c->last_nimg);
+    HIPCHK(hipSetDevice(c->cfg.device));
+    orbhip_status st = ensure_host_staging(c, false); if (st != ORBHIP_OK) return st;
+    if (!c->h_kpun) HIPCHK(hipHostMalloc((void**)&c->h_kpun, (size_t)c->B * c->out_cap * sizeof(orbhip_keypoint), hipHostMallocDefault));
+    HIPCHK(hipMemcpyAsync(c->h_n, c->d_out_n[c->cur], nimg * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_kpun, (c->distorted ? c->d_out_kpun : c->d_out_kp)[c->cur], (size_t)nimg * c->out_cap * sizeof(orbhip_keypoint), hipMemcpyDeviceToHost, c->stream));
+    st = orbhip_sync(c); if (st != ORBHIP_OK) return st;
+    bool overflow = false;
+    for (int f = 0; f < nimg; f++) {
+        const int m = std::min(c->h_n[f], cap);
+        if (c->h_n[f] > cap) overflow = true;
+        if (m > 0) memcpy(kps_un + (size_t)f * cap, c->h_kpun + (size_t)f * c->out_cap, (size_t)m * sizeof(orbhip_keypoint));
+    }
+    return overflow ? fail(ORBHIP_ERR_CAPACITY, "keypoint buffer too small") : ORBHIP_OK;
+}
+
+// Rectification of raw stereo frames (stereo_euroc.cc:136-137): remapped on the device into the context's level-0 plane
+extern "C" orbhip_status orbhip_set_rectification(orbhip_ctx* c, const float* map_x, const float* map_y, int src_w, int src_h)
+{
+    if (!c) return fail(ORBHIP_ERR_INVALID, "null context");
+    orbhip_status st = orbhip_sync(c); if (st != ORBHIP_OK) return st;
+    if (!map_x) { c->src_w = c->src_h = 0; return ORBHIP_OK; }
+    if (!map_y || src_w < 1 || src_h < 1 || src_w > 32767 || src_h > 32767) return fail(ORBHIP_ERR_INVALID, "bad argument");
+    HIPCHK(hipSetDevice(c->cfg.device));
+    const size_t n = (size_t)c->cfg.width * c->cfg.height;
+    if (!c->d_map_x) { HIPCHK(dalloc(&c->d_map_x, n)); HIPCHK(dalloc(&c->d_map_y, n)); }
+    HIPCHK(hipMemcpy(c->d_map_x, map_x, n * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_map_y, map_y, n * sizeof(float), hipMemcpyHostToDevice));
+    if (c->d_raw && (src_w != c->src_w || src_h != c->src_h)) { (void)hipFree(c->d_raw); (void)hipHostFree(c->h_raw); c->d_raw = nullptr; c->h_raw = nullptr; }
+    c->src_w = src_w; c->src_h = src_h; c->raw_pitch = (src_w + 63) & ~63;
+    return ORBHIP_OK;
+}
+extern "C" orbhip_status orbhip_extract_device_rectify(orbhip_ctx* c, int nimg, const uint8_t* d_raw, size_t frame_stride, int row_stride,
+                                                       int match_prev, int window, float nnratio, int check_ori)
+{
+    if (!c || !d_raw) return fail(ORBHIP_ERR_INVALID, "null argument");
+    if (c->src_w < 1) return fail(ORBHIP_ERR_INVALID, "no rectification maps: call orbhip_set_rectification first");
+    if (nimg < 1 || nimg > c->B) return fail(ORBHIP_ERR_INVALID, "nimg %d outside 1..%d", nimg, c->B);
+    if (row_stride < c->src_w) return fail(ORBHIP_ERR_INVALID, "row stride %d < raw width %d", row_stride, c->src_w);
+    HIPCHK(hipSetDevice(c->cfg.device));
+    orbhip_status st = ensure_host_staging(c, true); if (st != ORBHIP_OK) return st;
+    const size_t fbytes = (size_t)c->in_pitch * c->cfg.height;
+    {
+        ProfScope ps(c, K_REMAP, c->stream);
+        orbhip_launch_remap(d_raw, (long long)frame_stride, row_stride, c->src_w, c->src_h, c->d_map_x, c->d_map_y, c->d_in, (long long)fbytes, c->in_pitch,
+                            c->cfg.width, c->cfg.height, nimg, c->stream);
+    }
+    HIPCHK(hipGetLastError());
+    c->last_from_host = true;                                          // level 0 lives in the context's own plane
+    return run_pipeline(c, nimg, c->d_in, (long long)fbytes, c->in_pitch, match_prev, window, nnratio, check_ori);
+}
+extern "C" orbhip_status orbhip_extract_batch_rectify(orbhip_ctx* c, int nimg, const uint8_t* const* imgs, int stride, orbhip_keypoint* kps, uint8_t* desc, int cap, int* n_out)
+{
+    if (!c || !imgs || !n_out) return fail(ORBHIP_ERR_INVALID, "null argument");
+    if (c->src_w < 1) return fail(ORBHIP_ERR_INVALID, "no rectification maps: call orbhip_set_rectification first");
+    if (nimg < 1 || nimg > c->B) return fail(ORBHIP_ERR_INVALID, "nimg %d outside 1..%d", nimg, c->B);
+    if (stride < c->src_w) return fail(ORBHIP_ERR_INVALID, "stride %d < raw width %d", stride, c->src_w);
+    HIPCHK(hipSetDevice(c->cfg.device));
+    const size_t rfbytes = (size_t)c->raw_pitch * c->src_h;
+    if (!c->d_raw) {
+        HIPCHK(hipMalloc((void**)&c->d_raw, (size_t)c->B * rfbytes + 256));
+        HIPCHK(hipHostMalloc((void**)&c->h_raw, (size_t)c->B * rfbytes + 256, hipHostMallocDefault));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int f = 0; f < nimg; f++) {
+        if (!imgs[f]) return fail(ORBHIP_ERR_INVALID, "image %d is null", f);
+        uint8_t* dst = c->h_raw + f * rfbytes;
+        for (int y = 0; y < c->src_h; y++) memcpy(dst + (size_t)y * c->raw_pitch, imgs[f] + (size_t)y * stride, c->src_w);
+    }
+    HIPCHK(hipMemcpyAsync(c->d_raw, c->h_raw, nimg * rfbytes, hipMemcpyHostToDevice, c->stream));
+    const orbhip_status st = orbhip_extract_device_rectify(c, nimg, c->d_raw, rfbytes, c->raw_pitch, 0, 0, 0.f, 0);
+    if (st != ORBHIP_OK) return st;
+    return orbhip_fetch(c, nimg, kps, desc, cap, n_out);
+}
+
 // ---------------------------------------------------------------------------------------------- stateless matcher entry points
 extern "C" int orbhip_descriptor_distance(const uint8_t* a, const uint8_t* b)
 {
@@ -878,11 +1023,11 @@ extern "C" orbhip_status orbhip_hamming_nn(int device, const uint8_t* q, int nq,
     return st;
 }
 
-extern "C" orbhip_status orbhip_search_for_initialization(int device, const orbhip_keypoint* kps1, const uint8_t* desc1, int n1,
-                                                          const orbhip_keypoint* kps2, const uint8_t* desc2, int n2, int im_w, int im_h,
+extern "C" orbhip_status orbhip_search_for_initialization_bounds(int device, const orbhip_keypoint* kps1, const uint8_t* desc1, int n1,
+                                                          const orbhip_keypoint* kps2, const uint8_t* desc2, int n2, const orbhip_bounds* bounds,
                                                           float* prev_matched, int32_t* matches12, int window, float nnratio, int check_ori, int* nmatches)
 {
-    if (n1 < 0 || n2 < 0 || !nmatches || (n1 > 0 && (!kps1 || !desc1 || !prev_matched || !matches12)) || (n2 > 0 && (!kps2 || !desc2)) || im_w < 1 || im_h < 1)
+    if (n1 < 0 || n2 < 0 || !nmatches || (n1 > 0 && (!kps1 || !desc1 || !prev_matched || !matches12)) || (n2 > 0 && (!kps2 || !desc2)) || !bounds || !(bounds->max_x > bounds->min_x) || !(bounds->max_y > bounds->min_y))
         return fail(ORBHIP_ERR_INVALID, "bad argument");
     *nmatches = 0;
     for (int i = 0; i < n1; i++) matches12[i] = -1;
@@ -912,7 +1057,7 @@ extern "C" orbhip_status orbhip_search_for_initialization(int device, const orbh
     if (e == hipSuccess) {
         MatchParams M; memset(&M, 0, sizeof M);
         M.kp1 = dk1; M.desc1 = dd1; M.n1 = dn; M.n1_lvl0 = dn + 2; M.kp2 = dk2; M.desc2 = dd2; M.n2 = dn + 1; M.lvl_stride = 0; M.list1 = dlist; M.prev_from_kp1 = 0;
-        M.cap = cap; M.im_w = im_w; M.im_h = im_h; M.grid_start = dgs; M.grid_items = dgi; M.grid_xy = dgxy; M.cand = dcand; M.ncand = dnc; M.cand_stride = cstride; M.lvl0_cap = l0cap;
+        M.cap = cap; M.min_x = bounds->min_x; M.min_y = bounds->min_y; M.max_x = bounds->max_x; M.max_y = bounds->max_y; M.grid_start = dgs; M.grid_items = dgi; M.grid_xy = dgxy; M.cand = dcand; M.ncand = dnc; M.cand_stride = cstride; M.lvl0_cap = l0cap;
         M.prev = dprev; M.matches12 = dm12; M.nmatches = dn + 3; M.window = window; M.nnratio = nnratio; M.check_ori = check_ori;
         orbhip_launch_match_grid(M, 1, nullptr); orbhip_launch_match_candidates(M, 1, nullptr); orbhip_launch_match_select(M, 1, nullptr);
         e = hipGetLastError();
@@ -925,4 +1070,28 @@ extern "C" orbhip_status orbhip_search_for_initialization(int device, const orbh
     orbhip_status st = ORBHIP_OK;
     if (e != hipSuccess) st = fail(ORBHIP_ERR_HIP, "search_for_initialization: %s", hipGetErrorString(e));
     return st;
+}
+
+// the im_w / im_h forms: an undistorted camera, mnMinX = mnMinY = 0, mnMaxX = cols, mnMaxY = rows (Frame.cc:455-463)
+static bool whole_image(int im_w, int im_h, orbhip_bounds* b) { if (im_w < 1 || im_h < 1) return false; b->min_x = 0.0f; b->min_y = 0.0f; b->max_x = (float)im_w; b->max_y = (float)im_h; return true; }
+extern "C" orbhip_status orbhip_search_by_projection(int device, const orbhip_keypoint* kps, const uint8_t* desc, const float* u_right, const uint8_t* blocked, int n,
+                                                     int im_w, int im_h, const orbhip_proj_query* queries, const uint8_t* query_desc, int nq,
+                                                     int mode, float nnratio, int th_high, int check_ori, int32_t* feature_query, int* nmatches)
+{
+    orbhip_bounds b; if (!whole_image(im_w, im_h, &b)) return fail(ORBHIP_ERR_INVALID, "bad argument");
+    return orbhip_search_by_projection_bounds(device, kps, desc, u_right, blocked, n, &b, queries, query_desc, nq, mode, nnratio, th_high, check_ori, feature_query, nmatches);
+}
+extern "C" orbhip_status orbhip_search_best_in_window(int device, const orbhip_keypoint* kps, const uint8_t* desc, const float* u_right, int n, int im_w, int im_h,
+                                                      const float* inv_level_sigma2, int nlevels, const orbhip_best_query* queries, const uint8_t* query_desc, int nq,
+                                                      int chi2_gate, int32_t* best_idx, int32_t* best_dist)
+{
+    orbhip_bounds b; if (!whole_image(im_w, im_h, &b)) return fail(ORBHIP_ERR_INVALID, "bad argument");
+    return orbhip_search_best_in_window_bounds(device, kps, desc, u_right, n, &b, inv_level_sigma2, nlevels, queries, query_desc, nq, chi2_gate, best_idx, best_dist);
+}
+extern "C" orbhip_status orbhip_search_for_initialization(int device, const orbhip_keypoint* kps1, const uint8_t* desc1, int n1,
+                                                          const orbhip_keypoint* kps2, const uint8_t* desc2, int n2, int im_w, int im_h,
+                                                          float* prev_matched, int32_t* matches12, int window, float nnratio, int check_ori, int* nmatches)
+{
+    orbhip_bounds b; if (!whole_image(im_w, im_h, &b)) return fail(ORBHIP_ERR_INVALID, "bad argument");
+    return orbhip_search_for_initialization_bounds(device, kps1, desc1, n1, kps2, desc2, n2, &b, prev_matched, matches12, window, nnratio, check_ori, nmatches);
 }

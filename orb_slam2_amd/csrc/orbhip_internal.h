@@ -77,7 +77,7 @@ struct MatchParams {        // SearchForInitialization over camera slots (ORBmat
     int prev_from_kp1;                                                  // 1: vbPrevMatched starts as F1's keypoint positions (Tracking.cc:590-592)
     const orbhip_keypoint* kp2; const uint8_t* desc2; const int* n2;    // current frames
     int cap;                                      // keypoint capacity per frame (stride of the arrays above)
-    int im_w, im_h;
+    float min_x, min_y, max_x, max_y;                                   // Frame::mnMinX .. mnMaxY (Frame.cc:436-464)
     int* grid_start; int* grid_items; float2* grid_xy;   // [slot][GRID_CELLS+1], [slot][cap], [slot][cap]  (Frame.cc:230-245 on F2, level 0 only)
     unsigned* cand; int* ncand; int cand_stride;  // [slot][n1_lvl0_cap][cand_stride]: i2 | dist<<16, canonical order
     int lvl0_cap;
@@ -104,7 +104,7 @@ void orbhip_launch_stereo(const StereoParams& T, int nslots, int max_left, hipSt
 
 struct ProjParams {         // projection-guided search core (ORBmatcher.cc:45-129 and :1328-1470), one frame
     const orbhip_keypoint* kp; const uint8_t* desc; const float* u_right; int n;           // the Frame being searched
-    int im_w, im_h;
+    float min_x, min_y, max_x, max_y;                                   // Frame::mnMinX .. mnMaxY (Frame.cc:436-464)
     const int* grid_start; const int* grid_items; const float2* grid_xy;                   // 64x48 grid over ALL keypoints
     const orbhip_proj_query* q; const uint8_t* qdesc; int nq;
     unsigned* cand; int* ncand; int cand_stride;                                            // per query: i2 | dist<<19 | level<<28, reference order
@@ -135,6 +135,13 @@ void orbhip_launch_describe(const ExtractParams& P, int nframes, hipStream_t s);
 size_t orbhip_quadtree_lds_bytes(int maxn, int maxcells);
 int orbhip_quadtree_scr(int maxn, int maxcells);
 void* orbhip_nn_workspace(size_t bytes, hipStream_t s);
+
+// camera geometry kernels (orbhip_kernels_geom.hip)
+struct CameraD { double fx, fy, cx, cy, ifx, ify, k1, k2, p1, p2, k3; };       // mK / mDistCoef widened like cvUndistortPoints does
+void orbhip_launch_undistort_points(const CameraD& C, const float* d_xy, int n, float* d_out, hipStream_t s);
+void orbhip_launch_undistort_keys(const CameraD& C, const orbhip_keypoint* kp, const int* n, orbhip_keypoint* kp_un, int cap, int nslots, hipStream_t s);
+void orbhip_launch_remap(const uint8_t* src, long long src_frame_stride, int src_row_stride, int src_w, int src_h, const float* map_x, const float* map_y,
+                         uint8_t* dst, long long dst_frame_stride, int dst_pitch, int w, int h, int nframes, hipStream_t s);
 
 void orbhip_launch_hamming_nn(const uint8_t* d_q, int nq, const uint8_t* d_db, long long ndb, long long base,
                               long long* d_best_idx, int* d_best_dist, int* d_second, hipStream_t s);

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void k_match_grid(MatchParams M, float gwInv, 
     // filtering a cell keeps the relative order of its entries, so the buckets are built from level-0 keypoints only.
     for (int i = tid; i < n2; i += 256) {
         if (!M.grid_all_levels && kp[i].octave != 0) continue;
-        const int px = (int)roundf(__fmul_rn(__fsub_rn(kp[i].x, 0.0f), gwInv)), py = (int)roundf(__fmul_rn(__fsub_rn(kp[i].y, 0.0f), ghInv));
+        const int px = (int)roundf(__fmul_rn(__fsub_rn(kp[i].x, M.min_x), gwInv)), py = (int)roundf(__fmul_rn(__fsub_rn(kp[i].y, M.min_y), ghInv));
         if (px < 0 || px >= ORBHIP_GRID_COLS || py < 0 || py >= ORBHIP_GRID_ROWS) continue;
         atomicAdd(&s_cnt[px * ORBHIP_GRID_ROWS + py], 1);
     }
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void k_match_grid(MatchParams M, float gwInv, 
     __syncthreads();
     for (int i = tid; i < n2; i += 256) {
         if (!M.grid_all_levels && kp[i].octave != 0) continue;
-        const int px = (int)roundf(__fmul_rn(__fsub_rn(kp[i].x, 0.0f), gwInv)), py = (int)roundf(__fmul_rn(__fsub_rn(kp[i].y, 0.0f), ghInv));
+        const int px = (int)roundf(__fmul_rn(__fsub_rn(kp[i].x, M.min_x), gwInv)), py = (int)roundf(__fmul_rn(__fsub_rn(kp[i].y, M.min_y), ghInv));
         if (px < 0 || px >= ORBHIP_GRID_COLS || py < 0 || py >= ORBHIP_GRID_ROWS) continue;
         gitems[atomicAdd(&s_cnt[px * ORBHIP_GRID_ROWS + py], 1)] = i;
     }
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void k_match_grid(MatchParams M, float gwInv, 
 
 void orbhip_launch_match_grid(const MatchParams& M, int nslots, hipStream_t s)
 {
-    const float gwInv = (float)ORBHIP_GRID_COLS / (float)((float)M.im_w - 0.0f), ghInv = (float)ORBHIP_GRID_ROWS / (float)((float)M.im_h - 0.0f);   // Frame.cc:101-102
+    const float gwInv = (float)ORBHIP_GRID_COLS / (float)(M.max_x - M.min_x), ghInv = (float)ORBHIP_GRID_ROWS / (float)(M.max_y - M.min_y);   // Frame.cc:101-102
     hipLaunchKernelGGL(k_match_grid, dim3(nslots, 1, 1), dim3(256, 1, 1), 0, s, M, gwInv, ghInv);
 }
 
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void k_match_candidates(MatchParams M, float g
 
 void orbhip_launch_match_candidates(const MatchParams& M, int nslots, hipStream_t s)
 {
-    const float gwInv = (float)ORBHIP_GRID_COLS / (float)((float)M.im_w - 0.0f), ghInv = (float)ORBHIP_GRID_ROWS / (float)((float)M.im_h - 0.0f);
+    const float gwInv = (float)ORBHIP_GRID_COLS / (float)(M.max_x - M.min_x), ghInv = (float)ORBHIP_GRID_ROWS / (float)(M.max_y - M.min_y);
     hipLaunchKernelGGL(k_match_candidates, dim3((M.lvl0_cap + 3) / 4, nslots, 1), dim3(256, 1, 1), 0, s, M, gwInv, ghInv);
 }
 

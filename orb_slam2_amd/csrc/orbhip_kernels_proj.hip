@@ -28,10 +28,10 @@ __global__ __launch_bounds__(256) void k_proj_candidates(ProjParams J, float gwI
     const float x = q.x, y = q.y, r = q.radius;
     const bool check_levels = (q.min_level > 0) || (q.max_level >= 0);                   // Frame.cc:350
     int nc = 0;
-    const int minCX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, 0.0f), r), gwInv)));
-    const int maxCX = min(ORBHIP_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, 0.0f), r), gwInv)));
-    const int minCY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, 0.0f), r), ghInv)));
-    const int maxCY = min(ORBHIP_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, 0.0f), r), ghInv)));
+    const int minCX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, J.min_x), r), gwInv)));
+    const int maxCX = min(ORBHIP_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, J.min_x), r), gwInv)));
+    const int minCY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, J.min_y), r), ghInv)));
+    const int maxCY = min(ORBHIP_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, J.min_y), r), ghInv)));
     if (minCX < ORBHIP_GRID_COLS && maxCX >= 0 && minCY < ORBHIP_GRID_ROWS && maxCY >= 0 && maxCX >= minCX && maxCY >= minCY) {
         const int ny = maxCY - minCY + 1, ncell = (maxCX - minCX + 1) * ny;
         for (int cb = 0; cb < ncell; cb += 64) {
@@ -205,7 +205,7 @@ size_t orbhip_proj_select_lds(int n) { return sizeof(int) * ((size_t)3 * n + 4 *
 
 void orbhip_launch_proj(const ProjParams& J, hipStream_t s)
 {
-    const float gwInv = (float)ORBHIP_GRID_COLS / (float)((float)J.im_w - 0.0f), ghInv = (float)ORBHIP_GRID_ROWS / (float)((float)J.im_h - 0.0f);
+    const float gwInv = (float)ORBHIP_GRID_COLS / (float)(J.max_x - J.min_x), ghInv = (float)ORBHIP_GRID_ROWS / (float)(J.max_y - J.min_y);
     if (J.nq > 0) hipLaunchKernelGGL(k_proj_candidates, dim3((J.nq + 3) / 4, 1, 1), dim3(256, 1, 1), 0, s, J, gwInv, ghInv);
     hipLaunchKernelGGL(k_proj_select, dim3(1, 1, 1), dim3(PJ_T, 1, 1), orbhip_proj_select_lds(J.n), s, J);
 }

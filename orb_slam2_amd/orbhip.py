@@ -29,11 +29,42 @@ SYMBOLS = [
     "orbhip_compute_stereo_matches", "orbhip_search_by_projection", "orbhip_extract_batch_color",
     "orbhip_extract_device_color", "orbhip_voc_load_text", "orbhip_voc_destroy", "orbhip_voc_info", "orbhip_voc_transform_features",
     "orbhip_voc_transform", "orbhip_compute_bow", "orbhip_fetch_bow", "orbhip_voc_score", "orbhip_search_by_bow", "orbhip_search_for_triangulation", "orbhip_search_best_in_window",
+    "orbhip_undistort_points", "orbhip_image_bounds", "orbhip_set_camera", "orbhip_get_bounds", "orbhip_fetch_undistorted",
+    "orbhip_search_for_initialization_bounds", "orbhip_search_by_projection_bounds", "orbhip_search_best_in_window_bounds",
+    "orbhip_set_rectification", "orbhip_extract_batch_rectify", "orbhip_extract_device_rectify",
 ]
 
 
 class OrbHipError(RuntimeError):
     pass
+
+
+class Camera(C.Structure):          # orbhip_camera: mK (Tracking.cc:60-68) + mDistCoef (Tracking.cc:70-82)
+    _fields_ = [(n, C.c_float) for n in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3")]
+
+    @staticmethod
+    def of(camera):
+        """(fx, fy, cx, cy, k1, k2, p1, p2[, k3]) or a Camera"""
+        if isinstance(camera, Camera):
+            return camera
+        c = [float(v) for v in camera]
+        assert len(c) in (8, 9), "camera = (fx, fy, cx, cy, k1, k2, p1, p2[, k3])"
+        return Camera(*(c + [0.0])[:9])
+
+
+class Bounds(C.Structure):          # orbhip_bounds: Frame::mnMinX, mnMinY, mnMaxX, mnMaxY
+    _fields_ = [(n, C.c_float) for n in ("min_x", "min_y", "max_x", "max_y")]
+
+    @staticmethod
+    def of(bounds, im_w=None, im_h=None):
+        if isinstance(bounds, Bounds):
+            return bounds
+        if bounds is None:
+            return Bounds(0.0, 0.0, float(im_w), float(im_h))
+        return Bounds(*[float(v) for v in bounds])
+
+    def array(self):
+        return np.array([self.min_x, self.min_y, self.max_x, self.max_y], np.float32)
 
 
 class Config(C.Structure):
@@ -87,6 +118,17 @@ def lib(path=None):
     L.orbhip_search_for_triangulation.argtypes = [C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int,
                                                   vp, C.c_float, C.c_float, vp, vp, C.c_int, C.c_int, C.c_int, vp, ip]
     L.orbhip_search_best_in_window.argtypes = [C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp]
+    L.orbhip_undistort_points.argtypes = [C.c_int, C.POINTER(Camera), vp, C.c_int, vp]
+    L.orbhip_image_bounds.argtypes = [C.c_int, C.POINTER(Camera), C.c_int, C.c_int, C.POINTER(Bounds)]
+    L.orbhip_set_camera.argtypes = [vp, C.POINTER(Camera)]
+    L.orbhip_get_bounds.argtypes = [vp, C.POINTER(Bounds)]
+    L.orbhip_fetch_undistorted.argtypes = [vp, C.c_int, vp, C.c_int]
+    L.orbhip_search_for_initialization_bounds.argtypes = [C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.POINTER(Bounds), vp, vp, C.c_int, C.c_float, C.c_int, ip]
+    L.orbhip_search_by_projection_bounds.argtypes = [C.c_int, vp, vp, vp, vp, C.c_int, C.POINTER(Bounds), vp, vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, vp, ip]
+    L.orbhip_search_best_in_window_bounds.argtypes = [C.c_int, vp, vp, vp, C.c_int, C.POINTER(Bounds), vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp]
+    L.orbhip_set_rectification.argtypes = [vp, vp, vp, C.c_int, C.c_int]
+    L.orbhip_extract_batch_rectify.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp]
+    L.orbhip_extract_device_rectify.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]
     L.orbhip_sync.argtypes = [vp]
     L.orbhip_fetch.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp]
     L.orbhip_fetch_matches.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
@@ -223,6 +265,54 @@ class ORBextractor:
                "orbhip_extract_batch_color")
         return [kps[f, :nout[f]].copy() for f in range(n)], [desc[f, :nout[f]].copy() for f in range(n)]
 
+    # ---- distorted cameras / rectification
+    def set_camera(self, camera):
+        """camera = (fx, fy, cx, cy, k1, k2, p1, p2[, k3]) or None.  With k1 != 0 every extraction also produces mvKeysUn
+        (Frame::UndistortKeyPoints) and the pipeline matcher works on it inside the undistorted image bounds."""
+        cam = None if camera is None else Camera.of(camera)
+        _check(self.L.orbhip_set_camera(self.h, None if cam is None else C.byref(cam)), "orbhip_set_camera", self.L)
+
+    def bounds(self):
+        """(mnMinX, mnMinY, mnMaxX, mnMaxY) of Frame::ComputeImageBounds for the attached camera"""
+        b = Bounds()
+        _check(self.L.orbhip_get_bounds(self.h, C.byref(b)), "orbhip_get_bounds", self.L)
+        return b.array()
+
+    def fetch_undistorted(self, nimg, counts):
+        """mvKeysUn of the last call's first nimg frames (counts = the key point counts orbhip_fetch reported)"""
+        cap = self.capacity
+        un = np.zeros((nimg, cap), KEYPOINT_DTYPE)
+        _check(self.L.orbhip_fetch_undistorted(self.h, nimg, _p(un), cap), "orbhip_fetch_undistorted", self.L)
+        return [un[f, :counts[f]].copy() for f in range(nimg)]
+
+    def set_rectification(self, map_x, map_y, src_w, src_h):
+        """CV_32FC1 maps [height, width] of cv::initUndistortRectifyMap (stereo_euroc.cc:97-98); None removes them"""
+        if map_x is None:
+            _check(self.L.orbhip_set_rectification(self.h, None, None, 0, 0), "orbhip_set_rectification", self.L)
+            self.src_w = self.src_h = 0
+            return
+        mx = np.ascontiguousarray(map_x, np.float32); my = np.ascontiguousarray(map_y, np.float32)
+        assert mx.shape == (self.height, self.width) and my.shape == mx.shape
+        _check(self.L.orbhip_set_rectification(self.h, _p(mx), _p(my), src_w, src_h), "orbhip_set_rectification", self.L)
+        self.src_w, self.src_h = src_w, src_h
+
+    def extract_batch_rectify(self, raw_images):
+        """RAW (unrectified) gray frames [src_h, src_w]; cv::remap of stereo_euroc.cc:136-137 runs on the device"""
+        n = len(raw_images)
+        assert 1 <= n <= self.max_batch
+        imgs = [np.ascontiguousarray(im, np.uint8) for im in raw_images]
+        for im in imgs:
+            assert im.shape == (self.src_h, self.src_w), (im.shape, (self.src_h, self.src_w))
+        ptrs = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
+        cap = self.capacity
+        kps = np.zeros((n, cap), KEYPOINT_DTYPE); desc = np.zeros((n, cap, 32), np.uint8); nout = np.zeros(n, np.int32)
+        _check(self.L.orbhip_extract_batch_rectify(self.h, n, ptrs, self.src_w, _p(kps), _p(desc), cap, _p(nout)), "orbhip_extract_batch_rectify", self.L)
+        return [kps[f, :nout[f]].copy() for f in range(n)], [desc[f, :nout[f]].copy() for f in range(n)]
+
+    def extract_device_rectify(self, dptr, nimg, frame_stride, row_stride, match_prev=False, window=100, nnratio=0.9, check_ori=True):
+        _check(self.L.orbhip_extract_device_rectify(self.h, nimg, C.c_void_p(dptr), frame_stride, row_stride, int(match_prev), window,
+                                                    nnratio, int(check_ori)), "orbhip_extract_device_rectify", self.L)
+
     def mvImagePyramid(self, level, frame=0):
         w, h = self.level_size(level)
         out = np.zeros((h, w), np.uint8)
@@ -315,8 +405,9 @@ class ORBmatcher:
         assert a.size == 32 and b.size == 32
         return lib(library).orbhip_descriptor_distance(_p(a), _p(b))
 
-    def SearchForInitialization(self, kps1, desc1, kps2, desc2, im_w, im_h, vbPrevMatched=None, windowSize=10):
-        """F1/F2 are passed as (mvKeysUn, mDescriptors) + the image bounds.  Returns (nmatches, vnMatches12, vbPrevMatched)."""
+    def SearchForInitialization(self, kps1, desc1, kps2, desc2, im_w, im_h, vbPrevMatched=None, windowSize=10, bounds=None):
+        """F1/F2 are passed as (mvKeysUn, mDescriptors) + the image bounds (bounds = (mnMinX, mnMinY, mnMaxX, mnMaxY) of a distorted
+        camera, default the whole im_w x im_h image).  Returns (nmatches, vnMatches12, vbPrevMatched)."""
         kps1 = np.ascontiguousarray(kps1)
         kps2 = np.ascontiguousarray(kps2)
         desc1 = np.ascontiguousarray(desc1, np.uint8)
@@ -326,9 +417,15 @@ class ORBmatcher:
         prev = np.ascontiguousarray(vbPrevMatched, np.float32).copy()
         m12 = np.full(max(len(kps1), 1), -1, np.int32)
         nm = C.c_int()
-        _check(self.L.orbhip_search_for_initialization(self.device, _p(kps1), _p(desc1), len(kps1), _p(kps2), _p(desc2), len(kps2),
-                                                       im_w, im_h, _p(prev), _p(m12), windowSize, self.nnratio, int(self.checkOri),
-                                                       C.byref(nm)), "orbhip_search_for_initialization")
+        if bounds is None:
+            _check(self.L.orbhip_search_for_initialization(self.device, _p(kps1), _p(desc1), len(kps1), _p(kps2), _p(desc2), len(kps2),
+                                                           im_w, im_h, _p(prev), _p(m12), windowSize, self.nnratio, int(self.checkOri),
+                                                           C.byref(nm)), "orbhip_search_for_initialization", self.L)
+        else:
+            b = Bounds.of(bounds)
+            _check(self.L.orbhip_search_for_initialization_bounds(self.device, _p(kps1), _p(desc1), len(kps1), _p(kps2), _p(desc2), len(kps2),
+                                                                  C.byref(b), _p(prev), _p(m12), windowSize, self.nnratio, int(self.checkOri),
+                                                                  C.byref(nm)), "orbhip_search_for_initialization_bounds", self.L)
         return nm.value, m12[:len(kps1)], prev
 
 
@@ -337,7 +434,7 @@ PROJ_QUERY_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("radius", "<f4"), ("ur
 
 
 def search_by_projection(kps, desc, im_w, im_h, queries, query_desc, mode, nnratio=0.8, th_high=100, check_ori=True, u_right=None,
-                         blocked=None, device=0, library=None):
+                         blocked=None, device=0, library=None, bounds=None):
     """Search loop of ORBmatcher::SearchByProjection(Frame, MapPoints) (mode 0) / (Current, Last) (mode 1) on flat data.
     Returns (nmatches, feature_query int32[n])."""
     L = lib(library)
@@ -349,9 +446,15 @@ def search_by_projection(kps, desc, im_w, im_h, queries, query_desc, mode, nnrat
     bl = None if blocked is None else np.ascontiguousarray(blocked, np.uint8)
     fq = np.full(max(len(kps), 1), -1, np.int32)
     nm = C.c_int()
-    _check(L.orbhip_search_by_projection(device, _p(kps), _p(desc), None if ur is None else _p(ur), None if bl is None else _p(bl), len(kps), im_w, im_h,
-                                         _p(queries), _p(query_desc), len(queries), mode, nnratio, th_high, int(check_ori), _p(fq), C.byref(nm)),
-           "orbhip_search_by_projection", L)
+    if bounds is None:
+        _check(L.orbhip_search_by_projection(device, _p(kps), _p(desc), None if ur is None else _p(ur), None if bl is None else _p(bl), len(kps), im_w, im_h,
+                                             _p(queries), _p(query_desc), len(queries), mode, nnratio, th_high, int(check_ori), _p(fq), C.byref(nm)),
+               "orbhip_search_by_projection", L)
+    else:
+        b = Bounds.of(bounds)
+        _check(L.orbhip_search_by_projection_bounds(device, _p(kps), _p(desc), None if ur is None else _p(ur), None if bl is None else _p(bl), len(kps), C.byref(b),
+                                                    _p(queries), _p(query_desc), len(queries), mode, nnratio, th_high, int(check_ori), _p(fq), C.byref(nm)),
+               "orbhip_search_by_projection_bounds", L)
     return nm.value, fq[:len(kps)]
 
 
@@ -494,7 +597,7 @@ def search_for_triangulation(desc1, kps1, has_mp1, stereo1, fv1, desc2, kps2, ha
 BEST_QUERY_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("radius", "<f4"), ("ur", "<f4"), ("level", "<i4")])
 
 
-def search_best_in_window(kps, desc, im_w, im_h, inv_level_sigma2, queries, qdesc, chi2_gate, u_right=None, device=0, library=None):
+def search_best_in_window(kps, desc, im_w, im_h, inv_level_sigma2, queries, qdesc, chi2_gate, u_right=None, device=0, library=None, bounds=None):
     """Candidate loop of ORBmatcher::Fuse / SearchBySim3 on flat data (include/orbhip.h) -> (best_idx[nq], best_dist[nq])"""
     L = lib(library)
     kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
@@ -502,6 +605,30 @@ def search_best_in_window(kps, desc, im_w, im_h, inv_level_sigma2, queries, qdes
     inv = np.ascontiguousarray(inv_level_sigma2, np.float32)
     ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
     bi = np.full(len(queries), -1, np.int32); bd = np.full(len(queries), 256, np.int32)
-    _check(L.orbhip_search_best_in_window(device, _p(kps), _p(desc), None if ur is None else _p(ur), len(kps), im_w, im_h, _p(inv), len(inv),
-                                          _p(queries), _p(qdesc), len(queries), int(chi2_gate), _p(bi), _p(bd)), "orbhip_search_best_in_window", L)
+    if bounds is None:
+        _check(L.orbhip_search_best_in_window(device, _p(kps), _p(desc), None if ur is None else _p(ur), len(kps), im_w, im_h, _p(inv), len(inv),
+                                              _p(queries), _p(qdesc), len(queries), int(chi2_gate), _p(bi), _p(bd)), "orbhip_search_best_in_window", L)
+    else:
+        b = Bounds.of(bounds)
+        _check(L.orbhip_search_best_in_window_bounds(device, _p(kps), _p(desc), None if ur is None else _p(ur), len(kps), C.byref(b), _p(inv), len(inv),
+                                                     _p(queries), _p(qdesc), len(queries), int(chi2_gate), _p(bi), _p(bd)), "orbhip_search_best_in_window_bounds", L)
     return bi, bd
+
+
+def undistort_points(camera, xy, device=0, library=None):
+    """cv::undistortPoints(xy, xy, K, D, Mat(), K) for [n,2] float points on the device (Frame.cc:421)"""
+    L = lib(library)
+    cam = Camera.of(camera)
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    out = np.zeros_like(xy)
+    _check(L.orbhip_undistort_points(device, C.byref(cam), _p(xy), len(xy), _p(out)), "orbhip_undistort_points", L)
+    return out
+
+
+def image_bounds(camera, im_w, im_h, device=0, library=None):
+    """Frame::ComputeImageBounds (Frame.cc:436-464) -> (mnMinX, mnMinY, mnMaxX, mnMaxY)"""
+    L = lib(library)
+    cam = Camera.of(camera)
+    b = Bounds()
+    _check(L.orbhip_image_bounds(device, C.byref(cam), im_w, im_h, C.byref(b)), "orbhip_image_bounds", L)
+    return b.array()

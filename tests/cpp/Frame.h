@@ -17,6 +17,15 @@ public:
         mvKeysUn = mvKeys;                                   // UndistortKeyPoints with k1 == 0 (Frame.cc:406-410)
         mnMinX = 0.0f; mnMaxX = (float)imGray.cols; mnMinY = 0.0f; mnMaxY = (float)imGray.rows;   // ComputeImageBounds (Frame.cc:455-463)
     }
+    // distorted monocular camera: Frame.cc:174-225 with UndistortKeyPoints / ComputeImageBounds forwarded to the extractor
+    Frame(const cv::Mat& imGray, ORBextractor* extractor, const cv::Mat& K, const cv::Mat& distCoef) : mpORBextractorLeft(extractor)
+    {
+        extractor->SetCamera(K, distCoef);
+        ExtractORB(0, imGray);
+        N = (int)mvKeys.size();
+        extractor->UndistortKeyPoints(mvKeysUn);
+        extractor->ComputeImageBounds(imGray.cols, imGray.rows, mnMinX, mnMaxX, mnMinY, mnMaxY);
+    }
     void ExtractORB(int flag, const cv::Mat& im) { (void)flag; (*mpORBextractorLeft)(im, cv::Mat(), mvKeys, mDescriptors); }   // Frame.cc:247-253
 
     int N;

@@ -1,6 +1,6 @@
 // Drives the drop-in classes exactly like the reference's callers do (Tracking.cc:119-125 constructs the extractor,
 // Frame::Frame calls ExtractORB, Tracking.cc:599-600 calls SearchForInitialization) and dumps the results for pytest.
-// usage: test_dropin W H nfeatures in0.raw in1.raw out.bin [vocabulary.txt [threads]]
+// usage: test_dropin W H nfeatures in0.raw in1.raw out.bin [vocabulary.txt [threads|- [maps.bin]]]
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -93,6 +93,40 @@ int main(int argc, char** argv)
             for (int i = 0; i < F2.N && ok; i++) ok = !memcmp(dR.ptr(i), F2.mDescriptors.ptr(i), 32);
         }
         fwrite(&ok, 4, 1, f);
+    }
+    // distorted monocular camera (TUM1.yaml scaled to the test image) and raw stereo input rectified on the device
+    if (argc > 9) {
+        cv::Mat K(3, 3, CV_32F), D(5, 1, CV_32F);
+        for (int i = 0; i < 9; i++) K.at<float>(i / 3, i % 3) = 0.0f;
+        K.at<float>(0, 0) = 517.306408f * W / 640; K.at<float>(1, 1) = 516.469215f * H / 480; K.at<float>(0, 2) = 318.643040f * W / 640; K.at<float>(1, 2) = 255.313989f * H / 480; K.at<float>(2, 2) = 1.0f;
+        const float d5[5] = {0.262383f, -0.953104f, -0.005358f, 0.002628f, 1.163314f};
+        for (int i = 0; i < 5; i++) D.at<float>(i, 0) = d5[i];
+        ORB_SLAM2::ORBextractor* exD = new ORB_SLAM2::ORBextractor(N, 1.2f, 8, 20, 7);
+        ORB_SLAM2::Frame D1(im[0], exD, K, D), D2(im[1], exD, K, D);
+        std::vector<cv::Point2f> prevD(D1.mvKeysUn.size());
+        for (size_t i = 0; i < prevD.size(); i++) prevD[i] = D1.mvKeysUn[i].pt;
+        std::vector<int> matchesD;
+        const int nmD = matcher.SearchForInitialization(D1, D2, prevD, matchesD, 100);
+        int nd1 = D1.N, nd2 = D2.N; fwrite(&nd1, 4, 1, f); fwrite(&nd2, 4, 1, f);
+        if (nd1) fwrite(&D1.mvKeysUn[0], sizeof(cv::KeyPoint), nd1, f);
+        if (nd2) fwrite(&D2.mvKeysUn[0], sizeof(cv::KeyPoint), nd2, f);
+        const float bnd[4] = {ORB_SLAM2::Frame::mnMinX, ORB_SLAM2::Frame::mnMinY, ORB_SLAM2::Frame::mnMaxX, ORB_SLAM2::Frame::mnMaxY}; fwrite(bnd, 4, 4, f);
+        fwrite(&nmD, 4, 1, f);
+        if (!matchesD.empty()) fwrite(&matchesD[0], 4, matchesD.size(), f);
+        delete exD;
+        // maps file: W*H floats of M1 then W*H floats of M2; the raw image is im[0]
+        cv::Mat M1(H, W, CV_32F), M2(H, W, CV_32F);
+        FILE* mf = fopen(argv[9], "rb");
+        if (!mf || fread(M1.data, 4, (size_t)W * H, mf) != (size_t)W * H || fread(M2.data, 4, (size_t)W * H, mf) != (size_t)W * H) return 5;
+        fclose(mf);
+        ORB_SLAM2::ORBextractor* exM = new ORB_SLAM2::ORBextractor(N, 1.2f, 8, 20, 7);
+        exM->SetRectification(M1, M2, W, H);
+        std::vector<cv::KeyPoint> kr; cv::Mat dr;
+        exM->ExtractRectified(im[0], kr, dr);
+        int nr = (int)kr.size(); fwrite(&nr, 4, 1, f);
+        if (nr) { fwrite(&kr[0], sizeof(cv::KeyPoint), nr, f); for (int i = 0; i < nr; i++) fwrite(dr.ptr(i), 1, 32, f); }
+        fwrite(exM->mvImagePyramid[0].data, 1, (size_t)W * H, f);
+        delete exM;
     }
     fclose(f);
     delete ex; delete exL; delete exR;

@@ -22,7 +22,13 @@ def _run(exe, tmp_path, oracle, threads=False):
         seq[k].tofile(str(tmp_path / f"in{k}.raw"))
     out = tmp_path / "out.bin"
     voc_path = os.path.join(ROOT, "tests", "golden", "voc_k6_L3_ref.txt")
-    subprocess.check_call([exe, str(w), str(h), str(n), str(tmp_path / "in0.raw"), str(tmp_path / "in1.raw"), str(out), voc_path] + (["threads"] if threads else []))
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)                      # a rectification-like warp, partly leaving the raw image
+    th = 0.015
+    mx = (w / 2 + (np.cos(th) * (xx - w / 2) - np.sin(th) * (yy - h / 2)) * 1.03 + 2.25).astype(np.float32)
+    my = (h / 2 + (np.sin(th) * (xx - w / 2) + np.cos(th) * (yy - h / 2)) * 1.03 - 1.4).astype(np.float32)
+    np.concatenate([mx.ravel(), my.ravel()]).tofile(str(tmp_path / "maps.bin"))
+    subprocess.check_call([exe, str(w), str(h), str(n), str(tmp_path / "in0.raw"), str(tmp_path / "in1.raw"), str(out), voc_path, "threads" if threads else "-",
+                           str(tmp_path / "maps.bin")])
     buf = out.read_bytes()
     off = 0
     frames = []
@@ -64,6 +70,17 @@ def _run(exe, tmp_path, oracle, threads=False):
     (nwords,) = struct.unpack_from("<I", buf, off); off += 4
     if threads:                                           # 20 rounds of concurrent left / right extraction reproduced the sequential results
         assert struct.unpack_from("<i", buf, off)[0] == 1
+        off += 4
+    nd1, nd2 = struct.unpack_from("<ii", buf, off); off += 8
+    un1 = np.frombuffer(buf, orb_slam2_amd.KEYPOINT_DTYPE, nd1, off); off += 28 * nd1
+    un2 = np.frombuffer(buf, orb_slam2_amd.KEYPOINT_DTYPE, nd2, off); off += 28 * nd2
+    bnd = np.frombuffer(buf, np.float32, 4, off); off += 16
+    (nm_d,) = struct.unpack_from("<i", buf, off); off += 4
+    m12_d = np.frombuffer(buf, np.int32, nd1, off); off += 4 * nd1
+    (nr,) = struct.unpack_from("<i", buf, off); off += 4
+    kr = np.frombuffer(buf, orb_slam2_amd.KEYPOINT_DTYPE, nr, off); off += 28 * nr
+    dr = np.frombuffer(buf, np.uint8, 32 * nr, off).reshape(nr, 32); off += 32 * nr
+    rect0 = np.frombuffer(buf, np.uint8, w * h, off).reshape(h, w); off += w * h
 
     ora = oracle.OracleExtractor(n, 1.2, 8, 20, 7)
     ref = [ora.extract(im) for im in seq]
@@ -82,6 +99,19 @@ def _run(exe, tmp_path, oracle, threads=False):
     gray = oracle.cvt_gray(np.stack([seq[0], seq[1], seq[0]], axis=-1), rgb=False)
     kco, dco = oracle.OracleExtractor(n, 1.2, 8, 20, 7).extract(gray)
     assert np.array_equal(gray0, gray) and kc.tobytes() == kco.tobytes() and np.array_equal(dc, dco)
+    # distorted camera: Frame(im, extractor, K, distCoef) -> mvKeysUn, image bounds, SearchForInitialization over them
+    cam = tuple(np.float32(v) for v in (np.float32(517.306408) * w / 640, np.float32(516.469215) * h / 480, np.float32(318.643040) * w / 640,
+                                        np.float32(255.313989) * h / 480, 0.262383, -0.953104, -0.005358, 0.002628, 1.163314))
+    U = [oracle.undistort_keypoints(cam, ref[f][0]) for f in range(2)]
+    assert un1.tobytes() == U[0].tobytes() and un2.tobytes() == U[1].tobytes()
+    assert bnd.tobytes() == oracle.image_bounds(cam, w, h).tobytes()
+    with oracle.image_bounds_set(bnd):
+        n_d, m_d, _ = oracle.search_for_initialization(U[0], ref[0][1], U[1], ref[1][1], w, h, window=100, nnratio=0.9)
+    assert nm_d == n_d and np.array_equal(m12_d, m_d) and n_d > 40
+    # raw input rectified on the device
+    rect = oracle.remap(seq[0], mx, my)
+    kro, dro = oracle.OracleExtractor(n, 1.2, 8, 20, 7).extract(rect)
+    assert np.array_equal(rect0, rect) and kr.tobytes() == kro.tobytes() and np.array_equal(dr, dro)
     ov = oracle.OracleVocabulary(voc_path)
     want = [ov.transform(ref[0][1], 4), ov.transform(ref[1][1], 4), ov.transform(ref[1][1], 4)]
     for got, exp in zip(bows, want):

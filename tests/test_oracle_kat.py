@@ -104,6 +104,60 @@ def test_cvt_gray_fixed_point(oracle):
     assert oracle.cvt_gray(px, rgb=False).tolist() == [[29, 150, 76, 255, 0, 128]]
 
 
+def test_undistort_points_known_answers(oracle):
+    """cv::undistortPoints(.., K, D, Mat(), K): hand-derivable cases of the 5-iteration inverse of the Brown model."""
+    cam = (500.0, 480.0, 320.0, 240.0, -0.2, 0.05, 0.001, -0.0005, 0.01)
+    # the principal point is a fixed point; without distortion the map is the identity for points whose normalisation is exact
+    assert oracle.undistort_points(cam, [[320.0, 240.0]]).tolist() == [[320.0, 240.0]]
+    flat = cam[:4] + (0.0, 0.0, 0.0, 0.0, 0.0)
+    pts = np.array([[320.0 + 500.0 * 0.25, 240.0 - 480.0 * 0.5], [70.0, 0.0], [0.0, 0.0]], np.float32)
+    assert oracle.undistort_points(flat, pts).tolist() == pts.tolist()
+    # one radial coefficient, point on the x axis: x' solves x = x'(1 + k1 x'^2); 5 iterations of x <- x0 / (1 + k1 x^2) in double
+    k1, x0 = 0.1, 0.5
+    x = x0
+    for _ in range(5):
+        x = x0 * (1 / (1 + k1 * (x * x)))
+    got = oracle.undistort_points((400.0, 400.0, 100.0, 100.0, k1, 0.0, 0.0, 0.0), [[100.0 + 400.0 * x0, 100.0]])
+    assert got[0, 0] == np.float32(400.0 * x + 100.0) and got[0, 1] == np.float32(100.0)
+    # re-distorting the result gives the input back (the iteration has converged well inside the image)
+    rng = np.random.default_rng(0)
+    p = np.stack([rng.uniform(170, 470, 200), rng.uniform(120, 360, 200)], axis=1).astype(np.float32)
+    u = oracle.undistort_points(cam, p).astype(np.float64)
+    xn, yn = (u[:, 0] - 320) / 500, (u[:, 1] - 240) / 480
+    r2 = xn * xn + yn * yn
+    rad = 1 + (-0.2) * r2 + 0.05 * r2 ** 2 + 0.01 * r2 ** 3
+    xd = xn * rad + 2 * 0.001 * xn * yn + (-0.0005) * (r2 + 2 * xn * xn)
+    yd = yn * rad + 0.001 * (r2 + 2 * yn * yn) + 2 * (-0.0005) * xn * yn
+    assert np.abs(xd * 500 + 320 - p[:, 0]).max() < 2e-3 and np.abs(yd * 480 + 240 - p[:, 1]).max() < 2e-3
+    # Frame::ComputeImageBounds: k1 == 0 -> the image rectangle
+    assert oracle.image_bounds(flat, 640, 480).tolist() == [0.0, 0.0, 640.0, 480.0]
+    b = oracle.image_bounds(cam, 640, 480)
+    c = oracle.undistort_points(cam, [[0, 0], [640, 0], [0, 480], [640, 480]])
+    assert b.tolist() == [min(c[0, 0], c[2, 0]), min(c[0, 1], c[1, 1]), max(c[1, 0], c[3, 0]), max(c[2, 1], c[3, 1])]
+
+
+def test_remap_fixed_point(oracle):
+    """cv::remap INTER_LINEAR 8U with CV_32FC1 maps: 5-bit fractions, (sum w p + 2^14) >> 15, constant 0 border."""
+    rng = np.random.default_rng(4)
+    src = rng.integers(0, 256, (9, 12), dtype=np.uint8)
+    yy, xx = np.mgrid[0:9, 0:12].astype(np.float32)
+    assert np.array_equal(oracle.remap(src, xx, yy), src)                                         # identity map
+    half = oracle.remap(src, xx + 0.5, yy)                                                        # a = 16: (p0 + p1 + 1) >> 1, last column reads the border
+    want = (src.astype(np.int32) + np.concatenate([src[:, 1:], np.zeros((9, 1), np.uint8)], axis=1) + 1) >> 1
+    assert np.array_equal(half, want)
+    # map quantisation: cvRound(32 m) is round-half-even -> m = 3 + 1/64 stays on pixel 3, m = 3 + 3/64 uses a = 2
+    one = lambda mx, my: int(oracle.remap(src, np.array([[mx]], np.float32), np.array([[my]], np.float32))[0, 0])
+    assert one(3 + 1 / 64, 2.0) == int(src[2, 3])
+    assert one(3 + 3 / 64, 2.0) == (30 * int(src[2, 3]) + 2 * int(src[2, 4]) + 16) >> 5
+    a, b = 7, 21                                                                                  # general bilinear case
+    p = src[4:6, 5:7].astype(np.int64)
+    acc = 32 * ((32 - b) * ((32 - a) * p[0, 0] + a * p[0, 1]) + b * ((32 - a) * p[1, 0] + a * p[1, 1]))
+    assert one(5 + a / 32, 4 + b / 32) == (acc + (1 << 14)) >> 15
+    # border: windows touching the image read 0 outside, windows entirely outside give 0
+    assert one(-0.5, 0.0) == (int(src[0, 0]) + 1) >> 1 and one(-1.0, 0.0) == 0 and one(-1.5, 3.0) == 0
+    assert one(11.0, 8.0) == int(src[8, 11]) and one(11.5, 8.5) == (int(src[8, 11]) * 256 + 512) >> 10 and one(12.0, 3.0) == 0
+
+
 def test_fast_known_corner(oracle):
     # isolated bright pixel: all 16 ring pixels are darker by exactly 100 -> corner with score 100 - 1, no other corner
     img = np.full((21, 23), 100, np.uint8)

@@ -1,0 +1,189 @@
+"""Camera geometry either side of the extractor through the C ABI:
+  output side — Frame::UndistortKeyPoints / ComputeImageBounds (Frame.cc:404-464) and the windowed searches over the undistorted
+                image bounds of a distorted monocular / RGB-D camera (TUM1-3.yaml);
+  input side  — the stereo rectification of the EuRoC example, cv::remap(raw, rect, M1, M2, INTER_LINEAR) (stereo_euroc.cc:136-137),
+                fused in front of the pyramid.
+Results must equal the oracle's restatements bit for bit (floats compared as bytes)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import orb_slam2_amd
+from orb_slam2_amd import synth
+
+TUM1 = (517.306408, 516.469215, 318.643040, 255.313989, 0.262383, -0.953104, -0.005358, 0.002628, 1.163314)      # Examples/Monocular/TUM1.yaml
+TUM2 = (520.908620, 521.007327, 325.141442, 249.701764, 0.231222, -0.784899, -0.003257, -0.000105, 0.917205)     # Examples/Monocular/TUM2.yaml
+BARREL4 = (400.0, 405.0, 322.5, 238.25, -0.28, 0.07, 0.0002, -0.0001)                                             # 4 coefficients (k3 absent)
+
+
+def _small(cam, w, h):
+    """a TUM camera scaled to a w x h test image (same distortion)"""
+    sx, sy = w / 640.0, h / 480.0
+    return (cam[0] * sx, cam[1] * sy, cam[2] * sx, cam[3] * sy) + tuple(cam[4:])
+
+
+@pytest.mark.parametrize("cam", [TUM1, TUM2, BARREL4])
+def test_undistort_points_and_bounds(backend, oracle, cam):
+    rng = np.random.default_rng(5)
+    pts = np.concatenate([rng.uniform(-40, 700, (3000, 2)), [[cam[2], cam[3]], [0, 0], [640, 480], [639.5, 0.25]]]).astype(np.float32)
+    got = orb_slam2_amd.undistort_points(cam, pts, library=backend)
+    want = oracle.undistort_points(cam, pts)
+    assert got.tobytes() == want.tobytes()
+    assert np.abs(got - pts).max() > 1.0                                            # the distortion really moves points
+    b_g = orb_slam2_amd.image_bounds(cam, 640, 480, library=backend)
+    assert b_g.tobytes() == oracle.image_bounds(cam, 640, 480).tobytes()
+    # k1 == 0 takes the undistorted branch whatever the other coefficients say (Frame.cc:438, 455-463)
+    flat = cam[:4] + (0.0,) + tuple(cam[5:])
+    assert orb_slam2_amd.image_bounds(flat, 640, 480, library=backend).tolist() == [0.0, 0.0, 640.0, 480.0]
+    assert len(orb_slam2_amd.undistort_points(cam, np.zeros((0, 2), np.float32), library=backend)) == 0
+
+
+def _device_frames(backend, host):
+    """host array -> pointer the library may read as device memory (the emulation reads host memory directly)"""
+    if backend.endswith("_emu.so"):
+        return host.ctypes.data, None
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    dptr = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dptr), host.nbytes) == 0
+    assert hip.hipMemcpy(dptr, host.ctypes.data_as(C.c_void_p), host.nbytes, 1) == 0
+    return dptr.value, hip
+
+
+def test_distorted_camera_pipeline(backend, oracle):
+    """Device-resident pipeline with a distorted camera: mvKeys unchanged, mvKeysUn = UndistortKeyPoints, and the frame-to-frame
+    matcher = SearchForInitialization on mvKeysUn inside the undistorted bounds (what Tracking::MonocularInitialization runs on TUM)."""
+    w, h, n = 384, 288, 400
+    cam = _small(TUM1, w, h)
+    seq = synth.sequence(w, h, 3, seed=77)
+    ora = oracle.OracleExtractor(n, 1.2, 8, 20, 7)
+    K = [ora.extract(im) for im in seq]
+    U = [oracle.undistort_keypoints(cam, k) for k, _ in K]
+    bounds = oracle.image_bounds(cam, w, h)
+    ex = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, max_batch=1, library=backend)
+    assert ex.bounds().tolist() == [0.0, 0.0, float(w), float(h)]
+    ex.set_camera(cam)
+    assert ex.bounds().tobytes() == bounds.tobytes()
+    pitch = w + 4
+    for t in range(3):
+        host = np.zeros((h, pitch), np.uint8); host[:, :w] = seq[t]
+        ex.sync()
+        ptr, _ = _device_frames(backend, host)
+        ex.extract_device(ptr, 1, h * pitch, pitch, match_prev=(t > 0), window=60, nnratio=0.9, check_ori=True)
+        ks, ds = ex.fetch(1)
+        assert ks[0].tobytes() == K[t][0].tobytes() and np.array_equal(ds[0], K[t][1])
+        un = ex.fetch_undistorted(1, [len(ks[0])])[0]
+        assert un.tobytes() == U[t].tobytes()
+        if t > 0:
+            m12, nm = ex.fetch_matches(1)
+            with oracle.image_bounds_set(bounds):
+                n_o, m_o, _ = oracle.search_for_initialization(U[t - 1], K[t - 1][1], U[t], K[t][1], w, h, window=60, nnratio=0.9)
+            assert nm[0] == n_o and np.array_equal(m12[0], m_o) and n_o > 40
+    # the host-buffer matcher with explicit bounds gives the same answer
+    m = orb_slam2_amd.ORBmatcher(0.9, True, library=backend)
+    n_g, m_g, p_g = m.SearchForInitialization(U[1], K[1][1], U[2], K[2][1], w, h, windowSize=60, bounds=bounds)
+    with oracle.image_bounds_set(bounds):
+        n_o, m_o, p_o = oracle.search_for_initialization(U[1], K[1][1], U[2], K[2][1], w, h, window=60, nnratio=0.9)
+    assert n_g == n_o and np.array_equal(m_g, m_o) and p_g.tobytes() == p_o.tobytes()
+    # back to an undistorted camera: mvKeysUn == mvKeys, no stale previous frame
+    ex.set_camera(None)
+    host = np.zeros((h, pitch), np.uint8); host[:, :w] = seq[0]
+    ptr, _ = _device_frames(backend, host)
+    ex.extract_device(ptr, 1, h * pitch, pitch, match_prev=True, window=60, nnratio=0.9, check_ori=True)
+    ks, _ = ex.fetch(1)
+    assert ex.fetch_undistorted(1, [len(ks[0])])[0].tobytes() == K[0][0].tobytes()
+    m12, nm = ex.fetch_matches(1)
+    assert nm[0] == 0 and len(m12[0]) == 0
+    ex.close()
+
+
+def test_windowed_searches_with_bounds(backend, oracle):
+    """SearchByProjection / Fuse-style searches on a frame of a distorted camera: grid over (mnMinX..mnMaxX) x (mnMinY..mnMaxY)"""
+    w, h, n = 480, 360, 700
+    cam = _small(TUM2, w, h)
+    seq = synth.sequence(w, h, 2, seed=41)
+    ora = oracle.OracleExtractor(n, 1.2, 8, 20, 7)
+    (kl, dl), (kc, dc) = ora.extract(seq[0]), ora.extract(seq[1])
+    kl, kc = oracle.undistort_keypoints(cam, kl), oracle.undistort_keypoints(cam, kc)
+    bounds = oracle.image_bounds(cam, w, h)
+    assert bounds[0] > 1.0 and bounds[2] < w - 1.0                                   # a grid that differs from the whole-image one
+    sf = ora.params()["scale_factors"]
+    rng = np.random.default_rng(11)
+    q = np.zeros(len(kl), oracle.PROJ_QUERY_DTYPE)
+    q["x"] = kl["x"] - 3.0 + rng.normal(0, 1.0, len(kl)).astype(np.float32)
+    q["y"] = kl["y"] - 1.0 + rng.normal(0, 1.0, len(kl)).astype(np.float32)
+    q["radius"] = (np.float32(7.0) * sf[kl["octave"]]).astype(np.float32)
+    q["ur"] = q["x"] - 10.0
+    q["min_level"], q["max_level"] = kl["octave"] - 1, kl["octave"] + 1
+    q["blocks"] = rng.random(len(kl)) < 0.9
+    q["angle"] = kl["angle"]
+    q["x"][:4] = bounds[0] - 30.0                                                     # windows left of the grid
+    q["y"][4:8] = bounds[3] + 3.0                                                     # windows straddling the bottom bound
+    for mode in (0, 1):
+        with oracle.image_bounds_set(bounds):
+            n_o, f_o = oracle.search_by_projection(kc, dc, w, h, q, dl, mode, nnratio=0.9, th_high=100, check_ori=True)
+        n_g, f_g = orb_slam2_amd.search_by_projection(kc, dc, w, h, q, dl, mode, nnratio=0.9, th_high=100, check_ori=True, bounds=bounds, library=backend)
+        assert n_g == n_o and np.array_equal(f_g, f_o) and n_o > 50
+    n_w, f_w = oracle.search_by_projection(kc, dc, w, h, q, dl, 0, nnratio=0.9, th_high=100, check_ori=True)
+    inv = (1.0 / (sf * sf)).astype(np.float32)
+    bq = np.zeros(len(kl), oracle.BEST_QUERY_DTYPE)
+    bq["x"], bq["y"], bq["ur"] = q["x"], q["y"], q["ur"]
+    bq["level"] = np.clip(kl["octave"] + rng.integers(0, 2, len(kl)), 0, 7)
+    bq["radius"] = (np.float32(3.0) * sf[bq["level"]]).astype(np.float32)
+    with oracle.image_bounds_set(bounds):
+        bi_o, bd_o = oracle.search_best_in_window(kc, dc, w, h, inv, bq, dl, True)
+    bi_g, bd_g = orb_slam2_amd.search_best_in_window(kc, dc, w, h, inv, bq, dl, True, bounds=bounds, library=backend)
+    assert np.array_equal(bi_g, bi_o) and np.array_equal(bd_g, bd_o) and int((bd_o <= 50).sum()) > 100
+    with pytest.raises(orb_slam2_amd.OrbHipError):
+        orb_slam2_amd.search_best_in_window(kc, dc, w, h, inv, bq, dl, True, bounds=(5.0, 0.0, 5.0, 10.0), library=backend)
+
+
+def _rectification_maps(w, h, src_w, src_h, seed):
+    """a smooth warp like a rectification (rotation + radial term), some of it leaving the raw image"""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    cx, cy = w / 2 + 3.3, h / 2 - 2.1
+    th = 0.021
+    dx, dy = xx - cx, yy - cy
+    r2 = (dx * dx + dy * dy) / (w * w)
+    mx = src_w / 2 + (np.cos(th) * dx - np.sin(th) * dy) * (1.0 + 0.18 * r2) * src_w / w + 1.7
+    my = src_h / 2 + (np.sin(th) * dx + np.cos(th) * dy) * (1.0 + 0.18 * r2) * src_h / h - 0.6
+    mx, my = mx.astype(np.float32), my.astype(np.float32)
+    mx[0, :8] = np.array([-2.0, -1.0, -0.5, -0.015625, src_w - 1.0, src_w - 0.5, src_w, 1e6], np.float32)          # border cases of the constant border
+    my[1, :4] = np.array([-1.0, -0.5, src_h - 1.0, src_h - 0.984375], np.float32)
+    mx[2, :64] = (np.arange(64) / 64.0 + 10.0).astype(np.float32)                                                    # every 1/64 step: ties of cvRound(32 x)
+    return mx, my
+
+
+def test_rectified_extraction(backend, oracle):
+    """Raw stereo frame -> cv::remap -> extractor, with the remap on the device: the rectified level 0 and everything behind it equal
+    the oracle's remap + extraction; host-buffer and device-resident entry points."""
+    w, h, src_w, src_h, n = 352, 264, 376, 240, 400
+    raw = [synth.frame(src_w, src_h, seed=s) for s in (5, 6)]
+    mx, my = _rectification_maps(w, h, src_w, src_h, 1)
+    rect = [oracle.remap(r, mx, my) for r in raw]
+    assert (rect[0] == 0).sum() > 50 and (rect[0] != 0).mean() > 0.8
+    ora = oracle.OracleExtractor(n, 1.2, 8, 20, 7)
+    K = [ora.extract(r) for r in rect]
+    ex = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, max_batch=2, library=backend)
+    with pytest.raises(orb_slam2_amd.OrbHipError):
+        ex.extract_device_rectify(0x1000, 1, src_w * src_h, src_w)                        # no maps yet
+    ex.set_rectification(mx, my, src_w, src_h)
+    ks, ds = ex.extract_batch_rectify(raw)
+    for f in range(2):
+        assert np.array_equal(ex.mvImagePyramid(0, frame=f), rect[f])
+        assert ks[f].tobytes() == K[f][0].tobytes() and np.array_equal(ds[f], K[f][1])
+    # device-resident raw frames at an odd address / pitch
+    pitch = src_w + 3
+    host = np.zeros(1 + 2 * src_h * pitch, np.uint8)
+    for f in range(2):
+        host[1 + f * src_h * pitch:1 + (f + 1) * src_h * pitch].reshape(src_h, pitch)[:, :src_w] = raw[1 - f]
+    ex.sync()
+    ptr, _ = _device_frames(backend, host)
+    ex.extract_device_rectify(ptr + 1, 2, src_h * pitch, pitch)
+    ks, ds = ex.fetch(2)
+    for f in range(2):
+        assert ks[f].tobytes() == K[1 - f][0].tobytes() and np.array_equal(ds[f], K[1 - f][1])
+    ex.close()

@@ -317,6 +317,41 @@ def test_search_by_sim3(ref, oracle, pair):
     assert n_r == int((m_o >= 0).sum()) and np.array_equal(m_r, m_o) and n_r > 100
 
 
+def test_distorted_camera_frames(ref, oracle, pair_oracle, emu_lib):
+    """Frame::Frame (mono) with TUM1's distortion: the reference's own UndistortKeyPoints / ComputeImageBounds / AssignFeaturesToGrid
+    / SearchForInitialization (cv::undistortPoints = the oracle's restatement) against the oracle's flat restatement with bounds —
+    and the HIP sources (emulation build) against the reference directly."""
+    w, h, n, seq, sf, K = pair_oracle
+    cam = (517.306408 * w / 640, 516.469215 * h / 480, 318.643040 * w / 640, 255.313989 * h / 480, 0.262383, -0.953104, -0.005358, 0.002628, 1.163314)
+    for dist in (cam[4:], cam[4:8]):                                          # 5 and 4 coefficient forms (Tracking.cc:70-82)
+        c = cam[:4] + tuple(dist)
+        ref.RefFrame._geometry = None
+        F = [ref.RefFrame(im, nfeatures=n, fx=c[0], fy=c[1], cx=c[2], cy=c[3], dist=dist) for im in seq]
+        bounds = ref.RefFrame.bounds()
+        assert bounds.tobytes() == oracle.image_bounds(c, w, h).tobytes()
+        U = [oracle.undistort_keypoints(c, k) for k, _ in K]
+        for f in range(2):
+            assert F[f].keys.tobytes() == K[f][0].tobytes() and F[f].keys_un.tobytes() == U[f].tobytes()
+        rng = np.random.default_rng(2)
+        with oracle.image_bounds_set(bounds):
+            for _ in range(300):
+                x, y = np.float32(rng.uniform(-40, w + 40)), np.float32(rng.uniform(-40, h + 40))
+                r, mn, mx = np.float32(rng.uniform(1, 150)), int(rng.integers(-1, 4)), int(rng.integers(-1, 8))
+                assert np.array_equal(F[1].features_in_area(x, y, r, mn, mx), oracle.features_in_area(U[1], w, h, x, y, r, mn, mx))
+            n_o, m_o, p_o = oracle.search_for_initialization(U[0], K[0][1], U[1], K[1][1], w, h, window=80, nnratio=0.9)
+        n_r, m_r, p_r = ref.search_for_initialization(F[0], F[1], window=80, nnratio=0.9, check_ori=True)
+        assert n_r == n_o and np.array_equal(m_r, m_o) and p_r.tobytes() == p_o.tobytes() and n_o > 40
+        m = orb_slam2_amd.ORBmatcher(0.9, True, library=emu_lib)
+        n_g, m_g, p_g = m.SearchForInitialization(U[0], K[0][1], U[1], K[1][1], w, h, windowSize=80, bounds=bounds)
+        assert n_g == n_r and np.array_equal(m_g, m_r) and p_g.tobytes() == p_r.tobytes()
+        assert orb_slam2_amd.image_bounds(c, w, h, library=emu_lib).tobytes() == bounds.tobytes()
+        un_g = orb_slam2_amd.undistort_points(c, np.stack([K[0][0]["x"], K[0][0]["y"]], axis=1), library=emu_lib)
+        assert un_g[:, 0].tobytes() == F[0].keys_un["x"].tobytes() and un_g[:, 1].tobytes() == F[0].keys_un["y"].tobytes()
+        for f in F:
+            f.close()
+    ref.RefFrame._geometry = None
+
+
 def test_product_equals_reference_matcher_and_stereo(ref, pair, emu_lib):
     """HIP kernel sources (emulation build) against the reference's code directly: frame-to-frame matching and stereo matching."""
     w, h, n, seq, sf, K, F = pair
