@@ -661,7 +661,9 @@ void remap_linear_8u(const View& src, const float* mapx, const float* mapy, int 
 {
     for (int y = 0; y < dh; y++)
         for (int x = 0; x < dw; x++) {
-            const int sxq = cvRoundF(mapx[(size_t)y * map_stride + x] * 32), syq = cvRoundF(mapy[(size_t)y * map_stride + x] * 32);
+            // cvRound(float) = cvtss2si: "integer indefinite" (INT_MIN) for NaN and values outside int
+            auto cvt = [](float v) -> int { return std::fabs(v) < 2147483648.0f ? cvRoundF(v) : INT_MIN; };
+            const int sxq = cvt(mapx[(size_t)y * map_stride + x] * 32), syq = cvt(mapy[(size_t)y * map_stride + x] * 32);
             const int sx = sat_short(sxq >> 5), sy = sat_short(syq >> 5), a = sxq & 31, b = syq & 31;
             int out = 0;
             if (!(sx >= src.w || sx + 1 < 0 || sy >= src.h || sy + 1 < 0)) {

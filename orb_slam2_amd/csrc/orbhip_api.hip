@@ -67,7 +67,7 @@ struct orbhip_ctx {
     int* d_grid_start = nullptr; int* d_grid_items = nullptr; float2* d_grid_xy = nullptr; unsigned* d_cand = nullptr; int* d_ncand = nullptr; float* d_prev = nullptr; int* d_m12 = nullptr; int* d_nm = nullptr;
     // camera geometry: undistorted key points of a distorted camera, rectification maps of a raw stereo camera
     orbhip_bounds bounds = {0, 0, 0, 0}; bool distorted = false; CameraD cam = {}; orbhip_keypoint* d_out_kpun[3] = {nullptr, nullptr, nullptr}; orbhip_keypoint* h_kpun = nullptr;
-    float* d_map_x = nullptr; float* d_map_y = nullptr; int src_w = 0, src_h = 0, raw_pitch = 0; uint8_t* d_raw = nullptr; uint8_t* h_raw = nullptr;
+    int* d_map_x = nullptr; int* d_map_y = nullptr; int src_w = 0, src_h = 0, raw_pitch = 0; uint8_t* d_raw = nullptr; uint8_t* h_raw = nullptr;
     // profiling
     bool prof = false; std::vector<ProfSpan> pending; std::vector<hipEvent_t> pool; double tot_ms[K_COUNT] = {0}; long long launches[K_COUNT] = {0};
 };
@@ -918,10 +918,20 @@ extern "C" orbhip_status orbhip_set_rectification(orbhip_ctx* c, const float* ma
     if (!map_x) { c->src_w = c->src_h = 0; return ORBHIP_OK; }
     if (!map_y || src_w < 1 || src_h < 1 || src_w > 32767 || src_h > 32767) return fail(ORBHIP_ERR_INVALID, "bad argument");
     HIPCHK(hipSetDevice(c->cfg.device));
-    const size_t n = (size_t)c->cfg.width * c->cfg.height;
+    const int qp = (c->cfg.width + 3) & ~3;
+    const size_t n = (size_t)qp * c->cfg.height;
     if (!c->d_map_x) { HIPCHK(dalloc(&c->d_map_x, n)); HIPCHK(dalloc(&c->d_map_y, n)); }
-    HIPCHK(hipMemcpy(c->d_map_x, map_x, n * sizeof(float), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(c->d_map_y, map_y, n * sizeof(float), hipMemcpyHostToDevice));
+    // cv::remap converts the float maps to 5 fractional bits for every image (RemapInvoker: cvRound(map * INTER_TAB_SIZE)); the maps of
+    // a camera never change, so the table is built here once.  cvRound = cvtss2si: round-half-even, INT_MIN when out of range / NaN.
+    std::vector<int> q(2 * n, 0);
+    for (int y = 0; y < c->cfg.height; y++)
+        for (int x = 0; x < c->cfg.width; x++) {
+            const float vx = map_x[(size_t)y * c->cfg.width + x] * 32.0f, vy = map_y[(size_t)y * c->cfg.width + x] * 32.0f;
+            q[(size_t)y * qp + x] = std::fabs(vx) < 2147483648.0f ? (int)lrintf(vx) : INT32_MIN;
+            q[n + (size_t)y * qp + x] = std::fabs(vy) < 2147483648.0f ? (int)lrintf(vy) : INT32_MIN;
+        }
+    HIPCHK(hipMemcpy(c->d_map_x, q.data(), n * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_map_y, q.data() + n, n * sizeof(int), hipMemcpyHostToDevice));
     if (c->d_raw && (src_w != c->src_w || src_h != c->src_h)) { (void)hipFree(c->d_raw); (void)hipHostFree(c->h_raw); c->d_raw = nullptr; c->h_raw = nullptr; }
     c->src_w = src_w; c->src_h = src_h; c->raw_pitch = (src_w + 63) & ~63;
     return ORBHIP_OK;
@@ -938,7 +948,7 @@ extern "C" orbhip_status orbhip_extract_device_rectify(orbhip_ctx* c, int nimg, 
     const size_t fbytes = (size_t)c->in_pitch * c->cfg.height;
     {
         ProfScope ps(c, K_REMAP, c->stream);
-        orbhip_launch_remap(d_raw, (long long)frame_stride, row_stride, c->src_w, c->src_h, c->d_map_x, c->d_map_y, c->d_in, (long long)fbytes, c->in_pitch,
+        orbhip_launch_remap(d_raw, (long long)frame_stride, row_stride, c->src_w, c->src_h, c->d_map_x, c->d_map_y, (c->cfg.width + 3) & ~3, c->d_in, (long long)fbytes, c->in_pitch,
                             c->cfg.width, c->cfg.height, nimg, c->stream);
     }
     HIPCHK(hipGetLastError());

@@ -62,48 +62,73 @@ void orbhip_launch_undistort_keys(const CameraD& C, const orbhip_keypoint* kp, c
 // with the fixed-point table BilinearTab_i = 32768 (1 - b/32)(1 - a/32) ... — integers 32 (32-b)(32-a) etc. — and
 // dst = (sum + 16384) >> 15 = ((32-b) ((32-a) p00 + a p01) + b ((32-a) p10 + a p11) + 512) >> 10.
 // BORDER_CONSTANT with value 0: taps outside the source read 0 (a window entirely outside gives 0).
-// Four destination pixels per thread: two 128-bit map loads, 16 byte gathers (the maps are smooth, so the taps of neighbouring
-// lanes share cache lines), one 32-bit store.  Per frame it moves 8 B of maps (L2-resident across the frames of a batch)
-// + ~1 B read + 1 B written per pixel.
+//
+// The maps are constant for a camera, so the float -> fixed-point step (OpenCV redoes it for every image) is done ONCE when the
+// maps are attached (orbhip_set_rectification, host, same cvRound): the kernel reads qx = cvRound(32 map_x), qy likewise.
+// Four destination pixels per lane: two 128-bit table loads, then per pixel two unaligned 16-bit gathers (the horizontal tap pair
+// of each source row; neighbouring lanes' taps share cache lines because rectification maps are smooth), one v_dot4 per row with
+// the packed weights (32-a, a), a two-term vertical blend; one 32-bit store.  ~18 VALU operations per pixel: the kernel is bound
+// by VALU issue and the texture-address path, not by HBM (2 B per pixel + the 8 B/pixel table, which stays in L2/MALL across the
+// frames of a batch).  A wave in which any window touches the source border takes the per-tap checked path.
 struct RemapParams {
     const uint8_t* src; long long src_frame_stride; int src_row_stride, src_w, src_h;
-    const float* map_x; const float* map_y;
+    const int* qx; const int* qy; int q_pitch;          // table rows are q_pitch ints apart (a multiple of 4: aligned 128-bit loads)
     uint8_t* dst; long long dst_frame_stride; int dst_pitch, w, h;
 };
-__device__ __forceinline__ unsigned remap_pixel(const uint8_t* src, int pitch, int sw, int sh, float mx, float my)
+typedef unsigned short u16_unaligned __attribute__((aligned(1)));
+struct alignas(16) Q4 { int x, y, z, w; };                                     // four table entries: one 128-bit load
+__device__ __forceinline__ unsigned remap_pixel_checked(const uint8_t* src, int pitch, int sw, int sh, int sxq, int syq)
 {
-    const int sxq = (int)rintf(__fmul_rn(mx, 32.0f)), syq = (int)rintf(__fmul_rn(my, 32.0f));
-    const int sx = min(max(sxq >> 5, -32768), 32767), sy = min(max(syq >> 5, -32768), 32767);
+    const int sx = min(max(sxq >> 5, -32768), 32767), sy = min(max(syq >> 5, -32768), 32767);        // saturate_cast<short>
     const int a = sxq & 31, b = syq & 31;
     if (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0) return 0u;
     const bool x0 = (unsigned)sx < (unsigned)sw, x1 = (unsigned)(sx + 1) < (unsigned)sw, y0 = (unsigned)sy < (unsigned)sh, y1 = (unsigned)(sy + 1) < (unsigned)sh;
-    const uint8_t* r0 = src + (long long)sy * pitch + sx;
-    const uint8_t* r1 = r0 + pitch;
-    const int p00 = (x0 && y0) ? r0[0] : 0, p01 = (x1 && y0) ? r0[1] : 0, p10 = (x0 && y1) ? r1[0] : 0, p11 = (x1 && y1) ? r1[1] : 0;
+    const long long o = (long long)sy * pitch + sx;
+    const int p00 = (x0 && y0) ? src[o] : 0, p01 = (x1 && y0) ? src[o + 1] : 0, p10 = (x0 && y1) ? src[o + pitch] : 0, p11 = (x1 && y1) ? src[o + pitch + 1] : 0;
     const int top = (32 - a) * p00 + a * p01, bot = (32 - a) * p10 + a * p11;
     return (unsigned)(((32 - b) * top + b * bot + 512) >> 10);
+}
+__device__ __forceinline__ unsigned remap_pixel_inside(const uint8_t* src, unsigned pitch, int sxq, int syq)
+{   // all four taps inside the source: (sx, sy) in [0, sw-2] x [0, sh-2]
+    const unsigned a = (unsigned)sxq & 31u, b = (unsigned)syq & 31u;
+    const unsigned o = (unsigned)(syq >> 5) * pitch + (unsigned)(sxq >> 5);
+    const unsigned r0 = *reinterpret_cast<const u16_unaligned*>(src + o), r1 = *reinterpret_cast<const u16_unaligned*>(src + (o + pitch));
+    const unsigned wa = a * 255u + 32u;                                        // (32 - a) | a << 8
+    const unsigned top = __builtin_amdgcn_udot4(r0, wa, 0u, false), bot = __builtin_amdgcn_udot4(r1, wa, 0u, false);
+    return (top * 32u + b * (bot - top) + 512u) >> 10;                         // (32-b) top + b bot + 512; the difference wraps mod 2^32 harmlessly
 }
 __global__ __launch_bounds__(256) void k_remap(RemapParams R)
 {
     const int x = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y, f = blockIdx.z;
-    if (x >= R.w) return;
+    const bool active = x < R.w;
     const uint8_t* src = R.src + (long long)f * R.src_frame_stride;
-    const float* mx = R.map_x + (long long)y * R.w + x;
-    const float* my = R.map_y + (long long)y * R.w + x;
+    const long long mo = (long long)y * R.q_pitch + (active ? x : 0);
+    const int* qx = R.qx + mo;
+    const int* qy = R.qy + mo;
     uint8_t* drow = R.dst + (long long)f * R.dst_frame_stride + (long long)y * R.dst_pitch + x;
-    if (x + 4 <= R.w && ((((unsigned long long)mx) | ((unsigned long long)my)) & 15ull) == 0) {
-        const float4 vx = *(const float4*)mx, vy = *(const float4*)my;
-        const unsigned g0 = remap_pixel(src, R.src_row_stride, R.src_w, R.src_h, vx.x, vy.x), g1 = remap_pixel(src, R.src_row_stride, R.src_w, R.src_h, vx.y, vy.y);
-        const unsigned g2 = remap_pixel(src, R.src_row_stride, R.src_w, R.src_h, vx.z, vy.z), g3 = remap_pixel(src, R.src_row_stride, R.src_w, R.src_h, vx.w, vy.w);
+    const bool whole = active && x + 4 <= R.w;
+    Q4 vx = {0, 0, 0, 0}, vy = {0, 0, 0, 0};
+    if (whole) { vx = *(const Q4*)qx; vy = *(const Q4*)qy; }
+    const unsigned mw = (unsigned)(R.src_w - 1) << 5, mh = (unsigned)(R.src_h - 1) << 5;      // q < (sw-1)*32  <=>  0 <= q >> 5 <= sw-2
+    const bool inside = (unsigned)vx.x < mw && (unsigned)vx.y < mw && (unsigned)vx.z < mw && (unsigned)vx.w < mw &&
+                        (unsigned)vy.x < mh && (unsigned)vy.y < mh && (unsigned)vy.z < mh && (unsigned)vy.w < mh;
+    if (__all(!active || (whole && inside))) {                                // wave-uniform
+        if (!active) return;
+        const unsigned g0 = remap_pixel_inside(src, (unsigned)R.src_row_stride, vx.x, vy.x), g1 = remap_pixel_inside(src, (unsigned)R.src_row_stride, vx.y, vy.y);
+        const unsigned g2 = remap_pixel_inside(src, (unsigned)R.src_row_stride, vx.z, vy.z), g3 = remap_pixel_inside(src, (unsigned)R.src_row_stride, vx.w, vy.w);
         *(uint32_t*)drow = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);          // dst_pitch is a multiple of 4
-    } else {
-        const int n = min(4, R.w - x);
-        for (int i = 0; i < n; i++) drow[i] = (uint8_t)remap_pixel(src, R.src_row_stride, R.src_w, R.src_h, mx[i], my[i]);
+        return;
     }
+    if (!active) return;
+    const int n = min(4, R.w - x);
+    unsigned g[4] = {0u, 0u, 0u, 0u};
+    for (int i = 0; i < n; i++) g[i] = remap_pixel_checked(src, R.src_row_stride, R.src_w, R.src_h, qx[i], qy[i]);
+    if (n == 4) *(uint32_t*)drow = g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24);
+    else for (int i = 0; i < n; i++) drow[i] = (uint8_t)g[i];
 }
-void orbhip_launch_remap(const uint8_t* src, long long src_frame_stride, int src_row_stride, int src_w, int src_h, const float* map_x, const float* map_y,
+void orbhip_launch_remap(const uint8_t* src, long long src_frame_stride, int src_row_stride, int src_w, int src_h, const int* qx, const int* qy, int q_pitch,
                          uint8_t* dst, long long dst_frame_stride, int dst_pitch, int w, int h, int nframes, hipStream_t s)
 {
-    RemapParams R{src, src_frame_stride, src_row_stride, src_w, src_h, map_x, map_y, dst, dst_frame_stride, dst_pitch, w, h};
+    RemapParams R{src, src_frame_stride, src_row_stride, src_w, src_h, qx, qy, q_pitch, dst, dst_frame_stride, dst_pitch, w, h};
     hipLaunchKernelGGL(k_remap, dim3((w + 1023) / 1024, h, nframes), dim3(256, 1, 1), 0, s, R);
 }

@@ -151,7 +151,8 @@ def _rectification_maps(w, h, src_w, src_h, seed):
     mx = src_w / 2 + (np.cos(th) * dx - np.sin(th) * dy) * (1.0 + 0.18 * r2) * src_w / w + 1.7
     my = src_h / 2 + (np.sin(th) * dx + np.cos(th) * dy) * (1.0 + 0.18 * r2) * src_h / h - 0.6
     mx, my = mx.astype(np.float32), my.astype(np.float32)
-    mx[0, :8] = np.array([-2.0, -1.0, -0.5, -0.015625, src_w - 1.0, src_w - 0.5, src_w, 1e6], np.float32)          # border cases of the constant border
+    mx[0, :8] = np.array([-2.0, -1.0, -0.5, -0.015625, src_w - 1.0, src_w - 0.5, src_w, 1e6], np.float32)
+    mx[3, :3] = np.array([1e9, -1e9, np.nan], np.float32)                                                           # cvRound saturates to INT_MIN: outside          # border cases of the constant border
     my[1, :4] = np.array([-1.0, -0.5, src_h - 1.0, src_h - 0.984375], np.float32)
     mx[2, :64] = (np.arange(64) / 64.0 + 10.0).astype(np.float32)                                                    # every 1/64 step: ties of cvRound(32 x)
     return mx, my
@@ -160,7 +161,7 @@ def _rectification_maps(w, h, src_w, src_h, seed):
 def test_rectified_extraction(backend, oracle):
     """Raw stereo frame -> cv::remap -> extractor, with the remap on the device: the rectified level 0 and everything behind it equal
     the oracle's remap + extraction; host-buffer and device-resident entry points."""
-    w, h, src_w, src_h, n = 352, 264, 376, 240, 400
+    w, h, src_w, src_h, n = 350, 264, 376, 240, 400                # a width that is not a multiple of 4: ragged row ends
     raw = [synth.frame(src_w, src_h, seed=s) for s in (5, 6)]
     mx, my = _rectification_maps(w, h, src_w, src_h, 1)
     rect = [oracle.remap(r, mx, my) for r in raw]

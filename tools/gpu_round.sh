@@ -22,6 +22,7 @@ timeout 200 python tools/db_query_rate.py > $OUT/db_query.json 2>> $OUT/bench.er
 ORBHIP_SERIAL=1 timeout 200 python bench.py --steps 20 --warmup 3 --batch 256 --no-cpu-baseline > $OUT/bench_serial_b256.json 2>> $OUT/bench.err
 timeout 200 python tools/matcher_latency.py > $OUT/matcher_latency.json 2>> $OUT/bench.err
 timeout 300 python tools/bow_rate.py > $OUT/bow_rate.json 2>> $OUT/bench.err
+timeout 300 python tools/camera_rate.py > $OUT/camera_rate.json 2>> $OUT/bench.err
 timeout 120 tools/ubench > $OUT/ubench.txt 2>&1; cat $OUT/ubench.txt
 tail -5 $OUT/pytest_gpu.log; tail -3 $OUT/smoke.log; cat $OUT/bench.json; python - <<PY
 import json
