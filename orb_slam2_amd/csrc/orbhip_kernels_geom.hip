@@ -97,38 +97,57 @@ __device__ __forceinline__ unsigned remap_pixel_inside(const uint8_t* src, unsig
     const unsigned top = __builtin_amdgcn_udot4(r0, wa, 0u, false), bot = __builtin_amdgcn_udot4(r1, wa, 0u, false);
     return (top * 32u + b * (bot - top) + 512u) >> 10;                         // (32-b) top + b bot + 512; the difference wraps mod 2^32 harmlessly
 }
+#define RM_ROWS 4                       // destination rows per workgroup: 4 x 4 pixels per lane, all table loads and gathers of a lane in flight together
 __global__ __launch_bounds__(256) void k_remap(RemapParams R)
 {
-    const int x = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y, f = blockIdx.z;
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 4, y0 = blockIdx.y * RM_ROWS, f = blockIdx.z;
     const bool active = x < R.w;
     const uint8_t* src = R.src + (long long)f * R.src_frame_stride;
-    const long long mo = (long long)y * R.q_pitch + (active ? x : 0);
-    const int* qx = R.qx + mo;
-    const int* qy = R.qy + mo;
-    uint8_t* drow = R.dst + (long long)f * R.dst_frame_stride + (long long)y * R.dst_pitch + x;
+    uint8_t* dst = R.dst + (long long)f * R.dst_frame_stride + x;
     const bool whole = active && x + 4 <= R.w;
-    Q4 vx = {0, 0, 0, 0}, vy = {0, 0, 0, 0};
-    if (whole) { vx = *(const Q4*)qx; vy = *(const Q4*)qy; }
     const unsigned mw = (unsigned)(R.src_w - 1) << 5, mh = (unsigned)(R.src_h - 1) << 5;      // q < (sw-1)*32  <=>  0 <= q >> 5 <= sw-2
-    const bool inside = (unsigned)vx.x < mw && (unsigned)vx.y < mw && (unsigned)vx.z < mw && (unsigned)vx.w < mw &&
-                        (unsigned)vy.x < mh && (unsigned)vy.y < mh && (unsigned)vy.z < mh && (unsigned)vy.w < mh;
+    Q4 vx[RM_ROWS], vy[RM_ROWS];
+    bool inside = true;
+#pragma unroll
+    for (int r = 0; r < RM_ROWS; r++) {
+        const int y = min(y0 + r, R.h - 1);                                    // rows past the image repeat the last row and are not stored
+        const long long mo = (long long)y * R.q_pitch + (active ? x : 0);
+        vx[r] = Q4{0, 0, 0, 0}; vy[r] = Q4{0, 0, 0, 0};
+        if (whole) { vx[r] = *(const Q4*)(R.qx + mo); vy[r] = *(const Q4*)(R.qy + mo); }
+    }
+#pragma unroll
+    for (int r = 0; r < RM_ROWS; r++)
+        inside = inside && (unsigned)vx[r].x < mw && (unsigned)vx[r].y < mw && (unsigned)vx[r].z < mw && (unsigned)vx[r].w < mw &&
+                 (unsigned)vy[r].x < mh && (unsigned)vy[r].y < mh && (unsigned)vy[r].z < mh && (unsigned)vy[r].w < mh;
     if (__all(!active || (whole && inside))) {                                // wave-uniform
         if (!active) return;
-        const unsigned g0 = remap_pixel_inside(src, (unsigned)R.src_row_stride, vx.x, vy.x), g1 = remap_pixel_inside(src, (unsigned)R.src_row_stride, vx.y, vy.y);
-        const unsigned g2 = remap_pixel_inside(src, (unsigned)R.src_row_stride, vx.z, vy.z), g3 = remap_pixel_inside(src, (unsigned)R.src_row_stride, vx.w, vy.w);
-        *(uint32_t*)drow = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);          // dst_pitch is a multiple of 4
+        unsigned g[RM_ROWS];
+#pragma unroll
+        for (int r = 0; r < RM_ROWS; r++) {
+            const unsigned g0 = remap_pixel_inside(src, (unsigned)R.src_row_stride, vx[r].x, vy[r].x), g1 = remap_pixel_inside(src, (unsigned)R.src_row_stride, vx[r].y, vy[r].y);
+            const unsigned g2 = remap_pixel_inside(src, (unsigned)R.src_row_stride, vx[r].z, vy[r].z), g3 = remap_pixel_inside(src, (unsigned)R.src_row_stride, vx[r].w, vy[r].w);
+            g[r] = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+        }
+#pragma unroll
+        for (int r = 0; r < RM_ROWS; r++)
+            if (y0 + r < R.h) *(uint32_t*)(dst + (long long)(y0 + r) * R.dst_pitch) = g[r];      // dst_pitch is a multiple of 4
         return;
     }
     if (!active) return;
     const int n = min(4, R.w - x);
-    unsigned g[4] = {0u, 0u, 0u, 0u};
-    for (int i = 0; i < n; i++) g[i] = remap_pixel_checked(src, R.src_row_stride, R.src_w, R.src_h, qx[i], qy[i]);
-    if (n == 4) *(uint32_t*)drow = g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24);
-    else for (int i = 0; i < n; i++) drow[i] = (uint8_t)g[i];
+    for (int r = 0; r < RM_ROWS && y0 + r < R.h; r++) {
+        const int* qx = R.qx + (long long)(y0 + r) * R.q_pitch + x;
+        const int* qy = R.qy + (long long)(y0 + r) * R.q_pitch + x;
+        uint8_t* drow = dst + (long long)(y0 + r) * R.dst_pitch;
+        unsigned g[4] = {0u, 0u, 0u, 0u};
+        for (int i = 0; i < n; i++) g[i] = remap_pixel_checked(src, R.src_row_stride, R.src_w, R.src_h, qx[i], qy[i]);
+        if (n == 4) *(uint32_t*)drow = g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24);
+        else for (int i = 0; i < n; i++) drow[i] = (uint8_t)g[i];
+    }
 }
 void orbhip_launch_remap(const uint8_t* src, long long src_frame_stride, int src_row_stride, int src_w, int src_h, const int* qx, const int* qy, int q_pitch,
                          uint8_t* dst, long long dst_frame_stride, int dst_pitch, int w, int h, int nframes, hipStream_t s)
 {
     RemapParams R{src, src_frame_stride, src_row_stride, src_w, src_h, qx, qy, q_pitch, dst, dst_frame_stride, dst_pitch, w, h};
-    hipLaunchKernelGGL(k_remap, dim3((w + 1023) / 1024, h, nframes), dim3(256, 1, 1), 0, s, R);
+    hipLaunchKernelGGL(k_remap, dim3((w + 1023) / 1024, (h + RM_ROWS - 1) / RM_ROWS, nframes), dim3(256, 1, 1), 0, s, R);
 }

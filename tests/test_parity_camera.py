@@ -161,7 +161,7 @@ def _rectification_maps(w, h, src_w, src_h, seed):
 def test_rectified_extraction(backend, oracle):
     """Raw stereo frame -> cv::remap -> extractor, with the remap on the device: the rectified level 0 and everything behind it equal
     the oracle's remap + extraction; host-buffer and device-resident entry points."""
-    w, h, src_w, src_h, n = 350, 264, 376, 240, 400                # a width that is not a multiple of 4: ragged row ends
+    w, h, src_w, src_h, n = 350, 262, 376, 240, 400                # neither a multiple of 4: ragged row ends and a ragged last row group
     raw = [synth.frame(src_w, src_h, seed=s) for s in (5, 6)]
     mx, my = _rectification_maps(w, h, src_w, src_h, 1)
     rect = [oracle.remap(r, mx, my) for r in raw]
