@@ -59,6 +59,10 @@ public:
     void SetCamera(const cv::Mat& K, const cv::Mat& distCoef);
     void UndistortKeyPoints(std::vector<cv::KeyPoint>& mvKeysUn);
     void ComputeImageBounds(int cols, int rows, float& mnMinX, float& mnMaxX, float& mnMinY, float& mnMaxY);
+    // RGB-D sensors: the body of Frame::ComputeStereoFromRGBD (Frame.cc:643-665) for the image this extractor processed last (key points
+    // and, with SetCamera, mvKeysUn are still on the device).  imDepth: CV_32F as the reference's Frame receives it (depthFactor 1), or the
+    // raw CV_16U map with mDepthMapFactor — the convertTo of Tracking::GrabImageRGBD (Tracking.cc:226-227) is then applied per key point.
+    void ComputeStereoFromRGBD(const cv::Mat& imDepth, float depthFactor, float mbf, int N, std::vector<float>& mvuRight, std::vector<float>& mvDepth);
     // Raw (unrectified) stereo input: the cv::remap(im, imRect, M1, M2, cv::INTER_LINEAR) the EuRoC example runs before TrackStereo
     // (Examples/Stereo/stereo_euroc.cc:136-137) moves onto the device.  M1 / M2: the CV_32FC1 maps of initUndistortRectifyMap
     // (stereo_euroc.cc:97-98).  ExtractRectified(raw, ..) == operator()(remap(raw), ..); mvImagePyramid[0] is the rectified image.

@@ -11,6 +11,7 @@
 
 #define CV_8U 0
 #define CV_8UC1 0
+#define CV_16U 2
 #define CV_32F 5
 
 namespace cv {
@@ -36,13 +37,13 @@ public:
     KeyPoint(float x, float y, float s, float a = -1, float r = 0, int o = 0, int c = -1) : pt(x, y), size(s), angle(a), response(r), octave(o), class_id(c) {}
 };
 
-class Mat {                 // 8-bit / 32-bit single-channel, ref-counted or borrowed storage
+class Mat {                 // 8-bit / 16-bit / 32-bit single-channel, ref-counted or borrowed storage
 public:
     int rows, cols, flags_type; size_t step; uchar* data;
     Mat() : rows(0), cols(0), flags_type(CV_8U), step(0), data(nullptr) {}
     Mat(int r, int c, int type) : Mat() { create(r, c, type); }
     Mat(int r, int c, int type, void* ext, size_t step_ = 0) : rows(r), cols(c), flags_type(type), step(step_ ? step_ : (size_t)c * elemSize1(type)), data((uchar*)ext) {}
-    static size_t elemSize1(int type) { return type == CV_32F ? 4 : 1; }
+    static size_t elemSize1(int type) { return type == CV_32F ? 4 : type == CV_16U ? 2 : 1; }
     void create(int r, int c, int type)
     {
         if (r == rows && c == cols && type == flags_type && data) return;     // like cv::Mat::create: a fitting buffer (also a view) is kept

@@ -175,6 +175,17 @@ orbhip_status orbhip_search_by_projection(int device, const orbhip_keypoint* kps
 orbhip_status orbhip_compute_stereo_matches(orbhip_ctx* left, orbhip_ctx* right, int nimg, float mbf, float mb,
                                             float* u_right, float* depth, int cap);
 
+/* -------- Frame::ComputeStereoFromRGBD (Frame.h:97-98, Frame.cc:643-665) ------------------------------ */
+/* RGB-D sensors: for the first nimg frames of the context's LAST extract call, d = imDepth(v, u) at every key point (mvKeys, the
+   distorted position, coordinates truncated like cv::Mat::at<float>(float, float)); d > 0 -> mvDepth = d, mvuRight = mvKeysUn.x - mbf / d,
+   else both -1.  mvKeysUn comes from the attached camera (orbhip_set_camera; none = mvKeys).  The depth maps are width x height like
+   the images: depth_type 0 = CV_32F, 1 = CV_16U (the TUM png files).  The imDepth.convertTo(imDepth, CV_32F, mDepthMapFactor) of
+   Tracking::GrabImageRGBD (Tracking.cc:226-227) is folded in under the reference's own condition — applied iff
+   |depth_factor - 1| > 1e-5 or the map is not CV_32F: d = (float)raw * depth_factor.  Host maps (one pointer per frame), synchronous;
+   u_right / depth are [nimg][cap]. */
+orbhip_status orbhip_compute_stereo_from_rgbd(orbhip_ctx* ctx, int nimg, const void* const* depth_maps, int stride_bytes,
+                                              int depth_type, float depth_factor, float mbf, float* u_right, float* depth, int cap);
+
 /* The candidate loop of ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th) (ORBmatcher.h:75, ORBmatcher.cc:825-972), of its
    Sim3 overload (ORBmatcher.h:78, :974-1100: the same loop without the chi-square gate) and of the two passes of
    ORBmatcher::SearchBySim3 (ORBmatcher.h:71-72, ORBmatcher.cc:1102-1326) on flat data.  The caller projects its

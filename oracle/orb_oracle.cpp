@@ -1090,6 +1090,25 @@ void orb_oracle_image_bounds(const float* K4, const float* D5, int cols, int row
         out[0] = std::min(m[0], m[4]); out[2] = std::max(m[2], m[6]); out[1] = std::min(m[1], m[3]); out[3] = std::max(m[5], m[7]);
     } else { out[0] = 0.0f; out[2] = (float)cols; out[1] = 0.0f; out[3] = (float)rows; }
 }
+// Frame::ComputeStereoFromRGBD (Frame.cc:643-665).  depth_type 0 = CV_32F, 1 = CV_16U; the conversion of Tracking::GrabImageRGBD
+// (Tracking.cc:226-227, cv::Mat::convertTo = cvtScale: dst = (float)src * scale + shift with float scale / shift) applied under the
+// reference's condition.  The conversion is an OpenCV primitive (parity unpinned, trivial); the loop is pinned against Frame.cc.
+void orb_oracle_stereo_from_rgbd(const void* keys, const void* keys_un, int n, const void* depth_map, int w, int h, int stride_bytes, int depth_type,
+                                 float depth_factor, float mbf, float* uRight, float* depth)
+{
+    const KeyPoint* mvKeys = (const KeyPoint*)keys; const KeyPoint* mvKeysUn = (const KeyPoint*)keys_un;
+    const bool convert = (fabs(depth_factor - 1.0f) > 1e-5) || depth_type != 0;
+    for (int i = 0; i < n; i++) {
+        uRight[i] = -1; depth[i] = -1;
+        const float& v = mvKeys[i].y; const float& u = mvKeys[i].x;
+        const int r = (int)v, c = (int)u;                       // cv::Mat::at<float>(int, int) called with float arguments
+        const uint8_t* row = (const uint8_t*)depth_map + (size_t)r * stride_bytes;
+        float d = depth_type == 0 ? ((const float*)row)[c] : (float)((const uint16_t*)row)[c];
+        if (convert) d = d * depth_factor + 0.0f;
+        if (d > 0) { depth[i] = d; uRight[i] = mvKeysUn[i].x - mbf / d; }
+    }
+    (void)w; (void)h;
+}
 void orb_oracle_remap(const uint8_t* src, int sw, int sh, int sstride, const float* mapx, const float* mapy, int map_stride, uint8_t* dst, int dw, int dh, int dstride)
 {
     remap_linear_8u(View{src, sw, sh, sstride}, mapx, mapy, map_stride, dst, dw, dh, dstride);

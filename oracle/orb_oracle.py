@@ -70,6 +70,7 @@ def lib(fast=False):
     L.orb_oracle_set_image_bounds.argtypes = [vp]
     L.orb_oracle_undistort_points.argtypes = [vp, vp, vp, C.c_int, vp]
     L.orb_oracle_image_bounds.argtypes = [vp, vp, C.c_int, C.c_int, vp]
+    L.orb_oracle_stereo_from_rgbd.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp, vp]
     L.orb_oracle_remap.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]
     L.orb_oracle_fast.restype = C.c_int
     L.orb_oracle_fast.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
@@ -276,6 +277,17 @@ def remap(src, map_x, map_y):
     out = np.zeros(mx.shape, np.uint8)
     lib().orb_oracle_remap(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(mx), _p(my), mx.shape[1], _p(out), mx.shape[1], mx.shape[0], mx.shape[1])
     return out
+
+
+def stereo_from_rgbd(keys, keys_un, depth_map, depth_factor, mbf):
+    """Frame::ComputeStereoFromRGBD (Frame.cc:643-665) + the convertTo of Tracking::GrabImageRGBD; depth_map float32 or uint16 [H,W]"""
+    keys = np.ascontiguousarray(keys); keys_un = np.ascontiguousarray(keys_un)
+    dm = np.ascontiguousarray(depth_map)
+    assert dm.dtype in (np.float32, np.uint16)
+    u = np.zeros(len(keys), np.float32); z = np.zeros(len(keys), np.float32)
+    lib().orb_oracle_stereo_from_rgbd(_p(keys), _p(keys_un), len(keys), _p(dm), dm.shape[1], dm.shape[0], dm.strides[0], int(dm.dtype == np.uint16),
+                                      float(depth_factor), float(mbf), _p(u), _p(z))
+    return u, z
 
 
 def gauss_kernel():

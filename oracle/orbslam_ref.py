@@ -43,6 +43,8 @@ def lib():
         L.orbslam_ref_frame_mono.argtypes = [vp, i, i, i, i, f, i, i, i, f, f, f, f, f, f, i]
         L.orbslam_ref_frame_mono_dist.restype = vp
         L.orbslam_ref_frame_mono_dist.argtypes = [vp, i, i, i, i, f, i, i, i, f, f, f, f, vp, i, f, f, i]
+        L.orbslam_ref_frame_rgbd.restype = vp
+        L.orbslam_ref_frame_rgbd.argtypes = [vp, vp, i, i, i, i, f, i, i, i, f, f, f, f, vp, i, f, f, i]
         L.orbslam_ref_frame_bounds.argtypes = [vp]
         L.orbslam_ref_frame_stereo.restype = vp
         L.orbslam_ref_frame_stereo.argtypes = [vp, vp, i, i, i, i, f, i, i, i, f, f, f, f, f, f, i]
@@ -73,13 +75,19 @@ class RefFrame:
     _geometry = None
 
     def __init__(self, img, right=None, nfeatures=1000, scale=1.2, nlevels=8, ini_th=20, min_th=7, fx=1.0, fy=1.0, cx=0.0, cy=0.0, bf=40.0, th_depth=35.0,
-                 dist=None):
+                 dist=None, depth=None):
         img = np.ascontiguousarray(img, np.uint8)
         h, w = img.shape
         geom = (w, h, fx, fy, cx, cy, None if dist is None else tuple(float(v) for v in dist))
         new = RefFrame._geometry != geom
         RefFrame._geometry = geom
-        if dist is not None:                  # distorted mono / RGB-D camera (mDistCoef, Tracking.cc:70-82)
+        if depth is not None:                 # RGB-D sensor: CV_32F depth map (already converted, Tracking.cc:226-227)
+            assert right is None
+            d = np.ascontiguousarray(np.zeros(4) if dist is None else dist, np.float32)
+            dm = np.ascontiguousarray(depth, np.float32)
+            assert dm.shape == (h, w)
+            self.h = lib().orbslam_ref_frame_rgbd(_p(img), _p(dm), w, h, img.strides[0], nfeatures, scale, nlevels, ini_th, min_th, fx, fy, cx, cy, _p(d), len(d), bf, th_depth, int(new))
+        elif dist is not None:                # distorted mono / RGB-D camera (mDistCoef, Tracking.cc:70-82)
             assert right is None
             d = np.ascontiguousarray(dist, np.float32)
             self.h = lib().orbslam_ref_frame_mono_dist(_p(img), w, h, img.strides[0], nfeatures, scale, nlevels, ini_th, min_th, fx, fy, cx, cy, _p(d), len(d), bf, th_depth, int(new))

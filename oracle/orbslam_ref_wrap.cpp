@@ -176,6 +176,16 @@ void* orbslam_ref_frame_mono_dist(const uint8_t* img, int w, int h, int stride, 
     for (int i = 0; i < ndist; i++) D.at<float>(i) = dist[i];
     return new Frame(im, 0.0, rig(nfeat, scale, nlevels, ini, mn).left, NULL, K, D, bf, thDepth);
 }
+// Frame::Frame(imGray, imDepth, ...)  (Frame.cc:117-172): RGB-D sensor, ComputeStereoFromRGBD (Frame.cc:643-665) on the CV_32F depth map
+void* orbslam_ref_frame_rgbd(const uint8_t* img, const float* depth, int w, int h, int stride, int nfeat, float scale, int nlevels, int ini, int mn,
+                             float fx, float fy, float cx, float cy, const float* dist, int ndist, float bf, float thDepth, int new_geometry)
+{
+    g_used = 0;
+    if (new_geometry) Frame::mbInitialComputations = true;
+    cv::Mat im(h, w, CV_8UC1, (void*)img, (size_t)stride), dm(h, w, CV_32F, (void*)depth), K = camera(fx, fy, cx, cy), D(ndist, 1, CV_32F);
+    for (int i = 0; i < ndist; i++) D.at<float>(i) = dist[i];
+    return new Frame(im, dm, 0.0, rig(nfeat, scale, nlevels, ini, mn).left, NULL, K, D, bf, thDepth);
+}
 void orbslam_ref_frame_bounds(float* out) { out[0] = Frame::mnMinX; out[1] = Frame::mnMinY; out[2] = Frame::mnMaxX; out[3] = Frame::mnMaxY; }
 // Frame::Frame(imLeft, imRight, ...)  (Frame.cc:62-115): two extractor threads, ComputeStereoMatches
 void* orbslam_ref_frame_stereo(const uint8_t* imgL, const uint8_t* imgR, int w, int h, int stride, int nfeat, float scale, int nlevels, int ini, int mn,

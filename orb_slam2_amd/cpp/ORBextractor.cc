@@ -125,6 +125,19 @@ void ORBextractor::ComputeImageBounds(int cols, int rows, float& mnMinX, float& 
     mnMinX = b.min_x; mnMaxX = b.max_x; mnMinY = b.min_y; mnMaxY = b.max_y;
 }
 
+void ORBextractor::ComputeStereoFromRGBD(const cv::Mat& imDepth, float depthFactor, float mbf, int N, std::vector<float>& mvuRight, std::vector<float>& mvDepth)
+{
+    mvuRight = std::vector<float>(N, -1);                        // Frame.cc:645-646
+    mvDepth = std::vector<float>(N, -1);
+    if (N == 0 || !mpCtx) return;
+    assert(imDepth.type() == CV_32F || imDepth.type() == CV_16U);
+    const void* maps[1] = {imDepth.data};
+    if (orbhip_compute_stereo_from_rgbd(mpCtx, 1, maps, (int)imDepth.step, imDepth.type() == CV_32F ? 0 : 1, depthFactor, mbf, &mvuRight[0], &mvDepth[0], N) != ORBHIP_OK) {
+        fprintf(stderr, "ORBextractor::ComputeStereoFromRGBD: %s\n", orbhip_last_error());
+        abort();
+    }
+}
+
 void ORBextractor::SetRectification(const cv::Mat& M1, const cv::Mat& M2, int rawCols, int rawRows)
 {
     assert(M1.type() == CV_32F && M2.type() == CV_32F && M1.rows == M2.rows && M1.cols == M2.cols);

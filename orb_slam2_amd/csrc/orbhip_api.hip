@@ -67,7 +67,7 @@ struct orbhip_ctx {
     int* d_grid_start = nullptr; int* d_grid_items = nullptr; float2* d_grid_xy = nullptr; unsigned* d_cand = nullptr; int* d_ncand = nullptr; float* d_prev = nullptr; int* d_m12 = nullptr; int* d_nm = nullptr;
     // camera geometry: undistorted key points of a distorted camera, rectification maps of a raw stereo camera
     orbhip_bounds bounds = {0, 0, 0, 0}; bool distorted = false; CameraD cam = {}; orbhip_keypoint* d_out_kpun[3] = {nullptr, nullptr, nullptr}; orbhip_keypoint* h_kpun = nullptr;
-    int* d_map_x = nullptr; int* d_map_y = nullptr; int src_w = 0, src_h = 0, raw_pitch = 0; uint8_t* d_raw = nullptr; uint8_t* h_raw = nullptr;
+    int* d_map_x = nullptr; int* d_map_y = nullptr; int src_w = 0, src_h = 0, raw_pitch = 0; uint8_t* d_raw = nullptr; uint8_t* h_raw = nullptr; uint8_t* d_depth = nullptr; size_t depth_bytes = 0;
     // profiling
     bool prof = false; std::vector<ProfSpan> pending; std::vector<hipEvent_t> pool; double tot_ms[K_COUNT] = {0}; long long launches[K_COUNT] = {0};
 };
@@ -182,7 +182,7 @@ extern "C" void orbhip_destroy(orbhip_ctx* c)
     if (c->h_in) (void)hipHostFree(c->h_in);
     if (c->d_col) (void)hipFree(c->d_col);
     if (c->h_col) (void)hipHostFree(c->h_col);
-    { void* g[] = {c->d_out_kpun[0], c->d_out_kpun[1], c->d_out_kpun[2], c->d_map_x, c->d_map_y, c->d_raw}; for (void* q : g) if (q) (void)hipFree(q); }
+    { void* g[] = {c->d_out_kpun[0], c->d_out_kpun[1], c->d_out_kpun[2], c->d_map_x, c->d_map_y, c->d_raw, c->d_depth}; for (void* q : g) if (q) (void)hipFree(q); }
     if (c->h_kpun) (void)hipHostFree(c->h_kpun);
     if (c->h_raw) (void)hipHostFree(c->h_raw);
     if (c->h_kp) (void)hipHostFree(c->h_kp);
@@ -908,6 +908,39 @@ extern "C" orbhip_status orbhip_fetch_undistorted(orbhip_ctx* c, int nimg, orbhi
         if (m > 0) memcpy(kps_un + (size_t)f * cap, c->h_kpun + (size_t)f * c->out_cap, (size_t)m * sizeof(orbhip_keypoint));
     }
     return overflow ? fail(ORBHIP_ERR_CAPACITY, "keypoint buffer too small") : ORBHIP_OK;
+}
+
+// Frame::ComputeStereoFromRGBD (Frame.cc:643-665) on the key points the last extraction left in HBM
+extern "C" orbhip_status orbhip_compute_stereo_from_rgbd(orbhip_ctx* c, int nimg, const void* const* depth_maps, int stride_bytes, int depth_type, float depth_factor,
+                                                         float mbf, float* u_right, float* depth, int cap)
+{
+    if (!c || !depth_maps || !u_right || !depth || cap < 0 || (depth_type != 0 && depth_type != 1)) return fail(ORBHIP_ERR_INVALID, "bad argument");
+    if (nimg < 1 || nimg > c->last_nimg) return fail(ORBHIP_ERR_INVALID, "nimg %d but the last call processed %d frames", nimg, c->last_nimg);
+    const int esz = depth_type == 0 ? 4 : 2, W = c->cfg.width, H = c->cfg.height;
+    if (stride_bytes < W * esz) return fail(ORBHIP_ERR_INVALID, "depth row stride %d < %d", stride_bytes, W * esz);
+    HIPCHK(hipSetDevice(c->cfg.device));
+    const size_t pitch = ((size_t)W * 4 + 63) & ~(size_t)63, fbytes = pitch * H, need = (size_t)c->B * fbytes + (size_t)2 * c->B * c->out_cap * sizeof(float);
+    if (c->depth_bytes < need) { if (c->d_depth) (void)hipFree(c->d_depth); c->d_depth = nullptr; c->depth_bytes = 0; HIPCHK(hipMalloc((void**)&c->d_depth, need)); c->depth_bytes = need; }
+    float* d_u = (float*)(c->d_depth + (size_t)c->B * fbytes); float* d_z = d_u + (size_t)c->B * c->out_cap;
+    for (int f = 0; f < nimg; f++) {
+        if (!depth_maps[f]) return fail(ORBHIP_ERR_INVALID, "depth map %d is null", f);
+        HIPCHK(hipMemcpy2DAsync(c->d_depth + f * fbytes, pitch, depth_maps[f], (size_t)stride_bytes, (size_t)W * esz, H, hipMemcpyHostToDevice, c->stream));
+    }
+    const int convert = (std::fabs(depth_factor - 1.0f) > 1e-5f) || depth_type != 0;          // Tracking.cc:226
+    orbhip_launch_stereo_from_rgbd(c->d_out_kp[c->cur], (c->distorted ? c->d_out_kpun : c->d_out_kp)[c->cur], c->d_out_n[c->cur], c->out_cap, c->d_depth, (long long)fbytes,
+                                   (int)pitch, depth_type, convert, depth_factor, mbf, d_u, d_z, nimg, c->stream);
+    HIPCHK(hipGetLastError());
+    orbhip_status st = ensure_host_staging(c, false); if (st != ORBHIP_OK) return st;
+    HIPCHK(hipMemcpyAsync(c->h_n, c->d_out_n[c->cur], nimg * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    st = orbhip_sync(c); if (st != ORBHIP_OK) return st;
+    for (int f = 0; f < nimg; f++) {
+        const int m = std::min(c->h_n[f], cap);
+        if (m > 0) {
+            HIPCHK(hipMemcpy(u_right + (size_t)f * cap, d_u + (size_t)f * c->out_cap, (size_t)m * sizeof(float), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(depth + (size_t)f * cap, d_z + (size_t)f * c->out_cap, (size_t)m * sizeof(float), hipMemcpyDeviceToHost));
+        }
+    }
+    return ORBHIP_OK;
 }
 
 // Rectification of raw stereo frames (stereo_euroc.cc:136-137): remapped on the device into the context's level-0 plane

@@ -140,6 +140,8 @@ void* orbhip_nn_workspace(size_t bytes, hipStream_t s);
 struct CameraD { double fx, fy, cx, cy, ifx, ify, k1, k2, p1, p2, k3; };       // mK / mDistCoef widened like cvUndistortPoints does
 void orbhip_launch_undistort_points(const CameraD& C, const float* d_xy, int n, float* d_out, hipStream_t s);
 void orbhip_launch_undistort_keys(const CameraD& C, const orbhip_keypoint* kp, const int* n, orbhip_keypoint* kp_un, int cap, int nslots, hipStream_t s);
+void orbhip_launch_stereo_from_rgbd(const orbhip_keypoint* kp, const orbhip_keypoint* kp_un, const int* n, int cap, const uint8_t* depth, long long frame_stride,
+                                    int row_stride, int type, int convert, float factor, float mbf, float* u_right, float* out_depth, int nslots, hipStream_t s);
 void orbhip_launch_remap(const uint8_t* src, long long src_frame_stride, int src_row_stride, int src_w, int src_h, const int* qx, const int* qy, int q_pitch,
                          uint8_t* dst, long long dst_frame_stride, int dst_pitch, int w, int h, int nframes, hipStream_t s);
 

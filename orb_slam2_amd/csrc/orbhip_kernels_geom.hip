@@ -56,6 +56,36 @@ void orbhip_launch_undistort_keys(const CameraD& C, const orbhip_keypoint* kp, c
     if (nslots > 0 && cap > 0) hipLaunchKernelGGL(k_undistort_keys, dim3((cap + 255) / 256, nslots, 1), dim3(256, 1, 1), 0, s, C, kp, n, kp_un, cap);
 }
 
+// ------------------------------------------------------------------------------------------------ Frame::ComputeStereoFromRGBD
+// Frame.cc:643-665 over camera slots, with the depth-map conversion of Tracking::GrabImageRGBD (Tracking.cc:226-227: OpenCV's
+// cvtScale, dst = (float)src * scale + 0) applied to the one pixel each key point reads instead of to the whole map.
+struct RgbdParams {
+    const orbhip_keypoint* kp; const orbhip_keypoint* kp_un; const int* n; int cap;
+    const uint8_t* depth; long long frame_stride; int row_stride, type, convert; float factor, mbf;
+    float* u_right; float* out_depth;
+};
+__global__ __launch_bounds__(256) void k_stereo_from_rgbd(RgbdParams G)
+{
+    const int slot = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= G.cap) return;
+    float ur = -1.0f, dz = -1.0f;                                              // mvuRight = vector<float>(N,-1)  (Frame.cc:645-646)
+    if (i < G.n[slot]) {
+        const orbhip_keypoint k = G.kp[(long long)slot * G.cap + i];
+        const int v = (int)k.y, u = (int)k.x;                                  // imDepth.at<float>(v,u) with float arguments: truncation
+        const uint8_t* row = G.depth + (long long)slot * G.frame_stride + (long long)v * G.row_stride;
+        float d = G.type == 0 ? ((const float*)row)[u] : (float)((const unsigned short*)row)[u];
+        if (G.convert) d = __fadd_rn(__fmul_rn(d, G.factor), 0.0f);
+        if (d > 0) { dz = d; ur = __fsub_rn(G.kp_un[(long long)slot * G.cap + i].x, __fdiv_rn(G.mbf, d)); }
+    }
+    G.u_right[(long long)slot * G.cap + i] = ur; G.out_depth[(long long)slot * G.cap + i] = dz;
+}
+void orbhip_launch_stereo_from_rgbd(const orbhip_keypoint* kp, const orbhip_keypoint* kp_un, const int* n, int cap, const uint8_t* depth, long long frame_stride,
+                                    int row_stride, int type, int convert, float factor, float mbf, float* u_right, float* out_depth, int nslots, hipStream_t s)
+{
+    RgbdParams G{kp, kp_un, n, cap, depth, frame_stride, row_stride, type, convert, factor, mbf, u_right, out_depth};
+    if (nslots > 0 && cap > 0) hipLaunchKernelGGL(k_stereo_from_rgbd, dim3((cap + 255) / 256, nslots, 1), dim3(256, 1, 1), 0, s, G);
+}
+
 // ------------------------------------------------------------------------------------------------ cv::remap, INTER_LINEAR, 8UC1
 // OpenCV 3.2 imgproc/imgwarp.cpp, CV_32FC1 map pair: sx = cvRound(map_x * 32), sy = cvRound(map_y * 32) (round-half-even; the
 // product by 32 is exact), integer parts sx >> 5 / sy >> 5 saturated to short, 5-bit fractions a, b; the four taps are weighted

@@ -31,7 +31,7 @@ SYMBOLS = [
     "orbhip_voc_transform", "orbhip_compute_bow", "orbhip_fetch_bow", "orbhip_voc_score", "orbhip_search_by_bow", "orbhip_search_for_triangulation", "orbhip_search_best_in_window",
     "orbhip_undistort_points", "orbhip_image_bounds", "orbhip_set_camera", "orbhip_get_bounds", "orbhip_fetch_undistorted",
     "orbhip_search_for_initialization_bounds", "orbhip_search_by_projection_bounds", "orbhip_search_best_in_window_bounds",
-    "orbhip_set_rectification", "orbhip_extract_batch_rectify", "orbhip_extract_device_rectify",
+    "orbhip_set_rectification", "orbhip_extract_batch_rectify", "orbhip_extract_device_rectify", "orbhip_compute_stereo_from_rgbd",
 ]
 
 
@@ -129,6 +129,7 @@ def lib(path=None):
     L.orbhip_set_rectification.argtypes = [vp, vp, vp, C.c_int, C.c_int]
     L.orbhip_extract_batch_rectify.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp]
     L.orbhip_extract_device_rectify.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]
+    L.orbhip_compute_stereo_from_rgbd.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_float, C.c_float, vp, vp, C.c_int]
     L.orbhip_sync.argtypes = [vp]
     L.orbhip_fetch.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp]
     L.orbhip_fetch_matches.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
@@ -312,6 +313,19 @@ class ORBextractor:
     def extract_device_rectify(self, dptr, nimg, frame_stride, row_stride, match_prev=False, window=100, nnratio=0.9, check_ori=True):
         _check(self.L.orbhip_extract_device_rectify(self.h, nimg, C.c_void_p(dptr), frame_stride, row_stride, int(match_prev), window,
                                                     nnratio, int(check_ori)), "orbhip_extract_device_rectify", self.L)
+
+    def ComputeStereoFromRGBD(self, depth_maps, depth_factor, mbf):
+        """Frame::ComputeStereoFromRGBD for the frames of the last call; depth_maps: float32 or uint16 [H,W] arrays (the conversion of
+        Tracking::GrabImageRGBD is folded in).  Returns (mvuRight[nimg, cap], mvDepth[nimg, cap])."""
+        n = len(depth_maps)
+        dms = [np.ascontiguousarray(d) for d in depth_maps]
+        assert all(d.dtype == dms[0].dtype and d.shape == (self.height, self.width) for d in dms) and dms[0].dtype in (np.float32, np.uint16)
+        ptrs = (C.c_void_p * n)(*[d.ctypes.data for d in dms])
+        cap = self.capacity
+        u = np.zeros((n, cap), np.float32); z = np.zeros((n, cap), np.float32)
+        _check(self.L.orbhip_compute_stereo_from_rgbd(self.h, n, ptrs, dms[0].strides[0], int(dms[0].dtype == np.uint16), float(depth_factor), float(mbf),
+                                                      _p(u), _p(z), cap), "orbhip_compute_stereo_from_rgbd", self.L)
+        return u, z
 
     def mvImagePyramid(self, level, frame=0):
         w, h = self.level_size(level)

@@ -113,6 +113,12 @@ int main(int argc, char** argv)
         const float bnd[4] = {ORB_SLAM2::Frame::mnMinX, ORB_SLAM2::Frame::mnMinY, ORB_SLAM2::Frame::mnMaxX, ORB_SLAM2::Frame::mnMaxY}; fwrite(bnd, 4, 4, f);
         fwrite(&nmD, 4, 1, f);
         if (!matchesD.empty()) fwrite(&matchesD[0], 4, matchesD.size(), f);
+        // RGB-D: the 16-bit depth map of a TUM sequence (5000 units per metre, 0 = hole) read at the key points of the distorted camera
+        cv::Mat dm(H, W, CV_16U);
+        for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) dm.at<unsigned short>(y, x) = (unsigned short)(((x + y) % 7 == 0) ? 0 : (x * 7 + y * 13) % 9000 + 2000);
+        std::vector<float> uR, dZ;
+        exD->ComputeStereoFromRGBD(dm, 1.0f / 5000.0f, 40.0f, D2.N, uR, dZ);          // exD processed im[1] last
+        if (nd2) { fwrite(&uR[0], 4, nd2, f); fwrite(&dZ[0], 4, nd2, f); }
         delete exD;
         // maps file: W*H floats of M1 then W*H floats of M2; the raw image is im[0]
         cv::Mat M1(H, W, CV_32F), M2(H, W, CV_32F);

@@ -77,6 +77,8 @@ def _run(exe, tmp_path, oracle, threads=False):
     bnd = np.frombuffer(buf, np.float32, 4, off); off += 16
     (nm_d,) = struct.unpack_from("<i", buf, off); off += 4
     m12_d = np.frombuffer(buf, np.int32, nd1, off); off += 4 * nd1
+    u_rgbd = np.frombuffer(buf, np.float32, nd2, off); off += 4 * nd2
+    z_rgbd = np.frombuffer(buf, np.float32, nd2, off); off += 4 * nd2
     (nr,) = struct.unpack_from("<i", buf, off); off += 4
     kr = np.frombuffer(buf, orb_slam2_amd.KEYPOINT_DTYPE, nr, off); off += 28 * nr
     dr = np.frombuffer(buf, np.uint8, 32 * nr, off).reshape(nr, 32); off += 32 * nr
@@ -108,6 +110,10 @@ def _run(exe, tmp_path, oracle, threads=False):
     with oracle.image_bounds_set(bnd):
         n_d, m_d, _ = oracle.search_for_initialization(U[0], ref[0][1], U[1], ref[1][1], w, h, window=100, nnratio=0.9)
     assert nm_d == n_d and np.array_equal(m12_d, m_d) and n_d > 40
+    yy, xx = np.mgrid[0:h, 0:w]
+    dm = np.where((xx + yy) % 7 == 0, 0, (xx * 7 + yy * 13) % 9000 + 2000).astype(np.uint16)
+    u_o, z_o = oracle.stereo_from_rgbd(ref[1][0], U[1], dm, np.float32(1.0) / np.float32(5000.0), 40.0)
+    assert u_rgbd.tobytes() == u_o.tobytes() and z_rgbd.tobytes() == z_o.tobytes() and (z_o > 0).sum() > 200
     # raw input rectified on the device
     rect = oracle.remap(seq[0], mx, my)
     kro, dro = oracle.OracleExtractor(n, 1.2, 8, 20, 7).extract(rect)

@@ -188,3 +188,48 @@ def test_rectified_extraction(backend, oracle):
     for f in range(2):
         assert ks[f].tobytes() == K[1 - f][0].tobytes() and np.array_equal(ds[f], K[1 - f][1])
     ex.close()
+
+
+def _depth_map(w, h, seed):
+    """a Kinect-like depth image in TUM's 16-bit encoding (5000 units per metre) with holes (0 = no measurement)"""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    z = 1.2 + 0.9 * np.sin(xx / 47.0) * np.cos(yy / 31.0) + 0.002 * xx
+    raw = np.clip(z * 5000.0, 0, 65535).astype(np.uint16)
+    raw[rng.random((h, w)) < 0.15] = 0
+    return raw
+
+
+@pytest.mark.parametrize("distorted", [False, True])
+def test_stereo_from_rgbd(backend, oracle, distorted):
+    """Frame::ComputeStereoFromRGBD on the key points in HBM: 16-bit maps with TUM's factor (converted per key point), float maps used
+    as they are, float maps with a factor; mvuRight from mvKeysUn of a distorted camera."""
+    w, h, n = 384, 288, 400
+    cam = _small(TUM1, w, h)
+    imgs = [synth.frame(w, h, seed=s) for s in (90, 91)]
+    ora = oracle.OracleExtractor(n, 1.2, 8, 20, 7)
+    K = [ora.extract(im) for im in imgs]
+    U = [oracle.undistort_keypoints(cam, k) if distorted else k for k, _ in K]
+    raw = [_depth_map(w, h, 3), _depth_map(w, h, 4)]
+    factor = np.float32(1.0) / np.float32(5000.0)                      # mDepthMapFactor = 1.0f / DepthMapFactor (Tracking.cc:113-117)
+    mbf = np.float32(40.0)
+    ex = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, max_batch=2, library=backend)
+    if distorted:
+        ex.set_camera(cam)
+    ks, _ = ex.extract_batch(imgs)
+    asfloat = [(r.astype(np.float32) * factor) for r in raw]
+    for maps, f in ((raw, factor), (asfloat, np.float32(1.0)), (asfloat, np.float32(0.5)), (raw, np.float32(1.0))):
+        u_g, z_g = ex.ComputeStereoFromRGBD(maps, f, mbf)
+        for i in range(2):
+            u_o, z_o = oracle.stereo_from_rgbd(K[i][0], U[i], maps[i], f, mbf)
+            nk = len(K[i][0])
+            assert u_g[i, :nk].tobytes() == u_o.tobytes() and z_g[i, :nk].tobytes() == z_o.tobytes()
+            assert 0.05 < (z_o < 0).mean() < 0.4 and (u_o[z_o > 0] < U[i]["x"][z_o > 0]).all()
+    # strided depth rows
+    wide = np.zeros((h, w + 9), np.uint16); wide[:, :w] = raw[0]
+    u_s = np.zeros((1, ex.capacity), np.float32); z_s = np.zeros((1, ex.capacity), np.float32)
+    ptrs = (C.c_void_p * 1)(wide.ctypes.data)
+    assert ex.L.orbhip_compute_stereo_from_rgbd(ex.h, 1, ptrs, wide.strides[0], 1, float(factor), float(mbf), u_s.ctypes.data_as(C.c_void_p), z_s.ctypes.data_as(C.c_void_p), ex.capacity) == 0
+    u_o, z_o = oracle.stereo_from_rgbd(K[0][0], U[0], raw[0], factor, mbf)
+    assert u_s[0, :len(u_o)].tobytes() == u_o.tobytes() and z_s[0, :len(z_o)].tobytes() == z_o.tobytes()
+    ex.close()

@@ -352,6 +352,33 @@ def test_distorted_camera_frames(ref, oracle, pair_oracle, emu_lib):
     ref.RefFrame._geometry = None
 
 
+@pytest.mark.parametrize("dist", [None, (0.262383, -0.953104, -0.005358, 0.002628, 1.163314)])
+def test_rgbd_frame(ref, oracle, pair_oracle, emu_lib, dist):
+    """Frame::Frame(imGray, imDepth, ...) (Frame.cc:117-172): the reference's ComputeStereoFromRGBD on a CV_32F depth map against the
+    oracle's restatement and the HIP sources (emulation build)."""
+    w, h, n, seq, sf, K = pair_oracle
+    rng = np.random.default_rng(8)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    depth = (np.float32(1.5) + np.float32(0.8) * np.sin(xx / np.float32(53.0)) * np.cos(yy / np.float32(29.0))).astype(np.float32)
+    depth[rng.random((h, w)) < 0.2] = 0.0
+    depth[rng.random((h, w)) < 0.02] = -1.0
+    cam = (517.306408 * w / 640, 516.469215 * h / 480, 318.643040 * w / 640, 255.313989 * h / 480)
+    ref.RefFrame._geometry = None
+    F = ref.RefFrame(seq[0], nfeatures=n, fx=cam[0], fy=cam[1], cx=cam[2], cy=cam[3], bf=40.0, dist=dist, depth=depth)
+    un = K[0][0] if dist is None else oracle.undistort_keypoints(cam + tuple(dist), K[0][0])
+    assert F.keys.tobytes() == K[0][0].tobytes() and F.keys_un.tobytes() == un.tobytes()
+    u_o, z_o = oracle.stereo_from_rgbd(K[0][0], un, depth, 1.0, 40.0)
+    assert F.u_right.tobytes() == u_o.tobytes() and F.depth.tobytes() == z_o.tobytes() and (z_o > 0).sum() > 300
+    ex = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, library=emu_lib)
+    if dist is not None:
+        ex.set_camera(cam + tuple(dist))
+    ex.extract_batch([seq[0]])
+    u_g, z_g = ex.ComputeStereoFromRGBD([depth], 1.0, 40.0)
+    assert u_g[0, :F.N].tobytes() == F.u_right.tobytes() and z_g[0, :F.N].tobytes() == F.depth.tobytes()
+    ex.close(); F.close()
+    ref.RefFrame._geometry = None
+
+
 def test_product_equals_reference_matcher_and_stereo(ref, pair, emu_lib):
     """HIP kernel sources (emulation build) against the reference's code directly: frame-to-frame matching and stereo matching."""
     w, h, n, seq, sf, K, F = pair
