@@ -661,13 +661,13 @@ extern "C" orbhip_status orbhip_search_by_projection_bounds(int device, const or
     int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(ORBHIP_ERR_HIP, "no HIP device available: no CPU fallback");
     HIPCHK(hipSetDevice(device));
     orbhip_keypoint* dk = nullptr; uint8_t *dd = nullptr, *dqd = nullptr; unsigned char *dbl_in = nullptr; float* dur = nullptr; int *dn = nullptr, *dgs = nullptr, *dgi = nullptr, *dnc = nullptr, *dfq = nullptr, *dev = nullptr;
-    float2* dgxy = nullptr; orbhip_proj_query* dq = nullptr; unsigned* dcand = nullptr;
+    float2* dgxy = nullptr; orbhip_proj_query* dq = nullptr; unsigned* dcand = nullptr; unsigned* dtop = nullptr;
     hipError_t e = hipSuccess;
 #define TRY(x) do { if (e == hipSuccess) e = (x); } while (0)
     TRY(arena_layout(device, [&](Arena& A) {
         A.take(&dk, n); A.take(&dd, (size_t)n * 32); A.take(&dqd, (size_t)nq * 32); A.take(&dq, nq); A.take(&dn, 8);
         A.take(&dgs, ORBHIP_GRID_CELLS + 1); A.take(&dgi, n); A.take(&dgxy, n); A.take(&dnc, nq); A.take(&dfq, n); A.take(&dev, nq);
-        A.take(&dcand, (size_t)nq * n);
+        A.take(&dcand, (size_t)nq * n); A.take(&dtop, (size_t)nq * 5);
         if (u_right) A.take(&dur, n);
         if (blocked) A.take(&dbl_in, n);
     }));
@@ -683,7 +683,7 @@ extern "C" orbhip_status orbhip_search_by_projection_bounds(int device, const or
         orbhip_launch_match_grid(M, 1, nullptr);
         ProjParams J; memset(&J, 0, sizeof J);
         J.kp = dk; J.desc = dd; J.u_right = dur; J.n = n; J.min_x = bounds->min_x; J.min_y = bounds->min_y; J.max_x = bounds->max_x; J.max_y = bounds->max_y; J.grid_start = dgs; J.grid_items = dgi; J.grid_xy = dgxy;
-        J.q = dq; J.qdesc = dqd; J.nq = nq; J.cand = dcand; J.ncand = dnc; J.cand_stride = n;
+        J.q = dq; J.qdesc = dqd; J.nq = nq; J.cand = dcand; J.ncand = dnc; J.cand_stride = n; J.top = dtop;
         J.blocked_in = dbl_in; J.blocked_out = nullptr; J.feature_query = dfq; J.nmatches = dn + 1; J.events = dev;
         J.mode = mode; J.nnratio = nnratio; J.th_high = th_high; J.check_ori = check_ori;
         orbhip_launch_proj(J, nullptr);

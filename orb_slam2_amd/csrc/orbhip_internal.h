@@ -108,6 +108,7 @@ struct ProjParams {         // projection-guided search core (ORBmatcher.cc:45-1
     const int* grid_start; const int* grid_items; const float2* grid_xy;                   // 64x48 grid over ALL keypoints
     const orbhip_proj_query* q; const uint8_t* qdesc; int nq;
     unsigned* cand; int* ncand; int cand_stride;                                            // per query: i2 | dist<<19 | level<<28, reference order
+    unsigned* top;                                                                          // per query: records of the best and second-best candidate under the initial state
     const unsigned char* blocked_in; unsigned char* blocked_out; int* feature_query; int* nmatches; int* events;
     int mode; float nnratio; int th_high, check_ori;
 };

@@ -6,16 +6,31 @@
 //   k_match_grid (all levels)  Frame::AssignFeaturesToGrid                                  Frame.cc:230-245
 //   k_proj_candidates          one wavefront per query: Frame::GetFeaturesInArea in reference order with the level
 //                              arguments of the call, the stereo right-coordinate gate and DescriptorDistance
-//   k_proj_select              one wave replays the order-dependent loop: features claimed by a map point with observations are
-//                              skipped by later queries; best / second-best with the same-level ratio rule (mode 0) or best only +
-//                              rotation histogram (mode 1); ComputeThreeMaxima                ORBmatcher.cc:1601-1642
+//                              + the best / second-best candidate of the query under the INITIAL map-point state
+//   k_proj_select              one wave replays the order-dependent loop, 64 queries per step: features claimed by a map point with
+//                              observations are skipped by later queries, so a query's precomputed best / second-best is final
+//                              unless an earlier query claimed one of the two — those (rare) queries are rescanned one at a time;
+//                              same-level ratio rule (mode 0) or best only + rotation histogram (mode 1);
+//                              ComputeThreeMaxima                                             ORBmatcher.cc:1601-1642
 #include "orbhip_internal.h"
 
 #define IMAX 0x7fffffff
 #define PJ_T 256
-#define PJ_BLK 1024                    // queries staged per round
-#define PJ_CANDCAP 12288               // candidate records staged in LDS per round (48 KB)
+#define PJ_NONE 0xFFFFFFFFu             // "no candidate" in the per-query records
+#define PJ_K 4                          // best candidates recorded per query (under the initial map-point state)
+#define PJ_REC (PJ_K + 1)               // + one word: more selectable candidates exist
 
+// wave64 minimum with DPP row shifts / broadcasts (6 dependent VALU steps), broadcast from lane 63
+__device__ __forceinline__ int pj_wave_min(int v)
+{
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x111, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x112, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x114, 0xf, 0xe, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x118, 0xf, 0xc, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x142, 0xa, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x143, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
 __global__ __launch_bounds__(256) void k_proj_candidates(ProjParams J, float gwInv, float ghInv)
 {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -28,6 +43,9 @@ __global__ __launch_bounds__(256) void k_proj_candidates(ProjParams J, float gwI
     const float x = q.x, y = q.y, r = q.radius;
     const bool check_levels = (q.min_level > 0) || (q.max_level >= 0);                   // Frame.cc:350
     int nc = 0;
+    int tk[PJ_K]; unsigned te[PJ_K]; int nsel = 0;                             // this lane's PJ_K smallest (distance, list position) keys + their records
+#pragma unroll
+    for (int k = 0; k < PJ_K; k++) { tk[k] = IMAX; te[k] = PJ_NONE; }
     const int minCX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, J.min_x), r), gwInv)));
     const int maxCX = min(ORBHIP_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, J.min_x), r), gwInv)));
     const int minCY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, J.min_y), r), ghInv)));
@@ -58,7 +76,14 @@ __global__ __launch_bounds__(256) void k_proj_candidates(ProjParams J, float gwI
                 if (pos < J.cand_stride) {
                     const unsigned long long* d2 = (const unsigned long long*)(J.desc + (long long)i2 * 32);
                     const unsigned dist = (unsigned)(__popcll(q0 ^ d2[0]) + __popcll(q1 ^ d2[1]) + __popcll(q2 ^ d2[2]) + __popcll(q3 ^ d2[3]));
-                    cand[pos] = (unsigned)i2 | (dist << 19) | ((unsigned)(J.kp[i2].octave & 15) << 28);
+                    const unsigned e = (unsigned)i2 | (dist << 19) | ((unsigned)(J.kp[i2].octave & 15) << 28);
+                    cand[pos] = e;
+                    if (dist < 256u && !(J.blocked_in && J.blocked_in[i2])) {             // selectable under the initial state (ORBmatcher.cc:87-89, 1399-1401)
+                        int key = (int)((dist << 19) | (unsigned)pos); unsigned rec = e;
+                        nsel++;
+#pragma unroll
+                        for (int k = 0; k < PJ_K; k++) if (key < tk[k]) { const int tkk = tk[k]; const unsigned tee = te[k]; tk[k] = key; te[k] = rec; key = tkk; rec = tee; }   // sorted insert
+                    }
                 }
                 pos++;
             }
@@ -66,19 +91,29 @@ __global__ __launch_bounds__(256) void k_proj_candidates(ProjParams J, float gwI
         }
     }
     if (lane == 0) J.ncand[iq] = min(nc, J.cand_stride);
+    // The sequential update "dist < best -> shift, else dist < second" (ORBmatcher.cc:102-114) ends with the two smallest
+    // (distance, list position) keys among the candidates that are selectable at that moment.  Keep the PJ_K smallest under the
+    // initial state: the select kernel takes the first two that are still unclaimed.
+    unsigned out = PJ_NONE; int popped = 0;
+#pragma unroll
+    for (int r = 0; r < PJ_K; r++) {
+        const int m = pj_wave_min(tk[0]);
+        if (m == IMAX) break;
+        const int owner = __ffsll((long long)__ballot(tk[0] == m)) - 1;
+        const unsigned rec = (unsigned)__builtin_amdgcn_readlane((int)te[0], owner);
+        if (lane == r) out = rec;
+        if (lane == owner) {
+            popped++;
+#pragma unroll
+            for (int k = 0; k + 1 < PJ_K; k++) { tk[k] = tk[k + 1]; te[k] = te[k + 1]; }
+            tk[PJ_K - 1] = IMAX; te[PJ_K - 1] = PJ_NONE;
+        }
+    }
+    const bool more = __ballot(nsel > popped) != 0ull;         // selectable candidates beyond the PJ_K recorded ones
+    if (lane < PJ_K) J.top[PJ_REC * iq + lane] = out;
+    if (lane == PJ_K) J.top[PJ_REC * iq + PJ_K] = more ? 1u : 0u;
 }
 
-// wave64 minimum with DPP row shifts / broadcasts (6 dependent VALU steps), broadcast from lane 63
-__device__ __forceinline__ int pj_wave_min(int v)
-{
-    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x111, 0xf, 0xf, false));
-    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x112, 0xf, 0xf, false));
-    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x114, 0xf, 0xe, false));
-    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x118, 0xf, 0xc, false));
-    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x142, 0xa, 0xf, false));
-    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x143, 0xc, 0xf, false));
-    return __builtin_amdgcn_readlane(v, 63);
-}
 __device__ __forceinline__ unsigned long long pj_argmin_mask(int d, unsigned long long M)
 {
 #pragma unroll
@@ -92,88 +127,127 @@ __global__ __launch_bounds__(PJ_T) void k_proj_select(ProjParams J)
     HIP_DYNAMIC_SHARED(int, lds)
     int* s_blocked = lds;                                   // F.mvpMapPoints[i] && Observations() > 0
     int* s_fq = s_blocked + n;                              // query whose map point sits in F.mvpMapPoints[i]
-    float* s_fang = reinterpret_cast<float*>(s_fq + n);     // mvKeysUn[i].angle
-    int* s_nc = reinterpret_cast<int*>(s_fang + n);         // per staged query: list length, start, blocks flag, angle
-    int* s_off = s_nc + PJ_BLK;
-    int* s_qblocks = s_off + PJ_BLK + 1;
-    float* s_qang = reinterpret_cast<float*>(s_qblocks + PJ_BLK);
-    int* s_hist = reinterpret_cast<int*>(s_qang + PJ_BLK);  // [HISTO_LENGTH] + 8 misc
-    unsigned* s_cand = reinterpret_cast<unsigned*>(s_hist + ORBHIP_HISTO_LENGTH + 8);
-    for (int i = tid; i < n; i += PJ_T) { s_blocked[i] = J.blocked_in ? (int)J.blocked_in[i] : 0; s_fq[i] = -1; s_fang[i] = J.kp[i].angle; }
+    int* s_stamp = s_fq + n;                                // lowest query index that (speculatively) claims feature i with a blocking map point
+    float* s_fang = reinterpret_cast<float*>(s_stamp + n);  // mvKeysUn[i].angle
+    int* s_hist = reinterpret_cast<int*>(s_fang + n);       // [HISTO_LENGTH] + 8 misc
+    for (int i = tid; i < n; i += PJ_T) { s_blocked[i] = J.blocked_in ? (int)J.blocked_in[i] : 0; s_fq[i] = -1; s_stamp[i] = IMAX; s_fang[i] = J.kp[i].angle; }
     for (int i = tid; i < ORBHIP_HISTO_LENGTH + 8; i += PJ_T) s_hist[i] = 0;
     __syncthreads();
     const float factor = 1.0f / ORBHIP_HISTO_LENGTH;
-    int nmatches = 0, nev = 0;                               // meaningful in wave 0 only
-    for (int qb = 0; qb < J.nq; qb += PJ_BLK) {
-        const int nb = min(PJ_BLK, J.nq - qb);
-        for (int i = tid; i < nb; i += PJ_T) { s_nc[i] = J.ncand[qb + i]; s_qblocks[i] = J.q[qb + i].blocks; s_qang[i] = J.q[qb + i].angle; }
-        __syncthreads();
-        if (wave == 0) {
-            int run = 0;
-            for (int cb = 0; cb < nb; cb += 64) {
-                const int v = (cb + lane < nb) ? s_nc[cb + lane] : 0;
-                int incl = v;
+    const bool use_second = J.mode == 0;                     // mode 1 keeps the best candidate only (ORBmatcher.cc:1396-1425)
+    if (wave == 0) {
+        int nmatches = 0, nev = 0;
+        auto rot_bin = [&](float qang, int bidx) -> int {                                  // ORBmatcher.cc:1430-1440
+            float rot = __fsub_rn(qang, s_fang[bidx]);
+            if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+            int bin = (int)roundf(__fmul_rn(rot, factor));
+            if (bin == ORBHIP_HISTO_LENGTH) bin = 0;
+            return min(max(bin, 0), ORBHIP_HISTO_LENGTH - 1);
+        };
+        for (int qb = 0; qb < J.nq; qb += 64) {
+            const int q = qb + lane;
+            const bool inb = q < J.nq;
+            int ei[PJ_K], ed[PJ_K], el[PJ_K]; int nk = 0;
 #pragma unroll
-                for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(incl, off); if (lane >= off) incl += u; }
-                if (cb + lane < nb) s_off[cb + lane] = run + incl - v;
-                run += __shfl(incl, 63);
+            for (int k = 0; k < PJ_K; k++) {
+                const unsigned t = inb ? J.top[PJ_REC * q + k] : PJ_NONE;
+                ei[k] = (int)(t & 0x7FFFFu); ed[k] = (int)((t >> 19) & 0x1FFu); el[k] = (int)(t >> 28);
+                if (t != PJ_NONE) nk = k + 1;
             }
-        }
-        __syncthreads();
-        for (int j = wave; j < nb; j += PJ_T / 64) {
-            const int nc = s_nc[j], o = s_off[j];
-            if (o + nc > PJ_CANDCAP) continue;
-            for (int t = lane; t < nc; t += 64) s_cand[o + t] = J.cand[(long long)(qb + j) * J.cand_stride + t];
-        }
-        __syncthreads();
-        if (wave == 0) {
-            for (int j = 0; j < nb; j++) {
-                const int nc = s_nc[j];
-                if (nc == 0) continue;                                                      // vIndices.empty()
-                const int o = s_off[j];
-                const bool staged = o + nc <= PJ_CANDCAP;
-                const unsigned* cand = J.cand + (long long)(qb + j) * J.cand_stride;
+            const bool more = inb && J.top[PJ_REC * q + PJ_K] != 0u;
+            const int blocks = inb ? J.q[q].blocks : 0;
+            const float qang = inb ? J.q[q].angle : 0.0f;
+            int stamped = -1;                                // feature this lane's speculative claim currently marks
+            unsigned long long todo = __ballot(nk > 0);
+            while (todo) {
+                const bool mine = (todo >> lane) & 1ull;
+                const int lowest = __ffsll((long long)todo) - 1;
+                // first two recorded candidates nobody has claimed so far (claims only ever add up: a claimed feature stays claimed)
+                int a = -1, b = -1;
+#pragma unroll
+                for (int k = 0; k < PJ_K; k++)
+                    if (mine && k < nk && b < 0 && !s_blocked[ei[k]]) { if (a < 0) a = k; else b = k; }
+                if (!use_second) b = -1;
+                const int ia = a >= 0 ? ei[a] : 0, da = a >= 0 ? ed[a] : 256, la = a >= 0 ? el[a] : -1;
+                const int db = b >= 0 ? ed[b] : 256, lb = b >= 0 ? el[b] : -1;
+                // records used up while more selectable candidates exist: the answer is not in the records
+                const bool exhausted = mine && more && (a < 0 || (use_second && b < 0));
+                // the decision the reference takes if nothing this query looks at is claimed by a query between the committed ones and it
+                const bool accept = mine && !exhausted && a >= 0 && da <= J.th_high && !(J.mode == 0 && la == lb && (float)da > __fmul_rn(J.nnratio, (float)db));   // ORBmatcher.cc:116-126
+                const int want = (accept && blocks) ? ia : -1;
+                if (stamped >= 0 && stamped != want && s_stamp[stamped] == q) s_stamp[stamped] = IMAX;    // withdraw an outdated speculative claim
+                __builtin_amdgcn_wave_barrier();
+                if (want >= 0) atomicMin(&s_stamp[want], q);
+                stamped = want;
+                __builtin_amdgcn_wave_barrier();
+                // an earlier, not yet committed query of this step may still claim one of the candidates this decision rests on
+                bool unsure = false;
+                const int last = use_second ? (b >= 0 ? b : nk - 1) : a;
+#pragma unroll
+                for (int k = 0; k < PJ_K; k++)
+                    if (mine && lane != lowest && k <= last && !s_blocked[ei[k]] && s_stamp[ei[k]] < q) unsure = true;
+                const unsigned long long bad = __ballot(unsure || exhausted);
+                const int first_bad = bad ? __ffsll((long long)bad) - 1 : 64;
+                const unsigned long long commit = first_bad == 64 ? todo : (todo & ((1ull << first_bad) - 1ull));
+                const bool win = ((commit >> lane) & 1ull) && accept;
+                const unsigned long long wins = __ballot(win);
+                if (win) {
+                    atomicMax(&s_fq[ia], q);                                                // later queries overwrite earlier ones (ORBmatcher.cc:123)
+                    if (blocks) s_blocked[ia] = 1;
+                    if (J.mode == 1 && J.check_ori) {
+                        const int bin = rot_bin(qang, ia);
+                        atomicAdd(&s_hist[bin], 1);
+                        J.events[nev + __popcll(wins & ((1ull << lane) - 1ull))] = (bin << 20) | ia;     // rotHist[bin].push_back(bestIdx2)
+                    }
+                }
+                nmatches += __popcll(wins); nev += __popcll(wins);
+                __builtin_amdgcn_wave_barrier();
+                todo &= ~commit;
+                if (first_bad == 64) break;
+                // the first undecided query: if it merely waited for earlier ones it is re-evaluated now that they are final;
+                // only a query whose records are used up is rescanned against the current state
+                if (first_bad != lowest || !((__ballot(exhausted) >> first_bad) & 1ull)) continue;
+                todo &= ~(1ull << first_bad);
+                const int qs = qb + first_bad;
+                if (lane == first_bad && stamped >= 0 && s_stamp[stamped] == q) { s_stamp[stamped] = IMAX; }
+#ifdef PJ_DEBUG
+                if (lane == 0) s_hist[ORBHIP_HISTO_LENGTH + 2]++;
+#endif
+                // rescan query qb + first_bad against the current state (its speculative claim, if any, was withdrawn above)
+                const int nc = J.ncand[qs];
+                const unsigned* cand = J.cand + (long long)qs * J.cand_stride;
                 int best = 256, blevel = -1, second = 256, slevel = -1, bidx = -1;
                 for (int cb = 0; cb < nc; cb += 64) {
                     const int t = cb + lane;
-                    unsigned e = 0;
-                    if (t < nc) e = staged ? s_cand[o + t] : cand[t];
+                    const unsigned e = t < nc ? cand[t] : 0u;
                     const int i2 = (int)(e & 0x7FFFFu), dist = (int)((e >> 19) & 0x1FFu), lvl = (int)(e >> 28);
                     const bool valid = t < nc && dist < 256 && !s_blocked[i2];
                     // two smallest (distance, lane) keys by DPP min networks; the key carries the level so no extra readlane is needed
-                    const int key = valid ? ((dist << 10) | (lane << 4) | lvl) : 0x7fffffff;
+                    const int key = valid ? ((dist << 10) | (lane << 4) | lvl) : IMAX;
                     const int k1 = pj_wave_min(key);
-                    if (k1 == 0x7fffffff) continue;
+                    if (k1 == IMAX) continue;
                     const int f1 = (k1 >> 4) & 63, wmin = k1 >> 10, cl = k1 & 15, ci = __builtin_amdgcn_readlane(i2, f1);      // first candidate with the minimum
-                    const int k2 = pj_wave_min(lane == f1 ? 0x7fffffff : key);
-                    const int wsec = k2 == 0x7fffffff ? 256 : (k2 >> 10), l2 = k2 == 0x7fffffff ? -1 : (k2 & 15);
+                    const int k2 = pj_wave_min(lane == f1 ? IMAX : key);
+                    const int wsec = k2 == IMAX ? 256 : (k2 >> 10), l2 = k2 == IMAX ? -1 : (k2 & 15);
                     // the two smallest (distance, list position) keys == the reference's sequential best / second-best update
                     if (wmin < best) {
                         if (best <= wsec) { second = best; slevel = blevel; } else { second = wsec; slevel = l2; }
                         best = wmin; bidx = ci; blevel = cl;
                     } else if (wmin < second) { second = wmin; slevel = cl; }
                 }
-                if (best <= J.th_high) {
-                    if (J.mode == 0 && blevel == slevel && (float)best > __fmul_rn(J.nnratio, (float)second)) continue;   // ORBmatcher.cc:118-121
+                if (best <= J.th_high && !(J.mode == 0 && blevel == slevel && (float)best > __fmul_rn(J.nnratio, (float)second))) {
+                    const int sblocks = __builtin_amdgcn_readlane(blocks, first_bad);
+                    const float sang = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qang), first_bad));
                     if (lane == 0) {
-                        s_fq[bidx] = qb + j; s_blocked[bidx] = s_qblocks[j] ? 1 : 0;
-                        if (J.mode == 1 && J.check_ori) {
-                            float rot = __fsub_rn(s_qang[j], s_fang[bidx]);
-                            if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
-                            int bin = (int)roundf(__fmul_rn(rot, factor));
-                            if (bin == ORBHIP_HISTO_LENGTH) bin = 0;
-                            bin = min(max(bin, 0), ORBHIP_HISTO_LENGTH - 1);
-                            s_hist[bin]++; J.events[nev] = (bin << 20) | bidx;              // rotHist[bin].push_back(bestIdx2)
-                        }
+                        s_fq[bidx] = qs;
+                        if (sblocks) { s_blocked[bidx] = 1; atomicMin(&s_stamp[bidx], qs); }
+                        if (J.mode == 1 && J.check_ori) { const int bin = rot_bin(sang, bidx); s_hist[bin]++; J.events[nev] = (bin << 20) | bidx; }
                     }
                     nmatches++; nev++;
-                    __builtin_amdgcn_wave_barrier();              // lane 0's claim precedes the next query's reads (same wave: LDS ops stay in order)
                 }
+                __builtin_amdgcn_wave_barrier();              // lane 0's claim precedes the next reads (same wave: LDS ops stay in order)
             }
         }
-        __syncthreads();
-    }
-    if (wave == 0) {
         if (J.mode == 1 && J.check_ori) {
             if (lane == 0) {
                 int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
@@ -195,13 +269,16 @@ __global__ __launch_bounds__(PJ_T) void k_proj_select(ProjParams J)
             __builtin_amdgcn_wave_barrier();
             nmatches -= s_hist[ORBHIP_HISTO_LENGTH];
         }
+#ifdef PJ_DEBUG
+        if (lane == 0) printf("proj select: mode %d nq %d slow %d\n", J.mode, J.nq, s_hist[ORBHIP_HISTO_LENGTH + 2]);
+#endif
         if (lane == 0) *J.nmatches = nmatches;
     }
     __syncthreads();
     for (int i = tid; i < n; i += PJ_T) { J.feature_query[i] = s_fq[i]; if (J.blocked_out) J.blocked_out[i] = (unsigned char)s_blocked[i]; }
 }
 
-size_t orbhip_proj_select_lds(int n) { return sizeof(int) * ((size_t)3 * n + 4 * PJ_BLK + 1 + ORBHIP_HISTO_LENGTH + 8 + PJ_CANDCAP); }
+size_t orbhip_proj_select_lds(int n) { return sizeof(int) * ((size_t)4 * n + ORBHIP_HISTO_LENGTH + 8); }
 
 void orbhip_launch_proj(const ProjParams& J, hipStream_t s)
 {
