@@ -64,7 +64,7 @@ struct orbhip_ctx {
     const uint8_t* last_img0 = nullptr; long long last_img0_fstride = 0; int last_img0_pitch = 0;
     int* d_st_rowstart = nullptr; int* d_st_rowitems = nullptr; int st_rowcap = 0; float* d_st_u = nullptr; float* d_st_depth = nullptr; int* d_st_sad = nullptr;
     // matcher workspace
-    int* d_grid_start = nullptr; int* d_grid_items = nullptr; float2* d_grid_xy = nullptr; unsigned* d_cand = nullptr; int* d_ncand = nullptr; float* d_prev = nullptr; int* d_m12 = nullptr; int* d_nm = nullptr;
+    int* d_grid_start = nullptr; int* d_grid_items = nullptr; float2* d_grid_xy = nullptr; unsigned* d_cand = nullptr; unsigned* d_top = nullptr; int* d_ncand = nullptr; float* d_prev = nullptr; int* d_m12 = nullptr; int* d_nm = nullptr;
     // camera geometry: undistorted key points of a distorted camera, rectification maps of a raw stereo camera
     orbhip_bounds bounds = {0, 0, 0, 0}; bool distorted = false; CameraD cam = {}; orbhip_keypoint* d_out_kpun[3] = {nullptr, nullptr, nullptr}; orbhip_keypoint* h_kpun = nullptr;
     int* d_map_x = nullptr; int* d_map_y = nullptr; int src_w = 0, src_h = 0, raw_pitch = 0; uint8_t* d_raw = nullptr; uint8_t* h_raw = nullptr; uint8_t* d_depth = nullptr; size_t depth_bytes = 0;
@@ -174,7 +174,7 @@ extern "C" void orbhip_destroy(orbhip_ctx* c)
     for (auto e : c->pool) (void)hipEventDestroy(e);
     void* ptrs[] = {c->d_geom, c->d_cells, c->d_tiles, c->d_xtab, c->d_ytab, c->d_pattern, c->d_pyr, c->d_blur, c->d_cell_count, c->d_cell_cand,
                     c->d_qt_val, c->d_qt_code, c->d_qt_node, c->d_lvl_kp, c->d_lvl_n[0], c->d_lvl_n[1], c->d_lvl_n[2], c->d_out_kp[0], c->d_out_kp[1], c->d_out_kp[2],
-                    c->d_out_desc[0], c->d_out_desc[1], c->d_out_desc[2], c->d_out_n[0], c->d_out_n[1], c->d_out_n[2], c->d_grid_start, c->d_grid_items, c->d_grid_xy, c->d_cand, c->d_ncand,
+                    c->d_out_desc[0], c->d_out_desc[1], c->d_out_desc[2], c->d_out_n[0], c->d_out_n[1], c->d_out_n[2], c->d_grid_start, c->d_grid_items, c->d_grid_xy, c->d_cand, c->d_top, c->d_ncand,
                     c->d_prev, c->d_m12, c->d_nm};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     { void* st[] = {c->d_st_rowstart, c->d_st_rowitems, c->d_st_u, c->d_st_depth, c->d_st_sad}; for (void* q : st) if (q) (void)hipFree(q); }
@@ -286,7 +286,7 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
     c->lvl_kp_per_frame = kp_off; c->out_cap = kp_off; c->lvl0_cap = c->geom[0].kp_cap;
     if (cand_off >= (1 << 24)) { delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "too many candidate slots"); }
     if (orbhip_quadtree_lds_bytes(c->qt_maxn, c->qt_maxcells) > 150 * 1024) { delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "nfeatures too large for the LDS quadtree (%d nodes)", c->qt_maxn); }
-    if ((size_t)(3 * c->out_cap + 4 * c->lvl0_cap + 64) * sizeof(int) > 158 * 1024) { delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "nfeatures too large for the LDS matcher"); }
+    if ((size_t)(4 * c->out_cap + 4 * c->lvl0_cap + 64) * sizeof(int) > 158 * 1024) { delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "nfeatures too large for the LDS matcher"); }
 
     // ---- device
     if (cfg->stream) c->stream = (hipStream_t)cfg->stream;
@@ -321,7 +321,7 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
         if (e == hipSuccess) e = hipMemset(c->d_out_n[k], 0, B * sizeof(int));
     }
     TRY(dalloc(&c->d_grid_start, B * (ORBHIP_GRID_CELLS + 1))); TRY(dalloc(&c->d_grid_items, B * c->out_cap)); TRY(dalloc(&c->d_grid_xy, B * c->out_cap));
-    TRY(dalloc(&c->d_cand, B * c->lvl0_cap * (size_t)c->lvl0_cap)); TRY(dalloc(&c->d_ncand, B * c->lvl0_cap));
+    TRY(dalloc(&c->d_cand, B * c->lvl0_cap * (size_t)c->lvl0_cap)); TRY(dalloc(&c->d_ncand, B * c->lvl0_cap)); TRY(dalloc(&c->d_top, B * c->lvl0_cap * (size_t)5));
     TRY(dalloc(&c->d_prev, B * c->out_cap * 2)); TRY(dalloc(&c->d_m12, B * c->out_cap)); TRY(dalloc(&c->d_nm, B));
 #undef TRY
     if (e != hipSuccess) { fail(ORBHIP_ERR_HIP, "device allocation failed: %s", hipGetErrorString(e)); orbhip_destroy(c); return ORBHIP_ERR_HIP; }
@@ -414,7 +414,7 @@ static orbhip_status run_pipeline(orbhip_ctx* c, int nimg, const uint8_t* d_img0
         M.kp2 = c->distorted ? c->d_out_kpun[cur] : c->d_out_kp[cur]; M.desc2 = c->d_out_desc[cur]; M.n2 = c->d_out_n[cur];
         M.lvl_stride = c->L; M.list1 = nullptr; M.prev_from_kp1 = 1;
         M.cap = c->out_cap; M.min_x = c->bounds.min_x; M.min_y = c->bounds.min_y; M.max_x = c->bounds.max_x; M.max_y = c->bounds.max_y;
-        M.grid_start = c->d_grid_start; M.grid_items = c->d_grid_items; M.grid_xy = c->d_grid_xy; M.cand = c->d_cand; M.ncand = c->d_ncand; M.cand_stride = c->lvl0_cap; M.lvl0_cap = c->lvl0_cap;
+        M.grid_start = c->d_grid_start; M.grid_items = c->d_grid_items; M.grid_xy = c->d_grid_xy; M.cand = c->d_cand; M.top = c->d_top; M.ncand = c->d_ncand; M.cand_stride = c->lvl0_cap; M.lvl0_cap = c->lvl0_cap;
         M.prev = c->d_prev; M.matches12 = c->d_m12; M.nmatches = c->d_nm; M.window = window; M.nnratio = nnratio; M.check_ori = check_ori; M.slot0 = 0;
         // matcher of this batch on its own stream: latency-bound (one wave per slot), overlaps the next call's extraction
         hipStream_t ms = c->serial ? c->stream : c->mstream;
@@ -1081,15 +1081,15 @@ extern "C" orbhip_status orbhip_search_for_initialization_bounds(int device, con
     std::vector<int> list1; for (int i = 0; i < n1; i++) if (kps1[i].octave <= 0) list1.push_back(i);
     int n2l0 = 0; for (int i = 0; i < n2; i++) n2l0 += kps2[i].octave == 0;
     const int cap = std::max(std::max(n1, n2), 1), l0cap = std::max((int)list1.size(), 1), cstride = std::max(n2l0, 1);
-    if ((size_t)(3 * cap + 4 * l0cap + 64) * sizeof(int) > 158 * 1024) return fail(ORBHIP_ERR_UNSUPPORTED, "too many keypoints for the LDS matcher");
+    if ((size_t)(4 * cap + 4 * l0cap + 64) * sizeof(int) > 158 * 1024) return fail(ORBHIP_ERR_UNSUPPORTED, "too many keypoints for the LDS matcher");
     orbhip_keypoint *dk1 = nullptr, *dk2 = nullptr; uint8_t *dd1 = nullptr, *dd2 = nullptr; int *dn = nullptr, *dlist = nullptr, *dgs = nullptr, *dgi = nullptr, *dnc = nullptr, *dm12 = nullptr; float2* dgxy = nullptr;
-    unsigned* dcand = nullptr; float* dprev = nullptr;
+    unsigned* dcand = nullptr; unsigned* dtop = nullptr; float* dprev = nullptr;
     hipError_t e = hipSuccess;
 #define TRY(x) do { if (e == hipSuccess) e = (x); } while (0)
     TRY(arena_layout(device, [&](Arena& A) {
         A.take(&dk1, cap); A.take(&dk2, cap); A.take(&dd1, (size_t)cap * 32); A.take(&dd2, (size_t)cap * 32); A.take(&dn, 8);
         A.take(&dlist, l0cap); A.take(&dgs, ORBHIP_GRID_CELLS + 1); A.take(&dgi, cap); A.take(&dgxy, cap); A.take(&dnc, l0cap); A.take(&dm12, cap);
-        A.take(&dcand, (size_t)l0cap * cstride); A.take(&dprev, (size_t)cap * 2);
+        A.take(&dcand, (size_t)l0cap * cstride); A.take(&dtop, (size_t)l0cap * 5); A.take(&dprev, (size_t)cap * 2);
     }));
     const int hn[4] = {n1, n2, (int)list1.size(), 0};
     TRY(hipMemcpy(dk1, kps1, (size_t)n1 * sizeof(orbhip_keypoint), hipMemcpyHostToDevice)); TRY(hipMemcpy(dd1, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice));
@@ -1100,7 +1100,7 @@ extern "C" orbhip_status orbhip_search_for_initialization_bounds(int device, con
     if (e == hipSuccess) {
         MatchParams M; memset(&M, 0, sizeof M);
         M.kp1 = dk1; M.desc1 = dd1; M.n1 = dn; M.n1_lvl0 = dn + 2; M.kp2 = dk2; M.desc2 = dd2; M.n2 = dn + 1; M.lvl_stride = 0; M.list1 = dlist; M.prev_from_kp1 = 0;
-        M.cap = cap; M.min_x = bounds->min_x; M.min_y = bounds->min_y; M.max_x = bounds->max_x; M.max_y = bounds->max_y; M.grid_start = dgs; M.grid_items = dgi; M.grid_xy = dgxy; M.cand = dcand; M.ncand = dnc; M.cand_stride = cstride; M.lvl0_cap = l0cap;
+        M.cap = cap; M.min_x = bounds->min_x; M.min_y = bounds->min_y; M.max_x = bounds->max_x; M.max_y = bounds->max_y; M.grid_start = dgs; M.grid_items = dgi; M.grid_xy = dgxy; M.cand = dcand; M.top = dtop; M.ncand = dnc; M.cand_stride = cstride; M.lvl0_cap = l0cap;
         M.prev = dprev; M.matches12 = dm12; M.nmatches = dn + 3; M.window = window; M.nnratio = nnratio; M.check_ori = check_ori;
         orbhip_launch_match_grid(M, 1, nullptr); orbhip_launch_match_candidates(M, 1, nullptr); orbhip_launch_match_select(M, 1, nullptr);
         e = hipGetLastError();

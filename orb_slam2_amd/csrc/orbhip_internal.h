@@ -80,6 +80,7 @@ struct MatchParams {        // SearchForInitialization over camera slots (ORBmat
     float min_x, min_y, max_x, max_y;                                   // Frame::mnMinX .. mnMaxY (Frame.cc:436-464)
     int* grid_start; int* grid_items; float2* grid_xy;   // [slot][GRID_CELLS+1], [slot][cap], [slot][cap]  (Frame.cc:230-245 on F2, level 0 only)
     unsigned* cand; int* ncand; int cand_stride;  // [slot][n1_lvl0_cap][cand_stride]: i2 | dist<<16, canonical order
+    unsigned* top;                                // [slot][n1_lvl0_cap][5]: records of the 4 best candidates of the whole list + "more" flag
     int lvl0_cap;
     float* prev;                                  // [slot][cap][2] vbPrevMatched (in/out)
     int* matches12; int* nmatches;                // [slot][cap], [slot]

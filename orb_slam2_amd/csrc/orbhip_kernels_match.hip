@@ -173,6 +173,21 @@ void orbhip_launch_match_grid(const MatchParams& M, int nslots, hipStream_t s)
 // the 0.5 of the rounding), so the result is the sub-sequence of the whole table that passes the distance test.  One
 // wavefront scans the table (a few hundred entries: coalesced, all loads in flight at once) instead of walking ~300
 // mostly empty cells with dependent loads; ballot ranks keep the order.
+// wave64 minimum with DPP row shifts / broadcasts (6 dependent 4-cycle VALU steps); result broadcast from lane 63
+__device__ __forceinline__ int wave_min_dpp(int v)
+{
+    v = min(v, __builtin_amdgcn_update_dpp(IMAX, v, 0x111, 0xf, 0xf, false));      // row_shr:1
+    v = min(v, __builtin_amdgcn_update_dpp(IMAX, v, 0x112, 0xf, 0xf, false));      // row_shr:2
+    v = min(v, __builtin_amdgcn_update_dpp(IMAX, v, 0x114, 0xf, 0xe, false));      // row_shr:4
+    v = min(v, __builtin_amdgcn_update_dpp(IMAX, v, 0x118, 0xf, 0xc, false));      // row_shr:8 -> lane 15 of each row = row minimum
+    v = min(v, __builtin_amdgcn_update_dpp(IMAX, v, 0x142, 0xa, 0xf, false));      // row_bcast:15 into rows 1 and 3
+    v = min(v, __builtin_amdgcn_update_dpp(IMAX, v, 0x143, 0xc, 0xf, false));      // row_bcast:31 into rows 2 and 3 -> lane 63 = wave minimum
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+#define MS_K 4                          // best candidates recorded per query (under the initial state: nothing matched yet)
+#define MS_REC (MS_K + 1)               // + one word: more candidates exist
+#define MS_NONE 0xFFFFFFFFu
 #define MC_CHUNKS 8
 __global__ __launch_bounds__(256) void k_match_candidates(MatchParams M, float gwInv, float ghInv)
 {
@@ -193,6 +208,9 @@ __global__ __launch_bounds__(256) void k_match_candidates(MatchParams M, float g
     const unsigned long long q0 = d1[0], q1 = d1[1], q2 = d1[2], q3 = d1[3];
     const unsigned long long below = (1ull << lane) - 1ull;
     int nc = 0;
+    int tk[MS_K]; unsigned te[MS_K]; int nsel = 0;          // this lane's MS_K smallest (distance, list position) keys + their records
+#pragma unroll
+    for (int k = 0; k < MS_K; k++) { tk[k] = IMAX; te[k] = MS_NONE; }
     for (int tb = 0; tb < nitems; tb += 64 * MC_CHUNKS) {
         float2 k[MC_CHUNKS]; int it[MC_CHUNKS];
 #pragma unroll
@@ -211,13 +229,40 @@ __global__ __launch_bounds__(256) void k_match_candidates(MatchParams M, float g
             if (ok && pos < M.cand_stride) {
                 const unsigned long long* d2 = (const unsigned long long*)(M.desc2 + ((long long)slot * M.cap + it[c]) * 32);
                 const int dist = __popcll(q0 ^ d2[0]) + __popcll(q1 ^ d2[1]) + __popcll(q2 ^ d2[2]) + __popcll(q3 ^ d2[3]);
-                cand[pos] = (unsigned)it[c] | ((unsigned)dist << 20);          // DescriptorDistance (ORBmatcher.cc:442)
+                unsigned rec = (unsigned)it[c] | ((unsigned)dist << 20);       // DescriptorDistance (ORBmatcher.cc:442)
+                cand[pos] = rec;
+                int key = (dist << 20) | pos;
+                nsel++;
+#pragma unroll
+                for (int k = 0; k < MS_K; k++) if (key < tk[k]) { const int tkk = tk[k]; const unsigned tee = te[k]; tk[k] = key; te[k] = rec; key = tkk; rec = tee; }   // sorted insert
             }
             nc += __popcll(m);
         }
     }
     nc = min(nc, M.cand_stride);
     if (lane == 0) M.ncand[(long long)slot * M.lvl0_cap + j1] = nc;
+    // The best / second-best update of the reference (ORBmatcher.cc:447-456) ends with the two smallest (distance, list position)
+    // keys among the candidates it does not skip.  Record the MS_K smallest of the whole list: k_match_select takes the first two
+    // that are not skipped at its turn.
+    unsigned out = MS_NONE; int popped = 0;
+#pragma unroll
+    for (int r = 0; r < MS_K; r++) {
+        const int m = wave_min_dpp(tk[0]);
+        if (m == IMAX) break;
+        const int owner = __ffsll((long long)__ballot(tk[0] == m)) - 1;
+        const unsigned rec = (unsigned)__builtin_amdgcn_readlane((int)te[0], owner);
+        if (lane == r) out = rec;
+        if (lane == owner) {
+            popped++;
+#pragma unroll
+            for (int k = 0; k + 1 < MS_K; k++) { tk[k] = tk[k + 1]; te[k] = te[k + 1]; }
+            tk[MS_K - 1] = IMAX; te[MS_K - 1] = MS_NONE;
+        }
+    }
+    const bool more = __ballot(nsel > popped) != 0ull;
+    unsigned* top = M.top + ((long long)slot * M.lvl0_cap + j1) * MS_REC;
+    if (lane < MS_K) top[lane] = out;
+    if (lane == MS_K) top[MS_K] = more ? 1u : 0u;
 }
 
 void orbhip_launch_match_candidates(const MatchParams& M, int nslots, hipStream_t s)
@@ -236,26 +281,13 @@ __device__ __forceinline__ unsigned long long wave_argmin_mask(int d, unsigned l
     return M;
 }
 
-// wave64 minimum with DPP row shifts / broadcasts (6 dependent 4-cycle VALU steps); result broadcast from lane 63
-__device__ __forceinline__ int wave_min_dpp(int v)
-{
-    v = min(v, __builtin_amdgcn_update_dpp(IMAX, v, 0x111, 0xf, 0xf, false));      // row_shr:1
-    v = min(v, __builtin_amdgcn_update_dpp(IMAX, v, 0x112, 0xf, 0xf, false));      // row_shr:2
-    v = min(v, __builtin_amdgcn_update_dpp(IMAX, v, 0x114, 0xf, 0xe, false));      // row_shr:4
-    v = min(v, __builtin_amdgcn_update_dpp(IMAX, v, 0x118, 0xf, 0xc, false));      // row_shr:8 -> lane 15 of each row = row minimum
-    v = min(v, __builtin_amdgcn_update_dpp(IMAX, v, 0x142, 0xa, 0xf, false));      // row_bcast:15 into rows 1 and 3
-    v = min(v, __builtin_amdgcn_update_dpp(IMAX, v, 0x143, 0xc, 0xf, false));      // row_bcast:31 into rows 2 and 3 -> lane 63 = wave minimum
-    return __builtin_amdgcn_readlane(v, 63);
-}
-
 #define MS_T 256
-#define MS_DEPTH 4                      // candidate lists are fetched this many keypoints ahead of the replay
 
-// One workgroup per camera slot.  All 4 waves initialise the per-slot tables in LDS, then wave 0 alone replays the
-// order-dependent loop over F1's level-0 keypoints.  The candidate lists (i2 | dist<<20, canonical order) stay in HBM/L2:
-// the first 128 records of the list of keypoint j1+MS_DEPTH are loaded while j1 is processed (a register ring), so the memory
-// latency is off the critical path and the kernel's LDS footprint stays small enough not to displace the workgroups of the
-// extraction kernels it runs beside (an 80 KB staged copy of the lists used to halve k_fast_cells' occupancy on every CU).
+// One workgroup per camera slot.  All 4 waves initialise the per-slot tables in LDS, then wave 0 alone resolves the
+// order-dependent loop over F1's level-0 keypoints, 64 of them per step, from the MS_K records k_match_candidates left per key
+// point (see the loop).  The candidate lists themselves (i2 | dist<<20, canonical order) stay in HBM/L2 and are only read for the
+// rare key point whose records are used up; the kernel's LDS footprint stays small enough not to displace the workgroups of
+// the extraction kernels it runs beside (an 80 KB staged copy of the lists used to halve k_fast_cells' occupancy on every CU).
 __global__ __launch_bounds__(MS_T) void k_match_select(MatchParams M)
 {
     const int slot = blockIdx.x + M.slot0, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -269,75 +301,114 @@ __global__ __launch_bounds__(MS_T) void k_match_select(MatchParams M)
     int* s_bin = s_m12 + M.lvl0_cap;        // rotation bin of the accepted match of i1, -1 = none
     int* s_nc = s_bin + M.lvl0_cap;         // candidate count per level-0 i1
     int* s_hist = s_nc + M.lvl0_cap;        // [HISTO_LENGTH] + misc
-    float* s_ang1 = reinterpret_cast<float*>(s_hist + ORBHIP_HISTO_LENGTH + 8);   // angle of F1's level-0 keypoint j1
+    int* s_stamp = s_hist + ORBHIP_HISTO_LENGTH + 8;                               // lowest undecided query that wants to claim feature i2
+    float* s_ang1 = reinterpret_cast<float*>(s_stamp + M.cap);                    // angle of F1's level-0 keypoint j1
     float* s_ang2 = s_ang1 + M.lvl0_cap;                                           // angle of F2's keypoint i2
     const orbhip_keypoint* kp1 = M.kp1 + (long long)slot * M.cap;
     const orbhip_keypoint* kp2 = M.kp2 + (long long)slot * M.cap;
     int* m12 = M.matches12 + (long long)slot * M.cap;
     float* prev = M.prev + (long long)slot * M.cap * 2;
     const unsigned* cand0 = M.cand + (long long)slot * M.lvl0_cap * M.cand_stride;
-    for (int i = tid; i < n2; i += MS_T) { s_md[i] = IMAX; s_m21[i] = -1; s_ang2[i] = kp2[i].angle; }
+    for (int i = tid; i < n2; i += MS_T) { s_md[i] = IMAX; s_m21[i] = -1; s_stamp[i] = IMAX; s_ang2[i] = kp2[i].angle; }
     for (int i = tid; i < n1l; i += MS_T) { s_m12[i] = -1; s_bin[i] = -1; s_nc[i] = M.ncand[(long long)slot * M.lvl0_cap + i]; s_ang1[i] = kp1[list1 ? list1[i] : i].angle; }
     for (int i = tid; i < ORBHIP_HISTO_LENGTH + 8; i += MS_T) s_hist[i] = 0;
     for (int i = tid; i < n1; i += MS_T) { m12[i] = -1; if (M.prev_from_kp1) { prev[2 * i] = kp1[i].x; prev[2 * i + 1] = kp1[i].y; } }
     __syncthreads();
     if (wave == 0) {
         const float factor = 1.0f / ORBHIP_HISTO_LENGTH;
-        unsigned ring[MS_DEPTH][2];          // records [lane] and [64 + lane] of the lists of keypoints j1 .. j1+MS_DEPTH-1
-        auto fetch = [&](int j, unsigned (&r)[2]) {
-            r[0] = 0; r[1] = 0;
-            if (j < n1l) {
-                const int ncj = s_nc[j];
-                const unsigned* c = cand0 + (long long)j * M.cand_stride;
-                if (lane < ncj) r[0] = c[lane];
-                if (64 + lane < ncj) r[1] = c[64 + lane];
-            }
+        const unsigned* top0 = M.top + (long long)slot * M.lvl0_cap * MS_REC;
+        auto rot_bin = [&](int j1, int i2) -> int {                                        // :470-480
+            float rot = __fsub_rn(s_ang1[j1], s_ang2[i2]);
+            if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+            int bin = (int)roundf(__fmul_rn(rot, factor));
+            if (bin == ORBHIP_HISTO_LENGTH) bin = 0;
+            return min(max(bin, 0), ORBHIP_HISTO_LENGTH - 1);
         };
+        // 64 previous-frame key points per step.  A candidate is skipped once it is matched at a distance <= this query's
+        // (vMatchedDistance only ever decreases), so a query's best / second-best are the first two recorded candidates that are
+        // not skipped when its turn comes.  All lanes decide at once; a lane one of whose relevant records an earlier, still
+        // undecided lane wants to claim (atomicMin stamp) waits for the next iteration; only a query whose records are used up
+        // while its list holds more is rescanned from the list.
+        for (int jb = 0; jb < n1l; jb += 64) {
+            const int j1 = jb + lane;
+            const bool inb = j1 < n1l;
+            int ei[MS_K], ed[MS_K]; int nk = 0;
 #pragma unroll
-        for (int u = 0; u < MS_DEPTH; u++) fetch(u, ring[u]);
-        for (int jb = 0; jb < n1l; jb += MS_DEPTH) {
+            for (int k = 0; k < MS_K; k++) {
+                const unsigned t = (inb && s_nc[j1] != 0) ? top0[(long long)j1 * MS_REC + k] : MS_NONE;
+                ei[k] = (int)(t & 0xFFFFFu); ed[k] = (int)((t >> 20) & 0x1FFu);
+                if (t != MS_NONE) nk = k + 1;
+            }
+            const bool more = nk > 0 && top0[(long long)j1 * MS_REC + MS_K] != 0u;
+            int stamped = -1;
+            unsigned long long todo = __ballot(nk > 0);
+            while (todo) {
+                const bool mine = (todo >> lane) & 1ull;
+                const int lowest = __ffsll((long long)todo) - 1;
+                int a = -1, b = -1;
 #pragma unroll
-            for (int u = 0; u < MS_DEPTH; u++) {
-                const int j1 = jb + u;
-                const unsigned e0 = ring[u][0], e1 = ring[u][1];
-                fetch(j1 + MS_DEPTH, ring[u]);
-                const int nc = j1 < n1l ? s_nc[j1] : 0;
-                if (nc != 0) {
-                    const unsigned* cand = cand0 + (long long)j1 * M.cand_stride;
-                    int best = IMAX, second = IMAX, bidx = -1;
-                    for (int cb = 0; cb < nc; cb += 64) {
-                        const int t = cb + lane;
-                        unsigned e = cb == 0 ? e0 : e1;
-                        if (cb >= 128) { e = 0; if (t < nc) e = cand[t]; }              // lists longer than the prefetched 128 records
-                        const int i2 = (int)(e & 0xFFFFFu), dist = (int)(e >> 20);
-                        const bool valid = t < nc && !(s_md[i2] <= dist);                    // :444-445
-                        // smallest (distance, lane) key by a DPP min network: strict '<' means the first candidate with the minimum
-                        // wins (:447-452); the runner-up is the minimum with that lane masked out
-                        const int key = valid ? ((dist << 6) | lane) : IMAX;
-                        const int k1 = wave_min_dpp(key);
-                        if (k1 == IMAX) continue;
-                        const int first = k1 & 63, wmin = k1 >> 6, ci = __builtin_amdgcn_readlane(i2, first);
-                        const int k2 = wave_min_dpp(lane == first ? IMAX : key);
-                        const int wsec = k2 == IMAX ? IMAX : (k2 >> 6);
-                        if (wmin < best) { second = min(best, wsec); best = wmin; bidx = ci; } else second = min(second, wmin);
-                    }
-                    if (best <= ORBHIP_TH_LOW && (float)best < __fmul_rn((float)second, M.nnratio)) {      // :459-461
-                        if (lane == 0) {
-                            const int old = s_m21[bidx];
-                            if (old >= 0) s_m12[old] = -1;
-                            s_m12[j1] = bidx; s_m21[bidx] = j1; s_md[bidx] = best;
-                            if (M.check_ori) {
-                                float rot = __fsub_rn(s_ang1[j1], s_ang2[bidx]);
-                                if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
-                                int bin = (int)roundf(__fmul_rn(rot, factor));
-                                if (bin == ORBHIP_HISTO_LENGTH) bin = 0;
-                                bin = min(max(bin, 0), ORBHIP_HISTO_LENGTH - 1);
-                                s_bin[j1] = bin; s_hist[bin]++;               // rotHist[bin].push_back(i1): never removed when stolen
-                            }
-                        }
-                        __builtin_amdgcn_wave_barrier();                     // lane 0's LDS updates are read by the whole wave next
+                for (int k = 0; k < MS_K; k++)
+                    if (mine && k < nk && b < 0 && !(s_md[ei[k]] <= ed[k])) { if (a < 0) a = k; else b = k; }      // :444-445
+                const int ia = a >= 0 ? ei[a] : 0, da = a >= 0 ? ed[a] : IMAX, db = b >= 0 ? ed[b] : IMAX;
+                const bool exhausted = mine && more && b < 0;
+                const bool accept = mine && !exhausted && a >= 0 && da <= ORBHIP_TH_LOW && (float)da < __fmul_rn((float)db, M.nnratio);    // :459-461
+                const int want = accept ? ia : -1;
+                if (stamped >= 0 && stamped != want && s_stamp[stamped] == j1) s_stamp[stamped] = IMAX;       // withdraw an outdated claim
+                __builtin_amdgcn_wave_barrier();
+                if (want >= 0) atomicMin(&s_stamp[want], j1);
+                stamped = want;
+                __builtin_amdgcn_wave_barrier();
+                bool unsure = false;
+                const int last = b >= 0 ? b : nk - 1;
+#pragma unroll
+                for (int k = 0; k < MS_K; k++)
+                    if (mine && lane != lowest && k <= last && !(s_md[ei[k]] <= ed[k]) && s_stamp[ei[k]] < j1) unsure = true;
+                const unsigned long long bad = __ballot(unsure || exhausted);
+                const int first_bad = bad ? __ffsll((long long)bad) - 1 : 64;
+                const unsigned long long commit = first_bad == 64 ? todo : (todo & ((1ull << first_bad) - 1ull));
+                const bool win = ((commit >> lane) & 1ull) && accept;
+                if (win) {                                                                  // claimed features are distinct within one commit
+                    const int old = s_m21[ia];
+                    if (old >= 0) s_m12[old] = -1;                                          // :463-467
+                    s_m12[j1] = ia; s_m21[ia] = j1; s_md[ia] = da;
+                    if (s_stamp[ia] == j1) s_stamp[ia] = IMAX;                              // a decided claim lives in vMatchedDistance
+                    stamped = -1;
+                    if (M.check_ori) { const int bin = rot_bin(j1, ia); s_bin[j1] = bin; atomicAdd(&s_hist[bin], 1); }      // rotHist[bin].push_back(i1): never removed when stolen
+                }
+                __builtin_amdgcn_wave_barrier();
+                todo &= ~commit;
+                if (first_bad == 64) break;
+                if (first_bad != lowest || !((__ballot(exhausted) >> first_bad) & 1ull)) continue;
+                // rescan the list of key point jb + first_bad against the current state
+                todo &= ~(1ull << first_bad);
+                if (lane == first_bad && stamped >= 0 && s_stamp[stamped] == j1) s_stamp[stamped] = IMAX;
+                const int js = jb + first_bad, nc = s_nc[js];
+                const unsigned* cand = cand0 + (long long)js * M.cand_stride;
+                int best = IMAX, second = IMAX, bidx = -1;
+                for (int cb = 0; cb < nc; cb += 64) {
+                    const int t = cb + lane;
+                    const unsigned e = t < nc ? cand[t] : 0u;
+                    const int i2 = (int)(e & 0xFFFFFu), dist = (int)(e >> 20);
+                    const bool valid = t < nc && !(s_md[i2] <= dist);                    // :444-445
+                    // smallest (distance, lane) key by a DPP min network: strict '<' means the first candidate with the minimum
+                    // wins (:447-452); the runner-up is the minimum with that lane masked out
+                    const int key = valid ? ((dist << 6) | lane) : IMAX;
+                    const int k1 = wave_min_dpp(key);
+                    if (k1 == IMAX) continue;
+                    const int first = k1 & 63, wmin = k1 >> 6, ci = __builtin_amdgcn_readlane(i2, first);
+                    const int k2 = wave_min_dpp(lane == first ? IMAX : key);
+                    const int wsec = k2 == IMAX ? IMAX : (k2 >> 6);
+                    if (wmin < best) { second = min(best, wsec); best = wmin; bidx = ci; } else second = min(second, wmin);
+                }
+                if (best <= ORBHIP_TH_LOW && (float)best < __fmul_rn((float)second, M.nnratio)) {      // :459-461
+                    if (lane == 0) {
+                        const int old = s_m21[bidx];
+                        if (old >= 0) s_m12[old] = -1;
+                        s_m12[js] = bidx; s_m21[bidx] = js; s_md[bidx] = best;
+                        if (M.check_ori) { const int bin = rot_bin(js, bidx); s_bin[js] = bin; s_hist[bin]++; }
                     }
                 }
+                __builtin_amdgcn_wave_barrier();                     // lane 0's LDS updates are read by the whole wave next
             }
         }
     }
@@ -374,6 +445,6 @@ __global__ __launch_bounds__(MS_T) void k_match_select(MatchParams M)
 
 void orbhip_launch_match_select(const MatchParams& M, int nslots, hipStream_t s)
 {
-    const size_t lds = sizeof(int) * ((size_t)3 * M.cap + (size_t)4 * M.lvl0_cap + ORBHIP_HISTO_LENGTH + 8);
+    const size_t lds = sizeof(int) * ((size_t)4 * M.cap + (size_t)4 * M.lvl0_cap + ORBHIP_HISTO_LENGTH + 8);
     hipLaunchKernelGGL(k_match_select, dim3(nslots, 1, 1), dim3(MS_T, 1, 1), lds, s, M);
 }
