@@ -272,14 +272,6 @@ void orbhip_launch_match_candidates(const MatchParams& M, int nslots, hipStream_
 }
 
 // ------------------------------------------------------------------------------------------------ select
-// Lanes holding the minimum of a 9-bit key (0..256) among the lanes of `M`: MSB-first elimination with ballots
-// (v_cmp + scalar mask ops, no cross-lane data movement).
-__device__ __forceinline__ unsigned long long wave_argmin_mask(int d, unsigned long long M)
-{
-#pragma unroll
-    for (int b = 8; b >= 0; b--) { const unsigned long long z = __ballot(((d >> b) & 1) == 0) & M; if (z) M = z; }
-    return M;
-}
 
 #define MS_T 256
 

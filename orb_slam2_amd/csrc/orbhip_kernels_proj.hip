@@ -114,12 +114,6 @@ __global__ __launch_bounds__(256) void k_proj_candidates(ProjParams J, float gwI
     if (lane == PJ_K) J.top[PJ_REC * iq + PJ_K] = more ? 1u : 0u;
 }
 
-__device__ __forceinline__ unsigned long long pj_argmin_mask(int d, unsigned long long M)
-{
-#pragma unroll
-    for (int b = 8; b >= 0; b--) { const unsigned long long z = __ballot(((d >> b) & 1) == 0) & M; if (z) M = z; }
-    return M;
-}
 
 __global__ __launch_bounds__(PJ_T) void k_proj_select(ProjParams J)
 {
@@ -210,9 +204,6 @@ __global__ __launch_bounds__(PJ_T) void k_proj_select(ProjParams J)
                 todo &= ~(1ull << first_bad);
                 const int qs = qb + first_bad;
                 if (lane == first_bad && stamped >= 0 && s_stamp[stamped] == q) { s_stamp[stamped] = IMAX; }
-#ifdef PJ_DEBUG
-                if (lane == 0) s_hist[ORBHIP_HISTO_LENGTH + 2]++;
-#endif
                 // rescan query qb + first_bad against the current state (its speculative claim, if any, was withdrawn above)
                 const int nc = J.ncand[qs];
                 const unsigned* cand = J.cand + (long long)qs * J.cand_stride;
@@ -269,9 +260,6 @@ __global__ __launch_bounds__(PJ_T) void k_proj_select(ProjParams J)
             __builtin_amdgcn_wave_barrier();
             nmatches -= s_hist[ORBHIP_HISTO_LENGTH];
         }
-#ifdef PJ_DEBUG
-        if (lane == 0) printf("proj select: mode %d nq %d slow %d\n", J.mode, J.nq, s_hist[ORBHIP_HISTO_LENGTH + 2]);
-#endif
         if (lane == 0) *J.nmatches = nmatches;
     }
     __syncthreads();
