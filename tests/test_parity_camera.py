@@ -233,3 +233,32 @@ def test_stereo_from_rgbd(backend, oracle, distorted):
     u_o, z_o = oracle.stereo_from_rgbd(K[0][0], U[0], raw[0], factor, mbf)
     assert u_s[0, :len(u_o)].tobytes() == u_o.tobytes() and z_s[0, :len(z_o)].tobytes() == z_o.tobytes()
     ex.close()
+
+
+def test_camera_entry_points_reject_bad_arguments(backend):
+    """Error behaviour of the camera-geometry entry points: bad arguments come back as OrbHipError with a message, nothing is silently ignored."""
+    w, h = 160, 120
+    ex = orb_slam2_amd.ORBextractor(100, 1.2, 4, 20, 7, w, h, library=backend)
+    with pytest.raises(orb_slam2_amd.OrbHipError):
+        ex.set_camera((0.0, 100.0, 80.0, 60.0, 0.1, 0.0, 0.0, 0.0))                    # fx == 0
+    ex.src_w, ex.src_h = w, h                                                           # (the Python mirror only checks the frame shape)
+    with pytest.raises(orb_slam2_amd.OrbHipError):
+        ex.extract_batch_rectify([np.zeros((h, w), np.uint8)])                          # no maps attached
+    mx, my = np.meshgrid(np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32))
+    with pytest.raises(orb_slam2_amd.OrbHipError):
+        ex.set_rectification(mx, my, 40000, 100)                                        # raw size beyond remap's 16-bit coordinates
+    ex.set_rectification(mx, my, w, h)
+    ex.set_rectification(None, None, 0, 0)                                              # maps removed again
+    with pytest.raises(orb_slam2_amd.OrbHipError):
+        ex.extract_device_rectify(0x1000, 1, w * h, w)
+    with pytest.raises(orb_slam2_amd.OrbHipError):
+        ex.ComputeStereoFromRGBD([np.zeros((h, w), np.float32)], 1.0, 40.0)             # nothing extracted yet
+    ex.extract_batch([synth.frame(w, h, seed=1)])
+    u = np.zeros((1, ex.capacity), np.float32)
+    ptrs = (C.c_void_p * 1)(np.zeros((h, w), np.float32).ctypes.data)
+    assert ex.L.orbhip_compute_stereo_from_rgbd(ex.h, 1, ptrs, 4 * w, 7, 1.0, 40.0, u.ctypes.data_as(C.c_void_p), u.ctypes.data_as(C.c_void_p), ex.capacity) != 0   # unknown depth type
+    assert ex.L.orbhip_compute_stereo_from_rgbd(ex.h, 1, ptrs, 2 * w, 0, 1.0, 40.0, u.ctypes.data_as(C.c_void_p), u.ctypes.data_as(C.c_void_p), ex.capacity) != 0   # stride < row bytes
+    assert b"stride" in ex.L.orbhip_last_error()
+    with pytest.raises(orb_slam2_amd.OrbHipError):
+        orb_slam2_amd.image_bounds((0.0, 1.0, 0.0, 0.0, 0.1, 0, 0, 0), w, h, library=backend)
+    ex.close()
