@@ -103,13 +103,55 @@ template <typename T> static hipError_t dalloc(T** p, size_t count) { return hip
 // Per-thread, grow-only device scratch for the host-pointer matcher entry points: one hipMalloc the first time (or when a call
 // needs more), none afterwards — hipMalloc / hipFree cost more than the kernels of a single-frame call.
 static thread_local void* g_scratch = nullptr; static thread_local size_t g_scratch_bytes = 0; static thread_local int g_scratch_dev = -1;
+struct Xfer { size_t off; const void* src; void* dst; size_t bytes_in, bytes_out; };
+static thread_local std::vector<Xfer> g_xfers;               // host <-> arena transfers of the call being laid out
 struct Arena {
     uint8_t* base = nullptr; size_t off = 0;
     template <typename T> void take(T** p, size_t count) { *p = reinterpret_cast<T*>(base + off); off += (std::max<size_t>(count, 1) * sizeof(T) + 255) & ~(size_t)255; }
+    // a buffer with a host side: n_in elements are uploaded from src before the kernels, n_out elements downloaded to dst after them.
+    // Take every such buffer before the pure scratch ones so that all of them travel in ONE copy each way (arena_upload / arena_download).
+    template <typename T> void io(T** p, size_t count, const T* src, size_t n_in, T* dst = nullptr, size_t n_out = 0)
+    {
+        const size_t o = off;
+        take(p, count);
+        if (base && ((src && n_in) || (dst && n_out))) g_xfers.push_back(Xfer{o, src && n_in ? src : nullptr, dst && n_out ? dst : nullptr, n_in * sizeof(T), n_out * sizeof(T)});
+    }
 };
+static thread_local uint8_t* g_hstage = nullptr; static thread_local size_t g_hstage_bytes = 0;      // pinned mirror of the arena's host-visible head
+static hipError_t hstage_reserve(size_t bytes)
+{
+    if (g_hstage_bytes >= bytes) return hipSuccess;
+    if (g_hstage) (void)hipHostFree(g_hstage);
+    g_hstage = nullptr; g_hstage_bytes = 0;
+    const hipError_t e = hipHostMalloc((void**)&g_hstage, bytes + bytes / 4, hipHostMallocDefault);
+    if (e == hipSuccess) g_hstage_bytes = bytes + bytes / 4;
+    return e;
+}
+// One pageable->pinned gather on the host and ONE host-to-device copy for all inputs of a call (a hipMemcpy per array costs more
+// than the kernels of a single-frame matcher call); likewise one device-to-host copy for all outputs.
+static hipError_t arena_upload(hipStream_t s)
+{
+    size_t hi = 0;
+    for (const Xfer& x : g_xfers) hi = std::max(hi, x.off + std::max(x.bytes_in, x.bytes_out));
+    hipError_t e = hstage_reserve(hi); if (e != hipSuccess) return e;
+    size_t in_hi = 0;
+    for (const Xfer& x : g_xfers) if (x.src) { memcpy(g_hstage + x.off, x.src, x.bytes_in); in_hi = std::max(in_hi, x.off + x.bytes_in); }
+    return in_hi ? hipMemcpyAsync(g_scratch, g_hstage, in_hi, hipMemcpyHostToDevice, s) : hipSuccess;
+}
+static hipError_t arena_download(hipStream_t s)
+{
+    size_t lo = (size_t)-1, hi = 0;
+    for (const Xfer& x : g_xfers) if (x.dst) { lo = std::min(lo, x.off); hi = std::max(hi, x.off + x.bytes_out); }
+    if (hi == 0) return hipStreamSynchronize(s);
+    hipError_t e = hipMemcpyAsync(g_hstage + lo, static_cast<uint8_t*>(g_scratch) + lo, hi - lo, hipMemcpyDeviceToHost, s); if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(s); if (e != hipSuccess) return e;
+    for (const Xfer& x : g_xfers) if (x.dst) memcpy(x.dst, g_hstage + x.off, x.bytes_out);
+    return hipSuccess;
+}
 template <typename Layout> static hipError_t arena_layout(int device, Layout layout)
 {
-    Arena dry; layout(dry);                                   // first pass: sizes only
+    g_xfers.clear();
+    Arena dry; layout(dry);                                   // first pass: sizes only (no base: nothing is logged)
     if (g_scratch_dev != device || g_scratch_bytes < dry.off) {
         if (g_scratch) (void)hipFree(g_scratch);
         g_scratch = nullptr; g_scratch_bytes = 0;
@@ -664,19 +706,17 @@ extern "C" orbhip_status orbhip_search_by_projection_bounds(int device, const or
     float2* dgxy = nullptr; orbhip_proj_query* dq = nullptr; unsigned* dcand = nullptr; unsigned* dtop = nullptr;
     hipError_t e = hipSuccess;
 #define TRY(x) do { if (e == hipSuccess) e = (x); } while (0)
+    const int hn[2] = {n, 0}; int hres[2] = {0, 0};
     TRY(arena_layout(device, [&](Arena& A) {
-        A.take(&dk, n); A.take(&dd, (size_t)n * 32); A.take(&dqd, (size_t)nq * 32); A.take(&dq, nq); A.take(&dn, 8);
-        A.take(&dgs, ORBHIP_GRID_CELLS + 1); A.take(&dgi, n); A.take(&dgxy, n); A.take(&dnc, nq); A.take(&dfq, n); A.take(&dev, nq);
+        A.io(&dk, n, kps, n); A.io(&dd, (size_t)n * 32, desc, (size_t)n * 32); A.io(&dqd, (size_t)nq * 32, query_desc, (size_t)nq * 32); A.io(&dq, nq, queries, nq);
+        if (u_right) A.io(&dur, n, u_right, n);
+        if (blocked) A.io(&dbl_in, n, blocked, n);
+        A.io(&dn, 8, hn, 2, hres, 2);                         // [0] = n in, [1] = the return value out
+        A.io(&dfq, n, (const int*)nullptr, 0, feature_query, n);
+        A.take(&dgs, ORBHIP_GRID_CELLS + 1); A.take(&dgi, n); A.take(&dgxy, n); A.take(&dnc, nq); A.take(&dev, nq);
         A.take(&dcand, (size_t)nq * n); A.take(&dtop, (size_t)nq * 5);
-        if (u_right) A.take(&dur, n);
-        if (blocked) A.take(&dbl_in, n);
     }));
-    if (u_right) TRY(hipMemcpy(dur, u_right, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
-    if (blocked) TRY(hipMemcpy(dbl_in, blocked, (size_t)n, hipMemcpyHostToDevice));
-    const int hn[2] = {n, 0};
-    TRY(hipMemcpy(dk, kps, (size_t)n * sizeof(orbhip_keypoint), hipMemcpyHostToDevice)); TRY(hipMemcpy(dd, desc, (size_t)n * 32, hipMemcpyHostToDevice));
-    TRY(hipMemcpy(dq, queries, (size_t)nq * sizeof(orbhip_proj_query), hipMemcpyHostToDevice)); TRY(hipMemcpy(dqd, query_desc, (size_t)nq * 32, hipMemcpyHostToDevice));
-    TRY(hipMemcpy(dn, hn, sizeof hn, hipMemcpyHostToDevice));
+    TRY(arena_upload(nullptr));
     if (e == hipSuccess) {
         MatchParams M; memset(&M, 0, sizeof M);
         M.kp2 = dk; M.n2 = dn; M.cap = n; M.min_x = bounds->min_x; M.min_y = bounds->min_y; M.max_x = bounds->max_x; M.max_y = bounds->max_y; M.grid_start = dgs; M.grid_items = dgi; M.grid_xy = dgxy; M.grid_all_levels = 1;
@@ -689,9 +729,8 @@ extern "C" orbhip_status orbhip_search_by_projection_bounds(int device, const or
         orbhip_launch_proj(J, nullptr);
         e = hipGetLastError();
     }
-    TRY(hipDeviceSynchronize());
-    TRY(hipMemcpy(feature_query, dfq, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
-    TRY(hipMemcpy(nmatches, dn + 1, sizeof(int), hipMemcpyDeviceToHost));
+    TRY(arena_download(nullptr));
+    if (e == hipSuccess) *nmatches = hres[1];
 #undef TRY
     orbhip_status st = ORBHIP_OK;
     if (e != hipSuccess) st = fail(ORBHIP_ERR_HIP, "search_by_projection: %s", hipGetErrorString(e));
@@ -712,18 +751,15 @@ extern "C" orbhip_status orbhip_search_best_in_window_bounds(int device, const o
     float2* dgxy = nullptr; orbhip_best_query* dq = nullptr;
     hipError_t e = hipSuccess;
 #define TRY(x) do { if (e == hipSuccess) e = (x); } while (0)
-    TRY(arena_layout(device, [&](Arena& A) {
-        A.take(&dk, n); A.take(&dd, (size_t)n * 32); A.take(&dqd, (size_t)nq * 32); A.take(&dq, nq); A.take(&dn, 8);
-        A.take(&dgs, ORBHIP_GRID_CELLS + 1); A.take(&dgi, n); A.take(&dgxy, n); A.take(&dbi, nq); A.take(&dbd, nq);
-        if (u_right) A.take(&dur, n);
-        if (inv_level_sigma2 && nlevels > 0) A.take(&dsg, nlevels);
-    }));
-    if (u_right) TRY(hipMemcpy(dur, u_right, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
-    if (inv_level_sigma2 && nlevels > 0) TRY(hipMemcpy(dsg, inv_level_sigma2, (size_t)nlevels * sizeof(float), hipMemcpyHostToDevice));
     const int hn[2] = {n, 0};
-    TRY(hipMemcpy(dk, kps, (size_t)n * sizeof(orbhip_keypoint), hipMemcpyHostToDevice)); TRY(hipMemcpy(dd, desc, (size_t)n * 32, hipMemcpyHostToDevice));
-    TRY(hipMemcpy(dq, queries, (size_t)nq * sizeof(orbhip_best_query), hipMemcpyHostToDevice)); TRY(hipMemcpy(dqd, query_desc, (size_t)nq * 32, hipMemcpyHostToDevice));
-    TRY(hipMemcpy(dn, hn, sizeof hn, hipMemcpyHostToDevice));
+    TRY(arena_layout(device, [&](Arena& A) {
+        A.io(&dk, n, kps, n); A.io(&dd, (size_t)n * 32, desc, (size_t)n * 32); A.io(&dqd, (size_t)nq * 32, query_desc, (size_t)nq * 32); A.io(&dq, nq, queries, nq); A.io(&dn, 8, hn, 2);
+        if (u_right) A.io(&dur, n, u_right, n);
+        if (inv_level_sigma2 && nlevels > 0) A.io(&dsg, nlevels, inv_level_sigma2, nlevels);
+        A.io(&dbi, nq, (const int*)nullptr, 0, best_idx, nq); A.io(&dbd, nq, (const int*)nullptr, 0, best_dist, nq);
+        A.take(&dgs, ORBHIP_GRID_CELLS + 1); A.take(&dgi, n); A.take(&dgxy, n);
+    }));
+    TRY(arena_upload(nullptr));
     if (e == hipSuccess) {
         MatchParams M; memset(&M, 0, sizeof M);
         M.kp2 = dk; M.n2 = dn; M.cap = n; M.min_x = bounds->min_x; M.min_y = bounds->min_y; M.max_x = bounds->max_x; M.max_y = bounds->max_y; M.grid_start = dgs; M.grid_items = dgi; M.grid_xy = dgxy; M.grid_all_levels = 1;
@@ -734,9 +770,7 @@ extern "C" orbhip_status orbhip_search_best_in_window_bounds(int device, const o
         orbhip_launch_best_in_window(B, nullptr);
         e = hipGetLastError();
     }
-    TRY(hipDeviceSynchronize());
-    TRY(hipMemcpy(best_idx, dbi, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost));
-    TRY(hipMemcpy(best_dist, dbd, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost));
+    TRY(arena_download(nullptr));
 #undef TRY
     orbhip_status st = ORBHIP_OK;
     if (e != hipSuccess) st = fail(ORBHIP_ERR_HIP, "search_best_in_window: %s", hipGetErrorString(e));
@@ -1086,17 +1120,17 @@ extern "C" orbhip_status orbhip_search_for_initialization_bounds(int device, con
     unsigned* dcand = nullptr; unsigned* dtop = nullptr; float* dprev = nullptr;
     hipError_t e = hipSuccess;
 #define TRY(x) do { if (e == hipSuccess) e = (x); } while (0)
+    const int hn[4] = {n1, n2, (int)list1.size(), 0}; int hres[4] = {0, 0, 0, 0};
     TRY(arena_layout(device, [&](Arena& A) {
-        A.take(&dk1, cap); A.take(&dk2, cap); A.take(&dd1, (size_t)cap * 32); A.take(&dd2, (size_t)cap * 32); A.take(&dn, 8);
-        A.take(&dlist, l0cap); A.take(&dgs, ORBHIP_GRID_CELLS + 1); A.take(&dgi, cap); A.take(&dgxy, cap); A.take(&dnc, l0cap); A.take(&dm12, cap);
-        A.take(&dcand, (size_t)l0cap * cstride); A.take(&dtop, (size_t)l0cap * 5); A.take(&dprev, (size_t)cap * 2);
+        A.io(&dk1, cap, kps1, n1); A.io(&dk2, cap, kps2, n2); A.io(&dd1, (size_t)cap * 32, desc1, (size_t)n1 * 32); A.io(&dd2, (size_t)cap * 32, desc2, (size_t)n2 * 32);
+        A.io(&dlist, l0cap, (const int*)list1.data(), list1.size());
+        A.io(&dn, 8, hn, 4, hres, 4);                          // counts in, [3] = nmatches out
+        A.io(&dprev, (size_t)cap * 2, (const float*)prev_matched, (size_t)n1 * 2, prev_matched, (size_t)n1 * 2);
+        A.io(&dm12, cap, (const int*)nullptr, 0, matches12, n1);
+        A.take(&dgs, ORBHIP_GRID_CELLS + 1); A.take(&dgi, cap); A.take(&dgxy, cap); A.take(&dnc, l0cap);
+        A.take(&dcand, (size_t)l0cap * cstride); A.take(&dtop, (size_t)l0cap * 5);
     }));
-    const int hn[4] = {n1, n2, (int)list1.size(), 0};
-    TRY(hipMemcpy(dk1, kps1, (size_t)n1 * sizeof(orbhip_keypoint), hipMemcpyHostToDevice)); TRY(hipMemcpy(dd1, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice));
-    if (n2 > 0) { TRY(hipMemcpy(dk2, kps2, (size_t)n2 * sizeof(orbhip_keypoint), hipMemcpyHostToDevice)); TRY(hipMemcpy(dd2, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice)); }
-    TRY(hipMemcpy(dn, hn, sizeof hn, hipMemcpyHostToDevice));
-    if (!list1.empty()) TRY(hipMemcpy(dlist, list1.data(), list1.size() * sizeof(int), hipMemcpyHostToDevice));
-    TRY(hipMemcpy(dprev, prev_matched, (size_t)n1 * 2 * sizeof(float), hipMemcpyHostToDevice));
+    TRY(arena_upload(nullptr));
     if (e == hipSuccess) {
         MatchParams M; memset(&M, 0, sizeof M);
         M.kp1 = dk1; M.desc1 = dd1; M.n1 = dn; M.n1_lvl0 = dn + 2; M.kp2 = dk2; M.desc2 = dd2; M.n2 = dn + 1; M.lvl_stride = 0; M.list1 = dlist; M.prev_from_kp1 = 0;
@@ -1105,10 +1139,8 @@ extern "C" orbhip_status orbhip_search_for_initialization_bounds(int device, con
         orbhip_launch_match_grid(M, 1, nullptr); orbhip_launch_match_candidates(M, 1, nullptr); orbhip_launch_match_select(M, 1, nullptr);
         e = hipGetLastError();
     }
-    TRY(hipDeviceSynchronize());
-    TRY(hipMemcpy(matches12, dm12, (size_t)n1 * sizeof(int), hipMemcpyDeviceToHost));
-    TRY(hipMemcpy(prev_matched, dprev, (size_t)n1 * 2 * sizeof(float), hipMemcpyDeviceToHost));
-    TRY(hipMemcpy(nmatches, dn + 3, sizeof(int), hipMemcpyDeviceToHost));
+    TRY(arena_download(nullptr));
+    if (e == hipSuccess) *nmatches = hres[3];
 #undef TRY
     orbhip_status st = ORBHIP_OK;
     if (e != hipSuccess) st = fail(ORBHIP_ERR_HIP, "search_for_initialization: %s", hipGetErrorString(e));
