@@ -298,6 +298,18 @@ orbhip_status orbhip_search_best_in_window_bounds(int device, const orbhip_keypo
                                            const orbhip_best_query* queries, const uint8_t* query_desc, int nq, int chi2_gate,
                                            int32_t* best_idx, int32_t* best_dist);
 
+/* The same two searches on a frame that is still on the device (frame `frame` of the context's last extract call): key points
+   (mvKeysUn when a distorted camera is attached), descriptors, the image bounds and — with use_u_right != 0 — mvuRight of the last
+   orbhip_compute_stereo_matches (this context = left) / orbhip_compute_stereo_from_rgbd are read in HBM; only the queries, the
+   `blocked` flags and the results cross PCIe.  n = the frame's key point count as reported by orbhip_fetch (F.N); blocked / feature_query
+   hold n entries; inv_level_sigma2 of the best-in-window form = this extractor's own table. */
+orbhip_status orbhip_search_by_projection_frame(orbhip_ctx* ctx, int frame, int n, int use_u_right, const uint8_t* blocked,
+                                                const orbhip_proj_query* queries, const uint8_t* query_desc, int nq,
+                                                int mode, float nnratio, int th_high, int check_ori, int32_t* feature_query, int* nmatches);
+orbhip_status orbhip_search_best_in_window_frame(orbhip_ctx* ctx, int frame, int n, int use_u_right,
+                                                 const orbhip_best_query* queries, const uint8_t* query_desc, int nq, int chi2_gate,
+                                                 int32_t* best_idx, int32_t* best_dist);
+
 /* Stereo rectification on the input side: the EuRoC example runs cv::remap(raw, rect, M1, M2, cv::INTER_LINEAR) on the CPU for both
    images of every pair before TrackStereo (Examples/Stereo/stereo_euroc.cc:136-137; maps from cv::initUndistortRectifyMap(..,
    CV_32F, ..) :97-98).  orbhip_set_rectification uploads the two CV_32FC1 maps ([height][width] of the context, contiguous; they

@@ -67,7 +67,7 @@ struct orbhip_ctx {
     int* d_grid_start = nullptr; int* d_grid_items = nullptr; float2* d_grid_xy = nullptr; unsigned* d_cand = nullptr; unsigned* d_top = nullptr; int* d_ncand = nullptr; float* d_prev = nullptr; int* d_m12 = nullptr; int* d_nm = nullptr;
     // camera geometry: undistorted key points of a distorted camera, rectification maps of a raw stereo camera
     orbhip_bounds bounds = {0, 0, 0, 0}; bool distorted = false; CameraD cam = {}; orbhip_keypoint* d_out_kpun[3] = {nullptr, nullptr, nullptr}; orbhip_keypoint* h_kpun = nullptr;
-    int* d_map_x = nullptr; int* d_map_y = nullptr; int src_w = 0, src_h = 0, raw_pitch = 0; uint8_t* d_raw = nullptr; uint8_t* h_raw = nullptr; uint8_t* d_depth = nullptr; size_t depth_bytes = 0;
+    int* d_map_x = nullptr; int* d_map_y = nullptr; int src_w = 0, src_h = 0, raw_pitch = 0; uint8_t* d_raw = nullptr; uint8_t* h_raw = nullptr; uint8_t* d_depth = nullptr; size_t depth_bytes = 0; const float* d_last_uright = nullptr;   // mvuRight [slot][out_cap] of the last stereo / RGB-D step
     // profiling
     bool prof = false; std::vector<ProfSpan> pending; std::vector<hipEvent_t> pool; double tot_ms[K_COUNT] = {0}; long long launches[K_COUNT] = {0};
 };
@@ -413,7 +413,7 @@ static orbhip_status run_pipeline(orbhip_ctx* c, int nimg, const uint8_t* d_img0
     HIPCHK(hipSetDevice(c->cfg.device));
     c->cur = (c->cur + 1) % 3;
     const int cur = c->cur, prev = (cur + 2) % 3;
-    c->last_img0 = d_img0; c->last_img0_fstride = frame_stride; c->last_img0_pitch = row_stride;
+    c->last_img0 = d_img0; c->last_img0_fstride = frame_stride; c->last_img0_pitch = row_stride; c->d_last_uright = nullptr;
     // the buffer about to be overwritten was the "previous frame" of the matcher launched two calls ago
     for (int k = 0; k < 3; k++) if (c->match_pending[k] && (k == (cur + 1) % 3)) { HIPCHK(hipStreamWaitEvent(c->stream, c->ev_match[k], 0)); c->match_pending[k] = false; }
     ExtractParams P = make_params(c, d_img0, frame_stride, row_stride);
@@ -777,6 +777,97 @@ extern "C" orbhip_status orbhip_search_best_in_window_bounds(int device, const o
     return st;
 }
 
+// The two searches above on a frame that is still on the device: key points (mvKeysUn with a distorted camera attached), descriptors
+// and — if asked for — mvuRight of the last stereo / RGB-D step are read where the extraction left them; only the queries travel.
+static orbhip_status frame_args(orbhip_ctx* c, int frame, int n, int use_u_right, const orbhip_keypoint** kp, const uint8_t** desc, const float** ur)
+{
+    if (!c) return fail(ORBHIP_ERR_INVALID, "null context");
+    if (frame < 0 || frame >= c->last_nimg) return fail(ORBHIP_ERR_INVALID, "frame %d outside the %d frames of the last extraction", frame, c->last_nimg);
+    if (n < 0 || n > c->out_cap) return fail(ORBHIP_ERR_INVALID, "n %d outside 0..%d", n, c->out_cap);
+    if (use_u_right && !c->d_last_uright) return fail(ORBHIP_ERR_INVALID, "no mvuRight on the device: run orbhip_compute_stereo_matches / orbhip_compute_stereo_from_rgbd on this context first");
+    *kp = (c->distorted ? c->d_out_kpun : c->d_out_kp)[c->cur] + (size_t)frame * c->out_cap;
+    *desc = c->d_out_desc[c->cur] + (size_t)frame * c->out_cap * 32;
+    *ur = use_u_right ? c->d_last_uright + (size_t)frame * c->out_cap : nullptr;
+    return ORBHIP_OK;
+}
+extern "C" orbhip_status orbhip_search_by_projection_frame(orbhip_ctx* c, int frame, int n, int use_u_right, const uint8_t* blocked,
+                                                           const orbhip_proj_query* queries, const uint8_t* query_desc, int nq,
+                                                           int mode, float nnratio, int th_high, int check_ori, int32_t* feature_query, int* nmatches)
+{
+    const orbhip_keypoint* dk = nullptr; const uint8_t* dd = nullptr; const float* dur = nullptr;
+    orbhip_status st = frame_args(c, frame, n, use_u_right, &dk, &dd, &dur); if (st != ORBHIP_OK) return st;
+    if (nq < 0 || !nmatches || (n > 0 && !feature_query) || (nq > 0 && (!queries || !query_desc)) || (mode != 0 && mode != 1)) return fail(ORBHIP_ERR_INVALID, "bad argument");
+    *nmatches = 0;
+    for (int i = 0; i < n; i++) feature_query[i] = -1;
+    if (n == 0 || nq == 0) return ORBHIP_OK;
+    if (orbhip_proj_select_lds(n) > 150 * 1024) return fail(ORBHIP_ERR_UNSUPPORTED, "too many features for the LDS matcher (%d)", n);
+    HIPCHK(hipSetDevice(c->cfg.device));
+    uint8_t* dqd = nullptr; unsigned char* dbl_in = nullptr; int *dn = nullptr, *dgs = nullptr, *dgi = nullptr, *dnc = nullptr, *dfq = nullptr, *dev = nullptr;
+    float2* dgxy = nullptr; orbhip_proj_query* dq = nullptr; unsigned* dcand = nullptr; unsigned* dtop = nullptr;
+    hipError_t e = hipSuccess;
+#define TRY(x) do { if (e == hipSuccess) e = (x); } while (0)
+    const int hn[2] = {n, 0}; int hres[2] = {0, 0};
+    TRY(arena_layout(c->cfg.device, [&](Arena& A) {
+        A.io(&dqd, (size_t)nq * 32, query_desc, (size_t)nq * 32); A.io(&dq, nq, queries, nq);
+        if (blocked) A.io(&dbl_in, n, blocked, n);
+        A.io(&dn, 8, hn, 2, hres, 2);
+        A.io(&dfq, n, (const int*)nullptr, 0, feature_query, n);
+        A.take(&dgs, ORBHIP_GRID_CELLS + 1); A.take(&dgi, n); A.take(&dgxy, n); A.take(&dnc, nq); A.take(&dev, nq);
+        A.take(&dcand, (size_t)nq * n); A.take(&dtop, (size_t)nq * 5);
+    }));
+    TRY(arena_upload(c->stream));
+    if (e == hipSuccess) {
+        MatchParams M; memset(&M, 0, sizeof M);
+        M.kp2 = dk; M.n2 = dn; M.cap = n; M.min_x = c->bounds.min_x; M.min_y = c->bounds.min_y; M.max_x = c->bounds.max_x; M.max_y = c->bounds.max_y; M.grid_start = dgs; M.grid_items = dgi; M.grid_xy = dgxy; M.grid_all_levels = 1;
+        orbhip_launch_match_grid(M, 1, c->stream);
+        ProjParams J; memset(&J, 0, sizeof J);
+        J.kp = dk; J.desc = dd; J.u_right = dur; J.n = n; J.min_x = M.min_x; J.min_y = M.min_y; J.max_x = M.max_x; J.max_y = M.max_y; J.grid_start = dgs; J.grid_items = dgi; J.grid_xy = dgxy;
+        J.q = dq; J.qdesc = dqd; J.nq = nq; J.cand = dcand; J.ncand = dnc; J.cand_stride = n; J.top = dtop;
+        J.blocked_in = dbl_in; J.blocked_out = nullptr; J.feature_query = dfq; J.nmatches = dn + 1; J.events = dev;
+        J.mode = mode; J.nnratio = nnratio; J.th_high = th_high; J.check_ori = check_ori;
+        orbhip_launch_proj(J, c->stream);
+        e = hipGetLastError();
+    }
+    TRY(arena_download(c->stream));
+    if (e == hipSuccess) *nmatches = hres[1];
+#undef TRY
+    return e == hipSuccess ? ORBHIP_OK : fail(ORBHIP_ERR_HIP, "search_by_projection_frame: %s", hipGetErrorString(e));
+}
+extern "C" orbhip_status orbhip_search_best_in_window_frame(orbhip_ctx* c, int frame, int n, int use_u_right, const orbhip_best_query* queries, const uint8_t* query_desc, int nq,
+                                                            int chi2_gate, int32_t* best_idx, int32_t* best_dist)
+{
+    const orbhip_keypoint* dk = nullptr; const uint8_t* dd = nullptr; const float* dur = nullptr;
+    orbhip_status st = frame_args(c, frame, n, use_u_right, &dk, &dd, &dur); if (st != ORBHIP_OK) return st;
+    if (nq < 0 || (nq > 0 && (!queries || !query_desc || !best_idx || !best_dist))) return fail(ORBHIP_ERR_INVALID, "bad argument");
+    for (int i = 0; i < nq; i++) { best_idx[i] = -1; best_dist[i] = 256; }
+    if (n == 0 || nq == 0) return ORBHIP_OK;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    uint8_t* dqd = nullptr; float* dsg = nullptr; int *dn = nullptr, *dgs = nullptr, *dgi = nullptr, *dbi = nullptr, *dbd = nullptr; float2* dgxy = nullptr; orbhip_best_query* dq = nullptr;
+    hipError_t e = hipSuccess;
+#define TRY(x) do { if (e == hipSuccess) e = (x); } while (0)
+    const int hn[2] = {n, 0};
+    TRY(arena_layout(c->cfg.device, [&](Arena& A) {
+        A.io(&dqd, (size_t)nq * 32, query_desc, (size_t)nq * 32); A.io(&dq, nq, queries, nq); A.io(&dn, 8, hn, 2);
+        A.io(&dsg, c->L, (const float*)c->is2.data(), (size_t)c->L);                               // mvInvLevelSigma2 of this extractor
+        A.io(&dbi, nq, (const int*)nullptr, 0, best_idx, nq); A.io(&dbd, nq, (const int*)nullptr, 0, best_dist, nq);
+        A.take(&dgs, ORBHIP_GRID_CELLS + 1); A.take(&dgi, n); A.take(&dgxy, n);
+    }));
+    TRY(arena_upload(c->stream));
+    if (e == hipSuccess) {
+        MatchParams M; memset(&M, 0, sizeof M);
+        M.kp2 = dk; M.n2 = dn; M.cap = n; M.min_x = c->bounds.min_x; M.min_y = c->bounds.min_y; M.max_x = c->bounds.max_x; M.max_y = c->bounds.max_y; M.grid_start = dgs; M.grid_items = dgi; M.grid_xy = dgxy; M.grid_all_levels = 1;
+        orbhip_launch_match_grid(M, 1, c->stream);
+        BestParams B; memset(&B, 0, sizeof B);
+        B.kp = dk; B.desc = dd; B.u_right = dur; B.inv_level_sigma2 = dsg; B.grid_start = dgs; B.grid_items = dgi; B.grid_xy = dgxy;
+        B.q = dq; B.qdesc = dqd; B.nq = nq; B.chi2_gate = chi2_gate; B.best_idx = dbi; B.best_dist = dbd;
+        orbhip_launch_best_in_window(B, c->stream);
+        e = hipGetLastError();
+    }
+    TRY(arena_download(c->stream));
+#undef TRY
+    return e == hipSuccess ? ORBHIP_OK : fail(ORBHIP_ERR_HIP, "search_best_in_window_frame: %s", hipGetErrorString(e));
+}
+
 // ---------------------------------------------------------------------------------------------- stereo
 static StereoSide stereo_side(orbhip_ctx* c)
 {
@@ -813,7 +904,7 @@ extern "C" orbhip_status orbhip_compute_stereo_matches(orbhip_ctx* l, orbhip_ctx
     T.geom = l->d_geom; T.L = stereo_side(l); T.R = stereo_side(r);
     T.cap = l->out_cap; T.im_h = l->cfg.height;
     T.row_start = l->d_st_rowstart; T.row_items = l->d_st_rowitems; T.row_cap = l->st_rowcap;
-    T.u_right = l->d_st_u; T.depth = l->d_st_depth; T.sad = l->d_st_sad;
+    T.u_right = l->d_st_u; T.depth = l->d_st_depth; T.sad = l->d_st_sad; l->d_last_uright = l->d_st_u;
     T.mbf = mbf; T.maxD = mbf / mb;                                                 // minZ = mb, maxD = mbf/minZ (Frame.cc:496-498)
     orbhip_launch_stereo(T, nimg, l->out_cap, l->stream);
     HIPCHK(hipGetLastError());
@@ -955,7 +1046,7 @@ extern "C" orbhip_status orbhip_compute_stereo_from_rgbd(orbhip_ctx* c, int nimg
     HIPCHK(hipSetDevice(c->cfg.device));
     const size_t pitch = ((size_t)W * 4 + 63) & ~(size_t)63, fbytes = pitch * H, need = (size_t)c->B * fbytes + (size_t)2 * c->B * c->out_cap * sizeof(float);
     if (c->depth_bytes < need) { if (c->d_depth) (void)hipFree(c->d_depth); c->d_depth = nullptr; c->depth_bytes = 0; HIPCHK(hipMalloc((void**)&c->d_depth, need)); c->depth_bytes = need; }
-    float* d_u = (float*)(c->d_depth + (size_t)c->B * fbytes); float* d_z = d_u + (size_t)c->B * c->out_cap;
+    float* d_u = (float*)(c->d_depth + (size_t)c->B * fbytes); float* d_z = d_u + (size_t)c->B * c->out_cap; c->d_last_uright = d_u;
     for (int f = 0; f < nimg; f++) {
         if (!depth_maps[f]) return fail(ORBHIP_ERR_INVALID, "depth map %d is null", f);
         HIPCHK(hipMemcpy2DAsync(c->d_depth + f * fbytes, pitch, depth_maps[f], (size_t)stride_bytes, (size_t)W * esz, H, hipMemcpyHostToDevice, c->stream));

@@ -32,6 +32,7 @@ SYMBOLS = [
     "orbhip_undistort_points", "orbhip_image_bounds", "orbhip_set_camera", "orbhip_get_bounds", "orbhip_fetch_undistorted",
     "orbhip_search_for_initialization_bounds", "orbhip_search_by_projection_bounds", "orbhip_search_best_in_window_bounds",
     "orbhip_set_rectification", "orbhip_extract_batch_rectify", "orbhip_extract_device_rectify", "orbhip_compute_stereo_from_rgbd",
+    "orbhip_search_by_projection_frame", "orbhip_search_best_in_window_frame",
 ]
 
 
@@ -130,6 +131,8 @@ def lib(path=None):
     L.orbhip_extract_batch_rectify.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp]
     L.orbhip_extract_device_rectify.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]
     L.orbhip_compute_stereo_from_rgbd.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_float, C.c_float, vp, vp, C.c_int]
+    L.orbhip_search_by_projection_frame.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, vp, ip]
+    L.orbhip_search_best_in_window_frame.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp]
     L.orbhip_sync.argtypes = [vp]
     L.orbhip_fetch.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp]
     L.orbhip_fetch_matches.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
@@ -313,6 +316,24 @@ class ORBextractor:
     def extract_device_rectify(self, dptr, nimg, frame_stride, row_stride, match_prev=False, window=100, nnratio=0.9, check_ori=True):
         _check(self.L.orbhip_extract_device_rectify(self.h, nimg, C.c_void_p(dptr), frame_stride, row_stride, int(match_prev), window,
                                                     nnratio, int(check_ori)), "orbhip_extract_device_rectify", self.L)
+
+    # ---- windowed searches on a frame that is still on the device
+    def search_by_projection(self, frame, n, queries, query_desc, mode, nnratio=0.8, th_high=100, check_ori=True, use_u_right=False, blocked=None):
+        """orbhip_search_by_projection_frame: like the module-level search_by_projection, on frame `frame` of the last call"""
+        queries = np.ascontiguousarray(queries, PROJ_QUERY_DTYPE); query_desc = np.ascontiguousarray(query_desc, np.uint8)
+        bl = None if blocked is None else np.ascontiguousarray(blocked, np.uint8)
+        assert bl is None or len(bl) == n
+        fq = np.full(max(n, 1), -1, np.int32); nm = C.c_int()
+        _check(self.L.orbhip_search_by_projection_frame(self.h, frame, n, int(use_u_right), None if bl is None else _p(bl), _p(queries), _p(query_desc), len(queries),
+                                                        mode, nnratio, th_high, int(check_ori), _p(fq), C.byref(nm)), "orbhip_search_by_projection_frame", self.L)
+        return nm.value, fq[:n]
+
+    def search_best_in_window(self, frame, n, queries, query_desc, chi2_gate, use_u_right=False):
+        queries = np.ascontiguousarray(queries, BEST_QUERY_DTYPE); query_desc = np.ascontiguousarray(query_desc, np.uint8)
+        bi = np.full(len(queries), -1, np.int32); bd = np.full(len(queries), 256, np.int32)
+        _check(self.L.orbhip_search_best_in_window_frame(self.h, frame, n, int(use_u_right), _p(queries), _p(query_desc), len(queries), int(chi2_gate), _p(bi), _p(bd)),
+               "orbhip_search_best_in_window_frame", self.L)
+        return bi, bd
 
     def ComputeStereoFromRGBD(self, depth_maps, depth_factor, mbf):
         """Frame::ComputeStereoFromRGBD for the frames of the last call; depth_maps: float32 or uint16 [H,W] arrays (the conversion of

@@ -108,3 +108,55 @@ def test_search_best_in_window(backend, oracle, scene, chi2, stereo, th):
     assert int((bd_o <= 50).sum()) > 100 and np.all(bi_o[:5] == -1)
     e = orb_slam2_amd.search_best_in_window(kc, dc, w, h, inv, q[:0], dl[:0], chi2, library=backend)
     assert len(e[0]) == 0
+
+
+def test_searches_on_device_resident_frames(backend, oracle):
+    """orbhip_search_by_projection_frame / orbhip_search_best_in_window_frame: the frame's key points, descriptors and mvuRight stay on
+    the device (stereo pair extracted and matched there); results equal the oracle's on the fetched copies."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_parity_stereo import stereo_pair
+    w, h, n = 400, 300, 500
+    L, R = stereo_pair(w, h, 8, 7)
+    mbf, fx = np.float32(386.1448), np.float32(718.856)
+    xl = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, max_batch=2, library=backend)
+    xr = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, max_batch=2, library=backend)
+    imgs_l = [L, synth.frame(w, h, seed=3)]
+    ks, ds = xl.extract_batch(imgs_l); xr.extract_batch([R, R])
+    with pytest.raises(orb_slam2_amd.OrbHipError):
+        xl.search_by_projection(0, len(ks[0]), np.zeros(1, oracle.PROJ_QUERY_DTYPE), np.zeros((1, 32), np.uint8), 0, use_u_right=True)     # no mvuRight yet
+    u, d = xl.ComputeStereoMatches(xr, float(mbf), float(mbf / fx), nimg=2)
+    sf = xl.GetScaleFactors()
+    inv = (1.0 / (sf * sf)).astype(np.float32)
+    rng = np.random.default_rng(9)
+    for f in range(2):
+        kc, dc = ks[f], ds[f]
+        nk = len(kc)
+        q = np.zeros(nk, oracle.PROJ_QUERY_DTYPE)
+        q["x"] = kc["x"] + rng.normal(0, 1.5, nk).astype(np.float32); q["y"] = kc["y"] + rng.normal(0, 1.5, nk).astype(np.float32)
+        q["radius"] = (np.float32(5.0) * sf[kc["octave"]]).astype(np.float32)
+        q["ur"] = np.where(u[f, :nk] > 0, u[f, :nk] + rng.normal(0, 2.0, nk), q["x"] - 20).astype(np.float32)
+        q["min_level"], q["max_level"] = kc["octave"] - 1, kc["octave"] + 1
+        q["blocks"] = rng.random(nk) < 0.8
+        q["angle"] = kc["angle"]
+        qd = dc.copy()
+        for i in range(nk):
+            for b in rng.integers(0, 256, int(rng.integers(0, 25))):
+                qd[i, b >> 3] ^= 1 << (b & 7)
+        blocked = (rng.random(nk) < 0.1).astype(np.uint8)
+        for mode in (0, 1):
+            for use_ur in (False, True):
+                n_o, f_o = oracle.search_by_projection(kc, dc, w, h, q, qd, mode, nnratio=0.9, th_high=100, check_ori=True, u_right=u[f, :nk] if use_ur else None, blocked=blocked)
+                n_g, f_g = xl.search_by_projection(f, nk, q, qd, mode, nnratio=0.9, th_high=100, check_ori=True, use_u_right=use_ur, blocked=blocked)
+                assert n_g == n_o and np.array_equal(f_g, f_o) and n_o > 50
+        bq = np.zeros(nk, oracle.BEST_QUERY_DTYPE)
+        bq["x"], bq["y"], bq["ur"], bq["level"] = q["x"], q["y"], q["ur"], np.clip(kc["octave"] + rng.integers(0, 2, nk), 0, 7)
+        bq["radius"] = (np.float32(3.0) * sf[bq["level"]]).astype(np.float32)
+        for use_ur in (False, True):
+            bi_o, bd_o = oracle.search_best_in_window(kc, dc, w, h, inv, bq, qd, True, u_right=u[f, :nk] if use_ur else None)
+            bi_g, bd_g = xl.search_best_in_window(f, nk, bq, qd, True, use_u_right=use_ur)
+            assert np.array_equal(bi_g, bi_o) and np.array_equal(bd_g, bd_o)
+    xl.extract_batch(imgs_l)                                     # a new extraction invalidates mvuRight
+    with pytest.raises(orb_slam2_amd.OrbHipError):
+        xl.search_best_in_window(0, len(ks[0]), bq[:1], qd[:1], True, use_u_right=True)
+    xl.close(); xr.close()
