@@ -47,6 +47,9 @@ def main():
         "search_best_in_window_ms": timed(lambda: orb_slam2_amd.search_best_in_window(k2, d2, W, H, inv, bq, d1[keep], True)),
         "extract_single_frame_ms": timed(lambda: ex(seq[0])),
     }
+    ex.extract_batch(seq)                                  # frame 1 (k2, d2) is on the device again: only queries and results travel
+    out["search_by_projection_frame_on_device_ms"] = timed(lambda: ex.search_by_projection(1, len(k2), q, d1[keep], 0, nnratio=0.8))
+    out["search_best_in_window_frame_on_device_ms"] = timed(lambda: ex.search_best_in_window(1, len(k2), bq, d1[keep], True))
     print(json.dumps(out))
 
 
