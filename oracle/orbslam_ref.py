@@ -34,10 +34,34 @@ def build():
     return available()
 
 
+DROPIN_PATH = os.path.join(HERE, "_ref", "liborbslam_dropin.so")      # reference Frame.cc / ORBmatcher.cc calling THIS repo's drop-in ORBextractor class
+_dropin = None
+
+
+def build_dropin():
+    """reference callers + drop-in extractor class on the CPU emulation of the kernels (needs /root/reference and tests/emu/liborbhip_emu.so)"""
+    import subprocess
+    if os.path.isdir("/root/reference/src"):
+        subprocess.check_call(["make", "-C", HERE, "-s", "dropin"])
+    return os.path.exists(DROPIN_PATH)
+
+
+def dropin_lib():
+    global _dropin
+    if _dropin is None:
+        _dropin = _bind(C.CDLL(DROPIN_PATH))
+    return _dropin
+
+
 def lib():
     global _lib
     if _lib is None:
-        L = C.CDLL(FAST_PATH if _use_fast else PATH)
+        _lib = _bind(C.CDLL(FAST_PATH if _use_fast else PATH))
+    return _lib
+
+
+def _bind(L):
+    if True:
         vp, i, f = C.c_void_p, C.c_int, C.c_float
         L.orbslam_ref_frame_mono.restype = vp
         L.orbslam_ref_frame_mono.argtypes = [vp, i, i, i, i, f, i, i, i, f, f, f, f, f, f, i]
@@ -62,8 +86,7 @@ def lib():
         L.orbslam_ref_search_by_projection_kf.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, vp, i, vp]
         L.orbslam_ref_search_by_projection_reloc.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f, i, f, i, vp]
         L.orbslam_ref_search_by_sim3.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f, vp]
-        _lib = L
-    return _lib
+    return L
 
 
 def _p(a):
@@ -72,57 +95,63 @@ def _p(a):
 
 class RefFrame:
     """ORB_SLAM2::Frame built by the reference's own constructor."""
-    _geometry = None
+    _geometry = None                 # of the default library (tests reset it to force ComputeImageBounds)
+    _geometry_other = {}             # of other builds of the same sources (the drop-in build), by handle
 
     def __init__(self, img, right=None, nfeatures=1000, scale=1.2, nlevels=8, ini_th=20, min_th=7, fx=1.0, fy=1.0, cx=0.0, cy=0.0, bf=40.0, th_depth=35.0,
-                 dist=None, depth=None):
+                 dist=None, depth=None, library=None):
         img = np.ascontiguousarray(img, np.uint8)
         h, w = img.shape
         geom = (w, h, fx, fy, cx, cy, None if dist is None else tuple(float(v) for v in dist))
-        new = RefFrame._geometry != geom
-        RefFrame._geometry = geom
+        self.L = L = lib() if library is None else library
+        if library is None:
+            new = RefFrame._geometry != geom
+            RefFrame._geometry = geom
+        else:
+            new = RefFrame._geometry_other.get(id(L)) != geom
+            RefFrame._geometry_other[id(L)] = geom
         if depth is not None:                 # RGB-D sensor: CV_32F depth map (already converted, Tracking.cc:226-227)
             assert right is None
             d = np.ascontiguousarray(np.zeros(4) if dist is None else dist, np.float32)
             dm = np.ascontiguousarray(depth, np.float32)
             assert dm.shape == (h, w)
-            self.h = lib().orbslam_ref_frame_rgbd(_p(img), _p(dm), w, h, img.strides[0], nfeatures, scale, nlevels, ini_th, min_th, fx, fy, cx, cy, _p(d), len(d), bf, th_depth, int(new))
+            self.h = L.orbslam_ref_frame_rgbd(_p(img), _p(dm), w, h, img.strides[0], nfeatures, scale, nlevels, ini_th, min_th, fx, fy, cx, cy, _p(d), len(d), bf, th_depth, int(new))
         elif dist is not None:                # distorted mono / RGB-D camera (mDistCoef, Tracking.cc:70-82)
             assert right is None
             d = np.ascontiguousarray(dist, np.float32)
-            self.h = lib().orbslam_ref_frame_mono_dist(_p(img), w, h, img.strides[0], nfeatures, scale, nlevels, ini_th, min_th, fx, fy, cx, cy, _p(d), len(d), bf, th_depth, int(new))
+            self.h = L.orbslam_ref_frame_mono_dist(_p(img), w, h, img.strides[0], nfeatures, scale, nlevels, ini_th, min_th, fx, fy, cx, cy, _p(d), len(d), bf, th_depth, int(new))
         elif right is None:
-            self.h = lib().orbslam_ref_frame_mono(_p(img), w, h, img.strides[0], nfeatures, scale, nlevels, ini_th, min_th, fx, fy, cx, cy, bf, th_depth, int(new))
+            self.h = L.orbslam_ref_frame_mono(_p(img), w, h, img.strides[0], nfeatures, scale, nlevels, ini_th, min_th, fx, fy, cx, cy, bf, th_depth, int(new))
         else:
             right = np.ascontiguousarray(right, np.uint8)
-            self.h = lib().orbslam_ref_frame_stereo(_p(img), _p(right), w, h, img.strides[0], nfeatures, scale, nlevels, ini_th, min_th, fx, fy, cx, cy, bf, th_depth, int(new))
-        self.N = lib().orbslam_ref_frame_n(self.h)
+            self.h = L.orbslam_ref_frame_stereo(_p(img), _p(right), w, h, img.strides[0], nfeatures, scale, nlevels, ini_th, min_th, fx, fy, cx, cy, bf, th_depth, int(new))
+        self.N = L.orbslam_ref_frame_n(self.h)
         self.keys = np.zeros(self.N, KEYPOINT_DTYPE); self.keys_un = np.zeros(self.N, KEYPOINT_DTYPE)
         self.desc = np.zeros((self.N, 32), np.uint8); self.u_right = np.zeros(self.N, np.float32); self.depth = np.zeros(self.N, np.float32)
-        lib().orbslam_ref_frame_get(self.h, _p(self.keys), _p(self.keys_un), _p(self.desc), _p(self.u_right), _p(self.depth))
+        L.orbslam_ref_frame_get(self.h, _p(self.keys), _p(self.keys_un), _p(self.desc), _p(self.u_right), _p(self.depth))
 
     @staticmethod
-    def bounds():
+    def bounds(library=None):
         """(mnMinX, mnMinY, mnMaxX, mnMaxY): the static image bounds the first Frame of the current geometry computed"""
         out = np.zeros(4, np.float32)
-        lib().orbslam_ref_frame_bounds(_p(out))
+        (lib() if library is None else library).orbslam_ref_frame_bounds(_p(out))
         return out
 
     def close(self):
         if self.h:
-            lib().orbslam_ref_frame_delete(self.h)
+            self.L.orbslam_ref_frame_delete(self.h)
             self.h = None
 
     def features_in_area(self, x, y, r, min_level=-1, max_level=-1):
         out = np.zeros(max(self.N, 1), np.int32)
-        n = lib().orbslam_ref_features_in_area(self.h, x, y, r, min_level, max_level, _p(out), len(out))
+        n = self.L.orbslam_ref_features_in_area(self.h, x, y, r, min_level, max_level, _p(out), len(out))
         return out[:n].copy()
 
 
 def search_for_initialization(f1, f2, prev=None, window=100, nnratio=0.9, check_ori=True):
     prev = np.ascontiguousarray(np.stack([f1.keys_un["x"], f1.keys_un["y"]], axis=1) if prev is None else prev, np.float32).copy()
     m12 = np.full(f1.N, -1, np.int32)
-    n = lib().orbslam_ref_search_for_initialization(f1.h, f2.h, _p(prev), _p(m12), window, nnratio, int(check_ori))
+    n = f1.L.orbslam_ref_search_for_initialization(f1.h, f2.h, _p(prev), _p(m12), window, nnratio, int(check_ori))
     return n, m12, prev
 
 

@@ -25,6 +25,7 @@
 
 using namespace ORB_SLAM2;
 
+#ifndef ORBSLAM_DROPIN_BUILD     // (the drop-in extractor has no std::list: nothing to canonicalise, the default allocator stays)
 // ---- bump arena for std::list<ExtractorNode> nodes: (size, pointer) sort of DistributeOctTree == tie-break H1 (see orbextractor_ref_wrap.cpp)
 namespace {
 const size_t kNodeBytes = sizeof(std::_List_node<ORB_SLAM2::ExtractorNode>);
@@ -46,6 +47,9 @@ void* operator new(size_t n)
 }
 void operator delete(void* p) noexcept { if (p && !in_arena(p)) free(p); }
 void operator delete(void* p, size_t) noexcept { if (p && !in_arena(p)) free(p); }
+#else
+namespace { size_t g_used = 0; }
+#endif
 
 // ---- MapPoint / KeyFrame members referenced by Frame.cc / ORBmatcher.cc (their own .cc files are not part of this build)
 namespace ORB_SLAM2 {

@@ -1,0 +1,60 @@
+"""The drop-in classes under the reference's OWN callers (the binding of INTEGRATION.md §2, steps 1-3, built and run).
+
+oracle/_ref/liborbslam_dropin.so = the reference's src/Frame.cc and src/ORBmatcher.cc, compiled where they lie, against this repository's
+include/ORBextractor.h + orb_slam2_amd/cpp/ORBextractor.cc in place of the reference's header and src/ORBextractor.cc, with
+ORBmatcher::DescriptorDistance and ORBmatcher::SearchForInitialization taken from orb_slam2_amd/cpp/ORBmatcher.cc (the reference's two
+bodies are renamed out of the way in its translation unit), linked to the CPU emulation build of the HIP kernels.  In that build the
+reference's Frame constructors run
+    Frame::ExtractORB -> (*mpORBextractorLeft)(im, cv::Mat(), mvKeys, mDescriptors)          (Frame.cc:247-253)
+on the drop-in class, everything behind (UndistortKeyPoints, ComputeStereoFromRGBD, AssignFeaturesToGrid) consumes its output, and
+SearchForInitialization on two such Frames goes through orbhip_search_for_initialization_bounds with Frame's static image bounds.
+Every frame and every match list must equal what the all-reference build (liborbslam_ref.so) makes.
+Monocular, distorted monocular and RGB-D constructors (the stereo constructor extracts on two threads; the emulation is single-threaded —
+the real library's two-thread use is tests/test_dropin_cpp.py's GPU case).  Skipped where /root/reference is not mounted."""
+import numpy as np
+import pytest
+
+from orb_slam2_amd import synth
+
+
+@pytest.fixture(scope="module")
+def builds(emu_lib):
+    from oracle import orbslam_ref as S
+    if not (S.build() and S.build_dropin()):
+        pytest.skip("reference sources not mounted")
+    return S, S.dropin_lib()
+
+
+def _same(a, b):
+    return (a.N == b.N and a.keys.tobytes() == b.keys.tobytes() and a.keys_un.tobytes() == b.keys_un.tobytes() and np.array_equal(a.desc, b.desc)
+            and a.u_right.tobytes() == b.u_right.tobytes() and a.depth.tobytes() == b.depth.tobytes())
+
+
+@pytest.mark.parametrize("w,h,n,levels,scale", [(480, 360, 700, 8, 1.2), (640, 480, 1000, 8, 1.2), (333, 250, 300, 6, 1.3)])
+def test_reference_frame_on_dropin_extractor(builds, w, h, n, levels, scale):
+    S, D = builds
+    seq = synth.sequence(w, h, 2, seed=w + n)
+    tum1 = (0.262383, -0.953104, -0.005358, 0.002628, 1.163314)
+    cam = dict(fx=517.3 * w / 640, fy=516.5 * h / 480, cx=318.6 * w / 640, cy=255.3 * h / 480)
+    rng = np.random.default_rng(1)
+    depth = (1.0 + rng.random((h, w))).astype(np.float32)
+    depth[rng.random((h, w)) < 0.2] = 0.0
+    for kw in (dict(), dict(dist=tum1, **cam), dict(depth=depth, **cam), dict(depth=depth, dist=tum1, **cam)):
+        S.RefFrame._geometry = None
+        S.RefFrame._geometry_other.clear()
+        R = [S.RefFrame(im, nfeatures=n, nlevels=levels, scale=scale, **kw) for im in seq]
+        F = [S.RefFrame(im, nfeatures=n, nlevels=levels, scale=scale, library=D, **kw) for im in seq]
+        assert all(_same(a, b) for a, b in zip(R, F)) and R[0].N > 100
+        assert S.RefFrame.bounds().tobytes() == S.RefFrame.bounds(D).tobytes()
+        if "depth" in kw:
+            assert (R[0].depth > 0).sum() > 50
+        # all-reference matcher on reference frames  vs  drop-in matcher (C ABI, kernels) on frames whose features came from the drop-in extractor
+        n_r, m_r, p_r = S.search_for_initialization(R[0], R[1], window=80, nnratio=0.9, check_ori=True)
+        n_f, m_f, p_f = S.search_for_initialization(F[0], F[1], window=80, nnratio=0.9, check_ori=True)
+        assert n_r == n_f and np.array_equal(m_r, m_f) and p_r.tobytes() == p_f.tobytes() and n_r > 20
+        for _ in range(50):
+            x, y, r = np.float32(rng.uniform(0, w)), np.float32(rng.uniform(0, h)), np.float32(rng.uniform(2, 90))
+            assert np.array_equal(R[1].features_in_area(x, y, r, 0, 2), F[1].features_in_area(x, y, r, 0, 2))
+        for f in R + F:
+            f.close()
+    S.RefFrame._geometry = None
