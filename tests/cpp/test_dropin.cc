@@ -81,7 +81,7 @@ int main(int argc, char** argv)
         const unsigned int nw = voc.size(); fwrite(&nw, 4, 1, f);
     }
     // the reference extracts the left and the right image on two std::threads (Frame.cc:78-81): two extractor objects, two device
-    // contexts, concurrent calls into the library.  (Real library only: the CPU emulation of HIP is single-threaded.)
+    // contexts, concurrent calls into the library.
     if (argc > 8 && !strcmp(argv[8], "threads")) {
         int ok = 1;
         for (int rep = 0; rep < 20 && ok; rep++) {

@@ -18,6 +18,7 @@
 #include <cmath>
 #include <vector>
 #include <algorithm>
+#include <mutex>
 #include <functional>
 
 #define __global__
@@ -62,6 +63,7 @@ struct Globals {
     char* dyn_shared = nullptr; std::function<void()> body; size_t stack_size = 128 * 1024;
 };
 inline Globals g;
+inline std::mutex launch_mutex;          // one kernel at a time: the scheduler state above and the kernels' static __shared__ arrays are process-wide
 
 inline void yield() { swapcontext(&g.cur->ctx, &g.sched); }
 inline void fiber_main() {
@@ -92,6 +94,7 @@ inline uint64_t wave_collective(Op op, uint64_t val, int srclane) {
 
 template <typename K, typename... A>
 void launch(K kernel, dim3 grid, dim3 block, size_t shmem, A... args) {
+    std::lock_guard<std::mutex> serialise(launch_mutex);   // host threads (the reference extracts left / right images on two std::threads) take turns
     const int T = (int)(block.x * block.y * block.z);
     std::vector<char> dyn(shmem + 64);
     g.dyn_shared = dyn.data(); g.bdim = block; g.gdim = grid;

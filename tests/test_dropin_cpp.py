@@ -131,7 +131,7 @@ def _build(target):
 
 
 def test_dropin_classes_emulation(tmp_path, oracle, emu_lib):
-    _run(_build("test_dropin_emu"), tmp_path, oracle)
+    _run(_build("test_dropin_emu"), tmp_path, oracle, threads=True)      # the emulation serialises kernel launches of the two host threads
 
 
 @pytest.mark.gpu

@@ -9,8 +9,9 @@ reference's Frame constructors run
 on the drop-in class, everything behind (UndistortKeyPoints, ComputeStereoFromRGBD, AssignFeaturesToGrid) consumes its output, and
 SearchForInitialization on two such Frames goes through orbhip_search_for_initialization_bounds with Frame's static image bounds.
 Every frame and every match list must equal what the all-reference build (liborbslam_ref.so) makes.
-Monocular, distorted monocular and RGB-D constructors (the stereo constructor extracts on two threads; the emulation is single-threaded —
-the real library's two-thread use is tests/test_dropin_cpp.py's GPU case).  Skipped where /root/reference is not mounted."""
+Monocular, distorted monocular, RGB-D and stereo constructors (the stereo one extracts the two images on two std::threads — two device
+contexts used concurrently — and its ComputeStereoMatches reads the drop-in class's mvImagePyramid).  Skipped where /root/reference is not
+mounted."""
 import numpy as np
 import pytest
 
@@ -57,4 +58,23 @@ def test_reference_frame_on_dropin_extractor(builds, w, h, n, levels, scale):
             assert np.array_equal(R[1].features_in_area(x, y, r, 0, 2), F[1].features_in_area(x, y, r, 0, 2))
         for f in R + F:
             f.close()
+    S.RefFrame._geometry = None
+
+
+def test_reference_stereo_frame_on_dropin_extractors(builds):
+    """Frame::Frame(imLeft, imRight, ...) (Frame.cc:62-115): threadLeft / threadRight call the two drop-in extractor objects concurrently, then
+    the reference's own ComputeStereoMatches walks both classes' mvImagePyramid members."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_parity_stereo import stereo_pair
+    S, D = builds
+    fx, bf = 718.856, 386.1448
+    for (w, h, n, seed, disp) in ((400, 300, 500, 8, 7), (640, 240, 800, 3, 12)):
+        L, R = stereo_pair(w, h, seed, disp)
+        S.RefFrame._geometry = None
+        S.RefFrame._geometry_other.clear()
+        a = S.RefFrame(L, R, nfeatures=n, fx=fx, fy=fx, cx=w / 2, cy=h / 2, bf=bf)
+        b = S.RefFrame(L, R, nfeatures=n, fx=fx, fy=fx, cx=w / 2, cy=h / 2, bf=bf, library=D)
+        assert _same(a, b) and (a.depth > 0).sum() > 100
+        a.close(); b.close()
     S.RefFrame._geometry = None
