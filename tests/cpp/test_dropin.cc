@@ -82,9 +82,10 @@ int main(int argc, char** argv)
     }
     // the reference extracts the left and the right image on two std::threads (Frame.cc:78-81): two extractor objects, two device
     // contexts, concurrent calls into the library.
-    if (argc > 8 && !strcmp(argv[8], "threads")) {
+    if (argc > 8 && !strncmp(argv[8], "threads", 7)) {
         int ok = 1;
-        for (int rep = 0; rep < 20 && ok; rep++) {
+        const int reps = argv[8][7] ? atoi(argv[8] + 7) : 20;                 // "threads" or "threads<N>"
+        for (int rep = 0; rep < reps && ok; rep++) {
             std::vector<cv::KeyPoint> kL, kR; cv::Mat dL, dR;
             std::thread tl([&]() { (*exL)(im[0], cv::Mat(), kL, dL); }), tr([&]() { (*exR)(im[1], cv::Mat(), kR, dR); });
             tl.join(); tr.join();

@@ -27,7 +27,7 @@ def _run(exe, tmp_path, oracle, threads=False):
     mx = (w / 2 + (np.cos(th) * (xx - w / 2) - np.sin(th) * (yy - h / 2)) * 1.03 + 2.25).astype(np.float32)
     my = (h / 2 + (np.sin(th) * (xx - w / 2) + np.cos(th) * (yy - h / 2)) * 1.03 - 1.4).astype(np.float32)
     np.concatenate([mx.ravel(), my.ravel()]).tofile(str(tmp_path / "maps.bin"))
-    subprocess.check_call([exe, str(w), str(h), str(n), str(tmp_path / "in0.raw"), str(tmp_path / "in1.raw"), str(out), voc_path, "threads" if threads else "-",
+    subprocess.check_call([exe, str(w), str(h), str(n), str(tmp_path / "in0.raw"), str(tmp_path / "in1.raw"), str(out), voc_path, ("threads" if threads is True else f"threads{threads}") if threads else "-",
                            str(tmp_path / "maps.bin")])
     buf = out.read_bytes()
     off = 0
@@ -68,7 +68,7 @@ def _run(exe, tmp_path, oracle, threads=False):
         bows.append((rec["id"].copy(), rec["val"].copy(), np.array(fnode, np.uint32), np.array(foff, np.int32), np.array(ffeat, np.uint32)))
     (score12,) = struct.unpack_from("<d", buf, off); off += 8
     (nwords,) = struct.unpack_from("<I", buf, off); off += 4
-    if threads:                                           # 20 rounds of concurrent left / right extraction reproduced the sequential results
+    if threads:                                           # rounds of concurrent left / right extraction reproduced the sequential results
         assert struct.unpack_from("<i", buf, off)[0] == 1
         off += 4
     nd1, nd2 = struct.unpack_from("<ii", buf, off); off += 8
@@ -131,7 +131,7 @@ def _build(target):
 
 
 def test_dropin_classes_emulation(tmp_path, oracle, emu_lib):
-    _run(_build("test_dropin_emu"), tmp_path, oracle, threads=True)      # the emulation serialises kernel launches of the two host threads
+    _run(_build("test_dropin_emu"), tmp_path, oracle, threads=2)         # two rounds: the emulation serialises kernel launches of the two host threads
 
 
 @pytest.mark.gpu
