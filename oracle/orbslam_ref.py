@@ -43,7 +43,7 @@ def build_dropin():
     import subprocess
     if os.path.isdir("/root/reference/src"):
         subprocess.check_call(["make", "-C", HERE, "-s", "dropin"])
-    return os.path.exists(DROPIN_PATH)
+    return os.path.exists(DROPIN_PATH) and os.path.exists(DROPIN_FULL_PATH)
 
 
 def dropin_lib():
@@ -51,6 +51,17 @@ def dropin_lib():
     if _dropin is None:
         _dropin = _bind(C.CDLL(DROPIN_PATH))
     return _dropin
+
+
+DROPIN_FULL_PATH = os.path.join(HERE, "_ref", "liborbslam_dropin_full.so")   # + Frame's stereo / undistortion / RGB-D members forwarded to the extractor
+_dropin_full = None
+
+
+def dropin_full_lib():
+    global _dropin_full
+    if _dropin_full is None:
+        _dropin_full = _bind(C.CDLL(DROPIN_FULL_PATH))
+    return _dropin_full
 
 
 def lib():

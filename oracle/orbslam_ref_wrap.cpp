@@ -131,6 +131,12 @@ bool KeyFrame::IsInImage(const float& x, const float& y) const { return (x >= mn
 namespace {
 struct Rig { ORBextractor* left; ORBextractor* right; };
 std::map<std::vector<int>, Rig> g_rigs;
+#ifdef ORBSLAM_DROPIN_FULL
+// INTEGRATION.md §2-3d': Tracking hands mK / mDistCoef to the extractors once; stereo matching runs on the device, no pyramid download
+static void attach_camera(ORBextractor* e, const cv::Mat& K, const cv::Mat& D) { e->SetCamera(K, D); e->SetPyramidDownload(false); }
+#else
+static void attach_camera(ORBextractor*, const cv::Mat&, const cv::Mat&) {}
+#endif
 Rig& rig(int nfeat, float scale, int nlevels, int ini, int mn)
 {
     std::vector<int> key = {nfeat, (int)(scale * 100000), nlevels, ini, mn};
@@ -167,6 +173,7 @@ void* orbslam_ref_frame_mono(const uint8_t* img, int w, int h, int stride, int n
     g_used = 0;
     if (new_geometry) Frame::mbInitialComputations = true;
     cv::Mat im(h, w, CV_8UC1, (void*)img, (size_t)stride), K = camera(fx, fy, cx, cy), D = cv::Mat(cv::Mat::zeros(4, 1, CV_32F));
+    attach_camera(rig(nfeat, scale, nlevels, ini, mn).left, K, D);
     return new Frame(im, 0.0, rig(nfeat, scale, nlevels, ini, mn).left, NULL, K, D, bf, thDepth);
 }
 // the same with a distorted camera: mDistCoef = (k1, k2, p1, p2[, k3]) (Tracking.cc:70-82) -> UndistortKeyPoints / ComputeImageBounds
@@ -178,6 +185,7 @@ void* orbslam_ref_frame_mono_dist(const uint8_t* img, int w, int h, int stride, 
     if (new_geometry) Frame::mbInitialComputations = true;
     cv::Mat im(h, w, CV_8UC1, (void*)img, (size_t)stride), K = camera(fx, fy, cx, cy), D(ndist, 1, CV_32F);
     for (int i = 0; i < ndist; i++) D.at<float>(i) = dist[i];
+    attach_camera(rig(nfeat, scale, nlevels, ini, mn).left, K, D);
     return new Frame(im, 0.0, rig(nfeat, scale, nlevels, ini, mn).left, NULL, K, D, bf, thDepth);
 }
 // Frame::Frame(imGray, imDepth, ...)  (Frame.cc:117-172): RGB-D sensor, ComputeStereoFromRGBD (Frame.cc:643-665) on the CV_32F depth map
@@ -188,6 +196,7 @@ void* orbslam_ref_frame_rgbd(const uint8_t* img, const float* depth, int w, int 
     if (new_geometry) Frame::mbInitialComputations = true;
     cv::Mat im(h, w, CV_8UC1, (void*)img, (size_t)stride), dm(h, w, CV_32F, (void*)depth), K = camera(fx, fy, cx, cy), D(ndist, 1, CV_32F);
     for (int i = 0; i < ndist; i++) D.at<float>(i) = dist[i];
+    attach_camera(rig(nfeat, scale, nlevels, ini, mn).left, K, D);
     return new Frame(im, dm, 0.0, rig(nfeat, scale, nlevels, ini, mn).left, NULL, K, D, bf, thDepth);
 }
 void orbslam_ref_frame_bounds(float* out) { out[0] = Frame::mnMinX; out[1] = Frame::mnMinY; out[2] = Frame::mnMaxX; out[3] = Frame::mnMaxY; }
@@ -206,6 +215,7 @@ void* orbslam_ref_frame_stereo(const uint8_t* imgL, const uint8_t* imgR, int w, 
     void* mem = ::operator new(sizeof(Frame));
     memset(mem, 0, sizeof(Frame));
     *reinterpret_cast<float*>(reinterpret_cast<char*>(mem) + ((char*)&((Frame*)mem)->mb - (char*)mem)) = bf / fx;
+    attach_camera(r.left, K, D); attach_camera(r.right, K, D);
     return new (mem) Frame(L, R, 0.0, r.left, r.right, NULL, K, D, bf, thDepth);
 }
 void orbslam_ref_frame_delete(void* f) { delete (Frame*)f; }
