@@ -158,8 +158,9 @@ typedef struct {
      mode 1: ORBmatcher::SearchByProjection(Frame &Current, const Frame &Last, th, bMono)      ORBmatcher.h:54, ORBmatcher.cc:1328-1470
    on one frame given flat: kps / desc = F.mvKeysUn / F.mDescriptors (n), u_right = F.mvuRight or NULL, blocked[i] =
    (F.mvpMapPoints[i] && F.mvpMapPoints[i]->Observations() > 0) or NULL, image bounds as for SearchForInitialization.
-   feature_query[i] receives the index of the query whose map point the reference would leave in F.mvpMapPoints[i]
-   (-1 = untouched); *nmatches is the function's return value.  th_high = TH_HIGH (100).  Host buffers, synchronous. */
+   feature_query[i] receives the index of the query whose map point the reference would leave in F.mvpMapPoints[i];
+   -1 = untouched, -2 = claimed during the call and then removed by the rotation-consistency check (the reference leaves NULL there,
+   ORBmatcher.cc:1452-1466, whatever the feature held before); *nmatches is the function's return value.  th_high = TH_HIGH (100).  Host buffers, synchronous. */
 orbhip_status orbhip_search_by_projection(int device, const orbhip_keypoint* kps, const uint8_t* desc, const float* u_right,
                                           const uint8_t* blocked, int n, int im_w, int im_h,
                                           const orbhip_proj_query* queries, const uint8_t* query_desc, int nq,

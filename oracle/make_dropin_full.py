@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
-"""Build aid for oracle/_ref/liborbslam_dropin_full.so: the OPTIONAL steps of INTEGRATION.md §2 (3b, 3d') applied to the reference's
-src/Frame.cc.  Reads the reference source where it lies, replaces the BODIES of four Frame members by the one-line forwards to the
-drop-in extractor that INTEGRATION.md shows, and writes the result to the path given (a temporary file the Makefile deletes after
-compiling it — no reference source is kept in this repository).  usage: make_dropin_full.py <Frame.cc> <out.cc>"""
+"""Build aid for oracle/_ref/liborbslam_dropin_full.so: the OPTIONAL steps of INTEGRATION.md §2 (3b, 3c, 3d') applied to the reference's
+src/Frame.cc and src/ORBmatcher.cc.  Reads the reference sources where they lie, replaces the BODIES of four Frame members by the
+one-line forwards to the drop-in extractor and the search loops of the two per-frame SearchByProjection members by calls of the C ABI,
+exactly as INTEGRATION.md shows, and writes the results to the paths given (temporary files the Makefile deletes after compiling
+them — no reference source is kept in this repository).
+usage: make_dropin_full.py <Frame.cc> <out_frame.cc> [<ORBmatcher.cc> <out_matcher.cc>]"""
 import re
 import sys
 
@@ -36,11 +38,103 @@ def replace_body(src, signature, body):
     return src[:i] + body + src[j:]
 
 
+# the two per-frame projection matchers keep their map / pose code and hand the search loop to the library.
+LOCAL_MAP_SIG = r"int\s+ORBmatcher::SearchByProjection\s*\(\s*Frame\s*&\s*F\s*,\s*const\s+vector<MapPoint\*>\s*&\s*vpMapPoints\s*,\s*const\s+float\s+th\s*\)"
+LOCAL_MAP_BODY = """{
+    int nmatches=0;
+    const bool bFactor = th!=1.0;
+    std::vector<orbhip_proj_query> q; std::vector<unsigned char> qd; std::vector<MapPoint*> owner;
+    for(size_t iMP=0; iMP<vpMapPoints.size(); iMP++)
+    {
+        MapPoint* pMP = vpMapPoints[iMP];
+        if(!pMP->mbTrackInView || pMP->isBad()) continue;
+        const int &nPredictedLevel = pMP->mnTrackScaleLevel;
+        float r = RadiusByViewingCos(pMP->mTrackViewCos);
+        if(bFactor) r*=th;
+        orbhip_proj_query e = { pMP->mTrackProjX, pMP->mTrackProjY, r*F.mvScaleFactors[nPredictedLevel], pMP->mTrackProjXR,
+                                nPredictedLevel-1, nPredictedLevel, pMP->Observations()>0, 0.f };
+        const cv::Mat d = pMP->GetDescriptor();
+        q.push_back(e); qd.insert(qd.end(), d.ptr<unsigned char>(), d.ptr<unsigned char>()+32); owner.push_back(pMP);
+    }
+    if(q.empty() || F.N==0) return 0;
+    std::vector<unsigned char> blocked(F.N); std::vector<int> fq(F.N);
+    for(int i=0;i<F.N;i++) blocked[i] = F.mvpMapPoints[i] && F.mvpMapPoints[i]->Observations()>0;
+    const orbhip_bounds bounds = {Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY};
+    if(orbhip_search_by_projection_bounds(0, (const orbhip_keypoint*)&F.mvKeysUn[0], F.mDescriptors.ptr<unsigned char>(), &F.mvuRight[0], &blocked[0], F.N, &bounds,
+                                          &q[0], &qd[0], (int)q.size(), 0, mfNNratio, TH_HIGH, 0, &fq[0], &nmatches)!=ORBHIP_OK) abort();
+    for(int i=0;i<F.N;i++) if(fq[i]>=0) F.mvpMapPoints[i]=owner[fq[i]];
+    return nmatches;
+}"""
+LAST_FRAME_SIG = r"int\s+ORBmatcher::SearchByProjection\s*\(\s*Frame\s*&\s*CurrentFrame\s*,\s*const\s+Frame\s*&\s*LastFrame\s*,\s*const\s+float\s+th\s*,\s*const\s+bool\s+bMono\s*\)"
+LAST_FRAME_DECLS = """
+    std::vector<orbhip_proj_query> orbhip_q; std::vector<unsigned char> orbhip_qd; std::vector<MapPoint*> orbhip_owner;
+"""
+LAST_FRAME_QUERY = """orbhip_proj_query e = { u, v, radius, u - CurrentFrame.mbf*invzc,
+                                        bForward ? nLastOctave : (bBackward ? 0 : nLastOctave-1), bForward ? -1 : (bBackward ? nLastOctave : nLastOctave+1),
+                                        pMP->Observations()>0, LastFrame.mvKeysUn[i].angle };
+                const cv::Mat dMP = pMP->GetDescriptor();
+                orbhip_q.push_back(e); orbhip_qd.insert(orbhip_qd.end(), dMP.ptr<unsigned char>(), dMP.ptr<unsigned char>()+32); orbhip_owner.push_back(pMP);
+"""
+LAST_FRAME_SEARCH = """if(!orbhip_q.empty() && CurrentFrame.N>0)
+    {
+        std::vector<unsigned char> blocked(CurrentFrame.N); std::vector<int> fq(CurrentFrame.N);
+        for(int i=0;i<CurrentFrame.N;i++) blocked[i] = CurrentFrame.mvpMapPoints[i] && CurrentFrame.mvpMapPoints[i]->Observations()>0;
+        const orbhip_bounds bounds = {Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY};
+        if(orbhip_search_by_projection_bounds(0, (const orbhip_keypoint*)&CurrentFrame.mvKeysUn[0], CurrentFrame.mDescriptors.ptr<unsigned char>(), &CurrentFrame.mvuRight[0],
+                                              &blocked[0], CurrentFrame.N, &bounds, &orbhip_q[0], &orbhip_qd[0], (int)orbhip_q.size(), 1, mfNNratio, TH_HIGH,
+                                              mbCheckOrientation, &fq[0], &nmatches)!=ORBHIP_OK) abort();
+        for(int i=0;i<CurrentFrame.N;i++)
+        {
+            if(fq[i]>=0) CurrentFrame.mvpMapPoints[i]=orbhip_owner[fq[i]];
+            else if(fq[i]==-2) CurrentFrame.mvpMapPoints[i]=static_cast<MapPoint*>(NULL);
+        }
+    }
+"""
+
+
+def block_end(src, i):
+    """index just past the brace block that opens at or after i"""
+    i = src.index("{", i)
+    depth, j = 0, i
+    while True:
+        depth += src[j] == "{"
+        depth -= src[j] == "}"
+        j += 1
+        if depth == 0:
+            return j
+
+
+def patch_last_frame(src):
+    m = re.search(LAST_FRAME_SIG, src)
+    if not m:
+        raise SystemExit("SearchByProjection(CurrentFrame, LastFrame, ...) not found")
+    f0, f1 = m.start(), block_end(src, m.end())
+    fn = src[f0:f1]
+    # declarations of the flat query arrays right after the function's first statement
+    k = fn.index("int nmatches = 0;") + len("int nmatches = 0;")
+    fn = fn[:k] + LAST_FRAME_DECLS + fn[k:]
+    # the candidate search of one map point -> one flat query
+    a = fn.index("vector<size_t> vIndices2;")
+    b = block_end(fn, fn.index("if(bestDist<=TH_HIGH)", a))
+    fn = fn[:a] + LAST_FRAME_QUERY + fn[b:]
+    # the rotation-consistency pass after the loop -> the library call (which includes it) + the write-back
+    a = fn.rindex("if(mbCheckOrientation)")
+    b = block_end(fn, a)
+    fn = fn[:a] + LAST_FRAME_SEARCH + fn[b:]
+    return src[:f0] + fn + src[f1:]
+
+
 def main():
     src = open(sys.argv[1]).read()
     for sig, body in FORWARDS.items():
         src = replace_body(src, sig, body)
     open(sys.argv[2], "w").write(src)
+    if len(sys.argv) > 4:
+        src = open(sys.argv[3]).read()
+        src = replace_body(src, LOCAL_MAP_SIG, LOCAL_MAP_BODY)
+        src = patch_last_frame(src)
+        src = '#include "orbhip.h"\n#include <cstdlib>\n' + src
+        open(sys.argv[4], "w").write(src)
 
 
 if __name__ == "__main__":

@@ -840,7 +840,7 @@ int SearchByProjectionFlat(const FrameLite& F, const float* mvuRight, std::vecto
         ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
         for (int i = 0; i < HISTO_LENGTH; i++)
             if (i != ind1 && i != ind2 && i != ind3)
-                for (int idx : rotHist[i]) { feature_query[idx] = -1; nmatches--; }
+                for (int idx : rotHist[i]) { feature_query[idx] = -2; nmatches--; }     // CurrentFrame.mvpMapPoints[idx] = NULL (ORBmatcher.cc:1460): -2, distinct from "untouched"
     }
     return nmatches;
 }

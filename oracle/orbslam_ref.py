@@ -177,7 +177,7 @@ def search_by_projection_points(frame, px, py, pxr, level, viewcos, inview, bad,
          np.ascontiguousarray(desc, np.uint8)]
     st = None if feature_state is None else np.ascontiguousarray(feature_state, np.uint8)
     fq = np.full(frame.N, -1, np.int32)
-    n = lib().orbslam_ref_search_by_projection_points(frame.h, len(a[0]), *[_p(v) for v in a], _p(st), th, nnratio, _p(fq))
+    n = frame.L.orbslam_ref_search_by_projection_points(frame.h, len(a[0]), *[_p(v) for v in a], _p(st), th, nnratio, _p(fq))
     return n, fq
 
 
@@ -189,7 +189,7 @@ def search_by_projection_last(cur, last, has_point, X, Y, Z, desc, outlier=None,
     bd = None if bad is None else np.ascontiguousarray(bad, np.uint8)
     st = None if cur_state is None else np.ascontiguousarray(cur_state, np.uint8)
     fq = np.full(cur.N, -1, np.int32)
-    n = lib().orbslam_ref_search_by_projection_last(cur.h, last.h, _p(hp), _p(X), _p(Y), _p(Z), _p(desc), _p(out), _p(bd), _p(st), th, int(mono), nnratio, int(check_ori), _p(fq))
+    n = cur.L.orbslam_ref_search_by_projection_last(cur.h, last.h, _p(hp), _p(X), _p(Y), _p(Z), _p(desc), _p(out), _p(bd), _p(st), th, int(mono), nnratio, int(check_ori), _p(fq))
     return n, fq
 
 

@@ -299,8 +299,11 @@ int orbslam_ref_search_by_projection_last(void* cur, void* last, const uint8_t* 
         Lf.mvpMapPoints[i] = p; index[p] = i;
     }
     ORBmatcher matcher(nnratio, check_ori != 0);
+    std::vector<MapPoint*> before(C.mvpMapPoints);
     const int n = matcher.SearchByProjection(C, Lf, th, mono != 0);
-    for (int i = 0; i < C.N; i++) { auto it = index.find(C.mvpMapPoints[i]); feature_query[i] = it == index.end() ? -1 : it->second; }
+    // index of the last-frame point now attached; -2 = a feature that held a map point before the call and is NULL now (claimed, then removed by
+    // the rotation check, :1452-1466); -1 = as before the call
+    for (int i = 0; i < C.N; i++) { auto it = index.find(C.mvpMapPoints[i]); feature_query[i] = it != index.end() ? it->second : (!C.mvpMapPoints[i] && before[i]) ? -2 : -1; }
     return n;
 }
 

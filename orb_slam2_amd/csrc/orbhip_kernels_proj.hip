@@ -253,7 +253,7 @@ __global__ __launch_bounds__(PJ_T) void k_proj_select(ProjParams J)
                 int removed = 0;
                 for (int k = 0; k < nev; k++) {                                            // ORBmatcher.cc:1452-1466: one decrement per histogram entry
                     const int ev = J.events[k], bin = ev >> 20, idx = ev & 0xFFFFF;
-                    if (bin != ind1 && bin != ind2 && bin != ind3) { s_fq[idx] = -1; removed++; }
+                    if (bin != ind1 && bin != ind2 && bin != ind3) { s_fq[idx] = -2; removed++; }      // mvpMapPoints[idx] = NULL (:1460): reported as -2, not as "untouched"
                 }
                 s_hist[ORBHIP_HISTO_LENGTH] = removed;
             }

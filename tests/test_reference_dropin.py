@@ -83,3 +83,49 @@ def test_reference_stereo_frame_on_dropin_extractors(builds):
         assert _same(a, b) and (a.depth > 0).sum() > 100
         a.close(); b.close()
     S.RefFrame._geometry = None
+
+
+def test_projection_matchers_through_the_binding(builds, request):
+    """INTEGRATION.md §2-3c in the "all-steps" build: ORBmatcher::SearchByProjection(Frame, MapPoints, th) and (CurrentFrame, LastFrame, th, bMono)
+    keep the reference's projection / bookkeeping code and send their search loops through orbhip_search_by_projection_bounds; the final
+    Frame::mvpMapPoints and the return values must equal the unmodified reference's, on mono and stereo frames."""
+    if "all-steps" not in request.node.name:
+        pytest.skip("the steps 1-3 build keeps the reference's own search loops")
+    S, D = builds
+    w, h, n = 480, 360, 700
+    seq = synth.sequence(w, h, 2, seed=41)
+    for stereo in (False, True):
+        S.RefFrame._geometry = None
+        S.RefFrame._geometry_other.clear()
+        kw = dict(nfeatures=n)
+        if stereo:
+            kw.update(fx=64.0, fy=64.0, cx=0.0, cy=0.0, bf=40.0)
+        mk = lambda im, lib: S.RefFrame(im, np.roll(im, -9, axis=1) if stereo else None, library=lib, **kw)
+        R, F = [mk(im, None) for im in seq], [mk(im, D) for im in seq]
+        kl, dl, kc = R[0].keys_un, R[0].desc, R[1].keys_un
+        rng = np.random.default_rng(5 + stereo)
+        nq = len(kl)
+        # local map points (Tracking::SearchLocalPoints)
+        for th in (1.0, 3.0):
+            px = (kl["x"] - 3.0 + rng.normal(0, 1, nq)).astype(np.float32); py = (kl["y"] - 1.0 + rng.normal(0, 1, nq)).astype(np.float32)
+            pxr = (px - rng.uniform(2, 40, nq)).astype(np.float32); level = kl["octave"].astype(np.int32)
+            vc = np.where(rng.random(nq) < 0.5, 0.9995, 0.9).astype(np.float32)
+            inview = (rng.random(nq) < 0.85).astype(np.uint8); bad = (rng.random(nq) < 0.05).astype(np.uint8); nobs = (rng.random(nq) < 0.9).astype(np.int32)
+            state = rng.choice([0, 0, 0, 1, 2], len(kc)).astype(np.uint8)
+            n_r, fq_r = S.search_by_projection_points(R[1], px, py, pxr, level, vc, inview, bad, nobs, dl, state, th=th, nnratio=0.8)
+            n_f, fq_f = S.search_by_projection_points(F[1], px, py, pxr, level, vc, inview, bad, nobs, dl, state, th=th, nnratio=0.8)
+            assert n_r == n_f and np.array_equal(fq_r, fq_f) and n_r > 100
+        # last frame's points under the motion model (TrackWithMotionModel)
+        fx = np.float32(64.0 if stereo else 1.0)
+        for th, ori in ((7.0, True), (15.0, True), (15.0, False)):
+            has = (rng.random(nq) < 0.85).astype(np.uint8); outl = (rng.random(nq) < 0.1).astype(np.uint8)
+            X = (kl["x"] - 3.0 + rng.normal(0, 1.5, nq)).astype(np.float32); Y = (kl["y"] - 1.0 + rng.normal(0, 1.5, nq)).astype(np.float32)
+            state = rng.choice([0, 0, 0, 1, 2], len(kc)).astype(np.uint8)
+            args = (has, X / fx, Y / fx, np.ones(nq, np.float32), dl)
+            n_r, fq_r = S.search_by_projection_last(R[1], R[0], *args, outlier=outl, cur_state=state, th=th, mono=not stereo, nnratio=0.9, check_ori=ori)
+            n_f, fq_f = S.search_by_projection_last(F[1], F[0], *args, outlier=outl, cur_state=state, th=th, mono=not stereo, nnratio=0.9, check_ori=ori)
+            assert n_r == n_f and np.array_equal(fq_r, fq_f) and n_r > 100
+            assert not ori or (fq_r == -2).sum() > 0                  # features claimed and NULLed by the rotation check are part of the comparison
+        for f in R + F:
+            f.close()
+    S.RefFrame._geometry = None
