@@ -45,7 +45,8 @@ def test_reference_frame_on_dropin_extractor(builds, request, w, h, n, levels, s
     rng = np.random.default_rng(1)
     depth = (1.0 + rng.random((h, w))).astype(np.float32)
     depth[rng.random((h, w)) < 0.2] = 0.0
-    for kw in (dict(), dict(dist=tum1, **cam), dict(depth=depth, **cam), dict(depth=depth, dist=tum1, **cam)):
+    variants = (dict(), dict(depth=depth, dist=tum1, **cam)) if "steps1-3" in request.node.name else (dict(dist=tum1, **cam), dict(depth=depth, **cam))
+    for kw in variants:
         S.RefFrame._geometry = None
         S.RefFrame._geometry_other.clear()
         R = [S.RefFrame(im, nfeatures=n, nlevels=levels, scale=scale, **kw) for im in seq]
@@ -106,7 +107,7 @@ def test_projection_matchers_through_the_binding(builds, request):
         rng = np.random.default_rng(5 + stereo)
         nq = len(kl)
         # local map points (Tracking::SearchLocalPoints)
-        for th in (1.0, 3.0):
+        for th in (3.0,):
             px = (kl["x"] - 3.0 + rng.normal(0, 1, nq)).astype(np.float32); py = (kl["y"] - 1.0 + rng.normal(0, 1, nq)).astype(np.float32)
             pxr = (px - rng.uniform(2, 40, nq)).astype(np.float32); level = kl["octave"].astype(np.int32)
             vc = np.where(rng.random(nq) < 0.5, 0.9995, 0.9).astype(np.float32)
@@ -117,7 +118,7 @@ def test_projection_matchers_through_the_binding(builds, request):
             assert n_r == n_f and np.array_equal(fq_r, fq_f) and n_r > 100
         # last frame's points under the motion model (TrackWithMotionModel)
         fx = np.float32(64.0 if stereo else 1.0)
-        for th, ori in ((7.0, True), (15.0, True), (15.0, False)):
+        for th, ori in ((15.0, True), (7.0, False)):
             has = (rng.random(nq) < 0.85).astype(np.uint8); outl = (rng.random(nq) < 0.1).astype(np.uint8)
             X = (kl["x"] - 3.0 + rng.normal(0, 1.5, nq)).astype(np.float32); Y = (kl["y"] - 1.0 + rng.normal(0, 1.5, nq)).astype(np.float32)
             state = rng.choice([0, 0, 0, 1, 2], len(kc)).astype(np.uint8)
