@@ -124,6 +124,67 @@ def patch_last_frame(src):
     return src[:f0] + fn + src[f1:]
 
 
+# the loop-closing and relocalisation overloads are parameterisations of the same search (include/orbhip.h): levels, threshold, who blocks
+KF_SIM3_SIG = r"int\s+ORBmatcher::SearchByProjection\s*\(\s*KeyFrame\s*\*\s*pKF\s*,\s*cv::Mat\s+Scw\s*,"
+KF_SIM3_QUERY = """orbhip_proj_query e = { u, v, radius, 0.f, nPredictedLevel-1, nPredictedLevel, 1, 0.f };
+        const cv::Mat dMP = pMP->GetDescriptor();
+        orbhip_q.push_back(e); orbhip_qd.insert(orbhip_qd.end(), dMP.ptr<unsigned char>(), dMP.ptr<unsigned char>()+32); orbhip_owner.push_back(pMP);
+"""
+KF_SIM3_SEARCH = """if(!orbhip_q.empty() && pKF->N>0)
+    {
+        std::vector<unsigned char> blocked(pKF->N); std::vector<int> fq(pKF->N);
+        for(int i=0;i<pKF->N;i++) blocked[i] = vpMatched[i]!=NULL;
+        const orbhip_bounds bounds = {(float)pKF->mnMinX, (float)pKF->mnMinY, (float)pKF->mnMaxX, (float)pKF->mnMaxY};
+        if(orbhip_search_by_projection_bounds(0, (const orbhip_keypoint*)&pKF->mvKeysUn[0], pKF->mDescriptors.ptr<unsigned char>(), NULL, &blocked[0], pKF->N, &bounds,
+                                              &orbhip_q[0], &orbhip_qd[0], (int)orbhip_q.size(), 1, mfNNratio, TH_LOW, 0, &fq[0], &nmatches)!=ORBHIP_OK) abort();
+        for(int i=0;i<pKF->N;i++) if(fq[i]>=0) vpMatched[i]=orbhip_owner[fq[i]];
+    }
+
+    """
+RELOC_SIG = r"int\s+ORBmatcher::SearchByProjection\s*\(\s*Frame\s*&\s*CurrentFrame\s*,\s*KeyFrame\s*\*\s*pKF\s*,"
+RELOC_QUERY = """orbhip_proj_query e = { u, v, radius, 0.f, nPredictedLevel-1, nPredictedLevel+1, 1, pKF->mvKeysUn[i].angle };
+                const cv::Mat dMP = pMP->GetDescriptor();
+                orbhip_q.push_back(e); orbhip_qd.insert(orbhip_qd.end(), dMP.ptr<unsigned char>(), dMP.ptr<unsigned char>()+32); orbhip_owner.push_back(pMP);
+"""
+RELOC_SEARCH = """if(!orbhip_q.empty() && CurrentFrame.N>0)
+    {
+        std::vector<unsigned char> blocked(CurrentFrame.N); std::vector<int> fq(CurrentFrame.N);
+        for(int i=0;i<CurrentFrame.N;i++) blocked[i] = CurrentFrame.mvpMapPoints[i]!=NULL;
+        const orbhip_bounds bounds = {Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY};
+        if(orbhip_search_by_projection_bounds(0, (const orbhip_keypoint*)&CurrentFrame.mvKeysUn[0], CurrentFrame.mDescriptors.ptr<unsigned char>(), NULL, &blocked[0], CurrentFrame.N,
+                                              &bounds, &orbhip_q[0], &orbhip_qd[0], (int)orbhip_q.size(), 1, mfNNratio, ORBdist, mbCheckOrientation, &fq[0], &nmatches)!=ORBHIP_OK) abort();
+        for(int i=0;i<CurrentFrame.N;i++)
+        {
+            if(fq[i]>=0) CurrentFrame.mvpMapPoints[i]=orbhip_owner[fq[i]];
+            else if(fq[i]==-2) CurrentFrame.mvpMapPoints[i]=static_cast<MapPoint*>(NULL);
+        }
+    }
+"""
+
+
+def patch_projection_member(src, sig, first_stmt, loop_from, loop_until, query, search, search_replaces):
+    """one SearchByProjection overload: flat-query arrays declared after `first_stmt`; the text from `loop_from` to the end of the block
+    opened after `loop_until` becomes `query`; `search` replaces the block after the LAST `search_replaces` (the rotation pass) or, if that is
+    None, goes in front of the function's final return"""
+    m = re.search(sig, src)
+    if not m:
+        raise SystemExit(f"not found: {sig}")
+    f0, f1 = m.start(), block_end(src, m.end())
+    fn = src[f0:f1]
+    k = fn.index(first_stmt) + len(first_stmt)
+    fn = fn[:k] + LAST_FRAME_DECLS + fn[k:]
+    a = fn.index(loop_from)
+    b = block_end(fn, fn.index(loop_until, a))
+    fn = fn[:a] + query + fn[b:]
+    if search_replaces is None:
+        a = fn.rindex("return nmatches;")
+        fn = fn[:a] + search + fn[a:]
+    else:
+        a = fn.rindex(search_replaces)
+        fn = fn[:a] + search + fn[block_end(fn, a):]
+    return src[:f0] + fn + src[f1:]
+
+
 def main():
     src = open(sys.argv[1]).read()
     for sig, body in FORWARDS.items():
@@ -133,6 +194,10 @@ def main():
         src = open(sys.argv[3]).read()
         src = replace_body(src, LOCAL_MAP_SIG, LOCAL_MAP_BODY)
         src = patch_last_frame(src)
+        src = patch_projection_member(src, KF_SIM3_SIG, "int nmatches=0;", "const vector<size_t> vIndices = pKF->GetFeaturesInArea(u,v,radius);", "if(bestDist<=TH_LOW)",
+                                      KF_SIM3_QUERY, KF_SIM3_SEARCH, None)
+        src = patch_projection_member(src, RELOC_SIG, "int nmatches = 0;", "const vector<size_t> vIndices2 = CurrentFrame.GetFeaturesInArea(u, v, radius, nPredictedLevel-1, nPredictedLevel+1);",
+                                      "if(bestDist<=ORBdist)", RELOC_QUERY, RELOC_SEARCH, "if(mbCheckOrientation)")
         src = '#include "orbhip.h"\n#include <cstdlib>\n' + src
         open(sys.argv[4], "w").write(src)
 

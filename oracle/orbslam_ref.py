@@ -239,7 +239,7 @@ def search_by_projection_kf(frame, matched_state, X, Y, Z, level, bad, desc, th=
     nq = len(X)
     fq = np.full(frame.N, -1, np.int32)
     a = [_f32(X), _f32(Y), _f32(Z), np.ascontiguousarray(level, np.int32), _u8(bad, nq), np.ascontiguousarray(desc, np.uint8)]
-    n = lib().orbslam_ref_search_by_projection_kf(frame.h, _p(_u8(matched_state, frame.N)), nq, *[_p(v) for v in a], int(th), _p(fq))
+    n = frame.L.orbslam_ref_search_by_projection_kf(frame.h, _p(_u8(matched_state, frame.N)), nq, *[_p(v) for v in a], int(th), _p(fq))
     return n, fq
 
 
@@ -247,7 +247,7 @@ def search_by_projection_reloc(cur, kf_frame, has_point, X, Y, Z, level, bad, fo
     n1 = kf_frame.N
     fq = np.full(cur.N, -1, np.int32)
     a = [_u8(has_point, n1), _f32(X), _f32(Y), _f32(Z), np.ascontiguousarray(level, np.int32), _u8(bad, n1), _u8(found, n1), np.ascontiguousarray(desc, np.uint8), _u8(cur_state, cur.N)]
-    n = lib().orbslam_ref_search_by_projection_reloc(cur.h, kf_frame.h, *[_p(v) for v in a], th, int(orb_dist), nnratio, int(check_ori), _p(fq))
+    n = cur.L.orbslam_ref_search_by_projection_reloc(cur.h, kf_frame.h, *[_p(v) for v in a], th, int(orb_dist), nnratio, int(check_ori), _p(fq))
     return n, fq
 
 

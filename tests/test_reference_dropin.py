@@ -130,3 +130,38 @@ def test_projection_matchers_through_the_binding(builds, request):
         for f in R + F:
             f.close()
     S.RefFrame._geometry = None
+
+
+def test_loop_closing_and_relocalisation_matchers_through_the_binding(builds, request):
+    """The other two SearchByProjection overloads (loop closing: KeyFrame + Sim3, ORBmatcher.cc:290-403; relocalisation: Frame + KeyFrame,
+    :1472-1599) with their search loops sent through orbhip_search_by_projection_bounds in the "all-steps" build."""
+    if "all-steps" not in request.node.name:
+        pytest.skip("the steps 1-3 build keeps the reference's own search loops")
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_reference_matchers import _world
+    S, D = builds
+    w, h, n = 480, 360, 700
+    seq = synth.sequence(w, h, 2, seed=41)
+    S.RefFrame._geometry = None
+    S.RefFrame._geometry_other.clear()
+    R, F = [S.RefFrame(im, nfeatures=n) for im in seq], [S.RefFrame(im, nfeatures=n, library=D) for im in seq]
+    kl, dl, kc = R[0].keys_un, R[0].desc, R[1].keys_un
+    rng = np.random.default_rng(12)
+    X, Y, level = _world(rng, kl, w, h)
+    nq = len(kl)
+    bad = (rng.random(nq) < 0.05).astype(np.uint8)
+    ms = (rng.random(len(kc)) < 0.2).astype(np.uint8)
+    n_r, fq_r = S.search_by_projection_kf(R[1], ms, X, Y, np.ones(nq, np.float32), level, bad, dl, th=10)
+    n_f, fq_f = S.search_by_projection_kf(F[1], ms, X, Y, np.ones(nq, np.float32), level, bad, dl, th=10)
+    assert n_r == n_f and np.array_equal(fq_r, fq_f) and n_r > 100
+    for th, orb_dist, ori in ((10.0, 100, True), (3.0, 64, False)):
+        has = (rng.random(nq) < 0.8).astype(np.uint8); found = (rng.random(nq) < 0.1).astype(np.uint8)
+        cs = rng.choice([0, 0, 0, 1, 2], len(kc)).astype(np.uint8)
+        a = (has, X, Y, np.ones(nq, np.float32), level, bad, found, dl, cs)
+        n_r, fq_r = S.search_by_projection_reloc(R[1], R[0], *a, th=th, orb_dist=orb_dist, nnratio=0.9, check_ori=ori)
+        n_f, fq_f = S.search_by_projection_reloc(F[1], F[0], *a, th=th, orb_dist=orb_dist, nnratio=0.9, check_ori=ori)
+        assert n_r == n_f and np.array_equal(fq_r, fq_f) and n_r > 100
+    for f in R + F:
+        f.close()
+    S.RefFrame._geometry = None
