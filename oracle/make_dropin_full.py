@@ -185,6 +185,54 @@ def patch_projection_member(src, sig, first_stmt, loop_from, loop_until, query, 
     return src[:f0] + fn + src[f1:]
 
 
+# Fuse (LocalMapping::SearchInNeighbors): the candidate search of every map point does not depend on the map surgery of the others, so the
+# member becomes two passes — the reference's projection code collects one flat query per point, ONE library call finds the best key point of
+# every window, then the reference's own surgery block (Replace / AddObservation / AddMapPoint, moved, not rewritten) runs in the original
+# order.  (vpMapPoints holds each point once, LocalMapping.cc:mnFuseCandidateForKF, so no point's filters depend on an earlier point's surgery.)
+FUSE_SIG = r"int\s+ORBmatcher::Fuse\s*\(\s*KeyFrame\s*\*\s*pKF\s*,\s*const\s+vector<MapPoint\s*\*>\s*&\s*vpMapPoints\s*,\s*const\s+float\s+th\s*\)"
+FUSE_DECLS = """
+    std::vector<orbhip_best_query> orbhip_bq; std::vector<unsigned char> orbhip_qd; std::vector<MapPoint*> orbhip_owner;
+"""
+FUSE_QUERY = """orbhip_best_query e = { u, v, radius, ur, nPredictedLevel };
+        const cv::Mat dMP = pMP->GetDescriptor();
+        orbhip_bq.push_back(e); orbhip_qd.insert(orbhip_qd.end(), dMP.ptr<unsigned char>(), dMP.ptr<unsigned char>()+32); orbhip_owner.push_back(pMP);
+"""
+FUSE_SEARCH = """std::vector<int> orbhip_bi(orbhip_bq.size(), -1), orbhip_bd(orbhip_bq.size(), 256);
+    if(!orbhip_bq.empty() && pKF->N>0)
+    {
+        const orbhip_bounds bounds = {(float)pKF->mnMinX, (float)pKF->mnMinY, (float)pKF->mnMaxX, (float)pKF->mnMaxY};
+        if(orbhip_search_best_in_window_bounds(0, (const orbhip_keypoint*)&pKF->mvKeysUn[0], pKF->mDescriptors.ptr<unsigned char>(), &pKF->mvuRight[0], pKF->N, &bounds,
+                                               &pKF->mvInvLevelSigma2[0], (int)pKF->mvInvLevelSigma2.size(), &orbhip_bq[0], &orbhip_qd[0], (int)orbhip_bq.size(), 1,
+                                               &orbhip_bi[0], &orbhip_bd[0])!=ORBHIP_OK) abort();
+    }
+    for(size_t orbhip_k=0; orbhip_k<orbhip_owner.size(); orbhip_k++)
+    {
+        MapPoint* pMP = orbhip_owner[orbhip_k];
+        const int bestDist = orbhip_bd[orbhip_k], bestIdx = orbhip_bi[orbhip_k];
+        %s
+    }
+
+    """
+
+
+def patch_fuse(src):
+    m = re.search(FUSE_SIG, src)
+    if not m:
+        raise SystemExit("Fuse(pKF, vpMapPoints, th) not found")
+    f0, f1 = m.start(), block_end(src, m.end())
+    fn = src[f0:f1]
+    k = fn.index("int nFused=0;") + len("int nFused=0;")
+    fn = fn[:k] + FUSE_DECLS + fn[k:]
+    a = fn.index("const vector<size_t> vIndices = pKF->GetFeaturesInArea(u,v,radius);")
+    s0 = fn.index("if(bestDist<=TH_LOW)", a)
+    s1 = block_end(fn, s0)
+    surgery = fn[s0:s1]                                   # the reference's own block, moved into the second pass
+    fn = fn[:a] + FUSE_QUERY + fn[s1:]
+    r = fn.rindex("return nFused;")
+    fn = fn[:r] + (FUSE_SEARCH % surgery) + fn[r:]
+    return src[:f0] + fn + src[f1:]
+
+
 def main():
     src = open(sys.argv[1]).read()
     for sig, body in FORWARDS.items():
@@ -194,6 +242,7 @@ def main():
         src = open(sys.argv[3]).read()
         src = replace_body(src, LOCAL_MAP_SIG, LOCAL_MAP_BODY)
         src = patch_last_frame(src)
+        src = patch_fuse(src)
         src = patch_projection_member(src, KF_SIM3_SIG, "int nmatches=0;", "const vector<size_t> vIndices = pKF->GetFeaturesInArea(u,v,radius);", "if(bestDist<=TH_LOW)",
                                       KF_SIM3_QUERY, KF_SIM3_SEARCH, None)
         src = patch_projection_member(src, RELOC_SIG, "int nmatches = 0;", "const vector<size_t> vIndices2 = CurrentFrame.GetFeaturesInArea(u, v, radius, nPredictedLevel-1, nPredictedLevel+1);",

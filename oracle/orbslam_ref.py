@@ -231,7 +231,7 @@ def fuse(frame, kf_state, X, Y, Z, level, nobs, bad, desc, th=3.0):
     best = np.full(nq, -1, np.int32)
     a = [_f32(X), _f32(Y), _f32(Z), np.ascontiguousarray(level, np.int32), np.ascontiguousarray(nobs, np.int32), _u8(bad, nq), np.ascontiguousarray(desc, np.uint8)]
     st = _u8(kf_state, frame.N)
-    n = lib().orbslam_ref_fuse(frame.h, _p(st), nq, *[_p(v) for v in a], th, _p(best))
+    n = frame.L.orbslam_ref_fuse(frame.h, _p(st), nq, *[_p(v) for v in a], th, _p(best))
     return n, best
 
 

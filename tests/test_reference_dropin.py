@@ -132,9 +132,10 @@ def test_projection_matchers_through_the_binding(builds, request):
     S.RefFrame._geometry = None
 
 
-def test_loop_closing_and_relocalisation_matchers_through_the_binding(builds, request):
+def test_loop_closing_relocalisation_and_fuse_through_the_binding(builds, request):
     """The other two SearchByProjection overloads (loop closing: KeyFrame + Sim3, ORBmatcher.cc:290-403; relocalisation: Frame + KeyFrame,
-    :1472-1599) with their search loops sent through orbhip_search_by_projection_bounds in the "all-steps" build."""
+    :1472-1599) with their search loops sent through orbhip_search_by_projection_bounds, and ORBmatcher::Fuse(pKF, vpMapPoints, th) (:825-972)
+    around orbhip_search_best_in_window_bounds, in the "all-steps" build."""
     if "all-steps" not in request.node.name:
         pytest.skip("the steps 1-3 build keeps the reference's own search loops")
     import os, sys
@@ -162,6 +163,23 @@ def test_loop_closing_and_relocalisation_matchers_through_the_binding(builds, re
         n_r, fq_r = S.search_by_projection_reloc(R[1], R[0], *a, th=th, orb_dist=orb_dist, nnratio=0.9, check_ori=ori)
         n_f, fq_f = S.search_by_projection_reloc(F[1], F[0], *a, th=th, orb_dist=orb_dist, nnratio=0.9, check_ori=ori)
         assert n_r == n_f and np.array_equal(fq_r, fq_f) and n_r > 100
+    # Fuse (LocalMapping::SearchInNeighbors): two passes around one orbhip_search_best_in_window_bounds call, the reference's surgery block moved
+    for th in (3.0, 7.0):
+        nobs = rng.integers(0, 4, nq).astype(np.int32)
+        state = rng.choice([0, 0, 1, 2], len(kc)).astype(np.uint8)
+        a = (state, X, Y, np.ones(nq, np.float32), level, nobs, bad, dl)
+        n_r, b_r = S.fuse(R[1], *a, th=th)
+        n_f, b_f = S.fuse(F[1], *a, th=th)
+        assert n_r == n_f and np.array_equal(b_r, b_f) and n_r > 50
+    kw = dict(nfeatures=n, fx=64.0, fy=64.0, cx=0.0, cy=0.0, bf=40.0)                  # stereo key frame: the chi-square gate's stereo branch
+    S.RefFrame._geometry = None
+    S.RefFrame._geometry_other.clear()
+    ks_r = S.RefFrame(seq[1], np.roll(seq[1], -9, axis=1), **kw); ks_f = S.RefFrame(seq[1], np.roll(seq[1], -9, axis=1), library=D, **kw)
+    a = (rng.choice([0, 0, 1], len(kc)).astype(np.uint8), X / np.float32(64), Y / np.float32(64), np.ones(nq, np.float32), level, rng.integers(0, 4, nq).astype(np.int32), bad, dl)
+    n_r, b_r = S.fuse(ks_r, *a, th=3.0)
+    n_f, b_f = S.fuse(ks_f, *a, th=3.0)
+    assert n_r == n_f and np.array_equal(b_r, b_f) and n_r > 50 and int((ks_r.u_right >= 0).sum()) > 100
+    ks_r.close(); ks_f.close()
     for f in R + F:
         f.close()
     S.RefFrame._geometry = None
