@@ -233,6 +233,96 @@ def patch_fuse(src):
     return src[:f0] + fn + src[f1:]
 
 
+# SearchByBoW (TrackReferenceKeyFrame / Relocalization, LoopClosing::ComputeSim3): the two std::map FeatureVectors are flattened and the node-
+# matched search runs in one call; whole bodies (the reference's map-point vectors in, its output vector out).
+BOW_HELPERS = """
+static void orbhip_flatten(const DBoW2::FeatureVector& fv, std::vector<unsigned int>& node, std::vector<int>& off, std::vector<unsigned int>& feat)
+{
+    node.clear(); off.assign(1, 0); feat.clear();
+    for(DBoW2::FeatureVector::const_iterator it=fv.begin(); it!=fv.end(); ++it)
+    {
+        node.push_back(it->first); feat.insert(feat.end(), it->second.begin(), it->second.end()); off.push_back((int)feat.size());
+    }
+    if(node.empty()) node.push_back(0);
+    if(feat.empty()) feat.push_back(0);
+}
+"""
+BOW_KF_FRAME_SIG = r"int\s+ORBmatcher::SearchByBoW\s*\(\s*KeyFrame\s*\*\s*pKF\s*,\s*Frame\s*&\s*F\s*,"
+BOW_KF_FRAME_BODY = """{
+    const vector<MapPoint*> vpMapPointsKF = pKF->GetMapPointMatches();
+    vpMapPointMatches = vector<MapPoint*>(F.N,static_cast<MapPoint*>(NULL));
+    const int n1 = (int)vpMapPointsKF.size(), n2 = F.N;
+    if(n1==0 || n2==0 || pKF->mFeatVec.empty() || F.mFeatVec.empty()) return 0;
+    std::vector<unsigned char> valid1(n1); std::vector<float> ang1(n1), ang2(n2);
+    for(int i=0;i<n1;i++) { MapPoint* p = vpMapPointsKF[i]; valid1[i] = p && !p->isBad(); ang1[i] = pKF->mvKeysUn[i].angle; }
+    for(int i=0;i<n2;i++) ang2[i] = F.mvKeys[i].angle;
+    std::vector<unsigned int> node1, feat1, node2, feat2; std::vector<int> off1, off2;
+    orbhip_flatten(pKF->mFeatVec, node1, off1, feat1); orbhip_flatten(F.mFeatVec, node2, off2, feat2);
+    std::vector<int> m12(n1, -1); int nmatches=0;
+    if(orbhip_search_by_bow(0, 0, pKF->mDescriptors.ptr<unsigned char>(), &ang1[0], &valid1[0], n1, &node1[0], &off1[0], &feat1[0], (int)pKF->mFeatVec.size(),
+                            F.mDescriptors.ptr<unsigned char>(), &ang2[0], NULL, n2, &node2[0], &off2[0], &feat2[0], (int)F.mFeatVec.size(),
+                            mfNNratio, mbCheckOrientation, &m12[0], &nmatches)!=ORBHIP_OK) abort();
+    for(int i=0;i<n1;i++) if(m12[i]>=0) vpMapPointMatches[m12[i]] = vpMapPointsKF[i];
+    return nmatches;
+}"""
+BOW_KF_KF_SIG = r"int\s+ORBmatcher::SearchByBoW\s*\(\s*KeyFrame\s*\*\s*pKF1\s*,\s*KeyFrame\s*\*\s*pKF2\s*,"
+BOW_KF_KF_BODY = """{
+    const vector<MapPoint*> vpMapPoints1 = pKF1->GetMapPointMatches();
+    const vector<MapPoint*> vpMapPoints2 = pKF2->GetMapPointMatches();
+    vpMatches12 = vector<MapPoint*>(vpMapPoints1.size(),static_cast<MapPoint*>(NULL));
+    const int n1 = (int)vpMapPoints1.size(), n2 = (int)vpMapPoints2.size();
+    if(n1==0 || n2==0 || pKF1->mFeatVec.empty() || pKF2->mFeatVec.empty()) return 0;
+    std::vector<unsigned char> valid1(n1), valid2(n2); std::vector<float> ang1(n1), ang2(n2);
+    for(int i=0;i<n1;i++) { MapPoint* p = vpMapPoints1[i]; valid1[i] = p && !p->isBad(); ang1[i] = pKF1->mvKeysUn[i].angle; }
+    for(int i=0;i<n2;i++) { MapPoint* p = vpMapPoints2[i]; valid2[i] = p && !p->isBad(); ang2[i] = pKF2->mvKeysUn[i].angle; }
+    std::vector<unsigned int> node1, feat1, node2, feat2; std::vector<int> off1, off2;
+    orbhip_flatten(pKF1->mFeatVec, node1, off1, feat1); orbhip_flatten(pKF2->mFeatVec, node2, off2, feat2);
+    std::vector<int> m12(n1, -1); int nmatches=0;
+    if(orbhip_search_by_bow(0, 1, pKF1->mDescriptors.ptr<unsigned char>(), &ang1[0], &valid1[0], n1, &node1[0], &off1[0], &feat1[0], (int)pKF1->mFeatVec.size(),
+                            pKF2->mDescriptors.ptr<unsigned char>(), &ang2[0], &valid2[0], n2, &node2[0], &off2[0], &feat2[0], (int)pKF2->mFeatVec.size(),
+                            mfNNratio, mbCheckOrientation, &m12[0], &nmatches)!=ORBHIP_OK) abort();
+    for(int i=0;i<n1;i++) if(m12[i]>=0) vpMatches12[i] = vpMapPoints2[m12[i]];
+    return nmatches;
+}"""
+
+
+# SearchForTriangulation (LocalMapping::CreateNewMapPoints): the reference's epipole computation stays, the node-matched search with its
+# epipole / epipolar-line gates and the rotation pass become one call that fills the reference's own vMatches12; its pair list tail stays.
+TRI_SIG = r"int\s+ORBmatcher::SearchForTriangulation\s*\("
+TRI_SEARCH = """{
+        const int n1 = pKF1->N, n2 = pKF2->N;
+        if(n1>0 && n2>0 && !vFeatVec1.empty() && !vFeatVec2.empty())
+        {
+            std::vector<float> kp1(4*n1), kp2(4*n2); std::vector<unsigned char> has1(n1), st1(n1), has2(n2), st2(n2);
+            for(int i=0;i<n1;i++) { const cv::KeyPoint &k = pKF1->mvKeysUn[i]; kp1[4*i]=k.pt.x; kp1[4*i+1]=k.pt.y; kp1[4*i+2]=k.angle; kp1[4*i+3]=(float)k.octave;
+                                    has1[i] = pKF1->GetMapPoint(i)!=NULL; st1[i] = pKF1->mvuRight[i]>=0; }
+            for(int i=0;i<n2;i++) { const cv::KeyPoint &k = pKF2->mvKeysUn[i]; kp2[4*i]=k.pt.x; kp2[4*i+1]=k.pt.y; kp2[4*i+2]=k.angle; kp2[4*i+3]=(float)k.octave;
+                                    has2[i] = pKF2->GetMapPoint(i)!=NULL; st2[i] = pKF2->mvuRight[i]>=0; }
+            std::vector<unsigned int> node1, feat1, node2, feat2; std::vector<int> off1, off2;
+            orbhip_flatten(vFeatVec1, node1, off1, feat1); orbhip_flatten(vFeatVec2, node2, off2, feat2);
+            float F12flat[9]; for(int r=0;r<3;r++) for(int c=0;c<3;c++) F12flat[3*r+c] = F12.at<float>(r,c);
+            if(orbhip_search_for_triangulation(0, pKF1->mDescriptors.ptr<unsigned char>(), &kp1[0], &has1[0], &st1[0], n1, &node1[0], &off1[0], &feat1[0], (int)vFeatVec1.size(),
+                                               pKF2->mDescriptors.ptr<unsigned char>(), &kp2[0], &has2[0], &st2[0], n2, &node2[0], &off2[0], &feat2[0], (int)vFeatVec2.size(),
+                                               F12flat, ex, ey, &pKF2->mvScaleFactors[0], &pKF2->mvLevelSigma2[0], (int)pKF2->mvScaleFactors.size(),
+                                               bOnlyStereo, mbCheckOrientation, &vMatches12[0], &nmatches)!=ORBHIP_OK) abort();
+        }
+    }
+
+    """
+
+
+def patch_triangulation(src):
+    m = re.search(TRI_SIG, src)
+    if not m:
+        raise SystemExit("SearchForTriangulation not found")
+    f0, f1 = m.start(), block_end(src, m.end())
+    fn = src[f0:f1]
+    a = fn.index("vector<int> rotHist[HISTO_LENGTH];")
+    b = block_end(fn, fn.rindex("if(mbCheckOrientation)"))
+    fn = fn[:a] + TRI_SEARCH + fn[b:]
+    return src[:f0] + fn + src[f1:]
+
+
 def main():
     src = open(sys.argv[1]).read()
     for sig, body in FORWARDS.items():
@@ -243,6 +333,12 @@ def main():
         src = replace_body(src, LOCAL_MAP_SIG, LOCAL_MAP_BODY)
         src = patch_last_frame(src)
         src = patch_fuse(src)
+        src = replace_body(src, BOW_KF_FRAME_SIG, BOW_KF_FRAME_BODY)
+        src = replace_body(src, BOW_KF_KF_SIG, BOW_KF_KF_BODY)
+        src = patch_triangulation(src)
+        k = src.index("namespace ORB_SLAM2")
+        k = src.index("{", k) + 1
+        src = src[:k] + BOW_HELPERS + src[k:]
         src = patch_projection_member(src, KF_SIM3_SIG, "int nmatches=0;", "const vector<size_t> vIndices = pKF->GetFeaturesInArea(u,v,radius);", "if(bestDist<=TH_LOW)",
                                       KF_SIM3_QUERY, KF_SIM3_SEARCH, None)
         src = patch_projection_member(src, RELOC_SIG, "int nmatches = 0;", "const vector<size_t> vIndices2 = CurrentFrame.GetFeaturesInArea(u, v, radius, nPredictedLevel-1, nPredictedLevel+1);",

@@ -200,7 +200,7 @@ def search_by_bow(mode, f1, has1, bad1, fv1, f2, has2, bad2, fv2, nnratio=0.7, c
     a1 = [np.ascontiguousarray(fv1[0], np.uint32), np.ascontiguousarray(fv1[1], np.int32), np.ascontiguousarray(fv1[2], np.uint32)]
     a2 = [np.ascontiguousarray(fv2[0], np.uint32), np.ascontiguousarray(fv2[1], np.int32), np.ascontiguousarray(fv2[2], np.uint32)]
     m12 = np.full(f1.N, -1, np.int32)
-    n = lib().orbslam_ref_search_by_bow(mode, f1.h, _p(has1), _p(bad1), _p(a1[0]), _p(a1[1]), _p(a1[2]), len(a1[0]),
+    n = f1.L.orbslam_ref_search_by_bow(mode, f1.h, _p(has1), _p(bad1), _p(a1[0]), _p(a1[1]), _p(a1[2]), len(a1[0]),
                                         f2.h, _p(has2), _p(bad2), _p(a2[0]), _p(a2[1]), _p(a2[2]), len(a2[0]), nnratio, int(check_ori), _p(m12))
     return n, m12
 
@@ -212,7 +212,7 @@ def search_for_triangulation(f1, has1, fv1, f2, has2, fv2, F12, t2w, only_stereo
     a2 = [np.ascontiguousarray(fv2[0], np.uint32), np.ascontiguousarray(fv2[1], np.int32), np.ascontiguousarray(fv2[2], np.uint32)]
     F = np.ascontiguousarray(F12, np.float32).reshape(9); t = np.ascontiguousarray(t2w, np.float32)
     m12 = np.full(f1.N, -1, np.int32)
-    n = lib().orbslam_ref_search_for_triangulation(f1.h, _p(has1), _p(a1[0]), _p(a1[1]), _p(a1[2]), len(a1[0]), f2.h, _p(has2), _p(a2[0]), _p(a2[1]), _p(a2[2]), len(a2[0]),
+    n = f1.L.orbslam_ref_search_for_triangulation(f1.h, _p(has1), _p(a1[0]), _p(a1[1]), _p(a1[2]), len(a1[0]), f2.h, _p(has2), _p(a2[0]), _p(a2[1]), _p(a2[2]), len(a2[0]),
                                                    _p(F), _p(t), int(only_stereo), int(check_ori), _p(m12))
     return n, m12
 

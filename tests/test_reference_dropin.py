@@ -132,10 +132,11 @@ def test_projection_matchers_through_the_binding(builds, request):
     S.RefFrame._geometry = None
 
 
-def test_loop_closing_relocalisation_and_fuse_through_the_binding(builds, request):
+def test_back_end_matchers_through_the_binding(builds, request):
     """The other two SearchByProjection overloads (loop closing: KeyFrame + Sim3, ORBmatcher.cc:290-403; relocalisation: Frame + KeyFrame,
     :1472-1599) with their search loops sent through orbhip_search_by_projection_bounds, and ORBmatcher::Fuse(pKF, vpMapPoints, th) (:825-972)
-    around orbhip_search_best_in_window_bounds, in the "all-steps" build."""
+    around orbhip_search_best_in_window_bounds, both SearchByBoW overloads (:159-288, :522-655) through orbhip_search_by_bow and
+    SearchForTriangulation (:657-823) through orbhip_search_for_triangulation, in the "all-steps" build."""
     if "all-steps" not in request.node.name:
         pytest.skip("the steps 1-3 build keeps the reference's own search loops")
     import os, sys
@@ -171,6 +172,25 @@ def test_loop_closing_relocalisation_and_fuse_through_the_binding(builds, reques
         n_r, b_r = S.fuse(R[1], *a, th=th)
         n_f, b_f = S.fuse(F[1], *a, th=th)
         assert n_r == n_f and np.array_equal(b_r, b_f) and n_r > 50
+    # SearchByBoW, both overloads: the FeatureVector maps flattened, one orbhip_search_by_bow call, the reference's point vectors written back
+    import os
+    from oracle import orb_oracle as O
+    ov = O.OracleVocabulary(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "voc_k6_L3_ref.txt"))
+    for mode, levelsup, ratio, ori in ((0, 2, 0.7, True), (1, 3, 0.9, True), (0, 4, 0.75, False)):
+        fv1, fv2 = ov.transform(R[0].desc, levelsup)[2:], ov.transform(R[1].desc, levelsup)[2:]
+        has1 = (rng.random(R[0].N) < 0.75).astype(np.uint8); bad1 = (rng.random(R[0].N) < 0.07).astype(np.uint8)
+        has2 = (rng.random(R[1].N) < 0.85).astype(np.uint8); bad2 = (rng.random(R[1].N) < 0.07).astype(np.uint8)
+        n_r, m_r = S.search_by_bow(mode, R[0], has1, bad1, fv1, R[1], has2, bad2, fv2, nnratio=ratio, check_ori=ori)
+        n_f, m_f = S.search_by_bow(mode, F[0], has1, bad1, fv1, F[1], has2, bad2, fv2, nnratio=ratio, check_ori=ori)
+        assert n_r == n_f and np.array_equal(m_r, m_f) and n_r > 30
+    # SearchForTriangulation: the reference's epipole code stays, the search fills its vMatches12 through orbhip_search_for_triangulation
+    Fm = np.array([[0, -1e-3, 1.0 / 300], [1e-3, 0, -3.0 / 300], [-1.0 / 300, 3.0 / 300, 0]], np.float32) + rng.normal(0, 1e-5, (3, 3)).astype(np.float32)
+    for levelsup, only, ori, t2w in ((2, False, True, (0.3, 0.1, 1.0)), (1, False, False, (2.0, 1.0, 4.0))):
+        fv1, fv2 = ov.transform(R[0].desc, levelsup)[2:], ov.transform(R[1].desc, levelsup)[2:]
+        has1 = (rng.random(R[0].N) < 0.3).astype(np.uint8); has2 = (rng.random(R[1].N) < 0.3).astype(np.uint8)
+        n_r, m_r = S.search_for_triangulation(R[0], has1, fv1, R[1], has2, fv2, Fm, np.array(t2w, np.float32), only_stereo=only, check_ori=ori)
+        n_f, m_f = S.search_for_triangulation(F[0], has1, fv1, F[1], has2, fv2, Fm, np.array(t2w, np.float32), only_stereo=only, check_ori=ori)
+        assert n_r == n_f and np.array_equal(m_r, m_f) and n_r > 30
     kw = dict(nfeatures=n, fx=64.0, fy=64.0, cx=0.0, cy=0.0, bf=40.0)                  # stereo key frame: the chi-square gate's stereo branch
     S.RefFrame._geometry = None
     S.RefFrame._geometry_other.clear()
