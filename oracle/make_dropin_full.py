@@ -323,6 +323,95 @@ def patch_triangulation(src):
     return src[:f0] + fn + src[f1:]
 
 
+# SearchBySim3 (LoopClosing::ComputeSim3): both directions' window searches are independent per point -> two flat query lists collected by
+# the reference's own projection code, two calls in front of its mutual-consistency pass.
+SIM3_SIG = r"int\s+ORBmatcher::SearchBySim3\s*\("
+SIM3_DECLS = """
+    std::vector<orbhip_best_query> orbhip_bq1, orbhip_bq2; std::vector<unsigned char> orbhip_qd1, orbhip_qd2; std::vector<int> orbhip_i1, orbhip_i2;
+"""
+SIM3_QUERY = """orbhip_best_query e = { u, v, radius, 0.f, nPredictedLevel };
+        const cv::Mat dMP = pMP->GetDescriptor();
+        orbhip_bq%(p)d.push_back(e); orbhip_qd%(p)d.insert(orbhip_qd%(p)d.end(), dMP.ptr<unsigned char>(), dMP.ptr<unsigned char>()+32); orbhip_i%(p)d.push_back(i%(p)d);
+"""
+SIM3_SEARCH = """{
+        KeyFrame* orbhip_kf[2] = {pKF2, pKF1};
+        std::vector<orbhip_best_query>* orbhip_bq[2] = {&orbhip_bq1, &orbhip_bq2}; std::vector<unsigned char>* orbhip_qd[2] = {&orbhip_qd1, &orbhip_qd2};
+        std::vector<int>* orbhip_ix[2] = {&orbhip_i1, &orbhip_i2}; std::vector<int>* orbhip_out[2] = {&vnMatch1, &vnMatch2};
+        for(int p=0;p<2;p++)
+        {
+            KeyFrame* kf = orbhip_kf[p];
+            const int nq = (int)orbhip_bq[p]->size();
+            if(nq==0 || kf->N==0) continue;
+            std::vector<int> bi(nq), bd(nq);
+            const orbhip_bounds bounds = {(float)kf->mnMinX, (float)kf->mnMinY, (float)kf->mnMaxX, (float)kf->mnMaxY};
+            if(orbhip_search_best_in_window_bounds(0, (const orbhip_keypoint*)&kf->mvKeysUn[0], kf->mDescriptors.ptr<unsigned char>(), NULL, kf->N, &bounds, NULL, 0,
+                                                   &(*orbhip_bq[p])[0], &(*orbhip_qd[p])[0], nq, 0, &bi[0], &bd[0])!=ORBHIP_OK) abort();
+            for(int k=0;k<nq;k++) if(bd[k]<=TH_HIGH) (*orbhip_out[p])[(*orbhip_ix[p])[k]] = bi[k];
+        }
+    }
+
+    """
+
+
+def patch_sim3(src):
+    m = re.search(SIM3_SIG, src)
+    if not m:
+        raise SystemExit("SearchBySim3 not found")
+    f0, f1 = m.start(), block_end(src, m.end())
+    fn = src[f0:f1]
+    k = fn.index("vector<int> vnMatch2(N2,-1);") + len("vector<int> vnMatch2(N2,-1);")
+    fn = fn[:k] + SIM3_DECLS + fn[k:]
+    for p, kf in ((1, "pKF2"), (2, "pKF1")):
+        a = fn.index("const vector<size_t> vIndices = %s->GetFeaturesInArea(u,v,radius);" % kf)
+        b = block_end(fn, fn.index("if(bestDist<=TH_HIGH)", a))
+        fn = fn[:a] + (SIM3_QUERY % {"p": p}) + fn[b:]
+    a = fn.index("int nFound = 0;")
+    fn = fn[:a] + SIM3_SEARCH + fn[a:]
+    return src[:f0] + fn + src[f1:]
+
+
+# Fuse, Sim3 overload (LoopClosing::SearchAndFuse): like Fuse above without the chi-square gate; its surgery block uses iMP (vpReplacePoint)
+FUSE_SIM3_SIG = r"int\s+ORBmatcher::Fuse\s*\(\s*KeyFrame\s*\*\s*pKF\s*,\s*cv::Mat\s+Scw\s*,"
+FUSE_SIM3_QUERY = """orbhip_best_query e = { u, v, radius, 0.f, nPredictedLevel };
+        const cv::Mat dMP = pMP->GetDescriptor();
+        orbhip_bq.push_back(e); orbhip_qd.insert(orbhip_qd.end(), dMP.ptr<unsigned char>(), dMP.ptr<unsigned char>()+32); orbhip_owner.push_back(pMP); orbhip_index.push_back(iMP);
+"""
+FUSE_SIM3_SEARCH = """std::vector<int> orbhip_bi(orbhip_bq.size(), -1), orbhip_bd(orbhip_bq.size(), 256);
+    if(!orbhip_bq.empty() && pKF->N>0)
+    {
+        const orbhip_bounds bounds = {(float)pKF->mnMinX, (float)pKF->mnMinY, (float)pKF->mnMaxX, (float)pKF->mnMaxY};
+        if(orbhip_search_best_in_window_bounds(0, (const orbhip_keypoint*)&pKF->mvKeysUn[0], pKF->mDescriptors.ptr<unsigned char>(), NULL, pKF->N, &bounds, NULL, 0,
+                                               &orbhip_bq[0], &orbhip_qd[0], (int)orbhip_bq.size(), 0, &orbhip_bi[0], &orbhip_bd[0])!=ORBHIP_OK) abort();
+    }
+    for(size_t orbhip_k=0; orbhip_k<orbhip_owner.size(); orbhip_k++)
+    {
+        MapPoint* pMP = orbhip_owner[orbhip_k];
+        const int iMP = orbhip_index[orbhip_k];
+        const int bestDist = orbhip_bd[orbhip_k], bestIdx = orbhip_bi[orbhip_k];
+        %s
+    }
+
+    """
+
+
+def patch_fuse_sim3(src):
+    m = re.search(FUSE_SIM3_SIG, src)
+    if not m:
+        raise SystemExit("Fuse(pKF, Scw, ...) not found")
+    f0, f1 = m.start(), block_end(src, m.end())
+    fn = src[f0:f1]
+    k = fn.index("int nFused=0;") + len("int nFused=0;")
+    fn = fn[:k] + FUSE_DECLS + "    std::vector<int> orbhip_index;\n" + fn[k:]
+    a = fn.index("const vector<size_t> vIndices = pKF->GetFeaturesInArea(u,v,radius);")
+    s0 = fn.index("if(bestDist<=TH_LOW)", a)
+    s1 = block_end(fn, s0)
+    surgery = fn[s0:s1]
+    fn = fn[:a] + FUSE_SIM3_QUERY + fn[s1:]
+    r = fn.rindex("return nFused;")
+    fn = fn[:r] + (FUSE_SIM3_SEARCH % surgery) + fn[r:]
+    return src[:f0] + fn + src[f1:]
+
+
 def main():
     src = open(sys.argv[1]).read()
     for sig, body in FORWARDS.items():
@@ -336,6 +425,8 @@ def main():
         src = replace_body(src, BOW_KF_FRAME_SIG, BOW_KF_FRAME_BODY)
         src = replace_body(src, BOW_KF_KF_SIG, BOW_KF_KF_BODY)
         src = patch_triangulation(src)
+        src = patch_sim3(src)
+        src = patch_fuse_sim3(src)
         k = src.index("namespace ORB_SLAM2")
         k = src.index("{", k) + 1
         src = src[:k] + BOW_HELPERS + src[k:]

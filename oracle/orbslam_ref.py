@@ -94,6 +94,7 @@ def _bind(L):
         L.orbslam_ref_search_by_bow.argtypes = [i, vp, vp, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, vp, i, f, i, vp]
         L.orbslam_ref_search_for_triangulation.argtypes = [vp, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, i, vp, vp, i, i, vp]
         L.orbslam_ref_fuse.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, vp, vp, f, vp]
+        L.orbslam_ref_fuse_sim3.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, vp, f, vp]
         L.orbslam_ref_search_by_projection_kf.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, vp, i, vp]
         L.orbslam_ref_search_by_projection_reloc.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f, i, f, i, vp]
         L.orbslam_ref_search_by_sim3.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f, vp]
@@ -235,6 +236,15 @@ def fuse(frame, kf_state, X, Y, Z, level, nobs, bad, desc, th=3.0):
     return n, best
 
 
+def fuse_sim3(frame, kf_state, X, Y, Z, level, bad, desc, th=4.0):
+    """ORBmatcher::Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) with Scw = identity -> (nFused, key point per candidate point)"""
+    nq = len(X)
+    best = np.full(nq, -1, np.int32)
+    a = [_f32(X), _f32(Y), _f32(Z), np.ascontiguousarray(level, np.int32), _u8(bad, nq), np.ascontiguousarray(desc, np.uint8)]
+    n = frame.L.orbslam_ref_fuse_sim3(frame.h, _p(_u8(kf_state, frame.N)), nq, *[_p(v) for v in a], th, _p(best))
+    return n, best
+
+
 def search_by_projection_kf(frame, matched_state, X, Y, Z, level, bad, desc, th=10):
     nq = len(X)
     fq = np.full(frame.N, -1, np.int32)
@@ -256,5 +266,5 @@ def search_by_sim3(f1, has1, X1, Y1, Z1, level1, desc1, f2, has2, X2, Y2, Z2, le
     al = np.full(f1.N, -1, np.int32) if already12 is None else np.ascontiguousarray(already12, np.int32)
     a1 = [_u8(has1, f1.N), _f32(X1), _f32(Y1), _f32(Z1), np.ascontiguousarray(level1, np.int32), np.ascontiguousarray(desc1, np.uint8)]
     a2 = [_u8(has2, f2.N), _f32(X2), _f32(Y2), _f32(Z2), np.ascontiguousarray(level2, np.int32), np.ascontiguousarray(desc2, np.uint8)]
-    n = lib().orbslam_ref_search_by_sim3(f1.h, *[_p(v) for v in a1], f2.h, *[_p(v) for v in a2], _p(al), th, _p(m12))
+    n = f1.L.orbslam_ref_search_by_sim3(f1.h, *[_p(v) for v in a1], f2.h, *[_p(v) for v in a2], _p(al), th, _p(m12))
     return n, m12

@@ -122,7 +122,7 @@ KeyFrame::KeyFrame(Frame& F, Map* pMap, KeyFrameDatabase* pKFDB)
     mnId = nNextId++;
     g_kf_frame[this] = &F;
 }
-std::set<MapPoint*> KeyFrame::GetMapPoints() { not_built("KeyFrame::GetMapPoints"); return std::set<MapPoint*>(); }
+std::set<MapPoint*> KeyFrame::GetMapPoints() { std::set<MapPoint*> s; for (size_t i = 0; i < mvpMapPoints.size(); i++) if (mvpMapPoints[i] && !mvpMapPoints[i]->isBad()) s.insert(mvpMapPoints[i]); return s; }   // KeyFrame.cc:230-243
 cv::Mat KeyFrame::GetRotation() { return Tcw.rowRange(0, 3).colRange(0, 3).clone(); }
 cv::Mat KeyFrame::GetTranslation() { return Tcw.rowRange(0, 3).col(3).clone(); }
 bool KeyFrame::IsInImage(const float& x, const float& y) const { return (x >= mnMinX && x < mnMaxX && y >= mnMinY && y < mnMaxY); }     // KeyFrame.cc:610-613
@@ -420,6 +420,26 @@ int orbslam_ref_fuse(void* fp, const uint8_t* kf_state, int nq, const float* X, 
         if (qIndex.count(a) && kfIndex.count(b)) best_idx[qIndex[a]] = kfIndex[b];
         if (qIndex.count(b) && kfIndex.count(a)) best_idx[qIndex[b]] = kfIndex[a];
     }
+    delete kf;
+    return n;
+}
+// ORBmatcher::Fuse(pKF, Scw = identity, vpPoints, th, vpReplacePoint)  (ORBmatcher.cc:974-1100): loop closing's fusion, no chi-square gate;
+// best_idx[q] = the key point the point was attached to, or the key point whose map point it should replace
+int orbslam_ref_fuse_sim3(void* fp, const uint8_t* kf_state, int nq, const float* X, const float* Y, const float* Z, const int* level, const uint8_t* bad,
+                          const uint8_t* desc, float th, int* best_idx)
+{
+    Frame& F = *(Frame*)fp;
+    std::map<MapPoint*, int> kfIndex;
+    for (int i = 0; i < F.N; i++) {
+        F.mvpMapPoints[i] = NULL;
+        if (kf_state && kf_state[i]) { MapPoint* p = make_point(0, 0, 1, NULL, 2, kf_state[i] == 2); F.mvpMapPoints[i] = p; kfIndex[p] = i; }
+    }
+    KeyFrame* kf = identity_keyframe(F);
+    std::vector<MapPoint*> pts(nq), repl(nq, static_cast<MapPoint*>(NULL));
+    for (int q = 0; q < nq; q++) pts[q] = make_query_point(X[q], Y[q], Z[q], desc + (size_t)q * 32, level[q], 1, bad[q] != 0);
+    ORBmatcher matcher(0.8f, true);
+    const int n = matcher.Fuse(kf, cv::Mat::eye(4, 4, CV_32F), pts, th, repl);
+    for (int q = 0; q < nq; q++) best_idx[q] = repl[q] ? kfIndex[repl[q]] : (pts[q]->mnBALocalForKF ? (int)pts[q]->mnBALocalForKF - 1 : -1);
     delete kf;
     return n;
 }

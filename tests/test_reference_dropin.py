@@ -136,7 +136,8 @@ def test_back_end_matchers_through_the_binding(builds, request):
     """The other two SearchByProjection overloads (loop closing: KeyFrame + Sim3, ORBmatcher.cc:290-403; relocalisation: Frame + KeyFrame,
     :1472-1599) with their search loops sent through orbhip_search_by_projection_bounds, and ORBmatcher::Fuse(pKF, vpMapPoints, th) (:825-972)
     around orbhip_search_best_in_window_bounds, both SearchByBoW overloads (:159-288, :522-655) through orbhip_search_by_bow and
-    SearchForTriangulation (:657-823) through orbhip_search_for_triangulation, in the "all-steps" build."""
+    SearchForTriangulation (:657-823) through orbhip_search_for_triangulation, SearchBySim3 (:1102-1326) through two
+    orbhip_search_best_in_window_bounds calls, in the "all-steps" build."""
     if "all-steps" not in request.node.name:
         pytest.skip("the steps 1-3 build keeps the reference's own search loops")
     import os, sys
@@ -191,6 +192,20 @@ def test_back_end_matchers_through_the_binding(builds, request):
         n_r, m_r = S.search_for_triangulation(R[0], has1, fv1, R[1], has2, fv2, Fm, np.array(t2w, np.float32), only_stereo=only, check_ori=ori)
         n_f, m_f = S.search_for_triangulation(F[0], has1, fv1, F[1], has2, fv2, Fm, np.array(t2w, np.float32), only_stereo=only, check_ori=ori)
         assert n_r == n_f and np.array_equal(m_r, m_f) and n_r > 30
+    # Fuse, Sim3 overload (loop closing): same two-pass shape, no chi-square gate, vpReplacePoint filled by the moved surgery block
+    st = rng.choice([0, 0, 1], len(kc)).astype(np.uint8)
+    n_r, b_r = S.fuse_sim3(R[1], st, X, Y, np.ones(nq, np.float32), level, bad, dl, th=4.0)
+    n_f, b_f = S.fuse_sim3(F[1], st, X, Y, np.ones(nq, np.float32), level, bad, dl, th=4.0)
+    assert n_r == n_f and np.array_equal(b_r, b_f) and n_r > 50
+    # SearchBySim3: both directions collected by the reference's projection code, searched by two calls in front of its mutual check
+    X2 = (kc["x"] + 3.0 + rng.normal(0, 1.2, len(kc))).astype(np.float32); Y2 = (kc["y"] + 1.0 + rng.normal(0, 1.2, len(kc))).astype(np.float32)
+    lev2 = np.clip(kc["octave"] + rng.integers(0, 2, len(kc)), 0, 7).astype(np.int32)
+    hs1 = (rng.random(nq) < 0.8).astype(np.uint8); hs2 = (rng.random(len(kc)) < 0.8).astype(np.uint8)
+    a = (hs1, X, Y, np.ones(nq, np.float32), level, dl)
+    b = (hs2, X2, Y2, np.ones(len(kc), np.float32), lev2, R[1].desc)
+    n_r, m_r = S.search_by_sim3(R[0], *a, R[1], *b, th=7.5)
+    n_f, m_f = S.search_by_sim3(F[0], *a, F[1], *b, th=7.5)
+    assert n_r == n_f and np.array_equal(m_r, m_f) and n_r > 100
     kw = dict(nfeatures=n, fx=64.0, fy=64.0, cx=0.0, cy=0.0, bf=40.0)                  # stereo key frame: the chi-square gate's stereo branch
     S.RefFrame._geometry = None
     S.RefFrame._geometry_other.clear()

@@ -249,6 +249,29 @@ def test_fuse(ref, oracle, pair, th, stereo):
         kf.close()
 
 
+@pytest.mark.parametrize("th", [4.0, 8.0])
+def test_fuse_sim3(ref, oracle, pair, th):
+    """ORBmatcher::Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (ORBmatcher.cc:974-1100, loop closing) with Scw = identity: the key point each
+    candidate point is attached to (or whose map point it should replace) = the oracle's best-in-window search without the chi-square gate."""
+    w, h, n, seq, sf, K, F = pair
+    (kl, dl), (kc, dc) = K
+    par = oracle.OracleExtractor(n, 1.2, 8, 20, 7).params()
+    rng = np.random.default_rng(int(th) + 40)
+    X, Y, level = _world(rng, kl, w, h)
+    nq = len(kl)
+    bad = (rng.random(nq) < 0.05).astype(np.uint8)
+    state = rng.choice([0, 0, 1], len(kc)).astype(np.uint8)
+    n_r, b_r = ref.fuse_sim3(F[1], state, X, Y, np.ones(nq, np.float32), level, bad, dl, th=th)
+    keep = np.nonzero((bad == 0) & (X >= 0) & (X < w) & (Y >= 0) & (Y < h))[0]
+    q = np.zeros(len(keep), oracle.BEST_QUERY_DTYPE)
+    q["x"], q["y"], q["radius"], q["level"] = X[keep], Y[keep], (np.float32(th) * sf[level[keep]]).astype(np.float32), level[keep]
+    bi, bd = oracle.search_best_in_window(kc, dc, w, h, par["inv_sigma2"], q, dl[keep], False)
+    b_o = np.full(nq, -1, np.int32)
+    ok = bd <= 50
+    b_o[keep[ok]] = bi[ok]
+    assert n_r == int(ok.sum()) and np.array_equal(b_r, b_o) and n_r > 50
+
+
 def test_search_by_projection_keyframe_sim3(ref, oracle, pair):
     """ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (ORBmatcher.cc:290-403, loop closing) = the flat mode-1 search
     with levels [L-1, L], TH_LOW, no orientation check, vpMatched as the blocked set."""
