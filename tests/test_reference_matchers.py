@@ -419,3 +419,68 @@ def test_product_equals_reference_matcher_and_stereo(ref, pair, emu_lib):
     u, d = xl.ComputeStereoMatches(xr, float(BF), float(BF / FX), nimg=1)
     assert u[0, :Fs.N].tobytes() == Fs.u_right.tobytes() and d[0, :Fs.N].tobytes() == Fs.depth.tobytes()
     xl.close(); xr.close(); Fs.close()
+
+
+def test_keyframe_side_searches_with_a_distorted_camera(ref, oracle, pair_oracle, emu_lib):
+    """a KeyFrame keeps the image bounds as ints (truncated from the Frame's floats, KeyFrame.h:185-188) but the Frame's grid, so
+    with a distorted camera KeyFrame::GetFeaturesInArea lays a window's cell range out from truncated minima.  That cannot change which key
+    points a window returns (cells are assigned by rounding: half a cell of margin against < 1 px of truncation) — checked here: Fuse (both
+    overloads) and the loop-closing SearchByProjection through real KeyFrame objects of a TUM1-distorted frame equal the oracle and the HIP
+    sources (emulation build) run with the Frame's float bounds."""
+    w, h, n, seq, sf, K = pair_oracle
+    cam = (np.float32(517.306408 * w / 640), np.float32(516.469215 * h / 480), np.float32(318.643040 * w / 640), np.float32(255.313989 * h / 480))
+    dist = (0.262383, -0.953104, -0.005358, 0.002628, 1.163314)
+    ref.RefFrame._geometry = None
+    F = ref.RefFrame(seq[1], nfeatures=n, fx=float(cam[0]), fy=float(cam[1]), cx=float(cam[2]), cy=float(cam[3]), dist=dist)
+    b = ref.RefFrame.bounds()
+    assert b[0] != np.floor(b[0]) and b[1] != np.floor(b[1])                      # truncation changes the minima
+    kun, dc = F.keys_un, F.desc
+    par = oracle.OracleExtractor(n, 1.2, 8, 20, 7).params()
+    rng = np.random.default_rng(77)
+    nq = 3000
+    src = rng.integers(0, len(kun), nq)
+    ut = (kun["x"][src] + rng.normal(0, 6, nq)).astype(np.float32); vt = (kun["y"][src] + rng.normal(0, 6, nq)).astype(np.float32)
+    X = ((ut - cam[2]) / cam[0]).astype(np.float32); Y = ((vt - cam[3]) / cam[1]).astype(np.float32)
+    u = (cam[0] * X + cam[2]).astype(np.float32); v = (cam[1] * Y + cam[3]).astype(np.float32)         # what the reference's projection computes (z = 1)
+    level = kun["octave"][src].astype(np.int32)
+    qd = dc[src].copy()
+    for i in range(nq):
+        for bit in rng.integers(0, 256, int(rng.integers(0, 30))):
+            qd[i, bit >> 3] ^= 1 << (bit & 7)
+    bad = np.zeros(nq, np.uint8)
+    ib = b.astype(np.int32)                                                        # KeyFrame::IsInImage compares with the int bounds (KeyFrame.cc:610-613)
+    keep = np.nonzero((u >= ib[0]) & (u < ib[2]) & (v >= ib[1]) & (v < ib[3]))[0]
+    kb = tuple(b)
+    for th in (3.0, 6.0):
+        q = np.zeros(len(keep), oracle.BEST_QUERY_DTYPE)
+        q["x"], q["y"], q["radius"], q["ur"], q["level"] = u[keep], v[keep], (np.float32(th) * sf[level[keep]]).astype(np.float32), u[keep] - np.float32(40.0), level[keep]
+        # Fuse (pose overload, chi-square gate)
+        state = rng.choice([0, 0, 1], len(kun)).astype(np.uint8)
+        n_r, b_r = ref.fuse(F, state, X, Y, np.ones(nq, np.float32), level, np.ones(nq, np.int32), bad, qd, th=th)
+        with oracle.image_bounds_set(b):
+            bi, bd = oracle.search_best_in_window(kun, dc, w, h, par["inv_sigma2"], q, qd[keep], True, u_right=F.u_right)
+        b_o = np.full(nq, -1, np.int32); ok = bd <= 50; b_o[keep[ok]] = bi[ok]
+        assert n_r == int(ok.sum()) and np.array_equal(b_r, b_o) and n_r > 200
+        bi_g, bd_g = orb_slam2_amd.search_best_in_window(kun, dc, w, h, par["inv_sigma2"], q, qd[keep], True, u_right=F.u_right, bounds=kb, library=emu_lib)
+        assert np.array_equal(bi_g, bi) and np.array_equal(bd_g, bd)
+        # Fuse (Sim3 overload, no gate)
+        n_r, b_r = ref.fuse_sim3(F, state, X, Y, np.ones(nq, np.float32), level, bad, qd, th=th)
+        with oracle.image_bounds_set(b):
+            bi, bd = oracle.search_best_in_window(kun, dc, w, h, par["inv_sigma2"], q, qd[keep], False)
+        b_o = np.full(nq, -1, np.int32); ok = bd <= 50; b_o[keep[ok]] = bi[ok]
+        assert n_r == int(ok.sum()) and np.array_equal(b_r, b_o)
+        bi_g, bd_g = orb_slam2_amd.search_best_in_window(kun, dc, w, h, par["inv_sigma2"], q, qd[keep], False, bounds=kb, library=emu_lib)
+        assert np.array_equal(bi_g, bi) and np.array_equal(bd_g, bd)
+    # loop-closing SearchByProjection(pKF, Scw, ...): the cell-walking kernel
+    ms = (rng.random(len(kun)) < 0.2).astype(np.uint8)
+    n_r, fq_r = ref.search_by_projection_kf(F, ms, X, Y, np.ones(nq, np.float32), level, bad, qd, th=10)
+    pq = np.zeros(len(keep), oracle.PROJ_QUERY_DTYPE)
+    pq["x"], pq["y"], pq["radius"] = u[keep], v[keep], (np.float32(10) * sf[level[keep]]).astype(np.float32)
+    pq["min_level"], pq["max_level"], pq["blocks"] = level[keep] - 1, level[keep], 1
+    with oracle.image_bounds_set(b):
+        n_o, fq_o = oracle.search_by_projection(kun, dc, w, h, pq, qd[keep], 1, nnratio=0.75, th_high=50, check_ori=False, blocked=ms)
+    assert n_r == n_o and np.array_equal(fq_r, np.where(fq_o >= 0, keep[np.maximum(fq_o, 0)], -1)) and n_o > 100
+    n_g, fq_g = orb_slam2_amd.search_by_projection(kun, dc, w, h, pq, qd[keep], 1, nnratio=0.75, th_high=50, check_ori=False, blocked=ms, bounds=kb, library=emu_lib)
+    assert n_g == n_o and np.array_equal(fq_g, fq_o)
+    F.close()
+    ref.RefFrame._geometry = None
