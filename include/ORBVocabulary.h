@@ -27,6 +27,17 @@
 #if defined(ORBHIP_USE_DBOW2_TYPES)
 #include "Thirdparty/DBoW2/DBoW2/BowVector.h"
 #include "Thirdparty/DBoW2/DBoW2/FeatureVector.h"
+// Inside the reference tree this header replaces one that includes Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h, and the reference's own
+// headers (Frame.h, KeyFrame.h, Map.h, KeyFrameDatabase.h ...) silently depend on what that file drags in: a handful of standard headers
+// and the using-directive at TemplatedVocabulary.h:36.  Reproduced here so that they compile unchanged.
+#include <algorithm>
+#include <cassert>
+#include <fstream>
+#include <limits>
+#include <list>
+#include <numeric>
+#include <set>
+using namespace std;
 #else
 namespace DBoW2 {
 typedef unsigned int WordId;

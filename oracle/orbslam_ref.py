@@ -80,6 +80,7 @@ def _bind(L):
         L.orbslam_ref_frame_mono_dist.argtypes = [vp, i, i, i, i, f, i, i, i, f, f, f, f, vp, i, f, f, i]
         L.orbslam_ref_frame_rgbd.restype = vp
         L.orbslam_ref_frame_rgbd.argtypes = [vp, vp, i, i, i, i, f, i, i, i, f, f, f, f, vp, i, f, f, i]
+        L.orbslam_ref_frame_compute_bow.argtypes = [vp, C.c_char_p, vp, vp, vp, vp, vp, vp, vp]
         L.orbslam_ref_frame_bounds.argtypes = [vp]
         L.orbslam_ref_frame_stereo.restype = vp
         L.orbslam_ref_frame_stereo.argtypes = [vp, vp, i, i, i, i, f, i, i, i, f, f, f, f, f, f, i]
@@ -148,6 +149,15 @@ class RefFrame:
         out = np.zeros(4, np.float32)
         (lib() if library is None else library).orbslam_ref_frame_bounds(_p(out))
         return out
+
+    def compute_bow(self, voc_path):
+        """Frame::ComputeBoW with the vocabulary file -> (bow ids, bow values, fv nodes, fv offsets, fv features), map order"""
+        n = max(self.N, 1)
+        bid = np.zeros(n, np.uint32); bval = np.zeros(n, np.float64); nb = C.c_int()
+        fnode = np.zeros(n, np.uint32); foff = np.zeros(n + 1, np.int32); ffeat = np.zeros(n, np.uint32); nf = C.c_int()
+        rc = self.L.orbslam_ref_frame_compute_bow(self.h, str(voc_path).encode(), _p(bid), _p(bval), C.byref(nb), _p(fnode), _p(foff), _p(ffeat), C.byref(nf))
+        assert rc == 0, "vocabulary not loaded"
+        return bid[:nb.value].copy(), bval[:nb.value].copy(), fnode[:nf.value].copy(), foff[:nf.value + 1].copy(), ffeat[:foff[nf.value]].copy()
 
     def close(self):
         if self.h:

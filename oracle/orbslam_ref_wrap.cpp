@@ -16,6 +16,7 @@
 #include <map>
 #include <set>
 #include <new>
+#include <string>
 #include <vector>
 #include "Frame.h"
 #include "KeyFrame.h"
@@ -198,6 +199,28 @@ void* orbslam_ref_frame_rgbd(const uint8_t* img, const float* depth, int w, int 
     for (int i = 0; i < ndist; i++) D.at<float>(i) = dist[i];
     attach_camera(rig(nfeat, scale, nlevels, ini, mn).left, K, D);
     return new Frame(im, dm, 0.0, rig(nfeat, scale, nlevels, ini, mn).left, NULL, K, D, bf, thDepth);
+}
+// Frame::ComputeBoW (Frame.cc:395-402) with a vocabulary read by ORBVocabulary::loadFromTextFile (System.cc:68): mBowVec / mFeatVec flattened
+// in map order.  ORBVocabulary is whatever include/ORBVocabulary.h of the build says: the DBoW2 template (reference) or the drop-in class.
+int orbslam_ref_frame_compute_bow(void* fp, const char* voc_path, uint32_t* bow_id, double* bow_val, int* nbow, uint32_t* fv_node, int* fv_off, uint32_t* fv_feat, int* nfv)
+{
+    static std::map<std::string, ORBVocabulary*> vocs;
+    ORBVocabulary*& voc = vocs[voc_path];
+    if (!voc) { voc = new ORBVocabulary(); if (!voc->loadFromTextFile(voc_path)) { delete voc; voc = NULL; return -1; } }
+    Frame& F = *(Frame*)fp;
+    F.mpORBvocabulary = voc; F.mBowVec.clear(); F.mFeatVec.clear();
+    F.ComputeBoW();
+    int i = 0;
+    for (DBoW2::BowVector::const_iterator it = F.mBowVec.begin(); it != F.mBowVec.end(); ++it, ++i) { bow_id[i] = it->first; bow_val[i] = it->second; }
+    *nbow = i;
+    int j = 0, o = 0; fv_off[0] = 0;
+    for (DBoW2::FeatureVector::const_iterator it = F.mFeatVec.begin(); it != F.mFeatVec.end(); ++it, ++j) {
+        fv_node[j] = it->first;
+        for (size_t k = 0; k < it->second.size(); k++) fv_feat[o++] = it->second[k];
+        fv_off[j + 1] = o;
+    }
+    *nfv = j;
+    return 0;
 }
 void orbslam_ref_frame_bounds(float* out) { out[0] = Frame::mnMinX; out[1] = Frame::mnMinY; out[2] = Frame::mnMaxX; out[3] = Frame::mnMaxY; }
 // Frame::Frame(imLeft, imRight, ...)  (Frame.cc:62-115): two extractor threads, ComputeStereoMatches

@@ -218,3 +218,26 @@ def test_back_end_matchers_through_the_binding(builds, request):
     for f in R + F:
         f.close()
     S.RefFrame._geometry = None
+
+
+def test_compute_bow_through_the_binding(builds, tmp_path):
+    """Frame::ComputeBoW (Frame.cc:395-402) on frames built by the reference's constructor: the reference's DBoW2 vocabulary in the all-reference
+    and the steps 1-3 builds, this repository's ORBVocabulary class (DBoW2's own BowVector / FeatureVector types) in the
+    all-steps build — same maps, and equal to the oracle's transform.  (The reference's loader must not see the file's final newline, H6.)"""
+    import os
+    from oracle import orb_oracle as O
+    S, D = builds
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "voc_k6_L3_ref.txt")
+    voc = tmp_path / "voc_no_final_newline.txt"
+    voc.write_text(open(golden).read().rstrip("\n"))
+    w, h, n = 480, 360, 700
+    img = synth.frame(w, h, seed=17)
+    S.RefFrame._geometry = None
+    S.RefFrame._geometry_other.clear()
+    a, b = S.RefFrame(img, nfeatures=n), S.RefFrame(img, nfeatures=n, library=D)
+    ra, rb = a.compute_bow(voc), b.compute_bow(voc)
+    assert all(x.tobytes() == y.tobytes() for x, y in zip(ra, rb)) and len(ra[0]) > 50
+    want = O.OracleVocabulary(golden).transform(a.desc, 4)
+    assert all(x.tobytes() == y.astype(x.dtype).tobytes() for x, y in zip(ra, want))
+    a.close(); b.close()
+    S.RefFrame._geometry = None
