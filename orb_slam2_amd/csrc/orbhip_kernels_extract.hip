@@ -337,17 +337,15 @@ void orbhip_launch_blur(const ExtractParams& P, const int gk[4], int nframes, hi
 }
 
 // ------------------------------------------------------------------------------------------------ FAST per cell
-// One wavefront per 30-px grid cell (4 cells per workgroup).  The cell's sub-image is staged in LDS, then
-//   A. every examined pixel gets the exact FAST-9/16 segment test at minThFAST as two 16-bit ring masks
-//      (darker / brighter) and a "9 consecutive bits" check; corners are compacted into an LDS list with
-//      ballot/popcount ranks, in row-major order;
-//   B. only the listed corners get the intrinsic score
+// One wavefront per 30-px grid cell (4 cells per workgroup, no workgroup barrier: every LDS region is wave-private).  The cell's
+// sub-image is staged in LDS, then the two cv::FAST calls of the reference (ORBextractor.cc:809-816) are served in turn:
+//   1. iniThFAST: a cheap NECESSARY test on every pixel pair (four opposite ring pairs must clear C +- t) -> ordered list of the pairs
+//      that may hold a corner; the exact intrinsic score
 //        S = max over the 16 nine-pixel arcs of min |centre - ring| margin (dark or bright) - 1     (cornerScore<16>)
-//      which satisfies "corner at threshold t  <=>  S >= t", so ONE pass serves both cv::FAST calls of the
-//      reference (iniThFAST, then minThFAST if the first returned nothing);
-//   C. 3x3 non-max suppression over the list; it sees only scores of the same cell (neighbours outside the examined
-//      interior count as 0, exactly like FAST on the cell sub-image);
-//   D. survivors are emitted in row-major order.
+//      ("corner at threshold t  <=>  S >= t") only for the listed pairs, one lane each; 3x3 non-max suppression over them (it sees only
+//      scores of the same cell: neighbours outside the examined interior count as 0, exactly like FAST on the cell sub-image); survivors
+//      emitted in row-major order;
+//   2. only if that found nothing: the exact score of every examined pixel at minThFAST, corners compacted in row-major order, NMS, emission.
 #define FC_WAVES 4
 #define FC_LD 6                        // patch-load passes a lane keeps in flight
 

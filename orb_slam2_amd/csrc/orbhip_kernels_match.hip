@@ -6,10 +6,11 @@
 //                                    best/second idiom :102-114, :447-456).  Integer-VALU bound (v_xor + v_bcnt), no MFMA.
 //   k_match_grid                     Frame::AssignFeaturesToGrid (Frame.cc:230-245, 382-392): 64x48 buckets, keypoint order
 //   k_match_candidates               Frame::GetFeaturesInArea (Frame.cc:327-380) in canonical order + all Hamming distances,
-//                                    one wavefront per previous-frame keypoint
+//                                    one wavefront per previous-frame keypoint; also records each key point's four best candidates
 //   k_match_select                   the order-dependent part of SearchForInitialization (ORBmatcher.cc:418-517): one
-//                                    wavefront per camera slot replays the i1 loop with wave reductions, rotation histogram,
-//                                    ComputeThreeMaxima (:1601-1642) and the vbPrevMatched update.
+//                                    wavefront per camera slot decides 64 key points per step from those records (a candidate is
+//                                    skipped once matched at a distance <= the query's), rescans the rare key point whose records
+//                                    are used up, then rotation histogram, ComputeThreeMaxima (:1601-1642), vbPrevMatched update.
 #include "orbhip_internal.h"
 
 #define WAVE 64
