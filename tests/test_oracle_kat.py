@@ -87,6 +87,11 @@ def test_resize_fixed_point(oracle):
         vals = {((b0 * (hsum >> 4)) >> 16) + (((2048 - b0) * (hsum >> 4)) >> 16) + 2 >> 2 for b0 in range(0, 2049)}
         assert int(out[5, dx]) in vals
     assert out.shape == (10, 50)
+    # exactly half size in both directions: OpenCV takes its INTER_AREA fast path, the 2x2 box average — identical to this path's result
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 256, (48, 64), dtype=np.uint8)
+    box = ((a[0::2, 0::2].astype(int) + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    assert np.array_equal(oracle.resize(a, 32, 24), box)
 
 
 def test_cvt_gray_fixed_point(oracle):
