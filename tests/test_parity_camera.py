@@ -262,3 +262,47 @@ def test_camera_entry_points_reject_bad_arguments(backend):
     with pytest.raises(orb_slam2_amd.OrbHipError):
         orb_slam2_amd.image_bounds((0.0, 1.0, 0.0, 0.0, 0.1, 0, 0, 0), w, h, library=backend)
     ex.close()
+
+
+def test_camera_paths_random_configurations(emu_lib, oracle):
+    """Random image / raw sizes, pyramid depths, rectification maps (with NaN, huge and border entries) and distortion models on the CPU
+    emulation of the kernels: rectified level 0, key points, descriptors, mvKeysUn, image bounds and the RGB-D columns against the oracle."""
+    for t in range(6):
+        rng = np.random.default_rng(9000 + t)
+        w, h = int(rng.integers(120, 420)), int(rng.integers(100, 330))
+        sw, sh = int(rng.integers(100, 450)), int(rng.integers(90, 350))
+        n, nl = int(rng.integers(60, 400)), int(rng.integers(2, 7))
+        raw = synth.frame(sw, sh, seed=int(rng.integers(1 << 30)))
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+        th, sc = rng.uniform(-0.05, 0.05), rng.uniform(0.8, 1.3)
+        mx = (sw / 2 + (np.cos(th) * (xx - w / 2) - np.sin(th) * (yy - h / 2)) * sc * sw / w + rng.uniform(-5, 5)).astype(np.float32)
+        my = (sh / 2 + (np.sin(th) * (xx - w / 2) + np.cos(th) * (yy - h / 2)) * sc * sh / h + rng.uniform(-5, 5)).astype(np.float32)
+        k = int(rng.integers(0, 40))
+        mx[rng.integers(0, h, k), rng.integers(0, w, k)] = rng.choice([-1.0, -0.5, sw - 1, sw - 0.5, sw, 1e7, -1e7, np.nan, 0.015625], k).astype(np.float32)
+        rect = oracle.remap(raw, mx, my)
+        try:
+            ex = orb_slam2_amd.ORBextractor(n, 1.2, nl, 20, 7, w, h, max_batch=1, library=emu_lib)
+        except orb_slam2_amd.OrbHipError:
+            continue                                                          # a pyramid level outside the supported envelope
+        ex.set_rectification(mx, my, sw, sh)
+        ks, ds = ex.extract_batch_rectify([raw])
+        ko, do = oracle.OracleExtractor(n, 1.2, nl, 20, 7).extract(rect)
+        assert np.array_equal(ex.mvImagePyramid(0), rect) and ks[0].tobytes() == ko.tobytes() and np.array_equal(ds[0], do), f"case {t}"
+        cam = (rng.uniform(200, 600), rng.uniform(200, 600), w / 2 + rng.uniform(-20, 20), h / 2 + rng.uniform(-20, 20),
+               rng.uniform(-0.3, 0.3), rng.uniform(-0.5, 0.5), rng.uniform(-0.01, 0.01), rng.uniform(-0.01, 0.01), rng.uniform(-0.5, 0.5))
+        try:
+            ex.set_camera(cam)
+        except orb_slam2_amd.OrbHipError:
+            ex.close()
+            continue                                                          # a model that folds the image corners
+        ks, ds = ex.extract_batch_rectify([raw])
+        un = ex.fetch_undistorted(1, [len(ks[0])])[0]
+        uo = oracle.undistort_keypoints(cam, ko)
+        assert un.tobytes() == uo.tobytes() and ex.bounds().tobytes() == oracle.image_bounds(cam, w, h).tobytes(), f"case {t}"
+        dep = (rng.random((h, w)) * 3).astype(np.float32)
+        dep[rng.random((h, w)) < 0.2] = 0
+        f = float(rng.choice([1.0, 0.5]))
+        u, z = ex.ComputeStereoFromRGBD([dep], f, 40.0)
+        u_o, z_o = oracle.stereo_from_rgbd(ko, uo, dep, f, 40.0)
+        assert u[0, :len(ko)].tobytes() == u_o.tobytes() and z[0, :len(ko)].tobytes() == z_o.tobytes(), f"case {t}"
+        ex.close()
