@@ -1,0 +1,78 @@
+"""Generates tests/golden/matchers_ref.npz with the REFERENCE's own ORBmatcher members run on real Frame / KeyFrame / MapPoint objects
+(oracle/_ref/liborbslam_ref.so; run from the repo root where /root/reference is mounted: python tests/golden/make_golden_matchers.py).
+
+For a seeded 480x360 frame pair: the flat queries a caller hands to the C ABI (include/orbhip.h) and what the reference's own code returned
+for the same map points —
+  local   ORBmatcher(0.8).SearchByProjection(Frame, vector<MapPoint*>, th = 3)                  ORBmatcher.cc:45-129
+  last    ORBmatcher(0.9, true).SearchByProjection(CurrentFrame, LastFrame, th = 15, bMono)     ORBmatcher.cc:1328-1470
+  fuse    ORBmatcher().Fuse(KeyFrame, vector<MapPoint*>, th = 3)                                ORBmatcher.cc:825-972
+so that machines without the reference (the GPU box) can compare the HIP path with the reference's results directly."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import orb_oracle as O, orbslam_ref as S  # noqa: E402
+from orb_slam2_amd import synth  # noqa: E402
+
+assert S.build(), "oracle/_ref/liborbslam_ref.so needs /root/reference"
+here = os.path.dirname(os.path.abspath(__file__))
+w, h, n = 480, 360, 700
+seq = synth.sequence(w, h, 2, seed=41)
+S.RefFrame._geometry = None
+F = [S.RefFrame(im, nfeatures=n) for im in seq]
+kl, dl, kc = F[0].keys_un, F[0].desc, F[1].keys_un
+par = O.OracleExtractor(n, 1.2, 8, 20, 7).params()
+sf = par["scale_factors"]
+rng = np.random.default_rng(2026)
+nq = len(kl)
+out = dict(width=w, height=h, nfeatures=n, inv_sigma2=par["inv_sigma2"])
+
+# ---- local map points
+px = (kl["x"] - 3.0 + rng.normal(0, 1, nq)).astype(np.float32); py = (kl["y"] - 1.0 + rng.normal(0, 1, nq)).astype(np.float32)
+pxr = (px - rng.uniform(2, 40, nq)).astype(np.float32); level = kl["octave"].astype(np.int32)
+vc = np.where(rng.random(nq) < 0.5, 0.9995, 0.9).astype(np.float32)
+inview = (rng.random(nq) < 0.85).astype(np.uint8); bad = (rng.random(nq) < 0.05).astype(np.uint8); nobs = (rng.random(nq) < 0.9).astype(np.int32)
+state = rng.choice([0, 0, 0, 1, 2], len(kc)).astype(np.uint8)
+n_r, fq_r = S.search_by_projection_points(F[1], px, py, pxr, level, vc, inview, bad, nobs, dl, state, th=3.0, nnratio=0.8)
+keep = np.nonzero((inview == 1) & (bad == 0))[0]
+r = (np.where(vc > np.float32(0.998), np.float32(2.5), np.float32(4.0)).astype(np.float32) * np.float32(3.0)).astype(np.float32)
+q = np.zeros(len(keep), O.PROJ_QUERY_DTYPE)
+q["x"], q["y"], q["radius"], q["ur"] = px[keep], py[keep], (r * sf[level])[keep].astype(np.float32), pxr[keep]
+q["min_level"], q["max_level"], q["blocks"] = level[keep] - 1, level[keep], nobs[keep] > 0
+inv = np.full(nq, -1, np.int32); inv[keep] = np.arange(len(keep))
+out.update(local_queries=q, local_qdesc=dl[keep], local_blocked=(state == 2).astype(np.uint8), local_n=n_r,
+           local_feature_query=np.where(fq_r >= 0, inv[np.maximum(fq_r, 0)], -1).astype(np.int32))
+
+# ---- last frame's points (identity poses, fx = 1: a point at (X, Y, 1) projects to (X, Y))
+has = (rng.random(nq) < 0.85).astype(np.uint8); outl = (rng.random(nq) < 0.1).astype(np.uint8)
+X = (kl["x"] - 3.0 + rng.normal(0, 1.5, nq)).astype(np.float32); Y = (kl["y"] - 1.0 + rng.normal(0, 1.5, nq)).astype(np.float32)
+state = rng.choice([0, 0, 0, 2], len(kc)).astype(np.uint8)            # (no observation-less points: their NULLing by the rotation check would need the -2 code)
+n_r, fq_r = S.search_by_projection_last(F[1], F[0], has, X, Y, np.ones(nq, np.float32), dl, outlier=outl, cur_state=state, th=15.0, mono=True, nnratio=0.9, check_ori=True)
+keep = np.nonzero((has == 1) & (outl == 0) & ~((X < 0) | (X > w) | (Y < 0) | (Y > h)))[0]
+oc = kl["octave"][keep]
+q = np.zeros(len(keep), O.PROJ_QUERY_DTYPE)
+q["x"], q["y"], q["radius"], q["ur"] = X[keep], Y[keep], (np.float32(15.0) * sf[oc]).astype(np.float32), X[keep] - np.float32(40.0)
+q["min_level"], q["max_level"], q["blocks"], q["angle"] = oc - 1, oc + 1, 1, kl["angle"][keep]
+inv = np.full(nq, -1, np.int32); inv[keep] = np.arange(len(keep))
+out.update(last_queries=q, last_qdesc=dl[keep], last_blocked=(state == 2).astype(np.uint8), last_n=n_r,
+           last_feature_query=np.where(fq_r >= 0, inv[np.maximum(fq_r, 0)], -1).astype(np.int32))
+
+# ---- Fuse
+lvl = np.clip(kl["octave"] + rng.integers(0, 2, nq), 0, 7).astype(np.int32)
+nobs = rng.integers(0, 4, nq).astype(np.int32); bad = (rng.random(nq) < 0.05).astype(np.uint8)
+state = rng.choice([0, 0, 1], len(kc)).astype(np.uint8)
+n_r, b_r = S.fuse(F[1], state, X, Y, np.ones(nq, np.float32), lvl, nobs, bad, dl, th=3.0)
+keep = np.nonzero((bad == 0) & (X >= 0) & (X < w) & (Y >= 0) & (Y < h))[0]
+bq = np.zeros(len(keep), O.BEST_QUERY_DTYPE)
+bq["x"], bq["y"], bq["radius"], bq["ur"], bq["level"] = X[keep], Y[keep], (np.float32(3.0) * sf[lvl[keep]]).astype(np.float32), X[keep] - np.float32(40.0), lvl[keep]
+out.update(fuse_queries=bq, fuse_qdesc=dl[keep], fuse_n=n_r, fuse_best=b_r[keep])          # key point each point was fused at / attached to, -1 = none (distance > TH_LOW)
+
+out.update(cur_keys=F[1].keys_un, cur_desc=F[1].desc, image_checksum=np.int64(seq[1].astype(np.uint64).sum()))
+np.savez_compressed(os.path.join(here, "matchers_ref.npz"), **out)
+print("golden matchers:", out["local_n"], "local-map matches,", out["last_n"], "last-frame matches,", out["fuse_n"], "fused points")
+for f in F:
+    f.close()
+S.RefFrame._geometry = None

@@ -1,0 +1,26 @@
+"""The matcher entry points against results FROZEN FROM THE REFERENCE's own ORBmatcher members (tests/golden/matchers_ref.npz, written by
+tests/golden/make_golden_matchers.py through real Frame / KeyFrame / MapPoint objects of the reference).  No oracle, no reference at run
+time: on the GPU box this compares the HIP path with the reference's results directly."""
+import os
+
+import numpy as np
+
+import orb_slam2_amd
+
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "matchers_ref.npz"))
+
+
+def test_projection_matchers_and_fuse_equal_the_reference(backend):
+    w, h = int(G["width"]), int(G["height"])
+    kc, dc = G["cur_keys"], G["cur_desc"]
+    # ORBmatcher(0.8).SearchByProjection(Frame, MapPoints, th = 3)
+    n, fq = orb_slam2_amd.search_by_projection(kc, dc, w, h, G["local_queries"], G["local_qdesc"], 0, nnratio=0.8, th_high=100, blocked=G["local_blocked"], library=backend)
+    assert n == int(G["local_n"]) and np.array_equal(fq, G["local_feature_query"]) and n > 100
+    # ORBmatcher(0.9, true).SearchByProjection(CurrentFrame, LastFrame, th = 15, bMono = true)
+    n, fq = orb_slam2_amd.search_by_projection(kc, dc, w, h, G["last_queries"], G["last_qdesc"], 1, nnratio=0.9, th_high=100, check_ori=True, blocked=G["last_blocked"],
+                                               library=backend)
+    assert n == int(G["last_n"]) and np.array_equal(np.where(fq >= 0, fq, -1), G["last_feature_query"]) and n > 100
+    # ORBmatcher().Fuse(KeyFrame, MapPoints, th = 3): the key point per map point; the caller's threshold is TH_LOW
+    bi, bd = orb_slam2_amd.search_best_in_window(kc, dc, w, h, G["inv_sigma2"], G["fuse_queries"], G["fuse_qdesc"], True, library=backend)
+    best = np.where(bd <= 50, bi, -1)
+    assert np.array_equal(best, G["fuse_best"]) and int((best >= 0).sum()) == int(G["fuse_n"]) > 100
