@@ -6,6 +6,8 @@ for the same map points —
   local   ORBmatcher(0.8).SearchByProjection(Frame, vector<MapPoint*>, th = 3)                  ORBmatcher.cc:45-129
   last    ORBmatcher(0.9, true).SearchByProjection(CurrentFrame, LastFrame, th = 15, bMono)     ORBmatcher.cc:1328-1470
   fuse    ORBmatcher().Fuse(KeyFrame, vector<MapPoint*>, th = 3)                                ORBmatcher.cc:825-972
+  bow0/1  ORBmatcher(0.8, true).SearchByBoW(KeyFrame, Frame, ..) / (KeyFrame, KeyFrame, ..)     ORBmatcher.cc:159-288, 522-655
+  tri     ORBmatcher(0.6, true).SearchForTriangulation(KF1, KF2, F12, .., false)                ORBmatcher.cc:657-823
 so that machines without the reference (the GPU box) can compare the HIP path with the reference's results directly."""
 import os
 import sys
@@ -70,9 +72,29 @@ bq = np.zeros(len(keep), O.BEST_QUERY_DTYPE)
 bq["x"], bq["y"], bq["radius"], bq["ur"], bq["level"] = X[keep], Y[keep], (np.float32(3.0) * sf[lvl[keep]]).astype(np.float32), X[keep] - np.float32(40.0), lvl[keep]
 out.update(fuse_queries=bq, fuse_qdesc=dl[keep], fuse_n=n_r, fuse_best=b_r[keep])          # key point each point was fused at / attached to, -1 = none (distance > TH_LOW)
 
+# ---- SearchByBoW (both overloads) and SearchForTriangulation on the FeatureVectors of the golden vocabulary
+ov = O.OracleVocabulary(os.path.join(here, "voc_k6_L3_ref.txt"))
+fv1, fv2 = ov.transform(F[0].desc, 3)[2:], ov.transform(F[1].desc, 3)[2:]
+has1 = (rng.random(F[0].N) < 0.75).astype(np.uint8); bad1 = (rng.random(F[0].N) < 0.07).astype(np.uint8)
+has2 = (rng.random(F[1].N) < 0.85).astype(np.uint8); bad2 = (rng.random(F[1].N) < 0.07).astype(np.uint8)
+for mode in (0, 1):
+    n_r, m_r = S.search_by_bow(mode, F[0], has1, bad1, fv1, F[1], has2, bad2, fv2, nnratio=0.8, check_ori=True)
+    out["bow%d_n" % mode], out["bow%d_match12" % mode] = n_r, m_r
+out.update(bow_valid1=(has1 & (1 - bad1)).astype(np.uint8), bow_valid2=(has2 & (1 - bad2)).astype(np.uint8),
+           fv1_node=fv1[0], fv1_off=fv1[1], fv1_feat=fv1[2], fv2_node=fv2[0], fv2_off=fv2[1], fv2_feat=fv2[2])
+tri_has1 = (rng.random(F[0].N) < 0.3).astype(np.uint8); tri_has2 = (rng.random(F[1].N) < 0.3).astype(np.uint8)
+F12 = np.array([[0, -1e-3, 1.0 / 300], [1e-3, 0, -3.0 / 300], [-1.0 / 300, 3.0 / 300, 0]], np.float32) + rng.normal(0, 1e-5, (3, 3)).astype(np.float32)
+t2w = np.array([0.3, 0.1, 1.0], np.float32)
+n_r, m_r = S.search_for_triangulation(F[0], tri_has1, fv1, F[1], tri_has2, fv2, F12, t2w, only_stereo=False, check_ori=True)
+invz = np.float32(1.0) / t2w[2]
+out.update(tri_has1=tri_has1, tri_has2=tri_has2, tri_F12=F12, tri_ex=np.float32(1.0) * t2w[0] * invz + np.float32(0.0), tri_ey=np.float32(1.0) * t2w[1] * invz + np.float32(0.0),
+           tri_n=n_r, tri_match12=m_r, scale_factors=sf, sigma2=par["sigma2"])
+
+out.update(prev_keys=F[0].keys_un, prev_desc=F[0].desc)
 out.update(cur_keys=F[1].keys_un, cur_desc=F[1].desc, image_checksum=np.int64(seq[1].astype(np.uint64).sum()))
 np.savez_compressed(os.path.join(here, "matchers_ref.npz"), **out)
-print("golden matchers:", out["local_n"], "local-map matches,", out["last_n"], "last-frame matches,", out["fuse_n"], "fused points")
+print("golden matchers:", out["local_n"], "local-map matches,", out["last_n"], "last-frame matches,", out["fuse_n"], "fused points,", out["bow0_n"], out["bow1_n"], "BoW matches,",
+      out["tri_n"], "triangulation pairs")
 for f in F:
     f.close()
 S.RefFrame._geometry = None

@@ -24,3 +24,18 @@ def test_projection_matchers_and_fuse_equal_the_reference(backend):
     bi, bd = orb_slam2_amd.search_best_in_window(kc, dc, w, h, G["inv_sigma2"], G["fuse_queries"], G["fuse_qdesc"], True, library=backend)
     best = np.where(bd <= 50, bi, -1)
     assert np.array_equal(best, G["fuse_best"]) and int((best >= 0).sum()) == int(G["fuse_n"]) > 100
+
+
+def test_bow_matchers_and_triangulation_equal_the_reference(backend):
+    k1, d1, k2, d2 = G["prev_keys"], G["prev_desc"], G["cur_keys"], G["cur_desc"]
+    fv1, fv2 = (G["fv1_node"], G["fv1_off"], G["fv1_feat"]), (G["fv2_node"], G["fv2_off"], G["fv2_feat"])
+    # ORBmatcher(0.8, true).SearchByBoW(KeyFrame, Frame, ..) and (KeyFrame, KeyFrame, ..)
+    for mode in (0, 1):
+        n, m12 = orb_slam2_amd.search_by_bow(mode, d1, k1["angle"], G["bow_valid1"], fv1, d2, k2["angle"], G["bow_valid2"] if mode == 1 else None, fv2, nnratio=0.8, check_ori=True,
+                                             library=backend)
+        assert n == int(G["bow%d_n" % mode]) and np.array_equal(m12, G["bow%d_match12" % mode]) and n > 100
+    # ORBmatcher(0.6, true).SearchForTriangulation(KF1, KF2, F12, .., bOnlyStereo = false): monocular key frames (no stereo flags)
+    none1, none2 = np.zeros(len(k1), np.uint8), np.zeros(len(k2), np.uint8)
+    n, m12 = orb_slam2_amd.search_for_triangulation(d1, k1, G["tri_has1"], none1, fv1, d2, k2, G["tri_has2"], none2, fv2, G["tri_F12"], float(G["tri_ex"]), float(G["tri_ey"]),
+                                                    G["scale_factors"], G["sigma2"], only_stereo=False, check_ori=True, library=backend)
+    assert n == int(G["tri_n"]) and np.array_equal(m12, G["tri_match12"]) and n > 50
