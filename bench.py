@@ -8,6 +8,11 @@ slot saw in the previous step (the unit of work).  value = frame
 
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL, used ONLY for the barrier and the max-reduce of
 the timing): camera slots are independent, so ranks share nothing on the data path (no collective) -> weak scaling.
+`python bench.py --gpus N` without a launcher (WORLD_SIZE unset) re-executes itself under torch.distributed.run with N ranks;
+it refuses to run when fewer than N GPUs are visible instead of reporting a 1-GPU number.
+
+The timed region is `--repeats` (default 5) back-to-back measurements of EXACTLY `--steps` steps each, every one bracketed by
+barrier + synchronize; `value` / `ms_per_step` are the MEDIAN repeat, the spread is reported in `repeats`.
 
 Extra objects in the JSON line:
   roofline      dominant kernel (by HIP-event time measured inside the timed region on the library's stream):
@@ -31,13 +36,14 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 W, H, NFEAT, NLEVELS, SCALE, INI_TH, MIN_TH = 1241, 376, 2000, 8, 1.2, 20, 7
 WINDOW, NNRATIO = 100, 0.9
+NSCENES = 64               # distinct seeded scenes replicated over the camera slots (data-dependent kernels see 64 workloads x tsteps)
 
 
 def make_frames(batch, tsteps, pitch, rank):
     """[tsteps][batch][H][pitch] uint8: `nscenes` distinct seeded scenes (replicated over the slots), consecutive time
     steps of a slot are consecutive frames of its sequence (translated by (3,1) px + fresh noise)."""
     from orb_slam2_amd import synth
-    nscenes = min(batch, 16)
+    nscenes = min(batch, NSCENES)
     out = np.zeros((tsteps, batch, H, pitch), np.uint8)
     for s in range(nscenes):
         sc = synth.scene(W, H, seed=100 * rank + s)
@@ -112,11 +118,53 @@ def cpu_baseline(frames, budget_s=8.0):
             "oracle_port_single_thread_value": round(port_done / port_dt, 2)}
 
 
+def host_io(ex_resident, frames, device, budget_s=3.0):
+    """The drop-in boundary as every real caller sees it (Frame::ExtractORB, Frame.cc:247-253): host images in, host key points +
+    descriptors out, PCIe both ways, through the pipelined host path (orbhip_submit / orbhip_collect, two batches in flight).
+    Extraction only; never the bench `value`.  Measured from pinned caller buffers (DMA straight from / into them) and from pageable
+    ones (staged through the library's pinned ring by a few copy threads), plus the single-frame call latency of the drop-in class."""
+    import orb_slam2_amd
+    Bh = 128
+    ex = orb_slam2_amd.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, W, H, max_batch=Bh, device=device)
+    cap = ex.capacity
+    src_pageable = np.ascontiguousarray(frames[0, :Bh, :, :W]) if frames.shape[1] >= Bh else np.ascontiguousarray(np.resize(frames[0, :, :, :W], (Bh, H, W)))
+    out = {"batch": Bh, "bytes_per_frame_h2d": W * H, "bytes_per_frame_d2h": cap * 60 + 4}
+    for kind in ("pinned", "pageable"):
+        if kind == "pinned":
+            src = orb_slam2_amd.pinned_array((Bh, H, W), np.uint8); src[:] = src_pageable
+            bufs = [(orb_slam2_amd.pinned_array((Bh, cap), orb_slam2_amd.KEYPOINT_DTYPE), orb_slam2_amd.pinned_array((Bh, cap, 32), np.uint8), np.zeros(Bh, np.int32)) for _ in range(2)]
+        else:
+            src = src_pageable
+            bufs = [(np.zeros((Bh, cap), orb_slam2_amd.KEYPOINT_DTYPE), np.zeros((Bh, cap, 32), np.uint8), np.zeros(Bh, np.int32)) for _ in range(2)]
+        imgs = [src[f] for f in range(Bh)]
+        t = ex.submit(imgs); ex.collect(t, out=bufs[0])                # warm-up: allocates the ring
+        done, t0 = 0, time.perf_counter()
+        pending = [ex.submit(imgs)]
+        while time.perf_counter() - t0 < budget_s / 2:
+            pending.append(ex.submit(imgs))                           # batch t+1 uploads while batch t computes and downloads
+            nout = ex.collect(pending.pop(0), out=bufs[done % 2])
+            done += 1
+        nout = ex.collect(pending.pop(0), out=bufs[done % 2]); done += 1
+        dt = time.perf_counter() - t0
+        out[kind] = {"frames_per_s": round(done * Bh / dt, 1), "pcie_GBps": round(done * Bh * (W * H + cap * 60 + 4) / dt / 1e9, 2), "keypoints_per_frame": int(nout.mean())}
+    one = orb_slam2_amd.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, W, H, max_batch=1, device=device)
+    one(src_pageable[0])
+    t1 = time.perf_counter()
+    for i in range(100):
+        one(src_pageable[i % Bh])
+    out["single_frame_call_ms"] = round((time.perf_counter() - t1) / 100 * 1e3, 4)
+    out["value"] = out["pinned"]["frames_per_s"]; out["unit"] = "frames/s"
+    out["note"] = "extract only, PCIe both ways, host buffers in / out; value = pinned caller buffers"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=5, help="measurements of --steps steps each; value = the median one")
+    ap.add_argument("--no-host-io", action="store_true", help="skip the PCIe-inclusive host-buffer measurement (host_io object)")
     ap.add_argument("--batch", type=int, default=512, help="camera slots (frames) per step per GPU")
     ap.add_argument("--tsteps", type=int, default=4, help="distinct resident time steps cycled through")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the library splits each batch over")
@@ -126,13 +174,28 @@ def main():
 
     import torch
     import torch.distributed as dist
+    share = os.environ.get("ORB_BENCH_SHARE_GPU") == "1"
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # launched bare: become the launcher.  One rank per GPU; never a silent 1-GPU run labelled N.
+        ngpu = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if ngpu < args.gpus and not share:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {ngpu} GPU(s) visible on this box — refusing to report a {args.gpus}-GPU number")
+        import socket
+        import subprocess
+        sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the ORB front-end has no CPU fallback")
     # ORB_BENCH_SHARE_GPU=1 (test aid): all ranks use GPU 0 and rendezvous over gloo, to exercise the N>1 code path on a 1-GPU box
-    share = os.environ.get("ORB_BENCH_SHARE_GPU") == "1"
+    if not share and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible — refusing to share a GPU between ranks")
     if share:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -166,19 +229,22 @@ def main():
     ex.sync()
     ex.profile_enable(True)
     ex.profile_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    ex.sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    times = []
+    for r in range(max(args.repeats, 1)):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + r * args.steps + i)
+        ex.sync()
+        barrier()
+        times.append(time.perf_counter() - t0)
     prof = ex.profile()
     ex.profile_enable(False)
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else f"cuda:{local_rank}")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        tt = torch.tensor(times, dtype=torch.float64, device="cpu" if share else f"cuda:{local_rank}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)                    # per repeat: the slowest rank
+        times = [float(v) for v in tt.tolist()]
+    elapsed = sorted(times)[len(times) // 2]                         # the median repeat is the reported one
 
     # sanity of the timed work (not timed): every slot produced keypoints and matches
     kps, _ = ex.fetch(B)
@@ -217,7 +283,10 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "KITTI-shaped 1241x376 u8, 2000 features, 8 levels, scale 1.2, FAST 20/7, extract + SearchForInitialization(win 100, nnratio 0.9)",
-                       "frames_per_step_per_gpu": B, "resident_time_steps": T, "row_pitch": pitch, "streams_per_gpu": args.streams, "parallelism": f"frames sharded over {world} GPU(s), no collective"},
+                       "inputs": "hbm-resident, results stay on device (the PCIe-inclusive host-buffer rate is the host_io object)",
+                       "frames_per_step_per_gpu": B, "resident_time_steps": T, "distinct_scenes": min(B, NSCENES), "row_pitch": pitch, "streams_per_gpu": args.streams, "parallelism": f"frames sharded over {world} GPU(s), no collective"},
+            "repeats": {"n": len(times), "steps_each": args.steps, "timed_region_s": round(sum(times), 3), "frames_per_s_median": round(frames_total / elapsed, 1),
+                        "frames_per_s_min": round(frames_total / max(times), 1), "frames_per_s_max": round(frames_total / min(times), 1)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "alg_bytes_per_launch": alg * B, "launch_ms": round(kern[dom]["ms_per_launch"], 4), "note": note},
@@ -228,6 +297,8 @@ def main():
             "kernel_time_fraction_of_step": round(total_kernel_ms / (elapsed / args.steps * 1e3), 3),
             "check": {"keypoints_per_frame_min_max": [int(min(nkp)), int(max(nkp))], "matches_per_frame_min_max": [int(nm.min()), int(nm.max())]},
         }
+        if world == 1 and not args.no_host_io:
+            out["host_io"] = host_io(ex, host_frames, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host_frames)
             out["cpu_baseline"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)

@@ -6,6 +6,8 @@
 #define ORBEXTRACTOR_H
 
 #include <list>
+#include <mutex>
+#include <stdexcept>
 #include <vector>
 #ifdef ORBHIP_USE_OPENCV
 #include <opencv/cv.h>
@@ -17,6 +19,36 @@ struct orbhip_ctx;
 
 namespace ORB_SLAM2
 {
+
+// The reference's operator() cannot fail (ORBextractor.h:59-61 returns void); a GPU call can.  Every failure of the device library
+// (no usable GPU, a HIP error, an image geometry outside the supported envelope) is thrown as this exception with the library's
+// message — never swallowed (an empty key point list would silently derail tracking), never abort(): an application that wants
+// to survive a transient device fault can catch it around Frame construction; one that does not terminates with the message.
+class ORBhipError : public std::runtime_error
+{
+public:
+    explicit ORBhipError(const std::string& what) : std::runtime_error(what) {}
+};
+
+class ORBextractor;
+// What callers see as `std::vector<cv::Mat> mvImagePyramid` (ORBextractor.h:85).  The only readers in the reference are
+// Frame::ComputeStereoMatches' `mvImagePyramid[level]` expressions (Frame.cc:473, 563, 575, 580); monocular and RGB-D pipelines never
+// touch it.  The planes live in HBM: the first operator[] after an extraction fetches all levels of that image in one batched copy
+// with a single synchronisation, later accesses are free.  SetPyramidDownload(true) restores the eager download after every call.
+class ORBimagePyramid
+{
+public:
+    ORBimagePyramid() : mpOwner(NULL), mbStale(false) {}
+    cv::Mat& operator[](size_t level) { Refresh(); return mvLevels[level]; }
+    const cv::Mat& operator[](size_t level) const { const_cast<ORBimagePyramid*>(this)->Refresh(); return mvLevels[level]; }
+    size_t size() const { return mvLevels.size(); }
+    bool empty() const { return mvLevels.empty(); }
+    void resize(size_t n) { mvLevels.resize(n); }
+private:
+    friend class ORBextractor;
+    void Refresh();
+    ORBextractor* mpOwner; bool mbStale; std::vector<cv::Mat> mvLevels; std::mutex mMutex;
+};
 
 class ORBextractor
 {
@@ -42,10 +74,22 @@ public:
     std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
     std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
 
-    // mvImagePyramid[l] is filled after every call (read by Frame::ComputeStereoMatches, Frame.cc:473,563-580).
-    // Monocular / RGB-D pipelines never read it: SetPyramidDownload(false) skips the 8 device-to-host copies.
-    std::vector<cv::Mat> mvImagePyramid;
-    void SetPyramidDownload(bool on) { mbDownloadPyramid = on; }
+    // mvImagePyramid[l] of the last image (read by Frame::ComputeStereoMatches, Frame.cc:473,563-580): fetched from the device the first
+    // time it is indexed after a call (see ORBimagePyramid); SetPyramidDownload(true) downloads eagerly after every call instead.
+    ORBimagePyramid mvImagePyramid;
+    void SetPyramidDownload(bool eager) { mbDownloadPyramid = eager; }
+    // cv::GaussianBlur's last rounding step: 0 = OpenCV's generic C++ path, (sum + 2^15) >> 16; 1 = the SSE2 column filter
+    // every x86-64 build of OpenCV <= 3.3 runs (round-half-even on whole 4-column groups).  The default is the host's own: 1 when this
+    // class is compiled for x86-64, 0 elsewhere — i.e. what the OpenCV this class stands in for would have computed on this machine.
+    void SetBlurRounding(int mode);
+    int GetBlurRounding() const { return mnBlurRounding; }
+
+    // Asynchronous form for callers that own more than one camera or keep a queue of frames (the reference has none: Frame::ExtractORB is
+    // synchronous, Frame.cc:247-253).  Submit() uploads and enqueues a batch of equally sized CV_8UC1 images and returns a ticket; up to
+    // three batches may be in flight; Collect() blocks for the oldest ticket and delivers per image what operator() delivers.  Pageable
+    // images are consumed when Submit returns; pinned ones are read by DMA until Collect.  maxBatch is fixed by the first Submit.
+    int Submit(const std::vector<cv::Mat>& images, int maxBatch = 0);
+    void Collect(int ticket, std::vector<std::vector<cv::KeyPoint> >& keypoints, std::vector<cv::Mat>& descriptors);
     // Frame::ComputeStereoMatches (Frame.cc:466-640) on the GPU.  `this` is the left extractor, `right` the right one; both
     // must have processed their image of the current frame (Frame.cc:78-81).  N = number of left keypoints (Frame::N).
     // Fills mvuRight / mvDepth exactly like the reference; reads keypoints, descriptors and pyramids that are still in HBM.
@@ -72,7 +116,10 @@ public:
     void SetDevice(int device) { mnDevice = device; }
 
 protected:
-    void EnsureContext(int width, int height);
+    friend class ORBimagePyramid;
+    void EnsureContext(int width, int height, int maxBatch = 1);
+    void FetchPyramid(std::vector<cv::Mat>& levels);
+    void Fail(const char* where) const;
     void Deliver(int n, const std::vector<unsigned char>& desc, std::vector<cv::KeyPoint>& keypoints, cv::OutputArray descriptors);
 
     int nfeatures;
@@ -91,7 +138,8 @@ protected:
     std::vector<float> mvMapX, mvMapY; int mnRawCols, mnRawRows; // rectification maps (applied when the context is (re)created)
     int mnLastN;                                                 // key points of the last image
     orbhip_ctx* mpCtx;          // device context for the current image size (created lazily, re-created on a size change)
-    int mnCtxW, mnCtxH, mnDevice;
+    int mnCtxW, mnCtxH, mnCtxBatch, mnDevice, mnBlurRounding;
+    std::vector<int> mvTicketSizes;                              // images per ticket in flight (Submit / Collect), by ticket mod 4
     bool mbDownloadPyramid;
     float mfScaleFactorArg;
 };

@@ -74,6 +74,8 @@ int orbhip_keypoint_capacity(const orbhip_ctx* ctx);  /* upper bound of keypoint
 orbhip_status orbhip_get_scale_tables(const orbhip_ctx* ctx, float* scale_factors, float* inv_scale_factors,
                                       float* level_sigma2, float* inv_level_sigma2, int32_t* features_per_level);
 orbhip_status orbhip_level_size(const orbhip_ctx* ctx, int level, int* w, int* h);
+/* blur_round_mode of the configuration, changeable between calls (ORBextractor::SetBlurRounding) */
+orbhip_status orbhip_set_blur_rounding(orbhip_ctx* ctx, int mode);
 
 /* ORBextractor::operator() (ORBextractor.h:59-61, ORBextractor.cc:1043-1105): host image in, host keypoints +
    descriptors out, synchronous.  Keypoints are level-major, quadtree-list order within a level; descriptor
@@ -93,6 +95,60 @@ orbhip_status orbhip_extract_batch_color(orbhip_ctx* ctx, int nimg, const uint8_
                                          orbhip_keypoint* kps, uint8_t* desc, int cap, int* n_out /* nimg */);
 /* mvImagePyramid[level] of frame `frame` of the last call (ORBextractor.h:85; read by Frame.cc:473,563-580) */
 orbhip_status orbhip_pyramid_level(orbhip_ctx* ctx, int frame, int level, uint8_t* dst, int dst_stride);
+/* every level of that frame in one go (nlevels async copies, ONE synchronisation): dst[l] / dst_stride[l] per level; what the
+   drop-in class calls the first time a caller touches mvImagePyramid after an extraction */
+orbhip_status orbhip_pyramid_fetch_all(orbhip_ctx* ctx, int frame, uint8_t* const* dst, const int* dst_stride);
+
+/* -------- pipelined host-buffer path (Frame::ExtractORB callers, Frame.cc:247-253) ---------------------- */
+/* Every real caller hands over host images and wants host results.  orbhip_extract_batch splits a batch into chunks and
+   overlaps, on three HIP streams, the upload of chunk k+1 with the kernels of chunk k and the download of chunk k-1
+   (pinned staging mirrors; pageable -> pinned gathers are spread over a few helper threads).  orbhip_submit /
+   orbhip_collect expose the same machinery across calls: up to orbhip_ring_depth() batches in flight per context, so the
+   upload of batch t+1 also overlaps the tail of batch t.  Tickets are collected in submission order; a submit on a full
+   ring fails with ORBHIP_ERR_INVALID.  Caller buffers that are pinned (orbhip_host_alloc, hipHostMalloc, hipHostRegister)
+   are read / written by DMA directly, without the staging copy.  Results are bit-identical to orbhip_extract_batch. */
+orbhip_status orbhip_submit(orbhip_ctx* ctx, int nimg, const uint8_t* const* imgs, int stride_bytes, int* ticket);
+orbhip_status orbhip_collect(orbhip_ctx* ctx, int ticket, orbhip_keypoint* kps, uint8_t* desc, int cap, int* n_out /* nimg */);
+int orbhip_ring_depth(void);
+/* pinned host memory for callers that do not link the HIP runtime themselves (hipHostMalloc / hipHostFree) */
+void* orbhip_host_alloc(size_t bytes);
+void orbhip_host_free(void* p);
+
+/* -------- one node, G GPUs: cameras and descriptor-DB shards (BASELINE.json configs 4 and 5) --------
+   The reference's only concurrency on this path is the two extractor threads of the stereo Frame constructor
+   (Frame.cc:78-81).  A pool generalises that: one context + one host thread + pinned staging ring per device, camera c is
+   served by devices[c mod G], no device ever talks to another (no collective).  The descriptor DB of the relocalisation
+   query is split by contiguous row range, shard r resident on devices[r]; a query is broadcast by G independent copies,
+   every device scans its shard and the G partial answers per query are merged on the host with the matcher's rule
+   (strict '<': the lowest global index wins ties; second = second smallest of the union). */
+typedef struct orbhip_pool orbhip_pool;
+/* cfg->device and cfg->max_batch are ignored (per-device batch = ceil(ncameras / ndevices)); devices may repeat an ordinal
+   (several contexts on one GPU) — that is how the CPU test-suite and 1-GPU boxes exercise the N > 1 path */
+orbhip_status orbhip_pool_create(orbhip_pool** out, const int* devices, int ndevices, const orbhip_config* cfg, int ncameras);
+void orbhip_pool_destroy(orbhip_pool* pool);
+int orbhip_pool_num_devices(const orbhip_pool* pool);
+int orbhip_pool_device_of(const orbhip_pool* pool, int camera);          /* devices[camera mod G], -1 if out of range */
+int orbhip_pool_keypoint_capacity(const orbhip_pool* pool);
+/* one frame per camera (imgs[c] == NULL: that camera has no frame this round, n_out[c] = 0); outputs are [ncameras][cap].
+   orbhip_pool_extract = orbhip_pool_submit + orbhip_pool_collect; with submit / collect a caller keeps up to
+   orbhip_ring_depth() rounds in flight (tickets collected in order). */
+orbhip_status orbhip_pool_extract(orbhip_pool* pool, const uint8_t* const* imgs, int stride_bytes,
+                                  orbhip_keypoint* kps, uint8_t* desc, int cap, int* n_out /* ncameras */);
+orbhip_status orbhip_pool_submit(orbhip_pool* pool, const uint8_t* const* imgs, int stride_bytes, int* ticket);
+orbhip_status orbhip_pool_collect(orbhip_pool* pool, int ticket, orbhip_keypoint* kps, uint8_t* desc, int cap, int* n_out);
+/* descriptor DB: rows [lo_r, hi_r) of db go to devices[r] and stay there; ndb rows of 32 bytes */
+orbhip_status orbhip_pool_db_load(orbhip_pool* pool, const uint8_t* db, int64_t ndb);
+void orbhip_pool_db_shard(const orbhip_pool* pool, int r, int64_t* lo, int64_t* hi);
+orbhip_status orbhip_pool_db_query(orbhip_pool* pool, const uint8_t* q, int nq, int64_t* best_idx, int32_t* best_dist, int32_t* second_dist);
+/* relocalisation candidates from the brute-force DB (stands where Tracking::Relocalization calls
+   KeyFrameDatabase::DetectRelocalizationCandidates, Tracking.cc:1344-1348, KeyFrameDatabase.cc:199-309): every query descriptor
+   votes for the key frame that owns its nearest DB row if best <= th_dist and best < ratio * second; row_keyframe[i] = key frame
+   id of DB row i (ascending rows of one key frame need not be contiguous), nkf = number of key frames.  Returns the top_k key
+   frames by votes (ties: lower key frame id first; key frames without votes are not reported): kf_out / votes_out hold top_k
+   entries, *nout the number filled.  Host arithmetic over the answer of orbhip_hamming_nn / orbhip_pool_db_query. */
+orbhip_status orbhip_reloc_candidates(const int64_t* best_idx, const int32_t* best_dist, const int32_t* second_dist, int nq,
+                                      const int32_t* row_keyframe, int64_t ndb, int nkf, int th_dist, float ratio,
+                                      int top_k, int32_t* kf_out, int32_t* votes_out, int* nout);
 
 /* -------- device-resident pipeline (inputs already in HBM, results stay in HBM) ----------------------- */
 /* d_imgs: device pointer to nimg frames, frame f at d_imgs + f*frame_stride, rows row_stride bytes apart.

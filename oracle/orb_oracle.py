@@ -336,6 +336,26 @@ def bf_nn(q, db, fast=False):
     return bi, bd, sd
 
 
+def reloc_candidates(best_idx, best_dist, second_dist, row_keyframe, nkf, th_dist=50, ratio=0.75, top_k=10):
+    """Definition (this repository's) of the relocalisation candidate list built from the brute-force descriptor DB
+    (BASELINE.json config 5) where Tracking::Relocalization (Tracking.cc:1344-1348) asks KeyFrameDatabase::DetectRelocalizationCandidates
+    (KeyFrameDatabase.cc:199-309) for key frames: a query descriptor votes for the key frame owning its nearest row iff it passes the
+    matcher's own acceptance idiom (best <= th and best < ratio * second in float, ORBmatcher.cc:102-114); key frames ranked by votes,
+    ties by ascending id, key frames without votes not listed.  Plain Python loop: the checker, not a product path."""
+    votes = [0] * max(nkf, 1)
+    for i in range(len(best_idx)):
+        r = int(best_idx[i])
+        if r < 0 or r >= len(row_keyframe):
+            continue
+        if int(best_dist[i]) > th_dist:
+            continue
+        if not (np.float32(best_dist[i]) < np.float32(ratio) * np.float32(second_dist[i])):
+            continue
+        votes[int(row_keyframe[r])] += 1
+    order = sorted([k for k in range(nkf) if votes[k] > 0], key=lambda k: (-votes[k], k))[:top_k]
+    return np.array(order, np.int32), np.array([votes[k] for k in order], np.int32)
+
+
 def search_for_initialization(kps1, desc1, kps2, desc2, imw, imh, prev=None, window=100, nnratio=0.9, check_ori=True,
                               fast=False):
     """ORBmatcher(nnratio, check_ori).SearchForInitialization(F1, F2, prev, matches12, window).

@@ -140,9 +140,18 @@ static void attach_camera(ORBextractor*, const cv::Mat&, const cv::Mat&) {}
 #endif
 Rig& rig(int nfeat, float scale, int nlevels, int ini, int mn)
 {
-    std::vector<int> key = {nfeat, (int)(scale * 100000), nlevels, ini, mn};
+    // ORB_REF_BLUR_ROUND_MODE: which real-world cv::GaussianBlur both builds stand for (0 generic C++, 1 x86 SSE2).  The
+    // all-reference build reads it inside the GaussianBlur stand-in; the drop-in build hands it to the class (ORBextractor::SetBlurRounding).
+    const char* brm = getenv("ORB_REF_BLUR_ROUND_MODE"); const int mode = brm && atoi(brm) ? 1 : 0;
+    std::vector<int> key = {nfeat, (int)(scale * 100000), nlevels, ini, mn, mode};
     auto it = g_rigs.find(key);
-    if (it == g_rigs.end()) { Rig r = {new ORBextractor(nfeat, scale, nlevels, ini, mn), new ORBextractor(nfeat, scale, nlevels, ini, mn)}; it = g_rigs.insert(std::make_pair(key, r)).first; }
+    if (it == g_rigs.end()) {
+        Rig r = {new ORBextractor(nfeat, scale, nlevels, ini, mn), new ORBextractor(nfeat, scale, nlevels, ini, mn)};
+#ifdef ORBSLAM_DROPIN_BUILD
+        r.left->SetBlurRounding(mode); r.right->SetBlurRounding(mode);
+#endif
+        it = g_rigs.insert(std::make_pair(key, r)).first;
+    }
     return it->second;
 }
 cv::Mat camera(float fx, float fy, float cx, float cy)

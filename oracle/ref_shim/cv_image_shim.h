@@ -57,7 +57,9 @@ static inline void GaussianBlur(InputArray src, OutputArray dst, Size ksize, dou
     (void)ksize; (void)sx; (void)sy; (void)borderType;          // the reference's only call: 7x7, sigma 2, BORDER_REFLECT_101 (ORBextractor.cc:1086)
     const Mat s = src.getMat();
     std::vector<uint8_t> out((size_t)s.cols * s.rows);
-    orb_oracle_blur(s.data, s.cols, s.rows, (int)s.step, out.data(), 0);
+    // ORB_REF_BLUR_ROUND_MODE selects which real-world cv::GaussianBlur this stands for: 0 = generic C++ (default), 1 = x86 SSE2 build
+    const char* brm = getenv("ORB_REF_BLUR_ROUND_MODE");
+    orb_oracle_blur(s.data, s.cols, s.rows, (int)s.step, out.data(), brm && atoi(brm) ? 1 : 0);
     dst.create(s.rows, s.cols, s.type());
     Mat d = dst.getMat();
     for (int y = 0; y < s.rows; y++) memcpy(d.ptr(y), &out[(size_t)y * s.cols], s.cols);

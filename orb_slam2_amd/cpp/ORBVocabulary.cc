@@ -4,6 +4,7 @@
 #include "ORBVocabulary.h"
 #include "ORBextractor.h"
 #include "orbhip.h"
+#include <string>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -55,10 +56,7 @@ void ORBVocabulary::transform(const cv::Mat& descriptors, DBoW2::BowVector &v, D
     if ((size_t)descriptors.step != 32) { packed.resize((size_t)n * 32); for (int i = 0; i < n; i++) memcpy(&packed[(size_t)i * 32], descriptors.ptr(i), 32); d = &packed[0]; }
     std::vector<unsigned int> bowId(n), fvNode(n), fvFeat(n); std::vector<double> bowVal(n); std::vector<int> fvOff(n + 1);
     int nbow = 0, nfv = 0;
-    if (orbhip_voc_transform(mpVoc, d, n, levelsup, &bowId[0], &bowVal[0], &nbow, &fvNode[0], &fvOff[0], &fvFeat[0], &nfv) != ORBHIP_OK) {
-        fprintf(stderr, "ORBVocabulary::transform: %s\n", orbhip_last_error());
-        abort();
-    }
+    if (orbhip_voc_transform(mpVoc, d, n, levelsup, &bowId[0], &bowVal[0], &nbow, &fvNode[0], &fvOff[0], &fvFeat[0], &nfv) != ORBHIP_OK) throw ORBhipError(std::string("ORBVocabulary::transform: ") + orbhip_last_error());
     Deliver(n, bowId, bowVal, nbow, fvNode, fvOff, fvFeat, nfv, v, fv);
 }
 
@@ -79,10 +77,7 @@ void ORBVocabulary::ComputeBoW(ORBextractor& extractor, DBoW2::BowVector &v, DBo
     std::vector<unsigned int> bowId(n), fvNode(n), fvFeat(n); std::vector<double> bowVal(n); std::vector<int> fvOff(n + 1);
     int nbow = 0, nfv = 0;
     if (orbhip_compute_bow(ctx, mpVoc, 1, levelsup) != ORBHIP_OK ||
-        orbhip_fetch_bow(ctx, mpVoc, 0, &bowId[0], &bowVal[0], &nbow, &fvNode[0], &fvOff[0], &fvFeat[0], &nfv) != ORBHIP_OK) {
-        fprintf(stderr, "ORBVocabulary::ComputeBoW: %s\n", orbhip_last_error());
-        abort();
-    }
+        orbhip_fetch_bow(ctx, mpVoc, 0, &bowId[0], &bowVal[0], &nbow, &fvNode[0], &fvOff[0], &fvFeat[0], &nfv) != ORBHIP_OK) throw ORBhipError(std::string("ORBVocabulary::ComputeBoW: ") + orbhip_last_error());
     Deliver(n, bowId, bowVal, nbow, fvNode, fvOff, fvFeat, nfv, v, fv);
 }
 

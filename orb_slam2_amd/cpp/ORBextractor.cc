@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <string>
 
 namespace ORB_SLAM2
 {
@@ -18,7 +20,13 @@ static_assert(sizeof(cv::KeyPoint) == sizeof(orbhip_keypoint), "cv::KeyPoint and
 ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST)
     : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST),
       mbHasCamera(false), mnRawCols(0), mnRawRows(0), mnLastN(0),
-      mpCtx(NULL), mnCtxW(0), mnCtxH(0), mnDevice(0), mbDownloadPyramid(true), mfScaleFactorArg(_scaleFactor)
+      mpCtx(NULL), mnCtxW(0), mnCtxH(0), mnCtxBatch(0), mnDevice(0),
+#if defined(__SSE2__) || defined(_M_X64)
+      mnBlurRounding(1),          // an x86-64 OpenCV (<= 3.3) runs the SSE2 column filter: round-half-even on 4-column groups
+#else
+      mnBlurRounding(0),
+#endif
+      mvTicketSizes(4, 0), mbDownloadPyramid(false), mfScaleFactorArg(_scaleFactor)
 {
     memset(mCamera, 0, sizeof mCamera);
     mvScaleFactor.resize(nlevels); mvLevelSigma2.resize(nlevels);
@@ -26,32 +34,61 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int
     for (int i = 1; i < nlevels; i++) { mvScaleFactor[i] = (float)(mvScaleFactor[i - 1] * scaleFactor); mvLevelSigma2[i] = mvScaleFactor[i] * mvScaleFactor[i]; }
     mvInvScaleFactor.resize(nlevels); mvInvLevelSigma2.resize(nlevels);
     for (int i = 0; i < nlevels; i++) { mvInvScaleFactor[i] = 1.0f / mvScaleFactor[i]; mvInvLevelSigma2[i] = 1.0f / mvLevelSigma2[i]; }
-    mvImagePyramid.resize(nlevels);
+    mvImagePyramid.resize(nlevels); mvImagePyramid.mpOwner = this;
     mnFeaturesPerLevel.resize(nlevels);
     if (const char* dev = getenv("ORBHIP_DEVICE")) mnDevice = atoi(dev);
+    if (const char* br = getenv("ORBHIP_BLUR_ROUNDING")) mnBlurRounding = atoi(br) ? 1 : 0;      // deployment override of the host default (see SetBlurRounding)
 }
 
 ORBextractor::~ORBextractor() { if (mpCtx) orbhip_destroy(mpCtx); }
 
-void ORBextractor::EnsureContext(int width, int height)
+void ORBextractor::Fail(const char* where) const
 {
-    if (mpCtx && width == mnCtxW && height == mnCtxH) return;
+    throw ORBhipError(std::string(where) + ": " + orbhip_last_error());
+}
+
+void ORBextractor::SetBlurRounding(int mode)
+{
+    mnBlurRounding = mode ? 1 : 0;
+    if (mpCtx && orbhip_set_blur_rounding(mpCtx, mnBlurRounding) != ORBHIP_OK) Fail("ORBextractor::SetBlurRounding");
+}
+
+void ORBimagePyramid::Refresh()
+{
+    std::lock_guard<std::mutex> lock(mMutex);
+    if (!mbStale || !mpOwner) return;
+    mpOwner->FetchPyramid(mvLevels);
+    mbStale = false;
+}
+
+void ORBextractor::FetchPyramid(std::vector<cv::Mat>& levels)
+{
+    if (!mpCtx) return;
+    std::vector<uint8_t*> dst(nlevels); std::vector<int> stride(nlevels);
+    for (int l = 0; l < nlevels; l++) {
+        int w = 0, h = 0; orbhip_level_size(mpCtx, l, &w, &h);
+        levels[l].create(h, w, CV_8UC1);
+        dst[l] = levels[l].data; stride[l] = (int)levels[l].step;
+    }
+    if (orbhip_pyramid_fetch_all(mpCtx, 0, &dst[0], &stride[0]) != ORBHIP_OK) Fail("ORBextractor::mvImagePyramid");
+}
+
+void ORBextractor::EnsureContext(int width, int height, int maxBatch)
+{
+    if (mpCtx && width == mnCtxW && height == mnCtxH && maxBatch <= mnCtxBatch) return;
     if (mpCtx) { orbhip_destroy(mpCtx); mpCtx = NULL; }
     orbhip_config cfg; memset(&cfg, 0, sizeof cfg);
     cfg.nfeatures = nfeatures; cfg.scale_factor = mfScaleFactorArg; cfg.nlevels = nlevels; cfg.ini_th_fast = iniThFAST; cfg.min_th_fast = minThFAST;
-    cfg.width = width; cfg.height = height; cfg.max_batch = 1; cfg.device = mnDevice; cfg.stream = NULL; cfg.blur_round_mode = 0; cfg.num_streams = 1;
-    if (orbhip_create(&mpCtx, &cfg) != ORBHIP_OK) {
-        // the reference cannot fail here; a missing GPU must not silently produce empty frames
-        fprintf(stderr, "ORBextractor: %s\n", orbhip_last_error());
-        abort();
-    }
-    mnCtxW = width; mnCtxH = height;
+    cfg.width = width; cfg.height = height; cfg.max_batch = maxBatch; cfg.device = mnDevice; cfg.stream = NULL; cfg.blur_round_mode = mnBlurRounding; cfg.num_streams = 1;
+    // the reference cannot fail here; a missing GPU or an unsupported geometry must not silently produce empty frames
+    if (orbhip_create(&mpCtx, &cfg) != ORBHIP_OK) { mpCtx = NULL; Fail("ORBextractor"); }
+    mnCtxW = width; mnCtxH = height; mnCtxBatch = maxBatch;
     if (mbHasCamera) {
         orbhip_camera cam; memcpy(&cam, mCamera, sizeof cam);
-        if (orbhip_set_camera(mpCtx, &cam) != ORBHIP_OK) { fprintf(stderr, "ORBextractor: %s\n", orbhip_last_error()); abort(); }
+        if (orbhip_set_camera(mpCtx, &cam) != ORBHIP_OK) Fail("ORBextractor");
     }
     if (!mvMapX.empty() && (size_t)width * height == mvMapX.size() &&
-        orbhip_set_rectification(mpCtx, &mvMapX[0], &mvMapY[0], mnRawCols, mnRawRows) != ORBHIP_OK) { fprintf(stderr, "ORBextractor: %s\n", orbhip_last_error()); abort(); }
+        orbhip_set_rectification(mpCtx, &mvMapX[0], &mvMapY[0], mnRawCols, mnRawRows) != ORBHIP_OK) Fail("ORBextractor");
     // the device tables are the authority (bit-identical to the constructor's by construction; checked in tests)
     orbhip_get_scale_tables(mpCtx, &mvScaleFactor[0], &mvInvScaleFactor[0], &mvLevelSigma2[0], &mvInvLevelSigma2[0], &mnFeaturesPerLevel[0]);
 }
@@ -67,10 +104,7 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
     _keypoints.resize(cap);
     std::vector<unsigned char> desc((size_t)cap * 32);
     int n = 0;
-    if (orbhip_extract(mpCtx, image.data, (int)image.step, reinterpret_cast<orbhip_keypoint*>(&_keypoints[0]), &desc[0], cap, &n) != ORBHIP_OK) {
-        fprintf(stderr, "ORBextractor: %s\n", orbhip_last_error());
-        abort();
-    }
+    if (orbhip_extract(mpCtx, image.data, (int)image.step, reinterpret_cast<orbhip_keypoint*>(&_keypoints[0]), &desc[0], cap, &n) != ORBHIP_OK) Fail("ORBextractor");
     Deliver(n, desc, _keypoints, _descriptors);
 }
 
@@ -84,10 +118,7 @@ void ORBextractor::ExtractColor(const unsigned char* data, int step, int cols, i
     std::vector<unsigned char> desc((size_t)cap * 32);
     int n = 0;
     const uint8_t* imgs[1] = {data};
-    if (orbhip_extract_batch_color(mpCtx, 1, imgs, step, channels, bRGB ? 1 : 0, reinterpret_cast<orbhip_keypoint*>(&_keypoints[0]), &desc[0], cap, &n) != ORBHIP_OK) {
-        fprintf(stderr, "ORBextractor: %s\n", orbhip_last_error());
-        abort();
-    }
+    if (orbhip_extract_batch_color(mpCtx, 1, imgs, step, channels, bRGB ? 1 : 0, reinterpret_cast<orbhip_keypoint*>(&_keypoints[0]), &desc[0], cap, &n) != ORBHIP_OK) Fail("ORBextractor");
     Deliver(n, desc, _keypoints, _descriptors);
 }
 
@@ -101,7 +132,7 @@ void ORBextractor::SetCamera(const cv::Mat& K, const cv::Mat& distCoef)
     mbHasCamera = true;
     if (mpCtx) {
         orbhip_camera cam; memcpy(&cam, mCamera, sizeof cam);
-        if (orbhip_set_camera(mpCtx, &cam) != ORBHIP_OK) { fprintf(stderr, "ORBextractor: %s\n", orbhip_last_error()); abort(); }
+        if (orbhip_set_camera(mpCtx, &cam) != ORBHIP_OK) Fail("ORBextractor");
     }
 }
 
@@ -109,10 +140,7 @@ void ORBextractor::UndistortKeyPoints(std::vector<cv::KeyPoint>& mvKeysUn)
 {
     mvKeysUn.resize(mnLastN);
     if (mnLastN == 0 || !mpCtx) return;
-    if (orbhip_fetch_undistorted(mpCtx, 1, reinterpret_cast<orbhip_keypoint*>(&mvKeysUn[0]), mnLastN) != ORBHIP_OK) {
-        fprintf(stderr, "ORBextractor::UndistortKeyPoints: %s\n", orbhip_last_error());
-        abort();
-    }
+    if (orbhip_fetch_undistorted(mpCtx, 1, reinterpret_cast<orbhip_keypoint*>(&mvKeysUn[0]), mnLastN) != ORBHIP_OK) Fail("ORBextractor::UndistortKeyPoints");
 }
 
 void ORBextractor::ComputeImageBounds(int cols, int rows, float& mnMinX, float& mnMaxX, float& mnMinY, float& mnMaxY)
@@ -120,7 +148,7 @@ void ORBextractor::ComputeImageBounds(int cols, int rows, float& mnMinX, float& 
     orbhip_bounds b = {0.0f, 0.0f, (float)cols, (float)rows};     // Frame.cc:455-463
     if (mbHasCamera) {
         orbhip_camera cam; memcpy(&cam, mCamera, sizeof cam);
-        if (orbhip_image_bounds(mnDevice, &cam, cols, rows, &b) != ORBHIP_OK) { fprintf(stderr, "ORBextractor::ComputeImageBounds: %s\n", orbhip_last_error()); abort(); }
+        if (orbhip_image_bounds(mnDevice, &cam, cols, rows, &b) != ORBHIP_OK) Fail("ORBextractor::ComputeImageBounds");
     }
     mnMinX = b.min_x; mnMaxX = b.max_x; mnMinY = b.min_y; mnMaxY = b.max_y;
 }
@@ -132,10 +160,7 @@ void ORBextractor::ComputeStereoFromRGBD(const cv::Mat& imDepth, float depthFact
     if (N == 0 || !mpCtx) return;
     assert(imDepth.type() == CV_32F || imDepth.type() == CV_16U);
     const void* maps[1] = {imDepth.data};
-    if (orbhip_compute_stereo_from_rgbd(mpCtx, 1, maps, (int)imDepth.step, imDepth.type() == CV_32F ? 0 : 1, depthFactor, mbf, &mvuRight[0], &mvDepth[0], N) != ORBHIP_OK) {
-        fprintf(stderr, "ORBextractor::ComputeStereoFromRGBD: %s\n", orbhip_last_error());
-        abort();
-    }
+    if (orbhip_compute_stereo_from_rgbd(mpCtx, 1, maps, (int)imDepth.step, imDepth.type() == CV_32F ? 0 : 1, depthFactor, mbf, &mvuRight[0], &mvDepth[0], N) != ORBHIP_OK) Fail("ORBextractor::ComputeStereoFromRGBD");
 }
 
 void ORBextractor::SetRectification(const cv::Mat& M1, const cv::Mat& M2, int rawCols, int rawRows)
@@ -160,10 +185,7 @@ void ORBextractor::ExtractRectified(const cv::Mat& raw, std::vector<cv::KeyPoint
     std::vector<unsigned char> desc((size_t)cap * 32);
     int n = 0;
     const uint8_t* imgs[1] = {raw.data};
-    if (orbhip_extract_batch_rectify(mpCtx, 1, imgs, (int)raw.step, reinterpret_cast<orbhip_keypoint*>(&_keypoints[0]), &desc[0], cap, &n) != ORBHIP_OK) {
-        fprintf(stderr, "ORBextractor: %s\n", orbhip_last_error());
-        abort();
-    }
+    if (orbhip_extract_batch_rectify(mpCtx, 1, imgs, (int)raw.step, reinterpret_cast<orbhip_keypoint*>(&_keypoints[0]), &desc[0], cap, &n) != ORBHIP_OK) Fail("ORBextractor");
     Deliver(n, desc, _keypoints, _descriptors);
 }
 
@@ -177,12 +199,46 @@ void ORBextractor::Deliver(int n, const std::vector<unsigned char>& desc, std::v
         cv::Mat d = _descriptors.getMat();
         for (int i = 0; i < n; i++) memcpy(d.ptr(i), &desc[(size_t)i * 32], 32);
     }
-    if (mbDownloadPyramid)
-        for (int l = 0; l < nlevels; l++) {
-            int w = 0, h = 0; orbhip_level_size(mpCtx, l, &w, &h);
-            mvImagePyramid[l].create(h, w, CV_8UC1);
-            orbhip_pyramid_level(mpCtx, 0, l, mvImagePyramid[l].data, (int)mvImagePyramid[l].step);
-        }
+    {   // the planes stay in HBM until somebody indexes mvImagePyramid (only the reference's own ComputeStereoMatches does)
+        std::lock_guard<std::mutex> lock(mvImagePyramid.mMutex);
+        mvImagePyramid.mbStale = true;
+    }
+    if (mbDownloadPyramid) mvImagePyramid.Refresh();
+}
+
+int ORBextractor::Submit(const std::vector<cv::Mat>& images, int maxBatch)
+{
+    if (images.empty()) throw ORBhipError("ORBextractor::Submit: no images");
+    const int n = (int)images.size();
+    for (int i = 0; i < n; i++)
+        if (images[i].empty() || images[i].type() != CV_8UC1 || images[i].cols != images[0].cols || images[i].rows != images[0].rows || images[i].step != images[0].step)
+            throw ORBhipError("ORBextractor::Submit: images must be non-empty CV_8UC1 of one size and row step");
+    EnsureContext(images[0].cols, images[0].rows, std::max(std::max(maxBatch, n), mnCtxBatch));
+    std::vector<const uint8_t*> ptrs(n);
+    for (int i = 0; i < n; i++) ptrs[i] = images[i].data;
+    int ticket = -1;
+    if (orbhip_submit(mpCtx, n, &ptrs[0], (int)images[0].step, &ticket) != ORBHIP_OK) Fail("ORBextractor::Submit");
+    mvTicketSizes[ticket & 3] = n;
+    return ticket;
+}
+
+void ORBextractor::Collect(int ticket, std::vector<std::vector<cv::KeyPoint> >& keypoints, std::vector<cv::Mat>& descriptors)
+{
+    if (!mpCtx) throw ORBhipError("ORBextractor::Collect: nothing was submitted");
+    const int n = mvTicketSizes[ticket & 3], cap = orbhip_keypoint_capacity(mpCtx);
+    std::vector<orbhip_keypoint> kps((size_t)n * cap); std::vector<unsigned char> desc((size_t)n * cap * 32); std::vector<int> cnt(n, 0);
+    if (orbhip_collect(mpCtx, ticket, &kps[0], &desc[0], cap, &cnt[0]) != ORBHIP_OK) Fail("ORBextractor::Collect");
+    keypoints.resize(n); descriptors.resize(n);
+    for (int i = 0; i < n; i++) {
+        keypoints[i].resize(cnt[i]);
+        if (cnt[i] == 0) { descriptors[i].release(); continue; }
+        memcpy(&keypoints[i][0], &kps[(size_t)i * cap], (size_t)cnt[i] * sizeof(orbhip_keypoint));
+        descriptors[i].create(cnt[i], 32, CV_8U);
+        for (int r = 0; r < cnt[i]; r++) memcpy(descriptors[i].ptr(r), &desc[((size_t)i * cap + r) * 32], 32);
+    }
+    mnLastN = cnt[n - 1];
+    std::lock_guard<std::mutex> lock(mvImagePyramid.mMutex);
+    mvImagePyramid.mbStale = true;
 }
 
 void ORBextractor::ComputeStereoMatches(ORBextractor& right, float mbf, float mb, int N, std::vector<float>& mvuRight, std::vector<float>& mvDepth)
@@ -190,10 +246,7 @@ void ORBextractor::ComputeStereoMatches(ORBextractor& right, float mbf, float mb
     mvuRight = std::vector<float>(N, -1.0f);                     // Frame.cc:468-469
     mvDepth = std::vector<float>(N, -1.0f);
     if (N == 0 || !mpCtx || !right.mpCtx) return;
-    if (orbhip_compute_stereo_matches(mpCtx, right.mpCtx, 1, mbf, mb, &mvuRight[0], &mvDepth[0], N) != ORBHIP_OK) {
-        fprintf(stderr, "ORBextractor::ComputeStereoMatches: %s\n", orbhip_last_error());
-        abort();
-    }
+    if (orbhip_compute_stereo_matches(mpCtx, right.mpCtx, 1, mbf, mb, &mvuRight[0], &mvDepth[0], N) != ORBHIP_OK) Fail("ORBextractor::ComputeStereoMatches");
 }
 
 } // namespace ORB_SLAM2

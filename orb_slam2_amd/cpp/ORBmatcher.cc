@@ -10,6 +10,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 
 namespace ORB_SLAM2
 {
@@ -33,12 +34,12 @@ int ORBmatcher::SearchForInitialization(Frame& F1, Frame& F2, std::vector<cv::Po
     // the grid of GetFeaturesInArea spans the (undistorted) image bounds (Frame.cc:101-102, 327-346, 436-464)
     const orbhip_bounds bounds = {Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY};
     int nmatches = 0;
-    const int device = getenv("ORBHIP_DEVICE") ? atoi(getenv("ORBHIP_DEVICE")) : 0;
+    static const int device = getenv("ORBHIP_DEVICE") ? atoi(getenv("ORBHIP_DEVICE")) : 0;      // read once per process
     const orbhip_status st = orbhip_search_for_initialization_bounds(
         device, reinterpret_cast<const orbhip_keypoint*>(&F1.mvKeysUn[0]), F1.mDescriptors.ptr<unsigned char>(), n1,
         n2 ? reinterpret_cast<const orbhip_keypoint*>(&F2.mvKeysUn[0]) : NULL, n2 ? F2.mDescriptors.ptr<unsigned char>() : NULL, n2,
         &bounds, reinterpret_cast<float*>(&vbPrevMatched[0]), &vnMatches12[0], windowSize, mfNNratio, mbCheckOrientation ? 1 : 0, &nmatches);
-    if (st != ORBHIP_OK) { fprintf(stderr, "ORBmatcher: %s\n", orbhip_last_error()); abort(); }
+    if (st != ORBHIP_OK) throw ORBhipError(std::string("ORBmatcher::SearchForInitialization: ") + orbhip_last_error());   // see ORBextractor.h: never swallowed, never abort()
     return nmatches;
 }
 

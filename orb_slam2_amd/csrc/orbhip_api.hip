@@ -14,6 +14,12 @@
 #include <vector>
 #include <algorithm>
 #include <mutex>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <thread>
 
 static thread_local std::string g_err;
 static orbhip_status fail(orbhip_status st, const char* fmt, ...)
@@ -38,6 +44,19 @@ static const char* kKernelNames[K_COUNT] = {"k_pyramid_level", "k_fast_cells", "
                                             "k_match_grid", "k_match_candidates", "k_match_select", "k_undistort_keys", "k_remap"};
 
 struct ProfSpan { int k; hipEvent_t a, b; };
+
+// One batch of the pipelined host-buffer path (orbhip_submit / orbhip_collect, orbhip_extract_batch): its own pinned input mirror,
+// device input planes and pinned output mirrors, so that up to ORBHIP_RING batches are in flight; a batch is cut into chunks of
+// camera slots and chunk k+1 uploads while chunk k computes and chunk k-1 downloads.
+#define ORBHIP_RING 3
+#define ORBHIP_MAX_CHUNKS 16
+struct HostSet {
+    uint8_t* d_in = nullptr; uint8_t* h_in = nullptr; orbhip_keypoint* h_kp = nullptr; uint8_t* h_desc = nullptr; int* h_n = nullptr; bool owned = false;
+    bool busy = false; int ticket = -1, nimg = 0, out_buf = -1, nchunks = 0, chunk_f0[ORBHIP_MAX_CHUNKS + 1] = {0};
+    hipEvent_t ev_h2d[ORBHIP_MAX_CHUNKS] = {nullptr}, ev_k[ORBHIP_MAX_CHUNKS] = {nullptr}, ev_d2h[ORBHIP_MAX_CHUNKS] = {nullptr};
+    // outputs that went straight into the caller's pinned buffers by DMA (nothing left to copy at collect time)
+    orbhip_keypoint* direct_kp = nullptr; uint8_t* direct_desc = nullptr; int direct_cap = 0;
+};
 
 struct orbhip_ctx {
     orbhip_config cfg; int L = 0, B = 0;
@@ -68,6 +87,8 @@ struct orbhip_ctx {
     // camera geometry: undistorted key points of a distorted camera, rectification maps of a raw stereo camera
     orbhip_bounds bounds = {0, 0, 0, 0}; bool distorted = false; CameraD cam = {}; orbhip_keypoint* d_out_kpun[3] = {nullptr, nullptr, nullptr}; orbhip_keypoint* h_kpun = nullptr;
     int* d_map_x = nullptr; int* d_map_y = nullptr; int src_w = 0, src_h = 0, raw_pitch = 0; uint8_t* d_raw = nullptr; uint8_t* h_raw = nullptr; uint8_t* d_depth = nullptr; size_t depth_bytes = 0; const float* d_last_uright = nullptr;   // mvuRight [slot][out_cap] of the last stereo / RGB-D step
+    // pipelined host-buffer path
+    HostSet sets[ORBHIP_RING]; hipStream_t hstream = nullptr, dstream = nullptr; int next_ticket = 0, oldest_ticket = 0, ticket_set[ORBHIP_RING] = {0, 0, 0}; const uint8_t* last_d_in = nullptr; bool plane0_dirty = false;   // plane0_dirty: set 0's level-0 plane was last written by an un-ticketed entry (colour / rectify)
     // profiling
     bool prof = false; std::vector<ProfSpan> pending; std::vector<hipEvent_t> pool; double tot_ms[K_COUNT] = {0}; long long launches[K_COUNT] = {0};
 };
@@ -220,6 +241,12 @@ extern "C" void orbhip_destroy(orbhip_ctx* c)
                     c->d_prev, c->d_m12, c->d_nm};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     { void* st[] = {c->d_st_rowstart, c->d_st_rowitems, c->d_st_u, c->d_st_depth, c->d_st_sad}; for (void* q : st) if (q) (void)hipFree(q); }
+    for (auto& hs : c->sets) {
+        for (int k = 0; k < ORBHIP_MAX_CHUNKS; k++) { if (hs.ev_h2d[k]) (void)hipEventDestroy(hs.ev_h2d[k]); if (hs.ev_k[k]) (void)hipEventDestroy(hs.ev_k[k]); if (hs.ev_d2h[k]) (void)hipEventDestroy(hs.ev_d2h[k]); }
+        if (hs.owned) { if (hs.d_in) (void)hipFree(hs.d_in); if (hs.h_in) (void)hipHostFree(hs.h_in); if (hs.h_kp) (void)hipHostFree(hs.h_kp); if (hs.h_desc) (void)hipHostFree(hs.h_desc); if (hs.h_n) (void)hipHostFree(hs.h_n); }
+    }
+    if (c->hstream) { (void)hipStreamSynchronize(c->hstream); (void)hipStreamDestroy(c->hstream); }
+    if (c->dstream) { (void)hipStreamSynchronize(c->dstream); (void)hipStreamDestroy(c->dstream); }
     if (c->d_in) (void)hipFree(c->d_in);
     if (c->h_in) (void)hipHostFree(c->h_in);
     if (c->d_col) (void)hipFree(c->d_col);
@@ -386,6 +413,13 @@ extern "C" orbhip_status orbhip_level_size(const orbhip_ctx* c, int level, int* 
     return ORBHIP_OK;
 }
 
+extern "C" orbhip_status orbhip_set_blur_rounding(orbhip_ctx* c, int mode)
+{
+    if (!c || (mode != 0 && mode != 1)) return fail(ORBHIP_ERR_INVALID, "blur_round_mode is 0 (generic C++) or 1 (x86 SSE2 build)");
+    c->cfg.blur_round_mode = mode;          // read when the next call's kernel parameters are laid out
+    return ORBHIP_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- pipeline
 static ExtractParams make_params(orbhip_ctx* c, const uint8_t* d_img0, long long frame_stride, int row_stride)
 {
@@ -407,15 +441,54 @@ static ExtractParams make_params(orbhip_ctx* c, const uint8_t* d_img0, long long
     return P;
 }
 
-static orbhip_status run_pipeline(orbhip_ctx* c, int nimg, const uint8_t* d_img0, long long frame_stride, int row_stride,
-                                  int match_prev, int window, float nnratio, int check_ori)
+// pyramid -> FAST -> (quadtree || blur) -> describe for camera slots [f0, f0 + nf) on stream s.  own_blur_stream: the blur only meets
+// the detector again in k_describe, so it runs on the context's blur stream beside the quadtree, whose workgroups are latency-bound
+// (barriers, one per (frame, level)) and leave the VALUs idle.
+static orbhip_status pipeline_frames(orbhip_ctx* c, ExtractParams& P, int f0, int nf, hipStream_t s, bool own_blur_stream)
+{
+    if (nf <= 0) return ORBHIP_OK;
+    P.frame0 = f0;
+    { ProfScope ps(c, K_PYRAMID, s); for (int l = 1; l < c->L; l++) orbhip_launch_pyramid_level(P, l, c->geom[l].w, c->geom[l].h, c->pyr_staged[l] != 0, nf, s); }
+    if (own_blur_stream) {
+        { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nf, s); }
+        hipStream_t bs = c->serial ? s : c->bstream;
+        HIPCHK(hipEventRecord(c->ev_pyr, s)); HIPCHK(hipStreamWaitEvent(bs, c->ev_pyr, 0));
+        { ProfScope ps(c, K_QUADTREE, s); orbhip_launch_quadtree(P, nf, s); }       // enqueued first: its few, long workgroups get CUs before the blur floods them
+        { ProfScope ps(c, K_BLUR, bs); orbhip_launch_blur(P, c->gk, nf, bs); }
+        HIPCHK(hipEventRecord(c->ev_blur, bs));
+        HIPCHK(hipStreamWaitEvent(s, c->ev_blur, 0));
+    } else {
+        { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nf, s); }
+        { ProfScope ps(c, K_BLUR, s); orbhip_launch_blur(P, c->gk, nf, s); }
+        { ProfScope ps(c, K_QUADTREE, s); orbhip_launch_quadtree(P, nf, s); }
+    }
+    { ProfScope ps(c, K_DESCRIBE, s); orbhip_launch_describe(P, nf, s); }
+    if (c->distorted) {   // Frame::UndistortKeyPoints (Frame.cc:404-434) behind the descriptor kernel: mvKeysUn stays in HBM beside mvKeys
+        ProfScope ps(c, K_UNDISTORT, s);
+        orbhip_launch_undistort_keys(c->cam, c->d_out_kp[c->cur] + (size_t)f0 * c->out_cap, c->d_out_n[c->cur] + f0, c->d_out_kpun[c->cur] + (size_t)f0 * c->out_cap, c->out_cap, nf, s);
+    }
+    return ORBHIP_OK;
+}
+
+// a new batch: rotate the output buffers and make the main stream wait for the matcher that still reads the buffer about to be overwritten
+static orbhip_status begin_batch(orbhip_ctx* c, const uint8_t* d_img0, long long frame_stride, int row_stride)
 {
     HIPCHK(hipSetDevice(c->cfg.device));
     c->cur = (c->cur + 1) % 3;
-    const int cur = c->cur, prev = (cur + 2) % 3;
+    const int cur = c->cur;
     c->last_img0 = d_img0; c->last_img0_fstride = frame_stride; c->last_img0_pitch = row_stride; c->d_last_uright = nullptr;
     // the buffer about to be overwritten was the "previous frame" of the matcher launched two calls ago
     for (int k = 0; k < 3; k++) if (c->match_pending[k] && (k == (cur + 1) % 3)) { HIPCHK(hipStreamWaitEvent(c->stream, c->ev_match[k], 0)); c->match_pending[k] = false; }
+    // ... or may still be downloading (a submitted batch that has not been collected while un-ticketed calls rotate the buffers)
+    for (auto& hs : c->sets) if (hs.busy && hs.out_buf == cur && hs.nchunks > 0) HIPCHK(hipStreamWaitEvent(c->stream, hs.ev_d2h[hs.nchunks - 1], 0));
+    return ORBHIP_OK;
+}
+
+static orbhip_status run_pipeline(orbhip_ctx* c, int nimg, const uint8_t* d_img0, long long frame_stride, int row_stride,
+                                  int match_prev, int window, float nnratio, int check_ori)
+{
+    orbhip_status st = begin_batch(c, d_img0, frame_stride, row_stride); if (st != ORBHIP_OK) return st;
+    const int cur = c->cur, prev = (cur + 2) % 3;
     ExtractParams P = make_params(c, d_img0, frame_stride, row_stride);
     // camera slots are independent: optionally split the batch into groups, one HIP stream each
     const int ngroups = std::min((int)c->xstreams.size() + 1, nimg);
@@ -425,29 +498,8 @@ static orbhip_status run_pipeline(orbhip_ctx* c, int nimg, const uint8_t* d_img0
         hipStream_t s = gi == 0 ? c->stream : c->xstreams[gi - 1];
         if (gi > 0) HIPCHK(hipStreamWaitEvent(s, c->ev_fork, 0));
         if (nf <= 0) continue;
-        P.frame0 = f0;
-        { ProfScope ps(c, K_PYRAMID, s); for (int l = 1; l < c->L; l++) orbhip_launch_pyramid_level(P, l, c->geom[l].w, c->geom[l].h, c->pyr_staged[l] != 0, nf, s); }
-        if (ngroups == 1) {
-            // the blur only meets the detector again in k_describe: it runs on its own stream beside the quadtree, whose
-            // workgroups are latency-bound (barriers, one per (frame, level)) and leave the VALUs idle
-            { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nf, s); }
-            hipStream_t bs = c->serial ? s : c->bstream;
-            HIPCHK(hipEventRecord(c->ev_pyr, s)); HIPCHK(hipStreamWaitEvent(bs, c->ev_pyr, 0));
-            { ProfScope ps(c, K_QUADTREE, s); orbhip_launch_quadtree(P, nf, s); }       // enqueued first: its few, long workgroups get CUs before the blur floods them
-            { ProfScope ps(c, K_BLUR, bs); orbhip_launch_blur(P, c->gk, nf, bs); }
-            HIPCHK(hipEventRecord(c->ev_blur, bs));
-            HIPCHK(hipStreamWaitEvent(s, c->ev_blur, 0));
-        } else {
-            { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nf, s); }
-            { ProfScope ps(c, K_BLUR, s); orbhip_launch_blur(P, c->gk, nf, s); }
-            { ProfScope ps(c, K_QUADTREE, s); orbhip_launch_quadtree(P, nf, s); }
-        }
-        { ProfScope ps(c, K_DESCRIBE, s); orbhip_launch_describe(P, nf, s); }
+        st = pipeline_frames(c, P, f0, nf, s, ngroups == 1); if (st != ORBHIP_OK) return st;
         if (gi > 0) { HIPCHK(hipEventRecord(c->xevents[gi - 1], s)); HIPCHK(hipStreamWaitEvent(c->stream, c->xevents[gi - 1], 0)); }
-    }
-    if (c->distorted) {   // Frame::UndistortKeyPoints (Frame.cc:404-434) behind the descriptor kernel: mvKeysUn stays in HBM beside mvKeys
-        ProfScope ps(c, K_UNDISTORT, c->stream);
-        orbhip_launch_undistort_keys(c->cam, c->d_out_kp[cur], c->d_out_n[cur], c->d_out_kpun[cur], c->out_cap, nimg, c->stream);
     }
     if (match_prev) {
         MatchParams M; memset(&M, 0, sizeof M);
@@ -497,6 +549,8 @@ extern "C" orbhip_status orbhip_sync(orbhip_ctx* c)
     for (auto xs : c->xstreams) HIPCHK(hipStreamSynchronize(xs));
     if (c->mstream) HIPCHK(hipStreamSynchronize(c->mstream));
     if (c->bstream) HIPCHK(hipStreamSynchronize(c->bstream));
+    if (c->hstream) HIPCHK(hipStreamSynchronize(c->hstream));
+    if (c->dstream) HIPCHK(hipStreamSynchronize(c->dstream));
     prof_collect(c);
     return ORBHIP_OK;
 }
@@ -567,28 +621,213 @@ extern "C" orbhip_status orbhip_fetch_matches(orbhip_ctx* c, int nimg, int32_t* 
     return ORBHIP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- pipelined host-buffer path
+// A few helper threads for pageable <-> pinned gathers: one core copies ~10 GB/s, a batch of 64 KITTI frames is 30 MB in and
+// 8 MB out, so a single-threaded memcpy alone would cap the host path near 20 k frames/s.  Process-wide, created on first use,
+// never joined (the threads sleep on a condition variable; a dlclose'd library with live threads is the alternative).
+namespace {
+struct CopyJob { std::atomic<int> next{0}, done{0}; int n = 0; std::function<void(int)> fn; };
+class CopyPool {
+    std::mutex m; std::condition_variable cv; std::deque<std::shared_ptr<CopyJob>> q; int nthreads = 0;
+    static void drain(CopyJob& j) { for (int i; (i = j.next.fetch_add(1)) < j.n;) { j.fn(i); j.done.fetch_add(1); } }
+    void worker() {
+        for (;;) {
+            std::shared_ptr<CopyJob> j;
+            { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return !q.empty(); }); j = q.front(); if (j->next.load() >= j->n) { q.pop_front(); continue; } }
+            drain(*j);
+        }
+    }
+public:
+    CopyPool() {
+        const char* e = getenv("ORBHIP_COPY_THREADS");
+        const int hw = (int)std::thread::hardware_concurrency();
+        nthreads = e ? atoi(e) : std::min(8, std::max(hw / 4, 1));
+        for (int i = 0; i + 1 < nthreads; i++) std::thread([this] { worker(); }).detach();       // the calling thread is the n-th copier
+    }
+    static CopyPool& get() { static CopyPool* p = new CopyPool; return *p; }
+    // fn(0) .. fn(n-1), spread over the helpers and the caller; returns when all are done
+    void run(int n, size_t bytes_each, const std::function<void(int)>& fn) {
+        if (n <= 0) return;
+        if (nthreads <= 1 || n == 1 || (size_t)n * bytes_each < (size_t)(1 << 20)) { for (int i = 0; i < n; i++) fn(i); return; }
+        auto j = std::make_shared<CopyJob>(); j->n = n; j->fn = fn;
+        { std::lock_guard<std::mutex> lk(m); q.push_back(j); }
+        cv.notify_all();
+        drain(*j);
+        while (j->done.load() < n) std::this_thread::yield();
+    }
+};
+bool host_pointer_is_pinned(const void* p)
+{
+    hipPointerAttribute_t a; memset(&a, 0, sizeof a);
+    const hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }           // an unregistered pointer is an "error": clear it
+    return a.type == hipMemoryTypeHost;
+}
+}  // namespace
+
+extern "C" void* orbhip_host_alloc(size_t bytes) { void* p = nullptr; return hipHostMalloc(&p, std::max<size_t>(bytes, 1), hipHostMallocDefault) == hipSuccess ? p : nullptr; }
+extern "C" void orbhip_host_free(void* p) { if (p) (void)hipHostFree(p); }
+extern "C" int orbhip_ring_depth(void) { return ORBHIP_RING; }
+
+static orbhip_status ensure_set(orbhip_ctx* c, int si)
+{
+    HostSet& hs = c->sets[si];
+    orbhip_status st = ensure_host_staging(c, true); if (st != ORBHIP_OK) return st;
+    const size_t B = (size_t)c->B;
+    if (!hs.d_in) {
+        if (si == 0) { hs.d_in = c->d_in; hs.h_in = c->h_in; hs.h_kp = c->h_kp; hs.h_desc = c->h_desc; hs.h_n = c->h_n; hs.owned = false; }       // set 0 = the context's own mirrors
+        else {
+            const size_t bytes = B * (size_t)c->in_pitch * c->cfg.height + 256;
+            hs.owned = true;
+            HIPCHK(hipMalloc((void**)&hs.d_in, bytes)); HIPCHK(hipHostMalloc((void**)&hs.h_in, bytes, hipHostMallocDefault));
+            HIPCHK(hipHostMalloc((void**)&hs.h_n, B * sizeof(int), hipHostMallocDefault));
+            HIPCHK(hipHostMalloc((void**)&hs.h_kp, B * c->out_cap * sizeof(orbhip_keypoint), hipHostMallocDefault));
+            HIPCHK(hipHostMalloc((void**)&hs.h_desc, B * c->out_cap * 32, hipHostMallocDefault));
+        }
+    }
+    if (!c->hstream) { HIPCHK(hipStreamCreateWithFlags(&c->hstream, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&c->dstream, hipStreamNonBlocking)); }
+    for (int k = 0; k < ORBHIP_MAX_CHUNKS; k++)
+        if (!hs.ev_d2h[k]) { HIPCHK(hipEventCreateWithFlags(&hs.ev_h2d[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&hs.ev_k[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&hs.ev_d2h[k], hipEventDisableTiming)); }
+    return ORBHIP_OK;
+}
+
+// frames per chunk of a batch: small batches stay one chunk on the main stream (no cross-stream hops: single-frame latency is what
+// the stereo drop-in sees); larger ones are cut so that about eight chunks pipeline through upload / kernels / download
+static int host_chunk_frames(int nimg)
+{
+    const char* e = getenv("ORBHIP_HOST_CHUNK"); const int forced = e ? atoi(e) : 0;          // tuning / test knob: frames per chunk
+    if (forced > 0) return std::max((nimg + ORBHIP_MAX_CHUNKS - 1) / ORBHIP_MAX_CHUNKS, forced);
+    if (nimg < 32) return nimg;
+    const int ch = std::min(std::max(((nimg + 7) / 8 + 7) & ~7, 16), 64);
+    return std::max(ch, (nimg + ORBHIP_MAX_CHUNKS - 1) / ORBHIP_MAX_CHUNKS);
+}
+
+static orbhip_status submit_impl(orbhip_ctx* c, int nimg, const uint8_t* const* imgs, int stride, orbhip_keypoint* direct_kp, uint8_t* direct_desc, int direct_cap, int* ticket)
+{
+    if (nimg < 1 || nimg > c->B) return fail(ORBHIP_ERR_INVALID, "nimg %d outside 1..%d", nimg, c->B);
+    if (stride < c->cfg.width) return fail(ORBHIP_ERR_INVALID, "stride %d < width %d", stride, c->cfg.width);
+    for (int f = 0; f < nimg; f++) if (!imgs[f]) return fail(ORBHIP_ERR_INVALID, "image %d is null", f);
+    HIPCHK(hipSetDevice(c->cfg.device));
+    int si = 0; while (si < ORBHIP_RING && c->sets[si].busy) si++;         // lowest free set: synchronous use never leaves set 0
+    if (si == ORBHIP_RING) return fail(ORBHIP_ERR_INVALID, "ring full: %d batches in flight, collect ticket %d first", ORBHIP_RING, c->oldest_ticket);
+    HostSet& hs = c->sets[si];
+    orbhip_status st = ensure_set(c, si); if (st != ORBHIP_OK) return st;
+    const size_t fbytes = (size_t)c->in_pitch * c->cfg.height;
+    const int W = c->cfg.width, H = c->cfg.height;
+    const int ch = host_chunk_frames(nimg), nch = (nimg + ch - 1) / ch;
+    const bool piped = nch > 1;
+    hipStream_t hst = piped ? c->hstream : c->stream, dst = piped ? c->dstream : c->stream;
+    if (c->plane0_dirty) { HIPCHK(hipStreamSynchronize(c->stream)); c->plane0_dirty = false; }   // kernels of an un-ticketed colour / rectify call may still read set 0's level-0 plane
+    bool pinned_in = true;
+    for (int f = 0; f < nimg && pinned_in; f++) pinned_in = host_pointer_is_pinned(imgs[f]);
+    const bool direct_out = direct_kp && direct_desc && direct_cap > 0 && host_pointer_is_pinned(direct_kp) && host_pointer_is_pinned(direct_desc);
+    hs.direct_kp = direct_out ? direct_kp : nullptr; hs.direct_desc = direct_out ? direct_desc : nullptr; hs.direct_cap = direct_out ? direct_cap : 0;
+
+    st = begin_batch(c, hs.d_in, (long long)fbytes, c->in_pitch); if (st != ORBHIP_OK) return st;
+    c->last_from_host = true; c->last_d_in = hs.d_in;
+    ExtractParams P = make_params(c, hs.d_in, (long long)fbytes, c->in_pitch);
+    hs.nimg = nimg; hs.nchunks = nch;
+    for (int k = 0; k < nch; k++) {
+        const int f0 = k * ch, f1 = std::min(nimg, f0 + ch), nf = f1 - f0;
+        hs.chunk_f0[k] = f0; hs.chunk_f0[k + 1] = f1;
+        // ---- upload
+        if (pinned_in) {
+            for (int f = f0; f < f1; f++) {
+                if (stride == c->in_pitch) HIPCHK(hipMemcpyAsync(hs.d_in + f * fbytes, imgs[f], fbytes, hipMemcpyHostToDevice, hst));
+                else HIPCHK(hipMemcpy2DAsync(hs.d_in + f * fbytes, c->in_pitch, imgs[f], stride, W, H, hipMemcpyHostToDevice, hst));
+            }
+        } else {
+            uint8_t* h_in = hs.h_in; const int in_pitch = c->in_pitch;
+            CopyPool::get().run(nf, fbytes, [=](int i) {
+                const int f = f0 + i; uint8_t* dstp = h_in + f * fbytes;
+                if (stride == in_pitch) memcpy(dstp, imgs[f], fbytes);
+                else for (int y = 0; y < H; y++) memcpy(dstp + (size_t)y * in_pitch, imgs[f] + (size_t)y * stride, W);
+            });
+            HIPCHK(hipMemcpyAsync(hs.d_in + f0 * fbytes, hs.h_in + f0 * fbytes, nf * fbytes, hipMemcpyHostToDevice, hst));
+        }
+        if (piped) { HIPCHK(hipEventRecord(hs.ev_h2d[k], hst)); HIPCHK(hipStreamWaitEvent(c->stream, hs.ev_h2d[k], 0)); }
+        // ---- kernels
+        st = pipeline_frames(c, P, f0, nf, c->stream, true); if (st != ORBHIP_OK) return st;
+        if (piped) { HIPCHK(hipEventRecord(hs.ev_k[k], c->stream)); HIPCHK(hipStreamWaitEvent(dst, hs.ev_k[k], 0)); }
+        // ---- download
+        const int cur = c->cur; const size_t oc = (size_t)c->out_cap;
+        HIPCHK(hipMemcpyAsync(hs.h_n + f0, c->d_out_n[cur] + f0, nf * sizeof(int), hipMemcpyDeviceToHost, dst));
+        if (direct_out) {
+            const size_t m = (size_t)std::min(direct_cap, c->out_cap);
+            if ((size_t)direct_cap == oc) {
+                HIPCHK(hipMemcpyAsync(direct_kp + f0 * oc, c->d_out_kp[cur] + f0 * oc, nf * oc * sizeof(orbhip_keypoint), hipMemcpyDeviceToHost, dst));
+                HIPCHK(hipMemcpyAsync(direct_desc + f0 * oc * 32, c->d_out_desc[cur] + f0 * oc * 32, nf * oc * 32, hipMemcpyDeviceToHost, dst));
+            } else {
+                HIPCHK(hipMemcpy2DAsync(direct_kp + (size_t)f0 * direct_cap, (size_t)direct_cap * sizeof(orbhip_keypoint), c->d_out_kp[cur] + f0 * oc, oc * sizeof(orbhip_keypoint), m * sizeof(orbhip_keypoint), nf, hipMemcpyDeviceToHost, dst));
+                HIPCHK(hipMemcpy2DAsync(direct_desc + (size_t)f0 * direct_cap * 32, (size_t)direct_cap * 32, c->d_out_desc[cur] + f0 * oc * 32, oc * 32, m * 32, nf, hipMemcpyDeviceToHost, dst));
+            }
+        } else {
+            HIPCHK(hipMemcpyAsync(hs.h_kp + f0 * oc, c->d_out_kp[cur] + f0 * oc, nf * oc * sizeof(orbhip_keypoint), hipMemcpyDeviceToHost, dst));
+            HIPCHK(hipMemcpyAsync(hs.h_desc + f0 * oc * 32, c->d_out_desc[cur] + f0 * oc * 32, nf * oc * 32, hipMemcpyDeviceToHost, dst));
+        }
+        HIPCHK(hipEventRecord(hs.ev_d2h[k], dst));
+    }
+    c->last_matched = false; c->last_nimg = nimg;
+    HIPCHK(hipGetLastError());
+    hs.busy = true; hs.out_buf = c->cur; hs.ticket = c->next_ticket++; c->ticket_set[hs.ticket % ORBHIP_RING] = si;
+    if (ticket) *ticket = hs.ticket;
+    return ORBHIP_OK;
+}
+
+// per-frame destinations (NULL = not wanted): what the pool uses to scatter camera c's results straight to its rows
+orbhip_status orbhip_collect_scatter(orbhip_ctx* c, int ticket, orbhip_keypoint* const* kps, uint8_t* const* desc, int cap, int* const* n_out)
+{
+    if (!c || !kps || !desc || !n_out) return fail(ORBHIP_ERR_INVALID, "null argument");
+    if (ticket != c->oldest_ticket || ticket >= c->next_ticket) return fail(ORBHIP_ERR_INVALID, "ticket %d is not the oldest batch in flight (%d; %d submitted)", ticket, c->oldest_ticket, c->next_ticket);
+    HostSet& hs = c->sets[c->ticket_set[ticket % ORBHIP_RING]];
+    HIPCHK(hipSetDevice(c->cfg.device));
+    bool overflow = false;
+    const size_t oc = (size_t)c->out_cap;
+    for (int k = 0; k < hs.nchunks; k++) {
+        HIPCHK(hipEventSynchronize(hs.ev_d2h[k]));
+        const int f0 = hs.chunk_f0[k], nf = hs.chunk_f0[k + 1] - f0;
+        const orbhip_keypoint* h_kp = hs.h_kp; const uint8_t* h_desc = hs.h_desc; const int* h_n = hs.h_n; const bool direct = hs.direct_kp != nullptr;
+        for (int i = 0; i < nf; i++) { const int n = h_n[f0 + i]; if (n_out[f0 + i]) *n_out[f0 + i] = n; if (n > cap) overflow = true; }
+        if (!direct)
+            CopyPool::get().run(nf, oc * 60, [=](int i) {
+                const int f = f0 + i, m = std::min(h_n[f], cap);
+                if (m > 0 && kps[f]) memcpy(kps[f], h_kp + f * oc, (size_t)m * sizeof(orbhip_keypoint));
+                if (m > 0 && desc[f]) memcpy(desc[f], h_desc + f * oc * 32, (size_t)m * 32);
+            });
+    }
+    hs.busy = false; c->oldest_ticket++;
+    return overflow ? fail(ORBHIP_ERR_CAPACITY, "keypoint buffer too small") : ORBHIP_OK;
+}
+
+static orbhip_status collect_flat(orbhip_ctx* c, int ticket, orbhip_keypoint* kps, uint8_t* desc, int cap, int* n_out)
+{
+    if (ticket < 0 || ticket >= c->next_ticket) return fail(ORBHIP_ERR_INVALID, "unknown ticket %d", ticket);
+    const int nimg = c->sets[c->ticket_set[ticket % ORBHIP_RING]].nimg;
+    std::vector<orbhip_keypoint*> pk(nimg); std::vector<uint8_t*> pd(nimg); std::vector<int*> pn(nimg);
+    for (int f = 0; f < nimg; f++) { pk[f] = kps ? kps + (size_t)f * cap : nullptr; pd[f] = desc ? desc + (size_t)f * cap * 32 : nullptr; pn[f] = n_out + f; }
+    return orbhip_collect_scatter(c, ticket, pk.data(), pd.data(), cap, pn.data());
+}
+
+extern "C" orbhip_status orbhip_submit(orbhip_ctx* c, int nimg, const uint8_t* const* imgs, int stride, int* ticket)
+{
+    if (!c || !imgs || !ticket) return fail(ORBHIP_ERR_INVALID, "null argument");
+    return submit_impl(c, nimg, imgs, stride, nullptr, nullptr, 0, ticket);
+}
+extern "C" orbhip_status orbhip_collect(orbhip_ctx* c, int ticket, orbhip_keypoint* kps, uint8_t* desc, int cap, int* n_out)
+{
+    if (!c || !n_out || cap < 0) return fail(ORBHIP_ERR_INVALID, "null argument");
+    return collect_flat(c, ticket, kps, desc, cap, n_out);
+}
+
 extern "C" orbhip_status orbhip_extract_batch(orbhip_ctx* c, int nimg, const uint8_t* const* imgs, int stride, orbhip_keypoint* kps, uint8_t* desc, int cap, int* n_out)
 {
     if (!c || !imgs || !n_out) return fail(ORBHIP_ERR_INVALID, "null argument");
-    if (nimg < 1 || nimg > c->B) return fail(ORBHIP_ERR_INVALID, "nimg %d outside 1..%d", nimg, c->B);
-    if (stride < c->cfg.width) return fail(ORBHIP_ERR_INVALID, "stride %d < width %d", stride, c->cfg.width);
-    HIPCHK(hipSetDevice(c->cfg.device));
-    orbhip_status st = ensure_host_staging(c, true); if (st != ORBHIP_OK) return st;
-    HIPCHK(hipStreamSynchronize(c->stream));                          // the pinned input mirror may still feed the previous call
-    const size_t fbytes = (size_t)c->in_pitch * c->cfg.height;
-    for (int f = 0; f < nimg; f++) {
-        if (!imgs[f]) return fail(ORBHIP_ERR_INVALID, "image %d is null", f);
-        uint8_t* dst = c->h_in + f * fbytes;
-        if (stride == c->in_pitch) memcpy(dst, imgs[f], fbytes);
-        else for (int y = 0; y < c->cfg.height; y++) memcpy(dst + (size_t)y * c->in_pitch, imgs[f] + (size_t)y * stride, c->cfg.width);
-    }
-    c->last_from_host = true;
+    if (c->oldest_ticket != c->next_ticket) return fail(ORBHIP_ERR_INVALID, "orbhip_extract_batch with %d submitted batches still in flight: collect them first", c->next_ticket - c->oldest_ticket);
+    int ticket = -1;
     // (a hipGraph replay of this whole call was measured and is NOT used: 0.52 ms vs 0.31 ms per single-frame call with plain
     //  launches on ROCm 7.2 — see DESIGN.md §5)
-    HIPCHK(hipMemcpyAsync(c->d_in, c->h_in, nimg * fbytes, hipMemcpyHostToDevice, c->stream));
-    st = run_pipeline(c, nimg, c->d_in, (long long)fbytes, c->in_pitch, 0, 0, 0.f, 0);
-    if (st != ORBHIP_OK) return st;
-    return orbhip_fetch(c, nimg, kps, desc, cap, n_out);
+    orbhip_status st = submit_impl(c, nimg, imgs, stride, kps, desc, cap, &ticket); if (st != ORBHIP_OK) return st;
+    return collect_flat(c, ticket, kps, desc, cap, n_out);
 }
 
 // Colour input (Tracking.cc:172-198, 217-229, 248-260 convert with cv::cvtColor before building the Frame): the
@@ -611,7 +850,7 @@ extern "C" orbhip_status orbhip_extract_device_color(orbhip_ctx* c, int nimg, co
     orbhip_launch_to_gray(d_imgs, (long long)frame_stride, row_stride, c->d_in, (long long)fbytes, c->in_pitch, c->cfg.width, c->cfg.height,
                           channels, rgb_order != 0, nimg, c->stream);
     HIPCHK(hipGetLastError());
-    c->last_from_host = true;                                          // level 0 lives in the context's own plane
+    c->last_from_host = true; c->last_d_in = c->d_in; c->plane0_dirty = true;   // level 0 lives in the context's own plane
     return run_pipeline(c, nimg, c->d_in, (long long)fbytes, c->in_pitch, match_prev, window, nnratio, check_ori);
 }
 extern "C" orbhip_status orbhip_extract_batch_color(orbhip_ctx* c, int nimg, const uint8_t* const* imgs, int stride, int channels, int rgb_order,
@@ -660,8 +899,23 @@ extern "C" orbhip_status orbhip_pyramid_level(orbhip_ctx* c, int frame, int leve
     if (!c || !dst || level < 0 || level >= c->L || frame < 0 || frame >= c->last_nimg) return fail(ORBHIP_ERR_INVALID, "bad argument");
     const LevelGeom& g = c->geom[level];
     if (level == 0 && !c->last_from_host) return fail(ORBHIP_ERR_INVALID, "level 0 of a device-resident call is the caller's own buffer");
-    if (level == 0) return copy_plane(c, c->d_in + (size_t)frame * c->in_pitch * c->cfg.height, c->in_pitch, g.w, g.h, dst, dst_stride);
+    if (level == 0) return copy_plane(c, (c->last_d_in ? c->last_d_in : c->d_in) + (size_t)frame * c->in_pitch * c->cfg.height, c->in_pitch, g.w, g.h, dst, dst_stride);
     return copy_plane(c, c->d_pyr + (size_t)frame * c->plane_frame_bytes + g.plane_off, g.pitch, g.w, g.h, dst, dst_stride);
+}
+extern "C" orbhip_status orbhip_pyramid_fetch_all(orbhip_ctx* c, int frame, uint8_t* const* dst, const int* dst_stride)
+{
+    if (!c || !dst || !dst_stride || frame < 0 || frame >= c->last_nimg) return fail(ORBHIP_ERR_INVALID, "bad argument");
+    if (!c->last_from_host) return fail(ORBHIP_ERR_INVALID, "level 0 of a device-resident call is the caller's own buffer");
+    HIPCHK(hipSetDevice(c->cfg.device));
+    if (c->bstream) HIPCHK(hipStreamSynchronize(c->bstream));               // everything that writes the planes is ordered before the main stream's tail
+    for (int l = 0; l < c->L; l++) {
+        if (!dst[l]) continue;
+        const LevelGeom& g = c->geom[l];
+        const uint8_t* src = l == 0 ? (c->last_d_in ? c->last_d_in : c->d_in) + (size_t)frame * c->in_pitch * c->cfg.height : c->d_pyr + (size_t)frame * c->plane_frame_bytes + g.plane_off;
+        HIPCHK(hipMemcpy2DAsync(dst[l], dst_stride[l], src, l == 0 ? c->in_pitch : g.pitch, g.w, g.h, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return ORBHIP_OK;
 }
 extern "C" orbhip_status orbhip_debug_blurred_level(orbhip_ctx* c, int frame, int level, uint8_t* dst, int dst_stride)
 {
@@ -1110,7 +1364,7 @@ extern "C" orbhip_status orbhip_extract_device_rectify(orbhip_ctx* c, int nimg, 
                             c->cfg.width, c->cfg.height, nimg, c->stream);
     }
     HIPCHK(hipGetLastError());
-    c->last_from_host = true;                                          // level 0 lives in the context's own plane
+    c->last_from_host = true; c->last_d_in = c->d_in; c->plane0_dirty = true;   // level 0 lives in the context's own plane
     return run_pipeline(c, nimg, c->d_in, (long long)fbytes, c->in_pitch, match_prev, window, nnratio, check_ori);
 }
 extern "C" orbhip_status orbhip_extract_batch_rectify(orbhip_ctx* c, int nimg, const uint8_t* const* imgs, int stride, orbhip_keypoint* kps, uint8_t* desc, int cap, int* n_out)
@@ -1144,14 +1398,19 @@ extern "C" int orbhip_descriptor_distance(const uint8_t* a, const uint8_t* b)
     return __builtin_popcountll(x[0] ^ y[0]) + __builtin_popcountll(x[1] ^ y[1]) + __builtin_popcountll(x[2] ^ y[2]) + __builtin_popcountll(x[3] ^ y[3]);
 }
 
-static thread_local void* g_nn_ws = nullptr; static thread_local size_t g_nn_ws_bytes = 0;
+// Partials of the brute-force scan: a per-thread, grow-only buffer tied to the device it was allocated on and to the stream that used it
+// last (a second stream of the same thread waits for the first before it reuses the buffer).
+static thread_local void* g_nn_ws = nullptr; static thread_local size_t g_nn_ws_bytes = 0; static thread_local int g_nn_ws_dev = -1; static thread_local hipStream_t g_nn_ws_stream = nullptr;
 void* orbhip_nn_workspace(size_t bytes, hipStream_t s)
 {
-    if (bytes > g_nn_ws_bytes) {
-        if (g_nn_ws) { (void)hipStreamSynchronize(s); (void)hipFree(g_nn_ws); g_nn_ws = nullptr; g_nn_ws_bytes = 0; }
-        if (hipMalloc(&g_nn_ws, bytes) != hipSuccess) { g_nn_ws = nullptr; return nullptr; }
-        g_nn_ws_bytes = bytes;
+    int dev = -1; if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    if (g_nn_ws && g_nn_ws_dev == dev && g_nn_ws_stream != s) (void)hipStreamSynchronize(g_nn_ws_stream);
+    if (g_nn_ws_dev != dev || bytes > g_nn_ws_bytes) {
+        if (g_nn_ws) { const int cur = dev; (void)hipSetDevice(g_nn_ws_dev); (void)hipStreamSynchronize(g_nn_ws_stream); (void)hipFree(g_nn_ws); (void)hipSetDevice(cur); g_nn_ws = nullptr; g_nn_ws_bytes = 0; }
+        if (hipMalloc(&g_nn_ws, bytes) != hipSuccess) { (void)hipGetLastError(); g_nn_ws = nullptr; g_nn_ws_dev = -1; return nullptr; }
+        g_nn_ws_bytes = bytes; g_nn_ws_dev = dev;
     }
+    g_nn_ws_stream = s;
     return g_nn_ws;
 }
 
@@ -1159,7 +1418,7 @@ extern "C" orbhip_status orbhip_hamming_nn_device(void* stream, const uint8_t* d
                                                   int64_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second)
 {
     if (nq < 0 || ndb < 0 || (nq > 0 && (!d_q || !d_best_idx || !d_best_dist || !d_second)) || (ndb > 0 && !d_db)) return fail(ORBHIP_ERR_INVALID, "bad argument");
-    orbhip_launch_hamming_nn(d_q, nq, d_db, ndb, base, (long long*)d_best_idx, d_best_dist, d_second, (hipStream_t)stream);
+    if (!orbhip_launch_hamming_nn(d_q, nq, d_db, ndb, base, (long long*)d_best_idx, d_best_dist, d_second, (hipStream_t)stream)) return fail(ORBHIP_ERR_HIP, "hamming_nn: no device memory for the scan partials");
     HIPCHK(hipGetLastError());
     return ORBHIP_OK;
 }
@@ -1181,7 +1440,7 @@ extern "C" orbhip_status orbhip_hamming_nn(int device, const uint8_t* q, int nq,
     if (e == hipSuccess) e = hipMalloc((void**)&dsd, (size_t)nq * 4);
     if (e == hipSuccess) e = hipMemcpy(dq, q, (size_t)nq * 32, hipMemcpyHostToDevice);
     if (e == hipSuccess && ndb > 0) e = hipMemcpy(ddb, db, (size_t)ndb * 32, hipMemcpyHostToDevice);
-    if (e == hipSuccess) { orbhip_launch_hamming_nn(dq, nq, ddb, ndb, base, dbi, dbd, dsd, nullptr); e = hipGetLastError(); }
+    if (e == hipSuccess) { e = orbhip_launch_hamming_nn(dq, nq, ddb, ndb, base, dbi, dbd, dsd, nullptr) ? hipGetLastError() : hipErrorOutOfMemory; }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemcpy(best_idx, dbi, (size_t)nq * 8, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(best_dist, dbd, (size_t)nq * 4, hipMemcpyDeviceToHost);
@@ -1260,4 +1519,35 @@ extern "C" orbhip_status orbhip_search_for_initialization(int device, const orbh
 {
     orbhip_bounds b; if (!whole_image(im_w, im_h, &b)) return fail(ORBHIP_ERR_INVALID, "bad argument");
     return orbhip_search_for_initialization_bounds(device, kps1, desc1, n1, kps2, desc2, n2, &b, prev_matched, matches12, window, nnratio, check_ori, nmatches);
+}
+
+// ---------------------------------------------------------------------------------------------- relocalisation candidates
+// Stands where Tracking::Relocalization asks KeyFrameDatabase::DetectRelocalizationCandidates for key frames that share words with the
+// frame (Tracking.cc:1344-1348, KeyFrameDatabase.cc:199-309): here the evidence is the brute-force nearest neighbour of every query
+// descriptor over the descriptors of ALL key frames (BASELINE.json config 5), filtered with the matcher's own acceptance idiom
+// (distance threshold + ratio to the second best, ORBmatcher.cc:102-114), one vote per accepted descriptor for the owning key frame.
+extern "C" orbhip_status orbhip_reloc_candidates(const int64_t* best_idx, const int32_t* best_dist, const int32_t* second_dist, int nq,
+                                                 const int32_t* row_keyframe, int64_t ndb, int nkf, int th_dist, float ratio,
+                                                 int top_k, int32_t* kf_out, int32_t* votes_out, int* nout)
+{
+    if (nq < 0 || ndb < 0 || nkf < 0 || top_k < 0 || !nout || (nq > 0 && (!best_idx || !best_dist || !second_dist)) || (ndb > 0 && !row_keyframe) || (top_k > 0 && (!kf_out || !votes_out)))
+        return fail(ORBHIP_ERR_INVALID, "bad argument");
+    *nout = 0;
+    std::vector<int> votes((size_t)std::max(nkf, 1), 0);
+    for (int i = 0; i < nq; i++) {
+        const int64_t r = best_idx[i];
+        if (r < 0 || r >= ndb) continue;
+        if (best_dist[i] > th_dist) continue;
+        if (!((float)best_dist[i] < ratio * (float)second_dist[i])) continue;
+        const int kf = row_keyframe[r];
+        if (kf < 0 || kf >= nkf) return fail(ORBHIP_ERR_INVALID, "row %lld belongs to key frame %d outside 0..%d", (long long)r, kf, nkf - 1);
+        votes[kf]++;
+    }
+    std::vector<int> order; order.reserve(nkf);
+    for (int k = 0; k < nkf; k++) if (votes[k] > 0) order.push_back(k);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return votes[a] > votes[b]; });      // ties keep ascending key frame id
+    const int m = std::min<int>(top_k, (int)order.size());
+    for (int i = 0; i < m; i++) { kf_out[i] = order[i]; votes_out[i] = votes[order[i]]; }
+    *nout = m;
+    return ORBHIP_OK;
 }

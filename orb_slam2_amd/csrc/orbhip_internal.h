@@ -137,6 +137,8 @@ void orbhip_launch_describe(const ExtractParams& P, int nframes, hipStream_t s);
 size_t orbhip_quadtree_lds_bytes(int maxn, int maxcells);
 int orbhip_quadtree_scr(int maxn, int maxcells);
 void* orbhip_nn_workspace(size_t bytes, hipStream_t s);
+// orbhip_collect with one destination per frame (NULL = not wanted): the pool scatters camera c's results straight to row c
+orbhip_status orbhip_collect_scatter(orbhip_ctx* c, int ticket, orbhip_keypoint* const* kps, uint8_t* const* desc, int cap, int* const* n_out);
 
 // camera geometry kernels (orbhip_kernels_geom.hip)
 struct CameraD { double fx, fy, cx, cy, ifx, ify, k1, k2, p1, p2, k3; };       // mK / mDistCoef widened like cvUndistortPoints does
@@ -147,7 +149,7 @@ void orbhip_launch_stereo_from_rgbd(const orbhip_keypoint* kp, const orbhip_keyp
 void orbhip_launch_remap(const uint8_t* src, long long src_frame_stride, int src_row_stride, int src_w, int src_h, const int* qx, const int* qy, int q_pitch,
                          uint8_t* dst, long long dst_frame_stride, int dst_pitch, int w, int h, int nframes, hipStream_t s);
 
-void orbhip_launch_hamming_nn(const uint8_t* d_q, int nq, const uint8_t* d_db, long long ndb, long long base,
+bool orbhip_launch_hamming_nn(const uint8_t* d_q, int nq, const uint8_t* d_db, long long ndb, long long base,
                               long long* d_best_idx, int* d_best_dist, int* d_second, hipStream_t s);
 void orbhip_launch_match_grid(const MatchParams& M, int nslots, hipStream_t s);
 void orbhip_launch_match_candidates(const MatchParams& M, int nslots, hipStream_t s);

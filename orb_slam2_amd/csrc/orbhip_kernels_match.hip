@@ -95,17 +95,18 @@ __global__ __launch_bounds__(256) void k_hamming_merge(const NNPart* parts, int 
 
 // workspace for the partials lives in a small per-thread cache owned by the API layer
 
-void orbhip_launch_hamming_nn(const uint8_t* d_q, int nq, const uint8_t* d_db, long long ndb, long long base,
+bool orbhip_launch_hamming_nn(const uint8_t* d_q, int nq, const uint8_t* d_db, long long ndb, long long base,
                               long long* d_best_idx, int* d_best_dist, int* d_second, hipStream_t s)
 {
-    if (nq <= 0) return;
+    if (nq <= 0) return true;
     const int nchunks = (int)max(1LL, (ndb + NN_CHUNK - 1) / NN_CHUNK);
     NNPart* parts = (NNPart*)orbhip_nn_workspace(sizeof(NNPart) * (size_t)nq * nchunks, s);
-    if (!parts) return;
+    if (!parts) return false;                                    // the caller reports it: results would be left unwritten
     const int qblocks = (nq + NN_T * NN_QPT - 1) / (NN_T * NN_QPT);
     hipLaunchKernelGGL(k_hamming_nn, dim3(qblocks, nchunks, 1), dim3(NN_T, 1, 1), 0, s, (const unsigned long long*)d_q, nq,
                        (const unsigned long long*)d_db, ndb, base, parts, nchunks);
     hipLaunchKernelGGL(k_hamming_merge, dim3((nq + 3) / 4, 1, 1), dim3(256, 1, 1), 0, s, (const NNPart*)parts, nq, nchunks, d_best_idx, d_best_dist, d_second);
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------------ frame grid

@@ -33,6 +33,10 @@ SYMBOLS = [
     "orbhip_search_for_initialization_bounds", "orbhip_search_by_projection_bounds", "orbhip_search_best_in_window_bounds",
     "orbhip_set_rectification", "orbhip_extract_batch_rectify", "orbhip_extract_device_rectify", "orbhip_compute_stereo_from_rgbd",
     "orbhip_search_by_projection_frame", "orbhip_search_best_in_window_frame",
+    "orbhip_pyramid_fetch_all", "orbhip_set_blur_rounding", "orbhip_submit", "orbhip_collect", "orbhip_ring_depth", "orbhip_host_alloc", "orbhip_host_free",
+    "orbhip_pool_create", "orbhip_pool_destroy", "orbhip_pool_num_devices", "orbhip_pool_device_of", "orbhip_pool_keypoint_capacity",
+    "orbhip_pool_extract", "orbhip_pool_submit", "orbhip_pool_collect", "orbhip_pool_db_load", "orbhip_pool_db_shard", "orbhip_pool_db_query",
+    "orbhip_reloc_candidates",
 ]
 
 
@@ -153,6 +157,28 @@ def lib(path=None):
     L.orbhip_algorithmic_bytes_per_frame_kernel.restype = C.c_int64
     L.orbhip_debug_blurred_level.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
     L.orbhip_debug_candidates.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, ip]
+    L.orbhip_pyramid_fetch_all.argtypes = [vp, C.c_int, vp, vp]
+    L.orbhip_set_blur_rounding.argtypes = [vp, C.c_int]
+    L.orbhip_submit.argtypes = [vp, C.c_int, vp, C.c_int, ip]
+    L.orbhip_collect.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp]
+    L.orbhip_host_alloc.argtypes = [C.c_size_t]
+    L.orbhip_host_alloc.restype = vp
+    L.orbhip_host_free.argtypes = [vp]
+    L.orbhip_host_free.restype = None
+    L.orbhip_pool_create.argtypes = [C.POINTER(vp), vp, C.c_int, C.POINTER(Config), C.c_int]
+    L.orbhip_pool_destroy.argtypes = [vp]
+    L.orbhip_pool_destroy.restype = None
+    L.orbhip_pool_num_devices.argtypes = [vp]
+    L.orbhip_pool_device_of.argtypes = [vp, C.c_int]
+    L.orbhip_pool_keypoint_capacity.argtypes = [vp]
+    L.orbhip_pool_extract.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, vp]
+    L.orbhip_pool_submit.argtypes = [vp, vp, C.c_int, ip]
+    L.orbhip_pool_collect.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp]
+    L.orbhip_pool_db_load.argtypes = [vp, vp, C.c_int64]
+    L.orbhip_pool_db_shard.argtypes = [vp, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.orbhip_pool_db_shard.restype = None
+    L.orbhip_pool_db_query.argtypes = [vp, vp, C.c_int, vp, vp, vp]
+    L.orbhip_reloc_candidates.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_int, vp, vp, ip]
     _libs[path] = L
     return L
 
@@ -206,7 +232,7 @@ class ORBextractor:
         n = self.nlevels
         sf, isf, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
         fpl = np.zeros(n, np.int32)
-        _check(self.L.orbhip_get_scale_tables(self.h, _p(sf), _p(isf), _p(s2), _p(is2), _p(fpl)), "orbhip_get_scale_tables")
+        _check(self.L.orbhip_get_scale_tables(self.h, _p(sf), _p(isf), _p(s2), _p(is2), _p(fpl)), "orbhip_get_scale_tables", self.L)
         return sf, isf, s2, is2, fpl
 
     def GetScaleFactors(self):
@@ -226,8 +252,12 @@ class ORBextractor:
 
     def level_size(self, level):
         w, h = C.c_int(), C.c_int()
-        _check(self.L.orbhip_level_size(self.h, level, C.byref(w), C.byref(h)), "orbhip_level_size")
+        _check(self.L.orbhip_level_size(self.h, level, C.byref(w), C.byref(h)), "orbhip_level_size", self.L)
         return w.value, h.value
+
+    def SetBlurRounding(self, mode):
+        """cv::GaussianBlur's last rounding: 0 = OpenCV generic C++, 1 = the SSE2 column filter of x86-64 builds (DESIGN.md H2)"""
+        _check(self.L.orbhip_set_blur_rounding(self.h, int(mode)), "orbhip_set_blur_rounding", self.L)
 
     # ---- operator()
     def __call__(self, image, mask=None):
@@ -248,7 +278,33 @@ class ORBextractor:
         kps = np.zeros((n, cap), KEYPOINT_DTYPE)
         desc = np.zeros((n, cap, 32), np.uint8)
         nout = np.zeros(n, np.int32)
-        _check(self.L.orbhip_extract_batch(self.h, n, ptrs, self.width, _p(kps), _p(desc), cap, _p(nout)), "orbhip_extract_batch")
+        _check(self.L.orbhip_extract_batch(self.h, n, ptrs, self.width, _p(kps), _p(desc), cap, _p(nout)), "orbhip_extract_batch", self.L)
+        return [kps[f, :nout[f]].copy() for f in range(n)], [desc[f, :nout[f]].copy() for f in range(n)]
+
+    # ---- pipelined host path: up to ring_depth() batches in flight (orbhip_submit / orbhip_collect)
+    def submit(self, images):
+        """Stage + upload `images` and enqueue their extraction; returns a ticket for collect().  Pageable images are consumed when this
+        returns; pinned ones (pinned_array) are read by DMA until the ticket is collected."""
+        n = len(images)
+        assert 1 <= n <= self.max_batch
+        imgs = [np.ascontiguousarray(im, np.uint8) for im in images]
+        for im in imgs:
+            assert im.shape == (self.height, self.width), (im.shape, (self.height, self.width))
+        ptrs = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
+        t = C.c_int(-1)
+        _check(self.L.orbhip_submit(self.h, n, ptrs, self.width, C.byref(t)), "orbhip_submit", self.L)
+        self._inflight = getattr(self, "_inflight", {})
+        self._inflight[t.value] = (n, imgs)                       # keeps the (possibly pinned) sources alive until collect
+        return t.value
+
+    def collect(self, ticket, out=None):
+        """Results of a submitted batch (tickets in submission order): ([keypoints], [descriptors]).  out = (kps, desc, nout) buffers to reuse."""
+        n, _ = self._inflight.pop(ticket)
+        cap = self.capacity
+        kps, desc, nout = out if out is not None else (np.zeros((n, cap), KEYPOINT_DTYPE), np.zeros((n, cap, 32), np.uint8), np.zeros(n, np.int32))
+        _check(self.L.orbhip_collect(self.h, ticket, _p(kps), _p(desc), cap, _p(nout)), "orbhip_collect", self.L)
+        if out is not None:
+            return nout
         return [kps[f, :nout[f]].copy() for f in range(n)], [desc[f, :nout[f]].copy() for f in range(n)]
 
     def extract_batch_color(self, images, rgb=True):
@@ -266,7 +322,7 @@ class ORBextractor:
         desc = np.zeros((n, cap, 32), np.uint8)
         nout = np.zeros(n, np.int32)
         _check(self.L.orbhip_extract_batch_color(self.h, n, ptrs, self.width * ch, ch, int(rgb), _p(kps), _p(desc), cap, _p(nout)),
-               "orbhip_extract_batch_color")
+               "orbhip_extract_batch_color", self.L)
         return [kps[f, :nout[f]].copy() for f in range(n)], [desc[f, :nout[f]].copy() for f in range(n)]
 
     # ---- distorted cameras / rectification
@@ -351,28 +407,28 @@ class ORBextractor:
     def mvImagePyramid(self, level, frame=0):
         w, h = self.level_size(level)
         out = np.zeros((h, w), np.uint8)
-        _check(self.L.orbhip_pyramid_level(self.h, frame, level, _p(out), w), "orbhip_pyramid_level")
+        _check(self.L.orbhip_pyramid_level(self.h, frame, level, _p(out), w), "orbhip_pyramid_level", self.L)
         return out
 
     # ---- device-resident pipeline
     def extract_device(self, dptr, nimg, frame_stride, row_stride, match_prev=False, window=100, nnratio=0.9, check_ori=True):
         _check(self.L.orbhip_extract_device(self.h, nimg, C.c_void_p(dptr), frame_stride, row_stride, int(match_prev), window,
-                                            nnratio, int(check_ori)), "orbhip_extract_device")
+                                            nnratio, int(check_ori)), "orbhip_extract_device", self.L)
 
     def extract_device_color(self, dptr, nimg, frame_stride, row_stride, channels, rgb=True, match_prev=False, window=100,
                              nnratio=0.9, check_ori=True):
         _check(self.L.orbhip_extract_device_color(self.h, nimg, C.c_void_p(dptr), frame_stride, row_stride, channels, int(rgb),
-                                                  int(match_prev), window, nnratio, int(check_ori)), "orbhip_extract_device_color")
+                                                  int(match_prev), window, nnratio, int(check_ori)), "orbhip_extract_device_color", self.L)
 
     def sync(self):
-        _check(self.L.orbhip_sync(self.h), "orbhip_sync")
+        _check(self.L.orbhip_sync(self.h), "orbhip_sync", self.L)
 
     def fetch(self, nimg):
         cap = self.capacity
         kps = np.zeros((nimg, cap), KEYPOINT_DTYPE)
         desc = np.zeros((nimg, cap, 32), np.uint8)
         nout = np.zeros(nimg, np.int32)
-        _check(self.L.orbhip_fetch(self.h, nimg, _p(kps), _p(desc), cap, _p(nout)), "orbhip_fetch")
+        _check(self.L.orbhip_fetch(self.h, nimg, _p(kps), _p(desc), cap, _p(nout)), "orbhip_fetch", self.L)
         return [kps[f, :nout[f]].copy() for f in range(nimg)], [desc[f, :nout[f]].copy() for f in range(nimg)]
 
     def fetch_matches(self, nimg):
@@ -380,7 +436,7 @@ class ORBextractor:
         m12 = np.full((nimg, cap), -1, np.int32)
         n1 = np.zeros(nimg, np.int32)
         nm = np.zeros(nimg, np.int32)
-        _check(self.L.orbhip_fetch_matches(self.h, nimg, _p(m12), cap, _p(n1), _p(nm)), "orbhip_fetch_matches")
+        _check(self.L.orbhip_fetch_matches(self.h, nimg, _p(m12), cap, _p(n1), _p(nm)), "orbhip_fetch_matches", self.L)
         return [m12[f, :n1[f]].copy() for f in range(nimg)], nm
 
     # ---- Frame::ComputeStereoMatches (this extractor = left camera)
@@ -394,16 +450,16 @@ class ORBextractor:
 
     # ---- measurement / stage dumps
     def profile_enable(self, on=True):
-        _check(self.L.orbhip_profile_enable(self.h, int(on)), "orbhip_profile_enable")
+        _check(self.L.orbhip_profile_enable(self.h, int(on)), "orbhip_profile_enable", self.L)
 
     def profile_reset(self):
-        _check(self.L.orbhip_profile_reset(self.h), "orbhip_profile_reset")
+        _check(self.L.orbhip_profile_reset(self.h), "orbhip_profile_reset", self.L)
 
     def profile(self):
         out = {}
         for k in range(self.L.orbhip_profile_num_kernels(self.h)):
             name, ms, n = C.c_char_p(), C.c_double(), C.c_int64()
-            _check(self.L.orbhip_profile_get(self.h, k, C.byref(name), C.byref(ms), C.byref(n)), "orbhip_profile_get")
+            _check(self.L.orbhip_profile_get(self.h, k, C.byref(name), C.byref(ms), C.byref(n)), "orbhip_profile_get", self.L)
             out[name.value.decode()] = dict(index=k, total_ms=ms.value, launches=n.value,
                                             alg_bytes_per_frame=self.L.orbhip_algorithmic_bytes_per_frame_kernel(self.h, k))
         return out
@@ -414,15 +470,127 @@ class ORBextractor:
     def blurred_level(self, level, frame=0):
         w, h = self.level_size(level)
         out = np.zeros((h, w), np.uint8)
-        _check(self.L.orbhip_debug_blurred_level(self.h, frame, level, _p(out), w), "orbhip_debug_blurred_level")
+        _check(self.L.orbhip_debug_blurred_level(self.h, frame, level, _p(out), w), "orbhip_debug_blurred_level", self.L)
         return out
 
     def candidates(self, level, frame=0):
         n = C.c_int()
-        _check(self.L.orbhip_debug_candidates(self.h, frame, level, None, 0, C.byref(n)), "orbhip_debug_candidates")
+        _check(self.L.orbhip_debug_candidates(self.h, frame, level, None, 0, C.byref(n)), "orbhip_debug_candidates", self.L)
         out = np.zeros((max(n.value, 1), 3), np.int32)
-        _check(self.L.orbhip_debug_candidates(self.h, frame, level, _p(out), n.value, C.byref(n)), "orbhip_debug_candidates")
+        _check(self.L.orbhip_debug_candidates(self.h, frame, level, _p(out), n.value, C.byref(n)), "orbhip_debug_candidates", self.L)
         return out[:n.value].copy()
+
+
+def pinned_array(shape, dtype=np.uint8, library=None):
+    """A numpy array in pinned host memory (orbhip_host_alloc): images handed over in such arrays and result buffers of this kind are
+    moved by DMA directly, without the staging copy.  The memory is released when the array (and every view of it) is gone."""
+    L = lib(library)
+    dt = np.dtype(dtype)
+    nbytes = int(np.prod(shape)) * dt.itemsize
+    ptr = L.orbhip_host_alloc(max(nbytes, 1))
+    if not ptr:
+        raise OrbHipError("orbhip_host_alloc failed")
+
+    class _Owner:
+        def __del__(self, L=L, ptr=ptr):
+            L.orbhip_host_free(ptr)
+    buf = (C.c_uint8 * max(nbytes, 1)).from_address(ptr)
+    arr = np.frombuffer(buf, dtype=np.uint8, count=nbytes).view(dt).reshape(shape)
+    buf._owner = _Owner()                                         # the ctypes buffer is the array's base: the owner lives as long as it does
+    return arr
+
+
+class MultiGpuExtractor:
+    """One node, G GPUs (orbhip_pool_*): camera c is served by devices[c mod G] — one context, one host thread and one pinned staging
+    ring per device, no collective.  Also owns the row-sharded descriptor DB of the relocalisation query (BASELINE.json config 5).
+    The reference's analogue is the pair of extractor threads of the stereo Frame constructor (Frame.cc:78-81)."""
+
+    def __init__(self, devices, ncameras, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, width, height, blur_round_mode=0, library=None):
+        self.L = lib(library)
+        self.devices = [int(d) for d in devices]
+        self.ncameras, self.width, self.height = ncameras, width, height
+        cfg = Config(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, width, height, 1, 0, None, blur_round_mode, 1)
+        devs = (C.c_int * len(self.devices))(*self.devices)
+        self.h = C.c_void_p()
+        _check(self.L.orbhip_pool_create(C.byref(self.h), devs, len(self.devices), C.byref(cfg), ncameras), "orbhip_pool_create", self.L)
+        self.capacity = self.L.orbhip_pool_keypoint_capacity(self.h)
+        self._inflight = {}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.orbhip_pool_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_of(self, camera):
+        return self.L.orbhip_pool_device_of(self.h, camera)
+
+    def _ptrs(self, images):
+        assert len(images) == self.ncameras
+        imgs = [None if im is None else np.ascontiguousarray(im, np.uint8) for im in images]
+        for im in imgs:
+            assert im is None or im.shape == (self.height, self.width)
+        return imgs, (C.c_void_p * self.ncameras)(*[None if im is None else im.ctypes.data for im in imgs])
+
+    def _outputs(self):
+        return np.zeros((self.ncameras, self.capacity), KEYPOINT_DTYPE), np.zeros((self.ncameras, self.capacity, 32), np.uint8), np.zeros(self.ncameras, np.int32)
+
+    def extract(self, images):
+        """One frame per camera (None = no frame this round) -> ([keypoints], [descriptors]) per camera"""
+        imgs, ptrs = self._ptrs(images)
+        kps, desc, nout = self._outputs()
+        _check(self.L.orbhip_pool_extract(self.h, ptrs, self.width, _p(kps), _p(desc), self.capacity, _p(nout)), "orbhip_pool_extract", self.L)
+        return [kps[c, :nout[c]].copy() for c in range(self.ncameras)], [desc[c, :nout[c]].copy() for c in range(self.ncameras)]
+
+    def submit(self, images):
+        imgs, ptrs = self._ptrs(images)
+        t = C.c_int(-1)
+        _check(self.L.orbhip_pool_submit(self.h, ptrs, self.width, C.byref(t)), "orbhip_pool_submit", self.L)
+        self._inflight[t.value] = imgs
+        return t.value
+
+    def collect(self, ticket, out=None):
+        self._inflight.pop(ticket)
+        kps, desc, nout = out if out is not None else self._outputs()
+        _check(self.L.orbhip_pool_collect(self.h, ticket, _p(kps), _p(desc), self.capacity, _p(nout)), "orbhip_pool_collect", self.L)
+        if out is not None:
+            return nout
+        return [kps[c, :nout[c]].copy() for c in range(self.ncameras)], [desc[c, :nout[c]].copy() for c in range(self.ncameras)]
+
+    # ---- descriptor DB sharded by contiguous row ranges (config 5)
+    def db_load(self, db):
+        db = np.ascontiguousarray(db, np.uint8)
+        assert db.ndim == 2 and db.shape[1] == 32
+        _check(self.L.orbhip_pool_db_load(self.h, _p(db), len(db)), "orbhip_pool_db_load", self.L)
+        self.ndb = len(db)
+
+    def db_shard(self, r):
+        lo, hi = C.c_int64(), C.c_int64()
+        self.L.orbhip_pool_db_shard(self.h, r, C.byref(lo), C.byref(hi))
+        return lo.value, hi.value
+
+    def db_query(self, q):
+        q = np.ascontiguousarray(q, np.uint8)
+        bi = np.zeros(len(q), np.int64); bd = np.zeros(len(q), np.int32); sd = np.zeros(len(q), np.int32)
+        _check(self.L.orbhip_pool_db_query(self.h, _p(q), len(q), _p(bi), _p(bd), _p(sd)), "orbhip_pool_db_query", self.L)
+        return bi, bd, sd
+
+
+def reloc_candidates(best_idx, best_dist, second_dist, row_keyframe, nkf, th_dist=50, ratio=0.75, top_k=10, library=None):
+    """Top-k key frames by accepted nearest-neighbour votes (orbhip_reloc_candidates): the relocalisation candidate source that stands
+    where Tracking::Relocalization calls DetectRelocalizationCandidates (Tracking.cc:1344-1348).  -> (keyframe ids, votes)"""
+    L = lib(library)
+    bi = np.ascontiguousarray(best_idx, np.int64); bd = np.ascontiguousarray(best_dist, np.int32); sd = np.ascontiguousarray(second_dist, np.int32)
+    rk = np.ascontiguousarray(row_keyframe, np.int32)
+    kf = np.zeros(max(top_k, 1), np.int32); votes = np.zeros(max(top_k, 1), np.int32); n = C.c_int(0)
+    _check(L.orbhip_reloc_candidates(_p(bi), _p(bd), _p(sd), len(bi), _p(rk), len(rk), nkf, th_dist, ratio, top_k, _p(kf), _p(votes), C.byref(n)),
+           "orbhip_reloc_candidates", L)
+    return kf[:n.value].copy(), votes[:n.value].copy()
 
 
 class ORBmatcher:
@@ -508,7 +676,7 @@ def hamming_nn(q, db, device=0, index_base=0, library=None):
 def hamming_nn_device(stream, d_q, nq, d_db, ndb, d_best_idx, d_best_dist, d_second, index_base=0, library=None):
     _check(lib(library).orbhip_hamming_nn_device(C.c_void_p(stream) if stream else None, C.c_void_p(d_q), nq, C.c_void_p(d_db), ndb,
                                           index_base, C.c_void_p(d_best_idx), C.c_void_p(d_best_dist), C.c_void_p(d_second)),
-           "orbhip_hamming_nn_device")
+           "orbhip_hamming_nn_device", self.L)
 
 
 class ORBVocabulary:

@@ -222,7 +222,12 @@ inline int min(int a, unsigned b) { return a < (int)b ? a : (int)b; }
 // ---- host API
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
-inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+// HIPEMU_DEVICE_COUNT=n: pretend n devices (all of them this process's heap) so that the multi-device host logic runs on CPU
+inline hipError_t hipGetDeviceCount(int* n) { const char* e = getenv("HIPEMU_DEVICE_COUNT"); *n = e ? std::max(atoi(e), 1) : 1; return hipSuccess; }
+enum hipMemoryType { hipMemoryTypeUnregistered = 0, hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2 };
+struct hipPointerAttribute_t { hipMemoryType type; int device; };
+// HIPEMU_ALL_PINNED=1: every host pointer counts as pinned (exercises the direct-DMA branches of the host path)
+inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void*) { const char* e = getenv("HIPEMU_ALL_PINNED"); if (e && e[0] == '1') { a->type = hipMemoryTypeHost; a->device = 0; return hipSuccess; } return hipErrorInvalidValue; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { memset(p, 0, sizeof(*p)); strcpy(p->name, "hipemu (CPU fibers, test only)"); strcpy(p->gcnArchName, "emu"); p->multiProcessorCount = 1; return hipSuccess; }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 template <typename T> inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }

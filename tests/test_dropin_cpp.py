@@ -15,7 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CPP = os.path.join(ROOT, "tests", "cpp")
 
 
-def _run(exe, tmp_path, oracle, threads=False):
+def _run(exe, tmp_path, oracle, threads=False, blur=None):
+    """blur: ORBHIP_BLUR_ROUNDING for the classes (None = their own default: the x86 SSE2 rounding on this host)"""
     w, h, n = 400, 300, 500
     seq = synth.sequence(w, h, 2, seed=31)
     for k in range(2):
@@ -28,7 +29,9 @@ def _run(exe, tmp_path, oracle, threads=False):
     my = (h / 2 + (np.sin(th) * (xx - w / 2) + np.cos(th) * (yy - h / 2)) * 1.03 - 1.4).astype(np.float32)
     np.concatenate([mx.ravel(), my.ravel()]).tofile(str(tmp_path / "maps.bin"))
     subprocess.check_call([exe, str(w), str(h), str(n), str(tmp_path / "in0.raw"), str(tmp_path / "in1.raw"), str(out), voc_path, ("threads" if threads is True else f"threads{threads}") if threads else "-",
-                           str(tmp_path / "maps.bin")])
+                           str(tmp_path / "maps.bin")], env=dict(os.environ, **({} if blur is None else {"ORBHIP_BLUR_ROUNDING": str(blur)})))
+    blur = 1 if blur is None else blur                     # this container and the GPU box are x86-64
+    mk = lambda: oracle.OracleExtractor(n, 1.2, 8, 20, 7, blur_round_mode=blur)
     buf = out.read_bytes()
     off = 0
     frames = []
@@ -84,7 +87,7 @@ def _run(exe, tmp_path, oracle, threads=False):
     dr = np.frombuffer(buf, np.uint8, 32 * nr, off).reshape(nr, 32); off += 32 * nr
     rect0 = np.frombuffer(buf, np.uint8, w * h, off).reshape(h, w); off += w * h
 
-    ora = oracle.OracleExtractor(n, 1.2, 8, 20, 7)
+    ora = mk()
     ref = [ora.extract(im) for im in seq]
     for f in range(2):
         assert frames[f][0].tobytes() == ref[f][0].tobytes() and np.array_equal(frames[f][1], ref[f][1])
@@ -93,13 +96,13 @@ def _run(exe, tmp_path, oracle, threads=False):
     n_o, m_o, p_o = oracle.search_for_initialization(ref[0][0], ref[0][1], ref[1][0], ref[1][1], w, h, window=100, nnratio=0.9)
     assert nm == n_o and np.array_equal(m12, m_o) and prev.tobytes() == p_o.tobytes()
     assert dd == oracle.hamming(ref[0][1][0], ref[1][1][0])
-    eL, eR = oracle.OracleExtractor(n, 1.2, 8, 20, 7), oracle.OracleExtractor(n, 1.2, 8, 20, 7)
+    eL, eR = mk(), mk()
     eL.extract(seq[0])
     eR.extract(seq[1])
     uo, do = oracle.stereo_matches(eL, eR, np.float32(386.1448), np.float32(386.1448) / np.float32(718.856))
     assert ns == len(uo) and u_right.tobytes() == uo.tobytes() and depth.tobytes() == do.tobytes()
     gray = oracle.cvt_gray(np.stack([seq[0], seq[1], seq[0]], axis=-1), rgb=False)
-    kco, dco = oracle.OracleExtractor(n, 1.2, 8, 20, 7).extract(gray)
+    kco, dco = mk().extract(gray)
     assert np.array_equal(gray0, gray) and kc.tobytes() == kco.tobytes() and np.array_equal(dc, dco)
     # distorted camera: Frame(im, extractor, K, distCoef) -> mvKeysUn, image bounds, SearchForInitialization over them
     cam = tuple(np.float32(v) for v in (np.float32(517.306408) * w / 640, np.float32(516.469215) * h / 480, np.float32(318.643040) * w / 640,
@@ -116,7 +119,7 @@ def _run(exe, tmp_path, oracle, threads=False):
     assert u_rgbd.tobytes() == u_o.tobytes() and z_rgbd.tobytes() == z_o.tobytes() and (z_o > 0).sum() > 200
     # raw input rectified on the device
     rect = oracle.remap(seq[0], mx, my)
-    kro, dro = oracle.OracleExtractor(n, 1.2, 8, 20, 7).extract(rect)
+    kro, dro = mk().extract(rect)
     assert np.array_equal(rect0, rect) and kr.tobytes() == kro.tobytes() and np.array_equal(dr, dro)
     ov = oracle.OracleVocabulary(voc_path)
     want = [ov.transform(ref[0][1], 4), ov.transform(ref[1][1], 4), ov.transform(ref[1][1], 4)]
@@ -135,6 +138,7 @@ def test_dropin_classes_emulation(tmp_path, oracle, emu_lib):
 
 
 @pytest.mark.gpu
-def test_dropin_classes_gpu(tmp_path, oracle, gpu_lib):
+@pytest.mark.parametrize("blur", [None, 0])
+def test_dropin_classes_gpu(tmp_path, oracle, gpu_lib, blur):
     exe = _build("test_dropin_gpu")               # make: a no-op when the binary built by __graft_entry__.build() is current
-    _run(exe, tmp_path, oracle, threads=True)
+    _run(exe, tmp_path, oracle, threads=True, blur=blur)

@@ -99,3 +99,37 @@ def test_shard_helpers():
     c = (np.array([7]), np.array([3], np.int32), np.array([40], np.int32))
     idx, best, second = sharding.merge_nn([a, c])
     assert (idx[0], best[0], second[0]) == (7, 3, 10)
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus N` launched bare becomes its own launcher — and must fail loudly, not report a 1-GPU number, when the box
+    has fewer than N GPUs (here: none)."""
+    import subprocess
+    env = dict(os.environ); env.pop("WORLD_SIZE", None); env.pop("ORB_BENCH_SHARE_GPU", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "refusing" in (r.stderr + r.stdout) and '"n_gpus"' not in r.stdout
+    # a launcher that started a different number of ranks than --gpus says is an error too
+    env["WORLD_SIZE"] = "2"; env["RANK"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+def test_bench_gpus_flag_on_this_box():
+    """On the GPU box: `python bench.py --gpus N` with N > the visible GPUs fails loudly; with N <= visible it launches N ranks itself and
+    rank 0 reports n_gpus = N."""
+    import json
+    import subprocess
+    import torch
+    g = torch.cuda.device_count()
+    assert g >= 1
+    env = dict(os.environ); env.pop("WORLD_SIZE", None); env.pop("ORB_BENCH_SHARE_GPU", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(g + 1), "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout) and '"n_gpus"' not in r.stdout
+    if g >= 2:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--repeats", "1", "--batch", "32", "--no-cpu-baseline", "--no-host-io"],
+                           env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        assert json.loads(line)["n_gpus"] == 2
