@@ -62,6 +62,8 @@ typedef struct {
 } orbhip_config;
 
 const char* orbhip_version(void);
+/* HIP devices this process can use (0 = none: nothing in this library can run, there is no CPU fallback) */
+int orbhip_device_count(void);
 /* last error message of the calling thread ("" if none) */
 const char* orbhip_last_error(void);
 

@@ -1,11 +1,28 @@
 #!/usr/bin/env python3
-"""Build aid for oracle/_ref/liborbslam_dropin_full.so: the OPTIONAL steps of INTEGRATION.md §2 (3b, 3c, 3d') applied to the reference's
-src/Frame.cc and src/ORBmatcher.cc.  Reads the reference sources where they lie, replaces the BODIES of four Frame members by the
-one-line forwards to the drop-in extractor and the search loops of the two per-frame SearchByProjection members by calls of the C ABI,
-exactly as INTEGRATION.md shows, and writes the results to the paths given (temporary files the Makefile deletes after compiling
-them — no reference source is kept in this repository).
-usage: make_dropin_full.py <Frame.cc> <out_frame.cc> [<ORBmatcher.cc> <out_matcher.cc>]"""
+"""apply_dropin.py — the binding of INTEGRATION.md §2 as ONE command a maintainer of raulmur/ORB_SLAM2 runs on a checkout.
+
+    python integration/apply_dropin.py /path/to/ORB_SLAM2 /path/to/out      # writes the edited tree pieces under out/
+    python integration/apply_dropin.py --patch /path/to/ORB_SLAM2 > dropin.patch   # the same edits as a unified diff (patch -p1)
+
+What it produces (nothing else of the checkout changes; Tracking.cc, LocalMapping.cc, LoopClosing.cc, KeyFrame*.cc compile as they are):
+  out/include/ORBextractor.h, out/src/ORBextractor.cc     this repository's drop-in class (include/ORBextractor.h, orb_slam2_amd/cpp/)
+  out/include/orbhip.h                                    the C ABI of liborbhip.so (link with -lorbhip)
+  out/src/Frame.cc         the reference's file with the bodies of ComputeStereoMatches, UndistortKeyPoints, ComputeImageBounds and
+                           ComputeStereoFromRGBD replaced by one-line forwards to the extractor that just processed the frame (§2-3b, 3d')
+  out/src/ORBmatcher.cc    the reference's file with DescriptorDistance forwarded and the candidate / search loop of EVERY search member
+                           (SearchForInitialization, four SearchByProjection overloads, two SearchByBoW, SearchForTriangulation,
+                           SearchBySim3, two Fuse) replaced by one call of the C ABI each; the reference's pose algebra, MapPoint /
+                           KeyFrame bookkeeping and return values around them stay untouched (§2-3, 3c, 3e, 3f)
+The edits are located by the reference's own statements (regular expressions on signatures and anchor lines), so the script fails
+loudly — never silently skips — if a checkout differs from upstream at one of them.
+
+The test builds of this repository consume exactly this script (oracle/Makefile, target _ref/liborbslam_dropin_full.so, legacy form
+`apply_dropin.py --files <Frame.cc> <out> <ORBmatcher.cc> <out>`), so what tests/test_reference_dropin.py checks against the unmodified
+reference is what a maintainer applies.  No reference source is kept in this repository."""
+import difflib
+import os
 import re
+import shutil
 import sys
 
 FORWARDS = {
@@ -412,30 +429,100 @@ def patch_fuse_sim3(src):
     return src[:f0] + fn + src[f1:]
 
 
-def main():
-    src = open(sys.argv[1]).read()
+# the two map-free members
+DESC_DIST_SIG = r"int\s+ORBmatcher::DescriptorDistance\s*\(\s*const\s+cv::Mat\s*&\s*a\s*,\s*const\s+cv::Mat\s*&\s*b\s*\)"
+DESC_DIST_BODY = "{ return orbhip_descriptor_distance(a.ptr<unsigned char>(), b.ptr<unsigned char>()); }"
+INIT_SIG = r"int\s+ORBmatcher::SearchForInitialization\s*\(\s*Frame\s*&\s*F1\s*,\s*Frame\s*&\s*F2\s*,\s*vector<cv::Point2f>\s*&\s*vbPrevMatched\s*,\s*vector<int>\s*&\s*vnMatches12\s*,\s*int\s+windowSize\s*\)"
+INIT_BODY = """{
+    const int n1 = (int)F1.mvKeysUn.size(), n2 = (int)F2.mvKeysUn.size();
+    vnMatches12 = vector<int>(n1,-1);
+    if(n1==0) return 0;
+    const orbhip_bounds bounds = {Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY};
+    int nmatches = 0;
+    if(orbhip_search_for_initialization_bounds(orbhip_device(), reinterpret_cast<const orbhip_keypoint*>(&F1.mvKeysUn[0]), F1.mDescriptors.ptr<unsigned char>(), n1,
+            n2 ? reinterpret_cast<const orbhip_keypoint*>(&F2.mvKeysUn[0]) : NULL, n2 ? F2.mDescriptors.ptr<unsigned char>() : NULL, n2,
+            &bounds, reinterpret_cast<float*>(&vbPrevMatched[0]), &vnMatches12[0], windowSize, mfNNratio, mbCheckOrientation, &nmatches)!=ORBHIP_OK) abort();
+    return nmatches;
+}"""
+
+
+PROLOGUE = """#include "orbhip.h"
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+static int orbhip_device() { static const int d = getenv("ORBHIP_DEVICE") ? atoi(getenv("ORBHIP_DEVICE")) : 0; return d; }
+static void orbhip_fail() { throw std::runtime_error(std::string("ORBmatcher: ") + orbhip_last_error()); }
+"""
+
+
+def patch_frame(src):
     for sig, body in FORWARDS.items():
         src = replace_body(src, sig, body)
-    open(sys.argv[2], "w").write(src)
-    if len(sys.argv) > 4:
-        src = open(sys.argv[3]).read()
-        src = replace_body(src, LOCAL_MAP_SIG, LOCAL_MAP_BODY)
-        src = patch_last_frame(src)
-        src = patch_fuse(src)
-        src = replace_body(src, BOW_KF_FRAME_SIG, BOW_KF_FRAME_BODY)
-        src = replace_body(src, BOW_KF_KF_SIG, BOW_KF_KF_BODY)
-        src = patch_triangulation(src)
-        src = patch_sim3(src)
-        src = patch_fuse_sim3(src)
-        k = src.index("namespace ORB_SLAM2")
-        k = src.index("{", k) + 1
-        src = src[:k] + BOW_HELPERS + src[k:]
-        src = patch_projection_member(src, KF_SIM3_SIG, "int nmatches=0;", "const vector<size_t> vIndices = pKF->GetFeaturesInArea(u,v,radius);", "if(bestDist<=TH_LOW)",
-                                      KF_SIM3_QUERY, KF_SIM3_SEARCH, None)
-        src = patch_projection_member(src, RELOC_SIG, "int nmatches = 0;", "const vector<size_t> vIndices2 = CurrentFrame.GetFeaturesInArea(u, v, radius, nPredictedLevel-1, nPredictedLevel+1);",
-                                      "if(bestDist<=ORBdist)", RELOC_QUERY, RELOC_SEARCH, "if(mbCheckOrientation)")
-        src = '#include "orbhip.h"\n#include <cstdlib>\n' + src
-        open(sys.argv[4], "w").write(src)
+    return src
+
+
+def patch_matcher(src, map_free_members=True):
+    src = replace_body(src, LOCAL_MAP_SIG, LOCAL_MAP_BODY)
+    src = patch_last_frame(src)
+    src = patch_fuse(src)
+    src = replace_body(src, BOW_KF_FRAME_SIG, BOW_KF_FRAME_BODY)
+    src = replace_body(src, BOW_KF_KF_SIG, BOW_KF_KF_BODY)
+    src = patch_triangulation(src)
+    src = patch_sim3(src)
+    src = patch_fuse_sim3(src)
+    k = src.index("namespace ORB_SLAM2")
+    k = src.index("{", k) + 1
+    src = src[:k] + BOW_HELPERS + src[k:]
+    src = patch_projection_member(src, KF_SIM3_SIG, "int nmatches=0;", "const vector<size_t> vIndices = pKF->GetFeaturesInArea(u,v,radius);", "if(bestDist<=TH_LOW)",
+                                  KF_SIM3_QUERY, KF_SIM3_SEARCH, None)
+    src = patch_projection_member(src, RELOC_SIG, "int nmatches = 0;", "const vector<size_t> vIndices2 = CurrentFrame.GetFeaturesInArea(u, v, radius, nPredictedLevel-1, nPredictedLevel+1);",
+                                  "if(bestDist<=ORBdist)", RELOC_QUERY, RELOC_SEARCH, "if(mbCheckOrientation)")
+    if map_free_members:
+        src = replace_body(src, DESC_DIST_SIG, DESC_DIST_BODY)
+        src = replace_body(src, INIT_SIG, INIT_BODY)
+    # every inserted call: the device of ORBHIP_DEVICE (default 0), failures thrown (never swallowed, never abort(): include/ORBextractor.h)
+    src = re.sub(r"(orbhip_[a-z_]+\()0, ", r"\1orbhip_device(), ", src)
+    src = src.replace("!=ORBHIP_OK) abort();", "!=ORBHIP_OK) orbhip_fail();")
+    return PROLOGUE + src
+
+
+def main():
+    argv = sys.argv[1:]
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if argv and argv[0] == "--files":                       # the form the test builds use: explicit input / output files
+        # --keep-map-free: leave DescriptorDistance / SearchForInitialization to orb_slam2_amd/cpp/ORBmatcher.cc (the steps-1-3 build renames
+        # the reference's two bodies out of the way with -D and links that file)
+        keep = "--keep-map-free" in argv
+        argv = [a for a in argv[1:] if a != "--keep-map-free"]
+        open(argv[1], "w").write(patch_frame(open(argv[0]).read()))
+        if len(argv) > 3:
+            open(argv[3], "w").write(patch_matcher(open(argv[2]).read(), map_free_members=not keep))
+        return
+    emit_patch = bool(argv) and argv[0] == "--patch"
+    if emit_patch:
+        argv = argv[1:]
+    if len(argv) < (1 if emit_patch else 2):
+        raise SystemExit(__doc__)
+    ref = argv[0]
+    edited = {"src/Frame.cc": patch_frame(open(os.path.join(ref, "src/Frame.cc")).read()),
+              "src/ORBmatcher.cc": patch_matcher(open(os.path.join(ref, "src/ORBmatcher.cc")).read())}
+    copies = {"include/ORBextractor.h": "include/ORBextractor.h", "src/ORBextractor.cc": "orb_slam2_amd/cpp/ORBextractor.cc", "include/orbhip.h": "include/orbhip.h"}
+    if emit_patch:
+        for rel, new in edited.items():
+            old = open(os.path.join(ref, rel)).read()
+            sys.stdout.writelines(difflib.unified_diff(old.splitlines(True), new.splitlines(True), "a/" + rel, "b/" + rel))
+        for rel, mine in copies.items():
+            old = open(os.path.join(ref, rel)).read() if os.path.exists(os.path.join(ref, rel)) else ""
+            sys.stdout.writelines(difflib.unified_diff(old.splitlines(True), open(os.path.join(here, mine)).read().splitlines(True), "a/" + rel, "b/" + rel))
+        return
+    out = argv[1]
+    for rel, new in edited.items():
+        os.makedirs(os.path.dirname(os.path.join(out, rel)), exist_ok=True)
+        open(os.path.join(out, rel), "w").write(new)
+    for rel, mine in copies.items():
+        os.makedirs(os.path.dirname(os.path.join(out, rel)), exist_ok=True)
+        shutil.copyfile(os.path.join(here, mine), os.path.join(out, rel))
+    print("wrote", ", ".join(sorted(list(edited) + list(copies))), "under", out)
 
 
 if __name__ == "__main__":

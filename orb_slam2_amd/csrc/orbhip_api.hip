@@ -51,6 +51,7 @@ struct ProfSpan { int k; hipEvent_t a, b; };
 #define ORBHIP_RING 3
 #define ORBHIP_MAX_CHUNKS 16
 struct HostSet {
+    uint8_t* d_packed = nullptr; size_t packed_bytes = 0;     // pinned caller images land here as they are (rows `stride` apart) and are re-pitched on the device
     uint8_t* d_in = nullptr; uint8_t* h_in = nullptr; orbhip_keypoint* h_kp = nullptr; uint8_t* h_desc = nullptr; int* h_n = nullptr; bool owned = false;
     bool busy = false; int ticket = -1, nimg = 0, out_buf = -1, nchunks = 0, chunk_f0[ORBHIP_MAX_CHUNKS + 1] = {0};
     hipEvent_t ev_h2d[ORBHIP_MAX_CHUNKS] = {nullptr}, ev_k[ORBHIP_MAX_CHUNKS] = {nullptr}, ev_d2h[ORBHIP_MAX_CHUNKS] = {nullptr};
@@ -216,7 +217,8 @@ static void build_yresize_table(int sh, int dh, std::vector<int2>& tab)  // rows
     }
 }
 
-extern "C" const char* orbhip_version(void) { return "orbhip 0.1 (gfx950)"; }
+extern "C" const char* orbhip_version(void) { return "orbhip 0.2 (gfx950)"; }
+extern "C" int orbhip_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; } return n; }
 extern "C" const char* orbhip_last_error(void) { return g_err.c_str(); }
 
 extern "C" void orbhip_destroy(orbhip_ctx* c)
@@ -243,6 +245,7 @@ extern "C" void orbhip_destroy(orbhip_ctx* c)
     { void* st[] = {c->d_st_rowstart, c->d_st_rowitems, c->d_st_u, c->d_st_depth, c->d_st_sad}; for (void* q : st) if (q) (void)hipFree(q); }
     for (auto& hs : c->sets) {
         for (int k = 0; k < ORBHIP_MAX_CHUNKS; k++) { if (hs.ev_h2d[k]) (void)hipEventDestroy(hs.ev_h2d[k]); if (hs.ev_k[k]) (void)hipEventDestroy(hs.ev_k[k]); if (hs.ev_d2h[k]) (void)hipEventDestroy(hs.ev_d2h[k]); }
+        if (hs.d_packed) (void)hipFree(hs.d_packed);
         if (hs.owned) { if (hs.d_in) (void)hipFree(hs.d_in); if (hs.h_in) (void)hipHostFree(hs.h_in); if (hs.h_kp) (void)hipHostFree(hs.h_kp); if (hs.h_desc) (void)hipHostFree(hs.h_desc); if (hs.h_n) (void)hipHostFree(hs.h_n); }
     }
     if (c->hstream) { (void)hipStreamSynchronize(c->hstream); (void)hipStreamDestroy(c->hstream); }
@@ -698,7 +701,7 @@ static int host_chunk_frames(int nimg)
     const char* e = getenv("ORBHIP_HOST_CHUNK"); const int forced = e ? atoi(e) : 0;          // tuning / test knob: frames per chunk
     if (forced > 0) return std::max((nimg + ORBHIP_MAX_CHUNKS - 1) / ORBHIP_MAX_CHUNKS, forced);
     if (nimg < 32) return nimg;
-    const int ch = std::min(std::max(((nimg + 7) / 8 + 7) & ~7, 16), 64);
+    const int ch = std::min(std::max(((nimg + 3) / 4 + 7) & ~7, 16), 64);       // measured on MI355X: 64-frame chunks at batch 256 beat 32-frame ones by 25 % (launch efficiency)
     return std::max(ch, (nimg + ORBHIP_MAX_CHUNKS - 1) / ORBHIP_MAX_CHUNKS);
 }
 
@@ -731,10 +734,21 @@ static orbhip_status submit_impl(orbhip_ctx* c, int nimg, const uint8_t* const* 
         const int f0 = k * ch, f1 = std::min(nimg, f0 + ch), nf = f1 - f0;
         hs.chunk_f0[k] = f0; hs.chunk_f0[k + 1] = f1;
         // ---- upload
-        if (pinned_in) {
-            for (int f = f0; f < f1; f++) {
-                if (stride == c->in_pitch) HIPCHK(hipMemcpyAsync(hs.d_in + f * fbytes, imgs[f], fbytes, hipMemcpyHostToDevice, hst));
-                else HIPCHK(hipMemcpy2DAsync(hs.d_in + f * fbytes, c->in_pitch, imgs[f], stride, W, H, hipMemcpyHostToDevice, hst));
+        if (pinned_in && stride == c->in_pitch) {
+            for (int f = f0; f < f1; f++) HIPCHK(hipMemcpyAsync(hs.d_in + f * fbytes, imgs[f], fbytes, hipMemcpyHostToDevice, hst));
+        } else if (pinned_in) {
+            // dense rows: linear DMA of every image as it lies in the caller's memory (adjacent images in one copy), rows spread to the
+            // pipeline's pitch by k_repitch on the main stream
+            const size_t ibytes = (size_t)stride * H;
+            if (hs.packed_bytes < (size_t)c->B * ibytes) {
+                if (hs.d_packed) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(hs.d_packed)); hs.d_packed = nullptr; hs.packed_bytes = 0; }
+                HIPCHK(hipMalloc((void**)&hs.d_packed, (size_t)c->B * ibytes + 256)); hs.packed_bytes = (size_t)c->B * ibytes;
+            }
+            for (int f = f0; f < f1;) {
+                int g = f + 1; while (g < f1 && imgs[g] == imgs[g - 1] + ibytes) g++;
+                const size_t bytes = (size_t)(g - f - 1) * ibytes + (size_t)stride * (H - 1) + W;       // never past the last image's last pixel
+                HIPCHK(hipMemcpyAsync(hs.d_packed + f * ibytes, imgs[f], bytes, hipMemcpyHostToDevice, hst));
+                f = g;
             }
         } else {
             uint8_t* h_in = hs.h_in; const int in_pitch = c->in_pitch;
@@ -746,6 +760,8 @@ static orbhip_status submit_impl(orbhip_ctx* c, int nimg, const uint8_t* const* 
             HIPCHK(hipMemcpyAsync(hs.d_in + f0 * fbytes, hs.h_in + f0 * fbytes, nf * fbytes, hipMemcpyHostToDevice, hst));
         }
         if (piped) { HIPCHK(hipEventRecord(hs.ev_h2d[k], hst)); HIPCHK(hipStreamWaitEvent(c->stream, hs.ev_h2d[k], 0)); }
+        if (pinned_in && stride != c->in_pitch)
+            orbhip_launch_repitch(hs.d_packed + (size_t)f0 * stride * H, (long long)stride * H, stride, hs.d_in + f0 * fbytes, (long long)fbytes, c->in_pitch, W, H, nf, c->stream);
         // ---- kernels
         st = pipeline_frames(c, P, f0, nf, c->stream, true); if (st != ORBHIP_OK) return st;
         if (piped) { HIPCHK(hipEventRecord(hs.ev_k[k], c->stream)); HIPCHK(hipStreamWaitEvent(dst, hs.ev_k[k], 0)); }

@@ -149,6 +149,8 @@ void orbhip_launch_stereo_from_rgbd(const orbhip_keypoint* kp, const orbhip_keyp
 void orbhip_launch_remap(const uint8_t* src, long long src_frame_stride, int src_row_stride, int src_w, int src_h, const int* qx, const int* qy, int q_pitch,
                          uint8_t* dst, long long dst_frame_stride, int dst_pitch, int w, int h, int nframes, hipStream_t s);
 
+void orbhip_launch_repitch(const uint8_t* src, long long src_frame_stride, int src_row_stride, uint8_t* dst, long long dst_frame_stride, int dst_pitch, int w, int h, int nframes, hipStream_t s);
+
 bool orbhip_launch_hamming_nn(const uint8_t* d_q, int nq, const uint8_t* d_db, long long ndb, long long base,
                               long long* d_best_idx, int* d_best_dist, int* d_second, hipStream_t s);
 void orbhip_launch_match_grid(const MatchParams& M, int nslots, hipStream_t s);

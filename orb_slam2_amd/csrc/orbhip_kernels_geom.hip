@@ -181,3 +181,24 @@ void orbhip_launch_remap(const uint8_t* src, long long src_frame_stride, int src
     RemapParams R{src, src_frame_stride, src_row_stride, src_w, src_h, qx, qy, q_pitch, dst, dst_frame_stride, dst_pitch, w, h};
     hipLaunchKernelGGL(k_remap, dim3((w + 1023) / 1024, (h + RM_ROWS - 1) / RM_ROWS, nframes), dim3(256, 1, 1), 0, s, R);
 }
+
+// ------------------------------------------------------------------------------------------------ row re-pitch
+// Host images arrive densely packed (cv::Mat rows `stride` bytes apart, usually stride == width) and are DMA'd as they are — one
+// linear copy per image, or per run of adjacent images; a strided host-to-device copy with an odd width falls off the DMA engines'
+// fast path by two orders of magnitude.  This kernel spreads the rows to the 64-byte-multiple pitch the pipeline's aligned 32-bit
+// loads want: 4 bytes per thread, unaligned load, aligned store (pad bytes past the row end are never read).
+typedef unsigned u32_any_align __attribute__((aligned(1)));
+__global__ __launch_bounds__(256) void k_repitch(const uint8_t* src, long long src_frame_stride, int src_row_stride, uint8_t* dst, long long dst_frame_stride, int dst_pitch, int w, int h)
+{
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y, f = blockIdx.z;
+    if (x >= w) return;
+    const uint8_t* s = src + (long long)f * src_frame_stride + (long long)y * src_row_stride + x;
+    unsigned v;
+    if (x + 4 <= w || y + 1 < h) v = *reinterpret_cast<const u32_any_align*>(s);         // reading into the next row is inside the frame
+    else { v = 0; for (int k = 0; k < w - x; k++) v |= (unsigned)s[k] << (8 * k); }       // the last bytes of the last row
+    *reinterpret_cast<unsigned*>(dst + (long long)f * dst_frame_stride + (long long)y * dst_pitch + x) = v;
+}
+void orbhip_launch_repitch(const uint8_t* src, long long src_frame_stride, int src_row_stride, uint8_t* dst, long long dst_frame_stride, int dst_pitch, int w, int h, int nframes, hipStream_t s)
+{
+    if (nframes > 0) hipLaunchKernelGGL(k_repitch, dim3((w + 1023) / 1024, h, nframes), dim3(256, 1, 1), 0, s, src, src_frame_stride, src_row_stride, dst, dst_frame_stride, dst_pitch, w, h);
+}

@@ -20,7 +20,7 @@ KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle"
 
 # every symbol include/orbhip.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "orbhip_version", "orbhip_last_error", "orbhip_create", "orbhip_destroy", "orbhip_keypoint_capacity",
+    "orbhip_version", "orbhip_device_count", "orbhip_last_error", "orbhip_create", "orbhip_destroy", "orbhip_keypoint_capacity",
     "orbhip_get_scale_tables", "orbhip_level_size", "orbhip_extract", "orbhip_extract_batch", "orbhip_pyramid_level",
     "orbhip_extract_device", "orbhip_sync", "orbhip_fetch", "orbhip_fetch_matches", "orbhip_descriptor_distance",
     "orbhip_hamming_nn", "orbhip_hamming_nn_device", "orbhip_search_for_initialization", "orbhip_profile_enable",
@@ -479,6 +479,11 @@ class ORBextractor:
         out = np.zeros((max(n.value, 1), 3), np.int32)
         _check(self.L.orbhip_debug_candidates(self.h, frame, level, _p(out), n.value, C.byref(n)), "orbhip_debug_candidates", self.L)
         return out[:n.value].copy()
+
+
+def device_count(library=None):
+    """HIP devices visible to the library (0 = nothing can run; there is no CPU fallback)"""
+    return lib(library).orbhip_device_count()
 
 
 def pinned_array(shape, dtype=np.uint8, library=None):

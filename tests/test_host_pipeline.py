@@ -106,8 +106,7 @@ def _pool_devices(backend, monkeypatch, n):
     if backend.endswith("_emu.so"):
         monkeypatch.setenv("HIPEMU_DEVICE_COUNT", str(n))         # n pretend devices on the emulation
         return list(range(n))
-    import torch
-    g = torch.cuda.device_count()
+    g = orb_slam2_amd.device_count(backend)                      # not torch: its bundled HIP runtime must not enter this test process
     return [i % g for i in range(n)]                              # a 1-GPU box runs both contexts on GPU 0; an 8-GPU node gets 0, 1
 
 

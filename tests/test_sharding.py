@@ -121,8 +121,8 @@ def test_bench_gpus_flag_on_this_box():
     rank 0 reports n_gpus = N."""
     import json
     import subprocess
-    import torch
-    g = torch.cuda.device_count()
+    import orb_slam2_amd
+    g = orb_slam2_amd.device_count()                  # the library's own count: torch (and its bundled HIP runtime) stays out of the test process
     assert g >= 1
     env = dict(os.environ); env.pop("WORLD_SIZE", None); env.pop("ORB_BENCH_SHARE_GPU", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(g + 1), "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=600)

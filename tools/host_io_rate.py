@@ -57,7 +57,7 @@ def rate(B, chunk, kind, mode):
 
 
 rows = []
-for B, chunk in ((64, 0), (64, 8), (64, 32), (128, 0), (128, 32), (256, 0), (256, 64), (512, 0)):
+for B, chunk in ((64, 0), (64, 16), (128, 0), (128, 32), (256, 0), (256, 64)):
     for kind in ("pinned", "pageable"):
         for mode in ("ring", "sync"):
             rows.append({"batch": B, "chunk": chunk or "auto", "buffers": kind, "mode": mode, "frames_per_s": rate(B, chunk, kind, mode)})
