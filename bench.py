@@ -58,7 +58,7 @@ def _cpu_worker(args):
     """One CPU instance per process: extract + match consecutive frames of one slot until the time budget is spent.
     kind "reference": the reference's own Frame constructor (ORBextractor::operator()) + ORBmatcher::SearchForInitialization from
     oracle/_ref/liborbslam_ref_fast.so; kind "port": the oracle's restatement."""
-    frames_slot, budget_s, kind = args
+    frames_slot, budget_s, kind, blur = args
     done, prev, t = 0, None, 0
     t0 = time.perf_counter()
     if kind == "reference":
@@ -74,7 +74,7 @@ def _cpu_worker(args):
             t += 1
         return done, time.perf_counter() - t0
     from oracle import orb_oracle as O
-    ex = O.OracleExtractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, fast=True)
+    ex = O.OracleExtractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, fast=True, blur_round_mode=blur)
     while time.perf_counter() - t0 < budget_s:
         k, d = ex.extract(frames_slot[t % len(frames_slot)])
         if prev is not None:
@@ -85,7 +85,7 @@ def _cpu_worker(args):
     return done, time.perf_counter() - t0
 
 
-def cpu_baseline(frames, budget_s=8.0):
+def cpu_baseline(frames, budget_s=8.0, blur_round_mode=0):
     """The CPU path on this box's host cores, one frame stream per core on all cores (SURVEY.md §8d iii) plus the single-thread
     rate.  If the build of the reference's own sources travelled with the repo (oracle/_ref/liborbslam_ref_fast.so: src/Frame.cc,
     src/ORBextractor.cc, src/ORBmatcher.cc at -O3, with the four OpenCV image primitives they call supplied by the oracle's
@@ -100,13 +100,13 @@ def cpu_baseline(frames, budget_s=8.0):
     ncores = os.cpu_count() or 1
     ctx = mp.get_context("fork")
     with ctx.Pool(1) as pool:                                   # the single-thread rate in a child too: the library choice is per process
-        one_done, one_dt = pool.map(_cpu_worker, [(slots[0], min(budget_s, 6.0), kind)])[0]
-        port_done, port_dt = pool.map(_cpu_worker, [(slots[0], 3.0, "port")])[0] if kind == "reference" else (one_done, one_dt)
+        one_done, one_dt = pool.map(_cpu_worker, [(slots[0], min(budget_s, 6.0), kind, blur_round_mode)])[0]
+        port_done, port_dt = pool.map(_cpu_worker, [(slots[0], 3.0, "port", blur_round_mode)])[0] if kind == "reference" else (one_done, one_dt)
     with ctx.Pool(2) as pool:                                   # the reference's own stereo concurrency: two extractor threads (Frame.cc:78-81)
-        two = pool.map(_cpu_worker, [(slots[i % len(slots)], 4.0, kind) for i in range(2)])
+        two = pool.map(_cpu_worker, [(slots[i % len(slots)], 4.0, kind, blur_round_mode) for i in range(2)])
     t0 = time.perf_counter()
     with ctx.Pool(ncores) as pool:
-        res = pool.map(_cpu_worker, [(slots[i % len(slots)], budget_s, kind) for i in range(ncores)])
+        res = pool.map(_cpu_worker, [(slots[i % len(slots)], budget_s, kind, blur_round_mode) for i in range(ncores)])
     wall = time.perf_counter() - t0
     total = sum(r[0] for r in res)
     rate = sum(r[0] / r[1] for r in res)
@@ -118,14 +118,14 @@ def cpu_baseline(frames, budget_s=8.0):
             "oracle_port_single_thread_value": round(port_done / port_dt, 2)}
 
 
-def host_io(ex_resident, frames, device, budget_s=3.0):
+def host_io(ex_resident, frames, device, blur_round_mode, budget_s=3.0):
     """The drop-in boundary as every real caller sees it (Frame::ExtractORB, Frame.cc:247-253): host images in, host key points +
     descriptors out, PCIe both ways, through the pipelined host path (orbhip_submit / orbhip_collect, two batches in flight).
     Extraction only; never the bench `value`.  Measured from pinned caller buffers (DMA straight from / into them) and from pageable
     ones (staged through the library's pinned ring by a few copy threads), plus the single-frame call latency of the drop-in class."""
     import orb_slam2_amd
     Bh = 128
-    ex = orb_slam2_amd.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, W, H, max_batch=Bh, device=device)
+    ex = orb_slam2_amd.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, W, H, max_batch=Bh, device=device, blur_round_mode=blur_round_mode)
     cap = ex.capacity
     src_pageable = np.ascontiguousarray(frames[0, :Bh, :, :W]) if frames.shape[1] >= Bh else np.ascontiguousarray(np.resize(frames[0, :, :, :W], (Bh, H, W)))
     out = {"batch": Bh, "bytes_per_frame_h2d": W * H, "bytes_per_frame_d2h": cap * 60 + 4}
@@ -147,7 +147,7 @@ def host_io(ex_resident, frames, device, budget_s=3.0):
         nout = ex.collect(pending.pop(0), out=bufs[done % 2]); done += 1
         dt = time.perf_counter() - t0
         out[kind] = {"frames_per_s": round(done * Bh / dt, 1), "pcie_GBps": round(done * Bh * (W * H + cap * 60 + 4) / dt / 1e9, 2), "keypoints_per_frame": int(nout.mean())}
-    one = orb_slam2_amd.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, W, H, max_batch=1, device=device)
+    one = orb_slam2_amd.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, W, H, max_batch=1, device=device, blur_round_mode=blur_round_mode)
     one(src_pageable[0])
     t1 = time.perf_counter()
     for i in range(100):
@@ -168,6 +168,8 @@ def main():
     ap.add_argument("--batch", type=int, default=512, help="camera slots (frames) per step per GPU")
     ap.add_argument("--tsteps", type=int, default=4, help="distinct resident time steps cycled through")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the library splits each batch over")
+    ap.add_argument("--blur-round-mode", type=int, default=1, help="cv::GaussianBlur rounding the extractor reproduces: 1 = the SSE2 column filter of x86-64 OpenCV builds "
+                    "(what the reference computes on this x86 box; default), 0 = OpenCV's generic C++ path (DESIGN.md H2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extract-only", action="store_true", help="diagnostic: skip the matcher (NOT the metric's workload; the JSON line says so)")
     args = ap.parse_args()
@@ -212,7 +214,7 @@ def main():
     host_frames = make_frames(B, T, pitch, rank)
     d_frames = torch.from_numpy(host_frames).to(f"cuda:{local_rank}")          # inputs resident in HBM before timing
     torch.cuda.synchronize()
-    ex = orb_slam2_amd.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, W, H, max_batch=B, device=local_rank, num_streams=args.streams)
+    ex = orb_slam2_amd.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, W, H, max_batch=B, device=local_rank, num_streams=args.streams, blur_round_mode=args.blur_round_mode)
     frame_stride, step_stride = H * pitch, B * H * pitch
     base = d_frames.data_ptr()
 
@@ -284,7 +286,7 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "KITTI-shaped 1241x376 u8, 2000 features, 8 levels, scale 1.2, FAST 20/7, extract + SearchForInitialization(win 100, nnratio 0.9)",
                        "inputs": "hbm-resident, results stay on device (the PCIe-inclusive host-buffer rate is the host_io object)",
-                       "frames_per_step_per_gpu": B, "resident_time_steps": T, "distinct_scenes": min(B, NSCENES), "row_pitch": pitch, "streams_per_gpu": args.streams, "parallelism": f"frames sharded over {world} GPU(s), no collective"},
+                       "frames_per_step_per_gpu": B, "resident_time_steps": T, "distinct_scenes": min(B, NSCENES), "blur_round_mode": args.blur_round_mode, "row_pitch": pitch, "streams_per_gpu": args.streams, "parallelism": f"frames sharded over {world} GPU(s), no collective"},
             "repeats": {"n": len(times), "steps_each": args.steps, "timed_region_s": round(sum(times), 3), "frames_per_s_median": round(frames_total / elapsed, 1),
                         "frames_per_s_min": round(frames_total / max(times), 1), "frames_per_s_max": round(frames_total / min(times), 1)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -298,9 +300,10 @@ def main():
             "check": {"keypoints_per_frame_min_max": [int(min(nkp)), int(max(nkp))], "matches_per_frame_min_max": [int(nm.min()), int(nm.max())]},
         }
         if world == 1 and not args.no_host_io:
-            out["host_io"] = host_io(ex, host_frames, local_rank)
+            out["host_io"] = host_io(ex, host_frames, local_rank, args.blur_round_mode)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(host_frames)
+            os.environ["ORB_REF_BLUR_ROUND_MODE"] = str(args.blur_round_mode)      # the reference build's GaussianBlur stand-in follows the same rounding
+            out["cpu_baseline"] = cpu_baseline(host_frames, blur_round_mode=args.blur_round_mode)
             out["cpu_baseline"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -13,13 +13,15 @@ def _same(kg, dg, ko, do):
     assert kg.tobytes() == ko.tobytes() and np.array_equal(dg, do)
 
 
-def test_kitti_config_bit_exact_batch(gpu_lib, oracle):
-    """configs[1]: 1241x376, 2000 features, 8 levels — 6 frames (3 scenes x 2 time steps) in one batch vs the oracle."""
+@pytest.mark.parametrize("blur", [0, 1])
+def test_kitti_config_bit_exact_batch(gpu_lib, oracle, blur):
+    """configs[1]: 1241x376, 2000 features, 8 levels — 6 frames (3 scenes x 2 time steps) in one batch vs the oracle, under both
+    real-world roundings of cv::GaussianBlur (0 = generic C++ OpenCV, 1 = the SSE2 column filter of x86-64 builds; DESIGN.md H2)."""
     w, h, n = 1241, 376, 2000
     frames = [f for s in (0, 1, 2) for f in synth.sequence(w, h, 2, seed=s)]
-    ex = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, max_batch=len(frames), library=gpu_lib)
+    ex = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, max_batch=len(frames), blur_round_mode=blur, library=gpu_lib)
     ks, ds = ex.extract_batch(frames)
-    ora = oracle.OracleExtractor(n, 1.2, 8, 20, 7, fast=True)
+    ora = oracle.OracleExtractor(n, 1.2, 8, 20, 7, fast=True, blur_round_mode=blur)
     ref = [ora.extract(f) for f in frames]
     for f in range(len(frames)):
         _same(ks[f], ds[f], *ref[f])
@@ -34,12 +36,15 @@ def test_kitti_config_bit_exact_batch(gpu_lib, oracle):
 
 @pytest.mark.parametrize("w,h,n", [(640, 480, 1000), (640, 480, 2000), (752, 480, 1200), (1920, 1080, 4000)])
 def test_other_configs_bit_exact(gpu_lib, oracle, w, h, n):
-    """configs[0] TUM (1000 and the 2x initialisation extractor), configs[2] EuRoC, configs[3] the 1920x1080 rig camera."""
+    """configs[0] TUM (1000 and the 2x initialisation extractor), configs[2] EuRoC, configs[3] the 1920x1080 rig camera; both blur roundings
+    on one context (orbhip_set_blur_rounding between calls)."""
     img = synth.frame(w, h, seed=9)
     ex = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, library=gpu_lib)
-    kg, dg = ex(img)
-    ko, do = oracle.OracleExtractor(n, 1.2, 8, 20, 7, fast=True).extract(img)
-    _same(kg, dg, ko, do)
+    for blur in (0, 1):
+        ex.SetBlurRounding(blur)
+        kg, dg = ex(img)
+        ko, do = oracle.OracleExtractor(n, 1.2, 8, 20, 7, fast=True, blur_round_mode=blur).extract(img)
+        _same(kg, dg, ko, do)
     ex.close()
 
 
