@@ -393,39 +393,33 @@ __host__ __device__ __forceinline__ int fc_wave_bytes(int pstride, int prows, in
     return ((pstride * prows + 15) & ~15) + ((sstride * srows + 15) & ~15) + ((2 * listcap + 15) & ~15);
 }
 
-// ring of the pixel pair whose first pixel is byte C0 of the 7 x 12-byte window w[7][3] (circle: FAST 16-point Bresenham);
-// ring element k of pixel q sits at row 3+dy_k, byte C0+q+dx_k
-#define FC_RING(C0) { \
-    row_pair<C0 + 0>(w[6][0], w[6][1], w[6][2]), row_pair<C0 + 1>(w[6][0], w[6][1], w[6][2]), row_pair<C0 + 2>(w[5][0], w[5][1], w[5][2]), row_pair<C0 + 3>(w[4][0], w[4][1], w[4][2]), \
-    row_pair<C0 + 3>(w[3][0], w[3][1], w[3][2]), row_pair<C0 + 3>(w[2][0], w[2][1], w[2][2]), row_pair<C0 + 2>(w[1][0], w[1][1], w[1][2]), row_pair<C0 + 1>(w[0][0], w[0][1], w[0][2]), \
-    row_pair<C0 + 0>(w[0][0], w[0][1], w[0][2]), row_pair<C0 - 1>(w[0][0], w[0][1], w[0][2]), row_pair<C0 - 2>(w[1][0], w[1][1], w[1][2]), row_pair<C0 - 3>(w[2][0], w[2][1], w[2][2]), \
-    row_pair<C0 - 3>(w[3][0], w[3][1], w[3][2]), row_pair<C0 - 3>(w[4][0], w[4][1], w[4][2]), row_pair<C0 - 2>(w[5][0], w[5][1], w[5][2]), row_pair<C0 - 1>(w[6][0], w[6][1], w[6][2]) }
+// ring of the pixel pair (Q, Q+1) of a 4-pixel group whose 7 x 12-byte window is w[7][3] (circle: FAST 16-point Bresenham);
+// ring element k of pixel q sits at row 3+dy_k, byte 3+q+dx_k
+#define FC_RING(Q) { \
+    row_pair<3 + Q + 0>(w[6][0], w[6][1], w[6][2]), row_pair<3 + Q + 1>(w[6][0], w[6][1], w[6][2]), row_pair<3 + Q + 2>(w[5][0], w[5][1], w[5][2]), row_pair<3 + Q + 3>(w[4][0], w[4][1], w[4][2]), \
+    row_pair<3 + Q + 3>(w[3][0], w[3][1], w[3][2]), row_pair<3 + Q + 3>(w[2][0], w[2][1], w[2][2]), row_pair<3 + Q + 2>(w[1][0], w[1][1], w[1][2]), row_pair<3 + Q + 1>(w[0][0], w[0][1], w[0][2]), \
+    row_pair<3 + Q + 0>(w[0][0], w[0][1], w[0][2]), row_pair<3 + Q - 1>(w[0][0], w[0][1], w[0][2]), row_pair<3 + Q - 2>(w[1][0], w[1][1], w[1][2]), row_pair<3 + Q - 3>(w[2][0], w[2][1], w[2][2]), \
+    row_pair<3 + Q - 3>(w[3][0], w[3][1], w[3][2]), row_pair<3 + Q - 3>(w[4][0], w[4][1], w[4][2]), row_pair<3 + Q - 2>(w[5][0], w[5][1], w[5][2]), row_pair<3 + Q - 1>(w[6][0], w[6][1], w[6][2]) }
 
-// Necessary condition for "corner at threshold t", four pixels at a time in byte-SWAR arithmetic built only from the operations this
-// part issues at full rate (add / sub / and / or / lshr: 2 cycles per wave64 instruction; min / max / perm / compare-select, also packed,
-// take 4 — profiles/r02_valu_issue_rates_ubench.txt).  A 9-arc of the 16-pixel ring contains one pixel of every opposite pair (k, k+8),
-// so for a bright corner every pair has a member above C + t and for a dark one every pair has a member below C - t.  Four of the eight
-// pairs are tested (compass + diagonals).  All values are halved to 7 bits first, which keeps every per-byte sum or difference inside its
-// byte (no carries between the four pixels) and only ever WEAKENS the test (it stays necessary; the exact score decides):
-//   R > C + t  =>  (R >> 1) >= (C >> 1) + (t >> 1),        R < C - t  =>  (R >> 1) <= (C >> 1) - (t >> 1),
-// and saturating the two thresholds at 127 / 0 can only add false positives as well.  With nb = 128 - min(c7 + th, 127) and
-// sd80 = 128 + max(c7 - th, 0) per byte,  bit 7 of (r7 + nb) is "bright" and bit 7 of (sd80 - r7) is "dark" for all four pixels at once.
-struct FastSwar { unsigned nb, sd80; };
-__device__ __forceinline__ FastSwar fast_swar_centre(unsigned C, unsigned th4)
+// Necessary condition for "corner at threshold t" of a pixel pair: a 9-arc contains one pixel of every opposite pair (k, k+8),
+// so each max(r_k, r_k+8) exceeds C + t (bright arc) or each min(r_k, r_k+8) is below C - t (dark arc).  Four of the eight
+// pairs are tested (compass + diagonals: 14 % of the 4-pixel groups of a textured frame survive at t = 20, against 11 % with
+// all eight and 23 % with the compass pairs alone), which needs 5 of the 7 window rows, 9 byte-pair extractions and 19
+// packed min/max per pixel pair instead of 17 and 118 for the exact score.  Returns per 16-bit lane non-zero where it passes.
+// (Round 2 measured the alternative the instruction-rate table suggests — the same four pairs for four pixels at a time in byte-SWAR
+//  arithmetic built only from full-rate add / sub / and / or / lshr on 7-bit halved values: 65 full-rate + 29 half-rate operations per
+//  group instead of 16 + 74, but the halving weakens the test by up to two grey levels, 11.1 % instead of 9.0 % of the pixel pairs reach
+//  the exact score (1.37 instead of 1.21 passes of that loop per cell) and the kernel ran 0.624 ms against 0.630 ms: kept as it was.
+//  With byte-offset LDS reads instead of v_alignbyte it ran 0.846 ms: a DS read off its natural alignment is replayed.
+//  profiles/r02_exp_fast_swar_*.json)
+__device__ __forceinline__ pki16 fast_pretest_pair(const pku16 r[16], pku16 c, int t)
 {
-    const unsigned c7 = (C >> 1) & 0x7f7f7f7fu;
-    const unsigned t1 = c7 + th4, ov = t1 & 0x80808080u;                      // per byte <= 254: no carry; bit 7 = above 127
-    const unsigned sb = (t1 | (ov - (ov >> 7))) & 0x7f7f7f7fu;                // saturate to 127
-    const unsigned u = (c7 | 0x80808080u) - th4, m = u & 0x80808080u;         // per byte c7 + 128 - th >= 1: no borrow; bit 7 = c7 >= th
-    FastSwar f; f.nb = 0x80808080u - sb; f.sd80 = (u & (m - (m >> 7))) | 0x80808080u;
-    return f;
-}
-// flags of one opposite pair (ring dwords Ra, Rb = the four pixels' ring bytes): bit 7 of each byte of .x (bright) / .y (dark)
-__device__ __forceinline__ void fast_swar_pair(const FastSwar& f, unsigned Ra, unsigned Rb, unsigned& bright, unsigned& dark)
-{
-    const unsigned a7 = (Ra >> 1) & 0x7f7f7f7fu, b7 = (Rb >> 1) & 0x7f7f7f7fu;
-    bright &= (a7 + f.nb) | (b7 + f.nb);
-    dark &= (f.sd80 - a7) | (f.sd80 - b7);
+    pku16 mn = pmax(r[0], r[8]), mx = pmin(r[0], r[8]);
+#pragma unroll
+    for (int k = 2; k < 8; k += 2) { mn = pmin(mn, pmax(r[k], r[k + 8])); mx = pmax(mx, pmin(r[k], r[k + 8])); }
+    const pki16 tt = {(short)t, (short)t};
+    const pki16 bright = (pki16)mn - (pki16)c, dark = (pki16)c - (pki16)mx;          // margins of the weakest tested pair
+    return (bright > tt) | (dark > tt);
 }
 
 __device__ __forceinline__ void fc_load_window(const uint8_t* patch, int PS, int y, int grp, unsigned (&w)[7][3])
@@ -451,18 +445,17 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
     if (!work) { if (lane == 0) P.cell_count[(long long)frame * P.ncells_total + cell_id] = 0; return; }
     const int PS = P.fc_pstride, SS = P.fc_sstride;                  // byte strides, multiples of 4
     uint8_t* wbase = reinterpret_cast<uint8_t*>(fc_lds) + wave * fc_wave_bytes(PS, P.fc_prows, SS, P.fc_srows, P.fc_listcap);
-    uint8_t* patch = wbase;                                          // sub-image column p sits at LDS column p + 1: interior column x = p - 3 at x + 4, so the
-                                                                     // four centre pixels of a group are ONE aligned dword and ring columns are plain byte offsets
+    uint8_t* patch = wbase;                                          // patch column 0 is 4-byte aligned
     uint8_t* score = wbase + ((PS * P.fc_prows + 15) & ~15);         // interior (x, y) at score[(y+1)*SS + 4 + x]; zero ring around it
     unsigned short* list = reinterpret_cast<unsigned short*>(score + ((SS * P.fc_srows + 15) & ~15));
     const int ng = (cw + 3) >> 2;                                    // 4-pixel groups per interior row
     {
         int spitch; const uint8_t* src = level_src(P, frame, cd.level, spitch);
-        src += (long long)cd.iniY * spitch + cd.iniX - 1;              // the byte left of the sub-image is inside the image (cells start >= 16 px in)
-        const int nd = (pw + 1 + 3) >> 2;
+        src += (long long)cd.iniY * spitch + cd.iniX;
+        const int nd = (pw + 3) >> 2;
         {
-            // 32-bit loads at the patch's own byte alignment (global loads need no alignment on this target), so LDS column 0
-            // is a dword boundary without any shifting.  Lane = (row, dword column) with 16 (or 32) lanes per row;
+            // 32-bit loads at the patch's own byte alignment (global loads need no alignment on this target), so patch column 0
+            // lands on an LDS dword boundary without any shifting.  Lane = (row, dword column) with 16 (or 32) lanes per row;
             // FC_LD passes are put in flight before the first LDS write.  The last dword of a row may read up to 3 bytes past
             // the patch: still inside the image row (cells end >= 16 px before the right border).
             const int lw = nd <= 16 ? 4 : 5, rpp = 64 >> lw;             // log2 lanes per row, rows per pass
@@ -504,23 +497,17 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
     //      b. exact scores of those pairs only (compacted: a lane per listed pair)
     //      c. NMS + row-major emission over the listed pairs
     int nq = 0;
-    const unsigned th4 = (unsigned)min(P.iniTh >> 1, 127) * 0x01010101u;
     for (int it = 0; it < iters; it++) {
         const int y = it * rp + sr;
         bool pass_a = false, pass_b = false;
         if (lane_ok && y < ch) {
-            // window rows y .. y+6 of the sub-image, centre row y+3; centre pixels = LDS columns 4*grp+4 .. 4*grp+7 (one aligned dword);
-            // ring columns dx = -3 .. 3 are byte offsets from there (LDS dword reads need no alignment on this target)
-            const uint8_t* c = patch + (y + 3) * PS + 4 * grp + 4;
-            typedef const u32_unaligned* up;
-            const FastSwar f = fast_swar_centre(*reinterpret_cast<const unsigned*>(c), th4);
-            unsigned bright = 0x80808080u, dark = 0x80808080u;
-            fast_swar_pair(f, *reinterpret_cast<const unsigned*>(c + 3 * PS), *reinterpret_cast<const unsigned*>(c - 3 * PS), bright, dark);       // k = 0, 8:  (0, +3), (0, -3)
-            fast_swar_pair(f, *reinterpret_cast<up>(c + 3), *reinterpret_cast<up>(c - 3), bright, dark);                                         // k = 4, 12: (+3, 0), (-3, 0)
-            fast_swar_pair(f, *reinterpret_cast<up>(c + 2 * PS + 2), *reinterpret_cast<up>(c - 2 * PS - 2), bright, dark);                       // k = 2, 10: (+2, +2), (-2, -2)
-            fast_swar_pair(f, *reinterpret_cast<up>(c - 2 * PS + 2), *reinterpret_cast<up>(c + 2 * PS - 2), bright, dark);                       // k = 6, 14: (+2, -2), (-2, +2)
-            const unsigned hit = bright | dark;                      // bit 7 of byte q: pixel q of the group may be a corner at iniThFAST
-            pass_a = (hit & 0x00008080u) != 0; pass_b = (hit & 0x80800000u) != 0;
+            unsigned w[7][3];
+            fc_load_window(patch, PS, y, grp, w);
+            const pku16 ra[16] = FC_RING(0);
+            const pku16 rb[16] = FC_RING(2);
+            const pki16 pa = fast_pretest_pair(ra, row_pair<3>(w[3][0], w[3][1], w[3][2]), P.iniTh);         // score >= t  <=>  best arc margin > t  =>  every opposite pair's margin > t
+            const pki16 pb = fast_pretest_pair(rb, row_pair<5>(w[3][0], w[3][1], w[3][2]), P.iniTh);
+            pass_a = (pa[0] | pa[1]) != 0; pass_b = (pb[0] | pb[1]) != 0;
         }
         const unsigned long long ma = __ballot(pass_a), mb = __ballot(pass_b);
         int pos = nq + __popcll(ma & below) + __popcll(mb & below);
@@ -534,14 +521,14 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
             const int id = list[qb + lane], y = id >> 8, pr = id & 0xff, x0 = 2 * pr;
             // the pair's 7 x 8-byte window, shifted so that it starts at byte 0 of the first dword whichever half of the group it is
             const unsigned* prow = reinterpret_cast<const unsigned*>(patch + y * PS) + (pr >> 1);
-            const unsigned sh = 2u * (unsigned)(pr & 1) + 1u;          // + 1: LDS column = sub-image column + 1
+            const unsigned sh = 2u * (unsigned)(pr & 1);
             unsigned w[7][3];
 #pragma unroll
             for (int r = 0; r < 7; r++) {
                 const unsigned d0 = prow[r * (PS >> 2)], d1 = prow[r * (PS >> 2) + 1], d2 = prow[r * (PS >> 2) + 2];
                 w[r][0] = __builtin_amdgcn_alignbyte(d1, d0, sh); w[r][1] = __builtin_amdgcn_alignbyte(d2, d1, sh); w[r][2] = 0;
             }
-            const pku16 ra[16] = FC_RING(3);
+            const pku16 ra[16] = FC_RING(0);
             const pki16 sa = fast_score_pair(ra, row_pair<3>(w[3][0], w[3][1], w[3][2]));
             int s0 = sa[0], s1 = sa[1];
             if (s0 < P.iniTh || x0 >= cw) s0 = 0;
@@ -603,10 +590,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
         if (lane_ok && y < ch) {
             unsigned w[7][3];
             fc_load_window(patch, PS, y, grp, w);
-            const pku16 ra[16] = FC_RING(4);
-            const pku16 rb[16] = FC_RING(6);
-            const pki16 sa = fast_score_pair(ra, row_pair<4>(w[3][0], w[3][1], w[3][2]));
-            const pki16 sb = fast_score_pair(rb, row_pair<6>(w[3][0], w[3][1], w[3][2]));
+            const pku16 ra[16] = FC_RING(0);
+            const pku16 rb[16] = FC_RING(2);
+            const pki16 sa = fast_score_pair(ra, row_pair<3>(w[3][0], w[3][1], w[3][2]));
+            const pki16 sb = fast_score_pair(rb, row_pair<5>(w[3][0], w[3][1], w[3][2]));
             const int x0 = 4 * grp;
             sc[0] = sa[0]; sc[1] = sa[1]; sc[2] = sb[0]; sc[3] = sb[1];
 #pragma unroll
