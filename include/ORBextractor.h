@@ -83,6 +83,12 @@ public:
     // class is compiled for x86-64, 0 elsewhere — i.e. what the OpenCV this class stands in for would have computed on this machine.
     void SetBlurRounding(int mode);
     int GetBlurRounding() const { return mnBlurRounding; }
+    // The pattern rotation of computeOrbDescriptor (ORBextractor.cc:118-120): 1 = the fused multiply-adds gcc emits for the
+    // reference's own flags (-O3 -march=native on an FMA-capable host), 0 = two roundings per expression.  The default is what THIS class's
+    // compiler flags say the reference's translation unit would have been built like: 1 when compiled with FMA code generation enabled
+    // (__FMA__, e.g. by the reference's -march=native), 0 otherwise.  About one descriptor bit per few hundred frames depends on it.
+    void SetFpContract(int mode);
+    int GetFpContract() const { return mnFpContract; }
 
     // Asynchronous form for callers that own more than one camera or keep a queue of frames (the reference has none: Frame::ExtractORB is
     // synchronous, Frame.cc:247-253).  Submit() uploads and enqueues a batch of equally sized CV_8UC1 images and returns a ticket; up to
@@ -138,7 +144,7 @@ protected:
     std::vector<float> mvMapX, mvMapY; int mnRawCols, mnRawRows; // rectification maps (applied when the context is (re)created)
     int mnLastN;                                                 // key points of the last image
     orbhip_ctx* mpCtx;          // device context for the current image size (created lazily, re-created on a size change)
-    int mnCtxW, mnCtxH, mnCtxBatch, mnDevice, mnBlurRounding;
+    int mnCtxW, mnCtxH, mnCtxBatch, mnDevice, mnBlurRounding, mnFpContract;
     std::vector<int> mvTicketSizes;                              // images per ticket in flight (Submit / Collect), by ticket mod 4
     bool mbDownloadPyramid;
     float mfScaleFactorArg;

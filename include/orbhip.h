@@ -78,6 +78,10 @@ orbhip_status orbhip_get_scale_tables(const orbhip_ctx* ctx, float* scale_factor
 orbhip_status orbhip_level_size(const orbhip_ctx* ctx, int level, int* w, int* h);
 /* blur_round_mode of the configuration, changeable between calls (ORBextractor::SetBlurRounding) */
 orbhip_status orbhip_set_blur_rounding(orbhip_ctx* ctx, int mode);
+/* The pattern rotation of computeOrbDescriptor (ORBextractor.cc:118-120): 0 (default) = two roundings per expression, the form of a build
+   with -ffp-contract=off; 1 = the fused forms gcc emits with the reference's own flags (CMakeLists.txt:11-14, -O3 -march=native on an
+   FMA-capable host): fma(x, b, y*a) and fma(x, a, -(y*b)).  The two differ in about one descriptor bit per few hundred frames (H3). */
+orbhip_status orbhip_set_fp_contract(orbhip_ctx* ctx, int mode);
 
 /* ORBextractor::operator() (ORBextractor.h:59-61, ORBextractor.cc:1043-1105): host image in, host keypoints +
    descriptors out, synchronous.  Keypoints are level-major, quadtree-list order within a level; descriptor

@@ -357,7 +357,10 @@ float IC_Angle(const View& image, float ptx, float pty, const std::vector<int>& 
 
 // ORBextractor.cc:107-147
 const float factorPI = (float)(3.14159265358979323846 / 180.f);
-void computeOrbDescriptor(const KeyPoint& kpt, const View& img, uint8_t* desc)
+// fp_contract = 1: the arithmetic of a reference binary built with the reference's own flags (CMakeLists.txt:11-14, -O3 -march=native:
+// gcc contracts  x*b + y*a  to  fma(x, b, y*a)  and  x*a - y*b  to  fma(x, a, -(y*b)) — read off the object code of
+// oracle/_ref/liborbextractor_ref_native.so); 0: two roundings per expression (the canonical form, H3)
+void computeOrbDescriptor(const KeyPoint& kpt, const View& img, uint8_t* desc, int fp_contract = 0)
 {
     float angle = (float)kpt.angle * factorPI;
     float a, b; glibc_sincosf(angle, &b, &a);      // a = cos, b = sin
@@ -368,8 +371,14 @@ void computeOrbDescriptor(const KeyPoint& kpt, const View& img, uint8_t* desc)
         int val = 0;
         for (int k = 0; k < 8; k++) {
             int x0 = pat[4 * k], y0 = pat[4 * k + 1], x1 = pat[4 * k + 2], y1 = pat[4 * k + 3];
-            int t0 = center[cvRoundF(x0 * b + y0 * a) * step + cvRoundF(x0 * a - y0 * b)];
-            int t1 = center[cvRoundF(x1 * b + y1 * a) * step + cvRoundF(x1 * a - y1 * b)];
+            int t0, t1;
+            if (fp_contract) {
+                t0 = center[cvRoundF(std::fmaf((float)x0, b, (float)y0 * a)) * step + cvRoundF(std::fmaf((float)x0, a, -((float)y0 * b)))];
+                t1 = center[cvRoundF(std::fmaf((float)x1, b, (float)y1 * a)) * step + cvRoundF(std::fmaf((float)x1, a, -((float)y1 * b)))];
+            } else {
+                t0 = center[cvRoundF(x0 * b + y0 * a) * step + cvRoundF(x0 * a - y0 * b)];
+                t1 = center[cvRoundF(x1 * b + y1 * a) * step + cvRoundF(x1 * a - y1 * b)];
+            }
             val |= (t0 < t1) << k;
         }
         desc[i] = (uint8_t)val;
@@ -486,7 +495,7 @@ std::vector<KeyPoint> DistributeOctTree(const std::vector<KeyPoint>& vToDistribu
 
 // ---------------------------------------------------------------- the extractor (ORBextractor.cc:410-470, 765-853, 1043-1132)
 struct Extractor {
-    int nfeatures; double scaleFactor; int nlevels, iniThFAST, minThFAST; int blur_round_mode = 0;
+    int nfeatures; double scaleFactor; int nlevels, iniThFAST, minThFAST; int blur_round_mode = 0, fp_contract = 0;
     std::vector<int> mnFeaturesPerLevel, umax;
     std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
     std::vector<Image> pyr, blurred;                       // level interiors (apron never read)
@@ -588,7 +597,7 @@ struct Extractor {
             if (n == 0) continue;
             gaussian_blur_7x7(pyr[level].view(), blurred[level], blur_round_mode);
             View wm = blurred[level].view();
-            for (int i = 0; i < n; i++) computeOrbDescriptor(keypoints[i], wm, &desc[(size_t)(offset + i) * 32]);
+            for (int i = 0; i < n; i++) computeOrbDescriptor(keypoints[i], wm, &desc[(size_t)(offset + i) * 32], fp_contract);
             offset += n;
             if (level != 0) { float scale = mvScaleFactor[level]; for (auto& k : keypoints) { k.x *= scale; k.y *= scale; } }
             keys.insert(keys.end(), keypoints.begin(), keypoints.end());
@@ -979,6 +988,7 @@ void* orb_oracle_create(int nfeatures, float scaleFactor, int nlevels, int iniTh
 { return new Extractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST); }
 void orb_oracle_destroy(void* h) { delete (Extractor*)h; }
 void orb_oracle_set_blur_round_mode(void* h, int mode) { ((Extractor*)h)->blur_round_mode = mode; }
+void orb_oracle_set_fp_contract(void* h, int mode) { ((Extractor*)h)->fp_contract = mode; }
 
 // runs ORBextractor::operator(); returns N; copies up to cap keypoints (28 B each) and descriptors (32 B each)
 int orb_oracle_extract(void* h, const uint8_t* img, int w, int ht, int stride, void* kps, uint8_t* desc, int cap)

@@ -41,6 +41,7 @@ def lib(fast=False):
     L.orb_oracle_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
     L.orb_oracle_destroy.argtypes = [vp]
     L.orb_oracle_set_blur_round_mode.argtypes = [vp, C.c_int]
+    L.orb_oracle_set_fp_contract.argtypes = [vp, C.c_int]
     L.orb_oracle_extract.restype = C.c_int
     L.orb_oracle_extract.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int]
     L.orb_oracle_get_params.argtypes = [vp, vp, vp, vp, vp, vp, vp]
@@ -106,12 +107,13 @@ class OracleExtractor:
     """CPU restatement of ORB_SLAM2::ORBextractor (ORBextractor.h:45-111)."""
 
     def __init__(self, nfeatures=2000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7, fast=False,
-                 blur_round_mode=0):
+                 blur_round_mode=0, fp_contract=0):
         self.L = lib(fast)
         self.nlevels = nlevels
         self.nfeatures = nfeatures
         self.h = self.L.orb_oracle_create(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)
         self.L.orb_oracle_set_blur_round_mode(self.h, blur_round_mode)
+        self.L.orb_oracle_set_fp_contract(self.h, fp_contract)      # 1 = the FMA forms gcc emits for the reference's own flags (H3)
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -64,6 +64,26 @@ def dropin_full_lib():
     return _dropin_full
 
 
+# the same two builds linked to the real liborbhip.so (make dropin_gpu): built where /root/reference is mounted, run by the -m gpu tests
+DROPIN_GPU_PATH = os.path.join(HERE, "_ref", "liborbslam_dropin_gpu.so")
+DROPIN_FULL_GPU_PATH = os.path.join(HERE, "_ref", "liborbslam_dropin_full_gpu.so")
+_dropin_gpu = {}
+
+
+def build_dropin_gpu():
+    import subprocess
+    if os.path.isdir("/root/reference/src"):
+        subprocess.check_call(["make", "-C", HERE, "-s", "dropin_gpu"])
+    return os.path.exists(DROPIN_GPU_PATH) and os.path.exists(DROPIN_FULL_GPU_PATH)
+
+
+def dropin_gpu_lib(full=False):
+    path = DROPIN_FULL_GPU_PATH if full else DROPIN_GPU_PATH
+    if path not in _dropin_gpu:
+        _dropin_gpu[path] = _bind(C.CDLL(path))
+    return _dropin_gpu[path]
+
+
 def lib():
     global _lib
     if _lib is None:

@@ -149,6 +149,7 @@ Rig& rig(int nfeat, float scale, int nlevels, int ini, int mn)
         Rig r = {new ORBextractor(nfeat, scale, nlevels, ini, mn), new ORBextractor(nfeat, scale, nlevels, ini, mn)};
 #ifdef ORBSLAM_DROPIN_BUILD
         r.left->SetBlurRounding(mode); r.right->SetBlurRounding(mode);
+        r.left->SetFpContract(0); r.right->SetFpContract(0);        // the all-reference build beside it is compiled with -ffp-contract=off
 #endif
         it = g_rigs.insert(std::make_pair(key, r)).first;
     }

@@ -26,6 +26,11 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int
 #else
       mnBlurRounding(0),
 #endif
+#if defined(__FMA__)
+      mnFpContract(1),            // this translation unit is compiled with FMA code generation (the reference's -march=native): gcc would have fused the rotation
+#else
+      mnFpContract(0),
+#endif
       mvTicketSizes(4, 0), mbDownloadPyramid(false), mfScaleFactorArg(_scaleFactor)
 {
     memset(mCamera, 0, sizeof mCamera);
@@ -38,6 +43,7 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int
     mnFeaturesPerLevel.resize(nlevels);
     if (const char* dev = getenv("ORBHIP_DEVICE")) mnDevice = atoi(dev);
     if (const char* br = getenv("ORBHIP_BLUR_ROUNDING")) mnBlurRounding = atoi(br) ? 1 : 0;      // deployment override of the host default (see SetBlurRounding)
+    if (const char* fc = getenv("ORBHIP_FP_CONTRACT")) mnFpContract = atoi(fc) ? 1 : 0;
 }
 
 ORBextractor::~ORBextractor() { if (mpCtx) orbhip_destroy(mpCtx); }
@@ -51,6 +57,12 @@ void ORBextractor::SetBlurRounding(int mode)
 {
     mnBlurRounding = mode ? 1 : 0;
     if (mpCtx && orbhip_set_blur_rounding(mpCtx, mnBlurRounding) != ORBHIP_OK) Fail("ORBextractor::SetBlurRounding");
+}
+
+void ORBextractor::SetFpContract(int mode)
+{
+    mnFpContract = mode ? 1 : 0;
+    if (mpCtx && orbhip_set_fp_contract(mpCtx, mnFpContract) != ORBHIP_OK) Fail("ORBextractor::SetFpContract");
 }
 
 void ORBimagePyramid::Refresh()
@@ -83,6 +95,7 @@ void ORBextractor::EnsureContext(int width, int height, int maxBatch)
     // the reference cannot fail here; a missing GPU or an unsupported geometry must not silently produce empty frames
     if (orbhip_create(&mpCtx, &cfg) != ORBHIP_OK) { mpCtx = NULL; Fail("ORBextractor"); }
     mnCtxW = width; mnCtxH = height; mnCtxBatch = maxBatch;
+    if (orbhip_set_fp_contract(mpCtx, mnFpContract) != ORBHIP_OK) Fail("ORBextractor");
     if (mbHasCamera) {
         orbhip_camera cam; memcpy(&cam, mCamera, sizeof cam);
         if (orbhip_set_camera(mpCtx, &cam) != ORBHIP_OK) Fail("ORBextractor");

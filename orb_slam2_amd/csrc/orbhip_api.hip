@@ -60,7 +60,7 @@ struct HostSet {
 };
 
 struct orbhip_ctx {
-    orbhip_config cfg; int L = 0, B = 0;
+    orbhip_config cfg; int L = 0, B = 0, fp_contract = 0;
     std::vector<LevelGeom> geom; std::vector<float> sf, isf, s2, is2; std::vector<int> nfeat;
     std::vector<CellDesc> cells; std::vector<TileDesc> blur_tiles; std::vector<int2> xtab, ytab; std::vector<char> pyr_staged;
     int gk[4] = {0, 0, 0, 0};
@@ -423,6 +423,13 @@ extern "C" orbhip_status orbhip_set_blur_rounding(orbhip_ctx* c, int mode)
     return ORBHIP_OK;
 }
 
+extern "C" orbhip_status orbhip_set_fp_contract(orbhip_ctx* c, int mode)
+{
+    if (!c || (mode != 0 && mode != 1)) return fail(ORBHIP_ERR_INVALID, "fp_contract is 0 (two roundings) or 1 (gcc's fused forms)");
+    c->fp_contract = mode;
+    return ORBHIP_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- pipeline
 static ExtractParams make_params(orbhip_ctx* c, const uint8_t* d_img0, long long frame_stride, int row_stride)
 {
@@ -437,7 +444,7 @@ static ExtractParams make_params(orbhip_ctx* c, const uint8_t* d_img0, long long
     P.out_kp = c->d_out_kp[c->cur]; P.out_desc = c->d_out_desc[c->cur]; P.out_n = c->d_out_n[c->cur]; P.out_cap = c->out_cap;
     P.blur_tiles = c->d_tiles; P.nblur_tiles = (int)c->blur_tiles.size();
     P.xtab = c->d_xtab; P.ytab = c->d_ytab; P.patternf = c->d_pattern;
-    P.iniTh = c->cfg.ini_th_fast; P.minTh = c->cfg.min_th_fast; P.blur_round_mode = c->cfg.blur_round_mode;
+    P.iniTh = c->cfg.ini_th_fast; P.minTh = c->cfg.min_th_fast; P.blur_round_mode = c->cfg.blur_round_mode; P.fp_contract = c->fp_contract;
     P.qt_maxn = c->qt_maxn; P.qt_maxcells = c->qt_maxcells; P.qt_scr = orbhip_quadtree_scr(c->qt_maxn, c->qt_maxcells);
     P.fc_pstride = (c->fc_maxpw + 8 + 3) & ~3; P.fc_prows = c->fc_maxph; P.fc_sstride = 8 + 4 * ((std::max(c->fc_maxpw - 6, 0) + 3) / 4); P.fc_srows = std::max(c->fc_maxph - 6, 0) + 2;
     P.fc_listcap = std::max(c->fc_maxpw - 6, 0) * std::max(c->fc_maxph - 6, 0);

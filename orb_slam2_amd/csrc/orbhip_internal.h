@@ -63,7 +63,7 @@ struct ExtractParams {
     const TileDesc* blur_tiles; int nblur_tiles;
     const int2* xtab; const int2* ytab;
     const float* patternf;                                                 // 256 x (x0,y0,x1,y1) as floats (rBRIEF pattern, ORBextractor.cc:150-408)
-    int iniTh, minTh, blur_round_mode;
+    int iniTh, minTh, blur_round_mode, fp_contract;
     int qt_maxn;                                                           // LDS node capacity of the quadtree kernel
     int qt_maxcells;                                                       // max cells of one level
     int qt_scr;                                                            // ints of scan scratch in the quadtree's LDS layout

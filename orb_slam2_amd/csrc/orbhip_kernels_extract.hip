@@ -1068,15 +1068,26 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
     __syncthreads();                                               // window visible to all lanes of the wave (exited waves do not participate)
     const uint8_t* w8 = reinterpret_cast<const uint8_t*>(win) + 18 * (DS_WDW * 4) + (cx - wx0);   // keypoint position inside the window
     unsigned long long* dout = reinterpret_cast<unsigned long long*>(P.out_desc + ((long long)frame * P.out_cap + oi) * 32);
+    // P.fp_contract (wave-uniform): 0 = x*b + y*a as two roundings (a build with -ffp-contract=off, H3), 1 = the fused forms gcc emits
+    // for the reference's own flags, fma(x, b, y*a) and fma(x, a, -(y*b))
+    auto brief = [&](auto fused) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const float x0 = pt[r].x, y0 = pt[r].y, x1 = pt[r].z, y1 = pt[r].w;
-        const int iy0 = round_half_even_small(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a))), ix0 = round_half_even_small(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-        const int iy1 = round_half_even_small(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a))), ix1 = round_half_even_small(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        const int t0 = w8[iy0 * (DS_WDW * 4) + ix0], t1 = w8[iy1 * (DS_WDW * 4) + ix1];
-        const unsigned long long bits = __ballot(t0 < t1);       // test 64r+lane -> byte (64r+lane)/8, bit lane%8
-        if (lane == 0) dout[r] = bits;
-    }
+        for (int r = 0; r < 4; r++) {
+            const float x0 = pt[r].x, y0 = pt[r].y, x1 = pt[r].z, y1 = pt[r].w;
+            int iy0, ix0, iy1, ix1;
+            if (decltype(fused)::value) {
+                iy0 = round_half_even_small(__fmaf_rn(x0, b, __fmul_rn(y0, a))); ix0 = round_half_even_small(__fmaf_rn(x0, a, -__fmul_rn(y0, b)));
+                iy1 = round_half_even_small(__fmaf_rn(x1, b, __fmul_rn(y1, a))); ix1 = round_half_even_small(__fmaf_rn(x1, a, -__fmul_rn(y1, b)));
+            } else {
+                iy0 = round_half_even_small(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a))); ix0 = round_half_even_small(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+                iy1 = round_half_even_small(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a))); ix1 = round_half_even_small(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+            }
+            const int t0 = w8[iy0 * (DS_WDW * 4) + ix0], t1 = w8[iy1 * (DS_WDW * 4) + ix1];
+            const unsigned long long bits = __ballot(t0 < t1);       // test 64r+lane -> byte (64r+lane)/8, bit lane%8
+            if (lane == 0) dout[r] = bits;
+        }
+    };
+    if (P.fp_contract) brief(std::true_type{}); else brief(std::false_type{});
     if (lane == 0) {
         orbhip_keypoint kp;
         kp.x = __fmul_rn((float)cx, g.scale); kp.y = __fmul_rn((float)cy, g.scale);     // pt *= scale (:1095-1101); scale[0] == 1

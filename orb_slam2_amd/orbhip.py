@@ -33,7 +33,7 @@ SYMBOLS = [
     "orbhip_search_for_initialization_bounds", "orbhip_search_by_projection_bounds", "orbhip_search_best_in_window_bounds",
     "orbhip_set_rectification", "orbhip_extract_batch_rectify", "orbhip_extract_device_rectify", "orbhip_compute_stereo_from_rgbd",
     "orbhip_search_by_projection_frame", "orbhip_search_best_in_window_frame",
-    "orbhip_pyramid_fetch_all", "orbhip_set_blur_rounding", "orbhip_submit", "orbhip_collect", "orbhip_ring_depth", "orbhip_host_alloc", "orbhip_host_free",
+    "orbhip_pyramid_fetch_all", "orbhip_set_blur_rounding", "orbhip_set_fp_contract", "orbhip_submit", "orbhip_collect", "orbhip_ring_depth", "orbhip_host_alloc", "orbhip_host_free",
     "orbhip_pool_create", "orbhip_pool_destroy", "orbhip_pool_num_devices", "orbhip_pool_device_of", "orbhip_pool_keypoint_capacity",
     "orbhip_pool_extract", "orbhip_pool_submit", "orbhip_pool_collect", "orbhip_pool_db_load", "orbhip_pool_db_shard", "orbhip_pool_db_query",
     "orbhip_reloc_candidates",
@@ -159,6 +159,7 @@ def lib(path=None):
     L.orbhip_debug_candidates.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, ip]
     L.orbhip_pyramid_fetch_all.argtypes = [vp, C.c_int, vp, vp]
     L.orbhip_set_blur_rounding.argtypes = [vp, C.c_int]
+    L.orbhip_set_fp_contract.argtypes = [vp, C.c_int]
     L.orbhip_submit.argtypes = [vp, C.c_int, vp, C.c_int, ip]
     L.orbhip_collect.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp]
     L.orbhip_host_alloc.argtypes = [C.c_size_t]
@@ -258,6 +259,11 @@ class ORBextractor:
     def SetBlurRounding(self, mode):
         """cv::GaussianBlur's last rounding: 0 = OpenCV generic C++, 1 = the SSE2 column filter of x86-64 builds (DESIGN.md H2)"""
         _check(self.L.orbhip_set_blur_rounding(self.h, int(mode)), "orbhip_set_blur_rounding", self.L)
+
+    def SetFpContract(self, mode):
+        """Pattern rotation of computeOrbDescriptor: 0 = two roundings (-ffp-contract=off), 1 = gcc's fused forms under the reference's own
+        flags (-O3 -march=native), DESIGN.md H3"""
+        _check(self.L.orbhip_set_fp_contract(self.h, int(mode)), "orbhip_set_fp_contract", self.L)
 
     # ---- operator()
     def __call__(self, image, mask=None):

@@ -201,6 +201,7 @@ inline void __threadfence_block() {}
 
 // IEEE round-to-nearest arithmetic intrinsics (the emu build uses -ffp-contract=off, so plain ops are exact)
 inline float __fmul_rn(float a, float b) { return a * b; }
+inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }       // correctly rounded fused multiply-add
 inline float __fadd_rn(float a, float b) { return a + b; }
 inline float __fsub_rn(float a, float b) { return a - b; }
 inline float __fdiv_rn(float a, float b) { return a / b; }

@@ -52,3 +52,19 @@ def test_frames_equal_the_reference_constructors(backend):
     ns = len(kl[0])
     assert u[0, :ns].tobytes() == G["stereo_u_right"].tobytes() and z[0, :ns].tobytes() == G["stereo_depth"].tobytes()
     xl.close(); xr.close()
+
+
+def test_native_flags_build_fixture(backend):
+    """tests/golden/extract_native_flags_640x480.npz: a frame on which the reference's ORBextractor.cc built with its own flags (FMA
+    contraction) and the canonical two-rounding build disagree in a descriptor bit.  fp_contract = 1 reproduces the former, 0 the latter."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "extract_native_flags_640x480.npz"))
+    w, h, n, nl = [int(v) for v in g["config"]]
+    img = synth.frame(w, h, seed=int(g["seed"]))
+    ex = orb_slam2_amd.ORBextractor(n, float(g["scale"]), nl, 20, 7, w, h, library=backend)
+    assert not np.array_equal(g["descriptors"], g["canonical_descriptors"])
+    for mode, want in ((1, g["descriptors"]), (0, g["canonical_descriptors"])):
+        ex.SetFpContract(mode)
+        k, d = ex(img)
+        assert k.tobytes() == g["keypoints"].tobytes() and np.array_equal(d, want), f"fp_contract {mode}"
+    ex.close()

@@ -21,12 +21,19 @@ import pytest
 from orb_slam2_amd import synth
 
 
-@pytest.fixture(scope="module", params=[lambda S: S.dropin_lib(), lambda S: S.dropin_full_lib()], ids=["steps1-3", "all-steps"])
-def builds(request, emu_lib):
+@pytest.fixture(scope="module", params=["steps1-3", "all-steps", pytest.param("steps1-3-gpu", marks=pytest.mark.gpu), pytest.param("all-steps-gpu", marks=pytest.mark.gpu)])
+def builds(request):
+    """The binding on the CPU emulation of the kernels (here) and — the same reference sources, the same drop-in classes, linked to the real
+    liborbhip.so (oracle/_ref/liborbslam_dropin*_gpu.so, built here, shipped with the repository snapshot) — on the MI355X box."""
     from oracle import orbslam_ref as S
+    if request.param.endswith("-gpu"):
+        if not (S.build() and S.build_dropin_gpu()):
+            pytest.fail("oracle/_ref/liborbslam_dropin_gpu.so did not travel with the repository (build it with `make -C oracle dropin_gpu` where /root/reference is mounted)")
+        return S, S.dropin_gpu_lib(full=request.param.startswith("all-steps"))
+    request.getfixturevalue("emu_lib")
     if not (S.build() and S.build_dropin()):
         pytest.skip("reference sources not mounted")
-    return S, request.param(S)
+    return S, (S.dropin_full_lib() if request.param == "all-steps" else S.dropin_lib())
 
 
 def _same(a, b):
