@@ -8,6 +8,10 @@ for the same map points —
   fuse    ORBmatcher().Fuse(KeyFrame, vector<MapPoint*>, th = 3)                                ORBmatcher.cc:825-972
   bow0/1  ORBmatcher(0.8, true).SearchByBoW(KeyFrame, Frame, ..) / (KeyFrame, KeyFrame, ..)     ORBmatcher.cc:159-288, 522-655
   tri     ORBmatcher(0.6, true).SearchForTriangulation(KF1, KF2, F12, .., false)                ORBmatcher.cc:657-823
+  fuse3   ORBmatcher().Fuse(KeyFrame, Scw = identity, vpPoints, th = 4, vpReplacePoint)           ORBmatcher.cc:974-1100
+  kfsim3  ORBmatcher(0.75, true).SearchByProjection(KeyFrame, Scw = identity, vpPoints, vpMatched, th = 10)   ORBmatcher.cc:290-403
+  reloc   ORBmatcher(0.9, true).SearchByProjection(CurrentFrame, KeyFrame, sAlreadyFound, th = 10, ORBdist = 100)   ORBmatcher.cc:1472-1599
+  sim3    ORBmatcher(0.75, true).SearchBySim3(KF1, KF2, vpMatches12, s = 1, R = I, t = 0, th = 7.5)   ORBmatcher.cc:1102-1326
 so that machines without the reference (the GPU box) can compare the HIP path with the reference's results directly."""
 import os
 import sys
@@ -90,11 +94,63 @@ invz = np.float32(1.0) / t2w[2]
 out.update(tri_has1=tri_has1, tri_has2=tri_has2, tri_F12=F12, tri_ex=np.float32(1.0) * t2w[0] * invz + np.float32(0.0), tri_ey=np.float32(1.0) * t2w[1] * invz + np.float32(0.0),
            tri_n=n_r, tri_match12=m_r, scale_factors=sf, sigma2=par["sigma2"])
 
+# ---- the loop-closing / relocalisation members (identity pose and similarity: a world point (X, Y, 1) projects to (X, Y))
+dc = F[1].desc
+def world(kpts):
+    m = len(kpts)
+    Xw = (kpts["x"] - 3.0 + rng.normal(0, 1.2, m)).astype(np.float32); Yw = (kpts["y"] - 1.0 + rng.normal(0, 1.2, m)).astype(np.float32)
+    Xw[:4] = -2.0; Xw[4:7] = w + 1.0; Yw[7:9] = h                                  # outside the image: skipped by IsInImage / the bounds test
+    return Xw, Yw, np.clip(kpts["octave"] + rng.integers(0, 2, m), 0, 7).astype(np.int32)
+one = np.ones(nq, np.float32)
+# Fuse(pKF, Scw, vpPoints, th, vpReplacePoint): no chi-square gate
+X, Y, lvl = world(kl)
+bad = (rng.random(nq) < 0.05).astype(np.uint8); state = rng.choice([0, 0, 1], len(kc)).astype(np.uint8)
+n_r, b_r = S.fuse_sim3(F[1], state, X, Y, one, lvl, bad, dl, th=4.0)
+keep = np.nonzero((bad == 0) & (X >= 0) & (X < w) & (Y >= 0) & (Y < h))[0]
+bq = np.zeros(len(keep), O.BEST_QUERY_DTYPE)
+bq["x"], bq["y"], bq["radius"], bq["level"] = X[keep], Y[keep], (np.float32(4.0) * sf[lvl[keep]]).astype(np.float32), lvl[keep]
+out.update(fuse3_queries=bq, fuse3_qdesc=dl[keep], fuse3_n=n_r, fuse3_best=b_r[keep])
+# SearchByProjection(pKF, Scw, vpPoints, vpMatched, th): levels [L-1, L], TH_LOW, no orientation check, vpMatched = the blocked set
+X, Y, lvl = world(kl)
+bad = (rng.random(nq) < 0.05).astype(np.uint8); ms = (rng.random(len(kc)) < 0.2).astype(np.uint8)
+n_r, fq_r = S.search_by_projection_kf(F[1], ms, X, Y, one, lvl, bad, dl, th=10)
+keep = np.nonzero((bad == 0) & (X >= 0) & (X < w) & (Y >= 0) & (Y < h))[0]
+q = np.zeros(len(keep), O.PROJ_QUERY_DTYPE)
+q["x"], q["y"], q["radius"] = X[keep], Y[keep], (np.float32(10) * sf[lvl[keep]]).astype(np.float32)
+q["min_level"], q["max_level"], q["blocks"] = lvl[keep] - 1, lvl[keep], 1
+inv = np.full(nq, -1, np.int32); inv[keep] = np.arange(len(keep))
+out.update(kfsim3_queries=q, kfsim3_qdesc=dl[keep], kfsim3_blocked=ms, kfsim3_n=n_r, kfsim3_feature_query=np.where(fq_r >= 0, inv[np.maximum(fq_r, 0)], -1).astype(np.int32))
+# SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist): levels [L-1, L+1], th_high = ORBdist, every feature with a map point blocked
+X, Y, lvl = world(kl)
+bad = (rng.random(nq) < 0.05).astype(np.uint8); has = (rng.random(nq) < 0.8).astype(np.uint8); found = (rng.random(nq) < 0.1).astype(np.uint8)
+cs = rng.choice([0, 0, 0, 1, 2], len(kc)).astype(np.uint8)
+n_r, fq_r = S.search_by_projection_reloc(F[1], F[0], has, X, Y, one, lvl, bad, found, dl, cs, th=10.0, orb_dist=100, nnratio=0.9, check_ori=True)
+keep = np.nonzero((has == 1) & (bad == 0) & (found == 0) & ~((X < 0) | (X > w) | (Y < 0) | (Y > h)))[0]
+q = np.zeros(len(keep), O.PROJ_QUERY_DTYPE)
+q["x"], q["y"], q["radius"] = X[keep], Y[keep], (np.float32(10.0) * sf[lvl[keep]]).astype(np.float32)
+q["min_level"], q["max_level"], q["blocks"], q["angle"] = lvl[keep] - 1, lvl[keep] + 1, 1, kl["angle"][keep]
+inv = np.full(nq, -1, np.int32); inv[keep] = np.arange(len(keep))
+out.update(reloc_queries=q, reloc_qdesc=dl[keep], reloc_blocked=(cs != 0).astype(np.uint8), reloc_n=n_r, reloc_feature_query=np.where(fq_r >= 0, inv[np.maximum(fq_r, 0)], -1).astype(np.int32))
+# SearchBySim3: two best-in-window passes (no gate, TH_HIGH) + the mutual check
+X1, Y1, lev1 = world(kl)
+X2 = (kc["x"] + 3.0 + rng.normal(0, 1.2, len(kc))).astype(np.float32); Y2 = (kc["y"] + 1.0 + rng.normal(0, 1.2, len(kc))).astype(np.float32)
+lev2 = np.clip(kc["octave"] + rng.integers(0, 2, len(kc)), 0, 7).astype(np.int32)
+has1 = (rng.random(len(kl)) < 0.8).astype(np.uint8); has2 = (rng.random(len(kc)) < 0.8).astype(np.uint8)
+n_r, m_r = S.search_by_sim3(F[0], has1, X1, Y1, np.ones(len(kl), np.float32), lev1, dl, F[1], has2, X2, Y2, np.ones(len(kc), np.float32), lev2, dc, th=7.5)
+def sim3_pass(hasA, XA, YA, levA):
+    keepA = np.nonzero((hasA == 1) & (XA >= 0) & (XA < w) & (YA >= 0) & (YA < h))[0]
+    qa = np.zeros(len(keepA), O.BEST_QUERY_DTYPE)
+    qa["x"], qa["y"], qa["radius"], qa["level"] = XA[keepA], YA[keepA], (np.float32(7.5) * sf[levA[keepA]]).astype(np.float32), levA[keepA]
+    return keepA.astype(np.int32), qa
+k1, q1 = sim3_pass(has1, X1, Y1, lev1)
+k2, q2 = sim3_pass(has2, X2, Y2, lev2)
+out.update(sim3_keep1=k1, sim3_queries1=q1, sim3_keep2=k2, sim3_queries2=q2, sim3_n=n_r, sim3_match12=m_r)
+
 out.update(prev_keys=F[0].keys_un, prev_desc=F[0].desc)
 out.update(cur_keys=F[1].keys_un, cur_desc=F[1].desc, image_checksum=np.int64(seq[1].astype(np.uint64).sum()))
 np.savez_compressed(os.path.join(here, "matchers_ref.npz"), **out)
 print("golden matchers:", out["local_n"], "local-map matches,", out["last_n"], "last-frame matches,", out["fuse_n"], "fused points,", out["bow0_n"], out["bow1_n"], "BoW matches,",
-      out["tri_n"], "triangulation pairs")
+      out["tri_n"], "triangulation pairs,", out["fuse3_n"], "Sim3-fused,", out["kfsim3_n"], "loop-closing,", out["reloc_n"], "relocalisation,", out["sim3_n"], "Sim3 matches")
 for f in F:
     f.close()
 S.RefFrame._geometry = None
