@@ -361,6 +361,18 @@ orbhip_status orbhip_search_best_in_window_bounds(int device, const orbhip_keypo
                                            const orbhip_best_query* queries, const uint8_t* query_desc, int nq, int chi2_gate,
                                            int32_t* best_idx, int32_t* best_dist);
 
+/* The same search for several frames (camera slots) in ONE pass (the multi-camera form of M2 / M3): slot s searches its
+   own frame with its own queries, the slots share mode, thresholds and image bounds (one camera geometry, e.g. the cameras of a rig or a
+   queue of frames of one camera).  One upload, one launch sequence with one workgroup per slot in the order-dependent kernel, one download
+   — the per-slot results are identical to nslots calls of orbhip_search_by_projection_bounds.  u_right / blocked may be NULL per slot. */
+typedef struct {
+    const orbhip_keypoint* kps; const uint8_t* desc; const float* u_right; const uint8_t* blocked; int32_t n;        /* the frame searched */
+    const orbhip_proj_query* queries; const uint8_t* query_desc; int32_t nq;                                         /* its map points */
+    int32_t* feature_query; int32_t nmatches;                                                                        /* out: n entries; the return value */
+} orbhip_proj_slot;
+orbhip_status orbhip_search_by_projection_batch(int device, int nslots, orbhip_proj_slot* slots, const orbhip_bounds* bounds,
+                                                int mode, float nnratio, int th_high, int check_ori);
+
 /* The same two searches on a frame that is still on the device (frame `frame` of the context's last extract call): key points
    (mvKeysUn when a distorted camera is attached), descriptors, the image bounds and — with use_u_right != 0 — mvuRight of the last
    orbhip_compute_stereo_matches (this context = left) / orbhip_compute_stereo_from_rgbd are read in HBM; only the queries, the

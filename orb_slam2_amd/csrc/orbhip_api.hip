@@ -1014,6 +1014,83 @@ extern "C" orbhip_status orbhip_search_by_projection_bounds(int device, const or
     return st;
 }
 
+// Several frames in one pass: every per-slot array lives at [slot][cap] of one arena (one copy each way), the order-dependent kernel runs
+// one workgroup per slot.
+extern "C" orbhip_status orbhip_search_by_projection_batch(int device, int nslots, orbhip_proj_slot* slots, const orbhip_bounds* bounds,
+                                                           int mode, float nnratio, int th_high, int check_ori)
+{
+    if (nslots < 0 || (nslots > 0 && !slots) || !bounds || !(bounds->max_x > bounds->min_x) || !(bounds->max_y > bounds->min_y) || (mode != 0 && mode != 1))
+        return fail(ORBHIP_ERR_INVALID, "bad argument");
+    int cap = 1, qcap = 1; bool any_ur = false, any_bl = false, work = false;
+    for (int s = 0; s < nslots; s++) {
+        orbhip_proj_slot& S = slots[s];
+        if (S.n < 0 || S.nq < 0 || (S.n > 0 && (!S.kps || !S.desc || !S.feature_query)) || (S.nq > 0 && (!S.queries || !S.query_desc))) return fail(ORBHIP_ERR_INVALID, "bad argument in slot %d", s);
+        S.nmatches = 0;
+        for (int i = 0; i < S.n; i++) S.feature_query[i] = -1;
+        cap = std::max(cap, S.n); qcap = std::max(qcap, S.nq);
+        any_ur = any_ur || S.u_right; any_bl = any_bl || S.blocked; work = work || (S.n > 0 && S.nq > 0);
+    }
+    if (!work) return ORBHIP_OK;
+    if (cap >= (1 << 19)) return fail(ORBHIP_ERR_UNSUPPORTED, "too many features");
+    if (orbhip_proj_select_lds(cap) > 150 * 1024) return fail(ORBHIP_ERR_UNSUPPORTED, "too many features for the LDS matcher (%d)", cap);
+    if ((size_t)nslots * qcap * cap * sizeof(unsigned) > ((size_t)2 << 30)) return fail(ORBHIP_ERR_UNSUPPORTED, "candidate lists of %d slots x %d queries x %d features exceed 2 GB: split the batch", nslots, qcap, cap);
+    int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(ORBHIP_ERR_HIP, "no HIP device available: no CPU fallback");
+    HIPCHK(hipSetDevice(device));
+    orbhip_keypoint* dk = nullptr; uint8_t *dd = nullptr, *dqd = nullptr; unsigned char* dbl = nullptr; float* dur = nullptr; int *dn = nullptr, *dnm = nullptr, *dgs = nullptr, *dgi = nullptr, *dnc = nullptr, *dfq = nullptr, *dev = nullptr;
+    float2* dgxy = nullptr; orbhip_proj_query* dq = nullptr; unsigned *dcand = nullptr, *dtop = nullptr; ProjParams* dJ = nullptr;
+    std::vector<int> hn(nslots), hnm(nslots, 0); std::vector<ProjParams> hJ(nslots);
+    std::vector<float> no_ur(any_ur ? cap : 0, -1.0f); std::vector<uint8_t> no_bl(any_bl ? cap : 0, 0);
+    for (int s = 0; s < nslots; s++) hn[s] = slots[s].n;
+    hipError_t e = hipSuccess;
+#define TRY(x) do { if (e == hipSuccess) e = (x); } while (0)
+    const size_t C = (size_t)cap, Q = (size_t)qcap;
+    {   // the parameter table is read from hJ when the arena is uploaded, i.e. after the device addresses below have been filled in
+        TRY(arena_layout(device, [&](Arena& A) {
+            A.io(&dJ, (size_t)nslots, (const ProjParams*)hJ.data(), (size_t)nslots);
+            A.io(&dn, (size_t)nslots, (const int*)hn.data(), (size_t)nslots);
+            A.io(&dnm, (size_t)nslots, (const int*)hnm.data(), (size_t)nslots, hnm.data(), (size_t)nslots);
+            for (int s = 0; s < nslots; s++) {                                        // [slot][cap] / [slot][qcap] blocks, each slot's rows from its own host arrays
+                const orbhip_proj_slot& S = slots[s];
+                orbhip_keypoint* k = nullptr; uint8_t *d = nullptr, *qd = nullptr; orbhip_proj_query* q = nullptr; float* ur = nullptr; unsigned char* bl = nullptr; int* fq = nullptr;
+                A.io(&k, C, S.kps, (size_t)S.n); A.io(&d, C * 32, S.desc, (size_t)S.n * 32); A.io(&q, Q, S.queries, (size_t)S.nq); A.io(&qd, Q * 32, S.query_desc, (size_t)S.nq * 32);
+                if (any_ur) A.io(&ur, C, S.u_right ? S.u_right : no_ur.data(), (size_t)S.n);
+                if (any_bl) A.io(&bl, C, (const unsigned char*)(S.blocked ? S.blocked : no_bl.data()), (size_t)S.n);
+                A.io(&fq, C, (const int*)nullptr, 0, S.feature_query, (size_t)S.n);
+                if (s == 0) { dk = k; dd = d; dq = q; dqd = qd; dur = ur; dbl = bl; dfq = fq; }
+                ProjParams& J = hJ[s]; memset(&J, 0, sizeof J);
+                J.kp = k; J.desc = d; J.u_right = S.u_right ? ur : nullptr; J.n = S.n; J.q = q; J.qdesc = qd; J.nq = S.nq; J.blocked_in = S.blocked ? bl : nullptr; J.feature_query = fq;
+            }
+            A.take(&dgs, (size_t)nslots * (ORBHIP_GRID_CELLS + 1)); A.take(&dgi, nslots * C); A.take(&dgxy, nslots * C); A.take(&dnc, nslots * Q); A.take(&dev, nslots * Q);
+            A.take(&dcand, nslots * Q * C); A.take(&dtop, nslots * Q * 5);
+        }));
+        for (int s = 0; s < nslots && e == hipSuccess; s++) {
+            ProjParams& J = hJ[s];
+            J.min_x = bounds->min_x; J.min_y = bounds->min_y; J.max_x = bounds->max_x; J.max_y = bounds->max_y;
+            J.grid_start = dgs + (size_t)s * (ORBHIP_GRID_CELLS + 1); J.grid_items = dgi + s * C; J.grid_xy = dgxy + s * C;
+            J.cand = dcand + s * Q * C; J.ncand = dnc + s * Q; J.cand_stride = cap; J.top = dtop + s * Q * 5; J.nmatches = dnm + s; J.events = dev + s * Q;
+            J.mode = mode; J.nnratio = nnratio; J.th_high = th_high; J.check_ori = check_ori;
+        }
+    }
+    TRY(arena_upload(nullptr));
+    if (e == hipSuccess) {
+        // Frame::AssignFeaturesToGrid of every slot: the grid kernel indexes [slot][stride]
+        for (int s = 0; s < nslots; s++) {
+            MatchParams M; memset(&M, 0, sizeof M);
+            M.kp2 = hJ[s].kp; M.n2 = dn + s; M.cap = cap; M.min_x = bounds->min_x; M.min_y = bounds->min_y; M.max_x = bounds->max_x; M.max_y = bounds->max_y;
+            M.grid_start = dgs + (size_t)s * (ORBHIP_GRID_CELLS + 1); M.grid_items = dgi + s * C; M.grid_xy = dgxy + s * C; M.grid_all_levels = 1;
+            orbhip_launch_match_grid(M, 1, nullptr);
+        }
+        const float gwInv = (float)ORBHIP_GRID_COLS / (bounds->max_x - bounds->min_x), ghInv = (float)ORBHIP_GRID_ROWS / (bounds->max_y - bounds->min_y);
+        orbhip_launch_proj_batch(dJ, nslots, qcap, cap, gwInv, ghInv, nullptr);
+        e = hipGetLastError();
+    }
+    TRY(arena_download(nullptr));
+#undef TRY
+    if (e != hipSuccess) return fail(ORBHIP_ERR_HIP, "search_by_projection_batch: %s", hipGetErrorString(e));
+    for (int s = 0; s < nslots; s++) slots[s].nmatches = hnm[s];
+    return ORBHIP_OK;
+}
+
 extern "C" orbhip_status orbhip_search_best_in_window_bounds(int device, const orbhip_keypoint* kps, const uint8_t* desc, const float* u_right, int n, const orbhip_bounds* bounds,
                                                       const float* inv_level_sigma2, int nlevels, const orbhip_best_query* queries, const uint8_t* query_desc, int nq,
                                                       int chi2_gate, int32_t* best_idx, int32_t* best_dist)

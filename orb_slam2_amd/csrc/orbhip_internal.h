@@ -114,6 +114,7 @@ struct ProjParams {         // projection-guided search core (ORBmatcher.cc:45-1
     int mode; float nnratio; int th_high, check_ori;
 };
 void orbhip_launch_proj(const ProjParams& J, hipStream_t s);
+void orbhip_launch_proj_batch(const ProjParams* d_slots, int nslots, int max_nq, int max_n, float gwInv, float ghInv, hipStream_t s);
 struct BestParams {
     const orbhip_keypoint* kp; const uint8_t* desc; const float* u_right; const float* inv_level_sigma2;
     const int* grid_start; const int* grid_items; const float2* grid_xy;        // ordered bucket table over ALL key points (k_match_grid, grid_all_levels)

@@ -31,7 +31,7 @@ __device__ __forceinline__ int pj_wave_min(int v)
     v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x143, 0xc, 0xf, false));
     return __builtin_amdgcn_readlane(v, 63);
 }
-__global__ __launch_bounds__(256) void k_proj_candidates(ProjParams J, float gwInv, float ghInv)
+__device__ __forceinline__ void proj_candidates_body(const ProjParams& J, float gwInv, float ghInv)
 {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int iq = blockIdx.x * 4 + wave;
@@ -113,9 +113,12 @@ __global__ __launch_bounds__(256) void k_proj_candidates(ProjParams J, float gwI
     if (lane < PJ_K) J.top[PJ_REC * iq + lane] = out;
     if (lane == PJ_K) J.top[PJ_REC * iq + PJ_K] = more ? 1u : 0u;
 }
+__global__ __launch_bounds__(256) void k_proj_candidates(ProjParams J, float gwInv, float ghInv) { proj_candidates_body(J, gwInv, ghInv); }
+// several frames (camera slots) per launch: blockIdx.y = slot, its parameters come from a table in device memory
+__global__ __launch_bounds__(256) void k_proj_candidates_batch(const ProjParams* Js, float gwInv, float ghInv) { const ProjParams J = Js[blockIdx.y]; proj_candidates_body(J, gwInv, ghInv); }
 
 
-__global__ __launch_bounds__(PJ_T) void k_proj_select(ProjParams J)
+__device__ __forceinline__ void proj_select_body(const ProjParams& J)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = J.n;
     HIP_DYNAMIC_SHARED(int, lds)
@@ -265,6 +268,8 @@ __global__ __launch_bounds__(PJ_T) void k_proj_select(ProjParams J)
     __syncthreads();
     for (int i = tid; i < n; i += PJ_T) { J.feature_query[i] = s_fq[i]; if (J.blocked_out) J.blocked_out[i] = (unsigned char)s_blocked[i]; }
 }
+__global__ __launch_bounds__(PJ_T) void k_proj_select(ProjParams J) { proj_select_body(J); }
+__global__ __launch_bounds__(PJ_T) void k_proj_select_batch(const ProjParams* Js) { const ProjParams J = Js[blockIdx.x]; proj_select_body(J); }      // one workgroup per camera slot
 
 size_t orbhip_proj_select_lds(int n) { return sizeof(int) * ((size_t)4 * n + ORBHIP_HISTO_LENGTH + 8); }
 
@@ -275,6 +280,13 @@ void orbhip_launch_proj(const ProjParams& J, hipStream_t s)
     hipLaunchKernelGGL(k_proj_select, dim3(1, 1, 1), dim3(PJ_T, 1, 1), orbhip_proj_select_lds(J.n), s, J);
 }
 
+
+void orbhip_launch_proj_batch(const ProjParams* d_slots, int nslots, int max_nq, int max_n, float gwInv, float ghInv, hipStream_t s)
+{
+    if (nslots <= 0) return;
+    if (max_nq > 0) hipLaunchKernelGGL(k_proj_candidates_batch, dim3((max_nq + 3) / 4, nslots, 1), dim3(256, 1, 1), 0, s, d_slots, gwInv, ghInv);
+    hipLaunchKernelGGL(k_proj_select_batch, dim3(nslots, 1, 1), dim3(PJ_T, 1, 1), orbhip_proj_select_lds(max_n), s, d_slots);
+}
 
 // ------------------------------------------------------------------------------------------------ best candidate in a window
 // The candidate loop of ORBmatcher::Fuse (both overloads, ORBmatcher.cc:884-948 / 1038-1079) and of the two passes of

@@ -32,7 +32,7 @@ SYMBOLS = [
     "orbhip_undistort_points", "orbhip_image_bounds", "orbhip_set_camera", "orbhip_get_bounds", "orbhip_fetch_undistorted",
     "orbhip_search_for_initialization_bounds", "orbhip_search_by_projection_bounds", "orbhip_search_best_in_window_bounds",
     "orbhip_set_rectification", "orbhip_extract_batch_rectify", "orbhip_extract_device_rectify", "orbhip_compute_stereo_from_rgbd",
-    "orbhip_search_by_projection_frame", "orbhip_search_best_in_window_frame",
+    "orbhip_search_by_projection_frame", "orbhip_search_best_in_window_frame", "orbhip_search_by_projection_batch",
     "orbhip_pyramid_fetch_all", "orbhip_set_blur_rounding", "orbhip_set_fp_contract", "orbhip_submit", "orbhip_collect", "orbhip_ring_depth", "orbhip_host_alloc", "orbhip_host_free",
     "orbhip_pool_create", "orbhip_pool_destroy", "orbhip_pool_num_devices", "orbhip_pool_device_of", "orbhip_pool_keypoint_capacity",
     "orbhip_pool_extract", "orbhip_pool_submit", "orbhip_pool_collect", "orbhip_pool_db_load", "orbhip_pool_db_shard", "orbhip_pool_db_query",
@@ -135,6 +135,7 @@ def lib(path=None):
     L.orbhip_extract_batch_rectify.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp]
     L.orbhip_extract_device_rectify.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]
     L.orbhip_compute_stereo_from_rgbd.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_float, C.c_float, vp, vp, C.c_int]
+    L.orbhip_search_by_projection_batch.argtypes = [C.c_int, C.c_int, vp, C.POINTER(Bounds), C.c_int, C.c_float, C.c_int, C.c_int]
     L.orbhip_search_by_projection_frame.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, vp, ip]
     L.orbhip_search_best_in_window_frame.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp]
     L.orbhip_sync.argtypes = [vp]
@@ -670,6 +671,33 @@ def search_by_projection(kps, desc, im_w, im_h, queries, query_desc, mode, nnrat
                                                     _p(queries), _p(query_desc), len(queries), mode, nnratio, th_high, int(check_ori), _p(fq), C.byref(nm)),
                "orbhip_search_by_projection_bounds", L)
     return nm.value, fq[:len(kps)]
+
+
+class ProjSlot(C.Structure):        # orbhip_proj_slot
+    _fields_ = [("kps", C.c_void_p), ("desc", C.c_void_p), ("u_right", C.c_void_p), ("blocked", C.c_void_p), ("n", C.c_int32),
+                ("queries", C.c_void_p), ("query_desc", C.c_void_p), ("nq", C.c_int32), ("feature_query", C.c_void_p), ("nmatches", C.c_int32)]
+
+
+def search_by_projection_batch(frames, im_w, im_h, mode, nnratio=0.8, th_high=100, check_ori=True, device=0, library=None, bounds=None):
+    """orbhip_search_by_projection_batch: frames = [(kps, desc, queries, query_desc[, u_right[, blocked]])] — one camera slot each, searched in
+    one pass.  Returns [(nmatches, feature_query)] per slot, identical to per-slot search_by_projection calls."""
+    L = lib(library)
+    keep, slots = [], (ProjSlot * len(frames))()
+    for s, fr in enumerate(frames):
+        kps, desc, queries, qdesc = fr[:4]
+        ur = fr[4] if len(fr) > 4 else None
+        bl = fr[5] if len(fr) > 5 else None
+        kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
+        queries = np.ascontiguousarray(queries, PROJ_QUERY_DTYPE); qdesc = np.ascontiguousarray(qdesc, np.uint8)
+        ur = None if ur is None else np.ascontiguousarray(ur, np.float32)
+        bl = None if bl is None else np.ascontiguousarray(bl, np.uint8)
+        fq = np.full(max(len(kps), 1), -1, np.int32)
+        keep.append((kps, desc, queries, qdesc, ur, bl, fq))
+        slots[s] = ProjSlot(kps.ctypes.data, desc.ctypes.data, None if ur is None else ur.ctypes.data, None if bl is None else bl.ctypes.data, len(kps),
+                            queries.ctypes.data, qdesc.ctypes.data, len(queries), fq.ctypes.data, 0)
+    b = Bounds.of(bounds, im_w, im_h)
+    _check(L.orbhip_search_by_projection_batch(device, len(frames), slots, C.byref(b), mode, nnratio, th_high, int(check_ori)), "orbhip_search_by_projection_batch", L)
+    return [(slots[s].nmatches, keep[s][6][:len(keep[s][0])]) for s in range(len(frames))]
 
 
 def hamming_nn(q, db, device=0, index_base=0, library=None):

@@ -160,3 +160,30 @@ def test_searches_on_device_resident_frames(backend, oracle):
     with pytest.raises(orb_slam2_amd.OrbHipError):
         xl.search_best_in_window(0, len(ks[0]), bq[:1], qd[:1], True, use_u_right=True)
     xl.close(); xr.close()
+
+
+@pytest.mark.parametrize("mode,rule,th,ratio", [(0, "local_map", 3.0, 0.8), (1, "window", 7.0, 0.9)])
+def test_search_by_projection_batch_of_camera_slots(backend, oracle, scene, mode, rule, th, ratio):
+    """orbhip_search_by_projection_batch (the multi-camera form of M2 / M3): slots with different frames, query sets, stereo
+    gates and blocked sets in ONE pass; every slot must equal the oracle's answer for that slot alone (and thereby the per-slot entry point)."""
+    w, h, sf, (kl, dl), (kc, dc) = scene
+    rng = np.random.default_rng(mode * 10 + 3)
+    slots, want = [], []
+    for s in range(5):
+        q, qd = _queries(oracle, scene, mode, th + s, rng, rule)
+        if s == 2:                                                    # a slot searching the OTHER frame with fewer queries; one empty slot below
+            q, qd = q[:200], qd[:200]
+            kf, df = kl, dl
+        else:
+            kf, df = kc, dc
+        ur = np.where(rng.random(len(kf)) < 0.6, kf["x"] - rng.uniform(1, 45, len(kf)), -1).astype(np.float32) if s % 2 else None
+        bl = (rng.random(len(kf)) < 0.15).astype(np.uint8) if s != 3 else None
+        slots.append((kf, df, q, qd, ur, bl))
+        want.append(oracle.search_by_projection(kf, df, w, h, q, qd, mode, nnratio=ratio, th_high=100, check_ori=True, u_right=ur, blocked=bl))
+    slots.append((kc[:0], dc[:0], slots[0][2][:0], slots[0][3][:0]))                     # no features, no queries
+    want.append((0, np.zeros(0, np.int32)))
+    got = orb_slam2_amd.search_by_projection_batch(slots, w, h, mode, nnratio=ratio, th_high=100, check_ori=True, library=backend)
+    assert len(got) == len(want)
+    for s, ((n_g, f_g), (n_o, f_o)) in enumerate(zip(got, want)):
+        assert n_g == n_o and np.array_equal(f_g, f_o), f"slot {s}"
+    assert sum(n for n, _ in want) > 500
