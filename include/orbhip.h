@@ -62,6 +62,9 @@ typedef struct {
 } orbhip_config;
 
 const char* orbhip_version(void);
+/* The stateless matcher entry points keep a per-thread device scratch and pinned mirror (grow-only, no hipMalloc per call).  A worker thread
+   that exits returns them automatically; orbhip_thread_release() does it on demand for the calling thread. */
+void orbhip_thread_release(void);
 /* HIP devices this process can use (0 = none: nothing in this library can run, there is no CPU fallback) */
 int orbhip_device_count(void);
 /* last error message of the calling thread ("" if none) */

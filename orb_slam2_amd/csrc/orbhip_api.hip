@@ -142,6 +142,7 @@ struct Arena {
 static thread_local uint8_t* g_hstage = nullptr; static thread_local size_t g_hstage_bytes = 0;      // pinned mirror of the arena's host-visible head
 static hipError_t hstage_reserve(size_t bytes)
 {
+    orbhip_touch_thread_caches();
     if (g_hstage_bytes >= bytes) return hipSuccess;
     if (g_hstage) (void)hipHostFree(g_hstage);
     g_hstage = nullptr; g_hstage_bytes = 0;
@@ -149,6 +150,29 @@ static hipError_t hstage_reserve(size_t bytes)
     if (e == hipSuccess) g_hstage_bytes = bytes + bytes / 4;
     return e;
 }
+// The per-thread caches above (and the brute-force / BoW matcher workspaces) belong to the thread that made the calls: a worker thread that
+// exits gives them back (thread_local holder below), any thread may do so explicitly with orbhip_thread_release().  The main thread's are
+// left to process exit: its thread-local destructors run while the interpreter / runtime that loaded this library is already unwinding.
+static thread_local void* g_nn_ws = nullptr; static thread_local size_t g_nn_ws_bytes = 0; static thread_local int g_nn_ws_dev = -1; static thread_local hipStream_t g_nn_ws_stream = nullptr;
+extern "C" void orbhip_thread_release(void)
+{
+    int cur = -1; (void)hipGetDevice(&cur);
+    if (g_scratch) { (void)hipSetDevice(g_scratch_dev); (void)hipDeviceSynchronize(); (void)hipFree(g_scratch); }
+    g_scratch = nullptr; g_scratch_bytes = 0; g_scratch_dev = -1;
+    if (g_hstage) (void)hipHostFree(g_hstage);
+    g_hstage = nullptr; g_hstage_bytes = 0;
+    if (g_nn_ws) { (void)hipSetDevice(g_nn_ws_dev); (void)hipDeviceSynchronize(); (void)hipFree(g_nn_ws); }
+    g_nn_ws = nullptr; g_nn_ws_bytes = 0; g_nn_ws_dev = -1; g_nn_ws_stream = nullptr;
+    orbhip_bow_thread_release();
+    if (cur >= 0) (void)hipSetDevice(cur);
+    (void)hipGetLastError();
+}
+#include <unistd.h>
+#include <sys/syscall.h>
+namespace { struct ThreadCacheHolder { ~ThreadCacheHolder() { if ((long)syscall(SYS_gettid) != (long)getpid()) orbhip_thread_release(); } }; }
+static thread_local ThreadCacheHolder g_cache_holder;
+void orbhip_touch_thread_caches() { (void)&g_cache_holder; }
+
 // One pageable->pinned gather on the host and ONE host-to-device copy for all inputs of a call (a hipMemcpy per array costs more
 // than the kernels of a single-frame matcher call); likewise one device-to-host copy for all outputs.
 static hipError_t arena_upload(hipStream_t s)
@@ -1007,6 +1031,7 @@ extern "C" orbhip_status orbhip_search_by_projection_bounds(int device, const or
         e = hipGetLastError();
     }
     TRY(arena_download(nullptr));
+    if (e != hipSuccess) (void)hipStreamSynchronize(nullptr);            // never leave a copy in flight on the per-thread mirrors
     if (e == hipSuccess) *nmatches = hres[1];
 #undef TRY
     orbhip_status st = ORBHIP_OK;
@@ -1085,6 +1110,7 @@ extern "C" orbhip_status orbhip_search_by_projection_batch(int device, int nslot
         e = hipGetLastError();
     }
     TRY(arena_download(nullptr));
+    if (e != hipSuccess) (void)hipStreamSynchronize(nullptr);            // never leave a copy in flight on the per-thread mirrors
 #undef TRY
     if (e != hipSuccess) return fail(ORBHIP_ERR_HIP, "search_by_projection_batch: %s", hipGetErrorString(e));
     for (int s = 0; s < nslots; s++) slots[s].nmatches = hnm[s];
@@ -1125,6 +1151,7 @@ extern "C" orbhip_status orbhip_search_best_in_window_bounds(int device, const o
         e = hipGetLastError();
     }
     TRY(arena_download(nullptr));
+    if (e != hipSuccess) (void)hipStreamSynchronize(nullptr);            // never leave a copy in flight on the per-thread mirrors
 #undef TRY
     orbhip_status st = ORBHIP_OK;
     if (e != hipSuccess) st = fail(ORBHIP_ERR_HIP, "search_best_in_window: %s", hipGetErrorString(e));
@@ -1183,6 +1210,7 @@ extern "C" orbhip_status orbhip_search_by_projection_frame(orbhip_ctx* c, int fr
         e = hipGetLastError();
     }
     TRY(arena_download(c->stream));
+    if (e != hipSuccess) (void)hipStreamSynchronize(c->stream);            // never leave a copy in flight on the per-thread mirrors
     if (e == hipSuccess) *nmatches = hres[1];
 #undef TRY
     return e == hipSuccess ? ORBHIP_OK : fail(ORBHIP_ERR_HIP, "search_by_projection_frame: %s", hipGetErrorString(e));
@@ -1218,6 +1246,7 @@ extern "C" orbhip_status orbhip_search_best_in_window_frame(orbhip_ctx* c, int f
         e = hipGetLastError();
     }
     TRY(arena_download(c->stream));
+    if (e != hipSuccess) (void)hipStreamSynchronize(c->stream);            // never leave a copy in flight on the per-thread mirrors
 #undef TRY
     return e == hipSuccess ? ORBHIP_OK : fail(ORBHIP_ERR_HIP, "search_best_in_window_frame: %s", hipGetErrorString(e));
 }
@@ -1500,9 +1529,9 @@ extern "C" int orbhip_descriptor_distance(const uint8_t* a, const uint8_t* b)
 
 // Partials of the brute-force scan: a per-thread, grow-only buffer tied to the device it was allocated on and to the stream that used it
 // last (a second stream of the same thread waits for the first before it reuses the buffer).
-static thread_local void* g_nn_ws = nullptr; static thread_local size_t g_nn_ws_bytes = 0; static thread_local int g_nn_ws_dev = -1; static thread_local hipStream_t g_nn_ws_stream = nullptr;
 void* orbhip_nn_workspace(size_t bytes, hipStream_t s)
 {
+    orbhip_touch_thread_caches();
     int dev = -1; if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     if (g_nn_ws && g_nn_ws_dev == dev && g_nn_ws_stream != s) (void)hipStreamSynchronize(g_nn_ws_stream);
     if (g_nn_ws_dev != dev || bytes > g_nn_ws_bytes) {
@@ -1590,6 +1619,7 @@ extern "C" orbhip_status orbhip_search_for_initialization_bounds(int device, con
         e = hipGetLastError();
     }
     TRY(arena_download(nullptr));
+    if (e != hipSuccess) (void)hipStreamSynchronize(nullptr);            // never leave a copy in flight on the per-thread mirrors
     if (e == hipSuccess) *nmatches = hres[3];
 #undef TRY
     orbhip_status st = ORBHIP_OK;

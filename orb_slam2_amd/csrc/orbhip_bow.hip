@@ -27,6 +27,8 @@
 #include <algorithm>
 #include "../../include/orbhip.h"
 #include "orbhip_internal.h"
+#include <map>
+#include <mutex>
 
 #define BOWCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return orbhip_set_error(ORBHIP_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 
@@ -38,6 +40,7 @@ struct BowParams {
     uint32_t* word; double* weight; uint32_t* node;            // [frame][cap]
     uint32_t* bow_id; double* bow_val; int* nbow;              // [frame][cap], [frame]
     uint32_t* fv_node; int* fv_off; uint32_t* fv_feat; int* nfv;   // [frame][cap], [frame][cap+1], [frame][cap], [frame]
+    int lcap;                          // features the LDS arrays of k_bow_assemble are carved for (>= every frame's count, <= cap)
 };
 
 __device__ __forceinline__ int bow_count(const BowParams& P, int frame) { return min(P.nfeat ? P.nfeat[frame] : P.nfeat_fixed, P.cap); }
@@ -109,11 +112,12 @@ __device__ __forceinline__ void ba_rank_sort(const unsigned long long* key, unsi
 __global__ __launch_bounds__(BA_T) void k_bow_assemble(BowParams P)
 {
     HIP_DYNAMIC_SHARED(unsigned long long, lds64)
-    const int frame = blockIdx.x, tid = threadIdx.x, n = bow_count(P, frame), cap = P.cap;
-    unsigned long long* key = lds64;                       // [cap]  (reused as f64 values after the sort)
-    unsigned long long* sorted = lds64 + cap;              // [cap]
-    int* flag = reinterpret_cast<int*>(lds64 + 2 * cap);   // [cap]
-    int* scratch = flag + cap;                             // [8]
+    const int frame = blockIdx.x, tid = threadIdx.x, n = min(bow_count(P, frame), P.lcap), cap = P.cap;
+    const int lcap = P.lcap;                               // LDS arrays hold lcap entries; `cap` is the row stride of the HBM arrays
+    unsigned long long* key = lds64;                       // [lcap]  (reused as f64 values after the sort)
+    unsigned long long* sorted = lds64 + lcap;             // [lcap]
+    int* flag = reinterpret_cast<int*>(lds64 + 2 * lcap);  // [lcap]
+    int* scratch = flag + lcap;                            // [8]
     double* vals = reinterpret_cast<double*>(key);
     const uint32_t* word = P.word + (long long)frame * cap; const double* wt = P.weight + (long long)frame * cap; const uint32_t* node = P.node + (long long)frame * cap;
     uint32_t* bow_id = P.bow_id + (long long)frame * cap; double* bow_val = P.bow_val + (long long)frame * cap;
@@ -368,60 +372,70 @@ __global__ __launch_bounds__(256) void k_bow_triangulate(TriParams T)
 }
 
 // ------------------------------------------------------------------------------------------------ host side
+// Workspace for nframes x cap features.  Grow-only (a transform per frame / key frame with a different feature count must not pay eleven
+// hipFree + hipMalloc, each a device-wide synchronisation): `cap` is the row stride of every per-feature array, the feature count of a
+// call travels separately.
+struct BowWs {
+    int frames = 0, cap = 0, last_frames = 0;
+    uint8_t* d_desc = nullptr; uint32_t *d_word = nullptr, *d_node = nullptr, *d_bow_id = nullptr, *d_fv_node = nullptr, *d_fv_feat = nullptr;
+    double *d_weight = nullptr, *d_bow_val = nullptr; int *d_nbow = nullptr, *d_nfv = nullptr, *d_fv_off = nullptr;
+};
+// The reference shares ONE vocabulary between the Tracking (Frame.cc:400), LocalMapping and LoopClosing threads (KeyFrame.cc:66) and its
+// DBoW2 transform is read-only.  Here the tree is read-only too, the mutable state is not: `host` serves the host-descriptor entry points
+// (transform, transform_features) and is held under `m` for the whole call, so concurrent callers take turns; compute_bow / fetch_bow work in
+// a workspace that belongs to the extractor context they are called with (a context is used by one thread at a time, include/orbhip.h), found
+// under `m`.
 struct orbhip_voc {
     int k = 0, L = 0, scoring = 0, weighting = 0, nnodes = 0, nwords = 0, device = 0;
     std::vector<int> child_start, child_ids, node_word; std::vector<uint8_t> node_desc; std::vector<double> node_weight;
     int *d_child_start = nullptr, *d_child_ids = nullptr, *d_node_word = nullptr; uint8_t* d_node_desc = nullptr; double* d_node_weight = nullptr;
     hipStream_t stream = nullptr;
-    // workspace for nframes x cap features
-    int ws_frames = 0, ws_cap = 0;
-    uint8_t* d_desc = nullptr; uint32_t *d_word = nullptr, *d_node = nullptr, *d_bow_id = nullptr, *d_fv_node = nullptr, *d_fv_feat = nullptr;
-    double *d_weight = nullptr, *d_bow_val = nullptr; int *d_nbow = nullptr, *d_nfv = nullptr, *d_fv_off = nullptr;
-    int last_frames = 0;
+    std::mutex m; BowWs host; std::map<const orbhip_ctx*, BowWs> per_ctx;
 };
 
-static void voc_free_ws(orbhip_voc* v)
+static void voc_free_ws(BowWs* w)
 {
-    void* ptrs[] = {v->d_desc, v->d_word, v->d_node, v->d_bow_id, v->d_fv_node, v->d_fv_feat, v->d_weight, v->d_bow_val, v->d_nbow, v->d_nfv, v->d_fv_off};
+    void* ptrs[] = {w->d_desc, w->d_word, w->d_node, w->d_bow_id, w->d_fv_node, w->d_fv_feat, w->d_weight, w->d_bow_val, w->d_nbow, w->d_nfv, w->d_fv_off};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    v->d_desc = nullptr; v->d_word = v->d_node = v->d_bow_id = v->d_fv_node = v->d_fv_feat = nullptr; v->d_weight = v->d_bow_val = nullptr; v->d_nbow = v->d_nfv = v->d_fv_off = nullptr;
-    v->ws_frames = v->ws_cap = 0;
+    *w = BowWs();
 }
 
 #define BOW_MAX_FEATURES 7168          // 20 B of LDS per feature in k_bow_assemble
 
-static orbhip_status voc_ensure_ws(orbhip_voc* v, int nframes, int cap, bool with_desc)
+static orbhip_status voc_ensure_ws(BowWs* w, int nframes, int cap, hipStream_t s)
 {
     if (cap > BOW_MAX_FEATURES) return orbhip_set_error(ORBHIP_ERR_UNSUPPORTED, "%d features per frame (at most %d)", cap, BOW_MAX_FEATURES);
-    if (nframes <= v->ws_frames && cap == v->ws_cap && (!with_desc || v->d_desc)) return ORBHIP_OK;
-    BOWCHK(hipStreamSynchronize(v->stream));
-    voc_free_ws(v);
-    const size_t F = (size_t)nframes, C = (size_t)cap;
-    BOWCHK(hipMalloc((void**)&v->d_desc, F * C * 32 + 64));
-    BOWCHK(hipMalloc((void**)&v->d_word, F * C * 4)); BOWCHK(hipMalloc((void**)&v->d_node, F * C * 4)); BOWCHK(hipMalloc((void**)&v->d_weight, F * C * 8));
-    BOWCHK(hipMalloc((void**)&v->d_bow_id, F * C * 4)); BOWCHK(hipMalloc((void**)&v->d_bow_val, F * C * 8));
-    BOWCHK(hipMalloc((void**)&v->d_fv_node, F * C * 4)); BOWCHK(hipMalloc((void**)&v->d_fv_feat, F * C * 4)); BOWCHK(hipMalloc((void**)&v->d_fv_off, F * (C + 1) * 4));
-    BOWCHK(hipMalloc((void**)&v->d_nbow, F * 4)); BOWCHK(hipMalloc((void**)&v->d_nfv, F * 4));
-    v->ws_frames = nframes; v->ws_cap = cap;
+    if (nframes <= w->frames && cap <= w->cap) return ORBHIP_OK;
+    BOWCHK(hipStreamSynchronize(s));                                               // nothing of this workspace is in flight when it is replaced
+    const int nf = std::max(nframes, w->frames), nc = std::min(std::max(cap + cap / 4, w->cap), BOW_MAX_FEATURES);
+    voc_free_ws(w);
+    const size_t F = (size_t)nf, C = (size_t)nc;
+    BOWCHK(hipMalloc((void**)&w->d_desc, F * C * 32 + 64));
+    BOWCHK(hipMalloc((void**)&w->d_word, F * C * 4)); BOWCHK(hipMalloc((void**)&w->d_node, F * C * 4)); BOWCHK(hipMalloc((void**)&w->d_weight, F * C * 8));
+    BOWCHK(hipMalloc((void**)&w->d_bow_id, F * C * 4)); BOWCHK(hipMalloc((void**)&w->d_bow_val, F * C * 8));
+    BOWCHK(hipMalloc((void**)&w->d_fv_node, F * C * 4)); BOWCHK(hipMalloc((void**)&w->d_fv_feat, F * C * 4)); BOWCHK(hipMalloc((void**)&w->d_fv_off, F * (C + 1) * 4));
+    BOWCHK(hipMalloc((void**)&w->d_nbow, F * 4)); BOWCHK(hipMalloc((void**)&w->d_nfv, F * 4));
+    w->frames = nf; w->cap = nc;
     return ORBHIP_OK;
 }
 
-static orbhip_status voc_run(orbhip_voc* v, const uint8_t* d_desc, long long frame_stride, const int* d_nfeat, int nfeat_fixed, int nframes, int cap,
+// nfeat_max: upper bound of the features of one frame in this call (sizes the grid and the LDS of the assembly); w->cap is the row stride
+static orbhip_status voc_run(orbhip_voc* v, BowWs* w, const uint8_t* d_desc, long long frame_stride, const int* d_nfeat, int nfeat_fixed, int nframes, int nfeat_max,
                              int levelsup, bool assemble, hipStream_t s)
 {
     BowParams P; memset(&P, 0, sizeof P);
-    P.desc = d_desc; P.desc_frame_stride = frame_stride; P.nfeat = d_nfeat; P.nfeat_fixed = nfeat_fixed; P.cap = cap;
+    P.desc = d_desc; P.desc_frame_stride = frame_stride; P.nfeat = d_nfeat; P.nfeat_fixed = nfeat_fixed; P.cap = w->cap; P.lcap = nfeat_max;
     P.child_start = v->d_child_start; P.child_ids = v->d_child_ids; P.node_desc = v->d_node_desc; P.node_weight = v->d_node_weight; P.node_word = v->d_node_word;
     P.L = v->L; P.levelsup = levelsup;
     P.accumulate = (v->weighting == 0 || v->weighting == 1);                     // TF_IDF, TF (:1142) vs IDF, BINARY (:1173)
     P.must_normalize = v->scoring != 5; P.l2 = v->scoring == 1;                    // ScoringObject.h:73-90
-    P.word = v->d_word; P.weight = v->d_weight; P.node = v->d_node;
-    P.bow_id = v->d_bow_id; P.bow_val = v->d_bow_val; P.nbow = v->d_nbow; P.fv_node = v->d_fv_node; P.fv_off = v->d_fv_off; P.fv_feat = v->d_fv_feat; P.nfv = v->d_nfv;
-    if (cap <= 0 || nframes <= 0) return ORBHIP_OK;
-    hipLaunchKernelGGL(k_bow_descend, dim3((cap + 255) / 256, nframes, 1), dim3(256, 1, 1), 0, s, P);
-    if (assemble) hipLaunchKernelGGL(k_bow_assemble, dim3(nframes, 1, 1), dim3(BA_T, 1, 1), (size_t)cap * 20 + 64, s, P);
+    P.word = w->d_word; P.weight = w->d_weight; P.node = w->d_node;
+    P.bow_id = w->d_bow_id; P.bow_val = w->d_bow_val; P.nbow = w->d_nbow; P.fv_node = w->d_fv_node; P.fv_off = w->d_fv_off; P.fv_feat = w->d_fv_feat; P.nfv = w->d_nfv;
+    if (nfeat_max <= 0 || nframes <= 0) return ORBHIP_OK;
+    hipLaunchKernelGGL(k_bow_descend, dim3((nfeat_max + 255) / 256, nframes, 1), dim3(256, 1, 1), 0, s, P);
+    if (assemble) hipLaunchKernelGGL(k_bow_assemble, dim3(nframes, 1, 1), dim3(BA_T, 1, 1), (size_t)nfeat_max * 20 + 64, s, P);
     BOWCHK(hipGetLastError());
-    v->last_frames = nframes;
+    w->last_frames = nframes;
     return ORBHIP_OK;
 }
 
@@ -430,7 +444,9 @@ extern "C" void orbhip_voc_destroy(orbhip_voc* v)
     if (!v) return;
     (void)hipSetDevice(v->device);
     if (v->stream) (void)hipStreamSynchronize(v->stream);
-    voc_free_ws(v);
+    (void)hipDeviceSynchronize();                                       // per-context workspaces were used on the extractors' streams
+    voc_free_ws(&v->host);
+    for (auto& kv : v->per_ctx) voc_free_ws(&kv.second);
     void* ptrs[] = {v->d_child_start, v->d_child_ids, v->d_node_word, v->d_node_desc, v->d_node_weight};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (v->stream) (void)hipStreamDestroy(v->stream);
@@ -509,8 +525,8 @@ extern "C" orbhip_status orbhip_voc_info(const orbhip_voc* v, int* k, int* L, in
 static orbhip_status voc_upload(orbhip_voc* v, const uint8_t* desc, int n)
 {
     BOWCHK(hipSetDevice(v->device));
-    orbhip_status st = voc_ensure_ws(v, 1, std::max(n, 1), true); if (st != ORBHIP_OK) return st;
-    if (n > 0) BOWCHK(hipMemcpyAsync(v->d_desc, desc, (size_t)n * 32, hipMemcpyHostToDevice, v->stream));
+    orbhip_status st = voc_ensure_ws(&v->host, 1, std::max(n, 1), v->stream); if (st != ORBHIP_OK) return st;
+    if (n > 0) BOWCHK(hipMemcpyAsync(v->host.d_desc, desc, (size_t)n * 32, hipMemcpyHostToDevice, v->stream));
     return ORBHIP_OK;
 }
 
@@ -518,30 +534,36 @@ extern "C" orbhip_status orbhip_voc_transform_features(orbhip_voc* v, const uint
 {
     if (!v || (n > 0 && !desc) || n < 0) return orbhip_set_error(ORBHIP_ERR_INVALID, "bad argument");
     if (v->nwords == 0 || n == 0) return ORBHIP_OK;
+    std::lock_guard<std::mutex> lock(v->m);                                        // upload, kernels and fetch of ONE caller at a time
     orbhip_status st = voc_upload(v, desc, n); if (st != ORBHIP_OK) return st;
-    st = voc_run(v, v->d_desc, 0, nullptr, n, 1, v->ws_cap, levelsup, false, v->stream); if (st != ORBHIP_OK) return st;
-    if (word) BOWCHK(hipMemcpyAsync(word, v->d_word, (size_t)n * 4, hipMemcpyDeviceToHost, v->stream));
-    if (weight) BOWCHK(hipMemcpyAsync(weight, v->d_weight, (size_t)n * 8, hipMemcpyDeviceToHost, v->stream));
-    if (node) BOWCHK(hipMemcpyAsync(node, v->d_node, (size_t)n * 4, hipMemcpyDeviceToHost, v->stream));
-    BOWCHK(hipStreamSynchronize(v->stream));
-    return ORBHIP_OK;
+    BowWs* w = &v->host;
+    st = voc_run(v, w, w->d_desc, 0, nullptr, n, 1, n, levelsup, false, v->stream);
+    if (st == ORBHIP_OK) {
+        hipError_t e = hipSuccess;
+        if (word) e = hipMemcpyAsync(word, w->d_word, (size_t)n * 4, hipMemcpyDeviceToHost, v->stream);
+        if (e == hipSuccess && weight) e = hipMemcpyAsync(weight, w->d_weight, (size_t)n * 8, hipMemcpyDeviceToHost, v->stream);
+        if (e == hipSuccess && node) e = hipMemcpyAsync(node, w->d_node, (size_t)n * 4, hipMemcpyDeviceToHost, v->stream);
+        const hipError_t e2 = hipStreamSynchronize(v->stream);                     // also on the error path: the workspace is idle when the lock is released
+        if (e != hipSuccess || e2 != hipSuccess) st = orbhip_set_error(ORBHIP_ERR_HIP, "orbhip_voc_transform_features: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    } else (void)hipStreamSynchronize(v->stream);
+    return st;
 }
 
-static orbhip_status voc_fetch(orbhip_voc* v, int frame, hipStream_t s, uint32_t* bow_id, double* bow_val, int* nbow, uint32_t* fv_node, int32_t* fv_off, uint32_t* fv_feat, int* nfv)
+static orbhip_status voc_fetch(BowWs* w, int frame, hipStream_t s, uint32_t* bow_id, double* bow_val, int* nbow, uint32_t* fv_node, int32_t* fv_off, uint32_t* fv_feat, int* nfv)
 {
-    const size_t C = (size_t)v->ws_cap;
+    const size_t C = (size_t)w->cap;
     int cnt[2] = {0, 0};
-    BOWCHK(hipMemcpyAsync(&cnt[0], v->d_nbow + frame, 4, hipMemcpyDeviceToHost, s));
-    BOWCHK(hipMemcpyAsync(&cnt[1], v->d_nfv + frame, 4, hipMemcpyDeviceToHost, s));
+    BOWCHK(hipMemcpyAsync(&cnt[0], w->d_nbow + frame, 4, hipMemcpyDeviceToHost, s));
+    BOWCHK(hipMemcpyAsync(&cnt[1], w->d_nfv + frame, 4, hipMemcpyDeviceToHost, s));
     BOWCHK(hipStreamSynchronize(s));
     const int nb = cnt[0], nf = cnt[1];
     int m = 0;
-    if (nf > 0 || fv_off) { BOWCHK(hipMemcpyAsync(&m, v->d_fv_off + frame * (C + 1) + nf, 4, hipMemcpyDeviceToHost, s)); BOWCHK(hipStreamSynchronize(s)); }
-    if (nb > 0 && bow_id) BOWCHK(hipMemcpyAsync(bow_id, v->d_bow_id + frame * C, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
-    if (nb > 0 && bow_val) BOWCHK(hipMemcpyAsync(bow_val, v->d_bow_val + frame * C, (size_t)nb * 8, hipMemcpyDeviceToHost, s));
-    if (nf > 0 && fv_node) BOWCHK(hipMemcpyAsync(fv_node, v->d_fv_node + frame * C, (size_t)nf * 4, hipMemcpyDeviceToHost, s));
-    if (fv_off) BOWCHK(hipMemcpyAsync(fv_off, v->d_fv_off + frame * (C + 1), (size_t)(nf + 1) * 4, hipMemcpyDeviceToHost, s));
-    if (m > 0 && fv_feat) BOWCHK(hipMemcpyAsync(fv_feat, v->d_fv_feat + frame * C, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+    if (nf > 0 || fv_off) { BOWCHK(hipMemcpyAsync(&m, w->d_fv_off + frame * (C + 1) + nf, 4, hipMemcpyDeviceToHost, s)); BOWCHK(hipStreamSynchronize(s)); }
+    if (nb > 0 && bow_id) BOWCHK(hipMemcpyAsync(bow_id, w->d_bow_id + frame * C, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
+    if (nb > 0 && bow_val) BOWCHK(hipMemcpyAsync(bow_val, w->d_bow_val + frame * C, (size_t)nb * 8, hipMemcpyDeviceToHost, s));
+    if (nf > 0 && fv_node) BOWCHK(hipMemcpyAsync(fv_node, w->d_fv_node + frame * C, (size_t)nf * 4, hipMemcpyDeviceToHost, s));
+    if (fv_off) BOWCHK(hipMemcpyAsync(fv_off, w->d_fv_off + frame * (C + 1), (size_t)(nf + 1) * 4, hipMemcpyDeviceToHost, s));
+    if (m > 0 && fv_feat) BOWCHK(hipMemcpyAsync(fv_feat, w->d_fv_feat + frame * C, (size_t)m * 4, hipMemcpyDeviceToHost, s));
     BOWCHK(hipStreamSynchronize(s));
     if (nbow) *nbow = nb;
     if (nfv) *nfv = nf;
@@ -556,9 +578,12 @@ extern "C" orbhip_status orbhip_voc_transform(orbhip_voc* v, const uint8_t* desc
     if (nfv) *nfv = 0;
     if (fv_off) fv_off[0] = 0;
     if (v->nwords == 0 || n == 0) return ORBHIP_OK;                              // v.clear(); fv.clear(); if(empty()) return;  (:1130-1136)
-    orbhip_status st = voc_upload(v, desc, n); if (st != ORBHIP_OK) return st;
-    st = voc_run(v, v->d_desc, 0, nullptr, n, 1, v->ws_cap, levelsup, true, v->stream); if (st != ORBHIP_OK) return st;
-    return voc_fetch(v, 0, v->stream, bow_id, bow_val, nbow, fv_node, fv_off, fv_feat, nfv);
+    std::lock_guard<std::mutex> lock(v->m);                                        // the reference's transform is const and called from three threads
+    orbhip_status st = voc_upload(v, desc, n);
+    if (st == ORBHIP_OK) st = voc_run(v, &v->host, v->host.d_desc, 0, nullptr, n, 1, n, levelsup, true, v->stream);
+    if (st == ORBHIP_OK) st = voc_fetch(&v->host, 0, v->stream, bow_id, bow_val, nbow, fv_node, fv_off, fv_feat, nfv);
+    if (st != ORBHIP_OK) (void)hipStreamSynchronize(v->stream);
+    return st;
 }
 
 // Frame::ComputeBoW (Frame.cc:395-402) for the frames of the extractor's last call: descriptors are read where k_describe left them
@@ -570,20 +595,24 @@ extern "C" orbhip_status orbhip_compute_bow(orbhip_ctx* ctx, orbhip_voc* v, int 
     if (nimg < 1 || nimg > last) return orbhip_set_error(ORBHIP_ERR_INVALID, "nimg %d but the last call processed %d frames", nimg, last);
     if (device != v->device) return orbhip_set_error(ORBHIP_ERR_INVALID, "extractor on device %d, vocabulary on device %d", device, v->device);
     BOWCHK(hipSetDevice(v->device));
-    orbhip_status st = voc_ensure_ws(v, nimg, cap, false); if (st != ORBHIP_OK) return st;
-    if (v->nwords == 0) { BOWCHK(hipMemsetAsync(v->d_nbow, 0, (size_t)nimg * 4, s)); BOWCHK(hipMemsetAsync(v->d_nfv, 0, (size_t)nimg * 4, s)); BOWCHK(hipMemsetAsync(v->d_fv_off, 0, (size_t)nimg * (cap + 1) * 4, s)); return ORBHIP_OK; }
-    return voc_run(v, d_desc, (long long)cap * 32, d_n, 0, nimg, cap, levelsup, true, s);     // on the extractor's stream: ordered after k_describe
+    BowWs* w = nullptr;
+    { std::lock_guard<std::mutex> lock(v->m); w = &v->per_ctx[ctx]; }             // std::map nodes do not move: the pointer outlives the lock
+    orbhip_status st = voc_ensure_ws(w, nimg, cap, s); if (st != ORBHIP_OK) return st;
+    if (v->nwords == 0) { BOWCHK(hipMemsetAsync(w->d_nbow, 0, (size_t)nimg * 4, s)); BOWCHK(hipMemsetAsync(w->d_nfv, 0, (size_t)nimg * 4, s)); BOWCHK(hipMemsetAsync(w->d_fv_off, 0, (size_t)nimg * (w->cap + 1) * 4, s)); w->last_frames = nimg; return ORBHIP_OK; }
+    return voc_run(v, w, d_desc, (long long)cap * 32, d_n, 0, nimg, cap, levelsup, true, s);     // on the extractor's stream: ordered after k_describe
 }
 
 extern "C" orbhip_status orbhip_fetch_bow(orbhip_ctx* ctx, orbhip_voc* v, int frame, uint32_t* bow_id, double* bow_val, int* nbow,
                                           uint32_t* fv_node, int32_t* fv_off, uint32_t* fv_feat, int* nfv)
 {
     if (!ctx || !v) return orbhip_set_error(ORBHIP_ERR_INVALID, "null argument");
-    if (frame < 0 || frame >= v->last_frames) return orbhip_set_error(ORBHIP_ERR_INVALID, "frame %d outside the %d frames of the last orbhip_compute_bow", frame, v->last_frames);
+    BowWs* w = nullptr;
+    { std::lock_guard<std::mutex> lock(v->m); auto it = v->per_ctx.find(ctx); if (it != v->per_ctx.end()) w = &it->second; }
+    if (!w || frame < 0 || frame >= w->last_frames) return orbhip_set_error(ORBHIP_ERR_INVALID, "frame %d outside the %d frames of this extractor's last orbhip_compute_bow", frame, w ? w->last_frames : 0);
     const uint8_t* d_desc = nullptr; const int* d_n = nullptr; int cap = 0, last = 0, device = 0; hipStream_t s = nullptr;
     orbhip_internal_outputs(ctx, &d_desc, &d_n, &cap, &last, &device, &s);
     BOWCHK(hipSetDevice(v->device));
-    return voc_fetch(v, frame, s, bow_id, bow_val, nbow, fv_node, fv_off, fv_feat, nfv);
+    return voc_fetch(w, frame, s, bow_id, bow_val, nbow, fv_node, fv_off, fv_feat, nfv);
 }
 
 // TemplatedVocabulary::score -> the scoring object selected by the file header (ScoringObject.cpp:24-313); two ascending
@@ -620,6 +649,7 @@ extern "C" double orbhip_voc_score(const orbhip_voc* v, const uint32_t* id1, con
 }
 
 static thread_local void* g_bm_ws = nullptr; static thread_local size_t g_bm_ws_bytes = 0; static thread_local int g_bm_dev = -1;
+void orbhip_bow_thread_release() { if (g_bm_ws) { (void)hipSetDevice(g_bm_dev); (void)hipDeviceSynchronize(); (void)hipFree(g_bm_ws); } g_bm_ws = nullptr; g_bm_ws_bytes = 0; g_bm_dev = -1; }
 
 // ORBmatcher::SearchByBoW on flat data; see include/orbhip.h
 extern "C" orbhip_status orbhip_search_by_bow(int device, int mode,
@@ -640,6 +670,7 @@ extern "C" orbhip_status orbhip_search_by_bow(int device, int mode,
                          al((size_t)n2 * 32), al((size_t)n2 * 4), al((size_t)n2), al((size_t)nfv2 * 4), al((size_t)(nfv2 + 1) * 4), al((size_t)std::max(m2, 1) * 4),
                          al((size_t)n1 * 4), al((size_t)n1 * 4), al((ORBHIP_HISTO_LENGTH + 2) * 4)};
     size_t total = 0; for (size_t b : sz) total += b;
+    orbhip_touch_thread_caches();
     if (g_bm_dev != device || g_bm_ws_bytes < total) {
         if (g_bm_ws) (void)hipFree(g_bm_ws);
         g_bm_ws = nullptr; g_bm_ws_bytes = 0;
@@ -693,6 +724,7 @@ extern "C" orbhip_status orbhip_search_for_triangulation(int device,
                            (size_t)n2 * 32, (size_t)n2 * 16, (size_t)n2, (size_t)n2, (size_t)nfv2 * 4, (size_t)(nfv2 + 1) * 4, (size_t)std::max(m2, 1) * 4,
                            (size_t)nlevels2 * 4, (size_t)nlevels2 * 4, (size_t)n1 * 4, (size_t)n1 * 4};
     size_t total = al((ORBHIP_HISTO_LENGTH + 2) * 4); for (size_t b : nb) total += al(b);
+    orbhip_touch_thread_caches();
     if (g_bm_dev != device || g_bm_ws_bytes < total) {
         if (g_bm_ws) (void)hipFree(g_bm_ws);
         g_bm_ws = nullptr; g_bm_ws_bytes = 0;

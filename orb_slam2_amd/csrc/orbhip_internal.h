@@ -159,5 +159,7 @@ void orbhip_launch_match_candidates(const MatchParams& M, int nslots, hipStream_
 void orbhip_launch_match_select(const MatchParams& M, int nslots, hipStream_t s);
 
 // shared with orbhip_bow.hip
+void orbhip_bow_thread_release();
+void orbhip_touch_thread_caches();      // makes sure the calling thread's cache holder exists (its destructor releases the caches of worker threads)
 orbhip_status orbhip_set_error(orbhip_status st, const char* fmt, ...);
 void orbhip_internal_outputs(orbhip_ctx* c, const uint8_t** d_desc, const int** d_n, int* cap, int* last_nimg, int* device, hipStream_t* s);

@@ -20,7 +20,7 @@ KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle"
 
 # every symbol include/orbhip.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "orbhip_version", "orbhip_device_count", "orbhip_last_error", "orbhip_create", "orbhip_destroy", "orbhip_keypoint_capacity",
+    "orbhip_version", "orbhip_thread_release", "orbhip_device_count", "orbhip_last_error", "orbhip_create", "orbhip_destroy", "orbhip_keypoint_capacity",
     "orbhip_get_scale_tables", "orbhip_level_size", "orbhip_extract", "orbhip_extract_batch", "orbhip_pyramid_level",
     "orbhip_extract_device", "orbhip_sync", "orbhip_fetch", "orbhip_fetch_matches", "orbhip_descriptor_distance",
     "orbhip_hamming_nn", "orbhip_hamming_nn_device", "orbhip_search_for_initialization", "orbhip_profile_enable",
