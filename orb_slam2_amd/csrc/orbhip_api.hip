@@ -353,6 +353,7 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
                 const int cw = std::max((int)maxX - (int)iniX - 6, 0), ch = std::max((int)maxY - (int)iniY - 6, 0);
                 cd.cand_cap = cd.skipped ? 0 : ((cw + 1) / 2) * ((ch + 1) / 2);       // strict 3x3 maxima are never 8-adjacent
                 if (!cd.skipped) { c->fc_maxpw = std::max(c->fc_maxpw, (int)maxX - (int)iniX); c->fc_maxph = std::max(c->fc_maxph, (int)maxY - (int)iniY); }
+                { const int ng = std::max((cw + 3) / 4, 1); cd.inv_ng = (65536 + ng - 1) / ng; }
                 cd.cand_idx = (int)cand_off; cand_off += cd.cand_cap;
                 c->cells.push_back(cd);
             }
@@ -471,7 +472,7 @@ static ExtractParams make_params(orbhip_ctx* c, const uint8_t* d_img0, long long
     P.iniTh = c->cfg.ini_th_fast; P.minTh = c->cfg.min_th_fast; P.blur_round_mode = c->cfg.blur_round_mode; P.fp_contract = c->fp_contract;
     P.qt_maxn = c->qt_maxn; P.qt_maxcells = c->qt_maxcells; P.qt_scr = orbhip_quadtree_scr(c->qt_maxn, c->qt_maxcells);
     P.fc_pstride = (c->fc_maxpw + 8 + 3) & ~3; P.fc_prows = c->fc_maxph; P.fc_sstride = 8 + 4 * ((std::max(c->fc_maxpw - 6, 0) + 3) / 4); P.fc_srows = std::max(c->fc_maxph - 6, 0) + 2;
-    P.fc_listcap = std::max(c->fc_maxpw - 6, 0) * std::max(c->fc_maxph - 6, 0);
+    P.fc_listcap = 2 * ((std::max(c->fc_maxpw - 6, 0) + 3) / 4) * std::max(c->fc_maxph - 6, 0);       // pixel pairs of the largest cell
     return P;
 }
 

@@ -46,6 +46,7 @@ struct CellDesc {           // one FAST cell (ORBextractor.cc:789-816)
     short shiftX, shiftY;           // j*wCell, i*hCell (added to cell-local coordinates, :822-823)
     int cand_idx;                   // first slot of this cell in cell_cand (per frame)
     int cand_cap;
+    int inv_ng;                     // ceil(2^16 / ng), ng = 4-pixel groups per interior row: k_fast_cells divides lane ids by ng with it
 };
 
 struct TileDesc { short level, x0, y0, pad; };

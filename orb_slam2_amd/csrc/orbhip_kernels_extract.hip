@@ -405,21 +405,28 @@ __host__ __device__ __forceinline__ int fc_wave_bytes(int pstride, int prows, in
 // so each max(r_k, r_k+8) exceeds C + t (bright arc) or each min(r_k, r_k+8) is below C - t (dark arc).  Four of the eight
 // pairs are tested (compass + diagonals: 14 % of the 4-pixel groups of a textured frame survive at t = 20, against 11 % with
 // all eight and 23 % with the compass pairs alone), which needs 5 of the 7 window rows, 9 byte-pair extractions and 19
-// packed min/max per pixel pair instead of 17 and 118 for the exact score.  Returns per 16-bit lane non-zero where it passes.
+// packed min/max per pixel pair instead of 17 and 118 for the exact score.  Returns non-zero where either pixel of the pair passes:
+// the two comparisons are saturating subtractions (v_pk_sub_u16 clamp), so no compare / select chain is needed.
 // (Round 2 measured the alternative the instruction-rate table suggests — the same four pairs for four pixels at a time in byte-SWAR
 //  arithmetic built only from full-rate add / sub / and / or / lshr on 7-bit halved values: 65 full-rate + 29 half-rate operations per
 //  group instead of 16 + 74, but the halving weakens the test by up to two grey levels, 11.1 % instead of 9.0 % of the pixel pairs reach
 //  the exact score (1.37 instead of 1.21 passes of that loop per cell) and the kernel ran 0.624 ms against 0.630 ms: kept as it was.
 //  With byte-offset LDS reads instead of v_alignbyte it ran 0.846 ms: a DS read off its natural alignment is replayed.
 //  profiles/r02_exp_fast_swar_*.json)
-__device__ __forceinline__ pki16 fast_pretest_pair(const pku16 r[16], pku16 c, int t)
+__device__ __forceinline__ pku16 psubsat(pku16 a, pku16 b) { return __builtin_elementwise_sub_sat(a, b); }
+__device__ __forceinline__ unsigned fast_pretest_pair(const pku16 r[16], pku16 c, pku16 tt)
 {
     pku16 mn = pmax(r[0], r[8]), mx = pmin(r[0], r[8]);
 #pragma unroll
     for (int k = 2; k < 8; k += 2) { mn = pmin(mn, pmax(r[k], r[k + 8])); mx = pmax(mx, pmin(r[k], r[k + 8])); }
-    const pki16 tt = {(short)t, (short)t};
-    const pki16 bright = (pki16)mn - (pki16)c, dark = (pki16)c - (pki16)mx;          // margins of the weakest tested pair
-    return (bright > tt) | (dark > tt);
+    // bright: weakest tested pair's maximum > C + t;  dark: weakest tested pair's minimum < C - t (never true when C - t clamps to 0)
+    return (unsigned)(psubsat(mn, c + tt) | psubsat(psubsat(c, tt), mx));
+}
+
+// number of set bits of m below this lane, plus base (v_mbcnt_lo / v_mbcnt_hi)
+__device__ __forceinline__ int fc_rank(unsigned long long m, int base)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)base));
 }
 
 __device__ __forceinline__ void fc_load_window(const uint8_t* patch, int PS, int y, int grp, unsigned (&w)[7][3])
@@ -448,7 +455,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
     uint8_t* patch = wbase;                                          // patch column 0 is 4-byte aligned
     uint8_t* score = wbase + ((PS * P.fc_prows + 15) & ~15);         // interior (x, y) at score[(y+1)*SS + 4 + x]; zero ring around it
     unsigned short* list = reinterpret_cast<unsigned short*>(score + ((SS * P.fc_srows + 15) & ~15));
-    const int ng = (cw + 3) >> 2;                                    // 4-pixel groups per interior row
+    const int ng = (cw + 3) >> 2;                                    // 4-pixel groups per interior row (<= 16)
     {
         int spitch; const uint8_t* src = level_src(P, frame, cd.level, spitch);
         src += (long long)cd.iniY * spitch + cd.iniX;
@@ -483,151 +490,111 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
         for (int i = lane; i < (SS >> 2) * (ch + 2); i += 64) reinterpret_cast<unsigned*>(score)[i] = 0;
     }
     __builtin_amdgcn_wave_barrier();
-    const int rp = 64 / ng;                                           // interior rows handled per wave iteration
-    const int sr = lane / ng, grp = lane - sr * ng;
-    const int iters = (ch + rp - 1) / rp;
+    // interior rows handled per wave iteration and this lane's (row, group): divisions by the wave-uniform ng through the cell's
+    // reciprocal ceil(2^16 / ng) from the host table (exact for lane < 64, ng <= 16)
+    const int rp = (64 * cd.inv_ng) >> 16;
+    const int sr = (lane * cd.inv_ng) >> 16, grp = lane - sr * ng;
     const bool lane_ok = sr < rp;
-    const unsigned long long below = (1ull << lane) - 1ull;
     unsigned* out = P.cell_cand + (long long)frame * P.cand_slots_per_frame + cd.cand_idx;
 
-    // ---- 1. the first cv::FAST call of the reference (iniThFAST, ORBextractor.cc:809-810).  Only pixels with score >= iniThFAST
-    //      matter for it, and NMS at iniThFAST sees every weaker pixel as 0, so:
-    //      a. cheap necessary test at iniThFAST on every pixel pair (a lane tests the two pairs of its 4-pixel group) -> ordered
+    // The two cv::FAST calls of the reference (ORBextractor.cc:809-816): iniThFAST, and minThFAST only when the first returned
+    // nothing.  Only pixels with score >= th matter for a call, and its NMS sees every weaker pixel as 0, so each call is
+    //      a. cheap necessary test at th on every pixel pair (a lane tests the two pairs of its 4-pixel group) -> ordered
     //         list of the pairs that may hold such a pixel
     //      b. exact scores of those pairs only (compacted: a lane per listed pair)
     //      c. NMS + row-major emission over the listed pairs
-    int nq = 0;
-    for (int it = 0; it < iters; it++) {
-        const int y = it * rp + sr;
-        bool pass_a = false, pass_b = false;
-        if (lane_ok && y < ch) {
-            unsigned w[7][3];
-            fc_load_window(patch, PS, y, grp, w);
-            const pku16 ra[16] = FC_RING(0);
-            const pku16 rb[16] = FC_RING(2);
-            const pki16 pa = fast_pretest_pair(ra, row_pair<3>(w[3][0], w[3][1], w[3][2]), P.iniTh);         // score >= t  <=>  best arc margin > t  =>  every opposite pair's margin > t
-            const pki16 pb = fast_pretest_pair(rb, row_pair<5>(w[3][0], w[3][1], w[3][2]), P.iniTh);
-            pass_a = (pa[0] | pa[1]) != 0; pass_b = (pb[0] | pb[1]) != 0;
-        }
-        const unsigned long long ma = __ballot(pass_a), mb = __ballot(pass_b);
-        int pos = nq + __popcll(ma & below) + __popcll(mb & below);
-        if (pass_a) list[pos++] = (unsigned short)((y << 8) | (2 * grp));          // id = row << 8 | pair index in the row
-        if (pass_b) list[pos] = (unsigned short)((y << 8) | (2 * grp + 1));
-        nq += __popcll(ma) + __popcll(mb);
-    }
-    __builtin_amdgcn_wave_barrier();
-    for (int qb = 0; qb < nq; qb += 64) {
-        if (qb + lane < nq) {
-            const int id = list[qb + lane], y = id >> 8, pr = id & 0xff, x0 = 2 * pr;
-            // the pair's 7 x 8-byte window, shifted so that it starts at byte 0 of the first dword whichever half of the group it is
-            const unsigned* prow = reinterpret_cast<const unsigned*>(patch + y * PS) + (pr >> 1);
-            const unsigned sh = 2u * (unsigned)(pr & 1);
-            unsigned w[7][3];
-#pragma unroll
-            for (int r = 0; r < 7; r++) {
-                const unsigned d0 = prow[r * (PS >> 2)], d1 = prow[r * (PS >> 2) + 1], d2 = prow[r * (PS >> 2) + 2];
-                w[r][0] = __builtin_amdgcn_alignbyte(d1, d0, sh); w[r][1] = __builtin_amdgcn_alignbyte(d2, d1, sh); w[r][2] = 0;
+    int count = 0;
+    for (int phase = 0; phase < 2; phase++) {
+        const int th = phase ? P.minTh : P.iniTh;
+        const pku16 tt = {(unsigned short)th, (unsigned short)th};
+        int nq = 0;
+        for (int yb = 0; yb < ch; yb += rp) {
+            // branch-free: idle lanes (beyond the last row / the last whole row group) test a clamped row and are masked afterwards
+            const int yy = yb + sr, y = min(yy, ch - 1);
+            const bool act = lane_ok && yy < ch;
+            unsigned pa, pb;
+            {
+                unsigned w[7][3];
+                fc_load_window(patch, PS, y, grp, w);
+                const pku16 ra[16] = FC_RING(0);
+                const pku16 rb[16] = FC_RING(2);
+                pa = fast_pretest_pair(ra, row_pair<3>(w[3][0], w[3][1], w[3][2]), tt);         // score >= t  <=>  best arc margin > t  =>  every opposite pair's margin > t
+                pb = fast_pretest_pair(rb, row_pair<5>(w[3][0], w[3][1], w[3][2]), tt);
             }
-            const pku16 ra[16] = FC_RING(0);
-            const pki16 sa = fast_score_pair(ra, row_pair<3>(w[3][0], w[3][1], w[3][2]));
-            int s0 = sa[0], s1 = sa[1];
-            if (s0 < P.iniTh || x0 >= cw) s0 = 0;
-            if (s1 < P.iniTh || x0 + 1 >= cw) s1 = 0;
-            *reinterpret_cast<unsigned short*>(score + (y + 1) * SS + 4 + x0) = (unsigned short)(s0 | (s1 << 8));
+            pa = act ? pa : 0u; pb = act ? pb : 0u;
+            const unsigned long long ma = __ballot(pa != 0), mb = __ballot(pb != 0);
+            int pos = fc_rank(mb, fc_rank(ma, nq));
+            if (pa != 0) list[pos++] = (unsigned short)((y << 8) | (2 * grp));          // id = row << 8 | pair index in the row
+            if (pb != 0) list[pos] = (unsigned short)((y << 8) | (2 * grp + 1));
+            nq += __popcll(ma) + __popcll(mb);
         }
-    }
-    __builtin_amdgcn_wave_barrier();
-    int count_ini = 0;
-    for (int qb = 0; qb < nq; qb += 64) {
-        bool keep[2] = {false, false}; int scv[2] = {0, 0}; int y = 0, x0 = 0;
-        if (qb + lane < nq) {
-            const int id = list[qb + lane];
-            y = id >> 8; x0 = 2 * (id & 0xff);
-            // rows above / at / below, bytes x0-1 .. x0+2 (the pad dwords left and right of a row are zero)
-            const uint8_t* q0 = &score[(y + 1) * SS + 4 + x0 - 1];
-            const unsigned* qa = reinterpret_cast<const unsigned*>(reinterpret_cast<uintptr_t>(q0) & ~(uintptr_t)3);
-            const unsigned shb = (unsigned)(reinterpret_cast<uintptr_t>(q0) & 3);
-            const int sdw = SS >> 2;
-            const unsigned ra4 = __builtin_amdgcn_alignbyte(qa[1 - sdw], qa[-sdw], shb);
-            const unsigned rb4 = __builtin_amdgcn_alignbyte(qa[1], qa[0], shb);
-            const unsigned rc4 = __builtin_amdgcn_alignbyte(qa[1 + sdw], qa[sdw], shb);
+        __builtin_amdgcn_wave_barrier();
+        for (int qb = 0; qb < nq; qb += 64) {
+            if (qb + lane < nq) {
+                const int id = list[qb + lane], y = id >> 8, pr = id & 0xff, x0 = 2 * pr;
+                // the pair's 7 x 8-byte window, shifted so that it starts at byte 0 of the first dword whichever half of the group it is
+                const unsigned* prow = reinterpret_cast<const unsigned*>(patch + y * PS) + (pr >> 1);
+                const unsigned sh = 2u * (unsigned)(pr & 1);
+                unsigned w[7][3];
 #pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const int sc = (int)((rb4 >> (8 * (q + 1))) & 0xff);
-                scv[q] = sc;
-                if (sc > 0) {
-                    const int l = (int)((rb4 >> (8 * q)) & 0xff), r = (int)((rb4 >> (8 * (q + 2))) & 0xff);
-                    const int u0 = (int)((ra4 >> (8 * q)) & 0xff), u1 = (int)((ra4 >> (8 * (q + 1))) & 0xff), u2 = (int)((ra4 >> (8 * (q + 2))) & 0xff);
-                    const int d0 = (int)((rc4 >> (8 * q)) & 0xff), d1 = (int)((rc4 >> (8 * (q + 1))) & 0xff), d2 = (int)((rc4 >> (8 * (q + 2))) & 0xff);
-                    keep[q] = sc > l && sc > r && sc > u0 && sc > u1 && sc > u2 && sc > d0 && sc > d1 && sc > d2;
+                for (int r = 0; r < 7; r++) {
+                    const unsigned d0 = prow[r * (PS >> 2)], d1 = prow[r * (PS >> 2) + 1], d2 = prow[r * (PS >> 2) + 2];
+                    w[r][0] = __builtin_amdgcn_alignbyte(d1, d0, sh); w[r][1] = __builtin_amdgcn_alignbyte(d2, d1, sh); w[r][2] = 0;
+                }
+                const pku16 ra[16] = FC_RING(0);
+                const pki16 sa = fast_score_pair(ra, row_pair<3>(w[3][0], w[3][1], w[3][2]));
+                int s0 = sa[0], s1 = sa[1];
+                if (s0 < th || x0 >= cw) s0 = 0;                                         // corner at th  <=>  score >= th
+                if (s1 < th || x0 + 1 >= cw) s1 = 0;
+                *reinterpret_cast<unsigned short*>(score + (y + 1) * SS + 4 + x0) = (unsigned short)(s0 | (s1 << 8));
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int qb = 0; qb < nq; qb += 64) {
+            bool keep[2] = {false, false}; int scv[2] = {0, 0}; int y = 0, x0 = 0;
+            if (qb + lane < nq) {
+                const int id = list[qb + lane];
+                y = id >> 8; x0 = 2 * (id & 0xff);
+                // rows above / at / below, bytes x0-1 .. x0+2 (the pad dwords left and right of a row are zero)
+                const uint8_t* q0 = &score[(y + 1) * SS + 4 + x0 - 1];
+                const unsigned* qa = reinterpret_cast<const unsigned*>(reinterpret_cast<uintptr_t>(q0) & ~(uintptr_t)3);
+                const unsigned shb = (unsigned)(reinterpret_cast<uintptr_t>(q0) & 3);
+                const int sdw = SS >> 2;
+                const unsigned ra4 = __builtin_amdgcn_alignbyte(qa[1 - sdw], qa[-sdw], shb);
+                const unsigned rb4 = __builtin_amdgcn_alignbyte(qa[1], qa[0], shb);
+                const unsigned rc4 = __builtin_amdgcn_alignbyte(qa[1 + sdw], qa[sdw], shb);
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int sc = (int)((rb4 >> (8 * (q + 1))) & 0xff);
+                    scv[q] = sc;
+                    if (sc > 0) {
+                        const int l = (int)((rb4 >> (8 * q)) & 0xff), r = (int)((rb4 >> (8 * (q + 2))) & 0xff);
+                        const int u0 = (int)((ra4 >> (8 * q)) & 0xff), u1 = (int)((ra4 >> (8 * (q + 1))) & 0xff), u2 = (int)((ra4 >> (8 * (q + 2))) & 0xff);
+                        const int d0 = (int)((rc4 >> (8 * q)) & 0xff), d1 = (int)((rc4 >> (8 * (q + 1))) & 0xff), d2 = (int)((rc4 >> (8 * (q + 2))) & 0xff);
+                        keep[q] = sc > l && sc > r && sc > u0 && sc > u1 && sc > u2 && sc > d0 && sc > d1 && sc > d2;
+                    }
                 }
             }
-        }
-        const unsigned long long m0 = __ballot(keep[0]), m1 = __ballot(keep[1]);
-        int rank = count_ini + __popcll(m0 & below) + __popcll(m1 & below);
+            const unsigned long long m0 = __ballot(keep[0]), m1 = __ballot(keep[1]);
+            int rank = fc_rank(m1, fc_rank(m0, count));
 #pragma unroll
-        for (int q = 0; q < 2; q++)
-            if (keep[q]) {
-                // FAST reports cell-local (x, y); the reference adds (j*wCell, i*hCell)  (ORBextractor.cc:822-823)
-                const unsigned px = (unsigned)(x0 + q + 3 + cd.shiftX), py = (unsigned)(y + 3 + cd.shiftY);
-                if (rank < cd.cand_cap) out[rank] = px | (py << 12) | ((unsigned)scv[q] << 24);
-                rank++;
-            }
-        count_ini += __popcll(m0) + __popcll(m1);
-    }
-    if (count_ini > 0) {
-        if (lane == 0) P.cell_count[(long long)frame * P.ncells_total + cell_id] = min(count_ini, cd.cand_cap);
-        return;
-    }
-
-    // ---- 2. vKeysCell.empty() -> cv::FAST again with minThFAST (ORBextractor.cc:812-816): exact scores of every examined pixel,
-    //      corners compacted in row-major order, NMS over that list.  Rare on textured frames.
-    __builtin_amdgcn_wave_barrier();
-    int ncorn = 0;
-    for (int it = 0; it < iters; it++) {
-        const int y = it * rp + sr;
-        int sc[4] = {0, 0, 0, 0};
-        if (lane_ok && y < ch) {
-            unsigned w[7][3];
-            fc_load_window(patch, PS, y, grp, w);
-            const pku16 ra[16] = FC_RING(0);
-            const pku16 rb[16] = FC_RING(2);
-            const pki16 sa = fast_score_pair(ra, row_pair<3>(w[3][0], w[3][1], w[3][2]));
-            const pki16 sb = fast_score_pair(rb, row_pair<5>(w[3][0], w[3][1], w[3][2]));
-            const int x0 = 4 * grp;
-            sc[0] = sa[0]; sc[1] = sa[1]; sc[2] = sb[0]; sc[3] = sb[1];
-#pragma unroll
-            for (int q = 0; q < 4; q++) if (sc[q] < P.minTh || x0 + q >= cw) sc[q] = 0;          // corner at minThFAST  <=>  score >= minThFAST
-            *reinterpret_cast<unsigned*>(score + (y + 1) * SS + 4 + x0) = (unsigned)sc[0] | ((unsigned)sc[1] << 8) | ((unsigned)sc[2] << 16) | ((unsigned)sc[3] << 24);
+            for (int q = 0; q < 2; q++)
+                if (keep[q]) {
+                    // FAST reports cell-local (x, y); the reference adds (j*wCell, i*hCell)  (ORBextractor.cc:822-823)
+                    const unsigned px = (unsigned)(x0 + q + 3 + cd.shiftX), py = (unsigned)(y + 3 + cd.shiftY);
+                    if (rank < cd.cand_cap) out[rank] = px | (py << 12) | ((unsigned)scv[q] << 24);
+                    rank++;
+                }
+            count += __popcll(m0) + __popcll(m1);
         }
-        const unsigned long long m0 = __ballot(sc[0] > 0), m1 = __ballot(sc[1] > 0), m2 = __ballot(sc[2] > 0), m3 = __ballot(sc[3] > 0);
-        int pos = ncorn + __popcll(m0 & below) + __popcll(m1 & below) + __popcll(m2 & below) + __popcll(m3 & below);
-#pragma unroll
-        for (int q = 0; q < 4; q++) if (sc[q] > 0) list[pos++] = (unsigned short)((y << 8) | (4 * grp + q));
-        ncorn += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+        if (count > 0) break;
+        // vKeysCell.empty() -> cv::FAST again with minThFAST (ORBextractor.cc:812-816).  The score map restarts from zero: scores the
+        // first call left behind (maxima that suppressed each other) are not this call's
+        __builtin_amdgcn_wave_barrier();
+        if (phase == 0) for (int i = lane; i < (SS >> 2) * (ch + 2); i += 64) reinterpret_cast<unsigned*>(score)[i] = 0;
+        __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_wave_barrier();
-    int count_min = 0;
-    const int nchunks = (ncorn + 63) >> 6;
-    for (int cb = 0; cb < nchunks; cb++) {
-        const int i = cb * 64 + lane;
-        bool keep = false; int sc = 0, id = 0;
-        if (i < ncorn) {
-            id = list[i];
-            const uint8_t* q = &score[((id >> 8) + 1) * SS + (id & 0xff) + 4];
-            sc = q[0];
-            keep = sc > q[-1] && sc > q[1] && sc > q[-SS - 1] && sc > q[-SS] && sc > q[-SS + 1] &&
-                   sc > q[SS - 1] && sc > q[SS] && sc > q[SS + 1];
-        }
-        const unsigned long long mmin = __ballot(keep);
-        if (keep) {
-            const int rank = count_min + __popcll(mmin & below);
-            const unsigned px = (unsigned)((id & 0xff) + 3 + cd.shiftX), py = (unsigned)((id >> 8) + 3 + cd.shiftY);
-            if (rank < cd.cand_cap) out[rank] = px | (py << 12) | ((unsigned)sc << 24);
-        }
-        count_min += __popcll(mmin);
-    }
-    if (lane == 0) P.cell_count[(long long)frame * P.ncells_total + cell_id] = min(count_min, cd.cand_cap);
+    if (lane == 0) P.cell_count[(long long)frame * P.ncells_total + cell_id] = min(count, cd.cand_cap);
 }
 #undef FC_RING
 

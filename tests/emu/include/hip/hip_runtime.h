@@ -185,6 +185,11 @@ inline unsigned __builtin_amdgcn_cvt_pk_u8_f32(float v, unsigned pos, unsigned o
     const unsigned sh = 8 * (pos & 3);
     return (old & ~(0xffu << sh)) | ((unsigned)r << sh);
 }
+// v_pk_sub_u16 clamp (clang's __builtin_elementwise_sub_sat on a two-lane u16 vector): unsigned saturating subtraction per lane
+template <typename V> inline V __builtin_elementwise_sub_sat(V a, V b) { return a > b ? a - b : a - a; }
+// v_mbcnt_lo_u32_b32 / v_mbcnt_hi_u32_b32: set bits of the mask half below this lane, plus base
+inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned mask, unsigned base) { const int l = __lane_id(); return base + (unsigned)__builtin_popcount(mask & (l >= 32 ? 0xffffffffu : ((1u << l) - 1u))); }
+inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned mask, unsigned base) { const int l = __lane_id(); return base + (unsigned)__builtin_popcount(l > 32 ? mask & ((1u << (l - 32)) - 1u) : 0u); }
 // v_readfirstlane_b32: the kernels only apply it to wave-uniform values (to move them to the scalar unit)
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 // atomics (single OS thread: plain read-modify-write is atomic w.r.t. fibers)
