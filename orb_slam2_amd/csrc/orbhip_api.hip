@@ -69,7 +69,7 @@ struct orbhip_ctx {
     int fc_maxpw = 0, fc_maxph = 0;
     long long plane_frame_bytes = 0, cand_slots_per_frame = 0, qt_per_frame = 0; int lvl_kp_per_frame = 0, out_cap = 0, qt_maxn = 0, qt_maxcells = 0, lvl0_cap = 0;
     // device
-    LevelGeom* d_geom = nullptr; CellDesc* d_cells = nullptr; TileDesc* d_tiles = nullptr; int2* d_xtab = nullptr; int2* d_ytab = nullptr; float* d_pattern = nullptr;
+    LevelGeom* d_geom = nullptr; CellDesc* d_cells = nullptr; TileDesc* d_tiles = nullptr; int2* d_xtab = nullptr; int2* d_ytab = nullptr; float* d_pattern = nullptr; int4* d_fc_dma = nullptr; int fc_np = 0;
     uint8_t* d_pyr = nullptr; uint8_t* d_blur = nullptr; int* d_cell_count = nullptr; unsigned* d_cell_cand = nullptr;
     unsigned* d_qt_val = nullptr; unsigned* d_qt_code = nullptr; int* d_qt_node = nullptr; unsigned* d_lvl_kp = nullptr;
     // outputs are triple-buffered: batch t writes buffer t%3 while the matcher of batch t-1 (own stream) still reads buffers (t-1)%3 and (t-2)%3
@@ -261,7 +261,7 @@ extern "C" void orbhip_destroy(orbhip_ctx* c)
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     prof_collect(c);
     for (auto e : c->pool) (void)hipEventDestroy(e);
-    void* ptrs[] = {c->d_geom, c->d_cells, c->d_tiles, c->d_xtab, c->d_ytab, c->d_pattern, c->d_pyr, c->d_blur, c->d_cell_count, c->d_cell_cand,
+    void* ptrs[] = {c->d_fc_dma, c->d_geom, c->d_cells, c->d_tiles, c->d_xtab, c->d_ytab, c->d_pattern, c->d_pyr, c->d_blur, c->d_cell_count, c->d_cell_cand,
                     c->d_qt_val, c->d_qt_code, c->d_qt_node, c->d_lvl_kp, c->d_lvl_n[0], c->d_lvl_n[1], c->d_lvl_n[2], c->d_out_kp[0], c->d_out_kp[1], c->d_out_kp[2],
                     c->d_out_desc[0], c->d_out_desc[1], c->d_out_desc[2], c->d_out_n[0], c->d_out_n[1], c->d_out_n[2], c->d_grid_start, c->d_grid_items, c->d_grid_xy, c->d_cand, c->d_top, c->d_ncand,
                     c->d_prev, c->d_m12, c->d_nm};
@@ -287,6 +287,10 @@ extern "C" void orbhip_destroy(orbhip_ctx* c)
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
+
+// LDS row stride of a k_fast_cells patch: 4 * (groups + 2) bytes cover every window read; 48 bytes for the usual 37-px cells puts the
+// eight rows a wave reads at once on each LDS bank exactly twice (the minimum for 64 lanes x 4 bytes)
+static int fc_pstride(const orbhip_ctx* c) { return (c->fc_maxpw + 8 + 3) & ~3; }
 
 extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cfg)
 {
@@ -408,6 +412,18 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
 #define TRY(x) do { if (e == hipSuccess) e = (x); } while (0)
     TRY(upload(&c->d_geom, c->geom)); TRY(upload(&c->d_cells, c->cells)); TRY(upload(&c->d_tiles, c->blur_tiles));
     TRY(upload(&c->d_xtab, c->xtab)); TRY(upload(&c->d_ytab, c->ytab)); TRY(upload(&c->d_pattern, pat));
+    {   // k_fast_cells stages a cell's sub-image by LDS-DMA: pass k, lane l fills patch dword 64k + l = (row, column) in the PS-strided LDS layout
+        const int psd = fc_pstride(c) / 4, nd = psd * std::max(c->fc_maxph, 1);
+        c->fc_np = (nd + 63) / 64;
+        const int np8 = (c->fc_np + 7) & ~7;
+        std::vector<int4> tab((size_t)(np8 / 4) * 2 * 64);
+        for (int k = 0; k < np8; k++) for (int l = 0; l < 64; l++) {
+            const int pos = 64 * k + l, row = pos / psd, col4 = 4 * (pos % psd);
+            int* r = &tab[(size_t)((k >> 2) * 2) * 64 + l].x; int* d = &tab[(size_t)((k >> 2) * 2 + 1) * 64 + l].x;
+            r[k & 3] = row; d[k & 3] = col4;
+        }
+        TRY(upload(&c->d_fc_dma, tab));
+    }
     TRY(dalloc(&c->d_pyr, B * c->plane_frame_bytes + 256)); TRY(dalloc(&c->d_blur, B * c->plane_frame_bytes + 256));
     TRY(dalloc(&c->d_cell_count, B * c->cells.size())); TRY(dalloc(&c->d_cell_cand, B * c->cand_slots_per_frame));
     TRY(dalloc(&c->d_qt_val, B * c->qt_per_frame)); TRY(dalloc(&c->d_qt_code, B * c->qt_per_frame)); TRY(dalloc(&c->d_qt_node, B * c->qt_per_frame));
@@ -471,7 +487,7 @@ static ExtractParams make_params(orbhip_ctx* c, const uint8_t* d_img0, long long
     P.xtab = c->d_xtab; P.ytab = c->d_ytab; P.patternf = c->d_pattern;
     P.iniTh = c->cfg.ini_th_fast; P.minTh = c->cfg.min_th_fast; P.blur_round_mode = c->cfg.blur_round_mode; P.fp_contract = c->fp_contract;
     P.qt_maxn = c->qt_maxn; P.qt_maxcells = c->qt_maxcells; P.qt_scr = orbhip_quadtree_scr(c->qt_maxn, c->qt_maxcells);
-    P.fc_pstride = (c->fc_maxpw + 8 + 3) & ~3; P.fc_prows = c->fc_maxph; P.fc_sstride = 8 + 4 * ((std::max(c->fc_maxpw - 6, 0) + 3) / 4); P.fc_srows = std::max(c->fc_maxph - 6, 0) + 2;
+    P.fc_pstride = fc_pstride(c); P.fc_prows = c->fc_maxph; P.fc_np = c->fc_np; P.fc_pbytes = 256 * c->fc_np; P.fc_dma = c->d_fc_dma; P.fc_sstride = 8 + 4 * ((std::max(c->fc_maxpw - 6, 0) + 3) / 4); P.fc_srows = std::max(c->fc_maxph - 6, 0) + 2;
     P.fc_listcap = 2 * ((std::max(c->fc_maxpw - 6, 0) + 3) / 4) * std::max(c->fc_maxph - 6, 0);       // pixel pairs of the largest cell
     return P;
 }

@@ -69,6 +69,7 @@ struct ExtractParams {
     int qt_maxcells;                                                       // max cells of one level
     int qt_scr;                                                            // ints of scan scratch in the quadtree's LDS layout
     int fc_pstride, fc_prows, fc_sstride, fc_srows, fc_listcap;            // per-wave LDS layout of k_fast_cells (largest cell of the context)
+    int fc_pbytes, fc_np; const int4* fc_dma;                              // patch region = fc_np LDS-DMA passes of 256 bytes; (row, 4*column) of every (pass, lane)
 };
 
 struct MatchParams {        // SearchForInitialization over camera slots (ORBmatcher.cc:405-520)

@@ -347,7 +347,6 @@ void orbhip_launch_blur(const ExtractParams& P, const int gk[4], int nframes, hi
 //      emitted in row-major order;
 //   2. only if that found nothing: the exact score of every examined pixel at minThFAST, corners compacted in row-major order, NMS, emission.
 #define FC_WAVES 4
-#define FC_LD 6                        // patch-load passes a lane keeps in flight
 
 typedef unsigned short pku16 __attribute__((vector_size(4)));      // two u16 lanes in one VGPR -> v_pk_min_u16 / v_pk_max_u16
 typedef short pki16 __attribute__((vector_size(4)));
@@ -388,10 +387,21 @@ __device__ __forceinline__ pki16 fast_score_pair(const pku16 r[16], pku16 c)
     return (dark > bright ? dark : bright) - one;
 }
 
-__host__ __device__ __forceinline__ int fc_wave_bytes(int pstride, int prows, int sstride, int srows, int listcap)
+__host__ __device__ __forceinline__ int fc_wave_bytes(int pbytes, int sstride, int srows, int listcap)
 {
-    return ((pstride * prows + 15) & ~15) + ((sstride * srows + 15) & ~15) + ((2 * listcap + 15) & ~15);
+    return ((pbytes + 15) & ~15) + ((sstride * srows + 15) & ~15) + ((2 * listcap + 15) & ~15);
 }
+
+// LDS-DMA: every lane's dword goes from global memory straight to LDS dword (lane) of the 256-byte block at lds_block, without a
+// VGPR round trip (global_load_lds_dword; M0 = block address, wave-uniform).  The source may sit at any byte address
+// (tools/lds_dma_probe.hip, measured on MI355X).  The loads count on vmcnt: lds_dma_wait() before the first LDS read.
+typedef const __attribute__((address_space(1))) void* orbhip_gptr;
+typedef __attribute__((address_space(3))) void* orbhip_lptr;
+__device__ __forceinline__ void lds_dma_dword(const uint8_t* gsrc, uint8_t* lds_block)
+{
+    __builtin_amdgcn_global_load_lds((orbhip_gptr)gsrc, (orbhip_lptr)lds_block, 4, 0, 0);
+}
+__device__ __forceinline__ void lds_dma_wait() { __builtin_amdgcn_s_waitcnt(0x0f70); }     // s_waitcnt vmcnt(0)
 
 // ring of the pixel pair (Q, Q+1) of a 4-pixel group whose 7 x 12-byte window is w[7][3] (circle: FAST 16-point Bresenham);
 // ring element k of pixel q sits at row 3+dy_k, byte 3+q+dx_k
@@ -451,43 +461,38 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
     const bool work = !cd.skipped && cw > 0 && ch > 0;
     if (!work) { if (lane == 0) P.cell_count[(long long)frame * P.ncells_total + cell_id] = 0; return; }
     const int PS = P.fc_pstride, SS = P.fc_sstride;                  // byte strides, multiples of 4
-    uint8_t* wbase = reinterpret_cast<uint8_t*>(fc_lds) + wave * fc_wave_bytes(PS, P.fc_prows, SS, P.fc_srows, P.fc_listcap);
-    uint8_t* patch = wbase;                                          // patch column 0 is 4-byte aligned
-    uint8_t* score = wbase + ((PS * P.fc_prows + 15) & ~15);         // interior (x, y) at score[(y+1)*SS + 4 + x]; zero ring around it
+    uint8_t* wbase = reinterpret_cast<uint8_t*>(fc_lds) + wave * fc_wave_bytes(P.fc_pbytes, SS, P.fc_srows, P.fc_listcap);
+    uint8_t* patch = wbase;                                          // patch column 0 is 4-byte aligned; row stride PS
+    uint8_t* score = wbase + ((P.fc_pbytes + 15) & ~15);             // interior (x, y) at score[(y+1)*SS + 4 + x]; zero ring around it
     unsigned short* list = reinterpret_cast<unsigned short*>(score + ((SS * P.fc_srows + 15) & ~15));
     const int ng = (cw + 3) >> 2;                                    // 4-pixel groups per interior row (<= 16)
     {
+        // The cell's sub-image goes to LDS by LDS-DMA at the patch's own byte alignment, so patch column 0 lands on an LDS dword
+        // boundary without any shifting: pass k fills LDS dwords [64k, 64k+64) of the patch, lane l the dword (row, col) =
+        // divmod(64k + l, PS/4), both from a host table that only depends on PS.  Positions outside the patch (rows >= ph, the
+        // row tail) read the patch's last dword instead: any in-bounds address does, nothing reads those LDS bytes.  The last
+        // dword of a row may read up to 3 bytes past the patch: still inside the image row (cells end >= 13 px before the border).
         int spitch; const uint8_t* src = level_src(P, frame, cd.level, spitch);
         src += (long long)cd.iniY * spitch + cd.iniX;
-        const int nd = (pw + 3) >> 2;
-        {
-            // 32-bit loads at the patch's own byte alignment (global loads need no alignment on this target), so patch column 0
-            // lands on an LDS dword boundary without any shifting.  Lane = (row, dword column) with 16 (or 32) lanes per row;
-            // FC_LD passes are put in flight before the first LDS write.  The last dword of a row may read up to 3 bytes past
-            // the patch: still inside the image row (cells end >= 16 px before the right border).
-            const int lw = nd <= 16 ? 4 : 5, rpp = 64 >> lw;             // log2 lanes per row, rows per pass
-            const int d = lane & ((1 << lw) - 1), r0 = lane >> lw;
-            const uint8_t* gp = uniform_ptr(src);
-            const unsigned off0 = (unsigned)(r0 * spitch + 4 * d);
-            unsigned* lp = reinterpret_cast<unsigned*>(patch) + d;
-            const int lstep = PS >> 2;
-            for (int rb = 0; rb < ph; rb += FC_LD * rpp) {
-                unsigned v[FC_LD];
+        const uint8_t* gp = uniform_ptr(src);
+        const unsigned maxoff = (unsigned)((ph - 1) * spitch + 4 * (((pw + 3) >> 2) - 1));
+        const int np = P.fc_np;
+        for (int k0 = 0; k0 < np; k0 += 8) {
+            const int4* tab = P.fc_dma + (k0 >> 1) * 64 + lane;     // per 4 passes: int4 rows, int4 4*dword columns, [..][64 lanes]
+            int4 rr[2], dd[2];
 #pragma unroll
-                for (int k = 0; k < FC_LD; k++) {
-                    const int r = rb + k * rpp + r0;
-                    v[k] = 0;
-                    if (d < nd && r < ph) v[k] = *reinterpret_cast<const u32_unaligned*>(gp + off0 + (unsigned)((rb + k * rpp) * spitch));
-                }
+            for (int j = 0; j < 2; j++) if (k0 + 4 * j < np) { rr[j] = tab[(2 * j) * 64]; dd[j] = tab[(2 * j + 1) * 64]; }
 #pragma unroll
-                for (int k = 0; k < FC_LD; k++) {
-                    const int r = rb + k * rpp + r0;
-                    if (d < nd && r < ph) lp[r * lstep] = v[k];
-                }
+            for (int j = 0; j < 2; j++) if (k0 + 4 * j < np) {
+                const int r4[4] = {rr[j].x, rr[j].y, rr[j].z, rr[j].w}, d4[4] = {dd[j].x, dd[j].y, dd[j].z, dd[j].w};
+#pragma unroll
+                for (int q = 0; q < 4; q++) if (k0 + 4 * j + q < np)
+                    lds_dma_dword(gp + min(__umul24((unsigned)r4[q], (unsigned)spitch) + (unsigned)d4[q], maxoff), patch + (k0 + 4 * j + q) * 256);
             }
         }
-        // the whole score map starts at zero: the first pass below only fills the 4-pixel groups it examines
+        // the whole score map starts at zero: the passes below only fill the pixel pairs they examine
         for (int i = lane; i < (SS >> 2) * (ch + 2); i += 64) reinterpret_cast<unsigned*>(score)[i] = 0;
+        lds_dma_wait();
     }
     __builtin_amdgcn_wave_barrier();
     // interior rows handled per wave iteration and this lane's (row, group): divisions by the wave-uniform ng through the cell's
@@ -600,7 +605,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
 
 void orbhip_launch_fast_cells(const ExtractParams& P, int nframes, hipStream_t s)
 {
-    const size_t lds = (size_t)FC_WAVES * fc_wave_bytes(P.fc_pstride, P.fc_prows, P.fc_sstride, P.fc_srows, P.fc_listcap);
+    const size_t lds = (size_t)FC_WAVES * fc_wave_bytes(P.fc_pbytes, P.fc_sstride, P.fc_srows, P.fc_listcap);
     ExtractParams Q = P; Q.nframes = nframes;
     hipLaunchKernelGGL(k_fast_cells, dim3(xcd_grid((P.ncells_total + FC_WAVES - 1) / FC_WAVES, nframes), 1, 1), dim3(256, 1, 1), lds, s, Q);
 }

@@ -38,6 +38,7 @@ struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
 struct uint2 { unsigned x, y; };
 struct uint4 { unsigned x, y, z, w; };
+struct int4 { int x, y, z, w; };
 struct uchar4 { unsigned char x, y, z, w; };
 
 typedef int hipError_t;
@@ -190,6 +191,10 @@ template <typename V> inline V __builtin_elementwise_sub_sat(V a, V b) { return 
 // v_mbcnt_lo_u32_b32 / v_mbcnt_hi_u32_b32: set bits of the mask half below this lane, plus base
 inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned mask, unsigned base) { const int l = __lane_id(); return base + (unsigned)__builtin_popcount(mask & (l >= 32 ? 0xffffffffu : ((1u << l) - 1u))); }
 inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned mask, unsigned base) { const int l = __lane_id(); return base + (unsigned)__builtin_popcount(l > 32 ? mask & ((1u << (l - 32)) - 1u) : 0u); }
+// global_load_lds_dword (LDS-DMA): lane l's dword lands at LDS dword l of the block; s_waitcnt is a no-op here
+inline void __builtin_amdgcn_global_load_lds(const void* gsrc, void* lds_block, unsigned size, int offset, unsigned) { memcpy((char*)lds_block + offset + (size_t)__lane_id() * size, (const char*)gsrc + offset, size); }
+inline void __builtin_amdgcn_s_waitcnt(int) {}
+inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 // v_readfirstlane_b32: the kernels only apply it to wave-uniform values (to move them to the scalar unit)
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 // atomics (single OS thread: plain read-modify-write is atomic w.r.t. fibers)
