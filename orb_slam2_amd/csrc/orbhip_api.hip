@@ -62,14 +62,14 @@ struct HostSet {
 struct orbhip_ctx {
     orbhip_config cfg; int L = 0, B = 0, fp_contract = 0;
     std::vector<LevelGeom> geom; std::vector<float> sf, isf, s2, is2; std::vector<int> nfeat;
-    std::vector<CellDesc> cells; std::vector<TileDesc> blur_tiles; std::vector<int2> xtab, ytab; std::vector<char> pyr_staged;
+    std::vector<CellDesc> cells; std::vector<TileDesc> blur_tiles; std::vector<int2> xtab, ytab; std::vector<PyrGroup> xgrp; std::vector<char> pyr_staged;
     int gk[4] = {0, 0, 0, 0};
     hipStream_t stream = nullptr; bool own_stream = false;
     std::vector<hipStream_t> xstreams; std::vector<hipEvent_t> xevents; hipEvent_t ev_fork = nullptr;     // extra streams of a multi-stream context
     int fc_maxpw = 0, fc_maxph = 0;
     long long plane_frame_bytes = 0, cand_slots_per_frame = 0, qt_per_frame = 0; int lvl_kp_per_frame = 0, out_cap = 0, qt_maxn = 0, qt_maxcells = 0, lvl0_cap = 0;
     // device
-    LevelGeom* d_geom = nullptr; CellDesc* d_cells = nullptr; TileDesc* d_tiles = nullptr; int2* d_xtab = nullptr; int2* d_ytab = nullptr; float* d_pattern = nullptr; int4* d_fc_dma = nullptr; int fc_np = 0;
+    LevelGeom* d_geom = nullptr; CellDesc* d_cells = nullptr; TileDesc* d_tiles = nullptr; int2* d_xtab = nullptr; int2* d_ytab = nullptr; float* d_pattern = nullptr; int4* d_fc_dma = nullptr; int fc_np = 0; PyrGroup* d_xgrp = nullptr;
     uint8_t* d_pyr = nullptr; uint8_t* d_blur = nullptr; int* d_cell_count = nullptr; unsigned* d_cell_cand = nullptr;
     unsigned* d_qt_val = nullptr; unsigned* d_qt_code = nullptr; int* d_qt_node = nullptr; unsigned* d_lvl_kp = nullptr;
     // outputs are triple-buffered: batch t writes buffer t%3 while the matcher of batch t-1 (own stream) still reads buffers (t-1)%3 and (t-2)%3
@@ -261,7 +261,7 @@ extern "C" void orbhip_destroy(orbhip_ctx* c)
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     prof_collect(c);
     for (auto e : c->pool) (void)hipEventDestroy(e);
-    void* ptrs[] = {c->d_fc_dma, c->d_geom, c->d_cells, c->d_tiles, c->d_xtab, c->d_ytab, c->d_pattern, c->d_pyr, c->d_blur, c->d_cell_count, c->d_cell_cand,
+    void* ptrs[] = {c->d_xgrp, c->d_fc_dma, c->d_geom, c->d_cells, c->d_tiles, c->d_xtab, c->d_ytab, c->d_pattern, c->d_pyr, c->d_blur, c->d_cell_count, c->d_cell_cand,
                     c->d_qt_val, c->d_qt_code, c->d_qt_node, c->d_lvl_kp, c->d_lvl_n[0], c->d_lvl_n[1], c->d_lvl_n[2], c->d_out_kp[0], c->d_out_kp[1], c->d_out_kp[2],
                     c->d_out_desc[0], c->d_out_desc[1], c->d_out_desc[2], c->d_out_n[0], c->d_out_n[1], c->d_out_n[2], c->d_grid_start, c->d_grid_items, c->d_grid_xy, c->d_cand, c->d_top, c->d_ncand,
                     c->d_prev, c->d_m12, c->d_nm};
@@ -380,6 +380,24 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
             for (int x0 = 0; x0 < g.w; x0 += tw) { const int xl = std::min(x0 + tw - 1, g.w - 1); const int a = c->xtab[g.xtab_off + x0].x & ~3, b = std::min(c->xtab[g.xtab_off + xl].x + 1, g.src_w - 1); fits = fits && orbhip_pyramid_tile_fits(b - a + 1, 1); }
             for (int y0 = 0; y0 < g.h; y0 += th) { const int yl = std::min(y0 + th - 1, g.h - 1); const int a = std::min(std::max(c->ytab[g.ytab_off + y0].x, 0), g.src_h - 1), b = std::min(std::max(c->ytab[g.ytab_off + yl].x + 1, 0), g.src_h - 1); fits = fits && orbhip_pyramid_tile_fits(1, b - a + 1); }
             c->pyr_staged.resize(L, 0); c->pyr_staged[l] = fits ? 1 : 0;
+            // 4-pixel groups (k_pyramid_level_g): usable when every group's taps lie within 8 source bytes of its first tap and the three
+            // dwords a thread reads stay inside the staged row
+            g.xgrp_off = (int)c->xgrp.size(); bool grouped = fits;
+            for (int x4 = 0; x4 < g.w; x4 += 4) {
+                PyrGroup G; memset(&G, 0, sizeof G);
+                G.sx0 = c->xtab[g.xtab_off + x4].x;
+                for (int k = 0; k < 4; k++) {
+                    const int2 e = c->xtab[g.xtab_off + std::min(x4 + k, g.w - 1)];
+                    const int o0 = e.x - G.sx0, o1 = std::min(e.x + 1, g.src_w - 1) - G.sx0;
+                    if (o0 < 0 || o1 < 0 || o0 > 7 || o1 > 7) grouped = false;
+                    G.sel[k] = (unsigned)(o0 & 7) | (0x0cu << 8) | ((unsigned)(o1 & 7) << 16) | (0x0cu << 24);
+                    G.coef[k] = (unsigned)e.y;
+                }
+                const int sxa = c->xtab[g.xtab_off + (x4 / tw) * tw].x & ~3;
+                if (((G.sx0 - sxa) >> 2) + 2 >= orbhip_pyramid_tile_dwords()) grouped = false;
+                c->xgrp.push_back(G);
+            }
+            if (grouped) c->pyr_staged[l] = 2;
         }
         for (int y0 = 0; y0 < g.h; y0 += 32) for (int x0 = 0; x0 < g.w; x0 += 128) { TileDesc t; t.level = (short)l; t.x0 = (short)x0; t.y0 = (short)y0; t.pad = 0; c->blur_tiles.push_back(t); }
     }
@@ -411,7 +429,7 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
     hipError_t e = hipSuccess;
 #define TRY(x) do { if (e == hipSuccess) e = (x); } while (0)
     TRY(upload(&c->d_geom, c->geom)); TRY(upload(&c->d_cells, c->cells)); TRY(upload(&c->d_tiles, c->blur_tiles));
-    TRY(upload(&c->d_xtab, c->xtab)); TRY(upload(&c->d_ytab, c->ytab)); TRY(upload(&c->d_pattern, pat));
+    TRY(upload(&c->d_xtab, c->xtab)); TRY(upload(&c->d_ytab, c->ytab)); TRY(upload(&c->d_xgrp, c->xgrp)); TRY(upload(&c->d_pattern, pat));
     {   // k_fast_cells stages a cell's sub-image by LDS-DMA: pass k, lane l fills patch dword 64k + l = (row, column) in the PS-strided LDS layout
         const int psd = fc_pstride(c) / 4, nd = psd * std::max(c->fc_maxph, 1);
         c->fc_np = (nd + 63) / 64;
@@ -484,7 +502,7 @@ static ExtractParams make_params(orbhip_ctx* c, const uint8_t* d_img0, long long
     P.lvl_kp = c->d_lvl_kp; P.lvl_kp_per_frame = c->lvl_kp_per_frame; P.lvl_n = c->d_lvl_n[c->cur];
     P.out_kp = c->d_out_kp[c->cur]; P.out_desc = c->d_out_desc[c->cur]; P.out_n = c->d_out_n[c->cur]; P.out_cap = c->out_cap;
     P.blur_tiles = c->d_tiles; P.nblur_tiles = (int)c->blur_tiles.size();
-    P.xtab = c->d_xtab; P.ytab = c->d_ytab; P.patternf = c->d_pattern;
+    P.xtab = c->d_xtab; P.ytab = c->d_ytab; P.xgrp = c->d_xgrp; P.patternf = c->d_pattern;
     P.iniTh = c->cfg.ini_th_fast; P.minTh = c->cfg.min_th_fast; P.blur_round_mode = c->cfg.blur_round_mode; P.fp_contract = c->fp_contract;
     P.qt_maxn = c->qt_maxn; P.qt_maxcells = c->qt_maxcells; P.qt_scr = orbhip_quadtree_scr(c->qt_maxn, c->qt_maxcells);
     P.fc_pstride = fc_pstride(c); P.fc_prows = c->fc_maxph; P.fc_np = c->fc_np; P.fc_pbytes = 256 * c->fc_np; P.fc_dma = c->d_fc_dma; P.fc_sstride = 8 + 4 * ((std::max(c->fc_maxpw - 6, 0) + 3) / 4); P.fc_srows = std::max(c->fc_maxph - 6, 0) + 2;
@@ -499,7 +517,7 @@ static orbhip_status pipeline_frames(orbhip_ctx* c, ExtractParams& P, int f0, in
 {
     if (nf <= 0) return ORBHIP_OK;
     P.frame0 = f0;
-    { ProfScope ps(c, K_PYRAMID, s); for (int l = 1; l < c->L; l++) orbhip_launch_pyramid_level(P, l, c->geom[l].w, c->geom[l].h, c->pyr_staged[l] != 0, nf, s); }
+    { ProfScope ps(c, K_PYRAMID, s); for (int l = 1; l < c->L; l++) orbhip_launch_pyramid_level(P, l, c->geom[l].w, c->geom[l].h, (int)c->pyr_staged[l], nf, s); }
     if (own_blur_stream) {
         { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nf, s); }
         hipStream_t bs = c->serial ? s : c->bstream;

@@ -37,6 +37,7 @@ struct LevelGeom {
     int nIni; float hX;                         // quadtree roots (ORBextractor.cc:543-545)
     float scale, kp_size, inv_scale;            // mvScaleFactor[l], (float)(int)(31*scale), mvInvScaleFactor[l]
     int xtab_off, ytab_off;                     // resize coefficient tables (levels >= 1): {src index, a0 | a1<<16}
+    int xgrp_off;                               // PyrGroup table (one entry per 4 output columns)
     int src_w, src_h;                           // size of level l-1
 };
 
@@ -48,6 +49,10 @@ struct CellDesc {           // one FAST cell (ORBextractor.cc:789-816)
     int cand_cap;
     int inv_ng;                     // ceil(2^16 / ng), ng = 4-pixel groups per interior row: k_fast_cells divides lane ids by ng with it
 };
+
+// four output pixels of cv::resize (k_pyramid_level_g): first source column, v_perm selectors that pick each pixel's two taps out of the
+// eight source bytes from sx0 on (second tap already clamped at the right border), coefficient pairs a0 | a1 << 16
+struct alignas(16) PyrGroup { int sx0; unsigned sel[4]; unsigned coef[4]; int pad[3]; };
 
 struct TileDesc { short level, x0, y0, pad; };
 
@@ -62,7 +67,7 @@ struct ExtractParams {
     unsigned* lvl_kp; int lvl_kp_per_frame; int* lvl_n;
     orbhip_keypoint* out_kp; uint8_t* out_desc; int* out_n; int out_cap;
     const TileDesc* blur_tiles; int nblur_tiles;
-    const int2* xtab; const int2* ytab;
+    const int2* xtab; const int2* ytab; const PyrGroup* xgrp;
     const float* patternf;                                                 // 256 x (x0,y0,x1,y1) as floats (rBRIEF pattern, ORBextractor.cc:150-408)
     int iniTh, minTh, blur_round_mode, fp_contract;
     int qt_maxn;                                                           // LDS node capacity of the quadtree kernel
@@ -127,7 +132,8 @@ void orbhip_launch_best_in_window(const BestParams& B, hipStream_t s);
 size_t orbhip_proj_select_lds(int n);
 
 // kernel launchers (orbhip_kernels_extract.hip / orbhip_kernels_match.hip)
-void orbhip_launch_pyramid_level(const ExtractParams& P, int level, int w, int h, bool staged, int nframes, hipStream_t s);
+void orbhip_launch_pyramid_level(const ExtractParams& P, int level, int w, int h, int mode, int nframes, hipStream_t s);
+int orbhip_pyramid_tile_dwords();
 bool orbhip_pyramid_tile_fits(int src_cols_per_tile, int src_rows_per_tile);
 void orbhip_launch_to_gray(const uint8_t* src, long long src_frame_stride, int src_row_stride, uint8_t* dst, long long dst_frame_stride,
                            int dst_pitch, int w, int h, int channels, bool rgb_order, int nframes, hipStream_t s);

@@ -28,6 +28,8 @@ __device__ __forceinline__ bool xcd_frame_map(int nb, int nframes, int& tile, in
 }
 static inline unsigned xcd_grid(int nb, int nframes) { return (unsigned)nb * 8u * (unsigned)((nframes + 7) / 8); }
 
+typedef unsigned short pku16 __attribute__((vector_size(4)));      // two u16 lanes in one VGPR -> v_pk_min_u16 / v_pk_max_u16, v_dot2_u32_u16
+typedef short pki16 __attribute__((vector_size(4)));
 typedef unsigned u32_unaligned __attribute__((aligned(1)));     // a 32-bit global load at any byte address
 // a pointer every lane of the wave agrees on, moved to SGPRs so that loads use the scalar-base + 32-bit lane offset form
 template <typename T> __device__ __forceinline__ T* uniform_ptr(T* p)
@@ -83,30 +85,16 @@ __device__ __forceinline__ void pyr_rows(const LevelGeom& g, const int2* xt, con
 #define PYR_TH (4 * PYR_RPT)
 #define PYR_SROWS 24
 #define PYR_SDW 84                      // dwords per staged source row (>= (256*1.25+2+3)/4)
-__global__ __launch_bounds__(256) void k_pyramid_level(ExtractParams P, int level)
+// wave w stages source rows w, w+4, ...: row address on the scalar unit, lane = dword (two chunks of 64), all loads in flight
+// before the first LDS write; byte path only for the ragged row end / unaligned sources
+__device__ __forceinline__ void pyr_stage(const uint8_t* src, int spitch, int src_w, int sxa, int sya, int ndw, int nrows, bool aligned, int tid, unsigned* s_t)
 {
-    const LevelGeom g = P.geom[level];
-    const int gx = (g.w + PYR_TW - 1) / PYR_TW, gy = (g.h + PYR_TH - 1) / PYR_TH;
-    int tile, frame;
-    if (!xcd_frame_map(gx * gy, P.nframes, tile, frame)) return;
-    frame += P.frame0;
-    const int tid = threadIdx.y * 64 + threadIdx.x;
-    const int x0 = (tile % gx) * PYR_TW, y0 = (tile / gx) * PYR_TH;
-    int spitch; const uint8_t* src = level_src(P, frame, level - 1, spitch);
-    __shared__ unsigned s_t[PYR_SROWS * PYR_SDW];
-    const int2* xt = P.xtab + g.xtab_off; const int2* yt = P.ytab + g.ytab_off;
-    const int xl = min(x0 + PYR_TW - 1, g.w - 1), yl = min(y0 + PYR_TH - 1, g.h - 1);
-    const int sxa = xt[x0].x & ~3, sxb = min(xt[xl].x + 1, g.src_w - 1);                    // staged source columns [sxa, sxb]
-    const int sya = min(max(yt[y0].x, 0), g.src_h - 1), syb = min(max(yt[yl].x + 1, 0), g.src_h - 1);
-    const int ndw = ((sxb - sxa) >> 2) + 1, nrows = syb - sya + 1;
-    const bool aligned = ((((unsigned long long)src) | (unsigned long long)spitch) & 3ull) == 0;
-    {   // wave w stages source rows w, w+4, ...: row address on the scalar unit, lane = dword (two chunks of 64), all loads
-        // in flight before the first LDS write; byte path only for the ragged row end / unaligned sources
+    {
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
         unsigned v[PYR_SROWS / 4][2];
         bool edge[2];
 #pragma unroll
-        for (int c = 0; c < 2; c++) { const int d = lane + 64 * c; edge[c] = d < ndw && !(aligned && sxa + 4 * d + 3 < g.src_w); }
+        for (int c = 0; c < 2; c++) { const int d = lane + 64 * c; edge[c] = d < ndw && !(aligned && sxa + 4 * d + 3 < src_w); }
 #pragma unroll
         for (int j = 0; j < PYR_SROWS / 4; j++) {
             const uint8_t* row = src + (long long)(sya + min(wave + 4 * j, nrows - 1)) * spitch + sxa;     // wave-uniform -> SGPR base
@@ -124,7 +112,7 @@ __global__ __launch_bounds__(256) void k_pyramid_level(ExtractParams P, int leve
                 for (int j = 0; j < PYR_SROWS / 4; j++) {
                     const uint8_t* row = src + (long long)(sya + min(wave + 4 * j, nrows - 1)) * spitch + sxa + 4 * d;
                     unsigned w = 0;
-                    for (int q = 0; q < 4; q++) if (sxa + 4 * d + q < g.src_w) w |= (unsigned)row[q] << (8 * q);
+                    for (int q = 0; q < 4; q++) if (sxa + 4 * d + q < src_w) w |= (unsigned)row[q] << (8 * q);
                     v[j][c] = w;
                 }
             }
@@ -135,11 +123,94 @@ __global__ __launch_bounds__(256) void k_pyramid_level(ExtractParams P, int leve
             for (int c = 0; c < 2; c++) { const int d = lane + 64 * c; if (r < nrows && d < ndw) s_t[r * PYR_SDW + d] = v[j][c]; }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_pyramid_level(ExtractParams P, int level)
+{
+    const LevelGeom g = P.geom[level];
+    const int gx = (g.w + PYR_TW - 1) / PYR_TW, gy = (g.h + PYR_TH - 1) / PYR_TH;
+    int tile, frame;
+    if (!xcd_frame_map(gx * gy, P.nframes, tile, frame)) return;
+    frame += P.frame0;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const int x0 = (tile % gx) * PYR_TW, y0 = (tile / gx) * PYR_TH;
+    int spitch; const uint8_t* src = level_src(P, frame, level - 1, spitch);
+    __shared__ unsigned s_t[PYR_SROWS * PYR_SDW];
+    const int2* xt = P.xtab + g.xtab_off; const int2* yt = P.ytab + g.ytab_off;
+    const int xl = min(x0 + PYR_TW - 1, g.w - 1), yl = min(y0 + PYR_TH - 1, g.h - 1);
+    const int sxa = xt[x0].x & ~3, sxb = min(xt[xl].x + 1, g.src_w - 1);                    // staged source columns [sxa, sxb]
+    const int sya = min(max(yt[y0].x, 0), g.src_h - 1), syb = min(max(yt[yl].x + 1, 0), g.src_h - 1);
+    const int ndw = ((sxb - sxa) >> 2) + 1, nrows = syb - sya + 1;
+    const bool aligned = ((((unsigned long long)src) | (unsigned long long)spitch) & 3ull) == 0;
+    pyr_stage(src, spitch, g.src_w, sxa, sya, ndw, nrows, aligned, tid, s_t);
     __syncthreads();
     const int x4 = x0 + threadIdx.x * 4;
     if (x4 >= g.w) return;
     uint8_t* dstp = P.pyr + (long long)frame * P.plane_frame_bytes + g.plane_off + x4;
     pyr_rows(g, xt, yt, reinterpret_cast<const uint8_t*>(s_t) - sxa, PYR_SDW * 4, sya, x4, y0 + threadIdx.y * PYR_RPT, dstp);
+}
+
+// The same tile, four pixels at a time from dword reads (levels whose 4-pixel groups span <= 8 source bytes, i.e. every scale
+// factor below ~1.6; the host decides and fills the PyrGroup table).  Per staged source row a thread reads the three dwords
+// around its first source pixel, funnel-shifts them so that byte 0 is that pixel (2 v_alignbyte), picks each output pixel's two
+// taps as u16 lanes (v_perm, selector from the table: the right-border clamp of the second tap is already in it) and multiplies
+// them with the packed coefficient pair in one v_dot2_u32_u16: 18 VALU per row of four horizontal results against 4 LDS byte
+// reads + 2 multiply-adds per result before.  A source row shared with the previous output row is not recomputed (wave-uniform
+// test: all lanes of a wave work on the same output rows).
+__device__ __forceinline__ void pyr_hrow(const unsigned* rowp, unsigned sh, const PyrGroup& G, unsigned (&hs)[4])
+{
+    const unsigned w0 = rowp[0], w1 = rowp[1], w2 = rowp[2];
+    const unsigned v0 = __builtin_amdgcn_alignbyte(w1, w0, sh), v1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        hs[k] = __builtin_amdgcn_udot2((pku16)__builtin_amdgcn_perm(v1, v0, G.sel[k]), (pku16)G.coef[k], 0u, false) >> 4;
+}
+__global__ __launch_bounds__(256) void k_pyramid_level_g(ExtractParams P, int level)
+{
+    const LevelGeom g = P.geom[level];
+    const int gx = (g.w + PYR_TW - 1) / PYR_TW, gy = (g.h + PYR_TH - 1) / PYR_TH;
+    int tile, frame;
+    if (!xcd_frame_map(gx * gy, P.nframes, tile, frame)) return;
+    frame += P.frame0;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const int x0 = (tile % gx) * PYR_TW, y0 = (tile / gx) * PYR_TH;
+    int spitch; const uint8_t* src = level_src(P, frame, level - 1, spitch);
+    __shared__ unsigned s_t[PYR_SROWS * PYR_SDW];
+    const int2* xt = P.xtab + g.xtab_off; const int2* yt = P.ytab + g.ytab_off;
+    const int xl = min(x0 + PYR_TW - 1, g.w - 1), yl = min(y0 + PYR_TH - 1, g.h - 1);
+    const int sxa = xt[x0].x & ~3, sxb = min(xt[xl].x + 1, g.src_w - 1);                    // staged source columns [sxa, sxb]
+    const int sya = min(max(yt[y0].x, 0), g.src_h - 1), syb = min(max(yt[yl].x + 1, 0), g.src_h - 1);
+    const int ndw = ((sxb - sxa) >> 2) + 1, nrows = syb - sya + 1;
+    const bool aligned = ((((unsigned long long)src) | (unsigned long long)spitch) & 3ull) == 0;
+    pyr_stage(src, spitch, g.src_w, sxa, sya, ndw, nrows, aligned, tid, s_t);
+    __syncthreads();
+    const int x4 = x0 + threadIdx.x * 4;
+    if (x4 >= g.w) return;
+    const PyrGroup G = P.xgrp[g.xgrp_off + (x4 >> 2)];
+    const unsigned sh = (unsigned)G.sx0 & 3u;                      // sxa is a multiple of 4
+    const unsigned* colp = s_t + ((G.sx0 - sxa) >> 2);
+    const unsigned omask = x4 + 4 <= g.w ? 0xffffffffu : (0xffffffffu >> (8 * (x4 + 4 - g.w)));
+    uint8_t* dstp = P.pyr + (long long)frame * P.plane_frame_bytes + g.plane_off + x4;
+    const int ytop = y0 + __builtin_amdgcn_readfirstlane((int)threadIdx.y) * PYR_RPT;
+    unsigned hp[4] = {0, 0, 0, 0}; int prow = -1;                  // horizontal results of staged row prow
+#pragma unroll
+    for (int rr = 0; rr < PYR_RPT; rr++) {
+        const int y = ytop + rr;
+        if (y >= g.h) break;
+        const int2 ye = yt[y];
+        const unsigned b0s = (unsigned)ye.y << 16, b1s = (unsigned)ye.y & 0xffff0000u;    // coefficients << 16: (b * t) >> 16 == mul_hi(b << 16, t)
+        const int ra = min(max(ye.x, 0), g.src_h - 1) - sya, rb = min(max(ye.x + 1, 0), g.src_h - 1) - sya;
+        unsigned h0[4], h1[4];
+        if (ra == prow) { h0[0] = hp[0]; h0[1] = hp[1]; h0[2] = hp[2]; h0[3] = hp[3]; }
+        else pyr_hrow(colp + ra * PYR_SDW, sh, G, h0);
+        if (rb == ra) { h1[0] = h0[0]; h1[1] = h0[1]; h1[2] = h0[2]; h1[3] = h0[3]; }
+        else pyr_hrow(colp + rb * PYR_SDW, sh, G, h1);
+        unsigned out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) out |= ((__umulhi(b0s, h0[k]) + __umulhi(b1s, h1[k]) + 2u) >> 2) << (8 * k);
+        *reinterpret_cast<unsigned*>(dstp + (long long)y * g.pitch) = out & omask;
+        hp[0] = h1[0]; hp[1] = h1[1]; hp[2] = h1[2]; hp[3] = h1[3]; prow = rb;
+    }
 }
 
 // Same arithmetic straight from global memory: used for scale factors whose source footprint does not fit the LDS tile
@@ -158,14 +229,16 @@ __global__ __launch_bounds__(256) void k_pyramid_level_direct(ExtractParams P, i
 }
 
 bool orbhip_pyramid_tile_fits(int src_cols_per_tile, int src_rows_per_tile) { return ((src_cols_per_tile + 3) >> 2) + 1 <= PYR_SDW && src_rows_per_tile <= PYR_SROWS; }
+int orbhip_pyramid_tile_dwords() { return PYR_SDW; }
 int orbhip_pyramid_tile_w() { return PYR_TW; }
 int orbhip_pyramid_tile_h() { return PYR_TH; }
 
-void orbhip_launch_pyramid_level(const ExtractParams& P, int level, int w, int h, bool staged, int nframes, hipStream_t s)
-{
+void orbhip_launch_pyramid_level(const ExtractParams& P, int level, int w, int h, int mode, int nframes, hipStream_t s)
+{   // mode 2: staged + 4-pixel groups, 1: staged, 0: straight from global memory
     ExtractParams Q = P; Q.nframes = nframes;
     dim3 grid(xcd_grid(((w + PYR_TW - 1) / PYR_TW) * ((h + PYR_TH - 1) / PYR_TH), nframes), 1, 1), block(64, 4, 1);
-    if (staged) hipLaunchKernelGGL(k_pyramid_level, grid, block, 0, s, Q, level);
+    if (mode == 2) hipLaunchKernelGGL(k_pyramid_level_g, grid, block, 0, s, Q, level);
+    else if (mode == 1) hipLaunchKernelGGL(k_pyramid_level, grid, block, 0, s, Q, level);
     else hipLaunchKernelGGL(k_pyramid_level_direct, grid, block, 0, s, Q, level);
 }
 
@@ -348,8 +421,6 @@ void orbhip_launch_blur(const ExtractParams& P, const int gk[4], int nframes, hi
 //   2. only if that found nothing: the exact score of every examined pixel at minThFAST, corners compacted in row-major order, NMS, emission.
 #define FC_WAVES 4
 
-typedef unsigned short pku16 __attribute__((vector_size(4)));      // two u16 lanes in one VGPR -> v_pk_min_u16 / v_pk_max_u16
-typedef short pki16 __attribute__((vector_size(4)));
 __device__ __forceinline__ pku16 pmin(pku16 a, pku16 b) { return a < b ? a : b; }
 __device__ __forceinline__ pku16 pmax(pku16 a, pku16 b) { return a > b ? a : b; }
 

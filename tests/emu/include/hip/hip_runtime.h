@@ -179,6 +179,8 @@ inline unsigned __builtin_amdgcn_udot4(unsigned a, unsigned b, unsigned c, bool 
     for (int i = 0; i < 4; i++) c += ((a >> (8 * i)) & 0xff) * ((b >> (8 * i)) & 0xff);
     return c;
 }
+// v_dot2_u32_u16: two u16 products + c
+template <typename V> inline unsigned __builtin_amdgcn_udot2(V a, V b, unsigned c, bool /*clamp*/) { return (unsigned)a[0] * (unsigned)b[0] + (unsigned)a[1] * (unsigned)b[1] + c; }
 // v_cvt_pk_u8_f32: round to nearest even, saturate to [0, 255], insert into byte `pos` of `old` (measured on MI355X:
 // 0.5 -> 0, 1.5 -> 2, 2.5 -> 2, 255.7 -> 255, 300 -> 255, -1 -> 0; tools/ubench.hip probe)
 inline unsigned __builtin_amdgcn_cvt_pk_u8_f32(float v, unsigned pos, unsigned old) {
