@@ -79,6 +79,9 @@ struct orbhip_ctx {
     int cur = 0; int last_nimg = 0; bool last_matched = false; bool last_from_host = false;
     // host-buffer API staging: one contiguous device input buffer + pinned host mirrors (single bulk copies instead of per-frame pageable copies)
     bool serial = false;      // ORBHIP_SERIAL=1 (measurement only): every kernel on the main stream, no overlap
+    int sched = 0;            // ORBHIP_SCHED (measurement only): where the blur runs, see pipeline_frames
+    int blur_tiles_l0 = 0;    // blur tiles of level 0 (the tile list is level-major)
+    hipEvent_t ev_start = nullptr;
     uint8_t* d_in = nullptr; uint8_t* h_in = nullptr; uint8_t* d_col = nullptr; uint8_t* h_col = nullptr; size_t col_bytes = 0; orbhip_keypoint* h_kp = nullptr; uint8_t* h_desc = nullptr; int* h_n = nullptr; int in_pitch = 0;
     // stereo (Frame::ComputeStereoMatches): level-0 source of the last call + lazily allocated workspace on the LEFT context
     const uint8_t* last_img0 = nullptr; long long last_img0_fstride = 0; int last_img0_pitch = 0;
@@ -259,6 +262,7 @@ extern "C" void orbhip_destroy(orbhip_ctx* c)
     for (auto xs : c->xstreams) { (void)hipStreamSynchronize(xs); (void)hipStreamDestroy(xs); }
     for (auto e : c->xevents) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     prof_collect(c);
     for (auto e : c->pool) (void)hipEventDestroy(e);
     void* ptrs[] = {c->d_xgrp, c->d_fc_dma, c->d_geom, c->d_cells, c->d_tiles, c->d_xtab, c->d_ytab, c->d_pattern, c->d_pyr, c->d_blur, c->d_cell_count, c->d_cell_cand,
@@ -417,6 +421,9 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
     }
     if (!c->xstreams.empty() && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { orbhip_destroy(c); return fail(ORBHIP_ERR_HIP, "event creation failed"); }
     { const char* e = getenv("ORBHIP_SERIAL"); c->serial = e && e[0] == '1'; }
+    { const char* e = getenv("ORBHIP_SCHED"); c->sched = e ? atoi(e) : 0; }
+    for (const TileDesc& t : c->blur_tiles) if (t.level == 0) c->blur_tiles_l0++;
+    if (hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming) != hipSuccess) { orbhip_destroy(c); return fail(ORBHIP_ERR_HIP, "event creation failed"); }
     {   // the matcher runs on its own stream so that it overlaps the next batch's extraction
         bool ok = hipStreamCreateWithFlags(&c->mstream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&c->ev_extract, hipEventDisableTiming) == hipSuccess &&
                   hipStreamCreateWithFlags(&c->bstream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&c->ev_pyr, hipEventDisableTiming) == hipSuccess &&
@@ -517,20 +524,34 @@ static orbhip_status pipeline_frames(orbhip_ctx* c, ExtractParams& P, int f0, in
 {
     if (nf <= 0) return ORBHIP_OK;
     P.frame0 = f0;
-    { ProfScope ps(c, K_PYRAMID, s); for (int l = 1; l < c->L; l++) orbhip_launch_pyramid_level(P, l, c->geom[l].w, c->geom[l].h, (int)c->pyr_staged[l], nf, s); }
-    if (own_blur_stream) {
-        { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nf, s); }
-        hipStream_t bs = c->serial ? s : c->bstream;
+    if (own_blur_stream && !c->serial && c->sched == 1) {
+        // blur beside the pyramid and FAST instead of beside the quadtree: level 0 needs nothing, the other levels the pyramid
+        hipStream_t bs = c->bstream;
+        HIPCHK(hipEventRecord(c->ev_start, s)); HIPCHK(hipStreamWaitEvent(bs, c->ev_start, 0));
+        { ProfScope ps(c, K_BLUR, bs); orbhip_launch_blur(P, c->gk, nf, bs, 0, c->blur_tiles_l0); }
+        { ProfScope ps(c, K_PYRAMID, s); for (int l = 1; l < c->L; l++) orbhip_launch_pyramid_level(P, l, c->geom[l].w, c->geom[l].h, (int)c->pyr_staged[l], nf, s); }
         HIPCHK(hipEventRecord(c->ev_pyr, s)); HIPCHK(hipStreamWaitEvent(bs, c->ev_pyr, 0));
-        { ProfScope ps(c, K_QUADTREE, s); orbhip_launch_quadtree(P, nf, s); }       // enqueued first: its few, long workgroups get CUs before the blur floods them
-        { ProfScope ps(c, K_BLUR, bs); orbhip_launch_blur(P, c->gk, nf, bs); }
+        { ProfScope ps(c, K_BLUR, bs); orbhip_launch_blur(P, c->gk, nf, bs, c->blur_tiles_l0, (int)c->blur_tiles.size() - c->blur_tiles_l0); }
         HIPCHK(hipEventRecord(c->ev_blur, bs));
+        { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nf, s); }
+        { ProfScope ps(c, K_QUADTREE, s); orbhip_launch_quadtree(P, nf, s); }
         HIPCHK(hipStreamWaitEvent(s, c->ev_blur, 0));
     } else {
-        { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nf, s); }
-        { ProfScope ps(c, K_BLUR, s); orbhip_launch_blur(P, c->gk, nf, s); }
-        { ProfScope ps(c, K_QUADTREE, s); orbhip_launch_quadtree(P, nf, s); }
-    }
+    { ProfScope ps(c, K_PYRAMID, s); for (int l = 1; l < c->L; l++) orbhip_launch_pyramid_level(P, l, c->geom[l].w, c->geom[l].h, (int)c->pyr_staged[l], nf, s); }
+        if (own_blur_stream) {
+            { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nf, s); }
+            hipStream_t bs = c->serial ? s : c->bstream;
+            HIPCHK(hipEventRecord(c->ev_pyr, s)); HIPCHK(hipStreamWaitEvent(bs, c->ev_pyr, 0));
+            { ProfScope ps(c, K_QUADTREE, s); orbhip_launch_quadtree(P, nf, s); }       // enqueued first: its few, long workgroups get CUs before the blur floods them
+            { ProfScope ps(c, K_BLUR, bs); orbhip_launch_blur(P, c->gk, nf, bs); }
+            HIPCHK(hipEventRecord(c->ev_blur, bs));
+            HIPCHK(hipStreamWaitEvent(s, c->ev_blur, 0));
+        } else {
+            { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nf, s); }
+            { ProfScope ps(c, K_BLUR, s); orbhip_launch_blur(P, c->gk, nf, s); }
+            { ProfScope ps(c, K_QUADTREE, s); orbhip_launch_quadtree(P, nf, s); }
+        }
+}
     { ProfScope ps(c, K_DESCRIBE, s); orbhip_launch_describe(P, nf, s); }
     if (c->distorted) {   // Frame::UndistortKeyPoints (Frame.cc:404-434) behind the descriptor kernel: mvKeysUn stays in HBM beside mvKeys
         ProfScope ps(c, K_UNDISTORT, s);

@@ -400,13 +400,15 @@ __global__ __launch_bounds__(256) void k_blur(ExtractParams P, BlurK K)
     if (half_even) strip(std::true_type{}); else strip(std::false_type{});
 }
 
-void orbhip_launch_blur(const ExtractParams& P, const int gk[4], int nframes, hipStream_t s)
-{
+void orbhip_launch_blur(const ExtractParams& P, const int gk[4], int nframes, hipStream_t s, int tile0, int ntiles)
+{   // tiles [tile0, tile0 + ntiles) of the level-major tile list (ntiles < 0: all)
     BlurK K; K.k0 = (float)gk[0]; K.k1 = (float)gk[1]; K.k2 = (float)gk[2]; K.k3 = (float)gk[3];
     K.dot_lo = (unsigned)gk[3] | ((unsigned)gk[2] << 8) | ((unsigned)gk[1] << 16) | ((unsigned)gk[0] << 24);    // bytes x-3 .. x
     K.dot_hi = (unsigned)gk[1] | ((unsigned)gk[2] << 8) | ((unsigned)gk[3] << 16);                              // bytes x+1 .. x+3
     ExtractParams Q = P; Q.nframes = nframes;
-    hipLaunchKernelGGL(k_blur, dim3(xcd_grid(P.nblur_tiles, nframes), 1, 1), dim3(256, 1, 1), 0, s, Q, K);
+    if (ntiles >= 0) { Q.blur_tiles = P.blur_tiles + tile0; Q.nblur_tiles = ntiles; }
+    if (Q.nblur_tiles <= 0) return;
+    hipLaunchKernelGGL(k_blur, dim3(xcd_grid(Q.nblur_tiles, nframes), 1, 1), dim3(256, 1, 1), 0, s, Q, K);
 }
 
 // ------------------------------------------------------------------------------------------------ FAST per cell
@@ -733,34 +735,37 @@ __device__ __forceinline__ int qt_block_exscan(int* a, int n, int* scratch, int 
     return total;
 }
 
-#define QT_LDSKEYS 4096                 // candidates per (frame, level) whose keys stay in LDS (6 B each); more -> HBM workspace
+#define QT_KPT 16                       // candidates per thread whose keys stay in registers
+#define QT_REGKEYS (QT_KPT * QT_T)      // = 4096 candidates per (frame, level); more -> HBM workspace
 
 int orbhip_quadtree_scr(int maxn, int maxcells) { return (std::max(maxn, maxcells) + 63) / 64 + 2; }
 size_t orbhip_quadtree_lds_bytes(int maxn, int maxcells)
 {
     // ints: s_pref[maxcells+1] | s_slot[maxcells] | cnt[2][maxn] | cc[4*maxn] | a | b | sidx | split | best [maxn each] | scratch[scr] | misc[16]
-    // then key code u32 [QT_LDSKEYS] | map u16 [4*maxn] | key node u16 [QT_LDSKEYS] | depth u8 [2][maxn]
-    // KITTI shape: 51.9 KB -> three workgroups per CU (with 32-bit map / depth tables it was 59.9 KB -> two: 0.23 -> 0.18 ms)
+    // then map u16 [4*maxn] | depth u8 [2][maxn]
+    // KITTI shape: 27.3 KB -> five workgroups per CU.  Round 1 kept the per-candidate keys in LDS too (6 B x 4096 = 24 KB, 51.9 KB in all,
+    // three per CU): beside the blur or FAST its three workgroups took 156 of a CU's 160 KB and starved the throughput kernel it was
+    // supposed to run under; candidate k is only ever touched by thread k mod 256, so its path code and node now live in that thread's VGPRs.
     const size_t ints = (size_t)(2 * maxcells + 1) + (size_t)maxn * (2 + 4 + 5) + orbhip_quadtree_scr(maxn, maxcells) + 16;
-    return sizeof(int) * ints + (size_t)QT_LDSKEYS * 6 + (size_t)maxn * 4 * 2 + (((size_t)maxn * 2 + 3) & ~(size_t)3);
+    return sizeof(int) * ints + (size_t)maxn * 4 * 2 + (((size_t)maxn * 2 + 3) & ~(size_t)3);
 }
 
-// per-candidate state of the quadtree replay: path code, current node (list position), FAST score
-struct QtKeysLds {
-    unsigned* code; unsigned short* node; const unsigned* val;
-    __device__ __forceinline__ unsigned getCode(int k) const { return code[k]; }
-    __device__ __forceinline__ int getNode(int k) const { return node[k]; }
-    __device__ __forceinline__ int getScore(int k) const { return (int)(val[k] >> 24); }      // read once, at the very end
-    __device__ __forceinline__ void setNode(int k, int v) const { node[k] = (unsigned short)v; }
-    __device__ __forceinline__ void init(int k, unsigned c, int nd, int) const { code[k] = c; node[k] = (unsigned short)nd; }
+// per-candidate state of the quadtree replay: path code and current node (list position).  Candidate k belongs to thread k mod QT_T in
+// every loop, so up to QT_REGKEYS candidates keep both in registers (the loops are fully unrolled); beyond that they live in HBM.
+struct QtKeysReg {
+    unsigned code[QT_KPT]; int node[QT_KPT];
+    template <class F> __device__ __forceinline__ void each(int n, int tid, F f)
+    {
+#pragma unroll
+        for (int j = 0; j < QT_KPT; j++) { const int k = tid + j * QT_T; if (k < n) f(k, code[j], node[j]); }
+    }
 };
 struct QtKeysHbm {
-    unsigned* code; int* node; const unsigned* val;
-    __device__ __forceinline__ unsigned getCode(int k) const { return code[k]; }
-    __device__ __forceinline__ int getNode(int k) const { return node[k]; }
-    __device__ __forceinline__ int getScore(int k) const { return (int)(val[k] >> 24); }
-    __device__ __forceinline__ void setNode(int k, int v) const { node[k] = v; }
-    __device__ __forceinline__ void init(int k, unsigned c, int nd, int) const { code[k] = c; node[k] = nd; }
+    unsigned* code; int* node;
+    template <class F> __device__ __forceinline__ void each(int n, int tid, F f)
+    {
+        for (int k = tid; k < n; k += QT_T) f(k, code[k], node[k]);
+    }
 };
 
 struct QtLds {
@@ -769,7 +774,7 @@ struct QtLds {
 };
 
 template <class Keys>
-__device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeom& g, const QtLds& L, const Keys keys, unsigned* qval, int n,
+__device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeom& g, const QtLds& L, Keys& keys, unsigned* qval, int n,
                                           int frame, int level, int tid)
 {
     const int N = g.nfeat;
@@ -777,7 +782,7 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
     // ---- A. dense canonical candidate order: cells row-major, row-major inside a cell (ORBextractor.cc:789-829).
     //      One thread per candidate: its cell is found by bisection on the per-cell prefix sums.
     const unsigned* cand = P.cell_cand + (long long)frame * P.cand_slots_per_frame;
-    for (int idx = tid; idx < n; idx += QT_T) {
+    keys.each(n, tid, [&](int idx, unsigned& kcode, int& knode) {
         int lo = 0, hi = g.ncells - 1;
         while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (L.pref[mid] <= idx) lo = mid; else hi = mid - 1; }
         const unsigned v = cand[L.slot[lo] + (idx - L.pref[lo])];
@@ -795,8 +800,8 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
             if (right) ULx = mx; else URx = mx;
             if (bottom) ULy = my; else BRy = my;
         }
-        qval[idx] = v; keys.init(idx, code, root, (int)(v >> 24)); atomicAdd(&L.cntA[root], 1);
-    }
+        qval[idx] = v; kcode = code; knode = root; atomicAdd(&L.cntA[root], 1);
+    });
     __syncthreads();
     // ---- B. initial list: non-empty roots in order (:552-585)
     if (tid == 0) {
@@ -806,7 +811,7 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
     }
     __syncthreads();
     int m = L.misc[0];
-    for (int k = tid; k < n; k += QT_T) keys.setNode(k, L.map[keys.getNode(k)]);
+    keys.each(n, tid, [&](int, unsigned&, int& knode) { knode = L.map[knode]; });
     int* cnt = L.cntB; unsigned char* dep = L.depB; int* cnt2 = L.cntA; unsigned char* dep2 = L.depA;
     unsigned short* s_map = L.map;
     int *s_cc = L.cc, *s_a = L.a, *s_b = L.b, *s_sidx = L.sidx, *s_split = L.split, *s_best = L.best, *s_scratch = L.scratch, *s_misc = L.misc;
@@ -818,10 +823,10 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
         for (int i = tid; i < 4 * m; i += QT_T) s_cc[i] = 0;
         if (tid == 0) { s_misc[1] = 0; s_misc[2] = 0x7fffffff; s_misc[3] = 0; }
         __syncthreads();
-        for (int k = tid; k < n; k += QT_T) {
-            const int p = keys.getNode(k);
-            if (cnt[p] > 1) atomicAdd(&s_cc[4 * p + qt_digit(keys.getCode(k), dep[p])], 1);
-        }
+        keys.each(n, tid, [&](int, unsigned& kcode, int& knode) {
+            const int p = knode;
+            if (cnt[p] > 1) atomicAdd(&s_cc[4 * p + qt_digit(kcode, dep[p])], 1);
+        });
         __syncthreads();
         int Ctot, nsplit;
         if (!modeB) {
@@ -884,10 +889,10 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
         }
         __syncthreads();
         const int m2 = Ctot + (m - nsplit);
-        for (int k = tid; k < n; k += QT_T) {
-            const int p = keys.getNode(k);
-            keys.setNode(k, s_split[p] ? s_map[4 * p + qt_digit(keys.getCode(k), dep[p])] : s_map[4 * p]);
-        }
+        keys.each(n, tid, [&](int, unsigned& kcode, int& knode) {
+            const int p = knode;
+            knode = s_split[p] ? s_map[4 * p + qt_digit(kcode, dep[p])] : s_map[4 * p];
+        });
         int nexp = 0;
         for (int p = tid; p < m2; p += QT_T) nexp += cnt2[p] > 1;
         if (nexp) atomicAdd(&s_misc[3], nexp);
@@ -903,8 +908,9 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
     // ---- D. best response per leaf, first wins (:744-760); list order = output order
     for (int p = tid; p < m; p += QT_T) s_best[p] = 0;
     __syncthreads();
-    for (int k = tid; k < n; k += QT_T)
-        atomicMax((unsigned*)&s_best[keys.getNode(k)], ((unsigned)keys.getScore(k) << 24) | (0xFFFFFFu - (unsigned)k));
+    keys.each(n, tid, [&](int k, unsigned&, int& knode) {                  // the FAST score is read once, here
+        atomicMax((unsigned*)&s_best[knode], (qval[k] & 0xff000000u) | (0xFFFFFFu - (unsigned)k));
+    });
     __syncthreads();
     unsigned* outk = P.lvl_kp + (long long)frame * P.lvl_kp_per_frame + g.kp_off;
     const int mout = min(m, g.kp_cap);
@@ -937,10 +943,8 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(ExtractParams P)
     L.cntA = L.slot + P.qt_maxcells; L.cntB = L.cntA + maxn;
     L.cc = L.cntB + maxn; L.a = L.cc + 4 * maxn; L.b = L.a + maxn; L.sidx = L.b + maxn; L.split = L.sidx + maxn;
     L.best = L.split + maxn; L.scratch = L.best + maxn + 1; L.misc = L.scratch - 1 + P.qt_scr;      // scratch[-1] holds the scan total
-    unsigned* kcode = reinterpret_cast<unsigned*>(L.misc + 16);
-    L.map = reinterpret_cast<unsigned short*>(kcode + QT_LDSKEYS);
-    unsigned short* knode = L.map + 4 * maxn;
-    L.depA = reinterpret_cast<unsigned char*>(knode + QT_LDSKEYS); L.depB = L.depA + maxn;
+    L.map = reinterpret_cast<unsigned short*>(L.misc + 16);
+    L.depA = reinterpret_cast<unsigned char*>(L.map + 4 * maxn); L.depB = L.depA + maxn;
 
     const int* ccount = P.cell_count + (long long)frame * P.ncells_total + g.cell_first;
     for (int c = tid; c < g.ncells; c += QT_T) { L.pref[c] = ccount[c]; L.slot[c] = P.cells[g.cell_first + c].cand_idx; }
@@ -949,12 +953,14 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(ExtractParams P)
     int n = qt_block_exscan(L.pref, g.ncells, L.scratch, tid);
     n = min(n, g.cand_total_cap);
     unsigned* qval = P.qt_val + (long long)frame * P.qt_per_frame + g.cand_total_off;
-    if (n <= QT_LDSKEYS) {
-        QtKeysLds keys; keys.code = kcode; keys.node = knode; keys.val = qval;
+    if (n <= QT_REGKEYS) {
+        QtKeysReg keys;
+#pragma unroll
+        for (int j = 0; j < QT_KPT; j++) { keys.code[j] = 0; keys.node[j] = 0; }
         qt_replay(P, g, L, keys, qval, n, frame, level, tid);
     } else {
         QtKeysHbm keys; keys.code = P.qt_code + (long long)frame * P.qt_per_frame + g.cand_total_off;
-        keys.node = P.qt_node + (long long)frame * P.qt_per_frame + g.cand_total_off; keys.val = qval;
+        keys.node = P.qt_node + (long long)frame * P.qt_per_frame + g.cand_total_off;
         qt_replay(P, g, L, keys, qval, n, frame, level, tid);
     }
 }
