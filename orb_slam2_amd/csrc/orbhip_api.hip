@@ -43,7 +43,7 @@ enum { K_PYRAMID = 0, K_FAST, K_BLUR, K_QUADTREE, K_DESCRIBE, K_MGRID, K_MCAND, 
 static const char* kKernelNames[K_COUNT] = {"k_pyramid_level", "k_fast_cells", "k_blur", "k_quadtree", "k_describe",
                                             "k_match_grid", "k_match_candidates", "k_match_select", "k_undistort_keys", "k_remap"};
 
-struct ProfSpan { int k; hipEvent_t a, b; };
+struct ProfSpan { int k; hipEvent_t a, b; int counts; };
 
 // One batch of the pipelined host-buffer path (orbhip_submit / orbhip_collect, orbhip_extract_batch): its own pinned input mirror,
 // device input planes and pinned output mirrors, so that up to ORBHIP_RING batches are in flight; a batch is cut into chunks of
@@ -69,7 +69,7 @@ struct orbhip_ctx {
     int fc_maxpw = 0, fc_maxph = 0;
     long long plane_frame_bytes = 0, cand_slots_per_frame = 0, qt_per_frame = 0; int lvl_kp_per_frame = 0, out_cap = 0, qt_maxn = 0, qt_maxcells = 0, lvl0_cap = 0;
     // device
-    LevelGeom* d_geom = nullptr; CellDesc* d_cells = nullptr; TileDesc* d_tiles = nullptr; int2* d_xtab = nullptr; int2* d_ytab = nullptr; float* d_pattern = nullptr; int4* d_fc_dma = nullptr; int fc_np = 0; PyrGroup* d_xgrp = nullptr;
+    LevelGeom* d_geom = nullptr; CellDesc* d_cells = nullptr; TileDesc* d_tiles = nullptr; int2* d_xtab = nullptr; int2* d_ytab = nullptr; float* d_pattern = nullptr; int4* d_fc_dma = nullptr; int fc_np = 0; PyrGroup* d_xgrp = nullptr; unsigned* d_ic_mask = nullptr;
     uint8_t* d_pyr = nullptr; uint8_t* d_blur = nullptr; int* d_cell_count = nullptr; unsigned* d_cell_cand = nullptr;
     unsigned* d_qt_val = nullptr; unsigned* d_qt_code = nullptr; int* d_qt_node = nullptr; unsigned* d_lvl_kp = nullptr;
     // outputs are triple-buffered: batch t writes buffer t%3 while the matcher of batch t-1 (own stream) still reads buffers (t-1)%3 and (t-2)%3
@@ -79,7 +79,7 @@ struct orbhip_ctx {
     int cur = 0; int last_nimg = 0; bool last_matched = false; bool last_from_host = false;
     // host-buffer API staging: one contiguous device input buffer + pinned host mirrors (single bulk copies instead of per-frame pageable copies)
     bool serial = false;      // ORBHIP_SERIAL=1 (measurement only): every kernel on the main stream, no overlap
-    int sched = 0;            // ORBHIP_SCHED (measurement only): where the blur runs, see pipeline_frames
+    int sched = 1;            // ORBHIP_SCHED=0 (measurement only): the blur beside the quadtree instead of beside pyramid + FAST, see pipeline_frames
     int blur_tiles_l0 = 0;    // blur tiles of level 0 (the tile list is level-major)
     hipEvent_t ev_start = nullptr;
     uint8_t* d_in = nullptr; uint8_t* h_in = nullptr; uint8_t* d_col = nullptr; uint8_t* h_col = nullptr; size_t col_bytes = 0; orbhip_keypoint* h_kp = nullptr; uint8_t* h_desc = nullptr; int* h_n = nullptr; int in_pitch = 0;
@@ -107,17 +107,17 @@ static hipEvent_t prof_event(orbhip_ctx* c)
     if (!c->pool.empty()) { hipEvent_t e = c->pool.back(); c->pool.pop_back(); return e; }
     hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
 }
-struct ProfScope {
-    orbhip_ctx* c; int k; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(orbhip_ctx* c_, int k_, hipStream_t s_) : c(c_), k(k_), s(s_) { if (c->prof) { a = prof_event(c); b = prof_event(c); (void)hipEventRecord(a, s); } }
-    ~ProfScope() { if (c->prof) { (void)hipEventRecord(b, s); c->pending.push_back(ProfSpan{k, a, b}); } }
+struct ProfScope {       // counts = 0: a further part of a kernel that is launched in pieces (its time adds up, the launch count does not)
+    orbhip_ctx* c; int k; hipStream_t s; int counts; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(orbhip_ctx* c_, int k_, hipStream_t s_, int counts_ = 1) : c(c_), k(k_), s(s_), counts(counts_) { if (c->prof) { a = prof_event(c); b = prof_event(c); (void)hipEventRecord(a, s); } }
+    ~ProfScope() { if (c->prof) { (void)hipEventRecord(b, s); c->pending.push_back(ProfSpan{k, a, b, counts}); } }
 };
 static void prof_collect(orbhip_ctx* c)
 {
     for (auto& s : c->pending) {
         (void)hipEventSynchronize(s.b);
         float ms = 0; (void)hipEventElapsedTime(&ms, s.a, s.b);
-        c->tot_ms[s.k] += ms; c->launches[s.k]++;
+        c->tot_ms[s.k] += ms; c->launches[s.k] += s.counts;
         c->pool.push_back(s.a); c->pool.push_back(s.b);
     }
     c->pending.clear();
@@ -265,7 +265,7 @@ extern "C" void orbhip_destroy(orbhip_ctx* c)
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     prof_collect(c);
     for (auto e : c->pool) (void)hipEventDestroy(e);
-    void* ptrs[] = {c->d_xgrp, c->d_fc_dma, c->d_geom, c->d_cells, c->d_tiles, c->d_xtab, c->d_ytab, c->d_pattern, c->d_pyr, c->d_blur, c->d_cell_count, c->d_cell_cand,
+    void* ptrs[] = {c->d_ic_mask, c->d_xgrp, c->d_fc_dma, c->d_geom, c->d_cells, c->d_tiles, c->d_xtab, c->d_ytab, c->d_pattern, c->d_pyr, c->d_blur, c->d_cell_count, c->d_cell_cand,
                     c->d_qt_val, c->d_qt_code, c->d_qt_node, c->d_lvl_kp, c->d_lvl_n[0], c->d_lvl_n[1], c->d_lvl_n[2], c->d_out_kp[0], c->d_out_kp[1], c->d_out_kp[2],
                     c->d_out_desc[0], c->d_out_desc[1], c->d_out_desc[2], c->d_out_n[0], c->d_out_n[1], c->d_out_n[2], c->d_grid_start, c->d_grid_items, c->d_grid_xy, c->d_cand, c->d_top, c->d_ncand,
                     c->d_prev, c->d_m12, c->d_nm};
@@ -421,7 +421,7 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
     }
     if (!c->xstreams.empty() && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { orbhip_destroy(c); return fail(ORBHIP_ERR_HIP, "event creation failed"); }
     { const char* e = getenv("ORBHIP_SERIAL"); c->serial = e && e[0] == '1'; }
-    { const char* e = getenv("ORBHIP_SCHED"); c->sched = e ? atoi(e) : 0; }
+    { const char* e = getenv("ORBHIP_SCHED"); c->sched = e ? atoi(e) : 1; }
     for (const TileDesc& t : c->blur_tiles) if (t.level == 0) c->blur_tiles_l0++;
     if (hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming) != hipSuccess) { orbhip_destroy(c); return fail(ORBHIP_ERR_HIP, "event creation failed"); }
     {   // the matcher runs on its own stream so that it overlaps the next batch's extraction
@@ -437,6 +437,17 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
 #define TRY(x) do { if (e == hipSuccess) e = (x); } while (0)
     TRY(upload(&c->d_geom, c->geom)); TRY(upload(&c->d_cells, c->cells)); TRY(upload(&c->d_tiles, c->blur_tiles));
     TRY(upload(&c->d_xtab, c->xtab)); TRY(upload(&c->d_ytab, c->ytab)); TRY(upload(&c->d_xgrp, c->xgrp)); TRY(upload(&c->d_pattern, pat));
+    {   // circular patch of IC_Angle as byte masks over 32 rows x 8 dwords (byte b of dword d = column 4d + b - 15); umax as ORBextractor.cc:452-469 computes it
+        int umax[16]; const int vmax = (int)floor(15 * sqrt(2.0) / 2 + 1), vmin = (int)ceil(15 * sqrt(2.0) / 2);
+        for (int v = 0; v <= vmax; v++) umax[v] = cvRoundF((float)sqrt(225.0 - (double)v * v));
+        for (int v = 15, v0 = 0; v >= vmin; --v) { while (umax[v0] == umax[v0 + 1]) ++v0; umax[v] = v0; ++v0; }
+        std::vector<unsigned> mask(32 * 8, 0u);
+        for (int r = 0; r < 31; r++) for (int d = 0; d < 8; d++) for (int b = 0; b < 4; b++) {
+            const int v = r - 15, uu = 4 * d + b - 15;
+            if (abs(uu) <= 15 && abs(uu) <= umax[abs(v)]) mask[r * 8 + d] |= 0xffu << (8 * b);
+        }
+        TRY(upload(&c->d_ic_mask, mask));
+    }
     {   // k_fast_cells stages a cell's sub-image by LDS-DMA: pass k, lane l fills patch dword 64k + l = (row, column) in the PS-strided LDS layout
         const int psd = fc_pstride(c) / 4, nd = psd * std::max(c->fc_maxph, 1);
         c->fc_np = (nd + 63) / 64;
@@ -509,7 +520,7 @@ static ExtractParams make_params(orbhip_ctx* c, const uint8_t* d_img0, long long
     P.lvl_kp = c->d_lvl_kp; P.lvl_kp_per_frame = c->lvl_kp_per_frame; P.lvl_n = c->d_lvl_n[c->cur];
     P.out_kp = c->d_out_kp[c->cur]; P.out_desc = c->d_out_desc[c->cur]; P.out_n = c->d_out_n[c->cur]; P.out_cap = c->out_cap;
     P.blur_tiles = c->d_tiles; P.nblur_tiles = (int)c->blur_tiles.size();
-    P.xtab = c->d_xtab; P.ytab = c->d_ytab; P.xgrp = c->d_xgrp; P.patternf = c->d_pattern;
+    P.xtab = c->d_xtab; P.ytab = c->d_ytab; P.xgrp = c->d_xgrp; P.patternf = c->d_pattern; P.ic_mask = c->d_ic_mask;
     P.iniTh = c->cfg.ini_th_fast; P.minTh = c->cfg.min_th_fast; P.blur_round_mode = c->cfg.blur_round_mode; P.fp_contract = c->fp_contract;
     P.qt_maxn = c->qt_maxn; P.qt_maxcells = c->qt_maxcells; P.qt_scr = orbhip_quadtree_scr(c->qt_maxn, c->qt_maxcells);
     P.fc_pstride = fc_pstride(c); P.fc_prows = c->fc_maxph; P.fc_np = c->fc_np; P.fc_pbytes = 256 * c->fc_np; P.fc_dma = c->d_fc_dma; P.fc_sstride = 8 + 4 * ((std::max(c->fc_maxpw - 6, 0) + 3) / 4); P.fc_srows = std::max(c->fc_maxph - 6, 0) + 2;
@@ -517,41 +528,41 @@ static ExtractParams make_params(orbhip_ctx* c, const uint8_t* d_img0, long long
     return P;
 }
 
-// pyramid -> FAST -> (quadtree || blur) -> describe for camera slots [f0, f0 + nf) on stream s.  own_blur_stream: the blur only meets
-// the detector again in k_describe, so it runs on the context's blur stream beside the quadtree, whose workgroups are latency-bound
-// (barriers, one per (frame, level)) and leave the VALUs idle.
+// pyramid -> FAST -> quadtree -> describe for camera slots [f0, f0 + nf) on stream s, with the blur (which only meets the detector
+// again in k_describe) on the context's blur stream when own_blur_stream: level 0 at once, the other levels behind the pyramid, i.e.
+// beside the pyramid and FAST, joined before describe.  ORBHIP_SCHED=0 (measurement only) is round 1's placement, the whole blur beside
+// the quadtree: 1-2.5 % slower now that the quadtree's workgroups are short and small (gpurun s2 / st2).
 static orbhip_status pipeline_frames(orbhip_ctx* c, ExtractParams& P, int f0, int nf, hipStream_t s, bool own_blur_stream)
 {
     if (nf <= 0) return ORBHIP_OK;
     P.frame0 = f0;
-    if (own_blur_stream && !c->serial && c->sched == 1) {
-        // blur beside the pyramid and FAST instead of beside the quadtree: level 0 needs nothing, the other levels the pyramid
+    const int nt0 = c->blur_tiles_l0, nt1 = (int)c->blur_tiles.size() - nt0;
+    if (own_blur_stream && !c->serial && c->sched != 0) {
         hipStream_t bs = c->bstream;
         HIPCHK(hipEventRecord(c->ev_start, s)); HIPCHK(hipStreamWaitEvent(bs, c->ev_start, 0));
-        { ProfScope ps(c, K_BLUR, bs); orbhip_launch_blur(P, c->gk, nf, bs, 0, c->blur_tiles_l0); }
+        { ProfScope ps(c, K_BLUR, bs); orbhip_launch_blur(P, c->gk, nf, bs, 0, nt0); }
         { ProfScope ps(c, K_PYRAMID, s); for (int l = 1; l < c->L; l++) orbhip_launch_pyramid_level(P, l, c->geom[l].w, c->geom[l].h, (int)c->pyr_staged[l], nf, s); }
         HIPCHK(hipEventRecord(c->ev_pyr, s)); HIPCHK(hipStreamWaitEvent(bs, c->ev_pyr, 0));
-        { ProfScope ps(c, K_BLUR, bs); orbhip_launch_blur(P, c->gk, nf, bs, c->blur_tiles_l0, (int)c->blur_tiles.size() - c->blur_tiles_l0); }
+        { ProfScope ps(c, K_BLUR, bs, 0); orbhip_launch_blur(P, c->gk, nf, bs, nt0, nt1); }
         HIPCHK(hipEventRecord(c->ev_blur, bs));
         { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nf, s); }
         { ProfScope ps(c, K_QUADTREE, s); orbhip_launch_quadtree(P, nf, s); }
         HIPCHK(hipStreamWaitEvent(s, c->ev_blur, 0));
     } else {
-    { ProfScope ps(c, K_PYRAMID, s); for (int l = 1; l < c->L; l++) orbhip_launch_pyramid_level(P, l, c->geom[l].w, c->geom[l].h, (int)c->pyr_staged[l], nf, s); }
+        { ProfScope ps(c, K_PYRAMID, s); for (int l = 1; l < c->L; l++) orbhip_launch_pyramid_level(P, l, c->geom[l].w, c->geom[l].h, (int)c->pyr_staged[l], nf, s); }
+        { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nf, s); }
         if (own_blur_stream) {
-            { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nf, s); }
             hipStream_t bs = c->serial ? s : c->bstream;
             HIPCHK(hipEventRecord(c->ev_pyr, s)); HIPCHK(hipStreamWaitEvent(bs, c->ev_pyr, 0));
-            { ProfScope ps(c, K_QUADTREE, s); orbhip_launch_quadtree(P, nf, s); }       // enqueued first: its few, long workgroups get CUs before the blur floods them
+            { ProfScope ps(c, K_QUADTREE, s); orbhip_launch_quadtree(P, nf, s); }
             { ProfScope ps(c, K_BLUR, bs); orbhip_launch_blur(P, c->gk, nf, bs); }
             HIPCHK(hipEventRecord(c->ev_blur, bs));
             HIPCHK(hipStreamWaitEvent(s, c->ev_blur, 0));
         } else {
-            { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nf, s); }
             { ProfScope ps(c, K_BLUR, s); orbhip_launch_blur(P, c->gk, nf, s); }
             { ProfScope ps(c, K_QUADTREE, s); orbhip_launch_quadtree(P, nf, s); }
         }
-}
+    }
     { ProfScope ps(c, K_DESCRIBE, s); orbhip_launch_describe(P, nf, s); }
     if (c->distorted) {   // Frame::UndistortKeyPoints (Frame.cc:404-434) behind the descriptor kernel: mvKeysUn stays in HBM beside mvKeys
         ProfScope ps(c, K_UNDISTORT, s);

@@ -68,6 +68,7 @@ struct ExtractParams {
     orbhip_keypoint* out_kp; uint8_t* out_desc; int* out_n; int out_cap;
     const TileDesc* blur_tiles; int nblur_tiles;
     const int2* xtab; const int2* ytab; const PyrGroup* xgrp;
+    const unsigned* ic_mask;                                               // IC_Angle: [32 rows][8 dwords] byte masks of the circular patch (u, v in -15..15, |u| <= umax[|v|])
     const float* patternf;                                                 // 256 x (x0,y0,x1,y1) as floats (rBRIEF pattern, ORBextractor.cc:150-408)
     int iniTh, minTh, blur_round_mode, fp_contract;
     int qt_maxn;                                                           // LDS node capacity of the quadtree kernel

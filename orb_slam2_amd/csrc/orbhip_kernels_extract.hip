@@ -31,12 +31,15 @@ static inline unsigned xcd_grid(int nb, int nframes) { return (unsigned)nb * 8u 
 typedef unsigned short pku16 __attribute__((vector_size(4)));      // two u16 lanes in one VGPR -> v_pk_min_u16 / v_pk_max_u16, v_dot2_u32_u16
 typedef short pki16 __attribute__((vector_size(4)));
 typedef unsigned u32_unaligned __attribute__((aligned(1)));     // a 32-bit global load at any byte address
-// a pointer every lane of the wave agrees on, moved to SGPRs so that loads use the scalar-base + 32-bit lane offset form
-template <typename T> __device__ __forceinline__ T* uniform_ptr(T* p)
+// a pointer every lane of the wave agrees on, moved to SGPRs so that loads use the scalar-base + 32-bit lane offset form.  The result is
+// typed as a GLOBAL pointer: rebuilt from integers it would otherwise be a generic one, and every access through it a flat_load with a
+// 64-bit address per lane (k_describe paid 26 v_lshl_add_u64 per key point for that in round 1).
+#define ORBHIP_GLOBAL __attribute__((address_space(1)))
+template <typename T> __device__ __forceinline__ ORBHIP_GLOBAL T* uniform_ptr(T* p)
 {
     const unsigned long long a = (unsigned long long)p;
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
-    return (T*)(((unsigned long long)hi << 32) | lo);
+    return (ORBHIP_GLOBAL T*)(((unsigned long long)hi << 32) | lo);
 }
 __device__ __forceinline__ const uint8_t* level_src(const ExtractParams& P, int frame, int level, int& pitch)
 {
@@ -470,11 +473,13 @@ __host__ __device__ __forceinline__ int fc_wave_bytes(int pbytes, int sstride, i
 // (tools/lds_dma_probe.hip, measured on MI355X).  The loads count on vmcnt: lds_dma_wait() before the first LDS read.
 typedef const __attribute__((address_space(1))) void* orbhip_gptr;
 typedef __attribute__((address_space(3))) void* orbhip_lptr;
-__device__ __forceinline__ void lds_dma_dword(const uint8_t* gsrc, uint8_t* lds_block)
+__device__ __forceinline__ void lds_dma_dword(const ORBHIP_GLOBAL uint8_t* gsrc, uint8_t* lds_block)
 {
     __builtin_amdgcn_global_load_lds((orbhip_gptr)gsrc, (orbhip_lptr)lds_block, 4, 0, 0);
 }
-__device__ __forceinline__ void lds_dma_wait() { __builtin_amdgcn_s_waitcnt(0x0f70); }     // s_waitcnt vmcnt(0)
+// s_waitcnt vmcnt(n) only (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14)
+#define ORBHIP_VMCNT(n) (0x0f70 | ((n) & 15) | (((n) >> 4) << 14))
+__device__ __forceinline__ void lds_dma_wait() { __builtin_amdgcn_s_waitcnt(ORBHIP_VMCNT(0)); }
 
 // ring of the pixel pair (Q, Q+1) of a 4-pixel group whose 7 x 12-byte window is w[7][3] (circle: FAST 16-point Bresenham);
 // ring element k of pixel q sits at row 3+dy_k, byte 3+q+dx_k
@@ -547,7 +552,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
         // dword of a row may read up to 3 bytes past the patch: still inside the image row (cells end >= 13 px before the border).
         int spitch; const uint8_t* src = level_src(P, frame, cd.level, spitch);
         src += (long long)cd.iniY * spitch + cd.iniX;
-        const uint8_t* gp = uniform_ptr(src);
+        const ORBHIP_GLOBAL uint8_t* gp = uniform_ptr(src);
         const unsigned maxoff = (unsigned)((ph - 1) * spitch + 4 * (((pw + 3) >> 2) - 1));
         const int np = P.fc_np;
         for (int k0 = 0; k0 < np; k0 += 8) {
@@ -634,9 +639,9 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
                 const int id = list[qb + lane];
                 y = id >> 8; x0 = 2 * (id & 0xff);
                 // rows above / at / below, bytes x0-1 .. x0+2 (the pad dwords left and right of a row are zero)
-                const uint8_t* q0 = &score[(y + 1) * SS + 4 + x0 - 1];
-                const unsigned* qa = reinterpret_cast<const unsigned*>(reinterpret_cast<uintptr_t>(q0) & ~(uintptr_t)3);
-                const unsigned shb = (unsigned)(reinterpret_cast<uintptr_t>(q0) & 3);
+                const int qo = (y + 1) * SS + 4 + x0 - 1;                                // byte offset in the score map (its base is 16-byte aligned)
+                const unsigned* qa = reinterpret_cast<const unsigned*>(score) + (qo >> 2);      // index arithmetic, not pointer bits: the reads stay ds_read
+                const unsigned shb = (unsigned)qo & 3u;
                 const int sdw = SS >> 2;
                 const unsigned ra4 = __builtin_amdgcn_alignbyte(qa[1 - sdw], qa[-sdw], shb);
                 const unsigned rb4 = __builtin_amdgcn_alignbyte(qa[1], qa[0], shb);
@@ -1037,116 +1042,193 @@ __device__ __forceinline__ int wave_sum_dpp(int v)
 __device__ __forceinline__ int round_half_even_small(float x) { return __float_as_int(__fadd_rn(x, 12582912.0f)) - 0x4B400000; }
 
 #define DS_WAVES 4
+#define DS_KPW 4                       // key point slots per wavefront
 #define DS_WROWS 37                    // blurred window rows: pattern reach is +-18 after rotation
-#define DS_WDW 11                      // dwords per staged window row (37 bytes + up to 3 bytes of alignment slack)
+#define DS_WSTRIDE 40                  // bytes per staged window row (37 used; the window starts exactly at cx - 18)
+#define DS_WPASSES 6                   // LDS-DMA passes per window: 6 x 64 dwords >= 37 rows x 10 dwords
+#define DS_WDWORDS (DS_WPASSES * 64)
+// One wavefront per DS_KPW consecutive key point slots, in three phases, so that what is per-key-point scalar work in the reference is
+// done once per lane instead of once per wave:
+//   1. IC_Angle (ORBextractor.cc:77-104) of every slot: the 31 x 31 orientation patch as 31 rows x 8 unaligned dwords (4 loads per
+//      lane), circular mask from a table, sum I, sum (u+15) I and row sums by v_dot4_u32_u8, two DPP wave sums; m10 / m01 of slot j
+//      are kept by lane j;
+//   2. cv::fastAtan2 and the glibc sincosf for all slots at once, lane j = slot j;
+//   3. per slot: the 37 x 37 blurred window, brought to LDS by LDS-DMA issued at the very start (one buffer per slot), a and b back by
+//      v_readlane, 256 rotated BRIEF tests whose 4 ballots are the descriptor words.
+// The rBRIEF pattern, the mask and the DMA layout are loaded / computed once per wave.
 __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
 {
-    __shared__ unsigned s_win[DS_WAVES][DS_WROWS * DS_WDW];
+    __shared__ unsigned s_win[DS_WAVES][DS_KPW][DS_WDWORDS];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int tile, frame;
-    if (!xcd_frame_map((P.lvl_kp_per_frame + DS_WAVES - 1) / DS_WAVES, P.nframes, tile, frame)) return;
+    if (!xcd_frame_map((P.lvl_kp_per_frame + DS_WAVES * DS_KPW - 1) / (DS_WAVES * DS_KPW), P.nframes, tile, frame)) return;
     frame += P.frame0;
-    const int slot = tile * DS_WAVES + wave;
-    if (slot >= P.lvl_kp_per_frame) return;
-    // everything about "which keypoint" is the same for the 64 lanes: kept on the scalar unit (U() = v_readfirstlane)
+    const int slot0 = (tile * DS_WAVES + wave) * DS_KPW;
+    if (slot0 >= P.lvl_kp_per_frame) return;
 #define U(x) __builtin_amdgcn_readfirstlane(x)
-    int level = 0;
-    for (int l = 1; l < P.nlevels; l++) if (slot >= U(P.geom[l].kp_off)) level = l;
-    const LevelGeom g = P.geom[level];
-    const int i = slot - U(g.kp_off);
-    const int* ln = P.lvl_n + frame * P.nlevels;
-    if (slot == 0 && lane == 0) { int tot = 0; for (int l = 0; l < P.nlevels; l++) tot += ln[l]; P.out_n[frame] = min(tot, P.out_cap); }
-    if (i >= U(ln[level])) return;
-    int obase = 0;
-    for (int l = 0; l < level; l++) obase += U(ln[l]);
-    const int oi = obase + i;
-    if (oi >= P.out_cap) return;
-    const unsigned v = (unsigned)U((int)P.lvl_kp[(long long)frame * P.lvl_kp_per_frame + slot]);
-    const int cx = v & 0xfff, cy = (v >> 12) & 0xfff, sc = v >> 24;
+    // Everything the wave needs to know about its slots comes from ONE round of vector loads (lane l = level l, lane j = slot j) and is
+    // then passed around with v_readlane: a chain of dependent "load, wait, readfirstlane" steps costs a memory latency each.
+    const int lq = min(lane, P.nlevels - 1);
+    const int g_kpoff = P.geom[lq].kp_off, g_pitch = P.geom[lq].pitch, g_poff = P.geom[lq].plane_off, g_n = P.lvl_n[frame * P.nlevels + lq];
+    const float g_scale = P.geom[lq].scale, g_size = P.geom[lq].kp_size;
+    const int mySlot = min(slot0 + lane, P.lvl_kp_per_frame - 1);
+    const unsigned myV = P.lvl_kp[(long long)frame * P.lvl_kp_per_frame + mySlot];
+#define RL(v, l) __builtin_amdgcn_readlane((v), (l))
+#define RLF(v, l) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (l)))
 
-    // ---- all global loads of this keypoint are issued up-front (wave-uniform base + 32-bit lane offsets, no predication:
-    //      keypoints keep >= 19 px from every border, so every address below is inside the plane)
-    // (a) rBRIEF pattern of this lane's 4 tests, stored as floats (x0, y0, x1, y1)
-    const float4* pat = reinterpret_cast<const float4*>(P.patternf);
+    // ---- per-lane constants of the wave
+    const float4* pat = reinterpret_cast<const float4*>(P.patternf);      // rBRIEF pattern of this lane's 4 tests as floats (x0, y0, x1, y1)
     float4 pt[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) pt[r] = pat[(unsigned)(r * 64 + lane)];
-    // (b) 31x31 orientation patch of the un-blurred level: lane = column u (coalesced rows), two rows per load
-    int spitch_v; const uint8_t* img_v = level_src(P, frame, level, spitch_v);
-    const int spitch = U(spitch_v);
-    const uint8_t* img = uniform_ptr(img_v);
-    const int half = lane >> 5, u = (lane & 31) - 15;              // lanes 0..30 and 32..62 carry columns -15..15
-    const bool col_ok = (lane & 31) < 31;
-    const unsigned ioff = (unsigned)((cy + half - 15) * spitch + cx + min(u, 15));
-    int pxv[16];
+    const int prow = lane >> 3, pd = lane & 7;                             // orientation patch: lane = (row mod 8, dword of the row)
+    unsigned pmask[4];
 #pragma unroll
-    for (int k = 0; k < 16; k++)                                    // rows 2k + half - 15 = -15..16; row 16 (k = 15, half = 1) is loaded but unused
-        pxv[k] = img[ioff + (unsigned)(2 * k * spitch)];
-    // (c) 37-row window of the blurred level -> LDS with aligned 32-bit loads: 16 lanes per row (11 used), 4 rows per pass
-    const uint8_t* blv = uniform_ptr(P.blur + (long long)frame * P.plane_frame_bytes + U(g.plane_off));
-    const int bpitch = U(g.pitch);
-    const int wx0 = (cx - 18) & ~3;                                 // window byte x of LDS column 0 (level pitch and plane offsets are multiples of 4)
-    unsigned* win = s_win[wave];
-    const int wr = lane >> 4, wd = min(lane & 15, DS_WDW - 1);
-    const unsigned woff = (unsigned)((cy - 18 + wr) * bpitch + wx0 + 4 * wd);
-    unsigned wv[10];
+    for (int q = 0; q < 4; q++) pmask[q] = P.ic_mask[(prow + 8 * q) * 8 + pd];      // bytes inside the circle (row 31 does not exist: 0)
+    const unsigned ucoef = 0x03020100u + 0x04040404u * (unsigned)pd;       // u + 15 of the dword's four bytes
+    int wrow[DS_WPASSES], wcol[DS_WPASSES];                                // window DMA: pass k, lane l fills dword 64k + l = (row, dword) of the 10-dword rows
 #pragma unroll
-    for (int k = 0; k < 10; k++)                                    // rows wr + 4k = 0..39: rows 37..39 clamp to 36 (in bounds, not stored)
-        wv[k] = *reinterpret_cast<const unsigned*>(blv + woff + (unsigned)(min(4 * k, DS_WROWS - 1 - wr) * bpitch));
-#pragma unroll
-    for (int k = 0; k < 10; k++) { const int r = wr + 4 * k; if (r < DS_WROWS && (lane & 15) < DS_WDW) win[r * DS_WDW + wd] = wv[k]; }
-#undef U
+    for (int k = 0; k < DS_WPASSES; k++) {
+        const int pos = 64 * k + lane, row = (pos * 6554) >> 16;          // pos / 10 for pos < 16384
+        wrow[k] = min(row, DS_WROWS - 1); wcol[k] = 4 * (pos - 10 * row); // rows past the window re-read its last row (in bounds, never used)
+    }
 
-    // ---- IC_Angle (ORBextractor.cc:77-104): m10 = sum u*I, m01 = sum v*I over the circular patch
-    int m10 = 0, m01 = 0;
+    // ---- 0. slot -> (level, index in the level, output index), lane j for slot j; then wave-uniform copies (SGPRs) of the wave's slots.
+    //      Valid slots of a wave have consecutive output indices (slots and outputs are both level-major).
+    int myLevel = 0, myOi = -1;
     {
-        const int au = u < 0 ? -u : u;
-        // vmax(|u|): by symmetry of the circle the row limit for column u equals umax[|u|] (ORBextractor.cc:452-469)
-        const int vm = (au <= 3) ? 15 : (au <= 6) ? 14 : (au <= 8) ? 13 : (au == 9) ? 12 : (au == 10) ? 11 : (au == 11) ? 10 : (au == 12) ? 9 : (au == 13) ? 8 : (au == 14) ? 6 : 3;
-        int s = 0, sv = 0;
-#pragma unroll
-        for (int k = 0; k < 16; k++) { const int vr = 2 * k + half - 15; const int p = (col_ok && vr >= -vm && vr <= vm) ? pxv[k] : 0; s += p; sv += vr * p; }
-        m10 = u * s; m01 = sv;
-    }
-    m10 = wave_sum_dpp(m10); m01 = wave_sum_dpp(m01);
-    const float angle = dev_fast_atan2((float)m01, (float)m10);
-
-    // ---- steered BRIEF (ORBextractor.cc:107-147) on the blurred window in LDS
-    const float factorPI = (float)(3.14159265358979323846 / 180.f);
-    float a, b; dev_sincosf(__fmul_rn(angle, factorPI), &b, &a);
-    __syncthreads();                                               // window visible to all lanes of the wave (exited waves do not participate)
-    const uint8_t* w8 = reinterpret_cast<const uint8_t*>(win) + 18 * (DS_WDW * 4) + (cx - wx0);   // keypoint position inside the window
-    unsigned long long* dout = reinterpret_cast<unsigned long long*>(P.out_desc + ((long long)frame * P.out_cap + oi) * 32);
-    // P.fp_contract (wave-uniform): 0 = x*b + y*a as two roundings (a build with -ffp-contract=off, H3), 1 = the fused forms gcc emits
-    // for the reference's own flags, fma(x, b, y*a) and fma(x, a, -(y*b))
-    auto brief = [&](auto fused) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const float x0 = pt[r].x, y0 = pt[r].y, x1 = pt[r].z, y1 = pt[r].w;
-            int iy0, ix0, iy1, ix1;
-            if (decltype(fused)::value) {
-                iy0 = round_half_even_small(__fmaf_rn(x0, b, __fmul_rn(y0, a))); ix0 = round_half_even_small(__fmaf_rn(x0, a, -__fmul_rn(y0, b)));
-                iy1 = round_half_even_small(__fmaf_rn(x1, b, __fmul_rn(y1, a))); ix1 = round_half_even_small(__fmaf_rn(x1, a, -__fmul_rn(y1, b)));
-            } else {
-                iy0 = round_half_even_small(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a))); ix0 = round_half_even_small(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-                iy1 = round_half_even_small(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a))); ix1 = round_half_even_small(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-            }
-            const int t0 = w8[iy0 * (DS_WDW * 4) + ix0], t1 = w8[iy1 * (DS_WDW * 4) + ix1];
-            const unsigned long long bits = __ballot(t0 < t1);       // test 64r+lane -> byte (64r+lane)/8, bit lane%8
-            if (lane == 0) dout[r] = bits;
+        int obase = 0, koff = RL(g_kpoff, 0), nsel = RL(g_n, 0), tot = nsel;
+        for (int l = 1; l < P.nlevels; l++) {
+            const int kl = RL(g_kpoff, l), nl = RL(g_n, l), nprev = RL(g_n, l - 1);
+            tot += nl;
+            if (slot0 + lane >= kl) { myLevel = l; obase += nprev; koff = kl; nsel = nl; }
         }
-    };
-    if (P.fp_contract) brief(std::true_type{}); else brief(std::false_type{});
-    if (lane == 0) {
-        orbhip_keypoint kp;
-        kp.x = __fmul_rn((float)cx, g.scale); kp.y = __fmul_rn((float)cy, g.scale);     // pt *= scale (:1095-1101); scale[0] == 1
-        kp.size = g.kp_size; kp.angle = angle; kp.response = (float)sc; kp.octave = level; kp.class_id = -1;
-        P.out_kp[(long long)frame * P.out_cap + oi] = kp;
+        if (slot0 == 0 && lane == 0) P.out_n[frame] = min(tot, P.out_cap);
+        const int i = slot0 + lane - koff;
+        if (lane < DS_KPW && slot0 + lane < P.lvl_kp_per_frame && i < nsel && obase + i < P.out_cap) myOi = obase + i;
     }
+    bool ok[DS_KPW]; int lv[DS_KPW], oi[DS_KPW]; unsigned vv[DS_KPW];
+    int oi_first = -1;
+#pragma unroll
+    for (int j = 0; j < DS_KPW; j++) {
+        oi[j] = RL(myOi, j); lv[j] = RL(myLevel, j); vv[j] = (unsigned)RL((int)myV, j);
+        ok[j] = oi[j] >= 0;
+        if (ok[j] && oi_first < 0) oi_first = oi[j];
+    }
+    if (oi_first < 0) return;
+
+    // ---- 1. IC_Angle of every slot.  Every memory request of the wave is issued here, before anything is waited for: the patch loads of
+    //      all slots, then the LDS-DMA of all blurred windows (one LDS buffer per slot) - a wave pays the memory latency once
+    auto window_dma = [&](int level, unsigned v, unsigned* win) {
+        const ORBHIP_GLOBAL uint8_t* blv = uniform_ptr(P.blur + (long long)frame * P.plane_frame_bytes + RL(g_poff, level));
+        const int bpitch = RL(g_pitch, level);
+        const int cx = v & 0xfff, cy = (v >> 12) & 0xfff;
+        const unsigned base = (unsigned)((cy - 18) * bpitch + cx - 18);
+#pragma unroll
+        for (int k = 0; k < DS_WPASSES; k++)
+            lds_dma_dword(blv + (base + __umul24((unsigned)wrow[k], (unsigned)bpitch) + (unsigned)wcol[k]), reinterpret_cast<uint8_t*>(win) + 256 * k);
+    };
+    int M10 = 0, M01 = 0;
+    {
+        unsigned pw[DS_KPW][4];
+#pragma unroll
+        for (int j = 0; j < DS_KPW; j++) if (ok[j]) {
+            const int spitch = lv[j] == 0 ? P.img0_pitch : RL(g_pitch, lv[j]);
+            const ORBHIP_GLOBAL uint8_t* img = uniform_ptr(lv[j] == 0 ? P.img0 + (long long)frame * P.img0_frame_stride
+                                                                      : P.pyr + (long long)frame * P.plane_frame_bytes + RL(g_poff, lv[j]));
+            const int cx = vv[j] & 0xfff, cy = (vv[j] >> 12) & 0xfff;
+            const unsigned off = (unsigned)((cy - 15 + prow) * spitch + cx - 15 + 4 * pd);
+#pragma unroll
+            for (int q = 0; q < 4; q++)                                    // rows prow + 8q - 15 = -15 .. 16; row 16 is loaded (in bounds) and masked
+                pw[j][q] = *reinterpret_cast<const ORBHIP_GLOBAL u32_unaligned*>(img + (off + (unsigned)(8 * q * spitch)));
+        }
+#pragma unroll
+        for (int j = 0; j < DS_KPW; j++) if (ok[j]) window_dma(lv[j], vv[j], s_win[wave][j]);
+#pragma unroll
+        for (int j = 0; j < DS_KPW; j++) if (ok[j]) {
+            unsigned s = 0, su = 0; int sv = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const unsigned x = pw[j][q] & pmask[q];
+                const unsigned t = __builtin_amdgcn_udot4(x, 0x01010101u, 0u, false);
+                su = __builtin_amdgcn_udot4(x, ucoef, su, false);
+                s += t; sv += (prow + 8 * q - 15) * (int)t;
+            }
+            const int m10 = wave_sum_dpp((int)su - 15 * (int)s), m01 = wave_sum_dpp(sv);     // sum u*I, sum v*I (wave-uniform)
+            if (lane == j) { M10 = m10; M01 = m01; }
+        }
+    }
+
+    // ---- 2. orientation and its sine / cosine, lane j = slot j
+    const float angle_l = dev_fast_atan2((float)M01, (float)M10);
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    float a_l, b_l; dev_sincosf(__fmul_rn(angle_l, factorPI), &b_l, &a_l);
+
+    // ---- 3. steered BRIEF (ORBextractor.cc:107-147) per slot on the blurred window in LDS; descriptor word r of the wave's k-th output
+    //      is collected in lane 4k + r, so nothing is stored (and no store is waited for) inside the loop
+    unsigned long long dword_l = 0;
+    {
+        int later = 0;                                                      // valid slots behind slot j: their windows' loads are the youngest outstanding ones
+#pragma unroll
+        for (int j = 0; j < DS_KPW; j++) later += ok[j] ? 1 : 0;
+#pragma unroll
+        for (int j = 0; j < DS_KPW; j++) {
+            if (!ok[j]) continue;
+            later--;
+            // vmcnt counts in order: at most 6 * later loads outstanding  <=>  this slot's window (and everything older) has landed
+            if (later >= 3) __builtin_amdgcn_s_waitcnt(ORBHIP_VMCNT(3 * DS_WPASSES));
+            else if (later == 2) __builtin_amdgcn_s_waitcnt(ORBHIP_VMCNT(2 * DS_WPASSES));
+            else if (later == 1) __builtin_amdgcn_s_waitcnt(ORBHIP_VMCNT(DS_WPASSES));
+            else lds_dma_wait();
+            __builtin_amdgcn_wave_barrier();
+            const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a_l), j)), b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b_l), j));
+            const uint8_t* w8 = reinterpret_cast<const uint8_t*>(s_win[wave][j]) + 18 * DS_WSTRIDE + 18;      // key point position inside the window
+            const int dlane = 4 * (oi[j] - oi_first);
+            // P.fp_contract (wave-uniform): 0 = x*b + y*a as two roundings (a build with -ffp-contract=off, H3), 1 = the fused forms gcc emits
+            // for the reference's own flags, fma(x, b, y*a) and fma(x, a, -(y*b))
+            auto brief = [&](auto fused) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float x0 = pt[r].x, y0 = pt[r].y, x1 = pt[r].z, y1 = pt[r].w;
+                    int iy0, ix0, iy1, ix1;
+                    if (decltype(fused)::value) {
+                        iy0 = round_half_even_small(__fmaf_rn(x0, b, __fmul_rn(y0, a))); ix0 = round_half_even_small(__fmaf_rn(x0, a, -__fmul_rn(y0, b)));
+                        iy1 = round_half_even_small(__fmaf_rn(x1, b, __fmul_rn(y1, a))); ix1 = round_half_even_small(__fmaf_rn(x1, a, -__fmul_rn(y1, b)));
+                    } else {
+                        iy0 = round_half_even_small(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a))); ix0 = round_half_even_small(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+                        iy1 = round_half_even_small(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a))); ix1 = round_half_even_small(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+                    }
+                    const int t0 = w8[iy0 * DS_WSTRIDE + ix0], t1 = w8[iy1 * DS_WSTRIDE + ix1];
+                    const unsigned long long bits = __ballot(t0 < t1);       // test 64r+lane -> byte (64r+lane)/8, bit lane%8
+                    if (lane == dlane + r) dword_l = bits;
+                }
+            };
+            if (P.fp_contract) brief(std::true_type{}); else brief(std::false_type{});
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // ---- outputs: the wave's descriptors are one contiguous run of 8-byte words, its key point records one per lane
+    int nvalid = 0;
+#pragma unroll
+    for (int j = 0; j < DS_KPW; j++) nvalid += ok[j] ? 1 : 0;
+    if (lane < 4 * nvalid)
+        reinterpret_cast<unsigned long long*>(P.out_desc + ((long long)frame * P.out_cap + oi_first) * 32)[lane] = dword_l;
+    float myScale = RLF(g_scale, 0), mySize = RLF(g_size, 0);
+    for (int l = 1; l < P.nlevels; l++) { const float sl = RLF(g_scale, l), zl = RLF(g_size, l); if (myLevel == l) { myScale = sl; mySize = zl; } }
+    if (myOi >= 0) {
+        const int cx = myV & 0xfff, cy = (myV >> 12) & 0xfff;
+        orbhip_keypoint kp;
+        kp.x = __fmul_rn((float)cx, myScale); kp.y = __fmul_rn((float)cy, myScale);     // pt *= scale (:1095-1101); scale[0] == 1
+        kp.size = mySize; kp.angle = angle_l; kp.response = (float)(myV >> 24); kp.octave = myLevel; kp.class_id = -1;
+        P.out_kp[(long long)frame * P.out_cap + myOi] = kp;
+    }
+#undef RL
+#undef RLF
+#undef U
 }
 
 void orbhip_launch_describe(const ExtractParams& P, int nframes, hipStream_t s)
 {
     ExtractParams Q = P; Q.nframes = nframes;
-    hipLaunchKernelGGL(k_describe, dim3(xcd_grid((P.lvl_kp_per_frame + DS_WAVES - 1) / DS_WAVES, nframes), 1, 1), dim3(256, 1, 1), 0, s, Q);
+    hipLaunchKernelGGL(k_describe, dim3(xcd_grid((P.lvl_kp_per_frame + DS_WAVES * DS_KPW - 1) / (DS_WAVES * DS_KPW), nframes), 1, 1), dim3(256, 1, 1), 0, s, Q);
 }
