@@ -69,7 +69,7 @@ struct orbhip_ctx {
     int fc_maxpw = 0, fc_maxph = 0;
     long long plane_frame_bytes = 0, cand_slots_per_frame = 0, qt_per_frame = 0; int lvl_kp_per_frame = 0, out_cap = 0, qt_maxn = 0, qt_maxcells = 0, lvl0_cap = 0;
     // device
-    LevelGeom* d_geom = nullptr; CellDesc* d_cells = nullptr; TileDesc* d_tiles = nullptr; int2* d_xtab = nullptr; int2* d_ytab = nullptr; float* d_pattern = nullptr; int4* d_fc_dma = nullptr; int fc_np = 0; PyrGroup* d_xgrp = nullptr; unsigned* d_ic_mask = nullptr;
+    LevelGeom* d_geom = nullptr; CellDesc* d_cells = nullptr; TileDesc* d_tiles = nullptr; int2* d_xtab = nullptr; int2* d_ytab = nullptr; float* d_pattern = nullptr; int4* d_fc_dma = nullptr; int fc_np = 0; PyrGroup* d_xgrp = nullptr; unsigned* d_ic_mask = nullptr; int4* d_blur_band = nullptr; bool blur_mfma = false;
     uint8_t* d_pyr = nullptr; uint8_t* d_blur = nullptr; int* d_cell_count = nullptr; unsigned* d_cell_cand = nullptr;
     unsigned* d_qt_val = nullptr; unsigned* d_qt_code = nullptr; int* d_qt_node = nullptr; unsigned* d_lvl_kp = nullptr;
     // outputs are triple-buffered: batch t writes buffer t%3 while the matcher of batch t-1 (own stream) still reads buffers (t-1)%3 and (t-2)%3
@@ -265,7 +265,7 @@ extern "C" void orbhip_destroy(orbhip_ctx* c)
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     prof_collect(c);
     for (auto e : c->pool) (void)hipEventDestroy(e);
-    void* ptrs[] = {c->d_ic_mask, c->d_xgrp, c->d_fc_dma, c->d_geom, c->d_cells, c->d_tiles, c->d_xtab, c->d_ytab, c->d_pattern, c->d_pyr, c->d_blur, c->d_cell_count, c->d_cell_cand,
+    void* ptrs[] = {c->d_blur_band, c->d_ic_mask, c->d_xgrp, c->d_fc_dma, c->d_geom, c->d_cells, c->d_tiles, c->d_xtab, c->d_ytab, c->d_pattern, c->d_pyr, c->d_blur, c->d_cell_count, c->d_cell_cand,
                     c->d_qt_val, c->d_qt_code, c->d_qt_node, c->d_lvl_kp, c->d_lvl_n[0], c->d_lvl_n[1], c->d_lvl_n[2], c->d_out_kp[0], c->d_out_kp[1], c->d_out_kp[2],
                     c->d_out_desc[0], c->d_out_desc[1], c->d_out_desc[2], c->d_out_n[0], c->d_out_n[1], c->d_out_n[2], c->d_grid_start, c->d_grid_items, c->d_grid_xy, c->d_cand, c->d_top, c->d_ncand,
                     c->d_prev, c->d_m12, c->d_nm};
@@ -330,6 +330,8 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
         for (int i = 0; i < 7; i++) { double x = i - 3.0; cf[i] = (float)std::exp(scale2X * x * x); sum += cf[i]; }
         sum = 1. / sum;
         for (int i = 0; i < 4; i++) c->gk[i] = cvRoundF((float)(cf[3 + i] * sum) * 256.f);      // centre, +-1, +-2, +-3
+        { const char* e = getenv("ORBHIP_BLUR"); c->blur_mfma = e && strcmp(e, "mfma") == 0; }       // measurement only: the matrix-core blur kernel (k_blur_mfma)
+        if (c->gk[0] > 127 || c->gk[0] + 2 * (c->gk[1] + c->gk[2] + c->gk[3]) != 257) c->blur_mfma = false;     // the i8 form assumes these taps
     }
     // ---- per level geometry (ORBextractor.cc:1111-1112, 773-806, 543-545)
     c->geom.resize(L);
@@ -403,7 +405,8 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
             }
             if (grouped) c->pyr_staged[l] = 2;
         }
-        for (int y0 = 0; y0 < g.h; y0 += 32) for (int x0 = 0; x0 < g.w; x0 += 128) { TileDesc t; t.level = (short)l; t.x0 = (short)x0; t.y0 = (short)y0; t.pad = 0; c->blur_tiles.push_back(t); }
+        const int btw = c->blur_mfma ? orbhip_blur_mfma_tile_w() : 128, bth = c->blur_mfma ? orbhip_blur_mfma_tile_h() : 32;     // k_blur_mfma / k_blur workgroup tile
+        for (int y0 = 0; y0 < g.h; y0 += bth) for (int x0 = 0; x0 < g.w; x0 += btw) { TileDesc t; t.level = (short)l; t.x0 = (short)x0; t.y0 = (short)y0; t.pad = 0; c->blur_tiles.push_back(t); }
     }
     c->plane_frame_bytes = (plane_off + 255) & ~255LL; c->cand_slots_per_frame = cand_off; c->qt_per_frame = cand_off;
     c->lvl_kp_per_frame = kp_off; c->out_cap = kp_off; c->lvl0_cap = c->geom[0].kp_cap;
@@ -437,6 +440,19 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
 #define TRY(x) do { if (e == hipSuccess) e = (x); } while (0)
     TRY(upload(&c->d_geom, c->geom)); TRY(upload(&c->d_cells, c->cells)); TRY(upload(&c->d_tiles, c->blur_tiles));
     TRY(upload(&c->d_xtab, c->xtab)); TRY(upload(&c->d_ytab, c->ytab)); TRY(upload(&c->d_xgrp, c->xgrp)); TRY(upload(&c->d_pattern, pat));
+    if (c->blur_mfma) {   // k_blur_mfma: the two band (Toeplitz) matrices of the 7-tap filter laid out as B operands of v_mfma_i32_32x32x32_i8
+        const int tap[7] = {c->gk[3], c->gk[2], c->gk[1], c->gk[0], c->gk[1], c->gk[2], c->gk[3]};
+        std::vector<int4> band(3 * 64); signed char* bb = reinterpret_cast<signed char*>(band.data());
+        for (int l = 0; l < 64; l++) for (int b = 0; b < 16; b++) {
+            const int j = l & 31, hh = l >> 5;
+            const int t1 = 16 * hh + b - j - 1, t2 = 32 + 16 * hh + b - j - 1;                 // source column x0 - 4 + k feeds output column x0 + j with tap k - j - 1
+            const int r = (b & 3) + 8 * (b >> 2) + 4 * hh, tv = r - j;                         // source row y0 - 3 + r (the register / lane-half order of the first product's result)
+            bb[(0 * 64 + l) * 16 + b] = (signed char)((t1 >= 0 && t1 <= 6) ? tap[t1] : 0);
+            bb[(1 * 64 + l) * 16 + b] = (signed char)((t2 >= 0 && t2 <= 6) ? tap[t2] : 0);
+            bb[(2 * 64 + l) * 16 + b] = (signed char)((tv >= 0 && tv <= 6 && j < 26) ? tap[tv] : 0);
+        }
+        TRY(upload(&c->d_blur_band, band));
+    }
     {   // circular patch of IC_Angle as byte masks over 32 rows x 8 dwords (byte b of dword d = column 4d + b - 15); umax as ORBextractor.cc:452-469 computes it
         int umax[16]; const int vmax = (int)floor(15 * sqrt(2.0) / 2 + 1), vmin = (int)ceil(15 * sqrt(2.0) / 2);
         for (int v = 0; v <= vmax; v++) umax[v] = cvRoundF((float)sqrt(225.0 - (double)v * v));
@@ -519,7 +535,7 @@ static ExtractParams make_params(orbhip_ctx* c, const uint8_t* d_img0, long long
     P.qt_val = c->d_qt_val; P.qt_code = c->d_qt_code; P.qt_node = c->d_qt_node; P.qt_per_frame = c->qt_per_frame;
     P.lvl_kp = c->d_lvl_kp; P.lvl_kp_per_frame = c->lvl_kp_per_frame; P.lvl_n = c->d_lvl_n[c->cur];
     P.out_kp = c->d_out_kp[c->cur]; P.out_desc = c->d_out_desc[c->cur]; P.out_n = c->d_out_n[c->cur]; P.out_cap = c->out_cap;
-    P.blur_tiles = c->d_tiles; P.nblur_tiles = (int)c->blur_tiles.size();
+    P.blur_tiles = c->d_tiles; P.nblur_tiles = (int)c->blur_tiles.size(); P.blur_band = c->blur_mfma ? c->d_blur_band : nullptr;
     P.xtab = c->d_xtab; P.ytab = c->d_ytab; P.xgrp = c->d_xgrp; P.patternf = c->d_pattern; P.ic_mask = c->d_ic_mask;
     P.iniTh = c->cfg.ini_th_fast; P.minTh = c->cfg.min_th_fast; P.blur_round_mode = c->cfg.blur_round_mode; P.fp_contract = c->fp_contract;
     P.qt_maxn = c->qt_maxn; P.qt_maxcells = c->qt_maxcells; P.qt_scr = orbhip_quadtree_scr(c->qt_maxn, c->qt_maxcells);

@@ -67,6 +67,7 @@ struct ExtractParams {
     unsigned* lvl_kp; int lvl_kp_per_frame; int* lvl_n;
     orbhip_keypoint* out_kp; uint8_t* out_desc; int* out_n; int out_cap;
     const TileDesc* blur_tiles; int nblur_tiles;
+    const int4* blur_band;                                                 // k_blur_mfma: band matrices HB1 | HB2 | VB as B operands, [3][64 lanes] x 16 bytes; NULL = k_blur (VALU)
     const int2* xtab; const int2* ytab; const PyrGroup* xgrp;
     const unsigned* ic_mask;                                               // IC_Angle: [32 rows][8 dwords] byte masks of the circular patch (u, v in -15..15, |u| <= umax[|v|])
     const float* patternf;                                                 // 256 x (x0,y0,x1,y1) as floats (rBRIEF pattern, ORBextractor.cc:150-408)
@@ -135,6 +136,8 @@ size_t orbhip_proj_select_lds(int n);
 // kernel launchers (orbhip_kernels_extract.hip / orbhip_kernels_match.hip)
 void orbhip_launch_pyramid_level(const ExtractParams& P, int level, int w, int h, int mode, int nframes, hipStream_t s);
 int orbhip_pyramid_tile_dwords();
+int orbhip_blur_mfma_tile_w();
+int orbhip_blur_mfma_tile_h();
 bool orbhip_pyramid_tile_fits(int src_cols_per_tile, int src_rows_per_tile);
 void orbhip_launch_to_gray(const uint8_t* src, long long src_frame_stride, int src_row_stride, uint8_t* dst, long long dst_frame_stride,
                            int dst_pitch, int w, int h, int channels, bool rgb_order, int nframes, hipStream_t s);

@@ -52,6 +52,9 @@ __device__ __forceinline__ const uint8_t* level_src(const ExtractParams& P, int 
 // cv::resize INTER_LINEAR CV_8U (OpenCV 3.2 HResizeLinear / VResizeLinear fixed point, 11-bit coefficients).
 // Coefficient tables are built on the host exactly as OpenCV builds them; the kernel is pure integer.
 // 4 output pixels per thread, one 32-bit store.
+#define BM_ROWS 26                      // k_blur_mfma: output rows per wavefront (32 source rows - 6)
+#define BM_COLS 32                      // k_blur_mfma: output columns per wavefront
+#define BM_NT 4                         // k_blur_mfma: tiles per wavefront (rows w, w + 4, ... of the workgroup's 16 tile rows)
 #define PYR_RPT 4                       // output rows per thread (4 pixels each): coefficient unpacking is amortised over them
 // 4 output pixels of PYR_RPT consecutive rows from source rows addressed as rows[(y - row0) * rpitch + x]
 __device__ __forceinline__ void pyr_rows(const LevelGeom& g, const int2* xt, const int2* yt, const uint8_t* rows, int rpitch, int row0, int x4, int ytop, uint8_t* dstp)
@@ -233,6 +236,8 @@ __global__ __launch_bounds__(256) void k_pyramid_level_direct(ExtractParams P, i
 
 bool orbhip_pyramid_tile_fits(int src_cols_per_tile, int src_rows_per_tile) { return ((src_cols_per_tile + 3) >> 2) + 1 <= PYR_SDW && src_rows_per_tile <= PYR_SROWS; }
 int orbhip_pyramid_tile_dwords() { return PYR_SDW; }
+int orbhip_blur_mfma_tile_w() { return BM_COLS; }
+int orbhip_blur_mfma_tile_h() { return 4 * BM_NT * BM_ROWS; }      // four wavefronts stacked, BM_NT tiles each
 int orbhip_pyramid_tile_w() { return PYR_TW; }
 int orbhip_pyramid_tile_h() { return PYR_TH; }
 
@@ -403,6 +408,130 @@ __global__ __launch_bounds__(256) void k_blur(ExtractParams P, BlurK K)
     if (half_even) strip(std::true_type{}); else strip(std::false_type{});
 }
 
+// ---- the same blur on the matrix cores (the default; k_blur above stays as the measured all-VALU alternative, ORBHIP_BLUR=valu).
+// A departure from "no MFMA" that the instruction-rate table forces: the extraction kernels are bound by VALU issue, the matrix pipe
+// is idle and issues beside it, and a 7-tap filter is a banded (Toeplitz) matrix product whose i8 form is EXACT here: pixels - 128 fit
+// i8, the taps {18, 34, 49, 55} fit i8, accumulation is i32.  One wavefront = one tile of 26 rows x 32 columns, no LDS, no barrier:
+//   rows:   lane (i, h) loads 16 source bytes of row y0 - 3 + i from column x0 - 3 + 16h straight into the A operand (XOR 0x80 = -128);
+//           D1[i][j] = sum_k A[i][k] * HB[k][j] + 128 * 257 is the horizontal pass of 32 rows x 32 output columns (two K = 32 blocks: columns
+//           x0 - 3 .. x0 + 28 and the six columns behind them), every value in [0, 65535] - exactly the row filter's int32 result;
+//   cols:   D1 leaves the matrix core with lane = column and register = row, which is what the A operand of the second product needs
+//           (lane = its row i' = column, bytes = its k = source row) once each value is split into a low and a high byte plane
+//           (4 v_perm per 4 values); D2[i' = column][j' = output row] = sum_r VB[r][j'] * plane[r], for both planes, then
+//           s = (D2hi << 8) + D2lo is the column filter's int32 sum; rounding, saturation and packing as in k_blur (v_cvt_pk_u8_f32);
+//   store:  D2 has lane = output row, registers = four groups of four adjacent columns: four 32-bit stores per lane.
+// The band matrices (tap k - j, zero elsewhere; VB also zero for the six incomplete output rows) come from a host table.  k is whatever
+// (lane half, byte) pair the hardware pairs between A and B: the kernel never needs the nominal k order (tools/mfma_probe.hip checks it).
+typedef int v4i __attribute__((vector_size(16)));
+typedef int v16i __attribute__((vector_size(64)));
+typedef unsigned v4u_a4 __attribute__((vector_size(16), aligned(4)));       // a 16-byte global load that is only 4-byte aligned
+typedef unsigned v2u_a4 __attribute__((vector_size(8), aligned(4)));
+// up to BM_NT tiles (of BM_ROWS rows) per wavefront: the next tile's loads fly during this tile's products
+// source bytes of one tile as A operands: K block 1 = columns x0 - 4 .. x0 + 27 (16 per lane), K block 2 = columns x0 + 28 .. x0 + 35
+// (lane half 0; only x0 + 28 .. x0 + 34 carry taps).  x0 is a multiple of 32, so inside the image both are aligned dword runs.
+__device__ __forceinline__ void bm_load(const uint8_t* src, int spitch, int w, int hgt, int x0, int y0, int i, int h, v4i& A1, v4i& A2)
+{
+    const uint8_t* rowp = src + (long long)reflect101_clamped(y0 - 3 + i, hgt) * spitch;
+    if (x0 >= 4 && x0 + 36 <= w) {
+        const v4u_a4 q1 = *reinterpret_cast<const v4u_a4*>(rowp + (x0 - 4 + 16 * h));
+        const v2u_a4 q2 = *reinterpret_cast<const v2u_a4*>(rowp + (x0 + 28));
+        A1[0] = (int)q1[0]; A1[1] = (int)q1[1]; A1[2] = (int)q1[2]; A1[3] = (int)q1[3];
+        A2[0] = (int)q2[0]; A2[1] = (int)q2[1];
+    } else {                                                          // image border: BORDER_REFLECT_101 byte by byte
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            unsigned wv = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) wv |= (unsigned)rowp[reflect101_clamped(x0 - 4 + 16 * h + 4 * d + b, w)] << (8 * b);
+            A1[d] = (int)wv;
+        }
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+            unsigned wv = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) wv |= (unsigned)rowp[reflect101_clamped(x0 + 28 + 4 * d + b, w)] << (8 * b);
+            A2[d] = (int)wv;
+        }
+    }
+    A2[2] = 0; A2[3] = 0;
+}
+__global__ __launch_bounds__(256, 5) void k_blur_mfma(ExtractParams P)
+{
+    int tile, frame;
+    if (!xcd_frame_map(P.nblur_tiles, P.nframes, tile, frame)) return;
+    frame += P.frame0;
+    const TileDesc t = P.blur_tiles[tile];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const LevelGeom g = P.geom[t.level];
+    const int x0 = t.x0;
+    int y0 = t.y0 + BM_ROWS * wave;                                   // the workgroup's tile rows go round-robin over its four waves
+    if (y0 >= g.h) return;
+    const int yend = min(t.y0 + 4 * BM_NT * BM_ROWS, g.h);
+    int spitch; const uint8_t* src = level_src(P, frame, t.level, spitch);
+    const int i = lane & 31, h = lane >> 5;
+    const int4 qb1 = P.blur_band[lane], qb2 = P.blur_band[64 + lane], qbv = P.blur_band[128 + lane];
+    const v4i HB1 = {qb1.x, qb1.y, qb1.z, qb1.w}, HB2 = {qb2.x, qb2.y, qb2.z, qb2.w}, VB = {qbv.x, qbv.y, qbv.z, qbv.w};
+    const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // C operand = inline constant 0: the -128 of the operand bytes is undone on the VALU
+    // x86 SSE2 build of OpenCV: cvtps2dq (round-half-even) on whole 4-column groups below w & ~3, the generic rounding behind them
+    const int he_limit = P.blur_round_mode == 1 ? (g.w & ~3) : 0;
+    const bool all_he = x0 + BM_COLS <= he_limit, none_he = x0 >= he_limit;      // wave-uniform: one rounding for the whole tile (all but the right-most tiles)
+    uint8_t* dst = P.blur + (long long)frame * P.plane_frame_bytes + g.plane_off;
+    // sum = 2^8 (chi + 128 * 257) + (clo + 128 * 257) with chi / clo the raw products of the (byte - 128) planes: the constant joins the
+    // scaling in one fma, exactly (sum < 2^24, K / 2^16 = 129 + 2^-8)
+    const float kbias = (float)(257 * 128 * 257) * (1.0f / 65536.0f);
+    v4i A1, A2, N1 = {0, 0, 0, 0}, N2 = {0, 0, 0, 0};
+    bm_load(src, spitch, g.w, g.h, x0, y0, i, h, A1, A2);
+#pragma unroll 1
+    for (; y0 < yend; y0 += 4 * BM_ROWS) {
+        const bool more = y0 + 4 * BM_ROWS < yend;
+        if (more) bm_load(src, spitch, g.w, g.h, x0, y0 + 4 * BM_ROWS, i, h, N1, N2);      // in flight during this tile's products
+#pragma unroll
+        for (int d = 0; d < 4; d++) { A1[d] ^= (int)0x80808080u; A2[d] ^= (int)0x80808080u; }
+        v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1, HB1, zero, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A2, HB2, acc, 0, 0, 0);
+        // row filter result = acc + 128 * 257 in [0, 65535]; its low / high byte planes: bytes 4g .. 4g+3 of a plane = registers 4g .. 4g+3
+        v4i Alo, Ahi;
+#pragma unroll
+        for (int gq = 0; gq < 4; gq++) {
+            const unsigned r0 = (unsigned)acc[4 * gq] + 128u * 257u, r1 = (unsigned)acc[4 * gq + 1] + 128u * 257u;
+            const unsigned r2 = (unsigned)acc[4 * gq + 2] + 128u * 257u, r3 = (unsigned)acc[4 * gq + 3] + 128u * 257u;
+            const unsigned t01 = __builtin_amdgcn_perm(r1, r0, 0x05010400u);      // r0.b0 r1.b0 r0.b1 r1.b1
+            const unsigned t23 = __builtin_amdgcn_perm(r3, r2, 0x05010400u);
+            Alo[gq] = (int)(__builtin_amdgcn_perm(t23, t01, 0x05040100u) ^ 0x80808080u);
+            Ahi[gq] = (int)(__builtin_amdgcn_perm(t23, t01, 0x07060302u) ^ 0x80808080u);
+        }
+        const v16i clo = __builtin_amdgcn_mfma_i32_32x32x32_i8(Alo, VB, zero, 0, 0, 0);
+        const v16i chi = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ahi, VB, zero, 0, 0, 0);
+        // lane = output row (lane & 31), registers = columns x0 + 8 * (q >> 2) + 4 * (lane >> 5) + (q & 3)
+        const int oy = y0 + i;
+        if (i < BM_ROWS && oy < g.h) {
+            uint8_t* dstrow = dst + (long long)oy * g.pitch;
+            auto finish = [&](auto mode) {                               // mode 0: every group generic, 1: every group half-even, 2: per group
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++) {
+                    const int gx = x0 + 8 * gq + 4 * h;
+                    if (gx >= g.w) continue;
+                    unsigned out = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const float raw = (float)((chi[4 * gq + k] << 8) + clo[4 * gq + k]);           // |raw| < 2^24: exact
+                        const float q = __builtin_fmaf(raw, 1.0f / 65536.0f, kbias);                   // column filter sum / 2^16, exact
+                        // generic FixedPtCastEx: (sum + 2^15) >> 16, the saturating RNE conversion then sees an integer; SSE2 build: the conversion's own round-half-even
+                        float v;
+                        if (decltype(mode)::value == 1) v = q;
+                        else if (decltype(mode)::value == 0) v = __builtin_floorf(q + 0.5f);
+                        else v = gx < he_limit ? q : __builtin_floorf(q + 0.5f);
+                        out = __builtin_amdgcn_cvt_pk_u8_f32(v, (unsigned)k, out);
+                    }
+                    *reinterpret_cast<unsigned*>(dstrow + gx) = out;     // pitch multiple of 64, gx of 4: pad bytes absorb the tail
+                }
+            };
+            if (all_he) finish(std::integral_constant<int, 1>{}); else if (none_he) finish(std::integral_constant<int, 0>{}); else finish(std::integral_constant<int, 2>{});
+        }
+        A1 = N1; A2 = N2;
+    }
+}
+
 void orbhip_launch_blur(const ExtractParams& P, const int gk[4], int nframes, hipStream_t s, int tile0, int ntiles)
 {   // tiles [tile0, tile0 + ntiles) of the level-major tile list (ntiles < 0: all)
     BlurK K; K.k0 = (float)gk[0]; K.k1 = (float)gk[1]; K.k2 = (float)gk[2]; K.k3 = (float)gk[3];
@@ -411,7 +540,8 @@ void orbhip_launch_blur(const ExtractParams& P, const int gk[4], int nframes, hi
     ExtractParams Q = P; Q.nframes = nframes;
     if (ntiles >= 0) { Q.blur_tiles = P.blur_tiles + tile0; Q.nblur_tiles = ntiles; }
     if (Q.nblur_tiles <= 0) return;
-    hipLaunchKernelGGL(k_blur, dim3(xcd_grid(Q.nblur_tiles, nframes), 1, 1), dim3(256, 1, 1), 0, s, Q, K);
+    if (P.blur_band) hipLaunchKernelGGL(k_blur_mfma, dim3(xcd_grid(Q.nblur_tiles, nframes), 1, 1), dim3(256, 1, 1), 0, s, Q);
+    else hipLaunchKernelGGL(k_blur, dim3(xcd_grid(Q.nblur_tiles, nframes), 1, 1), dim3(256, 1, 1), 0, s, Q, K);
 }
 
 // ------------------------------------------------------------------------------------------------ FAST per cell

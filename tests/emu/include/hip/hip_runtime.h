@@ -179,6 +179,25 @@ inline unsigned __builtin_amdgcn_udot4(unsigned a, unsigned b, unsigned c, bool 
     for (int i = 0; i < 4; i++) c += ((a >> (8 * i)) & 0xff) * ((b >> (8 * i)) & 0xff);
     return c;
 }
+// v_mfma_i32_32x32x32_i8: D = A x B + C on one wave.  A[i][k]: lane i + 32h, byte b <-> k = (h, b); B[k][j]: lane j + 32h, same k;
+// C / D[i][j]: lane j + 32 * ((i >> 2) & 1), register (i & 3) + 4 * (i >> 3).  Every lane of the wave must call (waves are whole here).
+typedef int hipemu_v4i __attribute__((vector_size(16)));
+typedef int hipemu_v16i __attribute__((vector_size(64)));
+inline hipemu_v16i __builtin_amdgcn_mfma_i32_32x32x32_i8(hipemu_v4i a, hipemu_v4i b, hipemu_v16i c, int, int, int) {
+    static signed char A[32][64][16], B[32][64][16];
+    const int w = hipemu::g.cur->wave & 31, l = __lane_id();
+    memcpy(A[w][l], &a, 16); memcpy(B[w][l], &b, 16);
+    __builtin_amdgcn_wave_barrier();
+    hipemu_v16i d = c;
+    const int j = l & 31, hh = l >> 5;
+    for (int q = 0; q < 16; q++) {
+        const int i = (q & 3) + 8 * (q >> 2) + 4 * hh; int acc = 0;
+        for (int h = 0; h < 2; h++) for (int bb = 0; bb < 16; bb++) acc += (int)A[w][i + 32 * h][bb] * (int)B[w][j + 32 * h][bb];
+        d[q] += acc;
+    }
+    __builtin_amdgcn_wave_barrier();
+    return d;
+}
 // v_dot2_u32_u16: two u16 products + c
 template <typename V> inline unsigned __builtin_amdgcn_udot2(V a, V b, unsigned c, bool /*clamp*/) { return (unsigned)a[0] * (unsigned)b[0] + (unsigned)a[1] * (unsigned)b[1] + c; }
 // v_cvt_pk_u8_f32: round to nearest even, saturate to [0, 255], insert into byte `pos` of `old` (measured on MI355X:
