@@ -69,7 +69,7 @@ struct orbhip_ctx {
     int fc_maxpw = 0, fc_maxph = 0;
     long long plane_frame_bytes = 0, cand_slots_per_frame = 0, qt_per_frame = 0; int lvl_kp_per_frame = 0, out_cap = 0, qt_maxn = 0, qt_maxcells = 0, lvl0_cap = 0;
     // device
-    LevelGeom* d_geom = nullptr; CellDesc* d_cells = nullptr; TileDesc* d_tiles = nullptr; int2* d_xtab = nullptr; int2* d_ytab = nullptr; float* d_pattern = nullptr; int4* d_fc_dma = nullptr; int fc_np = 0; PyrGroup* d_xgrp = nullptr; unsigned* d_ic_mask = nullptr; int4* d_blur_band = nullptr; bool blur_mfma = false;
+    LevelGeom* d_geom = nullptr; CellDesc* d_cells = nullptr; TileDesc* d_tiles = nullptr; int2* d_xtab = nullptr; int2* d_ytab = nullptr; float* d_pattern = nullptr; int4* d_fc_dma = nullptr; int fc_np = 0; PyrGroup* d_xgrp = nullptr; unsigned* d_ic_mask = nullptr; int4* d_blur_band = nullptr; bool blur_mfma = true;
     uint8_t* d_pyr = nullptr; uint8_t* d_blur = nullptr; int* d_cell_count = nullptr; unsigned* d_cell_cand = nullptr;
     unsigned* d_qt_val = nullptr; unsigned* d_qt_code = nullptr; int* d_qt_node = nullptr; unsigned* d_lvl_kp = nullptr;
     // outputs are triple-buffered: batch t writes buffer t%3 while the matcher of batch t-1 (own stream) still reads buffers (t-1)%3 and (t-2)%3
@@ -330,7 +330,7 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
         for (int i = 0; i < 7; i++) { double x = i - 3.0; cf[i] = (float)std::exp(scale2X * x * x); sum += cf[i]; }
         sum = 1. / sum;
         for (int i = 0; i < 4; i++) c->gk[i] = cvRoundF((float)(cf[3 + i] * sum) * 256.f);      // centre, +-1, +-2, +-3
-        { const char* e = getenv("ORBHIP_BLUR"); c->blur_mfma = e && strcmp(e, "mfma") == 0; }       // measurement only: the matrix-core blur kernel (k_blur_mfma)
+        { const char* e = getenv("ORBHIP_BLUR"); c->blur_mfma = !(e && strcmp(e, "valu") == 0); }       // ORBHIP_BLUR=valu (measurement only): the all-VALU blur kernel instead of k_blur_mfma
         if (c->gk[0] > 127 || c->gk[0] + 2 * (c->gk[1] + c->gk[2] + c->gk[3]) != 257) c->blur_mfma = false;     // the i8 form assumes these taps
     }
     // ---- per level geometry (ORBextractor.cc:1111-1112, 773-806, 543-545)

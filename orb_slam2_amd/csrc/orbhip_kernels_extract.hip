@@ -41,6 +41,19 @@ template <typename T> __device__ __forceinline__ ORBHIP_GLOBAL T* uniform_ptr(T*
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
     return (ORBHIP_GLOBAL T*)(((unsigned long long)hi << 32) | lo);
 }
+// LDS-DMA: every lane's dword goes from global memory straight to LDS dword (lane) of the 256-byte block at lds_block, without a
+// VGPR round trip (global_load_lds_dword; M0 = block address, wave-uniform).  The source may sit at any byte address
+// (tools/lds_dma_probe.hip, measured on MI355X).  The loads count on vmcnt: lds_dma_wait() before the first LDS read.
+typedef const __attribute__((address_space(1))) void* orbhip_gptr;
+typedef __attribute__((address_space(3))) void* orbhip_lptr;
+__device__ __forceinline__ void lds_dma_dword(const ORBHIP_GLOBAL uint8_t* gsrc, uint8_t* lds_block)
+{
+    __builtin_amdgcn_global_load_lds((orbhip_gptr)gsrc, (orbhip_lptr)lds_block, 4, 0, 0);
+}
+// s_waitcnt vmcnt(n) only (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14)
+#define ORBHIP_VMCNT(n) (0x0f70 | ((n) & 15) | (((n) >> 4) << 14))
+__device__ __forceinline__ void lds_dma_wait() { __builtin_amdgcn_s_waitcnt(ORBHIP_VMCNT(0)); }
+
 __device__ __forceinline__ const uint8_t* level_src(const ExtractParams& P, int frame, int level, int& pitch)
 {
     if (level == 0) { pitch = P.img0_pitch; return P.img0 + (long long)frame * P.img0_frame_stride; }
@@ -54,7 +67,7 @@ __device__ __forceinline__ const uint8_t* level_src(const ExtractParams& P, int 
 // 4 output pixels per thread, one 32-bit store.
 #define BM_ROWS 26                      // k_blur_mfma: output rows per wavefront (32 source rows - 6)
 #define BM_COLS 32                      // k_blur_mfma: output columns per wavefront
-#define BM_NT 4                         // k_blur_mfma: tiles per wavefront (rows w, w + 4, ... of the workgroup's 16 tile rows)
+#define BM_BLOCKS 7                     // k_blur_mfma: 32-column blocks per workgroup tile (224 columns: their sources fill one 256-byte row per LDS-DMA)
 #define PYR_RPT 4                       // output rows per thread (4 pixels each): coefficient unpacking is amortised over them
 // 4 output pixels of PYR_RPT consecutive rows from source rows addressed as rows[(y - row0) * rpitch + x]
 __device__ __forceinline__ void pyr_rows(const LevelGeom& g, const int2* xt, const int2* yt, const uint8_t* rows, int rpitch, int row0, int x4, int ytop, uint8_t* dstp)
@@ -236,8 +249,8 @@ __global__ __launch_bounds__(256) void k_pyramid_level_direct(ExtractParams P, i
 
 bool orbhip_pyramid_tile_fits(int src_cols_per_tile, int src_rows_per_tile) { return ((src_cols_per_tile + 3) >> 2) + 1 <= PYR_SDW && src_rows_per_tile <= PYR_SROWS; }
 int orbhip_pyramid_tile_dwords() { return PYR_SDW; }
-int orbhip_blur_mfma_tile_w() { return BM_COLS; }
-int orbhip_blur_mfma_tile_h() { return 4 * BM_NT * BM_ROWS; }      // four wavefronts stacked, BM_NT tiles each
+int orbhip_blur_mfma_tile_w() { return BM_COLS * BM_BLOCKS; }
+int orbhip_blur_mfma_tile_h() { return BM_ROWS; }
 int orbhip_pyramid_tile_w() { return PYR_TW; }
 int orbhip_pyramid_tile_h() { return PYR_TH; }
 
@@ -408,83 +421,89 @@ __global__ __launch_bounds__(256) void k_blur(ExtractParams P, BlurK K)
     if (half_even) strip(std::true_type{}); else strip(std::false_type{});
 }
 
-// ---- the same blur on the matrix cores (the default; k_blur above stays as the measured all-VALU alternative, ORBHIP_BLUR=valu).
-// A departure from "no MFMA" that the instruction-rate table forces: the extraction kernels are bound by VALU issue, the matrix pipe
+// ---- the same blur on the matrix cores (the default; k_blur above is the all-VALU form, ORBHIP_BLUR=valu: 0.36 ms against 0.23 ms
+// for 256 KITTI frames).
+// A departure from "no MFMA" that the instruction-rate table invites: the extraction kernels are bound by VALU issue, the matrix pipe
 // is idle and issues beside it, and a 7-tap filter is a banded (Toeplitz) matrix product whose i8 form is EXACT here: pixels - 128 fit
-// i8, the taps {18, 34, 49, 55} fit i8, accumulation is i32.  One wavefront = one tile of 26 rows x 32 columns, no LDS, no barrier:
-//   rows:   lane (i, h) loads 16 source bytes of row y0 - 3 + i from column x0 - 3 + 16h straight into the A operand (XOR 0x80 = -128);
-//           D1[i][j] = sum_k A[i][k] * HB[k][j] + 128 * 257 is the horizontal pass of 32 rows x 32 output columns (two K = 32 blocks: columns
-//           x0 - 3 .. x0 + 28 and the six columns behind them), every value in [0, 65535] - exactly the row filter's int32 result;
+// i8, the taps {18, 34, 49, 55} fit i8, accumulation is i32.  One workgroup = 26 rows x 224 columns; a wavefront owns two of its seven
+// 32-column blocks:
+//   stage:  the 32 x 256 source bytes behind the tile go to LDS by LDS-DMA, one whole row (256 contiguous bytes) per instruction - the
+//           first version loaded the A operand straight from global memory, 16 bytes per lane from 32 different rows, and stored 8
+//           bytes per row: the texture addresser was 94 % busy and the kernel slower than k_blur (PMC pass pm1);
+//   rows:   lane (i, h) reads 16 staged bytes of row i from column 32c - 4 + 16h as the A operand (XOR 0x80 = -128);
+//           D1[i][j] = sum_k A[i][k] * HB[k][j] is the horizontal pass of 32 rows x 32 output columns (two K = 32 blocks: columns
+//           32c - 4 .. 32c + 27 and the seven behind them), + 128 * 257 it lies in [0, 65535] - exactly the row filter's int32 result;
 //   cols:   D1 leaves the matrix core with lane = column and register = row, which is what the A operand of the second product needs
 //           (lane = its row i' = column, bytes = its k = source row) once each value is split into a low and a high byte plane
 //           (4 v_perm per 4 values); D2[i' = column][j' = output row] = sum_r VB[r][j'] * plane[r], for both planes, then
-//           s = (D2hi << 8) + D2lo is the column filter's int32 sum; rounding, saturation and packing as in k_blur (v_cvt_pk_u8_f32);
-//   store:  D2 has lane = output row, registers = four groups of four adjacent columns: four 32-bit stores per lane.
-// The band matrices (tap k - j, zero elsewhere; VB also zero for the six incomplete output rows) come from a host table.  k is whatever
+//           2^8 D2hi + D2lo (+ constant) is the column filter's int32 sum; rounding, saturation and packing as in k_blur (v_cvt_pk_u8_f32);
+//   store:  D2 has lane = output row: the tile is transposed through LDS and leaves as whole rows (224 contiguous bytes per instruction).
+// The band matrices (tap k - j - 1, zero elsewhere; VB also zero for the six incomplete output rows) come from a host table.  k is whatever
 // (lane half, byte) pair the hardware pairs between A and B: the kernel never needs the nominal k order (tools/mfma_probe.hip checks it).
 typedef int v4i __attribute__((vector_size(16)));
+typedef int v2i __attribute__((vector_size(8)));
 typedef int v16i __attribute__((vector_size(64)));
-typedef unsigned v4u_a4 __attribute__((vector_size(16), aligned(4)));       // a 16-byte global load that is only 4-byte aligned
-typedef unsigned v2u_a4 __attribute__((vector_size(8), aligned(4)));
-// up to BM_NT tiles (of BM_ROWS rows) per wavefront: the next tile's loads fly during this tile's products
-// source bytes of one tile as A operands: K block 1 = columns x0 - 4 .. x0 + 27 (16 per lane), K block 2 = columns x0 + 28 .. x0 + 35
-// (lane half 0; only x0 + 28 .. x0 + 34 carry taps).  x0 is a multiple of 32, so inside the image both are aligned dword runs.
-__device__ __forceinline__ void bm_load(const uint8_t* src, int spitch, int w, int hgt, int x0, int y0, int i, int h, v4i& A1, v4i& A2)
-{
-    const uint8_t* rowp = src + (long long)reflect101_clamped(y0 - 3 + i, hgt) * spitch;
-    if (x0 >= 4 && x0 + 36 <= w) {
-        const v4u_a4 q1 = *reinterpret_cast<const v4u_a4*>(rowp + (x0 - 4 + 16 * h));
-        const v2u_a4 q2 = *reinterpret_cast<const v2u_a4*>(rowp + (x0 + 28));
-        A1[0] = (int)q1[0]; A1[1] = (int)q1[1]; A1[2] = (int)q1[2]; A1[3] = (int)q1[3];
-        A2[0] = (int)q2[0]; A2[1] = (int)q2[1];
-    } else {                                                          // image border: BORDER_REFLECT_101 byte by byte
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-            unsigned wv = 0;
-#pragma unroll
-            for (int b = 0; b < 4; b++) wv |= (unsigned)rowp[reflect101_clamped(x0 - 4 + 16 * h + 4 * d + b, w)] << (8 * b);
-            A1[d] = (int)wv;
-        }
-#pragma unroll
-        for (int d = 0; d < 2; d++) {
-            unsigned wv = 0;
-#pragma unroll
-            for (int b = 0; b < 4; b++) wv |= (unsigned)rowp[reflect101_clamped(x0 + 28 + 4 * d + b, w)] << (8 * b);
-            A2[d] = (int)wv;
-        }
-    }
-    A2[2] = 0; A2[3] = 0;
-}
+#define BM_IN_DW 68                     // dwords per staged source row: 64 loaded (columns x0 - 4 .. x0 + 251) + 4 of padding against bank conflicts
+#define BM_OUT_DW 57                    // dwords per row of the output tile in LDS (56 used)
 __global__ __launch_bounds__(256, 5) void k_blur_mfma(ExtractParams P)
 {
+    __shared__ __attribute__((aligned(16))) unsigned s_in[32 * BM_IN_DW];
+    __shared__ unsigned s_out[BM_ROWS * BM_OUT_DW];
     int tile, frame;
     if (!xcd_frame_map(P.nblur_tiles, P.nframes, tile, frame)) return;
     frame += P.frame0;
     const TileDesc t = P.blur_tiles[tile];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const LevelGeom g = P.geom[t.level];
-    const int x0 = t.x0;
-    int y0 = t.y0 + BM_ROWS * wave;                                   // the workgroup's tile rows go round-robin over its four waves
-    if (y0 >= g.h) return;
-    const int yend = min(t.y0 + 4 * BM_NT * BM_ROWS, g.h);
+    const int x0 = t.x0, y0 = t.y0;
     int spitch; const uint8_t* src = level_src(P, frame, t.level, spitch);
+    const int w4 = g.w & ~3;
+    {   // ---- stage: wave w brings source rows 8w .. 8w+7 (BORDER_REFLECT_101 on the row index), lane = dword of the row.  Dwords that are not
+        //      entirely inside the image re-read a dword that is (never used as loaded): the two border fix-ups below write them
+        const int c0 = x0 - 4 + 4 * lane;
+        const unsigned coff = (unsigned)min(max(c0, 0), w4 - 4);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int row = 8 * wave + r;
+            const ORBHIP_GLOBAL uint8_t* rp = uniform_ptr(src + (long long)reflect101_clamped(y0 - 3 + row, g.h) * spitch);
+            lds_dma_dword(rp + coff, reinterpret_cast<uint8_t*>(s_in + row * BM_IN_DW));
+        }
+        lds_dma_wait();
+        __builtin_amdgcn_wave_barrier();                                  // every lane's dwords have landed before any lane patches one
+        const bool fix_left = x0 == 0, fix_right = x0 + 252 > w4;     // wave-uniform
+        if (fix_left || fix_right) {
+            // lane = (row of this wave, slot): slot 0 = the dword left of the image, slots 1 / 2 = the two dwords from column w & ~3 on (the last
+            // 0..3 real columns, then reflected ones: a tile reads at most 3 columns past the last one it writes)
+            const int rr = lane >> 3, slot = lane & 7, row = 8 * wave + rr;
+            const int cfix = slot == 0 ? -4 : w4 + 4 * (slot - 1);
+            const int dw = (cfix - (x0 - 4)) >> 2;
+            const bool act = (slot == 0 ? fix_left : (slot <= 2 && fix_right)) && dw >= 0 && dw < 64;
+            if (act) {
+                const uint8_t* rowp = src + (long long)reflect101_clamped(y0 - 3 + row, g.h) * spitch;
+                unsigned wv = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) wv |= (unsigned)rowp[reflect101_clamped(cfix + b, g.w)] << (8 * b);
+                s_in[row * BM_IN_DW + dw] = wv;
+            }
+        }
+    }
+    __syncthreads();
     const int i = lane & 31, h = lane >> 5;
     const int4 qb1 = P.blur_band[lane], qb2 = P.blur_band[64 + lane], qbv = P.blur_band[128 + lane];
     const v4i HB1 = {qb1.x, qb1.y, qb1.z, qb1.w}, HB2 = {qb2.x, qb2.y, qb2.z, qb2.w}, VB = {qbv.x, qbv.y, qbv.z, qbv.w};
     const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // C operand = inline constant 0: the -128 of the operand bytes is undone on the VALU
     // x86 SSE2 build of OpenCV: cvtps2dq (round-half-even) on whole 4-column groups below w & ~3, the generic rounding behind them
-    const int he_limit = P.blur_round_mode == 1 ? (g.w & ~3) : 0;
-    const bool all_he = x0 + BM_COLS <= he_limit, none_he = x0 >= he_limit;      // wave-uniform: one rounding for the whole tile (all but the right-most tiles)
-    uint8_t* dst = P.blur + (long long)frame * P.plane_frame_bytes + g.plane_off;
+    const int he_limit = P.blur_round_mode == 1 ? w4 : 0;
     // sum = 2^8 (chi + 128 * 257) + (clo + 128 * 257) with chi / clo the raw products of the (byte - 128) planes: the constant joins the
     // scaling in one fma, exactly (sum < 2^24, K / 2^16 = 129 + 2^-8)
     const float kbias = (float)(257 * 128 * 257) * (1.0f / 65536.0f);
-    v4i A1, A2, N1 = {0, 0, 0, 0}, N2 = {0, 0, 0, 0};
-    bm_load(src, spitch, g.w, g.h, x0, y0, i, h, A1, A2);
 #pragma unroll 1
-    for (; y0 < yend; y0 += 4 * BM_ROWS) {
-        const bool more = y0 + 4 * BM_ROWS < yend;
-        if (more) bm_load(src, spitch, g.w, g.h, x0, y0 + 4 * BM_ROWS, i, h, N1, N2);      // in flight during this tile's products
+    for (int c = wave; c < BM_BLOCKS; c += 4) {
+        const int xb = x0 + 32 * c;
+        if (xb >= g.w) break;
+        v4i A1 = *reinterpret_cast<const v4i*>(s_in + i * BM_IN_DW + 8 * c + 4 * h);
+        const v2i a2 = *reinterpret_cast<const v2i*>(s_in + i * BM_IN_DW + 8 * c + 8);
+        v4i A2 = {a2[0], a2[1], 0, 0};
 #pragma unroll
         for (int d = 0; d < 4; d++) { A1[d] ^= (int)0x80808080u; A2[d] ^= (int)0x80808080u; }
         v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1, HB1, zero, 0, 0, 0);
@@ -502,15 +521,13 @@ __global__ __launch_bounds__(256, 5) void k_blur_mfma(ExtractParams P)
         }
         const v16i clo = __builtin_amdgcn_mfma_i32_32x32x32_i8(Alo, VB, zero, 0, 0, 0);
         const v16i chi = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ahi, VB, zero, 0, 0, 0);
-        // lane = output row (lane & 31), registers = columns x0 + 8 * (q >> 2) + 4 * (lane >> 5) + (q & 3)
-        const int oy = y0 + i;
-        if (i < BM_ROWS && oy < g.h) {
-            uint8_t* dstrow = dst + (long long)oy * g.pitch;
+        // lane = output row (lane & 31), registers = columns xb + 8 * (q >> 2) + 4 * (lane >> 5) + (q & 3)
+        if (i < BM_ROWS) {
+            const bool all_he = xb + 32 <= he_limit, none_he = xb >= he_limit;  // wave-uniform: one rounding for the whole block (all but the right-most)
             auto finish = [&](auto mode) {                               // mode 0: every group generic, 1: every group half-even, 2: per group
 #pragma unroll
                 for (int gq = 0; gq < 4; gq++) {
-                    const int gx = x0 + 8 * gq + 4 * h;
-                    if (gx >= g.w) continue;
+                    const int gx = xb + 8 * gq + 4 * h;
                     unsigned out = 0;
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
@@ -523,13 +540,19 @@ __global__ __launch_bounds__(256, 5) void k_blur_mfma(ExtractParams P)
                         else v = gx < he_limit ? q : __builtin_floorf(q + 0.5f);
                         out = __builtin_amdgcn_cvt_pk_u8_f32(v, (unsigned)k, out);
                     }
-                    *reinterpret_cast<unsigned*>(dstrow + gx) = out;     // pitch multiple of 64, gx of 4: pad bytes absorb the tail
+                    s_out[i * BM_OUT_DW + 8 * c + 2 * gq + h] = out;
                 }
             };
             if (all_he) finish(std::integral_constant<int, 1>{}); else if (none_he) finish(std::integral_constant<int, 0>{}); else finish(std::integral_constant<int, 2>{});
         }
-        A1 = N1; A2 = N2;
     }
+    __syncthreads();
+    // ---- store: wave w writes output rows w, w + 4, ..., lane = dword of the row (224 contiguous bytes per instruction)
+    uint8_t* dst = P.blur + (long long)frame * P.plane_frame_bytes + g.plane_off;
+    const int gx = x0 + 4 * lane;
+    if (lane < 8 * BM_BLOCKS && gx < g.w)
+        for (int r = wave; r < BM_ROWS && y0 + r < g.h; r += 4)
+            *reinterpret_cast<unsigned*>(dst + (long long)(y0 + r) * g.pitch + gx) = s_out[r * BM_OUT_DW + lane];      // pitch multiple of 64, gx of 4: pad bytes absorb the tail
 }
 
 void orbhip_launch_blur(const ExtractParams& P, const int gk[4], int nframes, hipStream_t s, int tile0, int ntiles)
@@ -597,19 +620,6 @@ __host__ __device__ __forceinline__ int fc_wave_bytes(int pbytes, int sstride, i
 {
     return ((pbytes + 15) & ~15) + ((sstride * srows + 15) & ~15) + ((2 * listcap + 15) & ~15);
 }
-
-// LDS-DMA: every lane's dword goes from global memory straight to LDS dword (lane) of the 256-byte block at lds_block, without a
-// VGPR round trip (global_load_lds_dword; M0 = block address, wave-uniform).  The source may sit at any byte address
-// (tools/lds_dma_probe.hip, measured on MI355X).  The loads count on vmcnt: lds_dma_wait() before the first LDS read.
-typedef const __attribute__((address_space(1))) void* orbhip_gptr;
-typedef __attribute__((address_space(3))) void* orbhip_lptr;
-__device__ __forceinline__ void lds_dma_dword(const ORBHIP_GLOBAL uint8_t* gsrc, uint8_t* lds_block)
-{
-    __builtin_amdgcn_global_load_lds((orbhip_gptr)gsrc, (orbhip_lptr)lds_block, 4, 0, 0);
-}
-// s_waitcnt vmcnt(n) only (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14)
-#define ORBHIP_VMCNT(n) (0x0f70 | ((n) & 15) | (((n) >> 4) << 14))
-__device__ __forceinline__ void lds_dma_wait() { __builtin_amdgcn_s_waitcnt(ORBHIP_VMCNT(0)); }
 
 // ring of the pixel pair (Q, Q+1) of a 4-pixel group whose 7 x 12-byte window is w[7][3] (circle: FAST 16-point Bresenham);
 // ring element k of pixel q sits at row 3+dy_k, byte 3+q+dx_k
