@@ -435,7 +435,8 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
         if (!ok) { orbhip_destroy(c); return fail(ORBHIP_ERR_HIP, "match stream creation failed"); }
     }
     const size_t B = (size_t)c->B;
-    std::vector<float> pat(kPatternHost, kPatternHost + 1024);
+    std::vector<float> pat(1024);                                      // k_describe reads [component x0 y0 x1 y1][round][lane]: test 64 r + lane
+    for (int t = 0; t < 256; t++) for (int k = 0; k < 4; k++) pat[(k * 4 + (t >> 6)) * 64 + (t & 63)] = kPatternHost[4 * t + k];
     hipError_t e = hipSuccess;
 #define TRY(x) do { if (e == hipSuccess) e = (x); } while (0)
     TRY(upload(&c->d_geom, c->geom)); TRY(upload(&c->d_cells, c->cells)); TRY(upload(&c->d_tiles, c->blur_tiles));
@@ -457,10 +458,10 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
         int umax[16]; const int vmax = (int)floor(15 * sqrt(2.0) / 2 + 1), vmin = (int)ceil(15 * sqrt(2.0) / 2);
         for (int v = 0; v <= vmax; v++) umax[v] = cvRoundF((float)sqrt(225.0 - (double)v * v));
         for (int v = 15, v0 = 0; v >= vmin; --v) { while (umax[v0] == umax[v0 + 1]) ++v0; umax[v] = v0; ++v0; }
-        std::vector<unsigned> mask(32 * 8, 0u);
-        for (int r = 0; r < 31; r++) for (int d = 0; d < 8; d++) for (int b = 0; b < 4; b++) {
-            const int v = r - 15, uu = 4 * d + b - 15;
-            if (abs(uu) <= 15 && abs(uu) <= umax[abs(v)]) mask[r * 8 + d] |= 0xffu << (8 * b);
+        std::vector<unsigned> mask(8 * 64, 0u);                       // k_describe: pass q, lane l = (row 4q + l / 16, dword l % 16 of the row from column -15 on)
+        for (int q = 0; q < 8; q++) for (int l = 0; l < 64; l++) for (int b = 0; b < 4; b++) {
+            const int r = 4 * q + (l >> 4), d = l & 15, v = r - 15, uu = 4 * d + b - 15;
+            if (r <= 30 && d <= 7 && abs(uu) <= 15 && abs(uu) <= umax[abs(v)]) mask[q * 64 + l] |= 0xffu << (8 * b);
         }
         TRY(upload(&c->d_ic_mask, mask));
     }

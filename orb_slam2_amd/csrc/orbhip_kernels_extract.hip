@@ -1185,6 +1185,7 @@ __device__ __forceinline__ int round_half_even_small(float x) { return __float_a
 #define DS_KPW 4                       // key point slots per wavefront
 #define DS_WROWS 37                    // blurred window rows: pattern reach is +-18 after rotation
 #define DS_WSTRIDE 40                  // bytes per staged window row (37 used; the window starts exactly at cx - 18)
+#define DS_PPASS 8                     // orientation patch: 32-bit load passes of 4 rows x 16 lanes
 #define DS_WPASSES 6                   // LDS-DMA passes per window: 6 x 64 dwords >= 37 rows x 10 dwords
 #define DS_WDWORDS (DS_WPASSES * 64)
 // One wavefront per DS_KPW consecutive key point slots, in three phases, so that what is per-key-point scalar work in the reference is
@@ -1199,6 +1200,12 @@ __device__ __forceinline__ int round_half_even_small(float x) { return __float_a
 __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
 {
     __shared__ unsigned s_win[DS_WAVES][DS_KPW][DS_WDWORDS];
+    __shared__ float s_pat[16 * 64];                                       // rBRIEF pattern, [component][round][lane]
+    // the pattern (4 KB) is fetched once per workgroup with four coalesced 32-bit loads per thread: as 16-byte loads per lane it cost every
+    // wave 4 x 71 cycles of the texture addresser, more than the wave's orientation patches (tools/ta_ubench.hip)
+#pragma unroll
+    for (int k = 0; k < 4; k++) s_pat[256 * k + threadIdx.x] = P.patternf[256 * k + threadIdx.x];
+    __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int tile, frame;
     if (!xcd_frame_map((P.lvl_kp_per_frame + DS_WAVES * DS_KPW - 1) / (DS_WAVES * DS_KPW), P.nframes, tile, frame)) return;
@@ -1217,14 +1224,15 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
 #define RLF(v, l) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (l)))
 
     // ---- per-lane constants of the wave
-    const float4* pat = reinterpret_cast<const float4*>(P.patternf);      // rBRIEF pattern of this lane's 4 tests as floats (x0, y0, x1, y1)
-    float4 pt[4];
+    float4 pt[4];                                                          // rBRIEF pattern of this lane's 4 tests as floats (x0, y0, x1, y1), from the workgroup's LDS copy
 #pragma unroll
-    for (int r = 0; r < 4; r++) pt[r] = pat[(unsigned)(r * 64 + lane)];
-    const int prow = lane >> 3, pd = lane & 7;                             // orientation patch: lane = (row mod 8, dword of the row)
-    unsigned pmask[4];
+    for (int r = 0; r < 4; r++) { pt[r].x = s_pat[(0 * 4 + r) * 64 + lane]; pt[r].y = s_pat[(1 * 4 + r) * 64 + lane]; pt[r].z = s_pat[(2 * 4 + r) * 64 + lane]; pt[r].w = s_pat[(3 * 4 + r) * 64 + lane]; }
+    // orientation patch: lane = (row mod 4, dword of the row); 9 of a row's 16 lanes load the aligned dwords around its 31 bytes, which are
+    // then funnel-shifted into place (an unaligned 32-bit load of this shape costs the texture addresser 3.5 x an aligned one)
+    const int prow = lane >> 4, pd = lane & 15;
+    unsigned pmask[DS_PPASS];
 #pragma unroll
-    for (int q = 0; q < 4; q++) pmask[q] = P.ic_mask[(prow + 8 * q) * 8 + pd];      // bytes inside the circle (row 31 does not exist: 0)
+    for (int q = 0; q < DS_PPASS; q++) pmask[q] = P.ic_mask[q * 64 + lane];        // bytes inside the circle (row 31, dwords 8..15: 0)
     const unsigned ucoef = 0x03020100u + 0x04040404u * (unsigned)pd;       // u + 15 of the dword's four bytes
     int wrow[DS_WPASSES], wcol[DS_WPASSES];                                // window DMA: pass k, lane l fills dword 64k + l = (row, dword) of the 10-dword rows
 #pragma unroll
@@ -1270,29 +1278,31 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
     };
     int M10 = 0, M01 = 0;
     {
-        unsigned pw[DS_KPW][4];
+        unsigned pw[DS_KPW][DS_PPASS];
 #pragma unroll
         for (int j = 0; j < DS_KPW; j++) if (ok[j]) {
             const int spitch = lv[j] == 0 ? P.img0_pitch : RL(g_pitch, lv[j]);
             const ORBHIP_GLOBAL uint8_t* img = uniform_ptr(lv[j] == 0 ? P.img0 + (long long)frame * P.img0_frame_stride
                                                                       : P.pyr + (long long)frame * P.plane_frame_bytes + RL(g_poff, lv[j]));
             const int cx = vv[j] & 0xfff, cy = (vv[j] >> 12) & 0xfff;
-            const unsigned off = (unsigned)((cy - 15 + prow) * spitch + cx - 15 + 4 * pd);
+            const unsigned off = (unsigned)((cy - 15 + prow) * spitch + ((cx - 15) & ~3) + 4 * min(pd, 8));
 #pragma unroll
-            for (int q = 0; q < 4; q++)                                    // rows prow + 8q - 15 = -15 .. 16; row 16 is loaded (in bounds) and masked
-                pw[j][q] = *reinterpret_cast<const ORBHIP_GLOBAL u32_unaligned*>(img + (off + (unsigned)(8 * q * spitch)));
+            for (int q = 0; q < DS_PPASS; q++)                             // rows prow + 4q - 15 = -15 .. 16; row 16 is loaded (in bounds) and masked
+                pw[j][q] = *reinterpret_cast<const ORBHIP_GLOBAL unsigned*>(img + (off + (unsigned)(4 * q * spitch)));
         }
 #pragma unroll
         for (int j = 0; j < DS_KPW; j++) if (ok[j]) window_dma(lv[j], vv[j], s_win[wave][j]);
 #pragma unroll
         for (int j = 0; j < DS_KPW; j++) if (ok[j]) {
             unsigned s = 0, su = 0; int sv = 0;
+            const unsigned sh = (unsigned)((vv[j] & 0xfff) - 15) & 3u;        // (cx - 15) & 3: byte 0 of the shifted dword is column cx - 15 + 4 pd
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const unsigned x = pw[j][q] & pmask[q];
+            for (int q = 0; q < DS_PPASS; q++) {
+                const unsigned nxt = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pw[j][q], 0x101, 0xf, 0xf, false);     // row_shl:1 = the next dword of the row
+                const unsigned x = __builtin_amdgcn_alignbyte(nxt, pw[j][q], sh) & pmask[q];
                 const unsigned t = __builtin_amdgcn_udot4(x, 0x01010101u, 0u, false);
                 su = __builtin_amdgcn_udot4(x, ucoef, su, false);
-                s += t; sv += (prow + 8 * q - 15) * (int)t;
+                s += t; sv += (prow + 4 * q - 15) * (int)t;
             }
             const int m10 = wave_sum_dpp((int)su - 15 * (int)s), m01 = wave_sum_dpp(sv);     // sum u*I, sum v*I (wave-uniform)
             if (lane == j) { M10 = m10; M01 = m01; }

@@ -141,11 +141,12 @@ template <typename T> inline T __shfl_up(T v, unsigned d, int width = 64) { int 
 template <typename T> inline T __shfl_xor(T v, int m, int width = 64) { int l = __lane_id(); int s = l ^ m; if ((s & ~(width - 1)) != (l & ~(width - 1))) s = l; return hipemu_shfl(v, s); }
 
 inline int __builtin_amdgcn_readlane(int v, int srcLane) { return hipemu_shfl(v, srcLane); }     // v_readlane_b32: uniform source lane
-// v_mov_b32_dpp semantics for the controls the kernels use: row_shr:n (0x110+n), row_bcast:15 (0x142), row_bcast:31 (0x143)
+// v_mov_b32_dpp semantics for the controls the kernels use: row_shl:n (0x100+n), row_shr:n (0x110+n), row_bcast:15 (0x142), row_bcast:31 (0x143)
 inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
     const int l = __lane_id(), row = l >> 4, bank = (l >> 2) & 3;
     int s = -1;
     if (ctrl >= 0x111 && ctrl <= 0x11f) { const int n = ctrl - 0x110; s = ((l & 15) >= n) ? l - n : -1; }
+    else if (ctrl >= 0x101 && ctrl <= 0x10f) { const int n = ctrl - 0x100; s = ((l & 15) + n < 16) ? l + n : -1; }      // row_shl:n
     else if (ctrl == 0x142) s = (row >= 1) ? row * 16 - 1 : -1;
     else if (ctrl == 0x143) s = (row >= 2) ? 31 : -1;
     const int got = hipemu_shfl(src, s < 0 ? l : s);
