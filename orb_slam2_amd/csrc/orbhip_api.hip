@@ -79,9 +79,9 @@ struct orbhip_ctx {
     int cur = 0; int last_nimg = 0; bool last_matched = false; bool last_from_host = false;
     // host-buffer API staging: one contiguous device input buffer + pinned host mirrors (single bulk copies instead of per-frame pageable copies)
     bool serial = false;      // ORBHIP_SERIAL=1 (measurement only): every kernel on the main stream, no overlap
-    int sched = 1;            // ORBHIP_SCHED=0 (measurement only): the blur beside the quadtree instead of beside pyramid + FAST, see pipeline_frames
+    int sched = 0;            // ORBHIP_SCHED (measurement only): what runs on the second stream, see pipeline_frames
     int blur_tiles_l0 = 0;    // blur tiles of level 0 (the tile list is level-major)
-    hipEvent_t ev_start = nullptr;
+    hipEvent_t ev_start = nullptr, ev_fast0 = nullptr;
     uint8_t* d_in = nullptr; uint8_t* h_in = nullptr; uint8_t* d_col = nullptr; uint8_t* h_col = nullptr; size_t col_bytes = 0; orbhip_keypoint* h_kp = nullptr; uint8_t* h_desc = nullptr; int* h_n = nullptr; int in_pitch = 0;
     // stereo (Frame::ComputeStereoMatches): level-0 source of the last call + lazily allocated workspace on the LEFT context
     const uint8_t* last_img0 = nullptr; long long last_img0_fstride = 0; int last_img0_pitch = 0;
@@ -263,6 +263,7 @@ extern "C" void orbhip_destroy(orbhip_ctx* c)
     for (auto e : c->xevents) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+    if (c->ev_fast0) (void)hipEventDestroy(c->ev_fast0);
     prof_collect(c);
     for (auto e : c->pool) (void)hipEventDestroy(e);
     void* ptrs[] = {c->d_blur_band, c->d_ic_mask, c->d_xgrp, c->d_fc_dma, c->d_geom, c->d_cells, c->d_tiles, c->d_xtab, c->d_ytab, c->d_pattern, c->d_pyr, c->d_blur, c->d_cell_count, c->d_cell_cand,
@@ -424,9 +425,9 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
     }
     if (!c->xstreams.empty() && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { orbhip_destroy(c); return fail(ORBHIP_ERR_HIP, "event creation failed"); }
     { const char* e = getenv("ORBHIP_SERIAL"); c->serial = e && e[0] == '1'; }
-    { const char* e = getenv("ORBHIP_SCHED"); c->sched = e ? atoi(e) : 1; }
+    { const char* e = getenv("ORBHIP_SCHED"); c->sched = e ? atoi(e) : 0; }
     for (const TileDesc& t : c->blur_tiles) if (t.level == 0) c->blur_tiles_l0++;
-    if (hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming) != hipSuccess) { orbhip_destroy(c); return fail(ORBHIP_ERR_HIP, "event creation failed"); }
+    if (hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_fast0, hipEventDisableTiming) != hipSuccess) { orbhip_destroy(c); return fail(ORBHIP_ERR_HIP, "event creation failed"); }
     {   // the matcher runs on its own stream so that it overlaps the next batch's extraction
         bool ok = hipStreamCreateWithFlags(&c->mstream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&c->ev_extract, hipEventDisableTiming) == hipSuccess &&
                   hipStreamCreateWithFlags(&c->bstream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&c->ev_pyr, hipEventDisableTiming) == hipSuccess &&
@@ -545,16 +546,34 @@ static ExtractParams make_params(orbhip_ctx* c, const uint8_t* d_img0, long long
     return P;
 }
 
-// pyramid -> FAST -> quadtree -> describe for camera slots [f0, f0 + nf) on stream s, with the blur (which only meets the detector
-// again in k_describe) on the context's blur stream when own_blur_stream: level 0 at once, the other levels behind the pyramid, i.e.
-// beside the pyramid and FAST, joined before describe.  ORBHIP_SCHED=0 (measurement only) is round 1's placement, the whole blur beside
-// the quadtree: 1-2.5 % slower now that the quadtree's workgroups are short and small (gpurun s2 / st2).
+// pyramid -> FAST -> quadtree -> describe for camera slots [f0, f0 + nf) on stream s.  With own_blur_stream the context's second stream
+// takes what does not depend on the main chain's current step (ORBHIP_SCHED, measured at B = 512 with the round-2 kernels, gpurun s3):
+//   0 (default): the blur beside the quadtree, whose workgroups are latency-bound (barriers, one per (frame, level))      167.7 k frames/s
+//   1: the blur beside pyramid + FAST (level 0 at once, the rest behind the pyramid)                                       168.2 k
+//   2: FAST of level 0 beside the pyramid (neither needs the other), then the blur beside FAST of the other levels         169.9 k
+// All three land within 1.3 %: the step is the sum of the kernels' standalone times whatever runs beside what.  0 keeps every throughput
+// kernel alone on the GPU, so its HIP-event time in the timed region is its own (the bench's roofline object relies on that).
 static orbhip_status pipeline_frames(orbhip_ctx* c, ExtractParams& P, int f0, int nf, hipStream_t s, bool own_blur_stream)
 {
     if (nf <= 0) return ORBHIP_OK;
     P.frame0 = f0;
     const int nt0 = c->blur_tiles_l0, nt1 = (int)c->blur_tiles.size() - nt0;
-    if (own_blur_stream && !c->serial && c->sched != 0) {
+    const int nc0 = c->geom[0].ncells, nc1 = (int)c->cells.size() - nc0;
+    const int sched = (own_blur_stream && !c->serial) ? c->sched : -1;
+    if (sched == 2) {
+        hipStream_t bs = c->bstream;
+        HIPCHK(hipEventRecord(c->ev_start, s)); HIPCHK(hipStreamWaitEvent(bs, c->ev_start, 0));
+        { ProfScope ps(c, K_FAST, bs); orbhip_launch_fast_cells(P, nf, bs, 0, nc0); }
+        HIPCHK(hipEventRecord(c->ev_fast0, bs));
+        { ProfScope ps(c, K_PYRAMID, s); for (int l = 1; l < c->L; l++) orbhip_launch_pyramid_level(P, l, c->geom[l].w, c->geom[l].h, (int)c->pyr_staged[l], nf, s); }
+        HIPCHK(hipEventRecord(c->ev_pyr, s)); HIPCHK(hipStreamWaitEvent(bs, c->ev_pyr, 0));
+        { ProfScope ps(c, K_BLUR, bs); orbhip_launch_blur(P, c->gk, nf, bs); }
+        HIPCHK(hipEventRecord(c->ev_blur, bs));
+        { ProfScope ps(c, K_FAST, s, 0); orbhip_launch_fast_cells(P, nf, s, nc0, nc1); }
+        HIPCHK(hipStreamWaitEvent(s, c->ev_fast0, 0));
+        { ProfScope ps(c, K_QUADTREE, s); orbhip_launch_quadtree(P, nf, s); }
+        HIPCHK(hipStreamWaitEvent(s, c->ev_blur, 0));
+    } else if (sched == 1) {
         hipStream_t bs = c->bstream;
         HIPCHK(hipEventRecord(c->ev_start, s)); HIPCHK(hipStreamWaitEvent(bs, c->ev_start, 0));
         { ProfScope ps(c, K_BLUR, bs); orbhip_launch_blur(P, c->gk, nf, bs, 0, nt0); }

@@ -76,6 +76,7 @@ struct ExtractParams {
     int qt_maxcells;                                                       // max cells of one level
     int qt_scr;                                                            // ints of scan scratch in the quadtree's LDS layout
     int fc_pstride, fc_prows, fc_sstride, fc_srows, fc_listcap;            // per-wave LDS layout of k_fast_cells (largest cell of the context)
+    int fc_cell0, fc_ncells;                                               // cell range of this k_fast_cells launch
     int fc_pbytes, fc_np; const int4* fc_dma;                              // patch region = fc_np LDS-DMA passes of 256 bytes; (row, 4*column) of every (pass, lane)
 };
 
@@ -144,7 +145,7 @@ void orbhip_launch_to_gray(const uint8_t* src, long long src_frame_stride, int s
 int orbhip_pyramid_tile_w();
 int orbhip_pyramid_tile_h();
 void orbhip_launch_blur(const ExtractParams& P, const int gk[4], int nframes, hipStream_t s, int tile0 = 0, int ntiles = -1);
-void orbhip_launch_fast_cells(const ExtractParams& P, int nframes, hipStream_t s);
+void orbhip_launch_fast_cells(const ExtractParams& P, int nframes, hipStream_t s, int cell0 = 0, int ncells = -1);
 void orbhip_launch_quadtree(const ExtractParams& P, int nframes, hipStream_t s);
 void orbhip_launch_describe(const ExtractParams& P, int nframes, hipStream_t s);
 size_t orbhip_quadtree_lds_bytes(int maxn, int maxcells);

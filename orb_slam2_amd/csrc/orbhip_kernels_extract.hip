@@ -669,10 +669,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
     HIP_DYNAMIC_SHARED(unsigned, fc_lds)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int tile, frame;
-    if (!xcd_frame_map((P.ncells_total + FC_WAVES - 1) / FC_WAVES, P.nframes, tile, frame)) return;
+    if (!xcd_frame_map((P.fc_ncells + FC_WAVES - 1) / FC_WAVES, P.nframes, tile, frame)) return;      // this launch: cells [fc_cell0, fc_cell0 + fc_ncells)
     frame += P.frame0;
-    const int cell_id = tile * FC_WAVES + wave;
-    if (cell_id >= P.ncells_total) return;                              // every LDS region below is private to its wave: no workgroup barriers
+    const int cell_id = P.fc_cell0 + tile * FC_WAVES + wave;
+    if (cell_id >= P.fc_cell0 + P.fc_ncells) return;                              // every LDS region below is private to its wave: no workgroup barriers
     const CellDesc cd = P.cells[cell_id];
     const int pw = cd.maxX - cd.iniX, ph = cd.maxY - cd.iniY;       // sub-image
     const int cw = pw - 6, ch = ph - 6;                              // examined interior (rows/cols 3 .. n-4)
@@ -786,17 +786,16 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
                 const unsigned ra4 = __builtin_amdgcn_alignbyte(qa[1 - sdw], qa[-sdw], shb);
                 const unsigned rb4 = __builtin_amdgcn_alignbyte(qa[1], qa[0], shb);
                 const unsigned rc4 = __builtin_amdgcn_alignbyte(qa[1 + sdw], qa[sdw], shb);
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    const int sc = (int)((rb4 >> (8 * (q + 1))) & 0xff);
-                    scv[q] = sc;
-                    if (sc > 0) {
-                        const int l = (int)((rb4 >> (8 * q)) & 0xff), r = (int)((rb4 >> (8 * (q + 2))) & 0xff);
-                        const int u0 = (int)((ra4 >> (8 * q)) & 0xff), u1 = (int)((ra4 >> (8 * (q + 1))) & 0xff), u2 = (int)((ra4 >> (8 * (q + 2))) & 0xff);
-                        const int d0 = (int)((rc4 >> (8 * q)) & 0xff), d1 = (int)((rc4 >> (8 * (q + 1))) & 0xff), d2 = (int)((rc4 >> (8 * (q + 2))) & 0xff);
-                        keep[q] = sc > l && sc > r && sc > u0 && sc > u1 && sc > u2 && sc > d0 && sc > d1 && sc > d2;
-                    }
-                }
+                // both pixels at once as u16 lanes: centre pair, its eight neighbour pairs, one packed maximum, strict comparison by saturating
+                // subtraction (a kept pixel beats a neighbour that is >= 0, so it is a corner: no separate score > 0 test)
+                auto bp = [](unsigned r, unsigned sel) { return (pku16)__builtin_amdgcn_perm(0u, r, sel); };
+                const pku16 cpair = bp(rb4, 0x0c020c01u);
+                pku16 nb = pmax(bp(rb4, 0x0c010c00u), bp(rb4, 0x0c030c02u));
+                nb = pmax(nb, pmax(bp(ra4, 0x0c010c00u), pmax(bp(ra4, 0x0c020c01u), bp(ra4, 0x0c030c02u))));
+                nb = pmax(nb, pmax(bp(rc4, 0x0c010c00u), pmax(bp(rc4, 0x0c020c01u), bp(rc4, 0x0c030c02u))));
+                const unsigned gt = (unsigned)psubsat(cpair, nb);
+                keep[0] = (gt & 0xffffu) != 0; keep[1] = (gt >> 16) != 0;
+                scv[0] = (int)(rb4 >> 8) & 0xff; scv[1] = (int)(rb4 >> 16) & 0xff;
             }
             const unsigned long long m0 = __ballot(keep[0]), m1 = __ballot(keep[1]);
             int rank = fc_rank(m1, fc_rank(m0, count));
@@ -821,11 +820,13 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
 }
 #undef FC_RING
 
-void orbhip_launch_fast_cells(const ExtractParams& P, int nframes, hipStream_t s)
-{
+void orbhip_launch_fast_cells(const ExtractParams& P, int nframes, hipStream_t s, int cell0, int ncells)
+{   // cells [cell0, cell0 + ncells) of the level-major cell table (ncells < 0: all)
     const size_t lds = (size_t)FC_WAVES * fc_wave_bytes(P.fc_pbytes, P.fc_sstride, P.fc_srows, P.fc_listcap);
     ExtractParams Q = P; Q.nframes = nframes;
-    hipLaunchKernelGGL(k_fast_cells, dim3(xcd_grid((P.ncells_total + FC_WAVES - 1) / FC_WAVES, nframes), 1, 1), dim3(256, 1, 1), lds, s, Q);
+    Q.fc_cell0 = ncells < 0 ? 0 : cell0; Q.fc_ncells = ncells < 0 ? P.ncells_total : ncells;
+    if (Q.fc_ncells <= 0) return;
+    hipLaunchKernelGGL(k_fast_cells, dim3(xcd_grid((Q.fc_ncells + FC_WAVES - 1) / FC_WAVES, nframes), 1, 1), dim3(256, 1, 1), lds, s, Q);
 }
 
 // ------------------------------------------------------------------------------------------------ quadtree
