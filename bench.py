@@ -124,7 +124,7 @@ def host_io(ex_resident, frames, device, blur_round_mode, budget_s=3.0):
     Extraction only; never the bench `value`.  Measured from pinned caller buffers (DMA straight from / into them) and from pageable
     ones (staged through the library's pinned ring by a few copy threads), plus the single-frame call latency of the drop-in class."""
     import orb_slam2_amd
-    Bh = 128
+    Bh = 256
     ex = orb_slam2_amd.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, W, H, max_batch=Bh, device=device, blur_round_mode=blur_round_mode)
     cap = ex.capacity
     src_pageable = np.ascontiguousarray(frames[0, :Bh, :, :W]) if frames.shape[1] >= Bh else np.ascontiguousarray(np.resize(frames[0, :, :, :W], (Bh, H, W)))
@@ -161,7 +161,7 @@ def host_io(ex_resident, frames, device, blur_round_mode, budget_s=3.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=150)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--repeats", type=int, default=5, help="measurements of --steps steps each; value = the median one")
     ap.add_argument("--no-host-io", action="store_true", help="skip the PCIe-inclusive host-buffer measurement (host_io object)")
@@ -271,7 +271,8 @@ def main():
         # B = 256 frames per launch): FETCH_SIZE counts half of a wide coalesced read on gfx950 (MI355X_MICROARCH.md §HBM) -> x2.
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
+            pmc = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+            with open(pmc if os.path.exists(pmc) else os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
                 for row in json.load(f):
                     if row["kernel"] == dom:
                         traffic = int((2 * row["fetch_MB_per_dispatch_raw"] + row["write_MB_per_dispatch_raw"]) * 1024 * 1024 * B / 256)   # PMC passes ran at B = 256

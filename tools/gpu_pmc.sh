@@ -7,7 +7,7 @@ REPO=$(pwd)
 export TMPDIR=/tmp
 cd /tmp
 rocprofv3 -L > $OUT/counters_list.txt 2>&1
-CMD="python $REPO/bench.py --steps 3 --warmup 1 --batch 256 --no-cpu-baseline"
+CMD="python $REPO/bench.py --steps 3 --warmup 1 --repeats 1 --batch 256 --no-cpu-baseline --no-host-io"
 i=0
 while read -r line; do
   [ -z "$line" ] && continue
