@@ -2,16 +2,17 @@
 //
 // Kernels (one launch each covers every camera slot of the batch; grid.y / grid.z = frame):
 //   k_pyramid_level  level l from level l-1, fixed-point bilinear        (ORBextractor.cc:1107-1132, cv::resize)
-//   k_blur           7x7 sigma-2 fixed-point Gaussian, LDS tiled          (ORBextractor.cc:1085-1086, cv::GaussianBlur)
+//   k_blur_mfma      7x7 sigma-2 fixed-point Gaussian as two banded i8 products on the matrix cores, LDS staged (default)
+//   k_blur           the same on the VALU (ORBHIP_BLUR=valu)             (ORBextractor.cc:1085-1086, cv::GaussianBlur)
 //   k_fast_cells     ONE WAVEFRONT PER GRID CELL: FAST-9/16 scores in LDS, iniTh/minTh fallback, 3x3 NMS inside
 //                    the cell, row-major emission                          (ORBextractor.cc:789-829, cv::FAST)
 //   k_quadtree       one workgroup per (frame, level): DistributeOctTree replayed with exact list order
 //                    (ORBextractor.cc:539-763) on per-candidate quad-path codes instead of std::list nodes
-//   k_describe       one wavefront per keypoint: IC_Angle, fastAtan2, steered BRIEF via 4 ballots
+//   k_describe       one wavefront per four keypoint slots: IC_Angle, fastAtan2, steered BRIEF via 4 ballots
 //                    (ORBextractor.cc:77-147, 1034-1104)
 // Everything is integer / bitwise except the orientation and the pattern rotation, which use explicitly
 // rounded IEEE ops (__fmul_rn ...; file built with -ffp-contract=off) so results are bit-identical to the CPU
-// oracle's two-rounding form.  No MFMA: nothing here is GEMM-shaped.
+// oracle's two-rounding form.  The one GEMM-shaped piece is the blur (a banded product, exact in i8): it runs on MFMA.
 #include "orbhip_internal.h"
 #include <type_traits>
 
