@@ -3,7 +3,8 @@
 //
 //   k_hamming_nn / k_hamming_merge   brute-force 256-bit Hamming NN, queries in registers, DB rows broadcast from LDS,
 //                                    __popcll on 4 x u64 per pair (ORBmatcher::DescriptorDistance, ORBmatcher.cc:1647-1663;
-//                                    best/second idiom :102-114, :447-456).  Integer-VALU bound (v_xor + v_bcnt), no MFMA.
+//                                    best/second idiom :102-114, :447-456).  Integer-VALU bound (v_xor + v_bcnt); small databases.
+//   k_hamming_nn_mfma                the same scan as +-1 i8 products on the matrix cores (databases from 32 K rows on)
 //   k_match_grid                     Frame::AssignFeaturesToGrid (Frame.cc:230-245, 382-392): 64x48 buckets, keypoint order
 //   k_match_candidates               Frame::GetFeaturesInArea (Frame.cc:327-380) in canonical order + all Hamming distances,
 //                                    one wavefront per previous-frame keypoint; also records each key point's four best candidates
@@ -12,6 +13,9 @@
 //                                    skipped once matched at a distance <= the query's), rescans the rare key point whose records
 //                                    are used up, then rotation histogram, ComputeThreeMaxima (:1601-1642), vbPrevMatched update.
 #include "orbhip_internal.h"
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
 
 #define WAVE 64
 #define IMAX 0x7fffffff
@@ -72,6 +76,123 @@ __global__ __launch_bounds__(NN_T) void k_hamming_nn(const unsigned long long* q
         }
 }
 
+// ---- the same scan on the matrix cores.  With descriptor bits as +-1, <a, b> = 256 - 2 * Hamming(a, b): the distance table of 32 DB rows x
+// 32 queries is one 32 x 32 x 256 i8 product (8 x v_mfma_i32_32x32x32_i8), exact, and the popcount formulation's ceiling (1.7e12 pair
+// distances/s, VALU-bound on v_xor + v_bcnt) does not apply.  A workgroup keeps 256 queries as B operands in registers (4 waves x 2 tiles of
+// 32 queries, lane = query) and streams its chunk of DB rows: 32 rows at a time are expanded from bits to +-1 bytes through a 256-entry LDS
+// table (once per workgroup, shared by its eight query tiles) and read back as A operands (lane = row, bytes = 16 bits of one dword).
+// The result leaves with lane = query, register = DB row, so the running (best, second) keys of a query are two registers of its lane:
+//   key = distance << 13 | row-in-chunk = C_row + (-dot << 12)  (one v_lshl_add_u32; the queries are expanded with the opposite sign),   second = min(second, max(best, key)), best = min(best, key)
+// exactly as in k_hamming_nn, whose partial format and merge kernel are reused.
+typedef int nn_v4i __attribute__((vector_size(16)));
+typedef int nn_v16i __attribute__((vector_size(64)));
+#define NNM_QT 2                        // query tiles (of 32) per wavefront
+#define NNM_QG (4 * NNM_QT * 32)        // queries per workgroup
+__global__ __launch_bounds__(256, 2) void k_hamming_nn_mfma(const unsigned* q, int nq, const unsigned* db, long long ndb, long long base, NNPart* parts, int nchunks)
+{
+    __shared__ unsigned long long s_tab[256];                          // byte -> its 8 bits as +-1 bytes
+    __shared__ __attribute__((aligned(16))) unsigned s_a[2][16 * 32 * 4];   // expanded DB tile: [K block kb][lane half h][row i] x 16 bytes, double-buffered
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), chunk = blockIdx.y;
+    {
+        unsigned long long e = 0;
+#pragma unroll
+        for (int t = 0; t < 8; t++) e |= (unsigned long long)(((tid >> t) & 1) ? 0x01u : 0xffu) << (8 * t);
+        s_tab[tid] = e;
+    }
+    __syncthreads();
+    const int j = lane & 31, h = lane >> 5;
+    // ---- the wave's queries as B operands: lane (j, h), K block kb = bits 16h .. 16h+15 of dword kb of query j
+    nn_v4i B[NNM_QT][8];
+    int qidx[NNM_QT];
+#pragma unroll
+    for (int t = 0; t < NNM_QT; t++) {
+        qidx[t] = blockIdx.x * NNM_QG + (wave * NNM_QT + t) * 32 + j;
+        const unsigned* qp = q + (long long)min(qidx[t], nq - 1) * 8;
+#pragma unroll
+        for (int kb = 0; kb < 8; kb++) {
+            const unsigned half = (qp[kb] >> (16 * h)) & 0xffffu;
+            // the queries carry the opposite sign (+-1 bytes: x ^ 0xfe), so the product is -dot and key = C_row + (product << 12) is one v_lshl_add_u32
+            const unsigned long long lo = s_tab[half & 0xff] ^ 0xfefefefefefefefeull, hi = s_tab[half >> 8] ^ 0xfefefefefefefefeull;
+            B[t][kb] = nn_v4i{(int)(unsigned)lo, (int)(unsigned)(lo >> 32), (int)(unsigned)hi, (int)(unsigned)(hi >> 32)};
+        }
+    }
+    unsigned kbest[NNM_QT], ksec[NNM_QT];
+#pragma unroll
+    for (int t = 0; t < NNM_QT; t++) { kbest[t] = 0xffffffffu; ksec[t] = 0xffffffffu; }
+    const long long row0 = (long long)chunk * NN_CHUNK;
+    const int nrows = (int)min((long long)NN_CHUNK, ndb - row0);
+    const int ntiles = (nrows + 31) >> 5;
+    // staging role of this thread: row r of the tile, dword kb of that row
+    const int sr = tid & 31, skb = tid >> 5;
+    auto stage = [&](int tile, int buf) {
+        const int r = tile * 32 + sr;
+        const unsigned w = r < nrows ? db[(row0 + r) * 8 + skb] : 0u;
+        const unsigned long long e0 = s_tab[w & 0xff], e1 = s_tab[(w >> 8) & 0xff], e2 = s_tab[(w >> 16) & 0xff], e3 = s_tab[w >> 24];
+        unsigned* d0 = s_a[buf] + ((skb * 2 + 0) * 32 + sr) * 4;        // bits 0..15 -> lane half 0
+        unsigned* d1 = s_a[buf] + ((skb * 2 + 1) * 32 + sr) * 4;        // bits 16..31 -> lane half 1
+        *reinterpret_cast<uint4*>(d0) = uint4{(unsigned)e0, (unsigned)(e0 >> 32), (unsigned)e1, (unsigned)(e1 >> 32)};
+        *reinterpret_cast<uint4*>(d1) = uint4{(unsigned)e2, (unsigned)(e2 >> 32), (unsigned)e3, (unsigned)(e3 >> 32)};
+    };
+    // C_row of register reg: (256 << 12) + row-in-chunk of D's row (reg & 3) + 8 (reg >> 2) + 4 h; rows past the chunk get a key no real one beats
+    const nn_v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int crow[16];
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) crow[reg] = (256 << 12) + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    // best two of three keys in two instructions (v_min3 / v_med3), then (best, second) pairs merged in three
+    auto top2_of3 = [](unsigned a, unsigned b, unsigned c, unsigned& lo, unsigned& mid) { lo = min(min(a, b), c); mid = max(min(a, b), min(max(a, b), c)); };
+    auto merge2 = [](unsigned& b, unsigned& s2, unsigned ob, unsigned os) { s2 = min(min(s2, os), max(b, ob)); b = min(b, ob); };
+    // one tile of 32 DB rows against the wave's query tiles; `ragged` (compile-time) = the chunk's last, partial tile
+    auto do_tile = [&](int tile, auto ragged) {
+        const int buf = tile & 1;
+        if (tile + 1 < ntiles) stage(tile + 1, buf ^ 1);
+        nn_v16i acc[NNM_QT];
+#pragma unroll
+        for (int t = 0; t < NNM_QT; t++) acc[t] = zero;
+#pragma unroll
+        for (int kb = 0; kb < 8; kb++) {
+            const nn_v4i A = *reinterpret_cast<const nn_v4i*>(s_a[buf] + ((kb * 2 + h) * 32 + j) * 4);     // lane (i = j, h): row i of the tile
+#pragma unroll
+            for (int t = 0; t < NNM_QT; t++) acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B[t][kb], acc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < NNM_QT; t++) {
+            unsigned x[16];
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                x[reg] = ((unsigned)acc[t][reg] << 12) + (unsigned)crow[reg];                                // acc = -dot: (256 - dot) / 2 << 13 | row
+                if (decltype(ragged)::value && tile * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h >= nrows) x[reg] = 0x7f000000u + (unsigned)reg;
+            }
+            unsigned b, s2;
+            top2_of3(x[0], x[1], x[2], b, s2);
+#pragma unroll
+            for (int g = 1; g < 5; g++) { unsigned lo, mid; top2_of3(x[3 * g], x[3 * g + 1], x[3 * g + 2], lo, mid); merge2(b, s2, lo, mid); }
+            merge2(b, s2, x[15], 0xffffffffu);
+            merge2(kbest[t], ksec[t], b, s2);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) crow[reg] += 32;
+        __syncthreads();
+    };
+    stage(0, 0);
+    __syncthreads();
+    const int nfull = nrows >> 5;
+    for (int tile = 0; tile < nfull; tile++) do_tile(tile, std::false_type{});
+    if (nfull < ntiles) do_tile(nfull, std::true_type{});
+    // ---- a query's rows were split over its two lanes (j, 0) and (j, 1): fold, then one partial per (query, chunk)
+#pragma unroll
+    for (int t = 0; t < NNM_QT; t++) {
+        const unsigned ob = (unsigned)__shfl_xor((int)kbest[t], 32), os = (unsigned)__shfl_xor((int)ksec[t], 32);
+        const unsigned b = min(kbest[t], ob), s2 = min(min(ksec[t], os), max(kbest[t], ob));
+        if (h == 0 && qidx[t] < nq) {
+            NNPart p;
+            p.best = b >= 0x7f000000u ? IMAX : (int)(b >> 13);
+            p.second = s2 >= 0x7f000000u ? IMAX : (int)(s2 >> 13);
+            p.idx = b >= 0x7f000000u ? -1 : row0 + (long long)(b & 0x1fffu) + base;
+            parts[(long long)qidx[t] * nchunks + chunk] = p;
+        }
+    }
+}
+
 // fold the per-chunk partials of one query in ascending DB order: stable arg-min + second smallest of the multiset
 __device__ __forceinline__ void nn_combine(int& b, long long& i, int& s, int rb, long long ri, int rs)
 {
@@ -102,9 +223,16 @@ bool orbhip_launch_hamming_nn(const uint8_t* d_q, int nq, const uint8_t* d_db, l
     const int nchunks = (int)max(1LL, (ndb + NN_CHUNK - 1) / NN_CHUNK);
     NNPart* parts = (NNPart*)orbhip_nn_workspace(sizeof(NNPart) * (size_t)nq * nchunks, s);
     if (!parts) return false;                                    // the caller reports it: results would be left unwritten
-    const int qblocks = (nq + NN_T * NN_QPT - 1) / (NN_T * NN_QPT);
-    hipLaunchKernelGGL(k_hamming_nn, dim3(qblocks, nchunks, 1), dim3(NN_T, 1, 1), 0, s, (const unsigned long long*)d_q, nq,
-                       (const unsigned long long*)d_db, ndb, base, parts, nchunks);
+    // the matrix-core scan from a few chunks on (below that a call is latency, not throughput); ORBHIP_NN=valu (measurement only) keeps the popcount kernel
+    static const bool force_valu = [] { const char* e = getenv("ORBHIP_NN"); return e && strcmp(e, "valu") == 0; }();
+    if (!force_valu && ndb >= 4 * NN_CHUNK) {
+        hipLaunchKernelGGL(k_hamming_nn_mfma, dim3((nq + NNM_QG - 1) / NNM_QG, nchunks, 1), dim3(256, 1, 1), 0, s, (const unsigned*)d_q, nq,
+                           (const unsigned*)d_db, ndb, base, parts, nchunks);
+    } else {
+        const int qblocks = (nq + NN_T * NN_QPT - 1) / (NN_T * NN_QPT);
+        hipLaunchKernelGGL(k_hamming_nn, dim3(qblocks, nchunks, 1), dim3(NN_T, 1, 1), 0, s, (const unsigned long long*)d_q, nq,
+                           (const unsigned long long*)d_db, ndb, base, parts, nchunks);
+    }
     hipLaunchKernelGGL(k_hamming_merge, dim3((nq + 3) / 4, 1, 1), dim3(256, 1, 1), 0, s, (const NNPart*)parts, nq, nchunks, d_best_idx, d_best_dist, d_second);
     return true;
 }

@@ -713,9 +713,10 @@ def hamming_nn(q, db, device=0, index_base=0, library=None):
 
 
 def hamming_nn_device(stream, d_q, nq, d_db, ndb, d_best_idx, d_best_dist, d_second, index_base=0, library=None):
-    _check(lib(library).orbhip_hamming_nn_device(C.c_void_p(stream) if stream else None, C.c_void_p(d_q), nq, C.c_void_p(d_db), ndb,
-                                          index_base, C.c_void_p(d_best_idx), C.c_void_p(d_best_dist), C.c_void_p(d_second)),
-           "orbhip_hamming_nn_device", self.L)
+    L = lib(library)
+    _check(L.orbhip_hamming_nn_device(C.c_void_p(stream) if stream else None, C.c_void_p(d_q), nq, C.c_void_p(d_db), ndb,
+                                      index_base, C.c_void_p(d_best_idx), C.c_void_p(d_best_dist), C.c_void_p(d_second)),
+           "orbhip_hamming_nn_device", L)
 
 
 class ORBVocabulary:

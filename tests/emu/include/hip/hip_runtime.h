@@ -216,6 +216,7 @@ inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned mask, unsigned base) { const 
 // global_load_lds_dword (LDS-DMA): lane l's dword lands at LDS dword l of the block; s_waitcnt is a no-op here
 inline void __builtin_amdgcn_global_load_lds(const void* gsrc, void* lds_block, unsigned size, int offset, unsigned) { memcpy((char*)lds_block + offset + (size_t)__lane_id() * size, (const char*)gsrc + offset, size); }
 inline void __builtin_amdgcn_s_waitcnt(int) {}
+inline int __mul24(int a, int b) { return a * b; }
 inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 // v_readfirstlane_b32: the kernels only apply it to wave-uniform values (to move them to the scalar unit)
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }

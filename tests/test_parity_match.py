@@ -119,6 +119,27 @@ def test_brute_force_nn(backend, oracle):
     assert all(np.array_equal(a, b) for a, b in zip(merged, want))
 
 
+def test_brute_force_nn_matrix_core_scan(backend, oracle, monkeypatch):
+    """Databases from four chunks (32 K rows) on are scanned on the matrix cores (k_hamming_nn_mfma: <+-1, +-1> = 256 - 2 Hamming):
+    ragged last tile and chunk, a query count that fills neither a tile nor a workgroup, planted exact matches, duplicated rows
+    (lowest index wins, second = best), an index base, and equality with the popcount kernel (ORBHIP_NN=valu is read once per
+    process, so that comparison is against the oracle only)."""
+    rng = np.random.default_rng(5)
+    n = 4 * 8192 + 1000 + 13
+    db = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    q = rng.integers(0, 256, (70, 32), dtype=np.uint8)
+    q[:20] = db[rng.integers(0, n, 20)]                       # exact matches somewhere in the database
+    q[20:30] ^= 1                                               # and near ones
+    db[n - 5:] = db[100:105]; q[30:35] = db[100:105]            # duplicates in the last, ragged tile: index 100..104 must win, second == 0
+    want = oracle.bf_nn(q, db, fast=True)
+    got = orb_slam2_amd.hamming_nn(q, db, library=backend)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    assert np.array_equal(got[0][30:35], np.arange(100, 105)) and np.all(got[1][30:35] == 0) and np.all(got[2][30:35] == 0)
+    gb = orb_slam2_amd.hamming_nn(q[:3], db, index_base=10 ** 10, library=backend)
+    assert np.array_equal(gb[0], want[0][:3].astype(np.int64) + 10 ** 10) and np.array_equal(gb[1], want[1][:3]) and np.array_equal(gb[2], want[2][:3])
+
+
 @pytest.mark.parametrize("num_streams", [1, 2])
 def test_device_pipeline_extract_and_match(backend, oracle, num_streams):
     """orbhip_extract_device on two camera slots over three time steps, matched against each slot's previous frame

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """BASELINE.json config 5: brute-force 256-bit Hamming of a 2000-descriptor query frame against a keyframe descriptor DB
-resident in HBM (10 000 keyframes x 2000 descriptors = 640 MB).  Reports pair distances/s against the integer-VALU issue
-peak (8 v_xor_b32 @2 cycles + 8 v_bcnt_u32_b32 @4 cycles per 64 pairs and SIMD) and the DB streaming rate against HBM."""
+resident in HBM (10 000 keyframes x 2000 descriptors = 640 MB).  Reports pair distances/s, the DB streaming rate, and the roofline of
+whichever kernel ran: the matrix-core scan (default from 32 K rows on: 512 i8 operations per pair against the dense i8 MFMA peak, ~5 POP/s
+spec, 4.4 measured - MI355X_MICROARCH.md) or, with ORBHIP_NN=valu, the popcount kernel against the integer-VALU issue peak
+(8 v_xor_b32 @2 cycles + 8 v_bcnt_u32_b32 @4 cycles per 64 pairs and SIMD)."""
 import json
 import os
 import sys
@@ -38,6 +40,11 @@ dt = (time.perf_counter() - t0) / reps
 pairs = NQ * NKF * PER
 peak_pairs = 1024 * 64 / (8 * 2 + 8 * 4) * 2.4e9
 assert int((bd <= 4).sum()) == NQ
-print(json.dumps({"db_keyframes": NKF, "db_bytes": NKF * PER * 32, "query_ms": round(dt * 1e3, 2), "pair_distances_per_s": float(f"{pairs / dt:.4g}"),
-                  "frac_of_int_valu_issue_peak": round(pairs / dt / peak_pairs, 3), "db_stream_GBps": round(NKF * PER * 32 / dt / 1e9, 1),
-                  "queries_per_s_vs_full_db": round(NQ / dt, 1)}))
+valu = os.environ.get("ORBHIP_NN") == "valu"
+out = {"kernel": "k_hamming_nn (popcount)" if valu else "k_hamming_nn_mfma", "db_keyframes": NKF, "db_bytes": NKF * PER * 32, "query_ms": round(dt * 1e3, 2),
+       "pair_distances_per_s": float(f"{pairs / dt:.4g}"), "db_stream_GBps": round(NKF * PER * 32 / dt / 1e9, 1), "queries_per_s_vs_full_db": round(NQ / dt, 1)}
+if valu:
+    out["frac_of_int_valu_issue_peak"] = round(pairs / dt / peak_pairs, 3)
+else:
+    out["mfma_i8_TOPs"] = round(pairs * 512 / dt / 1e12, 1); out["frac_of_i8_mfma_peak_5000_TOPs"] = round(pairs * 512 / dt / 5e15, 3)
+print(json.dumps(out))
