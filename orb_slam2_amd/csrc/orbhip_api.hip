@@ -82,6 +82,7 @@ struct orbhip_ctx {
     int sched = 0;            // ORBHIP_SCHED (measurement only): what runs on the second stream, see pipeline_frames
     int blur_tiles_l0 = 0;    // blur tiles of level 0 (the tile list is level-major)
     hipEvent_t ev_start = nullptr, ev_fast0 = nullptr;
+    bool pyr_tail = false;    // ORBHIP_PYR_TAIL=1 (measurement only): the last pyramid levels in one launch, see launch_pyramid
     uint8_t* d_in = nullptr; uint8_t* h_in = nullptr; uint8_t* d_col = nullptr; uint8_t* h_col = nullptr; size_t col_bytes = 0; orbhip_keypoint* h_kp = nullptr; uint8_t* h_desc = nullptr; int* h_n = nullptr; int in_pitch = 0;
     // stereo (Frame::ComputeStereoMatches): level-0 source of the last call + lazily allocated workspace on the LEFT context
     const uint8_t* last_img0 = nullptr; long long last_img0_fstride = 0; int last_img0_pitch = 0;
@@ -425,6 +426,7 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
     }
     if (!c->xstreams.empty() && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { orbhip_destroy(c); return fail(ORBHIP_ERR_HIP, "event creation failed"); }
     { const char* e = getenv("ORBHIP_SERIAL"); c->serial = e && e[0] == '1'; }
+    { const char* e = getenv("ORBHIP_PYR_TAIL"); c->pyr_tail = e && e[0] == '1'; }
     { const char* e = getenv("ORBHIP_SCHED"); c->sched = e ? atoi(e) : 0; }
     for (const TileDesc& t : c->blur_tiles) if (t.level == 0) c->blur_tiles_l0++;
     if (hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_fast0, hipEventDisableTiming) != hipSuccess) { orbhip_destroy(c); return fail(ORBHIP_ERR_HIP, "event creation failed"); }
@@ -546,6 +548,19 @@ static ExtractParams make_params(orbhip_ctx* c, const uint8_t* d_img0, long long
     return P;
 }
 
+// levels 1 .. L-1, each from the one before.  ORBHIP_PYR_TAIL=1 (measurement only) sends the small levels at the end (up to four, all in 4-pixel-group
+// mode, from 64 frames on) through ONE launch (k_pyramid_tail_g: a workgroup per frame): 11 -> 8 launches per extraction step, but measured
+// twice as slow as the separate launches (pyramid 0.27 -> 0.54 ms at B = 256, 167 k -> 133 k frames/s at B = 512, gpurun tl1): a single workgroup
+// per frame walks stage / barrier / compute / barrier / fence per tile group with nothing to hide the latency behind.  Off by default.
+static void launch_pyramid(orbhip_ctx* c, const ExtractParams& P, int nf, hipStream_t s)
+{
+    int tail0 = c->L;
+    if (nf >= 64 && c->pyr_tail) { while (tail0 - 1 >= 1 && c->L - (tail0 - 1) <= 4 && c->pyr_staged[tail0 - 1] == 2 && c->geom[tail0 - 1].w * c->geom[tail0 - 1].h <= 160 * 1024) tail0--; }
+    if (c->L - tail0 < 2) tail0 = c->L;
+    for (int l = 1; l < tail0; l++) orbhip_launch_pyramid_level(P, l, c->geom[l].w, c->geom[l].h, (int)c->pyr_staged[l], nf, s);
+    if (tail0 < c->L) orbhip_launch_pyramid_tail(P, tail0, nf, s);
+}
+
 // pyramid -> FAST -> quadtree -> describe for camera slots [f0, f0 + nf) on stream s.  With own_blur_stream the context's second stream
 // takes what does not depend on the main chain's current step (ORBHIP_SCHED, measured at B = 512 with the round-2 kernels, gpurun s3):
 //   0 (default): the blur beside the quadtree, whose workgroups are latency-bound (barriers, one per (frame, level))      167.7 k frames/s
@@ -565,7 +580,7 @@ static orbhip_status pipeline_frames(orbhip_ctx* c, ExtractParams& P, int f0, in
         HIPCHK(hipEventRecord(c->ev_start, s)); HIPCHK(hipStreamWaitEvent(bs, c->ev_start, 0));
         { ProfScope ps(c, K_FAST, bs); orbhip_launch_fast_cells(P, nf, bs, 0, nc0); }
         HIPCHK(hipEventRecord(c->ev_fast0, bs));
-        { ProfScope ps(c, K_PYRAMID, s); for (int l = 1; l < c->L; l++) orbhip_launch_pyramid_level(P, l, c->geom[l].w, c->geom[l].h, (int)c->pyr_staged[l], nf, s); }
+        { ProfScope ps(c, K_PYRAMID, s); launch_pyramid(c, P, nf, s); }
         HIPCHK(hipEventRecord(c->ev_pyr, s)); HIPCHK(hipStreamWaitEvent(bs, c->ev_pyr, 0));
         { ProfScope ps(c, K_BLUR, bs); orbhip_launch_blur(P, c->gk, nf, bs); }
         HIPCHK(hipEventRecord(c->ev_blur, bs));
@@ -577,7 +592,7 @@ static orbhip_status pipeline_frames(orbhip_ctx* c, ExtractParams& P, int f0, in
         hipStream_t bs = c->bstream;
         HIPCHK(hipEventRecord(c->ev_start, s)); HIPCHK(hipStreamWaitEvent(bs, c->ev_start, 0));
         { ProfScope ps(c, K_BLUR, bs); orbhip_launch_blur(P, c->gk, nf, bs, 0, nt0); }
-        { ProfScope ps(c, K_PYRAMID, s); for (int l = 1; l < c->L; l++) orbhip_launch_pyramid_level(P, l, c->geom[l].w, c->geom[l].h, (int)c->pyr_staged[l], nf, s); }
+        { ProfScope ps(c, K_PYRAMID, s); launch_pyramid(c, P, nf, s); }
         HIPCHK(hipEventRecord(c->ev_pyr, s)); HIPCHK(hipStreamWaitEvent(bs, c->ev_pyr, 0));
         { ProfScope ps(c, K_BLUR, bs, 0); orbhip_launch_blur(P, c->gk, nf, bs, nt0, nt1); }
         HIPCHK(hipEventRecord(c->ev_blur, bs));
@@ -585,7 +600,7 @@ static orbhip_status pipeline_frames(orbhip_ctx* c, ExtractParams& P, int f0, in
         { ProfScope ps(c, K_QUADTREE, s); orbhip_launch_quadtree(P, nf, s); }
         HIPCHK(hipStreamWaitEvent(s, c->ev_blur, 0));
     } else {
-        { ProfScope ps(c, K_PYRAMID, s); for (int l = 1; l < c->L; l++) orbhip_launch_pyramid_level(P, l, c->geom[l].w, c->geom[l].h, (int)c->pyr_staged[l], nf, s); }
+        { ProfScope ps(c, K_PYRAMID, s); launch_pyramid(c, P, nf, s); }
         { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nf, s); }
         if (own_blur_stream) {
             hipStream_t bs = c->serial ? s : c->bstream;

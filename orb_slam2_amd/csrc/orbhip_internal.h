@@ -137,6 +137,7 @@ size_t orbhip_proj_select_lds(int n);
 // kernel launchers (orbhip_kernels_extract.hip / orbhip_kernels_match.hip)
 void orbhip_launch_pyramid_level(const ExtractParams& P, int level, int w, int h, int mode, int nframes, hipStream_t s);
 int orbhip_pyramid_tile_dwords();
+void orbhip_launch_pyramid_tail(const ExtractParams& P, int level0, int nframes, hipStream_t s);    // levels level0 .. L-1 (all in 4-pixel-group mode) in one launch
 int orbhip_blur_mfma_tile_w();
 int orbhip_blur_mfma_tile_h();
 bool orbhip_pyramid_tile_fits(int src_cols_per_tile, int src_rows_per_tile);

@@ -75,3 +75,20 @@ def test_slot_counts_not_multiples_of_four(backend, oracle, n):
     kg, dg = ex(img)
     _same(kg, dg, ko, do)
     ex.close()
+
+
+def test_fused_pyramid_tail_from_64_frames_on(backend, oracle, env):
+    """ORBHIP_PYR_TAIL=1 (an opt-in experiment, slower than the default): from 64 frames on the last (up to four) pyramid levels are built by one
+    launch (k_pyramid_tail_g: a 1024-thread workgroup per frame walks the levels, re-reading each from global memory behind a device-scope fence)."""
+    env(ORBHIP_PYR_TAIL=1)
+    w, h, n, B = 320, 240, 300, 64
+    imgs = np.stack([synth.frame(w, h, seed=900 + s) for s in range(B)])
+    ex = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, max_batch=B, library=backend)
+    kps, descs = ex.extract_batch(imgs)
+    for f in (0, 31, 63):
+        ora = oracle.OracleExtractor(n, 1.2, 8, 20, 7)
+        ko, do = ora.extract(imgs[f])
+        for l in range(1, 8):
+            assert np.array_equal(ex.mvImagePyramid(l, frame=f), ora.level(l)), f"frame {f} pyramid level {l}"
+        _same(kps[f], descs[f], ko, do)
+    ex.close()
