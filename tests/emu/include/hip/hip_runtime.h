@@ -3,13 +3,12 @@
 // Purpose: this container has no GPU.  To debug kernel LOGIC (index math, barriers, wave collectives,
 // list-order semantics) before spending scarce GPU minutes, tests/emu builds the unmodified product sources
 // (orb_slam2_amd/csrc/*.hip, *.cpp) with g++ against this header and runs every workgroup as a set of
-// cooperatively scheduled fibers (ucontext).  __syncthreads and the wave64 collectives (__ballot, __shfl*,
+// cooperatively scheduled fibers (a hand-written x86-64 context switch).  __syncthreads and the wave64 collectives (__ballot, __shfl*,
 // __any/__all) are rendezvous points.  It is NOT a product path, NOT a CPU fallback and is never shipped or
 // benchmarked: liborbhip.so is built by hipcc for gfx950 only and fails loudly without a GPU.
 // Semantics emulated: wave = 64 consecutive threads of a block; collectives are assumed to be called
 // convergently by all live lanes of a wave (as on hardware, anything else is a kernel bug).
 #pragma once
-#include <ucontext.h>
 #include <time.h>
 #include <cstdint>
 #include <cstdlib>
@@ -52,25 +51,34 @@ struct hipDeviceProp_t { char name[256]; int multiProcessorCount; size_t totalGl
 namespace hipemu {
 
 struct Fiber {
-    ucontext_t ctx; char* stack = nullptr; bool done = false; uint3 tid; int lane, wave;
+    void* sp = nullptr; char* stack = nullptr; bool done = false; uint3 tid; int lane, wave;
 };
 struct Wave {
     int live = 0, arrived = 0; unsigned gen = 0;
     uint64_t in[64]; int src[64]; uint64_t out[64]; bool present[64];
 };
 struct Globals {
-    ucontext_t sched; Fiber* cur = nullptr; std::vector<Fiber> fibers; std::vector<Wave> waves;
+    void* sched_sp = nullptr; Fiber* cur = nullptr; std::vector<Fiber> fibers; std::vector<Wave> waves;
     uint3 bid; dim3 bdim, gdim; int live = 0, bar_count = 0; unsigned bar_gen = 0;
     char* dyn_shared = nullptr; std::function<void()> body; size_t stack_size = 128 * 1024;
 };
 inline Globals g;
 inline std::mutex launch_mutex;          // one kernel at a time: the scheduler state above and the kernels' static __shared__ arrays are process-wide
 
-inline void yield() { swapcontext(&g.cur->ctx, &g.sched); }
+// Context switch of the cooperative fibers (x86-64 SysV): callee-saved registers + stack pointer, no system call.  glibc's swapcontext saves
+// and restores the signal mask with two rt_sigprocmask calls per switch, which was most of the emulation's run time (every wave collective
+// is 128 switches).
+__attribute__((naked, noinline)) static void switch_to(void** /*save_sp*/, void* /*load_sp*/) {
+    __asm__ volatile("pushq %rbp\n\tpushq %rbx\n\tpushq %r12\n\tpushq %r13\n\tpushq %r14\n\tpushq %r15\n\t"
+                     "movq %rsp, (%rdi)\n\tmovq %rsi, %rsp\n\t"
+                     "popq %r15\n\tpopq %r14\n\tpopq %r13\n\tpopq %r12\n\tpopq %rbx\n\tpopq %rbp\n\tret");
+}
+inline void yield() { switch_to(&g.cur->sp, g.sched_sp); }
 inline void fiber_main() {
     g.body();
     Fiber* f = g.cur; f->done = true; g.live--; g.waves[f->wave].live--;
-    swapcontext(&f->ctx, &g.sched);
+    switch_to(&f->sp, g.sched_sp);
+    abort();                                                           // a finished fiber is never resumed
 }
 inline void syncthreads() {
     unsigned gen = g.bar_gen; g.bar_count++;
@@ -109,11 +117,14 @@ void launch(K kernel, dim3 grid, dim3 block, size_t shmem, A... args) {
             Fiber& f = g.fibers[t]; f.done = false;
             f.tid = uint3{(unsigned)(t % block.x), (unsigned)((t / block.x) % block.y), (unsigned)(t / (block.x * block.y))};
             f.lane = t & 63; f.wave = t >> 6; g.waves[f.wave].live++;
-            getcontext(&f.ctx); f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = g.stack_size; f.ctx.uc_link = nullptr;
-            makecontext(&f.ctx, (void (*)())fiber_main, 0);
+            // first switch into the fiber pops six zeroed registers and returns into fiber_main with the stack the ABI expects at a function entry
+            void** sp = (void**)(((uintptr_t)(f.stack + g.stack_size) & ~(uintptr_t)15) - 64);
+            for (int k = 0; k < 6; k++) sp[k] = nullptr;
+            sp[6] = (void*)(void (*)())fiber_main; sp[7] = nullptr;
+            f.sp = sp;
         }
         while (g.live > 0)
-            for (int t = 0; t < T; t++) { Fiber& f = g.fibers[t]; if (f.done) continue; g.cur = &f; swapcontext(&g.sched, &f.ctx); }
+            for (int t = 0; t < T; t++) { Fiber& f = g.fibers[t]; if (f.done) continue; g.cur = &f; switch_to(&g.sched_sp, f.sp); }
     }
     g.cur = nullptr;
 }
