@@ -232,17 +232,71 @@ __device__ __forceinline__ void pyr_tile_compute(const ExtractParams& P, const L
         hp[0] = h1[0]; hp[1] = h1[1]; hp[2] = h1[2]; hp[3] = h1[3]; prow = rb;
     }
 }
+// LDS-DMA staging of a tile's source footprint, so that a workgroup can have the NEXT tile's rows in flight while it computes this one
+// (the loads never touch a VGPR): wave w brings rows w, w+4, ... (clamped to the footprint's last row), always 6 rows x 2 instructions
+// (dwords 0..63 and 64..83 of the LDS row), so "everything but the newest 12" is an exact s_waitcnt for the tile before.  A lane whose dword
+// is not entirely inside the source row re-reads the last one that is; pyr_dma_patch then writes the row's ragged last dword byte by byte.
+struct PyrSrc { const uint8_t* src; int spitch, ndw, nrows, dfull; };
+__device__ __forceinline__ PyrTile pyr_dma_issue(const ExtractParams& P, const LevelGeom& g, int level, int tile_x, int tile_y, int frame, int tid, unsigned* s_t, PyrSrc& S)
+{
+    PyrTile T; T.x0 = tile_x * PYR_TW; T.y0 = tile_y * PYR_TH;
+    S.src = level_src(P, frame, level - 1, S.spitch);
+    const int2* xt = P.xtab + g.xtab_off; const int2* yt = P.ytab + g.ytab_off;
+    const int xl = min(T.x0 + PYR_TW - 1, g.w - 1), yl = min(T.y0 + PYR_TH - 1, g.h - 1);
+    T.sxa = xt[T.x0].x & ~3; const int sxb = min(xt[xl].x + 1, g.src_w - 1);
+    T.sya = min(max(yt[T.y0].x, 0), g.src_h - 1); const int syb = min(max(yt[yl].x + 1, 0), g.src_h - 1);
+    S.ndw = ((sxb - T.sxa) >> 2) + 1; S.nrows = syb - T.sya + 1; S.dfull = (g.src_w - T.sxa) >> 2;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int dmax = max(S.dfull - 1, 0);
+    const unsigned off0 = 4u * (unsigned)min(lane, dmax), off1 = 4u * (unsigned)min(lane + 64, dmax);
+#pragma unroll
+    for (int j = 0; j < PYR_SROWS / 4; j++) {
+        const int r = wave + 4 * j;
+        const ORBHIP_GLOBAL uint8_t* row = uniform_ptr(S.src + (long long)(T.sya + min(r, S.nrows - 1)) * S.spitch + T.sxa);
+        lds_dma_dword(row + off0, reinterpret_cast<uint8_t*>(s_t + r * PYR_SDW));
+        if (lane < PYR_SDW - 64) lds_dma_dword(row + off1, reinterpret_cast<uint8_t*>(s_t + r * PYR_SDW + 64));
+    }
+    return T;
+}
+__device__ __forceinline__ void pyr_dma_patch(const LevelGeom& g, const PyrTile& T, const PyrSrc& S, int tid, unsigned* s_t)
+{
+    const int part = g.src_w & 3;                                      // sxa is a multiple of 4
+    if (part == 0 || S.dfull >= S.ndw) return;                         // wave-uniform
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, r = wave + 4 * lane;
+    if (lane < PYR_SROWS / 4 && r < S.nrows) {
+        const uint8_t* row = S.src + (long long)(T.sya + r) * S.spitch + T.sxa + 4 * S.dfull;
+        unsigned w = 0;
+        for (int q = 0; q < part; q++) w |= (unsigned)row[q] << (8 * q);
+        s_t[r * PYR_SDW + S.dfull] = w;
+    }
+}
+#define PYR_NT 2                        // tiles (one below the other) per workgroup of k_pyramid_level_g
 __global__ __launch_bounds__(256) void k_pyramid_level_g(ExtractParams P, int level)
 {
     const LevelGeom g = P.geom[level];
-    const int gx = (g.w + PYR_TW - 1) / PYR_TW, gy = (g.h + PYR_TH - 1) / PYR_TH;
+    const int gx = (g.w + PYR_TW - 1) / PYR_TW, gy = (g.h + PYR_TH - 1) / PYR_TH, gyn = (gy + PYR_NT - 1) / PYR_NT;
     int tile, frame;
-    if (!xcd_frame_map(gx * gy, P.nframes, tile, frame)) return;
+    if (!xcd_frame_map(gx * gyn, P.nframes, tile, frame)) return;
     frame += P.frame0;
-    __shared__ unsigned s_t[PYR_SROWS * PYR_SDW];
-    const PyrTile T = pyr_tile_stage(P, g, level, tile, frame, threadIdx.y * 64 + threadIdx.x, s_t);
-    __syncthreads();
-    pyr_tile_compute(P, g, T, frame, threadIdx.x, __builtin_amdgcn_readfirstlane((int)threadIdx.y), s_t);
+    __shared__ unsigned s_t[2][PYR_SROWS * PYR_SDW];
+    const int tid = threadIdx.y * 64 + threadIdx.x, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.y);
+    const int tx = tile % gx;
+    int ty = (tile / gx) * PYR_NT;
+    const int tyend = min(ty + PYR_NT, gy);
+    PyrSrc S, Sn;
+    PyrTile T = pyr_dma_issue(P, g, level, tx, ty, frame, tid, s_t[0], S), Tn = T;
+    int buf = 0;
+    for (; ty < tyend; ty++) {
+        const bool more = ty + 1 < tyend;
+        if (more) Tn = pyr_dma_issue(P, g, level, tx, ty + 1, frame, tid, s_t[buf ^ 1], Sn);      // in flight during this tile's arithmetic
+        if (more) __builtin_amdgcn_s_waitcnt(ORBHIP_VMCNT(2 * (PYR_SROWS / 4))); else lds_dma_wait();
+        __builtin_amdgcn_wave_barrier();
+        pyr_dma_patch(g, T, S, tid, s_t[buf]);
+        __syncthreads();
+        pyr_tile_compute(P, g, T, frame, threadIdx.x, wv, s_t[buf]);
+        __syncthreads();
+        T = Tn; S = Sn; buf ^= 1;
+    }
 }
 
 // The small levels in ONE launch (opt-in experiment, ORBHIP_PYR_TAIL=1): a workgroup of 1024 threads owns one frame and computes levels
@@ -303,7 +357,8 @@ void orbhip_launch_pyramid_level(const ExtractParams& P, int level, int w, int h
 {   // mode 2: staged + 4-pixel groups, 1: staged, 0: straight from global memory
     ExtractParams Q = P; Q.nframes = nframes;
     dim3 grid(xcd_grid(((w + PYR_TW - 1) / PYR_TW) * ((h + PYR_TH - 1) / PYR_TH), nframes), 1, 1), block(64, 4, 1);
-    if (mode == 2) hipLaunchKernelGGL(k_pyramid_level_g, grid, block, 0, s, Q, level);
+    const int gyn = (((h + PYR_TH - 1) / PYR_TH) + PYR_NT - 1) / PYR_NT;
+    if (mode == 2) hipLaunchKernelGGL(k_pyramid_level_g, dim3(xcd_grid(((w + PYR_TW - 1) / PYR_TW) * gyn, nframes), 1, 1), block, 0, s, Q, level);
     else if (mode == 1) hipLaunchKernelGGL(k_pyramid_level, grid, block, 0, s, Q, level);
     else hipLaunchKernelGGL(k_pyramid_level_direct, grid, block, 0, s, Q, level);
 }
