@@ -247,8 +247,8 @@ __device__ __forceinline__ PyrTile pyr_dma_issue(const ExtractParams& P, const L
     T.sya = min(max(yt[T.y0].x, 0), g.src_h - 1); const int syb = min(max(yt[yl].x + 1, 0), g.src_h - 1);
     S.ndw = ((sxb - T.sxa) >> 2) + 1; S.nrows = syb - T.sya + 1; S.dfull = (g.src_w - T.sxa) >> 2;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int dmax = max(S.dfull - 1, 0);
-    const unsigned off0 = 4u * (unsigned)min(lane, dmax), off1 = 4u * (unsigned)min(lane + 64, dmax);
+    const int omax = g.src_w - 4 - T.sxa;                              // byte offset of the last dword that ends inside the row (negative when fewer than 4 columns remain: still in the row)
+    const int off0 = min(4 * lane, omax), off1 = min(4 * (lane + 64), omax);
 #pragma unroll
     for (int j = 0; j < PYR_SROWS / 4; j++) {
         const int r = wave + 4 * j;

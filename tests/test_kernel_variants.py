@@ -92,3 +92,19 @@ def test_fused_pyramid_tail_from_64_frames_on(backend, oracle, env):
             assert np.array_equal(ex.mvImagePyramid(l, frame=f), ora.level(l)), f"frame {f} pyramid level {l}"
         _same(kps[f], descs[f], ko, do)
     ex.close()
+
+
+@pytest.mark.parametrize("w,h", [(1230, 260), (617, 300)])      # level 1 = 1025 and 514 columns
+def test_pyramid_tiles_that_end_in_the_last_columns(backend, oracle, w, h):
+    """Level widths one or two columns past a multiple of the 256-column tile: the last tile stages a footprint that starts within three
+    bytes of the source row's end (the LDS-DMA lanes are clamped into the row, the ragged dword is patched byte by byte)."""
+    n = 400
+    img = synth.frame(w, h, seed=w)
+    ora = oracle.OracleExtractor(n, 1.2, 8, 20, 7)
+    ko, do = ora.extract(img)
+    ex = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, library=backend)
+    kg, dg = ex(img)
+    for l in range(1, 8):
+        assert np.array_equal(ex.mvImagePyramid(l), ora.level(l)), f"pyramid level {l} of {ora.level_size(l)}"
+    _same(kg, dg, ko, do)
+    ex.close()
