@@ -82,6 +82,8 @@ struct orbhip_ctx {
     int sched = 0;            // ORBHIP_SCHED (measurement only): what runs on the second stream, see pipeline_frames
     int blur_tiles_l0 = 0;    // blur tiles of level 0 (the tile list is level-major)
     hipEvent_t ev_start = nullptr, ev_fast0 = nullptr;
+    // ORBHIP_SCHED=3 (measurement only): the pyramid of call t+1 on its own stream beside the kernels of call t, into the other of two plane sets
+    uint8_t* d_pyr_sets[2] = {nullptr, nullptr}; int pyr_set = 0; hipStream_t pstream = nullptr; hipEvent_t ev_desc[2] = {nullptr, nullptr}, ev_pyr_ahead = nullptr; bool desc_pending[2] = {false, false};
     bool pyr_tail = false;    // ORBHIP_PYR_TAIL=1 (measurement only): the last pyramid levels in one launch, see launch_pyramid
     uint8_t* d_in = nullptr; uint8_t* h_in = nullptr; uint8_t* d_col = nullptr; uint8_t* h_col = nullptr; size_t col_bytes = 0; orbhip_keypoint* h_kp = nullptr; uint8_t* h_desc = nullptr; int* h_n = nullptr; int in_pitch = 0;
     // stereo (Frame::ComputeStereoMatches): level-0 source of the last call + lazily allocated workspace on the LEFT context
@@ -265,9 +267,12 @@ extern "C" void orbhip_destroy(orbhip_ctx* c)
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_fast0) (void)hipEventDestroy(c->ev_fast0);
+    if (c->pstream) { (void)hipStreamSynchronize(c->pstream); (void)hipStreamDestroy(c->pstream); }
+    for (int k = 0; k < 2; k++) if (c->ev_desc[k]) (void)hipEventDestroy(c->ev_desc[k]);
+    if (c->ev_pyr_ahead) (void)hipEventDestroy(c->ev_pyr_ahead);
     prof_collect(c);
     for (auto e : c->pool) (void)hipEventDestroy(e);
-    void* ptrs[] = {c->d_blur_band, c->d_ic_mask, c->d_xgrp, c->d_fc_dma, c->d_geom, c->d_cells, c->d_tiles, c->d_xtab, c->d_ytab, c->d_pattern, c->d_pyr, c->d_blur, c->d_cell_count, c->d_cell_cand,
+    void* ptrs[] = {c->d_blur_band, c->d_ic_mask, c->d_xgrp, c->d_fc_dma, c->d_geom, c->d_cells, c->d_tiles, c->d_xtab, c->d_ytab, c->d_pattern, c->d_pyr_sets[0], c->d_pyr_sets[1], c->d_blur, c->d_cell_count, c->d_cell_cand,
                     c->d_qt_val, c->d_qt_code, c->d_qt_node, c->d_lvl_kp, c->d_lvl_n[0], c->d_lvl_n[1], c->d_lvl_n[2], c->d_out_kp[0], c->d_out_kp[1], c->d_out_kp[2],
                     c->d_out_desc[0], c->d_out_desc[1], c->d_out_desc[2], c->d_out_n[0], c->d_out_n[1], c->d_out_n[2], c->d_grid_start, c->d_grid_items, c->d_grid_xy, c->d_cand, c->d_top, c->d_ncand,
                     c->d_prev, c->d_m12, c->d_nm};
@@ -481,6 +486,13 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
         TRY(upload(&c->d_fc_dma, tab));
     }
     TRY(dalloc(&c->d_pyr, B * c->plane_frame_bytes + 256)); TRY(dalloc(&c->d_blur, B * c->plane_frame_bytes + 256));
+    c->d_pyr_sets[0] = c->d_pyr;
+    if (c->sched == 3 && c->own_stream && c->mstream) {
+        TRY(dalloc(&c->d_pyr_sets[1], B * c->plane_frame_bytes + 256));
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->pstream, hipStreamNonBlocking);
+        for (int k = 0; k < 2 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&c->ev_desc[k], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_pyr_ahead, hipEventDisableTiming);
+    }
     TRY(dalloc(&c->d_cell_count, B * c->cells.size())); TRY(dalloc(&c->d_cell_cand, B * c->cand_slots_per_frame));
     TRY(dalloc(&c->d_qt_val, B * c->qt_per_frame)); TRY(dalloc(&c->d_qt_code, B * c->qt_per_frame)); TRY(dalloc(&c->d_qt_node, B * c->qt_per_frame));
     TRY(dalloc(&c->d_lvl_kp, B * c->lvl_kp_per_frame));
@@ -566,15 +578,18 @@ static void launch_pyramid(orbhip_ctx* c, const ExtractParams& P, int nf, hipStr
 //   0 (default): the blur beside the quadtree, whose workgroups are latency-bound (barriers, one per (frame, level))      167.7 k frames/s
 //   1: the blur beside pyramid + FAST (level 0 at once, the rest behind the pyramid)                                       168.2 k
 //   2: FAST of level 0 beside the pyramid (neither needs the other), then the blur beside FAST of the other levels         169.9 k
-// All three land within 1.3 %: the step is the sum of the kernels' standalone times whatever runs beside what.  0 keeps every throughput
-// kernel alone on the GPU, so its HIP-event time in the timed region is its own (the bench's roofline object relies on that).
-static orbhip_status pipeline_frames(orbhip_ctx* c, ExtractParams& P, int f0, int nf, hipStream_t s, bool own_blur_stream)
-{
+//   3: the pyramid of call t+1 on a stream of its own, into the other of two plane sets, beside the kernels of call t (device-resident
+//      entry only; + one plane set of memory): 171.7 k at B = 512 (+1.2 %), +1.9 % at B = 256, +4.2 % at B = 128 (gpurun s4)
+// 0-2 land within 1.3 %: the step is the sum of the kernels' standalone times whatever runs beside what.  0 keeps every throughput kernel
+// alone on the GPU, so its HIP-event time in the timed region is its own (the bench's roofline object relies on that; under 3 the previous
+// call's matcher moves from beside the pyramid to beside FAST, whose event time then reads 1.15 instead of 0.98 ms for the same work).
+static orbhip_status pipeline_frames(orbhip_ctx* c, ExtractParams& P, int f0, int nf, hipStream_t s, bool own_blur_stream, hipEvent_t pyr_done = nullptr)
+{   // pyr_done: the pyramid of these frames was launched elsewhere (ORBHIP_SCHED=3); s waits for it instead of building it
     if (nf <= 0) return ORBHIP_OK;
     P.frame0 = f0;
     const int nt0 = c->blur_tiles_l0, nt1 = (int)c->blur_tiles.size() - nt0;
     const int nc0 = c->geom[0].ncells, nc1 = (int)c->cells.size() - nc0;
-    const int sched = (own_blur_stream && !c->serial) ? c->sched : -1;
+    const int sched = (own_blur_stream && !c->serial && !pyr_done) ? c->sched : -1;
     if (sched == 2) {
         hipStream_t bs = c->bstream;
         HIPCHK(hipEventRecord(c->ev_start, s)); HIPCHK(hipStreamWaitEvent(bs, c->ev_start, 0));
@@ -600,7 +615,8 @@ static orbhip_status pipeline_frames(orbhip_ctx* c, ExtractParams& P, int f0, in
         { ProfScope ps(c, K_QUADTREE, s); orbhip_launch_quadtree(P, nf, s); }
         HIPCHK(hipStreamWaitEvent(s, c->ev_blur, 0));
     } else {
-        { ProfScope ps(c, K_PYRAMID, s); launch_pyramid(c, P, nf, s); }
+        if (pyr_done) HIPCHK(hipStreamWaitEvent(s, pyr_done, 0));
+        else { ProfScope ps(c, K_PYRAMID, s); launch_pyramid(c, P, nf, s); }
         { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nf, s); }
         if (own_blur_stream) {
             hipStream_t bs = c->serial ? s : c->bstream;
@@ -641,9 +657,22 @@ static orbhip_status run_pipeline(orbhip_ctx* c, int nimg, const uint8_t* d_img0
 {
     orbhip_status st = begin_batch(c, d_img0, frame_stride, row_stride); if (st != ORBHIP_OK) return st;
     const int cur = c->cur, prev = (cur + 2) % 3;
-    ExtractParams P = make_params(c, d_img0, frame_stride, row_stride);
     // camera slots are independent: optionally split the batch into groups, one HIP stream each
     const int ngroups = std::min((int)c->xstreams.size() + 1, nimg);
+    const bool ahead = c->pstream && ngroups == 1 && !c->serial;
+    if (ahead) { c->pyr_set ^= 1; c->d_pyr = c->d_pyr_sets[c->pyr_set]; }
+    ExtractParams P = make_params(c, d_img0, frame_stride, row_stride);
+    if (ahead) {
+        // this plane set was last read by the call before the previous one (its FAST / blur / describe are stream-ordered before ev_desc); the
+        // previous call's kernels are still running on the other set: that is what this pyramid overlaps with
+        const int set = c->pyr_set;
+        if (c->desc_pending[set]) HIPCHK(hipStreamWaitEvent(c->pstream, c->ev_desc[set], 0));
+        P.frame0 = 0;
+        { ProfScope ps(c, K_PYRAMID, c->pstream); launch_pyramid(c, P, nimg, c->pstream); }
+        HIPCHK(hipEventRecord(c->ev_pyr_ahead, c->pstream));
+        st = pipeline_frames(c, P, 0, nimg, c->stream, true, c->ev_pyr_ahead); if (st != ORBHIP_OK) return st;
+        HIPCHK(hipEventRecord(c->ev_desc[set], c->stream)); c->desc_pending[set] = true;
+    } else {
     if (ngroups > 1) { HIPCHK(hipEventRecord(c->ev_fork, c->stream)); }
     for (int gi = 0; gi < ngroups; gi++) {
         const int f0 = (int)((long long)nimg * gi / ngroups), f1 = (int)((long long)nimg * (gi + 1) / ngroups), nf = f1 - f0;
@@ -652,6 +681,7 @@ static orbhip_status run_pipeline(orbhip_ctx* c, int nimg, const uint8_t* d_img0
         if (nf <= 0) continue;
         st = pipeline_frames(c, P, f0, nf, s, ngroups == 1); if (st != ORBHIP_OK) return st;
         if (gi > 0) { HIPCHK(hipEventRecord(c->xevents[gi - 1], s)); HIPCHK(hipStreamWaitEvent(c->stream, c->xevents[gi - 1], 0)); }
+    }
     }
     if (match_prev) {
         MatchParams M; memset(&M, 0, sizeof M);
