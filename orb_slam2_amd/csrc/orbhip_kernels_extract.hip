@@ -549,8 +549,11 @@ __global__ __launch_bounds__(256, 5) void k_blur_mfma(ExtractParams P)
 {
     __shared__ __attribute__((aligned(16))) unsigned s_in[32 * BM_IN_DW];
     __shared__ unsigned s_out[BM_ROWS * BM_OUT_DW];
-    int tile, frame;
+    __shared__ __attribute__((aligned(16))) unsigned s_band[3 * 64 * 4];   // HB1 | HB2 | VB: fetched once per workgroup with coalesced 32-bit loads
+    int tile, frame;                                                        // (as three 128-bit loads per lane they cost each wave 3 x 71 cycles of the texture addresser)
     if (!xcd_frame_map(P.nblur_tiles, P.nframes, tile, frame)) return;
+#pragma unroll
+    for (int k = 0; k < 3; k++) s_band[256 * k + threadIdx.x] = reinterpret_cast<const unsigned*>(P.blur_band)[256 * k + threadIdx.x];
     frame += P.frame0;
     const TileDesc t = P.blur_tiles[tile];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -589,8 +592,7 @@ __global__ __launch_bounds__(256, 5) void k_blur_mfma(ExtractParams P)
     }
     __syncthreads();
     const int i = lane & 31, h = lane >> 5;
-    const int4 qb1 = P.blur_band[lane], qb2 = P.blur_band[64 + lane], qbv = P.blur_band[128 + lane];
-    const v4i HB1 = {qb1.x, qb1.y, qb1.z, qb1.w}, HB2 = {qb2.x, qb2.y, qb2.z, qb2.w}, VB = {qbv.x, qbv.y, qbv.z, qbv.w};
+    const v4i HB1 = *reinterpret_cast<const v4i*>(s_band + 4 * lane), HB2 = *reinterpret_cast<const v4i*>(s_band + 256 + 4 * lane), VB = *reinterpret_cast<const v4i*>(s_band + 512 + 4 * lane);
     const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // C operand = inline constant 0: the -128 of the operand bytes is undone on the VALU
     // x86 SSE2 build of OpenCV: cvtps2dq (round-half-even) on whole 4-column groups below w & ~3, the generic rounding behind them
     const int he_limit = P.blur_round_mode == 1 ? w4 : 0;
