@@ -201,12 +201,11 @@ __device__ __forceinline__ PyrTile pyr_tile_stage(const ExtractParams& P, const 
     pyr_stage(src, spitch, g.src_w, T.sxa, T.sya, ndw, nrows, aligned, tid, s_t);
     return T;
 }
-__device__ __forceinline__ void pyr_tile_compute(const ExtractParams& P, const LevelGeom& g, const PyrTile& T, int frame, int tx, int ty, const unsigned* s_t)
-{
+__device__ __forceinline__ void pyr_tile_compute(const ExtractParams& P, const LevelGeom& g, const PyrTile& T, int frame, int tx, int ty, const unsigned* s_t, const PyrGroup& G)
+{   // G = P.xgrp[g.xgrp_off + (x4 >> 2)], loaded by the caller (the same for every tile of a column of tiles)
     const int x4 = T.x0 + tx * 4;
     if (x4 >= g.w) return;
     const int2* yt = P.ytab + g.ytab_off;
-    const PyrGroup G = P.xgrp[g.xgrp_off + (x4 >> 2)];
     const unsigned sh = (unsigned)G.sx0 & 3u;                      // sxa is a multiple of 4
     const unsigned* colp = s_t + ((G.sx0 - T.sxa) >> 2);
     const unsigned omask = x4 + 4 <= g.w ? 0xffffffffu : (0xffffffffu >> (8 * (x4 + 4 - g.w)));
@@ -285,6 +284,7 @@ __global__ __launch_bounds__(256) void k_pyramid_level_g(ExtractParams P, int le
     const int tyend = min(ty + PYR_NT, gy);
     PyrSrc S, Sn;
     PyrTile T = pyr_dma_issue(P, g, level, tx, ty, frame, tid, s_t[0], S), Tn = T;
+    const PyrGroup G = P.xgrp[g.xgrp_off + min(tx * (PYR_TW / 4) + (int)threadIdx.x, (g.w - 1) >> 2)];      // this lane's four columns: the same in every tile below
     int buf = 0;
     for (; ty < tyend; ty++) {
         const bool more = ty + 1 < tyend;
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void k_pyramid_level_g(ExtractParams P, int le
         __builtin_amdgcn_wave_barrier();
         pyr_dma_patch(g, T, S, tid, s_t[buf]);
         __syncthreads();
-        pyr_tile_compute(P, g, T, frame, threadIdx.x, wv, s_t[buf]);
+        pyr_tile_compute(P, g, T, frame, threadIdx.x, wv, s_t[buf], G);
         __syncthreads();
         T = Tn; S = Sn; buf ^= 1;
     }
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(1024) void k_pyramid_tail_g(ExtractParams P, int le
             PyrTile T = {0, 0, 0, 0};
             if (tile < ntiles) T = pyr_tile_stage(P, g, level, tile, frame, tid, s_t[sub]);
             __syncthreads();
-            if (tile < ntiles) pyr_tile_compute(P, g, T, frame, threadIdx.x, ty, s_t[sub]);
+            if (tile < ntiles) { const PyrGroup G = P.xgrp[g.xgrp_off + min((T.x0 >> 2) + (int)threadIdx.x, (g.w - 1) >> 2)]; pyr_tile_compute(P, g, T, frame, threadIdx.x, ty, s_t[sub], G); }
             __syncthreads();
         }
         __threadfence();                                               // level l is complete and visible before anyone stages it as a source
