@@ -6,8 +6,10 @@ already resident in HBM): ORBextractor::operator() with 2000 features / 8 levels
 frame PLUS ORBmatcher(0.9,true).SearchForInitialization(F_{t-1}, F_t, window 100) of every slot against the frame the
 slot saw in the previous step (the unit of work).  value = frames of all ranks / max-over-ranks time.
 
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL, used ONLY for the barrier and the max-reduce of
-the timing): camera slots are independent, so ranks share nothing on the data path (no collective) -> weak scaling.
+N = 1 imports no framework: the frames are made resident through the library's own HIP runtime (orbhip_device_alloc), the one the tests,
+smoke() and a real ORB_SLAM2 binary run on.  N > 1: one process per GPU; the library is loaded first, torch.distributed afterwards
+(backend nccl = RCCL, used ONLY for the barrier and the max-reduce of the timing; gloo if RCCL will not start on the system runtime):
+camera slots are independent, so ranks share nothing on the data path (no collective) -> weak scaling.
 `python bench.py --gpus N` without a launcher (WORLD_SIZE unset) re-executes itself under torch.distributed.run with N ranks;
 it refuses to run when fewer than N GPUs are visible instead of reporting a 1-GPU number.
 
@@ -15,6 +17,9 @@ The timed region is `--repeats` (default 5) back-to-back measurements of EXACTLY
 barrier + synchronize; `value` / `ms_per_step` are the MEDIAN repeat, the spread is reported in `repeats`.
 
 Extra objects in the JSON line:
+  parity        key points, descriptors and matches12 of 4 camera slots of the LAST timed step compared bit for bit with the oracle, and
+                every replica slot of a scene with the first slot of that scene (whole batch); a mismatch marks the line INVALID
+  runtime       the HIP runtime the library ran on (versions, file), every libamdhip64 mapped into the process (must be one)
   roofline      dominant kernel (by HIP-event time measured inside the timed region on the library's stream):
                 algorithmic bytes per launch / average launch duration vs the 8 TB/s HBM peak
   cpu_baseline  the CPU path timed on this box's host cores on a bounded sample of the same workload (rank 0, N=1 only): the
@@ -158,6 +163,46 @@ def host_io(ex_resident, frames, device, blur_round_mode, budget_s=3.0):
     return out
 
 
+def parity_of_last_step(host_frames, kps, descs, m12, last_step, T, blur_round_mode, nslots):
+    """Bit-for-bit check of what the LAST timed step left in the context (the oracle is the checker, never the thing measured):
+    key points, descriptors and matches12 of `nslots` camera slots with distinct scenes against oracle.OracleExtractor /
+    search_for_initialization on the same frames, plus — size-independent, over the whole batch — every replica of a scene must equal
+    the first slot that holds that scene."""
+    from oracle import orb_oracle as O
+    O.build()
+    B = host_frames.shape[1]
+    nscenes = min(B, NSCENES)
+    t_cur, t_prev = last_step % T, (last_step - 1) % T
+    ora = O.OracleExtractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, blur_round_mode=blur_round_mode)
+    slots = [int(v) for v in np.linspace(0, nscenes - 1, min(nslots, nscenes)).round()]
+    mism, detail = 0, []
+    for b in slots:
+        k2, d2 = ora.extract(np.ascontiguousarray(host_frames[t_cur, b, :, :W]))
+        bad = []
+        if kps[b].tobytes() != k2.tobytes():
+            bad.append("keypoints")
+        if not np.array_equal(descs[b], d2):
+            bad.append("descriptors")
+        if m12[b] is not None and last_step > 0:
+            k1, d1 = ora.extract(np.ascontiguousarray(host_frames[t_prev, b, :, :W]))
+            n_o, m_o, _ = O.search_for_initialization(k1, d1, k2, d2, W, H, window=WINDOW, nnratio=NNRATIO, check_ori=True)
+            if not np.array_equal(m12[b], m_o):
+                bad.append("matches12")
+        if bad:
+            mism += 1
+            detail.append({"slot": b, "differs": bad})
+    replica_mismatch = 0
+    for b in range(nscenes, B):
+        a = b % nscenes
+        same = kps[b].tobytes() == kps[a].tobytes() and np.array_equal(descs[b], descs[a]) and (m12[b] is None or np.array_equal(m12[b], m12[a]))
+        replica_mismatch += 0 if same else 1
+    out = {"slots": len(slots), "slot_ids": slots, "mismatches": mism, "compared": "keypoints (28-byte records), descriptors, matches12 — bit for bit vs oracle/ on the last timed step",
+           "replica_slots_checked": max(B - nscenes, 0), "replica_mismatches": replica_mismatch}
+    if detail:
+        out["detail"] = detail
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -171,15 +216,20 @@ def main():
     ap.add_argument("--blur-round-mode", type=int, default=1, help="cv::GaussianBlur rounding the extractor reproduces: 1 = the SSE2 column filter of x86-64 OpenCV builds "
                     "(what the reference computes on this x86 box; default), 0 = OpenCV's generic C++ path (DESIGN.md H2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parity-slots", type=int, default=4, help="camera slots of the last timed step compared bit for bit with the oracle (0 = skip)")
     ap.add_argument("--extract-only", action="store_true", help="diagnostic: skip the matcher (NOT the metric's workload; the JSON line says so)")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
+    # The product library is loaded FIRST, so that it runs on the HIP runtime its RUNPATH names (/opt/rocm, the one the tests, smoke() and a
+    # real ORB_SLAM2 binary use).  N = 1 needs no framework at all: frames are made resident through the library (orbhip_device_alloc).
+    # N > 1 imports torch afterwards for the rendezvous only; its bundled libamdhip64 has the same SONAME, so the loader binds torch to the
+    # runtime that is already mapped — `runtime.mapped` in the JSON line lists what /proc/self/maps shows (must be one file).
+    import orb_slam2_amd
     share = os.environ.get("ORB_BENCH_SHARE_GPU") == "1"
+    force_dist = os.environ.get("ORB_BENCH_FORCE_DIST") == "1"       # test aid: take the N > 1 code path (process group, all-reduce) with one rank
+    ngpu = orb_slam2_amd.device_count()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # launched bare: become the launcher.  One rank per GPU; never a silent 1-GPU run labelled N.
-        ngpu = torch.cuda.device_count() if torch.cuda.is_available() else 0
         if ngpu < args.gpus and not share:
             raise SystemExit(f"bench.py --gpus {args.gpus}: only {ngpu} GPU(s) visible on this box — refusing to report a {args.gpus}-GPU number")
         import socket
@@ -193,37 +243,53 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
+    if ngpu < 1:
         raise SystemExit("bench.py needs a GPU: the ORB front-end has no CPU fallback")
     # ORB_BENCH_SHARE_GPU=1 (test aid): all ranks use GPU 0 and rendezvous over gloo, to exercise the N>1 code path on a 1-GPU box
-    if not share and torch.cuda.device_count() < world:
-        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible — refusing to share a GPU between ranks")
+    if not share and ngpu < world:
+        raise SystemExit(f"bench.py: {world} ranks but only {ngpu} GPU(s) visible — refusing to share a GPU between ranks")
     if share:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-    if world > 1:
+    runtime_line = orb_slam2_amd.runtime_info()                      # first device touch: on the library's runtime
+    dist = torch = None
+    control = "none (single process, no framework imported)"
+    if world > 1 or force_dist:
+        import torch
+        import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if force_dist:
+            os.environ.setdefault("MASTER_PORT", "29533"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if share:
-            dist.init_process_group(backend="gloo")
+            dist.init_process_group(backend="gloo"); control = "gloo (ranks share GPU 0: test aid)"
         else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    import orb_slam2_amd
+            try:
+                torch.cuda.set_device(local_rank)
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+                probe = torch.zeros(1, device=f"cuda:{local_rank}"); dist.all_reduce(probe); torch.cuda.synchronize()
+                control = "nccl (RCCL): barrier + max-reduce of the timings only"
+            except Exception as e:                                       # noqa: BLE001 - the data path has no collective: the rendezvous may fall back
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                dist.init_process_group(backend="gloo")
+                control = f"gloo (RCCL rendezvous failed on the system HIP runtime: {type(e).__name__})"
+    on_gpu_ctl = control.startswith("nccl")
 
     B, T = args.batch, max(args.tsteps, 2)
     pitch = (W + 63) // 64 * 64
     host_frames = make_frames(B, T, pitch, rank)
-    d_frames = torch.from_numpy(host_frames).to(f"cuda:{local_rank}")          # inputs resident in HBM before timing
-    torch.cuda.synchronize()
+    d_frames = orb_slam2_amd.DeviceBuffer.from_array(host_frames, device=local_rank)          # inputs resident in HBM before timing
     ex = orb_slam2_amd.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, W, H, max_batch=B, device=local_rank, num_streams=args.streams, blur_round_mode=args.blur_round_mode)
     frame_stride, step_stride = H * pitch, B * H * pitch
-    base = d_frames.data_ptr()
+    base = d_frames.ptr
 
     def step(i):
         ex.extract_device(base + (i % T) * step_stride, B, frame_stride, pitch, match_prev=not args.extract_only, window=WINDOW, nnratio=NNRATIO, check_ori=True)
 
     def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
+        orb_slam2_amd.device_synchronize(local_rank)                 # hipDeviceSynchronize: every stream of this rank's GPU
+        if dist is not None:
+            if on_gpu_ctl:
+                torch.cuda.synchronize()
             dist.barrier()
 
     for i in range(args.warmup):
@@ -242,16 +308,18 @@ def main():
         times.append(time.perf_counter() - t0)
     prof = ex.profile()
     ex.profile_enable(False)
-    if world > 1:
-        tt = torch.tensor(times, dtype=torch.float64, device="cpu" if share else f"cuda:{local_rank}")
+    last_step = args.warmup + max(args.repeats, 1) * args.steps - 1  # the step whose results are still in the context
+    if dist is not None:
+        tt = torch.tensor(times, dtype=torch.float64, device=f"cuda:{local_rank}" if on_gpu_ctl else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)                    # per repeat: the slowest rank
         times = [float(v) for v in tt.tolist()]
     elapsed = sorted(times)[len(times) // 2]                         # the median repeat is the reported one
 
-    # sanity of the timed work (not timed): every slot produced keypoints and matches
-    kps, _ = ex.fetch(B)
-    nm = np.zeros(B, np.int32) if args.extract_only else ex.fetch_matches(B)[1]
+    # the timed work's results (not timed): what the last step left in the context
+    kps, descs = ex.fetch(B)
+    m12, nm = ([None] * B, np.zeros(B, np.int32)) if args.extract_only else ex.fetch_matches(B)
     nkp = [len(k) for k in kps]
+    parity = parity_of_last_step(host_frames, kps, descs, m12, last_step, T, args.blur_round_mode, args.parity_slots) if rank == 0 and args.parity_slots > 0 else None
 
     if rank == 0:
         frames_total = B * args.steps * world
@@ -267,17 +335,24 @@ def main():
         if alg == 0:
             alg = {"k_quadtree": 16 * 12 * 1024, "k_match_grid": NFEAT * 32, "k_match_candidates": 434 * 40 * 36, "k_match_select": 434 * 40 * 4}.get(dom, 0)
             note = "dominant kernel is latency-bound list/control work outside B(W,H,N); bytes = records it streams (DESIGN.md §4)"
-        # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs,
-        # B = 256 frames per launch): FETCH_SIZE counts half of a wide coalesced read on gfx950 (MI355X_MICROARCH.md §HBM) -> x2.
+        # roofline.traffic is the HBM bytes counted IN THIS RUN: PMC counters need rocprofv3 around the process, so a plain run reports
+        # null; the committed PMC passes of the same workload (separate rocprofv3 --pmc runs, guide's x2 FETCH_SIZE correction) are quoted
+        # beside it as traffic_profiled, with their source.
         traffic = None
+        traffic_profiled = None
         try:
-            pmc = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
-            with open(pmc if os.path.exists(pmc) else os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
-                for row in json.load(f):
-                    if row["kernel"] == dom:
-                        traffic = int((2 * row["fetch_MB_per_dispatch_raw"] + row["write_MB_per_dispatch_raw"]) * 1024 * 1024 * B / 256)   # PMC passes ran at B = 256
+            for name in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
+                pmc = os.path.join(ROOT, "profiles", name)
+                if not os.path.exists(pmc):
+                    continue
+                with open(pmc) as f:
+                    for row in json.load(f):
+                        if row["kernel"] == dom:
+                            traffic_profiled = {"bytes_per_launch": int((2 * row["fetch_MB_per_dispatch_raw"] + row["write_MB_per_dispatch_raw"]) * 1024 * 1024 * B / 256),
+                                                "source": f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE at B = 256, scaled to B = {B}; not measured in this run)"}
+                break
         except Exception:
-            traffic = None
+            traffic_profiled = None
         dur_s = kern[dom]["ms_per_launch"] * 1e-3
         achieved = (alg * B / dur_s) / 1e9 if dur_s > 0 else 0.0
         out = {
@@ -292,7 +367,7 @@ def main():
             "repeats": {"n": len(times), "steps_each": args.steps, "timed_region_s": round(sum(times), 3), "frames_per_s_median": round(frames_total / elapsed, 1),
                         "frames_per_s_min": round(frames_total / max(times), 1), "frames_per_s_max": round(frames_total / min(times), 1)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_profiled": traffic_profiled,
                          "alg_bytes_per_launch": alg * B, "launch_ms": round(kern[dom]["ms_per_launch"], 4), "note": note},
             "pipeline_roofline": {"alg_bytes_per_frame": ex.algorithmic_bytes_per_frame(),
                                   "achieved_GBps": round(ex.algorithmic_bytes_per_frame() * value / world / 1e9, 2),
@@ -300,7 +375,11 @@ def main():
             "kernels_ms_per_launch": {k: round(v["ms_per_launch"], 4) for k, v in kern.items()},
             "kernel_time_fraction_of_step": round(total_kernel_ms / (elapsed / args.steps * 1e3), 3),
             "check": {"keypoints_per_frame_min_max": [int(min(nkp)), int(max(nkp))], "matches_per_frame_min_max": [int(nm.min()), int(nm.max())]},
+            "parity": parity,
+            "runtime": {"library": runtime_line, "mapped": orb_slam2_amd.mapped_hip_runtimes(), "framework_imported": "torch" in sys.modules, "control_plane": control},
         }
+        if parity and (parity["mismatches"] or parity["replica_mismatches"]):
+            out["INVALID"] = "results of the timed region differ from the oracle: the throughput above does not count"
         if world == 1 and not args.no_host_io:
             out["host_io"] = host_io(ex, host_frames, local_rank, args.blur_round_mode)
         if world == 1 and not args.no_cpu_baseline:
@@ -308,7 +387,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(host_frames, blur_round_mode=args.blur_round_mode)
             out["cpu_baseline"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

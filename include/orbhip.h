@@ -69,6 +69,18 @@ void orbhip_thread_release(void);
 int orbhip_device_count(void);
 /* last error message of the calling thread ("" if none) */
 const char* orbhip_last_error(void);
+/* Which HIP runtime this library is running on, as one line of text: runtime / driver version, the file libamdhip64 was mapped from
+   (dladdr), device 0's name, ISA and compute-unit count.  Truncated to cap bytes (NUL-terminated).  Touches the device: on a box whose
+   GPU cannot be used it fails with ORBHIP_ERR_HIP — before any kernel of this library has run. */
+orbhip_status orbhip_runtime_info(char* buf, int cap);
+/* Device memory for callers that keep frames resident in HBM (orbhip_extract_device*) but do not link the HIP runtime themselves:
+   hipMalloc / hipFree / blocking hipMemcpy on `device`, and hipDeviceSynchronize.  (A caller that already owns device memory — from its
+   own hipMalloc or another framework on the SAME HIP runtime — passes those pointers instead.) */
+orbhip_status orbhip_device_alloc(int device, size_t bytes, void** out);
+orbhip_status orbhip_device_free(int device, void* p);
+orbhip_status orbhip_device_upload(int device, void* dst, const void* src_host, size_t bytes);
+orbhip_status orbhip_device_download(int device, void* dst_host, const void* src, size_t bytes);
+orbhip_status orbhip_device_synchronize(int device);
 
 /* -------- ORBextractor (ORBextractor.h:45-111) ------------------------------------------------------- */
 orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cfg);            /* ORBextractor::ORBextractor */

@@ -127,7 +127,7 @@ static void prof_collect(orbhip_ctx* c)
 }
 
 // ---------------------------------------------------------------------------------------------- creation
-template <typename T> static hipError_t dalloc(T** p, size_t count) { return hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T)); }
+template <typename T> static hipError_t dalloc(T** p, size_t count) { return orbhip_dmalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T)); }
 // Per-thread, grow-only device scratch for the host-pointer matcher entry points: one hipMalloc the first time (or when a call
 // needs more), none afterwards — hipMalloc / hipFree cost more than the kernels of a single-frame call.
 static thread_local void* g_scratch = nullptr; static thread_local size_t g_scratch_bytes = 0; static thread_local int g_scratch_dev = -1;
@@ -207,7 +207,7 @@ template <typename Layout> static hipError_t arena_layout(int device, Layout lay
     if (g_scratch_dev != device || g_scratch_bytes < dry.off) {
         if (g_scratch) (void)hipFree(g_scratch);
         g_scratch = nullptr; g_scratch_bytes = 0;
-        const hipError_t e = hipMalloc(&g_scratch, dry.off + dry.off / 4);
+        const hipError_t e = orbhip_dmalloc(&g_scratch, dry.off + dry.off / 4);
         if (e != hipSuccess) return e;
         g_scratch_bytes = dry.off + dry.off / 4; g_scratch_dev = device;
     }
@@ -346,13 +346,13 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
     for (int l = 0; l < L; l++) {
         LevelGeom& g = c->geom[l]; memset(&g, 0, sizeof g);
         g.w = cvRoundF((float)cfg->width * c->isf[l]); g.h = cvRoundF((float)cfg->height * c->isf[l]);
-        if (g.w < 32 + 30 || g.h < 32 + 30 || g.w > 4095 || g.h > 4095) { delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "level %d is %dx%d: supported level sizes are 62..4095 px per side (the reference divides by zero below 30 px of interior)", l, g.w, g.h); }
+        if (g.w < 32 + 30 || g.h < 32 + 30 || g.w > 4095 || g.h > 4095) { const int gw = g.w, gh = g.h; delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "level %d is %dx%d: supported level sizes are 62..4095 px per side (the reference divides by zero below 30 px of interior)", l, gw, gh); }
         g.pitch = (g.w + 63) & ~63; g.plane_off = (int)plane_off; plane_off += (long long)g.pitch * g.h;
         g.maxBorderX = g.w - ORBHIP_EDGE; g.maxBorderY = g.h - ORBHIP_EDGE;
         const float width = (float)(g.maxBorderX - ORBHIP_EDGE), height = (float)(g.maxBorderY - ORBHIP_EDGE), W = 30;
         g.nCols = (int)(width / W); g.nRows = (int)(height / W);
         g.wCell = (int)ceil(width / g.nCols); g.hCell = (int)ceil(height / g.nRows);
-        if (g.wCell > 59 || g.hCell > 59) { delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "cell %dx%d too large", g.wCell, g.hCell); }
+        if (g.wCell > 59 || g.hCell > 59) { const int cw = g.wCell, ch = g.hCell; delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "cell %dx%d too large", cw, ch); }
         g.cell_first = (int)c->cells.size(); g.ncells = g.nCols * g.nRows;
         g.cand_total_off = (int)cand_off;
         for (int i = 0; i < g.nRows; i++) {
@@ -418,7 +418,7 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
     c->plane_frame_bytes = (plane_off + 255) & ~255LL; c->cand_slots_per_frame = cand_off; c->qt_per_frame = cand_off;
     c->lvl_kp_per_frame = kp_off; c->out_cap = kp_off; c->lvl0_cap = c->geom[0].kp_cap;
     if (cand_off >= (1 << 24)) { delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "too many candidate slots"); }
-    if (orbhip_quadtree_lds_bytes(c->qt_maxn, c->qt_maxcells) > 150 * 1024) { delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "nfeatures too large for the LDS quadtree (%d nodes)", c->qt_maxn); }
+    if (orbhip_quadtree_lds_bytes(c->qt_maxn, c->qt_maxcells) > 150 * 1024) { const int qn = c->qt_maxn; delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "nfeatures too large for the LDS quadtree (%d nodes)", qn); }
     if ((size_t)(4 * c->out_cap + 4 * c->lvl0_cap + 64) * sizeof(int) > 158 * 1024) { delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "nfeatures too large for the LDS matcher"); }
 
     // ---- device
@@ -748,7 +748,7 @@ static orbhip_status ensure_host_staging(orbhip_ctx* c, bool input)
     if (input && !c->d_in) {
         c->in_pitch = c->geom[0].pitch;
         const size_t bytes = B * (size_t)c->in_pitch * c->cfg.height + 256;
-        HIPCHK(hipMalloc((void**)&c->d_in, bytes));
+        HIPCHK(orbhip_dmalloc((void**)&c->d_in, bytes));
         HIPCHK(hipHostMalloc((void**)&c->h_in, bytes, hipHostMallocDefault));
     }
     return ORBHIP_OK;
@@ -847,6 +847,54 @@ bool host_pointer_is_pinned(const void* p)
 }
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------- device memory for runtime-less callers
+#include <dlfcn.h>
+extern "C" orbhip_status orbhip_runtime_info(char* buf, int cap)
+{
+    if (!buf || cap < 1) return fail(ORBHIP_ERR_INVALID, "null argument");
+    int rt = 0, drv = 0, nd = 0;
+    HIPCHK(hipRuntimeGetVersion(&rt)); HIPCHK(hipDriverGetVersion(&drv)); HIPCHK(hipGetDeviceCount(&nd));
+    if (nd < 1) return fail(ORBHIP_ERR_HIP, "no HIP device available");
+    hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, 0));
+    Dl_info di; memset(&di, 0, sizeof di);
+    const char* where = dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &di) && di.dli_fname ? di.dli_fname : "?";
+    snprintf(buf, (size_t)cap, "hip runtime %d driver %d from %s; %d device(s); device 0: %s %s, %d CUs", rt, drv, where, nd, pr.name, pr.gcnArchName, pr.multiProcessorCount);
+    return ORBHIP_OK;
+}
+extern "C" orbhip_status orbhip_device_alloc(int device, size_t bytes, void** out)
+{
+    if (!out) return fail(ORBHIP_ERR_INVALID, "null argument");
+    *out = nullptr;
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(orbhip_dmalloc(out, std::max<size_t>(bytes, 1)));
+    return ORBHIP_OK;
+}
+extern "C" orbhip_status orbhip_device_free(int device, void* p)
+{
+    if (!p) return ORBHIP_OK;
+    HIPCHK(hipSetDevice(device)); HIPCHK(hipFree(p));
+    return ORBHIP_OK;
+}
+extern "C" orbhip_status orbhip_device_upload(int device, void* dst, const void* src_host, size_t bytes)
+{
+    if (bytes == 0) return ORBHIP_OK;
+    if (!dst || !src_host) return fail(ORBHIP_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(device)); HIPCHK(hipMemcpy(dst, src_host, bytes, hipMemcpyHostToDevice));
+    return ORBHIP_OK;
+}
+extern "C" orbhip_status orbhip_device_download(int device, void* dst_host, const void* src, size_t bytes)
+{
+    if (bytes == 0) return ORBHIP_OK;
+    if (!dst_host || !src) return fail(ORBHIP_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(device)); HIPCHK(hipMemcpy(dst_host, src, bytes, hipMemcpyDeviceToHost));
+    return ORBHIP_OK;
+}
+extern "C" orbhip_status orbhip_device_synchronize(int device)
+{
+    HIPCHK(hipSetDevice(device)); HIPCHK(hipDeviceSynchronize());
+    return ORBHIP_OK;
+}
+
 extern "C" void* orbhip_host_alloc(size_t bytes) { void* p = nullptr; return hipHostMalloc(&p, std::max<size_t>(bytes, 1), hipHostMallocDefault) == hipSuccess ? p : nullptr; }
 extern "C" void orbhip_host_free(void* p) { if (p) (void)hipHostFree(p); }
 extern "C" int orbhip_ring_depth(void) { return ORBHIP_RING; }
@@ -861,7 +909,7 @@ static orbhip_status ensure_set(orbhip_ctx* c, int si)
         else {
             const size_t bytes = B * (size_t)c->in_pitch * c->cfg.height + 256;
             hs.owned = true;
-            HIPCHK(hipMalloc((void**)&hs.d_in, bytes)); HIPCHK(hipHostMalloc((void**)&hs.h_in, bytes, hipHostMallocDefault));
+            HIPCHK(orbhip_dmalloc((void**)&hs.d_in, bytes)); HIPCHK(hipHostMalloc((void**)&hs.h_in, bytes, hipHostMallocDefault));
             HIPCHK(hipHostMalloc((void**)&hs.h_n, B * sizeof(int), hipHostMallocDefault));
             HIPCHK(hipHostMalloc((void**)&hs.h_kp, B * c->out_cap * sizeof(orbhip_keypoint), hipHostMallocDefault));
             HIPCHK(hipHostMalloc((void**)&hs.h_desc, B * c->out_cap * 32, hipHostMallocDefault));
@@ -921,7 +969,7 @@ static orbhip_status submit_impl(orbhip_ctx* c, int nimg, const uint8_t* const* 
             const size_t ibytes = (size_t)stride * H;
             if (hs.packed_bytes < (size_t)c->B * ibytes) {
                 if (hs.d_packed) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(hs.d_packed)); hs.d_packed = nullptr; hs.packed_bytes = 0; }
-                HIPCHK(hipMalloc((void**)&hs.d_packed, (size_t)c->B * ibytes + 256)); hs.packed_bytes = (size_t)c->B * ibytes;
+                HIPCHK(orbhip_dmalloc((void**)&hs.d_packed, (size_t)c->B * ibytes + 256)); hs.packed_bytes = (size_t)c->B * ibytes;
             }
             for (int f = f0; f < f1;) {
                 int g = f + 1; while (g < f1 && imgs[g] == imgs[g - 1] + ibytes) g++;
@@ -1058,7 +1106,7 @@ extern "C" orbhip_status orbhip_extract_batch_color(orbhip_ctx* c, int nimg, con
     const size_t cpitch = ((size_t)c->cfg.width * 4 + 63) & ~(size_t)63, cfbytes = cpitch * c->cfg.height;   // room for 4 channels
     if (!c->d_col) {
         c->col_bytes = (size_t)c->B * cfbytes + 256;
-        HIPCHK(hipMalloc((void**)&c->d_col, c->col_bytes));
+        HIPCHK(orbhip_dmalloc((void**)&c->d_col, c->col_bytes));
         HIPCHK(hipHostMalloc((void**)&c->h_col, c->col_bytes, hipHostMallocDefault));
     }
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1576,7 +1624,7 @@ extern "C" orbhip_status orbhip_compute_stereo_from_rgbd(orbhip_ctx* c, int nimg
     if (stride_bytes < W * esz) return fail(ORBHIP_ERR_INVALID, "depth row stride %d < %d", stride_bytes, W * esz);
     HIPCHK(hipSetDevice(c->cfg.device));
     const size_t pitch = ((size_t)W * 4 + 63) & ~(size_t)63, fbytes = pitch * H, need = (size_t)c->B * fbytes + (size_t)2 * c->B * c->out_cap * sizeof(float);
-    if (c->depth_bytes < need) { if (c->d_depth) (void)hipFree(c->d_depth); c->d_depth = nullptr; c->depth_bytes = 0; HIPCHK(hipMalloc((void**)&c->d_depth, need)); c->depth_bytes = need; }
+    if (c->depth_bytes < need) { if (c->d_depth) (void)hipFree(c->d_depth); c->d_depth = nullptr; c->depth_bytes = 0; HIPCHK(orbhip_dmalloc((void**)&c->d_depth, need)); c->depth_bytes = need; }
     float* d_u = (float*)(c->d_depth + (size_t)c->B * fbytes); float* d_z = d_u + (size_t)c->B * c->out_cap; c->d_last_uright = d_u;
     for (int f = 0; f < nimg; f++) {
         if (!depth_maps[f]) return fail(ORBHIP_ERR_INVALID, "depth map %d is null", f);
@@ -1653,7 +1701,7 @@ extern "C" orbhip_status orbhip_extract_batch_rectify(orbhip_ctx* c, int nimg, c
     HIPCHK(hipSetDevice(c->cfg.device));
     const size_t rfbytes = (size_t)c->raw_pitch * c->src_h;
     if (!c->d_raw) {
-        HIPCHK(hipMalloc((void**)&c->d_raw, (size_t)c->B * rfbytes + 256));
+        HIPCHK(orbhip_dmalloc((void**)&c->d_raw, (size_t)c->B * rfbytes + 256));
         HIPCHK(hipHostMalloc((void**)&c->h_raw, (size_t)c->B * rfbytes + 256, hipHostMallocDefault));
     }
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1684,7 +1732,7 @@ void* orbhip_nn_workspace(size_t bytes, hipStream_t s)
     if (g_nn_ws && g_nn_ws_dev == dev && g_nn_ws_stream != s) (void)hipStreamSynchronize(g_nn_ws_stream);
     if (g_nn_ws_dev != dev || bytes > g_nn_ws_bytes) {
         if (g_nn_ws) { const int cur = dev; (void)hipSetDevice(g_nn_ws_dev); (void)hipStreamSynchronize(g_nn_ws_stream); (void)hipFree(g_nn_ws); (void)hipSetDevice(cur); g_nn_ws = nullptr; g_nn_ws_bytes = 0; }
-        if (hipMalloc(&g_nn_ws, bytes) != hipSuccess) { (void)hipGetLastError(); g_nn_ws = nullptr; g_nn_ws_dev = -1; return nullptr; }
+        if (orbhip_dmalloc(&g_nn_ws, bytes) != hipSuccess) { (void)hipGetLastError(); g_nn_ws = nullptr; g_nn_ws_dev = -1; return nullptr; }
         g_nn_ws_bytes = bytes; g_nn_ws_dev = dev;
     }
     g_nn_ws_stream = s;
@@ -1710,11 +1758,11 @@ extern "C" orbhip_status orbhip_hamming_nn(int device, const uint8_t* q, int nq,
     uint8_t *dq = nullptr, *ddb = nullptr; long long* dbi = nullptr; int *dbd = nullptr, *dsd = nullptr;
     orbhip_status st = ORBHIP_OK;
     hipError_t e = hipSuccess;
-    if (e == hipSuccess) e = hipMalloc((void**)&dq, (size_t)nq * 32);
-    if (e == hipSuccess) e = hipMalloc((void**)&ddb, std::max<size_t>((size_t)ndb * 32, 32));
-    if (e == hipSuccess) e = hipMalloc((void**)&dbi, (size_t)nq * 8);
-    if (e == hipSuccess) e = hipMalloc((void**)&dbd, (size_t)nq * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&dsd, (size_t)nq * 4);
+    if (e == hipSuccess) e = orbhip_dmalloc((void**)&dq, (size_t)nq * 32);
+    if (e == hipSuccess) e = orbhip_dmalloc((void**)&ddb, std::max<size_t>((size_t)ndb * 32, 32));
+    if (e == hipSuccess) e = orbhip_dmalloc((void**)&dbi, (size_t)nq * 8);
+    if (e == hipSuccess) e = orbhip_dmalloc((void**)&dbd, (size_t)nq * 4);
+    if (e == hipSuccess) e = orbhip_dmalloc((void**)&dsd, (size_t)nq * 4);
     if (e == hipSuccess) e = hipMemcpy(dq, q, (size_t)nq * 32, hipMemcpyHostToDevice);
     if (e == hipSuccess && ndb > 0) e = hipMemcpy(ddb, db, (size_t)ndb * 32, hipMemcpyHostToDevice);
     if (e == hipSuccess) { e = orbhip_launch_hamming_nn(dq, nq, ddb, ndb, base, dbi, dbd, dsd, nullptr) ? hipGetLastError() : hipErrorOutOfMemory; }

@@ -410,11 +410,11 @@ static orbhip_status voc_ensure_ws(BowWs* w, int nframes, int cap, hipStream_t s
     const int nf = std::max(nframes, w->frames), nc = std::min(std::max(cap + cap / 4, w->cap), BOW_MAX_FEATURES);
     voc_free_ws(w);
     const size_t F = (size_t)nf, C = (size_t)nc;
-    BOWCHK(hipMalloc((void**)&w->d_desc, F * C * 32 + 64));
-    BOWCHK(hipMalloc((void**)&w->d_word, F * C * 4)); BOWCHK(hipMalloc((void**)&w->d_node, F * C * 4)); BOWCHK(hipMalloc((void**)&w->d_weight, F * C * 8));
-    BOWCHK(hipMalloc((void**)&w->d_bow_id, F * C * 4)); BOWCHK(hipMalloc((void**)&w->d_bow_val, F * C * 8));
-    BOWCHK(hipMalloc((void**)&w->d_fv_node, F * C * 4)); BOWCHK(hipMalloc((void**)&w->d_fv_feat, F * C * 4)); BOWCHK(hipMalloc((void**)&w->d_fv_off, F * (C + 1) * 4));
-    BOWCHK(hipMalloc((void**)&w->d_nbow, F * 4)); BOWCHK(hipMalloc((void**)&w->d_nfv, F * 4));
+    BOWCHK(orbhip_dmalloc((void**)&w->d_desc, F * C * 32 + 64));
+    BOWCHK(orbhip_dmalloc((void**)&w->d_word, F * C * 4)); BOWCHK(orbhip_dmalloc((void**)&w->d_node, F * C * 4)); BOWCHK(orbhip_dmalloc((void**)&w->d_weight, F * C * 8));
+    BOWCHK(orbhip_dmalloc((void**)&w->d_bow_id, F * C * 4)); BOWCHK(orbhip_dmalloc((void**)&w->d_bow_val, F * C * 8));
+    BOWCHK(orbhip_dmalloc((void**)&w->d_fv_node, F * C * 4)); BOWCHK(orbhip_dmalloc((void**)&w->d_fv_feat, F * C * 4)); BOWCHK(orbhip_dmalloc((void**)&w->d_fv_off, F * (C + 1) * 4));
+    BOWCHK(orbhip_dmalloc((void**)&w->d_nbow, F * 4)); BOWCHK(orbhip_dmalloc((void**)&w->d_nfv, F * 4));
     w->frames = nf; w->cap = nc;
     return ORBHIP_OK;
 }
@@ -495,11 +495,11 @@ extern "C" orbhip_status orbhip_voc_load_text(orbhip_voc** out, const char* path
         if ((word[i] >= 0) != (nchild[i] == 0) && i != 0) { delete v; return orbhip_set_error(ORBHIP_ERR_INVALID, "vocabulary node %d: leaf flag and children disagree", i); }
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc((void**)&v->d_child_start, (size_t)(nn + 1) * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&v->d_child_ids, v->child_ids.size() * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&v->d_node_word, (size_t)nn * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&v->d_node_desc, (size_t)nn * 32);
-    if (e == hipSuccess) e = hipMalloc((void**)&v->d_node_weight, (size_t)nn * 8);
+    if (e == hipSuccess) e = orbhip_dmalloc((void**)&v->d_child_start, (size_t)(nn + 1) * 4);
+    if (e == hipSuccess) e = orbhip_dmalloc((void**)&v->d_child_ids, v->child_ids.size() * 4);
+    if (e == hipSuccess) e = orbhip_dmalloc((void**)&v->d_node_word, (size_t)nn * 4);
+    if (e == hipSuccess) e = orbhip_dmalloc((void**)&v->d_node_desc, (size_t)nn * 32);
+    if (e == hipSuccess) e = orbhip_dmalloc((void**)&v->d_node_weight, (size_t)nn * 8);
     if (e == hipSuccess) e = hipMemcpy(v->d_child_start, v->child_start.data(), (size_t)(nn + 1) * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(v->d_child_ids, v->child_ids.data(), v->child_ids.size() * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(v->d_node_word, v->node_word.data(), (size_t)nn * 4, hipMemcpyHostToDevice);
@@ -674,7 +674,7 @@ extern "C" orbhip_status orbhip_search_by_bow(int device, int mode,
     if (g_bm_dev != device || g_bm_ws_bytes < total) {
         if (g_bm_ws) (void)hipFree(g_bm_ws);
         g_bm_ws = nullptr; g_bm_ws_bytes = 0;
-        BOWCHK(hipMalloc(&g_bm_ws, total)); g_bm_ws_bytes = total; g_bm_dev = device;
+        BOWCHK(orbhip_dmalloc(&g_bm_ws, total)); g_bm_ws_bytes = total; g_bm_dev = device;
     }
     uint8_t* base = (uint8_t*)g_bm_ws; uint8_t* p[15]; { size_t o = 0; for (int i = 0; i < 15; i++) { p[i] = base + o; o += sz[i]; } }
     std::vector<uint8_t> ones;
@@ -728,7 +728,7 @@ extern "C" orbhip_status orbhip_search_for_triangulation(int device,
     if (g_bm_dev != device || g_bm_ws_bytes < total) {
         if (g_bm_ws) (void)hipFree(g_bm_ws);
         g_bm_ws = nullptr; g_bm_ws_bytes = 0;
-        BOWCHK(hipMalloc(&g_bm_ws, total)); g_bm_ws_bytes = total; g_bm_dev = device;
+        BOWCHK(orbhip_dmalloc(&g_bm_ws, total)); g_bm_ws_bytes = total; g_bm_dev = device;
     }
     uint8_t* p[19]; { size_t o = 0; for (int i = 0; i < 18; i++) { p[i] = (uint8_t*)g_bm_ws + o; o += al(nb[i]); } p[18] = (uint8_t*)g_bm_ws + o; }
     for (int i = 0; i < 16; i++) if (src[i] && nb[i] && !((i == 6 && m1 == 0) || (i == 13 && m2 == 0))) BOWCHK(hipMemcpyAsync(p[i], src[i], i == 6 ? (size_t)m1 * 4 : i == 13 ? (size_t)m2 * 4 : nb[i], hipMemcpyHostToDevice, 0));

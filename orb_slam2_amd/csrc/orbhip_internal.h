@@ -18,6 +18,20 @@
 #include <cstdint>
 #include "../../include/orbhip.h"
 
+// Every device allocation of the library goes through here.  ORBHIP_POISON=<byte 0..255> (test knob) fills each new allocation with that
+// byte, so that a kernel which depends on what a previous owner left in the memory shows up on any box, not only on a box whose memory a
+// previous process has dirtied (tests/test_00_device.py runs the pipeline under two poison values).
+#include <cstdlib>
+inline hipError_t orbhip_dmalloc(void** p, size_t bytes)
+{
+    const hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) return e;
+    static const int poison = [] { const char* v = getenv("ORBHIP_POISON"); return v && *v ? atoi(v) & 255 : -1; }();
+    if (poison < 0) return hipSuccess;
+    const hipError_t m = hipMemset(*p, poison, bytes);
+    return m != hipSuccess ? m : hipDeviceSynchronize();
+}
+
 #define ORBHIP_MAX_LEVELS 16
 #define ORBHIP_QT_DEPTH 13          // quadtree path digits kept per candidate (2 bits each)
 #define ORBHIP_GRID_COLS 64         // Frame.h:37-38

@@ -184,7 +184,7 @@ extern "C" orbhip_status orbhip_pool_db_load(orbhip_pool* p, const uint8_t* db, 
             hipError_t e = hipSetDevice(w->device);
             if (e == hipSuccess && w->d_db) { e = hipFree(w->d_db); w->d_db = nullptr; }
             const size_t bytes = (size_t)(w->hi - w->lo) * 32;
-            if (e == hipSuccess) e = hipMalloc((void**)&w->d_db, std::max<size_t>(bytes, 32));
+            if (e == hipSuccess) e = orbhip_dmalloc((void**)&w->d_db, std::max<size_t>(bytes, 32));
             if (e == hipSuccess && bytes) e = hipMemcpy(w->d_db, db + (size_t)w->lo * 32, bytes, hipMemcpyHostToDevice);
             if (e == hipSuccess && !w->qstream) e = hipStreamCreateWithFlags(&w->qstream, hipStreamNonBlocking);
             if (e != hipSuccess) w->fail_hip("descriptor DB shard upload", e);
@@ -208,10 +208,10 @@ extern "C" orbhip_status orbhip_pool_db_query(orbhip_pool* p, const uint8_t* q, 
                 void* h[] = {w->h_q, w->h_bi, w->h_bd, w->h_sd}; for (void* x : h) if (x) (void)hipHostFree(x);
                 w->d_q = nullptr; w->d_bi = nullptr; w->d_bd = nullptr; w->d_sd = nullptr; w->h_q = nullptr; w->h_bi = nullptr; w->h_bd = nullptr; w->h_sd = nullptr; w->q_cap = 0;
                 const size_t n = (size_t)nq + nq / 4;
-                if (e == hipSuccess) e = hipMalloc((void**)&w->d_q, n * 32);
-                if (e == hipSuccess) e = hipMalloc((void**)&w->d_bi, n * 8);
-                if (e == hipSuccess) e = hipMalloc((void**)&w->d_bd, n * 4);
-                if (e == hipSuccess) e = hipMalloc((void**)&w->d_sd, n * 4);
+                if (e == hipSuccess) e = orbhip_dmalloc((void**)&w->d_q, n * 32);
+                if (e == hipSuccess) e = orbhip_dmalloc((void**)&w->d_bi, n * 8);
+                if (e == hipSuccess) e = orbhip_dmalloc((void**)&w->d_bd, n * 4);
+                if (e == hipSuccess) e = orbhip_dmalloc((void**)&w->d_sd, n * 4);
                 if (e == hipSuccess) e = hipHostMalloc((void**)&w->h_q, n * 32, hipHostMallocDefault);
                 if (e == hipSuccess) e = hipHostMalloc((void**)&w->h_bi, n * 8, hipHostMallocDefault);
                 if (e == hipSuccess) e = hipHostMalloc((void**)&w->h_bd, n * 4, hipHostMallocDefault);

@@ -36,7 +36,8 @@ SYMBOLS = [
     "orbhip_pyramid_fetch_all", "orbhip_set_blur_rounding", "orbhip_set_fp_contract", "orbhip_submit", "orbhip_collect", "orbhip_ring_depth", "orbhip_host_alloc", "orbhip_host_free",
     "orbhip_pool_create", "orbhip_pool_destroy", "orbhip_pool_num_devices", "orbhip_pool_device_of", "orbhip_pool_keypoint_capacity",
     "orbhip_pool_extract", "orbhip_pool_submit", "orbhip_pool_collect", "orbhip_pool_db_load", "orbhip_pool_db_shard", "orbhip_pool_db_query",
-    "orbhip_reloc_candidates",
+    "orbhip_reloc_candidates", "orbhip_runtime_info", "orbhip_device_alloc", "orbhip_device_free", "orbhip_device_upload", "orbhip_device_download",
+    "orbhip_device_synchronize",
 ]
 
 
@@ -96,6 +97,12 @@ def lib(path=None):
     L = C.CDLL(path)
     vp, i32p, ip = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int)
     L.orbhip_version.restype = C.c_char_p
+    L.orbhip_runtime_info.argtypes = [C.c_char_p, C.c_int]
+    L.orbhip_device_alloc.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
+    L.orbhip_device_free.argtypes = [C.c_int, C.c_void_p]
+    L.orbhip_device_upload.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.orbhip_device_download.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.orbhip_device_synchronize.argtypes = [C.c_int]
     L.orbhip_last_error.restype = C.c_char_p
     L.orbhip_create.argtypes = [C.POINTER(vp), C.POINTER(Config)]
     L.orbhip_destroy.argtypes = [vp]
@@ -491,6 +498,76 @@ class ORBextractor:
 def device_count(library=None):
     """HIP devices visible to the library (0 = nothing can run; there is no CPU fallback)"""
     return lib(library).orbhip_device_count()
+
+
+def runtime_info(library=None):
+    """One line naming the HIP runtime the library is running on (versions, the file libamdhip64 was mapped from, device 0)."""
+    L = lib(library)
+    buf = C.create_string_buffer(1024)
+    _check(L.orbhip_runtime_info(buf, 1024), "orbhip_runtime_info", L)
+    return buf.value.decode()
+
+
+def mapped_hip_runtimes():
+    """Files named libamdhip64* that are mapped into this process (there must be exactly one: a process that mixes the system
+    runtime with a framework's bundled copy hands raw device pointers across two runtimes)."""
+    seen = set()
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                parts = line.split()
+                if len(parts) >= 6 and "libamdhip64" in parts[-1]:
+                    seen.add(os.path.realpath(parts[-1]))
+    except OSError:
+        pass
+    return sorted(seen)
+
+
+class DeviceBuffer:
+    """Frames resident in HBM without a framework: orbhip_device_alloc / upload / download / free on the library's own HIP runtime.
+    `ptr` is what orbhip_extract_device* take."""
+
+    def __init__(self, nbytes, device=0, library=None):
+        self.L, self.device, self.nbytes = lib(library), int(device), int(nbytes)
+        p = C.c_void_p()
+        _check(self.L.orbhip_device_alloc(self.device, max(self.nbytes, 1), C.byref(p)), "orbhip_device_alloc", self.L)
+        self.ptr = p.value
+
+    @classmethod
+    def from_array(cls, arr, device=0, library=None):
+        arr = np.ascontiguousarray(arr)
+        b = cls(arr.nbytes, device, library)
+        b.upload(arr)
+        return b
+
+    def upload(self, arr, offset=0):
+        arr = np.ascontiguousarray(arr)
+        assert offset + arr.nbytes <= self.nbytes
+        _check(self.L.orbhip_device_upload(self.device, C.c_void_p(self.ptr + offset), _p(arr), arr.nbytes), "orbhip_device_upload", self.L)
+
+    def download(self, shape, dtype=np.uint8, offset=0):
+        out = np.empty(shape, dtype)
+        assert offset + out.nbytes <= self.nbytes
+        _check(self.L.orbhip_device_download(self.device, _p(out), C.c_void_p(self.ptr + offset), out.nbytes), "orbhip_device_download", self.L)
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.L.orbhip_device_free(self.device, C.c_void_p(self.ptr))
+            self.ptr = None
+
+    close = free
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def device_synchronize(device=0, library=None):
+    L = lib(library)
+    _check(L.orbhip_device_synchronize(int(device)), "orbhip_device_synchronize", L)
 
 
 def pinned_array(shape, dtype=np.uint8, library=None):

@@ -26,6 +26,26 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X GPU (liborbhip.so built for gfx950)")
 
 
+def pytest_report_header(config):
+    """GPU runs name their box in the log's first lines: the product-free probe's verdict and the runtime the product is on (a red run on
+    a machine whose GPU faults for every process then says so itself)."""
+    expr = (config.getoption("-m") or "").strip()
+    if "gpu" not in expr or "not gpu" in expr:
+        return None
+    lines = []
+    probe = os.path.join(ROOT, "tests", "cpp", "hip_touch")
+    try:
+        r = subprocess.run([probe], capture_output=True, text=True, timeout=300)
+        ok = r.returncode == 0 and "hip_touch ok" in r.stdout
+        facts = [l for l in r.stdout.splitlines() if l.startswith("devices ") or "gfx" in l]
+        lines.append(f"box probe (product-free HIP program): {'ok' if ok else 'FAILED rc=%d -- THE BOX, NOT THE PRODUCT' % r.returncode}; " + "; ".join(facts))
+        if not ok:
+            lines.append("box probe tail: " + (r.stdout + r.stderr)[-600:].replace("\n", " | "))
+    except Exception as e:                                             # noqa: BLE001 - the header must never stop the run
+        lines.append(f"box probe could not run: {e}")
+    return lines
+
+
 def _newer(target, sources):
     if not os.path.exists(target):
         return False

@@ -267,6 +267,8 @@ inline int min(int a, unsigned b) { return a < (int)b ? a : (int)b; }
 // ---- host API
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipRuntimeGetVersion(int* v) { *v = 0; return hipSuccess; }
+inline hipError_t hipDriverGetVersion(int* v) { *v = 0; return hipSuccess; }
 // HIPEMU_DEVICE_COUNT=n: pretend n devices (all of them this process's heap) so that the multi-device host logic runs on CPU
 inline hipError_t hipGetDeviceCount(int* n) { const char* e = getenv("HIPEMU_DEVICE_COUNT"); *n = e ? std::max(atoi(e), 1) : 1; return hipSuccess; }
 enum hipMemoryType { hipMemoryTypeUnregistered = 0, hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2 };

@@ -41,15 +41,8 @@ def test_undistort_points_and_bounds(backend, oracle, cam):
 
 def _device_frames(backend, host):
     """host array -> pointer the library may read as device memory (the emulation reads host memory directly)"""
-    if backend.endswith("_emu.so"):
-        return host.ctypes.data, None
-    hip = C.CDLL("libamdhip64.so")
-    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
-    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-    dptr = C.c_void_p()
-    assert hip.hipMalloc(C.byref(dptr), host.nbytes) == 0
-    assert hip.hipMemcpy(dptr, host.ctypes.data_as(C.c_void_p), host.nbytes, 1) == 0
-    return dptr.value, hip
+    buf = orb_slam2_amd.DeviceBuffer.from_array(host, library=backend)      # the library's own runtime (emulation: host heap)
+    return buf.ptr, buf
 
 
 def test_distorted_camera_pipeline(backend, oracle):

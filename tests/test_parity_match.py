@@ -152,23 +152,13 @@ def test_device_pipeline_extract_and_match(backend, oracle, num_streams, sched, 
     K = [[ora.extract(im) for im in s] for s in seqs]
     ex = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, max_batch=2, library=backend, num_streams=num_streams)
     pitch = 448
-    is_gpu = not backend.endswith("_emu.so")
-    if is_gpu:                                           # plain HIP runtime through ctypes: device memory is plumbing, not product
-        import ctypes as C
-        hip = C.CDLL("libamdhip64.so")
-        hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
-        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-        dptr = C.c_void_p()
-        assert hip.hipMalloc(C.byref(dptr), 2 * h * pitch) == 0
+    dbuf = orb_slam2_amd.DeviceBuffer(2 * h * pitch, library=backend)     # device memory through the library's own runtime: plumbing, not product
     for t in range(4):
         host = np.zeros((2, h, pitch), np.uint8)
         host[0, :, :w], host[1, :, :w] = seqs[0][t], seqs[1][t]
-        if is_gpu:
-            ex.sync()
-            assert hip.hipMemcpy(dptr, host.ctypes.data_as(C.c_void_p), host.nbytes, 1) == 0      # hipMemcpyHostToDevice
-            ptr = dptr.value
-        else:
-            ptr = host.ctypes.data                       # emulation: host memory is the "device" memory
+        ex.sync()
+        dbuf.upload(host)
+        ptr = dbuf.ptr
         ex.extract_device(ptr, 2, h * pitch, pitch, match_prev=(t > 0), window=100, nnratio=0.9, check_ori=True)
         ks, ds = ex.fetch(2)
         for s in range(2):
@@ -194,17 +184,8 @@ def test_device_pipeline_unaligned_input(backend, oracle):
     pitch = w + 6                                            # 339: not a multiple of 4
     host = np.zeros(1 + h * pitch + 64, np.uint8)
     host[1:1 + h * pitch].reshape(h, pitch)[:, :w] = img   # frame starts at byte offset 1
-    if backend.endswith("_emu.so"):
-        ptr = host.ctypes.data + 1
-    else:
-        import ctypes as C
-        hip = C.CDLL("libamdhip64.so")
-        hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
-        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-        dptr = C.c_void_p()
-        assert hip.hipMalloc(C.byref(dptr), host.nbytes) == 0
-        assert hip.hipMemcpy(dptr, host.ctypes.data_as(C.c_void_p), host.nbytes, 1) == 0
-        ptr = dptr.value + 1
+    dbuf = orb_slam2_amd.DeviceBuffer.from_array(host, library=backend)
+    ptr = dbuf.ptr + 1
     ex.extract_device(ptr, 1, h * pitch, pitch)
     ks, ds = ex.fetch(1)
     assert ks[0].tobytes() == ko.tobytes() and np.array_equal(ds[0], do)
@@ -220,23 +201,13 @@ def test_device_pipeline_colour_unaligned_with_matching(backend, oracle):
     K = [ora.extract(oracle.cvt_gray(col, rgb=False)) for col in seq]
     ex = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, max_batch=1, library=backend)
     pitch = 3 * w + 5
-    is_gpu = not backend.endswith("_emu.so")
-    if is_gpu:
-        import ctypes as C
-        hip = C.CDLL("libamdhip64.so")
-        hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
-        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-        dptr = C.c_void_p()
-        assert hip.hipMalloc(C.byref(dptr), 1 + h * pitch + 64) == 0
+    dbuf = orb_slam2_amd.DeviceBuffer(1 + h * pitch + 64, library=backend)
     for t in range(2):
         host = np.zeros(1 + h * pitch + 64, np.uint8)
         host[1:1 + h * pitch].reshape(h, pitch)[:, :3 * w] = seq[t].reshape(h, 3 * w)
-        if is_gpu:
-            ex.sync()
-            assert hip.hipMemcpy(dptr, host.ctypes.data_as(C.c_void_p), host.nbytes, 1) == 0
-            ptr = dptr.value + 1
-        else:
-            ptr = host.ctypes.data + 1
+        ex.sync()
+        dbuf.upload(host)
+        ptr = dbuf.ptr + 1
         ex.extract_device_color(ptr, 1, h * pitch, pitch, 3, rgb=False, match_prev=(t > 0), window=100, nnratio=0.9, check_ori=True)
         ks, ds = ex.fetch(1)
         assert ks[0].tobytes() == K[t][0].tobytes() and np.array_equal(ds[0], K[t][1])

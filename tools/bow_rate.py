@@ -77,11 +77,11 @@ def main():
     host = np.zeros((B, H, pitch), np.uint8)
     for b in range(B):
         host[b, :, :W] = scenes[b % len(scenes)]
-    hip = C.CDLL("libamdhip64.so")
-    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
-    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-    dptr = C.c_void_p()
-    assert hip.hipMalloc(C.byref(dptr), host.nbytes) == 0 and hip.hipMemcpy(dptr, host.ctypes.data_as(C.c_void_p), host.nbytes, 1) == 0
+    dbuf = orb_slam2_amd.DeviceBuffer.from_array(host)
+
+    class _P:
+        value = dbuf.ptr
+    dptr = _P()
     ex = orb_slam2_amd.ORBextractor(N, 1.2, 8, 20, 7, W, H, max_batch=B)
     ex.extract_device(dptr.value, B, H * pitch, pitch)
     voc.compute_bow(ex, B, 4)

@@ -21,10 +21,14 @@ sys.path.insert(0, ROOT)
 TUM1 = (517.306408, 516.469215, 318.643040, 255.313989, 0.262383, -0.953104, -0.005358, 0.002628, 1.163314)
 
 
+_KEEP = []
+
+
 def _upload(hip, host):
-    dptr = C.c_void_p()
-    assert hip.hipMalloc(C.byref(dptr), host.nbytes) == 0 and hip.hipMemcpy(dptr, host.ctypes.data_as(C.c_void_p), host.nbytes, 1) == 0
-    return dptr.value
+    import orb_slam2_amd
+    b = orb_slam2_amd.DeviceBuffer.from_array(host)          # the library's own HIP runtime
+    _KEEP.append(b)
+    return b.ptr
 
 
 def _ms(prof, name):
@@ -48,9 +52,7 @@ def main():
     args = ap.parse_args()
     import orb_slam2_amd
     from orb_slam2_amd import synth
-    hip = C.CDLL("libamdhip64.so")
-    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
-    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip = None
     B = args.batch
     out = {"batch": B}
 
