@@ -6,10 +6,10 @@ already resident in HBM): ORBextractor::operator() with 2000 features / 8 levels
 frame PLUS ORBmatcher(0.9,true).SearchForInitialization(F_{t-1}, F_t, window 100) of every slot against the frame the
 slot saw in the previous step (the unit of work).  value = frames of all ranks / max-over-ranks time.
 
-N = 1 imports no framework: the frames are made resident through the library's own HIP runtime (orbhip_device_alloc), the one the tests,
-smoke() and a real ORB_SLAM2 binary run on.  N > 1: one process per GPU; the library is loaded first, torch.distributed afterwards
-(backend nccl = RCCL, used ONLY for the barrier and the max-reduce of the timing; gloo if RCCL will not start on the system runtime):
-camera slots are independent, so ranks share nothing on the data path (no collective) -> weak scaling.
+No framework is imported at any N: the frames are made resident through the library's own HIP runtime (orbhip_device_alloc), the one
+the tests, smoke() and a real ORB_SLAM2 binary run on.  N > 1: one process per GPU (torch.distributed.run is only the launcher); camera
+slots are independent, so ranks share nothing on the data path (no collective, north_star: "no RCCL collective needed") -> weak scaling;
+the barrier and the max-over-ranks of the timings go over a Unix socket among the node's ranks (orb_slam2_amd.sharding.NodeRendezvous).
 `python bench.py --gpus N` without a launcher (WORLD_SIZE unset) re-executes itself under torch.distributed.run with N ranks;
 it refuses to run when fewer than N GPUs are visible instead of reporting a 1-GPU number.
 
@@ -203,6 +203,65 @@ def parity_of_last_step(host_frames, kps, descs, m12, last_step, T, blur_round_m
     return out
 
 
+def pool_mode(args):
+    """`--pool`: the product-side multi-GPU owner (orbhip_pool_*, what north_star describes: ONE process, one host thread + context +
+    pinned staging ring per GPU, camera c on devices[c mod G], no collective) timed at the drop-in boundary — host frames in, host key
+    points + descriptors out, PCIe both ways, rounds pipelined two deep.  Extraction only; its own JSON line (never the bench `value` of the
+    N-process mode).  G = --gpus (must be visible), cameras = G x --pool-cameras-per-gpu."""
+    import orb_slam2_amd
+    from oracle import orb_oracle as O                                  # the checker of the last round only
+    g = orb_slam2_amd.device_count()
+    if g < args.gpus:
+        raise SystemExit(f"bench.py --pool --gpus {args.gpus}: only {g} GPU(s) visible — refusing to report a {args.gpus}-GPU number")
+    G, per = args.gpus, args.pool_cameras_per_gpu
+    ncam = G * per
+    pool = orb_slam2_amd.MultiGpuExtractor(list(range(G)), ncam, NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, W, H, blur_round_mode=args.blur_round_mode)
+    nscenes = min(ncam, NSCENES)
+    rounds = []
+    for t in range(2):
+        src = orb_slam2_amd.pinned_array((ncam, H, W), np.uint8)
+        for s_ in range(nscenes):
+            from orb_slam2_amd import synth
+            fr = synth.frame_from_scene(synth.scene(W, H, seed=s_), W, H, t=t, seed=s_)
+            for c in range(s_, ncam, nscenes):
+                src[c] = fr
+        rounds.append(src)
+    cap = pool.capacity
+    bufs = [(orb_slam2_amd.pinned_array((ncam, cap), orb_slam2_amd.KEYPOINT_DTYPE), orb_slam2_amd.pinned_array((ncam, cap, 32), np.uint8), np.zeros(ncam, np.int32)) for _ in range(2)]
+    imgs = [[r[c] for c in range(ncam)] for r in rounds]
+    for i in range(max(args.warmup, 1)):
+        pool.collect(pool.submit(imgs[i & 1]), out=bufs[i & 1])
+    times = []
+    for rep in range(max(args.repeats, 1)):
+        t0 = time.perf_counter()
+        pending = [pool.submit(imgs[0])]
+        for i in range(1, args.steps):
+            pending.append(pool.submit(imgs[i & 1]))                   # round i uploads while round i-1 computes / downloads
+            pool.collect(pending.pop(0), out=bufs[(i - 1) & 1])
+        nout = pool.collect(pending.pop(0), out=bufs[(args.steps - 1) & 1])
+        times.append(time.perf_counter() - t0)
+    elapsed = sorted(times)[len(times) // 2]
+    last = (args.steps - 1) & 1
+    ora = O.OracleExtractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, blur_round_mode=args.blur_round_mode)
+    mism = 0
+    slots = [int(v) for v in np.linspace(0, nscenes - 1, min(args.parity_slots, nscenes)).round()] if args.parity_slots > 0 else []
+    for c in slots:
+        ko, do = ora.extract(np.ascontiguousarray(rounds[last][c]))
+        n = int(nout[c])
+        mism += 0 if (n == len(ko) and bufs[last][0][c, :n].tobytes() == ko.tobytes() and np.array_equal(bufs[last][1][c, :n], do)) else 1
+    frames_total = ncam * args.steps
+    out = {"metric": "frames/s ORB extract through the one-process GPU pool, host buffers in / out (PCIe both ways), 1241x376 gray, 2000 kpts, 8 lvls",
+           "mode": "pool", "value": round(frames_total / elapsed, 1), "unit": "frames/s", "n_gpus": G, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+           "config": {"workload": "KITTI-shaped 1241x376 u8, 2000 features, 8 levels, extract only", "cameras": ncam, "cameras_per_gpu": per,
+                      "parallelism": f"one process, {G} pool worker thread(s), camera c -> device c mod {G}, no collective", "buffers": "pinned caller buffers, two rounds in flight"},
+           "repeats": {"n": len(times), "frames_per_s_min": round(frames_total / max(times), 1), "frames_per_s_max": round(frames_total / min(times), 1)},
+           "parity": {"slots": len(slots), "mismatches": mism, "compared": "key points + descriptors of the last round vs oracle/"},
+           "runtime": {"library": orb_slam2_amd.runtime_info(), "mapped": orb_slam2_amd.mapped_hip_runtimes(), "framework_imported": "torch" in sys.modules}}
+    pool.close()
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -216,17 +275,25 @@ def main():
     ap.add_argument("--blur-round-mode", type=int, default=1, help="cv::GaussianBlur rounding the extractor reproduces: 1 = the SSE2 column filter of x86-64 OpenCV builds "
                     "(what the reference computes on this x86 box; default), 0 = OpenCV's generic C++ path (DESIGN.md H2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pool", action="store_true", help="time the one-process multi-GPU pool (orbhip_pool_*: one host thread per GPU) at the host-buffer boundary instead of "
+                    "the one-process-per-GPU device-resident benchmark; prints its own JSON line (mode: pool)")
+    ap.add_argument("--pool-cameras-per-gpu", type=int, default=128)
     ap.add_argument("--parity-slots", type=int, default=4, help="camera slots of the last timed step compared bit for bit with the oracle (0 = skip)")
     ap.add_argument("--extract-only", action="store_true", help="diagnostic: skip the matcher (NOT the metric's workload; the JSON line says so)")
     args = ap.parse_args()
+    if args.pool:
+        if args.steps == 150:
+            args.steps = 20
+        return pool_mode(args)
 
-    # The product library is loaded FIRST, so that it runs on the HIP runtime its RUNPATH names (/opt/rocm, the one the tests, smoke() and a
-    # real ORB_SLAM2 binary use).  N = 1 needs no framework at all: frames are made resident through the library (orbhip_device_alloc).
-    # N > 1 imports torch afterwards for the rendezvous only; its bundled libamdhip64 has the same SONAME, so the loader binds torch to the
-    # runtime that is already mapped — `runtime.mapped` in the JSON line lists what /proc/self/maps shows (must be one file).
+    # No framework in this process, at any N: the library runs on the HIP runtime its RUNPATH names (/opt/rocm — the one the tests, smoke()
+    # and a real ORB_SLAM2 binary use), frames are made resident through the library (orbhip_device_alloc), and the ranks of an N > 1 run
+    # (started by torch.distributed.run, which only spawns them and sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*) rendezvous over a
+    # Unix socket.  Importing torch here would map its bundled ROCm-7.0 libamdhip64 beside the system one (its libraries NEED the
+    # unversioned file name under RPATH $ORIGIN, so the loader does not reuse the mapped libamdhip64.so.7): measured, profiles/r03_*.
+    # `runtime.mapped` in the JSON line lists every libamdhip64 /proc/self/maps shows — it must be one file.
     import orb_slam2_amd
     share = os.environ.get("ORB_BENCH_SHARE_GPU") == "1"
-    force_dist = os.environ.get("ORB_BENCH_FORCE_DIST") == "1"       # test aid: take the N > 1 code path (process group, all-reduce) with one rank
     ngpu = orb_slam2_amd.device_count()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # launched bare: become the launcher.  One rank per GPU; never a silent 1-GPU run labelled N.
@@ -251,28 +318,9 @@ def main():
     if share:
         local_rank = 0
     runtime_line = orb_slam2_amd.runtime_info()                      # first device touch: on the library's runtime
-    dist = torch = None
-    control = "none (single process, no framework imported)"
-    if world > 1 or force_dist:
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if force_dist:
-            os.environ.setdefault("MASTER_PORT", "29533"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        if share:
-            dist.init_process_group(backend="gloo"); control = "gloo (ranks share GPU 0: test aid)"
-        else:
-            try:
-                torch.cuda.set_device(local_rank)
-                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-                probe = torch.zeros(1, device=f"cuda:{local_rank}"); dist.all_reduce(probe); torch.cuda.synchronize()
-                control = "nccl (RCCL): barrier + max-reduce of the timings only"
-            except Exception as e:                                       # noqa: BLE001 - the data path has no collective: the rendezvous may fall back
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                dist.init_process_group(backend="gloo")
-                control = f"gloo (RCCL rendezvous failed on the system HIP runtime: {type(e).__name__})"
-    on_gpu_ctl = control.startswith("nccl")
+    from orb_slam2_amd.sharding import NodeRendezvous
+    rdzv = NodeRendezvous(rank, world)                                # N > 1: barrier + max-reduce of the timings over a Unix socket; no data-path collective exists
+    control = "none (single process)" if world == 1 else "unix-socket rendezvous among the node's ranks: barrier + max-reduce of the timings only (no framework, no collective)"
 
     B, T = args.batch, max(args.tsteps, 2)
     pitch = (W + 63) // 64 * 64
@@ -287,10 +335,7 @@ def main():
 
     def barrier():
         orb_slam2_amd.device_synchronize(local_rank)                 # hipDeviceSynchronize: every stream of this rank's GPU
-        if dist is not None:
-            if on_gpu_ctl:
-                torch.cuda.synchronize()
-            dist.barrier()
+        rdzv.barrier()
 
     for i in range(args.warmup):
         step(i)
@@ -309,10 +354,7 @@ def main():
     prof = ex.profile()
     ex.profile_enable(False)
     last_step = args.warmup + max(args.repeats, 1) * args.steps - 1  # the step whose results are still in the context
-    if dist is not None:
-        tt = torch.tensor(times, dtype=torch.float64, device=f"cuda:{local_rank}" if on_gpu_ctl else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)                    # per repeat: the slowest rank
-        times = [float(v) for v in tt.tolist()]
+    times = rdzv.allreduce_max(times)                                # per repeat: the slowest rank
     elapsed = sorted(times)[len(times) // 2]                         # the median repeat is the reported one
 
     # the timed work's results (not timed): what the last step left in the context
@@ -387,9 +429,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(host_frames, blur_round_mode=args.blur_round_mode)
             out["cpu_baseline"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    rdzv.barrier()
+    rdzv.close()
 
 
 if __name__ == "__main__":

@@ -94,6 +94,11 @@ public:
     // synchronous, Frame.cc:247-253).  Submit() uploads and enqueues a batch of equally sized CV_8UC1 images and returns a ticket; up to
     // three batches may be in flight; Collect() blocks for the oldest ticket and delivers per image what operator() delivers.  Pageable
     // images are consumed when Submit returns; pinned ones are read by DMA until Collect.  maxBatch is fixed by the first Submit.
+    // The per-frame follow-ups below (UndistortKeyPoints, mvImagePyramid, ComputeStereoMatches, ComputeStereoFromRGBD) read the state of
+    // the last SINGLE-image call (operator(), ExtractColor, ExtractRectified).  After a Submit or a Collect that state belongs to some
+    // batch, not to one image: those members then throw ORBhipError until the next single-image call — batched callers use what Collect
+    // hands back.  A Submit that would have to re-create the context (a larger batch, another image size) while tickets are still in
+    // flight throws as well instead of destroying them.
     int Submit(const std::vector<cv::Mat>& images, int maxBatch = 0);
     void Collect(int ticket, std::vector<std::vector<cv::KeyPoint> >& keypoints, std::vector<cv::Mat>& descriptors);
     // Frame::ComputeStereoMatches (Frame.cc:466-640) on the GPU.  `this` is the left extractor, `right` the right one; both
@@ -147,6 +152,9 @@ protected:
     int mnCtxW, mnCtxH, mnCtxBatch, mnDevice, mnBlurRounding, mnFpContract;
     std::vector<int> mvTicketSizes;                              // images per ticket in flight (Submit / Collect), by ticket mod 4
     bool mbDownloadPyramid;
+    int mnPendingTickets;                                        // Submit()ed, not yet Collect()ed
+    bool mbFrameState;                                           // the context's current state is that of one single-image call
+    void RequireFrameState(const char* where) const;
     float mfScaleFactorArg;
 };
 

@@ -6,7 +6,7 @@
 //       the constructor, DescriptorDistance and SearchForInitialization — the part of the matcher that needs no map;
 //   * the nine map-dependent searches keep the reference's own bodies for their pose algebra and map bookkeeping; their candidate
 //     loops — the data-parallel part — are entry points of liborbhip.so on flat queries; INTEGRATION.md §2 shows the few lines that
-//     hand each loop over and oracle/make_dropin_full.py applies them to the reference's ORBmatcher.cc (checked against the unmodified
+//     hand each loop over and integration/apply_dropin.py applies them to the reference's ORBmatcher.cc (checked against the unmodified
 //     reference by tests/test_reference_dropin.py).  The comment on each declaration names the entry point.
 #ifndef ORBMATCHER_H
 #define ORBMATCHER_H

@@ -152,7 +152,10 @@ int orbhip_pool_device_of(const orbhip_pool* pool, int camera);          /* devi
 int orbhip_pool_keypoint_capacity(const orbhip_pool* pool);
 /* one frame per camera (imgs[c] == NULL: that camera has no frame this round, n_out[c] = 0); outputs are [ncameras][cap].
    orbhip_pool_extract = orbhip_pool_submit + orbhip_pool_collect; with submit / collect a caller keeps up to
-   orbhip_ring_depth() rounds in flight (tickets collected in order). */
+   orbhip_ring_depth() rounds in flight (tickets collected in order).  A round that only SOME devices could take (a HIP failure on one
+   device) still gets its ticket — the parts the other devices took must be collected in order like any other — and
+   orbhip_pool_collect of that ticket delivers the healthy cameras and returns the refusing device's status; a round no device took
+   fails in orbhip_pool_submit itself, without a ticket.  Either way the pool stays usable. */
 orbhip_status orbhip_pool_extract(orbhip_pool* pool, const uint8_t* const* imgs, int stride_bytes,
                                   orbhip_keypoint* kps, uint8_t* desc, int cap, int* n_out /* ncameras */);
 orbhip_status orbhip_pool_submit(orbhip_pool* pool, const uint8_t* const* imgs, int stride_bytes, int* ticket);

@@ -31,7 +31,7 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int
 #else
       mnFpContract(0),
 #endif
-      mvTicketSizes(4, 0), mbDownloadPyramid(false), mfScaleFactorArg(_scaleFactor)
+      mvTicketSizes(4, 0), mbDownloadPyramid(false), mnPendingTickets(0), mbFrameState(false), mfScaleFactorArg(_scaleFactor)
 {
     memset(mCamera, 0, sizeof mCamera);
     mvScaleFactor.resize(nlevels); mvLevelSigma2.resize(nlevels);
@@ -51,6 +51,13 @@ ORBextractor::~ORBextractor() { if (mpCtx) orbhip_destroy(mpCtx); }
 void ORBextractor::Fail(const char* where) const
 {
     throw ORBhipError(std::string(where) + ": " + orbhip_last_error());
+}
+
+void ORBextractor::RequireFrameState(const char* where) const
+{
+    if (!mbFrameState)
+        throw ORBhipError(std::string(where) + ": only valid after a single-image call (operator(), ExtractColor, ExtractRectified); after Submit / Collect the "
+                          "context holds a batch — use the results Collect returned");
 }
 
 void ORBextractor::SetBlurRounding(int mode)
@@ -76,6 +83,7 @@ void ORBimagePyramid::Refresh()
 void ORBextractor::FetchPyramid(std::vector<cv::Mat>& levels)
 {
     if (!mpCtx) return;
+    RequireFrameState("ORBextractor::mvImagePyramid");
     std::vector<uint8_t*> dst(nlevels); std::vector<int> stride(nlevels);
     for (int l = 0; l < nlevels; l++) {
         int w = 0, h = 0; orbhip_level_size(mpCtx, l, &w, &h);
@@ -88,6 +96,8 @@ void ORBextractor::FetchPyramid(std::vector<cv::Mat>& levels)
 void ORBextractor::EnsureContext(int width, int height, int maxBatch)
 {
     if (mpCtx && width == mnCtxW && height == mnCtxH && maxBatch <= mnCtxBatch) return;
+    if (mpCtx && mnPendingTickets > 0)
+        throw ORBhipError("ORBextractor: the device context would have to be re-created (image size or batch changed) while Submit()ed batches are still in flight: Collect them first");
     if (mpCtx) { orbhip_destroy(mpCtx); mpCtx = NULL; }
     orbhip_config cfg; memset(&cfg, 0, sizeof cfg);
     cfg.nfeatures = nfeatures; cfg.scale_factor = mfScaleFactorArg; cfg.nlevels = nlevels; cfg.ini_th_fast = iniThFAST; cfg.min_th_fast = minThFAST;
@@ -151,6 +161,7 @@ void ORBextractor::SetCamera(const cv::Mat& K, const cv::Mat& distCoef)
 
 void ORBextractor::UndistortKeyPoints(std::vector<cv::KeyPoint>& mvKeysUn)
 {
+    if (mpCtx) RequireFrameState("ORBextractor::UndistortKeyPoints");
     mvKeysUn.resize(mnLastN);
     if (mnLastN == 0 || !mpCtx) return;
     if (orbhip_fetch_undistorted(mpCtx, 1, reinterpret_cast<orbhip_keypoint*>(&mvKeysUn[0]), mnLastN) != ORBHIP_OK) Fail("ORBextractor::UndistortKeyPoints");
@@ -171,6 +182,7 @@ void ORBextractor::ComputeStereoFromRGBD(const cv::Mat& imDepth, float depthFact
     mvuRight = std::vector<float>(N, -1);                        // Frame.cc:645-646
     mvDepth = std::vector<float>(N, -1);
     if (N == 0 || !mpCtx) return;
+    RequireFrameState("ORBextractor::ComputeStereoFromRGBD");
     assert(imDepth.type() == CV_32F || imDepth.type() == CV_16U);
     const void* maps[1] = {imDepth.data};
     if (orbhip_compute_stereo_from_rgbd(mpCtx, 1, maps, (int)imDepth.step, imDepth.type() == CV_32F ? 0 : 1, depthFactor, mbf, &mvuRight[0], &mvDepth[0], N) != ORBHIP_OK) Fail("ORBextractor::ComputeStereoFromRGBD");
@@ -204,7 +216,7 @@ void ORBextractor::ExtractRectified(const cv::Mat& raw, std::vector<cv::KeyPoint
 
 void ORBextractor::Deliver(int n, const std::vector<unsigned char>& desc, std::vector<cv::KeyPoint>& _keypoints, cv::OutputArray _descriptors)
 {
-    mnLastN = n;
+    mnLastN = n; mbFrameState = true;
     _keypoints.resize(n);
     if (n == 0) _descriptors.release();                          // ORBextractor.cc:1064-1065
     else {
@@ -231,7 +243,7 @@ int ORBextractor::Submit(const std::vector<cv::Mat>& images, int maxBatch)
     for (int i = 0; i < n; i++) ptrs[i] = images[i].data;
     int ticket = -1;
     if (orbhip_submit(mpCtx, n, &ptrs[0], (int)images[0].step, &ticket) != ORBHIP_OK) Fail("ORBextractor::Submit");
-    mvTicketSizes[ticket & 3] = n;
+    mvTicketSizes[ticket & 3] = n; mnPendingTickets++; mbFrameState = false;
     return ticket;
 }
 
@@ -241,6 +253,7 @@ void ORBextractor::Collect(int ticket, std::vector<std::vector<cv::KeyPoint> >& 
     const int n = mvTicketSizes[ticket & 3], cap = orbhip_keypoint_capacity(mpCtx);
     std::vector<orbhip_keypoint> kps((size_t)n * cap); std::vector<unsigned char> desc((size_t)n * cap * 32); std::vector<int> cnt(n, 0);
     if (orbhip_collect(mpCtx, ticket, &kps[0], &desc[0], cap, &cnt[0]) != ORBHIP_OK) Fail("ORBextractor::Collect");
+    if (mnPendingTickets > 0) mnPendingTickets--;
     keypoints.resize(n); descriptors.resize(n);
     for (int i = 0; i < n; i++) {
         keypoints[i].resize(cnt[i]);
@@ -249,7 +262,7 @@ void ORBextractor::Collect(int ticket, std::vector<std::vector<cv::KeyPoint> >& 
         descriptors[i].create(cnt[i], 32, CV_8U);
         for (int r = 0; r < cnt[i]; r++) memcpy(descriptors[i].ptr(r), &desc[((size_t)i * cap + r) * 32], 32);
     }
-    mnLastN = cnt[n - 1];
+    mnLastN = 0; mbFrameState = false;                            // the context's planes / key points are some batch's, not one image's
     std::lock_guard<std::mutex> lock(mvImagePyramid.mMutex);
     mvImagePyramid.mbStale = true;
 }
@@ -259,6 +272,7 @@ void ORBextractor::ComputeStereoMatches(ORBextractor& right, float mbf, float mb
     mvuRight = std::vector<float>(N, -1.0f);                     // Frame.cc:468-469
     mvDepth = std::vector<float>(N, -1.0f);
     if (N == 0 || !mpCtx || !right.mpCtx) return;
+    RequireFrameState("ORBextractor::ComputeStereoMatches"); right.RequireFrameState("ORBextractor::ComputeStereoMatches (right)");
     if (orbhip_compute_stereo_matches(mpCtx, right.mpCtx, 1, mbf, mb, &mvuRight[0], &mvDepth[0], N) != ORBHIP_OK) Fail("ORBextractor::ComputeStereoMatches");
 }
 

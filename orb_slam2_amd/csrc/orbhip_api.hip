@@ -932,7 +932,21 @@ static int host_chunk_frames(int nimg)
     return std::max(ch, (nimg + ORBHIP_MAX_CHUNKS - 1) / ORBHIP_MAX_CHUNKS);
 }
 
+static orbhip_status submit_body(orbhip_ctx* c, int nimg, const uint8_t* const* imgs, int stride, orbhip_keypoint* direct_kp, uint8_t* direct_desc, int direct_cap, int* ticket);
+// A submit that fails half-way (a HIP error between the first upload and the last download of the batch) issued no ticket: whatever it
+// enqueued is drained here, so that the staging set it used is quiet again and the ring state is exactly what it was before the call.
 static orbhip_status submit_impl(orbhip_ctx* c, int nimg, const uint8_t* const* imgs, int stride, orbhip_keypoint* direct_kp, uint8_t* direct_desc, int direct_cap, int* ticket)
+{
+    const int before = c->next_ticket;
+    const orbhip_status st = submit_body(c, nimg, imgs, stride, direct_kp, direct_desc, direct_cap, ticket);
+    if (st != ORBHIP_OK && c->next_ticket == before && st == ORBHIP_ERR_HIP) {
+        const std::string msg = orbhip_last_error();
+        (void)hipDeviceSynchronize(); (void)hipGetLastError();
+        return fail(st, "%s", msg.c_str());
+    }
+    return st;
+}
+static orbhip_status submit_body(orbhip_ctx* c, int nimg, const uint8_t* const* imgs, int stride, orbhip_keypoint* direct_kp, uint8_t* direct_desc, int direct_cap, int* ticket)
 {
     if (nimg < 1 || nimg > c->B) return fail(ORBHIP_ERR_INVALID, "nimg %d outside 1..%d", nimg, c->B);
     if (stride < c->cfg.width) return fail(ORBHIP_ERR_INVALID, "stride %d < width %d", stride, c->cfg.width);
@@ -1027,7 +1041,11 @@ orbhip_status orbhip_collect_scatter(orbhip_ctx* c, int ticket, orbhip_keypoint*
     bool overflow = false;
     const size_t oc = (size_t)c->out_cap;
     for (int k = 0; k < hs.nchunks; k++) {
-        HIPCHK(hipEventSynchronize(hs.ev_d2h[k]));
+        const hipError_t we = hipEventSynchronize(hs.ev_d2h[k]);
+        if (we != hipSuccess) {      // the ticket is retired all the same: a ticket that stays "oldest" for ever would block the ring behind it
+            hs.busy = false; c->oldest_ticket++;
+            return fail(ORBHIP_ERR_HIP, "hipEventSynchronize (batch %d, chunk %d): %s", ticket, k, hipGetErrorString(we));
+        }
         const int f0 = hs.chunk_f0[k], nf = hs.chunk_f0[k + 1] - f0;
         const orbhip_keypoint* h_kp = hs.h_kp; const uint8_t* h_desc = hs.h_desc; const int* h_n = hs.h_n; const bool direct = hs.direct_kp != nullptr;
         for (int i = 0; i < nf; i++) { const int n = h_n[f0 + i]; if (n_out[f0 + i]) *n_out[f0 + i] = n; if (n > cap) overflow = true; }

@@ -28,7 +28,7 @@ struct Worker {
     // result of the last task(s)
     orbhip_status st = ORBHIP_OK; std::string err;
     // frames: per pool ticket (mod ring) the context's ticket and the cameras it covered
-    int ctx_ticket[8]; std::vector<int> cams[8];
+    int ctx_ticket[8]; std::vector<int> cams[8]; orbhip_status slot_st[8] = {}; std::string slot_err[8];
     // descriptor DB shard + query staging
     uint8_t* d_db = nullptr; int64_t lo = 0, hi = 0;
     hipStream_t qstream = nullptr; uint8_t* d_q = nullptr; long long* d_bi = nullptr; int* d_bd = nullptr; int* d_sd = nullptr; int q_cap = 0;
@@ -97,7 +97,7 @@ extern "C" orbhip_status orbhip_pool_create(orbhip_pool** out, const int* device
         Worker* wp = w.get();
         w->th = std::thread([wp] { wp->loop(); });
         orbhip_config c = *cfg; c.device = devices[r]; c.max_batch = p->per_dev; c.stream = nullptr;
-        w->post([wp, c] { if (orbhip_create(&wp->ctx, &c) != ORBHIP_OK) wp->fail_from_thread(ORBHIP_ERR_HIP); });
+        w->post([wp, c] { const orbhip_status s = orbhip_create(&wp->ctx, &c); if (s != ORBHIP_OK) wp->fail_from_thread(s); });
         p->w.push_back(std::move(w));
     }
     for (auto& w : p->w) w->wait();
@@ -124,11 +124,22 @@ extern "C" orbhip_status orbhip_pool_submit(orbhip_pool* p, const uint8_t* const
         if (w->cams[slot].empty()) continue;
         w->post([w, slot, imgs, stride] {
             std::vector<const uint8_t*> mine; for (int c : w->cams[slot]) mine.push_back(imgs[c]);
-            if (orbhip_submit(w->ctx, (int)mine.size(), mine.data(), stride, &w->ctx_ticket[slot]) != ORBHIP_OK) w->fail_from_thread(ORBHIP_ERR_HIP);
+            // ORBHIP_TEST_FAIL_SUBMIT_WORKER=<r> (fault injection for the test of the partial-failure path): worker r refuses its submits
+            const char* inj = getenv("ORBHIP_TEST_FAIL_SUBMIT_WORKER");
+            if (inj && *inj && atoi(inj) == w->index) { w->ctx_ticket[slot] = -1; w->st = ORBHIP_ERR_HIP; w->err = "injected submit failure"; return; }
+            const orbhip_status s = orbhip_submit(w->ctx, (int)mine.size(), mine.data(), stride, &w->ctx_ticket[slot]);
+            if (s != ORBHIP_OK) { w->ctx_ticket[slot] = -1; w->fail_from_thread(s); }
         });
     }
     for (auto& w : p->w) w->wait();                       // pageable frames are staged (in parallel, one thread per device) when this returns
-    const orbhip_status st = pool_status(p, "orbhip_pool_submit"); if (st != ORBHIP_OK) return st;
+    // A device that refused its part of the round: tickets are collected strictly in submission order, so the parts the other devices did
+    // take cannot be withdrawn (older rounds may still be in flight before them).  The round therefore gets its pool ticket all the same —
+    // every context ticket has an owner — and the refusal is reported by orbhip_pool_collect of that ticket (the refused cameras deliver
+    // nothing).  Only a round that NO device took fails here, without a ticket.
+    bool any_taken = false, any_failed = false;
+    for (auto& w : p->w) { any_taken = any_taken || w->ctx_ticket[slot] >= 0; any_failed = any_failed || w->st != ORBHIP_OK; }
+    if (any_failed && !any_taken) return pool_status(p, "orbhip_pool_submit");
+    for (auto& w : p->w) { w->slot_st[slot] = w->st; w->slot_err[slot] = w->err; w->st = ORBHIP_OK; w->err.clear(); }
     *ticket = p->next_ticket++;
     return ORBHIP_OK;
 }
@@ -152,7 +163,10 @@ extern "C" orbhip_status orbhip_pool_collect(orbhip_pool* p, int ticket, orbhip_
     }
     for (auto& w : p->w) w->wait();
     p->oldest_ticket++;
-    return pool_status(p, "orbhip_pool_collect");
+    const orbhip_status st = pool_status(p, "orbhip_pool_collect"); if (st != ORBHIP_OK) return st;
+    for (auto& w : p->w)                                  // a device that had refused this round at submit time
+        if (w->slot_st[slot] != ORBHIP_OK) { const orbhip_status s = w->slot_st[slot]; w->slot_st[slot] = ORBHIP_OK; return orbhip_set_error(s, "orbhip_pool_submit of this round (device %d): %s", w->device, w->slot_err[slot].c_str()); }
+    return ORBHIP_OK;
 }
 
 extern "C" orbhip_status orbhip_pool_extract(orbhip_pool* p, const uint8_t* const* imgs, int stride, orbhip_keypoint* kps, uint8_t* desc, int cap, int* n_out)

@@ -64,6 +64,12 @@ def oracle():
 def emu_lib():
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc"))]
     srcs += [os.path.join(ROOT, "include", "orbhip.h"), os.path.join(ROOT, "tests", "emu", "include", "hip", "hip_runtime.h")]
+    override = os.environ.get("ORBHIP_EMU_LIB")                      # e.g. the AddressSanitizer build (make -C orb_slam2_amd/csrc emu_asan; tools/asan_suite.sh)
+    if override:
+        override = os.path.abspath(override)
+        if not os.path.exists(override):
+            pytest.fail(f"ORBHIP_EMU_LIB={override} does not exist")
+        return override
     if not _newer(EMU_LIB, srcs):
         subprocess.check_call(["make", "-C", CSRC, "-s", "emu"])
     return EMU_LIB

@@ -134,6 +134,34 @@ int main(int argc, char** argv)
         if (nr) { fwrite(&kr[0], sizeof(cv::KeyPoint), nr, f); for (int i = 0; i < nr; i++) fwrite(dr.ptr(i), 1, 32, f); }
         fwrite(exM->mvImagePyramid[0].data, 1, (size_t)W * H, f);
         delete exM;
+        // Submit / Collect: two batches in flight deliver what operator() delivers; afterwards the per-frame follow-ups refuse (the
+        // context holds a batch), a Submit that would re-create the context with a ticket in flight refuses, and a single-image call
+        // makes the follow-ups valid again.  One int per expectation.
+        {
+            ORB_SLAM2::ORBextractor* exB = new ORB_SLAM2::ORBextractor(N, 1.2f, 8, 20, 7);
+            std::vector<cv::Mat> b01(2), b10(2); b01[0] = im[0]; b01[1] = im[1]; b10[0] = im[1]; b10[1] = im[0];
+            const int t0 = exB->Submit(b01, 2), t1 = exB->Submit(b10);
+            std::vector<std::vector<cv::KeyPoint> > k0, k1; std::vector<cv::Mat> d0, d1;
+            int refuse_grow = 0;
+            std::vector<cv::Mat> three(3, im[0]);
+            try { exB->Submit(three); } catch (const ORB_SLAM2::ORBhipError&) { refuse_grow = 1; }      // would destroy tickets t0, t1
+            exB->Collect(t0, k0, d0); exB->Collect(t1, k1, d1);
+            int same = (int)k0[0].size() == F1.N && (int)k0[1].size() == F2.N && (int)k1[0].size() == F2.N && (int)k1[1].size() == F1.N;
+            same = same && !memcmp(&k0[0][0], &F1.mvKeys[0], sizeof(cv::KeyPoint) * F1.N) && !memcmp(&k1[0][0], &F2.mvKeys[0], sizeof(cv::KeyPoint) * F2.N)
+                        && !memcmp(&k0[1][0], &F2.mvKeys[0], sizeof(cv::KeyPoint) * F2.N) && !memcmp(&k1[1][0], &F1.mvKeys[0], sizeof(cv::KeyPoint) * F1.N);
+            for (int i = 0; i < F1.N && same; i++) same = !memcmp(d0[0].ptr(i), F1.mDescriptors.ptr(i), 32) && !memcmp(d1[1].ptr(i), F1.mDescriptors.ptr(i), 32);
+            int refuse_un = 0, refuse_pyr = 0;
+            std::vector<cv::KeyPoint> un;
+            try { exB->UndistortKeyPoints(un); } catch (const ORB_SLAM2::ORBhipError&) { refuse_un = 1; }
+            try { (void)exB->mvImagePyramid[0].cols; } catch (const ORB_SLAM2::ORBhipError&) { refuse_pyr = 1; }
+            std::vector<cv::KeyPoint> ks; cv::Mat ds;
+            (*exB)(im[0], cv::Mat(), ks, ds);                                                           // grows nothing: same size, batch 1 <= 2
+            int valid_again = 1;
+            try { exB->UndistortKeyPoints(un); valid_again = (int)un.size() == F1.N && exB->mvImagePyramid[0].cols == W; } catch (const ORB_SLAM2::ORBhipError&) { valid_again = 0; }
+            const int flags[5] = {same, refuse_grow, refuse_un, refuse_pyr, valid_again};
+            fwrite(flags, 4, 5, f);
+            delete exB;
+        }
     }
     fclose(f);
     delete ex; delete exL; delete exR;

@@ -86,6 +86,9 @@ def _run(exe, tmp_path, oracle, threads=False, blur=None):
     kr = np.frombuffer(buf, orb_slam2_amd.KEYPOINT_DTYPE, nr, off); off += 28 * nr
     dr = np.frombuffer(buf, np.uint8, 32 * nr, off).reshape(nr, 32); off += 32 * nr
     rect0 = np.frombuffer(buf, np.uint8, w * h, off).reshape(h, w); off += w * h
+    batch_flags = struct.unpack_from("<5i", buf, off); off += 20
+    assert batch_flags == (1, 1, 1, 1, 1), f"Submit/Collect (same results, refuse context growth in flight, refuse undistort, refuse pyramid, valid again): {batch_flags}"
+    assert off == len(buf)
 
     ora = mk()
     ref = [ora.extract(im) for im in seq]

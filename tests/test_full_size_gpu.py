@@ -1,5 +1,7 @@
 """GPU-only tests at BASELINE.json's full sizes: bit-exact parity on the metric's own configuration (KITTI 1241x376,
 2000 features), the other configs' shapes, and size-independent properties where the oracle would be too slow."""
+import os
+
 import numpy as np
 import pytest
 
@@ -90,3 +92,45 @@ def test_descriptor_db_shards_full_width(gpu_lib, oracle):
     # linear-algebra style check of the distance itself: d(q, db[idx]) recomputed on the host
     d = np.unpackbits(q ^ db[full[0]], axis=1).sum(axis=1)
     assert np.array_equal(d.astype(np.int32), full[1])
+
+
+def test_descriptor_db_config5_full_size():
+    """BASELINE.json configs[4] at its own size: 10 000 key frames x 2000 = 20 M rows (640 MB), a 2000-descriptor query, EVERY query's
+    (best index, best distance, second distance) against the oracle's brute force (4 x 10^10 distances over the host cores, ~20 s on the
+    GPU box), and the row-sharded pool answer against the single scan (ORBmatcher.cc:447-456 idiom: strict '<', lowest index wins).
+    Runs tools/db_full_parity.py in its own process (the oracle side forks one worker per core)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "db_full_parity.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["rows"] == 20_000_000 and out["queries_compared"] == 2000
+    assert out["parity"] == "bit-exact" and out["sharded_equals_single_scan"] is True
+    assert out["mismatches_best_idx"] == out["mismatches_best_dist"] == out["mismatches_second_dist"] == 0
+    assert out["planted_found"] >= 900
+
+
+def test_config4_rig_through_the_pool(gpu_lib, oracle):
+    """BASELINE.json configs[3] at its own shape through the product-side pool: an 8-camera rig, 1920x1080 per camera, 4000 features each,
+    camera c on devices[c mod G] over every visible device (a 1-GPU box: two contexts on GPU 0, four cameras each), two rounds in flight —
+    every camera's key points and descriptors bit-exact against the oracle (the reference's analogue: the two extractor threads of the
+    stereo Frame constructor, Frame.cc:78-81)."""
+    w, h, n, ncam = 1920, 1080, 4000, 8
+    g = orb_slam2_amd.device_count(gpu_lib)
+    devices = list(range(g)) if g >= 2 else [0, 0]
+    frames = [synth.frame(w, h, seed=300 + c) for c in range(ncam)]
+    nxt = [synth.frame(w, h, seed=400 + c) for c in range(ncam)]
+    ora = oracle.OracleExtractor(n, 1.2, 8, 20, 7, fast=True)
+    pool = orb_slam2_amd.MultiGpuExtractor(devices, ncam, n, 1.2, 8, 20, 7, w, h, library=gpu_lib)
+    assert [pool.device_of(c) for c in range(ncam)] == [devices[c % len(devices)] for c in range(ncam)]
+    t0 = pool.submit(frames)
+    t1 = pool.submit(nxt)
+    for t, fr in ((t0, frames), (t1, nxt)):
+        k, d = pool.collect(t)
+        for c in range(ncam):
+            ko, do = ora.extract(fr[c])
+            assert len(k[c]) >= n - 50
+            _same(k[c], d[c], ko, do)
+    pool.close()

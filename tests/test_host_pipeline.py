@@ -127,6 +127,31 @@ def test_pool_cameras_round_robin(backend, frames, want, monkeypatch):
     pool.close()
 
 
+def test_pool_survives_partial_submit_failure(backend, frames, want, monkeypatch):
+    """One device refuses a round (injected): the round keeps its ticket (the other device's part must be collected in order), collect
+    delivers the healthy cameras and reports the refusal, and the pool keeps working — a context ticket nobody collects would wedge its
+    ring for good.  A round NO device takes fails at submit, without a ticket."""
+    devices = _pool_devices(backend, monkeypatch, 2)
+    pool = orb_slam2_amd.MultiGpuExtractor(devices, 4, N, 1.2, 8, 20, 7, W, H, library=backend)
+    t0 = pool.submit(frames[:4])
+    monkeypatch.setenv("ORBHIP_TEST_FAIL_SUBMIT_WORKER", "1")
+    t1 = pool.submit(frames[4:8])                                 # worker 1 (cameras 1, 3) refuses; worker 0 took cameras 0, 2
+    with pytest.raises(orb_slam2_amd.OrbHipError, match="injected submit failure"):
+        pool.submit([None, frames[5], None, frames[7]])           # only worker 1 has work and it refuses: no ticket
+    monkeypatch.delenv("ORBHIP_TEST_FAIL_SUBMIT_WORKER")
+    t2 = pool.submit(frames[8:12])
+    k, d = pool.collect(t0)
+    _same(k, d, want, range(4))
+    with pytest.raises(orb_slam2_amd.OrbHipError, match="injected submit failure"):
+        pool.collect(t1)
+    k, d = pool.collect(t2)
+    _same(k, d, want, range(8, 12))
+    for _ in range(4):                                            # more rounds than the ring is deep: nothing is left in flight
+        k, d = pool.extract(frames[4:8])
+        _same(k, d, want, range(4, 8))
+    pool.close()
+
+
 def test_pool_db_shards_and_reloc_candidates(backend, oracle, monkeypatch):
     devices = _pool_devices(backend, monkeypatch, 3)
     pool = orb_slam2_amd.MultiGpuExtractor(devices, 3, N, 1.2, 8, 20, 7, W, H, library=backend)

@@ -133,3 +133,37 @@ def test_bench_gpus_flag_on_this_box():
         assert r.returncode == 0, r.stderr[-2000:]
         line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
         assert json.loads(line)["n_gpus"] == 2
+
+
+def _rdzv_worker(rank, world, key, q):
+    sys.path.insert(0, ROOT)
+    from orb_slam2_amd.sharding import NodeRendezvous
+    r = NodeRendezvous(rank, world, key=key, timeout_s=60)
+    r.barrier()
+    a = r.allreduce_max([float(rank), 10.0 - rank, 3.5])
+    b = r.allreduce_max([1.0 / (rank + 1)])
+    r.barrier()
+    r.close()
+    q.put((rank, a, b))
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_node_rendezvous_barrier_and_max(world):
+    """bench.py's N > 1 control plane (framework-free): element-wise max over ranks, identical on every rank, repeated exchanges."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    key = f"test_{os.getpid()}_{world}"
+    ps = [ctx.Process(target=_rdzv_worker, args=(r, world, key, q)) for r in range(world)]
+    for p in ps[::-1]:                                   # the listener (rank 0) starts last: clients must wait for it
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, a, b in got:
+        assert a == [float(world - 1), 10.0, 3.5] and b == [1.0]
+    from orb_slam2_amd.sharding import NodeRendezvous
+    solo = NodeRendezvous(0, 1)
+    assert solo.allreduce_max([2.0, 1.0]) == [2.0, 1.0]
+    solo.barrier(); solo.close()
