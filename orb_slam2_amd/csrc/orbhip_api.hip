@@ -301,7 +301,13 @@ extern "C" void orbhip_destroy(orbhip_ctx* c)
 
 // LDS row stride of a k_fast_cells patch: 4 * (groups + 2) bytes cover every window read; 48 bytes for the usual 37-px cells puts the
 // eight rows a wave reads at once on each LDS bank exactly twice (the minimum for 64 lanes x 4 bytes)
-static int fc_pstride(const orbhip_ctx* c) { return (c->fc_maxpw + 8 + 3) & ~3; }
+static int fc_pstride(const orbhip_ctx* c)
+{
+    const int need = (c->fc_maxpw + 8 + 3) & ~3;
+    const char* e = getenv("ORBHIP_FC_PSTRIDE");                  // experiment knob: a larger LDS row stride of the FAST patch (bytes, multiple of 4)
+    const int forced = e ? atoi(e) & ~3 : 0;
+    return forced >= need ? forced : need;
+}
 
 extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cfg)
 {

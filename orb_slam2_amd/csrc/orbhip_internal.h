@@ -188,6 +188,17 @@ void orbhip_launch_match_select(const MatchParams& M, int nslots, hipStream_t s)
 
 // shared with orbhip_bow.hip
 void orbhip_bow_thread_release();
+// v_writelane_b32: a wave-uniform value dropped into ONE lane of a register (lane index wave-uniform too).  The compiler has no builtin for
+// it, so the device pass spells the instruction; every other pass (hipcc's host pass, the test emulation) sees the plain selection.
+__device__ __forceinline__ int orbhip_writelane(int v, int dst_lane, int old)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && __HIP_DEVICE_COMPILE__
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(v), "s"(dst_lane) : "m0");      // one SGPR operand on the constant bus: the lane select goes through M0
+    return old;
+#else
+    return (int)__lane_id() == dst_lane ? v : old;
+#endif
+}
 void orbhip_touch_thread_caches();      // makes sure the calling thread's cache holder exists (its destructor releases the caches of worker threads)
 orbhip_status orbhip_set_error(orbhip_status st, const char* fmt, ...);
 void orbhip_internal_outputs(orbhip_ctx* c, const uint8_t** d_desc, const int** d_n, int* cap, int* last_nimg, int* device, hipStream_t* s);

@@ -242,18 +242,24 @@ __device__ __forceinline__ PyrTile pyr_dma_issue(const ExtractParams& P, const L
     S.src = level_src(P, frame, level - 1, S.spitch);
     const int2* xt = P.xtab + g.xtab_off; const int2* yt = P.ytab + g.ytab_off;
     const int xl = min(T.x0 + PYR_TW - 1, g.w - 1), yl = min(T.y0 + PYR_TH - 1, g.h - 1);
-    T.sxa = xt[T.x0].x & ~3; const int sxb = min(xt[xl].x + 1, g.src_w - 1);
-    T.sya = min(max(yt[T.y0].x, 0), g.src_h - 1); const int syb = min(max(yt[yl].x + 1, 0), g.src_h - 1);
+    // the table entries are the same for every lane: pinned to SGPRs, so that the footprint and every row address below are scalar arithmetic
+    // (as vector loads they made each row's address a 64-bit VALU multiply-add plus two v_readfirstlane: 65 VALU per tile, PMC round 3)
+    const int e_x0 = __builtin_amdgcn_readfirstlane(xt[T.x0].x), e_xl = __builtin_amdgcn_readfirstlane(xt[xl].x);
+    const int e_y0 = __builtin_amdgcn_readfirstlane(yt[T.y0].x), e_yl = __builtin_amdgcn_readfirstlane(yt[yl].x);
+    T.sxa = e_x0 & ~3; const int sxb = min(e_xl + 1, g.src_w - 1);
+    T.sya = min(max(e_y0, 0), g.src_h - 1); const int syb = min(max(e_yl + 1, 0), g.src_h - 1);
     S.ndw = ((sxb - T.sxa) >> 2) + 1; S.nrows = syb - T.sya + 1; S.dfull = (g.src_w - T.sxa) >> 2;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int omax = g.src_w - 4 - T.sxa;                              // byte offset of the last dword that ends inside the row (negative when fewer than 4 columns remain: still in the row)
     const int off0 = min(4 * lane, omax), off1 = min(4 * (lane + 64), omax);
+    const ORBHIP_GLOBAL uint8_t* plane = uniform_ptr(S.src);
+    const unsigned spitch = (unsigned)__builtin_amdgcn_readfirstlane(S.spitch);
 #pragma unroll
     for (int j = 0; j < PYR_SROWS / 4; j++) {
         const int r = wave + 4 * j;
-        const ORBHIP_GLOBAL uint8_t* row = uniform_ptr(S.src + (long long)(T.sya + min(r, S.nrows - 1)) * S.spitch + T.sxa);
-        lds_dma_dword(row + off0, reinterpret_cast<uint8_t*>(s_t + r * PYR_SDW));
-        if (lane < PYR_SDW - 64) lds_dma_dword(row + off1, reinterpret_cast<uint8_t*>(s_t + r * PYR_SDW + 64));
+        const unsigned roff = (unsigned)(T.sya + min(r, S.nrows - 1)) * spitch + (unsigned)T.sxa;      // scalar; a level plane is far below 2^31 bytes
+        lds_dma_dword(plane + (roff + (unsigned)off0), reinterpret_cast<uint8_t*>(s_t + r * PYR_SDW));
+        if (lane < PYR_SDW - 64) lds_dma_dword(plane + (roff + (unsigned)off1), reinterpret_cast<uint8_t*>(s_t + r * PYR_SDW + 64));
     }
     return T;
 }
@@ -820,6 +826,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
     const int rp = (64 * cd.inv_ng) >> 16;
     const int sr = (lane * cd.inv_ng) >> 16, grp = lane - sr * ng;
     const bool lane_ok = sr < rp;
+    const unsigned long long lok_mask = __builtin_amdgcn_ballot_w64(lane_ok);
     unsigned* out = P.cell_cand + (long long)frame * P.cand_slots_per_frame + cd.cand_idx;
 
     // The two cv::FAST calls of the reference (ORBextractor.cc:809-816): iniThFAST, and minThFAST only when the first returned
@@ -846,11 +853,14 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
                 pa = fast_pretest_pair(ra, row_pair<3>(w[3][0], w[3][1], w[3][2]), tt);         // score >= t  <=>  best arc margin > t  =>  every opposite pair's margin > t
                 pb = fast_pretest_pair(rb, row_pair<5>(w[3][0], w[3][1], w[3][2]), tt);
             }
-            pa = act ? pa : 0u; pb = act ? pb : 0u;
-            const unsigned long long ma = __ballot(pa != 0), mb = __ballot(pb != 0);
+            // ballots of plain compares are the compare's own lane mask; their conjunctions stay on the scalar unit (a ballot of `a && b` is
+            // materialised as select + re-compare, 2 VALU each)
+            const unsigned long long am = __builtin_amdgcn_ballot_w64(yy < ch) & lok_mask;
+            const unsigned long long ma = __builtin_amdgcn_ballot_w64(pa != 0) & am, mb = __builtin_amdgcn_ballot_w64(pb != 0) & am;
+            const bool la = act && pa != 0, lb = act && pb != 0;
             int pos = fc_rank(mb, fc_rank(ma, nq));
-            if (pa != 0) list[pos++] = (unsigned short)((y << 8) | (2 * grp));          // id = row << 8 | pair index in the row
-            if (pb != 0) list[pos] = (unsigned short)((y << 8) | (2 * grp + 1));
+            if (la) list[pos++] = (unsigned short)((y << 8) | (2 * grp));               // id = row << 8 | pair index in the row
+            if (lb) list[pos] = (unsigned short)((y << 8) | (2 * grp + 1));
             nq += __popcll(ma) + __popcll(mb);
         }
         __builtin_amdgcn_wave_barrier();
@@ -876,7 +886,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
         }
         __builtin_amdgcn_wave_barrier();
         for (int qb = 0; qb < nq; qb += 64) {
-            bool keep[2] = {false, false}; int scv[2] = {0, 0}; int y = 0, x0 = 0;
+            unsigned gtm = 0, rbm = 0; int y = 0, x0 = 0;
             if (qb + lane < nq) {
                 const int id = list[qb + lane];
                 y = id >> 8; x0 = 2 * (id & 0xff);
@@ -895,11 +905,11 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
                 pku16 nb = pmax(bp(rb4, 0x0c010c00u), bp(rb4, 0x0c030c02u));
                 nb = pmax(nb, pmax(bp(ra4, 0x0c010c00u), pmax(bp(ra4, 0x0c020c01u), bp(ra4, 0x0c030c02u))));
                 nb = pmax(nb, pmax(bp(rc4, 0x0c010c00u), pmax(bp(rc4, 0x0c020c01u), bp(rc4, 0x0c030c02u))));
-                const unsigned gt = (unsigned)psubsat(cpair, nb);
-                keep[0] = (gt & 0xffffu) != 0; keep[1] = (gt >> 16) != 0;
-                scv[0] = (int)(rb4 >> 8) & 0xff; scv[1] = (int)(rb4 >> 16) & 0xff;
+                gtm = (unsigned)psubsat(cpair, nb); rbm = rb4;
             }
-            const unsigned long long m0 = __ballot(keep[0]), m1 = __ballot(keep[1]);
+            const bool keep[2] = {(gtm & 0xffffu) != 0, (gtm >> 16) != 0};                 // idle lanes: gtm = 0
+            const int scv[2] = {(int)(rbm >> 8) & 0xff, (int)(rbm >> 16) & 0xff};
+            const unsigned long long m0 = __builtin_amdgcn_ballot_w64(keep[0]), m1 = __builtin_amdgcn_ballot_w64(keep[1]);
             int rank = fc_rank(m1, fc_rank(m0, count));
 #pragma unroll
             for (int q = 0; q < 2; q++)
@@ -1397,7 +1407,7 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
         for (int j = 0; j < DS_KPW; j++) if (ok[j]) window_dma(lv[j], vv[j], s_win[wave][j]);
 #pragma unroll
         for (int j = 0; j < DS_KPW; j++) if (ok[j]) {
-            unsigned s = 0, su = 0; int sv = 0;
+            unsigned s = 0, su = 0, cs = 0;                                   // cs = sum over passes of the running row sum = sum_q (8 - q) t_q
             const unsigned sh = (unsigned)((vv[j] & 0xfff) - 15) & 3u;        // (cx - 15) & 3: byte 0 of the shifted dword is column cx - 15 + 4 pd
 #pragma unroll
             for (int q = 0; q < DS_PPASS; q++) {
@@ -1405,8 +1415,10 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
                 const unsigned x = __builtin_amdgcn_alignbyte(nxt, pw[j][q], sh) & pmask[q];
                 const unsigned t = __builtin_amdgcn_udot4(x, 0x01010101u, 0u, false);
                 su = __builtin_amdgcn_udot4(x, ucoef, su, false);
-                s += t; sv += (prow + 4 * q - 15) * (int)t;
+                s += t; cs += s;
             }
+            // sum_q (prow + 4q - 15) t_q = (prow - 15) S + 4 (8 S - cs): two additions per pass instead of a 32-bit multiply-add
+            const int sv = (prow + 17) * (int)s - 4 * (int)cs;
             const int m10 = wave_sum_dpp((int)su - 15 * (int)s), m01 = wave_sum_dpp(sv);     // sum u*I, sum v*I (wave-uniform)
             if (lane == j) { M10 = m10; M01 = m01; }
         }
@@ -1419,7 +1431,7 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
 
     // ---- 3. steered BRIEF (ORBextractor.cc:107-147) per slot on the blurred window in LDS; descriptor word r of the wave's k-th output
     //      is collected in lane 4k + r, so nothing is stored (and no store is waited for) inside the loop
-    unsigned long long dword_l = 0;
+    int dlo_l = 0, dhi_l = 0;                                               // the 64-bit word as two registers: v_writelane_b32 drops a wave-uniform value into one lane
     {
         int later = 0;                                                      // valid slots behind slot j: their windows' loads are the youngest outstanding ones
 #pragma unroll
@@ -1453,7 +1465,8 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
                     }
                     const int t0 = w8[iy0 * DS_WSTRIDE + ix0], t1 = w8[iy1 * DS_WSTRIDE + ix1];
                     const unsigned long long bits = __ballot(t0 < t1);       // test 64r+lane -> byte (64r+lane)/8, bit lane%8
-                    if (lane == dlane + r) dword_l = bits;
+                    dlo_l = orbhip_writelane((int)(unsigned)bits, dlane + r, dlo_l);          // 2 VALU instead of compare + 2 moves + 2 selects
+                    dhi_l = orbhip_writelane((int)(unsigned)(bits >> 32), dlane + r, dhi_l);
                 }
             };
             if (P.fp_contract) brief(std::true_type{}); else brief(std::false_type{});
@@ -1465,7 +1478,7 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
 #pragma unroll
     for (int j = 0; j < DS_KPW; j++) nvalid += ok[j] ? 1 : 0;
     if (lane < 4 * nvalid)
-        reinterpret_cast<unsigned long long*>(P.out_desc + ((long long)frame * P.out_cap + oi_first) * 32)[lane] = dword_l;
+        reinterpret_cast<unsigned long long*>(P.out_desc + ((long long)frame * P.out_cap + oi_first) * 32)[lane] = ((unsigned long long)(unsigned)dhi_l << 32) | (unsigned)dlo_l;
     float myScale = RLF(g_scale, 0), mySize = RLF(g_size, 0);
     for (int l = 1; l < P.nlevels; l++) { const float sl = RLF(g_scale, l), zl = RLF(g_size, l); if (myLevel == l) { myScale = sl; mySize = zl; } }
     if (myOi >= 0) {

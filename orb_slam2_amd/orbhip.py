@@ -80,7 +80,9 @@ class Config(C.Structure):
 
 
 def library_path():
-    return os.path.join(_HERE, "liborbhip.so")
+    """The in-tree liborbhip.so.  ORBHIP_LIBRARY (measurement aid) names another build of the same C ABI, e.g. an older revision built by
+    tools/build_ref_lib.sh for an A/B run inside one GPU call."""
+    return os.environ.get("ORBHIP_LIBRARY") or os.path.join(_HERE, "liborbhip.so")
 
 
 _libs = {}

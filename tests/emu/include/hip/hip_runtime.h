@@ -139,6 +139,7 @@ void launch(K kernel, dim3 grid, dim3 block, size_t shmem, A... args) {
 
 inline void __syncthreads() { hipemu::syncthreads(); }
 inline unsigned long long __ballot(int pred) { return hipemu::wave_collective(hipemu::OP_BALLOT, pred != 0, 0); }
+inline unsigned long long __builtin_amdgcn_ballot_w64(bool pred) { return __ballot(pred ? 1 : 0); }
 inline int __any(int pred) { return __ballot(pred) != 0; }
 inline int __all(int pred) { return hipemu::wave_collective(hipemu::OP_BALLOT, pred == 0, 0) == 0; }
 inline int __lane_id() { return hipemu::g.cur->lane; }
