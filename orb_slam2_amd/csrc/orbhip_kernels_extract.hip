@@ -772,6 +772,9 @@ __device__ __forceinline__ void fc_load_window(const uint8_t* patch, int PS, int
     for (int r = 0; r < 7; r++) { w[r][0] = prow[r * (PS >> 2)]; w[r][1] = prow[r * (PS >> 2) + 1]; w[r][2] = prow[r * (PS >> 2) + 2]; }
 }
 
+// CPS / CSS: the patch / score row strides as compile-time constants (0 = read them from the parameters): with the strides of the usual
+// 30-px grid (48 and 40 bytes) every window row is an immediate offset of one LDS address instead of an address addition per row.
+template <int CPS, int CSS>
 __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
 {
     HIP_DYNAMIC_SHARED(unsigned, fc_lds)
@@ -786,7 +789,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
     const int cw = pw - 6, ch = ph - 6;                              // examined interior (rows/cols 3 .. n-4)
     const bool work = !cd.skipped && cw > 0 && ch > 0;
     if (!work) { if (lane == 0) P.cell_count[(long long)frame * P.ncells_total + cell_id] = 0; return; }
-    const int PS = P.fc_pstride, SS = P.fc_sstride;                  // byte strides, multiples of 4
+    const int PS = CPS ? CPS : P.fc_pstride, SS = CSS ? CSS : P.fc_sstride;      // byte strides, multiples of 4
     uint8_t* wbase = reinterpret_cast<uint8_t*>(fc_lds) + wave * fc_wave_bytes(P.fc_pbytes, SS, P.fc_srows, P.fc_listcap);
     uint8_t* patch = wbase;                                          // patch column 0 is 4-byte aligned; row stride PS
     uint8_t* score = wbase + ((P.fc_pbytes + 15) & ~15);             // interior (x, y) at score[(y+1)*SS + 4 + x]; zero ring around it
@@ -816,8 +819,9 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
                     lds_dma_dword(gp + min(__umul24((unsigned)r4[q], (unsigned)spitch) + (unsigned)d4[q], maxoff), patch + (k0 + 4 * j + q) * 256);
             }
         }
-        // the whole score map starts at zero: the passes below only fill the pixel pairs they examine
-        for (int i = lane; i < (SS >> 2) * (ch + 2); i += 64) reinterpret_cast<unsigned*>(score)[i] = 0;
+        // the whole score map starts at zero: the passes below only fill the pixel pairs they examine (16 bytes per lane and store: the map's
+        // base and its reserved size are multiples of 16, so rounding the count up stays inside it)
+        for (int i = lane; i < ((SS >> 2) * (ch + 2) + 3) >> 2; i += 64) reinterpret_cast<uint4*>(score)[i] = uint4{0u, 0u, 0u, 0u};
         lds_dma_wait();
     }
     __builtin_amdgcn_wave_barrier();
@@ -925,7 +929,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
         // vKeysCell.empty() -> cv::FAST again with minThFAST (ORBextractor.cc:812-816).  The score map restarts from zero: scores the
         // first call left behind (maxima that suppressed each other) are not this call's
         __builtin_amdgcn_wave_barrier();
-        if (phase == 0) for (int i = lane; i < (SS >> 2) * (ch + 2); i += 64) reinterpret_cast<unsigned*>(score)[i] = 0;
+        if (phase == 0) for (int i = lane; i < ((SS >> 2) * (ch + 2) + 3) >> 2; i += 64) reinterpret_cast<uint4*>(score)[i] = uint4{0u, 0u, 0u, 0u};
         __builtin_amdgcn_wave_barrier();
     }
     if (lane == 0) P.cell_count[(long long)frame * P.ncells_total + cell_id] = min(count, cd.cand_cap);
@@ -938,7 +942,9 @@ void orbhip_launch_fast_cells(const ExtractParams& P, int nframes, hipStream_t s
     ExtractParams Q = P; Q.nframes = nframes;
     Q.fc_cell0 = ncells < 0 ? 0 : cell0; Q.fc_ncells = ncells < 0 ? P.ncells_total : ncells;
     if (Q.fc_ncells <= 0) return;
-    hipLaunchKernelGGL(k_fast_cells, dim3(xcd_grid((Q.fc_ncells + FC_WAVES - 1) / FC_WAVES, nframes), 1, 1), dim3(256, 1, 1), lds, s, Q);
+    const dim3 grid(xcd_grid((Q.fc_ncells + FC_WAVES - 1) / FC_WAVES, nframes), 1, 1);
+    if (Q.fc_pstride == 48 && Q.fc_sstride == 40) hipLaunchKernelGGL((k_fast_cells<48, 40>), grid, dim3(256, 1, 1), lds, s, Q);
+    else hipLaunchKernelGGL((k_fast_cells<0, 0>), grid, dim3(256, 1, 1), lds, s, Q);
 }
 
 // ------------------------------------------------------------------------------------------------ quadtree
@@ -1413,9 +1419,9 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
             for (int q = 0; q < DS_PPASS; q++) {
                 const unsigned nxt = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pw[j][q], 0x101, 0xf, 0xf, false);     // row_shl:1 = the next dword of the row
                 const unsigned x = __builtin_amdgcn_alignbyte(nxt, pw[j][q], sh) & pmask[q];
-                const unsigned t = __builtin_amdgcn_udot4(x, 0x01010101u, 0u, false);
+                s = __builtin_amdgcn_sad_u8(x, 0u, s);                           // running sum of the masked bytes (v_sad_u8 accumulates: no separate addition)
                 su = __builtin_amdgcn_udot4(x, ucoef, su, false);
-                s += t; cs += s;
+                cs += s;
             }
             // sum_q (prow + 4q - 15) t_q = (prow - 15) S + 4 (8 S - cs): two additions per pass instead of a 32-bit multiply-add
             const int sv = (prow + 17) * (int)s - 4 * (int)cs;

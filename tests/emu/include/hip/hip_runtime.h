@@ -188,6 +188,10 @@ inline unsigned __builtin_amdgcn_alignbyte(unsigned hi, unsigned lo, unsigned sh
     return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (8 * (shift & 3)));
 }
 // v_dot4_u32_u8: sum of the four byte products + c
+inline unsigned __builtin_amdgcn_sad_u8(unsigned a, unsigned b, unsigned c) {                     // v_sad_u8: sum of |a.byte - b.byte| + c
+    for (int k = 0; k < 4; k++) { const int x = (a >> (8 * k)) & 0xff, y = (b >> (8 * k)) & 0xff; c += (unsigned)(x > y ? x - y : y - x); }
+    return c;
+}
 inline unsigned __builtin_amdgcn_udot4(unsigned a, unsigned b, unsigned c, bool /*clamp*/) {
     for (int i = 0; i < 4; i++) c += ((a >> (8 * i)) & 0xff) * ((b >> (8 * i)) & 0xff);
     return c;
