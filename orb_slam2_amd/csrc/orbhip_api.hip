@@ -53,6 +53,7 @@ struct ProfSpan { int k; hipEvent_t a, b; int counts; };
 struct HostSet {
     uint8_t* d_packed = nullptr; size_t packed_bytes = 0;     // pinned caller images land here as they are (rows `stride` apart) and are re-pitched on the device
     uint8_t* d_in = nullptr; uint8_t* h_in = nullptr; orbhip_keypoint* h_kp = nullptr; uint8_t* h_desc = nullptr; int* h_n = nullptr; bool owned = false;
+    uint8_t* h_block = nullptr;                               // h_n | h_kp | h_desc are parts of this one pinned allocation (same layout as the device block)
     bool busy = false; int ticket = -1, nimg = 0, out_buf = -1, nchunks = 0, chunk_f0[ORBHIP_MAX_CHUNKS + 1] = {0};
     hipEvent_t ev_h2d[ORBHIP_MAX_CHUNKS] = {nullptr}, ev_k[ORBHIP_MAX_CHUNKS] = {nullptr}, ev_d2h[ORBHIP_MAX_CHUNKS] = {nullptr};
     // outputs that went straight into the caller's pinned buffers by DMA (nothing left to copy at collect time)
@@ -74,6 +75,9 @@ struct orbhip_ctx {
     unsigned* d_qt_val = nullptr; unsigned* d_qt_code = nullptr; int* d_qt_node = nullptr; unsigned* d_lvl_kp = nullptr;
     // outputs are triple-buffered: batch t writes buffer t%3 while the matcher of batch t-1 (own stream) still reads buffers (t-1)%3 and (t-2)%3
     int* d_lvl_n[3] = {nullptr, nullptr, nullptr}; orbhip_keypoint* d_out_kp[3] = {nullptr, nullptr, nullptr}; uint8_t* d_out_desc[3] = {nullptr, nullptr, nullptr}; int* d_out_n[3] = {nullptr, nullptr, nullptr};
+    // the three output arrays of a buffer are carved from ONE allocation ([counts | key points | descriptors], 256-byte aligned parts): the whole
+    // result of a small batch is one device-to-host copy instead of three (a single-frame call spent 60 us between its second and third copy)
+    uint8_t* d_out_block[3] = {nullptr, nullptr, nullptr}; size_t out_off_kp = 0, out_off_desc = 0, out_block_bytes = 0; uint8_t* h_block = nullptr;
     hipStream_t bstream = nullptr; hipEvent_t ev_pyr = nullptr, ev_blur = nullptr;      // blur runs beside FAST + quadtree (independent until describe)
     hipStream_t mstream = nullptr; hipEvent_t ev_extract = nullptr; hipEvent_t ev_match[3] = {nullptr, nullptr, nullptr}; bool match_pending[3] = {false, false, false};
     int cur = 0; int last_nimg = 0; bool last_matched = false; bool last_from_host = false;
@@ -273,15 +277,14 @@ extern "C" void orbhip_destroy(orbhip_ctx* c)
     prof_collect(c);
     for (auto e : c->pool) (void)hipEventDestroy(e);
     void* ptrs[] = {c->d_blur_band, c->d_ic_mask, c->d_xgrp, c->d_fc_dma, c->d_geom, c->d_cells, c->d_tiles, c->d_xtab, c->d_ytab, c->d_pattern, c->d_pyr_sets[0], c->d_pyr_sets[1], c->d_blur, c->d_cell_count, c->d_cell_cand,
-                    c->d_qt_val, c->d_qt_code, c->d_qt_node, c->d_lvl_kp, c->d_lvl_n[0], c->d_lvl_n[1], c->d_lvl_n[2], c->d_out_kp[0], c->d_out_kp[1], c->d_out_kp[2],
-                    c->d_out_desc[0], c->d_out_desc[1], c->d_out_desc[2], c->d_out_n[0], c->d_out_n[1], c->d_out_n[2], c->d_grid_start, c->d_grid_items, c->d_grid_xy, c->d_cand, c->d_top, c->d_ncand,
+                    c->d_qt_val, c->d_qt_code, c->d_qt_node, c->d_lvl_kp, c->d_lvl_n[0], c->d_lvl_n[1], c->d_lvl_n[2], c->d_out_block[0], c->d_out_block[1], c->d_out_block[2], c->d_grid_start, c->d_grid_items, c->d_grid_xy, c->d_cand, c->d_top, c->d_ncand,
                     c->d_prev, c->d_m12, c->d_nm};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     { void* st[] = {c->d_st_rowstart, c->d_st_rowitems, c->d_st_u, c->d_st_depth, c->d_st_sad}; for (void* q : st) if (q) (void)hipFree(q); }
     for (auto& hs : c->sets) {
         for (int k = 0; k < ORBHIP_MAX_CHUNKS; k++) { if (hs.ev_h2d[k]) (void)hipEventDestroy(hs.ev_h2d[k]); if (hs.ev_k[k]) (void)hipEventDestroy(hs.ev_k[k]); if (hs.ev_d2h[k]) (void)hipEventDestroy(hs.ev_d2h[k]); }
         if (hs.d_packed) (void)hipFree(hs.d_packed);
-        if (hs.owned) { if (hs.d_in) (void)hipFree(hs.d_in); if (hs.h_in) (void)hipHostFree(hs.h_in); if (hs.h_kp) (void)hipHostFree(hs.h_kp); if (hs.h_desc) (void)hipHostFree(hs.h_desc); if (hs.h_n) (void)hipHostFree(hs.h_n); }
+        if (hs.owned) { if (hs.d_in) (void)hipFree(hs.d_in); if (hs.h_in) (void)hipHostFree(hs.h_in); if (hs.h_block) (void)hipHostFree(hs.h_block); }
     }
     if (c->hstream) { (void)hipStreamSynchronize(c->hstream); (void)hipStreamDestroy(c->hstream); }
     if (c->dstream) { (void)hipStreamSynchronize(c->dstream); (void)hipStreamDestroy(c->dstream); }
@@ -292,9 +295,7 @@ extern "C" void orbhip_destroy(orbhip_ctx* c)
     { void* g[] = {c->d_out_kpun[0], c->d_out_kpun[1], c->d_out_kpun[2], c->d_map_x, c->d_map_y, c->d_raw, c->d_depth}; for (void* q : g) if (q) (void)hipFree(q); }
     if (c->h_kpun) (void)hipHostFree(c->h_kpun);
     if (c->h_raw) (void)hipHostFree(c->h_raw);
-    if (c->h_kp) (void)hipHostFree(c->h_kp);
-    if (c->h_desc) (void)hipHostFree(c->h_desc);
-    if (c->h_n) (void)hipHostFree(c->h_n);
+    if (c->h_block) (void)hipHostFree(c->h_block);             // h_n | h_kp | h_desc
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -503,7 +504,11 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
     TRY(dalloc(&c->d_qt_val, B * c->qt_per_frame)); TRY(dalloc(&c->d_qt_code, B * c->qt_per_frame)); TRY(dalloc(&c->d_qt_node, B * c->qt_per_frame));
     TRY(dalloc(&c->d_lvl_kp, B * c->lvl_kp_per_frame));
     for (int k = 0; k < 3; k++) {
-        TRY(dalloc(&c->d_lvl_n[k], B * L)); TRY(dalloc(&c->d_out_kp[k], B * c->out_cap)); TRY(dalloc(&c->d_out_desc[k], B * c->out_cap * 32)); TRY(dalloc(&c->d_out_n[k], B));
+        TRY(dalloc(&c->d_lvl_n[k], B * L));
+        c->out_off_kp = (B * sizeof(int) + 255) & ~(size_t)255; c->out_off_desc = c->out_off_kp + ((B * c->out_cap * sizeof(orbhip_keypoint) + 255) & ~(size_t)255);
+        c->out_block_bytes = c->out_off_desc + B * c->out_cap * 32;
+        TRY(dalloc(&c->d_out_block[k], c->out_block_bytes));
+        if (e == hipSuccess) { c->d_out_n[k] = reinterpret_cast<int*>(c->d_out_block[k]); c->d_out_kp[k] = reinterpret_cast<orbhip_keypoint*>(c->d_out_block[k] + c->out_off_kp); c->d_out_desc[k] = c->d_out_block[k] + c->out_off_desc; }
         if (e == hipSuccess) e = hipMemset(c->d_lvl_n[k], 0, B * L * sizeof(int));
         if (e == hipSuccess) e = hipMemset(c->d_out_n[k], 0, B * sizeof(int));
     }
@@ -624,7 +629,7 @@ static orbhip_status pipeline_frames(orbhip_ctx* c, ExtractParams& P, int f0, in
         if (pyr_done) HIPCHK(hipStreamWaitEvent(s, pyr_done, 0));
         else { ProfScope ps(c, K_PYRAMID, s); launch_pyramid(c, P, nf, s); }
         { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nf, s); }
-        if (own_blur_stream) {
+        if (own_blur_stream && nf > 8) {      // (a handful of frames: the two event hops of the second stream cost more than the blur's 11 us - a single-frame call lost 75 us in them)
             hipStream_t bs = c->serial ? s : c->bstream;
             HIPCHK(hipEventRecord(c->ev_pyr, s)); HIPCHK(hipStreamWaitEvent(bs, c->ev_pyr, 0));
             { ProfScope ps(c, K_QUADTREE, s); orbhip_launch_quadtree(P, nf, s); }
@@ -747,9 +752,8 @@ static orbhip_status ensure_host_staging(orbhip_ctx* c, bool input)
 {
     const size_t B = (size_t)c->B;
     if (!c->h_n) {
-        HIPCHK(hipHostMalloc((void**)&c->h_n, B * sizeof(int), hipHostMallocDefault));
-        HIPCHK(hipHostMalloc((void**)&c->h_kp, B * c->out_cap * sizeof(orbhip_keypoint), hipHostMallocDefault));
-        HIPCHK(hipHostMalloc((void**)&c->h_desc, B * c->out_cap * 32, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void**)&c->h_block, c->out_block_bytes, hipHostMallocDefault));
+        c->h_n = reinterpret_cast<int*>(c->h_block); c->h_kp = reinterpret_cast<orbhip_keypoint*>(c->h_block + c->out_off_kp); c->h_desc = c->h_block + c->out_off_desc;
     }
     if (input && !c->d_in) {
         c->in_pitch = c->geom[0].pitch;
@@ -911,14 +915,13 @@ static orbhip_status ensure_set(orbhip_ctx* c, int si)
     orbhip_status st = ensure_host_staging(c, true); if (st != ORBHIP_OK) return st;
     const size_t B = (size_t)c->B;
     if (!hs.d_in) {
-        if (si == 0) { hs.d_in = c->d_in; hs.h_in = c->h_in; hs.h_kp = c->h_kp; hs.h_desc = c->h_desc; hs.h_n = c->h_n; hs.owned = false; }       // set 0 = the context's own mirrors
+        if (si == 0) { hs.d_in = c->d_in; hs.h_in = c->h_in; hs.h_kp = c->h_kp; hs.h_desc = c->h_desc; hs.h_n = c->h_n; hs.h_block = c->h_block; hs.owned = false; }       // set 0 = the context's own mirrors
         else {
             const size_t bytes = B * (size_t)c->in_pitch * c->cfg.height + 256;
             hs.owned = true;
             HIPCHK(orbhip_dmalloc((void**)&hs.d_in, bytes)); HIPCHK(hipHostMalloc((void**)&hs.h_in, bytes, hipHostMallocDefault));
-            HIPCHK(hipHostMalloc((void**)&hs.h_n, B * sizeof(int), hipHostMallocDefault));
-            HIPCHK(hipHostMalloc((void**)&hs.h_kp, B * c->out_cap * sizeof(orbhip_keypoint), hipHostMallocDefault));
-            HIPCHK(hipHostMalloc((void**)&hs.h_desc, B * c->out_cap * 32, hipHostMallocDefault));
+            HIPCHK(hipHostMalloc((void**)&hs.h_block, c->out_block_bytes, hipHostMallocDefault));
+            hs.h_n = reinterpret_cast<int*>(hs.h_block); hs.h_kp = reinterpret_cast<orbhip_keypoint*>(hs.h_block + c->out_off_kp); hs.h_desc = hs.h_block + c->out_off_desc;
         }
     }
     if (!c->hstream) { HIPCHK(hipStreamCreateWithFlags(&c->hstream, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&c->dstream, hipStreamNonBlocking)); }
@@ -929,12 +932,15 @@ static orbhip_status ensure_set(orbhip_ctx* c, int si)
 
 // frames per chunk of a batch: small batches stay one chunk on the main stream (no cross-stream hops: single-frame latency is what
 // the stereo drop-in sees); larger ones are cut so that about eight chunks pipeline through upload / kernels / download
-static int host_chunk_frames(int nimg)
+static int host_chunk_frames(int nimg, bool dma_both_ways)
 {
     const char* e = getenv("ORBHIP_HOST_CHUNK"); const int forced = e ? atoi(e) : 0;          // tuning / test knob: frames per chunk
     if (forced > 0) return std::max((nimg + ORBHIP_MAX_CHUNKS - 1) / ORBHIP_MAX_CHUNKS, forced);
     if (nimg < 32) return nimg;
-    const int ch = std::min(std::max(((nimg + 3) / 4 + 7) & ~7, 16), 64);       // measured on MI355X: 64-frame chunks at batch 256 beat 32-frame ones by 25 % (launch efficiency)
+    // measured on MI355X at batch 256 (tools/host_io_matrix.py, round 3): pinned frames in + pinned results named at submit (DMA both ways, no
+    // host copy) 111.5 k frames/s with 64-frame chunks, 103 k with 128, 70 k with 32 (launch-bound); every path with a host copy in it
+    // (pageable frames or results) 93 k with 64-frame chunks and 105 k with 128: fewer, larger chunks amortise the copy threads' hand-offs
+    const int ch = dma_both_ways ? std::min(std::max(((nimg + 3) / 4 + 7) & ~7, 16), 64) : std::min(std::max(((nimg + 1) / 2 + 7) & ~7, 16), 128);
     return std::max(ch, (nimg + ORBHIP_MAX_CHUNKS - 1) / ORBHIP_MAX_CHUNKS);
 }
 
@@ -964,13 +970,26 @@ static orbhip_status submit_body(orbhip_ctx* c, int nimg, const uint8_t* const* 
     orbhip_status st = ensure_set(c, si); if (st != ORBHIP_OK) return st;
     const size_t fbytes = (size_t)c->in_pitch * c->cfg.height;
     const int W = c->cfg.width, H = c->cfg.height;
-    const int ch = host_chunk_frames(nimg), nch = (nimg + ch - 1) / ch;
+    if (c->plane0_dirty) { HIPCHK(hipStreamSynchronize(c->stream)); c->plane0_dirty = false; }   // kernels of an un-ticketed colour / rectify call may still read set 0's level-0 plane
+    // pinned input: asked of the runtime once per run of images that lie back to back in memory (its first and its last image) - a batch cut
+    // from one pinned array is two queries, not one per image (hipPointerGetAttributes costs a microsecond or two each)
+    bool pinned_in = true;
+    {
+        const size_t ibytes_run = (size_t)stride * c->cfg.height;
+        for (int f = 0; f < nimg && pinned_in;) {
+            int g = f + 1; while (g < nimg && imgs[g] == imgs[g - 1] + ibytes_run) g++;
+            pinned_in = host_pointer_is_pinned(imgs[f]) && (g - 1 == f || host_pointer_is_pinned(imgs[g - 1] + (size_t)stride * (c->cfg.height - 1) + c->cfg.width - 1));
+            f = g;
+        }
+    }
+    const bool pinned_out = direct_kp && direct_desc && direct_cap > 0 && host_pointer_is_pinned(direct_kp) && host_pointer_is_pinned(direct_desc);
+    const int ch = host_chunk_frames(nimg, pinned_in && pinned_out), nch = (nimg + ch - 1) / ch;
     const bool piped = nch > 1;
     hipStream_t hst = piped ? c->hstream : c->stream, dst = piped ? c->dstream : c->stream;
-    if (c->plane0_dirty) { HIPCHK(hipStreamSynchronize(c->stream)); c->plane0_dirty = false; }   // kernels of an un-ticketed colour / rectify call may still read set 0's level-0 plane
-    bool pinned_in = true;
-    for (int f = 0; f < nimg && pinned_in; f++) pinned_in = host_pointer_is_pinned(imgs[f]);
-    const bool direct_out = direct_kp && direct_desc && direct_cap > 0 && host_pointer_is_pinned(direct_kp) && host_pointer_is_pinned(direct_desc);
+    // A small batch that fills the context (the drop-in's single-frame call): the whole output block comes back in ONE copy into the pinned
+    // mirror and is handed over by memcpy - three DMA submissions cost more than copying 120 KB (the second and third of them started 60 us apart)
+    const bool whole_block = !piped && nimg == c->B && c->out_block_bytes <= ((size_t)1 << 20);
+    const bool direct_out = !whole_block && pinned_out;
     hs.direct_kp = direct_out ? direct_kp : nullptr; hs.direct_desc = direct_out ? direct_desc : nullptr; hs.direct_cap = direct_out ? direct_cap : 0;
 
     st = begin_batch(c, hs.d_in, (long long)fbytes, c->in_pitch); if (st != ORBHIP_OK) return st;
@@ -982,7 +1001,11 @@ static orbhip_status submit_body(orbhip_ctx* c, int nimg, const uint8_t* const* 
         hs.chunk_f0[k] = f0; hs.chunk_f0[k + 1] = f1;
         // ---- upload
         if (pinned_in && stride == c->in_pitch) {
-            for (int f = f0; f < f1; f++) HIPCHK(hipMemcpyAsync(hs.d_in + f * fbytes, imgs[f], fbytes, hipMemcpyHostToDevice, hst));
+            for (int f = f0; f < f1;) {                                   // images that lie back to back travel in one copy (one copy per image is launch-bound: 25 of 56 GB/s)
+                int g = f + 1; while (g < f1 && imgs[g] == imgs[g - 1] + fbytes) g++;
+                HIPCHK(hipMemcpyAsync(hs.d_in + f * fbytes, imgs[f], (size_t)(g - f) * fbytes, hipMemcpyHostToDevice, hst));
+                f = g;
+            }
         } else if (pinned_in) {
             // dense rows: linear DMA of every image as it lies in the caller's memory (adjacent images in one copy), rows spread to the
             // pipeline's pitch by k_repitch on the main stream
@@ -1014,6 +1037,8 @@ static orbhip_status submit_body(orbhip_ctx* c, int nimg, const uint8_t* const* 
         if (piped) { HIPCHK(hipEventRecord(hs.ev_k[k], c->stream)); HIPCHK(hipStreamWaitEvent(dst, hs.ev_k[k], 0)); }
         // ---- download
         const int cur = c->cur; const size_t oc = (size_t)c->out_cap;
+        if (whole_block) { HIPCHK(hipMemcpyAsync(hs.h_block, c->d_out_block[cur], c->out_block_bytes, hipMemcpyDeviceToHost, dst)); }
+        else {
         HIPCHK(hipMemcpyAsync(hs.h_n + f0, c->d_out_n[cur] + f0, nf * sizeof(int), hipMemcpyDeviceToHost, dst));
         if (direct_out) {
             const size_t m = (size_t)std::min(direct_cap, c->out_cap);
@@ -1027,6 +1052,7 @@ static orbhip_status submit_body(orbhip_ctx* c, int nimg, const uint8_t* const* 
         } else {
             HIPCHK(hipMemcpyAsync(hs.h_kp + f0 * oc, c->d_out_kp[cur] + f0 * oc, nf * oc * sizeof(orbhip_keypoint), hipMemcpyDeviceToHost, dst));
             HIPCHK(hipMemcpyAsync(hs.h_desc + f0 * oc * 32, c->d_out_desc[cur] + f0 * oc * 32, nf * oc * 32, hipMemcpyDeviceToHost, dst));
+        }
         }
         HIPCHK(hipEventRecord(hs.ev_d2h[k], dst));
     }
@@ -1043,6 +1069,8 @@ orbhip_status orbhip_collect_scatter(orbhip_ctx* c, int ticket, orbhip_keypoint*
     if (!c || !kps || !desc || !n_out) return fail(ORBHIP_ERR_INVALID, "null argument");
     if (ticket != c->oldest_ticket || ticket >= c->next_ticket) return fail(ORBHIP_ERR_INVALID, "ticket %d is not the oldest batch in flight (%d; %d submitted)", ticket, c->oldest_ticket, c->next_ticket);
     HostSet& hs = c->sets[c->ticket_set[ticket % ORBHIP_RING]];
+    if (hs.direct_kp && ((kps[0] && kps[0] != hs.direct_kp) || (desc[0] && desc[0] != hs.direct_desc) || cap != hs.direct_cap))      // the ticket stays collectable
+        return fail(ORBHIP_ERR_INVALID, "batch %d was submitted with its result buffers (orbhip_submit_to): collect it with the same buffers and capacity", ticket);
     HIPCHK(hipSetDevice(c->cfg.device));
     bool overflow = false;
     const size_t oc = (size_t)c->out_cap;
@@ -1079,6 +1107,11 @@ extern "C" orbhip_status orbhip_submit(orbhip_ctx* c, int nimg, const uint8_t* c
 {
     if (!c || !imgs || !ticket) return fail(ORBHIP_ERR_INVALID, "null argument");
     return submit_impl(c, nimg, imgs, stride, nullptr, nullptr, 0, ticket);
+}
+extern "C" orbhip_status orbhip_submit_to(orbhip_ctx* c, int nimg, const uint8_t* const* imgs, int stride, orbhip_keypoint* kps, uint8_t* desc, int cap, int* ticket)
+{
+    if (!c || !imgs || !ticket) return fail(ORBHIP_ERR_INVALID, "null argument");
+    return submit_impl(c, nimg, imgs, stride, kps, desc, cap, ticket);
 }
 extern "C" orbhip_status orbhip_collect(orbhip_ctx* c, int ticket, orbhip_keypoint* kps, uint8_t* desc, int cap, int* n_out)
 {

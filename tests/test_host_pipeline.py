@@ -179,3 +179,31 @@ def test_pool_db_shards_and_reloc_candidates(backend, oracle, monkeypatch):
 def test_pool_rejects_missing_devices(backend):
     with pytest.raises(orb_slam2_amd.OrbHipError, match="out of range"):
         orb_slam2_amd.MultiGpuExtractor([0, 97], 2, N, 1.2, 8, 20, 7, W, H, library=backend)
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_submit_to_named_result_buffers(backend, frames, want, monkeypatch, pinned):
+    """orbhip_submit_to: result buffers named at submit (pinned: filled by DMA, collect copies nothing), frames handed over as ONE array
+    (arithmetic pointer table), three batches in flight, and a collect with other buffers than the submit named is refused without losing
+    the ticket."""
+    if backend.endswith("_emu.so") and pinned:
+        monkeypatch.setenv("HIPEMU_ALL_PINNED", "1")
+    monkeypatch.setenv("ORBHIP_HOST_CHUNK", "2")
+    ex = orb_slam2_amd.ORBextractor(N, 1.2, 8, 20, 7, W, H, max_batch=4, library=backend)
+    cap = ex.capacity
+    mk = (lambda shape, dt: orb_slam2_amd.pinned_array(shape, dt, library=backend)) if pinned else (lambda shape, dt: np.zeros(shape, dt))
+    src = mk((12, H, W), np.uint8)
+    src[:] = np.stack(frames[:12])
+    bufs = [(mk((4, cap), orb_slam2_amd.KEYPOINT_DTYPE), mk((4, cap, 32), np.uint8), np.zeros(4, np.int32)) for _ in range(3)]
+    tickets = [ex.submit(src[4 * b:4 * b + 4], out=bufs[b]) for b in range(3)]
+    other = (mk((4, cap), orb_slam2_amd.KEYPOINT_DTYPE), mk((4, cap, 32), np.uint8), np.zeros(4, np.int32))
+    if pinned:
+        with pytest.raises(orb_slam2_amd.OrbHipError, match="same buffers"):
+            orb_slam2_amd.orbhip._check(ex.L.orbhip_collect(ex.h, tickets[0], orb_slam2_amd.orbhip._p(other[0]), orb_slam2_amd.orbhip._p(other[1]), cap,
+                                                            orb_slam2_amd.orbhip._p(other[2])), "orbhip_collect", ex.L)
+    for b in range(3):
+        nout = ex.collect(tickets[b])
+        k, d, _ = bufs[b]
+        _same([k[f, :nout[f]] for f in range(4)], [d[f, :nout[f]] for f in range(4)], want, range(4 * b, 4 * b + 4))
+    k, d = ex.extract_batch(frames[:2])
+    _same(k, d, want, range(2))
