@@ -81,12 +81,15 @@ __global__ __launch_bounds__(NN_T) void k_hamming_nn(const unsigned long long* q
 // distances/s, VALU-bound on v_xor + v_bcnt) does not apply.  A workgroup keeps 256 queries as B operands in registers (4 waves x 2 tiles of
 // 32 queries, lane = query) and streams its chunk of DB rows: 32 rows at a time are expanded from bits to +-1 bytes through a 256-entry LDS
 // table (once per workgroup, shared by its eight query tiles) and read back as A operands (lane = row, bytes = 16 bits of one dword).
-// The result leaves with lane = query, register = DB row, so the running (best, second) keys of a query are two registers of its lane:
-//   key = distance << 13 | row-in-chunk = C_row + (-dot << 12)  (one v_lshl_add_u32; the queries are expanded with the opposite sign),   second = min(second, max(best, key)), best = min(best, key)
+// The result leaves with lane = query, register = DB row, so the running (best, second) keys of a query are two registers of its lane.
+// The accumulators ARE the tile's keys, with no VALU work per pair: the queries are expanded to -+64 instead of -+1 and the C operand of the
+// first product of a tile is the constant 256 * 64 + row-in-tile, so that   acc = (256 - dot) * 64 + r = distance << 7 | r   (r < 64).
+// A v_min3 / v_med3 tournament picks the tile's two smallest, and only those two are turned into chunk keys distance << 13 | row-in-chunk
+// (three operations each) for   second = min(second, max(best, key)), best = min(best, key)
 // exactly as in k_hamming_nn, whose partial format and merge kernel are reused.
 typedef int nn_v4i __attribute__((vector_size(16)));
 typedef int nn_v16i __attribute__((vector_size(64)));
-#define NNM_QT 2                        // query tiles (of 32) per wavefront
+#define NNM_QT 2                        // query tiles (of 32) per wavefront (3: 9.7 ms against 7.9 - a sixth workgroup column of padding; 4: spills)
 #define NNM_QG (4 * NNM_QT * 32)        // queries per workgroup
 __global__ __launch_bounds__(256, 2) void k_hamming_nn_mfma(const unsigned* q, int nq, const unsigned* db, long long ndb, long long base, NNPart* parts, int nchunks)
 {
@@ -111,8 +114,8 @@ __global__ __launch_bounds__(256, 2) void k_hamming_nn_mfma(const unsigned* q, i
 #pragma unroll
         for (int kb = 0; kb < 8; kb++) {
             const unsigned half = (qp[kb] >> (16 * h)) & 0xffffu;
-            // the queries carry the opposite sign (+-1 bytes: x ^ 0xfe), so the product is -dot and key = C_row + (product << 12) is one v_lshl_add_u32
-            const unsigned long long lo = s_tab[half & 0xff] ^ 0xfefefefefefefefeull, hi = s_tab[half >> 8] ^ 0xfefefefefefefefeull;
+            // the queries carry the opposite sign and the weight 64: table byte 0x01 (bit set) -> 0xc0 = -64, 0xff (bit clear) -> 0x40 = +64
+            const unsigned long long lo = (s_tab[half & 0xff] & 0x8080808080808080ull) ^ 0xc0c0c0c0c0c0c0c0ull, hi = (s_tab[half >> 8] & 0x8080808080808080ull) ^ 0xc0c0c0c0c0c0c0c0ull;
             B[t][kb] = nn_v4i{(int)(unsigned)lo, (int)(unsigned)(lo >> 32), (int)(unsigned)hi, (int)(unsigned)(hi >> 32)};
         }
     }
@@ -127,57 +130,63 @@ __global__ __launch_bounds__(256, 2) void k_hamming_nn_mfma(const unsigned* q, i
     auto stage = [&](int tile, int buf) {
         const int r = tile * 32 + sr;
         const unsigned w = r < nrows ? db[(row0 + r) * 8 + skb] : 0u;
-        const unsigned long long e0 = s_tab[w & 0xff], e1 = s_tab[(w >> 8) & 0xff], e2 = s_tab[(w >> 16) & 0xff], e3 = s_tab[w >> 24];
         unsigned* d0 = s_a[buf] + ((skb * 2 + 0) * 32 + sr) * 4;        // bits 0..15 -> lane half 0
         unsigned* d1 = s_a[buf] + ((skb * 2 + 1) * 32 + sr) * 4;        // bits 16..31 -> lane half 1
+        // (the same expansion by VALU arithmetic - n * 0x204081 & 0x01010101, * 0xfe, complement: 40 VALU per thread and tile - measured 8.3 against 7.9 ms)
+        const unsigned long long e0 = s_tab[w & 0xff], e1 = s_tab[(w >> 8) & 0xff], e2 = s_tab[(w >> 16) & 0xff], e3 = s_tab[w >> 24];
         *reinterpret_cast<uint4*>(d0) = uint4{(unsigned)e0, (unsigned)(e0 >> 32), (unsigned)e1, (unsigned)(e1 >> 32)};
         *reinterpret_cast<uint4*>(d1) = uint4{(unsigned)e2, (unsigned)(e2 >> 32), (unsigned)e3, (unsigned)(e3 >> 32)};
     };
-    // C_row of register reg: (256 << 12) + row-in-chunk of D's row (reg & 3) + 8 (reg >> 2) + 4 h; rows past the chunk get a key no real one beats
-    const nn_v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    int crow[16];
+    // C operand of a tile's first product: 256 * 64 + row-in-tile of D's register reg = (reg & 3) + 8 (reg >> 2) + 4 h (constant registers, shared by the query tiles)
+    nn_v16i cinit;
 #pragma unroll
-    for (int reg = 0; reg < 16; reg++) crow[reg] = (256 << 12) + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    for (int reg = 0; reg < 16; reg++) cinit[reg] = 256 * 64 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
     // best two of three keys in two instructions (v_min3 / v_med3), then (best, second) pairs merged in three
     auto top2_of3 = [](unsigned a, unsigned b, unsigned c, unsigned& lo, unsigned& mid) { lo = min(min(a, b), c); mid = max(min(a, b), min(max(a, b), c)); };
     auto merge2 = [](unsigned& b, unsigned& s2, unsigned ob, unsigned os) { s2 = min(min(s2, os), max(b, ob)); b = min(b, ob); };
-    // one tile of 32 DB rows against the wave's query tiles; `ragged` (compile-time) = the chunk's last, partial tile
-    auto do_tile = [&](int tile, auto ragged) {
+    // One tile of 32 DB rows against the wave's query tiles: products, then the (best, second) selection.  `ragged` (compile-time) = the chunk's
+    // last, partial tile, whose rows past the chunk get keys no real row beats.  (Measured in round 3, 2000 x 20 M: this form 7.8 ms; the same with
+    // the products of tile t issued before the selection of tile t-1 on a second accumulator set 10.0 ms - the wave's own matrix / VALU overlap
+    // costs more registers and scheduling freedom than the two resident workgroups already provide; four query tiles per wave 10.4 ms, spilling.)
+    auto products = [&](int tile, nn_v16i (&acc)[NNM_QT]) {
         const int buf = tile & 1;
         if (tile + 1 < ntiles) stage(tile + 1, buf ^ 1);
-        nn_v16i acc[NNM_QT];
-#pragma unroll
-        for (int t = 0; t < NNM_QT; t++) acc[t] = zero;
 #pragma unroll
         for (int kb = 0; kb < 8; kb++) {
             const nn_v4i A = *reinterpret_cast<const nn_v4i*>(s_a[buf] + ((kb * 2 + h) * 32 + j) * 4);     // lane (i = j, h): row i of the tile
 #pragma unroll
-            for (int t = 0; t < NNM_QT; t++) acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B[t][kb], acc[t], 0, 0, 0);
+            for (int t = 0; t < NNM_QT; t++) acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B[t][kb], kb == 0 ? cinit : acc[t], 0, 0, 0);
         }
+    };
+    auto select = [&](int tile, const nn_v16i (&acc)[NNM_QT], auto ragged) {
+        const unsigned tbase = (unsigned)tile * 32u;
 #pragma unroll
         for (int t = 0; t < NNM_QT; t++) {
             unsigned x[16];
 #pragma unroll
             for (int reg = 0; reg < 16; reg++) {
-                x[reg] = ((unsigned)acc[t][reg] << 12) + (unsigned)crow[reg];                                // acc = -dot: (256 - dot) / 2 << 13 | row
-                if (decltype(ragged)::value && tile * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h >= nrows) x[reg] = 0x7f000000u + (unsigned)reg;
+                x[reg] = (unsigned)acc[t][reg];                                                              // distance << 7 | row-in-tile
+                if (decltype(ragged)::value && tile * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h >= nrows) x[reg] = (511u << 7) + (unsigned)((reg & 3) + 8 * (reg >> 2) + 4 * h);   // distance 511: loses to every real row
             }
             unsigned b, s2;
             top2_of3(x[0], x[1], x[2], b, s2);
 #pragma unroll
             for (int g = 1; g < 5; g++) { unsigned lo, mid; top2_of3(x[3 * g], x[3 * g + 1], x[3 * g + 2], lo, mid); merge2(b, s2, lo, mid); }
             merge2(b, s2, x[15], 0xffffffffu);
-            merge2(kbest[t], ksec[t], b, s2);
+            // tile key d << 7 | r  ->  chunk key d << 13 | (tile * 32 + r):  (k << 6) - 63 r + tile * 32  with r = k & 127 (bit 6 of r is clear)
+            const unsigned kb1 = (b << 6) - 63u * (b & 127u) + tbase, ks1 = (s2 << 6) - 63u * (s2 & 127u) + tbase;     // (both are real keys: 16 rows per lane)
+            merge2(kbest[t], ksec[t], kb1, ks1);
         }
-#pragma unroll
-        for (int reg = 0; reg < 16; reg++) crow[reg] += 32;
-        __syncthreads();
     };
     stage(0, 0);
     __syncthreads();
-    const int nfull = nrows >> 5;
-    for (int tile = 0; tile < nfull; tile++) do_tile(tile, std::false_type{});
-    if (nfull < ntiles) do_tile(nfull, std::true_type{});
+    const int nfull = nrows >> 5;                                      // whole tiles; tile nfull (if any) is the ragged one
+    nn_v16i acc[NNM_QT];
+    for (int tile = 0; tile < ntiles; tile++) {
+        products(tile, acc);
+        if (tile < nfull) select(tile, acc, std::false_type{}); else select(tile, acc, std::true_type{});
+        __syncthreads();
+    }
     // ---- a query's rows were split over its two lanes (j, 0) and (j, 1): fold, then one partial per (query, chunk)
 #pragma unroll
     for (int t = 0; t < NNM_QT; t++) {
@@ -185,9 +194,9 @@ __global__ __launch_bounds__(256, 2) void k_hamming_nn_mfma(const unsigned* q, i
         const unsigned b = min(kbest[t], ob), s2 = min(min(ksec[t], os), max(kbest[t], ob));
         if (h == 0 && qidx[t] < nq) {
             NNPart p;
-            p.best = b >= 0x7f000000u ? IMAX : (int)(b >> 13);
-            p.second = s2 >= 0x7f000000u ? IMAX : (int)(s2 >> 13);
-            p.idx = b >= 0x7f000000u ? -1 : row0 + (long long)(b & 0x1fffu) + base;
+            p.best = (b >> 13) > 256u ? IMAX : (int)(b >> 13);                     // never-set keys and the ragged tile's filler rows carry a distance above 256
+            p.second = (s2 >> 13) > 256u ? IMAX : (int)(s2 >> 13);
+            p.idx = (b >> 13) > 256u ? -1 : row0 + (long long)(b & 0x1fffu) + base;
             parts[(long long)qidx[t] * nchunks + chunk] = p;
         }
     }

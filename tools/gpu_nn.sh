@@ -1,8 +1,12 @@
 #!/bin/bash
-# brute-force descriptor DB (config 5): parity + rate, matrix-core scan vs popcount kernel.  usage: tools/gpu_nn.sh <tag>
-TAG=${1:-nn}; OUT=gpurun_out/$TAG; mkdir -p $OUT; cd "$(dirname "$0")/.."
-timeout 600 python -m pytest tests/test_parity_match.py tests/test_full_size_gpu.py tests/test_host_pipeline.py -m gpu -q -x -k "brute or nn or db or pool or shard" 2>&1 | tail -2
-timeout 600 python tools/db_full_parity.py > $OUT/db_full_parity_mfma.json 2> $OUT/err.log; cut -c1-700 $OUT/db_full_parity_mfma.json
-timeout 300 python tools/db_query_rate.py > $OUT/db_query_mfma.json 2>> $OUT/err.log; cat $OUT/db_query_mfma.json
-ORBHIP_NN=valu timeout 300 python tools/db_query_rate.py > $OUT/db_query_valu.json 2>> $OUT/err.log; cat $OUT/db_query_valu.json
-tail -3 $OUT/err.log
+TAG=${1:-nn}
+cd "$(dirname "$0")/.."
+REPO=$(pwd); OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT
+export TMPDIR=/tmp
+timeout 900 python3 -m pytest tests/test_full_size_gpu.py tests/test_parity_match.py tests/test_sharding.py tests/test_host_pipeline.py -x -q -m gpu -p no:cacheprovider > $OUT/pytest.log 2>&1; echo "pytest exit $?" >> $OUT/pytest.log
+for r in 1 2; do
+  ORBHIP_LIBRARY=$REPO/ab/liborbhip_base.so timeout 300 python3 tools/db_query_rate.py >> $OUT/db_query.jsonl 2>> $OUT/err.txt
+  timeout 300 python3 tools/db_query_rate.py >> $OUT/db_query.jsonl 2>> $OUT/err.txt
+done
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/nnprof -o nn -- python3 $REPO/tools/db_query_rate.py > /dev/null 2>> $OUT/err.txt ); f=$(find /tmp/nnprof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/nn_kernel_stats.csv
+tail -3 $OUT/pytest.log; cat $OUT/db_query.jsonl; head -5 $OUT/nn_kernel_stats.csv; tail -3 $OUT/err.txt
