@@ -260,6 +260,7 @@ extern "C" void orbhip_destroy(orbhip_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    orbhip_bow_forget_ctx(c);                                      // BoW workspaces the vocabularies keep for this context (they ran on c->stream)
     if (c->mstream) { (void)hipStreamSynchronize(c->mstream); (void)hipStreamDestroy(c->mstream); }
     if (c->bstream) { (void)hipStreamSynchronize(c->bstream); (void)hipStreamDestroy(c->bstream); }
     if (c->ev_pyr) (void)hipEventDestroy(c->ev_pyr);
@@ -764,8 +765,17 @@ static orbhip_status ensure_host_staging(orbhip_ctx* c, bool input)
     return ORBHIP_OK;
 }
 
+// The un-ticketed host entry points (orbhip_fetch*, the colour / rectify batch calls, the stereo calls) download into the context's OWN pinned
+// mirrors - which are also staging set 0 of the ticketed path: while a submitted batch is still in flight they would overwrite (or read) what
+// its collect is about to deliver.  They refuse instead, like orbhip_extract_batch does.
+static orbhip_status mirrors_free(const orbhip_ctx* c, const char* who)
+{
+    if (c->oldest_ticket != c->next_ticket) return fail(ORBHIP_ERR_INVALID, "%s with %d submitted batch(es) still in flight: collect them first", who, c->next_ticket - c->oldest_ticket);
+    return ORBHIP_OK;
+}
 static orbhip_status enqueue_fetch(orbhip_ctx* c, int nimg, bool want_kp, bool want_desc)
 {   // bulk device-to-host copies into the pinned mirrors, ordered after the extraction on the context's stream
+    { const orbhip_status st = mirrors_free(c, "a fetch into the context's mirrors"); if (st != ORBHIP_OK) return st; }
     HIPCHK(hipMemcpyAsync(c->h_n, c->d_out_n[c->cur], nimg * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     if (want_kp) HIPCHK(hipMemcpyAsync(c->h_kp, c->d_out_kp[c->cur], (size_t)nimg * c->out_cap * sizeof(orbhip_keypoint), hipMemcpyDeviceToHost, c->stream));
     if (want_desc) HIPCHK(hipMemcpyAsync(c->h_desc, c->d_out_desc[c->cur], (size_t)nimg * c->out_cap * 32, hipMemcpyDeviceToHost, c->stream));
@@ -1546,6 +1556,7 @@ extern "C" orbhip_status orbhip_compute_stereo_matches(orbhip_ctx* l, orbhip_ctx
     HIPCHK(hipGetLastError());
     st = ensure_host_staging(l, false); if (st != ORBHIP_OK) return st;
     std::vector<int> n(nimg);
+    { const orbhip_status stf = mirrors_free(l, "orbhip_compute_stereo_matches"); if (stf != ORBHIP_OK) return stf; }
     HIPCHK(hipMemcpyAsync(l->h_n, l->d_out_n[l->cur], nimg * sizeof(int), hipMemcpyDeviceToHost, l->stream));
     float* hu = reinterpret_cast<float*>(l->h_kp); float* hd = hu + (size_t)nimg * l->out_cap;       // pinned mirror reused (28 B/keypoint >= 8 B)
     HIPCHK(hipMemcpyAsync(hu, l->d_st_u, (size_t)nimg * l->out_cap * sizeof(float), hipMemcpyDeviceToHost, l->stream));
@@ -1659,6 +1670,7 @@ extern "C" orbhip_status orbhip_fetch_undistorted(orbhip_ctx* c, int nimg, orbhi
     HIPCHK(hipSetDevice(c->cfg.device));
     orbhip_status st = ensure_host_staging(c, false); if (st != ORBHIP_OK) return st;
     if (!c->h_kpun) HIPCHK(hipHostMalloc((void**)&c->h_kpun, (size_t)c->B * c->out_cap * sizeof(orbhip_keypoint), hipHostMallocDefault));
+    { const orbhip_status stf = mirrors_free(c, "orbhip_fetch_undistorted"); if (stf != ORBHIP_OK) return stf; }
     HIPCHK(hipMemcpyAsync(c->h_n, c->d_out_n[c->cur], nimg * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(c->h_kpun, (c->distorted ? c->d_out_kpun : c->d_out_kp)[c->cur], (size_t)nimg * c->out_cap * sizeof(orbhip_keypoint), hipMemcpyDeviceToHost, c->stream));
     st = orbhip_sync(c); if (st != ORBHIP_OK) return st;
@@ -1692,6 +1704,7 @@ extern "C" orbhip_status orbhip_compute_stereo_from_rgbd(orbhip_ctx* c, int nimg
                                    (int)pitch, depth_type, convert, depth_factor, mbf, d_u, d_z, nimg, c->stream);
     HIPCHK(hipGetLastError());
     orbhip_status st = ensure_host_staging(c, false); if (st != ORBHIP_OK) return st;
+    { const orbhip_status stf = mirrors_free(c, "orbhip_compute_stereo_from_rgbd"); if (stf != ORBHIP_OK) return stf; }
     HIPCHK(hipMemcpyAsync(c->h_n, c->d_out_n[c->cur], nimg * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     st = orbhip_sync(c); if (st != ORBHIP_OK) return st;
     for (int f = 0; f < nimg; f++) {

@@ -439,9 +439,27 @@ static orbhip_status voc_run(orbhip_voc* v, BowWs* w, const uint8_t* d_desc, lon
     return ORBHIP_OK;
 }
 
+// Every live vocabulary, so that a context that goes away can take its per-context workspaces with it (orbhip_destroy -> orbhip_bow_forget_ctx):
+// the drop-in extractor re-creates its context on every image-size change, and a NEW context allocated at the old one's address must not
+// inherit the old one's workspace (stale last_frames: orbhip_fetch_bow before orbhip_compute_bow would have returned the old frames' words).
+static std::mutex g_vocs_m; static std::vector<orbhip_voc*> g_vocs;
+void orbhip_bow_forget_ctx(const orbhip_ctx* ctx)
+{
+    std::lock_guard<std::mutex> all(g_vocs_m);
+    for (orbhip_voc* v : g_vocs) {
+        std::lock_guard<std::mutex> lock(v->m);
+        auto it = v->per_ctx.find(ctx);
+        if (it == v->per_ctx.end()) continue;
+        (void)hipSetDevice(v->device);
+        voc_free_ws(&it->second);                                       // the context's streams are drained by its destructor before this is called
+        v->per_ctx.erase(it);
+    }
+}
+
 extern "C" void orbhip_voc_destroy(orbhip_voc* v)
 {
     if (!v) return;
+    { std::lock_guard<std::mutex> all(g_vocs_m); g_vocs.erase(std::remove(g_vocs.begin(), g_vocs.end(), v), g_vocs.end()); }
     (void)hipSetDevice(v->device);
     if (v->stream) (void)hipStreamSynchronize(v->stream);
     (void)hipDeviceSynchronize();                                       // per-context workspaces were used on the extractors' streams
@@ -506,6 +524,7 @@ extern "C" orbhip_status orbhip_voc_load_text(orbhip_voc** out, const char* path
     if (e == hipSuccess) e = hipMemcpy(v->d_node_desc, v->node_desc.data(), (size_t)nn * 32, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(v->d_node_weight, v->node_weight.data(), (size_t)nn * 8, hipMemcpyHostToDevice);
     if (e != hipSuccess) { orbhip_voc_destroy(v); return orbhip_set_error(ORBHIP_ERR_HIP, "vocabulary upload failed: %s", hipGetErrorString(e)); }
+    { std::lock_guard<std::mutex> all(g_vocs_m); g_vocs.push_back(v); }
     *out = v;
     return ORBHIP_OK;
 }

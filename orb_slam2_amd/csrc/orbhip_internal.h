@@ -188,6 +188,7 @@ void orbhip_launch_match_select(const MatchParams& M, int nslots, hipStream_t s)
 
 // shared with orbhip_bow.hip
 void orbhip_bow_thread_release();
+void orbhip_bow_forget_ctx(const orbhip_ctx* ctx);      // frees the per-context BoW workspaces every live vocabulary keeps for ctx (called by orbhip_destroy)
 // v_writelane_b32: a wave-uniform value dropped into ONE lane of a register (lane index wave-uniform too).  The compiler has no builtin for
 // it, so the device pass spells the instruction; every other pass (hipcc's host pass, the test emulation) sees the plain selection.
 __device__ __forceinline__ int orbhip_writelane(int v, int dst_lane, int old)

@@ -65,6 +65,8 @@ def test_submit_collect_ring(backend, frames, want, monkeypatch):
         orb_slam2_amd.orbhip._check(ex.L.orbhip_collect(ex.h, tickets[-1], None, None, 0, orb_slam2_amd.orbhip._p(np.zeros(4, np.int32))), "orbhip_collect", ex.L)
     with pytest.raises(orb_slam2_amd.OrbHipError, match="in flight"):
         ex.extract_batch(frames[:1])                              # the synchronous entry refuses to jump the queue
+    with pytest.raises(orb_slam2_amd.OrbHipError, match="in flight"):
+        ex.fetch(1)                                               # ... and so does everything else that downloads into the context's own mirrors (= staging set 0)
     while done < len(tickets):
         k, d = ex.collect(tickets[done])
         _same(k, d, want, batches[done])
