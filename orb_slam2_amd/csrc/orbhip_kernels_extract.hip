@@ -774,8 +774,10 @@ __device__ __forceinline__ void fc_load_window(const uint8_t* patch, int PS, int
 
 // CPS / CSS: the patch / score row strides as compile-time constants (0 = read them from the parameters): with the strides of the usual
 // 30-px grid (48 and 40 bytes) every window row is an immediate offset of one LDS address instead of an address addition per row.
+// (FAST and the blur as ONE launch with workgroups of both kinds alternating on every CU - k_fast_blur, round 3 - was bit-exact and slower: 1.41-1.46 ms
+//  against 0.92 + 0.42 standalone; what one kind leaves idle the other cannot use.  profiles/r03_exp_fast_blur_one_launch.jsonl)
 template <int CPS, int CSS>
-__global__ __launch_bounds__(256) void k_fast_cells(ExtractParams P)
+__global__ __launch_bounds__(256, 7) void k_fast_cells(ExtractParams P)       // 7 waves per SIMD = what the LDS block allows (7 workgroups per CU): at most 72 VGPRs (75 uncapped: 6 waves, 3 % slower)
 {
     HIP_DYNAMIC_SHARED(unsigned, fc_lds)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;

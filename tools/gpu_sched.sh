@@ -1,15 +1,20 @@
 #!/bin/bash
-# schedule experiments: ORBHIP_SCHED variants at B = 512 (and 256), parity under the variant.  usage: tools/gpu_sched.sh <tag> "<sched values>"
-TAG=${1:-sch}; OUT=gpurun_out/$TAG; mkdir -p $OUT; cd "$(dirname "$0")/.."
-for v in ${2:-0 1}; do
-  ORBHIP_SCHED=$v timeout 300 python -m pytest tests/test_full_size_gpu.py tests/test_parity_extract.py -m gpu -q -x 2>&1 | tail -1
-  for b in 256 512; do ORBHIP_SCHED=$v timeout 300 python bench.py --steps 50 --warmup 3 --repeats 3 --batch $b --no-cpu-baseline --no-host-io > $OUT/bench_s${v}_b$b.json 2>> $OUT/bench.err; done
+# schedules x library variants in one call    usage: tools/gpu_sched.sh <tag> "<variants>" "<scheds>"
+TAG=${1:-sch}; VARS=${2:-new}; SCHEDS=${3:-"0 4"}
+cd "$(dirname "$0")/.."
+REPO=$(pwd); OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT
+for r in 1 2; do
+  for v in $VARS; do for sc in $SCHEDS; do
+    if [ $v = new ]; then unset ORBHIP_LIBRARY; else export ORBHIP_LIBRARY=$REPO/ab/liborbhip_$v.so; fi
+    ORBHIP_SCHED=$sc timeout 300 python3 bench.py --steps 40 --warmup 3 --repeats 3 --no-cpu-baseline --no-host-io >> $OUT/bench_${v}_s$sc.jsonl 2>> $OUT/err.txt
+  done; done
 done
+unset ORBHIP_LIBRARY
 python3 - <<PY
-import json, glob
-for f in sorted(glob.glob("$OUT/bench_s*.json")):
-    try:
-        d = json.loads(open(f).read().strip().splitlines()[-1]); print(f.split("/")[-1], d["value"], d["ms_per_step"], {k: v for k, v in d["kernels_ms_per_launch"].items() if v})
-    except Exception as e: print(f, "failed", e)
+import json,glob
+for f in sorted(glob.glob("$OUT/bench_*.jsonl")):
+    rows=[json.loads(l) for l in open(f).read().strip().splitlines()]
+    ks=[k for k in rows[0]["kernels_ms_per_launch"] if rows[0]["kernels_ms_per_launch"][k]]
+    print(f.split("/")[-1], [r["value"] for r in rows], "parity", [r["parity"]["mismatches"] for r in rows], {k: round(sum(r["kernels_ms_per_launch"][k] for r in rows)/len(rows),4) for k in ks})
 PY
-tail -3 $OUT/bench.err
+tail -2 $OUT/err.txt
