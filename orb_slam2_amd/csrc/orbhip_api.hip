@@ -474,9 +474,9 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
         int umax[16]; const int vmax = (int)floor(15 * sqrt(2.0) / 2 + 1), vmin = (int)ceil(15 * sqrt(2.0) / 2);
         for (int v = 0; v <= vmax; v++) umax[v] = cvRoundF((float)sqrt(225.0 - (double)v * v));
         for (int v = 15, v0 = 0; v >= vmin; --v) { while (umax[v0] == umax[v0 + 1]) ++v0; umax[v] = v0; ++v0; }
-        std::vector<unsigned> mask(8 * 64, 0u);                       // k_describe: pass q, lane l = (row 4q + l / 16, dword l % 16 of the row from column -15 on)
-        for (int q = 0; q < 8; q++) for (int l = 0; l < 64; l++) for (int b = 0; b < 4; b++) {
-            const int r = 4 * q + (l >> 4), d = l & 15, v = r - 15, uu = 4 * d + b - 15;
+        std::vector<unsigned> mask(5 * 64, 0u);                       // k_describe: pass q, lane l = (row 7q + l / 9, dword l % 9 of the row from column -15 on); lane 63 idles
+        for (int q = 0; q < 5; q++) for (int l = 0; l < 63; l++) for (int b = 0; b < 4; b++) {
+            const int r = 7 * q + l / 9, d = l % 9, v = r - 15, uu = 4 * d + b - 15;
             if (r <= 30 && d <= 7 && abs(uu) <= 15 && abs(uu) <= umax[abs(v)]) mask[q * 64 + l] |= 0xffu << (8 * b);
         }
         TRY(upload(&c->d_ic_mask, mask));
@@ -602,6 +602,38 @@ static orbhip_status pipeline_frames(orbhip_ctx* c, ExtractParams& P, int f0, in
     const int nt0 = c->blur_tiles_l0, nt1 = (int)c->blur_tiles.size() - nt0;
     const int nc0 = c->geom[0].ncells, nc1 = (int)c->cells.size() - nc0;
     const int sched = (own_blur_stream && !c->serial && !pyr_done) ? c->sched : -1;
+    if ((sched == 4 || sched == 5) && nf >= 32) {      // 5 (measurement): the blur in front of FAST instead of behind it
+        // The quadtree off the critical path: the batch goes through FAST and the descriptor kernel as two halves A | B (A a multiple of 8 frames: a
+        // frame keeps its XCD), so that quadtree(A) runs beside FAST(B) and quadtree(B) beside the blur, and describe(A) has waited for neither.
+        // Main stream: pyramid, FAST(A), FAST(B), blur, describe(A), describe(B) - the throughput kernels back to back; second stream: the two
+        // quadtree launches, each behind its half of FAST.
+        hipStream_t bs = c->bstream;
+        const int nA = std::max(8, ((nf / 2) + 7) & ~7), nB = nf - nA;
+        { ProfScope ps(c, K_PYRAMID, s); launch_pyramid(c, P, nf, s); }
+        if (sched == 5) { ProfScope ps(c, K_BLUR, s); orbhip_launch_blur(P, c->gk, nf, s); }
+        { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nA, s); }
+        HIPCHK(hipEventRecord(c->ev_pyr, s)); HIPCHK(hipStreamWaitEvent(bs, c->ev_pyr, 0));
+        { ProfScope ps(c, K_QUADTREE, bs); orbhip_launch_quadtree(P, nA, bs); }
+        HIPCHK(hipEventRecord(c->ev_fast0, bs));
+        P.frame0 = f0 + nA;
+        { ProfScope ps(c, K_FAST, s, 0); orbhip_launch_fast_cells(P, nB, s); }
+        HIPCHK(hipEventRecord(c->ev_start, s)); HIPCHK(hipStreamWaitEvent(bs, c->ev_start, 0));
+        { ProfScope ps(c, K_QUADTREE, bs, 0); orbhip_launch_quadtree(P, nB, bs); }
+        HIPCHK(hipEventRecord(c->ev_blur, bs));
+        P.frame0 = f0;
+        if (sched == 4) { ProfScope ps(c, K_BLUR, s); orbhip_launch_blur(P, c->gk, nf, s); }
+        HIPCHK(hipStreamWaitEvent(s, c->ev_fast0, 0));
+        { ProfScope ps(c, K_DESCRIBE, s); orbhip_launch_describe(P, nA, s); }
+        P.frame0 = f0 + nA;
+        HIPCHK(hipStreamWaitEvent(s, c->ev_blur, 0));
+        { ProfScope ps(c, K_DESCRIBE, s, 0); orbhip_launch_describe(P, nB, s); }
+        P.frame0 = f0;
+        if (c->distorted) {
+            ProfScope ps(c, K_UNDISTORT, s);
+            orbhip_launch_undistort_keys(c->cam, c->d_out_kp[c->cur] + (size_t)f0 * c->out_cap, c->d_out_n[c->cur] + f0, c->d_out_kpun[c->cur] + (size_t)f0 * c->out_cap, c->out_cap, nf, s);
+        }
+        return ORBHIP_OK;
+    }
     if (sched == 2) {
         hipStream_t bs = c->bstream;
         HIPCHK(hipEventRecord(c->ev_start, s)); HIPCHK(hipStreamWaitEvent(bs, c->ev_start, 0));

@@ -731,6 +731,16 @@ __host__ __device__ __forceinline__ int fc_wave_bytes(int pbytes, int sstride, i
 
 // ring of the pixel pair (Q, Q+1) of a 4-pixel group whose 7 x 12-byte window is w[7][3] (circle: FAST 16-point Bresenham);
 // ring element k of pixel q sits at row 3+dy_k, byte 3+q+dx_k
+// The same ring for a pair that starts at byte 3 + SH of the window rows (SH = 0 or 2, per lane): the byte pair (I, I+1), I = 3 + dx, sits in
+// dwords {w0, w1} for I <= 4 and in {w1, w2} for I = 5, 6 whichever SH is, so every ring element is ONE v_perm_b32 whose selector carries the
+// lane's shift (selector of byte pair (i, i+1) of a dword pair = 0x0c000c00 | i | (i+1) << 16; + 0x00020002 moves it two bytes on) - no
+// funnel shift of the window rows first.  s[i] = that selector for i = 0..4; I = 5, 6 are i = 1, 2 of {w1, w2}.
+__device__ __forceinline__ pku16 row_pair_v(unsigned lo, unsigned hi, unsigned sel) { return (pku16)__builtin_amdgcn_perm(hi, lo, sel); }
+#define FC_RING_V(s) { \
+    row_pair_v(w[6][0], w[6][1], s[3]), row_pair_v(w[6][0], w[6][1], s[4]), row_pair_v(w[5][1], w[5][2], s[1]), row_pair_v(w[4][1], w[4][2], s[2]), \
+    row_pair_v(w[3][1], w[3][2], s[2]), row_pair_v(w[2][1], w[2][2], s[2]), row_pair_v(w[1][1], w[1][2], s[1]), row_pair_v(w[0][0], w[0][1], s[4]), \
+    row_pair_v(w[0][0], w[0][1], s[3]), row_pair_v(w[0][0], w[0][1], s[2]), row_pair_v(w[1][0], w[1][1], s[1]), row_pair_v(w[2][0], w[2][1], s[0]), \
+    row_pair_v(w[3][0], w[3][1], s[0]), row_pair_v(w[4][0], w[4][1], s[0]), row_pair_v(w[5][0], w[5][1], s[1]), row_pair_v(w[6][0], w[6][1], s[2]) }
 #define FC_RING(Q) { \
     row_pair<3 + Q + 0>(w[6][0], w[6][1], w[6][2]), row_pair<3 + Q + 1>(w[6][0], w[6][1], w[6][2]), row_pair<3 + Q + 2>(w[5][0], w[5][1], w[5][2]), row_pair<3 + Q + 3>(w[4][0], w[4][1], w[4][2]), \
     row_pair<3 + Q + 3>(w[3][0], w[3][1], w[3][2]), row_pair<3 + Q + 3>(w[2][0], w[2][1], w[2][2]), row_pair<3 + Q + 2>(w[1][0], w[1][1], w[1][2]), row_pair<3 + Q + 1>(w[0][0], w[0][1], w[0][2]), \
@@ -782,22 +792,27 @@ __global__ __launch_bounds__(256, 7) void k_fast_cells(ExtractParams P)       //
     HIP_DYNAMIC_SHARED(unsigned, fc_lds)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int tile, frame;
-    if (!xcd_frame_map((P.fc_ncells + FC_WAVES - 1) / FC_WAVES, P.nframes, tile, frame)) return;      // this launch: cells [fc_cell0, fc_cell0 + fc_ncells)
+    if (!xcd_frame_map((P.fc_ncells + FC_WAVES - 1) / FC_WAVES, P.nframes, tile, frame)) return;      // this launch: cells [fc_cell0, fc_cell0 + fc_ncells); the whole workgroup leaves
     frame += P.frame0;
-    const int cell_id = P.fc_cell0 + tile * FC_WAVES + wave;
-    if (cell_id >= P.fc_cell0 + P.fc_ncells) return;                              // every LDS region below is private to its wave: no workgroup barriers
+    const int cell_last = P.fc_cell0 + P.fc_ncells - 1;
+    const bool have = P.fc_cell0 + tile * FC_WAVES + wave <= cell_last;           // a wave without a cell of its own still serves the workgroup's shared stage
+    const int cell_id = min(P.fc_cell0 + tile * FC_WAVES + wave, cell_last);
     const CellDesc cd = P.cells[cell_id];
     const int pw = cd.maxX - cd.iniX, ph = cd.maxY - cd.iniY;       // sub-image
     const int cw = pw - 6, ch = ph - 6;                              // examined interior (rows/cols 3 .. n-4)
-    const bool work = !cd.skipped && cw > 0 && ch > 0;
-    if (!work) { if (lane == 0) P.cell_count[(long long)frame * P.ncells_total + cell_id] = 0; return; }
+    const bool work = have && !cd.skipped && cw > 0 && ch > 0;
     const int PS = CPS ? CPS : P.fc_pstride, SS = CSS ? CSS : P.fc_sstride;      // byte strides, multiples of 4
-    uint8_t* wbase = reinterpret_cast<uint8_t*>(fc_lds) + wave * fc_wave_bytes(P.fc_pbytes, SS, P.fc_srows, P.fc_listcap);
+    const int WB = fc_wave_bytes(P.fc_pbytes, SS, P.fc_srows, P.fc_listcap);      // per-wave LDS region: patch | score map | pair list
+    const int score_off = (P.fc_pbytes + 15) & ~15, list_off = score_off + ((SS * P.fc_srows + 15) & ~15);
+    uint8_t* const lds0 = reinterpret_cast<uint8_t*>(fc_lds);
+    uint8_t* wbase = lds0 + wave * WB;
     uint8_t* patch = wbase;                                          // patch column 0 is 4-byte aligned; row stride PS
-    uint8_t* score = wbase + ((P.fc_pbytes + 15) & ~15);             // interior (x, y) at score[(y+1)*SS + 4 + x]; zero ring around it
-    unsigned short* list = reinterpret_cast<unsigned short*>(score + ((SS * P.fc_srows + 15) & ~15));
+    uint8_t* score = wbase + score_off;                              // interior (x, y) at score[(y+1)*SS + 4 + x]; zero ring around it
+    unsigned short* list = reinterpret_cast<unsigned short*>(wbase + list_off);
+    int* const sh = reinterpret_cast<int*>(lds0 + FC_WAVES * WB);    // workgroup header: [0..3] listed pairs of each wave, [4..7] interior width of each wave's cell
     const int ng = (cw + 3) >> 2;                                    // 4-pixel groups per interior row (<= 16)
-    {
+    if (lane == 0) sh[4 + wave] = cw;
+    if (work) {
         // The cell's sub-image goes to LDS by LDS-DMA at the patch's own byte alignment, so patch column 0 lands on an LDS dword
         // boundary without any shifting: pass k fills LDS dwords [64k, 64k+64) of the patch, lane l the dword (row, col) =
         // divmod(64k + l, PS/4), both from a host table that only depends on PS.  Positions outside the patch (rows >= ph, the
@@ -838,14 +853,19 @@ __global__ __launch_bounds__(256, 7) void k_fast_cells(ExtractParams P)       //
     // The two cv::FAST calls of the reference (ORBextractor.cc:809-816): iniThFAST, and minThFAST only when the first returned
     // nothing.  Only pixels with score >= th matter for a call, and its NMS sees every weaker pixel as 0, so each call is
     //      a. cheap necessary test at th on every pixel pair (a lane tests the two pairs of its 4-pixel group) -> ordered
-    //         list of the pairs that may hold such a pixel
-    //      b. exact scores of those pairs only (compacted: a lane per listed pair)
-    //      c. NMS + row-major emission over the listed pairs
+    //         list of the pairs that may hold such a pixel                                                   [the cell's own wave]
+    //      b. exact scores of those pairs only, a lane per listed pair: THE WORKGROUP'S FOUR LISTS AS ONE - a cell lists 40 pairs on
+    //         average, so its own wave would run this stage (the most expensive instructions of the kernel) with 40 of 64 lanes busy in
+    //         one pass and a handful in a second one (1.21 passes per cell); four cells' pairs fill 3 wave passes instead of 4.8
+    //      c. NMS + row-major emission over the listed pairs                                                 [the cell's own wave]
+    // Both calls run for the whole workgroup (two barriers each); a wave whose cell is finished lists nothing and only serves stage b.
     int count = 0;
+    bool busy = work;
     for (int phase = 0; phase < 2; phase++) {
         const int th = phase ? P.minTh : P.iniTh;
         const pku16 tt = {(unsigned short)th, (unsigned short)th};
         int nq = 0;
+        if (busy)
         for (int yb = 0; yb < ch; yb += rp) {
             // branch-free: idle lanes (beyond the last row / the last whole row group) test a clamped row and are masked afterwards
             const int yy = yb + sr, y = min(yy, ch - 1);
@@ -869,32 +889,52 @@ __global__ __launch_bounds__(256, 7) void k_fast_cells(ExtractParams P)       //
             if (lb) list[pos] = (unsigned short)((y << 8) | (2 * grp + 1));
             nq += __popcll(ma) + __popcll(mb);
         }
-        __builtin_amdgcn_wave_barrier();
-        for (int qb = 0; qb < nq; qb += 64) {
-            if (qb + lane < nq) {
-                const int id = list[qb + lane], y = id >> 8, pr = id & 0xff, x0 = 2 * pr;
-                // the pair's 7 x 8-byte window, shifted so that it starts at byte 0 of the first dword whichever half of the group it is
-                const unsigned* prow = reinterpret_cast<const unsigned*>(patch + y * PS) + (pr >> 1);
-                const unsigned sh = 2u * (unsigned)(pr & 1);
-                unsigned w[7][3];
+        if (lane == 0) sh[wave] = nq;
+        __syncthreads();
+        {
+            // stage b over the concatenation of the four lists: entry e belongs to wave j's cell (patch, score map, list, width of ITS region)
+            const int o1 = __builtin_amdgcn_readfirstlane(sh[0]), o2 = o1 + __builtin_amdgcn_readfirstlane(sh[1]), o3 = o2 + __builtin_amdgcn_readfirstlane(sh[2]);
+            const int T = o3 + __builtin_amdgcn_readfirstlane(sh[3]);
+            // Chunks of 64 entries go to the waves round-robin from a starting wave that differs between the workgroups resident on a CU
+            // (a wave's index fixes its SIMD: with chunk c always on wave c, SIMD 0 would run this stage for every workgroup and SIMD 3 for
+            // almost none - measured as 0.899 ms against 0.922 ms without the shared stage, where the instruction count promised 0.84)
+            const int rot = (tile ^ (tile >> 2) ^ (tile >> 5) ^ (tile >> 7) ^ frame) & (FC_WAVES - 1);
+            for (int e0 = 64 * ((wave - rot) & (FC_WAVES - 1)); e0 < T; e0 += 64 * FC_WAVES) {
+                const int e = e0 + lane;
+                if (e < T) {
+                    // owner j of entry e and its index le in the owner's list: with o1 <= o2 <= o3 the differences e - o_k fall with k, the
+                    // negative ones are huge as unsigned numbers, so le is their unsigned minimum and j the number of non-negative ones
+                    const int d1 = e - o1, d2 = e - o2, d3 = e - o3;
+                    const int le = (int)min(min((unsigned)e, (unsigned)d1), min((unsigned)d2, (unsigned)d3));
+                    const int j = 3 + (d1 >> 31) + (d2 >> 31) + (d3 >> 31);
+                    const int jo = (int)__umul24((unsigned)j, (unsigned)WB);
+                    const int cwj = sh[4 + j];
+                    const uint8_t* jb = lds0 + jo;
+                    const int id = *reinterpret_cast<const unsigned short*>(lds0 + jo + list_off + 2 * le), y = id >> 8, pr = id & 0xff, x0 = 2 * pr;
+                    // the pair's 7 x 8-byte window, shifted so that it starts at byte 0 of the first dword whichever half of the group it is
+                    const unsigned* prow = reinterpret_cast<const unsigned*>(jb + y * PS) + (pr >> 1);
+                    const unsigned shsel = (pr & 1) ? 0x00020002u : 0u;                      // the pair is the second one of its 4-pixel group: two bytes on
+                    const unsigned sel[5] = {0x0c010c00u + shsel, 0x0c020c01u + shsel, 0x0c030c02u + shsel, 0x0c040c03u + shsel, 0x0c050c04u + shsel};
+                    unsigned w[7][3];
 #pragma unroll
-                for (int r = 0; r < 7; r++) {
-                    const unsigned d0 = prow[r * (PS >> 2)], d1 = prow[r * (PS >> 2) + 1], d2 = prow[r * (PS >> 2) + 2];
-                    w[r][0] = __builtin_amdgcn_alignbyte(d1, d0, sh); w[r][1] = __builtin_amdgcn_alignbyte(d2, d1, sh); w[r][2] = 0;
+                    for (int r = 0; r < 7; r++) { w[r][0] = prow[r * (PS >> 2)]; w[r][1] = prow[r * (PS >> 2) + 1]; w[r][2] = prow[r * (PS >> 2) + 2]; }
+                    const pku16 ra[16] = FC_RING_V(sel);
+                    const pki16 sa = fast_score_pair(ra, row_pair_v(w[3][0], w[3][1], sel[3]));
+                    int s0 = sa[0], s1 = sa[1];
+                    if (s0 < th || x0 >= cwj) s0 = 0;                                        // corner at th  <=>  score >= th
+                    if (s1 < th || x0 + 1 >= cwj) s1 = 0;
+                    *reinterpret_cast<unsigned short*>(lds0 + jo + score_off + (y + 1) * SS + 4 + x0) = (unsigned short)(s0 | (s1 << 8));
                 }
-                const pku16 ra[16] = FC_RING(0);
-                const pki16 sa = fast_score_pair(ra, row_pair<3>(w[3][0], w[3][1], w[3][2]));
-                int s0 = sa[0], s1 = sa[1];
-                if (s0 < th || x0 >= cw) s0 = 0;                                         // corner at th  <=>  score >= th
-                if (s1 < th || x0 + 1 >= cw) s1 = 0;
-                *reinterpret_cast<unsigned short*>(score + (y + 1) * SS + 4 + x0) = (unsigned short)(s0 | (s1 << 8));
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
+        if (busy)
         for (int qb = 0; qb < nq; qb += 64) {
             unsigned gtm = 0, rbm = 0; int y = 0, x0 = 0;
             if (qb + lane < nq) {
-                const int id = list[qb + lane];
+                int li = qb + lane;
+                asm volatile("" : "+v"(li));            // the list address is rebuilt here: kept live across stage b it was spilled to scratch (72-VGPR cap)
+                const int id = list[li];
                 y = id >> 8; x0 = 2 * (id & 0xff);
                 // rows above / at / below, bytes x0-1 .. x0+2 (the pad dwords left and right of a row are zero)
                 const int qo = (y + 1) * SS + 4 + x0 - 1;                                // byte offset in the score map (its base is 16-byte aligned)
@@ -927,20 +967,20 @@ __global__ __launch_bounds__(256, 7) void k_fast_cells(ExtractParams P)       //
                 }
             count += __popcll(m0) + __popcll(m1);
         }
-        if (count > 0) break;
+        if (count > 0) busy = false;
         // vKeysCell.empty() -> cv::FAST again with minThFAST (ORBextractor.cc:812-816).  The score map restarts from zero: scores the
-        // first call left behind (maxima that suppressed each other) are not this call's
-        __builtin_amdgcn_wave_barrier();
-        if (phase == 0) for (int i = lane; i < ((SS >> 2) * (ch + 2) + 3) >> 2; i += 64) reinterpret_cast<uint4*>(score)[i] = uint4{0u, 0u, 0u, 0u};
-        __builtin_amdgcn_wave_barrier();
+        // first call left behind (maxima that suppressed each other) are not this call's.  (Every other wave's stage-b stores into this map
+        // are behind the barrier above; the next ones come after the next barrier.)
+        if (phase == 0 && busy) for (int i = lane; i < ((SS >> 2) * (ch + 2) + 3) >> 2; i += 64) reinterpret_cast<uint4*>(score)[i] = uint4{0u, 0u, 0u, 0u};
     }
-    if (lane == 0) P.cell_count[(long long)frame * P.ncells_total + cell_id] = min(count, cd.cand_cap);
+    if (have && lane == 0) P.cell_count[(long long)frame * P.ncells_total + cell_id] = work ? min(count, cd.cand_cap) : 0;
 }
 #undef FC_RING
+#undef FC_RING_V
 
 void orbhip_launch_fast_cells(const ExtractParams& P, int nframes, hipStream_t s, int cell0, int ncells)
 {   // cells [cell0, cell0 + ncells) of the level-major cell table (ncells < 0: all)
-    const size_t lds = (size_t)FC_WAVES * fc_wave_bytes(P.fc_pbytes, P.fc_sstride, P.fc_srows, P.fc_listcap);
+    const size_t lds = (size_t)FC_WAVES * fc_wave_bytes(P.fc_pbytes, P.fc_sstride, P.fc_srows, P.fc_listcap) + 32;      // + the workgroup header
     ExtractParams Q = P; Q.nframes = nframes;
     Q.fc_cell0 = ncells < 0 ? 0 : cell0; Q.fc_ncells = ncells < 0 ? P.ncells_total : ncells;
     if (Q.fc_ncells <= 0) return;
@@ -1305,8 +1345,8 @@ __device__ __forceinline__ int round_half_even_small(float x) { return __float_a
 #define DS_WAVES 4
 #define DS_KPW 4                       // key point slots per wavefront
 #define DS_WROWS 37                    // blurred window rows: pattern reach is +-18 after rotation
-#define DS_WSTRIDE 40                  // bytes per staged window row (37 used; the window starts exactly at cx - 18)
-#define DS_PPASS 8                     // orientation patch: 32-bit load passes of 4 rows x 16 lanes
+#define DS_WSTRIDE 40                  // bytes per staged window row (37 used, starting 0..3 bytes into the row: the row is staged from the dword boundary below cx - 18)
+#define DS_PPASS 5                     // orientation patch: 32-bit load passes of 7 rows x 9 lanes
 #define DS_WPASSES 6                   // LDS-DMA passes per window: 6 x 64 dwords >= 37 rows x 10 dwords
 #define DS_WDWORDS (DS_WPASSES * 64)
 // One wavefront per DS_KPW consecutive key point slots, in three phases, so that what is per-key-point scalar work in the reference is
@@ -1348,12 +1388,13 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
     float4 pt[4];                                                          // rBRIEF pattern of this lane's 4 tests as floats (x0, y0, x1, y1), from the workgroup's LDS copy
 #pragma unroll
     for (int r = 0; r < 4; r++) { pt[r].x = s_pat[(0 * 4 + r) * 64 + lane]; pt[r].y = s_pat[(1 * 4 + r) * 64 + lane]; pt[r].z = s_pat[(2 * 4 + r) * 64 + lane]; pt[r].w = s_pat[(3 * 4 + r) * 64 + lane]; }
-    // orientation patch: lane = (row mod 4, dword of the row); 9 of a row's 16 lanes load the aligned dwords around its 31 bytes, which are
-    // then funnel-shifted into place (an unaligned 32-bit load of this shape costs the texture addresser 3.5 x an aligned one)
-    const int prow = lane >> 4, pd = lane & 15;
+    // orientation patch: lane = (row mod 7, dword of the row), 9 lanes per row (63 of the 64 busy; 16 lanes per row left 28 of them idle and
+    // took 8 passes instead of 5): the aligned dwords around the row's 31 bytes, which are then funnel-shifted into place with the next lane's
+    // dword (an unaligned 32-bit load of this shape costs the texture addresser 3.5 x an aligned one)
+    const int prow = min((lane * 7282) >> 16, 6), pd = min(lane - 9 * prow, 8);         // lane / 9 for lane < 64; lane 63 doubles lane 62 (its mask is 0)
     unsigned pmask[DS_PPASS];
 #pragma unroll
-    for (int q = 0; q < DS_PPASS; q++) pmask[q] = P.ic_mask[q * 64 + lane];        // bytes inside the circle (row 31, dwords 8..15: 0)
+    for (int q = 0; q < DS_PPASS; q++) pmask[q] = P.ic_mask[q * 64 + lane];        // bytes inside the circle (rows past the 31st, dword 8 of a row, lane 63: 0)
     const unsigned ucoef = 0x03020100u + 0x04040404u * (unsigned)pd;       // u + 15 of the dword's four bytes
     int wrow[DS_WPASSES], wcol[DS_WPASSES];                                // window DMA: pass k, lane l fills dword 64k + l = (row, dword) of the 10-dword rows
 #pragma unroll
@@ -1392,7 +1433,7 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
         const ORBHIP_GLOBAL uint8_t* blv = uniform_ptr(P.blur + (long long)frame * P.plane_frame_bytes + RL(g_poff, level));
         const int bpitch = RL(g_pitch, level);
         const int cx = v & 0xfff, cy = (v >> 12) & 0xfff;
-        const unsigned base = (unsigned)((cy - 18) * bpitch + cx - 18);
+        const unsigned base = (unsigned)((cy - 18) * bpitch + ((cx - 18) & ~3));        // rows start on a dword (planes and pitches are 64-byte aligned): 40 bytes from there still hold the 37 of the window, and an LDS-DMA pass of this shape costs the texture addresser 20 cycles instead of 25 (tools/ta_ubench.hip)
 #pragma unroll
         for (int k = 0; k < DS_WPASSES; k++)
             lds_dma_dword(blv + (base + __umul24((unsigned)wrow[k], (unsigned)bpitch) + (unsigned)wcol[k]), reinterpret_cast<uint8_t*>(win) + 256 * k);
@@ -1406,27 +1447,27 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
             const ORBHIP_GLOBAL uint8_t* img = uniform_ptr(lv[j] == 0 ? P.img0 + (long long)frame * P.img0_frame_stride
                                                                       : P.pyr + (long long)frame * P.plane_frame_bytes + RL(g_poff, lv[j]));
             const int cx = vv[j] & 0xfff, cy = (vv[j] >> 12) & 0xfff;
-            const unsigned off = (unsigned)((cy - 15 + prow) * spitch + ((cx - 15) & ~3) + 4 * min(pd, 8));
+            const unsigned off = (unsigned)((cy - 15) * spitch + ((cx - 15) & ~3) + 4 * pd);
 #pragma unroll
-            for (int q = 0; q < DS_PPASS; q++)                             // rows prow + 4q - 15 = -15 .. 16; row 16 is loaded (in bounds) and masked
-                pw[j][q] = *reinterpret_cast<const ORBHIP_GLOBAL unsigned*>(img + (off + (unsigned)(4 * q * spitch)));
+            for (int q = 0; q < DS_PPASS; q++)                             // rows prow + 7q - 15 = -15 .. 19; those past 15 re-read row 15 and are masked
+                pw[j][q] = *reinterpret_cast<const ORBHIP_GLOBAL unsigned*>(img + (off + __umul24((unsigned)min(prow + 7 * q, 30), (unsigned)spitch)));
         }
 #pragma unroll
         for (int j = 0; j < DS_KPW; j++) if (ok[j]) window_dma(lv[j], vv[j], s_win[wave][j]);
 #pragma unroll
         for (int j = 0; j < DS_KPW; j++) if (ok[j]) {
-            unsigned s = 0, su = 0, cs = 0;                                   // cs = sum over passes of the running row sum = sum_q (8 - q) t_q
+            unsigned s = 0, su = 0, cs = 0;                                   // cs = sum over passes of the running row sum = sum_q (5 - q) t_q
             const unsigned sh = (unsigned)((vv[j] & 0xfff) - 15) & 3u;        // (cx - 15) & 3: byte 0 of the shifted dword is column cx - 15 + 4 pd
 #pragma unroll
             for (int q = 0; q < DS_PPASS; q++) {
-                const unsigned nxt = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pw[j][q], 0x101, 0xf, 0xf, false);     // row_shl:1 = the next dword of the row
+                const unsigned nxt = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pw[j][q], 0x130, 0xf, 0xf, false);     // wave_shl:1 = the next lane's dword = the next dword of the row (a row's last lane is masked)
                 const unsigned x = __builtin_amdgcn_alignbyte(nxt, pw[j][q], sh) & pmask[q];
                 s = __builtin_amdgcn_sad_u8(x, 0u, s);                           // running sum of the masked bytes (v_sad_u8 accumulates: no separate addition)
                 su = __builtin_amdgcn_udot4(x, ucoef, su, false);
                 cs += s;
             }
-            // sum_q (prow + 4q - 15) t_q = (prow - 15) S + 4 (8 S - cs): two additions per pass instead of a 32-bit multiply-add
-            const int sv = (prow + 17) * (int)s - 4 * (int)cs;
+            // sum_q (prow + 7q - 15) t_q = (prow - 15) S + 7 (5 S - cs): two additions per pass instead of a 32-bit multiply-add
+            const int sv = (prow + 20) * (int)s - 7 * (int)cs;
             const int m10 = wave_sum_dpp((int)su - 15 * (int)s), m01 = wave_sum_dpp(sv);     // sum u*I, sum v*I (wave-uniform)
             if (lane == j) { M10 = m10; M01 = m01; }
         }
@@ -1455,7 +1496,7 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
             else lds_dma_wait();
             __builtin_amdgcn_wave_barrier();
             const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a_l), j)), b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b_l), j));
-            const uint8_t* w8 = reinterpret_cast<const uint8_t*>(s_win[wave][j]) + 18 * DS_WSTRIDE + 18;      // key point position inside the window
+            const uint8_t* w8 = reinterpret_cast<const uint8_t*>(s_win[wave][j]) + 18 * DS_WSTRIDE + 18 + (((vv[j] & 0xfff) - 18) & 3);      // key point position inside the window (staged from the dword boundary at or below cx - 18)
             const int dlane = 4 * (oi[j] - oi_first);
             // P.fp_contract (wave-uniform): 0 = x*b + y*a as two roundings (a build with -ffp-contract=off, H3), 1 = the fused forms gcc emits
             // for the reference's own flags, fma(x, b, y*a) and fma(x, a, -(y*b))

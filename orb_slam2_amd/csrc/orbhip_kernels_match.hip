@@ -350,18 +350,29 @@ __global__ __launch_bounds__(256) void k_match_candidates(MatchParams M, float g
     int tk[MS_K]; unsigned te[MS_K]; int nsel = 0;          // this lane's MS_K smallest (distance, list position) keys + their records
 #pragma unroll
     for (int k = 0; k < MS_K; k++) { tk[k] = IMAX; te[k] = MS_NONE; }
-    for (int tb = 0; tb < nitems; tb += 64 * MC_CHUNKS) {
+    // The table is ordered by grid column first, so the entries of the columns the window can reach are ONE contiguous run of it: the columns
+    // GetFeaturesInArea visits (Frame.cc:333-343: floor((x - mnMinX - r) inv) .. ceil((x - mnMinX + r) inv)), widened by one on either side (far
+    // more than the float slack of that arithmetic).  A key point outside the run fails |dx| < r, so scanning the run alone gives the same
+    // sub-sequence as scanning the whole table: at the metric's window (100 px of 1241) that is a fifth of it, 2 passes of 64 entries instead of 7.
+    const int* gstart = M.grid_start + (long long)slot * (ORBHIP_GRID_CELLS + 1);
+    const float cl = __fmul_rn(__fsub_rn(__fsub_rn(x, M.min_x), r), gwInv), ch = __fmul_rn(__fadd_rn(__fsub_rn(x, M.min_x), r), gwInv);
+    // (the comparisons are written so that a NaN position scans the whole table, like the distance test it would fail everywhere)
+    const int col_lo = cl >= 1.0f ? (int)fminf(floorf(cl) - 1.0f, (float)ORBHIP_GRID_COLS) : 0;
+    const int col_hi = ch < (float)(ORBHIP_GRID_COLS - 2) ? (int)fmaxf(ceilf(ch) + 2.0f, 0.0f) : ORBHIP_GRID_COLS;       // one past the last column scanned
+    const int t_lo = __builtin_amdgcn_readfirstlane(gstart[min(col_lo, col_hi) * ORBHIP_GRID_ROWS]), t_hi = __builtin_amdgcn_readfirstlane(gstart[col_hi * ORBHIP_GRID_ROWS]);
+    (void)nitems;
+    for (int tb = t_lo; tb < t_hi; tb += 64 * MC_CHUNKS) {
         float2 k[MC_CHUNKS]; int it[MC_CHUNKS];
 #pragma unroll
         for (int c = 0; c < MC_CHUNKS; c++) {
             const int t = tb + 64 * c + lane;
             k[c].x = 0.0f; k[c].y = 0.0f; it[c] = 0;
-            if (t < nitems) { k[c] = gxy[t]; it[c] = gitems[t]; }
+            if (t < t_hi) { k[c] = gxy[t]; it[c] = gitems[t]; }
         }
 #pragma unroll
         for (int c = 0; c < MC_CHUNKS; c++) {
-            if (tb + 64 * c >= nitems) break;
-            const bool ok = tb + 64 * c + lane < nitems && fabsf(__fsub_rn(k[c].x, x)) < r && fabsf(__fsub_rn(k[c].y, y)) < r;    // Frame.cc:367-371
+            if (tb + 64 * c >= t_hi) break;
+            const bool ok = tb + 64 * c + lane < t_hi && fabsf(__fsub_rn(k[c].x, x)) < r && fabsf(__fsub_rn(k[c].y, y)) < r;    // Frame.cc:367-371
             const unsigned long long m = __ballot(ok);
             if (m == 0) continue;
             const int pos = nc + __popcll(m & below);

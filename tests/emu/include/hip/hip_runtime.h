@@ -159,6 +159,7 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask,
     int s = -1;
     if (ctrl >= 0x111 && ctrl <= 0x11f) { const int n = ctrl - 0x110; s = ((l & 15) >= n) ? l - n : -1; }
     else if (ctrl >= 0x101 && ctrl <= 0x10f) { const int n = ctrl - 0x100; s = ((l & 15) + n < 16) ? l + n : -1; }      // row_shl:n
+    else if (ctrl == 0x130) s = (l + 1 < 64) ? l + 1 : -1;                                                                // wave_shl:1
     else if (ctrl == 0x142) s = (row >= 1) ? row * 16 - 1 : -1;
     else if (ctrl == 0x143) s = (row >= 2) ? 31 : -1;
     const int got = hipemu_shfl(src, s < 0 ? l : s);

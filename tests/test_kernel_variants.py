@@ -64,6 +64,23 @@ def test_stream_schedules(backend, oracle, env, sched):
     ex.close()
 
 
+@pytest.mark.parametrize("B", [40, 33])
+def test_half_batch_schedule_keeps_the_quadtree_off_the_main_chain(backend, oracle, env, B):
+    """ORBHIP_SCHED=4: from 32 frames on a batch goes through FAST and the descriptor kernel as two halves (the first a multiple of 8 frames), the
+    quadtree of each half on the second stream beside the other half's FAST / the blur.  Every frame of both halves and the frames at the seam."""
+    env(ORBHIP_SCHED=4, ORBHIP_HOST_CHUNK=64)
+    w, h, n = 320, 240, 300
+    imgs = np.stack([synth.frame(w, h, seed=700 + s) for s in range(B)])
+    ex = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, max_batch=B, library=backend)
+    kps, descs = ex.extract_batch(imgs)
+    nA = max(8, ((B // 2) + 7) & ~7)
+    for f in sorted({0, 7, nA - 1, nA, nA + 1, B - 1}):
+        ora = oracle.OracleExtractor(n, 1.2, 8, 20, 7)
+        ko, do = ora.extract(imgs[f])
+        _same(kps[f], descs[f], ko, do)
+    ex.close()
+
+
 @pytest.mark.parametrize("n", [37, 101, 250])
 def test_slot_counts_not_multiples_of_four(backend, oracle, n):
     """k_describe takes four consecutive key point slots per wavefront: levels whose capacity / fill leaves ragged groups."""

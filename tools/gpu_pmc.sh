@@ -1,6 +1,7 @@
 #!/bin/bash
 # PMC passes (each in its own rocprofv3 run, kernel-trace only) over a short bench; CSVs land in gpurun_out/$TAG/
-TAG=${1:-pmc}
+# usage: tools/gpu_pmc.sh <tag> [number of passes, default all six]
+TAG=${1:-pmc}; NPASS=${2:-6}
 OUT=$(pwd)/gpurun_out/$TAG
 mkdir -p $OUT
 REPO=$(pwd)
@@ -12,6 +13,7 @@ i=0
 while read -r line; do
   [ -z "$line" ] && continue
   i=$((i+1))
+  [ $i -gt $NPASS ] && break
   timeout 300 rocprofv3 --pmc $line --kernel-trace --output-format csv -d /tmp/pmc_$TAG/p$i -o p$i -- $CMD > $OUT/p$i.stdout 2> $OUT/p$i.stderr
   f=$(find /tmp/pmc_$TAG/p$i -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && cp $f $OUT/p${i}_counters.csv
