@@ -474,9 +474,9 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
         int umax[16]; const int vmax = (int)floor(15 * sqrt(2.0) / 2 + 1), vmin = (int)ceil(15 * sqrt(2.0) / 2);
         for (int v = 0; v <= vmax; v++) umax[v] = cvRoundF((float)sqrt(225.0 - (double)v * v));
         for (int v = 15, v0 = 0; v >= vmin; --v) { while (umax[v0] == umax[v0 + 1]) ++v0; umax[v] = v0; ++v0; }
-        std::vector<unsigned> mask(5 * 64, 0u);                       // k_describe: pass q, lane l = (row 7q + l / 9, dword l % 9 of the row from column -15 on); lane 63 idles
-        for (int q = 0; q < 5; q++) for (int l = 0; l < 63; l++) for (int b = 0; b < 4; b++) {
-            const int r = 7 * q + l / 9, d = l % 9, v = r - 15, uu = 4 * d + b - 15;
+        std::vector<unsigned> mask(8 * 64, 0u);                       // k_describe: pass q, lane l = (row 4q + l / 16, dword l % 16 of the row from column -15 on)
+        for (int q = 0; q < 8; q++) for (int l = 0; l < 64; l++) for (int b = 0; b < 4; b++) {
+            const int r = 4 * q + (l >> 4), d = l & 15, v = r - 15, uu = 4 * d + b - 15;
             if (r <= 30 && d <= 7 && abs(uu) <= 15 && abs(uu) <= umax[abs(v)]) mask[q * 64 + l] |= 0xffu << (8 * b);
         }
         TRY(upload(&c->d_ic_mask, mask));

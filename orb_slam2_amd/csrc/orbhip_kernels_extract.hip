@@ -1345,9 +1345,11 @@ __device__ __forceinline__ int round_half_even_small(float x) { return __float_a
 #define DS_WAVES 4
 #define DS_KPW 4                       // key point slots per wavefront
 #define DS_WROWS 37                    // blurred window rows: pattern reach is +-18 after rotation
-#define DS_WSTRIDE 40                  // bytes per staged window row (37 used, starting 0..3 bytes into the row: the row is staged from the dword boundary below cx - 18)
-#define DS_PPASS 5                     // orientation patch: 32-bit load passes of 7 rows x 9 lanes
-#define DS_WPASSES 6                   // LDS-DMA passes per window: 6 x 64 dwords >= 37 rows x 10 dwords
+#define DS_WSTRIDE 48                  // bytes per staged window row: 37 used, starting 0..3 bytes into the row (staged from the dword boundary below cx - 18).  12 dwords, not the
+                                       // 10 that would do: the texture addresser takes an LDS-DMA pass in groups of four lanes, and a group that straddles two image rows is what
+                                       // costs - 9.1 cycles for a pass of 5.33 rows x 48 B against 20.1 for 6.4 rows x 40 B (tools/ta_ubench.hip, profiles/r03_ta_cost_*.txt)
+#define DS_PPASS 8                     // orientation patch: 32-bit load passes of 4 rows x 16 lanes
+#define DS_WPASSES 7                   // LDS-DMA passes per window: 7 x 64 dwords >= 37 rows x 12 dwords (16 slots x 1792 B = 28 KB per workgroup)
 #define DS_WDWORDS (DS_WPASSES * 64)
 // One wavefront per DS_KPW consecutive key point slots, in three phases, so that what is per-key-point scalar work in the reference is
 // done once per lane instead of once per wave:
@@ -1361,13 +1363,20 @@ __device__ __forceinline__ int round_half_even_small(float x) { return __float_a
 __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
 {
     __shared__ unsigned s_win[DS_WAVES][DS_KPW][DS_WDWORDS];
-    __shared__ float s_pat[16 * 64];                                       // rBRIEF pattern, [component][round][lane]
-    // the pattern (4 KB) is fetched once per workgroup with four coalesced 32-bit loads per thread: as 16-byte loads per lane it cost every
-    // wave 4 x 71 cycles of the texture addresser, more than the wave's orientation patches (tools/ta_ubench.hip)
+    // the rBRIEF pattern (4 KB, [component][round][lane]) is fetched once per workgroup with four coalesced 32-bit loads per thread - as 16-byte
+    // loads per lane it cost every wave 4 x 71 cycles of the texture addresser, more than the wave's orientation patches (tools/ta_ubench.hip) -
+    // and passes through the first window buffers on its way to the lanes' registers (two barriers, before any wave leaves or stages a window):
+    // the workgroup's LDS stays at 28 KB, five workgroups per CU with room to spare
+    float* s_pat = reinterpret_cast<float*>(&s_win[0][0][0]);
+    static_assert(DS_KPW * DS_WDWORDS >= 16 * 64, "the pattern passes through wave 0's window buffers");
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
 #pragma unroll
     for (int k = 0; k < 4; k++) s_pat[256 * k + threadIdx.x] = P.patternf[256 * k + threadIdx.x];
     __syncthreads();
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    float4 pt[4];                                                          // rBRIEF pattern of this lane's 4 tests as floats (x0, y0, x1, y1)
+#pragma unroll
+    for (int r = 0; r < 4; r++) { pt[r].x = s_pat[(0 * 4 + r) * 64 + lane]; pt[r].y = s_pat[(1 * 4 + r) * 64 + lane]; pt[r].z = s_pat[(2 * 4 + r) * 64 + lane]; pt[r].w = s_pat[(3 * 4 + r) * 64 + lane]; }
+    __syncthreads();
     int tile, frame;
     if (!xcd_frame_map((P.lvl_kp_per_frame + DS_WAVES * DS_KPW - 1) / (DS_WAVES * DS_KPW), P.nframes, tile, frame)) return;
     frame += P.frame0;
@@ -1385,22 +1394,20 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
 #define RLF(v, l) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (l)))
 
     // ---- per-lane constants of the wave
-    float4 pt[4];                                                          // rBRIEF pattern of this lane's 4 tests as floats (x0, y0, x1, y1), from the workgroup's LDS copy
-#pragma unroll
-    for (int r = 0; r < 4; r++) { pt[r].x = s_pat[(0 * 4 + r) * 64 + lane]; pt[r].y = s_pat[(1 * 4 + r) * 64 + lane]; pt[r].z = s_pat[(2 * 4 + r) * 64 + lane]; pt[r].w = s_pat[(3 * 4 + r) * 64 + lane]; }
-    // orientation patch: lane = (row mod 7, dword of the row), 9 lanes per row (63 of the 64 busy; 16 lanes per row left 28 of them idle and
-    // took 8 passes instead of 5): the aligned dwords around the row's 31 bytes, which are then funnel-shifted into place with the next lane's
-    // dword (an unaligned 32-bit load of this shape costs the texture addresser 3.5 x an aligned one)
-    const int prow = min((lane * 7282) >> 16, 6), pd = min(lane - 9 * prow, 8);         // lane / 9 for lane < 64; lane 63 doubles lane 62 (its mask is 0)
+    // orientation patch: lane = (row mod 4, dword of the row); 9 of a row's 16 lanes load the aligned dwords around its 31 bytes, which are
+    // then funnel-shifted into place (an unaligned 32-bit load of this shape costs the texture addresser 3.5 x an aligned one).
+    // (Round 3 packed the rows 9 lanes apiece - 7 rows per pass, 5 passes instead of 8, the next dword by wave_shl:1: 80 VALU fewer per wave and
+    //  bit-exact, but 0.674 -> 0.734 ms: groups of four lanes that straddle two rows cost the texture addresser more than the three passes saved.)
+    const int prow = lane >> 4, pd = lane & 15;
     unsigned pmask[DS_PPASS];
 #pragma unroll
-    for (int q = 0; q < DS_PPASS; q++) pmask[q] = P.ic_mask[q * 64 + lane];        // bytes inside the circle (rows past the 31st, dword 8 of a row, lane 63: 0)
+    for (int q = 0; q < DS_PPASS; q++) pmask[q] = P.ic_mask[q * 64 + lane];        // bytes inside the circle (row 31, dwords 8..15: 0)
     const unsigned ucoef = 0x03020100u + 0x04040404u * (unsigned)pd;       // u + 15 of the dword's four bytes
-    int wrow[DS_WPASSES], wcol[DS_WPASSES];                                // window DMA: pass k, lane l fills dword 64k + l = (row, dword) of the 10-dword rows
+    int wrow[DS_WPASSES], wcol[DS_WPASSES];                                // window DMA: pass k, lane l fills dword 64k + l = (row, dword) of the 12-dword rows
 #pragma unroll
     for (int k = 0; k < DS_WPASSES; k++) {
-        const int pos = 64 * k + lane, row = (pos * 6554) >> 16;          // pos / 10 for pos < 16384
-        wrow[k] = min(row, DS_WROWS - 1); wcol[k] = 4 * (pos - 10 * row); // rows past the window re-read its last row (in bounds, never used)
+        const int pos = 64 * k + lane, row = (pos * 5462) >> 16;          // pos / 12 for pos < 448
+        wrow[k] = min(row, DS_WROWS - 1); wcol[k] = 4 * (pos - 12 * row); // the four dwords past the window re-read the start of its last row (in bounds, never used)
     }
 
     // ---- 0. slot -> (level, index in the level, output index), lane j for slot j; then wave-uniform copies (SGPRs) of the wave's slots.
@@ -1447,27 +1454,27 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
             const ORBHIP_GLOBAL uint8_t* img = uniform_ptr(lv[j] == 0 ? P.img0 + (long long)frame * P.img0_frame_stride
                                                                       : P.pyr + (long long)frame * P.plane_frame_bytes + RL(g_poff, lv[j]));
             const int cx = vv[j] & 0xfff, cy = (vv[j] >> 12) & 0xfff;
-            const unsigned off = (unsigned)((cy - 15) * spitch + ((cx - 15) & ~3) + 4 * pd);
+            const unsigned off = (unsigned)((cy - 15 + prow) * spitch + ((cx - 15) & ~3) + 4 * min(pd, 8));
 #pragma unroll
-            for (int q = 0; q < DS_PPASS; q++)                             // rows prow + 7q - 15 = -15 .. 19; those past 15 re-read row 15 and are masked
-                pw[j][q] = *reinterpret_cast<const ORBHIP_GLOBAL unsigned*>(img + (off + __umul24((unsigned)min(prow + 7 * q, 30), (unsigned)spitch)));
+            for (int q = 0; q < DS_PPASS; q++)                             // rows prow + 4q - 15 = -15 .. 16; row 16 is loaded (in bounds) and masked
+                pw[j][q] = *reinterpret_cast<const ORBHIP_GLOBAL unsigned*>(img + (off + (unsigned)(4 * q * spitch)));
         }
 #pragma unroll
         for (int j = 0; j < DS_KPW; j++) if (ok[j]) window_dma(lv[j], vv[j], s_win[wave][j]);
 #pragma unroll
         for (int j = 0; j < DS_KPW; j++) if (ok[j]) {
-            unsigned s = 0, su = 0, cs = 0;                                   // cs = sum over passes of the running row sum = sum_q (5 - q) t_q
+            unsigned s = 0, su = 0, cs = 0;                                   // cs = sum over passes of the running row sum = sum_q (8 - q) t_q
             const unsigned sh = (unsigned)((vv[j] & 0xfff) - 15) & 3u;        // (cx - 15) & 3: byte 0 of the shifted dword is column cx - 15 + 4 pd
 #pragma unroll
             for (int q = 0; q < DS_PPASS; q++) {
-                const unsigned nxt = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pw[j][q], 0x130, 0xf, 0xf, false);     // wave_shl:1 = the next lane's dword = the next dword of the row (a row's last lane is masked)
+                const unsigned nxt = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pw[j][q], 0x101, 0xf, 0xf, false);     // row_shl:1 = the next dword of the row
                 const unsigned x = __builtin_amdgcn_alignbyte(nxt, pw[j][q], sh) & pmask[q];
                 s = __builtin_amdgcn_sad_u8(x, 0u, s);                           // running sum of the masked bytes (v_sad_u8 accumulates: no separate addition)
                 su = __builtin_amdgcn_udot4(x, ucoef, su, false);
                 cs += s;
             }
-            // sum_q (prow + 7q - 15) t_q = (prow - 15) S + 7 (5 S - cs): two additions per pass instead of a 32-bit multiply-add
-            const int sv = (prow + 20) * (int)s - 7 * (int)cs;
+            // sum_q (prow + 4q - 15) t_q = (prow - 15) S + 4 (8 S - cs): two additions per pass instead of a 32-bit multiply-add
+            const int sv = (prow + 17) * (int)s - 4 * (int)cs;
             const int m10 = wave_sum_dpp((int)su - 15 * (int)s), m01 = wave_sum_dpp(sv);     // sum u*I, sum v*I (wave-uniform)
             if (lane == j) { M10 = m10; M01 = m01; }
         }

@@ -27,8 +27,15 @@ template <int SHAPE> __global__ __launch_bounds__(256) void k(const uint8_t* buf
         if (SHAPE == 6) { const int p = lane; __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b + (p / 10) * PITCH + 4 * (p % 10)), (__attribute__((address_space(3))) void*)(lds[wave] + 64 * (n & 7)), 4, 0, 0); }   // LDS-DMA 6.4 rows x 40 B
         if (SHAPE == 7) { v2u v = *(const v2u*)(b + (lane >> 2) * PITCH + 8 * (lane & 3)); acc += v[0] + v[1]; }      // 16 rows x 32 B, 8 B per lane
         if (SHAPE == 8) { const int p = lane; __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b + 4 * p), (__attribute__((address_space(3))) void*)(lds[wave] + 64 * (n & 7)), 4, 0, 0); }   // LDS-DMA 1 row x 256 B
+        if (SHAPE == 9) acc += *(const u32u*)(b + (lane >> 4) * PITCH + 4 * min(lane & 15, 8));               // 4 rows x 36 B, lanes 9..15 of a row repeat its dword 8 (k_describe's patch load)
+        if (SHAPE == 10) { const int r = min(lane / 9, 6); acc += *(const u32u*)(b + r * PITCH + 4 * min(lane - 9 * r, 8)); }   // 7 rows x 36 B, 9 lanes per row
+        if (SHAPE == 15) acc += *(const u32u*)(b + (lane >> 4) * PITCH + 4 * (lane & 15));                    // 4 rows x 64 B
+        if (SHAPE == 11 || SHAPE == 12 || SHAPE == 13) {
+            const int dpr = SHAPE == 11 ? 12 : SHAPE == 12 ? 16 : 8, p = lane;                                  // LDS-DMA, rows of 48 / 64 / 32 bytes
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b + (p / dpr) * PITCH + 4 * (p % dpr)), (__attribute__((address_space(3))) void*)(lds[wave] + 64 * (n & 7)), 4, 0, 0);
+        }
     }
-    if (SHAPE == 6 || SHAPE == 8) { __builtin_amdgcn_s_waitcnt(0x0f70); acc += lds[wave][lane]; }
+    if (SHAPE == 6 || SHAPE == 8 || SHAPE == 11 || SHAPE == 12 || SHAPE == 13) { __builtin_amdgcn_s_waitcnt(0x0f70); acc += lds[wave][lane]; }
     out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
 template <int SHAPE> static void run(const char* name, const uint8_t* buf, unsigned* out)
@@ -57,5 +64,11 @@ int main()
     run<5>("ubyte, 2 rows x 32 B", buf, out);
     run<8>("LDS-DMA dword, 1 row x 256 B", buf, out);
     run<6>("LDS-DMA dword, 6.4 rows x 40 B", buf, out);
+    run<11>("LDS-DMA dword, 5.33 rows x 48 B", buf, out);
+    run<12>("LDS-DMA dword, 4 rows x 64 B", buf, out);
+    run<13>("LDS-DMA dword, 8 rows x 32 B", buf, out);
+    run<9>("dword, 4 rows x 36 B (7 lanes repeat)", buf, out);
+    run<15>("dword, 4 rows x 64 B", buf, out);
+    run<10>("dword, 7 rows x 36 B (9 lanes per row)", buf, out);
     return 0;
 }
