@@ -134,27 +134,32 @@ def host_io(ex_resident, frames, device, blur_round_mode, budget_s=3.0):
     cap = ex.capacity
     src_pageable = np.ascontiguousarray(frames[0, :Bh, :, :W]) if frames.shape[1] >= Bh else np.ascontiguousarray(np.resize(frames[0, :, :, :W], (Bh, H, W)))
     out = {"batch": Bh, "bytes_per_frame_h2d": W * H, "bytes_per_frame_d2h": cap * 60 + 4}
-    for kind in ("pinned", "pageable"):
-        if kind == "pinned":
-            src = orb_slam2_amd.pinned_array((Bh, H, W), np.uint8); src[:] = src_pageable
-            bufs = [(orb_slam2_amd.pinned_array((Bh, cap), orb_slam2_amd.KEYPOINT_DTYPE), orb_slam2_amd.pinned_array((Bh, cap, 32), np.uint8), np.zeros(Bh, np.int32)) for _ in range(3)]
-        else:
-            src = src_pageable
-            bufs = [(np.zeros((Bh, cap), orb_slam2_amd.KEYPOINT_DTYPE), np.zeros((Bh, cap, 32), np.uint8), np.zeros(Bh, np.int32)) for _ in range(3)]
-        imgs = src                                                     # one [B, H, W] array: the binding builds the pointer table arithmetically
-        t = ex.submit(imgs, out=bufs[0]); ex.collect(t)                # warm-up: allocates the ring
-        sub, done, t0 = 0, 0, time.perf_counter()
-        pending = []
-        for _ in range(2):                                             # the ring holds three batches: two are queued ahead of the one being collected,
-            pending.append(ex.submit(imgs, out=bufs[sub % 3])); sub += 1   # so the upload engine never waits for the host to come back from a collect
-        while time.perf_counter() - t0 < budget_s / 2:
-            pending.append(ex.submit(imgs, out=bufs[sub % 3])); sub += 1    # result buffers named at submit: pinned ones are filled by DMA, no host copy
-            nout = ex.collect(pending.pop(0))
-            done += 1
-        while pending:
-            nout = ex.collect(pending.pop(0)); done += 1
-        dt = time.perf_counter() - t0
-        out[kind] = {"frames_per_s": round(done * Bh / dt, 1), "pcie_GBps": round(done * Bh * (W * H + cap * 60 + 4) / dt / 1e9, 2), "keypoints_per_frame": int(nout.mean())}
+    pin_src = orb_slam2_amd.pinned_array((Bh, H, W), np.uint8); pin_src[:] = src_pageable
+    sets = {"pinned": (pin_src, [(orb_slam2_amd.pinned_array((Bh, cap), orb_slam2_amd.KEYPOINT_DTYPE), orb_slam2_amd.pinned_array((Bh, cap, 32), np.uint8), np.zeros(Bh, np.int32)) for _ in range(3)]),
+            "pageable": (src_pageable, [(np.zeros((Bh, cap), orb_slam2_amd.KEYPOINT_DTYPE), np.zeros((Bh, cap, 32), np.uint8), np.zeros(Bh, np.int32)) for _ in range(3)])}
+    t = ex.submit(pin_src, out=sets["pinned"][1][0]); ex.collect(t)        # warm-up: allocates the ring
+    # the two kinds alternate, two rounds each, and the better round of a kind is reported: the link is shared with whatever else the host does, and
+    # one round of 0.75 s apiece had the kinds trade places from run to run (98 k / 115 k frames/s, then 107 k / 105 k, on the same build)
+    for rnd in range(2):
+        for kind in ("pinned", "pageable"):
+            imgs, bufs = sets[kind]                                        # one [B, H, W] array: the binding builds the pointer table arithmetically
+            t = ex.submit(imgs, out=bufs[0]); ex.collect(t)
+            sub, done, t0 = 0, 0, time.perf_counter()
+            pending = []
+            for _ in range(2):                                             # the ring holds three batches: two are queued ahead of the one being collected,
+                pending.append(ex.submit(imgs, out=bufs[sub % 3])); sub += 1   # so the upload engine never waits for the host to come back from a collect
+            while time.perf_counter() - t0 < budget_s / 4:
+                pending.append(ex.submit(imgs, out=bufs[sub % 3])); sub += 1    # result buffers named at submit: pinned ones are filled by DMA, no host copy
+                nout = ex.collect(pending.pop(0))
+                done += 1
+            while pending:
+                nout = ex.collect(pending.pop(0)); done += 1
+            dt = time.perf_counter() - t0
+            rate = round(done * Bh / dt, 1)
+            rounds = (out[kind]["rounds"] if kind in out else []) + [rate]
+            if kind not in out or rate > out[kind]["frames_per_s"]:
+                out[kind] = {"frames_per_s": rate, "pcie_GBps": round(done * Bh * (W * H + cap * 60 + 4) / dt / 1e9, 2), "keypoints_per_frame": int(nout.mean())}
+            out[kind]["rounds"] = rounds
     one = orb_slam2_amd.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, W, H, max_batch=1, device=device, blur_round_mode=blur_round_mode)
     one(src_pageable[0])
     t1 = time.perf_counter()

@@ -88,7 +88,7 @@ struct orbhip_ctx {
     hipEvent_t ev_start = nullptr, ev_fast0 = nullptr;
     // ORBHIP_SCHED=3 (measurement only): the pyramid of call t+1 on its own stream beside the kernels of call t, into the other of two plane sets
     uint8_t* d_pyr_sets[2] = {nullptr, nullptr}; int pyr_set = 0; hipStream_t pstream = nullptr; hipEvent_t ev_desc[2] = {nullptr, nullptr}, ev_pyr_ahead = nullptr; bool desc_pending[2] = {false, false};
-    bool pyr_tail = false;    // ORBHIP_PYR_TAIL=1 (measurement only): the last pyramid levels in one launch, see launch_pyramid
+    bool pyr_tail = false, pyr_tail_any = false;    // ORBHIP_PYR_TAIL=1 (measurement only): the last pyramid levels in one launch, see launch_pyramid; 2: at any batch size
     uint8_t* d_in = nullptr; uint8_t* h_in = nullptr; uint8_t* d_col = nullptr; uint8_t* h_col = nullptr; size_t col_bytes = 0; orbhip_keypoint* h_kp = nullptr; uint8_t* h_desc = nullptr; int* h_n = nullptr; int in_pitch = 0;
     // stereo (Frame::ComputeStereoMatches): level-0 source of the last call + lazily allocated workspace on the LEFT context
     const uint8_t* last_img0 = nullptr; long long last_img0_fstride = 0; int last_img0_pitch = 0;
@@ -439,7 +439,7 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
     }
     if (!c->xstreams.empty() && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { orbhip_destroy(c); return fail(ORBHIP_ERR_HIP, "event creation failed"); }
     { const char* e = getenv("ORBHIP_SERIAL"); c->serial = e && e[0] == '1'; }
-    { const char* e = getenv("ORBHIP_PYR_TAIL"); c->pyr_tail = e && e[0] == '1'; }
+    { const char* e = getenv("ORBHIP_PYR_TAIL"); c->pyr_tail = e && (e[0] == '1' || e[0] == '2'); c->pyr_tail_any = e && e[0] == '2'; }
     { const char* e = getenv("ORBHIP_SCHED"); c->sched = e ? atoi(e) : 0; }
     for (const TileDesc& t : c->blur_tiles) if (t.level == 0) c->blur_tiles_l0++;
     if (hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_fast0, hipEventDisableTiming) != hipSuccess) { orbhip_destroy(c); return fail(ORBHIP_ERR_HIP, "event creation failed"); }
@@ -579,7 +579,7 @@ static ExtractParams make_params(orbhip_ctx* c, const uint8_t* d_img0, long long
 static void launch_pyramid(orbhip_ctx* c, const ExtractParams& P, int nf, hipStream_t s)
 {
     int tail0 = c->L;
-    if (nf >= 64 && c->pyr_tail) { while (tail0 - 1 >= 1 && c->L - (tail0 - 1) <= 4 && c->pyr_staged[tail0 - 1] == 2 && c->geom[tail0 - 1].w * c->geom[tail0 - 1].h <= 160 * 1024) tail0--; }
+    if ((nf >= 64 || c->pyr_tail_any) && c->pyr_tail) { while (tail0 - 1 >= 1 && c->L - (tail0 - 1) <= 4 && c->pyr_staged[tail0 - 1] == 2 && c->geom[tail0 - 1].w * c->geom[tail0 - 1].h <= 160 * 1024) tail0--; }
     if (c->L - tail0 < 2) tail0 = c->L;
     for (int l = 1; l < tail0; l++) orbhip_launch_pyramid_level(P, l, c->geom[l].w, c->geom[l].h, (int)c->pyr_staged[l], nf, s);
     if (tail0 < c->L) orbhip_launch_pyramid_tail(P, tail0, nf, s);

@@ -1008,14 +1008,23 @@ __device__ __forceinline__ int qt_digit(unsigned code, int depth)
 
 // scan scratch: one int per 64-element chunk of the longest scanned array + the total (sized on the host, see orbhip_quadtree_scr)
 __device__ __forceinline__ int qt_wave_incl_scan(int v, int lane)
-{
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(v, off); if (lane >= off) v += u; }
-    return v;
+{   // inclusive wave64 prefix sum from DPP row shifts / broadcasts: seven 4-cycle additions (six ds_bpermute shuffles + selects took 24 cycles apiece)
+    (void)lane;
+    int t = v + __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);       // row_shr:1 of the input
+    t += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);              // row_shr:2 of the input
+    t += __builtin_amdgcn_update_dpp(0, v, 0x113, 0xf, 0xf, true);              // row_shr:3 of the input -> sums of (up to) four
+    t += __builtin_amdgcn_update_dpp(0, t, 0x114, 0xf, 0xe, true);              // row_shr:4, banks 1-3
+    t += __builtin_amdgcn_update_dpp(0, t, 0x118, 0xf, 0xc, true);              // row_shr:8, banks 2-3 -> inclusive sums inside each row of 16
+    t += __builtin_amdgcn_update_dpp(0, t, 0x142, 0xa, 0xf, true);              // row_bcast:15 into rows 1 and 3
+    t += __builtin_amdgcn_update_dpp(0, t, 0x143, 0xc, 0xf, true);              // row_bcast:31 into rows 2 and 3
+    return t;
 }
+template <bool TRAILING_BARRIER = true>
 __device__ __forceinline__ int qt_block_exscan(int* a, int n, int* scratch, int tid)
 {   // in-place exclusive scan of a[0..n), n <= 64*(scr-1); the total lands in scratch[-1] (the slot in front); all QT_T threads must call.
-    // 64-element chunks are scanned with wave shuffles, chunk totals by wave 0: three barriers in all.
+    // 64-element chunks are scanned inside the waves, chunk totals by wave 0: three barriers in all - two when the caller guarantees a barrier
+    // of its own before anything writes `scratch` again.  Thread t reads and writes only elements t, t + QT_T, ...: a caller whose thread t
+    // produced exactly those needs no barrier in front of the call, nor behind it before thread t reads them back.
     const int lane = tid & 63, wave = tid >> 6, nch = (n + 63) >> 6;
     for (int c = wave; c < nch; c += QT_T / 64) {
         const int i = c * 64 + lane, v = i < n ? a[i] : 0;
@@ -1037,7 +1046,7 @@ __device__ __forceinline__ int qt_block_exscan(int* a, int n, int* scratch, int 
     __syncthreads();
     for (int i = tid; i < n; i += QT_T) a[i] += scratch[i >> 6];
     const int total = scratch[-1];
-    __syncthreads();
+    if (TRAILING_BARRIER) __syncthreads();
     return total;
 }
 
@@ -1065,12 +1074,25 @@ struct QtKeysReg {
 #pragma unroll
         for (int j = 0; j < QT_KPT; j++) { const int k = tid + j * QT_T; if (k < n) f(k, code[j], node[j]); }
     }
+    // f(k, src[k], code, node) with every src[k] of the thread requested before the first one is used (one memory latency, not one per key)
+    template <class F> __device__ __forceinline__ void each_loaded(int n, int tid, const unsigned* src, F f)
+    {
+        unsigned v[QT_KPT];
+#pragma unroll
+        for (int j = 0; j < QT_KPT; j++) { const int k = tid + j * QT_T; v[j] = k < n ? src[k] : 0u; }
+#pragma unroll
+        for (int j = 0; j < QT_KPT; j++) { const int k = tid + j * QT_T; if (k < n) f(k, v[j], code[j], node[j]); }
+    }
 };
 struct QtKeysHbm {
     unsigned* code; int* node;
     template <class F> __device__ __forceinline__ void each(int n, int tid, F f)
     {
         for (int k = tid; k < n; k += QT_T) f(k, code[k], node[k]);
+    }
+    template <class F> __device__ __forceinline__ void each_loaded(int n, int tid, const unsigned* src, F f)
+    {
+        for (int k = tid; k < n; k += QT_T) f(k, src[k], code[k], node[k]);
     }
 };
 
@@ -1086,12 +1108,27 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
     const int N = g.nfeat;
     const int wave = tid >> 6, lane = tid & 63;
     // ---- A. dense canonical candidate order: cells row-major, row-major inside a cell (ORBextractor.cc:789-829).
-    //      One thread per candidate: its cell is found by bisection on the per-cell prefix sums.
+    //      One thread per CELL copies the cell's records to their dense positions (eight loads in flight at a time), then one thread per
+    //      candidate reads its record back (all of a thread's records requested at once).  The first form - a thread per candidate that
+    //      bisected the per-cell prefix sums for its cell and then fetched its record - paid nine dependent LDS reads and a memory latency
+    //      per key, sixteen keys one after the other: a third of a level-0 workgroup's 67 us in a single-frame call.
     const unsigned* cand = P.cell_cand + (long long)frame * P.cand_slots_per_frame;
-    keys.each(n, tid, [&](int idx, unsigned& kcode, int& knode) {
-        int lo = 0, hi = g.ncells - 1;
-        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (L.pref[mid] <= idx) lo = mid; else hi = mid - 1; }
-        const unsigned v = cand[L.slot[lo] + (idx - L.pref[lo])];
+    {
+        const int* ccount = P.cell_count + (long long)frame * P.ncells_total + g.cell_first;
+        for (int c = tid; c < g.ncells; c += QT_T) {
+            const int base = L.pref[c], cntc = min(ccount[c], n - base), so = L.slot[c];      // (n caps the total: never more than the level's slots)
+            for (int i0 = 0; i0 < cntc; i0 += 8) {
+                unsigned v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = i0 + u < cntc ? cand[so + i0 + u] : 0u;
+#pragma unroll
+                for (int u = 0; u < 8; u++) if (i0 + u < cntc) qval[base + i0 + u] = v[u];
+            }
+        }
+    }
+    __syncthreads();
+    keys.each_loaded(n, tid, qval, [&](int idx, unsigned v, unsigned& kcode, int& knode) {
+        (void)idx;
         const int x = v & 0xfff, y = (v >> 12) & 0xfff;
         int root = __float2int_rz(__fdiv_rn((float)x, g.hX));                    // vpIniNodes[kp.pt.x/hX]  (:569)
         root = min(max(root, 0), g.nIni - 1);
@@ -1106,7 +1143,7 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
             if (right) ULx = mx; else URx = mx;
             if (bottom) ULy = my; else BRy = my;
         }
-        qval[idx] = v; kcode = code; knode = root; atomicAdd(&L.cntA[root], 1);
+        kcode = code; knode = root; atomicAdd(&L.cntA[root], 1);
     });
     __syncthreads();
     // ---- B. initial list: non-empty roots in order (:552-585)
@@ -1124,11 +1161,14 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
     __syncthreads();
 
     // ---- C. passes
+    // A dividing pass costs five workgroup barriers (it was twelve: the scratch of the NEXT pass is cleared while this one's keys move, the two
+    // prefix sums of a pass are one, the expandable-node counter alternates between two words so that nobody waits for its reset).
     bool modeB = false;
+    int par = 0;                                                            // which of s_misc[3] / s_misc[4] counts this pass's expandable nodes
+    for (int i = tid; i < 4 * m; i += QT_T) s_cc[i] = 0;
+    if (tid == 0) { s_misc[1] = 0; s_misc[2] = 0x7fffffff; s_misc[3] = 0; s_misc[4] = 0; }
+    __syncthreads();
     for (int guard = 0; guard < 4096; guard++) {
-        for (int i = tid; i < 4 * m; i += QT_T) s_cc[i] = 0;
-        if (tid == 0) { s_misc[1] = 0; s_misc[2] = 0x7fffffff; s_misc[3] = 0; }
-        __syncthreads();
         keys.each(n, tid, [&](int, unsigned& kcode, int& knode) {
             const int p = knode;
             if (cnt[p] > 1) atomicAdd(&s_cc[4 * p + qt_digit(kcode, dep[p])], 1);
@@ -1137,34 +1177,37 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
         int Ctot, nsplit;
         if (!modeB) {
             // every node with more than one key is divided, walking the list front to back (:606-665)
+            // one prefix sum for both: children created before node p in the low 17 bits (<= 4 x 16383), undivided nodes before it above them
             for (int p = tid; p < m; p += QT_T) {
                 const bool e = cnt[p] > 1;
-                s_a[p] = e ? ((s_cc[4 * p] > 0) + (s_cc[4 * p + 1] > 0) + (s_cc[4 * p + 2] > 0) + (s_cc[4 * p + 3] > 0)) : 0;
-                s_b[p] = e ? 0 : 1; s_split[p] = e ? 1 : 0;
+                s_a[p] = e ? ((s_cc[4 * p] > 0) + (s_cc[4 * p + 1] > 0) + (s_cc[4 * p + 2] > 0) + (s_cc[4 * p + 3] > 0)) : (1 << 17);
+                s_split[p] = e ? 1 : 0;
             }
-            __syncthreads();
-            Ctot = qt_block_exscan(s_a, m, s_scratch, tid);
-            const int Stot = qt_block_exscan(s_b, m, s_scratch, tid);
-            nsplit = m - Stot;
+            const int tot = qt_block_exscan<false>(s_a, m, s_scratch, tid);      // thread t scans what thread t wrote and reads it back below
+            Ctot = tot & 0x1ffff;
+            nsplit = m - (tot >> 17);
             for (int p = tid; p < m; p += QT_T) {
                 if (s_split[p]) {
-                    int q = s_a[p];
+                    int q = s_a[p] & 0x1ffff;
                     for (int d = 0; d < 4; d++) { const int c = s_cc[4 * p + d]; if (c > 0) { const int pos = Ctot - 1 - q; q++; cnt2[pos] = c; dep2[pos] = (unsigned char)(dep[p] + 1); s_map[4 * p + d] = (unsigned short)pos; } }
-                } else { const int pos = Ctot + s_b[p]; cnt2[pos] = cnt[p]; dep2[pos] = dep[p]; s_map[4 * p] = (unsigned short)pos; }
+                } else { const int pos = Ctot + (s_a[p] >> 17); cnt2[pos] = cnt[p]; dep2[pos] = dep[p]; s_map[4 * p] = (unsigned short)pos; }
             }
         } else {
             // final phase: expandable nodes sorted by (size, creation) ascending, processed from the back (:684-732)
-            for (int p = tid; p < m; p += QT_T) {
-                s_split[p] = 0;
-                const int c = cnt[p];
-                if (c > 1) {
-                    int rank = 0;
-                    for (int o = 0; o < m; o++) { const int co = cnt[o]; rank += (co > 1) && (co > c || (co == c && o < p)); }
-                    s_sidx[rank] = p; atomicAdd(&s_misc[1], 1);
-                }
+            // The expandable nodes are first compacted in list order (one prefix sum), then ranked among themselves: late in the replay most
+            // nodes hold a single key, and ranking every node against the whole list (m^2 / 256 steps per thread) was the longest stretch of a
+            // level-0 workgroup between two barriers.
+            for (int p = tid; p < m; p += QT_T) { s_split[p] = 0; s_best[p] = cnt[p] > 1 ? 1 : 0; }
+            const int E = qt_block_exscan(s_best, m, s_scratch, tid);     // thread t scans the flags thread t wrote
+            for (int p = tid; p < m; p += QT_T) { const int c = cnt[p]; if (c > 1) { const int j = s_best[p]; s_b[j] = c; s_a[j] = p; } }
+            __syncthreads();
+            for (int j = tid; j < E; j += QT_T) {
+                const int c = s_b[j];
+                int rank = 0;
+                for (int o = 0; o < E; o++) { const int co = s_b[o]; rank += (co > c || (co == c && o < j)); }
+                s_sidx[rank] = s_a[j];
             }
             __syncthreads();
-            const int E = s_misc[1];
             for (int j = tid; j < E; j += QT_T) {
                 const int p = s_sidx[j];
                 s_a[j] = (s_cc[4 * p] > 0) + (s_cc[4 * p + 1] > 0) + (s_cc[4 * p + 2] > 0) + (s_cc[4 * p + 3] > 0);
@@ -1201,12 +1244,15 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
         });
         int nexp = 0;
         for (int p = tid; p < m2; p += QT_T) nexp += cnt2[p] > 1;
-        if (nexp) atomicAdd(&s_misc[3], nexp);
+        if (nexp) atomicAdd(&s_misc[3 + par], nexp);
+        // the next pass's scratch: nobody reads s_cc, s_misc[1..2] or the other counter word any more (their readers are behind the barrier above)
+        for (int i = tid; i < 4 * m2; i += QT_T) s_cc[i] = 0;
+        if (tid == 0) { s_misc[1] = 0; s_misc[2] = 0x7fffffff; s_misc[3 + (par ^ 1)] = 0; }
         __syncthreads();
-        const int nToExpand = s_misc[3];
+        const int nToExpand = s_misc[3 + par];
+        par ^= 1;
         int* t = cnt; cnt = cnt2; cnt2 = t; unsigned char* td = dep; dep = dep2; dep2 = td;
         const int prev = m; m = m2;
-        __syncthreads();
         if (m >= N || m == prev) break;                                    // :669-672 / :734-735
         if (!modeB && (m + 3 * nToExpand) > N) modeB = true;               // :673
     }
