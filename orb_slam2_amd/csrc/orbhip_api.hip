@@ -1442,6 +1442,7 @@ extern "C" orbhip_status orbhip_search_best_in_window_bounds(int device, const o
         BestParams B; memset(&B, 0, sizeof B);
         B.kp = dk; B.desc = dd; B.u_right = dur; B.inv_level_sigma2 = dsg; B.grid_start = dgs; B.grid_items = dgi; B.grid_xy = dgxy;
         B.q = dq; B.qdesc = dqd; B.nq = nq; B.chi2_gate = chi2_gate; B.best_idx = dbi; B.best_dist = dbd;
+        B.min_x = bounds->min_x; B.gw_inv = (float)ORBHIP_GRID_COLS / (float)(bounds->max_x - bounds->min_x);      // as orbhip_launch_match_grid lays the grid out
         orbhip_launch_best_in_window(B, nullptr);
         e = hipGetLastError();
     }
@@ -1537,6 +1538,7 @@ extern "C" orbhip_status orbhip_search_best_in_window_frame(orbhip_ctx* c, int f
         BestParams B; memset(&B, 0, sizeof B);
         B.kp = dk; B.desc = dd; B.u_right = dur; B.inv_level_sigma2 = dsg; B.grid_start = dgs; B.grid_items = dgi; B.grid_xy = dgxy;
         B.q = dq; B.qdesc = dqd; B.nq = nq; B.chi2_gate = chi2_gate; B.best_idx = dbi; B.best_dist = dbd;
+        B.min_x = c->bounds.min_x; B.gw_inv = (float)ORBHIP_GRID_COLS / (float)(c->bounds.max_x - c->bounds.min_x);
         orbhip_launch_best_in_window(B, c->stream);
         e = hipGetLastError();
     }

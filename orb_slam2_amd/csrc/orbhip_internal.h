@@ -144,6 +144,7 @@ struct BestParams {
     const int* grid_start; const int* grid_items; const float2* grid_xy;        // ordered bucket table over ALL key points (k_match_grid, grid_all_levels)
     const orbhip_best_query* q; const uint8_t* qdesc; int nq; int chi2_gate;
     int* best_idx; int* best_dist;
+    float min_x, gw_inv;        // left image bound and grid columns per pixel of the table's grid (gw_inv = 0: scan the whole table)
 };
 void orbhip_launch_best_in_window(const BestParams& B, hipStream_t s);
 size_t orbhip_proj_select_lds(int n);

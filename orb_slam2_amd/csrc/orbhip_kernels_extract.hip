@@ -1320,7 +1320,8 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(ExtractParams P)
 void orbhip_launch_quadtree(const ExtractParams& P, int nframes, hipStream_t s)
 {
     ExtractParams Q = P; Q.nframes = nframes;
-    hipLaunchKernelGGL(k_quadtree, dim3(xcd_grid(P.nlevels, nframes), 1, 1), dim3(QT_T, 1, 1), orbhip_quadtree_lds_bytes(P.qt_maxn, P.qt_maxcells), s, Q);
+    static const size_t pad = [] { const char* e = getenv("ORBHIP_QT_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }();      // experiment knob: unused LDS per workgroup = fewer resident quadtree workgroups per CU
+    hipLaunchKernelGGL(k_quadtree, dim3(xcd_grid(P.nlevels, nframes), 1, 1), dim3(QT_T, 1, 1), orbhip_quadtree_lds_bytes(P.qt_maxn, P.qt_maxcells) + pad, s, Q);
 }
 
 // ------------------------------------------------------------------------------------------------ describe

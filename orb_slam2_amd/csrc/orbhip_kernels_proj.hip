@@ -302,9 +302,17 @@ __global__ __launch_bounds__(256) void k_best_in_window(BestParams B)
     const orbhip_best_query q = B.q[iq];
     const uint4* q4 = reinterpret_cast<const uint4*>(B.qdesc + (long long)iq * 32);
     const uint4 qa = q4[0], qb = q4[1];
-    const int nitems = B.grid_start[ORBHIP_GRID_CELLS];
+    // only the run of the table that holds the grid columns the radius can reach (+-1, see k_match_candidates): the table is ordered by column
+    int t_lo = 0, nitems = 0;
+    {
+        const float cl = __fmul_rn(__fsub_rn(__fsub_rn(q.x, B.min_x), q.radius), B.gw_inv), ch = __fmul_rn(__fadd_rn(__fsub_rn(q.x, B.min_x), q.radius), B.gw_inv);
+        const bool all = !(B.gw_inv > 0.0f);
+        const int col_lo = (!all && cl >= 1.0f) ? (int)fminf(floorf(cl) - 1.0f, (float)ORBHIP_GRID_COLS) : 0;
+        const int col_hi = (!all && ch < (float)(ORBHIP_GRID_COLS - 2)) ? (int)fmaxf(ceilf(ch) + 2.0f, 0.0f) : ORBHIP_GRID_COLS;
+        t_lo = __builtin_amdgcn_readfirstlane(B.grid_start[min(col_lo, col_hi) * ORBHIP_GRID_ROWS]); nitems = __builtin_amdgcn_readfirstlane(B.grid_start[col_hi * ORBHIP_GRID_ROWS]);
+    }
     int best = 256, bidx = -1;
-    for (int tb = 0; tb < nitems; tb += 64) {
+    for (int tb = t_lo; tb < nitems; tb += 64) {
         const int t = tb + lane;
         int idx = 0, dist = 256; bool ok = false;
         if (t < nitems) {
