@@ -551,52 +551,54 @@ typedef int v2i __attribute__((vector_size(8)));
 typedef int v16i __attribute__((vector_size(64)));
 #define BM_IN_DW 68                     // dwords per staged source row: 64 loaded (columns x0 - 4 .. x0 + 251) + 4 of padding against bank conflicts
 #define BM_OUT_DW 57                    // dwords per row of the output tile in LDS (56 used)
-__global__ __launch_bounds__(256, 5) void k_blur_mfma(ExtractParams P)
+// ---- k_blur_mfma in four steps (shared by the one-tile and the pipelined form of the kernel)
+struct BlurTile { TileDesc t; LevelGeom g; const uint8_t* src; int spitch; };
+__device__ __forceinline__ BlurTile blur_tile(const ExtractParams& P, int frame, int tile)
 {
-    __shared__ __attribute__((aligned(16))) unsigned s_in[32 * BM_IN_DW];
-    __shared__ unsigned s_out[BM_ROWS * BM_OUT_DW];
-    __shared__ __attribute__((aligned(16))) unsigned s_band[3 * 64 * 4];   // HB1 | HB2 | VB: fetched once per workgroup with coalesced 32-bit loads
-    int tile, frame;                                                        // (as three 128-bit loads per lane they cost each wave 3 x 71 cycles of the texture addresser)
-    if (!xcd_frame_map(P.nblur_tiles, P.nframes, tile, frame)) return;
-#pragma unroll
-    for (int k = 0; k < 3; k++) s_band[256 * k + threadIdx.x] = reinterpret_cast<const unsigned*>(P.blur_band)[256 * k + threadIdx.x];
-    frame += P.frame0;
-    const TileDesc t = P.blur_tiles[tile];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const LevelGeom g = P.geom[t.level];
-    const int x0 = t.x0, y0 = t.y0;
-    int spitch; const uint8_t* src = level_src(P, frame, t.level, spitch);
+    BlurTile T; T.t = P.blur_tiles[tile]; T.g = P.geom[T.t.level]; T.src = level_src(P, frame, T.t.level, T.spitch);
+    return T;
+}
+// stage: wave w brings source rows 8w .. 8w+7 (BORDER_REFLECT_101 on the row index), lane = dword of the row.  Dwords that are not
+// entirely inside the image re-read a dword that is (never used as loaded): the two border fix-ups write them.  8 LDS-DMA instructions per wave.
+__device__ __forceinline__ void blur_issue(const BlurTile& T, int wave, int lane, unsigned* s_in)
+{
+    const LevelGeom& g = T.g; const int x0 = T.t.x0, y0 = T.t.y0, spitch = T.spitch; const uint8_t* src = T.src;
     const int w4 = g.w & ~3;
-    {   // ---- stage: wave w brings source rows 8w .. 8w+7 (BORDER_REFLECT_101 on the row index), lane = dword of the row.  Dwords that are not
-        //      entirely inside the image re-read a dword that is (never used as loaded): the two border fix-ups below write them
-        const int c0 = x0 - 4 + 4 * lane;
-        const unsigned coff = (unsigned)min(max(c0, 0), w4 - 4);
+    const int c0 = x0 - 4 + 4 * lane;
+    const unsigned coff = (unsigned)min(max(c0, 0), w4 - 4);
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const int row = 8 * wave + r;
-            const ORBHIP_GLOBAL uint8_t* rp = uniform_ptr(src + (long long)reflect101_clamped(y0 - 3 + row, g.h) * spitch);
-            lds_dma_dword(rp + coff, reinterpret_cast<uint8_t*>(s_in + row * BM_IN_DW));
-        }
-        lds_dma_wait();
-        __builtin_amdgcn_wave_barrier();                                  // every lane's dwords have landed before any lane patches one
-        const bool fix_left = x0 == 0, fix_right = x0 + 252 > w4;     // wave-uniform
-        if (fix_left || fix_right) {
-            // lane = (row of this wave, slot): slot 0 = the dword left of the image, slots 1 / 2 = the two dwords from column w & ~3 on (the last
-            // 0..3 real columns, then reflected ones: a tile reads at most 3 columns past the last one it writes)
-            const int rr = lane >> 3, slot = lane & 7, row = 8 * wave + rr;
-            const int cfix = slot == 0 ? -4 : w4 + 4 * (slot - 1);
-            const int dw = (cfix - (x0 - 4)) >> 2;
-            const bool act = (slot == 0 ? fix_left : (slot <= 2 && fix_right)) && dw >= 0 && dw < 64;
-            if (act) {
-                const uint8_t* rowp = src + (long long)reflect101_clamped(y0 - 3 + row, g.h) * spitch;
-                unsigned wv = 0;
+    for (int r = 0; r < 8; r++) {
+        const int row = 8 * wave + r;
+        const ORBHIP_GLOBAL uint8_t* rp = uniform_ptr(src + (long long)reflect101_clamped(y0 - 3 + row, g.h) * spitch);
+        lds_dma_dword(rp + coff, reinterpret_cast<uint8_t*>(s_in + row * BM_IN_DW));
+    }
+}
+// after the tile's rows have landed (and a wave barrier): the dwords that straddle the image's left / right border
+__device__ __forceinline__ void blur_fix(const BlurTile& T, int wave, int lane, unsigned* s_in)
+{
+    const LevelGeom& g = T.g; const int x0 = T.t.x0, y0 = T.t.y0, spitch = T.spitch; const uint8_t* src = T.src;
+    const int w4 = g.w & ~3;
+    const bool fix_left = x0 == 0, fix_right = x0 + 252 > w4;     // wave-uniform
+    if (fix_left || fix_right) {
+        // lane = (row of this wave, slot): slot 0 = the dword left of the image, slots 1 / 2 = the two dwords from column w & ~3 on (the last
+        // 0..3 real columns, then reflected ones: a tile reads at most 3 columns past the last one it writes)
+        const int rr = lane >> 3, slot = lane & 7, row = 8 * wave + rr;
+        const int cfix = slot == 0 ? -4 : w4 + 4 * (slot - 1);
+        const int dw = (cfix - (x0 - 4)) >> 2;
+        const bool act = (slot == 0 ? fix_left : (slot <= 2 && fix_right)) && dw >= 0 && dw < 64;
+        if (act) {
+            const uint8_t* rowp = src + (long long)reflect101_clamped(y0 - 3 + row, g.h) * spitch;
+            unsigned wv = 0;
 #pragma unroll
-                for (int b = 0; b < 4; b++) wv |= (unsigned)rowp[reflect101_clamped(cfix + b, g.w)] << (8 * b);
-                s_in[row * BM_IN_DW + dw] = wv;
-            }
+            for (int b = 0; b < 4; b++) wv |= (unsigned)rowp[reflect101_clamped(cfix + b, g.w)] << (8 * b);
+            s_in[row * BM_IN_DW + dw] = wv;
         }
     }
-    __syncthreads();
+}
+__device__ __forceinline__ void blur_compute(const ExtractParams& P, const BlurTile& T, int wave, int lane, const unsigned* s_in, unsigned* s_out, const unsigned* s_band)
+{
+    const LevelGeom& g = T.g; const int x0 = T.t.x0;
+    const int w4 = g.w & ~3;
     const int i = lane & 31, h = lane >> 5;
     const v4i HB1 = *reinterpret_cast<const v4i*>(s_band + 4 * lane), HB2 = *reinterpret_cast<const v4i*>(s_band + 256 + 4 * lane), VB = *reinterpret_cast<const v4i*>(s_band + 512 + 4 * lane);
     const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // C operand = inline constant 0: the -128 of the operand bytes is undone on the VALU
@@ -654,13 +656,70 @@ __global__ __launch_bounds__(256, 5) void k_blur_mfma(ExtractParams P)
             if (all_he) finish(std::integral_constant<int, 1>{}); else if (none_he) finish(std::integral_constant<int, 0>{}); else finish(std::integral_constant<int, 2>{});
         }
     }
-    __syncthreads();
+}
+__device__ __forceinline__ void blur_store(const ExtractParams& P, const BlurTile& T, int frame, int wave, int lane, const unsigned* s_out)
+{
+    const LevelGeom& g = T.g; const int x0 = T.t.x0, y0 = T.t.y0;
     // ---- store: wave w writes output rows w, w + 4, ..., lane = dword of the row (224 contiguous bytes per instruction)
     uint8_t* dst = P.blur + (long long)frame * P.plane_frame_bytes + g.plane_off;
     const int gx = x0 + 4 * lane;
     if (lane < 8 * BM_BLOCKS && gx < g.w)
         for (int r = wave; r < BM_ROWS && y0 + r < g.h; r += 4)
             *reinterpret_cast<unsigned*>(dst + (long long)(y0 + r) * g.pitch + gx) = s_out[r * BM_OUT_DW + lane];      // pitch multiple of 64, gx of 4: pad bytes absorb the tail
+}
+
+__global__ __launch_bounds__(256, 5) void k_blur_mfma(ExtractParams P)
+{
+    __shared__ __attribute__((aligned(16))) unsigned s_in[32 * BM_IN_DW];
+    __shared__ unsigned s_out[BM_ROWS * BM_OUT_DW];
+    __shared__ __attribute__((aligned(16))) unsigned s_band[3 * 64 * 4];   // HB1 | HB2 | VB: fetched once per workgroup with coalesced 32-bit loads
+    int tile, frame;                                                        // (as three 128-bit loads per lane they cost each wave 3 x 71 cycles of the texture addresser)
+    if (!xcd_frame_map(P.nblur_tiles, P.nframes, tile, frame)) return;
+#pragma unroll
+    for (int k = 0; k < 3; k++) s_band[256 * k + threadIdx.x] = reinterpret_cast<const unsigned*>(P.blur_band)[256 * k + threadIdx.x];
+    frame += P.frame0;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const BlurTile T = blur_tile(P, frame, tile);
+    blur_issue(T, wave, lane, s_in);
+    lds_dma_wait();
+    __builtin_amdgcn_wave_barrier();                                  // every lane's dwords have landed before any lane patches one
+    blur_fix(T, wave, lane, s_in);
+    __syncthreads();
+    blur_compute(P, T, wave, lane, s_in, s_out, s_band);
+    __syncthreads();
+    blur_store(P, T, frame, wave, lane, s_out);
+}
+
+// The same tile arithmetic, `nt` tiles (consecutive in the level-major list) per workgroup, with the NEXT tile's source rows in flight (LDS-DMA into the
+// other of two staging buffers) while this tile is multiplied, rounded and stored: the load, compute and store phases of a workgroup no longer add up.
+__global__ __launch_bounds__(256, 5) void k_blur_mfma_p(ExtractParams P, int nt)
+{
+    __shared__ __attribute__((aligned(16))) unsigned s_in[2][32 * BM_IN_DW];
+    __shared__ unsigned s_out[BM_ROWS * BM_OUT_DW];
+    __shared__ __attribute__((aligned(16))) unsigned s_band[3 * 64 * 4];
+    int grp, frame;
+    if (!xcd_frame_map((P.nblur_tiles + nt - 1) / nt, P.nframes, grp, frame)) return;
+#pragma unroll
+    for (int k = 0; k < 3; k++) s_band[256 * k + threadIdx.x] = reinterpret_cast<const unsigned*>(P.blur_band)[256 * k + threadIdx.x];
+    frame += P.frame0;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int tile0 = grp * nt, tile1 = min(tile0 + nt, P.nblur_tiles);
+    BlurTile T = blur_tile(P, frame, tile0), Tn = T;
+    blur_issue(T, wave, lane, s_in[0]);
+    for (int ti = tile0; ti < tile1; ti++) {
+        const int buf = (ti - tile0) & 1;
+        const bool more = ti + 1 < tile1;
+        if (more) { Tn = blur_tile(P, frame, ti + 1); blur_issue(Tn, wave, lane, s_in[buf ^ 1]); }      // its readers (tile ti - 1) are behind the barrier that ended the last iteration's arithmetic
+        // loads return in order: at most the 8 just issued outstanding  <=>  this tile's rows (and the stores of the tile before) are done
+        if (more) __builtin_amdgcn_s_waitcnt(ORBHIP_VMCNT(8)); else lds_dma_wait();
+        __builtin_amdgcn_wave_barrier();
+        blur_fix(T, wave, lane, s_in[buf]);
+        __syncthreads();
+        blur_compute(P, T, wave, lane, s_in[buf], s_out, s_band);
+        __syncthreads();
+        blur_store(P, T, frame, wave, lane, s_out);
+        T = Tn;
+    }
 }
 
 void orbhip_launch_blur(const ExtractParams& P, const int gk[4], int nframes, hipStream_t s, int tile0, int ntiles)
@@ -671,7 +730,9 @@ void orbhip_launch_blur(const ExtractParams& P, const int gk[4], int nframes, hi
     ExtractParams Q = P; Q.nframes = nframes;
     if (ntiles >= 0) { Q.blur_tiles = P.blur_tiles + tile0; Q.nblur_tiles = ntiles; }
     if (Q.nblur_tiles <= 0) return;
-    if (P.blur_band) hipLaunchKernelGGL(k_blur_mfma, dim3(xcd_grid(Q.nblur_tiles, nframes), 1, 1), dim3(256, 1, 1), 0, s, Q);
+    static const int nt = [] { const char* e = getenv("ORBHIP_BLUR_NT"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : v > 16 ? 16 : v; }();      // tiles per workgroup of the pipelined form (1: the one-tile kernel)
+    if (P.blur_band && nt > 1) hipLaunchKernelGGL(k_blur_mfma_p, dim3(xcd_grid((Q.nblur_tiles + nt - 1) / nt, nframes), 1, 1), dim3(256, 1, 1), 0, s, Q, nt);
+    else if (P.blur_band) hipLaunchKernelGGL(k_blur_mfma, dim3(xcd_grid(Q.nblur_tiles, nframes), 1, 1), dim3(256, 1, 1), 0, s, Q);
     else hipLaunchKernelGGL(k_blur, dim3(xcd_grid(Q.nblur_tiles, nframes), 1, 1), dim3(256, 1, 1), 0, s, Q, K);
 }
 

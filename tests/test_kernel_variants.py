@@ -64,6 +64,23 @@ def test_stream_schedules(backend, oracle, env, sched):
     ex.close()
 
 
+@pytest.mark.parametrize("w,h", [(450, 224), (227, 231)])
+def test_pipelined_blur_three_tiles_per_workgroup(backend, oracle, env, w, h):
+    """ORBHIP_BLUR_NT=3 (k_blur_mfma_p, an opt-in measurement: slower than the one-tile kernel): three tiles per workgroup, the next tile's rows in
+    flight in a second staging buffer; tile groups that end inside a level and groups that straddle two levels."""
+    env(ORBHIP_BLUR_NT=3)
+    n = 500
+    img = synth.frame(w, h, seed=w + h)
+    ora = oracle.OracleExtractor(n, 1.2, 8, 20, 7)
+    ko, do = ora.extract(img)
+    ex = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, library=backend)
+    kg, dg = ex(img)
+    for l in range(8):
+        assert np.array_equal(ex.blurred_level(l), ora.blurred(l)), f"blurred level {l}"
+    _same(kg, dg, ko, do)
+    ex.close()
+
+
 @pytest.mark.parametrize("B", [40, 33])
 def test_half_batch_schedule_keeps_the_quadtree_off_the_main_chain(backend, oracle, env, B):
     """ORBHIP_SCHED=4: from 32 frames on a batch goes through FAST and the descriptor kernel as two halves (the first a multiple of 8 frames), the
