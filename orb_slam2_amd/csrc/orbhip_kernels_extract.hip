@@ -1451,7 +1451,9 @@ __device__ __forceinline__ int wave_sum_dpp(int v)
 __device__ __forceinline__ int round_half_even_small(float x) { return __float_as_int(__fadd_rn(x, 12582912.0f)) - 0x4B400000; }
 
 #define DS_WAVES 4
-#define DS_KPW 4                       // key point slots per wavefront
+#ifndef DS_KPW
+#define DS_KPW 4                       // key point slots per wavefront (3: 0.652 -> see DESIGN §11)
+#endif
 #define DS_WROWS 37                    // blurred window rows: pattern reach is +-18 after rotation
 #define DS_WSTRIDE 48                  // bytes per staged window row: 37 used, starting 0..3 bytes into the row (staged from the dword boundary below cx - 18).  12 dwords, not the
                                        // 10 that would do: the texture addresser takes an LDS-DMA pass in groups of four lanes, and a group that straddles two image rows is what
@@ -1615,19 +1617,29 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
             const int dlane = 4 * (oi[j] - oi_first);
             // P.fp_contract (wave-uniform): 0 = x*b + y*a as two roundings (a build with -ffp-contract=off, H3), 1 = the fused forms gcc emits
             // for the reference's own flags, fma(x, b, y*a) and fma(x, a, -(y*b))
+            // Both points of a test go through the rotation as one packed-f32 pair (v_pk_mul_f32 / v_pk_add_f32: every product and sum still
+            // rounded on its own), and cvRound comes out of the float's own bits: x + (2^23 + 64) is an integer-valued float with ulp 1 for
+            // |x| < 64 - the same round-half-to-even as rint (64 is even) - whose low 24 bits are 64 + rint(x).  v_mad_u32_u24 takes exactly
+            // those of the row coordinate, so   (64 + iy) * 48 + bits(x') = 48 iy + ix + C   with C = 3072 + 64 + 0x4B000000:
+            // one multiply-add and one addition of a wave-uniform constant per point instead of two subtractions, a multiplication and two additions.
+            typedef float f2v __attribute__((vector_size(8)));
+            const f2v A2 = {a, a}, B2 = {b, b}, MG = {8388672.0f, 8388672.0f};
+            const unsigned cbias = 3072u + 64u + 0x4B000000u;
             auto brief = [&](auto fused) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const float x0 = pt[r].x, y0 = pt[r].y, x1 = pt[r].z, y1 = pt[r].w;
-                    int iy0, ix0, iy1, ix1;
+                    const f2v X = {pt[r].x, pt[r].z}, Y = {pt[r].y, pt[r].w};        // (x0, x1), (y0, y1)
+                    f2v fy, fx;
                     if (decltype(fused)::value) {
-                        iy0 = round_half_even_small(__fmaf_rn(x0, b, __fmul_rn(y0, a))); ix0 = round_half_even_small(__fmaf_rn(x0, a, -__fmul_rn(y0, b)));
-                        iy1 = round_half_even_small(__fmaf_rn(x1, b, __fmul_rn(y1, a))); ix1 = round_half_even_small(__fmaf_rn(x1, a, -__fmul_rn(y1, b)));
+                        fy[0] = __fmaf_rn(X[0], b, __fmul_rn(Y[0], a)); fy[1] = __fmaf_rn(X[1], b, __fmul_rn(Y[1], a));
+                        fx[0] = __fmaf_rn(X[0], a, -__fmul_rn(Y[0], b)); fx[1] = __fmaf_rn(X[1], a, -__fmul_rn(Y[1], b));
                     } else {
-                        iy0 = round_half_even_small(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a))); ix0 = round_half_even_small(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-                        iy1 = round_half_even_small(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a))); ix1 = round_half_even_small(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+                        fy = X * B2 + Y * A2; fx = X * A2 - Y * B2;                    // -ffp-contract=off: two roundings each (H3)
                     }
-                    const int t0 = w8[iy0 * DS_WSTRIDE + ix0], t1 = w8[iy1 * DS_WSTRIDE + ix1];
+                    const f2v ry = fy + MG, rx = fx + MG;
+                    const int o0 = (int)(__umul24(__float_as_uint(ry[0]), (unsigned)DS_WSTRIDE) + __float_as_uint(rx[0]) - cbias);
+                    const int o1 = (int)(__umul24(__float_as_uint(ry[1]), (unsigned)DS_WSTRIDE) + __float_as_uint(rx[1]) - cbias);
+                    const int t0 = w8[o0], t1 = w8[o1];
                     const unsigned long long bits = __ballot(t0 < t1);       // test 64r+lane -> byte (64r+lane)/8, bit lane%8
                     dlo_l = orbhip_writelane((int)(unsigned)bits, dlane + r, dlo_l);          // 2 VALU instead of compare + 2 moves + 2 selects
                     dhi_l = orbhip_writelane((int)(unsigned)(bits >> 32), dlane + r, dhi_l);

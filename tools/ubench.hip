@@ -10,6 +10,18 @@ __global__ __launch_bounds__(256) void NAME(unsigned* out, unsigned seed) { \
         asm volatile(ASM(0) ASM(1) ASM(2) ASM(3) ASM(4) ASM(5) ASM(6) ASM(7) \
                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c)); } \
     out[blockIdx.x * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7; }
+// the same with 64-bit register pairs (packed f32 operands)
+#define DEFK64(NAME, ASM) \
+__global__ __launch_bounds__(256) void NAME(unsigned* out, unsigned seed) { \
+    unsigned long long a0 = 0x3f8000003f800000ull + seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
+    unsigned long long b = 0x3f8000013f800001ull ^ seed, c = 0x3a0000003a000000ull | seed; \
+    for (int it = 0; it < N_IT; it++) { \
+        asm volatile(ASM(0) ASM(1) ASM(2) ASM(3) ASM(4) ASM(5) ASM(6) ASM(7) \
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c)); } \
+    out[blockIdx.x * 256 + threadIdx.x] = (unsigned)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7); }
+#define A_PKMULF32(i) "v_pk_mul_f32 %" #i ", %" #i ", %8\n"
+#define A_PKADDF32(i) "v_pk_add_f32 %" #i ", %" #i ", %8\n"
+#define A_PKFMAF32(i) "v_pk_fma_f32 %" #i ", %" #i ", %8, %9\n"
 #define A_ADD(i)      "v_add_u32 %" #i ", %" #i ", %8\n"
 #define A_MINU(i)     "v_min_u32 %" #i ", %" #i ", %8\n"
 #define A_PKMINU16(i) "v_pk_min_u16 %" #i ", %" #i ", %8\n"
@@ -87,6 +99,7 @@ __global__ __launch_bounds__(256) void NAME(unsigned* out, unsigned seed) { \
 #define A_ADDK(i)     "v_add_u32 %" #i ", 0x80808080, %" #i "\n"
 #define A_ANDK(i)     "v_and_b32 %" #i ", 0x7f7f7f7f, %" #i "\n"
 DEFK(k_add, A_ADD) DEFK(k_minu, A_MINU) DEFK(k_pkminu16, A_PKMINU16) DEFK(k_pkminf16, A_PKMINF16) DEFK(k_pkmaxi16, A_PKMAXI16)
+DEFK64(k_pkmulf32, A_PKMULF32) DEFK64(k_pkaddf32, A_PKADDF32) DEFK64(k_pkfmaf32, A_PKFMAF32)
 DEFK(k_minf32, A_MINF32) DEFK(k_fmaf32, A_FMAF32) DEFK(k_mulf32, A_MULF32) DEFK(k_min3u, A_MIN3U) DEFK(k_max3f, A_MAX3F)
 DEFK(k_perm, A_PERM) DEFK(k_mad24, A_MAD24) DEFK(k_lshladd, A_LSHLADD) DEFK(k_andor, A_ANDOR) DEFK(k_cvtf, A_CVTF) DEFK(k_rndne, A_RNDNE)
 DEFK(k_cvti, A_CVTI) DEFK(k_mullo, A_MULLO) DEFK(k_bfe, A_BFE) DEFK(k_alignbit, A_ALIGNBIT) DEFK(k_pkaddf16, A_PKADDF16) DEFK(k_pkmulf16, A_PKMULF16)
@@ -143,6 +156,7 @@ int main()
 {
 #define R(n, c) run(#n, n, c)
     R(k_add, 1); R(k_xor, 1); R(k_minu, 1); R(k_min3u, 1); R(k_pkminu16, 1); R(k_pkmaxi16, 1); R(k_pkminf16, 1); R(k_pkaddf16, 1); R(k_pkmulf16, 1);
+    R(k_pkmulf32, 1); R(k_pkaddf32, 1); R(k_pkfmaf32, 1);
     R(k_minf32, 1); R(k_max3f, 1); R(k_mulf32, 1); R(k_fmaf32, 1); R(k_perm, 1); R(k_mad24, 1); R(k_lshladd, 1); R(k_andor, 1); R(k_bfe, 1);
     R(k_alignbit, 1); R(k_cvtf, 1); R(k_rndne, 1); R(k_cvti, 1); R(k_mullo, 1); R(k_bcnt, 1); R(k_sadu8, 1); R(k_cmpsel, 2); R(k_dpp, 1); R(k_bperm, 1);
     R(k_pkmadu16, 1); R(k_pkmulu16, 1); R(k_pkaddu16, 1); R(k_dot4u8, 1); R(k_addf32, 1); R(k_cvtub1, 1); R(k_floor, 1); R(k_cvtpku8, 1);
