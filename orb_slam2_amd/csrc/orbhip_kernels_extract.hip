@@ -1518,6 +1518,9 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
     for (int k = 0; k < DS_WPASSES; k++) {
         const int pos = 64 * k + lane, row = (pos * 5462) >> 16;          // pos / 12 for pos < 448
         wrow[k] = min(row, DS_WROWS - 1); wcol[k] = 4 * (pos - 12 * row); // the four dwords past the window re-read the start of its last row (in bounds, never used)
+#ifdef DS_EXP_WINDOW_ONE_ROW
+        wrow[k] = 18;                                                     // (timing experiment: every staged row is the window's middle row - the same instructions, 1-2 cache lines instead of ~48)
+#endif
     }
 
     // ---- 0. slot -> (level, index in the level, output index), lane j for slot j; then wave-uniform copies (SGPRs) of the wave's slots.
@@ -1567,10 +1570,18 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
             const unsigned off = (unsigned)((cy - 15 + prow) * spitch + ((cx - 15) & ~3) + 4 * min(pd, 8));
 #pragma unroll
             for (int q = 0; q < DS_PPASS; q++)                             // rows prow + 4q - 15 = -15 .. 16; row 16 is loaded (in bounds) and masked
+#if defined(DS_EXP_NO_PATCH)          // timing experiments of round 3 (results are wrong with any DS_EXP_* defined; profiles/r03_exp_describe_memory_ablation.jsonl)
+                pw[j][q] = (unsigned)(off + q);                    // no orientation-patch loads
+#elif defined(DS_EXP_PATCH_ONE_ROW)
+                pw[j][q] = *reinterpret_cast<const ORBHIP_GLOBAL unsigned*>(img + ((unsigned)(cy * spitch + ((cx - 15) & ~3) + 4 * min(pd, 8))));      // every patch row is row cy: the same instructions, 1-2 cache lines
+#else
                 pw[j][q] = *reinterpret_cast<const ORBHIP_GLOBAL unsigned*>(img + (off + (unsigned)(4 * q * spitch)));
+#endif
         }
+#ifndef DS_EXP_NO_WINDOW                                                 // (timing experiment: no blurred-window staging)
 #pragma unroll
         for (int j = 0; j < DS_KPW; j++) if (ok[j]) window_dma(lv[j], vv[j], s_win[wave][j]);
+#endif
 #pragma unroll
         for (int j = 0; j < DS_KPW; j++) if (ok[j]) {
             unsigned s = 0, su = 0, cs = 0;                                   // cs = sum over passes of the running row sum = sum_q (8 - q) t_q
@@ -1639,7 +1650,11 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
                     const f2v ry = fy + MG, rx = fx + MG;
                     const int o0 = (int)(__umul24(__float_as_uint(ry[0]), (unsigned)DS_WSTRIDE) + __float_as_uint(rx[0]) - cbias);
                     const int o1 = (int)(__umul24(__float_as_uint(ry[1]), (unsigned)DS_WSTRIDE) + __float_as_uint(rx[1]) - cbias);
+#ifdef DS_EXP_NO_GATHER
+                    const int t0 = o0 & 0xff, t1 = o1 & 0xff;                        // (timing experiment: no LDS byte gathers)
+#else
                     const int t0 = w8[o0], t1 = w8[o1];
+#endif
                     const unsigned long long bits = __ballot(t0 < t1);       // test 64r+lane -> byte (64r+lane)/8, bit lane%8
                     dlo_l = orbhip_writelane((int)(unsigned)bits, dlane + r, dlo_l);          // 2 VALU instead of compare + 2 moves + 2 selects
                     dhi_l = orbhip_writelane((int)(unsigned)(bits >> 32), dlane + r, dhi_l);
