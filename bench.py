@@ -397,7 +397,7 @@ def main():
                     continue
                 with open(pmc) as f:
                     for row in json.load(f):
-                        if row["kernel"] == dom:
+                        if row["kernel"].split("<")[0] == dom:          # (k_fast_cells is a template: "k_fast_cells<48, 40>" in the profiler's rows)
                             traffic_profiled = {"bytes_per_launch": int((2 * row["fetch_MB_per_dispatch_raw"] + row["write_MB_per_dispatch_raw"]) * 1024 * 1024 * B / 256),
                                                 "source": f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE at B = 256, scaled to B = {B}; not measured in this run)"}
                 break

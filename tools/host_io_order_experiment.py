@@ -1,0 +1,47 @@
+import json, os, sys, time
+sys.path.insert(0, '/root/repo' if os.path.isdir('/root/repo/orb_slam2_amd') else os.getcwd())
+import numpy as np
+import orb_slam2_amd
+from orb_slam2_amd import synth
+W, H, Bh = 1241, 376, 256
+base = np.stack([synth.frame(W, H, seed=s % 16, t=s // 16) for s in range(64)])
+src_pageable = np.ascontiguousarray(np.resize(base, (Bh, H, W)))
+
+def run(ex, imgs, bufs, budget=0.75):
+    t = ex.submit(imgs, out=bufs[0]); ex.collect(t)
+    sub = done = 0; t0 = time.perf_counter(); pending = []
+    for _ in range(2): pending.append(ex.submit(imgs, out=bufs[sub % 3])); sub += 1
+    while time.perf_counter() - t0 < budget:
+        pending.append(ex.submit(imgs, out=bufs[sub % 3])); sub += 1
+        ex.collect(pending.pop(0)); done += 1
+    while pending: ex.collect(pending.pop(0)); done += 1
+    return round(done * Bh / (time.perf_counter() - t0), 1)
+
+def mk(ex, kind):
+    cap = ex.capacity
+    if kind == "pinned":
+        src = orb_slam2_amd.pinned_array((Bh, H, W), np.uint8); src[:] = src_pageable
+        bufs = [(orb_slam2_amd.pinned_array((Bh, cap), orb_slam2_amd.KEYPOINT_DTYPE), orb_slam2_amd.pinned_array((Bh, cap, 32), np.uint8), np.zeros(Bh, np.int32)) for _ in range(3)]
+    else:
+        src = src_pageable
+        bufs = [(np.zeros((Bh, cap), orb_slam2_amd.KEYPOINT_DTYPE), np.zeros((Bh, cap, 32), np.uint8), np.zeros(Bh, np.int32)) for _ in range(3)]
+    return src, bufs
+
+mode = sys.argv[1]
+big = None
+if "big" in mode:      # a large resident context like the bench's
+    big = orb_slam2_amd.ORBextractor(2000, 1.2, 8, 20, 7, W, H, max_batch=512, blur_round_mode=1)
+    d = orb_slam2_amd.DeviceBuffer(512 * 376 * 1280)
+if "closed" in mode:   # ... and destroyed again before the host path is measured
+    big.close(); d.free(); big = None
+out = {"mode": mode, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}
+if "fresh" in mode:
+    for kind in ("pinned", "pageable", "pinned", "pageable"):
+        ex = orb_slam2_amd.ORBextractor(2000, 1.2, 8, 20, 7, W, H, max_batch=Bh, blur_round_mode=1)
+        s, b = mk(ex, kind); out.setdefault(kind, []).append(run(ex, s, b)); ex.close()
+else:
+    ex = orb_slam2_amd.ORBextractor(2000, 1.2, 8, 20, 7, W, H, max_batch=Bh, blur_round_mode=1)
+    sets = {k: mk(ex, k) for k in (("pageable", "pinned") if "pagefirst" in mode else ("pinned", "pageable"))}
+    for rnd in range(2):
+        for kind in sets: out.setdefault(kind, []).append(run(ex, *sets[kind]))
+print(json.dumps(out), flush=True)
