@@ -167,8 +167,19 @@ def host_io(ex_resident, frames, device, blur_round_mode, budget_s=3.0):
         one(src_pageable[i % Bh])
     out["single_frame_call_ms"] = round((time.perf_counter() - t1) / 100 * 1e3, 4)
     out["value"] = out["pinned"]["frames_per_s"]; out["unit"] = "frames/s"
-    out["note"] = "extract only, PCIe both ways, host buffers in / out; value = pinned caller buffers"
+    out["note"] = "extract only, PCIe both ways, host buffers in / out; value = pinned caller buffers; measured in a fresh process (the drop-in's situation), the better of two alternating rounds per kind"
     return out
+
+
+def host_io_subprocess(device, blur_round_mode):
+    """host_io() in a fresh interpreter (python bench.py --host-io-only): one JSON object on its stdout."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--host-io-only", "--blur-round-mode", str(blur_round_mode), "--device", str(device)],
+                       capture_output=True, text=True, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": f"host_io subprocess failed (rc {r.returncode}): {r.stderr[-300:]}"}
+    return json.loads(lines[-1])
 
 
 def parity_of_last_step(host_frames, kps, descs, m12, last_step, T, blur_round_mode, nslots):
@@ -283,12 +294,23 @@ def main():
     ap.add_argument("--blur-round-mode", type=int, default=1, help="cv::GaussianBlur rounding the extractor reproduces: 1 = the SSE2 column filter of x86-64 OpenCV builds "
                     "(what the reference computes on this x86 box; default), 0 = OpenCV's generic C++ path (DESIGN.md H2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-io-only", action="store_true", help="internal: measure the host_io object in this (fresh) process and print it")
+    ap.add_argument("--device", type=int, default=0, help="with --host-io-only: the GPU to use")
     ap.add_argument("--pool", action="store_true", help="time the one-process multi-GPU pool (orbhip_pool_*: one host thread per GPU) at the host-buffer boundary instead of "
                     "the one-process-per-GPU device-resident benchmark; prints its own JSON line (mode: pool)")
     ap.add_argument("--pool-cameras-per-gpu", type=int, default=128)
     ap.add_argument("--parity-slots", type=int, default=4, help="camera slots of the last timed step compared bit for bit with the oracle (0 = skip)")
     ap.add_argument("--extract-only", action="store_true", help="diagnostic: skip the matcher (NOT the metric's workload; the JSON line says so)")
     args = ap.parse_args()
+    if args.host_io_only:
+        from orb_slam2_amd import synth
+        frames = np.zeros((1, 256, H, W), np.uint8)
+        for s in range(64):
+            fr = synth.frame_from_scene(synth.scene(W, H, seed=s), W, H, t=0, seed=s)
+            for b in range(s, 256, 64):
+                frames[0, b] = fr
+        print(json.dumps(host_io(None, frames, args.device, args.blur_round_mode)), flush=True)
+        return
     if args.pool:
         if args.steps == 150:
             args.steps = 20
@@ -431,7 +453,11 @@ def main():
         if parity and (parity["mismatches"] or parity["replica_mismatches"]):
             out["INVALID"] = "results of the timed region differ from the oracle: the throughput above does not count"
         if world == 1 and not args.no_host_io:
-            out["host_io"] = host_io(ex, host_frames, local_rank, args.blur_round_mode)
+            # measured in a process of its own: in a process that holds (or has held) a large resident context the DMA path from / into the caller's
+            # pinned buffers delivers 93-100 k frames/s instead of the 112-117 k of a fresh process, on every box tried, while the pageable path is
+            # unaffected (profiles/r03_exp_host_io_pinned_vs_pageable_by_box.jsonl; cause not found) - and the drop-in's callers are such fresh processes
+            ex.close(); d_frames.free()
+            out["host_io"] = host_io_subprocess(local_rank, args.blur_round_mode)
         if world == 1 and not args.no_cpu_baseline:
             os.environ["ORB_REF_BLUR_ROUND_MODE"] = str(args.blur_round_mode)      # the reference build's GaussianBlur stand-in follows the same rounding
             out["cpu_baseline"] = cpu_baseline(host_frames, blur_round_mode=args.blur_round_mode)

@@ -275,19 +275,19 @@ __device__ __forceinline__ void pyr_dma_patch(const LevelGeom& g, const PyrTile&
         s_t[r * PYR_SDW + S.dfull] = w;
     }
 }
-#define PYR_NT 2                        // tiles (one below the other) per workgroup of k_pyramid_level_g
-__global__ __launch_bounds__(256) void k_pyramid_level_g(ExtractParams P, int level)
+// nt = tiles (one below the other) per workgroup: 2, or 4 from 384 frames on (ORBHIP_PYR_NT overrides: a measurement knob)
+__global__ __launch_bounds__(256) void k_pyramid_level_g(ExtractParams P, int level, int nt)
 {
     const LevelGeom g = P.geom[level];
-    const int gx = (g.w + PYR_TW - 1) / PYR_TW, gy = (g.h + PYR_TH - 1) / PYR_TH, gyn = (gy + PYR_NT - 1) / PYR_NT;
+    const int gx = (g.w + PYR_TW - 1) / PYR_TW, gy = (g.h + PYR_TH - 1) / PYR_TH, gyn = (gy + nt - 1) / nt;
     int tile, frame;
     if (!xcd_frame_map(gx * gyn, P.nframes, tile, frame)) return;
     frame += P.frame0;
     __shared__ unsigned s_t[2][PYR_SROWS * PYR_SDW];
     const int tid = threadIdx.y * 64 + threadIdx.x, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.y);
     const int tx = tile % gx;
-    int ty = (tile / gx) * PYR_NT;
-    const int tyend = min(ty + PYR_NT, gy);
+    int ty = (tile / gx) * nt;
+    const int tyend = min(ty + nt, gy);
     PyrSrc S, Sn;
     PyrTile T = pyr_dma_issue(P, g, level, tx, ty, frame, tid, s_t[0], S), Tn = T;
     const PyrGroup G = P.xgrp[g.xgrp_off + min(tx * (PYR_TW / 4) + (int)threadIdx.x, (g.w - 1) >> 2)];      // this lane's four columns: the same in every tile below
@@ -363,8 +363,10 @@ void orbhip_launch_pyramid_level(const ExtractParams& P, int level, int w, int h
 {   // mode 2: staged + 4-pixel groups, 1: staged, 0: straight from global memory
     ExtractParams Q = P; Q.nframes = nframes;
     dim3 grid(xcd_grid(((w + PYR_TW - 1) / PYR_TW) * ((h + PYR_TH - 1) / PYR_TH), nframes), 1, 1), block(64, 4, 1);
-    const int gyn = (((h + PYR_TH - 1) / PYR_TH) + PYR_NT - 1) / PYR_NT;
-    if (mode == 2) hipLaunchKernelGGL(k_pyramid_level_g, dim3(xcd_grid(((w + PYR_TW - 1) / PYR_TW) * gyn, nframes), 1, 1), block, 0, s, Q, level);
+    static const int nt_env = [] { const char* e = getenv("ORBHIP_PYR_NT"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : v > 64 ? 64 : v; }();
+    const int nt = nt_env ? nt_env : (nframes >= 384 ? 4 : 2);          // measured (round 3, same call): B = 512: 181.7 k frames/s with 2, 183.3 k with 4, 181.8 k with 8, 180.3 k with 1; B = 128: 157.6 k with 2, 155.2 k with 4
+    const int gyn = (((h + PYR_TH - 1) / PYR_TH) + nt - 1) / nt;
+    if (mode == 2) hipLaunchKernelGGL(k_pyramid_level_g, dim3(xcd_grid(((w + PYR_TW - 1) / PYR_TW) * gyn, nframes), 1, 1), block, 0, s, Q, level, nt);
     else if (mode == 1) hipLaunchKernelGGL(k_pyramid_level, grid, block, 0, s, Q, level);
     else hipLaunchKernelGGL(k_pyramid_level_direct, grid, block, 0, s, Q, level);
 }
