@@ -767,29 +767,37 @@ template <int I> __device__ __forceinline__ pku16 row_pair(unsigned w0, unsigned
 //   best bright margin = max_arcs min_k (R_k - C) = max_arcs min_k R_k - C
 // so only u8 min / max of ring values are needed (no per-element subtraction).  The 16 nine-element circular windows
 // come from prefix / suffix minima of the two 8-element blocks: win[i] = op(suffix[i], prefix[(i+8)&15]).
+// ONE polarity per pixel is enough: a 9-arc i..i+8 holds both elements of the opposite pair (i, i+8) and one element of every other
+// opposite pair, so with m = max_k min(R_k, R_k+8): a pixel whose bright margin is positive has m > C, one whose dark margin is positive has
+// every pair's minimum below C, m < C - and a margin that is not positive gives a score below any threshold >= 0, which the caller zeroes
+// whatever its value.  Pixels with m <= C are complemented (R -> 255 - R, C -> 255 - C: their dark margin becomes the bright one), then only
+// the arc minima are evaluated: 15 + 59 packed min / max and 17 full-rate xors instead of 118 (round 3).
 __device__ __forceinline__ pki16 fast_score_pair(const pku16 r[16], pku16 c)
 {
-    pku16 pn[16], sn[16], px[16], sx[16];
+    pku16 m = pmin(r[0], r[8]);
+#pragma unroll
+    for (int k = 1; k < 8; k++) m = pmax(m, pmin(r[k], r[k + 8]));
+    const pki16 nb = ~(((pki16)c - (pki16)m) >> 15);                 // all ones where m <= C (not a bright corner)
+    const pku16 cm = (pku16)nb & (pku16){0x00ff, 0x00ff};
+    pku16 q[16], pn[16], sn[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) q[i] = r[i] ^ cm;
 #pragma unroll
     for (int b = 0; b < 16; b += 8) {
-        pn[b] = r[b]; px[b] = r[b]; sn[b + 7] = r[b + 7]; sx[b + 7] = r[b + 7];
+        pn[b] = q[b]; sn[b + 7] = q[b + 7];
 #pragma unroll
-        for (int i = 1; i < 8; i++) {
-            pn[b + i] = pmin(pn[b + i - 1], r[b + i]); px[b + i] = pmax(px[b + i - 1], r[b + i]);
-            sn[b + 7 - i] = pmin(sn[b + 8 - i], r[b + 7 - i]); sx[b + 7 - i] = pmax(sx[b + 8 - i], r[b + 7 - i]);
-        }
+        for (int i = 1; i < 8; i++) { pn[b + i] = pmin(pn[b + i - 1], q[b + i]); sn[b + 7 - i] = pmin(sn[b + 8 - i], q[b + 7 - i]); }
     }
-    pku16 lo = pmax(sx[0], px[8]), hi = pmin(sn[0], pn[8]);         // min over arcs of the arc maximum / max over arcs of the arc minimum
+    pku16 hi = pmin(sn[0], pn[8]);                                   // max over arcs of the arc minimum
 #pragma unroll
-    for (int i = 1; i < 16; i++) { lo = pmin(lo, pmax(sx[i], px[(i + 8) & 15])); hi = pmax(hi, pmin(sn[i], pn[(i + 8) & 15])); }
-    const pki16 dark = (pki16)c - (pki16)lo, bright = (pki16)hi - (pki16)c;
+    for (int i = 1; i < 16; i++) hi = pmax(hi, pmin(sn[i], pn[(i + 8) & 15]));
     const pki16 one = {1, 1};
-    return (dark > bright ? dark : bright) - one;
+    return (pki16)hi - (pki16)(c ^ cm) - one;
 }
 
 __host__ __device__ __forceinline__ int fc_wave_bytes(int pbytes, int sstride, int srows, int listcap)
 {
-    return ((pbytes + 15) & ~15) + ((sstride * srows + 15) & ~15) + ((2 * listcap + 15) & ~15);
+    return ((pbytes + 15) & ~15) + ((sstride * srows + 4 + 15) & ~15) + ((2 * listcap + 15) & ~15);      // + 4: the dword behind the map's last row is part of it (see the score map's layout in k_fast_cells)
 }
 
 // ring of the pixel pair (Q, Q+1) of a 4-pixel group whose 7 x 12-byte window is w[7][3] (circle: FAST 16-point Bresenham);
@@ -850,7 +858,7 @@ __device__ __forceinline__ void fc_load_window(const uint8_t* patch, int PS, int
 // (FAST and the blur as ONE launch with workgroups of both kinds alternating on every CU - k_fast_blur, round 3 - was bit-exact and slower: 1.41-1.46 ms
 //  against 0.92 + 0.42 standalone; what one kind leaves idle the other cannot use.  profiles/r03_exp_fast_blur_one_launch.jsonl)
 template <int CPS, int CSS>
-__global__ __launch_bounds__(256, 7) void k_fast_cells(ExtractParams P)       // 7 waves per SIMD = what the LDS block allows (7 workgroups per CU): at most 72 VGPRs (75 uncapped: 6 waves, 3 % slower)
+__global__ __launch_bounds__(256, 8) void k_fast_cells(ExtractParams P)       // 8 waves per SIMD = what the LDS block allows at the metric's geometry (20 448 bytes: 8 workgroups per CU): at most 64 VGPRs
 {
     HIP_DYNAMIC_SHARED(unsigned, fc_lds)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -866,11 +874,12 @@ __global__ __launch_bounds__(256, 7) void k_fast_cells(ExtractParams P)       //
     const bool work = have && !cd.skipped && cw > 0 && ch > 0;
     const int PS = CPS ? CPS : P.fc_pstride, SS = CSS ? CSS : P.fc_sstride;      // byte strides, multiples of 4
     const int WB = fc_wave_bytes(P.fc_pbytes, SS, P.fc_srows, P.fc_listcap);      // per-wave LDS region: patch | score map | pair list
-    const int score_off = (P.fc_pbytes + 15) & ~15, list_off = score_off + ((SS * P.fc_srows + 15) & ~15);
+    const int score_off = (P.fc_pbytes + 15) & ~15, list_off = score_off + ((SS * P.fc_srows + 4 + 15) & ~15);
     uint8_t* const lds0 = reinterpret_cast<uint8_t*>(fc_lds);
     uint8_t* wbase = lds0 + wave * WB;
     uint8_t* patch = wbase;                                          // patch column 0 is 4-byte aligned; row stride PS
-    uint8_t* score = wbase + score_off;                              // interior (x, y) at score[(y+1)*SS + 4 + x]; zero ring around it
+    uint8_t* score = wbase + score_off;                              // interior (x, y) at score[(y+1)*SS + 4 + x]; zero ring around it: a row's four bytes in front are the
+                                                                     // row above's pad behind (SS = 4 + the interior width rounded up to 4), the last row's pad behind is the spare dword
     unsigned short* list = reinterpret_cast<unsigned short*>(wbase + list_off);
     int* const sh = reinterpret_cast<int*>(lds0 + FC_WAVES * WB);    // workgroup header: [0..3] listed pairs of each wave, [4..7] interior width of each wave's cell
     const int ng = (cw + 3) >> 2;                                    // 4-pixel groups per interior row (<= 16)
@@ -901,7 +910,7 @@ __global__ __launch_bounds__(256, 7) void k_fast_cells(ExtractParams P)       //
         }
         // the whole score map starts at zero: the passes below only fill the pixel pairs they examine (16 bytes per lane and store: the map's
         // base and its reserved size are multiples of 16, so rounding the count up stays inside it)
-        for (int i = lane; i < ((SS >> 2) * (ch + 2) + 3) >> 2; i += 64) reinterpret_cast<uint4*>(score)[i] = uint4{0u, 0u, 0u, 0u};
+        for (int i = lane; i < ((SS >> 2) * (ch + 2) + 1 + 3) >> 2; i += 64) reinterpret_cast<uint4*>(score)[i] = uint4{0u, 0u, 0u, 0u};
         lds_dma_wait();
     }
     __builtin_amdgcn_wave_barrier();
@@ -1034,7 +1043,7 @@ __global__ __launch_bounds__(256, 7) void k_fast_cells(ExtractParams P)       //
         // vKeysCell.empty() -> cv::FAST again with minThFAST (ORBextractor.cc:812-816).  The score map restarts from zero: scores the
         // first call left behind (maxima that suppressed each other) are not this call's.  (Every other wave's stage-b stores into this map
         // are behind the barrier above; the next ones come after the next barrier.)
-        if (phase == 0 && busy) for (int i = lane; i < ((SS >> 2) * (ch + 2) + 3) >> 2; i += 64) reinterpret_cast<uint4*>(score)[i] = uint4{0u, 0u, 0u, 0u};
+        if (phase == 0 && busy) for (int i = lane; i < ((SS >> 2) * (ch + 2) + 1 + 3) >> 2; i += 64) reinterpret_cast<uint4*>(score)[i] = uint4{0u, 0u, 0u, 0u};
     }
     if (have && lane == 0) P.cell_count[(long long)frame * P.ncells_total + cell_id] = work ? min(count, cd.cand_cap) : 0;
 }
@@ -1048,7 +1057,7 @@ void orbhip_launch_fast_cells(const ExtractParams& P, int nframes, hipStream_t s
     Q.fc_cell0 = ncells < 0 ? 0 : cell0; Q.fc_ncells = ncells < 0 ? P.ncells_total : ncells;
     if (Q.fc_ncells <= 0) return;
     const dim3 grid(xcd_grid((Q.fc_ncells + FC_WAVES - 1) / FC_WAVES, nframes), 1, 1);
-    if (Q.fc_pstride == 48 && Q.fc_sstride == 40) hipLaunchKernelGGL((k_fast_cells<48, 40>), grid, dim3(256, 1, 1), lds, s, Q);
+    if (Q.fc_pstride == 48 && Q.fc_sstride == 36) hipLaunchKernelGGL((k_fast_cells<48, 36>), grid, dim3(256, 1, 1), lds, s, Q);
     else hipLaunchKernelGGL((k_fast_cells<0, 0>), grid, dim3(256, 1, 1), lds, s, Q);
 }
 

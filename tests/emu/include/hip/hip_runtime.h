@@ -106,11 +106,13 @@ void launch(K kernel, dim3 grid, dim3 block, size_t shmem, A... args) {
     std::lock_guard<std::mutex> serialise(launch_mutex);   // host threads (the reference extracts left / right images on two std::threads) take turns
     const int T = (int)(block.x * block.y * block.z);
     std::vector<char> dyn(shmem + 64);
+    static const bool poison_lds = getenv("HIPEMU_POISON_LDS") != nullptr;
     g.dyn_shared = dyn.data(); g.bdim = block; g.gdim = grid;
     if ((int)g.fibers.size() < T) { size_t old = g.fibers.size(); g.fibers.resize(T); for (size_t i = old; i < (size_t)T; i++) g.fibers[i].stack = (char*)malloc(g.stack_size); }
     g.body = [&]() { kernel(args...); };
     for (unsigned bz = 0; bz < grid.z; bz++) for (unsigned by = 0; by < grid.y; by++) for (unsigned bx = 0; bx < grid.x; bx++) {
         g.bid = uint3{bx, by, bz}; g.live = T; g.bar_count = 0; g.bar_gen = 0;
+        if (poison_lds) memset(dyn.data(), 0xa5, dyn.size());          // HIPEMU_POISON_LDS=1: a workgroup starts on garbage, as on the device (reads of never-written LDS show)
         g.waves.assign((T + 63) / 64, Wave());
         for (auto& w : g.waves) for (int l = 0; l < 64; l++) w.present[l] = false;
         for (int t = 0; t < T; t++) {
