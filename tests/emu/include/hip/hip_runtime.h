@@ -106,7 +106,7 @@ void launch(K kernel, dim3 grid, dim3 block, size_t shmem, A... args) {
     std::lock_guard<std::mutex> serialise(launch_mutex);   // host threads (the reference extracts left / right images on two std::threads) take turns
     const int T = (int)(block.x * block.y * block.z);
     std::vector<char> dyn(shmem + 64);
-    static const bool poison_lds = getenv("HIPEMU_POISON_LDS") != nullptr;
+    const bool poison_lds = getenv("HIPEMU_POISON_LDS") != nullptr;
     g.dyn_shared = dyn.data(); g.bdim = block; g.gdim = grid;
     if ((int)g.fibers.size() < T) { size_t old = g.fibers.size(); g.fibers.resize(T); for (size_t i = old; i < (size_t)T; i++) g.fibers[i].stack = (char*)malloc(g.stack_size); }
     g.body = [&]() { kernel(args...); };

@@ -65,6 +65,19 @@ def run_case(rng, O, library=None):
     return tag + f" kp {[len(k) for k in ks]} matches {n_o}", ok
 
 
+def test_random_configurations_emulation(emu_lib, oracle, monkeypatch):
+    """The same sweep on the CPU emulation of the kernel sources, every workgroup starting on garbage LDS (HIPEMU_POISON_LDS): a read of
+    LDS the kernel never wrote changes results here as it would on the device (tools/fuzz_emu.py runs hundreds of cases this way)."""
+    monkeypatch.setenv("HIPEMU_POISON_LDS", "1")
+    rng = np.random.default_rng(5)
+    ran = 0
+    for _ in range(6):
+        tag, ok = run_case(rng, oracle, emu_lib)
+        assert ok is not False, tag
+        ran += ok is True
+    assert ran >= 3
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", [7, 11, 23])
 def test_random_configurations_gpu(gpu_lib, oracle, seed):
