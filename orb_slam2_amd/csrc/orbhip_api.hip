@@ -565,7 +565,8 @@ static ExtractParams make_params(orbhip_ctx* c, const uint8_t* d_img0, long long
     P.out_kp = c->d_out_kp[c->cur]; P.out_desc = c->d_out_desc[c->cur]; P.out_n = c->d_out_n[c->cur]; P.out_cap = c->out_cap;
     P.blur_tiles = c->d_tiles; P.nblur_tiles = (int)c->blur_tiles.size(); P.blur_band = c->blur_mfma ? c->d_blur_band : nullptr;
     P.xtab = c->d_xtab; P.ytab = c->d_ytab; P.xgrp = c->d_xgrp; P.patternf = c->d_pattern; P.ic_mask = c->d_ic_mask;
-    P.iniTh = c->cfg.ini_th_fast; P.minTh = c->cfg.min_th_fast; P.blur_round_mode = c->cfg.blur_round_mode; P.fp_contract = c->fp_contract;
+    P.iniTh = std::min(std::max(c->cfg.ini_th_fast, 0), 255); P.minTh = std::min(std::max(c->cfg.min_th_fast, 0), 255);      // cv::FAST clamps its threshold to [0, 255] (OpenCV 3.2 fast.cpp, FAST_t)
+    P.blur_round_mode = c->cfg.blur_round_mode; P.fp_contract = c->fp_contract;
     P.qt_maxn = c->qt_maxn; P.qt_maxcells = c->qt_maxcells; P.qt_scr = orbhip_quadtree_scr(c->qt_maxn, c->qt_maxcells);
     P.fc_pstride = fc_pstride(c); P.fc_prows = c->fc_maxph; P.fc_np = c->fc_np; P.fc_pbytes = 256 * c->fc_np; P.fc_dma = c->d_fc_dma; P.fc_sstride = 4 + 4 * ((std::max(c->fc_maxpw - 6, 0) + 3) / 4); P.fc_srows = std::max(c->fc_maxph - 6, 0) + 2;
     P.fc_listcap = 2 * ((std::max(c->fc_maxpw - 6, 0) + 3) / 4) * std::max(c->fc_maxph - 6, 0);       // pixel pairs of the largest cell

@@ -39,6 +39,25 @@ def test_extract_bit_exact_with_stages(backend, oracle, w, h, n, seed):
     ex.close()
 
 
+@pytest.mark.parametrize("ini,mn", [(0, 0), (1, 0), (255, 200), (255, 255), (300, -5), (-3, -9), (254, 0)])
+def test_fast_threshold_extremes(backend, oracle, ini, mn):
+    """iniThFAST / minThFAST at and beyond the ends of [0, 255]: cv::FAST clamps its threshold into that range (OpenCV 3.2 fast.cpp, FAST_t), so
+    the reference accepts any integer from the settings file.  Threshold 0 is where the one-polarity exact score needs its premise (a margin that
+    is not positive is never a corner) and the low-contrast frame sends most cells through the minThFAST call."""
+    w, h, n = 320, 240, 500
+    img = synth.frame(w, h, seed=3)
+    low = np.clip(110 + (img.astype(np.float32) - 128) * 0.1, 0, 255).astype(np.uint8)
+    ex = orb_slam2_amd.ORBextractor(n, 1.2, 4, ini, mn, w, h, library=backend)
+    ora = oracle.OracleExtractor(n, 1.2, 4, ini, mn)
+    for im in (img, low):
+        ko, do = ora.extract(im)
+        kg, dg = ex(im)
+        for l in range(4):
+            assert np.array_equal(ex.candidates(l), ora.candidates(l)), f"FAST candidates level {l}"
+        _same(kg, dg, ko, do)
+    ex.close()
+
+
 def test_dense_candidates_overflow_lds_keys(backend, oracle):
     """White noise: > 4096 FAST candidates on level 0, so the quadtree keeps its per-candidate keys in the HBM workspace
     instead of LDS, and the quadtree is ~40x over-subscribed."""
