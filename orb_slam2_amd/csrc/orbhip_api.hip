@@ -661,6 +661,19 @@ static orbhip_status pipeline_frames(orbhip_ctx* c, ExtractParams& P, int f0, in
         HIPCHK(hipStreamWaitEvent(s, c->ev_blur, 0));
     } else {
         if (pyr_done) HIPCHK(hipStreamWaitEvent(s, pyr_done, 0));
+        else if (sched == 6 && nf >= 64) {
+            // 6 (measurement): the pyramid as two half batches, one per stream - each half's seven dependent launches fill the other's tails and launch gaps;
+            // every other kernel as under 0 (alone on the GPU).  The scope's end event is recorded behind the join: its time is both halves'.
+            // Measured (gpurun sc6, B = 512): pyramid 0.605 -> 0.559 ms, but the previous call's matcher then runs beside FAST (0.826 -> 0.852 ms): 185.7 -> 187.3 k frames/s,
+            // nothing at B = 256 - not worth FAST's event time no longer being its own.  profiles/r03_exp_pyramid_two_half_batches.jsonl
+            hipStream_t bs = c->bstream;
+            const int nA = std::max(8, ((nf / 2) + 7) & ~7), nB = nf - nA;
+            ProfScope ps(c, K_PYRAMID, s);
+            HIPCHK(hipEventRecord(c->ev_start, s)); HIPCHK(hipStreamWaitEvent(bs, c->ev_start, 0));
+            launch_pyramid(c, P, nA, s);
+            P.frame0 = f0 + nA; launch_pyramid(c, P, nB, bs); P.frame0 = f0;
+            HIPCHK(hipEventRecord(c->ev_fast0, bs)); HIPCHK(hipStreamWaitEvent(s, c->ev_fast0, 0));
+        }
         else { ProfScope ps(c, K_PYRAMID, s); launch_pyramid(c, P, nf, s); }
         { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nf, s); }
         if (own_blur_stream && nf > 8) {      // (a handful of frames: the two event hops of the second stream cost more than the blur's 11 us - a single-frame call lost 75 us in them)
