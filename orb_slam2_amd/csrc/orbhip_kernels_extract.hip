@@ -1491,18 +1491,18 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
     float* s_pat = reinterpret_cast<float*>(&s_win[0][0][0]);
     static_assert(DS_KPW * DS_WDWORDS >= 16 * 64, "the pattern passes through wave 0's window buffers");
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-#pragma unroll
-    for (int k = 0; k < 4; k++) s_pat[256 * k + threadIdx.x] = P.patternf[256 * k + threadIdx.x];
-    __syncthreads();
-    float4 pt[4];                                                          // rBRIEF pattern of this lane's 4 tests as floats (x0, y0, x1, y1)
-#pragma unroll
-    for (int r = 0; r < 4; r++) { pt[r].x = s_pat[(0 * 4 + r) * 64 + lane]; pt[r].y = s_pat[(1 * 4 + r) * 64 + lane]; pt[r].z = s_pat[(2 * 4 + r) * 64 + lane]; pt[r].w = s_pat[(3 * 4 + r) * 64 + lane]; }
-    __syncthreads();
+    // A workgroup's start is a chain of memory latencies (pattern -> LDS -> barriers, slot metadata, orientation patches), and a wave lives for
+    // only ~11 us: the pattern, the metadata and the circle mask are requested together, and the patch loads are issued BEFORE the pattern's
+    // two barriers, so the pattern's trip through LDS runs under the patches' latency instead of in front of it (round 3: three latencies -> two).
+    // Nobody leaves before the second barrier: a wave without slots (live == false) loads in-bounds dummies and skips the patches.
     int tile, frame;
-    if (!xcd_frame_map((P.lvl_kp_per_frame + DS_WAVES * DS_KPW - 1) / (DS_WAVES * DS_KPW), P.nframes, tile, frame)) return;
-    frame += P.frame0;
-    const int slot0 = (tile * DS_WAVES + wave) * DS_KPW;
-    if (slot0 >= P.lvl_kp_per_frame) return;
+    bool live = xcd_frame_map((P.lvl_kp_per_frame + DS_WAVES * DS_KPW - 1) / (DS_WAVES * DS_KPW), P.nframes, tile, frame);
+    frame = live ? frame + P.frame0 : P.frame0;
+    const int slot0 = live ? (tile * DS_WAVES + wave) * DS_KPW : 0;
+    live = live && slot0 < P.lvl_kp_per_frame;
+    float pv[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) pv[k] = P.patternf[256 * k + threadIdx.x];
 #define U(x) __builtin_amdgcn_readfirstlane(x)
     // Everything the wave needs to know about its slots comes from ONE round of vector loads (lane l = level l, lane j = slot j) and is
     // then passed around with v_readlane: a chain of dependent "load, wait, readfirstlane" steps costs a memory latency each.
@@ -1523,6 +1523,8 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
     unsigned pmask[DS_PPASS];
 #pragma unroll
     for (int q = 0; q < DS_PPASS; q++) pmask[q] = P.ic_mask[q * 64 + lane];        // bytes inside the circle (row 31, dwords 8..15: 0)
+#pragma unroll
+    for (int k = 0; k < 4; k++) s_pat[256 * k + threadIdx.x] = pv[k];              // (the pattern's loads are the oldest outstanding ones: this waits for them alone)
     const unsigned ucoef = 0x03020100u + 0x04040404u * (unsigned)pd;       // u + 15 of the dword's four bytes
     int wrow[DS_WPASSES], wcol[DS_WPASSES];                                // window DMA: pass k, lane l fills dword 64k + l = (row, dword) of the 12-dword rows
 #pragma unroll
@@ -1544,9 +1546,9 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
             tot += nl;
             if (slot0 + lane >= kl) { myLevel = l; obase += nprev; koff = kl; nsel = nl; }
         }
-        if (slot0 == 0 && lane == 0) P.out_n[frame] = min(tot, P.out_cap);
+        if (live && slot0 == 0 && lane == 0) P.out_n[frame] = min(tot, P.out_cap);
         const int i = slot0 + lane - koff;
-        if (lane < DS_KPW && slot0 + lane < P.lvl_kp_per_frame && i < nsel && obase + i < P.out_cap) myOi = obase + i;
+        if (live && lane < DS_KPW && slot0 + lane < P.lvl_kp_per_frame && i < nsel && obase + i < P.out_cap) myOi = obase + i;
     }
     bool ok[DS_KPW]; int lv[DS_KPW], oi[DS_KPW]; unsigned vv[DS_KPW];
     int oi_first = -1;
@@ -1556,6 +1558,30 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
         ok[j] = oi[j] >= 0;
         if (ok[j] && oi_first < 0) oi_first = oi[j];
     }
+    // the orientation patches of the wave's slots: requested here, in front of the pattern's barriers
+    unsigned pw[DS_KPW][DS_PPASS];
+#pragma unroll
+    for (int j = 0; j < DS_KPW; j++) if (ok[j]) {
+        const int spitch = lv[j] == 0 ? P.img0_pitch : RL(g_pitch, lv[j]);
+        const ORBHIP_GLOBAL uint8_t* img = uniform_ptr(lv[j] == 0 ? P.img0 + (long long)frame * P.img0_frame_stride
+                                                                  : P.pyr + (long long)frame * P.plane_frame_bytes + RL(g_poff, lv[j]));
+        const int cx = vv[j] & 0xfff, cy = (vv[j] >> 12) & 0xfff;
+        const unsigned off = (unsigned)((cy - 15 + prow) * spitch + ((cx - 15) & ~3) + 4 * min(pd, 8));
+#pragma unroll
+        for (int q = 0; q < DS_PPASS; q++)                             // rows prow + 4q - 15 = -15 .. 16; row 16 is loaded (in bounds) and masked
+#if defined(DS_EXP_NO_PATCH)          // timing experiments of round 3 (results are wrong with any DS_EXP_* defined; profiles/r03_exp_describe_memory_ablation.jsonl)
+            pw[j][q] = (unsigned)(off + q);                    // no orientation-patch loads
+#elif defined(DS_EXP_PATCH_ONE_ROW)
+            pw[j][q] = *reinterpret_cast<const ORBHIP_GLOBAL unsigned*>(img + ((unsigned)(cy * spitch + ((cx - 15) & ~3) + 4 * min(pd, 8))));      // every patch row is row cy: the same instructions, 1-2 cache lines
+#else
+            pw[j][q] = *reinterpret_cast<const ORBHIP_GLOBAL unsigned*>(img + (off + (unsigned)(4 * q * spitch)));
+#endif
+    }
+    __syncthreads();
+    float4 pt[4];                                                          // rBRIEF pattern of this lane's 4 tests as floats (x0, y0, x1, y1)
+#pragma unroll
+    for (int r = 0; r < 4; r++) { pt[r].x = s_pat[(0 * 4 + r) * 64 + lane]; pt[r].y = s_pat[(1 * 4 + r) * 64 + lane]; pt[r].z = s_pat[(2 * 4 + r) * 64 + lane]; pt[r].w = s_pat[(3 * 4 + r) * 64 + lane]; }
+    __syncthreads();                                                       // (behind it the window buffers are the windows')
     if (oi_first < 0) return;
 
     // ---- 1. IC_Angle of every slot.  Every memory request of the wave is issued here, before anything is waited for: the patch loads of
@@ -1571,24 +1597,6 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
     };
     int M10 = 0, M01 = 0;
     {
-        unsigned pw[DS_KPW][DS_PPASS];
-#pragma unroll
-        for (int j = 0; j < DS_KPW; j++) if (ok[j]) {
-            const int spitch = lv[j] == 0 ? P.img0_pitch : RL(g_pitch, lv[j]);
-            const ORBHIP_GLOBAL uint8_t* img = uniform_ptr(lv[j] == 0 ? P.img0 + (long long)frame * P.img0_frame_stride
-                                                                      : P.pyr + (long long)frame * P.plane_frame_bytes + RL(g_poff, lv[j]));
-            const int cx = vv[j] & 0xfff, cy = (vv[j] >> 12) & 0xfff;
-            const unsigned off = (unsigned)((cy - 15 + prow) * spitch + ((cx - 15) & ~3) + 4 * min(pd, 8));
-#pragma unroll
-            for (int q = 0; q < DS_PPASS; q++)                             // rows prow + 4q - 15 = -15 .. 16; row 16 is loaded (in bounds) and masked
-#if defined(DS_EXP_NO_PATCH)          // timing experiments of round 3 (results are wrong with any DS_EXP_* defined; profiles/r03_exp_describe_memory_ablation.jsonl)
-                pw[j][q] = (unsigned)(off + q);                    // no orientation-patch loads
-#elif defined(DS_EXP_PATCH_ONE_ROW)
-                pw[j][q] = *reinterpret_cast<const ORBHIP_GLOBAL unsigned*>(img + ((unsigned)(cy * spitch + ((cx - 15) & ~3) + 4 * min(pd, 8))));      // every patch row is row cy: the same instructions, 1-2 cache lines
-#else
-                pw[j][q] = *reinterpret_cast<const ORBHIP_GLOBAL unsigned*>(img + (off + (unsigned)(4 * q * spitch)));
-#endif
-        }
 #ifndef DS_EXP_NO_WINDOW                                                 // (timing experiment: no blurred-window staging)
 #pragma unroll
         for (int j = 0; j < DS_KPW; j++) if (ok[j]) window_dma(lv[j], vv[j], s_win[wave][j]);
