@@ -26,11 +26,24 @@ _lib = None
 def available():
     return os.path.exists(PATH)
 
+def _locked_make(args):
+    """`make` under an exclusive file lock: pytest-xdist workers (and parallel tools) reach these builds at the same moment."""
+    import fcntl
+    import subprocess
+    import tempfile
+    with open(os.path.join(tempfile.gettempdir(), "orbhip_test_make.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            subprocess.check_call(["make"] + list(args))
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
+
+
 
 def build():
     import subprocess
     if os.path.isdir("/root/reference/src"):
-        subprocess.check_call(["make", "-C", HERE, "-s", "ref"])
+        _locked_make(["-C", HERE, "-s", "ref"])
     return available()
 
 
@@ -42,7 +55,7 @@ def build_dropin():
     """reference callers + drop-in extractor class on the CPU emulation of the kernels (needs /root/reference and tests/emu/liborbhip_emu.so)"""
     import subprocess
     if os.path.isdir("/root/reference/src"):
-        subprocess.check_call(["make", "-C", HERE, "-s", "dropin"])
+        _locked_make(["-C", HERE, "-s", "dropin"])
     return os.path.exists(DROPIN_PATH) and os.path.exists(DROPIN_FULL_PATH)
 
 
@@ -73,7 +86,7 @@ _dropin_gpu = {}
 def build_dropin_gpu():
     import subprocess
     if os.path.isdir("/root/reference/src"):
-        subprocess.check_call(["make", "-C", HERE, "-s", "dropin_gpu"])
+        _locked_make(["-C", HERE, "-s", "dropin_gpu"])
     return os.path.exists(DROPIN_GPU_PATH) and os.path.exists(DROPIN_FULL_GPU_PATH)
 
 

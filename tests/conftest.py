@@ -71,7 +71,8 @@ def emu_lib():
             pytest.fail(f"ORBHIP_EMU_LIB={override} does not exist")
         return override
     if not _newer(EMU_LIB, srcs):
-        subprocess.check_call(["make", "-C", CSRC, "-s", "emu"])
+        from oracle.orbslam_ref import _locked_make
+        _locked_make(["-C", CSRC, "-s", "emu"])
     return EMU_LIB
 
 

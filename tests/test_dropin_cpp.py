@@ -132,7 +132,8 @@ def _run(exe, tmp_path, oracle, threads=False, blur=None):
 
 
 def _build(target):
-    subprocess.check_call(["make", "-C", CPP, "-s", target])
+    from oracle.orbslam_ref import _locked_make
+    _locked_make(["-C", CPP, "-s", target])
     return os.path.join(CPP, target)
 
 
