@@ -1128,12 +1128,14 @@ __device__ __forceinline__ int qt_block_exscan(int* a, int n, int* scratch, int 
 int orbhip_quadtree_scr(int maxn, int maxcells) { return (std::max(maxn, maxcells) + 63) / 64 + 2; }
 size_t orbhip_quadtree_lds_bytes(int maxn, int maxcells)
 {
-    // ints: s_pref[maxcells+1] | s_slot[maxcells] | cnt[2][maxn] | cc[4*maxn] | a | b | sidx | split | best [maxn each] | scratch[scr] | misc[16]
+    // ints: cnt[2][maxn] | cc[4*maxn] | { a | b | sidx | split | best [maxn each] } = { s_pref[maxcells+1] | s_slot[maxcells] } | scratch[scr] | misc[16]
     // then map u16 [4*maxn] | depth u8 [2][maxn]
-    // KITTI shape: 27.3 KB -> five workgroups per CU.  Round 1 kept the per-candidate keys in LDS too (6 B x 4096 = 24 KB, 51.9 KB in all,
+    // The per-cell prefix sums and slots are only read while the candidates are copied into their dense order (phase A), the five per-node
+    // arrays only written from the first dividing pass on (three barriers later): they share one region.  KITTI shape: 23.7 KB (27.2 KB with
+    // both) -> six workgroups per CU instead of five.  Round 1 kept the per-candidate keys in LDS too (6 B x 4096 = 24 KB, 51.9 KB in all,
     // three per CU): beside the blur or FAST its three workgroups took 156 of a CU's 160 KB and starved the throughput kernel it was
     // supposed to run under; candidate k is only ever touched by thread k mod 256, so its path code and node now live in that thread's VGPRs.
-    const size_t ints = (size_t)(2 * maxcells + 1) + (size_t)maxn * (2 + 4 + 5) + orbhip_quadtree_scr(maxn, maxcells) + 16;
+    const size_t ints = (size_t)maxn * (2 + 4) + (size_t)std::max(2 * maxcells + 1, 5 * maxn) + orbhip_quadtree_scr(maxn, maxcells) + 16;
     return sizeof(int) * ints + (size_t)maxn * 4 * 2 + (((size_t)maxn * 2 + 3) & ~(size_t)3);
 }
 
@@ -1363,10 +1365,12 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(ExtractParams P)
     const int maxn = P.qt_maxn;
     HIP_DYNAMIC_SHARED(int, lds)
     QtLds L;
-    L.pref = lds; L.slot = L.pref + (P.qt_maxcells + 1);
-    L.cntA = L.slot + P.qt_maxcells; L.cntB = L.cntA + maxn;
+    L.cntA = lds; L.cntB = L.cntA + maxn;
     L.cc = L.cntB + maxn; L.a = L.cc + 4 * maxn; L.b = L.a + maxn; L.sidx = L.b + maxn; L.split = L.sidx + maxn;
-    L.best = L.split + maxn; L.scratch = L.best + maxn + 1; L.misc = L.scratch - 1 + P.qt_scr;      // scratch[-1] holds the scan total
+    L.best = L.split + maxn;
+    L.pref = L.a; L.slot = L.pref + (P.qt_maxcells + 1);       // phase A only: the region of the five per-node arrays (first written three barriers after phase A's last read)
+    const int shared = max(2 * P.qt_maxcells + 1, 5 * maxn);
+    L.scratch = L.a + shared + 1; L.misc = L.scratch - 1 + P.qt_scr;      // scratch[-1] holds the scan total
     L.map = reinterpret_cast<unsigned short*>(L.misc + 16);
     L.depA = reinterpret_cast<unsigned char*>(L.map + 4 * maxn); L.depB = L.depA + maxn;
 
