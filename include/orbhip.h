@@ -48,7 +48,7 @@ typedef struct {
     int32_t nfeatures;
     float scale_factor;
     int32_t nlevels;
-    int32_t ini_th_fast;
+    int32_t ini_th_fast;      /* any integer: used clamped to [0, 255], as cv::FAST does with the threshold the reference passes it (ORBextractor.cc:809-816) */
     int32_t min_th_fast;
     /* geometry of the frames this context processes (the reference re-allocates per call; here the pyramid,
        candidate and keypoint buffers are laid out once in HBM for a fixed size) */
