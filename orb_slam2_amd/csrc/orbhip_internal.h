@@ -89,6 +89,7 @@ struct ExtractParams {
     int qt_maxn;                                                           // LDS node capacity of the quadtree kernel
     int qt_maxcells;                                                       // max cells of one level
     int qt_scr;                                                            // ints of scan scratch in the quadtree's LDS layout
+    int qt_level0;                                                         // first level of this k_quadtree launch (the launcher sets it; one launch covers levels [qt_level0, qt_level0 + n))
     int fc_pstride, fc_prows, fc_sstride, fc_srows, fc_listcap;            // per-wave LDS layout of k_fast_cells (largest cell of the context)
     int fc_cell0, fc_ncells;                                               // cell range of this k_fast_cells launch
     int fc_pbytes, fc_np; const int4* fc_dma;                              // patch region = fc_np LDS-DMA passes of 256 bytes; (row, 4*column) of every (pass, lane)

@@ -1356,8 +1356,8 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(ExtractParams P)
     // level-major ids (still frame == id mod 8 for the XCD affinity): workgroups are dispatched in id order and a level-0
     // workgroup runs ~4x longer than a level-7 one, so the long ones start first and the short ones fill the tail
     const int nfg = (P.nframes + 7) >> 3, jj = (int)blockIdx.x >> 3;
-    const int level = jj / nfg;
-    int frame = (jj - level * nfg) * 8 + ((int)blockIdx.x & 7);
+    const int lrel = jj / nfg, level = P.qt_level0 + lrel;
+    int frame = (jj - lrel * nfg) * 8 + ((int)blockIdx.x & 7);
     if (frame >= P.nframes) return;
     frame += P.frame0;
     const int tid = threadIdx.x;
@@ -1397,7 +1397,20 @@ void orbhip_launch_quadtree(const ExtractParams& P, int nframes, hipStream_t s)
 {
     ExtractParams Q = P; Q.nframes = nframes;
     static const size_t pad = [] { const char* e = getenv("ORBHIP_QT_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }();      // experiment knob: unused LDS per workgroup = fewer resident quadtree workgroups per CU
-    hipLaunchKernelGGL(k_quadtree, dim3(xcd_grid(P.nlevels, nframes), 1, 1), dim3(QT_T, 1, 1), orbhip_quadtree_lds_bytes(P.qt_maxn, P.qt_maxcells) + pad, s, Q);
+    // ORBHIP_QT_SPLIT=k (measurement knob, batches of 64 frames and more): levels [0, k) in a launch of their own, the rest behind it on the same stream - the few
+    // long workgroups of the large levels then leave most of every CU to the blur on the other stream instead of filling it with the whole batch's 8 x B workgroups at once
+    static const int split = [] { const char* e = getenv("ORBHIP_QT_SPLIT"); return e ? atoi(e) : 0; }();
+    static const int split_min = [] { const char* e = getenv("ORBHIP_QT_SPLIT_MIN"); return e ? atoi(e) : 64; }();      // (tests lower it to reach the two-launch path with a handful of frames)
+    const size_t lds = orbhip_quadtree_lds_bytes(P.qt_maxn, P.qt_maxcells) + pad;
+    if (split > 0 && split < P.nlevels && nframes >= split_min) {
+        Q.qt_level0 = 0;
+        hipLaunchKernelGGL(k_quadtree, dim3(xcd_grid(split, nframes), 1, 1), dim3(QT_T, 1, 1), lds, s, Q);
+        Q.qt_level0 = split;
+        hipLaunchKernelGGL(k_quadtree, dim3(xcd_grid(P.nlevels - split, nframes), 1, 1), dim3(QT_T, 1, 1), lds, s, Q);
+        return;
+    }
+    Q.qt_level0 = 0;
+    hipLaunchKernelGGL(k_quadtree, dim3(xcd_grid(P.nlevels, nframes), 1, 1), dim3(QT_T, 1, 1), lds, s, Q);
 }
 
 // ------------------------------------------------------------------------------------------------ describe
