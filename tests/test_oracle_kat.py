@@ -278,3 +278,37 @@ def test_golden_fixtures(oracle):
     g = np.load(os.path.join(GOLDEN, "match_320x240_n300_seed21.npz"))
     n, m12, prev = oracle.search_for_initialization(g["k1"], g["d1"], g["k2"], g["d2"], 320, 240, window=100, nnratio=0.9)
     assert n == int(g["nmatches"]) and np.array_equal(m12, g["matches12"]) and prev.tobytes() == g["prev"].tobytes()
+
+
+def test_fast_score_needs_one_polarity_only():
+    """The identity k_fast_cells' exact-score stage rests on (orbhip_kernels_extract.hip, fast_score_pair): with ring values R_0..R_15, centre C and
+    m = max_k min(R_k, R_k+8), the cornerScore  S = max(C - min_arcs max R, max_arcs min R - C) - 1  equals the one-sided score of the pixel
+    (complemented when m <= C) whenever S >= 0, and the one-sided score is negative whenever S is - so "score >= threshold" and the score itself agree
+    for every threshold >= 0 (cv::FAST clamps its threshold to [0, 255]).  Checked on random, near-flat, arc-shaped, bright-arc-on-dark and two-valued rings."""
+    rng = np.random.default_rng(20260922)
+    idx = (np.arange(16)[:, None] + np.arange(9)[None, :]) % 16
+    n = 200_000
+
+    def both(R, C):
+        A = R[:, idx]
+        two_sided = np.maximum(C - A.max(axis=2).min(axis=1), A.min(axis=2).max(axis=1) - C) - 1
+        dark = np.minimum(R[:, :8], R[:, 8:]).max(axis=1) <= C
+        Q = np.where(dark[:, None], 255 - R, R)
+        one_sided = Q[:, idx].min(axis=2).max(axis=1) - np.where(dark, 255 - C, C) - 1
+        return two_sided, one_sided
+
+    cases = []
+    cases.append((rng.integers(0, 256, (n, 16)), rng.integers(0, 256, n)))
+    cases.append((rng.integers(100, 140, (n, 16)), rng.integers(100, 140, n)))
+    C = rng.integers(0, 256, n)
+    R = np.clip(C[:, None] + rng.integers(-40, 41, (n, 16)), 0, 255)
+    k = (np.arange(16)[None, :] - rng.integers(0, 16, n)[:, None]) % 16
+    arc = k < rng.integers(7, 12, n)[:, None]
+    cases.append((np.where(arc, np.clip(C + rng.choice([-1, 1], n) * rng.integers(1, 80, n), 0, 255)[:, None], R), C))
+    C = rng.integers(20, 236, n)
+    cases.append((np.where(arc, np.clip(C[:, None] + rng.integers(1, 60, (n, 16)), 0, 255), np.clip(C[:, None] - rng.integers(1, 60, (n, 16)), 0, 255)), C))
+    cases.append((rng.choice([0, 255], (n, 16)), rng.choice([0, 1, 127, 128, 254, 255], n)))
+    for R, C in cases:
+        s2, s1 = both(R.astype(np.int32), C.astype(np.int32))
+        assert np.array_equal(s1[s2 >= 0], s2[s2 >= 0])
+        assert (s1[s2 < 0] < 0).all()
