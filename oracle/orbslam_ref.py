@@ -132,6 +132,8 @@ def _bind(L):
         L.orbslam_ref_search_by_projection_kf.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, vp, i, vp]
         L.orbslam_ref_search_by_projection_reloc.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f, i, f, i, vp]
         L.orbslam_ref_search_by_sim3.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f, vp]
+        L.orbslam_ref_tracking_loop.argtypes = [i, vp, vp, i, i, i, i, f, i, i, i, f, f, f, f, f, f, vp, vp, i, i]
+        L.orbslam_ref_loop_get.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     return L
 
 
@@ -311,3 +313,46 @@ def search_by_sim3(f1, has1, X1, Y1, Z1, level1, desc1, f2, has2, X2, Y2, Z2, le
     a2 = [_u8(has2, f2.N), _f32(X2), _f32(Y2), _f32(Z2), np.ascontiguousarray(level2, np.int32), np.ascontiguousarray(desc2, np.uint8)]
     n = f1.L.orbslam_ref_search_by_sim3(f1.h, *[_p(v) for v in a1], f2.h, *[_p(v) for v in a2], _p(al), th, _p(m12))
     return n, m12
+
+
+class LoopFrame:
+    """what one frame of tracking_loop left behind: features, stereo columns, MapPoint::mnId per feature after TrackWithMotionModel
+    (mp_motion) and after SearchLocalPoints (mp_final), the counters and the wall time of the frame"""
+    FIELDS = ("N", "n_motion", "used_wide", "n_to_match", "n_local", "n_new_points", "n_local_points")
+
+    def same(self, o):
+        return (all(getattr(self, k) == getattr(o, k) for k in self.FIELDS) and self.keys.tobytes() == o.keys.tobytes() and self.keys_un.tobytes() == o.keys_un.tobytes()
+                and np.array_equal(self.desc, o.desc) and self.u_right.tobytes() == o.u_right.tobytes() and self.depth.tobytes() == o.depth.tobytes()
+                and np.array_equal(self.mp_motion, o.mp_motion) and np.array_equal(self.mp_final, o.mp_final))
+
+
+def tracking_loop(lefts, rights, Tcw, Tpred, nfeatures, fx, fy, cx, cy, bf, th_depth, scale=1.2, nlevels=8, ini_th=20, min_th=7, kf_every=5, capture=True, library=None):
+    """Tracking's per-frame sequence on a stereo stream through the reference's own Frame.cc / ORBmatcher.cc (orbslam_ref_tracking_loop in
+    orbslam_ref_wrap.cpp); `library` = another build of the same sources (the drop-in build).  -> list of LoopFrame"""
+    L = lib() if library is None else library
+    n = len(lefts)
+    lefts = [np.ascontiguousarray(a, np.uint8) for a in lefts]; rights = [np.ascontiguousarray(a, np.uint8) for a in rights]
+    h, w = lefts[0].shape
+    assert all(a.shape == (h, w) for a in lefts + rights)
+    lp = (C.c_void_p * n)(*[a.ctypes.data for a in lefts]); rp = (C.c_void_p * n)(*[a.ctypes.data for a in rights])
+    tc = np.ascontiguousarray(np.stack(Tcw), np.float32); tp = np.ascontiguousarray(np.stack(Tpred), np.float32)
+    assert tc.shape == (n, 4, 4) and tp.shape == (n, 4, 4)
+    RefFrame._geometry = None
+    RefFrame._geometry_other.clear()
+    got = L.orbslam_ref_tracking_loop(n, lp, rp, w, h, w, nfeatures, scale, nlevels, ini_th, min_th, fx, fy, cx, cy, bf, th_depth, _p(tp), _p(tc), kf_every, int(capture))
+    assert got == n
+    out = []
+    for k in range(n):
+        cnt = np.zeros(8, np.int32); ms = C.c_double()
+        L.orbslam_ref_loop_get(k, _p(cnt), C.byref(ms), None, None, None, None, None, None, None)
+        fr = LoopFrame()
+        for name, v in zip(LoopFrame.FIELDS, cnt):
+            setattr(fr, name, int(v))
+        fr.ms = ms.value
+        N = fr.N if capture else 0
+        fr.keys = np.zeros(N, KEYPOINT_DTYPE); fr.keys_un = np.zeros(N, KEYPOINT_DTYPE); fr.desc = np.zeros((N, 32), np.uint8)
+        fr.u_right = np.zeros(N, np.float32); fr.depth = np.zeros(N, np.float32); fr.mp_motion = np.full(N, -1, np.int32); fr.mp_final = np.full(N, -1, np.int32)
+        if N:
+            L.orbslam_ref_loop_get(k, None, None, _p(fr.keys), _p(fr.keys_un), _p(fr.desc), _p(fr.u_right), _p(fr.depth), _p(fr.mp_motion), _p(fr.mp_final))
+        out.append(fr)
+    return out

@@ -9,6 +9,9 @@
 // matrix algebra (include/cvlite/cvlite.h, CVLITE_ALGEBRA) and the MapPoint / KeyFrame members below — MapPoint.cc and
 // KeyFrame.cc pull in the whole map / optimiser, so the handful of accessors the two files call are defined here as plain
 // getters over the same members.  Test infrastructure only.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -67,6 +70,30 @@ MapPoint::MapPoint(const cv::Mat& Pos, KeyFrame* pRefKF, Map* pMap)
     mNormalVector = cv::Mat(cv::Mat::zeros(3, 1, CV_32F));
     mnId = nNextId++;
 }
+// MapPoint(Pos, pMap, pFrame, idxF)  (MapPoint.cc:60-85, restated without the map's creation mutex): normal, scale-invariance range and
+// descriptor from the frame that observes the point — the constructor Tracking::UpdateLastFrame uses, and what UpdateNormalAndDepth +
+// ComputeDistinctiveDescriptors (MapPoint.cc:237-328, 330-377) reduce to for a point with its one observation in that frame
+MapPoint::MapPoint(const cv::Mat& Pos, Map* pMap, Frame* pFrame, const int& idxF)
+    : mnFirstKFid(-1), mnFirstFrame(pFrame->mnId), nObs(0), mTrackProjX(0), mTrackProjY(0), mTrackProjXR(0), mbTrackInView(false), mnTrackScaleLevel(0),
+      mTrackViewCos(1.0f), mnTrackReferenceForFrame(0), mnLastFrameSeen(0), mnBALocalForKF(0), mnFuseCandidateForKF(0), mnLoopPointForKF(0),
+      mnCorrectedByKF(0), mnCorrectedReference(0), mnBAGlobalForKF(0), mpRefKF(static_cast<KeyFrame*>(NULL)), mnVisible(1), mnFound(1), mbBad(false),
+      mpReplaced(static_cast<MapPoint*>(NULL)), mfMinDistance(0), mfMaxDistance(0), mpMap(pMap)
+{
+    Pos.copyTo(mWorldPos);
+    cv::Mat Ow = pFrame->GetCameraCenter();
+    mNormalVector = mWorldPos - Ow;
+    mNormalVector = mNormalVector / cv::norm(mNormalVector);
+    cv::Mat PC = Pos - Ow;
+    const float dist = cv::norm(PC);
+    const int level = pFrame->mvKeysUn[idxF].octave;
+    const float levelScaleFactor = pFrame->mvScaleFactors[level];
+    const int nLevels = pFrame->mnScaleLevels;
+    mfMaxDistance = dist * levelScaleFactor;
+    mfMinDistance = mfMaxDistance / pFrame->mvScaleFactors[nLevels - 1];
+    pFrame->mDescriptors.row(idxF).copyTo(mDescriptor);
+    mnId = nNextId++;
+}
+static bool g_real_predict_scale = false;             // the front-end loop below: MapPoint.cc:407-421 instead of a level handed in by the test
 cv::Mat MapPoint::GetWorldPos() { return mWorldPos.clone(); }
 cv::Mat MapPoint::GetNormal() { return mNormalVector.clone(); }
 cv::Mat MapPoint::GetDescriptor() { return mDescriptor.clone(); }
@@ -83,7 +110,16 @@ std::vector<std::pair<MapPoint*, MapPoint*> > g_replaced;             // (replac
 void MapPoint::Replace(MapPoint* pMP) { g_replaced.push_back(std::make_pair(this, pMP)); }
 // the level is handed in by the test (the real function is a log of the distance ratio, MapPoint.cc:393-421; not on this path)
 int MapPoint::PredictScale(const float&, KeyFrame*) { return mnTrackScaleLevel; }
-int MapPoint::PredictScale(const float&, Frame*) { return mnTrackScaleLevel; }
+int MapPoint::PredictScale(const float& currentDist, Frame* pF)
+{
+    if (!g_real_predict_scale) return mnTrackScaleLevel;
+    const float ratio = mfMaxDistance / currentDist;                                    // MapPoint.cc:407-421
+    int nScale = ceil(log(ratio) / pF->mfLogScaleFactor);
+    if (nScale < 0) nScale = 0;
+    else if (nScale >= pF->mnScaleLevels) nScale = pF->mnScaleLevels - 1;
+    return nScale;
+}
+void MapPoint::IncreaseVisible(int n) { mnVisible += n; }
 void MapPoint::UpdateNormalAndDepth()
 {   // viewing direction = from the origin to the point, scale-invariance range wide open
     const float n = (float)cv::norm(mWorldPos);
@@ -544,6 +580,158 @@ int orbslam_ref_search_by_sim3(void* f1, const uint8_t* has1, const float* X1, c
     for (int i = 0; i < F1.N; i++) { std::map<MapPoint*, int>::iterator it = idx2.find(m12[i]); match12[i] = it == idx2.end() ? -1 : it->second; }
     delete kf1; delete kf2;
     return n;
+}
+
+// ---- the front-end loop: Tracking's per-frame sequence on a stereo stream, without the optimiser ------------------------------------
+// What Tracking::GrabImageStereo -> Track() does with every stereo pair (Tracking.cc:167-204, 267-503), restated around the reference's own
+// Frame / ORBmatcher code: the stereo Frame constructor (Frame.cc:61-117: two extractor threads, UndistortKeyPoints, ComputeStereoMatches,
+// AssignFeaturesToGrid), StereoInitialization on the first pair (Tracking.cc:509-561), then per frame TrackWithMotionModel (:867-928:
+// SetPose(mVelocity*mLastFrame.mTcw), SearchByProjection(Current, Last, th = 7, bMono = false), the 2*th retry under 20 matches),
+// TrackLocalMap's SearchLocalPoints (:1143-1193: Frame::isInFrustum on every local point, ORBmatcher(0.8).SearchByProjection(F, points, 1)),
+// CreateNewKeyFrame's stereo point creation (:1063-1133) every kf_every frames, and mLastFrame = Frame(mCurrentFrame) (:497).
+// Optimizer::PoseOptimization (g2o) is not part of this build: the pose it would return is handed in (Tcw[k]), as is the motion model's
+// prediction (Tpred[k]); no match is declared an outlier.  Both builds of this file (all-reference / drop-in) run the same statements here:
+// every difference between them is a difference of the extractor, the stereo matcher or the two projection matchers.
+struct LoopFrame {
+    int N = 0, nMotion = 0, usedWide = 0, nToMatch = 0, nLocal = 0, nNewPoints = 0, nLocalPoints = 0;
+    double ms = 0;
+    std::vector<cv::KeyPoint> keys, keysUn; std::vector<uint8_t> desc; std::vector<float> uRight, depth;
+    std::vector<int> mpMotion, mpFinal;         // MapPoint::mnId per feature after TrackWithMotionModel / after SearchLocalPoints (-1 = none)
+};
+static std::vector<LoopFrame> g_loop;
+
+static Frame* stereo_frame(const uint8_t* l, const uint8_t* r, int w, int h, int stride, Rig& rg, cv::Mat& K, cv::Mat& D, float bf, float thDepth, float fx)
+{
+    cv::Mat L(h, w, CV_8UC1, (void*)l, (size_t)stride), R(h, w, CV_8UC1, (void*)r, (size_t)stride);
+    void* mem = ::operator new(sizeof(Frame));                 // `mb` is read before it is assigned: pre-seeded as in orbslam_ref_frame_stereo (H7)
+    memset(mem, 0, sizeof(Frame));
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(mem) + ((char*)&((Frame*)mem)->mb - (char*)mem)) = bf / fx;
+    return new (mem) Frame(L, R, 0.0, rg.left, rg.right, NULL, K, D, bf, thDepth);
+}
+// the stereo branch of Tracking::CreateNewKeyFrame (Tracking.cc:1073-1131) / of StereoInitialization when all_points (:525-541)
+static int create_points(Frame& F, std::vector<MapPoint*>& local, bool all_points)
+{
+    std::vector<std::pair<float, int> > vDepthIdx;
+    vDepthIdx.reserve(F.N);
+    for (int i = 0; i < F.N; i++) { const float z = F.mvDepth[i]; if (z > 0) vDepthIdx.push_back(std::make_pair(z, i)); }
+    if (vDepthIdx.empty()) return 0;
+    if (!all_points) std::sort(vDepthIdx.begin(), vDepthIdx.end());
+    int nPoints = 0, created = 0;
+    for (size_t j = 0; j < vDepthIdx.size(); j++) {
+        const int i = vDepthIdx[j].second;
+        bool bCreateNew = false;
+        MapPoint* pMP = F.mvpMapPoints[i];
+        if (!pMP) bCreateNew = true;
+        else if (pMP->Observations() < 1) { bCreateNew = true; F.mvpMapPoints[i] = static_cast<MapPoint*>(NULL); }
+        if (bCreateNew) {
+            cv::Mat x3D = F.UnprojectStereo(i);
+            MapPoint* p = new MapPoint(x3D, static_cast<Map*>(NULL), &F, i);
+            p->nObs = 1;                                       // AddObservation(pKF, i) of a stereo key point would count 2; only `> 0` is ever read
+            g_keep.push_back(p); local.push_back(p);
+            F.mvpMapPoints[i] = p;
+            created++;
+        }
+        nPoints++;
+        if (!all_points && vDepthIdx[j].first > F.mThDepth && nPoints > 100) break;
+    }
+    return created;
+}
+static void ids_of(const Frame& F, std::vector<int>& out)
+{
+    out.resize(F.N);
+    for (int i = 0; i < F.N; i++) out[i] = F.mvpMapPoints[i] ? (int)F.mvpMapPoints[i]->mnId : -1;
+}
+
+// Runs nframes stereo pairs; capture != 0 keeps every frame's features and map-point assignments for orbslam_ref_loop_get (the copies are
+// made outside the timed span of each frame).  Returns the number of frames processed.
+int orbslam_ref_tracking_loop(int nframes, const uint8_t* const* left, const uint8_t* const* right, int w, int h, int stride,
+                              int nfeat, float scale, int nlevels, int ini, int mn, float fx, float fy, float cx, float cy, float bf, float thDepth,
+                              const float* Tpred /* nframes x 16 */, const float* Tcw /* nframes x 16 */, int kf_every, int capture)
+{
+    g_used = 0;
+    Frame::mbInitialComputations = true;
+    Frame::nNextId = 0; MapPoint::nNextId = 0;
+    ORB_SLAM2::g_real_predict_scale = true;
+    cv::Mat K = camera(fx, fy, cx, cy), D = cv::Mat(cv::Mat::zeros(4, 1, CV_32F));
+    Rig& rg = rig(nfeat, scale, nlevels, ini, mn);
+    attach_camera(rg.left, K, D); attach_camera(rg.right, K, D);
+    g_loop.assign(nframes, LoopFrame());
+    std::vector<MapPoint*> local;
+    Frame* last = NULL;
+    auto pose = [](const float* t) { cv::Mat T(4, 4, CV_32F); for (int i = 0; i < 16; i++) T.at<float>(i / 4, i % 4) = t[i]; return T; };
+    for (int k = 0; k < nframes; k++) {
+        LoopFrame& o = g_loop[k];
+        g_used = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        Frame* C = stereo_frame(left[k], right[k], w, h, stride, rg, K, D, bf, thDepth, fx);            // Tracking.cc:200
+        std::vector<int> afterMotion;
+        if (!last) {                                                                                     // StereoInitialization, Tracking.cc:509-561
+            C->SetPose(pose(Tcw));
+            o.nNewPoints = create_points(*C, local, true);
+        } else {
+            ORBmatcher matcher(0.9, true);                                                               // TrackWithMotionModel, Tracking.cc:867-928
+            C->SetPose(pose(Tpred + 16 * k));
+            std::fill(C->mvpMapPoints.begin(), C->mvpMapPoints.end(), static_cast<MapPoint*>(NULL));
+            const int th = 7;
+            int nmatches = matcher.SearchByProjection(*C, *last, th, false);
+            if (nmatches < 20) {
+                std::fill(C->mvpMapPoints.begin(), C->mvpMapPoints.end(), static_cast<MapPoint*>(NULL));
+                nmatches = matcher.SearchByProjection(*C, *last, 2 * th, false);
+                o.usedWide = 1;
+            }
+            o.nMotion = nmatches;
+            C->SetPose(pose(Tcw + 16 * k));                                                              // stands where Optimizer::PoseOptimization returns
+            if (capture) ids_of(*C, afterMotion);
+            for (std::vector<MapPoint*>::iterator vit = C->mvpMapPoints.begin(); vit != C->mvpMapPoints.end(); vit++) {   // SearchLocalPoints, Tracking.cc:1143-1193
+                MapPoint* pMP = *vit;
+                if (!pMP) continue;
+                if (pMP->isBad()) *vit = static_cast<MapPoint*>(NULL);
+                else { pMP->IncreaseVisible(); pMP->mnLastFrameSeen = C->mnId; pMP->mbTrackInView = false; }
+            }
+            int nToMatch = 0;
+            for (std::vector<MapPoint*>::iterator vit = local.begin(); vit != local.end(); vit++) {
+                MapPoint* pMP = *vit;
+                if (pMP->mnLastFrameSeen == C->mnId) continue;
+                if (pMP->isBad()) continue;
+                if (C->isInFrustum(pMP, 0.5)) { pMP->IncreaseVisible(); nToMatch++; }
+            }
+            o.nToMatch = nToMatch;
+            if (nToMatch > 0) { ORBmatcher m2(0.8); o.nLocal = m2.SearchByProjection(*C, local, 1); }
+            if (kf_every > 0 && k % kf_every == 0) o.nNewPoints = create_points(*C, local, false);       // NeedNewKeyFrame stands for "every kf_every frames"
+        }
+        Frame* copy = new Frame(*C);                                                                     // mLastFrame = Frame(mCurrentFrame), Tracking.cc:497
+        o.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        o.N = C->N; o.nLocalPoints = (int)local.size();
+        if (capture) {
+            o.keys = C->mvKeys; o.keysUn = C->mvKeysUn; o.uRight = C->mvuRight; o.depth = C->mvDepth;
+            o.desc.resize((size_t)C->N * 32);
+            for (int i = 0; i < C->N; i++) memcpy(&o.desc[(size_t)i * 32], C->mDescriptors.ptr(i), 32);
+            o.mpMotion = afterMotion; ids_of(*C, o.mpFinal);
+            if (o.mpMotion.empty()) o.mpMotion.assign(C->N, -1);
+        }
+        delete last; delete C;
+        last = copy;
+    }
+    delete last;
+    ORB_SLAM2::g_real_predict_scale = false;
+    return nframes;
+}
+// counts[8] = N, nMotion, usedWide, nToMatch, nLocal, nNewPoints, nLocalPoints, 0; every pointer may be NULL
+int orbslam_ref_loop_get(int k, int* counts, double* ms, void* keys, void* keysUn, uint8_t* desc, float* uRight, float* depth, int* mpMotion, int* mpFinal)
+{
+    if (k < 0 || k >= (int)g_loop.size()) return -1;
+    const LoopFrame& o = g_loop[k];
+    if (counts) { counts[0] = o.N; counts[1] = o.nMotion; counts[2] = o.usedWide; counts[3] = o.nToMatch; counts[4] = o.nLocal; counts[5] = o.nNewPoints; counts[6] = o.nLocalPoints; counts[7] = 0; }
+    if (ms) *ms = o.ms;
+    const size_t n = o.keys.size();
+    if (keys && n) memcpy(keys, &o.keys[0], n * 28);
+    if (keysUn && n) memcpy(keysUn, &o.keysUn[0], n * 28);
+    if (desc && n) memcpy(desc, &o.desc[0], n * 32);
+    if (uRight && n) memcpy(uRight, &o.uRight[0], n * 4);
+    if (depth && n) memcpy(depth, &o.depth[0], n * 4);
+    if (mpMotion && n) memcpy(mpMotion, &o.mpMotion[0], n * 4);
+    if (mpFinal && n) memcpy(mpFinal, &o.mpFinal[0], n * 4);
+    return (int)n;
 }
 
 }  // extern "C"

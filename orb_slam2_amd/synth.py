@@ -80,6 +80,44 @@ def sequence(width, height, nframes, seed=0):
     return [frame_from_scene(sc, width, height, t=t, seed=seed) for t in range(nframes)]
 
 
+def stereo_sequence(width, height, nframes, fx, bf, seed=0, disp_near=24, disp_far=8, step=(0.25, 0.125)):
+    """A rectified stereo stream of a two-layer scene with a known camera trajectory (the input of a front-end loop).
+
+    Two fronto-parallel textured planes: a far one (disparity disp_far px, depth bf/disp_far) and, in front of it over about a third of
+    the view, a near one (disparity disp_near px).  The camera translates by step = (x, y) baselines per frame without rotating, so a
+    plane of disparity d moves by exactly d*step px per frame (disparities divisible by 8 keep every shift an integer: each image is an
+    exact crop of the layer textures, composited near-over-far, plus fresh sensor noise).  Returns (lefts, rights, Tcw, Tpred):
+    Tcw[k] = the true world-to-camera pose of frame k, float32 4x4 (world = camera 0); Tpred[k] = the constant-velocity prediction
+    Tcw[k-1] * inv(Tcw[k-2]) * Tcw[k-1] a motion model would hand the matcher (k >= 2; Tpred[1] = Tcw[0], Tpred[0] = Tcw[0])."""
+    assert disp_near % 8 == 0 and disp_far % 8 == 0
+    margin = int(disp_near * (nframes * max(step) + 1)) + 16
+    far = scene(width, height, seed=seed, margin=margin)
+    near = scene(width, height, seed=seed + 1, margin=margin)
+    rng = np.random.default_rng(BASE_SEED + 555 + seed)
+    H, W = far.shape
+    mask = np.zeros((H, W), bool)                       # where the near plane exists, in its own texture coordinates
+    for _ in range(max(4, (W * H) // 90000)):
+        bw, bh = int(rng.integers(W // 10, W // 4)), int(rng.integers(H // 6, H // 2))
+        x0, y0 = int(rng.integers(0, W - bw)), int(rng.integers(0, H - bh))
+        mask[y0:y0 + bh, x0:x0 + bw] = True
+    b = bf / fx
+    lefts, rights, poses = [], [], []
+    for k in range(nframes):
+        for cam, out in ((0.0, lefts), (1.0, rights)):
+            px, py = k * step[0] + cam, k * step[1]     # camera position in baselines
+            def crop(tex, d):
+                ox, oy = margin // 2 + int(round(d * px)), margin // 2 + int(round(d * py))
+                return tex[oy:oy + height, ox:ox + width]
+            img = np.where(crop(mask, disp_near), crop(near, disp_near), crop(far, disp_far))
+            nrng = np.random.default_rng((BASE_SEED + seed) * 1000003 + 7919 * k + 31 * int(cam) + 5)
+            out.append(np.clip(np.rint(img) + nrng.integers(-6, 7, size=(height, width)), 0, 255).astype(np.uint8))
+        T = np.eye(4, dtype=np.float32)
+        T[0, 3], T[1, 3] = np.float32(-k * step[0] * b), np.float32(-k * step[1] * b)
+        poses.append(T)
+    pred = [poses[0], poses[0]] + [(poses[k - 1] @ np.linalg.inv(poses[k - 2]) @ poses[k - 1]).astype(np.float32) for k in range(2, nframes)]
+    return lefts, rights, poses, pred[:nframes]
+
+
 # degenerate cases the parity tests cover (SURVEY.md §8d)
 def zeros(width, height):
     return np.zeros((height, width), np.uint8)
