@@ -123,8 +123,16 @@ public:
     // (stereo_euroc.cc:97-98).  ExtractRectified(raw, ..) == operator()(remap(raw), ..); mvImagePyramid[0] is the rectified image.
     void SetRectification(const cv::Mat& M1, const cv::Mat& M2, int rawCols, int rawRows);
     void ExtractRectified(const cv::Mat& raw, std::vector<cv::KeyPoint>& keypoints, cv::OutputArray descriptors);
-    // HIP device this extractor runs on (default 0); takes effect at the next (re)creation of the device context.
+    // HIP device this extractor runs on (default: ORBHIP_DEVICE, else 0); SetDevice takes effect at the next (re)creation of the device context.
     void SetDevice(int device) { mnDevice = device; }
+    int Device() const { return mnDevice; }
+    // Which Frame the features in HBM belong to.  The forwarded Frame::UndistortKeyPoints (every Frame constructor calls it right after
+    // ExtractORB, Frame.cc:84, 136, 194) names the frame with its mnId; the next image replaces the state.  A matcher that is handed that
+    // Frame (Tracking's SearchByProjection calls on mCurrentFrame) then searches the resident key points / descriptors / mvuRight through the
+    // *_frame entry points of orbhip.h — only its queries cross PCIe — and any other Frame goes through host buffers as before.
+    void BindFrame(unsigned long frameId) { mnBoundFrame = frameId; mbBound = true; }
+    bool HoldsFrame(unsigned long frameId, int N) const { return mpCtx && mbFrameState && mbBound && mnBoundFrame == frameId && N == mnLastN; }
+    bool HoldsStereoColumns() const { return mbStereoColumns; }      // mvuRight of that frame is on the device too (ComputeStereoMatches / ComputeStereoFromRGBD ran)
 
 protected:
     friend class ORBimagePyramid;
@@ -156,6 +164,7 @@ protected:
     bool mbFrameState;                                           // the context's current state is that of one single-image call
     void RequireFrameState(const char* where) const;
     float mfScaleFactorArg;
+    unsigned long mnBoundFrame; bool mbBound, mbStereoColumns;
 };
 
 } // namespace ORB_SLAM2

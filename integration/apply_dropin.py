@@ -31,7 +31,7 @@ FORWARDS = {
         "{ mpORBextractorLeft->ComputeStereoMatches(*mpORBextractorRight, mbf, mb, N, mvuRight, mvDepth); }",
     # §2-3d': mvKeysUn / the image bounds / the depth lookup come from the extractor that just processed this frame
     r"void\s+Frame::UndistortKeyPoints\s*\(\s*\)":
-        "{ mpORBextractorLeft->UndistortKeyPoints(mvKeysUn); }",
+        "{ mpORBextractorLeft->UndistortKeyPoints(mvKeysUn); mpORBextractorLeft->BindFrame(mnId); }",
     r"void\s+Frame::ComputeImageBounds\s*\(\s*const\s+cv::Mat\s*&\s*imLeft\s*\)":
         "{ mpORBextractorLeft->ComputeImageBounds(imLeft.cols, imLeft.rows, mnMinX, mnMaxX, mnMinY, mnMaxY); }",
     r"void\s+Frame::ComputeStereoFromRGBD\s*\(\s*const\s+cv::Mat\s*&\s*imDepth\s*\)":
@@ -76,9 +76,7 @@ LOCAL_MAP_BODY = """{
     if(q.empty() || F.N==0) return 0;
     std::vector<unsigned char> blocked(F.N); std::vector<int> fq(F.N);
     for(int i=0;i<F.N;i++) blocked[i] = F.mvpMapPoints[i] && F.mvpMapPoints[i]->Observations()>0;
-    const orbhip_bounds bounds = {Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY};
-    if(orbhip_search_by_projection_bounds(0, (const orbhip_keypoint*)&F.mvKeysUn[0], F.mDescriptors.ptr<unsigned char>(), &F.mvuRight[0], &blocked[0], F.N, &bounds,
-                                          &q[0], &qd[0], (int)q.size(), 0, mfNNratio, TH_HIGH, 0, &fq[0], &nmatches)!=ORBHIP_OK) abort();
+    orbhip_projection_search(F, true, blocked, q, qd, 0, mfNNratio, TH_HIGH, false, fq, nmatches);
     for(int i=0;i<F.N;i++) if(fq[i]>=0) F.mvpMapPoints[i]=owner[fq[i]];
     return nmatches;
 }"""
@@ -96,10 +94,7 @@ LAST_FRAME_SEARCH = """if(!orbhip_q.empty() && CurrentFrame.N>0)
     {
         std::vector<unsigned char> blocked(CurrentFrame.N); std::vector<int> fq(CurrentFrame.N);
         for(int i=0;i<CurrentFrame.N;i++) blocked[i] = CurrentFrame.mvpMapPoints[i] && CurrentFrame.mvpMapPoints[i]->Observations()>0;
-        const orbhip_bounds bounds = {Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY};
-        if(orbhip_search_by_projection_bounds(0, (const orbhip_keypoint*)&CurrentFrame.mvKeysUn[0], CurrentFrame.mDescriptors.ptr<unsigned char>(), &CurrentFrame.mvuRight[0],
-                                              &blocked[0], CurrentFrame.N, &bounds, &orbhip_q[0], &orbhip_qd[0], (int)orbhip_q.size(), 1, mfNNratio, TH_HIGH,
-                                              mbCheckOrientation, &fq[0], &nmatches)!=ORBHIP_OK) abort();
+        orbhip_projection_search(CurrentFrame, true, blocked, orbhip_q, orbhip_qd, 1, mfNNratio, TH_HIGH, mbCheckOrientation, fq, nmatches);
         for(int i=0;i<CurrentFrame.N;i++)
         {
             if(fq[i]>=0) CurrentFrame.mvpMapPoints[i]=orbhip_owner[fq[i]];
@@ -152,8 +147,8 @@ KF_SIM3_SEARCH = """if(!orbhip_q.empty() && pKF->N>0)
         std::vector<unsigned char> blocked(pKF->N); std::vector<int> fq(pKF->N);
         for(int i=0;i<pKF->N;i++) blocked[i] = vpMatched[i]!=NULL;
         const orbhip_bounds bounds = {(float)pKF->mnMinX, (float)pKF->mnMinY, (float)pKF->mnMaxX, (float)pKF->mnMaxY};
-        if(orbhip_search_by_projection_bounds(0, (const orbhip_keypoint*)&pKF->mvKeysUn[0], pKF->mDescriptors.ptr<unsigned char>(), NULL, &blocked[0], pKF->N, &bounds,
-                                              &orbhip_q[0], &orbhip_qd[0], (int)orbhip_q.size(), 1, mfNNratio, TH_LOW, 0, &fq[0], &nmatches)!=ORBHIP_OK) abort();
+        orbhip_check(orbhip_search_by_projection_bounds(orbhip_default_device(), (const orbhip_keypoint*)&pKF->mvKeysUn[0], pKF->mDescriptors.ptr<unsigned char>(), NULL, &blocked[0], pKF->N, &bounds,
+                                              &orbhip_q[0], &orbhip_qd[0], (int)orbhip_q.size(), 1, mfNNratio, TH_LOW, 0, &fq[0], &nmatches));
         for(int i=0;i<pKF->N;i++) if(fq[i]>=0) vpMatched[i]=orbhip_owner[fq[i]];
     }
 
@@ -167,9 +162,7 @@ RELOC_SEARCH = """if(!orbhip_q.empty() && CurrentFrame.N>0)
     {
         std::vector<unsigned char> blocked(CurrentFrame.N); std::vector<int> fq(CurrentFrame.N);
         for(int i=0;i<CurrentFrame.N;i++) blocked[i] = CurrentFrame.mvpMapPoints[i]!=NULL;
-        const orbhip_bounds bounds = {Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY};
-        if(orbhip_search_by_projection_bounds(0, (const orbhip_keypoint*)&CurrentFrame.mvKeysUn[0], CurrentFrame.mDescriptors.ptr<unsigned char>(), NULL, &blocked[0], CurrentFrame.N,
-                                              &bounds, &orbhip_q[0], &orbhip_qd[0], (int)orbhip_q.size(), 1, mfNNratio, ORBdist, mbCheckOrientation, &fq[0], &nmatches)!=ORBHIP_OK) abort();
+        orbhip_projection_search(CurrentFrame, false, blocked, orbhip_q, orbhip_qd, 1, mfNNratio, ORBdist, mbCheckOrientation, fq, nmatches);
         for(int i=0;i<CurrentFrame.N;i++)
         {
             if(fq[i]>=0) CurrentFrame.mvpMapPoints[i]=orbhip_owner[fq[i]];
@@ -218,9 +211,9 @@ FUSE_SEARCH = """std::vector<int> orbhip_bi(orbhip_bq.size(), -1), orbhip_bd(orb
     if(!orbhip_bq.empty() && pKF->N>0)
     {
         const orbhip_bounds bounds = {(float)pKF->mnMinX, (float)pKF->mnMinY, (float)pKF->mnMaxX, (float)pKF->mnMaxY};
-        if(orbhip_search_best_in_window_bounds(0, (const orbhip_keypoint*)&pKF->mvKeysUn[0], pKF->mDescriptors.ptr<unsigned char>(), &pKF->mvuRight[0], pKF->N, &bounds,
+        orbhip_check(orbhip_search_best_in_window_bounds(orbhip_default_device(), (const orbhip_keypoint*)&pKF->mvKeysUn[0], pKF->mDescriptors.ptr<unsigned char>(), &pKF->mvuRight[0], pKF->N, &bounds,
                                                &pKF->mvInvLevelSigma2[0], (int)pKF->mvInvLevelSigma2.size(), &orbhip_bq[0], &orbhip_qd[0], (int)orbhip_bq.size(), 1,
-                                               &orbhip_bi[0], &orbhip_bd[0])!=ORBHIP_OK) abort();
+                                               &orbhip_bi[0], &orbhip_bd[0]));
     }
     for(size_t orbhip_k=0; orbhip_k<orbhip_owner.size(); orbhip_k++)
     {
@@ -276,9 +269,9 @@ BOW_KF_FRAME_BODY = """{
     std::vector<unsigned int> node1, feat1, node2, feat2; std::vector<int> off1, off2;
     orbhip_flatten(pKF->mFeatVec, node1, off1, feat1); orbhip_flatten(F.mFeatVec, node2, off2, feat2);
     std::vector<int> m12(n1, -1); int nmatches=0;
-    if(orbhip_search_by_bow(0, 0, pKF->mDescriptors.ptr<unsigned char>(), &ang1[0], &valid1[0], n1, &node1[0], &off1[0], &feat1[0], (int)pKF->mFeatVec.size(),
+    orbhip_check(orbhip_search_by_bow(orbhip_default_device(), 0, pKF->mDescriptors.ptr<unsigned char>(), &ang1[0], &valid1[0], n1, &node1[0], &off1[0], &feat1[0], (int)pKF->mFeatVec.size(),
                             F.mDescriptors.ptr<unsigned char>(), &ang2[0], NULL, n2, &node2[0], &off2[0], &feat2[0], (int)F.mFeatVec.size(),
-                            mfNNratio, mbCheckOrientation, &m12[0], &nmatches)!=ORBHIP_OK) abort();
+                            mfNNratio, mbCheckOrientation, &m12[0], &nmatches));
     for(int i=0;i<n1;i++) if(m12[i]>=0) vpMapPointMatches[m12[i]] = vpMapPointsKF[i];
     return nmatches;
 }"""
@@ -295,9 +288,9 @@ BOW_KF_KF_BODY = """{
     std::vector<unsigned int> node1, feat1, node2, feat2; std::vector<int> off1, off2;
     orbhip_flatten(pKF1->mFeatVec, node1, off1, feat1); orbhip_flatten(pKF2->mFeatVec, node2, off2, feat2);
     std::vector<int> m12(n1, -1); int nmatches=0;
-    if(orbhip_search_by_bow(0, 1, pKF1->mDescriptors.ptr<unsigned char>(), &ang1[0], &valid1[0], n1, &node1[0], &off1[0], &feat1[0], (int)pKF1->mFeatVec.size(),
+    orbhip_check(orbhip_search_by_bow(orbhip_default_device(), 1, pKF1->mDescriptors.ptr<unsigned char>(), &ang1[0], &valid1[0], n1, &node1[0], &off1[0], &feat1[0], (int)pKF1->mFeatVec.size(),
                             pKF2->mDescriptors.ptr<unsigned char>(), &ang2[0], &valid2[0], n2, &node2[0], &off2[0], &feat2[0], (int)pKF2->mFeatVec.size(),
-                            mfNNratio, mbCheckOrientation, &m12[0], &nmatches)!=ORBHIP_OK) abort();
+                            mfNNratio, mbCheckOrientation, &m12[0], &nmatches));
     for(int i=0;i<n1;i++) if(m12[i]>=0) vpMatches12[i] = vpMapPoints2[m12[i]];
     return nmatches;
 }"""
@@ -318,10 +311,10 @@ TRI_SEARCH = """{
             std::vector<unsigned int> node1, feat1, node2, feat2; std::vector<int> off1, off2;
             orbhip_flatten(vFeatVec1, node1, off1, feat1); orbhip_flatten(vFeatVec2, node2, off2, feat2);
             float F12flat[9]; for(int r=0;r<3;r++) for(int c=0;c<3;c++) F12flat[3*r+c] = F12.at<float>(r,c);
-            if(orbhip_search_for_triangulation(0, pKF1->mDescriptors.ptr<unsigned char>(), &kp1[0], &has1[0], &st1[0], n1, &node1[0], &off1[0], &feat1[0], (int)vFeatVec1.size(),
+            orbhip_check(orbhip_search_for_triangulation(orbhip_default_device(), pKF1->mDescriptors.ptr<unsigned char>(), &kp1[0], &has1[0], &st1[0], n1, &node1[0], &off1[0], &feat1[0], (int)vFeatVec1.size(),
                                                pKF2->mDescriptors.ptr<unsigned char>(), &kp2[0], &has2[0], &st2[0], n2, &node2[0], &off2[0], &feat2[0], (int)vFeatVec2.size(),
                                                F12flat, ex, ey, &pKF2->mvScaleFactors[0], &pKF2->mvLevelSigma2[0], (int)pKF2->mvScaleFactors.size(),
-                                               bOnlyStereo, mbCheckOrientation, &vMatches12[0], &nmatches)!=ORBHIP_OK) abort();
+                                               bOnlyStereo, mbCheckOrientation, &vMatches12[0], &nmatches));
         }
     }
 
@@ -361,8 +354,8 @@ SIM3_SEARCH = """{
             if(nq==0 || kf->N==0) continue;
             std::vector<int> bi(nq), bd(nq);
             const orbhip_bounds bounds = {(float)kf->mnMinX, (float)kf->mnMinY, (float)kf->mnMaxX, (float)kf->mnMaxY};
-            if(orbhip_search_best_in_window_bounds(0, (const orbhip_keypoint*)&kf->mvKeysUn[0], kf->mDescriptors.ptr<unsigned char>(), NULL, kf->N, &bounds, NULL, 0,
-                                                   &(*orbhip_bq[p])[0], &(*orbhip_qd[p])[0], nq, 0, &bi[0], &bd[0])!=ORBHIP_OK) abort();
+            orbhip_check(orbhip_search_best_in_window_bounds(orbhip_default_device(), (const orbhip_keypoint*)&kf->mvKeysUn[0], kf->mDescriptors.ptr<unsigned char>(), NULL, kf->N, &bounds, NULL, 0,
+                                                   &(*orbhip_bq[p])[0], &(*orbhip_qd[p])[0], nq, 0, &bi[0], &bd[0]));
             for(int k=0;k<nq;k++) if(bd[k]<=TH_HIGH) (*orbhip_out[p])[(*orbhip_ix[p])[k]] = bi[k];
         }
     }
@@ -397,8 +390,8 @@ FUSE_SIM3_SEARCH = """std::vector<int> orbhip_bi(orbhip_bq.size(), -1), orbhip_b
     if(!orbhip_bq.empty() && pKF->N>0)
     {
         const orbhip_bounds bounds = {(float)pKF->mnMinX, (float)pKF->mnMinY, (float)pKF->mnMaxX, (float)pKF->mnMaxY};
-        if(orbhip_search_best_in_window_bounds(0, (const orbhip_keypoint*)&pKF->mvKeysUn[0], pKF->mDescriptors.ptr<unsigned char>(), NULL, pKF->N, &bounds, NULL, 0,
-                                               &orbhip_bq[0], &orbhip_qd[0], (int)orbhip_bq.size(), 0, &orbhip_bi[0], &orbhip_bd[0])!=ORBHIP_OK) abort();
+        orbhip_check(orbhip_search_best_in_window_bounds(orbhip_default_device(), (const orbhip_keypoint*)&pKF->mvKeysUn[0], pKF->mDescriptors.ptr<unsigned char>(), NULL, pKF->N, &bounds, NULL, 0,
+                                               &orbhip_bq[0], &orbhip_qd[0], (int)orbhip_bq.size(), 0, &orbhip_bi[0], &orbhip_bd[0]));
     }
     for(size_t orbhip_k=0; orbhip_k<orbhip_owner.size(); orbhip_k++)
     {
@@ -439,19 +432,39 @@ INIT_BODY = """{
     if(n1==0) return 0;
     const orbhip_bounds bounds = {Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY};
     int nmatches = 0;
-    if(orbhip_search_for_initialization_bounds(orbhip_device(), reinterpret_cast<const orbhip_keypoint*>(&F1.mvKeysUn[0]), F1.mDescriptors.ptr<unsigned char>(), n1,
+    orbhip_check(orbhip_search_for_initialization_bounds(F1.mpORBextractorLeft ? F1.mpORBextractorLeft->Device() : orbhip_default_device(), reinterpret_cast<const orbhip_keypoint*>(&F1.mvKeysUn[0]), F1.mDescriptors.ptr<unsigned char>(), n1,
             n2 ? reinterpret_cast<const orbhip_keypoint*>(&F2.mvKeysUn[0]) : NULL, n2 ? F2.mDescriptors.ptr<unsigned char>() : NULL, n2,
-            &bounds, reinterpret_cast<float*>(&vbPrevMatched[0]), &vnMatches12[0], windowSize, mfNNratio, mbCheckOrientation, &nmatches)!=ORBHIP_OK) abort();
+            &bounds, reinterpret_cast<float*>(&vbPrevMatched[0]), &vnMatches12[0], windowSize, mfNNratio, mbCheckOrientation, &nmatches));
     return nmatches;
 }"""
 
 
 PROLOGUE = """#include "orbhip.h"
 #include <cstdlib>
-#include <stdexcept>
 #include <string>
-static int orbhip_device() { static const int d = getenv("ORBHIP_DEVICE") ? atoi(getenv("ORBHIP_DEVICE")) : 0; return d; }
-static void orbhip_fail() { throw std::runtime_error(std::string("ORBmatcher: ") + orbhip_last_error()); }
+"""
+# helpers every inserted call goes through (placed inside namespace ORB_SLAM2, after the reference's own includes):
+#   failures are thrown as ORBhipError (include/ORBextractor.h) like the extractor's, never abort();
+#   the device is the searched frame's extractor's, or ORBHIP_DEVICE (the class's own default) where a KeyFrame is searched;
+#   a Frame whose features the extractor still holds in HBM (Tracking's calls on mCurrentFrame) is searched there: only the queries travel.
+HELPERS = """
+static int orbhip_default_device() { static const int d = getenv("ORBHIP_DEVICE") ? atoi(getenv("ORBHIP_DEVICE")) : 0; return d; }
+static void orbhip_check(orbhip_status st) { if(st!=ORBHIP_OK) throw ORBhipError(std::string("ORBmatcher: ") + orbhip_last_error()); }
+static void orbhip_projection_search(Frame &F, bool bUseRight, const std::vector<unsigned char> &blocked, const std::vector<orbhip_proj_query> &q,
+                                     const std::vector<unsigned char> &qd, int mode, float nnratio, int thHigh, bool bCheckOri, std::vector<int> &fq, int &nmatches)
+{
+    ORBextractor* ex = F.mpORBextractorLeft;
+    if(ex && ex->HoldsFrame(F.mnId, F.N))
+        orbhip_check(orbhip_search_by_projection_frame(ex->Context(), 0, F.N, bUseRight && ex->HoldsStereoColumns(), &blocked[0], &q[0], &qd[0], (int)q.size(),
+                                                       mode, nnratio, thHigh, bCheckOri, &fq[0], &nmatches));
+    else
+    {
+        const orbhip_bounds bounds = {Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY};
+        orbhip_check(orbhip_search_by_projection_bounds(ex ? ex->Device() : orbhip_default_device(), (const orbhip_keypoint*)&F.mvKeysUn[0], F.mDescriptors.ptr<unsigned char>(),
+                                                        bUseRight ? &F.mvuRight[0] : NULL, &blocked[0], F.N, &bounds, &q[0], &qd[0], (int)q.size(),
+                                                        mode, nnratio, thHigh, bCheckOri, &fq[0], &nmatches));
+    }
+}
 """
 
 
@@ -472,7 +485,7 @@ def patch_matcher(src, map_free_members=True):
     src = patch_fuse_sim3(src)
     k = src.index("namespace ORB_SLAM2")
     k = src.index("{", k) + 1
-    src = src[:k] + BOW_HELPERS + src[k:]
+    src = src[:k] + HELPERS + BOW_HELPERS + src[k:]
     src = patch_projection_member(src, KF_SIM3_SIG, "int nmatches=0;", "const vector<size_t> vIndices = pKF->GetFeaturesInArea(u,v,radius);", "if(bestDist<=TH_LOW)",
                                   KF_SIM3_QUERY, KF_SIM3_SEARCH, None)
     src = patch_projection_member(src, RELOC_SIG, "int nmatches = 0;", "const vector<size_t> vIndices2 = CurrentFrame.GetFeaturesInArea(u, v, radius, nPredictedLevel-1, nPredictedLevel+1);",
@@ -480,9 +493,6 @@ def patch_matcher(src, map_free_members=True):
     if map_free_members:
         src = replace_body(src, DESC_DIST_SIG, DESC_DIST_BODY)
         src = replace_body(src, INIT_SIG, INIT_BODY)
-    # every inserted call: the device of ORBHIP_DEVICE (default 0), failures thrown (never swallowed, never abort(): include/ORBextractor.h)
-    src = re.sub(r"(orbhip_[a-z_]+\()0, ", r"\1orbhip_device(), ", src)
-    src = src.replace("!=ORBHIP_OK) abort();", "!=ORBHIP_OK) orbhip_fail();")
     return PROLOGUE + src
 
 

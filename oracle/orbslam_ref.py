@@ -343,12 +343,12 @@ def tracking_loop(lefts, rights, Tcw, Tpred, nfeatures, fx, fy, cx, cy, bf, th_d
     assert got == n
     out = []
     for k in range(n):
-        cnt = np.zeros(8, np.int32); ms = C.c_double()
-        L.orbslam_ref_loop_get(k, _p(cnt), C.byref(ms), None, None, None, None, None, None, None)
+        cnt = np.zeros(8, np.int32); ms = np.zeros(4, np.float64)
+        L.orbslam_ref_loop_get(k, _p(cnt), _p(ms), None, None, None, None, None, None, None)
         fr = LoopFrame()
         for name, v in zip(LoopFrame.FIELDS, cnt):
             setattr(fr, name, int(v))
-        fr.ms = ms.value
+        fr.ms, fr.ms_ctor, fr.ms_motion, fr.ms_local = (float(v) for v in ms)
         N = fr.N if capture else 0
         fr.keys = np.zeros(N, KEYPOINT_DTYPE); fr.keys_un = np.zeros(N, KEYPOINT_DTYPE); fr.desc = np.zeros((N, 32), np.uint8)
         fr.u_right = np.zeros(N, np.float32); fr.depth = np.zeros(N, np.float32); fr.mp_motion = np.full(N, -1, np.int32); fr.mp_final = np.full(N, -1, np.int32)

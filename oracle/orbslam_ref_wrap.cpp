@@ -594,7 +594,7 @@ int orbslam_ref_search_by_sim3(void* f1, const uint8_t* has1, const float* X1, c
 // every difference between them is a difference of the extractor, the stereo matcher or the two projection matchers.
 struct LoopFrame {
     int N = 0, nMotion = 0, usedWide = 0, nToMatch = 0, nLocal = 0, nNewPoints = 0, nLocalPoints = 0;
-    double ms = 0;
+    double ms = 0, msCtor = 0, msMotion = 0, msLocal = 0;      // whole frame; Frame constructor; TrackWithMotionModel's search; SearchLocalPoints
     std::vector<cv::KeyPoint> keys, keysUn; std::vector<uint8_t> desc; std::vector<float> uRight, depth;
     std::vector<int> mpMotion, mpFinal;         // MapPoint::mnId per feature after TrackWithMotionModel / after SearchLocalPoints (-1 = none)
 };
@@ -663,7 +663,10 @@ int orbslam_ref_tracking_loop(int nframes, const uint8_t* const* left, const uin
         LoopFrame& o = g_loop[k];
         g_used = 0;
         const auto t0 = std::chrono::steady_clock::now();
+        double t0skip = 0;                                                                                // the capture copy between the two matchers is not the loop's
         Frame* C = stereo_frame(left[k], right[k], w, h, stride, rg, K, D, bf, thDepth, fx);            // Tracking.cc:200
+        const auto t1 = std::chrono::steady_clock::now();
+        o.msCtor = std::chrono::duration<double, std::milli>(t1 - t0).count();
         std::vector<int> afterMotion;
         if (!last) {                                                                                     // StereoInitialization, Tracking.cc:509-561
             C->SetPose(pose(Tcw));
@@ -681,7 +684,10 @@ int orbslam_ref_tracking_loop(int nframes, const uint8_t* const* left, const uin
             }
             o.nMotion = nmatches;
             C->SetPose(pose(Tcw + 16 * k));                                                              // stands where Optimizer::PoseOptimization returns
+            const auto t2 = std::chrono::steady_clock::now();
+            o.msMotion = std::chrono::duration<double, std::milli>(t2 - t1).count();
             if (capture) ids_of(*C, afterMotion);
+            const auto t3 = std::chrono::steady_clock::now();
             for (std::vector<MapPoint*>::iterator vit = C->mvpMapPoints.begin(); vit != C->mvpMapPoints.end(); vit++) {   // SearchLocalPoints, Tracking.cc:1143-1193
                 MapPoint* pMP = *vit;
                 if (!pMP) continue;
@@ -697,10 +703,12 @@ int orbslam_ref_tracking_loop(int nframes, const uint8_t* const* left, const uin
             }
             o.nToMatch = nToMatch;
             if (nToMatch > 0) { ORBmatcher m2(0.8); o.nLocal = m2.SearchByProjection(*C, local, 1); }
+            o.msLocal = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t3).count();
+            t0skip = std::chrono::duration<double, std::milli>(t3 - t2).count();
             if (kf_every > 0 && k % kf_every == 0) o.nNewPoints = create_points(*C, local, false);       // NeedNewKeyFrame stands for "every kf_every frames"
         }
         Frame* copy = new Frame(*C);                                                                     // mLastFrame = Frame(mCurrentFrame), Tracking.cc:497
-        o.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        o.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() - t0skip;
         o.N = C->N; o.nLocalPoints = (int)local.size();
         if (capture) {
             o.keys = C->mvKeys; o.keysUn = C->mvKeysUn; o.uRight = C->mvuRight; o.depth = C->mvDepth;
@@ -717,12 +725,12 @@ int orbslam_ref_tracking_loop(int nframes, const uint8_t* const* left, const uin
     return nframes;
 }
 // counts[8] = N, nMotion, usedWide, nToMatch, nLocal, nNewPoints, nLocalPoints, 0; every pointer may be NULL
-int orbslam_ref_loop_get(int k, int* counts, double* ms, void* keys, void* keysUn, uint8_t* desc, float* uRight, float* depth, int* mpMotion, int* mpFinal)
+int orbslam_ref_loop_get(int k, int* counts, double* ms /* 4: frame, constructor, motion-model search, local-map search */, void* keys, void* keysUn, uint8_t* desc, float* uRight, float* depth, int* mpMotion, int* mpFinal)
 {
     if (k < 0 || k >= (int)g_loop.size()) return -1;
     const LoopFrame& o = g_loop[k];
     if (counts) { counts[0] = o.N; counts[1] = o.nMotion; counts[2] = o.usedWide; counts[3] = o.nToMatch; counts[4] = o.nLocal; counts[5] = o.nNewPoints; counts[6] = o.nLocalPoints; counts[7] = 0; }
-    if (ms) *ms = o.ms;
+    if (ms) { ms[0] = o.ms; ms[1] = o.msCtor; ms[2] = o.msMotion; ms[3] = o.msLocal; }
     const size_t n = o.keys.size();
     if (keys && n) memcpy(keys, &o.keys[0], n * 28);
     if (keysUn && n) memcpy(keysUn, &o.keysUn[0], n * 28);

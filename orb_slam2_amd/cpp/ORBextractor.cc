@@ -31,7 +31,7 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int
 #else
       mnFpContract(0),
 #endif
-      mvTicketSizes(4, 0), mbDownloadPyramid(false), mnPendingTickets(0), mbFrameState(false), mfScaleFactorArg(_scaleFactor)
+      mvTicketSizes(4, 0), mbDownloadPyramid(false), mnPendingTickets(0), mbFrameState(false), mfScaleFactorArg(_scaleFactor), mnBoundFrame(0), mbBound(false), mbStereoColumns(false)
 {
     memset(mCamera, 0, sizeof mCamera);
     mvScaleFactor.resize(nlevels); mvLevelSigma2.resize(nlevels);
@@ -186,6 +186,7 @@ void ORBextractor::ComputeStereoFromRGBD(const cv::Mat& imDepth, float depthFact
     assert(imDepth.type() == CV_32F || imDepth.type() == CV_16U);
     const void* maps[1] = {imDepth.data};
     if (orbhip_compute_stereo_from_rgbd(mpCtx, 1, maps, (int)imDepth.step, imDepth.type() == CV_32F ? 0 : 1, depthFactor, mbf, &mvuRight[0], &mvDepth[0], N) != ORBHIP_OK) Fail("ORBextractor::ComputeStereoFromRGBD");
+    mbStereoColumns = true;
 }
 
 void ORBextractor::SetRectification(const cv::Mat& M1, const cv::Mat& M2, int rawCols, int rawRows)
@@ -216,7 +217,7 @@ void ORBextractor::ExtractRectified(const cv::Mat& raw, std::vector<cv::KeyPoint
 
 void ORBextractor::Deliver(int n, const std::vector<unsigned char>& desc, std::vector<cv::KeyPoint>& _keypoints, cv::OutputArray _descriptors)
 {
-    mnLastN = n; mbFrameState = true;
+    mnLastN = n; mbFrameState = true; mbBound = false; mbStereoColumns = false;
     _keypoints.resize(n);
     if (n == 0) _descriptors.release();                          // ORBextractor.cc:1064-1065
     else {
@@ -262,7 +263,7 @@ void ORBextractor::Collect(int ticket, std::vector<std::vector<cv::KeyPoint> >& 
         descriptors[i].create(cnt[i], 32, CV_8U);
         for (int r = 0; r < cnt[i]; r++) memcpy(descriptors[i].ptr(r), &desc[((size_t)i * cap + r) * 32], 32);
     }
-    mnLastN = 0; mbFrameState = false;                            // the context's planes / key points are some batch's, not one image's
+    mnLastN = 0; mbFrameState = false; mbBound = false; mbStereoColumns = false;                            // the context's planes / key points are some batch's, not one image's
     std::lock_guard<std::mutex> lock(mvImagePyramid.mMutex);
     mvImagePyramid.mbStale = true;
 }
@@ -274,6 +275,7 @@ void ORBextractor::ComputeStereoMatches(ORBextractor& right, float mbf, float mb
     if (N == 0 || !mpCtx || !right.mpCtx) return;
     RequireFrameState("ORBextractor::ComputeStereoMatches"); right.RequireFrameState("ORBextractor::ComputeStereoMatches (right)");
     if (orbhip_compute_stereo_matches(mpCtx, right.mpCtx, 1, mbf, mb, &mvuRight[0], &mvDepth[0], N) != ORBHIP_OK) Fail("ORBextractor::ComputeStereoMatches");
+    mbStereoColumns = true;
 }
 
 } // namespace ORB_SLAM2

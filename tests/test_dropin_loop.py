@@ -68,4 +68,6 @@ def test_front_end_loop_baseline_shapes(builds, request, name, cfg):
         pytest.skip("one shape is enough for the steps 1-3 build")
     ref, got = run_and_compare(S, D, cfg, nframes=24, seed=5, kf_every=5)
     ms_ref, ms_got = np.median([f.ms for f in ref[1:]]), np.median([f.ms for f in got[1:]])
-    print(f"\n[dropin_loop] {request.node.name}: {cfg['w']}x{cfg['h']} / {cfg['n']}: reference {ms_ref:.2f} ms/frame, drop-in {ms_got:.3f} ms/frame ({ms_ref / ms_got:.0f}x), bit-exact over 24 frames")
+    part = lambda fs: " + ".join(f"{np.median([getattr(f, k) for f in fs[1:]]):.3f}" for k in ("ms_ctor", "ms_motion", "ms_local"))
+    print(f"\n[dropin_loop] {request.node.name}: {cfg['w']}x{cfg['h']} / {cfg['n']}: reference {ms_ref:.2f} ms/frame ({part(ref)}), drop-in {ms_got:.3f} ms/frame ({part(got)}: "
+          f"Frame constructor + motion-model search + local-map search), {ms_ref / ms_got:.0f}x, bit-exact over 24 frames")
