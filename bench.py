@@ -22,6 +22,9 @@ Extra objects in the JSON line:
   runtime       the HIP runtime the library ran on (versions, file), every libamdhip64 mapped into the process (must be one)
   roofline      dominant kernel (by HIP-event time measured inside the timed region on the library's stream):
                 algorithmic bytes per launch / average launch duration vs the 8 TB/s HBM peak
+  dropin_loop   the drop-in as ORB_SLAM2 drives it: >= 20 stereo frames through the reference's own Frame.cc / ORBmatcher.cc (stereo Frame
+                constructor, ComputeStereoMatches, SearchByProjection(Current, Last), SearchByProjection(Frame, MapPoints)), ms per frame with
+                the drop-in on the GPU and with the reference on the host, bit-exact per frame (KITTI shape; EuRoC shape under "euroc")
   cpu_baseline  the CPU path timed on this box's host cores on a bounded sample of the same workload (rank 0, N=1 only): the
                 reference's own Frame / ORBextractor / ORBmatcher sources built into oracle/_ref (kind "reference"; the four
                 OpenCV image primitives they call are the oracle's restatements), or the oracle's restatement (kind "port")
@@ -182,6 +185,22 @@ def host_io_subprocess(device, blur_round_mode):
     return json.loads(lines[-1])
 
 
+def dropin_loop_subprocess(blur_round_mode):
+    """The drop-in as ORB_SLAM2 drives it (tools/dropin_loop_rate.py, tests/test_dropin_loop.py): Tracking's per-frame stereo sequence through
+    the reference's own Frame.cc / ORBmatcher.cc, ms per frame with this repository's extractor / stereo matcher / projection matchers on the
+    GPU and with the reference's on the host cores, every frame of both compared bit for bit.  Fresh interpreter, like a maintainer's binary.
+    -> the KITTI-shape object (the metric's shape) with the EuRoC-shape object (BASELINE.json configs[2]) under "euroc"."""
+    import subprocess
+    env = dict(os.environ, ORB_REF_BLUR_ROUND_MODE=str(blur_round_mode))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dropin_loop_rate.py"), "kitti", "euroc"], capture_output=True, text=True, timeout=600, env=env)
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or len(lines) != 2:
+        return {"error": f"dropin_loop subprocess failed (rc {r.returncode}): {r.stderr[-300:]}"}
+    out = lines[0]
+    out["euroc"] = lines[1]
+    return out
+
+
 def parity_of_last_step(host_frames, kps, descs, m12, last_step, T, blur_round_mode, nslots):
     """Bit-for-bit check of what the LAST timed step left in the context (the oracle is the checker, never the thing measured):
     key points, descriptors and matches12 of `nslots` camera slots with distinct scenes against oracle.OracleExtractor /
@@ -294,6 +313,7 @@ def main():
     ap.add_argument("--blur-round-mode", type=int, default=1, help="cv::GaussianBlur rounding the extractor reproduces: 1 = the SSE2 column filter of x86-64 OpenCV builds "
                     "(what the reference computes on this x86 box; default), 0 = OpenCV's generic C++ path (DESIGN.md H2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropin-loop", action="store_true", help="skip the front-end loop through the reference's own callers (dropin_loop object)")
     ap.add_argument("--host-io-only", action="store_true", help="internal: measure the host_io object in this (fresh) process and print it")
     ap.add_argument("--device", type=int, default=0, help="with --host-io-only: the GPU to use")
     ap.add_argument("--pool", action="store_true", help="time the one-process multi-GPU pool (orbhip_pool_*: one host thread per GPU) at the host-buffer boundary instead of "
@@ -458,6 +478,10 @@ def main():
             # unaffected (profiles/r03_exp_host_io_pinned_vs_pageable_by_box.jsonl; cause not found) - and the drop-in's callers are such fresh processes
             ex.close(); d_frames.free()
             out["host_io"] = host_io_subprocess(local_rank, args.blur_round_mode)
+        if world == 1 and not args.no_dropin_loop:
+            if args.no_host_io:
+                ex.close(); d_frames.free()                              # (otherwise closed above) the loop runs beside nothing, like the host_io object
+            out["dropin_loop"] = dropin_loop_subprocess(args.blur_round_mode)
         if world == 1 and not args.no_cpu_baseline:
             os.environ["ORB_REF_BLUR_ROUND_MODE"] = str(args.blur_round_mode)      # the reference build's GaussianBlur stand-in follows the same rounding
             out["cpu_baseline"] = cpu_baseline(host_frames, blur_round_mode=args.blur_round_mode)

@@ -156,6 +156,7 @@ protected:
     float mCamera[9]; bool mbHasCamera;                         // fx, fy, cx, cy, k1, k2, p1, p2, k3
     std::vector<float> mvMapX, mvMapY; int mnRawCols, mnRawRows; // rectification maps (applied when the context is (re)created)
     int mnLastN;                                                 // key points of the last image
+    std::vector<cv::KeyPoint> mvLastKeys;                        // ... and the key points themselves (mvKeysUn of an undistorted camera)
     orbhip_ctx* mpCtx;          // device context for the current image size (created lazily, re-created on a size change)
     int mnCtxW, mnCtxH, mnCtxBatch, mnDevice, mnBlurRounding, mnFpContract;
     std::vector<int> mvTicketSizes;                              // images per ticket in flight (Submit / Collect), by ticket mod 4

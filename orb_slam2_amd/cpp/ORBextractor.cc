@@ -164,6 +164,7 @@ void ORBextractor::UndistortKeyPoints(std::vector<cv::KeyPoint>& mvKeysUn)
     if (mpCtx) RequireFrameState("ORBextractor::UndistortKeyPoints");
     mvKeysUn.resize(mnLastN);
     if (mnLastN == 0 || !mpCtx) return;
+    if (!(mbHasCamera && mCamera[4] != 0.0f)) { mvKeysUn = mvLastKeys; return; }      // if(mDistCoef.at<float>(0)==0.0) mvKeysUn=mvKeys (Frame.cc:406-410): no device trip
     if (orbhip_fetch_undistorted(mpCtx, 1, reinterpret_cast<orbhip_keypoint*>(&mvKeysUn[0]), mnLastN) != ORBHIP_OK) Fail("ORBextractor::UndistortKeyPoints");
 }
 
@@ -219,6 +220,7 @@ void ORBextractor::Deliver(int n, const std::vector<unsigned char>& desc, std::v
 {
     mnLastN = n; mbFrameState = true; mbBound = false; mbStereoColumns = false;
     _keypoints.resize(n);
+    mvLastKeys = _keypoints;
     if (n == 0) _descriptors.release();                          // ORBextractor.cc:1064-1065
     else {
         _descriptors.create(n, 32, CV_8U);                       // :1068

@@ -81,6 +81,7 @@ struct orbhip_ctx {
     hipStream_t bstream = nullptr; hipEvent_t ev_pyr = nullptr, ev_blur = nullptr;      // blur runs beside FAST + quadtree (independent until describe)
     hipStream_t mstream = nullptr; hipEvent_t ev_extract = nullptr; hipEvent_t ev_match[3] = {nullptr, nullptr, nullptr}; bool match_pending[3] = {false, false, false};
     int cur = 0; int last_nimg = 0; bool last_matched = false; bool last_from_host = false;
+    std::vector<int> last_n; bool last_n_valid = false;      // key point counts of the last call as already delivered to the host (the call's results were waited for)
     // host-buffer API staging: one contiguous device input buffer + pinned host mirrors (single bulk copies instead of per-frame pageable copies)
     bool serial = false;      // ORBHIP_SERIAL=1 (measurement only): every kernel on the main stream, no overlap
     int sched = 0;            // ORBHIP_SCHED (measurement only): what runs on the second stream, see pipeline_frames
@@ -281,7 +282,7 @@ extern "C" void orbhip_destroy(orbhip_ctx* c)
                     c->d_qt_val, c->d_qt_code, c->d_qt_node, c->d_lvl_kp, c->d_lvl_n[0], c->d_lvl_n[1], c->d_lvl_n[2], c->d_out_block[0], c->d_out_block[1], c->d_out_block[2], c->d_grid_start, c->d_grid_items, c->d_grid_xy, c->d_cand, c->d_top, c->d_ncand,
                     c->d_prev, c->d_m12, c->d_nm};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    { void* st[] = {c->d_st_rowstart, c->d_st_rowitems, c->d_st_u, c->d_st_depth, c->d_st_sad}; for (void* q : st) if (q) (void)hipFree(q); }
+    { void* st[] = {c->d_st_rowstart, c->d_st_rowitems, c->d_st_u /* | d_st_depth */, c->d_st_sad}; for (void* q : st) if (q) (void)hipFree(q); }
     for (auto& hs : c->sets) {
         for (int k = 0; k < ORBHIP_MAX_CHUNKS; k++) { if (hs.ev_h2d[k]) (void)hipEventDestroy(hs.ev_h2d[k]); if (hs.ev_k[k]) (void)hipEventDestroy(hs.ev_k[k]); if (hs.ev_d2h[k]) (void)hipEventDestroy(hs.ev_d2h[k]); }
         if (hs.d_packed) (void)hipFree(hs.d_packed);
@@ -702,7 +703,7 @@ static orbhip_status begin_batch(orbhip_ctx* c, const uint8_t* d_img0, long long
     HIPCHK(hipSetDevice(c->cfg.device));
     c->cur = (c->cur + 1) % 3;
     const int cur = c->cur;
-    c->last_img0 = d_img0; c->last_img0_fstride = frame_stride; c->last_img0_pitch = row_stride; c->d_last_uright = nullptr;
+    c->last_img0 = d_img0; c->last_img0_fstride = frame_stride; c->last_img0_pitch = row_stride; c->d_last_uright = nullptr; c->last_n_valid = false;
     // the buffer about to be overwritten was the "previous frame" of the matcher launched two calls ago
     for (int k = 0; k < 3; k++) if (c->match_pending[k] && (k == (cur + 1) % 3)) { HIPCHK(hipStreamWaitEvent(c->stream, c->ev_match[k], 0)); c->match_pending[k] = false; }
     // ... or may still be downloading (a submitted batch that has not been collected while un-ticketed calls rotate the buffers)
@@ -830,6 +831,7 @@ static orbhip_status enqueue_fetch(orbhip_ctx* c, int nimg, bool want_kp, bool w
 static orbhip_status finish_fetch(orbhip_ctx* c, int nimg, orbhip_keypoint* kps, uint8_t* desc, int cap, int* n_out)
 {
     bool overflow = false;
+    c->last_n.assign(c->h_n, c->h_n + nimg); c->last_n_valid = nimg == c->last_nimg;
     for (int f = 0; f < nimg; f++) {
         const int n = c->h_n[f];
         n_out[f] = n;
@@ -1147,6 +1149,7 @@ orbhip_status orbhip_collect_scatter(orbhip_ctx* c, int ticket, orbhip_keypoint*
             });
     }
     hs.busy = false; c->oldest_ticket++;
+    if (c->oldest_ticket == c->next_ticket && hs.out_buf == c->cur && hs.nimg == c->last_nimg) { c->last_n.assign(hs.h_n, hs.h_n + hs.nimg); c->last_n_valid = true; }   // the context's current state
     return overflow ? fail(ORBHIP_ERR_CAPACITY, "keypoint buffer too small") : ORBHIP_OK;
 }
 
@@ -1582,15 +1585,17 @@ extern "C" orbhip_status orbhip_compute_stereo_matches(orbhip_ctx* l, orbhip_ctx
     if (!(mb > 0) || !(mbf > 0)) return fail(ORBHIP_ERR_INVALID, "mbf and mb must be positive");
     if (l->out_cap >= 65536) return fail(ORBHIP_ERR_UNSUPPORTED, "too many keypoints per frame for the stereo matcher");
     HIPCHK(hipSetDevice(l->cfg.device));
-    orbhip_status st = orbhip_sync(r); if (st != ORBHIP_OK) return st;           // the right frame's results must be complete; left work is stream-ordered
+    // the right frame's results must be complete (left work is stream-ordered): they are if its caller already holds them
+    orbhip_status st = ORBHIP_OK;
+    if (!r->last_n_valid) { st = orbhip_sync(r); if (st != ORBHIP_OK) return st; }
     const size_t B = (size_t)l->B;
     if (!l->d_st_rowstart) {
         l->st_rowcap = l->out_cap * ((int)ceilf(4.0f * l->sf[l->L - 1]) + 3);      // rows [floor(y-r), ceil(y+r)], r = 2*scale
         hipError_t e = hipSuccess;
         if (e == hipSuccess) e = dalloc(&l->d_st_rowstart, B * (l->cfg.height + 1));
         if (e == hipSuccess) e = dalloc(&l->d_st_rowitems, B * (size_t)l->st_rowcap);
-        if (e == hipSuccess) e = dalloc(&l->d_st_u, B * l->out_cap);
-        if (e == hipSuccess) e = dalloc(&l->d_st_depth, B * l->out_cap);
+        if (e == hipSuccess) e = dalloc(&l->d_st_u, 2 * B * l->out_cap);           // [mvuRight | mvDepth]: one allocation, one download when the call fills the context
+        if (e == hipSuccess) l->d_st_depth = l->d_st_u + B * l->out_cap;
         if (e == hipSuccess) e = dalloc(&l->d_st_sad, B * l->out_cap);
         if (e != hipSuccess) return fail(ORBHIP_ERR_HIP, "stereo workspace allocation failed: %s", hipGetErrorString(e));
     }
@@ -1603,15 +1608,19 @@ extern "C" orbhip_status orbhip_compute_stereo_matches(orbhip_ctx* l, orbhip_ctx
     orbhip_launch_stereo(T, nimg, l->out_cap, l->stream);
     HIPCHK(hipGetLastError());
     st = ensure_host_staging(l, false); if (st != ORBHIP_OK) return st;
-    std::vector<int> n(nimg);
     { const orbhip_status stf = mirrors_free(l, "orbhip_compute_stereo_matches"); if (stf != ORBHIP_OK) return stf; }
-    HIPCHK(hipMemcpyAsync(l->h_n, l->d_out_n[l->cur], nimg * sizeof(int), hipMemcpyDeviceToHost, l->stream));
+    const bool know_n = l->last_n_valid && (int)l->last_n.size() >= nimg;
+    if (!know_n) HIPCHK(hipMemcpyAsync(l->h_n, l->d_out_n[l->cur], nimg * sizeof(int), hipMemcpyDeviceToHost, l->stream));
     float* hu = reinterpret_cast<float*>(l->h_kp); float* hd = hu + (size_t)nimg * l->out_cap;       // pinned mirror reused (28 B/keypoint >= 8 B)
-    HIPCHK(hipMemcpyAsync(hu, l->d_st_u, (size_t)nimg * l->out_cap * sizeof(float), hipMemcpyDeviceToHost, l->stream));
-    HIPCHK(hipMemcpyAsync(hd, l->d_st_depth, (size_t)nimg * l->out_cap * sizeof(float), hipMemcpyDeviceToHost, l->stream));
-    st = orbhip_sync(l); if (st != ORBHIP_OK) return st;
+    if ((size_t)nimg == B) HIPCHK(hipMemcpyAsync(hu, l->d_st_u, 2 * B * l->out_cap * sizeof(float), hipMemcpyDeviceToHost, l->stream));
+    else {
+        HIPCHK(hipMemcpyAsync(hu, l->d_st_u, (size_t)nimg * l->out_cap * sizeof(float), hipMemcpyDeviceToHost, l->stream));
+        HIPCHK(hipMemcpyAsync(hd, l->d_st_depth, (size_t)nimg * l->out_cap * sizeof(float), hipMemcpyDeviceToHost, l->stream));
+    }
+    HIPCHK(hipStreamSynchronize(l->stream));
+    if (l->prof) prof_collect(l);
     for (int f = 0; f < nimg; f++) {
-        const int m = std::min(l->h_n[f], cap);
+        const int m = std::min(know_n ? l->last_n[f] : l->h_n[f], cap);
         for (int i = 0; i < cap; i++) { u_right[(size_t)f * cap + i] = -1.0f; depth[(size_t)f * cap + i] = -1.0f; }
         if (m > 0) { memcpy(u_right + (size_t)f * cap, hu + (size_t)f * l->out_cap, m * sizeof(float)); memcpy(depth + (size_t)f * cap, hd + (size_t)f * l->out_cap, m * sizeof(float)); }
     }

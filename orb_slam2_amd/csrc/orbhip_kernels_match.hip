@@ -248,12 +248,25 @@ bool orbhip_launch_hamming_nn(const uint8_t* d_q, int nq, const uint8_t* d_db, l
 
 // ------------------------------------------------------------------------------------------------ frame grid
 // Frame::AssignFeaturesToGrid on the current frame F2.  posX = round((x-mnMinX)*inv) — `round`, not floor (Frame.cc:384-385).
+// One workgroup per frame, everything between the first read of the key points and the last write of the table in LDS: cell of every key point
+// (u16), 3072 counters, the bucket table itself.  A frame's grid is latency, not work - as one launch among three of a single-frame search it
+// used to cost 37 us of dependent global-memory round trips (per-cell insertion sort and key point gathers in HBM); now the key points are read
+// once, coalesced, and the table is written once.
+__device__ __forceinline__ int mg_wave_incl_scan(int v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(v, off); if (lane >= off) v += t; }
+    return v;
+}
 __global__ __launch_bounds__(256) void k_match_grid(MatchParams M, float gwInv, float ghInv)
 {
-    __shared__ int s_cnt[ORBHIP_GRID_CELLS + 1];
-    __shared__ int s_scan[256];
-    const int slot = blockIdx.x + M.slot0, tid = threadIdx.x;
-    const int n2 = M.n2[slot];
+    HIP_DYNAMIC_SHARED(int, lds)
+    int* s_cnt = lds;                                                    // [CELLS + 1] counters, then cursors
+    int* s_items = s_cnt + ORBHIP_GRID_CELLS + 1;                         // [cap] bucket table (key point indices)
+    unsigned short* s_cell = reinterpret_cast<unsigned short*>(s_items + M.cap);      // [cap] cell of key point i (0xFFFF: not in the grid)
+    __shared__ int s_wsum[4];
+    const int slot = blockIdx.x + M.slot0, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n2 = min(M.n2[slot], M.cap);
     const orbhip_keypoint* kp = M.kp2 + (long long)slot * M.cap;
     int* gstart = M.grid_start + (long long)slot * (ORBHIP_GRID_CELLS + 1);
     int* gitems = M.grid_items + (long long)slot * M.cap;
@@ -263,42 +276,47 @@ __global__ __launch_bounds__(256) void k_match_grid(MatchParams M, float gwInv, 
     // Only level-0 keypoints can ever be returned by GetFeaturesInArea(.., minLevel 0, maxLevel 0) (Frame.cc:362-370), and
     // filtering a cell keeps the relative order of its entries, so the buckets are built from level-0 keypoints only.
     for (int i = tid; i < n2; i += 256) {
-        if (!M.grid_all_levels && kp[i].octave != 0) continue;
-        const int px = (int)roundf(__fmul_rn(__fsub_rn(kp[i].x, M.min_x), gwInv)), py = (int)roundf(__fmul_rn(__fsub_rn(kp[i].y, M.min_y), ghInv));
-        if (px < 0 || px >= ORBHIP_GRID_COLS || py < 0 || py >= ORBHIP_GRID_ROWS) continue;
-        atomicAdd(&s_cnt[px * ORBHIP_GRID_ROWS + py], 1);
+        const orbhip_keypoint k = kp[i];
+        int cell = 0xFFFF;
+        if (M.grid_all_levels || k.octave == 0) {
+            const int px = (int)roundf(__fmul_rn(__fsub_rn(k.x, M.min_x), gwInv)), py = (int)roundf(__fmul_rn(__fsub_rn(k.y, M.min_y), ghInv));
+            if (!(px < 0 || px >= ORBHIP_GRID_COLS || py < 0 || py >= ORBHIP_GRID_ROWS)) { cell = px * ORBHIP_GRID_ROWS + py; atomicAdd(&s_cnt[cell], 1); }
+        }
+        s_cell[i] = (unsigned short)cell;
     }
     __syncthreads();
-    // exclusive scan of 3072 counters: 12 per thread
+    // exclusive scan of 3072 counters: 12 consecutive ones per thread, a shuffle scan per wave, the four wave totals through LDS
     const int per = ORBHIP_GRID_CELLS / 256;
     int sum = 0;
     for (int k = 0; k < per; k++) sum += s_cnt[tid * per + k];
-    s_scan[tid] = sum;
+    const int incl = mg_wave_incl_scan(sum, lane);
+    if (lane == 63) s_wsum[wave] = incl;
     __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) { const int v = tid >= off ? s_scan[tid - off] : 0; __syncthreads(); s_scan[tid] += v; __syncthreads(); }
-    int run = s_scan[tid] - sum;
+    int run = incl - sum;
+    for (int w = 0; w < wave; w++) run += s_wsum[w];
     for (int k = 0; k < per; k++) { const int v = s_cnt[tid * per + k]; s_cnt[tid * per + k] = run; gstart[tid * per + k] = run; run += v; }
-    if (tid == 255) gstart[ORBHIP_GRID_CELLS] = run;
+    if (tid == 255) { gstart[ORBHIP_GRID_CELLS] = run; s_cnt[ORBHIP_GRID_CELLS] = run; }
     __syncthreads();
-    for (int i = tid; i < n2; i += 256) {
-        if (!M.grid_all_levels && kp[i].octave != 0) continue;
-        const int px = (int)roundf(__fmul_rn(__fsub_rn(kp[i].x, M.min_x), gwInv)), py = (int)roundf(__fmul_rn(__fsub_rn(kp[i].y, M.min_y), ghInv));
-        if (px < 0 || px >= ORBHIP_GRID_COLS || py < 0 || py >= ORBHIP_GRID_ROWS) continue;
-        gitems[atomicAdd(&s_cnt[px * ORBHIP_GRID_ROWS + py], 1)] = i;
-    }
+    const int total = s_cnt[ORBHIP_GRID_CELLS];
     __syncthreads();
-    // cells are tiny: restore keypoint order inside each cell (mGrid[x][y].push_back(i) for ascending i)
+    for (int i = tid; i < n2; i += 256) { const int cell = s_cell[i]; if (cell != 0xFFFF) s_items[atomicAdd(&s_cnt[cell], 1)] = i; }
+    __syncthreads();
+    // cells are tiny: restore keypoint order inside each cell (mGrid[x][y].push_back(i) for ascending i); after the scatter s_cnt[c] is the END of
+    // cell c, which is where cell c + 1 starts
     for (int c = tid; c < ORBHIP_GRID_CELLS; c += 256) {
-        const int a = gstart[c], b = s_cnt[c];          // after the scatter s_cnt[c] == end of cell c
-        for (int i = a + 1; i < b; i++) { const int v = gitems[i]; int j = i - 1; while (j >= a && gitems[j] > v) { gitems[j + 1] = gitems[j]; j--; } gitems[j + 1] = v; }
-        for (int i = a; i < b; i++) { const orbhip_keypoint k = kp[gitems[i]]; float2 xy; xy.x = k.x; xy.y = k.y; gxy[i] = xy; }
+        const int a = c ? s_cnt[c - 1] : 0, b = s_cnt[c];
+        for (int i = a + 1; i < b; i++) { const int v = s_items[i]; int j = i - 1; while (j >= a && s_items[j] > v) { s_items[j + 1] = s_items[j]; j--; } s_items[j + 1] = v; }
     }
+    __syncthreads();
+    for (int t = tid; t < total; t += 256) { const int i = s_items[t]; gitems[t] = i; const orbhip_keypoint k = kp[i]; float2 xy; xy.x = k.x; xy.y = k.y; gxy[t] = xy; }
 }
+
+size_t orbhip_match_grid_lds(int cap) { return sizeof(int) * (ORBHIP_GRID_CELLS + 1 + (size_t)cap) + sizeof(unsigned short) * ((size_t)cap + 2); }
 
 void orbhip_launch_match_grid(const MatchParams& M, int nslots, hipStream_t s)
 {
     const float gwInv = (float)ORBHIP_GRID_COLS / (float)(M.max_x - M.min_x), ghInv = (float)ORBHIP_GRID_ROWS / (float)(M.max_y - M.min_y);   // Frame.cc:101-102
-    hipLaunchKernelGGL(k_match_grid, dim3(nslots, 1, 1), dim3(256, 1, 1), 0, s, M, gwInv, ghInv);
+    hipLaunchKernelGGL(k_match_grid, dim3(nslots, 1, 1), dim3(256, 1, 1), orbhip_match_grid_lds(M.cap), s, M, gwInv, ghInv);
 }
 
 // ------------------------------------------------------------------------------------------------ candidates

@@ -253,15 +253,22 @@ __device__ __forceinline__ void proj_select_body(const ProjParams& J)
                 }
                 if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
                 else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
-                int removed = 0;
-                for (int k = 0; k < nev; k++) {                                            // ORBmatcher.cc:1452-1466: one decrement per histogram entry
-                    const int ev = J.events[k], bin = ev >> 20, idx = ev & 0xFFFFF;
-                    if (bin != ind1 && bin != ind2 && bin != ind3) { s_fq[idx] = -2; removed++; }      // mvpMapPoints[idx] = NULL (:1460): reported as -2, not as "untouched"
-                }
-                s_hist[ORBHIP_HISTO_LENGTH] = removed;
+                s_hist[ORBHIP_HISTO_LENGTH] = ind1; s_hist[ORBHIP_HISTO_LENGTH + 1] = ind2; s_hist[ORBHIP_HISTO_LENGTH + 2] = ind3;
             }
             __builtin_amdgcn_wave_barrier();
-            nmatches -= s_hist[ORBHIP_HISTO_LENGTH];
+            const int ind1 = s_hist[ORBHIP_HISTO_LENGTH], ind2 = s_hist[ORBHIP_HISTO_LENGTH + 1], ind3 = s_hist[ORBHIP_HISTO_LENGTH + 2];
+            // ORBmatcher.cc:1452-1466: one decrement per histogram entry of a bin outside the three maxima.  The entries do not interact (a feature
+            // NULLed through one entry stays NULL whatever its other entries say), so the wave takes 64 of them per step.
+            int removed = 0;
+            for (int kb = 0; kb < nev; kb += 64) {
+                const int k = kb + lane;
+                bool out = false; int idx = 0;
+                if (k < nev) { const int ev = J.events[k], bin = ev >> 20; idx = ev & 0xFFFFF; out = bin != ind1 && bin != ind2 && bin != ind3; }
+                if (out) s_fq[idx] = -2;                                                             // mvpMapPoints[idx] = NULL (:1460): reported as -2, not as "untouched"
+                removed += __popcll(__ballot(out));
+            }
+            __builtin_amdgcn_wave_barrier();
+            nmatches -= removed;
         }
         if (lane == 0) *J.nmatches = nmatches;
     }

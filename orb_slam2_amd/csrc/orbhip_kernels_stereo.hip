@@ -45,7 +45,7 @@ __device__ __forceinline__ const uint8_t* st_level(const StereoSide& S, const Le
 __global__ __launch_bounds__(256) void k_stereo_rows(StereoParams T)
 {
     HIP_DYNAMIC_SHARED(int, lds)                       // [H + 1] row counters / cursors
-    __shared__ int s_scan[256];
+    __shared__ int s_scan[4];
     const int slot = blockIdx.x, tid = threadIdx.x, H = T.im_h;
     const int nr = T.R.n[slot];
     const orbhip_keypoint* kp = T.R.kp + (long long)slot * T.cap;
@@ -62,10 +62,13 @@ __global__ __launch_bounds__(256) void k_stereo_rows(StereoParams T)
     const int per = (H + 256) / 256;                    // exclusive scan of H+1 counters, `per` consecutive entries per thread
     int sum = 0;
     for (int k = 0; k < per; k++) { const int i = tid * per + k; if (i <= H) sum += lds[i]; }
-    s_scan[tid] = sum;
+    int incl = sum;                                     // shuffle scan per wave, the four wave totals through LDS
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if ((tid & 63) >= off) incl += t; }
+    if ((tid & 63) == 63) s_scan[tid >> 6] = incl;
     __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) { const int v = tid >= off ? s_scan[tid - off] : 0; __syncthreads(); s_scan[tid] += v; __syncthreads(); }
-    int run = s_scan[tid] - sum;
+    int run = incl - sum;
+    for (int w = 0; w < (tid >> 6); w++) run += s_scan[w];
     for (int k = 0; k < per; k++) { const int i = tid * per + k; if (i <= H) { const int v = lds[i]; lds[i] = run; rstart[i] = run; run += v; } }
     __syncthreads();
     for (int i = tid; i < nr; i += 256) {
@@ -168,37 +171,49 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoParams T)
 }
 
 // ------------------------------------------------------------------------------------------------ median prune
+// One workgroup per frame.  Every thread keeps its share of the correlation distances in registers (ST_PR per thread; key points beyond
+// 256 * ST_PR are re-read from memory): the 16 steps of the bisection then count registers and meet in LDS, instead of walking the array in
+// HBM sixteen times (36 us of a single frame's 60 us stereo step were this kernel's dependent round trips).
+#define ST_PR 16
 __global__ __launch_bounds__(256) void k_stereo_prune(StereoParams T)
 {
-    __shared__ int s_cnt, s_le;
-    const int slot = blockIdx.x, tid = threadIdx.x;
+    __shared__ int s_part[2][4];
+    const int slot = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nl = T.L.n[slot];
     float* uout = T.u_right + (long long)slot * T.cap;
     float* dout = T.depth + (long long)slot * T.cap;
     const int* sad = T.sad + (long long)slot * T.cap;
-    if (tid == 0) s_cnt = 0;
-    __syncthreads();
-    int mine = 0;
-    for (int i = tid; i < nl; i += 256) mine += sad[i] >= 0;
-    if (mine) atomicAdd(&s_cnt, mine);
-    __syncthreads();
-    const int n = s_cnt;
+    int v[ST_PR];
+#pragma unroll
+    for (int k = 0; k < ST_PR; k++) { const int i = tid + 256 * k; v[k] = i < nl ? sad[i] : -1; }
+    auto count_le = [&](int mid) -> int {                   // #{0 <= sad <= mid} over the whole frame, in every thread
+        int c = 0;
+#pragma unroll
+        for (int k = 0; k < ST_PR; k++) c += (v[k] >= 0 && v[k] <= mid);
+        for (int i = tid + 256 * ST_PR; i < nl; i += 256) { const int s = sad[i]; c += (s >= 0 && s <= mid); }
+        return c;
+    };
+    int par = 0;
+    auto block_sum = [&](int c) -> int {                     // two LDS rows used in turn: one barrier per sum
+        c = st_wave_sum(c);
+        if (lane == 0) s_part[par][wave] = c;
+        __syncthreads();
+        const int t = s_part[par][0] + s_part[par][1] + s_part[par][2] + s_part[par][3];
+        par ^= 1;
+        return t;
+    };
+    const int n = block_sum(count_le(IMAX));
     if (n == 0) return;                                   // reference: vDistIdx[0] of an empty vector (undefined) — nothing to prune
     const int k = n / 2;                                  // sorted vDistIdx[size/2].first: the k-th smallest value (0-based)
     int lo = 0, hi = 121 * 510;                           // smallest v with #{sad <= v} >= k + 1
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        __syncthreads();
-        if (tid == 0) s_le = 0;
-        __syncthreads();
-        int c = 0;
-        for (int i = tid; i < nl; i += 256) { const int s = sad[i]; c += (s >= 0 && s <= mid); }
-        if (c) atomicAdd(&s_le, c);
-        __syncthreads();
-        if (s_le >= k + 1) hi = mid; else lo = mid + 1;
+        if (block_sum(count_le(mid)) >= k + 1) hi = mid; else lo = mid + 1;
     }
     const float thDist = __fmul_rn(__fmul_rn(1.5f, 1.4f), (float)lo);
-    for (int i = tid; i < nl; i += 256) { const int s = sad[i]; if (s >= 0 && !((float)s < thDist)) { uout[i] = -1.0f; dout[i] = -1.0f; } }
+#pragma unroll
+    for (int q = 0; q < ST_PR; q++) { const int i = tid + 256 * q; if (v[q] >= 0 && !((float)v[q] < thDist)) { uout[i] = -1.0f; dout[i] = -1.0f; } }
+    for (int i = tid + 256 * ST_PR; i < nl; i += 256) { const int s = sad[i]; if (s >= 0 && !((float)s < thDist)) { uout[i] = -1.0f; dout[i] = -1.0f; } }
 }
 
 void orbhip_launch_stereo(const StereoParams& T, int nslots, int max_left, hipStream_t s)
