@@ -81,6 +81,14 @@ struct orbhip_ctx {
     hipStream_t bstream = nullptr; hipEvent_t ev_pyr = nullptr, ev_blur = nullptr;      // blur runs beside FAST + quadtree (independent until describe)
     hipStream_t mstream = nullptr; hipEvent_t ev_extract = nullptr; hipEvent_t ev_match[3] = {nullptr, nullptr, nullptr}; bool match_pending[3] = {false, false, false};
     int cur = 0; int last_nimg = 0; bool last_matched = false; bool last_from_host = false;
+    // Frame epilogues.  ORB_SLAM2 calls one image at a time and follows every extraction with the same steps (Frame.cc:61-117, Tracking.cc:867-928,
+    // 1143-1193): the right image's row table for ComputeStereoMatches, the 64x48 feature grid for the projection searches.  Both depend on
+    // nothing but the extraction's own results, so once a context has seen such a follow-up it enqueues them BEHIND the result download of every
+    // single-image call: they run while the host is still copying key points out, and the follow-up call finds them done instead of launching
+    // them on its critical path (18 us each of a stereo frame's ~0.9 ms).  Learned per context (a monocular extractor never pays for a row table).
+    bool want_fgrid = false, want_rrows = false, fgrid_valid = false, rrows_valid = false; int fgrid_cur = -1, rrows_cur = -1;
+    int* d_fgrid_start = nullptr; int* d_fgrid_items = nullptr; float2* d_fgrid_xy = nullptr; int* d_rrow_start = nullptr; int* d_rrow_items = nullptr; int rrow_cap = 0;
+    hipEvent_t ev_epilogue = nullptr;
     std::vector<int> last_n; bool last_n_valid = false;      // key point counts of the last call as already delivered to the host (the call's results were waited for)
     // host-buffer API staging: one contiguous device input buffer + pinned host mirrors (single bulk copies instead of per-frame pageable copies)
     bool serial = false;      // ORBHIP_SERIAL=1 (measurement only): every kernel on the main stream, no overlap
@@ -282,6 +290,7 @@ extern "C" void orbhip_destroy(orbhip_ctx* c)
                     c->d_qt_val, c->d_qt_code, c->d_qt_node, c->d_lvl_kp, c->d_lvl_n[0], c->d_lvl_n[1], c->d_lvl_n[2], c->d_out_block[0], c->d_out_block[1], c->d_out_block[2], c->d_grid_start, c->d_grid_items, c->d_grid_xy, c->d_cand, c->d_top, c->d_ncand,
                     c->d_prev, c->d_m12, c->d_nm};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    { void* ep[] = {c->d_fgrid_start, c->d_fgrid_items, c->d_fgrid_xy, c->d_rrow_start, c->d_rrow_items}; for (void* q : ep) if (q) (void)hipFree(q); if (c->ev_epilogue) (void)hipEventDestroy(c->ev_epilogue); }
     { void* st[] = {c->d_st_rowstart, c->d_st_rowitems, c->d_st_u /* | d_st_depth */, c->d_st_sad}; for (void* q : st) if (q) (void)hipFree(q); }
     for (auto& hs : c->sets) {
         for (int k = 0; k < ORBHIP_MAX_CHUNKS; k++) { if (hs.ev_h2d[k]) (void)hipEventDestroy(hs.ev_h2d[k]); if (hs.ev_k[k]) (void)hipEventDestroy(hs.ev_k[k]); if (hs.ev_d2h[k]) (void)hipEventDestroy(hs.ev_d2h[k]); }
@@ -703,7 +712,7 @@ static orbhip_status begin_batch(orbhip_ctx* c, const uint8_t* d_img0, long long
     HIPCHK(hipSetDevice(c->cfg.device));
     c->cur = (c->cur + 1) % 3;
     const int cur = c->cur;
-    c->last_img0 = d_img0; c->last_img0_fstride = frame_stride; c->last_img0_pitch = row_stride; c->d_last_uright = nullptr; c->last_n_valid = false;
+    c->last_img0 = d_img0; c->last_img0_fstride = frame_stride; c->last_img0_pitch = row_stride; c->d_last_uright = nullptr; c->last_n_valid = false; c->fgrid_valid = false; c->rrows_valid = false;
     // the buffer about to be overwritten was the "previous frame" of the matcher launched two calls ago
     for (int k = 0; k < 3; k++) if (c->match_pending[k] && (k == (cur + 1) % 3)) { HIPCHK(hipStreamWaitEvent(c->stream, c->ev_match[k], 0)); c->match_pending[k] = false; }
     // ... or may still be downloading (a submitted batch that has not been collected while un-ticketed calls rotate the buffers)
@@ -1002,6 +1011,31 @@ static int host_chunk_frames(int nimg, bool dma_both_ways)
     return std::max(ch, (nimg + ORBHIP_MAX_CHUNKS - 1) / ORBHIP_MAX_CHUNKS);
 }
 
+static int stereo_row_cap(const orbhip_ctx* c) { return c->out_cap * ((int)ceilf(4.0f * c->sf[c->L - 1]) + 3); }      // rows [floor(y-r), ceil(y+r)], r = 2*scale
+static StereoSide stereo_side(orbhip_ctx* c);
+// what the follow-up calls of a single-image extraction will ask for, enqueued behind its result download (see orbhip_ctx::want_fgrid)
+static orbhip_status frame_epilogues(orbhip_ctx* c, hipStream_t s)
+{
+    if (c->want_fgrid) {
+        if (!c->d_fgrid_start) { HIPCHK(dalloc(&c->d_fgrid_start, (size_t)ORBHIP_GRID_CELLS + 1)); HIPCHK(dalloc(&c->d_fgrid_items, (size_t)c->out_cap)); HIPCHK(dalloc(&c->d_fgrid_xy, (size_t)c->out_cap)); }
+        MatchParams M; memset(&M, 0, sizeof M);
+        M.kp2 = (c->distorted ? c->d_out_kpun : c->d_out_kp)[c->cur]; M.n2 = c->d_out_n[c->cur]; M.cap = c->out_cap;
+        M.min_x = c->bounds.min_x; M.min_y = c->bounds.min_y; M.max_x = c->bounds.max_x; M.max_y = c->bounds.max_y;
+        M.grid_start = c->d_fgrid_start; M.grid_items = c->d_fgrid_items; M.grid_xy = c->d_fgrid_xy; M.grid_all_levels = 1;
+        orbhip_launch_match_grid(M, 1, s);
+        c->fgrid_valid = true; c->fgrid_cur = c->cur;
+    }
+    if (c->want_rrows) {
+        if (!c->d_rrow_start) { c->rrow_cap = stereo_row_cap(c); HIPCHK(dalloc(&c->d_rrow_start, (size_t)c->cfg.height + 1)); HIPCHK(dalloc(&c->d_rrow_items, (size_t)c->rrow_cap)); }
+        StereoParams T; memset(&T, 0, sizeof T);
+        T.geom = c->d_geom; T.R = stereo_side(c); T.cap = c->out_cap; T.im_h = c->cfg.height; T.row_start = c->d_rrow_start; T.row_items = c->d_rrow_items; T.row_cap = c->rrow_cap;
+        orbhip_launch_stereo_rows(T, 1, s);
+        c->rrows_valid = true; c->rrows_cur = c->cur;
+        if (!c->ev_epilogue) HIPCHK(hipEventCreateWithFlags(&c->ev_epilogue, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(c->ev_epilogue, s));                  // the LEFT context's stream runs the stereo matcher: it waits for this
+    }
+    return ORBHIP_OK;
+}
 static orbhip_status submit_body(orbhip_ctx* c, int nimg, const uint8_t* const* imgs, int stride, orbhip_keypoint* direct_kp, uint8_t* direct_desc, int direct_cap, int* ticket);
 // A submit that fails half-way (a HIP error between the first upload and the last download of the batch) issued no ticket: whatever it
 // enqueued is drained here, so that the staging set it used is quiet again and the ring state is exactly what it was before the call.
@@ -1114,6 +1148,7 @@ static orbhip_status submit_body(orbhip_ctx* c, int nimg, const uint8_t* const* 
         }
         HIPCHK(hipEventRecord(hs.ev_d2h[k], dst));
     }
+    if (nimg == 1 && !piped && (c->want_fgrid || c->want_rrows)) { st = frame_epilogues(c, c->stream); if (st != ORBHIP_OK) return st; }
     c->last_matched = false; c->last_nimg = nimg;
     HIPCHK(hipGetLastError());
     hs.busy = true; hs.out_buf = c->cur; hs.ticket = c->next_ticket++; c->ticket_set[hs.ticket % ORBHIP_RING] = si;
@@ -1513,7 +1548,10 @@ extern "C" orbhip_status orbhip_search_by_projection_frame(orbhip_ctx* c, int fr
     if (e == hipSuccess) {
         MatchParams M; memset(&M, 0, sizeof M);
         M.kp2 = dk; M.n2 = dn; M.cap = n; M.min_x = c->bounds.min_x; M.min_y = c->bounds.min_y; M.max_x = c->bounds.max_x; M.max_y = c->bounds.max_y; M.grid_start = dgs; M.grid_items = dgi; M.grid_xy = dgxy; M.grid_all_levels = 1;
-        orbhip_launch_match_grid(M, 1, c->stream);
+        // the grid of this frame was built behind its extraction (frame epilogue, same stream): take it; from now on it always will be
+        if (frame == 0 && c->fgrid_valid && c->fgrid_cur == c->cur && c->last_n_valid && c->last_n[0] == n) { dgs = c->d_fgrid_start; dgi = c->d_fgrid_items; dgxy = c->d_fgrid_xy; }
+        else orbhip_launch_match_grid(M, 1, c->stream);
+        if (c->last_nimg == 1) c->want_fgrid = true;
         ProjParams J; memset(&J, 0, sizeof J);
         J.kp = dk; J.desc = dd; J.u_right = dur; J.n = n; J.min_x = M.min_x; J.min_y = M.min_y; J.max_x = M.max_x; J.max_y = M.max_y; J.grid_start = dgs; J.grid_items = dgi; J.grid_xy = dgxy;
         J.q = dq; J.qdesc = dqd; J.nq = nq; J.cand = dcand; J.ncand = dnc; J.cand_stride = n; J.top = dtop;
@@ -1551,7 +1589,9 @@ extern "C" orbhip_status orbhip_search_best_in_window_frame(orbhip_ctx* c, int f
     if (e == hipSuccess) {
         MatchParams M; memset(&M, 0, sizeof M);
         M.kp2 = dk; M.n2 = dn; M.cap = n; M.min_x = c->bounds.min_x; M.min_y = c->bounds.min_y; M.max_x = c->bounds.max_x; M.max_y = c->bounds.max_y; M.grid_start = dgs; M.grid_items = dgi; M.grid_xy = dgxy; M.grid_all_levels = 1;
-        orbhip_launch_match_grid(M, 1, c->stream);
+        if (frame == 0 && c->fgrid_valid && c->fgrid_cur == c->cur && c->last_n_valid && c->last_n[0] == n) { dgs = c->d_fgrid_start; dgi = c->d_fgrid_items; dgxy = c->d_fgrid_xy; }   // frame epilogue
+        else orbhip_launch_match_grid(M, 1, c->stream);
+        if (c->last_nimg == 1) c->want_fgrid = true;
         BestParams B; memset(&B, 0, sizeof B);
         B.kp = dk; B.desc = dd; B.u_right = dur; B.inv_level_sigma2 = dsg; B.grid_start = dgs; B.grid_items = dgi; B.grid_xy = dgxy;
         B.q = dq; B.qdesc = dqd; B.nq = nq; B.chi2_gate = chi2_gate; B.best_idx = dbi; B.best_dist = dbd;
@@ -1590,7 +1630,7 @@ extern "C" orbhip_status orbhip_compute_stereo_matches(orbhip_ctx* l, orbhip_ctx
     if (!r->last_n_valid) { st = orbhip_sync(r); if (st != ORBHIP_OK) return st; }
     const size_t B = (size_t)l->B;
     if (!l->d_st_rowstart) {
-        l->st_rowcap = l->out_cap * ((int)ceilf(4.0f * l->sf[l->L - 1]) + 3);      // rows [floor(y-r), ceil(y+r)], r = 2*scale
+        l->st_rowcap = stereo_row_cap(l);
         hipError_t e = hipSuccess;
         if (e == hipSuccess) e = dalloc(&l->d_st_rowstart, B * (l->cfg.height + 1));
         if (e == hipSuccess) e = dalloc(&l->d_st_rowitems, B * (size_t)l->st_rowcap);
@@ -1603,9 +1643,13 @@ extern "C" orbhip_status orbhip_compute_stereo_matches(orbhip_ctx* l, orbhip_ctx
     T.geom = l->d_geom; T.L = stereo_side(l); T.R = stereo_side(r);
     T.cap = l->out_cap; T.im_h = l->cfg.height;
     T.row_start = l->d_st_rowstart; T.row_items = l->d_st_rowitems; T.row_cap = l->st_rowcap;
+    // the right context built its frame's row table behind its own extraction (frame epilogue): take it; from now on it always will
+    const bool rows_ready = nimg == 1 && r->rrows_valid && r->rrows_cur == r->cur;
+    if (rows_ready) { T.row_start = r->d_rrow_start; T.row_items = r->d_rrow_items; T.row_cap = r->rrow_cap; HIPCHK(hipStreamWaitEvent(l->stream, r->ev_epilogue, 0)); }
+    if (nimg == 1) r->want_rrows = true;
     T.u_right = l->d_st_u; T.depth = l->d_st_depth; T.sad = l->d_st_sad; l->d_last_uright = l->d_st_u;
     T.mbf = mbf; T.maxD = mbf / mb;                                                 // minZ = mb, maxD = mbf/minZ (Frame.cc:496-498)
-    orbhip_launch_stereo(T, nimg, l->out_cap, l->stream);
+    orbhip_launch_stereo(T, nimg, l->out_cap, l->stream, rows_ready);
     HIPCHK(hipGetLastError());
     st = ensure_host_staging(l, false); if (st != ORBHIP_OK) return st;
     { const orbhip_status stf = mirrors_free(l, "orbhip_compute_stereo_matches"); if (stf != ORBHIP_OK) return stf; }

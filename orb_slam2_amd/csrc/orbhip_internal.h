@@ -126,7 +126,8 @@ struct StereoParams {       // Frame::ComputeStereoMatches (Frame.cc:466-640)
     float* u_right; float* depth; int* sad;                                // [slot][cap]
     float mbf, maxD;                                                       // maxD = mbf / mb
 };
-void orbhip_launch_stereo(const StereoParams& T, int nslots, int max_left, hipStream_t s);
+void orbhip_launch_stereo(const StereoParams& T, int nslots, int max_left, hipStream_t s, bool rows_ready = false);
+void orbhip_launch_stereo_rows(const StereoParams& T, int nslots, hipStream_t s);     // the right frame's row table alone (needs only T.R, geom, im_h, cap, row_*)
 
 struct ProjParams {         // projection-guided search core (ORBmatcher.cc:45-129 and :1328-1470), one frame
     const orbhip_keypoint* kp; const uint8_t* desc; const float* u_right; int n;           // the Frame being searched

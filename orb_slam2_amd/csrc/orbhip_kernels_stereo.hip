@@ -216,9 +216,13 @@ __global__ __launch_bounds__(256) void k_stereo_prune(StereoParams T)
     for (int i = tid + 256 * ST_PR; i < nl; i += 256) { const int s = sad[i]; if (s >= 0 && !((float)s < thDist)) { uout[i] = -1.0f; dout[i] = -1.0f; } }
 }
 
-void orbhip_launch_stereo(const StereoParams& T, int nslots, int max_left, hipStream_t s)
+void orbhip_launch_stereo_rows(const StereoParams& T, int nslots, hipStream_t s)
 {
     hipLaunchKernelGGL(k_stereo_rows, dim3(nslots, 1, 1), dim3(256, 1, 1), sizeof(int) * (T.im_h + 1), s, T);
+}
+void orbhip_launch_stereo(const StereoParams& T, int nslots, int max_left, hipStream_t s, bool rows_ready)
+{
+    if (!rows_ready) orbhip_launch_stereo_rows(T, nslots, s);
     hipLaunchKernelGGL(k_stereo_match, dim3((max_left + 3) / 4, nslots, 1), dim3(256, 1, 1), 0, s, T);
     hipLaunchKernelGGL(k_stereo_prune, dim3(nslots, 1, 1), dim3(256, 1, 1), 0, s, T);
 }

@@ -162,6 +162,54 @@ def test_searches_on_device_resident_frames(backend, oracle):
     xl.close(); xr.close()
 
 
+def test_frame_epilogues_single_image_sequence(backend, oracle):
+    """What ORB_SLAM2 does: one stereo pair at a time on two max_batch = 1 contexts, each pair followed by ComputeStereoMatches and two
+    projection searches on the left frame.  From the second pair on the contexts build the right image's row table and the left image's 64x48
+    grid behind their own extractions (frame epilogues, orbhip_api.hip); every pair's results must equal the oracle's all the same, also when
+    the follow-ups change (a pair without any, a search without the stereo step)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_parity_stereo import stereo_pair
+    w, h, n = 400, 300, 500
+    mbf, fx = np.float32(386.1448), np.float32(718.856)
+    xl = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, max_batch=1, library=backend)
+    xr = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, max_batch=1, library=backend)
+    eL, eR = oracle.OracleExtractor(n, 1.2, 8, 20, 7), oracle.OracleExtractor(n, 1.2, 8, 20, 7)
+    sf = xl.GetScaleFactors()
+    rng = np.random.default_rng(21)
+    for t, (seed, disp, follow) in enumerate([(8, 7, "all"), (9, 11, "all"), (10, 5, "none"), (11, 9, "search"), (12, 7, "all")]):
+        L, R = stereo_pair(w, h, seed, disp)
+        kc, dc = xl(L)
+        xr(R)
+        ko, do = eL.extract(L); eR.extract(R)
+        assert kc.tobytes() == ko.tobytes() and np.array_equal(dc, do)
+        nk = len(kc)
+        if follow == "none":
+            continue
+        u = None
+        if follow == "all":
+            u, d = xl.ComputeStereoMatches(xr, float(mbf), float(mbf / fx))
+            uo, dpo = oracle.stereo_matches(eL, eR, float(mbf), float(mbf / fx))
+            assert u[0, :nk].tobytes() == uo.tobytes() and d[0, :nk].tobytes() == dpo.tobytes() and (uo > 0).sum() > 50
+            u = u[0, :nk]
+        q = np.zeros(nk, oracle.PROJ_QUERY_DTYPE)
+        q["x"] = kc["x"] + rng.normal(0, 1.5, nk).astype(np.float32); q["y"] = kc["y"] + rng.normal(0, 1.5, nk).astype(np.float32)
+        q["radius"] = (np.float32(5.0) * sf[kc["octave"]]).astype(np.float32)
+        q["ur"] = (q["x"] - 20).astype(np.float32) if u is None else np.where(u > 0, u + rng.normal(0, 2.0, nk), q["x"] - 20).astype(np.float32)
+        q["min_level"], q["max_level"] = kc["octave"] - 1, kc["octave"] + 1
+        q["blocks"] = rng.random(nk) < 0.8
+        q["angle"] = kc["angle"]
+        qd = dc.copy()
+        for i in range(nk):
+            for b in rng.integers(0, 256, int(rng.integers(0, 25))):
+                qd[i, b >> 3] ^= 1 << (b & 7)
+        for mode in (1, 0):
+            n_o, f_o = oracle.search_by_projection(kc, dc, w, h, q, qd, mode, nnratio=0.9, th_high=100, check_ori=True, u_right=u)
+            n_g, f_g = xl.search_by_projection(0, nk, q, qd, mode, nnratio=0.9, th_high=100, check_ori=True, use_u_right=u is not None)
+            assert n_g == n_o and np.array_equal(f_g, f_o) and n_o > 50, (t, mode)
+    xl.close(); xr.close()
+
+
 @pytest.mark.parametrize("mode,rule,th,ratio", [(0, "local_map", 3.0, 0.8), (1, "window", 7.0, 0.9)])
 def test_search_by_projection_batch_of_camera_slots(backend, oracle, scene, mode, rule, th, ratio):
     """orbhip_search_by_projection_batch (the multi-camera form of M2 / M3): slots with different frames, query sets, stereo
