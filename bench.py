@@ -21,7 +21,10 @@ Extra objects in the JSON line:
                 every replica slot of a scene with the first slot of that scene (whole batch); a mismatch marks the line INVALID
   runtime       the HIP runtime the library ran on (versions, file), every libamdhip64 mapped into the process (must be one)
   roofline      dominant kernel (by HIP-event time measured inside the timed region on the library's stream):
-                algorithmic bytes per launch / average launch duration vs the 8 TB/s HBM peak
+                algorithmic bytes per launch / average launch duration vs the 8 TB/s HBM peak; `traffic` = HBM bytes per launch from
+                two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; gfx950 correction) over a short child run of the same workload;
+                `bound` = what the evidence says limits the kernel
+  roofline_valu the same kernel against its VALU-issue floor: instructions per wave x waves x 4 cycles / (1024 SIMDs x 2.4 GHz)
   dropin_loop   the drop-in as ORB_SLAM2 drives it: >= 20 stereo frames through the reference's own Frame.cc / ORBmatcher.cc (stereo Frame
                 constructor, ComputeStereoMatches, SearchByProjection(Current, Last), SearchByProjection(Frame, MapPoints)), ms per frame with
                 the drop-in on the GPU and with the reference on the host, bit-exact per frame (KITTI shape; EuRoC shape under "euroc")
@@ -141,9 +144,9 @@ def host_io(ex_resident, frames, device, blur_round_mode, budget_s=3.0):
     sets = {"pinned": (pin_src, [(orb_slam2_amd.pinned_array((Bh, cap), orb_slam2_amd.KEYPOINT_DTYPE), orb_slam2_amd.pinned_array((Bh, cap, 32), np.uint8), np.zeros(Bh, np.int32)) for _ in range(3)]),
             "pageable": (src_pageable, [(np.zeros((Bh, cap), orb_slam2_amd.KEYPOINT_DTYPE), np.zeros((Bh, cap, 32), np.uint8), np.zeros(Bh, np.int32)) for _ in range(3)])}
     t = ex.submit(pin_src, out=sets["pinned"][1][0]); ex.collect(t)        # warm-up: allocates the ring
-    # the two kinds alternate, two rounds each, and the better round of a kind is reported: the link is shared with whatever else the host does, and
-    # one round of 0.75 s apiece had the kinds trade places from run to run (98 k / 115 k frames/s, then 107 k / 105 k, on the same build)
-    for rnd in range(2):
+    # the two kinds alternate, three rounds each, and the MEDIAN round of a kind is reported (every round is listed beside it): the link is shared with
+    # whatever else the host does, and single rounds of 0.75 s had the kinds trade places from run to run (98 k / 115 k frames/s, then 107 k / 105 k)
+    for rnd in range(3):
         for kind in ("pinned", "pageable"):
             imgs, bufs = sets[kind]                                        # one [B, H, W] array: the binding builds the pointer table arithmetically
             t = ex.submit(imgs, out=bufs[0]); ex.collect(t)
@@ -160,9 +163,8 @@ def host_io(ex_resident, frames, device, blur_round_mode, budget_s=3.0):
             dt = time.perf_counter() - t0
             rate = round(done * Bh / dt, 1)
             rounds = (out[kind]["rounds"] if kind in out else []) + [rate]
-            if kind not in out or rate > out[kind]["frames_per_s"]:
-                out[kind] = {"frames_per_s": rate, "pcie_GBps": round(done * Bh * (W * H + cap * 60 + 4) / dt / 1e9, 2), "keypoints_per_frame": int(nout.mean())}
-            out[kind]["rounds"] = rounds
+            med = sorted(rounds)[len(rounds) // 2]
+            out[kind] = {"frames_per_s": med, "pcie_GBps": round(med * (W * H + cap * 60 + 4) / 1e9, 2), "keypoints_per_frame": int(nout.mean()), "rounds": rounds}
     one = orb_slam2_amd.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, W, H, max_batch=1, device=device, blur_round_mode=blur_round_mode)
     one(src_pageable[0])
     t1 = time.perf_counter()
@@ -170,7 +172,7 @@ def host_io(ex_resident, frames, device, blur_round_mode, budget_s=3.0):
         one(src_pageable[i % Bh])
     out["single_frame_call_ms"] = round((time.perf_counter() - t1) / 100 * 1e3, 4)
     out["value"] = out["pinned"]["frames_per_s"]; out["unit"] = "frames/s"
-    out["note"] = "extract only, PCIe both ways, host buffers in / out; value = pinned caller buffers; measured in a fresh process (the drop-in's situation), the better of two alternating rounds per kind"
+    out["note"] = "extract only, PCIe both ways, host buffers in / out; value = pinned caller buffers; measured in a fresh process (the drop-in's situation), the median of three alternating rounds per kind (all rounds listed)"
     return out
 
 
@@ -183,6 +185,63 @@ def host_io_subprocess(device, blur_round_mode):
     if r.returncode != 0 or not lines:
         return {"error": f"host_io subprocess failed (rc {r.returncode}): {r.stderr[-300:]}"}
     return json.loads(lines[-1])
+
+
+def valu_roofline(dom, launch_ms, B):
+    """The instruction roofline of the dominant kernel (the HBM object beside it is what north_star demands; this is what bounds the kernel):
+    floor_ms = VALU instructions per wave x waves per launch x cycles per wave64 VALU instruction / (SIMDs x clock).  Instruction and wave
+    counts are the SQ counters of the committed PMC passes of this workload (rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES at B = 256, tools/gpu_pmc.sh),
+    waves scaled to this run's batch; 4 cycles per instruction is the measured issue rate of the kernel's packed-u16 / v_perm / v_alignbyte mix
+    (profiles/r02_valu_issue_rates_ubench.txt); 1024 SIMDs and 2.4 GHz are the chip's (MI355X_MICROARCH.md)."""
+    for name in ("r04_pmc_summary.json", "r03_pmc_summary.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            rows = json.load(f)
+        for row in rows:
+            if row["kernel"].split("<")[0] == dom:
+                valu, waves = row["valu_per_wave"], int(row["waves_per_dispatch"] * B / 256)
+                simds, clock, cpi = 1024, 2.4, 4
+                floor_ms = valu * waves * cpi / (simds * clock * 1e9) * 1e3
+                return {"kernel": dom, "valu_insts_per_wave": valu, "waves_per_launch": waves, "cycles_per_inst": cpi, "simds": simds, "clock_GHz": clock,
+                        "floor_ms": round(floor_ms, 4), "launch_ms": round(launch_ms, 4), "frac": round(floor_ms / launch_ms, 4) if launch_ms > 0 else None,
+                        "lds_bank_conflict_frac": row.get("lds_bank_conflict_frac"), "frac_wave_cycles_waiting": row.get("frac_wait_any"),
+                        "source": f"profiles/{name} (SQ_INSTS_VALU / SQ_WAVES per dispatch at B = 256, waves scaled to B = {B}; launch_ms measured in this run)"}
+    return None
+
+
+def hbm_traffic_subprocess(dom, B, args):
+    """HBM bytes the dominant kernel moves per launch, from the L2's memory-side counters, collected as MI355X_MICROARCH.md (HBM / rocprofv3)
+    prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc passes (kernel trace only), KB as reported, FETCH_SIZE doubled (gfx950 tallies
+    a 128-byte request as 64 bytes), WRITE_SIZE as is.  Each pass profiles a short child run of this same workload at this batch."""
+    import glob, csv, shutil, subprocess, tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    per = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="orb_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+               "--batch", str(B), "--steps", "3", "--warmup", "1", "--repeats", "1", "--streams", str(args.streams), "--blur-round-mode", str(args.blur_round_mode),
+               "--no-cpu-baseline", "--no-host-io", "--no-dropin-loop", "--no-traffic", "--parity-slots", "0"]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=300)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode}): {r.stderr[-200:]}"
+            tot, disp = 0.0, set()
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] == counter and row["Kernel_Name"].replace("void ", "").split("(")[0].split("<")[0].strip() == dom:
+                    tot += float(row["Counter_Value"]); disp.add(row.get("Dispatch_Id", row.get("Correlation_Id")))
+            if not disp:
+                return None, f"no {counter} rows for {dom}"
+            per[counter] = (tot * 1024.0 / len(disp), len(disp))
+        except Exception as e:                                            # noqa: BLE001 - a failed profiler pass must not cost the bench line
+            return None, f"rocprofv3 --pmc {counter} pass: {e}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return {"bytes_per_launch": int(2 * per["FETCH_SIZE"][0] + per["WRITE_SIZE"][0]), "fetch_bytes_raw": int(per["FETCH_SIZE"][0]), "write_bytes_raw": int(per["WRITE_SIZE"][0]),
+            "launches_profiled": per["FETCH_SIZE"][1], "method": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, one pass each over a 4-step child run of this workload at this batch; 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction)"}, None
 
 
 def dropin_loop_subprocess(blur_round_mode):
@@ -313,6 +372,7 @@ def main():
     ap.add_argument("--blur-round-mode", type=int, default=1, help="cv::GaussianBlur rounding the extractor reproduces: 1 = the SSE2 column filter of x86-64 OpenCV builds "
                     "(what the reference computes on this x86 box; default), 0 = OpenCV's generic C++ path (DESIGN.md H2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) that measure roofline.traffic")
     ap.add_argument("--no-dropin-loop", action="store_true", help="skip the front-end loop through the reference's own callers (dropin_loop object)")
     ap.add_argument("--host-io-only", action="store_true", help="internal: measure the host_io object in this (fresh) process and print it")
     ap.add_argument("--device", type=int, default=0, help="with --host-io-only: the GPU to use")
@@ -447,6 +507,9 @@ def main():
             traffic_profiled = None
         dur_s = kern[dom]["ms_per_launch"] * 1e-3
         achieved = (alg * B / dur_s) / 1e9 if dur_s > 0 else 0.0
+        rv = valu_roofline(dom, kern[dom]["ms_per_launch"], B)
+        # what bounds the dominant kernel, by the evidence in this line: the VALU-issue floor when the kernel runs within 25 % of it, HBM otherwise
+        bound = "valu" if rv and rv["frac"] and rv["frac"] >= 0.75 and achieved / HBM_PEAK_GBS < 0.5 else "hbm"
         out = {
             "metric": "frames/s ORB extract+match, 1241x376 gray, 2000 kpts, 8 lvls" if not args.extract_only else "DIAGNOSTIC extract only (not the metric)",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -458,9 +521,11 @@ def main():
                        "blur_kernel": "k_blur (VALU)" if os.environ.get("ORBHIP_BLUR") == "valu" else "k_blur_mfma (i8 matrix cores)", "second_stream_schedule": int(os.environ.get("ORBHIP_SCHED", "0"))},
             "repeats": {"n": len(times), "steps_each": args.steps, "timed_region_s": round(sum(times), 3), "frames_per_s_median": round(frames_total / elapsed, 1),
                         "frames_per_s_min": round(frames_total / max(times), 1), "frames_per_s_max": round(frames_total / min(times), 1)},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": bound, "bound_note": "achieved / peak / frac are the HBM figures north_star asks for; `bound` names what the evidence says limits the kernel (roofline_valu.frac)",
+                         "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_profiled": traffic_profiled,
                          "alg_bytes_per_launch": alg * B, "launch_ms": round(kern[dom]["ms_per_launch"], 4), "note": note},
+            "roofline_valu": rv,
             "pipeline_roofline": {"alg_bytes_per_frame": ex.algorithmic_bytes_per_frame(),
                                   "achieved_GBps": round(ex.algorithmic_bytes_per_frame() * value / world / 1e9, 2),
                                   "frac_of_hbm_peak": round(ex.algorithmic_bytes_per_frame() * value / world / 1e9 / HBM_PEAK_GBS, 5)},
@@ -470,17 +535,28 @@ def main():
             "parity": parity,
             "runtime": {"library": runtime_line, "mapped": orb_slam2_amd.mapped_hip_runtimes(), "framework_imported": "torch" in sys.modules, "control_plane": control},
         }
+        closed = False
         if parity and (parity["mismatches"] or parity["replica_mismatches"]):
             out["INVALID"] = "results of the timed region differ from the oracle: the throughput above does not count"
+        if world == 1 and not args.no_traffic:
+            ex.close(); d_frames.free(); closed = True
+            t, why = hbm_traffic_subprocess(dom, B, args)
+            if t:
+                out["roofline"]["traffic"] = t["bytes_per_launch"]
+                out["roofline"]["traffic_measured"] = t
+                out["roofline"]["traffic_over_algorithmic"] = round(t["bytes_per_launch"] / max(alg * B, 1), 3)
+            else:
+                out["roofline"]["traffic_note"] = why
         if world == 1 and not args.no_host_io:
             # measured in a process of its own: in a process that holds (or has held) a large resident context the DMA path from / into the caller's
             # pinned buffers delivers 93-100 k frames/s instead of the 112-117 k of a fresh process, on every box tried, while the pageable path is
             # unaffected (profiles/r03_exp_host_io_pinned_vs_pageable_by_box.jsonl; cause not found) - and the drop-in's callers are such fresh processes
-            ex.close(); d_frames.free()
+            if not closed:
+                ex.close(); d_frames.free(); closed = True
             out["host_io"] = host_io_subprocess(local_rank, args.blur_round_mode)
         if world == 1 and not args.no_dropin_loop:
-            if args.no_host_io:
-                ex.close(); d_frames.free()                              # (otherwise closed above) the loop runs beside nothing, like the host_io object
+            if not closed:
+                ex.close(); d_frames.free(); closed = True               # the loop runs beside nothing, like the host_io object
             out["dropin_loop"] = dropin_loop_subprocess(args.blur_round_mode)
         if world == 1 and not args.no_cpu_baseline:
             os.environ["ORB_REF_BLUR_ROUND_MODE"] = str(args.blur_round_mode)      # the reference build's GaussianBlur stand-in follows the same rounding
