@@ -154,6 +154,10 @@ void orbhip_pool_destroy(orbhip_pool* pool);
 int orbhip_pool_num_devices(const orbhip_pool* pool);
 int orbhip_pool_device_of(const orbhip_pool* pool, int camera);          /* devices[camera mod G], -1 if out of range */
 int orbhip_pool_keypoint_capacity(const orbhip_pool* pool);
+/* NUMA placement of worker r: the node its device hangs off (/sys/bus/pci/devices/<bus id>/numa_node; -1 = unknown) and, in *bound (may be
+   NULL), whether the worker thread - and with it the pinned staging ring it allocates - was bound to that node's CPUs.  ORBHIP_POOL_NUMA=0
+   disables the binding. */
+int orbhip_pool_numa_node(const orbhip_pool* pool, int r, int* bound);
 /* one frame per camera (imgs[c] == NULL: that camera has no frame this round, n_out[c] = 0); outputs are [ncameras][cap].
    orbhip_pool_extract = orbhip_pool_submit + orbhip_pool_collect; with submit / collect a caller keeps up to
    orbhip_ring_depth() rounds in flight (tickets collected in order).  A round that only SOME devices could take (a HIP failure on one

@@ -255,8 +255,10 @@ void ORBextractor::Collect(int ticket, std::vector<std::vector<cv::KeyPoint> >& 
     if (!mpCtx) throw ORBhipError("ORBextractor::Collect: nothing was submitted");
     const int n = mvTicketSizes[ticket & 3], cap = orbhip_keypoint_capacity(mpCtx);
     std::vector<orbhip_keypoint> kps((size_t)n * cap); std::vector<unsigned char> desc((size_t)n * cap * 32); std::vector<int> cnt(n, 0);
-    if (orbhip_collect(mpCtx, ticket, &kps[0], &desc[0], cap, &cnt[0]) != ORBHIP_OK) Fail("ORBextractor::Collect");
-    if (mnPendingTickets > 0) mnPendingTickets--;
+    const orbhip_status st = orbhip_collect(mpCtx, ticket, &kps[0], &desc[0], cap, &cnt[0]);
+    // every status but INVALID (not the oldest ticket: it stays collectable) retired the ticket on the C side, a device failure included
+    if (st != ORBHIP_ERR_INVALID && mnPendingTickets > 0) mnPendingTickets--;
+    if (st != ORBHIP_OK) Fail("ORBextractor::Collect");
     keypoints.resize(n); descriptors.resize(n);
     for (int i = 0; i < n; i++) {
         keypoints[i].resize(cnt[i]);

@@ -8,8 +8,10 @@
 // independent uploads of the same 64 KB query + G shard scans whose per-query (best, second, index) triples are merged on the host
 // with the matcher's rule — 2000 x G x 16 B, not worth an all-gather over xGMI.
 #include "orbhip_internal.h"
+#include <sched.h>
 #include <algorithm>
 #include <condition_variable>
+#include <cstdio>
 #include <cstring>
 #include <deque>
 #include <functional>
@@ -22,7 +24,7 @@
 namespace {
 
 struct Worker {
-    int device = 0, index = 0;
+    int device = 0, index = 0, numa_node = -1; bool numa_bound = false;
     orbhip_ctx* ctx = nullptr;
     std::thread th; std::mutex m; std::condition_variable cv, cv_done; std::deque<std::function<void()>> q; int pending = 0; bool stop = false;
     // result of the last task(s)
@@ -58,9 +60,53 @@ struct orbhip_pool {
 };
 
 static orbhip_status pool_status(orbhip_pool* p, const char* what)
-{   // first failure of the round, reported on the calling thread
-    for (auto& w : p->w) if (w->st != ORBHIP_OK) { const orbhip_status s = w->st; const std::string e = w->err; w->st = ORBHIP_OK; return orbhip_set_error(s, "%s (device %d): %s", what, w->device, e.c_str()); }
-    return ORBHIP_OK;
+{   // first failure of the round, reported on the calling thread; EVERY worker's status is cleared with it (a round that all devices refuse must
+    // not leave the second device's refusal behind to be blamed on the next, healthy round)
+    orbhip_status first = ORBHIP_OK; int dev = -1; std::string msg;
+    for (auto& w : p->w) {
+        if (w->st != ORBHIP_OK && first == ORBHIP_OK) { first = w->st; dev = w->device; msg = w->err; }
+        w->st = ORBHIP_OK; w->err.clear();
+    }
+    return first == ORBHIP_OK ? ORBHIP_OK : orbhip_set_error(first, "%s (device %d): %s", what, dev, msg.c_str());
+}
+
+// ---- NUMA placement.  On a two-socket node every GPU hangs off one socket's PCIe root: a worker whose copy loops (pageable -> pinned gathers,
+// result scatters) and pinned ring live on the other socket pay a cross-socket hop on every byte, and at 8 GPUs x ~55 GB/s of uploads the host side
+// is what bends the scaling curve.  Each worker therefore binds itself to the CPUs of its device's NUMA node BEFORE it creates its context:
+// the context's pinned mirrors (hipHostMalloc, first touched by this thread) then come from that node's memory.  ORBHIP_POOL_NUMA=0 turns it off.
+static int device_numa_node(int device)
+{
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    for (char* c = bus; *c; c++) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
+    const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/numa_node";
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) return -1;
+    int node = -1;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    return node;
+}
+static bool bind_thread_to_node(int node)
+{   // /sys/devices/system/node/node<N>/cpulist: "0-63,128-191"
+    if (node < 0) return false;
+    char path[128]; snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE* f = fopen(path, "r");
+    if (!f) return false;
+    char buf[4096] = {0};
+    const bool got = fgets(buf, sizeof buf, f) != nullptr;
+    fclose(f);
+    if (!got) return false;
+    cpu_set_t set; CPU_ZERO(&set);
+    int ncpu = 0;
+    for (char* tok = strtok(buf, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+        int a = 0, b = 0;
+        const int k = sscanf(tok, "%d-%d", &a, &b);
+        if (k < 1) continue;
+        if (k == 1) b = a;
+        for (int c = a; c <= b && c < CPU_SETSIZE; c++) { CPU_SET(c, &set); ncpu++; }
+    }
+    return ncpu > 0 && sched_setaffinity(0, sizeof set, &set) == 0;
 }
 
 extern "C" void orbhip_pool_destroy(orbhip_pool* p)
@@ -97,7 +143,11 @@ extern "C" orbhip_status orbhip_pool_create(orbhip_pool** out, const int* device
         Worker* wp = w.get();
         w->th = std::thread([wp] { wp->loop(); });
         orbhip_config c = *cfg; c.device = devices[r]; c.max_batch = p->per_dev; c.stream = nullptr;
-        w->post([wp, c] { const orbhip_status s = orbhip_create(&wp->ctx, &c); if (s != ORBHIP_OK) wp->fail_from_thread(s); });
+        w->post([wp, c] {
+            static const bool numa = [] { const char* e = getenv("ORBHIP_POOL_NUMA"); return !(e && *e == '0'); }();
+            if (numa) { wp->numa_node = device_numa_node(wp->device); wp->numa_bound = bind_thread_to_node(wp->numa_node); }
+            const orbhip_status s = orbhip_create(&wp->ctx, &c); if (s != ORBHIP_OK) wp->fail_from_thread(s);
+        });
         p->w.push_back(std::move(w));
     }
     for (auto& w : p->w) w->wait();
@@ -111,6 +161,12 @@ extern "C" orbhip_status orbhip_pool_create(orbhip_pool** out, const int* device
 extern "C" int orbhip_pool_num_devices(const orbhip_pool* p) { return p ? (int)p->w.size() : 0; }
 extern "C" int orbhip_pool_device_of(const orbhip_pool* p, int camera) { return (p && camera >= 0 && camera < p->ncam) ? p->w[camera % p->w.size()]->device : -1; }
 extern "C" int orbhip_pool_keypoint_capacity(const orbhip_pool* p) { return p ? p->cap : 0; }
+extern "C" int orbhip_pool_numa_node(const orbhip_pool* p, int r, int* bound)
+{
+    if (!p || r < 0 || r >= (int)p->w.size()) { if (bound) *bound = 0; return -1; }
+    if (bound) *bound = p->w[r]->numa_bound ? 1 : 0;
+    return p->w[r]->numa_node;
+}
 
 extern "C" orbhip_status orbhip_pool_submit(orbhip_pool* p, const uint8_t* const* imgs, int stride, int* ticket)
 {
@@ -124,9 +180,10 @@ extern "C" orbhip_status orbhip_pool_submit(orbhip_pool* p, const uint8_t* const
         if (w->cams[slot].empty()) continue;
         w->post([w, slot, imgs, stride] {
             std::vector<const uint8_t*> mine; for (int c : w->cams[slot]) mine.push_back(imgs[c]);
-            // ORBHIP_TEST_FAIL_SUBMIT_WORKER=<r> (fault injection for the test of the partial-failure path): worker r refuses its submits
+#ifdef ORBHIP_TEST_HOOKS      // the CPU emulation build only (tests/emu): ORBHIP_TEST_FAIL_SUBMIT_WORKER=<r> makes worker r refuse its submits (partial-failure path)
             const char* inj = getenv("ORBHIP_TEST_FAIL_SUBMIT_WORKER");
             if (inj && *inj && atoi(inj) == w->index) { w->ctx_ticket[slot] = -1; w->st = ORBHIP_ERR_HIP; w->err = "injected submit failure"; return; }
+#endif
             const orbhip_status s = orbhip_submit(w->ctx, (int)mine.size(), mine.data(), stride, &w->ctx_ticket[slot]);
             if (s != ORBHIP_OK) { w->ctx_ticket[slot] = -1; w->fail_from_thread(s); }
         });

@@ -34,7 +34,7 @@ SYMBOLS = [
     "orbhip_set_rectification", "orbhip_extract_batch_rectify", "orbhip_extract_device_rectify", "orbhip_compute_stereo_from_rgbd",
     "orbhip_search_by_projection_frame", "orbhip_search_best_in_window_frame", "orbhip_search_by_projection_batch",
     "orbhip_pyramid_fetch_all", "orbhip_set_blur_rounding", "orbhip_set_fp_contract", "orbhip_submit", "orbhip_collect", "orbhip_ring_depth", "orbhip_host_alloc", "orbhip_host_free",
-    "orbhip_pool_create", "orbhip_pool_destroy", "orbhip_pool_num_devices", "orbhip_pool_device_of", "orbhip_pool_keypoint_capacity",
+    "orbhip_pool_create", "orbhip_pool_destroy", "orbhip_pool_num_devices", "orbhip_pool_device_of", "orbhip_pool_keypoint_capacity", "orbhip_pool_numa_node",
     "orbhip_pool_extract", "orbhip_pool_submit", "orbhip_pool_collect", "orbhip_pool_db_load", "orbhip_pool_db_shard", "orbhip_pool_db_query",
     "orbhip_reloc_candidates", "orbhip_runtime_info", "orbhip_device_alloc", "orbhip_device_free", "orbhip_device_upload", "orbhip_device_download",
     "orbhip_device_synchronize", "orbhip_submit_to",
@@ -183,6 +183,7 @@ def lib(path=None):
     L.orbhip_pool_num_devices.argtypes = [vp]
     L.orbhip_pool_device_of.argtypes = [vp, C.c_int]
     L.orbhip_pool_keypoint_capacity.argtypes = [vp]
+    L.orbhip_pool_numa_node.argtypes = [vp, C.c_int, ip]
     L.orbhip_pool_extract.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, vp]
     L.orbhip_pool_submit.argtypes = [vp, vp, C.c_int, ip]
     L.orbhip_pool_collect.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp]
@@ -197,6 +198,9 @@ def lib(path=None):
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+OK, ERR_INVALID, ERR_HIP, ERR_CAPACITY, ERR_UNSUPPORTED = 0, 1, 2, 3, 4      # orbhip_status (include/orbhip.h)
 
 
 def _check(st, what, L=None):
@@ -306,7 +310,7 @@ class ORBextractor:
         n = len(images)
         assert 1 <= n <= self.max_batch
         if isinstance(images, np.ndarray) and images.ndim == 3 and images.dtype == np.uint8 and images.shape[1:] == (self.height, self.width) \
-                and images.strides[2] == 1 and images.strides[1] == self.width:
+                and images.strides[2] == 1 and images.strides[1] == self.width and images.strides[0] >= self.height * self.width:
             # one array of frames: the pointer table is arithmetic (no per-image Python work: at 100 k frames/s a batch of 256 is 2.5 ms)
             imgs = images
             table = (images.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(images.strides[0])).astype(np.uint64)
@@ -319,6 +323,14 @@ class ORBextractor:
             ptrs = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
         t = C.c_int(-1)
         if out is not None:
+            # pinned result buffers are written by DMA, n * capacity records each: anything smaller or strided would be a silent host-memory overrun
+            k_, d_ = out[0], out[1]
+            if not (isinstance(k_, np.ndarray) and k_.dtype == KEYPOINT_DTYPE and k_.ndim == 2 and k_.shape[0] >= n and k_.shape[1] == self.capacity and k_.flags["C_CONTIGUOUS"]):
+                raise ValueError(f"submit(out=...): key point buffer must be a C-contiguous [>= {n}, {self.capacity}] array of KEYPOINT_DTYPE")
+            if not (isinstance(d_, np.ndarray) and d_.dtype == np.uint8 and d_.ndim == 3 and d_.shape[0] >= n and d_.shape[1:] == (self.capacity, 32) and d_.flags["C_CONTIGUOUS"]):
+                raise ValueError(f"submit(out=...): descriptor buffer must be a C-contiguous [>= {n}, {self.capacity}, 32] uint8 array")
+            if len(out) > 2 and not (isinstance(out[2], np.ndarray) and out[2].dtype == np.int32 and out[2].size >= n and out[2].flags["C_CONTIGUOUS"]):
+                raise ValueError(f"submit(out=...): the count buffer must be a C-contiguous int32 array of >= {n} entries")
             _check(self.L.orbhip_submit_to(self.h, n, ptrs, self.width, _p(out[0]), _p(out[1]), self.capacity, C.byref(t)), "orbhip_submit_to", self.L)
         else:
             _check(self.L.orbhip_submit(self.h, n, ptrs, self.width, C.byref(t)), "orbhip_submit", self.L)
@@ -328,12 +340,15 @@ class ORBextractor:
 
     def collect(self, ticket, out=None):
         """Results of a submitted batch (tickets in submission order): ([keypoints], [descriptors]).  out = (kps, desc, nout) buffers to reuse."""
-        n, held = self._inflight.pop(ticket)
+        n, held = self._inflight[ticket]
         cap = self.capacity
         if out is None and held[2] is not None:
             out = held[2]                                          # the buffers named at submit
         kps, desc, nout = out if out is not None else (np.zeros((n, cap), KEYPOINT_DTYPE), np.zeros((n, cap, 32), np.uint8), np.zeros(n, np.int32))
-        _check(self.L.orbhip_collect(self.h, ticket, _p(kps), _p(desc), cap, _p(nout)), "orbhip_collect", self.L)
+        st = self.L.orbhip_collect(self.h, ticket, _p(kps), _p(desc), cap, _p(nout))
+        if st != ERR_INVALID:                                      # every other status retired the ticket on the C side; INVALID (wrong ticket / wrong buffers) left it collectable
+            self._inflight.pop(ticket, None)
+        _check(st, "orbhip_collect", self.L)
         if out is not None:
             return nout
         return [kps[f, :nout[f]].copy() for f in range(n)], [desc[f, :nout[f]].copy() for f in range(n)]
@@ -635,6 +650,12 @@ class MultiGpuExtractor:
 
     def device_of(self, camera):
         return self.L.orbhip_pool_device_of(self.h, camera)
+
+    def numa_node(self, r):
+        """(NUMA node of worker r's device or -1, whether the worker thread and its pinned ring were bound to that node)"""
+        b = C.c_int(0)
+        node = self.L.orbhip_pool_numa_node(self.h, r, C.byref(b))
+        return node, bool(b.value)
 
     def _ptrs(self, images):
         assert len(images) == self.ncameras

@@ -299,6 +299,7 @@ inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr
 inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return hipSuccess; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
 inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipDeviceGetPCIBusId(char* buf, int len, int dev) { snprintf(buf, (size_t)len, "emu0:%02x:00.0", dev); return hipSuccess; }      // no such sysfs entry: NUMA node unknown
 inline hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = 0; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }

@@ -133,6 +133,8 @@ def test_pool_survives_partial_submit_failure(backend, frames, want, monkeypatch
     """One device refuses a round (injected): the round keeps its ticket (the other device's part must be collected in order), collect
     delivers the healthy cameras and reports the refusal, and the pool keeps working — a context ticket nobody collects would wedge its
     ring for good.  A round NO device takes fails at submit, without a ticket."""
+    if not backend.endswith("_emu.so"):
+        pytest.skip("the fault-injection hook is compiled into the CPU emulation build only (-DORBHIP_TEST_HOOKS), not into liborbhip.so")
     devices = _pool_devices(backend, monkeypatch, 2)
     pool = orb_slam2_amd.MultiGpuExtractor(devices, 4, N, 1.2, 8, 20, 7, W, H, library=backend)
     t0 = pool.submit(frames[:4])
@@ -151,6 +153,26 @@ def test_pool_survives_partial_submit_failure(backend, frames, want, monkeypatch
     for _ in range(4):                                            # more rounds than the ring is deep: nothing is left in flight
         k, d = pool.extract(frames[4:8])
         _same(k, d, want, range(4, 8))
+    pool.close()
+
+
+def test_pool_round_refused_by_every_device_leaves_nothing_behind(backend, frames, want, monkeypatch):
+    """A round EVERY device refuses (a row stride below the width: ERR_INVALID on all workers) fails at submit without a ticket - and the next,
+    healthy round must not inherit the second device's refusal (only the first failing worker's status used to be cleared)."""
+    import ctypes as C
+    devices = _pool_devices(backend, monkeypatch, 2)
+    pool = orb_slam2_amd.MultiGpuExtractor(devices, 4, N, 1.2, 8, 20, 7, W, H, library=backend)
+    imgs, ptrs = pool._ptrs(frames[:4])
+    t = C.c_int(-1)
+    for _ in range(2):
+        assert pool.L.orbhip_pool_submit(pool.h, ptrs, W - 1, C.byref(t)) == orb_slam2_amd.orbhip.ERR_INVALID and t.value == -1
+        assert b"stride" in pool.L.orbhip_last_error()
+    for lo in (0, 4):
+        t0 = pool.submit(frames[lo:lo + 4])
+        k, d = pool.collect(t0)                                   # no "orbhip_pool_submit of this round (device ...)" error from the refused rounds
+        _same(k, d, want, range(lo, lo + 4))
+    node, bound = pool.numa_node(0)
+    assert node >= -1 and (bound is False or node >= 0) and pool.numa_node(7) == (-1, False)
     pool.close()
 
 

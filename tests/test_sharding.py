@@ -135,6 +135,32 @@ def test_bench_gpus_flag_on_this_box():
         assert json.loads(line)["n_gpus"] == 2
 
 
+@pytest.mark.gpu
+def test_bench_eight_ranks_on_one_gpu():
+    """The 8-GPU command the driver runs at round end, first time right: `bench.py --gpus 8` becomes its own launcher, eight ranks rendezvous,
+    every rank builds its resident batch and context, the timed region is bracketed by the 8-way barrier, rank 0 prints ONE JSON line with
+    n_gpus = 8 and a bit-exact parity object.  No 8-GPU node is available to the builder, so the eight ranks share this box's GPU
+    (ORB_BENCH_SHARE_GPU=1: a test aid bench.py names in its config line; the number it prints is not a scaling figure)."""
+    import json
+    import subprocess
+    import time
+    env = dict(os.environ); env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    env["ORB_BENCH_SHARE_GPU"] = "1"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--batch", "32", "--steps", "3", "--warmup", "1", "--repeats", "2",
+                        "--no-cpu-baseline", "--no-host-io", "--no-traffic", "--no-dropin-loop"], env=env, capture_output=True, text=True, timeout=1200)
+    wall = time.time() - t0
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["steps"] == 3 and d["unit"] == "frames/s" and d["value"] > 0
+    assert d["config"]["frames_per_step_per_gpu"] == 32 and "8 GPU" in d["config"]["parallelism"]
+    assert d["parity"]["mismatches"] == 0 and d["parity"]["replica_mismatches"] == 0 and "INVALID" not in d
+    assert "unix-socket rendezvous" in d["runtime"]["control_plane"] and d["runtime"]["framework_imported"] is False
+    print(f"\n[8 ranks on one GPU] launcher + 8 ranks + rendezvous + run: {wall:.1f} s wall; {d['value']:.0f} frames/s over the shared GPU (not a scaling figure)")
+
+
 def _rdzv_worker(rank, world, key, q):
     sys.path.insert(0, ROOT)
     from orb_slam2_amd.sharding import NodeRendezvous
