@@ -518,7 +518,7 @@ def main():
             "config": {"workload": "KITTI-shaped 1241x376 u8, 2000 features, 8 levels, scale 1.2, FAST 20/7, extract + SearchForInitialization(win 100, nnratio 0.9)",
                        "inputs": "hbm-resident, results stay on device (the PCIe-inclusive host-buffer rate is the host_io object)",
                        "frames_per_step_per_gpu": B, "resident_time_steps": T, "distinct_scenes": min(B, NSCENES), "blur_round_mode": args.blur_round_mode, "row_pitch": pitch, "streams_per_gpu": args.streams, "parallelism": f"frames sharded over {world} GPU(s), no collective",
-                       "blur_kernel": "k_blur (VALU)" if os.environ.get("ORBHIP_BLUR") == "valu" else "k_blur_mfma (i8 matrix cores)", "second_stream_schedule": int(os.environ.get("ORBHIP_SCHED", "0"))},
+                       "blur_kernel": "k_blur (VALU)" if os.environ.get("ORBHIP_BLUR") == "valu" else "k_blur_mfma (i8 matrix cores)"},
             "repeats": {"n": len(times), "steps_each": args.steps, "timed_region_s": round(sum(times), 3), "frames_per_s_median": round(frames_total / elapsed, 1),
                         "frames_per_s_min": round(frames_total / max(times), 1), "frames_per_s_max": round(frames_total / min(times), 1)},
             "roofline": {"bound": bound, "bound_note": "achieved / peak / frac are the HBM figures north_star asks for; `bound` names what the evidence says limits the kernel (roofline_valu.frac)",

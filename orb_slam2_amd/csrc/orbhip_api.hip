@@ -91,13 +91,7 @@ struct orbhip_ctx {
     hipEvent_t ev_epilogue = nullptr;
     std::vector<int> last_n; bool last_n_valid = false;      // key point counts of the last call as already delivered to the host (the call's results were waited for)
     // host-buffer API staging: one contiguous device input buffer + pinned host mirrors (single bulk copies instead of per-frame pageable copies)
-    bool serial = false;      // ORBHIP_SERIAL=1 (measurement only): every kernel on the main stream, no overlap
-    int sched = 0;            // ORBHIP_SCHED (measurement only): what runs on the second stream, see pipeline_frames
-    int blur_tiles_l0 = 0;    // blur tiles of level 0 (the tile list is level-major)
-    hipEvent_t ev_start = nullptr, ev_fast0 = nullptr;
-    // ORBHIP_SCHED=3 (measurement only): the pyramid of call t+1 on its own stream beside the kernels of call t, into the other of two plane sets
-    uint8_t* d_pyr_sets[2] = {nullptr, nullptr}; int pyr_set = 0; hipStream_t pstream = nullptr; hipEvent_t ev_desc[2] = {nullptr, nullptr}, ev_pyr_ahead = nullptr; bool desc_pending[2] = {false, false};
-    bool pyr_tail = false, pyr_tail_any = false;    // ORBHIP_PYR_TAIL=1 (measurement only): the last pyramid levels in one launch, see launch_pyramid; 2: at any batch size
+    bool serial = false;      // ORBHIP_SERIAL=1 (profiling aid): every kernel on the main stream, nothing overlaps - per-kernel times are standalone times
     uint8_t* d_in = nullptr; uint8_t* h_in = nullptr; uint8_t* d_col = nullptr; uint8_t* h_col = nullptr; size_t col_bytes = 0; orbhip_keypoint* h_kp = nullptr; uint8_t* h_desc = nullptr; int* h_n = nullptr; int in_pitch = 0;
     // stereo (Frame::ComputeStereoMatches): level-0 source of the last call + lazily allocated workspace on the LEFT context
     const uint8_t* last_img0 = nullptr; long long last_img0_fstride = 0; int last_img0_pitch = 0;
@@ -279,14 +273,9 @@ extern "C" void orbhip_destroy(orbhip_ctx* c)
     for (auto xs : c->xstreams) { (void)hipStreamSynchronize(xs); (void)hipStreamDestroy(xs); }
     for (auto e : c->xevents) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
-    if (c->ev_fast0) (void)hipEventDestroy(c->ev_fast0);
-    if (c->pstream) { (void)hipStreamSynchronize(c->pstream); (void)hipStreamDestroy(c->pstream); }
-    for (int k = 0; k < 2; k++) if (c->ev_desc[k]) (void)hipEventDestroy(c->ev_desc[k]);
-    if (c->ev_pyr_ahead) (void)hipEventDestroy(c->ev_pyr_ahead);
     prof_collect(c);
     for (auto e : c->pool) (void)hipEventDestroy(e);
-    void* ptrs[] = {c->d_blur_band, c->d_ic_mask, c->d_xgrp, c->d_fc_dma, c->d_geom, c->d_cells, c->d_tiles, c->d_xtab, c->d_ytab, c->d_pattern, c->d_pyr_sets[0], c->d_pyr_sets[1], c->d_blur, c->d_cell_count, c->d_cell_cand,
+    void* ptrs[] = {c->d_blur_band, c->d_ic_mask, c->d_xgrp, c->d_fc_dma, c->d_geom, c->d_cells, c->d_tiles, c->d_xtab, c->d_ytab, c->d_pattern, c->d_pyr, c->d_blur, c->d_cell_count, c->d_cell_cand,
                     c->d_qt_val, c->d_qt_code, c->d_qt_node, c->d_lvl_kp, c->d_lvl_n[0], c->d_lvl_n[1], c->d_lvl_n[2], c->d_out_block[0], c->d_out_block[1], c->d_out_block[2], c->d_grid_start, c->d_grid_items, c->d_grid_xy, c->d_cand, c->d_top, c->d_ncand,
                     c->d_prev, c->d_m12, c->d_nm};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -315,10 +304,7 @@ extern "C" void orbhip_destroy(orbhip_ctx* c)
 // eight rows a wave reads at once on each LDS bank exactly twice (the minimum for 64 lanes x 4 bytes)
 static int fc_pstride(const orbhip_ctx* c)
 {
-    const int need = (c->fc_maxpw + 8 + 3) & ~3;
-    const char* e = getenv("ORBHIP_FC_PSTRIDE");                  // experiment knob: a larger LDS row stride of the FAST patch (bytes, multiple of 4)
-    const int forced = e ? atoi(e) & ~3 : 0;
-    return forced >= need ? forced : need;
+    return (c->fc_maxpw + 8 + 3) & ~3;
 }
 
 extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cfg)
@@ -355,7 +341,7 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
         for (int i = 0; i < 7; i++) { double x = i - 3.0; cf[i] = (float)std::exp(scale2X * x * x); sum += cf[i]; }
         sum = 1. / sum;
         for (int i = 0; i < 4; i++) c->gk[i] = cvRoundF((float)(cf[3 + i] * sum) * 256.f);      // centre, +-1, +-2, +-3
-        { const char* e = getenv("ORBHIP_BLUR"); c->blur_mfma = !(e && strcmp(e, "valu") == 0); }       // ORBHIP_BLUR=valu (measurement only): the all-VALU blur kernel instead of k_blur_mfma
+        { const char* e = getenv("ORBHIP_BLUR"); c->blur_mfma = !(e && strcmp(e, "valu") == 0); }       // ORBHIP_BLUR=valu: the all-VALU blur kernel instead of k_blur_mfma
         if (c->gk[0] > 127 || c->gk[0] + 2 * (c->gk[1] + c->gk[2] + c->gk[3]) != 257) c->blur_mfma = false;     // the i8 form assumes these taps
     }
     // ---- per level geometry (ORBextractor.cc:1111-1112, 773-806, 543-545)
@@ -449,10 +435,6 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
     }
     if (!c->xstreams.empty() && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { orbhip_destroy(c); return fail(ORBHIP_ERR_HIP, "event creation failed"); }
     { const char* e = getenv("ORBHIP_SERIAL"); c->serial = e && e[0] == '1'; }
-    { const char* e = getenv("ORBHIP_PYR_TAIL"); c->pyr_tail = e && (e[0] == '1' || e[0] == '2'); c->pyr_tail_any = e && e[0] == '2'; }
-    { const char* e = getenv("ORBHIP_SCHED"); c->sched = e ? atoi(e) : 0; }
-    for (const TileDesc& t : c->blur_tiles) if (t.level == 0) c->blur_tiles_l0++;
-    if (hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_fast0, hipEventDisableTiming) != hipSuccess) { orbhip_destroy(c); return fail(ORBHIP_ERR_HIP, "event creation failed"); }
     {   // the matcher runs on its own stream so that it overlaps the next batch's extraction
         bool ok = hipStreamCreateWithFlags(&c->mstream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&c->ev_extract, hipEventDisableTiming) == hipSuccess &&
                   hipStreamCreateWithFlags(&c->bstream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&c->ev_pyr, hipEventDisableTiming) == hipSuccess &&
@@ -504,13 +486,6 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
         TRY(upload(&c->d_fc_dma, tab));
     }
     TRY(dalloc(&c->d_pyr, B * c->plane_frame_bytes + 256)); TRY(dalloc(&c->d_blur, B * c->plane_frame_bytes + 256));
-    c->d_pyr_sets[0] = c->d_pyr;
-    if (c->sched == 3 && c->own_stream && c->mstream) {
-        TRY(dalloc(&c->d_pyr_sets[1], B * c->plane_frame_bytes + 256));
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->pstream, hipStreamNonBlocking);
-        for (int k = 0; k < 2 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&c->ev_desc[k], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_pyr_ahead, hipEventDisableTiming);
-    }
     TRY(dalloc(&c->d_cell_count, B * c->cells.size())); TRY(dalloc(&c->d_cell_cand, B * c->cand_slots_per_frame));
     TRY(dalloc(&c->d_qt_val, B * c->qt_per_frame)); TRY(dalloc(&c->d_qt_code, B * c->qt_per_frame)); TRY(dalloc(&c->d_qt_node, B * c->qt_per_frame));
     TRY(dalloc(&c->d_lvl_kp, B * c->lvl_kp_per_frame));
@@ -583,120 +558,34 @@ static ExtractParams make_params(orbhip_ctx* c, const uint8_t* d_img0, long long
     return P;
 }
 
-// levels 1 .. L-1, each from the one before.  ORBHIP_PYR_TAIL=1 (measurement only) sends the small levels at the end (up to four, all in 4-pixel-group
-// mode, from 64 frames on) through ONE launch (k_pyramid_tail_g: a workgroup per frame): 11 -> 8 launches per extraction step, but measured
-// twice as slow as the separate launches (pyramid 0.27 -> 0.54 ms at B = 256, 167 k -> 133 k frames/s at B = 512, gpurun tl1): a single workgroup
-// per frame walks stage / barrier / compute / barrier / fence per tile group with nothing to hide the latency behind.  Off by default.
+// levels 1 .. L-1, each from the one before: seven dependent launches.  (Fewer were tried and lost: the small levels in one launch of one
+// workgroup per frame, 0.27 -> 0.54 ms at B = 256 and +0.09 ms per single-frame call; see docs/ROUND_LOG.md.)
 static void launch_pyramid(orbhip_ctx* c, const ExtractParams& P, int nf, hipStream_t s)
 {
-    int tail0 = c->L;
-    if ((nf >= 64 || c->pyr_tail_any) && c->pyr_tail) { while (tail0 - 1 >= 1 && c->L - (tail0 - 1) <= 4 && c->pyr_staged[tail0 - 1] == 2 && c->geom[tail0 - 1].w * c->geom[tail0 - 1].h <= 160 * 1024) tail0--; }
-    if (c->L - tail0 < 2) tail0 = c->L;
-    for (int l = 1; l < tail0; l++) orbhip_launch_pyramid_level(P, l, c->geom[l].w, c->geom[l].h, (int)c->pyr_staged[l], nf, s);
-    if (tail0 < c->L) orbhip_launch_pyramid_tail(P, tail0, nf, s);
+    for (int l = 1; l < c->L; l++) orbhip_launch_pyramid_level(P, l, c->geom[l].w, c->geom[l].h, (int)c->pyr_staged[l], nf, s);
 }
 
-// pyramid -> FAST -> quadtree -> describe for camera slots [f0, f0 + nf) on stream s.  With own_blur_stream the context's second stream
-// takes what does not depend on the main chain's current step (ORBHIP_SCHED, measured at B = 512 with the round-2 kernels, gpurun s3):
-//   0 (default): the blur beside the quadtree, whose workgroups are latency-bound (barriers, one per (frame, level))      167.7 k frames/s
-//   1: the blur beside pyramid + FAST (level 0 at once, the rest behind the pyramid)                                       168.2 k
-//   2: FAST of level 0 beside the pyramid (neither needs the other), then the blur beside FAST of the other levels         169.9 k
-//   3: the pyramid of call t+1 on a stream of its own, into the other of two plane sets, beside the kernels of call t (device-resident
-//      entry only; + one plane set of memory): 171.7 k at B = 512 (+1.2 %), +1.9 % at B = 256, +4.2 % at B = 128 (gpurun s4)
-// 0-2 land within 1.3 %: the step is the sum of the kernels' standalone times whatever runs beside what.  0 keeps every throughput kernel
-// alone on the GPU, so its HIP-event time in the timed region is its own (the bench's roofline object relies on that; under 3 the previous
-// call's matcher moves from beside the pyramid to beside FAST, whose event time then reads 1.15 instead of 0.98 ms for the same work).
-static orbhip_status pipeline_frames(orbhip_ctx* c, ExtractParams& P, int f0, int nf, hipStream_t s, bool own_blur_stream, hipEvent_t pyr_done = nullptr)
-{   // pyr_done: the pyramid of these frames was launched elsewhere (ORBHIP_SCHED=3); s waits for it instead of building it
+// pyramid -> FAST -> quadtree -> describe for camera slots [f0, f0 + nf) on stream s.  With own_blur_stream (and more than a handful of frames)
+// the blur - independent of FAST and the quadtree until the descriptor kernel - runs on the context's second stream beside the quadtree, whose
+// workgroups are latency-bound (barriers, one workgroup per (frame, level)); every throughput kernel is alone on the GPU, so its HIP-event time
+// in a timed region is its own (bench.py's roofline object relies on that).  Other placements of the second stream landed within 1.3 % of this
+// one and are gone from the code (docs/ROUND_LOG.md, round 3 "schedules").
+static orbhip_status pipeline_frames(orbhip_ctx* c, ExtractParams& P, int f0, int nf, hipStream_t s, bool own_blur_stream)
+{
     if (nf <= 0) return ORBHIP_OK;
     P.frame0 = f0;
-    const int nt0 = c->blur_tiles_l0, nt1 = (int)c->blur_tiles.size() - nt0;
-    const int nc0 = c->geom[0].ncells, nc1 = (int)c->cells.size() - nc0;
-    const int sched = (own_blur_stream && !c->serial && !pyr_done) ? c->sched : -1;
-    if ((sched == 4 || sched == 5) && nf >= 32) {      // 5 (measurement): the blur in front of FAST instead of behind it
-        // The quadtree off the critical path: the batch goes through FAST and the descriptor kernel as two halves A | B (A a multiple of 8 frames: a
-        // frame keeps its XCD), so that quadtree(A) runs beside FAST(B) and quadtree(B) beside the blur, and describe(A) has waited for neither.
-        // Main stream: pyramid, FAST(A), FAST(B), blur, describe(A), describe(B) - the throughput kernels back to back; second stream: the two
-        // quadtree launches, each behind its half of FAST.
+    { ProfScope ps(c, K_PYRAMID, s); launch_pyramid(c, P, nf, s); }
+    { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nf, s); }
+    if (own_blur_stream && nf > 8 && !c->serial) {      // (a handful of frames: the two event hops of the second stream cost more than the blur's 11 us - a single-frame call lost 75 us in them)
         hipStream_t bs = c->bstream;
-        const int nA = std::max(8, ((nf / 2) + 7) & ~7), nB = nf - nA;
-        { ProfScope ps(c, K_PYRAMID, s); launch_pyramid(c, P, nf, s); }
-        if (sched == 5) { ProfScope ps(c, K_BLUR, s); orbhip_launch_blur(P, c->gk, nf, s); }
-        { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nA, s); }
         HIPCHK(hipEventRecord(c->ev_pyr, s)); HIPCHK(hipStreamWaitEvent(bs, c->ev_pyr, 0));
-        { ProfScope ps(c, K_QUADTREE, bs); orbhip_launch_quadtree(P, nA, bs); }
-        HIPCHK(hipEventRecord(c->ev_fast0, bs));
-        P.frame0 = f0 + nA;
-        { ProfScope ps(c, K_FAST, s, 0); orbhip_launch_fast_cells(P, nB, s); }
-        HIPCHK(hipEventRecord(c->ev_start, s)); HIPCHK(hipStreamWaitEvent(bs, c->ev_start, 0));
-        { ProfScope ps(c, K_QUADTREE, bs, 0); orbhip_launch_quadtree(P, nB, bs); }
-        HIPCHK(hipEventRecord(c->ev_blur, bs));
-        P.frame0 = f0;
-        if (sched == 4) { ProfScope ps(c, K_BLUR, s); orbhip_launch_blur(P, c->gk, nf, s); }
-        HIPCHK(hipStreamWaitEvent(s, c->ev_fast0, 0));
-        { ProfScope ps(c, K_DESCRIBE, s); orbhip_launch_describe(P, nA, s); }
-        P.frame0 = f0 + nA;
-        HIPCHK(hipStreamWaitEvent(s, c->ev_blur, 0));
-        { ProfScope ps(c, K_DESCRIBE, s, 0); orbhip_launch_describe(P, nB, s); }
-        P.frame0 = f0;
-        if (c->distorted) {
-            ProfScope ps(c, K_UNDISTORT, s);
-            orbhip_launch_undistort_keys(c->cam, c->d_out_kp[c->cur] + (size_t)f0 * c->out_cap, c->d_out_n[c->cur] + f0, c->d_out_kpun[c->cur] + (size_t)f0 * c->out_cap, c->out_cap, nf, s);
-        }
-        return ORBHIP_OK;
-    }
-    if (sched == 2) {
-        hipStream_t bs = c->bstream;
-        HIPCHK(hipEventRecord(c->ev_start, s)); HIPCHK(hipStreamWaitEvent(bs, c->ev_start, 0));
-        { ProfScope ps(c, K_FAST, bs); orbhip_launch_fast_cells(P, nf, bs, 0, nc0); }
-        HIPCHK(hipEventRecord(c->ev_fast0, bs));
-        { ProfScope ps(c, K_PYRAMID, s); launch_pyramid(c, P, nf, s); }
-        HIPCHK(hipEventRecord(c->ev_pyr, s)); HIPCHK(hipStreamWaitEvent(bs, c->ev_pyr, 0));
+        { ProfScope ps(c, K_QUADTREE, s); orbhip_launch_quadtree(P, nf, s); }
         { ProfScope ps(c, K_BLUR, bs); orbhip_launch_blur(P, c->gk, nf, bs); }
         HIPCHK(hipEventRecord(c->ev_blur, bs));
-        { ProfScope ps(c, K_FAST, s, 0); orbhip_launch_fast_cells(P, nf, s, nc0, nc1); }
-        HIPCHK(hipStreamWaitEvent(s, c->ev_fast0, 0));
-        { ProfScope ps(c, K_QUADTREE, s); orbhip_launch_quadtree(P, nf, s); }
-        HIPCHK(hipStreamWaitEvent(s, c->ev_blur, 0));
-    } else if (sched == 1) {
-        hipStream_t bs = c->bstream;
-        HIPCHK(hipEventRecord(c->ev_start, s)); HIPCHK(hipStreamWaitEvent(bs, c->ev_start, 0));
-        { ProfScope ps(c, K_BLUR, bs); orbhip_launch_blur(P, c->gk, nf, bs, 0, nt0); }
-        { ProfScope ps(c, K_PYRAMID, s); launch_pyramid(c, P, nf, s); }
-        HIPCHK(hipEventRecord(c->ev_pyr, s)); HIPCHK(hipStreamWaitEvent(bs, c->ev_pyr, 0));
-        { ProfScope ps(c, K_BLUR, bs, 0); orbhip_launch_blur(P, c->gk, nf, bs, nt0, nt1); }
-        HIPCHK(hipEventRecord(c->ev_blur, bs));
-        { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nf, s); }
-        { ProfScope ps(c, K_QUADTREE, s); orbhip_launch_quadtree(P, nf, s); }
         HIPCHK(hipStreamWaitEvent(s, c->ev_blur, 0));
     } else {
-        if (pyr_done) HIPCHK(hipStreamWaitEvent(s, pyr_done, 0));
-        else if (sched == 6 && nf >= 64) {
-            // 6 (measurement): the pyramid as two half batches, one per stream - each half's seven dependent launches fill the other's tails and launch gaps;
-            // every other kernel as under 0 (alone on the GPU).  The scope's end event is recorded behind the join: its time is both halves'.
-            // Measured (gpurun sc6, B = 512): pyramid 0.605 -> 0.559 ms, but the previous call's matcher then runs beside FAST (0.826 -> 0.852 ms): 185.7 -> 187.3 k frames/s,
-            // nothing at B = 256 - not worth FAST's event time no longer being its own.  profiles/r03_exp_pyramid_two_half_batches.jsonl
-            hipStream_t bs = c->bstream;
-            const int nA = std::max(8, ((nf / 2) + 7) & ~7), nB = nf - nA;
-            ProfScope ps(c, K_PYRAMID, s);
-            HIPCHK(hipEventRecord(c->ev_start, s)); HIPCHK(hipStreamWaitEvent(bs, c->ev_start, 0));
-            launch_pyramid(c, P, nA, s);
-            P.frame0 = f0 + nA; launch_pyramid(c, P, nB, bs); P.frame0 = f0;
-            HIPCHK(hipEventRecord(c->ev_fast0, bs)); HIPCHK(hipStreamWaitEvent(s, c->ev_fast0, 0));
-        }
-        else { ProfScope ps(c, K_PYRAMID, s); launch_pyramid(c, P, nf, s); }
-        { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nf, s); }
-        if (own_blur_stream && nf > 8) {      // (a handful of frames: the two event hops of the second stream cost more than the blur's 11 us - a single-frame call lost 75 us in them)
-            hipStream_t bs = c->serial ? s : c->bstream;
-            HIPCHK(hipEventRecord(c->ev_pyr, s)); HIPCHK(hipStreamWaitEvent(bs, c->ev_pyr, 0));
-            { ProfScope ps(c, K_QUADTREE, s); orbhip_launch_quadtree(P, nf, s); }
-            { ProfScope ps(c, K_BLUR, bs); orbhip_launch_blur(P, c->gk, nf, bs); }
-            HIPCHK(hipEventRecord(c->ev_blur, bs));
-            HIPCHK(hipStreamWaitEvent(s, c->ev_blur, 0));
-        } else {
-            { ProfScope ps(c, K_BLUR, s); orbhip_launch_blur(P, c->gk, nf, s); }
-            { ProfScope ps(c, K_QUADTREE, s); orbhip_launch_quadtree(P, nf, s); }
-        }
+        { ProfScope ps(c, K_BLUR, s); orbhip_launch_blur(P, c->gk, nf, s); }
+        { ProfScope ps(c, K_QUADTREE, s); orbhip_launch_quadtree(P, nf, s); }
     }
     { ProfScope ps(c, K_DESCRIBE, s); orbhip_launch_describe(P, nf, s); }
     if (c->distorted) {   // Frame::UndistortKeyPoints (Frame.cc:404-434) behind the descriptor kernel: mvKeysUn stays in HBM beside mvKeys
@@ -727,20 +616,7 @@ static orbhip_status run_pipeline(orbhip_ctx* c, int nimg, const uint8_t* d_img0
     const int cur = c->cur, prev = (cur + 2) % 3;
     // camera slots are independent: optionally split the batch into groups, one HIP stream each
     const int ngroups = std::min((int)c->xstreams.size() + 1, nimg);
-    const bool ahead = c->pstream && ngroups == 1 && !c->serial;
-    if (ahead) { c->pyr_set ^= 1; c->d_pyr = c->d_pyr_sets[c->pyr_set]; }
     ExtractParams P = make_params(c, d_img0, frame_stride, row_stride);
-    if (ahead) {
-        // this plane set was last read by the call before the previous one (its FAST / blur / describe are stream-ordered before ev_desc); the
-        // previous call's kernels are still running on the other set: that is what this pyramid overlaps with
-        const int set = c->pyr_set;
-        if (c->desc_pending[set]) HIPCHK(hipStreamWaitEvent(c->pstream, c->ev_desc[set], 0));
-        P.frame0 = 0;
-        { ProfScope ps(c, K_PYRAMID, c->pstream); launch_pyramid(c, P, nimg, c->pstream); }
-        HIPCHK(hipEventRecord(c->ev_pyr_ahead, c->pstream));
-        st = pipeline_frames(c, P, 0, nimg, c->stream, true, c->ev_pyr_ahead); if (st != ORBHIP_OK) return st;
-        HIPCHK(hipEventRecord(c->ev_desc[set], c->stream)); c->desc_pending[set] = true;
-    } else {
     if (ngroups > 1) { HIPCHK(hipEventRecord(c->ev_fork, c->stream)); }
     for (int gi = 0; gi < ngroups; gi++) {
         const int f0 = (int)((long long)nimg * gi / ngroups), f1 = (int)((long long)nimg * (gi + 1) / ngroups), nf = f1 - f0;
@@ -749,7 +625,6 @@ static orbhip_status run_pipeline(orbhip_ctx* c, int nimg, const uint8_t* d_img0
         if (nf <= 0) continue;
         st = pipeline_frames(c, P, f0, nf, s, ngroups == 1); if (st != ORBHIP_OK) return st;
         if (gi > 0) { HIPCHK(hipEventRecord(c->xevents[gi - 1], s)); HIPCHK(hipStreamWaitEvent(c->stream, c->xevents[gi - 1], 0)); }
-    }
     }
     if (match_prev) {
         MatchParams M; memset(&M, 0, sizeof M);

@@ -89,7 +89,6 @@ struct ExtractParams {
     int qt_maxn;                                                           // LDS node capacity of the quadtree kernel
     int qt_maxcells;                                                       // max cells of one level
     int qt_scr;                                                            // ints of scan scratch in the quadtree's LDS layout
-    int qt_level0;                                                         // first level of this k_quadtree launch (the launcher sets it; one launch covers levels [qt_level0, qt_level0 + n))
     int fc_pstride, fc_prows, fc_sstride, fc_srows, fc_listcap;            // per-wave LDS layout of k_fast_cells (largest cell of the context)
     int fc_cell0, fc_ncells;                                               // cell range of this k_fast_cells launch
     int fc_pbytes, fc_np; const int4* fc_dma;                              // patch region = fc_np LDS-DMA passes of 256 bytes; (row, 4*column) of every (pass, lane)
@@ -154,7 +153,6 @@ size_t orbhip_proj_select_lds(int n);
 // kernel launchers (orbhip_kernels_extract.hip / orbhip_kernels_match.hip)
 void orbhip_launch_pyramid_level(const ExtractParams& P, int level, int w, int h, int mode, int nframes, hipStream_t s);
 int orbhip_pyramid_tile_dwords();
-void orbhip_launch_pyramid_tail(const ExtractParams& P, int level0, int nframes, hipStream_t s);    // levels level0 .. L-1 (all in 4-pixel-group mode) in one launch
 int orbhip_blur_mfma_tile_w();
 int orbhip_blur_mfma_tile_h();
 bool orbhip_pyramid_tile_fits(int src_cols_per_tile, int src_rows_per_tile);

@@ -186,21 +186,7 @@ __device__ __forceinline__ void pyr_hrow(const unsigned* rowp, unsigned sh, cons
         hs[k] = __builtin_amdgcn_udot2((pku16)__builtin_amdgcn_perm(v1, v0, G.sel[k]), (pku16)G.coef[k], 0u, false) >> 4;
 }
 struct PyrTile { int x0, y0, sxa, sya; };
-// one 256 x 16 tile of level `level`: stage (256 threads tid, LDS s_t), caller's barrier, compute (lane tx, wave ty of the tile's four)
-__device__ __forceinline__ PyrTile pyr_tile_stage(const ExtractParams& P, const LevelGeom& g, int level, int tile, int frame, int tid, unsigned* s_t)
-{
-    const int gx = (g.w + PYR_TW - 1) / PYR_TW;
-    PyrTile T; T.x0 = (tile % gx) * PYR_TW; T.y0 = (tile / gx) * PYR_TH;
-    int spitch; const uint8_t* src = level_src(P, frame, level - 1, spitch);
-    const int2* xt = P.xtab + g.xtab_off; const int2* yt = P.ytab + g.ytab_off;
-    const int xl = min(T.x0 + PYR_TW - 1, g.w - 1), yl = min(T.y0 + PYR_TH - 1, g.h - 1);
-    T.sxa = xt[T.x0].x & ~3; const int sxb = min(xt[xl].x + 1, g.src_w - 1);               // staged source columns [sxa, sxb]
-    T.sya = min(max(yt[T.y0].x, 0), g.src_h - 1); const int syb = min(max(yt[yl].x + 1, 0), g.src_h - 1);
-    const int ndw = ((sxb - T.sxa) >> 2) + 1, nrows = syb - T.sya + 1;
-    const bool aligned = ((((unsigned long long)src) | (unsigned long long)spitch) & 3ull) == 0;
-    pyr_stage(src, spitch, g.src_w, T.sxa, T.sya, ndw, nrows, aligned, tid, s_t);
-    return T;
-}
+// one 256 x 16 tile of level `level` from its staged source footprint (lane tx, wave ty of the tile's four)
 __device__ __forceinline__ void pyr_tile_compute(const ExtractParams& P, const LevelGeom& g, const PyrTile& T, int frame, int tx, int ty, const unsigned* s_t, const PyrGroup& G)
 {   // G = P.xgrp[g.xgrp_off + (x4 >> 2)], loaded by the caller (the same for every tile of a column of tiles)
     const int x4 = T.x0 + tx * 4;
@@ -275,7 +261,7 @@ __device__ __forceinline__ void pyr_dma_patch(const LevelGeom& g, const PyrTile&
         s_t[r * PYR_SDW + S.dfull] = w;
     }
 }
-// nt = tiles (one below the other) per workgroup: 2, or 4 from 384 frames on (ORBHIP_PYR_NT overrides: a measurement knob)
+// nt = tiles (one below the other) per workgroup: 2, or 4 from 384 frames on
 __global__ __launch_bounds__(256) void k_pyramid_level_g(ExtractParams P, int level, int nt)
 {
     const LevelGeom g = P.geom[level];
@@ -305,33 +291,6 @@ __global__ __launch_bounds__(256) void k_pyramid_level_g(ExtractParams P, int le
     }
 }
 
-// The small levels in ONE launch (opt-in experiment, ORBHIP_PYR_TAIL=1): a workgroup of 1024 threads owns one frame and computes levels
-// level0 .. nlevels-1 one after the other, four tiles at a time (one per group of four waves), reading level l-1 back from global memory after a
-// device-scope fence and a barrier.  The pyramid becomes 4 launches instead of 7 - and twice as slow (0.27 -> 0.54 ms for 256 frames): one workgroup
-// per frame has nothing to overlap its stage / barrier / compute chain with.  Kept for the measurement, not used by default.
-__global__ __launch_bounds__(1024) void k_pyramid_tail_g(ExtractParams P, int level0)
-{
-    __shared__ unsigned s_t[4][PYR_SROWS * PYR_SDW];
-    int tile0, frame;
-    if (!xcd_frame_map(1, P.nframes, tile0, frame)) return;
-    frame += P.frame0;
-    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.y), sub = wv >> 2, ty = wv & 3, tid = ty * 64 + threadIdx.x;
-    for (int level = level0; level < P.nlevels; level++) {
-        const LevelGeom g = P.geom[level];
-        const int ntiles = ((g.w + PYR_TW - 1) / PYR_TW) * ((g.h + PYR_TH - 1) / PYR_TH);
-        for (int t0 = 0; t0 < ntiles; t0 += 4) {
-            const int tile = t0 + sub;
-            PyrTile T = {0, 0, 0, 0};
-            if (tile < ntiles) T = pyr_tile_stage(P, g, level, tile, frame, tid, s_t[sub]);
-            __syncthreads();
-            if (tile < ntiles) { const PyrGroup G = P.xgrp[g.xgrp_off + min((T.x0 >> 2) + (int)threadIdx.x, (g.w - 1) >> 2)]; pyr_tile_compute(P, g, T, frame, threadIdx.x, ty, s_t[sub], G); }
-            __syncthreads();
-        }
-        __threadfence();                                               // level l is complete and visible before anyone stages it as a source
-        __syncthreads();
-    }
-}
-
 // Same arithmetic straight from global memory: used for scale factors whose source footprint does not fit the LDS tile
 // (the host decides per level from the coefficient tables).
 __global__ __launch_bounds__(256) void k_pyramid_level_direct(ExtractParams P, int level)
@@ -354,17 +313,11 @@ int orbhip_blur_mfma_tile_h() { return BM_ROWS; }
 int orbhip_pyramid_tile_w() { return PYR_TW; }
 int orbhip_pyramid_tile_h() { return PYR_TH; }
 
-void orbhip_launch_pyramid_tail(const ExtractParams& P, int level0, int nframes, hipStream_t s)
-{
-    ExtractParams Q = P; Q.nframes = nframes;
-    hipLaunchKernelGGL(k_pyramid_tail_g, dim3(xcd_grid(1, nframes), 1, 1), dim3(64, 16, 1), 0, s, Q, level0);
-}
 void orbhip_launch_pyramid_level(const ExtractParams& P, int level, int w, int h, int mode, int nframes, hipStream_t s)
 {   // mode 2: staged + 4-pixel groups, 1: staged, 0: straight from global memory
     ExtractParams Q = P; Q.nframes = nframes;
     dim3 grid(xcd_grid(((w + PYR_TW - 1) / PYR_TW) * ((h + PYR_TH - 1) / PYR_TH), nframes), 1, 1), block(64, 4, 1);
-    static const int nt_env = [] { const char* e = getenv("ORBHIP_PYR_NT"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : v > 64 ? 64 : v; }();
-    const int nt = nt_env ? nt_env : (nframes >= 384 ? 4 : 2);          // measured (round 3, same call): B = 512: 181.7 k frames/s with 2, 183.3 k with 4, 181.8 k with 8, 180.3 k with 1; B = 128: 157.6 k with 2, 155.2 k with 4
+    const int nt = nframes >= 384 ? 4 : 2;          // measured (round 3, same call): B = 512: 181.7 k frames/s with 2, 183.3 k with 4, 181.8 k with 8, 180.3 k with 1; B = 128: 157.6 k with 2, 155.2 k with 4
     const int gyn = (((h + PYR_TH - 1) / PYR_TH) + nt - 1) / nt;
     if (mode == 2) hipLaunchKernelGGL(k_pyramid_level_g, dim3(xcd_grid(((w + PYR_TW - 1) / PYR_TW) * gyn, nframes), 1, 1), block, 0, s, Q, level, nt);
     else if (mode == 1) hipLaunchKernelGGL(k_pyramid_level, grid, block, 0, s, Q, level);
@@ -692,38 +645,6 @@ __global__ __launch_bounds__(256, 5) void k_blur_mfma(ExtractParams P)
     blur_store(P, T, frame, wave, lane, s_out);
 }
 
-// The same tile arithmetic, `nt` tiles (consecutive in the level-major list) per workgroup, with the NEXT tile's source rows in flight (LDS-DMA into the
-// other of two staging buffers) while this tile is multiplied, rounded and stored: the load, compute and store phases of a workgroup no longer add up.
-__global__ __launch_bounds__(256, 5) void k_blur_mfma_p(ExtractParams P, int nt)
-{
-    __shared__ __attribute__((aligned(16))) unsigned s_in[2][32 * BM_IN_DW];
-    __shared__ unsigned s_out[BM_ROWS * BM_OUT_DW];
-    __shared__ __attribute__((aligned(16))) unsigned s_band[3 * 64 * 4];
-    int grp, frame;
-    if (!xcd_frame_map((P.nblur_tiles + nt - 1) / nt, P.nframes, grp, frame)) return;
-#pragma unroll
-    for (int k = 0; k < 3; k++) s_band[256 * k + threadIdx.x] = reinterpret_cast<const unsigned*>(P.blur_band)[256 * k + threadIdx.x];
-    frame += P.frame0;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int tile0 = grp * nt, tile1 = min(tile0 + nt, P.nblur_tiles);
-    BlurTile T = blur_tile(P, frame, tile0), Tn = T;
-    blur_issue(T, wave, lane, s_in[0]);
-    for (int ti = tile0; ti < tile1; ti++) {
-        const int buf = (ti - tile0) & 1;
-        const bool more = ti + 1 < tile1;
-        if (more) { Tn = blur_tile(P, frame, ti + 1); blur_issue(Tn, wave, lane, s_in[buf ^ 1]); }      // its readers (tile ti - 1) are behind the barrier that ended the last iteration's arithmetic
-        // loads return in order: at most the 8 just issued outstanding  <=>  this tile's rows (and the stores of the tile before) are done
-        if (more) __builtin_amdgcn_s_waitcnt(ORBHIP_VMCNT(8)); else lds_dma_wait();
-        __builtin_amdgcn_wave_barrier();
-        blur_fix(T, wave, lane, s_in[buf]);
-        __syncthreads();
-        blur_compute(P, T, wave, lane, s_in[buf], s_out, s_band);
-        __syncthreads();
-        blur_store(P, T, frame, wave, lane, s_out);
-        T = Tn;
-    }
-}
-
 void orbhip_launch_blur(const ExtractParams& P, const int gk[4], int nframes, hipStream_t s, int tile0, int ntiles)
 {   // tiles [tile0, tile0 + ntiles) of the level-major tile list (ntiles < 0: all)
     BlurK K; K.k0 = (float)gk[0]; K.k1 = (float)gk[1]; K.k2 = (float)gk[2]; K.k3 = (float)gk[3];
@@ -732,9 +653,7 @@ void orbhip_launch_blur(const ExtractParams& P, const int gk[4], int nframes, hi
     ExtractParams Q = P; Q.nframes = nframes;
     if (ntiles >= 0) { Q.blur_tiles = P.blur_tiles + tile0; Q.nblur_tiles = ntiles; }
     if (Q.nblur_tiles <= 0) return;
-    static const int nt = [] { const char* e = getenv("ORBHIP_BLUR_NT"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : v > 16 ? 16 : v; }();      // tiles per workgroup of the pipelined form (1: the one-tile kernel)
-    if (P.blur_band && nt > 1) hipLaunchKernelGGL(k_blur_mfma_p, dim3(xcd_grid((Q.nblur_tiles + nt - 1) / nt, nframes), 1, 1), dim3(256, 1, 1), 0, s, Q, nt);
-    else if (P.blur_band) hipLaunchKernelGGL(k_blur_mfma, dim3(xcd_grid(Q.nblur_tiles, nframes), 1, 1), dim3(256, 1, 1), 0, s, Q);
+    if (P.blur_band) hipLaunchKernelGGL(k_blur_mfma, dim3(xcd_grid(Q.nblur_tiles, nframes), 1, 1), dim3(256, 1, 1), 0, s, Q);
     else hipLaunchKernelGGL(k_blur, dim3(xcd_grid(Q.nblur_tiles, nframes), 1, 1), dim3(256, 1, 1), 0, s, Q, K);
 }
 
@@ -1356,7 +1275,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(ExtractParams P)
     // level-major ids (still frame == id mod 8 for the XCD affinity): workgroups are dispatched in id order and a level-0
     // workgroup runs ~4x longer than a level-7 one, so the long ones start first and the short ones fill the tail
     const int nfg = (P.nframes + 7) >> 3, jj = (int)blockIdx.x >> 3;
-    const int lrel = jj / nfg, level = P.qt_level0 + lrel;
+    const int level = jj / nfg, lrel = level;
     int frame = (jj - lrel * nfg) * 8 + ((int)blockIdx.x & 7);
     if (frame >= P.nframes) return;
     frame += P.frame0;
@@ -1396,20 +1315,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(ExtractParams P)
 void orbhip_launch_quadtree(const ExtractParams& P, int nframes, hipStream_t s)
 {
     ExtractParams Q = P; Q.nframes = nframes;
-    static const size_t pad = [] { const char* e = getenv("ORBHIP_QT_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }();      // experiment knob: unused LDS per workgroup = fewer resident quadtree workgroups per CU
-    // ORBHIP_QT_SPLIT=k (measurement knob, batches of 64 frames and more): levels [0, k) in a launch of their own, the rest behind it on the same stream - the few
-    // long workgroups of the large levels then leave most of every CU to the blur on the other stream instead of filling it with the whole batch's 8 x B workgroups at once
-    static const int split = [] { const char* e = getenv("ORBHIP_QT_SPLIT"); return e ? atoi(e) : 0; }();
-    static const int split_min = [] { const char* e = getenv("ORBHIP_QT_SPLIT_MIN"); return e ? atoi(e) : 64; }();      // (tests lower it to reach the two-launch path with a handful of frames)
-    const size_t lds = orbhip_quadtree_lds_bytes(P.qt_maxn, P.qt_maxcells) + pad;
-    if (split > 0 && split < P.nlevels && nframes >= split_min) {
-        Q.qt_level0 = 0;
-        hipLaunchKernelGGL(k_quadtree, dim3(xcd_grid(split, nframes), 1, 1), dim3(QT_T, 1, 1), lds, s, Q);
-        Q.qt_level0 = split;
-        hipLaunchKernelGGL(k_quadtree, dim3(xcd_grid(P.nlevels - split, nframes), 1, 1), dim3(QT_T, 1, 1), lds, s, Q);
-        return;
-    }
-    Q.qt_level0 = 0;
+    const size_t lds = orbhip_quadtree_lds_bytes(P.qt_maxn, P.qt_maxcells);
     hipLaunchKernelGGL(k_quadtree, dim3(xcd_grid(P.nlevels, nframes), 1, 1), dim3(QT_T, 1, 1), lds, s, Q);
 }
 
@@ -1479,9 +1385,7 @@ __device__ __forceinline__ int wave_sum_dpp(int v)
 __device__ __forceinline__ int round_half_even_small(float x) { return __float_as_int(__fadd_rn(x, 12582912.0f)) - 0x4B400000; }
 
 #define DS_WAVES 4
-#ifndef DS_KPW
-#define DS_KPW 4                       // key point slots per wavefront (3: 0.652 -> see DESIGN §11)
-#endif
+#define DS_KPW 4                       // key point slots per wavefront (3 and 5 measured slower: docs/ROUND_LOG.md, round 3 "describe")
 #define DS_WROWS 37                    // blurred window rows: pattern reach is +-18 after rotation
 #define DS_WSTRIDE 48                  // bytes per staged window row: 37 used, starting 0..3 bytes into the row (staged from the dword boundary below cx - 18).  12 dwords, not the
                                        // 10 that would do: the texture addresser takes an LDS-DMA pass in groups of four lanes, and a group that straddles two image rows is what
@@ -1548,9 +1452,6 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
     for (int k = 0; k < DS_WPASSES; k++) {
         const int pos = 64 * k + lane, row = (pos * 5462) >> 16;          // pos / 12 for pos < 448
         wrow[k] = min(row, DS_WROWS - 1); wcol[k] = 4 * (pos - 12 * row); // the four dwords past the window re-read the start of its last row (in bounds, never used)
-#ifdef DS_EXP_WINDOW_ONE_ROW
-        wrow[k] = 18;                                                     // (timing experiment: every staged row is the window's middle row - the same instructions, 1-2 cache lines instead of ~48)
-#endif
     }
 
     // ---- 0. slot -> (level, index in the level, output index), lane j for slot j; then wave-uniform copies (SGPRs) of the wave's slots.
@@ -1586,13 +1487,7 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
         const unsigned off = (unsigned)((cy - 15 + prow) * spitch + ((cx - 15) & ~3) + 4 * min(pd, 8));
 #pragma unroll
         for (int q = 0; q < DS_PPASS; q++)                             // rows prow + 4q - 15 = -15 .. 16; row 16 is loaded (in bounds) and masked
-#if defined(DS_EXP_NO_PATCH)          // timing experiments of round 3 (results are wrong with any DS_EXP_* defined; profiles/r03_exp_describe_memory_ablation.jsonl)
-            pw[j][q] = (unsigned)(off + q);                    // no orientation-patch loads
-#elif defined(DS_EXP_PATCH_ONE_ROW)
-            pw[j][q] = *reinterpret_cast<const ORBHIP_GLOBAL unsigned*>(img + ((unsigned)(cy * spitch + ((cx - 15) & ~3) + 4 * min(pd, 8))));      // every patch row is row cy: the same instructions, 1-2 cache lines
-#else
             pw[j][q] = *reinterpret_cast<const ORBHIP_GLOBAL unsigned*>(img + (off + (unsigned)(4 * q * spitch)));
-#endif
     }
     __syncthreads();
     float4 pt[4];                                                          // rBRIEF pattern of this lane's 4 tests as floats (x0, y0, x1, y1)
@@ -1614,10 +1509,8 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
     };
     int M10 = 0, M01 = 0;
     {
-#ifndef DS_EXP_NO_WINDOW                                                 // (timing experiment: no blurred-window staging)
 #pragma unroll
         for (int j = 0; j < DS_KPW; j++) if (ok[j]) window_dma(lv[j], vv[j], s_win[wave][j]);
-#endif
 #pragma unroll
         for (int j = 0; j < DS_KPW; j++) if (ok[j]) {
             unsigned s = 0, su = 0, cs = 0;                                   // cs = sum over passes of the running row sum = sum_q (8 - q) t_q
@@ -1686,11 +1579,7 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
                     const f2v ry = fy + MG, rx = fx + MG;
                     const int o0 = (int)(__umul24(__float_as_uint(ry[0]), (unsigned)DS_WSTRIDE) + __float_as_uint(rx[0]) - cbias);
                     const int o1 = (int)(__umul24(__float_as_uint(ry[1]), (unsigned)DS_WSTRIDE) + __float_as_uint(rx[1]) - cbias);
-#ifdef DS_EXP_NO_GATHER
-                    const int t0 = o0 & 0xff, t1 = o1 & 0xff;                        // (timing experiment: no LDS byte gathers)
-#else
                     const int t0 = w8[o0], t1 = w8[o1];
-#endif
                     const unsigned long long bits = __ballot(t0 < t1);       // test 64r+lane -> byte (64r+lane)/8, bit lane%8
                     dlo_l = orbhip_writelane((int)(unsigned)bits, dlane + r, dlo_l);          // 2 VALU instead of compare + 2 moves + 2 selects
                     dhi_l = orbhip_writelane((int)(unsigned)(bits >> 32), dlane + r, dhi_l);

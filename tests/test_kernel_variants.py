@@ -1,7 +1,7 @@
-"""The kernel / schedule alternatives of round 2 all produce the oracle's bytes: the matrix-core blur (k_blur_mfma, default) and the
-all-VALU one (ORBHIP_BLUR=valu) in both GaussianBlur rounding modes, on widths that exercise every border case of the 224-column
-tiles (w % 4 = 0..3, a tile that ends at the border, one that is a single block wide); the three stream schedules (ORBHIP_SCHED);
-key point slots whose count is not a multiple of the four slots a describing wavefront takes.
+"""Both blur kernels produce the oracle's bytes: the matrix-core one (k_blur_mfma, default) and the all-VALU one (ORBHIP_BLUR=valu, the
+library's fallback when the taps do not fit the i8 form) in both GaussianBlur rounding modes, on widths that exercise every border case of
+the 224-column tiles (w % 4 = 0..3, a tile that ends at the border, one that is a single block wide); the serial schedule (ORBHIP_SERIAL=1, the
+profiling aid) beside the default one; key point slots whose count is not a multiple of the four slots a describing wavefront takes.
 
 backend = "emu" (kernel sources under the test-only fiber emulation, CPU) or "gpu" (real liborbhip.so, marked gpu).
 """
@@ -50,51 +50,18 @@ def test_blur_kernels_and_rounding_modes(backend, oracle, env, blur, mode, w, h)
     ex.close()
 
 
-@pytest.mark.parametrize("sched", [0, 1, 2])
-def test_stream_schedules(backend, oracle, env, sched):
-    env(ORBHIP_SCHED=sched)
-    w, h, n = 400, 300, 700
-    imgs = np.stack([synth.frame(w, h, seed=40 + s) for s in range(3)])
-    ex = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, max_batch=3, library=backend)
+@pytest.mark.parametrize("serial", [0, 1])
+def test_second_stream_and_serial_schedule(backend, oracle, env, serial):
+    """a batch of more than eight frames puts the blur on the context's second stream beside the quadtree; ORBHIP_SERIAL=1 keeps every kernel on one"""
+    env(ORBHIP_SERIAL=serial)
+    w, h, n, B = 320, 240, 300, 11
+    imgs = np.stack([synth.frame(w, h, seed=40 + s) for s in range(B)])
+    ex = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, max_batch=B, library=backend)
     kps, descs = ex.extract_batch(imgs)
-    for i in range(3):
+    for i in (0, 7, 8, 10):
         ora = oracle.OracleExtractor(n, 1.2, 8, 20, 7)
         ko, do = ora.extract(imgs[i])
         _same(kps[i], descs[i], ko, do)
-    ex.close()
-
-
-@pytest.mark.parametrize("w,h", [(450, 224), (227, 231)])
-def test_pipelined_blur_three_tiles_per_workgroup(backend, oracle, env, w, h):
-    """ORBHIP_BLUR_NT=3 (k_blur_mfma_p, an opt-in measurement: slower than the one-tile kernel): three tiles per workgroup, the next tile's rows in
-    flight in a second staging buffer; tile groups that end inside a level and groups that straddle two levels."""
-    env(ORBHIP_BLUR_NT=3)
-    n = 500
-    img = synth.frame(w, h, seed=w + h)
-    ora = oracle.OracleExtractor(n, 1.2, 8, 20, 7)
-    ko, do = ora.extract(img)
-    ex = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, library=backend)
-    kg, dg = ex(img)
-    for l in range(8):
-        assert np.array_equal(ex.blurred_level(l), ora.blurred(l)), f"blurred level {l}"
-    _same(kg, dg, ko, do)
-    ex.close()
-
-
-@pytest.mark.parametrize("B", [40, 33])
-def test_half_batch_schedule_keeps_the_quadtree_off_the_main_chain(backend, oracle, env, B):
-    """ORBHIP_SCHED=4: from 32 frames on a batch goes through FAST and the descriptor kernel as two halves (the first a multiple of 8 frames), the
-    quadtree of each half on the second stream beside the other half's FAST / the blur.  Every frame of both halves and the frames at the seam."""
-    env(ORBHIP_SCHED=4, ORBHIP_HOST_CHUNK=64)
-    w, h, n = 320, 240, 300
-    imgs = np.stack([synth.frame(w, h, seed=700 + s) for s in range(B)])
-    ex = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, max_batch=B, library=backend)
-    kps, descs = ex.extract_batch(imgs)
-    nA = max(8, ((B // 2) + 7) & ~7)
-    for f in sorted({0, 7, nA - 1, nA, nA + 1, B - 1}):
-        ora = oracle.OracleExtractor(n, 1.2, 8, 20, 7)
-        ko, do = ora.extract(imgs[f])
-        _same(kps[f], descs[f], ko, do)
     ex.close()
 
 
@@ -108,23 +75,6 @@ def test_slot_counts_not_multiples_of_four(backend, oracle, n):
     ex = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, library=backend)
     kg, dg = ex(img)
     _same(kg, dg, ko, do)
-    ex.close()
-
-
-def test_fused_pyramid_tail_from_64_frames_on(backend, oracle, env):
-    """ORBHIP_PYR_TAIL=1 (an opt-in experiment, slower than the default): from 64 frames on the last (up to four) pyramid levels are built by one
-    launch (k_pyramid_tail_g: a 1024-thread workgroup per frame walks the levels, re-reading each from global memory behind a device-scope fence)."""
-    env(ORBHIP_PYR_TAIL=1)
-    w, h, n, B = 320, 240, 300, 64
-    imgs = np.stack([synth.frame(w, h, seed=900 + s) for s in range(B)])
-    ex = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, max_batch=B, library=backend)
-    kps, descs = ex.extract_batch(imgs)
-    for f in (0, 31, 63):
-        ora = oracle.OracleExtractor(n, 1.2, 8, 20, 7)
-        ko, do = ora.extract(imgs[f])
-        for l in range(1, 8):
-            assert np.array_equal(ex.mvImagePyramid(l, frame=f), ora.level(l)), f"frame {f} pyramid level {l}"
-        _same(kps[f], descs[f], ko, do)
     ex.close()
 
 

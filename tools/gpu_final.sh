@@ -16,7 +16,6 @@ timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench exi
 for f in $(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1); do cp $f $OUT/kernel_stats.csv; done
 for b in 64 128 256 512 1024; do timeout 200 python bench.py --steps 30 --warmup 3 --repeats 3 --batch $b --no-cpu-baseline --no-host-io >> $OUT/bench_sweep.jsonl 2>> $OUT/bench.err; done
 ORBHIP_SERIAL=1 timeout 200 python bench.py --steps 20 --warmup 3 --repeats 3 --batch 256 --no-cpu-baseline --no-host-io > $OUT/bench_serial_b256.json 2>> $OUT/bench.err
-for v in 1 2 3; do ORBHIP_SCHED=$v timeout 200 python bench.py --steps 50 --warmup 3 --repeats 3 --no-cpu-baseline --no-host-io > $OUT/bench_sched$v.json 2>> $OUT/bench.err; done
 ORBHIP_BLUR=valu timeout 200 python bench.py --steps 50 --warmup 3 --repeats 3 --no-cpu-baseline --no-host-io > $OUT/bench_blur_valu.json 2>> $OUT/bench.err
 timeout 600 python tools/db_full_parity.py > $OUT/db_full_parity.json 2> $OUT/db_full_parity.err
 timeout 120 python tools/host_io_rate.py > $OUT/host_io.jsonl 2>> $OUT/bench.err
