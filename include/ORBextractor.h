@@ -157,8 +157,14 @@ protected:
     std::vector<float> mvMapX, mvMapY; int mnRawCols, mnRawRows; // rectification maps (applied when the context is (re)created)
     int mnLastN;                                                 // key points of the last image
     std::vector<cv::KeyPoint> mvLastKeys;                        // ... and the key points themselves (mvKeysUn of an undistorted camera)
-    orbhip_ctx* mpCtx;          // device context for the current image size (created lazily, re-created on a size change)
+    orbhip_ctx* mpCtx;          // device context for the current image size (created lazily at the first image of that size)
     int mnCtxW, mnCtxH, mnCtxBatch, mnDevice, mnBlurRounding, mnFpContract;
+    // The reference takes any image size per call (it re-allocates its pyramid every time, ORBextractor.cc:1043-1056, 1107-1132); a device context is
+    // laid out for ONE size.  Contexts of the sizes seen recently are therefore kept (up to four, least recently used goes first): a caller that
+    // alternates between sizes switches contexts in microseconds instead of paying a context creation (tens of milliseconds) per change.
+    struct CtxSlot { orbhip_ctx* ctx; int w, h, batch; unsigned settings, stamp; };
+    std::vector<CtxSlot> mvCtxCache; unsigned mnSettings, mnStamp;          // mnSettings counts SetBlurRounding / SetFpContract / SetCamera calls
+    void ApplySettings(orbhip_ctx* ctx);
     std::vector<int> mvTicketSizes;                              // images per ticket in flight (Submit / Collect), by ticket mod 4
     bool mbDownloadPyramid;
     int mnPendingTickets;                                        // Submit()ed, not yet Collect()ed

@@ -31,7 +31,7 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int
 #else
       mnFpContract(0),
 #endif
-      mvTicketSizes(4, 0), mbDownloadPyramid(false), mnPendingTickets(0), mbFrameState(false), mfScaleFactorArg(_scaleFactor), mnBoundFrame(0), mbBound(false), mbStereoColumns(false)
+      mvTicketSizes(4, 0), mbDownloadPyramid(false), mnPendingTickets(0), mbFrameState(false), mfScaleFactorArg(_scaleFactor), mnBoundFrame(0), mbBound(false), mbStereoColumns(false), mnSettings(0), mnStamp(0)
 {
     memset(mCamera, 0, sizeof mCamera);
     mvScaleFactor.resize(nlevels); mvLevelSigma2.resize(nlevels);
@@ -46,7 +46,11 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int
     if (const char* fc = getenv("ORBHIP_FP_CONTRACT")) mnFpContract = atoi(fc) ? 1 : 0;
 }
 
-ORBextractor::~ORBextractor() { if (mpCtx) orbhip_destroy(mpCtx); }
+ORBextractor::~ORBextractor()
+{
+    if (mpCtx) orbhip_destroy(mpCtx);
+    for (size_t i = 0; i < mvCtxCache.size(); i++) orbhip_destroy(mvCtxCache[i].ctx);
+}
 
 void ORBextractor::Fail(const char* where) const
 {
@@ -62,13 +66,13 @@ void ORBextractor::RequireFrameState(const char* where) const
 
 void ORBextractor::SetBlurRounding(int mode)
 {
-    mnBlurRounding = mode ? 1 : 0;
+    mnBlurRounding = mode ? 1 : 0; mnSettings++;
     if (mpCtx && orbhip_set_blur_rounding(mpCtx, mnBlurRounding) != ORBHIP_OK) Fail("ORBextractor::SetBlurRounding");
 }
 
 void ORBextractor::SetFpContract(int mode)
 {
-    mnFpContract = mode ? 1 : 0;
+    mnFpContract = mode ? 1 : 0; mnSettings++;
     if (mpCtx && orbhip_set_fp_contract(mpCtx, mnFpContract) != ORBHIP_OK) Fail("ORBextractor::SetFpContract");
 }
 
@@ -93,12 +97,39 @@ void ORBextractor::FetchPyramid(std::vector<cv::Mat>& levels)
     if (orbhip_pyramid_fetch_all(mpCtx, 0, &dst[0], &stride[0]) != ORBHIP_OK) Fail("ORBextractor::mvImagePyramid");
 }
 
+void ORBextractor::ApplySettings(orbhip_ctx* ctx)
+{
+    if (orbhip_set_blur_rounding(ctx, mnBlurRounding) != ORBHIP_OK || orbhip_set_fp_contract(ctx, mnFpContract) != ORBHIP_OK) Fail("ORBextractor");
+    orbhip_camera cam; memcpy(&cam, mCamera, sizeof cam);
+    if (orbhip_set_camera(ctx, mbHasCamera ? &cam : NULL) != ORBHIP_OK) Fail("ORBextractor");
+}
+
 void ORBextractor::EnsureContext(int width, int height, int maxBatch)
 {
     if (mpCtx && width == mnCtxW && height == mnCtxH && maxBatch <= mnCtxBatch) return;
     if (mpCtx && mnPendingTickets > 0)
-        throw ORBhipError("ORBextractor: the device context would have to be re-created (image size or batch changed) while Submit()ed batches are still in flight: Collect them first");
-    if (mpCtx) { orbhip_destroy(mpCtx); mpCtx = NULL; }
+        throw ORBhipError("ORBextractor: another device context is needed (image size or batch changed) while Submit()ed batches are still in flight: Collect them first");
+    // the current context steps aside (its size may come back: a rig of two resolutions, a caller that crops) ...
+    if (mpCtx) {
+        CtxSlot keep = {mpCtx, mnCtxW, mnCtxH, mnCtxBatch, mnSettings, ++mnStamp};
+        mvCtxCache.push_back(keep); mpCtx = NULL;
+        if (mvCtxCache.size() > 3) {                                  // four contexts alive at most: the least recently used one goes
+            size_t lru = 0;
+            for (size_t i = 1; i < mvCtxCache.size(); i++) if (mvCtxCache[i].stamp < mvCtxCache[lru].stamp) lru = i;
+            orbhip_destroy(mvCtxCache[lru].ctx); mvCtxCache.erase(mvCtxCache.begin() + lru);
+        }
+    }
+    mbFrameState = false; mbBound = false; mbStereoColumns = false; mnLastN = 0;      // whatever follows belongs to another context
+    // ... and one that was laid out for this size comes back (rectification maps belong to one size: such contexts are never shared)
+    for (size_t i = 0; i < mvCtxCache.size() && mvMapX.empty(); i++) {
+        const CtxSlot c = mvCtxCache[i];
+        if (c.w != width || c.h != height || c.batch < maxBatch) continue;
+        mvCtxCache.erase(mvCtxCache.begin() + i);
+        mpCtx = c.ctx; mnCtxW = c.w; mnCtxH = c.h; mnCtxBatch = c.batch;
+        if (c.settings != mnSettings) ApplySettings(mpCtx);
+        orbhip_get_scale_tables(mpCtx, &mvScaleFactor[0], &mvInvScaleFactor[0], &mvLevelSigma2[0], &mvInvLevelSigma2[0], &mnFeaturesPerLevel[0]);
+        return;
+    }
     orbhip_config cfg; memset(&cfg, 0, sizeof cfg);
     cfg.nfeatures = nfeatures; cfg.scale_factor = mfScaleFactorArg; cfg.nlevels = nlevels; cfg.ini_th_fast = iniThFAST; cfg.min_th_fast = minThFAST;
     cfg.width = width; cfg.height = height; cfg.max_batch = maxBatch; cfg.device = mnDevice; cfg.stream = NULL; cfg.blur_round_mode = mnBlurRounding; cfg.num_streams = 1;
@@ -149,6 +180,13 @@ static_assert(sizeof(orbhip_camera) == 9 * sizeof(float), "orbhip_camera is nine
 
 void ORBextractor::SetCamera(const cv::Mat& K, const cv::Mat& distCoef)
 {
+    {   // the same camera again (a caller that attaches it per frame): nothing to do
+        float c[9] = {K.at<float>(0, 0), K.at<float>(1, 1), K.at<float>(0, 2), K.at<float>(1, 2), 0, 0, 0, 0, 0};
+        const int ndc = distCoef.rows * distCoef.cols;
+        for (int i = 0; i < 5; i++) c[4 + i] = i < ndc ? (distCoef.rows == 1 ? distCoef.at<float>(0, i) : distCoef.at<float>(i, 0)) : 0.0f;
+        if (mbHasCamera && !memcmp(c, mCamera, sizeof c)) return;
+    }
+    mnSettings++;
     mCamera[0] = K.at<float>(0, 0); mCamera[1] = K.at<float>(1, 1); mCamera[2] = K.at<float>(0, 2); mCamera[3] = K.at<float>(1, 2);
     const int nd = distCoef.rows * distCoef.cols;                 // 4x1, or 5x1 when Camera.k3 != 0 (Tracking.cc:70-82)
     for (int i = 0; i < 5; i++) mCamera[4 + i] = i < nd ? (distCoef.rows == 1 ? distCoef.at<float>(0, i) : distCoef.at<float>(i, 0)) : 0.0f;
@@ -200,6 +238,8 @@ void ORBextractor::SetRectification(const cv::Mat& M1, const cv::Mat& M2, int ra
     }
     mnRawCols = rawCols; mnRawRows = rawRows;
     if (mpCtx) { orbhip_destroy(mpCtx); mpCtx = NULL; }            // the context of the rectified size is re-created with the maps
+    for (size_t i = 0; i < mvCtxCache.size(); i++) orbhip_destroy(mvCtxCache[i].ctx);
+    mvCtxCache.clear();
     EnsureContext(M1.cols, M1.rows);
 }
 

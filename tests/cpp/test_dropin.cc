@@ -1,6 +1,7 @@
 // Drives the drop-in classes exactly like the reference's callers do (Tracking.cc:119-125 constructs the extractor,
 // Frame::Frame calls ExtractORB, Tracking.cc:599-600 calls SearchForInitialization) and dumps the results for pytest.
 // usage: test_dropin W H nfeatures in0.raw in1.raw out.bin [vocabulary.txt [threads|- [maps.bin]]]
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -161,6 +162,36 @@ int main(int argc, char** argv)
             const int flags[5] = {same, refuse_grow, refuse_un, refuse_pyr, valid_again};
             fwrite(flags, 4, 5, f);
             delete exB;
+        }
+        // Per-call image-size freedom (the reference re-allocates per call and takes any size, ORBextractor.cc:1043-1056): ONE extractor object
+        // alternates between the full image and a crop of it (a cv::Mat view: same data, same row step) for three rounds.  Every round delivers the
+        // same bytes per size, the follow-ups (UndistortKeyPoints, mvImagePyramid) belong to the last call's size, and from the second round on a
+        // size change is a switch between two kept contexts, not a context creation (the times are reported, not asserted).
+        {
+            ORB_SLAM2::ORBextractor* exS = new ORB_SLAM2::ORBextractor(N, 1.2f, 8, 20, 7);
+            const cv::Mat crop = im[0].rowRange(0, H - 24).colRange(0, W - 32);
+            std::vector<cv::KeyPoint> kFull0, kCrop0, k; cv::Mat dFull0, dCrop0, d;
+            int same = 1; double ms[6];
+            for (int round = 0; round < 3; round++)
+                for (int which = 0; which < 2; which++) {
+                    const auto t0 = std::chrono::steady_clock::now();
+                    (*exS)(which ? crop : im[0], cv::Mat(), k, d);
+                    ms[2 * round + which] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                    std::vector<cv::KeyPoint>& k0 = which ? kCrop0 : kFull0; cv::Mat& d0 = which ? dCrop0 : dFull0;
+                    if (round == 0) { k0 = k; d0 = d.clone(); }
+                    else {
+                        same = same && k.size() == k0.size() && !memcmp(&k[0], &k0[0], sizeof(cv::KeyPoint) * k.size());
+                        for (size_t i = 0; i < k.size() && same; i++) same = !memcmp(d.ptr((int)i), d0.ptr((int)i), 32);
+                    }
+                    std::vector<cv::KeyPoint> un; exS->UndistortKeyPoints(un);
+                    same = same && un.size() == k.size() && exS->mvImagePyramid[0].cols == (which ? W - 32 : W) && exS->mvImagePyramid[0].rows == (which ? H - 24 : H);
+                }
+            same = same && (int)kFull0.size() == F1.N && !memcmp(&kFull0[0], &F1.mvKeys[0], sizeof(cv::KeyPoint) * F1.N);
+            fwrite(&same, 4, 1, f);
+            int ncrop = (int)kCrop0.size(); fwrite(&ncrop, 4, 1, f);
+            if (ncrop) { fwrite(&kCrop0[0], sizeof(cv::KeyPoint), ncrop, f); for (int i = 0; i < ncrop; i++) fwrite(dCrop0.ptr(i), 1, 32, f); }
+            fwrite(ms, 8, 6, f);
+            delete exS;
         }
     }
     fclose(f);

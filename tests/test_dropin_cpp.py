@@ -88,9 +88,19 @@ def _run(exe, tmp_path, oracle, threads=False, blur=None):
     rect0 = np.frombuffer(buf, np.uint8, w * h, off).reshape(h, w); off += w * h
     batch_flags = struct.unpack_from("<5i", buf, off); off += 20
     assert batch_flags == (1, 1, 1, 1, 1), f"Submit/Collect (same results, refuse context growth in flight, refuse undistort, refuse pyramid, valid again): {batch_flags}"
+    (size_same,) = struct.unpack_from("<i", buf, off); off += 4
+    (ncrop,) = struct.unpack_from("<i", buf, off); off += 4
+    kcrop = np.frombuffer(buf, orb_slam2_amd.KEYPOINT_DTYPE, ncrop, off); off += 28 * ncrop
+    dcrop = np.frombuffer(buf, np.uint8, 32 * ncrop, off).reshape(ncrop, 32); off += 32 * ncrop
+    size_ms = struct.unpack_from("<6d", buf, off); off += 48
+    assert size_same == 1, "one extractor object alternating between two image sizes: results or follow-ups changed between rounds"
+    print(f"\n[image-size freedom] full / crop / full / crop / full / crop calls on one extractor: " + " / ".join(f"{v:.2f}" for v in size_ms) +
+          " ms (the first call of each size creates its device context; later size changes switch between kept contexts)")
     assert off == len(buf)
 
     ora = mk()
+    kcrop_o, dcrop_o = mk().extract(np.ascontiguousarray(seq[0][:h - 24, :w - 32]))
+    assert kcrop.tobytes() == kcrop_o.tobytes() and np.array_equal(dcrop, dcrop_o)
     ref = [ora.extract(im) for im in seq]
     for f in range(2):
         assert frames[f][0].tobytes() == ref[f][0].tobytes() and np.array_equal(frames[f][1], ref[f][1])
