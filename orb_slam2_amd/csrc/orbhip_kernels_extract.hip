@@ -1574,7 +1574,10 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
                         fy[0] = __fmaf_rn(X[0], b, __fmul_rn(Y[0], a)); fy[1] = __fmaf_rn(X[1], b, __fmul_rn(Y[1], a));
                         fx[0] = __fmaf_rn(X[0], a, -__fmul_rn(Y[0], b)); fx[1] = __fmaf_rn(X[1], a, -__fmul_rn(Y[1], b));
                     } else {
-                        fy = X * B2 + Y * A2; fx = X * A2 - Y * B2;                    // -ffp-contract=off: two roundings each (H3)
+                        // two roundings each (H3) whatever flags this file is built with: the pragma pins what the Makefile's -ffp-contract=off says
+                        // (hipcc's own default, fast-honor-pragmas, would fuse these into v_pk_fma_f32 and change a descriptor bit per few frames)
+#pragma clang fp contract(off)
+                        fy = X * B2 + Y * A2; fx = X * A2 - Y * B2;
                     }
                     const f2v ry = fy + MG, rx = fx + MG;
                     const int o0 = (int)(__umul24(__float_as_uint(ry[0]), (unsigned)DS_WSTRIDE) + __float_as_uint(rx[0]) - cbias);
