@@ -583,6 +583,9 @@ static orbhip_status pipeline_frames(orbhip_ctx* c, ExtractParams& P, int f0, in
         { ProfScope ps(c, K_BLUR, bs); orbhip_launch_blur(P, c->gk, nf, bs); }
         HIPCHK(hipEventRecord(c->ev_blur, bs));
         HIPCHK(hipStreamWaitEvent(s, c->ev_blur, 0));
+    } else if (nf <= 8 && P.blur_band && !c->serial) {
+        // a handful of frames: one launch for both (the quadtree's few long workgroups beside the blur's tiles); its time is booked on the quadtree
+        ProfScope ps(c, K_QUADTREE, s); orbhip_launch_blur_quadtree(P, nf, s);
     } else {
         { ProfScope ps(c, K_BLUR, s); orbhip_launch_blur(P, c->gk, nf, s); }
         { ProfScope ps(c, K_QUADTREE, s); orbhip_launch_quadtree(P, nf, s); }

@@ -161,6 +161,7 @@ void orbhip_launch_to_gray(const uint8_t* src, long long src_frame_stride, int s
 int orbhip_pyramid_tile_w();
 int orbhip_pyramid_tile_h();
 void orbhip_launch_blur(const ExtractParams& P, const int gk[4], int nframes, hipStream_t s, int tile0 = 0, int ntiles = -1);
+void orbhip_launch_blur_quadtree(const ExtractParams& P, int nframes, hipStream_t s);      // both in one launch (small batches, matrix-core blur only)
 void orbhip_launch_fast_cells(const ExtractParams& P, int nframes, hipStream_t s, int cell0 = 0, int ncells = -1);
 void orbhip_launch_quadtree(const ExtractParams& P, int nframes, hipStream_t s);
 void orbhip_launch_describe(const ExtractParams& P, int nframes, hipStream_t s);

@@ -623,16 +623,11 @@ __device__ __forceinline__ void blur_store(const ExtractParams& P, const BlurTil
             *reinterpret_cast<unsigned*>(dst + (long long)(y0 + r) * g.pitch + gx) = s_out[r * BM_OUT_DW + lane];      // pitch multiple of 64, gx of 4: pad bytes absorb the tail
 }
 
-__global__ __launch_bounds__(256, 5) void k_blur_mfma(ExtractParams P)
+// one tile of the matrix-core blur by the calling workgroup (256 threads): stage, patch, two banded products, round, store
+__device__ __forceinline__ void blur_mfma_tile(const ExtractParams& P, int tile, int frame, unsigned* s_in, unsigned* s_out, unsigned* s_band)
 {
-    __shared__ __attribute__((aligned(16))) unsigned s_in[32 * BM_IN_DW];
-    __shared__ unsigned s_out[BM_ROWS * BM_OUT_DW];
-    __shared__ __attribute__((aligned(16))) unsigned s_band[3 * 64 * 4];   // HB1 | HB2 | VB: fetched once per workgroup with coalesced 32-bit loads
-    int tile, frame;                                                        // (as three 128-bit loads per lane they cost each wave 3 x 71 cycles of the texture addresser)
-    if (!xcd_frame_map(P.nblur_tiles, P.nframes, tile, frame)) return;
 #pragma unroll
     for (int k = 0; k < 3; k++) s_band[256 * k + threadIdx.x] = reinterpret_cast<const unsigned*>(P.blur_band)[256 * k + threadIdx.x];
-    frame += P.frame0;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const BlurTile T = blur_tile(P, frame, tile);
     blur_issue(T, wave, lane, s_in);
@@ -643,6 +638,15 @@ __global__ __launch_bounds__(256, 5) void k_blur_mfma(ExtractParams P)
     blur_compute(P, T, wave, lane, s_in, s_out, s_band);
     __syncthreads();
     blur_store(P, T, frame, wave, lane, s_out);
+}
+__global__ __launch_bounds__(256, 5) void k_blur_mfma(ExtractParams P)
+{
+    __shared__ __attribute__((aligned(16))) unsigned s_in[32 * BM_IN_DW];
+    __shared__ unsigned s_out[BM_ROWS * BM_OUT_DW];
+    __shared__ __attribute__((aligned(16))) unsigned s_band[3 * 64 * 4];   // HB1 | HB2 | VB: fetched once per workgroup with coalesced 32-bit loads
+    int tile, frame;                                                        // (as three 128-bit loads per lane they cost each wave 3 x 71 cycles of the texture addresser)
+    if (!xcd_frame_map(P.nblur_tiles, P.nframes, tile, frame)) return;
+    blur_mfma_tile(P, tile, frame + P.frame0, s_in, s_out, s_band);
 }
 
 void orbhip_launch_blur(const ExtractParams& P, const int gk[4], int nframes, hipStream_t s, int tile0, int ntiles)
@@ -1269,20 +1273,12 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
     (void)wave; (void)lane;
 }
 
-__global__ __launch_bounds__(QT_T) void k_quadtree(ExtractParams P)
+// DistributeOctTree of one (frame, level) by the calling workgroup (QT_T threads, `lds` = its dynamic LDS block)
+__device__ __forceinline__ void quadtree_level(const ExtractParams& P, int frame, int level, int* lds)
 {
-    __builtin_amdgcn_s_setprio(3);          // latency-bound: win issue arbitration against the VALU-bound blur running beside it
-    // level-major ids (still frame == id mod 8 for the XCD affinity): workgroups are dispatched in id order and a level-0
-    // workgroup runs ~4x longer than a level-7 one, so the long ones start first and the short ones fill the tail
-    const int nfg = (P.nframes + 7) >> 3, jj = (int)blockIdx.x >> 3;
-    const int level = jj / nfg, lrel = level;
-    int frame = (jj - lrel * nfg) * 8 + ((int)blockIdx.x & 7);
-    if (frame >= P.nframes) return;
-    frame += P.frame0;
     const int tid = threadIdx.x;
     const LevelGeom g = P.geom[level];
     const int maxn = P.qt_maxn;
-    HIP_DYNAMIC_SHARED(int, lds)
     QtLds L;
     L.cntA = lds; L.cntB = L.cntA + maxn;
     L.cc = L.cntB + maxn; L.a = L.cc + 4 * maxn; L.b = L.a + maxn; L.sidx = L.b + maxn; L.split = L.sidx + maxn;
@@ -1310,6 +1306,46 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(ExtractParams P)
         keys.node = P.qt_node + (long long)frame * P.qt_per_frame + g.cand_total_off;
         qt_replay(P, g, L, keys, qval, n, frame, level, tid);
     }
+}
+
+__global__ __launch_bounds__(QT_T) void k_quadtree(ExtractParams P)
+{
+    __builtin_amdgcn_s_setprio(3);          // latency-bound: win issue arbitration against the VALU-bound blur running beside it
+    // level-major ids (still frame == id mod 8 for the XCD affinity): workgroups are dispatched in id order and a level-0
+    // workgroup runs ~4x longer than a level-7 one, so the long ones start first and the short ones fill the tail
+    const int nfg = (P.nframes + 7) >> 3, jj = (int)blockIdx.x >> 3;
+    const int level = jj / nfg;
+    const int frame = (jj - level * nfg) * 8 + ((int)blockIdx.x & 7);
+    if (frame >= P.nframes) return;
+    HIP_DYNAMIC_SHARED(int, lds)
+    quadtree_level(P, frame + P.frame0, level, lds);
+}
+
+// A handful of frames (the drop-in's single-image call): the blur and the quadtree in ONE launch.  They do not depend on each other (both follow
+// FAST / the pyramid, both precede the descriptor kernel); as two launches on one stream a frame's eight quadtree workgroups (59 us at level 0 of a
+// 1241 x 376 frame) ran behind the blur's 11 us, on two streams the event hops cost more than the blur.  The quadtree workgroups take the first
+// ids (level-major: the longest start first), the blur tiles fill the rest of the chip beside them.
+__global__ __launch_bounds__(256) void k_blur_quadtree(ExtractParams P)
+{
+    __shared__ __attribute__((aligned(16))) unsigned s_in[32 * BM_IN_DW];
+    __shared__ unsigned s_out[BM_ROWS * BM_OUT_DW];
+    __shared__ __attribute__((aligned(16))) unsigned s_band[3 * 64 * 4];
+    HIP_DYNAMIC_SHARED(int, lds)
+    const int nqt = P.nlevels * P.nframes, id = (int)blockIdx.x;
+    if (id < nqt) {
+        __builtin_amdgcn_s_setprio(3);
+        quadtree_level(P, P.frame0 + id % P.nframes, id / P.nframes, lds);
+    } else {
+        const int b = id - nqt;
+        blur_mfma_tile(P, b / P.nframes, P.frame0 + b % P.nframes, s_in, s_out, s_band);
+    }
+}
+
+void orbhip_launch_blur_quadtree(const ExtractParams& P, int nframes, hipStream_t s)
+{   // requires the matrix-core blur (P.blur_band); the caller falls back to the two launches otherwise
+    ExtractParams Q = P; Q.nframes = nframes;
+    const size_t lds = orbhip_quadtree_lds_bytes(P.qt_maxn, P.qt_maxcells);
+    hipLaunchKernelGGL(k_blur_quadtree, dim3((unsigned)((P.nlevels + P.nblur_tiles) * nframes), 1, 1), dim3(256, 1, 1), lds, s, Q);
 }
 
 void orbhip_launch_quadtree(const ExtractParams& P, int nframes, hipStream_t s)
