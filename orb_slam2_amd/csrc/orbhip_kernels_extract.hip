@@ -1098,9 +1098,15 @@ struct QtLds {
     unsigned short* map; unsigned char *depA, *depB;
 };
 
+// cell id <-> its position in the list order after K regular passes (see "regular passes" below): an involution
+__device__ __forceinline__ int qt_jump_xform(int t, int K, int nIni)
+{
+    const int bits = 2 * K, low = (t & ((1 << bits) - 1)) ^ (0x33333333 & ((1 << bits) - 1)), root = t >> bits;
+    return (((K & 1) ? nIni - 1 - root : root) << bits) | low;
+}
 template <class Keys>
 __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeom& g, const QtLds& L, Keys& keys, unsigned* qval, int n,
-                                          int frame, int level, int tid)
+                                          int frame, int level, int tid, int D)
 {
     const int N = g.nfeat;
     const int wave = tid >> 6, lane = tid & 63;
@@ -1141,30 +1147,92 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
             if (bottom) ULy = my; else BRy = my;
         }
         kcode = code; knode = root; atomicAdd(&L.cntA[root], 1);
+        if (D > 0) atomicAdd(&L.cc[(root << (2 * D)) + (int)(code >> (2 * (ORBHIP_QT_DEPTH - D)))], 1);      // keys per depth-D cell (regular passes, below)
     });
     __syncthreads();
-    // ---- B. initial list: non-empty roots in order (:552-585)
-    if (tid == 0) {
-        int m0 = 0;
-        for (int r = 0; r < g.nIni; r++) { const int c = L.cntA[r]; if (c > 0) { L.map[r] = m0; L.cntB[m0] = c; L.depB[m0] = 0; m0++; } else L.map[r] = 0; }
-        L.misc[0] = m0;
-    }
-    __syncthreads();
-    int m = L.misc[0];
-    keys.each(n, tid, [&](int, unsigned&, int& knode) { knode = L.map[knode]; });
+    // ---- B'. the regular passes in one step.
+    // While every node of the list holds more than one key, a pass divides EVERY node (:606-665): the list after K such passes is exactly the
+    // non-empty depth-K cells, and since children are pushed to the front in n1..n4 order while the parents are walked front to back,
+    //     list after pass k+1  =  for p in REVERSED(list after pass k): children of p in the order n4, n3, n2, n1,
+    // i.e. the lexicographic order of (root, d1 .. dK) with digit j descending when K - j is even and ascending when it is odd (the root like
+    // d1).  A node's position is therefore the number of non-empty cells before it in that order - one prefix sum over the per-cell key counts,
+    // which the candidates' path codes give in one histogram (one LDS atomic per key onto nIni * 4^D counters, taken above) instead of one
+    // contended histogram + five barriers per pass.  K = the number of passes the reference runs in that regime: pass 1 if no root holds a single
+    // key; pass k+1 if after pass k the loop goes on (m_k < N, m_k != m_(k-1)), stays in its first phase (m_k + 3 * nToExpand <= N, :673) and
+    // again every node holds more than one key.  Measured: 3 of 4 passes of a 1241 x 376 frame's level 0, 20 of its 57 us
+    // (profiles/r04_exp_quadtree_phase_times.txt).  Whatever does not fit (K = 0: a root with one key; deeper passes) is replayed as before.
     int* cnt = L.cntB; unsigned char* dep = L.depB; int* cnt2 = L.cntA; unsigned char* dep2 = L.depA;
     unsigned short* s_map = L.map;
     int *s_cc = L.cc, *s_a = L.a, *s_b = L.b, *s_sidx = L.sidx, *s_split = L.split, *s_best = L.best, *s_scratch = L.scratch, *s_misc = L.misc;
-    __syncthreads();
+    int m = 0, K = 0, jumpPrev = 0, jumpExp = 0;
+    if (D > 0) {
+        int* Hd[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};          // key counts per depth-d cell
+        Hd[D] = s_cc;
+        if (D >= 1) Hd[D - 1] = L.cntB;
+        if (D >= 2) Hd[D - 2] = s_best;
+        if (D >= 3) Hd[D - 3] = s_split;
+        if (D >= 4) Hd[D - 4] = s_sidx;
+        if (tid < 10) s_misc[5 + tid] = 0;                                   // [5 + 2d] = non-empty depth-d cells, [6 + 2d] = those with more than one key
+        for (int d = D; d >= 0; d--) {
+            const int nc = g.nIni << (2 * d);
+            if (d < D) for (int c = tid; c < nc; c += QT_T) Hd[d][c] = Hd[d + 1][4 * c] + Hd[d + 1][4 * c + 1] + Hd[d + 1][4 * c + 2] + Hd[d + 1][4 * c + 3];
+            __syncthreads();
+            int ne = 0, ex = 0;
+            for (int c = tid; c < nc; c += QT_T) { const int h = Hd[d][c]; ne += h > 0; ex += h > 1; }
+            if (ne) atomicAdd(&s_misc[5 + 2 * d], ne);
+            if (ex) atomicAdd(&s_misc[6 + 2 * d], ex);
+        }
+        __syncthreads();
+        if (s_misc[5] > 0 && s_misc[6] == s_misc[5]) {
+            K = 1;
+            while (K < D) {
+                const int mk = s_misc[5 + 2 * K], ek = s_misc[6 + 2 * K], mp = s_misc[5 + 2 * (K - 1)];
+                if (!(mk < N && mk != mp && ek == mk && 4 * mk <= N)) break;
+                K++;
+            }
+        }
+        if (K > 0) {
+            const int nc = g.nIni << (2 * K);
+            const int* H = Hd[K];
+            int* F = s_a;                                                    // [nc <= 4 maxn]: a | b | sidx | split (the shallower histograms there are dead, H_K never lies under F's nc entries)
+            for (int t = tid; t < nc; t += QT_T) F[t] = H[qt_jump_xform(t, K, g.nIni)] > 0 ? 1 : 0;
+            m = qt_block_exscan(F, nc, s_scratch, tid);                      // thread t scans the flags thread t wrote, and reads them back below
+            cnt = L.cntA; dep = L.depA; cnt2 = L.cntB; dep2 = L.depB;        // (H_(D-1) lives in cntB)
+            for (int t = tid; t < nc; t += QT_T) { const int h = H[qt_jump_xform(t, K, g.nIni)]; if (h > 0) { cnt[F[t]] = h; dep[F[t]] = (unsigned char)K; } }
+            __syncthreads();
+            keys.each(n, tid, [&](int, unsigned& kcode, int& knode) {
+                knode = F[qt_jump_xform((knode << (2 * K)) + (int)(kcode >> (2 * (ORBHIP_QT_DEPTH - K))), K, g.nIni)];
+            });
+            jumpPrev = s_misc[5 + 2 * (K - 1)]; jumpExp = s_misc[6 + 2 * K];
+            __syncthreads();                                                 // F and the histograms are read: their regions become the passes' scratch again
+        }
+    }
+    if (K == 0) {
+        // ---- B. initial list: non-empty roots in order (:552-585)
+        if (tid == 0) {
+            int m0 = 0;
+            for (int r = 0; r < g.nIni; r++) { const int c = L.cntA[r]; if (c > 0) { L.map[r] = m0; L.cntB[m0] = c; L.depB[m0] = 0; m0++; } else L.map[r] = 0; }
+            L.misc[0] = m0;
+        }
+        __syncthreads();
+        m = L.misc[0];
+        keys.each(n, tid, [&](int, unsigned&, int& knode) { knode = L.map[knode]; });
+        __syncthreads();
+    }
 
     // ---- C. passes
     // A dividing pass costs five workgroup barriers (it was twelve: the scratch of the NEXT pass is cleared while this one's keys move, the two
     // prefix sums of a pass are one, the expandable-node counter alternates between two words so that nobody waits for its reset).
-    bool modeB = false;
+    bool modeB = false, finished = false;
     int par = 0;                                                            // which of s_misc[3] / s_misc[4] counts this pass's expandable nodes
-    for (int i = tid; i < 4 * m; i += QT_T) s_cc[i] = 0;
+    if (K > 0) {                                                            // the checks behind pass K (:669-673)
+        if (m >= N || m == jumpPrev) finished = true;
+        else if ((m + 3 * jumpExp) > N) modeB = true;
+    }
+    { const int nz = max(4 * m, D > 0 ? (g.nIni << (2 * D)) : 0); for (int i = tid; i < nz; i += QT_T) s_cc[i] = 0; }
     if (tid == 0) { s_misc[1] = 0; s_misc[2] = 0x7fffffff; s_misc[3] = 0; s_misc[4] = 0; }
     __syncthreads();
+    if (!finished)
     for (int guard = 0; guard < 4096; guard++) {
         keys.each(n, tid, [&](int, unsigned& kcode, int& knode) {
             const int p = knode;
@@ -1292,6 +1360,10 @@ __device__ __forceinline__ void quadtree_level(const ExtractParams& P, int frame
     const int* ccount = P.cell_count + (long long)frame * P.ncells_total + g.cell_first;
     for (int c = tid; c < g.ncells; c += QT_T) { L.pref[c] = ccount[c]; L.slot[c] = P.cells[g.cell_first + c].cand_idx; }
     for (int r = tid; r < maxn; r += QT_T) L.cntA[r] = 0;
+    // depth of the per-cell histogram behind the regular-pass jump of qt_replay: nIni * 4^D counters must fit the child-count array and one prefix sum
+    int D = 0;
+    { const int cap = min(4 * maxn, 64 * (P.qt_scr - 2)); while (D < 4 && D < ORBHIP_QT_DEPTH && (g.nIni << (2 * (D + 1))) <= cap) D++; }
+    for (int i = tid; i < (D > 0 ? (g.nIni << (2 * D)) : 0); i += QT_T) L.cc[i] = 0;
     __syncthreads();
     int n = qt_block_exscan(L.pref, g.ncells, L.scratch, tid);
     n = min(n, g.cand_total_cap);
@@ -1300,11 +1372,11 @@ __device__ __forceinline__ void quadtree_level(const ExtractParams& P, int frame
         QtKeysReg keys;
 #pragma unroll
         for (int j = 0; j < QT_KPT; j++) { keys.code[j] = 0; keys.node[j] = 0; }
-        qt_replay(P, g, L, keys, qval, n, frame, level, tid);
+        qt_replay(P, g, L, keys, qval, n, frame, level, tid, D);
     } else {
         QtKeysHbm keys; keys.code = P.qt_code + (long long)frame * P.qt_per_frame + g.cand_total_off;
         keys.node = P.qt_node + (long long)frame * P.qt_per_frame + g.cand_total_off;
-        qt_replay(P, g, L, keys, qval, n, frame, level, tid);
+        qt_replay(P, g, L, keys, qval, n, frame, level, tid, D);
     }
 }
 

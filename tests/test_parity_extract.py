@@ -74,6 +74,48 @@ def test_dense_candidates_overflow_lds_keys(backend, oracle):
     ex.close()
 
 
+def _clusters(w, h, boxes, seed):
+    """flat background with white-noise boxes: every FAST candidate of the frame lies inside them"""
+    rng = np.random.default_rng(seed)
+    img = np.full((h, w), 110, np.uint8)
+    for (x, y, bw, bh) in boxes:
+        img[y:y + bh, x:x + bw] = rng.integers(0, 256, (bh, bw), dtype=np.uint8)
+    return img
+
+
+@pytest.mark.parametrize("case", ["one_cluster", "two_roots", "corner_cluster", "tiny_N", "N_between_passes", "wide_many_roots", "dense_big_N"])
+def test_quadtree_regular_pass_jump_and_its_exits(backend, oracle, case):
+    """k_quadtree resolves the passes in which every node divides in one step (per-cell key counts -> list positions) and replays the rest.
+    Candidate sets that leave that regime at every possible point: all keys in one small region (a pass after which the list did not grow:
+    the loop ends right behind the jump), two regions in different roots with empty roots between them, a cluster in the image corner (single
+    child chains), so few features that the list reaches N after the first pass, an N that falls between two regular passes (the final phase
+    starts behind the jump), a wide image with many roots, white noise with a large N (the deepest jump, keys beyond the register budget)."""
+    w, h, n, nl = 480, 320, 400, 4
+    if case == "one_cluster":
+        img = _clusters(w, h, [(200, 130, 44, 40)], 1)
+    elif case == "two_roots":
+        img = _clusters(w, h, [(30, 40, 60, 50), (400, 230, 50, 60)], 2)
+    elif case == "corner_cluster":
+        img = _clusters(w, h, [(20, 20, 36, 36)], 3)
+    elif case == "tiny_N":
+        img, n = synth.frame(w, h, seed=4), 8
+    elif case == "N_between_passes":
+        img, n = synth.frame(w, h, seed=5), 70
+    elif case == "wide_many_roots":
+        w, h, n = 900, 130, 600
+        img = synth.frame(w, h, seed=6)
+    else:
+        w, h, n, nl = 640, 480, 5000, 3
+        img = np.random.default_rng(7).integers(0, 256, (h, w), dtype=np.uint8)
+    ora = oracle.OracleExtractor(n, 1.2, nl, 20, 7)
+    ko, do = ora.extract(img)
+    ex = orb_slam2_amd.ORBextractor(n, 1.2, nl, 20, 7, w, h, library=backend)
+    kg, dg = ex(img)
+    assert kg.tobytes() == ko.tobytes() and np.array_equal(dg, do), case
+    assert len(ko) > 0
+    ex.close()
+
+
 @pytest.mark.parametrize("name", ["zeros", "checkerboard", "ramp", "low_texture", "saturated"])
 def test_degenerate_inputs(backend, oracle, name):
     w, h, n = 320, 240, 400

@@ -54,6 +54,21 @@ def test_oracle_equals_reference_extractor_degenerate(ref, oracle, name):
     r.close()
 
 
+@pytest.mark.parametrize("boxes,n", [([(200, 130, 44, 40)], 400), ([(30, 40, 60, 50), (400, 230, 50, 60)], 400), ([(20, 20, 36, 36)], 400), ([(100, 100, 200, 120)], 70)])
+def test_oracle_equals_reference_extractor_on_clustered_candidates(ref, oracle, boxes, n):
+    """candidate sets that leave the quadtree's "every node divides" regime early (tests/test_parity_extract.py runs the kernels on the same images):
+    the reference's own DistributeOctTree on its std::list is the authority for what the oracle - and through it the kernel's jump - must produce"""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_parity_extract import _clusters
+    img = _clusters(480, 320, boxes, len(boxes) + n)
+    r, o = ref.RefExtractor(n, 1.2, 4, 20, 7), oracle.OracleExtractor(n, 1.2, 4, 20, 7)
+    kr, dr = r.extract(img)
+    ko, do = o.extract(img)
+    assert len(kr) > 10 and kr.tobytes() == ko.tobytes() and np.array_equal(dr, do)
+    r.close()
+
+
 def test_product_equals_reference_extractor(ref, emu_lib):
     """The HIP kernel sources (CPU emulation build) against the reference's code directly, two batched frames."""
     w, h, n = 400, 300, 500
