@@ -75,11 +75,12 @@ def test_dense_candidates_overflow_lds_keys(backend, oracle):
 
 
 def _clusters(w, h, boxes, seed):
-    """flat background with white-noise boxes: every FAST candidate of the frame lies inside them"""
+    """flat background with boxes of dense texture (a scene at quarter scale plus noise): every FAST candidate of the frame lies inside them"""
     rng = np.random.default_rng(seed)
     img = np.full((h, w), 110, np.uint8)
+    tex = synth.frame(4 * w, 4 * h, seed=seed)[::4, ::4]
     for (x, y, bw, bh) in boxes:
-        img[y:y + bh, x:x + bw] = rng.integers(0, 256, (bh, bw), dtype=np.uint8)
+        img[y:y + bh, x:x + bw] = np.clip(tex[y:y + bh, x:x + bw].astype(np.int32) + rng.integers(-25, 26, (bh, bw)), 0, 255).astype(np.uint8)
     return img
 
 
@@ -112,7 +113,7 @@ def test_quadtree_regular_pass_jump_and_its_exits(backend, oracle, case):
     ex = orb_slam2_amd.ORBextractor(n, 1.2, nl, 20, 7, w, h, library=backend)
     kg, dg = ex(img)
     assert kg.tobytes() == ko.tobytes() and np.array_equal(dg, do), case
-    assert len(ko) > 0
+    assert len(ko) >= 4, (case, len(ko))          # (clustered candidates end the replay early: the reference returns a handful of key points per level)
     ex.close()
 
 
