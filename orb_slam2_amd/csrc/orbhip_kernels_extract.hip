@@ -1172,15 +1172,31 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
         if (D >= 2) Hd[D - 2] = s_best;
         if (D >= 3) Hd[D - 3] = s_split;
         if (D >= 4) Hd[D - 4] = s_sidx;
-        if (tid < 10) s_misc[5 + tid] = 0;                                   // [5 + 2d] = non-empty depth-d cells, [6 + 2d] = those with more than one key
-        for (int d = D; d >= 0; d--) {
-            const int nc = g.nIni << (2 * d);
-            if (d < D) for (int c = tid; c < nc; c += QT_T) Hd[d][c] = Hd[d + 1][4 * c] + Hd[d + 1][4 * c + 1] + Hd[d + 1][4 * c + 2] + Hd[d + 1][4 * c + 3];
-            __syncthreads();
-            int ne = 0, ex = 0;
-            for (int c = tid; c < nc; c += QT_T) { const int h = Hd[d][c]; ne += h > 0; ex += h > 1; }
-            if (ne) atomicAdd(&s_misc[5 + 2 * d], ne);
-            if (ex) atomicAdd(&s_misc[6 + 2 * d], ex);
+        // [5 + 2d] = non-empty depth-d cells, [6 + 2d] = those with more than one key (zeroed with the counters at kernel start).  Every shallower
+        // histogram is summed straight from H_D and counted in the same step, each count reduced inside the wave first: one barrier for all depths
+        // (a barrier and 256 same-address LDS atomics per depth cost more than the three passes' worth of work this replaces saves).
+        {
+            int ne[5] = {0, 0, 0, 0, 0}, ex[5] = {0, 0, 0, 0, 0};
+            const int ncD = g.nIni << (2 * D);
+            for (int c = tid; c < ncD; c += QT_T) { const int h = s_cc[c]; ne[D] += h > 0; ex[D] += h > 1; }
+            int base = 0;
+            for (int d = D - 1; d >= 0; d--) {
+                const int nc = g.nIni << (2 * d), span = 1 << (2 * (D - d));
+                // cells of depth d are handed out behind those of the deeper levels, so that the few long sums of the shallow levels spread over threads
+                for (int c = tid - base; c < nc; c += QT_T) {
+                    if (c < 0) continue;
+                    int h = 0;
+                    for (int k = 0; k < span; k++) h += s_cc[c * span + k];
+                    Hd[d][c] = h; ne[d] += h > 0; ex[d] += h > 1;
+                }
+                base = (base + nc) % QT_T;
+            }
+#pragma unroll
+            for (int d = 0; d < 5; d++) {
+                if (d > D) break;
+                const int a1 = __builtin_amdgcn_readlane(qt_wave_incl_scan(ne[d], lane), 63), a2 = __builtin_amdgcn_readlane(qt_wave_incl_scan(ex[d], lane), 63);
+                if (lane == 0) { if (a1) atomicAdd(&s_misc[5 + 2 * d], a1); if (a2) atomicAdd(&s_misc[6 + 2 * d], a2); }
+            }
         }
         __syncthreads();
         if (s_misc[5] > 0 && s_misc[6] == s_misc[5]) {
@@ -1195,8 +1211,19 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
             const int nc = g.nIni << (2 * K);
             const int* H = Hd[K];
             int* F = s_a;                                                    // [nc <= 4 maxn]: a | b | sidx | split (the shallower histograms there are dead, H_K never lies under F's nc entries)
-            for (int t = tid; t < nc; t += QT_T) F[t] = H[qt_jump_xform(t, K, g.nIni)] > 0 ? 1 : 0;
-            m = qt_block_exscan(F, nc, s_scratch, tid);                      // thread t scans the flags thread t wrote, and reads them back below
+            if (nc <= QT_T) {                                                // one cell per thread: a wave scan and four partial sums, one barrier
+                const int f = tid < nc ? (H[qt_jump_xform(tid, K, g.nIni)] > 0 ? 1 : 0) : 0;
+                const int incl = qt_wave_incl_scan(f, lane);
+                if (lane == 63) s_scratch[wave] = incl;
+                __syncthreads();
+                int off = 0;
+                for (int w2 = 0; w2 < wave; w2++) off += s_scratch[w2];
+                if (tid < nc) F[tid] = off + incl - f;
+                m = s_scratch[0] + s_scratch[1] + s_scratch[2] + s_scratch[3];
+            } else {
+                for (int t = tid; t < nc; t += QT_T) F[t] = H[qt_jump_xform(t, K, g.nIni)] > 0 ? 1 : 0;
+                m = qt_block_exscan(F, nc, s_scratch, tid);                  // thread t scans the flags thread t wrote, and reads them back below
+            }
             cnt = L.cntA; dep = L.depA; cnt2 = L.cntB; dep2 = L.depB;        // (H_(D-1) lives in cntB)
             for (int t = tid; t < nc; t += QT_T) { const int h = H[qt_jump_xform(t, K, g.nIni)]; if (h > 0) { cnt[F[t]] = h; dep[F[t]] = (unsigned char)K; } }
             __syncthreads();
@@ -1364,6 +1391,7 @@ __device__ __forceinline__ void quadtree_level(const ExtractParams& P, int frame
     int D = 0;
     { const int cap = min(4 * maxn, 64 * (P.qt_scr - 2)); while (D < 4 && D < ORBHIP_QT_DEPTH && (g.nIni << (2 * (D + 1))) <= cap) D++; }
     for (int i = tid; i < (D > 0 ? (g.nIni << (2 * D)) : 0); i += QT_T) L.cc[i] = 0;
+    if (tid < 16) L.misc[tid] = 0;
     __syncthreads();
     int n = qt_block_exscan(L.pref, g.ncells, L.scratch, tid);
     n = min(n, g.cand_total_cap);
