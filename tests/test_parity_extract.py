@@ -84,13 +84,14 @@ def _clusters(w, h, boxes, seed):
     return img
 
 
-@pytest.mark.parametrize("case", ["one_cluster", "two_roots", "corner_cluster", "tiny_N", "N_between_passes", "wide_many_roots", "dense_big_N"])
+@pytest.mark.parametrize("case", ["one_cluster", "two_roots", "corner_cluster", "tiny_N", "N_between_passes", "wide_many_roots", "dense_big_N", "deep_cluster", "two_deep_clusters"])
 def test_quadtree_regular_pass_jump_and_its_exits(backend, oracle, case):
     """k_quadtree resolves the passes in which every node divides in one step (per-cell key counts -> list positions) and replays the rest.
     Candidate sets that leave that regime at every possible point: all keys in one small region (a pass after which the list did not grow:
     the loop ends right behind the jump), two regions in different roots with empty roots between them, a cluster in the image corner (single
     child chains), so few features that the list reaches N after the first pass, an N that falls between two regular passes (the final phase
-    starts behind the jump), a wide image with many roots, white noise with a large N (the deepest jump, keys beyond the register budget)."""
+    starts behind the jump), a wide image with many roots, white noise with a large N (keys beyond the register budget), and many features wanted
+    from one or two regions (a four-pass jump, then passes deeper than the path digits computed up front: those are recomputed on demand)."""
     w, h, n, nl = 480, 320, 400, 4
     if case == "one_cluster":
         img = _clusters(w, h, [(200, 130, 44, 40)], 1)
@@ -105,6 +106,10 @@ def test_quadtree_regular_pass_jump_and_its_exits(backend, oracle, case):
     elif case == "wide_many_roots":
         w, h, n = 900, 130, 600
         img = synth.frame(w, h, seed=6)
+    elif case == "deep_cluster":          # many features wanted from one region: the tree goes past the path digits computed up front (and jumps four passes)
+        img, n, nl = _clusters(w, h, [(150, 100, 110, 90)], 9), 1500, 2
+    elif case == "two_deep_clusters":
+        img, n, nl = _clusters(w, h, [(40, 60, 90, 70), (300, 200, 80, 70)], 9), 2000, 3
     else:
         w, h, n, nl = 640, 480, 5000, 3
         img = np.random.default_rng(7).integers(0, 256, (h, w), dtype=np.uint8)
