@@ -1028,19 +1028,6 @@ __device__ __forceinline__ int qt_block_exscan(int* a, int n, int* scratch, int 
         if (lane == 63) scratch[c] = incl;
     }
     __syncthreads();
-    if (nch <= 16) {
-        // up to 1024 elements (every list of the metric's shapes): each thread adds the chunk totals in front of its own chunks itself - one barrier
-        // less than handing them to wave 0 (callers that need scratch[-1] read the returned total instead)
-        int run = 0, total = 0;
-        for (int c = 0; c < nch; c++) { const int v = scratch[c]; total += v; if (c < (tid >> 6)) run += v; }
-        int off = run;
-        for (int i = tid, c = tid >> 6; i < n; i += QT_T, c += QT_T / 64) {
-            a[i] += off;
-            for (int k = c; k < c + QT_T / 64 && k < nch; k++) off += scratch[k];
-        }
-        if (TRAILING_BARRIER) __syncthreads();
-        return total;
-    }
     if (wave == 0) {
         int run = 0;
         for (int cb = 0; cb < nch; cb += 64) {
@@ -1058,7 +1045,6 @@ __device__ __forceinline__ int qt_block_exscan(int* a, int n, int* scratch, int 
     return total;
 }
 
-#define QT_EAGER 6                       // path digits computed up front (<= ORBHIP_QT_DEPTH, >= the jump's depth 4); the rest on demand
 #define QT_KPT 16                       // candidates per thread whose keys stay in registers
 #define QT_REGKEYS (QT_KPT * QT_T)      // = 4096 candidates per (frame, level); more -> HBM workspace
 
@@ -1144,29 +1130,22 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
         }
     }
     __syncthreads();
-    // A key's path: root and the first QT_EAGER digits now (7 of a level-0 workgroup's 57 us went into all 13 digits of 16 keys per thread, of which a
-    // replay uses four to six); the deeper digits are computed by the pass that first needs them (node depth <= number of passes so far).
-    auto path_code = [&](unsigned v, int ndigits, int& root_out) -> unsigned {
+    keys.each_loaded(n, tid, qval, [&](int idx, unsigned v, unsigned& kcode, int& knode) {
+        (void)idx;
         const int x = v & 0xfff, y = (v >> 12) & 0xfff;
         int root = __float2int_rz(__fdiv_rn((float)x, g.hX));                    // vpIniNodes[kp.pt.x/hX]  (:569)
         root = min(max(root, 0), g.nIni - 1);
         int ULx = __float2int_rz(__fmul_rn(g.hX, (float)root)), URx = __float2int_rz(__fmul_rn(g.hX, (float)(root + 1)));   // :555-556
         int ULy = 0, BRy = g.maxBorderY - ORBHIP_EDGE;
         unsigned code = 0;
-        for (int d = 0; d < ndigits; d++) {                                       // DivideNode :483-526
+#pragma unroll
+        for (int d = 0; d < ORBHIP_QT_DEPTH; d++) {                               // DivideNode :483-526
             const int mx = ULx + ((URx - ULx + 1) >> 1), my = ULy + ((BRy - ULy + 1) >> 1);
             const int right = !(x < mx), bottom = !(y < my);
             code = (code << 2) | (unsigned)(right + 2 * bottom);                  // n1=0 n2=1 n3=2 n4=3
             if (right) ULx = mx; else URx = mx;
             if (bottom) ULy = my; else BRy = my;
         }
-        root_out = root;
-        return code << (2 * (ORBHIP_QT_DEPTH - ndigits));                         // digit d at the same bits whatever ndigits
-    };
-    keys.each_loaded(n, tid, qval, [&](int idx, unsigned v, unsigned& kcode, int& knode) {
-        (void)idx;
-        int root;
-        const unsigned code = path_code(v, QT_EAGER, root);
         kcode = code; knode = root; atomicAdd(&L.cntA[root], 1);
         if (D > 0) atomicAdd(&L.cc[(root << (2 * D)) + (int)(code >> (2 * (ORBHIP_QT_DEPTH - D)))], 1);      // keys per depth-D cell (regular passes, below)
     });
@@ -1272,7 +1251,6 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
     // A dividing pass costs five workgroup barriers (it was twelve: the scratch of the NEXT pass is cleared while this one's keys move, the two
     // prefix sums of a pass are one, the expandable-node counter alternates between two words so that nobody waits for its reset).
     bool modeB = false, finished = false;
-    int nExp = jumpExp;                                                      // nodes with more than one key in the current list (known from the pass before)
     int par = 0;                                                            // which of s_misc[3] / s_misc[4] counts this pass's expandable nodes
     if (K > 0) {                                                            // the checks behind pass K (:669-673)
         if (m >= N || m == jumpPrev) finished = true;
@@ -1281,13 +1259,8 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
     { const int nz = max(4 * m, D > 0 ? (g.nIni << (2 * D)) : 0); for (int i = tid; i < nz; i += QT_T) s_cc[i] = 0; }
     if (tid == 0) { s_misc[1] = 0; s_misc[2] = 0x7fffffff; s_misc[3] = 0; s_misc[4] = 0; }
     __syncthreads();
-    bool deep = QT_EAGER >= ORBHIP_QT_DEPTH;
     if (!finished)
     for (int guard = 0; guard < 4096; guard++) {
-        if (!deep && K + guard >= QT_EAGER) {                               // a node may now sit at depth QT_EAGER: its keys need the digits behind it
-            keys.each_loaded(n, tid, qval, [&](int, unsigned v, unsigned& kcode, int&) { int root; kcode = path_code(v, ORBHIP_QT_DEPTH, root); });
-            deep = true;
-        }
         keys.each(n, tid, [&](int, unsigned& kcode, int& knode) {
             const int p = knode;
             if (cnt[p] > 1) atomicAdd(&s_cc[4 * p + qt_digit(kcode, dep[p])], 1);
@@ -1316,18 +1289,15 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
             // The expandable nodes are first compacted in list order (one prefix sum), then ranked among themselves: late in the replay most
             // nodes hold a single key, and ranking every node against the whole list (m^2 / 256 steps per thread) was the longest stretch of a
             // level-0 workgroup between two barriers.
-            // The expandable nodes are ranked where they stand (no compaction first): node p's rank is the number of expandable nodes that are larger,
-            // or as large and nearer the front - list order IS creation order, descending.  m reads per expandable node instead of a prefix sum, a
-            // compaction and E reads, three barriers less.
-            const int E = nExp;
-            for (int p = tid; p < m; p += QT_T) {
-                s_split[p] = 0;
-                const int c = cnt[p];
-                if (c > 1) {
-                    int rank = 0;
-                    for (int o = 0; o < m; o++) { const int co = cnt[o]; rank += (co > 1) && (co > c || (co == c && o < p)); }
-                    s_sidx[rank] = p;
-                }
+            for (int p = tid; p < m; p += QT_T) { s_split[p] = 0; s_best[p] = cnt[p] > 1 ? 1 : 0; }
+            const int E = qt_block_exscan(s_best, m, s_scratch, tid);     // thread t scans the flags thread t wrote
+            for (int p = tid; p < m; p += QT_T) { const int c = cnt[p]; if (c > 1) { const int j = s_best[p]; s_b[j] = c; s_a[j] = p; } }
+            __syncthreads();
+            for (int j = tid; j < E; j += QT_T) {
+                const int c = s_b[j];
+                int rank = 0;
+                for (int o = 0; o < E; o++) { const int co = s_b[o]; rank += (co > c || (co == c && o < j)); }
+                s_sidx[rank] = s_a[j];
             }
             __syncthreads();
             for (int j = tid; j < E; j += QT_T) {
@@ -1335,6 +1305,7 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
                 s_a[j] = (s_cc[4 * p] > 0) + (s_cc[4 * p + 1] > 0) + (s_cc[4 * p + 2] > 0) + (s_cc[4 * p + 3] > 0);
                 s_b[j] = s_a[j];
             }
+            __syncthreads();
             const int Call = qt_block_exscan(s_a, E, s_scratch, tid);     // s_a[j] = children created before sorted node j
             for (int j = tid; j < E; j += QT_T) {                          // list size after processing sorted node j
                 const int size_after = m + s_a[j] + s_b[j] - (j + 1);
@@ -1348,7 +1319,8 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
             for (int j = tid; j < nsplit; j += QT_T) s_split[s_sidx[j]] = 1 + j;
             __syncthreads();
             for (int p = tid; p < m; p += QT_T) s_best[p] = s_split[p] ? 0 : 1;
-            qt_block_exscan(s_best, m, s_scratch, tid);                   // thread t scans the flags thread t wrote
+            __syncthreads();
+            qt_block_exscan(s_best, m, s_scratch, tid);
             for (int p = tid; p < m; p += QT_T) {
                 if (s_split[p]) {
                     int q = s_a[s_split[p] - 1];
@@ -1370,7 +1342,6 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
         if (tid == 0) { s_misc[1] = 0; s_misc[2] = 0x7fffffff; s_misc[3 + (par ^ 1)] = 0; }
         __syncthreads();
         const int nToExpand = s_misc[3 + par];
-        nExp = nToExpand;
         par ^= 1;
         int* t = cnt; cnt = cnt2; cnt2 = t; unsigned char* td = dep; dep = dep2; dep2 = td;
         const int prev = m; m = m2;
