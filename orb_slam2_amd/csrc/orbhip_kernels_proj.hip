@@ -141,19 +141,33 @@ __device__ __forceinline__ void proj_select_body(const ProjParams& J)
             if (bin == ORBHIP_HISTO_LENGTH) bin = 0;
             return min(max(bin, 0), ORBHIP_HISTO_LENGTH - 1);
         };
+        // The records of step s + 1 (64 queries x 7 words from global memory: one memory latency) are requested before step s is resolved and
+        // consumed after it: 18 steps of a 1100-query search used to pay that latency 18 times, one after the other - most of the kernel's 41 us.
+        unsigned nt[PJ_K], nmore = 0u; int nblocks = 0; float nqang = 0.0f;
+        auto fetch = [&](int qb) {
+            const int q = qb + lane;
+            const bool inb = q < J.nq;
+#pragma unroll
+            for (int k = 0; k < PJ_K; k++) nt[k] = inb ? J.top[PJ_REC * q + k] : PJ_NONE;
+            nmore = inb ? J.top[PJ_REC * q + PJ_K] : 0u;
+            nblocks = inb ? J.q[q].blocks : 0;
+            nqang = inb ? J.q[q].angle : 0.0f;
+        };
+        fetch(0);
         for (int qb = 0; qb < J.nq; qb += 64) {
             const int q = qb + lane;
             const bool inb = q < J.nq;
             int ei[PJ_K], ed[PJ_K], el[PJ_K]; int nk = 0;
 #pragma unroll
             for (int k = 0; k < PJ_K; k++) {
-                const unsigned t = inb ? J.top[PJ_REC * q + k] : PJ_NONE;
+                const unsigned t = nt[k];
                 ei[k] = (int)(t & 0x7FFFFu); ed[k] = (int)((t >> 19) & 0x1FFu); el[k] = (int)(t >> 28);
                 if (t != PJ_NONE) nk = k + 1;
             }
-            const bool more = inb && J.top[PJ_REC * q + PJ_K] != 0u;
-            const int blocks = inb ? J.q[q].blocks : 0;
-            const float qang = inb ? J.q[q].angle : 0.0f;
+            const bool more = inb && nmore != 0u;
+            const int blocks = nblocks;
+            const float qang = nqang;
+            if (qb + 64 < J.nq) fetch(qb + 64);
             int stamped = -1;                                // feature this lane's speculative claim currently marks
             unsigned long long todo = __ballot(nk > 0);
             while (todo) {
