@@ -6,6 +6,7 @@
 // here at context creation and uploaded; per call the host only enqueues kernels on the context's HIP stream.
 // Float expressions mirror the reference's types step by step (file built with -ffp-contract=off).
 #include "orbhip_internal.h"
+#include <sched.h>
 #include <cmath>
 #include <cstdio>
 #include <cstdarg>
@@ -762,7 +763,49 @@ extern "C" orbhip_status orbhip_fetch_matches(orbhip_ctx* c, int nimg, int32_t* 
 // A few helper threads for pageable <-> pinned gathers: one core copies ~10 GB/s, a batch of 64 KITTI frames is 30 MB in and
 // 8 MB out, so a single-threaded memcpy alone would cap the host path near 20 k frames/s.  Process-wide, created on first use,
 // never joined (the threads sleep on a condition variable; a dlclose'd library with live threads is the alternative).
+// ---- NUMA placement (used by the pool's workers, orbhip_pool.hip, and by the copy helpers below)
+int orbhip_device_numa_node(int device)
+{
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    for (char* c = bus; *c; c++) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
+    const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/numa_node";
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) return -1;
+    int node = -1;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    return node;
+}
+static thread_local int tl_numa_node = -1;      // node the calling thread was bound to by orbhip_bind_thread_to_node (-1: not bound)
+bool orbhip_bind_thread_to_node(int node)
+{   // /sys/devices/system/node/node<N>/cpulist: "0-63,128-191"
+    if (node < 0) return false;
+    char path[128]; snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE* f = fopen(path, "r");
+    if (!f) return false;
+    char buf[4096] = {0};
+    const bool got = fgets(buf, sizeof buf, f) != nullptr;
+    fclose(f);
+    if (!got) return false;
+    cpu_set_t set; CPU_ZERO(&set);
+    int ncpu = 0;
+    for (char* tok = strtok(buf, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+        int a = 0, b = 0;
+        const int k = sscanf(tok, "%d-%d", &a, &b);
+        if (k < 1) continue;
+        if (k == 1) b = a;
+        for (int c = a; c <= b && c < CPU_SETSIZE; c++) { CPU_SET(c, &set); ncpu++; }
+    }
+    const bool ok = ncpu > 0 && sched_setaffinity(0, sizeof set, &set) == 0;
+    if (ok) tl_numa_node = node;
+    return ok;
+}
+
 namespace {
+// the CPUs this process may use, as they were when the library was loaded: what an unbound helper thread goes back to (it must not inherit the
+// affinity of whichever bound worker happened to create it)
+static cpu_set_t g_process_cpus; static const bool g_have_process_cpus = sched_getaffinity(0, sizeof g_process_cpus, &g_process_cpus) == 0;
 struct CopyJob { std::atomic<int> next{0}, done{0}; int n = 0; std::function<void(int)> fn; };
 class CopyPool {
     std::mutex m; std::condition_variable cv; std::deque<std::shared_ptr<CopyJob>> q; int nthreads = 0;
@@ -775,13 +818,26 @@ class CopyPool {
         }
     }
 public:
-    CopyPool() {
+    explicit CopyPool(int node) {
         const char* e = getenv("ORBHIP_COPY_THREADS");
         const int hw = (int)std::thread::hardware_concurrency();
         nthreads = e ? atoi(e) : std::min(8, std::max(hw / 4, 1));
-        for (int i = 0; i + 1 < nthreads; i++) std::thread([this] { worker(); }).detach();       // the calling thread is the n-th copier
+        for (int i = 0; i + 1 < nthreads; i++)                                                   // the calling thread is the n-th copier
+            std::thread([this, node] {
+                if (node >= 0) (void)orbhip_bind_thread_to_node(node);
+                else if (g_have_process_cpus) (void)sched_setaffinity(0, sizeof g_process_cpus, &g_process_cpus);
+                worker();
+            }).detach();
     }
-    static CopyPool& get() { static CopyPool* p = new CopyPool; return *p; }
+    // one set of helpers per NUMA node: a caller that is bound to a node (a pool worker) gets copiers on that node's CPUs - pageable frames are
+    // gathered into that node's pinned ring without crossing the socket; unbound callers share a set that roams
+    static CopyPool& get() {
+        static std::mutex gm; static CopyPool* pools[18] = {nullptr};
+        const int k = (tl_numa_node >= 0 && tl_numa_node < 17) ? tl_numa_node + 1 : 0;
+        std::lock_guard<std::mutex> lk(gm);
+        if (!pools[k]) pools[k] = new CopyPool(k - 1);
+        return *pools[k];
+    }
     // fn(0) .. fn(n-1), spread over the helpers and the caller; returns when all are done
     void run(int n, size_t bytes_each, const std::function<void(int)>& fn) {
         if (n <= 0) return;

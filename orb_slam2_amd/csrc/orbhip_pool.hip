@@ -74,40 +74,7 @@ static orbhip_status pool_status(orbhip_pool* p, const char* what)
 // result scatters) and pinned ring live on the other socket pay a cross-socket hop on every byte, and at 8 GPUs x ~55 GB/s of uploads the host side
 // is what bends the scaling curve.  Each worker therefore binds itself to the CPUs of its device's NUMA node BEFORE it creates its context:
 // the context's pinned mirrors (hipHostMalloc, first touched by this thread) then come from that node's memory.  ORBHIP_POOL_NUMA=0 turns it off.
-static int device_numa_node(int device)
-{
-    char bus[64] = {0};
-    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); return -1; }
-    for (char* c = bus; *c; c++) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
-    const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/numa_node";
-    FILE* f = fopen(path.c_str(), "r");
-    if (!f) return -1;
-    int node = -1;
-    if (fscanf(f, "%d", &node) != 1) node = -1;
-    fclose(f);
-    return node;
-}
-static bool bind_thread_to_node(int node)
-{   // /sys/devices/system/node/node<N>/cpulist: "0-63,128-191"
-    if (node < 0) return false;
-    char path[128]; snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
-    FILE* f = fopen(path, "r");
-    if (!f) return false;
-    char buf[4096] = {0};
-    const bool got = fgets(buf, sizeof buf, f) != nullptr;
-    fclose(f);
-    if (!got) return false;
-    cpu_set_t set; CPU_ZERO(&set);
-    int ncpu = 0;
-    for (char* tok = strtok(buf, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
-        int a = 0, b = 0;
-        const int k = sscanf(tok, "%d-%d", &a, &b);
-        if (k < 1) continue;
-        if (k == 1) b = a;
-        for (int c = a; c <= b && c < CPU_SETSIZE; c++) { CPU_SET(c, &set); ncpu++; }
-    }
-    return ncpu > 0 && sched_setaffinity(0, sizeof set, &set) == 0;
-}
+// (orbhip_device_numa_node / orbhip_bind_thread_to_node live in orbhip_api.hip: the host path's copy helpers are placed with them too)
 
 extern "C" void orbhip_pool_destroy(orbhip_pool* p)
 {
@@ -145,7 +112,7 @@ extern "C" orbhip_status orbhip_pool_create(orbhip_pool** out, const int* device
         orbhip_config c = *cfg; c.device = devices[r]; c.max_batch = p->per_dev; c.stream = nullptr;
         w->post([wp, c] {
             static const bool numa = [] { const char* e = getenv("ORBHIP_POOL_NUMA"); return !(e && *e == '0'); }();
-            if (numa) { wp->numa_node = device_numa_node(wp->device); wp->numa_bound = bind_thread_to_node(wp->numa_node); }
+            if (numa) { wp->numa_node = orbhip_device_numa_node(wp->device); wp->numa_bound = orbhip_bind_thread_to_node(wp->numa_node); }
             const orbhip_status s = orbhip_create(&wp->ctx, &c); if (s != ORBHIP_OK) wp->fail_from_thread(s);
         });
         p->w.push_back(std::move(w));
