@@ -17,4 +17,8 @@ for f in $(find /tmp/prof_loop_$TAG -name "*kernel_stats.csv" | head -1); do cp 
 for f in $(find /tmp/prof_loop_$TAG -name "*kernel_trace.csv" | head -1); do cp $f $OUT/loop_kernel_trace.csv; done
 for f in $(find /tmp/prof_loop_$TAG -name "*memory_copy_trace.csv" | head -1); do cp $f $OUT/loop_memory_copy_trace.csv; done
 timeout 100 python tools/single_frame_calls.py > $OUT/single_frame.txt 2>&1
-tail -4 $OUT/pytest_gpu.log; tail -2 $OUT/smoke.log; cut -c1-600 $OUT/bench.json; tail -6 $OUT/bench.err; cat $OUT/single_frame.txt; cat $OUT/bench_kernel_stats.csv | cut -c1-140 | head -14
+timeout 200 python tools/matcher_latency.py > $OUT/matcher_latency.json 2>> $OUT/bench.err
+ORBHIP_SERIAL=1 timeout 200 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-host-io --no-traffic --no-dropin-loop > $OUT/bench_serial_b512.json 2>> $OUT/bench.err
+( cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_single_$TAG -o s -- python $REPO/tools/single_frame_calls.py > /dev/null 2>> $OUT/rocprof.err )
+for f in $(find /tmp/prof_single_$TAG -name "*kernel_stats.csv" | head -1); do cp $f $OUT/single_frame_kernel_stats.csv; done
+tail -4 $OUT/pytest_gpu.log; tail -2 $OUT/smoke.log; cut -c1-600 $OUT/bench.json; tail -6 $OUT/bench.err; cat $OUT/single_frame.txt; cat $OUT/matcher_latency.json; cat $OUT/bench_kernel_stats.csv | cut -c1-140 | head -14

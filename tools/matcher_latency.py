@@ -47,6 +47,19 @@ def main():
         "search_best_in_window_ms": timed(lambda: orb_slam2_amd.search_best_in_window(k2, d2, W, H, inv, bq, d1[keep], True)),
         "extract_single_frame_ms": timed(lambda: ex(seq[0])),
     }
+    # M4 / M5: the BoW-guided matchers on FeatureVectors of the small golden vocabulary (k = 6, L = 3: 216 words, levelsup 2 -> 6 nodes of
+    # ~330 features each; the real ORBvoc at levelsup 4 gives ~100 nodes of ~20 features, i.e. far fewer pairs per node), Fuse's / SearchBySim3's window search
+    voc = orb_slam2_amd.ORBVocabulary(os.path.join(ROOT, "tests", "golden", "voc_k6_L3_ref.txt"))
+    fv1, fv2 = voc.transform(d1, 2)[2:], voc.transform(d2, 2)[2:]
+    valid1 = (rng.random(len(k1)) < 0.8).astype(np.uint8); valid2 = (rng.random(len(k2)) < 0.8).astype(np.uint8)
+    out["search_by_bow_keyframe_frame_ms"] = timed(lambda: orb_slam2_amd.search_by_bow(0, d1, k1["angle"], valid1, fv1, d2, k2["angle"], None, fv2, nnratio=0.7), reps=10)
+    out["search_by_bow_keyframe_keyframe_ms"] = timed(lambda: orb_slam2_amd.search_by_bow(1, d1, k1["angle"], valid1, fv1, d2, k2["angle"], valid2, fv2, nnratio=0.75), reps=10)
+    F12 = np.array([[0, -1e-3, 1.0 / 300], [1e-3, 0, -3.0 / 300], [-1.0 / 300, 3.0 / 300, 0]], np.float32)
+    no1 = (rng.random(len(k1)) < 0.3).astype(np.uint8); no2 = (rng.random(len(k2)) < 0.3).astype(np.uint8)
+    z1, z2 = np.zeros(len(k1), np.uint8), np.zeros(len(k2), np.uint8)
+    out["search_for_triangulation_ms"] = timed(lambda: orb_slam2_amd.search_for_triangulation(d1, k1, no1, z1, fv1, d2, k2, no2, z2, fv2, F12, 620.0, 190.0, sf, sf * sf), reps=10)
+    out["fuse_window_search_ms"] = timed(lambda: orb_slam2_amd.search_best_in_window(k2, d2, W, H, inv, bq, d1[keep], True))
+    out["search_by_sim3_two_window_searches_ms"] = round(2 * timed(lambda: orb_slam2_amd.search_best_in_window(k2, d2, W, H, inv, bq, d1[keep], False)), 3)
     ex.extract_batch(seq)                                  # frame 1 (k2, d2) is on the device again: only queries and results travel
     out["search_by_projection_frame_on_device_ms"] = timed(lambda: ex.search_by_projection(1, len(k2), q, d1[keep], 0, nnratio=0.8))
     out["search_best_in_window_frame_on_device_ms"] = timed(lambda: ex.search_best_in_window(1, len(k2), bq, d1[keep], True))
