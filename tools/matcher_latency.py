@@ -54,10 +54,21 @@ def main():
     valid1 = (rng.random(len(k1)) < 0.8).astype(np.uint8); valid2 = (rng.random(len(k2)) < 0.8).astype(np.uint8)
     out["search_by_bow_keyframe_frame_ms"] = timed(lambda: orb_slam2_amd.search_by_bow(0, d1, k1["angle"], valid1, fv1, d2, k2["angle"], None, fv2, nnratio=0.7), reps=10)
     out["search_by_bow_keyframe_keyframe_ms"] = timed(lambda: orb_slam2_amd.search_by_bow(1, d1, k1["angle"], valid1, fv1, d2, k2["angle"], valid2, fv2, nnratio=0.75), reps=10)
+    # ... and on a partition shaped like ORBvoc's at levelsup 4 (k = 10, L = 6: the 100 nodes of level 2, ~20 features each): features of both frames dealt to
+    # 100 nodes by the same rule (their first descriptor byte mod 100), so that a node holds similar counts on both sides - the matcher's work per node
+    def partition(desc):
+        node = desc[:, 0].astype(np.int64) % 100
+        order = np.argsort(node, kind="stable")
+        ids, counts = np.unique(node, return_counts=True)
+        return ids.astype(np.uint32), np.concatenate([[0], np.cumsum(counts)]).astype(np.int32), order.astype(np.uint32)
+    pv1, pv2 = partition(d1), partition(d2)
+    out["search_by_bow_keyframe_frame_100_nodes_ms"] = timed(lambda: orb_slam2_amd.search_by_bow(0, d1, k1["angle"], valid1, pv1, d2, k2["angle"], None, pv2, nnratio=0.7), reps=10)
+    out["search_by_bow_keyframe_keyframe_100_nodes_ms"] = timed(lambda: orb_slam2_amd.search_by_bow(1, d1, k1["angle"], valid1, pv1, d2, k2["angle"], valid2, pv2, nnratio=0.75), reps=10)
     F12 = np.array([[0, -1e-3, 1.0 / 300], [1e-3, 0, -3.0 / 300], [-1.0 / 300, 3.0 / 300, 0]], np.float32)
     no1 = (rng.random(len(k1)) < 0.3).astype(np.uint8); no2 = (rng.random(len(k2)) < 0.3).astype(np.uint8)
     z1, z2 = np.zeros(len(k1), np.uint8), np.zeros(len(k2), np.uint8)
     out["search_for_triangulation_ms"] = timed(lambda: orb_slam2_amd.search_for_triangulation(d1, k1, no1, z1, fv1, d2, k2, no2, z2, fv2, F12, 620.0, 190.0, sf, sf * sf), reps=10)
+    out["search_for_triangulation_100_nodes_ms"] = timed(lambda: orb_slam2_amd.search_for_triangulation(d1, k1, no1, z1, pv1, d2, k2, no2, z2, pv2, F12, 620.0, 190.0, sf, sf * sf), reps=10)
     out["fuse_window_search_ms"] = timed(lambda: orb_slam2_amd.search_best_in_window(k2, d2, W, H, inv, bq, d1[keep], True))
     out["search_by_sim3_two_window_searches_ms"] = round(2 * timed(lambda: orb_slam2_amd.search_best_in_window(k2, d2, W, H, inv, bq, d1[keep], False)), 3)
     ex.extract_batch(seq)                                  # frame 1 (k2, d2) is on the device again: only queries and results travel
