@@ -196,14 +196,14 @@ static hipError_t arena_upload(hipStream_t s)
     hipError_t e = hstage_reserve(hi); if (e != hipSuccess) return e;
     size_t in_hi = 0;
     for (const Xfer& x : g_xfers) if (x.src) { memcpy(g_hstage + x.off, x.src, x.bytes_in); in_hi = std::max(in_hi, x.off + x.bytes_in); }
-    return in_hi ? hipMemcpyAsync(g_scratch, g_hstage, in_hi, hipMemcpyHostToDevice, s) : hipSuccess;
+    return in_hi ? orbhip_copy_async(g_scratch, g_hstage, in_hi, hipMemcpyHostToDevice, s) : hipSuccess;
 }
 static hipError_t arena_download(hipStream_t s)
 {
     size_t lo = (size_t)-1, hi = 0;
     for (const Xfer& x : g_xfers) if (x.dst) { lo = std::min(lo, x.off); hi = std::max(hi, x.off + x.bytes_out); }
     if (hi == 0) return hipStreamSynchronize(s);
-    hipError_t e = hipMemcpyAsync(g_hstage + lo, static_cast<uint8_t*>(g_scratch) + lo, hi - lo, hipMemcpyDeviceToHost, s); if (e != hipSuccess) return e;
+    hipError_t e = orbhip_copy_async(g_hstage + (lo & ~(size_t)255), static_cast<uint8_t*>(g_scratch) + (lo & ~(size_t)255), hi - (lo & ~(size_t)255), hipMemcpyDeviceToHost, s); if (e != hipSuccess) return e;
     e = hipStreamSynchronize(s); if (e != hipSuccess) return e;
     for (const Xfer& x : g_xfers) if (x.dst) memcpy(x.dst, g_hstage + x.off, x.bytes_out);
     return hipSuccess;
@@ -711,9 +711,10 @@ static orbhip_status mirrors_free(const orbhip_ctx* c, const char* who)
 static orbhip_status enqueue_fetch(orbhip_ctx* c, int nimg, bool want_kp, bool want_desc)
 {   // bulk device-to-host copies into the pinned mirrors, ordered after the extraction on the context's stream
     { const orbhip_status st = mirrors_free(c, "a fetch into the context's mirrors"); if (st != ORBHIP_OK) return st; }
-    HIPCHK(hipMemcpyAsync(c->h_n, c->d_out_n[c->cur], nimg * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    if (want_kp) HIPCHK(hipMemcpyAsync(c->h_kp, c->d_out_kp[c->cur], (size_t)nimg * c->out_cap * sizeof(orbhip_keypoint), hipMemcpyDeviceToHost, c->stream));
-    if (want_desc) HIPCHK(hipMemcpyAsync(c->h_desc, c->d_out_desc[c->cur], (size_t)nimg * c->out_cap * 32, hipMemcpyDeviceToHost, c->stream));
+    // (orbhip_copy_async: a kernel for a few frames' worth, the DMA engines beyond 2 MB)
+    HIPCHK(orbhip_copy_async(c->h_n, c->d_out_n[c->cur], nimg * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (want_kp) HIPCHK(orbhip_copy_async(c->h_kp, c->d_out_kp[c->cur], (size_t)nimg * c->out_cap * sizeof(orbhip_keypoint), hipMemcpyDeviceToHost, c->stream));
+    if (want_desc) HIPCHK(orbhip_copy_async(c->h_desc, c->d_out_desc[c->cur], (size_t)nimg * c->out_cap * 32, hipMemcpyDeviceToHost, c->stream));
     return ORBHIP_OK;
 }
 static orbhip_status finish_fetch(orbhip_ctx* c, int nimg, orbhip_keypoint* kps, uint8_t* desc, int cap, int* n_out)
@@ -1053,7 +1054,8 @@ static orbhip_status submit_body(orbhip_ctx* c, int nimg, const uint8_t* const* 
                 if (stride == in_pitch) memcpy(dstp, imgs[f], fbytes);
                 else for (int y = 0; y < H; y++) memcpy(dstp + (size_t)y * in_pitch, imgs[f] + (size_t)y * stride, W);
             });
-            HIPCHK(hipMemcpyAsync(hs.d_in + f0 * fbytes, hs.h_in + f0 * fbytes, nf * fbytes, hipMemcpyHostToDevice, hst));
+            if (!piped) HIPCHK(orbhip_copy_async(hs.d_in + f0 * fbytes, hs.h_in + f0 * fbytes, nf * fbytes, hipMemcpyHostToDevice, hst));      // a few frames: a copy kernel, no DMA hand-over
+            else HIPCHK(hipMemcpyAsync(hs.d_in + f0 * fbytes, hs.h_in + f0 * fbytes, nf * fbytes, hipMemcpyHostToDevice, hst));
         }
         if (piped) { HIPCHK(hipEventRecord(hs.ev_h2d[k], hst)); HIPCHK(hipStreamWaitEvent(c->stream, hs.ev_h2d[k], 0)); }
         if (pinned_in && stride != c->in_pitch)
@@ -1063,7 +1065,7 @@ static orbhip_status submit_body(orbhip_ctx* c, int nimg, const uint8_t* const* 
         if (piped) { HIPCHK(hipEventRecord(hs.ev_k[k], c->stream)); HIPCHK(hipStreamWaitEvent(dst, hs.ev_k[k], 0)); }
         // ---- download
         const int cur = c->cur; const size_t oc = (size_t)c->out_cap;
-        if (whole_block) { HIPCHK(hipMemcpyAsync(hs.h_block, c->d_out_block[cur], c->out_block_bytes, hipMemcpyDeviceToHost, dst)); }
+        if (whole_block) { HIPCHK(orbhip_copy_async(hs.h_block, c->d_out_block[cur], c->out_block_bytes, hipMemcpyDeviceToHost, dst)); }
         else {
         HIPCHK(hipMemcpyAsync(hs.h_n + f0, c->d_out_n[cur] + f0, nf * sizeof(int), hipMemcpyDeviceToHost, dst));
         if (direct_out) {
@@ -1076,8 +1078,13 @@ static orbhip_status submit_body(orbhip_ctx* c, int nimg, const uint8_t* const* 
                 HIPCHK(hipMemcpy2DAsync(direct_desc + (size_t)f0 * direct_cap * 32, (size_t)direct_cap * 32, c->d_out_desc[cur] + f0 * oc * 32, oc * 32, m * 32, nf, hipMemcpyDeviceToHost, dst));
             }
         } else {
-            HIPCHK(hipMemcpyAsync(hs.h_kp + f0 * oc, c->d_out_kp[cur] + f0 * oc, nf * oc * sizeof(orbhip_keypoint), hipMemcpyDeviceToHost, dst));
-            HIPCHK(hipMemcpyAsync(hs.h_desc + f0 * oc * 32, c->d_out_desc[cur] + f0 * oc * 32, nf * oc * 32, hipMemcpyDeviceToHost, dst));
+            if (!piped) {       // a few frames on the main stream: copy kernels (no DMA hand-over between the last kernel and the download)
+                HIPCHK(orbhip_copy_async(hs.h_kp + f0 * oc, c->d_out_kp[cur] + f0 * oc, nf * oc * sizeof(orbhip_keypoint), hipMemcpyDeviceToHost, dst));
+                HIPCHK(orbhip_copy_async(hs.h_desc + f0 * oc * 32, c->d_out_desc[cur] + f0 * oc * 32, nf * oc * 32, hipMemcpyDeviceToHost, dst));
+            } else {
+                HIPCHK(hipMemcpyAsync(hs.h_kp + f0 * oc, c->d_out_kp[cur] + f0 * oc, nf * oc * sizeof(orbhip_keypoint), hipMemcpyDeviceToHost, dst));
+                HIPCHK(hipMemcpyAsync(hs.h_desc + f0 * oc * 32, c->d_out_desc[cur] + f0 * oc * 32, nf * oc * 32, hipMemcpyDeviceToHost, dst));
+            }
         }
         }
         HIPCHK(hipEventRecord(hs.ev_d2h[k], dst));
@@ -1590,7 +1597,7 @@ extern "C" orbhip_status orbhip_compute_stereo_matches(orbhip_ctx* l, orbhip_ctx
     const bool know_n = l->last_n_valid && (int)l->last_n.size() >= nimg;
     if (!know_n) HIPCHK(hipMemcpyAsync(l->h_n, l->d_out_n[l->cur], nimg * sizeof(int), hipMemcpyDeviceToHost, l->stream));
     float* hu = reinterpret_cast<float*>(l->h_kp); float* hd = hu + (size_t)nimg * l->out_cap;       // pinned mirror reused (28 B/keypoint >= 8 B)
-    if ((size_t)nimg == B) HIPCHK(hipMemcpyAsync(hu, l->d_st_u, 2 * B * l->out_cap * sizeof(float), hipMemcpyDeviceToHost, l->stream));
+    if ((size_t)nimg == B) HIPCHK(orbhip_copy_async(hu, l->d_st_u, 2 * B * l->out_cap * sizeof(float), hipMemcpyDeviceToHost, l->stream));
     else {
         HIPCHK(hipMemcpyAsync(hu, l->d_st_u, (size_t)nimg * l->out_cap * sizeof(float), hipMemcpyDeviceToHost, l->stream));
         HIPCHK(hipMemcpyAsync(hd, l->d_st_depth, (size_t)nimg * l->out_cap * sizeof(float), hipMemcpyDeviceToHost, l->stream));
@@ -1706,8 +1713,8 @@ extern "C" orbhip_status orbhip_fetch_undistorted(orbhip_ctx* c, int nimg, orbhi
     orbhip_status st = ensure_host_staging(c, false); if (st != ORBHIP_OK) return st;
     if (!c->h_kpun) HIPCHK(hipHostMalloc((void**)&c->h_kpun, (size_t)c->B * c->out_cap * sizeof(orbhip_keypoint), hipHostMallocDefault));
     { const orbhip_status stf = mirrors_free(c, "orbhip_fetch_undistorted"); if (stf != ORBHIP_OK) return stf; }
-    HIPCHK(hipMemcpyAsync(c->h_n, c->d_out_n[c->cur], nimg * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(c->h_kpun, (c->distorted ? c->d_out_kpun : c->d_out_kp)[c->cur], (size_t)nimg * c->out_cap * sizeof(orbhip_keypoint), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(orbhip_copy_async(c->h_n, c->d_out_n[c->cur], nimg * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(orbhip_copy_async(c->h_kpun, (c->distorted ? c->d_out_kpun : c->d_out_kp)[c->cur], (size_t)nimg * c->out_cap * sizeof(orbhip_keypoint), hipMemcpyDeviceToHost, c->stream));
     st = orbhip_sync(c); if (st != ORBHIP_OK) return st;
     bool overflow = false;
     for (int f = 0; f < nimg; f++) {

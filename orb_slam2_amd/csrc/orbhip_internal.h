@@ -125,6 +125,8 @@ struct StereoParams {       // Frame::ComputeStereoMatches (Frame.cc:466-640)
     float* u_right; float* depth; int* sad;                                // [slot][cap]
     float mbf, maxD;                                                       // maxD = mbf / mb
 };
+// host <-> device copy of a PINNED host buffer on stream s: a kernel for small sizes (no DMA-engine hand-over), hipMemcpyAsync otherwise
+hipError_t orbhip_copy_async(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s);
 int orbhip_device_numa_node(int device);            // /sys/bus/pci/devices/<bus id>/numa_node of a HIP device, -1 if unknown
 bool orbhip_bind_thread_to_node(int node);          // binds the CALLING thread to the node's CPUs (and remembers the node for the copy helpers)
 void orbhip_launch_stereo(const StereoParams& T, int nslots, int max_left, hipStream_t s, bool rows_ready = false);

@@ -202,3 +202,28 @@ void orbhip_launch_repitch(const uint8_t* src, long long src_frame_stride, int s
 {
     if (nframes > 0) hipLaunchKernelGGL(k_repitch, dim3((w + 1023) / 1024, h, nframes), dim3(256, 1, 1), 0, s, src, src_frame_stride, src_row_stride, dst, dst_frame_stride, dst_pitch, w, h);
 }
+
+// ------------------------------------------------------------------------------------------------ small copies as kernels
+// A hipMemcpyAsync between two kernels of a stream runs on a DMA engine: the queue hands over to the engine and back, and each hand-over idles
+// the chain for 8-9 us (profiles/r04_single_frame_call_timeline.txt: H2D end -> first kernel 8.2 us, last kernel -> D2H start 8.9 us) - on a
+// single-image call that is 17 of 160 us, on a matcher call more than its kernels.  Pinned host memory is addressable from the device, so a copy
+// of a few hundred KB is a kernel like any other: 16 bytes per lane over PCIe, no hand-over.  Bulk transfers stay on the DMA engines (they overlap
+// with compute and do not occupy CUs).
+__global__ __launch_bounds__(256) void k_copy16(uint4* __restrict__ dst, const uint4* __restrict__ src, long long n16, int tail)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+    if (tail && i == 0) {
+        uint8_t* d = reinterpret_cast<uint8_t*>(dst + n16); const uint8_t* sp = reinterpret_cast<const uint8_t*>(src + n16);
+        for (int k = 0; k < tail; k++) d[k] = sp[k];
+    }
+}
+hipError_t orbhip_copy_async(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s)
+{
+    static const bool dma_only = [] { const char* e = getenv("ORBHIP_COPY_KERNELS"); return e && *e == '0'; }();      // ORBHIP_COPY_KERNELS=0: every copy on the DMA engines
+    if (bytes == 0) return hipSuccess;
+    if (dma_only || bytes > ((size_t)2 << 20) || (((uintptr_t)dst | (uintptr_t)src) & 15)) return hipMemcpyAsync(dst, src, bytes, kind, s);
+    const long long n16 = (long long)(bytes >> 4);
+    hipLaunchKernelGGL(k_copy16, dim3((unsigned)std::max<long long>((n16 + 255) / 256, 1), 1, 1), dim3(256, 1, 1), 0, s, (uint4*)dst, (const uint4*)src, n16, (int)(bytes & 15));
+    return hipGetLastError();
+}
