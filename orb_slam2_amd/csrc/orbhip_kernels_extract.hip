@@ -317,7 +317,7 @@ void orbhip_launch_pyramid_level(const ExtractParams& P, int level, int w, int h
 {   // mode 2: staged + 4-pixel groups, 1: staged, 0: straight from global memory
     ExtractParams Q = P; Q.nframes = nframes;
     dim3 grid(xcd_grid(((w + PYR_TW - 1) / PYR_TW) * ((h + PYR_TH - 1) / PYR_TH), nframes), 1, 1), block(64, 4, 1);
-    const int nt = nframes >= 384 ? 4 : 2;          // measured (round 3, same call): B = 512: 181.7 k frames/s with 2, 183.3 k with 4, 181.8 k with 8, 180.3 k with 1; B = 128: 157.6 k with 2, 155.2 k with 4
+    const int nt = nframes >= 384 ? 4 : nframes <= 8 ? 1 : 2;          // measured (round 3, same call): B = 512: 181.7 k frames/s with 2, 183.3 k with 4, 181.8 k with 8, 180.3 k with 1; B = 128: 157.6 k with 2, 155.2 k with 4
     const int gyn = (((h + PYR_TH - 1) / PYR_TH) + nt - 1) / nt;
     if (mode == 2) hipLaunchKernelGGL(k_pyramid_level_g, dim3(xcd_grid(((w + PYR_TW - 1) / PYR_TW) * gyn, nframes), 1, 1), block, 0, s, Q, level, nt);
     else if (mode == 1) hipLaunchKernelGGL(k_pyramid_level, grid, block, 0, s, Q, level);
