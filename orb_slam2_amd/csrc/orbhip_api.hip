@@ -584,7 +584,7 @@ static orbhip_status pipeline_frames(orbhip_ctx* c, ExtractParams& P, int f0, in
         { ProfScope ps(c, K_BLUR, bs); orbhip_launch_blur(P, c->gk, nf, bs); }
         HIPCHK(hipEventRecord(c->ev_blur, bs));
         HIPCHK(hipStreamWaitEvent(s, c->ev_blur, 0));
-    } else if (nf <= 8 && P.blur_band && !c->serial) {
+    } else if (nf <= 8 && P.blur_band && !c->serial && orbhip_quadtree_lds_bytes(c->qt_maxn, c->qt_maxcells) + 18 * 1024 <= 160 * 1024) {        // (the blur's tile is static LDS beside the quadtree's dynamic block)
         // a handful of frames: one launch for both (the quadtree's few long workgroups beside the blur's tiles); its time is booked on the quadtree
         ProfScope ps(c, K_QUADTREE, s); orbhip_launch_blur_quadtree(P, nf, s);
     } else {
