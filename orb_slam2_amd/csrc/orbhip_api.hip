@@ -80,6 +80,9 @@ struct orbhip_ctx {
     // result of a small batch is one device-to-host copy instead of three (a single-frame call spent 60 us between its second and third copy)
     uint8_t* d_out_block[3] = {nullptr, nullptr, nullptr}; size_t out_off_kp = 0, out_off_desc = 0, out_block_bytes = 0; uint8_t* h_block = nullptr;
     hipStream_t bstream = nullptr; hipEvent_t ev_pyr = nullptr, ev_blur = nullptr;      // blur runs beside FAST + quadtree (independent until describe)
+    // k_pyramid_cascade (every level in one launch, used for a handful of frames): per level the column ranges of each tile column and the row ranges of
+    // each tile row, LDS layout sizes; pc_ok = the context's shape fits
+    short2* d_pc_xr = nullptr; short2* d_pc_yr = nullptr; int pc_ntx = 0, pc_nty = 0, pc_buf0 = 0, pc_buf1 = 0, pc_xcap = 0, pc_ycap = 0; bool pc_ok = false;
     hipStream_t mstream = nullptr; hipEvent_t ev_extract = nullptr; hipEvent_t ev_match[3] = {nullptr, nullptr, nullptr}; bool match_pending[3] = {false, false, false};
     int cur = 0; int last_nimg = 0; bool last_matched = false; bool last_from_host = false;
     // Frame epilogues.  ORB_SLAM2 calls one image at a time and follows every extraction with the same steps (Frame.cc:61-117, Tracking.cc:867-928,
@@ -255,6 +258,59 @@ static void build_yresize_table(int sh, int dh, std::vector<int2>& tab)  // rows
     }
 }
 
+// k_pyramid_cascade's rectangles.  A workgroup owns a TW x TH tile of the last level; the rectangle of level l-1 it needs is the source footprint of its
+// rectangle of level l (first column aligned down to 4), widened where necessary so that the rectangles of all tiles cover level l-1 completely (a
+// level's last columns / rows need not be referenced by the next level).  Columns and rows are independent: one table per tile column, one per tile row.
+static hipError_t build_cascade(orbhip_ctx* c)
+{
+    c->pc_ok = false;
+    const int L = c->L;
+    if (L < 2 || L > ORBHIP_MAX_LEVELS) return hipSuccess;
+    for (int l = 1; l < L; l++) if (c->pyr_staged[l] != 2) return hipSuccess;       // the kernel computes four pixels at a time from PyrGroup entries (scale factors below ~1.6)
+    int TW = 32, TH = 16;      // measured on MI355X at 1241 x 376 / 8 levels: 32x16 0.167-0.170 ms per call, 64x8 0.169-0.172, 32x8 0.172, 16x8 0.175, 64x16 0.179-0.190 (seven launches: 0.179-0.183)
+    if (const char* e = getenv("ORBHIP_PC_TILE")) { int w = 0, h = 0; if (sscanf(e, "%dx%d", &w, &h) == 2 && w >= 4 && h >= 1 && w % 4 == 0) { TW = w; TH = h; } else if (*e == '0') return hipSuccess; }
+    const LevelGeom& gl = c->geom[L - 1];
+    const int ntx = (gl.w + TW - 1) / TW, nty = (gl.h + TH - 1) / TH;
+    std::vector<short2> xr((size_t)L * ntx), yr((size_t)L * nty);
+    for (int t = 0; t < ntx; t++) xr[(size_t)(L - 1) * ntx + t] = short2{(short)(t * TW), (short)(std::min((t + 1) * TW, gl.w) - 1)};
+    for (int t = 0; t < nty; t++) yr[(size_t)(L - 1) * nty + t] = short2{(short)(t * TH), (short)(std::min((t + 1) * TH, gl.h) - 1)};
+    for (int l = L - 1; l >= 1; l--) {
+        const LevelGeom& g = c->geom[l];
+        if (g.src_w > 32767 || g.src_h > 32767) return hipSuccess;
+        const int2* xt = c->xtab.data() + g.xtab_off; const int2* yt = c->ytab.data() + g.ytab_off;
+        short2* sx = &xr[(size_t)(l - 1) * ntx]; short2* sy = &yr[(size_t)(l - 1) * nty];
+        // (a rectangle's columns are computed in groups of 4 from its first one: the pixels up to the end of the last group are computed - and stored - too)
+        for (int t = 0; t < ntx; t++) { short2& r = xr[(size_t)l * ntx + t]; r.y = (short)std::min(r.x + 4 * (((r.y - r.x) >> 2) + 1) - 1, g.w - 1); }
+        for (int t = 0; t < ntx; t++) { const short2 r = xr[(size_t)l * ntx + t]; sx[t] = short2{(short)(xt[r.x].x & ~3), (short)std::min(xt[r.y].x + 1, g.src_w - 1)}; }
+        for (int t = 0; t < nty; t++) { const short2 r = yr[(size_t)l * nty + t]; sy[t] = short2{(short)std::min(std::max(yt[r.x].x, 0), g.src_h - 1), (short)std::min(std::max(yt[r.y].x + 1, 0), g.src_h - 1)}; }
+        sx[0].x = 0; sx[ntx - 1].y = (short)(g.src_w - 1); sy[0].x = 0; sy[nty - 1].y = (short)(g.src_h - 1);
+        for (int t = 0; t + 1 < ntx; t++) sx[t].y = std::max<short>(sx[t].y, (short)(sx[t + 1].x - 1));
+        for (int t = 0; t + 1 < nty; t++) sy[t].y = std::max<short>(sy[t].y, (short)(sy[t + 1].x - 1));
+    }
+    // LDS: the widest x tallest rectangle of the even levels | of the odd levels (the last level is not kept) | the tables
+    auto xbytes = [&](int l, int t) { const short2 r = xr[(size_t)l * ntx + t]; return 4 * (((r.y - r.x) >> 2) + 1); };
+    auto yrows = [&](int l, int t) { const short2 r = yr[(size_t)l * nty + t]; return r.y - r.x + 1; };
+    int buf[2] = {16, 16}, xcap = 0, ycap = 0;
+    for (int l = 0; l + 1 < L; l++) {
+        int mx = 0, my = 0;
+        for (int t = 0; t < ntx; t++) mx = std::max(mx, xbytes(l, t));
+        for (int t = 0; t < nty; t++) my = std::max(my, yrows(l, t));
+        buf[l & 1] = std::max(buf[l & 1], (mx * my + 16 + 15) & ~15);        // + 16: a group reads the three dwords from its first tap's on, used or not
+    }
+    for (int t = 0; t < ntx; t++) { int n = 0; for (int l = 1; l < L; l++) n += xbytes(l, t) / 4; xcap = std::max(xcap, n); }        // PyrGroup entries
+    for (int t = 0; t < nty; t++) { int n = 0; for (int l = 1; l < L; l++) n += yrows(l, t); ycap = std::max(ycap, n); }
+    {   // level 0 too (it has no footprint to take, but its last group is staged whole)
+        const LevelGeom& g0 = c->geom[0];
+        for (int t = 0; t < ntx; t++) { short2& r = xr[t]; r.y = (short)std::min(r.x + 4 * (((r.y - r.x) >> 2) + 1) - 1, g0.w - 1); }
+    }
+    int r0max = 0; for (int tx = 0; tx < ntx; tx++) for (int ty = 0; ty < nty; ty++) r0max = std::max(r0max, xbytes(0, tx) / 4 * yrows(0, ty));
+    if ((size_t)buf[0] + buf[1] + (size_t)xcap * sizeof(PyrGroup) + (size_t)ycap * sizeof(int2) > 60 * 1024 || xcap > 256 || ycap > 512 || r0max > 4096) return hipSuccess;      // (k_pyramid_cascade's PC_GIT / PC_YIT / PC_RIT)
+    hipError_t e = upload(&c->d_pc_xr, xr); if (e != hipSuccess) return e;
+    e = upload(&c->d_pc_yr, yr); if (e != hipSuccess) return e;
+    c->pc_ntx = ntx; c->pc_nty = nty; c->pc_buf0 = buf[0]; c->pc_buf1 = buf[1]; c->pc_xcap = xcap; c->pc_ycap = ycap; c->pc_ok = true;
+    return hipSuccess;
+}
+
 extern "C" const char* orbhip_version(void) { return "orbhip 0.2 (gfx950)"; }
 extern "C" int orbhip_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; } return n; }
 extern "C" const char* orbhip_last_error(void) { return g_err.c_str(); }
@@ -267,6 +323,8 @@ extern "C" void orbhip_destroy(orbhip_ctx* c)
     orbhip_bow_forget_ctx(c);                                      // BoW workspaces the vocabularies keep for this context (they ran on c->stream)
     if (c->mstream) { (void)hipStreamSynchronize(c->mstream); (void)hipStreamDestroy(c->mstream); }
     if (c->bstream) { (void)hipStreamSynchronize(c->bstream); (void)hipStreamDestroy(c->bstream); }
+    if (c->d_pc_xr) (void)hipFree(c->d_pc_xr);
+    if (c->d_pc_yr) (void)hipFree(c->d_pc_yr);
     if (c->ev_pyr) (void)hipEventDestroy(c->ev_pyr);
     if (c->ev_blur) (void)hipEventDestroy(c->ev_blur);
     if (c->ev_extract) (void)hipEventDestroy(c->ev_extract);
@@ -450,6 +508,7 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
 #define TRY(x) do { if (e == hipSuccess) e = (x); } while (0)
     TRY(upload(&c->d_geom, c->geom)); TRY(upload(&c->d_cells, c->cells)); TRY(upload(&c->d_tiles, c->blur_tiles));
     TRY(upload(&c->d_xtab, c->xtab)); TRY(upload(&c->d_ytab, c->ytab)); TRY(upload(&c->d_xgrp, c->xgrp)); TRY(upload(&c->d_pattern, pat));
+    TRY(build_cascade(c));
     if (c->blur_mfma) {   // k_blur_mfma: the two band (Toeplitz) matrices of the 7-tap filter laid out as B operands of v_mfma_i32_32x32x32_i8
         const int tap[7] = {c->gk[3], c->gk[2], c->gk[1], c->gk[0], c->gk[1], c->gk[2], c->gk[3]};
         std::vector<int4> band(3 * 64); signed char* bb = reinterpret_cast<signed char*>(band.data());
@@ -551,6 +610,7 @@ static ExtractParams make_params(orbhip_ctx* c, const uint8_t* d_img0, long long
     P.out_kp = c->d_out_kp[c->cur]; P.out_desc = c->d_out_desc[c->cur]; P.out_n = c->d_out_n[c->cur]; P.out_cap = c->out_cap;
     P.blur_tiles = c->d_tiles; P.nblur_tiles = (int)c->blur_tiles.size(); P.blur_band = c->blur_mfma ? c->d_blur_band : nullptr;
     P.xtab = c->d_xtab; P.ytab = c->d_ytab; P.xgrp = c->d_xgrp; P.patternf = c->d_pattern; P.ic_mask = c->d_ic_mask;
+    P.pc_xr = c->d_pc_xr; P.pc_yr = c->d_pc_yr; P.pc_ntx = c->pc_ntx; P.pc_nty = c->pc_nty; P.pc_buf0 = c->pc_buf0; P.pc_buf1 = c->pc_buf1; P.pc_xcap = c->pc_xcap; P.pc_ycap = c->pc_ycap;
     P.iniTh = std::min(std::max(c->cfg.ini_th_fast, 0), 255); P.minTh = std::min(std::max(c->cfg.min_th_fast, 0), 255);      // cv::FAST clamps its threshold to [0, 255] (OpenCV 3.2 fast.cpp, FAST_t)
     P.blur_round_mode = c->cfg.blur_round_mode; P.fp_contract = c->fp_contract;
     P.qt_maxn = c->qt_maxn; P.qt_maxcells = c->qt_maxcells; P.qt_scr = orbhip_quadtree_scr(c->qt_maxn, c->qt_maxcells);
@@ -563,6 +623,7 @@ static ExtractParams make_params(orbhip_ctx* c, const uint8_t* d_img0, long long
 // workgroup per frame, 0.27 -> 0.54 ms at B = 256 and +0.09 ms per single-frame call; see docs/ROUND_LOG.md.)
 static void launch_pyramid(orbhip_ctx* c, const ExtractParams& P, int nf, hipStream_t s)
 {
+    if (nf <= 8 && c->pc_ok) { orbhip_launch_pyramid_cascade(P, nf, s); return; }      // a handful of frames: one launch for all levels (k_pyramid_cascade)
     for (int l = 1; l < c->L; l++) orbhip_launch_pyramid_level(P, l, c->geom[l].w, c->geom[l].h, (int)c->pyr_staged[l], nf, s);
 }
 

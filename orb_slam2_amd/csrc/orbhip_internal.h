@@ -92,6 +92,9 @@ struct ExtractParams {
     int fc_pstride, fc_prows, fc_sstride, fc_srows, fc_listcap;            // per-wave LDS layout of k_fast_cells (largest cell of the context)
     int fc_cell0, fc_ncells;                                               // cell range of this k_fast_cells launch
     int fc_pbytes, fc_np; const int4* fc_dma;                              // patch region = fc_np LDS-DMA passes of 256 bytes; (row, 4*column) of every (pass, lane)
+    // k_pyramid_cascade (a handful of frames: every level in ONE launch): column / row ranges {first, last} of each level that the workgroup of tile
+    // column tx / tile row ty computes, [level][tx] and [level][ty]; LDS layout: buffer of the even levels | of the odd levels | x tables | y tables
+    const short2* pc_xr; const short2* pc_yr; int pc_ntx, pc_nty, pc_buf0, pc_buf1, pc_xcap, pc_ycap;
 };
 
 struct MatchParams {        // SearchForInitialization over camera slots (ORBmatcher.cc:405-520)
@@ -156,6 +159,7 @@ size_t orbhip_proj_select_lds(int n);
 
 // kernel launchers (orbhip_kernels_extract.hip / orbhip_kernels_match.hip)
 void orbhip_launch_pyramid_level(const ExtractParams& P, int level, int w, int h, int mode, int nframes, hipStream_t s);
+void orbhip_launch_pyramid_cascade(const ExtractParams& P, int nframes, hipStream_t s);     // levels 1 .. L-1 in one launch (needs P.pc_*)
 int orbhip_pyramid_tile_dwords();
 int orbhip_blur_mfma_tile_w();
 int orbhip_blur_mfma_tile_h();

@@ -306,6 +306,136 @@ __global__ __launch_bounds__(256) void k_pyramid_level_direct(ExtractParams P, i
     pyr_rows(g, P.xtab + g.xtab_off, P.ytab + g.ytab_off, src, spitch, 0, x4, ytop, P.pyr + (long long)frame * P.plane_frame_bytes + g.plane_off + x4);
 }
 
+// A handful of frames (the drop-in's single-image call): ALL levels in one launch.  Seven dependent launches cost a single frame 34 us for ~8 us of
+// arithmetic (2.3 us per dependent launch, then every level starts with a cold L2 and its own chain of load latencies).  Here a workgroup owns one
+// small tile of the LAST level and computes, level by level, exactly the rectangle of every level that its tile descends from: the level-0 rectangle
+// is staged in LDS, level l's rectangle is computed from level l-1's in LDS and written both to LDS (for level l+1) and to the level's plane.  The
+// rectangles of neighbouring workgroups overlap (a halo that grows towards level 0): those pixels are computed more than once and stored more than
+// once - the same integer arithmetic on the same sources, so every store of a pixel carries the same value.  The host makes the rectangles cover
+// every level completely (also where the next level does not reference a level's last pixels) and aligns their columns to 4.
+// Arithmetic: k_pyramid_level_g's (cv::resize INTER_LINEAR, OpenCV 3.2 fixed point), from the same PyrGroup / row tables.
+// Memory latency is what a single frame's kernels consist of (every launch starts with a cold L2), so the kernel reads memory in TWO rounds: (1) lane l of
+// the first wave fetches level l's constants and the workgroup's rectangle of level l; (2) every thread requests its share of ALL PyrGroup / row-table
+// entries and of the level-0 rectangle before it waits for any of them.  After that the seven levels run from LDS, four pixels at a time like
+// k_pyramid_level_g (pyr_hrow), behind barriers that wait for LDS only (__syncthreads would also wait for the level's stores to reach memory: 0.5 us a level).
+__device__ __forceinline__ int qt_wave_incl_scan(int v, int lane);      // (DPP prefix sum, defined with the quadtree)
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+#define PC_T 256            // threads.  (1024 - four waves per SIMD to hide the LDS latencies - was slower, 22.6 against 21.3 us: a big workgroup starts and synchronises
+                            // slowly; four rows of a group column per step with all their LDS reads requested together measured the same as one row per step)
+#define PC_GIT 3            // per thread: 16-byte pieces of PyrGroup entries (<= 256 entries), row-table entries (<= 512), dwords of the level-0 rectangle (<= 4096); the host checks
+#define PC_YIT 2
+#define PC_RIT 16
+struct PcLevel { int w, src_h, pitch, plane_off, xgrp_off, ytab_off, goff, yoff, x0, x1, y0, y1; unsigned rcp; };
+__global__ __launch_bounds__(PC_T) void k_pyramid_cascade(ExtractParams P)
+{
+    HIP_DYNAMIC_SHARED(unsigned char, pc_lds)
+    __shared__ PcLevel s_lv[ORBHIP_MAX_LEVELS];
+    int tile, frame;
+    if (!xcd_frame_map(P.pc_ntx * P.pc_nty, P.nframes, tile, frame)) return;
+    frame += P.frame0;
+    const int tid = (int)threadIdx.x, L = P.nlevels;
+    const int ty = tile / P.pc_ntx, tx = tile - ty * P.pc_ntx;
+    if (tid < 64) {         // ---- round 1 (one wave): lane l = level l; the table offsets are prefix sums over the lanes
+        const int l = min(tid, L - 1);
+        const LevelGeom g = P.geom[l];
+        const short2 a = P.pc_xr[l * P.pc_ntx + tx], b = P.pc_yr[l * P.pc_nty + ty];
+        const int ng = ((a.y - a.x) >> 2) + 1;
+        const int nx = (tid >= 1 && tid < L) ? ng : 0, ny = (tid >= 1 && tid < L) ? b.y - b.x + 1 : 0;
+        const int go = qt_wave_incl_scan(nx, tid) - nx, yo = qt_wave_incl_scan(ny, tid) - ny;
+        if (tid < L) s_lv[tid] = PcLevel{g.w, g.src_h, g.pitch, g.plane_off, g.xgrp_off, g.ytab_off, go, yo, a.x, a.y, b.x, b.y, 0xffffffffu / (unsigned)ng + 1u};
+        if (tid == L - 1) { s_lv[0].goff = go + nx; s_lv[0].yoff = yo + ny; }      // (level 0 has no table: its slots carry the totals)
+    }
+    __syncthreads();
+    // (the two rectangle buffers are addressed as pc_lds + offset, never through an array of pointers: that made them generic pointers and every row read a
+    //  flat_load, which waits for the level's outstanding global stores - 5 us for level 1 instead of 1)
+    uint4* const s_grp = reinterpret_cast<uint4*>(pc_lds + P.pc_buf0 + P.pc_buf1);       // PyrGroup entries of levels 1 .. L-1 (three 16-byte pieces each)
+    int2* const s_yt = reinterpret_cast<int2*>(s_grp + 3 * P.pc_xcap);
+    {   // ---- round 2: all requests, then all LDS stores
+        const int gtot = s_lv[0].goff, ytot = s_lv[0].yoff;
+        int goffs[ORBHIP_MAX_LEVELS], yoffs[ORBHIP_MAX_LEVELS];
+#pragma unroll
+        for (int l = 0; l < ORBHIP_MAX_LEVELS; l++) { goffs[l] = s_lv[min(l, L - 1)].goff; yoffs[l] = s_lv[min(l, L - 1)].yoff; }
+        uint4 gv[PC_GIT]; int2 yv[PC_YIT]; unsigned rv[PC_RIT];
+#pragma unroll
+        for (int k = 0; k < PC_GIT; k++) {      // (entries past the end re-read the last one: every load is unconditional, nothing waits before the last request is out)
+            const int i = min(tid + PC_T * k, 3 * gtot - 1), e = i / 3, piece = i - 3 * e;
+            int l = 1;
+#pragma unroll
+            for (int q = 2; q < ORBHIP_MAX_LEVELS; q++) if (q < L && e >= goffs[q]) l = q;
+            const PcLevel& v = s_lv[l];
+            gv[k] = reinterpret_cast<const uint4*>(P.xgrp + v.xgrp_off + (v.x0 >> 2) + (e - v.goff))[piece];
+        }
+#pragma unroll
+        for (int k = 0; k < PC_YIT; k++) {
+            const int i = min(tid + PC_T * k, ytot - 1);
+            int l = 1;
+#pragma unroll
+            for (int q = 2; q < ORBHIP_MAX_LEVELS; q++) if (q < L && i >= yoffs[q]) l = q;
+            const PcLevel& v = s_lv[l];
+            yv[k] = P.ytab[v.ytab_off + v.y0 + i - v.yoff];
+        }
+        const PcLevel R = s_lv[0];
+        int spitch; const uint8_t* src = level_src(P, frame, 0, spitch);
+        const int ng = ((R.x1 - R.x0) >> 2) + 1, n0 = ng * (R.y1 - R.y0 + 1);
+#pragma unroll
+        for (int k = 0; k < PC_RIT; k++) {
+            const int i = min(tid + PC_T * k, n0 - 1);
+            const int r = ng == 1 ? i : (int)__umulhi((unsigned)i, R.rcp), g4 = i - r * ng, x = R.x0 + 4 * g4;       // (ceil(2^32 / 1) does not fit)
+            const uint8_t* p = src + (long long)(R.y0 + r) * spitch + x;
+            unsigned w;
+            if (x + 3 < R.w) w = *reinterpret_cast<const u32_unaligned*>(p);
+            else { w = 0; for (int q = 0; q < 4; q++) if (x + q < R.w) w |= (unsigned)p[q] << (8 * q); }
+            rv[k] = w;
+        }
+#pragma unroll
+        for (int k = 0; k < PC_GIT; k++) if (tid + PC_T * k < 3 * gtot) s_grp[tid + PC_T * k] = gv[k];
+#pragma unroll
+        for (int k = 0; k < PC_YIT; k++) if (tid + PC_T * k < ytot) s_yt[tid + PC_T * k] = yv[k];
+#pragma unroll
+        for (int k = 0; k < PC_RIT; k++) if (tid + PC_T * k < n0) reinterpret_cast<unsigned*>(pc_lds)[tid + PC_T * k] = rv[k];
+    }
+    __syncthreads();
+    for (int l = 1; l < L; l++) {
+        const PcLevel R = s_lv[l], S = s_lv[l - 1];
+        const int ng = ((R.x1 - R.x0) >> 2) + 1, rows = R.y1 - R.y0 + 1, spd = ((S.x1 - S.x0) >> 2) + 1;
+        const unsigned* sb = reinterpret_cast<const unsigned*>(pc_lds + ((l & 1) ? 0 : P.pc_buf0));      // source rectangle: dword (x - S.x0) / 4 of row y - S.y0 at sb[(y - S.y0) * spd + ...]
+        unsigned* db = reinterpret_cast<unsigned*>(pc_lds + ((l & 1) ? P.pc_buf0 : 0));
+        const PyrGroup* grp = reinterpret_cast<const PyrGroup*>(s_grp) + R.goff; const int2* yt = s_yt + R.yoff;
+        uint8_t* gdst = P.pyr + (long long)frame * P.plane_frame_bytes + R.plane_off;
+        const bool keep = l + 1 < L;                                       // the last level has no reader in here
+        for (int i = tid; i < ng * rows; i += PC_T) {
+            const int gy = ng == 1 ? i : (int)__umulhi((unsigned)i, R.rcp), g4 = i - gy * ng, y = R.y0 + gy, x4 = R.x0 + 4 * g4;
+            const PyrGroup G = grp[g4];
+            const int2 ye = yt[gy];
+            const unsigned b0s = (unsigned)ye.y << 16, b1s = (unsigned)ye.y & 0xffff0000u;
+            const int ra = min(max(ye.x, 0), R.src_h - 1) - S.y0, rb = min(max(ye.x + 1, 0), R.src_h - 1) - S.y0;
+            const unsigned sh = (unsigned)G.sx0 & 3u;
+            const unsigned* colp = sb + ((G.sx0 - S.x0) >> 2);             // S.x0 is a multiple of 4
+            unsigned h0[4], h1[4];
+            pyr_hrow(colp + ra * spd, sh, G, h0);
+            pyr_hrow(colp + rb * spd, sh, G, h1);
+            unsigned out = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) out |= ((__umulhi(b0s, h0[k]) + __umulhi(b1s, h1[k]) + 2u) >> 2) << (8 * k);
+            out &= x4 + 4 <= R.w ? 0xffffffffu : (0xffffffffu >> (8 * (x4 + 4 - R.w)));
+            if (keep) db[i] = out;
+            *reinterpret_cast<unsigned*>(gdst + (long long)y * R.pitch + x4) = out;
+        }
+        lds_barrier();
+    }
+}
+void orbhip_launch_pyramid_cascade(const ExtractParams& P, int nframes, hipStream_t s)
+{
+    ExtractParams Q = P; Q.nframes = nframes;
+    const size_t lds = (size_t)P.pc_buf0 + P.pc_buf1 + (size_t)P.pc_xcap * sizeof(PyrGroup) + (size_t)P.pc_ycap * sizeof(int2);
+    hipLaunchKernelGGL(k_pyramid_cascade, dim3(xcd_grid(P.pc_ntx * P.pc_nty, nframes), 1, 1), dim3(PC_T, 1, 1), lds, s, Q);
+}
+
 bool orbhip_pyramid_tile_fits(int src_cols_per_tile, int src_rows_per_tile) { return ((src_cols_per_tile + 3) >> 2) + 1 <= PYR_SDW && src_rows_per_tile <= PYR_SROWS; }
 int orbhip_pyramid_tile_dwords() { return PYR_SDW; }
 int orbhip_blur_mfma_tile_w() { return BM_COLS * BM_BLOCKS; }
@@ -1166,12 +1296,14 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
     int *s_cc = L.cc, *s_a = L.a, *s_b = L.b, *s_sidx = L.sidx, *s_split = L.split, *s_best = L.best, *s_scratch = L.scratch, *s_misc = L.misc;
     int m = 0, K = 0, jumpPrev = 0, jumpExp = 0;
     if (D > 0) {
-        int* Hd[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};          // key counts per depth-d cell
-        Hd[D] = s_cc;
-        if (D >= 1) Hd[D - 1] = L.cntB;
-        if (D >= 2) Hd[D - 2] = s_best;
-        if (D >= 3) Hd[D - 3] = s_split;
-        if (D >= 4) Hd[D - 4] = s_sidx;
+        // key counts per depth-d cell at L.cntA + hoff[d] (offsets, not an array of pointers: a pointer picked from an array by a run-time index is a
+        // generic one, and reads through it were flat_loads that wait for every outstanding global access as well)
+        int hoff[5] = {0, 0, 0, 0, 0};
+        hoff[D] = (int)(s_cc - L.cntA);
+        if (D >= 1) hoff[D - 1] = (int)(L.cntB - L.cntA);
+        if (D >= 2) hoff[D - 2] = (int)(s_best - L.cntA);
+        if (D >= 3) hoff[D - 3] = (int)(s_split - L.cntA);
+        if (D >= 4) hoff[D - 4] = (int)(s_sidx - L.cntA);
         // [5 + 2d] = non-empty depth-d cells, [6 + 2d] = those with more than one key (zeroed with the counters at kernel start).  Every shallower
         // histogram is summed straight from H_D and counted in the same step, each count reduced inside the wave first: one barrier for all depths
         // (a barrier and 256 same-address LDS atomics per depth cost more than the three passes' worth of work this replaces saves).
@@ -1187,7 +1319,7 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
                     if (c < 0) continue;
                     int h = 0;
                     for (int k = 0; k < span; k++) h += s_cc[c * span + k];
-                    Hd[d][c] = h; ne[d] += h > 0; ex[d] += h > 1;
+                    (L.cntA + hoff[d])[c] = h; ne[d] += h > 0; ex[d] += h > 1;
                 }
                 base = (base + nc) % QT_T;
             }
@@ -1209,7 +1341,7 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
         }
         if (K > 0) {
             const int nc = g.nIni << (2 * K);
-            const int* H = Hd[K];
+            const int* H = L.cntA + hoff[K];
             int* F = s_a;                                                    // [nc <= 4 maxn]: a | b | sidx | split (the shallower histograms there are dead, H_K never lies under F's nc entries)
             if (nc <= QT_T) {                                                // one cell per thread: a wave scan and four partial sums, one barrier
                 const int f = tid < nc ? (H[qt_jump_xform(tid, K, g.nIni)] > 0 ? 1 : 0) : 0;

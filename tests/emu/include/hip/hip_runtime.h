@@ -32,6 +32,7 @@
 
 struct dim3 { unsigned x, y, z; constexpr dim3(unsigned X = 1, unsigned Y = 1, unsigned Z = 1) : x(X), y(Y), z(Z) {} };
 struct uint3 { unsigned x, y, z; };
+struct short2 { short x, y; };
 struct int2 { int x, y; };
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
@@ -249,6 +250,8 @@ template <typename T> inline T atomicAnd(T* p, T v) { T o = *p; *p = o & v; retu
 template <typename T> inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 template <typename T> inline T atomicCAS(T* p, T c, T v) { T o = *p; if (o == c) *p = v; return o; }
 inline void __threadfence() {}
+template <typename... A> inline void __builtin_amdgcn_fence(int, A...) {}      // (scope [, address space: "local" = LDS only])
+inline void __builtin_amdgcn_s_barrier() { __syncthreads(); }
 inline void __threadfence_block() {}
 
 // IEEE round-to-nearest arithmetic intrinsics (the emu build uses -ffp-contract=off, so plain ops are exact)
