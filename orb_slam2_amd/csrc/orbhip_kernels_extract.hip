@@ -21,13 +21,19 @@
 // XCD-aware block -> (tile, frame) map.  The dispatcher places consecutive workgroup ids round-robin over the 8 XCDs
 // (observed, used for speed only): giving all workgroups of frame f ids congruent to f mod 8 keeps that frame's planes
 // (~3 MB) in ONE XCD's 4 MiB L2 instead of being re-fetched from HBM by all eight.
+// FEWER THAN EIGHT FRAMES (the drop-in's single-image call): that rule would leave seven of the eight XCDs idle - a single frame's FAST ran its ~300
+// workgroups on 32 CUs, two rounds deep, 19 us from the first workgroup's start to the last one's end (tools/span_experiment.py) - and every launch starts
+// with a cold L2 anyway.  Then consecutive ids simply walk over (tile, frame): the work spreads over all XCDs.
 __device__ __forceinline__ bool xcd_frame_map(int nb, int nframes, int& tile, int& frame)
 {
-    const int id = blockIdx.x, j = id >> 3, fg = j / nb;
+    const int id = blockIdx.x;
+    if (nframes == 1) { tile = id; frame = 0; return true; }
+    if (nframes < 8) { tile = id / nframes; frame = id - tile * nframes; return true; }
+    const int j = id >> 3, fg = j / nb;
     tile = j - fg * nb; frame = fg * 8 + (id & 7);
     return frame < nframes;
 }
-static inline unsigned xcd_grid(int nb, int nframes) { return (unsigned)nb * 8u * (unsigned)((nframes + 7) / 8); }
+static inline unsigned xcd_grid(int nb, int nframes) { return nframes < 8 ? (unsigned)nb * (unsigned)nframes : (unsigned)nb * 8u * (unsigned)((nframes + 7) / 8); }
 
 typedef unsigned short pku16 __attribute__((vector_size(4)));      // two u16 lanes in one VGPR -> v_pk_min_u16 / v_pk_max_u16, v_dot2_u32_u16
 typedef short pki16 __attribute__((vector_size(4)));
@@ -1545,9 +1551,13 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(ExtractParams P)
     __builtin_amdgcn_s_setprio(3);          // latency-bound: win issue arbitration against the VALU-bound blur running beside it
     // level-major ids (still frame == id mod 8 for the XCD affinity): workgroups are dispatched in id order and a level-0
     // workgroup runs ~4x longer than a level-7 one, so the long ones start first and the short ones fill the tail
-    const int nfg = (P.nframes + 7) >> 3, jj = (int)blockIdx.x >> 3;
-    const int level = jj / nfg;
-    const int frame = (jj - level * nfg) * 8 + ((int)blockIdx.x & 7);
+    int level, frame;
+    if (P.nframes < 8) { level = (int)blockIdx.x / P.nframes; frame = (int)blockIdx.x - level * P.nframes; }      // (xcd_grid's rule for a handful of frames)
+    else {
+        const int nfg = (P.nframes + 7) >> 3, jj = (int)blockIdx.x >> 3;
+        level = jj / nfg;
+        frame = (jj - level * nfg) * 8 + ((int)blockIdx.x & 7);
+    }
     if (frame >= P.nframes) return;
     HIP_DYNAMIC_SHARED(int, lds)
     quadtree_level(P, frame + P.frame0, level, lds);
