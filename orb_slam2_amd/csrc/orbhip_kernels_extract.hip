@@ -1324,7 +1324,7 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
                 for (int c = tid - base; c < nc; c += QT_T) {
                     if (c < 0) continue;
                     int h = 0;
-                    for (int k = 0; k < span; k++) h += s_cc[c * span + k];
+                    for (int k = 0; k < span; k += 4) h += (s_cc[c * span + k] + s_cc[c * span + k + 1]) + (s_cc[c * span + k + 2] + s_cc[c * span + k + 3]);      // (span = 4, 16 or 64: four reads in flight)
                     (L.cntA + hoff[d])[c] = h; ne[d] += h > 0; ex[d] += h > 1;
                 }
                 base = (base + nc) % QT_T;
@@ -1429,12 +1429,32 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
             // level-0 workgroup between two barriers.
             for (int p = tid; p < m; p += QT_T) { s_split[p] = 0; s_best[p] = cnt[p] > 1 ? 1 : 0; }
             const int E = qt_block_exscan(s_best, m, s_scratch, tid);     // thread t scans the flags thread t wrote
-            for (int p = tid; p < m; p += QT_T) { const int c = cnt[p]; if (c > 1) { const int j = s_best[p]; s_b[j] = c; s_a[j] = p; } }
+            // (size, earlier in the list) as ONE number: size << 14 | 16383 - position (positions < 16384 by the context's limits, sizes < 2^18 checked here),
+            // so a node's rank is the number of larger keys - a compare and an add per pair instead of three compares and their logic.  This loop
+            // is E steps per thread however it is cut: 11 of a level-0 workgroup's 40 us at E = 255 before, ~2 after.
+            bool packed = n < (1 << 18);
+#ifdef ORBHIP_TEST_HOOKS      // (the CPU emulation build only: ORBHIP_TEST_QT_UNPACKED=1 runs the three-compare form that levels with >= 2^18 candidates take)
+            { const char* e = getenv("ORBHIP_TEST_QT_UNPACKED"); if (e && *e == '1') packed = false; }
+#endif
+            for (int p = tid; p < m; p += QT_T) { const int c = cnt[p]; if (c > 1) { const int j = s_best[p]; s_b[j] = packed ? (int)(((unsigned)c << 14) | (unsigned)(16383 - j)) : c; s_a[j] = p; } }
             __syncthreads();
             for (int j = tid; j < E; j += QT_T) {
-                const int c = s_b[j];
                 int rank = 0;
-                for (int o = 0; o < E; o++) { const int co = s_b[o]; rank += (co > c || (co == c && o < j)); }
+                if (packed) {
+                    const unsigned key = (unsigned)s_b[j];
+                    int o = 0;
+                    for (; o + 8 <= E; o += 8) {
+                        unsigned k8[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) k8[u] = (unsigned)s_b[o + u];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) rank += k8[u] > key;
+                    }
+                    for (; o < E; o++) rank += (unsigned)s_b[o] > key;
+                } else {
+                    const int c = s_b[j];
+                    for (int o = 0; o < E; o++) { const int co = s_b[o]; rank += (co > c || (co == c && o < j)); }
+                }
                 s_sidx[rank] = s_a[j];
             }
             __syncthreads();
@@ -1445,9 +1465,11 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
             }
             __syncthreads();
             const int Call = qt_block_exscan(s_a, E, s_scratch, tid);     // s_a[j] = children created before sorted node j
-            for (int j = tid; j < E; j += QT_T) {                          // list size after processing sorted node j
-                const int size_after = m + s_a[j] + s_b[j] - (j + 1);
-                if (size_after >= N) atomicMin(&s_misc[2], j);            // first position where `break` fires (:730-731)
+            for (int j0 = 0; j0 < E; j0 += QT_T) {                         // list size after processing sorted node j
+                const int j = j0 + tid;
+                const bool hit = j < E && m + s_a[j] + s_b[j] - (j + 1) >= N;
+                const unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);   // first position where `break` fires (:730-731): the wave's first hit, one atomic per wave
+                if (hm && lane == 0) atomicMin(&s_misc[2], j0 + 64 * wave + __builtin_ctzll(hm));
             }
             __syncthreads();
             const int jstar = s_misc[2];
@@ -1474,7 +1496,8 @@ __device__ __forceinline__ void qt_replay(const ExtractParams& P, const LevelGeo
         });
         int nexp = 0;
         for (int p = tid; p < m2; p += QT_T) nexp += cnt2[p] > 1;
-        if (nexp) atomicAdd(&s_misc[3 + par], nexp);
+        nexp = __builtin_amdgcn_readlane(qt_wave_incl_scan(nexp, lane), 63);      // (256 atomics onto one word cost 2 us)
+        if (nexp && lane == 0) atomicAdd(&s_misc[3 + par], nexp);
         // the next pass's scratch: nobody reads s_cc, s_misc[1..2] or the other counter word any more (their readers are behind the barrier above)
         for (int i = tid; i < 4 * m2; i += QT_T) s_cc[i] = 0;
         if (tid == 0) { s_misc[1] = 0; s_misc[2] = 0x7fffffff; s_misc[3 + (par ^ 1)] = 0; }

@@ -122,6 +122,19 @@ def test_quadtree_regular_pass_jump_and_its_exits(backend, oracle, case):
     ex.close()
 
 
+def test_quadtree_final_phase_ranking_both_forms(emu_lib, oracle, monkeypatch):
+    """The final phase ranks the expandable nodes by (size, list position): as one packed number per node where sizes fit 18 bits, by three compares
+    for levels with 2^18 candidates or more.  ORBHIP_TEST_QT_UNPACKED=1 (emulation build only) sends ordinary frames through the second form."""
+    monkeypatch.setenv("ORBHIP_TEST_QT_UNPACKED", "1")
+    for (w, h, n, seed) in ((640, 480, 1000, 3), (480, 320, 70, 5), (752, 480, 1200, 8)):
+        img = synth.frame(w, h, seed=seed)
+        ko, do = oracle.OracleExtractor(n, 1.2, 8, 20, 7).extract(img)
+        ex = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, library=emu_lib)
+        kg, dg = ex(img)
+        assert kg.tobytes() == ko.tobytes() and np.array_equal(dg, do), (w, h, n)
+        ex.close()
+
+
 @pytest.mark.parametrize("name", ["zeros", "checkerboard", "ramp", "low_texture", "saturated"])
 def test_degenerate_inputs(backend, oracle, name):
     w, h, n = 320, 240, 400

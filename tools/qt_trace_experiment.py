@@ -10,9 +10,13 @@ for (W, H, N) in ((1241, 376, 2000), (752, 480, 1200)):
     ex.L.orbhip_debug_qt_trace(t.ctypes.data_as(C.c_void_p))
     t = t.reshape(8, 64)
     for lvl in range(8):
-        r = t[lvl].astype(np.int64); n = int(r[63]); npass = int(r[62])
+        r = t[lvl].astype(np.int64); n = int(r[63]); npass = int(r[62]); K = int(r[61]); m = int(r[60])
         us = lambda a, b: (r[b] - r[a]) / 100.0
-        passes = [round(us(4 + k, 5 + k) if k else us(4, 5), 1) for k in range(min(npass, 40))]
-        ms = [(int(r[46 + k]) >> 1, int(r[46 + k]) & 1) for k in range(min(npass, 16))]
-        print(f"{W}x{H} level {lvl}: n={n} total {us(0,45):.1f} us | cells+scan {us(0,1):.1f} | dense copy {us(1,2):.1f} | read back + path codes {us(2,3):.1f} | roots {us(3,4):.1f} | {npass} passes {passes} (m, modeB) {ms} | best+out {us(44,45):.1f}")
+        st = [5 + k for k in range(min(npass, 30))] + [44]
+        passes = [round(us(st[k], st[k + 1]), 1) for k in range(len(st) - 1)]
+        print(f"{W}x{H} level {lvl}: n={n} m={m} total {us(0,45):.1f} us | cells+scan {us(0,1):.1f} | dense copy {us(1,2):.1f} | read back + path codes {us(2,3):.1f} | jump (K={K}) {us(3,4):.1f} | setup {us(4, 5) if npass else us(4,44):.1f} | {npass} passes {passes} | best+out {us(44,45):.1f}")
+        if lvl in (0, 3):
+            names = ["child histogram (16 LDS atomics / key) + barrier", "flags + scan", "compaction + rank", "barrier", "children + barrier", "scan", "break position + barrier", "marks, flags (3 barriers)", "scan", "new nodes", "barrier", "keys to their new nodes", "count, clear, barrier"]
+            idx = [5, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32]
+            print("      final-phase pass: " + " | ".join("%s %.1f" % (names[i], us(idx[i], idx[i + 1])) for i in range(13)))
     ex.close()
