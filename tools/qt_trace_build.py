@@ -34,6 +34,17 @@ steps = [
  ("        const int nToExpand = s_misc[3 + par];\n", "        QT_STAMP(32);\n        const int nToExpand = s_misc[3 + par];\n"),
 ]
 for a, b in steps: rep(a, b)
+# ... and inside the regular-pass jump (slots 33..)
+jsteps = [
+ ("            const int ncD = g.nIni << (2 * D);\n", "            QT_STAMP(33);\n            const int ncD = g.nIni << (2 * D);\n"),
+ ("#pragma unroll\n            for (int d = 0; d < 5; d++) {\n                if (d > D) break;\n                const int a1 =", "            QT_STAMP(34);\n#pragma unroll\n            for (int d = 0; d < 5; d++) {\n                if (d > D) break;\n                const int a1 ="),
+ ("        __syncthreads();\n        if (s_misc[5] > 0 && s_misc[6] == s_misc[5]) {", "        QT_STAMP(35);\n        __syncthreads();\n        QT_STAMP(36);\n        if (s_misc[5] > 0 && s_misc[6] == s_misc[5]) {"),
+ ("        if (K > 0) {\n            const int nc = g.nIni << (2 * K);\n", "        QT_STAMP(37);\n        if (K > 0) {\n            const int nc = g.nIni << (2 * K);\n"),
+ ("            cnt = L.cntA; dep = L.depA; cnt2 = L.cntB; dep2 = L.depB;        // (H_(D-1) lives in cntB)\n", "            QT_STAMP(38);\n            cnt = L.cntA; dep = L.depA; cnt2 = L.cntB; dep2 = L.depB;        // (H_(D-1) lives in cntB)\n"),
+ ("            __syncthreads();\n            keys.each(n, tid, [&](int, unsigned& kcode, int& knode) {\n                knode = F[qt_jump_xform(", "            __syncthreads();\n            QT_STAMP(39);\n            keys.each(n, tid, [&](int, unsigned& kcode, int& knode) {\n                knode = F[qt_jump_xform("),
+ ("            jumpPrev = s_misc[5 + 2 * (K - 1)]; jumpExp = s_misc[6 + 2 * K];\n", "            QT_STAMP(40);\n            jumpPrev = s_misc[5 + 2 * (K - 1)]; jumpExp = s_misc[6 + 2 * K];\n"),
+]
+for a, b in jsteps: rep(a, b)
 open(os.path.join(C, "_qttrace.hip"), "w").write(s)
 os.makedirs(os.path.join(R, "ab"), exist_ok=True)
 flags = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math".split()

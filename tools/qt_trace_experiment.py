@@ -18,5 +18,8 @@ for (W, H, N) in ((1241, 376, 2000), (752, 480, 1200)):
         if lvl in (0, 3):
             names = ["child histogram (16 LDS atomics / key) + barrier", "flags + scan", "compaction + rank", "barrier", "children + barrier", "scan", "break position + barrier", "marks, flags (3 barriers)", "scan", "new nodes", "barrier", "keys to their new nodes", "count, clear, barrier"]
             idx = [5, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32]
+            jn = ["entry", "histogram sums", "wave sums + atomics", "barrier", "K", "flags + scan", "node sizes + barrier", "keys to their nodes", "barrier"]
+            ji = [3, 33, 34, 35, 36, 37, 38, 39, 40, 4]
+            print("      jump: " + " | ".join("%s %.1f" % (jn[i], us(ji[i], ji[i + 1])) for i in range(9)))
             print("      final-phase pass: " + " | ".join("%s %.1f" % (names[i], us(idx[i], idx[i + 1])) for i in range(13)))
     ex.close()
