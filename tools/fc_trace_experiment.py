@@ -1,4 +1,4 @@
-"""Phase times inside k_fast_cells for a single frame (an instrumented build, ab/liborbhip_fctrace.so: s_memrealtime stamps of eight workgroups).  Measurement aid."""
+"""(instrumented build: tools/trace_builds.py; run with ORBHIP_LIBRARY=$PWD/ab/liborbhip_<name>.so)  Phase times inside k_fast_cells for a single frame (an instrumented build, ab/liborbhip_fctrace.so: s_memrealtime stamps of eight workgroups).  Measurement aid."""
 import sys, os, ctypes as C
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, orb_slam2_amd

@@ -1,5 +1,5 @@
-"""Phase times inside k_pyramid_cascade.  Needs an instrumented build: apply tools/pc_trace_experiment.patch (s_memrealtime stamps of eight workgroups), build it as
-ab/liborbhip_pctrace.so and run with ORBHIP_LIBRARY pointing at it.  Measurement aid, not part of the product."""
+"""Phase times inside k_pyramid_cascade.  Needs an instrumented build: `tools/trace_builds.py pctrace` (s_memrealtime stamps of eight workgroups) builds
+ab/liborbhip_pctrace.so; run with ORBHIP_LIBRARY pointing at it.  Measurement aid, not part of the product."""
 import sys, os, ctypes as C
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, orb_slam2_amd

@@ -1,3 +1,4 @@
+# instrumented build: tools/trace_builds.py qttrace; run with ORBHIP_LIBRARY=$PWD/ab/liborbhip_qttrace.so
 import sys, os, ctypes as C
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, orb_slam2_amd

@@ -1,4 +1,4 @@
-"""Start / end of every workgroup of the kernels of one single-image call on the GPU's own 100 MHz clock (instrumented build ab/liborbhip_span.so; one store per
+"""(instrumented build: tools/trace_builds.py; run with ORBHIP_LIBRARY=$PWD/ab/liborbhip_<name>.so)  Start / end of every workgroup of the kernels of one single-image call on the GPU's own 100 MHz clock (instrumented build ab/liborbhip_span.so; one store per
 workgroup, no atomics): how long the kernels' workgroups really run and what lies BETWEEN the kernels of the dependent chain.  Measurement aid."""
 import sys, os, ctypes as C
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
