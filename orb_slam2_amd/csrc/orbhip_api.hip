@@ -619,8 +619,8 @@ static ExtractParams make_params(orbhip_ctx* c, const uint8_t* d_img0, long long
     return P;
 }
 
-// levels 1 .. L-1, each from the one before: seven dependent launches.  (Fewer were tried and lost: the small levels in one launch of one
-// workgroup per frame, 0.27 -> 0.54 ms at B = 256 and +0.09 ms per single-frame call; see docs/ROUND_LOG.md.)
+// levels 1 .. L-1, each from the one before: seven dependent launches for a batch (fewer were tried and lost there: the small levels in one launch of one
+// workgroup per frame, 0.27 -> 0.54 ms at B = 256; docs/ROUND_LOG.md), ONE launch for up to eight frames, where the seven cost 35 us of pure latency
 static void launch_pyramid(orbhip_ctx* c, const ExtractParams& P, int nf, hipStream_t s)
 {
     if (nf <= 8 && c->pc_ok) { orbhip_launch_pyramid_cascade(P, nf, s); return; }      // a handful of frames: one launch for all levels (k_pyramid_cascade)
