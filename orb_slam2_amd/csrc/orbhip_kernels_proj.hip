@@ -7,7 +7,7 @@
 //   k_proj_candidates          one wavefront per query: Frame::GetFeaturesInArea in reference order with the level
 //                              arguments of the call, the stereo right-coordinate gate and DescriptorDistance
 //                              + the best / second-best candidate of the query under the INITIAL map-point state
-//   k_proj_select              one wave replays the order-dependent loop, 64 queries per step: features claimed by a map point with
+//   k_proj_select              one workgroup replays the order-dependent loop, 256 queries per step: features claimed by a map point with
 //                              observations are skipped by later queries, so a query's precomputed best / second-best is final
 //                              unless an earlier query claimed one of the two — those (rare) queries are rescanned one at a time;
 //                              same-level ratio rule (mode 0) or best only + rotation histogram (mode 1);
@@ -118,117 +118,143 @@ __global__ __launch_bounds__(256) void k_proj_candidates(ProjParams J, float gwI
 __global__ __launch_bounds__(256) void k_proj_candidates_batch(const ProjParams* Js, float gwInv, float ghInv) { const ProjParams J = Js[blockIdx.y]; proj_candidates_body(J, gwInv, ghInv); }
 
 
+// The order-dependent loop, 256 queries per step on all four waves.  A query's decision (its first recorded candidates nobody has claimed) is final once
+// no EARLIER undecided query can still claim something it looked at: every undecided query marks what it would claim (atomicMin of its index onto the
+// feature's stamp), then checks the stamps of what it looked at; the queries before the first one that is unsure (or whose records are used up) commit,
+// the rest go round again.  (One wave did this 64 queries at a time before.  A round is ~450 instructions, 1.0-1.4 us, either way; four times the
+// queries per step did NOT mean a quarter of the rounds - neighbouring map points look at the same features, and a search's length is the depth of
+// those chains: 33.5 -> 31.1 us per search in the front-end loop, 4-5 % off the matcher calls.)
+#define PJM_LOW 0                       // misc words (two sets, alternating by round): lowest undecided query of the round
+#define PJM_BAD 1                       //   first query that cannot be decided this round: 2 q + (records used up ? 0 : 1)
+#define PJM_NEV 4                       // (one set) rotation-histogram entries written, matches
+#define PJM_NM 5
 __device__ __forceinline__ void proj_select_body(const ProjParams& J)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = J.n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), n = J.n;
     HIP_DYNAMIC_SHARED(int, lds)
     int* s_blocked = lds;                                   // F.mvpMapPoints[i] && Observations() > 0
     int* s_fq = s_blocked + n;                              // query whose map point sits in F.mvpMapPoints[i]
     int* s_stamp = s_fq + n;                                // lowest query index that (speculatively) claims feature i with a blocking map point
     float* s_fang = reinterpret_cast<float*>(s_stamp + n);  // mvKeysUn[i].angle
-    int* s_hist = reinterpret_cast<int*>(s_fang + n);       // [HISTO_LENGTH] + 8 misc
+    int* s_hist = reinterpret_cast<int*>(s_fang + n);       // [HISTO_LENGTH] + 3 maxima + 13 misc
+    int* s_misc = s_hist + ORBHIP_HISTO_LENGTH + 3;
     for (int i = tid; i < n; i += PJ_T) { s_blocked[i] = J.blocked_in ? (int)J.blocked_in[i] : 0; s_fq[i] = -1; s_stamp[i] = IMAX; s_fang[i] = J.kp[i].angle; }
-    for (int i = tid; i < ORBHIP_HISTO_LENGTH + 8; i += PJ_T) s_hist[i] = 0;
+    for (int i = tid; i < ORBHIP_HISTO_LENGTH + 16; i += PJ_T) s_hist[i] = 0;
+    __syncthreads();
+    if (tid < 4) s_misc[tid] = IMAX;                         // PJM_LOW / PJM_BAD of both sets
     __syncthreads();
     const float factor = 1.0f / ORBHIP_HISTO_LENGTH;
     const bool use_second = J.mode == 0;                     // mode 1 keeps the best candidate only (ORBmatcher.cc:1396-1425)
-    if (wave == 0) {
-        int nmatches = 0, nev = 0;
-        auto rot_bin = [&](float qang, int bidx) -> int {                                  // ORBmatcher.cc:1430-1440
-            float rot = __fsub_rn(qang, s_fang[bidx]);
-            if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
-            int bin = (int)roundf(__fmul_rn(rot, factor));
-            if (bin == ORBHIP_HISTO_LENGTH) bin = 0;
-            return min(max(bin, 0), ORBHIP_HISTO_LENGTH - 1);
-        };
-        // The records of step s + 1 (64 queries x 7 words from global memory: one memory latency) are requested before step s is resolved and
-        // consumed after it: 18 steps of a 1100-query search used to pay that latency 18 times, one after the other - most of the kernel's 41 us.
-        unsigned nt[PJ_K], nmore = 0u; int nblocks = 0; float nqang = 0.0f;
-        auto fetch = [&](int qb) {
-            const int q = qb + lane;
-            const bool inb = q < J.nq;
+    auto rot_bin = [&](float qang, int bidx) -> int {                                  // ORBmatcher.cc:1430-1440
+        float rot = __fsub_rn(qang, s_fang[bidx]);
+        if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+        int bin = (int)roundf(__fmul_rn(rot, factor));
+        if (bin == ORBHIP_HISTO_LENGTH) bin = 0;
+        return min(max(bin, 0), ORBHIP_HISTO_LENGTH - 1);
+    };
+    // the records of step s + 1 (7 words per query from global memory) are requested before step s is resolved and consumed after it
+    unsigned nt[PJ_K], nmore = 0u; int nblocks = 0; float nqang = 0.0f;
+    auto fetch = [&](int qb) {
+        const int q = qb + tid;
+        const bool inb = q < J.nq;
 #pragma unroll
-            for (int k = 0; k < PJ_K; k++) nt[k] = inb ? J.top[PJ_REC * q + k] : PJ_NONE;
-            nmore = inb ? J.top[PJ_REC * q + PJ_K] : 0u;
-            nblocks = inb ? J.q[q].blocks : 0;
-            nqang = inb ? J.q[q].angle : 0.0f;
-        };
-        fetch(0);
-        for (int qb = 0; qb < J.nq; qb += 64) {
-            const int q = qb + lane;
-            const bool inb = q < J.nq;
-            int ei[PJ_K], ed[PJ_K], el[PJ_K]; int nk = 0;
+        for (int k = 0; k < PJ_K; k++) nt[k] = inb ? J.top[PJ_REC * q + k] : PJ_NONE;
+        nmore = inb ? J.top[PJ_REC * q + PJ_K] : 0u;
+        nblocks = inb ? J.q[q].blocks : 0;
+        nqang = inb ? J.q[q].angle : 0.0f;
+    };
+    int wmatches = 0, par = 0;                              // this wave's matches (wave-uniform); which misc set the round uses
+    fetch(0);
+    for (int qb = 0; qb < J.nq; qb += PJ_T) {
+        const int q = qb + tid;
+        const bool inb = q < J.nq;
+        int ei[PJ_K], ed[PJ_K], el[PJ_K]; int nk = 0;
 #pragma unroll
-            for (int k = 0; k < PJ_K; k++) {
-                const unsigned t = nt[k];
-                ei[k] = (int)(t & 0x7FFFFu); ed[k] = (int)((t >> 19) & 0x1FFu); el[k] = (int)(t >> 28);
-                if (t != PJ_NONE) nk = k + 1;
-            }
-            const bool more = inb && nmore != 0u;
-            const int blocks = nblocks;
-            const float qang = nqang;
-            if (qb + 64 < J.nq) fetch(qb + 64);
-            int stamped = -1;                                // feature this lane's speculative claim currently marks
-            unsigned long long todo = __ballot(nk > 0);
-            while (todo) {
-                const bool mine = (todo >> lane) & 1ull;
-                const int lowest = __ffsll((long long)todo) - 1;
-                // first two recorded candidates nobody has claimed so far (claims only ever add up: a claimed feature stays claimed)
-                int a = -1, b = -1;
+        for (int k = 0; k < PJ_K; k++) {
+            const unsigned t = nt[k];
+            ei[k] = min((int)(t & 0x7FFFFu), n - 1); ed[k] = (int)((t >> 19) & 0x1FFu); el[k] = (int)(t >> 28);      // (an empty record's index is out of range: any valid entry, unused)
+            if (t != PJ_NONE) nk = k + 1;
+        }
+        const bool more = inb && nmore != 0u;
+        const int blocks = nblocks;
+        const float qang = nqang;
+        if (qb + PJ_T < J.nq) fetch(qb + PJ_T);
+        bool pend = nk > 0;                                  // this query is still undecided
+        int stamped = -1;                                    // feature this query's speculative claim currently marks
+        for (;;) {
+            int* misc = s_misc + 2 * par; int* other = s_misc + 2 * (par ^ 1);
+            // first two recorded candidates nobody has claimed so far (claims only ever add up: a claimed feature stays claimed); the state of all
+            // recorded candidates in ONE round of LDS reads (tested one by one behind each other's outcome they were up to twelve dependent latencies)
+            int blk[PJ_K];
 #pragma unroll
-                for (int k = 0; k < PJ_K; k++)
-                    if (mine && k < nk && b < 0 && !s_blocked[ei[k]]) { if (a < 0) a = k; else b = k; }
-                if (!use_second) b = -1;
-                const int ia = a >= 0 ? ei[a] : 0, da = a >= 0 ? ed[a] : 256, la = a >= 0 ? el[a] : -1;
-                const int db = b >= 0 ? ed[b] : 256, lb = b >= 0 ? el[b] : -1;
-                // records used up while more selectable candidates exist: the answer is not in the records
-                const bool exhausted = mine && more && (a < 0 || (use_second && b < 0));
-                // the decision the reference takes if nothing this query looks at is claimed by a query between the committed ones and it
-                const bool accept = mine && !exhausted && a >= 0 && da <= J.th_high && !(J.mode == 0 && la == lb && (float)da > __fmul_rn(J.nnratio, (float)db));   // ORBmatcher.cc:116-126
-                const int want = (accept && blocks) ? ia : -1;
-                if (stamped >= 0 && stamped != want && s_stamp[stamped] == q) s_stamp[stamped] = IMAX;    // withdraw an outdated speculative claim
-                __builtin_amdgcn_wave_barrier();
-                if (want >= 0) atomicMin(&s_stamp[want], q);
-                stamped = want;
-                __builtin_amdgcn_wave_barrier();
-                // an earlier, not yet committed query of this step may still claim one of the candidates this decision rests on
-                bool unsure = false;
-                const int last = use_second ? (b >= 0 ? b : nk - 1) : a;
+            for (int k = 0; k < PJ_K; k++) blk[k] = s_blocked[ei[k]];
+            int a = -1, b = -1;
 #pragma unroll
-                for (int k = 0; k < PJ_K; k++)
-                    if (mine && lane != lowest && k <= last && !s_blocked[ei[k]] && s_stamp[ei[k]] < q) unsure = true;
-                const unsigned long long bad = __ballot(unsure || exhausted);
-                const int first_bad = bad ? __ffsll((long long)bad) - 1 : 64;
-                const unsigned long long commit = first_bad == 64 ? todo : (todo & ((1ull << first_bad) - 1ull));
-                const bool win = ((commit >> lane) & 1ull) && accept;
-                const unsigned long long wins = __ballot(win);
-                if (win) {
-                    atomicMax(&s_fq[ia], q);                                                // later queries overwrite earlier ones (ORBmatcher.cc:123)
-                    if (blocks) s_blocked[ia] = 1;
-                    if (J.mode == 1 && J.check_ori) {
-                        const int bin = rot_bin(qang, ia);
-                        atomicAdd(&s_hist[bin], 1);
-                        J.events[nev + __popcll(wins & ((1ull << lane) - 1ull))] = (bin << 20) | ia;     // rotHist[bin].push_back(bestIdx2)
-                    }
+            for (int k = 0; k < PJ_K; k++)
+                if (pend && k < nk && b < 0 && !blk[k]) { if (a < 0) a = k; else b = k; }
+            if (!use_second) b = -1;
+            const int ia = a >= 0 ? ei[a] : 0, da = a >= 0 ? ed[a] : 256, la = a >= 0 ? el[a] : -1;
+            const int db = b >= 0 ? ed[b] : 256, lb = b >= 0 ? el[b] : -1;
+            // records used up while more selectable candidates exist: the answer is not in the records
+            const bool exhausted = pend && more && (a < 0 || (use_second && b < 0));
+            // the decision the reference takes if nothing this query looks at is claimed by a query between the committed ones and it
+            const bool accept = pend && !exhausted && a >= 0 && da <= J.th_high && !(J.mode == 0 && la == lb && (float)da > __fmul_rn(J.nnratio, (float)db));   // ORBmatcher.cc:116-126
+            const int want = (accept && blocks) ? ia : -1;
+            if (stamped >= 0 && stamped != want && s_stamp[stamped] == q) s_stamp[stamped] = IMAX;    // withdraw an outdated speculative claim (its own: the stamp is its index)
+            { const int lo = pj_wave_min(pend ? q : IMAX); if (lane == 0 && lo != IMAX) atomicMin(&misc[PJM_LOW], lo); }
+            __syncthreads();
+            if (want >= 0) atomicMin(&s_stamp[want], q);
+            stamped = want;
+            if (tid == 0) { other[PJM_LOW] = IMAX; other[PJM_BAD] = IMAX; }                           // the next round's set: nobody reads or writes it between these two barriers
+            __syncthreads();
+            // an earlier, not yet committed query of this step may still claim one of the candidates this decision rests on
+            const int lowest = misc[PJM_LOW];
+            int stp[PJ_K];
+#pragma unroll
+            for (int k = 0; k < PJ_K; k++) stp[k] = s_stamp[ei[k]];
+            bool unsure = false;
+            const int last = use_second ? (b >= 0 ? b : nk - 1) : a;
+#pragma unroll
+            for (int k = 0; k < PJ_K; k++)
+                if (pend && q != lowest && k <= last && !blk[k] && stp[k] < q) unsure = true;          // (nothing is blocked between the reads above and here: commits follow)
+            { const int bk = pj_wave_min((unsure || exhausted) ? 2 * q + (exhausted ? 0 : 1) : IMAX); if (lane == 0 && bk != IMAX) atomicMin(&misc[PJM_BAD], bk); }
+            __syncthreads();
+            const int badkey = misc[PJM_BAD];
+            const int first_bad = badkey == IMAX ? IMAX : (badkey >> 1);
+            const bool bad_exhausted = badkey != IMAX && !(badkey & 1);
+            const bool commit = pend && q < first_bad;
+            const bool win = commit && accept;
+            const unsigned long long wins = __ballot(win);
+            int evbase = 0;
+            if (J.mode == 1 && J.check_ori && wins) { if (lane == 0) evbase = atomicAdd(&s_misc[PJM_NEV], (int)__popcll(wins)); evbase = __builtin_amdgcn_readlane(evbase, 0); }
+            if (win) {
+                atomicMax(&s_fq[ia], q);                                                // later queries overwrite earlier ones (ORBmatcher.cc:123)
+                if (blocks) s_blocked[ia] = 1;
+                if (J.mode == 1 && J.check_ori) {
+                    const int bin = rot_bin(qang, ia);
+                    atomicAdd(&s_hist[bin], 1);
+                    J.events[evbase + __popcll(wins & ((1ull << lane) - 1ull))] = (bin << 20) | ia;     // rotHist[bin].push_back(bestIdx2): the entries do not interact, any order
                 }
-                nmatches += __popcll(wins); nev += __popcll(wins);
+            }
+            wmatches += (int)__popcll(wins);
+            pend = pend && !commit;
+            par ^= 1;
+            __syncthreads();
+            if (first_bad == IMAX) break;
+            // the first undecided query: if it merely waited for earlier ones it is re-evaluated now that they are final;
+            // only a query whose records are used up is rescanned against the current state - by its own wave, the others wait
+            if (first_bad != lowest || !bad_exhausted) continue;
+            if (wave == ((first_bad - qb) >> 6)) {
+                const int fl = (first_bad - qb) & 63, qs = first_bad;
+                if (lane == fl) { pend = false; if (stamped >= 0 && s_stamp[stamped] == q) s_stamp[stamped] = IMAX; stamped = -1; }
                 __builtin_amdgcn_wave_barrier();
-                todo &= ~commit;
-                if (first_bad == 64) break;
-                // the first undecided query: if it merely waited for earlier ones it is re-evaluated now that they are final;
-                // only a query whose records are used up is rescanned against the current state
-                if (first_bad != lowest || !((__ballot(exhausted) >> first_bad) & 1ull)) continue;
-                todo &= ~(1ull << first_bad);
-                const int qs = qb + first_bad;
-                if (lane == first_bad && stamped >= 0 && s_stamp[stamped] == q) { s_stamp[stamped] = IMAX; }
-                // rescan query qb + first_bad against the current state (its speculative claim, if any, was withdrawn above)
                 const int nc = J.ncand[qs];
                 const unsigned* cand = J.cand + (long long)qs * J.cand_stride;
                 int best = 256, blevel = -1, second = 256, slevel = -1, bidx = -1;
                 for (int cb = 0; cb < nc; cb += 64) {
                     const int t = cb + lane;
                     const unsigned e = t < nc ? cand[t] : 0u;
-                    const int i2 = (int)(e & 0x7FFFFu), dist = (int)((e >> 19) & 0x1FFu), lvl = (int)(e >> 28);
+                    const int i2 = min((int)(e & 0x7FFFFu), n - 1), dist = (int)((e >> 19) & 0x1FFu), lvl = (int)(e >> 28);
                     const bool valid = t < nc && dist < 256 && !s_blocked[i2];
                     // two smallest (distance, lane) keys by DPP min networks; the key carries the level so no extra readlane is needed
                     const int key = valid ? ((dist << 10) | (lane << 4) | lvl) : IMAX;
@@ -244,18 +270,24 @@ __device__ __forceinline__ void proj_select_body(const ProjParams& J)
                     } else if (wmin < second) { second = wmin; slevel = cl; }
                 }
                 if (best <= J.th_high && !(J.mode == 0 && blevel == slevel && (float)best > __fmul_rn(J.nnratio, (float)second))) {
-                    const int sblocks = __builtin_amdgcn_readlane(blocks, first_bad);
-                    const float sang = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qang), first_bad));
+                    const int sblocks = __builtin_amdgcn_readlane(blocks, fl);
+                    const float sang = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qang), fl));
                     if (lane == 0) {
                         s_fq[bidx] = qs;
                         if (sblocks) { s_blocked[bidx] = 1; atomicMin(&s_stamp[bidx], qs); }
-                        if (J.mode == 1 && J.check_ori) { const int bin = rot_bin(sang, bidx); s_hist[bin]++; J.events[nev] = (bin << 20) | bidx; }
+                        if (J.mode == 1 && J.check_ori) { const int bin = rot_bin(sang, bidx); atomicAdd(&s_hist[bin], 1); J.events[atomicAdd(&s_misc[PJM_NEV], 1)] = (bin << 20) | bidx; }
                     }
-                    nmatches++; nev++;
+                    wmatches++;
                 }
-                __builtin_amdgcn_wave_barrier();              // lane 0's claim precedes the next reads (same wave: LDS ops stay in order)
             }
+            __syncthreads();                                 // the rescanned query's claim precedes the next round's reads
         }
+    }
+    if (lane == 0 && wmatches) atomicAdd(&s_misc[PJM_NM], wmatches);
+    __syncthreads();
+    if (wave == 0) {
+        int nmatches = s_misc[PJM_NM];
+        const int nev = s_misc[PJM_NEV];
         if (J.mode == 1 && J.check_ori) {
             if (lane == 0) {
                 int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
@@ -292,7 +324,7 @@ __device__ __forceinline__ void proj_select_body(const ProjParams& J)
 __global__ __launch_bounds__(PJ_T) void k_proj_select(ProjParams J) { proj_select_body(J); }
 __global__ __launch_bounds__(PJ_T) void k_proj_select_batch(const ProjParams* Js) { const ProjParams J = Js[blockIdx.x]; proj_select_body(J); }      // one workgroup per camera slot
 
-size_t orbhip_proj_select_lds(int n) { return sizeof(int) * ((size_t)4 * n + ORBHIP_HISTO_LENGTH + 8); }
+size_t orbhip_proj_select_lds(int n) { return sizeof(int) * ((size_t)4 * n + ORBHIP_HISTO_LENGTH + 16); }
 
 void orbhip_launch_proj(const ProjParams& J, hipStream_t s)
 {
