@@ -1,4 +1,4 @@
-"""Rounds, rescans and us per round of k_proj_select (needs a build with the counters of the round-4 experiment: orbhip_debug_pj; see docs/ROUND_LOG.md).  Measurement aid."""
+"""Rounds, rescans and us per round of k_proj_select (instrumented build: tools/trace_builds.py pjtrace; run with ORBHIP_LIBRARY=$PWD/ab/liborbhip_pjtrace.so).  Measurement aid."""
 import sys, os, ctypes as C
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, orb_slam2_amd
@@ -20,4 +20,4 @@ for frac in (0.75, 0.4):
     t = np.zeros(8, np.uint64); L.orbhip_debug_pj(t.ctypes.data_as(C.c_void_p))
     for i in range(10): r = orb_slam2_amd.search_by_projection(k2, d2, W, H, q, d1[keep], mode, nnratio=nn)
     L.orbhip_debug_pj(t.ctypes.data_as(C.c_void_p)); t = t.astype(np.int64); c = t[0]
-    print(f"mode {mode} nq {t[6]//c}: steps {t[1]/c:.0f} iterations {t[2]/c:.1f} rescans {t[3]/c:.1f} | prologue {t[4]/c/100:.1f} us, selection loop {t[5]/c/100:.1f} us ({t[5]/t[1]/100:.2f} us per step, {t[5]/t[2]/100:.2f} per iteration)")
+    print(f"mode {mode} nq {t[6]//c}: steps of 256 {t[1]/c:.0f} rounds {t[2]/c:.1f} rescans {t[3]/c:.1f} | prologue {t[4]/c/100:.1f} us, selection loop {t[5]/c/100:.1f} us ({t[5]/t[1]/100:.2f} us per step, {t[5]/t[2]/100:.2f} per round)")

@@ -6,10 +6,12 @@ carries none), linked with the in-tree objects into ab/liborbhip_<name>.so.  Run
   pctrace  phases of k_pyramid_cascade (eight workgroups)         -> tools/pc_trace_experiment.py
   fctrace  phases of k_fast_cells (eight workgroups)              -> tools/fc_trace_experiment.py
   span     start / end of every workgroup of a call's kernels     -> tools/span_experiment.py
+  pjtrace  rounds / rescans / time of k_proj_select               -> tools/pj_select_experiment.py
 usage: tools/trace_builds.py <name> [<name> ...]"""
 import os, subprocess, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); C = os.path.join(R, "orb_slam2_amd", "csrc")
 SRC = open(os.path.join(C, "orbhip_kernels_extract.hip")).read()
+SRC_PROJ = open(os.path.join(C, "orbhip_kernels_proj.hip")).read()
 s = ""
 def rep(old, new):
     global s
@@ -87,16 +89,26 @@ def span():
     rep("        blur_mfma_tile(P, b / P.nframes, P.frame0 + b % P.nframes, s_in, s_out, s_band);\n    }\n}", "        blur_mfma_tile(P, b / P.nframes, P.frame0 + b % P.nframes, s_in, s_out, s_band);\n    }\n    WG_END(2, id);\n}")
     rep("    float* s_pat = reinterpret_cast<float*>(&s_win[0][0][0]);\n", "    float* s_pat = reinterpret_cast<float*>(&s_win[0][0][0]);\n    WG_START(3, (int)blockIdx.x);\n")
 
+def pjtrace():
+    rep("__device__ __forceinline__ void proj_select_body(const ProjParams& J)\n{", "__device__ unsigned long long g_pj[8];\nextern \"C\" void orbhip_debug_pj(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pj), 64); unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pj), z, 64); }\n"
+        "__device__ __forceinline__ void proj_select_body(const ProjParams& J)\n{\n    const unsigned long long T0 = __builtin_amdgcn_s_memrealtime(); unsigned long long T1 = 0; int c_steps = 0, c_iter = 0;")
+    rep("    fetch(0);\n    for (int qb = 0; qb < J.nq; qb += PJ_T) {", "    T1 = __builtin_amdgcn_s_memrealtime();\n    fetch(0);\n    for (int qb = 0; qb < J.nq; qb += PJ_T) {\n        c_steps++;")
+    rep("        for (;;) {\n            int* misc = s_misc + 2 * par;", "        for (;;) {\n            c_iter++;\n            int* misc = s_misc + 2 * par;")
+    rep("                const int nc = J.ncand[qs];", "                if (lane == 0) atomicAdd(&g_pj[3], 1ull);\n                const int nc = J.ncand[qs];")
+    rep("    if (lane == 0 && wmatches) atomicAdd(&s_misc[PJM_NM], wmatches);", "    if (tid == 0) { const unsigned long long T2 = __builtin_amdgcn_s_memrealtime(); g_pj[0] += 1; g_pj[1] += c_steps; g_pj[2] += c_iter; g_pj[4] += T1 - T0; g_pj[5] += T2 - T1; g_pj[6] += J.nq; }\n    if (lane == 0 && wmatches) atomicAdd(&s_misc[PJM_NM], wmatches);")
+
 flags = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math".split()
-objs = "orbhip_api.o orbhip_kernels_match.o orbhip_kernels_stereo.o orbhip_kernels_proj.o orbhip_kernels_geom.o orbhip_bow.o orbhip_pool.o".split()
+allobjs = "orbhip_api.o orbhip_kernels_extract.o orbhip_kernels_match.o orbhip_kernels_stereo.o orbhip_kernels_proj.o orbhip_kernels_geom.o orbhip_bow.o orbhip_pool.o".split()
 for name in sys.argv[1:] or ["qttrace"]:
-    s = SRC
-    {"qttrace": qttrace, "pctrace": pctrace, "fctrace": fctrace, "span": span}[name]()
+    proj = name == "pjtrace"
+    s = SRC_PROJ if proj else SRC
+    {"qttrace": qttrace, "pctrace": pctrace, "fctrace": fctrace, "span": span, "pjtrace": pjtrace}[name]()
     tmp = os.path.join(C, "_trace.hip")
     open(tmp, "w").write(s)
     os.makedirs(os.path.join(R, "ab"), exist_ok=True)
     try:
         subprocess.check_call(["/opt/rocm/bin/hipcc", *flags, "-c", "_trace.hip", "-o", "/tmp/_trace.o"], cwd=C, stderr=subprocess.DEVNULL)
+        objs = [o for o in allobjs if o != ("orbhip_kernels_proj.o" if proj else "orbhip_kernels_extract.o")]
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", *objs, "/tmp/_trace.o", "-o", "../../ab/liborbhip_%s.so" % name, "-Wl,-rpath,/opt/rocm/lib"], cwd=C)
     finally:
         os.remove(tmp)
