@@ -1,11 +1,17 @@
 """Search loops of the projection-guided matchers on flat data: ORBmatcher::SearchByProjection(Frame&,
 vector<MapPoint*>&, th) (ORBmatcher.cc:45-129, mode 0) and SearchByProjection(Current, Last, th, bMono) (:1328-1470, mode 1).
 The queries play the map points the caller would have projected; assignments must equal the oracle's restatement."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
-import orb_slam2_amd
-from orb_slam2_amd import synth
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+import orb_slam2_amd  # noqa: E402
+from orb_slam2_amd import synth  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -235,3 +241,59 @@ def test_search_by_projection_batch_of_camera_slots(backend, oracle, scene, mode
     for s, ((n_g, f_g), (n_o, f_o)) in enumerate(zip(got, want)):
         assert n_g == n_o and np.array_equal(f_g, f_o), f"slot {s}"
     assert sum(n for n, _ in want) > 500
+
+
+def _fuzz_case(oracle, rng, library):
+    """one random projection search: scene size, feature count, window, level rule, conflicts (many queries crowded onto few features), blocked features"""
+    w, h, n = int(rng.integers(200, 900)), int(rng.integers(160, 500)), int(rng.integers(150, 1600))
+    seq = synth.sequence(w, h, 2, seed=int(rng.integers(1 << 30)))
+    ora = oracle.OracleExtractor(n, 1.2, int(rng.integers(3, 9)), 20, 7)
+    (kl, dl), (kc, dc) = ora.extract(seq[0]), ora.extract(seq[1])
+    if len(kl) < 20 or len(kc) < 20:
+        return None
+    sf = ora.params()["scale_factors"]
+    mode = int(rng.integers(0, 2))
+    rule = ["local_map", "window", "forward", "backward"][int(rng.integers(0, 4))]
+    th = float(rng.choice([3.0, 7.0, 15.0, 40.0]))                     # 40: windows so wide that chains of queries looking at the same features get long
+    scene = (w, h, sf, (kl, dl), (kc, dc))
+    q, qd = _queries(oracle, scene, mode, th, rng, rule)
+    if rng.random() < 0.5:                                             # crowd: repeat a block of queries (the same map point seen twice, near-duplicates)
+        rep = rng.integers(0, len(q), int(len(q) * rng.uniform(0.2, 1.5)))
+        q, qd = np.concatenate([q, q[rep]]), np.concatenate([qd, qd[rep]])
+        perm = rng.permutation(len(q)); q, qd = q[perm], qd[perm]
+    u_right = np.where(rng.random(len(kc)) < 0.6, kc["x"] - rng.uniform(1, 45, len(kc)), -1).astype(np.float32) if rng.random() < 0.4 else None
+    blocked = (rng.random(len(kc)) < rng.uniform(0, 0.4)).astype(np.uint8)
+    ratio, check_ori = float(rng.choice([0.6, 0.8, 0.9])), bool(rng.integers(0, 2))
+    n_o, f_o = oracle.search_by_projection(kc, dc, w, h, q, qd, mode, nnratio=ratio, th_high=100, check_ori=check_ori, u_right=u_right, blocked=blocked)
+    n_g, f_g = orb_slam2_amd.search_by_projection(kc, dc, w, h, q, qd, mode, nnratio=ratio, th_high=100, check_ori=check_ori, u_right=u_right,
+                                                  blocked=blocked, library=library)
+    return f"{w}x{h} n={len(kc)} nq={len(q)} mode={mode} {rule} th={th} ratio={ratio} ori={check_ori}: {n_o} matches", n_g == n_o and np.array_equal(f_g, f_o)
+
+
+def test_search_by_projection_random_cases(backend, oracle, request):
+    """random scenes / windows / level rules / crowded query sets through the 256-queries-per-step selection (k_proj_select): 12 cases on the emulation,
+    40 on the GPU; `python tests/test_parity_projection.py [ncases] [seed]` runs a longer sweep by hand"""
+    rng = np.random.default_rng(77)
+    done = 0
+    for _ in range(40 if "gpu" in request.node.name else 12):
+        r = _fuzz_case(oracle, rng, backend)
+        if r is None:
+            continue
+        assert r[1], r[0]
+        done += 1
+    assert done >= 8
+
+
+if __name__ == "__main__":
+    from oracle import orb_oracle as O
+    ncases, seed = (int(sys.argv[1]) if len(sys.argv) > 1 else 200), (int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for c in range(ncases):
+        r = _fuzz_case(O, rng, None)
+        if r is None:
+            continue
+        print(f"case {c}: {r[0]} {'OK' if r[1] else 'MISMATCH'}")
+        bad += not r[1]
+    print(f"projection fuzz: {ncases} cases, {bad} mismatches")
+    sys.exit(1 if bad else 0)
