@@ -1,4 +1,6 @@
-cd /root/repo
+#!/bin/bash
+# quadtree phase stamps (ab/liborbhip_qttrace.so), then the in-tree library against ab/liborbhip_prev.so: single-image call, B = 512 bench, standalone kernel times (ORBHIP_SERIAL=1)
+cd "$(dirname "$0")/.."
 R=$(pwd)
 ORBHIP_LIBRARY=$R/ab/liborbhip_qttrace.so python3 tools/qt_trace_experiment.py 2>&1 | grep -A1 "1241x376 level [037]:\|752x480 level 0" | grep -v "^--" | cut -c1-330
 for r in 1 2; do
