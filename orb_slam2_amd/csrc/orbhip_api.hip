@@ -267,7 +267,7 @@ static hipError_t build_cascade(orbhip_ctx* c)
     const int L = c->L;
     if (L < 2 || L > ORBHIP_MAX_LEVELS) return hipSuccess;
     for (int l = 1; l < L; l++) if (c->pyr_staged[l] != 2) return hipSuccess;       // the kernel computes four pixels at a time from PyrGroup entries (scale factors below ~1.6)
-    int TW = 32, TH = 16;      // measured on MI355X at 1241 x 376 / 8 levels: 32x16 0.167-0.170 ms per call, 64x8 0.169-0.172, 32x8 0.172, 16x8 0.175, 64x16 0.179-0.190 (seven launches: 0.179-0.183)
+    int TW = 32, TH = 16;      // measured on MI355X at 1241 x 376 / 8 levels, ms per call: 32x16 0.139-0.142, 64x8 0.140-0.141, 16x8 0.139-0.142, 32x8 0.141-0.142, 16x16 0.141-0.145, 64x16 0.159-0.160 (seven launches: 0.158-0.162)
     if (const char* e = getenv("ORBHIP_PC_TILE")) { int w = 0, h = 0; if (sscanf(e, "%dx%d", &w, &h) == 2 && w >= 4 && h >= 1 && w % 4 == 0) { TW = w; TH = h; } else if (*e == '0') return hipSuccess; }
     const LevelGeom& gl = c->geom[L - 1];
     const int ntx = (gl.w + TW - 1) / TW, nty = (gl.h + TH - 1) / TH;

@@ -4,12 +4,9 @@ TAG=${1:-cascade}
 cd "$(dirname "$0")/.."
 R=$(pwd); OUT=gpurun_out/$TAG; mkdir -p $OUT
 run() { name=$1; shift; env "$@" timeout 100 python3 tools/single_frame_calls.py 2>&1 | grep single_frame | sed "s/^/$name /" >> $OUT/single.txt; }
-for r in 1 2; do
+for r in 1 2 3; do
   run levels ORBHIP_PC_TILE=0
-  for t in 32x8 64x8 32x16 64x16 32x32 16x16; do run tile_$t ORBHIP_PC_TILE=$t; done
+  for t in 32x16 32x8 16x8 64x8 16x16 64x16; do run tile_$t ORBHIP_PC_TILE=$t; done
 done
 sort $OUT/single.txt
 NROWS=7 tools/gpu_trace_variant.sh $TAG t32x8 ORBHIP_PC_TILE=32x8 | tail -8
-NROWS=7 tools/gpu_trace_variant.sh $TAG t32x16 ORBHIP_PC_TILE=32x16 | tail -8
-NROWS=13 tools/gpu_trace_variant.sh $TAG levels ORBHIP_PC_TILE=0 | tail -14
-timeout 600 python3 -m pytest tests/test_pyramid_cascade.py tests/test_parity_extract.py tests/test_parity_camera.py tests/test_full_size_gpu.py tests/test_dropin_loop.py -m gpu -x -q 2>&1 | tail -3
