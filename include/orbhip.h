@@ -429,6 +429,9 @@ orbhip_status orbhip_profile_enable(orbhip_ctx* ctx, int on);
 int orbhip_profile_num_kernels(const orbhip_ctx* ctx);
 orbhip_status orbhip_profile_get(orbhip_ctx* ctx, int k, const char** name, double* total_ms, int64_t* launches);
 orbhip_status orbhip_profile_reset(orbhip_ctx* ctx);
+/* Tiles of the last pyramid level that k_pyramid_cascade's workgroups own (calls with up to eight frames compute every level in one launch,
+ * DESIGN.md section 4), or 0 where the context's shape takes the level-by-level kernels instead (scale factors from ~1.6, very large levels). */
+int orbhip_pyramid_cascade_tiles(const orbhip_ctx* ctx);
 /* algorithmic bytes one frame moves (BASELINE.md §3 formula B(W,H,N)) */
 int64_t orbhip_algorithmic_bytes_per_frame(const orbhip_ctx* ctx);
 /* the terms of that formula moved by profiled kernel k (0 for kernels outside the formula) */

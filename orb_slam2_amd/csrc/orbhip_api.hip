@@ -267,7 +267,7 @@ static hipError_t build_cascade(orbhip_ctx* c)
     const int L = c->L;
     if (L < 2 || L > ORBHIP_MAX_LEVELS) return hipSuccess;
     for (int l = 1; l < L; l++) if (c->pyr_staged[l] != 2) return hipSuccess;       // the kernel computes four pixels at a time from PyrGroup entries (scale factors below ~1.6)
-    int TW = 32, TH = 16;      // measured on MI355X at 1241 x 376 / 8 levels, ms per call: 32x16 0.139-0.142, 64x8 0.140-0.141, 16x8 0.139-0.142, 32x8 0.141-0.142, 16x16 0.141-0.145, 64x16 0.159-0.160 (seven launches: 0.158-0.162)
+    int TW = 32, TH = 16;      // measured on MI355X at 1241 x 376 / 8 levels, ms per call: 32x16 0.139-0.142, 64x8 0.140-0.141, 16x8 0.139-0.142, 32x8 0.141-0.142, 16x16 0.141-0.145 (seven launches: 0.158-0.162; 64x16 and larger exceed the kernel's 256 table entries per workgroup and fall back to them)
     if (const char* e = getenv("ORBHIP_PC_TILE")) { int w = 0, h = 0; if (sscanf(e, "%dx%d", &w, &h) == 2 && w >= 4 && h >= 1 && w % 4 == 0) { TW = w; TH = h; } else if (*e == '0') return hipSuccess; }
     const LevelGeom& gl = c->geom[L - 1];
     const int ntx = (gl.w + TW - 1) / TW, nty = (gl.h + TH - 1) / TH;
@@ -305,12 +305,35 @@ static hipError_t build_cascade(orbhip_ctx* c)
     }
     int r0max = 0; for (int tx = 0; tx < ntx; tx++) for (int ty = 0; ty < nty; ty++) r0max = std::max(r0max, xbytes(0, tx) / 4 * yrows(0, ty));
     if ((size_t)buf[0] + buf[1] + (size_t)xcap * sizeof(PyrGroup) + (size_t)ycap * sizeof(int2) > 60 * 1024 || xcap > 256 || ycap > 512 || r0max > 4096) return hipSuccess;      // (k_pyramid_cascade's PC_GIT / PC_YIT / PC_RIT)
+    // self-check before the tables are used: every level covered without a gap, and every tap of every pixel a workgroup computes (whole 4-pixel groups)
+    // inside the rectangle it holds of the level below.  A table that fails is not used (the level kernels run instead).
+    for (int l = 0; l < L; l++) {
+        const LevelGeom& g = c->geom[l];
+        int next = 0;
+        for (int t = 0; t < ntx; t++) { const short2 r = xr[(size_t)l * ntx + t]; if (r.x > next || r.y < r.x || (r.x & 3)) return hipSuccess; next = std::max(next, r.y + 1); }
+        if (next < g.w) return hipSuccess;
+        next = 0;
+        for (int t = 0; t < nty; t++) { const short2 r = yr[(size_t)l * nty + t]; if (r.x > next || r.y < r.x) return hipSuccess; next = std::max(next, r.y + 1); }
+        if (next < g.h) return hipSuccess;
+        if (l == 0) continue;
+        const int2* xt = c->xtab.data() + g.xtab_off; const int2* yt = c->ytab.data() + g.ytab_off;
+        for (int t = 0; t < ntx; t++) {
+            const short2 r = xr[(size_t)l * ntx + t], sr = xr[(size_t)(l - 1) * ntx + t];
+            const int sx_last = std::min(sr.x + xbytes(l - 1, t) - 1, g.src_w - 1);            // last source column the workgroup holds
+            for (int x = r.x; x <= std::min(r.x + xbytes(l, t) - 1, g.w - 1); x++) { const int a = xt[x].x, b = std::min(a + 1, g.src_w - 1); if (a < sr.x || b > sx_last) return hipSuccess; }
+        }
+        for (int t = 0; t < nty; t++) {
+            const short2 r = yr[(size_t)l * nty + t], sr = yr[(size_t)(l - 1) * nty + t];
+            for (int y = r.x; y <= r.y; y++) { const int a = std::min(std::max(yt[y].x, 0), g.src_h - 1), b = std::min(std::max(yt[y].x + 1, 0), g.src_h - 1); if (a < sr.x || b > sr.y) return hipSuccess; }
+        }
+    }
     hipError_t e = upload(&c->d_pc_xr, xr); if (e != hipSuccess) return e;
     e = upload(&c->d_pc_yr, yr); if (e != hipSuccess) return e;
     c->pc_ntx = ntx; c->pc_nty = nty; c->pc_buf0 = buf[0]; c->pc_buf1 = buf[1]; c->pc_xcap = xcap; c->pc_ycap = ycap; c->pc_ok = true;
     return hipSuccess;
 }
 
+extern "C" int orbhip_pyramid_cascade_tiles(const orbhip_ctx* c) { return c && c->pc_ok ? c->pc_ntx * c->pc_nty : 0; }
 extern "C" const char* orbhip_version(void) { return "orbhip 0.2 (gfx950)"; }
 extern "C" int orbhip_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; } return n; }
 extern "C" const char* orbhip_last_error(void) { return g_err.c_str(); }

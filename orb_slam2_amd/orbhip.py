@@ -24,7 +24,7 @@ SYMBOLS = [
     "orbhip_get_scale_tables", "orbhip_level_size", "orbhip_extract", "orbhip_extract_batch", "orbhip_pyramid_level",
     "orbhip_extract_device", "orbhip_sync", "orbhip_fetch", "orbhip_fetch_matches", "orbhip_descriptor_distance",
     "orbhip_hamming_nn", "orbhip_hamming_nn_device", "orbhip_search_for_initialization", "orbhip_profile_enable",
-    "orbhip_profile_num_kernels", "orbhip_profile_get", "orbhip_profile_reset", "orbhip_algorithmic_bytes_per_frame",
+    "orbhip_profile_num_kernels", "orbhip_profile_get", "orbhip_profile_reset", "orbhip_pyramid_cascade_tiles", "orbhip_algorithmic_bytes_per_frame",
     "orbhip_algorithmic_bytes_per_frame_kernel", "orbhip_debug_blurred_level", "orbhip_debug_candidates",
     "orbhip_compute_stereo_matches", "orbhip_search_by_projection", "orbhip_extract_batch_color",
     "orbhip_extract_device_color", "orbhip_voc_load_text", "orbhip_voc_destroy", "orbhip_voc_info", "orbhip_voc_transform_features",
@@ -162,6 +162,7 @@ def lib(path=None):
     L.orbhip_profile_num_kernels.argtypes = [vp]
     L.orbhip_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.orbhip_profile_reset.argtypes = [vp]
+    L.orbhip_pyramid_cascade_tiles.argtypes = [vp]; L.orbhip_pyramid_cascade_tiles.restype = C.c_int
     L.orbhip_algorithmic_bytes_per_frame.argtypes = [vp]
     L.orbhip_algorithmic_bytes_per_frame.restype = C.c_int64
     L.orbhip_algorithmic_bytes_per_frame_kernel.argtypes = [vp, C.c_int]
@@ -495,6 +496,10 @@ class ORBextractor:
         return u, d
 
     # ---- measurement / stage dumps
+    def pyramid_cascade_tiles(self):
+        """tiles of the last level owned by k_pyramid_cascade's workgroups; 0 = the level-by-level kernels run (orbhip_pyramid_cascade_tiles)"""
+        return int(self.L.orbhip_pyramid_cascade_tiles(self.h))
+
     def profile_enable(self, on=True):
         _check(self.L.orbhip_profile_enable(self.h, int(on)), "orbhip_profile_enable", self.L)
 

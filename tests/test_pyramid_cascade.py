@@ -22,6 +22,10 @@ def test_cascade_planes_and_extraction(backend, oracle, monkeypatch, tile, w, h,
     ko, do = ora.extract(img)
     ex = orb_slam2_amd.ORBextractor(400, 1.2, nl, 20, 7, w, h, library=backend)
     kg, dg = ex(img)
+    if tile == "0":
+        assert ex.pyramid_cascade_tiles() == 0
+    elif tile in ("32x8", "16x4", "8x1"):              # (64x16 and 128x32 hold more table entries per workgroup than the kernel stages: those contexts take the level kernels)
+        assert ex.pyramid_cascade_tiles() > 0, "the cascade's tables failed their self-check"
     for l in range(nl):
         assert np.array_equal(ex.mvImagePyramid(l), ora.level(l)), f"pyramid level {l}"
     assert kg.tobytes() == ko.tobytes() and np.array_equal(dg, do)
@@ -49,6 +53,15 @@ def test_cascade_is_skipped_where_it_does_not_apply(backend, oracle):
     img = synth.frame(w, h, seed=5)
     ex = orb_slam2_amd.ORBextractor(300, 1.7, 3, 20, 7, w, h, library=backend)
     kg, dg = ex(img)
+    assert ex.pyramid_cascade_tiles() == 0
     ko, do = oracle.OracleExtractor(300, 1.7, 3, 20, 7).extract(img)
     assert kg.tobytes() == ko.tobytes() and np.array_equal(dg, do)
+    ex.close()
+
+
+@pytest.mark.parametrize("w,h,n", [(1241, 376, 2000), (752, 480, 1200), (640, 480, 1000), (1920, 1080, 4000)])
+def test_cascade_serves_the_baseline_shapes(emu_lib, w, h, n):
+    """BASELINE.json's four image shapes at scale 1.2 / 8 levels: the tables pass their self-check and the launch fits its LDS"""
+    ex = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, library=emu_lib)
+    assert ex.pyramid_cascade_tiles() > 0
     ex.close()
