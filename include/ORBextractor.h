@@ -123,7 +123,8 @@ public:
     // (stereo_euroc.cc:97-98).  ExtractRectified(raw, ..) == operator()(remap(raw), ..); mvImagePyramid[0] is the rectified image.
     void SetRectification(const cv::Mat& M1, const cv::Mat& M2, int rawCols, int rawRows);
     void ExtractRectified(const cv::Mat& raw, std::vector<cv::KeyPoint>& keypoints, cv::OutputArray descriptors);
-    // HIP device this extractor runs on (default: ORBHIP_DEVICE, else 0); SetDevice takes effect at the next (re)creation of the device context.
+    // HIP device this extractor runs on (default: ORBHIP_DEVICE, else 0); SetDevice takes effect at the next call: the context of another device is
+    // never reused (the ones kept for recently seen image sizes remember their device).
     void SetDevice(int device) { mnDevice = device; }
     int Device() const { return mnDevice; }
     // Which Frame the features in HBM belong to.  The forwarded Frame::UndistortKeyPoints (every Frame constructor calls it right after
@@ -158,11 +159,11 @@ protected:
     int mnLastN;                                                 // key points of the last image
     std::vector<cv::KeyPoint> mvLastKeys;                        // ... and the key points themselves (mvKeysUn of an undistorted camera)
     orbhip_ctx* mpCtx;          // device context for the current image size (created lazily at the first image of that size)
-    int mnCtxW, mnCtxH, mnCtxBatch, mnDevice, mnBlurRounding, mnFpContract;
+    int mnCtxW, mnCtxH, mnCtxBatch, mnCtxDevice, mnDevice, mnBlurRounding, mnFpContract;      // mnCtxDevice: where mpCtx lives; mnDevice: where the next one goes
     // The reference takes any image size per call (it re-allocates its pyramid every time, ORBextractor.cc:1043-1056, 1107-1132); a device context is
     // laid out for ONE size.  Contexts of the sizes seen recently are therefore kept (up to four, least recently used goes first): a caller that
     // alternates between sizes switches contexts in microseconds instead of paying a context creation (tens of milliseconds) per change.
-    struct CtxSlot { orbhip_ctx* ctx; int w, h, batch; unsigned settings, stamp; };
+    struct CtxSlot { orbhip_ctx* ctx; int w, h, batch, device; unsigned settings, stamp; };
     std::vector<CtxSlot> mvCtxCache; unsigned mnSettings, mnStamp;          // mnSettings counts SetBlurRounding / SetFpContract / SetCamera calls
     void ApplySettings(orbhip_ctx* ctx);
     std::vector<int> mvTicketSizes;                              // images per ticket in flight (Submit / Collect), by ticket mod 4

@@ -134,6 +134,7 @@ def _bind(L):
         L.orbslam_ref_search_by_sim3.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f, vp]
         L.orbslam_ref_tracking_loop.argtypes = [i, vp, vp, i, i, i, i, f, i, i, i, f, f, f, f, f, f, vp, vp, i, i]
         L.orbslam_ref_loop_get.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.orbslam_ref_concurrency.argtypes = [i, i, i, C.c_uint, i, vp, vp, i, i, i, i, f, i, i, i, f, f, f, f, f, f, vp, vp, i, vp, i, vp, i, vp, vp, vp, vp]
     return L
 
 
@@ -356,3 +357,89 @@ def tracking_loop(lefts, rights, Tcw, Tpred, nfeatures, fx, fy, cx, cy, bf, th_d
             L.orbslam_ref_loop_get(k, None, None, _p(fr.keys), _p(fr.keys_un), _p(fr.desc), _p(fr.u_right), _p(fr.depth), _p(fr.mp_motion), _p(fr.mp_final))
         out.append(fr)
     return out
+
+
+class ConcCall(C.Structure):
+    """one matcher call of orbslam_ref_concurrency (struct ConcCall in orbslam_ref_wrap.cpp)"""
+    _fields_ = [("fn", C.c_int32), ("i", C.c_int32 * 6), ("f", C.c_float * 2), ("p", C.c_void_p * 16)]
+
+
+class ConcCalls:
+    """A list of ConcCall that keeps every array it points to alive."""
+    FN = dict(triangulation=0, fuse=1, bow=2, sim3=3, projection_kf=4, compute_bow=5, fuse_sim3=6)
+
+    def __init__(self):
+        self.calls, self.keep = [], []
+
+    def _add(self, fn, ptrs, ints=(), floats=()):
+        c = ConcCall()
+        c.fn = self.FN[fn]
+        for k, v in enumerate(ints):
+            c.i[k] = int(v)
+        for k, v in enumerate(floats):
+            c.f[k] = float(v)
+        for k, v in enumerate(ptrs):
+            if isinstance(v, RefFrame):
+                c.p[k] = v.h
+            elif isinstance(v, bytes):
+                self.keep.append(v); c.p[k] = C.cast(C.c_char_p(v), C.c_void_p)
+            elif v is None:
+                c.p[k] = None
+            else:
+                self.keep.append(v); c.p[k] = v.ctypes.data
+        self.calls.append(c)
+
+    @staticmethod
+    def _fv(fv):
+        return [np.ascontiguousarray(fv[0], np.uint32), np.ascontiguousarray(fv[1], np.int32), np.ascontiguousarray(fv[2], np.uint32)]
+
+    def triangulation(self, f1, has1, fv1, f2, has2, fv2, F12, t2w, only_stereo=False, check_ori=True):
+        a1, a2 = self._fv(fv1), self._fv(fv2)
+        self._add("triangulation", [f1, _u8(has1, f1.N), *a1, f2, _u8(has2, f2.N), *a2, np.ascontiguousarray(F12, np.float32).reshape(9), np.ascontiguousarray(t2w, np.float32)],
+                  ints=(len(a1[0]), len(a2[0]), int(only_stereo), int(check_ori)))
+
+    def fuse(self, frame, kf_state, X, Y, Z, level, nobs, bad, desc, th=3.0):
+        nq = len(X)
+        self._add("fuse", [frame, _u8(kf_state, frame.N), _f32(X), _f32(Y), _f32(Z), np.ascontiguousarray(level, np.int32), np.ascontiguousarray(nobs, np.int32), _u8(bad, nq),
+                           np.ascontiguousarray(desc, np.uint8)], ints=(nq,), floats=(th,))
+
+    def bow(self, mode, f1, has1, bad1, fv1, f2, has2, bad2, fv2, nnratio=0.7, check_ori=True):
+        a1, a2 = self._fv(fv1), self._fv(fv2)
+        self._add("bow", [f1, _u8(has1, f1.N), _u8(bad1, f1.N), *a1, f2, _u8(has2, f2.N), _u8(bad2, f2.N), *a2], ints=(mode, len(a1[0]), len(a2[0]), int(check_ori)), floats=(nnratio,))
+
+    def sim3(self, f1, has1, X1, Y1, Z1, level1, desc1, f2, has2, X2, Y2, Z2, level2, desc2, already12=None, th=7.5):
+        al = np.full(f1.N, -1, np.int32) if already12 is None else np.ascontiguousarray(already12, np.int32)
+        self._add("sim3", [f1, _u8(has1, f1.N), _f32(X1), _f32(Y1), _f32(Z1), np.ascontiguousarray(level1, np.int32), np.ascontiguousarray(desc1, np.uint8),
+                           f2, _u8(has2, f2.N), _f32(X2), _f32(Y2), _f32(Z2), np.ascontiguousarray(level2, np.int32), np.ascontiguousarray(desc2, np.uint8), al], floats=(th,))
+
+    def projection_kf(self, frame, matched_state, X, Y, Z, level, bad, desc, th=10):
+        nq = len(X)
+        self._add("projection_kf", [frame, _u8(matched_state, frame.N), _f32(X), _f32(Y), _f32(Z), np.ascontiguousarray(level, np.int32), _u8(bad, nq), np.ascontiguousarray(desc, np.uint8)],
+                  ints=(nq, int(th)))
+
+    def compute_bow(self, frame, voc_path):
+        self._add("compute_bow", [frame, str(voc_path).encode() + b"\0"])
+
+    def fuse_sim3(self, frame, kf_state, X, Y, Z, level, bad, desc, th=4.0):
+        nq = len(X)
+        self._add("fuse_sim3", [frame, _u8(kf_state, frame.N), _f32(X), _f32(Y), _f32(Z), np.ascontiguousarray(level, np.int32), _u8(bad, nq), np.ascontiguousarray(desc, np.uint8)],
+                  ints=(nq,), floats=(th,))
+
+    def array(self):
+        return (ConcCall * max(len(self.calls), 1))(*self.calls)
+
+
+def concurrency(library, threaded, iters, t_rounds, seed, lefts, rights, Tcw, Tpred, nfeatures, fx, fy, cx, cy, bf, th_depth, lcalls, ccalls,
+                scale=1.2, nlevels=8, ini_th=20, min_th=7, kf_every=5):
+    """orbslam_ref_concurrency: Tracking's stereo loop, LocalMapping's and LoopClosing's matcher calls - one after another on this thread (threaded = False) or
+    on three threads at once.  -> (hashes of T's frames, of L's calls, of C's calls, T rounds run, T rounds that differed from the first)"""
+    n = len(lefts)
+    lefts = [np.ascontiguousarray(a, np.uint8) for a in lefts]; rights = [np.ascontiguousarray(a, np.uint8) for a in rights]
+    h, w = lefts[0].shape
+    lp = (C.c_void_p * n)(*[a.ctypes.data for a in lefts]); rp = (C.c_void_p * n)(*[a.ctypes.data for a in rights])
+    tc = np.ascontiguousarray(np.stack(Tcw), np.float32); tp = np.ascontiguousarray(np.stack(Tpred), np.float32)
+    hT = np.zeros(n, np.uint64); hL = np.zeros(iters, np.uint64); hC = np.zeros(iters, np.uint64); differing = C.c_int(0)
+    la, ca = lcalls.array(), ccalls.array()
+    rounds = library.orbslam_ref_concurrency(int(threaded), iters, t_rounds, seed, n, lp, rp, w, h, w, nfeatures, scale, nlevels, ini_th, min_th, fx, fy, cx, cy, bf, th_depth,
+                                             _p(tp), _p(tc), kf_every, la, len(lcalls.calls), ca, len(ccalls.calls), _p(hT), _p(hL), _p(hC), C.byref(differing))
+    return hT, hL, hC, rounds, differing.value

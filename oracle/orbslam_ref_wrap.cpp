@@ -17,6 +17,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
+#include <thread>
+#include <atomic>
 #include <set>
 #include <new>
 #include <string>
@@ -59,7 +62,10 @@ namespace { size_t g_used = 0; }
 namespace ORB_SLAM2 {
 long unsigned int MapPoint::nNextId = 0;
 std::mutex MapPoint::mGlobalMutex;
-static const uint8_t* g_next_desc = nullptr;          // descriptor handed to the next ComputeDistinctiveDescriptors()
+// The wrapper's own bookkeeping is per thread: orbslam_ref_concurrency below runs Tracking's, LocalMapping's and LoopClosing's matcher calls on three
+// threads at once, as ORB_SLAM2 does, and nothing of this test scaffolding may be what they share.
+static thread_local const uint8_t* g_next_desc = nullptr;          // descriptor handed to the next ComputeDistinctiveDescriptors()
+static thread_local long unsigned int tl_next_point_id = 0;        // MapPoint::mnId (the reference guards nNextId with the map's creation mutex, MapPoint.cc:42-44)
 MapPoint::MapPoint(const cv::Mat& Pos, KeyFrame* pRefKF, Map* pMap)
     : mnFirstKFid(0), mnFirstFrame(0), nObs(0), mTrackProjX(0), mTrackProjY(0), mTrackProjXR(0), mbTrackInView(false), mnTrackScaleLevel(0),
       mTrackViewCos(1.0f), mnTrackReferenceForFrame(0), mnLastFrameSeen(0), mnBALocalForKF(0), mnFuseCandidateForKF(0), mnLoopPointForKF(0),
@@ -68,7 +74,7 @@ MapPoint::MapPoint(const cv::Mat& Pos, KeyFrame* pRefKF, Map* pMap)
 {
     Pos.copyTo(mWorldPos);
     mNormalVector = cv::Mat(cv::Mat::zeros(3, 1, CV_32F));
-    mnId = nNextId++;
+    mnId = tl_next_point_id++;
 }
 // MapPoint(Pos, pMap, pFrame, idxF)  (MapPoint.cc:60-85, restated without the map's creation mutex): normal, scale-invariance range and
 // descriptor from the frame that observes the point — the constructor Tracking::UpdateLastFrame uses, and what UpdateNormalAndDepth +
@@ -91,9 +97,9 @@ MapPoint::MapPoint(const cv::Mat& Pos, Map* pMap, Frame* pFrame, const int& idxF
     mfMaxDistance = dist * levelScaleFactor;
     mfMinDistance = mfMaxDistance / pFrame->mvScaleFactors[nLevels - 1];
     pFrame->mDescriptors.row(idxF).copyTo(mDescriptor);
-    mnId = nNextId++;
+    mnId = tl_next_point_id++;
 }
-static bool g_real_predict_scale = false;             // the front-end loop below: MapPoint.cc:407-421 instead of a level handed in by the test
+static thread_local bool g_real_predict_scale = false;             // the front-end loop below: MapPoint.cc:407-421 instead of a level handed in by the test
 cv::Mat MapPoint::GetWorldPos() { return mWorldPos.clone(); }
 cv::Mat MapPoint::GetNormal() { return mNormalVector.clone(); }
 cv::Mat MapPoint::GetDescriptor() { return mDescriptor.clone(); }
@@ -106,7 +112,7 @@ float MapPoint::GetMaxDistanceInvariance() { return 1.2f * mfMaxDistance; }
 void MapPoint::AddObservation(KeyFrame* pKF, size_t idx) { mObservations[pKF] = idx; mnBALocalForKF = idx + 1; }   // also records where Fuse attached the point
 int MapPoint::GetIndexInKeyFrame(KeyFrame* pKF) { std::map<KeyFrame*, size_t>::iterator it = mObservations.find(pKF); return it == mObservations.end() ? -1 : (int)it->second; }
 bool MapPoint::IsInKeyFrame(KeyFrame*) { return false; }
-std::vector<std::pair<MapPoint*, MapPoint*> > g_replaced;             // (replaced, by): what Fuse decided for features that already had a point
+thread_local std::vector<std::pair<MapPoint*, MapPoint*> > g_replaced;             // (replaced, by): what Fuse decided for features that already had a point
 void MapPoint::Replace(MapPoint* pMP) { g_replaced.push_back(std::make_pair(this, pMP)); }
 // the level is handed in by the test (the real function is a log of the distance ratio, MapPoint.cc:393-421; not on this path)
 int MapPoint::PredictScale(const float&, KeyFrame*) { return mnTrackScaleLevel; }
@@ -135,7 +141,7 @@ void KeyFrame::SetPose(const cv::Mat& Tcw_)
     Ow = -Rwc * tcw;
     Twc = cv::Mat::eye(4, 4, CV_32F);
 }
-static std::map<const KeyFrame*, Frame*> g_kf_frame;
+static thread_local std::map<const KeyFrame*, Frame*> g_kf_frame;
 // KeyFrame.cc:569-608 is Frame::GetFeaturesInArea (Frame.cc:327-380) without the level filter on a copy of the same grid
 std::vector<size_t> KeyFrame::GetFeaturesInArea(const float& x, const float& y, const float& r) const { return g_kf_frame[this]->GetFeaturesInArea(x, y, r, -1, -1); }
 MapPoint* KeyFrame::GetMapPoint(const size_t& idx) { return mvpMapPoints[idx]; }
@@ -156,7 +162,7 @@ KeyFrame::KeyFrame(Frame& F, Map* pMap, KeyFrameDatabase* pKFDB)
       mvpMapPoints(F.mvpMapPoints), mpKeyFrameDB(pKFDB), mpORBvocabulary(F.mpORBvocabulary), mbFirstConnection(true), mpParent(NULL),
       mbNotErase(false), mbToBeErased(false), mbBad(false), mHalfBaseline(F.mb / 2), mpMap(pMap)
 {
-    mnId = nNextId++;
+    mnId = __atomic_fetch_add(&nNextId, 1, __ATOMIC_RELAXED);      // (KeyFrame.cc:46 increments it on the tracking thread only)
     g_kf_frame[this] = &F;
 }
 std::set<MapPoint*> KeyFrame::GetMapPoints() { std::set<MapPoint*> s; for (size_t i = 0; i < mvpMapPoints.size(); i++) if (mvpMapPoints[i] && !mvpMapPoints[i]->isBad()) s.insert(mvpMapPoints[i]); return s; }   // KeyFrame.cc:230-243
@@ -197,7 +203,7 @@ cv::Mat camera(float fx, float fy, float cx, float cy)
     K.at<float>(0, 0) = fx; K.at<float>(1, 1) = fy; K.at<float>(0, 2) = cx; K.at<float>(1, 2) = cy;
     return K;
 }
-std::vector<MapPoint*> g_keep;           // map points live as long as the process (the reference never frees them either)
+thread_local std::vector<MapPoint*> g_keep;   // map points live as long as the process (the reference never frees them either) - or until release_points()
 MapPoint* make_point(float x, float y, float z, const uint8_t* desc, int nobs, bool bad)
 {
     cv::Mat pos(3, 1, CV_32F); pos.at<float>(0) = x; pos.at<float>(1) = y; pos.at<float>(2) = z;
@@ -250,9 +256,14 @@ void* orbslam_ref_frame_rgbd(const uint8_t* img, const float* depth, int w, int 
 // in map order.  ORBVocabulary is whatever include/ORBVocabulary.h of the build says: the DBoW2 template (reference) or the drop-in class.
 int orbslam_ref_frame_compute_bow(void* fp, const char* voc_path, uint32_t* bow_id, double* bow_val, int* nbow, uint32_t* fv_node, int* fv_off, uint32_t* fv_feat, int* nfv)
 {
-    static std::map<std::string, ORBVocabulary*> vocs;
-    ORBVocabulary*& voc = vocs[voc_path];
-    if (!voc) { voc = new ORBVocabulary(); if (!voc->loadFromTextFile(voc_path)) { delete voc; voc = NULL; return -1; } }
+    static std::map<std::string, ORBVocabulary*> vocs; static std::mutex vocs_m;
+    ORBVocabulary* voc = NULL;
+    {   // one vocabulary per file for the whole process (System.cc:68 loads it once; Tracking, LocalMapping and LoopClosing share the pointer)
+        std::lock_guard<std::mutex> lock(vocs_m);
+        ORBVocabulary*& slot = vocs[voc_path];
+        if (!slot) { slot = new ORBVocabulary(); if (!slot->loadFromTextFile(voc_path)) { delete slot; slot = NULL; return -1; } }
+        voc = slot;
+    }
     Frame& F = *(Frame*)fp;
     F.mpORBvocabulary = voc; F.mBowVec.clear(); F.mFeatVec.clear();
     F.ComputeBoW();
@@ -644,13 +655,14 @@ static void ids_of(const Frame& F, std::vector<int>& out)
 
 // Runs nframes stereo pairs; capture != 0 keeps every frame's features and map-point assignments for orbslam_ref_loop_get (the copies are
 // made outside the timed span of each frame).  Returns the number of frames processed.
-int orbslam_ref_tracking_loop(int nframes, const uint8_t* const* left, const uint8_t* const* right, int w, int h, int stride,
+static int tracking_loop_impl(int nframes, const uint8_t* const* left, const uint8_t* const* right, int w, int h, int stride,
                               int nfeat, float scale, int nlevels, int ini, int mn, float fx, float fy, float cx, float cy, float bf, float thDepth,
-                              const float* Tpred /* nframes x 16 */, const float* Tcw /* nframes x 16 */, int kf_every, int capture)
+                              const float* Tpred /* nframes x 16 */, const float* Tcw /* nframes x 16 */, int kf_every, int capture, bool fresh_statics)
 {
     g_used = 0;
-    Frame::mbInitialComputations = true;
-    Frame::nNextId = 0; MapPoint::nNextId = 0;
+    // (not while other threads read Frame's static grid geometry: orbslam_ref_concurrency computes it once, before its threads start)
+    if (fresh_statics) { Frame::mbInitialComputations = true; Frame::nNextId = 0; }
+    MapPoint::nNextId = 0; ORB_SLAM2::tl_next_point_id = 0;
     ORB_SLAM2::g_real_predict_scale = true;
     cv::Mat K = camera(fx, fy, cx, cy), D = cv::Mat(cv::Mat::zeros(4, 1, CV_32F));
     Rig& rg = rig(nfeat, scale, nlevels, ini, mn);
@@ -724,6 +736,12 @@ int orbslam_ref_tracking_loop(int nframes, const uint8_t* const* left, const uin
     ORB_SLAM2::g_real_predict_scale = false;
     return nframes;
 }
+int orbslam_ref_tracking_loop(int nframes, const uint8_t* const* left, const uint8_t* const* right, int w, int h, int stride,
+                              int nfeat, float scale, int nlevels, int ini, int mn, float fx, float fy, float cx, float cy, float bf, float thDepth,
+                              const float* Tpred /* nframes x 16 */, const float* Tcw /* nframes x 16 */, int kf_every, int capture)
+{
+    return tracking_loop_impl(nframes, left, right, w, h, stride, nfeat, scale, nlevels, ini, mn, fx, fy, cx, cy, bf, thDepth, Tpred, Tcw, kf_every, capture, true);
+}
 // counts[8] = N, nMotion, usedWide, nToMatch, nLocal, nNewPoints, nLocalPoints, 0; every pointer may be NULL
 int orbslam_ref_loop_get(int k, int* counts, double* ms /* 4: frame, constructor, motion-model search, local-map search */, void* keys, void* keysUn, uint8_t* desc, float* uRight, float* depth, int* mpMotion, int* mpFinal)
 {
@@ -742,4 +760,116 @@ int orbslam_ref_loop_get(int k, int* counts, double* ms /* 4: frame, constructor
     return (int)n;
 }
 
+
+// ---- three threads, as ORB_SLAM2 runs them (the binding must be re-entrant from >= 3 threads) -------------------------------
+// Thread T: the stereo front-end loop above (Tracking).  Thread L: LocalMapping's matcher calls on key frames — SearchForTriangulation per
+// neighbour (LocalMapping.cc:237-268), Fuse per target (:483-514), KeyFrame::ComputeBoW (ProcessNewKeyFrame, :135).  Thread C: LoopClosing's —
+// SearchByBoW(KF, KF), SearchBySim3, SearchByProjection(KF, Scw, ...), Fuse(KF, Scw, ...) (LoopClosing.cc:239-375, 589-599).  All three run at
+// once on one device and one shared vocabulary; every result is reduced to a 64-bit hash (return value + the whole output array), iteration by
+// iteration, so that a run with mode = 1 (threads) can be compared with mode = 0 (the same calls one after another on the calling thread) and
+// with the all-reference build.  The Frames of L and C are made by the caller before the threads start and are not shared between threads
+// (the wrappers above write map points / feature vectors into them); nothing here is shared but the library under test.
+struct ConcCall {
+    int32_t fn;            // 0 SearchForTriangulation, 1 Fuse, 2 SearchByBoW, 3 SearchBySim3, 4 SearchByProjection(KF, Scw), 5 ComputeBoW, 6 Fuse(KF, Scw)
+    int32_t i[6];
+    float f[2];
+    const void* p[16];
+};
+static inline uint64_t fnv(uint64_t h, const void* data, size_t n) { const uint8_t* b = (const uint8_t*)data; for (size_t k = 0; k < n; k++) { h ^= b[k]; h *= 1099511628211ull; } return h; }
+static void release_points() { for (size_t k = 0; k < g_keep.size(); k++) delete g_keep[k]; g_keep.clear(); }
+int orbslam_ref_frame_compute_bow(void* fp, const char* voc_path, uint32_t* bow_id, double* bow_val, int* nbow, uint32_t* fv_node, int* fv_off, uint32_t* fv_feat, int* nfv);
+static uint64_t run_call(const ConcCall& c)
+{
+    uint64_t h = 1469598103934665603ull;
+    const void* const* p = c.p;
+    int ret = 0;
+    std::vector<int> out;
+    switch (c.fn) {
+    case 0: { Frame* f1 = (Frame*)p[0]; out.assign(f1->N, -1);
+        ret = orbslam_ref_search_for_triangulation((void*)p[0], (const uint8_t*)p[1], (const uint32_t*)p[2], (const int*)p[3], (const uint32_t*)p[4], c.i[0],
+                                                   (void*)p[5], (const uint8_t*)p[6], (const uint32_t*)p[7], (const int*)p[8], (const uint32_t*)p[9], c.i[1],
+                                                   (const float*)p[10], (const float*)p[11], c.i[2], c.i[3], out.data()); break; }
+    case 1: { out.assign(c.i[0], -1);
+        ret = orbslam_ref_fuse((void*)p[0], (const uint8_t*)p[1], c.i[0], (const float*)p[2], (const float*)p[3], (const float*)p[4], (const int*)p[5], (const int*)p[6],
+                               (const uint8_t*)p[7], (const uint8_t*)p[8], c.f[0], out.data()); break; }
+    case 2: { Frame* f1 = (Frame*)p[0]; out.assign(f1->N, -1);
+        ret = orbslam_ref_search_by_bow(c.i[0], (void*)p[0], (const uint8_t*)p[1], (const uint8_t*)p[2], (const uint32_t*)p[3], (const int*)p[4], (const uint32_t*)p[5], c.i[1],
+                                        (void*)p[6], (const uint8_t*)p[7], (const uint8_t*)p[8], (const uint32_t*)p[9], (const int*)p[10], (const uint32_t*)p[11], c.i[2],
+                                        c.f[0], c.i[3], out.data()); break; }
+    case 3: { Frame* f1 = (Frame*)p[0]; out.assign(f1->N, -1);
+        ret = orbslam_ref_search_by_sim3((void*)p[0], (const uint8_t*)p[1], (const float*)p[2], (const float*)p[3], (const float*)p[4], (const int*)p[5], (const uint8_t*)p[6],
+                                         (void*)p[7], (const uint8_t*)p[8], (const float*)p[9], (const float*)p[10], (const float*)p[11], (const int*)p[12], (const uint8_t*)p[13],
+                                         (const int*)p[14], c.f[0], out.data()); break; }
+    case 4: { Frame* f = (Frame*)p[0]; out.assign(f->N, -1);
+        ret = orbslam_ref_search_by_projection_kf((void*)p[0], (const uint8_t*)p[1], c.i[0], (const float*)p[2], (const float*)p[3], (const float*)p[4], (const int*)p[5],
+                                                  (const uint8_t*)p[6], (const uint8_t*)p[7], c.i[1], out.data()); break; }
+    case 5: { Frame* f = (Frame*)p[0]; const int n = std::max(f->N, 1);
+        std::vector<uint32_t> bid(n), fnode(n), ffeat(n); std::vector<double> bval(n); std::vector<int> foff(n + 1); int nb = 0, nf = 0;
+        ret = orbslam_ref_frame_compute_bow((void*)p[0], (const char*)p[1], bid.data(), bval.data(), &nb, fnode.data(), foff.data(), ffeat.data(), &nf);
+        h = fnv(h, &nb, 4); h = fnv(h, &nf, 4); h = fnv(h, bid.data(), (size_t)nb * 4); h = fnv(h, bval.data(), (size_t)nb * 8);
+        h = fnv(h, fnode.data(), (size_t)nf * 4); h = fnv(h, foff.data(), (size_t)(nf + 1) * 4); h = fnv(h, ffeat.data(), (size_t)foff[nf] * 4); break; }
+    case 6: { out.assign(c.i[0], -1);
+        ret = orbslam_ref_fuse_sim3((void*)p[0], (const uint8_t*)p[1], c.i[0], (const float*)p[2], (const float*)p[3], (const float*)p[4], (const int*)p[5],
+                                    (const uint8_t*)p[6], (const uint8_t*)p[7], c.f[0], out.data()); break; }
+    default: return 0;
+    }
+    h = fnv(h, &ret, 4);
+    if (!out.empty()) h = fnv(h, out.data(), out.size() * 4);
+    release_points();
+    return h;
+}
+static uint64_t hash_loop_frame(const LoopFrame& o)
+{
+    uint64_t h = 1469598103934665603ull;
+    const int cnt[7] = {o.N, o.nMotion, o.usedWide, o.nToMatch, o.nLocal, o.nNewPoints, o.nLocalPoints};
+    h = fnv(h, cnt, sizeof cnt);
+    if (!o.keys.empty()) { h = fnv(h, &o.keys[0], o.keys.size() * 28); h = fnv(h, &o.keysUn[0], o.keysUn.size() * 28); h = fnv(h, &o.desc[0], o.desc.size());
+                           h = fnv(h, &o.uRight[0], o.uRight.size() * 4); h = fnv(h, &o.depth[0], o.depth.size() * 4);
+                           h = fnv(h, &o.mpMotion[0], o.mpMotion.size() * 4); h = fnv(h, &o.mpFinal[0], o.mpFinal.size() * 4); }
+    return h;
+}
+// mode 0: T's loop once, then L's `iters` calls, then C's, on the calling thread.  mode 1: three threads; T repeats its loop until L and C are both
+// done (at least t_rounds times), every round must reproduce the first one (rounds_differing counts those that do not); the threads start after
+// random offsets and L / C pause a random few microseconds between calls (seed).  hashT[nframes], hashL[iters], hashC[iters] (call k % ncalls at
+// iteration k).  Returns the number of T rounds run, negative on an exception (what() goes to stderr).
+int orbslam_ref_concurrency(int mode, int iters, int t_rounds, unsigned seed,
+                            int nframes, const uint8_t* const* left, const uint8_t* const* right, int w, int h, int stride,
+                            int nfeat, float scale, int nlevels, int ini, int mn, float fx, float fy, float cx, float cy, float bf, float thDepth,
+                            const float* Tpred, const float* Tcw, int kf_every,
+                            const ConcCall* lcalls, int nl, const ConcCall* ccalls, int nc,
+                            uint64_t* hashT, uint64_t* hashL, uint64_t* hashC, int* rounds_differing)
+{
+    std::atomic<int> done(0), failed(0);
+    int rounds = 0, differing = 0;
+    auto pause = [](unsigned& st, unsigned max_us) { st = st * 1664525u + 1013904223u; if (max_us) std::this_thread::sleep_for(std::chrono::microseconds((st >> 8) % max_us)); };
+    auto t_body = [&](bool threaded) {
+        try {
+            unsigned st = seed * 2654435761u + 1; if (threaded) pause(st, 3000);
+            std::vector<uint64_t> first(nframes);
+            while (true) {
+                tracking_loop_impl(nframes, left, right, w, h, stride, nfeat, scale, nlevels, ini, mn, fx, fy, cx, cy, bf, thDepth, Tpred, Tcw, kf_every, 1, !threaded);
+                bool same = true;
+                for (int k = 0; k < nframes; k++) { const uint64_t hk = hash_loop_frame(g_loop[k]); if (rounds == 0) { first[k] = hk; hashT[k] = hk; } else if (hk != first[k]) same = false; }
+                if (!same) differing++;
+                rounds++;
+                release_points();
+                if (!threaded || (rounds >= t_rounds && done.load() >= 2) || failed.load()) break;
+            }
+        } catch (const std::exception& e) { fprintf(stderr, "orbslam_ref_concurrency, thread T: %s\n", e.what()); failed++; }
+    };
+    auto m_body = [&](const ConcCall* calls, int ncalls, uint64_t* out, unsigned salt, bool threaded) {
+        try {
+            unsigned st = seed * 40503u + salt; if (threaded) pause(st, 3000);
+            for (int k = 0; k < iters && !failed.load(); k++) { out[k] = ncalls > 0 ? run_call(calls[k % ncalls]) : 0; if (threaded) pause(st, 200); }
+        } catch (const std::exception& e) { fprintf(stderr, "orbslam_ref_concurrency, thread %s: %s\n", salt == 7 ? "L" : "C", e.what()); failed++; }
+        done++;
+    };
+    if (mode == 0) { t_body(false); m_body(lcalls, nl, hashL, 7, false); m_body(ccalls, nc, hashC, 13, false); }
+    else {
+        std::thread tt([&] { t_body(true); }), tl([&] { m_body(lcalls, nl, hashL, 7, true); }), tc([&] { m_body(ccalls, nc, hashC, 13, true); });
+        tt.join(); tl.join(); tc.join();
+    }
+    if (rounds_differing) *rounds_differing = differing;
+    return failed.load() ? -failed.load() : rounds;
+}
 }  // extern "C"

@@ -20,7 +20,7 @@ static_assert(sizeof(cv::KeyPoint) == sizeof(orbhip_keypoint), "cv::KeyPoint and
 ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST)
     : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST),
       mbHasCamera(false), mnRawCols(0), mnRawRows(0), mnLastN(0),
-      mpCtx(NULL), mnCtxW(0), mnCtxH(0), mnCtxBatch(0), mnDevice(0),
+      mpCtx(NULL), mnCtxW(0), mnCtxH(0), mnCtxBatch(0), mnCtxDevice(0), mnDevice(0),
 #if defined(__SSE2__) || defined(_M_X64)
       mnBlurRounding(1),          // an x86-64 OpenCV (<= 3.3) runs the SSE2 column filter: round-half-even on 4-column groups
 #else
@@ -31,7 +31,8 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int
 #else
       mnFpContract(0),
 #endif
-      mvTicketSizes(4, 0), mbDownloadPyramid(false), mnPendingTickets(0), mbFrameState(false), mfScaleFactorArg(_scaleFactor), mnBoundFrame(0), mbBound(false), mbStereoColumns(false), mnSettings(0), mnStamp(0)
+      mnSettings(0), mnStamp(0), mvTicketSizes(4, 0), mbDownloadPyramid(false), mnPendingTickets(0), mbFrameState(false), mfScaleFactorArg(_scaleFactor),
+      mnBoundFrame(0), mbBound(false), mbStereoColumns(false)
 {
     memset(mCamera, 0, sizeof mCamera);
     mvScaleFactor.resize(nlevels); mvLevelSigma2.resize(nlevels);
@@ -106,13 +107,19 @@ void ORBextractor::ApplySettings(orbhip_ctx* ctx)
 
 void ORBextractor::EnsureContext(int width, int height, int maxBatch)
 {
-    if (mpCtx && width == mnCtxW && height == mnCtxH && maxBatch <= mnCtxBatch) return;
+    if (mpCtx && width == mnCtxW && height == mnCtxH && maxBatch <= mnCtxBatch && mnCtxDevice == mnDevice) return;      // (SetDevice takes effect here)
     if (mpCtx && mnPendingTickets > 0)
         throw ORBhipError("ORBextractor: another device context is needed (image size or batch changed) while Submit()ed batches are still in flight: Collect them first");
     // the current context steps aside (its size may come back: a rig of two resolutions, a caller that crops) ...
     if (mpCtx) {
-        CtxSlot keep = {mpCtx, mnCtxW, mnCtxH, mnCtxBatch, mnSettings, ++mnStamp};
-        mvCtxCache.push_back(keep); mpCtx = NULL;
+        // ... unless nobody could ever take it back: the same size with a batch that only grew (every later call needs at least the new batch), or a
+        // context that carries rectification maps (such contexts are never looked up below)
+        const bool reusable = !(width == mnCtxW && height == mnCtxH && mnCtxDevice == mnDevice) && mvMapX.empty();
+        if (reusable) {
+            CtxSlot keep = {mpCtx, mnCtxW, mnCtxH, mnCtxBatch, mnCtxDevice, mnSettings, ++mnStamp};
+            mvCtxCache.push_back(keep);
+        } else orbhip_destroy(mpCtx);
+        mpCtx = NULL;
         if (mvCtxCache.size() > 3) {                                  // four contexts alive at most: the least recently used one goes
             size_t lru = 0;
             for (size_t i = 1; i < mvCtxCache.size(); i++) if (mvCtxCache[i].stamp < mvCtxCache[lru].stamp) lru = i;
@@ -120,12 +127,12 @@ void ORBextractor::EnsureContext(int width, int height, int maxBatch)
         }
     }
     mbFrameState = false; mbBound = false; mbStereoColumns = false; mnLastN = 0;      // whatever follows belongs to another context
-    // ... and one that was laid out for this size comes back (rectification maps belong to one size: such contexts are never shared)
+    // ... and one that was laid out for this size ON THIS DEVICE comes back (rectification maps belong to one size: such contexts are never shared)
     for (size_t i = 0; i < mvCtxCache.size() && mvMapX.empty(); i++) {
         const CtxSlot c = mvCtxCache[i];
-        if (c.w != width || c.h != height || c.batch < maxBatch) continue;
+        if (c.w != width || c.h != height || c.batch < maxBatch || c.device != mnDevice) continue;
         mvCtxCache.erase(mvCtxCache.begin() + i);
-        mpCtx = c.ctx; mnCtxW = c.w; mnCtxH = c.h; mnCtxBatch = c.batch;
+        mpCtx = c.ctx; mnCtxW = c.w; mnCtxH = c.h; mnCtxBatch = c.batch; mnCtxDevice = c.device;
         if (c.settings != mnSettings) ApplySettings(mpCtx);
         orbhip_get_scale_tables(mpCtx, &mvScaleFactor[0], &mvInvScaleFactor[0], &mvLevelSigma2[0], &mvInvLevelSigma2[0], &mnFeaturesPerLevel[0]);
         return;
@@ -135,7 +142,7 @@ void ORBextractor::EnsureContext(int width, int height, int maxBatch)
     cfg.width = width; cfg.height = height; cfg.max_batch = maxBatch; cfg.device = mnDevice; cfg.stream = NULL; cfg.blur_round_mode = mnBlurRounding; cfg.num_streams = 1;
     // the reference cannot fail here; a missing GPU or an unsupported geometry must not silently produce empty frames
     if (orbhip_create(&mpCtx, &cfg) != ORBHIP_OK) { mpCtx = NULL; Fail("ORBextractor"); }
-    mnCtxW = width; mnCtxH = height; mnCtxBatch = maxBatch;
+    mnCtxW = width; mnCtxH = height; mnCtxBatch = maxBatch; mnCtxDevice = mnDevice;
     if (orbhip_set_fp_contract(mpCtx, mnFpContract) != ORBHIP_OK) Fail("ORBextractor");
     if (mbHasCamera) {
         orbhip_camera cam; memcpy(&cam, mCamera, sizeof cam);

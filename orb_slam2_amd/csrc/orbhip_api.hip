@@ -140,23 +140,27 @@ static void prof_collect(orbhip_ctx* c)
 // ---------------------------------------------------------------------------------------------- creation
 template <typename T> static hipError_t dalloc(T** p, size_t count) { return orbhip_dmalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T)); }
 // Per-thread, grow-only device scratch for the host-pointer matcher entry points: one hipMalloc the first time (or when a call
-// needs more), none afterwards — hipMalloc / hipFree cost more than the kernels of a single-frame call.
-static thread_local void* g_scratch = nullptr; static thread_local size_t g_scratch_bytes = 0; static thread_local int g_scratch_dev = -1;
-struct Xfer { size_t off; const void* src; void* dst; size_t bytes_in, bytes_out; };
-static thread_local std::vector<Xfer> g_xfers;               // host <-> arena transfers of the call being laid out
-struct Arena {
-    uint8_t* base = nullptr; size_t off = 0;
-    template <typename T> void take(T** p, size_t count) { *p = reinterpret_cast<T*>(base + off); off += (std::max<size_t>(count, 1) * sizeof(T) + 255) & ~(size_t)255; }
-    // a buffer with a host side: n_in elements are uploaded from src before the kernels, n_out elements downloaded to dst after them.
-    // Take every such buffer before the pure scratch ones so that all of them travel in ONE copy each way (arena_upload / arena_download).
-    template <typename T> void io(T** p, size_t count, const T* src, size_t n_in, T* dst = nullptr, size_t n_out = 0)
-    {
-        const size_t o = off;
-        take(p, count);
-        if (base && ((src && n_in) || (dst && n_out))) g_xfers.push_back(Xfer{o, src && n_in ? src : nullptr, dst && n_out ? dst : nullptr, n_in * sizeof(T), n_out * sizeof(T)});
-    }
-};
+// needs more), none afterwards — hipMalloc / hipFree cost more than the kernels of a single-frame call.  (Arena: orbhip_internal.h)
+thread_local void* orbhip_tl_scratch = nullptr; thread_local size_t orbhip_tl_scratch_bytes = 0; thread_local int orbhip_tl_scratch_dev = -1;
+thread_local std::vector<OrbXfer> orbhip_tl_xfers;           // host <-> arena transfers of the call being laid out
+#define g_scratch orbhip_tl_scratch
+#define g_scratch_bytes orbhip_tl_scratch_bytes
+#define g_scratch_dev orbhip_tl_scratch_dev
+#define g_xfers orbhip_tl_xfers
+typedef OrbXfer Xfer;
 static thread_local uint8_t* g_hstage = nullptr; static thread_local size_t g_hstage_bytes = 0;      // pinned mirror of the arena's host-visible head
+// The stream of the calling thread's stateless matcher calls: its own, non-blocking.  (They used to share the NULL stream: Tracking's, LocalMapping's
+// and LoopClosing's calls then queue behind each other on the device and every hipStreamSynchronize waits for all three.)
+static thread_local hipStream_t g_tstream = nullptr; static thread_local int g_tstream_dev = -1;
+hipStream_t orbhip_thread_stream(int device)
+{
+    orbhip_touch_thread_caches();
+    if (g_tstream && g_tstream_dev == device) return g_tstream;
+    if (g_tstream) { (void)hipSetDevice(g_tstream_dev); (void)hipStreamSynchronize(g_tstream); (void)hipStreamDestroy(g_tstream); g_tstream = nullptr; (void)hipSetDevice(device); }
+    if (hipStreamCreateWithFlags(&g_tstream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); g_tstream = nullptr; g_tstream_dev = -1; return nullptr; }   // the NULL stream still works
+    g_tstream_dev = device;
+    return g_tstream;
+}
 static hipError_t hstage_reserve(size_t bytes)
 {
     orbhip_touch_thread_caches();
@@ -176,6 +180,8 @@ extern "C" void orbhip_thread_release(void)
     int cur = -1; (void)hipGetDevice(&cur);
     if (g_scratch) { (void)hipSetDevice(g_scratch_dev); (void)hipDeviceSynchronize(); (void)hipFree(g_scratch); }
     g_scratch = nullptr; g_scratch_bytes = 0; g_scratch_dev = -1;
+    if (g_tstream) { (void)hipSetDevice(g_tstream_dev); (void)hipStreamSynchronize(g_tstream); (void)hipStreamDestroy(g_tstream); }
+    g_tstream = nullptr; g_tstream_dev = -1;
     if (g_hstage) (void)hipHostFree(g_hstage);
     g_hstage = nullptr; g_hstage_bytes = 0;
     if (g_nn_ws) { (void)hipSetDevice(g_nn_ws_dev); (void)hipDeviceSynchronize(); (void)hipFree(g_nn_ws); }
@@ -192,7 +198,7 @@ void orbhip_touch_thread_caches() { (void)&g_cache_holder; }
 
 // One pageable->pinned gather on the host and ONE host-to-device copy for all inputs of a call (a hipMemcpy per array costs more
 // than the kernels of a single-frame matcher call); likewise one device-to-host copy for all outputs.
-static hipError_t arena_upload(hipStream_t s)
+hipError_t arena_upload(hipStream_t s)
 {
     size_t hi = 0;
     for (const Xfer& x : g_xfers) hi = std::max(hi, x.off + std::max(x.bytes_in, x.bytes_out));
@@ -201,7 +207,7 @@ static hipError_t arena_upload(hipStream_t s)
     for (const Xfer& x : g_xfers) if (x.src) { memcpy(g_hstage + x.off, x.src, x.bytes_in); in_hi = std::max(in_hi, x.off + x.bytes_in); }
     return in_hi ? orbhip_copy_async(g_scratch, g_hstage, in_hi, hipMemcpyHostToDevice, s) : hipSuccess;
 }
-static hipError_t arena_download(hipStream_t s)
+hipError_t arena_download(hipStream_t s)
 {
     size_t lo = (size_t)-1, hi = 0;
     for (const Xfer& x : g_xfers) if (x.dst) { lo = std::min(lo, x.off); hi = std::max(hi, x.off + x.bytes_out); }
@@ -211,18 +217,15 @@ static hipError_t arena_download(hipStream_t s)
     for (const Xfer& x : g_xfers) if (x.dst) memcpy(x.dst, g_hstage + x.off, x.bytes_out);
     return hipSuccess;
 }
-template <typename Layout> static hipError_t arena_layout(int device, Layout layout)
+hipError_t orbhip_arena_reserve(int device, size_t bytes)
 {
-    g_xfers.clear();
-    Arena dry; layout(dry);                                   // first pass: sizes only (no base: nothing is logged)
-    if (g_scratch_dev != device || g_scratch_bytes < dry.off) {
-        if (g_scratch) (void)hipFree(g_scratch);
+    if (g_scratch_dev != device || g_scratch_bytes < bytes) {
+        if (g_scratch) { (void)hipSetDevice(g_scratch_dev); (void)hipFree(g_scratch); (void)hipSetDevice(device); }
         g_scratch = nullptr; g_scratch_bytes = 0;
-        const hipError_t e = orbhip_dmalloc(&g_scratch, dry.off + dry.off / 4);
+        const hipError_t e = orbhip_dmalloc(&g_scratch, bytes + bytes / 4);
         if (e != hipSuccess) return e;
-        g_scratch_bytes = dry.off + dry.off / 4; g_scratch_dev = device;
+        g_scratch_bytes = bytes + bytes / 4; g_scratch_dev = device;
     }
-    Arena real; real.base = static_cast<uint8_t*>(g_scratch); layout(real);
     return hipSuccess;
 }
 template <typename T> static hipError_t upload(T** p, const std::vector<T>& v)
@@ -863,8 +866,34 @@ int orbhip_device_numa_node(int device)
     return node;
 }
 static thread_local int tl_numa_node = -1;      // node the calling thread was bound to by orbhip_bind_thread_to_node (-1: not bound)
+// the CPUs this process may use, as they were when the library was loaded (taskset / numactl / a cpuset): what an unbound helper thread goes back to
+// (it must not inherit the affinity of whichever bound worker happened to create it), and what a node binding never widens
+static cpu_set_t g_process_cpus; static const bool g_have_process_cpus = sched_getaffinity(0, sizeof g_process_cpus, &g_process_cpus) == 0;
+// "0-63,128-191" -> CPU set; no shared parser state (pool workers and copy helpers come through here at the same moment)
+int orbhip_parse_cpulist(const char* text, cpu_set_t* set)
+{
+    CPU_ZERO(set);
+    int ncpu = 0;
+    for (const char* p = text; *p;) {
+        if (*p < '0' || *p > '9') { p++; continue; }
+        char* end = nullptr;
+        long a = strtol(p, &end, 10), b = a;
+        if (*end == '-' && end[1] >= '0' && end[1] <= '9') b = strtol(end + 1, &end, 10);
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++) if (!CPU_ISSET((int)c, set)) { CPU_SET((int)c, set); ncpu++; }
+        p = end;
+    }
+    return ncpu;
+}
+#ifdef ORBHIP_TEST_HOOKS      // the CPU emulation build only: the parser alone (tests/test_host_pipeline.py calls it from several threads at once)
+extern "C" int orbhip_test_parse_cpulist(const char* text, int* cpus, int cap)
+{
+    cpu_set_t set; const int n = orbhip_parse_cpulist(text, &set);
+    for (int c = 0, k = 0; c < CPU_SETSIZE && k < cap; c++) if (CPU_ISSET(c, &set)) cpus[k++] = c;
+    return n;
+}
+#endif
 bool orbhip_bind_thread_to_node(int node)
-{   // /sys/devices/system/node/node<N>/cpulist: "0-63,128-191"
+{   // /sys/devices/system/node/node<N>/cpulist
     if (node < 0) return false;
     char path[128]; snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
     FILE* f = fopen(path, "r");
@@ -873,24 +902,18 @@ bool orbhip_bind_thread_to_node(int node)
     const bool got = fgets(buf, sizeof buf, f) != nullptr;
     fclose(f);
     if (!got) return false;
-    cpu_set_t set; CPU_ZERO(&set);
-    int ncpu = 0;
-    for (char* tok = strtok(buf, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
-        int a = 0, b = 0;
-        const int k = sscanf(tok, "%d-%d", &a, &b);
-        if (k < 1) continue;
-        if (k == 1) b = a;
-        for (int c = a; c <= b && c < CPU_SETSIZE; c++) { CPU_SET(c, &set); ncpu++; }
+    cpu_set_t set;
+    int ncpu = orbhip_parse_cpulist(buf, &set);
+    if (g_have_process_cpus) {                                   // never beyond what the user allowed this process (taskset, numactl --physcpubind)
+        ncpu = 0;
+        for (int c = 0; c < CPU_SETSIZE; c++) { if (CPU_ISSET(c, &set) && !CPU_ISSET(c, &g_process_cpus)) CPU_CLR(c, &set); if (CPU_ISSET(c, &set)) ncpu++; }
     }
-    const bool ok = ncpu > 0 && sched_setaffinity(0, sizeof set, &set) == 0;
+    const bool ok = ncpu > 0 && sched_setaffinity(0, sizeof set, &set) == 0;      // an empty intersection: the thread stays where the user put it
     if (ok) tl_numa_node = node;
     return ok;
 }
 
 namespace {
-// the CPUs this process may use, as they were when the library was loaded: what an unbound helper thread goes back to (it must not inherit the
-// affinity of whichever bound worker happened to create it)
-static cpu_set_t g_process_cpus; static const bool g_have_process_cpus = sched_getaffinity(0, sizeof g_process_cpus, &g_process_cpus) == 0;
 struct CopyJob { std::atomic<int> next{0}, done{0}; int n = 0; std::function<void(int)> fn; };
 class CopyPool {
     std::mutex m; std::condition_variable cv; std::deque<std::shared_ptr<CopyJob>> q; int nthreads = 0;
@@ -1375,6 +1398,7 @@ extern "C" orbhip_status orbhip_search_by_projection_bounds(int device, const or
     if (orbhip_proj_select_lds(n) > 150 * 1024) return fail(ORBHIP_ERR_UNSUPPORTED, "too many features for the LDS matcher (%d)", n);
     int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(ORBHIP_ERR_HIP, "no HIP device available: no CPU fallback");
     HIPCHK(hipSetDevice(device));
+    hipStream_t ts = orbhip_thread_stream(device);
     orbhip_keypoint* dk = nullptr; uint8_t *dd = nullptr, *dqd = nullptr; unsigned char *dbl_in = nullptr; float* dur = nullptr; int *dn = nullptr, *dgs = nullptr, *dgi = nullptr, *dnc = nullptr, *dfq = nullptr, *dev = nullptr;
     float2* dgxy = nullptr; orbhip_proj_query* dq = nullptr; unsigned* dcand = nullptr; unsigned* dtop = nullptr;
     hipError_t e = hipSuccess;
@@ -1389,21 +1413,21 @@ extern "C" orbhip_status orbhip_search_by_projection_bounds(int device, const or
         A.take(&dgs, ORBHIP_GRID_CELLS + 1); A.take(&dgi, n); A.take(&dgxy, n); A.take(&dnc, nq); A.take(&dev, nq);
         A.take(&dcand, (size_t)nq * n); A.take(&dtop, (size_t)nq * 5);
     }));
-    TRY(arena_upload(nullptr));
+    TRY(arena_upload(ts));
     if (e == hipSuccess) {
         MatchParams M; memset(&M, 0, sizeof M);
         M.kp2 = dk; M.n2 = dn; M.cap = n; M.min_x = bounds->min_x; M.min_y = bounds->min_y; M.max_x = bounds->max_x; M.max_y = bounds->max_y; M.grid_start = dgs; M.grid_items = dgi; M.grid_xy = dgxy; M.grid_all_levels = 1;
-        orbhip_launch_match_grid(M, 1, nullptr);
+        orbhip_launch_match_grid(M, 1, ts);
         ProjParams J; memset(&J, 0, sizeof J);
         J.kp = dk; J.desc = dd; J.u_right = dur; J.n = n; J.min_x = bounds->min_x; J.min_y = bounds->min_y; J.max_x = bounds->max_x; J.max_y = bounds->max_y; J.grid_start = dgs; J.grid_items = dgi; J.grid_xy = dgxy;
         J.q = dq; J.qdesc = dqd; J.nq = nq; J.cand = dcand; J.ncand = dnc; J.cand_stride = n; J.top = dtop;
         J.blocked_in = dbl_in; J.blocked_out = nullptr; J.feature_query = dfq; J.nmatches = dn + 1; J.events = dev;
         J.mode = mode; J.nnratio = nnratio; J.th_high = th_high; J.check_ori = check_ori;
-        orbhip_launch_proj(J, nullptr);
+        orbhip_launch_proj(J, ts);
         e = hipGetLastError();
     }
-    TRY(arena_download(nullptr));
-    if (e != hipSuccess) (void)hipStreamSynchronize(nullptr);            // never leave a copy in flight on the per-thread mirrors
+    TRY(arena_download(ts));
+    if (e != hipSuccess) (void)hipStreamSynchronize(ts);            // never leave a copy in flight on the per-thread mirrors
     if (e == hipSuccess) *nmatches = hres[1];
 #undef TRY
     orbhip_status st = ORBHIP_OK;
@@ -1433,6 +1457,7 @@ extern "C" orbhip_status orbhip_search_by_projection_batch(int device, int nslot
     if ((size_t)nslots * qcap * cap * sizeof(unsigned) > ((size_t)2 << 30)) return fail(ORBHIP_ERR_UNSUPPORTED, "candidate lists of %d slots x %d queries x %d features exceed 2 GB: split the batch", nslots, qcap, cap);
     int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(ORBHIP_ERR_HIP, "no HIP device available: no CPU fallback");
     HIPCHK(hipSetDevice(device));
+    hipStream_t ts = orbhip_thread_stream(device);
     orbhip_keypoint* dk = nullptr; uint8_t *dd = nullptr, *dqd = nullptr; unsigned char* dbl = nullptr; float* dur = nullptr; int *dn = nullptr, *dnm = nullptr, *dgs = nullptr, *dgi = nullptr, *dnc = nullptr, *dfq = nullptr, *dev = nullptr;
     float2* dgxy = nullptr; orbhip_proj_query* dq = nullptr; unsigned *dcand = nullptr, *dtop = nullptr; ProjParams* dJ = nullptr;
     std::vector<int> hn(nslots), hnm(nslots, 0); std::vector<ProjParams> hJ(nslots);
@@ -1468,21 +1493,21 @@ extern "C" orbhip_status orbhip_search_by_projection_batch(int device, int nslot
             J.mode = mode; J.nnratio = nnratio; J.th_high = th_high; J.check_ori = check_ori;
         }
     }
-    TRY(arena_upload(nullptr));
+    TRY(arena_upload(ts));
     if (e == hipSuccess) {
         // Frame::AssignFeaturesToGrid of every slot: the grid kernel indexes [slot][stride]
         for (int s = 0; s < nslots; s++) {
             MatchParams M; memset(&M, 0, sizeof M);
             M.kp2 = hJ[s].kp; M.n2 = dn + s; M.cap = cap; M.min_x = bounds->min_x; M.min_y = bounds->min_y; M.max_x = bounds->max_x; M.max_y = bounds->max_y;
             M.grid_start = dgs + (size_t)s * (ORBHIP_GRID_CELLS + 1); M.grid_items = dgi + s * C; M.grid_xy = dgxy + s * C; M.grid_all_levels = 1;
-            orbhip_launch_match_grid(M, 1, nullptr);
+            orbhip_launch_match_grid(M, 1, ts);
         }
         const float gwInv = (float)ORBHIP_GRID_COLS / (bounds->max_x - bounds->min_x), ghInv = (float)ORBHIP_GRID_ROWS / (bounds->max_y - bounds->min_y);
-        orbhip_launch_proj_batch(dJ, nslots, qcap, cap, gwInv, ghInv, nullptr);
+        orbhip_launch_proj_batch(dJ, nslots, qcap, cap, gwInv, ghInv, ts);
         e = hipGetLastError();
     }
-    TRY(arena_download(nullptr));
-    if (e != hipSuccess) (void)hipStreamSynchronize(nullptr);            // never leave a copy in flight on the per-thread mirrors
+    TRY(arena_download(ts));
+    if (e != hipSuccess) (void)hipStreamSynchronize(ts);            // never leave a copy in flight on the per-thread mirrors
 #undef TRY
     if (e != hipSuccess) return fail(ORBHIP_ERR_HIP, "search_by_projection_batch: %s", hipGetErrorString(e));
     for (int s = 0; s < nslots; s++) slots[s].nmatches = hnm[s];
@@ -1499,6 +1524,7 @@ extern "C" orbhip_status orbhip_search_best_in_window_bounds(int device, const o
     if (n == 0 || nq == 0) return ORBHIP_OK;
     int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(ORBHIP_ERR_HIP, "no HIP device available: no CPU fallback");
     HIPCHK(hipSetDevice(device));
+    hipStream_t ts = orbhip_thread_stream(device);
     orbhip_keypoint* dk = nullptr; uint8_t *dd = nullptr, *dqd = nullptr; float *dur = nullptr, *dsg = nullptr; int *dn = nullptr, *dgs = nullptr, *dgi = nullptr, *dbi = nullptr, *dbd = nullptr;
     float2* dgxy = nullptr; orbhip_best_query* dq = nullptr;
     hipError_t e = hipSuccess;
@@ -1511,20 +1537,20 @@ extern "C" orbhip_status orbhip_search_best_in_window_bounds(int device, const o
         A.io(&dbi, nq, (const int*)nullptr, 0, best_idx, nq); A.io(&dbd, nq, (const int*)nullptr, 0, best_dist, nq);
         A.take(&dgs, ORBHIP_GRID_CELLS + 1); A.take(&dgi, n); A.take(&dgxy, n);
     }));
-    TRY(arena_upload(nullptr));
+    TRY(arena_upload(ts));
     if (e == hipSuccess) {
         MatchParams M; memset(&M, 0, sizeof M);
         M.kp2 = dk; M.n2 = dn; M.cap = n; M.min_x = bounds->min_x; M.min_y = bounds->min_y; M.max_x = bounds->max_x; M.max_y = bounds->max_y; M.grid_start = dgs; M.grid_items = dgi; M.grid_xy = dgxy; M.grid_all_levels = 1;
-        orbhip_launch_match_grid(M, 1, nullptr);
+        orbhip_launch_match_grid(M, 1, ts);
         BestParams B; memset(&B, 0, sizeof B);
         B.kp = dk; B.desc = dd; B.u_right = dur; B.inv_level_sigma2 = dsg; B.grid_start = dgs; B.grid_items = dgi; B.grid_xy = dgxy;
         B.q = dq; B.qdesc = dqd; B.nq = nq; B.chi2_gate = chi2_gate; B.best_idx = dbi; B.best_dist = dbd;
         B.min_x = bounds->min_x; B.gw_inv = (float)ORBHIP_GRID_COLS / (float)(bounds->max_x - bounds->min_x);      // as orbhip_launch_match_grid lays the grid out
-        orbhip_launch_best_in_window(B, nullptr);
+        orbhip_launch_best_in_window(B, ts);
         e = hipGetLastError();
     }
-    TRY(arena_download(nullptr));
-    if (e != hipSuccess) (void)hipStreamSynchronize(nullptr);            // never leave a copy in flight on the per-thread mirrors
+    TRY(arena_download(ts));
+    if (e != hipSuccess) (void)hipStreamSynchronize(ts);            // never leave a copy in flight on the per-thread mirrors
 #undef TRY
     orbhip_status st = ORBHIP_OK;
     if (e != hipSuccess) st = fail(ORBHIP_ERR_HIP, "search_best_in_window: %s", hipGetErrorString(e));
@@ -1747,13 +1773,14 @@ extern "C" orbhip_status orbhip_undistort_points(int device, const orbhip_camera
     if (n == 0) return ORBHIP_OK;
     int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(ORBHIP_ERR_HIP, "no HIP device available: no CPU fallback");
     HIPCHK(hipSetDevice(device));
+    hipStream_t ts = orbhip_thread_stream(device);
     float *din = nullptr, *dout = nullptr;
     HIPCHK(arena_layout(device, [&](Arena& A) { A.take(&din, (size_t)n * 2); A.take(&dout, (size_t)n * 2); }));
-    HIPCHK(hipMemcpyAsync(din, xy, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, nullptr));
-    orbhip_launch_undistort_points(widen(*cam), din, n, dout, nullptr);
+    HIPCHK(hipMemcpyAsync(din, xy, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, ts));
+    orbhip_launch_undistort_points(widen(*cam), din, n, dout, ts);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(xy_out, dout, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost, nullptr));
-    HIPCHK(hipStreamSynchronize(nullptr));
+    HIPCHK(hipMemcpyAsync(xy_out, dout, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost, ts));
+    HIPCHK(hipStreamSynchronize(ts));
     return ORBHIP_OK;
 }
 extern "C" orbhip_status orbhip_image_bounds(int device, const orbhip_camera* cam, int im_w, int im_h, orbhip_bounds* out)
@@ -1982,6 +2009,7 @@ extern "C" orbhip_status orbhip_search_for_initialization_bounds(int device, con
     if (n1 == 0) return ORBHIP_OK;
     int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(ORBHIP_ERR_HIP, "no HIP device available: no CPU fallback");
     HIPCHK(hipSetDevice(device));
+    hipStream_t ts = orbhip_thread_stream(device);
     // Frame members flattened: level-0 keypoints of F1 in index order (the loop at ORBmatcher.cc:418-423 skips the rest)
     std::vector<int> list1; for (int i = 0; i < n1; i++) if (kps1[i].octave <= 0) list1.push_back(i);
     int n2l0 = 0; for (int i = 0; i < n2; i++) n2l0 += kps2[i].octave == 0;
@@ -2001,17 +2029,17 @@ extern "C" orbhip_status orbhip_search_for_initialization_bounds(int device, con
         A.take(&dgs, ORBHIP_GRID_CELLS + 1); A.take(&dgi, cap); A.take(&dgxy, cap); A.take(&dnc, l0cap);
         A.take(&dcand, (size_t)l0cap * cstride); A.take(&dtop, (size_t)l0cap * 5);
     }));
-    TRY(arena_upload(nullptr));
+    TRY(arena_upload(ts));
     if (e == hipSuccess) {
         MatchParams M; memset(&M, 0, sizeof M);
         M.kp1 = dk1; M.desc1 = dd1; M.n1 = dn; M.n1_lvl0 = dn + 2; M.kp2 = dk2; M.desc2 = dd2; M.n2 = dn + 1; M.lvl_stride = 0; M.list1 = dlist; M.prev_from_kp1 = 0;
         M.cap = cap; M.min_x = bounds->min_x; M.min_y = bounds->min_y; M.max_x = bounds->max_x; M.max_y = bounds->max_y; M.grid_start = dgs; M.grid_items = dgi; M.grid_xy = dgxy; M.cand = dcand; M.top = dtop; M.ncand = dnc; M.cand_stride = cstride; M.lvl0_cap = l0cap;
         M.prev = dprev; M.matches12 = dm12; M.nmatches = dn + 3; M.window = window; M.nnratio = nnratio; M.check_ori = check_ori;
-        orbhip_launch_match_grid(M, 1, nullptr); orbhip_launch_match_candidates(M, 1, nullptr); orbhip_launch_match_select(M, 1, nullptr);
+        orbhip_launch_match_grid(M, 1, ts); orbhip_launch_match_candidates(M, 1, ts); orbhip_launch_match_select(M, 1, ts);
         e = hipGetLastError();
     }
-    TRY(arena_download(nullptr));
-    if (e != hipSuccess) (void)hipStreamSynchronize(nullptr);            // never leave a copy in flight on the per-thread mirrors
+    TRY(arena_download(ts));
+    if (e != hipSuccess) (void)hipStreamSynchronize(ts);            // never leave a copy in flight on the per-thread mirrors
     if (e == hipSuccess) *nmatches = hres[3];
 #undef TRY
     orbhip_status st = ORBHIP_OK;

@@ -667,10 +667,10 @@ extern "C" double orbhip_voc_score(const orbhip_voc* v, const uint32_t* id1, con
     }
 }
 
-static thread_local void* g_bm_ws = nullptr; static thread_local size_t g_bm_ws_bytes = 0; static thread_local int g_bm_dev = -1;
-void orbhip_bow_thread_release() { if (g_bm_ws) { (void)hipSetDevice(g_bm_dev); (void)hipDeviceSynchronize(); (void)hipFree(g_bm_ws); } g_bm_ws = nullptr; g_bm_ws_bytes = 0; g_bm_dev = -1; }
+void orbhip_bow_thread_release() {}      // (the two matchers below live in the calling thread's arena, orbhip_internal.h: nothing of their own to give back)
 
-// ORBmatcher::SearchByBoW on flat data; see include/orbhip.h
+// ORBmatcher::SearchByBoW on flat data; see include/orbhip.h.  Every array of the call is one block of the thread's arena: ONE copy up (the -1 / 0
+// initial values of the outputs included), two launches, ONE copy down, on the thread's own stream.
 extern "C" orbhip_status orbhip_search_by_bow(int device, int mode,
     const uint8_t* desc1, const float* angle1, const uint8_t* valid1, int n1, const uint32_t* fv1_node, const int32_t* fv1_off, const uint32_t* fv1_feat, int nfv1,
     const uint8_t* desc2, const float* angle2, const uint8_t* valid2, int n2, const uint32_t* fv2_node, const int32_t* fv2_off, const uint32_t* fv2_feat, int nfv2,
@@ -683,42 +683,37 @@ extern "C" orbhip_status orbhip_search_by_bow(int device, int mode,
     if (!desc1 || !desc2 || !angle1 || !angle2 || !valid1 || !fv1_node || !fv1_off || !fv1_feat || !fv2_node || !fv2_off || !fv2_feat || (mode == 1 && !valid2))
         return orbhip_set_error(ORBHIP_ERR_INVALID, "null argument");
     BOWCHK(hipSetDevice(device));
+    hipStream_t ts = orbhip_thread_stream(device);
     const int m1 = fv1_off[nfv1], m2 = fv2_off[nfv2];
-    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t sz[] = {al((size_t)n1 * 32), al((size_t)n1 * 4), al((size_t)n1), al((size_t)nfv1 * 4), al((size_t)(nfv1 + 1) * 4), al((size_t)std::max(m1, 1) * 4),
-                         al((size_t)n2 * 32), al((size_t)n2 * 4), al((size_t)n2), al((size_t)nfv2 * 4), al((size_t)(nfv2 + 1) * 4), al((size_t)std::max(m2, 1) * 4),
-                         al((size_t)n1 * 4), al((size_t)n1 * 4), al((ORBHIP_HISTO_LENGTH + 2) * 4)};
-    size_t total = 0; for (size_t b : sz) total += b;
-    orbhip_touch_thread_caches();
-    if (g_bm_dev != device || g_bm_ws_bytes < total) {
-        if (g_bm_ws) (void)hipFree(g_bm_ws);
-        g_bm_ws = nullptr; g_bm_ws_bytes = 0;
-        BOWCHK(orbhip_dmalloc(&g_bm_ws, total)); g_bm_ws_bytes = total; g_bm_dev = device;
-    }
-    uint8_t* base = (uint8_t*)g_bm_ws; uint8_t* p[15]; { size_t o = 0; for (int i = 0; i < 15; i++) { p[i] = base + o; o += sz[i]; } }
     std::vector<uint8_t> ones;
     if (!valid2) { ones.assign(n2, 1); valid2 = ones.data(); }
-    const void* src[12] = {desc1, angle1, valid1, fv1_node, fv1_off, fv1_feat, desc2, angle2, valid2, fv2_node, fv2_off, fv2_feat};
-    const size_t nb[12] = {(size_t)n1 * 32, (size_t)n1 * 4, (size_t)n1, (size_t)nfv1 * 4, (size_t)(nfv1 + 1) * 4, (size_t)m1 * 4,
-                           (size_t)n2 * 32, (size_t)n2 * 4, (size_t)n2, (size_t)nfv2 * 4, (size_t)(nfv2 + 1) * 4, (size_t)m2 * 4};
-    for (int i = 0; i < 12; i++) if (nb[i]) BOWCHK(hipMemcpyAsync(p[i], src[i], nb[i], hipMemcpyHostToDevice, 0));
-    BOWCHK(hipMemsetAsync(p[12], 0xff, (size_t)n1 * 4, 0));                // match12 = -1
-    BOWCHK(hipMemsetAsync(p[13], 0xff, (size_t)n1 * 4, 0));                // bin12 = -1
-    BOWCHK(hipMemsetAsync(p[14], 0, (ORBHIP_HISTO_LENGTH + 2) * 4, 0));    // hist, nmatches, overflow
     BowMatchParams P; memset(&P, 0, sizeof P);
-    P.mode = mode; P.nnratio = nnratio; P.check_ori = check_ori;
-    P.d1 = p[0]; P.ang1 = (const float*)p[1]; P.valid1 = p[2]; P.n1 = n1; P.fn1 = (const uint32_t*)p[3]; P.fo1 = (const int*)p[4]; P.ff1 = (const uint32_t*)p[5]; P.nf1 = nfv1;
-    P.d2 = p[6]; P.ang2 = (const float*)p[7]; P.valid2 = p[8]; P.n2 = n2; P.fn2 = (const uint32_t*)p[9]; P.fo2 = (const int*)p[10]; P.ff2 = (const uint32_t*)p[11]; P.nf2 = nfv2;
-    P.match12 = (int*)p[12]; P.bin12 = (int*)p[13]; P.hist = (int*)p[14]; P.nmatches = P.hist + ORBHIP_HISTO_LENGTH; P.overflow = P.nmatches + 1;
-    hipLaunchKernelGGL(k_bow_match, dim3((nfv1 + 3) / 4, 1, 1), dim3(256, 1, 1), 0, 0, P);
-    hipLaunchKernelGGL(k_bow_match_finish, dim3(1, 1, 1), dim3(256, 1, 1), 0, 0, P);
-    BOWCHK(hipGetLastError());
-    int tail[2] = {0, 0};
-    BOWCHK(hipMemcpyAsync(match12, p[12], (size_t)n1 * 4, hipMemcpyDeviceToHost, 0));
-    BOWCHK(hipMemcpyAsync(tail, P.nmatches, 8, hipMemcpyDeviceToHost, 0));
-    BOWCHK(hipStreamSynchronize(0));
-    if (tail[1]) return orbhip_set_error(ORBHIP_ERR_UNSUPPORTED, "a vocabulary node holds more than %d features of side 2", 64 * BM_CHUNKS);
-    *nmatches = tail[0];
+    int zeros[ORBHIP_HISTO_LENGTH + 2] = {0}, tail[ORBHIP_HISTO_LENGTH + 2] = {0};
+    uint8_t *d1 = nullptr, *d2 = nullptr, *v1 = nullptr, *v2 = nullptr; float *a1 = nullptr, *a2 = nullptr; uint32_t *fn1 = nullptr, *ff1 = nullptr, *fn2 = nullptr, *ff2 = nullptr;
+    int *fo1 = nullptr, *fo2 = nullptr, *m12 = nullptr, *bin12 = nullptr, *hist = nullptr;
+    BOWCHK(arena_layout(device, [&](Arena& A) {
+        A.io(&d1, (size_t)n1 * 32, desc1, (size_t)n1 * 32); A.io(&a1, n1, angle1, n1); A.io(&v1, n1, valid1, n1);
+        A.io(&fn1, nfv1, fv1_node, nfv1); A.io(&fo1, nfv1 + 1, (const int*)fv1_off, nfv1 + 1); A.io(&ff1, std::max(m1, 1), fv1_feat, m1);
+        A.io(&d2, (size_t)n2 * 32, desc2, (size_t)n2 * 32); A.io(&a2, n2, angle2, n2); A.io(&v2, n2, valid2, n2);
+        A.io(&fn2, nfv2, fv2_node, nfv2); A.io(&fo2, nfv2 + 1, (const int*)fv2_off, nfv2 + 1); A.io(&ff2, std::max(m2, 1), fv2_feat, m2);
+        A.io(&bin12, n1, (const int*)match12, n1);                                        // bin12 = -1 (match12 holds n1 of them)
+        A.io(&m12, n1, (const int*)match12, n1, (int*)match12, n1);                       // match12 = -1 in, the answer out
+        A.io(&hist, ORBHIP_HISTO_LENGTH + 2, (const int*)zeros, ORBHIP_HISTO_LENGTH + 2, tail, ORBHIP_HISTO_LENGTH + 2);      // hist, nmatches, overflow
+    }));
+    hipError_t e = arena_upload(ts);
+    if (e == hipSuccess) {
+        P.mode = mode; P.nnratio = nnratio; P.check_ori = check_ori;
+        P.d1 = d1; P.ang1 = a1; P.valid1 = v1; P.n1 = n1; P.fn1 = fn1; P.fo1 = fo1; P.ff1 = ff1; P.nf1 = nfv1;
+        P.d2 = d2; P.ang2 = a2; P.valid2 = v2; P.n2 = n2; P.fn2 = fn2; P.fo2 = fo2; P.ff2 = ff2; P.nf2 = nfv2;
+        P.match12 = m12; P.bin12 = bin12; P.hist = hist; P.nmatches = hist + ORBHIP_HISTO_LENGTH; P.overflow = P.nmatches + 1;
+        hipLaunchKernelGGL(k_bow_match, dim3((nfv1 + 3) / 4, 1, 1), dim3(256, 1, 1), 0, ts, P);
+        hipLaunchKernelGGL(k_bow_match_finish, dim3(1, 1, 1), dim3(256, 1, 1), 0, ts, P);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = arena_download(ts);
+    if (e != hipSuccess) { (void)hipStreamSynchronize(ts); for (int i = 0; i < n1; i++) match12[i] = -1; return orbhip_set_error(ORBHIP_ERR_HIP, "search_by_bow: %s", hipGetErrorString(e)); }
+    if (tail[ORBHIP_HISTO_LENGTH + 1]) { for (int i = 0; i < n1; i++) match12[i] = -1; return orbhip_set_error(ORBHIP_ERR_UNSUPPORTED, "a vocabulary node holds more than %d features of side 2", 64 * BM_CHUNKS); }
+    *nmatches = tail[ORBHIP_HISTO_LENGTH];
     return ORBHIP_OK;
 }
 
@@ -736,40 +731,38 @@ extern "C" orbhip_status orbhip_search_for_triangulation(int device,
     if (!desc1 || !desc2 || !kp1 || !kp2 || !has_mp1 || !has_mp2 || !stereo1 || !stereo2 || !fv1_node || !fv1_off || !fv1_feat || !fv2_node || !fv2_off || !fv2_feat ||
         !F12 || !scale_factors2 || !level_sigma2_2) return orbhip_set_error(ORBHIP_ERR_INVALID, "null argument");
     BOWCHK(hipSetDevice(device));
+    hipStream_t ts = orbhip_thread_stream(device);
     const int m1 = fv1_off[nfv1], m2 = fv2_off[nfv2];
-    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const void* src[18] = {desc1, kp1, has_mp1, stereo1, fv1_node, fv1_off, fv1_feat, desc2, kp2, has_mp2, stereo2, fv2_node, fv2_off, fv2_feat, scale_factors2, level_sigma2_2, nullptr, nullptr};
-    const size_t nb[18] = {(size_t)n1 * 32, (size_t)n1 * 16, (size_t)n1, (size_t)n1, (size_t)nfv1 * 4, (size_t)(nfv1 + 1) * 4, (size_t)std::max(m1, 1) * 4,
-                           (size_t)n2 * 32, (size_t)n2 * 16, (size_t)n2, (size_t)n2, (size_t)nfv2 * 4, (size_t)(nfv2 + 1) * 4, (size_t)std::max(m2, 1) * 4,
-                           (size_t)nlevels2 * 4, (size_t)nlevels2 * 4, (size_t)n1 * 4, (size_t)n1 * 4};
-    size_t total = al((ORBHIP_HISTO_LENGTH + 2) * 4); for (size_t b : nb) total += al(b);
-    orbhip_touch_thread_caches();
-    if (g_bm_dev != device || g_bm_ws_bytes < total) {
-        if (g_bm_ws) (void)hipFree(g_bm_ws);
-        g_bm_ws = nullptr; g_bm_ws_bytes = 0;
-        BOWCHK(orbhip_dmalloc(&g_bm_ws, total)); g_bm_ws_bytes = total; g_bm_dev = device;
+    int zeros[ORBHIP_HISTO_LENGTH + 2] = {0}, tail[ORBHIP_HISTO_LENGTH + 2] = {0};
+    uint8_t *d1 = nullptr, *d2 = nullptr, *h1 = nullptr, *h2 = nullptr, *s1 = nullptr, *s2 = nullptr; float *k1 = nullptr, *k2 = nullptr, *sc2 = nullptr, *sg2 = nullptr;
+    uint32_t *fn1 = nullptr, *ff1 = nullptr, *fn2 = nullptr, *ff2 = nullptr; int *fo1 = nullptr, *fo2 = nullptr, *m12 = nullptr, *bin12 = nullptr, *hist = nullptr;
+    BOWCHK(arena_layout(device, [&](Arena& A) {
+        A.io(&d1, (size_t)n1 * 32, desc1, (size_t)n1 * 32); A.io(&k1, (size_t)n1 * 4, kp1, (size_t)n1 * 4); A.io(&h1, n1, has_mp1, n1); A.io(&s1, n1, stereo1, n1);
+        A.io(&fn1, nfv1, fv1_node, nfv1); A.io(&fo1, nfv1 + 1, (const int*)fv1_off, nfv1 + 1); A.io(&ff1, std::max(m1, 1), fv1_feat, m1);
+        A.io(&d2, (size_t)n2 * 32, desc2, (size_t)n2 * 32); A.io(&k2, (size_t)n2 * 4, kp2, (size_t)n2 * 4); A.io(&h2, n2, has_mp2, n2); A.io(&s2, n2, stereo2, n2);
+        A.io(&fn2, nfv2, fv2_node, nfv2); A.io(&fo2, nfv2 + 1, (const int*)fv2_off, nfv2 + 1); A.io(&ff2, std::max(m2, 1), fv2_feat, m2);
+        A.io(&sc2, nlevels2, scale_factors2, nlevels2); A.io(&sg2, nlevels2, level_sigma2_2, nlevels2);
+        A.io(&bin12, n1, (const int*)match12, n1);
+        A.io(&m12, n1, (const int*)match12, n1, (int*)match12, n1);
+        A.io(&hist, ORBHIP_HISTO_LENGTH + 2, (const int*)zeros, ORBHIP_HISTO_LENGTH + 2, tail, ORBHIP_HISTO_LENGTH + 2);
+    }));
+    hipError_t e = arena_upload(ts);
+    if (e == hipSuccess) {
+        TriParams T; memset(&T, 0, sizeof T);
+        BowMatchParams& P = T.M;
+        P.mode = 0; P.nnratio = 0.f; P.check_ori = check_ori;
+        P.d1 = d1; P.valid1 = h1; P.n1 = n1; P.fn1 = fn1; P.fo1 = fo1; P.ff1 = ff1; P.nf1 = nfv1;
+        P.d2 = d2; P.valid2 = h2; P.n2 = n2; P.fn2 = fn2; P.fo2 = fo2; P.ff2 = ff2; P.nf2 = nfv2;
+        P.match12 = m12; P.bin12 = bin12; P.hist = hist; P.nmatches = hist + ORBHIP_HISTO_LENGTH; P.overflow = P.nmatches + 1;
+        T.kp1 = k1; T.kp2 = k2; T.st1 = s1; T.st2 = s2;
+        for (int i = 0; i < 9; i++) T.F[i] = F12[i];
+        T.ex = ex; T.ey = ey; T.scale2 = sc2; T.sigma2_2 = sg2; T.only_stereo = only_stereo;
+        hipLaunchKernelGGL(k_bow_triangulate, dim3((nfv1 + 3) / 4, 1, 1), dim3(256, 1, 1), 0, ts, T);
+        hipLaunchKernelGGL(k_bow_match_finish, dim3(1, 1, 1), dim3(256, 1, 1), 0, ts, P);
+        e = hipGetLastError();
     }
-    uint8_t* p[19]; { size_t o = 0; for (int i = 0; i < 18; i++) { p[i] = (uint8_t*)g_bm_ws + o; o += al(nb[i]); } p[18] = (uint8_t*)g_bm_ws + o; }
-    for (int i = 0; i < 16; i++) if (src[i] && nb[i] && !((i == 6 && m1 == 0) || (i == 13 && m2 == 0))) BOWCHK(hipMemcpyAsync(p[i], src[i], i == 6 ? (size_t)m1 * 4 : i == 13 ? (size_t)m2 * 4 : nb[i], hipMemcpyHostToDevice, 0));
-    BOWCHK(hipMemsetAsync(p[16], 0xff, (size_t)n1 * 4, 0));
-    BOWCHK(hipMemsetAsync(p[17], 0xff, (size_t)n1 * 4, 0));
-    BOWCHK(hipMemsetAsync(p[18], 0, (ORBHIP_HISTO_LENGTH + 2) * 4, 0));
-    TriParams T; memset(&T, 0, sizeof T);
-    BowMatchParams& P = T.M;
-    P.mode = 0; P.nnratio = 0.f; P.check_ori = check_ori;
-    P.d1 = p[0]; P.valid1 = p[2]; P.n1 = n1; P.fn1 = (const uint32_t*)p[4]; P.fo1 = (const int*)p[5]; P.ff1 = (const uint32_t*)p[6]; P.nf1 = nfv1;
-    P.d2 = p[7]; P.valid2 = p[9]; P.n2 = n2; P.fn2 = (const uint32_t*)p[11]; P.fo2 = (const int*)p[12]; P.ff2 = (const uint32_t*)p[13]; P.nf2 = nfv2;
-    P.match12 = (int*)p[16]; P.bin12 = (int*)p[17]; P.hist = (int*)p[18]; P.nmatches = P.hist + ORBHIP_HISTO_LENGTH; P.overflow = P.nmatches + 1;
-    T.kp1 = (const float*)p[1]; T.kp2 = (const float*)p[8]; T.st1 = p[3]; T.st2 = p[10];
-    for (int i = 0; i < 9; i++) T.F[i] = F12[i];
-    T.ex = ex; T.ey = ey; T.scale2 = (const float*)p[14]; T.sigma2_2 = (const float*)p[15]; T.only_stereo = only_stereo;
-    hipLaunchKernelGGL(k_bow_triangulate, dim3((nfv1 + 3) / 4, 1, 1), dim3(256, 1, 1), 0, 0, T);
-    hipLaunchKernelGGL(k_bow_match_finish, dim3(1, 1, 1), dim3(256, 1, 1), 0, 0, P);
-    BOWCHK(hipGetLastError());
-    int nm = 0;
-    BOWCHK(hipMemcpyAsync(match12, p[16], (size_t)n1 * 4, hipMemcpyDeviceToHost, 0));
-    BOWCHK(hipMemcpyAsync(&nm, P.nmatches, 4, hipMemcpyDeviceToHost, 0));
-    BOWCHK(hipStreamSynchronize(0));
-    *nmatches = nm;
+    if (e == hipSuccess) e = arena_download(ts);
+    if (e != hipSuccess) { (void)hipStreamSynchronize(ts); for (int i = 0; i < n1; i++) match12[i] = -1; return orbhip_set_error(ORBHIP_ERR_HIP, "search_for_triangulation: %s", hipGetErrorString(e)); }
+    *nmatches = tail[ORBHIP_HISTO_LENGTH];
     return ORBHIP_OK;
 }

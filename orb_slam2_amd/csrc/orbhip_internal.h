@@ -210,6 +210,37 @@ __device__ __forceinline__ int orbhip_writelane(int v, int dst_lane, int old)
     return (int)__lane_id() == dst_lane ? v : old;
 #endif
 }
+// ---- the calling thread's arena for the host-pointer ("stateless") matcher entry points: every array of a call is laid out in ONE device
+// allocation (grow-only, per thread) whose head mirrors a pinned host block, so that all inputs travel in one copy and all outputs in one copy
+#include <vector>
+#include <algorithm>
+struct OrbXfer { size_t off; const void* src; void* dst; size_t bytes_in, bytes_out; };
+extern thread_local void* orbhip_tl_scratch; extern thread_local size_t orbhip_tl_scratch_bytes; extern thread_local int orbhip_tl_scratch_dev;
+extern thread_local std::vector<OrbXfer> orbhip_tl_xfers;
+struct Arena {
+    uint8_t* base = nullptr; size_t off = 0;
+    template <typename T> void take(T** p, size_t count) { *p = reinterpret_cast<T*>(base + off); off += (std::max<size_t>(count, 1) * sizeof(T) + 255) & ~(size_t)255; }
+    // a buffer with a host side: n_in elements are uploaded from src before the kernels, n_out elements downloaded to dst after them.
+    // Take every such buffer before the pure scratch ones so that all of them travel in ONE copy each way (arena_upload / arena_download).
+    template <typename T> void io(T** p, size_t count, const T* src, size_t n_in, T* dst = nullptr, size_t n_out = 0)
+    {
+        const size_t o = off;
+        take(p, count);
+        if (base && ((src && n_in) || (dst && n_out))) orbhip_tl_xfers.push_back(OrbXfer{o, src && n_in ? src : nullptr, dst && n_out ? dst : nullptr, n_in * sizeof(T), n_out * sizeof(T)});
+    }
+};
+hipError_t orbhip_arena_reserve(int device, size_t bytes);
+template <typename Layout> static hipError_t arena_layout(int device, Layout layout)
+{
+    orbhip_tl_xfers.clear();
+    Arena dry; layout(dry);                                   // first pass: sizes only (no base: nothing is logged)
+    const hipError_t e = orbhip_arena_reserve(device, dry.off); if (e != hipSuccess) return e;
+    Arena real; real.base = static_cast<uint8_t*>(orbhip_tl_scratch); layout(real);
+    return hipSuccess;
+}
+hipError_t arena_upload(hipStream_t s);       // pageable -> pinned gather on the host, ONE host-to-device copy
+hipError_t arena_download(hipStream_t s);     // ONE device-to-host copy, synchronises s, pinned -> pageable scatter
+hipStream_t orbhip_thread_stream(int device); // the calling thread's own non-blocking stream for these calls
 void orbhip_touch_thread_caches();      // makes sure the calling thread's cache holder exists (its destructor releases the caches of worker threads)
 orbhip_status orbhip_set_error(orbhip_status st, const char* fmt, ...);
 void orbhip_internal_outputs(orbhip_ctx* c, const uint8_t** d_desc, const int** d_n, int* cap, int* last_nimg, int* device, hipStream_t* s);

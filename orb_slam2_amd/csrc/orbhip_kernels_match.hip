@@ -258,6 +258,12 @@ __device__ __forceinline__ int mg_wave_incl_scan(int v, int lane)
     for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(v, off); if (lane >= off) v += t; }
     return v;
 }
+__device__ __forceinline__ int mg_cell(const orbhip_keypoint& k, const MatchParams& M, float gwInv, float ghInv)
+{
+    if (!(M.grid_all_levels || k.octave == 0)) return 0xFFFF;
+    const int px = (int)roundf(__fmul_rn(__fsub_rn(k.x, M.min_x), gwInv)), py = (int)roundf(__fmul_rn(__fsub_rn(k.y, M.min_y), ghInv));
+    return (px < 0 || px >= ORBHIP_GRID_COLS || py < 0 || py >= ORBHIP_GRID_ROWS) ? 0xFFFF : px * ORBHIP_GRID_ROWS + py;
+}
 __global__ __launch_bounds__(256) void k_match_grid(MatchParams M, float gwInv, float ghInv)
 {
     HIP_DYNAMIC_SHARED(int, lds)
@@ -276,12 +282,8 @@ __global__ __launch_bounds__(256) void k_match_grid(MatchParams M, float gwInv, 
     // Only level-0 keypoints can ever be returned by GetFeaturesInArea(.., minLevel 0, maxLevel 0) (Frame.cc:362-370), and
     // filtering a cell keeps the relative order of its entries, so the buckets are built from level-0 keypoints only.
     for (int i = tid; i < n2; i += 256) {
-        const orbhip_keypoint k = kp[i];
-        int cell = 0xFFFF;
-        if (M.grid_all_levels || k.octave == 0) {
-            const int px = (int)roundf(__fmul_rn(__fsub_rn(k.x, M.min_x), gwInv)), py = (int)roundf(__fmul_rn(__fsub_rn(k.y, M.min_y), ghInv));
-            if (!(px < 0 || px >= ORBHIP_GRID_COLS || py < 0 || py >= ORBHIP_GRID_ROWS)) { cell = px * ORBHIP_GRID_ROWS + py; atomicAdd(&s_cnt[cell], 1); }
-        }
+        const int cell = mg_cell(kp[i], M, gwInv, ghInv);
+        if (cell != 0xFFFF) atomicAdd(&s_cnt[cell], 1);
         s_cell[i] = (unsigned short)cell;
     }
     __syncthreads();
@@ -311,12 +313,58 @@ __global__ __launch_bounds__(256) void k_match_grid(MatchParams M, float gwInv, 
     for (int t = tid; t < total; t += 256) { const int i = s_items[t]; gitems[t] = i; const orbhip_keypoint k = kp[i]; float2 xy; xy.x = k.x; xy.y = k.y; gxy[t] = xy; }
 }
 
+// The same table for frames whose capacity does not fit the LDS form (12 KB + 6 bytes per key point: from ~23 000 key points per frame): counters and
+// cursors in LDS, the bucket table built in place in global memory, the cell of a key point computed twice instead of kept.
+__global__ __launch_bounds__(256) void k_match_grid_big(MatchParams M, float gwInv, float ghInv)
+{
+    __shared__ int s_cnt[ORBHIP_GRID_CELLS + 1];
+    __shared__ int s_wsum[4];
+    const int slot = blockIdx.x + M.slot0, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n2 = min(M.n2[slot], M.cap);
+    const orbhip_keypoint* kp = M.kp2 + (long long)slot * M.cap;
+    int* gstart = M.grid_start + (long long)slot * (ORBHIP_GRID_CELLS + 1);
+    int* gitems = M.grid_items + (long long)slot * M.cap;
+    float2* gxy = M.grid_xy + (long long)slot * M.cap;
+    for (int c = tid; c <= ORBHIP_GRID_CELLS; c += 256) s_cnt[c] = 0;
+    __syncthreads();
+    for (int i = tid; i < n2; i += 256) { const int cell = mg_cell(kp[i], M, gwInv, ghInv); if (cell != 0xFFFF) atomicAdd(&s_cnt[cell], 1); }
+    __syncthreads();
+    const int per = ORBHIP_GRID_CELLS / 256;
+    int sum = 0;
+    for (int k = 0; k < per; k++) sum += s_cnt[tid * per + k];
+    const int incl = mg_wave_incl_scan(sum, lane);
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    int run = incl - sum;
+    for (int w = 0; w < wave; w++) run += s_wsum[w];
+    for (int k = 0; k < per; k++) { const int v = s_cnt[tid * per + k]; s_cnt[tid * per + k] = run; gstart[tid * per + k] = run; run += v; }
+    if (tid == 255) { gstart[ORBHIP_GRID_CELLS] = run; s_cnt[ORBHIP_GRID_CELLS] = run; }
+    __syncthreads();
+    const int total = s_cnt[ORBHIP_GRID_CELLS];
+    __syncthreads();
+    for (int i = tid; i < n2; i += 256) { const int cell = mg_cell(kp[i], M, gwInv, ghInv); if (cell != 0xFFFF) gitems[atomicAdd(&s_cnt[cell], 1)] = i; }
+    __threadfence_block();
+    __syncthreads();
+    for (int c = tid; c < ORBHIP_GRID_CELLS; c += 256) {                 // key point order inside each cell (see k_match_grid)
+        const int a = c ? s_cnt[c - 1] : 0, b = s_cnt[c];
+        for (int i = a + 1; i < b; i++) { const int v = gitems[i]; int j = i - 1; while (j >= a && gitems[j] > v) { gitems[j + 1] = gitems[j]; j--; } gitems[j + 1] = v; }
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int t = tid; t < total; t += 256) { const orbhip_keypoint k = kp[gitems[t]]; float2 xy; xy.x = k.x; xy.y = k.y; gxy[t] = xy; }
+}
+
 size_t orbhip_match_grid_lds(int cap) { return sizeof(int) * (ORBHIP_GRID_CELLS + 1 + (size_t)cap) + sizeof(unsigned short) * ((size_t)cap + 2); }
 
 void orbhip_launch_match_grid(const MatchParams& M, int nslots, hipStream_t s)
 {
     const float gwInv = (float)ORBHIP_GRID_COLS / (float)(M.max_x - M.min_x), ghInv = (float)ORBHIP_GRID_ROWS / (float)(M.max_y - M.min_y);   // Frame.cc:101-102
-    hipLaunchKernelGGL(k_match_grid, dim3(nslots, 1, 1), dim3(256, 1, 1), orbhip_match_grid_lds(M.cap), s, M, gwInv, ghInv);
+    size_t lds_max = (size_t)150 * 1024;
+#ifdef ORBHIP_TEST_HOOKS      // the CPU emulation build only: small frames through the large-frame form
+    if (const char* e = getenv("ORBHIP_TEST_MATCH_GRID_LDS_MAX")) lds_max = (size_t)atol(e);
+#endif
+    if (orbhip_match_grid_lds(M.cap) <= lds_max) hipLaunchKernelGGL(k_match_grid, dim3(nslots, 1, 1), dim3(256, 1, 1), orbhip_match_grid_lds(M.cap), s, M, gwInv, ghInv);
+    else hipLaunchKernelGGL(k_match_grid_big, dim3(nslots, 1, 1), dim3(256, 1, 1), 0, s, M, gwInv, ghInv);
 }
 
 // ------------------------------------------------------------------------------------------------ candidates

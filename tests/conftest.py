@@ -26,11 +26,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X GPU (liborbhip.so built for gfx950)")
 
 
+def gpu_session(config):
+    """True when this run selects the gpu-marked tests (`-m gpu`): fixtures with both emulation and GPU parameters then skip their emulation
+    parameters BEFORE loading anything, so that no emulation library is mapped into a process whose record says which native code ran."""
+    expr = (config.getoption("-m") or "").strip()
+    return "gpu" in expr and "not gpu" not in expr
+
+
 def pytest_report_header(config):
     """GPU runs name their box in the log's first lines: the product-free probe's verdict and the runtime the product is on (a red run on
     a machine whose GPU faults for every process then says so itself)."""
-    expr = (config.getoption("-m") or "").strip()
-    if "gpu" not in expr or "not gpu" in expr:
+    if not gpu_session(config):
         return None
     lines = []
     probe = os.path.join(ROOT, "tests", "cpp", "hip_touch")

@@ -17,6 +17,7 @@ import numpy as np
 import pytest
 
 from orb_slam2_amd import synth
+from conftest import gpu_session
 
 EUROC = dict(w=752, h=480, n=1200, fx=435.2047, fy=435.2047, cx=367.4517, cy=252.2008, bf=47.9064, th_depth=35.0)       # Examples/Stereo/EuRoC.yaml
 KITTI = dict(w=1241, h=376, n=2000, fx=718.856, fy=718.856, cx=607.1928, cy=185.2157, bf=386.1448, th_depth=35.0)       # Examples/Stereo/KITTI00-02.yaml
@@ -30,6 +31,8 @@ def builds(request):
         if not (S.build() and S.build_dropin_gpu()):
             pytest.fail("oracle/_ref/liborbslam_dropin_gpu.so did not travel with the repository (build it with `make -C oracle dropin_gpu` where /root/reference is mounted)")
         return S, S.dropin_gpu_lib(full=request.param.startswith("all-steps"))
+    if gpu_session(request.config):
+        pytest.skip("a -m gpu session maps liborbhip.so only: the CPU-emulation builds of the binding are not loaded beside it")
     request.getfixturevalue("emu_lib")
     if not (S.build() and S.build_dropin()):
         pytest.skip("reference sources not mounted")

@@ -231,3 +231,29 @@ def test_submit_to_named_result_buffers(backend, frames, want, monkeypatch, pinn
         _same([k[f, :nout[f]] for f in range(4)], [d[f, :nout[f]] for f in range(4)], want, range(4 * b, 4 * b + 4))
     k, d = ex.extract_batch(frames[:2])
     _same(k, d, want, range(2))
+
+
+def test_cpulist_parser_is_reentrant(emu_lib):
+    """The NUMA binding of the pool workers and of the copy helpers parses /sys/devices/system/node/node<N>/cpulist from several threads at the same
+    moment (orbhip_pool_create posts the workers in parallel; each CopyPool spawns its helpers at once): the parser must keep no shared state
+    (it used strtok).  Eight threads parse different lists 2000 times each; every result must be that thread's own list."""
+    import ctypes as C
+    import threading
+    L = C.CDLL(emu_lib)
+    L.orbhip_test_parse_cpulist.argtypes = [C.c_char_p, C.c_void_p, C.c_int]
+    cases = [("0-63,128-191\n", list(range(0, 64)) + list(range(128, 192))), ("64-127,192-255\n", list(range(64, 128)) + list(range(192, 256))),
+             ("3\n", [3]), ("0,2,4,6-9", [0, 2, 4, 6, 7, 8, 9]), ("", []), ("10-12,12-14\n", [10, 11, 12, 13, 14]), ("1-1,5", [1, 5]), ("200-203\n", [200, 201, 202, 203])]
+    bad = []
+
+    def work(text, want):
+        out = (C.c_int * 1024)()
+        for _ in range(2000):
+            n = L.orbhip_test_parse_cpulist(text.encode(), out, 1024)
+            if n != len(want) or list(out[:n]) != want:
+                bad.append((text, n))
+                return
+
+    ts = [threading.Thread(target=work, args=c) for c in cases]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not bad, bad

@@ -116,6 +116,40 @@ def test_search_best_in_window(backend, oracle, scene, chi2, stereo, th):
     assert len(e[0]) == 0
 
 
+def test_feature_grid_of_a_frame_too_large_for_lds(backend, oracle, scene, monkeypatch):
+    """AssignFeaturesToGrid for a frame whose bucket table does not fit the LDS form of k_match_grid (12 KB + 6 bytes per key point, ~23 000 key
+    points): the same table built in place in global memory.  On the GPU a real 30 000-key-point frame; on the CPU emulation the small scene, pushed
+    through the large-frame form by the test hook (and once more through the LDS form: same answers)."""
+    w, h, sf, (kl, dl), (kc, dc) = scene
+    inv = (1.0 / (sf * sf)).astype(np.float32)
+    rng = np.random.default_rng(77)
+    if backend.endswith("_emu.so"):
+        monkeypatch.setenv("ORBHIP_TEST_MATCH_GRID_LDS_MAX", "1024")
+        K, D = kc, dc
+    else:
+        reps = 30000 // len(kc) + 1                                # the scene's key points, repeated with jitter: dense cells, ties in the cell order
+        K = np.concatenate([kc] * reps)[:30000].copy(); D = np.concatenate([dc] * reps)[:30000].copy()
+        K["x"] = np.clip(K["x"] + rng.normal(0, 6, len(K)), 0, w - 1).astype(np.float32); K["y"] = np.clip(K["y"] + rng.normal(0, 6, len(K)), 0, h - 1).astype(np.float32)
+        D[rng.random(len(D)) < 0.5, 5] ^= 0x10
+    nq = len(kl)
+    q = np.zeros(nq, oracle.BEST_QUERY_DTYPE)
+    q["x"] = kl["x"] - 3.0 + rng.normal(0, 1.2, nq).astype(np.float32); q["y"] = kl["y"] - 1.0 + rng.normal(0, 1.2, nq).astype(np.float32)
+    q["level"] = np.clip(kl["octave"] + rng.integers(0, 2, nq), 0, 7); q["radius"] = (np.float32(7.5) * sf[q["level"]]).astype(np.float32); q["ur"] = q["x"] - np.float32(9.0)
+    bi_o, bd_o = oracle.search_best_in_window(K, D, w, h, inv, q, dl, False)
+    bi_g, bd_g = orb_slam2_amd.search_best_in_window(K, D, w, h, inv, q, dl, False, library=backend)
+    assert np.array_equal(bi_g, bi_o) and np.array_equal(bd_g, bd_o) and int((bd_o <= 50).sum()) > 100
+    if backend.endswith("_emu.so"):
+        monkeypatch.delenv("ORBHIP_TEST_MATCH_GRID_LDS_MAX")
+        bi_l, bd_l = orb_slam2_amd.search_best_in_window(K, D, w, h, inv, q, dl, False, library=backend)
+        assert np.array_equal(bi_l, bi_o) and np.array_equal(bd_l, bd_o)
+        # the other users of the table: the order-dependent projection search
+        monkeypatch.setenv("ORBHIP_TEST_MATCH_GRID_LDS_MAX", "1024")
+        pq, pqd = _queries(oracle, scene, 1, 7.0, rng, "window")
+        n_o, f_o = oracle.search_by_projection(kc, dc, w, h, pq, pqd, 1, nnratio=0.9, th_high=100, check_ori=True)
+        n_g, f_g = orb_slam2_amd.search_by_projection(kc, dc, w, h, pq, pqd, 1, nnratio=0.9, th_high=100, check_ori=True, library=backend)
+        assert n_g == n_o and np.array_equal(f_g, f_o)
+
+
 def test_searches_on_device_resident_frames(backend, oracle):
     """orbhip_search_by_projection_frame / orbhip_search_best_in_window_frame: the frame's key points, descriptors and mvuRight stay on
     the device (stereo pair extracted and matched there); results equal the oracle's on the fetched copies."""

@@ -19,6 +19,7 @@ import numpy as np
 import pytest
 
 from orb_slam2_amd import synth
+from conftest import gpu_session
 
 
 @pytest.fixture(scope="module", params=["steps1-3", "all-steps", pytest.param("steps1-3-gpu", marks=pytest.mark.gpu), pytest.param("all-steps-gpu", marks=pytest.mark.gpu)])
@@ -30,6 +31,8 @@ def builds(request):
         if not (S.build() and S.build_dropin_gpu()):
             pytest.fail("oracle/_ref/liborbslam_dropin_gpu.so did not travel with the repository (build it with `make -C oracle dropin_gpu` where /root/reference is mounted)")
         return S, S.dropin_gpu_lib(full=request.param.startswith("all-steps"))
+    if gpu_session(request.config):
+        pytest.skip("a -m gpu session maps liborbhip.so only: the CPU-emulation builds of the binding are not loaded beside it")
     request.getfixturevalue("emu_lib")
     if not (S.build() and S.build_dropin()):
         pytest.skip("reference sources not mounted")
