@@ -28,6 +28,9 @@ Extra objects in the JSON line:
   dropin_loop   the drop-in as ORB_SLAM2 drives it: >= 20 stereo frames through the reference's own Frame.cc / ORBmatcher.cc (stereo Frame
                 constructor, ComputeStereoMatches, SearchByProjection(Current, Last), SearchByProjection(Frame, MapPoints)), ms per frame with
                 the drop-in on the GPU and with the reference on the host, bit-exact per frame (KITTI shape; EuRoC shape under "euroc")
+  matcher_calls / config5 / config4   every secondary unit with the reference beside it (tools/secondary_units.py): per ORBmatcher / Frame member
+                gpu_ms, ref_ms and a parity flag through the reference's own callers; the brute-force DB query vs the CPU scan on all host threads;
+                the 8-camera 1080p rig through the pool vs the reference extractor on all host threads
   cpu_baseline  the CPU path timed on this box's host cores on a bounded sample of the same workload (rank 0, N=1 only): the
                 reference's own Frame / ORBextractor / ORBmatcher sources built into oracle/_ref (kind "reference"; the four
                 OpenCV image primitives they call are the oracle's restatements), or the oracle's restatement (kind "port")
@@ -123,7 +126,11 @@ def cpu_baseline(frames, budget_s=8.0, blur_round_mode=0):
     rate = sum(r[0] / r[1] for r in res)
     what = ("the reference's own Frame constructor + ORBmatcher::SearchForInitialization (oracle/_ref, -O3 -march=x86-64-v3; its four OpenCV image "
             "primitives are the oracle's restatements)") if kind == "reference" else "oracle -O3 -march=x86-64-v3 build"
-    return {"value": round(rate, 1), "unit": "frames/s", "cores": ncores, "kind": kind,
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from secondary_units import host_cpu
+    hc = host_cpu()
+    return {"value": round(rate, 1), "unit": "frames/s", "cores": ncores, "cores_note": "`cores` = worker processes run at once = hardware threads of the box",
+            "physical_cores": hc["physical_cores"], "hardware_threads": hc["hardware_threads"], "cpu_model": hc["model"], "kind": kind,
             "sample": f"{total} frames 1241x376 (extract + SearchForInitialization vs previous frame) over {ncores} processes x {budget_s:.0f} s (wall {wall:.1f} s), {what}",
             "single_thread_value": round(one_done / one_dt, 2), "two_thread_value": round(sum(r[0] / r[1] for r in two), 2),
             "oracle_port_single_thread_value": round(port_done / port_dt, 2)}
@@ -261,6 +268,18 @@ def dropin_loop_subprocess(blur_round_mode):
     return out
 
 
+def secondary_units_subprocess(blur_round_mode):
+    """tools/secondary_units.py in a fresh interpreter: every secondary unit with the reference beside it -
+    matcher_calls (M1-M5, S1, ComputeBoW: gpu_ms / ref_ms / parity per member, through the reference's own callers), config5 (brute-force DB query vs the
+    CPU scan on all host threads), config4 (8 x 1920x1080 x 4000 rig through the pool vs the reference extractor on all host threads)."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "secondary_units.py"), "--blur-round-mode", str(blur_round_mode)], capture_output=True, text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": f"secondary_units subprocess failed (rc {r.returncode}): {r.stderr[-400:]}"}
+    return json.loads(lines[-1])
+
+
 def parity_of_last_step(host_frames, kps, descs, m12, last_step, T, blur_round_mode, nslots):
     """Bit-for-bit check of what the LAST timed step left in the context (the oracle is the checker, never the thing measured):
     key points, descriptors and matches12 of `nslots` camera slots with distinct scenes against oracle.OracleExtractor /
@@ -375,6 +394,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) that measure roofline.traffic")
     ap.add_argument("--no-dropin-loop", action="store_true", help="skip the front-end loop through the reference's own callers (dropin_loop object)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary units with the reference beside them (matcher_calls, config5, config4 objects)")
     ap.add_argument("--host-io-only", action="store_true", help="internal: measure the host_io object in this (fresh) process and print it")
     ap.add_argument("--device", type=int, default=0, help="with --host-io-only: the GPU to use")
     ap.add_argument("--pool", action="store_true", help="time the one-process multi-GPU pool (orbhip_pool_*: one host thread per GPU) at the host-buffer boundary instead of "
@@ -565,6 +585,12 @@ def main():
             if not closed:
                 ex.close(); d_frames.free(); closed = True               # the loop runs beside nothing, like the host_io object
             out["dropin_loop"] = dropin_loop_subprocess(args.blur_round_mode)
+        if world == 1 and not args.no_secondary:
+            if not closed:
+                ex.close(); d_frames.free(); closed = True
+            sec = secondary_units_subprocess(args.blur_round_mode)
+            for key in ("matcher_calls", "config5", "config4"):
+                out[key] = sec.get(key, {"error": sec.get("error", "missing")})
         if world == 1 and not args.no_cpu_baseline:
             os.environ["ORB_REF_BLUR_ROUND_MODE"] = str(args.blur_round_mode)      # the reference build's GaussianBlur stand-in follows the same rounding
             out["cpu_baseline"] = cpu_baseline(host_frames, blur_round_mode=args.blur_round_mode)

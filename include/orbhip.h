@@ -347,6 +347,36 @@ orbhip_status orbhip_search_for_triangulation(int device,
     const uint32_t* fv2_node, const int32_t* fv2_off, const uint32_t* fv2_feat, int nfv2,
     const float* F12, float ex, float ey, const float* scale_factors2, const float* level_sigma2_2, int nlevels2,
     int only_stereo, int check_ori, int32_t* match12, int* nmatches);
+/* -------- batched forms of the back end's matcher loops --------------------------------------------------------
+   The reference calls these members in loops: one SearchByBoW per relocalisation candidate (Tracking.cc:1357-1380) / per loop candidate
+   (LoopClosing.cc:239-375), one SearchForTriangulation per neighbour key frame (LocalMapping.cc:237-268), one Fuse per target key frame
+   (LocalMapping.cc:483-514, LoopClosing.cc:589-599).  At 0.07-0.13 ms a call is launch latency, not work.  The batch entries run a whole loop
+   as ONE upload (every distinct key frame / frame travels once), ONE launch set and ONE download; per pair / slot the answers are identical to
+   the per-call entries above.  Host pointers, synchronous, on the calling thread's own stream. */
+typedef struct {
+    const uint8_t* desc; const float* angle; const uint8_t* valid; int32_t n;                   /* as desc1 / angle1 / valid1 / n1 of orbhip_search_by_bow (valid may be NULL on side 2 of mode 0) */
+    const uint32_t* fv_node; const int32_t* fv_off; const uint32_t* fv_feat; int32_t nfv;      /* the FeatureVector, flattened */
+} orbhip_bow_side;
+typedef struct { const orbhip_bow_side* side1; const orbhip_bow_side* side2; int32_t* match12 /* side1->n entries */; int32_t nmatches; } orbhip_bow_pair;
+/* npairs independent SearchByBoW calls (mode as in orbhip_search_by_bow).  Sides are recognised by POINTER: a side that several pairs name
+   (the current frame of Relocalization, the current key frame of LoopClosing::ComputeSim3) is uploaded once. */
+orbhip_status orbhip_search_by_bow_batch(int device, int mode, int npairs, orbhip_bow_pair* pairs, float nnratio, int check_ori);
+
+typedef struct {
+    const uint8_t* desc; const float* kp; const uint8_t* has_mp; const uint8_t* stereo; int32_t n;   /* as desc1 / kp1 / has_mp1 / stereo1 / n1 of orbhip_search_for_triangulation */
+    const uint32_t* fv_node; const int32_t* fv_off; const uint32_t* fv_feat; int32_t nfv;
+    const float* scale_factors; const float* level_sigma2; int32_t nlevels;                          /* mvScaleFactors / mvLevelSigma2: read of a pair's SECOND key frame only */
+} orbhip_tri_side;
+typedef struct { const orbhip_tri_side* kf2; float F12[9]; float ex, ey; int32_t* match12 /* kf1->n entries */; int32_t nmatches; } orbhip_tri_pair;
+/* SearchForTriangulation of ONE key frame against npairs neighbours (LocalMapping::CreateNewMapPoints).  Every pair is searched with kf1->has_mp as
+   handed in.  The reference's loop gives key frame 1 new map points between neighbours (LocalMapping.cc:437 AddMapPoint); its SearchForTriangulation
+   never marks a feature of key frame 2 as taken (ORBmatcher.cc:677, 725: vbMatched2 is read, never written), so the features of key frame 1 do not
+   interact and - WITHOUT the orientation check, which is how LocalMapping constructs its matcher (LocalMapping.cc:215: ORBmatcher(0.6, false)) - the
+   reference's answer for neighbour i is this batch's answer minus the features that received a map point from neighbours < i: the caller drops
+   those pairs (the member emitted by integration/apply_dropin.py does).  With check_ori != 0 the rotation histogram couples the features: use the
+   batch only when key frame 1's map points do not change inside the loop. */
+orbhip_status orbhip_search_for_triangulation_batch(int device, const orbhip_tri_side* kf1, int npairs, orbhip_tri_pair* pairs, int only_stereo, int check_ori);
+
 /* TemplatedVocabulary::score(v1, v2) with the scoring object named by the file header (ScoringObject.cpp:24-313;
    KeyFrameDatabase.cc:133,249, LoopClosing.cc:134); host arithmetic */
 double orbhip_voc_score(const orbhip_voc* voc, const uint32_t* id1, const double* val1, int n1,
@@ -398,6 +428,18 @@ typedef struct {
 } orbhip_proj_slot;
 orbhip_status orbhip_search_by_projection_batch(int device, int nslots, orbhip_proj_slot* slots, const orbhip_bounds* bounds,
                                                 int mode, float nnratio, int th_high, int check_ori);
+
+/* orbhip_search_best_in_window_bounds for several key frames in ONE pass (Fuse over all target key frames, LocalMapping.cc:483-514: the same
+   map points projected into every target; LoopClosing::SearchAndFuse, LoopClosing.cc:589-599): slot s searches its own key frame with its own
+   queries.  Per slot the answers equal a call of orbhip_search_best_in_window_bounds.  (Fuse's map surgery can change a later target's inputs -
+   Replace() makes a point bad and recomputes the survivor's descriptor, MapPoint.cc:205-235: the caller re-runs the queries whose point changed.) */
+typedef struct {
+    const orbhip_keypoint* kps; const uint8_t* desc; const float* u_right; int32_t n;                    /* the key frame searched: mvKeysUn, mDescriptors, mvuRight (may be NULL) */
+    orbhip_bounds bounds; const float* inv_level_sigma2; int32_t nlevels;
+    const orbhip_best_query* queries; const uint8_t* query_desc; int32_t nq;
+    int32_t* best_idx; int32_t* best_dist;                                                              /* out: nq entries each */
+} orbhip_best_slot;
+orbhip_status orbhip_search_best_in_window_batch(int device, int nslots, orbhip_best_slot* slots, int chi2_gate);
 
 /* The same two searches on a frame that is still on the device (frame `frame` of the context's last extract call): key points
    (mvKeysUn when a distorted camera is attached), descriptors, the image bounds and — with use_u_right != 0 — mvuRight of the last

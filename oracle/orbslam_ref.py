@@ -31,6 +31,8 @@ def _locked_make(args):
     import fcntl
     import subprocess
     import tempfile
+    if os.environ.get("ORBHIP_NO_MAKE"):      # sanitizer runs (tools/sanitize_concurrency.sh builds everything first): fork() under a preloaded ThreadSanitizer runtime can deadlock
+        return
     with open(os.path.join(tempfile.gettempdir(), "orbhip_test_make.lock"), "w") as lk:
         fcntl.flock(lk, fcntl.LOCK_EX)
         try:
@@ -71,9 +73,10 @@ _dropin_full = None
 
 
 def dropin_full_lib():
+    """ORBSLAM_DROPIN_FULL_LIB: another build of the same library (the sanitizer builds of tools/sanitize_concurrency.sh)"""
     global _dropin_full
     if _dropin_full is None:
-        _dropin_full = _bind(C.CDLL(DROPIN_FULL_PATH))
+        _dropin_full = _bind(C.CDLL(os.environ.get("ORBSLAM_DROPIN_FULL_LIB") or DROPIN_FULL_PATH))
     return _dropin_full
 
 
@@ -118,6 +121,8 @@ def _bind(L):
         L.orbslam_ref_frame_stereo.restype = vp
         L.orbslam_ref_frame_stereo.argtypes = [vp, vp, i, i, i, i, f, i, i, i, f, f, f, f, f, f, i]
         L.orbslam_ref_frame_delete.argtypes = [vp]
+        L.orbslam_ref_last_call_ms.restype = C.c_double
+        L.orbslam_ref_frame_stereo_matches_again.argtypes = [vp, vp, vp]
         L.orbslam_ref_frame_n.argtypes = [vp]
         L.orbslam_ref_frame_get.argtypes = [vp, vp, vp, vp, vp, vp]
         L.orbslam_ref_features_in_area.argtypes = [vp, f, f, f, i, i, vp, i]
@@ -195,6 +200,12 @@ class RefFrame:
         assert rc == 0, "vocabulary not loaded"
         return bid[:nb.value].copy(), bval[:nb.value].copy(), fnode[:nf.value].copy(), foff[:nf.value + 1].copy(), ffeat[:foff[nf.value]].copy()
 
+    def stereo_matches_again(self):
+        """Frame::ComputeStereoMatches once more (this frame must be the last one its rig made) -> (mvuRight, mvDepth); timed (last_call_ms)"""
+        u = np.zeros(self.N, np.float32); d = np.zeros(self.N, np.float32)
+        self.L.orbslam_ref_frame_stereo_matches_again(self.h, _p(u), _p(d))
+        return u, d
+
     def close(self):
         if self.h:
             self.L.orbslam_ref_frame_delete(self.h)
@@ -204,6 +215,11 @@ class RefFrame:
         out = np.zeros(max(self.N, 1), np.int32)
         n = self.L.orbslam_ref_features_in_area(self.h, x, y, r, min_level, max_level, _p(out), len(out))
         return out[:n].copy()
+
+
+def last_call_ms(library=None):
+    """wall time of the ORBmatcher / Frame member the last wrapper call on this thread made (the member alone)"""
+    return float((lib() if library is None else library).orbslam_ref_last_call_ms())
 
 
 def search_for_initialization(f1, f2, prev=None, window=100, nnratio=0.9, check_ori=True):

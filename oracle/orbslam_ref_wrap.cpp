@@ -203,6 +203,10 @@ cv::Mat camera(float fx, float fy, float cx, float cy)
     K.at<float>(0, 0) = fx; K.at<float>(1, 1) = fy; K.at<float>(0, 2) = cx; K.at<float>(1, 2) = cy;
     return K;
 }
+// wall time of the last ORBmatcher / Frame member call a wrapper below made - the member alone, without the wrapper's own map-point scaffolding
+// (bench.py's matcher_calls: the same member timed in the all-reference build and in the drop-in build)
+thread_local double g_call_ms = 0;
+struct CallTimer { std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); ~CallTimer() { g_call_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } };
 thread_local std::vector<MapPoint*> g_keep;   // map points live as long as the process (the reference never frees them either) - or until release_points()
 MapPoint* make_point(float x, float y, float z, const uint8_t* desc, int nobs, bool bad)
 {
@@ -266,7 +270,7 @@ int orbslam_ref_frame_compute_bow(void* fp, const char* voc_path, uint32_t* bow_
     }
     Frame& F = *(Frame*)fp;
     F.mpORBvocabulary = voc; F.mBowVec.clear(); F.mFeatVec.clear();
-    F.ComputeBoW();
+    { CallTimer ct; F.ComputeBoW(); }
     int i = 0;
     for (DBoW2::BowVector::const_iterator it = F.mBowVec.begin(); it != F.mBowVec.end(); ++it, ++i) { bow_id[i] = it->first; bow_val[i] = it->second; }
     *nbow = i;
@@ -299,6 +303,15 @@ void* orbslam_ref_frame_stereo(const uint8_t* imgL, const uint8_t* imgR, int w, 
     return new (mem) Frame(L, R, 0.0, r.left, r.right, NULL, K, D, bf, thDepth);
 }
 void orbslam_ref_frame_delete(void* f) { delete (Frame*)f; }
+double orbslam_ref_last_call_ms() { return g_call_ms; }
+// Frame::ComputeStereoMatches (Frame.cc:466-640) once more on a stereo Frame that is still the LAST one its rig made (the drop-in's forward reads the
+// two extractors' resident results): mvuRight / mvDepth are rebuilt from scratch, the call is timed
+void orbslam_ref_frame_stereo_matches_again(void* fp, float* uRight, float* depth)
+{
+    Frame* f = (Frame*)fp;
+    { CallTimer ct; f->ComputeStereoMatches(); }
+    for (int i = 0; i < f->N; i++) { if (uRight) uRight[i] = f->mvuRight[i]; if (depth) depth[i] = f->mvDepth[i]; }
+}
 int orbslam_ref_frame_n(void* f) { return ((Frame*)f)->N; }
 void orbslam_ref_frame_get(void* fp, void* keys, void* keysUn, uint8_t* desc, float* uRight, float* depth)
 {
@@ -327,7 +340,7 @@ int orbslam_ref_search_for_initialization(void* f1, void* f2, float* prev_xy, in
     for (int i = 0; i < F1.N; i++) prev[i] = cv::Point2f(prev_xy[2 * i], prev_xy[2 * i + 1]);
     std::vector<int> m12;
     ORBmatcher matcher(nnratio, check_ori != 0);
-    const int n = matcher.SearchForInitialization(F1, F2, prev, m12, window);
+    int n; { CallTimer ct; n = matcher.SearchForInitialization(F1, F2, prev, m12, window); }
     for (int i = 0; i < F1.N; i++) { matches12[i] = m12[i]; prev_xy[2 * i] = prev[i].x; prev_xy[2 * i + 1] = prev[i].y; }
     return n;
 }
@@ -357,7 +370,7 @@ int orbslam_ref_search_by_projection_points(void* fp, int nq, const float* px, c
         pts[q] = p; index[p] = q;
     }
     ORBmatcher matcher(nnratio);
-    const int n = matcher.SearchByProjection(F, pts, th);
+    int n; { CallTimer ct; n = matcher.SearchByProjection(F, pts, th); }
     for (int i = 0; i < F.N; i++) { auto it = index.find(F.mvpMapPoints[i]); feature_query[i] = it == index.end() ? -1 : it->second; }
     return n;
 }
@@ -380,7 +393,7 @@ int orbslam_ref_search_by_projection_last(void* cur, void* last, const uint8_t* 
     }
     ORBmatcher matcher(nnratio, check_ori != 0);
     std::vector<MapPoint*> before(C.mvpMapPoints);
-    const int n = matcher.SearchByProjection(C, Lf, th, mono != 0);
+    int n; { CallTimer ct; n = matcher.SearchByProjection(C, Lf, th, mono != 0); }
     // index of the last-frame point now attached; -2 = a feature that held a map point before the call and is NULL now (claimed, then removed by
     // the rotation check, :1452-1466); -1 = as before the call
     for (int i = 0; i < C.N; i++) { auto it = index.find(C.mvpMapPoints[i]); feature_query[i] = it != index.end() ? it->second : (!C.mvpMapPoints[i] && before[i]) ? -2 : -1; }
@@ -419,13 +432,13 @@ int orbslam_ref_search_by_bow(int mode, void* f1, const uint8_t* has1, const uin
     int n = 0;
     if (mode == 0) {
         std::vector<MapPoint*> out;
-        n = matcher.SearchByBoW(kf1, F2, out);
+        { CallTimer ct; n = matcher.SearchByBoW(kf1, F2, out); }
         for (int i2 = 0; i2 < F2.N; i2++) if (out[i2]) match12[idx1[out[i2]]] = i2;
     } else {
         give_points(F2, has2, bad2, idx2);
         KeyFrame* kf2 = new KeyFrame(F2, NULL, NULL);
         std::vector<MapPoint*> out;
-        n = matcher.SearchByBoW(kf1, kf2, out);
+        { CallTimer ct; n = matcher.SearchByBoW(kf1, kf2, out); }
         for (int i1 = 0; i1 < F1.N; i1++) if (out[i1]) match12[i1] = idx2[out[i1]];
         delete kf2;
     }
@@ -454,7 +467,7 @@ int orbslam_ref_search_for_triangulation(void* f1, const uint8_t* has1, const ui
     for (int i = 0; i < 9; i++) F.at<float>(i / 3, i % 3) = F12[i];
     std::vector<std::pair<size_t, size_t> > pairs;
     ORBmatcher matcher(0.6f, check_ori != 0);
-    const int n = matcher.SearchForTriangulation(kf1, kf2, F, pairs, only_stereo != 0);
+    int n; { CallTimer ct; n = matcher.SearchForTriangulation(kf1, kf2, F, pairs, only_stereo != 0); }
     for (int i = 0; i < F1.N; i++) match12[i] = -1;
     for (size_t i = 0; i < pairs.size(); i++) match12[pairs[i].first] = (int)pairs[i].second;
     delete kf1; delete kf2;
@@ -492,7 +505,7 @@ int orbslam_ref_fuse(void* fp, const uint8_t* kf_state, int nq, const float* X, 
     for (int q = 0; q < nq; q++) pts[q] = make_query_point(X[q], Y[q], Z[q], desc + (size_t)q * 32, level[q], nobs[q], bad[q] != 0);
     ORB_SLAM2::g_replaced.clear();
     ORBmatcher matcher(0.6f, true);
-    const int n = matcher.Fuse(kf, pts, th);
+    int n; { CallTimer ct; n = matcher.Fuse(kf, pts, th); }
     std::map<MapPoint*, int> qIndex;
     for (int q = 0; q < nq; q++) { qIndex[pts[q]] = q; best_idx[q] = pts[q]->mnBALocalForKF ? (int)pts[q]->mnBALocalForKF - 1 : -1; }
     for (size_t r = 0; r < ORB_SLAM2::g_replaced.size(); r++) {
@@ -518,7 +531,7 @@ int orbslam_ref_fuse_sim3(void* fp, const uint8_t* kf_state, int nq, const float
     std::vector<MapPoint*> pts(nq), repl(nq, static_cast<MapPoint*>(NULL));
     for (int q = 0; q < nq; q++) pts[q] = make_query_point(X[q], Y[q], Z[q], desc + (size_t)q * 32, level[q], 1, bad[q] != 0);
     ORBmatcher matcher(0.8f, true);
-    const int n = matcher.Fuse(kf, cv::Mat::eye(4, 4, CV_32F), pts, th, repl);
+    int n; { CallTimer ct; n = matcher.Fuse(kf, cv::Mat::eye(4, 4, CV_32F), pts, th, repl); }
     for (int q = 0; q < nq; q++) best_idx[q] = repl[q] ? kfIndex[repl[q]] : (pts[q]->mnBALocalForKF ? (int)pts[q]->mnBALocalForKF - 1 : -1);
     delete kf;
     return n;
@@ -537,7 +550,7 @@ int orbslam_ref_search_by_projection_kf(void* fp, const uint8_t* matched_state, 
     for (int q = 0; q < nq; q++) { pts[q] = make_query_point(X[q], Y[q], Z[q], desc + (size_t)q * 32, level[q], 1, bad[q] != 0); qIndex[pts[q]] = q; }
     ORBmatcher matcher(0.75f, true);
     cv::Mat S = cv::Mat::eye(4, 4, CV_32F);
-    const int n = matcher.SearchByProjection(kf, S, pts, matched, th);
+    int n; { CallTimer ct; n = matcher.SearchByProjection(kf, S, pts, matched, th); }
     for (int i = 0; i < F.N; i++) { std::map<MapPoint*, int>::iterator it = qIndex.find(matched[i]); feature_query[i] = it == qIndex.end() ? -1 : it->second; }
     delete kf;
     return n;
@@ -563,7 +576,7 @@ int orbslam_ref_search_by_projection_reloc(void* cur, void* kfp, const uint8_t* 
     }
     KeyFrame* kf = identity_keyframe(Fk);
     ORBmatcher matcher(nnratio, check_ori != 0);
-    const int n = matcher.SearchByProjection(C, kf, already, th, orb_dist);
+    int n; { CallTimer ct; n = matcher.SearchByProjection(C, kf, already, th, orb_dist); }
     for (int i = 0; i < C.N; i++) { std::map<MapPoint*, int>::iterator it = index.find(C.mvpMapPoints[i]); feature_query[i] = it == index.end() ? -1 : it->second; }
     delete kf;
     return n;
@@ -587,7 +600,7 @@ int orbslam_ref_search_by_sim3(void* f1, const uint8_t* has1, const float* X1, c
     }
     ORBmatcher matcher(0.75f, true);
     cv::Mat R = cv::Mat::eye(3, 3, CV_32F), t = cv::Mat(cv::Mat::zeros(3, 1, CV_32F));
-    const int n = matcher.SearchBySim3(kf1, kf2, m12, 1.0f, R, t, th);
+    int n; { CallTimer ct; n = matcher.SearchBySim3(kf1, kf2, m12, 1.0f, R, t, th); }
     for (int i = 0; i < F1.N; i++) { std::map<MapPoint*, int>::iterator it = idx2.find(m12[i]); match12[i] = it == idx2.end() ? -1 : it->second; }
     delete kf1; delete kf2;
     return n;

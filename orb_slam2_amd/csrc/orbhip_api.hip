@@ -1557,6 +1557,77 @@ extern "C" orbhip_status orbhip_search_best_in_window_bounds(int device, const o
     return st;
 }
 
+// Several key frames in one pass (Fuse over all targets): [slot][cap] key point / descriptor / grid blocks in one arena; the feature grids of all slots are
+// built by ONE k_match_grid launch when the slots share their image bounds (key frames of one camera do), the searches by one launch over all queries.
+extern "C" orbhip_status orbhip_search_best_in_window_batch(int device, int nslots, orbhip_best_slot* slots, int chi2_gate)
+{
+    if (nslots < 0 || (nslots > 0 && !slots)) return fail(ORBHIP_ERR_INVALID, "bad argument");
+    std::vector<int> live;
+    int cap = 1;
+    for (int s = 0; s < nslots; s++) {
+        orbhip_best_slot& S = slots[s];
+        if (S.n < 0 || S.nq < 0 || (S.nq > 0 && (!S.queries || !S.query_desc || !S.best_idx || !S.best_dist)) || (S.n > 0 && (!S.kps || !S.desc)) ||
+            !(S.bounds.max_x > S.bounds.min_x) || !(S.bounds.max_y > S.bounds.min_y) || (chi2_gate && (!S.inv_level_sigma2 || S.nlevels < 1))) return fail(ORBHIP_ERR_INVALID, "bad argument in slot %d", s);
+        for (int i = 0; i < S.nq; i++) { S.best_idx[i] = -1; S.best_dist[i] = 256; }
+        if (S.n == 0 || S.nq == 0) continue;
+        live.push_back(s); cap = std::max(cap, S.n);
+    }
+    if (live.empty()) return ORBHIP_OK;
+    int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(ORBHIP_ERR_HIP, "no HIP device available: no CPU fallback");
+    HIPCHK(hipSetDevice(device));
+    hipStream_t ts = orbhip_thread_stream(device);
+    cap = (cap + 63) & ~63;                                  // 64 key points = 7 x 256 bytes: the arena's 256-byte blocks then lie exactly cap records apart ([slot][cap])
+    const int NL = (int)live.size(); const size_t C = (size_t)cap;
+    bool same_bounds = true;
+    for (int k = 1; k < NL; k++) same_bounds = same_bounds && !memcmp(&slots[live[k]].bounds, &slots[live[0]].bounds, sizeof(orbhip_bounds));
+    std::vector<BestParams> hB(NL); std::vector<int> pref(NL + 1, 0), hn(NL);
+    for (int k = 0; k < NL; k++) { pref[k + 1] = pref[k] + (slots[live[k]].nq + 3) / 4; hn[k] = slots[live[k]].n; }
+    BestParams* dB = nullptr; int *dpref = nullptr, *dn = nullptr, *dgs = nullptr, *dgi = nullptr; float2* dgxy = nullptr; orbhip_keypoint* dk0 = nullptr;
+    hipError_t e = hipSuccess;
+#define TRY(x) do { if (e == hipSuccess) e = (x); } while (0)
+    TRY(arena_layout(device, [&](Arena& A) {
+        A.io(&dB, (size_t)NL, (const BestParams*)hB.data(), (size_t)NL);
+        A.io(&dpref, (size_t)NL + 1, (const int*)pref.data(), (size_t)NL + 1);
+        A.io(&dn, (size_t)NL, (const int*)hn.data(), (size_t)NL);
+        for (int k = 0; k < NL; k++) {                                                  // [slot][cap] key points first: k_match_grid indexes them by slot
+            orbhip_keypoint* dk = nullptr; A.io(&dk, C, slots[live[k]].kps, (size_t)slots[live[k]].n);
+            if (k == 0) dk0 = dk;
+            hB[k].kp = dk;
+        }
+        for (int k = 0; k < NL; k++) {
+            const orbhip_best_slot& S = slots[live[k]]; BestParams& B = hB[k];
+            uint8_t *dd = nullptr, *dqd = nullptr; float *dur = nullptr, *dsg = nullptr; orbhip_best_query* dq = nullptr; int *dbi = nullptr, *dbd = nullptr;
+            A.io(&dd, (size_t)S.n * 32, S.desc, (size_t)S.n * 32); A.io(&dqd, (size_t)S.nq * 32, S.query_desc, (size_t)S.nq * 32); A.io(&dq, S.nq, S.queries, S.nq);
+            if (S.u_right) A.io(&dur, S.n, S.u_right, S.n);
+            if (S.inv_level_sigma2 && S.nlevels > 0) A.io(&dsg, S.nlevels, S.inv_level_sigma2, S.nlevels);
+            A.io(&dbi, S.nq, (const int*)nullptr, 0, S.best_idx, S.nq); A.io(&dbd, S.nq, (const int*)nullptr, 0, S.best_dist, S.nq);
+            B.desc = dd; B.u_right = dur; B.inv_level_sigma2 = dsg; B.q = dq; B.qdesc = dqd; B.nq = S.nq; B.chi2_gate = chi2_gate; B.best_idx = dbi; B.best_dist = dbd;
+            B.min_x = S.bounds.min_x; B.gw_inv = (float)ORBHIP_GRID_COLS / (float)(S.bounds.max_x - S.bounds.min_x);
+        }
+        A.take(&dgs, (size_t)NL * (ORBHIP_GRID_CELLS + 1)); A.take(&dgi, NL * C); A.take(&dgxy, NL * C);
+    }));
+    for (int k = 0; k < NL && e == hipSuccess; k++) { hB[k].grid_start = dgs + (size_t)k * (ORBHIP_GRID_CELLS + 1); hB[k].grid_items = dgi + k * C; hB[k].grid_xy = dgxy + k * C; }
+    TRY(arena_upload(ts));
+    if (e == hipSuccess) {
+        for (int k = 0; k < (same_bounds ? 1 : NL); k++) {
+            const orbhip_bounds& b = slots[live[k]].bounds;
+            MatchParams M; memset(&M, 0, sizeof M);
+            M.kp2 = dk0; M.n2 = dn; M.cap = cap; M.min_x = b.min_x; M.min_y = b.min_y; M.max_x = b.max_x; M.max_y = b.max_y; M.grid_start = dgs; M.grid_items = dgi; M.grid_xy = dgxy; M.grid_all_levels = 1; M.slot0 = k;
+            orbhip_launch_match_grid(M, same_bounds ? NL : 1, ts);
+        }
+        orbhip_launch_best_in_window_batch(dB, dpref, NL, pref[NL], ts);
+        e = hipGetLastError();
+    }
+    TRY(arena_download(ts));
+    if (e != hipSuccess) (void)hipStreamSynchronize(ts);
+#undef TRY
+    if (e != hipSuccess) {
+        for (int k = 0; k < NL; k++) { orbhip_best_slot& S = slots[live[k]]; for (int i = 0; i < S.nq; i++) { S.best_idx[i] = -1; S.best_dist[i] = 256; } }
+        return fail(ORBHIP_ERR_HIP, "search_best_in_window_batch: %s", hipGetErrorString(e));
+    }
+    return ORBHIP_OK;
+}
+
 // The two searches above on a frame that is still on the device: key points (mvKeysUn with a distorted camera attached), descriptors
 // and — if asked for — mvuRight of the last stereo / RGB-D step are read where the extraction left them; only the queries travel.
 static orbhip_status frame_args(orbhip_ctx* c, int frame, int n, int use_u_right, const orbhip_keypoint** kp, const uint8_t** desc, const float** ur)

@@ -25,6 +25,7 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <array>
 #include "../../include/orbhip.h"
 #include "orbhip_internal.h"
 #include <map>
@@ -198,9 +199,11 @@ __device__ __forceinline__ unsigned long long bm_argmin_mask(int d, unsigned lon
     return M;
 }
 
-__global__ __launch_bounds__(256) void k_bow_match(BowMatchParams P)
+// slot of a batched launch that block `block` belongs to: pref[s] = first block of slot s (ascending, pref[nslots] = grid size); uniform -> scalar loads
+__device__ __forceinline__ int bm_batch_slot(const int* pref, int nslots, int block) { int s = 0; while (s + 1 < nslots && block >= pref[s + 1]) s++; return s; }
+
+__device__ __forceinline__ void bow_match_body(const BowMatchParams& P, int a, int lane)
 {
-    const int lane = threadIdx.x & 63, a = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (a >= P.nf1) return;
     const uint32_t node = P.fn1[a];
     int lo = 0, hi = P.nf2;                                    // lower_bound on side 2's node ids
@@ -258,11 +261,21 @@ __global__ __launch_bounds__(256) void k_bow_match(BowMatchParams P)
     }
 }
 
+__global__ __launch_bounds__(256) void k_bow_match(BowMatchParams P)
+{
+    bow_match_body(P, blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63);
+}
+// several independent pairs in one launch (orbhip_search_by_bow_batch): the parameter blocks live in device memory
+__global__ __launch_bounds__(256) void k_bow_match_batch(const BowMatchParams* Ps, const int* pref, int npairs)
+{
+    const int sl = bm_batch_slot(pref, npairs, blockIdx.x);
+    bow_match_body(Ps[sl], (blockIdx.x - pref[sl]) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63);
+}
+
 // ComputeThreeMaxima (ORBmatcher.cc:1601-1642), rejection of the other bins (:262-285 / :629-652), nmatches
-__global__ __launch_bounds__(256) void k_bow_match_finish(BowMatchParams P)
+__device__ __forceinline__ void bow_finish_body(const BowMatchParams& P, int tid)
 {
     __shared__ int s_ind[3]; __shared__ int s_cnt;
-    const int tid = threadIdx.x;
     if (tid == 0) {
         int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
         for (int i = 0; i < ORBHIP_HISTO_LENGTH; i++) {
@@ -286,6 +299,8 @@ __global__ __launch_bounds__(256) void k_bow_match_finish(BowMatchParams P)
     __syncthreads();
     if (tid == 0) *P.nmatches = s_cnt;
 }
+__global__ __launch_bounds__(256) void k_bow_match_finish(BowMatchParams P) { bow_finish_body(P, threadIdx.x); }
+__global__ __launch_bounds__(256) void k_bow_match_finish_batch(const BowMatchParams* Ps) { bow_finish_body(Ps[blockIdx.x], threadIdx.x); }
 
 // ------------------------------------------------------------------------------------------------ SearchForTriangulation
 // ORBmatcher::SearchForTriangulation (ORBmatcher.cc:657-823) + CheckDistEpipolarLine (:140-157) on flat data: features of two
@@ -300,10 +315,9 @@ struct TriParams {
     float F[9]; float ex, ey; const float* scale2; const float* sigma2_2; int only_stereo;
 };
 
-__global__ __launch_bounds__(256) void k_bow_triangulate(TriParams T)
+__device__ __forceinline__ void bow_triangulate_body(const TriParams& T, int a, int lane)
 {
     const BowMatchParams& P = T.M;
-    const int lane = threadIdx.x & 63, a = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (a >= P.nf1) return;
     const uint32_t node = P.fn1[a];
     int lo = 0, hi = P.nf2;
@@ -370,6 +384,17 @@ __global__ __launch_bounds__(256) void k_bow_triangulate(TriParams T)
         }
     }
 }
+__global__ __launch_bounds__(256) void k_bow_triangulate(TriParams T)
+{
+    bow_triangulate_body(T, blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63);
+}
+// one key frame against several neighbours in one launch (orbhip_search_for_triangulation_batch)
+__global__ __launch_bounds__(256) void k_bow_triangulate_batch(const TriParams* Ts, const int* pref, int npairs)
+{
+    const int sl = bm_batch_slot(pref, npairs, blockIdx.x);
+    bow_triangulate_body(Ts[sl], (blockIdx.x - pref[sl]) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63);
+}
+__global__ __launch_bounds__(256) void k_bow_triangulate_finish_batch(const TriParams* Ts) { bow_finish_body(Ts[blockIdx.x].M, threadIdx.x); }
 
 // ------------------------------------------------------------------------------------------------ host side
 // Workspace for nframes x cap features.  Grow-only (a transform per frame / key frame with a different feature count must not pay eleven
@@ -764,5 +789,156 @@ extern "C" orbhip_status orbhip_search_for_triangulation(int device,
     if (e == hipSuccess) e = arena_download(ts);
     if (e != hipSuccess) { (void)hipStreamSynchronize(ts); for (int i = 0; i < n1; i++) match12[i] = -1; return orbhip_set_error(ORBHIP_ERR_HIP, "search_for_triangulation: %s", hipGetErrorString(e)); }
     *nmatches = tail[ORBHIP_HISTO_LENGTH];
+    return ORBHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ batched forms (include/orbhip.h)
+// The back end calls these matchers in loops over neighbours / candidates (Tracking.cc:1357-1380, LoopClosing.cc:239-375,
+// LocalMapping.cc:237-268); a call is launch latency, not work.  Here every distinct side travels once, all pairs run in ONE launch set (the
+// parameter blocks in device memory, a prefix table from block to pair) and all answers come back in one copy.
+namespace {
+struct SideDev { uint8_t* d = nullptr; float* ang = nullptr; uint8_t* valid = nullptr; uint32_t* fn = nullptr; int* fo = nullptr; uint32_t* ff = nullptr; };
+}
+extern "C" orbhip_status orbhip_search_by_bow_batch(int device, int mode, int npairs, orbhip_bow_pair* pairs, float nnratio, int check_ori)
+{
+    if (npairs < 0 || (npairs > 0 && !pairs) || (mode != 0 && mode != 1)) return orbhip_set_error(ORBHIP_ERR_INVALID, "bad argument");
+    std::vector<const orbhip_bow_side*> sides;                       // distinct sides, in order of first use
+    std::vector<int> live;                                           // pairs with work
+    auto side_index = [&](const orbhip_bow_side* sd) { for (size_t i = 0; i < sides.size(); i++) if (sides[i] == sd) return (int)i; sides.push_back(sd); return (int)sides.size() - 1; };
+    for (int p = 0; p < npairs; p++) {
+        orbhip_bow_pair& Q = pairs[p];
+        if (!Q.side1 || !Q.side2 || Q.side1->n < 0 || (Q.side1->n > 0 && !Q.match12) || Q.side2->n < 0 || Q.side1->nfv < 0 || Q.side2->nfv < 0) return orbhip_set_error(ORBHIP_ERR_INVALID, "bad argument in pair %d", p);
+        Q.nmatches = 0;
+        for (int i = 0; i < Q.side1->n; i++) Q.match12[i] = -1;
+        if (Q.side1->n == 0 || Q.side2->n == 0 || Q.side1->nfv == 0 || Q.side2->nfv == 0) continue;
+        for (const orbhip_bow_side* sd : {Q.side1, Q.side2})
+            if (!sd->desc || !sd->angle || !sd->fv_node || !sd->fv_off || !sd->fv_feat) return orbhip_set_error(ORBHIP_ERR_INVALID, "null array in pair %d", p);
+        if (!Q.side1->valid || (mode == 1 && !Q.side2->valid)) return orbhip_set_error(ORBHIP_ERR_INVALID, "null validity flags in pair %d", p);
+        live.push_back(p);
+    }
+    if (live.empty()) return ORBHIP_OK;
+    BOWCHK(hipSetDevice(device));
+    hipStream_t ts = orbhip_thread_stream(device);
+    const int NL = (int)live.size();
+    std::vector<int> s1(NL), s2(NL), pref(NL + 1, 0);
+    for (int k = 0; k < NL; k++) { s1[k] = side_index(pairs[live[k]].side1); s2[k] = side_index(pairs[live[k]].side2); pref[k + 1] = pref[k] + (pairs[live[k]].side1->nfv + 3) / 4; }
+    int nmax2 = 1; for (const orbhip_bow_side* sd : sides) nmax2 = std::max(nmax2, sd->n);
+    const std::vector<uint8_t> ones(nmax2, 1);                       // mode 0 ignores side 2's flags
+    std::vector<SideDev> D(sides.size());
+    std::vector<BowMatchParams> hP(NL);
+    std::vector<std::array<int, ORBHIP_HISTO_LENGTH + 2>> zeros(NL), tail(NL);
+    for (auto& z : zeros) z.fill(0);
+    BowMatchParams* dP = nullptr; int* dpref = nullptr;
+    std::vector<int*> dm12(NL), dbin(NL), dhist(NL);
+    BOWCHK(arena_layout(device, [&](Arena& A) {
+        A.io(&dP, (size_t)NL, (const BowMatchParams*)hP.data(), (size_t)NL);                 // (filled below, read when the arena is uploaded)
+        A.io(&dpref, (size_t)NL + 1, (const int*)pref.data(), (size_t)NL + 1);
+        for (size_t i = 0; i < sides.size(); i++) {
+            const orbhip_bow_side& sd = *sides[i]; const int m = sd.fv_off[sd.nfv];
+            A.io(&D[i].d, (size_t)sd.n * 32, sd.desc, (size_t)sd.n * 32); A.io(&D[i].ang, sd.n, sd.angle, sd.n);
+            A.io(&D[i].valid, sd.n, sd.valid ? sd.valid : ones.data(), sd.n);
+            A.io(&D[i].fn, sd.nfv, sd.fv_node, sd.nfv); A.io(&D[i].fo, sd.nfv + 1, (const int*)sd.fv_off, sd.nfv + 1); A.io(&D[i].ff, std::max(m, 1), sd.fv_feat, m);
+        }
+        for (int k = 0; k < NL; k++) {
+            orbhip_bow_pair& Q = pairs[live[k]]; const int n1 = Q.side1->n;
+            A.io(&dbin[k], n1, (const int*)Q.match12, n1);                                   // bin12 = -1
+            A.io(&dm12[k], n1, (const int*)Q.match12, n1, (int*)Q.match12, n1);             // match12 = -1 in, the answer out
+            A.io(&dhist[k], ORBHIP_HISTO_LENGTH + 2, (const int*)zeros[k].data(), ORBHIP_HISTO_LENGTH + 2, tail[k].data(), ORBHIP_HISTO_LENGTH + 2);
+        }
+    }));
+    for (int k = 0; k < NL; k++) {
+        const orbhip_bow_pair& Q = pairs[live[k]]; BowMatchParams& P = hP[k]; memset(&P, 0, sizeof P);
+        const SideDev &a = D[s1[k]], &b = D[s2[k]];
+        P.mode = mode; P.nnratio = nnratio; P.check_ori = check_ori;
+        P.d1 = a.d; P.ang1 = a.ang; P.valid1 = a.valid; P.n1 = Q.side1->n; P.fn1 = a.fn; P.fo1 = a.fo; P.ff1 = a.ff; P.nf1 = Q.side1->nfv;
+        P.d2 = b.d; P.ang2 = b.ang; P.valid2 = b.valid; P.n2 = Q.side2->n; P.fn2 = b.fn; P.fo2 = b.fo; P.ff2 = b.ff; P.nf2 = Q.side2->nfv;
+        P.match12 = dm12[k]; P.bin12 = dbin[k]; P.hist = dhist[k]; P.nmatches = dhist[k] + ORBHIP_HISTO_LENGTH; P.overflow = P.nmatches + 1;
+    }
+    hipError_t e = arena_upload(ts);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_bow_match_batch, dim3(pref[NL], 1, 1), dim3(256, 1, 1), 0, ts, (const BowMatchParams*)dP, (const int*)dpref, NL);
+        hipLaunchKernelGGL(k_bow_match_finish_batch, dim3(NL, 1, 1), dim3(256, 1, 1), 0, ts, (const BowMatchParams*)dP);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = arena_download(ts);
+    bool overflow = false;
+    for (int k = 0; k < NL; k++) overflow = overflow || tail[k][ORBHIP_HISTO_LENGTH + 1] != 0;
+    if (e != hipSuccess || overflow) {
+        if (e != hipSuccess) (void)hipStreamSynchronize(ts);
+        for (int k = 0; k < NL; k++) { orbhip_bow_pair& Q = pairs[live[k]]; for (int i = 0; i < Q.side1->n; i++) Q.match12[i] = -1; }
+        return e != hipSuccess ? orbhip_set_error(ORBHIP_ERR_HIP, "search_by_bow_batch: %s", hipGetErrorString(e))
+                               : orbhip_set_error(ORBHIP_ERR_UNSUPPORTED, "a vocabulary node holds more than %d features of side 2", 64 * BM_CHUNKS);
+    }
+    for (int k = 0; k < NL; k++) pairs[live[k]].nmatches = tail[k][ORBHIP_HISTO_LENGTH];
+    return ORBHIP_OK;
+}
+
+extern "C" orbhip_status orbhip_search_for_triangulation_batch(int device, const orbhip_tri_side* kf1, int npairs, orbhip_tri_pair* pairs, int only_stereo, int check_ori)
+{
+    if (!kf1 || npairs < 0 || (npairs > 0 && !pairs) || kf1->n < 0 || kf1->nfv < 0) return orbhip_set_error(ORBHIP_ERR_INVALID, "bad argument");
+    std::vector<int> live;
+    for (int p = 0; p < npairs; p++) {
+        orbhip_tri_pair& Q = pairs[p];
+        if (!Q.kf2 || (kf1->n > 0 && !Q.match12) || Q.kf2->n < 0 || Q.kf2->nfv < 0 || Q.kf2->nlevels < 1) return orbhip_set_error(ORBHIP_ERR_INVALID, "bad argument in pair %d", p);
+        Q.nmatches = 0;
+        for (int i = 0; i < kf1->n; i++) Q.match12[i] = -1;
+        if (kf1->n == 0 || Q.kf2->n == 0 || kf1->nfv == 0 || Q.kf2->nfv == 0) continue;
+        const orbhip_tri_side& b = *Q.kf2;
+        if (!b.desc || !b.kp || !b.has_mp || !b.stereo || !b.fv_node || !b.fv_off || !b.fv_feat || !b.scale_factors || !b.level_sigma2) return orbhip_set_error(ORBHIP_ERR_INVALID, "null array in pair %d", p);
+        live.push_back(p);
+    }
+    if (live.empty()) return ORBHIP_OK;
+    if (!kf1->desc || !kf1->kp || !kf1->has_mp || !kf1->stereo || !kf1->fv_node || !kf1->fv_off || !kf1->fv_feat) return orbhip_set_error(ORBHIP_ERR_INVALID, "null array in key frame 1");
+    BOWCHK(hipSetDevice(device));
+    hipStream_t ts = orbhip_thread_stream(device);
+    const int NL = (int)live.size(), n1 = kf1->n, m1 = kf1->fv_off[kf1->nfv], blocks1 = (kf1->nfv + 3) / 4;
+    std::vector<int> pref(NL + 1, 0);
+    for (int k = 0; k < NL; k++) pref[k + 1] = pref[k] + blocks1;
+    std::vector<TriParams> hT(NL);
+    std::vector<std::array<int, ORBHIP_HISTO_LENGTH + 2>> zeros(NL), tail(NL);
+    for (auto& z : zeros) z.fill(0);
+    TriParams* dT = nullptr; int* dpref = nullptr;
+    uint8_t *d1 = nullptr, *h1 = nullptr, *st1 = nullptr; float* k1 = nullptr; uint32_t *fn1 = nullptr, *ff1 = nullptr; int* fo1 = nullptr;
+    struct Side2 { uint8_t *d, *h, *st; float *k, *sc, *sg; uint32_t *fn, *ff; int* fo; };
+    std::vector<Side2> B(NL); std::vector<int*> dm12(NL), dbin(NL), dhist(NL);
+    BOWCHK(arena_layout(device, [&](Arena& A) {
+        A.io(&dT, (size_t)NL, (const TriParams*)hT.data(), (size_t)NL);
+        A.io(&dpref, (size_t)NL + 1, (const int*)pref.data(), (size_t)NL + 1);
+        A.io(&d1, (size_t)n1 * 32, kf1->desc, (size_t)n1 * 32); A.io(&k1, (size_t)n1 * 4, kf1->kp, (size_t)n1 * 4); A.io(&h1, n1, kf1->has_mp, n1); A.io(&st1, n1, kf1->stereo, n1);
+        A.io(&fn1, kf1->nfv, kf1->fv_node, kf1->nfv); A.io(&fo1, kf1->nfv + 1, (const int*)kf1->fv_off, kf1->nfv + 1); A.io(&ff1, std::max(m1, 1), kf1->fv_feat, m1);
+        for (int k = 0; k < NL; k++) {
+            orbhip_tri_pair& Q = pairs[live[k]]; const orbhip_tri_side& b = *Q.kf2; const int n2 = b.n, m2 = b.fv_off[b.nfv]; Side2& S = B[k];
+            A.io(&S.d, (size_t)n2 * 32, b.desc, (size_t)n2 * 32); A.io(&S.k, (size_t)n2 * 4, b.kp, (size_t)n2 * 4); A.io(&S.h, n2, b.has_mp, n2); A.io(&S.st, n2, b.stereo, n2);
+            A.io(&S.fn, b.nfv, b.fv_node, b.nfv); A.io(&S.fo, b.nfv + 1, (const int*)b.fv_off, b.nfv + 1); A.io(&S.ff, std::max(m2, 1), b.fv_feat, m2);
+            A.io(&S.sc, b.nlevels, b.scale_factors, b.nlevels); A.io(&S.sg, b.nlevels, b.level_sigma2, b.nlevels);
+            A.io(&dbin[k], n1, (const int*)Q.match12, n1);
+            A.io(&dm12[k], n1, (const int*)Q.match12, n1, (int*)Q.match12, n1);
+            A.io(&dhist[k], ORBHIP_HISTO_LENGTH + 2, (const int*)zeros[k].data(), ORBHIP_HISTO_LENGTH + 2, tail[k].data(), ORBHIP_HISTO_LENGTH + 2);
+        }
+    }));
+    for (int k = 0; k < NL; k++) {
+        const orbhip_tri_pair& Q = pairs[live[k]]; const Side2& S = B[k]; TriParams& T = hT[k]; memset(&T, 0, sizeof T);
+        BowMatchParams& P = T.M;
+        P.mode = 0; P.nnratio = 0.f; P.check_ori = check_ori;
+        P.d1 = d1; P.valid1 = h1; P.n1 = n1; P.fn1 = fn1; P.fo1 = fo1; P.ff1 = ff1; P.nf1 = kf1->nfv;
+        P.d2 = S.d; P.valid2 = S.h; P.n2 = Q.kf2->n; P.fn2 = S.fn; P.fo2 = S.fo; P.ff2 = S.ff; P.nf2 = Q.kf2->nfv;
+        P.match12 = dm12[k]; P.bin12 = dbin[k]; P.hist = dhist[k]; P.nmatches = dhist[k] + ORBHIP_HISTO_LENGTH; P.overflow = P.nmatches + 1;
+        T.kp1 = k1; T.kp2 = S.k; T.st1 = st1; T.st2 = S.st;
+        for (int i = 0; i < 9; i++) T.F[i] = Q.F12[i];
+        T.ex = Q.ex; T.ey = Q.ey; T.scale2 = S.sc; T.sigma2_2 = S.sg; T.only_stereo = only_stereo;
+    }
+    hipError_t e = arena_upload(ts);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_bow_triangulate_batch, dim3(pref[NL], 1, 1), dim3(256, 1, 1), 0, ts, (const TriParams*)dT, (const int*)dpref, NL);
+        hipLaunchKernelGGL(k_bow_triangulate_finish_batch, dim3(NL, 1, 1), dim3(256, 1, 1), 0, ts, (const TriParams*)dT);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = arena_download(ts);
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(ts);
+        for (int k = 0; k < NL; k++) { orbhip_tri_pair& Q = pairs[live[k]]; for (int i = 0; i < n1; i++) Q.match12[i] = -1; }
+        return orbhip_set_error(ORBHIP_ERR_HIP, "search_for_triangulation_batch: %s", hipGetErrorString(e));
+    }
+    for (int k = 0; k < NL; k++) pairs[live[k]].nmatches = tail[k][ORBHIP_HISTO_LENGTH];
     return ORBHIP_OK;
 }

@@ -155,6 +155,7 @@ struct BestParams {
     float min_x, gw_inv;        // left image bound and grid columns per pixel of the table's grid (gw_inv = 0: scan the whole table)
 };
 void orbhip_launch_best_in_window(const BestParams& B, hipStream_t s);
+void orbhip_launch_best_in_window_batch(const BestParams* d_slots, const int* d_pref, int nslots, int nblocks, hipStream_t s);
 size_t orbhip_proj_select_lds(int n);
 
 // kernel launchers (orbhip_kernels_extract.hip / orbhip_kernels_match.hip)

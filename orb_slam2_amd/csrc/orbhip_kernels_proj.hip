@@ -348,9 +348,8 @@ void orbhip_launch_proj_batch(const ProjParams* d_slots, int nslots, int max_nq,
 // literals), FIRST smallest descriptor distance.  Queries do not interact: one wavefront per query scans the ordered bucket table
 // (cell ix*ROWS+iy, then index == GetFeaturesInArea's order; a key point within the radius always lies in a visited cell, see
 // k_match_candidates), lane-parallel, first-minimum by (distance, table position).
-__global__ __launch_bounds__(256) void k_best_in_window(BestParams B)
+__device__ __forceinline__ void best_in_window_body(const BestParams& B, int iq, int lane)
 {
-    const int lane = threadIdx.x & 63, iq = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (iq >= B.nq) return;
     const orbhip_best_query q = B.q[iq];
     const uint4* q4 = reinterpret_cast<const uint4*>(B.qdesc + (long long)iq * 32);
@@ -406,8 +405,22 @@ __global__ __launch_bounds__(256) void k_best_in_window(BestParams B)
     }
     if (lane == 0) { B.best_idx[iq] = bidx; B.best_dist[iq] = best; }
 }
+__global__ __launch_bounds__(256) void k_best_in_window(BestParams B)
+{
+    best_in_window_body(B, blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63);
+}
+// several key frames in one launch (orbhip_search_best_in_window_batch): parameter blocks in device memory, pref[s] = first block of slot s
+__global__ __launch_bounds__(256) void k_best_in_window_batch(const BestParams* Bs, const int* pref, int nslots)
+{
+    int sl = 0; while (sl + 1 < nslots && (int)blockIdx.x >= pref[sl + 1]) sl++;
+    best_in_window_body(Bs[sl], ((int)blockIdx.x - pref[sl]) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63);
+}
 
 void orbhip_launch_best_in_window(const BestParams& B, hipStream_t s)
 {
     if (B.nq > 0) hipLaunchKernelGGL(k_best_in_window, dim3((B.nq + 3) / 4, 1, 1), dim3(256, 1, 1), 0, s, B);
+}
+void orbhip_launch_best_in_window_batch(const BestParams* d_slots, const int* d_pref, int nslots, int nblocks, hipStream_t s)
+{
+    if (nblocks > 0) hipLaunchKernelGGL(k_best_in_window_batch, dim3(nblocks, 1, 1), dim3(256, 1, 1), 0, s, d_slots, d_pref, nslots);
 }

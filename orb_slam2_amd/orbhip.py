@@ -133,6 +133,9 @@ def lib(path=None):
     L.orbhip_search_for_triangulation.argtypes = [C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int,
                                                   vp, C.c_float, C.c_float, vp, vp, C.c_int, C.c_int, C.c_int, vp, ip]
     L.orbhip_search_best_in_window.argtypes = [C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp]
+    L.orbhip_search_by_bow_batch.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.c_float, C.c_int]
+    L.orbhip_search_for_triangulation_batch.argtypes = [C.c_int, vp, C.c_int, vp, C.c_int, C.c_int]
+    L.orbhip_search_best_in_window_batch.argtypes = [C.c_int, C.c_int, vp, C.c_int]
     L.orbhip_undistort_points.argtypes = [C.c_int, C.POINTER(Camera), vp, C.c_int, vp]
     L.orbhip_image_bounds.argtypes = [C.c_int, C.POINTER(Camera), C.c_int, C.c_int, C.POINTER(Bounds)]
     L.orbhip_set_camera.argtypes = [vp, C.POINTER(Camera)]
@@ -957,7 +960,105 @@ def search_for_triangulation(desc1, kps1, has_mp1, stereo1, fv1, desc2, kps2, ha
     return nm.value, m12
 
 
+class BowSide(C.Structure):          # orbhip_bow_side
+    _fields_ = [("desc", C.c_void_p), ("angle", C.c_void_p), ("valid", C.c_void_p), ("n", C.c_int32), ("fv_node", C.c_void_p), ("fv_off", C.c_void_p), ("fv_feat", C.c_void_p), ("nfv", C.c_int32)]
+
+
+class BowPair(C.Structure):          # orbhip_bow_pair
+    _fields_ = [("side1", C.POINTER(BowSide)), ("side2", C.POINTER(BowSide)), ("match12", C.c_void_p), ("nmatches", C.c_int32)]
+
+
+class TriSide(C.Structure):          # orbhip_tri_side
+    _fields_ = [("desc", C.c_void_p), ("kp", C.c_void_p), ("has_mp", C.c_void_p), ("stereo", C.c_void_p), ("n", C.c_int32), ("fv_node", C.c_void_p), ("fv_off", C.c_void_p), ("fv_feat", C.c_void_p),
+                ("nfv", C.c_int32), ("scale_factors", C.c_void_p), ("level_sigma2", C.c_void_p), ("nlevels", C.c_int32)]
+
+
+class TriPair(C.Structure):          # orbhip_tri_pair
+    _fields_ = [("kf2", C.POINTER(TriSide)), ("F12", C.c_float * 9), ("ex", C.c_float), ("ey", C.c_float), ("match12", C.c_void_p), ("nmatches", C.c_int32)]
+
+
+class BestSlot(C.Structure):         # orbhip_best_slot
+    _fields_ = [("kps", C.c_void_p), ("desc", C.c_void_p), ("u_right", C.c_void_p), ("n", C.c_int32), ("bounds", Bounds), ("inv_level_sigma2", C.c_void_p), ("nlevels", C.c_int32),
+                ("queries", C.c_void_p), ("query_desc", C.c_void_p), ("nq", C.c_int32), ("best_idx", C.c_void_p), ("best_dist", C.c_void_p)]
+
+
+def _fv3(fv):
+    return [np.ascontiguousarray(fv[0], np.uint32), np.ascontiguousarray(fv[1], np.int32), np.ascontiguousarray(fv[2], np.uint32)]
+
+
+def search_by_bow_batch(mode, pairs, nnratio=0.7, check_ori=True, device=0, library=None):
+    """orbhip_search_by_bow_batch.  pairs = [(side1, side2), ...], a side = dict(desc=, angle=, valid= (or None), fv=(nodes, offsets, features)); a side OBJECT named by several
+    pairs (the current frame of Relocalization) is uploaded once.  -> [(nmatches, match12), ...]"""
+    L = lib(library)
+    keep, sides = [], {}
+
+    def side(d):
+        if id(d) not in sides:
+            desc = np.ascontiguousarray(d["desc"], np.uint8); ang = np.ascontiguousarray(d["angle"], np.float32)
+            val = None if d.get("valid") is None else np.ascontiguousarray(d["valid"], np.uint8)
+            f = _fv3(d["fv"])
+            keep.extend([desc, ang, val] + f)
+            sides[id(d)] = BowSide(_p(desc).value if len(desc) else None, _p(ang).value if len(ang) else None, None if val is None else _p(val).value, len(desc), _p(f[0]).value, _p(f[1]).value, _p(f[2]).value, len(f[0]))
+        return sides[id(d)]
+    arr = (BowPair * max(len(pairs), 1))()
+    outs = []
+    for k, (a, b) in enumerate(pairs):
+        sa, sb = side(a), side(b)
+        m12 = np.full(sa.n, -1, np.int32); outs.append(m12)
+        arr[k].side1 = C.pointer(sa); arr[k].side2 = C.pointer(sb); arr[k].match12 = _p(m12).value if len(m12) else None; arr[k].nmatches = 0
+    _check(L.orbhip_search_by_bow_batch(device, mode, len(pairs), arr, nnratio, int(check_ori)), "orbhip_search_by_bow_batch", L)
+    return [(int(arr[k].nmatches), outs[k]) for k in range(len(pairs))]
+
+
+def search_for_triangulation_batch(kf1, neighbours, only_stereo=False, check_ori=False, device=0, library=None):
+    """orbhip_search_for_triangulation_batch.  kf1 / a neighbour's "kf" = dict(desc=, kps= (KEYPOINT array, mvKeysUn), has_mp=, stereo=, fv=, scale_factors=, level_sigma2=);
+    neighbours = [dict(kf=..., F12=, ex=, ey=), ...].  Every pair is searched with kf1's has_mp as given.  -> [(nmatches, match12[n1]), ...]"""
+    L = lib(library)
+    keep = []
+    kp4 = lambda k: np.ascontiguousarray(np.stack([k["x"], k["y"], k["angle"], k["octave"].astype(np.float32)], axis=1), np.float32) if len(k) else np.zeros((0, 4), np.float32)
+
+    def side(d):
+        desc = np.ascontiguousarray(d["desc"], np.uint8); kp = kp4(d["kps"]); hm = np.ascontiguousarray(d["has_mp"], np.uint8); st = np.ascontiguousarray(d["stereo"], np.uint8)
+        f = _fv3(d["fv"]); sc = np.ascontiguousarray(d["scale_factors"], np.float32); sg = np.ascontiguousarray(d["level_sigma2"], np.float32)
+        keep.extend([desc, kp, hm, st, sc, sg] + f)
+        return TriSide(_p(desc).value, _p(kp).value, _p(hm).value, _p(st).value, len(desc), _p(f[0]).value, _p(f[1]).value, _p(f[2]).value, len(f[0]), _p(sc).value, _p(sg).value, len(sc))
+    s1 = side(kf1)
+    arr = (TriPair * max(len(neighbours), 1))()
+    outs, s2s = [], []
+    for k, nb in enumerate(neighbours):
+        s2 = side(nb["kf"]); s2s.append(s2)
+        m12 = np.full(s1.n, -1, np.int32); outs.append(m12)
+        arr[k].kf2 = C.pointer(s2)
+        for i, v in enumerate(np.ascontiguousarray(nb["F12"], np.float32).reshape(9)):
+            arr[k].F12[i] = float(v)
+        arr[k].ex = float(nb["ex"]); arr[k].ey = float(nb["ey"]); arr[k].match12 = _p(m12).value if len(m12) else None
+    _check(L.orbhip_search_for_triangulation_batch(device, C.byref(s1), len(neighbours), arr, int(only_stereo), int(check_ori)), "orbhip_search_for_triangulation_batch", L)
+    return [(int(arr[k].nmatches), outs[k]) for k in range(len(neighbours))]
+
+
 BEST_QUERY_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("radius", "<f4"), ("ur", "<f4"), ("level", "<i4")])
+
+
+def search_best_in_window_batch(slots, chi2_gate, device=0, library=None):
+    """orbhip_search_best_in_window_batch.  slots = [dict(kps=, desc=, u_right= (or None), bounds=(min_x, min_y, max_x, max_y), inv_level_sigma2=, queries=, qdesc=), ...]
+    -> [(best_idx, best_dist), ...]"""
+    L = lib(library)
+    keep, outs = [], []
+    arr = (BestSlot * max(len(slots), 1))()
+    for k, sl in enumerate(slots):
+        kps = np.ascontiguousarray(sl["kps"], KEYPOINT_DTYPE); desc = np.ascontiguousarray(sl["desc"], np.uint8)
+        q = np.ascontiguousarray(sl["queries"], BEST_QUERY_DTYPE); qd = np.ascontiguousarray(sl["qdesc"], np.uint8)
+        inv = np.ascontiguousarray(sl["inv_level_sigma2"], np.float32)
+        ur = None if sl.get("u_right") is None else np.ascontiguousarray(sl["u_right"], np.float32)
+        bi = np.full(len(q), -1, np.int32); bd = np.full(len(q), 256, np.int32)
+        keep.extend([kps, desc, q, qd, inv, ur]); outs.append((bi, bd))
+        a = arr[k]
+        a.kps = _p(kps).value if len(kps) else None; a.desc = _p(desc).value if len(desc) else None; a.u_right = None if ur is None else _p(ur).value; a.n = len(kps)
+        a.bounds = Bounds.of(sl["bounds"]); a.inv_level_sigma2 = _p(inv).value; a.nlevels = len(inv)
+        a.queries = _p(q).value if len(q) else None; a.query_desc = _p(qd).value if len(qd) else None; a.nq = len(q)
+        a.best_idx = _p(bi).value if len(q) else None; a.best_dist = _p(bd).value if len(q) else None
+    _check(L.orbhip_search_best_in_window_batch(device, len(slots), arr, int(chi2_gate)), "orbhip_search_best_in_window_batch", L)
+    return outs
 
 
 def search_best_in_window(kps, desc, im_w, im_h, inv_level_sigma2, queries, qdesc, chi2_gate, u_right=None, device=0, library=None, bounds=None):

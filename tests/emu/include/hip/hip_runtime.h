@@ -74,8 +74,9 @@ __attribute__((naked, noinline)) static void switch_to(void** /*save_sp*/, void*
                      "movq %rsp, (%rdi)\n\tmovq %rsi, %rsp\n\t"
                      "popq %r15\n\tpopq %r14\n\tpopq %r13\n\tpopq %r12\n\tpopq %rbx\n\tpopq %rbp\n\tret");
 }
-inline void yield() { switch_to(&g.cur->sp, g.sched_sp); }
-inline void fiber_main() {
+#define HIPEMU_NO_TSAN __attribute__((no_sanitize_thread))      // ThreadSanitizer builds (make emu_tsan): frames that do not return are not instrumented
+HIPEMU_NO_TSAN inline void yield() { switch_to(&g.cur->sp, g.sched_sp); }
+HIPEMU_NO_TSAN inline void fiber_main() {
     g.body();
     Fiber* f = g.cur; f->done = true; g.live--; g.waves[f->wave].live--;
     switch_to(&f->sp, g.sched_sp);
@@ -103,7 +104,7 @@ inline uint64_t wave_collective(Op op, uint64_t val, int srclane) {
 }
 
 template <typename K, typename... A>
-void launch(K kernel, dim3 grid, dim3 block, size_t shmem, A... args) {
+HIPEMU_NO_TSAN void launch(K kernel, dim3 grid, dim3 block, size_t shmem, A... args) {
     std::lock_guard<std::mutex> serialise(launch_mutex);   // host threads (the reference extracts left / right images on two std::threads) take turns
     const int T = (int)(block.x * block.y * block.z);
     std::vector<char> dyn(shmem + 64);
