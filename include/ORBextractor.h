@@ -105,6 +105,13 @@ public:
     // must have processed their image of the current frame (Frame.cc:78-81).  N = number of left keypoints (Frame::N).
     // Fills mvuRight / mvDepth exactly like the reference; reads keypoints, descriptors and pyramids that are still in HBM.
     void ComputeStereoMatches(ORBextractor& right, float mbf, float mb, int N, std::vector<float>& mvuRight, std::vector<float>& mvDepth);
+    // The stereo pair as ONE call: what Frame::Frame(imLeft, imRight, ...) does with two std::threads, two extractors and ComputeStereoMatches
+    // (Frame.cc:78-90), on THIS extractor alone - both images are uploaded together and run through one launch chain on one device context, the stereo
+    // matcher is queued behind it, one synchronisation.  mb = mbf / fx (the reference reads the member before assigning it, Frame.cc:89, 113: DESIGN.md
+    // H7).  The ComputeStereoMatches() that follows (on this object, any `right`) hands out the columns computed here without another device call;
+    // UndistortKeyPoints / BindFrame / the resident-frame searches see the LEFT image.  integration/apply_dropin.py --stereo-one-call emits the call.
+    void ExtractStereo(cv::InputArray imLeft, cv::InputArray imRight, std::vector<cv::KeyPoint>& keysLeft, cv::OutputArray descLeft,
+                       std::vector<cv::KeyPoint>& keysRight, cv::OutputArray descRight, float mbf, float mb);
     // The device context of the last image (NULL before the first call): ORBVocabulary::ComputeBoW reads the descriptors there.
     orbhip_ctx* Context() { return mpCtx; }
     // Distorted cameras (TUM1-3.yaml).  SetCamera takes Frame's mK / mDistCoef (CV_32F; 4 or 5 coefficients, Tracking.cc:60-82);
@@ -140,7 +147,8 @@ protected:
     void EnsureContext(int width, int height, int maxBatch = 1);
     void FetchPyramid(std::vector<cv::Mat>& levels);
     void Fail(const char* where) const;
-    void Deliver(int n, const std::vector<unsigned char>& desc, std::vector<cv::KeyPoint>& keypoints, cv::OutputArray descriptors);
+    void Deliver(int n, int slot, std::vector<cv::KeyPoint>& keypoints, cv::OutputArray descriptors);
+    void ReserveStage(int slots);
 
     int nfeatures;
     double scaleFactor;
@@ -157,7 +165,10 @@ protected:
     float mCamera[9]; bool mbHasCamera;                         // fx, fy, cx, cy, k1, k2, p1, p2, k3
     std::vector<float> mvMapX, mvMapY; int mnRawCols, mnRawRows; // rectification maps (applied when the context is (re)created)
     int mnLastN;                                                 // key points of the last image
-    std::vector<cv::KeyPoint> mvLastKeys;                        // ... and the key points themselves (mvKeysUn of an undistorted camera)
+    // what the library hands back lands here (sized once per context: no allocation, no value-initialisation per call), [slot][capacity]; slot 0 also
+    // serves UndistortKeyPoints of an undistorted camera (mvKeysUn = mvKeys) until the next call
+    std::vector<unsigned char> mvKpStage, mvDescStage; int mnStageCap;
+    std::vector<float> mvPairURight, mvPairDepth; bool mbPairResults;      // mvuRight / mvDepth of the last ExtractStereo, until ComputeStereoMatches picks them up
     orbhip_ctx* mpCtx;          // device context for the current image size (created lazily at the first image of that size)
     int mnCtxW, mnCtxH, mnCtxBatch, mnCtxDevice, mnDevice, mnBlurRounding, mnFpContract;      // mnCtxDevice: where mpCtx lives; mnDevice: where the next one goes
     // The reference takes any image size per call (it re-allocates its pyramid every time, ORBextractor.cc:1043-1056, 1107-1132); a device context is

@@ -264,6 +264,17 @@ orbhip_status orbhip_search_by_projection(int device, const orbhip_keypoint* kps
 orbhip_status orbhip_compute_stereo_matches(orbhip_ctx* left, orbhip_ctx* right, int nimg, float mbf, float mb,
                                             float* u_right, float* depth, int cap);
 
+/* The stereo pair as ONE call: what the stereo Frame constructor does with its two extractor threads and ComputeStereoMatches (Frame.cc:78-90) on a
+   single context created with max_batch >= 2 (2 is best: the whole result block then travels in one copy).  Both images are uploaded together and
+   run through one launch chain, the stereo matcher (left = slot 0, right = slot 1) is queued behind it; kps / desc are [2][cap] (left, right),
+   n_out[2]; u_right / depth hold cap entries for the LEFT key points (-1 = no match).  mb is passed explicitly.  Afterwards the
+   context's frame 0 is the left image: orbhip_search_by_projection_frame / orbhip_search_best_in_window_frame(ctx, 0, n_out[0], use_u_right = 1, ...),
+   orbhip_compute_bow and orbhip_fetch_undistorted work on it as after a single-image call.  Results are identical to two orbhip_extract calls +
+   orbhip_compute_stereo_matches. */
+orbhip_status orbhip_extract_stereo(orbhip_ctx* ctx, const uint8_t* img_left, const uint8_t* img_right, int stride_bytes,
+                                    orbhip_keypoint* kps, uint8_t* desc /* 2 x cap x 32 */, int cap, int* n_out /* 2 */,
+                                    float mbf, float mb, float* u_right, float* depth);
+
 /* -------- Frame::ComputeStereoFromRGBD (Frame.h:97-98, Frame.cc:643-665) ------------------------------ */
 /* RGB-D sensors: for the first nimg frames of the context's LAST extract call, d = imDepth(v, u) at every key point (mvKeys, the
    distorted position, coordinates truncated like cv::Mat::at<float>(float, float)); d > 0 -> mvDepth = d, mvuRight = mvKeysUn.x - mbf / d,

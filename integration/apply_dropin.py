@@ -3,6 +3,7 @@
 
     python integration/apply_dropin.py /path/to/ORB_SLAM2 /path/to/out      # writes the edited tree pieces under out/
     python integration/apply_dropin.py --patch /path/to/ORB_SLAM2 > dropin.patch   # the same edits as a unified diff (patch -p1)
+    ... --stereo-one-call        optional: the stereo Frame constructor extracts both images in ONE call on one device context (ORBextractor::ExtractStereo)
 
 What it produces (nothing else of the checkout changes; Tracking.cc, LocalMapping.cc, LoopClosing.cc, KeyFrame*.cc compile as they are):
   out/include/ORBextractor.h, out/src/ORBextractor.cc     this repository's drop-in class (include/ORBextractor.h, orb_slam2_amd/cpp/)
@@ -468,9 +469,21 @@ static void orbhip_projection_search(Frame &F, bool bUseRight, const std::vector
 """
 
 
-def patch_frame(src):
+# INTEGRATION.md §2-3g (optional, --stereo-one-call): the stereo constructor's two extractor threads (Frame.cc:78-81) become ONE call on the left
+# extractor - both images through one device context, the stereo matcher queued behind the extraction; the forwarded ComputeStereoMatches() that
+# follows (step 3b) hands out the columns computed there.  mb = mbf / fx: the constructor assigns the member only at its end (Frame.cc:113).
+STEREO_THREADS = (r"thread\s+threadLeft\s*\(\s*&Frame::ExtractORB\s*,\s*this\s*,\s*0\s*,\s*imLeft\s*\)\s*;\s*thread\s+threadRight\s*\(\s*&Frame::ExtractORB\s*,\s*this\s*,\s*1\s*,\s*imRight\s*\)\s*;"
+                  r"\s*threadLeft\.join\(\)\s*;\s*threadRight\.join\(\)\s*;")
+STEREO_ONE_CALL = "mpORBextractorLeft->ExtractStereo(imLeft, imRight, mvKeys, mDescriptors, mvKeysRight, mDescriptorsRight, mbf, mbf/K.at<float>(0,0));"
+
+
+def patch_frame(src, stereo_one_call=False):
     for sig, body in FORWARDS.items():
         src = replace_body(src, sig, body)
+    if stereo_one_call:
+        src, n = re.subn(STEREO_THREADS, STEREO_ONE_CALL, src)
+        if n != 1:
+            raise SystemExit("the stereo constructor's two extractor threads (Frame.cc:78-81) were not found")
     return src
 
 
@@ -503,18 +516,21 @@ def main():
         # --keep-map-free: leave DescriptorDistance / SearchForInitialization to orb_slam2_amd/cpp/ORBmatcher.cc (the steps-1-3 build renames
         # the reference's two bodies out of the way with -D and links that file)
         keep = "--keep-map-free" in argv
-        argv = [a for a in argv[1:] if a != "--keep-map-free"]
-        open(argv[1], "w").write(patch_frame(open(argv[0]).read()))
+        one_call = "--stereo-one-call" in argv
+        argv = [a for a in argv[1:] if a not in ("--keep-map-free", "--stereo-one-call")]
+        open(argv[1], "w").write(patch_frame(open(argv[0]).read(), stereo_one_call=one_call))
         if len(argv) > 3:
             open(argv[3], "w").write(patch_matcher(open(argv[2]).read(), map_free_members=not keep))
         return
+    one_call = "--stereo-one-call" in argv
+    argv = [a for a in argv if a != "--stereo-one-call"]
     emit_patch = bool(argv) and argv[0] == "--patch"
     if emit_patch:
         argv = argv[1:]
     if len(argv) < (1 if emit_patch else 2):
         raise SystemExit(__doc__)
     ref = argv[0]
-    edited = {"src/Frame.cc": patch_frame(open(os.path.join(ref, "src/Frame.cc")).read()),
+    edited = {"src/Frame.cc": patch_frame(open(os.path.join(ref, "src/Frame.cc")).read(), stereo_one_call=one_call),
               "src/ORBmatcher.cc": patch_matcher(open(os.path.join(ref, "src/ORBmatcher.cc")).read())}
     copies = {"include/ORBextractor.h": "include/ORBextractor.h", "src/ORBextractor.cc": "orb_slam2_amd/cpp/ORBextractor.cc", "include/orbhip.h": "include/orbhip.h"}
     if emit_patch:

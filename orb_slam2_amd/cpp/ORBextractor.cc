@@ -19,7 +19,7 @@ static_assert(sizeof(cv::KeyPoint) == sizeof(orbhip_keypoint), "cv::KeyPoint and
 
 ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST)
     : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST),
-      mbHasCamera(false), mnRawCols(0), mnRawRows(0), mnLastN(0),
+      mbHasCamera(false), mnRawCols(0), mnRawRows(0), mnLastN(0), mnStageCap(0), mbPairResults(false),
       mpCtx(NULL), mnCtxW(0), mnCtxH(0), mnCtxBatch(0), mnCtxDevice(0), mnDevice(0),
 #if defined(__SSE2__) || defined(_M_X64)
       mnBlurRounding(1),          // an x86-64 OpenCV (<= 3.3) runs the SSE2 column filter: round-half-even on 4-column groups
@@ -161,12 +161,39 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
     assert(image.type() == CV_8UC1);
     EnsureContext(image.cols, image.rows);
 
-    const int cap = orbhip_keypoint_capacity(mpCtx);
-    _keypoints.resize(cap);
-    std::vector<unsigned char> desc((size_t)cap * 32);
+    ReserveStage(1);
     int n = 0;
-    if (orbhip_extract(mpCtx, image.data, (int)image.step, reinterpret_cast<orbhip_keypoint*>(&_keypoints[0]), &desc[0], cap, &n) != ORBHIP_OK) Fail("ORBextractor");
-    Deliver(n, desc, _keypoints, _descriptors);
+    if (orbhip_extract(mpCtx, image.data, (int)image.step, reinterpret_cast<orbhip_keypoint*>(&mvKpStage[0]), &mvDescStage[0], mnStageCap, &n) != ORBHIP_OK) Fail("ORBextractor");
+    Deliver(n, 0, _keypoints, _descriptors);
+}
+
+void ORBextractor::ReserveStage(int slots)
+{
+    mnStageCap = orbhip_keypoint_capacity(mpCtx);
+    const size_t need = (size_t)slots * mnStageCap;
+    if (mvKpStage.size() < need * sizeof(orbhip_keypoint)) { mvKpStage.resize(need * sizeof(orbhip_keypoint)); mvDescStage.resize(need * 32); }
+}
+
+void ORBextractor::ExtractStereo(cv::InputArray _imLeft, cv::InputArray _imRight, std::vector<cv::KeyPoint>& keysLeft, cv::OutputArray descLeft,
+                                 std::vector<cv::KeyPoint>& keysRight, cv::OutputArray descRight, float mbf, float mb)
+{
+    if (_imLeft.empty() || _imRight.empty()) {                   // the reference's two operator() calls return silently on an empty image (ORBextractor.cc:1046-1047)
+        if (!_imLeft.empty()) (*this)(_imLeft, cv::Mat(), keysLeft, descLeft);
+        mbPairResults = false;
+        return;
+    }
+    cv::Mat L = _imLeft.getMat(), R = _imRight.getMat();
+    assert(L.type() == CV_8UC1 && R.type() == CV_8UC1 && L.cols == R.cols && L.rows == R.rows);
+    if (L.step != R.step) throw ORBhipError("ORBextractor::ExtractStereo: the two images must share their row step");
+    EnsureContext(L.cols, L.rows, 2);
+    ReserveStage(2);
+    mvPairURight.resize(mnStageCap); mvPairDepth.resize(mnStageCap);
+    int n[2] = {0, 0};
+    if (orbhip_extract_stereo(mpCtx, L.data, R.data, (int)L.step, reinterpret_cast<orbhip_keypoint*>(&mvKpStage[0]), &mvDescStage[0], mnStageCap, n, mbf, mb,
+                              &mvPairURight[0], &mvPairDepth[0]) != ORBHIP_OK) Fail("ORBextractor::ExtractStereo");
+    Deliver(n[1], 1, keysRight, descRight);
+    Deliver(n[0], 0, keysLeft, descLeft);                        // last: the extractor's frame state is the LEFT image's
+    mbPairResults = true; mbStereoColumns = true;
 }
 
 void ORBextractor::ExtractColor(const unsigned char* data, int step, int cols, int rows, int channels, bool bRGB,
@@ -174,13 +201,11 @@ void ORBextractor::ExtractColor(const unsigned char* data, int step, int cols, i
 {
     if (!data || cols <= 0 || rows <= 0) return;
     EnsureContext(cols, rows);
-    const int cap = orbhip_keypoint_capacity(mpCtx);
-    _keypoints.resize(cap);
-    std::vector<unsigned char> desc((size_t)cap * 32);
+    ReserveStage(1);
     int n = 0;
     const uint8_t* imgs[1] = {data};
-    if (orbhip_extract_batch_color(mpCtx, 1, imgs, step, channels, bRGB ? 1 : 0, reinterpret_cast<orbhip_keypoint*>(&_keypoints[0]), &desc[0], cap, &n) != ORBHIP_OK) Fail("ORBextractor");
-    Deliver(n, desc, _keypoints, _descriptors);
+    if (orbhip_extract_batch_color(mpCtx, 1, imgs, step, channels, bRGB ? 1 : 0, reinterpret_cast<orbhip_keypoint*>(&mvKpStage[0]), &mvDescStage[0], mnStageCap, &n) != ORBHIP_OK) Fail("ORBextractor");
+    Deliver(n, 0, _keypoints, _descriptors);
 }
 
 static_assert(sizeof(orbhip_camera) == 9 * sizeof(float), "orbhip_camera is nine floats");
@@ -207,9 +232,13 @@ void ORBextractor::SetCamera(const cv::Mat& K, const cv::Mat& distCoef)
 void ORBextractor::UndistortKeyPoints(std::vector<cv::KeyPoint>& mvKeysUn)
 {
     if (mpCtx) RequireFrameState("ORBextractor::UndistortKeyPoints");
+    if (mnLastN == 0 || !mpCtx) { mvKeysUn.clear(); return; }
+    if (!(mbHasCamera && mCamera[4] != 0.0f)) {                                       // if(mDistCoef.at<float>(0)==0.0) mvKeysUn=mvKeys (Frame.cc:406-410): no device trip
+        const cv::KeyPoint* src = reinterpret_cast<const cv::KeyPoint*>(&mvKpStage[0]);
+        mvKeysUn.assign(src, src + mnLastN);
+        return;
+    }
     mvKeysUn.resize(mnLastN);
-    if (mnLastN == 0 || !mpCtx) return;
-    if (!(mbHasCamera && mCamera[4] != 0.0f)) { mvKeysUn = mvLastKeys; return; }      // if(mDistCoef.at<float>(0)==0.0) mvKeysUn=mvKeys (Frame.cc:406-410): no device trip
     if (orbhip_fetch_undistorted(mpCtx, 1, reinterpret_cast<orbhip_keypoint*>(&mvKeysUn[0]), mnLastN) != ORBHIP_OK) Fail("ORBextractor::UndistortKeyPoints");
 }
 
@@ -254,26 +283,28 @@ void ORBextractor::ExtractRectified(const cv::Mat& raw, std::vector<cv::KeyPoint
 {
     if (raw.empty() || !mpCtx || mvMapX.empty()) return;
     assert(raw.type() == CV_8UC1 && raw.cols == mnRawCols && raw.rows == mnRawRows);
-    const int cap = orbhip_keypoint_capacity(mpCtx);
-    _keypoints.resize(cap);
-    std::vector<unsigned char> desc((size_t)cap * 32);
+    ReserveStage(1);
     int n = 0;
     const uint8_t* imgs[1] = {raw.data};
-    if (orbhip_extract_batch_rectify(mpCtx, 1, imgs, (int)raw.step, reinterpret_cast<orbhip_keypoint*>(&_keypoints[0]), &desc[0], cap, &n) != ORBHIP_OK) Fail("ORBextractor");
-    Deliver(n, desc, _keypoints, _descriptors);
+    if (orbhip_extract_batch_rectify(mpCtx, 1, imgs, (int)raw.step, reinterpret_cast<orbhip_keypoint*>(&mvKpStage[0]), &mvDescStage[0], mnStageCap, &n) != ORBHIP_OK) Fail("ORBextractor");
+    Deliver(n, 0, _keypoints, _descriptors);
 }
 
-void ORBextractor::Deliver(int n, const std::vector<unsigned char>& desc, std::vector<cv::KeyPoint>& _keypoints, cv::OutputArray _descriptors)
+void ORBextractor::Deliver(int n, int slot, std::vector<cv::KeyPoint>& _keypoints, cv::OutputArray _descriptors)
 {
-    mnLastN = n; mbFrameState = true; mbBound = false; mbStereoColumns = false;
-    _keypoints.resize(n);
-    mvLastKeys = _keypoints;
+    if (slot == 0) { mnLastN = n; mbFrameState = true; mbBound = false; mbStereoColumns = false; mbPairResults = false; }
+    // one copy of exactly n records each (the staging block belongs to the object: nothing is allocated or value-initialised per call)
+    const cv::KeyPoint* src = reinterpret_cast<const cv::KeyPoint*>(&mvKpStage[(size_t)slot * mnStageCap * sizeof(orbhip_keypoint)]);
+    _keypoints.assign(src, src + n);
     if (n == 0) _descriptors.release();                          // ORBextractor.cc:1064-1065
     else {
         _descriptors.create(n, 32, CV_8U);                       // :1068
         cv::Mat d = _descriptors.getMat();
-        for (int i = 0; i < n; i++) memcpy(d.ptr(i), &desc[(size_t)i * 32], 32);
+        const unsigned char* ds = &mvDescStage[(size_t)slot * mnStageCap * 32];
+        if ((size_t)d.step == 32) memcpy(d.data, ds, (size_t)n * 32);
+        else for (int i = 0; i < n; i++) memcpy(d.ptr(i), ds + (size_t)i * 32, 32);
     }
+    if (slot != 0) return;
     {   // the planes stay in HBM until somebody indexes mvImagePyramid (only the reference's own ComputeStereoMatches does)
         std::lock_guard<std::mutex> lock(mvImagePyramid.mMutex);
         mvImagePyramid.mbStale = true;
@@ -310,7 +341,7 @@ void ORBextractor::Collect(int ticket, std::vector<std::vector<cv::KeyPoint> >& 
     for (int i = 0; i < n; i++) {
         keypoints[i].resize(cnt[i]);
         if (cnt[i] == 0) { descriptors[i].release(); continue; }
-        memcpy(&keypoints[i][0], &kps[(size_t)i * cap], (size_t)cnt[i] * sizeof(orbhip_keypoint));
+        memcpy(static_cast<void*>(&keypoints[i][0]), &kps[(size_t)i * cap], (size_t)cnt[i] * sizeof(orbhip_keypoint));
         descriptors[i].create(cnt[i], 32, CV_8U);
         for (int r = 0; r < cnt[i]; r++) memcpy(descriptors[i].ptr(r), &desc[((size_t)i * cap + r) * 32], 32);
     }
@@ -321,6 +352,10 @@ void ORBextractor::Collect(int ticket, std::vector<std::vector<cv::KeyPoint> >& 
 
 void ORBextractor::ComputeStereoMatches(ORBextractor& right, float mbf, float mb, int N, std::vector<float>& mvuRight, std::vector<float>& mvDepth)
 {
+    if (mbPairResults && N == mnLastN) {                         // ExtractStereo already ran the matcher behind the extraction
+        mvuRight.assign(mvPairURight.begin(), mvPairURight.begin() + N); mvDepth.assign(mvPairDepth.begin(), mvPairDepth.begin() + N);
+        return;
+    }
     mvuRight = std::vector<float>(N, -1.0f);                     // Frame.cc:468-469
     mvDepth = std::vector<float>(N, -1.0f);
     if (N == 0 || !mpCtx || !right.mpCtx) return;

@@ -93,6 +93,7 @@ struct orbhip_ctx {
     bool want_fgrid = false, want_rrows = false, fgrid_valid = false, rrows_valid = false; int fgrid_cur = -1, rrows_cur = -1;
     int* d_fgrid_start = nullptr; int* d_fgrid_items = nullptr; float2* d_fgrid_xy = nullptr; int* d_rrow_start = nullptr; int* d_rrow_items = nullptr; int rrow_cap = 0;
     hipEvent_t ev_epilogue = nullptr;
+    bool pair_mode = false; float* h_st = nullptr;           // the last call was orbhip_extract_stereo: slot 0 = the frame (left image), slot 1 = its right image; pinned mirror of [mvuRight | mvDepth]
     std::vector<int> last_n; bool last_n_valid = false;      // key point counts of the last call as already delivered to the host (the call's results were waited for)
     // host-buffer API staging: one contiguous device input buffer + pinned host mirrors (single bulk copies instead of per-frame pageable copies)
     bool serial = false;      // ORBHIP_SERIAL=1 (profiling aid): every kernel on the main stream, nothing overlaps - per-kernel times are standalone times
@@ -364,7 +365,7 @@ extern "C" void orbhip_destroy(orbhip_ctx* c)
                     c->d_qt_val, c->d_qt_code, c->d_qt_node, c->d_lvl_kp, c->d_lvl_n[0], c->d_lvl_n[1], c->d_lvl_n[2], c->d_out_block[0], c->d_out_block[1], c->d_out_block[2], c->d_grid_start, c->d_grid_items, c->d_grid_xy, c->d_cand, c->d_top, c->d_ncand,
                     c->d_prev, c->d_m12, c->d_nm};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    { void* ep[] = {c->d_fgrid_start, c->d_fgrid_items, c->d_fgrid_xy, c->d_rrow_start, c->d_rrow_items}; for (void* q : ep) if (q) (void)hipFree(q); if (c->ev_epilogue) (void)hipEventDestroy(c->ev_epilogue); }
+    { void* ep[] = {c->d_fgrid_start, c->d_fgrid_items, c->d_fgrid_xy, c->d_rrow_start, c->d_rrow_items}; for (void* q : ep) if (q) (void)hipFree(q); if (c->ev_epilogue) (void)hipEventDestroy(c->ev_epilogue); if (c->h_st) (void)hipHostFree(c->h_st); }
     { void* st[] = {c->d_st_rowstart, c->d_st_rowitems, c->d_st_u /* | d_st_depth */, c->d_st_sad}; for (void* q : st) if (q) (void)hipFree(q); }
     for (auto& hs : c->sets) {
         for (int k = 0; k < ORBHIP_MAX_CHUNKS; k++) { if (hs.ev_h2d[k]) (void)hipEventDestroy(hs.ev_h2d[k]); if (hs.ev_k[k]) (void)hipEventDestroy(hs.ev_k[k]); if (hs.ev_d2h[k]) (void)hipEventDestroy(hs.ev_d2h[k]); }
@@ -1197,7 +1198,7 @@ static orbhip_status submit_body(orbhip_ctx* c, int nimg, const uint8_t* const* 
         HIPCHK(hipEventRecord(hs.ev_d2h[k], dst));
     }
     if (nimg == 1 && !piped && (c->want_fgrid || c->want_rrows)) { st = frame_epilogues(c, c->stream); if (st != ORBHIP_OK) return st; }
-    c->last_matched = false; c->last_nimg = nimg;
+    c->last_matched = false; c->last_nimg = nimg; c->pair_mode = false;
     HIPCHK(hipGetLastError());
     hs.busy = true; hs.out_buf = c->cur; hs.ticket = c->next_ticket++; c->ticket_set[hs.ticket % ORBHIP_RING] = si;
     if (ticket) *ticket = hs.ticket;
@@ -1673,7 +1674,7 @@ extern "C" orbhip_status orbhip_search_by_projection_frame(orbhip_ctx* c, int fr
         // the grid of this frame was built behind its extraction (frame epilogue, same stream): take it; from now on it always will be
         if (frame == 0 && c->fgrid_valid && c->fgrid_cur == c->cur && c->last_n_valid && c->last_n[0] == n) { dgs = c->d_fgrid_start; dgi = c->d_fgrid_items; dgxy = c->d_fgrid_xy; }
         else orbhip_launch_match_grid(M, 1, c->stream);
-        if (c->last_nimg == 1) c->want_fgrid = true;
+        if (c->last_nimg == 1 || c->pair_mode) c->want_fgrid = true;
         ProjParams J; memset(&J, 0, sizeof J);
         J.kp = dk; J.desc = dd; J.u_right = dur; J.n = n; J.min_x = M.min_x; J.min_y = M.min_y; J.max_x = M.max_x; J.max_y = M.max_y; J.grid_start = dgs; J.grid_items = dgi; J.grid_xy = dgxy;
         J.q = dq; J.qdesc = dqd; J.nq = nq; J.cand = dcand; J.ncand = dnc; J.cand_stride = n; J.top = dtop;
@@ -1713,7 +1714,7 @@ extern "C" orbhip_status orbhip_search_best_in_window_frame(orbhip_ctx* c, int f
         M.kp2 = dk; M.n2 = dn; M.cap = n; M.min_x = c->bounds.min_x; M.min_y = c->bounds.min_y; M.max_x = c->bounds.max_x; M.max_y = c->bounds.max_y; M.grid_start = dgs; M.grid_items = dgi; M.grid_xy = dgxy; M.grid_all_levels = 1;
         if (frame == 0 && c->fgrid_valid && c->fgrid_cur == c->cur && c->last_n_valid && c->last_n[0] == n) { dgs = c->d_fgrid_start; dgi = c->d_fgrid_items; dgxy = c->d_fgrid_xy; }   // frame epilogue
         else orbhip_launch_match_grid(M, 1, c->stream);
-        if (c->last_nimg == 1) c->want_fgrid = true;
+        if (c->last_nimg == 1 || c->pair_mode) c->want_fgrid = true;
         BestParams B; memset(&B, 0, sizeof B);
         B.kp = dk; B.desc = dd; B.u_right = dur; B.inv_level_sigma2 = dsg; B.grid_start = dgs; B.grid_items = dgi; B.grid_xy = dgxy;
         B.q = dq; B.qdesc = dqd; B.nq = nq; B.chi2_gate = chi2_gate; B.best_idx = dbi; B.best_dist = dbd;
@@ -1791,6 +1792,61 @@ extern "C" orbhip_status orbhip_compute_stereo_matches(orbhip_ctx* l, orbhip_ctx
         if (m > 0) { memcpy(u_right + (size_t)f * cap, hu + (size_t)f * l->out_cap, m * sizeof(float)); memcpy(depth + (size_t)f * cap, hd + (size_t)f * l->out_cap, m * sizeof(float)); }
     }
     return ORBHIP_OK;
+}
+
+// The stereo pair as ONE call (include/orbhip.h): both images through one context with two camera slots - one staging copy + upload, one launch
+// chain for both frames, the stereo matcher (slot 0 against slot 1) and the frame's feature grid queued behind it on the same stream; the host copies
+// the key points out while the stereo kernels run, then picks up mvuRight / mvDepth.
+extern "C" orbhip_status orbhip_extract_stereo(orbhip_ctx* c, const uint8_t* img_left, const uint8_t* img_right, int stride, orbhip_keypoint* kps, uint8_t* desc, int cap, int* n_out,
+                                               float mbf, float mb, float* u_right, float* depth)
+{
+    if (!c || !n_out || !u_right || !depth || cap < 0) return fail(ORBHIP_ERR_INVALID, "null argument");
+    if (c->B < 2) return fail(ORBHIP_ERR_INVALID, "orbhip_extract_stereo needs a context with max_batch >= 2 (this one has %d)", c->B);
+    if (!(mb > 0) || !(mbf > 0)) return fail(ORBHIP_ERR_INVALID, "mbf and mb must be positive");
+    if (c->out_cap >= 65536) return fail(ORBHIP_ERR_UNSUPPORTED, "too many keypoints per frame for the stereo matcher");
+    n_out[0] = n_out[1] = 0;
+    for (int i = 0; i < cap; i++) { u_right[i] = -1.0f; depth[i] = -1.0f; }
+    if (!img_left || !img_right) return ORBHIP_OK;                      // an empty image: the reference's operator() returns silently, the frame has no features
+    if (c->oldest_ticket != c->next_ticket) return fail(ORBHIP_ERR_INVALID, "orbhip_extract_stereo with %d submitted batches still in flight: collect them first", c->next_ticket - c->oldest_ticket);
+    HIPCHK(hipSetDevice(c->cfg.device));
+    const size_t B = (size_t)c->B, oc = (size_t)c->out_cap;
+    if (!c->d_st_rowstart) {
+        c->st_rowcap = stereo_row_cap(c);
+        hipError_t e = hipSuccess;
+        if (e == hipSuccess) e = dalloc(&c->d_st_rowstart, B * (c->cfg.height + 1));
+        if (e == hipSuccess) e = dalloc(&c->d_st_rowitems, B * (size_t)c->st_rowcap);
+        if (e == hipSuccess) e = dalloc(&c->d_st_u, 2 * B * oc);
+        if (e == hipSuccess) c->d_st_depth = c->d_st_u + B * oc;
+        if (e == hipSuccess) e = dalloc(&c->d_st_sad, B * oc);
+        if (e != hipSuccess) return fail(ORBHIP_ERR_HIP, "stereo workspace allocation failed: %s", hipGetErrorString(e));
+    }
+    if (!c->h_st) HIPCHK(hipHostMalloc((void**)&c->h_st, 2 * oc * sizeof(float), hipHostMallocDefault));
+    const uint8_t* imgs[2] = {img_left, img_right};
+    int ticket = -1;
+    orbhip_status st = submit_impl(c, 2, imgs, stride, nullptr, nullptr, 0, &ticket); if (st != ORBHIP_OK) return st;
+    c->pair_mode = true;
+    // slot 0 against slot 1 of this context
+    StereoParams T; memset(&T, 0, sizeof T);
+    T.geom = c->d_geom; T.L = stereo_side(c); T.R = stereo_side(c);
+    T.R.kp += oc; T.R.desc += oc * 32; T.R.n += 1; T.R.img0 += T.R.img0_frame_stride; T.R.pyr += T.R.plane_frame_bytes;
+    T.cap = c->out_cap; T.im_h = c->cfg.height; T.row_start = c->d_st_rowstart; T.row_items = c->d_st_rowitems; T.row_cap = c->st_rowcap;
+    T.u_right = c->d_st_u; T.depth = c->d_st_depth; T.sad = c->d_st_sad; c->d_last_uright = c->d_st_u;
+    T.mbf = mbf; T.maxD = mbf / mb;
+    orbhip_launch_stereo(T, 1, c->out_cap, c->stream, false);
+    hipError_t e = hipGetLastError();
+    // [mvuRight | mvDepth] of slot 0: two runs of out_cap floats, B * out_cap apart on the device, back to back in the mirror
+    if (e == hipSuccess) e = orbhip_copy_async(c->h_st, c->d_st_u, oc * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = orbhip_copy_async(c->h_st + oc, c->d_st_depth, oc * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && c->want_fgrid) { const bool rr = c->want_rrows; c->want_rrows = false; const orbhip_status se = frame_epilogues(c, c->stream); c->want_rrows = rr; if (se != ORBHIP_OK) e = hipErrorInvalidValue; }
+    // key points + descriptors of both images (waits for the result block only: the stereo kernels are still running)
+    st = collect_flat(c, ticket, kps, desc, cap, n_out);
+    const hipError_t es = hipStreamSynchronize(c->stream);
+    if (c->prof) prof_collect(c);
+    if (e != hipSuccess || es != hipSuccess) return fail(ORBHIP_ERR_HIP, "extract_stereo: %s", hipGetErrorString(e != hipSuccess ? e : es));
+    if (st != ORBHIP_OK && st != ORBHIP_ERR_CAPACITY) return st;
+    const int m = std::min(n_out[0], cap);
+    if (m > 0) { memcpy(u_right, c->h_st, (size_t)m * sizeof(float)); memcpy(depth, c->h_st + oc, (size_t)m * sizeof(float)); }
+    return st;
 }
 
 // ---------------------------------------------------------------------------------------------- measurement

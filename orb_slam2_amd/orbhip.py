@@ -26,9 +26,10 @@ SYMBOLS = [
     "orbhip_hamming_nn", "orbhip_hamming_nn_device", "orbhip_search_for_initialization", "orbhip_profile_enable",
     "orbhip_profile_num_kernels", "orbhip_profile_get", "orbhip_profile_reset", "orbhip_pyramid_cascade_tiles", "orbhip_algorithmic_bytes_per_frame",
     "orbhip_algorithmic_bytes_per_frame_kernel", "orbhip_debug_blurred_level", "orbhip_debug_candidates",
-    "orbhip_compute_stereo_matches", "orbhip_search_by_projection", "orbhip_extract_batch_color",
+    "orbhip_compute_stereo_matches", "orbhip_extract_stereo", "orbhip_search_by_projection", "orbhip_extract_batch_color",
     "orbhip_extract_device_color", "orbhip_voc_load_text", "orbhip_voc_destroy", "orbhip_voc_info", "orbhip_voc_transform_features",
     "orbhip_voc_transform", "orbhip_compute_bow", "orbhip_fetch_bow", "orbhip_voc_score", "orbhip_search_by_bow", "orbhip_search_for_triangulation", "orbhip_search_best_in_window",
+    "orbhip_search_by_bow_batch", "orbhip_search_for_triangulation_batch", "orbhip_search_best_in_window_batch",
     "orbhip_undistort_points", "orbhip_image_bounds", "orbhip_set_camera", "orbhip_get_bounds", "orbhip_fetch_undistorted",
     "orbhip_search_for_initialization_bounds", "orbhip_search_by_projection_bounds", "orbhip_search_best_in_window_bounds",
     "orbhip_set_rectification", "orbhip_extract_batch_rectify", "orbhip_extract_device_rectify", "orbhip_compute_stereo_from_rgbd",
@@ -161,6 +162,7 @@ def lib(path=None):
                                                    C.c_int, C.c_float, C.c_int, ip]
     L.orbhip_search_by_projection.argtypes = [C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, vp, ip]
     L.orbhip_compute_stereo_matches.argtypes = [vp, vp, C.c_int, C.c_float, C.c_float, vp, vp, C.c_int]
+    L.orbhip_extract_stereo.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, C.c_float, C.c_float, vp, vp]
     L.orbhip_profile_enable.argtypes = [vp, C.c_int]
     L.orbhip_profile_num_kernels.argtypes = [vp]
     L.orbhip_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
@@ -497,6 +499,17 @@ class ORBextractor:
         d = np.zeros((nimg, cap), np.float32)
         _check(self.L.orbhip_compute_stereo_matches(self.h, right.h, nimg, mbf, mb, _p(u), _p(d), cap), "orbhip_compute_stereo_matches", self.L)
         return u, d
+
+    def extract_stereo(self, left, right, mbf, mb):
+        """orbhip_extract_stereo: the stereo pair as one call on this context (max_batch >= 2).
+        -> (keys_left, desc_left, keys_right, desc_right, mvuRight[N_left], mvDepth[N_left])"""
+        left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8)
+        assert left.shape == (self.height, self.width) and right.shape == left.shape
+        cap = self.capacity
+        kps = np.zeros((2, cap), KEYPOINT_DTYPE); desc = np.zeros((2, cap, 32), np.uint8); n = np.zeros(2, np.int32)
+        u = np.zeros(cap, np.float32); d = np.zeros(cap, np.float32)
+        _check(self.L.orbhip_extract_stereo(self.h, _p(left), _p(right), left.strides[0], _p(kps), _p(desc), cap, _p(n), mbf, mb, _p(u), _p(d)), "orbhip_extract_stereo", self.L)
+        return kps[0, :n[0]].copy(), desc[0, :n[0]].copy(), kps[1, :n[1]].copy(), desc[1, :n[1]].copy(), u[:n[0]].copy(), d[:n[0]].copy()
 
     # ---- measurement / stage dumps
     def pyramid_cascade_tiles(self):

@@ -94,6 +94,27 @@ int main(int argc, char** argv)
             for (int i = 0; i < F1.N && ok; i++) ok = !memcmp(dL.ptr(i), F1.mDescriptors.ptr(i), 32);
             for (int i = 0; i < F2.N && ok; i++) ok = !memcmp(dR.ptr(i), F2.mDescriptors.ptr(i), 32);
         }
+        // ... and the same pair as ONE call on one extractor (ORBextractor::ExtractStereo: one context with two camera slots, the stereo matcher queued
+        // behind the extraction): key points and descriptors of both images and mvuRight / mvDepth must equal the two-extractor path, call after call
+        {
+            const float mbf = 386.1448f, mb = 386.1448f / 718.856f;
+            std::vector<float> uTwo, dTwo, uOne, dOne;
+            exL->ComputeStereoMatches(*exR, mbf, mb, F1.N, uTwo, dTwo);        // exL / exR processed im[0] / im[1] last
+            ORB_SLAM2::ORBextractor* exP = new ORB_SLAM2::ORBextractor(N, 1.2f, 8, 20, 7);
+            for (int rep = 0; rep < 3 && ok; rep++) {
+                std::vector<cv::KeyPoint> kL, kR, un; cv::Mat dL, dR;
+                exP->ExtractStereo(im[0], im[1], kL, dL, kR, dR, mbf, mb);
+                exP->UndistortKeyPoints(un);
+                exP->ComputeStereoMatches(*exR, mbf, mb, (int)kL.size(), uOne, dOne);
+                ok = (int)kL.size() == F1.N && (int)kR.size() == F2.N && !memcmp(&kL[0], &F1.mvKeys[0], sizeof(cv::KeyPoint) * kL.size()) && !memcmp(&kR[0], &F2.mvKeys[0], sizeof(cv::KeyPoint) * kR.size())
+                     && un.size() == kL.size() && !memcmp(&un[0], &kL[0], sizeof(cv::KeyPoint) * kL.size()) && exP->HoldsStereoColumns()
+                     && uOne.size() == uTwo.size() && !memcmp(&uOne[0], &uTwo[0], 4 * uOne.size()) && !memcmp(&dOne[0], &dTwo[0], 4 * dOne.size());
+                for (int i = 0; i < F1.N && ok; i++) ok = !memcmp(dL.ptr(i), F1.mDescriptors.ptr(i), 32);
+                for (int i = 0; i < F2.N && ok; i++) ok = !memcmp(dR.ptr(i), F2.mDescriptors.ptr(i), 32);
+                if (rep == 1) { std::vector<cv::KeyPoint> k1; cv::Mat d1; (*exP)(im[1], cv::Mat(), k1, d1); ok = ok && (int)k1.size() == F2.N && !exP->HoldsStereoColumns(); }      // a single-image call in between
+            }
+            delete exP;
+        }
         fwrite(&ok, 4, 1, f);
     }
     // distorted monocular camera (TUM1.yaml scaled to the test image) and raw stereo input rectified on the device
