@@ -139,6 +139,9 @@ def _bind(L):
         L.orbslam_ref_search_by_sim3.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f, vp]
         L.orbslam_ref_tracking_loop.argtypes = [i, vp, vp, i, i, i, i, f, i, i, i, f, f, f, f, f, f, vp, vp, i, i]
         L.orbslam_ref_loop_get.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.orbslam_ref_sequence_loop.argtypes = [i, i, vp, vp, i, i, i, i, f, i, i, i, f, f, f, f, vp, i, f, f, vp, vp, i, i, C.c_char_p, i]
+        L.orbslam_ref_loop_bow_hash.argtypes = [i]
+        L.orbslam_ref_loop_bow_hash.restype = C.c_uint64
         L.orbslam_ref_concurrency.argtypes = [i, i, i, C.c_uint, i, vp, vp, i, i, i, i, f, i, i, i, f, f, f, f, f, f, vp, vp, i, vp, i, vp, i, vp, vp, vp, vp]
     return L
 
@@ -332,13 +335,54 @@ def search_by_sim3(f1, has1, X1, Y1, Z1, level1, desc1, f2, has2, X2, Y2, Z2, le
     return n, m12
 
 
+def _collect_loop(L, n, capture):
+    out = []
+    for k in range(n):
+        cnt = np.zeros(8, np.int32); ms = np.zeros(4, np.float64)
+        L.orbslam_ref_loop_get(k, _p(cnt), _p(ms), None, None, None, None, None, None, None)
+        fr = LoopFrame()
+        for name, v in zip(LoopFrame.FIELDS + ("n_extra",), cnt):
+            setattr(fr, name, int(v))
+        fr.bow_hash = int(L.orbslam_ref_loop_bow_hash(k))
+        fr.ms, fr.ms_ctor, fr.ms_motion, fr.ms_local = (float(v) for v in ms)
+        N = fr.N if capture else 0
+        fr.keys = np.zeros(N, KEYPOINT_DTYPE); fr.keys_un = np.zeros(N, KEYPOINT_DTYPE); fr.desc = np.zeros((N, 32), np.uint8)
+        fr.u_right = np.zeros(N, np.float32); fr.depth = np.zeros(N, np.float32); fr.mp_motion = np.full(N, -1, np.int32); fr.mp_final = np.full(N, -1, np.int32)
+        if N:
+            L.orbslam_ref_loop_get(k, None, None, _p(fr.keys), _p(fr.keys_un), _p(fr.desc), _p(fr.u_right), _p(fr.depth), _p(fr.mp_motion), _p(fr.mp_final))
+        out.append(fr)
+    return out
+
+
+def sequence_loop(sensor, images, gt_depth, Tcw, Tpred, nfeatures, fx, fy, cx, cy, bf, th_depth, voc_path, dist=None, scale=1.2, nlevels=8, ini_th=20, min_th=7, kf_every=5, lost_every=0,
+                  capture=True, library=None):
+    """Tracking's monocular (sensor "mono") / RGB-D ("rgbd") matcher sequences with relocalisation through the reference's own Frame.cc / ORBmatcher.cc
+    (orbslam_ref_sequence_loop in orbslam_ref_wrap.cpp).  -> list of LoopFrame; `used_wide` carries the frame's mode (10 / 11 / 12: initialisation without
+    / with the initial frame / map created; 2 TrackReferenceKeyFrame; 0 / 1 TrackWithMotionModel (1: the 2*th retry); 4 Relocalization), `n_motion` the
+    first matcher's return value, `n_extra` Relocalization's two projection searches, `bow_hash` the frame's bag of words where one was computed."""
+    L = lib() if library is None else library
+    n = len(images)
+    images = [np.ascontiguousarray(a, np.uint8) for a in images]; gt = [np.ascontiguousarray(a, np.float32) for a in gt_depth]
+    h, w = images[0].shape
+    ip = (C.c_void_p * n)(*[a.ctypes.data for a in images]); dp = (C.c_void_p * n)(*[a.ctypes.data for a in gt])
+    tc = np.ascontiguousarray(np.stack(Tcw), np.float32); tp = np.ascontiguousarray(np.stack(Tpred), np.float32)
+    d = np.zeros(0, np.float32) if dist is None else np.ascontiguousarray(dist, np.float32)
+    RefFrame._geometry = None
+    RefFrame._geometry_other.clear()
+    got = L.orbslam_ref_sequence_loop(dict(mono=0, rgbd=1)[sensor], n, ip, dp, w, h, w, nfeatures, scale, nlevels, ini_th, min_th, fx, fy, cx, cy, _p(d) if len(d) else None, len(d), bf, th_depth,
+                                      _p(tp), _p(tc), kf_every, lost_every, None if voc_path is None else str(voc_path).encode(), int(capture))
+    assert got == n, f"orbslam_ref_sequence_loop returned {got}"
+    return _collect_loop(L, n, capture)
+
+
 class LoopFrame:
     """what one frame of tracking_loop left behind: features, stereo columns, MapPoint::mnId per feature after TrackWithMotionModel
     (mp_motion) and after SearchLocalPoints (mp_final), the counters and the wall time of the frame"""
     FIELDS = ("N", "n_motion", "used_wide", "n_to_match", "n_local", "n_new_points", "n_local_points")
 
     def same(self, o):
-        return (all(getattr(self, k) == getattr(o, k) for k in self.FIELDS) and self.keys.tobytes() == o.keys.tobytes() and self.keys_un.tobytes() == o.keys_un.tobytes()
+        return (all(getattr(self, k) == getattr(o, k) for k in self.FIELDS) and getattr(self, "n_extra", 0) == getattr(o, "n_extra", 0) and getattr(self, "bow_hash", 0) == getattr(o, "bow_hash", 0)
+                and self.keys.tobytes() == o.keys.tobytes() and self.keys_un.tobytes() == o.keys_un.tobytes()
                 and np.array_equal(self.desc, o.desc) and self.u_right.tobytes() == o.u_right.tobytes() and self.depth.tobytes() == o.depth.tobytes()
                 and np.array_equal(self.mp_motion, o.mp_motion) and np.array_equal(self.mp_final, o.mp_final))
 

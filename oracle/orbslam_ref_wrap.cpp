@@ -617,7 +617,8 @@ int orbslam_ref_search_by_sim3(void* f1, const uint8_t* has1, const float* X1, c
 // prediction (Tpred[k]); no match is declared an outlier.  Both builds of this file (all-reference / drop-in) run the same statements here:
 // every difference between them is a difference of the extractor, the stereo matcher or the two projection matchers.
 struct LoopFrame {
-    int N = 0, nMotion = 0, usedWide = 0, nToMatch = 0, nLocal = 0, nNewPoints = 0, nLocalPoints = 0;
+    int N = 0, nMotion = 0, usedWide = 0, nToMatch = 0, nLocal = 0, nNewPoints = 0, nLocalPoints = 0, nExtra = 0;
+    uint64_t bowHash = 0;                       // mBowVec + mFeatVec of the frame where the sequence computed them (orbslam_ref_sequence_loop)
     double ms = 0, msCtor = 0, msMotion = 0, msLocal = 0;      // whole frame; Frame constructor; TrackWithMotionModel's search; SearchLocalPoints
     std::vector<cv::KeyPoint> keys, keysUn; std::vector<uint8_t> desc; std::vector<float> uRight, depth;
     std::vector<int> mpMotion, mpFinal;         // MapPoint::mnId per feature after TrackWithMotionModel / after SearchLocalPoints (-1 = none)
@@ -755,12 +756,255 @@ int orbslam_ref_tracking_loop(int nframes, const uint8_t* const* left, const uin
 {
     return tracking_loop_impl(nframes, left, right, w, h, stride, nfeat, scale, nlevels, ini, mn, fx, fy, cx, cy, bf, thDepth, Tpred, Tcw, kf_every, capture, true);
 }
+// ---- monocular and RGB-D sequences, with relocalisation: the rest of Tracking's matcher sequences around the reference's own Frame / ORBmatcher ------------
+// sensor 0, MONOCULAR (Tracking::GrabImageMonocular -> Track(), Tracking.cc:240-265, 267-503):
+//   frames are made by the 2 x nFeatures initialisation extractor until the map exists (mpIniORBextractor, Tracking.cc:124-125, 257-260);
+//   MonocularInitialization (:563-635): the first frame with > 100 key points becomes the initial frame, every following frame is matched to it by
+//   ORBmatcher(0.9, true).SearchForInitialization(mInitialFrame, mCurrentFrame, mvbPrevMatched, mvIniMatches, 100) until >= 100 matches (a failed
+//   attempt restarts, :606-611); Initializer::Initialize (RANSAC on H / F) is not part of this build: the pair is accepted, CreateInitialMapMonocular
+//   (:637-720) computes both key frames' bags of words and gives every match a map point (3-D position from the sequence's ground truth);
+//   then per frame, alternating, TrackReferenceKeyFrame (:757-799: Frame::ComputeBoW + ORBmatcher(0.7, true).SearchByBoW(mpReferenceKF, Frame)) and
+//   TrackWithMotionModel (:867-928: SearchByProjection(Current, Last, 15, bMono = true) with its 2 * th retry), both followed by SearchLocalPoints
+//   (:1143-1193); a new key frame every kf_every frames (its new points stand for LocalMapping::CreateNewMapPoints; ComputeBoW; it becomes the reference).
+//   Every lost_every-th frame is "lost": Relocalization's matcher sequence (:1341-1502) - ComputeBoW, ORBmatcher(0.75, true).SearchByBoW(pKF, Frame) for each
+//   of the last <= 5 key frames (the candidates KeyFrameDatabase would return), the best one's matches adopted (stands for PnP + PoseOptimization), then
+//   ORBmatcher(0.9, true).SearchByProjection(Frame, pKF, sFound, 10, 100) and (.., 3, 64) (:1451-1475) - followed by SearchLocalPoints with th = 5 (:1189).
+// sensor 1, RGB-D (GrabImageRGBD, :206-238): Frame(imGray, imDepth, ...) with a distorted camera (Frame.cc:119-172: UndistortKeyPoints' cv::undistortPoints
+//   branch, ComputeStereoFromRGBD); StereoInitialization on the first frame, then TrackWithMotionModel (th = 15) + SearchLocalPoints (th = 3, :1186-1187)
+//   and CreateNewKeyFrame's depth points, like the stereo loop above.
+// The optimiser's pose = Tcw[k], the motion model's prediction = Tpred[k].  gt_depth[k] (w x h floats, metres along the optical axis) is what the
+// sequence knows about the scene: it places the new map points of the monocular sequence and IS the sensor's depth image of the RGB-D one.
+static ORBVocabulary* shared_voc(const char* voc_path)
+{
+    static std::map<std::string, ORBVocabulary*> vocs; static std::mutex m;
+    std::lock_guard<std::mutex> lock(m);
+    ORBVocabulary*& slot = vocs[voc_path];
+    if (!slot) { slot = new ORBVocabulary(); if (!slot->loadFromTextFile(voc_path)) { delete slot; slot = NULL; } }
+    return slot;
+}
+static uint64_t bow_hash(const Frame& F)
+{
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void* d, size_t n) { const uint8_t* b = (const uint8_t*)d; for (size_t k = 0; k < n; k++) { h ^= b[k]; h *= 1099511628211ull; } };
+    for (DBoW2::BowVector::const_iterator it = F.mBowVec.begin(); it != F.mBowVec.end(); ++it) { mix(&it->first, 4); mix(&it->second, 8); }
+    for (DBoW2::FeatureVector::const_iterator it = F.mFeatVec.begin(); it != F.mFeatVec.end(); ++it) { mix(&it->first, 4); if (!it->second.empty()) mix(&it->second[0], 4 * it->second.size()); }
+    return h;
+}
+// world position of feature i of frame F at depth z along the optical axis (mvKeysUn, like Frame::UnprojectStereo, Frame.cc:667-682)
+static cv::Mat unproject(Frame& F, int i, float z)
+{
+    const float u = F.mvKeysUn[i].pt.x, v = F.mvKeysUn[i].pt.y;
+    const float x = (u - F.cx) * z * F.invfx, y = (v - F.cy) * z * F.invfy;
+    cv::Mat x3Dc(3, 1, CV_32F); x3Dc.at<float>(0) = x; x3Dc.at<float>(1) = y; x3Dc.at<float>(2) = z;
+    cv::Mat Rwc = F.mTcw.rowRange(0, 3).colRange(0, 3).t(), Ow = F.GetCameraCenter();
+    return Rwc * x3Dc + Ow;
+}
+static float depth_at(const float* dm, int w, int h, const cv::KeyPoint& kp)
+{
+    const int x = std::min(std::max((int)kp.pt.x, 0), w - 1), y = std::min(std::max((int)kp.pt.y, 0), h - 1);
+    return dm[(size_t)y * w + x];
+}
+static int search_local_points(Frame* C, std::vector<MapPoint*>& local, float th, LoopFrame& o)
+{   // Tracking::SearchLocalPoints, Tracking.cc:1143-1193
+    for (std::vector<MapPoint*>::iterator vit = C->mvpMapPoints.begin(); vit != C->mvpMapPoints.end(); vit++) {
+        MapPoint* pMP = *vit;
+        if (!pMP) continue;
+        if (pMP->isBad()) *vit = static_cast<MapPoint*>(NULL);
+        else { pMP->IncreaseVisible(); pMP->mnLastFrameSeen = C->mnId; pMP->mbTrackInView = false; }
+    }
+    int nToMatch = 0;
+    for (std::vector<MapPoint*>::iterator vit = local.begin(); vit != local.end(); vit++) {
+        MapPoint* pMP = *vit;
+        if (pMP->mnLastFrameSeen == C->mnId) continue;
+        if (pMP->isBad()) continue;
+        if (C->isInFrustum(pMP, 0.5)) { pMP->IncreaseVisible(); nToMatch++; }
+    }
+    o.nToMatch = nToMatch;
+    if (nToMatch > 0) { ORBmatcher m2(0.8); o.nLocal = m2.SearchByProjection(*C, local, th); }
+    return nToMatch;
+}
+struct SeqKF { Frame* F; KeyFrame* kf; };
+int orbslam_ref_sequence_loop(int sensor, int nframes, const uint8_t* const* imgs, const float* const* gt_depth, int w, int h, int stride,
+                              int nfeat, float scale, int nlevels, int ini, int mn, float fx, float fy, float cx, float cy, const float* dist, int ndist, float bf, float thDepth,
+                              const float* Tpred, const float* Tcw, int kf_every, int lost_every, const char* voc_path, int capture)
+{
+    g_used = 0;
+    Frame::mbInitialComputations = true; Frame::nNextId = 0; MapPoint::nNextId = 0; ORB_SLAM2::tl_next_point_id = 0;
+    ORB_SLAM2::g_real_predict_scale = true;
+    ORBVocabulary* voc = voc_path ? shared_voc(voc_path) : NULL;
+    if (sensor == 0 && !voc) return -1;
+    cv::Mat K = camera(fx, fy, cx, cy), D(std::max(ndist, 4), 1, CV_32F);
+    for (int i = 0; i < D.rows; i++) D.at<float>(i) = i < ndist ? dist[i] : 0.0f;
+    ORBextractor* exN = rig(nfeat, scale, nlevels, ini, mn).left;
+    ORBextractor* exI = sensor == 0 ? rig(2 * nfeat, scale, nlevels, ini, mn).left : exN;
+    attach_camera(exN, K, D); attach_camera(exI, K, D);
+    g_loop.assign(nframes, LoopFrame());
+    std::vector<MapPoint*> local;
+    std::vector<SeqKF> kfs;                               // key frames, oldest first; the last one is the reference key frame
+    auto pose = [](const float* t) { cv::Mat T(4, 4, CV_32F); for (int i = 0; i < 16; i++) T.at<float>(i / 4, i % 4) = t[i]; return T; };
+    auto add_keyframe = [&](Frame* C) {                   // a frozen copy of the frame: its key frame (bag of words computed first, KeyFrame.cc:42-57)
+        Frame* Fk = new Frame(*C);
+        KeyFrame* kf = new KeyFrame(*Fk, NULL, NULL); kf->SetPose(Fk->mTcw);
+        SeqKF e = {Fk, kf}; kfs.push_back(e);
+    };
+    int state = sensor == 0 ? 0 : 2;                      // 0: no initial frame, 1: waiting for the second frame, 2: tracking
+    Frame *last = NULL, *init = NULL; int kInit = 0;
+    std::vector<cv::Point2f> prevMatched; std::vector<int> iniMatches;
+    int lastReloc = -100;
+    for (int k = 0; k < nframes; k++) {
+        LoopFrame& o = g_loop[k];
+        g_used = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        double t0skip = 0;
+        cv::Mat im(h, w, CV_8UC1, (void*)imgs[k], (size_t)stride);
+        Frame* C;
+        if (sensor == 1) { cv::Mat dm(h, w, CV_32F, (void*)gt_depth[k]); C = new Frame(im, dm, 0.0, exN, voc, K, D, bf, thDepth); }
+        else C = new Frame(im, 0.0, state < 2 ? exI : exN, voc, K, D, bf, thDepth);
+        const auto t1 = std::chrono::steady_clock::now();
+        o.msCtor = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        std::vector<int> afterMotion;
+        bool tracked = false;
+        if (state == 0) {                                                                                 // Tracking.cc:567-588
+            o.usedWide = 10;
+            if ((int)C->mvKeys.size() > 100) {
+                delete init; init = new Frame(*C); kInit = k;
+                prevMatched.resize(C->mvKeysUn.size());
+                for (size_t i = 0; i < C->mvKeysUn.size(); i++) prevMatched[i] = C->mvKeysUn[i].pt;
+                std::fill(iniMatches.begin(), iniMatches.end(), -1);
+                state = 1;
+            }
+        } else if (state == 1) {                                                                          // :589-635
+            o.usedWide = 11;
+            if ((int)C->mvKeys.size() <= 100) state = 0;
+            else {
+                ORBmatcher matcher(0.9, true);
+                const int nmatches = matcher.SearchForInitialization(*init, *C, prevMatched, iniMatches, 100);
+                o.nMotion = nmatches;
+                if (nmatches < 100) state = 0;
+                else {                                                                                    // CreateInitialMapMonocular, :637-720
+                    o.usedWide = 12;
+                    init->SetPose(pose(Tcw + 16 * kInit)); C->SetPose(pose(Tcw + 16 * k));
+                    init->ComputeBoW(); C->ComputeBoW();
+                    o.bowHash = bow_hash(*C) ^ (bow_hash(*init) * 31);
+                    for (size_t i = 0; i < iniMatches.size(); i++) {
+                        if (iniMatches[i] < 0) continue;
+                        const float z = depth_at(gt_depth[kInit], w, h, init->mvKeysUn[i]);
+                        if (!(z > 0)) continue;
+                        MapPoint* p = new MapPoint(unproject(*init, (int)i, z), static_cast<Map*>(NULL), init, (int)i);
+                        p->nObs = 2; g_keep.push_back(p); local.push_back(p);
+                        init->mvpMapPoints[i] = p; C->mvpMapPoints[iniMatches[i]] = p;
+                        o.nNewPoints++;
+                    }
+                    add_keyframe(init); add_keyframe(C);
+                    state = 2;
+                }
+            }
+        } else if (sensor == 1 && !last) {                                                                // StereoInitialization, :509-561
+            C->SetPose(pose(Tcw));
+            o.nNewPoints = create_points(*C, local, true);
+            add_keyframe(C);
+        } else {
+            const bool lost = lost_every > 0 && k % lost_every == 0 && !kfs.empty();
+            if (lost) {                                                                                   // Relocalization, :1341-1502
+                o.usedWide = 4;
+                C->ComputeBoW();
+                o.bowHash = bow_hash(*C);
+                ORBmatcher matcher(0.75, true);
+                const size_t first = kfs.size() > 5 ? kfs.size() - 5 : 0;
+                std::vector<std::vector<MapPoint*> > vvp(kfs.size() - first);
+                int best = -1, bestN = -1, sum = 0;
+                for (size_t c = first; c < kfs.size(); c++) {
+                    const int nm = matcher.SearchByBoW(kfs[c].kf, *C, vvp[c - first]);
+                    sum += nm;
+                    if (nm > bestN) { bestN = nm; best = (int)c; }
+                }
+                o.nMotion = sum;
+                std::fill(C->mvpMapPoints.begin(), C->mvpMapPoints.end(), static_cast<MapPoint*>(NULL));
+                C->SetPose(pose(Tcw + 16 * k));                                                           // stands where the PnP solver + PoseOptimization return
+                if (bestN >= 15) {
+                    std::set<MapPoint*> sFound;
+                    for (int j = 0; j < C->N; j++) { MapPoint* p = vvp[best - first][j]; if (p) { C->mvpMapPoints[j] = p; sFound.insert(p); } }
+                    ORBmatcher matcher2(0.9, true);
+                    const int nadd = matcher2.SearchByProjection(*C, kfs[best].kf, sFound, 10, 100);      // :1451-1453
+                    sFound.clear();
+                    for (int j = 0; j < C->N; j++) if (C->mvpMapPoints[j]) sFound.insert(C->mvpMapPoints[j]);
+                    const int nadd2 = matcher2.SearchByProjection(*C, kfs[best].kf, sFound, 3, 64);       // :1466-1468
+                    o.nExtra = nadd + 10000 * nadd2 + 100000000 * (best - (int)first);
+                    lastReloc = k;
+                }
+            } else if (sensor == 0 && (k & 1)) {                                                          // TrackReferenceKeyFrame, :757-799
+                o.usedWide = 2;
+                C->ComputeBoW();
+                o.bowHash = bow_hash(*C);
+                ORBmatcher matcher(0.7, true);
+                std::vector<MapPoint*> vpMapPointMatches;
+                o.nMotion = matcher.SearchByBoW(kfs.back().kf, *C, vpMapPointMatches);
+                C->mvpMapPoints = vpMapPointMatches;
+            } else {                                                                                      // TrackWithMotionModel, :867-928
+                ORBmatcher matcher(0.9, true);
+                C->SetPose(pose(Tpred + 16 * k));
+                std::fill(C->mvpMapPoints.begin(), C->mvpMapPoints.end(), static_cast<MapPoint*>(NULL));
+                const int th = 15;                                                                        // (mSensor != STEREO, :881-884)
+                int nmatches = matcher.SearchByProjection(*C, *last, th, sensor == 0);
+                if (nmatches < 20) {
+                    std::fill(C->mvpMapPoints.begin(), C->mvpMapPoints.end(), static_cast<MapPoint*>(NULL));
+                    nmatches = matcher.SearchByProjection(*C, *last, 2 * th, sensor == 0);
+                    o.usedWide = 1;
+                }
+                o.nMotion = nmatches;
+            }
+            C->SetPose(pose(Tcw + 16 * k));                                                               // stands where Optimizer::PoseOptimization returns
+            const auto t2 = std::chrono::steady_clock::now();
+            o.msMotion = std::chrono::duration<double, std::milli>(t2 - t1).count();
+            if (capture) ids_of(*C, afterMotion);
+            const auto t3 = std::chrono::steady_clock::now();
+            search_local_points(C, local, k < lastReloc + 2 ? 5.0f : (sensor == 1 ? 3.0f : 1.0f), o);     // :1185-1190
+            o.msLocal = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t3).count();
+            t0skip = std::chrono::duration<double, std::milli>(t3 - t2).count();
+            tracked = true;
+        }
+        if (tracked && kf_every > 0 && k % kf_every == 0) {                                              // CreateNewKeyFrame, :1063-1133
+            if (sensor == 1) o.nNewPoints = create_points(*C, local, false);
+            else {                                                                                        // new points: what LocalMapping::CreateNewMapPoints would add
+                int created = 0;
+                for (int i = 0; i < C->N && created < 100; i++) {
+                    if (C->mvpMapPoints[i]) continue;
+                    const float z = depth_at(gt_depth[k], w, h, C->mvKeysUn[i]);
+                    if (!(z > 0)) continue;
+                    MapPoint* p = new MapPoint(unproject(*C, i, z), static_cast<Map*>(NULL), C, i);
+                    p->nObs = 1; g_keep.push_back(p); local.push_back(p); C->mvpMapPoints[i] = p; created++;
+                }
+                o.nNewPoints = created;
+            }
+            if (voc) { C->ComputeBoW(); if (!o.bowHash) o.bowHash = bow_hash(*C); }                       // KeyFrame::ComputeBoW (LocalMapping::ProcessNewKeyFrame)
+            add_keyframe(C);
+        }
+        Frame* copy = new Frame(*C);                                                                      // mLastFrame = Frame(mCurrentFrame), :497
+        o.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() - t0skip;
+        o.N = C->N; o.nLocalPoints = (int)local.size();
+        if (capture) {
+            o.keys = C->mvKeys; o.keysUn = C->mvKeysUn; o.uRight = C->mvuRight; o.depth = C->mvDepth;
+            o.desc.resize((size_t)C->N * 32);
+            for (int i = 0; i < C->N; i++) memcpy(&o.desc[(size_t)i * 32], C->mDescriptors.ptr(i), 32);
+            o.mpMotion = afterMotion; ids_of(*C, o.mpFinal);
+            if (o.mpMotion.empty()) o.mpMotion.assign(C->N, -1);
+        }
+        delete last; delete C;
+        last = copy;
+    }
+    delete last; delete init;
+    for (size_t c = 0; c < kfs.size(); c++) { delete kfs[c].kf; delete kfs[c].F; }
+    ORB_SLAM2::g_real_predict_scale = false;
+    return nframes;
+}
+uint64_t orbslam_ref_loop_bow_hash(int k) { return k >= 0 && k < (int)g_loop.size() ? g_loop[k].bowHash : 0; }
+
 // counts[8] = N, nMotion, usedWide, nToMatch, nLocal, nNewPoints, nLocalPoints, 0; every pointer may be NULL
 int orbslam_ref_loop_get(int k, int* counts, double* ms /* 4: frame, constructor, motion-model search, local-map search */, void* keys, void* keysUn, uint8_t* desc, float* uRight, float* depth, int* mpMotion, int* mpFinal)
 {
     if (k < 0 || k >= (int)g_loop.size()) return -1;
     const LoopFrame& o = g_loop[k];
-    if (counts) { counts[0] = o.N; counts[1] = o.nMotion; counts[2] = o.usedWide; counts[3] = o.nToMatch; counts[4] = o.nLocal; counts[5] = o.nNewPoints; counts[6] = o.nLocalPoints; counts[7] = 0; }
+    if (counts) { counts[0] = o.N; counts[1] = o.nMotion; counts[2] = o.usedWide; counts[3] = o.nToMatch; counts[4] = o.nLocal; counts[5] = o.nNewPoints; counts[6] = o.nLocalPoints; counts[7] = o.nExtra; }
     if (ms) { ms[0] = o.ms; ms[1] = o.msCtor; ms[2] = o.msMotion; ms[3] = o.msLocal; }
     const size_t n = o.keys.size();
     if (keys && n) memcpy(keys, &o.keys[0], n * 28);

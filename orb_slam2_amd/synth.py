@@ -80,7 +80,7 @@ def sequence(width, height, nframes, seed=0):
     return [frame_from_scene(sc, width, height, t=t, seed=seed) for t in range(nframes)]
 
 
-def stereo_sequence(width, height, nframes, fx, bf, seed=0, disp_near=24, disp_far=8, step=(0.25, 0.125)):
+def stereo_sequence(width, height, nframes, fx, bf, seed=0, disp_near=24, disp_far=8, step=(0.25, 0.125), return_depth=False):
     """A rectified stereo stream of a two-layer scene with a known camera trajectory (the input of a front-end loop).
 
     Two fronto-parallel textured planes: a far one (disparity disp_far px, depth bf/disp_far) and, in front of it over about a third of
@@ -101,7 +101,7 @@ def stereo_sequence(width, height, nframes, fx, bf, seed=0, disp_near=24, disp_f
         x0, y0 = int(rng.integers(0, W - bw)), int(rng.integers(0, H - bh))
         mask[y0:y0 + bh, x0:x0 + bw] = True
     b = bf / fx
-    lefts, rights, poses = [], [], []
+    lefts, rights, poses, depths = [], [], [], []
     for k in range(nframes):
         for cam, out in ((0.0, lefts), (1.0, rights)):
             px, py = k * step[0] + cam, k * step[1]     # camera position in baselines
@@ -111,10 +111,14 @@ def stereo_sequence(width, height, nframes, fx, bf, seed=0, disp_near=24, disp_f
             img = np.where(crop(mask, disp_near), crop(near, disp_near), crop(far, disp_far))
             nrng = np.random.default_rng((BASE_SEED + seed) * 1000003 + 7919 * k + 31 * int(cam) + 5)
             out.append(np.clip(np.rint(img) + nrng.integers(-6, 7, size=(height, width)), 0, 255).astype(np.uint8))
+            if cam == 0.0:                              # what the left camera sees, in metres along the optical axis: bf / disparity of the visible plane
+                depths.append(np.where(crop(mask, disp_near), np.float32(bf / disp_near), np.float32(bf / disp_far)).astype(np.float32))
         T = np.eye(4, dtype=np.float32)
         T[0, 3], T[1, 3] = np.float32(-k * step[0] * b), np.float32(-k * step[1] * b)
         poses.append(T)
     pred = [poses[0], poses[0]] + [(poses[k - 1] @ np.linalg.inv(poses[k - 2]) @ poses[k - 1]).astype(np.float32) for k in range(2, nframes)]
+    if return_depth:                                    # (+ the left camera's true depth maps: the depth sensor of an RGB-D sequence, the scene knowledge of a monocular one)
+        return lefts, rights, poses, pred[:nframes], depths
     return lefts, rights, poses, pred[:nframes]
 
 
