@@ -259,12 +259,14 @@ def dropin_loop_subprocess(blur_round_mode):
     -> the KITTI-shape object (the metric's shape) with the EuRoC-shape object (BASELINE.json configs[2]) under "euroc"."""
     import subprocess
     env = dict(os.environ, ORB_REF_BLUR_ROUND_MODE=str(blur_round_mode))
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dropin_loop_rate.py"), "kitti", "euroc"], capture_output=True, text=True, timeout=600, env=env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dropin_loop_rate.py"), "kitti", "euroc", "mono", "rgbd"], capture_output=True, text=True, timeout=900, env=env)
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
-    if r.returncode != 0 or len(lines) != 2:
+    if r.returncode != 0 or len(lines) != 4:
         return {"error": f"dropin_loop subprocess failed (rc {r.returncode}): {r.stderr[-300:]}"}
     out = lines[0]
     out["euroc"] = lines[1]
+    out["mono"] = lines[2]          # configs[0]'s shape: the monocular sequence (initialisation on 2 x nFeatures, TrackReferenceKeyFrame, relocalisation)
+    out["rgbd"] = lines[3]          # ... and the RGB-D one (distorted camera)
     return out
 
 

@@ -201,29 +201,88 @@ def patch_projection_member(src, sig, first_stmt, loop_from, loop_until, query, 
 # every window, then the reference's own surgery block (Replace / AddObservation / AddMapPoint, moved, not rewritten) runs in the original
 # order.  (vpMapPoints holds each point once, LocalMapping.cc:mnFuseCandidateForKF, so no point's filters depend on an earlier point's surgery.)
 FUSE_SIG = r"int\s+ORBmatcher::Fuse\s*\(\s*KeyFrame\s*\*\s*pKF\s*,\s*const\s+vector<MapPoint\s*\*>\s*&\s*vpMapPoints\s*,\s*const\s+float\s+th\s*\)"
+# The member becomes three pieces (all from the reference's own text):
+#   orbhip_fuse_collect   its projection code, unchanged, up to the window search: one flat query per point that passed the filters
+#   orbhip_fuse_apply     its surgery block, unchanged, in the original order - after re-checking, per point, what the surgery of EARLIER points or
+#                         targets may have changed since the query was collected (Replace() makes a point bad, can put it into this key frame and
+#                         recomputes the survivor's descriptor, MapPoint.cc:177-215): such a point is skipped / searched again by itself
+#   Fuse = collect + one library call + apply;  FuseBatch (include/ORBmatcherBatch.h) = collect for every target + ONE library call + apply per target
 FUSE_DECLS = """
     std::vector<orbhip_best_query> orbhip_bq; std::vector<unsigned char> orbhip_qd; std::vector<MapPoint*> orbhip_owner;
 """
+FUSE_JOB = """
+struct OrbhipFuseJob
+{
+    KeyFrame* pKF; std::vector<orbhip_best_query> bq; std::vector<unsigned char> qd; std::vector<MapPoint*> owner; std::vector<int> bi, bd;
+};
+static orbhip_bounds orbhip_kf_bounds(KeyFrame* pKF) { orbhip_bounds b = {(float)pKF->mnMinX, (float)pKF->mnMinY, (float)pKF->mnMaxX, (float)pKF->mnMaxY}; return b; }
+"""
 FUSE_QUERY = """orbhip_best_query e = { u, v, radius, ur, nPredictedLevel };
         const cv::Mat dMP = pMP->GetDescriptor();
-        orbhip_bq.push_back(e); orbhip_qd.insert(orbhip_qd.end(), dMP.ptr<unsigned char>(), dMP.ptr<unsigned char>()+32); orbhip_owner.push_back(pMP);
+        job.bq.push_back(e); job.qd.insert(job.qd.end(), dMP.ptr<unsigned char>(), dMP.ptr<unsigned char>()+32); job.owner.push_back(pMP);
 """
-FUSE_SEARCH = """std::vector<int> orbhip_bi(orbhip_bq.size(), -1), orbhip_bd(orbhip_bq.size(), 256);
-    if(!orbhip_bq.empty() && pKF->N>0)
+FUSE_TAIL = """
+static int orbhip_fuse_apply(OrbhipFuseJob &job)
+{
+    KeyFrame* pKF = job.pKF;
+    const int TH_LOW = ORBmatcher::TH_LOW;
+    int nFused=0;
+    for(size_t orbhip_k=0; orbhip_k<job.owner.size(); orbhip_k++)
     {
-        const orbhip_bounds bounds = {(float)pKF->mnMinX, (float)pKF->mnMinY, (float)pKF->mnMaxX, (float)pKF->mnMaxY};
-        orbhip_check(orbhip_search_best_in_window_bounds(orbhip_default_device(), (const orbhip_keypoint*)&pKF->mvKeysUn[0], pKF->mDescriptors.ptr<unsigned char>(), &pKF->mvuRight[0], pKF->N, &bounds,
-                                               &pKF->mvInvLevelSigma2[0], (int)pKF->mvInvLevelSigma2.size(), &orbhip_bq[0], &orbhip_qd[0], (int)orbhip_bq.size(), 1,
-                                               &orbhip_bi[0], &orbhip_bd[0]));
-    }
-    for(size_t orbhip_k=0; orbhip_k<orbhip_owner.size(); orbhip_k++)
-    {
-        MapPoint* pMP = orbhip_owner[orbhip_k];
-        const int bestDist = orbhip_bd[orbhip_k], bestIdx = orbhip_bi[orbhip_k];
+        MapPoint* pMP = job.owner[orbhip_k];
+        if(pMP->isBad() || pMP->IsInKeyFrame(pKF))        // (the reference's own filter, as of NOW)
+            continue;
+        const cv::Mat dNow = pMP->GetDescriptor();
+        if(memcmp(dNow.ptr<unsigned char>(), &job.qd[32*orbhip_k], 32))
+        {   // the point absorbed another one since its query was collected: its descriptor is a new one - search its window again
+            const orbhip_bounds bounds = orbhip_kf_bounds(pKF);
+            orbhip_check(orbhip_search_best_in_window_bounds(orbhip_default_device(), (const orbhip_keypoint*)&pKF->mvKeysUn[0], pKF->mDescriptors.ptr<unsigned char>(), &pKF->mvuRight[0], pKF->N, &bounds,
+                                                   &pKF->mvInvLevelSigma2[0], (int)pKF->mvInvLevelSigma2.size(), &job.bq[orbhip_k], dNow.ptr<unsigned char>(), 1, 1, &job.bi[orbhip_k], &job.bd[orbhip_k]));
+        }
+        const int bestDist = job.bd[orbhip_k], bestIdx = job.bi[orbhip_k];
         %s
     }
+    return nFused;
+}
 
-    """
+int ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint *> &vpMapPoints, const float th)
+{
+    OrbhipFuseJob job;
+    orbhip_fuse_collect(pKF, vpMapPoints, th, job);
+    job.bi.assign(job.bq.size(), -1); job.bd.assign(job.bq.size(), 256);
+    if(!job.bq.empty() && pKF->N>0)
+    {
+        const orbhip_bounds bounds = orbhip_kf_bounds(pKF);
+        orbhip_check(orbhip_search_best_in_window_bounds(orbhip_default_device(), (const orbhip_keypoint*)&pKF->mvKeysUn[0], pKF->mDescriptors.ptr<unsigned char>(), &pKF->mvuRight[0], pKF->N, &bounds,
+                                               &pKF->mvInvLevelSigma2[0], (int)pKF->mvInvLevelSigma2.size(), &job.bq[0], &job.qd[0], (int)job.bq.size(), 1, &job.bi[0], &job.bd[0]));
+    }
+    return orbhip_fuse_apply(job);
+}
+
+// LocalMapping::SearchInNeighbors (LocalMapping.cc:483-514): `for every target key frame: matcher.Fuse(pKFi, vpMapPointMatches)` as ONE device pass
+int FuseBatch(const std::vector<KeyFrame*> &vpTargetKFs, const std::vector<MapPoint*> &vpMapPoints, const float th)
+{
+    std::vector<OrbhipFuseJob> jobs(vpTargetKFs.size());
+    std::vector<orbhip_best_slot> slots(vpTargetKFs.size());
+    for(size_t t=0; t<vpTargetKFs.size(); t++)
+    {
+        OrbhipFuseJob &job = jobs[t]; KeyFrame* pKF = vpTargetKFs[t];
+        orbhip_fuse_collect(pKF, vpMapPoints, th, job);
+        job.bi.assign(job.bq.size(), -1); job.bd.assign(job.bq.size(), 256);
+        orbhip_best_slot &S = slots[t];
+        S.kps = pKF->N>0 ? (const orbhip_keypoint*)&pKF->mvKeysUn[0] : NULL; S.desc = pKF->N>0 ? pKF->mDescriptors.ptr<unsigned char>() : NULL; S.u_right = pKF->N>0 ? &pKF->mvuRight[0] : NULL; S.n = pKF->N;
+        S.bounds = orbhip_kf_bounds(pKF); S.inv_level_sigma2 = &pKF->mvInvLevelSigma2[0]; S.nlevels = (int)pKF->mvInvLevelSigma2.size();
+        S.queries = job.bq.empty() ? NULL : &job.bq[0]; S.query_desc = job.qd.empty() ? NULL : &job.qd[0]; S.nq = (int)job.bq.size();
+        S.best_idx = job.bi.empty() ? NULL : &job.bi[0]; S.best_dist = job.bd.empty() ? NULL : &job.bd[0];
+    }
+    if(!slots.empty())
+        orbhip_check(orbhip_search_best_in_window_batch(orbhip_default_device(), (int)slots.size(), &slots[0], 1));
+    int nFused=0;
+    for(size_t t=0; t<jobs.size(); t++)
+        nFused += orbhip_fuse_apply(jobs[t]);
+    return nFused;
+}
+"""
 
 
 def patch_fuse(src):
@@ -232,16 +291,18 @@ def patch_fuse(src):
         raise SystemExit("Fuse(pKF, vpMapPoints, th) not found")
     f0, f1 = m.start(), block_end(src, m.end())
     fn = src[f0:f1]
-    k = fn.index("int nFused=0;") + len("int nFused=0;")
-    fn = fn[:k] + FUSE_DECLS + fn[k:]
     a = fn.index("const vector<size_t> vIndices = pKF->GetFeaturesInArea(u,v,radius);")
     s0 = fn.index("if(bestDist<=TH_LOW)", a)
     s1 = block_end(fn, s0)
-    surgery = fn[s0:s1]                                   # the reference's own block, moved into the second pass
+    surgery = fn[s0:s1]                                   # the reference's own block, moved into orbhip_fuse_apply
     fn = fn[:a] + FUSE_QUERY + fn[s1:]
+    # the collecting half keeps the reference's text; only its head and its return change
+    head = re.match(FUSE_SIG, fn)
+    fn = "static void orbhip_fuse_collect(KeyFrame *pKF, const vector<MapPoint *> &vpMapPoints, const float th, OrbhipFuseJob &job)" + fn[head.end():]
+    fn = fn.replace("{", "{\n    job.pKF = pKF;", 1)
     r = fn.rindex("return nFused;")
-    fn = fn[:r] + (FUSE_SEARCH % surgery) + fn[r:]
-    return src[:f0] + fn + src[f1:]
+    fn = fn[:r] + "(void)nFused;" + fn[r + len("return nFused;"):]
+    return src[:f0] + FUSE_JOB + fn + (FUSE_TAIL % surgery) + src[f1:]
 
 
 # SearchByBoW (TrackReferenceKeyFrame / Relocalization, LoopClosing::ComputeSim3): the two std::map FeatureVectors are flattened and the node-
@@ -296,6 +357,102 @@ BOW_KF_KF_BODY = """{
     return nmatches;
 }"""
 
+
+# include/ORBmatcherBatch.h: the loops of the back end as single device passes (free functions next to the members above)
+BATCH_FUNCTIONS = """
+// Tracking::Relocalization (Tracking.cc:1357-1380): `for every candidate: matcher.SearchByBoW(pKF, mCurrentFrame, vvpMapPointMatches[i])` as ONE device pass.
+// vpKFs[i] == NULL or bad: skipped (vnMatches[i] = 0, vvpMapPointMatches[i] all NULL).
+void SearchByBoWBatch(float nnratio, bool checkOri, const std::vector<KeyFrame*> &vpKFs, Frame &F, std::vector<std::vector<MapPoint*> > &vvpMapPointMatches, std::vector<int> &vnMatches)
+{
+    const size_t nKFs = vpKFs.size();
+    vvpMapPointMatches.assign(nKFs, std::vector<MapPoint*>(F.N, static_cast<MapPoint*>(NULL)));
+    vnMatches.assign(nKFs, 0);
+    if(nKFs==0 || F.N==0 || F.mFeatVec.empty()) return;
+    struct Side { std::vector<unsigned char> valid; std::vector<float> ang; std::vector<unsigned int> node, feat; std::vector<int> off; std::vector<MapPoint*> pts; std::vector<int> m12; orbhip_bow_side s; };
+    std::vector<Side> sides(nKFs); Side fr;
+    fr.ang.resize(F.N);
+    for(int i=0;i<F.N;i++) fr.ang[i] = F.mvKeys[i].angle;
+    orbhip_flatten(F.mFeatVec, fr.node, fr.off, fr.feat);
+    orbhip_bow_side s2 = { F.mDescriptors.ptr<unsigned char>(), &fr.ang[0], NULL, F.N, &fr.node[0], &fr.off[0], &fr.feat[0], (int)F.mFeatVec.size() };
+    std::vector<orbhip_bow_pair> pairs; std::vector<size_t> which;
+    for(size_t k=0;k<nKFs;k++)
+    {
+        KeyFrame* pKF = vpKFs[k];
+        if(!pKF || pKF->isBad() || pKF->mFeatVec.empty()) continue;
+        Side &S = sides[k];
+        S.pts = pKF->GetMapPointMatches();
+        const int n1 = (int)S.pts.size();
+        if(n1==0) continue;
+        S.valid.resize(n1); S.ang.resize(n1); S.m12.assign(n1, -1);
+        for(int i=0;i<n1;i++) { MapPoint* p = S.pts[i]; S.valid[i] = p && !p->isBad(); S.ang[i] = pKF->mvKeysUn[i].angle; }
+        orbhip_flatten(pKF->mFeatVec, S.node, S.off, S.feat);
+        const orbhip_bow_side s1 = { pKF->mDescriptors.ptr<unsigned char>(), &S.ang[0], &S.valid[0], n1, &S.node[0], &S.off[0], &S.feat[0], (int)pKF->mFeatVec.size() };
+        S.s = s1;
+        which.push_back(k);
+    }
+    for(size_t j=0;j<which.size();j++) { Side &S = sides[which[j]]; const orbhip_bow_pair p = { &S.s, &s2, &S.m12[0], 0 }; pairs.push_back(p); }
+    if(pairs.empty()) return;
+    orbhip_check(orbhip_search_by_bow_batch(orbhip_default_device(), 0, (int)pairs.size(), &pairs[0], nnratio, checkOri));
+    for(size_t j=0;j<which.size();j++)
+    {
+        const size_t k = which[j]; Side &S = sides[k];
+        for(size_t i=0;i<S.m12.size();i++) if(S.m12[i]>=0) vvpMapPointMatches[k][S.m12[i]] = S.pts[i];
+        vnMatches[k] = pairs[j].nmatches;
+    }
+}
+
+// LocalMapping::CreateNewMapPoints (LocalMapping.cc:237-268): `for every neighbour: matcher.SearchForTriangulation(mpCurrentKeyFrame, pKF2, F12, vMatchedIndices, false)`
+// as ONE device pass.  vvMatches12[i][idx1] = feature of neighbour i, searched with key frame 1's map points as they are NOW; the reference's loop gives key
+// frame 1 new map points between neighbours, and its search (no orientation check, LocalMapping.cc:215; vbMatched2 is never written, ORBmatcher.cc:677, 725)
+// treats every feature of key frame 1 by itself: TriangulationPairs(pKF1, vvMatches12[i], vMatchedPairs), called when neighbour i's turn comes, drops the
+// features that have received a map point in the meantime and returns exactly the reference's vMatchedPairs.
+void SearchForTriangulationBatch(KeyFrame* pKF1, const std::vector<KeyFrame*> &vpKF2, const std::vector<cv::Mat> &vF12, const bool bOnlyStereo, std::vector<std::vector<int> > &vvMatches12)
+{
+    const size_t nn = vpKF2.size();
+    const int n1 = pKF1->N;
+    vvMatches12.assign(nn, std::vector<int>(n1, -1));
+    if(nn==0 || n1==0 || pKF1->mFeatVec.empty()) return;
+    struct Side { std::vector<float> kp; std::vector<unsigned char> has, st; std::vector<unsigned int> node, feat; std::vector<int> off; orbhip_tri_side s; };
+    struct Fill { static void of(KeyFrame* pKF, Side &S) {
+        const int n = pKF->N; S.kp.resize(4*std::max(n,1)); S.has.resize(std::max(n,1)); S.st.resize(std::max(n,1));
+        for(int i=0;i<n;i++) { const cv::KeyPoint &k = pKF->mvKeysUn[i]; S.kp[4*i]=k.pt.x; S.kp[4*i+1]=k.pt.y; S.kp[4*i+2]=k.angle; S.kp[4*i+3]=(float)k.octave;
+                               S.has[i] = pKF->GetMapPoint(i)!=NULL; S.st[i] = pKF->mvuRight[i]>=0; }
+        orbhip_flatten(pKF->mFeatVec, S.node, S.off, S.feat);
+        const orbhip_tri_side s = { pKF->mDescriptors.ptr<unsigned char>(), &S.kp[0], &S.has[0], &S.st[0], n, &S.node[0], &S.off[0], &S.feat[0], (int)pKF->mFeatVec.size(),
+                                    &pKF->mvScaleFactors[0], &pKF->mvLevelSigma2[0], (int)pKF->mvScaleFactors.size() };
+        S.s = s; } };
+    Side s1; Fill::of(pKF1, s1);
+    std::vector<Side> s2(nn); std::vector<orbhip_tri_pair> pairs(nn);
+    cv::Mat Cw = pKF1->GetCameraCenter();
+    for(size_t i=0;i<nn;i++)
+    {
+        KeyFrame* pKF2 = vpKF2[i];
+        Fill::of(pKF2, s2[i]);
+        orbhip_tri_pair &P = pairs[i];
+        P.kf2 = &s2[i].s; P.match12 = &vvMatches12[i][0]; P.nmatches = 0;
+        for(int r=0;r<3;r++) for(int c=0;c<3;c++) P.F12[3*r+c] = vF12[i].at<float>(r,c);
+        // the epipole in the second image (ORBmatcher.cc:663-669)
+        cv::Mat R2w = pKF2->GetRotation();
+        cv::Mat t2w = pKF2->GetTranslation();
+        cv::Mat C2 = R2w*Cw+t2w;
+        const float invz = 1.0f/C2.at<float>(2);
+        P.ex = pKF2->fx*C2.at<float>(0)*invz+pKF2->cx;
+        P.ey = pKF2->fy*C2.at<float>(1)*invz+pKF2->cy;
+    }
+    orbhip_check(orbhip_search_for_triangulation_batch(orbhip_default_device(), &s1.s, (int)nn, &pairs[0], bOnlyStereo, 0));
+}
+int TriangulationPairs(KeyFrame* pKF1, const std::vector<int> &vMatches12, std::vector<std::pair<size_t,size_t> > &vMatchedPairs)
+{
+    vMatchedPairs.clear();
+    for(size_t i=0, iend=vMatches12.size(); i<iend; i++)
+    {
+        if(vMatches12[i]<0 || pKF1->GetMapPoint(i))          // "If there is already a MapPoint skip" (ORBmatcher.cc:698-700), as of now
+            continue;
+        vMatchedPairs.push_back(make_pair(i,vMatches12[i]));
+    }
+    return (int)vMatchedPairs.size();
+}
+"""
 
 # SearchForTriangulation (LocalMapping::CreateNewMapPoints): the reference's epipole computation stays, the node-matched search with its
 # epipole / epipolar-line gates and the rotation pass become one call that fills the reference's own vMatches12; its pair list tail stays.
@@ -441,7 +598,9 @@ INIT_BODY = """{
 
 
 PROLOGUE = """#include "orbhip.h"
+#include "ORBmatcherBatch.h"
 #include <cstdlib>
+#include <cstring>
 #include <string>
 """
 # helpers every inserted call goes through (placed inside namespace ORB_SLAM2, after the reference's own includes):
@@ -506,6 +665,10 @@ def patch_matcher(src, map_free_members=True):
     if map_free_members:
         src = replace_body(src, DESC_DIST_SIG, DESC_DIST_BODY)
         src = replace_body(src, INIT_SIG, INIT_BODY)
+    k = src.rindex("}")                                       # the namespace's closing brace: the batch forms go in front of it
+    if "namespace" not in src[k:k + 40] and "ORB_SLAM" not in src[k:k + 40]:
+        raise SystemExit("closing brace of namespace ORB_SLAM2 not found at the end of ORBmatcher.cc")
+    src = src[:k] + BATCH_FUNCTIONS + "\n" + src[k:]
     return PROLOGUE + src
 
 
@@ -532,7 +695,8 @@ def main():
     ref = argv[0]
     edited = {"src/Frame.cc": patch_frame(open(os.path.join(ref, "src/Frame.cc")).read(), stereo_one_call=one_call),
               "src/ORBmatcher.cc": patch_matcher(open(os.path.join(ref, "src/ORBmatcher.cc")).read())}
-    copies = {"include/ORBextractor.h": "include/ORBextractor.h", "src/ORBextractor.cc": "orb_slam2_amd/cpp/ORBextractor.cc", "include/orbhip.h": "include/orbhip.h"}
+    copies = {"include/ORBextractor.h": "include/ORBextractor.h", "src/ORBextractor.cc": "orb_slam2_amd/cpp/ORBextractor.cc", "include/orbhip.h": "include/orbhip.h",
+              "include/ORBmatcherBatch.h": "include/ORBmatcherBatch.h"}
     if emit_patch:
         for rel, new in edited.items():
             old = open(os.path.join(ref, rel)).read()

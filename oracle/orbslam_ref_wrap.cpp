@@ -28,6 +28,9 @@
 #include "KeyFrame.h"
 #include "MapPoint.h"
 #include "ORBmatcher.h"
+#ifdef ORBSLAM_DROPIN_FULL
+#include "ORBmatcherBatch.h"      // the back end's loops as single device passes (defined in the ORBmatcher.cc integration/apply_dropin.py emits)
+#endif
 #include "ORBextractor.h"
 
 using namespace ORB_SLAM2;
@@ -65,6 +68,7 @@ std::mutex MapPoint::mGlobalMutex;
 // The wrapper's own bookkeeping is per thread: orbslam_ref_concurrency below runs Tracking's, LocalMapping's and LoopClosing's matcher calls on three
 // threads at once, as ORB_SLAM2 does, and nothing of this test scaffolding may be what they share.
 static thread_local const uint8_t* g_next_desc = nullptr;          // descriptor handed to the next ComputeDistinctiveDescriptors()
+static thread_local bool g_real_map_surgery = false;                // (see MapPoint::Replace below)
 static thread_local long unsigned int tl_next_point_id = 0;        // MapPoint::mnId (the reference guards nNextId with the map's creation mutex, MapPoint.cc:42-44)
 MapPoint::MapPoint(const cv::Mat& Pos, KeyFrame* pRefKF, Map* pMap)
     : mnFirstKFid(0), mnFirstFrame(0), nObs(0), mTrackProjX(0), mTrackProjY(0), mTrackProjXR(0), mbTrackInView(false), mnTrackScaleLevel(0),
@@ -109,11 +113,25 @@ void MapPoint::SetBadFlag() { mbBad = true; }
 void MapPoint::ComputeDistinctiveDescriptors() { mDescriptor.create(1, 32, CV_8U); memcpy(mDescriptor.data, g_next_desc, 32); }
 float MapPoint::GetMinDistanceInvariance() { return 0.8f * mfMinDistance; }
 float MapPoint::GetMaxDistanceInvariance() { return 1.2f * mfMaxDistance; }
-void MapPoint::AddObservation(KeyFrame* pKF, size_t idx) { mObservations[pKF] = idx; mnBALocalForKF = idx + 1; }   // also records where Fuse attached the point
+void MapPoint::AddObservation(KeyFrame* pKF, size_t idx) { if (g_real_map_surgery && !mObservations.count(pKF)) nObs++; mObservations[pKF] = idx; mnBALocalForKF = idx + 1; }   // also records where Fuse attached the point
 int MapPoint::GetIndexInKeyFrame(KeyFrame* pKF) { std::map<KeyFrame*, size_t>::iterator it = mObservations.find(pKF); return it == mObservations.end() ? -1 : (int)it->second; }
-bool MapPoint::IsInKeyFrame(KeyFrame*) { return false; }
+// orbslam_ref_local_mapping_loops below switches the real bookkeeping on: Replace() makes the replaced point bad, hands its observations to the survivor and
+// gives the survivor another descriptor (MapPoint.cc:177-215; ComputeDistinctiveDescriptors picks the median descriptor of the merged observations - here,
+// deterministically, the replaced point's), IsInKeyFrame reads the observations (MapPoint.cc:237-241), KeyFrame::AddMapPoint stores the point (KeyFrame.cc:203-207)
+bool MapPoint::IsInKeyFrame(KeyFrame* pKF) { return g_real_map_surgery && mObservations.count(pKF) != 0; }
 thread_local std::vector<std::pair<MapPoint*, MapPoint*> > g_replaced;             // (replaced, by): what Fuse decided for features that already had a point
-void MapPoint::Replace(MapPoint* pMP) { g_replaced.push_back(std::make_pair(this, pMP)); }
+void MapPoint::Replace(MapPoint* pMP)
+{
+    g_replaced.push_back(std::make_pair(this, pMP));
+    if (!g_real_map_surgery || pMP->mnId == mnId) return;
+    std::map<KeyFrame*, size_t> obs = mObservations;
+    mObservations.clear(); mbBad = true; mpReplaced = pMP;
+    for (std::map<KeyFrame*, size_t>::iterator mit = obs.begin(); mit != obs.end(); ++mit) {
+        if (!pMP->IsInKeyFrame(mit->first)) { mit->first->ReplaceMapPointMatch(mit->second, pMP); pMP->mObservations[mit->first] = mit->second; pMP->nObs++; }
+        else mit->first->EraseMapPointMatch(mit->second);
+    }
+    mDescriptor.copyTo(pMP->mDescriptor);
+}
 // the level is handed in by the test (the real function is a log of the distance ratio, MapPoint.cc:393-421; not on this path)
 int MapPoint::PredictScale(const float&, KeyFrame*) { return mnTrackScaleLevel; }
 int MapPoint::PredictScale(const float& currentDist, Frame* pF)
@@ -132,8 +150,11 @@ void MapPoint::UpdateNormalAndDepth()
     mNormalVector = mWorldPos / n; mfMinDistance = 0.0f; mfMaxDistance = 1e30f;
 }
 static void not_built(const char* what) { fprintf(stderr, "%s is not part of the oracle build\n", what); abort(); }
-void KeyFrame::AddMapPoint(MapPoint*, const size_t&) {}      // Fuse's bookkeeping; the search result is read from the map point (AddObservation above)
+void KeyFrame::AddMapPoint(MapPoint* pMP, const size_t& idx) { if (g_real_map_surgery) mvpMapPoints[idx] = pMP; }      // Fuse's bookkeeping; otherwise the search result is read from the map point (AddObservation above)
+void KeyFrame::ReplaceMapPointMatch(const size_t& idx, MapPoint* pMP) { mvpMapPoints[idx] = pMP; }      // KeyFrame.cc:225-228
+void KeyFrame::EraseMapPointMatch(const size_t& idx) { mvpMapPoints[idx] = static_cast<MapPoint*>(NULL); }      // KeyFrame.cc:213-217
 cv::Mat KeyFrame::GetCameraCenter() { return Ow.clone(); }
+bool KeyFrame::isBad() { return mbBad; }
 void KeyFrame::SetPose(const cv::Mat& Tcw_)
 {   // KeyFrame.cc:61-79 without the stereo centre: Tcw, Ow = -Rcw' tcw, Twc
     Tcw_.copyTo(Tcw);
@@ -206,8 +227,10 @@ cv::Mat camera(float fx, float fy, float cx, float cy)
 // wall time of the last ORBmatcher / Frame member call a wrapper below made - the member alone, without the wrapper's own map-point scaffolding
 // (bench.py's matcher_calls: the same member timed in the all-reference build and in the drop-in build)
 thread_local double g_call_ms = 0;
+thread_local double g_loop_ms[2] = {0, 0};
 struct CallTimer { std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); ~CallTimer() { g_call_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } };
 thread_local std::vector<MapPoint*> g_keep;   // map points live as long as the process (the reference never frees them either) - or until release_points()
+void release_points() { for (size_t i = 0; i < g_keep.size(); i++) delete g_keep[i]; g_keep.clear(); }
 MapPoint* make_point(float x, float y, float z, const uint8_t* desc, int nobs, bool bad)
 {
     cv::Mat pos(3, 1, CV_32F); pos.at<float>(0) = x; pos.at<float>(1) = y; pos.at<float>(2) = z;
@@ -913,11 +936,20 @@ int orbslam_ref_sequence_loop(int sensor, int nframes, const uint8_t* const* img
                 const size_t first = kfs.size() > 5 ? kfs.size() - 5 : 0;
                 std::vector<std::vector<MapPoint*> > vvp(kfs.size() - first);
                 int best = -1, bestN = -1, sum = 0;
+#ifdef ORBSLAM_DROPIN_FULL
+                {   // the loop over the candidates as one device pass (include/ORBmatcherBatch.h)
+                    std::vector<KeyFrame*> cand; std::vector<int> vn;
+                    for (size_t c = first; c < kfs.size(); c++) cand.push_back(kfs[c].kf);
+                    SearchByBoWBatch(0.75f, true, cand, *C, vvp, vn);
+                    for (size_t c = first; c < kfs.size(); c++) { const int nm = vn[c - first]; sum += nm; if (nm > bestN) { bestN = nm; best = (int)c; } }
+                }
+#else
                 for (size_t c = first; c < kfs.size(); c++) {
                     const int nm = matcher.SearchByBoW(kfs[c].kf, *C, vvp[c - first]);
                     sum += nm;
                     if (nm > bestN) { bestN = nm; best = (int)c; }
                 }
+#endif
                 o.nMotion = sum;
                 std::fill(C->mvpMapPoints.begin(), C->mvpMapPoints.end(), static_cast<MapPoint*>(NULL));
                 C->SetPose(pose(Tcw + 16 * k));                                                           // stands where the PnP solver + PoseOptimization return
@@ -999,6 +1031,100 @@ int orbslam_ref_sequence_loop(int sensor, int nframes, const uint8_t* const* img
 }
 uint64_t orbslam_ref_loop_bow_hash(int k) { return k >= 0 && k < (int)g_loop.size() ? g_loop[k].bowHash : 0; }
 
+// ---- LocalMapping's two matcher loops on one key frame and its neighbours -----------------------------------------------------------------------------
+// CreateNewMapPoints (LocalMapping.cc:207-446): for every neighbour SearchForTriangulation(mpCurrentKeyFrame, pKF2, F12, vMatchedIndices, false) with
+// ORBmatcher(0.6, false); every match that passes the triangulation checks becomes a map point of BOTH key frames before the next neighbour is searched
+// (here a rule on (idx1, idx2) stands for the parallax / reprojection / scale checks, :275-440).  SearchInNeighbors (:448-545): for every target
+// Fuse(pKFi, vpMapPointMatches) with the current key frame's points, the map surgery real (MapPoint::Replace makes points bad and changes descriptors
+// between targets).  The all-reference and the steps 1-3 builds run the reference's loops; the all-steps build runs them as the single device passes of
+// include/ORBmatcherBatch.h.  frames[0] = the current key frame, frames[1..nn] its neighbours (their Frames keep the key frames' features); F12 = nn x 9;
+// t2w = nn x 3 (neighbour i at [I | t2w_i], the current key frame at the origin).  Out: pairs1 / pairs2 [nn][cap] + npairs[nn] = vMatchedIndices per neighbour;
+// kf_points [nn + 1][cap] = MapPoint::mnId per feature of every key frame after both loops (-1 = none); nfused.
+int orbslam_ref_local_mapping_loops(int nn, void* const* frames, const float* F12, const float* t2w, const char* voc_path, float fuse_th, int cap,
+                                    int* pairs1, int* pairs2, int* npairs, int* kf_points, int* nfused)
+{
+    ORBVocabulary* voc = shared_voc(voc_path);
+    if (!voc || nn < 1) return -1;
+    ORB_SLAM2::tl_next_point_id = 0;
+    ORB_SLAM2::g_real_map_surgery = true; ORB_SLAM2::g_real_predict_scale = false;
+    std::vector<KeyFrame*> kf(nn + 1);
+    for (int i = 0; i <= nn; i++) {
+        Frame& F = *(Frame*)frames[i];
+        F.mpORBvocabulary = voc; F.mBowVec.clear(); F.mFeatVec.clear(); F.ComputeBoW();                // KeyFrame::ComputeBoW (ProcessNewKeyFrame, LocalMapping.cc:135)
+        for (int j = 0; j < F.N; j++) F.mvpMapPoints[j] = NULL;
+        // a third of every key frame's features carry a map point already (tracked points), each observed by its own key frame
+        kf[i] = new KeyFrame(F, NULL, NULL);
+        cv::Mat T = cv::Mat::eye(4, 4, CV_32F);
+        if (i > 0) for (int r = 0; r < 3; r++) T.at<float>(r, 3) = t2w[3 * (i - 1) + r];
+        kf[i]->SetPose(T);
+        for (int j = 0; j < F.N; j++) {
+            if ((j * 2654435761u + i * 40503u) % 3 != 0) continue;
+            cv::Mat pos(3, 1, CV_32F);                                                                  // on the viewing ray of the feature, depth 1 from the current key frame's origin
+            pos.at<float>(0) = (F.mvKeysUn[j].pt.x - F.cx) * F.invfx - (i > 0 ? t2w[3 * (i - 1)] : 0.f); pos.at<float>(1) = (F.mvKeysUn[j].pt.y - F.cy) * F.invfy - (i > 0 ? t2w[3 * (i - 1) + 1] : 0.f);
+            pos.at<float>(2) = 1.0f - (i > 0 ? t2w[3 * (i - 1) + 2] : 0.f);
+            MapPoint* p = new MapPoint(pos, kf[i], NULL);
+            ORB_SLAM2::g_next_desc = F.mDescriptors.ptr(j); p->ComputeDistinctiveDescriptors();
+            p->mnTrackScaleLevel = F.mvKeysUn[j].octave; p->UpdateNormalAndDepth();
+            g_keep.push_back(p);
+            kf[i]->ReplaceMapPointMatch(j, p); p->AddObservation(kf[i], j);
+        }
+    }
+    // ---- CreateNewMapPoints
+    std::vector<KeyFrame*> neigh(kf.begin() + 1, kf.end());
+    std::vector<cv::Mat> vF12(nn);
+    for (int i = 0; i < nn; i++) { vF12[i] = cv::Mat(3, 3, CV_32F); for (int e = 0; e < 9; e++) vF12[i].at<float>(e / 3, e % 3) = F12[9 * i + e]; }
+    const auto t0 = std::chrono::steady_clock::now();
+#ifdef ORBSLAM_DROPIN_FULL
+    std::vector<std::vector<int> > vvMatches12;
+    SearchForTriangulationBatch(kf[0], neigh, vF12, false, vvMatches12);
+#else
+    ORBmatcher matcher(0.6, false);
+#endif
+    for (int i = 0; i < nn; i++) {
+        std::vector<std::pair<size_t, size_t> > vMatchedIndices;
+#ifdef ORBSLAM_DROPIN_FULL
+        TriangulationPairs(kf[0], vvMatches12[i], vMatchedIndices);
+#else
+        matcher.SearchForTriangulation(kf[0], neigh[i], vF12[i], vMatchedIndices, false);
+#endif
+        npairs[i] = (int)vMatchedIndices.size();
+        for (size_t m = 0; m < vMatchedIndices.size() && (int)m < cap; m++) {
+            const size_t idx1 = vMatchedIndices[m].first, idx2 = vMatchedIndices[m].second;
+            pairs1[(size_t)i * cap + m] = (int)idx1; pairs2[(size_t)i * cap + m] = (int)idx2;
+            if ((idx1 * 7 + idx2) % 3 == 0) continue;                                                   // "triangulation failed"
+            Frame& F1 = *(Frame*)frames[0];
+            cv::Mat pos(3, 1, CV_32F);
+            pos.at<float>(0) = (F1.mvKeysUn[idx1].pt.x - F1.cx) * F1.invfx; pos.at<float>(1) = (F1.mvKeysUn[idx1].pt.y - F1.cy) * F1.invfy; pos.at<float>(2) = 1.0f;
+            MapPoint* pMP = new MapPoint(pos, kf[0], NULL);                                            // LocalMapping.cc:427-438
+            ORB_SLAM2::g_next_desc = F1.mDescriptors.ptr((int)idx1); pMP->ComputeDistinctiveDescriptors();
+            pMP->mnTrackScaleLevel = F1.mvKeysUn[idx1].octave; pMP->UpdateNormalAndDepth();
+            g_keep.push_back(pMP);
+            pMP->AddObservation(kf[0], idx1); pMP->AddObservation(neigh[i], idx2);
+            kf[0]->ReplaceMapPointMatch(idx1, pMP); neigh[i]->ReplaceMapPointMatch(idx2, pMP);
+        }
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    // ---- SearchInNeighbors, first half (:483-491)
+    std::vector<MapPoint*> vpMapPointMatches = kf[0]->GetMapPointMatches();
+#ifdef ORBSLAM_DROPIN_FULL
+    *nfused = FuseBatch(neigh, vpMapPointMatches, fuse_th);
+#else
+    { ORBmatcher fm; int nf = 0; for (int i = 0; i < nn; i++) nf += fm.Fuse(neigh[i], vpMapPointMatches, fuse_th); *nfused = nf; }
+#endif
+    g_call_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+    const double tri_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    for (int i = 0; i <= nn; i++) {
+        std::vector<MapPoint*> pts = kf[i]->GetMapPointMatches();
+        for (int j = 0; j < cap; j++) kf_points[(size_t)i * cap + j] = j < (int)pts.size() && pts[j] ? (int)pts[j]->mnId + (pts[j]->isBad() ? 1000000 : 0) : -1;
+        delete kf[i];
+    }
+    ORB_SLAM2::g_real_map_surgery = false;
+    release_points();
+    g_loop_ms[0] = tri_ms; g_loop_ms[1] = g_call_ms;
+    return 0;
+}
+void orbslam_ref_local_mapping_ms(double* tri_ms, double* fuse_ms) { *tri_ms = g_loop_ms[0]; *fuse_ms = g_loop_ms[1]; }
+
 // counts[8] = N, nMotion, usedWide, nToMatch, nLocal, nNewPoints, nLocalPoints, 0; every pointer may be NULL
 int orbslam_ref_loop_get(int k, int* counts, double* ms /* 4: frame, constructor, motion-model search, local-map search */, void* keys, void* keysUn, uint8_t* desc, float* uRight, float* depth, int* mpMotion, int* mpFinal)
 {
@@ -1033,7 +1159,6 @@ struct ConcCall {
     const void* p[16];
 };
 static inline uint64_t fnv(uint64_t h, const void* data, size_t n) { const uint8_t* b = (const uint8_t*)data; for (size_t k = 0; k < n; k++) { h ^= b[k]; h *= 1099511628211ull; } return h; }
-static void release_points() { for (size_t k = 0; k < g_keep.size(); k++) delete g_keep[k]; g_keep.clear(); }
 int orbslam_ref_frame_compute_bow(void* fp, const char* voc_path, uint32_t* bow_id, double* bow_val, int* nbow, uint32_t* fv_node, int* fv_off, uint32_t* fv_feat, int* nfv);
 static uint64_t run_call(const ConcCall& c)
 {

@@ -404,6 +404,8 @@ struct BowWs {
     int frames = 0, cap = 0, last_frames = 0;
     uint8_t* d_desc = nullptr; uint32_t *d_word = nullptr, *d_node = nullptr, *d_bow_id = nullptr, *d_fv_node = nullptr, *d_fv_feat = nullptr;
     double *d_weight = nullptr, *d_bow_val = nullptr; int *d_nbow = nullptr, *d_nfv = nullptr, *d_fv_off = nullptr;
+    uint8_t* h_frame = nullptr; size_t h_frame_bytes = 0;      // pinned mirror of ONE frame's results (voc_fetch): [bow_val C | bow_id C | fv_node C | fv_feat C | fv_off C+1 | nbow, nfv]
+    uint8_t* h_desc = nullptr; size_t h_desc_bytes = 0;        // pinned mirror of the host-descriptor entry points' input
 };
 // The reference shares ONE vocabulary between the Tracking (Frame.cc:400), LocalMapping and LoopClosing threads (KeyFrame.cc:66) and its
 // DBoW2 transform is read-only.  Here the tree is read-only too, the mutable state is not: `host` serves the host-descriptor entry points
@@ -422,6 +424,8 @@ static void voc_free_ws(BowWs* w)
 {
     void* ptrs[] = {w->d_desc, w->d_word, w->d_node, w->d_bow_id, w->d_fv_node, w->d_fv_feat, w->d_weight, w->d_bow_val, w->d_nbow, w->d_nfv, w->d_fv_off};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (w->h_frame) (void)hipHostFree(w->h_frame);
+    if (w->h_desc) (void)hipHostFree(w->h_desc);
     *w = BowWs();
 }
 
@@ -570,7 +574,16 @@ static orbhip_status voc_upload(orbhip_voc* v, const uint8_t* desc, int n)
 {
     BOWCHK(hipSetDevice(v->device));
     orbhip_status st = voc_ensure_ws(&v->host, 1, std::max(n, 1), v->stream); if (st != ORBHIP_OK) return st;
-    if (n > 0) BOWCHK(hipMemcpyAsync(v->host.d_desc, desc, (size_t)n * 32, hipMemcpyHostToDevice, v->stream));
+    if (n > 0) {
+        BowWs& w = v->host; const size_t bytes = (size_t)n * 32;
+        if (w.h_desc_bytes < bytes) {
+            if (w.h_desc) { BOWCHK(hipStreamSynchronize(v->stream)); (void)hipHostFree(w.h_desc); }
+            w.h_desc = nullptr; w.h_desc_bytes = 0;
+            BOWCHK(hipHostMalloc((void**)&w.h_desc, bytes + bytes / 4, hipHostMallocDefault)); w.h_desc_bytes = bytes + bytes / 4;
+        }
+        memcpy(w.h_desc, desc, bytes);                                               // (the previous call synchronised the stream: the mirror is free)
+        BOWCHK(orbhip_copy_async(w.d_desc, w.h_desc, bytes, hipMemcpyHostToDevice, v->stream));
+    }
     return ORBHIP_OK;
 }
 
@@ -593,22 +606,35 @@ extern "C" orbhip_status orbhip_voc_transform_features(orbhip_voc* v, const uint
     return st;
 }
 
+// One frame's bag of words to the host: every array travels at its full row capacity into a pinned mirror (copy kernels on the stream, no DMA hand-over, no
+// pageable staging) behind ONE synchronisation - the counts are not needed before the copies are issued - and is cut to size on the host.
 static orbhip_status voc_fetch(BowWs* w, int frame, hipStream_t s, uint32_t* bow_id, double* bow_val, int* nbow, uint32_t* fv_node, int32_t* fv_off, uint32_t* fv_feat, int* nfv)
 {
     const size_t C = (size_t)w->cap;
-    int cnt[2] = {0, 0};
-    BOWCHK(hipMemcpyAsync(&cnt[0], w->d_nbow + frame, 4, hipMemcpyDeviceToHost, s));
-    BOWCHK(hipMemcpyAsync(&cnt[1], w->d_nfv + frame, 4, hipMemcpyDeviceToHost, s));
+    auto up = [](size_t b) { return (b + 15) & ~(size_t)15; };      // 16-byte sections: the copy kernel moves 16 bytes per lane
+    const size_t o_val = 0, o_id = up(o_val + C * 8), o_fn = up(o_id + C * 4), o_ff = up(o_fn + C * 4), o_fo = up(o_ff + C * 4), o_cnt = up(o_fo + (C + 1) * 4), total = o_cnt + 32;
+    if (w->h_frame_bytes < total) {
+        if (w->h_frame) (void)hipHostFree(w->h_frame);
+        w->h_frame = nullptr; w->h_frame_bytes = 0;
+        BOWCHK(hipHostMalloc((void**)&w->h_frame, total + 64, hipHostMallocDefault)); w->h_frame_bytes = total;
+    }
+    uint8_t* h = w->h_frame;
+    BOWCHK(orbhip_copy_async(h + o_cnt, w->d_nbow + frame, 4, hipMemcpyDeviceToHost, s));
+    BOWCHK(orbhip_copy_async(h + o_cnt + 16, w->d_nfv + frame, 4, hipMemcpyDeviceToHost, s));
+    if (bow_val) BOWCHK(orbhip_copy_async(h + o_val, w->d_bow_val + frame * C, C * 8, hipMemcpyDeviceToHost, s));
+    if (bow_id) BOWCHK(orbhip_copy_async(h + o_id, w->d_bow_id + frame * C, C * 4, hipMemcpyDeviceToHost, s));
+    if (fv_node) BOWCHK(orbhip_copy_async(h + o_fn, w->d_fv_node + frame * C, C * 4, hipMemcpyDeviceToHost, s));
+    if (fv_feat) BOWCHK(orbhip_copy_async(h + o_ff, w->d_fv_feat + frame * C, C * 4, hipMemcpyDeviceToHost, s));
+    if (fv_off || fv_feat) BOWCHK(orbhip_copy_async(h + o_fo, w->d_fv_off + frame * (C + 1), (C + 1) * 4, hipMemcpyDeviceToHost, s));
     BOWCHK(hipStreamSynchronize(s));
+    int cnt[2]; memcpy(&cnt[0], h + o_cnt, 4); memcpy(&cnt[1], h + o_cnt + 16, 4);
     const int nb = cnt[0], nf = cnt[1];
-    int m = 0;
-    if (nf > 0 || fv_off) { BOWCHK(hipMemcpyAsync(&m, w->d_fv_off + frame * (C + 1) + nf, 4, hipMemcpyDeviceToHost, s)); BOWCHK(hipStreamSynchronize(s)); }
-    if (nb > 0 && bow_id) BOWCHK(hipMemcpyAsync(bow_id, w->d_bow_id + frame * C, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
-    if (nb > 0 && bow_val) BOWCHK(hipMemcpyAsync(bow_val, w->d_bow_val + frame * C, (size_t)nb * 8, hipMemcpyDeviceToHost, s));
-    if (nf > 0 && fv_node) BOWCHK(hipMemcpyAsync(fv_node, w->d_fv_node + frame * C, (size_t)nf * 4, hipMemcpyDeviceToHost, s));
-    if (fv_off) BOWCHK(hipMemcpyAsync(fv_off, w->d_fv_off + frame * (C + 1), (size_t)(nf + 1) * 4, hipMemcpyDeviceToHost, s));
-    if (m > 0 && fv_feat) BOWCHK(hipMemcpyAsync(fv_feat, w->d_fv_feat + frame * C, (size_t)m * 4, hipMemcpyDeviceToHost, s));
-    BOWCHK(hipStreamSynchronize(s));
+    if (nb < 0 || nf < 0 || (size_t)nb > C || (size_t)nf > C) return orbhip_set_error(ORBHIP_ERR_HIP, "bag of words: counts %d / %d outside the workspace's capacity %zu", nb, nf, C);
+    if (nb > 0 && bow_id) memcpy(bow_id, h + o_id, (size_t)nb * 4);
+    if (nb > 0 && bow_val) memcpy(bow_val, h + o_val, (size_t)nb * 8);
+    if (nf > 0 && fv_node) memcpy(fv_node, h + o_fn, (size_t)nf * 4);
+    if (fv_off) memcpy(fv_off, h + o_fo, (size_t)(nf + 1) * 4);
+    if (fv_feat) { int m = 0; memcpy(&m, h + o_fo + (size_t)nf * 4, 4); if (m > 0 && (size_t)m <= C) memcpy(fv_feat, h + o_ff, (size_t)m * 4); }
     if (nbow) *nbow = nb;
     if (nfv) *nfv = nf;
     return ORBHIP_OK;

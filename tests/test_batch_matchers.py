@@ -152,3 +152,57 @@ def test_search_best_in_window_batch(backend, oracle, frames, chi2, same_bounds)
         close += int((bd_o <= 50).sum())
     assert close > 200
     assert orb_slam2_amd.search_best_in_window_batch([], chi2, library=backend) == []
+
+
+# ---- the same loops through the reference's own callers: per-call members (all-reference build) vs include/ORBmatcherBatch.h (the all-steps build) -----------
+@pytest.fixture(scope="module", params=["all-steps", pytest.param("all-steps-gpu", marks=pytest.mark.gpu)])
+def builds(request):
+    from oracle import orbslam_ref as S
+    from conftest import gpu_session
+    if request.param.endswith("-gpu"):
+        if not (S.build() and S.build_dropin_gpu()):
+            pytest.fail("oracle/_ref/liborbslam_dropin_full_gpu.so did not travel with the repository (build it with `make -C oracle dropin_gpu` where /root/reference is mounted)")
+        return S, S.dropin_gpu_lib(full=True)
+    if gpu_session(request.config):
+        pytest.skip("a -m gpu session maps liborbhip.so only")
+    request.getfixturevalue("emu_lib")
+    if not (S.build() and S.build_dropin()):
+        pytest.skip("reference sources not mounted")
+    return S, S.dropin_full_lib()
+
+
+def test_local_mapping_loops_through_the_binding(builds, request, tmp_path):
+    """LocalMapping::CreateNewMapPoints and SearchInNeighbors on a key frame with five neighbours: the all-reference build runs the reference's loops
+    (SearchForTriangulation per neighbour with map points created in between; Fuse per target with REAL map surgery: Replace makes points bad and changes
+    descriptors between targets), the all-steps build runs SearchForTriangulationBatch + TriangulationPairs and FuseBatch.  The matched pairs of every
+    neighbour, the map point of every feature of every key frame afterwards and nFused must be equal."""
+    S, D = builds
+    gpu = "gpu" in request.node.name
+    cfg = dict(w=1241, h=376, n=2000, fx=718.856, fy=718.856, cx=607.1928, cy=185.2157, bf=386.1448, th_depth=35.0) if gpu else dict(w=400, h=300, n=500, fx=231.5, fy=231.5, cx=200.0, cy=150.0, bf=25.5, th_depth=35.0)
+    nn = 5
+    L, R, _, _ = synth.stereo_sequence(cfg["w"], cfg["h"], nn + 1, cfg["fx"], cfg["bf"], seed=9)
+    voc = tmp_path / "voc_no_final_newline.txt"
+    voc.write_text(open(VOC).read().rstrip("\n"))
+    cam = dict(nfeatures=cfg["n"], fx=cfg["fx"], fy=cfg["fy"], cx=cfg["cx"], cy=cfg["cy"], bf=cfg["bf"], th_depth=cfg["th_depth"])
+    rng = np.random.default_rng(2)
+    F12 = np.stack([np.array([[0, -1e-3, 1.0 / 300], [1e-3, 0, -3.0 / 300], [-1.0 / 300, 3.0 / 300, 0]], np.float32) + rng.normal(0, 1e-5, (3, 3)).astype(np.float32) for _ in range(nn)])
+    b = cfg["bf"] / cfg["fx"]
+    t2w = np.stack([np.array([-0.25 * b * (i + 1), -0.125 * b * (i + 1), 0.0], np.float32) for i in range(nn)])       # the sequence's own camera motion
+    res = {}
+    for name, lib in (("ref", None), ("dropin", D)):
+        S.RefFrame._geometry = None
+        S.RefFrame._geometry_other.clear()
+        frames = [S.RefFrame(L[i], R[i], library=lib, **cam) for i in range(nn + 1)]
+        res[name] = S.local_mapping_loops(frames, F12, t2w, str(voc))
+        for f in frames:
+            f.close()
+    S.RefFrame._geometry = None
+    (pr, ptr, nfr, msr), (pd, ptd, nfd, msd) = res["ref"], res["dropin"]
+    for i in range(nn):
+        assert np.array_equal(pr[i], pd[i]), f"matched pairs of neighbour {i} differ"
+    assert np.array_equal(ptr, ptd) and nfr == nfd
+    ids0 = set(int(v) for v in ptr[0] if v >= 0)
+    shared = sum(len(ids0 & set(int(v) for v in ptr[i] if v >= 0)) for i in range(1, nn + 1))
+    assert sum(len(p) for p in pr) > 100 and nfr > 50 and shared > 100 and int((ptr >= 1000000).sum()) == 0      # triangulation matches, fusions, points now seen by two key frames; no bad point left in a key frame
+    print(f"\n[local_mapping] {cfg['w']}x{cfg['h']}, {nn} neighbours: SearchForTriangulation loop reference {msr[0]:.3f} ms / batch {msd[0]:.3f} ms, Fuse loop reference {msr[1]:.3f} ms / batch {msd[1]:.3f} ms, "
+          f"{sum(len(p) for p in pr)} pairs, {nfr} fused, equal")

@@ -55,6 +55,50 @@ def measure(shape="kitti", nframes=24, passes=5, ref_passes=1, seed=5, kf_every=
     }
 
 
+TUM1 = dict(w=640, h=480, n=1000, fx=517.306408, fy=516.469215, cx=318.643040, cy=255.313989, bf=40.0, th_depth=40.0)       # Examples/Monocular/TUM1.yaml (BASELINE.json configs[0])
+TUM1_DIST = (0.262383, -0.953104, -0.005358, 0.002628, 1.163314)
+
+
+def measure_sequence(sensor, nframes=24, passes=5, ref_passes=1, seed=3, kf_every=4, lost_every=5):
+    """tests/test_sequences.py as a measurement: the monocular / RGB-D matcher sequences with relocalisation at configs[0]'s shape (640x480, 1000 features)."""
+    import tempfile
+    from orb_slam2_amd import synth
+    from oracle import orbslam_ref as S
+    cfg = TUM1
+    if not (os.path.exists(S.FAST_PATH) and os.path.exists(S.DROPIN_FULL_GPU_PATH)):
+        return {"shape": sensor, "skipped": "oracle/_ref/liborbslam_ref_fast.so / liborbslam_dropin_full_gpu.so did not travel with the repository"}
+    ref_lib = S._bind(C.CDLL(S.FAST_PATH))
+    gpu_lib = S.dropin_gpu_lib(full=True)
+    voc = os.path.join(tempfile.gettempdir(), "orbhip_voc_k6_L3_nonl.txt")
+    with open(voc, "w") as f:
+        f.write(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "voc_k6_L3_ref.txt")).read().rstrip("\n"))
+    L, R, T, P, depth = synth.stereo_sequence(cfg["w"], cfg["h"], nframes, cfg["fx"], cfg["bf"], seed=seed, return_depth=True)
+    args = (sensor, L, depth, T, P, cfg["n"], cfg["fx"], cfg["fy"], cfg["cx"], cfg["cy"], cfg["bf"], cfg["th_depth"], voc)
+    kw = dict(dist=TUM1_DIST if sensor == "rgbd" else None, kf_every=kf_every, lost_every=lost_every)
+    ref = S.sequence_loop(*args, library=ref_lib, **kw)
+    got = S.sequence_loop(*args, library=gpu_lib, **kw)
+    mismatched = [k for k, (a, b) in enumerate(zip(ref, got)) if not a.same(b)]
+    names = {0: "TrackWithMotionModel", 1: "TrackWithMotionModel (2*th retry)", 2: "TrackReferenceKeyFrame", 4: "Relocalization"}
+
+    def timed(lib, n):
+        runs = [S.sequence_loop(*args, capture=False, library=lib, **kw) for _ in range(n)]
+        per = {}
+        for f in range(2, nframes):
+            mode = ref[f].used_wide
+            if mode in names:
+                per.setdefault(mode, []).append(float(np.median([r[f].ms for r in runs])))
+        allms = [float(np.median([r[f].ms for r in runs])) for f in range(2, nframes)]
+        ctor = [float(np.median([r[f].ms_ctor for r in runs])) for f in range(2, nframes)]
+        return round(float(np.median(allms)), 4), round(float(np.median(ctor)), 4), {names[m]: round(float(np.median(v)), 4) for m, v in per.items()}
+    g, gc, gparts = timed(gpu_lib, passes)
+    r, rc, rparts = timed(ref_lib, ref_passes)
+    return {"shape": f"{cfg['w']}x{cfg['h']} {sensor}, {cfg['n']} features, 8 levels, {nframes} frames, a key frame every {kf_every}, lost every {lost_every}" + (", TUM1 distortion" if sensor == "rgbd" else ", 2 x nFeatures until initialised"),
+            "ms_per_frame_gpu": g, "ms_per_frame_ref": r, "speedup": round(r / g, 1), "frame_constructor_ms": {"gpu": gc, "ref": rc},
+            "ms_per_frame_by_mode_gpu": gparts, "ms_per_frame_by_mode_ref": rparts,
+            "parity": {"frames_compared": nframes, "frames_mismatched": len(mismatched), "compared": "keys, mvKeysUn, descriptors, depth columns, map point per feature after each matcher, counters, bag-of-words hashes"},
+            "modes": [int(f.used_wide) for f in ref]}
+
+
 if __name__ == "__main__":
     for name in (sys.argv[1:] or list(SHAPES)):
-        print(json.dumps(measure(name)), flush=True)
+        print(json.dumps(measure_sequence(name) if name in ("mono", "rgbd") else measure(name)), flush=True)
