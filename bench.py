@@ -195,13 +195,23 @@ def host_io_subprocess(device, blur_round_mode):
     return json.loads(lines[-1])
 
 
-def valu_roofline(dom, launch_ms, B):
+def valu_roofline(dom, launch_ms, B, measured=None):
     """The instruction roofline of the dominant kernel (the HBM object beside it is what north_star demands; this is what bounds the kernel):
-    floor_ms = VALU instructions per wave x waves per launch x cycles per wave64 VALU instruction / (SIMDs x clock).  Instruction and wave
-    counts are the SQ counters of the committed PMC passes of this workload (rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES at B = 256, tools/gpu_pmc.sh),
-    waves scaled to this run's batch; 4 cycles per instruction is the measured issue rate of the kernel's packed-u16 / v_perm / v_alignbyte mix
-    (profiles/r02_valu_issue_rates_ubench.txt); 1024 SIMDs and 2.4 GHz are the chip's (MI355X_MICROARCH.md)."""
-    for name in ("r04_pmc_summary.json", "r03_pmc_summary.json"):
+    floor_ms = VALU instructions per wave x waves per launch x cycles per wave64 VALU instruction / (SIMDs x clock).  Instruction and wave counts are SQ
+    counters (SQ_INSTS_VALU, SQ_WAVES) - measured IN THIS RUN by a rocprofv3 --pmc child pass of the same workload at the same batch (`measured`), else
+    taken from the newest committed PMC summary, waves scaled to this run's batch; 4 cycles per instruction is the measured issue rate of the kernel's
+    packed-u16 / v_perm / v_alignbyte mix (profiles/r02_valu_issue_rates_ubench.txt); 1024 SIMDs and 2.4 GHz are the chip's (MI355X_MICROARCH.md)."""
+    simds, clock, cpi = 1024, 2.4, 4
+
+    def obj(valu, waves, source, extra=None):
+        floor_ms = valu * waves * cpi / (simds * clock * 1e9) * 1e3
+        o = {"kernel": dom, "valu_insts_per_wave": valu, "waves_per_launch": waves, "cycles_per_inst": cpi, "simds": simds, "clock_GHz": clock,
+             "floor_ms": round(floor_ms, 4), "launch_ms": round(launch_ms, 4), "frac": round(floor_ms / launch_ms, 4) if launch_ms > 0 else None, "source": source}
+        o.update(extra or {})
+        return o
+    if measured:
+        return obj(measured["valu_per_wave"], measured["waves_per_launch"], "rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES over a short child run of this workload at this batch, in this run; launch_ms by HIP events in the timed region")
+    for name in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -209,13 +219,8 @@ def valu_roofline(dom, launch_ms, B):
             rows = json.load(f)
         for row in rows:
             if row["kernel"].split("<")[0] == dom:
-                valu, waves = row["valu_per_wave"], int(row["waves_per_dispatch"] * B / 256)
-                simds, clock, cpi = 1024, 2.4, 4
-                floor_ms = valu * waves * cpi / (simds * clock * 1e9) * 1e3
-                return {"kernel": dom, "valu_insts_per_wave": valu, "waves_per_launch": waves, "cycles_per_inst": cpi, "simds": simds, "clock_GHz": clock,
-                        "floor_ms": round(floor_ms, 4), "launch_ms": round(launch_ms, 4), "frac": round(floor_ms / launch_ms, 4) if launch_ms > 0 else None,
-                        "lds_bank_conflict_frac": row.get("lds_bank_conflict_frac"), "frac_wave_cycles_waiting": row.get("frac_wait_any"),
-                        "source": f"profiles/{name} (SQ_INSTS_VALU / SQ_WAVES per dispatch at B = 256, waves scaled to B = {B}; launch_ms measured in this run)"}
+                return obj(row["valu_per_wave"], int(row["waves_per_dispatch"] * B / 256), f"profiles/{name} (SQ_INSTS_VALU / SQ_WAVES per dispatch at B = 256, waves scaled to B = {B}; launch_ms measured in this run)",
+                           {"lds_bank_conflict_frac": row.get("lds_bank_conflict_frac"), "frac_wave_cycles_waiting": row.get("frac_wait_any")})
     return None
 
 
@@ -227,28 +232,30 @@ def hbm_traffic_subprocess(dom, B, args):
     if shutil.which("rocprofv3") is None:
         return None, "rocprofv3 not on PATH"
     per = {}
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU SQ_WAVES"):
         d = tempfile.mkdtemp(prefix="orb_pmc_", dir="/tmp")
-        cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+        cmd = ["rocprofv3", "--pmc"] + counter.split() + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
                "--batch", str(B), "--steps", "3", "--warmup", "1", "--repeats", "1", "--streams", str(args.streams), "--blur-round-mode", str(args.blur_round_mode),
-               "--no-cpu-baseline", "--no-host-io", "--no-dropin-loop", "--no-traffic", "--parity-slots", "0"]
+               "--no-cpu-baseline", "--no-host-io", "--no-dropin-loop", "--no-traffic", "--no-secondary", "--parity-slots", "0"]
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=300)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode}): {r.stderr[-200:]}"
-            tot, disp = 0.0, set()
-            for row in csv.DictReader(open(files[0])):
-                if row["Counter_Name"] == counter and row["Kernel_Name"].replace("void ", "").split("(")[0].split("<")[0].strip() == dom:
-                    tot += float(row["Counter_Value"]); disp.add(row.get("Dispatch_Id", row.get("Correlation_Id")))
-            if not disp:
-                return None, f"no {counter} rows for {dom}"
-            per[counter] = (tot * 1024.0 / len(disp), len(disp))
+            for cname in counter.split():
+                tot, disp = 0.0, set()
+                for row in csv.DictReader(open(files[0])):
+                    if row["Counter_Name"] == cname and row["Kernel_Name"].replace("void ", "").split("(")[0].split("<")[0].strip() == dom:
+                        tot += float(row["Counter_Value"]); disp.add(row.get("Dispatch_Id", row.get("Correlation_Id")))
+                if not disp:
+                    return None, f"no {cname} rows for {dom}"
+                per[cname] = (tot * (1024.0 if cname.endswith("_SIZE") else 1.0) / len(disp), len(disp))
         except Exception as e:                                            # noqa: BLE001 - a failed profiler pass must not cost the bench line
             return None, f"rocprofv3 --pmc {counter} pass: {e}"
         finally:
             shutil.rmtree(d, ignore_errors=True)
     return {"bytes_per_launch": int(2 * per["FETCH_SIZE"][0] + per["WRITE_SIZE"][0]), "fetch_bytes_raw": int(per["FETCH_SIZE"][0]), "write_bytes_raw": int(per["WRITE_SIZE"][0]),
+            "valu_per_wave": round(per["SQ_INSTS_VALU"][0] / max(per["SQ_WAVES"][0], 1.0), 1), "waves_per_launch": int(per["SQ_WAVES"][0]),
             "launches_profiled": per["FETCH_SIZE"][1], "method": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, one pass each over a 4-step child run of this workload at this batch; 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction)"}, None
 
 
@@ -568,6 +575,7 @@ def main():
                 out["roofline"]["traffic"] = t["bytes_per_launch"]
                 out["roofline"]["traffic_measured"] = t
                 out["roofline"]["traffic_over_algorithmic"] = round(t["bytes_per_launch"] / max(alg * B, 1), 3)
+                out["roofline_valu"] = valu_roofline(dom, kern[dom]["ms_per_launch"], B, measured=t)       # the instruction count of THIS run replaces the committed summary's
             else:
                 out["roofline"]["traffic_note"] = why
         if world == 1 and not args.no_host_io:

@@ -65,6 +65,9 @@ const char* orbhip_version(void);
 /* The stateless matcher entry points keep a per-thread device scratch and pinned mirror (grow-only, no hipMalloc per call).  A worker thread
    that exits returns them automatically; orbhip_thread_release() does it on demand for the calling thread. */
 void orbhip_thread_release(void);
+/* Wall time, in milliseconds, the CALLING thread has spent inside this library's extraction and matcher entry points since the last reset (reset != 0
+   clears it): lets a measurement of a caller - an ORBmatcher member around one library call - say how much of its time is the library's. */
+double orbhip_thread_api_ms(int reset);
 /* HIP devices this process can use (0 = none: nothing in this library can run, there is no CPU fallback) */
 int orbhip_device_count(void);
 /* last error message of the calling thread ("" if none) */

@@ -122,6 +122,7 @@ def _bind(L):
         L.orbslam_ref_frame_stereo.argtypes = [vp, vp, i, i, i, i, f, i, i, i, f, f, f, f, f, f, i]
         L.orbslam_ref_frame_delete.argtypes = [vp]
         L.orbslam_ref_last_call_ms.restype = C.c_double
+        L.orbslam_ref_last_call_lib_ms.restype = C.c_double
         L.orbslam_ref_frame_stereo_matches_again.argtypes = [vp, vp, vp]
         L.orbslam_ref_frame_n.argtypes = [vp]
         L.orbslam_ref_frame_get.argtypes = [vp, vp, vp, vp, vp, vp]
@@ -225,6 +226,11 @@ class RefFrame:
 def last_call_ms(library=None):
     """wall time of the ORBmatcher / Frame member the last wrapper call on this thread made (the member alone)"""
     return float((lib() if library is None else library).orbslam_ref_last_call_ms())
+
+
+def last_call_lib_ms(library=None):
+    """... and the part of it spent inside liborbhip's entry points (0 in the all-reference build)"""
+    return float((lib() if library is None else library).orbslam_ref_last_call_lib_ms())
 
 
 def search_for_initialization(f1, f2, prev=None, window=100, nnratio=0.9, check_ori=True):

@@ -226,9 +226,18 @@ cv::Mat camera(float fx, float fy, float cx, float cy)
 }
 // wall time of the last ORBmatcher / Frame member call a wrapper below made - the member alone, without the wrapper's own map-point scaffolding
 // (bench.py's matcher_calls: the same member timed in the all-reference build and in the drop-in build)
-thread_local double g_call_ms = 0;
+thread_local double g_call_ms = 0, g_call_lib_ms = 0;      // ... and how much of it was spent inside liborbhip's entry points (drop-in builds; orbhip_thread_api_ms)
 thread_local double g_loop_ms[2] = {0, 0};
-struct CallTimer { std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); ~CallTimer() { g_call_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } };
+#ifdef ORBSLAM_DROPIN_BUILD
+extern "C" double orbhip_thread_api_ms(int reset);
+static double lib_ms_now() { return orbhip_thread_api_ms(0); }
+#else
+static double lib_ms_now() { return 0.0; }
+#endif
+struct CallTimer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); double lib0 = lib_ms_now();
+    ~CallTimer() { g_call_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); g_call_lib_ms = lib_ms_now() - lib0; }
+};
 thread_local std::vector<MapPoint*> g_keep;   // map points live as long as the process (the reference never frees them either) - or until release_points()
 void release_points() { for (size_t i = 0; i < g_keep.size(); i++) delete g_keep[i]; g_keep.clear(); }
 MapPoint* make_point(float x, float y, float z, const uint8_t* desc, int nobs, bool bad)
@@ -254,6 +263,7 @@ void* orbslam_ref_frame_mono(const uint8_t* img, int w, int h, int stride, int n
     if (new_geometry) Frame::mbInitialComputations = true;
     cv::Mat im(h, w, CV_8UC1, (void*)img, (size_t)stride), K = camera(fx, fy, cx, cy), D = cv::Mat(cv::Mat::zeros(4, 1, CV_32F));
     attach_camera(rig(nfeat, scale, nlevels, ini, mn).left, K, D);
+    CallTimer ct;
     return new Frame(im, 0.0, rig(nfeat, scale, nlevels, ini, mn).left, NULL, K, D, bf, thDepth);
 }
 // the same with a distorted camera: mDistCoef = (k1, k2, p1, p2[, k3]) (Tracking.cc:70-82) -> UndistortKeyPoints / ComputeImageBounds
@@ -277,6 +287,7 @@ void* orbslam_ref_frame_rgbd(const uint8_t* img, const float* depth, int w, int 
     cv::Mat im(h, w, CV_8UC1, (void*)img, (size_t)stride), dm(h, w, CV_32F, (void*)depth), K = camera(fx, fy, cx, cy), D(ndist, 1, CV_32F);
     for (int i = 0; i < ndist; i++) D.at<float>(i) = dist[i];
     attach_camera(rig(nfeat, scale, nlevels, ini, mn).left, K, D);
+    CallTimer ct;
     return new Frame(im, dm, 0.0, rig(nfeat, scale, nlevels, ini, mn).left, NULL, K, D, bf, thDepth);
 }
 // Frame::ComputeBoW (Frame.cc:395-402) with a vocabulary read by ORBVocabulary::loadFromTextFile (System.cc:68): mBowVec / mFeatVec flattened
@@ -323,10 +334,12 @@ void* orbslam_ref_frame_stereo(const uint8_t* imgL, const uint8_t* imgR, int w, 
     memset(mem, 0, sizeof(Frame));
     *reinterpret_cast<float*>(reinterpret_cast<char*>(mem) + ((char*)&((Frame*)mem)->mb - (char*)mem)) = bf / fx;
     attach_camera(r.left, K, D); attach_camera(r.right, K, D);
+    CallTimer ct;
     return new (mem) Frame(L, R, 0.0, r.left, r.right, NULL, K, D, bf, thDepth);
 }
 void orbslam_ref_frame_delete(void* f) { delete (Frame*)f; }
 double orbslam_ref_last_call_ms() { return g_call_ms; }
+double orbslam_ref_last_call_lib_ms() { return g_call_lib_ms; }
 // Frame::ComputeStereoMatches (Frame.cc:466-640) once more on a stereo Frame that is still the LAST one its rig made (the drop-in's forward reads the
 // two extractors' resident results): mvuRight / mvDepth are rebuilt from scratch, the call is timed
 void orbslam_ref_frame_stereo_matches_again(void* fp, float* uRight, float* depth)

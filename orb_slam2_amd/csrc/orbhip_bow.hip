@@ -589,6 +589,7 @@ static orbhip_status voc_upload(orbhip_voc* v, const uint8_t* desc, int n)
 
 extern "C" orbhip_status orbhip_voc_transform_features(orbhip_voc* v, const uint8_t* desc, int n, int levelsup, uint32_t* word, double* weight, uint32_t* node)
 {
+    OrbApiTimer api_timer;
     if (!v || (n > 0 && !desc) || n < 0) return orbhip_set_error(ORBHIP_ERR_INVALID, "bad argument");
     if (v->nwords == 0 || n == 0) return ORBHIP_OK;
     std::lock_guard<std::mutex> lock(v->m);                                        // upload, kernels and fetch of ONE caller at a time
@@ -643,6 +644,7 @@ static orbhip_status voc_fetch(BowWs* w, int frame, hipStream_t s, uint32_t* bow
 extern "C" orbhip_status orbhip_voc_transform(orbhip_voc* v, const uint8_t* desc, int n, int levelsup, uint32_t* bow_id, double* bow_val, int* nbow,
                                               uint32_t* fv_node, int32_t* fv_off, uint32_t* fv_feat, int* nfv)
 {
+    OrbApiTimer api_timer;
     if (!v || (n > 0 && !desc) || n < 0) return orbhip_set_error(ORBHIP_ERR_INVALID, "bad argument");
     if (nbow) *nbow = 0;
     if (nfv) *nfv = 0;
@@ -659,6 +661,7 @@ extern "C" orbhip_status orbhip_voc_transform(orbhip_voc* v, const uint8_t* desc
 // Frame::ComputeBoW (Frame.cc:395-402) for the frames of the extractor's last call: descriptors are read where k_describe left them
 extern "C" orbhip_status orbhip_compute_bow(orbhip_ctx* ctx, orbhip_voc* v, int nimg, int levelsup)
 {
+    OrbApiTimer api_timer;
     if (!ctx || !v) return orbhip_set_error(ORBHIP_ERR_INVALID, "null argument");
     const uint8_t* d_desc = nullptr; const int* d_n = nullptr; int cap = 0, last = 0, device = 0; hipStream_t s = nullptr;
     orbhip_internal_outputs(ctx, &d_desc, &d_n, &cap, &last, &device, &s);
@@ -675,6 +678,7 @@ extern "C" orbhip_status orbhip_compute_bow(orbhip_ctx* ctx, orbhip_voc* v, int 
 extern "C" orbhip_status orbhip_fetch_bow(orbhip_ctx* ctx, orbhip_voc* v, int frame, uint32_t* bow_id, double* bow_val, int* nbow,
                                           uint32_t* fv_node, int32_t* fv_off, uint32_t* fv_feat, int* nfv)
 {
+    OrbApiTimer api_timer;
     if (!ctx || !v) return orbhip_set_error(ORBHIP_ERR_INVALID, "null argument");
     BowWs* w = nullptr;
     { std::lock_guard<std::mutex> lock(v->m); auto it = v->per_ctx.find(ctx); if (it != v->per_ctx.end()) w = &it->second; }
@@ -727,6 +731,7 @@ extern "C" orbhip_status orbhip_search_by_bow(int device, int mode,
     const uint8_t* desc2, const float* angle2, const uint8_t* valid2, int n2, const uint32_t* fv2_node, const int32_t* fv2_off, const uint32_t* fv2_feat, int nfv2,
     float nnratio, int check_ori, int32_t* match12, int* nmatches)
 {
+    OrbApiTimer api_timer;
     if (!match12 || !nmatches || n1 < 0 || n2 < 0 || nfv1 < 0 || nfv2 < 0 || (mode != 0 && mode != 1)) return orbhip_set_error(ORBHIP_ERR_INVALID, "bad argument");
     *nmatches = 0;
     for (int i = 0; i < n1; i++) match12[i] = -1;
@@ -775,6 +780,7 @@ extern "C" orbhip_status orbhip_search_for_triangulation(int device,
     const float* F12, float ex, float ey, const float* scale_factors2, const float* level_sigma2_2, int nlevels2, int only_stereo, int check_ori,
     int32_t* match12, int* nmatches)
 {
+    OrbApiTimer api_timer;
     if (!match12 || !nmatches || n1 < 0 || n2 < 0 || nfv1 < 0 || nfv2 < 0 || nlevels2 < 1) return orbhip_set_error(ORBHIP_ERR_INVALID, "bad argument");
     *nmatches = 0;
     for (int i = 0; i < n1; i++) match12[i] = -1;
@@ -827,6 +833,7 @@ struct SideDev { uint8_t* d = nullptr; float* ang = nullptr; uint8_t* valid = nu
 }
 extern "C" orbhip_status orbhip_search_by_bow_batch(int device, int mode, int npairs, orbhip_bow_pair* pairs, float nnratio, int check_ori)
 {
+    OrbApiTimer api_timer;
     if (npairs < 0 || (npairs > 0 && !pairs) || (mode != 0 && mode != 1)) return orbhip_set_error(ORBHIP_ERR_INVALID, "bad argument");
     std::vector<const orbhip_bow_side*> sides;                       // distinct sides, in order of first use
     std::vector<int> live;                                           // pairs with work
@@ -901,6 +908,7 @@ extern "C" orbhip_status orbhip_search_by_bow_batch(int device, int mode, int np
 
 extern "C" orbhip_status orbhip_search_for_triangulation_batch(int device, const orbhip_tri_side* kf1, int npairs, orbhip_tri_pair* pairs, int only_stereo, int check_ori)
 {
+    OrbApiTimer api_timer;
     if (!kf1 || npairs < 0 || (npairs > 0 && !pairs) || kf1->n < 0 || kf1->nfv < 0) return orbhip_set_error(ORBHIP_ERR_INVALID, "bad argument");
     std::vector<int> live;
     for (int p = 0; p < npairs; p++) {

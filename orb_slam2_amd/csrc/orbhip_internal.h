@@ -242,6 +242,14 @@ template <typename Layout> static hipError_t arena_layout(int device, Layout lay
 hipError_t arena_upload(hipStream_t s);       // pageable -> pinned gather on the host, ONE host-to-device copy
 hipError_t arena_download(hipStream_t s);     // ONE device-to-host copy, synchronises s, pinned -> pageable scatter
 hipStream_t orbhip_thread_stream(int device); // the calling thread's own non-blocking stream for these calls
+// time the calling thread has spent inside the library's entry points (orbhip_thread_api_ms): lets a caller's measurement separate the library from its own code
+#include <chrono>
+extern thread_local double orbhip_tl_api_ms; extern thread_local int orbhip_tl_api_depth;
+struct OrbApiTimer {
+    std::chrono::steady_clock::time_point t0;
+    OrbApiTimer() : t0(std::chrono::steady_clock::now()) { orbhip_tl_api_depth++; }
+    ~OrbApiTimer() { if (--orbhip_tl_api_depth == 0) orbhip_tl_api_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
 void orbhip_touch_thread_caches();      // makes sure the calling thread's cache holder exists (its destructor releases the caches of worker threads)
 orbhip_status orbhip_set_error(orbhip_status st, const char* fmt, ...);
 void orbhip_internal_outputs(orbhip_ctx* c, const uint8_t** d_desc, const int** d_n, int* cap, int* last_nimg, int* device, hipStream_t* s);

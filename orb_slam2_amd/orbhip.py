@@ -20,7 +20,7 @@ KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle"
 
 # every symbol include/orbhip.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "orbhip_version", "orbhip_thread_release", "orbhip_device_count", "orbhip_last_error", "orbhip_create", "orbhip_destroy", "orbhip_keypoint_capacity",
+    "orbhip_version", "orbhip_thread_release", "orbhip_thread_api_ms", "orbhip_device_count", "orbhip_last_error", "orbhip_create", "orbhip_destroy", "orbhip_keypoint_capacity",
     "orbhip_get_scale_tables", "orbhip_level_size", "orbhip_extract", "orbhip_extract_batch", "orbhip_pyramid_level",
     "orbhip_extract_device", "orbhip_sync", "orbhip_fetch", "orbhip_fetch_matches", "orbhip_descriptor_distance",
     "orbhip_hamming_nn", "orbhip_hamming_nn_device", "orbhip_search_for_initialization", "orbhip_profile_enable",
@@ -134,6 +134,8 @@ def lib(path=None):
     L.orbhip_search_for_triangulation.argtypes = [C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int,
                                                   vp, C.c_float, C.c_float, vp, vp, C.c_int, C.c_int, C.c_int, vp, ip]
     L.orbhip_search_best_in_window.argtypes = [C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp]
+    L.orbhip_thread_api_ms.argtypes = [C.c_int]
+    L.orbhip_thread_api_ms.restype = C.c_double
     L.orbhip_search_by_bow_batch.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.c_float, C.c_int]
     L.orbhip_search_for_triangulation_batch.argtypes = [C.c_int, vp, C.c_int, vp, C.c_int, C.c_int]
     L.orbhip_search_best_in_window_batch.argtypes = [C.c_int, C.c_int, vp, C.c_int]

@@ -1,14 +1,15 @@
 #!/bin/bash
 # PMC passes (each in its own rocprofv3 run, kernel-trace only) over a short bench; CSVs land in gpurun_out/$TAG/
 # usage: tools/gpu_pmc.sh <tag> [number of passes, default all six]
-TAG=${1:-pmc}; NPASS=${2:-6}
+TAG=${1:-pmc}; NPASS=${2:-6}; WHAT=${3:-bench}      # WHAT = bench (the B = $PMC_BATCH batch pipeline, default 256) | single (single-image calls + the stereo front-end loop)
 OUT=$(pwd)/gpurun_out/$TAG
 mkdir -p $OUT
 REPO=$(pwd)
 export TMPDIR=/tmp
 cd /tmp
 rocprofv3 -L > $OUT/counters_list.txt 2>&1
-CMD="python $REPO/bench.py --steps 3 --warmup 1 --repeats 1 --batch 256 --no-cpu-baseline --no-host-io"
+CMD="python $REPO/bench.py --steps 3 --warmup 1 --repeats 1 --batch ${PMC_BATCH:-256} --no-cpu-baseline --no-host-io --no-traffic --no-dropin-loop --no-secondary --parity-slots 0"
+[ "$WHAT" = single ] && CMD="python $REPO/tools/pmc_single_workload.py"
 i=0
 while read -r line; do
   [ -z "$line" ] && continue

@@ -31,6 +31,7 @@ def load(path):
 def main():
     src = sys.argv[1]
     prefix = sys.argv[2] if len(sys.argv) > 2 else "r01"
+    suffix = sys.argv[3] if len(sys.argv) > 3 else ""         # e.g. "_single": profiles/<prefix>_pmc<suffix>_summary.json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     passes = sorted(glob.glob(os.path.join(src, "p*_counters.csv")))
     if not passes:
@@ -39,7 +40,7 @@ def main():
     ndisp = {}
     for i, p in enumerate(passes, 1):
         agg, disp = load(p)
-        shutil.copyfile(p, os.path.join(root, "profiles", f"{prefix}_pmc_pass{i}.csv"))      # raw rocprofv3 rows, as collected
+        shutil.copyfile(p, os.path.join(root, "profiles", f"{prefix}_pmc{suffix}_pass{i}.csv"))      # raw rocprofv3 rows, as collected
         for k, d in agg.items():
             merged[k].update(d)
             ndisp[k] = disp[k]
@@ -58,12 +59,15 @@ def main():
             "frac_wait_any": round(d.get("SQ_WAIT_ANY", 0) / wc, 2), "frac_wait_inst": round(d.get("SQ_WAIT_INST_ANY", 0) / wc, 2),
             "frac_active": round(d.get("SQ_ACTIVE_INST_ANY", 0) / wc, 2),
             "fetch_MB_per_dispatch_raw": round(d.get("FETCH_SIZE", 0) / 1024 / n), "write_MB_per_dispatch_raw": round(d.get("WRITE_SIZE", 0) / 1024 / n),
+            "fetch_KB_per_dispatch_raw": round(d.get("FETCH_SIZE", 0) / n, 1), "write_KB_per_dispatch_raw": round(d.get("WRITE_SIZE", 0) / n, 1),
+            "flat_per_wave": round(d.get("SQ_INSTS_FLAT", 0) / w, 1), "smem_per_wave": round(d.get("SQ_INSTS_SMEM", 0) / w, 1),
+            "frac_wait_inst_lds": round(d.get("SQ_WAIT_INST_LDS", 0) / wc, 2), "frac_active_valu": round(d.get("SQ_ACTIVE_INST_VALU", 0) / wc, 2),
             "tcc_hit": round(d.get("TCC_HIT_sum", 0) / max(d.get("TCC_HIT_sum", 0) + d.get("TCC_MISS_sum", 0), 1), 2),
             "lds_bank_conflict_frac": round(d.get("SQ_LDS_BANK_CONFLICT", 0) / max(d.get("SQ_LDS_IDX_ACTIVE", 0), 1), 2),
         }
         out.append(row)
     out.sort(key=lambda r: r["kernel"])
-    with open(os.path.join(root, "profiles", f"{prefix}_pmc_summary.json"), "w") as f:
+    with open(os.path.join(root, "profiles", f"{prefix}_pmc{suffix}_summary.json"), "w") as f:
         json.dump(out, f, indent=1)
     for r in out:
         print(r)

@@ -55,11 +55,11 @@ def host_cpu():
 
 
 def _median_call(S, lib, fn, reps):
-    out, ms = None, []
+    out, ms, lms = None, [], []
     for _ in range(reps):
         out = fn()
-        ms.append(S.last_call_ms(lib))
-    return out, float(np.median(ms))
+        ms.append(S.last_call_ms(lib)); lms.append(S.last_call_lib_ms(lib))
+    return out, float(np.median(ms)), float(np.median(lms))
 
 
 def _same(a, b):
@@ -118,7 +118,13 @@ def matcher_calls(cfg, ref_lib, gpu_lib, voc_path, reps=7, ref_reps=3):
         r = reps if name == "gpu" else ref_reps
         call = lambda fn: _median_call(S, lib, fn, r)
         o = res[name]
-        o["ComputeStereoMatches (S1)"] = call(lambda: s1.stereo_matches_again())
+        def stereo_ctor():
+            f = S.RefFrame(L[2], R[2], library=lib, **cam)
+            r = (f.keys.copy(), f.desc.copy(), f.u_right.copy(), f.depth.copy())
+            f.close()
+            return r
+        o["Frame::Frame(imLeft, imRight, ...) incl. ComputeStereoMatches (S1)"] = call(stereo_ctor)
+        s1b = S.RefFrame(L[2], R[2], library=lib, **cam); s1.close(); s1 = s1b; sides[name] = (lib, m0, m1, s0, s1)      # the last frame the rig made again
         o["SearchByProjection(Current, Last) (M2)"] = call(lambda: S.search_by_projection_last(s1, s0, has, X, Y, Z, da, cur_state=state, th=7.0, mono=False, nnratio=0.9, check_ori=True))
         o["SearchByProjection(Frame, MapPoints) (M3)"] = call(lambda: S.search_by_projection_points(s1, px, py, (px - 9.0).astype(np.float32), lev, vc, inview, bad, nobs, da, state, th=3.0, nnratio=0.8))
         o["SearchForInitialization (M1)"] = call(lambda: S.search_for_initialization(m0, m1, window=100, nnratio=0.9, check_ori=True))
@@ -136,15 +142,75 @@ def matcher_calls(cfg, ref_lib, gpu_lib, voc_path, reps=7, ref_reps=3):
         o["SearchByProjection(Frame, KF) (M5, relocalisation)"] = call(lambda: S.search_by_projection_reloc(s1, s0, has, X, Y, Z, lev, bad, found, da, state, th=10.0, orb_dist=100, nnratio=0.9, check_ori=True))
     shape = f"{w}x{h} stereo, {na} / {nb} features, ~{int(has.sum())} map points per call"
     for k in res["ref"]:
-        (ro, rms), (go, gms) = res["ref"][k], res["gpu"][k]
-        out[k] = {"gpu_ms": round(gms, 4), "ref_ms": round(rms, 4), "ref_over_gpu": round(rms / gms, 2) if gms > 0 else None, "parity": bool(_same(ro, go))}
+        (ro, rms, _), (go, gms, glib) = res["ref"][k], res["gpu"][k]
+        out[k] = {"gpu_ms": round(gms, 4), "gpu_ms_inside_the_library": round(glib, 4), "ref_ms": round(rms, 4), "ref_over_gpu": round(rms / gms, 2) if gms > 0 else None, "parity": bool(_same(ro, go))}
     nodes = len(res["ref"]["Frame::ComputeBoW"][0][2])
+    # ---- the C ABI alone: ten per-call entries vs one batch entry on the same arrays (no reference code around them)
+    abi = None
+    try:
+        import orb_slam2_amd as A
+        _, _, _, g0, g1 = sides["gpu"]
+        k0, d0, k1, d1 = g0.keys_un, g0.desc, g1.keys_un, g1.desc
+        fva, fvb = res["gpu"]["Frame::ComputeBoW"][0][2:], res["gpu"]["Frame::ComputeBoW"][0][2:]
+        fva = g0.compute_bow(voc_path)[2:]; fvb = g1.compute_bow(voc_path)[2:]
+        sf = (1.2 ** np.arange(8)).astype(np.float32)
+        def t(fn, reps=7):
+            fn(); ts = []
+            for _ in range(reps):
+                t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+            return float(np.median(ts)) * 1e3
+        NB = 10
+        z0, z1 = np.zeros(len(k0), np.uint8), np.zeros(len(k1), np.uint8)
+        kf1 = dict(desc=d0, kps=k0, has_mp=hmp1, stereo=z0, fv=fva, scale_factors=sf, level_sigma2=sf * sf)
+        nbs = [dict(kf=dict(desc=d1, kps=k1, has_mp=hmp2, stereo=z1, fv=fvb, scale_factors=sf, level_sigma2=sf * sf), F12=Fm, ex=620.0, ey=190.0) for _ in range(NB)]
+        tri_call = t(lambda: [A.search_for_triangulation(d0, k0, hmp1, z0, fva, d1, k1, hmp2, z1, fvb, Fm, 620.0, 190.0, sf, sf * sf, check_ori=False) for _ in range(NB)])
+        tri_batch = t(lambda: A.search_for_triangulation_batch(kf1, nbs, check_ori=False))
+        frame_side = dict(desc=d1, angle=k1["angle"], valid=None, fv=fvb)
+        cands = [dict(desc=d0, angle=k0["angle"], valid=v1, fv=fva) for _ in range(5)]
+        bow_call = t(lambda: [A.search_by_bow(0, d0, k0["angle"], v1, fva, d1, k1["angle"], None, fvb, nnratio=0.75) for _ in range(5)])
+        bow_batch = t(lambda: A.search_by_bow_batch(0, [(c, frame_side) for c in cands], nnratio=0.75))
+        q = np.zeros(na, A.BEST_QUERY_DTYPE); q["x"], q["y"], q["radius"], q["ur"], q["level"] = px, py, (3.0 * sf[lev]).astype(np.float32), px - 9.0, lev
+        inv = (1.0 / (sf * sf)).astype(np.float32)
+        slot = dict(kps=k1, desc=d1, u_right=g1.u_right, bounds=(0.0, 0.0, float(w), float(h)), inv_level_sigma2=inv, queries=q, qdesc=d0)
+        win_call = t(lambda: [A.search_best_in_window(k1, d1, w, h, inv, q, d0, True, u_right=g1.u_right) for _ in range(NB)])
+        win_batch = t(lambda: A.search_best_in_window_batch([slot] * NB, True))
+        abi = {"orbhip_search_for_triangulation x 10 vs _batch(10)": {"per_call_ms": round(tri_call, 4), "batch_ms": round(tri_batch, 4), "ratio": round(tri_call / tri_batch, 2)},
+               "orbhip_search_by_bow x 5 vs _batch(5)": {"per_call_ms": round(bow_call, 4), "batch_ms": round(bow_batch, 4), "ratio": round(bow_call / bow_batch, 2)},
+               "orbhip_search_best_in_window x 10 vs _batch(10)": {"per_call_ms": round(win_call, 4), "batch_ms": round(win_batch, 4), "ratio": round(win_call / win_batch, 2)},
+               "note": "host arrays in, host arrays out, through the ctypes mirror (its per-call marshalling included on both sides)"}
+    except Exception as e:                                            # noqa: BLE001
+        abi = {"error": str(e)[:300]}
     for name in sides:
         for f in sides[name][1:]:
             f.close()
+    # ---- LocalMapping's two loops over ten neighbours: the reference's per-call loops vs the single device passes of include/ORBmatcherBatch.h
+    loops = None
+    try:
+        nn = 10
+        Ls, Rs, _, _ = synth.stereo_sequence(w, h, nn + 1, cfg["fx"], cfg["bf"], seed=9)
+        rngl = np.random.default_rng(2)
+        F12 = np.stack([Fm + rngl.normal(0, 1e-5, (3, 3)).astype(np.float32) for _ in range(nn)])
+        b = cfg["bf"] / cfg["fx"]
+        t2 = np.stack([np.array([-0.25 * b * (i + 1), -0.125 * b * (i + 1), 0.0], np.float32) for i in range(nn)])
+        lres = {}
+        for name in ("ref", "gpu"):
+            lib = sides[name][0]
+            S.RefFrame._geometry = None; S.RefFrame._geometry_other.clear()
+            fr = [S.RefFrame(Ls[i], Rs[i], library=lib, **cam) for i in range(nn + 1)]
+            runs = [S.local_mapping_loops(fr, F12, t2, voc_path) for _ in range(3 if name == "gpu" else 1)]
+            lres[name] = (runs[-1], float(np.median([r[3][0] for r in runs])), float(np.median([r[3][1] for r in runs])))
+            for f in fr:
+                f.close()
+        (rr, rt, rf), (gr, gt, gf) = lres["ref"], lres["gpu"]
+        same = all(np.array_equal(a, b2) for a, b2 in zip(rr[0], gr[0])) and np.array_equal(rr[1], gr[1]) and rr[2] == gr[2]
+        loops = {"neighbours": nn, "CreateNewMapPoints: SearchForTriangulation over all neighbours": {"gpu_batch_ms": round(gt, 4), "ref_loop_ms": round(rt, 4), "pairs": int(sum(len(p) for p in rr[0]))},
+                 "SearchInNeighbors: Fuse over all targets": {"gpu_batch_ms": round(gf, 4), "ref_loop_ms": round(rf, 4), "fused": int(rr[2])}, "parity": bool(same),
+                 "note": "the reference's loops (map points created / replaced between key frames) vs SearchForTriangulationBatch + TriangulationPairs and FuseBatch (include/ORBmatcherBatch.h), whole loop incl. the reference's host code"}
+    except Exception as e:                                            # noqa: BLE001
+        loops = {"error": str(e)[:300]}
     S.RefFrame._geometry = None
-    return {"shape": shape, "feature_vector_nodes": nodes, "timer": "the member call alone (inside the wrapper), median of %d (gpu) / %d (ref) calls; ref = one host thread" % (reps, ref_reps),
-            "members": out, "all_parity": all(v["parity"] for v in out.values())}
+    return {"shape": shape, "feature_vector_nodes": nodes, "timer": "the member call alone (inside the wrapper), median of %d (gpu) / %d (ref) calls; ref = one host thread; gpu_ms_inside_the_library = the part of gpu_ms spent in liborbhip's entry points (orbhip_thread_api_ms), the rest is the reference's own host code of the member" % (reps, ref_reps),
+            "members": out, "all_parity": all(v["parity"] for v in out.values()), "back_end_loops": loops, "batch_entries": abi}
 
 
 # ---- config 5
