@@ -140,7 +140,7 @@ def _bind(L):
         L.orbslam_ref_search_by_sim3.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f, vp]
         L.orbslam_ref_tracking_loop.argtypes = [i, vp, vp, i, i, i, i, f, i, i, i, f, f, f, f, f, f, vp, vp, i, i]
         L.orbslam_ref_loop_get.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, vp, vp]
-        L.orbslam_ref_local_mapping_loops.argtypes = [i, vp, vp, vp, C.c_char_p, f, i, vp, vp, vp, vp, vp]
+        L.orbslam_ref_local_mapping_loops.argtypes = [i, vp, vp, vp, C.c_char_p, f, f, i, vp, vp, vp, vp, vp]
         L.orbslam_ref_local_mapping_ms.argtypes = [vp, vp]
         L.orbslam_ref_sequence_loop.argtypes = [i, i, vp, vp, i, i, i, i, f, i, i, i, f, f, f, f, vp, i, f, f, vp, vp, i, i, C.c_char_p, i]
         L.orbslam_ref_loop_bow_hash.argtypes = [i]
@@ -383,7 +383,7 @@ def sequence_loop(sensor, images, gt_depth, Tcw, Tpred, nfeatures, fx, fy, cx, c
     return _collect_loop(L, n, capture)
 
 
-def local_mapping_loops(frames, F12, t2w, voc_path, fuse_th=3.0):
+def local_mapping_loops(frames, F12, t2w, voc_path, fuse_th=3.0, point_depth=1.0):
     """LocalMapping's CreateNewMapPoints + SearchInNeighbors matcher loops on frames[0] (the current key frame) and its neighbours frames[1:] through the
     reference's own ORBmatcher.cc (orbslam_ref_local_mapping_loops): per-call loops in the all-reference / steps 1-3 builds, the single device passes of
     include/ORBmatcherBatch.h in the all-steps build.  -> (pairs per neighbour [(idx1, idx2) array], map point id per feature of every key frame, nFused, (tri_ms, fuse_ms))"""
@@ -393,7 +393,7 @@ def local_mapping_loops(frames, F12, t2w, voc_path, fuse_th=3.0):
     hs = (C.c_void_p * (nn + 1))(*[f.h for f in frames])
     Fm = np.ascontiguousarray(F12, np.float32).reshape(nn, 9); tw = np.ascontiguousarray(t2w, np.float32).reshape(nn, 3)
     p1 = np.full((nn, cap), -1, np.int32); p2 = np.full((nn, cap), -1, np.int32); npairs = np.zeros(nn, np.int32); pts = np.full((nn + 1, cap), -1, np.int32); nf = C.c_int(0)
-    rc = L.orbslam_ref_local_mapping_loops(nn, hs, _p(Fm), _p(tw), str(voc_path).encode(), fuse_th, cap, _p(p1), _p(p2), _p(npairs), _p(pts), C.byref(nf))
+    rc = L.orbslam_ref_local_mapping_loops(nn, hs, _p(Fm), _p(tw), str(voc_path).encode(), fuse_th, point_depth, cap, _p(p1), _p(p2), _p(npairs), _p(pts), C.byref(nf))
     assert rc == 0, "orbslam_ref_local_mapping_loops failed (vocabulary?)"
     a, b = C.c_double(0), C.c_double(0)
     L.orbslam_ref_local_mapping_ms(C.byref(a), C.byref(b))

@@ -1053,7 +1053,7 @@ uint64_t orbslam_ref_loop_bow_hash(int k) { return k >= 0 && k < (int)g_loop.siz
 // include/ORBmatcherBatch.h.  frames[0] = the current key frame, frames[1..nn] its neighbours (their Frames keep the key frames' features); F12 = nn x 9;
 // t2w = nn x 3 (neighbour i at [I | t2w_i], the current key frame at the origin).  Out: pairs1 / pairs2 [nn][cap] + npairs[nn] = vMatchedIndices per neighbour;
 // kf_points [nn + 1][cap] = MapPoint::mnId per feature of every key frame after both loops (-1 = none); nfused.
-int orbslam_ref_local_mapping_loops(int nn, void* const* frames, const float* F12, const float* t2w, const char* voc_path, float fuse_th, int cap,
+int orbslam_ref_local_mapping_loops(int nn, void* const* frames, const float* F12, const float* t2w, const char* voc_path, float fuse_th, float point_depth, int cap,
                                     int* pairs1, int* pairs2, int* npairs, int* kf_points, int* nfused)
 {
     ORBVocabulary* voc = shared_voc(voc_path);
@@ -1072,9 +1072,10 @@ int orbslam_ref_local_mapping_loops(int nn, void* const* frames, const float* F1
         kf[i]->SetPose(T);
         for (int j = 0; j < F.N; j++) {
             if ((j * 2654435761u + i * 40503u) % 3 != 0) continue;
-            cv::Mat pos(3, 1, CV_32F);                                                                  // on the viewing ray of the feature, depth 1 from the current key frame's origin
-            pos.at<float>(0) = (F.mvKeysUn[j].pt.x - F.cx) * F.invfx - (i > 0 ? t2w[3 * (i - 1)] : 0.f); pos.at<float>(1) = (F.mvKeysUn[j].pt.y - F.cy) * F.invfy - (i > 0 ? t2w[3 * (i - 1) + 1] : 0.f);
-            pos.at<float>(2) = 1.0f - (i > 0 ? t2w[3 * (i - 1) + 2] : 0.f);
+            cv::Mat pos(3, 1, CV_32F);                                                                  // on the viewing ray of the feature at the scene's depth, in world (= current key frame) coordinates
+            const float z = point_depth;
+            pos.at<float>(0) = (F.mvKeysUn[j].pt.x - F.cx) * F.invfx * z - (i > 0 ? t2w[3 * (i - 1)] : 0.f); pos.at<float>(1) = (F.mvKeysUn[j].pt.y - F.cy) * F.invfy * z - (i > 0 ? t2w[3 * (i - 1) + 1] : 0.f);
+            pos.at<float>(2) = z - (i > 0 ? t2w[3 * (i - 1) + 2] : 0.f);
             MapPoint* p = new MapPoint(pos, kf[i], NULL);
             ORB_SLAM2::g_next_desc = F.mDescriptors.ptr(j); p->ComputeDistinctiveDescriptors();
             p->mnTrackScaleLevel = F.mvKeysUn[j].octave; p->UpdateNormalAndDepth();
@@ -1107,7 +1108,7 @@ int orbslam_ref_local_mapping_loops(int nn, void* const* frames, const float* F1
             if ((idx1 * 7 + idx2) % 3 == 0) continue;                                                   // "triangulation failed"
             Frame& F1 = *(Frame*)frames[0];
             cv::Mat pos(3, 1, CV_32F);
-            pos.at<float>(0) = (F1.mvKeysUn[idx1].pt.x - F1.cx) * F1.invfx; pos.at<float>(1) = (F1.mvKeysUn[idx1].pt.y - F1.cy) * F1.invfy; pos.at<float>(2) = 1.0f;
+            pos.at<float>(0) = (F1.mvKeysUn[idx1].pt.x - F1.cx) * F1.invfx * point_depth; pos.at<float>(1) = (F1.mvKeysUn[idx1].pt.y - F1.cy) * F1.invfy * point_depth; pos.at<float>(2) = point_depth;
             MapPoint* pMP = new MapPoint(pos, kf[0], NULL);                                            // LocalMapping.cc:427-438
             ORB_SLAM2::g_next_desc = F1.mDescriptors.ptr((int)idx1); pMP->ComputeDistinctiveDescriptors();
             pMP->mnTrackScaleLevel = F1.mvKeysUn[idx1].octave; pMP->UpdateNormalAndDepth();

@@ -514,12 +514,13 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
     if ((size_t)(4 * c->out_cap + 4 * c->lvl0_cap + 64) * sizeof(int) > 158 * 1024) { delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "nfeatures too large for the LDS matcher"); }
 
     // ---- device
-    // Stream priorities (ORBHIP_STREAM_PRIO, default 1): the blur's stream - tens of thousands of independent tiles - gets the LOWEST priority, so that
-    // the quadtree's few long workgroups on the main stream, which it runs beside, are always dispatched first.  Without it the order in which the two
-    // launches reach the hardware decided whether the quadtree ran 0.24 or 0.49 ms beside the blur (same binary, box by box: VERDICT r04 weak #6).
-    // 0 = no priorities (the old behaviour), 2 = additionally the main stream highest and the matcher's stream lowest.
+    // Stream priorities (ORBHIP_STREAM_PRIO, default 2): the blur's stream - tens of thousands of independent tiles - gets the LOWEST priority, so that
+    // the quadtree's few long workgroups on the main stream, which it runs beside, are always dispatched first (1); additionally the main stream the
+    // highest and the matcher's stream the lowest (2).  Without priorities the order in which the launches reach the hardware decided whether the
+    // quadtree ran 0.24 or 0.49 ms beside the blur (same binary, box by box: VERDICT r04 weak #6); with them 0.18 ms, and the B = 512 step gains 0.8 %
+    // (profiles/r05_exp_stream_priorities.jsonl).  0 = no priorities (the old behaviour).
     int prio_lo = 0, prio_hi = 0; (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);      // (numerically: lo = least urgent, hi = most urgent)
-    const int prio_mode = [] { const char* e = getenv("ORBHIP_STREAM_PRIO"); return e ? atoi(e) : 1; }();
+    const int prio_mode = [] { const char* e = getenv("ORBHIP_STREAM_PRIO"); return e ? atoi(e) : 2; }();
     if (cfg->stream) c->stream = (hipStream_t)cfg->stream;
     else {
         hipError_t e = prio_mode >= 2 ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);

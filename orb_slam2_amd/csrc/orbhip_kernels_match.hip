@@ -91,6 +91,7 @@ typedef int nn_v4i __attribute__((vector_size(16)));
 typedef int nn_v16i __attribute__((vector_size(64)));
 #define NNM_QT 2                        // query tiles (of 32) per wavefront (3: 9.7 ms against 7.9 - a sixth workgroup column of padding; 4: spills)
 #define NNM_QG (4 * NNM_QT * 32)        // queries per workgroup
+#define ORBHIP_NN_DEFAULT 1             // form of the matrix-core scan orbhip_launch_hamming_nn takes (1 = i8, 2..4 = FP4 with that many query tiles per wave)
 __global__ __launch_bounds__(256, 2) void k_hamming_nn_mfma(const unsigned* q, int nq, const unsigned* db, long long ndb, long long base, NNPart* parts, int nchunks)
 {
     __shared__ unsigned long long s_tab[256];                          // byte -> its 8 bits as +-1 bytes
@@ -202,6 +203,113 @@ __global__ __launch_bounds__(256, 2) void k_hamming_nn_mfma(const unsigned* q, i
     }
 }
 
+// ---- the same scan on the FP4 matrix path (gfx950 only: v_mfma_scale_f32_32x32x64_f8f6f4, twice the i8 rate).  +-1 is exact in E2M1 (+1 = 0x2,
+// -1 = 0xA); the query side's block scale 2^6 (E8M0 133) gives the weight 64, so a product is -+64, the f32 accumulator holds integers below 2^16 -
+// exact - and with the same C operand 256 * 64 + row-in-tile a tile's accumulators are again its keys  distance << 7 | row-in-tile.  Positive floats
+// order like their bit patterns: the v_min3 / v_med3 tournament runs on the raw registers and only the two winners are converted.  A descriptor is 256
+// nibbles = 8 x 16 bytes: the expanded DB tile is 4 KB (the i8 form's is 8 KB) and a query tile costs 16 operand registers instead of 32, which is what
+// lets a wave keep QT = 3 or 4 query tiles (the i8 form spills at 4) and amortise the tile's expansion and operand reads over more queries.
+typedef int nn_v8i __attribute__((vector_size(32)));
+typedef float nn_v16f __attribute__((vector_size(64)));
+template <int QT> __global__ __launch_bounds__(256, 2) void k_hamming_nn_fp4(const unsigned* q, int nq, const unsigned* db, long long ndb, long long base, NNPart* parts, int nchunks)
+{
+    __shared__ unsigned s_tab[256];                                    // byte -> its 8 bits as FP4 nibbles (bit k -> nibble k): set = +1 (0x2), clear = -1 (0xA)
+    __shared__ __attribute__((aligned(16))) unsigned s_a[2][8 * 32 * 4];    // expanded DB tile: [dword d of the row = 2 kb + h][row i] x 16 bytes, double-buffered
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), chunk = blockIdx.y;
+    {
+        unsigned e = 0;
+#pragma unroll
+        for (int t = 0; t < 8; t++) e |= (((tid >> t) & 1) ? 0x2u : 0xAu) << (4 * t);
+        s_tab[tid] = e;
+    }
+    __syncthreads();
+    const int j = lane & 31, h = lane >> 5;
+    constexpr int QG = 4 * QT * 32;
+    // ---- the wave's queries as B operands: lane (j, h), K block kb = dword 2 kb + h of query j; the opposite sign (set bit -> -1): x ^ 0x88888888
+    nn_v8i B[QT][4];
+    int qidx[QT];
+#pragma unroll
+    for (int t = 0; t < QT; t++) {
+        qidx[t] = blockIdx.x * QG + (wave * QT + t) * 32 + j;
+        const unsigned* qp = q + (long long)min(qidx[t], nq - 1) * 8;
+#pragma unroll
+        for (int kb = 0; kb < 4; kb++) {
+            const unsigned w = qp[2 * kb + h];
+            B[t][kb] = nn_v8i{(int)(s_tab[w & 0xff] ^ 0x88888888u), (int)(s_tab[(w >> 8) & 0xff] ^ 0x88888888u), (int)(s_tab[(w >> 16) & 0xff] ^ 0x88888888u), (int)(s_tab[w >> 24] ^ 0x88888888u), 0, 0, 0, 0};
+        }
+    }
+    unsigned kbest[QT], ksec[QT];
+#pragma unroll
+    for (int t = 0; t < QT; t++) { kbest[t] = 0xffffffffu; ksec[t] = 0xffffffffu; }
+    const long long row0 = (long long)chunk * NN_CHUNK;
+    const int nrows = (int)min((long long)NN_CHUNK, ndb - row0);
+    const int ntiles = (nrows + 31) >> 5;
+    const int sr = tid & 31, sd = tid >> 5;                            // staging role: row sr of the tile, dword sd of that row
+    auto stage = [&](int tile, int buf) {
+        const int r = tile * 32 + sr;
+        const unsigned w = r < nrows ? db[(row0 + r) * 8 + sd] : 0u;
+        *reinterpret_cast<uint4*>(s_a[buf] + (sd * 32 + sr) * 4) = uint4{s_tab[w & 0xff], s_tab[(w >> 8) & 0xff], s_tab[(w >> 16) & 0xff], s_tab[w >> 24]};
+    };
+    nn_v16f cinit;
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) cinit[reg] = (float)(256 * 64 + (reg & 3) + 8 * (reg >> 2) + 4 * h);
+    auto top2_of3 = [](unsigned a, unsigned b, unsigned c, unsigned& lo, unsigned& mid) { lo = min(min(a, b), c); mid = max(min(a, b), min(max(a, b), c)); };
+    auto merge2 = [](unsigned& b, unsigned& s2, unsigned ob, unsigned os) { s2 = min(min(s2, os), max(b, ob)); b = min(b, ob); };
+    auto products = [&](int tile, nn_v16f (&acc)[QT]) {
+        const int buf = tile & 1;
+        if (tile + 1 < ntiles) stage(tile + 1, buf ^ 1);
+#pragma unroll
+        for (int kb = 0; kb < 4; kb++) {
+            const uint4 a4 = *reinterpret_cast<const uint4*>(s_a[buf] + ((2 * kb + h) * 32 + j) * 4);         // lane (i = j, h): row i of the tile
+            const nn_v8i A = nn_v8i{(int)a4.x, (int)a4.y, (int)a4.z, (int)a4.w, 0, 0, 0, 0};
+#pragma unroll
+            for (int t = 0; t < QT; t++)      // (A, B, C, format of A = FP4, format of B = FP4, scale A: byte 0 of 127 = 2^0, scale B: byte 0 of 133 = 2^6)
+                acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B[t][kb], kb == 0 ? cinit : acc[t], 4, 4, 0, 127, 0, 133);
+        }
+    };
+    auto select = [&](int tile, const nn_v16f (&acc)[QT], auto ragged) {
+        const unsigned tbase = (unsigned)tile * 32u;
+#pragma unroll
+        for (int t = 0; t < QT; t++) {
+            unsigned x[16];
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                x[reg] = __float_as_uint(acc[t][reg]);                                                       // (float)(distance << 7 | row-in-tile): positive, ordered like its bits
+                if (decltype(ragged)::value && tile * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h >= nrows) x[reg] = __float_as_uint((float)((511u << 7) + (unsigned)((reg & 3) + 8 * (reg >> 2) + 4 * h)));
+            }
+            unsigned b, s2;
+            top2_of3(x[0], x[1], x[2], b, s2);
+#pragma unroll
+            for (int g = 1; g < 5; g++) { unsigned lo, mid; top2_of3(x[3 * g], x[3 * g + 1], x[3 * g + 2], lo, mid); merge2(b, s2, lo, mid); }
+            merge2(b, s2, x[15], 0x7f7fffffu);                                                              // (the largest finite float's bits: loses to every key)
+            const unsigned bi = (unsigned)__uint_as_float(b), si = (unsigned)__uint_as_float(s2);           // the two winners back to integers: d << 7 | r
+            const unsigned kb1 = (bi << 6) - 63u * (bi & 127u) + tbase, ks1 = (si << 6) - 63u * (si & 127u) + tbase;
+            merge2(kbest[t], ksec[t], kb1, ks1);
+        }
+    };
+    stage(0, 0);
+    __syncthreads();
+    const int nfull = nrows >> 5;
+    nn_v16f acc[QT];
+    for (int tile = 0; tile < ntiles; tile++) {
+        products(tile, acc);
+        if (tile < nfull) select(tile, acc, std::false_type{}); else select(tile, acc, std::true_type{});
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < QT; t++) {
+        const unsigned ob = (unsigned)__shfl_xor((int)kbest[t], 32), os = (unsigned)__shfl_xor((int)ksec[t], 32);
+        const unsigned b = min(kbest[t], ob), s2 = min(min(ksec[t], os), max(kbest[t], ob));
+        if (h == 0 && qidx[t] < nq) {
+            NNPart p;
+            p.best = (b >> 13) > 256u ? IMAX : (int)(b >> 13);
+            p.second = (s2 >> 13) > 256u ? IMAX : (int)(s2 >> 13);
+            p.idx = (b >> 13) > 256u ? -1 : row0 + (long long)(b & 0x1fffu) + base;
+            parts[(long long)qidx[t] * nchunks + chunk] = p;
+        }
+    }
+}
+
 // fold the per-chunk partials of one query in ascending DB order: stable arg-min + second smallest of the multiset
 __device__ __forceinline__ void nn_combine(int& b, long long& i, int& s, int rb, long long ri, int rs)
 {
@@ -233,8 +341,17 @@ bool orbhip_launch_hamming_nn(const uint8_t* d_q, int nq, const uint8_t* d_db, l
     NNPart* parts = (NNPart*)orbhip_nn_workspace(sizeof(NNPart) * (size_t)nq * nchunks, s);
     if (!parts) return false;                                    // the caller reports it: results would be left unwritten
     // the matrix-core scan from a few chunks on (below that a call is latency, not throughput); ORBHIP_NN=valu (measurement only) keeps the popcount kernel
-    static const bool force_valu = [] { const char* e = getenv("ORBHIP_NN"); return e && strcmp(e, "valu") == 0; }();
-    if (!force_valu && ndb >= 4 * NN_CHUNK) {
+    // ORBHIP_NN = valu | i8 | fp4 | fp4x2 | fp4x3 | fp4x4 (measurement only): the popcount kernel, the i8 matrix-core scan, the FP4 one with 2 / 3 / 4 query tiles per wave
+    const int form = [] { const char* e = getenv("ORBHIP_NN");      // (read per call: a scan is at least a hundred microseconds; tests switch forms inside one process)
+        if (!e) return ORBHIP_NN_DEFAULT; if (!strcmp(e, "valu")) return 0; if (!strcmp(e, "i8")) return 1;
+                                 if (!strcmp(e, "fp4x2")) return 2; if (!strcmp(e, "fp4x3") || !strcmp(e, "fp4")) return 3; if (!strcmp(e, "fp4x4")) return 4; return ORBHIP_NN_DEFAULT; }();
+    if (form >= 2 && ndb >= 4 * NN_CHUNK) {
+        const int qg = 4 * form * 32;
+        const dim3 grid((nq + qg - 1) / qg, nchunks, 1);
+        if (form == 2) hipLaunchKernelGGL(k_hamming_nn_fp4<2>, grid, dim3(256, 1, 1), 0, s, (const unsigned*)d_q, nq, (const unsigned*)d_db, ndb, base, parts, nchunks);
+        else if (form == 3) hipLaunchKernelGGL(k_hamming_nn_fp4<3>, grid, dim3(256, 1, 1), 0, s, (const unsigned*)d_q, nq, (const unsigned*)d_db, ndb, base, parts, nchunks);
+        else hipLaunchKernelGGL(k_hamming_nn_fp4<4>, grid, dim3(256, 1, 1), 0, s, (const unsigned*)d_q, nq, (const unsigned*)d_db, ndb, base, parts, nchunks);
+    } else if (form >= 1 && ndb >= 4 * NN_CHUNK) {
         hipLaunchKernelGGL(k_hamming_nn_mfma, dim3((nq + NNM_QG - 1) / NNM_QG, nchunks, 1), dim3(256, 1, 1), 0, s, (const unsigned*)d_q, nq,
                            (const unsigned*)d_db, ndb, base, parts, nchunks);
     } else {

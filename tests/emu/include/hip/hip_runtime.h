@@ -220,6 +220,30 @@ inline hipemu_v16i __builtin_amdgcn_mfma_i32_32x32x32_i8(hipemu_v4i a, hipemu_v4
     __builtin_amdgcn_wave_barrier();
     return d;
 }
+// v_mfma_scale_f32_32x32x64_f8f6f4 with FP4 (E2M1) operands (cbsz = blgp = 4): D = (2^(sa-127) A) x (2^(sb-127) B) + C on one wave.  As this header assumes it -
+// A[i][k]: lane i + 32h, nibble p of its first 16 bytes <-> k = 32h + p; B[k][j]: lane j + 32h, same k; one E8M0 scale per lane = per block of 32;
+// C / D as the i8 form.  (Only the hardware can say whether the k order inside a lane is this one; the kernels use the same order on both operands.)
+typedef int hipemu_v8i __attribute__((vector_size(32)));
+typedef float hipemu_v16f __attribute__((vector_size(64)));
+inline hipemu_v16f __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(hipemu_v8i a, hipemu_v8i b, hipemu_v16f c, int cbsz, int blgp, int, int scale_a, int, int scale_b) {
+    static unsigned char A[32][64][16], B[32][64][16]; static float SA[32][64], SB[32][64];
+    static const float e2m1[8] = {0.f, 0.5f, 1.f, 1.5f, 2.f, 3.f, 4.f, 6.f};
+    if (cbsz != 4 || blgp != 4) abort();                              // only the FP4 form is emulated
+    const int w = hipemu::g.cur->wave & 31, l = __lane_id();
+    memcpy(A[w][l], &a, 16); memcpy(B[w][l], &b, 16);
+    SA[w][l] = ldexpf(1.0f, (scale_a & 0xff) - 127); SB[w][l] = ldexpf(1.0f, (scale_b & 0xff) - 127);
+    __builtin_amdgcn_wave_barrier();
+    auto val = [&](const unsigned char* p, int k) { const unsigned n = (p[k >> 1] >> (4 * (k & 1))) & 0xf; const float v = e2m1[n & 7]; return (n & 8) ? -v : v; };
+    hipemu_v16f d = c;
+    const int j = l & 31, hh = l >> 5;
+    for (int q = 0; q < 16; q++) {
+        const int i = (q & 3) + 8 * (q >> 2) + 4 * hh; float acc = 0.f;
+        for (int h = 0; h < 2; h++) for (int k = 0; k < 32; k++) acc += SA[w][i + 32 * h] * val(A[w][i + 32 * h], k) * SB[w][j + 32 * h] * val(B[w][j + 32 * h], k);
+        d[q] += acc;
+    }
+    __builtin_amdgcn_wave_barrier();
+    return d;
+}
 // v_dot2_u32_u16: two u16 products + c
 template <typename V> inline unsigned __builtin_amdgcn_udot2(V a, V b, unsigned c, bool /*clamp*/) { return (unsigned)a[0] * (unsigned)b[0] + (unsigned)a[1] * (unsigned)b[1] + c; }
 // v_cvt_pk_u8_f32: round to nearest even, saturate to [0, 255], insert into byte `pos` of `old` (measured on MI355X:

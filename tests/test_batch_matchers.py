@@ -193,7 +193,7 @@ def test_local_mapping_loops_through_the_binding(builds, request, tmp_path):
         S.RefFrame._geometry = None
         S.RefFrame._geometry_other.clear()
         frames = [S.RefFrame(L[i], R[i], library=lib, **cam) for i in range(nn + 1)]
-        res[name] = S.local_mapping_loops(frames, F12, t2w, str(voc))
+        res[name] = S.local_mapping_loops(frames, F12, t2w, str(voc), point_depth=cfg["bf"] / 8.0)       # the far plane of the synthetic scene: disparity 8
         for f in frames:
             f.close()
     S.RefFrame._geometry = None

@@ -119,15 +119,20 @@ def test_brute_force_nn(backend, oracle):
     assert all(np.array_equal(a, b) for a, b in zip(merged, want))
 
 
-def test_brute_force_nn_matrix_core_scan(backend, oracle, monkeypatch):
-    """Databases from four chunks (32 K rows) on are scanned on the matrix cores (k_hamming_nn_mfma: <+-1, +-1> = 256 - 2 Hamming):
+@pytest.mark.parametrize("form", ["default", "i8", "fp4x2", "fp4x3", "fp4x4", "valu"])
+def test_brute_force_nn_matrix_core_scan(backend, oracle, monkeypatch, form):
+    """Databases from four chunks (32 K rows) on are scanned on the matrix cores - k_hamming_nn_mfma (<+-1, +-1> = 256 - 2 Hamming as i8 products) or
+    k_hamming_nn_fp4 (the same as FP4 products on v_mfma_scale_f32_32x32x64_f8f6f4, 2 / 3 / 4 query tiles per wave); ORBHIP_NN picks the form:
     ragged last tile and chunk, a query count that fills neither a tile nor a workgroup, planted exact matches, duplicated rows
-    (lowest index wins, second = best), an index base, and equality with the popcount kernel (ORBHIP_NN=valu is read once per
-    process, so that comparison is against the oracle only)."""
+    (lowest index wins, second = best), an index base; every form against the oracle (the popcount kernel included)."""
+    if form != "default":
+        monkeypatch.setenv("ORBHIP_NN", form)
+    if backend.endswith("_emu.so") and form in ("fp4x2", "fp4x4"):
+        pytest.skip("the emulation's FP4 matrix product is slow: one FP4 form is enough here, all run on the GPU")
     rng = np.random.default_rng(5)
     n = 4 * 8192 + 1000 + 13
     db = rng.integers(0, 256, (n, 32), dtype=np.uint8)
-    q = rng.integers(0, 256, (70, 32), dtype=np.uint8)
+    q = rng.integers(0, 256, (70 if backend.endswith("_emu.so") else 530, 32), dtype=np.uint8)      # (the GPU run fills more than one workgroup of every form)
     q[:20] = db[rng.integers(0, n, 20)]                       # exact matches somewhere in the database
     q[20:30] ^= 1                                               # and near ones
     db[n - 5:] = db[100:105]; q[30:35] = db[100:105]            # duplicates in the last, ragged tile: index 100..104 must win, second == 0

@@ -69,9 +69,13 @@ def measure_sequence(sensor, nframes=24, passes=5, ref_passes=1, seed=3, kf_ever
         return {"shape": sensor, "skipped": "oracle/_ref/liborbslam_ref_fast.so / liborbslam_dropin_full_gpu.so did not travel with the repository"}
     ref_lib = S._bind(C.CDLL(S.FAST_PATH))
     gpu_lib = S.dropin_gpu_lib(full=True)
-    voc = os.path.join(tempfile.gettempdir(), "orbhip_voc_k6_L3_nonl.txt")
-    with open(voc, "w") as f:
-        f.write(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "voc_k6_L3_ref.txt")).read().rstrip("\n"))
+    # a vocabulary of ORBvoc.txt's shape (k = 10, L = 6, random; the real file is not in the checkout): FeatureVectors at levelsup 4 then have ~100 nodes, as in
+    # ORB_SLAM2 - the 216-word golden vocabulary of the tests puts a whole frame into ONE node, which makes SearchByBoW a 1000 x 1000 scan on one wavefront
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from secondary_units import write_voc
+    voc = os.path.join(tempfile.gettempdir(), "orbhip_voc_k10_L6_nonl.txt")
+    if not os.path.exists(voc):
+        write_voc(voc, 10, 6)
     L, R, T, P, depth = synth.stereo_sequence(cfg["w"], cfg["h"], nframes, cfg["fx"], cfg["bf"], seed=seed, return_depth=True)
     args = (sensor, L, depth, T, P, cfg["n"], cfg["fx"], cfg["fy"], cfg["cx"], cfg["cy"], cfg["bf"], cfg["th_depth"], voc)
     kw = dict(dist=TUM1_DIST if sensor == "rgbd" else None, kf_every=kf_every, lost_every=lost_every)
@@ -95,7 +99,7 @@ def measure_sequence(sensor, nframes=24, passes=5, ref_passes=1, seed=3, kf_ever
     return {"shape": f"{cfg['w']}x{cfg['h']} {sensor}, {cfg['n']} features, 8 levels, {nframes} frames, a key frame every {kf_every}, lost every {lost_every}" + (", TUM1 distortion" if sensor == "rgbd" else ", 2 x nFeatures until initialised"),
             "ms_per_frame_gpu": g, "ms_per_frame_ref": r, "speedup": round(r / g, 1), "frame_constructor_ms": {"gpu": gc, "ref": rc},
             "ms_per_frame_by_mode_gpu": gparts, "ms_per_frame_by_mode_ref": rparts,
-            "parity": {"frames_compared": nframes, "frames_mismatched": len(mismatched), "compared": "keys, mvKeysUn, descriptors, depth columns, map point per feature after each matcher, counters, bag-of-words hashes"},
+            "vocabulary": "k = 10, L = 6 (ORBvoc.txt's shape), random", "parity": {"frames_compared": nframes, "frames_mismatched": len(mismatched), "compared": "keys, mvKeysUn, descriptors, depth columns, map point per feature after each matcher, counters, bag-of-words hashes"},
             "modes": [int(f.used_wide) for f in ref]}
 
 

@@ -197,7 +197,7 @@ def matcher_calls(cfg, ref_lib, gpu_lib, voc_path, reps=7, ref_reps=3):
             lib = sides[name][0]
             S.RefFrame._geometry = None; S.RefFrame._geometry_other.clear()
             fr = [S.RefFrame(Ls[i], Rs[i], library=lib, **cam) for i in range(nn + 1)]
-            runs = [S.local_mapping_loops(fr, F12, t2, voc_path) for _ in range(3 if name == "gpu" else 1)]
+            runs = [S.local_mapping_loops(fr, F12, t2, voc_path, point_depth=cfg["bf"] / 8.0) for _ in range(3 if name == "gpu" else 1)]
             lres[name] = (runs[-1], float(np.median([r[3][0] for r in runs])), float(np.median([r[3][1] for r in runs])))
             for f in fr:
                 f.close()
