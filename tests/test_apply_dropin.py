@@ -27,7 +27,7 @@ def test_patch_applies_and_patched_sources_compile(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     out = tmp_path / "out"
     subprocess.run([sys.executable, SCRIPT, REF, str(out)], capture_output=True, text=True, check=True)
-    for rel in ("src/Frame.cc", "src/ORBmatcher.cc", "src/ORBextractor.cc", "include/ORBextractor.h", "include/orbhip.h"):
+    for rel in ("src/Frame.cc", "src/ORBmatcher.cc", "src/ORBextractor.cc", "include/ORBextractor.h", "include/orbhip.h", "include/ORBmatcherBatch.h"):
         assert (co / rel).read_text() == (out / rel).read_text(), rel + ": patch -p1 and the directory mode disagree"
     patched = (co / "src/ORBmatcher.cc").read_text()
     assert "abort();" not in patched and "orbhip_search_by_projection_frame" in patched and patched.count("orbhip_check(orbhip_") >= 10
@@ -40,4 +40,35 @@ def test_patch_applies_and_patched_sources_compile(tmp_path):
              "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(REF, "Thirdparty/DBoW2")]
     for rel in ("src/ORBmatcher.cc", "src/Frame.cc"):
         r = subprocess.run(["g++"] + flags + [str(co / rel)], capture_output=True, text=True)
+        assert r.returncode == 0, rel + ":\n" + r.stderr[-3000:]
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src")), reason="reference sources not mounted")
+def test_optional_steps(tmp_path):
+    """--stereo-one-call replaces exactly the constructor's two extractor threads with ONE ExtractStereo call (and fails loudly on a checkout that has
+    none); the batch forms of the back end's loops are emitted with their header; both patched files still compile."""
+    plain, one = tmp_path / "plain", tmp_path / "one"
+    subprocess.run([sys.executable, SCRIPT, REF, str(plain)], capture_output=True, text=True, check=True)
+    subprocess.run([sys.executable, SCRIPT, "--stereo-one-call", REF, str(one)], capture_output=True, text=True, check=True)
+    a, b = (plain / "src/Frame.cc").read_text(), (one / "src/Frame.cc").read_text()
+    assert "thread threadLeft(&Frame::ExtractORB,this,0,imLeft);" in a and "threadLeft" not in b
+    assert b.count("mpORBextractorLeft->ExtractStereo(imLeft, imRight, mvKeys, mDescriptors, mvKeysRight, mDescriptorsRight, mbf, mbf/K.at<float>(0,0));") == 1
+    assert (plain / "src/ORBmatcher.cc").read_text() == (one / "src/ORBmatcher.cc").read_text()
+    m = (one / "src/ORBmatcher.cc").read_text()
+    for name in ("void SearchByBoWBatch(", "void SearchForTriangulationBatch(", "int TriangulationPairs(", "int FuseBatch(", "static int orbhip_fuse_apply(", "static void orbhip_fuse_collect("):
+        assert m.count(name) == 1, name
+    assert (one / "include/ORBmatcherBatch.h").read_text() == open(os.path.join(ROOT, "include", "ORBmatcherBatch.h")).read()
+    # a Frame.cc without the two threads (already patched, or a fork that extracts differently) is refused, not silently left alone
+    twice = tmp_path / "twice"
+    (twice / "src").mkdir(parents=True); (twice / "include").mkdir()
+    shutil.copyfile(one / "src/Frame.cc", twice / "src/Frame.cc")
+    r = subprocess.run([sys.executable, SCRIPT, "--files", "--stereo-one-call", str(twice / "src/Frame.cc"), str(tmp_path / "x.cc")], capture_output=True, text=True)
+    assert r.returncode != 0 and "not found" in (r.stderr + r.stdout)
+    ora = os.path.join(ROOT, "oracle")
+    flags = ["-std=c++14", "-fsyntax-only", "-w", "-DCVLITE_ALGEBRA", "-DORBHIP_USE_OPENCV", "-DORBSLAM_DROPIN_BUILD", "-DORBHIP_USE_DBOW2_TYPES",
+             "-include", os.path.join(ora, "ref_shim/dropin/ORBVocabulary.h"), "-include", os.path.join(ora, "ref_shim/dropin/ORBextractor.h"),
+             "-I" + os.path.join(ora, "ref_shim/dropin"), "-I" + os.path.join(ora, "ref_shim"), "-I" + os.path.join(REF, "include"), "-I" + REF,
+             "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(REF, "Thirdparty/DBoW2")]
+    for rel in ("src/ORBmatcher.cc", "src/Frame.cc"):
+        r = subprocess.run(["g++"] + flags + [str(one / rel)], capture_output=True, text=True)
         assert r.returncode == 0, rel + ":\n" + r.stderr[-3000:]
