@@ -39,26 +39,30 @@ using namespace ORB_SLAM2;
 // ---- bump arena for std::list<ExtractorNode> nodes: (size, pointer) sort of DistributeOctTree == tie-break H1 (see orbextractor_ref_wrap.cpp)
 namespace {
 const size_t kNodeBytes = sizeof(std::_List_node<ORB_SLAM2::ExtractorNode>);
-const size_t kArenaBytes = (size_t)256 << 20;
-char* g_arena = nullptr; size_t g_used = 0;
+const size_t kArenaBytes = (size_t)1 << 30;      // (virtual: pages are touched as the arena grows)
+char* g_arena = nullptr; size_t g_used = 0; long g_live = 0;
 inline bool in_arena(void* p) { return g_arena && (char*)p >= g_arena && (char*)p < g_arena + kArenaBytes; }
 }
+// Any allocation of exactly a list node's size lands here - also ones that have nothing to do with the extractor (a std::vector<unsigned> of 22 features in
+// a copied FeatureVector is 88 bytes too) and outlive the frame.  The arena therefore starts over only when NOTHING in it is alive (g_live counts the
+// blocks handed out and given back); otherwise it keeps growing and, once full, hands the request to malloc.
+static void arena_restart() { if (__atomic_load_n(&g_live, __ATOMIC_RELAXED) == 0) g_used = 0; }
 void* operator new(size_t n)
 {
     if (n == kNodeBytes) {
         if (!g_arena) g_arena = (char*)malloc(kArenaBytes);
         const size_t a = (n + 15) & ~(size_t)15;
         const size_t at = __atomic_fetch_add(&g_used, a, __ATOMIC_RELAXED);      // the stereo constructor extracts on two threads
-        if (g_arena && at + a <= kArenaBytes) return g_arena + at;
+        if (g_arena && at + a <= kArenaBytes) { __atomic_fetch_add(&g_live, 1, __ATOMIC_RELAXED); return g_arena + at; }
     }
     void* p = malloc(n ? n : 1);
     if (!p) throw std::bad_alloc();
     return p;
 }
-void operator delete(void* p) noexcept { if (p && !in_arena(p)) free(p); }
-void operator delete(void* p, size_t) noexcept { if (p && !in_arena(p)) free(p); }
+void operator delete(void* p) noexcept { if (!p) return; if (in_arena(p)) __atomic_fetch_sub(&g_live, 1, __ATOMIC_RELAXED); else free(p); }
+void operator delete(void* p, size_t) noexcept { if (!p) return; if (in_arena(p)) __atomic_fetch_sub(&g_live, 1, __ATOMIC_RELAXED); else free(p); }
 #else
-namespace { size_t g_used = 0; }
+static void arena_restart() {}
 #endif
 
 // ---- MapPoint / KeyFrame members referenced by Frame.cc / ORBmatcher.cc (their own .cc files are not part of this build)
@@ -259,7 +263,7 @@ extern "C" {
 void* orbslam_ref_frame_mono(const uint8_t* img, int w, int h, int stride, int nfeat, float scale, int nlevels, int ini, int mn,
                              float fx, float fy, float cx, float cy, float bf, float thDepth, int new_geometry)
 {
-    g_used = 0;
+    arena_restart();
     if (new_geometry) Frame::mbInitialComputations = true;
     cv::Mat im(h, w, CV_8UC1, (void*)img, (size_t)stride), K = camera(fx, fy, cx, cy), D = cv::Mat(cv::Mat::zeros(4, 1, CV_32F));
     attach_camera(rig(nfeat, scale, nlevels, ini, mn).left, K, D);
@@ -271,7 +275,7 @@ void* orbslam_ref_frame_mono(const uint8_t* img, int w, int h, int stride, int n
 void* orbslam_ref_frame_mono_dist(const uint8_t* img, int w, int h, int stride, int nfeat, float scale, int nlevels, int ini, int mn,
                                   float fx, float fy, float cx, float cy, const float* dist, int ndist, float bf, float thDepth, int new_geometry)
 {
-    g_used = 0;
+    arena_restart();
     if (new_geometry) Frame::mbInitialComputations = true;
     cv::Mat im(h, w, CV_8UC1, (void*)img, (size_t)stride), K = camera(fx, fy, cx, cy), D(ndist, 1, CV_32F);
     for (int i = 0; i < ndist; i++) D.at<float>(i) = dist[i];
@@ -282,7 +286,7 @@ void* orbslam_ref_frame_mono_dist(const uint8_t* img, int w, int h, int stride, 
 void* orbslam_ref_frame_rgbd(const uint8_t* img, const float* depth, int w, int h, int stride, int nfeat, float scale, int nlevels, int ini, int mn,
                              float fx, float fy, float cx, float cy, const float* dist, int ndist, float bf, float thDepth, int new_geometry)
 {
-    g_used = 0;
+    arena_restart();
     if (new_geometry) Frame::mbInitialComputations = true;
     cv::Mat im(h, w, CV_8UC1, (void*)img, (size_t)stride), dm(h, w, CV_32F, (void*)depth), K = camera(fx, fy, cx, cy), D(ndist, 1, CV_32F);
     for (int i = 0; i < ndist; i++) D.at<float>(i) = dist[i];
@@ -322,7 +326,7 @@ void orbslam_ref_frame_bounds(float* out) { out[0] = Frame::mnMinX; out[1] = Fra
 void* orbslam_ref_frame_stereo(const uint8_t* imgL, const uint8_t* imgR, int w, int h, int stride, int nfeat, float scale, int nlevels, int ini, int mn,
                                float fx, float fy, float cx, float cy, float bf, float thDepth, int new_geometry)
 {
-    g_used = 0;
+    arena_restart();
     if (new_geometry) Frame::mbInitialComputations = true;
     cv::Mat L(h, w, CV_8UC1, (void*)imgL, (size_t)stride), R(h, w, CV_8UC1, (void*)imgR, (size_t)stride), K = camera(fx, fy, cx, cy), D = cv::Mat(cv::Mat::zeros(4, 1, CV_32F));
     Rig& r = rig(nfeat, scale, nlevels, ini, mn);
@@ -709,7 +713,7 @@ static int tracking_loop_impl(int nframes, const uint8_t* const* left, const uin
                               int nfeat, float scale, int nlevels, int ini, int mn, float fx, float fy, float cx, float cy, float bf, float thDepth,
                               const float* Tpred /* nframes x 16 */, const float* Tcw /* nframes x 16 */, int kf_every, int capture, bool fresh_statics)
 {
-    g_used = 0;
+    arena_restart();
     // (not while other threads read Frame's static grid geometry: orbslam_ref_concurrency computes it once, before its threads start)
     if (fresh_statics) { Frame::mbInitialComputations = true; Frame::nNextId = 0; }
     MapPoint::nNextId = 0; ORB_SLAM2::tl_next_point_id = 0;
@@ -723,7 +727,7 @@ static int tracking_loop_impl(int nframes, const uint8_t* const* left, const uin
     auto pose = [](const float* t) { cv::Mat T(4, 4, CV_32F); for (int i = 0; i < 16; i++) T.at<float>(i / 4, i % 4) = t[i]; return T; };
     for (int k = 0; k < nframes; k++) {
         LoopFrame& o = g_loop[k];
-        g_used = 0;
+        arena_restart();
         const auto t0 = std::chrono::steady_clock::now();
         double t0skip = 0;                                                                                // the capture copy between the two matchers is not the loop's
         Frame* C = stereo_frame(left[k], right[k], w, h, stride, rg, K, D, bf, thDepth, fx);            // Tracking.cc:200
@@ -864,7 +868,7 @@ int orbslam_ref_sequence_loop(int sensor, int nframes, const uint8_t* const* img
                               int nfeat, float scale, int nlevels, int ini, int mn, float fx, float fy, float cx, float cy, const float* dist, int ndist, float bf, float thDepth,
                               const float* Tpred, const float* Tcw, int kf_every, int lost_every, const char* voc_path, int capture)
 {
-    g_used = 0;
+    arena_restart();
     Frame::mbInitialComputations = true; Frame::nNextId = 0; MapPoint::nNextId = 0; ORB_SLAM2::tl_next_point_id = 0;
     ORB_SLAM2::g_real_predict_scale = true;
     ORBVocabulary* voc = voc_path ? shared_voc(voc_path) : NULL;
@@ -889,7 +893,7 @@ int orbslam_ref_sequence_loop(int sensor, int nframes, const uint8_t* const* img
     int lastReloc = -100;
     for (int k = 0; k < nframes; k++) {
         LoopFrame& o = g_loop[k];
-        g_used = 0;
+        arena_restart();
         const auto t0 = std::chrono::steady_clock::now();
         double t0skip = 0;
         cv::Mat im(h, w, CV_8UC1, (void*)imgs[k], (size_t)stride);

@@ -98,26 +98,35 @@ __device__ __forceinline__ int ba_exscan(int* a, int n, int* scratch, int tid)
     return total;
 }
 
-// rank sort of n unique 64-bit keys (invalid = ~0 sorts last): out[rank] = key
-__device__ __forceinline__ void ba_rank_sort(const unsigned long long* key, unsigned long long* out, int n, int tid)
+// ascending sort of n unique 64-bit keys (invalid = ~0 sorts last) into out[0 .. p2), p2 = the power of two the array is carved for: a bitonic network in
+// LDS, p2 / 2 compare-exchanges per stage spread over the workgroup.  (It was a rank sort - every key counted against every other one: n^2 / 256 LDS reads
+// per thread, 0.46 ms of ONE workgroup for a 2000-feature frame, which is the whole latency of a single frame's ComputeBoW; the network is
+// log2(p2) (log2(p2) + 1) / 2 = 66 stages of 4 exchanges per thread at p2 = 2048.)
+__device__ __forceinline__ void ba_sort(const unsigned long long* key, unsigned long long* out, int n, int p2, int tid)
 {
-    for (int i = tid; i < n; i += BA_T) {
-        const unsigned long long k = key[i];
-        if (k == ~0ull) continue;
-        int r = 0;
-        for (int j = 0; j < n; j++) r += key[j] < k;
-        out[r] = k;
-    }
+    for (int i = tid; i < p2; i += BA_T) out[i] = i < n ? key[i] : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= p2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (p2 >> 1); t += BA_T) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), x = i | j;          // the pair (i, i + j), bit j of i clear
+                const unsigned long long a = out[i], b = out[x];
+                if ((a > b) == ((i & k) == 0)) { out[i] = b; out[x] = a; }
+            }
+            __syncthreads();
+        }
 }
+__host__ __device__ inline int ba_pow2(int n) { int p = 2; while (p < n) p <<= 1; return p; }
 
 __global__ __launch_bounds__(BA_T) void k_bow_assemble(BowParams P)
 {
     HIP_DYNAMIC_SHARED(unsigned long long, lds64)
     const int frame = blockIdx.x, tid = threadIdx.x, n = min(bow_count(P, frame), P.lcap), cap = P.cap;
     const int lcap = P.lcap;                               // LDS arrays hold lcap entries; `cap` is the row stride of the HBM arrays
+    const int p2 = ba_pow2(lcap);
     unsigned long long* key = lds64;                       // [lcap]  (reused as f64 values after the sort)
-    unsigned long long* sorted = lds64 + lcap;             // [lcap]
-    int* flag = reinterpret_cast<int*>(lds64 + 2 * lcap);  // [lcap]
+    unsigned long long* sorted = lds64 + lcap;             // [p2]: the sorting network works on a power of two
+    int* flag = reinterpret_cast<int*>(lds64 + lcap + p2); // [lcap]
     int* scratch = flag + lcap;                            // [8]
     double* vals = reinterpret_cast<double*>(key);
     const uint32_t* word = P.word + (long long)frame * cap; const double* wt = P.weight + (long long)frame * cap; const uint32_t* node = P.node + (long long)frame * cap;
@@ -128,8 +137,7 @@ __global__ __launch_bounds__(BA_T) void k_bow_assemble(BowParams P)
     for (int i = tid; i < n; i += BA_T) { key[i] = wt[i] > 0 ? (((unsigned long long)word[i] << 32) | (unsigned)i) : ~0ull; flag[i] = wt[i] > 0; }
     __syncthreads();
     const int m = ba_exscan(flag, n, scratch, tid);        // features that are "not stopped"
-    ba_rank_sort(key, sorted, n, tid);
-    __syncthreads();
+    ba_sort(key, sorted, n, p2, tid);
     for (int i = tid; i < m; i += BA_T) flag[i] = (i == 0) || ((sorted[i] >> 32) != (sorted[i - 1] >> 32));
     __syncthreads();
     for (int i = tid; i < m; i += BA_T) key[i] = (unsigned long long)flag[i];      // keep the head marks: the scan overwrites flag
@@ -166,8 +174,7 @@ __global__ __launch_bounds__(BA_T) void k_bow_assemble(BowParams P)
     // ---- FeatureVector: fv.addFeature(nid, i_feature) for the same features
     for (int i = tid; i < n; i += BA_T) key[i] = wt[i] > 0 ? (((unsigned long long)node[i] << 32) | (unsigned)i) : ~0ull;
     __syncthreads();
-    ba_rank_sort(key, sorted, n, tid);
-    __syncthreads();
+    ba_sort(key, sorted, n, p2, tid);
     for (int i = tid; i < m; i += BA_T) { flag[i] = (i == 0) || ((sorted[i] >> 32) != (sorted[i - 1] >> 32)); fv_feat[i] = (uint32_t)sorted[i]; }
     __syncthreads();
     for (int i = tid; i < m; i += BA_T) key[i] = (unsigned long long)flag[i];
@@ -429,7 +436,7 @@ static void voc_free_ws(BowWs* w)
     *w = BowWs();
 }
 
-#define BOW_MAX_FEATURES 7168          // 20 B of LDS per feature in k_bow_assemble
+#define BOW_MAX_FEATURES 7168          // 12 B of LDS per feature + 8 B per slot of the sorting network (8192 slots) in k_bow_assemble: 150 KB
 
 static orbhip_status voc_ensure_ws(BowWs* w, int nframes, int cap, hipStream_t s)
 {
@@ -462,7 +469,7 @@ static orbhip_status voc_run(orbhip_voc* v, BowWs* w, const uint8_t* d_desc, lon
     P.bow_id = w->d_bow_id; P.bow_val = w->d_bow_val; P.nbow = w->d_nbow; P.fv_node = w->d_fv_node; P.fv_off = w->d_fv_off; P.fv_feat = w->d_fv_feat; P.nfv = w->d_nfv;
     if (nfeat_max <= 0 || nframes <= 0) return ORBHIP_OK;
     hipLaunchKernelGGL(k_bow_descend, dim3((nfeat_max + 255) / 256, nframes, 1), dim3(256, 1, 1), 0, s, P);
-    if (assemble) hipLaunchKernelGGL(k_bow_assemble, dim3(nframes, 1, 1), dim3(BA_T, 1, 1), (size_t)nfeat_max * 20 + 64, s, P);
+    if (assemble) hipLaunchKernelGGL(k_bow_assemble, dim3(nframes, 1, 1), dim3(BA_T, 1, 1), (size_t)nfeat_max * 12 + (size_t)ba_pow2(nfeat_max) * 8 + 64, s, P);
     BOWCHK(hipGetLastError());
     w->last_frames = nframes;
     return ORBHIP_OK;

@@ -91,7 +91,10 @@ typedef int nn_v4i __attribute__((vector_size(16)));
 typedef int nn_v16i __attribute__((vector_size(64)));
 #define NNM_QT 2                        // query tiles (of 32) per wavefront (3: 9.7 ms against 7.9 - a sixth workgroup column of padding; 4: spills)
 #define NNM_QG (4 * NNM_QT * 32)        // queries per workgroup
-#define ORBHIP_NN_DEFAULT 1             // form of the matrix-core scan orbhip_launch_hamming_nn takes (1 = i8, 2..4 = FP4 with that many query tiles per wave)
+#define ORBHIP_NN_DEFAULT 1             // form of the matrix-core scan orbhip_launch_hamming_nn takes (1 = i8, 2 = FP4 in the shape below)
+#define ORBHIP_NN_FP4_QT 4
+#define ORBHIP_NN_FP4_OCC 2
+#define ORBHIP_NN_FP4_LCH 15
 __global__ __launch_bounds__(256, 2) void k_hamming_nn_mfma(const unsigned* q, int nq, const unsigned* db, long long ndb, long long base, NNPart* parts, int nchunks)
 {
     __shared__ unsigned long long s_tab[256];                          // byte -> its 8 bits as +-1 bytes
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void k_hamming_nn_mfma(const unsigned* q, i
 // lets a wave keep QT = 3 or 4 query tiles (the i8 form spills at 4) and amortise the tile's expansion and operand reads over more queries.
 typedef int nn_v8i __attribute__((vector_size(32)));
 typedef float nn_v16f __attribute__((vector_size(64)));
-template <int QT> __global__ __launch_bounds__(256, 2) void k_hamming_nn_fp4(const unsigned* q, int nq, const unsigned* db, long long ndb, long long base, NNPart* parts, int nchunks)
+template <int QT, int OCC, int LCH> __global__ __launch_bounds__(256, OCC) void k_hamming_nn_fp4(const unsigned* q, int nq, const unsigned* db, long long ndb, long long base, NNPart* parts, int nchunks)
 {
     __shared__ unsigned s_tab[256];                                    // byte -> its 8 bits as FP4 nibbles (bit k -> nibble k): set = +1 (0x2), clear = -1 (0xA)
     __shared__ __attribute__((aligned(16))) unsigned s_a[2][8 * 32 * 4];    // expanded DB tile: [dword d of the row = 2 kb + h][row i] x 16 bytes, double-buffered
@@ -238,11 +241,12 @@ template <int QT> __global__ __launch_bounds__(256, 2) void k_hamming_nn_fp4(con
             B[t][kb] = nn_v8i{(int)(s_tab[w & 0xff] ^ 0x88888888u), (int)(s_tab[(w >> 8) & 0xff] ^ 0x88888888u), (int)(s_tab[(w >> 16) & 0xff] ^ 0x88888888u), (int)(s_tab[w >> 24] ^ 0x88888888u), 0, 0, 0, 0};
         }
     }
-    unsigned kbest[QT], ksec[QT];
+    unsigned kbest[QT], ksec[QT], thr[QT];                            // thr: bits of (float)((distance of the running second best + 1) << 7): a tile key below it may still matter
 #pragma unroll
-    for (int t = 0; t < QT; t++) { kbest[t] = 0xffffffffu; ksec[t] = 0xffffffffu; }
-    const long long row0 = (long long)chunk * NN_CHUNK;
-    const int nrows = (int)min((long long)NN_CHUNK, ndb - row0);
+    for (int t = 0; t < QT; t++) { kbest[t] = 0xffffffffu; ksec[t] = 0xffffffffu; thr[t] = 0x7f7fffffu; }
+    constexpr int CH = 1 << LCH;                                      // DB rows per workgroup; chunk keys are distance << LCH | row-in-chunk
+    const long long row0 = (long long)chunk * CH;
+    const int nrows = (int)min((long long)CH, ndb - row0);
     const int ntiles = (nrows + 31) >> 5;
     const int sr = tid & 31, sd = tid >> 5;                            // staging role: row sr of the tile, dword sd of that row
     auto stage = [&](int tile, int buf) {
@@ -267,6 +271,10 @@ template <int QT> __global__ __launch_bounds__(256, 2) void k_hamming_nn_fp4(con
                 acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B[t][kb], kb == 0 ? cinit : acc[t], 4, 4, 0, 127, 0, 133);
         }
     };
+    // The selection of one tile.  Most tiles hold nothing a query still cares about: once a lane's running second best is small, a tile whose smallest key is
+    // not below it changes nothing.  So the tile's minimum is taken first (eight v_min3 on the raw accumulators) and compared with the lane's threshold; only
+    // if SOME lane of the wave may still improve does the wave run the top-two tournament, the conversion of the two winners and the merge (the skip is a
+    // wave-uniform branch).  With 2^15 rows per workgroup about two tiles in three are skipped (the running second best of a chunk starts from nothing).
     auto select = [&](int tile, const nn_v16f (&acc)[QT], auto ragged) {
         const unsigned tbase = (unsigned)tile * 32u;
 #pragma unroll
@@ -277,14 +285,20 @@ template <int QT> __global__ __launch_bounds__(256, 2) void k_hamming_nn_fp4(con
                 x[reg] = __float_as_uint(acc[t][reg]);                                                       // (float)(distance << 7 | row-in-tile): positive, ordered like its bits
                 if (decltype(ragged)::value && tile * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h >= nrows) x[reg] = __float_as_uint((float)((511u << 7) + (unsigned)((reg & 3) + 8 * (reg >> 2) + 4 * h)));
             }
+            if (!decltype(ragged)::value) {
+                const unsigned m0 = min(min(x[0], x[1]), x[2]), m1 = min(min(x[3], x[4]), x[5]), m2 = min(min(x[6], x[7]), x[8]), m3 = min(min(x[9], x[10]), x[11]), m4 = min(min(x[12], x[13]), x[14]);
+                const unsigned mn = min(min(min(m0, m1), m2), min(min(m3, m4), x[15]));
+                if (__ballot(mn < thr[t]) == 0) continue;
+            }
             unsigned b, s2;
             top2_of3(x[0], x[1], x[2], b, s2);
 #pragma unroll
             for (int g = 1; g < 5; g++) { unsigned lo, mid; top2_of3(x[3 * g], x[3 * g + 1], x[3 * g + 2], lo, mid); merge2(b, s2, lo, mid); }
             merge2(b, s2, x[15], 0x7f7fffffu);                                                              // (the largest finite float's bits: loses to every key)
             const unsigned bi = (unsigned)__uint_as_float(b), si = (unsigned)__uint_as_float(s2);           // the two winners back to integers: d << 7 | r
-            const unsigned kb1 = (bi << 6) - 63u * (bi & 127u) + tbase, ks1 = (si << 6) - 63u * (si & 127u) + tbase;
+            const unsigned kb1 = ((bi >> 7) << LCH) + (bi & 127u) + tbase, ks1 = ((si >> 7) << LCH) + (si & 127u) + tbase;      // chunk keys d << LCH | (tile * 32 + r)
             merge2(kbest[t], ksec[t], kb1, ks1);
+            thr[t] = __float_as_uint((float)(((ksec[t] >> LCH) + 1u) << 7));                                // (a never-set second best gives a threshold above every real key)
         }
     };
     stage(0, 0);
@@ -302,9 +316,9 @@ template <int QT> __global__ __launch_bounds__(256, 2) void k_hamming_nn_fp4(con
         const unsigned b = min(kbest[t], ob), s2 = min(min(ksec[t], os), max(kbest[t], ob));
         if (h == 0 && qidx[t] < nq) {
             NNPart p;
-            p.best = (b >> 13) > 256u ? IMAX : (int)(b >> 13);
-            p.second = (s2 >> 13) > 256u ? IMAX : (int)(s2 >> 13);
-            p.idx = (b >> 13) > 256u ? -1 : row0 + (long long)(b & 0x1fffu) + base;
+            p.best = (b >> LCH) > 256u ? IMAX : (int)(b >> LCH);
+            p.second = (s2 >> LCH) > 256u ? IMAX : (int)(s2 >> LCH);
+            p.idx = (b >> LCH) > 256u ? -1 : row0 + (long long)(b & (unsigned)(CH - 1)) + base;
             parts[(long long)qidx[t] * nchunks + chunk] = p;
         }
     }
@@ -341,16 +355,29 @@ bool orbhip_launch_hamming_nn(const uint8_t* d_q, int nq, const uint8_t* d_db, l
     NNPart* parts = (NNPart*)orbhip_nn_workspace(sizeof(NNPart) * (size_t)nq * nchunks, s);
     if (!parts) return false;                                    // the caller reports it: results would be left unwritten
     // the matrix-core scan from a few chunks on (below that a call is latency, not throughput); ORBHIP_NN=valu (measurement only) keeps the popcount kernel
-    // ORBHIP_NN = valu | i8 | fp4 | fp4x2 | fp4x3 | fp4x4 (measurement only): the popcount kernel, the i8 matrix-core scan, the FP4 one with 2 / 3 / 4 query tiles per wave
-    const int form = [] { const char* e = getenv("ORBHIP_NN");      // (read per call: a scan is at least a hundred microseconds; tests switch forms inside one process)
-        if (!e) return ORBHIP_NN_DEFAULT; if (!strcmp(e, "valu")) return 0; if (!strcmp(e, "i8")) return 1;
-                                 if (!strcmp(e, "fp4x2")) return 2; if (!strcmp(e, "fp4x3") || !strcmp(e, "fp4")) return 3; if (!strcmp(e, "fp4x4")) return 4; return ORBHIP_NN_DEFAULT; }();
+    // ORBHIP_NN = valu | i8 | fp4[:<query tiles 2-4>[:<workgroups per CU 2-3>[:<log2 rows per workgroup 13|15|16>]]] (measurement only): the popcount kernel, the i8
+    // matrix-core scan, the FP4 one in the given shape
+    int form = ORBHIP_NN_DEFAULT, qt = ORBHIP_NN_FP4_QT, occ = ORBHIP_NN_FP4_OCC, lch = ORBHIP_NN_FP4_LCH;
+    if (const char* e = getenv("ORBHIP_NN")) {      // (read per call: a scan is at least a hundred microseconds; tests switch forms inside one process)
+        if (!strcmp(e, "valu")) form = 0; else if (!strcmp(e, "i8")) form = 1;
+        else if (!strncmp(e, "fp4", 3)) { form = 2; int a = 0, b2 = 0, c = 0; const int k = sscanf(e + 3, ":%d:%d:%d", &a, &b2, &c); if (k >= 1) qt = a; if (k >= 2) occ = b2; if (k >= 3) lch = c; }
+    }
     if (form >= 2 && ndb >= 4 * NN_CHUNK) {
-        const int qg = 4 * form * 32;
-        const dim3 grid((nq + qg - 1) / qg, nchunks, 1);
-        if (form == 2) hipLaunchKernelGGL(k_hamming_nn_fp4<2>, grid, dim3(256, 1, 1), 0, s, (const unsigned*)d_q, nq, (const unsigned*)d_db, ndb, base, parts, nchunks);
-        else if (form == 3) hipLaunchKernelGGL(k_hamming_nn_fp4<3>, grid, dim3(256, 1, 1), 0, s, (const unsigned*)d_q, nq, (const unsigned*)d_db, ndb, base, parts, nchunks);
-        else hipLaunchKernelGGL(k_hamming_nn_fp4<4>, grid, dim3(256, 1, 1), 0, s, (const unsigned*)d_q, nq, (const unsigned*)d_db, ndb, base, parts, nchunks);
+        const int qg = 4 * qt * 32, nch = (int)((ndb + ((long long)1 << lch) - 1) >> lch);      // (<= nchunks: the partials fit the workspace)
+        const dim3 grid((nq + qg - 1) / qg, nch, 1);
+        bool ok = true;
+#define NN_FP4(QT, OCC, LCH) hipLaunchKernelGGL((k_hamming_nn_fp4<QT, OCC, LCH>), grid, dim3(256, 1, 1), 0, s, (const unsigned*)d_q, nq, (const unsigned*)d_db, ndb, base, parts, nch)
+        const int shape = qt * 1000 + occ * 100 + lch;
+        switch (shape) {
+        case 2213: NN_FP4(2, 2, 13); break; case 3213: NN_FP4(3, 2, 13); break; case 4213: NN_FP4(4, 2, 13); break; case 2313: NN_FP4(2, 3, 13); break;
+        case 2215: NN_FP4(2, 2, 15); break; case 4215: NN_FP4(4, 2, 15); break; case 2315: NN_FP4(2, 3, 15); break; case 3215: NN_FP4(3, 2, 15); break;
+        case 4216: NN_FP4(4, 2, 16); break; case 2316: NN_FP4(2, 3, 16); break;
+        default: ok = false;
+        }
+#undef NN_FP4
+        if (!ok) return false;
+        hipLaunchKernelGGL(k_hamming_merge, dim3((nq + 3) / 4, 1, 1), dim3(256, 1, 1), 0, s, (const NNPart*)parts, nq, nch, d_best_idx, d_best_dist, d_second);
+        return true;
     } else if (form >= 1 && ndb >= 4 * NN_CHUNK) {
         hipLaunchKernelGGL(k_hamming_nn_mfma, dim3((nq + NNM_QG - 1) / NNM_QG, nchunks, 1), dim3(256, 1, 1), 0, s, (const unsigned*)d_q, nq,
                            (const unsigned*)d_db, ndb, base, parts, nchunks);

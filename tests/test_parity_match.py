@@ -119,18 +119,18 @@ def test_brute_force_nn(backend, oracle):
     assert all(np.array_equal(a, b) for a, b in zip(merged, want))
 
 
-@pytest.mark.parametrize("form", ["default", "i8", "fp4x2", "fp4x3", "fp4x4", "valu"])
+@pytest.mark.parametrize("form", ["default", "i8", "fp4:2:2:13", "fp4:3:2:13", "fp4:4:2:15", "fp4:2:3:15", "fp4:4:2:16", "valu"])
 def test_brute_force_nn_matrix_core_scan(backend, oracle, monkeypatch, form):
     """Databases from four chunks (32 K rows) on are scanned on the matrix cores - k_hamming_nn_mfma (<+-1, +-1> = 256 - 2 Hamming as i8 products) or
-    k_hamming_nn_fp4 (the same as FP4 products on v_mfma_scale_f32_32x32x64_f8f6f4, 2 / 3 / 4 query tiles per wave); ORBHIP_NN picks the form:
+    k_hamming_nn_fp4 (the same as FP4 products on v_mfma_scale_f32_32x32x64_f8f6f4; query tiles per wave : workgroups per CU : log2 rows per workgroup); ORBHIP_NN picks the form:
     ragged last tile and chunk, a query count that fills neither a tile nor a workgroup, planted exact matches, duplicated rows
     (lowest index wins, second = best), an index base; every form against the oracle (the popcount kernel included)."""
     if form != "default":
         monkeypatch.setenv("ORBHIP_NN", form)
-    if backend.endswith("_emu.so") and form in ("fp4x2", "fp4x4"):
+    if backend.endswith("_emu.so") and form.startswith("fp4") and form not in ("fp4:3:2:13", "fp4:4:2:15"):
         pytest.skip("the emulation's FP4 matrix product is slow: one FP4 form is enough here, all run on the GPU")
     rng = np.random.default_rng(5)
-    n = 4 * 8192 + 1000 + 13
+    n = 4 * 8192 + 1000 + 13 if backend.endswith("_emu.so") else 3 * 65536 + 8192 + 1000 + 13      # (several workgroups of the largest chunk on the GPU)
     db = rng.integers(0, 256, (n, 32), dtype=np.uint8)
     q = rng.integers(0, 256, (70 if backend.endswith("_emu.so") else 530, 32), dtype=np.uint8)      # (the GPU run fills more than one workgroup of every form)
     q[:20] = db[rng.integers(0, n, 20)]                       # exact matches somewhere in the database
