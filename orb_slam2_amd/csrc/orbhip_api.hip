@@ -93,7 +93,7 @@ struct orbhip_ctx {
     bool want_fgrid = false, want_rrows = false, fgrid_valid = false, rrows_valid = false; int fgrid_cur = -1, rrows_cur = -1;
     int* d_fgrid_start = nullptr; int* d_fgrid_items = nullptr; float2* d_fgrid_xy = nullptr; int* d_rrow_start = nullptr; int* d_rrow_items = nullptr; int rrow_cap = 0;
     hipEvent_t ev_epilogue = nullptr;
-    bool pair_mode = false; float* h_st = nullptr;           // the last call was orbhip_extract_stereo: slot 0 = the frame (left image), slot 1 = its right image; pinned mirror of [mvuRight | mvDepth]
+    bool pair_mode = false; float* h_st = nullptr; hipEvent_t ev_stereo = nullptr;           // the last call was orbhip_extract_stereo: slot 0 = the frame (left image), slot 1 = its right image; pinned mirror of [mvuRight | mvDepth]
     std::vector<int> last_n; bool last_n_valid = false;      // key point counts of the last call as already delivered to the host (the call's results were waited for)
     // host-buffer API staging: one contiguous device input buffer + pinned host mirrors (single bulk copies instead of per-frame pageable copies)
     bool serial = false;      // ORBHIP_SERIAL=1 (profiling aid): every kernel on the main stream, nothing overlaps - per-kernel times are standalone times
@@ -367,7 +367,7 @@ extern "C" void orbhip_destroy(orbhip_ctx* c)
                     c->d_qt_val, c->d_qt_code, c->d_qt_node, c->d_lvl_kp, c->d_lvl_n[0], c->d_lvl_n[1], c->d_lvl_n[2], c->d_out_block[0], c->d_out_block[1], c->d_out_block[2], c->d_grid_start, c->d_grid_items, c->d_grid_xy, c->d_cand, c->d_top, c->d_ncand,
                     c->d_prev, c->d_m12, c->d_nm};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    { void* ep[] = {c->d_fgrid_start, c->d_fgrid_items, c->d_fgrid_xy, c->d_rrow_start, c->d_rrow_items}; for (void* q : ep) if (q) (void)hipFree(q); if (c->ev_epilogue) (void)hipEventDestroy(c->ev_epilogue); if (c->h_st) (void)hipHostFree(c->h_st); }
+    { void* ep[] = {c->d_fgrid_start, c->d_fgrid_items, c->d_fgrid_xy, c->d_rrow_start, c->d_rrow_items}; for (void* q : ep) if (q) (void)hipFree(q); if (c->ev_epilogue) (void)hipEventDestroy(c->ev_epilogue); if (c->h_st) (void)hipHostFree(c->h_st); if (c->ev_stereo) (void)hipEventDestroy(c->ev_stereo); }
     { void* st[] = {c->d_st_rowstart, c->d_st_rowitems, c->d_st_u /* | d_st_depth */, c->d_st_sad}; for (void* q : st) if (q) (void)hipFree(q); }
     for (auto& hs : c->sets) {
         for (int k = 0; k < ORBHIP_MAX_CHUNKS; k++) { if (hs.ev_h2d[k]) (void)hipEventDestroy(hs.ev_h2d[k]); if (hs.ev_k[k]) (void)hipEventDestroy(hs.ev_k[k]); if (hs.ev_d2h[k]) (void)hipEventDestroy(hs.ev_d2h[k]); }
@@ -964,7 +964,7 @@ public:
     // fn(0) .. fn(n-1), spread over the helpers and the caller; returns when all are done
     void run(int n, size_t bytes_each, const std::function<void(int)>& fn) {
         if (n <= 0) return;
-        if (nthreads <= 1 || n == 1 || (size_t)n * bytes_each < (size_t)(1 << 20)) { for (int i = 0; i < n; i++) fn(i); return; }
+        if (nthreads <= 1 || n == 1 || (size_t)n * bytes_each < (size_t)(1 << 19)) { for (int i = 0; i < n; i++) fn(i); return; }      // (a stereo pair's two 0.47 MB images are worth a second thread: ~40 us each from cold memory, a helper wakes in ~10)
         auto j = std::make_shared<CopyJob>(); j->n = n; j->fn = fn;
         { std::lock_guard<std::mutex> lk(m); q.push_back(j); }
         cv.notify_all();
@@ -1845,7 +1845,7 @@ extern "C" orbhip_status orbhip_extract_stereo(orbhip_ctx* c, const uint8_t* img
         if (e == hipSuccess) e = dalloc(&c->d_st_sad, B * oc);
         if (e != hipSuccess) return fail(ORBHIP_ERR_HIP, "stereo workspace allocation failed: %s", hipGetErrorString(e));
     }
-    if (!c->h_st) HIPCHK(hipHostMalloc((void**)&c->h_st, 2 * oc * sizeof(float), hipHostMallocDefault));
+    if (!c->h_st) HIPCHK(hipHostMalloc((void**)&c->h_st, (B + 1) * oc * sizeof(float), hipHostMallocDefault));
     const uint8_t* imgs[2] = {img_left, img_right};
     int ticket = -1;
     orbhip_status st = submit_impl(c, 2, imgs, stride, nullptr, nullptr, 0, &ticket); if (st != ORBHIP_OK) return st;
@@ -1859,18 +1859,20 @@ extern "C" orbhip_status orbhip_extract_stereo(orbhip_ctx* c, const uint8_t* img
     T.mbf = mbf; T.maxD = mbf / mb;
     orbhip_launch_stereo(T, 1, c->out_cap, c->stream, false);
     hipError_t e = hipGetLastError();
-    // [mvuRight | mvDepth] of slot 0: two runs of out_cap floats, B * out_cap apart on the device, back to back in the mirror
-    if (e == hipSuccess) e = orbhip_copy_async(c->h_st, c->d_st_u, oc * sizeof(float), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = orbhip_copy_async(c->h_st + oc, c->d_st_depth, oc * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    // [mvuRight of slot 0 .. mvDepth of slot 0]: ONE copy of (B + 1) * out_cap floats (slot 1's unused mvuRight rides along), then an event: the host waits for
+    // that, not for the stream - the frame's feature grid (an epilogue of the searches to come, 20 us) is queued behind it and is nobody's business yet
+    if (!c->ev_stereo) { if (hipEventCreateWithFlags(&c->ev_stereo, hipEventDisableTiming) != hipSuccess) e = hipErrorOutOfMemory; }
+    if (e == hipSuccess) e = orbhip_copy_async(c->h_st, c->d_st_u, (B + 1) * oc * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipEventRecord(c->ev_stereo, c->stream);
     if (e == hipSuccess && c->want_fgrid) { const bool rr = c->want_rrows; c->want_rrows = false; const orbhip_status se = frame_epilogues(c, c->stream); c->want_rrows = rr; if (se != ORBHIP_OK) e = hipErrorInvalidValue; }
     // key points + descriptors of both images (waits for the result block only: the stereo kernels are still running)
     st = collect_flat(c, ticket, kps, desc, cap, n_out);
-    const hipError_t es = hipStreamSynchronize(c->stream);
+    const hipError_t es = e == hipSuccess ? hipEventSynchronize(c->ev_stereo) : hipStreamSynchronize(c->stream);
     if (c->prof) prof_collect(c);
     if (e != hipSuccess || es != hipSuccess) return fail(ORBHIP_ERR_HIP, "extract_stereo: %s", hipGetErrorString(e != hipSuccess ? e : es));
     if (st != ORBHIP_OK && st != ORBHIP_ERR_CAPACITY) return st;
     const int m = std::min(n_out[0], cap);
-    if (m > 0) { memcpy(u_right, c->h_st, (size_t)m * sizeof(float)); memcpy(depth, c->h_st + oc, (size_t)m * sizeof(float)); }
+    if (m > 0) { memcpy(u_right, c->h_st, (size_t)m * sizeof(float)); memcpy(depth, c->h_st + B * oc, (size_t)m * sizeof(float)); }
     return st;
 }
 

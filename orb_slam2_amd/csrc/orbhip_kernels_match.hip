@@ -95,6 +95,7 @@ typedef int nn_v16i __attribute__((vector_size(64)));
 #define ORBHIP_NN_FP4_QT 4
 #define ORBHIP_NN_FP4_OCC 2
 #define ORBHIP_NN_FP4_LCH 15
+#define ORBHIP_NN_FP4_TPB 4
 __global__ __launch_bounds__(256, 2) void k_hamming_nn_mfma(const unsigned* q, int nq, const unsigned* db, long long ndb, long long base, NNPart* parts, int nchunks)
 {
     __shared__ unsigned long long s_tab[256];                          // byte -> its 8 bits as +-1 bytes
@@ -214,10 +215,10 @@ __global__ __launch_bounds__(256, 2) void k_hamming_nn_mfma(const unsigned* q, i
 // lets a wave keep QT = 3 or 4 query tiles (the i8 form spills at 4) and amortise the tile's expansion and operand reads over more queries.
 typedef int nn_v8i __attribute__((vector_size(32)));
 typedef float nn_v16f __attribute__((vector_size(64)));
-template <int QT, int OCC, int LCH> __global__ __launch_bounds__(256, OCC) void k_hamming_nn_fp4(const unsigned* q, int nq, const unsigned* db, long long ndb, long long base, NNPart* parts, int nchunks)
+template <int QT, int OCC, int LCH, int TPB> __global__ __launch_bounds__(256, OCC) void k_hamming_nn_fp4(const unsigned* q, int nq, const unsigned* db, long long ndb, long long base, NNPart* parts, int nchunks)
 {
     __shared__ unsigned s_tab[256];                                    // byte -> its 8 bits as FP4 nibbles (bit k -> nibble k): set = +1 (0x2), clear = -1 (0xA)
-    __shared__ __attribute__((aligned(16))) unsigned s_a[2][8 * 32 * 4];    // expanded DB tile: [dword d of the row = 2 kb + h][row i] x 16 bytes, double-buffered
+    __shared__ __attribute__((aligned(16))) unsigned s_a[2][TPB * 8 * 32 * 4];   // TPB expanded DB tiles per workgroup barrier: [tile u][dword d of the row = 2 kb + h][row i] x 16 bytes, double-buffered
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), chunk = blockIdx.y;
     {
         unsigned e = 0;
@@ -249,22 +250,28 @@ template <int QT, int OCC, int LCH> __global__ __launch_bounds__(256, OCC) void 
     const int nrows = (int)min((long long)CH, ndb - row0);
     const int ntiles = (nrows + 31) >> 5;
     const int sr = tid & 31, sd = tid >> 5;                            // staging role: row sr of the tile, dword sd of that row
-    auto stage = [&](int tile, int buf) {
-        const int r = tile * 32 + sr;
-        const unsigned w = r < nrows ? db[(row0 + r) * 8 + sd] : 0u;
-        *reinterpret_cast<uint4*>(s_a[buf] + (sd * 32 + sr) * 4) = uint4{s_tab[w & 0xff], s_tab[(w >> 8) & 0xff], s_tab[(w >> 16) & 0xff], s_tab[w >> 24]};
+    // the next TPB tiles: loads issued first (they fly while the current tiles are worked on), expanded into LDS just before the barrier
+    unsigned wnext[TPB];
+    auto fetch = [&](int sup) {
+#pragma unroll
+        for (int u = 0; u < TPB; u++) { const int r = (sup * TPB + u) * 32 + sr; wnext[u] = r < nrows ? db[(row0 + r) * 8 + sd] : 0u; }
+    };
+    auto expand = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < TPB; u++) {
+            const unsigned w = wnext[u];
+            *reinterpret_cast<uint4*>(s_a[buf] + u * 1024 + (sd * 32 + sr) * 4) = uint4{s_tab[w & 0xff], s_tab[(w >> 8) & 0xff], s_tab[(w >> 16) & 0xff], s_tab[w >> 24]};
+        }
     };
     nn_v16f cinit;
 #pragma unroll
     for (int reg = 0; reg < 16; reg++) cinit[reg] = (float)(256 * 64 + (reg & 3) + 8 * (reg >> 2) + 4 * h);
     auto top2_of3 = [](unsigned a, unsigned b, unsigned c, unsigned& lo, unsigned& mid) { lo = min(min(a, b), c); mid = max(min(a, b), min(max(a, b), c)); };
     auto merge2 = [](unsigned& b, unsigned& s2, unsigned ob, unsigned os) { s2 = min(min(s2, os), max(b, ob)); b = min(b, ob); };
-    auto products = [&](int tile, nn_v16f (&acc)[QT]) {
-        const int buf = tile & 1;
-        if (tile + 1 < ntiles) stage(tile + 1, buf ^ 1);
+    auto products = [&](const unsigned* ta, nn_v16f (&acc)[QT]) {
 #pragma unroll
         for (int kb = 0; kb < 4; kb++) {
-            const uint4 a4 = *reinterpret_cast<const uint4*>(s_a[buf] + ((2 * kb + h) * 32 + j) * 4);         // lane (i = j, h): row i of the tile
+            const uint4 a4 = *reinterpret_cast<const uint4*>(ta + ((2 * kb + h) * 32 + j) * 4);               // lane (i = j, h): row i of the tile
             const nn_v8i A = nn_v8i{(int)a4.x, (int)a4.y, (int)a4.z, (int)a4.w, 0, 0, 0, 0};
 #pragma unroll
             for (int t = 0; t < QT; t++)      // (A, B, C, format of A = FP4, format of B = FP4, scale A: byte 0 of 127 = 2^0, scale B: byte 0 of 133 = 2^6)
@@ -301,13 +308,21 @@ template <int QT, int OCC, int LCH> __global__ __launch_bounds__(256, OCC) void 
             thr[t] = __float_as_uint((float)(((ksec[t] >> LCH) + 1u) << 7));                                // (a never-set second best gives a threshold above every real key)
         }
     };
-    stage(0, 0);
+    fetch(0); expand(0);
     __syncthreads();
-    const int nfull = nrows >> 5;
+    const int nfull = nrows >> 5, nsuper = (ntiles + TPB - 1) / TPB;
     nn_v16f acc[QT];
-    for (int tile = 0; tile < ntiles; tile++) {
-        products(tile, acc);
-        if (tile < nfull) select(tile, acc, std::false_type{}); else select(tile, acc, std::true_type{});
+    for (int sup = 0; sup < nsuper; sup++) {
+        const int buf = sup & 1;
+        if (sup + 1 < nsuper) fetch(sup + 1);
+#pragma unroll
+        for (int u = 0; u < TPB; u++) {
+            const int tile = sup * TPB + u;
+            if (tile >= ntiles) break;
+            products(s_a[buf] + u * 1024, acc);
+            if (tile < nfull) select(tile, acc, std::false_type{}); else select(tile, acc, std::true_type{});
+        }
+        if (sup + 1 < nsuper) expand(buf ^ 1);
         __syncthreads();
     }
 #pragma unroll
@@ -357,21 +372,22 @@ bool orbhip_launch_hamming_nn(const uint8_t* d_q, int nq, const uint8_t* d_db, l
     // the matrix-core scan from a few chunks on (below that a call is latency, not throughput); ORBHIP_NN=valu (measurement only) keeps the popcount kernel
     // ORBHIP_NN = valu | i8 | fp4[:<query tiles 2-4>[:<workgroups per CU 2-3>[:<log2 rows per workgroup 13|15|16>]]] (measurement only): the popcount kernel, the i8
     // matrix-core scan, the FP4 one in the given shape
-    int form = ORBHIP_NN_DEFAULT, qt = ORBHIP_NN_FP4_QT, occ = ORBHIP_NN_FP4_OCC, lch = ORBHIP_NN_FP4_LCH;
+    int form = ORBHIP_NN_DEFAULT, qt = ORBHIP_NN_FP4_QT, occ = ORBHIP_NN_FP4_OCC, lch = ORBHIP_NN_FP4_LCH, tpb = ORBHIP_NN_FP4_TPB;
     if (const char* e = getenv("ORBHIP_NN")) {      // (read per call: a scan is at least a hundred microseconds; tests switch forms inside one process)
         if (!strcmp(e, "valu")) form = 0; else if (!strcmp(e, "i8")) form = 1;
-        else if (!strncmp(e, "fp4", 3)) { form = 2; int a = 0, b2 = 0, c = 0; const int k = sscanf(e + 3, ":%d:%d:%d", &a, &b2, &c); if (k >= 1) qt = a; if (k >= 2) occ = b2; if (k >= 3) lch = c; }
+        else if (!strncmp(e, "fp4", 3)) { form = 2; int a = 0, b2 = 0, c = 0, d = 0; const int k = sscanf(e + 3, ":%d:%d:%d:%d", &a, &b2, &c, &d); if (k >= 1) qt = a; if (k >= 2) occ = b2; if (k >= 3) lch = c; if (k >= 4) tpb = d; }
     }
     if (form >= 2 && ndb >= 4 * NN_CHUNK) {
         const int qg = 4 * qt * 32, nch = (int)((ndb + ((long long)1 << lch) - 1) >> lch);      // (<= nchunks: the partials fit the workspace)
         const dim3 grid((nq + qg - 1) / qg, nch, 1);
         bool ok = true;
-#define NN_FP4(QT, OCC, LCH) hipLaunchKernelGGL((k_hamming_nn_fp4<QT, OCC, LCH>), grid, dim3(256, 1, 1), 0, s, (const unsigned*)d_q, nq, (const unsigned*)d_db, ndb, base, parts, nch)
-        const int shape = qt * 1000 + occ * 100 + lch;
+#define NN_FP4(QT, OCC, LCH, TPB) hipLaunchKernelGGL((k_hamming_nn_fp4<QT, OCC, LCH, TPB>), grid, dim3(256, 1, 1), 0, s, (const unsigned*)d_q, nq, (const unsigned*)d_db, ndb, base, parts, nch)
+        const int shape = qt * 10000 + occ * 1000 + lch * 10 + tpb;
         switch (shape) {
-        case 2213: NN_FP4(2, 2, 13); break; case 3213: NN_FP4(3, 2, 13); break; case 4213: NN_FP4(4, 2, 13); break; case 2313: NN_FP4(2, 3, 13); break;
-        case 2215: NN_FP4(2, 2, 15); break; case 4215: NN_FP4(4, 2, 15); break; case 2315: NN_FP4(2, 3, 15); break; case 3215: NN_FP4(3, 2, 15); break;
-        case 4216: NN_FP4(4, 2, 16); break; case 2316: NN_FP4(2, 3, 16); break;
+        case 22131: NN_FP4(2, 2, 13, 1); break; case 32131: NN_FP4(3, 2, 13, 1); break; case 42131: NN_FP4(4, 2, 13, 1); break;
+        case 42151: NN_FP4(4, 2, 15, 1); break; case 42152: NN_FP4(4, 2, 15, 2); break; case 42154: NN_FP4(4, 2, 15, 4); break; case 42158: NN_FP4(4, 2, 15, 8); break;
+        case 23154: NN_FP4(2, 3, 15, 4); break; case 23151: NN_FP4(2, 3, 15, 1); break; case 22154: NN_FP4(2, 2, 15, 4); break; case 42134: NN_FP4(4, 2, 13, 4); break;
+        case 42164: NN_FP4(4, 2, 16, 4); break; case 32154: NN_FP4(3, 2, 15, 4); break;
         default: ok = false;
         }
 #undef NN_FP4

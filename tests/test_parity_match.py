@@ -119,7 +119,7 @@ def test_brute_force_nn(backend, oracle):
     assert all(np.array_equal(a, b) for a, b in zip(merged, want))
 
 
-@pytest.mark.parametrize("form", ["default", "i8", "fp4:2:2:13", "fp4:3:2:13", "fp4:4:2:15", "fp4:2:3:15", "fp4:4:2:16", "valu"])
+@pytest.mark.parametrize("form", ["default", "i8", "fp4:2:2:13:1", "fp4:3:2:13:1", "fp4:4:2:15:4", "fp4:2:3:15:4", "fp4:4:2:16:4", "fp4:4:2:15:8", "valu"])
 def test_brute_force_nn_matrix_core_scan(backend, oracle, monkeypatch, form):
     """Databases from four chunks (32 K rows) on are scanned on the matrix cores - k_hamming_nn_mfma (<+-1, +-1> = 256 - 2 Hamming as i8 products) or
     k_hamming_nn_fp4 (the same as FP4 products on v_mfma_scale_f32_32x32x64_f8f6f4; query tiles per wave : workgroups per CU : log2 rows per workgroup); ORBHIP_NN picks the form:
@@ -127,7 +127,7 @@ def test_brute_force_nn_matrix_core_scan(backend, oracle, monkeypatch, form):
     (lowest index wins, second = best), an index base; every form against the oracle (the popcount kernel included)."""
     if form != "default":
         monkeypatch.setenv("ORBHIP_NN", form)
-    if backend.endswith("_emu.so") and form.startswith("fp4") and form not in ("fp4:3:2:13", "fp4:4:2:15"):
+    if backend.endswith("_emu.so") and form.startswith("fp4") and form not in ("fp4:3:2:13:1", "fp4:4:2:15:4"):
         pytest.skip("the emulation's FP4 matrix product is slow: one FP4 form is enough here, all run on the GPU")
     rng = np.random.default_rng(5)
     n = 4 * 8192 + 1000 + 13 if backend.endswith("_emu.so") else 3 * 65536 + 8192 + 1000 + 13      # (several workgroups of the largest chunk on the GPU)
