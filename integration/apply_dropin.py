@@ -4,6 +4,7 @@
     python integration/apply_dropin.py /path/to/ORB_SLAM2 /path/to/out      # writes the edited tree pieces under out/
     python integration/apply_dropin.py --patch /path/to/ORB_SLAM2 > dropin.patch   # the same edits as a unified diff (patch -p1)
     ... --stereo-one-call        optional: the stereo Frame constructor extracts both images in ONE call on one device context (ORBextractor::ExtractStereo)
+    ... --resident-bow           optional (with this repository's ORBVocabulary class in place, step 3e): Frame::ComputeBoW reads the descriptors in HBM
 
 What it produces (nothing else of the checkout changes; Tracking.cc, LocalMapping.cc, LoopClosing.cc, KeyFrame*.cc compile as they are):
   out/include/ORBextractor.h, out/src/ORBextractor.cc     this repository's drop-in class (include/ORBextractor.h, orb_slam2_amd/cpp/)
@@ -203,9 +204,9 @@ def patch_projection_member(src, sig, first_stmt, loop_from, loop_until, query, 
 FUSE_SIG = r"int\s+ORBmatcher::Fuse\s*\(\s*KeyFrame\s*\*\s*pKF\s*,\s*const\s+vector<MapPoint\s*\*>\s*&\s*vpMapPoints\s*,\s*const\s+float\s+th\s*\)"
 # The member becomes three pieces (all from the reference's own text):
 #   orbhip_fuse_collect   its projection code, unchanged, up to the window search: one flat query per point that passed the filters
-#   orbhip_fuse_apply     its surgery block, unchanged, in the original order - after re-checking, per point, what the surgery of EARLIER points or
-#                         targets may have changed since the query was collected (Replace() makes a point bad, can put it into this key frame and
-#                         recomputes the survivor's descriptor, MapPoint.cc:177-215): such a point is skipped / searched again by itself
+#   orbhip_fuse_apply     its surgery block, unchanged, in the original order - after re-checking what the surgery of EARLIER targets may have changed since
+#                         the queries were collected (Replace() makes a point bad, can put it into this key frame and recomputes the survivor's
+#                         descriptor, MapPoint.cc:177-215): such points are skipped / searched again, together, before the target's surgery
 #   Fuse = collect + one library call + apply;  FuseBatch (include/ORBmatcherBatch.h) = collect for every target + ONE library call + apply per target
 FUSE_DECLS = """
     std::vector<orbhip_best_query> orbhip_bq; std::vector<unsigned char> orbhip_qd; std::vector<MapPoint*> orbhip_owner;
@@ -227,18 +228,33 @@ static int orbhip_fuse_apply(OrbhipFuseJob &job)
     KeyFrame* pKF = job.pKF;
     const int TH_LOW = ORBmatcher::TH_LOW;
     int nFused=0;
+    // Points that absorbed another point since their query was collected (the surgery of an EARLIER target: MapPoint::Replace recomputes the survivor's
+    // descriptor) are searched again, all of them in one call, before this target's surgery starts.  (Inside one target no collected point's descriptor
+    // changes: a survivor is either a point already handled or a point of this key frame, which the filter below skips.)
+    {
+        std::vector<size_t> again; std::vector<orbhip_best_query> bq; std::vector<unsigned char> qd;
+        for(size_t k=0; k<job.owner.size(); k++)
+        {
+            MapPoint* pMP = job.owner[k];
+            if(pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
+            const cv::Mat dNow = pMP->GetDescriptor();
+            if(!memcmp(dNow.ptr<unsigned char>(), &job.qd[32*k], 32)) continue;
+            again.push_back(k); bq.push_back(job.bq[k]); qd.insert(qd.end(), dNow.ptr<unsigned char>(), dNow.ptr<unsigned char>()+32);
+        }
+        if(!again.empty() && pKF->N>0)
+        {
+            std::vector<int> bi(again.size(), -1), bd(again.size(), 256);
+            const orbhip_bounds bounds = orbhip_kf_bounds(pKF);
+            orbhip_check(orbhip_search_best_in_window_bounds(orbhip_default_device(), (const orbhip_keypoint*)&pKF->mvKeysUn[0], pKF->mDescriptors.ptr<unsigned char>(), &pKF->mvuRight[0], pKF->N, &bounds,
+                                                   &pKF->mvInvLevelSigma2[0], (int)pKF->mvInvLevelSigma2.size(), &bq[0], &qd[0], (int)bq.size(), 1, &bi[0], &bd[0]));
+            for(size_t a=0; a<again.size(); a++) { job.bi[again[a]] = bi[a]; job.bd[again[a]] = bd[a]; }
+        }
+    }
     for(size_t orbhip_k=0; orbhip_k<job.owner.size(); orbhip_k++)
     {
         MapPoint* pMP = job.owner[orbhip_k];
         if(pMP->isBad() || pMP->IsInKeyFrame(pKF))        // (the reference's own filter, as of NOW)
             continue;
-        const cv::Mat dNow = pMP->GetDescriptor();
-        if(memcmp(dNow.ptr<unsigned char>(), &job.qd[32*orbhip_k], 32))
-        {   // the point absorbed another one since its query was collected: its descriptor is a new one - search its window again
-            const orbhip_bounds bounds = orbhip_kf_bounds(pKF);
-            orbhip_check(orbhip_search_best_in_window_bounds(orbhip_default_device(), (const orbhip_keypoint*)&pKF->mvKeysUn[0], pKF->mDescriptors.ptr<unsigned char>(), &pKF->mvuRight[0], pKF->N, &bounds,
-                                                   &pKF->mvInvLevelSigma2[0], (int)pKF->mvInvLevelSigma2.size(), &job.bq[orbhip_k], dNow.ptr<unsigned char>(), 1, 1, &job.bi[orbhip_k], &job.bd[orbhip_k]));
-        }
         const int bestDist = job.bd[orbhip_k], bestIdx = job.bi[orbhip_k];
         %s
     }
@@ -636,9 +652,29 @@ STEREO_THREADS = (r"thread\s+threadLeft\s*\(\s*&Frame::ExtractORB\s*,\s*this\s*,
 STEREO_ONE_CALL = "mpORBextractorLeft->ExtractStereo(imLeft, imRight, mvKeys, mDescriptors, mvKeysRight, mDescriptorsRight, mbf, mbf/K.at<float>(0,0));"
 
 
-def patch_frame(src, stereo_one_call=False):
+# INTEGRATION.md §2-3e (optional, --resident-bow; needs this repository's ORBVocabulary class): Frame::ComputeBoW (Frame.cc:395-402) transforms the descriptors
+# where the extraction left them while the frame is still its extractor's last one (TrackReferenceKeyFrame / Relocalization call it right after the
+# constructor); any other frame goes through the reference's own statement
+RESIDENT_BOW_SIG = r"void\s+Frame::ComputeBoW\s*\(\s*\)"
+RESIDENT_BOW_BODY = """{
+    if(mBowVec.empty())
+    {
+        if(mpORBextractorLeft && mpORBextractorLeft->HoldsFrame(mnId, N))
+            mpORBvocabulary->ComputeBoW(*mpORBextractorLeft, mBowVec, mFeatVec, 4);
+        else
+        {
+            vector<cv::Mat> vCurrentDesc = Converter::toDescriptorVector(mDescriptors);
+            mpORBvocabulary->transform(vCurrentDesc,mBowVec,mFeatVec,4);
+        }
+    }
+}"""
+
+
+def patch_frame(src, stereo_one_call=False, resident_bow=False):
     for sig, body in FORWARDS.items():
         src = replace_body(src, sig, body)
+    if resident_bow:
+        src = replace_body(src, RESIDENT_BOW_SIG, RESIDENT_BOW_BODY)
     if stereo_one_call:
         src, n = re.subn(STEREO_THREADS, STEREO_ONE_CALL, src)
         if n != 1:
@@ -680,20 +716,22 @@ def main():
         # the reference's two bodies out of the way with -D and links that file)
         keep = "--keep-map-free" in argv
         one_call = "--stereo-one-call" in argv
-        argv = [a for a in argv[1:] if a not in ("--keep-map-free", "--stereo-one-call")]
-        open(argv[1], "w").write(patch_frame(open(argv[0]).read(), stereo_one_call=one_call))
+        rbow = "--resident-bow" in argv
+        argv = [a for a in argv[1:] if a not in ("--keep-map-free", "--stereo-one-call", "--resident-bow")]
+        open(argv[1], "w").write(patch_frame(open(argv[0]).read(), stereo_one_call=one_call, resident_bow=rbow))
         if len(argv) > 3:
             open(argv[3], "w").write(patch_matcher(open(argv[2]).read(), map_free_members=not keep))
         return
     one_call = "--stereo-one-call" in argv
-    argv = [a for a in argv if a != "--stereo-one-call"]
+    rbow = "--resident-bow" in argv
+    argv = [a for a in argv if a not in ("--stereo-one-call", "--resident-bow")]
     emit_patch = bool(argv) and argv[0] == "--patch"
     if emit_patch:
         argv = argv[1:]
     if len(argv) < (1 if emit_patch else 2):
         raise SystemExit(__doc__)
     ref = argv[0]
-    edited = {"src/Frame.cc": patch_frame(open(os.path.join(ref, "src/Frame.cc")).read(), stereo_one_call=one_call),
+    edited = {"src/Frame.cc": patch_frame(open(os.path.join(ref, "src/Frame.cc")).read(), stereo_one_call=one_call, resident_bow=rbow),
               "src/ORBmatcher.cc": patch_matcher(open(os.path.join(ref, "src/ORBmatcher.cc")).read())}
     copies = {"include/ORBextractor.h": "include/ORBextractor.h", "src/ORBextractor.cc": "orb_slam2_amd/cpp/ORBextractor.cc", "include/orbhip.h": "include/orbhip.h",
               "include/ORBmatcherBatch.h": "include/ORBmatcherBatch.h"}

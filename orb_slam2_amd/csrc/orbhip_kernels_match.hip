@@ -91,7 +91,7 @@ typedef int nn_v4i __attribute__((vector_size(16)));
 typedef int nn_v16i __attribute__((vector_size(64)));
 #define NNM_QT 2                        // query tiles (of 32) per wavefront (3: 9.7 ms against 7.9 - a sixth workgroup column of padding; 4: spills)
 #define NNM_QG (4 * NNM_QT * 32)        // queries per workgroup
-#define ORBHIP_NN_DEFAULT 1             // form of the matrix-core scan orbhip_launch_hamming_nn takes (1 = i8, 2 = FP4 in the shape below)
+#define ORBHIP_NN_DEFAULT 2             // form of the matrix-core scan orbhip_launch_hamming_nn takes (1 = i8, 2 = FP4 in the shape below: 5.3 ms against 8.0 for 2000 x 20 M, profiles/r05_exp_config5_fp4_shapes.jsonl)
 #define ORBHIP_NN_FP4_QT 4
 #define ORBHIP_NN_FP4_OCC 2
 #define ORBHIP_NN_FP4_LCH 15

@@ -49,8 +49,11 @@ def test_optional_steps(tmp_path):
     none); the batch forms of the back end's loops are emitted with their header; both patched files still compile."""
     plain, one = tmp_path / "plain", tmp_path / "one"
     subprocess.run([sys.executable, SCRIPT, REF, str(plain)], capture_output=True, text=True, check=True)
-    subprocess.run([sys.executable, SCRIPT, "--stereo-one-call", REF, str(one)], capture_output=True, text=True, check=True)
+    subprocess.run([sys.executable, SCRIPT, "--stereo-one-call", "--resident-bow", REF, str(one)], capture_output=True, text=True, check=True)
     a, b = (plain / "src/Frame.cc").read_text(), (one / "src/Frame.cc").read_text()
+    # --resident-bow: Frame::ComputeBoW reads the descriptors where the extraction left them, the reference's statement kept for every other frame
+    assert "HoldsFrame" not in a and b.count("mpORBvocabulary->ComputeBoW(*mpORBextractorLeft, mBowVec, mFeatVec, 4);") == 1
+    assert b.count("mpORBvocabulary->transform(vCurrentDesc,mBowVec,mFeatVec,4);") == 1
     assert "thread threadLeft(&Frame::ExtractORB,this,0,imLeft);" in a and "threadLeft" not in b
     assert b.count("mpORBextractorLeft->ExtractStereo(imLeft, imRight, mvKeys, mDescriptors, mvKeysRight, mDescriptorsRight, mbf, mbf/K.at<float>(0,0));") == 1
     assert (plain / "src/ORBmatcher.cc").read_text() == (one / "src/ORBmatcher.cc").read_text()

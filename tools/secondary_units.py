@@ -265,13 +265,16 @@ def config5(nkf, ncores, per=2000, nq=2000):
     g_bi, g_bd, g_sd = gbi.download((nq,), np.int64), gbd.download((nq,), np.int32), gsd.download((nq,), np.int32)
     parity = bool(np.array_equal(g_bi, bi) and np.array_equal(g_bd, bd) and np.array_equal(g_sd, sd))
     pairs = nq * ndb
+    nn_form = os.environ.get("ORBHIP_NN", "")
     for b in (db, q, gbi, gbd, gsd):
         b.free()
     _DB = None
     return {"workload": f"{nq} query descriptors x {nkf} key frames x {per} descriptors ({ndb * 32 / 1e6:.0f} MB DB resident in HBM), best + second best per query",
-            "kernel": "k_hamming_nn (popcount)" if os.environ.get("ORBHIP_NN") == "valu" else "k_hamming_nn_mfma", "query_ms": round(dt * 1e3, 3),
-            "pair_distances_per_s": float(f"{pairs / dt:.4g}"), "db_stream_GBps": round(ndb * 32 / dt / 1e9, 1),
-            "mfma_i8_TOPs": round(pairs * 512 / dt / 1e12, 1), "frac_of_i8_mfma_peak": round(pairs * 512 / dt / 5e15, 3), "frac_of_i8_mfma_rate_measured_4400_TOPs": round(pairs * 512 / dt / 4.4e15, 3),
+            "kernel": {"valu": "k_hamming_nn (popcount)", "i8": "k_hamming_nn_mfma (i8 matrix cores)"}.get(nn_form, "k_hamming_nn_fp4 (FP4 matrix cores, %s)" % (nn_form or "default shape fp4:4:2:15:4")),
+            "query_ms": round(dt * 1e3, 3), "pair_distances_per_s": float(f"{pairs / dt:.4g}"), "db_stream_GBps": round(ndb * 32 / dt / 1e9, 1),
+            "matrix_TOPs": round(pairs * 512 / dt / 1e12, 1), "matrix_peak": "FP4 (v_mfma_scale_f32_32x32x64_f8f6f4): 10 PF spec, 9.1 PF measured; i8: 5 PF spec, 4.4 measured (MI355X_MICROARCH.md)",
+            "frac_of_fp4_mfma_peak": round(pairs * 512 / dt / 10e15, 3), "frac_of_fp4_mfma_rate_measured_9100_TOPs": round(pairs * 512 / dt / 9.1e15, 3),
+            "frac_of_i8_mfma_peak": round(pairs * 512 / dt / 5e15, 3),
             "ref_ms_all_threads": round(ref_s * 1e3, 1), "ref_threads": nw, "ref_kind": "port: oracle bf_nn (-O3 -march=x86-64-v3), the whole DB split by rows over all host threads, partial answers merged with the matcher's tie rule",
             "ref_over_gpu": round(ref_s / dt, 1), "parity_sample": {"queries_compared": nq, "rows": ndb, "equal": parity, "compared": "best row, best distance, second-best distance of every query, GPU vs the CPU scan of the whole DB"}}
 
