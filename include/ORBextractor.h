@@ -140,6 +140,9 @@ public:
     // *_frame entry points of orbhip.h — only its queries cross PCIe — and any other Frame goes through host buffers as before.
     void BindFrame(unsigned long frameId) { mnBoundFrame = frameId; mbBound = true; }
     bool HoldsFrame(unsigned long frameId, int N) const { return mpCtx && mbFrameState && mbBound && mnBoundFrame == frameId && N == mnLastN; }
+    // mvuRight the caller computed itself (the reference's Frame::ComputeStereoFromRGBD loop, Frame.cc:643-665) for the frame this extractor still holds:
+    // N floats go to the device for the resident searches instead of the depth map.  integration/apply_dropin.py appends the call to the reference's loop.
+    void SetStereoColumns(const std::vector<float>& mvuRight);
     bool HoldsStereoColumns() const { return mbStereoColumns; }      // mvuRight of that frame is on the device too (ComputeStereoMatches / ComputeStereoFromRGBD ran)
 
 protected:

@@ -289,6 +289,12 @@ orbhip_status orbhip_extract_stereo(orbhip_ctx* ctx, const uint8_t* img_left, co
 orbhip_status orbhip_compute_stereo_from_rgbd(orbhip_ctx* ctx, int nimg, const void* const* depth_maps, int stride_bytes,
                                               int depth_type, float depth_factor, float mbf, float* u_right, float* depth, int cap);
 
+/* One frame at a time, depth map in host memory (Tracking::GrabImageRGBD's case): the reference's own N-sample loop (Frame.cc:648-664) is cheaper than moving
+   the 1.2 MB map, and the frame that is still on the device only needs its result - mvuRight, N floats - for the right-coordinate test of the resident
+   searches (use_u_right of orbhip_search_by_projection_frame / _best_in_window_frame; ORBmatcher.cc:1418-1424, 96-101).  Copies u_right[0..n) before it returns,
+   uploads on the context's stream (nothing waits); replaces the columns a stereo / RGB-D step of the same extraction left. */
+orbhip_status orbhip_set_stereo_columns(orbhip_ctx* ctx, int frame, const float* u_right, int n);
+
 /* The candidate loop of ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th) (ORBmatcher.h:75, ORBmatcher.cc:825-972), of its
    Sim3 overload (ORBmatcher.h:78, :974-1100: the same loop without the chi-square gate) and of the two passes of
    ORBmatcher::SearchBySim3 (ORBmatcher.h:71-72, ORBmatcher.cc:1102-1326) on flat data.  The caller projects its

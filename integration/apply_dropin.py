@@ -4,6 +4,7 @@
     python integration/apply_dropin.py /path/to/ORB_SLAM2 /path/to/out      # writes the edited tree pieces under out/
     python integration/apply_dropin.py --patch /path/to/ORB_SLAM2 > dropin.patch   # the same edits as a unified diff (patch -p1)
     ... --stereo-one-call        optional: the stereo Frame constructor extracts both images in ONE call on one device context (ORBextractor::ExtractStereo)
+    ... --device-rgbd            optional: Frame::ComputeStereoFromRGBD samples the depth map on the device (default: the reference's loop + N floats uploaded)
     ... --resident-bow           optional (with this repository's ORBVocabulary class in place, step 3e): Frame::ComputeBoW reads the descriptors in HBM
 
 What it produces (nothing else of the checkout changes; Tracking.cc, LocalMapping.cc, LoopClosing.cc, KeyFrame*.cc compile as they are):
@@ -36,9 +37,35 @@ FORWARDS = {
         "{ mpORBextractorLeft->UndistortKeyPoints(mvKeysUn); mpORBextractorLeft->BindFrame(mnId); }",
     r"void\s+Frame::ComputeImageBounds\s*\(\s*const\s+cv::Mat\s*&\s*imLeft\s*\)":
         "{ mpORBextractorLeft->ComputeImageBounds(imLeft.cols, imLeft.rows, mnMinX, mnMaxX, mnMinY, mnMaxY); }",
-    r"void\s+Frame::ComputeStereoFromRGBD\s*\(\s*const\s+cv::Mat\s*&\s*imDepth\s*\)":
-        "{ mpORBextractorLeft->ComputeStereoFromRGBD(imDepth, 1.0f, mbf, N, mvuRight, mvDepth); }",
 }
+
+
+# Frame::ComputeStereoFromRGBD (Frame.cc:643-665) keeps the reference's own loop - N samples of a depth map that is in host memory cost less there than the map's
+# trip to the device - and hands its result to the frame the extractor still holds (the resident searches' right-coordinate test reads mvuRight in HBM).
+# --device-rgbd replaces the loop by ORBextractor::ComputeStereoFromRGBD instead (depth map sampled on the device: the form for batches of frames).
+RGBD_SIG = r"void\s+Frame::ComputeStereoFromRGBD\s*\(\s*const\s+cv::Mat\s*&\s*imDepth\s*\)"
+RGBD_APPEND = "    if(mpORBextractorLeft) mpORBextractorLeft->SetStereoColumns(mvuRight);\n"
+RGBD_DEVICE_BODY = "{ mpORBextractorLeft->ComputeStereoFromRGBD(imDepth, 1.0f, mbf, N, mvuRight, mvDepth); }"
+
+
+def body_span(src, signature):
+    m = re.search(signature, src)
+    if not m:
+        raise SystemExit(f"signature not found: {signature}")
+    i = src.index("{", m.end())
+    depth, j = 0, i
+    while True:
+        c = src[j]
+        depth += c == "{"
+        depth -= c == "}"
+        if depth == 0:
+            return i, j
+        j += 1
+
+
+def append_to_body(src, signature, statement):
+    i, j = body_span(src, signature)
+    return src[:j] + statement + src[j:]
 
 
 def replace_body(src, signature, body):
@@ -670,9 +697,10 @@ RESIDENT_BOW_BODY = """{
 }"""
 
 
-def patch_frame(src, stereo_one_call=False, resident_bow=False):
+def patch_frame(src, stereo_one_call=False, resident_bow=False, device_rgbd=False):
     for sig, body in FORWARDS.items():
         src = replace_body(src, sig, body)
+    src = replace_body(src, RGBD_SIG, RGBD_DEVICE_BODY) if device_rgbd else append_to_body(src, RGBD_SIG, RGBD_APPEND)
     if resident_bow:
         src = replace_body(src, RESIDENT_BOW_SIG, RESIDENT_BOW_BODY)
     if stereo_one_call:
@@ -717,21 +745,23 @@ def main():
         keep = "--keep-map-free" in argv
         one_call = "--stereo-one-call" in argv
         rbow = "--resident-bow" in argv
-        argv = [a for a in argv[1:] if a not in ("--keep-map-free", "--stereo-one-call", "--resident-bow")]
-        open(argv[1], "w").write(patch_frame(open(argv[0]).read(), stereo_one_call=one_call, resident_bow=rbow))
+        drgbd = "--device-rgbd" in argv
+        argv = [a for a in argv[1:] if a not in ("--keep-map-free", "--stereo-one-call", "--resident-bow", "--device-rgbd")]
+        open(argv[1], "w").write(patch_frame(open(argv[0]).read(), stereo_one_call=one_call, resident_bow=rbow, device_rgbd=drgbd))
         if len(argv) > 3:
             open(argv[3], "w").write(patch_matcher(open(argv[2]).read(), map_free_members=not keep))
         return
     one_call = "--stereo-one-call" in argv
     rbow = "--resident-bow" in argv
-    argv = [a for a in argv if a not in ("--stereo-one-call", "--resident-bow")]
+    drgbd = "--device-rgbd" in argv
+    argv = [a for a in argv if a not in ("--stereo-one-call", "--resident-bow", "--device-rgbd")]
     emit_patch = bool(argv) and argv[0] == "--patch"
     if emit_patch:
         argv = argv[1:]
     if len(argv) < (1 if emit_patch else 2):
         raise SystemExit(__doc__)
     ref = argv[0]
-    edited = {"src/Frame.cc": patch_frame(open(os.path.join(ref, "src/Frame.cc")).read(), stereo_one_call=one_call, resident_bow=rbow),
+    edited = {"src/Frame.cc": patch_frame(open(os.path.join(ref, "src/Frame.cc")).read(), stereo_one_call=one_call, resident_bow=rbow, device_rgbd=drgbd),
               "src/ORBmatcher.cc": patch_matcher(open(os.path.join(ref, "src/ORBmatcher.cc")).read())}
     copies = {"include/ORBextractor.h": "include/ORBextractor.h", "src/ORBextractor.cc": "orb_slam2_amd/cpp/ORBextractor.cc", "include/orbhip.h": "include/orbhip.h",
               "include/ORBmatcherBatch.h": "include/ORBmatcherBatch.h"}

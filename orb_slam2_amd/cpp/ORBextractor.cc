@@ -264,6 +264,13 @@ void ORBextractor::ComputeStereoFromRGBD(const cv::Mat& imDepth, float depthFact
     mbStereoColumns = true;
 }
 
+void ORBextractor::SetStereoColumns(const std::vector<float>& mvuRight)
+{
+    if (!mpCtx || !mbFrameState || (int)mvuRight.size() != mnLastN) return;                 // not this extractor's frame any more: the searches take the host path (HoldsFrame / HoldsStereoColumns)
+    if (orbhip_set_stereo_columns(mpCtx, 0, mvuRight.empty() ? NULL : &mvuRight[0], mnLastN) != ORBHIP_OK) Fail("ORBextractor::SetStereoColumns");
+    mbStereoColumns = true;
+}
+
 void ORBextractor::SetRectification(const cv::Mat& M1, const cv::Mat& M2, int rawCols, int rawRows)
 {
     assert(M1.type() == CV_32F && M2.type() == CV_32F && M1.rows == M2.rows && M1.cols == M2.cols);

@@ -105,7 +105,7 @@ struct orbhip_ctx {
     int* d_grid_start = nullptr; int* d_grid_items = nullptr; float2* d_grid_xy = nullptr; unsigned* d_cand = nullptr; unsigned* d_top = nullptr; int* d_ncand = nullptr; float* d_prev = nullptr; int* d_m12 = nullptr; int* d_nm = nullptr;
     // camera geometry: undistorted key points of a distorted camera, rectification maps of a raw stereo camera
     orbhip_bounds bounds = {0, 0, 0, 0}; bool distorted = false; CameraD cam = {}; orbhip_keypoint* d_out_kpun[3] = {nullptr, nullptr, nullptr}; orbhip_keypoint* h_kpun = nullptr;
-    int* d_map_x = nullptr; int* d_map_y = nullptr; int src_w = 0, src_h = 0, raw_pitch = 0; uint8_t* d_raw = nullptr; uint8_t* h_raw = nullptr; uint8_t* d_depth = nullptr; size_t depth_bytes = 0; const float* d_last_uright = nullptr;   // mvuRight [slot][out_cap] of the last stereo / RGB-D step
+    int* d_map_x = nullptr; int* d_map_y = nullptr; int src_w = 0, src_h = 0, raw_pitch = 0; uint8_t* d_raw = nullptr; uint8_t* h_raw = nullptr; uint8_t* d_depth = nullptr; size_t depth_bytes = 0; const float* d_last_uright = nullptr; float* d_ucols = nullptr; float* h_ucols = nullptr; hipEvent_t ev_ucols = nullptr; bool ucols_pending = false;   // mvuRight [slot][out_cap] of the last stereo / RGB-D step
     // pipelined host-buffer path
     HostSet sets[ORBHIP_RING]; hipStream_t hstream = nullptr, dstream = nullptr; int next_ticket = 0, oldest_ticket = 0, ticket_set[ORBHIP_RING] = {0, 0, 0}; const uint8_t* last_d_in = nullptr; bool plane0_dirty = false;   // plane0_dirty: set 0's level-0 plane was last written by an un-ticketed entry (colour / rectify)
     // profiling
@@ -367,7 +367,7 @@ extern "C" void orbhip_destroy(orbhip_ctx* c)
                     c->d_qt_val, c->d_qt_code, c->d_qt_node, c->d_lvl_kp, c->d_lvl_n[0], c->d_lvl_n[1], c->d_lvl_n[2], c->d_out_block[0], c->d_out_block[1], c->d_out_block[2], c->d_grid_start, c->d_grid_items, c->d_grid_xy, c->d_cand, c->d_top, c->d_ncand,
                     c->d_prev, c->d_m12, c->d_nm};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    { void* ep[] = {c->d_fgrid_start, c->d_fgrid_items, c->d_fgrid_xy, c->d_rrow_start, c->d_rrow_items}; for (void* q : ep) if (q) (void)hipFree(q); if (c->ev_epilogue) (void)hipEventDestroy(c->ev_epilogue); if (c->h_st) (void)hipHostFree(c->h_st); if (c->ev_stereo) (void)hipEventDestroy(c->ev_stereo); }
+    { void* ep[] = {c->d_fgrid_start, c->d_fgrid_items, c->d_fgrid_xy, c->d_rrow_start, c->d_rrow_items}; for (void* q : ep) if (q) (void)hipFree(q); if (c->ev_epilogue) (void)hipEventDestroy(c->ev_epilogue); if (c->h_st) (void)hipHostFree(c->h_st); if (c->d_ucols) (void)hipFree(c->d_ucols); if (c->h_ucols) (void)hipHostFree(c->h_ucols); if (c->ev_ucols) (void)hipEventDestroy(c->ev_ucols); if (c->ev_stereo) (void)hipEventDestroy(c->ev_stereo); }
     { void* st[] = {c->d_st_rowstart, c->d_st_rowitems, c->d_st_u /* | d_st_depth */, c->d_st_sad}; for (void* q : st) if (q) (void)hipFree(q); }
     for (auto& hs : c->sets) {
         for (int k = 0; k < ORBHIP_MAX_CHUNKS; k++) { if (hs.ev_h2d[k]) (void)hipEventDestroy(hs.ev_h2d[k]); if (hs.ev_k[k]) (void)hipEventDestroy(hs.ev_k[k]); if (hs.ev_d2h[k]) (void)hipEventDestroy(hs.ev_d2h[k]); }
@@ -2025,6 +2025,32 @@ extern "C" orbhip_status orbhip_compute_stereo_from_rgbd(orbhip_ctx* c, int nimg
             HIPCHK(hipMemcpy(depth + (size_t)f * cap, d_z + (size_t)f * c->out_cap, (size_t)m * sizeof(float), hipMemcpyDeviceToHost));
         }
     }
+    return ORBHIP_OK;
+}
+
+// mvuRight computed by the caller (Frame::ComputeStereoFromRGBD's own loop, Frame.cc:643-665: N samples of a depth map that lives in host memory) handed to
+// the frame that is still on the device, so that the resident searches' right-coordinate test (ORBmatcher.cc:1418-1424, 96-101) reads it in HBM: N floats travel,
+// not the depth map.  Asynchronous on the context's stream; the values are copied before the call returns.
+extern "C" orbhip_status orbhip_set_stereo_columns(orbhip_ctx* c, int frame, const float* u_right, int n)
+{
+    OrbApiTimer api_timer;
+    if (!c || (!u_right && n > 0)) return fail(ORBHIP_ERR_INVALID, "null argument");
+    if (frame < 0 || frame >= c->last_nimg) return fail(ORBHIP_ERR_INVALID, "frame %d outside the %d frames of the last extraction", frame, c->last_nimg);
+    if (n < 0 || n > c->out_cap) return fail(ORBHIP_ERR_INVALID, "n %d outside 0..%d", n, c->out_cap);
+    HIPCHK(hipSetDevice(c->cfg.device));
+    const size_t total = (size_t)c->B * c->out_cap;
+    if (!c->d_ucols) {
+        HIPCHK(orbhip_dmalloc((void**)&c->d_ucols, total * sizeof(float)));
+        HIPCHK(hipHostMalloc((void**)&c->h_ucols, total * sizeof(float), hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_ucols, hipEventDisableTiming));
+    }
+    if (c->ucols_pending) { HIPCHK(hipEventSynchronize(c->ev_ucols)); c->ucols_pending = false; }      // the pinned block is free again
+    if (n > 0) {
+        memcpy(c->h_ucols + (size_t)frame * c->out_cap, u_right, (size_t)n * sizeof(float));
+        HIPCHK(orbhip_copy_async(c->d_ucols + (size_t)frame * c->out_cap, c->h_ucols + (size_t)frame * c->out_cap, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipEventRecord(c->ev_ucols, c->stream)); c->ucols_pending = true;
+    }
+    c->d_last_uright = c->d_ucols;
     return ORBHIP_OK;
 }
 

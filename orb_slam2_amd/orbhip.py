@@ -32,7 +32,7 @@ SYMBOLS = [
     "orbhip_search_by_bow_batch", "orbhip_search_for_triangulation_batch", "orbhip_search_best_in_window_batch",
     "orbhip_undistort_points", "orbhip_image_bounds", "orbhip_set_camera", "orbhip_get_bounds", "orbhip_fetch_undistorted",
     "orbhip_search_for_initialization_bounds", "orbhip_search_by_projection_bounds", "orbhip_search_best_in_window_bounds",
-    "orbhip_set_rectification", "orbhip_extract_batch_rectify", "orbhip_extract_device_rectify", "orbhip_compute_stereo_from_rgbd",
+    "orbhip_set_rectification", "orbhip_extract_batch_rectify", "orbhip_extract_device_rectify", "orbhip_compute_stereo_from_rgbd", "orbhip_set_stereo_columns",
     "orbhip_search_by_projection_frame", "orbhip_search_best_in_window_frame", "orbhip_search_by_projection_batch",
     "orbhip_pyramid_fetch_all", "orbhip_set_blur_rounding", "orbhip_set_fp_contract", "orbhip_submit", "orbhip_collect", "orbhip_ring_depth", "orbhip_host_alloc", "orbhip_host_free",
     "orbhip_pool_create", "orbhip_pool_destroy", "orbhip_pool_num_devices", "orbhip_pool_device_of", "orbhip_pool_keypoint_capacity", "orbhip_pool_numa_node",
@@ -151,6 +151,7 @@ def lib(path=None):
     L.orbhip_extract_batch_rectify.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp]
     L.orbhip_extract_device_rectify.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]
     L.orbhip_compute_stereo_from_rgbd.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_float, C.c_float, vp, vp, C.c_int]
+    L.orbhip_set_stereo_columns.argtypes = [vp, C.c_int, vp, C.c_int]
     L.orbhip_search_by_projection_batch.argtypes = [C.c_int, C.c_int, vp, C.POINTER(Bounds), C.c_int, C.c_float, C.c_int, C.c_int]
     L.orbhip_search_by_projection_frame.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, vp, ip]
     L.orbhip_search_best_in_window_frame.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp]
@@ -457,6 +458,11 @@ class ORBextractor:
         _check(self.L.orbhip_compute_stereo_from_rgbd(self.h, n, ptrs, dms[0].strides[0], int(dms[0].dtype == np.uint16), float(depth_factor), float(mbf),
                                                       _p(u), _p(z), cap), "orbhip_compute_stereo_from_rgbd", self.L)
         return u, z
+
+    def set_stereo_columns(self, u_right, frame=0):
+        """mvuRight computed on the host (the reference's Frame::ComputeStereoFromRGBD loop) for a frame of the last call: the resident searches read it in HBM."""
+        u = np.ascontiguousarray(u_right, np.float32)
+        _check(self.L.orbhip_set_stereo_columns(self.h, frame, _p(u), len(u)), "orbhip_set_stereo_columns", self.L)
 
     def mvImagePyramid(self, level, frame=0):
         w, h = self.level_size(level)

@@ -202,6 +202,54 @@ def test_searches_on_device_resident_frames(backend, oracle):
     xl.close(); xr.close()
 
 
+def test_stereo_columns_handed_to_a_resident_frame(backend, oracle):
+    """orbhip_set_stereo_columns: mvuRight the caller computed itself (one RGB-D frame at a time: the reference's own depth-map loop) reaches the frame that is
+    still on the device; the resident searches with the right-coordinate test equal the oracle on the same columns; a second set replaces the first, a new
+    extraction drops them, a wrong count is refused."""
+    w, h, n = 400, 300, 500
+    x = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, max_batch=1, library=backend)
+    sf = x.GetScaleFactors()
+    inv = (1.0 / (sf * sf)).astype(np.float32)
+    rng = np.random.default_rng(33)
+    for t in range(3):
+        kc, dc = x(synth.frame(w, h, seed=40 + t))
+        nk = len(kc)
+        q = np.zeros(nk, oracle.PROJ_QUERY_DTYPE)
+        q["x"] = kc["x"] + rng.normal(0, 1.5, nk).astype(np.float32); q["y"] = kc["y"] + rng.normal(0, 1.5, nk).astype(np.float32)
+        q["radius"] = (np.float32(5.0) * sf[kc["octave"]]).astype(np.float32)
+        q["min_level"], q["max_level"] = kc["octave"] - 1, kc["octave"] + 1
+        q["blocks"] = rng.random(nk) < 0.8
+        q["angle"] = kc["angle"]
+        qd = dc.copy()
+        for i in range(nk):
+            for b in rng.integers(0, 256, int(rng.integers(0, 25))):
+                qd[i, b >> 3] ^= 1 << (b & 7)
+        if t == 0:
+            with pytest.raises(orb_slam2_amd.OrbHipError):
+                x.search_by_projection(0, nk, q[:1], qd[:1], 0, use_u_right=True)                      # none yet
+            with pytest.raises(orb_slam2_amd.OrbHipError):
+                x.set_stereo_columns(np.zeros(x.capacity + 1, np.float32))
+        for rep in range(2):                                                                              # the second set replaces the first
+            depth = np.where(rng.random(nk) < 0.7, rng.uniform(0.5, 8.0, nk), -1.0).astype(np.float32)
+            u = np.where(depth > 0, kc["x"] - np.float32(40.0) / depth, -1.0).astype(np.float32)         # Frame.cc:660-662
+            x.set_stereo_columns(u)
+            q["ur"] = np.where(u > 0, u + rng.normal(0, 2.0, nk), q["x"] - 20).astype(np.float32)
+            for mode in (0, 1):
+                n_o, f_o = oracle.search_by_projection(kc, dc, w, h, q, qd, mode, nnratio=0.9, th_high=100, check_ori=True, u_right=u)
+                n_g, f_g = x.search_by_projection(0, nk, q, qd, mode, nnratio=0.9, th_high=100, check_ori=True, use_u_right=True)
+                assert n_g == n_o and np.array_equal(f_g, f_o) and n_o > 50, (t, rep, mode)
+            bq = np.zeros(nk, oracle.BEST_QUERY_DTYPE)
+            bq["x"], bq["y"], bq["ur"], bq["level"] = q["x"], q["y"], q["ur"], np.clip(kc["octave"] + rng.integers(0, 2, nk), 0, 7)
+            bq["radius"] = (np.float32(3.0) * sf[bq["level"]]).astype(np.float32)
+            bi_o, bd_o = oracle.search_best_in_window(kc, dc, w, h, inv, bq, qd, True, u_right=u)
+            bi_g, bd_g = x.search_best_in_window(0, nk, bq, qd, True, use_u_right=True)
+            assert np.array_equal(bi_g, bi_o) and np.array_equal(bd_g, bd_o)
+    x(synth.frame(w, h, seed=50))
+    with pytest.raises(orb_slam2_amd.OrbHipError):
+        x.search_best_in_window(0, 10, bq[:1], qd[:1], True, use_u_right=True)                              # a new extraction drops the columns
+    x.close()
+
+
 def test_frame_epilogues_single_image_sequence(backend, oracle):
     """What ORB_SLAM2 does: one stereo pair at a time on two max_batch = 1 contexts, each pair followed by ComputeStereoMatches and two
     projection searches on the left frame.  From the second pair on the contexts build the right image's row table and the left image's 64x48
