@@ -5,14 +5,16 @@
 //   scoring objects                             ScoringObject.cpp:24-313                                   (host, tiny)
 // as called by Frame::ComputeBoW (Frame.cc:395-402: transform(vCurrentDesc, mBowVec, mFeatVec, 4)).
 //
-// Device layout: the k-ary tree as CSR (child_start[nnodes+1], child_ids[]), 32-byte node descriptors, f64 weights, word ids.
-// ORBvoc.txt (k = 10, L = 6) is 1.1 M nodes = 35 MB of descriptors: resident in HBM, hot upper levels in L2.
+// Device layout: the k-ary tree renumbered breadth first, so that the children of a node are neighbours (child order kept: the first minimum wins), one
+// 48-byte record per node: the 32-byte descriptor + {first child, number of children, the file's node id, word id}.  A child's record carries the pointer to
+// ITS children, so a level of the descent is ONE dependent fetch (the k child records), not three (child range -> child ids -> descriptors).  f64 weights apart.
+// ORBvoc.txt (k = 10, L = 6) is 1.1 M nodes = 52 MB of records: resident in HBM, hot upper levels in L2.
 //  k_bow_descend   one thread per feature walks the tree (<= L dependent steps, k Hamming distances each, strict '<' so the
 //                  first minimum wins) -> word id, weight, node id `levelsup` levels above the leaf.
 //  k_bow_assemble  one workgroup per frame turns the per-feature triples into the two std::map's of the reference, flattened
-//                  in key order: keys (word << 32 | feature index) are rank-sorted in LDS, run heads become entries, weights of a
-//                  word are added in feature order and the L1 norm is summed in word order by ONE lane (f64 addition order is
-//                  part of the result), then every value is divided by it.  Same for (node << 32 | index) -> FeatureVector.
+//                  in key order: keys (word << 32 | feature index) and (node << 32 | index) are sorted in LDS by ONE bitonic network working on both arrays,
+//                  run heads become entries, weights of a word are added in feature order and the L1 norm is summed in word order by ONE lane (f64 addition
+//                  order is part of the result), then every value is divided by it.  A frame's results are one contiguous block: one copy takes them home.
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdarg>
@@ -33,20 +35,23 @@
 
 #define BOWCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return orbhip_set_error(ORBHIP_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 
+struct BowNode { uint4 da, db; uint32_t first_child, nchildren, id, word; };      // 48 bytes
+struct BowOut { uint8_t* base; long long stride; int o_id, o_fn, o_ff, o_fo, o_cnt; };        // a frame's results: [bow_val C f64 | bow_id C | fv_node C | fv_feat C | fv_off C+1 | nbow, -, -, -, nfv] at base + frame * stride
+
 struct BowParams {
     const uint8_t* desc; long long desc_frame_stride;        // features of frame f at desc + f*stride, 32 B each
     const int* nfeat; int nfeat_fixed; int cap;                // per-frame count (device) or one fixed count; output stride
-    const int* child_start; const int* child_ids; const uint8_t* node_desc; const double* node_weight; const int* node_word;
+    const BowNode* nodes; const double* node_weight;           // breadth-first numbering, root = 0
     int L, levelsup, accumulate, must_normalize, l2;
     uint32_t* word; double* weight; uint32_t* node;            // [frame][cap]
-    uint32_t* bow_id; double* bow_val; int* nbow;              // [frame][cap], [frame]
-    uint32_t* fv_node; int* fv_off; uint32_t* fv_feat; int* nfv;   // [frame][cap], [frame][cap+1], [frame][cap], [frame]
+    BowOut out;
     int lcap;                          // features the LDS arrays of k_bow_assemble are carved for (>= every frame's count, <= cap)
 };
 
 __device__ __forceinline__ int bow_count(const BowParams& P, int frame) { return min(P.nfeat ? P.nfeat[frame] : P.nfeat_fixed, P.cap); }
 
 // transform(feature, word_id, weight, nid, levelsup)  (TemplatedVocabulary.h:1218-1262)
+#define BD_FETCH 5                     // child records in flight per step of the scan over a node's children
 __global__ __launch_bounds__(256) void k_bow_descend(BowParams P)
 {
     const int frame = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
@@ -54,25 +59,32 @@ __global__ __launch_bounds__(256) void k_bow_descend(BowParams P)
     const uint4* f4 = reinterpret_cast<const uint4*>(P.desc + (long long)frame * P.desc_frame_stride + (long long)i * 32);
     const uint4 fa = f4[0], fb = f4[1];
     const int nid_level = P.L - P.levelsup;
-    int final_id = 0, level = 0, nid = 0;
-    int a = P.child_start[0], b = P.child_start[1];
+    const uint4* rec = reinterpret_cast<const uint4*>(P.nodes);
+    int level = 0; uint32_t nid = 0, final_dev = 0;
+    uint4 cur = rec[2];                                                                  // the root's {first child, count, id, word}
     do {
         ++level;
-        int best = 0x7fffffff, best_id = 0;
-        for (int c = a; c < b; c++) {
-            const int id = P.child_ids[c];
-            const uint4* d4 = reinterpret_cast<const uint4*>(P.node_desc + (long long)id * 32);
-            const uint4 da = d4[0], db = d4[1];
-            const int d = __popc(fa.x ^ da.x) + __popc(fa.y ^ da.y) + __popc(fa.z ^ da.z) + __popc(fa.w ^ da.w) +
-                          __popc(fb.x ^ db.x) + __popc(fb.y ^ db.y) + __popc(fb.z ^ db.z) + __popc(fb.w ^ db.w);    // FORB::distance
-            if (d < best) { best = d; best_id = id; }                                   // strict: first minimum wins (:1243-1247)
+        int best = 0x7fffffff; uint4 best_info = cur; uint32_t best_dev = 0;
+        const uint32_t a = cur.x, cnt = cur.y;
+        for (uint32_t c = 0; c < cnt; c += BD_FETCH) {
+            uint4 ra[BD_FETCH], rb[BD_FETCH], ri[BD_FETCH];
+#pragma unroll
+            for (int u = 0; u < BD_FETCH; u++) {
+                const uint32_t dev = min(a + c + u, a + cnt - 1);                        // (past the end: the last child again, never compared)
+                ra[u] = rec[(size_t)dev * 3]; rb[u] = rec[(size_t)dev * 3 + 1]; ri[u] = rec[(size_t)dev * 3 + 2];
+            }
+#pragma unroll
+            for (int u = 0; u < BD_FETCH; u++) {
+                const int d = __popc(fa.x ^ ra[u].x) + __popc(fa.y ^ ra[u].y) + __popc(fa.z ^ ra[u].z) + __popc(fa.w ^ ra[u].w) +
+                              __popc(fb.x ^ rb[u].x) + __popc(fb.y ^ rb[u].y) + __popc(fb.z ^ rb[u].z) + __popc(fb.w ^ rb[u].w);    // FORB::distance
+                if (c + u < cnt && d < best) { best = d; best_info = ri[u]; best_dev = a + c + u; }    // strict: first minimum wins (:1243-1247)
+            }
         }
-        final_id = best_id;
-        if (level == nid_level) nid = final_id;
-        a = P.child_start[final_id]; b = P.child_start[final_id + 1];
-    } while (b > a);                                                                     // !isLeaf()
+        cur = best_info; final_dev = best_dev;
+        if (level == nid_level) nid = cur.z;
+    } while (cur.y > 0);                                                                  // !isLeaf()
     const long long o = (long long)frame * P.cap + i;
-    P.word[o] = (uint32_t)P.node_word[final_id]; P.weight[o] = P.node_weight[final_id]; P.node[o] = (uint32_t)nid;
+    P.word[o] = cur.w; P.weight[o] = P.node_weight[final_dev]; P.node[o] = nid;
 }
 
 #define BA_T 256
@@ -98,60 +110,77 @@ __device__ __forceinline__ int ba_exscan(int* a, int n, int* scratch, int tid)
     return total;
 }
 
-// ascending sort of n unique 64-bit keys (invalid = ~0 sorts last) into out[0 .. p2), p2 = the power of two the array is carved for: a bitonic network in
-// LDS, p2 / 2 compare-exchanges per stage spread over the workgroup.  (It was a rank sort - every key counted against every other one: n^2 / 256 LDS reads
-// per thread, 0.46 ms of ONE workgroup for a 2000-feature frame, which is the whole latency of a single frame's ComputeBoW; the network is
-// log2(p2) (log2(p2) + 1) / 2 = 66 stages of 4 exchanges per thread at p2 = 2048.)
-__device__ __forceinline__ void ba_sort(const unsigned long long* key, unsigned long long* out, int n, int p2, int tid)
+// ascending sort of NARR arrays of p2 (a power of two) unique 64-bit keys each (invalid = ~0 sorts last), in place: a bitonic network in LDS, p2 / 2
+// compare-exchanges per stage and array spread over the workgroup, both arrays in the same pass.  Exchange slot t always belongs to thread t % BA_T, so the 64
+// slots [64 q, 64 q + 64) - elements [128 q, 128 q + 128) - stay with one wavefront: stages whose partners are at most 64 apart (j <= 64: all of the first 28
+// stages, the last 7 of every later phase) only need the wavefront's own order (LDS operations of a wave execute in order; the fence keeps the compiler from
+// moving a stage's reads above the previous stage's writes), and only the stages with j >= 128 are bracketed by workgroup barriers: 9 instead of 55 at p2 = 1024.
+// (History: a rank sort - every key counted against every other one - was 0.46 ms of ONE workgroup for a 2000-feature frame; the network with a workgroup
+// barrier after each of its stages, one array after the other, 0.064 ms per 1000 features.)
+template <int NARR> __device__ __forceinline__ void ba_sort(unsigned long long* a0, unsigned long long* a1, int p2, int tid)
 {
-    for (int i = tid; i < p2; i += BA_T) out[i] = i < n ? key[i] : ~0ull;
-    __syncthreads();
+    bool wide = true;                                                                    // the previous stage crossed wavefronts (or: the keys were just written)
     for (int k = 2; k <= p2; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
+            const bool cross = j > 64;
+            if (cross || wide) __syncthreads();
+            else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+            wide = cross;
             for (int t = tid; t < (p2 >> 1); t += BA_T) {
                 const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), x = i | j;          // the pair (i, i + j), bit j of i clear
-                const unsigned long long a = out[i], b = out[x];
-                if ((a > b) == ((i & k) == 0)) { out[i] = b; out[x] = a; }
+                const bool up = (i & k) == 0;
+                { const unsigned long long a = a0[i], b = a0[x]; if ((a > b) == up) { a0[i] = b; a0[x] = a; } }
+                if (NARR > 1) { const unsigned long long a = a1[i], b = a1[x]; if ((a > b) == up) { a1[i] = b; a1[x] = a; } }
             }
-            __syncthreads();
         }
+    __syncthreads();
 }
 __host__ __device__ inline int ba_pow2(int n) { int p = 2; while (p < n) p <<= 1; return p; }
+#define BA_DUAL_MAX 4096               // features up to which both key arrays fit the LDS side by side (16 B per slot of the network + 8 B per feature: 96 KB)
+__host__ __device__ inline size_t ba_lds_bytes(int lcap) { return (size_t)ba_pow2(lcap) * (lcap <= BA_DUAL_MAX ? 16 : 8) + (size_t)lcap * 8 + 64; }
 
-__global__ __launch_bounds__(BA_T) void k_bow_assemble(BowParams P)
+template <bool DUAL> __global__ __launch_bounds__(BA_T) void k_bow_assemble(BowParams P)
 {
     HIP_DYNAMIC_SHARED(unsigned long long, lds64)
     const int frame = blockIdx.x, tid = threadIdx.x, n = min(bow_count(P, frame), P.lcap), cap = P.cap;
     const int lcap = P.lcap;                               // LDS arrays hold lcap entries; `cap` is the row stride of the HBM arrays
     const int p2 = ba_pow2(lcap);
-    unsigned long long* key = lds64;                       // [lcap]  (reused as f64 values after the sort)
-    unsigned long long* sorted = lds64 + lcap;             // [p2]: the sorting network works on a power of two
-    int* flag = reinterpret_cast<int*>(lds64 + lcap + p2); // [lcap]
-    int* scratch = flag + lcap;                            // [8]
-    double* vals = reinterpret_cast<double*>(key);
+    unsigned long long* sw = lds64;                        // [p2] (word << 32 | feature), after the sort; then the f64 values of the words
+    unsigned long long* sn = DUAL ? lds64 + p2 : lds64;    // [p2] (node << 32 | feature)   (one array after the other when both do not fit)
+    int* flag = reinterpret_cast<int*>(lds64 + (DUAL ? 2 : 1) * (size_t)p2);   // [lcap]
+    int* head = flag + lcap;                               // [lcap]
+    int* scratch = head + lcap;                            // [8]
+    double* vals = reinterpret_cast<double*>(sw);
     const uint32_t* word = P.word + (long long)frame * cap; const double* wt = P.weight + (long long)frame * cap; const uint32_t* node = P.node + (long long)frame * cap;
-    uint32_t* bow_id = P.bow_id + (long long)frame * cap; double* bow_val = P.bow_val + (long long)frame * cap;
-    uint32_t* fv_node = P.fv_node + (long long)frame * cap; int* fv_off = P.fv_off + (long long)frame * (cap + 1); uint32_t* fv_feat = P.fv_feat + (long long)frame * cap;
+    uint8_t* ob = P.out.base + (long long)frame * P.out.stride;
+    double* bow_val = reinterpret_cast<double*>(ob); uint32_t* bow_id = reinterpret_cast<uint32_t*>(ob + P.out.o_id);
+    uint32_t* fv_node = reinterpret_cast<uint32_t*>(ob + P.out.o_fn); uint32_t* fv_feat = reinterpret_cast<uint32_t*>(ob + P.out.o_ff);
+    int* fv_off = reinterpret_cast<int*>(ob + P.out.o_fo); int* counts = reinterpret_cast<int*>(ob + P.out.o_cnt);
 
-    // ---- BowVector: v.addWeight(id, w) for every feature with w > 0, in feature order (:1157-1161)
-    for (int i = tid; i < n; i += BA_T) { key[i] = wt[i] > 0 ? (((unsigned long long)word[i] << 32) | (unsigned)i) : ~0ull; flag[i] = wt[i] > 0; }
+    // ---- keys of both maps for every feature with w > 0 (:1157-1161), sorted
+    for (int i = tid; i < p2; i += BA_T) {
+        const bool on = i < n && wt[i] > 0;
+        sw[i] = on ? (((unsigned long long)word[i] << 32) | (unsigned)i) : ~0ull;
+        if (DUAL) sn[i] = on ? (((unsigned long long)node[i] << 32) | (unsigned)i) : ~0ull;
+        if (i < n) flag[i] = on;
+    }
     __syncthreads();
     const int m = ba_exscan(flag, n, scratch, tid);        // features that are "not stopped"
-    ba_sort(key, sorted, n, p2, tid);
-    for (int i = tid; i < m; i += BA_T) flag[i] = (i == 0) || ((sorted[i] >> 32) != (sorted[i - 1] >> 32));
-    __syncthreads();
-    for (int i = tid; i < m; i += BA_T) key[i] = (unsigned long long)flag[i];      // keep the head marks: the scan overwrites flag
+    ba_sort<DUAL ? 2 : 1>(sw, sn, p2, tid);
+
+    // ---- BowVector: v.addWeight(id, w) in feature order
+    for (int i = tid; i < m; i += BA_T) { const int h = (i == 0) || ((sw[i] >> 32) != (sw[i - 1] >> 32)); flag[i] = h; head[i] = h; }
     __syncthreads();
     const int nb = ba_exscan(flag, m, scratch, tid);
     for (int i = tid; i < m; i += BA_T) {
-        if (!key[i]) continue;
-        const uint32_t w = (uint32_t)(sorted[i] >> 32);
-        double v = wt[(uint32_t)sorted[i]];
-        if (P.accumulate) for (int j = i + 1; j < m && (uint32_t)(sorted[j] >> 32) == w; j++) v += wt[(uint32_t)sorted[j]];   // `vit->second += v`
+        if (!head[i]) continue;
+        const uint32_t w = (uint32_t)(sw[i] >> 32);
+        double v = wt[(uint32_t)sw[i]];
+        if (P.accumulate) for (int j = i + 1; j < m && (uint32_t)(sw[j] >> 32) == w; j++) v += wt[(uint32_t)sw[j]];   // `vit->second += v`
         bow_id[flag[i]] = w; bow_val[flag[i]] = v;                                         // addIfNotExist keeps the first
     }
     __syncthreads();
-    for (int i = tid; i < nb; i += BA_T) vals[i] = bow_val[i];
+    for (int i = tid; i < nb; i += BA_T) vals[i] = bow_val[i];                               // (the word keys are not needed any more)
     __syncthreads();
     if (P.accumulate && nb > 0 && !P.must_normalize) {                                      // :1164-1170
         const double nd = (double)nb;
@@ -172,26 +201,25 @@ __global__ __launch_bounds__(BA_T) void k_bow_assemble(BowParams P)
             }
             for (; i < nb; i++) norm += P.l2 ? vals[i] * vals[i] : fabs(vals[i]);
             if (P.l2) norm = sqrt(norm);
-            reinterpret_cast<double*>(sorted)[0] = norm;
+            reinterpret_cast<double*>(scratch)[1] = norm;
         }
         __syncthreads();
-        const double norm = reinterpret_cast<double*>(sorted)[0];
+        const double norm = reinterpret_cast<double*>(scratch)[1];
         if (norm > 0.0) for (int i = tid; i < nb; i += BA_T) bow_val[i] = vals[i] / norm;
     }
-    if (tid == 0) P.nbow[frame] = nb;
+    if (tid == 0) counts[0] = nb;
     __syncthreads();
 
     // ---- FeatureVector: fv.addFeature(nid, i_feature) for the same features
-    for (int i = tid; i < n; i += BA_T) key[i] = wt[i] > 0 ? (((unsigned long long)node[i] << 32) | (unsigned)i) : ~0ull;
-    __syncthreads();
-    ba_sort(key, sorted, n, p2, tid);
-    for (int i = tid; i < m; i += BA_T) { flag[i] = (i == 0) || ((sorted[i] >> 32) != (sorted[i - 1] >> 32)); fv_feat[i] = (uint32_t)sorted[i]; }
-    __syncthreads();
-    for (int i = tid; i < m; i += BA_T) key[i] = (unsigned long long)flag[i];
+    if (!DUAL) {
+        for (int i = tid; i < p2; i += BA_T) sn[i] = (i < n && wt[i] > 0) ? (((unsigned long long)node[i] << 32) | (unsigned)i) : ~0ull;
+        ba_sort<1>(sn, sn, p2, tid);
+    }
+    for (int i = tid; i < m; i += BA_T) { const int h = (i == 0) || ((sn[i] >> 32) != (sn[i - 1] >> 32)); flag[i] = h; head[i] = h; fv_feat[i] = (uint32_t)sn[i]; }
     __syncthreads();
     const int nf = ba_exscan(flag, m, scratch, tid);
-    for (int i = tid; i < m; i += BA_T) if (key[i]) { fv_node[flag[i]] = (uint32_t)(sorted[i] >> 32); fv_off[flag[i]] = i; }
-    if (tid == 0) { fv_off[nf] = m; P.nfv[frame] = nf; }
+    for (int i = tid; i < m; i += BA_T) if (head[i]) { fv_node[flag[i]] = (uint32_t)(sn[i] >> 32); fv_off[flag[i]] = i; }
+    if (tid == 0) { fv_off[nf] = m; counts[4] = nf; }
 }
 
 // ------------------------------------------------------------------------------------------------ SearchByBoW
@@ -419,9 +447,9 @@ __global__ __launch_bounds__(256) void k_bow_triangulate_finish_batch(const TriP
 // call travels separately.
 struct BowWs {
     int frames = 0, cap = 0, last_frames = 0;
-    uint8_t* d_desc = nullptr; uint32_t *d_word = nullptr, *d_node = nullptr, *d_bow_id = nullptr, *d_fv_node = nullptr, *d_fv_feat = nullptr;
-    double *d_weight = nullptr, *d_bow_val = nullptr; int *d_nbow = nullptr, *d_nfv = nullptr, *d_fv_off = nullptr;
-    uint8_t* h_frame = nullptr; size_t h_frame_bytes = 0;      // pinned mirror of ONE frame's results (voc_fetch): [bow_val C | bow_id C | fv_node C | fv_feat C | fv_off C+1 | nbow, nfv]
+    uint8_t* d_desc = nullptr; uint32_t *d_word = nullptr, *d_node = nullptr; double* d_weight = nullptr;
+    uint8_t* d_out = nullptr; BowOut out = {};                 // every frame's results as one block (BowOut)
+    uint8_t* h_frame = nullptr; size_t h_frame_bytes = 0;      // pinned mirror of ONE frame's block (voc_fetch)
     uint8_t* h_desc = nullptr; size_t h_desc_bytes = 0;        // pinned mirror of the host-descriptor entry points' input
 };
 // The reference shares ONE vocabulary between the Tracking (Frame.cc:400), LocalMapping and LoopClosing threads (KeyFrame.cc:66) and its
@@ -431,22 +459,21 @@ struct BowWs {
 // under `m`.
 struct orbhip_voc {
     int k = 0, L = 0, scoring = 0, weighting = 0, nnodes = 0, nwords = 0, device = 0;
-    std::vector<int> child_start, child_ids, node_word; std::vector<uint8_t> node_desc; std::vector<double> node_weight;
-    int *d_child_start = nullptr, *d_child_ids = nullptr, *d_node_word = nullptr; uint8_t* d_node_desc = nullptr; double* d_node_weight = nullptr;
+    BowNode* d_nodes = nullptr; double* d_node_weight = nullptr;      // breadth-first numbering
     hipStream_t stream = nullptr;
     std::mutex m; BowWs host; std::map<const orbhip_ctx*, BowWs> per_ctx;
 };
 
 static void voc_free_ws(BowWs* w)
 {
-    void* ptrs[] = {w->d_desc, w->d_word, w->d_node, w->d_bow_id, w->d_fv_node, w->d_fv_feat, w->d_weight, w->d_bow_val, w->d_nbow, w->d_nfv, w->d_fv_off};
+    void* ptrs[] = {w->d_desc, w->d_word, w->d_node, w->d_weight, w->d_out};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (w->h_frame) (void)hipHostFree(w->h_frame);
     if (w->h_desc) (void)hipHostFree(w->h_desc);
     *w = BowWs();
 }
 
-#define BOW_MAX_FEATURES 7168          // 12 B of LDS per feature + 8 B per slot of the sorting network (8192 slots) in k_bow_assemble: 150 KB
+#define BOW_MAX_FEATURES 8192          // 8 B of LDS per feature + 8 B per slot of the sorting network (one key array at a time beyond BA_DUAL_MAX features) in k_bow_assemble: 128 KB
 
 static orbhip_status voc_ensure_ws(BowWs* w, int nframes, int cap, hipStream_t s)
 {
@@ -458,9 +485,12 @@ static orbhip_status voc_ensure_ws(BowWs* w, int nframes, int cap, hipStream_t s
     const size_t F = (size_t)nf, C = (size_t)nc;
     BOWCHK(orbhip_dmalloc((void**)&w->d_desc, F * C * 32 + 64));
     BOWCHK(orbhip_dmalloc((void**)&w->d_word, F * C * 4)); BOWCHK(orbhip_dmalloc((void**)&w->d_node, F * C * 4)); BOWCHK(orbhip_dmalloc((void**)&w->d_weight, F * C * 8));
-    BOWCHK(orbhip_dmalloc((void**)&w->d_bow_id, F * C * 4)); BOWCHK(orbhip_dmalloc((void**)&w->d_bow_val, F * C * 8));
-    BOWCHK(orbhip_dmalloc((void**)&w->d_fv_node, F * C * 4)); BOWCHK(orbhip_dmalloc((void**)&w->d_fv_feat, F * C * 4)); BOWCHK(orbhip_dmalloc((void**)&w->d_fv_off, F * (C + 1) * 4));
-    BOWCHK(orbhip_dmalloc((void**)&w->d_nbow, F * 4)); BOWCHK(orbhip_dmalloc((void**)&w->d_nfv, F * 4));
+    auto up = [](size_t b) { return (b + 15) & ~(size_t)15; };      // 16-byte sections: the copy kernel moves 16 bytes per lane
+    BowOut o; memset(&o, 0, sizeof o);
+    o.o_id = (int)up(C * 8); o.o_fn = (int)up(o.o_id + C * 4); o.o_ff = (int)up(o.o_fn + C * 4); o.o_fo = (int)up(o.o_ff + C * 4); o.o_cnt = (int)up(o.o_fo + (C + 1) * 4);
+    o.stride = (long long)((o.o_cnt + 32 + 255) & ~255);
+    BOWCHK(orbhip_dmalloc((void**)&w->d_out, F * (size_t)o.stride));
+    o.base = w->d_out; w->out = o;
     w->frames = nf; w->cap = nc;
     return ORBHIP_OK;
 }
@@ -471,15 +501,18 @@ static orbhip_status voc_run(orbhip_voc* v, BowWs* w, const uint8_t* d_desc, lon
 {
     BowParams P; memset(&P, 0, sizeof P);
     P.desc = d_desc; P.desc_frame_stride = frame_stride; P.nfeat = d_nfeat; P.nfeat_fixed = nfeat_fixed; P.cap = w->cap; P.lcap = nfeat_max;
-    P.child_start = v->d_child_start; P.child_ids = v->d_child_ids; P.node_desc = v->d_node_desc; P.node_weight = v->d_node_weight; P.node_word = v->d_node_word;
+    P.nodes = v->d_nodes; P.node_weight = v->d_node_weight;
     P.L = v->L; P.levelsup = levelsup;
     P.accumulate = (v->weighting == 0 || v->weighting == 1);                     // TF_IDF, TF (:1142) vs IDF, BINARY (:1173)
     P.must_normalize = v->scoring != 5; P.l2 = v->scoring == 1;                    // ScoringObject.h:73-90
     P.word = w->d_word; P.weight = w->d_weight; P.node = w->d_node;
-    P.bow_id = w->d_bow_id; P.bow_val = w->d_bow_val; P.nbow = w->d_nbow; P.fv_node = w->d_fv_node; P.fv_off = w->d_fv_off; P.fv_feat = w->d_fv_feat; P.nfv = w->d_nfv;
+    P.out = w->out;
     if (nfeat_max <= 0 || nframes <= 0) return ORBHIP_OK;
     hipLaunchKernelGGL(k_bow_descend, dim3((nfeat_max + 255) / 256, nframes, 1), dim3(256, 1, 1), 0, s, P);
-    if (assemble) hipLaunchKernelGGL(k_bow_assemble, dim3(nframes, 1, 1), dim3(BA_T, 1, 1), (size_t)nfeat_max * 12 + (size_t)ba_pow2(nfeat_max) * 8 + 64, s, P);
+    if (assemble) {
+        if (nfeat_max <= BA_DUAL_MAX) hipLaunchKernelGGL(k_bow_assemble<true>, dim3(nframes, 1, 1), dim3(BA_T, 1, 1), ba_lds_bytes(nfeat_max), s, P);
+        else hipLaunchKernelGGL(k_bow_assemble<false>, dim3(nframes, 1, 1), dim3(BA_T, 1, 1), ba_lds_bytes(nfeat_max), s, P);
+    }
     BOWCHK(hipGetLastError());
     w->last_frames = nframes;
     return ORBHIP_OK;
@@ -511,7 +544,7 @@ extern "C" void orbhip_voc_destroy(orbhip_voc* v)
     (void)hipDeviceSynchronize();                                       // per-context workspaces were used on the extractors' streams
     voc_free_ws(&v->host);
     for (auto& kv : v->per_ctx) voc_free_ws(&kv.second);
-    void* ptrs[] = {v->d_child_start, v->d_child_ids, v->d_node_word, v->d_node_desc, v->d_node_weight};
+    void* ptrs[] = {v->d_nodes, v->d_node_weight};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (v->stream) (void)hipStreamDestroy(v->stream);
     delete v;
@@ -550,25 +583,30 @@ extern "C" orbhip_status orbhip_voc_load_text(orbhip_voc** out, const char* path
     const int nn = (int)parent.size();
     orbhip_voc* v = new orbhip_voc();
     v->k = k; v->L = L; v->scoring = n1; v->weighting = n2; v->nnodes = nn; v->nwords = nwords; v->device = device;
-    v->child_start.assign(nn + 1, 0);
-    for (int i = 0; i < nn; i++) v->child_start[i + 1] = v->child_start[i] + nchild[i];
-    v->child_ids.assign(std::max(nn - 1, 1), 0);
-    { std::vector<int> fill(v->child_start.begin(), v->child_start.end() - 1); for (int i = 1; i < nn; i++) v->child_ids[fill[parent[i]]++] = i; }   // children in file order
-    v->node_word = word; v->node_desc = desc; v->node_weight = weight;
+    std::vector<int> child_start(nn + 1, 0), child_ids(std::max(nn - 1, 1), 0);
+    for (int i = 0; i < nn; i++) child_start[i + 1] = child_start[i] + nchild[i];
+    { std::vector<int> fill(child_start.begin(), child_start.end() - 1); for (int i = 1; i < nn; i++) child_ids[fill[parent[i]]++] = i; }   // children in file order
     for (int i = 0; i < nn; i++)                                     // a leaf flag on an inner node / a childless inner node would make the descent undefined
         if ((word[i] >= 0) != (nchild[i] == 0) && i != 0) { delete v; return orbhip_set_error(ORBHIP_ERR_INVALID, "vocabulary node %d: leaf flag and children disagree", i); }
+    // breadth-first numbering: the children of a node become neighbours, in the file's child order (parents precede their children in the file, so every
+    // node hangs below the root and is reached)
+    std::vector<int> order(1, 0); order.reserve(nn);
+    std::vector<BowNode> nodes(nn); std::vector<double> wdev(nn);
+    for (size_t q = 0; q < order.size(); q++) {
+        const int id = order[q];
+        BowNode& r = nodes[q];
+        memcpy(&r.da, &desc[(size_t)id * 32], 16); memcpy(&r.db, &desc[(size_t)id * 32 + 16], 16);
+        r.first_child = (uint32_t)order.size(); r.nchildren = (uint32_t)nchild[id]; r.id = (uint32_t)id; r.word = (uint32_t)word[id];
+        wdev[q] = weight[id];
+        for (int c = child_start[id]; c < child_start[id + 1]; c++) order.push_back(child_ids[c]);
+    }
+    if ((int)order.size() != nn) { delete v; return orbhip_set_error(ORBHIP_ERR_INVALID, "vocabulary: %d of %d nodes hang below the root", (int)order.size(), nn); }
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = orbhip_dmalloc((void**)&v->d_child_start, (size_t)(nn + 1) * 4);
-    if (e == hipSuccess) e = orbhip_dmalloc((void**)&v->d_child_ids, v->child_ids.size() * 4);
-    if (e == hipSuccess) e = orbhip_dmalloc((void**)&v->d_node_word, (size_t)nn * 4);
-    if (e == hipSuccess) e = orbhip_dmalloc((void**)&v->d_node_desc, (size_t)nn * 32);
+    if (e == hipSuccess) e = orbhip_dmalloc((void**)&v->d_nodes, (size_t)nn * sizeof(BowNode));
     if (e == hipSuccess) e = orbhip_dmalloc((void**)&v->d_node_weight, (size_t)nn * 8);
-    if (e == hipSuccess) e = hipMemcpy(v->d_child_start, v->child_start.data(), (size_t)(nn + 1) * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(v->d_child_ids, v->child_ids.data(), v->child_ids.size() * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(v->d_node_word, v->node_word.data(), (size_t)nn * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(v->d_node_desc, v->node_desc.data(), (size_t)nn * 32, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(v->d_node_weight, v->node_weight.data(), (size_t)nn * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(v->d_nodes, nodes.data(), (size_t)nn * sizeof(BowNode), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(v->d_node_weight, wdev.data(), (size_t)nn * 8, hipMemcpyHostToDevice);
     if (e != hipSuccess) { orbhip_voc_destroy(v); return orbhip_set_error(ORBHIP_ERR_HIP, "vocabulary upload failed: %s", hipGetErrorString(e)); }
     { std::lock_guard<std::mutex> all(g_vocs_m); g_vocs.push_back(v); }
     *out = v;
@@ -624,35 +662,28 @@ extern "C" orbhip_status orbhip_voc_transform_features(orbhip_voc* v, const uint
     return st;
 }
 
-// One frame's bag of words to the host: every array travels at its full row capacity into a pinned mirror (copy kernels on the stream, no DMA hand-over, no
-// pageable staging) behind ONE synchronisation - the counts are not needed before the copies are issued - and is cut to size on the host.
+// One frame's bag of words to the host: its block travels whole (ONE copy kernel on the stream, at the arrays' full row capacity - the counts are not
+// known before the copy is issued) into a pinned mirror behind ONE synchronisation and is cut to size on the host.
 static orbhip_status voc_fetch(BowWs* w, int frame, hipStream_t s, uint32_t* bow_id, double* bow_val, int* nbow, uint32_t* fv_node, int32_t* fv_off, uint32_t* fv_feat, int* nfv)
 {
-    const size_t C = (size_t)w->cap;
-    auto up = [](size_t b) { return (b + 15) & ~(size_t)15; };      // 16-byte sections: the copy kernel moves 16 bytes per lane
-    const size_t o_val = 0, o_id = up(o_val + C * 8), o_fn = up(o_id + C * 4), o_ff = up(o_fn + C * 4), o_fo = up(o_ff + C * 4), o_cnt = up(o_fo + (C + 1) * 4), total = o_cnt + 32;
+    const size_t C = (size_t)w->cap, total = (size_t)w->out.stride;
     if (w->h_frame_bytes < total) {
         if (w->h_frame) (void)hipHostFree(w->h_frame);
         w->h_frame = nullptr; w->h_frame_bytes = 0;
         BOWCHK(hipHostMalloc((void**)&w->h_frame, total + 64, hipHostMallocDefault)); w->h_frame_bytes = total;
     }
     uint8_t* h = w->h_frame;
-    BOWCHK(orbhip_copy_async(h + o_cnt, w->d_nbow + frame, 4, hipMemcpyDeviceToHost, s));
-    BOWCHK(orbhip_copy_async(h + o_cnt + 16, w->d_nfv + frame, 4, hipMemcpyDeviceToHost, s));
-    if (bow_val) BOWCHK(orbhip_copy_async(h + o_val, w->d_bow_val + frame * C, C * 8, hipMemcpyDeviceToHost, s));
-    if (bow_id) BOWCHK(orbhip_copy_async(h + o_id, w->d_bow_id + frame * C, C * 4, hipMemcpyDeviceToHost, s));
-    if (fv_node) BOWCHK(orbhip_copy_async(h + o_fn, w->d_fv_node + frame * C, C * 4, hipMemcpyDeviceToHost, s));
-    if (fv_feat) BOWCHK(orbhip_copy_async(h + o_ff, w->d_fv_feat + frame * C, C * 4, hipMemcpyDeviceToHost, s));
-    if (fv_off || fv_feat) BOWCHK(orbhip_copy_async(h + o_fo, w->d_fv_off + frame * (C + 1), (C + 1) * 4, hipMemcpyDeviceToHost, s));
+    BOWCHK(orbhip_copy_async(h, w->d_out + (size_t)frame * total, total, hipMemcpyDeviceToHost, s));
     BOWCHK(hipStreamSynchronize(s));
-    int cnt[2]; memcpy(&cnt[0], h + o_cnt, 4); memcpy(&cnt[1], h + o_cnt + 16, 4);
+    const BowOut& o = w->out;
+    int cnt[2]; memcpy(&cnt[0], h + o.o_cnt, 4); memcpy(&cnt[1], h + o.o_cnt + 16, 4);
     const int nb = cnt[0], nf = cnt[1];
     if (nb < 0 || nf < 0 || (size_t)nb > C || (size_t)nf > C) return orbhip_set_error(ORBHIP_ERR_HIP, "bag of words: counts %d / %d outside the workspace's capacity %zu", nb, nf, C);
-    if (nb > 0 && bow_id) memcpy(bow_id, h + o_id, (size_t)nb * 4);
-    if (nb > 0 && bow_val) memcpy(bow_val, h + o_val, (size_t)nb * 8);
-    if (nf > 0 && fv_node) memcpy(fv_node, h + o_fn, (size_t)nf * 4);
-    if (fv_off) memcpy(fv_off, h + o_fo, (size_t)(nf + 1) * 4);
-    if (fv_feat) { int m = 0; memcpy(&m, h + o_fo + (size_t)nf * 4, 4); if (m > 0 && (size_t)m <= C) memcpy(fv_feat, h + o_ff, (size_t)m * 4); }
+    if (nb > 0 && bow_id) memcpy(bow_id, h + o.o_id, (size_t)nb * 4);
+    if (nb > 0 && bow_val) memcpy(bow_val, h, (size_t)nb * 8);
+    if (nf > 0 && fv_node) memcpy(fv_node, h + o.o_fn, (size_t)nf * 4);
+    if (fv_off) memcpy(fv_off, h + o.o_fo, (size_t)(nf + 1) * 4);
+    if (fv_feat) { int m = 0; memcpy(&m, h + o.o_fo + (size_t)nf * 4, 4); if (m > 0 && (size_t)m <= C) memcpy(fv_feat, h + o.o_ff, (size_t)m * 4); }
     if (nbow) *nbow = nb;
     if (nfv) *nfv = nf;
     return ORBHIP_OK;
@@ -688,7 +719,7 @@ extern "C" orbhip_status orbhip_compute_bow(orbhip_ctx* ctx, orbhip_voc* v, int 
     BowWs* w = nullptr;
     { std::lock_guard<std::mutex> lock(v->m); w = &v->per_ctx[ctx]; }             // std::map nodes do not move: the pointer outlives the lock
     orbhip_status st = voc_ensure_ws(w, nimg, cap, s); if (st != ORBHIP_OK) return st;
-    if (v->nwords == 0) { BOWCHK(hipMemsetAsync(w->d_nbow, 0, (size_t)nimg * 4, s)); BOWCHK(hipMemsetAsync(w->d_nfv, 0, (size_t)nimg * 4, s)); BOWCHK(hipMemsetAsync(w->d_fv_off, 0, (size_t)nimg * (w->cap + 1) * 4, s)); w->last_frames = nimg; return ORBHIP_OK; }
+    if (v->nwords == 0) { BOWCHK(hipMemsetAsync(w->d_out, 0, (size_t)nimg * (size_t)w->out.stride, s)); w->last_frames = nimg; return ORBHIP_OK; }
     return voc_run(v, w, d_desc, (long long)cap * 32, d_n, 0, nimg, cap, levelsup, true, s);     // on the extractor's stream: ordered after k_describe
 }
 
