@@ -6,9 +6,9 @@
 // as called by Frame::ComputeBoW (Frame.cc:395-402: transform(vCurrentDesc, mBowVec, mFeatVec, 4)).
 //
 // Device layout: the k-ary tree renumbered breadth first, so that the children of a node are neighbours (child order kept: the first minimum wins), one
-// 48-byte record per node: the 32-byte descriptor + {first child, number of children, the file's node id, word id}.  A child's record carries the pointer to
-// ITS children, so a level of the descent is ONE dependent fetch (the k child records), not three (child range -> child ids -> descriptors).  f64 weights apart.
-// ORBvoc.txt (k = 10, L = 6) is 1.1 M nodes = 52 MB of records: resident in HBM, hot upper levels in L2.
+// 64-byte record per node: the 32-byte descriptor + {first child, number of children, the file's node id, word id} + the f64 weight.  A child's record carries
+// the pointer to ITS children and its weight, so a level of the descent is ONE dependent fetch (the k child records), not three (child range -> child ids ->
+// descriptors), and nothing is fetched after the leaf.  ORBvoc.txt (k = 10, L = 6) is 1.1 M nodes = 71 MB of records: resident in HBM, hot upper levels in L2.
 //  k_bow_descend   one thread per feature walks the tree (<= L dependent steps, k Hamming distances each, strict '<' so the
 //                  first minimum wins) -> word id, weight, node id `levelsup` levels above the leaf.
 //  k_bow_assemble  one workgroup per frame turns the per-feature triples into the two std::map's of the reference, flattened
@@ -35,13 +35,13 @@
 
 #define BOWCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return orbhip_set_error(ORBHIP_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 
-struct BowNode { uint4 da, db; uint32_t first_child, nchildren, id, word; };      // 48 bytes
+struct BowNode { uint4 da, db; uint32_t first_child, nchildren, id, word; double weight; double pad; };      // 64 bytes
 struct BowOut { uint8_t* base; long long stride; int o_id, o_fn, o_ff, o_fo, o_cnt; };        // a frame's results: [bow_val C f64 | bow_id C | fv_node C | fv_feat C | fv_off C+1 | nbow, -, -, -, nfv] at base + frame * stride
 
 struct BowParams {
     const uint8_t* desc; long long desc_frame_stride;        // features of frame f at desc + f*stride, 32 B each
     const int* nfeat; int nfeat_fixed; int cap;                // per-frame count (device) or one fixed count; output stride
-    const BowNode* nodes; const double* node_weight;           // breadth-first numbering, root = 0
+    const BowNode* nodes;                                      // breadth-first numbering, root = 0
     int L, levelsup, accumulate, must_normalize, l2;
     uint32_t* word; double* weight; uint32_t* node;            // [frame][cap]
     BowOut out;
@@ -51,7 +51,7 @@ struct BowParams {
 __device__ __forceinline__ int bow_count(const BowParams& P, int frame) { return min(P.nfeat ? P.nfeat[frame] : P.nfeat_fixed, P.cap); }
 
 // transform(feature, word_id, weight, nid, levelsup)  (TemplatedVocabulary.h:1218-1262)
-#define BD_FETCH 5                     // child records in flight per step of the scan over a node's children
+#define BD_FETCH 10                    // child records in flight per step of the scan over a node's children: ORBvoc's k in ONE round trip per level
 __global__ __launch_bounds__(256) void k_bow_descend(BowParams P)
 {
     const int frame = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
@@ -60,35 +60,37 @@ __global__ __launch_bounds__(256) void k_bow_descend(BowParams P)
     const uint4 fa = f4[0], fb = f4[1];
     const int nid_level = P.L - P.levelsup;
     const uint4* rec = reinterpret_cast<const uint4*>(P.nodes);
-    int level = 0; uint32_t nid = 0, final_dev = 0;
+    int level = 0; uint32_t nid = 0;
     uint4 cur = rec[2];                                                                  // the root's {first child, count, id, word}
+    uint2 curw; curw.x = 0u; curw.y = 0u;                                                   // the weight's bits
     do {
         ++level;
-        int best = 0x7fffffff; uint4 best_info = cur; uint32_t best_dev = 0;
+        int best = 0x7fffffff; uint4 best_info = cur; uint2 best_w = curw;
         const uint32_t a = cur.x, cnt = cur.y;
         for (uint32_t c = 0; c < cnt; c += BD_FETCH) {
-            uint4 ra[BD_FETCH], rb[BD_FETCH], ri[BD_FETCH];
+            uint4 ra[BD_FETCH], rb[BD_FETCH], ri[BD_FETCH]; uint2 rw[BD_FETCH];
 #pragma unroll
             for (int u = 0; u < BD_FETCH; u++) {
-                const uint32_t dev = min(a + c + u, a + cnt - 1);                        // (past the end: the last child again, never compared)
-                ra[u] = rec[(size_t)dev * 3]; rb[u] = rec[(size_t)dev * 3 + 1]; ri[u] = rec[(size_t)dev * 3 + 2];
+                const size_t dev = (size_t)min(a + c + u, a + cnt - 1) * 4;              // (past the end: the last child again, never compared)
+                ra[u] = rec[dev]; rb[u] = rec[dev + 1]; ri[u] = rec[dev + 2]; rw[u] = *reinterpret_cast<const uint2*>(rec + dev + 3);
             }
 #pragma unroll
             for (int u = 0; u < BD_FETCH; u++) {
                 const int d = __popc(fa.x ^ ra[u].x) + __popc(fa.y ^ ra[u].y) + __popc(fa.z ^ ra[u].z) + __popc(fa.w ^ ra[u].w) +
                               __popc(fb.x ^ rb[u].x) + __popc(fb.y ^ rb[u].y) + __popc(fb.z ^ rb[u].z) + __popc(fb.w ^ rb[u].w);    // FORB::distance
-                if (c + u < cnt && d < best) { best = d; best_info = ri[u]; best_dev = a + c + u; }    // strict: first minimum wins (:1243-1247)
+                if (c + u < cnt && d < best) { best = d; best_info = ri[u]; best_w = rw[u]; }          // strict: first minimum wins (:1243-1247)
             }
         }
-        cur = best_info; final_dev = best_dev;
+        cur = best_info; curw = best_w;
         if (level == nid_level) nid = cur.z;
     } while (cur.y > 0);                                                                  // !isLeaf()
     const long long o = (long long)frame * P.cap + i;
-    P.word[o] = cur.w; P.weight[o] = P.node_weight[final_dev]; P.node[o] = nid;
+    P.word[o] = cur.w; reinterpret_cast<uint2*>(P.weight)[o] = curw; P.node[o] = nid;
 }
 
-#define BA_T 256
-// in-place exclusive scan of a[0..n) by the whole workgroup, returns the total (scratch: BA_T/64 + 1 ints)
+#define BA_T 1024                      // one workgroup of 16 wavefronts per frame: a single frame's latency is this kernel's length
+#define BA_HEADS 8                     // BOW_MAX_FEATURES / BA_T: entries one thread can own
+// in-place exclusive scan of a[0..n) by the whole workgroup, returns the total (scratch: BA_T/64 ints)
 __device__ __forceinline__ int ba_exscan(int* a, int n, int* scratch, int tid)
 {
     const int lane = tid & 63, wave = tid >> 6;
@@ -137,7 +139,31 @@ template <int NARR> __device__ __forceinline__ void ba_sort(unsigned long long* 
 }
 __host__ __device__ inline int ba_pow2(int n) { int p = 2; while (p < n) p <<= 1; return p; }
 #define BA_DUAL_MAX 4096               // features up to which both key arrays fit the LDS side by side (16 B per slot of the network + 8 B per feature: 96 KB)
-__host__ __device__ inline size_t ba_lds_bytes(int lcap) { return (size_t)ba_pow2(lcap) * (lcap <= BA_DUAL_MAX ? 16 : 8) + (size_t)lcap * 8 + 64; }
+__host__ __device__ inline size_t ba_lds_bytes(int lcap) { return (size_t)ba_pow2(lcap) * (lcap <= BA_DUAL_MAX ? 16 : 8) + (size_t)lcap * 8 + 128; }
+
+// lane l's f64 (l uniform) as seen by every lane: two v_readlane_b32, independent of whatever is done with the value
+__device__ __forceinline__ double ba_lane_f64(double v, int l)
+{
+    unsigned long long b; memcpy(&b, &v, 8);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+    b = ((unsigned long long)hi << 32) | lo; memcpy(&v, &b, 8);
+    return v;
+}
+
+// sum of |v| (or v * v) over vals[0 .. nb) in index order, by one wavefront (every lane ends up with the sum)
+template <bool L2> __device__ __forceinline__ double ba_norm(const double* vals, int nb, int lane)
+{
+    double norm = 0.0;
+    for (int c = 0; c < nb; c += 64) {
+        const double part = c + lane < nb ? vals[c + lane] : 0.0;
+        const int lim = min(64, nb - c);
+        if (lim == 64) {
+#pragma unroll
+            for (int l = 0; l < 64; l++) { const double x = ba_lane_f64(part, l); norm += L2 ? x * x : fabs(x); }
+        } else for (int l = 0; l < lim; l++) { const double x = ba_lane_f64(part, l); norm += L2 ? x * x : fabs(x); }
+    }
+    return norm;
+}
 
 template <bool DUAL> __global__ __launch_bounds__(BA_T) void k_bow_assemble(BowParams P)
 {
@@ -149,7 +175,7 @@ template <bool DUAL> __global__ __launch_bounds__(BA_T) void k_bow_assemble(BowP
     unsigned long long* sn = DUAL ? lds64 + p2 : lds64;    // [p2] (node << 32 | feature)   (one array after the other when both do not fit)
     int* flag = reinterpret_cast<int*>(lds64 + (DUAL ? 2 : 1) * (size_t)p2);   // [lcap]
     int* head = flag + lcap;                               // [lcap]
-    int* scratch = head + lcap;                            // [8]
+    int* scratch = head + lcap;                            // [BA_T / 64] + the norm
     double* vals = reinterpret_cast<double*>(sw);
     const uint32_t* word = P.word + (long long)frame * cap; const double* wt = P.weight + (long long)frame * cap; const uint32_t* node = P.node + (long long)frame * cap;
     uint8_t* ob = P.out.base + (long long)frame * P.out.stride;
@@ -172,41 +198,45 @@ template <bool DUAL> __global__ __launch_bounds__(BA_T) void k_bow_assemble(BowP
     for (int i = tid; i < m; i += BA_T) { const int h = (i == 0) || ((sw[i] >> 32) != (sw[i - 1] >> 32)); flag[i] = h; head[i] = h; }
     __syncthreads();
     const int nb = ba_exscan(flag, m, scratch, tid);
-    for (int i = tid; i < m; i += BA_T) {
-        if (!head[i]) continue;
-        const uint32_t w = (uint32_t)(sw[i] >> 32);
-        double v = wt[(uint32_t)sw[i]];
-        if (P.accumulate) for (int j = i + 1; j < m && (uint32_t)(sw[j] >> 32) == w; j++) v += wt[(uint32_t)sw[j]];   // `vit->second += v`
-        bow_id[flag[i]] = w; bow_val[flag[i]] = v;                                         // addIfNotExist keeps the first
+    double hv[BA_HEADS]; int hp[BA_HEADS];                                                  // the entries this thread owns: value, position
+#pragma unroll
+    for (int r = 0; r < BA_HEADS; r++) {
+        const int i = tid + r * BA_T;
+        hp[r] = -1; hv[r] = 0.0;
+        if (i < m && head[i]) {
+            const uint32_t w = (uint32_t)(sw[i] >> 32);
+            double v = wt[(uint32_t)sw[i]];
+            if (P.accumulate) for (int j = i + 1; j < m && (uint32_t)(sw[j] >> 32) == w; j++) v += wt[(uint32_t)sw[j]];   // `vit->second += v`
+            hp[r] = flag[i]; hv[r] = v; bow_id[flag[i]] = w;                                 // addIfNotExist keeps the first
+        }
     }
-    __syncthreads();
-    for (int i = tid; i < nb; i += BA_T) vals[i] = bow_val[i];                               // (the word keys are not needed any more)
-    __syncthreads();
+    __syncthreads();                                                                        // (the word keys are not needed any more: their LDS takes the values)
     if (P.accumulate && nb > 0 && !P.must_normalize) {                                      // :1164-1170
         const double nd = (double)nb;
-        for (int i = tid; i < nb; i += BA_T) { vals[i] = vals[i] / nd; bow_val[i] = vals[i]; }
+#pragma unroll
+        for (int r = 0; r < BA_HEADS; r++) hv[r] = hv[r] / nd;
     }
     if (P.must_normalize) {                                                                 // BowVector::normalize
-        if (tid == 0) {
-            // one lane, word order: the order of the f64 additions is part of the result.  Eight values are fetched at a time (independent LDS reads in flight)
-            // and then added one after the other - as written first, every addition waited for its own LDS read: 0.1 ms of a single frame's 0.3.
-            double norm = 0.0;
-            int i = 0;
-            for (; i + 8 <= nb; i += 8) {
-                double v[8];
 #pragma unroll
-                for (int k = 0; k < 8; k++) v[k] = vals[i + k];
-#pragma unroll
-                for (int k = 0; k < 8; k++) norm += P.l2 ? v[k] * v[k] : fabs(v[k]);
-            }
-            for (; i < nb; i++) norm += P.l2 ? vals[i] * vals[i] : fabs(vals[i]);
+        for (int r = 0; r < BA_HEADS; r++) if (hp[r] >= 0) vals[hp[r]] = hv[r];
+        __syncthreads();
+        if (tid < 64) {
+            // word order, one addition after the other: the order of the f64 additions is part of the result.  The wavefront reads 64 values with ONE LDS
+            // instruction, then every lane adds them up in order, each taken from its lane by v_readlane: the chain of additions never waits for memory.
+            // (One lane reading the values itself, eight at a time: 0.012 ms of a 1000-feature frame's 0.057.)
+            double norm = P.l2 ? ba_norm<true>(vals, nb, tid) : ba_norm<false>(vals, nb, tid);
             if (P.l2) norm = sqrt(norm);
-            reinterpret_cast<double*>(scratch)[1] = norm;
+            if (tid == 0) reinterpret_cast<double*>(scratch)[8] = norm;
         }
         __syncthreads();
-        const double norm = reinterpret_cast<double*>(scratch)[1];
-        if (norm > 0.0) for (int i = tid; i < nb; i += BA_T) bow_val[i] = vals[i] / norm;
+        const double norm = reinterpret_cast<double*>(scratch)[8];
+        if (norm > 0.0) {
+#pragma unroll
+            for (int r = 0; r < BA_HEADS; r++) hv[r] = hv[r] / norm;
+        }
     }
+#pragma unroll
+    for (int r = 0; r < BA_HEADS; r++) if (hp[r] >= 0) bow_val[hp[r]] = hv[r];
     if (tid == 0) counts[0] = nb;
     __syncthreads();
 
@@ -459,7 +489,7 @@ struct BowWs {
 // under `m`.
 struct orbhip_voc {
     int k = 0, L = 0, scoring = 0, weighting = 0, nnodes = 0, nwords = 0, device = 0;
-    BowNode* d_nodes = nullptr; double* d_node_weight = nullptr;      // breadth-first numbering
+    BowNode* d_nodes = nullptr;      // breadth-first numbering
     hipStream_t stream = nullptr;
     std::mutex m; BowWs host; std::map<const orbhip_ctx*, BowWs> per_ctx;
 };
@@ -501,7 +531,7 @@ static orbhip_status voc_run(orbhip_voc* v, BowWs* w, const uint8_t* d_desc, lon
 {
     BowParams P; memset(&P, 0, sizeof P);
     P.desc = d_desc; P.desc_frame_stride = frame_stride; P.nfeat = d_nfeat; P.nfeat_fixed = nfeat_fixed; P.cap = w->cap; P.lcap = nfeat_max;
-    P.nodes = v->d_nodes; P.node_weight = v->d_node_weight;
+    P.nodes = v->d_nodes;
     P.L = v->L; P.levelsup = levelsup;
     P.accumulate = (v->weighting == 0 || v->weighting == 1);                     // TF_IDF, TF (:1142) vs IDF, BINARY (:1173)
     P.must_normalize = v->scoring != 5; P.l2 = v->scoring == 1;                    // ScoringObject.h:73-90
@@ -544,7 +574,7 @@ extern "C" void orbhip_voc_destroy(orbhip_voc* v)
     (void)hipDeviceSynchronize();                                       // per-context workspaces were used on the extractors' streams
     voc_free_ws(&v->host);
     for (auto& kv : v->per_ctx) voc_free_ws(&kv.second);
-    void* ptrs[] = {v->d_nodes, v->d_node_weight};
+    void* ptrs[] = {v->d_nodes};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (v->stream) (void)hipStreamDestroy(v->stream);
     delete v;
@@ -591,22 +621,20 @@ extern "C" orbhip_status orbhip_voc_load_text(orbhip_voc** out, const char* path
     // breadth-first numbering: the children of a node become neighbours, in the file's child order (parents precede their children in the file, so every
     // node hangs below the root and is reached)
     std::vector<int> order(1, 0); order.reserve(nn);
-    std::vector<BowNode> nodes(nn); std::vector<double> wdev(nn);
+    std::vector<BowNode> nodes(nn);
     for (size_t q = 0; q < order.size(); q++) {
         const int id = order[q];
         BowNode& r = nodes[q];
         memcpy(&r.da, &desc[(size_t)id * 32], 16); memcpy(&r.db, &desc[(size_t)id * 32 + 16], 16);
         r.first_child = (uint32_t)order.size(); r.nchildren = (uint32_t)nchild[id]; r.id = (uint32_t)id; r.word = (uint32_t)word[id];
-        wdev[q] = weight[id];
+        r.weight = weight[id]; r.pad = 0.0;
         for (int c = child_start[id]; c < child_start[id + 1]; c++) order.push_back(child_ids[c]);
     }
     if ((int)order.size() != nn) { delete v; return orbhip_set_error(ORBHIP_ERR_INVALID, "vocabulary: %d of %d nodes hang below the root", (int)order.size(), nn); }
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = orbhip_dmalloc((void**)&v->d_nodes, (size_t)nn * sizeof(BowNode));
-    if (e == hipSuccess) e = orbhip_dmalloc((void**)&v->d_node_weight, (size_t)nn * 8);
     if (e == hipSuccess) e = hipMemcpy(v->d_nodes, nodes.data(), (size_t)nn * sizeof(BowNode), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(v->d_node_weight, wdev.data(), (size_t)nn * 8, hipMemcpyHostToDevice);
     if (e != hipSuccess) { orbhip_voc_destroy(v); return orbhip_set_error(ORBHIP_ERR_HIP, "vocabulary upload failed: %s", hipGetErrorString(e)); }
     { std::lock_guard<std::mutex> all(g_vocs_m); g_vocs.push_back(v); }
     *out = v;
