@@ -42,7 +42,7 @@ struct BowParams {
     const uint8_t* desc; long long desc_frame_stride;        // features of frame f at desc + f*stride, 32 B each
     const int* nfeat; int nfeat_fixed; int cap;                // per-frame count (device) or one fixed count; output stride
     const BowNode* nodes;                                      // breadth-first numbering, root = 0
-    int L, levelsup, accumulate, must_normalize, l2;
+    int L, levelsup, accumulate, must_normalize, l2, stop;
     uint32_t* word; double* weight; uint32_t* node;            // [frame][cap]
     BowOut out;
     int lcap;                          // features the LDS arrays of k_bow_assemble are carved for (>= every frame's count, <= cap)
@@ -51,45 +51,51 @@ struct BowParams {
 __device__ __forceinline__ int bow_count(const BowParams& P, int frame) { return min(P.nfeat ? P.nfeat[frame] : P.nfeat_fixed, P.cap); }
 
 // transform(feature, word_id, weight, nid, levelsup)  (TemplatedVocabulary.h:1218-1262)
-#define BD_FETCH 10                    // child records in flight per step of the scan over a node's children: ORBvoc's k in ONE round trip per level
-__global__ __launch_bounds__(256) void k_bow_descend(BowParams P)
+// Sixteen lanes per feature (a DPP row), one child record per lane: a level is ONE round trip in which every lane fetches 64 contiguous bytes, the sixteen
+// distances are reduced to (distance << 8 | child index) by four row exchanges, and the winner's lane hands on where its children are.  (One thread per
+// feature fetched its k records itself: 40 fetch instructions per level from the FOUR compute units a 1000-feature frame occupied - 0.020 - 0.030 ms of
+// texture-address time; with a wavefront per four features the frame spreads over 250 units.)
+#define BD_G 16
+__global__ __launch_bounds__(64) void k_bow_descend(BowParams P)
 {
-    const int frame = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const int frame = blockIdx.y, l16 = threadIdx.x & (BD_G - 1), i = blockIdx.x * (64 / BD_G) + (threadIdx.x / BD_G);
     if (i >= bow_count(P, frame)) return;
     const uint4* f4 = reinterpret_cast<const uint4*>(P.desc + (long long)frame * P.desc_frame_stride + (long long)i * 32);
     const uint4 fa = f4[0], fb = f4[1];
     const int nid_level = P.L - P.levelsup;
     const uint4* rec = reinterpret_cast<const uint4*>(P.nodes);
-    int level = 0; uint32_t nid = 0;
-    uint4 cur = rec[2];                                                                  // the root's {first child, count, id, word}
-    uint2 curw; curw.x = 0u; curw.y = 0u;                                                   // the weight's bits
-    do {
+    const uint4 root = rec[2];                                                           // {first child, count, id, word}
+    uint32_t a = root.x, cnt = root.y, nid = 0;
+    int level = 0, win = 0;
+    uint4 binfo = root; uint2 bw; bw.x = 0u; bw.y = 0u;                                  // this lane's best child: its record's tail, the weight's bits
+    while (cnt > 0) {                                                                    // !isLeaf()   (a vocabulary without words never gets here: the callers return before)
         ++level;
-        int best = 0x7fffffff; uint4 best_info = cur; uint2 best_w = curw;
-        const uint32_t a = cur.x, cnt = cur.y;
-        for (uint32_t c = 0; c < cnt; c += BD_FETCH) {
-            uint4 ra[BD_FETCH], rb[BD_FETCH], ri[BD_FETCH]; uint2 rw[BD_FETCH];
-#pragma unroll
-            for (int u = 0; u < BD_FETCH; u++) {
-                const size_t dev = (size_t)min(a + c + u, a + cnt - 1) * 4;              // (past the end: the last child again, never compared)
-                ra[u] = rec[dev]; rb[u] = rec[dev + 1]; ri[u] = rec[dev + 2]; rw[u] = *reinterpret_cast<const uint2*>(rec + dev + 3);
-            }
-#pragma unroll
-            for (int u = 0; u < BD_FETCH; u++) {
-                const int d = __popc(fa.x ^ ra[u].x) + __popc(fa.y ^ ra[u].y) + __popc(fa.z ^ ra[u].z) + __popc(fa.w ^ ra[u].w) +
-                              __popc(fb.x ^ rb[u].x) + __popc(fb.y ^ rb[u].y) + __popc(fb.z ^ rb[u].z) + __popc(fb.w ^ rb[u].w);    // FORB::distance
-                if (c + u < cnt && d < best) { best = d; best_info = ri[u]; best_w = rw[u]; }          // strict: first minimum wins (:1243-1247)
+        int bkey = 0x7fffffff;
+        for (uint32_t c0 = 0; c0 < cnt; c0 += BD_G) {                                    // k <= 20: at most two rounds
+            const uint32_t c = c0 + l16;
+            if (c < cnt) {
+                const size_t dev = (size_t)(a + c) * 4;
+                const uint4 ra = rec[dev], rb = rec[dev + 1], ri = rec[dev + 2]; const uint2 rw = *reinterpret_cast<const uint2*>(rec + dev + 3);
+                const int d = __popc(fa.x ^ ra.x) + __popc(fa.y ^ ra.y) + __popc(fa.z ^ ra.z) + __popc(fa.w ^ ra.w) +
+                              __popc(fb.x ^ rb.x) + __popc(fb.y ^ rb.y) + __popc(fb.z ^ rb.z) + __popc(fb.w ^ rb.w);    // FORB::distance
+                const int key = (d << 8) | (int)c;                                       // the smallest distance, the first child among equals (:1243-1247)
+                if (key < bkey) { bkey = key; binfo = ri; bw = rw; }
             }
         }
-        cur = best_info; curw = best_w;
-        if (level == nid_level) nid = cur.z;
-    } while (cur.y > 0);                                                                  // !isLeaf()
-    const long long o = (long long)frame * P.cap + i;
-    P.word[o] = cur.w; reinterpret_cast<uint2*>(P.weight)[o] = curw; P.node[o] = nid;
+        int m = bkey;
+#pragma unroll
+        for (int off = BD_G / 2; off > 0; off >>= 1) m = min(m, __shfl_xor(m, off, BD_G));
+        win = m & (BD_G - 1);                                                            // child c sits in lane c % 16
+        a = __shfl(binfo.x, win, BD_G); cnt = __shfl(binfo.y, win, BD_G);
+        if (level == nid_level) nid = __shfl(binfo.z, win, BD_G);
+    }
+    if (l16 == win) {
+        const long long o = (long long)frame * P.cap + i;
+        P.word[o] = binfo.w; reinterpret_cast<uint2*>(P.weight)[o] = bw; P.node[o] = nid;
+    }
 }
 
 #define BA_T 1024                      // one workgroup of 16 wavefronts per frame: a single frame's latency is this kernel's length
-#define BA_HEADS 8                     // BOW_MAX_FEATURES / BA_T: entries one thread can own
 // in-place exclusive scan of a[0..n) by the whole workgroup, returns the total (scratch: BA_T/64 ints)
 __device__ __forceinline__ int ba_exscan(int* a, int n, int* scratch, int tid)
 {
@@ -112,143 +118,178 @@ __device__ __forceinline__ int ba_exscan(int* a, int n, int* scratch, int tid)
     return total;
 }
 
-// ascending sort of NARR arrays of p2 (a power of two) unique 64-bit keys each (invalid = ~0 sorts last), in place: a bitonic network in LDS, p2 / 2
-// compare-exchanges per stage and array spread over the workgroup, both arrays in the same pass.  Exchange slot t always belongs to thread t % BA_T, so the 64
-// slots [64 q, 64 q + 64) - elements [128 q, 128 q + 128) - stay with one wavefront: stages whose partners are at most 64 apart (j <= 64: all of the first 28
-// stages, the last 7 of every later phase) only need the wavefront's own order (LDS operations of a wave execute in order; the fence keeps the compiler from
-// moving a stage's reads above the previous stage's writes), and only the stages with j >= 128 are bracketed by workgroup barriers: 9 instead of 55 at p2 = 1024.
-// (History: a rank sort - every key counted against every other one - was 0.46 ms of ONE workgroup for a 2000-feature frame; the network with a workgroup
-// barrier after each of its stages, one array after the other, 0.064 ms per 1000 features.)
-template <int NARR> __device__ __forceinline__ void ba_sort(unsigned long long* a0, unsigned long long* a1, int p2, int tid)
+// Ascending sort of NARR sets of E * BA_T keys (32 or 64 bits; unique but for the invalid ones, ~0, which sort last) held in REGISTERS, thread t owning the keys at
+// positions e * BA_T + t: a bitonic network in which a key meets its partner (position ^ j) and keeps the smaller or the larger of the two.  Partners less
+// than 64 apart are another lane's registers (__shfl_xor: 45 of the 55 stages at 1024 keys), partners BA_T or more apart are the thread's own registers, and
+// only the stages in between go through LDS (write, barrier, read the partner, barrier).  x0 / x1: LDS for E * BA_T keys each; the sorted keys are left there.
+// (History: a rank sort - every key counted against every other one - was 0.46 ms of ONE workgroup for a 2000-feature frame; the network in LDS with a
+// workgroup barrier after each stage, one array after the other, 0.064 ms per 1000 features; both arrays in one pass with wavefront-local stages 0.015 of
+// the kernel's 0.035 - every stage two LDS round trips.)
+template <typename KT, int NARR, int E> __device__ __forceinline__ void ba_sort(KT (&r0)[E], KT (&r1)[E], KT* x0, KT* x1, int tid)
 {
-    bool wide = true;                                                                    // the previous stage crossed wavefronts (or: the keys were just written)
-    for (int k = 2; k <= p2; k <<= 1)
+    for (int k = 2; k <= E * BA_T; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            const bool cross = j > 64;
-            if (cross || wide) __syncthreads();
-            else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
-            wide = cross;
-            for (int t = tid; t < (p2 >> 1); t += BA_T) {
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), x = i | j;          // the pair (i, i + j), bit j of i clear
-                const bool up = (i & k) == 0;
-                { const unsigned long long a = a0[i], b = a0[x]; if ((a > b) == up) { a0[i] = b; a0[x] = a; } }
-                if (NARR > 1) { const unsigned long long a = a1[i], b = a1[x]; if ((a > b) == up) { a1[i] = b; a1[x] = a; } }
+            if (j >= BA_T) {                                                             // the partner is one of this thread's own keys
+#pragma unroll
+                for (int je = E / 2; je >= 1; je >>= 1) {
+                    if (j != je * BA_T) continue;
+#pragma unroll
+                    for (int e = 0; e < E; e++) {
+                        if (e & je) continue;
+                        const bool up = (((e * BA_T + tid) & k) == 0);
+                        { const KT a = r0[e], b = r0[e | je]; if ((a > b) == up) { r0[e] = b; r0[e | je] = a; } }
+                        if (NARR > 1) { const KT a = r1[e], b = r1[e | je]; if ((a > b) == up) { r1[e] = b; r1[e | je] = a; } }
+                    }
+                }
+            } else if (j >= 64) {                                                        // another wavefront's
+#pragma unroll
+                for (int e = 0; e < E; e++) { x0[e * BA_T + tid] = r0[e]; if (NARR > 1) x1[e * BA_T + tid] = r1[e]; }
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    const int i = e * BA_T + tid;
+                    const bool low = ((i & j) == 0) == ((i & k) == 0);                    // this position keeps the smaller key
+                    { const KT q = x0[i ^ j]; r0[e] = (q < r0[e]) == low ? q : r0[e]; }
+                    if (NARR > 1) { const KT q = x1[i ^ j]; r1[e] = (q < r1[e]) == low ? q : r1[e]; }
+                }
+                __syncthreads();
+            } else {                                                                     // another lane's
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    const int i = e * BA_T + tid;
+                    const bool low = ((i & j) == 0) == ((i & k) == 0);
+                    { const KT q = __shfl_xor(r0[e], j); r0[e] = (q < r0[e]) == low ? q : r0[e]; }
+                    if (NARR > 1) { const KT q = __shfl_xor(r1[e], j); r1[e] = (q < r1[e]) == low ? q : r1[e]; }
+                }
             }
         }
+#pragma unroll
+    for (int e = 0; e < E; e++) { x0[e * BA_T + tid] = r0[e]; if (NARR > 1) x1[e * BA_T + tid] = r1[e]; }
     __syncthreads();
 }
-__host__ __device__ inline int ba_pow2(int n) { int p = 2; while (p < n) p <<= 1; return p; }
 #define BA_DUAL_MAX 4096               // features up to which both key arrays fit the LDS side by side (16 B per slot of the network + 8 B per feature: 96 KB)
-__host__ __device__ inline size_t ba_lds_bytes(int lcap) { return (size_t)ba_pow2(lcap) * (lcap <= BA_DUAL_MAX ? 16 : 8) + (size_t)lcap * 8 + 128; }
+__host__ __device__ inline int ba_keys_per_thread(int lcap) { return lcap <= BA_T ? 1 : lcap <= 2 * BA_T ? 2 : lcap <= 4 * BA_T ? 4 : 8; }
+// keys of `ks` bytes: [word keys][node keys, when both fit][flag, head: lcap ints each][scratch 128 B][the words' f64 values: their own block behind 4-byte keys, the
+// word keys' block behind 8-byte ones][128 B that ba_norm may read past the values]
+__host__ __device__ inline size_t ba_lds_bytes(int lcap, int ks) { return (size_t)ba_keys_per_thread(lcap) * BA_T * ks * (lcap <= BA_DUAL_MAX ? 2 : 1) + (size_t)lcap * 8 + 128 + (ks == 4 ? (size_t)lcap * 8 : 0) + 128; }
 
-// lane l's f64 (l uniform) as seen by every lane: two v_readlane_b32, independent of whatever is done with the value
-__device__ __forceinline__ double ba_lane_f64(double v, int l)
+// sum of |v| (or v * v) over vals[0 .. nb) in index order: the order of the f64 additions is part of the result, so it is ONE chain of dependent additions.
+// Every lane of the wavefront reads the same value (an LDS broadcast), eight values ahead of the addition that needs them: the chain never waits for memory.
+// (Fed by v_readlane from a 64-value register: two readlanes + a hazard nop per addition, 0.0105 ms per 1000 values.)
+template <bool L2> __device__ __forceinline__ double ba_norm(const double* vals, int nb)
 {
-    unsigned long long b; memcpy(&b, &v, 8);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
-    b = ((unsigned long long)hi << 32) | lo; memcpy(&v, &b, 8);
-    return v;
-}
-
-// sum of |v| (or v * v) over vals[0 .. nb) in index order, by one wavefront (every lane ends up with the sum)
-template <bool L2> __device__ __forceinline__ double ba_norm(const double* vals, int nb, int lane)
-{
-    double norm = 0.0;
-    for (int c = 0; c < nb; c += 64) {
-        const double part = c + lane < nb ? vals[c + lane] : 0.0;
-        const int lim = min(64, nb - c);
-        if (lim == 64) {
+    // (reads run up to 15 values past nb: still inside the kernel's LDS block - the key arrays are followed by flag / head / scratch - and never added)
+    double norm = 0.0, cur[8], nxt[8];
 #pragma unroll
-            for (int l = 0; l < 64; l++) { const double x = ba_lane_f64(part, l); norm += L2 ? x * x : fabs(x); }
-        } else for (int l = 0; l < lim; l++) { const double x = ba_lane_f64(part, l); norm += L2 ? x * x : fabs(x); }
+    for (int k = 0; k < 8; k++) cur[k] = vals[k];
+    int base = 0;
+    for (; base + 8 <= nb; base += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) nxt[k] = vals[base + 8 + k];
+#pragma unroll
+        for (int k = 0; k < 8; k++) norm += L2 ? cur[k] * cur[k] : fabs(cur[k]);
+#pragma unroll
+        for (int k = 0; k < 8; k++) cur[k] = nxt[k];
     }
+#pragma unroll
+    for (int k = 0; k < 8; k++) if (base + k < nb) norm += L2 ? cur[k] * cur[k] : fabs(cur[k]);
     return norm;
 }
 
-template <bool DUAL> __global__ __launch_bounds__(BA_T) void k_bow_assemble(BowParams P)
+// E = keys per thread: the network sorts E * BA_T >= lcap keys.  KT = uint32_t when (id << IB | feature index) fits 32 bits for every node id of the vocabulary
+// (IB = log2(E * BA_T); ORBvoc.txt's 1.1 M nodes with up to 2048 features), else uint64_t (id << 32 | index): half the exchanges and compare instructions of the sort.
+template <typename KT, bool DUAL, int E> __global__ __launch_bounds__(BA_T) void k_bow_assemble(BowParams P)
 {
     HIP_DYNAMIC_SHARED(unsigned long long, lds64)
+    constexpr int IB = sizeof(KT) == 4 ? (E == 1 ? 10 : E == 2 ? 11 : E == 4 ? 12 : 13) : 32;
+    constexpr KT IM = (KT)(((KT)1 << IB) - 1), INVALID = (KT)~(KT)0;
     const int frame = blockIdx.x, tid = threadIdx.x, n = min(bow_count(P, frame), P.lcap), cap = P.cap;
-    const int lcap = P.lcap;                               // LDS arrays hold lcap entries; `cap` is the row stride of the HBM arrays
-    const int p2 = ba_pow2(lcap);
-    unsigned long long* sw = lds64;                        // [p2] (word << 32 | feature), after the sort; then the f64 values of the words
-    unsigned long long* sn = DUAL ? lds64 + p2 : lds64;    // [p2] (node << 32 | feature)   (one array after the other when both do not fit)
-    int* flag = reinterpret_cast<int*>(lds64 + (DUAL ? 2 : 1) * (size_t)p2);   // [lcap]
+    const int lcap = P.lcap;                               // flag / head hold lcap entries; `cap` is the row stride of the HBM arrays
+    constexpr int p2 = E * BA_T;
+    KT* sw = reinterpret_cast<KT*>(lds64);                 // [p2] (word << IB | feature), after the sort
+    KT* sn = DUAL ? sw + p2 : sw;                          // [p2] (node << IB | feature)   (one array after the other when both do not fit)
+    int* flag = reinterpret_cast<int*>(sw + (DUAL ? 2 : 1) * (size_t)p2);   // [lcap]
     int* head = flag + lcap;                               // [lcap]
-    int* scratch = head + lcap;                            // [BA_T / 64] + the norm
-    double* vals = reinterpret_cast<double*>(sw);
+    int* scratch = head + lcap;                            // [BA_T / 64] + the norm: 128 bytes
+    double* vals = sizeof(KT) == 4 ? reinterpret_cast<double*>(scratch + 32) : reinterpret_cast<double*>(sw);   // the f64 values of the words
     const uint32_t* word = P.word + (long long)frame * cap; const double* wt = P.weight + (long long)frame * cap; const uint32_t* node = P.node + (long long)frame * cap;
     uint8_t* ob = P.out.base + (long long)frame * P.out.stride;
     double* bow_val = reinterpret_cast<double*>(ob); uint32_t* bow_id = reinterpret_cast<uint32_t*>(ob + P.out.o_id);
     uint32_t* fv_node = reinterpret_cast<uint32_t*>(ob + P.out.o_fn); uint32_t* fv_feat = reinterpret_cast<uint32_t*>(ob + P.out.o_ff);
     int* fv_off = reinterpret_cast<int*>(ob + P.out.o_fo); int* counts = reinterpret_cast<int*>(ob + P.out.o_cnt);
 
+    if (P.stop && tid == 0) { counts[0] = 0; counts[4] = 0; fv_off[0] = 0; }      // PROFILING ONLY
     // ---- keys of both maps for every feature with w > 0 (:1157-1161), sorted
-    for (int i = tid; i < p2; i += BA_T) {
+    KT kw[E], kn[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int i = e * BA_T + tid;
         const bool on = i < n && wt[i] > 0;
-        sw[i] = on ? (((unsigned long long)word[i] << 32) | (unsigned)i) : ~0ull;
-        if (DUAL) sn[i] = on ? (((unsigned long long)node[i] << 32) | (unsigned)i) : ~0ull;
+        kw[e] = on ? (KT)(((KT)word[i] << IB) | (KT)i) : INVALID;
+        kn[e] = on ? (KT)(((KT)node[i] << IB) | (KT)i) : INVALID;
         if (i < n) flag[i] = on;
     }
     __syncthreads();
     const int m = ba_exscan(flag, n, scratch, tid);        // features that are "not stopped"
-    ba_sort<DUAL ? 2 : 1>(sw, sn, p2, tid);
+    if (P.stop == 10) return;      // PROFILING ONLY
+    if (DUAL) ba_sort<KT, 2, E>(kw, kn, sw, sn, tid); else ba_sort<KT, 1, E>(kw, kw, sw, sw, tid);
+    if (P.stop == 20) return;      // PROFILING ONLY
 
     // ---- BowVector: v.addWeight(id, w) in feature order
-    for (int i = tid; i < m; i += BA_T) { const int h = (i == 0) || ((sw[i] >> 32) != (sw[i - 1] >> 32)); flag[i] = h; head[i] = h; }
+    for (int i = tid; i < m; i += BA_T) { const int h = (i == 0) || ((sw[i] >> IB) != (sw[i - 1] >> IB)); flag[i] = h; head[i] = h; }
     __syncthreads();
     const int nb = ba_exscan(flag, m, scratch, tid);
-    double hv[BA_HEADS]; int hp[BA_HEADS];                                                  // the entries this thread owns: value, position
+    if (P.stop == 25) return;      // PROFILING ONLY
+    double hv[E]; int hp[E];                                                                // the entries this thread owns: value, position
 #pragma unroll
-    for (int r = 0; r < BA_HEADS; r++) {
+    for (int r = 0; r < E; r++) {
         const int i = tid + r * BA_T;
         hp[r] = -1; hv[r] = 0.0;
         if (i < m && head[i]) {
-            const uint32_t w = (uint32_t)(sw[i] >> 32);
-            double v = wt[(uint32_t)sw[i]];
-            if (P.accumulate) for (int j = i + 1; j < m && (uint32_t)(sw[j] >> 32) == w; j++) v += wt[(uint32_t)sw[j]];   // `vit->second += v`
+            const uint32_t w = (uint32_t)(sw[i] >> IB);
+            double v = wt[(uint32_t)(sw[i] & IM)];
+            if (P.accumulate) for (int j = i + 1; j < m && (uint32_t)(sw[j] >> IB) == w; j++) v += wt[(uint32_t)(sw[j] & IM)];   // `vit->second += v`
             hp[r] = flag[i]; hv[r] = v; bow_id[flag[i]] = w;                                 // addIfNotExist keeps the first
         }
     }
+    if (P.stop == 30) return;      // PROFILING ONLY
     __syncthreads();                                                                        // (the word keys are not needed any more: their LDS takes the values)
     if (P.accumulate && nb > 0 && !P.must_normalize) {                                      // :1164-1170
         const double nd = (double)nb;
 #pragma unroll
-        for (int r = 0; r < BA_HEADS; r++) hv[r] = hv[r] / nd;
+        for (int r = 0; r < E; r++) if (hp[r] >= 0) hv[r] = hv[r] / nd;
     }
     if (P.must_normalize) {                                                                 // BowVector::normalize
 #pragma unroll
-        for (int r = 0; r < BA_HEADS; r++) if (hp[r] >= 0) vals[hp[r]] = hv[r];
+        for (int r = 0; r < E; r++) if (hp[r] >= 0) vals[hp[r]] = hv[r];
         __syncthreads();
+        if (P.stop == 40) return;      // PROFILING ONLY
         if (tid < 64) {
-            // word order, one addition after the other: the order of the f64 additions is part of the result.  The wavefront reads 64 values with ONE LDS
-            // instruction, then every lane adds them up in order, each taken from its lane by v_readlane: the chain of additions never waits for memory.
-            // (One lane reading the values itself, eight at a time: 0.012 ms of a 1000-feature frame's 0.057.)
-            double norm = P.l2 ? ba_norm<true>(vals, nb, tid) : ba_norm<false>(vals, nb, tid);
+            double norm = P.l2 ? ba_norm<true>(vals, nb) : ba_norm<false>(vals, nb);
             if (P.l2) norm = sqrt(norm);
             if (tid == 0) reinterpret_cast<double*>(scratch)[8] = norm;
         }
         __syncthreads();
+        if (P.stop == 50) return;      // PROFILING ONLY
         const double norm = reinterpret_cast<double*>(scratch)[8];
         if (norm > 0.0) {
 #pragma unroll
-            for (int r = 0; r < BA_HEADS; r++) hv[r] = hv[r] / norm;
+            for (int r = 0; r < E; r++) if (hp[r] >= 0) hv[r] = hv[r] / norm;
         }
     }
 #pragma unroll
-    for (int r = 0; r < BA_HEADS; r++) if (hp[r] >= 0) bow_val[hp[r]] = hv[r];
+    for (int r = 0; r < E; r++) if (hp[r] >= 0) bow_val[hp[r]] = hv[r];
     if (tid == 0) counts[0] = nb;
     __syncthreads();
+    if (P.stop == 60) return;      // PROFILING ONLY
 
     // ---- FeatureVector: fv.addFeature(nid, i_feature) for the same features
-    if (!DUAL) {
-        for (int i = tid; i < p2; i += BA_T) sn[i] = (i < n && wt[i] > 0) ? (((unsigned long long)node[i] << 32) | (unsigned)i) : ~0ull;
-        ba_sort<1>(sn, sn, p2, tid);
-    }
-    for (int i = tid; i < m; i += BA_T) { const int h = (i == 0) || ((sn[i] >> 32) != (sn[i - 1] >> 32)); flag[i] = h; head[i] = h; fv_feat[i] = (uint32_t)sn[i]; }
+    if (!DUAL) ba_sort<KT, 1, E>(kn, kn, sn, sn, tid);
+    for (int i = tid; i < m; i += BA_T) { const int h = (i == 0) || ((sn[i] >> IB) != (sn[i - 1] >> IB)); flag[i] = h; head[i] = h; fv_feat[i] = (uint32_t)(sn[i] & IM); }
     __syncthreads();
     const int nf = ba_exscan(flag, m, scratch, tid);
-    for (int i = tid; i < m; i += BA_T) if (head[i]) { fv_node[flag[i]] = (uint32_t)(sn[i] >> 32); fv_off[flag[i]] = i; }
+    if (P.stop == 70) return;      // PROFILING ONLY
+    for (int i = tid; i < m; i += BA_T) if (head[i]) { fv_node[flag[i]] = (uint32_t)(sn[i] >> IB); fv_off[flag[i]] = i; }
     if (tid == 0) { fv_off[nf] = m; counts[4] = nf; }
 }
 
@@ -532,16 +573,27 @@ static orbhip_status voc_run(orbhip_voc* v, BowWs* w, const uint8_t* d_desc, lon
     BowParams P; memset(&P, 0, sizeof P);
     P.desc = d_desc; P.desc_frame_stride = frame_stride; P.nfeat = d_nfeat; P.nfeat_fixed = nfeat_fixed; P.cap = w->cap; P.lcap = nfeat_max;
     P.nodes = v->d_nodes;
-    P.L = v->L; P.levelsup = levelsup;
+    P.L = v->L; P.levelsup = levelsup; { const char* e = getenv("ORBHIP_BOW_STOP"); P.stop = e ? atoi(e) : 0; }
     P.accumulate = (v->weighting == 0 || v->weighting == 1);                     // TF_IDF, TF (:1142) vs IDF, BINARY (:1173)
     P.must_normalize = v->scoring != 5; P.l2 = v->scoring == 1;                    // ScoringObject.h:73-90
     P.word = w->d_word; P.weight = w->d_weight; P.node = w->d_node;
     P.out = w->out;
     if (nfeat_max <= 0 || nframes <= 0) return ORBHIP_OK;
-    hipLaunchKernelGGL(k_bow_descend, dim3((nfeat_max + 255) / 256, nframes, 1), dim3(256, 1, 1), 0, s, P);
+    hipLaunchKernelGGL(k_bow_descend, dim3((nfeat_max + 64 / BD_G - 1) / (64 / BD_G), nframes, 1), dim3(64, 1, 1), 0, s, P);
     if (assemble) {
-        if (nfeat_max <= BA_DUAL_MAX) hipLaunchKernelGGL(k_bow_assemble<true>, dim3(nframes, 1, 1), dim3(BA_T, 1, 1), ba_lds_bytes(nfeat_max), s, P);
-        else hipLaunchKernelGGL(k_bow_assemble<false>, dim3(nframes, 1, 1), dim3(BA_T, 1, 1), ba_lds_bytes(nfeat_max), s, P);
+        const int E = ba_keys_per_thread(nfeat_max);
+        const char* force = getenv("ORBHIP_BOW_KEYS");                             // "64": the 8-byte keys also where 4 bytes would do (tests)
+        const bool k32 = E <= 4 && ((unsigned long long)v->nnodes * E * BA_T) <= 0xffffffffull && !(force && atoi(force) == 64);      // (E = 8: the values' own block would not fit the LDS)
+        const dim3 g(nframes, 1, 1), b(BA_T, 1, 1); const size_t lds = ba_lds_bytes(nfeat_max, k32 ? 4 : 8);
+        switch (E + (k32 ? 100 : 0)) {
+        case 101: hipLaunchKernelGGL((k_bow_assemble<uint32_t, true, 1>), g, b, lds, s, P); break;
+        case 102: hipLaunchKernelGGL((k_bow_assemble<uint32_t, true, 2>), g, b, lds, s, P); break;
+        case 104: hipLaunchKernelGGL((k_bow_assemble<uint32_t, true, 4>), g, b, lds, s, P); break;
+        case 1: hipLaunchKernelGGL((k_bow_assemble<unsigned long long, true, 1>), g, b, lds, s, P); break;
+        case 2: hipLaunchKernelGGL((k_bow_assemble<unsigned long long, true, 2>), g, b, lds, s, P); break;
+        case 4: hipLaunchKernelGGL((k_bow_assemble<unsigned long long, true, 4>), g, b, lds, s, P); break;
+        default: hipLaunchKernelGGL((k_bow_assemble<unsigned long long, false, 8>), g, b, lds, s, P); break;
+        }
     }
     BOWCHK(hipGetLastError());
     w->last_frames = nframes;
