@@ -11,10 +11,10 @@
 // descriptors), and nothing is fetched after the leaf.  ORBvoc.txt (k = 10, L = 6) is 1.1 M nodes = 71 MB of records: resident in HBM, hot upper levels in L2.
 //  k_bow_descend   one thread per feature walks the tree (<= L dependent steps, k Hamming distances each, strict '<' so the
 //                  first minimum wins) -> word id, weight, node id `levelsup` levels above the leaf.
-//  k_bow_assemble  one workgroup per frame turns the per-feature triples into the two std::map's of the reference, flattened
-//                  in key order: keys (word << 32 | feature index) and (node << 32 | index) are sorted in LDS by ONE bitonic network working on both arrays,
-//                  run heads become entries, weights of a word are added in feature order and the L1 norm is summed in word order by ONE lane (f64 addition
-//                  order is part of the result), then every value is divided by it.  A frame's results are one contiguous block: one copy takes them home.
+//  k_bow_assemble  two workgroups per frame turn the per-feature triples into the two std::map's of the reference, flattened in key order: one sorts the keys
+//                  (word << IB | feature index), the other (node << IB | index), by a bitonic network on registers; run heads become entries, weights of a
+//                  word are added in feature order and the L1 norm is summed in word order as ONE chain of f64 additions (their order is part of the
+//                  result), then every value is divided by it.  A frame's results are one contiguous block: one copy takes them home.
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdarg>
@@ -42,7 +42,7 @@ struct BowParams {
     const uint8_t* desc; long long desc_frame_stride;        // features of frame f at desc + f*stride, 32 B each
     const int* nfeat; int nfeat_fixed; int cap;                // per-frame count (device) or one fixed count; output stride
     const BowNode* nodes;                                      // breadth-first numbering, root = 0
-    int L, levelsup, accumulate, must_normalize, l2, stop;
+    int L, levelsup, accumulate, must_normalize, l2;
     uint32_t* word; double* weight; uint32_t* node;            // [frame][cap]
     BowOut out;
     int lcap;                          // features the LDS arrays of k_bow_assemble are carved for (>= every frame's count, <= cap)
@@ -167,11 +167,10 @@ template <typename KT, int NARR, int E> __device__ __forceinline__ void ba_sort(
     for (int e = 0; e < E; e++) { x0[e * BA_T + tid] = r0[e]; if (NARR > 1) x1[e * BA_T + tid] = r1[e]; }
     __syncthreads();
 }
-#define BA_DUAL_MAX 4096               // features up to which both key arrays fit the LDS side by side (16 B per slot of the network + 8 B per feature: 96 KB)
 __host__ __device__ inline int ba_keys_per_thread(int lcap) { return lcap <= BA_T ? 1 : lcap <= 2 * BA_T ? 2 : lcap <= 4 * BA_T ? 4 : 8; }
-// keys of `ks` bytes: [word keys][node keys, when both fit][flag, head: lcap ints each][scratch 128 B][the words' f64 values: their own block behind 4-byte keys, the
-// word keys' block behind 8-byte ones][128 B that ba_norm may read past the values]
-__host__ __device__ inline size_t ba_lds_bytes(int lcap, int ks) { return (size_t)ba_keys_per_thread(lcap) * BA_T * ks * (lcap <= BA_DUAL_MAX ? 2 : 1) + (size_t)lcap * 8 + 128 + (ks == 4 ? (size_t)lcap * 8 : 0) + 128; }
+// keys of `ks` bytes: [keys E * BA_T][flag, head: lcap ints each][scratch 128 B][the words' f64 values: their own lcap-block behind 4-byte keys, the keys' block
+// behind 8-byte ones][128 B that ba_norm may read past the values]
+__host__ __device__ inline size_t ba_lds_bytes(int lcap, int ks) { return (size_t)ba_keys_per_thread(lcap) * BA_T * ks + (size_t)lcap * 8 + 128 + (ks == 4 ? (size_t)lcap * 8 : 0) + 128; }
 
 // sum of |v| (or v * v) over vals[0 .. nb) in index order: the order of the f64 additions is part of the result, so it is ONE chain of dependent additions.
 // Every lane of the wavefront reads the same value (an LDS broadcast), eight values ahead of the addition that needs them: the chain never waits for memory.
@@ -196,81 +195,85 @@ template <bool L2> __device__ __forceinline__ double ba_norm(const double* vals,
     return norm;
 }
 
+// Two workgroups per frame, side by side: blockIdx.y = 0 builds the BowVector (word keys), 1 the FeatureVector (node keys) - the first one's chain of f64
+// additions (0.010 ms per 1000 words, nothing to be done about its order) is the kernel's length, the second finishes under it.
 // E = keys per thread: the network sorts E * BA_T >= lcap keys.  KT = uint32_t when (id << IB | feature index) fits 32 bits for every node id of the vocabulary
 // (IB = log2(E * BA_T); ORBvoc.txt's 1.1 M nodes with up to 2048 features), else uint64_t (id << 32 | index): half the exchanges and compare instructions of the sort.
-template <typename KT, bool DUAL, int E> __global__ __launch_bounds__(BA_T) void k_bow_assemble(BowParams P)
+template <typename KT, int E> __global__ __launch_bounds__(BA_T) void k_bow_assemble(BowParams P)
 {
     HIP_DYNAMIC_SHARED(unsigned long long, lds64)
     constexpr int IB = sizeof(KT) == 4 ? (E == 1 ? 10 : E == 2 ? 11 : E == 4 ? 12 : 13) : 32;
     constexpr KT IM = (KT)(((KT)1 << IB) - 1), INVALID = (KT)~(KT)0;
     const int frame = blockIdx.x, tid = threadIdx.x, n = min(bow_count(P, frame), P.lcap), cap = P.cap;
-    const int lcap = P.lcap;                               // flag / head hold lcap entries; `cap` is the row stride of the HBM arrays
+    const bool words = blockIdx.y == 0;
+    const int lcap = P.lcap;                               // flag / head / vals hold lcap entries; `cap` is the row stride of the HBM arrays
     constexpr int p2 = E * BA_T;
-    KT* sw = reinterpret_cast<KT*>(lds64);                 // [p2] (word << IB | feature), after the sort
-    KT* sn = DUAL ? sw + p2 : sw;                          // [p2] (node << IB | feature)   (one array after the other when both do not fit)
-    int* flag = reinterpret_cast<int*>(sw + (DUAL ? 2 : 1) * (size_t)p2);   // [lcap]
+    KT* sk = reinterpret_cast<KT*>(lds64);                 // [p2] (word or node << IB | feature), after the sort
+    int* flag = reinterpret_cast<int*>(sk + p2);           // [lcap]
     int* head = flag + lcap;                               // [lcap]
     int* scratch = head + lcap;                            // [BA_T / 64] + the norm: 128 bytes
-    double* vals = sizeof(KT) == 4 ? reinterpret_cast<double*>(scratch + 32) : reinterpret_cast<double*>(sw);   // the f64 values of the words
-    const uint32_t* word = P.word + (long long)frame * cap; const double* wt = P.weight + (long long)frame * cap; const uint32_t* node = P.node + (long long)frame * cap;
+    double* vals = sizeof(KT) == 4 ? reinterpret_cast<double*>(scratch + 32) : reinterpret_cast<double*>(sk);   // [lcap] the f64 values of the words
+    const uint32_t* id = (words ? P.word : P.node) + (long long)frame * cap; const double* wt = P.weight + (long long)frame * cap;
     uint8_t* ob = P.out.base + (long long)frame * P.out.stride;
     double* bow_val = reinterpret_cast<double*>(ob); uint32_t* bow_id = reinterpret_cast<uint32_t*>(ob + P.out.o_id);
     uint32_t* fv_node = reinterpret_cast<uint32_t*>(ob + P.out.o_fn); uint32_t* fv_feat = reinterpret_cast<uint32_t*>(ob + P.out.o_ff);
     int* fv_off = reinterpret_cast<int*>(ob + P.out.o_fo); int* counts = reinterpret_cast<int*>(ob + P.out.o_cnt);
 
-    if (P.stop && tid == 0) { counts[0] = 0; counts[4] = 0; fv_off[0] = 0; }      // PROFILING ONLY
-    // ---- keys of both maps for every feature with w > 0 (:1157-1161), sorted
-    KT kw[E], kn[E];
+    // ---- this map's keys for every feature with w > 0 (:1157-1161), sorted
+    KT key[E];
 #pragma unroll
     for (int e = 0; e < E; e++) {
         const int i = e * BA_T + tid;
         const bool on = i < n && wt[i] > 0;
-        kw[e] = on ? (KT)(((KT)word[i] << IB) | (KT)i) : INVALID;
-        kn[e] = on ? (KT)(((KT)node[i] << IB) | (KT)i) : INVALID;
+        key[e] = on ? (KT)(((KT)id[i] << IB) | (KT)i) : INVALID;
         if (i < n) flag[i] = on;
     }
     __syncthreads();
     const int m = ba_exscan(flag, n, scratch, tid);        // features that are "not stopped"
-    if (P.stop == 10) return;      // PROFILING ONLY
-    if (DUAL) ba_sort<KT, 2, E>(kw, kn, sw, sn, tid); else ba_sort<KT, 1, E>(kw, kw, sw, sw, tid);
-    if (P.stop == 20) return;      // PROFILING ONLY
+    ba_sort<KT, 1, E>(key, key, sk, sk, tid);
+    for (int i = tid; i < m; i += BA_T) {
+        const int h = (i == 0) || ((sk[i] >> IB) != (sk[i - 1] >> IB)); flag[i] = h; head[i] = h;
+        if (!words) fv_feat[i] = (uint32_t)(sk[i] & IM);
+    }
+    __syncthreads();
+    const int nh = ba_exscan(flag, m, scratch, tid);       // entries of the map
+
+    if (!words) {      // ---- FeatureVector: fv.addFeature(nid, i_feature)
+        for (int i = tid; i < m; i += BA_T) if (head[i]) { fv_node[flag[i]] = (uint32_t)(sk[i] >> IB); fv_off[flag[i]] = i; }
+        if (tid == 0) { fv_off[nh] = m; counts[4] = nh; }
+        return;
+    }
 
     // ---- BowVector: v.addWeight(id, w) in feature order
-    for (int i = tid; i < m; i += BA_T) { const int h = (i == 0) || ((sw[i] >> IB) != (sw[i - 1] >> IB)); flag[i] = h; head[i] = h; }
-    __syncthreads();
-    const int nb = ba_exscan(flag, m, scratch, tid);
-    if (P.stop == 25) return;      // PROFILING ONLY
+    const int nb = nh;
     double hv[E]; int hp[E];                                                                // the entries this thread owns: value, position
 #pragma unroll
     for (int r = 0; r < E; r++) {
         const int i = tid + r * BA_T;
         hp[r] = -1; hv[r] = 0.0;
         if (i < m && head[i]) {
-            const uint32_t w = (uint32_t)(sw[i] >> IB);
-            double v = wt[(uint32_t)(sw[i] & IM)];
-            if (P.accumulate) for (int j = i + 1; j < m && (uint32_t)(sw[j] >> IB) == w; j++) v += wt[(uint32_t)(sw[j] & IM)];   // `vit->second += v`
+            const uint32_t w = (uint32_t)(sk[i] >> IB);
+            double v = wt[(uint32_t)(sk[i] & IM)];
+            if (P.accumulate) for (int j = i + 1; j < m && (uint32_t)(sk[j] >> IB) == w; j++) v += wt[(uint32_t)(sk[j] & IM)];   // `vit->second += v`
             hp[r] = flag[i]; hv[r] = v; bow_id[flag[i]] = w;                                 // addIfNotExist keeps the first
         }
     }
-    if (P.stop == 30) return;      // PROFILING ONLY
-    __syncthreads();                                                                        // (the word keys are not needed any more: their LDS takes the values)
     if (P.accumulate && nb > 0 && !P.must_normalize) {                                      // :1164-1170
         const double nd = (double)nb;
 #pragma unroll
         for (int r = 0; r < E; r++) if (hp[r] >= 0) hv[r] = hv[r] / nd;
     }
     if (P.must_normalize) {                                                                 // BowVector::normalize
+        __syncthreads();                                                                    // (8-byte keys: the values take the keys' LDS, nobody reads a key any more)
 #pragma unroll
         for (int r = 0; r < E; r++) if (hp[r] >= 0) vals[hp[r]] = hv[r];
         __syncthreads();
-        if (P.stop == 40) return;      // PROFILING ONLY
         if (tid < 64) {
             double norm = P.l2 ? ba_norm<true>(vals, nb) : ba_norm<false>(vals, nb);
             if (P.l2) norm = sqrt(norm);
             if (tid == 0) reinterpret_cast<double*>(scratch)[8] = norm;
         }
         __syncthreads();
-        if (P.stop == 50) return;      // PROFILING ONLY
         const double norm = reinterpret_cast<double*>(scratch)[8];
         if (norm > 0.0) {
 #pragma unroll
@@ -280,17 +283,6 @@ template <typename KT, bool DUAL, int E> __global__ __launch_bounds__(BA_T) void
 #pragma unroll
     for (int r = 0; r < E; r++) if (hp[r] >= 0) bow_val[hp[r]] = hv[r];
     if (tid == 0) counts[0] = nb;
-    __syncthreads();
-    if (P.stop == 60) return;      // PROFILING ONLY
-
-    // ---- FeatureVector: fv.addFeature(nid, i_feature) for the same features
-    if (!DUAL) ba_sort<KT, 1, E>(kn, kn, sn, sn, tid);
-    for (int i = tid; i < m; i += BA_T) { const int h = (i == 0) || ((sn[i] >> IB) != (sn[i - 1] >> IB)); flag[i] = h; head[i] = h; fv_feat[i] = (uint32_t)(sn[i] & IM); }
-    __syncthreads();
-    const int nf = ba_exscan(flag, m, scratch, tid);
-    if (P.stop == 70) return;      // PROFILING ONLY
-    for (int i = tid; i < m; i += BA_T) if (head[i]) { fv_node[flag[i]] = (uint32_t)(sn[i] >> IB); fv_off[flag[i]] = i; }
-    if (tid == 0) { fv_off[nf] = m; counts[4] = nf; }
 }
 
 // ------------------------------------------------------------------------------------------------ SearchByBoW
@@ -544,7 +536,7 @@ static void voc_free_ws(BowWs* w)
     *w = BowWs();
 }
 
-#define BOW_MAX_FEATURES 8192          // 8 B of LDS per feature + 8 B per slot of the sorting network (one key array at a time beyond BA_DUAL_MAX features) in k_bow_assemble: 128 KB
+#define BOW_MAX_FEATURES 8192          // eight keys per thread of k_bow_assemble: 8 B per key + 8 B per feature of LDS = 128 KB
 
 static orbhip_status voc_ensure_ws(BowWs* w, int nframes, int cap, hipStream_t s)
 {
@@ -573,7 +565,7 @@ static orbhip_status voc_run(orbhip_voc* v, BowWs* w, const uint8_t* d_desc, lon
     BowParams P; memset(&P, 0, sizeof P);
     P.desc = d_desc; P.desc_frame_stride = frame_stride; P.nfeat = d_nfeat; P.nfeat_fixed = nfeat_fixed; P.cap = w->cap; P.lcap = nfeat_max;
     P.nodes = v->d_nodes;
-    P.L = v->L; P.levelsup = levelsup; { const char* e = getenv("ORBHIP_BOW_STOP"); P.stop = e ? atoi(e) : 0; }
+    P.L = v->L; P.levelsup = levelsup;
     P.accumulate = (v->weighting == 0 || v->weighting == 1);                     // TF_IDF, TF (:1142) vs IDF, BINARY (:1173)
     P.must_normalize = v->scoring != 5; P.l2 = v->scoring == 1;                    // ScoringObject.h:73-90
     P.word = w->d_word; P.weight = w->d_weight; P.node = w->d_node;
@@ -584,15 +576,15 @@ static orbhip_status voc_run(orbhip_voc* v, BowWs* w, const uint8_t* d_desc, lon
         const int E = ba_keys_per_thread(nfeat_max);
         const char* force = getenv("ORBHIP_BOW_KEYS");                             // "64": the 8-byte keys also where 4 bytes would do (tests)
         const bool k32 = E <= 4 && ((unsigned long long)v->nnodes * E * BA_T) <= 0xffffffffull && !(force && atoi(force) == 64);      // (E = 8: the values' own block would not fit the LDS)
-        const dim3 g(nframes, 1, 1), b(BA_T, 1, 1); const size_t lds = ba_lds_bytes(nfeat_max, k32 ? 4 : 8);
+        const dim3 g(nframes, 2, 1), b(BA_T, 1, 1); const size_t lds = ba_lds_bytes(nfeat_max, k32 ? 4 : 8);
         switch (E + (k32 ? 100 : 0)) {
-        case 101: hipLaunchKernelGGL((k_bow_assemble<uint32_t, true, 1>), g, b, lds, s, P); break;
-        case 102: hipLaunchKernelGGL((k_bow_assemble<uint32_t, true, 2>), g, b, lds, s, P); break;
-        case 104: hipLaunchKernelGGL((k_bow_assemble<uint32_t, true, 4>), g, b, lds, s, P); break;
-        case 1: hipLaunchKernelGGL((k_bow_assemble<unsigned long long, true, 1>), g, b, lds, s, P); break;
-        case 2: hipLaunchKernelGGL((k_bow_assemble<unsigned long long, true, 2>), g, b, lds, s, P); break;
-        case 4: hipLaunchKernelGGL((k_bow_assemble<unsigned long long, true, 4>), g, b, lds, s, P); break;
-        default: hipLaunchKernelGGL((k_bow_assemble<unsigned long long, false, 8>), g, b, lds, s, P); break;
+        case 101: hipLaunchKernelGGL((k_bow_assemble<uint32_t, 1>), g, b, lds, s, P); break;
+        case 102: hipLaunchKernelGGL((k_bow_assemble<uint32_t, 2>), g, b, lds, s, P); break;
+        case 104: hipLaunchKernelGGL((k_bow_assemble<uint32_t, 4>), g, b, lds, s, P); break;
+        case 1: hipLaunchKernelGGL((k_bow_assemble<unsigned long long, 1>), g, b, lds, s, P); break;
+        case 2: hipLaunchKernelGGL((k_bow_assemble<unsigned long long, 2>), g, b, lds, s, P); break;
+        case 4: hipLaunchKernelGGL((k_bow_assemble<unsigned long long, 4>), g, b, lds, s, P); break;
+        default: hipLaunchKernelGGL((k_bow_assemble<unsigned long long, 8>), g, b, lds, s, P); break;
         }
     }
     BOWCHK(hipGetLastError());
