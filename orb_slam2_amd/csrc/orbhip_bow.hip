@@ -310,15 +310,75 @@ __device__ __forceinline__ unsigned long long bm_argmin_mask(int d, unsigned lon
 // slot of a batched launch that block `block` belongs to: pref[s] = first block of slot s (ascending, pref[nslots] = grid size); uniform -> scalar loads
 __device__ __forceinline__ int bm_batch_slot(const int* pref, int nslots, int block) { int s = 0; while (s + 1 < nslots && block >= pref[s + 1]) s++; return s; }
 
+// position of `node` among side 2's ascending node ids, -1 if it is not there (whole wavefront, uniform result)
+__device__ __forceinline__ int bm_find_node(const uint32_t* fn2, int nf2, uint32_t node, int lane)
+{
+    if (nf2 <= 256) {                                          // the usual FeatureVector (levelsup = 4 of ORBvoc: ~100 nodes): the lanes look at all ids at once
+        uint32_t id[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) id[c] = c * 64 + lane < nf2 ? fn2[c * 64 + lane] : 0xffffffffu;
+        int lo = -1;
+#pragma unroll
+        for (int c = 3; c >= 0; c--) { const unsigned long long B = __ballot(c * 64 + lane < nf2 && id[c] == node); if (B) lo = c * 64 + __ffsll((long long)B) - 1; }
+        return lo;
+    }
+    int lo = 0, hi = nf2;                                      // lower_bound
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (fn2[mid] < node) lo = mid + 1; else hi = mid; }
+    return (lo < nf2 && fn2[lo] == node) ? lo : -1;
+}
+
 __device__ __forceinline__ void bow_match_body(const BowMatchParams& P, int a, int lane)
 {
     if (a >= P.nf1) return;
     const uint32_t node = P.fn1[a];
-    int lo = 0, hi = P.nf2;                                    // lower_bound on side 2's node ids
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (P.fn2[mid] < node) lo = mid + 1; else hi = mid; }
-    if (lo >= P.nf2 || P.fn2[lo] != node) return;
+    const int lo = bm_find_node(P.fn2, P.nf2, node, lane);
+    if (lo < 0) return;
     const int b1 = P.fo1[a], e1 = P.fo1[a + 1], b2 = P.fo2[lo], len2 = P.fo2[lo + 1] - b2;
     if (len2 > 64 * BM_CHUNKS) { if (lane == 0) atomicAdd(P.overflow, 1); return; }
+    if (e1 - b1 <= 64 && len2 <= 64) {
+        // The usual node: both sides' features fit one wavefront.  Lane t fetches feature t of either side ONCE - index, flag, descriptor - and the walk over
+        // side 1's features (in order: an earlier one takes a side-2 feature away from the later ones) runs on registers, the query taken from its lane by
+        // v_readlane.  (The general walk below fetches index -> flag -> descriptor for every side-1 feature in turn and side 2's for each of them again:
+        // some thirty dependent round trips per node, 0.027 ms for a pair of 1000-feature frames.)
+        const int len1 = e1 - b1;
+        int idx1 = 0, idx2 = 0, v1 = 0; bool ok2 = false, taken = false;
+        uint4 pa; pa.x = pa.y = pa.z = pa.w = 0u; uint4 pb = pa, da = pa, db = pa;
+        if (lane < len1) { idx1 = (int)P.ff1[b1 + lane]; v1 = P.valid1[idx1]; const uint4* q4 = reinterpret_cast<const uint4*>(P.d1 + (long long)idx1 * 32); pa = q4[0]; pb = q4[1]; }
+        if (lane < len2) { idx2 = (int)P.ff2[b2 + lane]; ok2 = !(P.mode == 1 && !P.valid2[idx2]); const uint4* d4 = reinterpret_cast<const uint4*>(P.d2 + (long long)idx2 * 32); da = d4[0]; db = d4[1]; }
+        for (int i = 0; i < len1; i++) {
+            if (!__builtin_amdgcn_readlane(v1, i)) continue;                                   // !pMP || pMP->isBad()   (:195-199)
+            const unsigned qx = __builtin_amdgcn_readlane((int)pa.x, i), qy = __builtin_amdgcn_readlane((int)pa.y, i), qz = __builtin_amdgcn_readlane((int)pa.z, i), qw = __builtin_amdgcn_readlane((int)pa.w, i);
+            const unsigned rx = __builtin_amdgcn_readlane((int)pb.x, i), ry = __builtin_amdgcn_readlane((int)pb.y, i), rz = __builtin_amdgcn_readlane((int)pb.z, i), rw = __builtin_amdgcn_readlane((int)pb.w, i);
+            const bool ok = ok2 && !taken;                                                   // :207-208 / :574-579
+            const int dist = ok ? __popc(qx ^ da.x) + __popc(qy ^ da.y) + __popc(qz ^ da.z) + __popc(qw ^ da.w) +
+                                  __popc(rx ^ db.x) + __popc(ry ^ db.y) + __popc(rz ^ db.z) + __popc(rw ^ db.w) : 256;
+            const unsigned long long V = __ballot(ok && dist < 256);
+            if (V == 0) continue;
+            const unsigned long long mk = bm_argmin_mask(dist, V);
+            const int first = __ffsll((long long)mk) - 1;
+            const int best = __builtin_amdgcn_readlane(dist, first), bidx = __builtin_amdgcn_readlane(idx2, first);
+            const unsigned long long V2 = V & ~(1ull << first);
+            int second = 256;
+            if (V2) { const unsigned long long mk2 = bm_argmin_mask(dist, V2); second = __builtin_amdgcn_readlane(dist, __ffsll((long long)mk2) - 1); }
+            const bool close = P.mode == 0 ? best <= ORBHIP_TH_LOW : best < ORBHIP_TH_LOW;                 // :221 / :588
+            const int i1 = __builtin_amdgcn_readlane(idx1, i);
+            if (close && (float)best < __fmul_rn(P.nnratio, (float)second)) {                               // :223 / :590
+                if (lane == first) taken = true;
+                if (lane == 0) {
+                    P.match12[i1] = bidx;
+                    if (P.check_ori) {
+                        float rot = __fsub_rn(P.ang1[i1], P.ang2[bidx]);
+                        if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                        int bin = (int)roundf(__fmul_rn(rot, 1.0f / ORBHIP_HISTO_LENGTH));
+                        if (bin == ORBHIP_HISTO_LENGTH) bin = 0;
+                        bin = min(max(bin, 0), ORBHIP_HISTO_LENGTH - 1);
+                        P.bin12[i1] = bin; atomicAdd(&P.hist[bin], 1);
+                    }
+                }
+            }
+        }
+        return;
+    }
     const int nch = (len2 + 63) >> 6;
     unsigned long long taken_lo = 0, taken_hi = 0;             // bit c: this lane's entry of chunk c is matched (c < 64 / c >= 64)
     for (int i1 = b1; i1 < e1; i1++) {
@@ -428,11 +488,69 @@ __device__ __forceinline__ void bow_triangulate_body(const TriParams& T, int a, 
     const BowMatchParams& P = T.M;
     if (a >= P.nf1) return;
     const uint32_t node = P.fn1[a];
-    int lo = 0, hi = P.nf2;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (P.fn2[mid] < node) lo = mid + 1; else hi = mid; }
-    if (lo >= P.nf2 || P.fn2[lo] != node) return;
+    const int lo = bm_find_node(P.fn2, P.nf2, node, lane);
+    if (lo < 0) return;
     const int b1 = P.fo1[a], e1 = P.fo1[a + 1], b2 = P.fo2[lo], len2 = P.fo2[lo + 1] - b2;
     const int nch = (len2 + 63) >> 6;
+    if (e1 - b1 <= 64 && len2 <= 64) {
+        // The usual node (see bow_match_body): lane t fetches feature t of either side once, the walk over side 1's features runs on registers
+        const int len1 = e1 - b1;
+        int idx1 = 0, idx2 = 0, go1 = 0, st1 = 0, oct2 = 0; bool ok2 = false, stereo2 = false;
+        float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f;
+        uint4 pa; pa.x = pa.y = pa.z = pa.w = 0u; uint4 pb = pa, da = pa, db = pa;
+        if (lane < len1) {
+            idx1 = (int)P.ff1[b1 + lane]; st1 = T.st1[idx1] != 0;
+            go1 = !P.valid1[idx1] && !(T.only_stereo && !st1);               // "If there is already a MapPoint skip" (:698-700), :708-711
+            x1 = T.kp1[4 * idx1]; y1 = T.kp1[4 * idx1 + 1];
+            const uint4* q4 = reinterpret_cast<const uint4*>(P.d1 + (long long)idx1 * 32); pa = q4[0]; pb = q4[1];
+        }
+        if (lane < len2) {
+            idx2 = (int)P.ff2[b2 + lane]; stereo2 = T.st2[idx2] != 0;
+            ok2 = !P.valid2[idx2] && !(T.only_stereo && !stereo2);           // :727-736
+            x2 = T.kp2[4 * idx2]; y2 = T.kp2[4 * idx2 + 1]; oct2 = (int)T.kp2[4 * idx2 + 3];
+            const uint4* d4 = reinterpret_cast<const uint4*>(P.d2 + (long long)idx2 * 32); da = d4[0]; db = d4[1];
+        }
+        const float gate2 = lane < len2 ? __fmul_rn(100.0f, T.scale2[oct2]) : 0.f; const double chi2 = lane < len2 ? 3.84 * (double)T.sigma2_2[oct2] : 0.0;
+        const float dxe = __fsub_rn(T.ex, x2), dye = __fsub_rn(T.ey, y2);
+        const bool near_epipole = __fadd_rn(__fmul_rn(dxe, dxe), __fmul_rn(dye, dye)) < gate2;
+        for (int i = 0; i < len1; i++) {
+            if (!__builtin_amdgcn_readlane(go1, i)) continue;
+            const bool stereo1 = __builtin_amdgcn_readlane(st1, i) != 0;
+            const float qx1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x1), i)), qy1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y1), i));
+            const float la = __fadd_rn(__fadd_rn(__fmul_rn(qx1, T.F[0]), __fmul_rn(qy1, T.F[3])), T.F[6]);      // epipolar line of kp1 in image 2 (:143-145)
+            const float lb = __fadd_rn(__fadd_rn(__fmul_rn(qx1, T.F[1]), __fmul_rn(qy1, T.F[4])), T.F[7]);
+            const float lc = __fadd_rn(__fadd_rn(__fmul_rn(qx1, T.F[2]), __fmul_rn(qy1, T.F[5])), T.F[8]);
+            const float den = __fadd_rn(__fmul_rn(la, la), __fmul_rn(lb, lb));
+            const unsigned qx = __builtin_amdgcn_readlane((int)pa.x, i), qy = __builtin_amdgcn_readlane((int)pa.y, i), qz = __builtin_amdgcn_readlane((int)pa.z, i), qw = __builtin_amdgcn_readlane((int)pa.w, i);
+            const unsigned rx = __builtin_amdgcn_readlane((int)pb.x, i), ry = __builtin_amdgcn_readlane((int)pb.y, i), rz = __builtin_amdgcn_readlane((int)pb.z, i), rw = __builtin_amdgcn_readlane((int)pb.w, i);
+            const int dist = __popc(qx ^ da.x) + __popc(qy ^ da.y) + __popc(qz ^ da.z) + __popc(qw ^ da.w) +
+                             __popc(rx ^ db.x) + __popc(ry ^ db.y) + __popc(rz ^ db.z) + __popc(rw ^ db.w);
+            bool ok = ok2 && dist <= ORBHIP_TH_LOW;                                          // :742
+            if (!stereo1 && !stereo2 && near_epipole) ok = false;                            // :747-753
+            const float num = __fadd_rn(__fadd_rn(__fmul_rn(la, x2), __fmul_rn(lb, y2)), lc);
+            const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
+            if (den == 0.0f || !((double)dsqr < chi2)) ok = false;                           // :149-156
+            const unsigned long long V = __ballot(ok);
+            const int i1 = __builtin_amdgcn_readlane(idx1, i);
+            if (V == 0) continue;
+            const unsigned long long mk = bm_argmin_mask(dist, V);
+            const int last = 63 - __clzll((long long)mk);                                    // `dist <= bestDist` keeps the LAST of equal candidates
+            const int bidx = __builtin_amdgcn_readlane(idx2, last);
+            const float ang1 = T.kp1[4 * i1 + 2];
+            if (lane == 0) {
+                P.match12[i1] = bidx;
+                if (P.check_ori) {
+                    float rot = __fsub_rn(ang1, T.kp2[4 * bidx + 2]);
+                    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                    int bin = (int)roundf(__fmul_rn(rot, 1.0f / ORBHIP_HISTO_LENGTH));
+                    if (bin == ORBHIP_HISTO_LENGTH) bin = 0;
+                    bin = min(max(bin, 0), ORBHIP_HISTO_LENGTH - 1);
+                    P.bin12[i1] = bin; atomicAdd(&P.hist[bin], 1);
+                }
+            }
+        }
+        return;
+    }
     for (int i1 = b1; i1 < e1; i1++) {
         const unsigned idx1 = P.ff1[i1];
         if (P.valid1[idx1]) continue;                                   // "If there is already a MapPoint skip" (:698-700)
