@@ -299,6 +299,7 @@ struct BowMatchParams {
     int* match12; int* bin12; int* hist; int* nmatches; int* overflow;
 };
 #define BM_CHUNKS 128                   // side-2 features of one node handled per wave: 64 * BM_CHUNKS
+#define BM_REG 4                        // ... of which a node with up to 64 * BM_REG keeps them in registers
 
 __device__ __forceinline__ unsigned long long bm_argmin_mask(int d, unsigned long long M)
 {   // lanes of M holding the minimum of a 9-bit key: MSB-first elimination with ballots
@@ -335,44 +336,63 @@ __device__ __forceinline__ void bow_match_body(const BowMatchParams& P, int a, i
     if (lo < 0) return;
     const int b1 = P.fo1[a], e1 = P.fo1[a + 1], b2 = P.fo2[lo], len2 = P.fo2[lo + 1] - b2;
     if (len2 > 64 * BM_CHUNKS) { if (lane == 0) atomicAdd(P.overflow, 1); return; }
-    if (e1 - b1 <= 64 && len2 <= 64) {
-        // The usual node: both sides' features fit one wavefront.  Lane t fetches feature t of either side ONCE - index, flag, descriptor - and the walk over
-        // side 1's features (in order: an earlier one takes a side-2 feature away from the later ones) runs on registers, the query taken from its lane by
-        // v_readlane.  (The general walk below fetches index -> flag -> descriptor for every side-1 feature in turn and side 2's for each of them again:
-        // some thirty dependent round trips per node, 0.027 ms for a pair of 1000-feature frames.)
-        const int len1 = e1 - b1;
-        int idx1 = 0, idx2 = 0, v1 = 0; bool ok2 = false, taken = false;
-        uint4 pa; pa.x = pa.y = pa.z = pa.w = 0u; uint4 pb = pa, da = pa, db = pa;
-        if (lane < len1) { idx1 = (int)P.ff1[b1 + lane]; v1 = P.valid1[idx1]; const uint4* q4 = reinterpret_cast<const uint4*>(P.d1 + (long long)idx1 * 32); pa = q4[0]; pb = q4[1]; }
-        if (lane < len2) { idx2 = (int)P.ff2[b2 + lane]; ok2 = !(P.mode == 1 && !P.valid2[idx2]); const uint4* d4 = reinterpret_cast<const uint4*>(P.d2 + (long long)idx2 * 32); da = d4[0]; db = d4[1]; }
-        for (int i = 0; i < len1; i++) {
-            if (!__builtin_amdgcn_readlane(v1, i)) continue;                                   // !pMP || pMP->isBad()   (:195-199)
-            const unsigned qx = __builtin_amdgcn_readlane((int)pa.x, i), qy = __builtin_amdgcn_readlane((int)pa.y, i), qz = __builtin_amdgcn_readlane((int)pa.z, i), qw = __builtin_amdgcn_readlane((int)pa.w, i);
-            const unsigned rx = __builtin_amdgcn_readlane((int)pb.x, i), ry = __builtin_amdgcn_readlane((int)pb.y, i), rz = __builtin_amdgcn_readlane((int)pb.z, i), rw = __builtin_amdgcn_readlane((int)pb.w, i);
-            const bool ok = ok2 && !taken;                                                   // :207-208 / :574-579
-            const int dist = ok ? __popc(qx ^ da.x) + __popc(qy ^ da.y) + __popc(qz ^ da.z) + __popc(qw ^ da.w) +
-                                  __popc(rx ^ db.x) + __popc(ry ^ db.y) + __popc(rz ^ db.z) + __popc(rw ^ db.w) : 256;
-            const unsigned long long V = __ballot(ok && dist < 256);
-            if (V == 0) continue;
-            const unsigned long long mk = bm_argmin_mask(dist, V);
-            const int first = __ffsll((long long)mk) - 1;
-            const int best = __builtin_amdgcn_readlane(dist, first), bidx = __builtin_amdgcn_readlane(idx2, first);
-            const unsigned long long V2 = V & ~(1ull << first);
-            int second = 256;
-            if (V2) { const unsigned long long mk2 = bm_argmin_mask(dist, V2); second = __builtin_amdgcn_readlane(dist, __ffsll((long long)mk2) - 1); }
-            const bool close = P.mode == 0 ? best <= ORBHIP_TH_LOW : best < ORBHIP_TH_LOW;                 // :221 / :588
-            const int i1 = __builtin_amdgcn_readlane(idx1, i);
-            if (close && (float)best < __fmul_rn(P.nnratio, (float)second)) {                               // :223 / :590
-                if (lane == first) taken = true;
-                if (lane == 0) {
-                    P.match12[i1] = bidx;
-                    if (P.check_ori) {
-                        float rot = __fsub_rn(P.ang1[i1], P.ang2[bidx]);
-                        if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
-                        int bin = (int)roundf(__fmul_rn(rot, 1.0f / ORBHIP_HISTO_LENGTH));
-                        if (bin == ORBHIP_HISTO_LENGTH) bin = 0;
-                        bin = min(max(bin, 0), ORBHIP_HISTO_LENGTH - 1);
-                        P.bin12[i1] = bin; atomicAdd(&P.hist[bin], 1);
+    if (len2 <= 64 * BM_REG) {
+        // The usual node: side 2's features fit the wavefront's registers (lane t holds features t, t + 64, ... of the node: index, flag, descriptor, fetched
+        // ONCE), side 1's are fetched 64 at a time, and the walk over them (in order: an earlier one takes a side-2 feature away from the later ones) runs on
+        // registers, the query taken from its lane by v_readlane.  (The general walk below fetches index -> flag -> descriptor for every side-1 feature in turn
+        // and side 2's for each of them again: some three dependent round trips per side-1 feature, 0.027 ms for a pair of 1000-feature frames with ten
+        // features a node and most of a 2000-feature pair's 0.2 ms, whose largest node decides.)
+        const int nchr = (len2 + 63) >> 6;
+        int idx2[BM_REG]; bool ok2[BM_REG]; uint4 da[BM_REG], db[BM_REG];
+#pragma unroll
+        for (int c = 0; c < BM_REG; c++) {
+            idx2[c] = 0; ok2[c] = false; da[c].x = da[c].y = da[c].z = da[c].w = 0u; db[c] = da[c];
+            const int t = c * 64 + lane;
+            if (t < len2) {
+                idx2[c] = (int)P.ff2[b2 + t]; ok2[c] = !(P.mode == 1 && !P.valid2[idx2[c]]);      // :207-208 / :574-579
+                const uint4* d4 = reinterpret_cast<const uint4*>(P.d2 + (long long)idx2[c] * 32); da[c] = d4[0]; db[c] = d4[1];
+            }
+        }
+        unsigned taken = 0;                                    // bit c: this lane's entry of chunk c is matched
+        for (int blk = b1; blk < e1; blk += 64) {
+            const int cnt = min(64, e1 - blk);
+            int idx1 = 0, v1 = 0; uint4 pa; pa.x = pa.y = pa.z = pa.w = 0u; uint4 pb = pa;
+            if (lane < cnt) { idx1 = (int)P.ff1[blk + lane]; v1 = P.valid1[idx1]; const uint4* q4 = reinterpret_cast<const uint4*>(P.d1 + (long long)idx1 * 32); pa = q4[0]; pb = q4[1]; }
+            for (int i = 0; i < cnt; i++) {
+                if (!__builtin_amdgcn_readlane(v1, i)) continue;                               // !pMP || pMP->isBad()   (:195-199)
+                const unsigned qx = __builtin_amdgcn_readlane((int)pa.x, i), qy = __builtin_amdgcn_readlane((int)pa.y, i), qz = __builtin_amdgcn_readlane((int)pa.z, i), qw = __builtin_amdgcn_readlane((int)pa.w, i);
+                const unsigned rx = __builtin_amdgcn_readlane((int)pb.x, i), ry = __builtin_amdgcn_readlane((int)pb.y, i), rz = __builtin_amdgcn_readlane((int)pb.z, i), rw = __builtin_amdgcn_readlane((int)pb.w, i);
+                const int i1 = __builtin_amdgcn_readlane(idx1, i);
+                int best = 256, second = 256, bidx = -1, bchunk = 0, blane = 0;
+#pragma unroll
+                for (int c = 0; c < BM_REG; c++) {
+                    if (c >= nchr) continue;
+                    const bool ok = ok2[c] && !((taken >> c) & 1u);
+                    const int dist = ok ? __popc(qx ^ da[c].x) + __popc(qy ^ da[c].y) + __popc(qz ^ da[c].z) + __popc(qw ^ da[c].w) +
+                                          __popc(rx ^ db[c].x) + __popc(ry ^ db[c].y) + __popc(rz ^ db[c].z) + __popc(rw ^ db[c].w) : 256;
+                    const unsigned long long V = __ballot(ok && dist < 256);        // dist == 256 can never pass `dist < bestDist` (init 256)
+                    if (V == 0) continue;
+                    const unsigned long long mk = bm_argmin_mask(dist, V);
+                    const int first = __ffsll((long long)mk) - 1;
+                    const int wmin = __builtin_amdgcn_readlane(dist, first), ci = __builtin_amdgcn_readlane(idx2[c], first);
+                    const unsigned long long V2 = V & ~(1ull << first);
+                    int wsec = 256;
+                    if (V2) { const unsigned long long mk2 = bm_argmin_mask(dist, V2); wsec = __builtin_amdgcn_readlane(dist, __ffsll((long long)mk2) - 1); }
+                    if (wmin < best) { second = min(best, wsec); best = wmin; bidx = ci; bchunk = c; blane = first; } else second = min(second, wmin);
+                }
+                const bool close = P.mode == 0 ? best <= ORBHIP_TH_LOW : best < ORBHIP_TH_LOW;                 // :221 / :588
+                if (close && (float)best < __fmul_rn(P.nnratio, (float)second)) {                               // :223 / :590
+                    if (lane == blane) taken |= 1u << bchunk;
+                    if (lane == 0) {
+                        P.match12[i1] = bidx;
+                        if (P.check_ori) {
+                            float rot = __fsub_rn(P.ang1[i1], P.ang2[bidx]);
+                            if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                            int bin = (int)roundf(__fmul_rn(rot, 1.0f / ORBHIP_HISTO_LENGTH));
+                            if (bin == ORBHIP_HISTO_LENGTH) bin = 0;
+                            bin = min(max(bin, 0), ORBHIP_HISTO_LENGTH - 1);
+                            P.bin12[i1] = bin; atomicAdd(&P.hist[bin], 1);
+                        }
                     }
                 }
             }
@@ -492,60 +512,72 @@ __device__ __forceinline__ void bow_triangulate_body(const TriParams& T, int a, 
     if (lo < 0) return;
     const int b1 = P.fo1[a], e1 = P.fo1[a + 1], b2 = P.fo2[lo], len2 = P.fo2[lo + 1] - b2;
     const int nch = (len2 + 63) >> 6;
-    if (e1 - b1 <= 64 && len2 <= 64) {
-        // The usual node (see bow_match_body): lane t fetches feature t of either side once, the walk over side 1's features runs on registers
-        const int len1 = e1 - b1;
-        int idx1 = 0, idx2 = 0, go1 = 0, st1 = 0, oct2 = 0; bool ok2 = false, stereo2 = false;
-        float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f;
-        uint4 pa; pa.x = pa.y = pa.z = pa.w = 0u; uint4 pb = pa, da = pa, db = pa;
-        if (lane < len1) {
-            idx1 = (int)P.ff1[b1 + lane]; st1 = T.st1[idx1] != 0;
-            go1 = !P.valid1[idx1] && !(T.only_stereo && !st1);               // "If there is already a MapPoint skip" (:698-700), :708-711
-            x1 = T.kp1[4 * idx1]; y1 = T.kp1[4 * idx1 + 1];
-            const uint4* q4 = reinterpret_cast<const uint4*>(P.d1 + (long long)idx1 * 32); pa = q4[0]; pb = q4[1];
+    if (len2 <= 64 * BM_REG) {
+        // The usual node (see bow_match_body): side 2's features in registers, side 1's fetched 64 at a time, the walk on registers
+        int idx2[BM_REG]; bool ok2[BM_REG], stereo2[BM_REG], near_epipole[BM_REG]; float x2[BM_REG], y2[BM_REG]; double chi2[BM_REG]; uint4 da[BM_REG], db[BM_REG];
+#pragma unroll
+        for (int c = 0; c < BM_REG; c++) {
+            idx2[c] = 0; ok2[c] = false; stereo2[c] = false; near_epipole[c] = false; x2[c] = y2[c] = 0.f; chi2[c] = 0.0; da[c].x = da[c].y = da[c].z = da[c].w = 0u; db[c] = da[c];
+            const int t = c * 64 + lane;
+            if (t < len2) {
+                idx2[c] = (int)P.ff2[b2 + t]; stereo2[c] = T.st2[idx2[c]] != 0;
+                ok2[c] = !P.valid2[idx2[c]] && !(T.only_stereo && !stereo2[c]);             // :727-736
+                x2[c] = T.kp2[4 * idx2[c]]; y2[c] = T.kp2[4 * idx2[c] + 1]; const int oct2 = (int)T.kp2[4 * idx2[c] + 3];
+                const uint4* d4 = reinterpret_cast<const uint4*>(P.d2 + (long long)idx2[c] * 32); da[c] = d4[0]; db[c] = d4[1];
+                const float dxe = __fsub_rn(T.ex, x2[c]), dye = __fsub_rn(T.ey, y2[c]);
+                near_epipole[c] = __fadd_rn(__fmul_rn(dxe, dxe), __fmul_rn(dye, dye)) < __fmul_rn(100.0f, T.scale2[oct2]);     // :747-753
+                chi2[c] = 3.84 * (double)T.sigma2_2[oct2];
+            }
         }
-        if (lane < len2) {
-            idx2 = (int)P.ff2[b2 + lane]; stereo2 = T.st2[idx2] != 0;
-            ok2 = !P.valid2[idx2] && !(T.only_stereo && !stereo2);           // :727-736
-            x2 = T.kp2[4 * idx2]; y2 = T.kp2[4 * idx2 + 1]; oct2 = (int)T.kp2[4 * idx2 + 3];
-            const uint4* d4 = reinterpret_cast<const uint4*>(P.d2 + (long long)idx2 * 32); da = d4[0]; db = d4[1];
-        }
-        const float gate2 = lane < len2 ? __fmul_rn(100.0f, T.scale2[oct2]) : 0.f; const double chi2 = lane < len2 ? 3.84 * (double)T.sigma2_2[oct2] : 0.0;
-        const float dxe = __fsub_rn(T.ex, x2), dye = __fsub_rn(T.ey, y2);
-        const bool near_epipole = __fadd_rn(__fmul_rn(dxe, dxe), __fmul_rn(dye, dye)) < gate2;
-        for (int i = 0; i < len1; i++) {
-            if (!__builtin_amdgcn_readlane(go1, i)) continue;
-            const bool stereo1 = __builtin_amdgcn_readlane(st1, i) != 0;
-            const float qx1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x1), i)), qy1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y1), i));
-            const float la = __fadd_rn(__fadd_rn(__fmul_rn(qx1, T.F[0]), __fmul_rn(qy1, T.F[3])), T.F[6]);      // epipolar line of kp1 in image 2 (:143-145)
-            const float lb = __fadd_rn(__fadd_rn(__fmul_rn(qx1, T.F[1]), __fmul_rn(qy1, T.F[4])), T.F[7]);
-            const float lc = __fadd_rn(__fadd_rn(__fmul_rn(qx1, T.F[2]), __fmul_rn(qy1, T.F[5])), T.F[8]);
-            const float den = __fadd_rn(__fmul_rn(la, la), __fmul_rn(lb, lb));
-            const unsigned qx = __builtin_amdgcn_readlane((int)pa.x, i), qy = __builtin_amdgcn_readlane((int)pa.y, i), qz = __builtin_amdgcn_readlane((int)pa.z, i), qw = __builtin_amdgcn_readlane((int)pa.w, i);
-            const unsigned rx = __builtin_amdgcn_readlane((int)pb.x, i), ry = __builtin_amdgcn_readlane((int)pb.y, i), rz = __builtin_amdgcn_readlane((int)pb.z, i), rw = __builtin_amdgcn_readlane((int)pb.w, i);
-            const int dist = __popc(qx ^ da.x) + __popc(qy ^ da.y) + __popc(qz ^ da.z) + __popc(qw ^ da.w) +
-                             __popc(rx ^ db.x) + __popc(ry ^ db.y) + __popc(rz ^ db.z) + __popc(rw ^ db.w);
-            bool ok = ok2 && dist <= ORBHIP_TH_LOW;                                          // :742
-            if (!stereo1 && !stereo2 && near_epipole) ok = false;                            // :747-753
-            const float num = __fadd_rn(__fadd_rn(__fmul_rn(la, x2), __fmul_rn(lb, y2)), lc);
-            const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
-            if (den == 0.0f || !((double)dsqr < chi2)) ok = false;                           // :149-156
-            const unsigned long long V = __ballot(ok);
-            const int i1 = __builtin_amdgcn_readlane(idx1, i);
-            if (V == 0) continue;
-            const unsigned long long mk = bm_argmin_mask(dist, V);
-            const int last = 63 - __clzll((long long)mk);                                    // `dist <= bestDist` keeps the LAST of equal candidates
-            const int bidx = __builtin_amdgcn_readlane(idx2, last);
-            const float ang1 = T.kp1[4 * i1 + 2];
-            if (lane == 0) {
-                P.match12[i1] = bidx;
-                if (P.check_ori) {
-                    float rot = __fsub_rn(ang1, T.kp2[4 * bidx + 2]);
-                    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
-                    int bin = (int)roundf(__fmul_rn(rot, 1.0f / ORBHIP_HISTO_LENGTH));
-                    if (bin == ORBHIP_HISTO_LENGTH) bin = 0;
-                    bin = min(max(bin, 0), ORBHIP_HISTO_LENGTH - 1);
-                    P.bin12[i1] = bin; atomicAdd(&P.hist[bin], 1);
+        for (int blk = b1; blk < e1; blk += 64) {
+            const int cnt = min(64, e1 - blk);
+            int idx1 = 0, go1 = 0, st1 = 0; float x1 = 0.f, y1 = 0.f, ang1 = 0.f; uint4 pa; pa.x = pa.y = pa.z = pa.w = 0u; uint4 pb = pa;
+            if (lane < cnt) {
+                idx1 = (int)P.ff1[blk + lane]; st1 = T.st1[idx1] != 0;
+                go1 = !P.valid1[idx1] && !(T.only_stereo && !st1);           // "If there is already a MapPoint skip" (:698-700), :708-711
+                x1 = T.kp1[4 * idx1]; y1 = T.kp1[4 * idx1 + 1]; ang1 = T.kp1[4 * idx1 + 2];
+                const uint4* q4 = reinterpret_cast<const uint4*>(P.d1 + (long long)idx1 * 32); pa = q4[0]; pb = q4[1];
+            }
+            for (int i = 0; i < cnt; i++) {
+                if (!__builtin_amdgcn_readlane(go1, i)) continue;
+                const bool stereo1 = __builtin_amdgcn_readlane(st1, i) != 0;
+                const float qx1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x1), i)), qy1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y1), i));
+                const float qang = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ang1), i));
+                const int i1 = __builtin_amdgcn_readlane(idx1, i);
+                const float la = __fadd_rn(__fadd_rn(__fmul_rn(qx1, T.F[0]), __fmul_rn(qy1, T.F[3])), T.F[6]);      // epipolar line of kp1 in image 2 (:143-145)
+                const float lb = __fadd_rn(__fadd_rn(__fmul_rn(qx1, T.F[1]), __fmul_rn(qy1, T.F[4])), T.F[7]);
+                const float lc = __fadd_rn(__fadd_rn(__fmul_rn(qx1, T.F[2]), __fmul_rn(qy1, T.F[5])), T.F[8]);
+                const float den = __fadd_rn(__fmul_rn(la, la), __fmul_rn(lb, lb));
+                const unsigned qx = __builtin_amdgcn_readlane((int)pa.x, i), qy = __builtin_amdgcn_readlane((int)pa.y, i), qz = __builtin_amdgcn_readlane((int)pa.z, i), qw = __builtin_amdgcn_readlane((int)pa.w, i);
+                const unsigned rx = __builtin_amdgcn_readlane((int)pb.x, i), ry = __builtin_amdgcn_readlane((int)pb.y, i), rz = __builtin_amdgcn_readlane((int)pb.z, i), rw = __builtin_amdgcn_readlane((int)pb.w, i);
+                int best = ORBHIP_TH_LOW, bidx = -1;
+#pragma unroll
+                for (int c = 0; c < BM_REG; c++) {
+                    if (c >= nch) continue;
+                    const int dist = __popc(qx ^ da[c].x) + __popc(qy ^ da[c].y) + __popc(qz ^ da[c].z) + __popc(qw ^ da[c].w) +
+                                     __popc(rx ^ db[c].x) + __popc(ry ^ db[c].y) + __popc(rz ^ db[c].z) + __popc(rw ^ db[c].w);
+                    bool ok = ok2[c] && dist <= ORBHIP_TH_LOW;                                   // :742
+                    if (!stereo1 && !stereo2[c] && near_epipole[c]) ok = false;                  // :747-753
+                    const float num = __fadd_rn(__fadd_rn(__fmul_rn(la, x2[c]), __fmul_rn(lb, y2[c])), lc);
+                    const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
+                    if (den == 0.0f || !((double)dsqr < chi2[c])) ok = false;                    // :149-156
+                    const unsigned long long V = __ballot(ok);
+                    if (V == 0) continue;
+                    const unsigned long long mk = bm_argmin_mask(dist, V);
+                    const int last = 63 - __clzll((long long)mk);                                // `dist <= bestDist` keeps the LAST of equal candidates
+                    const int wmin = __builtin_amdgcn_readlane(dist, last), ci = __builtin_amdgcn_readlane(idx2[c], last);
+                    if (wmin <= best) { best = wmin; bidx = ci; }
+                }
+                if (bidx >= 0 && lane == 0) {
+                    P.match12[i1] = bidx;
+                    if (P.check_ori) {
+                        float rot = __fsub_rn(qang, T.kp2[4 * bidx + 2]);
+                        if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                        int bin = (int)roundf(__fmul_rn(rot, 1.0f / ORBHIP_HISTO_LENGTH));
+                        if (bin == ORBHIP_HISTO_LENGTH) bin = 0;
+                        bin = min(max(bin, 0), ORBHIP_HISTO_LENGTH - 1);
+                        P.bin12[i1] = bin; atomicAdd(&P.hist[bin], 1);
+                    }
                 }
             }
         }
