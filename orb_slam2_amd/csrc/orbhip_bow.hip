@@ -311,6 +311,19 @@ __device__ __forceinline__ unsigned long long bm_argmin_mask(int d, unsigned lon
 // slot of a batched launch that block `block` belongs to: pref[s] = first block of slot s (ascending, pref[nslots] = grid size); uniform -> scalar loads
 __device__ __forceinline__ int bm_batch_slot(const int* pref, int nslots, int block) { int s = 0; while (s + 1 < nslots && block >= pref[s + 1]) s++; return s; }
 
+// wave64 minimum with DPP row shifts / broadcasts (6 dependent VALU steps against the 9 ballots of bm_argmin_mask); result broadcast from lane 63
+__device__ __forceinline__ int bm_wave_min(int v)
+{
+    const int IMAX = 0x7fffffff;
+    v = min(v, __builtin_amdgcn_update_dpp(IMAX, v, 0x111, 0xf, 0xf, false));      // row_shr:1
+    v = min(v, __builtin_amdgcn_update_dpp(IMAX, v, 0x112, 0xf, 0xf, false));      // row_shr:2
+    v = min(v, __builtin_amdgcn_update_dpp(IMAX, v, 0x114, 0xf, 0xe, false));      // row_shr:4
+    v = min(v, __builtin_amdgcn_update_dpp(IMAX, v, 0x118, 0xf, 0xc, false));      // row_shr:8 -> lane 15 of each row = row minimum
+    v = min(v, __builtin_amdgcn_update_dpp(IMAX, v, 0x142, 0xa, 0xf, false));      // row_bcast:15 into rows 1 and 3
+    v = min(v, __builtin_amdgcn_update_dpp(IMAX, v, 0x143, 0xc, 0xf, false));      // row_bcast:31 into rows 2 and 3 -> lane 63 = wave minimum
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 // position of `node` among side 2's ascending node ids, -1 if it is not there (whole wavefront, uniform result)
 __device__ __forceinline__ int bm_find_node(const uint32_t* fn2, int nf2, uint32_t node, int lane)
 {
@@ -370,14 +383,14 @@ __device__ __forceinline__ void bow_match_body(const BowMatchParams& P, int a, i
                     const bool ok = ok2[c] && !((taken >> c) & 1u);
                     const int dist = ok ? __popc(qx ^ da[c].x) + __popc(qy ^ da[c].y) + __popc(qz ^ da[c].z) + __popc(qw ^ da[c].w) +
                                           __popc(rx ^ db[c].x) + __popc(ry ^ db[c].y) + __popc(rz ^ db[c].z) + __popc(rw ^ db[c].w) : 256;
-                    const unsigned long long V = __ballot(ok && dist < 256);        // dist == 256 can never pass `dist < bestDist` (init 256)
-                    if (V == 0) continue;
-                    const unsigned long long mk = bm_argmin_mask(dist, V);
-                    const int first = __ffsll((long long)mk) - 1;
-                    const int wmin = __builtin_amdgcn_readlane(dist, first), ci = __builtin_amdgcn_readlane(idx2[c], first);
-                    const unsigned long long V2 = V & ~(1ull << first);
-                    int wsec = 256;
-                    if (V2) { const unsigned long long mk2 = bm_argmin_mask(dist, V2); wsec = __builtin_amdgcn_readlane(dist, __ffsll((long long)mk2) - 1); }
+                    // smallest (distance, lane) key: the first candidate with the minimum wins; the runner-up is the minimum with that lane masked out.
+                    // (dist == 256 can never pass `dist < bestDist`, init 256)
+                    const int key = (ok && dist < 256) ? ((dist << 6) | lane) : 0x7fffffff;
+                    const int k1 = bm_wave_min(key);
+                    if (k1 == 0x7fffffff) continue;
+                    const int first = k1 & 63, wmin = k1 >> 6, ci = __builtin_amdgcn_readlane(idx2[c], first);
+                    const int k2 = bm_wave_min(lane == first ? 0x7fffffff : key);
+                    const int wsec = k2 == 0x7fffffff ? 256 : (k2 >> 6);
                     if (wmin < best) { second = min(best, wsec); best = wmin; bidx = ci; bchunk = c; blane = first; } else second = min(second, wmin);
                 }
                 const bool close = P.mode == 0 ? best <= ORBHIP_TH_LOW : best < ORBHIP_TH_LOW;                 // :221 / :588
@@ -561,11 +574,9 @@ __device__ __forceinline__ void bow_triangulate_body(const TriParams& T, int a, 
                     const float num = __fadd_rn(__fadd_rn(__fmul_rn(la, x2[c]), __fmul_rn(lb, y2[c])), lc);
                     const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
                     if (den == 0.0f || !((double)dsqr < chi2[c])) ok = false;                    // :149-156
-                    const unsigned long long V = __ballot(ok);
-                    if (V == 0) continue;
-                    const unsigned long long mk = bm_argmin_mask(dist, V);
-                    const int last = 63 - __clzll((long long)mk);                                // `dist <= bestDist` keeps the LAST of equal candidates
-                    const int wmin = __builtin_amdgcn_readlane(dist, last), ci = __builtin_amdgcn_readlane(idx2[c], last);
+                    const int k1 = bm_wave_min(ok ? ((dist << 6) | (63 - lane)) : 0x7fffffff);      // `dist <= bestDist` keeps the LAST of equal candidates
+                    if (k1 == 0x7fffffff) continue;
+                    const int wmin = k1 >> 6, ci = __builtin_amdgcn_readlane(idx2[c], 63 - (k1 & 63));
                     if (wmin <= best) { best = wmin; bidx = ci; }
                 }
                 if (bidx >= 0 && lane == 0) {
