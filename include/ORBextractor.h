@@ -5,6 +5,7 @@
 #ifndef ORBEXTRACTOR_H
 #define ORBEXTRACTOR_H
 
+#include <atomic>
 #include <list>
 #include <mutex>
 #include <stdexcept>
@@ -138,8 +139,13 @@ public:
     // ExtractORB, Frame.cc:84, 136, 194) names the frame with its mnId; the next image replaces the state.  A matcher that is handed that
     // Frame (Tracking's SearchByProjection calls on mCurrentFrame) then searches the resident key points / descriptors / mvuRight through the
     // *_frame entry points of orbhip.h — only its queries cross PCIe — and any other Frame goes through host buffers as before.
-    void BindFrame(unsigned long frameId) { mnBoundFrame = frameId; mbBound = true; }
-    bool HoldsFrame(unsigned long frameId, int N) const { return mpCtx && mbFrameState && mbBound && mnBoundFrame == frameId && N == mnLastN; }
+    // The frame-resident forms are for the thread that built the frame (Tracking: the constructor, Frame::ComputeBoW and the Frame searches all run there,
+    // Tracking.cc:167-238, 867-928, 1143-1193, 1344-1520).  BindFrame records it; a caller on ANY OTHER thread is told "not held" without a look at the
+    // extractor's state - which the owning thread may be rewriting with its next image at that moment - and takes the host path on the frame's own copies.
+    void BindFrame(unsigned long frameId) { mnBoundFrame = frameId; mbBound = true; mnOwnerThread.store(ThisThread(), std::memory_order_release); }
+    bool HoldsFrame(unsigned long frameId, int N) const
+    { return mnOwnerThread.load(std::memory_order_acquire) == ThisThread() && mpCtx && mbFrameState && mbBound && mnBoundFrame == frameId && N == mnLastN; }
+    static unsigned long ThisThread() { static std::atomic<unsigned long> next(0); static thread_local unsigned long mine = ++next; return mine; }     // never 0, never reused
     // mvuRight the caller computed itself (the reference's Frame::ComputeStereoFromRGBD loop, Frame.cc:643-665) for the frame this extractor still holds:
     // N floats go to the device for the resident searches instead of the depth map.  integration/apply_dropin.py appends the call to the reference's loop.
     void SetStereoColumns(const std::vector<float>& mvuRight);
@@ -187,6 +193,7 @@ protected:
     void RequireFrameState(const char* where) const;
     float mfScaleFactorArg;
     unsigned long mnBoundFrame; bool mbBound, mbStereoColumns;
+    std::atomic<unsigned long> mnOwnerThread;                    // ThisThread() of the last BindFrame
 };
 
 } // namespace ORB_SLAM2

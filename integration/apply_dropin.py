@@ -657,8 +657,17 @@ static void orbhip_projection_search(Frame &F, bool bUseRight, const std::vector
                                      const std::vector<unsigned char> &qd, int mode, float nnratio, int thHigh, bool bCheckOri, std::vector<int> &fq, int &nmatches)
 {
     ORBextractor* ex = F.mpORBextractorLeft;
-    if(ex && ex->HoldsFrame(F.mnId, F.N))
-        orbhip_check(orbhip_search_by_projection_frame(ex->Context(), 0, F.N, bUseRight && ex->HoldsStereoColumns(), &blocked[0], &q[0], &qd[0], (int)q.size(),
+    bool resident = ex && ex->HoldsFrame(F.mnId, F.N), right = bUseRight;
+    if(resident && bUseRight && !ex->HoldsStereoColumns())
+    {
+        // no mvuRight on the device: a monocular frame (all -1: the right-coordinate test never fires) is searched there without it, a frame whose columns
+        // exist on the host only (a ComputeStereoFromRGBD that did not hand them over) is searched through its host copies
+        right = false;
+        for(int i=0; i<F.N; i++)
+            if(F.mvuRight[i]>0) { resident = false; break; }
+    }
+    if(resident)
+        orbhip_check(orbhip_search_by_projection_frame(ex->Context(), 0, F.N, right, &blocked[0], &q[0], &qd[0], (int)q.size(),
                                                        mode, nnratio, thHigh, bCheckOri, &fq[0], &nmatches));
     else
     {

@@ -32,7 +32,7 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int
       mnFpContract(0),
 #endif
       mnSettings(0), mnStamp(0), mvTicketSizes(4, 0), mbDownloadPyramid(false), mnPendingTickets(0), mbFrameState(false), mfScaleFactorArg(_scaleFactor),
-      mnBoundFrame(0), mbBound(false), mbStereoColumns(false)
+      mnBoundFrame(0), mbBound(false), mbStereoColumns(false), mnOwnerThread(0)
 {
     memset(mCamera, 0, sizeof mCamera);
     mvScaleFactor.resize(nlevels); mvLevelSigma2.resize(nlevels);

@@ -111,6 +111,10 @@ int main(int argc, char** argv)
                      && uOne.size() == uTwo.size() && !memcmp(&uOne[0], &uTwo[0], 4 * uOne.size()) && !memcmp(&dOne[0], &dTwo[0], 4 * dOne.size());
                 for (int i = 0; i < F1.N && ok; i++) ok = !memcmp(dL.ptr(i), F1.mDescriptors.ptr(i), 32);
                 for (int i = 0; i < F2.N && ok; i++) ok = !memcmp(dR.ptr(i), F2.mDescriptors.ptr(i), 32);
+                // the frame-resident forms belong to the thread that bound the frame: another thread is told "not held" (and takes the host path)
+                exP->BindFrame(100 + rep);
+                bool other = true; std::thread th([&] { other = exP->HoldsFrame(100 + rep, (int)kL.size()); }); th.join();
+                ok = ok && exP->HoldsFrame(100 + rep, (int)kL.size()) && !exP->HoldsFrame(99, (int)kL.size()) && !other;
                 if (rep == 1) { std::vector<cv::KeyPoint> k1; cv::Mat d1; (*exP)(im[1], cv::Mat(), k1, d1); ok = ok && (int)k1.size() == F2.N && !exP->HoldsStereoColumns(); }      // a single-image call in between
             }
             delete exP;
