@@ -79,7 +79,7 @@ struct orbhip_ctx {
     // the three output arrays of a buffer are carved from ONE allocation ([counts | key points | descriptors], 256-byte aligned parts): the whole
     // result of a small batch is one device-to-host copy instead of three (a single-frame call spent 60 us between its second and third copy)
     uint8_t* d_out_block[3] = {nullptr, nullptr, nullptr}; size_t out_off_kp = 0, out_off_desc = 0, out_block_bytes = 0; uint8_t* h_block = nullptr;
-    hipStream_t bstream = nullptr; hipEvent_t ev_pyr = nullptr, ev_blur = nullptr;      // blur runs beside FAST + quadtree (independent until describe)
+    hipStream_t bstream = nullptr, bstream_host = nullptr; hipEvent_t ev_pyr = nullptr, ev_blur = nullptr;      // blur runs beside FAST + quadtree (independent until describe)
     // k_pyramid_cascade (every level in one launch, used for a handful of frames): per level the column ranges of each tile column and the row ranges of
     // each tile row, LDS layout sizes; pc_ok = the context's shape fits
     short2* d_pc_xr = nullptr; short2* d_pc_yr = nullptr; int pc_ntx = 0, pc_nty = 0, pc_buf0 = 0, pc_buf1 = 0, pc_xcap = 0, pc_ycap = 0; bool pc_ok = false;
@@ -352,6 +352,7 @@ extern "C" void orbhip_destroy(orbhip_ctx* c)
     orbhip_bow_forget_ctx(c);                                      // BoW workspaces the vocabularies keep for this context (they ran on c->stream)
     if (c->mstream) { (void)hipStreamSynchronize(c->mstream); (void)hipStreamDestroy(c->mstream); }
     if (c->bstream) { (void)hipStreamSynchronize(c->bstream); (void)hipStreamDestroy(c->bstream); }
+    if (c->bstream_host) { (void)hipStreamSynchronize(c->bstream_host); (void)hipStreamDestroy(c->bstream_host); }
     if (c->d_pc_xr) (void)hipFree(c->d_pc_xr);
     if (c->d_pc_yr) (void)hipFree(c->d_pc_yr);
     if (c->ev_pyr) (void)hipEventDestroy(c->ev_pyr);
@@ -537,6 +538,7 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
         bool ok = (prio_mode >= 2 ? hipStreamCreateWithPriority(&c->mstream, hipStreamNonBlocking, prio_lo) : hipStreamCreateWithFlags(&c->mstream, hipStreamNonBlocking)) == hipSuccess &&
                   hipEventCreateWithFlags(&c->ev_extract, hipEventDisableTiming) == hipSuccess &&
                   (prio_mode >= 1 ? hipStreamCreateWithPriority(&c->bstream, hipStreamNonBlocking, prio_lo) : hipStreamCreateWithFlags(&c->bstream, hipStreamNonBlocking)) == hipSuccess &&
+                  hipStreamCreateWithFlags(&c->bstream_host, hipStreamNonBlocking) == hipSuccess &&
                   hipEventCreateWithFlags(&c->ev_pyr, hipEventDisableTiming) == hipSuccess &&
                   hipEventCreateWithFlags(&c->ev_blur, hipEventDisableTiming) == hipSuccess;
         for (int k = 0; k < 3 && ok; k++) ok = hipEventCreateWithFlags(&c->ev_match[k], hipEventDisableTiming) == hipSuccess;
@@ -673,14 +675,16 @@ static void launch_pyramid(orbhip_ctx* c, const ExtractParams& P, int nf, hipStr
 // workgroups are latency-bound (barriers, one workgroup per (frame, level)); every throughput kernel is alone on the GPU, so its HIP-event time
 // in a timed region is its own (bench.py's roofline object relies on that).  Other placements of the second stream landed within 1.3 % of this
 // one and are gone from the code (docs/ROUND_LOG.md, round 3 "schedules").
-static orbhip_status pipeline_frames(orbhip_ctx* c, ExtractParams& P, int f0, int nf, hipStream_t s, bool own_blur_stream)
+static orbhip_status pipeline_frames(orbhip_ctx* c, ExtractParams& P, int f0, int nf, hipStream_t s, bool own_blur_stream, bool host_path = false)
 {
     if (nf <= 0) return ORBHIP_OK;
     P.frame0 = f0;
     { ProfScope ps(c, K_PYRAMID, s); launch_pyramid(c, P, nf, s); }
     { ProfScope ps(c, K_FAST, s); orbhip_launch_fast_cells(P, nf, s); }
     if (own_blur_stream && nf > 8 && !c->serial) {      // (a handful of frames: the two event hops of the second stream cost more than the blur's 11 us - a single-frame call lost 75 us in them)
-        hipStream_t bs = c->bstream;
+        // (the host-buffer pipeline keeps a blur stream WITHOUT a priority: with the lowest one its pinned path fell from 110 k to 85 k frames/s - the blur of
+        // chunk k starved beside the copies of chunks k - 1 and k + 1, profiles/r05_exp_host_path_stream_priorities.jsonl)
+        hipStream_t bs = host_path ? c->bstream_host : c->bstream;
         HIPCHK(hipEventRecord(c->ev_pyr, s)); HIPCHK(hipStreamWaitEvent(bs, c->ev_pyr, 0));
         { ProfScope ps(c, K_QUADTREE, s); orbhip_launch_quadtree(P, nf, s); }
         { ProfScope ps(c, K_BLUR, bs); orbhip_launch_blur(P, c->gk, nf, bs); }
@@ -780,6 +784,7 @@ extern "C" orbhip_status orbhip_sync(orbhip_ctx* c)
     for (auto xs : c->xstreams) HIPCHK(hipStreamSynchronize(xs));
     if (c->mstream) HIPCHK(hipStreamSynchronize(c->mstream));
     if (c->bstream) HIPCHK(hipStreamSynchronize(c->bstream));
+    if (c->bstream_host) HIPCHK(hipStreamSynchronize(c->bstream_host));
     if (c->hstream) HIPCHK(hipStreamSynchronize(c->hstream));
     if (c->dstream) HIPCHK(hipStreamSynchronize(c->dstream));
     prof_collect(c);
@@ -1183,7 +1188,7 @@ static orbhip_status submit_body(orbhip_ctx* c, int nimg, const uint8_t* const* 
         if (pinned_in && stride != c->in_pitch)
             orbhip_launch_repitch(hs.d_packed + (size_t)f0 * stride * H, (long long)stride * H, stride, hs.d_in + f0 * fbytes, (long long)fbytes, c->in_pitch, W, H, nf, c->stream);
         // ---- kernels
-        st = pipeline_frames(c, P, f0, nf, c->stream, true); if (st != ORBHIP_OK) return st;
+        st = pipeline_frames(c, P, f0, nf, c->stream, true, true); if (st != ORBHIP_OK) return st;
         if (piped) { HIPCHK(hipEventRecord(hs.ev_k[k], c->stream)); HIPCHK(hipStreamWaitEvent(dst, hs.ev_k[k], 0)); }
         // ---- download
         const int cur = c->cur; const size_t oc = (size_t)c->out_cap;
@@ -1367,7 +1372,8 @@ extern "C" orbhip_status orbhip_pyramid_fetch_all(orbhip_ctx* c, int frame, uint
     if (!c || !dst || !dst_stride || frame < 0 || frame >= c->last_nimg) return fail(ORBHIP_ERR_INVALID, "bad argument");
     if (!c->last_from_host) return fail(ORBHIP_ERR_INVALID, "level 0 of a device-resident call is the caller's own buffer");
     HIPCHK(hipSetDevice(c->cfg.device));
-    if (c->bstream) HIPCHK(hipStreamSynchronize(c->bstream));               // everything that writes the planes is ordered before the main stream's tail
+    if (c->bstream) HIPCHK(hipStreamSynchronize(c->bstream));
+    if (c->bstream_host) HIPCHK(hipStreamSynchronize(c->bstream_host));               // everything that writes the planes is ordered before the main stream's tail
     for (int l = 0; l < c->L; l++) {
         if (!dst[l]) continue;
         const LevelGeom& g = c->geom[l];

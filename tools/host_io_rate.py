@@ -57,9 +57,14 @@ def rate(B, chunk, kind, mode):
 
 
 rows = []
+ONLY = os.environ.get("HOST_IO_ONLY")             # e.g. "256": just the configuration bench.py's host_io object quotes (batch 256, auto chunks, ring)
 for B, chunk in ((64, 0), (64, 16), (128, 0), (128, 32), (256, 0), (256, 64)):
+    if ONLY and (B != int(ONLY) or chunk):
+        continue
     for kind in ("pinned", "pageable"):
         for mode in ("ring", "sync"):
+            if ONLY and mode != "ring":
+                continue
             rows.append({"batch": B, "chunk": chunk or "auto", "buffers": kind, "mode": mode, "frames_per_s": rate(B, chunk, kind, mode)})
             print(json.dumps(rows[-1]), flush=True)
 os.environ.pop("ORBHIP_HOST_CHUNK", None)
