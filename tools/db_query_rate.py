@@ -46,5 +46,9 @@ out = {"kernel": "k_hamming_nn (popcount)" if valu else ("k_hamming_nn_mfma" if 
 if valu:
     out["frac_of_int_valu_issue_peak"] = round(pairs / dt / peak_pairs, 3)
 else:
-    out["mfma_i8_TOPs"] = round(pairs * 512 / dt / 1e12, 1); out["frac_of_i8_mfma_peak_measured_4400_TOPs"] = round(pairs * 512 / dt / 4.4e15, 3); out["frac_of_i8_mfma_spec_5000_TOPs"] = round(pairs * 512 / dt / 5e15, 3)
+    out["matrix_TOPs"] = round(pairs * 512 / dt / 1e12, 1)
+    if out["kernel"] == "k_hamming_nn_fp4":
+        out["frac_of_fp4_mfma_rate_measured_9100_TOPs"] = round(pairs * 512 / dt / 9.1e15, 3); out["frac_of_fp4_mfma_spec_10000_TOPs"] = round(pairs * 512 / dt / 10e15, 3)
+    else:
+        out["frac_of_i8_mfma_peak_measured_4400_TOPs"] = round(pairs * 512 / dt / 4.4e15, 3); out["frac_of_i8_mfma_spec_5000_TOPs"] = round(pairs * 512 / dt / 5e15, 3)
 print(json.dumps(out))
