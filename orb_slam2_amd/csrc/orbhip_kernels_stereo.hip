@@ -42,27 +42,44 @@ __device__ __forceinline__ const uint8_t* st_level(const StereoSide& S, const Le
 }
 
 // ------------------------------------------------------------------------------------------------ row table
-__global__ __launch_bounds__(256) void k_stereo_rows(StereoParams T)
+// 1024 threads per frame: a key point per thread for the usual 1000 - 2000 (its row range computed once and kept in registers between the counting
+// and the filling pass; a frame with more than SR_T * SR_K key points recomputes the rest), the prefix sum over the H + 1 rows one row per thread.
+// (256 threads re-reading the key points for the second pass: 17 us of a stereo pair's 33 us of matching.)
+#define SR_T 1024
+#define SR_K 4
+__global__ __launch_bounds__(SR_T) void k_stereo_rows(StereoParams T)
 {
     HIP_DYNAMIC_SHARED(int, lds)                       // [H + 1] row counters / cursors
-    __shared__ int s_scan[4];
+    __shared__ int s_scan[SR_T / 64];
     const int slot = blockIdx.x, tid = threadIdx.x, H = T.im_h;
     const int nr = T.R.n[slot];
     const orbhip_keypoint* kp = T.R.kp + (long long)slot * T.cap;
     int* rstart = T.row_start + (long long)slot * (H + 1);
     int* ritems = T.row_items + (long long)slot * T.row_cap;
-    for (int i = tid; i <= H; i += 256) lds[i] = 0;
+    int lo[SR_K], hi[SR_K];
+#pragma unroll
+    for (int k = 0; k < SR_K; k++) {
+        const int i = tid + k * SR_T;
+        lo[k] = 1; hi[k] = 0;
+        if (i < nr) {
+            const float r = __fmul_rn(2.0f, T.geom[kp[i].octave].scale);              // 2.0f*mvScaleFactors[octave]
+            hi[k] = min((int)ceilf(__fadd_rn(kp[i].y, r)), H - 1); lo[k] = max((int)floorf(__fsub_rn(kp[i].y, r)), 0);
+        }
+    }
+    for (int i = tid; i <= H; i += SR_T) lds[i] = 0;
     __syncthreads();
-    for (int i = tid; i < nr; i += 256) {
-        const float r = __fmul_rn(2.0f, T.geom[kp[i].octave].scale);                  // 2.0f*mvScaleFactors[octave]
+#pragma unroll
+    for (int k = 0; k < SR_K; k++) for (int y = lo[k]; y <= hi[k]; y++) atomicAdd(&lds[y], 1);
+    for (int i = tid + SR_K * SR_T; i < nr; i += SR_T) {
+        const float r = __fmul_rn(2.0f, T.geom[kp[i].octave].scale);
         const int maxr = min((int)ceilf(__fadd_rn(kp[i].y, r)), H - 1), minr = max((int)floorf(__fsub_rn(kp[i].y, r)), 0);
         for (int y = minr; y <= maxr; y++) atomicAdd(&lds[y], 1);
     }
     __syncthreads();
-    const int per = (H + 256) / 256;                    // exclusive scan of H+1 counters, `per` consecutive entries per thread
+    const int per = (H + SR_T) / SR_T;                  // exclusive scan of H+1 counters, `per` consecutive entries per thread
     int sum = 0;
     for (int k = 0; k < per; k++) { const int i = tid * per + k; if (i <= H) sum += lds[i]; }
-    int incl = sum;                                     // shuffle scan per wave, the four wave totals through LDS
+    int incl = sum;                                     // shuffle scan per wave, the wave totals through LDS
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if ((tid & 63) >= off) incl += t; }
     if ((tid & 63) == 63) s_scan[tid >> 6] = incl;
@@ -71,7 +88,10 @@ __global__ __launch_bounds__(256) void k_stereo_rows(StereoParams T)
     for (int w = 0; w < (tid >> 6); w++) run += s_scan[w];
     for (int k = 0; k < per; k++) { const int i = tid * per + k; if (i <= H) { const int v = lds[i]; lds[i] = run; rstart[i] = run; run += v; } }
     __syncthreads();
-    for (int i = tid; i < nr; i += 256) {
+    // a row's items in key point order within a pass is not required: k_stereo_match takes the best distance, the lowest index among equals
+#pragma unroll
+    for (int k = 0; k < SR_K; k++) for (int y = lo[k]; y <= hi[k]; y++) { const int p = atomicAdd(&lds[y], 1); if (p < T.row_cap) ritems[p] = tid + k * SR_T; }
+    for (int i = tid + SR_K * SR_T; i < nr; i += SR_T) {
         const float r = __fmul_rn(2.0f, T.geom[kp[i].octave].scale);
         const int maxr = min((int)ceilf(__fadd_rn(kp[i].y, r)), H - 1), minr = max((int)floorf(__fsub_rn(kp[i].y, r)), 0);
         for (int y = minr; y <= maxr; y++) { const int p = atomicAdd(&lds[y], 1); if (p < T.row_cap) ritems[p] = i; }
@@ -218,7 +238,7 @@ __global__ __launch_bounds__(256) void k_stereo_prune(StereoParams T)
 
 void orbhip_launch_stereo_rows(const StereoParams& T, int nslots, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_stereo_rows, dim3(nslots, 1, 1), dim3(256, 1, 1), sizeof(int) * (T.im_h + 1), s, T);
+    hipLaunchKernelGGL(k_stereo_rows, dim3(nslots, 1, 1), dim3(SR_T, 1, 1), sizeof(int) * (T.im_h + 1), s, T);
 }
 void orbhip_launch_stereo(const StereoParams& T, int nslots, int max_left, hipStream_t s, bool rows_ready)
 {
