@@ -45,6 +45,17 @@ public:
     size_t size() const { return mvLevels.size(); }
     bool empty() const { return mvLevels.empty(); }
     void resize(size_t n) { mvLevels.resize(n); }
+    // forks that walk the pyramid (`for (auto& im : mvImagePyramid)`, `.at(l)`, `.front()`, a copy into a std::vector<cv::Mat>): the same lazy fetch first
+    typedef std::vector<cv::Mat>::iterator iterator; typedef std::vector<cv::Mat>::const_iterator const_iterator;
+    iterator begin() { Refresh(); return mvLevels.begin(); }
+    iterator end() { Refresh(); return mvLevels.end(); }
+    const_iterator begin() const { const_cast<ORBimagePyramid*>(this)->Refresh(); return mvLevels.begin(); }
+    const_iterator end() const { const_cast<ORBimagePyramid*>(this)->Refresh(); return mvLevels.end(); }
+    cv::Mat& at(size_t level) { Refresh(); return mvLevels.at(level); }
+    const cv::Mat& at(size_t level) const { const_cast<ORBimagePyramid*>(this)->Refresh(); return mvLevels.at(level); }
+    cv::Mat& front() { Refresh(); return mvLevels.front(); }
+    cv::Mat& back() { Refresh(); return mvLevels.back(); }
+    operator const std::vector<cv::Mat>&() const { const_cast<ORBimagePyramid*>(this)->Refresh(); return mvLevels; }
 private:
     friend class ORBextractor;
     void Refresh();

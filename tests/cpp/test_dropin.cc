@@ -40,6 +40,12 @@ int main(int argc, char** argv)
     if (!prev.empty()) fwrite(&prev[0], 8, prev.size(), f);
     int lv = ex->GetLevels(); fwrite(&lv, 4, 1, f);
     for (int l = 0; l < lv; l++) { int wh[2] = {ex->mvImagePyramid[l].cols, ex->mvImagePyramid[l].rows}; fwrite(wh, 4, 2, f); fwrite(ex->mvImagePyramid[l].data, 1, (size_t)wh[0] * wh[1], f); }
+    {   // a fork that walks the pyramid instead of indexing it: range-for, at(), a copy into a std::vector<cv::Mat> - the same planes
+        int l = 0; bool same = true;
+        for (const cv::Mat& im : ex->mvImagePyramid) { same = same && im.data == ex->mvImagePyramid[l].data && im.cols == ex->mvImagePyramid.at(l).cols; l++; }
+        const std::vector<cv::Mat>& asVector = ex->mvImagePyramid;
+        if (!same || l != lv || (int)asVector.size() != lv || asVector[lv - 1].rows != ex->mvImagePyramid.back().rows) { fprintf(stderr, "mvImagePyramid iteration differs from indexing\n"); return 3; }
+    }
     const int d = ORB_SLAM2::ORBmatcher::DescriptorDistance(F1.mDescriptors.row(0), F2.mDescriptors.row(0)); fwrite(&d, 4, 1, f);
     // stereo: two extractor instances like Tracking.cc:119-122, Frame::ComputeStereoMatches replaced by the GPU entry point
     ORB_SLAM2::ORBextractor* exL = new ORB_SLAM2::ORBextractor(N, 1.2f, 8, 20, 7);
