@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC passes (each in its own rocprofv3 run, kernel-trace only) over a short bench; CSVs land in gpurun_out/$TAG/
 # usage: tools/gpu_pmc.sh <tag> [number of passes, default all six]
-TAG=${1:-pmc}; NPASS=${2:-6}; WHAT=${3:-bench}      # WHAT = bench (the B = $PMC_BATCH batch pipeline, default 256) | single (single-image calls + the stereo front-end loop)
+TAG=${1:-pmc}; NPASS=${2:-7}; WHAT=${3:-bench}      # WHAT = bench (the B = $PMC_BATCH batch pipeline, default 256) | single (single-image calls + the stereo front-end loop) | r05 (bag of words, walks, FP4 scan)
 OUT=$(pwd)/gpurun_out/$TAG
 mkdir -p $OUT
 REPO=$(pwd)
@@ -10,6 +10,7 @@ cd /tmp
 rocprofv3 -L > $OUT/counters_list.txt 2>&1
 CMD="python $REPO/bench.py --steps 3 --warmup 1 --repeats 1 --batch ${PMC_BATCH:-256} --no-cpu-baseline --no-host-io --no-traffic --no-dropin-loop --no-secondary --parity-slots 0"
 [ "$WHAT" = single ] && CMD="python $REPO/tools/pmc_single_workload.py"
+[ "$WHAT" = r05 ] && CMD="python $REPO/tools/pmc_r05_workload.py"
 i=0
 while read -r line; do
   [ -z "$line" ] && continue
@@ -25,6 +26,7 @@ SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLI
 FETCH_SIZE TCC_HIT_sum
 WRITE_SIZE TCC_MISS_sum TCC_REQ_sum
 TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TA_DATA_STALL_CYCLES_sum TA_BUSY_avr TA_TA_BUSY_sum
+SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_F6F4 SQ_INSTS_VALU_MFMA_MOPS_F6F4 SQ_INSTS_VALU_MFMA_I8 SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES
 PASSES
 ls -la $OUT | head -30
 python3 - <<PY

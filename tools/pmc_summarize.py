@@ -65,6 +65,12 @@ def main():
             "tcc_hit": round(d.get("TCC_HIT_sum", 0) / max(d.get("TCC_HIT_sum", 0) + d.get("TCC_MISS_sum", 0), 1), 2),
             "lds_bank_conflict_frac": round(d.get("SQ_LDS_BANK_CONFLICT", 0) / max(d.get("SQ_LDS_IDX_ACTIVE", 0), 1), 2),
         }
+        if d.get("SQ_INSTS_MFMA", 0) > 0:                   # the matrix-core pass (kernels that issue MFMA only)
+            row.update({"mfma_per_wave": round(d.get("SQ_INSTS_MFMA", 0) / w, 1), "mfma_f6f4_insts_per_dispatch": round(d.get("SQ_INSTS_VALU_MFMA_F6F4", 0) / n),
+                        "mfma_i8_insts_per_dispatch": round(d.get("SQ_INSTS_VALU_MFMA_I8", 0) / n),
+                        "mfma_mops_f6f4_per_dispatch": round(d.get("SQ_INSTS_VALU_MFMA_MOPS_F6F4", 0) / n), "mfma_mops_i8_per_dispatch": round(d.get("SQ_INSTS_VALU_MFMA_MOPS_I8", 0) / n),
+                        "mfma_busy_cycles_per_dispatch": round(d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / n), "busy_cu_cycles_per_dispatch": round(d.get("SQ_BUSY_CU_CYCLES", 0) / n),
+                        "mfma_busy_over_busy_cu_cycles": round(d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(d.get("SQ_BUSY_CU_CYCLES", 0), 1), 3)})
         out.append(row)
     out.sort(key=lambda r: r["kernel"])
     with open(os.path.join(root, "profiles", f"{prefix}_pmc{suffix}_summary.json"), "w") as f:
