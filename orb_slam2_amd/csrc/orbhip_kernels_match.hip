@@ -242,7 +242,7 @@ template <int QT, int OCC, int LCH, int TPB> __global__ __launch_bounds__(256, O
             B[t][kb] = nn_v8i{(int)(s_tab[w & 0xff] ^ 0x88888888u), (int)(s_tab[(w >> 8) & 0xff] ^ 0x88888888u), (int)(s_tab[(w >> 16) & 0xff] ^ 0x88888888u), (int)(s_tab[w >> 24] ^ 0x88888888u), 0, 0, 0, 0};
         }
     }
-    unsigned kbest[QT], ksec[QT], thr[QT];                            // thr: bits of (float)((distance of the running second best + 1) << 7): a tile key below it may still matter
+    unsigned kbest[QT], ksec[QT], thr[QT];                            // thr: bits of (float)(distance of the running second best << 7): a tile key below it may still matter
 #pragma unroll
     for (int t = 0; t < QT; t++) { kbest[t] = 0xffffffffu; ksec[t] = 0xffffffffu; thr[t] = 0x7f7fffffu; }
     constexpr int CH = 1 << LCH;                                      // DB rows per workgroup; chunk keys are distance << LCH | row-in-chunk
@@ -305,7 +305,8 @@ template <int QT, int OCC, int LCH, int TPB> __global__ __launch_bounds__(256, O
             const unsigned bi = (unsigned)__uint_as_float(b), si = (unsigned)__uint_as_float(s2);           // the two winners back to integers: d << 7 | r
             const unsigned kb1 = ((bi >> 7) << LCH) + (bi & 127u) + tbase, ks1 = ((si >> 7) << LCH) + (si & 127u) + tbase;      // chunk keys d << LCH | (tile * 32 + r)
             merge2(kbest[t], ksec[t], kb1, ks1);
-            thr[t] = __float_as_uint((float)(((ksec[t] >> LCH) + 1u) << 7));                                // (a never-set second best gives a threshold above every real key)
+            // a later row at the running second best's own distance has a larger key than it (rows ascend): only a strictly smaller distance matters
+            thr[t] = __float_as_uint((float)((ksec[t] >> LCH) << 7));                                       // (a never-set second best gives a threshold above every real key)
         }
     };
     fetch(0); expand(0);
