@@ -523,15 +523,17 @@ def main():
         traffic = None
         traffic_profiled = None
         try:
-            for name in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
+            for name, pmc_batch in (("r05_pmc_summary.json", 512), ("r03_pmc_summary.json", 256), ("r02_pmc_summary.json", 256), ("r01_pmc_summary.json", 256)):
                 pmc = os.path.join(ROOT, "profiles", name)
                 if not os.path.exists(pmc):
                     continue
                 with open(pmc) as f:
                     for row in json.load(f):
                         if row["kernel"].split("<")[0] == dom:          # (k_fast_cells is a template: "k_fast_cells<48, 40>" in the profiler's rows)
-                            traffic_profiled = {"bytes_per_launch": int((2 * row["fetch_MB_per_dispatch_raw"] + row["write_MB_per_dispatch_raw"]) * 1024 * 1024 * B / 256),
-                                                "source": f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE at B = 256, scaled to B = {B}; not measured in this run)"}
+                            raw_kb = 2 * row["fetch_KB_per_dispatch_raw"] + row["write_KB_per_dispatch_raw"] if "fetch_KB_per_dispatch_raw" in row else \
+                                (2 * row["fetch_MB_per_dispatch_raw"] + row["write_MB_per_dispatch_raw"]) * 1024
+                            traffic_profiled = {"bytes_per_launch": int(raw_kb * 1024 * B / pmc_batch),
+                                                "source": f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE at B = {pmc_batch}" + (f", scaled to B = {B}" if B != pmc_batch else "") + "; not measured in this run)"}
                 break
         except Exception:
             traffic_profiled = None
