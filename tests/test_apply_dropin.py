@@ -56,6 +56,12 @@ def test_optional_steps(tmp_path):
     assert b.count("mpORBvocabulary->transform(vCurrentDesc,mBowVec,mFeatVec,4);") == 1
     assert "thread threadLeft(&Frame::ExtractORB,this,0,imLeft);" in a and "threadLeft" not in b
     assert b.count("mpORBextractorLeft->ExtractStereo(imLeft, imRight, mvKeys, mDescriptors, mvKeysRight, mDescriptorsRight, mbf, mbf/K.at<float>(0,0));") == 1
+    # RGB-D: by default the reference's own depth loop stays and one line hands mvuRight to the resident frame; --device-rgbd replaces the loop by the device sampling
+    assert a.count("if(mpORBextractorLeft) mpORBextractorLeft->SetStereoColumns(mvuRight);") == 1 and "const float d = imDepth.at<float>(v,u);" in a
+    dev = tmp_path / "dev"
+    subprocess.run([sys.executable, SCRIPT, "--device-rgbd", REF, str(dev)], capture_output=True, text=True, check=True)
+    c = (dev / "src/Frame.cc").read_text()
+    assert "SetStereoColumns" not in c and c.count("mpORBextractorLeft->ComputeStereoFromRGBD(imDepth, 1.0f, mbf, N, mvuRight, mvDepth);") == 1 and "imDepth.at<float>(v,u)" not in c
     assert (plain / "src/ORBmatcher.cc").read_text() == (one / "src/ORBmatcher.cc").read_text()
     m = (one / "src/ORBmatcher.cc").read_text()
     for name in ("void SearchByBoWBatch(", "void SearchForTriangulationBatch(", "int TriangulationPairs(", "int FuseBatch(", "static int orbhip_fuse_apply(", "static void orbhip_fuse_collect("):
