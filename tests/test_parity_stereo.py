@@ -49,6 +49,20 @@ def test_stereo_matches_bit_exact(backend, oracle):
         assert abs(np.median(kl["x"][ok] - uo[ok]) - disp) < 0.5          # the synthetic rig's disparity is recovered
 
 
+def test_stereo_random_sweep(backend, oracle):
+    """Randomised sweep: image size, feature count, disparity (0 .. 40 px: the far / near ends of the search band) - ComputeStereoMatches bit for bit.
+    3 pairs on the emulation, 24 on the GPU."""
+    rng = np.random.default_rng(20260922)
+    for case in range(3 if backend.endswith("_emu.so") else 24):
+        w, h = int(rng.integers(80, 230)) * 4, int(rng.integers(60, 125)) * 4
+        n = int(rng.choice([200, 500, 1000, 1500]))
+        pairs = [stereo_pair(w, h, 100 + 2 * case + k, int(rng.integers(0, 41))) for k in range(1 if backend.endswith("_emu.so") else 2)]
+        res = _check(backend, oracle, w, h, n, pairs)
+        assert sum(int((uo >= 0).sum()) for _, uo in res) > 20, (case, w, h, n)
+        if not backend.endswith("_emu.so") and case % 3 == 0:
+            _pair_as_one_call(backend, oracle, w, h, n, pairs)                   # the same pairs through orbhip_extract_stereo (one context, two camera slots)
+
+
 def test_stereo_edge_cases(backend, oracle):
     w, h, n = 400, 300, 400
     left, right = stereo_pair(w, h, 6, 0)
