@@ -250,19 +250,23 @@ FUSE_QUERY = """orbhip_best_query e = { u, v, radius, ur, nPredictedLevel };
         job.bq.push_back(e); job.qd.insert(job.qd.end(), dMP.ptr<unsigned char>(), dMP.ptr<unsigned char>()+32); job.owner.push_back(pMP);
 """
 FUSE_TAIL = """
-static int orbhip_fuse_apply(OrbhipFuseJob &job)
+// survivors: the points that absorbed another one in the surgery of EARLIER targets of the same FuseBatch (MapPoint::Replace recomputes the survivor's
+// descriptor, MapPoint.cc:177-215) - NULL for a single Fuse, whose queries were collected just before its search: nothing to re-check
+static int orbhip_fuse_apply(OrbhipFuseJob &job, std::set<MapPoint*> *survivors)
 {
     KeyFrame* pKF = job.pKF;
     const int TH_LOW = ORBmatcher::TH_LOW;
     int nFused=0;
-    // Points that absorbed another point since their query was collected (the surgery of an EARLIER target: MapPoint::Replace recomputes the survivor's
-    // descriptor) are searched again, all of them in one call, before this target's surgery starts.  (Inside one target no collected point's descriptor
-    // changes: a survivor is either a point already handled or a point of this key frame, which the filter below skips.)
+    // Survivors whose descriptor is not the collected one any more are searched again, all of them in one call, before this target's surgery starts.
+    // (Inside one target no collected point's descriptor changes: a survivor is either a point already handled or a point of this key frame, which
+    // the filter below skips.)  Only survivors are looked at: GetDescriptor() - a lock and a clone - for every point of every target was half of FuseBatch.
+    if(survivors && !survivors->empty())
     {
         std::vector<size_t> again; std::vector<orbhip_best_query> bq; std::vector<unsigned char> qd;
         for(size_t k=0; k<job.owner.size(); k++)
         {
             MapPoint* pMP = job.owner[k];
+            if(!survivors->count(pMP)) continue;
             if(pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
             const cv::Mat dNow = pMP->GetDescriptor();
             if(!memcmp(dNow.ptr<unsigned char>(), &job.qd[32*k], 32)) continue;
@@ -299,7 +303,7 @@ int ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint *> &vpMapPoints, const
         orbhip_check(orbhip_search_best_in_window_bounds(orbhip_default_device(), (const orbhip_keypoint*)&pKF->mvKeysUn[0], pKF->mDescriptors.ptr<unsigned char>(), &pKF->mvuRight[0], pKF->N, &bounds,
                                                &pKF->mvInvLevelSigma2[0], (int)pKF->mvInvLevelSigma2.size(), &job.bq[0], &job.qd[0], (int)job.bq.size(), 1, &job.bi[0], &job.bd[0]));
     }
-    return orbhip_fuse_apply(job);
+    return orbhip_fuse_apply(job, NULL);
 }
 
 // LocalMapping::SearchInNeighbors (LocalMapping.cc:483-514): `for every target key frame: matcher.Fuse(pKFi, vpMapPointMatches)` as ONE device pass
@@ -321,8 +325,9 @@ int FuseBatch(const std::vector<KeyFrame*> &vpTargetKFs, const std::vector<MapPo
     if(!slots.empty())
         orbhip_check(orbhip_search_best_in_window_batch(orbhip_default_device(), (int)slots.size(), &slots[0], 1));
     int nFused=0;
+    std::set<MapPoint*> survivors;
     for(size_t t=0; t<jobs.size(); t++)
-        nFused += orbhip_fuse_apply(jobs[t]);
+        nFused += orbhip_fuse_apply(jobs[t], &survivors);
     return nFused;
 }
 """
@@ -338,6 +343,11 @@ def patch_fuse(src):
     s0 = fn.index("if(bestDist<=TH_LOW)", a)
     s1 = block_end(fn, s0)
     surgery = fn[s0:s1]                                   # the reference's own block, moved into orbhip_fuse_apply
+    # ... with the survivor of each of its two Replace() calls noted (the statements themselves stay): FuseBatch re-checks survivors only
+    for stmt, who in (("pMP->Replace(pMPinKF);", "pMPinKF"), ("pMPinKF->Replace(pMP);", "pMP")):
+        if surgery.count(stmt) != 1:
+            raise SystemExit(f"Fuse: `{stmt}` not found exactly once in the surgery block")
+        surgery = surgery.replace(stmt, "{ %s if(survivors) survivors->insert(%s); }" % (stmt, who))
     fn = fn[:a] + FUSE_QUERY + fn[s1:]
     # the collecting half keeps the reference's text; only its head and its return change
     head = re.match(FUSE_SIG, fn)
@@ -644,6 +654,7 @@ PROLOGUE = """#include "orbhip.h"
 #include "ORBmatcherBatch.h"
 #include <cstdlib>
 #include <cstring>
+#include <set>
 #include <string>
 """
 # helpers every inserted call goes through (placed inside namespace ORB_SLAM2, after the reference's own includes):
