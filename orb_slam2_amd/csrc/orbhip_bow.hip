@@ -735,8 +735,8 @@ static orbhip_status voc_run(orbhip_voc* v, BowWs* w, const uint8_t* d_desc, lon
     hipLaunchKernelGGL(k_bow_descend, dim3((nfeat_max + 64 / BD_G - 1) / (64 / BD_G), nframes, 1), dim3(64, 1, 1), 0, s, P);
     if (assemble) {
         const int E = ba_keys_per_thread(nfeat_max);
-        const char* force = getenv("ORBHIP_BOW_KEYS");                             // "64": the 8-byte keys also where 4 bytes would do (tests)
-        const bool k32 = E <= 4 && ((unsigned long long)v->nnodes * E * BA_T) <= 0xffffffffull && !(force && atoi(force) == 64);      // (E = 8: the values' own block would not fit the LDS)
+        const char* force = getenv("ORBHIP_BOW_KEYS");                             // "64": the 8-byte keys also where 4 bytes would do (tests switch it between calls)
+        const bool k32 = E <= 4 && ((unsigned long long)v->nnodes * E * BA_T) <= 0xffffffffull && !(force && force[0] == '6' && force[1] == '4');      // (E = 8: the values' own block would not fit the LDS)
         const dim3 g(nframes, 2, 1), b(BA_T, 1, 1); const size_t lds = ba_lds_bytes(nfeat_max, k32 ? 4 : 8);
         switch (E + (k32 ? 100 : 0)) {
         case 101: hipLaunchKernelGGL((k_bow_assemble<uint32_t, 1>), g, b, lds, s, P); break;
