@@ -259,7 +259,8 @@ static int orbhip_fuse_apply(OrbhipFuseJob &job, std::set<MapPoint*> *survivors)
     int nFused=0;
     // Survivors whose descriptor is not the collected one any more are searched again, all of them in one call, before this target's surgery starts.
     // (Inside one target no collected point's descriptor changes: a survivor is either a point already handled or a point of this key frame, which
-    // the filter below skips.)  Only survivors are looked at: GetDescriptor() - a lock and a clone - for every point of every target was half of FuseBatch.
+    // the filter below skips.)  Only survivors are looked at - nobody else's descriptor can have changed - instead of GetDescriptor() (a lock and a clone) for
+    // every point of every target.
     if(survivors && !survivors->empty())
     {
         std::vector<size_t> again; std::vector<orbhip_best_query> bq; std::vector<unsigned char> qd;
