@@ -17,14 +17,15 @@ The timed region is `--repeats` (default 5) back-to-back measurements of EXACTLY
 barrier + synchronize; `value` / `ms_per_step` are the MEDIAN repeat, the spread is reported in `repeats`.
 
 Extra objects in the JSON line:
-  parity        key points, descriptors and matches12 of 4 camera slots of the LAST timed step compared bit for bit with the oracle, and
-                every replica slot of a scene with the first slot of that scene (whole batch); a mismatch marks the line INVALID
+  parity        key points, descriptors and matches12 of one camera slot per DISTINCT scene (64) of the LAST timed step compared bit for bit with the
+                oracle, and every replica slot of a scene with the first slot of that scene: the whole batch; a mismatch marks the line INVALID
   runtime       the HIP runtime the library ran on (versions, file), every libamdhip64 mapped into the process (must be one)
   roofline      dominant kernel (by HIP-event time measured inside the timed region on the library's stream):
                 algorithmic bytes per launch / average launch duration vs the 8 TB/s HBM peak; `traffic` = HBM bytes per launch from
                 two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; gfx950 correction) over a short child run of the same workload;
                 `bound` = what the evidence says limits the kernel
-  roofline_valu the same kernel against its VALU-issue floor: instructions per wave x waves x 4 cycles / (1024 SIMDs x 2.4 GHz)
+  roofline_valu the same kernel against its VALU-issue floor: instructions per wave x waves x 4 cycles / (1024 SIMDs x 2.4 GHz), and against the
+                clock it actually ran at (GRBM_GUI_ACTIVE / dispatch time in a fourth --pmc child pass): clock_GHz_effective, frac_at_effective_clock
   dropin_loop   the drop-in as ORB_SLAM2 drives it: >= 20 stereo frames through the reference's own Frame.cc / ORBmatcher.cc (stereo Frame
                 constructor, ComputeStereoMatches, SearchByProjection(Current, Last), SearchByProjection(Frame, MapPoints)), ms per frame with
                 the drop-in on the GPU and with the reference on the host, bit-exact per frame (KITTI shape; EuRoC shape under "euroc")
@@ -50,6 +51,7 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 W, H, NFEAT, NLEVELS, SCALE, INI_TH, MIN_TH = 1241, 376, 2000, 8, 1.2, 20, 7
 WINDOW, NNRATIO = 100, 0.9
+PMC_SUMMARIES = (("r06_pmc_summary.json", 512), ("r05_pmc_summary.json", 512), ("r04_pmc_summary.json", 256), ("r03_pmc_summary.json", 256), ("r02_pmc_summary.json", 256), ("r01_pmc_summary.json", 256))
 NSCENES = 64               # distinct seeded scenes replicated over the camera slots (data-dependent kernels see 64 workloads x tsteps)
 
 
@@ -210,8 +212,18 @@ def valu_roofline(dom, launch_ms, B, measured=None):
         o.update(extra or {})
         return o
     if measured:
-        return obj(measured["valu_per_wave"], measured["waves_per_launch"], "rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES over a short child run of this workload at this batch, in this run; launch_ms by HIP events in the timed region")
-    for name in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json"):
+        extra = None
+        ck = measured.get("clock")
+        if ck and ck.get("GHz"):
+            # the floor against the clock the kernel actually ran at in the counter pass (the guide reports 1.9-2.3 GHz effective under load, and profiled
+            # passes a little lower than plain ones): the nominal-clock figures stay beside it
+            eff_floor = measured["valu_per_wave"] * measured["waves_per_launch"] * cpi / (simds * ck["GHz"] * 1e9) * 1e3
+            extra = {"clock_GHz_effective": ck["GHz"], "floor_ms_at_effective_clock": round(eff_floor, 4), "frac_at_effective_clock": round(eff_floor / launch_ms, 4) if launch_ms > 0 else None,
+                     "clock_measurement": ck}
+        elif ck:
+            extra = {"clock_measurement": ck}
+        return obj(measured["valu_per_wave"], measured["waves_per_launch"], "rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES over a short child run of this workload at this batch, in this run; launch_ms by HIP events in the timed region", extra)
+    for name, pmc_batch in PMC_SUMMARIES:                          # (file, the batch its passes ran at)
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -219,9 +231,44 @@ def valu_roofline(dom, launch_ms, B, measured=None):
             rows = json.load(f)
         for row in rows:
             if row["kernel"].split("<")[0] == dom:
-                return obj(row["valu_per_wave"], int(row["waves_per_dispatch"] * B / 256), f"profiles/{name} (SQ_INSTS_VALU / SQ_WAVES per dispatch at B = 256, waves scaled to B = {B}; launch_ms measured in this run)",
+                return obj(row["valu_per_wave"], int(row["waves_per_dispatch"] * B / pmc_batch),
+                           f"profiles/{name} (SQ_INSTS_VALU / SQ_WAVES per dispatch at B = {pmc_batch}" + (f", waves scaled to B = {B}" if B != pmc_batch else "") + "; launch_ms measured in this run)",
                            {"lds_bank_conflict_frac": row.get("lds_bank_conflict_frac"), "frac_wave_cycles_waiting": row.get("frac_wait_any")})
     return None
+
+
+def effective_clock(counter_csv, out_dir, dom):
+    """Effective shader clock of the dominant kernel under load = GRBM_GUI_ACTIVE / the dispatch's wall time (MI355X_MICROARCH.md, DVFS give-back), from
+    a rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace pass.  The dispatch's begin / end come from the counter file itself where it carries timestamps,
+    else from the kernel trace of the same pass, joined on the dispatch id.  -> {"GHz", "cycles_per_launch", "ns_per_launch", "launches"} or {"error"}."""
+    import csv, glob
+    try:
+        rows = [r for r in csv.DictReader(open(counter_csv)) if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and r["Kernel_Name"].replace("void ", "").split("(")[0].split("<")[0].strip() == dom]
+        if not rows:
+            return {"error": f"no GRBM_GUI_ACTIVE rows for {dom}"}
+        cyc = {}
+        for r in rows:                                                       # one row per (dispatch, dimension instance): sum them per dispatch
+            cyc[r.get("Dispatch_Id", r.get("Correlation_Id"))] = cyc.get(r.get("Dispatch_Id", r.get("Correlation_Id")), 0.0) + float(r["Counter_Value"])
+        span = {}
+        if "Start_Timestamp" in rows[0] and "End_Timestamp" in rows[0]:
+            for r in rows:
+                span[r.get("Dispatch_Id", r.get("Correlation_Id"))] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+        else:
+            for f in glob.glob(os.path.join(out_dir, "**", "*kernel_trace.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r.get("Dispatch_Id") in cyc:
+                        span[r["Dispatch_Id"]] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+        both = [k for k in cyc if k in span and span[k] > 0]
+        if not both:
+            return {"error": "no timestamps for the profiled dispatches"}
+        c = sum(cyc[k] for k in both) / len(both); ns = sum(span[k] for k in both) / len(both)
+        ghz = c / ns
+        note = "GRBM_GUI_ACTIVE / dispatch wall time in the counter pass"
+        if ghz > 3.0:                                                        # the counter came back summed over the eight XCDs' GRBMs
+            ghz /= 8.0; c /= 8.0; note += "; counter summed over 8 XCDs, divided by 8"
+        return {"GHz": round(ghz, 3), "cycles_per_launch": int(c), "ns_per_launch": int(ns), "launches": len(both), "note": note}
+    except Exception as e:                                                   # noqa: BLE001
+        return {"error": str(e)[:200]}
 
 
 def hbm_traffic_subprocess(dom, B, args):
@@ -232,7 +279,8 @@ def hbm_traffic_subprocess(dom, B, args):
     if shutil.which("rocprofv3") is None:
         return None, "rocprofv3 not on PATH"
     per = {}
-    for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU SQ_WAVES"):
+    clock = None
+    for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU SQ_WAVES", "GRBM_GUI_ACTIVE"):
         d = tempfile.mkdtemp(prefix="orb_pmc_", dir="/tmp")
         cmd = ["rocprofv3", "--pmc"] + counter.split() + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
                "--batch", str(B), "--steps", "3", "--warmup", "1", "--repeats", "1", "--streams", str(args.streams), "--blur-round-mode", str(args.blur_round_mode),
@@ -242,6 +290,9 @@ def hbm_traffic_subprocess(dom, B, args):
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode}): {r.stderr[-200:]}"
+            if counter == "GRBM_GUI_ACTIVE":
+                clock = effective_clock(files[0], d, dom)                  # a secondary figure: a failure here must not cost the traffic object
+                continue
             for cname in counter.split():
                 tot, disp = 0.0, set()
                 for row in csv.DictReader(open(files[0])):
@@ -256,7 +307,7 @@ def hbm_traffic_subprocess(dom, B, args):
             shutil.rmtree(d, ignore_errors=True)
     return {"bytes_per_launch": int(2 * per["FETCH_SIZE"][0] + per["WRITE_SIZE"][0]), "fetch_bytes_raw": int(per["FETCH_SIZE"][0]), "write_bytes_raw": int(per["WRITE_SIZE"][0]),
             "valu_per_wave": round(per["SQ_INSTS_VALU"][0] / max(per["SQ_WAVES"][0], 1.0), 1), "waves_per_launch": int(per["SQ_WAVES"][0]),
-            "launches_profiled": per["FETCH_SIZE"][1], "method": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, one pass each over a 4-step child run of this workload at this batch; 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction)"}, None
+            "launches_profiled": per["FETCH_SIZE"][1], "clock": clock, "method": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, one pass each over a 4-step child run of this workload at this batch; 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction)"}, None
 
 
 def dropin_loop_subprocess(blur_round_mode):
@@ -409,7 +460,8 @@ def main():
     ap.add_argument("--pool", action="store_true", help="time the one-process multi-GPU pool (orbhip_pool_*: one host thread per GPU) at the host-buffer boundary instead of "
                     "the one-process-per-GPU device-resident benchmark; prints its own JSON line (mode: pool)")
     ap.add_argument("--pool-cameras-per-gpu", type=int, default=128)
-    ap.add_argument("--parity-slots", type=int, default=4, help="camera slots of the last timed step compared bit for bit with the oracle (0 = skip)")
+    ap.add_argument("--parity-slots", type=int, default=NSCENES, help="camera slots of the last timed step compared bit for bit with the oracle: by default one per distinct scene, "
+                    "i.e. with the replica check every frame of the step (0 = skip)")
     ap.add_argument("--extract-only", action="store_true", help="diagnostic: skip the matcher (NOT the metric's workload; the JSON line says so)")
     args = ap.parse_args()
     if args.host_io_only:
@@ -523,7 +575,7 @@ def main():
         traffic = None
         traffic_profiled = None
         try:
-            for name, pmc_batch in (("r05_pmc_summary.json", 512), ("r03_pmc_summary.json", 256), ("r02_pmc_summary.json", 256), ("r01_pmc_summary.json", 256)):
+            for name, pmc_batch in PMC_SUMMARIES:
                 pmc = os.path.join(ROOT, "profiles", name)
                 if not os.path.exists(pmc):
                     continue

@@ -9,6 +9,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 PATH = os.path.join(HERE, "_ref", "liborbextractor_ref.so")
 NATIVE_PATH = os.path.join(HERE, "_ref", "liborbextractor_ref_native.so")     # the reference's own flags: -O3 -march=native, contraction on (make ref_native)
+STOCK_PATH = os.path.join(HERE, "_ref", "liborbextractor_ref_stock.so")       # glibc's allocator instead of the bump arena (make ref_stock): H1 as a maintainer's binary has it
 KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
 _lib = None
 
@@ -36,8 +37,22 @@ def build_native():
     return False
 
 
-def lib(native=False):
-    global _lib, _native
+_stock = None
+
+
+def build_stock():
+    import subprocess
+    if os.path.isdir("/root/reference/src"):
+        subprocess.check_call(["make", "-C", HERE, "-s", "ref_stock"])
+    return os.path.exists(STOCK_PATH)
+
+
+def lib(native=False, stock=False):
+    global _lib, _native, _stock
+    if stock:
+        if _stock is None:
+            _stock = _bind(C.CDLL(STOCK_PATH))
+        return _stock
     if native:
         if _native is None:
             _native = _bind(C.CDLL(NATIVE_PATH))
@@ -64,9 +79,9 @@ def _p(a):
 
 
 class RefExtractor:
-    def __init__(self, nfeatures, scale, nlevels, ini_th, min_th, native=False):
+    def __init__(self, nfeatures, scale, nlevels, ini_th, min_th, native=False, stock=False):
         self.nlevels = nlevels
-        self.L = lib(native)
+        self.L = lib(native, stock)
         self.h = self.L.orbextractor_ref_new(nfeatures, scale, nlevels, ini_th, min_th)
         self.cap = nfeatures * 2 + 64
 

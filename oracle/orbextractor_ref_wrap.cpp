@@ -14,6 +14,9 @@
 #include <vector>
 #include "ORBextractor.h"
 
+// -DORBEXTRACTOR_REF_STOCK_ALLOCATOR (`make -C oracle ref_stock`): no arena - the list nodes come from glibc's malloc, as in a maintainer's own binary.
+// tests/test_reference_stock_allocator.py measures what H1 costs a drop-in vs stock-binary A/B.
+#ifndef ORBEXTRACTOR_REF_STOCK_ALLOCATOR
 namespace {
 const size_t kNodeBytes = sizeof(std::_List_node<ORB_SLAM2::ExtractorNode>);
 const size_t kArenaBytes = (size_t)256 << 20;
@@ -33,6 +36,9 @@ void* operator new(size_t n)
 }
 void operator delete(void* p) noexcept { if (p && !in_arena(p)) free(p); }
 void operator delete(void* p, size_t) noexcept { if (p && !in_arena(p)) free(p); }
+#else
+namespace { size_t g_used = 0; }
+#endif
 
 struct RefExtractor : ORB_SLAM2::ORBextractor {
     RefExtractor(int n, float s, int l, int i, int m) : ORB_SLAM2::ORBextractor(n, s, l, i, m) {}
