@@ -1,13 +1,10 @@
 // ORBmatcher.h — drop-in replacement for raulmur/ORB_SLAM2 include/ORBmatcher.h (the class declared at ORBmatcher.h:37-102 there).
 //
 // The class keeps every public signature of the reference so that Tracking, LocalMapping, LoopClosing, MapPoint and Frame
-// compile unchanged.  What lives where:
-//   * implemented in this repository (orb_slam2_amd/cpp/ORBmatcher.cc, through the C ABI include/orbhip.h):
-//       the constructor, DescriptorDistance and SearchForInitialization — the part of the matcher that needs no map;
-//   * the nine map-dependent searches keep the reference's own bodies for their pose algebra and map bookkeeping; their candidate
-//     loops — the data-parallel part — are entry points of liborbhip.so on flat queries; INTEGRATION.md §2 shows the few lines that
-//     hand each loop over and integration/apply_dropin.py applies them to the reference's ORBmatcher.cc (checked against the unmodified
-//     reference by tests/test_reference_dropin.py).  The comment on each declaration names the entry point.
+// compile unchanged.  ALL twelve members are implemented in this repository (orb_slam2_amd/cpp/ORBmatcher.cc, through the C ABI include/orbhip.h):
+// each is a gather of what the member reads, one device call (Hamming distances, window / vocabulary-node searches with their order-dependent
+// bookkeeping, and the per-point projection algebra of the five pose-guided members) and the member's write-back / map surgery.
+// integration/apply_dropin.py installs both files into a checkout; the comment on each declaration names the entry point.
 #ifndef ORBMATCHER_H
 #define ORBMATCHER_H
 
@@ -48,15 +45,15 @@ public:
     int SearchForInitialization(Frame& F1, Frame& F2, std::vector<cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12,
                                 int windowSize = 10);
 
-    // ---- bodies stay the reference's; the search loop of each maps to the entry point named -----------------------------
-    // local map points projected into the frame (Tracking::SearchLocalPoints)             -> orbhip_search_by_projection, mode 0
+    // ---- the map-dependent members (compiled where the tree's MapPoint / KeyFrame / Frame types exist) ------------------
+    // local map points projected into the frame (Tracking::SearchLocalPoints)             -> orbhip_search_by_projection_frame / _bounds, mode 0
     int SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th = 3);
-    // last frame's map points projected with the motion model (TrackWithMotionModel)      -> orbhip_search_by_projection, mode 1
+    // last frame's map points projected with the motion model (TrackWithMotionModel)      -> orbhip_project_search_frame / _bounds, LAST_FRAME
     int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono);
-    // relocalisation: key-frame map points projected into the frame                       -> orbhip_search_by_projection, mode 1
+    // relocalisation: key-frame map points projected into the frame                       -> orbhip_project_search_frame / _bounds, FRAME_KF
     int SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound, const float th,
                            const int ORBdist);
-    // loop closing: points seen by the loop key frame projected with a similarity         -> orbhip_search_by_projection, mode 1
+    // loop closing: points seen by the loop key frame projected with a similarity         -> orbhip_project_search_bounds, KF_SIM3
     int SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, std::vector<MapPoint*>& vpMatched,
                            int th);
 
@@ -68,13 +65,18 @@ public:
     int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F12, std::vector<std::pair<size_t, size_t> >& vMatchedPairs,
                                const bool bOnlyStereo);
 
-    // Sim3-guided search in both directions (LoopClosing::ComputeSim3)                    -> orbhip_search_best_in_window
+    // Sim3-guided search in both directions (LoopClosing::ComputeSim3)                    -> orbhip_project_best_in_window_batch, SIM3 x 2 slots
     int SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const float& s12, const cv::Mat& R12,
                      const cv::Mat& t12, const float th);
 
-    // duplicate map points merged into a key frame, Euclidean / similarity pose           -> orbhip_search_best_in_window
+    // duplicate map points merged into a key frame, Euclidean / similarity pose           -> orbhip_project_best_in_window_batch, FUSE / FUSE_SIM3
     int Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, const float th = 3.0);
     int Fuse(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, float th, std::vector<MapPoint*>& vpReplacePoint);
+
+    // The readers behind `friend class ORBmatcher;` in include/MapPoint.h (integration/apply_dropin.py adds that line): a map point's position, viewing
+    // direction, scale-invariance range, mfMaxDistance and descriptor read in place under the point's own mutexes.  Defined in ORBmatcher.cc; declared here
+    // because friendship reaches the class's members (this nested type is one), not the file's free functions.  No data member: the class layout is the reference's.
+    struct Access;
 
 protected:
     // helpers of the reference's own bodies (ORBmatcher.cc:131-157, 1601-1642); the GPU entry points carry their own versions

@@ -103,12 +103,52 @@ private:
 
 #ifdef CVLITE_ALGEBRA
 enum { NORM_L1 = 2, NORM_L2 = 4 };
+#ifndef CVLITE_GEMM_SMALL
+// A*B: every element the sum of its products in double, rounded to float - cv::gemm's generic kernel (GEMMSingleMul<float, double>); `A*B + C` then adds in float
 inline Mat operator*(const Mat& a, const Mat& b)
 {
     Mat m(a.rows, b.cols, CV_32F);
     for (int y = 0; y < a.rows; y++) for (int x = 0; x < b.cols; x++) { double s = 0; for (int k = 0; k < a.cols; k++) s += (double)a.at<float>(y, k) * b.at<float>(k, x); m.at<float>(y, x) = (float)s; }
     return m;
 }
+#else
+// -DCVLITE_GEMM_SMALL: the OTHER way an OpenCV evaluates the reference's `Rcw*p3Dw+tcw`.  In OpenCV 2.4 / 3.x `A*B` is a MatExpr that absorbs a
+// following `+ C` (MatOp_GEMM) and cv::gemm has a path for small shapes (inner length 2..4 equal to a side of the result, no transposition flags) that
+// accumulates in FLOAT, left to right, and applies alpha / beta in double: d = (float)(t0*alpha + c*beta).  Other shapes: double accumulation and ONE rounding
+// of alpha*s + beta*c.  Here: the product is an expression object, `+ Mat` evaluates it fused, a conversion evaluates it alone.  Test infrastructure
+// (tests/cpp/test_gemm_probe.cc shows the drop-in's probe telling the two apart); compile with -ffp-contract=off.
+#if defined(__GNUC__) && !defined(__clang__)
+#pragma GCC push_options
+#pragma GCC optimize ("fp-contract=off")          // OpenCV's own binaries carry no FMA contraction (generic x86-64 builds): neither does this stand-in, whatever the flags
+#endif
+struct MatMul {
+    Mat a, b;
+    Mat eval(const Mat* c) const
+    {
+        const int len = a.cols;
+        Mat m(a.rows, b.cols, CV_32F);
+        const bool small = len >= 2 && len <= 4 && (len == b.cols || len == a.rows);
+        for (int y = 0; y < a.rows; y++) for (int x = 0; x < b.cols; x++) {
+            if (small) {
+                float t0 = a.at<float>(y, 0) * b.at<float>(0, x);
+                for (int k = 1; k < len; k++) t0 = t0 + a.at<float>(y, k) * b.at<float>(k, x);
+                m.at<float>(y, x) = (float)((double)t0 * 1.0 + (c ? (double)c->at<float>(y, x) : 0.0) * (c ? 1.0 : 0.0));
+            } else {
+                double s = 0; for (int k = 0; k < len; k++) s += (double)a.at<float>(y, k) * b.at<float>(k, x);
+                m.at<float>(y, x) = (float)(c ? s + (double)c->at<float>(y, x) : s);
+            }
+        }
+        return m;
+    }
+    operator Mat() const { return eval(nullptr); }
+};
+inline MatMul operator*(const Mat& a, const Mat& b) { MatMul m = {a, b}; return m; }
+inline MatMul operator*(const MatMul& p, const Mat& b) { MatMul m = {Mat(p), b}; return m; }
+inline Mat operator+(const MatMul& p, const Mat& c) { return p.eval(&c); }
+#if defined(__GNUC__) && !defined(__clang__)
+#pragma GCC pop_options
+#endif
+#endif
 inline Mat operator*(float f, const Mat& a) { Mat m(a.rows, a.cols, CV_32F); for (int y = 0; y < a.rows; y++) for (int x = 0; x < a.cols; x++) m.at<float>(y, x) = f * a.at<float>(y, x); return m; }
 inline Mat operator*(const Mat& a, float f) { return f * a; }
 inline Mat operator*(double f, const Mat& a) { return (float)f * a; }

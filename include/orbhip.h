@@ -473,6 +473,93 @@ orbhip_status orbhip_search_best_in_window_frame(orbhip_ctx* ctx, int frame, int
                                                  const orbhip_best_query* queries, const uint8_t* query_desc, int nq, int chi2_gate,
                                                  int32_t* best_idx, int32_t* best_dist);
 
+/* -------- the pose-guided matchers with the PROJECTION on the device ----------------------------------------
+   The five projection-guided members of ORBmatcher evaluate, per map point, a few lines of cv::Mat algebra before their window search:
+       SearchByProjection(Frame&, const Frame&, th, bMono)                 ORBmatcher.cc:1353-1395
+       SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist)   ORBmatcher.cc:1490-1528
+       SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th)         ORBmatcher.cc:316-362
+       Fuse(KeyFrame*, vpMapPoints, th) / Fuse(KeyFrame*, Scw, ...)        ORBmatcher.cc:850-892 / :1004-1051
+       SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th)            ORBmatcher.cc:1154-1191 / :1234-1271
+   The entries below take what the member READS - one orbhip_map_point per map point that passed the member's own pointer / isBad / already-found
+   filters, the pose(s) and intrinsics of the call - and run transform -> depth / image-bounds / distance / viewing-angle gates -> PredictScale ->
+   radius -> window search in ONE launch chain; the host keeps the MapPoint gathers and the map surgery.  A point that fails a gate is a query
+   without candidates (feature_query never names it, best_idx = -1).  Every float operation is the reference's, in its order, each rounded once
+   (no contraction); `kind` selects the member's statement sequence (they differ: 1/z vs 1.0/z, fx*x+cx vs fx*xc*invzc+cx, `<` vs `<=` bounds,
+   which gates exist).  orb_slam2_amd/cpp/ORBmatcher.cc is the caller. */
+#define ORBHIP_MAX_PROJ_LEVELS 16
+typedef struct {
+    float x, y, z;              /* MapPoint::GetWorldPos() */
+    float cam_x, cam_y, cam_z;  /* read only with gemm_mode 2: the point in the frame the member projects from, from the caller's own cv::Mat expression */
+    float nx, ny, nz;           /* MapPoint::GetNormal(): kinds with the viewing-angle gate (PO.dot(Pn) < 0.5*dist), else unused */
+    float min_dist, max_dist;   /* MapPoint::GetMinDistanceInvariance() / GetMaxDistanceInvariance(): kinds with the distance gate */
+    float scale_dist;           /* mfMaxDistance, the numerator of MapPoint::PredictScale (MapPoint.cc:390, 407); read when level < 0 */
+    int32_t level;              /* >= 0: the level is given (ORBmatcher.cc:1376: LastFrame.mvKeys[i].octave); -1: PredictScale on the device */
+    int32_t blocks;             /* orbhip_proj_query.blocks */
+    float angle;                /* orbhip_proj_query.angle */
+} orbhip_map_point;             /* 60 bytes */
+typedef enum {
+    ORBHIP_PROJ_LAST_FRAME = 0, /* :1353-1395  x3Dc = Rcw*x3Dw+tcw; invzc = 1.0/z; invzc<0 -> skip; u = fx*xc*invzc+cx; u<minX || u>maxX -> skip;
+                                               radius = th*sf[octave]; levels by forward / backward; ur = u - mbf*invzc */
+    ORBHIP_PROJ_FRAME_KF = 1,   /* :1490-1528  the same projection WITHOUT the depth test; PO = x3Dw-Ow, dist3D = norm(PO) in [min, max];
+                                               PredictScale; radius = th*sf[level]; levels level-1 .. level+1 */
+    ORBHIP_PROJ_KF_SIM3 = 2,    /* :316-362    p3Dc = Rcw*p3Dw+tcw; z<0 -> skip; invz = 1/z; x = X*invz; u = fx*x+cx; IsInImage; distance gate on
+                                               norm(p3Dw-Ow); PO.dot(Pn) < 0.5*dist -> skip; PredictScale; radius = th*sf[level]; levels level-1 .. level */
+    ORBHIP_PROJ_FUSE = 3,       /* :850-892    as KF_SIM3, + ur = u - bf*invz */
+    ORBHIP_PROJ_FUSE_SIM3 = 4,  /* :1004-1051  as KF_SIM3 with invz = 1.0/z */
+    ORBHIP_PROJ_SIM3 = 5        /* :1154-1191  p3Dc1 = R*p3Dw+t; p3Dc2 = R2*p3Dc1+t2; z<0 -> skip; invz = 1.0/z; IsInImage; distance gate on norm(p3Dc2);
+                                               PredictScale; radius = th*sf[level]; no viewing-angle gate */
+} orbhip_projection_kind;
+typedef struct {
+    int32_t kind;               /* orbhip_projection_kind */
+    int32_t gemm_mode;          /* how `R*x+t` rounds: 0 = products accumulated in double, rounded to float, then + t in float
+                                   (cv::gemm's generic kernel; include/cvlite); 1 = OpenCV's small-matrix path: a0*b0 + a1*b1 + a2*b2 in float,
+                                   then (float)((double)t0 + (double)c); 2 = not on the device: cam_x/y/z of every point hold the result of the
+                                   caller's own cv::Mat expression (after BOTH transforms for SIM3) */
+    float R[9], t[3];           /* Rcw | tcw, row-major (R1w | t1w for SIM3) */
+    float R2[9], t2[3];         /* SIM3: sR21 | t21 (searching key frame 2) or sR12 | t12 (searching key frame 1) */
+    float Ow[3];                /* camera centre the member computes (-Rcw.t()*tcw / KeyFrame::GetCameraCenter()) */
+    float fx, fy, cx, cy, bf;
+    float min_x, min_y, max_x, max_y;   /* Frame::mnMinX .. (float) / KeyFrame::mnMinX .. (int, converted): what the member's bounds test reads */
+    float th;
+    int32_t forward, backward;  /* LAST_FRAME: bForward / bBackward (:1348-1349) */
+    int32_t nlevels;            /* mnScaleLevels */
+    float scale_factors[ORBHIP_MAX_PROJ_LEVELS];    /* mvScaleFactors */
+    /* MapPoint::PredictScale (MapPoint.cc:385-421) without a device logarithm: nScale = ceil(log(ratio)/mfLogScaleFactor), clamped to [0, nlevels-1],
+       is a non-decreasing step function of ratio = mfMaxDistance/dist, so it equals the number of i < nlevels-1 with ratio >= level_ratio[i], where
+       level_ratio[i] = the smallest float ratio the HOST's own expression maps to a level > i (orbhip_predict_scale_table). */
+    float level_ratio[ORBHIP_MAX_PROJ_LEVELS];
+} orbhip_projection;
+/* level_ratio[0 .. nlevels-2] for a given mfLogScaleFactor by bisection over the floats with `level_of(ratio, user)` = the caller's own
+   PredictScale expression (so that whatever log / ceil overloads the caller's translation unit resolves to are the ones reproduced);
+   entries from nlevels-1 on are +inf.  Fails if level_of is not monotone around a threshold (checked +-64 floats). */
+orbhip_status orbhip_predict_scale_table(int (*level_of)(float ratio, void* user), void* user, int nlevels, float* level_ratio /* ORBHIP_MAX_PROJ_LEVELS */);
+
+/* orbhip_search_by_projection_bounds / _frame with one orbhip_map_point per query instead of one orbhip_proj_query; mode 1 semantics (best only,
+   rotation histogram when check_ori).  queries_out (may be NULL): np orbhip_proj_query records as the device derived them - radius < 0 marks a
+   point that failed a gate - for inspection and the parity tests. */
+orbhip_status orbhip_project_search_bounds(int device, const orbhip_keypoint* kps, const uint8_t* desc, const float* u_right,
+                                           const uint8_t* blocked, int n, const orbhip_bounds* bounds,
+                                           const orbhip_projection* proj, const orbhip_map_point* points, const uint8_t* point_desc, int np,
+                                           float nnratio, int th_high, int check_ori, int32_t* feature_query, int* nmatches,
+                                           orbhip_proj_query* queries_out);
+orbhip_status orbhip_project_search_frame(orbhip_ctx* ctx, int frame, int n, int use_u_right, const uint8_t* blocked,
+                                          const orbhip_projection* proj, const orbhip_map_point* points, const uint8_t* point_desc, int np,
+                                          float nnratio, int th_high, int check_ori, int32_t* feature_query, int* nmatches,
+                                          orbhip_proj_query* queries_out);
+/* orbhip_search_best_in_window_bounds / _batch likewise (Fuse x2, SearchBySim3's two passes as two slots of one call).  queries_out as above
+   (orbhip_best_query records, radius < 0 = gated out). */
+orbhip_status orbhip_project_best_in_window_bounds(int device, const orbhip_keypoint* kps, const uint8_t* desc, const float* u_right /* may be NULL */,
+                                                   int n, const orbhip_bounds* bounds, const float* inv_level_sigma2, int nlevels,
+                                                   const orbhip_projection* proj, const orbhip_map_point* points, const uint8_t* point_desc, int np,
+                                                   int chi2_gate, int32_t* best_idx, int32_t* best_dist, orbhip_best_query* queries_out);
+typedef struct {
+    const orbhip_keypoint* kps; const uint8_t* desc; const float* u_right; int32_t n;                    /* the key frame searched */
+    orbhip_bounds bounds; const float* inv_level_sigma2; int32_t nlevels;
+    const orbhip_projection* proj; const orbhip_map_point* points; const uint8_t* point_desc; int32_t np;
+    int32_t* best_idx; int32_t* best_dist;                                                              /* out: np entries each */
+} orbhip_project_best_slot;
+orbhip_status orbhip_project_best_in_window_batch(int device, int nslots, orbhip_project_best_slot* slots, int chi2_gate);
+
 /* Stereo rectification on the input side: the EuRoC example runs cv::remap(raw, rect, M1, M2, cv::INTER_LINEAR) on the CPU for both
    images of every pair before TrackStereo (Examples/Stereo/stereo_euroc.cc:136-137; maps from cv::initUndistortRectifyMap(..,
    CV_32F, ..) :97-98).  orbhip_set_rectification uploads the two CV_32FC1 maps ([height][width] of the context, contiguous; they

@@ -1,27 +1,29 @@
 #!/usr/bin/env python3
 """apply_dropin.py — the binding of INTEGRATION.md §2 as ONE command a maintainer of raulmur/ORB_SLAM2 runs on a checkout.
 
-    python integration/apply_dropin.py /path/to/ORB_SLAM2 /path/to/out      # writes the edited tree pieces under out/
-    python integration/apply_dropin.py --patch /path/to/ORB_SLAM2 > dropin.patch   # the same edits as a unified diff (patch -p1)
+    python integration/apply_dropin.py /path/to/ORB_SLAM2 /path/to/out      # writes the replaced / edited tree pieces under out/
+    python integration/apply_dropin.py --patch /path/to/ORB_SLAM2 > dropin.patch   # the same as a unified diff (patch -p1)
     ... --stereo-one-call        optional: the stereo Frame constructor extracts both images in ONE call on one device context (ORBextractor::ExtractStereo)
     ... --device-rgbd            optional: Frame::ComputeStereoFromRGBD samples the depth map on the device (default: the reference's loop + N floats uploaded)
     ... --resident-bow           optional (with this repository's ORBVocabulary class in place, step 3e): Frame::ComputeBoW reads the descriptors in HBM
 
-What it produces (nothing else of the checkout changes; Tracking.cc, LocalMapping.cc, LoopClosing.cc, KeyFrame*.cc compile as they are):
-  out/include/ORBextractor.h, out/src/ORBextractor.cc     this repository's drop-in class (include/ORBextractor.h, orb_slam2_amd/cpp/)
-  out/include/orbhip.h                                    the C ABI of liborbhip.so (link with -lorbhip)
-  out/src/Frame.cc         the reference's file with the bodies of ComputeStereoMatches, UndistortKeyPoints, ComputeImageBounds and
-                           ComputeStereoFromRGBD replaced by one-line forwards to the extractor that just processed the frame (§2-3b, 3d')
-  out/src/ORBmatcher.cc    the reference's file with DescriptorDistance forwarded and the candidate / search loop of EVERY search member
-                           (SearchForInitialization, four SearchByProjection overloads, two SearchByBoW, SearchForTriangulation,
-                           SearchBySim3, two Fuse) replaced by one call of the C ABI each; the reference's pose algebra, MapPoint /
-                           KeyFrame bookkeeping and return values around them stay untouched (§2-3, 3c, 3e, 3f)
-The edits are located by the reference's own statements (regular expressions on signatures and anchor lines), so the script fails
-loudly — never silently skips — if a checkout differs from upstream at one of them.
+What it produces (nothing else of the checkout changes; Tracking.cc, LocalMapping.cc, LoopClosing.cc, KeyFrame*.cc, MapPoint.cc compile as they are):
+  REPLACED by this repository's files (an installer's copy, no text surgery):
+    out/include/ORBextractor.h, out/src/ORBextractor.cc     the drop-in extractor class (include/ORBextractor.h, orb_slam2_amd/cpp/ORBextractor.cc)
+    out/include/ORBmatcher.h,   out/src/ORBmatcher.cc       the drop-in matcher class: all twelve members (orb_slam2_amd/cpp/ORBmatcher.cc)
+    out/include/ORBmatcherBatch.h                           the back end's matcher loops as single device passes (optional use)
+    out/include/orbhip_gemm_probe.h                         how the linked cv::Mat rounds `R*x+t` (ORBmatcher.cc asks once per process)
+    out/include/orbhip.h                                    the C ABI of liborbhip.so (link with -lorbhip)
+  EDITED (located by the reference's own statements; the script fails loudly - never skips silently - where a checkout differs from upstream):
+    out/src/Frame.cc         the bodies of ComputeStereoMatches, UndistortKeyPoints, ComputeImageBounds (and optionally ComputeStereoFromRGBD / ComputeBoW /
+                             the stereo constructor's two extractor threads) become one-line forwards to the extractor that just processed the frame (§2-3b, 3d')
+    out/include/MapPoint.h   ONE line: `friend class ORBmatcher;` (+ a #define saying so): the matcher's gathers read a map point's position, normal,
+                             descriptor and mfMaxDistance in place, under the point's own mutexes (§2-3c)
 
-The test builds of this repository consume exactly this script (oracle/Makefile, target _ref/liborbslam_dropin_full.so, legacy form
-`apply_dropin.py --files <Frame.cc> <out> <ORBmatcher.cc> <out>`), so what tests/test_reference_dropin.py checks against the unmodified
-reference is what a maintainer applies.  No reference source is kept in this repository."""
+Until round 5 src/ORBmatcher.cc was the reference's file with each member's search loop cut out by regular expressions; it is now a file of this repository
+like the extractor's (a fork that reformatted a signature loses nothing).  The test builds of this repository consume exactly this script for the two edited
+files (oracle/Makefile, `apply_dropin.py --files <Frame.cc> <out> <MapPoint.h> <out>`) and compile orb_slam2_amd/cpp/ORBmatcher.cc as it lies, so what
+tests/test_reference_dropin.py checks against the unmodified reference is what a maintainer installs.  No reference source is kept in this repository."""
 import difflib
 import os
 import re
@@ -84,612 +86,24 @@ def replace_body(src, signature, body):
     return src[:i] + body + src[j:]
 
 
-# the two per-frame projection matchers keep their map / pose code and hand the search loop to the library.
-LOCAL_MAP_SIG = r"int\s+ORBmatcher::SearchByProjection\s*\(\s*Frame\s*&\s*F\s*,\s*const\s+vector<MapPoint\*>\s*&\s*vpMapPoints\s*,\s*const\s+float\s+th\s*\)"
-LOCAL_MAP_BODY = """{
-    int nmatches=0;
-    const bool bFactor = th!=1.0;
-    std::vector<orbhip_proj_query> q; std::vector<unsigned char> qd; std::vector<MapPoint*> owner;
-    for(size_t iMP=0; iMP<vpMapPoints.size(); iMP++)
-    {
-        MapPoint* pMP = vpMapPoints[iMP];
-        if(!pMP->mbTrackInView || pMP->isBad()) continue;
-        const int &nPredictedLevel = pMP->mnTrackScaleLevel;
-        float r = RadiusByViewingCos(pMP->mTrackViewCos);
-        if(bFactor) r*=th;
-        orbhip_proj_query e = { pMP->mTrackProjX, pMP->mTrackProjY, r*F.mvScaleFactors[nPredictedLevel], pMP->mTrackProjXR,
-                                nPredictedLevel-1, nPredictedLevel, pMP->Observations()>0, 0.f };
-        const cv::Mat d = pMP->GetDescriptor();
-        q.push_back(e); qd.insert(qd.end(), d.ptr<unsigned char>(), d.ptr<unsigned char>()+32); owner.push_back(pMP);
-    }
-    if(q.empty() || F.N==0) return 0;
-    std::vector<unsigned char> blocked(F.N); std::vector<int> fq(F.N);
-    for(int i=0;i<F.N;i++) blocked[i] = F.mvpMapPoints[i] && F.mvpMapPoints[i]->Observations()>0;
-    orbhip_projection_search(F, true, blocked, q, qd, 0, mfNNratio, TH_HIGH, false, fq, nmatches);
-    for(int i=0;i<F.N;i++) if(fq[i]>=0) F.mvpMapPoints[i]=owner[fq[i]];
-    return nmatches;
-}"""
-LAST_FRAME_SIG = r"int\s+ORBmatcher::SearchByProjection\s*\(\s*Frame\s*&\s*CurrentFrame\s*,\s*const\s+Frame\s*&\s*LastFrame\s*,\s*const\s+float\s+th\s*,\s*const\s+bool\s+bMono\s*\)"
-LAST_FRAME_DECLS = """
-    std::vector<orbhip_proj_query> orbhip_q; std::vector<unsigned char> orbhip_qd; std::vector<MapPoint*> orbhip_owner;
-"""
-LAST_FRAME_QUERY = """orbhip_proj_query e = { u, v, radius, u - CurrentFrame.mbf*invzc,
-                                        bForward ? nLastOctave : (bBackward ? 0 : nLastOctave-1), bForward ? -1 : (bBackward ? nLastOctave : nLastOctave+1),
-                                        pMP->Observations()>0, LastFrame.mvKeysUn[i].angle };
-                const cv::Mat dMP = pMP->GetDescriptor();
-                orbhip_q.push_back(e); orbhip_qd.insert(orbhip_qd.end(), dMP.ptr<unsigned char>(), dMP.ptr<unsigned char>()+32); orbhip_owner.push_back(pMP);
-"""
-LAST_FRAME_SEARCH = """if(!orbhip_q.empty() && CurrentFrame.N>0)
-    {
-        std::vector<unsigned char> blocked(CurrentFrame.N); std::vector<int> fq(CurrentFrame.N);
-        for(int i=0;i<CurrentFrame.N;i++) blocked[i] = CurrentFrame.mvpMapPoints[i] && CurrentFrame.mvpMapPoints[i]->Observations()>0;
-        orbhip_projection_search(CurrentFrame, true, blocked, orbhip_q, orbhip_qd, 1, mfNNratio, TH_HIGH, mbCheckOrientation, fq, nmatches);
-        for(int i=0;i<CurrentFrame.N;i++)
-        {
-            if(fq[i]>=0) CurrentFrame.mvpMapPoints[i]=orbhip_owner[fq[i]];
-            else if(fq[i]==-2) CurrentFrame.mvpMapPoints[i]=static_cast<MapPoint*>(NULL);
-        }
-    }
-"""
+# src/ORBmatcher.cc is this repository's own file (orb_slam2_amd/cpp/ORBmatcher.cc: all twelve members, the projection of the five
+# pose-guided ones on the device).  Its gathers read a map point's position / normal / scale range / descriptor in place (no cv::Mat clones) and
+# mfMaxDistance, which MapPoint::PredictScale uses and no accessor returns: ONE line in include/MapPoint.h lets them.
+MAPPOINT_CLASS = r"class\s+MapPoint\s*\{\s*public\s*:"
+MAPPOINT_FRIEND = """class MapPoint
+{
+    friend class ORBmatcher;      // orbhip drop-in: src/ORBmatcher.cc reads mWorldPos / mNormalVector / mDescriptor / mfMaxDistance under the point's own mutexes
+public:"""
 
 
-def block_end(src, i):
-    """index just past the brace block that opens at or after i"""
-    i = src.index("{", i)
-    depth, j = 0, i
-    while True:
-        depth += src[j] == "{"
-        depth -= src[j] == "}"
-        j += 1
-        if depth == 0:
-            return j
-
-
-def patch_last_frame(src):
-    m = re.search(LAST_FRAME_SIG, src)
+def patch_mappoint_header(src):
+    src, n = re.subn(MAPPOINT_CLASS, MAPPOINT_FRIEND, src, count=1)
+    if n != 1:
+        raise SystemExit("`class MapPoint { public:` not found in include/MapPoint.h")
+    m = re.search(r"#define\s+MAPPOINT_H\s*\n", src)
     if not m:
-        raise SystemExit("SearchByProjection(CurrentFrame, LastFrame, ...) not found")
-    f0, f1 = m.start(), block_end(src, m.end())
-    fn = src[f0:f1]
-    # declarations of the flat query arrays right after the function's first statement
-    k = fn.index("int nmatches = 0;") + len("int nmatches = 0;")
-    fn = fn[:k] + LAST_FRAME_DECLS + fn[k:]
-    # the candidate search of one map point -> one flat query
-    a = fn.index("vector<size_t> vIndices2;")
-    b = block_end(fn, fn.index("if(bestDist<=TH_HIGH)", a))
-    fn = fn[:a] + LAST_FRAME_QUERY + fn[b:]
-    # the rotation-consistency pass after the loop -> the library call (which includes it) + the write-back
-    a = fn.rindex("if(mbCheckOrientation)")
-    b = block_end(fn, a)
-    fn = fn[:a] + LAST_FRAME_SEARCH + fn[b:]
-    return src[:f0] + fn + src[f1:]
-
-
-# the loop-closing and relocalisation overloads are parameterisations of the same search (include/orbhip.h): levels, threshold, who blocks
-KF_SIM3_SIG = r"int\s+ORBmatcher::SearchByProjection\s*\(\s*KeyFrame\s*\*\s*pKF\s*,\s*cv::Mat\s+Scw\s*,"
-KF_SIM3_QUERY = """orbhip_proj_query e = { u, v, radius, 0.f, nPredictedLevel-1, nPredictedLevel, 1, 0.f };
-        const cv::Mat dMP = pMP->GetDescriptor();
-        orbhip_q.push_back(e); orbhip_qd.insert(orbhip_qd.end(), dMP.ptr<unsigned char>(), dMP.ptr<unsigned char>()+32); orbhip_owner.push_back(pMP);
-"""
-KF_SIM3_SEARCH = """if(!orbhip_q.empty() && pKF->N>0)
-    {
-        std::vector<unsigned char> blocked(pKF->N); std::vector<int> fq(pKF->N);
-        for(int i=0;i<pKF->N;i++) blocked[i] = vpMatched[i]!=NULL;
-        const orbhip_bounds bounds = {(float)pKF->mnMinX, (float)pKF->mnMinY, (float)pKF->mnMaxX, (float)pKF->mnMaxY};
-        orbhip_check(orbhip_search_by_projection_bounds(orbhip_default_device(), (const orbhip_keypoint*)&pKF->mvKeysUn[0], pKF->mDescriptors.ptr<unsigned char>(), NULL, &blocked[0], pKF->N, &bounds,
-                                              &orbhip_q[0], &orbhip_qd[0], (int)orbhip_q.size(), 1, mfNNratio, TH_LOW, 0, &fq[0], &nmatches));
-        for(int i=0;i<pKF->N;i++) if(fq[i]>=0) vpMatched[i]=orbhip_owner[fq[i]];
-    }
-
-    """
-RELOC_SIG = r"int\s+ORBmatcher::SearchByProjection\s*\(\s*Frame\s*&\s*CurrentFrame\s*,\s*KeyFrame\s*\*\s*pKF\s*,"
-RELOC_QUERY = """orbhip_proj_query e = { u, v, radius, 0.f, nPredictedLevel-1, nPredictedLevel+1, 1, pKF->mvKeysUn[i].angle };
-                const cv::Mat dMP = pMP->GetDescriptor();
-                orbhip_q.push_back(e); orbhip_qd.insert(orbhip_qd.end(), dMP.ptr<unsigned char>(), dMP.ptr<unsigned char>()+32); orbhip_owner.push_back(pMP);
-"""
-RELOC_SEARCH = """if(!orbhip_q.empty() && CurrentFrame.N>0)
-    {
-        std::vector<unsigned char> blocked(CurrentFrame.N); std::vector<int> fq(CurrentFrame.N);
-        for(int i=0;i<CurrentFrame.N;i++) blocked[i] = CurrentFrame.mvpMapPoints[i]!=NULL;
-        orbhip_projection_search(CurrentFrame, false, blocked, orbhip_q, orbhip_qd, 1, mfNNratio, ORBdist, mbCheckOrientation, fq, nmatches);
-        for(int i=0;i<CurrentFrame.N;i++)
-        {
-            if(fq[i]>=0) CurrentFrame.mvpMapPoints[i]=orbhip_owner[fq[i]];
-            else if(fq[i]==-2) CurrentFrame.mvpMapPoints[i]=static_cast<MapPoint*>(NULL);
-        }
-    }
-"""
-
-
-def patch_projection_member(src, sig, first_stmt, loop_from, loop_until, query, search, search_replaces):
-    """one SearchByProjection overload: flat-query arrays declared after `first_stmt`; the text from `loop_from` to the end of the block
-    opened after `loop_until` becomes `query`; `search` replaces the block after the LAST `search_replaces` (the rotation pass) or, if that is
-    None, goes in front of the function's final return"""
-    m = re.search(sig, src)
-    if not m:
-        raise SystemExit(f"not found: {sig}")
-    f0, f1 = m.start(), block_end(src, m.end())
-    fn = src[f0:f1]
-    k = fn.index(first_stmt) + len(first_stmt)
-    fn = fn[:k] + LAST_FRAME_DECLS + fn[k:]
-    a = fn.index(loop_from)
-    b = block_end(fn, fn.index(loop_until, a))
-    fn = fn[:a] + query + fn[b:]
-    if search_replaces is None:
-        a = fn.rindex("return nmatches;")
-        fn = fn[:a] + search + fn[a:]
-    else:
-        a = fn.rindex(search_replaces)
-        fn = fn[:a] + search + fn[block_end(fn, a):]
-    return src[:f0] + fn + src[f1:]
-
-
-# Fuse (LocalMapping::SearchInNeighbors): the candidate search of every map point does not depend on the map surgery of the others, so the
-# member becomes two passes — the reference's projection code collects one flat query per point, ONE library call finds the best key point of
-# every window, then the reference's own surgery block (Replace / AddObservation / AddMapPoint, moved, not rewritten) runs in the original
-# order.  (vpMapPoints holds each point once, LocalMapping.cc:mnFuseCandidateForKF, so no point's filters depend on an earlier point's surgery.)
-FUSE_SIG = r"int\s+ORBmatcher::Fuse\s*\(\s*KeyFrame\s*\*\s*pKF\s*,\s*const\s+vector<MapPoint\s*\*>\s*&\s*vpMapPoints\s*,\s*const\s+float\s+th\s*\)"
-# The member becomes three pieces (all from the reference's own text):
-#   orbhip_fuse_collect   its projection code, unchanged, up to the window search: one flat query per point that passed the filters
-#   orbhip_fuse_apply     its surgery block, unchanged, in the original order - after re-checking what the surgery of EARLIER targets may have changed since
-#                         the queries were collected (Replace() makes a point bad, can put it into this key frame and recomputes the survivor's
-#                         descriptor, MapPoint.cc:177-215): such points are skipped / searched again, together, before the target's surgery
-#   Fuse = collect + one library call + apply;  FuseBatch (include/ORBmatcherBatch.h) = collect for every target + ONE library call + apply per target
-FUSE_DECLS = """
-    std::vector<orbhip_best_query> orbhip_bq; std::vector<unsigned char> orbhip_qd; std::vector<MapPoint*> orbhip_owner;
-"""
-FUSE_JOB = """
-struct OrbhipFuseJob
-{
-    KeyFrame* pKF; std::vector<orbhip_best_query> bq; std::vector<unsigned char> qd; std::vector<MapPoint*> owner; std::vector<int> bi, bd;
-};
-static orbhip_bounds orbhip_kf_bounds(KeyFrame* pKF) { orbhip_bounds b = {(float)pKF->mnMinX, (float)pKF->mnMinY, (float)pKF->mnMaxX, (float)pKF->mnMaxY}; return b; }
-"""
-FUSE_QUERY = """orbhip_best_query e = { u, v, radius, ur, nPredictedLevel };
-        const cv::Mat dMP = pMP->GetDescriptor();
-        job.bq.push_back(e); job.qd.insert(job.qd.end(), dMP.ptr<unsigned char>(), dMP.ptr<unsigned char>()+32); job.owner.push_back(pMP);
-"""
-FUSE_TAIL = """
-// survivors: the points that absorbed another one in the surgery of EARLIER targets of the same FuseBatch (MapPoint::Replace recomputes the survivor's
-// descriptor, MapPoint.cc:177-215) - NULL for a single Fuse, whose queries were collected just before its search: nothing to re-check
-static int orbhip_fuse_apply(OrbhipFuseJob &job, std::set<MapPoint*> *survivors)
-{
-    KeyFrame* pKF = job.pKF;
-    const int TH_LOW = ORBmatcher::TH_LOW;
-    int nFused=0;
-    // Survivors whose descriptor is not the collected one any more are searched again, all of them in one call, before this target's surgery starts.
-    // (Inside one target no collected point's descriptor changes: a survivor is either a point already handled or a point of this key frame, which
-    // the filter below skips.)  Only survivors are looked at - nobody else's descriptor can have changed - instead of GetDescriptor() (a lock and a clone) for
-    // every point of every target.
-    if(survivors && !survivors->empty())
-    {
-        std::vector<size_t> again; std::vector<orbhip_best_query> bq; std::vector<unsigned char> qd;
-        for(size_t k=0; k<job.owner.size(); k++)
-        {
-            MapPoint* pMP = job.owner[k];
-            if(!survivors->count(pMP)) continue;
-            if(pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
-            const cv::Mat dNow = pMP->GetDescriptor();
-            if(!memcmp(dNow.ptr<unsigned char>(), &job.qd[32*k], 32)) continue;
-            again.push_back(k); bq.push_back(job.bq[k]); qd.insert(qd.end(), dNow.ptr<unsigned char>(), dNow.ptr<unsigned char>()+32);
-        }
-        if(!again.empty() && pKF->N>0)
-        {
-            std::vector<int> bi(again.size(), -1), bd(again.size(), 256);
-            const orbhip_bounds bounds = orbhip_kf_bounds(pKF);
-            orbhip_check(orbhip_search_best_in_window_bounds(orbhip_default_device(), (const orbhip_keypoint*)&pKF->mvKeysUn[0], pKF->mDescriptors.ptr<unsigned char>(), &pKF->mvuRight[0], pKF->N, &bounds,
-                                                   &pKF->mvInvLevelSigma2[0], (int)pKF->mvInvLevelSigma2.size(), &bq[0], &qd[0], (int)bq.size(), 1, &bi[0], &bd[0]));
-            for(size_t a=0; a<again.size(); a++) { job.bi[again[a]] = bi[a]; job.bd[again[a]] = bd[a]; }
-        }
-    }
-    for(size_t orbhip_k=0; orbhip_k<job.owner.size(); orbhip_k++)
-    {
-        MapPoint* pMP = job.owner[orbhip_k];
-        if(pMP->isBad() || pMP->IsInKeyFrame(pKF))        // (the reference's own filter, as of NOW)
-            continue;
-        const int bestDist = job.bd[orbhip_k], bestIdx = job.bi[orbhip_k];
-        %s
-    }
-    return nFused;
-}
-
-int ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint *> &vpMapPoints, const float th)
-{
-    OrbhipFuseJob job;
-    orbhip_fuse_collect(pKF, vpMapPoints, th, job);
-    job.bi.assign(job.bq.size(), -1); job.bd.assign(job.bq.size(), 256);
-    if(!job.bq.empty() && pKF->N>0)
-    {
-        const orbhip_bounds bounds = orbhip_kf_bounds(pKF);
-        orbhip_check(orbhip_search_best_in_window_bounds(orbhip_default_device(), (const orbhip_keypoint*)&pKF->mvKeysUn[0], pKF->mDescriptors.ptr<unsigned char>(), &pKF->mvuRight[0], pKF->N, &bounds,
-                                               &pKF->mvInvLevelSigma2[0], (int)pKF->mvInvLevelSigma2.size(), &job.bq[0], &job.qd[0], (int)job.bq.size(), 1, &job.bi[0], &job.bd[0]));
-    }
-    return orbhip_fuse_apply(job, NULL);
-}
-
-// LocalMapping::SearchInNeighbors (LocalMapping.cc:483-514): `for every target key frame: matcher.Fuse(pKFi, vpMapPointMatches)` as ONE device pass
-int FuseBatch(const std::vector<KeyFrame*> &vpTargetKFs, const std::vector<MapPoint*> &vpMapPoints, const float th)
-{
-    std::vector<OrbhipFuseJob> jobs(vpTargetKFs.size());
-    std::vector<orbhip_best_slot> slots(vpTargetKFs.size());
-    for(size_t t=0; t<vpTargetKFs.size(); t++)
-    {
-        OrbhipFuseJob &job = jobs[t]; KeyFrame* pKF = vpTargetKFs[t];
-        orbhip_fuse_collect(pKF, vpMapPoints, th, job);
-        job.bi.assign(job.bq.size(), -1); job.bd.assign(job.bq.size(), 256);
-        orbhip_best_slot &S = slots[t];
-        S.kps = pKF->N>0 ? (const orbhip_keypoint*)&pKF->mvKeysUn[0] : NULL; S.desc = pKF->N>0 ? pKF->mDescriptors.ptr<unsigned char>() : NULL; S.u_right = pKF->N>0 ? &pKF->mvuRight[0] : NULL; S.n = pKF->N;
-        S.bounds = orbhip_kf_bounds(pKF); S.inv_level_sigma2 = &pKF->mvInvLevelSigma2[0]; S.nlevels = (int)pKF->mvInvLevelSigma2.size();
-        S.queries = job.bq.empty() ? NULL : &job.bq[0]; S.query_desc = job.qd.empty() ? NULL : &job.qd[0]; S.nq = (int)job.bq.size();
-        S.best_idx = job.bi.empty() ? NULL : &job.bi[0]; S.best_dist = job.bd.empty() ? NULL : &job.bd[0];
-    }
-    if(!slots.empty())
-        orbhip_check(orbhip_search_best_in_window_batch(orbhip_default_device(), (int)slots.size(), &slots[0], 1));
-    int nFused=0;
-    std::set<MapPoint*> survivors;
-    for(size_t t=0; t<jobs.size(); t++)
-        nFused += orbhip_fuse_apply(jobs[t], &survivors);
-    return nFused;
-}
-"""
-
-
-def patch_fuse(src):
-    m = re.search(FUSE_SIG, src)
-    if not m:
-        raise SystemExit("Fuse(pKF, vpMapPoints, th) not found")
-    f0, f1 = m.start(), block_end(src, m.end())
-    fn = src[f0:f1]
-    a = fn.index("const vector<size_t> vIndices = pKF->GetFeaturesInArea(u,v,radius);")
-    s0 = fn.index("if(bestDist<=TH_LOW)", a)
-    s1 = block_end(fn, s0)
-    surgery = fn[s0:s1]                                   # the reference's own block, moved into orbhip_fuse_apply
-    # ... with the survivor of each of its two Replace() calls noted (the statements themselves stay): FuseBatch re-checks survivors only
-    for stmt, who in (("pMP->Replace(pMPinKF);", "pMPinKF"), ("pMPinKF->Replace(pMP);", "pMP")):
-        if surgery.count(stmt) != 1:
-            raise SystemExit(f"Fuse: `{stmt}` not found exactly once in the surgery block")
-        surgery = surgery.replace(stmt, "{ %s if(survivors) survivors->insert(%s); }" % (stmt, who))
-    fn = fn[:a] + FUSE_QUERY + fn[s1:]
-    # the collecting half keeps the reference's text; only its head and its return change
-    head = re.match(FUSE_SIG, fn)
-    fn = "static void orbhip_fuse_collect(KeyFrame *pKF, const vector<MapPoint *> &vpMapPoints, const float th, OrbhipFuseJob &job)" + fn[head.end():]
-    fn = fn.replace("{", "{\n    job.pKF = pKF;", 1)
-    r = fn.rindex("return nFused;")
-    fn = fn[:r] + "(void)nFused;" + fn[r + len("return nFused;"):]
-    return src[:f0] + FUSE_JOB + fn + (FUSE_TAIL % surgery) + src[f1:]
-
-
-# SearchByBoW (TrackReferenceKeyFrame / Relocalization, LoopClosing::ComputeSim3): the two std::map FeatureVectors are flattened and the node-
-# matched search runs in one call; whole bodies (the reference's map-point vectors in, its output vector out).
-BOW_HELPERS = """
-static void orbhip_flatten(const DBoW2::FeatureVector& fv, std::vector<unsigned int>& node, std::vector<int>& off, std::vector<unsigned int>& feat)
-{
-    node.clear(); off.assign(1, 0); feat.clear();
-    for(DBoW2::FeatureVector::const_iterator it=fv.begin(); it!=fv.end(); ++it)
-    {
-        node.push_back(it->first); feat.insert(feat.end(), it->second.begin(), it->second.end()); off.push_back((int)feat.size());
-    }
-    if(node.empty()) node.push_back(0);
-    if(feat.empty()) feat.push_back(0);
-}
-"""
-BOW_KF_FRAME_SIG = r"int\s+ORBmatcher::SearchByBoW\s*\(\s*KeyFrame\s*\*\s*pKF\s*,\s*Frame\s*&\s*F\s*,"
-BOW_KF_FRAME_BODY = """{
-    const vector<MapPoint*> vpMapPointsKF = pKF->GetMapPointMatches();
-    vpMapPointMatches = vector<MapPoint*>(F.N,static_cast<MapPoint*>(NULL));
-    const int n1 = (int)vpMapPointsKF.size(), n2 = F.N;
-    if(n1==0 || n2==0 || pKF->mFeatVec.empty() || F.mFeatVec.empty()) return 0;
-    std::vector<unsigned char> valid1(n1); std::vector<float> ang1(n1), ang2(n2);
-    for(int i=0;i<n1;i++) { MapPoint* p = vpMapPointsKF[i]; valid1[i] = p && !p->isBad(); ang1[i] = pKF->mvKeysUn[i].angle; }
-    for(int i=0;i<n2;i++) ang2[i] = F.mvKeys[i].angle;
-    std::vector<unsigned int> node1, feat1, node2, feat2; std::vector<int> off1, off2;
-    orbhip_flatten(pKF->mFeatVec, node1, off1, feat1); orbhip_flatten(F.mFeatVec, node2, off2, feat2);
-    std::vector<int> m12(n1, -1); int nmatches=0;
-    orbhip_check(orbhip_search_by_bow(orbhip_default_device(), 0, pKF->mDescriptors.ptr<unsigned char>(), &ang1[0], &valid1[0], n1, &node1[0], &off1[0], &feat1[0], (int)pKF->mFeatVec.size(),
-                            F.mDescriptors.ptr<unsigned char>(), &ang2[0], NULL, n2, &node2[0], &off2[0], &feat2[0], (int)F.mFeatVec.size(),
-                            mfNNratio, mbCheckOrientation, &m12[0], &nmatches));
-    for(int i=0;i<n1;i++) if(m12[i]>=0) vpMapPointMatches[m12[i]] = vpMapPointsKF[i];
-    return nmatches;
-}"""
-BOW_KF_KF_SIG = r"int\s+ORBmatcher::SearchByBoW\s*\(\s*KeyFrame\s*\*\s*pKF1\s*,\s*KeyFrame\s*\*\s*pKF2\s*,"
-BOW_KF_KF_BODY = """{
-    const vector<MapPoint*> vpMapPoints1 = pKF1->GetMapPointMatches();
-    const vector<MapPoint*> vpMapPoints2 = pKF2->GetMapPointMatches();
-    vpMatches12 = vector<MapPoint*>(vpMapPoints1.size(),static_cast<MapPoint*>(NULL));
-    const int n1 = (int)vpMapPoints1.size(), n2 = (int)vpMapPoints2.size();
-    if(n1==0 || n2==0 || pKF1->mFeatVec.empty() || pKF2->mFeatVec.empty()) return 0;
-    std::vector<unsigned char> valid1(n1), valid2(n2); std::vector<float> ang1(n1), ang2(n2);
-    for(int i=0;i<n1;i++) { MapPoint* p = vpMapPoints1[i]; valid1[i] = p && !p->isBad(); ang1[i] = pKF1->mvKeysUn[i].angle; }
-    for(int i=0;i<n2;i++) { MapPoint* p = vpMapPoints2[i]; valid2[i] = p && !p->isBad(); ang2[i] = pKF2->mvKeysUn[i].angle; }
-    std::vector<unsigned int> node1, feat1, node2, feat2; std::vector<int> off1, off2;
-    orbhip_flatten(pKF1->mFeatVec, node1, off1, feat1); orbhip_flatten(pKF2->mFeatVec, node2, off2, feat2);
-    std::vector<int> m12(n1, -1); int nmatches=0;
-    orbhip_check(orbhip_search_by_bow(orbhip_default_device(), 1, pKF1->mDescriptors.ptr<unsigned char>(), &ang1[0], &valid1[0], n1, &node1[0], &off1[0], &feat1[0], (int)pKF1->mFeatVec.size(),
-                            pKF2->mDescriptors.ptr<unsigned char>(), &ang2[0], &valid2[0], n2, &node2[0], &off2[0], &feat2[0], (int)pKF2->mFeatVec.size(),
-                            mfNNratio, mbCheckOrientation, &m12[0], &nmatches));
-    for(int i=0;i<n1;i++) if(m12[i]>=0) vpMatches12[i] = vpMapPoints2[m12[i]];
-    return nmatches;
-}"""
-
-
-# include/ORBmatcherBatch.h: the loops of the back end as single device passes (free functions next to the members above)
-BATCH_FUNCTIONS = """
-// Tracking::Relocalization (Tracking.cc:1357-1380): `for every candidate: matcher.SearchByBoW(pKF, mCurrentFrame, vvpMapPointMatches[i])` as ONE device pass.
-// vpKFs[i] == NULL or bad: skipped (vnMatches[i] = 0, vvpMapPointMatches[i] all NULL).
-void SearchByBoWBatch(float nnratio, bool checkOri, const std::vector<KeyFrame*> &vpKFs, Frame &F, std::vector<std::vector<MapPoint*> > &vvpMapPointMatches, std::vector<int> &vnMatches)
-{
-    const size_t nKFs = vpKFs.size();
-    vvpMapPointMatches.assign(nKFs, std::vector<MapPoint*>(F.N, static_cast<MapPoint*>(NULL)));
-    vnMatches.assign(nKFs, 0);
-    if(nKFs==0 || F.N==0 || F.mFeatVec.empty()) return;
-    struct Side { std::vector<unsigned char> valid; std::vector<float> ang; std::vector<unsigned int> node, feat; std::vector<int> off; std::vector<MapPoint*> pts; std::vector<int> m12; orbhip_bow_side s; };
-    std::vector<Side> sides(nKFs); Side fr;
-    fr.ang.resize(F.N);
-    for(int i=0;i<F.N;i++) fr.ang[i] = F.mvKeys[i].angle;
-    orbhip_flatten(F.mFeatVec, fr.node, fr.off, fr.feat);
-    orbhip_bow_side s2 = { F.mDescriptors.ptr<unsigned char>(), &fr.ang[0], NULL, F.N, &fr.node[0], &fr.off[0], &fr.feat[0], (int)F.mFeatVec.size() };
-    std::vector<orbhip_bow_pair> pairs; std::vector<size_t> which;
-    for(size_t k=0;k<nKFs;k++)
-    {
-        KeyFrame* pKF = vpKFs[k];
-        if(!pKF || pKF->isBad() || pKF->mFeatVec.empty()) continue;
-        Side &S = sides[k];
-        S.pts = pKF->GetMapPointMatches();
-        const int n1 = (int)S.pts.size();
-        if(n1==0) continue;
-        S.valid.resize(n1); S.ang.resize(n1); S.m12.assign(n1, -1);
-        for(int i=0;i<n1;i++) { MapPoint* p = S.pts[i]; S.valid[i] = p && !p->isBad(); S.ang[i] = pKF->mvKeysUn[i].angle; }
-        orbhip_flatten(pKF->mFeatVec, S.node, S.off, S.feat);
-        const orbhip_bow_side s1 = { pKF->mDescriptors.ptr<unsigned char>(), &S.ang[0], &S.valid[0], n1, &S.node[0], &S.off[0], &S.feat[0], (int)pKF->mFeatVec.size() };
-        S.s = s1;
-        which.push_back(k);
-    }
-    for(size_t j=0;j<which.size();j++) { Side &S = sides[which[j]]; const orbhip_bow_pair p = { &S.s, &s2, &S.m12[0], 0 }; pairs.push_back(p); }
-    if(pairs.empty()) return;
-    orbhip_check(orbhip_search_by_bow_batch(orbhip_default_device(), 0, (int)pairs.size(), &pairs[0], nnratio, checkOri));
-    for(size_t j=0;j<which.size();j++)
-    {
-        const size_t k = which[j]; Side &S = sides[k];
-        for(size_t i=0;i<S.m12.size();i++) if(S.m12[i]>=0) vvpMapPointMatches[k][S.m12[i]] = S.pts[i];
-        vnMatches[k] = pairs[j].nmatches;
-    }
-}
-
-// LocalMapping::CreateNewMapPoints (LocalMapping.cc:237-268): `for every neighbour: matcher.SearchForTriangulation(mpCurrentKeyFrame, pKF2, F12, vMatchedIndices, false)`
-// as ONE device pass.  vvMatches12[i][idx1] = feature of neighbour i, searched with key frame 1's map points as they are NOW; the reference's loop gives key
-// frame 1 new map points between neighbours, and its search (no orientation check, LocalMapping.cc:215; vbMatched2 is never written, ORBmatcher.cc:677, 725)
-// treats every feature of key frame 1 by itself: TriangulationPairs(pKF1, vvMatches12[i], vMatchedPairs), called when neighbour i's turn comes, drops the
-// features that have received a map point in the meantime and returns exactly the reference's vMatchedPairs.
-void SearchForTriangulationBatch(KeyFrame* pKF1, const std::vector<KeyFrame*> &vpKF2, const std::vector<cv::Mat> &vF12, const bool bOnlyStereo, std::vector<std::vector<int> > &vvMatches12)
-{
-    const size_t nn = vpKF2.size();
-    const int n1 = pKF1->N;
-    vvMatches12.assign(nn, std::vector<int>(n1, -1));
-    if(nn==0 || n1==0 || pKF1->mFeatVec.empty()) return;
-    struct Side { std::vector<float> kp; std::vector<unsigned char> has, st; std::vector<unsigned int> node, feat; std::vector<int> off; orbhip_tri_side s; };
-    struct Fill { static void of(KeyFrame* pKF, Side &S) {
-        const int n = pKF->N; S.kp.resize(4*std::max(n,1)); S.has.resize(std::max(n,1)); S.st.resize(std::max(n,1));
-        for(int i=0;i<n;i++) { const cv::KeyPoint &k = pKF->mvKeysUn[i]; S.kp[4*i]=k.pt.x; S.kp[4*i+1]=k.pt.y; S.kp[4*i+2]=k.angle; S.kp[4*i+3]=(float)k.octave;
-                               S.has[i] = pKF->GetMapPoint(i)!=NULL; S.st[i] = pKF->mvuRight[i]>=0; }
-        orbhip_flatten(pKF->mFeatVec, S.node, S.off, S.feat);
-        const orbhip_tri_side s = { pKF->mDescriptors.ptr<unsigned char>(), &S.kp[0], &S.has[0], &S.st[0], n, &S.node[0], &S.off[0], &S.feat[0], (int)pKF->mFeatVec.size(),
-                                    &pKF->mvScaleFactors[0], &pKF->mvLevelSigma2[0], (int)pKF->mvScaleFactors.size() };
-        S.s = s; } };
-    Side s1; Fill::of(pKF1, s1);
-    std::vector<Side> s2(nn); std::vector<orbhip_tri_pair> pairs(nn);
-    cv::Mat Cw = pKF1->GetCameraCenter();
-    for(size_t i=0;i<nn;i++)
-    {
-        KeyFrame* pKF2 = vpKF2[i];
-        Fill::of(pKF2, s2[i]);
-        orbhip_tri_pair &P = pairs[i];
-        P.kf2 = &s2[i].s; P.match12 = &vvMatches12[i][0]; P.nmatches = 0;
-        for(int r=0;r<3;r++) for(int c=0;c<3;c++) P.F12[3*r+c] = vF12[i].at<float>(r,c);
-        // the epipole in the second image (ORBmatcher.cc:663-669)
-        cv::Mat R2w = pKF2->GetRotation();
-        cv::Mat t2w = pKF2->GetTranslation();
-        cv::Mat C2 = R2w*Cw+t2w;
-        const float invz = 1.0f/C2.at<float>(2);
-        P.ex = pKF2->fx*C2.at<float>(0)*invz+pKF2->cx;
-        P.ey = pKF2->fy*C2.at<float>(1)*invz+pKF2->cy;
-    }
-    orbhip_check(orbhip_search_for_triangulation_batch(orbhip_default_device(), &s1.s, (int)nn, &pairs[0], bOnlyStereo, 0));
-}
-int TriangulationPairs(KeyFrame* pKF1, const std::vector<int> &vMatches12, std::vector<std::pair<size_t,size_t> > &vMatchedPairs)
-{
-    vMatchedPairs.clear();
-    for(size_t i=0, iend=vMatches12.size(); i<iend; i++)
-    {
-        if(vMatches12[i]<0 || pKF1->GetMapPoint(i))          // "If there is already a MapPoint skip" (ORBmatcher.cc:698-700), as of now
-            continue;
-        vMatchedPairs.push_back(make_pair(i,vMatches12[i]));
-    }
-    return (int)vMatchedPairs.size();
-}
-"""
-
-# SearchForTriangulation (LocalMapping::CreateNewMapPoints): the reference's epipole computation stays, the node-matched search with its
-# epipole / epipolar-line gates and the rotation pass become one call that fills the reference's own vMatches12; its pair list tail stays.
-TRI_SIG = r"int\s+ORBmatcher::SearchForTriangulation\s*\("
-TRI_SEARCH = """{
-        const int n1 = pKF1->N, n2 = pKF2->N;
-        if(n1>0 && n2>0 && !vFeatVec1.empty() && !vFeatVec2.empty())
-        {
-            std::vector<float> kp1(4*n1), kp2(4*n2); std::vector<unsigned char> has1(n1), st1(n1), has2(n2), st2(n2);
-            for(int i=0;i<n1;i++) { const cv::KeyPoint &k = pKF1->mvKeysUn[i]; kp1[4*i]=k.pt.x; kp1[4*i+1]=k.pt.y; kp1[4*i+2]=k.angle; kp1[4*i+3]=(float)k.octave;
-                                    has1[i] = pKF1->GetMapPoint(i)!=NULL; st1[i] = pKF1->mvuRight[i]>=0; }
-            for(int i=0;i<n2;i++) { const cv::KeyPoint &k = pKF2->mvKeysUn[i]; kp2[4*i]=k.pt.x; kp2[4*i+1]=k.pt.y; kp2[4*i+2]=k.angle; kp2[4*i+3]=(float)k.octave;
-                                    has2[i] = pKF2->GetMapPoint(i)!=NULL; st2[i] = pKF2->mvuRight[i]>=0; }
-            std::vector<unsigned int> node1, feat1, node2, feat2; std::vector<int> off1, off2;
-            orbhip_flatten(vFeatVec1, node1, off1, feat1); orbhip_flatten(vFeatVec2, node2, off2, feat2);
-            float F12flat[9]; for(int r=0;r<3;r++) for(int c=0;c<3;c++) F12flat[3*r+c] = F12.at<float>(r,c);
-            orbhip_check(orbhip_search_for_triangulation(orbhip_default_device(), pKF1->mDescriptors.ptr<unsigned char>(), &kp1[0], &has1[0], &st1[0], n1, &node1[0], &off1[0], &feat1[0], (int)vFeatVec1.size(),
-                                               pKF2->mDescriptors.ptr<unsigned char>(), &kp2[0], &has2[0], &st2[0], n2, &node2[0], &off2[0], &feat2[0], (int)vFeatVec2.size(),
-                                               F12flat, ex, ey, &pKF2->mvScaleFactors[0], &pKF2->mvLevelSigma2[0], (int)pKF2->mvScaleFactors.size(),
-                                               bOnlyStereo, mbCheckOrientation, &vMatches12[0], &nmatches));
-        }
-    }
-
-    """
-
-
-def patch_triangulation(src):
-    m = re.search(TRI_SIG, src)
-    if not m:
-        raise SystemExit("SearchForTriangulation not found")
-    f0, f1 = m.start(), block_end(src, m.end())
-    fn = src[f0:f1]
-    a = fn.index("vector<int> rotHist[HISTO_LENGTH];")
-    b = block_end(fn, fn.rindex("if(mbCheckOrientation)"))
-    fn = fn[:a] + TRI_SEARCH + fn[b:]
-    return src[:f0] + fn + src[f1:]
-
-
-# SearchBySim3 (LoopClosing::ComputeSim3): both directions' window searches are independent per point -> two flat query lists collected by
-# the reference's own projection code, two calls in front of its mutual-consistency pass.
-SIM3_SIG = r"int\s+ORBmatcher::SearchBySim3\s*\("
-SIM3_DECLS = """
-    std::vector<orbhip_best_query> orbhip_bq1, orbhip_bq2; std::vector<unsigned char> orbhip_qd1, orbhip_qd2; std::vector<int> orbhip_i1, orbhip_i2;
-"""
-SIM3_QUERY = """orbhip_best_query e = { u, v, radius, 0.f, nPredictedLevel };
-        const cv::Mat dMP = pMP->GetDescriptor();
-        orbhip_bq%(p)d.push_back(e); orbhip_qd%(p)d.insert(orbhip_qd%(p)d.end(), dMP.ptr<unsigned char>(), dMP.ptr<unsigned char>()+32); orbhip_i%(p)d.push_back(i%(p)d);
-"""
-SIM3_SEARCH = """{
-        KeyFrame* orbhip_kf[2] = {pKF2, pKF1};
-        std::vector<orbhip_best_query>* orbhip_bq[2] = {&orbhip_bq1, &orbhip_bq2}; std::vector<unsigned char>* orbhip_qd[2] = {&orbhip_qd1, &orbhip_qd2};
-        std::vector<int>* orbhip_ix[2] = {&orbhip_i1, &orbhip_i2}; std::vector<int>* orbhip_out[2] = {&vnMatch1, &vnMatch2};
-        for(int p=0;p<2;p++)
-        {
-            KeyFrame* kf = orbhip_kf[p];
-            const int nq = (int)orbhip_bq[p]->size();
-            if(nq==0 || kf->N==0) continue;
-            std::vector<int> bi(nq), bd(nq);
-            const orbhip_bounds bounds = {(float)kf->mnMinX, (float)kf->mnMinY, (float)kf->mnMaxX, (float)kf->mnMaxY};
-            orbhip_check(orbhip_search_best_in_window_bounds(orbhip_default_device(), (const orbhip_keypoint*)&kf->mvKeysUn[0], kf->mDescriptors.ptr<unsigned char>(), NULL, kf->N, &bounds, NULL, 0,
-                                                   &(*orbhip_bq[p])[0], &(*orbhip_qd[p])[0], nq, 0, &bi[0], &bd[0]));
-            for(int k=0;k<nq;k++) if(bd[k]<=TH_HIGH) (*orbhip_out[p])[(*orbhip_ix[p])[k]] = bi[k];
-        }
-    }
-
-    """
-
-
-def patch_sim3(src):
-    m = re.search(SIM3_SIG, src)
-    if not m:
-        raise SystemExit("SearchBySim3 not found")
-    f0, f1 = m.start(), block_end(src, m.end())
-    fn = src[f0:f1]
-    k = fn.index("vector<int> vnMatch2(N2,-1);") + len("vector<int> vnMatch2(N2,-1);")
-    fn = fn[:k] + SIM3_DECLS + fn[k:]
-    for p, kf in ((1, "pKF2"), (2, "pKF1")):
-        a = fn.index("const vector<size_t> vIndices = %s->GetFeaturesInArea(u,v,radius);" % kf)
-        b = block_end(fn, fn.index("if(bestDist<=TH_HIGH)", a))
-        fn = fn[:a] + (SIM3_QUERY % {"p": p}) + fn[b:]
-    a = fn.index("int nFound = 0;")
-    fn = fn[:a] + SIM3_SEARCH + fn[a:]
-    return src[:f0] + fn + src[f1:]
-
-
-# Fuse, Sim3 overload (LoopClosing::SearchAndFuse): like Fuse above without the chi-square gate; its surgery block uses iMP (vpReplacePoint)
-FUSE_SIM3_SIG = r"int\s+ORBmatcher::Fuse\s*\(\s*KeyFrame\s*\*\s*pKF\s*,\s*cv::Mat\s+Scw\s*,"
-FUSE_SIM3_QUERY = """orbhip_best_query e = { u, v, radius, 0.f, nPredictedLevel };
-        const cv::Mat dMP = pMP->GetDescriptor();
-        orbhip_bq.push_back(e); orbhip_qd.insert(orbhip_qd.end(), dMP.ptr<unsigned char>(), dMP.ptr<unsigned char>()+32); orbhip_owner.push_back(pMP); orbhip_index.push_back(iMP);
-"""
-FUSE_SIM3_SEARCH = """std::vector<int> orbhip_bi(orbhip_bq.size(), -1), orbhip_bd(orbhip_bq.size(), 256);
-    if(!orbhip_bq.empty() && pKF->N>0)
-    {
-        const orbhip_bounds bounds = {(float)pKF->mnMinX, (float)pKF->mnMinY, (float)pKF->mnMaxX, (float)pKF->mnMaxY};
-        orbhip_check(orbhip_search_best_in_window_bounds(orbhip_default_device(), (const orbhip_keypoint*)&pKF->mvKeysUn[0], pKF->mDescriptors.ptr<unsigned char>(), NULL, pKF->N, &bounds, NULL, 0,
-                                               &orbhip_bq[0], &orbhip_qd[0], (int)orbhip_bq.size(), 0, &orbhip_bi[0], &orbhip_bd[0]));
-    }
-    for(size_t orbhip_k=0; orbhip_k<orbhip_owner.size(); orbhip_k++)
-    {
-        MapPoint* pMP = orbhip_owner[orbhip_k];
-        const int iMP = orbhip_index[orbhip_k];
-        const int bestDist = orbhip_bd[orbhip_k], bestIdx = orbhip_bi[orbhip_k];
-        %s
-    }
-
-    """
-
-
-def patch_fuse_sim3(src):
-    m = re.search(FUSE_SIM3_SIG, src)
-    if not m:
-        raise SystemExit("Fuse(pKF, Scw, ...) not found")
-    f0, f1 = m.start(), block_end(src, m.end())
-    fn = src[f0:f1]
-    k = fn.index("int nFused=0;") + len("int nFused=0;")
-    fn = fn[:k] + FUSE_DECLS + "    std::vector<int> orbhip_index;\n" + fn[k:]
-    a = fn.index("const vector<size_t> vIndices = pKF->GetFeaturesInArea(u,v,radius);")
-    s0 = fn.index("if(bestDist<=TH_LOW)", a)
-    s1 = block_end(fn, s0)
-    surgery = fn[s0:s1]
-    fn = fn[:a] + FUSE_SIM3_QUERY + fn[s1:]
-    r = fn.rindex("return nFused;")
-    fn = fn[:r] + (FUSE_SIM3_SEARCH % surgery) + fn[r:]
-    return src[:f0] + fn + src[f1:]
-
-
-# INTEGRATION.md §2-3: the two map-free members
-DESC_DIST_SIG = r"int\s+ORBmatcher::DescriptorDistance\s*\(\s*const\s+cv::Mat\s*&\s*a\s*,\s*const\s+cv::Mat\s*&\s*b\s*\)"
-DESC_DIST_BODY = "{ return orbhip_descriptor_distance(a.ptr<unsigned char>(), b.ptr<unsigned char>()); }"
-INIT_SIG = r"int\s+ORBmatcher::SearchForInitialization\s*\(\s*Frame\s*&\s*F1\s*,\s*Frame\s*&\s*F2\s*,\s*vector<cv::Point2f>\s*&\s*vbPrevMatched\s*,\s*vector<int>\s*&\s*vnMatches12\s*,\s*int\s+windowSize\s*\)"
-INIT_BODY = """{
-    const int n1 = (int)F1.mvKeysUn.size(), n2 = (int)F2.mvKeysUn.size();
-    vnMatches12 = vector<int>(n1,-1);
-    if(n1==0) return 0;
-    const orbhip_bounds bounds = {Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY};
-    int nmatches = 0;
-    orbhip_check(orbhip_search_for_initialization_bounds(F1.mpORBextractorLeft ? F1.mpORBextractorLeft->Device() : orbhip_default_device(), reinterpret_cast<const orbhip_keypoint*>(&F1.mvKeysUn[0]), F1.mDescriptors.ptr<unsigned char>(), n1,
-            n2 ? reinterpret_cast<const orbhip_keypoint*>(&F2.mvKeysUn[0]) : NULL, n2 ? F2.mDescriptors.ptr<unsigned char>() : NULL, n2,
-            &bounds, reinterpret_cast<float*>(&vbPrevMatched[0]), &vnMatches12[0], windowSize, mfNNratio, mbCheckOrientation, &nmatches));
-    return nmatches;
-}"""
-
-
-PROLOGUE = """#include "orbhip.h"
-#include "ORBmatcherBatch.h"
-#include <cstdlib>
-#include <cstring>
-#include <set>
-#include <string>
-"""
-# helpers every inserted call goes through (placed inside namespace ORB_SLAM2, after the reference's own includes):
-#   failures are thrown as ORBhipError (include/ORBextractor.h) like the extractor's, never abort();
-#   the device is the searched frame's extractor's, or ORBHIP_DEVICE (the class's own default) where a KeyFrame is searched;
-#   a Frame whose features the extractor still holds in HBM (Tracking's calls on mCurrentFrame) is searched there: only the queries travel.
-HELPERS = """
-static int orbhip_default_device() { static const int d = getenv("ORBHIP_DEVICE") ? atoi(getenv("ORBHIP_DEVICE")) : 0; return d; }
-static void orbhip_check(orbhip_status st) { if(st!=ORBHIP_OK) throw ORBhipError(std::string("ORBmatcher: ") + orbhip_last_error()); }
-static void orbhip_projection_search(Frame &F, bool bUseRight, const std::vector<unsigned char> &blocked, const std::vector<orbhip_proj_query> &q,
-                                     const std::vector<unsigned char> &qd, int mode, float nnratio, int thHigh, bool bCheckOri, std::vector<int> &fq, int &nmatches)
-{
-    ORBextractor* ex = F.mpORBextractorLeft;
-    bool resident = ex && ex->HoldsFrame(F.mnId, F.N), right = bUseRight;
-    if(resident && bUseRight && !ex->HoldsStereoColumns())
-    {
-        // no mvuRight on the device: a monocular frame (all -1: the right-coordinate test never fires) is searched there without it, a frame whose columns
-        // exist on the host only (a ComputeStereoFromRGBD that did not hand them over) is searched through its host copies
-        right = false;
-        for(int i=0; i<F.N; i++)
-            if(F.mvuRight[i]>0) { resident = false; break; }
-    }
-    if(resident)
-        orbhip_check(orbhip_search_by_projection_frame(ex->Context(), 0, F.N, right, &blocked[0], &q[0], &qd[0], (int)q.size(),
-                                                       mode, nnratio, thHigh, bCheckOri, &fq[0], &nmatches));
-    else
-    {
-        const orbhip_bounds bounds = {Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY};
-        orbhip_check(orbhip_search_by_projection_bounds(ex ? ex->Device() : orbhip_default_device(), (const orbhip_keypoint*)&F.mvKeysUn[0], F.mDescriptors.ptr<unsigned char>(),
-                                                        bUseRight ? &F.mvuRight[0] : NULL, &blocked[0], F.N, &bounds, &q[0], &qd[0], (int)q.size(),
-                                                        mode, nnratio, thHigh, bCheckOri, &fq[0], &nmatches));
-    }
-}
-"""
+        raise SystemExit("include guard MAPPOINT_H not found in include/MapPoint.h")
+    return src[:m.end()] + "#define ORBHIP_MAPPOINT_FRIEND 1     // orbhip drop-in: ORBmatcher is a friend of MapPoint (see below)\n" + src[m.end():]
 
 
 # INTEGRATION.md §2-3g (optional, --stereo-one-call): the stereo constructor's two extractor threads (Frame.cc:78-81) become ONE call on the left
@@ -731,46 +145,18 @@ def patch_frame(src, stereo_one_call=False, resident_bow=False, device_rgbd=Fals
     return src
 
 
-def patch_matcher(src, map_free_members=True):
-    src = replace_body(src, LOCAL_MAP_SIG, LOCAL_MAP_BODY)
-    src = patch_last_frame(src)
-    src = patch_fuse(src)
-    src = replace_body(src, BOW_KF_FRAME_SIG, BOW_KF_FRAME_BODY)
-    src = replace_body(src, BOW_KF_KF_SIG, BOW_KF_KF_BODY)
-    src = patch_triangulation(src)
-    src = patch_sim3(src)
-    src = patch_fuse_sim3(src)
-    k = src.index("namespace ORB_SLAM2")
-    k = src.index("{", k) + 1
-    src = src[:k] + HELPERS + BOW_HELPERS + src[k:]
-    src = patch_projection_member(src, KF_SIM3_SIG, "int nmatches=0;", "const vector<size_t> vIndices = pKF->GetFeaturesInArea(u,v,radius);", "if(bestDist<=TH_LOW)",
-                                  KF_SIM3_QUERY, KF_SIM3_SEARCH, None)
-    src = patch_projection_member(src, RELOC_SIG, "int nmatches = 0;", "const vector<size_t> vIndices2 = CurrentFrame.GetFeaturesInArea(u, v, radius, nPredictedLevel-1, nPredictedLevel+1);",
-                                  "if(bestDist<=ORBdist)", RELOC_QUERY, RELOC_SEARCH, "if(mbCheckOrientation)")
-    if map_free_members:
-        src = replace_body(src, DESC_DIST_SIG, DESC_DIST_BODY)
-        src = replace_body(src, INIT_SIG, INIT_BODY)
-    k = src.rindex("}")                                       # the namespace's closing brace: the batch forms go in front of it
-    if "namespace" not in src[k:k + 40] and "ORB_SLAM" not in src[k:k + 40]:
-        raise SystemExit("closing brace of namespace ORB_SLAM2 not found at the end of ORBmatcher.cc")
-    src = src[:k] + BATCH_FUNCTIONS + "\n" + src[k:]
-    return PROLOGUE + src
-
-
 def main():
     argv = sys.argv[1:]
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    if argv and argv[0] == "--files":                       # the form the test builds use: explicit input / output files
-        # --keep-map-free: leave DescriptorDistance / SearchForInitialization to orb_slam2_amd/cpp/ORBmatcher.cc (the steps-1-3 build renames
-        # the reference's two bodies out of the way with -D and links that file)
-        keep = "--keep-map-free" in argv
+    if argv and argv[0] == "--files":                       # the form the test builds use: explicit input / output files, Frame.cc [+ MapPoint.h]
         one_call = "--stereo-one-call" in argv
         rbow = "--resident-bow" in argv
         drgbd = "--device-rgbd" in argv
-        argv = [a for a in argv[1:] if a not in ("--keep-map-free", "--stereo-one-call", "--resident-bow", "--device-rgbd")]
+        argv = [a for a in argv[1:] if a not in ("--stereo-one-call", "--resident-bow", "--device-rgbd")]
         open(argv[1], "w").write(patch_frame(open(argv[0]).read(), stereo_one_call=one_call, resident_bow=rbow, device_rgbd=drgbd))
         if len(argv) > 3:
-            open(argv[3], "w").write(patch_matcher(open(argv[2]).read(), map_free_members=not keep))
+            os.makedirs(os.path.dirname(argv[3]) or ".", exist_ok=True)
+            open(argv[3], "w").write(patch_mappoint_header(open(argv[2]).read()))
         return
     one_call = "--stereo-one-call" in argv
     rbow = "--resident-bow" in argv
@@ -783,9 +169,10 @@ def main():
         raise SystemExit(__doc__)
     ref = argv[0]
     edited = {"src/Frame.cc": patch_frame(open(os.path.join(ref, "src/Frame.cc")).read(), stereo_one_call=one_call, resident_bow=rbow, device_rgbd=drgbd),
-              "src/ORBmatcher.cc": patch_matcher(open(os.path.join(ref, "src/ORBmatcher.cc")).read())}
+              "include/MapPoint.h": patch_mappoint_header(open(os.path.join(ref, "include/MapPoint.h")).read())}
     copies = {"include/ORBextractor.h": "include/ORBextractor.h", "src/ORBextractor.cc": "orb_slam2_amd/cpp/ORBextractor.cc", "include/orbhip.h": "include/orbhip.h",
-              "include/ORBmatcherBatch.h": "include/ORBmatcherBatch.h"}
+              "include/ORBmatcher.h": "include/ORBmatcher.h", "src/ORBmatcher.cc": "orb_slam2_amd/cpp/ORBmatcher.cc", "include/ORBmatcherBatch.h": "include/ORBmatcherBatch.h",
+              "include/orbhip_gemm_probe.h": "include/orbhip_gemm_probe.h"}
     if emit_patch:
         for rel, new in edited.items():
             old = open(os.path.join(ref, rel)).read()

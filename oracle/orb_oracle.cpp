@@ -854,6 +854,94 @@ int SearchByProjectionFlat(const FrameLite& F, const float* mvuRight, std::vecto
     return nmatches;
 }
 
+// ---------------------------------------------------------------- the per-point projection of the pose-guided matchers
+// What the five projection-guided members compute for ONE map point before their window search, restated statement by statement:
+//   kind 0  SearchByProjection(Frame&, const Frame&, th, bMono)               ORBmatcher.cc:1353-1395
+//   kind 1  SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) ORBmatcher.cc:1490-1528
+//   kind 2  SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th)       ORBmatcher.cc:316-362
+//   kind 3  Fuse(KeyFrame*, vpMapPoints, th)                                  ORBmatcher.cc:850-892
+//   kind 4  Fuse(KeyFrame*, Scw, vpPoints, th, vpReplacePoint)                ORBmatcher.cc:1004-1051
+//   kind 5  SearchBySim3, either direction                                    ORBmatcher.cc:1154-1191 / :1234-1271
+// cv::Mat semantics (the part that lives in OpenCV): `A*x + t` with gemm = 0 is include/cvlite's operator* (sum of the three products in
+// double, rounded to float) followed by its float operator+, which is also cv::gemm's generic kernel GEMMSingleMul<float,double> + a separate addition;
+// gemm = 1 is the small-matrix path of OpenCV's cv::gemm (matmul.cpp, `len` 2..4, flags 0) that one `Rcw*p3Dw+tcw` MatExpr takes in a real OpenCV 2.4 / 3.x:
+// float t0 = a0*b0 + a1*b1 + a2*b2; d = (float)(t0*alpha + c*beta) in double.  cv::norm(v) = sqrt of the double sum of squares; Mat::dot = double sum of
+// products.  MapPoint::PredictScale (MapPoint.cc:385-421) is evaluated as written there - ceil(logf(ratio)/mfLogScaleFactor) - NOT through the device's
+// threshold table.  This file is compiled with -ffp-contract=off: every operation rounds once.
+struct ProjCall {                                    // == orbhip_projection (include/orbhip.h), restated so that the oracle needs no product header
+    int kind, gemm; float R[9], t[3], R2[9], t2[3], Ow[3]; float fx, fy, cx, cy, bf; float min_x, min_y, max_x, max_y, th; int forward, backward, nlevels;
+    float scale_factors[16], level_ratio[16];
+};
+struct ProjPoint { float x, y, z, cam_x, cam_y, cam_z, nx, ny, nz, min_dist, max_dist, scale_dist; int level, blocks; float angle; };      // == orbhip_map_point
+static void MatVecAdd(int gemm, const float* A, const float* x, const float* c, float* d)
+{
+    for (int r = 0; r < 3; r++) {
+        if (gemm == 1) { const float t0 = A[3 * r] * x[0] + A[3 * r + 1] * x[1] + A[3 * r + 2] * x[2]; d[r] = (float)((double)t0 * 1.0 + (double)c[r] * 1.0); }
+        else { double s = 0; for (int k = 0; k < 3; k++) s += (double)A[3 * r + k] * x[k]; d[r] = (float)s + c[r]; }
+    }
+}
+static double NormD(const float* v) { double s = 0; for (int k = 0; k < 3; k++) s += (double)v[k] * v[k]; return std::sqrt(s); }
+static double DotD(const float* a, const float* b) { double s = 0; for (int k = 0; k < 3; k++) s += (double)a[k] * b[k]; return s; }
+static int PredictScale(float mfMaxDistance, float currentDist, float mfLogScaleFactor, int mnScaleLevels)
+{
+    const float ratio = mfMaxDistance / currentDist;
+    const float q = ceilf(logf(ratio) / mfLogScaleFactor);          // MapPoint.cc:393: float arguments under `using namespace std` -> the float overloads
+    int nScale = (q != q || q >= 2147483648.0f || q < -2147483648.0f) ? INT_MIN : (int)q;      // cvttss2si's "integer indefinite" for NaN / out of range
+    if (nScale < 0) nScale = 0;
+    else if (nScale >= mnScaleLevels) nScale = mnScaleLevels - 1;
+    return nScale;
+}
+// out[8] = { live, u, v, radius, ur, level, min_level, max_level }
+static void ProjectPoint(const ProjCall& P, const ProjPoint& m, float mfLogScaleFactor, float* out)
+{
+    for (int i = 0; i < 8; i++) out[i] = 0.0f;
+    const float p3Dw[3] = {m.x, m.y, m.z};
+    float pc[3];
+    if (P.gemm == 2) { pc[0] = m.cam_x; pc[1] = m.cam_y; pc[2] = m.cam_z; }
+    else {
+        MatVecAdd(P.gemm, P.R, p3Dw, P.t, pc);                                          // p3Dc = Rcw*p3Dw+tcw
+        if (P.kind == 5) { float p2[3]; MatVecAdd(P.gemm, P.R2, pc, P.t2, p2); pc[0] = p2[0]; pc[1] = p2[1]; pc[2] = p2[2]; }      // p3Dc2 = sR21*p3Dc1+t21
+    }
+    float u, v, invz;
+    if (P.kind == 0 || P.kind == 1) {
+        const float xc = pc[0], yc = pc[1];
+        invz = 1.0 / pc[2];                                                             // const float invzc = 1.0/x3Dc.at<float>(2)
+        if (P.kind == 0 && invz < 0) return;
+        u = P.fx * xc * invz + P.cx;
+        v = P.fy * yc * invz + P.cy;
+        if (u < P.min_x || u > P.max_x) return;
+        if (v < P.min_y || v > P.max_y) return;
+    } else {
+        if (pc[2] < 0.0) return;
+        if (P.kind == 2 || P.kind == 3) invz = 1 / pc[2]; else invz = 1.0 / pc[2];
+        const float x = pc[0] * invz, y = pc[1] * invz;
+        u = P.fx * x + P.cx;
+        v = P.fy * y + P.cy;
+        if (!(u >= P.min_x && u < P.max_x && v >= P.min_y && v < P.max_y)) return;      // pKF->IsInImage(u,v)
+    }
+    int level, lo, hi; float ur = 0.0f;
+    if (P.kind == 0) {
+        level = m.level;                                                                // nLastOctave
+        if (P.forward) { lo = level; hi = -1; } else if (P.backward) { lo = 0; hi = level; } else { lo = level - 1; hi = level + 1; }
+        ur = u - P.bf * invz;
+    } else {
+        float dist;
+        if (P.kind == 5) dist = NormD(pc);
+        else {
+            const float PO[3] = {p3Dw[0] - P.Ow[0], p3Dw[1] - P.Ow[1], p3Dw[2] - P.Ow[2]};
+            dist = NormD(PO);
+            if (dist < m.min_dist || dist > m.max_dist) return;
+            const float Pn[3] = {m.nx, m.ny, m.nz};
+            if (P.kind != 1 && DotD(PO, Pn) < 0.5 * dist) return;
+        }
+        if (P.kind == 5 && (dist < m.min_dist || dist > m.max_dist)) return;
+        level = m.level >= 0 ? m.level : PredictScale(m.scale_dist, dist, mfLogScaleFactor, P.nlevels);
+        lo = level - 1; hi = P.kind == 1 ? level + 1 : level;
+        if (P.kind == 3) ur = u - P.bf * invz;
+    }
+    out[0] = 1.0f; out[1] = u; out[2] = v; out[3] = P.th * P.scale_factors[level]; out[4] = ur; out[5] = (float)level; out[6] = (float)lo; out[7] = (float)hi;
+}
+
 // ---------------------------------------------------------------- Frame::ComputeStereoMatches, Frame.cc:466-640
 // Inputs are the members the reference reads: mvKeys / mDescriptors of the left frame, mvKeysRight / mDescriptorsRight,
 // both extractors' mvImagePyramid, mvScaleFactors / mvInvScaleFactors, mbf, mb.  Outputs mvuRight, mvDepth (N entries).
@@ -1124,6 +1212,23 @@ void orb_oracle_remap(const uint8_t* src, int sw, int sh, int sstride, const flo
     remap_linear_8u(View{src, sw, sh, sstride}, mapx, mapy, map_stride, dst, dw, dh, dstride);
 }
 // q: nq x {x, y, radius, ur, (int)min_level, (int)max_level, (int)blocks, angle} as 8 x 4-byte words each
+// MapPoint::PredictScale for a given distance RATIO (mfMaxDistance/currentDist): the expression of MapPoint.cc:393 / :410 with this machine's libm
+int orb_oracle_predict_scale_of_ratio(float ratio, float log_scale_factor, int nlevels)
+{
+    const float q = ceilf(logf(ratio) / log_scale_factor);
+    int nScale = (q != q || q >= 2147483648.0f || q < -2147483648.0f) ? INT_MIN : (int)q;
+    if (nScale < 0) nScale = 0;
+    else if (nScale >= nlevels) nScale = nlevels - 1;
+    return nScale;
+}
+// out = n x 8 floats: live, u, v, radius, ur, level, min_level, max_level (ProjectPoint above)
+void orb_oracle_project_points(const void* projection, const void* points, int n, float log_scale_factor, float* out)
+{
+    static_assert(sizeof(ProjPoint) == 60, "orbhip_map_point layout");
+    const ProjCall& P = *(const ProjCall*)projection;
+    const ProjPoint* m = (const ProjPoint*)points;
+    for (int i = 0; i < n; i++) ProjectPoint(P, m[i], log_scale_factor, out + (size_t)8 * i);
+}
 int orb_oracle_search_by_projection(const void* kps, const uint8_t* desc, const float* u_right, const uint8_t* blocked, int n, int imw, int imh,
                                     const void* q, const uint8_t* qdesc, int nq, int mode, float nnratio, int th_high, int check_ori, int* feature_query)
 {

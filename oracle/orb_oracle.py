@@ -86,6 +86,8 @@ def lib(fast=False):
     L.orb_oracle_hamming.argtypes = [vp, vp]
     L.orb_oracle_bf_nn.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp]
     L.orb_oracle_search_by_projection.restype = C.c_int
+    L.orb_oracle_project_points.argtypes = [vp, vp, C.c_int, C.c_float, vp]
+    L.orb_oracle_predict_scale_of_ratio.argtypes = [C.c_float, C.c_float, C.c_int]
     L.orb_oracle_search_by_projection.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, vp]
     L.orb_oracle_stereo_matches.restype = C.c_int
     L.orb_oracle_stereo_matches.argtypes = [vp, vp, C.c_float, C.c_float, vp, vp, C.c_int]
@@ -191,6 +193,22 @@ def search_by_projection(kps, desc, imw, imh, queries, qdesc, mode, nnratio=0.8,
     n = lib().orb_oracle_search_by_projection(_p(kps), _p(desc), None if ur is None else _p(ur), None if bl is None else _p(bl), len(kps), imw, imh,
                                               _p(queries), _p(qdesc), len(queries), mode, nnratio, th_high, int(check_ori), _p(fq))
     return n, fq[:len(kps)]
+
+
+def project_points(projection_bytes, points, log_scale_factor):
+    """The per-point projection of the pose-guided ORBmatcher members (orb_oracle.cpp: ProjectPoint) for one call: `projection_bytes` = the bytes of an
+    orbhip_projection, `points` = orbhip_map_point records -> float32 [n, 8]: live, u, v, radius, ur, level, min_level, max_level."""
+    pts = np.ascontiguousarray(points)
+    assert pts.dtype.itemsize == 60
+    buf = np.frombuffer(bytes(projection_bytes), np.uint8).copy()
+    out = np.zeros((len(pts), 8), np.float32)
+    lib().orb_oracle_project_points(_p(buf), _p(pts), len(pts), float(log_scale_factor), _p(out))
+    return out
+
+
+def predict_scale_of_ratio(ratio, log_scale_factor, nlevels):
+    """MapPoint::PredictScale (MapPoint.cc:385-421) for a distance ratio, with this machine's logf"""
+    return lib().orb_oracle_predict_scale_of_ratio(float(ratio), float(log_scale_factor), int(nlevels))
 
 
 def stereo_matches(left, right, mbf, mb):

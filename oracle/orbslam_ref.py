@@ -295,6 +295,26 @@ def _f32(a):
     return np.ascontiguousarray(a, np.float32)
 
 
+def set_test_poses(A=None, B=None, s12=1.0, R12=None, t12=None, library=None):
+    """Poses of the member-level calls below (orbslam_ref_set_test_poses): A = 4x4 pose of the frame / key frame searched, B = of the other one, the similarity handed
+    to SearchBySim3.  None restores identity.  Per library (the all-reference build and a drop-in build are two shared objects): call it on both."""
+    L = library or lib()
+    L.orbslam_ref_set_test_poses.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
+    if A is None:
+        L.orbslam_ref_set_test_poses(None, None, 1.0, None, None)
+        return
+    a = _f32(A).reshape(16); b = a if B is None else _f32(B).reshape(16)
+    r = None if R12 is None else _f32(R12).reshape(9); t = None if t12 is None else _f32(t12).reshape(3)
+    L.orbslam_ref_set_test_poses(_p(a), _p(b), float(s12), None if r is None else _p(r), None if t is None else _p(t))
+
+
+def gemm_mode(library=None):
+    """how the drop-in ORBmatcher.cc of `library` found its cv::Mat algebra to round R*x+t (-1: the build has no drop-in matcher)"""
+    L = library or lib()
+    L.orbslam_ref_gemm_mode.restype = C.c_int
+    return L.orbslam_ref_gemm_mode()
+
+
 def _u8(a, n):
     return np.zeros(n, np.uint8) if a is None else np.ascontiguousarray(a, np.uint8)
 

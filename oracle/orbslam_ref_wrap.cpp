@@ -107,7 +107,6 @@ MapPoint::MapPoint(const cv::Mat& Pos, Map* pMap, Frame* pFrame, const int& idxF
     pFrame->mDescriptors.row(idxF).copyTo(mDescriptor);
     mnId = tl_next_point_id++;
 }
-static thread_local bool g_real_predict_scale = false;             // the front-end loop below: MapPoint.cc:407-421 instead of a level handed in by the test
 cv::Mat MapPoint::GetWorldPos() { return mWorldPos.clone(); }
 cv::Mat MapPoint::GetNormal() { return mNormalVector.clone(); }
 cv::Mat MapPoint::GetDescriptor() { return mDescriptor.clone(); }
@@ -136,12 +135,18 @@ void MapPoint::Replace(MapPoint* pMP)
     }
     mDescriptor.copyTo(pMP->mDescriptor);
 }
-// the level is handed in by the test (the real function is a log of the distance ratio, MapPoint.cc:393-421; not on this path)
-int MapPoint::PredictScale(const float&, KeyFrame*) { return mnTrackScaleLevel; }
+// MapPoint.cc:385-421, restated without the position mutex: both overloads
+int MapPoint::PredictScale(const float& currentDist, KeyFrame* pKF)
+{
+    const float ratio = mfMaxDistance / currentDist;
+    int nScale = ceil(log(ratio) / pKF->mfLogScaleFactor);
+    if (nScale < 0) nScale = 0;
+    else if (nScale >= pKF->mnScaleLevels) nScale = pKF->mnScaleLevels - 1;
+    return nScale;
+}
 int MapPoint::PredictScale(const float& currentDist, Frame* pF)
 {
-    if (!g_real_predict_scale) return mnTrackScaleLevel;
-    const float ratio = mfMaxDistance / currentDist;                                    // MapPoint.cc:407-421
+    const float ratio = mfMaxDistance / currentDist;
     int nScale = ceil(log(ratio) / pF->mfLogScaleFactor);
     if (nScale < 0) nScale = 0;
     else if (nScale >= pF->mnScaleLevels) nScale = pF->mnScaleLevels - 1;
@@ -149,9 +154,18 @@ int MapPoint::PredictScale(const float& currentDist, Frame* pF)
 }
 void MapPoint::IncreaseVisible(int n) { mnVisible += n; }
 void MapPoint::UpdateNormalAndDepth()
-{   // viewing direction = from the origin to the point, scale-invariance range wide open
-    const float n = (float)cv::norm(mWorldPos);
-    mNormalVector = mWorldPos / n; mfMinDistance = 0.0f; mfMaxDistance = 1e30f;
+{   // MapPoint.cc:330-371 for a point with ONE observation, in its reference key frame at level mnTrackScaleLevel (the scaffolding sets it to the observing key
+    // point's octave): viewing direction from that camera, scale-invariance range from the distance and the level.  Without a reference key frame the point
+    // is seen from the origin and the range is wide open (make_query_point then sets mfMaxDistance for PredictScale).
+    cv::Mat Ow = mpRefKF ? mpRefKF->GetCameraCenter() : cv::Mat(cv::Mat::zeros(3, 1, CV_32F));
+    cv::Mat PC = mWorldPos - Ow;
+    const float dist = (float)cv::norm(PC);
+    mNormalVector = PC / dist;
+    if (mpRefKF) {
+        const int level = mnTrackScaleLevel, nLevels = mpRefKF->mnScaleLevels;
+        mfMaxDistance = dist * mpRefKF->mvScaleFactors[level];
+        mfMinDistance = mfMaxDistance / mpRefKF->mvScaleFactors[nLevels - 1];
+    } else { mfMinDistance = 0.0f; mfMaxDistance = 1e30f; }
 }
 static void not_built(const char* what) { fprintf(stderr, "%s is not part of the oracle build\n", what); abort(); }
 void KeyFrame::AddMapPoint(MapPoint* pMP, const size_t& idx) { if (g_real_map_surgery) mvpMapPoints[idx] = pMP; }      // Fuse's bookkeeping; otherwise the search result is read from the map point (AddObservation above)
@@ -256,7 +270,48 @@ MapPoint* make_point(float x, float y, float z, const uint8_t* desc, int nobs, b
 }
 }
 
+// Poses of the member-level scaffolding below.  By default every frame / key frame sits at the origin (identity), under which the members' `Rcw*p+tcw` is exact
+// whatever the rounding of a matrix product; orbslam_ref_set_test_poses installs GENERAL poses so that the per-point algebra is exercised with rotations:
+// A = pose of the frame / key frame searched (and of key frame 1 of SearchBySim3), B = pose of the other one (the last frame; key frame 2), and the
+// similarity s12 | R12 | t12 handed to SearchBySim3 (the Sim3 overloads of SearchByProjection / Fuse get Scw = [s12 * R_A | t_A]).  NULL restores identity.
+static thread_local bool g_poses_set = false;
+static thread_local float g_poseA[16], g_poseB[16], g_s12 = 1.0f, g_R12[9], g_t12[3];
+static cv::Mat test_pose(int which)
+{
+    cv::Mat T = cv::Mat::eye(4, 4, CV_32F);
+    if (g_poses_set) { const float* p = which ? g_poseB : g_poseA; for (int i = 0; i < 16; i++) T.at<float>(i / 4, i % 4) = p[i]; }
+    return T;
+}
+static cv::Mat test_sim3()
+{
+    cv::Mat S = test_pose(0);
+    if (g_poses_set) for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) S.at<float>(r, c) = g_s12 * S.at<float>(r, c);
+    return S;
+}
+#if defined(ORBSLAM_DROPIN_FULL)
+namespace ORB_SLAM2 { int orbhip_gemm_mode(); }     // orb_slam2_amd/cpp/ORBmatcher.cc: how it found the linked cv::Mat to round `R*x+t`
+#endif
+
 extern "C" {
+
+void orbslam_ref_set_test_poses(const float* A16, const float* B16, float s12, const float* R12, const float* t12)
+{
+    g_poses_set = A16 != NULL;
+    if (!g_poses_set) return;
+    memcpy(g_poseA, A16, sizeof g_poseA); memcpy(g_poseB, B16 ? B16 : A16, sizeof g_poseB);
+    g_s12 = s12;
+    static const float I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Z3[3] = {0, 0, 0};
+    memcpy(g_R12, R12 ? R12 : I9, sizeof g_R12); memcpy(g_t12, t12 ? t12 : Z3, sizeof g_t12);
+}
+// -1: this build does not contain the drop-in matcher; else ORBmatcher.cc's probe of the linked cv::Mat algebra (0 generic kernel, 1 small-matrix path, 2 host)
+int orbslam_ref_gemm_mode()
+{
+#if defined(ORBSLAM_DROPIN_FULL)
+    return ORB_SLAM2::orbhip_gemm_mode();
+#else
+    return -1;
+#endif
+}
 
 // Frame::Frame(imGray, timeStamp, extractor, voc, K, distCoef, bf, thDepth)  (Frame.cc:174-225).  new_geometry != 0 resets the
 // static image bounds / grid cell sizes the first Frame of a run computes (Frame.cc:204-221).
@@ -422,8 +477,7 @@ int orbslam_ref_search_by_projection_last(void* cur, void* last, const uint8_t* 
 {
     Frame &C = *(Frame*)cur, &Lf = *(Frame*)last;
     preset(C, cur_state);
-    cv::Mat T = cv::Mat::eye(4, 4, CV_32F);
-    C.SetPose(T); Lf.SetPose(T);
+    C.SetPose(test_pose(0)); Lf.SetPose(test_pose(1));
     std::map<MapPoint*, int> index;
     for (int i = 0; i < Lf.N; i++) {
         Lf.mvpMapPoints[i] = NULL; Lf.mvbOutlier[i] = outlier && outlier[i];
@@ -514,17 +568,23 @@ int orbslam_ref_search_for_triangulation(void* f1, const uint8_t* has1, const ui
     return n;
 }
 
-static MapPoint* make_query_point(float x, float y, float z, const uint8_t* desc, int level, int nobs, bool bad)
+// A map point whose REAL MapPoint::PredictScale lands on (about) the level the test asks for: mfMaxDistance = |pos| * scaleFactor^(level - 0.4), i.e. 0.4 of a level
+// below the boundary - and wherever it lands after the member's own rounding of the distance: the all-reference and
+// the drop-in build read the same mfMaxDistance.  Viewing direction = from the origin to the point, scale-invariance range wide open (UpdateNormalAndDepth above).
+struct QueryPointAccess : MapPoint { static void range(MapPoint* p, float mx) { static_cast<QueryPointAccess*>(p)->mfMaxDistance = mx; } };
+static MapPoint* make_query_point(float x, float y, float z, const uint8_t* desc, int level, int nobs, bool bad, float scaleFactor)
 {
     MapPoint* p = make_point(x, y, z, desc, nobs, bad);
     p->mnTrackScaleLevel = level;
     p->UpdateNormalAndDepth();
+    const float dist = std::sqrt(x * x + y * y + z * z);
+    QueryPointAccess::range(p, dist * std::pow(scaleFactor, (float)level - 0.4f));
     return p;
 }
-static KeyFrame* identity_keyframe(Frame& F)
+static KeyFrame* identity_keyframe(Frame& F, int which = 0)
 {
     KeyFrame* kf = new KeyFrame(F, NULL, NULL);
-    cv::Mat T = cv::Mat::eye(4, 4, CV_32F);
+    cv::Mat T = test_pose(which);
     kf->SetPose(T);
     return kf;
 }
@@ -542,7 +602,7 @@ int orbslam_ref_fuse(void* fp, const uint8_t* kf_state, int nq, const float* X, 
     }
     KeyFrame* kf = identity_keyframe(F);
     std::vector<MapPoint*> pts(nq);
-    for (int q = 0; q < nq; q++) pts[q] = make_query_point(X[q], Y[q], Z[q], desc + (size_t)q * 32, level[q], nobs[q], bad[q] != 0);
+    for (int q = 0; q < nq; q++) pts[q] = make_query_point(X[q], Y[q], Z[q], desc + (size_t)q * 32, level[q], nobs[q], bad[q] != 0, F.mfScaleFactor);
     ORB_SLAM2::g_replaced.clear();
     ORBmatcher matcher(0.6f, true);
     int n; { CallTimer ct; n = matcher.Fuse(kf, pts, th); }
@@ -569,9 +629,9 @@ int orbslam_ref_fuse_sim3(void* fp, const uint8_t* kf_state, int nq, const float
     }
     KeyFrame* kf = identity_keyframe(F);
     std::vector<MapPoint*> pts(nq), repl(nq, static_cast<MapPoint*>(NULL));
-    for (int q = 0; q < nq; q++) pts[q] = make_query_point(X[q], Y[q], Z[q], desc + (size_t)q * 32, level[q], 1, bad[q] != 0);
+    for (int q = 0; q < nq; q++) pts[q] = make_query_point(X[q], Y[q], Z[q], desc + (size_t)q * 32, level[q], 1, bad[q] != 0, F.mfScaleFactor);
     ORBmatcher matcher(0.8f, true);
-    int n; { CallTimer ct; n = matcher.Fuse(kf, cv::Mat::eye(4, 4, CV_32F), pts, th, repl); }
+    int n; { CallTimer ct; n = matcher.Fuse(kf, test_sim3(), pts, th, repl); }
     for (int q = 0; q < nq; q++) best_idx[q] = repl[q] ? kfIndex[repl[q]] : (pts[q]->mnBALocalForKF ? (int)pts[q]->mnBALocalForKF - 1 : -1);
     delete kf;
     return n;
@@ -587,9 +647,9 @@ int orbslam_ref_search_by_projection_kf(void* fp, const uint8_t* matched_state, 
     std::vector<MapPoint*> matched(F.N, static_cast<MapPoint*>(NULL)), pts(nq);
     for (int i = 0; i < F.N; i++) if (matched_state && matched_state[i]) matched[i] = make_point(0, 0, 1, NULL, 1, false);
     std::map<MapPoint*, int> qIndex;
-    for (int q = 0; q < nq; q++) { pts[q] = make_query_point(X[q], Y[q], Z[q], desc + (size_t)q * 32, level[q], 1, bad[q] != 0); qIndex[pts[q]] = q; }
+    for (int q = 0; q < nq; q++) { pts[q] = make_query_point(X[q], Y[q], Z[q], desc + (size_t)q * 32, level[q], 1, bad[q] != 0, F.mfScaleFactor); qIndex[pts[q]] = q; }
     ORBmatcher matcher(0.75f, true);
-    cv::Mat S = cv::Mat::eye(4, 4, CV_32F);
+    cv::Mat S = test_sim3();
     int n; { CallTimer ct; n = matcher.SearchByProjection(kf, S, pts, matched, th); }
     for (int i = 0; i < F.N; i++) { std::map<MapPoint*, int>::iterator it = qIndex.find(matched[i]); feature_query[i] = it == qIndex.end() ? -1 : it->second; }
     delete kf;
@@ -603,14 +663,13 @@ int orbslam_ref_search_by_projection_reloc(void* cur, void* kfp, const uint8_t* 
 {
     Frame &C = *(Frame*)cur, &Fk = *(Frame*)kfp;
     preset(C, cur_state);
-    cv::Mat T = cv::Mat::eye(4, 4, CV_32F);
-    C.SetPose(T);
+    C.SetPose(test_pose(0));
     std::map<MapPoint*, int> index;
     std::set<MapPoint*> already;
     for (int i = 0; i < Fk.N; i++) {
         Fk.mvpMapPoints[i] = NULL;
         if (!has_point[i]) continue;
-        MapPoint* p = make_query_point(X[i], Y[i], Z[i], desc + (size_t)i * 32, level[i], 1, bad && bad[i]);
+        MapPoint* p = make_query_point(X[i], Y[i], Z[i], desc + (size_t)i * 32, level[i], 1, bad && bad[i], C.mfScaleFactor);
         Fk.mvpMapPoints[i] = p; index[p] = i;
         if (found && found[i]) already.insert(p);
     }
@@ -630,9 +689,9 @@ int orbslam_ref_search_by_sim3(void* f1, const uint8_t* has1, const float* X1, c
 {
     Frame &F1 = *(Frame*)f1, &F2 = *(Frame*)f2;
     std::map<MapPoint*, int> idx2;
-    for (int i = 0; i < F1.N; i++) F1.mvpMapPoints[i] = has1[i] ? make_query_point(X1[i], Y1[i], Z1[i], desc1 + (size_t)i * 32, level1[i], 1, false) : NULL;
-    for (int i = 0; i < F2.N; i++) { F2.mvpMapPoints[i] = has2[i] ? make_query_point(X2[i], Y2[i], Z2[i], desc2 + (size_t)i * 32, level2[i], 1, false) : NULL; if (has2[i]) idx2[F2.mvpMapPoints[i]] = i; }
-    KeyFrame *kf1 = identity_keyframe(F1), *kf2 = identity_keyframe(F2);
+    for (int i = 0; i < F1.N; i++) F1.mvpMapPoints[i] = has1[i] ? make_query_point(X1[i], Y1[i], Z1[i], desc1 + (size_t)i * 32, level1[i], 1, false, F2.mfScaleFactor) : NULL;
+    for (int i = 0; i < F2.N; i++) { F2.mvpMapPoints[i] = has2[i] ? make_query_point(X2[i], Y2[i], Z2[i], desc2 + (size_t)i * 32, level2[i], 1, false, F1.mfScaleFactor) : NULL; if (has2[i]) idx2[F2.mvpMapPoints[i]] = i; }
+    KeyFrame *kf1 = identity_keyframe(F1, 0), *kf2 = identity_keyframe(F2, 1);
     std::vector<MapPoint*> m12(F1.N, static_cast<MapPoint*>(NULL));
     for (int i = 0; i < F1.N; i++) if (already12 && already12[i] >= 0 && F2.mvpMapPoints[already12[i]]) {
         m12[i] = F2.mvpMapPoints[already12[i]];
@@ -640,7 +699,9 @@ int orbslam_ref_search_by_sim3(void* f1, const uint8_t* has1, const float* X1, c
     }
     ORBmatcher matcher(0.75f, true);
     cv::Mat R = cv::Mat::eye(3, 3, CV_32F), t = cv::Mat(cv::Mat::zeros(3, 1, CV_32F));
-    int n; { CallTimer ct; n = matcher.SearchBySim3(kf1, kf2, m12, 1.0f, R, t, th); }
+    float s12 = 1.0f;
+    if (g_poses_set) { s12 = g_s12; for (int i = 0; i < 9; i++) R.at<float>(i / 3, i % 3) = g_R12[i]; for (int i = 0; i < 3; i++) t.at<float>(i) = g_t12[i]; }
+    int n; { CallTimer ct; n = matcher.SearchBySim3(kf1, kf2, m12, s12, R, t, th); }
     for (int i = 0; i < F1.N; i++) { std::map<MapPoint*, int>::iterator it = idx2.find(m12[i]); match12[i] = it == idx2.end() ? -1 : it->second; }
     delete kf1; delete kf2;
     return n;
@@ -717,7 +778,6 @@ static int tracking_loop_impl(int nframes, const uint8_t* const* left, const uin
     // (not while other threads read Frame's static grid geometry: orbslam_ref_concurrency computes it once, before its threads start)
     if (fresh_statics) { Frame::mbInitialComputations = true; Frame::nNextId = 0; }
     MapPoint::nNextId = 0; ORB_SLAM2::tl_next_point_id = 0;
-    ORB_SLAM2::g_real_predict_scale = true;
     cv::Mat K = camera(fx, fy, cx, cy), D = cv::Mat(cv::Mat::zeros(4, 1, CV_32F));
     Rig& rg = rig(nfeat, scale, nlevels, ini, mn);
     attach_camera(rg.left, K, D); attach_camera(rg.right, K, D);
@@ -787,7 +847,6 @@ static int tracking_loop_impl(int nframes, const uint8_t* const* left, const uin
         last = copy;
     }
     delete last;
-    ORB_SLAM2::g_real_predict_scale = false;
     return nframes;
 }
 int orbslam_ref_tracking_loop(int nframes, const uint8_t* const* left, const uint8_t* const* right, int w, int h, int stride,
@@ -870,7 +929,6 @@ int orbslam_ref_sequence_loop(int sensor, int nframes, const uint8_t* const* img
 {
     arena_restart();
     Frame::mbInitialComputations = true; Frame::nNextId = 0; MapPoint::nNextId = 0; ORB_SLAM2::tl_next_point_id = 0;
-    ORB_SLAM2::g_real_predict_scale = true;
     ORBVocabulary* voc = voc_path ? shared_voc(voc_path) : NULL;
     if (sensor == 0 && !voc) return -1;
     cv::Mat K = camera(fx, fy, cx, cy), D(std::max(ndist, 4), 1, CV_32F);
@@ -1043,7 +1101,6 @@ int orbslam_ref_sequence_loop(int sensor, int nframes, const uint8_t* const* img
     }
     delete last; delete init;
     for (size_t c = 0; c < kfs.size(); c++) { delete kfs[c].kf; delete kfs[c].F; }
-    ORB_SLAM2::g_real_predict_scale = false;
     return nframes;
 }
 uint64_t orbslam_ref_loop_bow_hash(int k) { return k >= 0 && k < (int)g_loop.size() ? g_loop[k].bowHash : 0; }
@@ -1063,7 +1120,7 @@ int orbslam_ref_local_mapping_loops(int nn, void* const* frames, const float* F1
     ORBVocabulary* voc = shared_voc(voc_path);
     if (!voc || nn < 1) return -1;
     ORB_SLAM2::tl_next_point_id = 0;
-    ORB_SLAM2::g_real_map_surgery = true; ORB_SLAM2::g_real_predict_scale = false;
+    ORB_SLAM2::g_real_map_surgery = true;
     std::vector<KeyFrame*> kf(nn + 1);
     for (int i = 0; i <= nn; i++) {
         Frame& F = *(Frame*)frames[i];

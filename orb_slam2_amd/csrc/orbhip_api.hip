@@ -1408,16 +1408,27 @@ extern "C" orbhip_status orbhip_debug_candidates(orbhip_ctx* c, int frame, int l
 }
 
 // ---------------------------------------------------------------------------------------------- projection-guided search
-extern "C" orbhip_status orbhip_search_by_projection_bounds(int device, const orbhip_keypoint* kps, const uint8_t* desc, const float* u_right,
-                                                     const uint8_t* blocked, int n, const orbhip_bounds* bounds,
-                                                     const orbhip_proj_query* queries, const uint8_t* query_desc, int nq,
-                                                     int mode, float nnratio, int th_high, int check_ori, int32_t* feature_query, int* nmatches)
+static bool projection_ok(const orbhip_projection* P)
+{
+    return P && P->kind >= ORBHIP_PROJ_LAST_FRAME && P->kind <= ORBHIP_PROJ_SIM3 && P->gemm_mode >= 0 && P->gemm_mode <= 2 && P->nlevels >= 1 && P->nlevels <= ORBHIP_MAX_PROJ_LEVELS;
+}
+static void gated_out(orbhip_proj_query* q, int np) { if (q) for (int i = 0; i < np; i++) { memset(&q[i], 0, sizeof q[i]); q[i].radius = -1.0f; } }
+static void gated_out(orbhip_best_query* q, int np) { if (q) for (int i = 0; i < np; i++) { memset(&q[i], 0, sizeof q[i]); q[i].radius = -1.0f; } }
+
+// queries given (P == nullptr) or derived on the device from map points under *P (orbhip_project_search_bounds): `queries` is then nullptr and nq = the point count
+static orbhip_status search_by_projection_impl(int device, const orbhip_keypoint* kps, const uint8_t* desc, const float* u_right,
+                                               const uint8_t* blocked, int n, const orbhip_bounds* bounds,
+                                               const orbhip_proj_query* queries, const uint8_t* query_desc, int nq,
+                                               const orbhip_projection* P, const orbhip_map_point* points, orbhip_proj_query* queries_out,
+                                               int mode, float nnratio, int th_high, int check_ori, int32_t* feature_query, int* nmatches)
 {
     OrbApiTimer api_timer;
-    if (n < 0 || nq < 0 || !nmatches || (n > 0 && (!kps || !desc || !feature_query)) || (nq > 0 && (!queries || !query_desc)) || !bounds || !(bounds->max_x > bounds->min_x) || !(bounds->max_y > bounds->min_y) || (mode != 0 && mode != 1))
+    if (n < 0 || nq < 0 || !nmatches || (n > 0 && (!kps || !desc || !feature_query)) || (nq > 0 && ((!queries && !points) || !query_desc)) || !bounds || !(bounds->max_x > bounds->min_x) || !(bounds->max_y > bounds->min_y) || (mode != 0 && mode != 1) ||
+        (points && !projection_ok(P)))
         return fail(ORBHIP_ERR_INVALID, "bad argument");
     *nmatches = 0;
     for (int i = 0; i < n; i++) feature_query[i] = -1;
+    if (points) gated_out(queries_out, nq);
     if (n == 0 || nq == 0) return ORBHIP_OK;
     if (n >= (1 << 19)) return fail(ORBHIP_ERR_UNSUPPORTED, "too many features");
     if (orbhip_proj_select_lds(n) > 150 * 1024) return fail(ORBHIP_ERR_UNSUPPORTED, "too many features for the LDS matcher (%d)", n);
@@ -1426,11 +1437,14 @@ extern "C" orbhip_status orbhip_search_by_projection_bounds(int device, const or
     hipStream_t ts = orbhip_thread_stream(device);
     orbhip_keypoint* dk = nullptr; uint8_t *dd = nullptr, *dqd = nullptr; unsigned char *dbl_in = nullptr; float* dur = nullptr; int *dn = nullptr, *dgs = nullptr, *dgi = nullptr, *dnc = nullptr, *dfq = nullptr, *dev = nullptr;
     float2* dgxy = nullptr; orbhip_proj_query* dq = nullptr; unsigned* dcand = nullptr; unsigned* dtop = nullptr;
+    orbhip_map_point* dpts = nullptr; orbhip_projection* dP = nullptr;
     hipError_t e = hipSuccess;
 #define TRY(x) do { if (e == hipSuccess) e = (x); } while (0)
     const int hn[2] = {n, 0}; int hres[2] = {0, 0};
     TRY(arena_layout(device, [&](Arena& A) {
-        A.io(&dk, n, kps, n); A.io(&dd, (size_t)n * 32, desc, (size_t)n * 32); A.io(&dqd, (size_t)nq * 32, query_desc, (size_t)nq * 32); A.io(&dq, nq, queries, nq);
+        A.io(&dk, n, kps, n); A.io(&dd, (size_t)n * 32, desc, (size_t)n * 32); A.io(&dqd, (size_t)nq * 32, query_desc, (size_t)nq * 32);
+        if (points) { A.io(&dpts, nq, points, nq); A.io(&dP, 1, P, 1); A.io(&dq, nq, (const orbhip_proj_query*)nullptr, 0, queries_out, queries_out ? nq : 0); }
+        else A.io(&dq, nq, queries, nq);
         if (u_right) A.io(&dur, n, u_right, n);
         if (blocked) A.io(&dbl_in, n, blocked, n);
         A.io(&dn, 8, hn, 2, hres, 2);                         // [0] = n in, [1] = the return value out
@@ -1446,6 +1460,7 @@ extern "C" orbhip_status orbhip_search_by_projection_bounds(int device, const or
         ProjParams J; memset(&J, 0, sizeof J);
         J.kp = dk; J.desc = dd; J.u_right = dur; J.n = n; J.min_x = bounds->min_x; J.min_y = bounds->min_y; J.max_x = bounds->max_x; J.max_y = bounds->max_y; J.grid_start = dgs; J.grid_items = dgi; J.grid_xy = dgxy;
         J.q = dq; J.qdesc = dqd; J.nq = nq; J.cand = dcand; J.ncand = dnc; J.cand_stride = n; J.top = dtop;
+        J.pts = dpts; J.proj = dP; J.q_out = dq;
         J.blocked_in = dbl_in; J.blocked_out = nullptr; J.feature_query = dfq; J.nmatches = dn + 1; J.events = dev;
         J.mode = mode; J.nnratio = nnratio; J.th_high = th_high; J.check_ori = check_ori;
         orbhip_launch_proj(J, ts);
@@ -1458,6 +1473,21 @@ extern "C" orbhip_status orbhip_search_by_projection_bounds(int device, const or
     orbhip_status st = ORBHIP_OK;
     if (e != hipSuccess) st = fail(ORBHIP_ERR_HIP, "search_by_projection: %s", hipGetErrorString(e));
     return st;
+}
+extern "C" orbhip_status orbhip_search_by_projection_bounds(int device, const orbhip_keypoint* kps, const uint8_t* desc, const float* u_right,
+                                                     const uint8_t* blocked, int n, const orbhip_bounds* bounds,
+                                                     const orbhip_proj_query* queries, const uint8_t* query_desc, int nq,
+                                                     int mode, float nnratio, int th_high, int check_ori, int32_t* feature_query, int* nmatches)
+{
+    if (nq > 0 && !queries) return fail(ORBHIP_ERR_INVALID, "bad argument");
+    return search_by_projection_impl(device, kps, desc, u_right, blocked, n, bounds, queries, query_desc, nq, nullptr, nullptr, nullptr, mode, nnratio, th_high, check_ori, feature_query, nmatches);
+}
+extern "C" orbhip_status orbhip_project_search_bounds(int device, const orbhip_keypoint* kps, const uint8_t* desc, const float* u_right, const uint8_t* blocked, int n, const orbhip_bounds* bounds,
+                                                      const orbhip_projection* proj, const orbhip_map_point* points, const uint8_t* point_desc, int np,
+                                                      float nnratio, int th_high, int check_ori, int32_t* feature_query, int* nmatches, orbhip_proj_query* queries_out)
+{
+    if (np > 0 && (!points || !proj)) return fail(ORBHIP_ERR_INVALID, "bad argument");
+    return search_by_projection_impl(device, kps, desc, u_right, blocked, n, bounds, nullptr, point_desc, np, np > 0 ? proj : nullptr, np > 0 ? points : nullptr, queries_out, 1, nnratio, th_high, check_ori, feature_query, nmatches);
 }
 
 // Several frames in one pass: every per-slot array lives at [slot][cap] of one arena (one copy each way), the order-dependent kernel runs
@@ -1540,25 +1570,29 @@ extern "C" orbhip_status orbhip_search_by_projection_batch(int device, int nslot
     return ORBHIP_OK;
 }
 
-extern "C" orbhip_status orbhip_search_best_in_window_bounds(int device, const orbhip_keypoint* kps, const uint8_t* desc, const float* u_right, int n, const orbhip_bounds* bounds,
-                                                      const float* inv_level_sigma2, int nlevels, const orbhip_best_query* queries, const uint8_t* query_desc, int nq,
-                                                      int chi2_gate, int32_t* best_idx, int32_t* best_dist)
+static orbhip_status search_best_in_window_impl(int device, const orbhip_keypoint* kps, const uint8_t* desc, const float* u_right, int n, const orbhip_bounds* bounds,
+                                                const float* inv_level_sigma2, int nlevels, const orbhip_best_query* queries, const uint8_t* query_desc, int nq,
+                                                const orbhip_projection* P, const orbhip_map_point* points, orbhip_best_query* queries_out,
+                                                int chi2_gate, int32_t* best_idx, int32_t* best_dist)
 {
     OrbApiTimer api_timer;
-    if (n < 0 || nq < 0 || (nq > 0 && (!queries || !query_desc || !best_idx || !best_dist)) || (n > 0 && (!kps || !desc)) || !bounds || !(bounds->max_x > bounds->min_x) || !(bounds->max_y > bounds->min_y) ||
-        (chi2_gate && (!inv_level_sigma2 || nlevels < 1))) return fail(ORBHIP_ERR_INVALID, "bad argument");
+    if (n < 0 || nq < 0 || (nq > 0 && ((!queries && !points) || !query_desc || !best_idx || !best_dist)) || (n > 0 && (!kps || !desc)) || !bounds || !(bounds->max_x > bounds->min_x) || !(bounds->max_y > bounds->min_y) ||
+        (chi2_gate && (!inv_level_sigma2 || nlevels < 1)) || (points && !projection_ok(P))) return fail(ORBHIP_ERR_INVALID, "bad argument");
     for (int i = 0; i < nq; i++) { best_idx[i] = -1; best_dist[i] = 256; }
+    if (points) gated_out(queries_out, nq);
     if (n == 0 || nq == 0) return ORBHIP_OK;
     int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(ORBHIP_ERR_HIP, "no HIP device available: no CPU fallback");
     HIPCHK(hipSetDevice(device));
     hipStream_t ts = orbhip_thread_stream(device);
     orbhip_keypoint* dk = nullptr; uint8_t *dd = nullptr, *dqd = nullptr; float *dur = nullptr, *dsg = nullptr; int *dn = nullptr, *dgs = nullptr, *dgi = nullptr, *dbi = nullptr, *dbd = nullptr;
-    float2* dgxy = nullptr; orbhip_best_query* dq = nullptr;
+    float2* dgxy = nullptr; orbhip_best_query* dq = nullptr; orbhip_map_point* dpts = nullptr; orbhip_projection* dP = nullptr;
     hipError_t e = hipSuccess;
 #define TRY(x) do { if (e == hipSuccess) e = (x); } while (0)
     const int hn[2] = {n, 0};
     TRY(arena_layout(device, [&](Arena& A) {
-        A.io(&dk, n, kps, n); A.io(&dd, (size_t)n * 32, desc, (size_t)n * 32); A.io(&dqd, (size_t)nq * 32, query_desc, (size_t)nq * 32); A.io(&dq, nq, queries, nq); A.io(&dn, 8, hn, 2);
+        A.io(&dk, n, kps, n); A.io(&dd, (size_t)n * 32, desc, (size_t)n * 32); A.io(&dqd, (size_t)nq * 32, query_desc, (size_t)nq * 32); A.io(&dn, 8, hn, 2);
+        if (points) { A.io(&dpts, nq, points, nq); A.io(&dP, 1, P, 1); if (queries_out) A.io(&dq, nq, (const orbhip_best_query*)nullptr, 0, queries_out, nq); }
+        else A.io(&dq, nq, queries, nq);
         if (u_right) A.io(&dur, n, u_right, n);
         if (inv_level_sigma2 && nlevels > 0) A.io(&dsg, nlevels, inv_level_sigma2, nlevels);
         A.io(&dbi, nq, (const int*)nullptr, 0, best_idx, nq); A.io(&dbd, nq, (const int*)nullptr, 0, best_dist, nq);
@@ -1572,6 +1606,7 @@ extern "C" orbhip_status orbhip_search_best_in_window_bounds(int device, const o
         BestParams B; memset(&B, 0, sizeof B);
         B.kp = dk; B.desc = dd; B.u_right = dur; B.inv_level_sigma2 = dsg; B.grid_start = dgs; B.grid_items = dgi; B.grid_xy = dgxy;
         B.q = dq; B.qdesc = dqd; B.nq = nq; B.chi2_gate = chi2_gate; B.best_idx = dbi; B.best_dist = dbd;
+        B.pts = dpts; B.proj = dP; B.q_out = points ? dq : nullptr;
         B.min_x = bounds->min_x; B.gw_inv = (float)ORBHIP_GRID_COLS / (float)(bounds->max_x - bounds->min_x);      // as orbhip_launch_match_grid lays the grid out
         orbhip_launch_best_in_window(B, ts);
         e = hipGetLastError();
@@ -1583,19 +1618,40 @@ extern "C" orbhip_status orbhip_search_best_in_window_bounds(int device, const o
     if (e != hipSuccess) st = fail(ORBHIP_ERR_HIP, "search_best_in_window: %s", hipGetErrorString(e));
     return st;
 }
+extern "C" orbhip_status orbhip_search_best_in_window_bounds(int device, const orbhip_keypoint* kps, const uint8_t* desc, const float* u_right, int n, const orbhip_bounds* bounds,
+                                                      const float* inv_level_sigma2, int nlevels, const orbhip_best_query* queries, const uint8_t* query_desc, int nq,
+                                                      int chi2_gate, int32_t* best_idx, int32_t* best_dist)
+{
+    if (nq > 0 && !queries) return fail(ORBHIP_ERR_INVALID, "bad argument");
+    return search_best_in_window_impl(device, kps, desc, u_right, n, bounds, inv_level_sigma2, nlevels, queries, query_desc, nq, nullptr, nullptr, nullptr, chi2_gate, best_idx, best_dist);
+}
+extern "C" orbhip_status orbhip_project_best_in_window_bounds(int device, const orbhip_keypoint* kps, const uint8_t* desc, const float* u_right, int n, const orbhip_bounds* bounds,
+                                                              const float* inv_level_sigma2, int nlevels, const orbhip_projection* proj, const orbhip_map_point* points, const uint8_t* point_desc, int np,
+                                                              int chi2_gate, int32_t* best_idx, int32_t* best_dist, orbhip_best_query* queries_out)
+{
+    if (np > 0 && (!points || !proj)) return fail(ORBHIP_ERR_INVALID, "bad argument");
+    return search_best_in_window_impl(device, kps, desc, u_right, n, bounds, inv_level_sigma2, nlevels, nullptr, point_desc, np, np > 0 ? proj : nullptr, np > 0 ? points : nullptr, queries_out, chi2_gate, best_idx, best_dist);
+}
 
 // Several key frames in one pass (Fuse over all targets): [slot][cap] key point / descriptor / grid blocks in one arena; the feature grids of all slots are
 // built by ONE k_match_grid launch when the slots share their image bounds (key frames of one camera do), the searches by one launch over all queries.
-extern "C" orbhip_status orbhip_search_best_in_window_batch(int device, int nslots, orbhip_best_slot* slots, int chi2_gate)
+// Queries given per slot, or derived on the device from the slot's map points under its projection (orbhip_project_best_in_window_batch).
+struct BestSlotIn {
+    const orbhip_keypoint* kps; const uint8_t* desc; const float* u_right; int n; orbhip_bounds bounds; const float* inv_level_sigma2; int nlevels;
+    const orbhip_best_query* queries; const uint8_t* query_desc; int nq; const orbhip_projection* proj; const orbhip_map_point* points;
+    int32_t* best_idx; int32_t* best_dist;
+};
+static orbhip_status search_best_in_window_batch_impl(int device, int nslots, BestSlotIn* slots, int chi2_gate)
 {
     OrbApiTimer api_timer;
     if (nslots < 0 || (nslots > 0 && !slots)) return fail(ORBHIP_ERR_INVALID, "bad argument");
     std::vector<int> live;
     int cap = 1;
     for (int s = 0; s < nslots; s++) {
-        orbhip_best_slot& S = slots[s];
-        if (S.n < 0 || S.nq < 0 || (S.nq > 0 && (!S.queries || !S.query_desc || !S.best_idx || !S.best_dist)) || (S.n > 0 && (!S.kps || !S.desc)) ||
-            !(S.bounds.max_x > S.bounds.min_x) || !(S.bounds.max_y > S.bounds.min_y) || (chi2_gate && (!S.inv_level_sigma2 || S.nlevels < 1))) return fail(ORBHIP_ERR_INVALID, "bad argument in slot %d", s);
+        BestSlotIn& S = slots[s];
+        if (S.n < 0 || S.nq < 0 || (S.nq > 0 && ((!S.queries && !S.points) || !S.query_desc || !S.best_idx || !S.best_dist)) || (S.n > 0 && (!S.kps || !S.desc)) ||
+            !(S.bounds.max_x > S.bounds.min_x) || !(S.bounds.max_y > S.bounds.min_y) || (chi2_gate && (!S.inv_level_sigma2 || S.nlevels < 1)) || (S.nq > 0 && S.points && !projection_ok(S.proj)))
+            return fail(ORBHIP_ERR_INVALID, "bad argument in slot %d", s);
         for (int i = 0; i < S.nq; i++) { S.best_idx[i] = -1; S.best_dist[i] = 256; }
         if (S.n == 0 || S.nq == 0) continue;
         live.push_back(s); cap = std::max(cap, S.n);
@@ -1622,15 +1678,23 @@ extern "C" orbhip_status orbhip_search_best_in_window_batch(int device, int nslo
             if (k == 0) dk0 = dk;
             hB[k].kp = dk;
         }
-        for (int k = 0; k < NL; k++) {
-            const orbhip_best_slot& S = slots[live[k]]; BestParams& B = hB[k];
-            uint8_t *dd = nullptr, *dqd = nullptr; float *dur = nullptr, *dsg = nullptr; orbhip_best_query* dq = nullptr; int *dbi = nullptr, *dbd = nullptr;
-            A.io(&dd, (size_t)S.n * 32, S.desc, (size_t)S.n * 32); A.io(&dqd, (size_t)S.nq * 32, S.query_desc, (size_t)S.nq * 32); A.io(&dq, S.nq, S.queries, S.nq);
+        for (int k = 0; k < NL; k++) {                                                  // every slot's inputs ...
+            const BestSlotIn& S = slots[live[k]]; BestParams& B = hB[k];
+            uint8_t *dd = nullptr, *dqd = nullptr; float *dur = nullptr, *dsg = nullptr; orbhip_best_query* dq = nullptr; orbhip_map_point* dpts = nullptr; orbhip_projection* dP = nullptr;
+            A.io(&dd, (size_t)S.n * 32, S.desc, (size_t)S.n * 32); A.io(&dqd, (size_t)S.nq * 32, S.query_desc, (size_t)S.nq * 32);
+            if (S.points) { A.io(&dpts, S.nq, S.points, S.nq); A.io(&dP, 1, S.proj, 1); }
+            else A.io(&dq, S.nq, S.queries, S.nq);
             if (S.u_right) A.io(&dur, S.n, S.u_right, S.n);
             if (S.inv_level_sigma2 && S.nlevels > 0) A.io(&dsg, S.nlevels, S.inv_level_sigma2, S.nlevels);
-            A.io(&dbi, S.nq, (const int*)nullptr, 0, S.best_idx, S.nq); A.io(&dbd, S.nq, (const int*)nullptr, 0, S.best_dist, S.nq);
-            B.desc = dd; B.u_right = dur; B.inv_level_sigma2 = dsg; B.q = dq; B.qdesc = dqd; B.nq = S.nq; B.chi2_gate = chi2_gate; B.best_idx = dbi; B.best_dist = dbd;
+            B.desc = dd; B.u_right = dur; B.inv_level_sigma2 = dsg; B.q = dq; B.qdesc = dqd; B.nq = S.nq; B.chi2_gate = chi2_gate;
+            B.pts = dpts; B.proj = dP; B.q_out = nullptr;
             B.min_x = S.bounds.min_x; B.gw_inv = (float)ORBHIP_GRID_COLS / (float)(S.bounds.max_x - S.bounds.min_x);
+        }
+        for (int k = 0; k < NL; k++) {                                                  // ... then every slot's answers, contiguous: the download is one small copy
+            const BestSlotIn& S = slots[live[k]]; BestParams& B = hB[k];
+            int *dbi = nullptr, *dbd = nullptr;
+            A.io(&dbi, S.nq, (const int*)nullptr, 0, S.best_idx, S.nq); A.io(&dbd, S.nq, (const int*)nullptr, 0, S.best_dist, S.nq);
+            B.best_idx = dbi; B.best_dist = dbd;
         }
         A.take(&dgs, (size_t)NL * (ORBHIP_GRID_CELLS + 1)); A.take(&dgi, NL * C); A.take(&dgxy, NL * C);
     }));
@@ -1650,10 +1714,32 @@ extern "C" orbhip_status orbhip_search_best_in_window_batch(int device, int nslo
     if (e != hipSuccess) (void)hipStreamSynchronize(ts);
 #undef TRY
     if (e != hipSuccess) {
-        for (int k = 0; k < NL; k++) { orbhip_best_slot& S = slots[live[k]]; for (int i = 0; i < S.nq; i++) { S.best_idx[i] = -1; S.best_dist[i] = 256; } }
+        for (int k = 0; k < NL; k++) { BestSlotIn& S = slots[live[k]]; for (int i = 0; i < S.nq; i++) { S.best_idx[i] = -1; S.best_dist[i] = 256; } }
         return fail(ORBHIP_ERR_HIP, "search_best_in_window_batch: %s", hipGetErrorString(e));
     }
     return ORBHIP_OK;
+}
+extern "C" orbhip_status orbhip_search_best_in_window_batch(int device, int nslots, orbhip_best_slot* slots, int chi2_gate)
+{
+    if (nslots < 0 || (nslots > 0 && !slots)) return fail(ORBHIP_ERR_INVALID, "bad argument");
+    std::vector<BestSlotIn> in((size_t)nslots);
+    for (int s = 0; s < nslots; s++) {
+        const orbhip_best_slot& S = slots[s];
+        if (S.nq > 0 && !S.queries) return fail(ORBHIP_ERR_INVALID, "bad argument in slot %d", s);
+        in[s] = BestSlotIn{S.kps, S.desc, S.u_right, S.n, S.bounds, S.inv_level_sigma2, S.nlevels, S.queries, S.query_desc, S.nq, nullptr, nullptr, S.best_idx, S.best_dist};
+    }
+    return search_best_in_window_batch_impl(device, nslots, in.data(), chi2_gate);
+}
+extern "C" orbhip_status orbhip_project_best_in_window_batch(int device, int nslots, orbhip_project_best_slot* slots, int chi2_gate)
+{
+    if (nslots < 0 || (nslots > 0 && !slots)) return fail(ORBHIP_ERR_INVALID, "bad argument");
+    std::vector<BestSlotIn> in((size_t)nslots);
+    for (int s = 0; s < nslots; s++) {
+        const orbhip_project_best_slot& S = slots[s];
+        if (S.np > 0 && (!S.points || !S.proj)) return fail(ORBHIP_ERR_INVALID, "bad argument in slot %d", s);
+        in[s] = BestSlotIn{S.kps, S.desc, S.u_right, S.n, S.bounds, S.inv_level_sigma2, S.nlevels, nullptr, S.point_desc, S.np, S.np > 0 ? S.proj : nullptr, S.np > 0 ? S.points : nullptr, S.best_idx, S.best_dist};
+    }
+    return search_best_in_window_batch_impl(device, nslots, in.data(), chi2_gate);
 }
 
 // The two searches above on a frame that is still on the device: key points (mvKeysUn with a distorted camera attached), descriptors
@@ -1669,26 +1755,31 @@ static orbhip_status frame_args(orbhip_ctx* c, int frame, int n, int use_u_right
     *ur = use_u_right ? c->d_last_uright + (size_t)frame * c->out_cap : nullptr;
     return ORBHIP_OK;
 }
-extern "C" orbhip_status orbhip_search_by_projection_frame(orbhip_ctx* c, int frame, int n, int use_u_right, const uint8_t* blocked,
-                                                           const orbhip_proj_query* queries, const uint8_t* query_desc, int nq,
-                                                           int mode, float nnratio, int th_high, int check_ori, int32_t* feature_query, int* nmatches)
+static orbhip_status search_by_projection_frame_impl(orbhip_ctx* c, int frame, int n, int use_u_right, const uint8_t* blocked,
+                                                     const orbhip_proj_query* queries, const uint8_t* query_desc, int nq,
+                                                     const orbhip_projection* P, const orbhip_map_point* points, orbhip_proj_query* queries_out,
+                                                     int mode, float nnratio, int th_high, int check_ori, int32_t* feature_query, int* nmatches)
 {
     OrbApiTimer api_timer;
     const orbhip_keypoint* dk = nullptr; const uint8_t* dd = nullptr; const float* dur = nullptr;
     orbhip_status st = frame_args(c, frame, n, use_u_right, &dk, &dd, &dur); if (st != ORBHIP_OK) return st;
-    if (nq < 0 || !nmatches || (n > 0 && !feature_query) || (nq > 0 && (!queries || !query_desc)) || (mode != 0 && mode != 1)) return fail(ORBHIP_ERR_INVALID, "bad argument");
+    if (nq < 0 || !nmatches || (n > 0 && !feature_query) || (nq > 0 && ((!queries && !points) || !query_desc)) || (mode != 0 && mode != 1) || (points && !projection_ok(P))) return fail(ORBHIP_ERR_INVALID, "bad argument");
     *nmatches = 0;
     for (int i = 0; i < n; i++) feature_query[i] = -1;
+    if (points) gated_out(queries_out, nq);
     if (n == 0 || nq == 0) return ORBHIP_OK;
     if (orbhip_proj_select_lds(n) > 150 * 1024) return fail(ORBHIP_ERR_UNSUPPORTED, "too many features for the LDS matcher (%d)", n);
     HIPCHK(hipSetDevice(c->cfg.device));
     uint8_t* dqd = nullptr; unsigned char* dbl_in = nullptr; int *dn = nullptr, *dgs = nullptr, *dgi = nullptr, *dnc = nullptr, *dfq = nullptr, *dev = nullptr;
     float2* dgxy = nullptr; orbhip_proj_query* dq = nullptr; unsigned* dcand = nullptr; unsigned* dtop = nullptr;
+    orbhip_map_point* dpts = nullptr; orbhip_projection* dP = nullptr;
     hipError_t e = hipSuccess;
 #define TRY(x) do { if (e == hipSuccess) e = (x); } while (0)
     const int hn[2] = {n, 0}; int hres[2] = {0, 0};
     TRY(arena_layout(c->cfg.device, [&](Arena& A) {
-        A.io(&dqd, (size_t)nq * 32, query_desc, (size_t)nq * 32); A.io(&dq, nq, queries, nq);
+        A.io(&dqd, (size_t)nq * 32, query_desc, (size_t)nq * 32);
+        if (points) { A.io(&dpts, nq, points, nq); A.io(&dP, 1, P, 1); A.io(&dq, nq, (const orbhip_proj_query*)nullptr, 0, queries_out, queries_out ? nq : 0); }
+        else A.io(&dq, nq, queries, nq);
         if (blocked) A.io(&dbl_in, n, blocked, n);
         A.io(&dn, 8, hn, 2, hres, 2);
         A.io(&dfq, n, (const int*)nullptr, 0, feature_query, n);
@@ -1706,6 +1797,7 @@ extern "C" orbhip_status orbhip_search_by_projection_frame(orbhip_ctx* c, int fr
         ProjParams J; memset(&J, 0, sizeof J);
         J.kp = dk; J.desc = dd; J.u_right = dur; J.n = n; J.min_x = M.min_x; J.min_y = M.min_y; J.max_x = M.max_x; J.max_y = M.max_y; J.grid_start = dgs; J.grid_items = dgi; J.grid_xy = dgxy;
         J.q = dq; J.qdesc = dqd; J.nq = nq; J.cand = dcand; J.ncand = dnc; J.cand_stride = n; J.top = dtop;
+        J.pts = dpts; J.proj = dP; J.q_out = dq;
         J.blocked_in = dbl_in; J.blocked_out = nullptr; J.feature_query = dfq; J.nmatches = dn + 1; J.events = dev;
         J.mode = mode; J.nnratio = nnratio; J.th_high = th_high; J.check_ori = check_ori;
         orbhip_launch_proj(J, c->stream);
@@ -1716,6 +1808,20 @@ extern "C" orbhip_status orbhip_search_by_projection_frame(orbhip_ctx* c, int fr
     if (e == hipSuccess) *nmatches = hres[1];
 #undef TRY
     return e == hipSuccess ? ORBHIP_OK : fail(ORBHIP_ERR_HIP, "search_by_projection_frame: %s", hipGetErrorString(e));
+}
+extern "C" orbhip_status orbhip_search_by_projection_frame(orbhip_ctx* c, int frame, int n, int use_u_right, const uint8_t* blocked,
+                                                           const orbhip_proj_query* queries, const uint8_t* query_desc, int nq,
+                                                           int mode, float nnratio, int th_high, int check_ori, int32_t* feature_query, int* nmatches)
+{
+    if (nq > 0 && !queries) return fail(ORBHIP_ERR_INVALID, "bad argument");
+    return search_by_projection_frame_impl(c, frame, n, use_u_right, blocked, queries, query_desc, nq, nullptr, nullptr, nullptr, mode, nnratio, th_high, check_ori, feature_query, nmatches);
+}
+extern "C" orbhip_status orbhip_project_search_frame(orbhip_ctx* c, int frame, int n, int use_u_right, const uint8_t* blocked,
+                                                     const orbhip_projection* proj, const orbhip_map_point* points, const uint8_t* point_desc, int np,
+                                                     float nnratio, int th_high, int check_ori, int32_t* feature_query, int* nmatches, orbhip_proj_query* queries_out)
+{
+    if (np > 0 && (!points || !proj)) return fail(ORBHIP_ERR_INVALID, "bad argument");
+    return search_by_projection_frame_impl(c, frame, n, use_u_right, blocked, nullptr, point_desc, np, np > 0 ? proj : nullptr, np > 0 ? points : nullptr, queries_out, 1, nnratio, th_high, check_ori, feature_query, nmatches);
 }
 extern "C" orbhip_status orbhip_search_best_in_window_frame(orbhip_ctx* c, int frame, int n, int use_u_right, const orbhip_best_query* queries, const uint8_t* query_desc, int nq,
                                                             int chi2_gate, int32_t* best_idx, int32_t* best_dist)
@@ -2268,6 +2374,29 @@ extern "C" orbhip_status orbhip_search_for_initialization(int device, const orbh
 // frame (Tracking.cc:1344-1348, KeyFrameDatabase.cc:199-309): here the evidence is the brute-force nearest neighbour of every query
 // descriptor over the descriptors of ALL key frames (BASELINE.json config 5), filtered with the matcher's own acceptance idiom
 // (distance threshold + ratio to the second best, ORBmatcher.cc:102-114), one vote per accepted descriptor for the owning key frame.
+// MapPoint::PredictScale as a table (include/orbhip.h): level_ratio[i] = the smallest positive float ratio the caller's own expression maps to a level > i.
+// Host arithmetic only (the caller's libm through level_of); the device compares ratios against the table (pj_predict_scale).
+extern "C" orbhip_status orbhip_predict_scale_table(int (*level_of)(float ratio, void* user), void* user, int nlevels, float* level_ratio)
+{
+    if (!level_of || !level_ratio || nlevels < 1 || nlevels > ORBHIP_MAX_PROJ_LEVELS) return fail(ORBHIP_ERR_INVALID, "bad argument");
+    auto as_float = [](uint32_t b) { float f; memcpy(&f, &b, 4); return f; };
+    const float inf = as_float(0x7f800000u);
+    for (int i = 0; i < ORBHIP_MAX_PROJ_LEVELS; i++) level_ratio[i] = inf;
+    for (int i = 0; i + 1 < nlevels; i++) {
+        auto above = [&](uint32_t b) { return level_of(as_float(b), user) > i; };
+        uint32_t lo = 1u, hi = 0x7f7fffffu;                                  // smallest denormal .. largest finite float: positive floats order like their bits
+        if (!above(hi)) continue;                                            // no finite ratio reaches level i + 1
+        if (above(lo)) { level_ratio[i] = as_float(lo); continue; }
+        while (hi - lo > 1u) { const uint32_t mid = lo + (hi - lo) / 2u; if (above(mid)) hi = mid; else lo = mid; }
+        for (uint32_t d = 1; d <= 64u; d++) {                                 // a step function: nothing above the threshold falls back, nothing below reaches over
+            if (hi + d <= 0x7f7fffffu && !above(hi + d)) return fail(ORBHIP_ERR_UNSUPPORTED, "PredictScale is not monotone in the distance ratio near %.9g (level %d)", (double)as_float(hi), i + 1);
+            if (lo >= d && lo - d >= 1u && above(lo - d)) return fail(ORBHIP_ERR_UNSUPPORTED, "PredictScale is not monotone in the distance ratio near %.9g (level %d)", (double)as_float(hi), i + 1);
+        }
+        level_ratio[i] = as_float(hi);
+    }
+    return ORBHIP_OK;
+}
+
 extern "C" orbhip_status orbhip_reloc_candidates(const int64_t* best_idx, const int32_t* best_dist, const int32_t* second_dist, int nq,
                                                  const int32_t* row_keyframe, int64_t ndb, int nkf, int th_dist, float ratio,
                                                  int top_k, int32_t* kf_out, int32_t* votes_out, int* nout)

@@ -140,6 +140,9 @@ struct ProjParams {         // projection-guided search core (ORBmatcher.cc:45-1
     float min_x, min_y, max_x, max_y;                                   // Frame::mnMinX .. mnMaxY (Frame.cc:436-464)
     const int* grid_start; const int* grid_items; const float2* grid_xy;                   // 64x48 grid over ALL keypoints
     const orbhip_proj_query* q; const uint8_t* qdesc; int nq;
+    // projection on the device (orbhip_project_search_*): with pts != nullptr query i is DERIVED from pts[i] under *proj by k_proj_candidates, which also
+    // writes it to q_out[i] (== q: the select kernel reads blocks / angle there; radius < 0 = the point failed a gate of its member)
+    const orbhip_map_point* pts; const orbhip_projection* proj; orbhip_proj_query* q_out;
     unsigned* cand; int* ncand; int cand_stride;                                            // per query: i2 | dist<<19 | level<<28, reference order
     unsigned* top;                                                                          // per query: records of the best and second-best candidate under the initial state
     const unsigned char* blocked_in; unsigned char* blocked_out; int* feature_query; int* nmatches; int* events;
@@ -151,6 +154,7 @@ struct BestParams {
     const orbhip_keypoint* kp; const uint8_t* desc; const float* u_right; const float* inv_level_sigma2;
     const int* grid_start; const int* grid_items; const float2* grid_xy;        // ordered bucket table over ALL key points (k_match_grid, grid_all_levels)
     const orbhip_best_query* q; const uint8_t* qdesc; int nq; int chi2_gate;
+    const orbhip_map_point* pts; const orbhip_projection* proj; orbhip_best_query* q_out;      // projection on the device, as in ProjParams (q_out may be nullptr)
     int* best_idx; int* best_dist;
     float min_x, gw_inv;        // left image bound and grid columns per pixel of the table's grid (gw_inv = 0: scan the whole table)
 };

@@ -31,12 +31,120 @@ __device__ __forceinline__ int pj_wave_min(int v)
     v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x143, 0xc, 0xf, false));
     return __builtin_amdgcn_readlane(v, 63);
 }
+
+// ------------------------------------------------------------------------------------------------ the members' per-point algebra
+// What the five projection-guided members of ORBmatcher compute per map point before their window search, as flat float code: every operation is the
+// reference's own, in its order, rounded once (the __f*_rn / __d*_rn forms are never contracted).  cv::Mat semantics restated:
+//   R*x + t     P.gemm_mode 0: per row ((0 + a0*b0) + a1*b1) + a2*b2 in double (products of floats are exact there), rounded to float, then + t in float
+//               (cv::gemm's generic kernel GEMMSingleMul<float,double> followed by a float add; include/cvlite's operator* and operator+);
+//               P.gemm_mode 1: OpenCV's small-matrix path of cv::gemm (len 3, flags 0): t0 = a0*b0 + a1*b1 + a2*b2 in float, d = (float)(t0*alpha + c*beta)
+//               in double with alpha = beta = 1 - what `Rcw*p3Dw+tcw` compiles to as ONE MatExpr (MatOp_GEMM absorbs the addition);
+//               P.gemm_mode 2: the caller's own result is in pts[i].cam_*.
+//   a - b       element-wise float subtraction
+//   cv::norm(a) sqrt(((0 + a0*a0) + a1*a1) + a2*a2) in double, narrowed by the member's `const float dist = ...`
+//   a.dot(b)    ((0 + a0*b0) + a1*b1) + a2*b2 in double
+__device__ __forceinline__ float pj_gemm_row(const float* R, int row, float tr, float x, float y, float z, int mode)
+{
+    const float a0 = R[3 * row], a1 = R[3 * row + 1], a2 = R[3 * row + 2];
+    if (mode == 1) {
+        const float t0 = __fadd_rn(__fadd_rn(__fmul_rn(a0, x), __fmul_rn(a1, y)), __fmul_rn(a2, z));
+        return __double2float_rn(__dadd_rn((double)t0, (double)tr));
+    }
+    double s = __dadd_rn(0.0, __dmul_rn((double)a0, (double)x));
+    s = __dadd_rn(s, __dmul_rn((double)a1, (double)y));
+    s = __dadd_rn(s, __dmul_rn((double)a2, (double)z));
+    return __fadd_rn(__double2float_rn(s), tr);
+}
+__device__ __forceinline__ double pj_dot3(float a0, float a1, float a2, float b0, float b1, float b2)
+{
+    double s = __dadd_rn(0.0, __dmul_rn((double)a0, (double)b0));
+    s = __dadd_rn(s, __dmul_rn((double)a1, (double)b1));
+    return __dadd_rn(s, __dmul_rn((double)a2, (double)b2));
+}
+// MapPoint::PredictScale (MapPoint.cc:385-421): ratio = mfMaxDistance/currentDist in float; nScale = ceil(log(ratio)/mfLogScaleFactor) clamped to
+// [0, nlevels-1] == the number of host-derived thresholds the ratio reaches (orbhip_predict_scale_table).  A NaN or infinite ratio converts to INT_MIN
+// on the reference's x86 (cvttss2si / cvttsd2si), i.e. to level 0.
+__device__ __forceinline__ int pj_predict_scale(const orbhip_projection& P, float max_dist, float dist)
+{
+    const float ratio = __fdiv_rn(max_dist, dist);
+    if (!(fabsf(ratio) < __int_as_float(0x7f800000))) return 0;
+    int level = 0;
+    for (int i = 0; i + 1 < P.nlevels && i < ORBHIP_MAX_PROJ_LEVELS; i++) level += ratio >= P.level_ratio[i] ? 1 : 0;
+    return level;
+}
+struct PjOut { float u, v, radius, ur; int level, min_level, max_level; };
+__device__ __forceinline__ bool pj_project(const orbhip_projection& P, const orbhip_map_point& m, PjOut& o)
+{
+    const int kind = P.kind, gm = P.gemm_mode;
+    float X, Y, Z;                                                     // the point in the frame the member projects from
+    if (gm == 2) { X = m.cam_x; Y = m.cam_y; Z = m.cam_z; }
+    else {
+        X = pj_gemm_row(P.R, 0, P.t[0], m.x, m.y, m.z, gm); Y = pj_gemm_row(P.R, 1, P.t[1], m.x, m.y, m.z, gm); Z = pj_gemm_row(P.R, 2, P.t[2], m.x, m.y, m.z, gm);
+        if (kind == ORBHIP_PROJ_SIM3) {                                // p3Dc2 = sR21*p3Dc1 + t21 (ORBmatcher.cc:1166-1168 / :1246-1248)
+            const float x1 = X, y1 = Y, z1 = Z;
+            X = pj_gemm_row(P.R2, 0, P.t2[0], x1, y1, z1, gm); Y = pj_gemm_row(P.R2, 1, P.t2[1], x1, y1, z1, gm); Z = pj_gemm_row(P.R2, 2, P.t2[2], x1, y1, z1, gm);
+        }
+    }
+    float invz, u, v;
+    if (kind == ORBHIP_PROJ_LAST_FRAME || kind == ORBHIP_PROJ_FRAME_KF) {
+        invz = __double2float_rn(__ddiv_rn(1.0, (double)Z));         // const float invzc = 1.0/x3Dc.at<float>(2)  (:1362, :1498)
+        if (kind == ORBHIP_PROJ_LAST_FRAME && invz < 0.0f) return false;                             // :1364-1365 (the relocalisation overload has no such test)
+        u = __fadd_rn(__fmul_rn(__fmul_rn(P.fx, X), invz), P.cx);     // CurrentFrame.fx*xc*invzc+CurrentFrame.cx  (:1367-1368, :1500-1501)
+        v = __fadd_rn(__fmul_rn(__fmul_rn(P.fy, Y), invz), P.cy);
+        if (u < P.min_x || u > P.max_x) return false;                 // :1370-1373, :1503-1506
+        if (v < P.min_y || v > P.max_y) return false;
+    } else {
+        if (Z < 0.0f) return false;                                   // "Depth must be positive" (:323, :857, :1011, :1171, :1251)
+        invz = (kind == ORBHIP_PROJ_KF_SIM3 || kind == ORBHIP_PROJ_FUSE) ? __fdiv_rn(1.0f, Z)          // 1/z  (:327, :860)
+                                                                          : __double2float_rn(__ddiv_rn(1.0, (double)Z));      // 1.0/z  (:1015, :1174, :1254)
+        const float x = __fmul_rn(X, invz), y = __fmul_rn(Y, invz);
+        u = __fadd_rn(__fmul_rn(P.fx, x), P.cx);                      // fx*x+cx
+        v = __fadd_rn(__fmul_rn(P.fy, y), P.cy);
+        if (!(u >= P.min_x && u < P.max_x && v >= P.min_y && v < P.max_y)) return false;                // KeyFrame::IsInImage (KeyFrame.cc:610-613)
+    }
+    o.u = u; o.v = v; o.ur = 0.0f;
+    if (kind == ORBHIP_PROJ_LAST_FRAME) {
+        const int oct = m.level;                                      // LastFrame.mvKeys[i].octave (:1375)
+        o.level = oct;
+        o.radius = __fmul_rn(P.th, P.scale_factors[min(max(oct, 0), ORBHIP_MAX_PROJ_LEVELS - 1)]);     // :1378
+        if (P.forward) { o.min_level = oct; o.max_level = -1; }       // :1382-1387
+        else if (P.backward) { o.min_level = 0; o.max_level = oct; }
+        else { o.min_level = oct - 1; o.max_level = oct + 1; }
+        o.ur = __fsub_rn(u, __fmul_rn(P.bf, invz));                   // u - CurrentFrame.mbf*invzc (:1410)
+        return true;
+    }
+    float dist;
+    if (kind == ORBHIP_PROJ_SIM3) dist = __double2float_rn(__dsqrt_rn(pj_dot3(X, Y, Z, X, Y, Z)));          // cv::norm(p3Dc2)  (:1184, :1264)
+    else {
+        const float p0 = __fsub_rn(m.x, P.Ow[0]), p1 = __fsub_rn(m.y, P.Ow[1]), p2 = __fsub_rn(m.z, P.Ow[2]);      // PO = p3Dw-Ow
+        dist = __double2float_rn(__dsqrt_rn(pj_dot3(p0, p1, p2, p0, p1, p2)));
+        if (dist < m.min_dist || dist > m.max_dist) return false;     // :343-344, :874-875, :1030-1031, :1516-1517
+        if (kind != ORBHIP_PROJ_FRAME_KF && pj_dot3(p0, p1, p2, m.nx, m.ny, m.nz) < __dmul_rn(0.5, (double)dist)) return false;    // PO.dot(Pn)<0.5*dist (:349, :881, :1036)
+    }
+    if (kind == ORBHIP_PROJ_SIM3 && (dist < m.min_dist || dist > m.max_dist)) return false;              // :1187-1188, :1267-1268
+    const int level = m.level >= 0 ? m.level : pj_predict_scale(P, m.scale_dist, dist);
+    o.level = level;
+    o.radius = __fmul_rn(P.th, P.scale_factors[min(max(level, 0), ORBHIP_MAX_PROJ_LEVELS - 1)]);
+    o.min_level = level - 1; o.max_level = kind == ORBHIP_PROJ_FRAME_KF ? level + 1 : level;          // :1524 / :364-366
+    if (kind == ORBHIP_PROJ_FUSE) o.ur = __fsub_rn(u, __fmul_rn(P.bf, invz));                       // const float ur = u-bf*invz (:868)
+    return true;
+}
+
 __device__ __forceinline__ void proj_candidates_body(const ProjParams& J, float gwInv, float ghInv)
 {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int iq = blockIdx.x * 4 + wave;
     if (iq >= J.nq) return;
-    const orbhip_proj_query q = J.q[iq];
+    orbhip_proj_query q;
+    bool live = true;
+    if (J.pts) {                                                       // the member's projection of map point iq (every lane the same arithmetic)
+        const orbhip_map_point m = J.pts[iq];
+        PjOut o;
+        live = pj_project(*J.proj, m, o);
+        q.x = live ? o.u : 0.0f; q.y = live ? o.v : 0.0f; q.radius = live ? o.radius : -1.0f; q.ur = live ? o.ur : 0.0f;
+        q.min_level = live ? o.min_level : 0; q.max_level = live ? o.max_level : 0; q.blocks = m.blocks; q.angle = m.angle;
+        if (lane == 0) J.q_out[iq] = q;
+    } else q = J.q[iq];
     unsigned* cand = J.cand + (long long)iq * J.cand_stride;
     const unsigned long long* d1 = (const unsigned long long*)(J.qdesc + (long long)iq * 32);
     const unsigned long long q0 = d1[0], q1 = d1[1], q2 = d1[2], q3 = d1[3];
@@ -50,7 +158,7 @@ __device__ __forceinline__ void proj_candidates_body(const ProjParams& J, float 
     const int maxCX = min(ORBHIP_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, J.min_x), r), gwInv)));
     const int minCY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, J.min_y), r), ghInv)));
     const int maxCY = min(ORBHIP_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, J.min_y), r), ghInv)));
-    if (minCX < ORBHIP_GRID_COLS && maxCX >= 0 && minCY < ORBHIP_GRID_ROWS && maxCY >= 0 && maxCX >= minCX && maxCY >= minCY) {
+    if (live && minCX < ORBHIP_GRID_COLS && maxCX >= 0 && minCY < ORBHIP_GRID_ROWS && maxCY >= 0 && maxCX >= minCX && maxCY >= minCY) {
         const int ny = maxCY - minCY + 1, ncell = (maxCX - minCX + 1) * ny;
         for (int cb = 0; cb < ncell; cb += 64) {
             const int c = cb + lane;
@@ -351,7 +459,14 @@ void orbhip_launch_proj_batch(const ProjParams* d_slots, int nslots, int max_nq,
 __device__ __forceinline__ void best_in_window_body(const BestParams& B, int iq, int lane)
 {
     if (iq >= B.nq) return;
-    const orbhip_best_query q = B.q[iq];
+    orbhip_best_query q;
+    if (B.pts) {
+        PjOut o;
+        const bool live = pj_project(*B.proj, B.pts[iq], o);
+        q.x = live ? o.u : 0.0f; q.y = live ? o.v : 0.0f; q.radius = live ? o.radius : -1.0f; q.ur = live ? o.ur : 0.0f; q.level = live ? o.level : 0;
+        if (lane == 0 && B.q_out) B.q_out[iq] = q;
+        if (!live) { if (lane == 0) { B.best_idx[iq] = -1; B.best_dist[iq] = 256; } return; }
+    } else q = B.q[iq];
     const uint4* q4 = reinterpret_cast<const uint4*>(B.qdesc + (long long)iq * 32);
     const uint4 qa = q4[0], qb = q4[1];
     // only the run of the table that holds the grid columns the radius can reach (+-1, see k_match_candidates): the table is ordered by column

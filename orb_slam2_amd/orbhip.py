@@ -39,6 +39,7 @@ SYMBOLS = [
     "orbhip_pool_extract", "orbhip_pool_submit", "orbhip_pool_collect", "orbhip_pool_db_load", "orbhip_pool_db_shard", "orbhip_pool_db_query",
     "orbhip_reloc_candidates", "orbhip_runtime_info", "orbhip_device_alloc", "orbhip_device_free", "orbhip_device_upload", "orbhip_device_download",
     "orbhip_device_synchronize", "orbhip_submit_to",
+    "orbhip_predict_scale_table", "orbhip_project_search_bounds", "orbhip_project_search_frame", "orbhip_project_best_in_window_bounds", "orbhip_project_best_in_window_batch",
 ]
 
 
@@ -72,6 +73,25 @@ class Bounds(C.Structure):          # orbhip_bounds: Frame::mnMinX, mnMinY, mnMa
 
     def array(self):
         return np.array([self.min_x, self.min_y, self.max_x, self.max_y], np.float32)
+
+
+MAX_PROJ_LEVELS = 16
+LEVEL_OF = C.CFUNCTYPE(C.c_int, C.c_float, C.c_void_p)       # int level_of(float ratio, void* user): the caller's own PredictScale expression
+PROJ_LAST_FRAME, PROJ_FRAME_KF, PROJ_KF_SIM3, PROJ_FUSE, PROJ_FUSE_SIM3, PROJ_SIM3 = range(6)        # orbhip_projection_kind
+
+
+class Projection(C.Structure):      # orbhip_projection: what one call of a pose-guided ORBmatcher member holds fixed
+    _fields_ = [("kind", C.c_int32), ("gemm_mode", C.c_int32), ("R", C.c_float * 9), ("t", C.c_float * 3), ("R2", C.c_float * 9), ("t2", C.c_float * 3), ("Ow", C.c_float * 3),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float),
+                ("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float), ("th", C.c_float),
+                ("forward", C.c_int32), ("backward", C.c_int32), ("nlevels", C.c_int32),
+                ("scale_factors", C.c_float * MAX_PROJ_LEVELS), ("level_ratio", C.c_float * MAX_PROJ_LEVELS)]
+
+
+# orbhip_map_point: what a member reads of one map point
+MAP_POINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("cam_x", "<f4"), ("cam_y", "<f4"), ("cam_z", "<f4"), ("nx", "<f4"), ("ny", "<f4"), ("nz", "<f4"),
+                            ("min_dist", "<f4"), ("max_dist", "<f4"), ("scale_dist", "<f4"), ("level", "<i4"), ("blocks", "<i4"), ("angle", "<f4")])
+assert MAP_POINT_DTYPE.itemsize == 60
 
 
 class Config(C.Structure):
@@ -164,6 +184,11 @@ def lib(path=None):
     L.orbhip_search_for_initialization.argtypes = [C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp,
                                                    C.c_int, C.c_float, C.c_int, ip]
     L.orbhip_search_by_projection.argtypes = [C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, vp, ip]
+    L.orbhip_predict_scale_table.argtypes = [LEVEL_OF, vp, C.c_int, vp]
+    L.orbhip_project_search_bounds.argtypes = [C.c_int, vp, vp, vp, vp, C.c_int, C.POINTER(Bounds), C.POINTER(Projection), vp, vp, C.c_int, C.c_float, C.c_int, C.c_int, vp, ip, vp]
+    L.orbhip_project_search_frame.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.POINTER(Projection), vp, vp, C.c_int, C.c_float, C.c_int, C.c_int, vp, ip, vp]
+    L.orbhip_project_best_in_window_bounds.argtypes = [C.c_int, vp, vp, vp, C.c_int, C.POINTER(Bounds), vp, C.c_int, C.POINTER(Projection), vp, vp, C.c_int, C.c_int, vp, vp, vp]
+    L.orbhip_project_best_in_window_batch.argtypes = [C.c_int, C.c_int, vp, C.c_int]
     L.orbhip_compute_stereo_matches.argtypes = [vp, vp, C.c_int, C.c_float, C.c_float, vp, vp, C.c_int]
     L.orbhip_extract_stereo.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, C.c_float, C.c_float, vp, vp]
     L.orbhip_profile_enable.argtypes = [vp, C.c_int]
@@ -1098,6 +1123,94 @@ def search_best_in_window(kps, desc, im_w, im_h, inv_level_sigma2, queries, qdes
         _check(L.orbhip_search_best_in_window_bounds(device, _p(kps), _p(desc), None if ur is None else _p(ur), len(kps), C.byref(b), _p(inv), len(inv),
                                                      _p(queries), _p(qdesc), len(queries), int(chi2_gate), _p(bi), _p(bd)), "orbhip_search_best_in_window_bounds", L)
     return bi, bd
+
+
+def predict_scale_table(log_scale_factor, nlevels, level_of=None, library=None):
+    """orbhip_predict_scale_table -> level_ratio[16].  level_of(ratio) = the caller's own MapPoint::PredictScale expression (the C++ drop-in passes its
+    translation unit's; the tests pass the oracle's, which calls this machine's logf); default: the expression in numpy float32 - whose log is numpy's own
+    and may round differently from libm's at a level boundary."""
+    L = lib(library)
+    lsf = np.float32(log_scale_factor)
+
+    def default(ratio):
+        with np.errstate(all="ignore"):
+            v = np.ceil(np.log(np.float32(ratio)) / lsf)
+        return 0 if not np.isfinite(v) else int(min(max(int(v), 0), nlevels - 1))
+    fn = level_of or default
+    out = np.zeros(MAX_PROJ_LEVELS, np.float32)
+    _check(L.orbhip_predict_scale_table(LEVEL_OF(lambda ratio, _: int(fn(ratio))), None, nlevels, _p(out)), "orbhip_predict_scale_table", L)
+    return out
+
+
+def make_projection(kind, R, t, fx, fy, cx, cy, bounds, th, scale_factors, level_ratio, Ow=(0, 0, 0), bf=0.0, R2=None, t2=None, gemm_mode=0, forward=False, backward=False):
+    P = Projection()
+    P.kind = kind; P.gemm_mode = gemm_mode
+    P.R = (C.c_float * 9)(*np.asarray(R, np.float32).reshape(9)); P.t = (C.c_float * 3)(*np.asarray(t, np.float32).reshape(3))
+    if R2 is not None:
+        P.R2 = (C.c_float * 9)(*np.asarray(R2, np.float32).reshape(9)); P.t2 = (C.c_float * 3)(*np.asarray(t2, np.float32).reshape(3))
+    P.Ow = (C.c_float * 3)(*np.asarray(Ow, np.float32).reshape(3))
+    P.fx, P.fy, P.cx, P.cy, P.bf = fx, fy, cx, cy, bf
+    P.min_x, P.min_y, P.max_x, P.max_y = bounds
+    P.th = th; P.forward = int(forward); P.backward = int(backward)
+    sf = np.asarray(scale_factors, np.float32)
+    P.nlevels = len(sf)
+    P.scale_factors = (C.c_float * MAX_PROJ_LEVELS)(*(list(sf) + [0.0] * (MAX_PROJ_LEVELS - len(sf))))
+    P.level_ratio = (C.c_float * MAX_PROJ_LEVELS)(*np.asarray(level_ratio, np.float32))
+    return P
+
+
+def project_search(kps, desc, bounds, proj, points, point_desc, nnratio=0.9, th_high=100, check_ori=True, u_right=None, blocked=None, device=0, library=None):
+    """orbhip_project_search_bounds -> (nmatches, feature_query[n], queries_out[np]): the projection of the pose-guided SearchByProjection overloads on the device"""
+    L = lib(library)
+    kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
+    points = np.ascontiguousarray(points, MAP_POINT_DTYPE); point_desc = np.ascontiguousarray(point_desc, np.uint8)
+    ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    bl = None if blocked is None else np.ascontiguousarray(blocked, np.uint8)
+    fq = np.full(len(kps), -1, np.int32); nm = C.c_int(0); qo = np.zeros(len(points), PROJ_QUERY_DTYPE)
+    b = Bounds.of(bounds)
+    _check(L.orbhip_project_search_bounds(device, _p(kps), _p(desc), None if ur is None else _p(ur), None if bl is None else _p(bl), len(kps), C.byref(b), C.byref(proj),
+                                          _p(points), _p(point_desc), len(points), nnratio, th_high, int(check_ori), _p(fq), C.byref(nm), _p(qo)), "orbhip_project_search_bounds", L)
+    return nm.value, fq, qo
+
+
+def project_best_in_window(kps, desc, bounds, inv_level_sigma2, proj, points, point_desc, chi2_gate, u_right=None, device=0, library=None):
+    """orbhip_project_best_in_window_bounds -> (best_idx[np], best_dist[np], queries_out[np]): Fuse x2 / SearchBySim3 with the projection on the device"""
+    L = lib(library)
+    kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
+    points = np.ascontiguousarray(points, MAP_POINT_DTYPE); point_desc = np.ascontiguousarray(point_desc, np.uint8)
+    inv = np.ascontiguousarray(inv_level_sigma2, np.float32)
+    ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    bi = np.full(len(points), -1, np.int32); bd = np.full(len(points), 256, np.int32); qo = np.zeros(len(points), BEST_QUERY_DTYPE)
+    b = Bounds.of(bounds)
+    _check(L.orbhip_project_best_in_window_bounds(device, _p(kps), _p(desc), None if ur is None else _p(ur), len(kps), C.byref(b), _p(inv), len(inv), C.byref(proj),
+                                                  _p(points), _p(point_desc), len(points), int(chi2_gate), _p(bi), _p(bd), _p(qo)), "orbhip_project_best_in_window_bounds", L)
+    return bi, bd, qo
+
+
+class ProjectBestSlot(C.Structure):  # orbhip_project_best_slot
+    _fields_ = [("kps", C.c_void_p), ("desc", C.c_void_p), ("u_right", C.c_void_p), ("n", C.c_int32), ("bounds", Bounds), ("inv_level_sigma2", C.c_void_p), ("nlevels", C.c_int32),
+                ("proj", C.POINTER(Projection)), ("points", C.c_void_p), ("point_desc", C.c_void_p), ("np", C.c_int32), ("best_idx", C.c_void_p), ("best_dist", C.c_void_p)]
+
+
+def project_best_in_window_batch(slots, chi2_gate, device=0, library=None):
+    """orbhip_project_best_in_window_batch.  slots = [dict(kps=, desc=, u_right= (or None), bounds=, inv_level_sigma2=, proj=, points=, pdesc=), ...] -> [(best_idx, best_dist), ...]"""
+    L = lib(library)
+    keep, outs = [], []
+    arr = (ProjectBestSlot * max(len(slots), 1))()
+    for k, sl in enumerate(slots):
+        kps = np.ascontiguousarray(sl["kps"], KEYPOINT_DTYPE); desc = np.ascontiguousarray(sl["desc"], np.uint8)
+        pts = np.ascontiguousarray(sl["points"], MAP_POINT_DTYPE); pd = np.ascontiguousarray(sl["pdesc"], np.uint8)
+        inv = np.ascontiguousarray(sl["inv_level_sigma2"], np.float32)
+        ur = None if sl.get("u_right") is None else np.ascontiguousarray(sl["u_right"], np.float32)
+        bi = np.full(len(pts), -1, np.int32); bd = np.full(len(pts), 256, np.int32)
+        keep.extend([kps, desc, pts, pd, inv, ur, sl["proj"]]); outs.append((bi, bd))
+        a = arr[k]
+        a.kps = _p(kps).value if len(kps) else None; a.desc = _p(desc).value if len(desc) else None; a.u_right = None if ur is None else _p(ur).value; a.n = len(kps)
+        a.bounds = Bounds.of(sl["bounds"]); a.inv_level_sigma2 = _p(inv).value; a.nlevels = len(inv)
+        a.proj = C.pointer(sl["proj"]); a.points = _p(pts).value if len(pts) else None; a.point_desc = _p(pd).value if len(pd) else None; a.np = len(pts)
+        a.best_idx = _p(bi).value if len(pts) else None; a.best_dist = _p(bd).value if len(pts) else None
+    _check(L.orbhip_project_best_in_window_batch(device, len(slots), arr, int(chi2_gate)), "orbhip_project_best_in_window_batch", L)
+    return outs
 
 
 def undistort_points(camera, xy, device=0, library=None):

@@ -288,6 +288,8 @@ inline float __fdiv_rn(float a, float b) { return a / b; }
 inline double __dmul_rn(double a, double b) { return a * b; }
 inline double __dadd_rn(double a, double b) { return a + b; }
 inline double __dsub_rn(double a, double b) { return a - b; }
+inline double __ddiv_rn(double a, double b) { return a / b; }
+inline double __dsqrt_rn(double a) { return sqrt(a); }
 inline int __float2int_rn(float v) { return (int)lrintf(v); }
 inline int __float2int_rz(float v) { return (int)v; }
 inline int __double2int_rz(double v) { return (int)v; }

@@ -1,7 +1,8 @@
 """integration/apply_dropin.py as a maintainer runs it: the unified diff it prints applies with `patch -p1` to a checkout of the reference, gives
-exactly the files its directory mode writes, and the patched src/Frame.cc / src/ORBmatcher.cc compile (syntax only: against the OpenCV type
-stand-in the oracle builds use, with the drop-in headers in place of the reference's).  Needs /root/reference (a scratch copy of the few files
-involved is made; nothing is written there) and patch(1); skipped elsewhere."""
+exactly the files its directory mode writes, and the installed src/ORBmatcher.cc (this repository's file) and the edited src/Frame.cc compile against the
+checkout's own headers with the one-line edit of include/MapPoint.h in place (syntax only: OpenCV is the type stand-in the oracle builds use).  Needs
+/root/reference (a scratch copy of src/ + include/ is made in the test's temporary directory; nothing is written there, nothing is kept) and patch(1);
+skipped elsewhere."""
 import os
 import shutil
 import subprocess
@@ -17,30 +18,42 @@ SCRIPT = os.path.join(ROOT, "integration", "apply_dropin.py")
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src")) or shutil.which("patch") is None, reason="reference sources not mounted or patch(1) missing")
 def test_patch_applies_and_patched_sources_compile(tmp_path):
     co = tmp_path / "ORB_SLAM2"
-    for sub in ("src", "include"):
-        (co / sub).mkdir(parents=True)
-    for rel in ("src/Frame.cc", "src/ORBmatcher.cc", "src/ORBextractor.cc", "include/ORBextractor.h"):
+    (co / "src").mkdir(parents=True)
+    shutil.copytree(os.path.join(REF, "include"), co / "include")
+    os.remove(co / "include/Converter.h")                      # needs Eigen / g2o, which this container lacks: oracle/ref_shim's stand-in (the one function Frame.cc uses) is found instead
+    for rel in ("src/Frame.cc", "src/ORBmatcher.cc", "src/ORBextractor.cc"):
         shutil.copyfile(os.path.join(REF, rel), co / rel)
     diff = subprocess.run([sys.executable, SCRIPT, "--patch", REF], capture_output=True, text=True, check=True).stdout
-    assert diff.count("\n--- a/") + diff.startswith("--- a/") >= 5 and "+++ b/include/orbhip.h" in diff
+    assert diff.count("\n--- a/") + diff.startswith("--- a/") >= 7 and "+++ b/include/orbhip.h" in diff and "+++ b/include/MapPoint.h" in diff
     r = subprocess.run(["patch", "-p1", "-d", str(co)], input=diff, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     out = tmp_path / "out"
     subprocess.run([sys.executable, SCRIPT, REF, str(out)], capture_output=True, text=True, check=True)
-    for rel in ("src/Frame.cc", "src/ORBmatcher.cc", "src/ORBextractor.cc", "include/ORBextractor.h", "include/orbhip.h", "include/ORBmatcherBatch.h"):
+    for rel in ("src/Frame.cc", "src/ORBmatcher.cc", "src/ORBextractor.cc", "include/ORBextractor.h", "include/ORBmatcher.h", "include/orbhip.h", "include/ORBmatcherBatch.h", "include/MapPoint.h"):
         assert (co / rel).read_text() == (out / rel).read_text(), rel + ": patch -p1 and the directory mode disagree"
-    patched = (co / "src/ORBmatcher.cc").read_text()
-    assert "abort();" not in patched and "orbhip_search_by_projection_frame" in patched and patched.count("orbhip_check(orbhip_") >= 10
+    installed = (co / "src/ORBmatcher.cc").read_text()
+    assert installed == open(os.path.join(ROOT, "orb_slam2_amd", "cpp", "ORBmatcher.cc")).read()              # the matcher is installed, not spliced
+    assert "abort();" not in installed and "orbhip_project_search_frame" in installed and installed.count("orbhip_check(orbhip_") >= 10
+    # the ONE line the map point's header gains (and the macro that tells ORBmatcher.cc it is there)
+    ref_mp, new_mp = open(os.path.join(REF, "include/MapPoint.h")).read().splitlines(), (co / "include/MapPoint.h").read_text().splitlines()
+    added = [l for l in new_mp if l not in ref_mp]
+    assert len(added) == 2 and any("friend class ORBmatcher;" in l for l in added) and any("#define ORBHIP_MAPPOINT_FRIEND" in l for l in added) and len(new_mp) == len(ref_mp) + 2
     assert "BindFrame(mnId)" in (co / "src/Frame.cc").read_text()
-    # the patched translation units compile against the drop-in headers (the flags of oracle/Makefile's dropin_full rule, -fsyntax-only)
-    ora = os.path.join(ROOT, "oracle")
-    flags = ["-std=c++14", "-fsyntax-only", "-w", "-DCVLITE_ALGEBRA", "-DORBHIP_USE_OPENCV", "-DORBSLAM_DROPIN_BUILD", "-DORBHIP_USE_DBOW2_TYPES",
-             "-include", os.path.join(ora, "ref_shim/dropin/ORBVocabulary.h"), "-include", os.path.join(ora, "ref_shim/dropin/ORBextractor.h"),
-             "-I" + os.path.join(ora, "ref_shim/dropin"), "-I" + os.path.join(ora, "ref_shim"), "-I" + os.path.join(REF, "include"), "-I" + REF,
-             "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(REF, "Thirdparty/DBoW2")]
     for rel in ("src/ORBmatcher.cc", "src/Frame.cc"):
-        r = subprocess.run(["g++"] + flags + [str(co / rel)], capture_output=True, text=True)
+        r = subprocess.run(["g++"] + _flags(co) + [str(co / rel)], capture_output=True, text=True)
         assert r.returncode == 0, rel + ":\n" + r.stderr[-3000:]
+    # without the friend line the matcher refuses to compile, and says why
+    shutil.copyfile(os.path.join(REF, "include/MapPoint.h"), co / "include/MapPoint.h")
+    r = subprocess.run(["g++"] + _flags(co) + [str(co / "src/ORBmatcher.cc")], capture_output=True, text=True)
+    assert r.returncode != 0 and "friend class ORBmatcher" in r.stderr
+
+
+def _flags(co):
+    """the flags of oracle/Makefile's all-steps rule, -fsyntax-only, with the checkout's own include/ first (a real tree's headers find each other there)"""
+    ora = os.path.join(ROOT, "oracle")
+    return ["-std=c++14", "-fsyntax-only", "-w", "-DCVLITE_ALGEBRA", "-DORBHIP_USE_OPENCV", "-DORBSLAM_DROPIN_BUILD", "-DORBHIP_USE_DBOW2_TYPES",
+            "-include", os.path.join(ora, "ref_shim/dropin/ORBVocabulary.h"),
+            "-I" + str(co / "include"), "-I" + os.path.join(ora, "ref_shim"), "-I" + REF, "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(REF, "Thirdparty/DBoW2")]
 
 
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src")), reason="reference sources not mounted")
@@ -73,11 +86,15 @@ def test_optional_steps(tmp_path):
     shutil.copyfile(one / "src/Frame.cc", twice / "src/Frame.cc")
     r = subprocess.run([sys.executable, SCRIPT, "--files", "--stereo-one-call", str(twice / "src/Frame.cc"), str(tmp_path / "x.cc")], capture_output=True, text=True)
     assert r.returncode != 0 and "not found" in (r.stderr + r.stdout)
-    ora = os.path.join(ROOT, "oracle")
-    flags = ["-std=c++14", "-fsyntax-only", "-w", "-DCVLITE_ALGEBRA", "-DORBHIP_USE_OPENCV", "-DORBSLAM_DROPIN_BUILD", "-DORBHIP_USE_DBOW2_TYPES",
-             "-include", os.path.join(ora, "ref_shim/dropin/ORBVocabulary.h"), "-include", os.path.join(ora, "ref_shim/dropin/ORBextractor.h"),
-             "-I" + os.path.join(ora, "ref_shim/dropin"), "-I" + os.path.join(ora, "ref_shim"), "-I" + os.path.join(REF, "include"), "-I" + REF,
-             "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(REF, "Thirdparty/DBoW2")]
+    # ... and so is a MapPoint.h whose class head differs from upstream
+    (twice / "include/MapPoint.h").write_text(open(os.path.join(REF, "include/MapPoint.h")).read().replace("class MapPoint", "class MapPoint final"))
+    r = subprocess.run([sys.executable, SCRIPT, "--files", os.path.join(REF, "src/Frame.cc"), str(tmp_path / "y.cc"), str(twice / "include/MapPoint.h"), str(tmp_path / "y.h")], capture_output=True, text=True)
+    assert r.returncode != 0 and "not found" in (r.stderr + r.stdout)
+    co = tmp_path / "co"
+    shutil.copytree(os.path.join(REF, "include"), co / "include")
+    os.remove(co / "include/Converter.h")
+    for rel in ("include/ORBextractor.h", "include/ORBmatcher.h", "include/orbhip.h", "include/ORBmatcherBatch.h", "include/MapPoint.h"):
+        shutil.copyfile(one / rel, co / rel)
     for rel in ("src/ORBmatcher.cc", "src/Frame.cc"):
-        r = subprocess.run(["g++"] + flags + [str(one / rel)], capture_output=True, text=True)
+        r = subprocess.run(["g++"] + _flags(co) + [str(one / rel)], capture_output=True, text=True)
         assert r.returncode == 0, rel + ":\n" + r.stderr[-3000:]

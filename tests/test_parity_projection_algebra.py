@@ -1,0 +1,178 @@
+"""The per-point algebra of the five projection-guided ORBmatcher members ON THE DEVICE (orbhip_project_search_* / orbhip_project_best_in_window_*):
+world point -> camera frame -> depth / image-bounds / distance / viewing-angle gates -> MapPoint::PredictScale -> radius, ORBmatcher.cc:316-362, 850-892,
+1004-1051, 1154-1191, 1234-1271, 1353-1395, 1490-1528.
+
+1. Bit for bit against the oracle's restatement of those statements (oracle/orb_oracle.cpp: ProjectPoint), on GENERAL poses (random rotations, translations,
+   similarity scales) and points scattered through and around the frustum: every derived query - u, v, radius, ur, level window - and which points a gate
+   drops, for all six statement sequences and both roundings of `R*x+t`.  The oracle evaluates PredictScale as MapPoint.cc writes it
+   (ceil(logf(ratio)/logScaleFactor)); the device compares the ratio with the thresholds orbhip_predict_scale_table derives from that expression - so the
+   test also pins the table, including ratios that sit exactly ON a level boundary (mfMaxDistance = dist * 1.2^k is how ORB_SLAM2 initialises it).
+2. The searches that follow are the flat-query entry points' (already pinned): the project_* entries must return exactly what the flat entries return
+   for the queries the oracle derives.
+Emulation on the CPU, the real library with -m gpu."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+import orb_slam2_amd  # noqa: E402
+from orb_slam2_amd import orbhip as H  # noqa: E402
+from orb_slam2_amd import synth  # noqa: E402
+
+W, HT, FX, FY, CX, CY = 752, 480, 435.2, 435.2, 367.2, 252.2
+KINDS = {"last_frame": H.PROJ_LAST_FRAME, "frame_kf": H.PROJ_FRAME_KF, "kf_sim3": H.PROJ_KF_SIM3, "fuse": H.PROJ_FUSE, "fuse_sim3": H.PROJ_FUSE_SIM3, "sim3": H.PROJ_SIM3}
+
+
+def _rot(rng, max_deg):
+    a = np.deg2rad(rng.uniform(-max_deg, max_deg, 3))
+    cx, sx, cy, sy, cz, sz = np.cos(a[0]), np.sin(a[0]), np.cos(a[1]), np.sin(a[1]), np.cos(a[2]), np.sin(a[2])
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]); Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]); Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+_tables = {}
+
+
+def _table(log_sf, nlevels, library):
+    """PredictScale's thresholds from the ORACLE's expression (this machine's logf), as the C++ drop-in derives them from its own"""
+    from oracle import orb_oracle as O
+    key = (float(log_sf), nlevels, library)
+    if key not in _tables:
+        _tables[key] = H.predict_scale_table(log_sf, nlevels, level_of=lambda r: O.predict_scale_of_ratio(r, log_sf, nlevels), library=library)
+    return _tables[key]
+
+
+def _case(rng, kind, gemm, nlevels=8, scale=1.2, npts=600):
+    """one call of a member: a projection and the map points it reads"""
+    sf = np.ones(nlevels, np.float32)
+    for i in range(1, nlevels):
+        sf[i] = np.float32(np.float64(sf[i - 1]) * np.float64(np.float32(scale)))              # mvScaleFactors as ORBextractor.cc:415-423 builds them
+    log_sf = np.float32(np.log(np.float32(scale)))                                               # Frame.cc:71: mfLogScaleFactor = log(mfScaleFactor)
+    R = _rot(rng, 25.0); t = rng.uniform(-1.5, 1.5, 3)
+    R2 = _rot(rng, 10.0) * rng.uniform(0.8, 1.25); t2 = rng.uniform(-0.5, 0.5, 3)
+    Ow = -(R.T @ t)
+    # points: where the camera sees them (most inside the image, some outside, some behind), then back into the world
+    u = rng.uniform(-60, W + 60, npts); v = rng.uniform(-60, HT + 60, npts); z = rng.uniform(0.8, 12.0, npts)
+    z[rng.random(npts) < 0.05] *= -1.0
+    cam = np.stack([(u - CX) / FX * z, (v - CY) / FY * z, z], 1)
+    if kind == "sim3":
+        cam = (np.linalg.inv(R2) @ (cam - t2).T).T
+    world = (R.T @ (cam - t).T).T
+    pts = np.zeros(npts, H.MAP_POINT_DTYPE)
+    pts["x"], pts["y"], pts["z"] = world[:, 0], world[:, 1], world[:, 2]
+    w32 = np.stack([pts["x"], pts["y"], pts["z"]], 1).astype(np.float64)
+    d = np.linalg.norm(w32 - Ow.astype(np.float32).astype(np.float64), axis=1) if kind != "sim3" else np.abs(z) * np.sqrt(((u - CX) / FX) ** 2 + ((v - CY) / FY) ** 2 + 1)
+    nrm = (w32 - Ow) / np.maximum(np.linalg.norm(w32 - Ow, axis=1, keepdims=True), 1e-9)
+    nrm = (np.stack([_rot(rng, 70.0) @ n for n in nrm]))                                         # viewing directions up to ~70 degrees off: the 60 degree gate splits them
+    pts["nx"], pts["ny"], pts["nz"] = nrm[:, 0], nrm[:, 1], nrm[:, 2]
+    lvl = rng.integers(0, nlevels, npts)
+    # mfMaxDistance = dist * sf[level] exactly (how UpdateNormalAndDepth sets it, MapPoint.cc:366: the ratio then sits ON the level boundary), or anywhere
+    exact = rng.random(npts) < 0.5
+    md = np.where(exact, d.astype(np.float32) * sf[lvl], (d * np.float64(scale) ** rng.uniform(-1.5, nlevels + 0.5, npts)).astype(np.float32)).astype(np.float32)
+    pts["scale_dist"] = md
+    pts["max_dist"] = np.float32(1.2) * md
+    pts["min_dist"] = np.float32(0.8) * (md / sf[nlevels - 1])
+    wide = rng.random(npts) < 0.3                                                                 # and some points whose range does not gate
+    pts["min_dist"][wide] = 0.0; pts["max_dist"][wide] = 1e30
+    pts["level"] = lvl if kind == "last_frame" else -1
+    pts["blocks"] = rng.integers(0, 2, npts); pts["angle"] = rng.uniform(0, 360, npts).astype(np.float32)
+    bounds = (0.0, 0.0, float(W), float(HT))
+    lr = _table(log_sf, nlevels, _case.library)
+    P = H.make_projection(KINDS[kind], R, t, FX, FY, CX, CY, bounds, float(rng.choice([3.0, 7.0, 15.0])), sf, lr, Ow=Ow, bf=float(rng.uniform(20, 400)), R2=R2, t2=t2, gemm_mode=gemm,
+                          forward=bool(rng.random() < 0.3), backward=bool(rng.random() < 0.2))
+    if gemm == 2:                                                                                # the caller's own transform: here the oracle's generic-kernel form
+        P0 = H.make_projection(KINDS[kind], R, t, FX, FY, CX, CY, bounds, P.th, sf, lr, Ow=Ow, bf=P.bf, R2=R2, t2=t2, gemm_mode=0)
+        Rf, tf = np.asarray(R, np.float32), np.asarray(t, np.float32)
+        c = np.stack([(np.float32(1) * (Rf[r].astype(np.float64) @ w32.T)).astype(np.float32) + tf[r] for r in range(3)], 1)
+        if kind == "sim3":
+            R2f, t2f = np.asarray(R2, np.float32), np.asarray(t2, np.float32)
+            c = np.stack([(R2f[r].astype(np.float64) @ c.astype(np.float64).T).astype(np.float32) + t2f[r] for r in range(3)], 1)
+        pts["cam_x"], pts["cam_y"], pts["cam_z"] = c[:, 0], c[:, 1], c[:, 2]
+        del P0
+    return P, pts, log_sf, bounds
+
+
+@pytest.fixture(scope="module")
+def frame():
+    rng = np.random.default_rng(77)
+    n = 900
+    kps = np.zeros(n, orb_slam2_amd.KEYPOINT_DTYPE)
+    kps["x"] = rng.uniform(0, W, n).astype(np.float32); kps["y"] = rng.uniform(0, HT, n).astype(np.float32)
+    kps["octave"] = rng.integers(0, 8, n); kps["angle"] = rng.uniform(0, 360, n).astype(np.float32); kps["size"] = 31.0
+    desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    ur = np.where(rng.random(n) < 0.6, kps["x"] - rng.uniform(1, 60, n), -1.0).astype(np.float32)
+    return kps, desc, ur
+
+
+@pytest.mark.parametrize("gemm", [0, 1, 2])
+@pytest.mark.parametrize("kind", list(KINDS))
+def test_device_projection_equals_the_oracle(backend, oracle, frame, kind, gemm):
+    _case.library = backend
+    kps, desc, ur = frame
+    rng = np.random.default_rng(1000 * KINDS[kind] + gemm)
+    total = dropped = 0
+    for rep in range(3):
+        nlevels, scale = ((8, 1.2), (5, 1.5), (12, 1.1))[rep]
+        P, pts, log_sf, bounds = _case(rng, kind, gemm, nlevels, scale)
+        pdesc = desc[rng.integers(0, len(desc), len(pts))] ^ (rng.random((len(pts), 32)) < 0.04).astype(np.uint8)       # near-copies of the frame's descriptors
+        want = oracle.project_points(bytes(P), pts, log_sf)
+        live = want[:, 0] > 0
+        if kind in ("last_frame", "frame_kf", "kf_sim3"):
+            blocked = (rng.random(len(kps)) < 0.2).astype(np.uint8)
+            nm, fq, q = H.project_search(kps, desc, bounds, P, pts, pdesc, nnratio=0.9, th_high=100, check_ori=kind != "kf_sim3", u_right=ur if kind == "last_frame" else None,
+                                         blocked=blocked, library=backend)
+            assert np.array_equal(q["radius"] >= 0, live), f"{kind} gemm {gemm}: the device and the oracle drop different points"
+            for name, col in (("x", 1), ("y", 2), ("radius", 3), ("ur", 4)):
+                assert q[name][live].tobytes() == want[live, col].tobytes(), f"{kind} gemm {gemm}: {name} differs"
+            assert np.array_equal(q["min_level"][live], want[live, 6].astype(np.int32)) and np.array_equal(q["max_level"][live], want[live, 7].astype(np.int32))
+            assert np.array_equal(q["blocks"], pts["blocks"]) and q["angle"].tobytes() == pts["angle"].tobytes()
+            # the search behind the projection == the flat-query entry on the oracle's queries
+            flat = np.zeros(int(live.sum()), H.PROJ_QUERY_DTYPE)
+            flat["x"], flat["y"], flat["radius"], flat["ur"] = want[live, 1], want[live, 2], want[live, 3], want[live, 4]
+            flat["min_level"], flat["max_level"], flat["blocks"], flat["angle"] = want[live, 6], want[live, 7], pts["blocks"][live], pts["angle"][live]
+            nm2, fq2 = H.search_by_projection(kps, desc, W, HT, flat, pdesc[live], 1, nnratio=0.9, th_high=100, check_ori=kind != "kf_sim3", u_right=ur if kind == "last_frame" else None,
+                                              blocked=blocked, library=backend, bounds=bounds)
+            back = np.flatnonzero(live)
+            assert nm == nm2 and np.array_equal(np.where(fq >= 0, fq, fq), np.where(fq2 >= 0, back[np.maximum(fq2, 0)], fq2))
+        else:
+            inv = (1.0 / (np.asarray(P.scale_factors[:P.nlevels], np.float32) ** 2)).astype(np.float32)
+            chi2 = kind == "fuse"
+            bi, bd, q = H.project_best_in_window(kps, desc, bounds, inv, P, pts, pdesc, chi2, u_right=ur if chi2 else None, library=backend)
+            assert np.array_equal(q["radius"] >= 0, live), f"{kind} gemm {gemm}: the device and the oracle drop different points"
+            for name, col in (("x", 1), ("y", 2), ("radius", 3), ("ur", 4)):
+                assert q[name][live].tobytes() == want[live, col].tobytes(), f"{kind} gemm {gemm}: {name} differs"
+            assert np.array_equal(q["level"][live], want[live, 5].astype(np.int32))
+            flat = np.zeros(int(live.sum()), H.BEST_QUERY_DTYPE)
+            flat["x"], flat["y"], flat["radius"], flat["ur"], flat["level"] = want[live, 1], want[live, 2], want[live, 3], want[live, 4], want[live, 5]
+            bi2, bd2 = H.search_best_in_window(kps, desc, W, HT, inv, flat, pdesc[live], chi2, u_right=ur if chi2 else None, library=backend, bounds=bounds)
+            assert np.array_equal(bi[live], bi2) and np.array_equal(bd[live], bd2) and (bi[~live] == -1).all() and (bd[~live] == 256).all()
+            # ... and as slots of the batch entry (SearchBySim3's two directions / FuseBatch's targets)
+            outs = H.project_best_in_window_batch([dict(kps=kps, desc=desc, u_right=ur if chi2 else None, bounds=bounds, inv_level_sigma2=inv, proj=P, points=pts, pdesc=pdesc)] * 2, chi2, library=backend)
+            for o in outs:
+                assert np.array_equal(o[0], bi) and np.array_equal(o[1], bd)
+        total += len(pts); dropped += int((~live).sum())
+    assert 0.15 * total < dropped < 0.9 * total, (kind, total, dropped)          # the gates are exercised, and so is what lies behind them
+
+
+def test_predict_scale_table_equals_the_expression(backend, oracle):
+    """level_ratio thresholds against MapPoint::PredictScale's expression itself (the oracle's, on this machine's logf): on the floats around every
+    threshold, at exact powers of the scale factor and on a random sweep"""
+    for nlevels, scale in ((8, 1.2), (5, 1.5), (12, 1.1), (16, 1.05), (1, 1.2)):
+        log_sf = np.float32(np.log(np.float32(scale)))
+        lr = _table(log_sf, nlevels, backend)
+        assert np.all(np.isinf(lr[max(nlevels - 1, 0):])) and np.all(np.diff(lr[:max(nlevels - 1, 0)]) > 0)
+        rng = np.random.default_rng(nlevels)
+        ratios = [np.exp(rng.uniform(-3, 3, 3000)).astype(np.float32), np.array([0.0, np.inf, np.nan, 1e-45, 3e38], np.float32),
+                  (np.float32(scale) ** np.arange(-2, nlevels + 2)).astype(np.float32)]
+        for t in lr[:max(nlevels - 1, 0)]:
+            b = np.frombuffer(np.float32(t).tobytes(), np.uint32)[0]
+            ratios.append(np.arange(b - 300, b + 300, dtype=np.uint32).view(np.float32))
+        r = np.concatenate(ratios)
+        want = np.array([oracle.predict_scale_of_ratio(x, log_sf, nlevels) for x in r], np.int32)
+        got = np.where(np.isfinite(r), (r[:, None] >= lr[None, :max(nlevels - 1, 0)]).sum(1), 0).astype(np.int32)      # (pj_predict_scale: a NaN / infinite ratio is level 0)
+        assert np.array_equal(want, got)
