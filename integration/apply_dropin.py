@@ -6,6 +6,7 @@
     ... --stereo-one-call        optional: the stereo Frame constructor extracts both images in ONE call on one device context (ORBextractor::ExtractStereo)
     ... --device-rgbd            optional: Frame::ComputeStereoFromRGBD samples the depth map on the device (default: the reference's loop + N floats uploaded)
     ... --resident-bow           optional (with this repository's ORBVocabulary class in place, step 3e): Frame::ComputeBoW reads the descriptors in HBM
+    ... --skip-host-grid         optional: Frame::AssignFeaturesToGrid does nothing - with this repository's ORBmatcher.cc nobody reads the host's 64 x 48 grid
 
 What it produces (nothing else of the checkout changes; Tracking.cc, LocalMapping.cc, LoopClosing.cc, KeyFrame*.cc, MapPoint.cc compile as they are):
   REPLACED by this repository's files (an installer's copy, no text surgery):
@@ -132,10 +133,20 @@ RESIDENT_BOW_BODY = """{
 }"""
 
 
-def patch_frame(src, stereo_one_call=False, resident_bow=False, device_rgbd=False):
+# optional, --skip-host-grid: Frame::AssignFeaturesToGrid (Frame.cc:230-245) fills the 64 x 48 vectors that only Frame::GetFeaturesInArea / KeyFrame::GetFeaturesInArea
+# read - and those two are called from src/ORBmatcher.cc alone, which is now this repository's file and searches the grid the DEVICE builds from the same key
+# points (k_match_grid).  With the flag the host grid stays empty: no 3072 vector reservations per Frame, nothing to copy in Frame(const Frame&) and KeyFrame().
+# Leave it out if your fork reads mGrid / GetFeaturesInArea elsewhere.
+GRID_SIG = r"void\s+Frame::AssignFeaturesToGrid\s*\(\s*\)"
+GRID_BODY = "{ /* orbhip drop-in (--skip-host-grid): the feature grid is built on the device by the matcher entry points; nothing on the host reads mGrid */ }"
+
+
+def patch_frame(src, stereo_one_call=False, resident_bow=False, device_rgbd=False, skip_host_grid=False):
     for sig, body in FORWARDS.items():
         src = replace_body(src, sig, body)
     src = replace_body(src, RGBD_SIG, RGBD_DEVICE_BODY) if device_rgbd else append_to_body(src, RGBD_SIG, RGBD_APPEND)
+    if skip_host_grid:
+        src = replace_body(src, GRID_SIG, GRID_BODY)
     if resident_bow:
         src = replace_body(src, RESIDENT_BOW_SIG, RESIDENT_BOW_BODY)
     if stereo_one_call:
@@ -152,8 +163,9 @@ def main():
         one_call = "--stereo-one-call" in argv
         rbow = "--resident-bow" in argv
         drgbd = "--device-rgbd" in argv
-        argv = [a for a in argv[1:] if a not in ("--stereo-one-call", "--resident-bow", "--device-rgbd")]
-        open(argv[1], "w").write(patch_frame(open(argv[0]).read(), stereo_one_call=one_call, resident_bow=rbow, device_rgbd=drgbd))
+        nogrid = "--skip-host-grid" in argv
+        argv = [a for a in argv[1:] if a not in ("--stereo-one-call", "--resident-bow", "--device-rgbd", "--skip-host-grid")]
+        open(argv[1], "w").write(patch_frame(open(argv[0]).read(), stereo_one_call=one_call, resident_bow=rbow, device_rgbd=drgbd, skip_host_grid=nogrid))
         if len(argv) > 3:
             os.makedirs(os.path.dirname(argv[3]) or ".", exist_ok=True)
             open(argv[3], "w").write(patch_mappoint_header(open(argv[2]).read()))
@@ -161,14 +173,15 @@ def main():
     one_call = "--stereo-one-call" in argv
     rbow = "--resident-bow" in argv
     drgbd = "--device-rgbd" in argv
-    argv = [a for a in argv if a not in ("--stereo-one-call", "--resident-bow", "--device-rgbd")]
+    nogrid = "--skip-host-grid" in argv
+    argv = [a for a in argv if a not in ("--stereo-one-call", "--resident-bow", "--device-rgbd", "--skip-host-grid")]
     emit_patch = bool(argv) and argv[0] == "--patch"
     if emit_patch:
         argv = argv[1:]
     if len(argv) < (1 if emit_patch else 2):
         raise SystemExit(__doc__)
     ref = argv[0]
-    edited = {"src/Frame.cc": patch_frame(open(os.path.join(ref, "src/Frame.cc")).read(), stereo_one_call=one_call, resident_bow=rbow, device_rgbd=drgbd),
+    edited = {"src/Frame.cc": patch_frame(open(os.path.join(ref, "src/Frame.cc")).read(), stereo_one_call=one_call, resident_bow=rbow, device_rgbd=drgbd, skip_host_grid=nogrid),
               "include/MapPoint.h": patch_mappoint_header(open(os.path.join(ref, "include/MapPoint.h")).read())}
     copies = {"include/ORBextractor.h": "include/ORBextractor.h", "src/ORBextractor.cc": "orb_slam2_amd/cpp/ORBextractor.cc", "include/orbhip.h": "include/orbhip.h",
               "include/ORBmatcher.h": "include/ORBmatcher.h", "src/ORBmatcher.cc": "orb_slam2_amd/cpp/ORBmatcher.cc", "include/ORBmatcherBatch.h": "include/ORBmatcherBatch.h",

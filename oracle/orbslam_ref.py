@@ -366,13 +366,13 @@ def search_by_sim3(f1, has1, X1, Y1, Z1, level1, desc1, f2, has2, X2, Y2, Z2, le
 def _collect_loop(L, n, capture):
     out = []
     for k in range(n):
-        cnt = np.zeros(8, np.int32); ms = np.zeros(4, np.float64)
+        cnt = np.zeros(8, np.int32); ms = np.zeros(6, np.float64)
         L.orbslam_ref_loop_get(k, _p(cnt), _p(ms), None, None, None, None, None, None, None)
         fr = LoopFrame()
         for name, v in zip(LoopFrame.FIELDS + ("n_extra",), cnt):
             setattr(fr, name, int(v))
         fr.bow_hash = int(L.orbslam_ref_loop_bow_hash(k))
-        fr.ms, fr.ms_ctor, fr.ms_motion, fr.ms_local = (float(v) for v in ms)
+        fr.ms, fr.ms_ctor, fr.ms_motion, fr.ms_local = (float(v) for v in ms[:4])
         N = fr.N if capture else 0
         fr.keys = np.zeros(N, KEYPOINT_DTYPE); fr.keys_un = np.zeros(N, KEYPOINT_DTYPE); fr.desc = np.zeros((N, 32), np.uint8)
         fr.u_right = np.zeros(N, np.float32); fr.depth = np.zeros(N, np.float32); fr.mp_motion = np.full(N, -1, np.int32); fr.mp_final = np.full(N, -1, np.int32)
@@ -449,12 +449,12 @@ def tracking_loop(lefts, rights, Tcw, Tpred, nfeatures, fx, fy, cx, cy, bf, th_d
     assert got == n
     out = []
     for k in range(n):
-        cnt = np.zeros(8, np.int32); ms = np.zeros(4, np.float64)
+        cnt = np.zeros(8, np.int32); ms = np.zeros(6, np.float64)
         L.orbslam_ref_loop_get(k, _p(cnt), _p(ms), None, None, None, None, None, None, None)
         fr = LoopFrame()
         for name, v in zip(LoopFrame.FIELDS, cnt):
             setattr(fr, name, int(v))
-        fr.ms, fr.ms_ctor, fr.ms_motion, fr.ms_local = (float(v) for v in ms)
+        fr.ms, fr.ms_ctor, fr.ms_motion, fr.ms_local, fr.ms_frustum, fr.ms_copy = (float(v) for v in ms)
         N = fr.N if capture else 0
         fr.keys = np.zeros(N, KEYPOINT_DTYPE); fr.keys_un = np.zeros(N, KEYPOINT_DTYPE); fr.desc = np.zeros((N, 32), np.uint8)
         fr.u_right = np.zeros(N, np.float32); fr.depth = np.zeros(N, np.float32); fr.mp_motion = np.full(N, -1, np.int32); fr.mp_final = np.full(N, -1, np.int32)

@@ -721,6 +721,7 @@ struct LoopFrame {
     int N = 0, nMotion = 0, usedWide = 0, nToMatch = 0, nLocal = 0, nNewPoints = 0, nLocalPoints = 0, nExtra = 0;
     uint64_t bowHash = 0;                       // mBowVec + mFeatVec of the frame where the sequence computed them (orbslam_ref_sequence_loop)
     double ms = 0, msCtor = 0, msMotion = 0, msLocal = 0;      // whole frame; Frame constructor; TrackWithMotionModel's search; SearchLocalPoints
+    double msFrustum = 0, msCopy = 0;                           // of msLocal: the isInFrustum loop (the reference's host code); mLastFrame = Frame(mCurrentFrame)
     std::vector<cv::KeyPoint> keys, keysUn; std::vector<uint8_t> desc; std::vector<float> uRight, depth;
     std::vector<int> mpMotion, mpFinal;         // MapPoint::mnId per feature after TrackWithMotionModel / after SearchLocalPoints (-1 = none)
 };
@@ -821,19 +822,23 @@ static int tracking_loop_impl(int nframes, const uint8_t* const* left, const uin
                 else { pMP->IncreaseVisible(); pMP->mnLastFrameSeen = C->mnId; pMP->mbTrackInView = false; }
             }
             int nToMatch = 0;
+            const auto tf0 = std::chrono::steady_clock::now();
             for (std::vector<MapPoint*>::iterator vit = local.begin(); vit != local.end(); vit++) {
                 MapPoint* pMP = *vit;
                 if (pMP->mnLastFrameSeen == C->mnId) continue;
                 if (pMP->isBad()) continue;
                 if (C->isInFrustum(pMP, 0.5)) { pMP->IncreaseVisible(); nToMatch++; }
             }
+            o.msFrustum = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tf0).count();
             o.nToMatch = nToMatch;
             if (nToMatch > 0) { ORBmatcher m2(0.8); o.nLocal = m2.SearchByProjection(*C, local, 1); }
             o.msLocal = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t3).count();
             t0skip = std::chrono::duration<double, std::milli>(t3 - t2).count();
             if (kf_every > 0 && k % kf_every == 0) o.nNewPoints = create_points(*C, local, false);       // NeedNewKeyFrame stands for "every kf_every frames"
         }
+        const auto tc0 = std::chrono::steady_clock::now();
         Frame* copy = new Frame(*C);                                                                     // mLastFrame = Frame(mCurrentFrame), Tracking.cc:497
+        o.msCopy = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count();
         o.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() - t0skip;
         o.N = C->N; o.nLocalPoints = (int)local.size();
         if (capture) {
@@ -1201,12 +1206,12 @@ int orbslam_ref_local_mapping_loops(int nn, void* const* frames, const float* F1
 void orbslam_ref_local_mapping_ms(double* tri_ms, double* fuse_ms) { *tri_ms = g_loop_ms[0]; *fuse_ms = g_loop_ms[1]; }
 
 // counts[8] = N, nMotion, usedWide, nToMatch, nLocal, nNewPoints, nLocalPoints, 0; every pointer may be NULL
-int orbslam_ref_loop_get(int k, int* counts, double* ms /* 4: frame, constructor, motion-model search, local-map search */, void* keys, void* keysUn, uint8_t* desc, float* uRight, float* depth, int* mpMotion, int* mpFinal)
+int orbslam_ref_loop_get(int k, int* counts, double* ms /* 6: frame, constructor, motion-model search, local-map search, of which isInFrustum, Frame copy */, void* keys, void* keysUn, uint8_t* desc, float* uRight, float* depth, int* mpMotion, int* mpFinal)
 {
     if (k < 0 || k >= (int)g_loop.size()) return -1;
     const LoopFrame& o = g_loop[k];
     if (counts) { counts[0] = o.N; counts[1] = o.nMotion; counts[2] = o.usedWide; counts[3] = o.nToMatch; counts[4] = o.nLocal; counts[5] = o.nNewPoints; counts[6] = o.nLocalPoints; counts[7] = o.nExtra; }
-    if (ms) { ms[0] = o.ms; ms[1] = o.msCtor; ms[2] = o.msMotion; ms[3] = o.msLocal; }
+    if (ms) { ms[0] = o.ms; ms[1] = o.msCtor; ms[2] = o.msMotion; ms[3] = o.msLocal; ms[4] = o.msFrustum; ms[5] = o.msCopy; }
     const size_t n = o.keys.size();
     if (keys && n) memcpy(keys, &o.keys[0], n * 28);
     if (keysUn && n) memcpy(keysUn, &o.keysUn[0], n * 28);

@@ -125,44 +125,69 @@ void ORBmatcher::ComputeThreeMaxima(vector<int>* histo, const int L, int &ind1, 
 // type the one-line friend declaration in include/MapPoint.h reaches.
 struct ORBmatcher::Access
 {
-    static inline void Point(MapPoint* pMP, orbhip_map_point &o, bool bRange)
+    // Everything a member reads of one map point in ONE visit: mMutexFeatures then mMutexPos, the order MapPoint::isBad() takes them (MapPoint.cc:170-175) -
+    // two lock operations per point where the reference's isBad() + GetWorldPos() + GetNormal() + Get{Min,Max}DistanceInvariance() + GetDescriptor() +
+    // Observations() take eight, and no cv::Mat clone.  Returns false for a bad point (nothing else is read then).
+    static inline bool Read(MapPoint* pMP, orbhip_map_point &o, unsigned char* d32, bool bRange, bool bSkipBad, int &nObs)
     {
-        unique_lock<mutex> lock(pMP->mMutexPos);
-        const cv::Mat &w = pMP->mWorldPos;
-        o.x = w.at<float>(0); o.y = w.at<float>(1); o.z = w.at<float>(2);
+        unique_lock<mutex> lock1(pMP->mMutexFeatures);
+        unique_lock<mutex> lock2(pMP->mMutexPos);
+        if(bSkipBad && pMP->mbBad) return false;
+        nObs = pMP->nObs;
+        memcpy(d32, pMP->mDescriptor.ptr<unsigned char>(), 32);
+        const float* w = pMP->mWorldPos.ptr<float>();             // 3 x 1 CV_32F made by copyTo / clone: continuous
+        const size_t ws = pMP->mWorldPos.step/sizeof(float);
+        o.x = w[0]; o.y = w[ws]; o.z = w[2*ws];
         if(bRange)
         {
-            const cv::Mat &nv = pMP->mNormalVector;
-            o.nx = nv.at<float>(0); o.ny = nv.at<float>(1); o.nz = nv.at<float>(2);
+            const float* nv = pMP->mNormalVector.ptr<float>(); const size_t ns = pMP->mNormalVector.step/sizeof(float);
+            o.nx = nv[0]; o.ny = nv[ns]; o.nz = nv[2*ns];
             o.min_dist = 0.8f*pMP->mfMinDistance;          // GetMinDistanceInvariance(), MapPoint.cc:373-377
             o.max_dist = 1.2f*pMP->mfMaxDistance;          // GetMaxDistanceInvariance(), MapPoint.cc:379-383
             o.scale_dist = pMP->mfMaxDistance;             // PredictScale's numerator, MapPoint.cc:390, 407
         }
+        return true;
     }
     static inline void Descriptor(MapPoint* pMP, unsigned char* d32)
     {
         unique_lock<mutex> lock(pMP->mMutexFeatures);
         memcpy(d32, pMP->mDescriptor.ptr<unsigned char>(), 32);
     }
+    // isBad() + Observations() + GetDescriptor() of a point whose projection the caller already holds (Tracking::SearchLocalPoints): one lock.
+    // (SetBadFlag writes mbBad under BOTH mutexes, MapPoint.cc:137-153: holding one of them excludes it.)
+    static inline bool Tracked(MapPoint* pMP, unsigned char* d32, int &nObs)
+    {
+        unique_lock<mutex> lock(pMP->mMutexFeatures);
+        if(pMP->mbBad) return false;
+        nObs = pMP->nObs;
+        memcpy(d32, pMP->mDescriptor.ptr<unsigned char>(), 32);
+        return true;
+    }
 };
-static inline void orbhip_read_point(MapPoint* pMP, orbhip_map_point &o, bool bRange) { ORBmatcher::Access::Point(pMP, o, bRange); }
 static inline void orbhip_read_descriptor(MapPoint* pMP, unsigned char* d32) { ORBmatcher::Access::Descriptor(pMP, d32); }
 struct OrbhipPoints
 {
     std::vector<orbhip_map_point> pts; std::vector<unsigned char> desc; std::vector<MapPoint*> owner; std::vector<int> index;
-    void reserve(size_t n) { pts.reserve(n); desc.reserve(32*n); owner.reserve(n); index.reserve(n); }
-    size_t size() const { return pts.size(); }
-    // level >= 0: given by the caller; -1: MapPoint::PredictScale on the device
-    void add(MapPoint* pMP, int idx, bool bRange, int level, int blocks, float angle)
+    size_t n;
+    OrbhipPoints() : n(0) {}
+    // room for `cap` points up front: add() writes in place, the vectors are cut to size by done()
+    void reserve(size_t cap) { pts.resize(cap); desc.resize(32*cap); owner.resize(cap); index.resize(cap); n = 0; }
+    size_t size() const { return n; }
+    // level >= 0: given by the caller; -1: MapPoint::PredictScale on the device.  blocks < 0: Observations() > 0 of the point itself.  false: the point is bad (bSkipBad)
+    bool add(MapPoint* pMP, int idx, bool bRange, bool bSkipBad, int level, int blocks, float angle)
     {
-        orbhip_map_point o; memset(&o, 0, sizeof o);
-        orbhip_read_point(pMP, o, bRange);
-        o.level = level; o.blocks = blocks; o.angle = angle;
-        pts.push_back(o);
-        desc.resize(desc.size()+32);
-        orbhip_read_descriptor(pMP, &desc[desc.size()-32]);
-        owner.push_back(pMP); index.push_back(idx);
+        if(n==pts.size()) { const size_t cap = std::max<size_t>(2*n, 64); pts.resize(cap); desc.resize(32*cap); owner.resize(cap); index.resize(cap); }
+        orbhip_map_point &o = pts[n];
+        int nObs = 0;
+        if(!ORBmatcher::Access::Read(pMP, o, &desc[32*n], bRange, bSkipBad, nObs)) return false;
+        o.cam_x = o.cam_y = o.cam_z = 0.f;
+        if(!bRange) { o.nx = o.ny = o.nz = o.min_dist = o.max_dist = o.scale_dist = 0.f; }
+        o.level = level; o.blocks = blocks<0 ? (nObs>0) : blocks; o.angle = angle;
+        owner[n] = pMP; index[n] = idx;
+        n++;
+        return true;
     }
+    void done() { pts.resize(std::max<size_t>(n,1)); desc.resize(32*std::max<size_t>(n,1)); owner.resize(n); index.resize(n); }
 };
 
 // ---- how the linked cv::Mat rounds `R*x+t` (header of this file; include/orbhip_gemm_probe.h): probed once per process
@@ -258,19 +283,23 @@ int ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoint
 {
     int nmatches=0;
     const bool bFactor = th!=1.0;
-    std::vector<orbhip_proj_query> q; std::vector<unsigned char> qd; std::vector<MapPoint*> owner;
-    q.reserve(vpMapPoints.size()); qd.reserve(32*vpMapPoints.size()); owner.reserve(vpMapPoints.size());
+    const size_t cap = std::max<size_t>(vpMapPoints.size(), 1);
+    std::vector<orbhip_proj_query> q(cap); std::vector<unsigned char> qd(32*cap); std::vector<MapPoint*> owner(cap);
+    size_t nq = 0;
     for(size_t iMP=0; iMP<vpMapPoints.size(); iMP++)
     {
         MapPoint* pMP = vpMapPoints[iMP];
-        if(!pMP->mbTrackInView || pMP->isBad()) continue;
+        if(!pMP->mbTrackInView) continue;
+        int nObs = 0;
+        if(!Access::Tracked(pMP, &qd[32*nq], nObs)) continue;
         const int nPredictedLevel = pMP->mnTrackScaleLevel;
         float r = RadiusByViewingCos(pMP->mTrackViewCos);       // the window depends on the viewing direction
         if(bFactor) r*=th;
         const orbhip_proj_query e = { pMP->mTrackProjX, pMP->mTrackProjY, r*F.mvScaleFactors[nPredictedLevel], pMP->mTrackProjXR,
-                                      nPredictedLevel-1, nPredictedLevel, pMP->Observations()>0, 0.f };
-        q.push_back(e); qd.resize(qd.size()+32); orbhip_read_descriptor(pMP, &qd[qd.size()-32]); owner.push_back(pMP);
+                                      nPredictedLevel-1, nPredictedLevel, nObs>0, 0.f };
+        q[nq] = e; owner[nq] = pMP; nq++;
     }
+    q.resize(nq);
     if(q.empty() || F.N==0) return 0;
     std::vector<unsigned char> blocked(F.N); std::vector<int> fq(F.N);
     for(int i=0;i<F.N;i++) blocked[i] = F.mvpMapPoints[i] && F.mvpMapPoints[i]->Observations()>0;
@@ -328,8 +357,9 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, 
     {
         MapPoint* pMP = LastFrame.mvpMapPoints[i];
         if(!pMP || LastFrame.mvbOutlier[i]) continue;
-        G.add(pMP, i, false, LastFrame.mvKeys[i].octave, pMP->Observations()>0, LastFrame.mvKeysUn[i].angle);
+        G.add(pMP, i, false, false, LastFrame.mvKeys[i].octave, -1, LastFrame.mvKeysUn[i].angle);          // (no isBad() test in this member)
     }
+    G.done();
     orbhip_projection P = orbhip_projection_of(ORBHIP_PROJ_LAST_FRAME, Rcw, tcw, cv::Mat(), CurrentFrame.fx, CurrentFrame.fy, CurrentFrame.cx, CurrentFrame.cy, CurrentFrame.mbf,
                                                Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY, th);
     P.forward = bForward; P.backward = bBackward;
@@ -352,9 +382,10 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set
     for(size_t i=0, iend=vpMPs.size(); i<iend; i++)
     {
         MapPoint* pMP = vpMPs[i];
-        if(!pMP || pMP->isBad() || sAlreadyFound.count(pMP)) continue;
-        G.add(pMP, (int)i, true, -1, 1, pKF->mvKeysUn[i].angle);
+        if(!pMP || sAlreadyFound.count(pMP)) continue;
+        G.add(pMP, (int)i, true, true, -1, 1, pKF->mvKeysUn[i].angle);
     }
+    G.done();
     orbhip_projection P = orbhip_projection_of(ORBHIP_PROJ_FRAME_KF, Rcw, tcw, Ow, CurrentFrame.fx, CurrentFrame.fy, CurrentFrame.cx, CurrentFrame.cy, CurrentFrame.mbf,
                                                Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY, th);
     orbhip_set_levels(P, CurrentFrame.mvScaleFactors, CurrentFrame.mnScaleLevels, CurrentFrame.mfLogScaleFactor);
@@ -386,9 +417,10 @@ int ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapP
     for(int iMP=0, iendMP=vpPoints.size(); iMP<iendMP; iMP++)
     {
         MapPoint* pMP = vpPoints[iMP];
-        if(pMP->isBad() || spAlreadyFound.count(pMP)) continue;
-        G.add(pMP, iMP, true, -1, 1, 0.f);
+        if(spAlreadyFound.count(pMP)) continue;
+        G.add(pMP, iMP, true, true, -1, 1, 0.f);
     }
+    G.done();
     int nmatches=0;
     if(G.size()==0 || pKF->N==0) return 0;
     const orbhip_bounds bounds = orbhip_kf_bounds(pKF);
@@ -424,9 +456,10 @@ static void orbhip_fuse_collect(KeyFrame* pKF, const vector<MapPoint*> &vpMapPoi
     for(int i=0; i<nMPs; i++)
     {
         MapPoint* pMP = vpMapPoints[i];
-        if(!pMP || pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
-        job.G.add(pMP, i, true, -1, 0, 0.f);
+        if(!pMP || pMP->IsInKeyFrame(pKF)) continue;
+        job.G.add(pMP, i, true, true, -1, 0, 0.f);
     }
+    job.G.done();
     if(job.P.gemm_mode==2) orbhip_host_transform(job.G, Rcw, tcw);
     job.bi.assign(job.G.size(), -1); job.bd.assign(job.G.size(), 256);
 }
@@ -459,7 +492,7 @@ static int orbhip_fuse_apply(OrbhipFuseJob &job, std::set<MapPoint*> *survivors)
             if(!survivors->count(pMP) || pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
             unsigned char dNow[32]; orbhip_read_descriptor(pMP, dNow);
             if(!memcmp(dNow, &job.G.desc[32*k], 32)) continue;
-            which.push_back(k); again.G.pts.push_back(job.G.pts[k]); again.G.desc.insert(again.G.desc.end(), dNow, dNow+32);
+            which.push_back(k); again.G.pts.push_back(job.G.pts[k]); again.G.desc.insert(again.G.desc.end(), dNow, dNow+32); again.G.n++;
         }
         if(!which.empty())
         {
@@ -539,9 +572,10 @@ int ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint *> &vpPoi
     for(int iMP=0; iMP<nPoints; iMP++)
     {
         MapPoint* pMP = vpPoints[iMP];
-        if(pMP->isBad() || spAlreadyFound.count(pMP)) continue;
-        job.G.add(pMP, iMP, true, -1, 0, 0.f);
+        if(spAlreadyFound.count(pMP)) continue;
+        job.G.add(pMP, iMP, true, true, -1, 0, 0.f);
     }
+    job.G.done();
     if(job.P.gemm_mode==2) orbhip_host_transform(job.G, Rcw, tcw);
     job.bi.assign(job.G.size(), -1); job.bd.assign(job.G.size(), 256);
     if(job.G.size()>0 && pKF->N>0)
@@ -613,9 +647,10 @@ int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &
         for(int i=0, n=(int)vp.size(); i<n; i++)
         {
             MapPoint* pMP = vp[i];
-            if(!pMP || vbAlready[i] || pMP->isBad()) continue;
-            S.G.add(pMP, i, true, -1, 0, 0.f);
+            if(!pMP || vbAlready[i]) continue;
+            S.G.add(pMP, i, true, true, -1, 0, 0.f);
         }
+        S.G.done();
         const orbhip_bounds b = orbhip_kf_bounds(S.target);
         // the intrinsics are key frame 1's in BOTH directions, as in the reference (:1105-1108)
         S.P = orbhip_projection_of(ORBHIP_PROJ_SIM3, Rw, tw, cv::Mat(), pKF1->fx, pKF1->fy, pKF1->cx, pKF1->cy, 0.f, b.min_x, b.min_y, b.max_x, b.max_y, th);

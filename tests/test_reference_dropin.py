@@ -73,7 +73,11 @@ def test_reference_frame_on_dropin_extractor(builds, request, monkeypatch, w, h,
         assert n_r == n_f and np.array_equal(m_r, m_f) and p_r.tobytes() == p_f.tobytes() and n_r > 20
         for _ in range(50):
             x, y, r = np.float32(rng.uniform(0, w)), np.float32(rng.uniform(0, h)), np.float32(rng.uniform(2, 90))
-            assert np.array_equal(R[1].features_in_area(x, y, r, 0, 2), F[1].features_in_area(x, y, r, 0, 2))
+            if "all-steps" in request.node.name:
+                # built with --skip-host-grid: the host's 64 x 48 grid has no reader left (src/ORBmatcher.cc is the drop-in's and searches the device's grid), it stays empty
+                assert len(F[1].features_in_area(x, y, r, 0, 2)) == 0
+            else:
+                assert np.array_equal(R[1].features_in_area(x, y, r, 0, 2), F[1].features_in_area(x, y, r, 0, 2))
         for f in R + F:
             f.close()
     S.RefFrame._geometry = None

@@ -32,7 +32,7 @@ def measure(shape="kitti", nframes=24, passes=5, ref_passes=1, seed=5, kf_every=
     ref = S.tracking_loop(*args, kf_every=kf_every, library=ref_lib)
     got = S.tracking_loop(*args, kf_every=kf_every, library=gpu_lib)
     mismatched = [k for k, (a, b) in enumerate(zip(ref, got)) if not a.same(b)]
-    keys = ("ms", "ms_ctor", "ms_motion", "ms_local")
+    keys = ("ms", "ms_ctor", "ms_motion", "ms_local", "ms_frustum", "ms_copy")
 
     def timed(lib, n):
         runs = [S.tracking_loop(*args, kf_every=kf_every, capture=False, library=lib) for _ in range(n)]
@@ -45,8 +45,8 @@ def measure(shape="kitti", nframes=24, passes=5, ref_passes=1, seed=5, kf_every=
         "what": "per stereo pair: reference Frame constructor (two extractor threads, ComputeStereoMatches, UndistortKeyPoints, grid) + SearchByProjection(Current, Last, 7) "
                 "+ isInFrustum over the local map + SearchByProjection(Frame, MapPoints, 1) + Frame copy; pose from the sequence instead of the optimiser",
         "ms_per_frame_gpu": g["ms"], "ms_per_frame_ref": r["ms"], "speedup": round(r["ms"] / g["ms"], 1),
-        "gpu_parts_ms": {"frame_constructor": g["ms_ctor"], "motion_model_search": g["ms_motion"], "local_map_search": g["ms_local"]},
-        "ref_parts_ms": {"frame_constructor": r["ms_ctor"], "motion_model_search": r["ms_motion"], "local_map_search": r["ms_local"]},
+        "gpu_parts_ms": {"frame_constructor": g["ms_ctor"], "motion_model_search": g["ms_motion"], "local_map_search": g["ms_local"], "of_which_isInFrustum_loop": g["ms_frustum"], "frame_copy": g["ms_copy"]},
+        "ref_parts_ms": {"frame_constructor": r["ms_ctor"], "motion_model_search": r["ms_motion"], "local_map_search": r["ms_local"], "of_which_isInFrustum_loop": r["ms_frustum"], "frame_copy": r["ms_copy"]},
         "worst_frame_ms_gpu": gmax, "worst_frame_ms_ref": rmax,
         "ref_build": "oracle/_ref/liborbslam_ref_fast.so (-O3 -march=x86-64-v3, the reference's two extractor threads)", "passes_gpu": passes, "passes_ref": ref_passes,
         "parity": {"frames_compared": nframes, "frames_mismatched": len(mismatched), "compared": "keys, mvKeysUn, descriptors, mvuRight, mvDepth, map point per feature after each matcher, counters"},
