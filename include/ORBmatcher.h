@@ -73,6 +73,11 @@ public:
     int Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, const float th = 3.0);
     int Fuse(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, float th, std::vector<MapPoint*>& vpReplacePoint);
 
+    // Frame::isInFrustum (Frame.cc:269-325; Tracking::SearchLocalPoints calls it for every local map point of every frame) without its five cv::Mat
+    // temporaries: the same statements on flat floats, the map point visited once.  integration/apply_dropin.py --flat-frustum makes the member a one-line
+    // forward to this (Rcw / tcw / Ow = the frame's private mRcw / mtcw / mOw, which only the member itself can name).
+    static bool IsInFrustum(Frame &F, const cv::Mat &Rcw, const cv::Mat &tcw, const cv::Mat &Ow, MapPoint* pMP, float viewingCosLimit);
+
     // The readers behind `friend class ORBmatcher;` in include/MapPoint.h (integration/apply_dropin.py adds that line): a map point's position, viewing
     // direction, scale-invariance range, mfMaxDistance and descriptor read in place under the point's own mutexes.  Defined in ORBmatcher.cc; declared here
     // because friendship reaches the class's members (this nested type is one), not the file's free functions.  No data member: the class layout is the reference's.

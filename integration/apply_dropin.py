@@ -6,6 +6,7 @@
     ... --stereo-one-call        optional: the stereo Frame constructor extracts both images in ONE call on one device context (ORBextractor::ExtractStereo)
     ... --device-rgbd            optional: Frame::ComputeStereoFromRGBD samples the depth map on the device (default: the reference's loop + N floats uploaded)
     ... --resident-bow           optional (with this repository's ORBVocabulary class in place, step 3e): Frame::ComputeBoW reads the descriptors in HBM
+    ... --flat-frustum           optional: Frame::isInFrustum forwards to ORBmatcher::IsInFrustum (flat floats, the map point visited once, no cv::Mat temporaries)
     ... --skip-host-grid         optional: Frame::AssignFeaturesToGrid does nothing - with this repository's ORBmatcher.cc nobody reads the host's 64 x 48 grid
 
 What it produces (nothing else of the checkout changes; Tracking.cc, LocalMapping.cc, LoopClosing.cc, KeyFrame*.cc, MapPoint.cc compile as they are):
@@ -141,12 +142,20 @@ GRID_SIG = r"void\s+Frame::AssignFeaturesToGrid\s*\(\s*\)"
 GRID_BODY = "{ /* orbhip drop-in (--skip-host-grid): the feature grid is built on the device by the matcher entry points; nothing on the host reads mGrid */ }"
 
 
-def patch_frame(src, stereo_one_call=False, resident_bow=False, device_rgbd=False, skip_host_grid=False):
+# optional, --flat-frustum: Frame::isInFrustum (Frame.cc:269-325), called by Tracking::SearchLocalPoints for every local map point of every frame, builds five
+# cv::Mat temporaries per point; ORBmatcher::IsInFrustum (this repository's ORBmatcher.cc) evaluates the same statements on flat floats, the point visited once
+FRUSTUM_SIG = r"bool\s+Frame::isInFrustum\s*\(\s*MapPoint\s*\*\s*pMP\s*,\s*float\s+viewingCosLimit\s*\)"
+FRUSTUM_BODY = "{ return ORBmatcher::IsInFrustum(*this, mRcw, mtcw, mOw, pMP, viewingCosLimit); }"
+
+
+def patch_frame(src, stereo_one_call=False, resident_bow=False, device_rgbd=False, skip_host_grid=False, flat_frustum=False):
     for sig, body in FORWARDS.items():
         src = replace_body(src, sig, body)
     src = replace_body(src, RGBD_SIG, RGBD_DEVICE_BODY) if device_rgbd else append_to_body(src, RGBD_SIG, RGBD_APPEND)
     if skip_host_grid:
         src = replace_body(src, GRID_SIG, GRID_BODY)
+    if flat_frustum:
+        src = replace_body(src, FRUSTUM_SIG, FRUSTUM_BODY)
     if resident_bow:
         src = replace_body(src, RESIDENT_BOW_SIG, RESIDENT_BOW_BODY)
     if stereo_one_call:
@@ -164,8 +173,9 @@ def main():
         rbow = "--resident-bow" in argv
         drgbd = "--device-rgbd" in argv
         nogrid = "--skip-host-grid" in argv
-        argv = [a for a in argv[1:] if a not in ("--stereo-one-call", "--resident-bow", "--device-rgbd", "--skip-host-grid")]
-        open(argv[1], "w").write(patch_frame(open(argv[0]).read(), stereo_one_call=one_call, resident_bow=rbow, device_rgbd=drgbd, skip_host_grid=nogrid))
+        flat = "--flat-frustum" in argv
+        argv = [a for a in argv[1:] if a not in ("--stereo-one-call", "--resident-bow", "--device-rgbd", "--skip-host-grid", "--flat-frustum")]
+        open(argv[1], "w").write(patch_frame(open(argv[0]).read(), stereo_one_call=one_call, resident_bow=rbow, device_rgbd=drgbd, skip_host_grid=nogrid, flat_frustum=flat))
         if len(argv) > 3:
             os.makedirs(os.path.dirname(argv[3]) or ".", exist_ok=True)
             open(argv[3], "w").write(patch_mappoint_header(open(argv[2]).read()))
@@ -174,14 +184,15 @@ def main():
     rbow = "--resident-bow" in argv
     drgbd = "--device-rgbd" in argv
     nogrid = "--skip-host-grid" in argv
-    argv = [a for a in argv if a not in ("--stereo-one-call", "--resident-bow", "--device-rgbd", "--skip-host-grid")]
+    flat = "--flat-frustum" in argv
+    argv = [a for a in argv if a not in ("--stereo-one-call", "--resident-bow", "--device-rgbd", "--skip-host-grid", "--flat-frustum")]
     emit_patch = bool(argv) and argv[0] == "--patch"
     if emit_patch:
         argv = argv[1:]
     if len(argv) < (1 if emit_patch else 2):
         raise SystemExit(__doc__)
     ref = argv[0]
-    edited = {"src/Frame.cc": patch_frame(open(os.path.join(ref, "src/Frame.cc")).read(), stereo_one_call=one_call, resident_bow=rbow, device_rgbd=drgbd, skip_host_grid=nogrid),
+    edited = {"src/Frame.cc": patch_frame(open(os.path.join(ref, "src/Frame.cc")).read(), stereo_one_call=one_call, resident_bow=rbow, device_rgbd=drgbd, skip_host_grid=nogrid, flat_frustum=flat),
               "include/MapPoint.h": patch_mappoint_header(open(os.path.join(ref, "include/MapPoint.h")).read())}
     copies = {"include/ORBextractor.h": "include/ORBextractor.h", "src/ORBextractor.cc": "orb_slam2_amd/cpp/ORBextractor.cc", "include/orbhip.h": "include/orbhip.h",
               "include/ORBmatcher.h": "include/ORBmatcher.h", "src/ORBmatcher.cc": "orb_slam2_amd/cpp/ORBmatcher.cc", "include/ORBmatcherBatch.h": "include/ORBmatcherBatch.h",

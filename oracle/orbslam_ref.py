@@ -308,6 +308,15 @@ def set_test_poses(A=None, B=None, s12=1.0, R12=None, t12=None, library=None):
     L.orbslam_ref_set_test_poses(_p(a), _p(b), float(s12), None if r is None else _p(r), None if t is None else _p(t))
 
 
+def is_in_frustum(frame, X, Y, Z, level, viewing_cos_limit=0.5):
+    """Frame::isInFrustum for every point under the frame's test pose A -> float32 [nq, 6]: in view, mTrackProjX, mTrackProjY, mTrackProjXR, level, mTrackViewCos"""
+    nq = len(X)
+    out = np.zeros((nq, 6), np.float32)
+    frame.L.orbslam_ref_is_in_frustum.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+    frame.L.orbslam_ref_is_in_frustum(frame.h, nq, _p(_f32(X)), _p(_f32(Y)), _p(_f32(Z)), _p(np.ascontiguousarray(level, np.int32)), viewing_cos_limit, _p(out))
+    return out
+
+
 def gemm_mode(library=None):
     """how the drop-in ORBmatcher.cc of `library` found its cv::Mat algebra to round R*x+t (-1: the build has no drop-in matcher)"""
     L = library or lib()

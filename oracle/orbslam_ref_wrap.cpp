@@ -449,6 +449,21 @@ static void preset(Frame& F, const uint8_t* state)
 {
     for (int i = 0; i < F.N; i++) F.mvpMapPoints[i] = (!state || state[i] == 0) ? NULL : make_point(0, 0, 1, NULL, state[i] == 2 ? 1 : 0, false);
 }
+static MapPoint* make_query_point(float x, float y, float z, const uint8_t* desc, int level, int nobs, bool bad, float scaleFactor);
+// Frame::isInFrustum(pMP, viewingCosLimit) (Frame.cc:269-325) for nq map points under the frame's test pose A: per point the return value and the
+// five fields it leaves in the map point.  out = nq x 6 floats: in view, mTrackProjX, mTrackProjY, mTrackProjXR, mnTrackScaleLevel, mTrackViewCos
+void orbslam_ref_is_in_frustum(void* fp, int nq, const float* X, const float* Y, const float* Z, const int* level, float viewing_cos_limit, float* out)
+{
+    Frame& F = *(Frame*)fp;
+    F.SetPose(test_pose(0));
+    for (int q = 0; q < nq; q++) {
+        MapPoint* p = make_query_point(X[q], Y[q], Z[q], NULL, level[q], 1, false, F.mfScaleFactor);
+        const bool in = F.isInFrustum(p, viewing_cos_limit);
+        float* o = out + 6 * q;
+        o[0] = in ? 1.0f : 0.0f; o[1] = p->mTrackProjX; o[2] = p->mTrackProjY; o[3] = p->mTrackProjXR; o[4] = (float)p->mnTrackScaleLevel; o[5] = p->mTrackViewCos;
+        if (!in) { o[1] = o[2] = o[3] = o[4] = o[5] = 0.0f; }               // (what a rejected point's fields hold is whatever an earlier call left)
+    }
+}
 // ORBmatcher(nnratio).SearchByProjection(F, vpMapPoints, th)  (ORBmatcher.cc:45-129).  Query q = a local-map point the caller
 // already projected (Frame::isInFrustum fills mTrackProjX/Y/XR, mnTrackScaleLevel, mTrackViewCos, mbTrackInView).
 int orbslam_ref_search_by_projection_points(void* fp, int nq, const float* px, const float* py, const float* pxr, const int* level, const float* viewcos,

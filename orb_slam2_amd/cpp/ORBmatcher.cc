@@ -153,6 +153,16 @@ struct ORBmatcher::Access
         unique_lock<mutex> lock(pMP->mMutexFeatures);
         memcpy(d32, pMP->mDescriptor.ptr<unsigned char>(), 32);
     }
+    // GetWorldPos() + GetNormal() + Get{Min,Max}DistanceInvariance() + PredictScale's numerator: one lock (Frame::isInFrustum's reads)
+    static inline void Position(MapPoint* pMP, orbhip_map_point &o)
+    {
+        unique_lock<mutex> lock(pMP->mMutexPos);
+        const float* w = pMP->mWorldPos.ptr<float>(); const size_t ws = pMP->mWorldPos.step/sizeof(float);
+        const float* nv = pMP->mNormalVector.ptr<float>(); const size_t ns = pMP->mNormalVector.step/sizeof(float);
+        o.x = w[0]; o.y = w[ws]; o.z = w[2*ws];
+        o.nx = nv[0]; o.ny = nv[ns]; o.nz = nv[2*ns];
+        o.min_dist = 0.8f*pMP->mfMinDistance; o.max_dist = 1.2f*pMP->mfMaxDistance; o.scale_dist = pMP->mfMaxDistance;
+    }
     // isBad() + Observations() + GetDescriptor() of a point whose projection the caller already holds (Tracking::SearchLocalPoints): one lock.
     // (SetBadFlag writes mbBad under BOTH mutexes, MapPoint.cc:137-153: holding one of them excludes it.)
     static inline bool Tracked(MapPoint* pMP, unsigned char* d32, int &nObs)
@@ -275,6 +285,64 @@ static bool orbhip_resident(Frame &F, bool bUseRight, bool &right)
             if(F.mvuRight[i]>0) { resident = false; break; }
     }
     return resident;
+}
+
+// ================================================================================================ Frame::isInFrustum   Frame.cc:269-325
+// The member's statements in their order on flat floats (installed by apply_dropin.py --flat-frustum).  `mRcw*P+mtcw` is evaluated in the rounding the probe
+// found in the linked cv::Mat (or by that cv::Mat itself, mode 2); cv::norm / Mat::dot accumulate in double like OpenCV's; MapPoint::PredictScale is the
+// expression of MapPoint.cc:407-421 (orbhip_level_of above).  Everything else is the member's own float arithmetic under this file's compiler flags.
+bool ORBmatcher::IsInFrustum(Frame &F, const cv::Mat &Rcw, const cv::Mat &tcw, const cv::Mat &Ow, MapPoint* pMP, float viewingCosLimit)
+{
+    pMP->mbTrackInView = false;
+    orbhip_map_point o;
+    Access::Position(pMP, o);
+    const float P[3] = {o.x, o.y, o.z};
+    float Pc[3];
+    const int gm = orbhip_gemm_mode();
+    if(gm==2)
+    {
+        cv::Mat Pm(3,1,CV_32F); Pm.at<float>(0) = P[0]; Pm.at<float>(1) = P[1]; Pm.at<float>(2) = P[2];
+        const cv::Mat Pcm = Rcw*Pm+tcw;
+        Pc[0] = Pcm.at<float>(0); Pc[1] = Pcm.at<float>(1); Pc[2] = Pcm.at<float>(2);
+    }
+    else
+    {
+        float R[9], t[3];
+        for(int r=0;r<3;r++) { for(int c=0;c<3;c++) R[3*r+c] = Rcw.at<float>(r,c); t[r] = tcw.at<float>(r); }
+        orbhip_flat_gemm(gm, R, P, t, Pc);
+    }
+    const float &PcX = Pc[0];
+    const float &PcY = Pc[1];
+    const float &PcZ = Pc[2];
+    if(PcZ<0.0f)                                     // positive depth
+        return false;
+    const float invz = 1.0f/PcZ;
+    const float u=F.fx*PcX*invz+F.cx;
+    const float v=F.fy*PcY*invz+F.cy;
+    if(u<Frame::mnMinX || u>Frame::mnMaxX)          // inside the image
+        return false;
+    if(v<Frame::mnMinY || v>Frame::mnMaxY)
+        return false;
+    const float maxDistance = o.max_dist;            // inside the scale-invariance range of the point
+    const float minDistance = o.min_dist;
+    const float PO[3] = {P[0]-Ow.at<float>(0), P[1]-Ow.at<float>(1), P[2]-Ow.at<float>(2)};
+    double ss = 0; for(int k=0;k<3;k++) ss += (double)PO[k]*(double)PO[k];
+    const float dist = std::sqrt(ss);               // cv::norm(PO)
+    if(dist<minDistance || dist>maxDistance)
+        return false;
+    double dp = 0; { const float Pn[3] = {o.nx, o.ny, o.nz}; for(int k=0;k<3;k++) dp += (double)PO[k]*(double)Pn[k]; }
+    const float viewCos = dp/dist;                   // PO.dot(Pn)/dist
+    if(viewCos<viewingCosLimit)
+        return false;
+    std::pair<float,int> spec(F.mfLogScaleFactor, F.mnScaleLevels);
+    const int nPredictedLevel = orbhip_level_of(o.scale_dist/dist, &spec);      // pMP->PredictScale(dist,this)
+    pMP->mbTrackInView = true;                       // what Tracking::SearchLocalPoints / SearchByProjection read afterwards
+    pMP->mTrackProjX = u;
+    pMP->mTrackProjXR = u - F.mbf*invz;
+    pMP->mTrackProjY = v;
+    pMP->mnTrackScaleLevel= nPredictedLevel;
+    pMP->mTrackViewCos = viewCos;
+    return true;
 }
 
 // ================================================================================================ SearchByProjection(Frame, local map points)   ORBmatcher.cc:45-129
@@ -442,7 +510,9 @@ struct OrbhipFuseJob
 {
     KeyFrame* pKF; orbhip_projection P; OrbhipPoints G; std::vector<int> bi, bd;
 };
-static void orbhip_fuse_collect(KeyFrame* pKF, const vector<MapPoint*> &vpMapPoints, const float th, OrbhipFuseJob &job)
+// `shared`: the points read ONCE for every target of a FuseBatch (shared->index[k] = position in vpMapPoints; bad points are absent) - a target then copies
+// the records of the points it does not hold instead of visiting every map point again; NULL: read here (a single Fuse)
+static void orbhip_fuse_collect(KeyFrame* pKF, const vector<MapPoint*> &vpMapPoints, const float th, OrbhipFuseJob &job, const OrbhipPoints* shared = NULL)
 {
     job.pKF = pKF;
     cv::Mat Rcw = pKF->GetRotation();
@@ -452,13 +522,25 @@ static void orbhip_fuse_collect(KeyFrame* pKF, const vector<MapPoint*> &vpMapPoi
     job.P = orbhip_projection_of(ORBHIP_PROJ_FUSE, Rcw, tcw, Ow, pKF->fx, pKF->fy, pKF->cx, pKF->cy, pKF->mbf, b.min_x, b.min_y, b.max_x, b.max_y, th);
     orbhip_set_levels(job.P, pKF->mvScaleFactors, pKF->mnScaleLevels, pKF->mfLogScaleFactor);
     const int nMPs = vpMapPoints.size();
-    job.G.reserve(nMPs);
-    for(int i=0; i<nMPs; i++)
+    job.G.reserve(shared ? shared->size() : nMPs);
+    if(shared)
     {
-        MapPoint* pMP = vpMapPoints[i];
-        if(!pMP || pMP->IsInKeyFrame(pKF)) continue;
-        job.G.add(pMP, i, true, true, -1, 0, 0.f);
+        OrbhipPoints &G = job.G;
+        for(size_t k=0; k<shared->size(); k++)
+        {
+            MapPoint* pMP = shared->owner[k];
+            if(pMP->IsInKeyFrame(pKF)) continue;
+            G.pts[G.n] = shared->pts[k]; memcpy(&G.desc[32*G.n], &shared->desc[32*k], 32); G.owner[G.n] = pMP; G.index[G.n] = shared->index[k];
+            G.n++;
+        }
     }
+    else
+        for(int i=0; i<nMPs; i++)
+        {
+            MapPoint* pMP = vpMapPoints[i];
+            if(!pMP || pMP->IsInKeyFrame(pKF)) continue;
+            job.G.add(pMP, i, true, true, -1, 0, 0.f);
+        }
     job.G.done();
     if(job.P.gemm_mode==2) orbhip_host_transform(job.G, Rcw, tcw);
     job.bi.assign(job.G.size(), -1); job.bd.assign(job.G.size(), 256);
@@ -544,8 +626,13 @@ int FuseBatch(const std::vector<KeyFrame*> &vpTargetKFs, const std::vector<MapPo
 {
     std::vector<OrbhipFuseJob> jobs(vpTargetKFs.size());
     std::vector<orbhip_project_best_slot> slots(vpTargetKFs.size());
+    // every target is offered the same points: each is visited once (position, range, descriptor as they are before the loop - what an earlier target's
+    // surgery changes afterwards is re-checked per target by orbhip_fuse_apply), a target keeps the ones it does not hold
+    OrbhipPoints shared; shared.reserve(vpMapPoints.size());
+    for(size_t i=0; i<vpMapPoints.size(); i++)
+        if(vpMapPoints[i]) shared.add(vpMapPoints[i], (int)i, true, true, -1, 0, 0.f);
     for(size_t t=0; t<vpTargetKFs.size(); t++)
-        orbhip_fuse_collect(vpTargetKFs[t], vpMapPoints, th, jobs[t]);
+        orbhip_fuse_collect(vpTargetKFs[t], vpMapPoints, th, jobs[t], &shared);
     for(size_t t=0; t<vpTargetKFs.size(); t++) slots[t] = orbhip_fuse_slot(jobs[t]);      // (after every job exists: the slots point into them)
     if(!slots.empty())
         orbhip_check(orbhip_project_best_in_window_batch(orbhip_default_device(), (int)slots.size(), &slots[0], 1));

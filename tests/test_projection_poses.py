@@ -94,6 +94,13 @@ def _run(S, D, strict=True):
                     differs[fn.__name__] = differs.get(fn.__name__, 0) + (0 if same else int((np.asarray(o_r) != np.asarray(o_f)).sum()) or 1)
                     return n_r
 
+                # Frame::isInFrustum: the reference's member against ORBmatcher::IsInFrustum (--flat-frustum), every field of every point bit for bit
+                if not stereo or seed == 0:
+                    Xf, Yf, Zf = _world(rng, kl, A, sigma=30.0)
+                    f_r, f_f = S.is_in_frustum(R[1], Xf, Yf, Zf, level), S.is_in_frustum(F[1], Xf, Yf, Zf, level)
+                    assert f_r.tobytes() == f_f.tobytes() or not strict, "isInFrustum"
+                    differs["frustum"] = differs.get("frustum", 0) + int((f_r != f_f).any(1).sum())
+                    checked["frustum"] = checked.get("frustum", 0) + int(f_r[:, 0].sum())
                 # TrackWithMotionModel: last frame's points under pose A (the last frame's own pose B decides forward / backward)
                 X, Y, Z = _world(rng, kl, A)
                 has = (rng.random(nq) < 0.85).astype(np.uint8); outl = (rng.random(nq) < 0.1).astype(np.uint8)
@@ -187,7 +194,7 @@ def test_members_under_general_poses(builds, capsys):
     with capsys.disabled():
         print("\nmatches compared under general poses (all identical): " + ", ".join(f"{k} {v}" for k, v in sorted(checked.items())))
     # the test is not vacuous: every member found matches through the rotated cameras
-    assert checked["last"] > 800 and checked["reloc"] > 300 and checked["kf_sim3"] > 150 and checked["fuse"] > 100 and checked["fuse_sim3"] > 100 and checked["sim3"] > 100 and checked["fuse_stereo"] > 20, checked
+    assert checked["last"] > 800 and checked["reloc"] > 300 and checked["kf_sim3"] > 150 and checked["fuse"] > 100 and checked["fuse_sim3"] > 100 and checked["sim3"] > 100 and checked["fuse_stereo"] > 20 and checked["frustum"] > 1000, checked
 
 
 def test_report_sensitivity_to_the_other_gemm_rounding(builds, capsys):
