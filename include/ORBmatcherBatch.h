@@ -6,9 +6,8 @@
 //   LocalMapping::SearchInNeighbors    for every target:     matcher.Fuse(pKFi, vpMapPointMatches)                                   LocalMapping.cc:483-514
 // On the device one such call is launch latency, not work.  The functions below run a whole loop as ONE upload, ONE launch set and ONE download
 // (orbhip_search_by_bow_batch, orbhip_search_for_triangulation_batch, orbhip_search_best_in_window_batch of include/orbhip.h) and return, per key frame,
-// exactly what the member returns when it is called in the reference's order.  They are defined in the ORBmatcher.cc that
-// integration/apply_dropin.py emits (the reference's own projection / map-surgery code around the library calls); INTEGRATION.md section 2-3h shows the
-// three loops rewritten.  Failures throw ORBhipError like the members'.
+// exactly what the member returns when it is called in the reference's order.  They are defined in orb_slam2_amd/cpp/ORBmatcher.cc (the file
+// integration/apply_dropin.py installs as src/ORBmatcher.cc); INTEGRATION.md section 2-3h shows the three loops rewritten.  Failures throw ORBhipError like the members'.
 #ifndef ORBMATCHERBATCH_H
 #define ORBMATCHERBATCH_H
 

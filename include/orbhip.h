@@ -393,7 +393,7 @@ typedef struct { const orbhip_tri_side* kf2; float F12[9]; float ex, ey; int32_t
    never marks a feature of key frame 2 as taken (ORBmatcher.cc:677, 725: vbMatched2 is read, never written), so the features of key frame 1 do not
    interact and - WITHOUT the orientation check, which is how LocalMapping constructs its matcher (LocalMapping.cc:215: ORBmatcher(0.6, false)) - the
    reference's answer for neighbour i is this batch's answer minus the features that received a map point from neighbours < i: the caller drops
-   those pairs (the member emitted by integration/apply_dropin.py does).  With check_ori != 0 the rotation histogram couples the features: use the
+   those pairs (TriangulationPairs of orb_slam2_amd/cpp/ORBmatcher.cc does).  With check_ori != 0 the rotation histogram couples the features: use the
    batch only when key frame 1's map points do not change inside the loop. */
 orbhip_status orbhip_search_for_triangulation_batch(int device, const orbhip_tri_side* kf1, int npairs, orbhip_tri_pair* pairs, int only_stereo, int check_ori);
 
