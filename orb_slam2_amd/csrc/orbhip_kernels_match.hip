@@ -95,7 +95,7 @@ typedef int nn_v16i __attribute__((vector_size(64)));
 #define ORBHIP_NN_FP4_QT 4
 #define ORBHIP_NN_FP4_OCC 2
 #define ORBHIP_NN_FP4_LCH 15
-#define ORBHIP_NN_FP4_TPB 4
+#define ORBHIP_NN_FP4_TPB 6
 __global__ __launch_bounds__(256, 2) void k_hamming_nn_mfma(const unsigned* q, int nq, const unsigned* db, long long ndb, long long base, NNPart* parts, int nchunks)
 {
     __shared__ unsigned long long s_tab[256];                          // byte -> its 8 bits as +-1 bytes
@@ -215,11 +215,18 @@ __global__ __launch_bounds__(256, 2) void k_hamming_nn_mfma(const unsigned* q, i
 // lets a wave keep QT = 3 or 4 query tiles (the i8 form spills at 4) and amortise the tile's expansion and operand reads over more queries.
 typedef int nn_v8i __attribute__((vector_size(32)));
 typedef float nn_v16f __attribute__((vector_size(64)));
-template <int QT, int OCC, int LCH, int TPB> __global__ __launch_bounds__(256, OCC) void k_hamming_nn_fp4(const unsigned* q, int nq, const unsigned* db, long long ndb, long long base, NNPart* parts, int nchunks)
+// Seeded scan (round 6): a query's FINAL second-best distance is at most the second-best distance over ANY subset of the rows; seed[q] carries that bound from
+// a first pass over the database's head (rows 0 .. 2^15).  A workgroup whose rows all lie BEHIND the head starts its skip threshold at the bound instead of at
+// "nothing seen yet": a tile can only matter if it holds a distance strictly below the bound (a row AT the bound loses the tie to the head's rows, which have
+// lower indices) - so the skip works from a chunk's first tile on (about one tile in sixteen survives instead of one in three).  chunk0 = index of this
+// launch's first chunk in rows / CH; part0, part_stride = where its partials go among all partials of the query (head sub-chunks first, then the rest).
+template <int QT, int OCC, int LCH, int TPB, int ABL = 0> __global__ __launch_bounds__(256, OCC) void k_hamming_nn_fp4(const unsigned* q, int nq, const unsigned* db, long long ndb, long long base, NNPart* parts, int nchunks,
+                                                                                                          const int* seed, int chunk0, int part0)
 {
+    constexpr int ablate = ABL;                                        // measurement only (ORBHIP_NN_ABLATE): 1 = no threshold tests, 2 = no staging of new tiles; results are wrong
     __shared__ unsigned s_tab[256];                                    // byte -> its 8 bits as FP4 nibbles (bit k -> nibble k): set = +1 (0x2), clear = -1 (0xA)
     __shared__ __attribute__((aligned(16))) unsigned s_a[2][TPB * 8 * 32 * 4];   // TPB expanded DB tiles per workgroup barrier: [tile u][dword d of the row = 2 kb + h][row i] x 16 bytes, double-buffered
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), chunk = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), chunk = blockIdx.y + chunk0;
     {
         unsigned e = 0;
 #pragma unroll
@@ -229,7 +236,10 @@ template <int QT, int OCC, int LCH, int TPB> __global__ __launch_bounds__(256, O
     __syncthreads();
     const int j = lane & 31, h = lane >> 5;
     constexpr int QG = 4 * QT * 32;
-    // ---- the wave's queries as B operands: lane (j, h), K block kb = dword 2 kb + h of query j; the opposite sign (set bit -> -1): x ^ 0x88888888
+    // ---- the wave's queries as B operands: lane (j, h), K block kb = dword 2 kb + h of query j, the SAME sign as the rows (set bit -> +1): a matching bit
+    // contributes +64, a differing one -64, and with C = 0 an accumulator is the similarity  sim = 64 (256 - 2 d) = 16384 - 128 d  of (row, query) - an
+    // integer of magnitude <= 2^14, exact in f32.  (Round 5 started the accumulators at 16384 + row so that they WERE the keys d << 7 | row: sixteen
+    // registers of constants that the second accumulator set below has no room for.  The keys are now made from the similarities only where a tile is kept.)
     nn_v8i B[QT][4];
     int qidx[QT];
 #pragma unroll
@@ -239,12 +249,16 @@ template <int QT, int OCC, int LCH, int TPB> __global__ __launch_bounds__(256, O
 #pragma unroll
         for (int kb = 0; kb < 4; kb++) {
             const unsigned w = qp[2 * kb + h];
-            B[t][kb] = nn_v8i{(int)(s_tab[w & 0xff] ^ 0x88888888u), (int)(s_tab[(w >> 8) & 0xff] ^ 0x88888888u), (int)(s_tab[(w >> 16) & 0xff] ^ 0x88888888u), (int)(s_tab[w >> 24] ^ 0x88888888u), 0, 0, 0, 0};
+            B[t][kb] = nn_v8i{(int)s_tab[w & 0xff], (int)s_tab[(w >> 8) & 0xff], (int)s_tab[(w >> 16) & 0xff], (int)s_tab[w >> 24], 0, 0, 0, 0};
         }
     }
-    unsigned kbest[QT], ksec[QT], thr[QT];                            // thr: bits of (float)(distance of the running second best << 7): a tile key below it may still matter
+    // thr: a tile matters to a query only if it holds a similarity ABOVE it, i.e. a distance strictly below the running (or seeded) second best
+    unsigned kbest[QT], ksec[QT]; float thr[QT];
 #pragma unroll
-    for (int t = 0; t < QT; t++) { kbest[t] = 0xffffffffu; ksec[t] = 0xffffffffu; thr[t] = 0x7f7fffffu; }
+    for (int t = 0; t < QT; t++) {
+        kbest[t] = 0xffffffffu; ksec[t] = 0xffffffffu; thr[t] = -3.0e38f;
+        if (seed) { const int sd2 = seed[min(qidx[t], nq - 1)]; if (sd2 >= 0 && sd2 <= 256) thr[t] = (float)(16384 - 128 * sd2); }
+    }
     constexpr int CH = 1 << LCH;                                      // DB rows per workgroup; chunk keys are distance << LCH | row-in-chunk
     const long long row0 = (long long)chunk * CH;
     const int nrows = (int)min((long long)CH, ndb - row0);
@@ -263,9 +277,8 @@ template <int QT, int OCC, int LCH, int TPB> __global__ __launch_bounds__(256, O
             *reinterpret_cast<uint4*>(s_a[buf] + u * 1024 + (sd * 32 + sr) * 4) = uint4{s_tab[w & 0xff], s_tab[(w >> 8) & 0xff], s_tab[(w >> 16) & 0xff], s_tab[w >> 24]};
         }
     };
-    nn_v16f cinit;
-#pragma unroll
-    for (int reg = 0; reg < 16; reg++) cinit[reg] = (float)(256 * 64 + (reg & 3) + 8 * (reg >> 2) + 4 * h);
+    const nn_v16f czero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const float off_h = (float)(4 * h);
     auto top2_of3 = [](unsigned a, unsigned b, unsigned c, unsigned& lo, unsigned& mid) { lo = min(min(a, b), c); mid = max(min(a, b), min(max(a, b), c)); };
     auto merge2 = [](unsigned& b, unsigned& s2, unsigned ob, unsigned os) { s2 = min(min(s2, os), max(b, ob)); b = min(b, ob); };
     auto products = [&](const unsigned* ta, nn_v16f (&acc)[QT]) {
@@ -275,56 +288,166 @@ template <int QT, int OCC, int LCH, int TPB> __global__ __launch_bounds__(256, O
             const nn_v8i A = nn_v8i{(int)a4.x, (int)a4.y, (int)a4.z, (int)a4.w, 0, 0, 0, 0};
 #pragma unroll
             for (int t = 0; t < QT; t++)      // (A, B, C, format of A = FP4, format of B = FP4, scale A: byte 0 of 127 = 2^0, scale B: byte 0 of 133 = 2^6)
-                acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B[t][kb], kb == 0 ? cinit : acc[t], 4, 4, 0, 127, 0, 133);
+                acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B[t][kb], kb == 0 ? czero : acc[t], 4, 4, 0, 127, 0, 133);
         }
     };
-    // The selection of one tile.  Most tiles hold nothing a query still cares about: once a lane's running second best is small, a tile whose smallest key is
-    // not below it changes nothing.  So the tile's minimum is taken first (eight v_min3 on the raw accumulators) and compared with the lane's threshold; only
-    // if SOME lane of the wave may still improve does the wave run the top-two tournament, the conversion of the two winners and the merge (the skip is a
-    // wave-uniform branch).  With 2^15 rows per workgroup about two tiles in three are skipped (the running second best of a chunk starts from nothing).
-    auto select = [&](int tile, const nn_v16f (&acc)[QT], auto ragged) {
+    // the threshold test of one query tile: does ANY lane see a similarity above its threshold in this tile?  (eight v_max3_f32, a compare, a ballot)
+    auto test = [&](int t, const nn_v16f (&a)[QT]) -> bool {
+        const nn_v16f& x = a[t];
+        const float m0 = fmaxf(fmaxf(x[0], x[1]), x[2]), m1 = fmaxf(fmaxf(x[3], x[4]), x[5]), m2 = fmaxf(fmaxf(x[6], x[7]), x[8]), m3 = fmaxf(fmaxf(x[9], x[10]), x[11]), m4 = fmaxf(fmaxf(x[12], x[13]), x[14]);
+        const float mx = fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), x[15]));
+        return __ballot(mx > thr[t]) != 0;
+    };
+    // a kept (tile, query tile): keys d << 7 | row-in-tile = 16384 + row - sim as floats (positive floats order like their bits: the v_min3 / v_med3 tournament
+    // runs on the raw registers, only the two winners are converted), the two smallest merged into the chunk's running pair; `ragged`: rows past the end lose
+    auto tournament = [&](int tile, int t, const nn_v16f (&a)[QT], bool ragged) {
         const unsigned tbase = (unsigned)tile * 32u;
+        unsigned x[16];
 #pragma unroll
-        for (int t = 0; t < QT; t++) {
+        for (int reg = 0; reg < 16; reg++) {
+            const int rbase = (reg & 3) + 8 * (reg >> 2);
+            x[reg] = __float_as_uint(((float)(16384 + rbase) - a[t][reg]) + off_h);
+            if (ragged && tile * 32 + rbase + 4 * h >= nrows) x[reg] = __float_as_uint((float)((511 << 7) + rbase) + off_h);
+        }
+        unsigned b, s2;
+        top2_of3(x[0], x[1], x[2], b, s2);
+#pragma unroll
+        for (int g = 1; g < 5; g++) { unsigned lo, mid; top2_of3(x[3 * g], x[3 * g + 1], x[3 * g + 2], lo, mid); merge2(b, s2, lo, mid); }
+        merge2(b, s2, x[15], 0x7f7fffffu);                                                                  // (the largest finite float's bits: loses to every key)
+        const unsigned bi = (unsigned)__uint_as_float(b), si = (unsigned)__uint_as_float(s2);               // the two winners back to integers: d << 7 | r
+        const unsigned kb1 = ((bi >> 7) << LCH) + (bi & 127u) + tbase, ks1 = ((si >> 7) << LCH) + (si & 127u) + tbase;      // chunk keys d << LCH | (tile * 32 + r)
+        merge2(kbest[t], ksec[t], kb1, ks1);
+        // a later row at the running second best's own distance has a larger key than it (rows ascend): only a strictly smaller distance matters.
+        // (a never-set second best gives a threshold below every similarity; a seeded threshold is never lowered)
+        thr[t] = fmaxf(thr[t], 16384.0f - 128.0f * (float)(ksec[t] >> LCH));
+    };
+    fetch(0); expand(0);
+    __syncthreads();
+    const int nfull = nrows >> 5, nsuper = (ntiles + TPB - 1) / TPB;
+    // ---- the tile loop.  A wave issues in order: with ONE accumulator set it runs the sixteen matrix instructions of a tile (512 cycles of the matrix pipe),
+    // then the threshold tests on their results - each pipe idle while the other works (0.44 of the matrix rate in round 5, two waves per SIMD).
+    // PIPELINED form (QT = 4, TPB a multiple of 3; round 6): the matrix instructions of tile i + 1 and the tests of tile i form one straight-line block, so the
+    // tests issue in the shadow of the matrix pipe.  A second full accumulator set does not fit beside the query operands (2 x 64 + 64 registers + the
+    // rest > 256 at two waves per SIMD: the first build spilled 260 loads per tile).  So the tile is handled as two HALVES of two query tiles and there are
+    // THREE register pairs: while the tests read the current tile's first half, the next tile's first half accumulates into the spare pair; the pair the
+    // tests just released takes the next tile's second half while the tests read the current second half.  The roles rotate with period three tiles,
+    // which is why TPB must be a multiple of 3 (all indices static after unrolling).  Inside a half the matrix instructions alternate between its two
+    // accumulators (consecutive instructions never share one: a filler between two instructions on the SAME accumulator costs ~40 cycles, MI355X_MICROARCH.md).
+    if constexpr (QT == 4 && TPB % 3 == 0) {
+        nn_v16f acc[6];
+        uint4 a4[4];
+        auto load_a = [&](const unsigned* ta) {
+#pragma unroll
+            for (int kb = 0; kb < 4; kb++) a4[kb] = *reinterpret_cast<const uint4*>(ta + ((2 * kb + h) * 32 + j) * 4);
+        };
+        auto mm = [&](nn_v16f& d, int t, int kb) {
+            const nn_v8i A = nn_v8i{(int)a4[kb].x, (int)a4[kb].y, (int)a4[kb].z, (int)a4[kb].w, 0, 0, 0, 0};
+            d = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B[t][kb], kb == 0 ? czero : d, 4, 4, 0, 127, 0, 133);
+        };
+        auto test1 = [&](int t, const nn_v16f& x) -> bool {
+            const float m0 = fmaxf(fmaxf(x[0], x[1]), x[2]), m1 = fmaxf(fmaxf(x[3], x[4]), x[5]), m2 = fmaxf(fmaxf(x[6], x[7]), x[8]), m3 = fmaxf(fmaxf(x[9], x[10]), x[11]), m4 = fmaxf(fmaxf(x[12], x[13]), x[14]);
+            const float mx = fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), x[15]));
+            return __ballot(mx > thr[t]) != 0;
+        };
+        auto tournament1 = [&](int tile, int t, const nn_v16f& a, bool ragged) {
+            const unsigned tbase = (unsigned)tile * 32u;
             unsigned x[16];
 #pragma unroll
             for (int reg = 0; reg < 16; reg++) {
-                x[reg] = __float_as_uint(acc[t][reg]);                                                       // (float)(distance << 7 | row-in-tile): positive, ordered like its bits
-                if (decltype(ragged)::value && tile * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h >= nrows) x[reg] = __float_as_uint((float)((511u << 7) + (unsigned)((reg & 3) + 8 * (reg >> 2) + 4 * h)));
-            }
-            if (!decltype(ragged)::value) {
-                const unsigned m0 = min(min(x[0], x[1]), x[2]), m1 = min(min(x[3], x[4]), x[5]), m2 = min(min(x[6], x[7]), x[8]), m3 = min(min(x[9], x[10]), x[11]), m4 = min(min(x[12], x[13]), x[14]);
-                const unsigned mn = min(min(min(m0, m1), m2), min(min(m3, m4), x[15]));
-                if (__ballot(mn < thr[t]) == 0) continue;
+                const int rbase = (reg & 3) + 8 * (reg >> 2);
+                x[reg] = __float_as_uint(((float)(16384 + rbase) - a[reg]) + off_h);
+                if (ragged && tile * 32 + rbase + 4 * h >= nrows) x[reg] = __float_as_uint((float)((511 << 7) + rbase) + off_h);
             }
             unsigned b, s2;
             top2_of3(x[0], x[1], x[2], b, s2);
 #pragma unroll
             for (int g = 1; g < 5; g++) { unsigned lo, mid; top2_of3(x[3 * g], x[3 * g + 1], x[3 * g + 2], lo, mid); merge2(b, s2, lo, mid); }
-            merge2(b, s2, x[15], 0x7f7fffffu);                                                              // (the largest finite float's bits: loses to every key)
-            const unsigned bi = (unsigned)__uint_as_float(b), si = (unsigned)__uint_as_float(s2);           // the two winners back to integers: d << 7 | r
-            const unsigned kb1 = ((bi >> 7) << LCH) + (bi & 127u) + tbase, ks1 = ((si >> 7) << LCH) + (si & 127u) + tbase;      // chunk keys d << LCH | (tile * 32 + r)
+            merge2(b, s2, x[15], 0x7f7fffffu);
+            const unsigned bi = (unsigned)__uint_as_float(b), si = (unsigned)__uint_as_float(s2);
+            const unsigned kb1 = ((bi >> 7) << LCH) + (bi & 127u) + tbase, ks1 = ((si >> 7) << LCH) + (si & 127u) + tbase;
             merge2(kbest[t], ksec[t], kb1, ks1);
-            // a later row at the running second best's own distance has a larger key than it (rows ascend): only a strictly smaller distance matters
-            thr[t] = __float_as_uint((float)((ksec[t] >> LCH) << 7));                                       // (a never-set second best gives a threshold above every real key)
-        }
-    };
-    fetch(0); expand(0);
-    __syncthreads();
-    const int nfull = nrows >> 5, nsuper = (ntiles + TPB - 1) / TPB;
-    nn_v16f acc[QT];
-    for (int sup = 0; sup < nsuper; sup++) {
-        const int buf = sup & 1;
-        if (sup + 1 < nsuper) fetch(sup + 1);
+            thr[t] = fmaxf(thr[t], 16384.0f - 128.0f * (float)(ksec[t] >> LCH));
+        };
+        load_a(s_a[0]);                                                // tile 0: first half into pair 0, second half into pair 1
 #pragma unroll
-        for (int u = 0; u < TPB; u++) {
-            const int tile = sup * TPB + u;
-            if (tile >= ntiles) break;
-            products(s_a[buf] + u * 1024, acc);
-            if (tile < nfull) select(tile, acc, std::false_type{}); else select(tile, acc, std::true_type{});
+        for (int kb = 0; kb < 4; kb++) { mm(acc[0], 0, kb); mm(acc[1], 1, kb); }
+#pragma unroll
+        for (int kb = 0; kb < 4; kb++) { mm(acc[2], 2, kb); mm(acc[3], 3, kb); }
+        for (int sup = 0; sup < nsuper; sup++) {
+            const int buf = sup & 1;
+            if (sup + 1 < nsuper && !(ablate & 2)) fetch(sup + 1);
+#pragma unroll
+            for (int u = 0; u < TPB; u++) {
+                const int tile = sup * TPB + u;
+                if (tile >= ntiles) break;
+                const int cA = (3 - u % 3) % 3, cB = (cA + 1) % 3, sp = (cA + 2) % 3;             // static after unrolling: pair holding the current first half / second half / the spare
+                nn_v16f &x0 = acc[2 * cA], &x1 = acc[2 * cA + 1], &x2 = acc[2 * cB], &x3 = acc[2 * cB + 1], &n0 = acc[2 * sp], &n1 = acc[2 * sp + 1];
+                const bool last_of_super = u == TPB - 1;
+                if (last_of_super && sup + 1 < nsuper && !(ablate & 2)) { expand(buf ^ 1); __syncthreads(); }      // the next tile lives in the other buffer: fill it, everybody has left it
+                const bool have_next = tile + 1 < ntiles;
+                const unsigned* tnext = last_of_super ? s_a[buf ^ 1] : s_a[buf] + (u + 1) * 1024;
+                if (tile < nfull) {
+                    unsigned keep = 0;
+                    if (have_next && (ablate & 1)) {                // (measurement only, ORBHIP_NN_ABLATE: the matrix instructions alone - results are wrong)
+                        load_a(tnext);
+                        if (ablate & 4) {                            // each accumulator's four instructions back to back
+                            mm(n0, 0, 0); mm(n0, 0, 1); mm(n0, 0, 2); mm(n0, 0, 3); mm(n1, 1, 0); mm(n1, 1, 1); mm(n1, 1, 2); mm(n1, 1, 3);
+                            mm(x0, 2, 0); mm(x0, 2, 1); mm(x0, 2, 2); mm(x0, 2, 3); mm(x1, 3, 0); mm(x1, 3, 1); mm(x1, 3, 2); mm(x1, 3, 3);
+                        } else {
+                            mm(n0, 0, 0); mm(n1, 1, 0); mm(n0, 0, 1); mm(n1, 1, 1); mm(n0, 0, 2); mm(n1, 1, 2); mm(n0, 0, 3); mm(n1, 1, 3);
+                            mm(x0, 2, 0); mm(x1, 3, 0); mm(x0, 2, 1); mm(x1, 3, 1); mm(x0, 2, 2); mm(x1, 3, 2); mm(x0, 2, 3); mm(x1, 3, 3);
+                        }
+                    } else if (have_next) {
+                        // Two straight-line blocks of eight matrix instructions and two tests each.  Left to itself the compiler issues the matrix
+                        // instructions of a block back to back and the tests behind them, and the two waves of a SIMD then fall into step - both queue
+                        // on the matrix pipe, both test while it idles: the tests cost their full 0.65 ms of 3.9 (profiles/r06_exp_config5_ablation.txt).
+                        // The group barriers spell the interleave out: one matrix instruction, three VALU instructions, eight times.
+                        load_a(tnext);
+                        mm(n0, 0, 0); mm(n1, 1, 0); mm(n0, 0, 1); mm(n1, 1, 1);
+                        keep |= test1(0, x0) ? 1u : 0u;
+                        mm(n0, 0, 2); mm(n1, 1, 2); mm(n0, 0, 3); mm(n1, 1, 3);
+                        keep |= test1(1, x1) ? 2u : 0u;
+                        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+                        for (int i = 0; i < 8; i++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); }
+                        if (keep & 1u) tournament1(tile, 0, x0, false);                             // (rare; the released pair is overwritten below)
+                        if (keep & 2u) tournament1(tile, 1, x1, false);
+                        mm(x0, 2, 0); mm(x1, 3, 0); mm(x0, 2, 1); mm(x1, 3, 1);
+                        keep |= test1(2, x2) ? 4u : 0u;
+                        mm(x0, 2, 2); mm(x1, 3, 2); mm(x0, 2, 3); mm(x1, 3, 3);
+                        keep |= test1(3, x3) ? 8u : 0u;
+#pragma unroll
+                        for (int i = 0; i < 8; i++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 1); __builtin_amdgcn_sched_group_barrier(0x002, 3, 1); }
+                        if (keep & 4u) tournament1(tile, 2, x2, false);
+                        if (keep & 8u) tournament1(tile, 3, x3, false);
+                    } else {
+                        if (test1(0, x0)) tournament1(tile, 0, x0, false);
+                        if (test1(1, x1)) tournament1(tile, 1, x1, false);
+                        if (test1(2, x2)) tournament1(tile, 2, x2, false);
+                        if (test1(3, x3)) tournament1(tile, 3, x3, false);
+                    }
+                } else {                                               // the chunk's last, ragged tile (nothing follows it): every query tile, rows past the end lose
+                    tournament1(tile, 0, x0, true); tournament1(tile, 1, x1, true); tournament1(tile, 2, x2, true); tournament1(tile, 3, x3, true);
+                }
+            }
         }
-        if (sup + 1 < nsuper) expand(buf ^ 1);
-        __syncthreads();
+    } else {
+        // one accumulator set: matrix instructions, then tests, then the kept tournaments (the experimental shapes of ORBHIP_NN=fp4:...)
+        nn_v16f acc[QT];
+        for (int sup = 0; sup < nsuper; sup++) {
+            const int buf = sup & 1;
+            if (sup + 1 < nsuper) fetch(sup + 1);
+#pragma unroll
+            for (int u = 0; u < TPB; u++) {
+                const int tile = sup * TPB + u;
+                if (tile >= ntiles) break;
+                products(s_a[buf] + u * 1024, acc);
+#pragma unroll
+                for (int t = 0; t < QT; t++) if (tile >= nfull || test(t, acc)) tournament(tile, t, acc, tile >= nfull);
+            }
+            if (sup + 1 < nsuper) expand(buf ^ 1);
+            __syncthreads();
+        }
     }
 #pragma unroll
     for (int t = 0; t < QT; t++) {
@@ -335,9 +458,18 @@ template <int QT, int OCC, int LCH, int TPB> __global__ __launch_bounds__(256, O
             p.best = (b >> LCH) > 256u ? IMAX : (int)(b >> LCH);
             p.second = (s2 >> LCH) > 256u ? IMAX : (int)(s2 >> LCH);
             p.idx = (b >> LCH) > 256u ? -1 : row0 + (long long)(b & (unsigned)(CH - 1)) + base;
-            parts[(long long)qidx[t] * nchunks + chunk] = p;
+            parts[(long long)qidx[t] * nchunks + part0 + (int)blockIdx.y] = p;
         }
     }
+}
+// second-best distance over the head's partials of every query: the seed of the main pass (a head with fewer than two rows in reach gives none)
+__global__ __launch_bounds__(256) void k_hamming_seed(const NNPart* parts, int nq, int stride, int nhead, int* seed)
+{
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= nq) return;
+    int b = IMAX, s2 = IMAX;
+    for (int c = 0; c < nhead; c++) { const NNPart p = parts[(long long)qi * stride + c]; if (p.best < b) { s2 = min(b, p.second); b = p.best; } else s2 = min(s2, p.best); }
+    seed[qi] = s2 == IMAX ? -1 : s2;
 }
 
 // fold the per-chunk partials of one query in ascending DB order: stable arg-min + second smallest of the multiset
@@ -380,17 +512,44 @@ bool orbhip_launch_hamming_nn(const uint8_t* d_q, int nq, const uint8_t* d_db, l
     }
     if (form >= 2 && ndb >= 4 * NN_CHUNK) {
         const int qg = 4 * qt * 32, nch = (int)((ndb + ((long long)1 << lch) - 1) >> lch);      // (<= nchunks: the partials fit the workspace)
-        const dim3 grid((nq + qg - 1) / qg, nch, 1);
         bool ok = true;
-#define NN_FP4(QT, OCC, LCH, TPB) hipLaunchKernelGGL((k_hamming_nn_fp4<QT, OCC, LCH, TPB>), grid, dim3(256, 1, 1), 0, s, (const unsigned*)d_q, nq, (const unsigned*)d_db, ndb, base, parts, nch)
+#define NN_FP4(QT, OCC, LCH, TPB, GY, SEED, C0, P0, STRIDE) hipLaunchKernelGGL((k_hamming_nn_fp4<QT, OCC, LCH, TPB>), dim3((nq + qg - 1) / qg, GY, 1), dim3(256, 1, 1), 0, s, (const unsigned*)d_q, nq, (const unsigned*)d_db, ndb, base, parts, STRIDE, SEED, C0, P0)
         const int shape = qt * 10000 + occ * 1000 + lch * 10 + tpb;
+        // The seeded two-pass form for the default shape on databases of more than a few chunks (ORBHIP_NN_SEED=0: one pass, as in round 5): the head = the
+        // first 2^15 rows as 64 sub-chunks of 512 rows (256 workgroups, sixteen tiles each - a chunk of 2^15 rows takes ONE workgroup a millisecond), their
+        // merged second-best distance per query is the bound, the rest of the database is scanned under it.  Partials: [64 head sub-chunks][chunks 1 .. nch - 1].
+        const int ablate = getenv("ORBHIP_NN_ABLATE") ? atoi(getenv("ORBHIP_NN_ABLATE")) : 0;      // measurement only: 1 = no threshold tests, 2 = no staging of new tiles (wrong results)
+        const char* seed_env = getenv("ORBHIP_NN_SEED");                              // (read per call, like ORBHIP_NN: tests switch forms inside one process)
+        const bool seeded_default = !(seed_env && seed_env[0] == '0');
+        if (seeded_default && shape == 42156 && nch >= 2) {
+            const int nhead = 64, stride = nhead + nch - 1;
+            NNPart* p2 = (NNPart*)orbhip_nn_workspace(sizeof(NNPart) * (size_t)nq * stride + sizeof(int) * (size_t)nq, s);
+            if (!p2) return false;
+            parts = p2;
+            int* seed = reinterpret_cast<int*>(p2 + (size_t)nq * stride);
+            const long long ndb_all = ndb;
+            ndb = (long long)1 << 15;                                              // the head pass sees the first chunk only
+            NN_FP4(4, 2, 9, 6, nhead, (const int*)nullptr, 0, 0, stride);
+            ndb = ndb_all;
+            hipLaunchKernelGGL(k_hamming_seed, dim3((nq + 255) / 256, 1, 1), dim3(256, 1, 1), 0, s, (const NNPart*)parts, nq, stride, nhead, seed);
+            if (ablate == 0) NN_FP4(4, 2, 15, 6, nch - 1, (const int*)seed, 1, nhead, stride);
+            else {          // the same launch with parts of the loop compiled out: where the time goes (profiles/r06_exp_config5_ablation.txt)
+#define NN_FP4_ABL(A) hipLaunchKernelGGL((k_hamming_nn_fp4<4, 2, 15, 6, A>), dim3((nq + qg - 1) / qg, nch - 1, 1), dim3(256, 1, 1), 0, s, (const unsigned*)d_q, nq, (const unsigned*)d_db, ndb, base, parts, stride, (const int*)seed, 1, nhead)
+                if (ablate == 1) NN_FP4_ABL(1); else if (ablate == 2) NN_FP4_ABL(2); else if (ablate == 7) NN_FP4_ABL(7); else NN_FP4_ABL(3);
+#undef NN_FP4_ABL
+            }
+            hipLaunchKernelGGL(k_hamming_merge, dim3((nq + 3) / 4, 1, 1), dim3(256, 1, 1), 0, s, (const NNPart*)parts, nq, stride, d_best_idx, d_best_dist, d_second);
+            return true;
+        }
+#define NN_FP4_PLAIN(QT, OCC, LCH, TPB) NN_FP4(QT, OCC, LCH, TPB, nch, (const int*)nullptr, 0, 0, nch)
         switch (shape) {
-        case 22131: NN_FP4(2, 2, 13, 1); break; case 32131: NN_FP4(3, 2, 13, 1); break; case 42131: NN_FP4(4, 2, 13, 1); break;
-        case 42151: NN_FP4(4, 2, 15, 1); break; case 42152: NN_FP4(4, 2, 15, 2); break; case 42154: NN_FP4(4, 2, 15, 4); break; case 42158: NN_FP4(4, 2, 15, 8); break;
-        case 23154: NN_FP4(2, 3, 15, 4); break; case 23151: NN_FP4(2, 3, 15, 1); break; case 22154: NN_FP4(2, 2, 15, 4); break; case 42134: NN_FP4(4, 2, 13, 4); break;
-        case 42164: NN_FP4(4, 2, 16, 4); break; case 32154: NN_FP4(3, 2, 15, 4); break;
+        case 22131: NN_FP4_PLAIN(2, 2, 13, 1); break; case 32131: NN_FP4_PLAIN(3, 2, 13, 1); break; case 42131: NN_FP4_PLAIN(4, 2, 13, 1); break;
+        case 42151: NN_FP4_PLAIN(4, 2, 15, 1); break; case 42152: NN_FP4_PLAIN(4, 2, 15, 2); break; case 42154: NN_FP4_PLAIN(4, 2, 15, 4); break; case 42158: NN_FP4_PLAIN(4, 2, 15, 8); break;
+        case 23154: NN_FP4_PLAIN(2, 3, 15, 4); break; case 23151: NN_FP4_PLAIN(2, 3, 15, 1); break; case 22154: NN_FP4_PLAIN(2, 2, 15, 4); break; case 42134: NN_FP4_PLAIN(4, 2, 13, 4); break;
+        case 42164: NN_FP4_PLAIN(4, 2, 16, 4); break; case 32154: NN_FP4_PLAIN(3, 2, 15, 4); break; case 42156: NN_FP4_PLAIN(4, 2, 15, 6); break; case 42153: NN_FP4_PLAIN(4, 2, 15, 3); break;
         default: ok = false;
         }
+#undef NN_FP4_PLAIN
 #undef NN_FP4
         if (!ok) return false;
         hipLaunchKernelGGL(k_hamming_merge, dim3((nq + 3) / 4, 1, 1), dim3(256, 1, 1), 0, s, (const NNPart*)parts, nq, nch, d_best_idx, d_best_dist, d_second);

@@ -288,6 +288,7 @@ inline float __fdiv_rn(float a, float b) { return a / b; }
 inline double __dmul_rn(double a, double b) { return a * b; }
 inline double __dadd_rn(double a, double b) { return a + b; }
 inline double __dsub_rn(double a, double b) { return a - b; }
+inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}            // a scheduling directive: nothing to emulate
 inline double __ddiv_rn(double a, double b) { return a / b; }
 inline double __dsqrt_rn(double a) { return sqrt(a); }
 inline int __float2int_rn(float v) { return (int)lrintf(v); }
