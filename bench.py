@@ -439,6 +439,75 @@ def pool_mode(args):
     print(json.dumps(out), flush=True)
 
 
+def multi_gpu_extras(args, G, share):
+    """What `--gpus N` adds for N > 1 after the resident measurement, on rank 0 while the other ranks wait (their contexts closed): the two multi-GPU curves that
+    CAN bend - the device-resident rate moves nothing over PCIe and is linear by construction.
+      host_io_pool     ONE process feeding all G devices from host buffers through the pool (orbhip_pool_*: a worker thread + context + pinned ring per device, camera
+                       c on device c mod G), pinned and pageable caller buffers, rounds pipelined two deep: frames/s, per-device share, the NUMA placement of every worker
+      config5_sharded  BASELINE.json configs[4] over G devices: the descriptor database split by contiguous row range (orbhip_pool_db_load), every device answers every
+                       query over its shard, the host merges G partial answers per query with the matcher's tie rule; query_ms = the whole call, merge_ms = that merge
+                       alone (the numpy mirror orb_slam2_amd.sharding.merge_nn on the G per-shard answers), parity = equal to one device scanning the whole database
+    `share` (ORB_BENCH_SHARE_GPU=1, the test aid): all G workers on device 0."""
+    import orb_slam2_amd
+    from orb_slam2_amd import sharding, synth
+    devices = [0] * G if share else list(range(G))
+    out = {}
+    # ---- the pool from host buffers
+    per = args.extras_cameras_per_gpu
+    ncam = G * per
+    pool = orb_slam2_amd.MultiGpuExtractor(devices, ncam, NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, W, H, blur_round_mode=args.blur_round_mode)
+    nscenes = min(ncam, 16)
+    scenes = [synth.frame_from_scene(synth.scene(W, H, seed=s_), W, H, t=0, seed=s_) for s_ in range(nscenes)]
+    cap = pool.capacity
+    res = {"cameras": ncam, "cameras_per_gpu": per, "devices": devices,
+           "numa_nodes": [{"worker": r, "device": devices[r], "numa_node": pool.numa_node(r)[0], "bound": pool.numa_node(r)[1]} for r in range(G)]}
+    for kind in ("pinned", "pageable"):
+        alloc = (lambda shape, dt: orb_slam2_amd.pinned_array(shape, dt)) if kind == "pinned" else (lambda shape, dt: np.zeros(shape, dt))
+        src = alloc((ncam, H, W), np.uint8)
+        for c in range(ncam):
+            src[c] = scenes[c % nscenes]
+        bufs = [(alloc((ncam, cap), orb_slam2_amd.KEYPOINT_DTYPE), alloc((ncam, cap, 32), np.uint8), np.zeros(ncam, np.int32)) for _ in range(2)]
+        imgs = [src[c] for c in range(ncam)]
+        pool.collect(pool.submit(imgs), out=bufs[0])
+        rounds = max(args.extras_rounds, 2)
+        t0 = time.perf_counter()
+        pending = [pool.submit(imgs)]
+        for i in range(1, rounds):
+            pending.append(pool.submit(imgs))
+            pool.collect(pending.pop(0), out=bufs[(i - 1) & 1])
+        nout = pool.collect(pending.pop(0), out=bufs[(rounds - 1) & 1])
+        dt = time.perf_counter() - t0
+        rate = ncam * rounds / dt
+        res[kind] = {"frames_per_s": round(rate, 1), "per_device_frames_per_s": round(rate / G, 1), "pcie_GBps_total": round(rate * (W * H + cap * 60 + 4) / 1e9, 2),
+                     "keypoints_per_frame": int(nout.mean()), "rounds": rounds}
+    res["note"] = "extract only, host buffers in / out, PCIe both ways, ONE process for all devices; the single-device figure of the same path is host_io in the N = 1 line"
+    out["host_io_pool"] = res
+    # ---- config 5 sharded by row range
+    nkf, perkf, nq = args.extras_db_keyframes, 2000, 2000
+    rng = np.random.default_rng(7)
+    db = rng.integers(0, 256, (nkf * perkf, 32), dtype=np.uint8)
+    q = db[rng.integers(0, len(db), nq)].copy()
+    q[::2, 0] ^= 0x5A
+    pool.db_load(db)
+    got = pool.db_query(q)
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter(); got = pool.db_query(q); ts.append(time.perf_counter() - t0)
+    shards = [pool.db_shard(r) for r in range(G)]
+    pool.close()
+    parts = [orb_slam2_amd.hamming_nn(q, db[lo:hi], device=devices[r], index_base=lo) for r, (lo, hi) in enumerate(shards)]
+    tm = []
+    for _ in range(5):
+        t0 = time.perf_counter(); merged = sharding.merge_nn(parts); tm.append(time.perf_counter() - t0)
+    whole = orb_slam2_amd.hamming_nn(q, db, device=devices[0])
+    out["config5_sharded"] = {"shards": G, "rows": len(db), "rows_per_shard": [hi - lo for lo, hi in shards], "queries": nq,
+                              "query_ms": round(float(np.median(ts)) * 1e3, 3), "merge_ms": round(float(np.median(tm)) * 1e3, 3),
+                              "merge_note": "merge_ms = orb_slam2_amd.sharding.merge_nn (numpy mirror of the library's host merge) over the G per-shard answers; query_ms = orbhip_pool_db_query, "
+                                            "host queries in, host answers out: upload to every device, the G scans side by side, download, merge",
+                              "parity": bool(all(np.array_equal(a, b) for a, b in zip(got, whole)) and all(np.array_equal(a, b) for a, b in zip(merged, whole)))}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -462,6 +531,10 @@ def main():
     ap.add_argument("--pool-cameras-per-gpu", type=int, default=128)
     ap.add_argument("--parity-slots", type=int, default=NSCENES, help="camera slots of the last timed step compared bit for bit with the oracle: by default one per distinct scene, "
                     "i.e. with the replica check every frame of the step (0 = skip)")
+    ap.add_argument("--no-extras", action="store_true", help="N > 1: skip the host-fed pool and the sharded descriptor database that rank 0 measures after the resident run")
+    ap.add_argument("--extras-cameras-per-gpu", type=int, default=64)
+    ap.add_argument("--extras-rounds", type=int, default=12)
+    ap.add_argument("--extras-db-keyframes", type=int, default=10000, help="key frames (x 2000 descriptors) of the sharded database of config5_sharded")
     ap.add_argument("--extract-only", action="store_true", help="diagnostic: skip the matcher (NOT the metric's workload; the JSON line says so)")
     args = ap.parse_args()
     if args.host_io_only:
@@ -546,6 +619,8 @@ def main():
     prof = ex.profile()
     ex.profile_enable(False)
     last_step = args.warmup + max(args.repeats, 1) * args.steps - 1  # the step whose results are still in the context
+    mine = sorted(times)[len(times) // 2]                            # this rank's own median repeat
+    spread = rdzv.allreduce_max([mine, -mine])                       # slowest and fastest rank (max of the negatives = the minimum)
     times = rdzv.allreduce_max(times)                                # per repeat: the slowest rank
     elapsed = sorted(times)[len(times) // 2]                         # the median repeat is the reported one
 
@@ -555,6 +630,17 @@ def main():
     nkp = [len(k) for k in kps]
     parity = parity_of_last_step(host_frames, kps, descs, m12, last_step, T, args.blur_round_mode, args.parity_slots) if rank == 0 and args.parity_slots > 0 else None
 
+    alg_bytes_per_frame = ex.algorithmic_bytes_per_frame()
+    extras = None
+    if world > 1 and not args.no_extras:
+        ex.close(); d_frames.free()                                   # every rank leaves its GPU; rank 0 then drives all of them from one process
+        rdzv.barrier()
+        if rank == 0:
+            try:
+                extras = multi_gpu_extras(args, world, share)
+            except Exception as e:                                    # noqa: BLE001 - a secondary figure must not cost the line
+                extras = {"error": str(e)[:300]}
+        rdzv.barrier()
     if rank == 0:
         frames_total = B * args.steps * world
         value = frames_total / elapsed
@@ -603,6 +689,8 @@ def main():
                        "inputs": "hbm-resident, results stay on device (the PCIe-inclusive host-buffer rate is the host_io object)",
                        "frames_per_step_per_gpu": B, "resident_time_steps": T, "distinct_scenes": min(B, NSCENES), "blur_round_mode": args.blur_round_mode, "row_pitch": pitch, "streams_per_gpu": args.streams, "parallelism": f"frames sharded over {world} GPU(s), no collective",
                        "blur_kernel": "k_blur (VALU)" if os.environ.get("ORBHIP_BLUR") == "valu" else "k_blur_mfma (i8 matrix cores)"},
+            "per_rank": {"frames_per_s_slowest_rank": round(B * args.steps / spread[0], 1), "frames_per_s_fastest_rank": round(B * args.steps / -spread[1], 1),
+                         "note": "each rank's own median repeat (its B x steps frames / its time); value divides all ranks' frames by the slowest rank's time per repeat"},
             "repeats": {"n": len(times), "steps_each": args.steps, "timed_region_s": round(sum(times), 3), "frames_per_s_median": round(frames_total / elapsed, 1),
                         "frames_per_s_min": round(frames_total / max(times), 1), "frames_per_s_max": round(frames_total / min(times), 1)},
             "roofline": {"bound": bound, "bound_note": "achieved / peak / frac are the HBM figures north_star asks for; `bound` names what the evidence says limits the kernel (roofline_valu.frac)",
@@ -610,16 +698,18 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_profiled": traffic_profiled,
                          "alg_bytes_per_launch": alg * B, "launch_ms": round(kern[dom]["ms_per_launch"], 4), "note": note},
             "roofline_valu": rv,
-            "pipeline_roofline": {"alg_bytes_per_frame": ex.algorithmic_bytes_per_frame(),
-                                  "achieved_GBps": round(ex.algorithmic_bytes_per_frame() * value / world / 1e9, 2),
-                                  "frac_of_hbm_peak": round(ex.algorithmic_bytes_per_frame() * value / world / 1e9 / HBM_PEAK_GBS, 5)},
+            "pipeline_roofline": {"alg_bytes_per_frame": alg_bytes_per_frame,
+                                  "achieved_GBps": round(alg_bytes_per_frame * value / world / 1e9, 2),
+                                  "frac_of_hbm_peak": round(alg_bytes_per_frame * value / world / 1e9 / HBM_PEAK_GBS, 5)},
             "kernels_ms_per_launch": {k: round(v["ms_per_launch"], 4) for k, v in kern.items()},
             "kernel_time_fraction_of_step": round(total_kernel_ms / (elapsed / args.steps * 1e3), 3),
             "check": {"keypoints_per_frame_min_max": [int(min(nkp)), int(max(nkp))], "matches_per_frame_min_max": [int(nm.min()), int(nm.max())]},
             "parity": parity,
             "runtime": {"library": runtime_line, "mapped": orb_slam2_amd.mapped_hip_runtimes(), "framework_imported": "torch" in sys.modules, "control_plane": control},
         }
-        closed = False
+        closed = world > 1 and not args.no_extras
+        if extras is not None:
+            out.update(extras)
         if parity and (parity["mismatches"] or parity["replica_mismatches"]):
             out["INVALID"] = "results of the timed region differ from the oracle: the throughput above does not count"
         if world == 1 and not args.no_traffic:

@@ -148,7 +148,8 @@ def test_bench_eight_ranks_on_one_gpu():
     env["ORB_BENCH_SHARE_GPU"] = "1"
     t0 = time.time()
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--batch", "32", "--steps", "3", "--warmup", "1", "--repeats", "2",
-                        "--no-cpu-baseline", "--no-host-io", "--no-traffic", "--no-dropin-loop"], env=env, capture_output=True, text=True, timeout=1200)
+                        "--no-cpu-baseline", "--no-host-io", "--no-traffic", "--no-dropin-loop",
+                        "--extras-cameras-per-gpu", "4", "--extras-rounds", "3", "--extras-db-keyframes", "40"], env=env, capture_output=True, text=True, timeout=1200)
     wall = time.time() - t0
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -158,6 +159,11 @@ def test_bench_eight_ranks_on_one_gpu():
     assert d["config"]["frames_per_step_per_gpu"] == 32 and "8 GPU" in d["config"]["parallelism"]
     assert d["parity"]["mismatches"] == 0 and d["parity"]["replica_mismatches"] == 0 and "INVALID" not in d
     assert "unix-socket rendezvous" in d["runtime"]["control_plane"] and d["runtime"]["framework_imported"] is False
+    # N > 1 also carries the two curves that can bend: the one-process pool from host buffers and the row-sharded descriptor database
+    hp, c5 = d["host_io_pool"], d["config5_sharded"]
+    assert hp["cameras"] == 32 and len(hp["numa_nodes"]) == 8 and hp["pinned"]["frames_per_s"] > 0 and hp["pageable"]["frames_per_s"] > 0 and hp["pinned"]["keypoints_per_frame"] > 1500
+    assert c5["shards"] == 8 and sum(c5["rows_per_shard"]) == c5["rows"] == 80000 and c5["parity"] is True and c5["query_ms"] > 0 and c5["merge_ms"] >= 0
+    assert d["per_rank"]["frames_per_s_fastest_rank"] >= d["per_rank"]["frames_per_s_slowest_rank"] > 0
     print(f"\n[8 ranks on one GPU] launcher + 8 ranks + rendezvous + run: {wall:.1f} s wall; {d['value']:.0f} frames/s over the shared GPU (not a scaling figure)")
 
 

@@ -270,7 +270,7 @@ def config5(nkf, ncores, per=2000, nq=2000):
         b.free()
     _DB = None
     return {"workload": f"{nq} query descriptors x {nkf} key frames x {per} descriptors ({ndb * 32 / 1e6:.0f} MB DB resident in HBM), best + second best per query",
-            "kernel": {"valu": "k_hamming_nn (popcount)", "i8": "k_hamming_nn_mfma (i8 matrix cores)"}.get(nn_form, "k_hamming_nn_fp4 (FP4 matrix cores, %s)" % (nn_form or "default shape fp4:4:2:15:4")),
+            "kernel": {"valu": "k_hamming_nn (popcount)", "i8": "k_hamming_nn_mfma (i8 matrix cores)"}.get(nn_form, "k_hamming_nn_fp4 (FP4 matrix cores, %s)" % (nn_form or "default shape fp4:4:2:15:6, seeded two-pass scan")),
             "query_ms": round(dt * 1e3, 3), "pair_distances_per_s": float(f"{pairs / dt:.4g}"), "db_stream_GBps": round(ndb * 32 / dt / 1e9, 1),
             "matrix_TOPs": round(pairs * 512 / dt / 1e12, 1), "matrix_peak": "FP4 (v_mfma_scale_f32_32x32x64_f8f6f4): 10 PF spec, 9.1 PF measured; i8: 5 PF spec, 4.4 measured (MI355X_MICROARCH.md)",
             "frac_of_fp4_mfma_peak": round(pairs * 512 / dt / 10e15, 3), "frac_of_fp4_mfma_rate_measured_9100_TOPs": round(pairs * 512 / dt / 9.1e15, 3),
