@@ -791,6 +791,52 @@ extern "C" orbhip_status orbhip_sync(orbhip_ctx* c)
     return ORBHIP_OK;
 }
 
+// The upload and the download stream of the pipelined host path.  Which hardware queue - and with it which DMA engine - a HIP stream lands on depends on how many
+// streams the process has created before; when the two land on the same engine the PCIe link runs half duplex and the path delivers 88 k frames/s instead of
+// 116 k.  Round 5 saw that as "the host path is slower inside a process that has held a resident context" and blamed the stream priorities; round 6's A/B showed the
+// good and the bad state swap places with GPU_MAX_HW_QUEUES=2 or ORBHIP_STREAM_PRIO=1 - a property of the process's stream-creation history, not of the priorities
+// (profiles/r06_exp_host_path_copy_streams.txt).  The copy pair is one factor of it that the library can choose (in-process 88 -> 101 k; the rest of the gap is open).
+// So the pair is CHOSEN: four candidate streams, every pair timed on one concurrent 8 MB upload + 8 MB download (three tries, the best counts), the fastest pair
+// kept, the others destroyed - a few milliseconds at the first host-path call of a context, which allocates its pinned ring anyway.  ORBHIP_COPY_STREAM_PROBE=0:
+// the first two streams, as before.
+static hipError_t create_copy_streams(hipStream_t* up, hipStream_t* down)
+{
+    const char* env = getenv("ORBHIP_COPY_STREAM_PROBE");
+    const int K = (env && env[0] == '0') ? 2 : 4;
+    hipStream_t s[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < K && e == hipSuccess; k++) e = hipStreamCreateWithFlags(&s[k], hipStreamNonBlocking);
+    int ba = 0, bb = 1;
+    if (e == hipSuccess && K > 2) {
+        const size_t bytes = (size_t)8 << 20;
+        void *h0 = nullptr, *h1 = nullptr, *d0 = nullptr, *d1 = nullptr;
+        if (hipHostMalloc(&h0, bytes, hipHostMallocDefault) == hipSuccess && hipHostMalloc(&h1, bytes, hipHostMallocDefault) == hipSuccess &&
+            orbhip_dmalloc(&d0, bytes) == hipSuccess && orbhip_dmalloc(&d1, bytes) == hipSuccess) {
+            memset(h0, 1, bytes);
+            for (int k = 0; k < K; k++) { (void)hipMemcpyAsync(d0, h0, 1 << 16, hipMemcpyHostToDevice, s[k]); (void)hipStreamSynchronize(s[k]); }      // every candidate has carried a copy once
+            double best = 1e30;
+            for (int a = 0; a < K; a++) for (int b = 0; b < K; b++) {
+                if (a == b) continue;
+                double t = 1e30;
+                for (int rep = 0; rep < 3; rep++) {
+                    const auto t0 = std::chrono::steady_clock::now();
+                    (void)hipMemcpyAsync(d0, h0, bytes, hipMemcpyHostToDevice, s[a]);
+                    (void)hipMemcpyAsync(h1, d1, bytes, hipMemcpyDeviceToHost, s[b]);
+                    (void)hipStreamSynchronize(s[a]); (void)hipStreamSynchronize(s[b]);
+                    t = std::min(t, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+                }
+                if (t < best * 0.97) { best = t; ba = a; bb = b; }              // (a later pair must be clearly faster to displace an earlier one)
+            }
+        }
+        (void)hipGetLastError();
+        if (h0) (void)hipHostFree(h0); if (h1) (void)hipHostFree(h1); if (d0) (void)hipFree(d0); if (d1) (void)hipFree(d1);
+    }
+    if (e != hipSuccess) { for (int k = 0; k < K; k++) if (s[k]) (void)hipStreamDestroy(s[k]); return e; }
+    *up = s[ba]; *down = s[bb];
+    for (int k = 0; k < K; k++) if (k != ba && k != bb && s[k]) (void)hipStreamDestroy(s[k]);
+    return hipSuccess;
+}
+
 static orbhip_status ensure_host_staging(orbhip_ctx* c, bool input)
 {
     const size_t B = (size_t)c->B;
@@ -1053,7 +1099,7 @@ static orbhip_status ensure_set(orbhip_ctx* c, int si)
             hs.h_n = reinterpret_cast<int*>(hs.h_block); hs.h_kp = reinterpret_cast<orbhip_keypoint*>(hs.h_block + c->out_off_kp); hs.h_desc = hs.h_block + c->out_off_desc;
         }
     }
-    if (!c->hstream) { HIPCHK(hipStreamCreateWithFlags(&c->hstream, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&c->dstream, hipStreamNonBlocking)); }
+    if (!c->hstream) { const hipError_t ce = create_copy_streams(&c->hstream, &c->dstream); if (ce != hipSuccess) return fail(ORBHIP_ERR_HIP, "copy stream creation: %s", hipGetErrorString(ce)); }
     for (int k = 0; k < ORBHIP_MAX_CHUNKS; k++)
         if (!hs.ev_d2h[k]) { HIPCHK(hipEventCreateWithFlags(&hs.ev_h2d[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&hs.ev_k[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&hs.ev_d2h[k], hipEventDisableTiming)); }
     return ORBHIP_OK;

@@ -29,18 +29,25 @@ def mk(ex, kind):
 
 mode = sys.argv[1]
 big = None
+first = None
+if "hostfirst" in mode:    # the host path's context (and so its streams) created BEFORE the resident one, and kept
+    first = orb_slam2_amd.ORBextractor(2000, 1.2, 8, 20, 7, W, H, max_batch=Bh, blur_round_mode=1)
 if "big" in mode:      # a large resident context like the bench's
     big = orb_slam2_amd.ORBextractor(2000, 1.2, 8, 20, 7, W, H, max_batch=512, blur_round_mode=1)
     d = orb_slam2_amd.DeviceBuffer(512 * 376 * 1280)
+    if "ran" in mode:      # ... that has also run, like the bench's
+        for i in range(8):
+            big.extract_device(d.ptr, 512, 376 * 1280, 1280, match_prev=i > 0, window=100, nnratio=0.9, check_ori=True)
+        big.sync()
 if "closed" in mode:   # ... and destroyed again before the host path is measured
     big.close(); d.free(); big = None
-out = {"mode": mode, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}
+out = {"mode": mode, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "ORBHIP_STREAM_PRIO": os.environ.get("ORBHIP_STREAM_PRIO")}
 if "fresh" in mode:
     for kind in ("pinned", "pageable", "pinned", "pageable"):
         ex = orb_slam2_amd.ORBextractor(2000, 1.2, 8, 20, 7, W, H, max_batch=Bh, blur_round_mode=1)
         s, b = mk(ex, kind); out.setdefault(kind, []).append(run(ex, s, b)); ex.close()
 else:
-    ex = orb_slam2_amd.ORBextractor(2000, 1.2, 8, 20, 7, W, H, max_batch=Bh, blur_round_mode=1)
+    ex = first if first is not None else orb_slam2_amd.ORBextractor(2000, 1.2, 8, 20, 7, W, H, max_batch=Bh, blur_round_mode=1)
     sets = {k: mk(ex, k) for k in (("pageable", "pinned") if "pagefirst" in mode else ("pinned", "pageable"))}
     for rnd in range(2):
         for kind in sets: out.setdefault(kind, []).append(run(ex, *sets[kind]))
