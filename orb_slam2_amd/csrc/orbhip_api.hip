@@ -666,7 +666,8 @@ static ExtractParams make_params(orbhip_ctx* c, const uint8_t* d_img0, long long
 // workgroup per frame, 0.27 -> 0.54 ms at B = 256; docs/ROUND_LOG.md), ONE launch for up to eight frames, where the seven cost 35 us of pure latency
 static void launch_pyramid(orbhip_ctx* c, const ExtractParams& P, int nf, hipStream_t s)
 {
-    if (nf <= 8 && c->pc_ok) { orbhip_launch_pyramid_cascade(P, nf, s); return; }      // a handful of frames: one launch for all levels (k_pyramid_cascade)
+    static const bool cascade_always = getenv("ORBHIP_PC_ALWAYS") && atoi(getenv("ORBHIP_PC_ALWAYS")) != 0;      // experiment: the cascade at any batch
+    if ((nf <= 8 || cascade_always) && c->pc_ok) { orbhip_launch_pyramid_cascade(P, nf, s); return; }      // a handful of frames: one launch for all levels (k_pyramid_cascade)
     for (int l = 1; l < c->L; l++) orbhip_launch_pyramid_level(P, l, c->geom[l].w, c->geom[l].h, (int)c->pyr_staged[l], nf, s);
 }
 

@@ -48,6 +48,16 @@ template <typename T> __device__ __forceinline__ ORBHIP_GLOBAL T* uniform_ptr(T*
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
     return (ORBHIP_GLOBAL T*)(((unsigned long long)hi << 32) | lo);
 }
+// One element of a read-only table at an index every lane agrees on, through the SCALAR cache (s_load: the result lands in SGPRs and counts on lgkmcnt).
+// As an ordinary load the compiler makes it a vector load - the kernel also stores to global memory, so it may not assume the table constant - and waiting
+// for a vector load means waiting for every LDS-DMA request issued before it (vmcnt returns in order).  Tables only: written by the host before the launch.
+#define ORBHIP_CONSTANT __attribute__((address_space(4)))
+template <typename T> __device__ __forceinline__ T scalar_load(const T* p)
+{
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    return *(const ORBHIP_CONSTANT T*)(((unsigned long long)hi << 32) | lo);
+}
 // LDS-DMA: every lane's dword goes from global memory straight to LDS dword (lane) of the 256-byte block at lds_block, without a
 // VGPR round trip (global_load_lds_dword; M0 = block address, wave-uniform).  The source may sit at any byte address
 // (tools/lds_dma_probe.hip, measured on MI355X).  The loads count on vmcnt: lds_dma_wait() before the first LDS read.
@@ -183,13 +193,41 @@ __global__ __launch_bounds__(256) void k_pyramid_level(ExtractParams P, int leve
 // them with the packed coefficient pair in one v_dot2_u32_u16: 18 VALU per row of four horizontal results against 4 LDS byte
 // reads + 2 multiply-adds per result before.  A source row shared with the previous output row is not recomputed (wave-uniform
 // test: all lanes of a wave work on the same output rows).
-__device__ __forceinline__ void pyr_hrow(const unsigned* rowp, unsigned sh, const PyrGroup& G, unsigned (&hs)[4])
+__device__ __forceinline__ void pyr_hrow_from(unsigned w0, unsigned w1, unsigned w2, unsigned sh, const PyrGroup& G, unsigned (&hs)[4])
 {
-    const unsigned w0 = rowp[0], w1 = rowp[1], w2 = rowp[2];
     const unsigned v0 = __builtin_amdgcn_alignbyte(w1, w0, sh), v1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
 #pragma unroll
     for (int k = 0; k < 4; k++)
         hs[k] = __builtin_amdgcn_udot2((pku16)__builtin_amdgcn_perm(v1, v0, G.sel[k]), (pku16)G.coef[k], 0u, false) >> 4;
+}
+__device__ __forceinline__ void pyr_hrow(const unsigned* rowp, unsigned sh, const PyrGroup& G, unsigned (&hs)[4])
+{
+    pyr_hrow_from(rowp[0], rowp[1], rowp[2], sh, G, hs);
+}
+// Three consecutive LDS dwords, requested without the compiler's knowledge.  In k_pyramid_level_g these reads happen while the NEXT tile's LDS-DMA is in
+// flight; as ordinary loads the compiler guards every one of them with `s_waitcnt vmcnt(0)` (an LDS read "may alias" a pending LDS-DMA write: the DMA's LDS
+// side carries no address the compiler could compare - neither distinct __shared__ arrays nor __restrict__ parameters change that) - i.e. it waits for the
+// prefetch itself.  The device pass therefore spells the reads and their wait out (lds_read3_issue ... lds_read_wait: the wait names the registers so that
+// nothing that uses them moves in front of it); the tile being read was waited for explicitly (s_waitcnt vmcnt(n) + barrier) before.  Other passes: plain loads.
+struct Lds3 { unsigned long long w01; unsigned w2; };
+__device__ __forceinline__ Lds3 lds_read3_issue(const unsigned* p)
+{
+    Lds3 r;
+#if defined(__HIP_DEVICE_COMPILE__) && __HIP_DEVICE_COMPILE__
+    const unsigned a = (unsigned)(unsigned long long)(orbhip_lptr)p;
+    asm volatile("ds_read2_b32 %0, %2 offset1:1\n\tds_read_b32 %1, %2 offset:8" : "=&v"(r.w01), "=&v"(r.w2) : "v"(a));      // (early clobber: the address register is read twice)
+#else
+    r.w01 = (unsigned long long)p[0] | ((unsigned long long)p[1] << 32); r.w2 = p[2];
+#endif
+    return r;
+}
+__device__ __forceinline__ void lds_read_wait(Lds3& a, Lds3& b)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && __HIP_DEVICE_COMPILE__
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.w01), "+v"(a.w2), "+v"(b.w01), "+v"(b.w2));
+#else
+    (void)a; (void)b;
+#endif
 }
 struct PyrTile { int x0, y0, sxa, sya; };
 // one 256 x 16 tile of level `level` from its staged source footprint (lane tx, wave ty of the tile's four)
@@ -204,18 +242,22 @@ __device__ __forceinline__ void pyr_tile_compute(const ExtractParams& P, const L
     uint8_t* dstp = P.pyr + (long long)frame * P.plane_frame_bytes + g.plane_off + x4;
     const int ytop = T.y0 + ty * PYR_RPT;
     unsigned hp[4] = {0, 0, 0, 0}; int prow = -1;                  // horizontal results of staged row prow
+    Lds3 wa = {0, 0}, wb = {0, 0};
 #pragma unroll
     for (int rr = 0; rr < PYR_RPT; rr++) {
         const int y = ytop + rr;
         if (y >= g.h) break;
-        const int2 ye = yt[y];
+        int2 ye; ye.x = scalar_load(&yt[y].x); ye.y = scalar_load(&yt[y].y);            // (y is the same for the whole wave)
         const unsigned b0s = (unsigned)ye.y << 16, b1s = (unsigned)ye.y & 0xffff0000u;    // coefficients << 16: (b * t) >> 16 == mul_hi(b << 16, t)
         const int ra = min(max(ye.x, 0), g.src_h - 1) - T.sya, rb = min(max(ye.x + 1, 0), g.src_h - 1) - T.sya;
         unsigned h0[4], h1[4];
+        if (ra != prow) wa = lds_read3_issue(colp + ra * PYR_SDW);
+        if (rb != ra) wb = lds_read3_issue(colp + rb * PYR_SDW);
+        lds_read_wait(wa, wb);
         if (ra == prow) { h0[0] = hp[0]; h0[1] = hp[1]; h0[2] = hp[2]; h0[3] = hp[3]; }
-        else pyr_hrow(colp + ra * PYR_SDW, sh, G, h0);
+        else pyr_hrow_from((unsigned)wa.w01, (unsigned)(wa.w01 >> 32), wa.w2, sh, G, h0);
         if (rb == ra) { h1[0] = h0[0]; h1[1] = h0[1]; h1[2] = h0[2]; h1[3] = h0[3]; }
-        else pyr_hrow(colp + rb * PYR_SDW, sh, G, h1);
+        else pyr_hrow_from((unsigned)wb.w01, (unsigned)(wb.w01 >> 32), wb.w2, sh, G, h1);
         unsigned out = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) out |= ((__umulhi(b0s, h0[k]) + __umulhi(b1s, h1[k]) + 2u) >> 2) << (8 * k);
@@ -223,21 +265,39 @@ __device__ __forceinline__ void pyr_tile_compute(const ExtractParams& P, const L
         hp[0] = h1[0]; hp[1] = h1[1]; hp[2] = h1[2]; hp[3] = h1[3]; prow = rb;
     }
 }
+// A workgroup barrier for phases that exchange LDS data only: __syncthreads() is a fence over ALL memory, i.e. `s_waitcnt vmcnt(0)` in front of the barrier -
+// it waits for the wave's global stores and, worse, for every LDS-DMA load still in flight (the NEXT tile's prefetch).
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+// The same for a phase whose LDS accesses are all spelled out (lds_read3_issue, pyr_fix_ragged): the wave's own LDS requests, then the barrier - as one
+// statement the compiler neither looks into nor moves memory accesses across.  (With lds_barrier() the tile loop's FIRST barrier still carried vmcnt(0).)
+__device__ __forceinline__ void lds_barrier_spelled()
+{
+#if defined(__HIP_DEVICE_COMPILE__) && __HIP_DEVICE_COMPILE__
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    lds_barrier();
+#endif
+}
 // LDS-DMA staging of a tile's source footprint, so that a workgroup can have the NEXT tile's rows in flight while it computes this one
 // (the loads never touch a VGPR): wave w brings rows w, w+4, ... (clamped to the footprint's last row), always 6 rows x 2 instructions
 // (dwords 0..63 and 64..83 of the LDS row), so "everything but the newest 12" is an exact s_waitcnt for the tile before.  A lane whose dword
-// is not entirely inside the source row re-reads the last one that is; pyr_dma_patch then writes the row's ragged last dword byte by byte.
+// is not entirely inside the source row reads the last one that is (the DMA takes any byte address); pyr_fix_ragged then shifts the row's ragged last dword into place.
 struct PyrSrc { const uint8_t* src; int spitch, ndw, nrows, dfull; };
-__device__ __forceinline__ PyrTile pyr_dma_issue(const ExtractParams& P, const LevelGeom& g, int level, int tile_x, int tile_y, int frame, int tid, unsigned* s_t, PyrSrc& S)
-{
+__device__ __forceinline__ PyrTile pyr_dma_issue(const ExtractParams& P, const LevelGeom& g, int tile_x, int tile_y, int tid, unsigned* s_t, PyrSrc& S)
+{   // S.src, S.spitch: the source level's plane of this frame (the same for every tile of the workgroup: set by the kernel)
     PyrTile T; T.x0 = tile_x * PYR_TW; T.y0 = tile_y * PYR_TH;
-    S.src = level_src(P, frame, level - 1, S.spitch);
     const int2* xt = P.xtab + g.xtab_off; const int2* yt = P.ytab + g.ytab_off;
     const int xl = min(T.x0 + PYR_TW - 1, g.w - 1), yl = min(T.y0 + PYR_TH - 1, g.h - 1);
-    // the table entries are the same for every lane: pinned to SGPRs, so that the footprint and every row address below are scalar arithmetic
-    // (as vector loads they made each row's address a 64-bit VALU multiply-add plus two v_readfirstlane: 65 VALU per tile, PMC round 3)
-    const int e_x0 = __builtin_amdgcn_readfirstlane(xt[T.x0].x), e_xl = __builtin_amdgcn_readfirstlane(xt[xl].x);
-    const int e_y0 = __builtin_amdgcn_readfirstlane(yt[T.y0].x), e_yl = __builtin_amdgcn_readfirstlane(yt[yl].x);
+    // the table entries are the same for every lane: scalar loads, so that the footprint and every row address below are scalar arithmetic
+    // (as vector loads they made each row's address a 64-bit VALU multiply-add plus two v_readfirstlane: 65 VALU per tile, PMC round 3) and
+    // nothing here waits on vmcnt (round 5 read them as vector loads: `s_waitcnt vmcnt(0)` in front of every tile's requests - the tile before's stores)
+    const int e_x0 = scalar_load(&xt[T.x0].x), e_xl = scalar_load(&xt[xl].x);
+    const int e_y0 = scalar_load(&yt[T.y0].x), e_yl = scalar_load(&yt[yl].x);
     T.sxa = e_x0 & ~3; const int sxb = min(e_xl + 1, g.src_w - 1);
     T.sya = min(max(e_y0, 0), g.src_h - 1); const int syb = min(max(e_yl + 1, 0), g.src_h - 1);
     S.ndw = ((sxb - T.sxa) >> 2) + 1; S.nrows = syb - T.sya + 1; S.dfull = (g.src_w - T.sxa) >> 2;
@@ -255,17 +315,48 @@ __device__ __forceinline__ PyrTile pyr_dma_issue(const ExtractParams& P, const L
     }
     return T;
 }
-__device__ __forceinline__ void pyr_dma_patch(const LevelGeom& g, const PyrTile& T, const PyrSrc& S, int tid, unsigned* s_t)
+// The ragged last dword of the footprint's rows (source widths that are not multiples of 4).  Its DMA lane read the four bytes that END at the row's end,
+// so LDS dword `dfull` holds the row's last `part` bytes in its TOP bytes: shifted down here (the bytes past the row's end become zero, as staging by
+// registers makes them).  Every wave fixes the rows it requested itself, right after its own wait: no barrier in between.  (Round 5 brought these
+// bytes with three byte loads per tile, carried in registers across the tile loop: registers with a load pending are what the compiler waits for with vmcnt(0).)
+__device__ __forceinline__ void pyr_fix_ragged(const LevelGeom& g, const PyrSrc& S, int tid, unsigned* s_t)
 {
-    const int part = g.src_w & 3;                                      // sxa is a multiple of 4
+    const int part = g.src_w & 3;
     if (part == 0 || S.dfull >= S.ndw) return;                         // wave-uniform
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, r = wave + 4 * lane;
-    if (lane < PYR_SROWS / 4 && r < S.nrows) {
-        const uint8_t* row = S.src + (long long)(T.sya + r) * S.spitch + T.sxa + 4 * S.dfull;
-        unsigned w = 0;
-        for (int q = 0; q < part; q++) w |= (unsigned)row[q] << (8 * q);
-        s_t[r * PYR_SDW + S.dfull] = w;
+    if (lane < PYR_SROWS / 4) {
+        unsigned* p = s_t + r * PYR_SDW + S.dfull;
+#if defined(__HIP_DEVICE_COMPILE__) && __HIP_DEVICE_COMPILE__
+        // (as ordinary LDS accesses these would carry `s_waitcnt vmcnt(0)` for the NEXT tile's LDS-DMA in flight: see lds_read3_issue)
+        const unsigned a = (unsigned)(unsigned long long)(orbhip_lptr)p, sh = 8u * (unsigned)(4 - part);
+        unsigned w;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\tv_lshrrev_b32 %0, %2, %0\n\tds_write_b32 %1, %0" : "=&v"(w) : "v"(a), "s"(sh) : "memory");
+#else
+        *p >>= 8 * (4 - part);
+#endif
     }
+}
+// One tile of k_pyramid_level_g: the NEXT tile's requests go out first, then everything but those is waited for (loads return in order; this tile's stores
+// only make the count more conservative), then the tile is computed from `cur` while `nxt` fills.  Round 5's form of this loop spent 62 % of its wave
+// cycles waiting (2.4 TB/s) because every wait in it was `s_waitcnt vmcnt(0)` - for the prefetch just issued and for the tile's own stores:
+//  * __syncthreads() is a fence over all memory: vmcnt(0) in front of the barrier.  lds_barrier() waits for LDS traffic only;
+//  * every ordinary LDS access while an LDS-DMA is pending gets a vmcnt(0) from the compiler (lds_read3_issue): the accesses of the tile loop are spelled out;
+//  * the row tables were vector loads (scalar_load) and the ragged bytes were carried in registers (pyr_fix_ragged).
+// (profiles/r06_exp_pyramid_lds_barriers.txt)
+struct PyrStep { PyrTile T; PyrSrc S; };
+__device__ __forceinline__ void pyr_step(const ExtractParams& P, const LevelGeom& g, int tx, int tyy, int tyend, int frame, int tid, int lane_x, int wv, const PyrGroup& G,
+                                         unsigned* cur, unsigned* nxt, PyrStep& st)
+{
+    const bool more = tyy + 1 < tyend;
+    PyrStep nx = st;
+    if (more) nx.T = pyr_dma_issue(P, g, tx, tyy + 1, tid, nxt, nx.S);
+    if (more) __builtin_amdgcn_s_waitcnt(ORBHIP_VMCNT(2 * (PYR_SROWS / 4))); else lds_dma_wait();
+    __builtin_amdgcn_wave_barrier();
+    pyr_fix_ragged(g, st.S, tid, cur);
+    lds_barrier_spelled();
+    pyr_tile_compute(P, g, st.T, frame, lane_x, wv, cur, G);
+    lds_barrier_spelled();
+    st = nx;
 }
 // nt = tiles (one below the other) per workgroup: 2, or 4 from 384 frames on
 __global__ __launch_bounds__(256) void k_pyramid_level_g(ExtractParams P, int level, int nt)
@@ -275,25 +366,18 @@ __global__ __launch_bounds__(256) void k_pyramid_level_g(ExtractParams P, int le
     int tile, frame;
     if (!xcd_frame_map(gx * gyn, P.nframes, tile, frame)) return;
     frame += P.frame0;
-    __shared__ unsigned s_t[2][PYR_SROWS * PYR_SDW];
+    __shared__ unsigned s_t0[PYR_SROWS * PYR_SDW], s_t1[PYR_SROWS * PYR_SDW];
     const int tid = threadIdx.y * 64 + threadIdx.x, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.y);
     const int tx = tile % gx;
     int ty = (tile / gx) * nt;
     const int tyend = min(ty + nt, gy);
-    PyrSrc S, Sn;
-    PyrTile T = pyr_dma_issue(P, g, level, tx, ty, frame, tid, s_t[0], S), Tn = T;
+    PyrStep st;
+    st.S.src = level_src(P, frame, level - 1, st.S.spitch);
+    st.T = pyr_dma_issue(P, g, tx, ty, tid, s_t0, st.S);
     const PyrGroup G = P.xgrp[g.xgrp_off + min(tx * (PYR_TW / 4) + (int)threadIdx.x, (g.w - 1) >> 2)];      // this lane's four columns: the same in every tile below
-    int buf = 0;
-    for (; ty < tyend; ty++) {
-        const bool more = ty + 1 < tyend;
-        if (more) Tn = pyr_dma_issue(P, g, level, tx, ty + 1, frame, tid, s_t[buf ^ 1], Sn);      // in flight during this tile's arithmetic
-        if (more) __builtin_amdgcn_s_waitcnt(ORBHIP_VMCNT(2 * (PYR_SROWS / 4))); else lds_dma_wait();
-        __builtin_amdgcn_wave_barrier();
-        pyr_dma_patch(g, T, S, tid, s_t[buf]);
-        __syncthreads();
-        pyr_tile_compute(P, g, T, frame, threadIdx.x, wv, s_t[buf], G);
-        __syncthreads();
-        T = Tn; S = Sn; buf ^= 1;
+    for (; ty < tyend; ty += 2) {                                      // (two steps per trip: the buffers swap roles with constant addresses)
+        pyr_step(P, g, tx, ty, tyend, frame, tid, threadIdx.x, wv, G, s_t0, s_t1, st);
+        if (ty + 1 < tyend) pyr_step(P, g, tx, ty + 1, tyend, frame, tid, threadIdx.x, wv, G, s_t1, s_t0, st);
     }
 }
 
@@ -325,12 +409,6 @@ __global__ __launch_bounds__(256) void k_pyramid_level_direct(ExtractParams P, i
 // entries and of the level-0 rectangle before it waits for any of them.  After that the seven levels run from LDS, four pixels at a time like
 // k_pyramid_level_g (pyr_hrow), behind barriers that wait for LDS only (__syncthreads would also wait for the level's stores to reach memory: 0.5 us a level).
 __device__ __forceinline__ int qt_wave_incl_scan(int v, int lane);      // (DPP prefix sum, defined with the quadtree)
-__device__ __forceinline__ void lds_barrier()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
 #define PC_T 256            // threads.  (1024 - four waves per SIMD to hide the LDS latencies - was slower, 22.6 against 21.3 us: a big workgroup starts and synchronises
                             // slowly; four rows of a group column per step with all their LDS reads requested together measured the same as one row per step)
 #define PC_GIT 3            // per thread: 16-byte pieces of PyrGroup entries (<= 256 entries), row-table entries (<= 512), dwords of the level-0 rectangle (<= 4096); the host checks
@@ -453,7 +531,8 @@ void orbhip_launch_pyramid_level(const ExtractParams& P, int level, int w, int h
 {   // mode 2: staged + 4-pixel groups, 1: staged, 0: straight from global memory
     ExtractParams Q = P; Q.nframes = nframes;
     dim3 grid(xcd_grid(((w + PYR_TW - 1) / PYR_TW) * ((h + PYR_TH - 1) / PYR_TH), nframes), 1, 1), block(64, 4, 1);
-    const int nt = nframes >= 384 ? 4 : nframes <= 8 ? 1 : 2;          // measured (round 3, same call): B = 512: 181.7 k frames/s with 2, 183.3 k with 4, 181.8 k with 8, 180.3 k with 1; B = 128: 157.6 k with 2, 155.2 k with 4
+    static const int nt_env = getenv("ORBHIP_PYR_NT") ? atoi(getenv("ORBHIP_PYR_NT")) : 0;
+    const int nt = nt_env > 0 ? nt_env : nframes >= 384 ? 4 : nframes <= 8 ? 1 : 2;          // measured (round 3, same call): B = 512: 181.7 k frames/s with 2, 183.3 k with 4, 181.8 k with 8, 180.3 k with 1; B = 128: 157.6 k with 2, 155.2 k with 4
     const int gyn = (((h + PYR_TH - 1) / PYR_TH) + nt - 1) / nt;
     if (mode == 2) hipLaunchKernelGGL(k_pyramid_level_g, dim3(xcd_grid(((w + PYR_TW - 1) / PYR_TW) * gyn, nframes), 1, 1), block, 0, s, Q, level, nt);
     else if (mode == 1) hipLaunchKernelGGL(k_pyramid_level, grid, block, 0, s, Q, level);
