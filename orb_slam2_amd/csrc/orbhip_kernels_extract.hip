@@ -1946,6 +1946,7 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
             const f2v A2 = {a, a}, B2 = {b, b}, MG = {8388672.0f, 8388672.0f};
             const unsigned cbias = 3072u + 64u + 0x4B000000u;
             auto brief = [&](auto fused) {
+                int t0[4], t1[4];
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const f2v X = {pt[r].x, pt[r].z}, Y = {pt[r].y, pt[r].w};        // (x0, x1), (y0, y1)
@@ -1962,8 +1963,13 @@ __global__ __launch_bounds__(256) void k_describe(ExtractParams P)
                     const f2v ry = fy + MG, rx = fx + MG;
                     const int o0 = (int)(__umul24(__float_as_uint(ry[0]), (unsigned)DS_WSTRIDE) + __float_as_uint(rx[0]) - cbias);
                     const int o1 = (int)(__umul24(__float_as_uint(ry[1]), (unsigned)DS_WSTRIDE) + __float_as_uint(rx[1]) - cbias);
-                    const int t0 = w8[o0], t1 = w8[o1];
-                    const unsigned long long bits = __ballot(t0 < t1);       // test 64r+lane -> byte (64r+lane)/8, bit lane%8
+                    t0[r] = w8[o0]; t1[r] = w8[o1];
+                }
+                // all eight byte reads are out before the first comparison: with the ballots and v_writelane (an asm statement: a scheduling boundary) in the
+                // same loop, every round waited for its own two reads - eight LDS round trips per slot one after the other (round 5)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const unsigned long long bits = __ballot(t0[r] < t1[r]);       // test 64r+lane -> byte (64r+lane)/8, bit lane%8
                     dlo_l = orbhip_writelane((int)(unsigned)bits, dlane + r, dlo_l);          // 2 VALU instead of compare + 2 moves + 2 selects
                     dhi_l = orbhip_writelane((int)(unsigned)(bits >> 32), dlane + r, dhi_l);
                 }

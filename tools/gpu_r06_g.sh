@@ -9,12 +9,12 @@ F="--no-traffic --no-dropin-loop --no-secondary --no-cpu-baseline --no-host-io -
 run() { name=$1; shift; timeout 600 "$@" > $OUT/$name.json 2>> $OUT/err.txt; python - <<PY
 import json
 d = json.loads(open("$OUT/$name.json").read().strip().splitlines()[-1])
-print("$name", d["value"], d["kernels_ms_per_launch"]["k_pyramid_level"], d["parity"]["mismatches"], d["parity"]["replica_mismatches"])
+print("$name", d["value"], d["kernels_ms_per_launch"]["k_pyramid_level"], d["kernels_ms_per_launch"]["k_describe"], d["parity"]["mismatches"], d["parity"]["replica_mismatches"])
 PY
 }
 run base python bench.py $F
-run nt2 env ORBHIP_PYR_NT=2 python bench.py $F
-run nt8 env ORBHIP_PYR_NT=8 python bench.py $F
-run nt1 env ORBHIP_PYR_NT=1 python bench.py $F
+
+
+run again python bench.py $F
 tail -3 $OUT/err.txt
 exit 0
