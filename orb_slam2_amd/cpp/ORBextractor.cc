@@ -126,7 +126,7 @@ void ORBextractor::EnsureContext(int width, int height, int maxBatch)
             orbhip_destroy(mvCtxCache[lru].ctx); mvCtxCache.erase(mvCtxCache.begin() + lru);
         }
     }
-    mbFrameState = false; mbBound = false; mbStereoColumns = false; mnLastN = 0;      // whatever follows belongs to another context
+    mbFrameState = false; mbBound = false; mbStereoColumns = false; mbPairResults = false; mnLastN = 0;      // whatever follows belongs to another context
     // ... and one that was laid out for this size ON THIS DEVICE comes back (rectification maps belong to one size: such contexts are never shared)
     for (size_t i = 0; i < mvCtxCache.size() && mvMapX.empty(); i++) {
         const CtxSlot c = mvCtxCache[i];
@@ -178,10 +178,11 @@ void ORBextractor::ExtractStereo(cv::InputArray _imLeft, cv::InputArray _imRight
                                  std::vector<cv::KeyPoint>& keysRight, cv::OutputArray descRight, float mbf, float mb)
 {
     if (_imLeft.empty() || _imRight.empty()) {                   // the reference's two operator() calls return silently on an empty image (ORBextractor.cc:1046-1047)
-        if (!_imLeft.empty()) (*this)(_imLeft, cv::Mat(), keysLeft, descLeft);
         mbPairResults = false;
+        if (!_imLeft.empty()) (*this)(_imLeft, cv::Mat(), keysLeft, descLeft);
         return;
     }
+    mbPairResults = false;                                       // (set again at the very end: a throw below must not leave the pair before's columns behind)
     cv::Mat L = _imLeft.getMat(), R = _imRight.getMat();
     assert(L.type() == CV_8UC1 && R.type() == CV_8UC1 && L.cols == R.cols && L.rows == R.rows);
     if (L.step != R.step) throw ORBhipError("ORBextractor::ExtractStereo: the two images must share their row step");
@@ -331,7 +332,7 @@ int ORBextractor::Submit(const std::vector<cv::Mat>& images, int maxBatch)
     for (int i = 0; i < n; i++) ptrs[i] = images[i].data;
     int ticket = -1;
     if (orbhip_submit(mpCtx, n, &ptrs[0], (int)images[0].step, &ticket) != ORBHIP_OK) Fail("ORBextractor::Submit");
-    mvTicketSizes[ticket & 3] = n; mnPendingTickets++; mbFrameState = false;
+    mvTicketSizes[ticket & 3] = n; mnPendingTickets++; mbFrameState = false; mbPairResults = false;
     return ticket;
 }
 
@@ -352,7 +353,7 @@ void ORBextractor::Collect(int ticket, std::vector<std::vector<cv::KeyPoint> >& 
         descriptors[i].create(cnt[i], 32, CV_8U);
         for (int r = 0; r < cnt[i]; r++) memcpy(descriptors[i].ptr(r), &desc[((size_t)i * cap + r) * 32], 32);
     }
-    mnLastN = 0; mbFrameState = false; mbBound = false; mbStereoColumns = false;                            // the context's planes / key points are some batch's, not one image's
+    mnLastN = 0; mbFrameState = false; mbBound = false; mbStereoColumns = false; mbPairResults = false;     // the context's planes / key points are some batch's, not one image's
     std::lock_guard<std::mutex> lock(mvImagePyramid.mMutex);
     mvImagePyramid.mbStale = true;
 }

@@ -2204,6 +2204,12 @@ extern "C" orbhip_status orbhip_set_stereo_columns(orbhip_ctx* c, int frame, con
         HIPCHK(hipEventCreateWithFlags(&c->ev_ucols, hipEventDisableTiming));
     }
     if (c->ucols_pending) { HIPCHK(hipEventSynchronize(c->ev_ucols)); c->ucols_pending = false; }      // the pinned block is free again
+    if (c->d_last_uright != c->d_ucols) {
+        // the block becomes the extraction's mvuRight for EVERY frame: the other frames keep the columns a stereo / RGB-D step left for them, or read
+        // "no right coordinate" (-1, Frame.cc:468) - never whatever the allocation held
+        if (c->d_last_uright) HIPCHK(orbhip_copy_async(c->d_ucols, c->d_last_uright, total * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        else HIPCHK(hipMemsetD32Async((hipDeviceptr_t)c->d_ucols, 0xBF800000, total, c->stream));
+    }
     if (n > 0) {
         memcpy(c->h_ucols + (size_t)frame * c->out_cap, u_right, (size_t)n * sizeof(float));
         HIPCHK(orbhip_copy_async(c->d_ucols + (size_t)frame * c->out_cap, c->h_ucols + (size_t)frame * c->out_cap, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));

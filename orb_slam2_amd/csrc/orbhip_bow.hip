@@ -1227,6 +1227,10 @@ extern "C" orbhip_status orbhip_search_for_triangulation_batch(int device, const
             A.io(&S.fn, b.nfv, b.fv_node, b.nfv); A.io(&S.fo, b.nfv + 1, (const int*)b.fv_off, b.nfv + 1); A.io(&S.ff, std::max(m2, 1), b.fv_feat, m2);
             A.io(&S.sc, b.nlevels, b.scale_factors, b.nlevels); A.io(&S.sg, b.nlevels, b.level_sigma2, b.nlevels);
             A.io(&dbin[k], n1, (const int*)Q.match12, n1);
+        }
+        // everything that travels back, of every pair, side by side behind the inputs: arena_download copies ONE span [first dst, last dst)
+        for (int k = 0; k < NL; k++) {
+            orbhip_tri_pair& Q = pairs[live[k]];
             A.io(&dm12[k], n1, (const int*)Q.match12, n1, (int*)Q.match12, n1);
             A.io(&dhist[k], ORBHIP_HISTO_LENGTH + 2, (const int*)zeros[k].data(), ORBHIP_HISTO_LENGTH + 2, tail[k].data(), ORBHIP_HISTO_LENGTH + 2);
         }

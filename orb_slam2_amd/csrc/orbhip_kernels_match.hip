@@ -509,6 +509,16 @@ bool orbhip_launch_hamming_nn(const uint8_t* d_q, int nq, const uint8_t* d_db, l
     if (const char* e = getenv("ORBHIP_NN")) {      // (read per call: a scan is at least a hundred microseconds; tests switch forms inside one process)
         if (!strcmp(e, "valu")) form = 0; else if (!strcmp(e, "i8")) form = 1;
         else if (!strncmp(e, "fp4", 3)) { form = 2; int a = 0, b2 = 0, c = 0, d = 0; const int k = sscanf(e + 3, ":%d:%d:%d:%d", &a, &b2, &c, &d); if (k >= 1) qt = a; if (k >= 2) occ = b2; if (k >= 3) lch = c; if (k >= 4) tpb = d; }
+        // a shape that was not compiled (the switch below lists them; all have >= 2^13 rows per workgroup, so their partials fit the workspace sized above):
+        // the default shape scans instead - said once on stderr - rather than a failure the callers could only report as "no device memory"
+        static const int known[] = {22131, 32131, 42131, 42151, 42152, 42154, 42158, 23154, 23151, 22154, 42134, 42164, 32154, 42156, 42153};
+        bool listed = false;
+        for (int v : known) listed = listed || v == qt * 10000 + occ * 1000 + lch * 10 + tpb;
+        if (form == 2 && !listed) {
+            static bool said = false;
+            if (!said) { said = true; fprintf(stderr, "orbhip: ORBHIP_NN=%s names a scan shape that is not built; the default fp4:%d:%d:%d:%d is used\n", e, ORBHIP_NN_FP4_QT, ORBHIP_NN_FP4_OCC, ORBHIP_NN_FP4_LCH, ORBHIP_NN_FP4_TPB); }
+            qt = ORBHIP_NN_FP4_QT; occ = ORBHIP_NN_FP4_OCC; lch = ORBHIP_NN_FP4_LCH; tpb = ORBHIP_NN_FP4_TPB;
+        }
     }
     if (form >= 2 && ndb >= 4 * NN_CHUNK) {
         const int qg = 4 * qt * 32, nch = (int)((ndb + ((long long)1 << lch) - 1) >> lch);      // (<= nchunks: the partials fit the workspace)

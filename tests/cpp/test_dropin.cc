@@ -123,6 +123,19 @@ int main(int argc, char** argv)
                 ok = ok && exP->HoldsFrame(100 + rep, (int)kL.size()) && !exP->HoldsFrame(99, (int)kL.size()) && !other;
                 if (rep == 1) { std::vector<cv::KeyPoint> k1; cv::Mat d1; (*exP)(im[1], cv::Mat(), k1, d1); ok = ok && (int)k1.size() == F2.N && !exP->HoldsStereoColumns(); }      // a single-image call in between
             }
+            // the pair's columns belong to the pair: a Submit in between takes them away - ComputeStereoMatches then says that there is no
+            // frame state instead of handing out the pair before's mvuRight / mvDepth
+            if (ok) {
+                std::vector<cv::KeyPoint> kL, kR; cv::Mat dL, dR;
+                exP->ExtractStereo(im[0], im[1], kL, dL, kR, dR, mbf, mb);
+                std::vector<cv::Mat> b(2); b[0] = im[0]; b[1] = im[1];
+                const int t = exP->Submit(b, 2);
+                bool refused = false;
+                try { exP->ComputeStereoMatches(*exR, mbf, mb, (int)kL.size(), uOne, dOne); } catch (const ORB_SLAM2::ORBhipError&) { refused = true; }
+                std::vector<std::vector<cv::KeyPoint> > kb; std::vector<cv::Mat> db;
+                exP->Collect(t, kb, db);
+                ok = refused && (int)kb[0].size() == F1.N;
+            }
             delete exP;
         }
         fwrite(&ok, 4, 1, f);

@@ -327,6 +327,8 @@ inline hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp,
     for (size_t y = 0; y < h; y++) memcpy((char*)d + y * dp, (const char*)s + y * sp, w); return hipSuccess; }
 inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { memset(d, v, n); return hipSuccess; }
+typedef void* hipDeviceptr_t;
+inline hipError_t hipMemsetD32Async(hipDeviceptr_t d, int v, size_t n, hipStream_t = nullptr) { for (size_t i = 0; i < n; i++) static_cast<int*>(d)[i] = v; return hipSuccess; }
 inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return hipSuccess; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
 inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = nullptr; return hipSuccess; }

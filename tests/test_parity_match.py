@@ -119,7 +119,7 @@ def test_brute_force_nn(backend, oracle):
     assert all(np.array_equal(a, b) for a, b in zip(merged, want))
 
 
-@pytest.mark.parametrize("form", ["default", "i8", "fp4:2:2:13:1", "fp4:3:2:13:1", "fp4:4:2:15:4", "fp4:4:2:15:6:unseeded", "fp4:4:2:15:3", "fp4:2:3:15:4", "fp4:4:2:16:4", "fp4:4:2:15:8", "valu"])
+@pytest.mark.parametrize("form", ["default", "i8", "fp4:2:2:13:1", "fp4:3:2:13:1", "fp4:4:2:15:4", "fp4:4:2:15:6:unseeded", "fp4:4:2:15:3", "fp4:2:3:15:4", "fp4:4:2:16:4", "fp4:4:2:15:8", "fp4:9:9:9:9", "valu"])
 def test_brute_force_nn_matrix_core_scan(backend, oracle, monkeypatch, form):
     """Databases from four chunks (32 K rows) on are scanned on the matrix cores - k_hamming_nn_mfma (<+-1, +-1> = 256 - 2 Hamming as i8 products) or
     k_hamming_nn_fp4 (the same as FP4 products on v_mfma_scale_f32_32x32x64_f8f6f4; query tiles per wave : workgroups per CU : log2 rows per workgroup); ORBHIP_NN picks the form:
@@ -128,12 +128,13 @@ def test_brute_force_nn_matrix_core_scan(backend, oracle, monkeypatch, form):
     # the default shape (fp4:4:2:15:6: four query tiles per wave, two workgroups per CU, 2^15 rows per workgroup, six tiles per barrier = the pipelined loop on
     # three accumulator pairs) scans in two passes: the head's second-best distance per query seeds the skip threshold of every later chunk
     # (ORBHIP_NN_SEED=0: one pass).  Both here: the duplicates of rows 100..104 in the last tile tie with the head's rows and must lose to them.
+    # fp4:9:9:9:9 is not a built shape: the default one scans (and says so on stderr) instead of a failed call
     if form.endswith(":unseeded"):
         form = form[:-len(":unseeded")]
         monkeypatch.setenv("ORBHIP_NN_SEED", "0")
     if form != "default":
         monkeypatch.setenv("ORBHIP_NN", form)
-    if backend.endswith("_emu.so") and form.startswith("fp4") and (form not in ("fp4:3:2:13:1",) or "ORBHIP_NN_SEED" in os.environ):
+    if backend.endswith("_emu.so") and form.startswith("fp4") and (form not in ("fp4:3:2:13:1", "fp4:9:9:9:9") or "ORBHIP_NN_SEED" in os.environ):
         pytest.skip("the emulation's FP4 matrix product is slow: one FP4 form is enough here, all run on the GPU")
     rng = np.random.default_rng(5)
     n = 4 * 8192 + 1000 + 13 if backend.endswith("_emu.so") else 3 * 65536 + 8192 + 1000 + 13      # (several workgroups of the largest chunk on the GPU)

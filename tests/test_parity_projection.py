@@ -250,6 +250,33 @@ def test_stereo_columns_handed_to_a_resident_frame(backend, oracle):
     x.close()
 
 
+def test_stereo_columns_of_one_frame_leave_the_others_without(backend, oracle):
+    """A context that holds two frames: columns handed to frame 1 only.  A resident search on frame 0 with the right-coordinate test then sees mvuRight = -1
+    everywhere (Frame.cc:468: no right coordinate) - not whatever the freshly allocated block held; frame 1 sees its own columns."""
+    w, h, n = 400, 300, 400
+    x = orb_slam2_amd.ORBextractor(n, 1.2, 8, 20, 7, w, h, max_batch=2, library=backend)
+    sf = x.GetScaleFactors()
+    kb, db = x.extract_batch(np.stack([synth.frame(w, h, seed=61), synth.frame(w, h, seed=62)]))
+    rng = np.random.default_rng(5)
+    k1 = kb[1]
+    u1 = np.where(rng.random(len(k1)) < 0.7, k1["x"] - np.float32(12.0), -1.0).astype(np.float32)
+    x.set_stereo_columns(u1, frame=1)
+    for fidx, u in ((0, None), (1, u1)):
+        kc, dc = kb[fidx], db[fidx]
+        nk = len(kc)
+        uu = np.full(nk, -1.0, np.float32) if u is None else u
+        q = np.zeros(nk, oracle.PROJ_QUERY_DTYPE)
+        q["x"], q["y"] = kc["x"] + np.float32(0.5), kc["y"] - np.float32(0.5)
+        q["radius"] = (np.float32(5.0) * sf[kc["octave"]]).astype(np.float32)
+        q["min_level"], q["max_level"] = kc["octave"] - 1, kc["octave"] + 1
+        q["blocks"] = 1; q["angle"] = kc["angle"]
+        q["ur"] = np.where(uu > 0, uu + np.float32(1.0), q["x"] - 20).astype(np.float32)
+        n_o, f_o = oracle.search_by_projection(kc, dc, w, h, q, dc, 0, nnratio=0.9, th_high=100, check_ori=True, u_right=uu)
+        n_g, f_g = x.search_by_projection(fidx, nk, q, dc, 0, nnratio=0.9, th_high=100, check_ori=True, use_u_right=True)
+        assert n_g == n_o and np.array_equal(f_g, f_o) and n_o > 50, fidx
+    x.close()
+
+
 def test_frame_epilogues_single_image_sequence(backend, oracle):
     """What ORB_SLAM2 does: one stereo pair at a time on two max_batch = 1 contexts, each pair followed by ComputeStereoMatches and two
     projection searches on the left frame.  From the second pair on the contexts build the right image's row table and the left image's 64x48
