@@ -105,7 +105,7 @@ struct orbhip_ctx {
     int* d_grid_start = nullptr; int* d_grid_items = nullptr; float2* d_grid_xy = nullptr; unsigned* d_cand = nullptr; unsigned* d_top = nullptr; int* d_ncand = nullptr; float* d_prev = nullptr; int* d_m12 = nullptr; int* d_nm = nullptr;
     // camera geometry: undistorted key points of a distorted camera, rectification maps of a raw stereo camera
     orbhip_bounds bounds = {0, 0, 0, 0}; bool distorted = false; CameraD cam = {}; orbhip_keypoint* d_out_kpun[3] = {nullptr, nullptr, nullptr}; orbhip_keypoint* h_kpun = nullptr;
-    int* d_map_x = nullptr; int* d_map_y = nullptr; int src_w = 0, src_h = 0, raw_pitch = 0; uint8_t* d_raw = nullptr; uint8_t* h_raw = nullptr; uint8_t* d_depth = nullptr; size_t depth_bytes = 0; const float* d_last_uright = nullptr; float* d_ucols = nullptr; float* h_ucols = nullptr; hipEvent_t ev_ucols = nullptr; bool ucols_pending = false;   // mvuRight [slot][out_cap] of the last stereo / RGB-D step
+    int* d_map_x = nullptr; int* d_map_y = nullptr; int src_w = 0, src_h = 0, raw_pitch = 0; uint8_t* d_raw = nullptr; uint8_t* h_raw = nullptr; uint8_t* d_depth = nullptr; size_t depth_bytes = 0; const float* d_last_uright = nullptr; float* d_ucols = nullptr; int* d_match_ws = nullptr; float* h_ucols = nullptr; hipEvent_t ev_ucols = nullptr; bool ucols_pending = false;   // mvuRight [slot][out_cap] of the last stereo / RGB-D step
     // pipelined host-buffer path
     HostSet sets[ORBHIP_RING]; hipStream_t hstream = nullptr, dstream = nullptr; int next_ticket = 0, oldest_ticket = 0, ticket_set[ORBHIP_RING] = {0, 0, 0}; const uint8_t* last_d_in = nullptr; bool plane0_dirty = false;   // plane0_dirty: set 0's level-0 plane was last written by an un-ticketed entry (colour / rectify)
     // profiling
@@ -368,7 +368,7 @@ extern "C" void orbhip_destroy(orbhip_ctx* c)
                     c->d_qt_val, c->d_qt_code, c->d_qt_node, c->d_lvl_kp, c->d_lvl_n[0], c->d_lvl_n[1], c->d_lvl_n[2], c->d_out_block[0], c->d_out_block[1], c->d_out_block[2], c->d_grid_start, c->d_grid_items, c->d_grid_xy, c->d_cand, c->d_top, c->d_ncand,
                     c->d_prev, c->d_m12, c->d_nm};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    { void* ep[] = {c->d_fgrid_start, c->d_fgrid_items, c->d_fgrid_xy, c->d_rrow_start, c->d_rrow_items}; for (void* q : ep) if (q) (void)hipFree(q); if (c->ev_epilogue) (void)hipEventDestroy(c->ev_epilogue); if (c->h_st) (void)hipHostFree(c->h_st); if (c->d_ucols) (void)hipFree(c->d_ucols); if (c->h_ucols) (void)hipHostFree(c->h_ucols); if (c->ev_ucols) (void)hipEventDestroy(c->ev_ucols); if (c->ev_stereo) (void)hipEventDestroy(c->ev_stereo); }
+    { void* ep[] = {c->d_fgrid_start, c->d_fgrid_items, c->d_fgrid_xy, c->d_rrow_start, c->d_rrow_items}; for (void* q : ep) if (q) (void)hipFree(q); if (c->ev_epilogue) (void)hipEventDestroy(c->ev_epilogue); if (c->h_st) (void)hipHostFree(c->h_st); if (c->d_ucols) (void)hipFree(c->d_ucols); if (c->d_match_ws) (void)hipFree(c->d_match_ws); if (c->h_ucols) (void)hipHostFree(c->h_ucols); if (c->ev_ucols) (void)hipEventDestroy(c->ev_ucols); if (c->ev_stereo) (void)hipEventDestroy(c->ev_stereo); }
     { void* st[] = {c->d_st_rowstart, c->d_st_rowitems, c->d_st_u /* | d_st_depth */, c->d_st_sad}; for (void* q : st) if (q) (void)hipFree(q); }
     for (auto& hs : c->sets) {
         for (int k = 0; k < ORBHIP_MAX_CHUNKS; k++) { if (hs.ev_h2d[k]) (void)hipEventDestroy(hs.ev_h2d[k]); if (hs.ev_k[k]) (void)hipEventDestroy(hs.ev_k[k]); if (hs.ev_d2h[k]) (void)hipEventDestroy(hs.ev_d2h[k]); }
@@ -512,7 +512,6 @@ extern "C" orbhip_status orbhip_create(orbhip_ctx** out, const orbhip_config* cf
     c->lvl_kp_per_frame = kp_off; c->out_cap = kp_off; c->lvl0_cap = c->geom[0].kp_cap;
     if (cand_off >= (1 << 24)) { delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "too many candidate slots"); }
     if (orbhip_quadtree_lds_bytes(c->qt_maxn, c->qt_maxcells) > 150 * 1024) { const int qn = c->qt_maxn; delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "nfeatures too large for the LDS quadtree (%d nodes)", qn); }
-    if ((size_t)(4 * c->out_cap + 4 * c->lvl0_cap + 64) * sizeof(int) > 158 * 1024) { delete c; return fail(ORBHIP_ERR_UNSUPPORTED, "nfeatures too large for the LDS matcher"); }
 
     // ---- device
     // Stream priorities (ORBHIP_STREAM_PRIO, default 2): the blur's stream - tens of thousands of independent tiles - gets the LOWEST priority, so that
@@ -746,6 +745,10 @@ static orbhip_status run_pipeline(orbhip_ctx* c, int nimg, const uint8_t* d_img0
         M.cap = c->out_cap; M.min_x = c->bounds.min_x; M.min_y = c->bounds.min_y; M.max_x = c->bounds.max_x; M.max_y = c->bounds.max_y;
         M.grid_start = c->d_grid_start; M.grid_items = c->d_grid_items; M.grid_xy = c->d_grid_xy; M.cand = c->d_cand; M.top = c->d_top; M.ncand = c->d_ncand; M.cand_stride = c->lvl0_cap; M.lvl0_cap = c->lvl0_cap;
         M.prev = c->d_prev; M.matches12 = c->d_m12; M.nmatches = c->d_nm; M.window = window; M.nnratio = nnratio; M.check_ori = check_ori; M.slot0 = 0;
+        if (orbhip_match_select_big(c->out_cap, c->lvl0_cap)) {     // nfeatures beyond what LDS holds: the select kernel's tables in device memory, [slot][...], allocated at the first matched call
+            if (!c->d_match_ws) HIPCHK(dalloc(&c->d_match_ws, (size_t)c->B * orbhip_match_select_ints(c->out_cap, c->lvl0_cap)));
+            M.big_ws = c->d_match_ws;
+        }
         // matcher of this batch on its own stream: latency-bound (one wave per slot), overlaps the next call's extraction
         hipStream_t ms = c->serial ? c->stream : c->mstream;
         HIPCHK(hipEventRecord(c->ev_extract, c->stream));
@@ -1478,11 +1481,10 @@ static orbhip_status search_by_projection_impl(int device, const orbhip_keypoint
     if (points) gated_out(queries_out, nq);
     if (n == 0 || nq == 0) return ORBHIP_OK;
     if (n >= (1 << 19)) return fail(ORBHIP_ERR_UNSUPPORTED, "too many features");
-    if (orbhip_proj_select_lds(n) > 150 * 1024) return fail(ORBHIP_ERR_UNSUPPORTED, "too many features for the LDS matcher (%d)", n);
     int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(ORBHIP_ERR_HIP, "no HIP device available: no CPU fallback");
     HIPCHK(hipSetDevice(device));
     hipStream_t ts = orbhip_thread_stream(device);
-    orbhip_keypoint* dk = nullptr; uint8_t *dd = nullptr, *dqd = nullptr; unsigned char *dbl_in = nullptr; float* dur = nullptr; int *dn = nullptr, *dgs = nullptr, *dgi = nullptr, *dnc = nullptr, *dfq = nullptr, *dev = nullptr;
+    orbhip_keypoint* dk = nullptr; uint8_t *dd = nullptr, *dqd = nullptr; unsigned char *dbl_in = nullptr; float* dur = nullptr; int *dn = nullptr, *dgs = nullptr, *dgi = nullptr, *dnc = nullptr, *dfq = nullptr, *dev = nullptr, *dbig = nullptr;
     float2* dgxy = nullptr; orbhip_proj_query* dq = nullptr; unsigned* dcand = nullptr; unsigned* dtop = nullptr;
     orbhip_map_point* dpts = nullptr; orbhip_projection* dP = nullptr;
     hipError_t e = hipSuccess;
@@ -1498,6 +1500,7 @@ static orbhip_status search_by_projection_impl(int device, const orbhip_keypoint
         A.io(&dfq, n, (const int*)nullptr, 0, feature_query, n);
         A.take(&dgs, ORBHIP_GRID_CELLS + 1); A.take(&dgi, n); A.take(&dgxy, n); A.take(&dnc, nq); A.take(&dev, nq);
         A.take(&dcand, (size_t)nq * n); A.take(&dtop, (size_t)nq * 5);
+        if (orbhip_proj_select_big(n)) A.take(&dbig, (size_t)4 * n);      // the select kernel's per-feature tables when they do not fit LDS
     }));
     TRY(arena_upload(ts));
     if (e == hipSuccess) {
@@ -1509,7 +1512,7 @@ static orbhip_status search_by_projection_impl(int device, const orbhip_keypoint
         J.q = dq; J.qdesc = dqd; J.nq = nq; J.cand = dcand; J.ncand = dnc; J.cand_stride = n; J.top = dtop;
         J.pts = dpts; J.proj = dP; J.q_out = dq;
         J.blocked_in = dbl_in; J.blocked_out = nullptr; J.feature_query = dfq; J.nmatches = dn + 1; J.events = dev;
-        J.mode = mode; J.nnratio = nnratio; J.th_high = th_high; J.check_ori = check_ori;
+        J.mode = mode; J.nnratio = nnratio; J.th_high = th_high; J.check_ori = check_ori; J.big_ws = dbig;
         orbhip_launch_proj(J, ts);
         e = hipGetLastError();
     }
@@ -1556,12 +1559,11 @@ extern "C" orbhip_status orbhip_search_by_projection_batch(int device, int nslot
     }
     if (!work) return ORBHIP_OK;
     if (cap >= (1 << 19)) return fail(ORBHIP_ERR_UNSUPPORTED, "too many features");
-    if (orbhip_proj_select_lds(cap) > 150 * 1024) return fail(ORBHIP_ERR_UNSUPPORTED, "too many features for the LDS matcher (%d)", cap);
     if ((size_t)nslots * qcap * cap * sizeof(unsigned) > ((size_t)2 << 30)) return fail(ORBHIP_ERR_UNSUPPORTED, "candidate lists of %d slots x %d queries x %d features exceed 2 GB: split the batch", nslots, qcap, cap);
     int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(ORBHIP_ERR_HIP, "no HIP device available: no CPU fallback");
     HIPCHK(hipSetDevice(device));
     hipStream_t ts = orbhip_thread_stream(device);
-    orbhip_keypoint* dk = nullptr; uint8_t *dd = nullptr, *dqd = nullptr; unsigned char* dbl = nullptr; float* dur = nullptr; int *dn = nullptr, *dnm = nullptr, *dgs = nullptr, *dgi = nullptr, *dnc = nullptr, *dfq = nullptr, *dev = nullptr;
+    orbhip_keypoint* dk = nullptr; uint8_t *dd = nullptr, *dqd = nullptr; unsigned char* dbl = nullptr; float* dur = nullptr; int *dn = nullptr, *dnm = nullptr, *dgs = nullptr, *dgi = nullptr, *dnc = nullptr, *dfq = nullptr, *dev = nullptr, *dbig = nullptr;
     float2* dgxy = nullptr; orbhip_proj_query* dq = nullptr; unsigned *dcand = nullptr, *dtop = nullptr; ProjParams* dJ = nullptr;
     std::vector<int> hn(nslots), hnm(nslots, 0); std::vector<ProjParams> hJ(nslots);
     std::vector<float> no_ur(any_ur ? cap : 0, -1.0f); std::vector<uint8_t> no_bl(any_bl ? cap : 0, 0);
@@ -1587,9 +1589,11 @@ extern "C" orbhip_status orbhip_search_by_projection_batch(int device, int nslot
             }
             A.take(&dgs, (size_t)nslots * (ORBHIP_GRID_CELLS + 1)); A.take(&dgi, nslots * C); A.take(&dgxy, nslots * C); A.take(&dnc, nslots * Q); A.take(&dev, nslots * Q);
             A.take(&dcand, nslots * Q * C); A.take(&dtop, nslots * Q * 5);
+            if (orbhip_proj_select_big(cap)) A.take(&dbig, nslots * 4 * C);      // the select kernel's per-feature tables when the largest slot's do not fit LDS
         }));
         for (int s = 0; s < nslots && e == hipSuccess; s++) {
             ProjParams& J = hJ[s];
+            J.big_ws = dbig ? dbig + s * 4 * C : nullptr;
             J.min_x = bounds->min_x; J.min_y = bounds->min_y; J.max_x = bounds->max_x; J.max_y = bounds->max_y;
             J.grid_start = dgs + (size_t)s * (ORBHIP_GRID_CELLS + 1); J.grid_items = dgi + s * C; J.grid_xy = dgxy + s * C;
             J.cand = dcand + s * Q * C; J.ncand = dnc + s * Q; J.cand_stride = cap; J.top = dtop + s * Q * 5; J.nmatches = dnm + s; J.events = dev + s * Q;
@@ -1815,9 +1819,8 @@ static orbhip_status search_by_projection_frame_impl(orbhip_ctx* c, int frame, i
     for (int i = 0; i < n; i++) feature_query[i] = -1;
     if (points) gated_out(queries_out, nq);
     if (n == 0 || nq == 0) return ORBHIP_OK;
-    if (orbhip_proj_select_lds(n) > 150 * 1024) return fail(ORBHIP_ERR_UNSUPPORTED, "too many features for the LDS matcher (%d)", n);
     HIPCHK(hipSetDevice(c->cfg.device));
-    uint8_t* dqd = nullptr; unsigned char* dbl_in = nullptr; int *dn = nullptr, *dgs = nullptr, *dgi = nullptr, *dnc = nullptr, *dfq = nullptr, *dev = nullptr;
+    uint8_t* dqd = nullptr; unsigned char* dbl_in = nullptr; int *dn = nullptr, *dgs = nullptr, *dgi = nullptr, *dnc = nullptr, *dfq = nullptr, *dev = nullptr, *dbig = nullptr;
     float2* dgxy = nullptr; orbhip_proj_query* dq = nullptr; unsigned* dcand = nullptr; unsigned* dtop = nullptr;
     orbhip_map_point* dpts = nullptr; orbhip_projection* dP = nullptr;
     hipError_t e = hipSuccess;
@@ -1832,6 +1835,7 @@ static orbhip_status search_by_projection_frame_impl(orbhip_ctx* c, int frame, i
         A.io(&dfq, n, (const int*)nullptr, 0, feature_query, n);
         A.take(&dgs, ORBHIP_GRID_CELLS + 1); A.take(&dgi, n); A.take(&dgxy, n); A.take(&dnc, nq); A.take(&dev, nq);
         A.take(&dcand, (size_t)nq * n); A.take(&dtop, (size_t)nq * 5);
+        if (orbhip_proj_select_big(n)) A.take(&dbig, (size_t)4 * n);
     }));
     TRY(arena_upload(c->stream));
     if (e == hipSuccess) {
@@ -1846,7 +1850,7 @@ static orbhip_status search_by_projection_frame_impl(orbhip_ctx* c, int frame, i
         J.q = dq; J.qdesc = dqd; J.nq = nq; J.cand = dcand; J.ncand = dnc; J.cand_stride = n; J.top = dtop;
         J.pts = dpts; J.proj = dP; J.q_out = dq;
         J.blocked_in = dbl_in; J.blocked_out = nullptr; J.feature_query = dfq; J.nmatches = dn + 1; J.events = dev;
-        J.mode = mode; J.nnratio = nnratio; J.th_high = th_high; J.check_ori = check_ori;
+        J.mode = mode; J.nnratio = nnratio; J.th_high = th_high; J.check_ori = check_ori; J.big_ws = dbig;
         orbhip_launch_proj(J, c->stream);
         e = hipGetLastError();
     }
@@ -2365,8 +2369,7 @@ extern "C" orbhip_status orbhip_search_for_initialization_bounds(int device, con
     std::vector<int> list1; for (int i = 0; i < n1; i++) if (kps1[i].octave <= 0) list1.push_back(i);
     int n2l0 = 0; for (int i = 0; i < n2; i++) n2l0 += kps2[i].octave == 0;
     const int cap = std::max(std::max(n1, n2), 1), l0cap = std::max((int)list1.size(), 1), cstride = std::max(n2l0, 1);
-    if ((size_t)(4 * cap + 4 * l0cap + 64) * sizeof(int) > 158 * 1024) return fail(ORBHIP_ERR_UNSUPPORTED, "too many keypoints for the LDS matcher");
-    orbhip_keypoint *dk1 = nullptr, *dk2 = nullptr; uint8_t *dd1 = nullptr, *dd2 = nullptr; int *dn = nullptr, *dlist = nullptr, *dgs = nullptr, *dgi = nullptr, *dnc = nullptr, *dm12 = nullptr; float2* dgxy = nullptr;
+    orbhip_keypoint *dk1 = nullptr, *dk2 = nullptr; uint8_t *dd1 = nullptr, *dd2 = nullptr; int *dn = nullptr, *dlist = nullptr, *dgs = nullptr, *dgi = nullptr, *dnc = nullptr, *dm12 = nullptr, *dbig = nullptr; float2* dgxy = nullptr;
     unsigned* dcand = nullptr; unsigned* dtop = nullptr; float* dprev = nullptr;
     hipError_t e = hipSuccess;
 #define TRY(x) do { if (e == hipSuccess) e = (x); } while (0)
@@ -2379,13 +2382,14 @@ extern "C" orbhip_status orbhip_search_for_initialization_bounds(int device, con
         A.io(&dm12, cap, (const int*)nullptr, 0, matches12, n1);
         A.take(&dgs, ORBHIP_GRID_CELLS + 1); A.take(&dgi, cap); A.take(&dgxy, cap); A.take(&dnc, l0cap);
         A.take(&dcand, (size_t)l0cap * cstride); A.take(&dtop, (size_t)l0cap * 5);
+        if (orbhip_match_select_big(cap, l0cap)) A.take(&dbig, orbhip_match_select_ints(cap, l0cap));      // the select kernel's tables when they do not fit LDS
     }));
     TRY(arena_upload(ts));
     if (e == hipSuccess) {
         MatchParams M; memset(&M, 0, sizeof M);
         M.kp1 = dk1; M.desc1 = dd1; M.n1 = dn; M.n1_lvl0 = dn + 2; M.kp2 = dk2; M.desc2 = dd2; M.n2 = dn + 1; M.lvl_stride = 0; M.list1 = dlist; M.prev_from_kp1 = 0;
         M.cap = cap; M.min_x = bounds->min_x; M.min_y = bounds->min_y; M.max_x = bounds->max_x; M.max_y = bounds->max_y; M.grid_start = dgs; M.grid_items = dgi; M.grid_xy = dgxy; M.cand = dcand; M.top = dtop; M.ncand = dnc; M.cand_stride = cstride; M.lvl0_cap = l0cap;
-        M.prev = dprev; M.matches12 = dm12; M.nmatches = dn + 3; M.window = window; M.nnratio = nnratio; M.check_ori = check_ori;
+        M.prev = dprev; M.matches12 = dm12; M.nmatches = dn + 3; M.window = window; M.nnratio = nnratio; M.check_ori = check_ori; M.big_ws = dbig;
         orbhip_launch_match_grid(M, 1, ts); orbhip_launch_match_candidates(M, 1, ts); orbhip_launch_match_select(M, 1, ts);
         e = hipGetLastError();
     }

@@ -114,7 +114,10 @@ struct MatchParams {        // SearchForInitialization over camera slots (ORBmat
     int window; float nnratio; int check_ori;
     int slot0;                                    // first camera slot of this launch group
     int grid_all_levels;                          // 0: buckets hold level-0 keypoints only (SearchForInitialization); 1: all keypoints
+    int* big_ws;                                  // [slot][orbhip_match_select_ints(cap, lvl0_cap)] when k_match_select's tables do not fit LDS (orbhip_match_select_big); nullptr otherwise
 };
+size_t orbhip_match_select_ints(int cap, int lvl0_cap);      // ints of k_match_select's per-slot tables
+bool orbhip_match_select_big(int cap, int lvl0_cap);         // they exceed the LDS budget: the caller provides MatchParams::big_ws
 
 struct StereoSide {         // device-resident results + pyramid of one extractor context (its last call)
     const orbhip_keypoint* kp; const uint8_t* desc; const int* n;
@@ -147,7 +150,9 @@ struct ProjParams {         // projection-guided search core (ORBmatcher.cc:45-1
     unsigned* top;                                                                          // per query: records of the best and second-best candidate under the initial state
     const unsigned char* blocked_in; unsigned char* blocked_out; int* feature_query; int* nmatches; int* events;
     int mode; float nnratio; int th_high, check_ori;
+    int* big_ws;                // 4 n ints of device memory when the select kernel's per-feature tables do not fit LDS (orbhip_proj_select_big(n)); nullptr otherwise
 };
+bool orbhip_proj_select_big(int n);       // the per-feature tables of k_proj_select exceed the LDS budget: the caller provides ProjParams::big_ws
 void orbhip_launch_proj(const ProjParams& J, hipStream_t s);
 void orbhip_launch_proj_batch(const ProjParams* d_slots, int nslots, int max_nq, int max_n, float gwInv, float ghInv, hipStream_t s);
 struct BestParams {

@@ -826,22 +826,30 @@ void orbhip_launch_match_candidates(const MatchParams& M, int nslots, hipStream_
 // point (see the loop).  The candidate lists themselves (i2 | dist<<20, canonical order) stay in HBM/L2 and are only read for the
 // rare key point whose records are used up; the kernel's LDS footprint stays small enough not to displace the workgroups of
 // the extraction kernels it runs beside (an 80 KB staged copy of the lists used to halve k_fast_cells' occupancy on every CU).
-__global__ __launch_bounds__(MS_T) void k_match_select(MatchParams M)
+__device__ __forceinline__ int orbhip_match_select_ints_d(int cap, int lvl0_cap) { return 4 * cap + 4 * lvl0_cap + ORBHIP_HISTO_LENGTH + 8; }
+// BIG: the per-slot tables in device memory (M.big_ws) instead of LDS, for frames of more key points than the LDS holds (nfeatures from ~8300 on at 1080p; the
+// reference takes any nFeatures, Tracking.cc:113-125).  Same statements on volatile global words (one wave resolves the loop: program order is the order), see
+// proj_select_body<BIG>.
+template <bool BIG> __device__ __forceinline__ void match_select_body(const MatchParams& M)
 {
+    typedef typename std::conditional<BIG, volatile int, int>::type TI;
+    typedef typename std::conditional<BIG, volatile float, float>::type TF;
     const int slot = blockIdx.x + M.slot0, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n1 = M.n1[slot], n2 = M.n2[slot];
     const int n1l = min(M.n1_lvl0[slot * M.lvl_stride], M.lvl0_cap);
     const int* list1 = M.list1 ? M.list1 + (long long)slot * M.lvl0_cap : nullptr;
     HIP_DYNAMIC_SHARED(int, lds)
-    int* s_md = lds;                        // vMatchedDistance[i2]
-    int* s_m21 = s_md + M.cap;              // vnMatches21[i2]
-    int* s_m12 = s_m21 + M.cap;             // vnMatches12[i1] for level-0 i1
-    int* s_bin = s_m12 + M.lvl0_cap;        // rotation bin of the accepted match of i1, -1 = none
-    int* s_nc = s_bin + M.lvl0_cap;         // candidate count per level-0 i1
-    int* s_hist = s_nc + M.lvl0_cap;        // [HISTO_LENGTH] + misc
-    int* s_stamp = s_hist + ORBHIP_HISTO_LENGTH + 8;                               // lowest undecided query that wants to claim feature i2
-    float* s_ang1 = reinterpret_cast<float*>(s_stamp + M.cap);                    // angle of F1's level-0 keypoint j1
-    float* s_ang2 = s_ang1 + M.lvl0_cap;                                           // angle of F2's keypoint i2
+    TI* s_md = BIG ? M.big_ws + (long long)(blockIdx.x + M.slot0) * (long long)orbhip_match_select_ints_d(M.cap, M.lvl0_cap) : lds;     // vMatchedDistance[i2]
+    TI* s_m21 = s_md + M.cap;               // vnMatches21[i2]
+    TI* s_m12 = s_m21 + M.cap;              // vnMatches12[i1] for level-0 i1
+    TI* s_bin = s_m12 + M.lvl0_cap;         // rotation bin of the accepted match of i1, -1 = none
+    TI* s_nc = s_bin + M.lvl0_cap;          // candidate count per level-0 i1
+    TI* s_hist = s_nc + M.lvl0_cap;         // [HISTO_LENGTH] + misc
+    TI* s_stamp = s_hist + ORBHIP_HISTO_LENGTH + 8;                                // lowest undecided query that wants to claim feature i2
+    TF* s_ang1 = reinterpret_cast<TF*>(s_stamp + M.cap);                           // angle of F1's level-0 keypoint j1
+    TF* s_ang2 = s_ang1 + M.lvl0_cap;                                              // angle of F2's keypoint i2
+    auto amin = [](TI* p, int v) { atomicMin(const_cast<int*>(p), v); };
+    auto aadd = [](TI* p, int v) { atomicAdd(const_cast<int*>(p), v); };
     const orbhip_keypoint* kp1 = M.kp1 + (long long)slot * M.cap;
     const orbhip_keypoint* kp2 = M.kp2 + (long long)slot * M.cap;
     int* m12 = M.matches12 + (long long)slot * M.cap;
@@ -893,7 +901,7 @@ __global__ __launch_bounds__(MS_T) void k_match_select(MatchParams M)
                 const int want = accept ? ia : -1;
                 if (stamped >= 0 && stamped != want && s_stamp[stamped] == j1) s_stamp[stamped] = IMAX;       // withdraw an outdated claim
                 __builtin_amdgcn_wave_barrier();
-                if (want >= 0) atomicMin(&s_stamp[want], j1);
+                if (want >= 0) amin(&s_stamp[want], j1);
                 stamped = want;
                 __builtin_amdgcn_wave_barrier();
                 bool unsure = false;
@@ -911,7 +919,7 @@ __global__ __launch_bounds__(MS_T) void k_match_select(MatchParams M)
                     s_m12[j1] = ia; s_m21[ia] = j1; s_md[ia] = da;
                     if (s_stamp[ia] == j1) s_stamp[ia] = IMAX;                              // a decided claim lives in vMatchedDistance
                     stamped = -1;
-                    if (M.check_ori) { const int bin = rot_bin(j1, ia); s_bin[j1] = bin; atomicAdd(&s_hist[bin], 1); }      // rotHist[bin].push_back(i1): never removed when stolen
+                    if (M.check_ori) { const int bin = rot_bin(j1, ia); s_bin[j1] = bin; aadd(&s_hist[bin], 1); }      // rotHist[bin].push_back(i1): never removed when stolen
                 }
                 __builtin_amdgcn_wave_barrier();
                 todo &= ~commit;
@@ -943,7 +951,7 @@ __global__ __launch_bounds__(MS_T) void k_match_select(MatchParams M)
                         const int old = s_m21[bidx];
                         if (old >= 0) s_m12[old] = -1;
                         s_m12[js] = bidx; s_m21[bidx] = js; s_md[bidx] = best;
-                        if (M.check_ori) { const int bin = rot_bin(js, bidx); s_bin[js] = bin; s_hist[bin]++; }
+                        if (M.check_ori) { const int bin = rot_bin(js, bidx); s_bin[js] = bin; s_hist[bin] = s_hist[bin] + 1; }
                     }
                 }
                 __builtin_amdgcn_wave_barrier();                     // lane 0's LDS updates are read by the whole wave next
@@ -981,8 +989,19 @@ __global__ __launch_bounds__(MS_T) void k_match_select(MatchParams M)
     if (lane == 0) M.nmatches[slot] = cnt;
 }
 
+__global__ __launch_bounds__(MS_T) void k_match_select(MatchParams M) { match_select_body<false>(M); }
+__global__ __launch_bounds__(MS_T) void k_match_select_big(MatchParams M) { match_select_body<true>(M); }
+
+#define MS_LDS_BUDGET (158 * 1024)
+size_t orbhip_match_select_ints(int cap, int lvl0_cap) { return (size_t)4 * cap + (size_t)4 * lvl0_cap + ORBHIP_HISTO_LENGTH + 8; }
+bool orbhip_match_select_big(int cap, int lvl0_cap)
+{
+    const char* env = getenv("ORBHIP_SELECT_BIG");                       // tests: 1 = the device-memory form at any size (read per call: tests switch inside one process)
+    const bool force = env && env[0] == '1';
+    return force || sizeof(int) * orbhip_match_select_ints(cap, lvl0_cap) > MS_LDS_BUDGET;
+}
 void orbhip_launch_match_select(const MatchParams& M, int nslots, hipStream_t s)
 {
-    const size_t lds = sizeof(int) * ((size_t)4 * M.cap + (size_t)4 * M.lvl0_cap + ORBHIP_HISTO_LENGTH + 8);
-    hipLaunchKernelGGL(k_match_select, dim3(nslots, 1, 1), dim3(MS_T, 1, 1), lds, s, M);
+    if (M.big_ws) hipLaunchKernelGGL(k_match_select_big, dim3(nslots, 1, 1), dim3(MS_T, 1, 1), 0, s, M);
+    else hipLaunchKernelGGL(k_match_select, dim3(nslots, 1, 1), dim3(MS_T, 1, 1), sizeof(int) * orbhip_match_select_ints(M.cap, M.lvl0_cap), s, M);
 }

@@ -13,6 +13,7 @@
 //                              same-level ratio rule (mode 0) or best only + rotation histogram (mode 1);
 //                              ComputeThreeMaxima                                             ORBmatcher.cc:1601-1642
 #include "orbhip_internal.h"
+#include <type_traits>
 
 #define IMAX 0x7fffffff
 #define PJ_T 256
@@ -236,16 +237,24 @@ __global__ __launch_bounds__(256) void k_proj_candidates_batch(const ProjParams*
 #define PJM_BAD 1                       //   first query that cannot be decided this round: 2 q + (records used up ? 0 : 1)
 #define PJM_NEV 4                       // (one set) rotation-histogram entries written, matches
 #define PJM_NM 5
-__device__ __forceinline__ void proj_select_body(const ProjParams& J)
+// BIG: the four per-feature tables live in device memory (J.big_ws) instead of LDS - frames of more features than 150 KB of LDS hold (from ~9600 on; the
+// reference takes any nFeatures, Tracking.cc:113-125).  The same statements on volatile global words: every access goes to the L2 (the workgroup's waves
+// exchange the tables between barriers, and within a wave between wave barriers), atomics are the L2's own; a round then costs global-memory round trips
+// instead of LDS ones - the price of a size the LDS form refuses.  The histogram and the round's counters stay in LDS.
+template <bool BIG> __device__ __forceinline__ void proj_select_body(const ProjParams& J)
 {
+    typedef typename std::conditional<BIG, volatile int, int>::type TI;
+    typedef typename std::conditional<BIG, volatile float, float>::type TF;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), n = J.n;
     HIP_DYNAMIC_SHARED(int, lds)
-    int* s_blocked = lds;                                   // F.mvpMapPoints[i] && Observations() > 0
-    int* s_fq = s_blocked + n;                              // query whose map point sits in F.mvpMapPoints[i]
-    int* s_stamp = s_fq + n;                                // lowest query index that (speculatively) claims feature i with a blocking map point
-    float* s_fang = reinterpret_cast<float*>(s_stamp + n);  // mvKeysUn[i].angle
-    int* s_hist = reinterpret_cast<int*>(s_fang + n);       // [HISTO_LENGTH] + 3 maxima + 13 misc
+    TI* s_blocked = BIG ? J.big_ws : lds;                   // F.mvpMapPoints[i] && Observations() > 0
+    TI* s_fq = s_blocked + n;                               // query whose map point sits in F.mvpMapPoints[i]
+    TI* s_stamp = s_fq + n;                                 // lowest query index that (speculatively) claims feature i with a blocking map point
+    TF* s_fang = reinterpret_cast<TF*>(s_stamp + n);        // mvKeysUn[i].angle
+    int* s_hist = BIG ? lds : lds + 4 * n;                  // [HISTO_LENGTH] + 3 maxima + 13 misc
     int* s_misc = s_hist + ORBHIP_HISTO_LENGTH + 3;
+    auto amin = [](TI* p, int v) { atomicMin(const_cast<int*>(p), v); };
+    auto amax = [](TI* p, int v) { atomicMax(const_cast<int*>(p), v); };
     for (int i = tid; i < n; i += PJ_T) { s_blocked[i] = J.blocked_in ? (int)J.blocked_in[i] : 0; s_fq[i] = -1; s_stamp[i] = IMAX; s_fang[i] = J.kp[i].angle; }
     for (int i = tid; i < ORBHIP_HISTO_LENGTH + 16; i += PJ_T) s_hist[i] = 0;
     __syncthreads();
@@ -311,7 +320,7 @@ __device__ __forceinline__ void proj_select_body(const ProjParams& J)
             if (stamped >= 0 && stamped != want && s_stamp[stamped] == q) s_stamp[stamped] = IMAX;    // withdraw an outdated speculative claim (its own: the stamp is its index)
             { const int lo = pj_wave_min(pend ? q : IMAX); if (lane == 0 && lo != IMAX) atomicMin(&misc[PJM_LOW], lo); }
             __syncthreads();
-            if (want >= 0) atomicMin(&s_stamp[want], q);
+            if (want >= 0) amin(&s_stamp[want], q);
             stamped = want;
             if (tid == 0) { other[PJM_LOW] = IMAX; other[PJM_BAD] = IMAX; }                           // the next round's set: nobody reads or writes it between these two barriers
             __syncthreads();
@@ -336,7 +345,7 @@ __device__ __forceinline__ void proj_select_body(const ProjParams& J)
             int evbase = 0;
             if (J.mode == 1 && J.check_ori && wins) { if (lane == 0) evbase = atomicAdd(&s_misc[PJM_NEV], (int)__popcll(wins)); evbase = __builtin_amdgcn_readlane(evbase, 0); }
             if (win) {
-                atomicMax(&s_fq[ia], q);                                                // later queries overwrite earlier ones (ORBmatcher.cc:123)
+                amax(&s_fq[ia], q);                                                // later queries overwrite earlier ones (ORBmatcher.cc:123)
                 if (blocks) s_blocked[ia] = 1;
                 if (J.mode == 1 && J.check_ori) {
                     const int bin = rot_bin(qang, ia);
@@ -382,7 +391,7 @@ __device__ __forceinline__ void proj_select_body(const ProjParams& J)
                     const float sang = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qang), fl));
                     if (lane == 0) {
                         s_fq[bidx] = qs;
-                        if (sblocks) { s_blocked[bidx] = 1; atomicMin(&s_stamp[bidx], qs); }
+                        if (sblocks) { s_blocked[bidx] = 1; amin(&s_stamp[bidx], qs); }
                         if (J.mode == 1 && J.check_ori) { const int bin = rot_bin(sang, bidx); atomicAdd(&s_hist[bin], 1); J.events[atomicAdd(&s_misc[PJM_NEV], 1)] = (bin << 20) | bidx; }
                     }
                     wmatches++;
@@ -429,16 +438,27 @@ __device__ __forceinline__ void proj_select_body(const ProjParams& J)
     __syncthreads();
     for (int i = tid; i < n; i += PJ_T) { J.feature_query[i] = s_fq[i]; if (J.blocked_out) J.blocked_out[i] = (unsigned char)s_blocked[i]; }
 }
-__global__ __launch_bounds__(PJ_T) void k_proj_select(ProjParams J) { proj_select_body(J); }
-__global__ __launch_bounds__(PJ_T) void k_proj_select_batch(const ProjParams* Js) { const ProjParams J = Js[blockIdx.x]; proj_select_body(J); }      // one workgroup per camera slot
+__global__ __launch_bounds__(PJ_T) void k_proj_select(ProjParams J) { proj_select_body<false>(J); }
+__global__ __launch_bounds__(PJ_T) void k_proj_select_big(ProjParams J) { proj_select_body<true>(J); }
+// one workgroup per camera slot (big_ws is set for every slot or for none: the launcher decides on the largest slot)
+__global__ __launch_bounds__(PJ_T) void k_proj_select_batch(const ProjParams* Js) { const ProjParams J = Js[blockIdx.x]; proj_select_body<false>(J); }
+__global__ __launch_bounds__(PJ_T) void k_proj_select_batch_big(const ProjParams* Js) { const ProjParams J = Js[blockIdx.x]; proj_select_body<true>(J); }
 
+#define PJ_LDS_BUDGET (150 * 1024)
 size_t orbhip_proj_select_lds(int n) { return sizeof(int) * ((size_t)4 * n + ORBHIP_HISTO_LENGTH + 16); }
+bool orbhip_proj_select_big(int n)
+{
+    const char* env = getenv("ORBHIP_SELECT_BIG");                       // tests: 1 = the device-memory form at any size (read per call: tests switch inside one process)
+    const bool force = env && env[0] == '1';
+    return force || orbhip_proj_select_lds(n) > PJ_LDS_BUDGET;
+}
 
 void orbhip_launch_proj(const ProjParams& J, hipStream_t s)
 {
     const float gwInv = (float)ORBHIP_GRID_COLS / (float)(J.max_x - J.min_x), ghInv = (float)ORBHIP_GRID_ROWS / (float)(J.max_y - J.min_y);
     if (J.nq > 0) hipLaunchKernelGGL(k_proj_candidates, dim3((J.nq + 3) / 4, 1, 1), dim3(256, 1, 1), 0, s, J, gwInv, ghInv);
-    hipLaunchKernelGGL(k_proj_select, dim3(1, 1, 1), dim3(PJ_T, 1, 1), orbhip_proj_select_lds(J.n), s, J);
+    if (J.big_ws) hipLaunchKernelGGL(k_proj_select_big, dim3(1, 1, 1), dim3(PJ_T, 1, 1), orbhip_proj_select_lds(0), s, J);
+    else hipLaunchKernelGGL(k_proj_select, dim3(1, 1, 1), dim3(PJ_T, 1, 1), orbhip_proj_select_lds(J.n), s, J);
 }
 
 
@@ -446,7 +466,8 @@ void orbhip_launch_proj_batch(const ProjParams* d_slots, int nslots, int max_nq,
 {
     if (nslots <= 0) return;
     if (max_nq > 0) hipLaunchKernelGGL(k_proj_candidates_batch, dim3((max_nq + 3) / 4, nslots, 1), dim3(256, 1, 1), 0, s, d_slots, gwInv, ghInv);
-    hipLaunchKernelGGL(k_proj_select_batch, dim3(nslots, 1, 1), dim3(PJ_T, 1, 1), orbhip_proj_select_lds(max_n), s, d_slots);
+    if (orbhip_proj_select_big(max_n)) hipLaunchKernelGGL(k_proj_select_batch_big, dim3(nslots, 1, 1), dim3(PJ_T, 1, 1), orbhip_proj_select_lds(0), s, d_slots);
+    else hipLaunchKernelGGL(k_proj_select_batch, dim3(nslots, 1, 1), dim3(PJ_T, 1, 1), orbhip_proj_select_lds(max_n), s, d_slots);
 }
 
 // ------------------------------------------------------------------------------------------------ best candidate in a window

@@ -95,3 +95,14 @@ def backend(request):
     if request.param == "emu":
         return request.getfixturevalue("emu_lib")
     return request.getfixturevalue("gpu_lib")
+
+
+@pytest.fixture(params=["lds", "device_memory"])
+def select_tables(request, monkeypatch):
+    """Where k_match_select / k_proj_select keep their per-feature tables: LDS (every frame of up to ~8000 features), or device memory - the form frames
+    with more features take (orbhip_match_select_big / orbhip_proj_select_big), forced here at the tests' small sizes by ORBHIP_SELECT_BIG=1 (read per call)."""
+    if request.param == "device_memory":
+        monkeypatch.setenv("ORBHIP_SELECT_BIG", "1")
+    else:
+        monkeypatch.delenv("ORBHIP_SELECT_BIG", raising=False)
+    return request.param

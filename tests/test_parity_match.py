@@ -20,7 +20,7 @@ def frames(oracle):
 
 
 @pytest.mark.parametrize("window,nnratio,ori", [(100, 0.9, True), (30, 0.6, False), (10, 0.75, True)])
-def test_search_for_initialization(backend, oracle, frames, window, nnratio, ori):
+def test_search_for_initialization(backend, oracle, frames, select_tables, window, nnratio, ori):
     w, h, n, seq, K = frames
     m = orb_slam2_amd.ORBmatcher(nnratio, ori, library=backend)
     for a, b in ((0, 1), (1, 2), (2, 0)):
@@ -76,7 +76,7 @@ def test_search_for_initialization_edge_cases(backend, oracle, frames):
     assert n_g == n_o and np.array_equal(m_g, m_o) and p_g.tobytes() == p_o.tobytes()
 
 
-def test_search_for_initialization_long_candidate_lists(backend, oracle):
+def test_search_for_initialization_long_candidate_lists(backend, oracle, select_tables):
     """Window larger than the image: every level-0 keypoint of F2 is a candidate of every level-0 keypoint of F1, more
     candidate records than the matcher stages in LDS (the lists are then read from HBM)."""
     w, h, n = 640, 480, 1000
@@ -153,7 +153,7 @@ def test_brute_force_nn_matrix_core_scan(backend, oracle, monkeypatch, form):
 
 
 @pytest.mark.parametrize("num_streams", [1, 2])
-def test_device_pipeline_extract_and_match(backend, oracle, num_streams):
+def test_device_pipeline_extract_and_match(backend, oracle, select_tables, num_streams):
     """orbhip_extract_device on two camera slots over four time steps, matched against each slot's previous frame
     (num_streams = 2: the two slots run concurrently on two HIP streams)."""
     w, h, n = 400, 300, 500

@@ -49,7 +49,7 @@ def _queries(oracle, scene, mode, th, rng, level_rule):
 @pytest.mark.parametrize("mode,rule,th,ratio,stereo", [(0, "local_map", 3.0, 0.8, False), (0, "local_map", 5.0, 0.8, True),
                                                      (1, "window", 7.0, 0.9, False), (1, "forward", 15.0, 0.9, True),
                                                      (1, "backward", 15.0, 0.9, False)])
-def test_search_by_projection(backend, oracle, scene, mode, rule, th, ratio, stereo):
+def test_search_by_projection(backend, oracle, scene, select_tables, mode, rule, th, ratio, stereo):
     w, h, sf, (kl, dl), (kc, dc) = scene
     rng = np.random.default_rng(mode * 100 + int(th))
     q, qd = _queries(oracle, scene, mode, th, rng, rule)
@@ -150,7 +150,7 @@ def test_feature_grid_of_a_frame_too_large_for_lds(backend, oracle, scene, monke
         assert n_g == n_o and np.array_equal(f_g, f_o)
 
 
-def test_searches_on_device_resident_frames(backend, oracle):
+def test_searches_on_device_resident_frames(backend, oracle, select_tables):
     """orbhip_search_by_projection_frame / orbhip_search_best_in_window_frame: the frame's key points, descriptors and mvuRight stay on
     the device (stereo pair extracted and matched there); results equal the oracle's on the fetched copies."""
     import sys, os
@@ -326,7 +326,7 @@ def test_frame_epilogues_single_image_sequence(backend, oracle):
 
 
 @pytest.mark.parametrize("mode,rule,th,ratio", [(0, "local_map", 3.0, 0.8), (1, "window", 7.0, 0.9)])
-def test_search_by_projection_batch_of_camera_slots(backend, oracle, scene, mode, rule, th, ratio):
+def test_search_by_projection_batch_of_camera_slots(backend, oracle, scene, select_tables, mode, rule, th, ratio):
     """orbhip_search_by_projection_batch (the multi-camera form of M2 / M3): slots with different frames, query sets, stereo
     gates and blocked sets in ONE pass; every slot must equal the oracle's answer for that slot alone (and thereby the per-slot entry point)."""
     w, h, sf, (kl, dl), (kc, dc) = scene
@@ -379,18 +379,18 @@ def _fuzz_case(oracle, rng, library):
     return f"{w}x{h} n={len(kc)} nq={len(q)} mode={mode} {rule} th={th} ratio={ratio} ori={check_ori}: {n_o} matches", n_g == n_o and np.array_equal(f_g, f_o)
 
 
-def test_search_by_projection_random_cases(backend, oracle, request):
+def test_search_by_projection_random_cases(backend, oracle, request, select_tables):
     """random scenes / windows / level rules / crowded query sets through the 256-queries-per-step selection (k_proj_select): 12 cases on the emulation,
     40 on the GPU; `python tests/test_parity_projection.py [ncases] [seed]` runs a longer sweep by hand"""
     rng = np.random.default_rng(77)
     done = 0
-    for _ in range(40 if "gpu" in request.node.name else 12):
+    for _ in range(40 if "gpu" in request.node.name else 12 if select_tables == "lds" else 6):
         r = _fuzz_case(oracle, rng, backend)
         if r is None:
             continue
         assert r[1], r[0]
         done += 1
-    assert done >= 8
+    assert done >= (8 if select_tables == "lds" or "gpu" in request.node.name else 4)
 
 
 if __name__ == "__main__":
