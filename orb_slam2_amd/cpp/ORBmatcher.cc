@@ -128,11 +128,21 @@ struct ORBmatcher::Access
     // Everything a member reads of one map point in ONE visit: mMutexFeatures then mMutexPos, the order MapPoint::isBad() takes them (MapPoint.cc:170-175) -
     // two lock operations per point where the reference's isBad() + GetWorldPos() + GetNormal() + Get{Min,Max}DistanceInvariance() + GetDescriptor() +
     // Observations() take eight, and no cv::Mat clone.  Returns false for a bad point (nothing else is read then).
-    static inline bool Read(MapPoint* pMP, orbhip_map_point &o, unsigned char* d32, bool bRange, bool bSkipBad, int &nObs)
+    // pKFs / nKFs / inKFs (optional): bit t of *inKFs = IsInKeyFrame(pKFs[t]) (MapPoint.cc:254-258: mObservations under mMutexFeatures, which is held here
+    // anyway) - Fuse's own filter (ORBmatcher.cc:848) for up to 64 key frames in the same visit instead of a lock per point and key frame
+    static inline bool Read(MapPoint* pMP, orbhip_map_point &o, unsigned char* d32, bool bRange, bool bSkipBad, int &nObs,
+                            KeyFrame* const* pKFs = NULL, int nKFs = 0, unsigned long long* inKFs = NULL)
     {
         unique_lock<mutex> lock1(pMP->mMutexFeatures);
         unique_lock<mutex> lock2(pMP->mMutexPos);
         if(bSkipBad && pMP->mbBad) return false;
+        if(inKFs)
+        {
+            unsigned long long m = 0;
+            for(int t=0; t<nKFs; t++) if(pMP->mObservations.count(pKFs[t])) m |= 1ull<<t;
+            *inKFs = m;
+            if(nKFs==1 && m) return true;          // a single Fuse skips the point: nothing else is read
+        }
         nObs = pMP->nObs;
         memcpy(d32, pMP->mDescriptor.ptr<unsigned char>(), 32);
         const float* w = pMP->mWorldPos.ptr<float>();             // 3 x 1 CV_32F made by copyTo / clone: continuous
@@ -184,12 +194,14 @@ struct OrbhipPoints
     void reserve(size_t cap) { pts.resize(cap); desc.resize(32*cap); owner.resize(cap); index.resize(cap); n = 0; }
     size_t size() const { return n; }
     // level >= 0: given by the caller; -1: MapPoint::PredictScale on the device.  blocks < 0: Observations() > 0 of the point itself.  false: the point is bad (bSkipBad)
-    bool add(MapPoint* pMP, int idx, bool bRange, bool bSkipBad, int level, int blocks, float angle)
+    // pKFs / nKFs / inKFs: see Access::Read; with ONE key frame a point that is in it is not added (returns false, *inKFs = 1)
+    bool add(MapPoint* pMP, int idx, bool bRange, bool bSkipBad, int level, int blocks, float angle, KeyFrame* const* pKFs = NULL, int nKFs = 0, unsigned long long* inKFs = NULL)
     {
         if(n==pts.size()) { const size_t cap = std::max<size_t>(2*n, 64); pts.resize(cap); desc.resize(32*cap); owner.resize(cap); index.resize(cap); }
         orbhip_map_point &o = pts[n];
         int nObs = 0;
-        if(!ORBmatcher::Access::Read(pMP, o, &desc[32*n], bRange, bSkipBad, nObs)) return false;
+        if(!ORBmatcher::Access::Read(pMP, o, &desc[32*n], bRange, bSkipBad, nObs, pKFs, nKFs, inKFs)) return false;
+        if(inKFs && nKFs==1 && *inKFs) return false;
         o.cam_x = o.cam_y = o.cam_z = 0.f;
         if(!bRange) { o.nx = o.ny = o.nz = o.min_dist = o.max_dist = o.scale_dist = 0.f; }
         o.level = level; o.blocks = blocks<0 ? (nObs>0) : blocks; o.angle = angle;
@@ -512,7 +524,9 @@ struct OrbhipFuseJob
 };
 // `shared`: the points read ONCE for every target of a FuseBatch (shared->index[k] = position in vpMapPoints; bad points are absent) - a target then copies
 // the records of the points it does not hold instead of visiting every map point again; NULL: read here (a single Fuse)
-static void orbhip_fuse_collect(KeyFrame* pKF, const vector<MapPoint*> &vpMapPoints, const float th, OrbhipFuseJob &job, const OrbhipPoints* shared = NULL)
+// `sharedIn` (with `shared`): bit `t` of sharedIn[k] = shared point k is in target t (read in the same visit as the point), t = this job's number
+static void orbhip_fuse_collect(KeyFrame* pKF, const vector<MapPoint*> &vpMapPoints, const float th, OrbhipFuseJob &job, const OrbhipPoints* shared = NULL,
+                                const std::vector<unsigned long long>* sharedIn = NULL, int t = 0)
 {
     job.pKF = pKF;
     cv::Mat Rcw = pKF->GetRotation();
@@ -529,7 +543,7 @@ static void orbhip_fuse_collect(KeyFrame* pKF, const vector<MapPoint*> &vpMapPoi
         for(size_t k=0; k<shared->size(); k++)
         {
             MapPoint* pMP = shared->owner[k];
-            if(pMP->IsInKeyFrame(pKF)) continue;
+            if(sharedIn ? (((*sharedIn)[k]>>t)&1ull)!=0 : pMP->IsInKeyFrame(pKF)) continue;
             G.pts[G.n] = shared->pts[k]; memcpy(&G.desc[32*G.n], &shared->desc[32*k], 32); G.owner[G.n] = pMP; G.index[G.n] = shared->index[k];
             G.n++;
         }
@@ -538,8 +552,9 @@ static void orbhip_fuse_collect(KeyFrame* pKF, const vector<MapPoint*> &vpMapPoi
         for(int i=0; i<nMPs; i++)
         {
             MapPoint* pMP = vpMapPoints[i];
-            if(!pMP || pMP->IsInKeyFrame(pKF)) continue;
-            job.G.add(pMP, i, true, true, -1, 0, 0.f);
+            if(!pMP) continue;
+            unsigned long long in = 0;
+            job.G.add(pMP, i, true, true, -1, 0, 0.f, &pKF, 1, &in);      // (:848-849: a bad point or one that is in the key frame already is not added)
         }
     job.G.done();
     if(job.P.gemm_mode==2) orbhip_host_transform(job.G, Rcw, tcw);
@@ -586,11 +601,11 @@ static int orbhip_fuse_apply(OrbhipFuseJob &job, std::set<MapPoint*> *survivors)
     }
     for(size_t k=0; k<job.G.size(); k++)
     {
+        const int bestDist = job.bd[k], bestIdx = job.bi[k];
+        if(bestDist>ORBmatcher::TH_LOW) continue;          // (:945; first, it needs no lock: either test alone skips the point and neither has a side effect)
         MapPoint* pMP = job.G.owner[k];
         if(pMP->isBad() || pMP->IsInKeyFrame(pKF))        // the member's own filter (:848-849), as of NOW: the surgery of earlier points / targets may have changed it
             continue;
-        const int bestDist = job.bd[k], bestIdx = job.bi[k];
-        if(bestDist>ORBmatcher::TH_LOW) continue;
         // a map point already there: the one with fewer observations is replaced by the other; otherwise a new measurement (:951-968)
         MapPoint* pMPinKF = pKF->GetMapPoint(bestIdx);
         if(pMPinKF)
@@ -629,10 +644,18 @@ int FuseBatch(const std::vector<KeyFrame*> &vpTargetKFs, const std::vector<MapPo
     // every target is offered the same points: each is visited once (position, range, descriptor as they are before the loop - what an earlier target's
     // surgery changes afterwards is re-checked per target by orbhip_fuse_apply), a target keeps the ones it does not hold
     OrbhipPoints shared; shared.reserve(vpMapPoints.size());
+    // ... together with "is the point in target t" for every target (up to 64 per visit; more targets: asked per target as before)
+    const bool bMasks = vpTargetKFs.size()>=2 && vpTargetKFs.size()<=64;
+    std::vector<unsigned long long> sharedIn; if(bMasks) sharedIn.reserve(vpMapPoints.size());
     for(size_t i=0; i<vpMapPoints.size(); i++)
-        if(vpMapPoints[i]) shared.add(vpMapPoints[i], (int)i, true, true, -1, 0, 0.f);
+    {
+        if(!vpMapPoints[i]) continue;
+        unsigned long long in = 0;
+        if(shared.add(vpMapPoints[i], (int)i, true, true, -1, 0, 0.f, bMasks ? &vpTargetKFs[0] : NULL, bMasks ? (int)vpTargetKFs.size() : 0, bMasks ? &in : NULL) && bMasks)
+            sharedIn.push_back(in);
+    }
     for(size_t t=0; t<vpTargetKFs.size(); t++)
-        orbhip_fuse_collect(vpTargetKFs[t], vpMapPoints, th, jobs[t], &shared);
+        orbhip_fuse_collect(vpTargetKFs[t], vpMapPoints, th, jobs[t], &shared, bMasks ? &sharedIn : NULL, (int)t);
     for(size_t t=0; t<vpTargetKFs.size(); t++) slots[t] = orbhip_fuse_slot(jobs[t]);      // (after every job exists: the slots point into them)
     if(!slots.empty())
         orbhip_check(orbhip_project_best_in_window_batch(orbhip_default_device(), (int)slots.size(), &slots[0], 1));
