@@ -84,6 +84,10 @@ public:
     static Mat eye(int r, int c, int type) { Mat m = Mat(zeros(r, c, type)); for (int i = 0; i < r && i < c; i++) { if (type == CV_32F) m.at<float>(i, i) = 1.0f; else m.at<uchar>(i, i) = 1; } return m; }
     Mat col(int x) const { return colRange(x, x + 1); }
     Mat t() const { Mat m(cols, rows, flags_type); for (int y = 0; y < rows; y++) for (int x = 0; x < cols; x++) m.at<float>(x, y) = at<float>(y, x); return m; }
+    // (no FMA contraction, whatever the flags of the translation unit: an OpenCV binary is not compiled with its caller's flags - see CVLITE_ALGEBRA below)
+#if defined(__GNUC__) && !defined(__clang__)
+    __attribute__((optimize("fp-contract=off")))
+#endif
     double dot(const Mat& o) const { double s = 0; for (int y = 0; y < rows; y++) for (int x = 0; x < cols; x++) s += (double)at<float>(y, x) * o.at<float>(y, x); return s; }
     void copyTo(Mat& m) const { m = clone(); }
     void convertTo(Mat& m, int rtype) const
@@ -103,6 +107,12 @@ private:
 
 #ifdef CVLITE_ALGEBRA
 enum { NORM_L1 = 2, NORM_L2 = 4 };
+// The stand-in's arithmetic carries no FMA contraction whatever the translation unit's flags say: the OpenCV it stands for is a separate binary, not compiled
+// with its caller's -march=native (oracle/Makefile ref_native_slam builds the reference's callers with their own flags around it: DESIGN.md H3)
+#if defined(__GNUC__) && !defined(__clang__)
+#pragma GCC push_options
+#pragma GCC optimize ("fp-contract=off")
+#endif
 #ifndef CVLITE_GEMM_SMALL
 // A*B: every element the sum of its products in double, rounded to float - cv::gemm's generic kernel (GEMMSingleMul<float, double>); `A*B + C` then adds in float
 inline Mat operator*(const Mat& a, const Mat& b)
@@ -169,6 +179,9 @@ public:
     struct Init { Mat m; int i; Init& operator,(T v) { m.at<T>(i / m.cols, i % m.cols) = v; i++; return *this; } operator Mat() const { return m; } };
     Init operator<<(T v) { Init in = {*this, 0}; in, v; return in; }
 };
+#if defined(__GNUC__) && !defined(__clang__)
+#pragma GCC pop_options
+#endif
 #endif
 
 class _InputArray {

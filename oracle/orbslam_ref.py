@@ -49,6 +49,23 @@ def build():
     return available()
 
 
+NATIVE_PATH = os.path.join(HERE, "_ref", "liborbslam_ref_native.so")   # the same sources with the reference's own flags (-O3 -march=native: FMA contraction); CPU only
+_native = None
+
+
+def build_native():
+    if os.path.isdir("/root/reference/src"):
+        _locked_make(["-C", HERE, "-s", "ref_native_slam"])
+    return os.path.exists(NATIVE_PATH)
+
+
+def native_lib():
+    global _native
+    if _native is None:
+        _native = _bind(C.CDLL(NATIVE_PATH))
+    return _native
+
+
 DROPIN_PATH = os.path.join(HERE, "_ref", "liborbslam_dropin.so")      # reference Frame.cc / ORBmatcher.cc calling THIS repo's drop-in ORBextractor class
 _dropin = None
 

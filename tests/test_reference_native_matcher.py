@@ -1,0 +1,32 @@
+"""H3 for the matcher's algebra, measured: the reference's Frame.cc / ORBmatcher.cc built with the reference's OWN flags (CMakeLists.txt:11-14: -O3 -march=native,
+C++ => -ffp-contract=fast - gcc fuses the scalar projection statements, `fx*xc*invz+cx` ..., into FMAs; `make -C oracle ref_native_slam`) against the canonical
+build (-ffp-contract=off: one rounding per operation, the form the drop-in's device code reproduces).  The cv::Mat stand-in keeps its own arithmetic
+uncontracted in both, like a separately built OpenCV.  Every pose-guided member under the general poses of tests/test_projection_poses.py; reported: how many
+entries of the members' outputs differ.  Asserted: the builds agree on (almost) every match - a contraction moves a projected pixel by an ulp, which matters only
+where that ulp crosses a cell / radius / level boundary.  CPU only (-march=native is the build host's)."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from conftest import gpu_session  # noqa: E402
+
+
+def test_native_flags_build_of_the_matcher_against_the_canonical_build(request, capsys):
+    if gpu_session(request.config):
+        pytest.skip("CPU only")
+    from oracle import orbslam_ref as S
+    if not (S.build() and S.build_native()):
+        pytest.skip("reference sources not mounted")
+    import test_projection_poses as T
+    checked, differs = T._run(S, S.native_lib(), strict=False)
+    total, bad = sum(v for k, v in checked.items() if k != "frustum"), sum(v for k, v in differs.items() if k != "frustum")
+    with capsys.disabled():
+        print("\nnative-flags build (-O3 -march=native, FMA contraction) against the canonical build: entries of the members' outputs that differ: "
+              + ", ".join(f"{k} {differs.get(k, 0)}" for k in sorted(checked)) + "  (of " + ", ".join(f"{k} {checked[k]}" for k in sorted(checked)) + " matches)")
+    assert total > 5000
+    assert bad <= total // 200, (bad, total)        # (0 on this host; a boundary crossing per few thousand matches would still be the same exposure)
