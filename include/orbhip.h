@@ -219,6 +219,14 @@ orbhip_status orbhip_hamming_nn(int device, const uint8_t* q, int nq, const uint
 orbhip_status orbhip_hamming_nn_device(void* stream, const uint8_t* d_q, int nq, const uint8_t* d_db, int64_t ndb,
                                        int64_t db_index_base, int64_t* d_best_idx, int32_t* d_best_dist,
                                        int32_t* d_second_dist);
+/* A database that is queried many times (a map's key frame descriptors: BASELINE.json configs[5]) can be EXPANDED once: orbhip_nn_expanded_size(ndb) bytes
+   (128 per row, rounded up to tiles of 32 rows; 16-byte aligned) filled by orbhip_nn_expand_device hold every descriptor bit as the +-1 the matrix cores
+   multiply, in the scan's own tile layout - a query then stages tiles by LDS-DMA instead of expanding each row again for every 512 queries.  Same answers as
+   orbhip_hamming_nn_device bit for bit (d_db is still read for databases too small for the matrix-core scan).  Asynchronous on `stream`. */
+size_t orbhip_nn_expanded_size(int64_t ndb);
+orbhip_status orbhip_nn_expand_device(void* stream, const uint8_t* d_db, int64_t ndb, uint8_t* d_expanded);
+orbhip_status orbhip_hamming_nn_device_expanded(void* stream, const uint8_t* d_q, int nq, const uint8_t* d_db, const uint8_t* d_expanded, int64_t ndb,
+                                                int64_t db_index_base, int64_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second_dist);
 
 /* ORBmatcher(nnratio, check_ori).SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, window)
    (ORBmatcher.h:69, ORBmatcher.cc:405-520) on host buffers.  The Frame members it reads are passed flat:

@@ -2325,6 +2325,26 @@ extern "C" orbhip_status orbhip_hamming_nn_device(void* stream, const uint8_t* d
     return ORBHIP_OK;
 }
 
+// A database that is queried many times (a key frame database: BASELINE.json config 5) expanded ONCE into the form the FP4 scan multiplies - 128 bytes per row
+// instead of 32 - so that a query stages tiles by LDS-DMA instead of expanding every row again for every 512 queries (include/orbhip.h)
+extern "C" size_t orbhip_nn_expanded_size(int64_t ndb) { return ndb < 0 ? 0 : orbhip_nn_expanded_bytes(ndb); }
+extern "C" orbhip_status orbhip_nn_expand_device(void* stream, const uint8_t* d_db, int64_t ndb, uint8_t* d_expanded)
+{
+    if (ndb < 0 || (ndb > 0 && (!d_db || !d_expanded))) return fail(ORBHIP_ERR_INVALID, "bad argument");
+    if (((uintptr_t)d_expanded & 15) != 0) return fail(ORBHIP_ERR_INVALID, "the expanded database must be 16-byte aligned");
+    orbhip_launch_nn_expand(d_db, ndb, d_expanded, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return ORBHIP_OK;
+}
+extern "C" orbhip_status orbhip_hamming_nn_device_expanded(void* stream, const uint8_t* d_q, int nq, const uint8_t* d_db, const uint8_t* d_expanded, int64_t ndb, int64_t base,
+                                                           int64_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second)
+{
+    if (nq < 0 || ndb < 0 || (nq > 0 && (!d_q || !d_best_idx || !d_best_dist || !d_second)) || (ndb > 0 && (!d_db || !d_expanded))) return fail(ORBHIP_ERR_INVALID, "bad argument");
+    if (!orbhip_launch_hamming_nn(d_q, nq, d_db, ndb, base, (long long*)d_best_idx, d_best_dist, d_second, (hipStream_t)stream, d_expanded)) return fail(ORBHIP_ERR_HIP, "hamming_nn: no device memory for the scan partials");
+    HIPCHK(hipGetLastError());
+    return ORBHIP_OK;
+}
+
 extern "C" orbhip_status orbhip_hamming_nn(int device, const uint8_t* q, int nq, const uint8_t* db, int64_t ndb, int64_t base,
                                            int64_t* best_idx, int32_t* best_dist, int32_t* second_dist)
 {

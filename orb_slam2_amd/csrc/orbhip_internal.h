@@ -201,7 +201,9 @@ void orbhip_launch_remap(const uint8_t* src, long long src_frame_stride, int src
 void orbhip_launch_repitch(const uint8_t* src, long long src_frame_stride, int src_row_stride, uint8_t* dst, long long dst_frame_stride, int dst_pitch, int w, int h, int nframes, hipStream_t s);
 
 bool orbhip_launch_hamming_nn(const uint8_t* d_q, int nq, const uint8_t* d_db, long long ndb, long long base,
-                              long long* d_best_idx, int* d_best_dist, int* d_second, hipStream_t s);
+                              long long* d_best_idx, int* d_best_dist, int* d_second, hipStream_t s, const uint8_t* d_dbx = nullptr);
+size_t orbhip_nn_expanded_bytes(long long ndb);
+void orbhip_launch_nn_expand(const uint8_t* d_db, long long ndb, uint8_t* d_out, hipStream_t s);
 void orbhip_launch_match_grid(const MatchParams& M, int nslots, hipStream_t s);
 void orbhip_launch_match_candidates(const MatchParams& M, int nslots, hipStream_t s);
 void orbhip_launch_match_select(const MatchParams& M, int nslots, hipStream_t s);

@@ -220,7 +220,9 @@ typedef float nn_v16f __attribute__((vector_size(64)));
 // "nothing seen yet": a tile can only matter if it holds a distance strictly below the bound (a row AT the bound loses the tie to the head's rows, which have
 // lower indices) - so the skip works from a chunk's first tile on (about one tile in sixteen survives instead of one in three).  chunk0 = index of this
 // launch's first chunk in rows / CH; part0, part_stride = where its partials go among all partials of the query (head sub-chunks first, then the rest).
-template <int QT, int OCC, int LCH, int TPB, int ABL = 0> __global__ __launch_bounds__(256, OCC) void k_hamming_nn_fp4(const unsigned* q, int nq, const unsigned* db, long long ndb, long long base, NNPart* parts, int nchunks,
+// EXP (round 6): `db` is the database EXPANDED in device memory (k_nn_expand: 128 B per row, 4 KB per tile of 32 rows in exactly the layout of the LDS tile),
+// so staging a tile is ONE 16-byte LDS-DMA per thread - no registers, no byte -> E2M1 table, no VALU - requested a whole superstep ahead.
+template <int QT, int OCC, int LCH, int TPB, int ABL = 0, bool EXP = false> __global__ __launch_bounds__(256, OCC) void k_hamming_nn_fp4(const unsigned* q, int nq, const unsigned* db, long long ndb, long long base, NNPart* parts, int nchunks,
                                                                                                           const int* seed, int chunk0, int part0)
 {
     constexpr int ablate = ABL;                                        // measurement only (ORBHIP_NN_ABLATE): 1 = no threshold tests, 2 = no staging of new tiles; results are wrong
@@ -277,6 +279,16 @@ template <int QT, int OCC, int LCH, int TPB, int ABL = 0> __global__ __launch_bo
             *reinterpret_cast<uint4*>(s_a[buf] + u * 1024 + (sd * 32 + sr) * 4) = uint4{s_tab[w & 0xff], s_tab[(w >> 8) & 0xff], s_tab[(w >> 16) & 0xff], s_tab[w >> 24]};
         }
     };
+    // EXP: the superstep's tiles by LDS-DMA, thread tid bytes [16 tid, 16 tid + 16) of each 4 KB tile (wave w: the tile's w-th KB)
+    auto stage_dma = [&](int sup, int buf) {
+#pragma unroll
+        for (int u = 0; u < TPB; u++) {
+            const int tile = sup * TPB + u;
+            if (tile < ntiles)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db + ((row0 >> 5) + tile) * 1024 + tid * 4),
+                                                 (__attribute__((address_space(3))) void*)(s_a[buf] + u * 1024 + wave * 256), 16, 0, 0);
+        }
+    };
     const nn_v16f czero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const float off_h = (float)(4 * h);
     auto top2_of3 = [](unsigned a, unsigned b, unsigned c, unsigned& lo, unsigned& mid) { lo = min(min(a, b), c); mid = max(min(a, b), min(max(a, b), c)); };
@@ -321,7 +333,8 @@ template <int QT, int OCC, int LCH, int TPB, int ABL = 0> __global__ __launch_bo
         // (a never-set second best gives a threshold below every similarity; a seeded threshold is never lowered)
         thr[t] = fmaxf(thr[t], 16384.0f - 128.0f * (float)(ksec[t] >> LCH));
     };
-    fetch(0); expand(0);
+    if constexpr (EXP) { stage_dma(0, 0); __builtin_amdgcn_s_waitcnt(0x0f70); }      // (vmcnt(0))
+    else { fetch(0); expand(0); }
     __syncthreads();
     const int nfull = nrows >> 5, nsuper = (ntiles + TPB - 1) / TPB;
     // ---- the tile loop.  A wave issues in order: with ONE accumulator set it runs the sixteen matrix instructions of a tile (512 cycles of the matrix pipe),
@@ -337,6 +350,21 @@ template <int QT, int OCC, int LCH, int TPB, int ABL = 0> __global__ __launch_bo
         nn_v16f acc[6];
         uint4 a4[4];
         auto load_a = [&](const unsigned* ta) {
+#if defined(__HIP_DEVICE_COMPILE__) && __HIP_DEVICE_COMPILE__
+            if constexpr (EXP) {
+                // spelled: while the NEXT superstep's LDS-DMA is in flight the compiler would put `s_waitcnt vmcnt(0)` in front of every ordinary LDS read
+                // (it has no address for the DMA's LDS side: orbhip_kernels_extract.hip, lds_read3_issue) - i.e. wait for the prefetch.  Lane (j, h) = lane l:
+                // its four operands are 1 KB apart from byte 16 l of the tile on
+                typedef int v4i_t __attribute__((vector_size(16)));
+                v4i_t q0, q1, q2, q3;
+                const unsigned addr = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)ta + 16u * (unsigned)lane;
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(addr) : "memory");
+                a4[0] = uint4{(unsigned)q0[0], (unsigned)q0[1], (unsigned)q0[2], (unsigned)q0[3]}; a4[1] = uint4{(unsigned)q1[0], (unsigned)q1[1], (unsigned)q1[2], (unsigned)q1[3]};
+                a4[2] = uint4{(unsigned)q2[0], (unsigned)q2[1], (unsigned)q2[2], (unsigned)q2[3]}; a4[3] = uint4{(unsigned)q3[0], (unsigned)q3[1], (unsigned)q3[2], (unsigned)q3[3]};
+                return;
+            }
+#endif
 #pragma unroll
             for (int kb = 0; kb < 4; kb++) a4[kb] = *reinterpret_cast<const uint4*>(ta + ((2 * kb + h) * 32 + j) * 4);
         };
@@ -375,7 +403,7 @@ template <int QT, int OCC, int LCH, int TPB, int ABL = 0> __global__ __launch_bo
         for (int kb = 0; kb < 4; kb++) { mm(acc[2], 2, kb); mm(acc[3], 3, kb); }
         for (int sup = 0; sup < nsuper; sup++) {
             const int buf = sup & 1;
-            if (sup + 1 < nsuper && !(ablate & 2)) fetch(sup + 1);
+            if (sup + 1 < nsuper && !(ablate & 2)) { if constexpr (EXP) stage_dma(sup + 1, buf ^ 1); else fetch(sup + 1); }      // (EXP: everybody left that buffer at the barrier of the superstep before)
 #pragma unroll
             for (int u = 0; u < TPB; u++) {
                 const int tile = sup * TPB + u;
@@ -383,7 +411,10 @@ template <int QT, int OCC, int LCH, int TPB, int ABL = 0> __global__ __launch_bo
                 const int cA = (3 - u % 3) % 3, cB = (cA + 1) % 3, sp = (cA + 2) % 3;             // static after unrolling: pair holding the current first half / second half / the spare
                 nn_v16f &x0 = acc[2 * cA], &x1 = acc[2 * cA + 1], &x2 = acc[2 * cB], &x3 = acc[2 * cB + 1], &n0 = acc[2 * sp], &n1 = acc[2 * sp + 1];
                 const bool last_of_super = u == TPB - 1;
-                if (last_of_super && sup + 1 < nsuper && !(ablate & 2)) { expand(buf ^ 1); __syncthreads(); }      // the next tile lives in the other buffer: fill it, everybody has left it
+                if (last_of_super && sup + 1 < nsuper && !(ablate & 2)) {                            // the next tile lives in the other buffer: it is filled, everybody has left this one
+                    if constexpr (EXP) __builtin_amdgcn_s_waitcnt(0x0f70); else expand(buf ^ 1);
+                    __syncthreads();
+                }
                 const bool have_next = tile + 1 < ntiles;
                 const unsigned* tnext = last_of_super ? s_a[buf ^ 1] : s_a[buf] + (u + 1) * 1024;
                 if (tile < nfull) {
@@ -462,6 +493,33 @@ template <int QT, int OCC, int LCH, int TPB, int ABL = 0> __global__ __launch_bo
         }
     }
 }
+// The database as the FP4 scan reads it (orbhip_nn_expand_device): tile T = rows 32 T .. 32 T + 31 as 4 KB, [dword d of the row][row i] x 16 bytes = the eight
+// E2M1 nibbles of each of the dword's four bytes - byte for byte what k_hamming_nn_fp4's `expand` writes into LDS.  Rows past the end: zeros (never a winner:
+// the scan's ragged tile masks them).  One thread per (tile, d, i).
+__global__ __launch_bounds__(256) void k_nn_expand(const unsigned* db, long long ndb, uint4* out, long long ntiles)
+{
+    __shared__ unsigned s_tab[256];
+    {
+        unsigned e = 0;
+#pragma unroll
+        for (int t = 0; t < 8; t++) e |= (((threadIdx.x >> t) & 1) ? 0x2u : 0xAu) << (4 * t);
+        s_tab[threadIdx.x] = e;
+    }
+    __syncthreads();
+    const long long tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    const int i = threadIdx.x & 31, d = threadIdx.x >> 5;
+    const long long row = tile * 32 + i;
+    const unsigned w = row < ndb ? db[row * 8 + d] : 0u;
+    out[tile * 256 + d * 32 + i] = row < ndb ? uint4{s_tab[w & 0xff], s_tab[(w >> 8) & 0xff], s_tab[(w >> 16) & 0xff], s_tab[w >> 24]} : uint4{0u, 0u, 0u, 0u};
+}
+size_t orbhip_nn_expanded_bytes(long long ndb) { return (size_t)((ndb + 31) / 32) * 4096; }
+void orbhip_launch_nn_expand(const uint8_t* d_db, long long ndb, uint8_t* d_out, hipStream_t s)
+{
+    const long long ntiles = (ndb + 31) / 32;
+    if (ntiles > 0) hipLaunchKernelGGL(k_nn_expand, dim3((unsigned)ntiles, 1, 1), dim3(256, 1, 1), 0, s, (const unsigned*)d_db, ndb, (uint4*)d_out, ntiles);
+}
+
 // second-best distance over the head's partials of every query: the seed of the main pass (a head with fewer than two rows in reach gives none)
 __global__ __launch_bounds__(256) void k_hamming_seed(const NNPart* parts, int nq, int stride, int nhead, int* seed)
 {
@@ -496,8 +554,8 @@ __global__ __launch_bounds__(256) void k_hamming_merge(const NNPart* parts, int 
 // workspace for the partials lives in a small per-thread cache owned by the API layer
 
 bool orbhip_launch_hamming_nn(const uint8_t* d_q, int nq, const uint8_t* d_db, long long ndb, long long base,
-                              long long* d_best_idx, int* d_best_dist, int* d_second, hipStream_t s)
-{
+                              long long* d_best_idx, int* d_best_dist, int* d_second, hipStream_t s, const uint8_t* d_dbx)
+{   // d_dbx: the same database expanded by orbhip_launch_nn_expand (nullptr: none) - taken by the default FP4 shape's seeded scan
     if (nq <= 0) return true;
     const int nchunks = (int)max(1LL, (ndb + NN_CHUNK - 1) / NN_CHUNK);
     NNPart* parts = (NNPart*)orbhip_nn_workspace(sizeof(NNPart) * (size_t)nq * nchunks, s);
@@ -539,10 +597,13 @@ bool orbhip_launch_hamming_nn(const uint8_t* d_q, int nq, const uint8_t* d_db, l
             int* seed = reinterpret_cast<int*>(p2 + (size_t)nq * stride);
             const long long ndb_all = ndb;
             ndb = (long long)1 << 15;                                              // the head pass sees the first chunk only
-            NN_FP4(4, 2, 9, 6, nhead, (const int*)nullptr, 0, 0, stride);
+#define NN_FP4X(LCH, GY, SEED, C0, P0) hipLaunchKernelGGL((k_hamming_nn_fp4<4, 2, LCH, 6, 0, true>), dim3((nq + qg - 1) / qg, GY, 1), dim3(256, 1, 1), 0, s, (const unsigned*)d_q, nq, (const unsigned*)d_dbx, ndb, base, parts, stride, SEED, C0, P0)
+            if (d_dbx) NN_FP4X(9, nhead, (const int*)nullptr, 0, 0); else NN_FP4(4, 2, 9, 6, nhead, (const int*)nullptr, 0, 0, stride);
             ndb = ndb_all;
             hipLaunchKernelGGL(k_hamming_seed, dim3((nq + 255) / 256, 1, 1), dim3(256, 1, 1), 0, s, (const NNPart*)parts, nq, stride, nhead, seed);
-            if (ablate == 0) NN_FP4(4, 2, 15, 6, nch - 1, (const int*)seed, 1, nhead, stride);
+            if (ablate == 0 && d_dbx) NN_FP4X(15, nch - 1, (const int*)seed, 1, nhead);
+#undef NN_FP4X
+            else if (ablate == 0) NN_FP4(4, 2, 15, 6, nch - 1, (const int*)seed, 1, nhead, stride);
             else {          // the same launch with parts of the loop compiled out: where the time goes (profiles/r06_exp_config5_ablation.txt)
 #define NN_FP4_ABL(A) hipLaunchKernelGGL((k_hamming_nn_fp4<4, 2, 15, 6, A>), dim3((nq + qg - 1) / qg, nch - 1, 1), dim3(256, 1, 1), 0, s, (const unsigned*)d_q, nq, (const unsigned*)d_db, ndb, base, parts, stride, (const int*)seed, 1, nhead)
                 if (ablate == 1) NN_FP4_ABL(1); else if (ablate == 2) NN_FP4_ABL(2); else if (ablate == 7) NN_FP4_ABL(7); else NN_FP4_ABL(3);

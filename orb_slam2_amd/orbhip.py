@@ -23,7 +23,7 @@ SYMBOLS = [
     "orbhip_version", "orbhip_thread_release", "orbhip_thread_api_ms", "orbhip_device_count", "orbhip_last_error", "orbhip_create", "orbhip_destroy", "orbhip_keypoint_capacity",
     "orbhip_get_scale_tables", "orbhip_level_size", "orbhip_extract", "orbhip_extract_batch", "orbhip_pyramid_level",
     "orbhip_extract_device", "orbhip_sync", "orbhip_fetch", "orbhip_fetch_matches", "orbhip_descriptor_distance",
-    "orbhip_hamming_nn", "orbhip_hamming_nn_device", "orbhip_search_for_initialization", "orbhip_profile_enable",
+    "orbhip_hamming_nn", "orbhip_hamming_nn_device", "orbhip_nn_expanded_size", "orbhip_nn_expand_device", "orbhip_hamming_nn_device_expanded", "orbhip_search_for_initialization", "orbhip_profile_enable",
     "orbhip_profile_num_kernels", "orbhip_profile_get", "orbhip_profile_reset", "orbhip_pyramid_cascade_tiles", "orbhip_algorithmic_bytes_per_frame",
     "orbhip_algorithmic_bytes_per_frame_kernel", "orbhip_debug_blurred_level", "orbhip_debug_candidates",
     "orbhip_compute_stereo_matches", "orbhip_extract_stereo", "orbhip_search_by_projection", "orbhip_extract_batch_color",
@@ -181,6 +181,9 @@ def lib(path=None):
     L.orbhip_descriptor_distance.argtypes = [vp, vp]
     L.orbhip_hamming_nn.argtypes = [C.c_int, vp, C.c_int, vp, C.c_int64, C.c_int64, vp, vp, vp]
     L.orbhip_hamming_nn_device.argtypes = [vp, vp, C.c_int, vp, C.c_int64, C.c_int64, vp, vp, vp]
+    L.orbhip_nn_expanded_size.argtypes = [C.c_int64]; L.orbhip_nn_expanded_size.restype = C.c_size_t
+    L.orbhip_nn_expand_device.argtypes = [vp, vp, C.c_int64, vp]
+    L.orbhip_hamming_nn_device_expanded.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int64, C.c_int64, vp, vp, vp]
     L.orbhip_search_for_initialization.argtypes = [C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp,
                                                    C.c_int, C.c_float, C.c_int, ip]
     L.orbhip_search_by_projection.argtypes = [C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, vp, ip]
@@ -879,6 +882,23 @@ def hamming_nn(q, db, device=0, index_base=0, library=None):
     L = lib(library)
     _check(L.orbhip_hamming_nn(device, _p(q), len(q), _p(db), len(db), index_base, _p(bi), _p(bd), _p(sd)), "orbhip_hamming_nn", L)
     return bi, bd, sd
+
+
+def nn_expanded_size(ndb, library=None):
+    """bytes of the expanded form of an ndb-row descriptor database (orbhip_nn_expanded_size)"""
+    return int(lib(library).orbhip_nn_expanded_size(int(ndb)))
+
+
+def nn_expand_device(stream, d_db, ndb, d_expanded, library=None):
+    L = lib(library)
+    _check(L.orbhip_nn_expand_device(C.c_void_p(stream) if stream else None, C.c_void_p(d_db), int(ndb), C.c_void_p(d_expanded)), "orbhip_nn_expand_device", L)
+
+
+def hamming_nn_device_expanded(stream, d_q, nq, d_db, d_expanded, ndb, d_best_idx, d_best_dist, d_second, index_base=0, library=None):
+    L = lib(library)
+    _check(L.orbhip_hamming_nn_device_expanded(C.c_void_p(stream) if stream else None, C.c_void_p(d_q), nq, C.c_void_p(d_db), C.c_void_p(d_expanded), ndb,
+                                               index_base, C.c_void_p(d_best_idx), C.c_void_p(d_best_dist), C.c_void_p(d_second)),
+           "orbhip_hamming_nn_device_expanded", L)
 
 
 def hamming_nn_device(stream, d_q, nq, d_db, ndb, d_best_idx, d_best_dist, d_second, index_base=0, library=None):

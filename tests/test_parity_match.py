@@ -152,6 +152,48 @@ def test_brute_force_nn_matrix_core_scan(backend, oracle, monkeypatch, form):
     assert np.array_equal(gb[0], want[0][:3].astype(np.int64) + 10 ** 10) and np.array_equal(gb[1], want[1][:3]) and np.array_equal(gb[2], want[2][:3])
 
 
+def test_brute_force_nn_expanded_database(backend, oracle):
+    """orbhip_nn_expand_device + orbhip_hamming_nn_device_expanded: the database expanded once into the FP4 scan's own tile layout (128 B per row), tiles staged by
+    16-byte LDS-DMA - the same answers as the scan that expands every row per query group, and as the oracle: ragged last tile and chunk, planted exact matches,
+    duplicates in the last tile (lowest index wins), an index base; the expansion itself byte for byte (bit k of a row -> nibble k: set 0x2, clear 0xA; rows past
+    the end zero)."""
+    emu = backend.endswith("_emu.so")
+    rng = np.random.default_rng(9)
+    n = 4 * 8192 + 1000 + 13 if emu else 3 * 65536 + 8192 + 1000 + 13
+    db = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    q = rng.integers(0, 256, (70 if emu else 530, 32), dtype=np.uint8)
+    q[:20] = db[rng.integers(0, n, 20)]; q[20:30] ^= 1
+    db[n - 5:] = db[100:105]; q[30:35] = db[100:105]
+    want = oracle.bf_nn(q, db, fast=True)
+    D = orb_slam2_amd.DeviceBuffer
+    ddb, dq = D.from_array(db, library=backend), D.from_array(q, library=backend)
+    nx = orb_slam2_amd.nn_expanded_size(n, library=backend)
+    assert nx == (n + 31) // 32 * 4096
+    dx = D(nx, library=backend)
+    orb_slam2_amd.nn_expand_device(None, ddb.ptr, n, dx.ptr, library=backend)
+    orb_slam2_amd.device_synchronize(library=backend)
+    x = dx.download((nx,), np.uint8)
+    # tile T: [dword d of the row][row i] x 16 bytes; byte b of the dword -> 4 bytes = its 8 bits as nibbles, low nibble first
+    for row in (0, 31, 32, 12345, n - 1):
+        T, i = divmod(row, 32)
+        for d in (0, 3, 7):
+            got = x[T * 4096 + (d * 32 + i) * 16:T * 4096 + (d * 32 + i) * 16 + 16]
+            bits = np.unpackbits(db[row, 4 * d:4 * d + 4], bitorder="little")
+            nib = np.where(bits == 1, 0x2, 0xA).astype(np.uint8)
+            assert np.array_equal(got, nib[0::2] | (nib[1::2] << 4)), (row, d)
+    if n % 32:
+        assert not x[(n // 32) * 4096:].reshape(8, 32, 16)[:, n % 32:, :].any()          # rows past the end: zero
+    bi, bd, sd = D(len(q) * 8, library=backend), D(len(q) * 4, library=backend), D(len(q) * 4, library=backend)
+    for base in (0, 10 ** 10):
+        orb_slam2_amd.hamming_nn_device_expanded(None, dq.ptr, len(q), ddb.ptr, dx.ptr, n, bi.ptr, bd.ptr, sd.ptr, index_base=base, library=backend)
+        orb_slam2_amd.device_synchronize(library=backend)
+        got = bi.download((len(q),), np.int64), bd.download((len(q),), np.int32), sd.download((len(q),), np.int32)
+        assert np.array_equal(got[0], want[0].astype(np.int64) + base) and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+    assert np.array_equal(got[0][30:35] - 10 ** 10, np.arange(100, 105))
+    for b in (ddb, dq, dx, bi, bd, sd):
+        b.free()
+
+
 @pytest.mark.parametrize("num_streams", [1, 2])
 def test_device_pipeline_extract_and_match(backend, oracle, select_tables, num_streams):
     """orbhip_extract_device on two camera slots over four time steps, matched against each slot's previous frame

@@ -25,8 +25,21 @@ bi = orb_slam2_amd.DeviceBuffer(NQ * 8); bd = orb_slam2_amd.DeviceBuffer(NQ * 4)
 orb_slam2_amd.device_synchronize()
 
 
+EXPANDED = os.environ.get("DB_EXPANDED", "0") == "1"           # the database expanded once (orbhip_nn_expand_device), tiles staged by LDS-DMA
+dx = None
+if EXPANDED:
+    dx = orb_slam2_amd.DeviceBuffer(orb_slam2_amd.nn_expanded_size(NKF * PER))
+    t_e = time.perf_counter()
+    orb_slam2_amd.nn_expand_device(None, db.ptr, NKF * PER, dx.ptr)
+    orb_slam2_amd.device_synchronize()
+    expand_ms = (time.perf_counter() - t_e) * 1e3
+
+
 def run():
-    orb_slam2_amd.hamming_nn_device(None, q.ptr, NQ, db.ptr, NKF * PER, bi.ptr, bd.ptr, sd.ptr)
+    if EXPANDED:
+        orb_slam2_amd.hamming_nn_device_expanded(None, q.ptr, NQ, db.ptr, dx.ptr, NKF * PER, bi.ptr, bd.ptr, sd.ptr)
+    else:
+        orb_slam2_amd.hamming_nn_device(None, q.ptr, NQ, db.ptr, NKF * PER, bi.ptr, bd.ptr, sd.ptr)
     orb_slam2_amd.device_synchronize()
 
 
@@ -51,4 +64,10 @@ else:
         out["frac_of_fp4_mfma_rate_measured_9100_TOPs"] = round(pairs * 512 / dt / 9.1e15, 3); out["frac_of_fp4_mfma_spec_10000_TOPs"] = round(pairs * 512 / dt / 10e15, 3)
     else:
         out["frac_of_i8_mfma_peak_measured_4400_TOPs"] = round(pairs * 512 / dt / 4.4e15, 3); out["frac_of_i8_mfma_spec_5000_TOPs"] = round(pairs * 512 / dt / 5e15, 3)
+if EXPANDED:
+    out["expanded_db_bytes"] = dx.nbytes; out["expand_once_ms"] = round(expand_ms, 2)
+    # the same queries through the ordinary scan: the answers must be identical
+    want = [b.download((NQ,), t) for b, t in ((bi, np.int64), (bd, np.int32), (sd, np.int32))]
+    orb_slam2_amd.hamming_nn_device(None, q.ptr, NQ, db.ptr, NKF * PER, bi.ptr, bd.ptr, sd.ptr); orb_slam2_amd.device_synchronize()
+    out["equals_unexpanded_scan"] = all(np.array_equal(w, b.download((NQ,), t)) for w, (b, t) in zip(want, ((bi, np.int64), (bd, np.int32), (sd, np.int32))))
 print(json.dumps(out))
