@@ -59,6 +59,23 @@ def build_native():
     return os.path.exists(NATIVE_PATH)
 
 
+DROPIN_NATIVE_PATH = os.path.join(HERE, "_ref", "liborbslam_dropin_full_native.so")   # the all-steps drop-in build with the same flags (CPU emulation of the kernels)
+_dropin_native = None
+
+
+def build_dropin_native():
+    if os.path.isdir("/root/reference/src"):
+        _locked_make(["-C", HERE, "-s", "dropin_native"])
+    return os.path.exists(DROPIN_NATIVE_PATH)
+
+
+def dropin_native_lib():
+    global _dropin_native
+    if _dropin_native is None:
+        _dropin_native = _bind(C.CDLL(DROPIN_NATIVE_PATH))
+    return _dropin_native
+
+
 def native_lib():
     global _native
     if _native is None:

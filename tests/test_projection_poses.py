@@ -62,8 +62,9 @@ def _world(rng, keys, T, dx=-3.0, dy=-1.0, sigma=1.2, scale=1.0):
     return w[:, 0].astype(np.float32), w[:, 1].astype(np.float32), w[:, 2].astype(np.float32)
 
 
-def _run(S, D, strict=True):
-    """every member under three random pose sets -> (matches compared per member, calls whose output differs per member); strict: assert equality"""
+def _run(S, D, strict=True, base=None):
+    """every member under three random pose sets -> (matches compared per member, calls whose output differs per member); strict: assert equality.
+    base: the library the reference side runs on (None: the canonical all-reference build)"""
     seq = synth.sequence(W, H, 2, seed=41)
     S.RefFrame._geometry = None
     S.RefFrame._geometry_other.clear()
@@ -72,7 +73,7 @@ def _run(S, D, strict=True):
         for stereo in (False, True):
             kw = dict(nfeatures=N, bf=40.0, **CAM)
             mk = lambda im, lib: S.RefFrame(im, np.roll(im, -9, axis=1) if stereo else None, library=lib, **kw)
-            R, F = [mk(im, None) for im in seq], [mk(im, D) for im in seq]
+            R, F = [mk(im, base) for im in seq], [mk(im, D) for im in seq]
             kl, dl, kc = R[0].keys_un, R[0].desc, R[1].keys_un
             nq = len(kl)
             for seed in range(3):
@@ -82,7 +83,7 @@ def _run(S, D, strict=True):
                 # the similarity between the two key frames: camera 1 = s12 * R12 * camera 2 + t12, consistent with A and B up to the scale
                 T12 = A @ np.linalg.inv(B)
                 R12, t12 = T12[:3, :3], T12[:3, 3]
-                for L in (None, D):
+                for L in (base, D):
                     S.set_test_poses(A, B, s12, R12, t12, library=L)
                 level = np.clip(kl["octave"] + rng.integers(0, 2, nq), 0, 7).astype(np.int32)
                 bad = (rng.random(nq) < 0.05).astype(np.uint8)
@@ -164,11 +165,11 @@ def _run(S, D, strict=True):
             S.RefFrame._geometry_other.clear()
         # stereo key frame for Fuse's chi-square gate with the right coordinate (ur = u - bf*invz)
         kw = dict(nfeatures=N, bf=40.0, **CAM)
-        ks_r = S.RefFrame(seq[1], np.roll(seq[1], -9, axis=1), **kw); ks_f = S.RefFrame(seq[1], np.roll(seq[1], -9, axis=1), library=D, **kw)
-        kl = S.RefFrame(seq[0], **kw)
+        ks_r = S.RefFrame(seq[1], np.roll(seq[1], -9, axis=1), library=base, **kw); ks_f = S.RefFrame(seq[1], np.roll(seq[1], -9, axis=1), library=D, **kw)
+        kl = S.RefFrame(seq[0], library=base, **kw)
         rng = np.random.default_rng(9)
         A = _pose(rng)
-        for L in (None, D):
+        for L in (base, D):
             S.set_test_poses(A, A, 1.0, None, None, library=L)
         X, Y, Z = _world(rng, kl.keys_un, A)
         nq = len(X)
@@ -180,7 +181,7 @@ def _run(S, D, strict=True):
         checked["fuse_stereo"] = n_r
         ks_r.close(); ks_f.close(); kl.close()
     finally:
-        for L in (None, D):
+        for L in (base, D):
             S.set_test_poses(None, library=L)
         S.RefFrame._geometry = None
         S.RefFrame._geometry_other.clear()

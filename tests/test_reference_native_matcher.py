@@ -30,3 +30,24 @@ def test_native_flags_build_of_the_matcher_against_the_canonical_build(request, 
               + ", ".join(f"{k} {differs.get(k, 0)}" for k in sorted(checked)) + "  (of " + ", ".join(f"{k} {checked[k]}" for k in sorted(checked)) + " matches)")
     assert total > 5000
     assert bad <= total // 200, (bad, total)        # (0 on this host; a boundary crossing per few thousand matches would still be the same exposure)
+
+
+def test_native_flags_build_of_the_dropin_against_the_native_flags_reference(request, capsys):
+    """What a maintainer's own CMake build of the installed drop-in is (the reference's flags: -O3 -march=native) against the reference built the same way:
+    the repository's ORBmatcher.cc / ORBextractor.cc and the patched Frame.cc are contracted by the compiler like the reference's files, the device (here: the
+    emulation) rounds every operation of the projection once.  ORBmatcher::IsInFrustum is host code written in the reference's expression shapes: its outputs must
+    be identical under these flags too.  The members' matches: reported; asserted equal up to the boundary crossings H3 / H11 allow (0 on this host)."""
+    if gpu_session(request.config):
+        pytest.skip("CPU only")
+    from oracle import orbslam_ref as S
+    if not (S.build() and S.build_native() and S.build_dropin() and S.build_dropin_native()):
+        pytest.skip("reference sources not mounted")
+    import test_projection_poses as T
+    checked, differs = T._run(S, S.dropin_native_lib(), strict=False, base=S.native_lib())
+    total, bad = sum(v for k, v in checked.items() if k != "frustum"), sum(v for k, v in differs.items() if k != "frustum")
+    with capsys.disabled():
+        print("\nnative-flags drop-in against the native-flags reference: entries of the members' outputs that differ: "
+              + ", ".join(f"{k} {differs.get(k, 0)}" for k in sorted(checked)) + "  (of " + ", ".join(f"{k} {checked[k]}" for k in sorted(checked)) + " matches)")
+    assert total > 5000
+    assert bad <= total // 200, (bad, total)
+    assert differs.get("frustum", 0) == 0, "ORBmatcher::IsInFrustum under the reference's own flags"
