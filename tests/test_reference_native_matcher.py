@@ -51,3 +51,25 @@ def test_native_flags_build_of_the_dropin_against_the_native_flags_reference(req
     assert total > 5000
     assert bad <= total // 200, (bad, total)
     assert differs.get("frustum", 0) == 0, "ORBmatcher::IsInFrustum under the reference's own flags"
+
+
+def test_native_flags_front_end_loop(request):
+    """Tracking's per-frame sequence (tests/test_dropin_loop.py) with BOTH sides built with the reference's own flags: the native reference's extractor fuses the
+    pattern rotation (H3: the drop-in class then starts with fp_contract = 1, its own translation unit being compiled with FMA code generation), its matcher
+    members contract their scalar statements; every frame must agree in key points, descriptors, mvuRight / mvDepth, the map point of every feature after each
+    matcher and the counters."""
+    if gpu_session(request.config):
+        pytest.skip("CPU only")
+    from oracle import orbslam_ref as S
+    if not (S.build() and S.build_native() and S.build_dropin() and S.build_dropin_native()):
+        pytest.skip("reference sources not mounted")
+    from orb_slam2_amd import synth
+    import test_dropin_loop as TL
+    cfg = TL.SMALL
+    L, R, T, P = synth.stereo_sequence(cfg["w"], cfg["h"], 7, cfg["fx"], cfg["bf"], seed=3)
+    args = (L, R, T, P, cfg["n"], cfg["fx"], cfg["fy"], cfg["cx"], cfg["cy"], cfg["bf"], cfg["th_depth"])
+    ref = S.tracking_loop(*args, kf_every=3, library=S.native_lib())
+    got = S.tracking_loop(*args, kf_every=3, library=S.dropin_native_lib())
+    for k, (a, b) in enumerate(zip(ref, got)):
+        assert a.same(b), f"frame {k} differs: " + ", ".join(f"{f} {getattr(a, f)} vs {getattr(b, f)}" for f in a.FIELDS if getattr(a, f) != getattr(b, f))
+    assert all(f.n_motion > 50 and f.n_local > 5 for f in ref[1:])
