@@ -73,3 +73,25 @@ def test_native_flags_front_end_loop(request):
     for k, (a, b) in enumerate(zip(ref, got)):
         assert a.same(b), f"frame {k} differs: " + ", ".join(f"{f} {getattr(a, f)} vs {getattr(b, f)}" for f in a.FIELDS if getattr(a, f) != getattr(b, f))
     assert all(f.n_motion > 50 and f.n_local > 5 for f in ref[1:])
+
+
+@pytest.mark.parametrize("sensor", ["mono", "rgbd"])
+def test_native_flags_sequences(request, tmp_path_factory, sensor):
+    """... and the monocular / RGB-D sequences with relocalisation (tests/test_sequences.py), both sides built with the reference's own flags: initialisation on
+    2 x nFeatures frames, TrackReferenceKeyFrame with its bags of words, the distorted RGB-D constructor, Relocalization's two projection searches."""
+    if gpu_session(request.config):
+        pytest.skip("CPU only")
+    from oracle import orbslam_ref as S
+    if not (S.build() and S.build_native() and S.build_dropin() and S.build_dropin_native()):
+        pytest.skip("reference sources not mounted")
+    from orb_slam2_amd import synth
+    import test_sequences as TS
+    cfg = TS.SMALL
+    L, R, T, P, depth = synth.stereo_sequence(cfg["w"], cfg["h"], 12, cfg["fx"], cfg["bf"], seed=3, return_depth=True)
+    args = (sensor, L, depth, T, P, cfg["n"], cfg["fx"], cfg["fy"], cfg["cx"], cfg["cy"], cfg["bf"], cfg["th_depth"], TS._voc(tmp_path_factory))
+    kw = dict(dist=TS.TUM1_DIST if sensor == "rgbd" else None, kf_every=3, lost_every=5)
+    ref = S.sequence_loop(*args, library=S.native_lib(), **kw)
+    got = S.sequence_loop(*args, library=S.dropin_native_lib(), **kw)
+    for k, (a, b) in enumerate(zip(ref, got)):
+        assert a.same(b), f"{sensor} frame {k} differs: " + ", ".join(f"{f} {getattr(a, f)} vs {getattr(b, f)}" for f in a.FIELDS + ("n_extra", "bow_hash") if getattr(a, f) != getattr(b, f))
+    assert sum(f.used_wide == 4 for f in ref) >= 1 and sum(f.n_local for f in ref) > 50
