@@ -515,14 +515,15 @@ template <int QT, int OCC, int LCH, int TPB, int ABL = 0, bool EXP = false> __gl
 // recomputed - a quarter of the scan's time (ORBHIP_NN_BLOCK_VAR=64).  The filter only decides which tiles are looked at: the answers do not depend on the order
 // the workgroups run in.
 template <int LCH, bool EXP, int VAR = 0> __global__ __launch_bounds__(256, 2) void k_hamming_nn_fp4b(const unsigned* q, int nq, const unsigned* db, long long ndb, long long base, NNPart* parts, int nchunks,
-                                                                                                        const int* seed, int* share, int chunk0, int part0, int* stats)
+                                                                                                        const int* seed, int* share, int chunk0, int part0, int* stats, int share_mask)
 {
     constexpr int QT = 4, TPB = NN_FP4B_TPB;
     static_assert(TPB <= 8, "the keep mask has eight bits per query tile");
     __shared__ unsigned s_tab[256];
     __shared__ __attribute__((aligned(16))) unsigned s_a[2][TPB * 1024];
     __shared__ int s_bnd[4][2 * QT][64];                               // the queries' shared pairs as last read: [wave][t] the second best, [wave][QT + t] the best
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), chunk = blockIdx.y + chunk0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bx = blockIdx.x, by = blockIdx.y, chunk = by + chunk0;
     {
         unsigned e = 0;
 #pragma unroll
@@ -536,7 +537,7 @@ template <int LCH, bool EXP, int VAR = 0> __global__ __launch_bounds__(256, 2) v
     int qidx[QT];
 #pragma unroll
     for (int t = 0; t < QT; t++) {
-        qidx[t] = blockIdx.x * QG + (wave * QT + t) * 32 + j;
+        qidx[t] = bx * QG + (wave * QT + t) * 32 + j;
         const unsigned* qp = q + (long long)min(qidx[t], nq - 1) * 8;
 #pragma unroll
         for (int kb = 0; kb < 4; kb++) {
@@ -644,15 +645,14 @@ template <int LCH, bool EXP, int VAR = 0> __global__ __launch_bounds__(256, 2) v
 #if defined(__HIP_DEVICE_COMPILE__) && __HIP_DEVICE_COMPILE__
         unsigned keep, stmp;
         const unsigned addr = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)ta);
-        const int sca = 127, scb = 133;
 #define NN_FP4B_ASM(BODY) asm volatile(BODY \
                      : "=&s"(keep), "=&s"(stmp) \
                      : "v"(B[0][0]), "v"(B[0][1]), "v"(B[0][2]), "v"(B[0][3]), "v"(B[1][0]), "v"(B[1][1]), "v"(B[1][2]), "v"(B[1][3]), \
                        "v"(B[2][0]), "v"(B[2][1]), "v"(B[2][2]), "v"(B[2][3]), "v"(B[3][0]), "v"(B[3][1]), "v"(B[3][2]), "v"(B[3][3]), \
-                       "v"(thr[0]), "v"(thr[1]), "v"(thr[2]), "v"(thr[3]), "v"(sca), "v"(scb), "s"(addr) \
+                       "v"(thr[0]), "v"(thr[1]), "v"(thr[2]), "v"(thr[3]), "s"(addr) \
                      : "memory", "vcc", "scc", NN_FP4B_CLOBBERS)
         // (VAR != 0: measurement only - ORBHIP_NN_BLOCK_VAR, tools/gen_nn_fp4_block.py: the same superstep with parts of its text left out; wrong answers)
-        if constexpr ((VAR & 3) == 1) NN_FP4B_ASM(NN_FP4B_BODY1); else if constexpr ((VAR & 3) == 2) NN_FP4B_ASM(NN_FP4B_BODY2); else if constexpr ((VAR & 3) == 3) NN_FP4B_ASM(NN_FP4B_BODY3); else NN_FP4B_ASM(NN_FP4B_BODY);
+        if constexpr ((VAR & 3) == 1) NN_FP4B_ASM(NN_FP4B_BODY1); else if constexpr ((VAR & 3) == 3) NN_FP4B_ASM(NN_FP4B_BODY3); else NN_FP4B_ASM(NN_FP4B_BODY);
 #undef NN_FP4B_ASM
         return keep;
 #else
@@ -674,20 +674,17 @@ template <int LCH, bool EXP, int VAR = 0> __global__ __launch_bounds__(256, 2) v
         const int buf = sup & 1, tile0 = sup * TPB;
         if (pending) bounds_take();                                                                         // (requested at the start of the superstep before, landed before its barrier)
         pending = false;
-        if constexpr (VAR >= 4) {                                                                           // (measurement only: 4..7 no staging of new tiles and no barrier, 8 the barrier alone, 16 the staging alone)
-            if constexpr (VAR == 16) { if (sup + 1 < nsuper) stage_dma(sup + 1, buf ^ 1); }
+        if constexpr (VAR >= 4) {                                                                           // (measurement only: no staging of new tiles, no barrier)
             const unsigned keep = superstep(s_a[0]);
             if (keep == 0x12345678u) tournament1(tile0, 0, products1(s_a[0], B[0]), false);
-            if constexpr (VAR == 8) __syncthreads();
             continue;
         }
         if (sup + 1 < nsuper) { if constexpr (EXP) stage_dma(sup + 1, buf ^ 1); else fetch(sup + 1); }      // (everybody left that buffer at the barrier of the superstep before)
         // every NN_SHARE_EVERY-th superstep, the workgroups out of step with each other: the reads are device-scope (they go past the L2) and all workgroups of a
         // query group read the same few lines - once per superstep they queued on those lines' memory channel (5.1 ms against 3.3 for the scan without them)
-        if (bound && sup + 1 < nsuper && ((sup + (int)blockIdx.y) & (NN_SHARE_EVERY - 1)) == 0) { bounds_request(); pending = true; }
-        if (tile0 + TPB <= nfull) {
-            unsigned keep = superstep(s_a[buf]);
-            if constexpr (VAR == 64) keep = keep == 0x12345678u;                                           // (measurement only: no kept pairs)
+        if (bound && sup + 1 < nsuper && ((sup + by) & share_mask) == 0) { bounds_request(); pending = true; }
+        if (tile0 + TPB <= nfull) {                                                                         // a superstep of whole tiles: the hand-ordered statement
+            const unsigned keep = superstep(s_a[buf]);
             nkept += __builtin_popcount(keep);
 #pragma unroll
             for (int t = 0; t < QT; t++) {
@@ -708,7 +705,7 @@ template <int LCH, bool EXP, int VAR = 0> __global__ __launch_bounds__(256, 2) v
                 }
             }
         }
-        if (sup + 1 < nsuper) { if constexpr (!EXP) expand(buf ^ 1); if constexpr (VAR != 32) __builtin_amdgcn_s_waitcnt(0x0f70); }      // (vmcnt(0): the next tiles and the bounds have landed; VAR 32, measurement only: not waited for)
+        if (sup + 1 < nsuper) { if constexpr (!EXP) expand(buf ^ 1); __builtin_amdgcn_s_waitcnt(0x0f70); }      // (vmcnt(0): the next tiles and the bounds have landed)
         __syncthreads();
     }
     if (stats && lane == 0) { atomicAdd(stats, nkept); atomicAdd(stats + 1, QT * min(ntiles, nfull)); }
@@ -721,7 +718,7 @@ template <int LCH, bool EXP, int VAR = 0> __global__ __launch_bounds__(256, 2) v
             p.best = (b >> LCH) > 256u ? IMAX : (int)(b >> LCH);
             p.second = (s2 >> LCH) > 256u ? IMAX : (int)(s2 >> LCH);
             p.idx = (b >> LCH) > 256u ? -1 : row0 + (long long)(b & (unsigned)(CH - 1)) + base;
-            parts[(long long)qidx[t] * nchunks + part0 + (int)blockIdx.y] = p;
+            parts[(long long)qidx[t] * nchunks + part0 + by] = p;
         }
     }
 }
@@ -829,12 +826,14 @@ bool orbhip_launch_hamming_nn(const uint8_t* d_q, int nq, const uint8_t* d_db, l
             parts = p2;
             int* seed = reinterpret_cast<int*>(p2 + (size_t)nq * stride);
             int* share = seed + nq;                                                // [nq] best, [nq] second best: k_hamming_nn_fp4b's shared bounds
+            int share_mask = NN_SHARE_EVERY - 1;                                   // ORBHIP_NN_SHARE_EVERY (measurement only): supersteps between two reads of the shared bounds, a power of two
+            if (const char* ev = getenv("ORBHIP_NN_SHARE_EVERY")) { const int v = atoi(ev); if (v >= 1 && (v & (v - 1)) == 0) share_mask = v - 1; }
             int* stats = nullptr;                                                  // ORBHIP_NN_STATS=1 (measurement only): kept / examined (tile, query tile) pairs of the main pass on stderr
             if (getenv("ORBHIP_NN_STATS")) stats = seed + 3 * (size_t)nq;
             const long long ndb_all = ndb;
             ndb = (long long)1 << 15;                                              // the head pass sees the first chunk only
 #define NN_FP4X(LCH, GY, SEED, C0, P0) hipLaunchKernelGGL((k_hamming_nn_fp4<4, 2, LCH, 6, 0, true>), dim3((nq + qg - 1) / qg, GY, 1), dim3(256, 1, 1), 0, s, (const unsigned*)d_q, nq, (const unsigned*)d_dbx, ndb, base, parts, stride, SEED, C0, P0)
-#define NN_FP4B(LCH, EXP, DB, GY, SEED, SHARE, C0, P0) hipLaunchKernelGGL((k_hamming_nn_fp4b<LCH, EXP>), dim3((nq + qg - 1) / qg, GY, 1), dim3(256, 1, 1), 0, s, (const unsigned*)d_q, nq, (const unsigned*)(DB), ndb, base, parts, stride, SEED, SHARE, C0, P0, stats)
+#define NN_FP4B(LCH, EXP, DB, GY, SEED, SHARE, C0, P0) hipLaunchKernelGGL((k_hamming_nn_fp4b<LCH, EXP>), dim3((nq + qg - 1) / qg, GY, 1), dim3(256, 1, 1), 0, s, (const unsigned*)d_q, nq, (const unsigned*)(DB), ndb, base, parts, stride, SEED, SHARE, C0, P0, stats, share_mask)
             // ORBHIP_NN_BLOCK=0 (measurement only): the compiler-scheduled tile loop of round 5 / 6 instead of the hand-ordered superstep
             const char* blk_env = getenv("ORBHIP_NN_BLOCK");
             const bool block = !(blk_env && blk_env[0] == '0') && ablate == 0;
@@ -846,9 +845,9 @@ bool orbhip_launch_hamming_nn(const uint8_t* d_q, int nq, const uint8_t* d_db, l
             const int bvar = getenv("ORBHIP_NN_BLOCK_VAR") ? atoi(getenv("ORBHIP_NN_BLOCK_VAR")) : 0;              // measurement only
             const char* share_env = getenv("ORBHIP_NN_SHARE");                                                       // ORBHIP_NN_SHARE=0 (measurement only): the head's bound alone
             int* const share_arg = share_env && share_env[0] == '0' ? (int*)nullptr : share;
-            if (block && d_dbx && bvar >= 1 && bvar <= 64) {
-#define NN_FP4BV(V) hipLaunchKernelGGL((k_hamming_nn_fp4b<15, true, V>), dim3((nq + qg - 1) / qg, nch - 1, 1), dim3(256, 1, 1), 0, s, (const unsigned*)d_q, nq, (const unsigned*)d_dbx, ndb, base, parts, stride, (const int*)seed, share_arg, 1, nhead, stats)
-                if (bvar == 1) NN_FP4BV(1); else if (bvar == 2) NN_FP4BV(2); else if (bvar == 3) NN_FP4BV(3); else if (bvar == 4) NN_FP4BV(4); else if (bvar == 5) NN_FP4BV(5); else if (bvar == 8) NN_FP4BV(8); else if (bvar == 16) NN_FP4BV(16); else if (bvar == 32) NN_FP4BV(32); else if (bvar == 64) NN_FP4BV(64); else NN_FP4BV(7);
+            if (block && d_dbx && (bvar == 1 || bvar == 3 || bvar == 4 || bvar == 5 || bvar == 7)) {
+#define NN_FP4BV(V) hipLaunchKernelGGL((k_hamming_nn_fp4b<15, true, V>), dim3((nq + qg - 1) / qg, nch - 1, 1), dim3(256, 1, 1), 0, s, (const unsigned*)d_q, nq, (const unsigned*)d_dbx, ndb, base, parts, stride, (const int*)seed, share_arg, 1, nhead, stats, share_mask)
+                if (bvar == 1) NN_FP4BV(1); else if (bvar == 3) NN_FP4BV(3); else if (bvar == 4) NN_FP4BV(4); else if (bvar == 5) NN_FP4BV(5); else NN_FP4BV(7);
 #undef NN_FP4BV
             }
             else if (block && d_dbx) NN_FP4B(15, true, d_dbx, nch - 1, (const int*)seed, share_arg, 1, nhead); else if (block) NN_FP4B(15, false, d_db, nch - 1, (const int*)seed, share_arg, 1, nhead);

@@ -33,6 +33,7 @@ struct Worker {
     int ctx_ticket[8]; std::vector<int> cams[8]; orbhip_status slot_st[8] = {}; std::string slot_err[8];
     // descriptor DB shard + query staging
     uint8_t* d_db = nullptr; int64_t lo = 0, hi = 0;
+    uint8_t* d_dbx = nullptr;          // the shard expanded once for the FP4 scan (orbhip_nn_expand_device): 128 B per row beside the 32; nullptr = scan the bit form
     hipStream_t qstream = nullptr; uint8_t* d_q = nullptr; long long* d_bi = nullptr; int* d_bd = nullptr; int* d_sd = nullptr; int q_cap = 0;
     uint8_t* h_q = nullptr; long long* h_bi = nullptr; int* h_bd = nullptr; int* h_sd = nullptr;
 
@@ -85,7 +86,7 @@ extern "C" void orbhip_pool_destroy(orbhip_pool* p)
             (void)hipSetDevice(wp->device);
             if (wp->ctx) orbhip_destroy(wp->ctx);
             if (wp->qstream) { (void)hipStreamSynchronize(wp->qstream); (void)hipStreamDestroy(wp->qstream); }
-            void* d[] = {wp->d_db, wp->d_q, wp->d_bi, wp->d_bd, wp->d_sd}; for (void* x : d) if (x) (void)hipFree(x);
+            void* d[] = {wp->d_db, wp->d_dbx, wp->d_q, wp->d_bi, wp->d_bd, wp->d_sd}; for (void* x : d) if (x) (void)hipFree(x);
             void* h[] = {wp->h_q, wp->h_bi, wp->h_bd, wp->h_sd}; for (void* x : h) if (x) (void)hipHostFree(x);
         });
         w->wait();
@@ -221,10 +222,18 @@ extern "C" orbhip_status orbhip_pool_db_load(orbhip_pool* p, const uint8_t* db, 
         w->post([w, db] {
             hipError_t e = hipSetDevice(w->device);
             if (e == hipSuccess && w->d_db) { e = hipFree(w->d_db); w->d_db = nullptr; }
+            if (e == hipSuccess && w->d_dbx) { e = hipFree(w->d_dbx); w->d_dbx = nullptr; }
             const size_t bytes = (size_t)(w->hi - w->lo) * 32;
             if (e == hipSuccess) e = orbhip_dmalloc((void**)&w->d_db, std::max<size_t>(bytes, 32));
             if (e == hipSuccess && bytes) e = hipMemcpy(w->d_db, db + (size_t)w->lo * 32, bytes, hipMemcpyHostToDevice);
             if (e == hipSuccess && !w->qstream) e = hipStreamCreateWithFlags(&w->qstream, hipStreamNonBlocking);
+            // A database is loaded once and asked many times: from the size on at which a query takes the matrix-core scan, the shard is also kept in the form
+            // that scan multiplies (four times the bytes; ORBHIP_POOL_DB_EXPAND=0 or no memory for it: the bit form is scanned, the answers are the same)
+            const char* ex = getenv("ORBHIP_POOL_DB_EXPAND");
+            if (e == hipSuccess && w->hi - w->lo >= 4 * 8192 && !(ex && ex[0] == '0')) {
+                if (orbhip_dmalloc((void**)&w->d_dbx, orbhip_nn_expanded_size(w->hi - w->lo)) != hipSuccess) { w->d_dbx = nullptr; (void)hipGetLastError(); }
+                else if (orbhip_nn_expand_device(w->qstream, w->d_db, w->hi - w->lo, w->d_dbx) != ORBHIP_OK || hipStreamSynchronize(w->qstream) != hipSuccess) { (void)hipFree(w->d_dbx); w->d_dbx = nullptr; }
+            }
             if (e != hipSuccess) w->fail_hip("descriptor DB shard upload", e);
         });
     }
@@ -259,7 +268,8 @@ extern "C" orbhip_status orbhip_pool_db_query(orbhip_pool* p, const uint8_t* q, 
             if (e != hipSuccess) { w->fail_hip("descriptor DB query buffers", e); return; }
             memcpy(w->h_q, q, (size_t)nq * 32);                                                    // the "broadcast": G independent 64 KB copies
             e = hipMemcpyAsync(w->d_q, w->h_q, (size_t)nq * 32, hipMemcpyHostToDevice, w->qstream);
-            if (e == hipSuccess && orbhip_hamming_nn_device(w->qstream, w->d_q, nq, w->d_db, w->hi - w->lo, w->lo, (int64_t*)w->d_bi, w->d_bd, w->d_sd) != ORBHIP_OK) { w->fail_from_thread(ORBHIP_ERR_HIP); return; }
+            if (e == hipSuccess && (w->d_dbx ? orbhip_hamming_nn_device_expanded(w->qstream, w->d_q, nq, w->d_db, w->d_dbx, w->hi - w->lo, w->lo, (int64_t*)w->d_bi, w->d_bd, w->d_sd)
+                                             : orbhip_hamming_nn_device(w->qstream, w->d_q, nq, w->d_db, w->hi - w->lo, w->lo, (int64_t*)w->d_bi, w->d_bd, w->d_sd)) != ORBHIP_OK) { w->fail_from_thread(ORBHIP_ERR_HIP); return; }
             if (e == hipSuccess) e = hipMemcpyAsync(w->h_bi, w->d_bi, (size_t)nq * 8, hipMemcpyDeviceToHost, w->qstream);
             if (e == hipSuccess) e = hipMemcpyAsync(w->h_bd, w->d_bd, (size_t)nq * 4, hipMemcpyDeviceToHost, w->qstream);
             if (e == hipSuccess) e = hipMemcpyAsync(w->h_sd, w->d_sd, (size_t)nq * 4, hipMemcpyDeviceToHost, w->qstream);

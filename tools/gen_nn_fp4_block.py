@@ -14,16 +14,18 @@ Schedule (TPB tiles, each two HALF tiles of two query tiles = eight matrix instr
            only after its tests have issued); operand kb of the NEXT tile is read into the same four registers behind the last matrix instruction of this
            tile that uses them (second half, instruction 2 kb + 1) and waited for with a counted lgkmcnt in front of its first use - one operand set, not two:
            the sixteen registers decide whether hipcc spills around the statement.
-Operands: %0 keep (s, out), %1 scalar scratch, %2 + 4 t + kb the query operand tuple (t, kb), %18 + t the threshold of query tile t, %22 / %23 the scale
-registers (A: 127, B: 133), %24 (s) the LDS byte address of the superstep's first tile.
+Operands: %0 keep (s, out), %1 scalar scratch, %2 + 4 t + kb the query operand tuple (t, kb), %18 + t the threshold of query tile t, %22 (s) the LDS byte
+address of the superstep's first tile.  (Tried and dropped, profiles/r06_exp_config5_superstep.txt: the next superstep's LDS-DMA requests inside the statement,
+one per tile in the shadow of a matrix instruction, instead of eight in a burst behind the barrier - the same 3.68 ms.)
 """
 import os
 import sys
 
 TPB = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-V0 = 141                      # first clobbered VGPR (1 address + 96 accumulator + 16 operand + 2 scratch registers end at v255)
-ADDR = V0                     # the lane's LDS byte address, made here from the wave-uniform base %24 (as an input it was spilled - and its reload's vmcnt(0) waited for the prefetch)
-ACC = V0 + 1                  # three pairs of 16-register accumulators: 96 registers
+V0 = 139                      # first clobbered VGPR (3 + 96 accumulator + 16 operand + 2 scratch registers end at v255)
+SCA, SCB = V0, V0 + 1         # the two block scales (127 = 2^0 for the rows, 133 = 2^6 for the queries)
+ADDR = V0 + 2                 # the lane's LDS byte address, made here from the wave-uniform base (as an input it was spilled - and its reload's vmcnt(0) waited for the prefetch)
+ACC = V0 + 3                  # three pairs of 16-register accumulators: 96 registers
 AOP = ACC + 96                # ONE set of four 4-register tile operands: operand kb of the next tile is read as soon as this tile's last matrix instruction on it has issued
 TMP = AOP + 16                # two running maxima
 assert TMP + 2 <= 256
@@ -40,7 +42,7 @@ def vr(b, n):
 
 def mfma(dst, aop, bop, first):
     c = "0" if first else vr(dst, 16)
-    return f"v_mfma_scale_f32_32x32x64_f8f6f4 {vr(dst, 16)}, {vr(aop, 4)}, {bop}, {c}, %22, %23 op_sel_hi:[0,0,0] cbsz:4 blgp:4"
+    return f"v_mfma_scale_f32_32x32x64_f8f6f4 {vr(dst, 16)}, {vr(aop, 4)}, {bop}, {c}, v{SCA}, v{SCB} op_sel_hi:[0,0,0] cbsz:4 blgp:4"
 
 
 def half_mfmas(s, one_operand_set=False):
@@ -86,17 +88,16 @@ def reads(u):
 
 
 def body(var):
-    """var 0: the production text.  Measurement only (ORBHIP_NN_BLOCK_VAR, wrong answers): 1 = no tests, 2 = the tests' maxima without compare / scalar part,
-    3 = matrix instructions alone (the first tile's operands reused for every tile)"""
-    lines = ["s_mov_b32 %0, 0", f"v_mbcnt_lo_u32_b32 v{ADDR}, -1, 0", f"v_mbcnt_hi_u32_b32 v{ADDR}, -1, v{ADDR}", f"v_lshl_add_u32 v{ADDR}, v{ADDR}, 4, %24"] + reads(0)
+    """var 0: the production text.  Measurement only (ORBHIP_NN_BLOCK_VAR, wrong answers): 1 = no tests, 3 = matrix instructions alone (the first tile's
+    operands reused for every tile)"""
+    lines = ["s_mov_b32 %0, 0", f"v_mbcnt_lo_u32_b32 v{ADDR}, -1, 0", f"v_mbcnt_hi_u32_b32 v{ADDR}, -1, v{ADDR}", f"v_mov_b32_e32 v{SCA}, 0x7f", f"v_mov_b32_e32 v{SCB}, 0x85"]
+    lines += [f"v_lshl_add_u32 v{ADDR}, v{ADDR}, 4, %22"] + reads(0)
     NH = 2 * TPB
     for s in range(NH + 2):
         mm = half_mfmas(s, var == 3) if s < NH else []
         tt = half_tests(s - 2) if s >= 2 else []
         if var in (1, 3):
             tt = []
-        if var == 2:
-            tt = [g for g in tt if g[0].startswith("v_max")]
         u, h = divmod(s, 2)
         if not mm:
             for g in tt:
@@ -124,8 +125,8 @@ out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "orb_slam2_
 with open(out, "w") as f:
     f.write(f"// generated by tools/gen_nn_fp4_block.py {TPB} - the hand-ordered superstep of k_hamming_nn_fp4b; do not edit\n")
     f.write(f"#define NN_FP4B_TPB {TPB}\n#define NN_FP4B_V0 {V0}\n")
-    for var in range(4):
-        lines = body(var)
+    for var in (0, 1, 3):
+        lines = [".p2align 6"] + body(var)
         f.write(f'#define NN_FP4B_BODY{var if var else ""} "' + "\\n\\t".join(lines) + '"\n')
     f.write(f"#define NN_FP4B_CLOBBERS {clob}\n")
 print(out, len(body(0)), "instructions")
