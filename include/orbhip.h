@@ -171,7 +171,8 @@ orbhip_status orbhip_pool_extract(orbhip_pool* pool, const uint8_t* const* imgs,
                                   orbhip_keypoint* kps, uint8_t* desc, int cap, int* n_out /* ncameras */);
 orbhip_status orbhip_pool_submit(orbhip_pool* pool, const uint8_t* const* imgs, int stride_bytes, int* ticket);
 orbhip_status orbhip_pool_collect(orbhip_pool* pool, int ticket, orbhip_keypoint* kps, uint8_t* desc, int cap, int* n_out);
-/* descriptor DB: rows [lo_r, hi_r) of db go to devices[r] and stay there; ndb rows of 32 bytes */
+/* descriptor DB: rows [lo_r, hi_r) of db go to devices[r] and stay there; ndb rows of 32 bytes.  A shard of 32 K rows or more is also kept in the expanded
+   form the FP4 scan multiplies (orbhip_nn_expand_device: four times the bytes) when the device has the memory; ORBHIP_POOL_DB_EXPAND=0: never.  Same answers. */
 orbhip_status orbhip_pool_db_load(orbhip_pool* pool, const uint8_t* db, int64_t ndb);
 void orbhip_pool_db_shard(const orbhip_pool* pool, int r, int64_t* lo, int64_t* hi);
 orbhip_status orbhip_pool_db_query(orbhip_pool* pool, const uint8_t* q, int nq, int64_t* best_idx, int32_t* best_dist, int32_t* second_dist);

@@ -496,24 +496,29 @@ template <int QT, int OCC, int LCH, int TPB, int ABL = 0, bool EXP = false> __gl
 // ---- the FP4 scan with the superstep's instruction order assigned by hand (k_hamming_nn_fp4b; the production form of the seeded scan).
 // k_hamming_nn_fp4 above is everything source order, scheduling barriers and priorities could get out of hipcc: the sixteen matrix instructions of a tile
 // come out back to back with the threshold tests and the tile's operand reads (+ their lgkmcnt(0)) in front of them, so a wave's matrix pipe idles while
-// it tests and waits (4.5 ms where the matrix instructions alone take 3.2).  Here a whole superstep of NN_FP4B_TPB tiles is ONE asm statement whose text is
+// it tests and waits (4.5 ms; this kernel: 3.7 on the expanded database, 4.2 on the bit form - profiles/r06_exp_config5_superstep.txt).  Here a whole superstep of NN_FP4B_TPB tiles is ONE asm statement whose text is
 // generated (tools/gen_nn_fp4_block.py -> nn_fp4_block.inc): matrix instruction, two or three v_max3_f32 of a tile finished long before, matrix
 // instruction, ...; the next tile's operands are read a half tile ahead.  The statement owns its accumulators (registers it clobbers), so nothing of a tile
-// outlives it except ONE scalar: bit 8 t + u = tile u may matter to query tile t.  Those rare pairs (about one in fifty under the seeded thresholds) are
-// recomputed - four matrix instructions - and folded in by compiled code behind the statement, while the superstep's tiles are still in LDS.  A threshold
-// is therefore up to one superstep stale: it only ever keeps more, never fewer.  Partial supersteps and the ragged tile take the compiled per-tile path.
+// outlives it except ONE scalar: bit 8 t + u = tile u may matter to query tile t.  Those rare pairs are recomputed - four matrix instructions - and folded
+// in by compiled code behind the statement, while the superstep's tiles are still in LDS.  A threshold is therefore up to one superstep stale: it only ever
+// keeps more, never fewer.  Partial supersteps and the ragged tile take the compiled per-tile path.  hipcc must NOT spill across the statement: a reload in
+// front of it comes with `s_waitcnt vmcnt(0)`, i.e. waits for the prefetch issued just before - hence one tile-operand set, the lane's LDS address and the
+// scales made inside the statement, and addresses rebuilt at their (rare) uses instead of kept (check: no scratch_ access between the loop's barriers).
 #include "nn_fp4_block.inc"
 #define NN_SHARE_EVERY 16                // supersteps between two reads of the shared bounds (a power of two)
 // SHARED BOUNDS.  `seed[q]` (nullptr: none) = the head's second-best distance: the head's rows precede every other row, so a later row AT that distance loses
-// the tie on the index and only a strictly smaller distance matters (as in k_hamming_nn_fp4).  `share` (nullptr: none) = two words per query, share[q] = the
-// smallest and share[nq + q] = the second smallest distance among the head's best pair and EVERY row any workgroup has looked at since and found below its
-// threshold: a row is offered with   old = atomicMin(best, d); atomicMin(second, max(old, d))   - every value but the final minimum loses exactly one such
-// exchange and is offered to `second`, so `second` is the second smallest of all offered values whatever the interleaving.  A tile whose distances all EXCEED
-// that second best S holds neither the final best, nor the final second best, nor a row tied with either - whichever rows S came from - so S + 1 is a
-// threshold for everybody.  A workgroup re-reads the shared second best of its queries once per superstep (LDS-DMA at the superstep's start, read behind its
-// barrier): its thresholds follow the best pair found ANYWHERE so far.  Under the head's bound alone one (tile, query tile) in twenty-three was kept and
-// recomputed - a quarter of the scan's time (ORBHIP_NN_BLOCK_VAR=64).  The filter only decides which tiles are looked at: the answers do not depend on the order
-// the workgroups run in.
+// the tie on the index and only a strictly smaller distance matters (as in k_hamming_nn_fp4).  `share` (nullptr: none) = two words per query: share[q] the
+// smallest, share[nq + q] the second smallest distance among the head's best pair (k_hamming_seed) and EVERY row any workgroup has found below its threshold
+// since.  A row at distance d is OFFERED with two non-returning atomics, atomicMin(best, d) and atomicMin(second, max(d, b)), b = the best as last read by
+// the offering lane: b is the distance of some OTHER row, so max(d, b) is at least the second smallest of two real rows - `second` never falls below the final
+// second-best distance.  (The exact exchange `old = atomicMin(best, d); atomicMin(second, max(old, d))` was built first: its returned value is a round trip of
+// microseconds in front of the workgroup's barrier and cost more than the bounds won.)  A tile whose distances all EXCEED some second best S holds neither
+// the final best, nor the final second best, nor a row tied with either - whichever rows S came from - so S + 1 is a threshold for everybody.  A workgroup
+// re-reads the pair of its queries every NN_SHARE_EVERY-th superstep by LDS-DMA with sc1 (device scope: a plain load is served from the reading XCD's L2, which
+// the other XCDs' atomics never reach), requested at a superstep's start and taken behind its barrier: the thresholds follow the best pair found ANYWHERE.
+// Under the head's bound alone one (tile, query tile) in twenty-three is kept and recomputed, with the shared bounds one in five hundred
+// (ORBHIP_NN_STATS=1; ORBHIP_NN_SHARE=0: without).  The filter only decides which tiles are looked at: the answers do not depend on the order the workgroups
+// run in (tests/test_parity_match.py: test_brute_force_nn_ties_across_chunks).
 template <int LCH, bool EXP, int VAR = 0> __global__ __launch_bounds__(256, 2) void k_hamming_nn_fp4b(const unsigned* q, int nq, const unsigned* db, long long ndb, long long base, NNPart* parts, int nchunks,
                                                                                                         const int* seed, int* share, int chunk0, int part0, int* stats, int share_mask)
 {

@@ -152,6 +152,43 @@ def test_brute_force_nn_matrix_core_scan(backend, oracle, monkeypatch, form):
     assert np.array_equal(gb[0], want[0][:3].astype(np.int64) + 10 ** 10) and np.array_equal(gb[1], want[1][:3]) and np.array_equal(gb[2], want[2][:3])
 
 
+@pytest.mark.parametrize("expanded", [False, True])
+def test_brute_force_nn_ties_across_chunks(backend, oracle, expanded):
+    """The hand-ordered FP4 scan (k_hamming_nn_fp4b) skips a tile when none of its distances beats a bound - the head's second best (strict: the head's rows have
+    the lowest indices) or the second best ANY workgroup has found so far + 1 (shared through device memory).  A database made of a few prototypes with a few
+    flipped bits is nothing but ties: hundreds of rows at the best and at the second-best distance of every query, in every chunk, the lowest index among them
+    often NOT in the head.  Best row (lowest index), best and second-best distance against the oracle, on the bit form and on the expanded database."""
+    emu = backend.endswith("_emu.so")
+    rng = np.random.default_rng(21)
+    n = 32768 + 8192 + 500 + 7 if emu else 5 * 32768 + 8192 + 500 + 7
+    proto = rng.integers(0, 256, (6, 32), dtype=np.uint8)
+    flips = np.zeros((16, 32), np.uint8)
+    for f in range(1, 16):
+        for b in rng.integers(0, 256, int(rng.integers(1, 5))):
+            flips[f, b >> 3] ^= np.uint8(1 << (b & 7))
+    db = proto[rng.integers(0, 6, n)] ^ flips[rng.integers(0, 16, n)]
+    db[:32768] = rng.integers(0, 256, (32768, 32), dtype=np.uint8)          # the head knows nothing of the prototypes: every good row lies behind it ...
+    db[5000] = proto[0]; db[5001] = proto[0] ^ flips[3]                        # ... except these two
+    nq = 70 if emu else 530
+    q = proto[rng.integers(0, 6, nq)] ^ flips[rng.integers(0, 16, nq)]
+    q[::7] = rng.integers(0, 256, (len(q[::7]), 32), dtype=np.uint8)           # and some queries near nothing
+    want = oracle.bf_nn(q, db, fast=True)
+    D = orb_slam2_amd.DeviceBuffer
+    ddb, dq = D.from_array(db, library=backend), D.from_array(q, library=backend)
+    bi, bd, sd = D(nq * 8, library=backend), D(nq * 4, library=backend), D(nq * 4, library=backend)
+    if expanded:
+        dx = D(orb_slam2_amd.nn_expanded_size(n, library=backend), library=backend)
+        orb_slam2_amd.nn_expand_device(None, ddb.ptr, n, dx.ptr, library=backend)
+        orb_slam2_amd.hamming_nn_device_expanded(None, dq.ptr, nq, ddb.ptr, dx.ptr, n, bi.ptr, bd.ptr, sd.ptr, library=backend)
+    else:
+        orb_slam2_amd.hamming_nn_device(None, dq.ptr, nq, ddb.ptr, n, bi.ptr, bd.ptr, sd.ptr, library=backend)
+    orb_slam2_amd.device_synchronize(library=backend)
+    got = bi.download((nq,), np.int64), bd.download((nq,), np.int32), sd.download((nq,), np.int32)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    assert (got[1] == got[2]).sum() > nq // 3                                  # (the case is what it claims: best == second best for many queries)
+
+
 def test_brute_force_nn_expanded_database(backend, oracle):
     """orbhip_nn_expand_device + orbhip_hamming_nn_device_expanded: the database expanded once into the FP4 scan's own tile layout (128 B per row), tiles staged by
     16-byte LDS-DMA - the same answers as the scan that expands every row per query group, and as the oracle: ragged last tile and chunk, planted exact matches,
