@@ -520,7 +520,7 @@ template <int QT, int OCC, int LCH, int TPB, int ABL = 0, bool EXP = false> __gl
 // (ORBHIP_NN_STATS=1; ORBHIP_NN_SHARE=0: without).  The filter only decides which tiles are looked at: the answers do not depend on the order the workgroups
 // run in (tests/test_parity_match.py: test_brute_force_nn_ties_across_chunks).
 template <int LCH, bool EXP, int VAR = 0> __global__ __launch_bounds__(256, 2) void k_hamming_nn_fp4b(const unsigned* q, int nq, const unsigned* db, long long ndb, long long base, NNPart* parts, int nchunks,
-                                                                                                        const int* seed, int* share, int chunk0, int part0, int* stats, int share_mask)
+                                                                                                        const int* seed, int* share, long long rows0, int chrows, int part0, int* stats, int share_mask)
 {
     constexpr int QT = 4, TPB = NN_FP4B_TPB;
     static_assert(TPB <= 8, "the keep mask has eight bits per query tile");
@@ -528,7 +528,7 @@ template <int LCH, bool EXP, int VAR = 0> __global__ __launch_bounds__(256, 2) v
     __shared__ __attribute__((aligned(16))) unsigned s_a[2][TPB * 1024];
     __shared__ int s_bnd[4][2 * QT][64];                               // the queries' shared pairs as last read: [wave][t] the second best, [wave][QT + t] the best
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bx = blockIdx.x, by = blockIdx.y, chunk = by + chunk0;
+    const int bx = blockIdx.x, by = blockIdx.y;
     {
         unsigned e = 0;
 #pragma unroll
@@ -571,8 +571,10 @@ template <int LCH, bool EXP, int VAR = 0> __global__ __launch_bounds__(256, 2) v
         for (int t = 0; t < QT; t++) { const int sd2 = s_bnd[wave][t][lane]; if (sd2 >= 0 && sd2 <= 256) thr[t] = fmaxf(thr[t], (float)(16384 - 128 * (sd2 + 1))); }
     };
     constexpr int CH = 1 << LCH;
-    const long long row0 = (long long)chunk * CH;
-    const int nrows = (int)min((long long)CH, ndb - row0);
+    // rows [rows0 + by * chrows, + chrows) are this workgroup's: chrows <= CH (the keys pack a row-in-chunk into LCH bits) and a multiple of 32 (tiles of the
+    // expanded database); the launcher sizes it so that the launch fills the chip's workgroup slots a whole number of times (below)
+    const long long row0 = rows0 + (long long)by * chrows;
+    const int nrows = (int)min((long long)chrows, ndb - row0);
     const int ntiles = (nrows + 31) >> 5;
     const int sr = tid & 31, sd = tid >> 5;
     unsigned wnext[TPB];
@@ -756,13 +758,22 @@ void orbhip_launch_nn_expand(const uint8_t* d_db, long long ndb, uint8_t* d_out,
 
 // second-best distance over the head's partials of every query: the seed of the main pass (a head with fewer than two rows in reach gives none)
 __global__ __launch_bounds__(256) void k_hamming_seed(const NNPart* parts, int nq, int stride, int nhead, int* seed, int* share)
-{   // share (nullptr: none): the shared best / second-best pair of k_hamming_nn_fp4b starts as the head's
-    const int qi = blockIdx.x * 256 + threadIdx.x;
+{   // share (nullptr: none): the shared best / second-best pair of k_hamming_nn_fp4b starts as the head's.
+    // One wavefront per query, a lane per head partial (one thread per query walked its 64 partials one load latency after the other: 30 us of a 3.7 ms query)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * 4 + wave;
     if (qi >= nq) return;
     int b = IMAX, s2 = IMAX;
-    for (int c = 0; c < nhead; c++) { const NNPart p = parts[(long long)qi * stride + c]; if (p.best < b) { s2 = min(b, p.second); b = p.best; } else s2 = min(s2, p.best); }
-    seed[qi] = s2 == IMAX ? -1 : s2;
-    if (share) { share[qi] = b == IMAX ? (1 << 20) : b; share[nq + qi] = s2 == IMAX ? (1 << 20) : s2; }      // (none: above every distance, and atomicMin can still lower it)
+    for (int c = lane; c < nhead; c += 64) { const NNPart p = parts[(long long)qi * stride + c]; s2 = min(min(s2, p.second), max(b, p.best)); b = min(b, p.best); }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {                 // the two smallest of the union: only the distances matter here, not which row
+        const int ob = __shfl_xor(b, off), os = __shfl_xor(s2, off);
+        s2 = min(min(s2, os), max(b, ob)); b = min(b, ob);
+    }
+    if (lane == 0) {
+        seed[qi] = s2 == IMAX ? -1 : s2;
+        if (share) { share[qi] = b == IMAX ? (1 << 20) : b; share[nq + qi] = s2 == IMAX ? (1 << 20) : s2; }      // (none: above every distance, and atomicMin can still lower it)
+    }
 }
 
 // fold the per-chunk partials of one query in ascending DB order: stable arg-min + second smallest of the multiset
@@ -825,7 +836,25 @@ bool orbhip_launch_hamming_nn(const uint8_t* d_q, int nq, const uint8_t* d_db, l
         const char* seed_env = getenv("ORBHIP_NN_SEED");                              // (read per call, like ORBHIP_NN: tests switch forms inside one process)
         const bool seeded_default = !(seed_env && seed_env[0] == '0');
         if (seeded_default && shape == 42156 && nch >= 2) {
-            const int nhead = 64, stride = nhead + nch - 1;
+            // ROWS PER WORKGROUP of the main pass.  Every workgroup does the same work, so a launch runs in rounds of (2 x CUs) workgroups: 609 chunks of 2^15
+            // rows x 4 query groups = 2436 workgroups on 512 slots took five rounds with the last one three quarters empty.  The rows behind the head are split
+            // into the number of chunks that fills a whole number of rounds instead (a multiple of 256 rows, at most 2^15, at least 2048: a short database is
+            // spread over the chip instead of scanned by a handful of workgroups).  ORBHIP_NN_BLOCK=0 and the ablations keep chunks of 2^15 rows.
+            const char* blk_env0 = getenv("ORBHIP_NN_BLOCK");
+            const bool balanced = !(blk_env0 && blk_env0[0] == '0') && !getenv("ORBHIP_NN_ABLATE") && !(getenv("ORBHIP_NN_BALANCE") && getenv("ORBHIP_NN_BALANCE")[0] == '0');
+            int chrows = 1 << 15, nmain = nch - 1;
+            if (balanced) {
+                static int ncu_of[64];                                             // (a benign race: every writer stores the same value)
+                int dev = 0; (void)hipGetDevice(&dev); dev = std::min(std::max(dev, 0), 63);
+                if (!ncu_of[dev]) { hipDeviceProp_t pr; ncu_of[dev] = hipGetDeviceProperties(&pr, dev) == hipSuccess ? std::max(1, pr.multiProcessorCount) : 256; }
+                const long long M = ndb - ((long long)1 << 15), nqg = (nq + qg - 1) / qg, slots = 2LL * ncu_of[dev];
+                const long long rounds = std::max(1LL, (M * nqg + 32768LL * slots - 1) / (32768LL * slots));
+                const long long want = std::max(1LL, rounds * slots / nqg);
+                long long cr = ((M + want - 1) / want + 255) / 256 * 256;
+                cr = std::min(32768LL, std::max(2048LL, cr));
+                chrows = (int)cr; nmain = (int)((M + cr - 1) / cr);
+            }
+            const int nhead = 64, stride = nhead + nmain;
             NNPart* p2 = (NNPart*)orbhip_nn_workspace(sizeof(NNPart) * (size_t)nq * stride + sizeof(int) * ((size_t)nq * 3 + 2), s);
             if (!p2) return false;
             parts = p2;
@@ -838,24 +867,24 @@ bool orbhip_launch_hamming_nn(const uint8_t* d_q, int nq, const uint8_t* d_db, l
             const long long ndb_all = ndb;
             ndb = (long long)1 << 15;                                              // the head pass sees the first chunk only
 #define NN_FP4X(LCH, GY, SEED, C0, P0) hipLaunchKernelGGL((k_hamming_nn_fp4<4, 2, LCH, 6, 0, true>), dim3((nq + qg - 1) / qg, GY, 1), dim3(256, 1, 1), 0, s, (const unsigned*)d_q, nq, (const unsigned*)d_dbx, ndb, base, parts, stride, SEED, C0, P0)
-#define NN_FP4B(LCH, EXP, DB, GY, SEED, SHARE, C0, P0) hipLaunchKernelGGL((k_hamming_nn_fp4b<LCH, EXP>), dim3((nq + qg - 1) / qg, GY, 1), dim3(256, 1, 1), 0, s, (const unsigned*)d_q, nq, (const unsigned*)(DB), ndb, base, parts, stride, SEED, SHARE, C0, P0, stats, share_mask)
+#define NN_FP4B(LCH, EXP, DB, GY, SEED, SHARE, C0, CR, P0) hipLaunchKernelGGL((k_hamming_nn_fp4b<LCH, EXP>), dim3((nq + qg - 1) / qg, GY, 1), dim3(256, 1, 1), 0, s, (const unsigned*)d_q, nq, (const unsigned*)(DB), ndb, base, parts, stride, SEED, SHARE, C0, CR, P0, stats, share_mask)
             // ORBHIP_NN_BLOCK=0 (measurement only): the compiler-scheduled tile loop of round 5 / 6 instead of the hand-ordered superstep
             const char* blk_env = getenv("ORBHIP_NN_BLOCK");
             const bool block = !(blk_env && blk_env[0] == '0') && ablate == 0;
-            if (block && d_dbx) NN_FP4B(9, true, d_dbx, nhead, (const int*)nullptr, (int*)nullptr, 0, 0); else if (block) NN_FP4B(9, false, d_db, nhead, (const int*)nullptr, (int*)nullptr, 0, 0);
+            if (block && d_dbx) NN_FP4B(9, true, d_dbx, nhead, (const int*)nullptr, (int*)nullptr, 0LL, 512, 0); else if (block) NN_FP4B(9, false, d_db, nhead, (const int*)nullptr, (int*)nullptr, 0LL, 512, 0);
             else if (d_dbx) NN_FP4X(9, nhead, (const int*)nullptr, 0, 0); else NN_FP4(4, 2, 9, 6, nhead, (const int*)nullptr, 0, 0, stride);
             ndb = ndb_all;
-            hipLaunchKernelGGL(k_hamming_seed, dim3((nq + 255) / 256, 1, 1), dim3(256, 1, 1), 0, s, (const NNPart*)parts, nq, stride, nhead, seed, share);
+            hipLaunchKernelGGL(k_hamming_seed, dim3((nq + 3) / 4, 1, 1), dim3(256, 1, 1), 0, s, (const NNPart*)parts, nq, stride, nhead, seed, share);
             if (stats) (void)hipMemsetAsync(stats, 0, 2 * sizeof(int), s);      // (the head's own pairs are not counted)
             const int bvar = getenv("ORBHIP_NN_BLOCK_VAR") ? atoi(getenv("ORBHIP_NN_BLOCK_VAR")) : 0;              // measurement only
             const char* share_env = getenv("ORBHIP_NN_SHARE");                                                       // ORBHIP_NN_SHARE=0 (measurement only): the head's bound alone
             int* const share_arg = share_env && share_env[0] == '0' ? (int*)nullptr : share;
             if (block && d_dbx && (bvar == 1 || bvar == 3 || bvar == 4 || bvar == 5 || bvar == 7)) {
-#define NN_FP4BV(V) hipLaunchKernelGGL((k_hamming_nn_fp4b<15, true, V>), dim3((nq + qg - 1) / qg, nch - 1, 1), dim3(256, 1, 1), 0, s, (const unsigned*)d_q, nq, (const unsigned*)d_dbx, ndb, base, parts, stride, (const int*)seed, share_arg, 1, nhead, stats, share_mask)
+#define NN_FP4BV(V) hipLaunchKernelGGL((k_hamming_nn_fp4b<15, true, V>), dim3((nq + qg - 1) / qg, nmain, 1), dim3(256, 1, 1), 0, s, (const unsigned*)d_q, nq, (const unsigned*)d_dbx, ndb, base, parts, stride, (const int*)seed, share_arg, 32768LL, chrows, nhead, stats, share_mask)
                 if (bvar == 1) NN_FP4BV(1); else if (bvar == 3) NN_FP4BV(3); else if (bvar == 4) NN_FP4BV(4); else if (bvar == 5) NN_FP4BV(5); else NN_FP4BV(7);
 #undef NN_FP4BV
             }
-            else if (block && d_dbx) NN_FP4B(15, true, d_dbx, nch - 1, (const int*)seed, share_arg, 1, nhead); else if (block) NN_FP4B(15, false, d_db, nch - 1, (const int*)seed, share_arg, 1, nhead);
+            else if (block && d_dbx) NN_FP4B(15, true, d_dbx, nmain, (const int*)seed, share_arg, 32768LL, chrows, nhead); else if (block) NN_FP4B(15, false, d_db, nmain, (const int*)seed, share_arg, 32768LL, chrows, nhead);
             else if (ablate == 0 && d_dbx) NN_FP4X(15, nch - 1, (const int*)seed, 1, nhead);
 #undef NN_FP4X
 #undef NN_FP4B
