@@ -519,17 +519,22 @@ template <int QT, int OCC, int LCH, int TPB, int ABL = 0, bool EXP = false> __gl
 // Under the head's bound alone one (tile, query tile) in twenty-three is kept and recomputed, with the shared bounds one in five hundred
 // (ORBHIP_NN_STATS=1; ORBHIP_NN_SHARE=0: without).  The filter only decides which tiles are looked at: the answers do not depend on the order the workgroups
 // run in (tests/test_parity_match.py: test_brute_force_nn_ties_across_chunks).
-template <int LCH, bool EXP, int VAR = 0> __global__ __launch_bounds__(256, 2) void k_hamming_nn_fp4b(const unsigned* q, int nq, const unsigned* db, long long ndb, long long base, NNPart* parts, int nchunks,
+// NW = wavefronts per workgroup: 4 (two workgroups per CU) or 8 (one: the same staged tiles serve 1024 queries instead of 512 - half the LDS-DMA requests and
+// bytes per matrix instruction; each half of the workgroup stages every other tile of a superstep).  The superstep's text does not depend on it.
+template <int LCH, bool EXP, int VAR = 0, int NW = 4> __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_hamming_nn_fp4b(const unsigned* q, int nq, const unsigned* db, long long ndb, long long base, NNPart* parts, int nchunks,
                                                                                                         const int* seed, int* share, long long rows0, int chrows, int part0, int* stats, int share_mask)
 {
     constexpr int QT = 4, TPB = NN_FP4B_TPB;
     static_assert(TPB <= 8, "the keep mask has eight bits per query tile");
     __shared__ unsigned s_tab[256];
     __shared__ __attribute__((aligned(16))) unsigned s_a[2][TPB * 1024];
-    __shared__ int s_bnd[4][2 * QT][64];                               // the queries' shared pairs as last read: [wave][t] the second best, [wave][QT + t] the best
+    static_assert(NW == 4 || NW == 8, "four or eight wavefronts");
+    constexpr int NH = NW / 4;                                         // groups of 256 threads: group g stages tiles g, g + NH, ... of a superstep
+    static_assert(TPB % NH == 0, "every group stages the same number of tiles");
+    __shared__ int s_bnd[NW][2 * QT][64];                              // the queries' shared pairs as last read: [wave][t] the second best, [wave][QT + t] the best
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bx = blockIdx.x, by = blockIdx.y;
-    {
+    if (tid < 256) {
         unsigned e = 0;
 #pragma unroll
         for (int t = 0; t < 8; t++) e |= (((tid >> t) & 1) ? 0x2u : 0xAu) << (4 * t);
@@ -537,7 +542,7 @@ template <int LCH, bool EXP, int VAR = 0> __global__ __launch_bounds__(256, 2) v
     }
     __syncthreads();
     const int j = lane & 31, h = lane >> 5;
-    constexpr int QG = 4 * QT * 32;
+    constexpr int QG = NW * QT * 32;
     nn_v4i B[QT][4];                                                   // (operand layout, signs and scales: k_hamming_nn_fp4)
     int qidx[QT];
 #pragma unroll
@@ -576,26 +581,26 @@ template <int LCH, bool EXP, int VAR = 0> __global__ __launch_bounds__(256, 2) v
     const long long row0 = rows0 + (long long)by * chrows;
     const int nrows = (int)min((long long)chrows, ndb - row0);
     const int ntiles = (nrows + 31) >> 5;
-    const int sr = tid & 31, sd = tid >> 5;
-    unsigned wnext[TPB];
+    const int sr = tid & 31, sd = (tid >> 5) & 7, grp = NH == 1 ? 0 : (wave >> 2), t256 = tid & 255;
+    unsigned wnext[TPB / NH];
     auto fetch = [&](int sup) {
 #pragma unroll
-        for (int u = 0; u < TPB; u++) { const int r = (sup * TPB + u) * 32 + sr; wnext[u] = r < nrows ? db[(row0 + r) * 8 + sd] : 0u; }
+        for (int u2 = 0; u2 < TPB / NH; u2++) { const int r = (sup * TPB + u2 * NH + grp) * 32 + sr; wnext[u2] = r < nrows ? db[(row0 + r) * 8 + sd] : 0u; }
     };
     auto expand = [&](int buf) {
 #pragma unroll
-        for (int u = 0; u < TPB; u++) {
-            const unsigned w = wnext[u];
-            *reinterpret_cast<uint4*>(s_a[buf] + u * 1024 + (sd * 32 + sr) * 4) = uint4{s_tab[w & 0xff], s_tab[(w >> 8) & 0xff], s_tab[(w >> 16) & 0xff], s_tab[w >> 24]};
+        for (int u2 = 0; u2 < TPB / NH; u2++) {
+            const unsigned w = wnext[u2];
+            *reinterpret_cast<uint4*>(s_a[buf] + (u2 * NH + grp) * 1024 + (sd * 32 + sr) * 4) = uint4{s_tab[w & 0xff], s_tab[(w >> 8) & 0xff], s_tab[(w >> 16) & 0xff], s_tab[w >> 24]};
         }
     };
     auto stage_dma = [&](int sup, int buf) {
 #pragma unroll
-        for (int u = 0; u < TPB; u++) {
-            const int tile = sup * TPB + u;
+        for (int u2 = 0; u2 < TPB / NH; u2++) {
+            const int u = u2 * NH + grp, tile = sup * TPB + u;
             if (tile < ntiles)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db + ((row0 >> 5) + tile) * 1024 + tid * 4),
-                                                 (__attribute__((address_space(3))) void*)(s_a[buf] + u * 1024 + wave * 256), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db + ((row0 >> 5) + tile) * 1024 + t256 * 4),
+                                                 (__attribute__((address_space(3))) void*)(s_a[buf] + u * 1024 + (wave & 3) * 256), 16, 0, 0);
         }
     };
     const nn_v16f czero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -842,12 +847,16 @@ bool orbhip_launch_hamming_nn(const uint8_t* d_q, int nq, const uint8_t* d_db, l
             // spread over the chip instead of scanned by a handful of workgroups).  ORBHIP_NN_BLOCK=0 and the ablations keep chunks of 2^15 rows.
             const char* blk_env0 = getenv("ORBHIP_NN_BLOCK");
             const bool balanced = !(blk_env0 && blk_env0[0] == '0') && !getenv("ORBHIP_NN_ABLATE") && !(getenv("ORBHIP_NN_BALANCE") && getenv("ORBHIP_NN_BALANCE")[0] == '0');
+            // ORBHIP_NN_WAVES=8 (measurement): the main pass with eight wavefronts per workgroup, one workgroup per CU, 1024 queries per staged tile
+            const char* blk_env1 = getenv("ORBHIP_NN_BLOCK");
+            const bool waves8 = getenv("ORBHIP_NN_WAVES") && atoi(getenv("ORBHIP_NN_WAVES")) == 8 && !(blk_env1 && blk_env1[0] == '0') && !getenv("ORBHIP_NN_ABLATE") && !getenv("ORBHIP_NN_BLOCK_VAR");
+            const int qgm = waves8 ? 2 * qg : qg;                                  // queries per workgroup of the main pass
             int chrows = 1 << 15, nmain = nch - 1;
             if (balanced) {
                 static int ncu_of[64];                                             // (a benign race: every writer stores the same value)
                 int dev = 0; (void)hipGetDevice(&dev); dev = std::min(std::max(dev, 0), 63);
                 if (!ncu_of[dev]) { hipDeviceProp_t pr; ncu_of[dev] = hipGetDeviceProperties(&pr, dev) == hipSuccess ? std::max(1, pr.multiProcessorCount) : 256; }
-                const long long M = ndb - ((long long)1 << 15), nqg = (nq + qg - 1) / qg, slots = 2LL * ncu_of[dev];
+                const long long M = ndb - ((long long)1 << 15), nqg = (nq + qgm - 1) / qgm, slots = (waves8 ? 1LL : 2LL) * ncu_of[dev];
                 const long long rounds = std::max(1LL, (M * nqg + 32768LL * slots - 1) / (32768LL * slots));
                 const long long want = std::max(1LL, rounds * slots / nqg);
                 long long cr = ((M + want - 1) / want + 255) / 256 * 256;
@@ -883,6 +892,11 @@ bool orbhip_launch_hamming_nn(const uint8_t* d_q, int nq, const uint8_t* d_db, l
 #define NN_FP4BV(V) hipLaunchKernelGGL((k_hamming_nn_fp4b<15, true, V>), dim3((nq + qg - 1) / qg, nmain, 1), dim3(256, 1, 1), 0, s, (const unsigned*)d_q, nq, (const unsigned*)d_dbx, ndb, base, parts, stride, (const int*)seed, share_arg, 32768LL, chrows, nhead, stats, share_mask)
                 if (bvar == 1) NN_FP4BV(1); else if (bvar == 3) NN_FP4BV(3); else if (bvar == 4) NN_FP4BV(4); else if (bvar == 5) NN_FP4BV(5); else NN_FP4BV(7);
 #undef NN_FP4BV
+            }
+            else if (block && waves8) {
+#define NN_FP4B8(EXP, DB) hipLaunchKernelGGL((k_hamming_nn_fp4b<15, EXP, 0, 8>), dim3((nq + qgm - 1) / qgm, nmain, 1), dim3(512, 1, 1), 0, s, (const unsigned*)d_q, nq, (const unsigned*)(DB), ndb, base, parts, stride, (const int*)seed, share_arg, 32768LL, chrows, nhead, stats, share_mask)
+                if (d_dbx) NN_FP4B8(true, d_dbx); else NN_FP4B8(false, d_db);
+#undef NN_FP4B8
             }
             else if (block && d_dbx) NN_FP4B(15, true, d_dbx, nmain, (const int*)seed, share_arg, 32768LL, chrows, nhead); else if (block) NN_FP4B(15, false, d_db, nmain, (const int*)seed, share_arg, 32768LL, chrows, nhead);
             else if (ablate == 0 && d_dbx) NN_FP4X(15, nch - 1, (const int*)seed, 1, nhead);
