@@ -1,0 +1,85 @@
+"""Create / use / destroy cycles give device memory back (GPU).
+
+ORB_SLAM2 builds its extractors once, but relocalisation databases, vocabularies, pools and key frame batches come and go for the life of a
+process, and every matcher call borrows from per-thread caches (arena, scan workspace, stream).  One cycle here touches each owner of device
+memory through the C ABI: an extractor context (batch + stereo pair + resident searches + bag of words), a vocabulary, the stateless
+matcher entries, the brute-force scan in its three sizes (popcount, matrix-core, seeded matrix-core with the registered form), a one-GPU
+pool with a sharded descriptor database.  After two warm-up cycles (the grow-only per-thread caches reach their size) the free device memory
+the HIP runtime reports must not fall from cycle to cycle: a leak of one context's pyramid would be ~10 MB a cycle.  The answers of the last
+cycle are compared with the first's - a soak that returns garbage is no soak."""
+import ctypes
+import gc
+import os
+
+import numpy as np
+import pytest
+
+import orb_slam2_amd
+from orb_slam2_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_bytes(gpu_lib):
+    orb_slam2_amd.device_synchronize(0, gpu_lib)
+    hip = ctypes.CDLL(orb_slam2_amd.mapped_hip_runtimes()[0])             # the one runtime already mapped (tests/test_00_device.py), no second copy
+    free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+    return free.value
+
+
+def _cycle(gpu_lib, seq, db, q):
+    W, H, N = seq[0].shape[1], seq[0].shape[0], 800
+    out = []
+    ex = orb_slam2_amd.ORBextractor(N, 1.2, 8, 20, 7, W, H, max_batch=2, library=gpu_lib)
+    k, d = ex.extract_batch(seq)
+    out += [k[0].tobytes(), d[1].tobytes()]
+    m = orb_slam2_amd.ORBmatcher(0.9, True, library=gpu_lib)
+    n12, m12, _ = m.SearchForInitialization(k[0], d[0], k[1], d[1], W, H, windowSize=60)
+    out += [int(n12), m12.tobytes()]
+    kl, dl, kr, dr, ur, dep = ex.extract_stereo(seq[0], seq[1], 386.1, 0.537)
+    out += [ur.tobytes(), dep.tobytes()]
+    voc = orb_slam2_amd.ORBVocabulary(os.path.join(ROOT, "tests", "golden", "voc_k6_L3_ref.txt"), library=gpu_lib)
+    ex.extract_batch(seq)
+    voc.compute_bow(ex, 2, levelsup=4)
+    out += [a.tobytes() for a in voc.fetch_bow(ex, 0)]
+    for rows in (3000, 40000, len(db)):                                     # popcount kernel / matrix-core scan / seeded two-pass scan
+        out += [a.tobytes() for a in orb_slam2_amd.hamming_nn(q, db[:rows], library=gpu_lib)]
+    D = orb_slam2_amd.DeviceBuffer
+    ddb, dq = D.from_array(db, library=gpu_lib), D.from_array(q, library=gpu_lib)
+    dx = D(orb_slam2_amd.nn_expanded_size(len(db), library=gpu_lib), library=gpu_lib)
+    bi, bd, sd = D(len(q) * 8, library=gpu_lib), D(len(q) * 4, library=gpu_lib), D(len(q) * 4, library=gpu_lib)
+    orb_slam2_amd.nn_expand_device(None, ddb.ptr, len(db), dx.ptr, library=gpu_lib)
+    orb_slam2_amd.hamming_nn_device_expanded(None, dq.ptr, len(q), ddb.ptr, dx.ptr, len(db), bi.ptr, bd.ptr, sd.ptr, library=gpu_lib)
+    orb_slam2_amd.device_synchronize(0, gpu_lib)
+    out += [bi.download((len(q),), np.int64).tobytes(), sd.download((len(q),), np.int32).tobytes()]
+    for b in (ddb, dq, dx, bi, bd, sd):
+        b.free()
+    pool = orb_slam2_amd.MultiGpuExtractor([0], 2, N, 1.2, 8, 20, 7, W, H, library=gpu_lib)
+    pk, pd = pool.extract(seq)
+    pool.db_load(db)
+    out += [pk[1].tobytes(), pd[0].tobytes()] + [a.tobytes() for a in pool.db_query(q)]
+    pool.close(); voc.close(); ex.close()
+    del pool, voc, ex, m
+    gc.collect()
+    return out
+
+
+def test_cycles_return_device_memory(gpu_lib):
+    seq = synth.sequence(480, 360, 2, seed=5)
+    rng = np.random.default_rng(3)
+    db = rng.integers(0, 256, (90000, 32), dtype=np.uint8)
+    q = db[rng.integers(0, len(db), 300)].copy(); q[::3, 5] ^= 0x11
+    first = _cycle(gpu_lib, seq, db, q)
+    _cycle(gpu_lib, seq, db, q)                                             # the per-thread caches have their size now
+    base = _free_bytes(gpu_lib)
+    frees = []
+    last = None
+    for _ in range(12):
+        last = _cycle(gpu_lib, seq, db, q)
+        frees.append(_free_bytes(gpu_lib))
+    assert last == first, "the answers of a cycle changed over the soak"
+    # nothing may be lost cycle after cycle: the last cycles stand where the first ones stood (a few MB of slack: the runtime's own pools move in 2 MB blocks)
+    slack = 8 << 20
+    assert min(frees[-3:]) >= min(frees[:3]) - slack and frees[-1] >= base - slack, f"free device memory fell over 12 cycles: baseline {base}, per cycle {frees}"
