@@ -1,10 +1,10 @@
 #!/bin/bash
 # tests/test_concurrency.py (three caller threads in the binding: Tracking's loop, LocalMapping's and LoopClosing's matcher calls) with the reference's
 # callers, the drop-in classes, the emitted matcher bodies and the CPU emulation of the kernels ALL compiled under AddressSanitizer, then under
-# ThreadSanitizer.  usage: tools/sanitize_concurrency.sh [iterations per thread, default 200]      log: profiles/r05_sanitize_concurrency.txt
+# ThreadSanitizer.  usage: tools/sanitize_concurrency.sh [iterations per thread, default 200]      log: profiles/r05_sanitize_concurrency.txt (SANITIZE_LOG overrides the name)
 cd "$(dirname "$0")/.."
 ITERS=${1:-200}
-LOG=profiles/r05_sanitize_concurrency.txt
+LOG=profiles/${SANITIZE_LOG:-r05_sanitize_concurrency.txt}
 make -C orb_slam2_amd/csrc -s emu_asan emu_tsan 2>&1 | grep -E "error" | head -3
 make -C oracle -s dropin_asan dropin_tsan 2>&1 | grep -E "error" | head -3
 { echo "# tests/test_concurrency.py::test_three_threads_on_the_emulation, $ITERS calls on each of threads L and C beside T's loop rounds"; date -u; } > $LOG
