@@ -157,11 +157,15 @@ template <typename T> inline T __shfl_up(T v, unsigned d, int width = 64) { int 
 template <typename T> inline T __shfl_xor(T v, int m, int width = 64) { int l = __lane_id(); int s = l ^ m; if ((s & ~(width - 1)) != (l & ~(width - 1))) s = l; return hipemu_shfl(v, s); }
 
 inline int __builtin_amdgcn_readlane(int v, int srcLane) { return hipemu_shfl(v, srcLane); }     // v_readlane_b32: uniform source lane
-// v_mov_b32_dpp semantics for the controls the kernels use: row_shl:n (0x100+n), row_shr:n (0x110+n), row_bcast:15 (0x142), row_bcast:31 (0x143)
+// v_mov_b32_dpp semantics for the controls the kernels use: quad_perm (0x00-0xff), row_shl:n (0x100+n), row_shr:n (0x110+n), row_ror:n (0x120+n),
+// row_half_mirror (0x141), row_bcast:15 (0x142), row_bcast:31 (0x143) - as tools/permlane_swap_probe.hip prints them on the device
 inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
     const int l = __lane_id(), row = l >> 4, bank = (l >> 2) & 3;
     int s = -1;
-    if (ctrl >= 0x111 && ctrl <= 0x11f) { const int n = ctrl - 0x110; s = ((l & 15) >= n) ? l - n : -1; }
+    if (ctrl >= 0 && ctrl <= 0xff) s = (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3);                                         // quad_perm
+    else if (ctrl >= 0x121 && ctrl <= 0x12f) { const int n = ctrl - 0x120; s = (l & ~15) | (((l & 15) - n) & 15); }     // row_ror:n
+    else if (ctrl == 0x141) s = (l & ~7) | (7 - (l & 7));                                                                // row_half_mirror
+    else if (ctrl >= 0x111 && ctrl <= 0x11f) { const int n = ctrl - 0x110; s = ((l & 15) >= n) ? l - n : -1; }
     else if (ctrl >= 0x101 && ctrl <= 0x10f) { const int n = ctrl - 0x100; s = ((l & 15) + n < 16) ? l + n : -1; }      // row_shl:n
     else if (ctrl == 0x130) s = (l + 1 < 64) ? l + 1 : -1;                                                                // wave_shl:1
     else if (ctrl == 0x142) s = (row >= 1) ? row * 16 - 1 : -1;
@@ -170,6 +174,16 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask,
     if (!((row_mask >> row) & 1) || !((bank_mask >> bank) & 1)) return old;
     if (s < 0) return bound_ctrl ? 0 : old;
     return got;
+}
+// v_permlane32_swap / v_permlane16_swap (gfx950): [0] = a with its upper half / odd rows replaced by b's lower half / even rows, [1] = the rest
+typedef unsigned hipemu_v2u __attribute__((vector_size(8)));
+inline hipemu_v2u __builtin_amdgcn_permlane32_swap(unsigned a, unsigned b, bool, bool) {
+    const int l = __lane_id(); const unsigned xa = hipemu_shfl(a, l ^ 32), xb = hipemu_shfl(b, l ^ 32);
+    hipemu_v2u r; r[0] = l < 32 ? a : xb; r[1] = l < 32 ? xa : b; return r;
+}
+inline hipemu_v2u __builtin_amdgcn_permlane16_swap(unsigned a, unsigned b, bool, bool) {
+    const int l = __lane_id(); const unsigned xa = hipemu_shfl(a, l ^ 16), xb = hipemu_shfl(b, l ^ 16);
+    hipemu_v2u r; r[0] = (l & 16) ? xb : a; r[1] = (l & 16) ? b : xa; return r;
 }
 inline void __builtin_amdgcn_s_setprio(int) {}
 inline void __builtin_amdgcn_wave_barrier() { hipemu::wave_collective(hipemu::OP_BALLOT, 0, 0); }   // rendezvous of the wave's lanes
