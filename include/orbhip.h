@@ -568,6 +568,16 @@ typedef struct {
     int32_t* best_idx; int32_t* best_dist;                                                              /* out: np entries each */
 } orbhip_project_best_slot;
 orbhip_status orbhip_project_best_in_window_batch(int device, int nslots, orbhip_project_best_slot* slots, int chi2_gate);
+/* The same with ONE set of points offered to every slot - LocalMapping::SearchInNeighbors (LocalMapping.cc:483-514) fuses the same map points into every
+   neighbour.  points / point_desc / np are taken from slots[0] and travel once (every slot must name the same arrays); proj, the key frame and the answers
+   are per slot (best_idx / best_dist: np entries each).  skip (may be NULL): np 64-bit masks, bit s set = point k is not searched in slot s (it is in that key
+   frame already, ORBmatcher.cc:848-849): best_idx -1, best_dist 256.  At most 64 slots. */
+orbhip_status orbhip_project_best_in_window_shared(int device, int nslots, orbhip_project_best_slot* slots, const uint64_t* skip, int chi2_gate);
+/* Slot `slot` of the calling thread's LAST orbhip_project_best_in_window_shared call searched again with other points (np entries in, np answers out): the
+   slot's key frame, descriptors and grid table are still in the thread's device scratch, only the points travel.  ORBHIP_ERR_INVALID when the thread has made
+   another scratch-using call since (any stateless matcher entry) or the held scratch has no room for np points: run the full entry then. */
+orbhip_status orbhip_project_best_in_window_held(int device, int slot, const orbhip_projection* proj, const orbhip_map_point* points, const uint8_t* point_desc, int np,
+                                                 int chi2_gate, int32_t* best_idx, int32_t* best_dist);
 
 /* Stereo rectification on the input side: the EuRoC example runs cv::remap(raw, rect, M1, M2, cv::INTER_LINEAR) on the CPU for both
    images of every pair before TrackStereo (Examples/Stereo/stereo_euroc.cc:136-137; maps from cv::initUndistortRectifyMap(..,

@@ -521,6 +521,9 @@ int ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapP
 struct OrbhipFuseJob
 {
     KeyFrame* pKF; orbhip_projection P; OrbhipPoints G; std::vector<int> bi, bd;
+    const OrbhipPoints* S;      // the points bi / bd answer for: &G, or FuseBatch's one shared set (orbhip_project_best_in_window_shared: the device skips the ones this target holds)
+    OrbhipFuseJob() : pKF(NULL), S(NULL) {}
+    const OrbhipPoints& pts() const { return S ? *S : G; }
 };
 // `shared`: the points read ONCE for every target of a FuseBatch (shared->index[k] = position in vpMapPoints; bad points are absent) - a target then copies
 // the records of the points it does not hold instead of visiting every map point again; NULL: read here (a single Fuse)
@@ -573,9 +576,10 @@ static orbhip_project_best_slot orbhip_fuse_slot(OrbhipFuseJob &job)
 }
 // survivors: the points that absorbed another one in the surgery of EARLIER targets of the same FuseBatch (MapPoint::Replace recomputes the survivor's
 // descriptor, MapPoint.cc:177-215) - NULL for a single Fuse, whose points were read just before its search: nothing to re-check
-static int orbhip_fuse_apply(OrbhipFuseJob &job, std::set<MapPoint*> *survivors)
+static int orbhip_fuse_apply(OrbhipFuseJob &job, std::set<MapPoint*> *survivors, int slot = -1)
 {
     KeyFrame* pKF = job.pKF;
+    const OrbhipPoints &Q = job.pts();      // (a shared set also lists the points this target held when they were read: the device answered 256 for them, the filters below skip them)
     int nFused=0;
     // Survivors whose descriptor is not the collected one any more are searched again, all of them in one call, before this target's surgery starts.
     // (Inside one target no collected point's descriptor changes: a survivor is either a point already handled or a point of this key frame, which the
@@ -583,27 +587,32 @@ static int orbhip_fuse_apply(OrbhipFuseJob &job, std::set<MapPoint*> *survivors)
     if(survivors && !survivors->empty() && pKF->N>0)
     {
         OrbhipFuseJob again; again.pKF = pKF; again.P = job.P; std::vector<size_t> which;
-        for(size_t k=0; k<job.G.size(); k++)
+        for(size_t k=0; k<Q.size(); k++)
         {
-            MapPoint* pMP = job.G.owner[k];
+            MapPoint* pMP = Q.owner[k];
             if(!survivors->count(pMP) || pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
             unsigned char dNow[32]; orbhip_read_descriptor(pMP, dNow);
-            if(!memcmp(dNow, &job.G.desc[32*k], 32)) continue;
-            which.push_back(k); again.G.pts.push_back(job.G.pts[k]); again.G.desc.insert(again.G.desc.end(), dNow, dNow+32); again.G.n++;
+            if(!memcmp(dNow, &Q.desc[32*k], 32)) continue;
+            which.push_back(k); again.G.pts.push_back(Q.pts[k]); again.G.desc.insert(again.G.desc.end(), dNow, dNow+32); again.G.n++;
         }
         if(!which.empty())
         {
             again.bi.assign(which.size(), -1); again.bd.assign(which.size(), 256);
-            orbhip_project_best_slot S = orbhip_fuse_slot(again);
-            orbhip_check(orbhip_project_best_in_window_batch(orbhip_default_device(), 1, &S, 1));
+            // this target's key frame and grid are still on the device when the points travelled as one shared set (slot = the job's number): only the changed
+            // points go up; otherwise (or when another call of this thread has used the scratch since) the whole search
+            if(slot<0 || orbhip_project_best_in_window_held(orbhip_default_device(), slot, &again.P, &again.G.pts[0], &again.G.desc[0], (int)which.size(), 1, &again.bi[0], &again.bd[0])!=ORBHIP_OK)
+            {
+                orbhip_project_best_slot S = orbhip_fuse_slot(again);
+                orbhip_check(orbhip_project_best_in_window_batch(orbhip_default_device(), 1, &S, 1));
+            }
             for(size_t a=0; a<which.size(); a++) { job.bi[which[a]] = again.bi[a]; job.bd[which[a]] = again.bd[a]; }
         }
     }
-    for(size_t k=0; k<job.G.size(); k++)
+    for(size_t k=0; k<Q.size(); k++)
     {
         const int bestDist = job.bd[k], bestIdx = job.bi[k];
         if(bestDist>ORBmatcher::TH_LOW) continue;          // (:945; first, it needs no lock: either test alone skips the point and neither has a side effect)
-        MapPoint* pMP = job.G.owner[k];
+        MapPoint* pMP = Q.owner[k];
         if(pMP->isBad() || pMP->IsInKeyFrame(pKF))        // the member's own filter (:848-849), as of NOW: the surgery of earlier points / targets may have changed it
             continue;
         // a map point already there: the one with fewer observations is replaced by the other; otherwise a new measurement (:951-968)
@@ -654,15 +663,44 @@ int FuseBatch(const std::vector<KeyFrame*> &vpTargetKFs, const std::vector<MapPo
         if(shared.add(vpMapPoints[i], (int)i, true, true, -1, 0, 0.f, bMasks ? &vpTargetKFs[0] : NULL, bMasks ? (int)vpTargetKFs.size() : 0, bMasks ? &in : NULL) && bMasks)
             sharedIn.push_back(in);
     }
-    for(size_t t=0; t<vpTargetKFs.size(); t++)
-        orbhip_fuse_collect(vpTargetKFs[t], vpMapPoints, th, jobs[t], &shared, bMasks ? &sharedIn : NULL, (int)t);
-    for(size_t t=0; t<vpTargetKFs.size(); t++) slots[t] = orbhip_fuse_slot(jobs[t]);      // (after every job exists: the slots point into them)
-    if(!slots.empty())
-        orbhip_check(orbhip_project_best_in_window_batch(orbhip_default_device(), (int)slots.size(), &slots[0], 1));
+    shared.done();
+    // With the masks the points travel ONCE for all targets (orbhip_project_best_in_window_shared: the device leaves out, per target, the points whose bit is
+    // set) - no per-target copy of the records either.  Not when the caller's own transform rides in the records (H11 mode 2: it differs per target).
+    const bool bOneUpload = bMasks && shared.size()>0 && orbhip_gemm_mode()!=2;
+    if(bOneUpload)
+    {
+        for(size_t t=0; t<vpTargetKFs.size(); t++)
+        {
+            OrbhipFuseJob &job = jobs[t]; KeyFrame* pKF = vpTargetKFs[t];
+            job.pKF = pKF; job.S = &shared;
+            cv::Mat Rcw = pKF->GetRotation();
+            cv::Mat tcw = pKF->GetTranslation();
+            cv::Mat Ow = pKF->GetCameraCenter();
+            const orbhip_bounds b = orbhip_kf_bounds(pKF);
+            job.P = orbhip_projection_of(ORBHIP_PROJ_FUSE, Rcw, tcw, Ow, pKF->fx, pKF->fy, pKF->cx, pKF->cy, pKF->mbf, b.min_x, b.min_y, b.max_x, b.max_y, th);
+            orbhip_set_levels(job.P, pKF->mvScaleFactors, pKF->mnScaleLevels, pKF->mfLogScaleFactor);
+            job.bi.assign(shared.size(), -1); job.bd.assign(shared.size(), 256);
+        }
+        for(size_t t=0; t<vpTargetKFs.size(); t++)
+        {
+            slots[t] = orbhip_fuse_slot(jobs[t]);
+            slots[t].points = &shared.pts[0]; slots[t].point_desc = &shared.desc[0]; slots[t].np = (int)shared.size();
+            slots[t].best_idx = &jobs[t].bi[0]; slots[t].best_dist = &jobs[t].bd[0];
+        }
+        orbhip_check(orbhip_project_best_in_window_shared(orbhip_default_device(), (int)slots.size(), &slots[0], (const uint64_t*)&sharedIn[0], 1));
+    }
+    else
+    {
+        for(size_t t=0; t<vpTargetKFs.size(); t++)
+            orbhip_fuse_collect(vpTargetKFs[t], vpMapPoints, th, jobs[t], &shared, bMasks ? &sharedIn : NULL, (int)t);
+        for(size_t t=0; t<vpTargetKFs.size(); t++) slots[t] = orbhip_fuse_slot(jobs[t]);      // (after every job exists: the slots point into them)
+        if(!slots.empty())
+            orbhip_check(orbhip_project_best_in_window_batch(orbhip_default_device(), (int)slots.size(), &slots[0], 1));
+    }
     int nFused=0;
     std::set<MapPoint*> survivors;
     for(size_t t=0; t<jobs.size(); t++)
-        nFused += orbhip_fuse_apply(jobs[t], &survivors);
+        nFused += orbhip_fuse_apply(jobs[t], &survivors, bOneUpload ? (int)t : -1);
     return nFused;
 }
 

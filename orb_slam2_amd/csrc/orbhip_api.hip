@@ -144,6 +144,10 @@ template <typename T> static hipError_t dalloc(T** p, size_t count) { return orb
 // needs more), none afterwards — hipMalloc / hipFree cost more than the kernels of a single-frame call.  (Arena: orbhip_internal.h)
 thread_local void* orbhip_tl_scratch = nullptr; thread_local size_t orbhip_tl_scratch_bytes = 0; thread_local int orbhip_tl_scratch_dev = -1;
 thread_local std::vector<OrbXfer> orbhip_tl_xfers;           // host <-> arena transfers of the call being laid out
+// What orbhip_project_best_in_window_shared left in the calling thread's scratch - every slot's key frame, grid table and parameter block - for
+// orbhip_project_best_in_window_held: valid until the thread's next ordinary layout (arena_layout with floor 0) or orbhip_thread_release
+thread_local bool orbhip_tl_held_valid = false;
+static thread_local struct HeldSlots { int device = -1; size_t floor = 0; std::vector<BestParams> B; std::vector<int> live_of_slot; } g_held;
 #define g_scratch orbhip_tl_scratch
 #define g_scratch_bytes orbhip_tl_scratch_bytes
 #define g_scratch_dev orbhip_tl_scratch_dev
@@ -180,7 +184,7 @@ extern "C" void orbhip_thread_release(void)
 {
     int cur = -1; (void)hipGetDevice(&cur);
     if (g_scratch) { (void)hipSetDevice(g_scratch_dev); (void)hipDeviceSynchronize(); (void)hipFree(g_scratch); }
-    g_scratch = nullptr; g_scratch_bytes = 0; g_scratch_dev = -1;
+    g_scratch = nullptr; g_scratch_bytes = 0; g_scratch_dev = -1; orbhip_tl_held_valid = false;
     if (g_tstream) { (void)hipSetDevice(g_tstream_dev); (void)hipStreamSynchronize(g_tstream); (void)hipStreamDestroy(g_tstream); }
     g_tstream = nullptr; g_tstream_dev = -1;
     if (g_hstage) (void)hipHostFree(g_hstage);
@@ -204,9 +208,11 @@ hipError_t arena_upload(hipStream_t s)
     size_t hi = 0;
     for (const Xfer& x : g_xfers) hi = std::max(hi, x.off + std::max(x.bytes_in, x.bytes_out));
     hipError_t e = hstage_reserve(hi); if (e != hipSuccess) return e;
-    size_t in_hi = 0;
-    for (const Xfer& x : g_xfers) if (x.src) { memcpy(g_hstage + x.off, x.src, x.bytes_in); in_hi = std::max(in_hi, x.off + x.bytes_in); }
-    return in_hi ? orbhip_copy_async(g_scratch, g_hstage, in_hi, hipMemcpyHostToDevice, s) : hipSuccess;
+    size_t in_lo = (size_t)-1, in_hi = 0;
+    for (const Xfer& x : g_xfers) if (x.src) { memcpy(g_hstage + x.off, x.src, x.bytes_in); in_lo = std::min(in_lo, x.off); in_hi = std::max(in_hi, x.off + x.bytes_in); }
+    if (!in_hi) return hipSuccess;
+    in_lo &= ~(size_t)255;                                    // (a layout above a floor leaves what lies below it alone)
+    return orbhip_copy_async(static_cast<uint8_t*>(g_scratch) + in_lo, g_hstage + in_lo, in_hi - in_lo, hipMemcpyHostToDevice, s);
 }
 hipError_t arena_download(hipStream_t s)
 {
@@ -1692,10 +1698,17 @@ struct BestSlotIn {
     const orbhip_best_query* queries; const uint8_t* query_desc; int nq; const orbhip_projection* proj; const orbhip_map_point* points;
     int32_t* best_idx; int32_t* best_dist;
 };
-static orbhip_status search_best_in_window_batch_impl(int device, int nslots, BestSlotIn* slots, int chi2_gate)
+// shared: every slot's queries are slots[0]'s (points / query_desc / nq: uploaded once); skip: see orbhip_project_best_in_window_shared
+static orbhip_status search_best_in_window_batch_impl(int device, int nslots, BestSlotIn* slots, int chi2_gate, bool shared = false, const uint64_t* skip = nullptr)
 {
     OrbApiTimer api_timer;
     if (nslots < 0 || (nslots > 0 && !slots)) return fail(ORBHIP_ERR_INVALID, "bad argument");
+    if (shared) {
+        if (nslots > 64) return fail(ORBHIP_ERR_INVALID, "at most 64 slots share one set of points");
+        for (int s = 1; s < nslots; s++)
+            if (slots[s].points != slots[0].points || slots[s].query_desc != slots[0].query_desc || slots[s].nq != slots[0].nq || !slots[s].points)
+                return fail(ORBHIP_ERR_INVALID, "slot %d does not name slot 0's points", s);
+    }
     std::vector<int> live;
     int cap = 1;
     for (int s = 0; s < nslots; s++) {
@@ -1718,6 +1731,8 @@ static orbhip_status search_best_in_window_batch_impl(int device, int nslots, Be
     std::vector<BestParams> hB(NL); std::vector<int> pref(NL + 1, 0), hn(NL);
     for (int k = 0; k < NL; k++) { pref[k + 1] = pref[k] + (slots[live[k]].nq + 3) / 4; hn[k] = slots[live[k]].n; }
     BestParams* dB = nullptr; int *dpref = nullptr, *dn = nullptr, *dgs = nullptr, *dgi = nullptr; float2* dgxy = nullptr; orbhip_keypoint* dk0 = nullptr;
+    uint8_t* dqd0 = nullptr; orbhip_map_point* dpts0 = nullptr; unsigned long long* dskip = nullptr;          // shared: the one copy of the points
+    size_t held_floor = 0;
     hipError_t e = hipSuccess;
 #define TRY(x) do { if (e == hipSuccess) e = (x); } while (0)
     TRY(arena_layout(device, [&](Arena& A) {
@@ -1732,13 +1747,23 @@ static orbhip_status search_best_in_window_batch_impl(int device, int nslots, Be
         for (int k = 0; k < NL; k++) {                                                  // every slot's inputs ...
             const BestSlotIn& S = slots[live[k]]; BestParams& B = hB[k];
             uint8_t *dd = nullptr, *dqd = nullptr; float *dur = nullptr, *dsg = nullptr; orbhip_best_query* dq = nullptr; orbhip_map_point* dpts = nullptr; orbhip_projection* dP = nullptr;
-            A.io(&dd, (size_t)S.n * 32, S.desc, (size_t)S.n * 32); A.io(&dqd, (size_t)S.nq * 32, S.query_desc, (size_t)S.nq * 32);
-            if (S.points) { A.io(&dpts, S.nq, S.points, S.nq); A.io(&dP, 1, S.proj, 1); }
-            else A.io(&dq, S.nq, S.queries, S.nq);
+            A.io(&dd, (size_t)S.n * 32, S.desc, (size_t)S.n * 32);
+            if (shared) {
+                if (k == 0) {
+                    A.io(&dqd0, (size_t)S.nq * 32, S.query_desc, (size_t)S.nq * 32); A.io(&dpts0, S.nq, S.points, S.nq);
+                    if (skip) A.io(&dskip, S.nq, reinterpret_cast<const unsigned long long*>(skip), S.nq);
+                }
+                dqd = dqd0; dpts = dpts0; A.io(&dP, 1, S.proj, 1);
+            } else {
+                A.io(&dqd, (size_t)S.nq * 32, S.query_desc, (size_t)S.nq * 32);
+                if (S.points) { A.io(&dpts, S.nq, S.points, S.nq); A.io(&dP, 1, S.proj, 1); }
+                else A.io(&dq, S.nq, S.queries, S.nq);
+            }
             if (S.u_right) A.io(&dur, S.n, S.u_right, S.n);
             if (S.inv_level_sigma2 && S.nlevels > 0) A.io(&dsg, S.nlevels, S.inv_level_sigma2, S.nlevels);
             B.desc = dd; B.u_right = dur; B.inv_level_sigma2 = dsg; B.q = dq; B.qdesc = dqd; B.nq = S.nq; B.chi2_gate = chi2_gate;
             B.pts = dpts; B.proj = dP; B.q_out = nullptr;
+            B.skip = shared ? dskip : nullptr; B.skip_bit = live[k];
             B.min_x = S.bounds.min_x; B.gw_inv = (float)ORBHIP_GRID_COLS / (float)(S.bounds.max_x - S.bounds.min_x);
         }
         for (int k = 0; k < NL; k++) {                                                  // ... then every slot's answers, contiguous: the download is one small copy
@@ -1748,6 +1773,9 @@ static orbhip_status search_best_in_window_batch_impl(int device, int nslots, Be
             B.best_idx = dbi; B.best_dist = dbd;
         }
         A.take(&dgs, (size_t)NL * (ORBHIP_GRID_CELLS + 1)); A.take(&dgi, NL * C); A.take(&dgxy, NL * C);
+        if (shared) {                                                                   // room for the held entry's queries behind everything: it never reallocates
+            held_floor = A.off; uint8_t* pad = nullptr; A.take(&pad, (size_t)slots[live[0]].nq * (sizeof(orbhip_map_point) + 32 + 8) + 4096);
+        }
     }));
     for (int k = 0; k < NL && e == hipSuccess; k++) { hB[k].grid_start = dgs + (size_t)k * (ORBHIP_GRID_CELLS + 1); hB[k].grid_items = dgi + k * C; hB[k].grid_xy = dgxy + k * C; }
     TRY(arena_upload(ts));
@@ -1768,6 +1796,47 @@ static orbhip_status search_best_in_window_batch_impl(int device, int nslots, Be
         for (int k = 0; k < NL; k++) { BestSlotIn& S = slots[live[k]]; for (int i = 0; i < S.nq; i++) { S.best_idx[i] = -1; S.best_dist[i] = 256; } }
         return fail(ORBHIP_ERR_HIP, "search_best_in_window_batch: %s", hipGetErrorString(e));
     }
+    if (shared) {                                                                       // the slots stay where they are for orbhip_project_best_in_window_held
+        g_held.device = device; g_held.floor = held_floor; g_held.B = hB; g_held.live_of_slot.assign((size_t)nslots, -1);
+        for (int k = 0; k < NL; k++) g_held.live_of_slot[(size_t)live[k]] = k;
+        orbhip_tl_held_valid = true;
+    }
+    return ORBHIP_OK;
+}
+// One slot of the calling thread's last orbhip_project_best_in_window_shared call searched again with other points: its key frame, descriptors and
+// grid table are still in the thread's scratch - only the points travel (ORBmatcher.cc's FuseBatch: the points whose descriptor an earlier target's
+// MapPoint::Replace changed, MapPoint.cc:177-215)
+extern "C" orbhip_status orbhip_project_best_in_window_held(int device, int slot, const orbhip_projection* proj, const orbhip_map_point* points, const uint8_t* point_desc, int np,
+                                                            int chi2_gate, int32_t* best_idx, int32_t* best_dist)
+{
+    OrbApiTimer api_timer;
+    if (np < 0 || (np > 0 && (!points || !point_desc || !best_idx || !best_dist || !projection_ok(proj)))) return fail(ORBHIP_ERR_INVALID, "bad argument");
+    if (!orbhip_tl_held_valid || g_held.device != device || slot < 0 || slot >= (int)g_held.live_of_slot.size())
+        return fail(ORBHIP_ERR_INVALID, "no held slot %d: the calling thread's last scratch-using call was not orbhip_project_best_in_window_shared on this device", slot);
+    for (int i = 0; i < np; i++) { best_idx[i] = -1; best_dist[i] = 256; }
+    const int k = g_held.live_of_slot[(size_t)slot];
+    if (k < 0 || np == 0) return ORBHIP_OK;                                             // (a slot without key points or a call without points: nothing to search)
+    HIPCHK(hipSetDevice(device));
+    hipStream_t ts = orbhip_thread_stream(device);
+    uint8_t* dqd = nullptr; orbhip_map_point* dpts = nullptr; orbhip_projection* dP = nullptr; int *dbi = nullptr, *dbd = nullptr;
+    hipError_t e = hipSuccess;
+#define TRY(x) do { if (e == hipSuccess) e = (x); } while (0)
+    TRY(arena_layout(device, [&](Arena& A) {
+        A.io(&dqd, (size_t)np * 32, point_desc, (size_t)np * 32); A.io(&dpts, np, points, np); A.io(&dP, 1, proj, 1);
+        A.io(&dbi, np, (const int*)nullptr, 0, best_idx, np); A.io(&dbd, np, (const int*)nullptr, 0, best_dist, np);
+    }, g_held.floor));
+    if (e == hipErrorOutOfMemory) return fail(ORBHIP_ERR_INVALID, "the held scratch has no room for %d points", np);      // (the caller falls back to the full entry)
+    TRY(arena_upload(ts));
+    if (e == hipSuccess) {
+        BestParams B = g_held.B[(size_t)k];
+        B.q = nullptr; B.qdesc = dqd; B.nq = np; B.chi2_gate = chi2_gate; B.pts = dpts; B.proj = dP; B.q_out = nullptr; B.best_idx = dbi; B.best_dist = dbd; B.skip = nullptr; B.skip_bit = 0;
+        orbhip_launch_best_in_window(B, ts);
+        e = hipGetLastError();
+    }
+    TRY(arena_download(ts));
+    if (e != hipSuccess) (void)hipStreamSynchronize(ts);
+#undef TRY
+    if (e != hipSuccess) { for (int i = 0; i < np; i++) { best_idx[i] = -1; best_dist[i] = 256; } return fail(ORBHIP_ERR_HIP, "project_best_in_window_held: %s", hipGetErrorString(e)); }
     return ORBHIP_OK;
 }
 extern "C" orbhip_status orbhip_search_best_in_window_batch(int device, int nslots, orbhip_best_slot* slots, int chi2_gate)
@@ -1791,6 +1860,17 @@ extern "C" orbhip_status orbhip_project_best_in_window_batch(int device, int nsl
         in[s] = BestSlotIn{S.kps, S.desc, S.u_right, S.n, S.bounds, S.inv_level_sigma2, S.nlevels, nullptr, S.point_desc, S.np, S.np > 0 ? S.proj : nullptr, S.np > 0 ? S.points : nullptr, S.best_idx, S.best_dist};
     }
     return search_best_in_window_batch_impl(device, nslots, in.data(), chi2_gate);
+}
+extern "C" orbhip_status orbhip_project_best_in_window_shared(int device, int nslots, orbhip_project_best_slot* slots, const uint64_t* skip, int chi2_gate)
+{
+    if (nslots < 0 || (nslots > 0 && !slots)) return fail(ORBHIP_ERR_INVALID, "bad argument");
+    std::vector<BestSlotIn> in((size_t)nslots);
+    for (int s = 0; s < nslots; s++) {
+        const orbhip_project_best_slot& S = slots[s];
+        if (S.np > 0 && (!S.points || !S.proj)) return fail(ORBHIP_ERR_INVALID, "bad argument in slot %d", s);
+        in[s] = BestSlotIn{S.kps, S.desc, S.u_right, S.n, S.bounds, S.inv_level_sigma2, S.nlevels, nullptr, S.point_desc, S.np, S.np > 0 ? S.proj : nullptr, S.np > 0 ? S.points : nullptr, S.best_idx, S.best_dist};
+    }
+    return search_best_in_window_batch_impl(device, nslots, in.data(), chi2_gate, true, skip);
 }
 
 // The two searches above on a frame that is still on the device: key points (mvKeysUn with a distorted camera attached), descriptors

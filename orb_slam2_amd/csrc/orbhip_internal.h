@@ -162,6 +162,7 @@ struct BestParams {
     const orbhip_map_point* pts; const orbhip_projection* proj; orbhip_best_query* q_out;      // projection on the device, as in ProjParams (q_out may be nullptr)
     int* best_idx; int* best_dist;
     float min_x, gw_inv;        // left image bound and grid columns per pixel of the table's grid (gw_inv = 0: scan the whole table)
+    const unsigned long long* skip; int skip_bit;     // (orbhip_project_best_in_window_shared) bit skip_bit of skip[iq] set: the query is not searched; nullptr: all are
 };
 void orbhip_launch_best_in_window(const BestParams& B, hipStream_t s);
 void orbhip_launch_best_in_window_batch(const BestParams* d_slots, const int* d_pref, int nslots, int nblocks, hipStream_t s);
@@ -242,12 +243,17 @@ struct Arena {
     }
 };
 hipError_t orbhip_arena_reserve(int device, size_t bytes);
-template <typename Layout> static hipError_t arena_layout(int device, Layout layout)
+// floor > 0: the layout starts there and what the thread's previous call left below it stays valid (orbhip_project_best_in_window_held) - such a layout
+// never reallocates (hipErrorOutOfMemory instead); every ordinary layout (floor 0) ends the validity of what was held (orbhip_tl_held_valid)
+extern thread_local bool orbhip_tl_held_valid;
+template <typename Layout> static hipError_t arena_layout(int device, Layout layout, size_t floor = 0)
 {
     orbhip_tl_xfers.clear();
-    Arena dry; layout(dry);                                   // first pass: sizes only (no base: nothing is logged)
+    if (floor == 0) orbhip_tl_held_valid = false;
+    Arena dry; dry.off = floor; layout(dry);                  // first pass: sizes only (no base: nothing is logged)
+    if (floor && (orbhip_tl_scratch_dev != device || orbhip_tl_scratch_bytes < dry.off)) return hipErrorOutOfMemory;
     const hipError_t e = orbhip_arena_reserve(device, dry.off); if (e != hipSuccess) return e;
-    Arena real; real.base = static_cast<uint8_t*>(orbhip_tl_scratch); layout(real);
+    Arena real; real.base = static_cast<uint8_t*>(orbhip_tl_scratch); real.off = floor; layout(real);
     return hipSuccess;
 }
 hipError_t arena_upload(hipStream_t s);       // pageable -> pinned gather on the host, ONE host-to-device copy

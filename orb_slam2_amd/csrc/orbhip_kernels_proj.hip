@@ -480,6 +480,7 @@ void orbhip_launch_proj_batch(const ProjParams* d_slots, int nslots, int max_nq,
 __device__ __forceinline__ void best_in_window_body(const BestParams& B, int iq, int lane)
 {
     if (iq >= B.nq) return;
+    if (B.skip && ((B.skip[iq] >> B.skip_bit) & 1ull)) { if (lane == 0) { B.best_idx[iq] = -1; B.best_dist[iq] = 256; } return; }     // the point is in this key frame already (ORBmatcher.cc:848-849)
     orbhip_best_query q;
     if (B.pts) {
         PjOut o;

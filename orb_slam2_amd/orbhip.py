@@ -39,7 +39,7 @@ SYMBOLS = [
     "orbhip_pool_extract", "orbhip_pool_submit", "orbhip_pool_collect", "orbhip_pool_db_load", "orbhip_pool_db_shard", "orbhip_pool_db_query",
     "orbhip_reloc_candidates", "orbhip_runtime_info", "orbhip_device_alloc", "orbhip_device_free", "orbhip_device_upload", "orbhip_device_download",
     "orbhip_device_synchronize", "orbhip_submit_to",
-    "orbhip_predict_scale_table", "orbhip_project_search_bounds", "orbhip_project_search_frame", "orbhip_project_best_in_window_bounds", "orbhip_project_best_in_window_batch",
+    "orbhip_predict_scale_table", "orbhip_project_search_bounds", "orbhip_project_search_frame", "orbhip_project_best_in_window_bounds", "orbhip_project_best_in_window_batch", "orbhip_project_best_in_window_shared", "orbhip_project_best_in_window_held",
 ]
 
 
@@ -192,6 +192,8 @@ def lib(path=None):
     L.orbhip_project_search_frame.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.POINTER(Projection), vp, vp, C.c_int, C.c_float, C.c_int, C.c_int, vp, ip, vp]
     L.orbhip_project_best_in_window_bounds.argtypes = [C.c_int, vp, vp, vp, C.c_int, C.POINTER(Bounds), vp, C.c_int, C.POINTER(Projection), vp, vp, C.c_int, C.c_int, vp, vp, vp]
     L.orbhip_project_best_in_window_batch.argtypes = [C.c_int, C.c_int, vp, C.c_int]
+    L.orbhip_project_best_in_window_shared.argtypes = [C.c_int, C.c_int, vp, vp, C.c_int]
+    L.orbhip_project_best_in_window_held.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, vp]
     L.orbhip_compute_stereo_matches.argtypes = [vp, vp, C.c_int, C.c_float, C.c_float, vp, vp, C.c_int]
     L.orbhip_extract_stereo.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, C.c_float, C.c_float, vp, vp]
     L.orbhip_profile_enable.argtypes = [vp, C.c_int]
@@ -1231,6 +1233,42 @@ def project_best_in_window_batch(slots, chi2_gate, device=0, library=None):
         a.best_idx = _p(bi).value if len(pts) else None; a.best_dist = _p(bd).value if len(pts) else None
     _check(L.orbhip_project_best_in_window_batch(device, len(slots), arr, int(chi2_gate)), "orbhip_project_best_in_window_batch", L)
     return outs
+
+
+def project_best_in_window_shared(slots, points, pdesc, skip, chi2_gate, device=0, library=None):
+    """orbhip_project_best_in_window_shared: ONE set of points (uploaded once) offered to every slot; skip[k] bit s set = point k is not searched in slot s.
+    slots = [dict(kps=, desc=, u_right= (or None), bounds=, inv_level_sigma2=, proj=), ...] -> [(best_idx, best_dist), ...]"""
+    L = lib(library)
+    pts = np.ascontiguousarray(points, MAP_POINT_DTYPE); pd = np.ascontiguousarray(pdesc, np.uint8)
+    sk = None if skip is None else np.ascontiguousarray(skip, np.uint64)
+    keep, outs = [], []
+    arr = (ProjectBestSlot * max(len(slots), 1))()
+    for k, sl in enumerate(slots):
+        kps = np.ascontiguousarray(sl["kps"], KEYPOINT_DTYPE); desc = np.ascontiguousarray(sl["desc"], np.uint8)
+        inv = np.ascontiguousarray(sl["inv_level_sigma2"], np.float32)
+        ur = None if sl.get("u_right") is None else np.ascontiguousarray(sl["u_right"], np.float32)
+        bi = np.full(len(pts), -1, np.int32); bd = np.full(len(pts), 256, np.int32)
+        keep.extend([kps, desc, inv, ur, sl["proj"]]); outs.append((bi, bd))
+        a = arr[k]
+        a.kps = _p(kps).value if len(kps) else None; a.desc = _p(desc).value if len(desc) else None; a.u_right = None if ur is None else _p(ur).value; a.n = len(kps)
+        a.bounds = Bounds.of(sl["bounds"]); a.inv_level_sigma2 = _p(inv).value; a.nlevels = len(inv)
+        a.proj = C.pointer(sl["proj"]); a.points = _p(pts).value if len(pts) else None; a.point_desc = _p(pd).value if len(pd) else None; a.np = len(pts)
+        a.best_idx = _p(bi).value if len(pts) else None; a.best_dist = _p(bd).value if len(pts) else None
+    _check(L.orbhip_project_best_in_window_shared(device, len(slots), arr, None if sk is None else _p(sk), int(chi2_gate)), "orbhip_project_best_in_window_shared", L)
+    return outs
+
+
+def project_best_in_window_held(slot, proj, points, pdesc, chi2_gate, device=0, library=None, check=True):
+    """orbhip_project_best_in_window_held: slot `slot` of this thread's last project_best_in_window_shared call searched again with other points.
+    check=False: returns (status, best_idx, best_dist) instead of raising"""
+    L = lib(library)
+    pts = np.ascontiguousarray(points, MAP_POINT_DTYPE); pd = np.ascontiguousarray(pdesc, np.uint8)
+    bi = np.full(len(pts), -1, np.int32); bd = np.full(len(pts), 256, np.int32)
+    st = L.orbhip_project_best_in_window_held(device, int(slot), C.byref(proj), _p(pts), _p(pd), len(pts), int(chi2_gate), _p(bi), _p(bd))
+    if not check:
+        return st, bi, bd
+    _check(st, "orbhip_project_best_in_window_held", L)
+    return bi, bd
 
 
 def undistort_points(camera, xy, device=0, library=None):

@@ -155,6 +155,32 @@ def test_device_projection_equals_the_oracle(backend, oracle, frame, kind, gemm)
             outs = H.project_best_in_window_batch([dict(kps=kps, desc=desc, u_right=ur if chi2 else None, bounds=bounds, inv_level_sigma2=inv, proj=P, points=pts, pdesc=pdesc)] * 2, chi2, library=backend)
             for o in outs:
                 assert np.array_equal(o[0], bi) and np.array_equal(o[1], bd)
+            # ... and as ONE set of points offered to several slots (FuseBatch): a different projection and a different skip bit per slot; every slot answers like
+            # the single call on the points it was not told to skip
+            if kind == "fuse":
+                nsl = 3
+                Ps = [P] + [_case(np.random.default_rng(31 * rep + s), kind, gemm, nlevels, scale)[0] for s in range(1, nsl)]
+                skip = rng.integers(0, 1 << nsl, len(pts)).astype(np.uint64) | (rng.integers(0, 2, len(pts)).astype(np.uint64) << np.uint64(40))
+                souts = H.project_best_in_window_shared([dict(kps=kps, desc=desc, u_right=ur, bounds=bounds, inv_level_sigma2=inv, proj=Ps[s]) for s in range(nsl)], pts, pdesc, skip, True, library=backend)
+                for s in range(nsl):
+                    keepm = ((skip >> np.uint64(s)) & np.uint64(1)) == 0
+                    bi_s, bd_s, _ = H.project_best_in_window(kps, desc, bounds, inv, Ps[s], pts[keepm], pdesc[keepm], True, u_right=ur, library=backend)
+                    assert np.array_equal(souts[s][0][keepm], bi_s) and np.array_equal(souts[s][1][keepm], bd_s)
+                    assert (souts[s][0][~keepm] == -1).all() and (souts[s][1][~keepm] == 256).all()
+                # ... and a held slot searched again with other points (FuseBatch's re-check of the points an earlier target's surgery changed): only the points travel
+                for s in (nsl - 1, 0):
+                    sub_ = rng.random(len(pts)) < 0.3
+                    pd2 = pdesc[sub_] ^ (rng.random((int(sub_.sum()), 32)) < 0.03).astype(np.uint8)
+                    H.project_best_in_window_shared([dict(kps=kps, desc=desc, u_right=ur, bounds=bounds, inv_level_sigma2=inv, proj=Ps[q]) for q in range(nsl)], pts, pdesc, skip, True, library=backend)
+                    hb, hd = H.project_best_in_window_held(s, Ps[s], pts[sub_], pd2, True, library=backend)
+                    hb2, hd2 = H.project_best_in_window_held(s, Ps[s], pts[sub_], pd2, True, library=backend)                                     # (held calls do not end the holding)
+                    bi_s, bd_s, _ = H.project_best_in_window(kps, desc, bounds, inv, Ps[s], pts[sub_], pd2, True, u_right=ur, library=backend)     # (an ordinary call: what was held is gone after it)
+                    assert np.array_equal(hb, bi_s) and np.array_equal(hd, bd_s) and np.array_equal(hb2, bi_s) and np.array_equal(hd2, bd_s)
+                    st, _, _ = H.project_best_in_window_held(s, Ps[s], pts[sub_], pd2, True, library=backend, check=False)
+                    assert st == H.ERR_INVALID
+                nosk = H.project_best_in_window_shared([dict(kps=kps, desc=desc, u_right=ur, bounds=bounds, inv_level_sigma2=inv, proj=P)] * 2, pts, pdesc, None, True, library=backend)
+                for o in nosk:
+                    assert np.array_equal(o[0], bi) and np.array_equal(o[1], bd)
         total += len(pts); dropped += int((~live).sum())
     assert 0.15 * total < dropped < 0.9 * total, (kind, total, dropped)          # the gates are exercised, and so is what lies behind them
 
