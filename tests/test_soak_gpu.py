@@ -79,6 +79,7 @@ def test_cycles_return_device_memory(gpu_lib):
     for _ in range(12):
         last = _cycle(gpu_lib, seq, db, q)
         frees.append(_free_bytes(gpu_lib))
+    print(f"\n[soak] free device memory: baseline {base}, after each cycle minus baseline (MB): {[round((f - base) / 2**20, 1) for f in frees]}")
     assert last == first, "the answers of a cycle changed over the soak"
     # nothing may be lost cycle after cycle: the last cycles stand where cycles 4-6 stood (a few MB of slack: the runtime's own pools move in 2 MB blocks), and
     # all twelve together have not taken what ONE leaked context per cycle would (12 x 25 MB).  A single step early in the soak is the runtime's, not a leak: in
