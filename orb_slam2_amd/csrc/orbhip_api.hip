@@ -1704,9 +1704,10 @@ static orbhip_status search_best_in_window_batch_impl(int device, int nslots, Be
     OrbApiTimer api_timer;
     if (nslots < 0 || (nslots > 0 && !slots)) return fail(ORBHIP_ERR_INVALID, "bad argument");
     if (shared) {
+        orbhip_tl_held_valid = false;                                                   // whatever an earlier call left held is not THIS call's (also when nothing is live below)
         if (nslots > 64) return fail(ORBHIP_ERR_INVALID, "at most 64 slots share one set of points");
         for (int s = 1; s < nslots; s++)
-            if (slots[s].points != slots[0].points || slots[s].query_desc != slots[0].query_desc || slots[s].nq != slots[0].nq || !slots[s].points)
+            if (slots[s].nq != slots[0].nq || (slots[0].nq > 0 && (slots[s].points != slots[0].points || slots[s].query_desc != slots[0].query_desc || !slots[s].points)))        // (no points: nothing to name)
                 return fail(ORBHIP_ERR_INVALID, "slot %d does not name slot 0's points", s);
     }
     std::vector<int> live;
