@@ -1721,7 +1721,14 @@ static orbhip_status search_best_in_window_batch_impl(int device, int nslots, Be
         if (S.n == 0 || S.nq == 0) continue;
         live.push_back(s); cap = std::max(cap, S.n);
     }
-    if (live.empty()) return ORBHIP_OK;
+    if (live.empty()) {
+        if (shared) {                                                                   // held: a slot without key points answers -1 / 256; one whose key frame never travelled (no points were offered) cannot answer (-2)
+            g_held.device = device; g_held.floor = 0; g_held.B.clear(); g_held.live_of_slot.assign((size_t)nslots, -1);
+            for (int s = 0; s < nslots; s++) if (slots[s].n > 0) g_held.live_of_slot[(size_t)s] = -2;
+            orbhip_tl_held_valid = true;
+        }
+        return ORBHIP_OK;
+    }
     int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(ORBHIP_ERR_HIP, "no HIP device available: no CPU fallback");
     HIPCHK(hipSetDevice(device));
     hipStream_t ts = orbhip_thread_stream(device);
@@ -1816,6 +1823,7 @@ extern "C" orbhip_status orbhip_project_best_in_window_held(int device, int slot
         return fail(ORBHIP_ERR_INVALID, "no held slot %d: the calling thread's last scratch-using call was not orbhip_project_best_in_window_shared on this device", slot);
     for (int i = 0; i < np; i++) { best_idx[i] = -1; best_dist[i] = 256; }
     const int k = g_held.live_of_slot[(size_t)slot];
+    if (k == -2) return fail(ORBHIP_ERR_INVALID, "held slot %d: its key frame did not travel (the shared call offered no points)", slot);
     if (k < 0 || np == 0) return ORBHIP_OK;                                             // (a slot without key points or a call without points: nothing to search)
     HIPCHK(hipSetDevice(device));
     hipStream_t ts = orbhip_thread_stream(device);

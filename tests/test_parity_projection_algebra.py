@@ -181,7 +181,7 @@ def test_device_projection_equals_the_oracle(backend, oracle, frame, kind, gemm)
                 none = H.project_best_in_window_shared([dict(kps=kps, desc=desc, u_right=ur, bounds=bounds, inv_level_sigma2=inv, proj=Ps[s]) for s in range(nsl)], pts[:0], pdesc[:0], None, True, library=backend)
                 assert len(none) == nsl and all(len(o[0]) == 0 for o in none)            # (no points offered: every slot answers with nothing)
                 st, _, _ = H.project_best_in_window_held(0, Ps[0], pts[:5], pdesc[:5], True, library=backend, check=False)
-                assert st == H.ERR_INVALID                                               # ... and nothing is held after it - not the slots of the call before either
+                assert st == H.ERR_INVALID                                               # ... and the slots of the call before are not held any more (this call's key frames never travelled)
                 nosk = H.project_best_in_window_shared([dict(kps=kps, desc=desc, u_right=ur, bounds=bounds, inv_level_sigma2=inv, proj=P)] * 2, pts, pdesc, None, True, library=backend)
                 for o in nosk:
                     assert np.array_equal(o[0], bi) and np.array_equal(o[1], bd)
