@@ -34,6 +34,8 @@ int TriangulationPairs(KeyFrame* pKF1, const std::vector<int> &vMatches12, std::
 
 // = sum over the targets, in order, of ORBmatcher().Fuse(vpTargetKFs[t], vpMapPoints, th): every target's window searches in one device pass, then the
 // reference's own map surgery target by target; a point whose state an earlier target's surgery changed (MapPoint::Replace) is re-checked / searched again.
+// The points travel once for all targets (orbhip_project_best_in_window_shared) and a re-check searches the target's slot where that call left it on the
+// device (orbhip_project_best_in_window_held); more than 64 targets, or a cv::Mat whose R*x+t rounding the probe does not know (H11 mode 2): one copy per target.
 int FuseBatch(const std::vector<KeyFrame*> &vpTargetKFs, const std::vector<MapPoint*> &vpMapPoints, const float th = 3.0);
 
 } // namespace ORB_SLAM2
